@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by RUNNING the reference (phASER v1.2.0) in this container.
+
+Only works where /root/reference exists (the build container).  The reference's
+Python is imported from a scratch copy under /tmp (its mapper compiled with the
+reference's own setup.py, exactly as phaser/README.md:20-25 prescribes); nothing
+of it is copied into the repository -- only inputs we generate ourselves and the
+outputs the reference computes for them land in tests/golden/.
+
+Recipe validated in SURVEY.md Appendix A:
+  * stub `pysam` (imported at phaser.py:15, never used)
+  * set phaser.args / devnull / haplo_count_bam_exclude / sample_column
+  * replace call_mapping_script (phaser.py:1330-1353, the samtools pipeline) with a
+    function that feeds pre-filtered SAM text to do_read_variant_map
+  * call process_vcf (phaser.py:378) with write_vcf=0
+
+Run:  PYTHONHASHSEED=0 python tools/make_golden.py [--only NAME]
+"""
+import argparse
+import gzip
+import hashlib
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/phaser"
+GOLD = os.path.join(REPO, "tests", "golden")
+BUILD = "/tmp/phz_ref_build"
+
+if os.environ.get("PYTHONHASHSEED") != "0":
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+
+sys.path.insert(0, REPO)
+
+
+def build_reference():
+    if not os.path.isdir(REF):
+        sys.exit("reference not present; golden fixtures can only be regenerated in the build container")
+    os.makedirs(BUILD, exist_ok=True)
+    for f in os.listdir(REF):
+        if f.endswith(".py"):
+            shutil.copy(os.path.join(REF, f), BUILD)
+    so = [f for f in os.listdir(BUILD) if f.startswith("read_variant_map") and f.endswith(".so")]
+    if not so:
+        subprocess.check_call([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=BUILD,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, BUILD)
+    sys.modules["pysam"] = types.ModuleType("pysam")
+    import phaser  # noqa
+    import read_variant_map  # noqa
+    return phaser, read_variant_map
+
+
+def default_args(**kw):
+    ns = argparse.Namespace(
+        bam="a.bam", vcf="in.vcf", sample="S1", mapq="255", baseq=10, paired_end="1", o="out",
+        python_string="python3", haplo_count_bam_exclude="", haplo_count_blacklist="", cc_threshold=0.01,
+        isize="0", as_q_cutoff=0.05, blacklist="", write_vcf=0, include_indels=0, output_read_ids=0,
+        remove_dups=1, pass_only=1, unphased_vars=1, chr_prefix="", gw_phase_method=0, gw_af_field="AF",
+        gw_phase_vcf=0, gw_phase_vcf_min_confidence=0.9, threads=1, max_block_size=15, temp_dir="",
+        max_items_per_thread=100000, show_warning=0, debug=0, chr="", unique_ids=0, id_separator="_",
+        output_network="", process_slow=0)
+    for k, v in kw.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def run_mapper(rvm, sam_text, table_text, baseq=10, isize=0.0):
+    """Drive do_read_variant_map (read_variant_map.py:3) on SAM text; returns the call TSV text."""
+    d = tempfile.mkdtemp()
+    tp = os.path.join(d, "table.tsv"); op = os.path.join(d, "out.tsv")
+    open(tp, "w").write(table_text)
+    old_in, old_out = sys.stdin, sys.stdout
+    sys.stdin = io.StringIO(sam_text); sys.stdout = io.StringIO()
+    try:
+        rvm.do_read_variant_map(tp, baseq, op, 1, isize)
+    finally:
+        sys.stdin, sys.stdout = old_in, old_out
+    out = open(op).read()
+    shutil.rmtree(d)
+    return out
+
+
+def run_pipeline(phaser, rvm, vcf_text, sams, outdir, capture_calls=True, **argkw):
+    """Drive process_vcf (phaser.py:378) end to end. `sams` = ordered {bam_path: sam_text}."""
+    ns = default_args(bam=",".join(sams.keys()), **argkw)
+    phaser.args = ns
+    phaser.devnull = open(os.devnull, "w")
+    if ns.haplo_count_bam_exclude != "":
+        phaser.haplo_count_bam_exclude = [x - 1 for x in map(int, ns.haplo_count_bam_exclude.split(","))]
+    else:
+        phaser.haplo_count_bam_exclude = []
+    phaser.sample_column = 9
+    work = tempfile.mkdtemp()
+    calls = {}
+
+    def fake_call_mapping_script(inp):
+        chrom, bed, table, samtools_arg, bam, mapq, isize = inp
+        out = phaser.new_temp_file()
+        old_in, old_out = sys.stdin, sys.stdout
+        sys.stdin = io.StringIO(sams[bam][chrom]); sys.stdout = io.StringIO()
+        try:
+            rvm.do_read_variant_map(table, ns.baseq, out, 1, isize)
+        finally:
+            sys.stdin, sys.stdout = old_in, old_out
+        if capture_calls:
+            calls[(bam, chrom)] = open(out).read()
+            calls[("table", chrom)] = open(table).read()
+        return out
+
+    phaser.call_mapping_script = fake_call_mapping_script
+    vp = os.path.join(work, "in.vcf")
+    open(vp, "w").write(vcf_text)
+    vcf_tmp = tempfile.NamedTemporaryFile(delete=False); vcf_tmp.close()
+    prefix = os.path.join(work, "out")
+    old_out = sys.stdout
+    log = io.StringIO()
+    sys.stdout = log
+    try:
+        phaser.process_vcf(open(vp), "", ["_", ":"], set(), time.time(), vcf_tmp, prefix, True, 0)
+    finally:
+        sys.stdout = old_out
+    os.makedirs(outdir, exist_ok=True)
+    res = {}
+    for suf in ["allelic_counts", "variant_connections", "haplotypes", "haplotypic_counts", "allele_config"]:
+        res[suf] = open(prefix + "." + suf + ".txt").read()
+    res["log"] = log.getvalue()
+    shutil.rmtree(work)
+    return res, calls
+
+
+def wgz(path, text):
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(text.encode())
+
+
+def sha(text):
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+# --------------------------------------------------------------------------------------------- fixtures
+
+def fx_kat(phaser, rvm):
+    """Micro known-answer tests on split_read / identify_allele (read_variant_map.py:165-258)."""
+    I = "I"
+    cases = [
+        ("plain", 100, "ACGTACGTAC", I * 10, "10M", [(p, "A,C", 1) for p in (99, 100, 109, 110)]),
+        ("low_baseq", 100, "ACGTACGTAC", "II#IIIIIII", "10M", [(p, "A,C", 1) for p in (101, 102, 103)]),
+        ("deletion", 100, "ACGTACGTAC", I * 10, "4M2D6M", [(p, "A,C", 1) for p in (103, 104, 105, 106)]),
+        ("ins_after_snp", 100, "ACGTTTACGT", I * 10, "4M2I4M", [(p, "A,C", 1) for p in (102, 103, 104)]),
+        ("clip_splice", 100, "NNACGTACGTAC", I * 12, "2S4M10N6M", [(p, "A,C", 1) for p in list(range(99, 122))]),
+        ("ins_seg2_dropped", 100, "ACGTACGTTTT", I * 11, "4M10N3M1I3M", [(p, "A,C", 1) for p in range(113, 121)]),
+        ("ins_seg2_misplaced", 100, "ACGTCCCCCCCCC", I * 13, "1M1N3M1I8M", [(p, "A,C", 1) for p in range(100, 112)]),
+        ("hard_eq_x", 100, "ACGTAC", I * 6, "3H2=2X2M5H", [(p, "A,C", 1) for p in range(99, 107)]),
+        ("indel_vars", 100, "ACGTACGTAC", I * 10, "10M", [(103, "TA,T", 2), (108, "AC,A", 2), (109, "CG,C", 2)]),
+        ("seq_star", 100, "*", "*", "10M", [(p, "A,C", 1) for p in range(99, 111)]),
+        ("del_then_ins", 100, "ACGTGACGT", I * 9, "4M2D1I4M", [(p, "A,C", 1) for p in range(99, 112)]),
+        ("ins_lowq", 100, "ACGTTTACGT", "IIII##IIII", "4M2I4M", [(p, "A,C", 1) for p in (102, 103, 104)]),
+        ("ins_one_lowq", 100, "ACGTTTACGT", "IIII#IIIII", "4M2I4M", [(p, "A,C", 1) for p in (102, 103, 104)]),
+        ("snp_lowq_ins", 100, "ACGTTTACGT", "III#IIIIII", "4M2I4M", [(p, "A,C", 1) for p in (102, 103, 104)]),
+        ("ins_at_start", 100, "TTACGTACGT", I * 10, "2I8M", [(p, "A,C", 1) for p in range(99, 109)]),
+        ("ins_after_clip", 100, "GGTTACGTAC", I * 10, "2S2I6M", [(p, "A,C", 1) for p in range(99, 107)]),
+        ("two_ins_same_key", 100, "ACGTTTGGAC", I * 10, "4M2I2I2M", [(p, "A,C", 1) for p in range(100, 107)]),
+        ("ins_right_after_N", 100, "ACGTTTACGT", I * 10, "4M5N2I4M", [(p, "A,C", 1) for p in range(100, 114)]),
+        ("ins_seg2_key_in_range", 100, "ACGTAAAAAAAAAATTCCCC", I * 20, "2M2N12M2I4M",
+         [(p, "A,C", 1) for p in range(100, 124)]),
+        ("pad_op", 100, "ACGTACGTAC", I * 10, "4M2P6M", [(p, "A,C", 1) for p in range(99, 111)]),
+        ("short_qual", 100, "ACGTACGTAC", "IIII", "10M", [(p, "A,C", 1) for p in range(99, 111)]),
+        ("short_seq_two_M", 100, "ACGTAC", I * 6, "4M3N4M", [(p, "A,C", 1) for p in range(99, 112)]),
+        ("iupac", 100, "ACRTDC=TAC", I * 10, "10M", [(p, "A,C", 1) for p in range(99, 111)]),
+        ("dup_pos_vars", 100, "ACGTACGTAC", I * 10, "10M", [(104, "A,C", 1), (104, "A,G", 1), (105, "C,T", 1)]),
+        ("baseq0", 100, "ACGNACGTAC", "!!!!!!!!!!", "10M", [(p, "A,C", 1) for p in range(100, 110)]),
+        ("all_deleted_var", 100, "ACGTAC", I * 6, "2M3D4M", [(101, "CGT,C", 3), (102, "GT,G", 2), (103, "T,A", 1)]),
+        ("ins_in_multibase_var", 100, "ACGTTTACGT", I * 10, "4M2I4M", [(102, "GT,G", 2), (103, "TA,T", 2), (101, "CGTA,C", 4)]),
+    ]
+    out = []
+    for name, pos, seq, qual, cigar, vars_ in cases:
+        for baseq in ([10] if name != "baseq0" else [0, 10]):
+            rvm.args = {"baseq": baseq, "splice": 1}
+            segs = rvm.split_read(pos, seq, qual, cigar, "r")
+            res = []
+            for (vp, alleles, reflen) in vars_:
+                v = rvm.variant(["1", str(vp), "1_%d_x" % vp, ".", alleles, str(reflen), "0|1", "None"])
+                per_seg = [rvm.identify_allele(s, pos, v) for s in segs]
+                res.append({"pos": vp, "alleles": alleles, "ref_len": reflen, "per_segment": per_seg})
+            out.append({"name": name, "pos": pos, "seq": seq, "qual": qual, "cigar": cigar, "baseq": baseq,
+                        "segments": [[s.read_start, s.read_stop, s.pseudo_read,
+                                      {str(k): v for k, v in s.insertions.items()}] for s in segs],
+                        "variants": res})
+    json.dump(out, open(os.path.join(GOLD, "kat_micro.json"), "w"), indent=1)
+    print("kat_micro: %d cases" % len(out))
+
+
+def table_text(v, include_maf="None"):
+    from phaser_amd import synth
+    rows = []
+    pos = v.pos.tolist(); ref = v.ref.tolist(); alt = v.alt.tolist()
+    for i in range(len(v)):
+        r, a = synth.BASES[ref[i]], synth.BASES[alt[i]]
+        uid = "%s_%d_%s_%s" % (v.chrom, pos[i], r, a)
+        rows.append("\t".join([v.chrom, str(pos[i]), uid, v.rsid[i], r + "," + a, "1", v.gt[i], include_maf]))
+    return "\n".join(rows) + "\n"
+
+
+def dataset(name, chrom, start, end, n_snps, n_pairs, seed, n_genes=None, prefix="s0.b0.r", L=76, vseed=None):
+    from phaser_amd import synth
+    v, gs, ge, w = synth.make_variants(chrom, start, end, n_snps, seed if vseed is None else vseed, n_genes=n_genes)
+    rb = synth.make_reads(v, gs, ge, w, n_pairs, seed + 1, L=L, qname_prefix=prefix)
+    rf = rb.select(synth.samtools_keep(rb, 255))
+    return v, rf, (v, gs, ge, w)
+
+
+def fx_mapper_small(phaser, rvm):
+    from phaser_amd import synth
+    d = os.path.join(GOLD, "mapper_small"); os.makedirs(d, exist_ok=True)
+    v, rf, _ = dataset("mapper_small", "chr22", 1, 2_000_000, 150, 4000, 101, n_genes=12)
+    sam = "\n".join(synth.sam_lines(rf, [("chr22", 50818468)])) + "\n"
+    tab = table_text(v)
+    meta = {"records": len(rf), "variants": len(v), "runs": []}
+    wgz(os.path.join(d, "in.sam.gz"), sam); open(os.path.join(d, "table.tsv"), "w").write(tab)
+    for baseq, isize in [(10, 0.0), (30, 0.0), (10, 260.0), (0, 0.0)]:
+        out = run_mapper(rvm, sam, tab, baseq, isize)
+        fn = "calls_bq%d_is%d.tsv.gz" % (baseq, int(isize))
+        wgz(os.path.join(d, fn), out)
+        meta["runs"].append({"baseq": baseq, "isize": isize, "file": fn, "lines": out.count("\n")})
+    json.dump(meta, open(os.path.join(d, "meta.json"), "w"), indent=1)
+    print("mapper_small:", meta)
+
+
+def split_by_chrom(sam_lists):
+    return sam_lists
+
+
+def fx_pipeline(phaser, rvm):
+    from phaser_amd import synth
+    contigs = [("chr21", 46709983), ("chr22", 50818468)]
+    # --- case A: one chromosome, one BAM
+    d = os.path.join(GOLD, "pipe_one"); os.makedirs(d, exist_ok=True)
+    v, rf, _ = dataset("pipe_one", "chr22", 1, 3_000_000, 300, 9000, 201, n_genes=20)
+    sam = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf = "\n".join(synth.vcf_lines([v])) + "\n"
+    res, calls = run_pipeline(phaser, rvm, vcf, {"a.bam": {"chr22": sam}}, d)
+    open(os.path.join(d, "in.vcf"), "w").write(vcf)
+    wgz(os.path.join(d, "a.chr22.sam.gz"), sam)
+    for k, t in res.items():
+        wgz(os.path.join(d, "out." + k + ".txt.gz"), t)
+    wgz(os.path.join(d, "calls.a.chr22.tsv.gz"), calls[("a.bam", "chr22")])
+    print("pipe_one: records=%d" % len(rf), [l for l in res["log"].splitlines() if "PHASED" in l or "noise" in l or "cutoff" in l])
+
+    # --- case B: two chromosomes, two BAMs sharing QNAMEs (T3 overwrite quirk), BAM 2 has other seeds
+    d = os.path.join(GOLD, "pipe_two"); os.makedirs(d, exist_ok=True)
+    vs = []; sams = {"t1.bam": {}, "t2.bam": {}}
+    for ci, (chrom, ln) in enumerate(contigs):
+        v, gs, ge, w = synth.make_variants(chrom, 1, 2_000_000, 160, 300 + ci, n_genes=12)
+        vs.append(v)
+        for bi, bam in enumerate(sams):
+            # same qname prefix in both BAMs => QNAME collisions across BAMs on purpose
+            rb = synth.make_reads(v, gs, ge, w, 3000, 310 + 10 * ci + bi, qname_prefix="s0.r")
+            rf = rb.select(synth.samtools_keep(rb, 255))
+            sams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf = "\n".join(synth.vcf_lines(vs)) + "\n"
+    res, calls = run_pipeline(phaser, rvm, vcf, sams, d)
+    open(os.path.join(d, "in.vcf"), "w").write(vcf)
+    for bam in sams:
+        for chrom in sams[bam]:
+            wgz(os.path.join(d, "%s.%s.sam.gz" % (bam.replace(".bam", ""), chrom)), sams[bam][chrom])
+    for k, t in res.items():
+        wgz(os.path.join(d, "out." + k + ".txt.gz"), t)
+    print("pipe_two:", [l for l in res["log"].splitlines() if "PHASED" in l or "noise" in l or "cutoff" in l])
+
+    # --- case C: noisy data (high error) to force conflicting blocks through split / brute-force / stitch paths
+    for tag, err, mbs, seed in [("a", 0.03, 6, 401), ("b", 0.05, 4, 501), ("c", 0.08, 15, 601)]:
+        d = os.path.join(GOLD, "pipe_noisy_" + tag); os.makedirs(d, exist_ok=True)
+        v, gs, ge, w = synth.make_variants("chr22", 1, 400_000, 260, seed, n_genes=6)
+        rb = synth.make_reads(v, gs, ge, w, 9000, seed + 1, err_rate=err)
+        rf = rb.select(synth.samtools_keep(rb, 255))
+        sam = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+        vcf = "\n".join(synth.vcf_lines([v])) + "\n"
+        res, calls = run_pipeline(phaser, rvm, vcf, {"n.bam": {"chr22": sam}}, d, max_block_size=mbs)
+        open(os.path.join(d, "in.vcf"), "w").write(vcf)
+        wgz(os.path.join(d, "n.chr22.sam.gz"), sam)
+        json.dump({"max_block_size": mbs, "err_rate": err}, open(os.path.join(d, "meta.json"), "w"))
+        for k, t in res.items():
+            wgz(os.path.join(d, "out." + k + ".txt.gz"), t)
+        print("pipe_noisy_" + tag, [l for l in res["log"].splitlines() if "PHASED" in l or "noise" in l or "dropped" in l])
+
+
+def fx_c1(phaser, rvm):
+    """BASELINE.json configs[0]: chr22:1-20Mb, 1k het SNPs, 100k records.  Inputs are regenerated from the
+    seed by tests (too large to commit); expected outputs are committed gz + sha256 of the inputs."""
+    from phaser_amd import synth
+    d = os.path.join(GOLD, "c1"); os.makedirs(d, exist_ok=True)
+    contigs = [("chr22", 50818468)]
+    v, gs, ge, w = synth.make_variants("chr22", 1, 20_000_000, 1000, 20240807, n_genes=100)
+    rb = synth.make_reads(v, gs, ge, w, 68000, 20240808)
+    rf = rb.select(synth.samtools_keep(rb, 255))
+    sam = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf = "\n".join(synth.vcf_lines([v])) + "\n"
+    t0 = time.time()
+    calls_txt = run_mapper(rvm, sam, table_text(v), 10, 0.0)
+    t_map = time.time() - t0
+    t0 = time.time()
+    res, calls = run_pipeline(phaser, rvm, vcf, {"c1.bam": {"chr22": sam}}, d, capture_calls=False)
+    t_all = time.time() - t0
+    for k, t in res.items():
+        wgz(os.path.join(d, "out." + k + ".txt.gz"), t)
+    wgz(os.path.join(d, "calls.tsv.gz"), calls_txt)
+    meta = {"records": len(rf), "variants": len(v), "sam_sha256": sha(sam), "vcf_sha256": sha(vcf),
+            "call_lines": calls_txt.count("\n"), "ref_mapper_seconds": round(t_map, 3),
+            "ref_pipeline_seconds": round(t_all, 3),
+            "gen": {"region": ["chr22", 1, 20000000], "n_snps": 1000, "n_genes": 100, "vseed": 20240807,
+                    "n_pairs": 68000, "rseed": 20240808, "mapq": 255}}
+    json.dump(meta, open(os.path.join(d, "meta.json"), "w"), indent=1)
+    print("c1:", meta, [l for l in res["log"].splitlines() if "PHASED" in l])
+
+
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    phaser, rvm = build_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    for name, fn in FIXTURES.items():
+        if a.only in ("", name):
+            fn(phaser, rvm)
