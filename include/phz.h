@@ -1,0 +1,115 @@
+/*
+ * phz.h -- C ABI of libphz.so: the MI355X (gfx950) implementation of phASER's read-backed
+ * phasing hot path.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Which reference interface each entry point replaces (paths relative to the phASER repo):
+ *
+ *   phz_map_reads        phaser/read_variant_map.py:3    do_read_variant_map(variant_table, baseq, o,
+ *                        splice, isize_cutoff) -- reached today through the process boundary
+ *                        phaser/phaser.py:1330-1353 call_mapping_script (bash | samtools | python).
+ *                        One call == one (chromosome, BAM) shard, exactly the unit parallelize()
+ *                        hands to a pool worker at phaser/phaser.py:533.
+ *   phz_as_histogram     phaser/phaser.py:545-553        `cut -f 5` over all call files + numpy.percentile
+ *   phz_tally            phaser/phaser.py:1287-1328      process_mapping_result (per-variant read lists),
+ *                        :610-632 noise counters, :1265-1285 generate_connectivity_map,
+ *                        :1594-1635 test_variant_connection's nine set intersections
+ *   phz_components       phaser/phaser.py:1861-1882      build_haplotypes / :1985 build_haplotype_v3
+ *
+ * Conventions
+ *   - every function returns 0 (PHZ_OK) or a negative phz_status; nothing throws across the ABI.
+ *   - a phz_ctx owns one HIP stream and scratch buffers; it is NOT thread-safe, use one per thread/GPU.
+ *   - `space` says where the caller's pointers live: PHZ_HOST (the library stages through HBM itself)
+ *     or PHZ_DEVICE (pointers are device pointers on the ctx's GPU; zero copies, used when the shard is
+ *     already resident in HBM).
+ *   - inputs of one call describe ONE chromosome: reads coordinate-sorted, variants position-sorted.
+ *
+ * Read shard layout (structure of arrays, see DESIGN.md "Data layout in HBM"):
+ *   pos[n]            1-based leftmost aligned position (SAM POS)
+ *   cigar_off[n+1]    op index range of read r is [cigar_off[r], cigar_off[r+1])
+ *   cigar[n_ops]      BAM encoding len<<4|op, op in MIDNSHP=X (0..8); op 9 ('G', produced only by the
+ *                     host packer for malformed records) advances the genome cursor without bases
+ *   seq_off[n+1]      start of read r in units of 4 bases: byte offset into seq2, x4 = byte offset into qual
+ *   seq2[...]         2 bits per base (A,C,G,T = 0..3), base j of a read in bits (2*(j&3)) of byte j>>2
+ *   qual[...]         one byte per base: low 7 bits phred; bit 7 set = base is not ACGT and the 2-bit
+ *                     code is a subtype (0: behaves like 'N', 1: other IUPAC symbol)
+ *
+ * Call list layout (mapper order: record, then segment, then variant position):
+ *   read_idx, var_idx   indices into the shard / variant arrays
+ *   code                0..3 = the allele is the single base A/C/G/T; 4 = any other string
+ *   aux0                read offset of the base under the variant (0xFFFFFFFF: deletion placeholder)
+ *   aux1                (read offset of spliced-in inserted bases << 12) | min(length,4095); 0 = none
+ *                       aux0/aux1 let the host print the exact allele text; they never change a decision.
+ */
+#ifndef PHZ_H
+#define PHZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct phz_ctx phz_ctx;
+
+typedef enum {
+    PHZ_OK = 0,
+    PHZ_E_ARG = -1,          /* bad argument / malformed shard */
+    PHZ_E_HIP = -2,          /* HIP runtime error, see phz_last_error */
+    PHZ_E_CAPACITY = -3,     /* output buffers too small; the needed count is returned */
+    PHZ_E_UNSUPPORTED = -4,  /* e.g. variants with ref_len != 1 (indel mode) */
+    PHZ_E_NOMEM = -5
+} phz_status;
+
+enum { PHZ_HOST = 0, PHZ_DEVICE = 1 };
+
+typedef struct {
+    int64_t n_reads, n_ops, n_seq_bytes;
+    const int32_t *pos;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    const uint32_t *seq_off;
+    const uint8_t *seq2;
+    const uint8_t *qual;
+} phz_reads;
+
+typedef struct {
+    int64_t n;
+    const int32_t *pos;      /* sorted ascending */
+    const uint8_t *ref_len;  /* len(REF); only 1 (SNP) is accelerated in this version */
+} phz_variants;
+
+typedef struct {
+    int64_t cap;             /* capacity of each array, in calls */
+    int32_t *read_idx;
+    int32_t *var_idx;
+    uint8_t *code;
+    uint32_t *aux0;
+    uint32_t *aux1;
+} phz_calls;
+
+/* timing slots for phz_get_timing */
+enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_COUNT = 8 };
+
+int phz_version(void);
+const char *phz_strerror(int status);
+const char *phz_last_error(const phz_ctx *ctx);
+
+int phz_device_count(int *n);
+int phz_ctx_create(int device, phz_ctx **out);
+int phz_ctx_destroy(phz_ctx *ctx);
+int phz_ctx_sync(phz_ctx *ctx);
+/* raw hipStream_t of the context (so a caller can order its own work against it) */
+void *phz_ctx_stream(phz_ctx *ctx);
+
+/* Read -> variant allele mapper.  On PHZ_E_CAPACITY *n_calls holds the required capacity. */
+int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_variants *vars, int baseq,
+                  phz_calls *out, int64_t *n_calls, int space);
+
+/* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
+int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
+int phz_reset_timing(phz_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHZ_H */

@@ -1,0 +1,139 @@
+"""ctypes binding of libphz.so (C ABI declared in include/phz.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is visible the
+product path raises.  The CPU restatement under oracle/ is test infrastructure only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libphz.so")
+CSRC = os.path.join(HERE, "csrc")
+
+PHZ_OK, PHZ_E_ARG, PHZ_E_HIP, PHZ_E_CAPACITY, PHZ_E_UNSUPPORTED, PHZ_E_NOMEM = 0, -1, -2, -3, -4, -5
+PHZ_HOST, PHZ_DEVICE = 0, 1
+PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS = 0, 1, 2, 3
+
+
+class PhzError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__("libphz status %d: %s" % (status, msg))
+        self.status = status
+
+
+class phz_reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_ops", C.c_int64), ("n_seq_bytes", C.c_int64),
+                ("pos", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq2", C.c_void_p), ("qual", C.c_void_p)]
+
+
+class phz_variants(C.Structure):
+    _fields_ = [("n", C.c_int64), ("pos", C.c_void_p), ("ref_len", C.c_void_p)]
+
+
+class phz_calls(C.Structure):
+    _fields_ = [("cap", C.c_int64), ("read_idx", C.c_void_p), ("var_idx", C.c_void_p), ("code", C.c_void_p),
+                ("aux0", C.c_void_p), ("aux1", C.c_void_p)]
+
+
+# every symbol include/phz.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "phz_version": (C.c_int, []),
+    "phz_strerror": (C.c_char_p, [C.c_int]),
+    "phz_last_error": (C.c_char_p, [C.c_void_p]),
+    "phz_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "phz_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "phz_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "phz_ctx_sync": (C.c_int, [C.c_void_p]),
+    "phz_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "phz_map_reads": (C.c_int, [C.c_void_p, C.POINTER(phz_reads), C.POINTER(phz_variants), C.c_int,
+                                C.POINTER(phz_calls), C.POINTER(C.c_int64), C.c_int]),
+    "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_int64)]),
+    "phz_reset_timing": (C.c_int, [C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def hip_sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 into phaser_amd/libphz.so (in-tree)."""
+    srcs = hip_sources()
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(REPO, "include", "phz.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(REPO, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libphz.so and bind every declared symbol; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PhzError(PHZ_E_HIP, "phaser_amd/libphz.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                                  "there is no CPU fallback for the product path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One phz_ctx (one HIP stream on one GPU).  Raises loudly when no GPU is usable."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        n = C.c_int(0)
+        self.lib.phz_device_count(C.byref(n))
+        if n.value <= 0:
+            raise PhzError(PHZ_E_HIP, "no HIP device visible; the phaser_amd hot path needs an MI355X")
+        h = C.c_void_p()
+        st = self.lib.phz_ctx_create(device, C.byref(h))
+        if st != PHZ_OK:
+            raise PhzError(st, "phz_ctx_create failed")
+        self.h = h
+        self.device = device
+
+    def check(self, st, allow=()):
+        if st != PHZ_OK and st not in allow:
+            raise PhzError(st, (self.lib.phz_last_error(self.h) or b"").decode() or
+                           self.lib.phz_strerror(st).decode())
+        return st
+
+    def timing(self, slot=PHZ_T_MAP):
+        last = C.c_float(); tot = C.c_double(); n = C.c_int64()
+        self.check(self.lib.phz_get_timing(self.h, slot, C.byref(last), C.byref(tot), C.byref(n)))
+        return last.value, tot.value, n.value
+
+    def reset_timing(self):
+        self.check(self.lib.phz_reset_timing(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.phz_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,71 @@
+"""Host wrapper around phz_map_reads (K_map): shard in, call list out.  GPU only, no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .soa import ReadShard
+
+
+@dataclasses.dataclass
+class Calls:
+    """Allele calls in mapper order (record, segment, variant position) -- see include/phz.h."""
+    read_idx: torch.Tensor   # int32
+    var_idx: torch.Tensor    # int32
+    code: torch.Tensor       # uint8: 0..3 = A,C,G,T; 4 = other text
+    aux0: torch.Tensor       # int32 bits of uint32
+    aux1: torch.Tensor
+
+    @property
+    def n(self) -> int:
+        return int(self.read_idx.numel())
+
+    def cpu(self) -> "Calls":
+        return Calls(*(t.cpu() for t in (self.read_idx, self.var_idx, self.code, self.aux0, self.aux1)))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Mapper:
+    def __init__(self, device: int = 0, ctx: Optional[_lib.Context] = None):
+        self.ctx = ctx or _lib.Context(device)
+        self.device = torch.device("cuda", self.ctx.device)
+
+    def map(self, shard: ReadShard, vpos: torch.Tensor, baseq: int, ref_len: Optional[torch.Tensor] = None,
+            cap: Optional[int] = None) -> Calls:
+        """Runs K_map.  Host tensors are staged through HBM by the library; cuda tensors are used in place."""
+        on_gpu = shard.device.type == "cuda"
+        space = _lib.PHZ_DEVICE if on_gpu else _lib.PHZ_HOST
+        out_dev = shard.device
+        vpos = vpos.to(out_dev).to(torch.int32).contiguous()
+        if ref_len is not None:
+            ref_len = ref_len.to(torch.uint8).contiguous()
+            if bool((ref_len != 1).any()):
+                raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "indel variants (ref_len != 1) are not supported by K_map yet")
+        r = _lib.phz_reads(shard.n, int(shard.cigar.numel()), int(shard.seq2.numel()), _ptr(shard.pos),
+                           _ptr(shard.cigar_off), _ptr(shard.cigar), _ptr(shard.seq_off), _ptr(shard.seq2),
+                           _ptr(shard.qual))
+        v = _lib.phz_variants(int(vpos.numel()), _ptr(vpos), None)
+        if cap is None:
+            cap = shard.n // 2 + 4096
+        if on_gpu:
+            torch.cuda.synchronize(out_dev)     # inputs were produced on torch's stream; K_map runs on the ctx stream
+        while True:
+            bufs = [torch.empty(cap, dtype=torch.int32, device=out_dev), torch.empty(cap, dtype=torch.int32, device=out_dev),
+                    torch.empty(cap, dtype=torch.uint8, device=out_dev), torch.empty(cap, dtype=torch.int32, device=out_dev),
+                    torch.empty(cap, dtype=torch.int32, device=out_dev)]
+            c = _lib.phz_calls(cap, *[_ptr(b) for b in bufs])
+            n = C.c_int64(0)
+            st = self.ctx.lib.phz_map_reads(self.ctx.h, C.byref(r), C.byref(v), int(baseq), C.byref(c), C.byref(n), space)
+            self.ctx.check(st, allow=(_lib.PHZ_E_CAPACITY,))
+            if st == _lib.PHZ_E_CAPACITY:
+                cap = int(n.value) + 16
+                continue
+            m = int(n.value)
+            return Calls(*[b[:m] for b in bufs])

@@ -1,0 +1,116 @@
+"""Drop-in for phASER's mapper module: same function, arguments, stdin/stdout contract and output file.
+
+Mirrors phaser/read_variant_map.py:3 `do_read_variant_map(variant_table, baseq, o, splice,
+isize_cutoff)`: SAM text (with @SQ header lines) on stdin, the variant table TSV written by
+generate_mapping_table (phaser/phaser.py:1402-1404), one output line per (record, variant) hit:
+    qname, unique_id, rsid, allele, AS, genotype, maf          (read_variant_map.py:117)
+The computation itself runs in the HIP kernel K_map through libphz.so; the host only parses text,
+packs the structure of arrays, and prints.  No GPU or no library => this raises (no CPU path).
+"""
+from __future__ import annotations
+
+import sys
+from typing import List
+
+import numpy as np
+import torch
+
+from . import soa
+from .mapper import Mapper
+
+_BASES = "ACGT"
+
+
+class VariantTable:
+    """Rows of the mapper's variant table (read_variant_map.py:126-135)."""
+
+    def __init__(self, path: str):
+        self.chr: List[str] = []; self.pos: List[int] = []; self.id: List[str] = []; self.rsid: List[str] = []
+        self.alleles: List[str] = []; self.ref_len: List[int] = []; self.gt: List[str] = []; self.maf: List[str] = []
+        with open(path) as f:
+            for line in f:
+                c = line.rstrip().split("\t")
+                if len(c) < 8:
+                    continue
+                self.chr.append(c[0]); self.pos.append(int(c[1])); self.id.append(c[2]); self.rsid.append(c[3])
+                self.alleles.append(c[4]); self.ref_len.append(int(c[5])); self.gt.append(c[6]); self.maf.append(c[7])
+
+
+def _allele_text(code, aux0, aux1, seq, qual, baseq):
+    """Exact allele text of one call.  Plain single-base calls come straight from `code`; for the rare
+    composite ones (inserted bases spliced after the SNP, IUPAC symbols) the kernel reports which read
+    offsets make up the text and the host only copies the characters."""
+    if code < 4:
+        return _BASES[code]
+    def ch(x):
+        return seq[x] if (ord(qual[x]) - 33) >= baseq else "N"
+    s = ""
+    if aux0 != 0xFFFFFFFF:
+        s += ch(aux0)
+    ilen = aux1 & 0xFFF
+    ioff = aux1 >> 12
+    for x in range(ioff, ioff + ilen):
+        s += ch(x)
+    return s.replace("D", "")
+
+
+def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=None):
+    table = VariantTable(variant_table)
+    contigs: List[str] = []
+    # records grouped per chromosome in input order
+    chrom_order: List[str] = []
+    by_chrom = {}
+    read_counter = 0
+    for line in sys.stdin:
+        cols = line.rstrip().split("\t")
+        if cols[0][0:3] == "@SQ":
+            contigs.append(cols[1].split(":")[1])
+        elif cols[0][0:1] != "@":
+            read_counter += 1
+            template_length = abs(int(cols[8]))
+            if not (isize_cutoff == 0 or template_length <= isize_cutoff):
+                continue
+            if not (splice == 1 or "N" not in cols[5]):
+                continue
+            alignment_score = ""
+            for i in range(11, len(cols)):
+                if cols[i].startswith("AS:"):
+                    alignment_score = str(int(cols[i].split(":")[2]))
+            chrom = cols[2]
+            if chrom not in by_chrom:
+                by_chrom[chrom] = []
+                chrom_order.append(chrom)
+            by_chrom[chrom].append((cols[0], int(cols[3]), cols[5], cols[9], cols[10], alignment_score))
+
+    # VCF / BAM contig check (read_variant_map.py:66-71)
+    tchroms = []
+    for c in table.chr:
+        if not tchroms or tchroms[-1] != c:
+            tchroms.append(c)
+    for rc in chrom_order:
+        for vc in tchroms:
+            if vc != rc and vc not in contigs:
+                print("Error, VCF and BAM contigs do not match VCF = %s BAM = %s" % (vc, rc))
+                sys.exit(1)
+
+    mapper = _mapper or Mapper()
+    tchr = np.asarray(table.chr, dtype=object)
+    with open(o, "w") as out:
+        for chrom in chrom_order:
+            recs = by_chrom[chrom]
+            vsel = np.nonzero(tchr == chrom)[0]
+            if len(vsel) == 0 or not recs:
+                continue
+            vpos = torch.tensor([table.pos[i] for i in vsel], dtype=torch.int32)
+            ref_len = torch.tensor([table.ref_len[i] for i in vsel], dtype=torch.uint8)
+            shard = soa.pack_sam([(r[1], r[2], r[3], r[4]) for r in recs])
+            calls = mapper.map(shard, vpos, int(baseq), ref_len).cpu()
+            ri = calls.read_idx.tolist(); vi = calls.var_idx.tolist(); cd = calls.code.tolist()
+            a0 = (calls.aux0.to(torch.int64) & 0xFFFFFFFF).tolist(); a1 = (calls.aux1.to(torch.int64) & 0xFFFFFFFF).tolist()
+            lines = []
+            for k in range(len(ri)):
+                rec = recs[ri[k]]; v = int(vsel[vi[k]])
+                allele = _allele_text(cd[k], a0[k], a1[k], rec[3], rec[4], baseq)
+                lines.append("\t".join([rec[0], table.id[v], table.rsid[v], allele, rec[5], table.gt[v], table.maf[v]]))
+            if lines:
+                out.write("\n".join(lines) + "\n")

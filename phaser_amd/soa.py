@@ -1,0 +1,173 @@
+"""Structure-of-arrays read shards for the HIP mapper (layout documented in include/phz.h).
+
+Two packers feed the same layout:
+  * pack_fixed()  -- vectorised torch packer for fixed-length reads already held as arrays
+                     (synthetic generator; runs on the GPU for the bench so shards are born in HBM)
+  * pack_sam()    -- general packer for SAM text records (variable length, odd records normalised
+                     so the kernel never has to clamp; see "normalisation" below)
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .synth import QUAL_NONACGT, SUB_IUPAC, SUB_N
+
+OP_CODE = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
+OP_G = 9   # genome advance without bases (packer-only op, see pack_sam)
+
+
+@dataclasses.dataclass
+class ReadShard:
+    """One (chromosome, BAM) shard.  Arrays are torch tensors (cpu or cuda) with int32/uint8 dtype;
+    int32 tensors carry the uint32 fields bit-for-bit (all values are < 2**31)."""
+    pos: torch.Tensor
+    cigar_off: torch.Tensor
+    cigar: torch.Tensor
+    seq_off: torch.Tensor
+    seq2: torch.Tensor
+    qual: torch.Tensor
+    # per-read fields consumed after the mapper (tally / writers), same order as pos
+    qid: Optional[torch.Tensor] = None         # int32 template (QNAME) id
+    aln_score: Optional[torch.Tensor] = None   # int32 AS:i value
+    has_as: Optional[torch.Tensor] = None      # uint8, 0 when the record carries no AS tag
+    iupac: Optional[Dict[Tuple[int, int], str]] = None   # (read, offset) -> original character
+
+    @property
+    def n(self) -> int:
+        return int(self.pos.numel())
+
+    @property
+    def device(self):
+        return self.pos.device
+
+    def nbytes_map_inputs(self) -> int:
+        """Bytes of the arrays K_map may touch (algorithmic input bytes of one pass)."""
+        return sum(int(t.numel()) * t.element_size() for t in
+                   (self.pos, self.cigar_off, self.cigar, self.seq_off, self.seq2, self.qual))
+
+    def to(self, device) -> "ReadShard":
+        f = lambda t: None if t is None else t.to(device)
+        return ReadShard(f(self.pos), f(self.cigar_off), f(self.cigar), f(self.seq_off), f(self.seq2), f(self.qual),
+                         f(self.qid), f(self.aln_score), f(self.has_as), self.iupac)
+
+
+def pack_fixed(pos: torch.Tensor, cigar_off: torch.Tensor, cigar: torch.Tensor, seq: torch.Tensor,
+               qual: torch.Tensor, qid=None, aln_score=None) -> ReadShard:
+    """seq: uint8 [n, L] base codes 0..3, 4 = N;  qual: uint8 [n, L] phred."""
+    n, L = seq.shape
+    dev = seq.device
+    Lp = (L + 3) // 4 * 4
+    isn = seq > 3
+    code = torch.where(isn, torch.zeros_like(seq), seq)           # SUB_N == 0
+    q = torch.where(isn, qual | QUAL_NONACGT, qual)
+    if Lp != L:
+        pad = torch.zeros(n, Lp - L, dtype=torch.uint8, device=dev)
+        code = torch.cat([code, pad], 1)
+        q = torch.cat([q, pad], 1)
+    c4 = code.view(n, Lp // 4, 4)
+    seq2 = (c4[:, :, 0] | (c4[:, :, 1] << 2) | (c4[:, :, 2] << 4) | (c4[:, :, 3] << 6)).contiguous()
+    seq_off = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (Lp // 4)).to(torch.int32)
+    return ReadShard(pos.to(torch.int32).contiguous(), cigar_off.to(torch.int32).contiguous(),
+                     cigar.to(torch.int32).contiguous(), seq_off, seq2.reshape(-1), q.reshape(-1).contiguous(),
+                     None if qid is None else qid.to(torch.int32), None if aln_score is None else aln_score.to(torch.int32),
+                     None if aln_score is None else torch.ones(n, dtype=torch.uint8, device=dev))
+
+
+def pack_readbatch(rb) -> ReadShard:
+    """Pack a synth.ReadBatch (already samtools-filtered) on whatever device it lives."""
+    return pack_fixed(rb.pos, rb.cigar_off, rb.cigar, rb.seq, rb.qual, rb.qid, rb.aln_score)
+
+
+# --------------------------------------------------------------------------------------------------
+_BASE_LUT = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _BASE_LUT[ord(_c)] = _i
+
+
+def parse_cigar(cigar: str) -> List[Tuple[int, int]]:
+    """CIGAR text -> [(op_code or -1 for characters the reference ignores, length)]
+    (read_variant_map.py:191-231 builds the number from digit characters the same way)."""
+    out = []
+    num = 0
+    for ch in cigar:
+        o = ord(ch)
+        if 48 <= o <= 57:
+            num = num * 10 + (o - 48)
+        else:
+            out.append((OP_CODE.get(ch, -1), num))
+            num = 0
+    return out
+
+
+def pack_sam(records: List[Tuple[int, str, str, str]]) -> ReadShard:
+    """records: (pos, cigar_text, seq_text, qual_text) per SAM line, coordinate-sorted.
+
+    Normalisation (keeps the kernel free of string-clamping logic while matching the reference on odd
+    records): the reference zips SEQ with QUAL (read_variant_map.py:179) and slices with Python
+    clamping (:200, :220), so only nb = min(len(SEQ), len(QUAL)) bases exist.  An M/=/X op that runs
+    past nb is rewritten as M(avail) + G(rest) where G (op 9) only advances the genome cursor; an I op
+    keeps its (possibly zero) available length so that the "later insertion overwrites" rule survives.
+    """
+    n = len(records)
+    pos = np.zeros(n, dtype=np.int32)
+    cigar_off = np.zeros(n + 1, dtype=np.int64)
+    seq_off = np.zeros(n + 1, dtype=np.int64)
+    cig: List[int] = []
+    seq_chunks = []
+    qual_chunks = []
+    iupac: Dict[Tuple[int, int], str] = {}
+    for r, (p, cg, sq, ql) in enumerate(records):
+        pos[r] = p
+        nb = min(len(sq), len(ql))
+        read_pos = 0
+        for op, ln in parse_cigar(cg):
+            if op in (0, 7, 8):
+                avail = max(0, min(read_pos + ln, nb) - min(read_pos, nb))
+                if avail == ln:
+                    cig.append((ln << 4) | op)
+                else:
+                    if avail:
+                        cig.append((avail << 4) | op)
+                    cig.append(((ln - avail) << 4) | OP_G)
+                read_pos += ln
+            elif op == 1:
+                avail = max(0, min(read_pos + ln, nb) - min(read_pos, nb))
+                cig.append((avail << 4) | 1)
+                read_pos += ln
+            elif op == 4:
+                cig.append((ln << 4) | 4)
+                read_pos += ln
+            elif op in (2, 3):
+                cig.append((ln << 4) | op)
+            # H, P and unknown characters have no effect in the reference (:227-229)
+        cigar_off[r + 1] = len(cig)
+        nbp = (nb + 3) // 4 * 4
+        sb = np.frombuffer(sq[:nb].encode("latin-1"), dtype=np.uint8)
+        qb = np.frombuffer(ql[:nb].encode("latin-1"), dtype=np.uint8).astype(np.int16) - 33
+        qb = np.clip(qb, 0, 127).astype(np.uint8)
+        code = _BASE_LUT[sb]
+        odd = code == 255
+        if odd.any():
+            sub = np.where((sb == ord("N")) | (sb == ord("D")), SUB_N, SUB_IUPAC).astype(np.uint8)
+            for j in np.nonzero(odd)[0]:
+                if sub[j] == SUB_IUPAC:
+                    iupac[(r, int(j))] = chr(sb[j])
+            code = np.where(odd, sub, code)
+            qb = np.where(odd, qb | QUAL_NONACGT, qb).astype(np.uint8)
+        cp = np.zeros(nbp, dtype=np.uint8); cp[:nb] = code
+        qp = np.zeros(nbp, dtype=np.uint8); qp[:nb] = qb
+        c4 = cp.reshape(-1, 4)
+        seq_chunks.append((c4[:, 0] | (c4[:, 1] << 2) | (c4[:, 2] << 4) | (c4[:, 3] << 6)).astype(np.uint8))
+        qual_chunks.append(qp)
+        seq_off[r + 1] = seq_off[r] + nbp // 4
+    seq2 = np.concatenate(seq_chunks) if seq_chunks else np.zeros(0, np.uint8)
+    qual = np.concatenate(qual_chunks) if qual_chunks else np.zeros(0, np.uint8)
+    if seq_off[-1] >= 2 ** 31 or cigar_off[-1] >= 2 ** 31:
+        raise ValueError("shard too large for 32-bit offsets; split it")
+    t = torch.from_numpy
+    return ReadShard(t(pos), t(cigar_off.astype(np.int32)), t(np.asarray(cig, dtype=np.int64).astype(np.int32)),
+                     t(seq_off.astype(np.int32)), t(seq2), t(qual), iupac=iupac)

@@ -134,44 +134,74 @@ def samtools_keep(rb: ReadBatch, mapq: int, remove_dups: bool = True, paired_end
     return keep
 
 
-def make_reads(v: Variants, gstart, gend, weight, n_pairs: int, seed: int, L: int = 76,
-               device: str = "cpu", qname_prefix: str = "s0.b0.r", n_rate: float = 0.0005,
-               err_rate: float = 0.002) -> ReadBatch:
+@dataclasses.dataclass
+class ReadPlan:
+    """Per-read primitive fields, coordinate-sorted; the expensive per-base content is filled per chunk."""
+    chrom: str
+    L: int
+    pos: torch.Tensor      # int64
+    flag: torch.Tensor
+    mapq: torch.Tensor
+    tlen: torch.Tensor
+    qid: torch.Tensor
+    hap: torch.Tensor
+    seed: int
+
+    def __len__(self):
+        return int(self.pos.numel())
+
+
+def make_read_plan(v: Variants, gstart, gend, weight, n_pairs: int, seed: int, L: int = 76,
+                   device: str = "cpu", all_pass: bool = False) -> ReadPlan:
+    """Place read pairs on genes (log-normal expression), draw flags/MAPQ, sort by position.
+    all_pass=True makes every record pass the samtools filters (bench: the filter is upstream of the path)."""
     dev = torch.device(device)
     g = torch.Generator(device=dev).manual_seed(seed)
-
-    def rnd(*shape):
-        return torch.rand(*shape, generator=g, device=dev)
-
-    def rint(lo, hi, shape):
-        return torch.randint(lo, hi, shape, generator=g, device=dev, dtype=torch.int64)
-
+    rnd = lambda *shape: torch.rand(*shape, generator=g, device=dev)
     gstart = gstart.to(dev); gend = gend.to(dev); weight = weight.to(dev)
-    snp_pos = v.pos.to(dev).to(torch.int64)
     n = 2 * n_pairs
     gene = torch.multinomial(weight / weight.sum(), n_pairs, replacement=True, generator=g)
     frag_start = gstart[gene] - L + (rnd(n_pairs).double() * (gend[gene] - gstart[gene] + L).double()).to(torch.int64)
     frag_start = torch.clamp(frag_start, min=1)
     tl = torch.clamp((torch.randn(n_pairs, generator=g, device=dev) * 60 + 250).to(torch.int64), min=L)
-    hap = rint(0, 2, (n_pairs,))
-    # per read (mate 1 = even index, mate 2 = odd index before sorting)
+    hap = torch.randint(0, 2, (n_pairs,), generator=g, device=dev, dtype=torch.int64)
     pos = torch.stack([frag_start, frag_start + tl - L], 1).reshape(n)
     tlen = torch.stack([tl, -tl], 1).reshape(n)
     pair = torch.arange(n_pairs, device=dev).repeat_interleave(2)
-    hap_r = hap.repeat_interleave(2)
     proper = (rnd(n_pairs) < 0.97).repeat_interleave(2)
     dup = (rnd(n_pairs) < 0.15).repeat_interleave(2)
     mate2 = (torch.arange(n, device=dev) & 1) == 1
     flag = torch.where(mate2, torch.full((n,), 0x1 | 0x10 | 0x80, device=dev), torch.full((n,), 0x1 | 0x20 | 0x40, device=dev))
-    flag = flag | torch.where(proper, 0x2, 0) | torch.where(dup, 0x400, 0)
     mq_r = rnd(n)
-    mapq = torch.where(mq_r < 0.9, torch.full((n,), 255, device=dev),
-                       torch.tensor([0, 1, 3], device=dev)[rint(0, 3, (n,))]).to(torch.uint8)
+    lowq = torch.tensor([0, 1, 3], device=dev)[torch.randint(0, 3, (n,), generator=g, device=dev)]
+    mapq = torch.where(mq_r < 0.9, torch.full((n,), 255, device=dev), lowq)
+    if all_pass:
+        flag = flag | 0x2
+        mapq = torch.full((n,), 255, device=dev)
+    else:
+        flag = flag | torch.where(proper, 0x2, 0) | torch.where(dup, 0x400, 0)
+    order = torch.sort(pos, stable=True).indices
+    return ReadPlan(v.chrom, L, pos[order], flag[order].to(torch.int32), mapq[order].to(torch.uint8),
+                    tlen[order].to(torch.int32), pair[order].to(torch.int32), hap.repeat_interleave(2)[order], seed)
+
+
+def fill_reads(plan: ReadPlan, lo: int, hi: int, v: Variants, n_rate: float = 0.0005, err_rate: float = 0.002,
+               qname_prefix: str = "s0.b0.r") -> ReadBatch:
+    """Generate alignment templates, bases, qualities and AS for plan records [lo, hi)."""
+    dev = plan.pos.device
+    L = plan.L
+    g = torch.Generator(device=dev).manual_seed(plan.seed * 1000003 + lo)
+    rnd = lambda *shape: torch.rand(*shape, generator=g, device=dev)
+    rint = lambda a, b, shape: torch.randint(a, b, shape, generator=g, device=dev, dtype=torch.int64)
+    snp_pos = v.pos.to(dev).to(torch.int64)
+    pos = plan.pos[lo:hi]
+    hap_r = plan.hap[lo:hi]
+    n = hi - lo
 
     # ---- alignment templates
     t = rnd(n)
     typ = torch.zeros(n, dtype=torch.int64, device=dev)
-    for k, thr in enumerate([0.68, 0.90, 0.94, 0.96, 0.98]):
+    for thr in [0.68, 0.90, 0.94, 0.96, 0.98]:
         typ += (t >= thr).to(torch.int64)
     lead = torch.zeros(n, dtype=torch.int64, device=dev); trail = torch.zeros_like(lead)
     blk = torch.zeros(n, 3, dtype=torch.int64, device=dev)
@@ -245,16 +275,20 @@ def make_reads(v: Variants, gstart, gend, weight, n_pairs: int, seed: int, L: in
     slot_len = torch.stack([lead, blk[:, 0], glen[:, 0], blk[:, 1], glen[:, 1], blk[:, 2], trail], 1)
     valid = torch.stack([lead > 0, blk[:, 0] > 0, gtype[:, 0] >= 0, blk[:, 1] > 0, gtype[:, 1] >= 0, blk[:, 2] > 0,
                          trail > 0], 1)
-
-    order = torch.sort(pos, stable=True).indices
-    slot_op, slot_len, valid = slot_op[order], slot_len[order], valid[order]
     counts = valid.sum(1)
     cigar_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     cigar_off[1:] = torch.cumsum(counts, 0)
     cigar = ((slot_len << 4) | slot_op)[valid]
-    return ReadBatch(v.chrom, L, pos[order].to(torch.int32), flag[order].to(torch.int32), mapq[order],
-                     tlen[order].to(torch.int32), aln[order], pair[order].to(torch.int32), cigar_off, cigar,
-                     seq[order], qual[order], qname_prefix)
+    return ReadBatch(plan.chrom, L, pos.to(torch.int32), plan.flag[lo:hi], plan.mapq[lo:hi], plan.tlen[lo:hi], aln,
+                     plan.qid[lo:hi], cigar_off, cigar, seq, qual, qname_prefix)
+
+
+def make_reads(v: Variants, gstart, gend, weight, n_pairs: int, seed: int, L: int = 76,
+               device: str = "cpu", qname_prefix: str = "s0.b0.r", n_rate: float = 0.0005,
+               err_rate: float = 0.002) -> ReadBatch:
+    """All records of one BAM x chromosome (pre-filter), coordinate-sorted."""
+    plan = make_read_plan(v, gstart, gend, weight, n_pairs, seed, L, device)
+    return fill_reads(plan, 0, len(plan), v, n_rate, err_rate, qname_prefix)
 
 
 # --------------------------------------------------------------------------- text renderings (small inputs)

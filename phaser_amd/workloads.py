@@ -1,0 +1,51 @@
+"""Synthetic workloads of BASELINE.json's configs, generated directly in HBM (SURVEY.md 8(d) shapes)."""
+from __future__ import annotations
+
+import torch
+
+from . import soa, synth
+
+CHR1_LEN = 248_956_422
+
+CONFIGS = {
+    # name: (chrom, length, het SNPs, records)
+    "C1": ("chr22", 20_000_000, 1_000, 100_000),
+    "C2": ("chr1", CHR1_LEN, 40_000, 50_000_000),
+}
+
+
+def make_shard(chrom: str, length: int, n_snps: int, n_records: int, seed: int, device: str,
+               chunk: int = 2_000_000, keep_sample: int = 0):
+    """One (chromosome, BAM) shard with every record passing the upstream samtools filters.
+    Returns (variants, ReadShard on `device`, sample ReadBatch on the CPU holding the first keep_sample records)."""
+    v, gs, ge, w = synth.make_variants(chrom, 1, length, n_snps, seed, n_genes=max(1, n_snps // 10))
+    plan = synth.make_read_plan(v, gs, ge, w, (n_records + 1) // 2, seed + 1, device=device, all_pass=True)
+    n = len(plan)
+    parts = []
+    sample = None
+    cig_base = 0
+    seq_base = 0
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        rb = synth.fill_reads(plan, lo, hi, v)
+        if lo == 0 and keep_sample:
+            m = min(keep_sample, hi)
+            keep = torch.zeros(hi, dtype=torch.bool, device=rb.pos.device); keep[:m] = True
+            s = rb.select(keep)
+            sample = synth.ReadBatch(s.chrom, s.L, s.pos.cpu(), s.flag.cpu(), s.mapq.cpu(), s.tlen.cpu(), s.aln_score.cpu(),
+                                     s.qid.cpu(), s.cigar_off.cpu(), s.cigar.cpu(), s.seq.cpu(), s.qual.cpu(), s.qname_prefix)
+        sh = soa.pack_readbatch(rb)
+        parts.append((sh, cig_base, seq_base))
+        cig_base += int(sh.cigar.numel()); seq_base += int(sh.seq2.numel())
+        del rb
+    if cig_base >= 2 ** 31 or seq_base >= 2 ** 31:
+        raise ValueError("shard exceeds 32-bit offsets")
+    cat = torch.cat
+    shard = soa.ReadShard(
+        cat([p[0].pos for p in parts]),
+        cat([p[0].cigar_off[:-1] + p[1] for p in parts] + [torch.tensor([cig_base], dtype=torch.int32, device=parts[0][0].pos.device)]),
+        cat([p[0].cigar for p in parts]),
+        cat([p[0].seq_off[:-1] + p[2] for p in parts] + [torch.tensor([seq_base], dtype=torch.int32, device=parts[0][0].pos.device)]),
+        cat([p[0].seq2 for p in parts]), cat([p[0].qual for p in parts]),
+        cat([p[0].qid for p in parts]), cat([p[0].aln_score for p in parts]), cat([p[0].has_as for p in parts]))
+    return v, shard, sample

@@ -11,3 +11,43 @@ def variant_table_text(v, maf="None"):
         uid = "%s_%d_%s_%s" % (v.chrom, pos[i], r, a)
         rows.append("\t".join([v.chrom, str(pos[i]), uid, v.rsid[i], r + "," + a, "1", v.gt[i], maf]))
     return "\n".join(rows) + "\n"
+
+
+# ------------------------------------------------------------------ oracle (CPU restatement) access
+import ctypes
+import os
+
+import numpy as np
+
+
+def oracle_lib(oracle_dir):
+    lib = ctypes.CDLL(os.path.join(oracle_dir, "librvm_oracle.so"))
+    lib.rvm_oracle_map_soa.restype = ctypes.c_long
+    lib.rvm_oracle_map_soa.argtypes = [ctypes.c_long] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_long,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long] + [ctypes.c_void_p] * 4
+    return lib
+
+
+def oracle_map_readbatch(oracle_dir, rb, vpos, baseq, with_text=True):
+    """Run the C restatement on a synth.ReadBatch (CPU tensors). Returns (read_idx, var_idx, code, text list)."""
+    lib = oracle_lib(oracle_dir)
+    n = len(rb)
+    pos = np.ascontiguousarray(rb.pos.numpy().astype(np.int32))
+    coff = np.ascontiguousarray(rb.cigar_off.numpy().astype(np.int64))
+    cig = np.ascontiguousarray(rb.cigar.numpy().astype(np.uint32))
+    seq = np.ascontiguousarray(rb.seq.numpy()); qual = np.ascontiguousarray(rb.qual.numpy())
+    vp = np.ascontiguousarray(np.asarray(vpos, dtype=np.int32)); rl = np.ones(len(vp), dtype=np.uint8)
+    cap = n * 2 + 1024
+    while True:
+        o_r = np.zeros(cap, np.int32); o_v = np.zeros(cap, np.int32); o_c = np.zeros(cap, np.uint8)
+        o_s = np.zeros(cap * 32, np.uint8) if with_text else None
+        m = lib.rvm_oracle_map_soa(n, pos.ctypes.data, coff.ctypes.data, cig.ctypes.data, seq.ctypes.data, qual.ctypes.data,
+                                   rb.L, baseq, len(vp), vp.ctypes.data, rl.ctypes.data, cap, o_r.ctypes.data,
+                                   o_v.ctypes.data, o_c.ctypes.data, o_s.ctypes.data if with_text else None)
+        if m <= cap:
+            break
+        cap = m + 16
+    text = None
+    if with_text:
+        text = [bytes(o_s[i * 32:(i + 1) * 32]).split(b"\0")[0].decode() for i in range(m)]
+    return o_r[:m], o_v[:m], o_c[:m], text

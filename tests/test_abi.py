@@ -1,0 +1,49 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every declared symbol."""
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from phaser_amd import _lib
+    _lib.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from phaser_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "phz.h")).read()
+    declared = set(re.findall(r"\b(phz_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_version_and_strerror(lib):
+    assert lib.phz_version() >= 100
+    assert lib.phz_strerror(0) == b"ok"
+    assert b"capacity" in lib.phz_strerror(-3)
+
+
+def test_product_path_refuses_without_gpu():
+    """No silent CPU fallback: without a HIP device the product path must raise."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from phaser_amd import _lib
+    with pytest.raises(_lib.PhzError):
+        _lib.Context(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "phaser_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "rvm_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
