@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--records", type=int, default=50_000_000)
     ap.add_argument("--snps", type=int, default=40_000)
     ap.add_argument("--baseq", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=8_000_000)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -85,6 +85,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Importing torch FIRST makes the
+    # dynamic loader resolve libphz.so's libamdhip64.so.N against that already-loaded copy, so the process
+    # holds exactly one HIP runtime (two runtimes => the second one sees no device).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PhzError(PHZ_E_HIP, "phaser_amd/libphz.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                   "there is no CPU fallback for the product path")
