@@ -51,3 +51,39 @@ def oracle_map_readbatch(oracle_dir, rb, vpos, baseq, with_text=True):
     if with_text:
         text = [bytes(o_s[i * 32:(i + 1) * 32]).split(b"\0")[0].decode() for i in range(m)]
     return o_r[:m], o_v[:m], o_c[:m], text
+
+
+# ------------------------------------------------------------------ canonical forms
+def _relabel(field):
+    """aReads / bReads: indices into list(set(reads)) are hash-order labels; relabel by first appearance."""
+    if field == "":
+        return field
+    m = {}
+    out = []
+    for part in field.split(";"):
+        if part == "":
+            out.append("")
+            continue
+        out.append(",".join(str(m.setdefault(x, len(m))) for x in part.split(",")))
+    return ";".join(out)
+
+
+def canonical(name, text):
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines = lines[:-1]
+    head, rows = lines[0], lines[1:]
+    if name in ("allelic_counts", "allele_config"):
+        return text                       # byte-stable files
+    if name == "haplotypic_counts":
+        fixed = []
+        for r in rows:
+            f = r.split("\t")
+            f[16] = _relabel(f[16]); f[17] = _relabel(f[17])
+            f[5] = ",".join(sorted(f[5].split(","))) if f[5] else f[5]
+            fixed.append("\t".join(f))
+        rows = fixed
+    return "\n".join([head] + sorted(rows)) + "\n"
+
+
+OUTPUTS = ["allelic_counts", "variant_connections", "haplotypes", "haplotypic_counts", "allele_config"]
