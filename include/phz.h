@@ -87,6 +87,36 @@ typedef struct {
     uint32_t *aux1;
 } phz_calls;
 
+/* One (chromosome, BAM) shard's call lines = K_map output + the per-record fields the phasing core reads
+ * from the mapper's TSV (qname -> read_qid, AS column -> read_as). */
+typedef struct {
+    int64_t n_calls;
+    const int32_t *read_idx;
+    const int32_t *var_idx;
+    const uint8_t *code;
+    int64_t n_reads;
+    const int32_t *read_qid;     /* template (QNAME) id per record; ids are per chromosome, shared by all BAMs */
+    const int32_t *read_as;      /* AS:i per record, must fit int16 */
+    const uint8_t *read_has_as;  /* NULL = every record carries AS */
+    double as_cutoff;            /* numpy.percentile value (phaser.py:551); used when use_cutoff != 0 */
+    int32_t use_cutoff;
+    int32_t bam_index;
+} phz_lines;
+
+#define PHZ_AS_BINS 65536        /* histogram bin = AS + 32768 */
+
+typedef struct {
+    int32_t *var_count;      /* [nv*3] kept call lines per (variant, class ref/alt/other), duplicates kept */
+    int64_t *var_first;      /* [nv]   global index of the first kept line, -1 if none */
+    int32_t *var_distinct;   /* [nv*3] distinct QNAMEs per (variant, class) */
+    uint8_t *line_cls;       /* [sum n_calls] 0 ref / 1 alt / 2 other / 255 dropped by the AS cutoff */
+    int64_t edge_cap;
+    int32_t *edge_a;         /* variant pair a < b (indices), sorted by (a, b) */
+    int32_t *edge_b;
+    int32_t *edge_cells;     /* [edge_cap*9] |S_a[i] & S_b[j]| at i*3+j, classes ref/alt/other */
+    uint8_t *edge_linked;    /* 1 when some QNAME's surviving read_vars list holds both variants */
+} phz_tally_out;
+
 /* timing slots for phz_get_timing */
 enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_COUNT = 8 };
 
@@ -104,6 +134,20 @@ void *phz_ctx_stream(phz_ctx *ctx);
 /* Read -> variant allele mapper.  On PHZ_E_CAPACITY *n_calls holds the required capacity. */
 int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_variants *vars, int baseq,
                   phz_calls *out, int64_t *n_calls, int space);
+
+/* AS histogram of one shard's call lines, ACCUMULATED into hist[PHZ_AS_BINS] (int64). */
+int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *hist, int space);
+
+/* Per-variant counters, distinct read sets and variant-pair co-occurrence cells of one chromosome over
+ * all its BAM shards (in BAM order).  a0/a1: the individual's two allele base codes per variant (255 when an
+ * allele is not a single ACGT base).  On PHZ_E_CAPACITY *n_edges holds the required edge capacity. */
+int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1,
+              int64_t n_qid, phz_tally_out *out, int64_t *n_edges, int space);
+
+/* Connected components of the variant graph restricted to edges with keep != 0: label[v] = smallest variant
+ * index of v's component. */
+int phz_components(phz_ctx *ctx, int64_t nv, int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b,
+                   const uint8_t *keep, int32_t *label, int space);
 
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);

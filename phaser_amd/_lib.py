@@ -41,6 +41,20 @@ class phz_calls(C.Structure):
                 ("aux0", C.c_void_p), ("aux1", C.c_void_p)]
 
 
+class phz_lines(C.Structure):
+    _fields_ = [("n_calls", C.c_int64), ("read_idx", C.c_void_p), ("var_idx", C.c_void_p), ("code", C.c_void_p),
+                ("n_reads", C.c_int64), ("read_qid", C.c_void_p), ("read_as", C.c_void_p), ("read_has_as", C.c_void_p),
+                ("as_cutoff", C.c_double), ("use_cutoff", C.c_int32), ("bam_index", C.c_int32)]
+
+
+class phz_tally_out(C.Structure):
+    _fields_ = [("var_count", C.c_void_p), ("var_first", C.c_void_p), ("var_distinct", C.c_void_p), ("line_cls", C.c_void_p),
+                ("edge_cap", C.c_int64), ("edge_a", C.c_void_p), ("edge_b", C.c_void_p), ("edge_cells", C.c_void_p),
+                ("edge_linked", C.c_void_p)]
+
+
+PHZ_AS_BINS = 65536
+
 # every symbol include/phz.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "phz_version": (C.c_int, []),
@@ -53,6 +67,10 @@ SYMBOLS = {
     "phz_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "phz_map_reads": (C.c_int, [C.c_void_p, C.POINTER(phz_reads), C.POINTER(phz_variants), C.c_int,
                                 C.POINTER(phz_calls), C.POINTER(C.c_int64), C.c_int]),
+    "phz_as_histogram": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_void_p, C.c_int]),
+    "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                            C.POINTER(phz_tally_out), C.POINTER(C.c_int64), C.c_int]),
+    "phz_components": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),

@@ -52,6 +52,7 @@ int phz_ctx_destroy(phz_ctx *c) {
     DevBuf *all[] = {&c->desc, &c->tile_w0, &c->scalars, &c->r_pos, &c->r_coff, &c->r_cig, &c->r_soff, &c->r_seq,
                      &c->r_qual, &c->v_pos, &c->v_reflen, &c->c_read, &c->c_var, &c->c_code, &c->c_aux0, &c->c_aux1};
     for (DevBuf *b : all) free_buf(*b);
+    for (DevBuf &b : c->scratch) free_buf(b);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
     delete c;

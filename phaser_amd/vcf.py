@@ -1,0 +1,149 @@
+"""Het-variant loading for the hot path: VCF text -> per-chromosome variant tables.
+
+Mirrors the filter of phaser/phaser.py:396-433 (GT present, no '.', more than one distinct allele,
+FILTER contains PASS unless --pass_only 0) and the table of generate_mapping_table :1355-1413
+(unique id, SNP-only unless --include_indels), plus the per-variant fields the phasing core derives
+from a call line in generate_variant_dict :1418-1462.
+"""
+from __future__ import annotations
+
+import dataclasses
+import gzip
+from typing import Dict, List
+
+import numpy as np
+
+_CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+@dataclasses.dataclass
+class ChromVariants:
+    chrom: str
+    pos: np.ndarray            # int32, VCF order (must be sorted for the mapper)
+    uid: List[str]
+    rsid_field: List[str]      # column 3 as written ('.' allowed)
+    rsid: List[str]            # '.'/'' replaced by uid (:1451-1455)
+    ref: List[str]
+    all_alleles: List[List[str]]
+    alleles: List[List[str]]   # the individual's alleles in allele-index order (:1430-1435)
+    phase: List[List[str]]     # alleles in GT order, or ['-','-'] when unphased (:1437-1443)
+    gt: List[str]
+    maf_text: List[str]        # str(maf) as written to the table ('None' unless --gw_phase_method 1)
+    maf: List[object]          # float, or int 0 when not parseable (:1445-1449)
+    ref_len: np.ndarray        # uint8
+    a0: np.ndarray             # uint8 base code of alleles[0] (255 when not a single ACGT base)
+    a1: np.ndarray
+
+    def __len__(self):
+        return len(self.uid)
+
+    def table_rows(self):
+        return [[self.chrom, str(int(self.pos[i])), self.uid[i], self.rsid_field[i], ",".join(self.all_alleles[i]),
+                 str(int(self.ref_len[i])), self.gt[i], self.maf_text[i]] for i in range(len(self))]
+
+
+@dataclasses.dataclass
+class VariantSet:
+    chroms: "Dict[str, ChromVariants]"       # insertion order = VCF order
+    het_count: int
+    filter_count: int
+    indels_excluded: int
+    unphased_count: int
+
+
+def read_text(path: str) -> str:
+    if path.endswith(".gz") or path.endswith(".bgz"):
+        with gzip.open(path, "rt") as f:
+            return f.read()
+    with open(path) as f:
+        return f.read()
+
+
+def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
+                  include_indels: int = 0, chr_prefix: str = "", id_separator: str = "_", gw_phase_method: int = 0,
+                  gw_af_field: str = "AF", contig_ban=("_", ":")) -> VariantSet:
+    per: Dict[str, list] = {}
+    filter_count = unphased = 0
+    for line in vcf_text.split("\n"):
+        if not line or line[0] == "#":
+            continue
+        c = line.split("\t")
+        chrom = c[0]
+        for item in contig_ban:
+            if item in chrom:
+                raise SystemExit("     FATAL ERROR: Character '%s' must not be present in contig name. Please change id separtor "
+                                 "using --id_separator to a character not found in the contig names and try again." % item)
+        if chrom_of_interest != "" and chrom_of_interest != chrom:
+            continue
+        rows = per.setdefault(chrom, [])
+        fields = c[8].split(":")
+        if "GT" not in fields:
+            continue
+        geno = c[sample_column].split(":")[fields.index("GT")]
+        g = list(geno)
+        if "." in g:
+            continue
+        if "|" in g:
+            g.remove("|")
+        is_unphased = False
+        if "/" in g:
+            g.remove("/")
+            is_unphased = True
+        if len(set(g)) > 1:
+            if pass_only == 0 or "PASS" in c[6].split(";"):
+                rows.append((c, geno, g))
+                unphased += is_unphased
+            else:
+                filter_count += 1
+    out: Dict[str, ChromVariants] = {}
+    het = excluded = 0
+    for chrom0, rows in per.items():
+        chrom = chr_prefix + chrom0
+        cv = ChromVariants(chrom, None, [], [], [], [], [], [], [], [], [], [], None, None, None)
+        pos = []; reflen = []; a0 = []; a1 = []
+        for c, geno, g in rows:
+            alts = c[4].split(",")
+            every = [c[3]] + alts
+            if not (max(len(x) for x in every) == 1 or include_indels == 1):
+                excluded += 1
+                continue
+            uid = chrom + id_separator + c[1] + id_separator + id_separator.join(every)
+            maf = None
+            if gw_phase_method == 1:
+                info = {}
+                for item in c[7].split(";"):
+                    if "=" in item:
+                        info[item.split("=")[0]] = item.split("=")[1]
+                if gw_af_field in info:
+                    afs = [float(x) for x in info[gw_af_field].split(",")]
+                    if len(afs) == len(alts):
+                        use = [int(x) - 1 for x in g if x != "." and int(x) != 0]
+                        if use:
+                            maf = min(min(afs[x], 1 - afs[x]) for x in use)
+            # fields the phasing core derives from the table row (generate_variant_dict)
+            gl = list(geno)
+            phased = "|" in gl
+            if phased:
+                gl.remove("|")
+            if "/" in gl:
+                gl.remove("/")
+            ind = [every[i] for i in range(len(every)) if str(i) in gl]
+            ph = [every[int(i)] for i in gl] if phased else ["-", "-"]
+            mtxt = str(maf)
+            try:
+                mval = float(mtxt)
+            except ValueError:
+                mval = 0
+            pos.append(int(c[1])); reflen.append(min(255, len(c[3])))
+            cv.uid.append(uid); cv.rsid_field.append(c[2]); cv.rsid.append(c[2] if c[2] not in (".", "") else uid)
+            cv.ref.append(c[3]); cv.all_alleles.append(every); cv.alleles.append(ind); cv.phase.append(ph); cv.gt.append(geno)
+            cv.maf_text.append(mtxt); cv.maf.append(mval)
+            a0.append(_CODE.get(ind[0], 255) if len(ind) > 0 else 255)
+            a1.append(_CODE.get(ind[1], 255) if len(ind) > 1 else 255)
+            het += 1
+        cv.pos = np.asarray(pos, dtype=np.int32); cv.ref_len = np.asarray(reflen, dtype=np.uint8)
+        cv.a0 = np.asarray(a0, dtype=np.uint8); cv.a1 = np.asarray(a1, dtype=np.uint8)
+        if len(pos) > 1 and bool((np.diff(cv.pos) < 0).any()):
+            raise SystemExit("     FATAL ERROR: VCF records of %s are not sorted by position." % chrom)
+        out[chrom] = cv
+    return VariantSet(out, het, filter_count, excluded, unphased)

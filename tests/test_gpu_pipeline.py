@@ -1,0 +1,82 @@
+"""GPU end-to-end parity: K_map + K_tally + components + host assembly vs the reference's five output files
+(tests/golden/pipe_*, c1/) and vs the pinned oracle on fresh seeded inputs.  Canonical forms per SURVEY.md 8(a)."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import GOLD, REPO, gz_text
+from helpers import OUTPUTS, canonical
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mapper():
+    from phaser_amd.mapper import Mapper
+    return Mapper(0)
+
+
+def run_product(mapper, vcf_text, bams, device="cpu", **cfgkw):
+    """bams: ordered {bam_path: {chrom: sam_text}}"""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from phasing_oracle import bam_display_names          # naming helper only (test side)
+    from phaser_amd import samio, vcf
+    from phaser_amd.engine import Config, Engine
+    vs = vcf.load_variants(vcf_text)
+    eng = Engine(vs, bam_display_names(list(bams.keys())), Config(**cfgkw), mapper=mapper)
+    interners = {}
+    for bi, (bam, per_chrom) in enumerate(bams.items()):
+        for chrom in vs.chroms:
+            if chrom not in per_chrom:
+                continue
+            shards = samio.shards_from_sam(per_chrom[chrom], interners)
+            for c2, sh in shards.items():
+                eng.add_shard(bi, c2, sh.to(device), len(interners[c2]), interners[c2].names)
+        for c2 in interners:
+            eng.n_qid[c2] = len(interners[c2])
+        eng.close_bam(bi)
+    return eng.finish(), eng
+
+
+def compare(out, gold_dir):
+    for name in OUTPUTS:
+        want = gz_text(os.path.join(gold_dir, "out.%s.txt.gz" % name))
+        assert canonical(name, out[name]) == canonical(name, want), name
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_pipe_one(mapper, device):
+    d = os.path.join(GOLD, "pipe_one")
+    out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(),
+                           {"a.bam": {"chr22": gz_text(os.path.join(d, "a.chr22.sam.gz"))}}, device)
+    compare(out, d)
+    log = gz_text(os.path.join(d, "out.log.txt.gz"))
+    for line in eng.log:
+        assert line in log, line
+
+
+def test_pipe_two_bams_two_chroms(mapper):
+    d = os.path.join(GOLD, "pipe_two")
+    bams = {}
+    for b in ("t1", "t2"):
+        bams[b + ".bam"] = {c: gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")}
+    out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(), bams, "cuda")
+    compare(out, d)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_pipe_noisy(mapper, tag):
+    d = os.path.join(GOLD, "pipe_noisy_" + tag)
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(),
+                           {"n.bam": {"chr22": gz_text(os.path.join(d, "n.chr22.sam.gz"))}}, "cuda",
+                           max_block_size=meta["max_block_size"])
+    compare(out, d)
+
+
+def test_c1(mapper, c1_inputs):
+    out, eng = run_product(mapper, c1_inputs["vcf"], {"c1.bam": {"chr22": c1_inputs["sam"]}}, "cuda")
+    compare(out, os.path.join(GOLD, "c1"))
