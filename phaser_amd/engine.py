@@ -17,6 +17,7 @@ import torch
 from scipy.stats import binom
 
 from . import _lib
+from . import dist as pdist
 from .mapper import Calls, Mapper
 from .phase import Block
 from .soa import ReadShard
@@ -60,13 +61,19 @@ class Engine:
         self.mapper = mapper or Mapper(device)
         self.ctx = self.mapper.ctx
         self.lib = self.ctx.lib
-        self.chrom_list = list(variants.chroms.keys())
-        self.shards: Dict[str, List[Optional[_Shard]]] = {c: [None] * len(bam_names) for c in self.chrom_list}
+        self.all_chroms = list(variants.chroms.keys())        # VCF order, identical on every rank
+        self.chrom_list = list(self.all_chroms)               # chromosomes this rank owns (set_owned)
+        self.shards: Dict[str, List[Optional[_Shard]]] = {c: [None] * len(bam_names) for c in self.all_chroms}
         self.qnames: Dict[str, List[str]] = {}
-        self.n_qid: Dict[str, int] = {c: 0 for c in self.chrom_list}
+        self.n_qid: Dict[str, int] = {c: 0 for c in self.all_chroms}
         self.log: List[str] = []
         self.stats: Dict[str, float] = {}
         self.total_lines = 0
+
+    def set_owned(self, chroms: List[str]):
+        """Multi-GPU: restrict this rank to its chromosomes (keeps VCF order)."""
+        own = set(chroms)
+        self.chrom_list = [c for c in self.all_chroms if c in own]
 
     # ---------------------------------------------------------------- stage 2: mapping (phaser.py:526-591)
     def add_shard(self, bam_index: int, chrom: str, shard: ReadShard, n_qid: int, qnames: Optional[List[str]] = None):
@@ -89,8 +96,8 @@ class Engine:
     def close_bam(self, bam_index: int):
         """AS quantile cutoff of one BAM over all its chromosomes (phaser.py:545-553)."""
         shards = [self.shards[c][bam_index] for c in self.chrom_list if self.shards[c][bam_index] is not None]
-        if self.cfg.as_q_cutoff > 0 and shards:
-            dev = shards[0].calls.read_idx.device
+        if self.cfg.as_q_cutoff > 0:
+            dev = shards[0].calls.read_idx.device if shards else self.mapper.device
             hist = torch.zeros(_lib.PHZ_AS_BINS, dtype=torch.int64, device=dev)
             space = _lib.PHZ_DEVICE if dev.type == "cuda" else _lib.PHZ_HOST
             for sh in shards:
@@ -99,6 +106,7 @@ class Engine:
                         raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
                     ln = self._lines(sh, bam_index)
                     self.ctx.check(self.lib.phz_as_histogram(self.ctx.h, C.byref(ln), _p(hist), space))
+            pdist.allreduce_sum_(hist)          # the quantile is over ALL chromosomes of this BAM
             h = hist.cpu().numpy()
             if int(h.sum()) > 0:
                 nz = np.nonzero(h)[0]
@@ -160,33 +168,51 @@ class Engine:
         res["bam_offsets"] = offs
         return res
 
-    def finish(self) -> Dict[str, str]:
-        cfg = self.cfg
-        per = {c: self._tally_chrom(c) for c in self.chrom_list}
-        self.tally = per
-        # ---- noise (phaser.py:610-632), global over chromosomes and BAMs
+    def tally_all(self):
+        """Stage A: K_tally per owned chromosome; returns the two global noise counters of these chromosomes."""
+        self.tally = {c: self._tally_chrom(c) for c in self.chrom_list}
         match = mism = 0
         for c in self.chrom_list:
-            vc = per[c]["var_count"].astype(np.int64)
+            vc = self.tally[c]["var_count"].astype(np.int64)
             m = vc[:, 0] + vc[:, 1]; mm = vc[:, 2]
             with np.errstate(divide="ignore", invalid="ignore"):
                 ok = (m > 0) & ((mm.astype(np.float64) / (mm + m).astype(np.float64)) < 0.05)
             match += int(m[ok].sum()); mism += int(mm[ok].sum())
-            self.total_lines += int((per[c]["line_cls"] != 255).sum())
+        return match, mism
+
+    @staticmethod
+    def noise_from_counts(match: int, mism: int) -> float:
+        """phaser.py:610-632 (global over chromosomes and BAMs)."""
         if match == 0:
             raise SystemExit("     FATAL ERROR: No reads could be matched to variants. Please double check your settings and input files. "
                              "Common reasons for this occurring include: 1) MAPQ or BASEQ set too conservatively 2) BAM and VCF have "
                              "different chromosome names (IE 'chr1' vs '1').")
-        noise = float(mism) / (float(match + mism) * 2)
-        self.noise = noise
-        self.log.append("     sequencing noise level estimated at %f" % noise)
+        return float(mism) / (float(match + mism) * 2)
 
+    def finish(self) -> Optional[Dict[str, str]]:
+        """Stages 3-6.  With torch.distributed initialised, every rank handles its own chromosomes and rank 0
+        returns the assembled files (other ranks return None)."""
+        match, mism = pdist.allreduce_counts(*self.tally_all())
+        noise = self.noise_from_counts(match, mism)
+        local = {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
+        frags = pdist.gather_fragments(local)
+        self.noise = noise
+        if frags is None:
+            return None
+        out, summary = merge_fragments(frags, [c for c in self.all_chroms if c in frags], self.cfg, noise)
+        self.noise = noise
+        self.log += summary["log"]
+        self.phased = summary["phased"]; self.total_lines = summary["lines"]
+        return out
+
+    def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
+        """Stage C for one chromosome: pair tests, pruning, components, block phasing, output rows."""
+        cfg = self.cfg
+        R = self.tally[c]; cv = self.vs.chroms[c]; nv = R["nv"]
+        frag = {"chrom": c, "lines": int((R["line_cls"] != 255).sum())}
         conn_rows: List[str] = []
-        dropped = 0
-        blocks_all = []                 # (chrom, [global variant idx...], [(i,j,cfg)...])
-        order_info = {}
-        for c in self.chrom_list:
-            R = per[c]; cv = self.vs.chroms[c]; nv = R["nv"]
+        blocks_all = []
+        if True:
             kept = R["line_cls"] != 255
             cls = R["line_cls"]
             # ---- ordering rules 3 and 4 (SURVEY.md 8.1): read_vars order, overlap-dict key order
@@ -213,7 +239,6 @@ class Engine:
                 idx = np.nonzero(multi)[0]
                 uv, first = np.unique(vs_[idx], return_index=True)
                 rank[uv] = idx[first]
-            order_info[c] = rank
             # ---- test every linked pair (phaser.py:1594-1654)
             sel = np.nonzero(R["linked"])[0]
             ea = R["ea"][sel]; eb = R["eb"][sel]; cells = R["cells"][sel].astype(np.int64)
@@ -249,7 +274,8 @@ class Engine:
                 else:
                     ptxt = "1"
                 conn_rows.append("\t".join([uid[a], uid[bb], str(int(sup[k])), str(int(tot[k])), ptxt, str(conc)]))
-            dropped += int((~keep_edge).sum())
+            frag["conn_rows"] = conn_rows
+            frag["dropped"] = int((~keep_edge).sum())
             # ---- connected components of the surviving graph on the GPU (phaser.py:1861-1882)
             dev = R["dev"]
             t_ea = torch.from_numpy(np.ascontiguousarray(ea)).to(dev); t_eb = torch.from_numpy(np.ascontiguousarray(eb)).to(dev)
@@ -262,7 +288,6 @@ class Engine:
             deg = np.zeros(nv, dtype=np.int64)
             np.add.at(deg, ea[keep_edge], 1); np.add.at(deg, eb[keep_edge], 1)
             members = np.nonzero(deg > 0)[0]
-            R["in_graph"] = deg > 0
             if len(members):
                 lab = label[members]
                 o2 = np.lexsort((members, lab))
@@ -270,7 +295,6 @@ class Engine:
                 starts = np.nonzero(np.r_[True, lab_s[1:] != lab_s[:-1]])[0]
                 ends = np.r_[starts[1:], len(lab_s)]
                 comp_rank = np.minimum.reduceat(rank[mem_s], starts)
-                # local edge lists per component
                 e_keep = np.nonzero(keep_edge)[0]
                 e_lab = label[ea[e_keep]]
                 eo = np.argsort(e_lab, kind="stable")
@@ -283,46 +307,31 @@ class Engine:
                     loc = {int(g): i for i, g in enumerate(mem)}
                     ek = e_keep[eo[e_starts[ci]:e_ends[ci]]]
                     edges = [(loc[int(ea[e])], loc[int(eb[e])], int(cfgv[e])) for e in ek]
-                    blocks_all.append((c, mem, edges))
-        self.log.append("     %d variant connections dropped because of conflicting configurations (threshold = %f)" % (dropped, cfg.cc_threshold))
-        out = {"variant_connections": "variant_a\tvariant_b\tsupporting_connections\ttotal_connections\tconflicting_configuration_p\tphase_concordant\n"
-               + "".join(r + "\n" for r in conn_rows)}
-
-        # ---- global first-appearance order of variants (rule 2) and allelic counts (phaser.py:737-749)
-        order = []
-        for ci, c in enumerate(self.chrom_list):
-            R = per[c]
-            vf = R["var_first"]
-            seen = np.nonzero(vf >= 0)[0]
-            if len(seen) == 0:
-                continue
-            bam_of = np.zeros(len(seen), dtype=np.int64)
-            for b, base, n in R["bam_offsets"]:
-                bam_of[(vf[seen] >= base) & (vf[seen] < base + n)] = b
-            for j, g in enumerate(seen):
-                order.append((int(bam_of[j]), ci, int(vf[g]), c, int(g)))
-        order.sort()
-        self.var_order = [(c, g) for _, _, _, c, g in order]
-        rows = ["contig\tposition\tvariantID\trefAllele\taltAllele\trefCount\taltCount\ttotalCount\n"]
-        covered = 0
-        for c, g in self.var_order:
-            cv = self.vs.chroms[c]; d = per[c]["var_distinct"][g]
+                    blocks_all.append((mem, edges))
+        # ---- first-appearance order keys of this chromosome's variants (rule 2) and allelic counts (:737-749)
+        vf = R["var_first"]
+        seen = np.nonzero(vf >= 0)[0]
+        bam_of = np.zeros(len(seen), dtype=np.int64)
+        for b_, base, n in R["bam_offsets"]:
+            bam_of[(vf[seen] >= base) & (vf[seen] < base + n)] = b_
+        keys = sorted((int(bam_of[j]), chrom_index, int(vf[g]), int(g)) for j, g in enumerate(seen))
+        allelic = []
+        for kb, kc, kl, g in keys:
+            d = R["var_distinct"][g]
             r0 = int(d[0]); r1 = int(d[1])
             if r0 + r1 > 0:
-                covered += 1
-                rows.append("\t".join([c, str(int(cv.pos[g])), cv.uid[g], cv.alleles[g][0], cv.alleles[g][1], str(r0), str(r1), str(r0 + r1) + "\n"]))
-        out["allelic_counts"] = "".join(rows)
-        self.log.append("     %d variants covered by at least 1 read" % covered)
-
-        # ---- phase blocks (phaser.py:795-814) and write (:832-1243)
-        final = []                  # (chrom, [(global idx, allele char)...])
-        for c, mem, edges in blocks_all:
+                allelic.append(((kb, kc, kl), "\t".join([c, str(int(cv.pos[g])), cv.uid[g], cv.alleles[g][0], cv.alleles[g][1], str(r0), str(r1),
+                                                         str(r0 + r1) + "\n"])))
+        frag["allelic"] = allelic
+        # ---- phase blocks (phaser.py:795-814) and format rows (:832-1243)
+        final = []
+        for mem, edges in blocks_all:
             blk = Block(len(mem), edges)
             for sub in blk.phase(cfg.max_block_size):
-                final.append((c, [(int(mem[i]), a) for i, a in sub]))
-        out.update(self._write(final, per, blocks_all))
-        self.phased = sum(len(b[1]) for b in final)
-        return out
+                final.append([(int(mem[i]), a) for i, a in sub])
+        frag.update(self._rows(c, final, R, blocks_all, keys))
+        frag["phased"] = sum(len(b) for b in final)
+        return frag
 
     # ---------------------------------------------------------------- output (phaser.py:832-1243)
     def _read_lists(self, R):
@@ -339,38 +348,29 @@ class Engine:
         R["by_var"] = (lines[o], starts, ends)
         return R["by_var"]
 
-    def _write(self, final, per, blocks_all):
+    def _rows(self, c, final, R, blocks_all, var_keys):
         cfg = self.cfg
         nb = len(self.bam_names)
-        cols = ["contig", "start", "stop", "variants", "variantCount", "variantsBlacklisted", "variantCountBlacklisted", "haplotypeA",
-                "haplotypeB", "aCount", "bCount", "totalCount", "blockGWPhase", "gwStat", "max_haplo_maf", "bam", "aReads", "bReads"]
-        if cfg.output_read_ids == 1:
-            cols += ["read_ids_a", "read_ids_b"]
-        ase = ["\t".join(cols) + "\n"]
-        hap = ["\t".join(['contig', 'start', 'stop', 'length', 'variants', 'variant_ids', 'variant_alleles', 'reads_hap_a', 'reads_hap_b',
-                          'reads_total', 'edges_supporting', 'edges_total', 'annotated_phase', 'phase_concordant', 'gw_phase',
-                          'gw_confidence']) + "\n"]
-        cfgf = ["\t".join(['variant_a', 'rsid_a', 'variant_b', 'rsid_b', 'configuration']) + "\n"]
-        # allele-edge lookup per chromosome for supporting / total edge counts: (a, b) -> cfg for surviving edges
-        edge_cfg: Dict[str, Dict[tuple, int]] = {}
-        for c, mem, edges in blocks_all:
-            d = edge_cfg.setdefault(c, {})
+        cv = self.vs.chroms[c]
+        blocks_out = []
+        # allele-edge lookup for supporting / total edge counts: (a, b) -> cfg for surviving edges
+        d: Dict[tuple, int] = {}
+        for mem, edges in blocks_all:
             for i, j, k in edges:
                 a, b = int(mem[i]), int(mem[j])
                 d[(a, b)] = k; d[(b, a)] = k
-        in_block: Dict[str, set] = {c: set() for c in self.chrom_list}
-        for c, blk in final:
-            cv = self.vs.chroms[c]; R = per[c]
-            lines_sorted, starts, ends = self._read_lists(R)
-            lq = R["line_qid"]; lbam = R["line_bam"]
+        in_block = set()
+        lines_sorted, starts, ends = self._read_lists(R)
+        lq = R["line_qid"]; lbam = R["line_bam"]
+        for blk in final:
+            ase = []; cfgf = []
             blk = sorted(blk, key=lambda t: (int(cv.pos[t[0]]), t[0]))     # sort_var_ids again (:869); already sorted
             variants = [g for g, _ in blk]
-            in_block[c].update(variants)
+            in_block.update(variants)
             ha = "".join(a for _, a in blk)
             hb = "".join(str(int(not int(x))) for x in ha)
             # edges supporting / total (:876-895): ordered allele pairs, halved
             sup = tot = 0
-            d = edge_cfg.get(c, {})
             alle_of = {g: int(a) for g, a in blk}
             for g1 in variants:
                 for g2 in variants:
@@ -396,8 +396,8 @@ class Engine:
                         phs[h].append(cv.phase[g].index(a))
                     except ValueError:
                         phs[h].append(float("nan"))
-                    s, e = starts[g * 2 + k], ends[g * 2 + k]
-                    pool.append(lq[lines_sorted[s:e]])
+                    s_, e_ = starts[g * 2 + k], ends[g * 2 + k]
+                    pool.append(lq[lines_sorted[s_:e_]])
                 counts[h] = len(np.unique(np.concatenate(pool))) if pool else 0
             usable = [x for x in phs[0] if str(x) != "nan"]
             conc = 1 if len(set(usable)) <= 1 else 0
@@ -438,8 +438,8 @@ class Engine:
                             cor = [[1] * len(variants), [0] * len(variants)]
                         stat = max([stat, 1 - stat])
             cstr = ["".join(str(x).replace("nan", "-") for x in cor[0]), "".join(str(x).replace("nan", "-") for x in cor[1])]
-            hap.append(_jl([c, min(poss), max(poss), max(poss) - min(poss), len(variants), _jl(rsids), _jl(alle[0]) + "|" + _jl(alle[1]),
-                            counts[0], counts[1], sum(counts), sup, tot, pstr[0] + "|" + pstr[1], conc, cstr[0] + "|" + cstr[1], stat], "\t") + "\n")
+            hap_row = _jl([c, min(poss), max(poss), max(poss) - min(poss), len(variants), _jl(rsids), _jl(alle[0]) + "|" + _jl(alle[1]),
+                           counts[0], counts[1], sum(counts), sup, tot, pstr[0] + "|" + pstr[1], conc, cstr[0] + "|" + cstr[1], stat], "\t") + "\n"
             # haplotypic counts, one row per BAM (:1048-1125)
             for b in range(nb):
                 if b in cfg.haplo_count_bam_exclude:
@@ -454,8 +454,8 @@ class Engine:
                             if g not in used_vars:
                                 used_vars.append(g)
                             used_alleles[h].append(cv.alleles[g][k])
-                            s, e = starts[g * 2 + k], ends[g * 2 + k]
-                            ln = lines_sorted[s:e]
+                            s_, e_ = starts[g * 2 + k], ends[g * 2 + k]
+                            ln = lines_sorted[s_:e_]
                             vreads[h].append(lq[ln[lbam[ln] == b]])
                         elif g not in black:
                             black.append(g)
@@ -488,17 +488,16 @@ class Engine:
                     if ga != gb:
                         ra = cv.ref[ga] == aa; rb = cv.ref[gb] == ab
                         cfgf.append("\t".join([cv.uid[ga], cv.rsid[ga], cv.uid[gb], cv.rsid[gb], "trans" if ra == rb else "cis"]) + "\n")
+            blocks_out.append({"hap": hap_row, "ase": ase, "cfg": cfgf})
         # ---- singletons (:1180-1239): variants kept in dict_variant_reads but in no block
+        singles = []
         if cfg.unphased_vars == 1:
-            single_rows_a = []; single_rows_h = []
-            for c, g in self.var_order:
-                R = per[c]; cv = self.vs.chroms[c]
+            for kb, kc, kl, g in var_keys:
                 vc = R["var_count"][g]
-                if int(vc[0]) + int(vc[1]) == 0 or g in in_block[c]:       # removed at :769-774, or phased
+                if int(vc[0]) + int(vc[1]) == 0 or g in in_block:       # removed at :769-774, or phased
                     continue
-                lines_sorted, starts, ends = self._read_lists(R)
-                lq = R["line_qid"]; lbam = R["line_bam"]
                 ph = cv.phase[g]
+                rows_a = []
                 if c + "_" + str(int(cv.pos[g])) not in cfg.haplo_blacklist:
                     for b in range(nb):
                         if b in cfg.haplo_count_bam_exclude:
@@ -516,12 +515,55 @@ class Engine:
                                 qn = self.qnames[c]
                                 f += [_jl(qn[int(x)] for x in per_allele[0]), _jl(qn[int(x)] for x in per_allele[1])]
                             f += [str(cv.maf[g]), self.bam_names[b], "", ""]
-                            single_rows_a.append("\t".join(f) + "\n")
-                d = R["var_distinct"][g]
+                            rows_a.append("\t".join(f) + "\n")
+                dd = R["var_distinct"][g]
                 ps = (str(ph.index(cv.alleles[g][0])) + "|" + str(ph.index(cv.alleles[g][1]))) if "-" not in ph else "-|-"
                 name = cv.rsid[g] if cfg.unique_ids == 0 else cv.uid[g]
-                single_rows_h.append("\t".join([c, str(int(cv.pos[g]) - 1), str(int(cv.pos[g])), "1", "1", name,
-                                                cv.alleles[g][0] + "|" + cv.alleles[g][1], str(int(d[0])), str(int(d[1])), str(int(d[0]) + int(d[1])),
-                                                "0", "0", ps, str(float("nan")), ps, str(float("nan"))]) + "\n")
-            ase += single_rows_a; hap += single_rows_h
-        return {"haplotypic_counts": "".join(ase), "haplotypes": "".join(hap), "allele_config": "".join(cfgf)}
+                hrow = "\t".join([c, str(int(cv.pos[g]) - 1), str(int(cv.pos[g])), "1", "1", name,
+                                  cv.alleles[g][0] + "|" + cv.alleles[g][1], str(int(dd[0])), str(int(dd[1])), str(int(dd[0]) + int(dd[1])),
+                                  "0", "0", ps, str(float("nan")), ps, str(float("nan"))]) + "\n"
+                singles.append(((kb, kc, kl), rows_a, hrow))
+        return {"blocks": blocks_out, "singles": singles}
+
+
+HEAD_ASE = ["contig", "start", "stop", "variants", "variantCount", "variantsBlacklisted", "variantCountBlacklisted", "haplotypeA",
+            "haplotypeB", "aCount", "bCount", "totalCount", "blockGWPhase", "gwStat", "max_haplo_maf", "bam", "aReads", "bReads"]
+HEAD_HAP = ['contig', 'start', 'stop', 'length', 'variants', 'variant_ids', 'variant_alleles', 'reads_hap_a', 'reads_hap_b',
+            'reads_total', 'edges_supporting', 'edges_total', 'annotated_phase', 'phase_concordant', 'gw_phase', 'gw_confidence']
+
+
+def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config", noise: float):
+    """Stage D (rank 0): assemble the five files from per-chromosome fragments in the reference's global order:
+    chromosomes in VCF order for connections / blocks, first-appearance keys (BAM, chromosome, line) for
+    allelic_counts and singletons.  Pure Python on plain data, so it is what the multi-GPU gather feeds."""
+    cols = list(HEAD_ASE)
+    if cfg.output_read_ids == 1:
+        cols += ["read_ids_a", "read_ids_b"]
+    conn = ["variant_a\tvariant_b\tsupporting_connections\ttotal_connections\tconflicting_configuration_p\tphase_concordant\n"]
+    ase = ["\t".join(cols) + "\n"]
+    hap = ["\t".join(HEAD_HAP) + "\n"]
+    cfgf = ["\t".join(['variant_a', 'rsid_a', 'variant_b', 'rsid_b', 'configuration']) + "\n"]
+    allelic = []
+    singles = []
+    dropped = phased = lines = 0
+    for c in chrom_list:
+        f = frags[c]
+        conn += [r + "\n" for r in f["conn_rows"]]
+        dropped += f["dropped"]; phased += f["phased"]; lines += f["lines"]
+        allelic += [(tuple(k), r) for k, r in f["allelic"]]
+        for b in f["blocks"]:
+            hap.append(b["hap"]); ase += b["ase"]; cfgf += b["cfg"]
+        singles += [(tuple(k), ra, rh) for k, ra, rh in f["singles"]]
+    allelic.sort(key=lambda t: t[0])
+    singles.sort(key=lambda t: t[0])
+    for _, ra, rh in singles:
+        ase += ra
+    for _, ra, rh in singles:
+        hap.append(rh)
+    out = {"variant_connections": "".join(conn),
+           "allelic_counts": "contig\tposition\tvariantID\trefAllele\taltAllele\trefCount\taltCount\ttotalCount\n" + "".join(r for _, r in allelic),
+           "haplotypic_counts": "".join(ase), "haplotypes": "".join(hap), "allele_config": "".join(cfgf)}
+    log = ["     sequencing noise level estimated at %f" % noise,
+           "     %d variant connections dropped because of conflicting configurations (threshold = %f)" % (dropped, cfg.cc_threshold),
+           "     %d variants covered by at least 1 read" % len(allelic)]
+    return out, {"log": log, "phased": phased, "lines": lines, "dropped": dropped, "covered": len(allelic)}
