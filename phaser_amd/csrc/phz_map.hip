@@ -7,28 +7,29 @@
 // Integer / branch work on an HBM-resident structure of arrays; no MFMA.
 //
 // Launch shape: one 256-thread workgroup per tile of 1024 consecutive (coordinate-sorted) reads, four
-// reads per lane strided by 256 so pos/cigar_off/seq_off loads coalesce.  Per tile:
-//   1. the het-SNP window starting at lower_bound(vpos, POS of the tile's first read) is staged in LDS
-//      (2048 positions = 8 KiB); lanes binary-search it per aligned run, falling through to global
-//      memory only for introns that reach past the window,
-//   2. pass A walks each read's packed CIGAR and counts its calls (seq/qual bytes are touched only
-//      under a variant), a wave shuffle scan + LDS combine gives per-read output offsets,
-//   3. a decoupled look-back over 8-byte {status,value} tile descriptors (single agent-scope atomics,
-//      wave-parallel with ballot) yields the tile's global output base, so the call list comes out in
-//      exact mapper order without a second launch,
-//   4. pass B re-walks only the reads that produced calls and writes them.
+// reads per lane strided by 256 so every streaming load (pos, cigar_off, seq_off, cigar words) is coalesced.
+// Per tile (k_map):
+//   1. LDS staging with coalesced block-wide loads: the tile's cigar_off slice, its contiguous run of packed
+//      CIGAR words, and the het-SNP window that starts at lower_bound(vpos, POS of the tile's first read),
+//      sized by a pre-pass (k_tile_window) to what the tile's reads reach without introns; lanes binary-search
+//      the window per aligned run and fall through to global memory only for introns reaching past it,
+//   2. each lane walks its reads' CIGARs out of LDS; seq/qual bytes are touched only under a variant (one
+//      gather of two bytes per call); calls are appended to an LDS call buffer tagged (read, ordinal),
+//   3. a wave shuffle scan + LDS combine turns per-read counts into offsets, and the buffer is flushed in
+//      exact mapper order into the tile's slot of a staging area (tile x CAP calls); a tile whose calls
+//      overflow the LDS buffer re-walks its reads and writes straight to the slot.
+// k_chunk_scan / k_chunk_base prefix-sum the per-tile totals; k_compact copies every slot to its final
+// offset, so the call list is in mapper order with no inter-workgroup dependency inside k_map (a
+// decoupled look-back was measured 0.8 ms slower here: tiles finish faster than descriptors travel).
 #include "phz_internal.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int MAP_BLOCK = 256;
-constexpr int MAP_RPT = 4;
-constexpr int MAP_TILE = MAP_BLOCK * MAP_RPT;
-constexpr int MAP_WIN = 2048;
+constexpr int MAP_WIN = 512;       // het-SNP positions staged per tile (max)
 
 constexpr uint32_t OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_EQ = 7, OP_X = 8, OP_G = 9;
-
-constexpr uint64_t ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1;
 
 struct MapArgs {
     const int32_t *pos;
@@ -38,24 +39,24 @@ struct MapArgs {
     const int32_t *vpos;
     int nv;
     int baseq;
+    // staging slots: tile t owns [t*slot_cap, (t+1)*slot_cap)
     int32_t *o_read, *o_var;
     uint8_t *o_code;
     uint32_t *o_aux0, *o_aux1;
-    int64_t cap;
-    const int32_t *tile_w0;
-    uint64_t *desc;
-    uint32_t *ticket;
-    unsigned long long *total;
+    const int32_t *tile_w0;       // [4*ntiles]: window start, window length | complete flag, first CIGAR word, CIGAR word count
+    int32_t *tile_total;          // [ntiles] calls per tile
+    int slot_cap;
     int64_t ntiles;
+    int dbg;          // ablation switches for profiling (PHZ_MAP_DBG env); 0 in production
 };
 
 struct VarWin {
     const int32_t *g;
     const int32_t *lds;
-    int w0, nv;
+    int w0, nv, wlen;
     __device__ __forceinline__ int at(int i) const {
         unsigned d = (unsigned)(i - w0);
-        return d < (unsigned)MAP_WIN ? lds[d] : g[i];
+        return d < (unsigned)wlen ? lds[d] : g[i];
     }
     // first index in [lo, nv) whose position is >= key
     __device__ __forceinline__ int lower_bound(int lo, int key) const {
@@ -75,6 +76,26 @@ struct VarWin {
     }
 };
 
+// the tile's packed CIGAR words: LDS for the staged prefix, global beyond it
+struct CigWin {
+    const uint32_t *g;
+    const uint32_t *lds;
+    uint32_t c_begin, cap;
+    __device__ __forceinline__ uint32_t at(uint32_t k) const {
+        const uint32_t d = k - c_begin;
+        return d < cap ? lds[d] : g[k];
+    }
+};
+
+// LDS candidate buffer (one per workgroup): every (read, variant) pair that passes the position rule
+struct CandBuf {
+    uint32_t *key;    // local read index << 16 | ordinal within the read << 8 | code (filled by the resolve phase)
+    int32_t *var;
+    uint32_t *aux0, *aux1;
+    int *n;           // candidates appended; > cap (or an ordinal >= 32) sends the tile down the in-lane fallback
+    int cap;
+};
+
 // symbol of read base x after baseq masking: 0..3 = ACGT, 4 = 'N', 5 = other IUPAC character
 __device__ __forceinline__ int masked_base(const MapArgs &a, uint32_t soff, int x) {
     uint32_t q = a.qual[(size_t)soff * 4 + x];
@@ -84,24 +105,24 @@ __device__ __forceinline__ int masked_base(const MapArgs &a, uint32_t soff, int 
     return (int)s;
 }
 
-template <bool EMIT>
-__device__ int walk_read(const MapArgs &a, const VarWin &vw, int64_t r, int64_t out_base) {
-    const int pos = a.pos[r];
-    const uint32_t c0 = a.cigar_off[r], c1 = a.cigar_off[r + 1];
+// MODE 0: position rule only, candidates appended to the LDS buffer (no global loads in the divergent walk)
+// MODE 1: count calls, resolving bases in-lane (fallback)      MODE 2: emit calls in-lane (fallback)
+template <int MODE>
+__device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, const CandBuf &cb, int j, int64_t r, int pos,
+                         uint32_t c0, uint32_t c1, uint32_t soff, int64_t out_base, int64_t out_limit) {
     int i = vw.lower_bound(vw.w0, pos);
     if (i >= vw.nv) return 0;
-    const uint32_t soff = a.seq_off[r];
     int cnt = 0;
     int gpos = 0, rpos = 0, seg_start = 0, plen = 0, seg_rpos = 0;
     uint32_t seg_op = c0;
     for (uint32_t k = c0; k < c1; k++) {
-        uint32_t w = a.cigar[k];
+        uint32_t w = cw.at(k);
         const int len = (int)(w >> 4);
         const uint32_t op = w & 15;
         if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) {
             const int lo = pos + seg_start + plen, hi = lo + len;
             if (i < vw.nv && vw.at(i) < lo) i = vw.lower_bound(i, lo);
-            while (i < vw.nv) {
+            while (i < vw.nv && !(a.dbg & 16)) {
                 const int vp = vw.at(i);
                 if (vp >= hi) break;
                 const int p = vp - pos - seg_start;            // index into the segment's pseudo read
@@ -111,7 +132,7 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, int64_t r, int64_t 
                 if (c1 - c0 > 1) {
                     int g2 = seg_start, r2 = seg_rpos;
                     for (uint32_t k2 = seg_op; k2 < c1; k2++) {
-                        uint32_t w2 = a.cigar[k2];
+                        uint32_t w2 = cw.at(k2);
                         const int l2 = (int)(w2 >> 4);
                         const uint32_t o2 = w2 & 15;
                         if (o2 == OP_N) break;
@@ -121,26 +142,40 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, int64_t r, int64_t 
                         else if (o2 == OP_S) r2 += l2;
                     }
                 }
-                int nchars = (op != OP_D) + ilen;
-                int code = -1;
-                if (nchars == 1) {
-                    const int s = masked_base(a, soff, op != OP_D ? rb : ioff);
-                    code = s < 4 ? s : (s == 4 ? -1 : 4);
-                } else if (nchars > 1) {
-                    code = 4;
-                }
-                if (code >= 0) {
-                    if (EMIT) {
-                        const int64_t o = out_base + cnt;
-                        if (o < a.cap) {
-                            a.o_read[o] = (int32_t)r;
-                            a.o_var[o] = i;
-                            a.o_code[o] = (uint8_t)code;
-                            a.o_aux0[o] = op != OP_D ? (uint32_t)rb : 0xFFFFFFFFu;
-                            a.o_aux1[o] = ilen > 0 ? (((uint32_t)ioff << 12) | (uint32_t)(ilen > 4095 ? 4095 : ilen)) : 0u;
+                const int nchars = (op != OP_D) + ilen;
+                if (nchars > 0) {
+                    const uint32_t x0 = op != OP_D ? (uint32_t)rb : 0xFFFFFFFFu;
+                    const uint32_t x1 = ilen > 0 ? (((uint32_t)ioff << 12) | (uint32_t)(ilen > 4095 ? 4095 : ilen)) : 0u;
+                    if (MODE == 0) {
+                        // code 7 = one character, to be resolved from seq/qual; 4 = composite text (always a call)
+                        const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicAdd(cb.n, 1 << 20), 1 << 20);
+                        if (slot < cb.cap) {
+                            cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)cnt << 8) | (nchars == 1 ? 7u : 4u);
+                            cb.var[slot] = i;
+                            cb.aux0[slot] = x0;
+                            cb.aux1[slot] = x1;
+                        }
+                        cnt++;
+                    } else {
+                        int code = 4;
+                        if (nchars == 1) {
+                            const int s = masked_base(a, soff, op != OP_D ? rb : ioff);
+                            code = s < 4 ? s : (s == 4 ? -1 : 4);
+                        }
+                        if (code >= 0) {
+                            if (MODE == 2) {
+                                const int64_t o = out_base + cnt;
+                                if (o < out_limit) {
+                                    a.o_read[o] = (int32_t)r;
+                                    a.o_var[o] = i;
+                                    a.o_code[o] = (uint8_t)code;
+                                    a.o_aux0[o] = x0;
+                                    a.o_aux1[o] = x1;
+                                }
+                            }
+                            cnt++;
                         }
                     }
-                    cnt++;
                 }
                 i++;
             }
@@ -157,56 +192,43 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, int64_t r, int64_t 
     return cnt;
 }
 
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl(lo, src); hi = __shfl(hi, src);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
-    return ((uint64_t)hi << 32) | lo;
-}
+constexpr int MAP_COVER = 65536;   // the staged window holds every het SNP below POS(last read of the tile) + MAP_COVER ...
+constexpr int MAP_SLACK = 64;      // ... plus this many further entries (probe overshoot / loop sentinels)
 
-// per-tile window start: tile_w0[t] = lower_bound(vpos, pos[t * MAP_TILE])
-__global__ void k_tile_window(const int32_t *pos, int64_t n, const int32_t *vpos, int nv, int32_t *tile_w0, int64_t ntiles) {
+// per-tile het-SNP window: start = lower_bound(vpos, POS of the tile's first read); tile_w[4t+1] = staged length,
+// bit 30 set when the window is complete (not truncated by MAP_WIN), which enables the LDS-only fast path
+__global__ void k_tile_window(const int32_t *pos, const uint32_t *cigar_off, int64_t n, const int32_t *vpos, int nv, int32_t *tile_w,
+                              int64_t ntiles, int tile_reads) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
-    const int key = pos[t * MAP_TILE];
+    const int key = pos[t * tile_reads];
     int lo = 0, hi = nv;
     while (lo < hi) {
         int m = (lo + hi) >> 1;
         if (vpos[m] < key) lo = m + 1; else hi = m;
     }
-    tile_w0[t] = lo;
+    const int64_t last = (t + 1) * tile_reads - 1 < n ? (t + 1) * tile_reads - 1 : n - 1;
+    const long long key2 = (long long)pos[last] + MAP_COVER;
+    int lo2 = lo; hi = nv;
+    while (lo2 < hi) {
+        int m = (lo2 + hi) >> 1;
+        if ((long long)vpos[m] < key2) lo2 = m + 1; else hi = m;
+    }
+    int len = lo2 - lo + MAP_SLACK;
+    int complete = 1 << 30;
+    if (len > MAP_WIN) { len = MAP_WIN; complete = 0; }
+    tile_w[4 * t] = lo;
+    tile_w[4 * t + 1] = len | complete;
+    tile_w[4 * t + 2] = (int32_t)cigar_off[t * tile_reads];            // first CIGAR word of the tile
+    tile_w[4 * t + 3] = (int32_t)(cigar_off[last + 1] - cigar_off[t * tile_reads]);
 }
 
-__global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
-    __shared__ int32_t s_vpos[MAP_WIN];
-    __shared__ int s_wsum[MAP_RPT][MAP_BLOCK / 64];
-    __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_tile;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
-    __syncthreads();
-    const int64_t tile = s_tile;
-    const int64_t r0 = tile * MAP_TILE;
-
-    VarWin vw;
-    vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = a.tile_w0[tile];
-    for (int j = tid; j < MAP_WIN; j += MAP_BLOCK) {
-        const int idx = vw.w0 + j;
-        s_vpos[j] = idx < a.nv ? a.vpos[idx] : 0x7fffffff;
-    }
-    __syncthreads();
-
-    // ---- pass A: count
-    int cnt[MAP_RPT], incl[MAP_RPT];
+// block-wide exclusive scan of RPT per-thread values laid out at [k*MAP_BLOCK + tid]; returns the block total
+template <int RPT>
+__device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT], int (*s_wsum)[MAP_BLOCK / 64], int lane, int wave) {
+    int incl[RPT];
 #pragma unroll
-    for (int k = 0; k < MAP_RPT; k++) {
-        const int64_t r = r0 + k * MAP_BLOCK + tid;
-        cnt[k] = r < a.n ? walk_read<false>(a, vw, r, 0) : 0;
+    for (int k = 0; k < RPT; k++) {
         int x = cnt[k];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -217,10 +239,9 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
         if (lane == 63) s_wsum[k][wave] = x;
     }
     __syncthreads();
-    int off[MAP_RPT];
     int running = 0;
 #pragma unroll
-    for (int k = 0; k < MAP_RPT; k++) {
+    for (int k = 0; k < RPT; k++) {
         int before = running;
 #pragma unroll
         for (int w2 = 0; w2 < MAP_BLOCK / 64; w2++) {
@@ -228,46 +249,302 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
             if (w2 < wave) before += s;
             running += s;
         }
-        off[k] = before + incl[k] - cnt[k];
+        excl[k] = before + incl[k] - cnt[k];
     }
-    const uint64_t T = (uint64_t)running;   // calls of this tile
+    return running;
+}
 
-    // ---- decoupled look-back for the tile's global base (wave 0)
-    if (wave == 0) {
-        if (lane == 0 && tile > 0)
-            __hip_atomic_store(&a.desc[tile], ST_AGG | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t sum = 0;
-        int64_t j = tile - 1;
-        for (;;) {
-            const int64_t idx = j - lane;
-            uint64_t d = idx >= 0 ? __hip_atomic_load(&a.desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_PREFIX;
-            const uint32_t st = (uint32_t)(d >> 62);
-            const uint64_t m_prefix = __ballot(st == 2), m_empty = __ballot(st == 0);
-            const int fp = m_prefix ? __ffsll((unsigned long long)m_prefix) - 1 : 64;
-            const uint64_t upto = fp >= 63 ? ~0ull : ((2ull << fp) - 1);
-            if (m_empty & upto) { __builtin_amdgcn_s_sleep(2); continue; }
-            uint64_t v = lane <= fp ? (d & ST_MASK) : 0;
+template <int RPT>
+__global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
+    constexpr int TILE = MAP_BLOCK * RPT;
+    constexpr int CIG = TILE * 5 / 2;          // packed CIGAR words staged per tile (max)
+    constexpr int CAND = TILE * 3 / 4;         // candidate buffer entries (complex records only)
+    __shared__ int32_t s_vpos[MAP_WIN];
+    __shared__ uint32_t s_coff[TILE + 1];      // cigar_off slice; reused as per-read output offsets after the walk
+    __shared__ uint32_t s_soff[TILE];
+    __shared__ int32_t s_pos[TILE];
+    __shared__ uint32_t s_mask[TILE];          // per read: bit o set <=> candidate with ordinal o is a call
+    __shared__ uint16_t s_cx[TILE];            // reads that need the general CIGAR walk
+    __shared__ uint32_t s_cig[CIG];
+    __shared__ uint32_t s_key[CAND];
+    __shared__ int32_t s_var[CAND];
+    __shared__ uint32_t s_aux0[CAND];
+    __shared__ uint32_t s_aux1[CAND];
+    __shared__ int s_wsum[RPT][MAP_BLOCK / 64];
+    __shared__ int s_ncand, s_ncx;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = blockIdx.x;
+    const int64_t r0 = tile * TILE;
+    const int nr = (int)((a.n - r0) < TILE ? (a.n - r0) : TILE);
+
+    // ---- coalesced streaming loads: pos / seq_off / cigar_off slices into LDS
+    int rpos_[RPT];
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
-            sum += v;
-            if (fp < 64) break;
-            j -= 64;
+    for (int k = 0; k < RPT; k++) {
+        const int j = k * MAP_BLOCK + tid;
+        const bool ok = j < nr;
+        rpos_[k] = ok ? a.pos[r0 + j] : 0;
+        s_pos[j] = rpos_[k];
+        s_soff[j] = ok ? a.seq_off[r0 + j] : 0;
+        s_coff[j] = a.cigar_off[r0 + (ok ? j : nr)];
+        s_mask[j] = 0;
+    }
+    if (tid == 0) { s_coff[TILE] = a.cigar_off[r0 + nr]; s_ncand = 0; s_ncx = 0; }
+    VarWin vw;
+    const int4 tw = *reinterpret_cast<const int4 *>(a.tile_w0 + 4 * tile);
+    vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = tw.x;
+    vw.wlen = tw.y & 0xFFFF;
+    const bool complete = (tw.y >> 30) & 1;
+    for (int j = tid; j < vw.wlen; j += MAP_BLOCK) {
+        const int idx = vw.w0 + j;
+        s_vpos[j] = idx < a.nv ? a.vpos[idx] : 0x7fffffff;
+    }
+    CigWin cw;
+    cw.g = a.cigar; cw.lds = s_cig; cw.c_begin = (uint32_t)tw.z; cw.cap = CIG;
+    {
+        uint32_t cnt_w = (uint32_t)tw.w;
+        if (cnt_w > (uint32_t)CIG) cnt_w = CIG;
+        for (uint32_t j = tid; j < cnt_w; j += MAP_BLOCK) s_cig[j] = a.cigar[cw.c_begin + j];
+    }
+    __syncthreads();
+    CandBuf cb;
+    cb.key = s_key; cb.var = s_var; cb.aux0 = s_aux0; cb.aux1 = s_aux1; cb.n = &s_ncand; cb.cap = CAND;
+    const long long cover = (long long)s_pos[nr - 1] + MAP_COVER;     // every het SNP below this is inside the window
+
+    // ---- phase 1a: records made of one aligned run (the common case) never leave registers: an LDS-only,
+    //      uniform-trip-count binary search yields (first window index, count) of the het SNPs under the read
+    uint32_t c0_[RPT], c1_[RPT];
+    int base_[RPT], n_[RPT];
+    uint32_t vmask_[RPT], codes_[RPT];
+    bool fast_[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int j = k * MAP_BLOCK + tid;
+        c0_[k] = s_coff[j]; c1_[k] = s_coff[j + 1];
+        base_[k] = 0; n_[k] = 0; vmask_[k] = 0; codes_[k] = 0; fast_[k] = false;
+    }
+    const bool walk_on = !(a.dbg & 8);
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int j = k * MAP_BLOCK + tid;
+        if (j >= nr || !walk_on) continue;
+        const uint32_t d = c0_[k] - cw.c_begin;
+        if (complete && c1_[k] - c0_[k] == 1 && d < (uint32_t)CIG) {
+            const uint32_t w = s_cig[d];
+            const uint32_t op = w & 15;
+            const int len = (int)(w >> 4);
+            const int pos = rpos_[k];
+            if ((op == OP_M || op == OP_EQ || op == OP_X) && (long long)pos + len <= cover) {
+                int base = 0, n = vw.wlen;
+                while (n > 1) {
+                    const int half = n >> 1;
+                    base += (s_vpos[base + half - 1] < pos) ? half : 0;
+                    n -= half;
+                }
+                base += (s_vpos[base] < pos) ? 1 : 0;
+                const int hi = pos + len;
+                int c = 0;
+                while (base + c < vw.wlen && s_vpos[base + c] < hi && c <= 8) c++;
+                if (c <= 8) { fast_[k] = true; base_[k] = base; n_[k] = c; }
+            }
         }
-        if (lane == 0) {
-            __hip_atomic_store(&a.desc[tile], ST_PREFIX | (sum + T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base = sum;
-            if (tile == a.ntiles - 1) *a.total = sum + T;
+        if (!fast_[k]) s_cx[atomicAdd(&s_ncx, 1)] = (uint16_t)j;
+    }
+    // ---- phase 2a: resolve the fast records' bases; iteration o gathers for every lane that has an o-th SNP
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        if (!fast_[k]) continue;
+        const int j = k * MAP_BLOCK + tid;
+        const uint32_t soff = s_soff[j];
+        for (int o = 0; o < n_[k]; o++) {
+            const int x = s_vpos[base_[k] + o] - rpos_[k];
+            const int sy = (a.dbg & 1) ? (x & 3) : masked_base(a, soff, x);
+            if (sy != 4) { vmask_[k] |= 1u << o; codes_[k] |= (uint32_t)(sy < 4 ? sy : 4) << (4 * o); }
         }
     }
     __syncthreads();
-    const int64_t base = (int64_t)s_base;
-
-    // ---- pass B: emit
+    // ---- phase 1b: spliced / gapped / clipped records, densely re-packed so the divergent walk runs on full waves
+    const int ncx = walk_on ? s_ncx : 0;
+    for (int t = tid; t < ncx; t += MAP_BLOCK) {
+        const int j = s_cx[t];
+        walk_read<0>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], 0, 0, 0);
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    const bool fb = ncand > CAND;              // candidate buffer overflow: complex records fall back to in-lane work
+    const int64_t slot0 = tile * (int64_t)a.slot_cap;
+    int cnt[RPT], off[RPT];
+    if (!fb) {
+        // ---- phase 2b: resolve the buffered candidates with all lanes gathering at once
+        for (int e = tid; e < ncand; e += MAP_BLOCK) {
+            uint32_t key = s_key[e];
+            const int j = (int)(key >> 16);
+            int code = (int)(key & 0xFF);
+            if (code == 7) {
+                const uint32_t x0 = s_aux0[e];
+                const int x = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(s_aux1[e] >> 12);
+                const int sy = (a.dbg & 1) ? (x & 3) : masked_base(a, s_soff[j], x);
+                code = sy < 4 ? sy : (sy == 4 ? -1 : 4);
+            }
+            if (code >= 0) {
+                atomicOr(&s_mask[j], 1u << ((key >> 8) & 31));
+                s_key[e] = (key & 0xFFFFFF00u) | (uint32_t)code;
+            } else {
+                s_key[e] = key | 0xFFu;            // not a call
+            }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < MAP_RPT; k++) {
-        if (cnt[k] > 0) {
-            const int64_t r = r0 + k * MAP_BLOCK + tid;
-            walk_read<true>(a, vw, r, base + off[k]);
+        for (int k = 0; k < RPT; k++) cnt[k] = fast_[k] ? __popc(vmask_[k]) : __popc(s_mask[k * MAP_BLOCK + tid]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int j = k * MAP_BLOCK + tid;
+            cnt[k] = fast_[k] ? __popc(vmask_[k])
+                              : (j < nr && walk_on ? walk_read<1>(a, vw, cw, cb, j, r0 + j, rpos_[k], c0_[k], c1_[k], s_soff[j], 0, 0) : 0);
+        }
+    }
+    // ---- phase 3: per-record counts -> offsets (s_coff is free now)
+    const int T = block_scan<RPT>(cnt, off, s_wsum, lane, wave);
+#pragma unroll
+    for (int k = 0; k < RPT; k++) s_coff[k * MAP_BLOCK + tid] = (uint32_t)off[k];
+    if (tid == 0) a.tile_total[tile] = T;
+    __syncthreads();
+    if (a.dbg & 2) return;
+    // ---- phase 4: ordered flush into the tile's staging slot
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int j = k * MAP_BLOCK + tid;
+        if (fast_[k]) {
+            int o2 = off[k];
+            for (int o = 0; o < n_[k]; o++) {
+                if (!((vmask_[k] >> o) & 1)) continue;
+                if (o2 < a.slot_cap) {
+                    const int64_t g = slot0 + o2;
+                    a.o_read[g] = (int32_t)(r0 + j);
+                    a.o_var[g] = vw.w0 + base_[k] + o;
+                    a.o_code[g] = (uint8_t)((codes_[k] >> (4 * o)) & 15);
+                    a.o_aux0[g] = (uint32_t)(s_vpos[base_[k] + o] - rpos_[k]);
+                    a.o_aux1[g] = 0;
+                }
+                o2++;
+            }
+        } else if (fb && cnt[k] > 0) {
+            walk_read<2>(a, vw, cw, cb, j, r0 + j, rpos_[k], c0_[k], c1_[k], s_soff[j], slot0 + off[k], slot0 + a.slot_cap);
+        }
+    }
+    if (!fb) {
+        for (int e = tid; e < ncand; e += MAP_BLOCK) {
+            const uint32_t key = s_key[e];
+            if ((key & 0xFF) == 0xFF) continue;
+            const int j = (int)(key >> 16);
+            const uint32_t ord = (key >> 8) & 31;
+            const int o = (int)s_coff[j] + __popc(s_mask[j] & ((1u << ord) - 1));
+            if (o < a.slot_cap) {
+                const int64_t g = slot0 + o;
+                a.o_read[g] = (int32_t)(r0 + j);
+                a.o_var[g] = s_var[e];
+                a.o_code[g] = (uint8_t)(key & 0xFF);
+                a.o_aux0[g] = s_aux0[e];
+                a.o_aux1[g] = s_aux1[e];
+            }
+        }
+    }
+}
+
+// two-level exclusive prefix sum of the per-tile totals: 1024-tile chunks in parallel, then one small pass
+__global__ __launch_bounds__(1024) void k_chunk_scan(const int32_t *tile_total, int64_t ntiles, int32_t *tile_pref, int64_t *chunk_sum,
+                                                     int32_t *chunk_max) {
+    __shared__ int s_w[16], s_m[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    const int v = i < ntiles ? tile_total[i] : 0;
+    int x = v, mx = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(mx, d); mx = y > mx ? y : mx; }
+    if (lane == 63) s_w[wave] = x;
+    if (lane == 0) s_m[wave] = mx;
+    __syncthreads();
+    int before = 0;
+    for (int w2 = 0; w2 < wave; w2++) before += s_w[w2];
+    if (i < ntiles) tile_pref[i] = before + x - v;
+    if (tid == 1023) chunk_sum[blockIdx.x] = before + x;
+    if (tid == 0) {
+        int m = 0;
+        for (int w2 = 0; w2 < 16; w2++) m = s_m[w2] > m ? s_m[w2] : m;
+        chunk_max[blockIdx.x] = m;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_chunk_base(const int64_t *chunk_sum, const int32_t *chunk_max, int nchunks, int64_t *chunk_base,
+                                                     unsigned long long *scal /* [0] total, [1] max tile */) {
+    __shared__ long long s_w[16];
+    __shared__ long long s_carry;
+    __shared__ int s_m[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    int mx = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nchunks; b0 += 1024) {
+        const int i = b0 + tid;
+        const long long v = i < nchunks ? chunk_sum[i] : 0;
+        if (i < nchunks) mx = chunk_max[i] > mx ? chunk_max[i] : mx;
+        long long x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            long long y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        long long before = s_carry;
+        for (int w2 = 0; w2 < wave; w2++) before += s_w[w2];
+        if (i < nchunks) chunk_base[i] = before + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + x;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(mx, d); mx = y > mx ? y : mx; }
+    if (lane == 0) s_m[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int w2 = 0; w2 < 16; w2++) m = s_m[w2] > m ? s_m[w2] : m;
+        scal[0] = (unsigned long long)s_carry;
+        scal[1] = (unsigned long long)m;
+    }
+}
+
+struct CompactArgs {
+    const int32_t *s_read, *s_var; const uint8_t *s_code; const uint32_t *s_aux0, *s_aux1;
+    int32_t *o_read, *o_var; uint8_t *o_code; uint32_t *o_aux0, *o_aux1;
+    const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base;
+    int slot_cap; int64_t cap; int64_t ntiles;
+};
+
+// one wave per tile: copy the tile's slot to its final offset
+__global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= c.ntiles) return;
+    const int lane = threadIdx.x & 63;
+    int n = c.tile_total[tile];
+    if (n > c.slot_cap) n = c.slot_cap;
+    const int64_t src = tile * (int64_t)c.slot_cap, dst = c.chunk_base[tile >> 10] + c.tile_pref[tile];
+    for (int e = lane; e < n; e += 64) {
+        const int64_t o = dst + e;
+        if (o < c.cap) {
+            c.o_read[o] = c.s_read[src + e];
+            c.o_var[o] = c.s_var[src + e];
+            c.o_code[o] = c.s_code[src + e];
+            c.o_aux0[o] = c.s_aux0[src + e];
+            c.o_aux1[o] = c.s_aux1[src + e];
         }
     }
 }
@@ -279,34 +556,70 @@ int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int 
     *n_calls = 0;
     if (r.n_reads == 0 || v.n == 0) return PHZ_OK;
     if (v.n > 0x7fffffff) return phz_fail(ctx, PHZ_E_ARG, "too many variants in one shard");
-    const int64_t ntiles = (r.n_reads + MAP_TILE - 1) / MAP_TILE;
-    if (int s = phz_reserve(ctx, ctx->desc, (size_t)ntiles * 8)) return s;
-    if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 4)) return s;
+    int rpt = 2;
+    { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) == 4) rpt = 4; }
+    const int tile_reads = MAP_BLOCK * rpt;
+    const int64_t ntiles = (r.n_reads + tile_reads - 1) / tile_reads;
+    DevBuf *S = ctx->scratch;      // 17..23: tile_total, tile_base, staged read/var/code/aux0/aux1
+    if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 16)) return s;
     if (int s = phz_reserve(ctx, ctx->scalars, 64)) return s;
-    PHZ_HIP(ctx, hipMemsetAsync(ctx->desc.p, 0, (size_t)ntiles * 8, ctx->stream));
-    PHZ_HIP(ctx, hipMemsetAsync(ctx->scalars.p, 0, 64, ctx->stream));
-    MapArgs a;
-    a.pos = r.pos; a.cigar_off = r.cigar_off; a.cigar = r.cigar; a.seq_off = r.seq_off; a.seq2 = r.seq2; a.qual = r.qual;
-    a.n = r.n_reads; a.vpos = v.pos; a.nv = (int)v.n; a.baseq = baseq;
-    a.o_read = out.read_idx; a.o_var = out.var_idx; a.o_code = out.code; a.o_aux0 = out.aux0; a.o_aux1 = out.aux1;
-    a.cap = out.cap;
-    a.tile_w0 = (const int32_t *)ctx->tile_w0.p;
-    a.desc = (uint64_t *)ctx->desc.p;
-    a.ticket = (uint32_t *)ctx->scalars.p;
-    a.total = (unsigned long long *)((char *)ctx->scalars.p + 8);
-    a.ntiles = ntiles;
-    hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx->stream,
-                       r.pos, r.n_reads, v.pos, (int)v.n, (int32_t *)ctx->tile_w0.p, ntiles);
-    PHZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_map, dim3((unsigned)ntiles), dim3(MAP_BLOCK), 0, ctx->stream, a);
-    PHZ_HIP(ctx, hipGetLastError());
-    PHZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    unsigned long long total = 0;
-    PHZ_HIP(ctx, hipMemcpyAsync(&total, a.total, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->last_ms[PHZ_T_MAP] = ms; ctx->total_ms[PHZ_T_MAP] += ms; ctx->launches[PHZ_T_MAP]++;
-    *n_calls = (int64_t)total;
-    return (int64_t)total > out.cap ? PHZ_E_CAPACITY : PHZ_OK;
+    if (int s = phz_reserve(ctx, S[17], (size_t)ntiles * 4)) return s;
+    const int nchunks = (int)((ntiles + 1023) / 1024);
+    if (int s = phz_reserve(ctx, ctx->desc, (size_t)ntiles * 4 + (size_t)nchunks * 24 + 64)) return s;
+    int32_t *tile_pref = (int32_t *)ctx->desc.p;
+    int64_t *chunk_sum = (int64_t *)((char *)ctx->desc.p + (((size_t)ntiles * 4 + 15) & ~(size_t)15));
+    int64_t *chunk_base = chunk_sum + nchunks;
+    int32_t *chunk_max = (int32_t *)(chunk_base + nchunks);
+    if (ctx->map_slot_cap <= 0) ctx->map_slot_cap = 256;
+    hipStream_t sm = ctx->stream;
+    hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm,
+                       r.pos, r.cigar_off, r.n_reads, v.pos, (int)v.n, (int32_t *)ctx->tile_w0.p, ntiles, tile_reads);
+    float ms_total = 0;
+    unsigned long long scal[2] = {0, 0};
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const int slot_cap = ctx->map_slot_cap;
+        const size_t slots = (size_t)ntiles * (size_t)slot_cap;
+        if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
+        if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
+        if (int s = phz_reserve(ctx, S[20], slots)) return s;
+        if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
+        if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
+        MapArgs a;
+        a.pos = r.pos; a.cigar_off = r.cigar_off; a.cigar = r.cigar; a.seq_off = r.seq_off; a.seq2 = r.seq2; a.qual = r.qual;
+        a.n = r.n_reads; a.vpos = v.pos; a.nv = (int)v.n; a.baseq = baseq;
+        a.o_read = (int32_t *)S[18].p; a.o_var = (int32_t *)S[19].p; a.o_code = (uint8_t *)S[20].p;
+        a.o_aux0 = (uint32_t *)S[21].p; a.o_aux1 = (uint32_t *)S[22].p;
+        a.tile_w0 = (const int32_t *)ctx->tile_w0.p;
+        a.tile_total = (int32_t *)S[17].p;
+        a.slot_cap = slot_cap;
+        a.ntiles = ntiles;
+        { const char *e = getenv("PHZ_MAP_DBG"); a.dbg = e ? atoi(e) : 0; }
+        PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
+        if (rpt == 4) hipLaunchKernelGGL(k_map<4>, dim3((unsigned)ntiles), dim3(MAP_BLOCK), 0, sm, a);
+        else hipLaunchKernelGGL(k_map<2>, dim3((unsigned)ntiles), dim3(MAP_BLOCK), 0, sm, a);
+        PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
+        hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
+                           chunk_max);
+        hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(1024), 0, sm, (const int64_t *)chunk_sum, (const int32_t *)chunk_max, nchunks, chunk_base,
+                           (unsigned long long *)ctx->scalars.p);
+        CompactArgs c;
+        c.s_read = a.o_read; c.s_var = a.o_var; c.s_code = a.o_code; c.s_aux0 = a.o_aux0; c.s_aux1 = a.o_aux1;
+        c.o_read = out.read_idx; c.o_var = out.var_idx; c.o_code = out.code; c.o_aux0 = out.aux0; c.o_aux1 = out.aux1;
+        c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base;
+        c.slot_cap = slot_cap; c.cap = out.cap; c.ntiles = ntiles;
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
+        PHZ_HIP(ctx, hipGetLastError());
+        PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, 16, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));
+        float ms = 0;
+        PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ms_total += ms;
+        if ((int64_t)scal[1] <= slot_cap) break;
+        // some tile produced more calls than a slot holds: grow the slots to the exact maximum and redo
+        ctx->map_slot_cap = (int)((scal[1] + 63) / 64 * 64);
+        if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging slots did not converge");
+    }
+    ctx->last_ms[PHZ_T_MAP] = ms_total; ctx->total_ms[PHZ_T_MAP] += ms_total; ctx->launches[PHZ_T_MAP]++;
+    *n_calls = (int64_t)scal[0];
+    return (int64_t)scal[0] > out.cap ? PHZ_E_CAPACITY : PHZ_OK;
 }
