@@ -1,0 +1,260 @@
+"""phASER command line, MI355X hot path underneath.
+
+Same flags, defaults and output files as phaser/phaser.py:26-178 (`main`), :182-321 (`parse_sample`) and
+:378-1263 (`process_vcf`).  What differs is below the CLI: no samtools / bedtools / tabix subprocesses (BAM,
+BED and VCF are read in-process) and the seven multiprocessing stages are one `Engine` driving libphz.so.
+Not produced by this build: the phased VCF (`write_vcf`) and `--process_slow` /
+`--output_network`.
+
+    python -m phaser_amd.phaser --vcf S.vcf.gz --bam a.bam,b.bam --sample S1 --mapq 255 --baseq 10 --paired_end 1 --o out
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import os
+import sys
+import time
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+from . import bamio, samio, vcf
+from . import dist as pdist
+from .engine import Config, Engine
+
+VERSION = "1.2.0"
+
+
+def out(text=""):
+    print(text)
+    sys.stdout.flush()
+
+
+def fatal_error(text):
+    out("     FATAL ERROR: " + text)
+    sys.exit(1)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--bam", required=False, default='')
+    p.add_argument("--vcf", required=True, default='')
+    p.add_argument("--sample", required=False, default='')
+    p.add_argument("--mapq", required=True)
+    p.add_argument("--baseq", type=int, required=True)
+    p.add_argument("--paired_end", required=True)
+    p.add_argument("--o", required=True)
+    p.add_argument("--python_string", default="python3")
+    p.add_argument("--haplo_count_bam_exclude", default="")
+    p.add_argument("--haplo_count_blacklist", default="")
+    p.add_argument("--cc_threshold", type=float, default=0.01)
+    p.add_argument("--isize", default="0")
+    p.add_argument("--as_q_cutoff", type=float, default=0.05)
+    p.add_argument("--blacklist", default="")
+    p.add_argument("--write_vcf", type=int, default=1)
+    p.add_argument("--include_indels", type=int, default=0)
+    p.add_argument("--output_read_ids", type=int, default=0)
+    p.add_argument("--remove_dups", type=int, default=1)
+    p.add_argument("--pass_only", type=int, default=1)
+    p.add_argument("--unphased_vars", type=int, default=1)
+    p.add_argument("--chr_prefix", type=str, default="")
+    p.add_argument("--gw_phase_method", type=int, default=0)
+    p.add_argument("--gw_af_field", default="AF")
+    p.add_argument("--gw_phase_vcf", type=int, default=0)
+    p.add_argument("--gw_phase_vcf_min_confidence", type=float, default=0.90)
+    p.add_argument("--threads", type=int, default=1)
+    p.add_argument("--max_block_size", type=int, default=15)
+    p.add_argument("--temp_dir", default="")
+    p.add_argument("--max_items_per_thread", type=int, default=100000)
+    p.add_argument("--show_warning", type=int, default=0)
+    p.add_argument("--debug", type=int, default=0)
+    p.add_argument("--chr", default="")
+    p.add_argument("--unique_ids", type=int, default=0)
+    p.add_argument("--id_separator", default="_")
+    p.add_argument("--output_network", default="")
+    p.add_argument("--process_slow", type=int, default=0, required=False)
+    return p
+
+
+def load_bed(path: str) -> Dict[str, List[tuple]]:
+    iv: Dict[str, List[tuple]] = {}
+    with open(path) as f:
+        for line in f:
+            c = line.rstrip("\n").split("\t")
+            if len(c) >= 3 and not line.startswith(("#", "track", "browser")):
+                iv.setdefault(c[0], []).append((int(c[1]), int(c[2])))
+    return iv
+
+
+def overlaps(iv, chrom, pos1, ref_len) -> bool:
+    """bedtools treats a VCF record as the 0-based interval [POS-1, POS-1+len(REF))."""
+    s, e = pos1 - 1, pos1 - 1 + max(1, ref_len)
+    return any(a < e and s < b for a, b in iv.get(chrom, ()))
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    rank, world = pdist.world()
+    if world == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        rank, world = pdist.world()
+    say = out if rank == 0 else (lambda *_: None)
+    say("")
+    say("##################################################")
+    say("              Welcome to phASER v%s" % VERSION)
+    say("  Author: Stephane Castel (stephanecastel@gmail.com)")
+    say("  Updated by: Bishwa K. Giri (bkgiri@uncg.edu)")
+    say("  MI355X hot path: phaser_amd (K_map / K_tally on gfx950)")
+    say("##################################################")
+    say("")
+    if args.id_separator == ":" or args.id_separator == "":
+        fatal_error("ID separator must not be ':' or blank. Please choose another separator that is not found in the contig names.")
+    if args.process_slow != 0:
+        fatal_error("--process_slow is not supported by this build (the GPU path holds all chromosomes; SURVEY.md section 2).")
+    if args.output_network != "":
+        fatal_error("--output_network is not supported by this build.")
+    if not os.path.isfile(args.vcf):
+        fatal_error("VCF file does not exist.")
+    for xfile in [args.blacklist, args.haplo_count_blacklist]:
+        if xfile != "" and not os.path.isfile(xfile):
+            fatal_error("File: %s not found." % xfile)
+    bam_list = args.bam.split(",")
+    for xfile in bam_list:
+        if xfile != "" and not os.path.isfile(xfile):
+            fatal_error("File: %s not found." % xfile)
+    start = time.time()
+    say('STARTED "Read backed phasing and ASE/haplotype analyses" ... ')
+    say("    DATE, TIME : %s" % (datetime.datetime.now().strftime('%Y-%m-%d, %H:%M:%S')))
+    say("#1. Loading heterozygous variants into intervals...")
+    text = vcf.read_text(args.vcf)
+    sample_col = None
+    for line in text.split("\n"):
+        if "#CHR" in line:
+            cols = line.rstrip().split("\t")
+            m = {cols[i]: i for i in range(9, len(cols))}
+            if args.sample not in m:
+                fatal_error("Sample '%s' not found in the input VCF file." % args.sample)
+            sample_col = m[args.sample]
+            break
+    if sample_col is None:
+        fatal_error("Sample '%s' not found in the input VCF file." % args.sample)
+    # cut -f 1-9,S | grep -v '0|0\|1|1' [| bedtools intersect -v]   (phaser.py:220-225)
+    bl = load_bed(args.blacklist) if args.blacklist != "" else None
+    kept = []
+    for line in text.split("\n"):
+        if not line:
+            continue
+        if line[0] == "#":
+            continue
+        c = line.split("\t")
+        cut = "\t".join(c[0:9] + [c[sample_col]])
+        if "0|0" in cut or "1|1" in cut:
+            continue
+        if bl is not None and overlaps(bl, c[0], int(c[1]), len(c[3])):
+            continue
+        kept.append(cut)
+    vtext = "\n".join(kept)
+    vs = vcf.load_variants(vtext, sample_column=9, chrom_of_interest=args.chr, pass_only=args.pass_only,
+                           include_indels=args.include_indels, chr_prefix=args.chr_prefix, id_separator=args.id_separator,
+                           gw_phase_method=args.gw_phase_method, gw_af_field=args.gw_af_field, contig_ban=(args.id_separator, ":"))
+    haplo_bl = set()
+    if args.haplo_count_blacklist != "":
+        say("#1b. Loading haplotypic count blacklist intervals...")
+        hb = load_bed(args.haplo_count_blacklist)
+        for line in kept:
+            c = line.split("\t")
+            if (args.chr == "" or args.chr == c[0]) and overlaps(hb, c[0], int(c[1]), len(c[3])):
+                haplo_bl.add(c[0] + "_" + str(int(c[1])))
+    say("     creating variant mapping table...")
+    say("          %d heterozygous sites being used for phasing (%d filtered, %d indels excluded, %d unphased)" %
+        (vs.het_count, vs.filter_count, vs.indels_excluded, vs.unphased_count))
+    say()
+    if vs.het_count == 0:
+        fatal_error("No heterozygous sites that passed all filters were included in the analysis, phASER cannot continue. "
+                    "Check blacklist and pass_only arguments.")
+    say("#2. Retrieving reads that overlap heterozygous sites...")
+    # per-BAM lists (phaser.py:469-513)
+    from collections import OrderedDict
+    base = [os.path.basename(x).replace(".bam", "") for x in bam_list]
+    counter = OrderedDict(); bam_names = []
+    for x in base:
+        if base.count(x) > 1:
+            counter[x] = counter.get(x, 0) + 1
+            bam_names.append(x + "." + str(counter[x]))
+        else:
+            bam_names.append(x)
+
+    def per_bam(val, what):
+        lst = val.split(",")
+        if len(lst) == 1 and len(bam_list) > 1:
+            lst = lst * len(bam_list)
+        elif len(lst) != len(bam_list):
+            fatal_error("Number of %s values and input BAMs does not match. Supply either one %s to be used for all BAMs or one %s per input BAM." % (what, what, what))
+        return lst
+    mapq_list = per_bam(args.mapq, "mapq")
+    isize_list = list(map(float, per_bam(args.isize, "isize")))
+    pe_list = per_bam(args.paired_end, "paired_end")
+    excl = [x - 1 for x in map(int, args.haplo_count_bam_exclude.split(","))] if args.haplo_count_bam_exclude != "" else []
+    cfg = Config(baseq=args.baseq, as_q_cutoff=args.as_q_cutoff, cc_threshold=args.cc_threshold, max_block_size=args.max_block_size,
+                 id_separator=args.id_separator, unphased_vars=args.unphased_vars, gw_phase_method=args.gw_phase_method,
+                 output_read_ids=args.output_read_ids, unique_ids=args.unique_ids, haplo_count_bam_exclude=excl,
+                 haplo_blacklist=frozenset(haplo_bl), include_indels=args.include_indels)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    eng = Engine(vs, bam_names, cfg, device=local)
+    device = "cuda:%d" % local
+    interners: Dict[str, samio.QnameInterner] = {}
+    # multi-GPU: chromosomes are sharded across ranks by variant count (a proxy for reads before decoding)
+    if world > 1:
+        owner = pdist.assign_chromosomes({c: float(len(v)) for c, v in vs.chroms.items()}, world)
+        eng.set_owned([c for c in vs.chroms if owner[c] == rank])
+    mine = set(eng.chrom_list)
+    for bi, (bam, mq, isz, pe) in enumerate(zip(bam_list, mapq_list, isize_list, pe_list)):
+        say("     file: %s" % bam)
+        say("          minimum mapq: %s" % mq)
+        say("          mapping reads to variants...")
+        if bam.endswith(".sam"):
+            shards = samio.shards_from_sam(open(bam).read(), interners, isz)
+        else:
+            shards = bamio.shards_from_bam(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine)
+        for chrom in vs.chroms:
+            if chrom in shards and chrom in mine:
+                eng.add_shard(bi, chrom, shards[chrom].to(device), len(interners[chrom]), interners[chrom].names)
+                say("               completed chromosome %s..." % chrom)
+        for chrom in interners:
+            if chrom in eng.n_qid:
+                eng.n_qid[chrom] = len(interners[chrom])
+        say("          processing mapped reads...")
+        n_before = len(eng.log)
+        eng.close_bam(bi)
+        for line in eng.log[n_before:]:
+            say(line)
+    say("#3. Identifying connected variants...")
+    say("     calculating sequencing noise level...")
+    n_before = len(eng.log)
+    files = eng.finish()
+    if files is not None:
+        for line in eng.log[n_before:]:
+            say(line)
+        say("#4. Identifying haplotype blocks...")
+        say("#5. Phasing blocks...")
+        say("#6. Outputting haplotypes...")
+        for name, body in files.items():
+            with open(args.o + "." + name + ".txt", "w") as f:
+                f.write(body)
+        if args.write_vcf == 1:
+            say("#7. Outputting phased VCF... (not produced by this build: write_vcf is outside the accelerated path)")
+        say('')
+        say("     COMPLETED using %d reads in %d seconds using %d GPU(s)" % (eng.total_lines, time.time() - start, world))
+        say("     PHASED  %d of %d all variants (= %f) with at least one other variant" %
+            (eng.phased, vs.het_count, float(eng.phased) / float(vs.het_count)))
+        say('')
+        say("The End.")
+    if world > 1:
+        dist.barrier()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -80,3 +80,24 @@ def test_pipe_noisy(mapper, tag):
 def test_c1(mapper, c1_inputs):
     out, eng = run_product(mapper, c1_inputs["vcf"], {"c1.bam": {"chr22": c1_inputs["sam"]}}, "cuda")
     compare(out, os.path.join(GOLD, "c1"))
+
+
+def test_cli_from_bam_matches_reference(tmp_path):
+    """The drop-in CLI on an UNFILTERED BAM + gzipped VCF (own BGZF reader, own duplicate / proper-pair / MAPQ
+    filters) reproduces what the reference wrote for the same sample (fixture pipe_one)."""
+    import gzip
+    from phaser_amd import bamio, phaser, synth
+    v, gs, ge, w = synth.make_variants("chr22", 1, 3_000_000, 300, 201, n_genes=20)
+    rb = synth.make_reads(v, gs, ge, w, 9000, 202)
+    bam = str(tmp_path / "a.bam")
+    bamio.readbatch_to_bam(bam, [rb], [("chr21", 46709983), ("chr22", 50818468)])
+    d = os.path.join(GOLD, "pipe_one")
+    vcfgz = str(tmp_path / "in.vcf.gz")
+    with gzip.open(vcfgz, "wt") as f:
+        f.write(open(os.path.join(d, "in.vcf")).read())
+    prefix = str(tmp_path / "out")
+    rc = phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1",
+                      "--o", prefix, "--write_vcf", "0"])
+    assert rc == 0
+    out = {name: open(prefix + "." + name + ".txt").read() for name in OUTPUTS}
+    compare(out, d)
