@@ -25,6 +25,27 @@ HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md); measured copy pea
 CALL_BYTES = 17           # read_idx 4 + var_idx 4 + code 1 + aux0 4 + aux1 4
 
 
+def pmc_traffic():
+    """HBM bytes per k_map launch from the committed PMC passes (profiles/<round>/pmc_kmap_*/{fetch,write}.csv, collected
+    with tools/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs).  Units are KiB; FETCH_SIZE is
+    doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B).  None when no PMC summary is present."""
+    import csv, glob
+    dirs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_kmap_*")))
+    if not dirs:
+        return None
+    vals = {}
+    for name in ("fetch", "write"):
+        f = os.path.join(dirs[-1], name + ".csv")
+        if not os.path.exists(f):
+            return None
+        rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_map" in r["Kernel_Name"]]
+        if not rows:
+            return None
+        vals[name] = sum(rows) / len(rows)
+    return {"bytes_per_launch": 2 * vals["fetch"] * 1024 + vals["write"] * 1024, "fetch_raw_kib": vals["fetch"], "write_kib": vals["write"],
+            "source": os.path.relpath(dirs[-1], REPO), "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; same command as bench (configs[1] shard)"}
+
+
 def cpu_baseline(sample, vpos, baseq):
     """Oracle (CPU restatement, kind 'port') timed on one host core over a bounded sample."""
     import subprocess
@@ -46,6 +67,7 @@ def main():
     ap.add_argument("--snps", type=int, default=40_000)
     ap.add_argument("--baseq", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=8_000_000)
+    ap.add_argument("--no-phasing", action="store_true", help="skip the (untimed-for-value) phasing-stage measurement")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,12 +137,35 @@ def main():
         dist.all_reduce(tot_calls); dist.all_reduce(tot_recs); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- second rate of the metric: phased variants/s over stages T1-O2 (AS cutoff, K_tally, pair test, components,
+    #      block phasing, row formatting) on the same resident shard; measured once, outside the timed K_map region
+    phasing = None
+    if not a.no_phasing:
+        from phaser_amd import synth, vcf as pvcf
+        from phaser_amd.engine import Engine, Config
+        vs = pvcf.load_variants("\n".join(synth.vcf_lines([v])))
+        eng = Engine(vs, ["bench"], Config(baseq=a.baseq), mapper=mapper)
+        eng.add_shard(0, "chr1", shard, int(shard.qid.max()) + 1)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        eng.close_bam(0)
+        tp1 = time.perf_counter()
+        counts = eng.tally_all()
+        tp2 = time.perf_counter()
+        noise = eng.noise_from_counts(*counts)
+        frag = eng.chrom_fragment("chr1", noise, 0)
+        tp3 = time.perf_counter()
+        phasing = {"value": frag["phased"] / (tp3 - tp0), "unit": "phased variants/s", "phased_variants": frag["phased"],
+                   "call_lines_kept": frag["lines"], "blocks": len(frag["blocks"]),
+                   "seconds": {"as_cutoff": tp1 - tp0, "k_tally_incl_copies": tp2 - tp1, "host_assembly": tp3 - tp2},
+                   "k_tally_kernel_ms": eng.ctx.timing(_lib.PHZ_T_TALLY)[0]}
+
     if rank == 0:
         alg_bytes = shard.nbytes_map_inputs() + int(vpos.numel()) * 4 + CALL_BYTES * n_calls
         k_avg_s = k_total_ms / max(1, k_n) / 1e3
         achieved = alg_bytes / k_avg_s / 1e9
         out = {
-            "metric": "het-SNP allele calls/sec (read->variant mapper K_map; phased variants/s pending the tally stage)",
+            "metric": "het-SNP allele calls/sec (value) + phased variants/sec (phasing.value), RNA-seq shape, per-GPU shards",
             "value": float(tot_calls.item()) * a.steps / dt, "unit": "allele calls/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
@@ -128,10 +173,12 @@ def main():
                        "records_per_gpu": shard.n, "het_snps": int(vpos.numel()), "calls_per_gpu": n_calls,
                        "records_per_s": float(tot_recs.item()) * a.steps / dt, "gen_seconds": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_record": alg_bytes / shard.n,
                          "kernel_ms_avg": k_avg_s * 1e3, "launches": k_n},
         }
+        if phasing is not None:
+            out["phasing"] = phasing
         if world == 1 and sample is not None:
             (o_r, o_v, o_c), cpu_dt = cpu_baseline(sample, v.pos.numpy(), a.baseq)
             m = len(o_r)

@@ -463,11 +463,16 @@ class Engine:
                 for h in (0, 1):
                     allq = np.concatenate(vreads[h]) if vreads[h] else np.zeros(0, np.int32)
                     # labels = index into the distinct-read list; we number reads by first appearance (canonical form)
-                    uq, first = np.unique(allq, return_index=True)
-                    order_q = uq[np.argsort(first, kind="stable")]
-                    where = {int(qq): i for i, qq in enumerate(order_q)}
-                    labels.append(";".join(",".join(str(where[int(qq)]) for qq in vr) for vr in vreads[h]))
-                    ns.append(len(order_q)); ids.append(order_q)
+                    uq, first, inv = np.unique(allq, return_index=True, return_inverse=True)
+                    order = np.argsort(first, kind="stable")
+                    rk = np.empty(len(uq), dtype=np.int64)
+                    rk[order] = np.arange(len(uq))
+                    txt = list(map(str, rk[inv].tolist()))
+                    parts = []; p0 = 0
+                    for vr in vreads[h]:
+                        parts.append(",".join(txt[p0:p0 + len(vr)])); p0 += len(vr)
+                    labels.append(";".join(parts))
+                    ns.append(len(uq)); ids.append(uq[order])
                 cov = ns[0] + ns[1]
                 if cov > 0:
                     gwp = "0/1"

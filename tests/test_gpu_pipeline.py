@@ -101,3 +101,39 @@ def test_cli_from_bam_matches_reference(tmp_path):
     assert rc == 0
     out = {name: open(prefix + "." + name + ".txt").read() for name in OUTPUTS}
     compare(out, d)
+
+
+@pytest.mark.parametrize("seed,err", [(9001, 0.002), (9002, 0.04)])
+def test_fresh_seed_vs_oracle(mapper, oracle_build, tmp_path, seed, err):
+    """Inputs nobody has seen before (2 chromosomes x 2 BAMs with shared QNAMEs): product (GPU) vs the pinned oracle."""
+    import subprocess
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import phasing_oracle as po
+    from phaser_amd import synth
+    contigs = [("chr5", 181538259), ("chr9", 138394717)]
+    vs = []; bams = {"x1.bam": {}, "x2.bam": {}}
+    for ci, (chrom, ln) in enumerate(contigs):
+        v, gs, ge, w = synth.make_variants(chrom, 1, 1_500_000, 220, seed + ci, n_genes=10)
+        vs.append(v)
+        for bi, bam in enumerate(bams):
+            rb = synth.make_reads(v, gs, ge, w, 5000, seed + 10 * ci + bi + 100, qname_prefix="q", err_rate=err)
+            rf = rb.select(synth.samtools_keep(rb, 255))
+            bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf_text = "\n".join(synth.vcf_lines(vs)) + "\n"
+    got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=8)
+    # oracle side
+    pool, _, _ = po.load_vcf(vcf_text)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=8)
+    for bam, per_chrom in bams.items():
+        texts = []
+        for c in pool:
+            tp = tmp_path / "t.tsv"; tp.write_text("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+            op = tmp_path / "c.tsv"
+            subprocess.run([os.path.join(oracle_build, "rvm_oracle"), "--variant_table", str(tp), "--baseq", "10", "--o", str(op)],
+                           input=per_chrom[c].encode(), check=True)
+            texts.append(op.read_text())
+        ph.add_bam(texts)
+    want = ph.finish()
+    for name in OUTPUTS:
+        assert canonical(name, got[name]) == canonical(name, want[name]), name
+    assert eng.phased == ph.phased and eng.phased > 50
