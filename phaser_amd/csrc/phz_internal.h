@@ -29,6 +29,7 @@ struct phz_ctx {
     DevBuf c_read, c_var, c_code, c_aux0, c_aux1;
     // generic per-call scratch slots (tally / components), grown on demand and reused across calls
     DevBuf scratch[24];
+    int map_tile_reads = 0;
     int map_slot_cap = 0;      // calls per tile slot of K_map's staging area (grown on demand)
 };
 

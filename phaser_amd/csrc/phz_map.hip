@@ -6,18 +6,23 @@
 //   and the extracted text is neither "" nor "N".
 // Integer / branch work on an HBM-resident structure of arrays; no MFMA.
 //
-// Launch shape: one 256-thread workgroup per tile of 1024 consecutive (coordinate-sorted) reads, four
-// reads per lane strided by 256 so every streaming load (pos, cigar_off, seq_off, cigar words) is coalesced.
+// Launch shape: one 128-thread workgroup per tile of 256 consecutive (coordinate-sorted) reads (template
+// parameters; 64..256 threads x 2..4 reads per lane were swept on MI355X, 128 x 2 is fastest), two
+// reads per lane strided by the workgroup size so every streaming load (pos, cigar_off, seq_off, cigar words) is coalesced.
 // Per tile (k_map):
 //   1. LDS staging with coalesced block-wide loads: the tile's cigar_off slice, its contiguous run of packed
 //      CIGAR words, and the het-SNP window that starts at lower_bound(vpos, POS of the tile's first read),
 //      sized by a pre-pass (k_tile_window) to what the tile's reads reach without introns; lanes binary-search
 //      the window per aligned run and fall through to global memory only for introns reaching past it,
-//   2. each lane walks its reads' CIGARs out of LDS; seq/qual bytes are touched only under a variant (one
-//      gather of two bytes per call); calls are appended to an LDS call buffer tagged (read, ordinal),
-//   3. a wave shuffle scan + LDS combine turns per-read counts into offsets, and the buffer is flushed in
-//      exact mapper order into the tile's slot of a staging area (tile x CAP calls); a tile whose calls
-//      overflow the LDS buffer re-walks its reads and writes straight to the slot.
+//   2. records made of one aligned run (the common case) stay in registers: a branch-free LDS binary search
+//      with a tile-uniform trip count yields (first het SNP, count); their seq/qual bytes are gathered in a
+//      per-lane `for o < count` loop, so iteration o is one gather for every lane that has an o-th SNP,
+//   3. spliced / gapped / clipped records are re-packed densely and walk their CIGAR out of LDS; their
+//      candidates go to an LDS buffer tagged (read, ordinal) and are resolved by all lanes at once
+//      (seq/qual bytes are touched only under a variant: two bytes per call),
+//   4. a wave shuffle scan + LDS combine turns per-read call counts into offsets and the calls are flushed in
+//      exact mapper order into the tile's slot of a staging area (tile x slot_cap calls); a tile whose
+//      candidates overflow the LDS buffer resolves its complex records in-lane instead.
 // k_chunk_scan / k_chunk_base prefix-sum the per-tile totals; k_compact copies every slot to its final
 // offset, so the call list is in mapper order with no inter-workgroup dependency inside k_map (a
 // decoupled look-back was measured 0.8 ms slower here: tiles finish faster than descriptors travel).
@@ -26,7 +31,6 @@
 
 namespace {
 
-constexpr int MAP_BLOCK = 256;
 constexpr int MAP_WIN = 512;       // het-SNP positions staged per tile (max)
 
 constexpr uint32_t OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_EQ = 7, OP_X = 8, OP_G = 9;
@@ -224,7 +228,7 @@ __global__ void k_tile_window(const int32_t *pos, const uint32_t *cigar_off, int
 }
 
 // block-wide exclusive scan of RPT per-thread values laid out at [k*MAP_BLOCK + tid]; returns the block total
-template <int RPT>
+template <int MAP_BLOCK, int RPT>
 __device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT], int (*s_wsum)[MAP_BLOCK / 64], int lane, int wave) {
     int incl[RPT];
 #pragma unroll
@@ -254,7 +258,7 @@ __device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT
     return running;
 }
 
-template <int RPT>
+template <int MAP_BLOCK, int RPT>
 __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
     constexpr int TILE = MAP_BLOCK * RPT;
     constexpr int CIG = TILE * 5 / 2;          // packed CIGAR words staged per tile (max)
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
         }
     }
     // ---- phase 3: per-record counts -> offsets (s_coff is free now)
-    const int T = block_scan<RPT>(cnt, off, s_wsum, lane, wave);
+    const int T = block_scan<MAP_BLOCK, RPT>(cnt, off, s_wsum, lane, wave);
 #pragma unroll
     for (int k = 0; k < RPT; k++) s_coff[k * MAP_BLOCK + tid] = (uint32_t)off[k];
     if (tid == 0) a.tile_total[tile] = T;
@@ -556,9 +560,11 @@ int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int 
     *n_calls = 0;
     if (r.n_reads == 0 || v.n == 0) return PHZ_OK;
     if (v.n > 0x7fffffff) return phz_fail(ctx, PHZ_E_ARG, "too many variants in one shard");
-    int rpt = 2;
-    { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) == 4) rpt = 4; }
-    const int tile_reads = MAP_BLOCK * rpt;
+    int rpt = 2, blk = 128;
+    { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) > 0) rpt = atoi(e); }
+    { const char *e = getenv("PHZ_MAP_BLOCK"); if (e && atoi(e) > 0) blk = atoi(e); }
+    if (!((blk == 64 || blk == 128 || blk == 256) && (rpt == 2 || rpt == 4))) return phz_fail(ctx, PHZ_E_ARG, "bad PHZ_MAP_BLOCK / PHZ_MAP_RPT");
+    const int tile_reads = blk * rpt;
     const int64_t ntiles = (r.n_reads + tile_reads - 1) / tile_reads;
     DevBuf *S = ctx->scratch;      // 17..23: tile_total, tile_base, staged read/var/code/aux0/aux1
     if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 16)) return s;
@@ -570,7 +576,7 @@ int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int 
     int64_t *chunk_sum = (int64_t *)((char *)ctx->desc.p + (((size_t)ntiles * 4 + 15) & ~(size_t)15));
     int64_t *chunk_base = chunk_sum + nchunks;
     int32_t *chunk_max = (int32_t *)(chunk_base + nchunks);
-    if (ctx->map_slot_cap <= 0) ctx->map_slot_cap = 256;
+    if (ctx->map_slot_cap <= 0 || ctx->map_tile_reads != tile_reads) { ctx->map_slot_cap = tile_reads / 2 < 64 ? 64 : tile_reads / 2; ctx->map_tile_reads = tile_reads; }
     hipStream_t sm = ctx->stream;
     hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm,
                        r.pos, r.cigar_off, r.n_reads, v.pos, (int)v.n, (int32_t *)ctx->tile_w0.p, ntiles, tile_reads);
@@ -595,8 +601,14 @@ int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int 
         a.ntiles = ntiles;
         { const char *e = getenv("PHZ_MAP_DBG"); a.dbg = e ? atoi(e) : 0; }
         PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
-        if (rpt == 4) hipLaunchKernelGGL(k_map<4>, dim3((unsigned)ntiles), dim3(MAP_BLOCK), 0, sm, a);
-        else hipLaunchKernelGGL(k_map<2>, dim3((unsigned)ntiles), dim3(MAP_BLOCK), 0, sm, a);
+#define PHZ_LAUNCH_MAP(B, R) hipLaunchKernelGGL((k_map<B, R>), dim3((unsigned)ntiles), dim3(B), 0, sm, a)
+        if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
+        else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
+        else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
+        else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
+        else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
+        else PHZ_LAUNCH_MAP(256, 4);
+#undef PHZ_LAUNCH_MAP
         PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
         hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
                            chunk_max);

@@ -10,9 +10,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 v, shard, _ = workloads.make_shard("chr1", workloads.CHR1_LEN, 40_000, n, 20240807, "cuda:0")
 m = Mapper(0); vpos = v.pos.to("cuda:0")
 calls = m.map(shard, vpos, 10); cap = calls.n + 16
-for rpt in ["2"]:
+for blk, rpt in [("256","2"),("128","2"),("64","2"),("64","4"),("128","4"),("64","2")]:
+  os.environ["PHZ_MAP_BLOCK"] = blk
+  if True:
     os.environ["PHZ_MAP_RPT"] = rpt
-    for dbg in [0, 1, 2, 8, 16, 17, 0]:
+    for dbg in [0, 8]:
         os.environ["PHZ_MAP_DBG"] = str(dbg)
         m.map(shard, vpos, 10, cap=cap)
         m.ctx.reset_timing()
@@ -20,4 +22,4 @@ for rpt in ["2"]:
         for _ in range(8):
             m.map(shard, vpos, 10, cap=cap)
         wall = (time.perf_counter() - t0) / 8 * 1e3
-        print("rpt=%s dbg=%2d  k_map avg %.3f ms   wall/step %.3f ms" % (rpt, dbg, m.ctx.timing()[1] / 8, wall), flush=True)
+        print("blk=%s rpt=%s dbg=%2d  k_map avg %.3f ms   wall/step %.3f ms" % (blk, rpt, dbg, m.ctx.timing()[1] / 8, wall), flush=True)
