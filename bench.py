@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--records", type=int, default=50_000_000)
     ap.add_argument("--snps", type=int, default=40_000)
     ap.add_argument("--baseq", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=8_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=24_000_000)
     ap.add_argument("--no-phasing", action="store_true", help="skip the (untimed-for-value) phasing-stage measurement")
     a = ap.parse_args()
 

@@ -28,12 +28,21 @@ def make_shard(chrom: str, length: int, n_snps: int, n_records: int, seed: int, 
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
         rb = synth.fill_reads(plan, lo, hi, v)
-        if lo == 0 and keep_sample:
-            m = min(keep_sample, hi)
-            keep = torch.zeros(hi, dtype=torch.bool, device=rb.pos.device); keep[:m] = True
+        if lo < keep_sample:
+            m = min(keep_sample, hi) - lo
+            keep = torch.zeros(hi - lo, dtype=torch.bool, device=rb.pos.device); keep[:m] = True
             s = rb.select(keep)
-            sample = synth.ReadBatch(s.chrom, s.L, s.pos.cpu(), s.flag.cpu(), s.mapq.cpu(), s.tlen.cpu(), s.aln_score.cpu(),
-                                     s.qid.cpu(), s.cigar_off.cpu(), s.cigar.cpu(), s.seq.cpu(), s.qual.cpu(), s.qname_prefix)
+            s = synth.ReadBatch(s.chrom, s.L, s.pos.cpu(), s.flag.cpu(), s.mapq.cpu(), s.tlen.cpu(), s.aln_score.cpu(),
+                                s.qid.cpu(), s.cigar_off.cpu(), s.cigar.cpu(), s.seq.cpu(), s.qual.cpu(), s.qname_prefix)
+            if sample is None:
+                sample = s
+            else:       # append (host side)
+                sample = synth.ReadBatch(s.chrom, s.L, torch.cat([sample.pos, s.pos]), torch.cat([sample.flag, s.flag]),
+                                         torch.cat([sample.mapq, s.mapq]), torch.cat([sample.tlen, s.tlen]),
+                                         torch.cat([sample.aln_score, s.aln_score]), torch.cat([sample.qid, s.qid]),
+                                         torch.cat([sample.cigar_off, s.cigar_off[1:] + sample.cigar_off[-1]]),
+                                         torch.cat([sample.cigar, s.cigar]), torch.cat([sample.seq, s.seq]),
+                                         torch.cat([sample.qual, s.qual]), s.qname_prefix)
         sh = soa.pack_readbatch(rb)
         parts.append((sh, cig_base, seq_base))
         cig_base += int(sh.cigar.numel()); seq_base += int(sh.seq2.numel())
