@@ -149,6 +149,44 @@ int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, c
 int phz_components(phz_ctx *ctx, int64_t nv, int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b,
                    const uint8_t *keep, int32_t *label, int space);
 
+/* ---- host side of the path's input: native BGZF/BAM decode, SoA packing, QNAME interning -------------------
+ * Replaces `samtools view -h BAM 'chr': | samtools view -Sh [-F 0x400] [-f 2] -q MAPQ -` (phaser/phaser.py:1346)
+ * and the mapper's per-record text parsing (phaser/read_variant_map.py:27-64).  Pure host code (zlib + threads). */
+typedef struct phz_bam phz_bam;
+typedef struct phz_interner phz_interner;
+
+typedef struct {                 /* one reference sequence's filtered records, arrays owned by the phz_bam */
+    const char *ref_name;
+    int64_t n_reads, n_ops, n_seq_bytes;
+    const int32_t *pos;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    const uint32_t *seq_off;
+    const uint8_t *seq2;
+    const uint8_t *qual;
+    const int32_t *aln_score;    /* AS:i (0 when absent) */
+    const uint8_t *has_as;
+    const uint32_t *qname_off;   /* [n_reads+1] into qnames */
+    const char *qnames;
+} phz_host_shard;
+
+int phz_bam_open(const char *path, int threads, phz_bam **out);      /* reads + inflates the file, parses the header */
+int phz_bam_close(phz_bam *bam);
+int phz_bam_n_ref(const phz_bam *bam);
+const char *phz_bam_ref_name(const phz_bam *bam, int i);
+int64_t phz_bam_ref_length(const phz_bam *bam, int i);
+/* keep records with ref_mask[refID] != 0 (NULL = all), MAPQ >= min_mapq, (flag & required) == required,
+ * (flag & forbidden) == 0 and |TLEN| <= isize_cutoff when isize_cutoff != 0 */
+int phz_bam_decode(phz_bam *bam, const uint8_t *ref_mask, int min_mapq, int flag_required, int flag_forbidden,
+                   double isize_cutoff, int threads, int *n_shards);
+int phz_bam_shard(phz_bam *bam, int i, phz_host_shard *out);
+
+int phz_interner_create(phz_interner **out);
+int phz_interner_destroy(phz_interner *it);
+int64_t phz_interner_size(const phz_interner *it);
+int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t n, int32_t *out_id);
+int phz_interner_names(const phz_interner *it, char *blob, int64_t blob_cap, uint32_t *off);
+
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
 int phz_reset_timing(phz_ctx *ctx);

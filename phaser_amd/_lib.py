@@ -53,6 +53,13 @@ class phz_tally_out(C.Structure):
                 ("edge_linked", C.c_void_p)]
 
 
+class phz_host_shard(C.Structure):
+    _fields_ = [("ref_name", C.c_char_p), ("n_reads", C.c_int64), ("n_ops", C.c_int64), ("n_seq_bytes", C.c_int64),
+                ("pos", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("seq_off", C.c_void_p),
+                ("seq2", C.c_void_p), ("qual", C.c_void_p), ("aln_score", C.c_void_p), ("has_as", C.c_void_p),
+                ("qname_off", C.c_void_p), ("qnames", C.c_void_p)]
+
+
 PHZ_AS_BINS = 65536
 
 # every symbol include/phz.h declares: name -> (restype, argtypes)
@@ -71,6 +78,18 @@ SYMBOLS = {
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                             C.POINTER(phz_tally_out), C.POINTER(C.c_int64), C.c_int]),
     "phz_components": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "phz_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "phz_bam_close": (C.c_int, [C.c_void_p]),
+    "phz_bam_n_ref": (C.c_int, [C.c_void_p]),
+    "phz_bam_ref_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "phz_bam_ref_length": (C.c_int64, [C.c_void_p, C.c_int]),
+    "phz_bam_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]),
+    "phz_bam_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_host_shard)]),
+    "phz_interner_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "phz_interner_destroy": (C.c_int, [C.c_void_p]),
+    "phz_interner_size": (C.c_int64, [C.c_void_p]),
+    "phz_intern": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "phz_interner_names": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),
@@ -80,7 +99,7 @@ _lib: Optional[C.CDLL] = None
 
 
 def hip_sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -91,7 +110,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH]
+           "-I" + os.path.join(REPO, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH, "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -3,8 +3,9 @@
 Reader = what phASER gets from `samtools view -h BAM 'chr': | samtools view -Sh [-F 0x400] [-f 2] -q MAPQ`
 (phaser/phaser.py:1346, :505-513): records of one reference sequence filtered by duplicate flag, proper-pair
 flag and MAPQ.  The `-L bed` restriction is an optimisation only (the mapper emits nothing for reads that
-touch no het site) and is not applied.  This is the functional Python path; a native multi-threaded
-inflate + packer is the "next-1" row of SURVEY.md 8(f).
+touch no het site) and is not applied.  Two readers with identical results: shards_from_bam (pure Python,
+reference implementation for the tests) and shards_from_bam_native (C++ in libphz.so: multi-threaded
+inflate, packer, QNAME interning -- SURVEY.md 8(f) next-1; ~60x the Python reader).
 """
 from __future__ import annotations
 
@@ -171,3 +172,87 @@ def readbatch_to_bam(path: str, rbs, refs: List[Tuple[str, int]]):
                          "qname": rb.qname(i), "cigar": cg, "seq": lut[seq[i]].tobytes().decode(), "qual": qual[i].tolist(),
                          "tags": {"NH": 1, "AS": int(rb.aln_score[i])}})
     write_bam(path, refs, recs)
+
+
+# ----------------------------------------------------------------------------------------- native reader (libphz.so)
+class NativeInterner:
+    """QNAME -> id map held in C++ (phz_interner); same first-appearance numbering as samio.QnameInterner."""
+
+    def __init__(self):
+        import ctypes as C
+        from . import _lib
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        self.lib.phz_interner_create(C.byref(h))
+        self.h = h
+
+    def __len__(self):
+        return int(self.lib.phz_interner_size(self.h))
+
+    @property
+    def names(self) -> List[str]:
+        import ctypes as C
+        n = len(self)
+        off = np.zeros(n + 1, dtype=np.uint32)
+        cap = 1 << 20
+        while True:
+            blob = np.zeros(cap, dtype=np.uint8)
+            st = self.lib.phz_interner_names(self.h, C.c_void_p(blob.ctypes.data), cap, C.c_void_p(off.ctypes.data))
+            if st == 0:
+                break
+            cap = int(off[n]) + 16
+        raw = blob.tobytes()
+        return [raw[int(off[i]):int(off[i + 1])].decode() for i in range(n)]
+
+    def __del__(self):
+        try:
+            self.lib.phz_interner_destroy(self.h)
+        except Exception:
+            pass
+
+
+def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], mapq: int, remove_dups: bool, paired_end: bool,
+                           isize_cutoff: float = 0.0, chroms=None, threads: int = 0) -> Dict[str, soa.ReadShard]:
+    """Same result as shards_from_bam, produced by the C++ decoder/packer in libphz.so (multi-threaded inflate)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    st = lib.phz_bam_open(path.encode(), threads, C.byref(h))
+    if st != 0:
+        raise _lib.PhzError(st, "cannot read BAM " + path)
+    try:
+        n_ref = lib.phz_bam_n_ref(h)
+        names = [lib.phz_bam_ref_name(h, i).decode() for i in range(n_ref)]
+        mask = np.array([1 if (chroms is None or nm in chroms) else 0 for nm in names], dtype=np.uint8)
+        ns = C.c_int(0)
+        st = lib.phz_bam_decode(h, C.c_void_p(mask.ctypes.data), int(mapq), 0x2 if paired_end else 0, 0x400 if remove_dups else 0,
+                                float(isize_cutoff), threads, C.byref(ns))
+        if st != 0:
+            raise _lib.PhzError(st, "BAM decode failed")
+        out = {}
+        for i in range(ns.value):
+            hs = _lib.phz_host_shard()
+            lib.phz_bam_shard(h, i, C.byref(hs))
+            n = hs.n_reads
+
+            def arr(ptr, count, dt):
+                if count == 0:
+                    return torch.zeros(0, dtype=dt)
+                ct = {torch.int32: C.c_int32, torch.uint8: C.c_uint8}[dt]
+                a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(count,))
+                return torch.from_numpy(a.copy())
+            chrom = hs.ref_name.decode()
+            sh = soa.ReadShard(arr(hs.pos, n, torch.int32), arr(hs.cigar_off, n + 1, torch.int32), arr(hs.cigar, hs.n_ops, torch.int32),
+                               arr(hs.seq_off, n + 1, torch.int32), arr(hs.seq2, hs.n_seq_bytes, torch.uint8),
+                               arr(hs.qual, hs.n_seq_bytes * 4, torch.uint8))
+            it = interners.setdefault(chrom, NativeInterner())
+            qid = np.zeros(n, dtype=np.int32)
+            lib.phz_intern(it.h, hs.qnames, hs.qname_off, n, C.c_void_p(qid.ctypes.data))
+            sh.qid = torch.from_numpy(qid)
+            sh.aln_score = arr(hs.aln_score, n, torch.int32)
+            sh.has_as = arr(hs.has_as, n, torch.uint8)
+            out[chrom] = sh
+        return out
+    finally:
+        lib.phz_bam_close(h)

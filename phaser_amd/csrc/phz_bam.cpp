@@ -1,0 +1,363 @@
+// Native BGZF / BAM decode + structure-of-arrays packing + QNAME interning (host side of the path's input,
+// SURVEY.md 8(f) next-1).  Replaces, for one BAM, what phASER obtains from
+//   samtools view -h BAM 'chr': | samtools view -Sh [-F 0x400] [-f 2] -q MAPQ -      (phaser/phaser.py:1346, :505-513)
+// plus the per-record parsing the mapper does on the SAM text (read_variant_map.py:27-64).
+// Multi-threaded raw-deflate inflate of the BGZF members (zlib), one sequential hop over the record chain,
+// multi-threaded packing into exactly the arrays soa.pack_sam() builds (tests compare them bit for bit).
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "phz.h"
+
+namespace {
+
+struct Shard {
+    std::string name;
+    std::vector<int32_t> pos, aln;
+    std::vector<uint32_t> cigar_off, cigar, seq_off, qname_off;
+    std::vector<uint8_t> seq2, qual, has_as;
+    std::vector<char> qnames;
+};
+
+struct Range { size_t rec_begin, rec_end; };
+
+inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline int32_t rdi32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+// value of the last AS tag; returns false when absent
+bool aux_as(const uint8_t *p, const uint8_t *e, int32_t *out) {
+    bool found = false;
+    while (p + 3 <= e) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        p += 3;
+        int sz = 0;
+        switch (ty) {
+            case 'c': case 'C': case 'A': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)(e - p)); if (!z) return found;
+                                   p = z + 1; continue; }
+            case 'B': { if (p + 5 > e) return found; const uint8_t st = p[0]; const uint32_t cnt = rd32(p + 1);
+                        int es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                        p += 5 + (size_t)cnt * es; continue; }
+            default: return found;
+        }
+        if (p + sz > e) return found;
+        if (t0 == 'A' && t1 == 'S' && ty != 'A' && ty != 'f') {
+            int32_t v = 0;
+            switch (ty) {
+                case 'c': v = (int8_t)p[0]; break;
+                case 'C': v = p[0]; break;
+                case 's': { int16_t x; memcpy(&x, p, 2); v = x; break; }
+                case 'S': v = rd16(p); break;
+                case 'i': v = rdi32(p); break;
+                case 'I': v = (int32_t)rd32(p); break;
+            }
+            *out = v; found = true;
+        }
+        p += sz;
+    }
+    return found;
+}
+
+// normalised op list of one record (see soa.pack_sam): returns the number of ops written
+inline int norm_ops(const uint8_t *cig, int n_cig, int nb, uint32_t *out) {
+    int n = 0;
+    long read_pos = 0;
+    for (int i = 0; i < n_cig; i++) {
+        const uint32_t c = rd32(cig + 4 * i);
+        const uint32_t op = c & 15, len = c >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            long lo = read_pos < nb ? read_pos : nb, hi = read_pos + (long)len < nb ? read_pos + (long)len : nb;
+            const uint32_t avail = (uint32_t)(hi > lo ? hi - lo : 0);
+            if (avail == len) { if (out) out[n] = c; n++; }
+            else {
+                if (avail) { if (out) out[n] = (avail << 4) | op; n++; }
+                if (out) out[n] = ((len - avail) << 4) | 9u; n++;
+            }
+            read_pos += len;
+        } else if (op == 1) {
+            long lo = read_pos < nb ? read_pos : nb, hi = read_pos + (long)len < nb ? read_pos + (long)len : nb;
+            const uint32_t avail = (uint32_t)(hi > lo ? hi - lo : 0);
+            if (out) out[n] = (avail << 4) | 1u; n++;
+            read_pos += len;
+        } else if (op == 4) {
+            if (out) out[n] = c; n++;
+            read_pos += len;
+        } else if (op == 2 || op == 3) {
+            if (out) out[n] = c; n++;
+        }
+    }
+    return n;
+}
+
+struct Bam {
+    std::vector<uint8_t> data;                 // inflated BAM stream
+    std::vector<std::pair<std::string, int32_t>> refs;
+    size_t first_record = 0;
+    std::vector<Shard> shards;                 // result of the last decode, indexed by position in `order`
+    std::string err;
+};
+
+bool inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t isize) {
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = (Bytef *)src; zs.avail_in = (uInt)csize;
+    zs.next_out = dst; zs.avail_out = (uInt)isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+int n_threads(int want) {
+    if (want > 0) return want;
+    unsigned h = std::thread::hardware_concurrency();
+    return h ? (int)(h > 32 ? 32 : h) : 4;
+}
+
+}  // namespace
+
+struct phz_bam { Bam b; };
+
+struct phz_interner {
+    std::unordered_map<std::string, int32_t> ids;
+};
+
+extern "C" {
+
+int phz_bam_open(const char *path, int threads, phz_bam **out) {
+    *out = nullptr;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return PHZ_E_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 28) { close(fd); return PHZ_E_ARG; }
+    const size_t fsz = (size_t)st.st_size;
+    const uint8_t *f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (f == MAP_FAILED) return PHZ_E_NOMEM;
+    // BGZF member table
+    struct Blk { size_t off, csize, isize, dst; };
+    std::vector<Blk> blks;
+    size_t off = 0, total = 0;
+    bool ok = true;
+    while (off + 18 <= fsz) {
+        if (f[off] != 0x1f || f[off + 1] != 0x8b || !(f[off + 3] & 4)) { ok = false; break; }
+        const uint16_t xlen = rd16(f + off + 10);
+        size_t x = off + 12, xe = x + xlen;
+        uint32_t bsize = 0;
+        while (x + 4 <= xe) {
+            const uint16_t slen = rd16(f + x + 2);
+            if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = (uint32_t)rd16(f + x + 4) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || off + bsize > fsz) { ok = false; break; }
+        const uint32_t isize = rd32(f + off + bsize - 4);
+        blks.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isize, total});
+        total += isize;
+        off += bsize;
+    }
+    if (!ok || blks.empty()) { munmap((void *)f, fsz); return PHZ_E_ARG; }
+    phz_bam *h = new phz_bam();
+    h->b.data.resize(total);
+    const int nt = n_threads(threads);
+    std::atomic<size_t> next(0);
+    std::atomic<bool> bad(false);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= blks.size()) break;
+                if (blks[i].isize && !inflate_block(f + blks[i].off, blks[i].csize, h->b.data.data() + blks[i].dst, blks[i].isize)) bad = true;
+            }
+        });
+    for (auto &t : th) t.join();
+    munmap((void *)f, fsz);
+    if (bad) { delete h; return PHZ_E_ARG; }
+    const std::vector<uint8_t> &d = h->b.data;
+    if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { delete h; return PHZ_E_ARG; }
+    size_t p = 8 + (size_t)rdi32(d.data() + 4);
+    const int32_t n_ref = rdi32(d.data() + p); p += 4;
+    for (int32_t i = 0; i < n_ref; i++) {
+        const int32_t l = rdi32(d.data() + p); p += 4;
+        std::string name((const char *)d.data() + p, (size_t)(l > 0 ? l - 1 : 0)); p += (size_t)l;
+        h->b.refs.emplace_back(name, rdi32(d.data() + p)); p += 4;
+    }
+    h->b.first_record = p;
+    *out = h;
+    return PHZ_OK;
+}
+
+int phz_bam_close(phz_bam *h) { delete h; return PHZ_OK; }
+int phz_bam_n_ref(const phz_bam *h) { return (int)h->b.refs.size(); }
+const char *phz_bam_ref_name(const phz_bam *h, int i) { return h->b.refs[(size_t)i].first.c_str(); }
+int64_t phz_bam_ref_length(const phz_bam *h, int i) { return h->b.refs[(size_t)i].second; }
+
+// Decode + filter + pack.  ref_mask[i] != 0 selects reference i (NULL = all).  Returns the number of references
+// that received at least one record; shards are then read with phz_bam_shard().
+int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_required, int flag_forbidden, double isize_cutoff,
+                   int threads, int *n_shards) {
+    Bam &b = h->b;
+    const uint8_t *d = b.data.data();
+    const size_t n = b.data.size();
+    const int n_ref = (int)b.refs.size();
+    // pass 1: hop over the record chain, apply the filters, size everything
+    struct Rec { size_t off; int32_t ref; uint32_t n_ops, nb; };
+    std::vector<Rec> recs;
+    size_t p = b.first_record;
+    while (p + 4 <= n) {
+        const int32_t bs = rdi32(d + p);
+        if (bs < 32 || p + 4 + (size_t)bs > n) break;
+        const uint8_t *r = d + p + 4;
+        const int32_t ref = rdi32(r);
+        const uint32_t l_rn = r[8], mapq = r[9], n_cig = rd16(r + 12), flag = rd16(r + 14);
+        const int32_t l_seq = rdi32(r + 16), tlen = rdi32(r + 28);
+        bool keep = ref >= 0 && ref < n_ref && (!ref_mask || ref_mask[ref]) && (int)mapq >= min_mapq &&
+                    ((int)flag & flag_required) == flag_required && ((int)flag & flag_forbidden) == 0;
+        if (keep && isize_cutoff != 0) { const double tl = tlen < 0 ? -(double)tlen : (double)tlen; keep = tl <= isize_cutoff; }
+        if (keep) {
+            const uint8_t *cig = r + 32 + l_rn;
+            const uint8_t *qual = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2;
+            uint32_t nb;
+            if (l_seq <= 0) nb = 1;                               // SEQ '*' / QUAL '*': zip() keeps one character
+            else nb = qual[0] == 0xFF ? 1u : (uint32_t)l_seq;     // QUAL '*'
+            recs.push_back({p + 4, ref, (uint32_t)norm_ops(cig, (int)n_cig, (int)nb, nullptr), nb});
+        }
+        p += 4 + (size_t)bs;
+    }
+    // bucket by reference, in reference order (file order within a reference is preserved)
+    std::vector<size_t> count((size_t)n_ref + 1, 0);
+    for (const Rec &x : recs) count[(size_t)x.ref + 1]++;
+    for (int i = 0; i < n_ref; i++) count[(size_t)i + 1] += count[(size_t)i];
+    std::vector<uint32_t> order(recs.size());
+    {
+        std::vector<size_t> cur(count.begin(), count.end() - 1);
+        for (size_t i = 0; i < recs.size(); i++) order[cur[(size_t)recs[i].ref]++] = (uint32_t)i;
+    }
+    b.shards.clear();
+    for (int i = 0; i < n_ref; i++) {
+        const size_t lo = count[(size_t)i], hi = count[(size_t)i + 1];
+        if (hi == lo) continue;
+        b.shards.emplace_back();
+        Shard &s = b.shards.back();
+        s.name = b.refs[(size_t)i].first;
+        const size_t m = hi - lo;
+        s.pos.resize(m); s.aln.resize(m); s.has_as.resize(m);
+        s.cigar_off.resize(m + 1); s.seq_off.resize(m + 1); s.qname_off.resize(m + 1);
+        uint64_t co = 0, so = 0, qo = 0;
+        for (size_t k = 0; k < m; k++) {
+            const Rec &x = recs[order[lo + k]];
+            s.cigar_off[k] = (uint32_t)co; s.seq_off[k] = (uint32_t)so; s.qname_off[k] = (uint32_t)qo;
+            co += x.n_ops; so += (x.nb + 3) / 4; qo += (uint32_t)(d[x.off + 8] ? d[x.off + 8] - 1 : 0);
+        }
+        if (co >= (1ull << 31) || so >= (1ull << 31) || qo >= (1ull << 32)) { b.err = "shard exceeds 32-bit offsets"; return PHZ_E_UNSUPPORTED; }
+        s.cigar_off[m] = (uint32_t)co; s.seq_off[m] = (uint32_t)so; s.qname_off[m] = (uint32_t)qo;
+        s.cigar.resize(co); s.seq2.assign(so, 0); s.qual.assign(so * 4, 0); s.qnames.resize(qo);
+        // pass 2: pack in parallel
+        const int nt = n_threads(threads);
+        std::atomic<size_t> next(0);
+        std::vector<std::thread> th;
+        const size_t grain = 8192;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&] {
+                static const int8_t code_of[16] = {-2, 0, 1, -2, 2, -2, -2, -2, 3, -2, -2, -2, -2, -1, -2, -1};   // =ACMGRSVTWYHKDBN
+                for (;;) {
+                    const size_t k0 = next.fetch_add(grain);
+                    if (k0 >= m) break;
+                    const size_t k1 = k0 + grain < m ? k0 + grain : m;
+                    for (size_t k = k0; k < k1; k++) {
+                        const Rec &x = recs[order[lo + k]];
+                        const uint8_t *r = d + x.off;
+                        const uint32_t l_rn = r[8], n_cig = rd16(r + 12);
+                        const int32_t l_seq = rdi32(r + 16);
+                        const int32_t bs = rdi32(r - 4);
+                        s.pos[k] = rdi32(r + 4) + 1;
+                        memcpy(s.qnames.data() + s.qname_off[k], r + 32, l_rn ? l_rn - 1 : 0);
+                        const uint8_t *cig = r + 32 + l_rn;
+                        norm_ops(cig, (int)n_cig, (int)x.nb, s.cigar.data() + s.cigar_off[k]);
+                        const uint8_t *sq = cig + 4 * (size_t)n_cig;
+                        const uint8_t *ql = sq + ((size_t)(l_seq > 0 ? l_seq : 0) + 1) / 2;
+                        uint8_t *o2 = s.seq2.data() + s.seq_off[k];
+                        uint8_t *oq = s.qual.data() + (size_t)s.seq_off[k] * 4;
+                        if (l_seq <= 0) {                  // SEQ '*' QUAL '*': one IUPAC-other character with phred 9
+                            o2[0] = 1; oq[0] = (uint8_t)(9 | 0x80);
+                        } else {
+                            const bool noq = ql[0] == 0xFF;
+                            for (uint32_t j = 0; j < x.nb; j++) {
+                                const uint8_t nib = (j & 1) ? (sq[j >> 1] & 15) : (sq[j >> 1] >> 4);
+                                const int c = code_of[nib];
+                                uint8_t q = noq ? 9 : (ql[j] > 127 ? 127 : ql[j]);
+                                uint8_t code2;
+                                if (c >= 0) code2 = (uint8_t)c;
+                                else { code2 = c == -1 ? 0 : 1; q |= 0x80; }
+                                o2[j >> 2] |= (uint8_t)(code2 << (2 * (j & 3)));
+                                oq[j] = q;
+                            }
+                        }
+                        int32_t as = 0;
+                        const uint8_t *aux = ql + (l_seq > 0 ? l_seq : 0);
+                        const bool has = aux_as(aux, r + bs, &as);
+                        s.aln[k] = has ? as : 0; s.has_as[k] = has ? 1 : 0;
+                    }
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    *n_shards = (int)b.shards.size();
+    return PHZ_OK;
+}
+
+int phz_bam_shard(phz_bam *h, int i, phz_host_shard *out) {
+    if (i < 0 || (size_t)i >= h->b.shards.size()) return PHZ_E_ARG;
+    Shard &s = h->b.shards[(size_t)i];
+    out->ref_name = s.name.c_str();
+    out->n_reads = (int64_t)s.pos.size(); out->n_ops = (int64_t)s.cigar.size(); out->n_seq_bytes = (int64_t)s.seq2.size();
+    out->pos = s.pos.data(); out->cigar_off = s.cigar_off.data(); out->cigar = s.cigar.data(); out->seq_off = s.seq_off.data();
+    out->seq2 = s.seq2.data(); out->qual = s.qual.data(); out->aln_score = s.aln.data(); out->has_as = s.has_as.data();
+    out->qname_off = s.qname_off.data(); out->qnames = s.qnames.data();
+    return PHZ_OK;
+}
+
+int phz_interner_create(phz_interner **out) { *out = new phz_interner(); return PHZ_OK; }
+int phz_interner_destroy(phz_interner *it) { delete it; return PHZ_OK; }
+int64_t phz_interner_size(const phz_interner *it) { return (int64_t)it->ids.size(); }
+
+// QNAME -> id in first-appearance order (mates and the same template in later BAMs get the same id)
+int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t n, int32_t *out_id) {
+    it->ids.reserve(it->ids.size() + (size_t)n / 2);
+    for (int64_t i = 0; i < n; i++) {
+        std::string key(blob + off[i], off[i + 1] - off[i]);
+        auto r = it->ids.emplace(std::move(key), (int32_t)it->ids.size());
+        out_id[i] = r.first->second;
+    }
+    return PHZ_OK;
+}
+
+// names of ids [0, size) as a blob + offsets (for --output_read_ids)
+int phz_interner_names(const phz_interner *it, char *blob, int64_t blob_cap, uint32_t *off) {
+    const size_t n = it->ids.size();
+    std::vector<const std::string *> by(n);
+    for (auto &kv : it->ids) by[(size_t)kv.second] = &kv.first;
+    uint64_t o = 0;
+    for (size_t i = 0; i < n; i++) {
+        off[i] = (uint32_t)o;
+        if ((int64_t)(o + by[i]->size()) <= blob_cap) memcpy(blob + o, by[i]->data(), by[i]->size());
+        o += by[i]->size();
+    }
+    off[n] = (uint32_t)o;
+    return (int64_t)o <= blob_cap ? PHZ_OK : PHZ_E_CAPACITY;
+}
+
+}  // extern "C"

@@ -204,7 +204,8 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     eng = Engine(vs, bam_names, cfg, device=local)
     device = "cuda:%d" % local
-    interners: Dict[str, samio.QnameInterner] = {}
+    interners: Dict[str, object] = {}
+    any_sam = any(b.endswith(".sam") for b in bam_list)       # text inputs keep everything on the Python reader
     # multi-GPU: chromosomes are sharded across ranks by variant count (a proxy for reads before decoding)
     if world > 1:
         owner = pdist.assign_chromosomes({c: float(len(v)) for c, v in vs.chroms.items()}, world)
@@ -216,11 +217,15 @@ def main(argv=None):
         say("          mapping reads to variants...")
         if bam.endswith(".sam"):
             shards = samio.shards_from_sam(open(bam).read(), interners, isz)
-        else:
+        elif any_sam:
             shards = bamio.shards_from_bam(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine)
+        else:   # native BGZF inflate + packer + QNAME interning (phz_bam_*), --threads host threads
+            shards = bamio.shards_from_bam_native(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
+                                                  threads=max(0, args.threads if args.threads > 1 else 0))
         for chrom in vs.chroms:
             if chrom in shards and chrom in mine:
-                eng.add_shard(bi, chrom, shards[chrom].to(device), len(interners[chrom]), interners[chrom].names)
+                eng.add_shard(bi, chrom, shards[chrom].to(device), len(interners[chrom]),
+                              interners[chrom].names if args.output_read_ids == 1 else None)
                 say("               completed chromosome %s..." % chrom)
         for chrom in interners:
             if chrom in eng.n_qid:

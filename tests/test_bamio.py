@@ -43,3 +43,48 @@ def test_aux_as_parsing():
     aux = b"NHC\x01" + b"XSZabc\0" + b"ASs" + struct.pack("<h", -7) + b"XBBc" + struct.pack("<i", 2) + b"\x01\x02" + b"ASC\x98"
     assert bamio.aux_AS(aux) == 152
     assert bamio.aux_AS(b"NHC\x01") is None
+
+
+def test_native_decoder_matches_python_reader(tmp_path):
+    """The C++ BGZF/BAM decoder + packer + interner (host code in libphz.so) gives bit-identical shards."""
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, rb = _pipe_one_unfiltered()
+    v2, gs, ge, w = synth.make_variants("chr21", 1, 1_000_000, 80, 77, n_genes=6)
+    rb2 = synth.make_reads(v2, gs, ge, w, 1500, 78, qname_prefix="s0.b0.r")      # QNAMEs collide with chr22's on purpose
+    path = str(tmp_path / "two.bam")
+    bamio.readbatch_to_bam(path, [rb2, rb], [("chr21", 46709983), ("chr22", 50818468)])
+    for args in [(255, True, True, 0.0), (0, False, False, 0.0), (255, True, True, 260.0)]:
+        ip = {}; inn = {}
+        want = bamio.shards_from_bam(path, ip, *args)
+        got = bamio.shards_from_bam_native(path, inn, *args, threads=3)
+        assert list(got) == list(want) == ["chr21", "chr22"]
+        for c in want:
+            for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
+                assert torch.equal(getattr(got[c], f), getattr(want[c], f)), (c, f, args)
+            assert inn[c].names == ip[c].names
+    only = bamio.shards_from_bam_native(path, {}, 255, True, True, chroms={"chr21"})
+    assert list(only) == ["chr21"]
+
+
+def test_native_decoder_odd_records(tmp_path):
+    """Malformed / unusual records: SEQ '*', QUAL missing, IUPAC bases, hard clips, padding, CIGAR longer than SEQ, no AS."""
+    from phaser_amd import bamio
+    recs = [
+        {"ref_id": 0, "pos": 100, "mapq": 60, "flag": 0, "tlen": 0, "qname": "r1", "cigar": [(5, 3), (0, 6), (6, 2), (0, 4), (5, 1)],
+         "seq": "ACGTNRYACG", "qual": [40] * 10, "tags": {"AS": -5}},
+        {"ref_id": 0, "pos": 120, "mapq": 60, "flag": 0, "tlen": 0, "qname": "r2", "cigar": [(0, 10)], "seq": "", "qual": [], "tags": {}},
+        {"ref_id": 0, "pos": 130, "mapq": 60, "flag": 0, "tlen": 0, "qname": "r3", "cigar": [(0, 4), (3, 7), (0, 6)], "seq": "ACGTAC", "qual": None,
+         "tags": {"NM": 1}},
+        {"ref_id": 0, "pos": 140, "mapq": 60, "flag": 0, "tlen": 0, "qname": "r4", "cigar": [(0, 4), (1, 3), (0, 9), (4, 2)], "seq": "ACGTACG",
+         "qual": [30] * 7, "tags": {"AS": 70000}},
+        {"ref_id": 0, "pos": 150, "mapq": 60, "flag": 0, "tlen": 0, "qname": "r1", "cigar": [], "seq": "AC=D", "qual": [20] * 4, "tags": {}},
+    ]
+    path = str(tmp_path / "odd.bam")
+    bamio.write_bam(path, [("c1", 1000)], recs)
+    ip = {}; inn = {}
+    want = bamio.shards_from_bam(path, ip, 0, False, False)["c1"]
+    got = bamio.shards_from_bam_native(path, inn, 0, False, False)["c1"]
+    for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
+        assert torch.equal(getattr(got, f), getattr(want, f)), f
+    assert got.qid.tolist() == [0, 1, 2, 3, 0]
