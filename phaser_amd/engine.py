@@ -202,7 +202,7 @@ class Engine:
         out, summary = merge_fragments(frags, [c for c in self.all_chroms if c in frags], self.cfg, noise)
         self.noise = noise
         self.log += summary["log"]
-        self.phased = summary["phased"]; self.total_lines = summary["lines"]
+        self.phased = summary["phased"]; self.total_lines = summary["lines"]; self.vcf_lookup = summary["vcf_lookup"]
         return out
 
     def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
@@ -493,7 +493,15 @@ class Engine:
                     if ga != gb:
                         ra = cv.ref[ga] == aa; rb = cv.ref[gb] == ab
                         cfgf.append("\t".join([cv.uid[ga], cv.rsid[ga], cv.uid[gb], cv.rsid[gb], "trans" if ra == rb else "cis"]) + "\n")
-            blocks_out.append({"hap": hap_row, "ase": ase, "cfg": cfgf})
+            def _gw(x):
+                return int(x) if isinstance(x, int) and not isinstance(x, bool) else None
+            vinfo = {"uids": [cv.uid[g] for g in variants], "hap": [ha[i] + "|" + hb[i] for i in range(len(variants))],
+                     "rsids": [cv.rsid[g] for g in variants], "stat": stat if isinstance(stat, (int, float)) and not isinstance(stat, np.floating) else float(stat),
+                     "stat_txt": str(stat), "max_maf_txt": str(max(mafs)),
+                     "alleles": [cv.alleles[g] for g in variants], "all_alleles": [cv.all_alleles[g] for g in variants],
+                     "gw": [[_gw(cor[0][i]) if int(ha[i]) == 0 else _gw(cor[1][i]), _gw(cor[1][i]) if int(ha[i]) == 0 else _gw(cor[0][i])]
+                            for i in range(len(variants))]}
+            blocks_out.append({"hap": hap_row, "ase": ase, "cfg": cfgf, "vcf": vinfo})
         # ---- singletons (:1180-1239): variants kept in dict_variant_reads but in no block
         singles = []
         if cfg.unphased_vars == 1:
@@ -551,6 +559,8 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
     allelic = []
     singles = []
     dropped = phased = lines = 0
+    lookup = {}
+    block_index = 0
     for c in chrom_list:
         f = frags[c]
         conn += [r + "\n" for r in f["conn_rows"]]
@@ -558,6 +568,11 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
         allelic += [(tuple(k), r) for k, r in f["allelic"]]
         for b in f["blocks"]:
             hap.append(b["hap"]); ase += b["ase"]; cfgf += b["cfg"]
+            block_index += 1
+            v = b.get("vcf")
+            if v is not None:
+                for i, uid in enumerate(v["uids"]):
+                    lookup[uid] = (v, i, block_index)
         singles += [(tuple(k), ra, rh) for k, ra, rh in f["singles"]]
     allelic.sort(key=lambda t: t[0])
     singles.sort(key=lambda t: t[0])
@@ -571,4 +586,4 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
     log = ["     sequencing noise level estimated at %f" % noise,
            "     %d variant connections dropped because of conflicting configurations (threshold = %f)" % (dropped, cfg.cc_threshold),
            "     %d variants covered by at least 1 read" % len(allelic)]
-    return out, {"log": log, "phased": phased, "lines": lines, "dropped": dropped, "covered": len(allelic)}
+    return out, {"log": log, "phased": phased, "lines": lines, "dropped": dropped, "covered": len(allelic), "vcf_lookup": lookup}

@@ -3,8 +3,8 @@
 Same flags, defaults and output files as phaser/phaser.py:26-178 (`main`), :182-321 (`parse_sample`) and
 :378-1263 (`process_vcf`).  What differs is below the CLI: no samtools / bedtools / tabix subprocesses (BAM,
 BED and VCF are read in-process) and the seven multiprocessing stages are one `Engine` driving libphz.so.
-Not produced by this build: the phased VCF (`write_vcf`) and `--process_slow` /
-`--output_network`.
+The phased VCF (`write_vcf`) is written as BGZF `<o>.vcf.gz` without a tabix index.  Not supported:
+`--process_slow`, `--output_network`.
 
     python -m phaser_amd.phaser --vcf S.vcf.gz --bam a.bam,b.bam --sample S1 --mapq 255 --baseq 10 --paired_end 1 --o out
 """
@@ -248,12 +248,37 @@ def main(argv=None):
         for name, body in files.items():
             with open(args.o + "." + name + ".txt", "w") as f:
                 f.write(body)
+        up = pc = 0
         if args.write_vcf == 1:
-            say("#7. Outputting phased VCF... (not produced by this build: write_vcf is outside the accelerated path)")
+            from . import vcfout
+            say("#7. Outputting phased VCF...")
+            if args.gw_phase_vcf == 1:
+                say("     GT field is being updated with phASER genome wide phase when applicable. This can be changed using the --gw_phase_vcf argument.")
+            elif args.gw_phase_vcf == 2:
+                say("     GT field is being updated with either phASER genome wide phase or phASER block phase with PS specified, depending on phase anchoring quality.")
+            else:
+                say("     GT field is not being updated with phASER genome wide phase. This can be changed using the --gw_phase_vcf argument.")
+            cut_lines = []
+            for line in text.split("\n"):
+                if not line:
+                    continue
+                if line.startswith("##"):
+                    cut_lines.append(line)
+                else:
+                    c = line.split("\t")
+                    cut_lines.append("\t".join(c[0:9] + [c[sample_col]]))
+            vtxt, up, pc = vcfout.phased_vcf_text(cut_lines, eng.vcf_lookup, args.id_separator, args.chr, args.gw_phase_vcf,
+                                                  args.gw_phase_vcf_min_confidence)
+            say("     Compressing output VCF (BGZF; no tabix index is written by this build)...")
+            vcfout.write_bgzf(args.o + ".vcf.gz", vtxt)
         say('')
         say("     COMPLETED using %d reads in %d seconds using %d GPU(s)" % (eng.total_lines, time.time() - start, world))
         say("     PHASED  %d of %d all variants (= %f) with at least one other variant" %
             (eng.phased, vs.het_count, float(eng.phased) / float(vs.het_count)))
+        if args.write_vcf == 1:
+            if vs.unphased_count > 0:
+                say("     GENOME WIDE PHASED  %d of %d unphased variants (= %f)" % (up, vs.unphased_count, float(up) / float(vs.unphased_count)))
+            say("     GENOME WIDE PHASE CORRECTED  %d of %d variants (= %f)" % (pc, vs.het_count, float(pc) / float(vs.het_count)))
         say('')
         say("The End.")
     if world > 1:

@@ -137,3 +137,20 @@ def test_fresh_seed_vs_oracle(mapper, oracle_build, tmp_path, seed, err):
     for name in OUTPUTS:
         assert canonical(name, got[name]) == canonical(name, want[name]), name
     assert eng.phased == ph.phased and eng.phased > 50
+
+
+@pytest.mark.parametrize("src,mode", [("pipe_one", 0), ("pipe_one", 1), ("pipe_one", 2), ("pipe_noisy_c", 2), ("pipe_two", 1)])
+def test_phased_vcf_matches_reference(mapper, src, mode):
+    """write_vcf (phaser.py:1661-1855): the phased VCF text equals what the reference wrote, byte for byte."""
+    from phaser_amd import vcfout
+    d = os.path.join(GOLD, src)
+    vcf_text = open(os.path.join(d, "in.vcf")).read()
+    if src == "pipe_two":
+        bams = {b + ".bam": {c: gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")} for b in ("t1", "t2")}
+    else:
+        b = "a" if src == "pipe_one" else "n"
+        bams = {b + ".bam": {"chr22": gz_text(os.path.join(d, b + ".chr22.sam.gz"))}}
+    out, eng = run_product(mapper, vcf_text, bams, "cuda")
+    lines = [l for l in vcf_text.split("\n") if l]
+    got, up, pc = vcfout.phased_vcf_text(lines, eng.vcf_lookup, gw_phase_vcf=mode)
+    assert got == gz_text(os.path.join(d, "out.vcf_gw%d.txt.gz" % mode))
