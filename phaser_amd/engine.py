@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+import sys
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -40,6 +42,8 @@ class Config:
         self.id_separator = "_"; self.unphased_vars = 1; self.gw_phase_method = 0; self.output_read_ids = 0
         self.unique_ids = 0; self.haplo_count_bam_exclude: List[int] = []; self.haplo_blacklist = frozenset()
         self.include_indels = 0
+        self.want_vcf = True           # keep per-block info for write_vcf (vcfout.phased_vcf_text)
+        self.host_threads = 1          # forked workers for block phasing / row formatting (the reference's --threads)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown option " + k)
@@ -192,21 +196,78 @@ class Engine:
     def finish(self) -> Optional[Dict[str, str]]:
         """Stages 3-6.  With torch.distributed initialised, every rank handles its own chromosomes and rank 0
         returns the assembled files (other ranks return None)."""
+        import time as _t
+        t0 = _t.perf_counter()
         match, mism = pdist.allreduce_counts(*self.tally_all())
         noise = self.noise_from_counts(match, mism)
-        local = {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
+        t1 = _t.perf_counter()
+        if self.cfg.host_threads > 1:
+            local = self._fragments_parallel(noise)
+        else:
+            local = {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
+        t2 = _t.perf_counter()
         frags = pdist.gather_fragments(local)
+        self.stats.update({"tally_s": t1 - t0, "fragments_s": t2 - t1})
         self.noise = noise
         if frags is None:
             return None
+        t3 = _t.perf_counter()
         out, summary = merge_fragments(frags, [c for c in self.all_chroms if c in frags], self.cfg, noise)
+        self.stats["merge_s"] = _t.perf_counter() - t3
         self.noise = noise
         self.log += summary["log"]
         self.phased = summary["phased"]; self.total_lines = summary["lines"]; self.vcf_lookup = summary["vcf_lookup"]
         return out
 
+    def _fragments_parallel(self, noise: float) -> Dict[str, dict]:
+        """Stage C with the host work fanned out like the reference's parallelize() (phaser.py:2077-2094): C1 (numpy,
+        scipy, GPU components) runs here per chromosome; C2 (block phasing + row formatting, pure Python on plain data)
+        runs in forked workers over chunks of blocks / singletons.  Workers never touch the GPU."""
+        import multiprocessing as mp
+        global _FORK_ENGINE
+        import time as _t
+        t0 = _t.perf_counter()
+        frags = {c: self.chrom_prepare(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
+        self.stats["prepare_s"] = _t.perf_counter() - t0
+        chunk = 1500
+        btasks = [(c, lo, min(lo + chunk, len(self._pre[c][0]))) for c in self.chrom_list for lo in range(0, len(self._pre[c][0]), chunk)]
+        _FORK_ENGINE = self
+        ctx = mp.get_context("fork")
+        nproc = min(self.cfg.host_threads, max(1, len(btasks)))
+        with ctx.Pool(nproc) as pool:
+            bres = pool.map(_fork_block_rows, btasks, chunksize=1)
+        phased: Dict[str, set] = {c: set() for c in self.chrom_list}
+        for (c, lo, hi), (chunk_rec, ph) in zip(btasks, bres):
+            frags[c].setdefault("blocks", []).append(chunk_rec)
+            phased[c].update(ph)
+        self._phased_sets = phased            # must exist before the second fork: singleton workers read it
+        schunk = 20000
+        stasks = [(c, lo, min(lo + schunk, len(self._pre[c][1]))) for c in self.chrom_list for lo in range(0, len(self._pre[c][1]), schunk)]
+        if stasks:
+            with ctx.Pool(min(self.cfg.host_threads, len(stasks))) as pool:
+                sres = pool.map(_fork_single_rows, stasks, chunksize=1)
+            for (c, lo, hi), rows in zip(stasks, sres):
+                frags[c].setdefault("singles", []).extend(rows)
+        for c in self.chrom_list:
+            frags[c].setdefault("blocks", []); frags[c].setdefault("singles", [])
+            frags[c]["phased"] = len(phased[c])
+        self.stats["rows_pool_s"] = _t.perf_counter() - t0 - self.stats["prepare_s"]
+        _FORK_ENGINE = None
+        return frags
+
     def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
-        """Stage C for one chromosome: pair tests, pruning, components, block phasing, output rows."""
+        """Stage C for one chromosome: pair tests, pruning, components (C1), block phasing + output rows (C2), serially."""
+        frag = self.chrom_prepare(c, noise, chrom_index)
+        blocks_all, keys = self._pre[c]
+        chunk, phased = self._block_rows(c, blocks_all)
+        frag["blocks"] = [chunk]
+        frag["singles"] = self._single_rows(c, keys, set(phased))
+        frag["phased"] = len(phased)
+        return frag
+
+    def chrom_prepare(self, c: str, noise: float, chrom_index: int) -> dict:
+        """Stage C1: ordering ranks, pair tests (scipy), pruning, connected components on the GPU, allelic counts.
+        Leaves the chromosome's unphased blocks and first-appearance keys in self._pre[c] for stage C2."""
         cfg = self.cfg
         R = self.tally[c]; cv = self.vs.chroms[c]; nv = R["nv"]
         frag = {"chrom": c, "lines": int((R["line_cls"] != 255).sum())}
@@ -323,14 +384,10 @@ class Engine:
                 allelic.append(((kb, kc, kl), "\t".join([c, str(int(cv.pos[g])), cv.uid[g], cv.alleles[g][0], cv.alleles[g][1], str(r0), str(r1),
                                                          str(r0 + r1) + "\n"])))
         frag["allelic"] = allelic
-        # ---- phase blocks (phaser.py:795-814) and format rows (:832-1243)
-        final = []
-        for mem, edges in blocks_all:
-            blk = Block(len(mem), edges)
-            for sub in blk.phase(cfg.max_block_size):
-                final.append([(int(mem[i]), a) for i, a in sub])
-        frag.update(self._rows(c, final, R, blocks_all, keys))
-        frag["phased"] = sum(len(b) for b in final)
+        if not hasattr(self, "_pre"):
+            self._pre = {}
+        self._pre[c] = (blocks_all, keys)
+        self._read_lists(R)          # cache the per-variant read lists (shared with forked row workers)
         return frag
 
     # ---------------------------------------------------------------- output (phaser.py:832-1243)
@@ -348,25 +405,34 @@ class Engine:
         R["by_var"] = (lines[o], starts, ends)
         return R["by_var"]
 
-    def _rows(self, c, final, R, blocks_all, var_keys):
+    def _block_rows(self, c, blocks_all):
+        """Stage C2a for a list of (members, edges) components: phase them (phaser.py:795-814) and format their rows
+        (:865-1172).  Pure host work on plain data -> safe to run in forked workers.  Returns (rows per final block,
+        phased variant indices)."""
         cfg = self.cfg
         nb = len(self.bam_names)
         cv = self.vs.chroms[c]
+        R = self.tally[c]
         blocks_out = []
+        final = []
+        for mem, edges in blocks_all:
+            blk = Block(len(mem), edges)
+            for sub in blk.phase(cfg.max_block_size):
+                final.append([(int(mem[i]), a) for i, a in sub])
         # allele-edge lookup for supporting / total edge counts: (a, b) -> cfg for surviving edges
         d: Dict[tuple, int] = {}
         for mem, edges in blocks_all:
             for i, j, k in edges:
                 a, b = int(mem[i]), int(mem[j])
                 d[(a, b)] = k; d[(b, a)] = k
-        in_block = set()
+        in_block = []
         lines_sorted, starts, ends = self._read_lists(R)
         lq = R["line_qid"]; lbam = R["line_bam"]
         for blk in final:
             ase = []; cfgf = []
             blk = sorted(blk, key=lambda t: (int(cv.pos[t[0]]), t[0]))     # sort_var_ids again (:869); already sorted
             variants = [g for g, _ in blk]
-            in_block.update(variants)
+            in_block += variants
             ha = "".join(a for _, a in blk)
             hb = "".join(str(int(not int(x))) for x in ha)
             # edges supporting / total (:876-895): ordered allele pairs, halved
@@ -502,8 +568,22 @@ class Engine:
                      "gw": [[_gw(cor[0][i]) if int(ha[i]) == 0 else _gw(cor[1][i]), _gw(cor[1][i]) if int(ha[i]) == 0 else _gw(cor[0][i])]
                             for i in range(len(variants))]}
             blocks_out.append({"hap": hap_row, "ase": ase, "cfg": cfgf, "vcf": vinfo})
-        # ---- singletons (:1180-1239): variants kept in dict_variant_reads but in no block
+        # one compact record per call (cheap to ship back from a forked worker): joined text + optional VCF info per block
+        chunk = {"hap": "".join(b["hap"] for b in blocks_out), "ase": "".join(r for b in blocks_out for r in b["ase"]),
+                 "cfg": "".join(r for b in blocks_out for r in b["cfg"]), "n": len(blocks_out),
+                 "vcf": [b["vcf"] for b in blocks_out] if cfg.want_vcf else None}
+        return chunk, in_block
+
+    def _single_rows(self, c, var_keys, in_block):
+        """Stage C2b: rows of variants with coverage that ended up in no block (phaser.py:1180-1239)."""
+        cfg = self.cfg
+        nb = len(self.bam_names)
+        cv = self.vs.chroms[c]
+        R = self.tally[c]
+        lines_sorted, starts, ends = self._read_lists(R)
+        lq = R["line_qid"]; lbam = R["line_bam"]
         singles = []
+        single_bam_fast = nb == 1 and cfg.output_read_ids != 1 and not cfg.haplo_count_bam_exclude
         if cfg.unphased_vars == 1:
             for kb, kc, kl, g in var_keys:
                 vc = R["var_count"][g]
@@ -515,15 +595,21 @@ class Engine:
                     for b in range(nb):
                         if b in cfg.haplo_count_bam_exclude:
                             continue
-                        per_allele = []
-                        for k in (0, 1):
-                            ln = lines_sorted[starts[g * 2 + k]:ends[g * 2 + k]]
-                            per_allele.append(np.unique(lq[ln[lbam[ln] == b]]))
-                        cov = len(per_allele[0]) + len(per_allele[1])
+                        if single_bam_fast:
+                            # one BAM: distinct QNAMEs per (variant, allele) were counted on the GPU (var_distinct)
+                            n0, n1 = int(R["var_distinct"][g][0]), int(R["var_distinct"][g][1])
+                            per_allele = None
+                        else:
+                            per_allele = []
+                            for k in (0, 1):
+                                ln = lines_sorted[starts[g * 2 + k]:ends[g * 2 + k]]
+                                per_allele.append(np.unique(lq[ln[lbam[ln] == b]]))
+                            n0, n1 = len(per_allele[0]), len(per_allele[1])
+                        cov = n0 + n1
                         if cov > 0:
                             ps = (str(ph.index(cv.alleles[g][0])) + "|" + str(ph.index(cv.alleles[g][1]))) if "-" not in ph else "0/1"
                             f = [c, str(int(cv.pos[g])), str(int(cv.pos[g])), cv.uid[g], "1", "", "0", cv.alleles[g][0], cv.alleles[g][1],
-                                 str(len(per_allele[0])), str(len(per_allele[1])), str(cov), ps, "1"]
+                                 str(n0), str(n1), str(cov), ps, "1"]
                             if cfg.output_read_ids == 1:
                                 qn = self.qnames[c]
                                 f += [_jl(qn[int(x)] for x in per_allele[0]), _jl(qn[int(x)] for x in per_allele[1])]
@@ -535,8 +621,22 @@ class Engine:
                 hrow = "\t".join([c, str(int(cv.pos[g]) - 1), str(int(cv.pos[g])), "1", "1", name,
                                   cv.alleles[g][0] + "|" + cv.alleles[g][1], str(int(dd[0])), str(int(dd[1])), str(int(dd[0]) + int(dd[1])),
                                   "0", "0", ps, str(float("nan")), ps, str(float("nan"))]) + "\n"
-                singles.append(((kb, kc, kl), rows_a, hrow))
-        return {"blocks": blocks_out, "singles": singles}
+                singles.append(((kb, kc, kl), "".join(rows_a), hrow))
+        return singles
+
+
+_FORK_ENGINE = None
+
+
+def _fork_block_rows(task):
+    c, lo, hi = task
+    return _FORK_ENGINE._block_rows(c, _FORK_ENGINE._pre[c][0][lo:hi])
+
+
+def _fork_single_rows(task):
+    c, lo, hi = task
+    e = _FORK_ENGINE
+    return e._single_rows(c, e._pre[c][1][lo:hi], e._phased_sets[c])
 
 
 HEAD_ASE = ["contig", "start", "stop", "variants", "variantCount", "variantsBlacklisted", "variantCountBlacklisted", "haplotypeA",
@@ -566,18 +666,20 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
         conn += [r + "\n" for r in f["conn_rows"]]
         dropped += f["dropped"]; phased += f["phased"]; lines += f["lines"]
         allelic += [(tuple(k), r) for k, r in f["allelic"]]
-        for b in f["blocks"]:
-            hap.append(b["hap"]); ase += b["ase"]; cfgf += b["cfg"]
-            block_index += 1
-            v = b.get("vcf")
-            if v is not None:
-                for i, uid in enumerate(v["uids"]):
-                    lookup[uid] = (v, i, block_index)
+        for ch in f["blocks"]:
+            hap.append(ch["hap"]); ase.append(ch["ase"]); cfgf.append(ch["cfg"])
+            if ch.get("vcf") is not None:
+                for v in ch["vcf"]:
+                    block_index += 1
+                    for i, uid in enumerate(v["uids"]):
+                        lookup[uid] = (v, i, block_index)
+            else:
+                block_index += ch["n"]
         singles += [(tuple(k), ra, rh) for k, ra, rh in f["singles"]]
     allelic.sort(key=lambda t: t[0])
     singles.sort(key=lambda t: t[0])
     for _, ra, rh in singles:
-        ase += ra
+        ase.append(ra)
     for _, ra, rh in singles:
         hap.append(rh)
     out = {"variant_connections": "".join(conn),

@@ -200,7 +200,7 @@ def main(argv=None):
     cfg = Config(baseq=args.baseq, as_q_cutoff=args.as_q_cutoff, cc_threshold=args.cc_threshold, max_block_size=args.max_block_size,
                  id_separator=args.id_separator, unphased_vars=args.unphased_vars, gw_phase_method=args.gw_phase_method,
                  output_read_ids=args.output_read_ids, unique_ids=args.unique_ids, haplo_count_bam_exclude=excl,
-                 haplo_blacklist=frozenset(haplo_bl), include_indels=args.include_indels)
+                 haplo_blacklist=frozenset(haplo_bl), include_indels=args.include_indels, host_threads=max(1, args.threads))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     eng = Engine(vs, bam_names, cfg, device=local)
     device = "cuda:%d" % local

@@ -58,12 +58,14 @@ def test_pipe_one(mapper, device):
         assert line in log, line
 
 
-def test_pipe_two_bams_two_chroms(mapper):
+@pytest.mark.parametrize("host_threads", [1, 3])
+def test_pipe_two_bams_two_chroms(mapper, host_threads):
+    """host_threads > 1 fans block phasing / row formatting out to forked workers (the reference's --threads)."""
     d = os.path.join(GOLD, "pipe_two")
     bams = {}
     for b in ("t1", "t2"):
         bams[b + ".bam"] = {c: gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")}
-    out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(), bams, "cuda")
+    out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(), bams, "cuda", host_threads=host_threads)
     compare(out, d)
 
 
