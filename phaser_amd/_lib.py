@@ -127,8 +127,13 @@ def load() -> C.CDLL:
     # holds exactly one HIP runtime (two runtimes => the second one sees no device).
     import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
-        raise PhzError(PHZ_E_HIP, "phaser_amd/libphz.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
-                                  "there is no CPU fallback for the product path")
+        # not a fallback: compile the same HIP sources in-tree when the toolchain is present, otherwise fail loudly
+        import shutil
+        if shutil.which("hipcc"):
+            build()
+        if not os.path.exists(LIB_PATH):
+            raise PhzError(PHZ_E_HIP, "phaser_amd/libphz.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                                      "there is no CPU fallback for the product path")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol

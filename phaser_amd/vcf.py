@@ -59,23 +59,28 @@ def read_text(path: str) -> str:
         return f.read()
 
 
-def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
-                  include_indels: int = 0, chr_prefix: str = "", id_separator: str = "_", gw_phase_method: int = 0,
-                  gw_af_field: str = "AF", contig_ban=("_", ":")) -> VariantSet:
-    per: Dict[str, list] = {}
-    filter_count = unphased = 0
-    for line in vcf_text.split("\n"):
+def _load_chunk(task):
+    """Filter + table fields for a slice of VCF lines -> ({chrom: column lists}, filter_count, unphased, excluded)."""
+    (lines, sample_column, chrom_of_interest, pass_only, include_indels, chr_prefix, id_separator, gw_phase_method, gw_af_field,
+     contig_ban) = task
+    per: Dict[str, dict] = {}
+    filter_count = unphased = excluded = 0
+    for line in lines:
         if not line or line[0] == "#":
             continue
         c = line.split("\t")
-        chrom = c[0]
+        chrom0 = c[0]
         for item in contig_ban:
-            if item in chrom:
+            if item in chrom0:
                 raise SystemExit("     FATAL ERROR: Character '%s' must not be present in contig name. Please change id separtor "
                                  "using --id_separator to a character not found in the contig names and try again." % item)
-        if chrom_of_interest != "" and chrom_of_interest != chrom:
+        if chrom_of_interest != "" and chrom_of_interest != chrom0:
             continue
-        rows = per.setdefault(chrom, [])
+        chrom = chr_prefix + chrom0
+        col = per.get(chrom)
+        if col is None:
+            col = per[chrom] = {k: [] for k in ("pos", "uid", "rsid_field", "rsid", "ref", "all_alleles", "alleles", "phase", "gt",
+                                                "maf_text", "maf", "ref_len", "a0", "a1")}
         fields = c[8].split(":")
         if "GT" not in fields:
             continue
@@ -83,67 +88,90 @@ def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str 
         g = list(geno)
         if "." in g:
             continue
-        if "|" in g:
+        phased = "|" in g
+        if phased:
             g.remove("|")
         is_unphased = False
         if "/" in g:
             g.remove("/")
             is_unphased = True
-        if len(set(g)) > 1:
-            if pass_only == 0 or "PASS" in c[6].split(";"):
-                rows.append((c, geno, g))
-                unphased += is_unphased
+        if len(set(g)) <= 1:
+            continue
+        if not (pass_only == 0 or "PASS" in c[6].split(";")):
+            filter_count += 1
+            continue
+        unphased += is_unphased
+        alts = c[4].split(",")
+        every = [c[3]] + alts
+        if not (max(len(x) for x in every) == 1 or include_indels == 1):
+            excluded += 1
+            continue
+        uid = chrom + id_separator + c[1] + id_separator + id_separator.join(every)
+        maf = None
+        if gw_phase_method == 1:
+            info = {}
+            for item in c[7].split(";"):
+                if "=" in item:
+                    info[item.split("=")[0]] = item.split("=")[1]
+            if gw_af_field in info:
+                afs = [float(x) for x in info[gw_af_field].split(",")]
+                if len(afs) == len(alts):
+                    use = [int(x) - 1 for x in g if x != "." and int(x) != 0]
+                    if use:
+                        maf = min(min(afs[x], 1 - afs[x]) for x in use)
+        # fields the phasing core derives from the table row (generate_variant_dict)
+        ind = [every[i] for i in range(len(every)) if str(i) in g]
+        ph = [every[int(i)] for i in g] if phased else ["-", "-"]
+        mtxt = str(maf)
+        try:
+            mval = float(mtxt)
+        except ValueError:
+            mval = 0
+        col["pos"].append(int(c[1])); col["ref_len"].append(min(255, len(c[3])))
+        col["uid"].append(uid); col["rsid_field"].append(c[2]); col["rsid"].append(c[2] if c[2] not in (".", "") else uid)
+        col["ref"].append(c[3]); col["all_alleles"].append(every); col["alleles"].append(ind); col["phase"].append(ph); col["gt"].append(geno)
+        col["maf_text"].append(mtxt); col["maf"].append(mval)
+        col["a0"].append(_CODE.get(ind[0], 255) if len(ind) > 0 else 255)
+        col["a1"].append(_CODE.get(ind[1], 255) if len(ind) > 1 else 255)
+    return per, filter_count, unphased, excluded
+
+
+def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
+                  include_indels: int = 0, chr_prefix: str = "", id_separator: str = "_", gw_phase_method: int = 0,
+                  gw_af_field: str = "AF", contig_ban=("_", ":"), threads: int = 1) -> VariantSet:
+    """threads > 1 fans the per-line work out to forked workers (call it before a GPU context exists: forks are cheap then)."""
+    lines = vcf_text.split("\n")
+    opts = (sample_column, chrom_of_interest, pass_only, include_indels, chr_prefix, id_separator, gw_phase_method, gw_af_field,
+            tuple(contig_ban))
+    if threads > 1 and len(lines) > 100_000:
+        import multiprocessing as mp
+        n = min(threads, 64)
+        step = (len(lines) + n - 1) // n
+        tasks = [(lines[i:i + step],) + opts for i in range(0, len(lines), step)]
+        with mp.get_context("fork").Pool(n) as pool:
+            parts = pool.map(_load_chunk, tasks, chunksize=1)
+    else:
+        parts = [_load_chunk((lines,) + opts)]
+    merged: Dict[str, dict] = {}
+    filter_count = unphased = excluded = 0
+    for per, fc, un, ex in parts:
+        filter_count += fc; unphased += un; excluded += ex
+        for chrom, col in per.items():
+            tgt = merged.get(chrom)
+            if tgt is None:
+                merged[chrom] = col
             else:
-                filter_count += 1
+                for k, v in col.items():
+                    tgt[k] += v
     out: Dict[str, ChromVariants] = {}
-    het = excluded = 0
-    for chrom0, rows in per.items():
-        chrom = chr_prefix + chrom0
-        cv = ChromVariants(chrom, None, [], [], [], [], [], [], [], [], [], [], None, None, None)
-        pos = []; reflen = []; a0 = []; a1 = []
-        for c, geno, g in rows:
-            alts = c[4].split(",")
-            every = [c[3]] + alts
-            if not (max(len(x) for x in every) == 1 or include_indels == 1):
-                excluded += 1
-                continue
-            uid = chrom + id_separator + c[1] + id_separator + id_separator.join(every)
-            maf = None
-            if gw_phase_method == 1:
-                info = {}
-                for item in c[7].split(";"):
-                    if "=" in item:
-                        info[item.split("=")[0]] = item.split("=")[1]
-                if gw_af_field in info:
-                    afs = [float(x) for x in info[gw_af_field].split(",")]
-                    if len(afs) == len(alts):
-                        use = [int(x) - 1 for x in g if x != "." and int(x) != 0]
-                        if use:
-                            maf = min(min(afs[x], 1 - afs[x]) for x in use)
-            # fields the phasing core derives from the table row (generate_variant_dict)
-            gl = list(geno)
-            phased = "|" in gl
-            if phased:
-                gl.remove("|")
-            if "/" in gl:
-                gl.remove("/")
-            ind = [every[i] for i in range(len(every)) if str(i) in gl]
-            ph = [every[int(i)] for i in gl] if phased else ["-", "-"]
-            mtxt = str(maf)
-            try:
-                mval = float(mtxt)
-            except ValueError:
-                mval = 0
-            pos.append(int(c[1])); reflen.append(min(255, len(c[3])))
-            cv.uid.append(uid); cv.rsid_field.append(c[2]); cv.rsid.append(c[2] if c[2] not in (".", "") else uid)
-            cv.ref.append(c[3]); cv.all_alleles.append(every); cv.alleles.append(ind); cv.phase.append(ph); cv.gt.append(geno)
-            cv.maf_text.append(mtxt); cv.maf.append(mval)
-            a0.append(_CODE.get(ind[0], 255) if len(ind) > 0 else 255)
-            a1.append(_CODE.get(ind[1], 255) if len(ind) > 1 else 255)
-            het += 1
-        cv.pos = np.asarray(pos, dtype=np.int32); cv.ref_len = np.asarray(reflen, dtype=np.uint8)
-        cv.a0 = np.asarray(a0, dtype=np.uint8); cv.a1 = np.asarray(a1, dtype=np.uint8)
-        if len(pos) > 1 and bool((np.diff(cv.pos) < 0).any()):
+    het = 0
+    for chrom, col in merged.items():
+        cv = ChromVariants(chrom, np.asarray(col["pos"], dtype=np.int32), col["uid"], col["rsid_field"], col["rsid"], col["ref"],
+                           col["all_alleles"], col["alleles"], col["phase"], col["gt"], col["maf_text"], col["maf"],
+                           np.asarray(col["ref_len"], dtype=np.uint8), np.asarray(col["a0"], dtype=np.uint8),
+                           np.asarray(col["a1"], dtype=np.uint8))
+        if len(cv.pos) > 1 and bool((np.diff(cv.pos) < 0).any()):
             raise SystemExit("     FATAL ERROR: VCF records of %s are not sorted by position." % chrom)
+        het += len(cv.uid)
         out[chrom] = cv
     return VariantSet(out, het, filter_count, excluded, unphased)
