@@ -36,6 +36,7 @@
  * Call list layout (mapper order: record, then segment, then variant position):
  *   read_idx, var_idx   indices into the shard / variant arrays
  *   code                0..3 = the allele is the single base A/C/G/T; 4 = any other string
+ *                       (phz_map_reads_general additionally: 5 / 6 = equals the individual's allele 0 / 1 string)
  *   aux0                read offset of the base under the variant (0xFFFFFFFF: deletion placeholder)
  *   aux1                (read offset of spliced-in inserted bases << 12) | min(length,4095); 0 = none
  *                       aux0/aux1 let the host print the exact allele text; they never change a decision.
@@ -117,6 +118,16 @@ typedef struct {
     uint8_t *edge_linked;    /* 1 when some QNAME's surviving read_vars list holds both variants */
 } phz_tally_out;
 
+/* Variant table for the general (indel) mapper: per variant REF length and the individual's two allele strings. */
+typedef struct {
+    int64_t n;
+    const int32_t *pos;            /* sorted ascending */
+    const uint8_t *ref_len;        /* len(REF), 1..255 */
+    const uint32_t *allele_off;    /* [2n+1]: allele 0 of variant v = bytes [off[2v], off[2v+1]), allele 1 = [off[2v+1], off[2v+2]) */
+    const char *allele_bytes;
+    int64_t n_allele_bytes;
+} phz_variants_general;
+
 /* timing slots for phz_get_timing */
 enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_COUNT = 8 };
 
@@ -186,6 +197,15 @@ int phz_interner_destroy(phz_interner *it);
 int64_t phz_interner_size(const phz_interner *it);
 int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t n, int32_t *out_id);
 int phz_interner_names(const phz_interner *it, char *blob, int64_t blob_cap, uint32_t *off);
+
+/* Mapper for variant sets with indels (phASER --include_indels 1; read_variant_map.py:236-258 with ref_length > 1).
+ * Same call list as phz_map_reads, but `code` is classified on the device against the allele strings:
+ * 5 = text equals allele 0, 6 = equals allele 1, 0..3 = another single base, 4 = any other text.
+ * Optional text pool (both NULL to skip): call_text_off[n_calls+1] / text_roff[] = read offsets of the characters of every
+ * code-4 call, so the host can print the exact allele text.  On PHZ_E_CAPACITY *n_calls / *n_text hold the needs. */
+int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const phz_variants_general *vars, int baseq,
+                          phz_calls *out, int64_t *n_calls, uint32_t *call_text_off, uint32_t *text_roff,
+                          int64_t text_cap, int64_t *n_text, int space);
 
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);

@@ -36,6 +36,11 @@ class phz_variants(C.Structure):
     _fields_ = [("n", C.c_int64), ("pos", C.c_void_p), ("ref_len", C.c_void_p)]
 
 
+class phz_variants_general(C.Structure):
+    _fields_ = [("n", C.c_int64), ("pos", C.c_void_p), ("ref_len", C.c_void_p), ("allele_off", C.c_void_p),
+                ("allele_bytes", C.c_void_p), ("n_allele_bytes", C.c_int64)]
+
+
 class phz_calls(C.Structure):
     _fields_ = [("cap", C.c_int64), ("read_idx", C.c_void_p), ("var_idx", C.c_void_p), ("code", C.c_void_p),
                 ("aux0", C.c_void_p), ("aux1", C.c_void_p)]
@@ -90,6 +95,9 @@ SYMBOLS = {
     "phz_interner_size": (C.c_int64, [C.c_void_p]),
     "phz_intern": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "phz_interner_names": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "phz_map_reads_general": (C.c_int, [C.c_void_p, C.POINTER(phz_reads), C.POINTER(phz_variants_general), C.c_int,
+                                        C.POINTER(phz_calls), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.POINTER(C.c_int64), C.c_int]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_line(LinesDev L, int64_t line_base, con
     }
     if (!keep) { line_cls[line_base + i] = 255; return; }
     const uint8_t c = L.code[i];
-    const int cls = (c < 4 && c == a0[v]) ? 0 : ((c < 4 && c == a1[v]) ? 1 : 2);
+    // codes 5 / 6 come from the general (indel) mapper, which compared the text with the allele strings itself
+    const int cls = c == 5 ? 0 : (c == 6 ? 1 : ((c < 4 && c == a0[v]) ? 0 : ((c < 4 && c == a1[v]) ? 1 : 2)));
     line_cls[line_base + i] = (uint8_t)cls;
     atomicAdd(&var_count[(int64_t)v * 3 + cls], 1);
     atomicMin(&var_first[v], (unsigned long long)(line_base + i));

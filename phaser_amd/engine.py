@@ -84,7 +84,13 @@ class Engine:
         """shard.qid must hold QNAME ids that are consistent across the BAMs of this chromosome."""
         cv = self.vs.chroms[chrom]
         vpos = torch.from_numpy(cv.pos)
-        calls = self.mapper.map(shard, vpos, self.cfg.baseq, torch.from_numpy(cv.ref_len))
+        if cv.is_general:
+            # indel mode (--include_indels 1): classification against the allele strings happens in the general mapper
+            aoff, abytes = cv.allele_pool()
+            calls, _ = self.mapper.map_general(shard, vpos, torch.from_numpy(cv.ref_len), torch.from_numpy(aoff.astype(np.int32)),
+                                               torch.from_numpy(abytes), self.cfg.baseq)
+        else:
+            calls = self.mapper.map(shard, vpos, self.cfg.baseq, torch.from_numpy(cv.ref_len))
         has_as = shard.has_as
         self.shards[chrom][bam_index] = _Shard(calls, shard.qid.contiguous(), shard.aln_score.contiguous(),
                                                None if has_as is None else has_as.contiguous(), shard.n)
@@ -134,7 +140,10 @@ class Engine:
         for i, (b, sh) in enumerate(present):
             arr[i] = self._lines(sh, b)
             total += sh.calls.n
-        a0 = torch.from_numpy(cv.a0).to(dev); a1 = torch.from_numpy(cv.a1).to(dev)
+        if cv.is_general:      # codes 5 / 6 carry the class; single-base codes must not be matched through a0 / a1
+            a0 = torch.full((nv,), 255, dtype=torch.uint8, device=dev); a1 = torch.full((nv,), 255, dtype=torch.uint8, device=dev)
+        else:
+            a0 = torch.from_numpy(cv.a0).to(dev); a1 = torch.from_numpy(cv.a1).to(dev)
         var_count = torch.empty(nv * 3, dtype=torch.int32, device=dev); var_first = torch.empty(nv, dtype=torch.int64, device=dev)
         var_distinct = torch.empty(nv * 3, dtype=torch.int32, device=dev); line_cls = torch.empty(max(1, total), dtype=torch.uint8, device=dev)
         cap = max(1024, 4 * nv)

@@ -32,6 +32,13 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+@dataclasses.dataclass
+class TextPool:
+    """Read offsets of the characters of every code-4 call of a general-mapper run (host tensors)."""
+    call_off: torch.Tensor    # int32 [n_calls + 1]
+    roff: torch.Tensor        # int32
+
+
 class Mapper:
     def __init__(self, device: int = 0, ctx: Optional[_lib.Context] = None):
         self.ctx = ctx or _lib.Context(device)
@@ -69,3 +76,38 @@ class Mapper:
                 continue
             m = int(n.value)
             return Calls(*[b[:m] for b in bufs])
+
+    def map_general(self, shard: ReadShard, vpos: torch.Tensor, ref_len: torch.Tensor, allele_off: torch.Tensor,
+                    allele_bytes: torch.Tensor, baseq: int, want_text: bool = False):
+        """K_map_general (indel mode).  Returns Calls (codes 5/6 = allele 0/1) and, when want_text, a TextPool."""
+        on_gpu = shard.device.type == "cuda"
+        space = _lib.PHZ_DEVICE if on_gpu else _lib.PHZ_HOST
+        dev = shard.device
+        vpos = vpos.to(dev).to(torch.int32).contiguous(); ref_len = ref_len.to(dev).to(torch.uint8).contiguous()
+        allele_off = allele_off.to(dev).to(torch.int32).contiguous(); allele_bytes = allele_bytes.to(dev).to(torch.uint8).contiguous()
+        r = _lib.phz_reads(shard.n, int(shard.cigar.numel()), int(shard.seq2.numel()), _ptr(shard.pos), _ptr(shard.cigar_off),
+                           _ptr(shard.cigar), _ptr(shard.seq_off), _ptr(shard.seq2), _ptr(shard.qual))
+        v = _lib.phz_variants_general(int(vpos.numel()), _ptr(vpos), _ptr(ref_len), _ptr(allele_off), _ptr(allele_bytes),
+                                      int(allele_bytes.numel()))
+        cap = shard.n // 2 + 4096
+        tcap = 4096
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+        while True:
+            bufs = [torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                    torch.empty(cap, dtype=torch.uint8, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                    torch.empty(cap, dtype=torch.int32, device=dev)]
+            toff = torch.zeros(cap + 1, dtype=torch.int32, device=dev) if want_text else None
+            troff = torch.zeros(tcap, dtype=torch.int32, device=dev) if want_text else None
+            c = _lib.phz_calls(cap, *[_ptr(b) for b in bufs])
+            n = C.c_int64(0); nt = C.c_int64(0)
+            st = self.ctx.lib.phz_map_reads_general(self.ctx.h, C.byref(r), C.byref(v), int(baseq), C.byref(c), C.byref(n),
+                                                    _ptr(toff), _ptr(troff), tcap, C.byref(nt), space)
+            self.ctx.check(st, allow=(_lib.PHZ_E_CAPACITY,))
+            if st == _lib.PHZ_E_CAPACITY:
+                cap = max(cap, int(n.value) + 16); tcap = max(tcap, int(nt.value) + 16)
+                continue
+            m = int(n.value)
+            calls = Calls(*[b[:m] for b in bufs])
+            pool = TextPool(toff[:m + 1].cpu(), troff[:int(nt.value)].cpu()) if want_text else None
+            return calls, pool

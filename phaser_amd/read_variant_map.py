@@ -36,6 +36,13 @@ class VariantTable:
                 self.alleles.append(c[4]); self.ref_len.append(int(c[5])); self.gt.append(c[6]); self.maf.append(c[7])
 
 
+def _individual_alleles(alleles_field: str, gt: str):
+    """The individual's alleles in allele-index order (generate_variant_dict, phaser.py:1430-1435)."""
+    every = alleles_field.split(",")
+    g = list(gt)
+    return [every[i] for i in range(len(every)) if str(i) in g]
+
+
 def _allele_text(code, aux0, aux1, seq, qual, baseq):
     """Exact allele text of one call.  Plain single-base calls come straight from `code`; for the rare
     composite ones (inserted bases spliced after the SNP, IUPAC symbols) the kernel reports which read
@@ -104,13 +111,37 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
             vpos = torch.tensor([table.pos[i] for i in vsel], dtype=torch.int32)
             ref_len = torch.tensor([table.ref_len[i] for i in vsel], dtype=torch.uint8)
             shard = soa.pack_sam([(r[1], r[2], r[3], r[4]) for r in recs])
-            calls = mapper.map(shard, vpos, int(baseq), ref_len).cpu()
-            ri = calls.read_idx.tolist(); vi = calls.var_idx.tolist(); cd = calls.code.tolist()
-            a0 = (calls.aux0.to(torch.int64) & 0xFFFFFFFF).tolist(); a1 = (calls.aux1.to(torch.int64) & 0xFFFFFFFF).tolist()
+            ind = [_individual_alleles(table.alleles[i], table.gt[i]) for i in vsel]
+            general = bool((ref_len != 1).any()) or any(len(a) != 1 or a not in _BASES for al in ind for a in al)
             lines = []
-            for k in range(len(ri)):
-                rec = recs[ri[k]]; v = int(vsel[vi[k]])
-                allele = _allele_text(cd[k], a0[k], a1[k], rec[3], rec[4], baseq)
-                lines.append("\t".join([rec[0], table.id[v], table.rsid[v], allele, rec[5], table.gt[v], table.maf[v]]))
+            if general:
+                # indel mode: the kernel classifies against the allele strings (codes 5 / 6) and reports, for any other
+                # text, which read offsets compose it
+                off = [0]; blob = b""
+                for al in ind:
+                    for a in (al + ["", ""])[:2]:
+                        blob += a.encode(); off.append(len(blob))
+                calls, pool = mapper.map_general(shard, vpos, ref_len, torch.tensor(off, dtype=torch.int32),
+                                                 torch.tensor(list(blob + b"\0"), dtype=torch.uint8), int(baseq), want_text=True)
+                calls = calls.cpu()
+                ri = calls.read_idx.tolist(); vi = calls.var_idx.tolist(); cd = calls.code.tolist()
+                toff = pool.call_off.tolist(); tro = pool.roff.tolist()
+                for k in range(len(ri)):
+                    rec = recs[ri[k]]; v = int(vsel[vi[k]])
+                    if cd[k] == 5 or cd[k] == 6:
+                        allele = ind[vi[k]][cd[k] - 5]
+                    elif cd[k] < 4:
+                        allele = _BASES[cd[k]]
+                    else:
+                        allele = "".join((rec[3][x] if (ord(rec[4][x]) - 33) >= baseq else "N") for x in tro[toff[k]:toff[k + 1]]).replace("D", "")
+                    lines.append("\t".join([rec[0], table.id[v], table.rsid[v], allele, rec[5], table.gt[v], table.maf[v]]))
+            else:
+                calls = mapper.map(shard, vpos, int(baseq), ref_len).cpu()
+                ri = calls.read_idx.tolist(); vi = calls.var_idx.tolist(); cd = calls.code.tolist()
+                a0 = (calls.aux0.to(torch.int64) & 0xFFFFFFFF).tolist(); a1 = (calls.aux1.to(torch.int64) & 0xFFFFFFFF).tolist()
+                for k in range(len(ri)):
+                    rec = recs[ri[k]]; v = int(vsel[vi[k]])
+                    allele = _allele_text(cd[k], a0[k], a1[k], rec[3], rec[4], baseq)
+                    lines.append("\t".join([rec[0], table.id[v], table.rsid[v], allele, rec[5], table.gt[v], table.maf[v]]))
             if lines:
                 out.write("\n".join(lines) + "\n")

@@ -46,6 +46,8 @@ class Variants:
     gt: List[str]            # "0|1", "1|0" or "0/1"
     hap_alt: torch.Tensor    # uint8 [n]: which haplotype (0/1) carries ALT
     rsid: List[str]
+    ref_text: Optional[List[str]] = None   # set when some variants are indels (REF / ALT longer than one base)
+    alt_text: Optional[List[str]] = None
 
     def __len__(self):
         return int(self.pos.numel())
@@ -53,7 +55,7 @@ class Variants:
 
 def make_variants(chrom: str, start: int, end: int, n_snps: int, seed: int,
                   n_genes: Optional[int] = None, unphased_frac: float = 0.05,
-                  dot_id_frac: float = 0.1):
+                  dot_id_frac: float = 0.1, indel_frac: float = 0.0):
     """Het SNPs clustered into 'genes'; returns (Variants, gene_start, gene_end, gene_weight)."""
     g = torch.Generator().manual_seed(seed)
     if n_genes is None:
@@ -83,6 +85,25 @@ def make_variants(chrom: str, start: int, end: int, n_snps: int, seed: int,
             gt.append("1|0" if int(hap_alt[i]) == 0 else "0|1")
         rsid.append("." if bool(dot[i]) else "rs%d" % (1000 + i))
     v = Variants(chrom, pos.to(torch.int32), ref, alt, gt, hap_alt, rsid)
+    if indel_frac > 0:
+        # a share of the sites become deletions (REF = 2-4 reference bases, ALT = its first base) or insertions
+        # (REF = one base, ALT = that base + 1-3 bases); reads are NOT edited for them (parity fixtures, not biology)
+        kind = torch.rand(n, generator=g)
+        extra = torch.randint(1, 4, (n,), generator=g)
+        ins_bases = torch.randint(0, 4, (n, 3), generator=g)
+        v.ref_text = []; v.alt_text = []
+        for i in range(n):
+            p0 = int(pos[i])
+            if float(kind[i]) < indel_frac / 2:
+                k = int(extra[i])
+                v.ref_text.append("".join(BASES[int(ref_base(torch.tensor([p0 + d]))[0])] for d in range(k + 1)))
+                v.alt_text.append(BASES[int(ref[i])])
+            elif float(kind[i]) < indel_frac:
+                k = int(extra[i])
+                v.ref_text.append(BASES[int(ref[i])])
+                v.alt_text.append(BASES[int(ref[i])] + "".join(BASES[int(b)] for b in ins_bases[i, :k]))
+            else:
+                v.ref_text.append(BASES[int(ref[i])]); v.alt_text.append(BASES[int(alt[i])])
     return v, gstart, gend, weight
 
 
@@ -326,6 +347,8 @@ def vcf_lines(vs: List[Variants], sample: str = "S1") -> List[str]:
     for v in vs:
         pos = v.pos.tolist(); ref = v.ref.tolist(); alt = v.alt.tolist()
         for i in range(len(v)):
-            out.append("\t".join([v.chrom, str(pos[i]), v.rsid[i], BASES[ref[i]], BASES[alt[i]], "100", "PASS",
+            rt = BASES[ref[i]] if v.ref_text is None else v.ref_text[i]
+            at = BASES[alt[i]] if v.alt_text is None else v.alt_text[i]
+            out.append("\t".join([v.chrom, str(pos[i]), v.rsid[i], rt, at, "100", "PASS",
                                   "AF=0.%d" % (1 + (pos[i] % 49)), "GT", v.gt[i]]))
     return out

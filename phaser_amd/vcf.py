@@ -37,6 +37,25 @@ class ChromVariants:
     def __len__(self):
         return len(self.uid)
 
+    @property
+    def is_general(self) -> bool:
+        """True when the set is not pure SNPs (some REF longer than one base or some allele not a single ACGT base):
+        such sets go through the general mapper (phz_map_reads_general)."""
+        return bool((self.ref_len != 1).any() or (self.a0 == 255).any() or (self.a1 == 255).any())
+
+    def allele_pool(self):
+        """-> (allele_off uint32 [2n+1], allele_bytes uint8) of the individual's two alleles per variant."""
+        off = np.zeros(2 * len(self) + 1, dtype=np.uint32)
+        parts = []
+        o = 0
+        for i, al in enumerate(self.alleles):
+            a0 = al[0].encode() if len(al) > 0 else b""
+            a1 = al[1].encode() if len(al) > 1 else b""
+            off[2 * i] = o; o += len(a0); off[2 * i + 1] = o; o += len(a1)
+            parts.append(a0); parts.append(a1)
+        off[2 * len(self)] = o
+        return off, np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8).copy()
+
     def table_rows(self):
         return [[self.chrom, str(int(self.pos[i])), self.uid[i], self.rsid_field[i], ",".join(self.all_alleles[i]),
                  str(int(self.ref_len[i])), self.gt[i], self.maf_text[i]] for i in range(len(self))]

@@ -116,7 +116,37 @@ def test_empty_and_edge_shards(mapper):
     calls = mapper.map(shard, vpos, 10).cpu()
     assert calls.var_idx.tolist() == list(range(10, 20))
     assert calls.code.tolist() == [0, 1, 2, 3, 0, 1, 2, 3, 0, 1]
-    # indel variants are refused loudly, not silently mis-mapped
+    # the SNP kernel refuses indel variants loudly (they go through map_general instead)
     from phaser_amd import _lib
     with pytest.raises(_lib.PhzError):
         mapper.map(shard, vpos, 10, ref_len=torch.full((30,), 2, dtype=torch.uint8))
+
+
+def test_indel_mode_calls_bytes(mapper, tmp_path):
+    """Mapper TSV with indel variants in the table (ref_len > 1, multi-base alleles): byte-identical to the reference."""
+    d = os.path.join(GOLD, "pipe_indel")
+    got = run_dropin(mapper, gz_text(os.path.join(d, "i.chr22.sam.gz")), os.path.join(d, "table.chr22.tsv"), str(tmp_path / "o.tsv"), 10, 0)
+    assert got == gz_text(os.path.join(d, "calls.i.chr22.tsv.gz"))
+
+
+def test_kat_micro_indel_variants(mapper, tmp_path):
+    """The known-answer cases whose variants are indels (ref_len 2..4), one table per case through the drop-in."""
+    cases = json.load(open(os.path.join(GOLD, "kat_micro.json")))
+    n = 0
+    for c in cases:
+        vs = [v for v in c["variants"] if v["ref_len"] > 1]
+        if not vs:
+            continue
+        vs = sorted(vs, key=lambda v: v["pos"])
+        tp = tmp_path / ("t%d.tsv" % n)
+        tp.write_text("".join("\t".join(["1", str(v["pos"]), "1_%d_x" % v["pos"], ".", v["alleles"], str(v["ref_len"]), "0|1", "None"]) + "\n" for v in vs))
+        sam = "@SQ\tSN:1\tLN:1000\n" + "\t".join(["r", "0", "1", str(c["pos"]), "255", c["cigar"], "*", "0", "0", c["seq"], c["qual"], "AS:i:9"]) + "\n"
+        got = run_dropin(mapper, sam, str(tp), str(tmp_path / "o.tsv"), c["baseq"], 0)
+        want = ""
+        for s_i in range(len(c["segments"])):
+            for v in vs:
+                if v["per_segment"][s_i] != "":
+                    want += "\t".join(["r", "1_%d_x" % v["pos"], ".", v["per_segment"][s_i], "9", "0|1", "None"]) + "\n"
+        assert got == want, c["name"]
+        n += 1
+    assert n >= 3

@@ -334,6 +334,30 @@ def fx_c1(phaser, rvm):
     print("c1:", meta, [l for l in res["log"].splitlines() if "PHASED" in l])
 
 
+def fx_indels(phaser, rvm):
+    """--include_indels 1: deletion / insertion variants next to SNPs, reads carrying I / D / N ops (general ref_len path,
+    read_variant_map.py:236-258 with ref_len > 1 and multi-base alleles)."""
+    from phaser_amd import synth
+    contigs = [("chr21", 46709983), ("chr22", 50818468)]
+    d = os.path.join(GOLD, "pipe_indel"); os.makedirs(d, exist_ok=True)
+    v, gs, ge, w = synth.make_variants("chr22", 1, 1_500_000, 320, 701, n_genes=10, indel_frac=0.3)
+    rb = synth.make_reads(v, gs, ge, w, 9000, 702, err_rate=0.004)
+    rf = rb.select(synth.samtools_keep(rb, 255))
+    sam = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf = "\n".join(synth.vcf_lines([v])) + "\n"
+    res, calls = run_pipeline(phaser, rvm, vcf, {"i.bam": {"chr22": sam}}, d, include_indels=1)
+    open(os.path.join(d, "in.vcf"), "w").write(vcf)
+    wgz(os.path.join(d, "i.chr22.sam.gz"), sam)
+    wgz(os.path.join(d, "calls.i.chr22.tsv.gz"), calls[("i.bam", "chr22")])
+    open(os.path.join(d, "table.chr22.tsv"), "w").write(calls[("table", "chr22")])
+    for k, t in res.items():
+        wgz(os.path.join(d, "out." + k + ".txt.gz"), t)
+    txt = calls[("i.bam", "chr22")]
+    multi = sum(1 for l in txt.splitlines() if len(l.split("\t")[3]) > 1)
+    print("pipe_indel: records=%d call lines=%d (multi-base texts %d)" % (len(rf), txt.count("\n"), multi),
+          [l for l in res["log"].splitlines() if "PHASED" in l or "heterozygous" in l])
+
+
 def fx_write_vcf(phaser, rvm):
     """Phased VCF text (write_vcf, phaser.py:1661-1855) for pipe_one / pipe_noisy_c inputs under the three --gw_phase_vcf modes."""
     for src, mbs in [("pipe_one", 15), ("pipe_noisy_c", 15), ("pipe_two", 15)]:
@@ -351,7 +375,7 @@ def fx_write_vcf(phaser, rvm):
         print("write_vcf", src, len(res["vcf"].splitlines()), "lines")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf}
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
