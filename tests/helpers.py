@@ -79,7 +79,9 @@ def canonical(name, text):
         fixed = []
         for r in rows:
             f = r.split("\t")
-            f[16] = _relabel(f[16]); f[17] = _relabel(f[17])
+            if len(f) == 20:       # --output_read_ids 1: two QNAME lists (set order in the reference) sit before max_haplo_maf
+                f[14] = ",".join(sorted(f[14].split(","))); f[15] = ",".join(sorted(f[15].split(",")))
+            f[-2] = _relabel(f[-2]); f[-1] = _relabel(f[-1])
             f[5] = ",".join(sorted(f[5].split(","))) if f[5] else f[5]
             fixed.append("\t".join(f))
         rows = fixed
@@ -87,3 +89,24 @@ def canonical(name, text):
 
 
 OUTPUTS = ["allelic_counts", "variant_connections", "haplotypes", "haplotypic_counts", "allele_config"]
+
+
+def option_case_kwargs(name, case, blacklist):
+    """tests/golden/pipe_opts/cases.json entry -> (vcf loader kwargs, engine Config kwargs, mapper baseq, isize)."""
+    load = {}; cfg = {}; baseq = 10; isize = 0.0
+    for k, v in case.items():
+        if k == "gw_phase_method":
+            load[k] = v; cfg[k] = v
+        elif k == "id_separator":
+            load[k] = v; cfg[k] = v
+        elif k == "haplo_count_bam_exclude":
+            cfg[k] = [int(x) - 1 for x in v.split(",")]
+        elif k == "baseq":
+            baseq = v; cfg[k] = v
+        elif k == "isize":
+            isize = float(v)
+        else:
+            cfg[k] = v
+    if name == "blacklist":
+        cfg["haplo_blacklist"] = frozenset(blacklist)
+    return load, cfg, baseq, isize

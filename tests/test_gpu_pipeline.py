@@ -19,20 +19,20 @@ def mapper():
     return Mapper(0)
 
 
-def run_product(mapper, vcf_text, bams, device="cpu", include_indels=0, **cfgkw):
+def run_product(mapper, vcf_text, bams, device="cpu", include_indels=0, load_kw=None, isize=0.0, **cfgkw):
     """bams: ordered {bam_path: {chrom: sam_text}}"""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from phasing_oracle import bam_display_names          # naming helper only (test side)
     from phaser_amd import samio, vcf
     from phaser_amd.engine import Config, Engine
-    vs = vcf.load_variants(vcf_text, include_indels=include_indels)
+    vs = vcf.load_variants(vcf_text, include_indels=include_indels, **(load_kw or {}))
     eng = Engine(vs, bam_display_names(list(bams.keys())), Config(**cfgkw), mapper=mapper)
     interners = {}
     for bi, (bam, per_chrom) in enumerate(bams.items()):
         for chrom in vs.chroms:
             if chrom not in per_chrom:
                 continue
-            shards = samio.shards_from_sam(per_chrom[chrom], interners)
+            shards = samio.shards_from_sam(per_chrom[chrom], interners, isize)
             for c2, sh in shards.items():
                 eng.add_shard(bi, c2, sh.to(device), len(interners[c2]), interners[c2].names)
         for c2 in interners:
@@ -165,3 +165,19 @@ def test_include_indels_pipeline(mapper):
                            {"i.bam": {"chr22": gz_text(os.path.join(d, "i.chr22.sam.gz"))}}, "cuda", include_indels=1)
     compare(out, d)
     assert eng.vs.chroms["chr22"].is_general
+
+
+def _opt_cases():
+    return list(json.load(open(os.path.join(GOLD, "pipe_opts", "cases.json")))["cases"].keys())
+
+
+@pytest.mark.parametrize("name", _opt_cases())
+def test_option_flags(mapper, name):
+    """Every flag that reaches the hot path, product (GPU) vs what the reference wrote (tests/golden/pipe_opts)."""
+    from helpers import option_case_kwargs
+    d0 = os.path.join(GOLD, "pipe_opts")
+    meta = json.load(open(os.path.join(d0, "cases.json")))
+    load, cfg, baseq, isize = option_case_kwargs(name, meta["cases"][name], meta["blacklist"])
+    bams = {b + ".bam": {c: gz_text(os.path.join(d0, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")} for b in ("o1", "o2")}
+    out, eng = run_product(mapper, open(os.path.join(d0, "in.vcf")).read(), bams, "cuda", load_kw=load, isize=isize, **cfg)
+    compare(out, os.path.join(d0, name))

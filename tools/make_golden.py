@@ -89,7 +89,7 @@ def run_mapper(rvm, sam_text, table_text, baseq=10, isize=0.0):
     return out
 
 
-def run_pipeline(phaser, rvm, vcf_text, sams, outdir, capture_calls=True, **argkw):
+def run_pipeline(phaser, rvm, vcf_text, sams, outdir, capture_calls=True, haplo_blacklist=None, **argkw):
     """Drive process_vcf (phaser.py:378) end to end. `sams` = ordered {bam_path: sam_text}."""
     ns = default_args(bam=",".join(sams.keys()), **argkw)
     phaser.args = ns
@@ -132,7 +132,7 @@ def run_pipeline(phaser, rvm, vcf_text, sams, outdir, capture_calls=True, **argk
     log = io.StringIO()
     sys.stdout = log
     try:
-        phaser.process_vcf(open(vp), "", ["_", ":"], set(), time.time(), vcf_tmp, prefix, True, 0)
+        phaser.process_vcf(open(vp), "", [ns.id_separator, ":"], haplo_blacklist or set(), time.time(), vcf_tmp, prefix, True, 0)
     except subprocess.CalledProcessError as e:
         if not (ns.write_vcf == 1 and "bgzip" in str(e.cmd)):
             raise
@@ -358,6 +358,57 @@ def fx_indels(phaser, rvm):
           [l for l in res["log"].splitlines() if "PHASED" in l or "heterozygous" in l])
 
 
+OPT_CASES = {
+    "gw_maf": dict(gw_phase_method=1),
+    "no_unphased": dict(unphased_vars=0),
+    "read_ids": dict(output_read_ids=1),
+    "bam_exclude": dict(haplo_count_bam_exclude="2"),
+    "unique_ids": dict(unique_ids=1),
+    "thresholds": dict(cc_threshold=0.5, as_q_cutoff=0, baseq=30),
+    "as_q20": dict(as_q_cutoff=0.2),
+    "isize": dict(isize="260"),
+    "separator": dict(id_separator="~"),
+    "blacklist": dict(),          # haplotypic-count blacklist passed as a set (see below)
+}
+
+
+def opts_inputs():
+    from phaser_amd import synth
+    contigs = [("chr21", 46709983), ("chr22", 50818468)]
+    vs = []; sams = {"o1.bam": {}, "o2.bam": {}}
+    for ci, (chrom, ln) in enumerate(contigs):
+        v, gs, ge, w = synth.make_variants(chrom, 1, 800_000, 90, 880 + ci, n_genes=5)
+        vs.append(v)
+        for bi, bam in enumerate(sams):
+            rb = synth.make_reads(v, gs, ge, w, 1400, 890 + 10 * ci + bi, qname_prefix="s0.r", err_rate=0.01)
+            rf = rb.select(synth.samtools_keep(rb, 255))
+            sams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    return vs, sams, "\n".join(synth.vcf_lines(vs)) + "\n"
+
+
+def fx_options(phaser, rvm):
+    """The flags that reach the hot path (phaser.py:30-78), one reference run each on a small 2-chromosome x 2-BAM sample."""
+    d0 = os.path.join(GOLD, "pipe_opts"); os.makedirs(d0, exist_ok=True)
+    vs, sams, vcf = opts_inputs()
+    open(os.path.join(d0, "in.vcf"), "w").write(vcf)
+    for bam in sams:
+        for chrom in sams[bam]:
+            wgz(os.path.join(d0, "%s.%s.sam.gz" % (bam.replace(".bam", ""), chrom)), sams[bam][chrom])
+    bl = set("%s_%d" % (v.chrom, int(p)) for v in vs for p in v.pos.tolist()[::7])
+    json.dump({"cases": {k: {kk: vv for kk, vv in kw.items()} for k, kw in OPT_CASES.items()}, "blacklist": sorted(bl)},
+              open(os.path.join(d0, "cases.json"), "w"), indent=1)
+    for name, kw in OPT_CASES.items():
+        d = os.path.join(d0, name); os.makedirs(d, exist_ok=True)
+        kw = dict(kw)
+        if name == "isize":
+            # the insert-size filter lives in the mapper call (phaser.py:1346 --isize_cutoff); run_pipeline passes it through
+            pass
+        res, _ = run_pipeline(phaser, rvm, vcf, sams, d, capture_calls=False, haplo_blacklist=(bl if name == "blacklist" else set()), **kw)
+        for k, t in res.items():
+            wgz(os.path.join(d, "out." + k + ".txt.gz"), t)
+        print("pipe_opts/%s" % name, [l.strip() for l in res["log"].splitlines() if "PHASED" in l])
+
+
 def fx_write_vcf(phaser, rvm):
     """Phased VCF text (write_vcf, phaser.py:1661-1855) for pipe_one / pipe_noisy_c inputs under the three --gw_phase_vcf modes."""
     for src, mbs in [("pipe_one", 15), ("pipe_noisy_c", 15), ("pipe_two", 15)]:
@@ -375,7 +426,7 @@ def fx_write_vcf(phaser, rvm):
         print("write_vcf", src, len(res["vcf"].splitlines()), "lines")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels}
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels, "options": fx_options}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
