@@ -72,10 +72,18 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL ("nccl"); PHZ_BENCH_BACKEND=gloo lets several ranks share a GPU (used only to exercise the
+    # multi-rank path on a 1-GPU box)
+    backend = os.environ.get("PHZ_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
+    red_dev = dev if backend == "nccl" else "cpu"
 
     from phaser_amd import workloads
     from phaser_amd.mapper import Mapper
@@ -131,8 +139,8 @@ def main():
     key = bufs[0][:n_calls].to(torch.int64) * (int(vpos.numel()) + 1) + bufs[1][:n_calls].to(torch.int64)
     assert bool((key[1:] > key[:-1]).all()), "call list not in mapper order"
 
-    tot_calls = torch.tensor([float(n_calls)], device=dev); tmax = torch.tensor([dt], device=dev)
-    tot_recs = torch.tensor([float(shard.n)], device=dev)
+    tot_calls = torch.tensor([float(n_calls)], device=red_dev, dtype=torch.float64); tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
+    tot_recs = torch.tensor([float(shard.n)], device=red_dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tot_calls); dist.all_reduce(tot_recs); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

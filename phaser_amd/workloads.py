@@ -50,11 +50,19 @@ def make_shard(chrom: str, length: int, n_snps: int, n_records: int, seed: int, 
     if cig_base >= 2 ** 31 or seq_base >= 2 ** 31:
         raise ValueError("shard exceeds 32-bit offsets")
     cat = torch.cat
+    # QNAME ids as an interner hands them out: numbered by first appearance in coordinate order (mates share the id)
+    q = cat([p[0].qid for p in parts]).to(torch.int64)
+    nq = int(q.max()) + 1
+    first = torch.full((nq,), q.numel(), dtype=torch.int64, device=q.device)
+    first.scatter_reduce_(0, q, torch.arange(q.numel(), device=q.device), "amin")
+    rank = torch.empty(nq, dtype=torch.int64, device=q.device)
+    rank[torch.argsort(first)] = torch.arange(nq, device=q.device)
+    qid_all = rank[q].to(torch.int32)
     shard = soa.ReadShard(
         cat([p[0].pos for p in parts]),
         cat([p[0].cigar_off[:-1] + p[1] for p in parts] + [torch.tensor([cig_base], dtype=torch.int32, device=parts[0][0].pos.device)]),
         cat([p[0].cigar for p in parts]),
         cat([p[0].seq_off[:-1] + p[2] for p in parts] + [torch.tensor([seq_base], dtype=torch.int32, device=parts[0][0].pos.device)]),
         cat([p[0].seq2 for p in parts]), cat([p[0].qual for p in parts]),
-        cat([p[0].qid for p in parts]), cat([p[0].aln_score for p in parts]), cat([p[0].has_as for p in parts]))
+        qid_all, cat([p[0].aln_score for p in parts]), cat([p[0].has_as for p in parts]))
     return v, shard, sample
