@@ -173,8 +173,8 @@ class Engine:
         base = 0
         for b, sh in present:
             offs.append((b, base, sh.calls.n))
-            v = sh.calls.var_idx.cpu().numpy(); r = sh.calls.read_idx.cpu().numpy().astype(np.int64)
-            lv.append(v); lq.append(sh.qid.cpu().numpy()[r]); lb.append(np.full(len(v), b, dtype=np.int32))
+            v = sh.calls.var_idx.cpu().numpy()
+            lv.append(v); lq.append(sh.qid[sh.calls.read_idx.long()].cpu().numpy()); lb.append(np.full(len(v), b, dtype=np.int32))
             base += sh.calls.n
         cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
         res["line_var"] = cat(lv, np.int32); res["line_qid"] = cat(lq, np.int32); res["line_bam"] = cat(lb, np.int32)
@@ -238,7 +238,8 @@ class Engine:
         t0 = _t.perf_counter()
         frags = {c: self.chrom_prepare(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
         self.stats["prepare_s"] = _t.perf_counter() - t0
-        chunk = 1500
+        nblocks = sum(len(self._pre[c][0]) for c in self.chrom_list)
+        chunk = max(50, min(1500, nblocks // (4 * self.cfg.host_threads) + 1))
         btasks = [(c, lo, min(lo + chunk, len(self._pre[c][0]))) for c in self.chrom_list for lo in range(0, len(self._pre[c][0]), chunk)]
         _FORK_ENGINE = self
         ctx = mp.get_context("fork")

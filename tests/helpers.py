@@ -110,3 +110,31 @@ def option_case_kwargs(name, case, blacklist):
     if name == "blacklist":
         cfg["haplo_blacklist"] = frozenset(blacklist)
     return load, cfg, baseq, isize
+
+
+def oracle_map_readbatch_threads(oracle_dir, rb, vpos, baseq, n_threads):
+    """Same work split into n_threads record ranges on Python threads (ctypes releases the GIL while the C code runs).
+    Returns the total number of calls; used by bench.py's all-cores CPU figure."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = oracle_lib(oracle_dir)
+    n = len(rb)
+    pos = np.ascontiguousarray(rb.pos.numpy().astype(np.int32))
+    coff = np.ascontiguousarray(rb.cigar_off.numpy().astype(np.int64))
+    cig = np.ascontiguousarray(rb.cigar.numpy().astype(np.uint32))
+    seq = np.ascontiguousarray(rb.seq.numpy()); qual = np.ascontiguousarray(rb.qual.numpy())
+    vp = np.ascontiguousarray(np.asarray(vpos, dtype=np.int32)); rl = np.ones(len(vp), dtype=np.uint8)
+    L = rb.L
+    bounds = [n * t // n_threads for t in range(n_threads + 1)]
+
+    def work(t):
+        lo, hi = bounds[t], bounds[t + 1]
+        m = hi - lo
+        if m == 0:
+            return 0
+        cap = m + 1024
+        o_r = np.zeros(cap, np.int32); o_v = np.zeros(cap, np.int32); o_c = np.zeros(cap, np.uint8)
+        return lib.rvm_oracle_map_soa(m, pos.ctypes.data + 4 * lo, coff.ctypes.data + 8 * lo, cig.ctypes.data, seq.ctypes.data + L * lo,
+                                      qual.ctypes.data + L * lo, L, baseq, len(vp), vp.ctypes.data, rl.ctypes.data, cap, o_r.ctypes.data,
+                                      o_v.ctypes.data, o_c.ctypes.data, None)
+    with ThreadPoolExecutor(n_threads) as ex:
+        return sum(ex.map(work, range(n_threads)))
