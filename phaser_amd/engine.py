@@ -238,28 +238,40 @@ class Engine:
         t0 = _t.perf_counter()
         frags = {c: self.chrom_prepare(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
         self.stats["prepare_s"] = _t.perf_counter() - t0
-        nblocks = sum(len(self._pre[c][0]) for c in self.chrom_list)
+        nblocks = sum(self._pre[c]["ncomp"] for c in self.chrom_list)
         chunk = max(50, min(1500, nblocks // (4 * self.cfg.host_threads) + 1))
-        btasks = [(c, lo, min(lo + chunk, len(self._pre[c][0]))) for c in self.chrom_list for lo in range(0, len(self._pre[c][0]), chunk)]
+        tasks = []
+        for c in self.chrom_list:
+            P = self._pre[c]
+            tasks += [("conn", c, lo, min(lo + 40000, len(P["eorder"]))) for lo in range(0, len(P["eorder"]), 40000)]
+            tasks += [("alle", c, lo, min(lo + 40000, len(P["key_g"]))) for lo in range(0, len(P["key_g"]), 40000)]
+            tasks += [("blk", c, lo, min(lo + chunk, P["ncomp"])) for lo in range(0, P["ncomp"], chunk)]
         _FORK_ENGINE = self
         ctx = mp.get_context("fork")
-        nproc = min(self.cfg.host_threads, max(1, len(btasks)))
-        with ctx.Pool(nproc) as pool:
-            bres = pool.map(_fork_block_rows, btasks, chunksize=1)
+        if tasks:
+            with ctx.Pool(min(self.cfg.host_threads, len(tasks))) as pool:
+                res = pool.map(_fork_task, tasks, chunksize=1)
+        else:
+            res = []
         phased: Dict[str, set] = {c: set() for c in self.chrom_list}
-        for (c, lo, hi), (chunk_rec, ph) in zip(btasks, bres):
-            frags[c].setdefault("blocks", []).append(chunk_rec)
-            phased[c].update(ph)
+        for (kind, c, lo, hi), r in zip(tasks, res):
+            if kind == "conn":
+                frags[c].setdefault("conn", []).append(r)
+            elif kind == "alle":
+                frags[c].setdefault("allelic", []).extend(r)
+            else:
+                frags[c].setdefault("blocks", []).append(r[0])
+                phased[c].update(r[1])
         self._phased_sets = phased            # must exist before the second fork: singleton workers read it
-        schunk = 20000
-        stasks = [(c, lo, min(lo + schunk, len(self._pre[c][1]))) for c in self.chrom_list for lo in range(0, len(self._pre[c][1]), schunk)]
+        stasks = [("sng", c, lo, min(lo + 20000, len(self._pre[c]["key_g"]))) for c in self.chrom_list
+                  for lo in range(0, len(self._pre[c]["key_g"]), 20000)]
         if stasks:
             with ctx.Pool(min(self.cfg.host_threads, len(stasks))) as pool:
-                sres = pool.map(_fork_single_rows, stasks, chunksize=1)
-            for (c, lo, hi), rows in zip(stasks, sres):
+                sres = pool.map(_fork_task, stasks, chunksize=1)
+            for (kind, c, lo, hi), rows in zip(stasks, sres):
                 frags[c].setdefault("singles", []).extend(rows)
         for c in self.chrom_list:
-            frags[c].setdefault("blocks", []); frags[c].setdefault("singles", [])
+            frags[c].setdefault("blocks", []); frags[c].setdefault("singles", []); frags[c].setdefault("conn", []); frags[c].setdefault("allelic", [])
             frags[c]["phased"] = len(phased[c])
         self.stats["rows_pool_s"] = _t.perf_counter() - t0 - self.stats["prepare_s"]
         _FORK_ENGINE = None
@@ -268,10 +280,12 @@ class Engine:
     def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
         """Stage C for one chromosome: pair tests, pruning, components (C1), block phasing + output rows (C2), serially."""
         frag = self.chrom_prepare(c, noise, chrom_index)
-        blocks_all, keys = self._pre[c]
-        chunk, phased = self._block_rows(c, blocks_all)
+        P = self._pre[c]
+        frag["conn"] = [self._conn_text(c, 0, len(P["eorder"]))]
+        frag["allelic"] = self._allelic_rows(c, 0, len(P["key_g"]))
+        chunk, phased = self._block_rows(c, 0, P["ncomp"])
         frag["blocks"] = [chunk]
-        frag["singles"] = self._single_rows(c, keys, set(phased))
+        frag["singles"] = self._single_rows(c, 0, len(P["key_g"]), set(phased))
         frag["phased"] = len(phased)
         return frag
 
@@ -281,8 +295,6 @@ class Engine:
         cfg = self.cfg
         R = self.tally[c]; cv = self.vs.chroms[c]; nv = R["nv"]
         frag = {"chrom": c, "lines": int((R["line_cls"] != 255).sum())}
-        conn_rows: List[str] = []
-        blocks_all = []
         if True:
             kept = R["line_cls"] != 255
             cls = R["line_cls"]
@@ -329,23 +341,6 @@ class Engine:
             keep_edge = ~(pv < cfg.cc_threshold)
             # row order of variant_connections is hash order in the reference; we emit sorted by (rank a, rank b)
             eorder = np.lexsort((rank[vb], rank[va]))
-            uid = cv.uid; phase = cv.phase; alle = cv.alleles
-            for k in eorder:
-                a = int(va[k]); bb = int(vb[k])
-                conc = "."
-                if "-" not in phase[a] and "-" not in phase[bb]:
-                    if cis[k] > trans[k]:
-                        conc = 1 if phase[a].index(alle[a][0]) == phase[bb].index(alle[bb][0]) else 0
-                    elif cis[k] < trans[k]:
-                        conc = 1 if phase[a].index(alle[a][1]) == phase[bb].index(alle[bb][0]) else 0
-                if sup[k] == 0:
-                    ptxt = "0"
-                elif tot[k] - sup[k] > 0:
-                    ptxt = str(np.float64(pv[k]))
-                else:
-                    ptxt = "1"
-                conn_rows.append("\t".join([uid[a], uid[bb], str(int(sup[k])), str(int(tot[k])), ptxt, str(conc)]))
-            frag["conn_rows"] = conn_rows
             frag["dropped"] = int((~keep_edge).sum())
             # ---- connected components of the surviving graph on the GPU (phaser.py:1861-1882)
             dev = R["dev"]
@@ -359,6 +354,8 @@ class Engine:
             deg = np.zeros(nv, dtype=np.int64)
             np.add.at(deg, ea[keep_edge], 1); np.add.at(deg, eb[keep_edge], 1)
             members = np.nonzero(deg > 0)[0]
+            P = {"va": va, "vb": vb, "cis": cis, "trans": trans, "sup": sup, "tot": tot, "pv": pv, "eorder": eorder, "ea": ea, "eb": eb,
+                 "cfgv": cfgv, "ncomp": 0}
             if len(members):
                 lab = label[members]
                 o2 = np.lexsort((members, lab))
@@ -371,34 +368,73 @@ class Engine:
                 eo = np.argsort(e_lab, kind="stable")
                 e_lab_s = e_lab[eo]
                 e_starts = np.searchsorted(e_lab_s, lab_s[starts], side="left"); e_ends = np.searchsorted(e_lab_s, lab_s[starts], side="right")
-                pos = cv.pos
-                for ci in np.argsort(comp_rank, kind="stable"):
-                    mem = mem_s[starts[ci]:ends[ci]]
-                    mem = mem[np.lexsort((mem, pos[mem]))]            # sort_var_ids (:1884): by position, ties by index
-                    loc = {int(g): i for i, g in enumerate(mem)}
-                    ek = e_keep[eo[e_starts[ci]:e_ends[ci]]]
-                    edges = [(loc[int(ea[e])], loc[int(eb[e])], int(cfgv[e])) for e in ek]
-                    blocks_all.append((mem, edges))
-        # ---- first-appearance order keys of this chromosome's variants (rule 2) and allelic counts (:737-749)
+                P.update({"mem_s": mem_s, "starts": starts, "ends": ends, "comp_order": np.argsort(comp_rank, kind="stable"), "e_keep": e_keep,
+                          "eo": eo, "e_starts": e_starts, "e_ends": e_ends, "ncomp": len(starts)})
+        # ---- first-appearance order keys of this chromosome's variants (rule 2): (BAM of first kept line, chromosome, line)
         vf = R["var_first"]
         seen = np.nonzero(vf >= 0)[0]
         bam_of = np.zeros(len(seen), dtype=np.int64)
         for b_, base, n in R["bam_offsets"]:
             bam_of[(vf[seen] >= base) & (vf[seen] < base + n)] = b_
-        keys = sorted((int(bam_of[j]), chrom_index, int(vf[g]), int(g)) for j, g in enumerate(seen))
-        allelic = []
-        for kb, kc, kl, g in keys:
+        ko = np.lexsort((seen, vf[seen], bam_of))
+        P.update({"key_bam": bam_of[ko], "key_line": vf[seen][ko], "key_g": seen[ko], "chrom_index": chrom_index})
+        if not hasattr(self, "_pre"):
+            self._pre = {}
+        self._pre[c] = P
+        self._read_lists(R)          # cache the per-variant read lists (shared with forked row workers)
+        return frag
+
+    # ---- stage C2 pieces: pure host work on the arrays of self._pre[c] (safe in forked workers)
+    def _conn_text(self, c, lo, hi) -> str:
+        """variant_connections rows (phaser.py:691-695) for eorder[lo:hi]."""
+        P = self._pre[c]; cv = self.vs.chroms[c]
+        va, vb, cis, trans, sup, tot, pv = P["va"], P["vb"], P["cis"], P["trans"], P["sup"], P["tot"], P["pv"]
+        uid = cv.uid; phase = cv.phase; alle = cv.alleles
+        rows = []
+        for k in P["eorder"][lo:hi]:
+            a = int(va[k]); bb = int(vb[k])
+            conc = "."
+            if "-" not in phase[a] and "-" not in phase[bb]:
+                if cis[k] > trans[k]:
+                    conc = 1 if phase[a].index(alle[a][0]) == phase[bb].index(alle[bb][0]) else 0
+                elif cis[k] < trans[k]:
+                    conc = 1 if phase[a].index(alle[a][1]) == phase[bb].index(alle[bb][0]) else 0
+            if sup[k] == 0:
+                ptxt = "0"
+            elif tot[k] - sup[k] > 0:
+                ptxt = str(np.float64(pv[k]))
+            else:
+                ptxt = "1"
+            rows.append("\t".join([uid[a], uid[bb], str(int(sup[k])), str(int(tot[k])), ptxt, str(conc)]) + "\n")
+        return "".join(rows)
+
+    def _allelic_rows(self, c, lo, hi):
+        """allelic_counts rows (phaser.py:737-749) for the first-appearance keys [lo, hi)."""
+        P = self._pre[c]; cv = self.vs.chroms[c]; R = self.tally[c]
+        out = []
+        ci = P["chrom_index"]
+        for kb, kl, g in zip(P["key_bam"][lo:hi].tolist(), P["key_line"][lo:hi].tolist(), P["key_g"][lo:hi].tolist()):
             d = R["var_distinct"][g]
             r0 = int(d[0]); r1 = int(d[1])
             if r0 + r1 > 0:
-                allelic.append(((kb, kc, kl), "\t".join([c, str(int(cv.pos[g])), cv.uid[g], cv.alleles[g][0], cv.alleles[g][1], str(r0), str(r1),
-                                                         str(r0 + r1) + "\n"])))
-        frag["allelic"] = allelic
-        if not hasattr(self, "_pre"):
-            self._pre = {}
-        self._pre[c] = (blocks_all, keys)
-        self._read_lists(R)          # cache the per-variant read lists (shared with forked row workers)
-        return frag
+                out.append(((kb, ci, kl), "\t".join([c, str(int(cv.pos[g])), cv.uid[g], cv.alleles[g][0], cv.alleles[g][1], str(r0), str(r1),
+                                                    str(r0 + r1) + "\n"])))
+        return out
+
+    def _components(self, c, lo, hi):
+        """(members, local edges) of the components ranked [lo, hi) in first-key order (phaser.py:1861-1882)."""
+        P = self._pre[c]; cv = self.vs.chroms[c]
+        blocks = []
+        if P["ncomp"] == 0:
+            return blocks
+        pos = cv.pos; ea, eb, cfgv = P["ea"], P["eb"], P["cfgv"]
+        for ci in P["comp_order"][lo:hi]:
+            mem = P["mem_s"][P["starts"][ci]:P["ends"][ci]]
+            mem = mem[np.lexsort((mem, pos[mem]))]            # sort_var_ids (:1884): by position, ties by index
+            loc = {int(g): i for i, g in enumerate(mem)}
+            ek = P["e_keep"][P["eo"][P["e_starts"][ci]:P["e_ends"][ci]]]
+            blocks.append((mem, [(loc[int(ea[e])], loc[int(eb[e])], int(cfgv[e])) for e in ek]))
+        return blocks
 
     # ---------------------------------------------------------------- output (phaser.py:832-1243)
     def _read_lists(self, R):
@@ -415,11 +451,12 @@ class Engine:
         R["by_var"] = (lines[o], starts, ends)
         return R["by_var"]
 
-    def _block_rows(self, c, blocks_all):
-        """Stage C2a for a list of (members, edges) components: phase them (phaser.py:795-814) and format their rows
-        (:865-1172).  Pure host work on plain data -> safe to run in forked workers.  Returns (rows per final block,
+    def _block_rows(self, c, comp_lo, comp_hi):
+        """Stage C2a for the components ranked [comp_lo, comp_hi): phase them (phaser.py:795-814) and format their rows
+        (:865-1172).  Pure host work on plain data -> safe to run in forked workers.  Returns (compact chunk record,
         phased variant indices)."""
         cfg = self.cfg
+        blocks_all = self._components(c, comp_lo, comp_hi)
         nb = len(self.bam_names)
         cv = self.vs.chroms[c]
         R = self.tally[c]
@@ -584,9 +621,12 @@ class Engine:
                  "vcf": [b["vcf"] for b in blocks_out] if cfg.want_vcf else None}
         return chunk, in_block
 
-    def _single_rows(self, c, var_keys, in_block):
-        """Stage C2b: rows of variants with coverage that ended up in no block (phaser.py:1180-1239)."""
+    def _single_rows(self, c, lo, hi, in_block):
+        """Stage C2b: rows of variants with coverage that ended up in no block (phaser.py:1180-1239), keys [lo, hi)."""
         cfg = self.cfg
+        P = self._pre[c]
+        ci_ = P["chrom_index"]
+        var_keys = [(kb, ci_, kl, g) for kb, kl, g in zip(P["key_bam"][lo:hi].tolist(), P["key_line"][lo:hi].tolist(), P["key_g"][lo:hi].tolist())]
         nb = len(self.bam_names)
         cv = self.vs.chroms[c]
         R = self.tally[c]
@@ -638,15 +678,16 @@ class Engine:
 _FORK_ENGINE = None
 
 
-def _fork_block_rows(task):
-    c, lo, hi = task
-    return _FORK_ENGINE._block_rows(c, _FORK_ENGINE._pre[c][0][lo:hi])
-
-
-def _fork_single_rows(task):
-    c, lo, hi = task
+def _fork_task(task):
+    kind, c, lo, hi = task
     e = _FORK_ENGINE
-    return e._single_rows(c, e._pre[c][1][lo:hi], e._phased_sets[c])
+    if kind == "conn":
+        return e._conn_text(c, lo, hi)
+    if kind == "alle":
+        return e._allelic_rows(c, lo, hi)
+    if kind == "blk":
+        return e._block_rows(c, lo, hi)
+    return e._single_rows(c, lo, hi, e._phased_sets[c])
 
 
 HEAD_ASE = ["contig", "start", "stop", "variants", "variantCount", "variantsBlacklisted", "variantCountBlacklisted", "haplotypeA",
@@ -673,7 +714,7 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
     block_index = 0
     for c in chrom_list:
         f = frags[c]
-        conn += [r + "\n" for r in f["conn_rows"]]
+        conn += f["conn"]
         dropped += f["dropped"]; phased += f["phased"]; lines += f["lines"]
         allelic += [(tuple(k), r) for k, r in f["allelic"]]
         for ch in f["blocks"]:

@@ -25,7 +25,7 @@ def _worker(rank, world, port, result_path):
     from phaser_amd.engine import Config, Engine, merge_fragments
     fx = json.load(gzip.open(os.path.join(GOLD, "frags_pipe_two.json.gz"), "rt"))
     chroms = fx["chroms"]
-    weights = {c: float(sum(len(fx["frags"][c]["conn_rows"]) for _ in [0]) + 1 + i) for i, c in enumerate(chroms)}
+    weights = {c: float(len(fx["frags"][c]["allelic"]) + 1 + i) for i, c in enumerate(chroms)}
     owner = pdist.assign_chromosomes(weights, world)
     assert sorted(set(owner.values())) == list(range(world))
     mine = [c for c in chroms if owner[c] == rank]
