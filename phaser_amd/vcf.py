@@ -155,6 +155,44 @@ def _load_chunk(task):
     return per, filter_count, unphased, excluded
 
 
+_US = "\x1f"
+_STR_COLS = ("uid", "rsid_field", "rsid", "ref", "gt", "maf_text")
+_LIST_COLS = ("all_alleles", "alleles", "phase")
+
+
+_FORK_LINES = None          # the VCF lines, inherited by forked workers (never pickled)
+
+
+def _load_chunk_compact(task):
+    """Worker wrapper: same as _load_chunk on lines [lo, hi) of the inherited text, with the nested Python lists flattened
+    into a few big strings / arrays, which cross the process boundary far faster than pickled lists of lists."""
+    lo, hi = task[0]
+    per, fc, un, ex = _load_chunk((_FORK_LINES[lo:hi],) + tuple(task[1:]))
+    out = {}
+    for chrom, col in per.items():
+        rec = {"n": len(col["uid"]), "maf": col["maf"]}
+        for k in ("pos", "ref_len", "a0", "a1"):
+            rec[k] = np.asarray(col[k], dtype=np.int64)
+        for k in _STR_COLS:
+            rec[k] = _US.join(col[k])
+        for k in _LIST_COLS:
+            rec[k] = _US.join(",".join(x) for x in col[k])
+        out[chrom] = rec
+    return out, fc, un, ex
+
+
+def _expand(rec):
+    n = rec["n"]
+    col = {"maf": rec["maf"]}
+    for k in ("pos", "ref_len", "a0", "a1"):
+        col[k] = rec[k].tolist()
+    for k in _STR_COLS:
+        col[k] = rec[k].split(_US) if n else []
+    for k in _LIST_COLS:
+        col[k] = [x.split(",") if x else [] for x in rec[k].split(_US)] if n else []
+    return col
+
+
 def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
                   include_indels: int = 0, chr_prefix: str = "", id_separator: str = "_", gw_phase_method: int = 0,
                   gw_af_field: str = "AF", contig_ban=("_", ":"), threads: int = 1) -> VariantSet:
@@ -166,9 +204,13 @@ def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str 
         import multiprocessing as mp
         n = min(threads, 64)
         step = (len(lines) + n - 1) // n
-        tasks = [(lines[i:i + step],) + opts for i in range(0, len(lines), step)]
+        global _FORK_LINES
+        _FORK_LINES = lines
+        tasks = [((i, min(i + step, len(lines))),) + opts for i in range(0, len(lines), step)]
         with mp.get_context("fork").Pool(n) as pool:
-            parts = pool.map(_load_chunk, tasks, chunksize=1)
+            cparts = pool.map(_load_chunk_compact, tasks, chunksize=1)
+        _FORK_LINES = None
+        parts = [({chrom: _expand(rec) for chrom, rec in per.items()}, fc, un, ex) for per, fc, un, ex in cparts]
     else:
         parts = [_load_chunk((lines,) + opts)]
     merged: Dict[str, dict] = {}
