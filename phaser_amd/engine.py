@@ -343,14 +343,7 @@ class Engine:
             eorder = np.lexsort((rank[vb], rank[va]))
             frag["dropped"] = int((~keep_edge).sum())
             # ---- connected components of the surviving graph on the GPU (phaser.py:1861-1882)
-            dev = R["dev"]
-            t_ea = torch.from_numpy(np.ascontiguousarray(ea)).to(dev); t_eb = torch.from_numpy(np.ascontiguousarray(eb)).to(dev)
-            t_keep = torch.from_numpy(keep_edge.astype(np.uint8)).to(dev)
-            label = torch.empty(max(1, nv), dtype=torch.int32, device=dev)
-            if dev.type == "cuda":
-                torch.cuda.synchronize(dev)
-            self.ctx.check(self.lib.phz_components(self.ctx.h, nv, len(sel), _p(t_ea), _p(t_eb), _p(t_keep), _p(label), R["space"]))
-            label = label[:nv].cpu().numpy()
+            label = self._component_labels(c, ea, eb, keep_edge)
             deg = np.zeros(nv, dtype=np.int64)
             np.add.at(deg, ea[keep_edge], 1); np.add.at(deg, eb[keep_edge], 1)
             members = np.nonzero(deg > 0)[0]
@@ -383,6 +376,17 @@ class Engine:
         self._pre[c] = P
         self._read_lists(R)          # cache the per-variant read lists (shared with forked row workers)
         return frag
+
+    def _component_labels(self, c, ea, eb, keep_edge):
+        """Connected-component label per variant of the surviving graph, on the GPU (phz_components)."""
+        R = self.tally[c]; nv = R["nv"]; dev = R["dev"]
+        t_ea = torch.from_numpy(np.ascontiguousarray(ea)).to(dev); t_eb = torch.from_numpy(np.ascontiguousarray(eb)).to(dev)
+        t_keep = torch.from_numpy(keep_edge.astype(np.uint8)).to(dev)
+        label = torch.empty(max(1, nv), dtype=torch.int32, device=dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        self.ctx.check(self.lib.phz_components(self.ctx.h, nv, len(ea), _p(t_ea), _p(t_eb), _p(t_keep), _p(label), R["space"]))
+        return label[:nv].cpu().numpy()
 
     # ---- stage C2 pieces: pure host work on the arrays of self._pre[c] (safe in forked workers)
     def _conn_text(self, c, lo, hi) -> str:

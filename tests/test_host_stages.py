@@ -1,0 +1,78 @@
+"""Host stages of the phasing path (ordering rules, pair tests, pruning, block phasing, row formatting, merge) on CPU:
+the GPU stage results (K_tally arrays, component labels) come from tests/golden/tally/*.pkl.gz (written on an MI355X by
+tools/make_tally_fixture.py); the expected files are the reference's own outputs (tests/golden/pipe_*, c1)."""
+import gzip
+import json
+import os
+import pickle
+import sys
+
+import pytest
+
+from conftest import GOLD, REPO, gz_text
+from helpers import OUTPUTS, canonical, option_case_kwargs
+
+
+def _cases():
+    base = [("pipe_one", "pipe_one", {}, {}), ("pipe_two", "pipe_two", {}, {}), ("c1", "c1", {}, {}),
+            ("pipe_indel", "pipe_indel", {"include_indels": 1}, {"include_indels": 1})]
+    for tag in "abc":
+        d = os.path.join(GOLD, "pipe_noisy_" + tag)
+        base.append(("pipe_noisy_" + tag, "pipe_noisy_" + tag, {}, {"max_block_size": json.load(open(os.path.join(d, "meta.json")))["max_block_size"]}))
+    meta = json.load(open(os.path.join(GOLD, "pipe_opts", "cases.json")))
+    for name in meta["cases"]:
+        load, cfg, baseq, isize = option_case_kwargs(name, meta["cases"][name], meta["blacklist"])
+        base.append(("opts_" + name, os.path.join("pipe_opts", name), load, cfg))
+    return base
+
+
+def run_host_stages(case, load, cfg, vcf_text, bam_names, host_threads=1):
+    from phaser_amd import vcf
+    from phaser_amd.engine import Config, Engine
+
+    load = dict(load); cfg = dict(cfg)
+    inc = load.pop("include_indels", 0); cfg.pop("include_indels", None)
+    vs = vcf.load_variants(vcf_text, include_indels=inc, **load)
+    saved = pickle.load(gzip.open(os.path.join(GOLD, "tally", case + ".pkl.gz"), "rb"))
+
+    class _M:                             # the host stages never touch the mapper or the GPU context
+        class ctx:
+            lib = None
+        device = None
+    eng = Engine(vs, bam_names, Config(include_indels=inc, host_threads=host_threads, **cfg), mapper=_M())
+    eng.n_qid.update(saved["n_qid"]); eng.qnames.update(saved["qnames"])
+    eng._tally_chrom = lambda c: saved["tally"][c]
+    eng._component_labels = lambda c, ea, eb, keep: saved["labels"][c]
+    return eng.finish(), eng
+
+
+@pytest.mark.parametrize("case,gold,load,cfg", _cases(), ids=[c[0] for c in _cases()])
+def test_host_stages_match_reference(case, gold, load, cfg, c1_inputs):
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from phasing_oracle import bam_display_names          # naming helper only
+    d = os.path.join(GOLD, gold)
+    if case == "c1":
+        vcf_text = c1_inputs["vcf"]; bams = ["c1.bam"]
+    elif case.startswith("opts_"):
+        vcf_text = open(os.path.join(GOLD, "pipe_opts", "in.vcf")).read(); bams = ["o1.bam", "o2.bam"]
+    else:
+        vcf_text = open(os.path.join(d, "in.vcf")).read()
+        bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"], "pipe_indel": ["i.bam"]}.get(case, ["n.bam"])
+    out, eng = run_host_stages(case, load, cfg, vcf_text, bam_display_names(bams))
+    for name in OUTPUTS:
+        want = gz_text(os.path.join(d, "out.%s.txt.gz" % name))
+        assert canonical(name, out[name]) == canonical(name, want), name
+
+
+@pytest.mark.parametrize("src,mode", [("pipe_one", 0), ("pipe_one", 1), ("pipe_one", 2), ("pipe_noisy_c", 2), ("pipe_two", 1)])
+def test_phased_vcf_from_host_stages(src, mode):
+    """write_vcf text (phaser.py:1661-1855) from the per-block lookup the host stages build, byte for byte."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from phasing_oracle import bam_display_names
+    from phaser_amd import vcfout
+    d = os.path.join(GOLD, src)
+    vcf_text = open(os.path.join(d, "in.vcf")).read()
+    bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"]}.get(src, ["n.bam"])
+    out, eng = run_host_stages(src, {}, {}, vcf_text, bam_display_names(bams))
+    got, up, pc = vcfout.phased_vcf_text([l for l in vcf_text.split("\n") if l], eng.vcf_lookup, gw_phase_vcf=mode)
+    assert got == gz_text(os.path.join(d, "out.vcf_gw%d.txt.gz" % mode))
