@@ -207,6 +207,64 @@ int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const phz_varian
                           phz_calls *out, int64_t *n_calls, uint32_t *call_text_off, uint32_t *text_roff,
                           int64_t text_cap, int64_t *n_text, int space);
 
+/* ---- host stage C2: block phasing + the text rows of the five output files, one chromosome per call ----------------
+ * Replaces phase_v3 (phaser/phaser.py:2107-2324), the block output loop (:865-1172), singleton rows (:1180-1239),
+ * variant_connections rows (:691-695) and allelic_counts rows (:737-749).  Host arrays only; multi-threaded.
+ * A "sep pool" is n strings joined by one separator byte: string i = bytes [off[i], off[i+1]-1). */
+typedef struct {
+    const char *chrom;
+    int32_t nv;
+    const int32_t *pos;
+    const uint32_t *uid_off;    const char *uid;       /* unique ids */
+    const uint32_t *rsid_off;   const char *rsid;      /* rsid, '.' already replaced by the unique id (:1451-1455) */
+    const uint32_t *allele_off; const char *allele;    /* [2nv] the individual's alleles, index 2*v + k */
+    const uint32_t *maf_off;    const char *maf_txt;   /* str(maf) per variant */
+    const double *maf;
+    const uint8_t *is_ref;        /* [2nv] allele k of v equals REF */
+    const int8_t *phase_idx;      /* [2nv] position of allele k in the VCF phase, -1 when the genotype is unphased */
+    const uint8_t *blacklisted;   /* [nv] --haplo_count_blacklist hit, may be NULL */
+    const int32_t *var_count;     /* [3nv] from phz_tally */
+    const int32_t *var_distinct;  /* [3nv] */
+    int64_t n_lines;
+    const int32_t *line_var, *line_qid, *line_bam;
+    const uint8_t *line_cls;
+    /* tested variant pairs (linked edges), oriented by first appearance: rows of variant_connections in eorder */
+    int64_t n_edges;
+    const int32_t *va, *vb, *ea, *eb;
+    const int64_t *sup, *tot, *cis, *trans, *cfgv, *eorder;
+    const double *pv;
+    /* connected components of the surviving graph */
+    int64_t ncomp;
+    const int32_t *mem_s;
+    const int64_t *comp_starts, *comp_ends, *comp_order, *e_keep, *eo, *e_starts, *e_ends;
+    /* first-appearance keys of covered variants, sorted by (BAM of first kept line, line) */
+    int64_t n_keys;
+    const int64_t *key_bam, *key_g;
+    int32_t nb;
+    const char *const *bam_names;
+    const uint8_t *bam_excluded;  /* [nb], may be NULL */
+    int32_t unique_ids, gw_phase_method, output_read_ids, unphased_vars, max_block_size, want_vcf, threads;
+    const uint32_t *qname_off;  const char *qname;     /* QNAME per template id; only read when output_read_ids == 1 */
+} phz_rows_in;
+
+typedef struct {
+    char *conn, *hap, *ase, *cfg, *allelic, *single_ase, *single_hap;     /* row text, reference order within the chromosome */
+    int64_t conn_len, hap_len, ase_len, cfg_len, allelic_len, single_ase_len, single_hap_len;
+    int64_t *allelic_seg, *single_ase_seg, *single_hap_seg;   /* [nb+1] byte offsets of the rows keyed to each first BAM */
+    int64_t allelic_rows, n_blocks, phased, n_blk_vars;
+    int32_t *blk_size;        /* [n_blocks] variants per block */
+    /* filled when want_vcf: per block variant lists and genome-wide phase for write_vcf (:1661-1855) */
+    int32_t *blk_var;         /* [n_blk_vars] */
+    uint8_t *blk_hap;         /* [n_blk_vars] allele index on haplotype A */
+    int8_t *blk_cor;          /* [2*n_blk_vars] corrected phase of haplotype A / B alleles, -1 = none */
+    double *blk_stat;         /* [n_blocks] gw confidence */
+    uint8_t *blk_stat_int;    /* [n_blocks] 1 when the reference prints the int 1 */
+    int32_t *blk_maxmaf;      /* [n_blocks] variant carrying max(maf) */
+} phz_rows_out;
+
+int phz_rows_format(const phz_rows_in *in, phz_rows_out *out);
+void phz_rows_free(phz_rows_out *out);
+
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
 int phz_reset_timing(phz_ctx *ctx);

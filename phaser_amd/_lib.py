@@ -65,6 +65,36 @@ class phz_host_shard(C.Structure):
                 ("qname_off", C.c_void_p), ("qnames", C.c_void_p)]
 
 
+class phz_rows_in(C.Structure):
+    _fields_ = [("chrom", C.c_char_p), ("nv", C.c_int32), ("pos", C.c_void_p),
+                ("uid_off", C.c_void_p), ("uid", C.c_void_p), ("rsid_off", C.c_void_p), ("rsid", C.c_void_p),
+                ("allele_off", C.c_void_p), ("allele", C.c_void_p), ("maf_off", C.c_void_p), ("maf_txt", C.c_void_p),
+                ("maf", C.c_void_p), ("is_ref", C.c_void_p), ("phase_idx", C.c_void_p), ("blacklisted", C.c_void_p),
+                ("var_count", C.c_void_p), ("var_distinct", C.c_void_p),
+                ("n_lines", C.c_int64), ("line_var", C.c_void_p), ("line_qid", C.c_void_p), ("line_bam", C.c_void_p),
+                ("line_cls", C.c_void_p),
+                ("n_edges", C.c_int64), ("va", C.c_void_p), ("vb", C.c_void_p), ("ea", C.c_void_p), ("eb", C.c_void_p),
+                ("sup", C.c_void_p), ("tot", C.c_void_p), ("cis", C.c_void_p), ("trans", C.c_void_p), ("cfgv", C.c_void_p),
+                ("eorder", C.c_void_p), ("pv", C.c_void_p),
+                ("ncomp", C.c_int64), ("mem_s", C.c_void_p), ("comp_starts", C.c_void_p), ("comp_ends", C.c_void_p),
+                ("comp_order", C.c_void_p), ("e_keep", C.c_void_p), ("eo", C.c_void_p), ("e_starts", C.c_void_p),
+                ("e_ends", C.c_void_p),
+                ("n_keys", C.c_int64), ("key_bam", C.c_void_p), ("key_g", C.c_void_p),
+                ("nb", C.c_int32), ("bam_names", C.POINTER(C.c_char_p)), ("bam_excluded", C.c_void_p),
+                ("unique_ids", C.c_int32), ("gw_phase_method", C.c_int32), ("output_read_ids", C.c_int32),
+                ("unphased_vars", C.c_int32), ("max_block_size", C.c_int32), ("want_vcf", C.c_int32), ("threads", C.c_int32),
+                ("qname_off", C.c_void_p), ("qname", C.c_void_p)]
+
+
+class phz_rows_out(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("conn", "hap", "ase", "cfg", "allelic", "single_ase", "single_hap")] + \
+               [(k, C.c_int64) for k in ("conn_len", "hap_len", "ase_len", "cfg_len", "allelic_len", "single_ase_len",
+                                         "single_hap_len")] + \
+               [(k, C.POINTER(C.c_int64)) for k in ("allelic_seg", "single_ase_seg", "single_hap_seg")] + \
+               [(k, C.c_int64) for k in ("allelic_rows", "n_blocks", "phased", "n_blk_vars")] + \
+               [(k, C.c_void_p) for k in ("blk_size", "blk_var", "blk_hap", "blk_cor", "blk_stat", "blk_stat_int", "blk_maxmaf")]
+
+
 PHZ_AS_BINS = 65536
 
 # every symbol include/phz.h declares: name -> (restype, argtypes)
@@ -98,6 +128,8 @@ SYMBOLS = {
     "phz_map_reads_general": (C.c_int, [C.c_void_p, C.POINTER(phz_reads), C.POINTER(phz_variants_general), C.c_int,
                                         C.POINTER(phz_calls), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64,
                                         C.POINTER(C.c_int64), C.c_int]),
+    "phz_rows_format": (C.c_int, [C.POINTER(phz_rows_in), C.POINTER(phz_rows_out)]),
+    "phz_rows_free": (None, [C.POINTER(phz_rows_out)]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),

@@ -1,0 +1,774 @@
+// Host stage C2 of the phasing path in native, multi-threaded code: block phasing and the text rows of the five
+// output files for one chromosome.  Restates, on integer-indexed arrays,
+//   phase_v3 / resolve_phase / sub_block_phase / split_by_weak      phaser/phaser.py:2107-2324
+//   the block output loop (haplotypes, haplotypic_counts, allele_config)  phaser/phaser.py:865-1172
+//   singleton rows :1180-1239, variant_connections rows :691-695, allelic_counts rows :737-749
+// Inputs are what K_tally / phz_components and the ordering stage produced (plain arrays); outputs are text buffers
+// in the reference's row order plus the per-block arrays write_vcf needs.  Numbers are printed the way Python prints
+// them (str(int), repr(float), str(numpy.float64)) because that is what ends up in the files (SURVEY.md 8.1 rule 7).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <vector>
+
+#include "phz.h"
+
+namespace {
+
+// strings joined by one separator byte: item i = [off[i], off[i+1] - 1)
+struct Pool {
+    const uint32_t *off = nullptr;
+    const char *b = nullptr;
+    std::string_view at(int64_t i) const { return std::string_view(b + off[i], off[i + 1] - off[i] - 1); }
+};
+
+inline void put_int(std::string &s, long long v) {
+    char buf[24];
+    auto r = std::to_chars(buf, buf + 24, v);
+    s.append(buf, (size_t)(r.ptr - buf));
+}
+
+// repr(float) / str(numpy.float64): shortest round-trip digits, fixed notation for 1e-4 <= |x| < 1e16
+void put_pyfloat(std::string &s, double x) {
+    if (std::isnan(x)) { s += "nan"; return; }
+    if (std::isinf(x)) { s += x < 0 ? "-inf" : "inf"; return; }
+    if (x == 0) { s += std::signbit(x) ? "-0.0" : "0.0"; return; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + 64, x, std::chars_format::scientific);
+    std::string_view v(buf, (size_t)(r.ptr - buf));
+    if (v[0] == '-') { s += '-'; v.remove_prefix(1); }
+    const size_t epos = v.find('e');
+    std::string digits(1, v[0]);
+    if (epos > 2) digits.append(v.substr(2, epos - 2));
+    const int exp = atoi(std::string(v.substr(epos + 1)).c_str());
+    if (exp >= -4 && exp < 16) {
+        if (exp >= 0) {
+            if ((int)digits.size() <= exp + 1) { s += digits; s.append((size_t)(exp + 1) - digits.size(), '0'); s += ".0"; }
+            else { s.append(digits, 0, (size_t)exp + 1); s += '.'; s.append(digits, (size_t)exp + 1, std::string::npos); }
+        } else {
+            s += "0."; s.append((size_t)(-exp - 1), '0'); s += digits;
+        }
+    } else {
+        s += digits[0];
+        if (digits.size() > 1) { s += '.'; s.append(digits, 1, std::string::npos); }
+        s += 'e'; s += exp < 0 ? '-' : '+';
+        const int a = abs(exp);
+        if (a < 10) s += '0';
+        put_int(s, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ block phasing
+// Allele graph of one component: node 2*i + a = allele a of the i-th (position-sorted) variant.
+struct AlleleGraph {
+    int n = 0;
+    std::vector<std::vector<int>> adj;            // allele-level neighbours
+    std::vector<std::pair<int, int>> vedges;      // variant-level edges (ties included), i < j not required
+    std::vector<char> mark;                       // scratch, all zero between calls
+};
+
+std::string flip(const std::string &c) {
+    std::string o(c);
+    for (auto &ch : o) ch = ch == '-' ? '-' : (ch == '0' ? '1' : '0');
+    return o;
+}
+
+// resolve_phase (:2172-2207): flood fill from (variant lo, allele 0); accepted iff the component has exactly hi-lo
+// nodes (not necessarily one per variant: the string then skips variants without a node -- quirk kept)
+bool resolve(AlleleGraph &g, int lo, int hi, bool clean, std::string &out) {
+    const int n = hi - lo;
+    std::vector<int> stack, seen;
+    const int seed = 2 * lo;
+    g.mark[seed] = 1; seen.push_back(seed); stack.push_back(seed);
+    while (!stack.empty()) {
+        const int x = stack.back(); stack.pop_back();
+        for (int y : g.adj[x]) {
+            if (clean && (y < 2 * lo || y >= 2 * hi)) continue;
+            if (!g.mark[y]) { g.mark[y] = 1; seen.push_back(y); stack.push_back(y); }
+        }
+    }
+    const bool ok = (int)seen.size() == n;
+    if (ok) {
+        out.clear();
+        for (int i = lo; i < hi; i++) {
+            if (i < g.n && g.mark[2 * i]) out += '0';
+            else if (i < g.n && g.mark[2 * i + 1]) out += '1';
+        }
+    }
+    for (int x : seen) g.mark[x] = 0;
+    return ok;
+}
+
+// supporting allele edges of configuration cfg over variants idx0, idx0+1, ... (zip truncates to the shorter; :2236-2249)
+int score_cfg(AlleleGraph &g, int idx0, int idx_n, const std::string &cfg) {
+    const int L = std::min(idx_n, (int)cfg.size());
+    for (int k = 0; k < L; k++)
+        if (cfg[k] != '-') g.mark[2 * (idx0 + k) + (cfg[k] == '1')] = 1;
+    int s = 0;
+    for (int k = 0; k < L; k++)
+        if (cfg[k] != '-') {
+            const int node = 2 * (idx0 + k) + (cfg[k] == '1');
+            for (int y : g.adj[node]) s += g.mark[y];
+        }
+    for (int k = 0; k < L; k++)
+        if (cfg[k] != '-') g.mark[2 * (idx0 + k) + (cfg[k] == '1')] = 0;
+    return s;
+}
+
+// sub_block_phase without a given configuration (:2209-2258): optional clean flood fill, else brute force over the
+// configurations whose first allele is 0; a tie for the best score gives all '-'
+int best_free(AlleleGraph &g, int base, int n, bool attempt, std::string &c0, std::string &c1) {
+    if (attempt && resolve(g, base, base + n, true, c0)) { c1 = flip(c0); return 0; }
+    if (n > 30) return PHZ_E_UNSUPPORTED;       // 2^(n-1) configurations: the reference does not finish either
+    uint64_t m[64];
+    for (int k = 0; k < 2 * n; k++) {
+        uint64_t x = 0;
+        for (int y : g.adj[2 * base + k]) {
+            const int l = y - 2 * base;
+            if (l >= 0 && l < 2 * n) x |= 1ull << l;
+        }
+        m[k] = x;
+    }
+    long best_s = -1; uint64_t best_c = 0; long ties = 0;
+    const uint64_t ncode = 1ull << (n - 1);
+    for (uint64_t code = 0; code < ncode; code++) {
+        uint64_t chosen = 1;                                     // variant 0 -> allele 0
+        for (int k = 1; k < n; k++) chosen |= 1ull << (2 * k + (int)((code >> (n - 1 - k)) & 1));
+        long s = 0;
+        for (uint64_t c = chosen; c; c &= c - 1) s += __builtin_popcountll(m[__builtin_ctzll(c)] & chosen);
+        if (s > best_s) { best_s = s; best_c = code; ties = 1; }
+        else if (s == best_s) ties++;
+    }
+    if (ties == 1) {
+        c0.assign(1, '0');
+        for (int k = 1; k < n; k++) c0 += ((best_c >> (n - 1 - k)) & 1) ? '1' : '0';
+        c1 = flip(c0);
+    } else {
+        c0.assign((size_t)n, '-'); c1 = c0;
+    }
+    return 0;
+}
+
+// sub_block_phase with two phased neighbours (:2225-2258): the 4 joint configurations, complements skipped
+void best_given(AlleleGraph &g, int idx0, int idx_n, const std::string cur[2], const std::string nxt[2], std::string out[2]) {
+    struct E { std::string c, inv; int s; };
+    std::vector<E> sc;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) {
+            std::string c = cur[a] + nxt[b];
+            std::string inv = flip(c);
+            bool dup = false;
+            for (auto &e : sc) if (e.c == c || e.c == inv) dup = true;
+            if (dup) continue;
+            const int s = score_cfg(g, idx0, idx_n, c);
+            sc.push_back({c, inv, s});
+        }
+    int top = -1, nwin = 0, win = 0;
+    for (auto &e : sc) top = std::max(top, e.s);
+    for (size_t i = 0; i < sc.size(); i++) if (sc[i].s == top) { nwin++; win = (int)i; }
+    if (nwin == 1) { out[0] = sc[win].c; out[1] = sc[win].inv; }
+    else { out[0].assign((size_t)idx_n, '-'); out[1] = out[0]; }
+}
+
+// split_by_weak (:2271-2324) -> fragment start offsets (last entry = n)
+int weak_split(const AlleleGraph &g, int max_size, std::vector<int> &bounds) {
+    const int n = g.n;
+    std::vector<long> weak((size_t)n + 2, 0);           // weak[p], 2 <= p <= n-2: variant edges (u, w) with u < p <= w
+    {
+        std::vector<long> diff((size_t)n + 2, 0);
+        for (auto &e : g.vedges) {
+            const int i = std::min(e.first, e.second), j = std::max(e.first, e.second);
+            if (i == j) continue;
+            diff[i + 1] += 1; diff[j + 1] -= 1;           // p in (i, j]
+        }
+        long run = 0;
+        for (int p = 0; p <= n; p++) { run += diff[p]; weak[p] = run; }
+    }
+    long maxw = 0;
+    for (int p = 2; p < n - 1; p++) maxw = std::max(maxw, weak[p]);
+    std::vector<char> inpts((size_t)n + 2, 0);
+    int biggest = n;
+    long level = 1;
+    bounds.assign({0, n});
+    while (biggest > max_size || level == 1) {
+        for (int p = 2; p < n - 1; p++)
+            if (weak[p] == level && !inpts[p + 1] && !inpts[p - 1]) inpts[p] = 1;
+        bounds.assign(1, 0);
+        for (int p = 2; p < n - 1; p++) if (inpts[p]) bounds.push_back(p);
+        bounds.push_back(n);
+        biggest = 0;
+        for (size_t i = 1; i < bounds.size(); i++) biggest = std::max(biggest, bounds[i] - bounds[i - 1]);
+        level++;
+        if (level > maxw + 1 && biggest > max_size) return PHZ_E_UNSUPPORTED;   // the reference loops forever here
+    }
+    return 0;
+}
+
+// phase_v3 (:2107-2170) -> final sub-blocks as (first local variant, configuration of haplotype A)
+int phase_component(AlleleGraph &g, int max_block_size, std::vector<std::pair<int, std::string>> &res) {
+    const int n = g.n;
+    std::vector<std::string> fin;
+    std::string c0, c1;
+    if (resolve(g, 0, n, false, c0)) {
+        fin.push_back(c0);
+    } else {
+        const int xmax = max_block_size == 0 ? n : max_block_size;
+        std::vector<int> bounds;
+        int st = weak_split(g, xmax, bounds);
+        if (st) return st;
+        const int nf = (int)bounds.size() - 1;
+        std::vector<std::string> p0((size_t)nf), p1((size_t)nf);
+        for (int f = 0; f < nf; f++) {
+            st = best_free(g, bounds[f], bounds[f + 1] - bounds[f], nf > 1, p0[f], p1[f]);
+            if (st) return st;
+        }
+        std::string cur[2] = {p0[0], p1[0]};
+        int start = 0;
+        for (int f = 1; f < nf; f++) {
+            const std::string nxt[2] = {p0[f], p1[f]};
+            const long total = (long)cur[0].size() + (long)cur[1].size() + (long)nxt[0].size() + (long)nxt[1].size();
+            const int used = (int)((total + 1) / 2);
+            const int hi = std::min(n, start + used);
+            std::string out[2];
+            best_given(g, start, std::max(0, hi - start), cur, nxt, out);
+            if (out[0].find('-') != std::string::npos) {
+                fin.push_back(cur[0]); start = used; cur[0] = nxt[0]; cur[1] = nxt[1];      // start is ASSIGNED (:2152)
+            } else {
+                cur[0] = out[0]; cur[1] = out[1];
+            }
+        }
+        fin.push_back(cur[0]);
+    }
+    int vi = 0;
+    for (auto &s : fin) {
+        const int first = vi;
+        vi += (int)s.size();
+        if (!s.empty() && s[0] != '-') res.emplace_back(first, s);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ read label ranks
+// distinct values of q[0..n) numbered by first appearance; label[i] = number of q[i]; ids = distinct values in that order
+struct Ranker {
+    std::vector<int32_t> key, val;
+    void run(const std::vector<int32_t> &q, std::vector<int32_t> *label, std::vector<int32_t> *ids, int64_t *ndistinct) {
+        size_t cap = 16;
+        while (cap < q.size() * 2) cap <<= 1;
+        key.assign(cap, -1); val.resize(cap);
+        const size_t mask = cap - 1;
+        int32_t next = 0;
+        if (label) label->resize(q.size());
+        if (ids) ids->clear();
+        for (size_t i = 0; i < q.size(); i++) {
+            const int32_t x = q[i];
+            size_t h = ((uint32_t)x * 2654435761u) & mask;
+            while (key[h] != -1 && key[h] != x) h = (h + 1) & mask;
+            if (key[h] == -1) { key[h] = x; val[h] = next++; if (ids) ids->push_back(x); }
+            if (label) (*label)[i] = val[h];
+        }
+        *ndistinct = next;
+    }
+};
+
+struct Ctx {
+    const phz_rows_in *in;
+    Pool uid, rsid, alle, maftxt, qname;
+    std::vector<int64_t> lstart;       // [2nv+1] read-list ranges per (variant, class 0/1)
+    std::vector<int32_t> lorder;       // kept ref/alt line indices grouped by (variant, class), line order inside
+    std::vector<uint8_t> phased;       // [nv]
+    std::string_view name_of(int g) const { return in->unique_ids ? uid.at(g) : rsid.at(g); }
+};
+
+struct BlockChunk {
+    std::string hap, ase, cfg;
+    std::vector<int32_t> bvar, bsize, bmaxmaf;
+    std::vector<uint8_t> bhap, bstat_int;
+    std::vector<int8_t> bcor;
+    std::vector<double> bstat;
+    int64_t phased = 0;
+    int status = 0;
+};
+
+void join_sv(std::string &s, const std::vector<std::string_view> &items) {
+    for (size_t i = 0; i < items.size(); i++) { if (i) s += ','; s.append(items[i]); }
+}
+
+// one final (phased) block: rows of haplotypes.txt, haplotypic_counts.txt, allele_config.txt (:865-1172)
+void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &ha, double sup_edges, double tot_edges, Ranker &rk,
+                BlockChunk &o) {
+    const phz_rows_in &I = *C.in;
+    const int n = (int)vars.size();
+    std::string hb = flip(ha);
+    const std::string *hx[2] = {&ha, &hb};
+    int minpos = I.pos[vars[0]], maxpos = I.pos[vars[0]];
+    for (int g : vars) { minpos = std::min(minpos, I.pos[g]); maxpos = std::max(maxpos, I.pos[g]); }
+    // phase indices of each haplotype's alleles in the VCF phase (-1 = not phased there)
+    std::vector<int8_t> phs[2];
+    int64_t counts[2];
+    std::vector<int32_t> pool;
+    for (int h = 0; h < 2; h++) {
+        phs[h].resize((size_t)n);
+        pool.clear();
+        for (int i = 0; i < n; i++) {
+            const int g = vars[i], k = (*hx[h])[i] - '0';
+            phs[h][i] = I.phase_idx[2 * g + k];
+            for (int64_t t = C.lstart[2 * g + k]; t < C.lstart[2 * g + k + 1]; t++) pool.push_back(I.line_qid[C.lorder[t]]);
+        }
+        rk.run(pool, nullptr, nullptr, &counts[h]);
+    }
+    int nknown = 0, ksum = 0, first_known = -1;
+    bool all_equal = true, any_nan = false;
+    for (int i = 0; i < n; i++) {
+        if (phs[0][i] >= 0) {
+            if (first_known < 0) first_known = phs[0][i];
+            else if (phs[0][i] != first_known) all_equal = false;
+            nknown++; ksum += phs[0][i];
+        } else any_nan = true;
+    }
+    const int conc = all_equal ? 1 : 0;                       // usable values all the same (or none)
+    // genome-wide phase (:945-1025)
+    std::vector<int8_t> cor[2] = {phs[0], phs[1]};
+    double stat = 0.5; bool stat_int = false;
+    auto by_mean = [&]() {
+        double m = (double)ksum / (double)nknown;
+        if (m < 0.5) { cor[0].assign((size_t)n, 0); cor[1].assign((size_t)n, 1); }
+        else if (m > 0.5) { cor[0].assign((size_t)n, 1); cor[1].assign((size_t)n, 0); }
+        const double other = 1 - m;
+        stat = m >= other ? m : other;
+    };
+    if (nknown > 0) {
+        if (!any_nan && all_equal) { stat = 1; stat_int = true; }
+        else if (I.gw_phase_method == 0) by_mean();
+        else if (I.gw_phase_method == 1) {
+            double w[2] = {0, 0};
+            for (int i = 0; i < n; i++) {
+                if (phs[0][i] == 0) w[0] += I.maf[vars[i]];
+                else if (phs[0][i] == 1) w[1] += I.maf[vars[i]];
+            }
+            const double sw = w[0] + w[1];
+            if (sw > 0) {
+                stat = (w[0] >= w[1] ? w[0] : w[1]) / sw;
+                if (w[0] > w[1]) { cor[0].assign((size_t)n, 0); cor[1].assign((size_t)n, 1); }
+                else if (w[1] > w[0]) { cor[0].assign((size_t)n, 1); cor[1].assign((size_t)n, 0); }
+            } else by_mean();
+        }
+    }
+    std::string stat_txt;
+    if (stat_int) stat_txt = "1"; else put_pyfloat(stat_txt, stat);
+    int maxmaf_g = vars[0];
+    for (int g : vars) if (I.maf[g] > I.maf[maxmaf_g]) maxmaf_g = g;       // first maximal element, like max()
+    auto phase_chars = [&](const std::vector<int8_t> &v, std::string &s) { for (int8_t x : v) s += x < 0 ? '-' : (char)('0' + x); };
+
+    // ---- haplotypes.txt
+    std::string &H = o.hap;
+    H.append(I.chrom); H += '\t'; put_int(H, minpos); H += '\t'; put_int(H, maxpos); H += '\t'; put_int(H, maxpos - minpos); H += '\t';
+    put_int(H, n); H += '\t';
+    for (int i = 0; i < n; i++) { if (i) H += ','; H.append(C.name_of(vars[i])); }
+    H += '\t';
+    for (int h = 0; h < 2; h++) {
+        if (h) H += '|';
+        for (int i = 0; i < n; i++) { if (i) H += ','; H.append(C.alle.at(2 * vars[i] + ((*hx[h])[i] - '0'))); }
+    }
+    H += '\t'; put_int(H, counts[0]); H += '\t'; put_int(H, counts[1]); H += '\t'; put_int(H, counts[0] + counts[1]); H += '\t';
+    put_pyfloat(H, sup_edges); H += '\t'; put_pyfloat(H, tot_edges); H += '\t';
+    phase_chars(phs[0], H); H += '|'; phase_chars(phs[1], H); H += '\t'; put_int(H, conc); H += '\t';
+    phase_chars(cor[0], H); H += '|'; phase_chars(cor[1], H); H += '\t'; H += stat_txt; H += '\n';
+
+    // ---- haplotypic_counts.txt: one row per BAM (:1048-1125)
+    std::vector<int> used_vars, black;
+    std::vector<int32_t> allq, label, ids[2];
+    std::vector<size_t> vlen;
+    std::string labels[2];
+    for (int b = 0; b < I.nb; b++) {
+        if (I.bam_excluded && I.bam_excluded[b]) continue;
+        used_vars.clear(); black.clear();
+        int64_t ns[2];
+        for (int h = 0; h < 2; h++) {
+            allq.clear(); vlen.clear();
+            for (int i = 0; i < n; i++) {
+                const int g = vars[i];
+                if (!(I.blacklisted && I.blacklisted[g])) {
+                    const int k = (*hx[h])[i] - '0';
+                    if (h == 0) used_vars.push_back(g);
+                    const size_t before = allq.size();
+                    for (int64_t t = C.lstart[2 * g + k]; t < C.lstart[2 * g + k + 1]; t++) {
+                        const int32_t ln = C.lorder[t];
+                        if (I.line_bam[ln] == b) allq.push_back(I.line_qid[ln]);
+                    }
+                    vlen.push_back(allq.size() - before);
+                } else if (h == 0) black.push_back(g);
+            }
+            rk.run(allq, &label, &ids[h], &ns[h]);
+            labels[h].clear();
+            size_t p0 = 0;
+            for (size_t v = 0; v < vlen.size(); v++) {
+                if (v) labels[h] += ';';
+                for (size_t t = 0; t < vlen[v]; t++) { if (t) labels[h] += ','; put_int(labels[h], label[p0 + t]); }
+                p0 += vlen[v];
+            }
+        }
+        const int64_t cov = ns[0] + ns[1];
+        if (cov <= 0) continue;
+        std::string &A = o.ase;
+        A.append(I.chrom); A += '\t'; put_int(A, minpos); A += '\t'; put_int(A, maxpos); A += '\t';
+        for (size_t i = 0; i < used_vars.size(); i++) { if (i) A += ','; A.append(C.uid.at(used_vars[i])); }
+        A += '\t'; put_int(A, (long long)used_vars.size()); A += '\t';
+        for (size_t i = 0; i < black.size(); i++) { if (i) A += ','; A.append(C.uid.at(black[i])); }
+        A += '\t'; put_int(A, (long long)black.size()); A += '\t';
+        for (int h = 0; h < 2; h++) {
+            bool firstv = true;
+            for (int i = 0; i < n; i++) {
+                const int g = vars[i];
+                if (I.blacklisted && I.blacklisted[g]) continue;
+                if (!firstv) A += ',';
+                firstv = false;
+                A.append(C.alle.at(2 * g + ((*hx[h])[i] - '0')));
+            }
+            A += '\t';
+        }
+        put_int(A, ns[0]); A += '\t'; put_int(A, ns[1]); A += '\t'; put_int(A, cov); A += '\t';
+        A += cor[0][0] == 0 ? "0|1" : (cor[0][0] == 1 ? "1|0" : "0/1");
+        A += '\t'; A += stat_txt; A += '\t';
+        if (I.output_read_ids == 1) {
+            for (int h = 0; h < 2; h++) {
+                for (size_t i = 0; i < ids[h].size(); i++) { if (i) A += ','; A.append(C.qname.at(ids[h][i])); }
+                A += '\t';
+            }
+        }
+        A.append(C.maftxt.at(maxmaf_g)); A += '\t'; A.append(I.bam_names[b]); A += '\t'; A += labels[0]; A += '\t'; A += labels[1]; A += '\n';
+    }
+
+    // ---- allele_config.txt (:1160-1172)
+    std::string &F = o.cfg;
+    for (int i = 0; i < n; i++) {
+        const int ga = vars[i];
+        const bool ra = I.is_ref[2 * ga + (ha[i] - '0')];
+        const std::string_view ua = C.uid.at(ga), sa = C.rsid.at(ga);
+        for (int j = 0; j < n; j++) {
+            if (i == j) continue;
+            const int gb = vars[j];
+            const bool rb = I.is_ref[2 * gb + (hb[j] - '0')];
+            F.append(ua); F += '\t'; F.append(sa); F += '\t'; F.append(C.uid.at(gb)); F += '\t'; F.append(C.rsid.at(gb));
+            F += (ra == rb) ? "\ttrans\n" : "\tcis\n";
+        }
+    }
+    // ---- per-block arrays for write_vcf
+    o.bsize.push_back(n); o.bstat.push_back(stat); o.bstat_int.push_back(stat_int ? 1 : 0); o.bmaxmaf.push_back(maxmaf_g);
+    for (int i = 0; i < n; i++) {
+        o.bvar.push_back(vars[i]); o.bhap.push_back((uint8_t)(ha[i] - '0'));
+        o.bcor.push_back(cor[0][i]); o.bcor.push_back(cor[1][i]);
+    }
+    o.phased += n;
+}
+
+// components ranked [lo, hi) in first-key order: phase them and write their rows
+void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
+    const phz_rows_in &I = *C.in;
+    Ranker rk;
+    AlleleGraph g;
+    std::vector<int> mem, vars, sub_of, alle_of;
+    std::vector<std::pair<int, std::string>> subs;
+    struct LE { int i, j, k; };
+    std::vector<LE> edges;
+    for (int64_t r = lo; r < hi && !o.status; r++) {
+        const int64_t ci = I.comp_order[r];
+        mem.assign(I.mem_s + I.comp_starts[ci], I.mem_s + I.comp_ends[ci]);
+        std::sort(mem.begin(), mem.end(), [&](int a, int b) { return I.pos[a] != I.pos[b] ? I.pos[a] < I.pos[b] : a < b; });   // sort_var_ids :1884
+        const int n = (int)mem.size();
+        std::vector<int> byid(mem);                                 // for the global -> local lookup
+        std::vector<int> idx((size_t)n);
+        for (int i = 0; i < n; i++) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return mem[a] < mem[b]; });
+        for (int i = 0; i < n; i++) byid[i] = mem[idx[i]];
+        auto loc = [&](int gid) { return idx[std::lower_bound(byid.begin(), byid.end(), gid) - byid.begin()]; };
+        g.n = n; g.adj.assign((size_t)2 * n, {}); g.vedges.clear(); g.mark.assign((size_t)2 * n + 2, 0);
+        edges.clear();
+        for (int64_t t = I.e_starts[ci]; t < I.e_ends[ci]; t++) {
+            const int64_t e = I.e_keep[I.eo[t]];
+            const int i = loc(I.ea[e]), j = loc(I.eb[e]), k = (int)I.cfgv[e];
+            edges.push_back({i, j, k});
+            g.vedges.emplace_back(i, j);
+            if (k == 0) {
+                g.adj[2 * i].push_back(2 * j); g.adj[2 * j].push_back(2 * i);
+                g.adj[2 * i + 1].push_back(2 * j + 1); g.adj[2 * j + 1].push_back(2 * i + 1);
+            } else if (k == 1) {
+                g.adj[2 * i].push_back(2 * j + 1); g.adj[2 * j + 1].push_back(2 * i);
+                g.adj[2 * i + 1].push_back(2 * j); g.adj[2 * j].push_back(2 * i + 1);
+            }
+        }
+        subs.clear();
+        o.status = phase_component(g, I.max_block_size, subs);
+        if (o.status) return;
+        sub_of.assign((size_t)n, -1); alle_of.assign((size_t)n, 0);
+        for (size_t s = 0; s < subs.size(); s++)
+            for (size_t t = 0; t < subs[s].second.size(); t++) {
+                const int li = subs[s].first + (int)t;
+                if (li < n) { sub_of[li] = (int)s; alle_of[li] = subs[s].second[t] - '0'; }
+            }
+        // allele edges supporting / total inside each final block (:876-895; ordered pairs halved = edges)
+        std::vector<long> sup(subs.size(), 0), tot(subs.size(), 0);
+        for (auto &e : edges) {
+            if (e.k < 0 || sub_of[e.i] < 0 || sub_of[e.i] != sub_of[e.j]) continue;
+            tot[sub_of[e.i]]++;
+            const int linked = e.k == 0 ? alle_of[e.i] : 1 - alle_of[e.i];
+            if (alle_of[e.j] == linked) sup[sub_of[e.i]]++;
+        }
+        for (size_t s = 0; s < subs.size(); s++) {
+            vars.clear();
+            std::string ha;
+            for (size_t t = 0; t < subs[s].second.size(); t++) {
+                const int li = subs[s].first + (int)t;
+                if (li < n) { vars.push_back(mem[li]); ha += subs[s].second[t]; }
+            }
+            if (vars.empty()) continue;
+            for (int v : vars) C.phased[v] = 1;
+            emit_block(C, vars, ha, (double)sup[s], (double)tot[s], rk, o);
+        }
+    }
+}
+
+struct TextChunk { std::string a, b; int64_t rows = 0; };
+
+// variant_connections rows (:691-695) for eorder[lo, hi)
+void run_conn(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
+    const phz_rows_in &I = *C.in;
+    for (int64_t t = lo; t < hi; t++) {
+        const int64_t k = I.eorder[t];
+        const int a = I.va[k], b = I.vb[k];
+        std::string &S = o.a;
+        S.append(C.uid.at(a)); S += '\t'; S.append(C.uid.at(b)); S += '\t'; put_int(S, I.sup[k]); S += '\t'; put_int(S, I.tot[k]); S += '\t';
+        if (I.sup[k] == 0) S += '0';
+        else if (I.tot[k] - I.sup[k] > 0) put_pyfloat(S, I.pv[k]);
+        else S += '1';
+        S += '\t';
+        if (I.phase_idx[2 * a] >= 0 && I.phase_idx[2 * b] >= 0 && I.cis[k] != I.trans[k]) {
+            const int pa = I.cis[k] > I.trans[k] ? I.phase_idx[2 * a] : I.phase_idx[2 * a + 1];
+            S += pa == I.phase_idx[2 * b] ? '1' : '0';
+        } else S += '.';
+        S += '\n';
+    }
+}
+
+// allelic_counts rows (:737-749) for the first-appearance keys [lo, hi)
+void run_allelic(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
+    const phz_rows_in &I = *C.in;
+    for (int64_t t = lo; t < hi; t++) {
+        const int g = (int)I.key_g[t];
+        const long long r0 = I.var_distinct[3 * g], r1 = I.var_distinct[3 * g + 1];
+        if (r0 + r1 <= 0) continue;
+        std::string &S = o.a;
+        S.append(I.chrom); S += '\t'; put_int(S, I.pos[g]); S += '\t'; S.append(C.uid.at(g)); S += '\t'; S.append(C.alle.at(2 * g)); S += '\t';
+        S.append(C.alle.at(2 * g + 1)); S += '\t'; put_int(S, r0); S += '\t'; put_int(S, r1); S += '\t'; put_int(S, r0 + r1); S += '\n';
+        o.rows++;
+    }
+}
+
+// singleton rows (:1180-1239) for the first-appearance keys [lo, hi): a = haplotypic_counts rows, b = haplotypes rows
+void run_singles(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
+    const phz_rows_in &I = *C.in;
+    std::vector<int32_t> q[2];
+    for (int64_t t = lo; t < hi; t++) {
+        const int g = (int)I.key_g[t];
+        if ((long long)I.var_count[3 * g] + I.var_count[3 * g + 1] == 0 || C.phased[g]) continue;
+        const bool is_phased = I.phase_idx[2 * g] >= 0;
+        if (!(I.blacklisted && I.blacklisted[g])) {
+            for (int b = 0; b < I.nb; b++) {
+                if (I.bam_excluded && I.bam_excluded[b]) continue;
+                for (int k = 0; k < 2; k++) {
+                    q[k].clear();
+                    for (int64_t u = C.lstart[2 * g + k]; u < C.lstart[2 * g + k + 1]; u++) {
+                        const int32_t ln = C.lorder[u];
+                        if (I.line_bam[ln] == b) q[k].push_back(I.line_qid[ln]);
+                    }
+                    std::sort(q[k].begin(), q[k].end());
+                    q[k].erase(std::unique(q[k].begin(), q[k].end()), q[k].end());
+                }
+                const long long n0 = (long long)q[0].size(), n1 = (long long)q[1].size();
+                if (n0 + n1 <= 0) continue;
+                std::string &A = o.a;
+                A.append(I.chrom); A += '\t'; put_int(A, I.pos[g]); A += '\t'; put_int(A, I.pos[g]); A += '\t'; A.append(C.uid.at(g));
+                A += "\t1\t\t0\t"; A.append(C.alle.at(2 * g)); A += '\t'; A.append(C.alle.at(2 * g + 1)); A += '\t';
+                put_int(A, n0); A += '\t'; put_int(A, n1); A += '\t'; put_int(A, n0 + n1); A += '\t';
+                if (is_phased) { put_int(A, I.phase_idx[2 * g]); A += '|'; put_int(A, I.phase_idx[2 * g + 1]); } else A += "0/1";
+                A += "\t1\t";
+                if (I.output_read_ids == 1) {
+                    for (int k = 0; k < 2; k++) {
+                        for (size_t i = 0; i < q[k].size(); i++) { if (i) A += ','; A.append(C.qname.at(q[k][i])); }
+                        A += '\t';
+                    }
+                }
+                A.append(C.maftxt.at(g)); A += '\t'; A.append(I.bam_names[b]); A += "\t\t\n";
+            }
+        }
+        const long long d0 = I.var_distinct[3 * g], d1 = I.var_distinct[3 * g + 1];
+        std::string &H = o.b;
+        H.append(I.chrom); H += '\t'; put_int(H, (long long)I.pos[g] - 1); H += '\t'; put_int(H, I.pos[g]); H += "\t1\t1\t";
+        H.append(C.name_of(g)); H += '\t'; H.append(C.alle.at(2 * g)); H += '|'; H.append(C.alle.at(2 * g + 1)); H += '\t';
+        put_int(H, d0); H += '\t'; put_int(H, d1); H += '\t'; put_int(H, d0 + d1); H += "\t0\t0\t";
+        std::string ps;
+        if (is_phased) { put_int(ps, I.phase_idx[2 * g]); ps += '|'; put_int(ps, I.phase_idx[2 * g + 1]); } else ps = "-|-";
+        H += ps; H += "\tnan\t"; H += ps; H += "\tnan\n";
+        o.rows++;
+    }
+}
+
+template <class F>
+void parallel_chunks(int threads, int64_t nchunks, F fn) {
+    if (nchunks <= 0) return;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, nchunks));
+    if (nt == 1) { for (int64_t i = 0; i < nchunks; i++) fn(i); return; }
+    std::atomic<int64_t> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&]() { for (;;) { const int64_t i = next.fetch_add(1); if (i >= nchunks) break; fn(i); } });
+    for (auto &t : th) t.join();
+}
+
+char *take(const std::string &s) {
+    char *p = (char *)malloc(s.size() + 1);
+    if (p) memcpy(p, s.data(), s.size() + 1);
+    return p;
+}
+
+template <class T>
+T *take_vec(const std::vector<T> &v) {
+    T *p = (T *)malloc(std::max<size_t>(1, v.size() * sizeof(T)));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+// chunk boundaries over keys [0, n) that never straddle a change of key_bam
+std::vector<int64_t> key_chunks(const phz_rows_in &I, int64_t step) {
+    std::vector<int64_t> b(1, 0);
+    int64_t start = 0;
+    for (int64_t t = 1; t <= I.n_keys; t++) {
+        if (t == I.n_keys || I.key_bam[t] != I.key_bam[t - 1] || t - start >= step) { b.push_back(t); start = t; }
+    }
+    if (I.n_keys == 0) b.assign(1, 0);
+    return b;
+}
+
+}  // namespace
+
+extern "C" int phz_rows_format(const phz_rows_in *in, phz_rows_out *out) {
+    if (!in || !out) return PHZ_E_ARG;
+    memset(out, 0, sizeof(*out));
+    const phz_rows_in &I = *in;
+    Ctx C;
+    C.in = in;
+    C.uid = {I.uid_off, I.uid}; C.rsid = {I.rsid_off, I.rsid}; C.alle = {I.allele_off, I.allele}; C.maftxt = {I.maf_off, I.maf_txt};
+    C.qname = {I.qname_off, I.qname};
+    const int nv = I.nv;
+    C.phased.assign((size_t)nv + 1, 0);
+    // read lists per (variant, class): counting sort of the kept ref/alt lines, line order preserved
+    C.lstart.assign((size_t)2 * nv + 2, 0);
+    for (int64_t l = 0; l < I.n_lines; l++)
+        if (I.line_cls[l] < 2) C.lstart[(size_t)2 * I.line_var[l] + I.line_cls[l] + 1]++;
+    for (int64_t k = 0; k < 2 * (int64_t)nv; k++) C.lstart[k + 1] += C.lstart[k];
+    C.lorder.resize((size_t)C.lstart[(size_t)2 * nv]);
+    {
+        std::vector<int64_t> cur(C.lstart.begin(), C.lstart.end() - 1);
+        for (int64_t l = 0; l < I.n_lines; l++)
+            if (I.line_cls[l] < 2) C.lorder[(size_t)cur[(size_t)2 * I.line_var[l] + I.line_cls[l]]++] = (int32_t)l;
+    }
+    const int threads = std::max(1, I.threads);
+
+    // ---- blocks: chunks of components balanced by size (members + read labels)
+    std::vector<int64_t> cb(1, 0);
+    {
+        int64_t total = 0;
+        std::vector<int64_t> w((size_t)I.ncomp);
+        for (int64_t r = 0; r < I.ncomp; r++) {
+            const int64_t ci = I.comp_order[r];
+            int64_t x = 4;
+            for (int64_t t = I.comp_starts[ci]; t < I.comp_ends[ci]; t++) {
+                const int g = (int)I.mem_s[t];
+                x += 2 + (C.lstart[2 * g + 2] - C.lstart[2 * g]) + (I.comp_ends[ci] - I.comp_starts[ci]);
+            }
+            w[r] = x; total += x;
+        }
+        const int64_t target = std::max<int64_t>(4096, total / (threads * 8) + 1);
+        int64_t acc = 0;
+        for (int64_t r = 0; r < I.ncomp; r++) {
+            acc += w[r];
+            if (acc >= target) { cb.push_back(r + 1); acc = 0; }
+        }
+        if (cb.back() != I.ncomp) cb.push_back(I.ncomp);
+    }
+    std::vector<BlockChunk> bc(cb.size() - 1);
+    parallel_chunks(threads, (int64_t)bc.size(), [&](int64_t i) { run_block_chunk(C, cb[i], cb[i + 1], bc[i]); });
+    for (auto &c : bc) if (c.status) return c.status;
+
+    // ---- connections, allelic counts, singletons
+    const int64_t estep = 16384;
+    std::vector<TextChunk> cc((size_t)((I.n_edges + estep - 1) / estep));
+    parallel_chunks(threads, (int64_t)cc.size(), [&](int64_t i) { run_conn(C, i * estep, std::min(I.n_edges, (i + 1) * estep), cc[i]); });
+    const std::vector<int64_t> kb = key_chunks(I, 8192);
+    std::vector<TextChunk> ac(kb.size() - 1), sc(kb.size() - 1);
+    parallel_chunks(threads, (int64_t)ac.size(), [&](int64_t i) {
+        run_allelic(C, kb[i], kb[i + 1], ac[i]);
+        if (I.unphased_vars == 1) run_singles(C, kb[i], kb[i + 1], sc[i]);
+    });
+
+    // ---- assemble
+    std::string conn, hap, ase, cfg, allelic, s_ase, s_hap;
+    {
+        size_t a = 0, b = 0, c = 0;
+        for (auto &x : bc) { a += x.hap.size(); b += x.ase.size(); c += x.cfg.size(); }
+        hap.reserve(a); ase.reserve(b); cfg.reserve(c);
+    }
+    std::vector<int32_t> bvar, bsize, bmaxmaf; std::vector<uint8_t> bhap, bstat_int; std::vector<int8_t> bcor; std::vector<double> bstat;
+    int64_t phased = 0;
+    for (auto &x : bc) {
+        hap += x.hap; ase += x.ase; cfg += x.cfg; phased += x.phased;
+        std::string().swap(x.hap); std::string().swap(x.ase); std::string().swap(x.cfg);
+        if (I.want_vcf) {
+            bvar.insert(bvar.end(), x.bvar.begin(), x.bvar.end()); bhap.insert(bhap.end(), x.bhap.begin(), x.bhap.end());
+            bcor.insert(bcor.end(), x.bcor.begin(), x.bcor.end()); bmaxmaf.insert(bmaxmaf.end(), x.bmaxmaf.begin(), x.bmaxmaf.end());
+            bstat.insert(bstat.end(), x.bstat.begin(), x.bstat.end()); bstat_int.insert(bstat_int.end(), x.bstat_int.begin(), x.bstat_int.end());
+        }
+        bsize.insert(bsize.end(), x.bsize.begin(), x.bsize.end());
+    }
+    for (auto &x : cc) conn += x.a;
+    std::vector<int64_t> aseg((size_t)I.nb + 1, 0), sseg_a((size_t)I.nb + 1, 0), sseg_h((size_t)I.nb + 1, 0);
+    int64_t arows = 0;
+    for (size_t i = 0; i + 1 < kb.size(); i++) {
+        const int64_t b = kb[i] < I.n_keys ? I.key_bam[kb[i]] : 0;
+        allelic += ac[i].a; s_ase += sc[i].a; s_hap += sc[i].b; arows += ac[i].rows;
+        for (int64_t k = b + 1; k <= I.nb; k++) { aseg[k] = (int64_t)allelic.size(); sseg_a[k] = (int64_t)s_ase.size(); sseg_h[k] = (int64_t)s_hap.size(); }
+    }
+    out->conn = take(conn); out->conn_len = (int64_t)conn.size();
+    out->hap = take(hap); out->hap_len = (int64_t)hap.size();
+    out->ase = take(ase); out->ase_len = (int64_t)ase.size();
+    out->cfg = take(cfg); out->cfg_len = (int64_t)cfg.size();
+    out->allelic = take(allelic); out->allelic_len = (int64_t)allelic.size(); out->allelic_rows = arows;
+    out->single_ase = take(s_ase); out->single_ase_len = (int64_t)s_ase.size();
+    out->single_hap = take(s_hap); out->single_hap_len = (int64_t)s_hap.size();
+    out->allelic_seg = take_vec(aseg); out->single_ase_seg = take_vec(sseg_a); out->single_hap_seg = take_vec(sseg_h);
+    out->n_blocks = (int64_t)bsize.size(); out->phased = phased;
+    out->blk_size = take_vec(bsize);
+    out->n_blk_vars = (int64_t)bvar.size();
+    out->blk_var = take_vec(bvar); out->blk_hap = take_vec(bhap); out->blk_cor = take_vec(bcor); out->blk_stat = take_vec(bstat);
+    out->blk_stat_int = take_vec(bstat_int); out->blk_maxmaf = take_vec(bmaxmaf);
+    if (!out->conn || !out->hap || !out->ase || !out->cfg || !out->allelic || !out->single_ase || !out->single_hap) {
+        phz_rows_free(out);
+        return PHZ_E_NOMEM;
+    }
+    return PHZ_OK;
+}
+
+extern "C" void phz_rows_free(phz_rows_out *o) {
+    if (!o) return;
+    free(o->conn); free(o->hap); free(o->ase); free(o->cfg); free(o->allelic); free(o->single_ase); free(o->single_hap);
+    free(o->allelic_seg); free(o->single_ase_seg); free(o->single_hap_seg); free(o->blk_size); free(o->blk_var); free(o->blk_hap);
+    free(o->blk_cor); free(o->blk_stat); free(o->blk_stat_int); free(o->blk_maxmaf);
+    memset(o, 0, sizeof(*o));
+}

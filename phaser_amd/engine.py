@@ -21,7 +21,7 @@ from scipy.stats import binom
 from . import _lib
 from . import dist as pdist
 from .mapper import Calls, Mapper
-from .phase import Block
+from . import rows
 from .soa import ReadShard
 from .vcf import ChromVariants, VariantSet
 
@@ -43,7 +43,7 @@ class Config:
         self.unique_ids = 0; self.haplo_count_bam_exclude: List[int] = []; self.haplo_blacklist = frozenset()
         self.include_indels = 0
         self.want_vcf = True           # keep per-block info for write_vcf (vcfout.phased_vcf_text)
-        self.host_threads = 1          # forked workers for block phasing / row formatting (the reference's --threads)
+        self.host_threads = 1          # threads of the native block phasing / row writer (the reference's --threads)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown option " + k)
@@ -202,18 +202,15 @@ class Engine:
                              "different chromosome names (IE 'chr1' vs '1').")
         return float(mism) / (float(match + mism) * 2)
 
-    def finish(self) -> Optional[Dict[str, str]]:
+    def finish(self, binary: bool = False) -> Optional[Dict[str, str]]:
         """Stages 3-6.  With torch.distributed initialised, every rank handles its own chromosomes and rank 0
-        returns the assembled files (other ranks return None)."""
+        returns the assembled files (other ranks return None).  binary=True returns bytes (no decode pass)."""
         import time as _t
         t0 = _t.perf_counter()
         match, mism = pdist.allreduce_counts(*self.tally_all())
         noise = self.noise_from_counts(match, mism)
         t1 = _t.perf_counter()
-        if self.cfg.host_threads > 1:
-            local = self._fragments_parallel(noise)
-        else:
-            local = {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
+        local = {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
         t2 = _t.perf_counter()
         frags = pdist.gather_fragments(local)
         self.stats.update({"tally_s": t1 - t0, "fragments_s": t2 - t1})
@@ -221,72 +218,30 @@ class Engine:
         if frags is None:
             return None
         t3 = _t.perf_counter()
-        out, summary = merge_fragments(frags, [c for c in self.all_chroms if c in frags], self.cfg, noise)
+        chroms = [c for c in self.all_chroms if c in frags]
+        out, summary = merge_fragments(frags, chroms, self.cfg, noise, len(self.bam_names))
+        self.vcf_lookup = {}
+        if self.cfg.want_vcf:
+            block_index = 0
+            for c in chroms:
+                if frags[c]["vcf"] is not None:
+                    block_index += rows.vcf_block_info(self.vs.chroms[c], frags[c]["vcf"], block_index, self.vcf_lookup)
         self.stats["merge_s"] = _t.perf_counter() - t3
-        self.noise = noise
         self.log += summary["log"]
-        self.phased = summary["phased"]; self.total_lines = summary["lines"]; self.vcf_lookup = summary["vcf_lookup"]
-        return out
-
-    def _fragments_parallel(self, noise: float) -> Dict[str, dict]:
-        """Stage C with the host work fanned out like the reference's parallelize() (phaser.py:2077-2094): C1 (numpy,
-        scipy, GPU components) runs here per chromosome; C2 (block phasing + row formatting, pure Python on plain data)
-        runs in forked workers over chunks of blocks / singletons.  Workers never touch the GPU."""
-        import multiprocessing as mp
-        global _FORK_ENGINE
-        import time as _t
-        t0 = _t.perf_counter()
-        frags = {c: self.chrom_prepare(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
-        self.stats["prepare_s"] = _t.perf_counter() - t0
-        nblocks = sum(self._pre[c]["ncomp"] for c in self.chrom_list)
-        chunk = max(50, min(1500, nblocks // (4 * self.cfg.host_threads) + 1))
-        tasks = []
-        for c in self.chrom_list:
-            P = self._pre[c]
-            tasks += [("conn", c, lo, min(lo + 40000, len(P["eorder"]))) for lo in range(0, len(P["eorder"]), 40000)]
-            tasks += [("alle", c, lo, min(lo + 40000, len(P["key_g"]))) for lo in range(0, len(P["key_g"]), 40000)]
-            tasks += [("blk", c, lo, min(lo + chunk, P["ncomp"])) for lo in range(0, P["ncomp"], chunk)]
-        _FORK_ENGINE = self
-        ctx = mp.get_context("fork")
-        if tasks:
-            with ctx.Pool(min(self.cfg.host_threads, len(tasks))) as pool:
-                res = pool.map(_fork_task, tasks, chunksize=1)
-        else:
-            res = []
-        phased: Dict[str, set] = {c: set() for c in self.chrom_list}
-        for (kind, c, lo, hi), r in zip(tasks, res):
-            if kind == "conn":
-                frags[c].setdefault("conn", []).append(r)
-            elif kind == "alle":
-                frags[c].setdefault("allelic", []).extend(r)
-            else:
-                frags[c].setdefault("blocks", []).append(r[0])
-                phased[c].update(r[1])
-        self._phased_sets = phased            # must exist before the second fork: singleton workers read it
-        stasks = [("sng", c, lo, min(lo + 20000, len(self._pre[c]["key_g"]))) for c in self.chrom_list
-                  for lo in range(0, len(self._pre[c]["key_g"]), 20000)]
-        if stasks:
-            with ctx.Pool(min(self.cfg.host_threads, len(stasks))) as pool:
-                sres = pool.map(_fork_task, stasks, chunksize=1)
-            for (kind, c, lo, hi), rows in zip(stasks, sres):
-                frags[c].setdefault("singles", []).extend(rows)
-        for c in self.chrom_list:
-            frags[c].setdefault("blocks", []); frags[c].setdefault("singles", []); frags[c].setdefault("conn", []); frags[c].setdefault("allelic", [])
-            frags[c]["phased"] = len(phased[c])
-        self.stats["rows_pool_s"] = _t.perf_counter() - t0 - self.stats["prepare_s"]
-        _FORK_ENGINE = None
-        return frags
+        self.phased = summary["phased"]; self.total_lines = summary["lines"]
+        return out if binary else {k: v.decode() for k, v in out.items()}
 
     def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
-        """Stage C for one chromosome: pair tests, pruning, components (C1), block phasing + output rows (C2), serially."""
+        """Stage C for one chromosome: C1 = ordering ranks, pair tests, pruning, components (numpy / scipy / GPU);
+        C2 = block phasing + row text in native code (rows.format_chrom -> phz_rows_format)."""
+        import time as _t
+        t0 = _t.perf_counter()
         frag = self.chrom_prepare(c, noise, chrom_index)
-        P = self._pre[c]
-        frag["conn"] = [self._conn_text(c, 0, len(P["eorder"]))]
-        frag["allelic"] = self._allelic_rows(c, 0, len(P["key_g"]))
-        chunk, phased = self._block_rows(c, 0, P["ncomp"])
-        frag["blocks"] = [chunk]
-        frag["singles"] = self._single_rows(c, 0, len(P["key_g"]), set(phased))
-        frag["phased"] = len(phased)
+        t1 = _t.perf_counter()
+        frag.update(rows.format_chrom(self, c, self.cfg.host_threads))
+        self.stats["prepare_s"] = self.stats.get("prepare_s", 0.0) + t1 - t0
+        self.stats["rows_s"] = self.stats.get("rows_s", 0.0) + _t.perf_counter() - t1
+        del self._pre[c]
         return frag
 
     def chrom_prepare(self, c: str, noise: float, chrom_index: int) -> dict:
@@ -374,7 +329,6 @@ class Engine:
         if not hasattr(self, "_pre"):
             self._pre = {}
         self._pre[c] = P
-        self._read_lists(R)          # cache the per-variant read lists (shared with forked row workers)
         return frag
 
     def _component_labels(self, c, ea, eb, keep_edge):
@@ -388,311 +342,6 @@ class Engine:
         self.ctx.check(self.lib.phz_components(self.ctx.h, nv, len(ea), _p(t_ea), _p(t_eb), _p(t_keep), _p(label), R["space"]))
         return label[:nv].cpu().numpy()
 
-    # ---- stage C2 pieces: pure host work on the arrays of self._pre[c] (safe in forked workers)
-    def _conn_text(self, c, lo, hi) -> str:
-        """variant_connections rows (phaser.py:691-695) for eorder[lo:hi]."""
-        P = self._pre[c]; cv = self.vs.chroms[c]
-        va, vb, cis, trans, sup, tot, pv = P["va"], P["vb"], P["cis"], P["trans"], P["sup"], P["tot"], P["pv"]
-        uid = cv.uid; phase = cv.phase; alle = cv.alleles
-        rows = []
-        for k in P["eorder"][lo:hi]:
-            a = int(va[k]); bb = int(vb[k])
-            conc = "."
-            if "-" not in phase[a] and "-" not in phase[bb]:
-                if cis[k] > trans[k]:
-                    conc = 1 if phase[a].index(alle[a][0]) == phase[bb].index(alle[bb][0]) else 0
-                elif cis[k] < trans[k]:
-                    conc = 1 if phase[a].index(alle[a][1]) == phase[bb].index(alle[bb][0]) else 0
-            if sup[k] == 0:
-                ptxt = "0"
-            elif tot[k] - sup[k] > 0:
-                ptxt = str(np.float64(pv[k]))
-            else:
-                ptxt = "1"
-            rows.append("\t".join([uid[a], uid[bb], str(int(sup[k])), str(int(tot[k])), ptxt, str(conc)]) + "\n")
-        return "".join(rows)
-
-    def _allelic_rows(self, c, lo, hi):
-        """allelic_counts rows (phaser.py:737-749) for the first-appearance keys [lo, hi)."""
-        P = self._pre[c]; cv = self.vs.chroms[c]; R = self.tally[c]
-        out = []
-        ci = P["chrom_index"]
-        for kb, kl, g in zip(P["key_bam"][lo:hi].tolist(), P["key_line"][lo:hi].tolist(), P["key_g"][lo:hi].tolist()):
-            d = R["var_distinct"][g]
-            r0 = int(d[0]); r1 = int(d[1])
-            if r0 + r1 > 0:
-                out.append(((kb, ci, kl), "\t".join([c, str(int(cv.pos[g])), cv.uid[g], cv.alleles[g][0], cv.alleles[g][1], str(r0), str(r1),
-                                                    str(r0 + r1) + "\n"])))
-        return out
-
-    def _components(self, c, lo, hi):
-        """(members, local edges) of the components ranked [lo, hi) in first-key order (phaser.py:1861-1882)."""
-        P = self._pre[c]; cv = self.vs.chroms[c]
-        blocks = []
-        if P["ncomp"] == 0:
-            return blocks
-        pos = cv.pos; ea, eb, cfgv = P["ea"], P["eb"], P["cfgv"]
-        for ci in P["comp_order"][lo:hi]:
-            mem = P["mem_s"][P["starts"][ci]:P["ends"][ci]]
-            mem = mem[np.lexsort((mem, pos[mem]))]            # sort_var_ids (:1884): by position, ties by index
-            loc = {int(g): i for i, g in enumerate(mem)}
-            ek = P["e_keep"][P["eo"][P["e_starts"][ci]:P["e_ends"][ci]]]
-            blocks.append((mem, [(loc[int(ea[e])], loc[int(eb[e])], int(cfgv[e])) for e in ek]))
-        return blocks
-
-    # ---------------------------------------------------------------- output (phaser.py:832-1243)
-    def _read_lists(self, R):
-        """Per (variant, class in {0,1}): QNAME ids of kept lines in line order, all BAMs and per BAM."""
-        if "by_var" in R:
-            return R["by_var"]
-        cls = R["line_cls"]
-        lines = np.nonzero(cls < 2)[0]
-        v = R["line_var"][lines]; k = cls[lines].astype(np.int64)
-        key = v.astype(np.int64) * 2 + k
-        o = np.argsort(key, kind="stable")
-        ks = key[o]
-        starts = np.searchsorted(ks, np.arange(R["nv"] * 2), side="left"); ends = np.searchsorted(ks, np.arange(R["nv"] * 2), side="right")
-        R["by_var"] = (lines[o], starts, ends)
-        return R["by_var"]
-
-    def _block_rows(self, c, comp_lo, comp_hi):
-        """Stage C2a for the components ranked [comp_lo, comp_hi): phase them (phaser.py:795-814) and format their rows
-        (:865-1172).  Pure host work on plain data -> safe to run in forked workers.  Returns (compact chunk record,
-        phased variant indices)."""
-        cfg = self.cfg
-        blocks_all = self._components(c, comp_lo, comp_hi)
-        nb = len(self.bam_names)
-        cv = self.vs.chroms[c]
-        R = self.tally[c]
-        blocks_out = []
-        final = []
-        for mem, edges in blocks_all:
-            blk = Block(len(mem), edges)
-            for sub in blk.phase(cfg.max_block_size):
-                final.append([(int(mem[i]), a) for i, a in sub])
-        # allele-edge lookup for supporting / total edge counts: (a, b) -> cfg for surviving edges
-        d: Dict[tuple, int] = {}
-        for mem, edges in blocks_all:
-            for i, j, k in edges:
-                a, b = int(mem[i]), int(mem[j])
-                d[(a, b)] = k; d[(b, a)] = k
-        in_block = []
-        lines_sorted, starts, ends = self._read_lists(R)
-        lq = R["line_qid"]; lbam = R["line_bam"]
-        for blk in final:
-            ase = []; cfgf = []
-            blk = sorted(blk, key=lambda t: (int(cv.pos[t[0]]), t[0]))     # sort_var_ids again (:869); already sorted
-            variants = [g for g, _ in blk]
-            in_block += variants
-            ha = "".join(a for _, a in blk)
-            hb = "".join(str(int(not int(x))) for x in ha)
-            # edges supporting / total (:876-895): ordered allele pairs, halved
-            sup = tot = 0
-            alle_of = {g: int(a) for g, a in blk}
-            for g1 in variants:
-                for g2 in variants:
-                    if g1 != g2 and (g1, g2) in d:
-                        k = d[(g1, g2)]
-                        if k >= 0:
-                            tot += 1           # exactly one of g2:0 / g2:1 is linked to g1's allele
-                            linked_allele = alle_of[g1] if k == 0 else 1 - alle_of[g1]
-                            if alle_of[g2] == linked_allele:
-                                sup += 1
-            sup = sup / 2; tot = tot / 2
-            rsids = [cv.rsid[g] for g in variants] if cfg.unique_ids == 0 else [cv.uid[g] for g in variants]
-            poss = [int(cv.pos[g]) for g in variants]
-            alle = [[], []]; phs = [[], []]; counts = [0, 0]
-            for h in (0, 1):
-                hx = (ha, hb)[h]
-                pool = []
-                for i, g in enumerate(variants):
-                    k = int(hx[i])
-                    a = cv.alleles[g][k]
-                    alle[h].append(a)
-                    try:
-                        phs[h].append(cv.phase[g].index(a))
-                    except ValueError:
-                        phs[h].append(float("nan"))
-                    s_, e_ = starts[g * 2 + k], ends[g * 2 + k]
-                    pool.append(lq[lines_sorted[s_:e_]])
-                counts[h] = len(np.unique(np.concatenate(pool))) if pool else 0
-            usable = [x for x in phs[0] if str(x) != "nan"]
-            conc = 1 if len(set(usable)) <= 1 else 0
-            pstr = ["".join(str(x).replace("nan", "-") for x in phs[0]), "".join(str(x).replace("nan", "-") for x in phs[1])]
-            known = [int(x) for x in phs[0] if x >= 0]
-            cor = [phs[0], phs[1]]
-            stat = 0.5
-            mafs = [cv.maf[g] for g in variants]
-            if known:
-                ps = set(phs[0])
-                if len(ps) == 1:
-                    stat = 1
-                elif cfg.gw_phase_method == 0:
-                    stat = np.mean(known)
-                    if stat < 0.5:
-                        cor = [[0] * len(variants), [1] * len(variants)]
-                    elif stat > 0.5:
-                        cor = [[1] * len(variants), [0] * len(variants)]
-                    stat = max([stat, 1 - stat])
-                elif cfg.gw_phase_method == 1:
-                    w = [0, 0]
-                    for p_, m_ in zip(phs[0], mafs):
-                        if p_ == 0:
-                            w[0] += m_
-                        elif p_ == 1:
-                            w[1] += m_
-                    if sum(w) > 0:
-                        stat = max(w) / sum(w)
-                        if w[0] > w[1]:
-                            cor = [[0] * len(variants), [1] * len(variants)]
-                        elif w[1] > w[0]:
-                            cor = [[1] * len(variants), [0] * len(variants)]
-                    else:
-                        stat = np.mean(known)
-                        if stat < 0.5:
-                            cor = [[0] * len(variants), [1] * len(variants)]
-                        elif stat > 0.5:
-                            cor = [[1] * len(variants), [0] * len(variants)]
-                        stat = max([stat, 1 - stat])
-            cstr = ["".join(str(x).replace("nan", "-") for x in cor[0]), "".join(str(x).replace("nan", "-") for x in cor[1])]
-            hap_row = _jl([c, min(poss), max(poss), max(poss) - min(poss), len(variants), _jl(rsids), _jl(alle[0]) + "|" + _jl(alle[1]),
-                           counts[0], counts[1], sum(counts), sup, tot, pstr[0] + "|" + pstr[1], conc, cstr[0] + "|" + cstr[1], stat], "\t") + "\n"
-            # haplotypic counts, one row per BAM (:1048-1125)
-            for b in range(nb):
-                if b in cfg.haplo_count_bam_exclude:
-                    continue
-                used_alleles = [[], []]; used_vars = []; vreads = [[], []]; upos = []; black = []
-                for h in (0, 1):
-                    hx = (ha, hb)[h]
-                    for i, g in enumerate(variants):
-                        upos.append(int(cv.pos[g]))
-                        if c + "_" + str(int(cv.pos[g])) not in cfg.haplo_blacklist:
-                            k = int(hx[i])
-                            if g not in used_vars:
-                                used_vars.append(g)
-                            used_alleles[h].append(cv.alleles[g][k])
-                            s_, e_ = starts[g * 2 + k], ends[g * 2 + k]
-                            ln = lines_sorted[s_:e_]
-                            vreads[h].append(lq[ln[lbam[ln] == b]])
-                        elif g not in black:
-                            black.append(g)
-                labels = []; ids = []; ns = []
-                for h in (0, 1):
-                    allq = np.concatenate(vreads[h]) if vreads[h] else np.zeros(0, np.int32)
-                    # labels = index into the distinct-read list; we number reads by first appearance (canonical form)
-                    uq, first, inv = np.unique(allq, return_index=True, return_inverse=True)
-                    order = np.argsort(first, kind="stable")
-                    rk = np.empty(len(uq), dtype=np.int64)
-                    rk[order] = np.arange(len(uq))
-                    txt = list(map(str, rk[inv].tolist()))
-                    parts = []; p0 = 0
-                    for vr in vreads[h]:
-                        parts.append(",".join(txt[p0:p0 + len(vr)])); p0 += len(vr)
-                    labels.append(";".join(parts))
-                    ns.append(len(uq)); ids.append(uq[order])
-                cov = ns[0] + ns[1]
-                if cov > 0:
-                    gwp = "0/1"
-                    if cor[0][0] == 0:
-                        gwp = "0|1"
-                    elif cor[0][0] == 1:
-                        gwp = "1|0"
-                    f = [c, min(upos), max(upos), _jl(cv.uid[g] for g in used_vars), len(used_vars), _jl(cv.uid[g] for g in black), len(black),
-                         _jl(used_alleles[0]), _jl(used_alleles[1]), ns[0], ns[1], cov, gwp, stat]
-                    if cfg.output_read_ids == 1:
-                        qn = self.qnames[c]
-                        f += [_jl(qn[int(x)] for x in ids[0]), _jl(qn[int(x)] for x in ids[1])]
-                    f += [str(max(mafs)), self.bam_names[b], labels[0], labels[1]]
-                    ase.append(_jl(f, "\t") + "\n")
-            # allele configuration (:1160-1172)
-            for ga, aa in zip(variants, alle[0]):
-                for gb, ab in zip(variants, alle[1]):
-                    if ga != gb:
-                        ra = cv.ref[ga] == aa; rb = cv.ref[gb] == ab
-                        cfgf.append("\t".join([cv.uid[ga], cv.rsid[ga], cv.uid[gb], cv.rsid[gb], "trans" if ra == rb else "cis"]) + "\n")
-            def _gw(x):
-                return int(x) if isinstance(x, int) and not isinstance(x, bool) else None
-            vinfo = {"uids": [cv.uid[g] for g in variants], "hap": [ha[i] + "|" + hb[i] for i in range(len(variants))],
-                     "rsids": [cv.rsid[g] for g in variants], "stat": stat if isinstance(stat, (int, float)) and not isinstance(stat, np.floating) else float(stat),
-                     "stat_txt": str(stat), "max_maf_txt": str(max(mafs)),
-                     "alleles": [cv.alleles[g] for g in variants], "all_alleles": [cv.all_alleles[g] for g in variants],
-                     "gw": [[_gw(cor[0][i]) if int(ha[i]) == 0 else _gw(cor[1][i]), _gw(cor[1][i]) if int(ha[i]) == 0 else _gw(cor[0][i])]
-                            for i in range(len(variants))]}
-            blocks_out.append({"hap": hap_row, "ase": ase, "cfg": cfgf, "vcf": vinfo})
-        # one compact record per call (cheap to ship back from a forked worker): joined text + optional VCF info per block
-        chunk = {"hap": "".join(b["hap"] for b in blocks_out), "ase": "".join(r for b in blocks_out for r in b["ase"]),
-                 "cfg": "".join(r for b in blocks_out for r in b["cfg"]), "n": len(blocks_out),
-                 "vcf": [b["vcf"] for b in blocks_out] if cfg.want_vcf else None}
-        return chunk, in_block
-
-    def _single_rows(self, c, lo, hi, in_block):
-        """Stage C2b: rows of variants with coverage that ended up in no block (phaser.py:1180-1239), keys [lo, hi)."""
-        cfg = self.cfg
-        P = self._pre[c]
-        ci_ = P["chrom_index"]
-        var_keys = [(kb, ci_, kl, g) for kb, kl, g in zip(P["key_bam"][lo:hi].tolist(), P["key_line"][lo:hi].tolist(), P["key_g"][lo:hi].tolist())]
-        nb = len(self.bam_names)
-        cv = self.vs.chroms[c]
-        R = self.tally[c]
-        lines_sorted, starts, ends = self._read_lists(R)
-        lq = R["line_qid"]; lbam = R["line_bam"]
-        singles = []
-        single_bam_fast = nb == 1 and cfg.output_read_ids != 1 and not cfg.haplo_count_bam_exclude
-        if cfg.unphased_vars == 1:
-            for kb, kc, kl, g in var_keys:
-                vc = R["var_count"][g]
-                if int(vc[0]) + int(vc[1]) == 0 or g in in_block:       # removed at :769-774, or phased
-                    continue
-                ph = cv.phase[g]
-                rows_a = []
-                if c + "_" + str(int(cv.pos[g])) not in cfg.haplo_blacklist:
-                    for b in range(nb):
-                        if b in cfg.haplo_count_bam_exclude:
-                            continue
-                        if single_bam_fast:
-                            # one BAM: distinct QNAMEs per (variant, allele) were counted on the GPU (var_distinct)
-                            n0, n1 = int(R["var_distinct"][g][0]), int(R["var_distinct"][g][1])
-                            per_allele = None
-                        else:
-                            per_allele = []
-                            for k in (0, 1):
-                                ln = lines_sorted[starts[g * 2 + k]:ends[g * 2 + k]]
-                                per_allele.append(np.unique(lq[ln[lbam[ln] == b]]))
-                            n0, n1 = len(per_allele[0]), len(per_allele[1])
-                        cov = n0 + n1
-                        if cov > 0:
-                            ps = (str(ph.index(cv.alleles[g][0])) + "|" + str(ph.index(cv.alleles[g][1]))) if "-" not in ph else "0/1"
-                            f = [c, str(int(cv.pos[g])), str(int(cv.pos[g])), cv.uid[g], "1", "", "0", cv.alleles[g][0], cv.alleles[g][1],
-                                 str(n0), str(n1), str(cov), ps, "1"]
-                            if cfg.output_read_ids == 1:
-                                qn = self.qnames[c]
-                                f += [_jl(qn[int(x)] for x in per_allele[0]), _jl(qn[int(x)] for x in per_allele[1])]
-                            f += [str(cv.maf[g]), self.bam_names[b], "", ""]
-                            rows_a.append("\t".join(f) + "\n")
-                dd = R["var_distinct"][g]
-                ps = (str(ph.index(cv.alleles[g][0])) + "|" + str(ph.index(cv.alleles[g][1]))) if "-" not in ph else "-|-"
-                name = cv.rsid[g] if cfg.unique_ids == 0 else cv.uid[g]
-                hrow = "\t".join([c, str(int(cv.pos[g]) - 1), str(int(cv.pos[g])), "1", "1", name,
-                                  cv.alleles[g][0] + "|" + cv.alleles[g][1], str(int(dd[0])), str(int(dd[1])), str(int(dd[0]) + int(dd[1])),
-                                  "0", "0", ps, str(float("nan")), ps, str(float("nan"))]) + "\n"
-                singles.append(((kb, kc, kl), "".join(rows_a), hrow))
-        return singles
-
-
-_FORK_ENGINE = None
-
-
-def _fork_task(task):
-    kind, c, lo, hi = task
-    e = _FORK_ENGINE
-    if kind == "conn":
-        return e._conn_text(c, lo, hi)
-    if kind == "alle":
-        return e._allelic_rows(c, lo, hi)
-    if kind == "blk":
-        return e._block_rows(c, lo, hi)
-    return e._single_rows(c, lo, hi, e._phased_sets[c])
-
 
 HEAD_ASE = ["contig", "start", "stop", "variants", "variantCount", "variantsBlacklisted", "variantCountBlacklisted", "haplotypeA",
             "haplotypeB", "aCount", "bCount", "totalCount", "blockGWPhase", "gwStat", "max_haplo_maf", "bam", "aReads", "bReads"]
@@ -700,47 +349,37 @@ HEAD_HAP = ['contig', 'start', 'stop', 'length', 'variants', 'variant_ids', 'var
             'reads_total', 'edges_supporting', 'edges_total', 'annotated_phase', 'phase_concordant', 'gw_phase', 'gw_confidence']
 
 
-def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config", noise: float):
+def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config", noise: float, n_bams: int = 1):
     """Stage D (rank 0): assemble the five files from per-chromosome fragments in the reference's global order:
-    chromosomes in VCF order for connections / blocks, first-appearance keys (BAM, chromosome, line) for
-    allelic_counts and singletons.  Pure Python on plain data, so it is what the multi-GPU gather feeds."""
+    chromosomes in VCF order for connections / blocks; allelic_counts and singleton rows follow the first-appearance
+    keys (BAM of the first kept line, chromosome, line), i.e. per first BAM the chromosomes in VCF order.  Works on
+    the bytes the row writer produced, so it is also what the multi-GPU gather feeds."""
     cols = list(HEAD_ASE)
     if cfg.output_read_ids == 1:
         cols += ["read_ids_a", "read_ids_b"]
-    conn = ["variant_a\tvariant_b\tsupporting_connections\ttotal_connections\tconflicting_configuration_p\tphase_concordant\n"]
-    ase = ["\t".join(cols) + "\n"]
-    hap = ["\t".join(HEAD_HAP) + "\n"]
-    cfgf = ["\t".join(['variant_a', 'rsid_a', 'variant_b', 'rsid_b', 'configuration']) + "\n"]
-    allelic = []
-    singles = []
-    dropped = phased = lines = 0
-    lookup = {}
-    block_index = 0
+    enc = lambda fields: ("\t".join(fields) + "\n").encode()
+    conn = [b"variant_a\tvariant_b\tsupporting_connections\ttotal_connections\tconflicting_configuration_p\tphase_concordant\n"]
+    ase = [enc(cols)]
+    hap = [enc(HEAD_HAP)]
+    cfgf = [enc(['variant_a', 'rsid_a', 'variant_b', 'rsid_b', 'configuration'])]
+    allelic = [b"contig\tposition\tvariantID\trefAllele\taltAllele\trefCount\taltCount\ttotalCount\n"]
+    dropped = phased = lines = covered = 0
     for c in chrom_list:
         f = frags[c]
-        conn += f["conn"]
-        dropped += f["dropped"]; phased += f["phased"]; lines += f["lines"]
-        allelic += [(tuple(k), r) for k, r in f["allelic"]]
-        for ch in f["blocks"]:
-            hap.append(ch["hap"]); ase.append(ch["ase"]); cfgf.append(ch["cfg"])
-            if ch.get("vcf") is not None:
-                for v in ch["vcf"]:
-                    block_index += 1
-                    for i, uid in enumerate(v["uids"]):
-                        lookup[uid] = (v, i, block_index)
-            else:
-                block_index += ch["n"]
-        singles += [(tuple(k), ra, rh) for k, ra, rh in f["singles"]]
-    allelic.sort(key=lambda t: t[0])
-    singles.sort(key=lambda t: t[0])
-    for _, ra, rh in singles:
-        ase.append(ra)
-    for _, ra, rh in singles:
-        hap.append(rh)
-    out = {"variant_connections": "".join(conn),
-           "allelic_counts": "contig\tposition\tvariantID\trefAllele\taltAllele\trefCount\taltCount\ttotalCount\n" + "".join(r for _, r in allelic),
-           "haplotypic_counts": "".join(ase), "haplotypes": "".join(hap), "allele_config": "".join(cfgf)}
+        conn.append(f["conn"]); hap.append(f["hap"]); ase.append(f["ase"]); cfgf.append(f["cfg"])
+        dropped += f["dropped"]; phased += f["phased"]; lines += f["lines"]; covered += f["allelic_rows"]
+    for b in range(n_bams):
+        for c in chrom_list:
+            f = frags[c]
+            s = f["allelic_seg"]; allelic.append(f["allelic"][s[b]:s[b + 1]])
+    for key, dst in (("single_ase", ase), ("single_hap", hap)):
+        for b in range(n_bams):
+            for c in chrom_list:
+                f = frags[c]
+                s = f[key + "_seg"]; dst.append(f[key][s[b]:s[b + 1]])
+    out = {"variant_connections": b"".join(conn), "allelic_counts": b"".join(allelic), "haplotypic_counts": b"".join(ase),
+           "haplotypes": b"".join(hap), "allele_config": b"".join(cfgf)}
     log = ["     sequencing noise level estimated at %f" % noise,
            "     %d variant connections dropped because of conflicting configurations (threshold = %f)" % (dropped, cfg.cc_threshold),
-           "     %d variants covered by at least 1 read" % len(allelic)]
-    return out, {"log": log, "phased": phased, "lines": lines, "dropped": dropped, "covered": len(allelic), "vcf_lookup": lookup}
+           "     %d variants covered by at least 1 read" % covered]
+    return out, {"log": log, "phased": phased, "lines": lines, "dropped": dropped, "covered": covered}

@@ -238,7 +238,7 @@ def main(argv=None):
     say("#3. Identifying connected variants...")
     say("     calculating sequencing noise level...")
     n_before = len(eng.log)
-    files = eng.finish()
+    files = eng.finish(binary=True)
     if files is not None:
         for line in eng.log[n_before:]:
             say(line)
@@ -246,7 +246,7 @@ def main(argv=None):
         say("#5. Phasing blocks...")
         say("#6. Outputting haplotypes...")
         for name, body in files.items():
-            with open(args.o + "." + name + ".txt", "w") as f:
+            with open(args.o + "." + name + ".txt", "wb") as f:
                 f.write(body)
         up = pc = 0
         if args.write_vcf == 1:

@@ -33,6 +33,20 @@ class ChromVariants:
     ref_len: np.ndarray        # uint8
     a0: np.ndarray             # uint8 base code of alleles[0] (255 when not a single ACGT base)
     a1: np.ndarray
+    is_ref: np.ndarray = None      # uint8 [2n]: alleles[k] == REF, index 2*v + k
+    phase_idx: np.ndarray = None   # int8 [2n]: position of alleles[k] in the VCF phase, -1 when unphased
+    _pools: dict = None
+
+    def pools(self):
+        """Separator-joined string pools of the per-variant texts the native row writer prints (phz_rows_format)."""
+        if self._pools is None:
+            flat = []
+            for al in self.alleles:
+                flat.append(al[0] if len(al) > 0 else ""); flat.append(al[1] if len(al) > 1 else "")
+            self._pools = {"uid": sep_pool(self.uid), "rsid": sep_pool(self.rsid), "allele": sep_pool(flat),
+                           "maf": sep_pool([str(x) for x in self.maf]),
+                           "maf_val": np.asarray([float(x) for x in self.maf], dtype=np.float64)}
+        return self._pools
 
     def __len__(self):
         return len(self.uid)
@@ -70,6 +84,19 @@ class VariantSet:
     unphased_count: int
 
 
+def sep_pool(strs):
+    """n strings -> (uint32 offsets [n+1], bytes): string i = bytes[off[i] : off[i+1]-1] (one separator byte after each)."""
+    if not strs:
+        return np.zeros(1, dtype=np.uint32), b"\n"
+    b = ("\n".join(strs) + "\n").encode()
+    ends = np.flatnonzero(np.frombuffer(b, dtype=np.uint8) == 10)
+    if len(ends) != len(strs) or len(b) >= 2 ** 32:
+        raise ValueError("string table holds a newline or exceeds 4 GiB")
+    off = np.empty(len(strs) + 1, dtype=np.uint32)
+    off[0] = 0; off[1:] = ends + 1
+    return off, b
+
+
 def read_text(path: str) -> str:
     if path.endswith(".gz") or path.endswith(".bgz"):
         with gzip.open(path, "rt") as f:
@@ -99,7 +126,7 @@ def _load_chunk(task):
         col = per.get(chrom)
         if col is None:
             col = per[chrom] = {k: [] for k in ("pos", "uid", "rsid_field", "rsid", "ref", "all_alleles", "alleles", "phase", "gt",
-                                                "maf_text", "maf", "ref_len", "a0", "a1")}
+                                                "maf_text", "maf", "ref_len", "a0", "a1", "r0", "r1", "p0", "p1")}
         fields = c[8].split(":")
         if "GT" not in fields:
             continue
@@ -152,12 +179,16 @@ def _load_chunk(task):
         col["maf_text"].append(mtxt); col["maf"].append(mval)
         col["a0"].append(_CODE.get(ind[0], 255) if len(ind) > 0 else 255)
         col["a1"].append(_CODE.get(ind[1], 255) if len(ind) > 1 else 255)
+        i0 = ind[0] if len(ind) > 0 else ""; i1 = ind[1] if len(ind) > 1 else ""
+        col["r0"].append(i0 == c[3]); col["r1"].append(i1 == c[3])
+        col["p0"].append(ph.index(i0) if i0 in ph else -1); col["p1"].append(ph.index(i1) if i1 in ph else -1)
     return per, filter_count, unphased, excluded
 
 
 _US = "\x1f"
 _STR_COLS = ("uid", "rsid_field", "rsid", "ref", "gt", "maf_text")
 _LIST_COLS = ("all_alleles", "alleles", "phase")
+_INT_COLS = ("pos", "ref_len", "a0", "a1", "r0", "r1", "p0", "p1")
 
 
 _FORK_LINES = None          # the VCF lines, inherited by forked workers (never pickled)
@@ -171,7 +202,7 @@ def _load_chunk_compact(task):
     out = {}
     for chrom, col in per.items():
         rec = {"n": len(col["uid"]), "maf": col["maf"]}
-        for k in ("pos", "ref_len", "a0", "a1"):
+        for k in _INT_COLS:
             rec[k] = np.asarray(col[k], dtype=np.int64)
         for k in _STR_COLS:
             rec[k] = _US.join(col[k])
@@ -184,7 +215,7 @@ def _load_chunk_compact(task):
 def _expand(rec):
     n = rec["n"]
     col = {"maf": rec["maf"]}
-    for k in ("pos", "ref_len", "a0", "a1"):
+    for k in _INT_COLS:
         col[k] = rec[k].tolist()
     for k in _STR_COLS:
         col[k] = rec[k].split(_US) if n else []
@@ -230,7 +261,9 @@ def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str 
         cv = ChromVariants(chrom, np.asarray(col["pos"], dtype=np.int32), col["uid"], col["rsid_field"], col["rsid"], col["ref"],
                            col["all_alleles"], col["alleles"], col["phase"], col["gt"], col["maf_text"], col["maf"],
                            np.asarray(col["ref_len"], dtype=np.uint8), np.asarray(col["a0"], dtype=np.uint8),
-                           np.asarray(col["a1"], dtype=np.uint8))
+                           np.asarray(col["a1"], dtype=np.uint8),
+                           np.stack([np.asarray(col["r0"], dtype=np.uint8), np.asarray(col["r1"], dtype=np.uint8)], axis=1).reshape(-1),
+                           np.stack([np.asarray(col["p0"], dtype=np.int8), np.asarray(col["p1"], dtype=np.int8)], axis=1).reshape(-1))
         if len(cv.pos) > 1 and bool((np.diff(cv.pos) < 0).any()):
             raise SystemExit("     FATAL ERROR: VCF records of %s are not sorted by position." % chrom)
         het += len(cv.uid)

@@ -1,10 +1,13 @@
 """Multi-rank path on CPU: 2 gloo processes own one chromosome each (LPT assignment), all-reduce the per-BAM
-AS histograms and the noise counters, gather the per-chromosome fragments to rank 0 and assemble the files.
-Per-chromosome stage results come from tests/golden/frags_pipe_two.json.gz (produced on an MI355X by
-tools/make_frag_fixture.py); the assembled files must equal what the reference wrote for the same inputs."""
+AS histograms and the noise counters, run the host stages (native block phasing + row writer) for their own
+chromosome, gather the per-chromosome fragments to rank 0 and assemble the files.
+GPU stage results come from fixtures written on an MI355X: tests/golden/tally/pipe_two.pkl.gz (K_tally arrays,
+component labels; tools/make_tally_fixture.py) and tests/golden/frags_pipe_two.json.gz (per-chromosome AS
+histograms; tools/make_frag_fixture.py).  The assembled files must equal what the reference wrote for the same inputs."""
 import gzip
 import json
 import os
+import pickle
 import sys
 
 import numpy as np
@@ -22,10 +25,13 @@ def _worker(rank, world, port, result_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from phaser_amd import dist as pdist
-    from phaser_amd.engine import Config, Engine, merge_fragments
+    from phaser_amd import vcf
+    from phaser_amd.engine import Config, Engine
     fx = json.load(gzip.open(os.path.join(GOLD, "frags_pipe_two.json.gz"), "rt"))
-    chroms = fx["chroms"]
-    weights = {c: float(len(fx["frags"][c]["allelic"]) + 1 + i) for i, c in enumerate(chroms)}
+    saved = pickle.load(gzip.open(os.path.join(GOLD, "tally", "pipe_two.pkl.gz"), "rb"))
+    vs = vcf.load_variants(open(os.path.join(GOLD, "pipe_two", "in.vcf")).read())
+    chroms = list(vs.chroms)
+    weights = {c: float(len(saved["tally"][c]["line_cls"]) + i) for i, c in enumerate(chroms)}
     owner = pdist.assign_chromosomes(weights, world)
     assert sorted(set(owner.values())) == list(range(world))
     mine = [c for c in chroms if owner[c] == rank]
@@ -38,15 +44,21 @@ def _worker(rank, world, port, result_path):
         pdist.allreduce_sum_(h)
         hh = h.numpy(); nz = np.nonzero(hh)[0]
         cutoffs.append(float(np.percentile(np.repeat(nz.astype(np.int64) - 32768, hh[nz]), 5.0)))
-    match = sum(fx["counts"][c][0] for c in mine); mism = sum(fx["counts"][c][1] for c in mine)
-    match, mism = pdist.allreduce_counts(match, mism)
-    noise = Engine.noise_from_counts(match, mism)
-    frags = pdist.gather_fragments({c: fx["frags"][c] for c in mine})
+
+    class _M:                             # the host stages never touch the mapper or the GPU context
+        class ctx:
+            lib = None
+        device = None
+    eng = Engine(vs, ["t1", "t2"], Config(), mapper=_M())
+    eng.set_owned(mine)
+    eng.n_qid.update(saved["n_qid"])
+    eng._tally_chrom = lambda c: saved["tally"][c]
+    eng._component_labels = lambda c, ea, eb, keep: saved["labels"][c]
+    out = eng.finish()                    # all-reduce of the noise counters + gather of the fragments inside
     if rank == 0:
-        out, summary = merge_fragments(frags, [c for c in chroms if c in frags], Config(), noise)
-        json.dump({"out": out, "cutoffs": cutoffs, "noise": noise, "log": summary["log"], "n_frags": len(frags)}, open(result_path, "w"))
+        json.dump({"out": out, "cutoffs": cutoffs, "noise": eng.noise, "log": eng.log, "phased": eng.phased}, open(result_path, "w"))
     else:
-        assert frags is None
+        assert out is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +69,7 @@ def test_two_rank_reduce_gather_merge(tmp_path):
     mp.spawn(_worker, args=(2, port, res), nprocs=2, join=True)
     r = json.load(open(res))
     d = os.path.join(GOLD, "pipe_two")
-    assert r["n_frags"] == 2
+    assert r["phased"] == 229
     for name in OUTPUTS:
         want = gz_text(os.path.join(d, "out.%s.txt.gz" % name))
         assert canonical(name, r["out"][name]) == canonical(name, want), name

@@ -60,7 +60,7 @@ def test_pipe_one(mapper, device):
 
 @pytest.mark.parametrize("host_threads", [1, 3])
 def test_pipe_two_bams_two_chroms(mapper, host_threads):
-    """host_threads > 1 fans block phasing / row formatting out to forked workers (the reference's --threads)."""
+    """host_threads > 1: the native block phasing / row writer runs multi-threaded (the reference's --threads)."""
     d = os.path.join(GOLD, "pipe_two")
     bams = {}
     for b in ("t1", "t2"):

@@ -62,6 +62,9 @@ def test_host_stages_match_reference(case, gold, load, cfg, c1_inputs):
     for name in OUTPUTS:
         want = gz_text(os.path.join(d, "out.%s.txt.gz" % name))
         assert canonical(name, out[name]) == canonical(name, want), name
+    # the row writer is deterministic under threading: same bytes with 5 threads
+    out5, _ = run_host_stages(case, load, cfg, vcf_text, bam_display_names(bams), host_threads=5)
+    assert out5 == out
 
 
 @pytest.mark.parametrize("src,mode", [("pipe_one", 0), ("pipe_one", 1), ("pipe_one", 2), ("pipe_noisy_c", 2), ("pipe_two", 1)])

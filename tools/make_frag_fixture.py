@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Runs ON THE GPU BOX (gpurun): per-chromosome stage results of the pipe_two fixture, saved so that the
-CPU-only gloo tests can exercise the multi-rank reduce / gather / merge path without a GPU.
-Writes gpurun_out/frags_pipe_two.json; copy it to tests/golden/."""
+"""Runs ON THE GPU BOX (gpurun): per-chromosome AS histograms and noise counters of the pipe_two fixture, saved so
+that the CPU-only gloo tests can exercise the multi-rank all-reduce path without a GPU (the K_tally arrays the host
+stages start from come from tools/make_tally_fixture.py).  Writes gpurun_out/frags_pipe_two.json; gzip it into tests/golden/."""
 import ctypes as C
 import gzip
 import json
@@ -51,8 +51,7 @@ for c in list(vs.chroms):
     match += m; mism += mm
 eng.tally = per
 noise = Engine.noise_from_counts(match, mism)
-frags = {c: eng.chrom_fragment(c, noise, i) for i, c in enumerate(vs.chroms)}
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump({"hists": hists, "counts": counts, "frags": frags, "chroms": list(vs.chroms), "log": eng.log},
+json.dump({"hists": hists, "counts": counts, "chroms": list(vs.chroms), "log": eng.log},
           open(os.path.join(REPO, "gpurun_out", "frags_pipe_two.json"), "w"))
-print("wrote fragments for", list(vs.chroms), "noise", noise)
+print("wrote histograms / counts for", list(vs.chroms), "noise", noise)

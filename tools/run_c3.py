@@ -26,10 +26,10 @@ for chrom, shard in shards.items():
     eng.add_shard(0, chrom, shard, int(shard.qid.max()) + 1)
 torch.cuda.synchronize(); t3 = time.perf_counter()
 eng.close_bam(0); t4 = time.perf_counter()
-files = eng.finish(); t5 = time.perf_counter()
+files = eng.finish(binary=True); t5 = time.perf_counter()
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 for name, body in files.items():
-    open("/tmp/c3." + name + ".txt", "w").write(body)
+    open("/tmp/c3." + name + ".txt", "wb").write(body)
 t6 = time.perf_counter()
 nrec = sum(s.n for s in shards.values()); ncalls = sum(sh.calls.n for c in eng.shards for sh in eng.shards[c] if sh is not None)
 print("C3 x%.2f: %d records, %d het SNPs, %d calls | generate %.1fs | vcf parse %.1fs | K_map all chroms %.3fs | AS cutoff %.3fs | "
