@@ -116,6 +116,9 @@ typedef struct {
     int32_t *edge_b;
     int32_t *edge_cells;     /* [edge_cap*9] |S_a[i] & S_b[j]| at i*3+j, classes ref/alt/other */
     uint8_t *edge_linked;    /* 1 when some QNAME's surviving read_vars list holds both variants */
+    uint64_t *var_rank;      /* [nv] order in which variants enter the connectivity map (phaser.py:1271-1283): smallest
+                              * (first ref/alt line of the QNAME << 32 | line) over surviving read_vars entries of QNAMEs
+                              * with >= 2 distinct variants; UINT64_MAX when the variant never gets a key */
 } phz_tally_out;
 
 /* Variant table for the general (indel) mapper: per variant REF length and the individual's two allele strings. */

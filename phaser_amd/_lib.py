@@ -55,7 +55,7 @@ class phz_lines(C.Structure):
 class phz_tally_out(C.Structure):
     _fields_ = [("var_count", C.c_void_p), ("var_first", C.c_void_p), ("var_distinct", C.c_void_p), ("line_cls", C.c_void_p),
                 ("edge_cap", C.c_int64), ("edge_a", C.c_void_p), ("edge_b", C.c_void_p), ("edge_cells", C.c_void_p),
-                ("edge_linked", C.c_void_p)]
+                ("edge_linked", C.c_void_p), ("var_rank", C.c_void_p)]
 
 
 class phz_host_shard(C.Structure):

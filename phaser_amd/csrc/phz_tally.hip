@@ -56,7 +56,7 @@ constexpr int LINES_PER_BLOCK = 2048;
 
 __global__ __launch_bounds__(256) void k_line(LinesDev L, int64_t line_base, const uint8_t *a0, const uint8_t *a1,
                                               uint8_t *line_cls, int32_t *var_count, unsigned long long *var_first,
-                                              int32_t *qid_owner, int single_bam) {
+                                              int32_t *qid_owner, uint32_t *qid_first, int single_bam) {
     __shared__ int s_cnt[TW * 3];
     __shared__ unsigned long long s_first[TW];
     __shared__ int s_vbase;
@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256) void k_line(LinesDev L, int64_t line_base, con
             atomicAdd(&var_count[(int64_t)v * 3 + cls], 1);
             atomicMin(&var_first[v], (unsigned long long)(line_base + i));
         }
-        if (cls < 2 && !single_bam) atomicMax(&qid_owner[L.read_qid[r]], L.bam);
+        if (cls < 2) {
+            const int q = L.read_qid[r];
+            if (!single_bam) atomicMax(&qid_owner[q], L.bam);
+            atomicMin(&qid_first[q], (uint32_t)(line_base + i));      // first ref/alt line of the QNAME over all BAMs
+        }
     }
     __syncthreads();
     for (int j = tid; j < TW * 3; j += 256) {
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(256) void k_line(LinesDev L, int64_t line_base, con
 
 // key = qid:32 | var:28 | cls:2 | spare:1 | linked:1
 __global__ __launch_bounds__(256) void k_keys(LinesDev L, int64_t line_base, const uint8_t *line_cls,
-                                              const int32_t *qid_owner, uint64_t *keys, int single_bam) {
+                                              const int32_t *qid_owner, uint64_t *keys, uint32_t *qid_vmin, int32_t *qid_vmax,
+                                              int single_bam) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= L.n) return;
     const uint8_t cls = line_cls[line_base + i];
@@ -111,9 +116,44 @@ __global__ __launch_bounds__(256) void k_keys(LinesDev L, int64_t line_base, con
         const int r = L.read_idx[i];
         const uint32_t q = (uint32_t)L.read_qid[r];
         const uint32_t linked = (cls < 2 && (single_bam || qid_owner[q] == L.bam)) ? 1u : 0u;
-        k = ((uint64_t)q << 32) | ((uint64_t)(uint32_t)L.var_idx[i] << 4) | ((uint64_t)cls << 2) | linked;
+        const uint32_t v = (uint32_t)L.var_idx[i];
+        k = ((uint64_t)q << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;
+        if (linked) { atomicMin(&qid_vmin[q], v); atomicMax(&qid_vmax[q], (int32_t)v); }     // span of the surviving read_vars list
     }
     keys[line_base + i] = k;
+}
+
+// Overlap-dictionary key order (SURVEY.md 8.1 rule 4, phaser.py:1271-1283): a variant's rank is the smallest
+// (first ref/alt line of the QNAME, line) over the surviving read_vars entries of QNAMEs that hold >= 2 distinct
+// variants; variants that never get a key keep the maximum value.  LDS window like k_line.
+__global__ __launch_bounds__(256) void k_rank(LinesDev L, int64_t line_base, const uint8_t *line_cls, const int32_t *qid_owner,
+                                              const uint32_t *qid_first, const uint32_t *qid_vmin, const int32_t *qid_vmax,
+                                              unsigned long long *var_rank, int single_bam) {
+    __shared__ unsigned long long s_rank[TW];
+    __shared__ int s_vbase;
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
+    for (int j = tid; j < TW; j += 256) s_rank[j] = ~0ull;
+    if (tid == 0) s_vbase = L.var_idx[i0];
+    __syncthreads();
+    const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;
+    for (int64_t i = i0 + tid; i < i0 + LINES_PER_BLOCK && i < L.n; i += 256) {
+        const uint8_t cls = line_cls[line_base + i];
+        if (cls >= 2) continue;
+        const uint32_t q = (uint32_t)L.read_qid[L.read_idx[i]];
+        if (!(single_bam || qid_owner[q] == L.bam)) continue;
+        if (qid_vmin[q] == (uint32_t)qid_vmax[q]) continue;
+        const int v = L.var_idx[i];
+        const unsigned long long key = ((unsigned long long)qid_first[q] << 32) | (unsigned long long)(line_base + i);
+        const unsigned d = (unsigned)(v - vbase);
+        if (d < (unsigned)TW) atomicMin(&s_rank[d], key);
+        else atomicMin(&var_rank[v], key);
+    }
+    __syncthreads();
+    for (int j = tid; j < TW; j += 256) {
+        const unsigned long long f = s_rank[j];
+        if (f != ~0ull) atomicMin(&var_rank[vbase + j], f);
+    }
 }
 
 // after the sort: an element is the representative of its (qid, var, cls) run when it is the LAST of the
@@ -374,6 +414,9 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     if (int s = st.out(out->edge_b, (size_t)out->edge_cap, space, &d_eb)) return s;
     if (int s = st.out(out->edge_cells, (size_t)out->edge_cap * 9, space, &d_cells)) return s;
     if (int s = st.out(out->edge_linked, (size_t)out->edge_cap, space, &d_linked)) return s;
+    uint64_t *d_rank;
+    if (int s = st.out(out->var_rank, (size_t)nv, space, &d_rank)) return s;
+    if (total >= (1ll << 32)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^32 call lines in one chromosome");
 
     hipStream_t sm = ctx->stream;
     Timer timer(ctx, PHZ_T_TALLY);
@@ -388,6 +431,12 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     if (int s = phz_reserve(ctx, S[5], (size_t)(total ? total : 1) * 8)) return s;
     if (int s = phz_reserve(ctx, S[7], 64)) return s;
     int32_t *qid_owner = (int32_t *)S[1].p;
+    const size_t nq = (size_t)(n_qid ? n_qid : 1);
+    if (int s = phz_reserve(ctx, S[16], nq * 12)) return s;          // per QNAME: first ref/alt line, min / max linked variant
+    uint32_t *qid_first = (uint32_t *)S[16].p, *qid_vmin = qid_first + nq;
+    int32_t *qid_vmax = (int32_t *)(qid_vmin + nq);
+    PHZ_HIP(ctx, hipMemsetAsync(qid_first, 0xff, nq * 12, sm));      // first = vmin = UINT_MAX, vmax = -1
+    PHZ_HIP(ctx, hipMemsetAsync(d_rank, 0xff, (size_t)nv * 8, sm));
     uint64_t *keys = (uint64_t *)S[2].p, *skeys = (uint64_t *)S[3].p, *items = (uint64_t *)S[5].p;
     uint8_t *flags = (uint8_t *)S[4].p;
     unsigned long long *counters = (unsigned long long *)S[7].p;
@@ -399,12 +448,19 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     int64_t base = 0;
     for (int b = 0; b < n_shards; b++) {
         if (L[b].n) hipLaunchKernelGGL(k_line, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b], base,
-                                       d_a0, d_a1, d_cls, d_cnt, (unsigned long long *)d_first, qid_owner, single_bam);
+                                       d_a0, d_a1, d_cls, d_cnt, (unsigned long long *)d_first, qid_owner, qid_first, single_bam);
         base += L[b].n;
     }
     base = 0;
     for (int b = 0; b < n_shards; b++) {
-        if (L[b].n) hipLaunchKernelGGL(k_keys, dim3(nblk(L[b].n)), dim3(256), 0, sm, L[b], base, d_cls, qid_owner, keys, single_bam);
+        if (L[b].n) hipLaunchKernelGGL(k_keys, dim3(nblk(L[b].n)), dim3(256), 0, sm, L[b], base, d_cls, qid_owner, keys, qid_vmin, qid_vmax,
+                                       single_bam);
+        base += L[b].n;
+    }
+    base = 0;
+    for (int b = 0; b < n_shards; b++) {
+        if (L[b].n) hipLaunchKernelGGL(k_rank, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b], base,
+                                       d_cls, qid_owner, qid_first, qid_vmin, qid_vmax, (unsigned long long *)d_rank, single_bam);
         base += L[b].n;
     }
     PHZ_HIP(ctx, hipGetLastError());
@@ -480,6 +536,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         PHZ_HIP(ctx, hipMemcpyAsync(out->var_count, d_cnt, (size_t)nv * 12, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(out->var_first, d_first, (size_t)nv * 8, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(out->var_distinct, d_dist, (size_t)nv * 12, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(out->var_rank, d_rank, (size_t)nv * 8, hipMemcpyDeviceToHost, sm));
         if (total) PHZ_HIP(ctx, hipMemcpyAsync(out->line_cls, d_cls, (size_t)total, hipMemcpyDeviceToHost, sm));
         const size_t k = (size_t)(ne < out->edge_cap ? ne : out->edge_cap);
         if (k) {

@@ -50,6 +50,30 @@ class Config:
             setattr(self, k, v)
 
 
+def percentile_from_hist(h: np.ndarray, q: float) -> float:
+    """numpy.percentile(scores, q) (default linear method, numpy/lib/_function_base_impl.py _quantile/_lerp) for the
+    multiset scores = {bin - 32768 repeated h[bin] times}, computed from the histogram: same float64 operations on the
+    two neighbouring order statistics, without materialising the scores (phaser.py:551)."""
+    n = int(h.sum())
+    quant = np.true_divide(q, 100)
+    virt = (n - 1) * quant
+    prev = int(np.floor(virt))
+    gamma = np.float64(virt - prev)
+    nxt = prev + 1
+    if virt >= n - 1:
+        prev = nxt = n - 1
+    if virt < 0:
+        prev = nxt = 0
+    csum = np.cumsum(h)
+    a = np.int64(int(np.searchsorted(csum, prev, side="right")) - 32768)
+    b = np.int64(int(np.searchsorted(csum, nxt, side="right")) - 32768)
+    diff = np.subtract(b, a)
+    out = np.add(a, diff * gamma)
+    if gamma >= 0.5:
+        out = np.subtract(b, diff * (1 - gamma))
+    return float(out)
+
+
 class _Shard:
     def __init__(self, calls: Calls, qid, aln, has_as, n_reads):
         self.calls = calls; self.qid = qid; self.aln = aln; self.has_as = has_as; self.n_reads = n_reads
@@ -119,9 +143,7 @@ class Engine:
             pdist.allreduce_sum_(hist)          # the quantile is over ALL chromosomes of this BAM
             h = hist.cpu().numpy()
             if int(h.sum()) > 0:
-                nz = np.nonzero(h)[0]
-                scores = np.repeat(nz.astype(np.int64) - 32768, h[nz])
-                cutoff = np.percentile(scores, self.cfg.as_q_cutoff * 100)
+                cutoff = percentile_from_hist(h, self.cfg.as_q_cutoff * 100)
                 self.log.append("          using alignment score cutoff of %d" % cutoff)
                 for sh in shards:
                     sh.cutoff = float(cutoff); sh.use_cutoff = 1
@@ -146,11 +168,13 @@ class Engine:
             a0 = torch.from_numpy(cv.a0).to(dev); a1 = torch.from_numpy(cv.a1).to(dev)
         var_count = torch.empty(nv * 3, dtype=torch.int32, device=dev); var_first = torch.empty(nv, dtype=torch.int64, device=dev)
         var_distinct = torch.empty(nv * 3, dtype=torch.int32, device=dev); line_cls = torch.empty(max(1, total), dtype=torch.uint8, device=dev)
+        var_rank = torch.empty(max(1, nv), dtype=torch.int64, device=dev)
         cap = max(1024, 4 * nv)
         while True:
             ea = torch.empty(cap, dtype=torch.int32, device=dev); eb = torch.empty(cap, dtype=torch.int32, device=dev)
             cells = torch.empty(cap * 9, dtype=torch.int32, device=dev); linked = torch.empty(cap, dtype=torch.uint8, device=dev)
-            out = _lib.phz_tally_out(_p(var_count), _p(var_first), _p(var_distinct), _p(line_cls), cap, _p(ea), _p(eb), _p(cells), _p(linked))
+            out = _lib.phz_tally_out(_p(var_count), _p(var_first), _p(var_distinct), _p(line_cls), cap, _p(ea), _p(eb), _p(cells), _p(linked),
+                                     _p(var_rank))
             ne = C.c_int64(0)
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
@@ -167,6 +191,7 @@ class Engine:
             "var_distinct": var_distinct.cpu().numpy().reshape(nv, 3), "line_cls": line_cls[:total].cpu().numpy(),
             "ea": ea[:ne].cpu().numpy(), "eb": eb[:ne].cpu().numpy(), "cells": cells[:ne * 9].cpu().numpy().reshape(ne, 9),
             "linked": linked[:ne].cpu().numpy().astype(bool), "dev": dev, "space": space,
+            "var_rank": var_rank[:nv].cpu().numpy().view(np.uint64),
         }
         # host copies of the kept call lines (for ordering rules and read lists)
         lv = []; lq = []; lb = []; offs = []
@@ -253,30 +278,8 @@ class Engine:
         if True:
             kept = R["line_cls"] != 255
             cls = R["line_cls"]
-            # ---- ordering rules 3 and 4: read_vars order, overlap-dict key order
-            lines = np.nonzero(kept & (cls < 2))[0]
-            q = R["line_qid"][lines]; b = R["line_bam"][lines]; v = R["line_var"][lines]
-            nq = max(1, self.n_qid[c])
-            owner = np.full(nq, -1, dtype=np.int32)
-            np.maximum.at(owner, q, b)
-            qfirst = np.full(nq, np.iinfo(np.int64).max, dtype=np.int64)
-            np.minimum.at(qfirst, q, lines)
-            own = b == owner[q]
-            lo = lines[own]; qo = q[own]; vo = v[own]
-            o = np.lexsort((lo, qfirst[qo]))            # by (first appearance of the QNAME, line)
-            qs = qo[o]; vs_ = vo[o]
-            rank = np.full(nv, np.iinfo(np.int64).max, dtype=np.int64)
-            if len(qs):
-                # QNAMEs with >= 2 distinct variants create overlap keys, in list order
-                newq = np.r_[True, qs[1:] != qs[:-1]]
-                gid = np.cumsum(newq) - 1
-                pair_key = gid.astype(np.int64) * (nv + 1) + vs_
-                uniq = np.unique(pair_key)
-                distinct_per_group = np.bincount((uniq // (nv + 1)).astype(np.int64), minlength=gid[-1] + 1)
-                multi = distinct_per_group[gid] >= 2
-                idx = np.nonzero(multi)[0]
-                uv, first = np.unique(vs_[idx], return_index=True)
-                rank[uv] = idx[first]
+            # ---- ordering rule 4: overlap-dict key order, computed by K_tally (k_rank)
+            rank = R["var_rank"]
             # ---- test every linked pair (phaser.py:1594-1654)
             sel = np.nonzero(R["linked"])[0]
             ea = R["ea"][sel]; eb = R["eb"][sel]; cells = R["cells"][sel].astype(np.int64)
@@ -299,8 +302,7 @@ class Engine:
             frag["dropped"] = int((~keep_edge).sum())
             # ---- connected components of the surviving graph on the GPU (phaser.py:1861-1882)
             label = self._component_labels(c, ea, eb, keep_edge)
-            deg = np.zeros(nv, dtype=np.int64)
-            np.add.at(deg, ea[keep_edge], 1); np.add.at(deg, eb[keep_edge], 1)
+            deg = np.bincount(ea[keep_edge], minlength=nv) + np.bincount(eb[keep_edge], minlength=nv)
             members = np.nonzero(deg > 0)[0]
             P = {"va": va, "vb": vb, "cis": cis, "trans": trans, "sup": sup, "tot": tot, "pv": pv, "eorder": eorder, "ea": ea, "eb": eb,
                  "cfgv": cfgv, "ncomp": 0}

@@ -79,3 +79,16 @@ def test_phased_vcf_from_host_stages(src, mode):
     out, eng = run_host_stages(src, {}, {}, vcf_text, bam_display_names(bams))
     got, up, pc = vcfout.phased_vcf_text([l for l in vcf_text.split("\n") if l], eng.vcf_lookup, gw_phase_vcf=mode)
     assert got == gz_text(os.path.join(d, "out.vcf_gw%d.txt.gz" % mode))
+
+
+def test_percentile_from_histogram_equals_numpy():
+    """AS cutoff (phaser.py:551): the histogram route reproduces numpy.percentile bit for bit."""
+    import numpy as np
+    from phaser_amd.engine import percentile_from_hist
+    rng = np.random.default_rng(7)
+    for t in range(400):
+        n = int(rng.integers(1, 300)) if t % 2 else int(rng.integers(1, 50000))
+        sc = rng.integers(-50, 160, size=n) if t % 3 else rng.integers(100, 153, size=n)
+        h = np.bincount(sc + 32768, minlength=65536).astype(np.int64)
+        for q in (0.05 * 100, 0.2 * 100, 0.0, 100.0, 37.3, 99.9):
+            assert float(np.percentile(sc.astype(np.int64), q)) == percentile_from_hist(h, q)
