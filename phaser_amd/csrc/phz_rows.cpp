@@ -718,18 +718,22 @@ extern "C" int phz_rows_format(const phz_rows_in *in, phz_rows_out *out) {
         if (I.unphased_vars == 1) run_singles(C, kb[i], kb[i + 1], sc[i]);
     });
 
-    // ---- assemble
-    std::string conn, hap, ase, cfg, allelic, s_ase, s_hap;
-    {
-        size_t a = 0, b = 0, c = 0;
-        for (auto &x : bc) { a += x.hap.size(); b += x.ase.size(); c += x.cfg.size(); }
-        hap.reserve(a); ase.reserve(b); cfg.reserve(c);
-    }
+    // ---- assemble: one allocation per file, chunks copied into place in parallel
+    auto gather = [&](const std::vector<const std::string *> &parts, int64_t *len) -> char * {
+        std::vector<size_t> off(parts.size() + 1, 0);
+        for (size_t i = 0; i < parts.size(); i++) off[i + 1] = off[i] + parts[i]->size();
+        char *p = (char *)malloc(off.back() + 1);
+        if (!p) return nullptr;
+        parallel_chunks(threads, (int64_t)parts.size(), [&](int64_t i) { if (parts[i]->size()) memcpy(p + off[i], parts[i]->data(), parts[i]->size()); });
+        p[off.back()] = 0;
+        *len = (int64_t)off.back();
+        return p;
+    };
+    std::vector<const std::string *> p_hap, p_ase, p_cfg, p_conn, p_all, p_sa, p_sh;
     std::vector<int32_t> bvar, bsize, bmaxmaf; std::vector<uint8_t> bhap, bstat_int; std::vector<int8_t> bcor; std::vector<double> bstat;
     int64_t phased = 0;
     for (auto &x : bc) {
-        hap += x.hap; ase += x.ase; cfg += x.cfg; phased += x.phased;
-        std::string().swap(x.hap); std::string().swap(x.ase); std::string().swap(x.cfg);
+        p_hap.push_back(&x.hap); p_ase.push_back(&x.ase); p_cfg.push_back(&x.cfg); phased += x.phased;
         if (I.want_vcf) {
             bvar.insert(bvar.end(), x.bvar.begin(), x.bvar.end()); bhap.insert(bhap.end(), x.bhap.begin(), x.bhap.end());
             bcor.insert(bcor.end(), x.bcor.begin(), x.bcor.end()); bmaxmaf.insert(bmaxmaf.end(), x.bmaxmaf.begin(), x.bmaxmaf.end());
@@ -737,21 +741,22 @@ extern "C" int phz_rows_format(const phz_rows_in *in, phz_rows_out *out) {
         }
         bsize.insert(bsize.end(), x.bsize.begin(), x.bsize.end());
     }
-    for (auto &x : cc) conn += x.a;
+    for (auto &x : cc) p_conn.push_back(&x.a);
     std::vector<int64_t> aseg((size_t)I.nb + 1, 0), sseg_a((size_t)I.nb + 1, 0), sseg_h((size_t)I.nb + 1, 0);
-    int64_t arows = 0;
+    int64_t arows = 0, la = 0, lsa = 0, lsh = 0;
     for (size_t i = 0; i + 1 < kb.size(); i++) {
         const int64_t b = kb[i] < I.n_keys ? I.key_bam[kb[i]] : 0;
-        allelic += ac[i].a; s_ase += sc[i].a; s_hap += sc[i].b; arows += ac[i].rows;
-        for (int64_t k = b + 1; k <= I.nb; k++) { aseg[k] = (int64_t)allelic.size(); sseg_a[k] = (int64_t)s_ase.size(); sseg_h[k] = (int64_t)s_hap.size(); }
+        p_all.push_back(&ac[i].a); p_sa.push_back(&sc[i].a); p_sh.push_back(&sc[i].b); arows += ac[i].rows;
+        la += (int64_t)ac[i].a.size(); lsa += (int64_t)sc[i].a.size(); lsh += (int64_t)sc[i].b.size();
+        for (int64_t k = b + 1; k <= I.nb; k++) { aseg[k] = la; sseg_a[k] = lsa; sseg_h[k] = lsh; }
     }
-    out->conn = take(conn); out->conn_len = (int64_t)conn.size();
-    out->hap = take(hap); out->hap_len = (int64_t)hap.size();
-    out->ase = take(ase); out->ase_len = (int64_t)ase.size();
-    out->cfg = take(cfg); out->cfg_len = (int64_t)cfg.size();
-    out->allelic = take(allelic); out->allelic_len = (int64_t)allelic.size(); out->allelic_rows = arows;
-    out->single_ase = take(s_ase); out->single_ase_len = (int64_t)s_ase.size();
-    out->single_hap = take(s_hap); out->single_hap_len = (int64_t)s_hap.size();
+    out->conn = gather(p_conn, &out->conn_len);
+    out->hap = gather(p_hap, &out->hap_len);
+    out->ase = gather(p_ase, &out->ase_len);
+    out->cfg = gather(p_cfg, &out->cfg_len);
+    out->allelic = gather(p_all, &out->allelic_len); out->allelic_rows = arows;
+    out->single_ase = gather(p_sa, &out->single_ase_len);
+    out->single_hap = gather(p_sh, &out->single_hap_len);
     out->allelic_seg = take_vec(aseg); out->single_ase_seg = take_vec(sseg_a); out->single_hap_seg = take_vec(sseg_h);
     out->n_blocks = (int64_t)bsize.size(); out->phased = phased;
     out->blk_size = take_vec(bsize);

@@ -64,6 +64,8 @@ def gather_fragments(local: Dict[str, dict]) -> Optional[Dict[str, dict]]:
     if w == 1:
         return dict(local)
     bucket: List[Optional[dict]] = [None] * w if r == 0 else None
+    # row text lives in native buffers (memoryviews): materialise it for pickling
+    local = {c: {k: (bytes(v) if isinstance(v, memoryview) else v) for k, v in f.items()} for c, f in local.items()}
     dist.gather_object(local, bucket, dst=0)
     if r != 0:
         return None

@@ -170,6 +170,8 @@ class Engine:
         var_distinct = torch.empty(nv * 3, dtype=torch.int32, device=dev); line_cls = torch.empty(max(1, total), dtype=torch.uint8, device=dev)
         var_rank = torch.empty(max(1, nv), dtype=torch.int64, device=dev)
         cap = max(1024, 4 * nv)
+        import time as _t
+        t0 = _t.perf_counter()
         while True:
             ea = torch.empty(cap, dtype=torch.int32, device=dev); eb = torch.empty(cap, dtype=torch.int32, device=dev)
             cells = torch.empty(cap * 9, dtype=torch.int32, device=dev); linked = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -186,6 +188,7 @@ class Engine:
                 continue
             break
         ne = int(ne.value)
+        t1 = _t.perf_counter()
         res = {
             "nv": nv, "var_count": var_count.cpu().numpy().reshape(nv, 3), "var_first": var_first.cpu().numpy(),
             "var_distinct": var_distinct.cpu().numpy().reshape(nv, 3), "line_cls": line_cls[:total].cpu().numpy(),
@@ -204,6 +207,8 @@ class Engine:
         cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
         res["line_var"] = cat(lv, np.int32); res["line_qid"] = cat(lq, np.int32); res["line_bam"] = cat(lb, np.int32)
         res["bam_offsets"] = offs
+        self.stats["tally_call_s"] = self.stats.get("tally_call_s", 0.0) + t1 - t0
+        self.stats["tally_d2h_s"] = self.stats.get("tally_d2h_s", 0.0) + _t.perf_counter() - t1
         return res
 
     def tally_all(self):

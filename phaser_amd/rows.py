@@ -25,6 +25,8 @@ def _vp(a):
 
 def format_chrom(eng, c: str, threads: int) -> Dict:
     """-> the chromosome's fragment fields produced by stage C2 (bytes row text, counts, write_vcf arrays)."""
+    import time as _t
+    t0 = _t.perf_counter()
     lib = _lib.load()
     cfg = eng.cfg
     P = eng._pre[c]; R = eng.tally[c]; cv = eng.vs.chroms[c]
@@ -84,35 +86,65 @@ def format_chrom(eng, c: str, threads: int) -> Dict:
         qoff, qb = sep_pool(list(eng.qnames[c]))
         I.qname_off = A(qoff, np.uint32); I.qname = B(qb)
     O = _lib.phz_rows_out()
+    t1 = _t.perf_counter()
     st = lib.phz_rows_format(C.byref(I), C.byref(O))
+    eng.stats["rows_glue_s"] = eng.stats.get("rows_glue_s", 0.0) + t1 - t0
+    eng.stats["rows_native_s"] = eng.stats.get("rows_native_s", 0.0) + _t.perf_counter() - t1
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_rows_format(%s): %s" % (c, lib.phz_strerror(st).decode()))
-    try:
-        def text(name):
-            n = getattr(O, name + "_len")
-            return C.string_at(getattr(O, name), n) if n else b""
+    owner = _NativeRows(lib, O)
 
-        def seg(name):
-            p = getattr(O, name)
-            return [int(p[i]) for i in range(nb + 1)]
+    def seg(name):
+        p = getattr(O, name)
+        return [int(p[i]) for i in range(nb + 1)]
 
-        def vec(name, dt, n):
-            if n == 0:
-                return np.zeros(0, dtype=dt)
-            return np.frombuffer(C.string_at(getattr(O, name), n * np.dtype(dt).itemsize), dtype=dt).copy()
-        out = {"conn": text("conn"), "hap": text("hap"), "ase": text("ase"), "cfg": text("cfg"),
-               "allelic": text("allelic"), "allelic_seg": seg("allelic_seg"), "allelic_rows": int(O.allelic_rows),
-               "single_ase": text("single_ase"), "single_ase_seg": seg("single_ase_seg"),
-               "single_hap": text("single_hap"), "single_hap_seg": seg("single_hap_seg"),
-               "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None}
-        if cfg.want_vcf:
-            nbk = int(O.n_blocks); nvv = int(O.n_blk_vars)
-            out["vcf"] = {"size": vec("blk_size", np.int32, nbk), "var": vec("blk_var", np.int32, nvv), "hap": vec("blk_hap", np.uint8, nvv),
-                          "cor": vec("blk_cor", np.int8, 2 * nvv), "stat": vec("blk_stat", np.float64, nbk),
-                          "stat_int": vec("blk_stat_int", np.uint8, nbk), "maxmaf": vec("blk_maxmaf", np.int32, nbk)}
-    finally:
-        lib.phz_rows_free(C.byref(O))
+    def vec(name, dt, n):
+        if n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.frombuffer(C.string_at(getattr(O, name), n * np.dtype(dt).itemsize), dtype=dt).copy()
+    out = {"conn": owner.text("conn"), "hap": owner.text("hap"), "ase": owner.text("ase"), "cfg": owner.text("cfg"),
+           "allelic": owner.text("allelic"), "allelic_seg": seg("allelic_seg"), "allelic_rows": int(O.allelic_rows),
+           "single_ase": owner.text("single_ase"), "single_ase_seg": seg("single_ase_seg"),
+           "single_hap": owner.text("single_hap"), "single_hap_seg": seg("single_hap_seg"),
+           "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None}
+    if cfg.want_vcf:
+        nbk = int(O.n_blocks); nvv = int(O.n_blk_vars)
+        out["vcf"] = {"size": vec("blk_size", np.int32, nbk), "var": vec("blk_var", np.int32, nvv), "hap": vec("blk_hap", np.uint8, nvv),
+                      "cor": vec("blk_cor", np.int8, 2 * nvv), "stat": vec("blk_stat", np.float64, nbk),
+                      "stat_int": vec("blk_stat_int", np.uint8, nbk), "maxmaf": vec("blk_maxmaf", np.int32, nbk)}
     return out
+
+
+class _NativeRows:
+    """Owns one phz_rows_out: hands out zero-copy views of its text buffers and frees them when the last view dies."""
+
+    def __init__(self, lib, O):
+        self.lib = lib; self.O = O
+
+    def text(self, name):
+        n = getattr(self.O, name + "_len")
+        if not n:
+            return b""
+        arr = np.ctypeslib.as_array(C.cast(getattr(self.O, name), C.POINTER(C.c_uint8)), shape=(n,))
+        return memoryview(_Keep(arr, self))
+
+    def __del__(self):
+        try:
+            self.lib.phz_rows_free(C.byref(self.O))
+        except Exception:
+            pass
+
+
+class _Keep(np.ndarray):
+    """uint8 view of native memory that keeps its owner alive (memoryview(_Keep) -> the buffer the merge / file writer reads)."""
+
+    def __new__(cls, arr, owner):
+        obj = arr.view(cls)
+        obj._owner = owner
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
 
 
 def vcf_block_info(cv, v: Dict, first_block_index: int, lookup: Dict):

@@ -267,5 +267,6 @@ def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str 
         if len(cv.pos) > 1 and bool((np.diff(cv.pos) < 0).any()):
             raise SystemExit("     FATAL ERROR: VCF records of %s are not sorted by position." % chrom)
         het += len(cv.uid)
+        cv.pools()                 # string tables of the variant table for the native row writer (built once, with the table)
         out[chrom] = cv
     return VariantSet(out, het, filter_count, excluded, unphased)
