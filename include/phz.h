@@ -267,6 +267,11 @@ typedef struct {
 
 int phz_rows_format(const phz_rows_in *in, phz_rows_out *out);
 void phz_rows_free(phz_rows_out *out);
+/* phase_v3 (phaser.py:2107-2170) on one connected component: n position-sorted variants, edges (i, j, cfg 0 cis / 1 trans /
+ * -1 tie) in local indices.  Outputs the final sub-blocks: first local variant, length, and haplotype-A allele characters
+ * written back to back into config (capacity n); sub_first / sub_len need capacity n. */
+int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i, const int32_t *edge_j, const int8_t *edge_cfg,
+                    int32_t max_block_size, int32_t *sub_first, int32_t *sub_len, char *config, int32_t *n_subs);
 
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);

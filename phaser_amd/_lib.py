@@ -130,6 +130,8 @@ SYMBOLS = {
                                         C.POINTER(C.c_int64), C.c_int]),
     "phz_rows_format": (C.c_int, [C.POINTER(phz_rows_in), C.POINTER(phz_rows_out)]),
     "phz_rows_free": (None, [C.POINTER(phz_rows_out)]),
+    "phz_phase_block": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(C.c_int32)]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),

@@ -770,6 +770,39 @@ extern "C" int phz_rows_format(const phz_rows_in *in, phz_rows_out *out) {
     return PHZ_OK;
 }
 
+// phase_v3 on one connected component (variants position-sorted, local indices): the same routine phz_rows_format runs
+// per component, exposed so that it can be checked against the reference restatement on arbitrary graphs
+extern "C" int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i, const int32_t *edge_j, const int8_t *edge_cfg,
+                               int32_t max_block_size, int32_t *sub_first, int32_t *sub_len, char *config, int32_t *n_subs) {
+    if (n <= 0 || n_edges < 0 || !sub_first || !sub_len || !config || !n_subs) return PHZ_E_ARG;
+    AlleleGraph g;
+    g.n = n; g.adj.assign((size_t)2 * n, {}); g.mark.assign((size_t)2 * n + 2, 0);
+    for (int64_t e = 0; e < n_edges; e++) {
+        const int i = edge_i[e], j = edge_j[e], k = edge_cfg[e];
+        if (i < 0 || j < 0 || i >= n || j >= n || i == j) return PHZ_E_ARG;
+        g.vedges.emplace_back(i, j);
+        if (k == 0) {
+            g.adj[2 * i].push_back(2 * j); g.adj[2 * j].push_back(2 * i);
+            g.adj[2 * i + 1].push_back(2 * j + 1); g.adj[2 * j + 1].push_back(2 * i + 1);
+        } else if (k == 1) {
+            g.adj[2 * i].push_back(2 * j + 1); g.adj[2 * j + 1].push_back(2 * i);
+            g.adj[2 * i + 1].push_back(2 * j); g.adj[2 * j].push_back(2 * i + 1);
+        }
+    }
+    std::vector<std::pair<int, std::string>> subs;
+    const int st = phase_component(g, max_block_size, subs);
+    if (st) return st;
+    int w = 0, k = 0;
+    for (auto &s : subs) {
+        int len = 0;
+        for (size_t t = 0; t < s.second.size(); t++)
+            if (s.first + (int)t < n) { config[w++] = s.second[t]; len++; }
+        sub_first[k] = s.first; sub_len[k] = len; k++;
+    }
+    *n_subs = k;
+    return PHZ_OK;
+}
+
 extern "C" void phz_rows_free(phz_rows_out *o) {
     if (!o) return;
     free(o->conn); free(o->hap); free(o->ase); free(o->cfg); free(o->allelic); free(o->single_ase); free(o->single_hap);
