@@ -426,7 +426,97 @@ def fx_write_vcf(phaser, rvm):
         print("write_vcf", src, len(res["vcf"].splitlines()), "lines")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels, "options": fx_options}
+def gene_ae_features(hc_text, seed):
+    """Synthetic BED features for a haplotypic_counts file: clusters over runs of variants, nested features, features that
+    END exactly at (variant position - 1) inside multi-variant blocks (the inclusive-end quirk of variant_feature_reads,
+    phaser_gene_ae.py:190), empty regions and a contig the counts never mention."""
+    import random
+    rng = random.Random(seed)
+    rows = [l.split("\t") for l in hc_text.split("\n")[1:] if l]
+    per = {}
+    for r in rows:
+        for u in r[3].split(","):
+            f = u.split("_")
+            per.setdefault(r[0], set()).add(int(f[1]))
+    feats = []
+    for chrom in sorted(per):
+        pos = sorted(per[chrom])
+        i = 0
+        while i < len(pos):
+            k = rng.randint(1, 9)
+            a = pos[i]; b = pos[min(len(pos) - 1, i + k - 1)]
+            feats.append((chrom, max(0, a - 1 - rng.randint(0, 300)), b + rng.randint(0, 300), "g%d" % len(feats)))
+            if rng.random() < 0.3:              # nested / overlapping neighbour
+                feats.append((chrom, max(0, a - 1), b, "g%d_inner" % len(feats)))
+            if rng.random() < 0.15:
+                feats.append((chrom, b + 400, b + 500, "g%d_empty" % len(feats)))
+            if rng.random() < 0.25:             # exactly one variant
+                feats.append((chrom, a - 1, a, "g%d_one" % len(feats)))
+            i += k if rng.random() < 0.8 else max(1, k - 2)
+        for r in rows:
+            vs = r[3].split(",")
+            if r[0] == chrom and len(vs) >= 3 and rng.random() < 0.35:
+                p = [int(u.split("_")[1]) for u in vs]
+                j = rng.randint(1, len(p) - 1)
+                feats.append((chrom, max(0, p[0] - 1 - rng.randint(0, 50)), p[j] - 1, "g%d_edge" % len(feats)))
+    feats.append(("chrUn_absent", 100, 5000, "g_absent"))
+    return "".join("%s\t%d\t%d\t%s\n" % f for f in feats if f[2] > f[1])
+
+
+def fx_gene_ae(phaser, rvm):
+    """phaser_gene_ae: run the reference's script on haplotypic_counts files the reference's phASER wrote
+    (other fixtures) and on synthetic BED features.  `intervaltree` is not installed here; the script gets a stand-in that
+    implements only what it uses (half-open intervals, `tree[a:b] = data`, `tree[a:b]` -> set of overlapping Interval tuples,
+    the published semantics of intervaltree 3.x `overlap(begin, end)`: iv.begin < end and iv.end > begin)."""
+    import collections
+    import runpy
+    Interval = collections.namedtuple("Interval", ["begin", "end", "data"])
+
+    class IntervalTree:
+        def __init__(self):
+            self.ivs = []
+
+        def __setitem__(self, sl, data):
+            if sl.start >= sl.stop:
+                raise ValueError("IntervalTree: Null Interval objects not allowed in IntervalTree")
+            self.ivs.append(Interval(sl.start, sl.stop, data))
+
+        def __getitem__(self, sl):
+            if sl.start >= sl.stop:
+                return set()
+            return set(iv for iv in self.ivs if iv.begin < sl.stop and iv.end > sl.start)
+    mod = types.ModuleType("intervaltree"); mod.IntervalTree = IntervalTree; mod.Interval = Interval
+    sys.modules["intervaltree"] = mod
+    script = "/root/reference/phaser_gene_ae/phaser_gene_ae.py"
+    cases = [("pipe_one", "pipe_one", 11, []), ("pipe_two", "pipe_two", 12, []), ("pipe_two_mincov", "pipe_two", 12, ["--min_cov", "5"]),
+             ("pipe_two_gw06", "pipe_two", 12, ["--gw_cutoff", "0.6"]), ("pipe_noisy_c", "pipe_noisy_c", 13, []), ("c1", "c1", 14, []),
+             ("opts_gw_maf", os.path.join("pipe_opts", "gw_maf"), 15, ["--min_haplo_maf", "0.1"]),
+             ("opts_bam_exclude", os.path.join("pipe_opts", "bam_exclude"), 16, []),
+             ("opts_blacklist", os.path.join("pipe_opts", "blacklist"), 17, ["--gw_cutoff", "0.75", "--min_cov", "2"]),
+             ("pipe_two_strict", "pipe_two", 18, ["--gw_cutoff", "1.01"]), ("pipe_noisy_b", "pipe_noisy_b", 19, []),
+             ("opts_gw_maf_strict", os.path.join("pipe_opts", "gw_maf"), 20, ["--min_haplo_maf", "0.35", "--min_cov", "1"])]
+    for name, src, seed, extra in cases:
+        hc = gzip.open(os.path.join(GOLD, src, "out.haplotypic_counts.txt.gz"), "rt").read()
+        d = os.path.join(GOLD, "gene_ae", name); os.makedirs(d, exist_ok=True)
+        bed = gene_ae_features(hc, seed)
+        with tempfile.TemporaryDirectory() as tmp:
+            hp = os.path.join(tmp, "hc.txt"); bp = os.path.join(tmp, "f.bed"); op = os.path.join(tmp, "o.txt")
+            open(hp, "w").write(hc); open(bp, "w").write(bed)
+            argv = sys.argv
+            sys.argv = [script, "--haplotypic_counts", hp, "--features", bp, "--o", op] + extra
+            buf = io.StringIO(); old = sys.stdout; sys.stdout = buf
+            try:
+                runpy.run_path(script, run_name="__main__")
+            finally:
+                sys.stdout = old; sys.argv = argv
+            out = open(op).read()
+        open(os.path.join(d, "features.bed"), "w").write(bed)
+        wgz(os.path.join(d, "out.gene_ae.txt.gz"), out)
+        json.dump({"haplotypic_counts": src.replace(os.sep, "/") + "/out.haplotypic_counts.txt.gz", "args": extra}, open(os.path.join(d, "case.json"), "w"))
+        print("gene_ae", name, len(bed.splitlines()), "features", len(out.splitlines()) - 1, "rows")
+
+
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
