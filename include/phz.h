@@ -132,7 +132,7 @@ typedef struct {
 } phz_variants_general;
 
 /* timing slots for phz_get_timing */
-enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_COUNT = 8 };
+enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_GENES = 4, PHZ_T_COUNT = 8 };
 
 int phz_version(void);
 const char *phz_strerror(int status);
@@ -272,6 +272,49 @@ void phz_rows_free(phz_rows_out *out);
  * written back to back into config (capacity n); sub_first / sub_len need capacity n. */
 int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i, const int32_t *edge_j, const int8_t *edge_cfg,
                     int32_t max_block_size, int32_t *sub_first, int32_t *sub_len, char *config, int32_t *n_subs);
+
+/* ---- phaser_gene_ae (phaser_gene_ae/phaser_gene_ae.py): gene-level haplotypic counts from a haplotypic_counts.txt ---------
+ * phz_hc_parse: multi-threaded parse of the file text (:78 pandas.read_csv + the per-row string splitting of :172-204).
+ * The arrays stay owned by the handle; var_id_off / var_id_len point into the caller's text buffer. */
+typedef struct phz_hc phz_hc;
+typedef struct {
+    int64_t n_rows, n_vars, n_lab_a, n_lab_b;
+    int32_t n_contigs, n_bams, has_maf;
+    const int32_t *contig, *start, *stop, *a_count, *b_count, *total, *bam;
+    const int32_t *phase;          /* blockGWPhase: 0 "0/1", 1 "0|1", 2 "1|0", 3 anything else */
+    const double *gw_stat, *maf;
+    const int64_t *var_off;        /* [n_rows+1] */
+    const int32_t *var_pos;        /* [n_vars] second separator-delimited field of the variant id (:186-187) */
+    const int64_t *var_id_off;     /* [n_vars] id text = input[var_id_off : var_id_off + var_id_len] */
+    const int32_t *var_id_len;
+    const int64_t *lab_off_a, *lab_off_b;   /* [n_rows+1] label runs per row (empty for single-variant rows, :193-197) */
+    const int32_t *lab_pos_a, *lab_prev_a, *lab_pos_b, *lab_prev_b;
+    const char *names;             /* contig names then BAM names, NUL-terminated, at names_off[i] */
+    const int64_t *names_off;      /* [n_contigs + n_bams + 1] */
+} phz_hc_arrays;
+
+int phz_hc_parse(const char *text, int64_t len, const char *id_separator, int threads, phz_hc **out);
+int phz_hc_view(const phz_hc *h, phz_hc_arrays *view);
+const char *phz_hc_error(const phz_hc *h);
+void phz_hc_free(phz_hc *h);
+
+/* K_genes: distinct reads per haplotype for every (row, feature) pair (variant_feature_reads :172-219).  A work item is a
+ * slice of one row-haplotype label run: labels [item_lo, item_lo + item_n), run start item_run (lab_prev is run-relative).
+ * pair_counts[2*pair + hap] receives the count; pair_begin / pair_end are the feature's BED start / stop. */
+typedef struct {
+    int64_t n_items;
+    const int64_t *item_lo;
+    const int32_t *item_n;
+    const int64_t *item_run;
+    const int32_t *item_pair;
+    const uint8_t *item_hap;
+    int64_t n_pairs;
+    const int32_t *pair_begin, *pair_end;
+    int64_t n_lab_a, n_lab_b;
+    const int32_t *lab_pos_a, *lab_prev_a, *lab_pos_b, *lab_prev_b;
+} phz_gene_work;
+
+int phz_gene_counts(phz_ctx *ctx, const phz_gene_work *work, int32_t *pair_counts, int space);
 
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);

@@ -95,6 +95,21 @@ class phz_rows_out(C.Structure):
                [(k, C.c_void_p) for k in ("blk_size", "blk_var", "blk_hap", "blk_cor", "blk_stat", "blk_stat_int", "blk_maxmaf")]
 
 
+class phz_hc_arrays(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_vars", C.c_int64), ("n_lab_a", C.c_int64), ("n_lab_b", C.c_int64),
+                ("n_contigs", C.c_int32), ("n_bams", C.c_int32), ("has_maf", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("contig", "start", "stop", "a_count", "b_count", "total", "bam", "phase", "gw_stat", "maf",
+                                          "var_off", "var_pos", "var_id_off", "var_id_len", "lab_off_a", "lab_off_b",
+                                          "lab_pos_a", "lab_prev_a", "lab_pos_b", "lab_prev_b", "names", "names_off")]
+
+
+class phz_gene_work(C.Structure):
+    _fields_ = [("n_items", C.c_int64), ("item_lo", C.c_void_p), ("item_n", C.c_void_p), ("item_run", C.c_void_p),
+                ("item_pair", C.c_void_p), ("item_hap", C.c_void_p), ("n_pairs", C.c_int64), ("pair_begin", C.c_void_p),
+                ("pair_end", C.c_void_p), ("n_lab_a", C.c_int64), ("n_lab_b", C.c_int64), ("lab_pos_a", C.c_void_p),
+                ("lab_prev_a", C.c_void_p), ("lab_pos_b", C.c_void_p), ("lab_prev_b", C.c_void_p)]
+
+
 PHZ_AS_BINS = 65536
 
 # every symbol include/phz.h declares: name -> (restype, argtypes)
@@ -132,6 +147,11 @@ SYMBOLS = {
     "phz_rows_free": (None, [C.POINTER(phz_rows_out)]),
     "phz_phase_block": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(C.c_int32)]),
+    "phz_hc_parse": (C.c_int, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "phz_hc_view": (C.c_int, [C.c_void_p, C.POINTER(phz_hc_arrays)]),
+    "phz_hc_error": (C.c_char_p, [C.c_void_p]),
+    "phz_hc_free": (None, [C.c_void_p]),
+    "phz_gene_counts": (C.c_int, [C.c_void_p, C.POINTER(phz_gene_work), C.c_void_p, C.c_int]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),

@@ -1,0 +1,103 @@
+"""phaser_gene_ae drop-in (phaser_amd/gene_ae.py): native parser + K_genes + host aggregation vs what the reference's script wrote
+(tests/golden/gene_ae/*).  The GPU test runs the product path; the CPU test replaces only the kernel launch by a Python
+restatement of the same per-item rule, so that parser, pair finding, aggregation and formatting are covered without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, REPO
+from test_oracle_gene_ae import CASES, case_inputs
+
+
+def _canon(text):
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gene_ae_oracle as go
+    return go.canonical(text)
+
+
+def _items_on_cpu(P, it_lo, it_n, it_run, it_pair, it_hap, p_begin, p_end, out):
+    """What k_gene_items computes, one label at a time (test-side checker of the host stages)."""
+    for lo, n, run, pair, hap in zip(it_lo.tolist(), it_n.tolist(), it_run.tolist(), it_pair.tolist(), it_hap.tolist()):
+        pos = P.lab_pos[hap]; prev = P.lab_prev[hap]
+        fb, fe = int(p_begin[pair]), int(p_end[pair])
+        c = 0
+        for p in range(lo, lo + n):
+            x = int(pos[p]) - 1
+            if x < fb or x > fe:
+                continue
+            q = int(prev[p]); first = True
+            while q >= 0:
+                y = int(pos[run + q]) - 1
+                if fb <= y <= fe:
+                    first = False
+                    break
+                q = int(prev[run + q])
+            c += first
+        out[pair, hap] += c
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gene_ae_host_stages(name):
+    from phaser_amd import _lib, gene_ae
+    _lib.build()
+    hc, bed, kw, want = case_inputs(name)
+    got = gene_ae.gene_ae(hc.encode(), bed, threads=3, _pair_counts=_items_on_cpu, **kw)
+    assert _canon(got) == _canon(want)
+
+
+def test_parser_arrays_small():
+    from phaser_amd import _lib, gene_ae
+    _lib.build()
+    text = ("contig\tstart\tstop\tvariants\tvariantCount\tvariantsBlacklisted\tvariantCountBlacklisted\thaplotypeA\thaplotypeB\taCount\tbCount\t"
+            "totalCount\tblockGWPhase\tgwStat\tmax_haplo_maf\tbam\taReads\tbReads\n"
+            "chr1\t10\t30\tchr1_10_A_C,chr1_20_G_T,chr1_30_T_A\t3\t\t0\tA,G,T\tC,T,A\t3\t2\t5\t0|1\t0.75\t0\tx\t0,1;1,2;\t;0;0,1\n"
+            "chr1\t50\t50\tchr1_50_A_C\t1\t\t0\tA\tC\t4\t1\t5\t0/1\t1\t0\tx\t\t\n").encode()
+    P = gene_ae.ParsedCounts(text, "_", 2)
+    assert P.n_rows == 2 and P.var_pos.tolist() == [10, 20, 30, 50] and P.var_id(1) == "chr1_20_G_T"
+    assert P.lab_off[0].tolist() == [0, 4, 4] and P.lab_pos[0].tolist() == [10, 10, 20, 20] and P.lab_prev[0].tolist() == [-1, -1, 1, -1]
+    assert P.lab_off[1].tolist() == [0, 3, 3] and P.lab_pos[1].tolist() == [20, 30, 30] and P.lab_prev[1].tolist() == [-1, 0, -1]
+    assert P.phase.tolist() == [1, 0] and P.gw_stat.tolist() == [0.75, 1.0] and P.bam_names == ["x"] and P.contig_names == ["chr1"]
+
+
+def test_wrong_separator_exits():
+    from phaser_amd import _lib, gene_ae
+    _lib.build()
+    hc, bed, kw, want = case_inputs("pipe_one")
+    with pytest.raises(SystemExit):
+        gene_ae.gene_ae(hc.encode(), bed, id_separator=":", _pair_counts=_items_on_cpu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gene_ae_gpu_matches_reference(name):
+    from phaser_amd import gene_ae
+    hc, bed, kw, want = case_inputs(name)
+    got = gene_ae.gene_ae(hc.encode(), bed, **kw)
+    assert _canon(got) == _canon(want)
+
+
+@pytest.mark.gpu
+def test_gene_ae_gpu_big_block_matches_oracle():
+    """A block with far more labels than one work item holds (several items per pair, long prev chains) vs the pinned oracle."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gene_ae_oracle as go
+    from phaser_amd import gene_ae
+    rng = np.random.default_rng(5)
+    nvar = 40; pos = np.sort(rng.choice(np.arange(1000, 9000), nvar, replace=False))
+    ids = ["chr7_%d_A_G" % p for p in pos]
+    def labels(nreads):
+        groups = []
+        for v in range(nvar):
+            k = int(rng.integers(500, 1500))
+            groups.append(",".join(map(str, rng.integers(0, nreads, k).tolist())))
+        return ";".join(groups)
+    a = labels(30000); b = labels(20000)
+    head = "contig\tstart\tstop\tvariants\tvariantCount\tvariantsBlacklisted\tvariantCountBlacklisted\thaplotypeA\thaplotypeB\taCount\tbCount\ttotalCount\tblockGWPhase\tgwStat\tmax_haplo_maf\tbam\taReads\tbReads\n"
+    row = "\t".join(["chr7", str(pos[0]), str(pos[-1]), ",".join(ids), str(nvar), "", "0", ",".join("A" * nvar), ",".join("G" * nvar), "100", "100", "200",
+                     "1|0", "0.95", "0", "big", a, b]) + "\n"
+    bed = "chr7\t900\t9100\tall\nchr7\t%d\t%d\tmid\nchr7\t%d\t%d\tedge\nchr7\t100\t200\tnone\n" % (pos[5] - 1, pos[25], pos[10] - 1, pos[30] - 1)
+    hc = head + row
+    got = gene_ae.gene_ae(hc.encode(), bed)
+    assert _canon(got) == _canon(go.gene_ae(hc, bed))
