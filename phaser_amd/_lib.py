@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 PHZ_OK, PHZ_E_ARG, PHZ_E_HIP, PHZ_E_CAPACITY, PHZ_E_UNSUPPORTED, PHZ_E_NOMEM = 0, -1, -2, -3, -4, -5
 PHZ_HOST, PHZ_DEVICE = 0, 1
-PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS = 0, 1, 2, 3
+PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS, PHZ_T_GENES = 0, 1, 2, 3, 4
 
 
 class PhzError(RuntimeError):

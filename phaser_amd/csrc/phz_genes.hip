@@ -7,7 +7,7 @@
 // A label occurrence counts iff its variant is inside the feature and no EARLIER occurrence of the same label is: the
 // kernel walks the prev chain (a read covers a handful of variants, so chains are short).  Works for any subset of the
 // row's variants, in any order.  HBM-bound: 8 B per label visited (+ the chain), no reuse -> plain coalesced streaming,
-// one work item = (pair, haplotype, <= ITEM_LABELS labels) per workgroup so that a block with millions of labels spreads
+// one work item = (pair, haplotype, <= ITEM_LABELS labels) per wave so that a block with millions of labels spreads
 // over the chip; per-item partial counts are added to the pair's counter.
 #include <hip/hip_runtime.h>
 
@@ -20,9 +20,10 @@ __global__ __launch_bounds__(256) void k_gene_items(int64_t n_items, const int64
                                                      const int32_t *item_pair, const uint8_t *item_hap, const int32_t *pair_begin,
                                                      const int32_t *pair_end, const int32_t *pos_a, const int32_t *prev_a,
                                                      const int32_t *pos_b, const int32_t *prev_b, int32_t *counts) {
-    const int64_t it = blockIdx.x;
+    // one wave per work item (most rows carry a few dozen labels; the big blocks arrive pre-split into ITEM-sized slices)
+    const int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (it >= n_items) return;
-    __shared__ int s_part[4];
+    const int lane = threadIdx.x & 63;
     const int hap = item_hap[it];
     const int32_t *lab_pos = hap ? pos_b : pos_a;
     const int32_t *lab_prev = hap ? prev_b : prev_a;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void k_gene_items(int64_t n_items, const int64
     const int pair = item_pair[it];
     const int fb = pair_begin[pair], fe = pair_end[pair];
     int cnt = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = lane; i < n; i += 64) {
         const int64_t p = lo + i;
         const int x = lab_pos[p] - 1;
         if (x < fb || x > fe) continue;                       // end inclusive, as in the reference (:190)
@@ -44,12 +45,7 @@ __global__ __launch_bounds__(256) void k_gene_items(int64_t n_items, const int64
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (t) atomicAdd(&counts[2 * (int64_t)pair + hap], t);
-    }
+    if (lane == 0 && cnt) atomicAdd(&counts[2 * (int64_t)pair + hap], cnt);
 }
 
 }  // namespace
@@ -77,7 +73,7 @@ extern "C" int phz_gene_counts(phz_ctx *ctx, const phz_gene_work *w, int32_t *pa
     PHZ_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(w->n_pairs ? w->n_pairs : 1) * 8, sm));
     if (w->n_items > 0) {
         if (w->n_items >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "too many gene work items");
-        hipLaunchKernelGGL(k_gene_items, dim3((unsigned)w->n_items), dim3(256), 0, sm, w->n_items, d_lo, d_n, d_run, d_pair, d_hap, d_pb, d_pe,
+        hipLaunchKernelGGL(k_gene_items, dim3((unsigned)((w->n_items + 3) / 4)), dim3(256), 0, sm, w->n_items, d_lo, d_n, d_run, d_pair, d_hap, d_pb, d_pe,
                            d_posa, d_preva, d_posb, d_prevb, d_counts);
         PHZ_HIP(ctx, hipGetLastError());
     }

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib
 
-ITEM_LABELS = 16384
+ITEM_LABELS = 4096
 HEADER = ["contig", "start", "stop", "name", "aCount", "bCount", "totalCount", "log2_aFC", "n_variants", "variants", "gw_phased", "bam"]
 
 
@@ -95,8 +95,10 @@ def gene_ae(hc_text: bytes, features_text: str, id_separator: str = "_", gw_cuto
             _pair_counts=None) -> str:
     """_pair_counts: test hook replacing the K_genes launch (the CPU-only tests check the host stages with it); the product
     path always runs the kernel and raises without a GPU."""
+    import time as _t
     if ctx is None and _pair_counts is None:
         ctx = _lib.Context(0)                      # raises without a GPU: there is no CPU path
+    t0 = _t.perf_counter()
     # ---- features (:36-55)
     f_chr = []; f_start = []; f_stop = []; f_name = []
     for line in features_text.split("\n"):
@@ -109,6 +111,7 @@ def gene_ae(hc_text: bytes, features_text: str, id_separator: str = "_", gw_cuto
     nf = len(f_chr)
     f_start_a = np.asarray(f_start, dtype=np.int64); f_stop_a = np.asarray(f_stop, dtype=np.int64)
     P = ParsedCounts(hc_text, id_separator, threads)
+    t1 = _t.perf_counter()
     nb = len(P.bam_names)
     # ---- rows x features (:96-103): half-open overlap of [start-1, stop) with [f.start, f.stop)
     pr_row = []; pr_feat = []
@@ -148,6 +151,7 @@ def gene_ae(hc_text: bytes, features_text: str, id_separator: str = "_", gw_cuto
     inside = (x >= p_begin[owner]) & (x <= p_end[owner])
     u_pair = owner[inside]; u_var = vglob[inside]
     n_used = np.bincount(u_pair, minlength=npairs)
+    t2 = _t.perf_counter()
     # ---- distinct reads per pair and haplotype (:193-216): single-variant rows use aCount/bCount, the rest goes to the GPU
     counts = np.zeros((npairs, 2), dtype=np.int64)
     single = nvar == 1
@@ -185,6 +189,7 @@ def gene_ae(hc_text: bytes, features_text: str, id_separator: str = "_", gw_cuto
             stats["labels_visited"] = int(it_n.sum()); stats["items"] = len(it_lo)
     if stats is not None:
         stats.update({"rows": int(P.n_rows), "pairs": npairs, "features": nf, "bams": nb})
+    t3 = _t.perf_counter()
     # ---- accumulation per (BAM, feature) (:104-139)
     row = pr_row
     key = P.bam[row].astype(np.int64) * nf + pr_feat
@@ -212,6 +217,7 @@ def gene_ae(hc_text: bytes, features_text: str, id_separator: str = "_", gw_cuto
     po = np.argsort(pk, kind="stable")
     pv_sorted = u_var[up_phased][po]; pk_sorted = pk[po]
     pv_lo = np.searchsorted(pk_sorted, np.arange(size), side="left"); pv_hi = np.searchsorted(pk_sorted, np.arange(size), side="right")
+    t4 = _t.perf_counter()
     out = ["\t".join(HEADER) + "\n"]
     ids = {}
 
@@ -244,6 +250,9 @@ def gene_ae(hc_text: bytes, features_text: str, id_separator: str = "_", gw_cuto
                     vs = [vid(int(i)) for i in u_var[np.searchsorted(u_pair, bp, side="left"):np.searchsorted(u_pair, bp, side="right")]]
                     out.append("\t".join(map(str, [f_chr[fi], f_start[fi], f_stop[fi], f_name[fi], ua, ub, tc,
                                                    _zero_log(_zero_divide(ua, ub), 2), len(vs), ",".join(vs), 0, xbam])) + "\n")
+    if stats is not None:
+        stats["seconds"] = {"parse": round(t1 - t0, 3), "pairs_and_variants": round(t2 - t1, 3), "counts_incl_copies": round(t3 - t2, 3),
+                            "aggregate": round(t4 - t3, 3), "format": round(_t.perf_counter() - t4, 3)}
     return "".join(out)
 
 
