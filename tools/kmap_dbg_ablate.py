@@ -5,8 +5,8 @@ from phaser_amd import workloads
 from phaser_amd.mapper import Mapper
 v, shard, _ = workloads.make_shard("chr1", workloads.CHR1_LEN, 40_000, 50_000_000, 20240807, "cuda:0")
 m = Mapper(0); vpos = v.pos.to("cuda:0")
-calls = m.map(shard, vpos, 10); cap = calls.n + 16
-for dbg in ["0", "16", "8", "1", "2", "3", "0"]:
+calls = m.map(shard, vpos, 10); cap = 2 * calls.n
+for dbg in ["0", "1", "16", "17", "8", "2", "0"]:
     os.environ["PHZ_MAP_DBG"] = dbg
     c2 = m.map(shard, vpos, 10, cap=cap)
     m.ctx.reset_timing()
