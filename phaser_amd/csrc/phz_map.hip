@@ -329,17 +329,59 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
         base_[k] = 0; n_[k] = 0; vmask_[k] = 0; codes_[k] = 0; fast_[k] = false;
     }
     const bool walk_on = !(a.dbg & 8);
+    // Records are position-sorted, so the het SNPs any single-run record of a wave can touch lie in ONE narrow index range
+    // [lo, hi) of the window: lo = lower_bound(position of the wave's first record), hi = lower_bound(largest end).  All
+    // 2*RPT bounds come out of a single uniform-trip search (lane group g looks for bound g); each record then needs only a
+    // scan over hi - lo entries (0 for most waves: nothing under any of their records) instead of its own search.
+    int len_[RPT]; bool one_[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
         const int j = k * MAP_BLOCK + tid;
-        if (j >= nr || !walk_on) continue;
+        one_[k] = false; len_[k] = 0;
         const uint32_t d = c0_[k] - cw.c_begin;
-        if (complete && c1_[k] - c0_[k] == 1 && d < (uint32_t)CIG) {
+        if (j < nr && walk_on && complete && c1_[k] - c0_[k] == 1 && d < (uint32_t)CIG) {
             const uint32_t w = s_cig[d];
             const uint32_t op = w & 15;
-            const int len = (int)(w >> 4);
-            const int pos = rpos_[k];
-            if ((op == OP_M || op == OP_EQ || op == OP_X) && (long long)pos + len <= cover) {
+            len_[k] = (int)(w >> 4);
+            one_[k] = (op == OP_M || op == OP_EQ || op == OP_X) && (long long)rpos_[k] + len_[k] <= cover;
+        }
+    }
+    constexpr int GROUP = 64 / (2 * RPT);
+    int target = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        int e = one_[k] ? rpos_[k] + len_[k] : (int)0x80000000;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(e, d); e = y > e ? y : e; }
+        const int first = __shfl(rpos_[k], 0);
+        if ((lane / GROUP) == 2 * k) target = first;
+        if ((lane / GROUP) == 2 * k + 1) target = e;
+    }
+    int bound = 0;
+    {
+        int n = vw.wlen;
+        while (n > 1) {
+            const int half = n >> 1;
+            bound += (s_vpos[bound + half - 1] < target) ? half : 0;
+            n -= half;
+        }
+        bound += (vw.wlen > 0 && s_vpos[bound] < target) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int j = k * MAP_BLOCK + tid;
+        const int lo = __shfl(bound, 2 * k * GROUP), hi = __shfl(bound, (2 * k + 1) * GROUP);
+        if (one_[k]) {
+            const int pos = rpos_[k], end = pos + len_[k];
+            if (hi - lo <= 24) {
+                int below = 0, c = 0;
+                for (int e = lo; e < hi; e++) {
+                    const int vp = s_vpos[e];
+                    below += vp < pos ? 1 : 0;
+                    c += (vp >= pos && vp < end) ? 1 : 0;
+                }
+                if (c <= 8) { fast_[k] = true; base_[k] = lo + below; n_[k] = c; }
+            } else {
                 int base = 0, n = vw.wlen;
                 while (n > 1) {
                     const int half = n >> 1;
@@ -347,13 +389,12 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
                     n -= half;
                 }
                 base += (s_vpos[base] < pos) ? 1 : 0;
-                const int hi = pos + len;
                 int c = 0;
-                while (base + c < vw.wlen && s_vpos[base + c] < hi && c <= 8) c++;
+                while (base + c < vw.wlen && s_vpos[base + c] < end && c <= 8) c++;
                 if (c <= 8) { fast_[k] = true; base_[k] = base; n_[k] = c; }
             }
         }
-        if (!fast_[k]) s_cx[atomicAdd(&s_ncx, 1)] = (uint16_t)j;
+        if (j < nr && walk_on && !fast_[k]) s_cx[atomicAdd(&s_ncx, 1)] = (uint16_t)j;
     }
     // ---- phase 2a: resolve the fast records' bases; iteration o gathers for every lane that has an o-th SNP
 #pragma unroll
