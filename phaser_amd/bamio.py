@@ -228,6 +228,8 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
         ns = C.c_int(0)
         st = lib.phz_bam_decode(h, C.c_void_p(mask.ctypes.data), int(mapq), 0x2 if paired_end else 0, 0x400 if remove_dups else 0,
                                 float(isize_cutoff), threads, C.byref(ns))
+        if st == _lib.PHZ_E_UNSUPPORTED:
+            raise _lib.PhzError(st, "BAM is not coordinate-sorted (the mapper is a merge join over sorted reads)")
         if st != 0:
             raise _lib.PhzError(st, "BAM decode failed")
         out = {}

@@ -216,6 +216,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
     // pass 1: hop over the record chain, apply the filters, size everything
     struct Rec { size_t off; int32_t ref; uint32_t n_ops, nb; };
     std::vector<Rec> recs;
+    std::vector<int32_t> last_pos((size_t)n_ref, -1);      // the mapper is a merge join: every reference must be coordinate-sorted
     size_t p = b.first_record;
     while (p + 4 <= n) {
         const int32_t bs = rdi32(d + p);
@@ -228,6 +229,9 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
                     ((int)flag & flag_required) == flag_required && ((int)flag & flag_forbidden) == 0;
         if (keep && isize_cutoff != 0) { const double tl = tlen < 0 ? -(double)tlen : (double)tlen; keep = tl <= isize_cutoff; }
         if (keep) {
+            const int32_t pos0 = rdi32(r + 4);
+            if (pos0 < last_pos[(size_t)ref]) return PHZ_E_UNSUPPORTED;     // BAM is not coordinate-sorted
+            last_pos[(size_t)ref] = pos0;
             const uint8_t *cig = r + 32 + l_rn;
             const uint8_t *qual = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2;
             uint32_t nb;

@@ -60,6 +60,7 @@ def pack_fixed(pos: torch.Tensor, cigar_off: torch.Tensor, cigar: torch.Tensor, 
     """seq: uint8 [n, L] base codes 0..3, 4 = N;  qual: uint8 [n, L] phred."""
     n, L = seq.shape
     dev = seq.device
+    check_sorted(pos)
     Lp = (L + 3) // 4 * 4
     isn = seq > 3
     code = torch.where(isn, torch.zeros_like(seq), seq)           # SUB_N == 0
@@ -75,6 +76,15 @@ def pack_fixed(pos: torch.Tensor, cigar_off: torch.Tensor, cigar: torch.Tensor, 
                      cigar.to(torch.int32).contiguous(), seq_off, seq2.reshape(-1), q.reshape(-1).contiguous(),
                      None if qid is None else qid.to(torch.int32), None if aln_score is None else aln_score.to(torch.int32),
                      None if aln_score is None else torch.ones(n, dtype=torch.uint8, device=dev))
+
+
+def check_sorted(pos):
+    """The mapper is a merge join over coordinate-sorted records (read_variant_map.py:98-114; the reference gets them from an
+    indexed BAM region query): every packer refuses a shard with an inversion, the kernels do not re-check."""
+    if len(pos) > 1:
+        bad = bool((pos[1:] < pos[:-1]).any())
+        if bad:
+            raise ValueError("records are not coordinate-sorted")
 
 
 def pack_readbatch(rb) -> ReadShard:
@@ -166,6 +176,7 @@ def pack_sam(records: List[Tuple[int, str, str, str]]) -> ReadShard:
         seq_off[r + 1] = seq_off[r] + nbp // 4
     seq2 = np.concatenate(seq_chunks) if seq_chunks else np.zeros(0, np.uint8)
     qual = np.concatenate(qual_chunks) if qual_chunks else np.zeros(0, np.uint8)
+    check_sorted(pos)
     if seq_off[-1] >= 2 ** 31 or cigar_off[-1] >= 2 ** 31:
         raise ValueError("shard too large for 32-bit offsets; split it")
     t = torch.from_numpy

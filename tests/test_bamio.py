@@ -3,6 +3,7 @@ import gzip
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLD, gz_text
@@ -88,3 +89,24 @@ def test_native_decoder_odd_records(tmp_path):
     for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
         assert torch.equal(getattr(got, f), getattr(want, f)), f
     assert got.qid.tolist() == [0, 1, 2, 3, 0]
+
+
+def test_unsorted_inputs_are_refused(tmp_path):
+    """The mapper is a merge join over coordinate-sorted records: every packer refuses an inversion (the kernels do not re-check)."""
+    import torch
+    from phaser_amd import _lib, bamio, soa, synth
+    v, gs, ge, w = synth.make_variants("chr22", 1, 2_000_000, 100, 41, n_genes=5)
+    rb = synth.make_reads(v, gs, ge, w, 400, 42)
+    rf = rb.select(synth.samtools_keep(rb, 255))
+    soa.pack_readbatch(rf)                                   # sorted: fine
+    import dataclasses
+    bad = dataclasses.replace(rf, pos=rf.pos.flip(0))          # positions descending
+    with pytest.raises(ValueError):
+        soa.pack_readbatch(bad)
+    with pytest.raises(ValueError):
+        soa.pack_sam([(100, "4M", "ACGT", "IIII"), (50, "4M", "ACGT", "IIII")])
+    path = str(tmp_path / "u.bam")
+    bamio.readbatch_to_bam(path, [bad], [("chr22", 50818468)])
+    _lib.build()
+    with pytest.raises(_lib.PhzError):
+        bamio.shards_from_bam_native(path, {}, mapq=0, paired_end=False, remove_dups=False)
