@@ -102,16 +102,6 @@ def main():
                                             keep_sample=a.cpu_sample if (rank == 0 and world == 1) else 0)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    if sample is not None:
-        # the multi-GB host copy kept for the CPU baseline must not be duplicated into the page tables of the forked
-        # row-formatting workers of the phasing stage: mark it MADV_DONTFORK
-        import ctypes as _C
-        _libc = _C.CDLL(None, use_errno=True)
-        for t in (sample.seq, sample.qual):
-            addr = t.data_ptr(); nbytes = t.numel() * t.element_size()
-            lo = (addr + 4095) & ~4095; hi = (addr + nbytes) & ~4095
-            if hi > lo:
-                _libc.madvise(_C.c_void_p(lo), _C.c_size_t(hi - lo), 10)
     mapper = Mapper(local)
     vpos = v.pos.to(dev)
 

@@ -232,9 +232,10 @@ class Engine:
                              "different chromosome names (IE 'chr1' vs '1').")
         return float(mism) / (float(match + mism) * 2)
 
-    def finish(self, binary: bool = False) -> Optional[Dict[str, str]]:
+    def finish(self, binary: bool = False, chunks: bool = False) -> Optional[Dict[str, str]]:
         """Stages 3-6.  With torch.distributed initialised, every rank handles its own chromosomes and rank 0
-        returns the assembled files (other ranks return None).  binary=True returns bytes (no decode pass)."""
+        returns the assembled files (other ranks return None).  binary=True returns bytes (no decode pass);
+        chunks=True returns, per file, the list of buffers in output order (no join pass; write them with writelines)."""
         import time as _t
         t0 = _t.perf_counter()
         match, mism = pdist.allreduce_counts(*self.tally_all())
@@ -259,6 +260,9 @@ class Engine:
         self.stats["merge_s"] = _t.perf_counter() - t3
         self.log += summary["log"]
         self.phased = summary["phased"]; self.total_lines = summary["lines"]
+        if chunks:
+            return out
+        out = {k: b"".join(v) for k, v in out.items()}
         return out if binary else {k: v.decode() for k, v in out.items()}
 
     def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
@@ -357,7 +361,8 @@ HEAD_HAP = ['contig', 'start', 'stop', 'length', 'variants', 'variant_ids', 'var
 
 
 def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config", noise: float, n_bams: int = 1):
-    """Stage D (rank 0): assemble the five files from per-chromosome fragments in the reference's global order:
+    """Stage D (rank 0): order the per-chromosome fragments of the five files in the reference's global order (returns, per
+    file, the list of buffers to write one after the other):
     chromosomes in VCF order for connections / blocks; allelic_counts and singleton rows follow the first-appearance
     keys (BAM of the first kept line, chromosome, line), i.e. per first BAM the chromosomes in VCF order.  Works on
     the bytes the row writer produced, so it is also what the multi-GPU gather feeds."""
@@ -384,8 +389,7 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
             for c in chrom_list:
                 f = frags[c]
                 s = f[key + "_seg"]; dst.append(f[key][s[b]:s[b + 1]])
-    out = {"variant_connections": b"".join(conn), "allelic_counts": b"".join(allelic), "haplotypic_counts": b"".join(ase),
-           "haplotypes": b"".join(hap), "allele_config": b"".join(cfgf)}
+    out = {"variant_connections": conn, "allelic_counts": allelic, "haplotypic_counts": ase, "haplotypes": hap, "allele_config": cfgf}
     log = ["     sequencing noise level estimated at %f" % noise,
            "     %d variant connections dropped because of conflicting configurations (threshold = %f)" % (dropped, cfg.cc_threshold),
            "     %d variants covered by at least 1 read" % covered]

@@ -238,7 +238,7 @@ def main(argv=None):
     say("#3. Identifying connected variants...")
     say("     calculating sequencing noise level...")
     n_before = len(eng.log)
-    files = eng.finish(binary=True)
+    files = eng.finish(chunks=True)
     if files is not None:
         for line in eng.log[n_before:]:
             say(line)
@@ -247,7 +247,7 @@ def main(argv=None):
         say("#6. Outputting haplotypes...")
         for name, body in files.items():
             with open(args.o + "." + name + ".txt", "wb") as f:
-                f.write(body)
+                f.writelines(body)
         up = pc = 0
         if args.write_vcf == 1:
             from . import vcfout

@@ -26,14 +26,14 @@ for chrom, shard in shards.items():
     eng.add_shard(0, chrom, shard, int(shard.qid.max()) + 1)
 torch.cuda.synchronize(); t3 = time.perf_counter()
 eng.close_bam(0); t4 = time.perf_counter()
-files = eng.finish(binary=True); t5 = time.perf_counter()
+files = eng.finish(chunks=True); t5 = time.perf_counter()
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 for name, body in files.items():
-    open("/tmp/c3." + name + ".txt", "wb").write(body)
+    open("/tmp/c3." + name + ".txt", "wb").writelines(body)
 t6 = time.perf_counter()
 nrec = sum(s.n for s in shards.values()); ncalls = sum(sh.calls.n for c in eng.shards for sh in eng.shards[c] if sh is not None)
 print("C3 x%.2f: %d records, %d het SNPs, %d calls | generate %.1fs | vcf parse %.1fs | K_map all chroms %.3fs | AS cutoff %.3fs | "
       "tally+phasing+rows %.1fs | write %.1fs | phased %d | hot path total %.1fs -> %.0f calls/s, %.0f phased variants/s"
       % (scale, nrec, vs.het_count, ncalls, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, eng.phased, t6 - t2,
          ncalls / (t6 - t2), eng.phased / (t6 - t3)))
-print({k: len(v) for k, v in files.items()}, {k: round(v, 2) for k, v in eng.stats.items()})
+print({k: sum(len(x) for x in v) for k, v in files.items()}, {k: round(v, 2) for k, v in eng.stats.items()})
