@@ -316,6 +316,43 @@ typedef struct {
 
 int phz_gene_counts(phz_ctx *ctx, const phz_gene_work *work, int32_t *pair_counts, int space);
 
+/* ---- native het-variant loader (phaser/phaser.py:396-433 filter, :1355-1413 table, :1418-1462 per-variant fields) ----------
+ * phz_vcf_parse reads VCF text (header lines skipped) with host threads; phz_vcf_chrom hands out one chromosome's table.
+ * String columns come as pools: every item is followed by one '\n'.  pool[]: 0 unique id, 1 ID column as written, 2 rsid
+ * ('.' replaced by the unique id), 3 REF, 4 "REF,ALT..." , 5 the individual's alleles in allele-index order, 6 alleles in GT
+ * order ("-,-" when unphased), 7 GT string, 8 str(maf) as written to the table ("None" without --gw_phase_method 1),
+ * 9 str(maf number) ("0" when None), 10 the individual's first two alleles (2 items per variant).  The handle owns all memory. */
+typedef struct phz_vcf phz_vcf;
+typedef struct {
+    int32_t sample_column;            /* 0-based column of the sample */
+    const char *chrom_of_interest;    /* "" = all */
+    int32_t pass_only, include_indels;
+    const char *chr_prefix, *id_separator;
+    int32_t gw_phase_method;
+    const char *gw_af_field;
+    int32_t n_contig_ban;
+    const char *const *contig_ban;    /* strings that must not occur in a contig name (:386-392) */
+    int32_t threads;
+    int32_t grep_hom;                 /* 1: drop lines whose columns 1-9 + sample hold "0|0" or "1|1" (the grep of :220-225) */
+} phz_vcf_opts;
+typedef struct {
+    const char *name;                 /* chr_prefix + CHROM */
+    int64_t n;
+    const int32_t *pos;
+    const uint8_t *ref_len, *a0, *a1; /* len(REF) capped at 255; base code of the individual's allele 0 / 1 (255 = not one ACGT base) */
+    const uint8_t *is_ref;            /* [2n] */
+    const int8_t *phase_idx;          /* [2n] */
+    const double *maf;
+    const char *pool[11];
+    int64_t pool_len[11];
+} phz_vcf_table;
+
+int phz_vcf_parse(const char *text, int64_t len, const phz_vcf_opts *opts, phz_vcf **out);
+int phz_vcf_summary(const phz_vcf *h, int32_t *n_chroms, int64_t *het, int64_t *filter_count, int64_t *indels_excluded, int64_t *unphased);
+int phz_vcf_chrom(const phz_vcf *h, int32_t i, phz_vcf_table *table);
+const char *phz_vcf_error(const phz_vcf *h);
+void phz_vcf_free(phz_vcf *h);
+
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
 int phz_reset_timing(phz_ctx *ctx);

@@ -110,6 +110,17 @@ class phz_gene_work(C.Structure):
                 ("lab_prev_a", C.c_void_p), ("lab_pos_b", C.c_void_p), ("lab_prev_b", C.c_void_p)]
 
 
+class phz_vcf_opts(C.Structure):
+    _fields_ = [("sample_column", C.c_int32), ("chrom_of_interest", C.c_char_p), ("pass_only", C.c_int32), ("include_indels", C.c_int32),
+                ("chr_prefix", C.c_char_p), ("id_separator", C.c_char_p), ("gw_phase_method", C.c_int32), ("gw_af_field", C.c_char_p),
+                ("n_contig_ban", C.c_int32), ("contig_ban", C.POINTER(C.c_char_p)), ("threads", C.c_int32), ("grep_hom", C.c_int32)]
+
+
+class phz_vcf_table(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("n", C.c_int64), ("pos", C.c_void_p), ("ref_len", C.c_void_p), ("a0", C.c_void_p), ("a1", C.c_void_p),
+                ("is_ref", C.c_void_p), ("phase_idx", C.c_void_p), ("maf", C.c_void_p), ("pool", C.c_void_p * 11), ("pool_len", C.c_int64 * 11)]
+
+
 PHZ_AS_BINS = 65536
 
 # every symbol include/phz.h declares: name -> (restype, argtypes)
@@ -152,6 +163,12 @@ SYMBOLS = {
     "phz_hc_error": (C.c_char_p, [C.c_void_p]),
     "phz_hc_free": (None, [C.c_void_p]),
     "phz_gene_counts": (C.c_int, [C.c_void_p, C.POINTER(phz_gene_work), C.c_void_p, C.c_int]),
+    "phz_vcf_parse": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(phz_vcf_opts), C.POINTER(C.c_void_p)]),
+    "phz_vcf_summary": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int64)]),
+    "phz_vcf_chrom": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(phz_vcf_table)]),
+    "phz_vcf_error": (C.c_char_p, [C.c_void_p]),
+    "phz_vcf_free": (None, [C.c_void_p]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),

@@ -1,0 +1,326 @@
+// Native het-variant loader (host side of SURVEY.md 8(a) M0): VCF text -> per-chromosome variant tables, multi-threaded.
+// Restates the filter of phaser/phaser.py:396-433 (GT present, no '.', more than one distinct allele character, FILTER holds
+// PASS unless --pass_only 0), the table of generate_mapping_table :1355-1413 (unique id, SNP-only unless --include_indels,
+// maf from the INFO AF field only with --gw_phase_method 1) and the per-variant fields generate_variant_dict :1418-1462
+// derives from a table row (individual's alleles in allele-index order, alleles in GT order when phased, maf number).
+// Strings are handed back as separator-joined pools (one '\n' after every item), numbers as arrays.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "phz.h"
+
+namespace {
+
+struct Cols {
+    std::vector<int32_t> pos;
+    std::vector<uint8_t> ref_len, a0, a1, is_ref;      // is_ref: 2 per variant
+    std::vector<int8_t> phase_idx;                    // 2 per variant
+    std::vector<double> maf;
+    std::string uid, rsid_field, rsid, ref, all_alleles, alleles, phase, gt, maf_text, maf_str, allele2;
+    int64_t n = 0;
+    void append(const Cols &o) {
+        pos.insert(pos.end(), o.pos.begin(), o.pos.end()); ref_len.insert(ref_len.end(), o.ref_len.begin(), o.ref_len.end());
+        a0.insert(a0.end(), o.a0.begin(), o.a0.end()); a1.insert(a1.end(), o.a1.begin(), o.a1.end());
+        is_ref.insert(is_ref.end(), o.is_ref.begin(), o.is_ref.end()); phase_idx.insert(phase_idx.end(), o.phase_idx.begin(), o.phase_idx.end());
+        maf.insert(maf.end(), o.maf.begin(), o.maf.end());
+        uid += o.uid; rsid_field += o.rsid_field; rsid += o.rsid; ref += o.ref; all_alleles += o.all_alleles; alleles += o.alleles;
+        phase += o.phase; gt += o.gt; maf_text += o.maf_text; maf_str += o.maf_str; allele2 += o.allele2;
+        n += o.n;
+    }
+};
+
+struct Chunk {
+    std::vector<std::string> names;                 // chromosomes in first-appearance order within the chunk
+    std::vector<Cols> cols;
+    std::unordered_map<std::string, int> idx;
+    int64_t filter_count = 0, unphased = 0, excluded = 0;
+    int status = 0; std::string error;
+};
+
+// repr(float): shortest round-trip digits, fixed notation for 1e-4 <= |x| < 1e16 (same routine as the row writer's)
+void put_pyfloat(std::string &s, double x) {
+    if (std::isnan(x)) { s += "nan"; return; }
+    if (std::isinf(x)) { s += x < 0 ? "-inf" : "inf"; return; }
+    if (x == 0) { s += std::signbit(x) ? "-0.0" : "0.0"; return; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + 64, x, std::chars_format::scientific);
+    std::string_view v(buf, (size_t)(r.ptr - buf));
+    if (v[0] == '-') { s += '-'; v.remove_prefix(1); }
+    const size_t epos = v.find('e');
+    std::string digits(1, v[0]);
+    if (epos > 2) digits.append(v.substr(2, epos - 2));
+    const int exp = atoi(std::string(v.substr(epos + 1)).c_str());
+    if (exp >= -4 && exp < 16) {
+        if (exp >= 0) {
+            if ((int)digits.size() <= exp + 1) { s += digits; s.append((size_t)(exp + 1) - digits.size(), '0'); s += ".0"; }
+            else { s.append(digits, 0, (size_t)exp + 1); s += '.'; s.append(digits, (size_t)exp + 1, std::string::npos); }
+        } else { s += "0."; s.append((size_t)(-exp - 1), '0'); s += digits; }
+    } else {
+        s += digits[0];
+        if (digits.size() > 1) { s += '.'; s.append(digits, 1, std::string::npos); }
+        s += 'e'; s += exp < 0 ? '-' : '+';
+        const int a = abs(exp);
+        if (a < 10) s += '0';
+        char b2[16]; auto r2 = std::to_chars(b2, b2 + 16, a); s.append(b2, (size_t)(r2.ptr - b2));
+    }
+}
+
+void split(std::string_view s, char sep, std::vector<std::string_view> &out) {
+    out.clear();
+    size_t i = 0;
+    while (true) {
+        size_t j = s.find(sep, i);
+        if (j == std::string_view::npos) { out.push_back(s.substr(i)); break; }
+        out.push_back(s.substr(i, j - i)); i = j + 1;
+    }
+}
+
+// Python float(): accepts surrounding whitespace, inf/nan spellings; here: strtod over the whole token
+bool py_float(std::string_view s, double *out) {
+    std::string t(s);
+    size_t a = 0, b = t.size();
+    while (a < b && isspace((unsigned char)t[a])) a++;
+    while (b > a && isspace((unsigned char)t[b - 1])) b--;
+    if (a == b) return false;
+    t = t.substr(a, b - a);
+    char *e = nullptr;
+    *out = strtod(t.c_str(), &e);
+    return *e == 0;
+}
+
+inline uint8_t base_code(std::string_view s) {
+    if (s.size() != 1) return 255;
+    switch (s[0]) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 255; }
+}
+
+void parse_lines(const char *text, const std::vector<int64_t> &ls, size_t lo, size_t hi, const phz_vcf_opts &O, Chunk &c) {
+    std::vector<std::string_view> f, fmt, sf, alts, every, info, ind, ph, afs_s;
+    std::vector<char> g;
+    std::vector<double> afs;
+    const std::string_view coi(O.chrom_of_interest ? O.chrom_of_interest : ""), prefix(O.chr_prefix ? O.chr_prefix : ""),
+        sep(O.id_separator ? O.id_separator : "_"), af_field(O.gw_af_field ? O.gw_af_field : "AF");
+    for (size_t li = lo; li < hi; li++) {
+        const char *p = text + ls[li]; const char *e = text + ls[li + 1] - 1;
+        if (e <= p || *p == '#') continue;
+        split(std::string_view(p, (size_t)(e - p)), '\t', f);
+        if (O.grep_hom) {      // cut -f 1-9,S | grep -v '0|0\|1|1' (phaser.py:220-225): the pattern anywhere in those columns drops the line
+            bool hom = false;
+            for (size_t k = 0; k < f.size(); k++)
+                if (k < 9 || (int)k == O.sample_column)
+                    if (f[k].find("0|0") != std::string_view::npos || f[k].find("1|1") != std::string_view::npos) hom = true;
+            if (hom) continue;
+        }
+        const std::string_view chrom0 = f[0];
+        for (int b = 0; b < O.n_contig_ban; b++)
+            if (chrom0.find(O.contig_ban[b]) != std::string_view::npos) {
+                c.status = PHZ_E_ARG;
+                c.error = std::string("     FATAL ERROR: Character '") + O.contig_ban[b] + "' must not be present in contig name. Please change id separtor "
+                          "using --id_separator to a character not found in the contig names and try again.";
+                return;
+            }
+        if (!coi.empty() && coi != chrom0) continue;
+        std::string chrom(prefix); chrom += chrom0;
+        auto it = c.idx.find(chrom);
+        int ci;
+        if (it == c.idx.end()) { ci = (int)c.names.size(); c.idx.emplace(chrom, ci); c.names.push_back(chrom); c.cols.emplace_back(); }
+        else ci = it->second;
+        if ((int)f.size() <= 8 || (int)f.size() <= O.sample_column) { c.status = PHZ_E_ARG; c.error = "VCF line with too few columns"; return; }
+        split(f[8], ':', fmt);
+        int gti = -1;
+        for (size_t k = 0; k < fmt.size(); k++) if (fmt[k] == "GT") { gti = (int)k; break; }
+        if (gti < 0) continue;
+        split(f[(size_t)O.sample_column], ':', sf);
+        if (gti >= (int)sf.size()) { c.status = PHZ_E_ARG; c.error = "VCF sample column has fewer fields than FORMAT"; return; }
+        const std::string_view geno = sf[(size_t)gti];
+        g.assign(geno.begin(), geno.end());
+        if (std::find(g.begin(), g.end(), '.') != g.end()) continue;
+        bool phased = false, is_unphased = false;
+        { auto q = std::find(g.begin(), g.end(), '|'); if (q != g.end()) { phased = true; g.erase(q); } }       // list.remove: first one only
+        { auto q = std::find(g.begin(), g.end(), '/'); if (q != g.end()) { is_unphased = true; g.erase(q); } }
+        {
+            bool distinct = false;
+            for (size_t k = 1; k < g.size(); k++) if (g[k] != g[0]) distinct = true;
+            if (!distinct) continue;
+        }
+        if (O.pass_only != 0) {
+            split(f[6], ';', info);
+            bool pass = false;
+            for (auto &x : info) if (x == "PASS") pass = true;
+            if (!pass) { c.filter_count++; continue; }
+        }
+        c.unphased += is_unphased ? 1 : 0;
+        split(f[4], ',', alts);
+        every.clear(); every.push_back(f[3]);
+        for (auto &x : alts) every.push_back(x);
+        size_t maxlen = 0;
+        for (auto &x : every) maxlen = std::max(maxlen, x.size());
+        if (!(maxlen == 1 || O.include_indels == 1)) { c.excluded++; continue; }
+        Cols &K = c.cols[(size_t)ci];
+        // maf (:1381-1396)
+        bool have_maf = false; double maf = 0;
+        if (O.gw_phase_method == 1) {
+            split(f[7], ';', info);
+            std::string_view val; bool found = false;
+            for (auto &item : info) {
+                const size_t eq = item.find('=');
+                if (eq == std::string_view::npos) continue;
+                if (item.substr(0, eq) == af_field) {              // later duplicates overwrite earlier ones (dict)
+                    const size_t eq2 = item.find('=', eq + 1);
+                    val = item.substr(eq + 1, (eq2 == std::string_view::npos ? item.size() : eq2) - eq - 1);
+                    found = true;
+                }
+            }
+            if (found) {
+                split(val, ',', afs_s);
+                afs.clear();
+                for (auto &x : afs_s) { double d; if (!py_float(x, &d)) { c.status = PHZ_E_ARG; c.error = "could not convert AF value to float"; return; } afs.push_back(d); }
+                if (afs.size() == alts.size()) {
+                    bool any = false; double best = 0;
+                    for (char ch : g) {
+                        if (ch < '0' || ch > '9') { c.status = PHZ_E_ARG; c.error = "genotype character is not an allele index"; return; }
+                        const int ai = ch - '0';
+                        if (ai == 0) continue;
+                        if (ai - 1 >= (int)afs.size()) { c.status = PHZ_E_ARG; c.error = "genotype allele index beyond ALT"; return; }
+                        const double a = afs[(size_t)ai - 1], m = a < 1 - a ? a : 1 - a;      // min(af, 1 - af), first argument wins ties
+                        if (!any || m < best) { best = m; any = true; }
+                    }
+                    if (any) { have_maf = true; maf = best; }
+                }
+            }
+        }
+        // the individual's alleles in allele-index order (:1433-1435), alleles in GT order when phased (:1437-1443)
+        ind.clear();
+        for (size_t i = 0; i < every.size() && i < 10; i++)
+            if (std::find(g.begin(), g.end(), (char)('0' + i)) != g.end()) ind.push_back(every[i]);
+        ph.clear();
+        if (phased) {
+            for (char ch : g) {
+                if (ch < '0' || ch > '9' || (size_t)(ch - '0') >= every.size()) { c.status = PHZ_E_ARG; c.error = "genotype allele index beyond ALT"; return; }
+                ph.push_back(every[(size_t)(ch - '0')]);
+            }
+        } else { ph.push_back("-"); ph.push_back("-"); }
+        long long posv = 0;
+        { std::string t(f[1]); char *e2 = nullptr; posv = strtoll(t.c_str(), &e2, 10); if (t.empty() || *e2) { c.status = PHZ_E_ARG; c.error = "VCF POS is not an integer"; return; } }
+        K.pos.push_back((int32_t)posv);
+        K.ref_len.push_back((uint8_t)std::min<size_t>(255, f[3].size()));
+        std::string uid(chrom); uid += sep; uid += f[1];
+        for (auto &x : every) { uid += sep; uid += x; }
+        K.uid += uid; K.uid += '\n';
+        K.rsid_field += f[2]; K.rsid_field += '\n';
+        if (f[2] == "." || f[2].empty()) K.rsid += uid; else K.rsid += f[2];
+        K.rsid += '\n';
+        K.ref += f[3]; K.ref += '\n';
+        for (size_t i = 0; i < every.size(); i++) { if (i) K.all_alleles += ','; K.all_alleles += every[i]; }
+        K.all_alleles += '\n';
+        for (size_t i = 0; i < ind.size(); i++) { if (i) K.alleles += ','; K.alleles += ind[i]; }
+        K.alleles += '\n';
+        for (size_t i = 0; i < ph.size(); i++) { if (i) K.phase += ','; K.phase += ph[i]; }
+        K.phase += '\n';
+        K.gt += geno; K.gt += '\n';
+        if (have_maf) { put_pyfloat(K.maf_text, maf); put_pyfloat(K.maf_str, maf); K.maf.push_back(maf); }
+        else { K.maf_text += "None"; K.maf_str += '0'; K.maf.push_back(0.0); }
+        K.maf_text += '\n'; K.maf_str += '\n';
+        const std::string_view i0 = ind.size() > 0 ? ind[0] : std::string_view(), i1 = ind.size() > 1 ? ind[1] : std::string_view();
+        K.allele2 += i0; K.allele2 += '\n'; K.allele2 += i1; K.allele2 += '\n';
+        K.a0.push_back(ind.size() > 0 ? base_code(i0) : 255); K.a1.push_back(ind.size() > 1 ? base_code(i1) : 255);
+        K.is_ref.push_back(i0 == f[3] ? 1 : 0); K.is_ref.push_back(i1 == f[3] ? 1 : 0);
+        auto pidx = [&](std::string_view a) -> int8_t { for (size_t k = 0; k < ph.size(); k++) if (ph[k] == a) return (int8_t)k; return -1; };
+        K.phase_idx.push_back(pidx(i0)); K.phase_idx.push_back(pidx(i1));
+        K.n++;
+    }
+}
+
+}  // namespace
+
+struct phz_vcf {
+    std::vector<std::string> names;
+    std::vector<Cols> cols;
+    int64_t filter_count = 0, unphased = 0, excluded = 0, het = 0;
+    int status = 0; std::string error;
+};
+
+extern "C" int phz_vcf_parse(const char *text, int64_t len, const phz_vcf_opts *opts, phz_vcf **out) {
+    if (!text || len < 0 || !opts || !out) return PHZ_E_ARG;
+    phz_vcf *h = new phz_vcf();
+    *out = h;
+    std::vector<int64_t> ls(1, 0);
+    for (const char *p = text, *e = text + len; p < e;) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!nl) { ls.push_back(len + 1); break; }
+        ls.push_back((int64_t)(nl - text) + 1); p = nl + 1;
+    }
+    const size_t nlines = ls.size() - 1;
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, opts->threads), (nlines + 8191) / 8192));
+    const size_t nchunks = nlines ? (size_t)nt * 4 : 0;
+    std::vector<Chunk> ch(nchunks);
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= nchunks) break;
+            parse_lines(text, ls, nlines * i / nchunks, nlines * (i + 1) / nchunks, *opts, ch[i]);
+        }
+    };
+    if (nt == 1) work();
+    else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto &t : th) t.join(); }
+    std::unordered_map<std::string, int> idx;
+    for (auto &c : ch) {
+        if (c.status) { h->status = c.status; h->error = c.error; return h->status; }
+        h->filter_count += c.filter_count; h->unphased += c.unphased; h->excluded += c.excluded;
+        for (size_t k = 0; k < c.names.size(); k++) {
+            auto it = idx.find(c.names[k]);
+            int gi;
+            if (it == idx.end()) { gi = (int)h->names.size(); idx.emplace(c.names[k], gi); h->names.push_back(c.names[k]); h->cols.emplace_back(); }
+            else gi = it->second;
+            h->cols[(size_t)gi].append(c.cols[k]);
+        }
+        c = Chunk();
+    }
+    for (size_t k = 0; k < h->names.size(); k++) {
+        const Cols &K = h->cols[k];
+        h->het += K.n;
+        for (size_t i = 1; i < K.pos.size(); i++)
+            if (K.pos[i] < K.pos[i - 1]) {
+                h->status = PHZ_E_ARG;
+                h->error = "     FATAL ERROR: VCF records of " + h->names[k] + " are not sorted by position.";
+                return h->status;
+            }
+    }
+    return PHZ_OK;
+}
+
+extern "C" int phz_vcf_summary(const phz_vcf *h, int32_t *n_chroms, int64_t *het, int64_t *filter_count, int64_t *indels_excluded, int64_t *unphased) {
+    if (!h) return PHZ_E_ARG;
+    if (n_chroms) *n_chroms = (int32_t)h->names.size();
+    if (het) *het = h->het;
+    if (filter_count) *filter_count = h->filter_count;
+    if (indels_excluded) *indels_excluded = h->excluded;
+    if (unphased) *unphased = h->unphased;
+    return PHZ_OK;
+}
+
+extern "C" int phz_vcf_chrom(const phz_vcf *h, int32_t i, phz_vcf_table *t) {
+    if (!h || !t || i < 0 || (size_t)i >= h->names.size()) return PHZ_E_ARG;
+    const Cols &K = h->cols[(size_t)i];
+    memset(t, 0, sizeof(*t));
+    t->name = h->names[(size_t)i].c_str(); t->n = K.n;
+    t->pos = K.pos.data(); t->ref_len = K.ref_len.data(); t->a0 = K.a0.data(); t->a1 = K.a1.data(); t->is_ref = K.is_ref.data();
+    t->phase_idx = K.phase_idx.data(); t->maf = K.maf.data();
+    const std::string *pools[11] = {&K.uid, &K.rsid_field, &K.rsid, &K.ref, &K.all_alleles, &K.alleles, &K.phase, &K.gt, &K.maf_text, &K.maf_str, &K.allele2};
+    for (int k = 0; k < 11; k++) { t->pool[k] = pools[k]->data(); t->pool_len[k] = (int64_t)pools[k]->size(); }
+    return PHZ_OK;
+}
+
+extern "C" const char *phz_vcf_error(const phz_vcf *h) { return h ? h->error.c_str() : ""; }
+
+extern "C" void phz_vcf_free(phz_vcf *h) { delete h; }

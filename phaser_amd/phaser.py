@@ -128,37 +128,42 @@ def main(argv=None):
     say('STARTED "Read backed phasing and ASE/haplotype analyses" ... ')
     say("    DATE, TIME : %s" % (datetime.datetime.now().strftime('%Y-%m-%d, %H:%M:%S')))
     say("#1. Loading heterozygous variants into intervals...")
-    text = vcf.read_text(args.vcf)
+    data = vcf.read_bytes(args.vcf)
     sample_col = None
-    for line in text.split("\n"):
-        if "#CHR" in line:
-            cols = line.rstrip().split("\t")
+    for raw in data.split(b"\n", 20000)[:20000]:          # the header sits at the top
+        if b"#CHR" in raw:
+            cols = raw.decode().rstrip().split("\t")
             m = {cols[i]: i for i in range(9, len(cols))}
             if args.sample not in m:
                 fatal_error("Sample '%s' not found in the input VCF file." % args.sample)
             sample_col = m[args.sample]
             break
+        if raw and raw[0:1] != b"#":
+            break
     if sample_col is None:
         fatal_error("Sample '%s' not found in the input VCF file." % args.sample)
-    # cut -f 1-9,S | grep -v '0|0\|1|1' [| bedtools intersect -v]   (phaser.py:220-225)
+    # cut -f 1-9,S | grep -v '0|0\|1|1' [| bedtools intersect -v]   (phaser.py:220-225): the cut + grep run inside the native
+    # loader; only a --blacklist needs the lines here first
     bl = load_bed(args.blacklist) if args.blacklist != "" else None
-    kept = []
-    for line in text.split("\n"):
-        if not line:
-            continue
-        if line[0] == "#":
-            continue
-        c = line.split("\t")
-        cut = "\t".join(c[0:9] + [c[sample_col]])
-        if "0|0" in cut or "1|1" in cut:
-            continue
-        if bl is not None and overlaps(bl, c[0], int(c[1]), len(c[3])):
-            continue
-        kept.append(cut)
-    vtext = "\n".join(kept)
-    vs = vcf.load_variants(vtext, sample_column=9, chrom_of_interest=args.chr, pass_only=args.pass_only,
-                           include_indels=args.include_indels, chr_prefix=args.chr_prefix, id_separator=args.id_separator,
-                           gw_phase_method=args.gw_phase_method, gw_af_field=args.gw_af_field, contig_ban=(args.id_separator, ":"))
+    kept = None
+    load_kw = dict(chrom_of_interest=args.chr, pass_only=args.pass_only, include_indels=args.include_indels, chr_prefix=args.chr_prefix,
+                   id_separator=args.id_separator, gw_phase_method=args.gw_phase_method, gw_af_field=args.gw_af_field,
+                   contig_ban=(args.id_separator, ":"), threads=max(1, args.threads))
+    if bl is None and args.haplo_count_blacklist == "":
+        vs = vcf.load_variants(data, sample_column=sample_col, grep_hom=True, **load_kw)
+    else:
+        kept = []
+        for line in data.decode().split("\n"):
+            if not line or line[0] == "#":
+                continue
+            c = line.split("\t")
+            cut = "\t".join(c[0:9] + [c[sample_col]])
+            if "0|0" in cut or "1|1" in cut:
+                continue
+            if bl is not None and overlaps(bl, c[0], int(c[1]), len(c[3])):
+                continue
+            kept.append(cut)
+        vs = vcf.load_variants("\n".join(kept), sample_column=9, **load_kw)
     haplo_bl = set()
     if args.haplo_count_blacklist != "":
         say("#1b. Loading haplotypic count blacklist intervals...")
@@ -259,7 +264,7 @@ def main(argv=None):
             else:
                 say("     GT field is not being updated with phASER genome wide phase. This can be changed using the --gw_phase_vcf argument.")
             cut_lines = []
-            for line in text.split("\n"):
+            for line in data.decode().split("\n"):
                 if not line:
                     continue
                 if line.startswith("##"):

@@ -1,87 +1,24 @@
 """Het-variant loading for the hot path: VCF text -> per-chromosome variant tables.
 
-Mirrors the filter of phaser/phaser.py:396-433 (GT present, no '.', more than one distinct allele,
-FILTER contains PASS unless --pass_only 0) and the table of generate_mapping_table :1355-1413
-(unique id, SNP-only unless --include_indels), plus the per-variant fields the phasing core derives
-from a call line in generate_variant_dict :1418-1462.
+The work is done by the native loader in libphz.so (phz_vcf_parse, phaser_amd/csrc/phz_vcf.cpp, host threads): the filter
+of phaser/phaser.py:396-433 (GT present, no '.', more than one distinct allele, FILTER contains PASS unless
+--pass_only 0), the table of generate_mapping_table :1355-1413 (unique id, SNP-only unless --include_indels) and the
+per-variant fields the phasing core derives from a table row in generate_variant_dict :1418-1462.  This module wraps the
+result: numeric columns are numpy arrays, string columns stay in the library's separator-joined pools (which is what the
+native row writer reads) and turn into Python lists only when somebody asks for them.
 """
 from __future__ import annotations
 
-import dataclasses
+import ctypes as C
 import gzip
 from typing import Dict, List
 
 import numpy as np
 
-_CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+from . import _lib
 
-
-@dataclasses.dataclass
-class ChromVariants:
-    chrom: str
-    pos: np.ndarray            # int32, VCF order (must be sorted for the mapper)
-    uid: List[str]
-    rsid_field: List[str]      # column 3 as written ('.' allowed)
-    rsid: List[str]            # '.'/'' replaced by uid (:1451-1455)
-    ref: List[str]
-    all_alleles: List[List[str]]
-    alleles: List[List[str]]   # the individual's alleles in allele-index order (:1430-1435)
-    phase: List[List[str]]     # alleles in GT order, or ['-','-'] when unphased (:1437-1443)
-    gt: List[str]
-    maf_text: List[str]        # str(maf) as written to the table ('None' unless --gw_phase_method 1)
-    maf: List[object]          # float, or int 0 when not parseable (:1445-1449)
-    ref_len: np.ndarray        # uint8
-    a0: np.ndarray             # uint8 base code of alleles[0] (255 when not a single ACGT base)
-    a1: np.ndarray
-    is_ref: np.ndarray = None      # uint8 [2n]: alleles[k] == REF, index 2*v + k
-    phase_idx: np.ndarray = None   # int8 [2n]: position of alleles[k] in the VCF phase, -1 when unphased
-    _pools: dict = None
-
-    def pools(self):
-        """Separator-joined string pools of the per-variant texts the native row writer prints (phz_rows_format)."""
-        if self._pools is None:
-            flat = []
-            for al in self.alleles:
-                flat.append(al[0] if len(al) > 0 else ""); flat.append(al[1] if len(al) > 1 else "")
-            self._pools = {"uid": sep_pool(self.uid), "rsid": sep_pool(self.rsid), "allele": sep_pool(flat),
-                           "maf": sep_pool([str(x) for x in self.maf]),
-                           "maf_val": np.asarray([float(x) for x in self.maf], dtype=np.float64)}
-        return self._pools
-
-    def __len__(self):
-        return len(self.uid)
-
-    @property
-    def is_general(self) -> bool:
-        """True when the set is not pure SNPs (some REF longer than one base or some allele not a single ACGT base):
-        such sets go through the general mapper (phz_map_reads_general)."""
-        return bool((self.ref_len != 1).any() or (self.a0 == 255).any() or (self.a1 == 255).any())
-
-    def allele_pool(self):
-        """-> (allele_off uint32 [2n+1], allele_bytes uint8) of the individual's two alleles per variant."""
-        off = np.zeros(2 * len(self) + 1, dtype=np.uint32)
-        parts = []
-        o = 0
-        for i, al in enumerate(self.alleles):
-            a0 = al[0].encode() if len(al) > 0 else b""
-            a1 = al[1].encode() if len(al) > 1 else b""
-            off[2 * i] = o; o += len(a0); off[2 * i + 1] = o; o += len(a1)
-            parts.append(a0); parts.append(a1)
-        off[2 * len(self)] = o
-        return off, np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8).copy()
-
-    def table_rows(self):
-        return [[self.chrom, str(int(self.pos[i])), self.uid[i], self.rsid_field[i], ",".join(self.all_alleles[i]),
-                 str(int(self.ref_len[i])), self.gt[i], self.maf_text[i]] for i in range(len(self))]
-
-
-@dataclasses.dataclass
-class VariantSet:
-    chroms: "Dict[str, ChromVariants]"       # insertion order = VCF order
-    het_count: int
-    filter_count: int
-    indels_excluded: int
-    unphased_count: int
+_POOLS = ("uid", "rsid_field", "rsid", "ref", "all_alleles", "alleles", "phase", "gt", "maf_text", "maf_str", "allele2")
+_SPLIT = ("all_alleles", "alleles", "phase")              # pools whose items are comma-joined lists
 
 
 def sep_pool(strs):
@@ -89,184 +26,137 @@ def sep_pool(strs):
     if not strs:
         return np.zeros(1, dtype=np.uint32), b"\n"
     b = ("\n".join(strs) + "\n").encode()
+    return pool_offsets(b, len(strs)), b
+
+
+def pool_offsets(b: bytes, n: int) -> np.ndarray:
     ends = np.flatnonzero(np.frombuffer(b, dtype=np.uint8) == 10)
-    if len(ends) != len(strs) or len(b) >= 2 ** 32:
+    if len(ends) != n or len(b) >= 2 ** 32:
         raise ValueError("string table holds a newline or exceeds 4 GiB")
-    off = np.empty(len(strs) + 1, dtype=np.uint32)
+    off = np.empty(n + 1, dtype=np.uint32)
     off[0] = 0; off[1:] = ends + 1
-    return off, b
+    return off
+
+
+class ChromVariants:
+    """One chromosome's het-variant table.  Arrays: pos int32 (VCF order, sorted), ref_len uint8, a0 / a1 uint8 base codes of
+    the individual's two alleles (255 = not a single ACGT base), is_ref uint8 [2n], phase_idx int8 [2n], maf_val float64.
+    String columns (lists, built on first use): uid, rsid_field (ID as written), rsid ('.' replaced by uid, :1451-1455), ref,
+    all_alleles, alleles (individual's, allele-index order, :1430-1435), phase (GT order or ['-','-'], :1437-1443), gt,
+    maf_text (str(maf) as written to the table), maf (float, or int 0 when not parseable, :1445-1449)."""
+
+    def __init__(self, chrom: str, arrays: Dict[str, np.ndarray], raw: Dict[str, bytes]):
+        self.chrom = chrom
+        self.pos = arrays["pos"]; self.ref_len = arrays["ref_len"]; self.a0 = arrays["a0"]; self.a1 = arrays["a1"]
+        self.is_ref = arrays["is_ref"]; self.phase_idx = arrays["phase_idx"]; self.maf_val = arrays["maf"]
+        self._raw = raw
+        self._pools = None
+
+    def __len__(self):
+        return len(self.pos)
+
+    def __getattr__(self, name):
+        if name in _POOLS and name != "allele2":
+            text = self._raw[name].decode()
+            items = text.split("\n")[:-1] if text else []
+            if name in _SPLIT:
+                items = [x.split(",") if x else [] for x in items]
+            setattr(self, name, items)
+            return items
+        if name == "maf":
+            vals = [0 if t == "0" else float(t) for t in self.__getattr__("maf_str")] if len(self) else []
+            setattr(self, "maf", vals)
+            return vals
+        raise AttributeError(name)
+
+    @property
+    def is_general(self) -> bool:
+        """True when the set is not pure SNPs (some REF longer than one base or some allele not a single ACGT base):
+        such sets go through the general mapper (phz_map_reads_general)."""
+        return bool((self.ref_len != 1).any() or (self.a0 == 255).any() or (self.a1 == 255).any())
+
+    def pools(self):
+        """Separator-joined string pools of the per-variant texts the native row writer prints (phz_rows_format)."""
+        if self._pools is None:
+            n = len(self)
+            self._pools = {"uid": (pool_offsets(self._raw["uid"], n), self._raw["uid"]),
+                           "rsid": (pool_offsets(self._raw["rsid"], n), self._raw["rsid"]),
+                           "allele": (pool_offsets(self._raw["allele2"], 2 * n), self._raw["allele2"]),
+                           "maf": (pool_offsets(self._raw["maf_str"], n), self._raw["maf_str"]),
+                           "maf_val": self.maf_val}
+        return self._pools
+
+    def allele_pool(self):
+        """-> (allele_off uint32 [2n+1], allele_bytes uint8) of the individual's two alleles per variant, no separators
+        (the layout phz_variants_general wants)."""
+        off, b = self.pools()["allele"]
+        a = np.frombuffer(b, dtype=np.uint8)
+        keep = a != 10
+        out_off = (off.astype(np.int64) - np.arange(len(off), dtype=np.int64)).astype(np.uint32)      # one separator dropped per item
+        return out_off, np.concatenate([a[keep], np.zeros(1, dtype=np.uint8)])
+
+    def table_rows(self):
+        return [[self.chrom, str(int(self.pos[i])), self.uid[i], self.rsid_field[i], ",".join(self.all_alleles[i]),
+                 str(int(self.ref_len[i])), self.gt[i], self.maf_text[i]] for i in range(len(self))]
+
+
+class VariantSet:
+    def __init__(self, chroms, het_count, filter_count, indels_excluded, unphased_count):
+        self.chroms: Dict[str, ChromVariants] = chroms      # insertion order = VCF order
+        self.het_count = het_count; self.filter_count = filter_count
+        self.indels_excluded = indels_excluded; self.unphased_count = unphased_count
 
 
 def read_text(path: str) -> str:
+    return read_bytes(path).decode()
+
+
+def read_bytes(path: str) -> bytes:
     if path.endswith(".gz") or path.endswith(".bgz"):
-        with gzip.open(path, "rt") as f:
+        with gzip.open(path, "rb") as f:
             return f.read()
-    with open(path) as f:
+    with open(path, "rb") as f:
         return f.read()
 
 
-def _load_chunk(task):
-    """Filter + table fields for a slice of VCF lines -> ({chrom: column lists}, filter_count, unphased, excluded)."""
-    (lines, sample_column, chrom_of_interest, pass_only, include_indels, chr_prefix, id_separator, gw_phase_method, gw_af_field,
-     contig_ban) = task
-    per: Dict[str, dict] = {}
-    filter_count = unphased = excluded = 0
-    for line in lines:
-        if not line or line[0] == "#":
-            continue
-        c = line.split("\t")
-        chrom0 = c[0]
-        for item in contig_ban:
-            if item in chrom0:
-                raise SystemExit("     FATAL ERROR: Character '%s' must not be present in contig name. Please change id separtor "
-                                 "using --id_separator to a character not found in the contig names and try again." % item)
-        if chrom_of_interest != "" and chrom_of_interest != chrom0:
-            continue
-        chrom = chr_prefix + chrom0
-        col = per.get(chrom)
-        if col is None:
-            col = per[chrom] = {k: [] for k in ("pos", "uid", "rsid_field", "rsid", "ref", "all_alleles", "alleles", "phase", "gt",
-                                                "maf_text", "maf", "ref_len", "a0", "a1", "r0", "r1", "p0", "p1")}
-        fields = c[8].split(":")
-        if "GT" not in fields:
-            continue
-        geno = c[sample_column].split(":")[fields.index("GT")]
-        g = list(geno)
-        if "." in g:
-            continue
-        phased = "|" in g
-        if phased:
-            g.remove("|")
-        is_unphased = False
-        if "/" in g:
-            g.remove("/")
-            is_unphased = True
-        if len(set(g)) <= 1:
-            continue
-        if not (pass_only == 0 or "PASS" in c[6].split(";")):
-            filter_count += 1
-            continue
-        unphased += is_unphased
-        alts = c[4].split(",")
-        every = [c[3]] + alts
-        if not (max(len(x) for x in every) == 1 or include_indels == 1):
-            excluded += 1
-            continue
-        uid = chrom + id_separator + c[1] + id_separator + id_separator.join(every)
-        maf = None
-        if gw_phase_method == 1:
-            info = {}
-            for item in c[7].split(";"):
-                if "=" in item:
-                    info[item.split("=")[0]] = item.split("=")[1]
-            if gw_af_field in info:
-                afs = [float(x) for x in info[gw_af_field].split(",")]
-                if len(afs) == len(alts):
-                    use = [int(x) - 1 for x in g if x != "." and int(x) != 0]
-                    if use:
-                        maf = min(min(afs[x], 1 - afs[x]) for x in use)
-        # fields the phasing core derives from the table row (generate_variant_dict)
-        ind = [every[i] for i in range(len(every)) if str(i) in g]
-        ph = [every[int(i)] for i in g] if phased else ["-", "-"]
-        mtxt = str(maf)
-        try:
-            mval = float(mtxt)
-        except ValueError:
-            mval = 0
-        col["pos"].append(int(c[1])); col["ref_len"].append(min(255, len(c[3])))
-        col["uid"].append(uid); col["rsid_field"].append(c[2]); col["rsid"].append(c[2] if c[2] not in (".", "") else uid)
-        col["ref"].append(c[3]); col["all_alleles"].append(every); col["alleles"].append(ind); col["phase"].append(ph); col["gt"].append(geno)
-        col["maf_text"].append(mtxt); col["maf"].append(mval)
-        col["a0"].append(_CODE.get(ind[0], 255) if len(ind) > 0 else 255)
-        col["a1"].append(_CODE.get(ind[1], 255) if len(ind) > 1 else 255)
-        i0 = ind[0] if len(ind) > 0 else ""; i1 = ind[1] if len(ind) > 1 else ""
-        col["r0"].append(i0 == c[3]); col["r1"].append(i1 == c[3])
-        col["p0"].append(ph.index(i0) if i0 in ph else -1); col["p1"].append(ph.index(i1) if i1 in ph else -1)
-    return per, filter_count, unphased, excluded
-
-
-_US = "\x1f"
-_STR_COLS = ("uid", "rsid_field", "rsid", "ref", "gt", "maf_text")
-_LIST_COLS = ("all_alleles", "alleles", "phase")
-_INT_COLS = ("pos", "ref_len", "a0", "a1", "r0", "r1", "p0", "p1")
-
-
-_FORK_LINES = None          # the VCF lines, inherited by forked workers (never pickled)
-
-
-def _load_chunk_compact(task):
-    """Worker wrapper: same as _load_chunk on lines [lo, hi) of the inherited text, with the nested Python lists flattened
-    into a few big strings / arrays, which cross the process boundary far faster than pickled lists of lists."""
-    lo, hi = task[0]
-    per, fc, un, ex = _load_chunk((_FORK_LINES[lo:hi],) + tuple(task[1:]))
-    out = {}
-    for chrom, col in per.items():
-        rec = {"n": len(col["uid"]), "maf": col["maf"]}
-        for k in _INT_COLS:
-            rec[k] = np.asarray(col[k], dtype=np.int64)
-        for k in _STR_COLS:
-            rec[k] = _US.join(col[k])
-        for k in _LIST_COLS:
-            rec[k] = _US.join(",".join(x) for x in col[k])
-        out[chrom] = rec
-    return out, fc, un, ex
-
-
-def _expand(rec):
-    n = rec["n"]
-    col = {"maf": rec["maf"]}
-    for k in _INT_COLS:
-        col[k] = rec[k].tolist()
-    for k in _STR_COLS:
-        col[k] = rec[k].split(_US) if n else []
-    for k in _LIST_COLS:
-        col[k] = [x.split(",") if x else [] for x in rec[k].split(_US)] if n else []
-    return col
-
-
-def load_variants(vcf_text: str, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
+def load_variants(vcf_text, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
                   include_indels: int = 0, chr_prefix: str = "", id_separator: str = "_", gw_phase_method: int = 0,
-                  gw_af_field: str = "AF", contig_ban=("_", ":"), threads: int = 1) -> VariantSet:
-    """threads > 1 fans the per-line work out to forked workers (call it before a GPU context exists: forks are cheap then)."""
-    lines = vcf_text.split("\n")
-    opts = (sample_column, chrom_of_interest, pass_only, include_indels, chr_prefix, id_separator, gw_phase_method, gw_af_field,
-            tuple(contig_ban))
-    if threads > 1 and len(lines) > 100_000:
-        import multiprocessing as mp
-        n = min(threads, 64)
-        step = (len(lines) + n - 1) // n
-        global _FORK_LINES
-        _FORK_LINES = lines
-        tasks = [((i, min(i + step, len(lines))),) + opts for i in range(0, len(lines), step)]
-        with mp.get_context("fork").Pool(n) as pool:
-            cparts = pool.map(_load_chunk_compact, tasks, chunksize=1)
-        _FORK_LINES = None
-        parts = [({chrom: _expand(rec) for chrom, rec in per.items()}, fc, un, ex) for per, fc, un, ex in cparts]
-    else:
-        parts = [_load_chunk((lines,) + opts)]
-    merged: Dict[str, dict] = {}
-    filter_count = unphased = excluded = 0
-    for per, fc, un, ex in parts:
-        filter_count += fc; unphased += un; excluded += ex
-        for chrom, col in per.items():
-            tgt = merged.get(chrom)
-            if tgt is None:
-                merged[chrom] = col
-            else:
-                for k, v in col.items():
-                    tgt[k] += v
-    out: Dict[str, ChromVariants] = {}
-    het = 0
-    for chrom, col in merged.items():
-        cv = ChromVariants(chrom, np.asarray(col["pos"], dtype=np.int32), col["uid"], col["rsid_field"], col["rsid"], col["ref"],
-                           col["all_alleles"], col["alleles"], col["phase"], col["gt"], col["maf_text"], col["maf"],
-                           np.asarray(col["ref_len"], dtype=np.uint8), np.asarray(col["a0"], dtype=np.uint8),
-                           np.asarray(col["a1"], dtype=np.uint8),
-                           np.stack([np.asarray(col["r0"], dtype=np.uint8), np.asarray(col["r1"], dtype=np.uint8)], axis=1).reshape(-1),
-                           np.stack([np.asarray(col["p0"], dtype=np.int8), np.asarray(col["p1"], dtype=np.int8)], axis=1).reshape(-1))
-        if len(cv.pos) > 1 and bool((np.diff(cv.pos) < 0).any()):
-            raise SystemExit("     FATAL ERROR: VCF records of %s are not sorted by position." % chrom)
-        het += len(cv.uid)
-        cv.pools()                 # string tables of the variant table for the native row writer (built once, with the table)
-        out[chrom] = cv
-    return VariantSet(out, het, filter_count, excluded, unphased)
+                  gw_af_field: str = "AF", contig_ban=("_", ":"), threads: int = 8, grep_hom: bool = False) -> VariantSet:
+    """vcf_text: str or bytes of the (decompressed) VCF.  Raises SystemExit with the reference's message on a banned
+    contig character (phaser.py:386-392) and on unsorted records.  grep_hom=True applies the reference's
+    `cut -f 1-9,S | grep -v '0|0\\|1|1'` pre-filter (phaser.py:220-225) inside the loader."""
+    lib = _lib.load()
+    data = vcf_text.encode() if isinstance(vcf_text, str) else bytes(vcf_text)
+    ban = [str(x).encode() for x in contig_ban]
+    ban_arr = (C.c_char_p * max(1, len(ban)))(*ban) if ban else (C.c_char_p * 1)()
+    o = _lib.phz_vcf_opts(int(sample_column), chrom_of_interest.encode(), int(pass_only), int(include_indels), chr_prefix.encode(),
+                          id_separator.encode(), int(gw_phase_method), gw_af_field.encode(), len(ban), ban_arr, max(1, int(threads)), 1 if grep_hom else 0)
+    h = C.c_void_p()
+    st = lib.phz_vcf_parse(C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(o), C.byref(h))
+    try:
+        if st != _lib.PHZ_OK:
+            msg = (lib.phz_vcf_error(h) or b"").decode()
+            if "FATAL ERROR" in msg:
+                raise SystemExit(msg)
+            raise _lib.PhzError(st, msg or "phz_vcf_parse failed")
+        nch = C.c_int32(0); het = C.c_int64(0); fc = C.c_int64(0); ex = C.c_int64(0); un = C.c_int64(0)
+        lib.phz_vcf_summary(h, C.byref(nch), C.byref(het), C.byref(fc), C.byref(ex), C.byref(un))
+        chroms: Dict[str, ChromVariants] = {}
+        for i in range(nch.value):
+            t = _lib.phz_vcf_table()
+            lib.phz_vcf_chrom(h, i, C.byref(t))
+            n = int(t.n)
+
+            def arr(ptr, count, dt):
+                if count == 0:
+                    return np.zeros(0, dtype=dt)
+                return np.frombuffer(C.string_at(ptr, count * np.dtype(dt).itemsize), dtype=dt).copy()
+            arrays = {"pos": arr(t.pos, n, np.int32), "ref_len": arr(t.ref_len, n, np.uint8), "a0": arr(t.a0, n, np.uint8),
+                      "a1": arr(t.a1, n, np.uint8), "is_ref": arr(t.is_ref, 2 * n, np.uint8), "phase_idx": arr(t.phase_idx, 2 * n, np.int8),
+                      "maf": arr(t.maf, n, np.float64)}
+            raw = {name: (C.string_at(t.pool[k], int(t.pool_len[k])) if t.pool_len[k] else b"") for k, name in enumerate(_POOLS)}
+            cv = ChromVariants(t.name.decode(), arrays, raw)
+            chroms[cv.chrom] = cv
+    finally:
+        lib.phz_vcf_free(h)
+    return VariantSet(chroms, int(het.value), int(fc.value), int(ex.value), int(un.value))

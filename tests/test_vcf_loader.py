@@ -1,0 +1,113 @@
+"""Native het-variant loader (phz_vcf_parse) vs the pinned oracle's loader (oracle/phasing_oracle.py load_vcf +
+variant_table_rows, phaser.py:396-433 / :1355-1413) on the fixture VCFs and on a VCF of awkward lines."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, REPO
+
+TRICKY = "\n".join([
+    "##fileformat=VCFv4.2",
+    "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1",
+    "chr1\t100\trs1\tA\tG\t.\tPASS\tAF=0.25\tGT\t0|1",
+    "chr1\t150\t.\tC\tT\t.\tPASS\tAF=0.75;DP=3\tGT:DP\t1|0:7",
+    "chr1\t180\t\tG\tT\t.\tPASS\tDP=3\tDP:GT\t9:0/1",
+    "chr1\t200\trs4\tA\tC,T\t.\tPASS\tAF=0.1,0.6\tGT\t1|2",
+    "chr1\t250\trs5\tA\tG\t.\tq10\tAF=0.5\tGT\t0|1",
+    "chr1\t260\trs6\tA\tG\t.\tq10;PASS\tAF=0.5\tGT\t0|1",
+    "chr1\t300\trs7\tA\tG\t.\tPASS\tAF=0.5\tGT\t1|1",
+    "chr1\t310\trs8\tA\tG\t.\tPASS\tAF=0.5\tGT\t.|1",
+    "chr1\t320\trs9\tA\tG\t.\tPASS\tAF=0.5\tDP\t5",
+    "chr1\t400\trs10\tAT\tA\t.\tPASS\tAF=0.3\tGT\t0|1",
+    "chr1\t450\trs11\tA\tATT\t.\tPASS\tAF=0.3\tGT\t1|0",
+    "chr1\t500\trs12\tA\tG\t.\tPASS\tXAF=0.9;AF=0.2=7\tGT\t0/1",
+    "chr1\t510\trs13\tA\tG,C\t.\tPASS\tAF=0.2\tGT\t0|2",
+    "chr2\t50\trs14\tT\tC\t.\tPASS\tAF=1e-05\tGT\t0|1",
+    "chr3\t50\trs15\tT\tC\t.\tPASS\tAF=0.4\tGT\t1|1",
+    ""])
+
+
+def _fixture_vcfs():
+    out = [("tricky", TRICKY)]
+    for d in ("pipe_one", "pipe_two", "pipe_indel", "pipe_opts"):
+        out.append((d, open(os.path.join(GOLD, d, "in.vcf")).read()))
+    return out
+
+
+@pytest.mark.parametrize("name,text", _fixture_vcfs(), ids=[n for n, _ in _fixture_vcfs()])
+@pytest.mark.parametrize("opts", [dict(), dict(pass_only=0), dict(include_indels=1), dict(gw_phase_method=1), dict(chr_prefix="c_", id_separator=":"),
+                                  dict(chrom_of_interest="chr1"), dict(gw_phase_method=1, include_indels=1, pass_only=0)])
+def test_native_loader_matches_oracle(name, text, opts):
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import phasing_oracle as po
+    from phaser_amd import _lib, vcf
+    _lib.build()
+    ban = () if "chr_prefix" in opts else ("_", ":")
+    vs = vcf.load_variants(text, contig_ban=ban, threads=3, **opts)
+    pool, filtered, unphased = po.load_vcf(text, opts.get("chrom_of_interest", ""), opts.get("pass_only", 1))
+    assert list(vs.chroms) == [opts.get("chr_prefix", "") + c for c in pool]
+    assert vs.filter_count == filtered and vs.unphased_count == unphased
+    excluded = 0
+    for c, rows in pool.items():
+        want, ex = po.variant_table_rows(rows, opts.get("id_separator", "_"), opts.get("include_indels", 0), opts.get("chr_prefix", ""),
+                                         opts.get("gw_phase_method", 0))
+        excluded += ex
+        cv = vs.chroms[opts.get("chr_prefix", "") + c]
+        assert cv.table_rows() == want
+        # per-variant fields of generate_variant_dict (:1418-1462) through the oracle's Var
+        for i, r in enumerate(want):
+            v = po.Var(r[2], r[3], r[6], r[7], opts.get("id_separator", "_"))
+            assert cv.alleles[i] == v.alleles and cv.phase[i] == v.phase and cv.rsid[i] == v.rsid and cv.maf[i] == v.maf
+            assert type(cv.maf[i]) is type(v.maf)
+            for k in (0, 1):
+                al = v.alleles[k] if k < len(v.alleles) else ""
+                assert bool(cv.is_ref[2 * i + k]) == (al == cv.ref[i])
+                assert int(cv.phase_idx[2 * i + k]) == (v.phase.index(al) if al in v.phase else -1)
+    assert vs.indels_excluded == excluded and vs.het_count == sum(len(cv) for cv in vs.chroms.values())
+
+
+def test_banned_contig_character_and_unsorted():
+    from phaser_amd import _lib, vcf
+    _lib.build()
+    with pytest.raises(SystemExit) as e:
+        vcf.load_variants(TRICKY.replace("chr2\t", "chr_2\t"))
+    assert "must not be present in contig name" in str(e.value)
+    with pytest.raises(SystemExit):
+        vcf.load_variants(TRICKY.replace("chr1\t150\t", "chr1\t90\t"))
+
+
+def test_grep_hom_prefilter_inside_the_loader():
+    """`cut -f 1-9,S | grep -v '0|0\\|1|1'` (phaser.py:220-225) done by the loader == done on the text first."""
+    from phaser_amd import _lib, vcf
+    _lib.build()
+    lines = TRICKY.split("\n")
+    # second sample column + a hom-ref line + a line whose INFO holds the pattern
+    wide = []
+    for l in lines:
+        if l.startswith("##") or not l:
+            wide.append(l)
+        elif l.startswith("#"):
+            wide.append(l + "\tS2")
+        else:
+            c = l.split("\t")
+            wide.append("\t".join(c[:9] + ["1|1" if c[1] == "100" else "0|0", c[9]]))
+    wide.insert(3, "chr1\t95\trsX\tA\tG\t.\tPASS\tNOTE=1|1\tGT\t0|0\t0|1")
+    wide.insert(3, "chr1\t90\trsY\tA\tG\t.\tPASS\tAF=0.5\tGT\t0|1\t0|0")
+    text = "\n".join(wide)
+    for col in (9, 10):
+        kept = []
+        for l in wide:
+            if not l or l[0] == "#":
+                continue
+            c = l.split("\t")
+            cut = "\t".join(c[0:9] + [c[col]])
+            if "0|0" in cut or "1|1" in cut:
+                continue
+            kept.append(cut)
+        a = vcf.load_variants(text, sample_column=col, grep_hom=True, gw_phase_method=1)
+        b = vcf.load_variants("\n".join(kept), sample_column=9, gw_phase_method=1)
+        assert list(a.chroms) == list(b.chroms) and a.het_count == b.het_count and a.filter_count == b.filter_count
+        for c in a.chroms:
+            assert a.chroms[c].table_rows() == b.chroms[c].table_rows()
