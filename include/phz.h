@@ -195,6 +195,12 @@ int phz_bam_decode(phz_bam *bam, const uint8_t *ref_mask, int min_mapq, int flag
                    double isize_cutoff, int threads, int *n_shards);
 int phz_bam_shard(phz_bam *bam, int i, phz_host_shard *out);
 
+/* whole BGZF file -> malloc'd buffer (free with phz_buf_free); PHZ_E_UNSUPPORTED when the file is plain gzip */
+int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len);
+void phz_buf_free(char *p);
+/* data -> BGZF file: 60,000-byte members deflated in parallel + EOF marker (what bgzip writes, phaser.py:1851) */
+int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads, int level);
+
 int phz_interner_create(phz_interner **out);
 int phz_interner_destroy(phz_interner *it);
 int64_t phz_interner_size(const phz_interner *it);

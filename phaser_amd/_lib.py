@@ -146,6 +146,9 @@ SYMBOLS = {
     "phz_bam_ref_length": (C.c_int64, [C.c_void_p, C.c_int]),
     "phz_bam_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]),
     "phz_bam_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_host_shard)]),
+    "phz_bgzf_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "phz_buf_free": (None, [C.c_void_p]),
+    "phz_bgzf_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     "phz_interner_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "phz_interner_destroy": (C.c_int, [C.c_void_p]),
     "phz_interner_size": (C.c_int64, [C.c_void_p]),

@@ -127,6 +127,60 @@ int n_threads(int want) {
     return h ? (int)(h > 32 ? 32 : h) : 4;
 }
 
+// Whole-file BGZF inflate: member table from the BC extra fields, members inflated in parallel into one buffer.
+// PHZ_E_UNSUPPORTED = a gzip member without the BGZF extra field (plain gzip: not splittable, caller falls back).
+template <class Vec>
+int inflate_bgzf_file(const char *path, int threads, Vec &outbuf) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return PHZ_E_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 28) { close(fd); return PHZ_E_ARG; }
+    const size_t fsz = (size_t)st.st_size;
+    const uint8_t *f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (f == MAP_FAILED) return PHZ_E_NOMEM;
+    struct Blk { size_t off, csize, isize, dst; };
+    std::vector<Blk> blks;
+    size_t off = 0, total = 0;
+    int status = PHZ_OK;
+    while (off + 18 <= fsz) {
+        if (f[off] != 0x1f || f[off + 1] != 0x8b) { status = PHZ_E_ARG; break; }
+        if (!(f[off + 3] & 4)) { status = PHZ_E_UNSUPPORTED; break; }
+        const uint16_t xlen = rd16(f + off + 10);
+        size_t x = off + 12, xe = x + xlen;
+        uint32_t bsize = 0;
+        while (x + 4 <= xe) {
+            const uint16_t slen = rd16(f + x + 2);
+            if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = (uint32_t)rd16(f + x + 4) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize) { status = PHZ_E_UNSUPPORTED; break; }
+        if (off + bsize > fsz) { status = PHZ_E_ARG; break; }
+        const uint32_t isize = rd32(f + off + bsize - 4);
+        blks.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isize, total});
+        total += isize;
+        off += bsize;
+    }
+    if (status == PHZ_OK && blks.empty()) status = PHZ_E_ARG;
+    if (status != PHZ_OK) { munmap((void *)f, fsz); return status; }
+    outbuf.resize(total);
+    const int nt = n_threads(threads);
+    std::atomic<size_t> next(0);
+    std::atomic<bool> bad(false);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= blks.size()) break;
+                if (blks[i].isize && !inflate_block(f + blks[i].off, blks[i].csize, (uint8_t *)outbuf.data() + blks[i].dst, blks[i].isize)) bad = true;
+            }
+        });
+    for (auto &t : th) t.join();
+    munmap((void *)f, fsz);
+    return bad ? PHZ_E_ARG : PHZ_OK;
+}
+
 }  // namespace
 
 struct phz_bam { Bam b; };
@@ -139,53 +193,8 @@ extern "C" {
 
 int phz_bam_open(const char *path, int threads, phz_bam **out) {
     *out = nullptr;
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return PHZ_E_ARG;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size < 28) { close(fd); return PHZ_E_ARG; }
-    const size_t fsz = (size_t)st.st_size;
-    const uint8_t *f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (f == MAP_FAILED) return PHZ_E_NOMEM;
-    // BGZF member table
-    struct Blk { size_t off, csize, isize, dst; };
-    std::vector<Blk> blks;
-    size_t off = 0, total = 0;
-    bool ok = true;
-    while (off + 18 <= fsz) {
-        if (f[off] != 0x1f || f[off + 1] != 0x8b || !(f[off + 3] & 4)) { ok = false; break; }
-        const uint16_t xlen = rd16(f + off + 10);
-        size_t x = off + 12, xe = x + xlen;
-        uint32_t bsize = 0;
-        while (x + 4 <= xe) {
-            const uint16_t slen = rd16(f + x + 2);
-            if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = (uint32_t)rd16(f + x + 4) + 1;
-            x += 4 + slen;
-        }
-        if (!bsize || off + bsize > fsz) { ok = false; break; }
-        const uint32_t isize = rd32(f + off + bsize - 4);
-        blks.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isize, total});
-        total += isize;
-        off += bsize;
-    }
-    if (!ok || blks.empty()) { munmap((void *)f, fsz); return PHZ_E_ARG; }
     phz_bam *h = new phz_bam();
-    h->b.data.resize(total);
-    const int nt = n_threads(threads);
-    std::atomic<size_t> next(0);
-    std::atomic<bool> bad(false);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++)
-        th.emplace_back([&] {
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= blks.size()) break;
-                if (blks[i].isize && !inflate_block(f + blks[i].off, blks[i].csize, h->b.data.data() + blks[i].dst, blks[i].isize)) bad = true;
-            }
-        });
-    for (auto &t : th) t.join();
-    munmap((void *)f, fsz);
-    if (bad) { delete h; return PHZ_E_ARG; }
+    if (int st = inflate_bgzf_file(path, threads, h->b.data)) { delete h; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
     const std::vector<uint8_t> &d = h->b.data;
     if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { delete h; return PHZ_E_ARG; }
     size_t p = 8 + (size_t)rdi32(d.data() + 4);
@@ -362,6 +371,71 @@ int phz_interner_names(const phz_interner *it, char *blob, int64_t blob_cap, uin
     }
     off[n] = (uint32_t)o;
     return (int64_t)o <= blob_cap ? PHZ_OK : PHZ_E_CAPACITY;
+}
+
+// ---- generic BGZF files (bgzip-compressed VCF in, phased VCF out) -------------------------------------------------------
+// Reads a whole BGZF file with parallel member inflate.  PHZ_E_UNSUPPORTED for plain gzip (the caller streams it itself).
+int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len) {
+    if (!path || !data || !len) return PHZ_E_ARG;
+    *data = nullptr; *len = 0;
+    std::vector<char> buf;
+    if (int st = inflate_bgzf_file(path, threads, buf)) return st;
+    char *p = (char *)malloc(buf.size() + 1);
+    if (!p) return PHZ_E_NOMEM;
+    memcpy(p, buf.data(), buf.size()); p[buf.size()] = 0;
+    *data = p; *len = (int64_t)buf.size();
+    return PHZ_OK;
+}
+
+void phz_buf_free(char *p) { free(p); }
+
+// Writes data as a BGZF file (60,000-byte members deflated in parallel, EOF marker at the end) -- what `bgzip` produces
+// for the phased VCF (phaser.py:1851).
+int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads, int level) {
+    if (!path || (!data && len) || len < 0) return PHZ_E_ARG;
+    const size_t BLK = 60000;
+    const size_t nblk = ((size_t)len + BLK - 1) / BLK;
+    std::vector<std::string> out(nblk);
+    std::atomic<size_t> next(0);
+    std::atomic<bool> bad(false);
+    const int nt = n_threads(threads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&] {
+            std::vector<uint8_t> tmp(BLK + 1024);
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= nblk) break;
+                const size_t lo = i * BLK, n = std::min(BLK, (size_t)len - lo);
+                z_stream zs; memset(&zs, 0, sizeof zs);
+                if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = true; break; }
+                zs.next_in = (Bytef *)(data + lo); zs.avail_in = (uInt)n;
+                zs.next_out = tmp.data(); zs.avail_out = (uInt)tmp.size();
+                const int rc = deflate(&zs, Z_FINISH);
+                const size_t csize = tmp.size() - zs.avail_out;
+                deflateEnd(&zs);
+                if (rc != Z_STREAM_END || csize + 26 > 65536) { bad = true; break; }
+                std::string &o = out[i];
+                const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+                o.assign((const char *)hdr, 16);
+                const uint16_t bsize = (uint16_t)(csize + 25);
+                o.push_back((char)(bsize & 0xff)); o.push_back((char)(bsize >> 8));
+                o.append((const char *)tmp.data(), csize);
+                const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(data + lo), (uInt)n), isz = (uint32_t)n;
+                for (int k = 0; k < 4; k++) o.push_back((char)((crc >> (8 * k)) & 0xff));
+                for (int k = 0; k < 4; k++) o.push_back((char)((isz >> (8 * k)) & 0xff));
+            }
+        });
+    for (auto &t : th) t.join();
+    if (bad) return PHZ_E_ARG;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return PHZ_E_ARG;
+    bool ok = true;
+    for (auto &o : out) ok = ok && fwrite(o.data(), 1, o.size(), fp) == o.size();
+    static const uint8_t eof_marker[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_marker, 1, 28, fp) == 28;
+    ok = fclose(fp) == 0 && ok;
+    return ok ? PHZ_OK : PHZ_E_ARG;
 }
 
 }  // extern "C"

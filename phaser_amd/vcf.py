@@ -111,8 +111,17 @@ def read_text(path: str) -> str:
     return read_bytes(path).decode()
 
 
-def read_bytes(path: str) -> bytes:
+def read_bytes(path: str, threads: int = 0) -> bytes:
     if path.endswith(".gz") or path.endswith(".bgz"):
+        # bgzip output is a chain of independent members: inflate them in parallel; plain gzip falls to the gzip module
+        lib = _lib.load()
+        p = C.c_void_p(); n = C.c_int64(0)
+        st = lib.phz_bgzf_read(path.encode(), int(threads), C.byref(p), C.byref(n))
+        if st == _lib.PHZ_OK:
+            try:
+                return C.string_at(p, n.value)
+            finally:
+                lib.phz_buf_free(p)
         with gzip.open(path, "rb") as f:
             return f.read()
     with open(path, "rb") as f:

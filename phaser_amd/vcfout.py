@@ -112,9 +112,12 @@ def phased_vcf_text(cut_lines: List[str], lookup: Dict[str, tuple], id_separator
     return "".join(out), unphased_phased, corrections
 
 
-def write_bgzf(path: str, text: str):
-    data = text.encode()
-    with open(path, "wb") as f:
-        for i in range(0, len(data), 60000):
-            f.write(bamio._bgzf_block(data[i:i + 60000]))
-        f.write(bamio._EOF)
+def write_bgzf(path: str, text, threads: int = 0):
+    """BGZF-compress the phased VCF text (what the reference gets from `bgzip`, phaser.py:1851) with the native parallel writer."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    data = text.encode() if isinstance(text, str) else bytes(text)
+    st = lib.phz_bgzf_write(path.encode(), C.cast(C.c_char_p(data), C.c_void_p), len(data), int(threads), 6)
+    if st != _lib.PHZ_OK:
+        raise _lib.PhzError(st, "phz_bgzf_write(%s) failed" % path)

@@ -110,3 +110,28 @@ def test_unsorted_inputs_are_refused(tmp_path):
     _lib.build()
     with pytest.raises(_lib.PhzError):
         bamio.shards_from_bam_native(path, {}, mapq=0, paired_end=False, remove_dups=False)
+
+
+def test_native_bgzf_write_and_read(tmp_path):
+    """phz_bgzf_write / phz_bgzf_read: what we write, the gzip module and our parallel reader both read back; plain gzip falls back."""
+    from phaser_amd import _lib, vcf, vcfout
+    _lib.build()
+    text = open(os.path.join(GOLD, "pipe_two", "in.vcf")).read() * 40
+    p = str(tmp_path / "t.vcf.gz")
+    vcfout.write_bgzf(p, text, 3)
+    assert gzip.open(p, "rt").read() == text
+    assert vcf.read_bytes(p, 3).decode() == text
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC" and raw.endswith(bamio_eof())
+    q = str(tmp_path / "plain.vcf.gz")
+    with gzip.open(q, "wt") as f:
+        f.write(text[:50000])
+    assert vcf.read_bytes(q).decode() == text[:50000]
+    e = str(tmp_path / "e.vcf.gz")
+    vcfout.write_bgzf(e, "")
+    assert gzip.open(e, "rb").read() == b""
+
+
+def bamio_eof():
+    from phaser_amd import bamio
+    return bamio._EOF
