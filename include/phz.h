@@ -359,6 +359,26 @@ int phz_vcf_chrom(const phz_vcf *h, int32_t i, phz_vcf_table *table);
 const char *phz_vcf_error(const phz_vcf *h);
 void phz_vcf_free(phz_vcf *h);
 
+/* ---- native write_vcf (phaser/phaser.py:1661-1855): the sample's VCF text with the phASER FORMAT tags --------------------------
+ * One phz_vcfout_chrom per chromosome that has blocks: the variant table's pools (phz_vcf_chrom: 0 unique id, 2 rsid,
+ * 5 individual's alleles, 9 str(maf)) and the block arrays of phz_rows_out; first_block_index = number of blocks of the
+ * chromosomes before it (PI is 1-based over all chromosomes, :867).  out is malloc'd (phz_buf_free). */
+typedef struct {
+    const char *uid;     int64_t uid_len;
+    const char *rsid;    int64_t rsid_len;
+    const char *alleles; int64_t alleles_len;
+    const char *maf_str; int64_t maf_str_len;
+    int64_t n_blocks, n_blk_vars, first_block_index;
+    const int32_t *blk_size, *blk_var, *blk_maxmaf;
+    const uint8_t *blk_hap, *blk_stat_int;
+    const int8_t *blk_cor;
+    const double *blk_stat;
+} phz_vcfout_chrom;
+
+int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_column, const char *id_separator, const char *chrom_of_interest,
+                       int32_t gw_phase_vcf, double min_confidence, const phz_vcfout_chrom *chroms, int32_t n_chroms, int32_t threads,
+                       char **out, int64_t *out_len, int64_t *unphased_phased, int64_t *corrections);
+
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
 int phz_reset_timing(phz_ctx *ctx);

@@ -121,6 +121,14 @@ class phz_vcf_table(C.Structure):
                 ("is_ref", C.c_void_p), ("phase_idx", C.c_void_p), ("maf", C.c_void_p), ("pool", C.c_void_p * 11), ("pool_len", C.c_int64 * 11)]
 
 
+class phz_vcfout_chrom(C.Structure):
+    _fields_ = [("uid", C.c_void_p), ("uid_len", C.c_int64), ("rsid", C.c_void_p), ("rsid_len", C.c_int64), ("alleles", C.c_void_p),
+                ("alleles_len", C.c_int64), ("maf_str", C.c_void_p), ("maf_str_len", C.c_int64), ("n_blocks", C.c_int64),
+                ("n_blk_vars", C.c_int64), ("first_block_index", C.c_int64), ("blk_size", C.c_void_p), ("blk_var", C.c_void_p),
+                ("blk_maxmaf", C.c_void_p), ("blk_hap", C.c_void_p), ("blk_stat_int", C.c_void_p), ("blk_cor", C.c_void_p),
+                ("blk_stat", C.c_void_p)]
+
+
 PHZ_AS_BINS = 65536
 
 # every symbol include/phz.h declares: name -> (restype, argtypes)
@@ -172,6 +180,9 @@ SYMBOLS = {
     "phz_vcf_chrom": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(phz_vcf_table)]),
     "phz_vcf_error": (C.c_char_p, [C.c_void_p]),
     "phz_vcf_free": (None, [C.c_void_p]),
+    "phz_vcf_phase_text": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, C.c_double,
+                                     C.POINTER(phz_vcfout_chrom), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "phz.h"
+#include "phz_text.h"
 
 namespace {
 
@@ -47,43 +48,8 @@ struct Chunk {
     int status = 0; std::string error;
 };
 
-// repr(float): shortest round-trip digits, fixed notation for 1e-4 <= |x| < 1e16 (same routine as the row writer's)
-void put_pyfloat(std::string &s, double x) {
-    if (std::isnan(x)) { s += "nan"; return; }
-    if (std::isinf(x)) { s += x < 0 ? "-inf" : "inf"; return; }
-    if (x == 0) { s += std::signbit(x) ? "-0.0" : "0.0"; return; }
-    char buf[64];
-    auto r = std::to_chars(buf, buf + 64, x, std::chars_format::scientific);
-    std::string_view v(buf, (size_t)(r.ptr - buf));
-    if (v[0] == '-') { s += '-'; v.remove_prefix(1); }
-    const size_t epos = v.find('e');
-    std::string digits(1, v[0]);
-    if (epos > 2) digits.append(v.substr(2, epos - 2));
-    const int exp = atoi(std::string(v.substr(epos + 1)).c_str());
-    if (exp >= -4 && exp < 16) {
-        if (exp >= 0) {
-            if ((int)digits.size() <= exp + 1) { s += digits; s.append((size_t)(exp + 1) - digits.size(), '0'); s += ".0"; }
-            else { s.append(digits, 0, (size_t)exp + 1); s += '.'; s.append(digits, (size_t)exp + 1, std::string::npos); }
-        } else { s += "0."; s.append((size_t)(-exp - 1), '0'); s += digits; }
-    } else {
-        s += digits[0];
-        if (digits.size() > 1) { s += '.'; s.append(digits, 1, std::string::npos); }
-        s += 'e'; s += exp < 0 ? '-' : '+';
-        const int a = abs(exp);
-        if (a < 10) s += '0';
-        char b2[16]; auto r2 = std::to_chars(b2, b2 + 16, a); s.append(b2, (size_t)(r2.ptr - b2));
-    }
-}
-
-void split(std::string_view s, char sep, std::vector<std::string_view> &out) {
-    out.clear();
-    size_t i = 0;
-    while (true) {
-        size_t j = s.find(sep, i);
-        if (j == std::string_view::npos) { out.push_back(s.substr(i)); break; }
-        out.push_back(s.substr(i, j - i)); i = j + 1;
-    }
-}
+using phztext::put_pyfloat;
+using phztext::split;
 
 // Python float(): accepts surrounding whitespace, inf/nan spellings; here: strtod over the whole token
 bool py_float(std::string_view s, double *out) {

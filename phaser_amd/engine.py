@@ -251,12 +251,14 @@ class Engine:
         t3 = _t.perf_counter()
         chroms = [c for c in self.all_chroms if c in frags]
         out, summary = merge_fragments(frags, chroms, self.cfg, noise, len(self.bam_names))
-        self.vcf_lookup = {}
+        # per chromosome with blocks: (name, block arrays of phz_rows_format, blocks before it) -- what write_vcf needs
+        self.vcf_blocks = []
         if self.cfg.want_vcf:
             block_index = 0
             for c in chroms:
                 if frags[c]["vcf"] is not None:
-                    block_index += rows.vcf_block_info(self.vs.chroms[c], frags[c]["vcf"], block_index, self.vcf_lookup)
+                    self.vcf_blocks.append((c, frags[c]["vcf"], block_index))
+                    block_index += len(frags[c]["vcf"]["size"])
         self.stats["merge_s"] = _t.perf_counter() - t3
         self.log += summary["log"]
         self.phased = summary["phased"]; self.total_lines = summary["lines"]

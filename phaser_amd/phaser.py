@@ -263,17 +263,8 @@ def main(argv=None):
                 say("     GT field is being updated with either phASER genome wide phase or phASER block phase with PS specified, depending on phase anchoring quality.")
             else:
                 say("     GT field is not being updated with phASER genome wide phase. This can be changed using the --gw_phase_vcf argument.")
-            cut_lines = []
-            for line in data.decode().split("\n"):
-                if not line:
-                    continue
-                if line.startswith("##"):
-                    cut_lines.append(line)
-                else:
-                    c = line.split("\t")
-                    cut_lines.append("\t".join(c[0:9] + [c[sample_col]]))
-            vtxt, up, pc = vcfout.phased_vcf_text(cut_lines, eng.vcf_lookup, args.id_separator, args.chr, args.gw_phase_vcf,
-                                                  args.gw_phase_vcf_min_confidence)
+            vtxt, up, pc = vcfout.phased_vcf_text(data, sample_col, eng, args.id_separator, args.chr, args.gw_phase_vcf,
+                                                  args.gw_phase_vcf_min_confidence, threads=max(1, args.threads))
             say("     Compressing output VCF (BGZF; no tabix index is written by this build)...")
             vcfout.write_bgzf(args.o + ".vcf.gz", vtxt)
         say('')

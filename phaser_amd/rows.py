@@ -145,26 +145,3 @@ class _Keep(np.ndarray):
 
     def __array_finalize__(self, obj):
         self._owner = getattr(obj, "_owner", None)
-
-
-def vcf_block_info(cv, v: Dict, first_block_index: int, lookup: Dict):
-    """Per-block records for write_vcf (vcfout.phased_vcf_text) from the arrays phz_rows_format returned."""
-    off = 0
-    size = v["size"].tolist(); var = v["var"].tolist(); hap = v["hap"].tolist(); cor = v["cor"].tolist()
-    stat = v["stat"].tolist(); stat_int = v["stat_int"].tolist(); maxmaf = v["maxmaf"].tolist()
-    for bi, n in enumerate(size):
-        gs = var[off:off + n]
-        ha = hap[off:off + n]
-        gw = []
-        for i in range(n):
-            c0 = cor[2 * (off + i)]; c1 = cor[2 * (off + i) + 1]
-            c0 = None if c0 < 0 else c0; c1 = None if c1 < 0 else c1
-            gw.append([c0, c1] if ha[i] == 0 else [c1, c0])
-        info = {"uids": [cv.uid[g] for g in gs], "hap": ["%d|%d" % (a, 1 - a) for a in ha], "rsids": [cv.rsid[g] for g in gs],
-                "stat": 1 if stat_int[bi] else stat[bi], "stat_txt": "1" if stat_int[bi] else repr(stat[bi]),
-                "max_maf_txt": str(cv.maf[maxmaf[bi]]), "alleles": [cv.alleles[g] for g in gs],
-                "all_alleles": [cv.all_alleles[g] for g in gs], "gw": gw}
-        for i, g in enumerate(gs):
-            lookup[cv.uid[g]] = (info, i, first_block_index + bi + 1)
-        off += n
-    return len(size)

@@ -1,115 +1,55 @@
 """Phased VCF output -- phaser/phaser.py:1661-1855 (`write_vcf`), SURVEY.md 8(f) next-2.
 
-Input is the sample's VCF cut to columns 1-9 + sample (what `gunzip -c | cut -f 1-9,S` hands the reference) and
-the per-variant block lookup built while the blocks were written (engine.merge_fragments).  Output text is what the
-reference writes to <o>.vcf before compressing it; we compress it as BGZF ourselves (bamio._bgzf_block) and do
-not write a tabix index.
+The text is produced by the native writer (phz_vcf_phase_text, phaser_amd/csrc/phz_vcfout.cpp): input is the sample's VCF
+(the reference feeds `gunzip -c | cut -f 1-9,S`; here the original text + the sample's column) and, per chromosome, the
+block arrays the row writer returned (engine.vcf_blocks) with the variant table's string pools.  Output text is what the
+reference writes to <o>.vcf before compressing it; we compress it as BGZF ourselves (phz_bgzf_write) and do not write a
+tabix index.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+import ctypes as C
+from typing import Tuple
 
-from . import bamio
+import numpy as np
 
-TAGS = ['PG', 'PB', 'PI', 'PW', 'PC', 'PM']
+from . import _lib
 
 
-def phased_vcf_text(cut_lines: List[str], lookup: Dict[str, tuple], id_separator: str = "_", chromosome_of_interest: str = "",
-                    gw_phase_vcf: int = 0, min_confidence: float = 0.9) -> Tuple[str, int, int]:
-    """-> (vcf text, unphased_phased, phase_corrections)"""
-    out: List[str] = []
-    format_text = ""
-    corrections = unphased_phased = 0
-    for line in cut_lines:
-        c = line.split("\t")
-        if "##FORMAT" in line:
-            format_text += line + "\n"
-            out.append(line + "\n")
-        elif line.startswith("#CHROM"):
-            for tag, desc in [("PG", "phASER Local Genotype"), ("PB", "phASER Local Block"),
-                              ("PI", "phASER Local Block Index (unique for each block)"), ("PM", "phASER Local Block Maximum Variant MAF"),
-                              ("PW", "phASER Genome Wide Genotype"), ("PC", "phASER Genome Wide Confidence")]:
-                if "##FORMAT=<ID=%s," % tag not in format_text:
-                    out.append("##FORMAT=<ID=%s,Number=1,Type=String,Description=\"%s\">\n" % (tag, desc))
-            if gw_phase_vcf == 2 and "##FORMAT=<ID=PS," not in format_text:
-                out.append("##FORMAT=<ID=PS,Number=1,Type=String,Description=\"Phase Set\">\n")
-            out.append("\t".join(c[0:9] + [c[9]]) + "\n")
-        elif line[0:1] == "#":
-            out.append(line + "\n")
-        else:
-            chrom = c[0]; pos = int(c[1])
-            if not (chromosome_of_interest == "" or chrom == chromosome_of_interest):
-                continue
-            if "GT" in c[8]:
-                gt_index = c[8].split(":").index("GT")
-                genotype = list(c[9].split(":")[gt_index])
-                if "|" in genotype:
-                    genotype.remove("|")
-                if "/" in genotype:
-                    genotype.remove("/")
-                all_alleles = [c[3]] + c[4].split(",")
-                n_fields = len(c[8].split(":"))
-                for i in range(9, len(c)):
-                    have = len(c[i].split(":"))
-                    if have != n_fields:
-                        c[i] += ":" * (n_fields - have)
-                fmt = c[8].split(":")
-                for tag in TAGS:
-                    if tag not in fmt:
-                        fmt.append(tag)
-                c[8] = ":".join(fmt)
-                # rebuilt WITHOUT --chr_prefix, as the reference does (phaser.py:1763): with a prefix nothing matches there either
-                uid = chrom + id_separator + str(pos) + id_separator + id_separator.join(all_alleles)
-                hit = lookup.get(uid)
-                if hit is not None:
-                    v, i, block_index = hit
-                    alleles_out = []; gw_out = ["", ""]
-                    for a in v["hap"][i].split("|"):
-                        base = v["alleles"][i][int(a)]
-                        vidx = all_alleles.index(base)
-                        g = v["gw"][i][int(a)]
-                        if g is not None:
-                            gw_out[g] = str(vidx)
-                        alleles_out.append(str(vidx))
-                    names = [r.replace(":", "_") for r in v["rsids"]]
-                    stat = v["stat"]
-                    if "-" not in gw_out:
-                        x = c[9].split(":")
-                        new_phase = "|".join(gw_out)
-                        if stat >= min_confidence:
-                            if "|" in x[gt_index] and x[gt_index] != new_phase:
-                                corrections += 1
-                            if "/" in x[gt_index] and x[gt_index] != "./." and x[gt_index] != new_phase:
-                                unphased_phased += 1
-                            if gw_phase_vcf in (1, 2):
-                                x[gt_index] = new_phase
-                                c[9] = ":".join(x)
-                        if gw_phase_vcf == 2 and stat < min_confidence:
-                            x[gt_index] = "|".join(alleles_out)
-                            c[9] = ":".join(x)
-                    sf = c[9].split(":")
-                    sf += [''] * (len(fmt) - len(sf))
-                    sf[fmt.index('PG')] = "|".join(alleles_out)
-                    sf[fmt.index('PB')] = ",".join(names)
-                    sf[fmt.index('PI')] = str(block_index)
-                    sf[fmt.index('PM')] = v["max_maf_txt"]
-                    sf[fmt.index('PW')] = "|".join(gw_out)
-                    sf[fmt.index('PC')] = v["stat_txt"]
-                    if gw_phase_vcf == 2 and stat < min_confidence:
-                        if 'PS' not in fmt:
-                            c[8] += ":PS"; fmt.append("PS"); sf.append('')
-                        sf[fmt.index('PS')] = str(block_index)
-                    c[9] = ":".join(sf)
-                else:
-                    sf = c[9].split(":")
-                    sf += [''] * (len(fmt) - len(sf))
-                    sf[fmt.index('PG')] = "/".join(sorted(genotype))
-                    sf[fmt.index('PB')] = '.'; sf[fmt.index('PI')] = '.'; sf[fmt.index('PM')] = '.'
-                    sf[fmt.index('PW')] = c[9].split(":")[gt_index]
-                    sf[fmt.index('PC')] = '.'
-                    c[9] = ":".join(sf)
-            out.append("\t".join(c[0:9] + [c[9]]) + "\n")
-    return "".join(out), unphased_phased, corrections
+def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", chromosome_of_interest: str = "",
+                    gw_phase_vcf: int = 0, min_confidence: float = 0.9, threads: int = 8) -> Tuple[str, int, int]:
+    """-> (vcf text, unphased_phased, phase_corrections).  eng: the Engine whose finish() ran with want_vcf (its vcf_blocks)."""
+    lib = _lib.load()
+    data = vcf_text.encode() if isinstance(vcf_text, str) else bytes(vcf_text)
+    keep = []
+    arr = (_lib.phz_vcfout_chrom * max(1, len(eng.vcf_blocks)))()
+
+    def P(b):
+        keep.append(b)
+        return C.cast(C.c_char_p(b), C.c_void_p)
+
+    def A(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+        return C.c_void_p(a.ctypes.data)
+    for k, (c, v, first) in enumerate(eng.vcf_blocks):
+        cv = eng.vs.chroms[c]; raw = cv._raw
+        x = arr[k]
+        x.uid = P(raw["uid"]); x.uid_len = len(raw["uid"]); x.rsid = P(raw["rsid"]); x.rsid_len = len(raw["rsid"])
+        x.alleles = P(raw["alleles"]); x.alleles_len = len(raw["alleles"]); x.maf_str = P(raw["maf_str"]); x.maf_str_len = len(raw["maf_str"])
+        x.n_blocks = len(v["size"]); x.n_blk_vars = len(v["var"]); x.first_block_index = first
+        x.blk_size = A(v["size"], np.int32); x.blk_var = A(v["var"], np.int32); x.blk_maxmaf = A(v["maxmaf"], np.int32)
+        x.blk_hap = A(v["hap"], np.uint8); x.blk_stat_int = A(v["stat_int"], np.uint8); x.blk_cor = A(v["cor"], np.int8)
+        x.blk_stat = A(v["stat"], np.float64)
+    out = C.c_void_p(); n = C.c_int64(0); up = C.c_int64(0); pc = C.c_int64(0)
+    st = lib.phz_vcf_phase_text(C.cast(C.c_char_p(data), C.c_void_p), len(data), int(sample_column), id_separator.encode(),
+                                chromosome_of_interest.encode(), int(gw_phase_vcf), float(min_confidence), arr, len(eng.vcf_blocks),
+                                max(1, int(threads)), C.byref(out), C.byref(n), C.byref(up), C.byref(pc))
+    if st != _lib.PHZ_OK:
+        raise _lib.PhzError(st, "phz_vcf_phase_text failed (malformed VCF line?)")
+    try:
+        return C.string_at(out, n.value).decode(), int(up.value), int(pc.value)
+    finally:
+        lib.phz_buf_free(out)
 
 
 def write_bgzf(path: str, text, threads: int = 0):

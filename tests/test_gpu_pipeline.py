@@ -153,8 +153,7 @@ def test_phased_vcf_matches_reference(mapper, src, mode):
         b = "a" if src == "pipe_one" else "n"
         bams = {b + ".bam": {"chr22": gz_text(os.path.join(d, b + ".chr22.sam.gz"))}}
     out, eng = run_product(mapper, vcf_text, bams, "cuda")
-    lines = [l for l in vcf_text.split("\n") if l]
-    got, up, pc = vcfout.phased_vcf_text(lines, eng.vcf_lookup, gw_phase_vcf=mode)
+    got, up, pc = vcfout.phased_vcf_text(vcf_text, 9, eng, gw_phase_vcf=mode)
     assert got == gz_text(os.path.join(d, "out.vcf_gw%d.txt.gz" % mode))
 
 

@@ -77,7 +77,7 @@ def test_phased_vcf_from_host_stages(src, mode):
     vcf_text = open(os.path.join(d, "in.vcf")).read()
     bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"]}.get(src, ["n.bam"])
     out, eng = run_host_stages(src, {}, {}, vcf_text, bam_display_names(bams))
-    got, up, pc = vcfout.phased_vcf_text([l for l in vcf_text.split("\n") if l], eng.vcf_lookup, gw_phase_vcf=mode)
+    got, up, pc = vcfout.phased_vcf_text(vcf_text, 9, eng, gw_phase_vcf=mode, threads=3)
     assert got == gz_text(os.path.join(d, "out.vcf_gw%d.txt.gz" % mode))
 
 
@@ -92,3 +92,22 @@ def test_percentile_from_histogram_equals_numpy():
         h = np.bincount(sc + 32768, minlength=65536).astype(np.int64)
         for q in (0.05 * 100, 0.2 * 100, 0.0, 100.0, 37.3, 99.9):
             assert float(np.percentile(sc.astype(np.int64), q)) == percentile_from_hist(h, q)
+
+
+def test_phased_vcf_takes_the_sample_column_of_a_wide_vcf():
+    """The reference cuts columns 1-9 + the sample before write_vcf; the native writer does the cut itself."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from phasing_oracle import bam_display_names
+    from phaser_amd import vcfout
+    d = os.path.join(GOLD, "pipe_one")
+    vcf_text = open(os.path.join(d, "in.vcf")).read()
+    out, eng = run_host_stages("pipe_one", {}, {}, vcf_text, bam_display_names(["a.bam"]))
+    wide = []
+    for l in vcf_text.split("\n"):
+        if l.startswith("##") or not l:
+            wide.append(l)
+        else:
+            c = l.split("\t")
+            wide.append("\t".join(c[:9] + ["OTHER" if l.startswith("#") else "0/0:1", c[9], "X" if l.startswith("#") else "1/1"]))
+    got, up, pc = vcfout.phased_vcf_text("\n".join(wide), 10, eng, gw_phase_vcf=1)
+    assert got == gz_text(os.path.join(d, "out.vcf_gw1.txt.gz"))
