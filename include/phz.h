@@ -201,6 +201,20 @@ void phz_buf_free(char *p);
 /* data -> BGZF file: 60,000-byte members deflated in parallel + EOF marker (what bgzip writes, phaser.py:1851) */
 int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads, int level);
 
+/* BAM writer for synthetic fixed-length read batches (test / benchmark tooling; one batch per reference, coordinate-sorted):
+ * seq holds base codes 0..3 (4 = N), qual phred values, cigar BAM-coded words, QNAME = qname_prefix + str(qid). */
+typedef struct {
+    int64_t n;
+    int32_t ref_id, L;
+    const int32_t *pos, *flag, *mapq, *tlen, *aln_score, *qid;   /* pos 1-based */
+    const int64_t *cigar_off;                                     /* [n+1] */
+    const uint32_t *cigar;
+    const uint8_t *seq, *qual;                                    /* [n*L] */
+    const char *qname_prefix;
+} phz_read_batch;
+int phz_bam_write(const char *path, int n_ref, const char *const *ref_names, const int32_t *ref_lens, const phz_read_batch *batches,
+                  int n_batches, int threads);
+
 int phz_interner_create(phz_interner **out);
 int phz_interner_destroy(phz_interner *it);
 int64_t phz_interner_size(const phz_interner *it);

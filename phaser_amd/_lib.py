@@ -129,6 +129,12 @@ class phz_vcfout_chrom(C.Structure):
                 ("blk_stat", C.c_void_p)]
 
 
+class phz_read_batch(C.Structure):
+    _fields_ = [("n", C.c_int64), ("ref_id", C.c_int32), ("L", C.c_int32), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
+                ("tlen", C.c_void_p), ("aln_score", C.c_void_p), ("qid", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("seq", C.c_void_p), ("qual", C.c_void_p), ("qname_prefix", C.c_char_p)]
+
+
 PHZ_AS_BINS = 65536
 
 # every symbol include/phz.h declares: name -> (restype, argtypes)
@@ -157,6 +163,7 @@ SYMBOLS = {
     "phz_bgzf_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "phz_buf_free": (None, [C.c_void_p]),
     "phz_bgzf_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "phz_bam_write": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(phz_read_batch), C.c_int, C.c_int]),
     "phz_interner_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "phz_interner_destroy": (C.c_int, [C.c_void_p]),
     "phz_interner_size": (C.c_int64, [C.c_void_p]),

@@ -174,6 +174,34 @@ def readbatch_to_bam(path: str, rbs, refs: List[Tuple[str, int]]):
     write_bam(path, refs, recs)
 
 
+def readbatch_to_bam_native(path: str, rbs, refs: List[Tuple[str, int]], threads: int = 0):
+    """Same file content as readbatch_to_bam (the inflated BAM stream is byte-identical), written by the native encoder in
+    libphz.so (phz_bam_write): what the at-scale runs use, there being no samtools in the image."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    names = [r[0] for r in refs]
+    arr = (_lib.phz_read_batch * max(1, len(rbs)))()
+    keep = []
+
+    def T(t, dt):
+        a = np.ascontiguousarray(t.cpu().numpy().astype(dt, copy=False)); keep.append(a)
+        return C.c_void_p(a.ctypes.data)
+    for k, rb in enumerate(rbs):
+        x = arr[k]
+        x.n = len(rb); x.ref_id = names.index(rb.chrom); x.L = rb.L
+        x.pos = T(rb.pos, np.int32); x.flag = T(rb.flag, np.int32); x.mapq = T(rb.mapq, np.int32); x.tlen = T(rb.tlen, np.int32)
+        x.aln_score = T(rb.aln_score, np.int32); x.qid = T(rb.qid, np.int32); x.cigar_off = T(rb.cigar_off, np.int64)
+        x.cigar = T(rb.cigar, np.uint32); x.seq = T(rb.seq, np.uint8); x.qual = T(rb.qual, np.uint8)
+        x.qname_prefix = rb.qname_prefix.encode()
+    nm = (C.c_char_p * len(refs))(*[r[0].encode() for r in refs])
+    ln = np.asarray([r[1] for r in refs], dtype=np.int32)
+    st = lib.phz_bam_write(path.encode(), len(refs), nm, C.c_void_p(ln.ctypes.data), arr, len(rbs), int(threads))
+    if st != _lib.PHZ_OK:
+        raise _lib.PhzError(st, "phz_bam_write failed")
+
+
 # ----------------------------------------------------------------------------------------- native reader (libphz.so)
 class NativeInterner:
     """QNAME -> id map held in C++ (phz_interner); same first-appearance numbering as samio.QnameInterner."""

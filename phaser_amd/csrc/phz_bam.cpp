@@ -438,4 +438,77 @@ int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads,
     return ok ? PHZ_OK : PHZ_E_ARG;
 }
 
+// ---- BAM writer for synthetic read batches (test / benchmark tooling: there is no samtools in the image) ----------------------
+// Encodes fixed-length reads held as arrays into BAM records (same bytes as phaser_amd/bamio.py:write_bam: bin 4680,
+// mate fields = own reference / position, tags NH:i:1 and AS:i), in parallel, and writes them BGZF-compressed.
+int phz_bam_write(const char *path, int n_ref, const char *const *ref_names, const int32_t *ref_lens, const phz_read_batch *batches,
+                  int n_batches, int threads) {
+    if (!path || n_ref < 0 || (!batches && n_batches)) return PHZ_E_ARG;
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (int i = 0; i < n_ref; i++) { text += "@SQ\tSN:"; text += ref_names[i]; text += "\tLN:"; text += std::to_string(ref_lens[i]); text += "\n"; }
+    std::string head("BAM\1", 4);
+    auto put32 = [](std::string &o, int32_t v) { o.append((const char *)&v, 4); };
+    put32(head, (int32_t)text.size()); head += text; put32(head, n_ref);
+    for (int i = 0; i < n_ref; i++) {
+        const std::string nm(ref_names[i]);
+        put32(head, (int32_t)nm.size() + 1); head += nm; head.push_back('\0'); put32(head, ref_lens[i]);
+    }
+    // record sizes -> offsets
+    std::vector<std::vector<uint64_t>> offs((size_t)n_batches);
+    uint64_t total = head.size();
+    static const uint8_t NT16[5] = {1, 2, 4, 8, 15};       // A C G T N
+    for (int b = 0; b < n_batches; b++) {
+        const phz_read_batch &B = batches[b];
+        const size_t plen = strlen(B.qname_prefix);
+        offs[(size_t)b].resize((size_t)B.n + 1);
+        for (int64_t i = 0; i < B.n; i++) {
+            offs[(size_t)b][(size_t)i] = total;
+            char num[24]; const int nd = snprintf(num, sizeof num, "%d", B.qid[i]);
+            const uint64_t nops = (uint64_t)(B.cigar_off[i + 1] - B.cigar_off[i]);
+            total += 4 + 32 + plen + (size_t)nd + 1 + 4 * nops + ((uint64_t)B.L + 1) / 2 + (uint64_t)B.L + 14;
+        }
+        offs[(size_t)b][(size_t)B.n] = total;
+    }
+    std::vector<char> raw(total);
+    memcpy(raw.data(), head.data(), head.size());
+    const int nt = n_threads(threads);
+    for (int b = 0; b < n_batches; b++) {
+        const phz_read_batch &B = batches[b];
+        const size_t plen = strlen(B.qname_prefix);
+        std::atomic<int64_t> next(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&] {
+                for (;;) {
+                    const int64_t lo = next.fetch_add(65536);
+                    if (lo >= B.n) break;
+                    const int64_t hi = std::min<int64_t>(B.n, lo + 65536);
+                    for (int64_t i = lo; i < hi; i++) {
+                        char *o = raw.data() + offs[(size_t)b][(size_t)i];
+                        const uint64_t size = offs[(size_t)b][(size_t)i + 1] - offs[(size_t)b][(size_t)i];
+                        char num[24]; const int nd = snprintf(num, sizeof num, "%d", B.qid[i]);
+                        const int32_t nops = (int32_t)(B.cigar_off[i + 1] - B.cigar_off[i]);
+                        auto w32 = [&](int32_t v) { memcpy(o, &v, 4); o += 4; };
+                        auto w16 = [&](uint16_t v) { memcpy(o, &v, 2); o += 2; };
+                        w32((int32_t)(size - 4)); w32(B.ref_id); w32(B.pos[i] - 1);
+                        *o++ = (char)(plen + (size_t)nd + 1); *o++ = (char)B.mapq[i]; w16(4680); w16((uint16_t)nops); w16((uint16_t)B.flag[i]);
+                        w32(B.L); w32(B.ref_id); w32(B.pos[i] - 1 > 0 ? B.pos[i] - 1 : 0); w32(B.tlen[i]);
+                        memcpy(o, B.qname_prefix, plen); o += plen; memcpy(o, num, (size_t)nd); o += nd; *o++ = 0;
+                        memcpy(o, B.cigar + B.cigar_off[i], 4 * (size_t)nops); o += 4 * (size_t)nops;
+                        const uint8_t *sq = B.seq + (size_t)i * (size_t)B.L, *ql = B.qual + (size_t)i * (size_t)B.L;
+                        for (int k = 0; k < B.L; k += 2) {
+                            const uint8_t a = NT16[sq[k] > 4 ? 4 : sq[k]], c = k + 1 < B.L ? NT16[sq[k + 1] > 4 ? 4 : sq[k + 1]] : 0;
+                            *o++ = (char)((a << 4) | c);
+                        }
+                        memcpy(o, ql, (size_t)B.L); o += B.L;
+                        memcpy(o, "NHi", 3); o += 3; w32(1);
+                        memcpy(o, "ASi", 3); o += 3; w32(B.aln_score[i]);
+                    }
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    return phz_bgzf_write(path, raw.data(), (int64_t)raw.size(), threads, 6);
+}
+
 }  // extern "C"

@@ -135,3 +135,15 @@ def test_native_bgzf_write_and_read(tmp_path):
 def bamio_eof():
     from phaser_amd import bamio
     return bamio._EOF
+
+
+def test_native_bam_writer_matches_python_writer(tmp_path):
+    """phz_bam_write (used for the at-scale runs) produces the same BAM stream as the Python writer the other tests rely on."""
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, gs, ge, w = synth.make_variants("chr22", 1, 3_000_000, 300, 201, n_genes=20)
+    rb = synth.make_reads(v, gs, ge, w, 1500, 202)
+    refs = [("chr21", 46709983), ("chr22", 50818468)]
+    a = str(tmp_path / "a.bam"); b = str(tmp_path / "b.bam")
+    bamio.readbatch_to_bam(a, [rb], refs); bamio.readbatch_to_bam_native(b, [rb], refs, 3)
+    assert gzip.open(a, "rb").read() == gzip.open(b, "rb").read()

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""GPU-box end-to-end run of the drop-in CLI at BASELINE.json configs[2] shape FROM FILES: a synthetic coordinate-sorted BAM
+(unfiltered: duplicates, improper pairs, low MAPQ present) and a bgzipped VCF are written to /tmp first (native writers,
+not timed), then `python -m phaser_amd.phaser` runs on them exactly as a user would: BGZF inflate + BAM decode + filters +
+QNAME interning on the host, H2D, K_map, AS cutoff, K_tally, phasing, the five files (+ the phased VCF with --write_vcf 1).
+usage: tools/run_cli_scale.py [scale=1.0] [threads=32] [write_vcf=0]"""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+import torch
+from phaser_amd import bamio, synth, vcfout
+HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309,
+        114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468]
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+write_vcf = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+total_len = sum(HG38)
+t0 = time.perf_counter()
+refs = [("chr%d" % (i + 1), ln) for i, ln in enumerate(HG38)]
+vsets = []; batches = []
+nrec = 0
+for i, ln in enumerate(HG38):
+    chrom = "chr%d" % (i + 1)
+    n_snps = int(1_500_000 * scale * ln / total_len); n_pairs = int(40_000_000 * scale * ln / total_len)
+    v, gs, ge, w = synth.make_variants(chrom, 1, ln, n_snps, 777 + i, n_genes=max(1, n_snps // 10))
+    plan = synth.make_read_plan(v, gs, ge, w, n_pairs, 1777 + i, device="cuda")
+    for lo in range(0, len(plan), 2_000_000):
+        rb = synth.fill_reads(plan, lo, min(len(plan), lo + 2_000_000), v, qname_prefix="s0.b0.%d." % i)
+        batches.append(synth.ReadBatch(rb.chrom, rb.L, rb.pos.cpu(), rb.flag.cpu(), rb.mapq.cpu(), rb.tlen.cpu(), rb.aln_score.cpu(), rb.qid.cpu(),
+                                       rb.cigar_off.cpu(), rb.cigar.cpu(), rb.seq.cpu(), rb.qual.cpu(), rb.qname_prefix))
+        nrec += len(rb)
+    vsets.append(v)
+    del plan
+torch.cuda.synchronize(); t1 = time.perf_counter()
+bam = "/tmp/cli_scale.bam"; vcfgz = "/tmp/cli_scale.vcf.gz"
+bamio.readbatch_to_bam_native(bam, batches, refs, threads)
+del batches
+vcfout.write_bgzf(vcfgz, "\n".join(synth.vcf_lines(vsets)) + "\n", threads)
+t2 = time.perf_counter()
+print("inputs: %d records, %d het SNPs | generate %.1fs | write BAM (%.2f GB) + VCF.gz (%.1f MB) %.1fs" %
+      (nrec, sum(len(v) for v in vsets), t1 - t0, os.path.getsize(bam) / 1e9, os.path.getsize(vcfgz) / 1e6, t2 - t1), flush=True)
+torch.cuda.empty_cache()
+from phaser_amd import phaser
+t3 = time.perf_counter()
+rc = phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1", "--o", "/tmp/cli_scale_out",
+                  "--threads", str(threads), "--write_vcf", str(write_vcf)])
+t4 = time.perf_counter()
+sizes = {n: os.path.getsize("/tmp/cli_scale_out.%s.txt" % n) for n in ("allelic_counts", "variant_connections", "haplotypes", "haplotypic_counts", "allele_config")}
+print("CLI rc=%d wall %.1fs for %d BAM records (%.0f records/s end to end from files) | outputs %s" % (rc, t4 - t3, nrec, nrec / (t4 - t3), sizes))
