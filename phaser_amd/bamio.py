@@ -245,10 +245,14 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
     import ctypes as C
     from . import _lib
     lib = _lib.load()
+    import time as _t0m
+    _topen = _t0m.perf_counter()
     h = C.c_void_p()
     st = lib.phz_bam_open(path.encode(), threads, C.byref(h))
     if st != 0:
         raise _lib.PhzError(st, "cannot read BAM " + path)
+    import os as _os, sys as _sys, time as _t
+    _prof = _os.environ.get("PHZ_TIMING"); _t0 = _t.perf_counter(); _tin = 0.0
     try:
         n_ref = lib.phz_bam_n_ref(h)
         names = [lib.phz_bam_ref_name(h, i).decode() for i in range(n_ref)]
@@ -261,6 +265,7 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
         if st != 0:
             raise _lib.PhzError(st, "BAM decode failed")
         out = {}
+        _t1 = _t.perf_counter()
         for i in range(ns.value):
             hs = _lib.phz_host_shard()
             lib.phz_bam_shard(h, i, C.byref(hs))
@@ -278,11 +283,16 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
                                arr(hs.qual, hs.n_seq_bytes * 4, torch.uint8))
             it = interners.setdefault(chrom, NativeInterner())
             qid = np.zeros(n, dtype=np.int32)
+            _ti = _t.perf_counter()
             lib.phz_intern(it.h, hs.qnames, hs.qname_off, n, C.c_void_p(qid.ctypes.data))
+            _tin += _t.perf_counter() - _ti
             sh.qid = torch.from_numpy(qid)
             sh.aln_score = arr(hs.aln_score, n, torch.int32)
             sh.has_as = arr(hs.has_as, n, torch.uint8)
             out[chrom] = sh
+        if _prof:
+            _sys.stderr.write("[phz timing]   bam: open+inflate %.2f s, decode+filter+pack %.2f s, copies to tensors %.2f s, qname interning %.2f s\n"
+                              % (_t0 - _topen, _t1 - _t0, _t.perf_counter() - _t1 - _tin, _tin))
         return out
     finally:
         lib.phz_bam_close(h)

@@ -11,7 +11,9 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -103,8 +105,22 @@ inline int norm_ops(const uint8_t *cig, int n_cig, int nb, uint32_t *out) {
     return n;
 }
 
+// inflate target: plain malloc (a std::vector would zero-fill tens of GB on one thread before the parallel inflate writes them)
+struct RawBuf {
+    uint8_t *p = nullptr; size_t n = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    bool resize(size_t m) { free(p); p = (uint8_t *)malloc(m ? m + 1 : 1); n = p ? m : 0; return p != nullptr; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    uint8_t *release() { uint8_t *q = p; p = nullptr; n = 0; return q; }
+};
+
 struct Bam {
-    std::vector<uint8_t> data;                 // inflated BAM stream
+    RawBuf data;                               // inflated BAM stream
     std::vector<std::pair<std::string, int32_t>> refs;
     size_t first_record = 0;
     std::vector<Shard> shards;                 // result of the last decode, indexed by position in `order`
@@ -163,7 +179,7 @@ int inflate_bgzf_file(const char *path, int threads, Vec &outbuf) {
     }
     if (status == PHZ_OK && blks.empty()) status = PHZ_E_ARG;
     if (status != PHZ_OK) { munmap((void *)f, fsz); return status; }
-    outbuf.resize(total);
+    if (!outbuf.resize(total)) { munmap((void *)f, fsz); return PHZ_E_NOMEM; }
     const int nt = n_threads(threads);
     std::atomic<size_t> next(0);
     std::atomic<bool> bad(false);
@@ -185,8 +201,25 @@ int inflate_bgzf_file(const char *path, int threads, Vec &outbuf) {
 
 struct phz_bam { Bam b; };
 
+// QNAME table split into hash partitions so that one call can be processed by many threads; ids are still handed out in
+// first-appearance order over the whole input (what a sequential dictionary would do), see phz_intern.
 struct phz_interner {
-    std::unordered_map<std::string, int32_t> ids;
+    static constexpr int P = 64;
+    struct Part {
+        std::unordered_map<std::string_view, int32_t> ids;
+        std::vector<std::unique_ptr<char[]>> arena; size_t arena_used = 0, arena_cap = 0;
+        const char *keep(std::string_view s) {
+            if (arena_used + s.size() > arena_cap) {
+                arena_cap = std::max<size_t>(1 << 20, s.size());
+                arena.emplace_back(new char[arena_cap]); arena_used = 0;
+            }
+            char *d = arena.back().get() + arena_used;
+            memcpy(d, s.data(), s.size()); arena_used += s.size();
+            return d;
+        }
+    };
+    Part part[P];
+    std::vector<std::string_view> names;          // id -> name
 };
 
 extern "C" {
@@ -195,7 +228,7 @@ int phz_bam_open(const char *path, int threads, phz_bam **out) {
     *out = nullptr;
     phz_bam *h = new phz_bam();
     if (int st = inflate_bgzf_file(path, threads, h->b.data)) { delete h; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
-    const std::vector<uint8_t> &d = h->b.data;
+    const RawBuf &d = h->b.data;
     if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { delete h; return PHZ_E_ARG; }
     size_t p = 8 + (size_t)rdi32(d.data() + 4);
     const int32_t n_ref = rdi32(d.data() + p); p += 4;
@@ -345,29 +378,102 @@ int phz_bam_shard(phz_bam *h, int i, phz_host_shard *out) {
 
 int phz_interner_create(phz_interner **out) { *out = new phz_interner(); return PHZ_OK; }
 int phz_interner_destroy(phz_interner *it) { delete it; return PHZ_OK; }
-int64_t phz_interner_size(const phz_interner *it) { return (int64_t)it->ids.size(); }
+int64_t phz_interner_size(const phz_interner *it) { return (int64_t)it->names.size(); }
 
-// QNAME -> id in first-appearance order (mates and the same template in later BAMs get the same id)
+// QNAME -> id in first-appearance order (mates and the same template in later BAMs get the same id).  Parallel: names are
+// bucketed by hash; every bucket resolves its names against its own table in input order and marks the first occurrence of
+// each new name; a prefix sum over those marks numbers the new names in input order; a last sweep writes the ids.
 int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t n, int32_t *out_id) {
-    it->ids.reserve(it->ids.size() + (size_t)n / 2);
-    for (int64_t i = 0; i < n; i++) {
-        std::string key(blob + off[i], off[i + 1] - off[i]);
-        auto r = it->ids.emplace(std::move(key), (int32_t)it->ids.size());
-        out_id[i] = r.first->second;
+    constexpr int P = phz_interner::P;
+    if (n <= 0) return PHZ_OK;
+    const int nt = n_threads(0);
+    auto par = [&](int64_t count, auto fn) {          // fn(lo, hi) over [0, count) in nt slices
+        if (count < 65536 || nt == 1) { fn((int64_t)0, count); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back([&, t] { fn(count * t / nt, count * (t + 1) / nt); });
+        for (auto &x : th) x.join();
+    };
+    auto name_of = [&](int64_t i) { return std::string_view(blob + off[i], off[i + 1] - off[i]); };
+    std::vector<uint8_t> bucket((size_t)n);
+    par(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) bucket[(size_t)i] = (uint8_t)(std::hash<std::string_view>()(name_of(i)) % P); });
+    std::vector<int64_t> start(P + 1, 0);
+    for (int64_t i = 0; i < n; i++) start[(size_t)bucket[(size_t)i] + 1]++;
+    for (int p = 0; p < P; p++) start[(size_t)p + 1] += start[(size_t)p];
+    std::vector<int32_t> order((size_t)n);
+    { std::vector<int64_t> cur(start.begin(), start.end() - 1); for (int64_t i = 0; i < n; i++) order[(size_t)cur[bucket[(size_t)i]]++] = (int32_t)i; }
+    // rep[i] >= 0: index of the first occurrence of this new name in the input; < 0: -(existing id) - 1
+    std::vector<int32_t> rep((size_t)n);
+    std::vector<uint8_t> first((size_t)n, 0);
+    {
+        std::atomic<int> next(0);
+        auto work = [&] {
+            for (;;) {
+                const int p = next.fetch_add(1);
+                if (p >= P) break;
+                phz_interner::Part &T = it->part[p];
+                std::unordered_map<std::string_view, int32_t> fresh;
+                fresh.reserve((size_t)(start[(size_t)p + 1] - start[(size_t)p]) / 2 + 8);
+                for (int64_t k = start[(size_t)p]; k < start[(size_t)p + 1]; k++) {
+                    const int32_t i = order[(size_t)k];
+                    const std::string_view nm = name_of(i);
+                    auto e = T.ids.find(nm);
+                    if (e != T.ids.end()) { rep[(size_t)i] = -e->second - 1; continue; }
+                    auto r = fresh.emplace(nm, i);
+                    rep[(size_t)i] = r.first->second;
+                    if (r.second) first[(size_t)i] = 1;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < std::min(nt, P); t++) th.emplace_back(work);
+        for (auto &x : th) x.join();
+    }
+    const int64_t base = (int64_t)it->names.size();
+    std::vector<int32_t> rank((size_t)n);
+    int64_t nnew = 0;
+    for (int64_t i = 0; i < n; i++) { rank[(size_t)i] = (int32_t)nnew; nnew += first[(size_t)i]; }
+    if (base + nnew > 0x7fffffff) return PHZ_E_ARG;
+    par(n, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            const int32_t r = rep[(size_t)i];
+            out_id[i] = r < 0 ? -r - 1 : (int32_t)(base + rank[(size_t)r]);
+        }
+    });
+    // the new names enter their bucket's table (own copy of the text: the caller's blob goes away)
+    it->names.resize((size_t)(base + nnew));
+    {
+        std::atomic<int> next(0);
+        auto work = [&] {
+            for (;;) {
+                const int p = next.fetch_add(1);
+                if (p >= P) break;
+                phz_interner::Part &T = it->part[p];
+                for (int64_t k = start[(size_t)p]; k < start[(size_t)p + 1]; k++) {
+                    const int32_t i = order[(size_t)k];
+                    if (!first[(size_t)i]) continue;
+                    const std::string_view nm = name_of(i);
+                    const std::string_view kept(T.keep(nm), nm.size());
+                    const int32_t id = (int32_t)(base + rank[(size_t)i]);
+                    T.ids.emplace(kept, id);
+                    it->names[(size_t)id] = kept;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < std::min(nt, P); t++) th.emplace_back(work);
+        for (auto &x : th) x.join();
     }
     return PHZ_OK;
 }
 
 // names of ids [0, size) as a blob + offsets (for --output_read_ids)
 int phz_interner_names(const phz_interner *it, char *blob, int64_t blob_cap, uint32_t *off) {
-    const size_t n = it->ids.size();
-    std::vector<const std::string *> by(n);
-    for (auto &kv : it->ids) by[(size_t)kv.second] = &kv.first;
+    const size_t n = it->names.size();
     uint64_t o = 0;
     for (size_t i = 0; i < n; i++) {
         off[i] = (uint32_t)o;
-        if ((int64_t)(o + by[i]->size()) <= blob_cap) memcpy(blob + o, by[i]->data(), by[i]->size());
-        o += by[i]->size();
+        if ((int64_t)(o + it->names[i].size()) <= blob_cap) memcpy(blob + o, it->names[i].data(), it->names[i].size());
+        o += it->names[i].size();
     }
     off[n] = (uint32_t)o;
     return (int64_t)o <= blob_cap ? PHZ_OK : PHZ_E_CAPACITY;
@@ -378,12 +484,11 @@ int phz_interner_names(const phz_interner *it, char *blob, int64_t blob_cap, uin
 int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len) {
     if (!path || !data || !len) return PHZ_E_ARG;
     *data = nullptr; *len = 0;
-    std::vector<char> buf;
+    RawBuf buf;
     if (int st = inflate_bgzf_file(path, threads, buf)) return st;
-    char *p = (char *)malloc(buf.size() + 1);
-    if (!p) return PHZ_E_NOMEM;
-    memcpy(p, buf.data(), buf.size()); p[buf.size()] = 0;
-    *data = p; *len = (int64_t)buf.size();
+    *len = (int64_t)buf.size();
+    buf.data()[buf.size()] = 0;
+    *data = (char *)buf.release();
     return PHZ_OK;
 }
 

@@ -125,6 +125,10 @@ def main(argv=None):
         if xfile != "" and not os.path.isfile(xfile):
             fatal_error("File: %s not found." % xfile)
     start = time.time()
+    marks = [("start", time.perf_counter())]
+
+    def mark(name):          # PHZ_TIMING=1: stage timings on stderr at the end (not part of the reference's output)
+        marks.append((name, time.perf_counter()))
     say('STARTED "Read backed phasing and ASE/haplotype analyses" ... ')
     say("    DATE, TIME : %s" % (datetime.datetime.now().strftime('%Y-%m-%d, %H:%M:%S')))
     say("#1. Loading heterozygous variants into intervals...")
@@ -164,6 +168,7 @@ def main(argv=None):
                 continue
             kept.append(cut)
         vs = vcf.load_variants("\n".join(kept), sample_column=9, **load_kw)
+    mark("vcf read + het-variant table")
     haplo_bl = set()
     if args.haplo_count_blacklist != "":
         say("#1b. Loading haplotypic count blacklist intervals...")
@@ -227,6 +232,7 @@ def main(argv=None):
         else:   # native BGZF inflate + packer + QNAME interning (phz_bam_*), --threads host threads
             shards = bamio.shards_from_bam_native(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
                                                   threads=max(0, args.threads if args.threads > 1 else 0))
+        mark("bam decode + filters + qname interning")
         for chrom in vs.chroms:
             if chrom in shards and chrom in mine:
                 eng.add_shard(bi, chrom, shards[chrom].to(device), len(interners[chrom]),
@@ -235,15 +241,18 @@ def main(argv=None):
         for chrom in interners:
             if chrom in eng.n_qid:
                 eng.n_qid[chrom] = len(interners[chrom])
+        mark("H2D + K_map")
         say("          processing mapped reads...")
         n_before = len(eng.log)
         eng.close_bam(bi)
+        mark("AS cutoff")
         for line in eng.log[n_before:]:
             say(line)
     say("#3. Identifying connected variants...")
     say("     calculating sequencing noise level...")
     n_before = len(eng.log)
     files = eng.finish(chunks=True)
+    mark("tally + pair tests + components + block phasing + rows")
     if files is not None:
         for line in eng.log[n_before:]:
             say(line)
@@ -253,6 +262,7 @@ def main(argv=None):
         for name, body in files.items():
             with open(args.o + "." + name + ".txt", "wb") as f:
                 f.writelines(body)
+        mark("write the five files")
         up = pc = 0
         if args.write_vcf == 1:
             from . import vcfout
@@ -265,8 +275,10 @@ def main(argv=None):
                 say("     GT field is not being updated with phASER genome wide phase. This can be changed using the --gw_phase_vcf argument.")
             vtxt, up, pc = vcfout.phased_vcf_text(data, sample_col, eng, args.id_separator, args.chr, args.gw_phase_vcf,
                                                   args.gw_phase_vcf_min_confidence, threads=max(1, args.threads))
+            mark("phased VCF text")
             say("     Compressing output VCF (BGZF; no tabix index is written by this build)...")
-            vcfout.write_bgzf(args.o + ".vcf.gz", vtxt)
+            vcfout.write_bgzf(args.o + ".vcf.gz", vtxt, max(0, args.threads if args.threads > 1 else 0))
+            mark("phased VCF bgzf")
         say('')
         say("     COMPLETED using %d reads in %d seconds using %d GPU(s)" % (eng.total_lines, time.time() - start, world))
         say("     PHASED  %d of %d all variants (= %f) with at least one other variant" %
@@ -277,6 +289,10 @@ def main(argv=None):
             say("     GENOME WIDE PHASE CORRECTED  %d of %d variants (= %f)" % (pc, vs.het_count, float(pc) / float(vs.het_count)))
         say('')
         say("The End.")
+        if os.environ.get("PHZ_TIMING"):
+            for (_, t_prev), (name, t) in zip(marks[:-1], marks[1:]):
+                sys.stderr.write("[phz timing] %-55s %7.2f s\n" % (name, t - t_prev))
+            sys.stderr.write("[phz timing] %-55s %7.2f s\n" % ("total", marks[-1][1] - marks[0][1]))
     if world > 1:
         dist.barrier()
     return 0

@@ -147,3 +147,25 @@ def test_native_bam_writer_matches_python_writer(tmp_path):
     a = str(tmp_path / "a.bam"); b = str(tmp_path / "b.bam")
     bamio.readbatch_to_bam(a, [rb], refs); bamio.readbatch_to_bam_native(b, [rb], refs, 3)
     assert gzip.open(a, "rb").read() == gzip.open(b, "rb").read()
+
+
+def test_parallel_interner_numbers_by_first_appearance():
+    """phz_intern (hash-partitioned, threaded) hands out the ids a sequential dictionary would, across calls."""
+    import ctypes as C
+    from phaser_amd import _lib, bamio
+    _lib.build()
+    rng = np.random.default_rng(3)
+    it = bamio.NativeInterner()
+    table = {}
+    for call in range(3):
+        n = 150_000
+        ids = rng.integers(0, 90_000 * (call + 1), n)
+        names = [b"q%d.%d" % (x % 7, x) for x in ids.tolist()]
+        off = np.zeros(n + 1, dtype=np.uint32); off[1:] = np.cumsum([len(x) for x in names])
+        blob = b"".join(names)
+        out = np.zeros(n, dtype=np.int32)
+        it.lib.phz_intern(it.h, blob, C.c_void_p(off.ctypes.data), n, C.c_void_p(out.ctypes.data))
+        want = [table.setdefault(x, len(table)) for x in names]
+        assert out.tolist() == want
+        assert len(it) == len(table)
+    assert it.names == [k.decode() for k in table]
