@@ -189,7 +189,8 @@ int phz_bam_close(phz_bam *bam);
 int phz_bam_n_ref(const phz_bam *bam);
 const char *phz_bam_ref_name(const phz_bam *bam, int i);
 int64_t phz_bam_ref_length(const phz_bam *bam, int i);
-/* keep records with ref_mask[refID] != 0 (NULL = all), MAPQ >= min_mapq, (flag & required) == required,
+/* one-shot (the inflated stream is released afterwards):
+ * keep records with ref_mask[refID] != 0 (NULL = all), MAPQ >= min_mapq, (flag & required) == required,
  * (flag & forbidden) == 0 and |TLEN| <= isize_cutoff when isize_cutoff != 0 */
 int phz_bam_decode(phz_bam *bam, const uint8_t *ref_mask, int min_mapq, int flag_required, int flag_forbidden,
                    double isize_cutoff, int threads, int *n_shards);

@@ -6,6 +6,8 @@ product path raises.  The CPU restatement under oracle/ is test infrastructure o
 from __future__ import annotations
 
 import ctypes as C
+
+import numpy as np
 import os
 import subprocess
 from typing import Optional
@@ -283,3 +285,23 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class OwnedArray(np.ndarray):
+    """numpy view of native memory that keeps the owning handle alive (zero-copy hand-over of library buffers)."""
+
+    def __new__(cls, arr, owner):
+        obj = arr.view(cls)
+        obj._owner = owner
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
+def native_view(ptr, count: int, ctype, owner):
+    """-> numpy array over `count` items of `ctype` at `ptr`, alive as long as the array (or anything built on it) is."""
+    if count == 0 or not ptr:
+        return np.zeros(0, dtype=np.dtype(ctype))
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,))
+    return OwnedArray(a, owner)

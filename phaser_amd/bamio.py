@@ -253,46 +253,51 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
         raise _lib.PhzError(st, "cannot read BAM " + path)
     import os as _os, sys as _sys, time as _t
     _prof = _os.environ.get("PHZ_TIMING"); _t0 = _t.perf_counter(); _tin = 0.0
-    try:
-        n_ref = lib.phz_bam_n_ref(h)
-        names = [lib.phz_bam_ref_name(h, i).decode() for i in range(n_ref)]
-        mask = np.array([1 if (chroms is None or nm in chroms) else 0 for nm in names], dtype=np.uint8)
-        ns = C.c_int(0)
-        st = lib.phz_bam_decode(h, C.c_void_p(mask.ctypes.data), int(mapq), 0x2 if paired_end else 0, 0x400 if remove_dups else 0,
-                                float(isize_cutoff), threads, C.byref(ns))
-        if st == _lib.PHZ_E_UNSUPPORTED:
-            raise _lib.PhzError(st, "BAM is not coordinate-sorted (the mapper is a merge join over sorted reads)")
-        if st != 0:
-            raise _lib.PhzError(st, "BAM decode failed")
-        out = {}
-        _t1 = _t.perf_counter()
-        for i in range(ns.value):
-            hs = _lib.phz_host_shard()
-            lib.phz_bam_shard(h, i, C.byref(hs))
-            n = hs.n_reads
 
-            def arr(ptr, count, dt):
-                if count == 0:
-                    return torch.zeros(0, dtype=dt)
-                ct = {torch.int32: C.c_int32, torch.uint8: C.c_uint8}[dt]
-                a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(count,))
-                return torch.from_numpy(a.copy())
-            chrom = hs.ref_name.decode()
-            sh = soa.ReadShard(arr(hs.pos, n, torch.int32), arr(hs.cigar_off, n + 1, torch.int32), arr(hs.cigar, hs.n_ops, torch.int32),
-                               arr(hs.seq_off, n + 1, torch.int32), arr(hs.seq2, hs.n_seq_bytes, torch.uint8),
-                               arr(hs.qual, hs.n_seq_bytes * 4, torch.uint8))
-            it = interners.setdefault(chrom, NativeInterner())
-            qid = np.zeros(n, dtype=np.int32)
-            _ti = _t.perf_counter()
-            lib.phz_intern(it.h, hs.qnames, hs.qname_off, n, C.c_void_p(qid.ctypes.data))
-            _tin += _t.perf_counter() - _ti
-            sh.qid = torch.from_numpy(qid)
-            sh.aln_score = arr(hs.aln_score, n, torch.int32)
-            sh.has_as = arr(hs.has_as, n, torch.uint8)
-            out[chrom] = sh
-        if _prof:
-            _sys.stderr.write("[phz timing]   bam: open+inflate %.2f s, decode+filter+pack %.2f s, copies to tensors %.2f s, qname interning %.2f s\n"
-                              % (_t0 - _topen, _t1 - _t0, _t.perf_counter() - _t1 - _tin, _tin))
-        return out
-    finally:
-        lib.phz_bam_close(h)
+    class _Owner:                      # closes the decoder when the last shard array built on its memory is gone
+        def __init__(self, lib, h):
+            self.lib = lib; self.h = h
+
+        def __del__(self):
+            try:
+                self.lib.phz_bam_close(self.h)
+            except Exception:
+                pass
+    owner = _Owner(lib, h)
+    n_ref = lib.phz_bam_n_ref(h)
+    names = [lib.phz_bam_ref_name(h, i).decode() for i in range(n_ref)]
+    mask = np.array([1 if (chroms is None or nm in chroms) else 0 for nm in names], dtype=np.uint8)
+    ns = C.c_int(0)
+    st = lib.phz_bam_decode(h, C.c_void_p(mask.ctypes.data), int(mapq), 0x2 if paired_end else 0, 0x400 if remove_dups else 0,
+                            float(isize_cutoff), threads, C.byref(ns))
+    if st == _lib.PHZ_E_UNSUPPORTED:
+        raise _lib.PhzError(st, "BAM is not coordinate-sorted (the mapper is a merge join over sorted reads)")
+    if st != 0:
+        raise _lib.PhzError(st, "BAM decode failed")
+    out = {}
+    _t1 = _t.perf_counter()
+    for i in range(ns.value):
+        hs = _lib.phz_host_shard()
+        lib.phz_bam_shard(h, i, C.byref(hs))
+        n = hs.n_reads
+
+        def arr(ptr, count, dt):       # zero-copy: the tensors live in the decoder's buffers (kept alive through `owner`)
+            ct = {torch.int32: C.c_int32, torch.uint8: C.c_uint8}[dt]
+            return torch.from_numpy(_lib.native_view(ptr, count, ct, owner))
+        chrom = hs.ref_name.decode()
+        sh = soa.ReadShard(arr(hs.pos, n, torch.int32), arr(hs.cigar_off, n + 1, torch.int32), arr(hs.cigar, hs.n_ops, torch.int32),
+                           arr(hs.seq_off, n + 1, torch.int32), arr(hs.seq2, hs.n_seq_bytes, torch.uint8),
+                           arr(hs.qual, hs.n_seq_bytes * 4, torch.uint8))
+        it = interners.setdefault(chrom, NativeInterner())
+        qid = np.zeros(n, dtype=np.int32)
+        _ti = _t.perf_counter()
+        lib.phz_intern(it.h, hs.qnames, hs.qname_off, n, C.c_void_p(qid.ctypes.data))
+        _tin += _t.perf_counter() - _ti
+        sh.qid = torch.from_numpy(qid)
+        sh.aln_score = arr(hs.aln_score, n, torch.int32)
+        sh.has_as = arr(hs.has_as, n, torch.uint8)
+        out[chrom] = sh
+    if _prof:
+        _sys.stderr.write("[phz timing]   bam: open+inflate %.2f s, decode+filter+pack %.2f s, shard views %.2f s, qname interning %.2f s\n"
+                          % (_t0 - _topen, _t1 - _t0, _t.perf_counter() - _t1 - _tin, _tin))
+    return out

@@ -24,11 +24,28 @@
 
 namespace {
 
+// inflate target: plain malloc (a std::vector would zero-fill tens of GB on one thread before the parallel inflate writes them)
+struct RawBuf {
+    uint8_t *p = nullptr; size_t n = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    RawBuf(RawBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    RawBuf &operator=(RawBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~RawBuf() { free(p); }
+    bool resize(size_t m) { free(p); p = (uint8_t *)malloc(m ? m + 1 : 1); n = p ? m : 0; return p != nullptr; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    uint8_t *release() { uint8_t *q = p; p = nullptr; n = 0; return q; }
+};
+
 struct Shard {
     std::string name;
     std::vector<int32_t> pos, aln;
     std::vector<uint32_t> cigar_off, cigar, seq_off, qname_off;
-    std::vector<uint8_t> seq2, qual, has_as;
+    std::vector<uint8_t> has_as;
+    RawBuf seq2, qual;                         // filled record by record in the parallel pack (no serial zero fill)
     std::vector<char> qnames;
 };
 
@@ -104,20 +121,6 @@ inline int norm_ops(const uint8_t *cig, int n_cig, int nb, uint32_t *out) {
     }
     return n;
 }
-
-// inflate target: plain malloc (a std::vector would zero-fill tens of GB on one thread before the parallel inflate writes them)
-struct RawBuf {
-    uint8_t *p = nullptr; size_t n = 0;
-    RawBuf() = default;
-    RawBuf(const RawBuf &) = delete;
-    RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
-    bool resize(size_t m) { free(p); p = (uint8_t *)malloc(m ? m + 1 : 1); n = p ? m : 0; return p != nullptr; }
-    uint8_t *data() { return p; }
-    const uint8_t *data() const { return p; }
-    size_t size() const { return n; }
-    uint8_t *release() { uint8_t *q = p; p = nullptr; n = 0; return q; }
-};
 
 struct Bam {
     RawBuf data;                               // inflated BAM stream
@@ -258,6 +261,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
     // pass 1: hop over the record chain, apply the filters, size everything
     struct Rec { size_t off; int32_t ref; uint32_t n_ops, nb; };
     std::vector<Rec> recs;
+    recs.reserve(n / 180 + 1024);
     std::vector<int32_t> last_pos((size_t)n_ref, -1);      // the mapper is a merge join: every reference must be coordinate-sorted
     size_t p = b.first_record;
     while (p + 4 <= n) {
@@ -310,7 +314,8 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         }
         if (co >= (1ull << 31) || so >= (1ull << 31) || qo >= (1ull << 32)) { b.err = "shard exceeds 32-bit offsets"; return PHZ_E_UNSUPPORTED; }
         s.cigar_off[m] = (uint32_t)co; s.seq_off[m] = (uint32_t)so; s.qname_off[m] = (uint32_t)qo;
-        s.cigar.resize(co); s.seq2.assign(so, 0); s.qual.assign(so * 4, 0); s.qnames.resize(qo);
+        s.cigar.resize(co); s.qnames.resize(qo);
+        if (!s.seq2.resize(so) || !s.qual.resize(so * 4)) return PHZ_E_NOMEM;
         // pass 2: pack in parallel
         const int nt = n_threads(threads);
         std::atomic<size_t> next(0);
@@ -337,6 +342,8 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
                         const uint8_t *ql = sq + ((size_t)(l_seq > 0 ? l_seq : 0) + 1) / 2;
                         uint8_t *o2 = s.seq2.data() + s.seq_off[k];
                         uint8_t *oq = s.qual.data() + (size_t)s.seq_off[k] * 4;
+                        memset(o2, 0, (size_t)(x.nb + 3) / 4);
+                        memset(oq + (x.nb & ~3u), 0, (size_t)((x.nb + 3) / 4 * 4 - (x.nb & ~3u)));     // last group incl. padding
                         if (l_seq <= 0) {                  // SEQ '*' QUAL '*': one IUPAC-other character with phred 9
                             o2[0] = 1; oq[0] = (uint8_t)(9 | 0x80);
                         } else {
@@ -362,6 +369,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         for (auto &t : th) t.join();
     }
     *n_shards = (int)b.shards.size();
+    b.data.resize(0);            // the inflated stream is not needed once the shards are packed (decode is a one-shot call)
     return PHZ_OK;
 }
 

@@ -125,23 +125,10 @@ class _NativeRows:
         n = getattr(self.O, name + "_len")
         if not n:
             return b""
-        arr = np.ctypeslib.as_array(C.cast(getattr(self.O, name), C.POINTER(C.c_uint8)), shape=(n,))
-        return memoryview(_Keep(arr, self))
+        return memoryview(_lib.native_view(getattr(self.O, name), n, C.c_uint8, self))
 
     def __del__(self):
         try:
             self.lib.phz_rows_free(C.byref(self.O))
         except Exception:
             pass
-
-
-class _Keep(np.ndarray):
-    """uint8 view of native memory that keeps its owner alive (memoryview(_Keep) -> the buffer the merge / file writer reads)."""
-
-    def __new__(cls, arr, owner):
-        obj = arr.view(cls)
-        obj._owner = owner
-        return obj
-
-    def __array_finalize__(self, obj):
-        self._owner = getattr(obj, "_owner", None)
