@@ -5,6 +5,7 @@
 // Multi-threaded raw-deflate inflate of the BGZF members (zlib), one sequential hop over the record chain,
 // multi-threaded packing into exactly the arrays soa.pack_sam() builds (tests compare them bit for bit).
 #include <fcntl.h>
+#include <stdio.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -26,18 +27,36 @@ namespace {
 
 // inflate target: plain malloc (a std::vector would zero-fill tens of GB on one thread before the parallel inflate writes them)
 struct RawBuf {
-    uint8_t *p = nullptr; size_t n = 0;
+    uint8_t *p = nullptr; size_t n = 0, mapped = 0;
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    RawBuf(RawBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    RawBuf &operator=(RawBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
-    ~RawBuf() { free(p); }
-    bool resize(size_t m) { free(p); p = (uint8_t *)malloc(m ? m + 1 : 1); n = p ? m : 0; return p != nullptr; }
+    RawBuf(RawBuf &&o) noexcept : p(o.p), n(o.n), mapped(o.mapped) { o.p = nullptr; o.n = 0; o.mapped = 0; }
+    RawBuf &operator=(RawBuf &&o) noexcept { if (this != &o) { drop(); p = o.p; n = o.n; mapped = o.mapped; o.p = nullptr; o.n = 0; o.mapped = 0; } return *this; }
+    ~RawBuf() { drop(); }
+    void drop() { if (mapped) munmap(p, mapped); else free(p); p = nullptr; n = 0; mapped = 0; }
+    // big buffers come from an anonymous mapping with transparent huge pages requested: the threads that fill them take
+    // 512x fewer page faults than with 4 KB pages
+    bool resize(size_t m) {
+        drop();
+        if (m >= (64u << 20)) {
+            const size_t len = (m + 1 + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+            void *q = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q != MAP_FAILED) { madvise(q, len, MADV_HUGEPAGE); p = (uint8_t *)q; n = m; mapped = len; return true; }
+        }
+        p = (uint8_t *)malloc(m ? m + 1 : 1); n = p ? m : 0;
+        return p != nullptr;
+    }
     uint8_t *data() { return p; }
     const uint8_t *data() const { return p; }
     size_t size() const { return n; }
-    uint8_t *release() { uint8_t *q = p; p = nullptr; n = 0; return q; }
+    // hands the memory to a caller that will free() it: only valid for malloc'd buffers, so copy out of a mapping
+    uint8_t *release() {
+        uint8_t *q;
+        if (mapped) { q = (uint8_t *)malloc(n + 1); if (q) memcpy(q, p, n + 1); drop(); }
+        else { q = p; p = nullptr; n = 0; }
+        return q;
+    }
 };
 
 struct Shard {
@@ -258,35 +277,134 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
     const uint8_t *d = b.data.data();
     const size_t n = b.data.size();
     const int n_ref = (int)b.refs.size();
-    // pass 1: hop over the record chain, apply the filters, size everything
+    // pass 1: hop over the record chain, apply the filters, size everything.  The chain is sequential by nature (every
+    // record's length sits in its own header), so the stream is cut into segments whose first record boundary is GUESSED by
+    // a plausibility scan, every segment is hopped by its own thread, and the guess is VERIFIED afterwards: segment k must
+    // end exactly where segment k+1 began (segment 0 starts at the true first record, so this proves every boundary).
+    // Any mismatch falls back to the plain sequential hop.
     struct Rec { size_t off; int32_t ref; uint32_t n_ops, nb; };
-    std::vector<Rec> recs;
-    recs.reserve(n / 180 + 1024);
-    std::vector<int32_t> last_pos((size_t)n_ref, -1);      // the mapper is a merge join: every reference must be coordinate-sorted
-    size_t p = b.first_record;
-    while (p + 4 <= n) {
+    auto plausible = [&](size_t p) -> size_t {          // -> offset of the next record, 0 when p cannot start a record
+        if (p + 36 > n) return 0;
         const int32_t bs = rdi32(d + p);
-        if (bs < 32 || p + 4 + (size_t)bs > n) break;
+        if (bs < 32 || bs > (1 << 24) || p + 4 + (size_t)bs > n) return 0;
         const uint8_t *r = d + p + 4;
-        const int32_t ref = rdi32(r);
-        const uint32_t l_rn = r[8], mapq = r[9], n_cig = rd16(r + 12), flag = rd16(r + 14);
-        const int32_t l_seq = rdi32(r + 16), tlen = rdi32(r + 28);
-        bool keep = ref >= 0 && ref < n_ref && (!ref_mask || ref_mask[ref]) && (int)mapq >= min_mapq &&
-                    ((int)flag & flag_required) == flag_required && ((int)flag & flag_forbidden) == 0;
-        if (keep && isize_cutoff != 0) { const double tl = tlen < 0 ? -(double)tlen : (double)tlen; keep = tl <= isize_cutoff; }
-        if (keep) {
-            const int32_t pos0 = rdi32(r + 4);
-            if (pos0 < last_pos[(size_t)ref]) return PHZ_E_UNSUPPORTED;     // BAM is not coordinate-sorted
-            last_pos[(size_t)ref] = pos0;
-            const uint8_t *cig = r + 32 + l_rn;
-            const uint8_t *qual = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2;
-            uint32_t nb;
-            if (l_seq <= 0) nb = 1;                               // SEQ '*' / QUAL '*': zip() keeps one character
-            else nb = qual[0] == 0xFF ? 1u : (uint32_t)l_seq;     // QUAL '*'
-            recs.push_back({p + 4, ref, (uint32_t)norm_ops(cig, (int)n_cig, (int)nb, nullptr), nb});
+        const int32_t ref = rdi32(r), pos0 = rdi32(r + 4), l_seq = rdi32(r + 16), nref = rdi32(r + 20);
+        const uint32_t l_rn = r[8], n_cig = rd16(r + 12);
+        if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 1) return 0;
+        const size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+        if (need > (size_t)bs) return 0;
+        if (r[32 + l_rn - 1] != 0) return 0;                 // read name is NUL-terminated
+        for (uint32_t k = 0; k + 1 < l_rn; k++) if (r[32 + k] < 33 || r[32 + k] > 126) return 0;
+        return p + 4 + (size_t)bs;
+    };
+    auto hop = [&](size_t p, size_t stop, std::vector<Rec> &out, std::vector<int32_t> &last_pos, bool *unsorted) -> size_t {
+        while (p < stop && p + 4 <= n) {
+            const int32_t bs = rdi32(d + p);
+            if (bs < 32 || p + 4 + (size_t)bs > n) return p;
+            const uint8_t *r = d + p + 4;
+            const int32_t ref = rdi32(r);
+            const uint32_t l_rn = r[8], mapq = r[9], n_cig = rd16(r + 12), flag = rd16(r + 14);
+            const int32_t l_seq = rdi32(r + 16), tlen = rdi32(r + 28);
+            bool keep = ref >= 0 && ref < n_ref && (!ref_mask || ref_mask[ref]) && (int)mapq >= min_mapq &&
+                        ((int)flag & flag_required) == flag_required && ((int)flag & flag_forbidden) == 0;
+            if (keep && isize_cutoff != 0) { const double tl = tlen < 0 ? -(double)tlen : (double)tlen; keep = tl <= isize_cutoff; }
+            if (keep) {
+                const int32_t pos0 = rdi32(r + 4);
+                if (pos0 < last_pos[(size_t)ref]) *unsorted = true;           // BAM is not coordinate-sorted
+                last_pos[(size_t)ref] = pos0;
+                const uint8_t *cig = r + 32 + l_rn;
+                const uint8_t *qual = cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2;
+                uint32_t nb;
+                if (l_seq <= 0) nb = 1;                               // SEQ '*' / QUAL '*': zip() keeps one character
+                else nb = qual[0] == 0xFF ? 1u : (uint32_t)l_seq;     // QUAL '*'
+                out.push_back({p + 4, ref, (uint32_t)norm_ops(cig, (int)n_cig, (int)nb, nullptr), nb});
+            }
+            p += 4 + (size_t)bs;
         }
-        p += 4 + (size_t)bs;
+        return p;
+    };
+    std::vector<Rec> recs;
+    bool unsorted = false;
+    bool done = false;
+    const int nt1 = n_threads(threads);
+    size_t par_min = 64u << 20;
+    { const char *e = getenv("PHZ_BAM_PAR_MIN"); if (e) par_min = (size_t)atoll(e); }
+    if (nt1 > 1 && n - b.first_record > par_min) {
+        const int K = nt1 * 4;
+        std::vector<size_t> seg_start((size_t)K + 1, n);
+        seg_start[0] = b.first_record;
+        std::vector<std::vector<Rec>> part((size_t)K);
+        std::vector<std::vector<int32_t>> lastp((size_t)K, std::vector<int32_t>((size_t)n_ref, -1)), firstp((size_t)K, std::vector<int32_t>((size_t)n_ref, -1));
+        std::vector<size_t> seg_end((size_t)K, 0);
+        std::vector<uint8_t> bad((size_t)K, 0);
+        {   // guessed boundaries
+            std::atomic<int> next(1);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt1; t++)
+                th.emplace_back([&] {
+                    for (;;) {
+                        const int k = next.fetch_add(1);
+                        if (k >= K) break;
+                        size_t p = b.first_record + (n - b.first_record) / (size_t)K * (size_t)k;
+                        const size_t limit = std::min(n, p + (size_t)(32 << 20));
+                        size_t found = n;
+                        for (; p < limit; p++) {
+                            size_t q = p; int ok = 0;
+                            while (ok < 12) { const size_t nx = plausible(q); if (!nx) break; ok++; q = nx; if (q + 4 > n) { ok = 12; break; } }
+                            if (ok >= 12) { found = p; break; }
+                        }
+                        seg_start[(size_t)k] = found;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        for (int k = 1; k <= K; k++) if (seg_start[(size_t)k] < seg_start[(size_t)k - 1]) seg_start[(size_t)k] = seg_start[(size_t)k - 1];
+        {
+            std::atomic<int> next(0);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt1; t++)
+                th.emplace_back([&] {
+                    for (;;) {
+                        const int k = next.fetch_add(1);
+                        if (k >= K) break;
+                        part[(size_t)k].reserve((seg_start[(size_t)k + 1] - seg_start[(size_t)k]) / 180 + 64);
+                        bool u = false;
+                        seg_end[(size_t)k] = hop(seg_start[(size_t)k], seg_start[(size_t)k + 1], part[(size_t)k], lastp[(size_t)k], &u);
+                        bad[(size_t)k] = u ? 1 : 0;
+                        for (const Rec &x : part[(size_t)k])
+                            if (firstp[(size_t)k][(size_t)x.ref] < 0) firstp[(size_t)k][(size_t)x.ref] = rdi32(d + x.off + 4) + 1;   // +1: 0 is a valid POS
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        bool ok = true;      // every guessed boundary must be where the previous segment's chain arrived
+        for (int k = 0; k < K; k++)
+            if (seg_start[(size_t)k + 1] < n && seg_end[(size_t)k] != seg_start[(size_t)k + 1]) ok = false;
+        if (ok) {
+            size_t total = 0;
+            for (auto &v : part) total += v.size();
+            recs.reserve(total);
+            std::vector<int32_t> last((size_t)n_ref, -1);
+            for (int k = 0; k < K; k++) {
+                if (bad[(size_t)k]) unsorted = true;
+                for (int r2 = 0; r2 < n_ref; r2++) {
+                    if (firstp[(size_t)k][(size_t)r2] >= 0 && firstp[(size_t)k][(size_t)r2] - 1 < last[(size_t)r2]) unsorted = true;
+                    if (lastp[(size_t)k][(size_t)r2] >= 0 || firstp[(size_t)k][(size_t)r2] >= 0) last[(size_t)r2] = std::max(last[(size_t)r2], lastp[(size_t)k][(size_t)r2]);
+                }
+                recs.insert(recs.end(), part[(size_t)k].begin(), part[(size_t)k].end());
+                std::vector<Rec>().swap(part[(size_t)k]);
+            }
+            done = true;
+        }
     }
+    if (!done) {
+        recs.clear(); unsorted = false;
+        recs.reserve(n / 180 + 1024);
+        std::vector<int32_t> last_pos((size_t)n_ref, -1);
+        hop(b.first_record, n, recs, last_pos, &unsorted);
+    }
+    if (getenv("PHZ_TIMING")) fprintf(stderr, "[phz timing]   bam record hop: %s, %zu records kept\n", done ? "parallel segments, boundaries verified" : "sequential", recs.size());
+    if (unsorted) return PHZ_E_UNSUPPORTED;
     // bucket by reference, in reference order (file order within a reference is preserved)
     std::vector<size_t> count((size_t)n_ref + 1, 0);
     for (const Rec &x : recs) count[(size_t)x.ref + 1]++;

@@ -169,3 +169,22 @@ def test_parallel_interner_numbers_by_first_appearance():
         assert out.tolist() == want
         assert len(it) == len(table)
     assert it.names == [k.decode() for k in table]
+
+
+def test_parallel_record_hop_gives_the_same_shards(tmp_path, monkeypatch):
+    """Large BAMs are hopped in segments whose guessed record boundaries are verified against the chain; forced here on a small file."""
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, rb = _pipe_one_unfiltered()
+    v2, gs, ge, w = synth.make_variants("chr21", 1, 1_000_000, 80, 77, n_genes=6)
+    rb2 = synth.make_reads(v2, gs, ge, w, 4000, 78)
+    path = str(tmp_path / "two.bam")
+    bamio.readbatch_to_bam_native(path, [rb2, rb], [("chr21", 46709983), ("chr22", 50818468)])
+    want = bamio.shards_from_bam_native(path, {}, 255, True, True, threads=1)
+    monkeypatch.setenv("PHZ_BAM_PAR_MIN", "0")
+    for th in (2, 7):
+        got = bamio.shards_from_bam_native(path, {}, 255, True, True, threads=th)
+        assert list(got) == list(want)
+        for c in want:
+            for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
+                assert torch.equal(getattr(got[c], f), getattr(want[c], f)), (c, f, th)
