@@ -516,7 +516,55 @@ def fx_gene_ae(phaser, rvm):
         print("gene_ae", name, len(bed.splitlines()), "features", len(out.splitlines()) - 1, "rows")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae}
+def fx_expr_matrix(phaser, rvm):
+    """phaser_pop/phaser_expr_matrix.py: run the reference's script on a directory of gene_ae files (the
+    reference's own gene_ae outputs of other fixtures, one sample per file, sample names made distinct) and keep the two
+    matrices it writes.  bgzip / tabix are not installed: the script's shell calls fail and leave the plain .bed files, which is
+    what we keep."""
+    import runpy
+    script = "/root/reference/phaser_pop/phaser_expr_matrix.py"
+    src = os.path.join(GOLD, "gene_ae")
+    bed = open(os.path.join(src, "pipe_two", "features.bed")).read()
+    assert bed == open(os.path.join(src, "pipe_two_gw06", "features.bed")).read() == open(os.path.join(src, "pipe_two_mincov", "features.bed")).read()
+    d = os.path.join(GOLD, "expr_matrix"); os.makedirs(os.path.join(d, "gene_ae"), exist_ok=True)
+    files = {}
+    for case, tag in (("pipe_two", "A"), ("pipe_two_gw06", "B"), ("pipe_two_mincov", "C")):
+        text = gzip.open(os.path.join(src, case, "out.gene_ae.txt.gz"), "rt").read()
+        lines = text.split("\n")
+        head, rows = lines[0], [l for l in lines[1:] if l]
+        for bam in ("t1", "t2"):
+            name = "%s_%s" % (tag, bam)
+            body = [l.rsplit("\t", 1)[0] + "\t" + name for l in rows if l.rsplit("\t", 1)[1] == bam]
+            files[name + ".gene_ae.txt"] = head + "\n" + "\n".join(body) + "\n"
+    outs = {}
+    for order in ("sorted", "reversed"):          # os.listdir order is arbitrary: pin the script's behaviour under both
+        with tempfile.TemporaryDirectory() as tmp:
+            gdir = os.path.join(tmp, "in"); os.makedirs(gdir)
+            for fn, body in files.items():
+                open(os.path.join(gdir, fn), "w").write(body)
+            bp = os.path.join(tmp, "f.bed"); open(bp, "w").write(bed)
+            cwd = os.getcwd(); os.chdir(tmp)
+            argv = sys.argv
+            sys.argv = [script, "--gene_ae_dir", gdir, "--features", bp, "--o", os.path.join(tmp, "out")]
+            buf = io.StringIO(); old = sys.stdout; sys.stdout = buf
+            real_listdir = os.listdir
+            os.listdir = lambda p=".": sorted(real_listdir(p), reverse=(order == "reversed"))
+            try:
+                runpy.run_path(script, run_name="__main__")
+            finally:
+                os.listdir = real_listdir
+                sys.stdout = old; sys.argv = argv; os.chdir(cwd)
+            outs[order] = (open(os.path.join(tmp, "out.bed")).read(), open(os.path.join(tmp, "out.gw_phased.bed")).read(), buf.getvalue())
+    for fn, body in files.items():
+        wgz(os.path.join(d, "gene_ae", fn + ".gz"), body)
+    open(os.path.join(d, "features.bed"), "w").write(bed)
+    for order, (out_all, out_gw, log) in outs.items():
+        wgz(os.path.join(d, "out.%s.bed.gz" % order), out_all); wgz(os.path.join(d, "out.%s.gw_phased.bed.gz" % order), out_gw)
+        wgz(os.path.join(d, "out.%s.log.txt.gz" % order), log)
+        print("expr_matrix", order, len(files), "files ->", out_all.split("\n")[0].count("\t") - 3, "sample columns,", len(out_all.splitlines()) - 1, "rows")
+
+
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
