@@ -49,6 +49,13 @@ class ReadShard:
         return sum(int(t.numel()) * t.element_size() for t in
                    (self.pos, self.cigar_off, self.cigar, self.seq_off, self.seq2, self.qual))
 
+    def slice(self, lo: int, hi: int) -> "ReadShard":
+        """Records [lo, hi) as a shard of their own (views; offsets stay absolute, which the mapper accepts because it only
+        ever indexes cigar / seq2 / qual through cigar_off / seq_off)."""
+        f = lambda t, a, b: None if t is None else t[a:b]
+        return ReadShard(self.pos[lo:hi], self.cigar_off[lo:hi + 1], self.cigar, self.seq_off[lo:hi + 1], self.seq2, self.qual,
+                         f(self.qid, lo, hi), f(self.aln_score, lo, hi), f(self.has_as, lo, hi), self.iupac)
+
     def to(self, device) -> "ReadShard":
         f = lambda t: None if t is None else t.to(device)
         return ReadShard(f(self.pos), f(self.cigar_off), f(self.cigar), f(self.seq_off), f(self.seq2), f(self.qual),
