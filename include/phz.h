@@ -337,6 +337,24 @@ typedef struct {
 
 int phz_gene_counts(phz_ctx *ctx, const phz_gene_work *work, int32_t *pair_counts, int space);
 
+/* Output rows of phaser_gene_ae (:147-163), threaded.  Keys are bam * n_features + feature.  Pools: items followed by '\n'.
+ * out is malloc'd (phz_buf_free). */
+typedef struct {
+    int64_t n_features;
+    const char *feat_chr;  int64_t feat_chr_len;
+    const char *feat_name; int64_t feat_name_len;
+    const int64_t *feat_start, *feat_stop;
+    int32_t n_bam_order; const int32_t *bam_order;      /* BAM ids in output order */
+    const char *bam_names; int64_t bam_names_len;
+    const int64_t *A, *B, *UA, *UB;                      /* phased a / b, best unphased a / b per key */
+    const int64_t *pv_lo, *pv_hi, *pv_sorted;            /* phased variants of a key = pv_sorted[pv_lo : pv_hi] */
+    const int64_t *best_lo, *best_hi, *u_var;            /* variants of the best unphased block = u_var[best_lo : best_hi] */
+    const char *text; const int64_t *var_id_off; const int32_t *var_id_len;   /* variant id text (phz_hc_arrays) */
+    int64_t min_cov;
+    int32_t threads;
+} phz_gene_rows_in;
+int phz_gene_rows(const phz_gene_rows_in *in, char **out, int64_t *out_len);
+
 /* ---- native het-variant loader (phaser/phaser.py:396-433 filter, :1355-1413 table, :1418-1462 per-variant fields) ----------
  * phz_vcf_parse reads VCF text (header lines skipped) with host threads; phz_vcf_chrom hands out one chromosome's table.
  * String columns come as pools: every item is followed by one '\n'.  pool[]: 0 unique id, 1 ID column as written, 2 rsid

@@ -137,6 +137,15 @@ class phz_read_batch(C.Structure):
                 ("seq", C.c_void_p), ("qual", C.c_void_p), ("qname_prefix", C.c_char_p)]
 
 
+class phz_gene_rows_in(C.Structure):
+    _fields_ = [("n_features", C.c_int64), ("feat_chr", C.c_void_p), ("feat_chr_len", C.c_int64), ("feat_name", C.c_void_p),
+                ("feat_name_len", C.c_int64), ("feat_start", C.c_void_p), ("feat_stop", C.c_void_p), ("n_bam_order", C.c_int32),
+                ("bam_order", C.c_void_p), ("bam_names", C.c_void_p), ("bam_names_len", C.c_int64), ("A", C.c_void_p), ("B", C.c_void_p),
+                ("UA", C.c_void_p), ("UB", C.c_void_p), ("pv_lo", C.c_void_p), ("pv_hi", C.c_void_p), ("pv_sorted", C.c_void_p),
+                ("best_lo", C.c_void_p), ("best_hi", C.c_void_p), ("u_var", C.c_void_p), ("text", C.c_void_p), ("var_id_off", C.c_void_p),
+                ("var_id_len", C.c_void_p), ("min_cov", C.c_int64), ("threads", C.c_int32)]
+
+
 PHZ_AS_BINS = 65536
 
 # every symbol include/phz.h declares: name -> (restype, argtypes)
@@ -182,6 +191,7 @@ SYMBOLS = {
     "phz_hc_view": (C.c_int, [C.c_void_p, C.POINTER(phz_hc_arrays)]),
     "phz_hc_error": (C.c_char_p, [C.c_void_p]),
     "phz_hc_free": (None, [C.c_void_p]),
+    "phz_gene_rows": (C.c_int, [C.POINTER(phz_gene_rows_in), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "phz_gene_counts": (C.c_int, [C.c_void_p, C.POINTER(phz_gene_work), C.c_void_p, C.c_int]),
     "phz_vcf_parse": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(phz_vcf_opts), C.POINTER(C.c_void_p)]),
     "phz_vcf_summary": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),

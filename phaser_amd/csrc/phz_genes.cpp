@@ -5,9 +5,11 @@
 //   lab_prev[p]  index (within the same row and haplotype) of the previous occurrence of the same label, -1 if none
 // which is all a distinct-count over any subset of the row's variants needs (phz_genes.hip).  Labels are compared as text
 // by the reference (set of strings); here they are keyed by their text too, so "7" and "07" stay different reads.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <string_view>
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "phz.h"
+#include "phz_text.h"
 
 struct phz_hc {
     std::vector<int32_t> contig, start, stop, a_count, b_count, total, phase, bam;
@@ -259,3 +262,60 @@ extern "C" int phz_hc_view(const phz_hc *h, phz_hc_arrays *v) {
 extern "C" const char *phz_hc_error(const phz_hc *h) { return h ? h->error.c_str() : ""; }
 
 extern "C" void phz_hc_free(phz_hc *h) { delete h; }
+
+// Output rows of phaser_gene_ae (:147-163) for every BAM (in the order given) and feature: phased counts when they are at
+// least as large as the best unphased block, else that block; log2(a/b) the way the script computes it
+// (zero_divide / zero_log with math.log(x, 2) = log(x) / log(2)), numbers printed as Python's str() prints them.
+extern "C" int phz_gene_rows(const phz_gene_rows_in *in, char **out, int64_t *out_len) {
+    if (!in || !out || !out_len) return PHZ_E_ARG;
+    const phz_gene_rows_in &I = *in;
+    using phztext::put_int; using phztext::put_pyfloat;
+    const std::vector<uint32_t> chr_off = phztext::pool_offsets(I.feat_chr, I.feat_chr_len), name_off = phztext::pool_offsets(I.feat_name, I.feat_name_len),
+                                bam_off = phztext::pool_offsets(I.bam_names, I.bam_names_len);
+    if ((int64_t)chr_off.size() != I.n_features + 1 || (int64_t)name_off.size() != I.n_features + 1) return PHZ_E_ARG;
+    auto at = [](const char *b, const std::vector<uint32_t> &off, int64_t i) { return std::string_view(b + off[(size_t)i], off[(size_t)i + 1] - off[(size_t)i] - 1); };
+    const int threads = std::max(1, I.threads);
+    const int64_t nf = I.n_features;
+    const int64_t total = (int64_t)I.n_bam_order * nf;
+    const int64_t step = 4096;
+    const int64_t nchunks = (total + step - 1) / step;
+    std::vector<std::string> parts((size_t)nchunks);
+    std::atomic<int64_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= nchunks) break;
+            std::string &o = parts[(size_t)c];
+            for (int64_t t = c * step; t < std::min(total, (c + 1) * step); t++) {
+                const int b = I.bam_order[t / nf];
+                const int64_t fi = t % nf, kx = (int64_t)b * nf + fi;
+                const long long a = I.A[kx], bb = I.B[kx], ua = I.UA[kx], ub = I.UB[kx];
+                const bool phased = a + bb >= ua + ub;
+                const long long x = phased ? a : ua, y = phased ? bb : ub, tc = x + y;
+                if (tc < I.min_cov) continue;
+                const int64_t *ids = phased ? I.pv_sorted + I.pv_lo[kx] : I.u_var + I.best_lo[kx];
+                const int64_t nids = phased ? I.pv_hi[kx] - I.pv_lo[kx] : I.best_hi[kx] - I.best_lo[kx];
+                o.append(at(I.feat_chr, chr_off, fi)); o += '\t'; put_int(o, I.feat_start[fi]); o += '\t'; put_int(o, I.feat_stop[fi]); o += '\t';
+                o.append(at(I.feat_name, name_off, fi)); o += '\t'; put_int(o, x); o += '\t'; put_int(o, y); o += '\t'; put_int(o, tc); o += '\t';
+                const double ratio = y == 0 ? INFINITY : (double)x / (double)y;
+                const double l2 = ratio == 0 ? -INFINITY : log(ratio) / log(2.0);
+                put_pyfloat(o, l2); o += '\t'; put_int(o, nids); o += '\t';
+                for (int64_t k = 0; k < nids; k++) { if (k) o += ','; o.append(I.text + I.var_id_off[ids[k]], (size_t)I.var_id_len[ids[k]]); }
+                o += phased ? "\t1\t" : "\t0\t";
+                o.append(at(I.bam_names, bam_off, b)); o += '\n';
+            }
+        }
+    };
+    const int nt = (int)std::min<int64_t>(threads, std::max<int64_t>(1, nchunks));
+    if (nt <= 1) work();
+    else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto &t : th) t.join(); }
+    size_t sz = 0;
+    for (auto &p2 : parts) sz += p2.size();
+    char *buf = (char *)malloc(sz + 1);
+    if (!buf) return PHZ_E_NOMEM;
+    size_t w = 0;
+    for (auto &p2 : parts) { memcpy(buf + w, p2.data(), p2.size()); w += p2.size(); }
+    buf[w] = 0;
+    *out = buf; *out_len = (int64_t)w;
+    return PHZ_OK;
+}

@@ -218,38 +218,44 @@ def gene_ae(hc_text: bytes, features_text: str, id_separator: str = "_", gw_cuto
     pv_sorted = u_var[up_phased][po]; pk_sorted = pk[po]
     pv_lo = np.searchsorted(pk_sorted, np.arange(size), side="left"); pv_hi = np.searchsorted(pk_sorted, np.arange(size), side="right")
     t4 = _t.perf_counter()
-    out = ["\t".join(HEADER) + "\n"]
-    ids = {}
-
-    def vid(i):
-        s = ids.get(i)
-        if s is None:
-            s = ids[i] = P.var_id(i)
-        return s
     # BAMs in first-appearance order
     if P.n_rows:
         _, first_idx = np.unique(P.bam, return_index=True)
-        bam_order = P.bam[np.sort(first_idx)].tolist()
+        bam_order = P.bam[np.sort(first_idx)].astype(np.int32)
     else:
-        bam_order = []
-    for b in bam_order:
-        xbam = P.bam_names[b]
-        for fi in range(nf):
-            kx = b * nf + fi
-            a = int(A[kx]); bb = int(B[kx]); ua = int(UA[kx]); ub = int(UB[kx])
-            if a + bb >= ua + ub:
-                tc = a + bb
-                if tc >= min_cov:
-                    vs = [vid(int(i)) for i in pv_sorted[pv_lo[kx]:pv_hi[kx]]]
-                    out.append("\t".join(map(str, [f_chr[fi], f_start[fi], f_stop[fi], f_name[fi], a, bb, tc,
-                                                   _zero_log(_zero_divide(a, bb), 2), len(vs), ",".join(vs), 1, xbam])) + "\n")
-            else:
-                tc = ua + ub
-                if tc >= min_cov:
-                    bp = int(best[kx])
-                    vs = [vid(int(i)) for i in u_var[np.searchsorted(u_pair, bp, side="left"):np.searchsorted(u_pair, bp, side="right")]]
-                    out.append("\t".join(map(str, [f_chr[fi], f_start[fi], f_stop[fi], f_name[fi], ua, ub, tc,
-                                                   _zero_log(_zero_divide(ua, ub), 2), len(vs), ",".join(vs), 0, xbam])) + "\n")
+        bam_order = np.zeros(0, dtype=np.int32)
+    has_best = best >= 0
+    best_lo = np.zeros(size, dtype=np.int64); best_hi = np.zeros(size, dtype=np.int64)
+    best_lo[has_best] = np.searchsorted(u_pair, best[has_best], side="left"); best_hi[has_best] = np.searchsorted(u_pair, best[has_best], side="right")
+    keep = []
+
+    def A_(x, dt):
+        a = np.ascontiguousarray(x, dtype=dt); keep.append(a)
+        return C.c_void_p(a.ctypes.data)
+
+    def B_(b):
+        keep.append(b)
+        return C.cast(C.c_char_p(b), C.c_void_p)
+    pool = lambda items: ("\n".join(items) + "\n").encode() if items else b""
+    R = _lib.phz_gene_rows_in()
+    cb = pool(f_chr); nbp = pool(f_name); bnp = pool(P.bam_names)
+    R.n_features = nf; R.feat_chr = B_(cb); R.feat_chr_len = len(cb); R.feat_name = B_(nbp); R.feat_name_len = len(nbp)
+    R.feat_start = A_(f_start_a, np.int64); R.feat_stop = A_(f_stop_a, np.int64)
+    R.n_bam_order = len(bam_order); R.bam_order = A_(bam_order, np.int32); R.bam_names = B_(bnp); R.bam_names_len = len(bnp)
+    R.A = A_(A, np.int64); R.B = A_(B, np.int64); R.UA = A_(UA, np.int64); R.UB = A_(UB, np.int64)
+    R.pv_lo = A_(pv_lo, np.int64); R.pv_hi = A_(pv_hi, np.int64); R.pv_sorted = A_(pv_sorted, np.int64)
+    R.best_lo = A_(best_lo, np.int64); R.best_hi = A_(best_hi, np.int64); R.u_var = A_(u_var, np.int64)
+    R.text = B_(P.text); R.var_id_off = A_(P.var_id_off, np.int64); R.var_id_len = A_(P.var_id_len, np.int32)
+    R.min_cov = int(min_cov); R.threads = max(1, int(threads))
+    optr = C.c_void_p(); olen = C.c_int64(0)
+    st = P.lib.phz_gene_rows(C.byref(R), C.byref(optr), C.byref(olen))
+    if st != _lib.PHZ_OK:
+        raise _lib.PhzError(st, "phz_gene_rows failed")
+    try:
+        body = C.string_at(optr, olen.value).decode()
+    finally:
+        P.lib.phz_buf_free(optr)
+    out = ["\t".join(HEADER) + "\n", body]
     if stats is not None:
         stats["seconds"] = {"parse": round(t1 - t0, 3), "pairs_and_variants": round(t2 - t1, 3), "counts_incl_copies": round(t3 - t2, 3),
                             "aggregate": round(t4 - t3, 3), "format": round(_t.perf_counter() - t4, 3)}
