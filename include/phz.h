@@ -216,6 +216,9 @@ typedef struct {
 int phz_bam_write(const char *path, int n_ref, const char *const *ref_names, const int32_t *ref_lens, const phz_read_batch *batches,
                   int n_batches, int threads);
 
+/* tabix index <bgzf_path>.tbi of a BGZF-compressed position-sorted file; preset 0 = VCF (tabix -p vcf), 1 = BED (tabix -p bed) */
+int phz_tabix_build(const char *bgzf_path, int preset, int threads);
+
 int phz_interner_create(phz_interner **out);
 int phz_interner_destroy(phz_interner *it);
 int64_t phz_interner_size(const phz_interner *it);

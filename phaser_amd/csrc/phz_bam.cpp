@@ -742,4 +742,160 @@ int phz_bam_write(const char *path, int n_ref, const char *const *ref_names, con
     return phz_bgzf_write(path, raw.data(), (int64_t)raw.size(), threads, 6);
 }
 
+// ---- tabix index (.tbi) of a BGZF-compressed, position-sorted VCF or BED file ----------------------------------------------
+// What `tabix -p vcf` / `tabix -p bed` write next to the file (phaser.py:1851, phaser_expr_matrix.py:66): UCSC binning index
+// (min_shift 14, depth 5) + 16 kb linear index over BGZF virtual offsets, itself BGZF-compressed.
+namespace {
+inline int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(4681 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(585 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(73 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(9 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(1 + (beg >> 26));
+    return 0;
+}
+}  // namespace
+
+int phz_tabix_build(const char *bgzf_path, int preset, int threads) {
+    if (!bgzf_path || (preset != 0 && preset != 1)) return PHZ_E_ARG;
+    // member table (compressed offset, uncompressed start) + inflated text
+    int fd = open(bgzf_path, O_RDONLY);
+    if (fd < 0) return PHZ_E_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return PHZ_E_ARG; }
+    const size_t fsz = (size_t)st.st_size;
+    const uint8_t *f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (f == MAP_FAILED) return PHZ_E_NOMEM;
+    std::vector<uint64_t> coff, ustart;
+    {
+        size_t off = 0; uint64_t u = 0;
+        while (off + 18 <= fsz) {
+            if (f[off] != 0x1f || f[off + 1] != 0x8b || !(f[off + 3] & 4)) { munmap((void *)f, fsz); return PHZ_E_ARG; }
+            const uint16_t xlen = rd16(f + off + 10);
+            size_t x = off + 12, xe = x + xlen; uint32_t bsize = 0;
+            while (x + 4 <= xe) { const uint16_t slen = rd16(f + x + 2); if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = (uint32_t)rd16(f + x + 4) + 1; x += 4 + slen; }
+            if (!bsize || off + bsize > fsz) { munmap((void *)f, fsz); return PHZ_E_ARG; }
+            coff.push_back(off); ustart.push_back(u);
+            u += rd32(f + off + bsize - 4);
+            off += bsize;
+        }
+        coff.push_back(off); ustart.push_back(u);
+    }
+    munmap((void *)f, fsz);
+    RawBuf text;
+    if (int s2 = inflate_bgzf_file(bgzf_path, threads, text)) return s2;
+    const char *d = (const char *)text.data(); const size_t n = text.size();
+    auto voff = [&](uint64_t upos) -> uint64_t {
+        size_t b = (size_t)(std::upper_bound(ustart.begin(), ustart.end() - 1, upos) - ustart.begin()) - 1;
+        while (b + 2 < ustart.size() && ustart[b + 1] == ustart[b]) b++;           // skip empty members
+        return (coff[b] << 16) | (upos - ustart[b]);
+    };
+    struct Ref {
+        std::string name;
+        std::vector<std::pair<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;   // in order of first use
+        std::unordered_map<uint32_t, size_t> bin_idx;
+        std::vector<uint64_t> ioff;
+        uint64_t off_beg = 0, off_end = 0, n_rec = 0;
+        int64_t last_beg = -1;
+    };
+    std::vector<Ref> refs;
+    std::unordered_map<std::string, size_t> ref_idx;
+    size_t p = 0;
+    int64_t last_ref = -1; uint32_t last_bin = 0xffffffffu;
+    while (p < n) {
+        const char *nl = (const char *)memchr(d + p, '\n', n - p);
+        const size_t e = nl ? (size_t)(nl - d) : n;
+        const size_t next = nl ? e + 1 : n;
+        if (e > p && d[p] != '#') {
+            // columns
+            const char *c0 = d + p; const char *le = d + e;
+            const char *t1 = (const char *)memchr(c0, '\t', (size_t)(le - c0));
+            if (!t1) return PHZ_E_ARG;
+            const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
+            const std::string chrom(c0, (size_t)(t1 - c0));
+            int64_t beg, end;
+            const long long v1 = strtoll(std::string(t1 + 1, (size_t)((t2 ? t2 : le) - t1 - 1)).c_str(), nullptr, 10);
+            if (preset == 0) {          // VCF: POS is 1-based, the record covers len(REF) bases unless INFO carries END=
+                beg = v1 - 1;
+                const char *t3 = t2 ? (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1)) : nullptr;        // end of ID
+                const char *t4 = t3 ? (const char *)memchr(t3 + 1, '\t', (size_t)(le - t3 - 1)) : nullptr;        // end of REF
+                end = beg + (t3 && t4 ? (int64_t)(t4 - t3 - 1) : 1);
+                const char *t = t4; int col = 4;
+                while (t && col < 7) { t = (const char *)memchr(t + 1, '\t', (size_t)(le - t - 1)); col++; }      // t = tab before INFO
+                if (t) {
+                    const char *ie = (const char *)memchr(t + 1, '\t', (size_t)(le - t - 1));
+                    std::string_view info(t + 1, (size_t)((ie ? ie : le) - t - 1));
+                    size_t q = 0;
+                    while (q < info.size()) {
+                        size_t r = info.find(';', q); if (r == std::string_view::npos) r = info.size();
+                        if (info.substr(q, 4) == "END=") { const long long ev = strtoll(std::string(info.substr(q + 4, r - q - 4)).c_str(), nullptr, 10); if (ev > beg) end = ev; }
+                        q = r + 1;
+                    }
+                }
+            } else {                    // BED: 0-based start, end exclusive
+                if (!t2) return PHZ_E_ARG;
+                const char *t3 = (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1));
+                beg = v1;
+                end = strtoll(std::string(t2 + 1, (size_t)((t3 ? t3 : le) - t2 - 1)).c_str(), nullptr, 10);
+            }
+            if (beg < 0) beg = 0;
+            if (end <= beg) end = beg + 1;
+            auto it = ref_idx.find(chrom);
+            size_t ri;
+            if (it == ref_idx.end()) { ri = refs.size(); ref_idx.emplace(chrom, ri); refs.emplace_back(); refs.back().name = chrom; }
+            else ri = it->second;
+            Ref &R = refs[ri];
+            // tabix needs every contig in one run and ascending starts inside it (it refuses such files too)
+            if (((int64_t)ri != last_ref && R.n_rec) || ((int64_t)ri == last_ref && beg < R.last_beg)) return PHZ_E_UNSUPPORTED;
+            R.last_beg = beg;
+            const uint64_t v0 = voff(p), v1e = voff(next);
+            if ((int64_t)ri != last_ref) { last_bin = 0xffffffffu; last_ref = (int64_t)ri; if (!R.n_rec) R.off_beg = v0; }
+            R.off_end = v1e; R.n_rec++;
+            const uint32_t bin = (uint32_t)reg2bin(beg, end);
+            if (bin != last_bin || R.bins.empty()) {
+                auto bi = R.bin_idx.find(bin);
+                size_t k;
+                if (bi == R.bin_idx.end()) { k = R.bins.size(); R.bin_idx.emplace(bin, k); R.bins.emplace_back(bin, std::vector<std::pair<uint64_t, uint64_t>>()); }
+                else k = bi->second;
+                R.bins[k].second.emplace_back(v0, v1e);
+                last_bin = bin;
+            } else {
+                R.bins[R.bin_idx[bin]].second.back().second = v1e;
+            }
+            const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+            if (R.ioff.size() <= w1) R.ioff.resize(w1 + 1, 0);
+            for (size_t w = w0; w <= w1; w++) if (R.ioff[w] == 0) R.ioff[w] = v0;
+        }
+        p = next;
+    }
+    // serialise
+    std::string o("TBI\1", 4);
+    auto p32 = [&](int32_t v) { o.append((const char *)&v, 4); };
+    auto p64 = [&](uint64_t v) { o.append((const char *)&v, 8); };
+    p32((int32_t)refs.size());
+    if (preset == 0) { p32(2); p32(1); p32(2); p32(0); } else { p32(0x10000); p32(1); p32(2); p32(3); }
+    p32('#'); p32(0);
+    size_t l_nm = 0;
+    for (auto &R : refs) l_nm += R.name.size() + 1;
+    p32((int32_t)l_nm);
+    for (auto &R : refs) { o += R.name; o.push_back('\0'); }
+    for (auto &R : refs) {
+        p32((int32_t)R.bins.size() + 1);
+        for (auto &b : R.bins) {
+            o.append((const char *)&b.first, 4); p32((int32_t)b.second.size());
+            for (auto &c : b.second) { p64(c.first); p64(c.second); }
+        }
+        const uint32_t meta_bin = 37450; o.append((const char *)&meta_bin, 4); p32(2);       // htslib's pseudo-bin: file span + record counts
+        p64(R.off_beg); p64(R.off_end); p64(R.n_rec); p64(0);
+        for (size_t w = 1; w < R.ioff.size(); w++) if (R.ioff[w] == 0) R.ioff[w] = R.ioff[w - 1];
+        p32((int32_t)R.ioff.size());
+        for (uint64_t v : R.ioff) p64(v);
+    }
+    p64(0);                                                                                  // n_no_coor
+    const std::string out_path = std::string(bgzf_path) + ".tbi";
+    return phz_bgzf_write(out_path.c_str(), o.data(), (int64_t)o.size(), 1, 6);
+}
+
 }  // extern "C"

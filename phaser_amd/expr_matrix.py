@@ -2,7 +2,7 @@
 
 Same arguments (`--gene_ae_dir --features --t --o`) and the same two outputs, `<o>.bed` (aCount|bCount of every sample and gene)
 and `<o>.gw_phased.bed` (0|0 where the gene-level count was not genome-wide phased); they are written BGZF-compressed as
-`<o>.bed.gz` / `<o>.gw_phased.bed.gz` with the native writer (no tabix index).  A plain join on the host -- no GPU work here.
+`<o>.bed.gz` / `<o>.gw_phased.bed.gz` with the native writer, with tabix indices when the rows are position-sorted.  A plain join on the host -- no GPU work here.
 
 Behaviour kept from the reference (file:line = phaser_pop/phaser_expr_matrix.py):
   * a sample enters only if its gene names, in order, equal column 4 of the features file (:108); otherwise the same error line;
@@ -97,6 +97,9 @@ def main(argv=None) -> int:
     vcfout.write_bgzf(args.o + ".bed.gz", a, args.t)
     print("#4 Saving sample matrix (gw_phased)...")
     vcfout.write_bgzf(args.o + ".gw_phased.bed.gz", g, args.t)
+    for path in (args.o + ".bed.gz", args.o + ".gw_phased.bed.gz"):      # bgzip -f ...; tabix -p bed -f ... (:66, :75)
+        if not vcfout.tabix_index(path, "bed", args.t):
+            print("WARNING - %s is not position-sorted, no tabix index written (tabix refuses such files too)" % path)
     return 0
 
 

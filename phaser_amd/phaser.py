@@ -276,9 +276,11 @@ def main(argv=None):
             vtxt, up, pc = vcfout.phased_vcf_text(data, sample_col, eng, args.id_separator, args.chr, args.gw_phase_vcf,
                                                   args.gw_phase_vcf_min_confidence, threads=max(1, args.threads))
             mark("phased VCF text")
-            say("     Compressing output VCF (BGZF; no tabix index is written by this build)...")
+            say("     Compressing and tabix indexing output VCF...")
             vcfout.write_bgzf(args.o + ".vcf.gz", vtxt, max(0, args.threads if args.threads > 1 else 0))
-            mark("phased VCF bgzf")
+            if not vcfout.tabix_index(args.o + ".vcf.gz", "vcf", max(0, args.threads if args.threads > 1 else 0)):
+                say("     WARNING: the VCF is not position-sorted, no tabix index written")
+            mark("phased VCF bgzf + tabix")
         say('')
         say("     COMPLETED using %d reads in %d seconds using %d GPU(s)" % (eng.total_lines, time.time() - start, world))
         say("     PHASED  %d of %d all variants (= %f) with at least one other variant" %

@@ -3,8 +3,8 @@
 The text is produced by the native writer (phz_vcf_phase_text, phaser_amd/csrc/phz_vcfout.cpp): input is the sample's VCF
 (the reference feeds `gunzip -c | cut -f 1-9,S`; here the original text + the sample's column) and, per chromosome, the
 block arrays the row writer returned (engine.vcf_blocks) with the variant table's string pools.  Output text is what the
-reference writes to <o>.vcf before compressing it; we compress it as BGZF ourselves (phz_bgzf_write) and do not write a
-tabix index.
+reference writes to <o>.vcf before compressing it; we compress it as BGZF ourselves (phz_bgzf_write) and write the tabix
+index with phz_tabix_build.
 """
 from __future__ import annotations
 
@@ -61,3 +61,15 @@ def write_bgzf(path: str, text, threads: int = 0):
     st = lib.phz_bgzf_write(path.encode(), C.cast(C.c_char_p(data), C.c_void_p), len(data), int(threads), 6)
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_bgzf_write(%s) failed" % path)
+
+
+def tabix_index(path: str, preset: str = "vcf", threads: int = 0) -> bool:
+    """Write <path>.tbi (what `tabix -p vcf|bed -f <path>` does, phaser.py:1851).  Returns False when the file is not position-sorted
+    (tabix refuses those as well)."""
+    lib = _lib.load()
+    st = lib.phz_tabix_build(path.encode(), {"vcf": 0, "bed": 1}[preset], int(threads))
+    if st == _lib.PHZ_E_UNSUPPORTED:
+        return False
+    if st != _lib.PHZ_OK:
+        raise _lib.PhzError(st, "phz_tabix_build(%s) failed" % path)
+    return True

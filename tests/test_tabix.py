@@ -1,0 +1,165 @@
+"""phz_tabix_build: the .tbi written next to the phased VCF / the expression matrix is read back with an independent,
+spec-following reader (TBI header, UCSC binning, linear index, BGZF virtual offsets) and every region query must return
+exactly the records a brute-force scan finds."""
+import gzip
+import os
+import random
+import struct
+
+import pytest
+
+from conftest import GOLD, gz_text
+
+
+def _members(path):
+    raw = open(path, "rb").read()
+    off = 0; u = 0; tab = []
+    while off + 18 <= len(raw):
+        xlen = struct.unpack_from("<H", raw, off + 10)[0]
+        x = off + 12; bsize = 0
+        while x + 4 <= off + 12 + xlen:
+            si1, si2, slen = raw[x], raw[x + 1], struct.unpack_from("<H", raw, x + 2)[0]
+            if si1 == 66 and si2 == 67:
+                bsize = struct.unpack_from("<H", raw, x + 4)[0] + 1
+            x += 4 + slen
+        isize = struct.unpack_from("<I", raw, off + bsize - 4)[0]
+        tab.append((off, u, isize)); u += isize; off += bsize
+    return tab
+
+
+def _reg2bins(beg, end):
+    end -= 1
+    bins = [0]
+    for shift, base in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        bins += list(range(base + (beg >> shift), base + (end >> shift) + 1))
+    return bins
+
+
+class Tbi:
+    def __init__(self, path):
+        d = gzip.open(path + ".tbi", "rb").read()
+        assert d[:4] == b"TBI\x01"
+        n_ref, self.fmt, self.col_seq, self.col_beg, self.col_end, self.meta, self.skip, l_nm = struct.unpack_from("<8i", d, 4)
+        p = 36
+        self.names = d[p:p + l_nm].split(b"\0")[:-1]; p += l_nm
+        assert len(self.names) == n_ref
+        self.refs = []
+        for _ in range(n_ref):
+            n_bin = struct.unpack_from("<i", d, p)[0]; p += 4
+            bins = {}
+            for _ in range(n_bin):
+                b, n_chunk = struct.unpack_from("<Ii", d, p); p += 8
+                bins[b] = [struct.unpack_from("<QQ", d, p + 16 * k) for k in range(n_chunk)]; p += 16 * n_chunk
+            n_intv = struct.unpack_from("<i", d, p)[0]; p += 4
+            ioff = list(struct.unpack_from("<%dQ" % n_intv, d, p)); p += 8 * n_intv
+            self.refs.append((bins, ioff))
+        assert len(d) - p in (0, 8)
+        self.tab = _members(path)
+        self.text = gzip.open(path, "rb").read()
+
+    def upos(self, v):
+        co, uo = v >> 16, v & 0xFFFF
+        for off, u, isize in self.tab:
+            if off == co:
+                return u + uo
+        raise AssertionError("virtual offset points at no BGZF member")
+
+    def query(self, chrom, beg, end, parse):
+        ri = self.names.index(chrom.encode())
+        bins, ioff = self.refs[ri]
+        w = beg >> 14
+        min_off = ioff[w] if w < len(ioff) else (ioff[-1] if ioff else 0)
+        out = []
+        for b in _reg2bins(beg, end):
+            for cb, ce in bins.get(b, []):
+                if ce <= min_off:
+                    continue
+                p = self.upos(max(cb, min_off)); pe = self.upos(ce)
+                while p < pe:
+                    e = self.text.index(b"\n", p)
+                    line = self.text[p:e].decode()
+                    c, lb, le = parse(line)
+                    if c == chrom and lb < end and le > beg:
+                        out.append(line)
+                    p = e + 1
+        return sorted(set(out))
+
+
+def _vcf_span(line):
+    c = line.split("\t")
+    return c[0], int(c[1]) - 1, int(c[1]) - 1 + len(c[3])
+
+
+def _bed_span(line):
+    c = line.split("\t")
+    return c[0], int(c[1]), int(c[2])
+
+
+def _check(path, parse, n_queries=300, seed=1):
+    t = Tbi(path)
+    lines = [l for l in t.text.decode().split("\n") if l and not l.startswith("#")]
+    spans = [parse(l) for l in lines]
+    rng = random.Random(seed)
+    chroms = sorted(set(s[0] for s in spans))
+    assert [n.decode() for n in t.names] == list(dict.fromkeys(s[0] for s in spans))
+    hits = 0
+    for _ in range(n_queries):
+        c = rng.choice(chroms)
+        pos = [s for s in spans if s[0] == c]
+        a = rng.choice(pos)[1] + rng.randint(-3000, 3000); a = max(0, a)
+        b = a + rng.choice([1, 10, 500, 20000, 300000])
+        want = sorted(set(l for l, s in zip(lines, spans) if s[0] == c and s[1] < b and s[2] > a))
+        assert t.query(c, a, b, parse) == want
+        hits += len(want)
+    assert hits > 100
+    return t
+
+
+def test_tabix_index_of_phased_vcf(tmp_path):
+    from phaser_amd import _lib, vcfout
+    _lib.build()
+    lib = _lib.load()
+    text = gz_text(os.path.join(GOLD, "pipe_two", "out.vcf_gw1.txt.gz"))
+    p = str(tmp_path / "o.vcf.gz")
+    vcfout.write_bgzf(p, text * 1, 2)
+    assert lib.phz_tabix_build(p.encode(), 0, 2) == 0
+    t = _check(p, _vcf_span)
+    assert (t.fmt, t.col_seq, t.col_beg, t.col_end, t.meta) == (2, 1, 2, 0, 35)
+
+
+def test_tabix_index_spanning_many_bgzf_blocks(tmp_path):
+    """A VCF large enough for hundreds of BGZF members and several linear-index windows per contig."""
+    from phaser_amd import _lib, synth, vcfout
+    _lib.build()
+    vs = []
+    for i, (c, ln) in enumerate((("chr1", 40_000_000), ("chr2", 25_000_000))):
+        v, gs, ge, w = synth.make_variants(c, 1, ln, 60_000, 11 + i, n_genes=3000)
+        vs.append(v)
+    p = str(tmp_path / "big.vcf.gz")
+    vcfout.write_bgzf(p, "\n".join(synth.vcf_lines(vs)) + "\n", 3)
+    assert _lib.load().phz_tabix_build(p.encode(), 0, 3) == 0
+    _check(p, _vcf_span, n_queries=120, seed=5)
+
+
+def test_tabix_index_of_bed_matrix(tmp_path):
+    from phaser_amd import _lib, vcfout
+    _lib.build()
+    text = gz_text(os.path.join(GOLD, "expr_matrix", "out.sorted.bed.gz"))
+    rows = text.split("\n")
+    body = sorted([r for r in rows[1:] if r], key=lambda r: (r.split("\t")[0], int(r.split("\t")[1])))     # tabix wants position order
+    p = str(tmp_path / "m.bed.gz")
+    vcfout.write_bgzf(p, rows[0] + "\n" + "\n".join(body) + "\n", 1)
+    assert _lib.load().phz_tabix_build(p.encode(), 1, 1) == 0
+    t = _check(p, _bed_span, n_queries=200, seed=3)
+    assert (t.fmt, t.col_seq, t.col_beg, t.col_end) == (0x10000, 1, 2, 3)
+
+
+def test_tabix_refuses_unsorted(tmp_path):
+    from phaser_amd import _lib, vcfout
+    _lib.build()
+    p = str(tmp_path / "u.bed.gz")
+    vcfout.write_bgzf(p, "chr1\t500\t600\ta\nchr1\t100\t200\tb\n")
+    assert vcfout.tabix_index(p, "bed") is False
+    q = str(tmp_path / "v.bed.gz")
+    vcfout.write_bgzf(q, "chr1\t100\t200\ta\nchr2\t100\t200\tb\nchr1\t300\t400\tc\n")
+    assert vcfout.tabix_index(q, "bed") is False
