@@ -247,8 +247,11 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise PhzError(PHZ_E_HIP, "phaser_amd/libphz.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                       "there is no CPU fallback for the product path")
-    lib = C.CDLL(LIB_PATH)
+    alt = os.environ.get("PHZ_LIB_PATH")          # debugging aid: a sanitizer build of the host-only translation units
+    lib = C.CDLL(alt or LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
+        if alt and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
