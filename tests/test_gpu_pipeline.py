@@ -99,10 +99,13 @@ def test_cli_from_bam_matches_reference(tmp_path):
         f.write(open(os.path.join(d, "in.vcf")).read())
     prefix = str(tmp_path / "out")
     rc = phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1",
-                      "--o", prefix, "--write_vcf", "0"])
+                      "--o", prefix, "--write_vcf", "1", "--threads", "3"])
     assert rc == 0
     out = {name: open(prefix + "." + name + ".txt").read() for name in OUTPUTS}
     compare(out, d)
+    # --write_vcf 1 (the default): phased VCF, bgzipped + tabix-indexed
+    assert gzip.open(prefix + ".vcf.gz", "rt").read() == gz_text(os.path.join(d, "out.vcf_gw0.txt.gz"))
+    assert gzip.open(prefix + ".vcf.gz.tbi", "rb").read()[:4] == b"TBI\x01"
 
 
 @pytest.mark.parametrize("seed,err", [(9001, 0.002), (9002, 0.04)])
