@@ -225,3 +225,38 @@ def test_full_size_pipeline_invariants(mapper):
     # connections: supporting <= total, one row per linked pair
     conn = rows("variant_connections")
     assert all(int(r[2]) <= int(r[3]) for r in conn) and len(conn) == int(R["linked"].sum())
+
+
+def test_population_flow_three_samples(mapper, tmp_path):
+    """phaser -> phaser_gene_ae -> phaser_expr_matrix for three samples (the phaser_pop flow of BASELINE configs[4] in miniature):
+    every stage is the GPU product path; the matrix cells must be the gene-level counts, which must come from the haplotypic counts."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gene_ae_oracle as go
+    from phaser_amd import expr_matrix, gene_ae, synth
+    contigs = [("chr7", 159345973)]
+    gdir = tmp_path / "gene_ae"; gdir.mkdir()
+    bed = None
+    per_sample = {}
+    for s in range(3):
+        v, gs, ge, w = synth.make_variants("chr7", 1, 2_000_000, 260, 500, n_genes=12)          # same variant sites for every sample
+        if bed is None:
+            bed = "".join("chr7\t%d\t%d\tgene%d\n" % (int(a) - 1, int(b), i) for i, (a, b) in enumerate(zip(gs.tolist(), ge.tolist())))
+            (tmp_path / "genes.bed").write_text(bed)
+        rb = synth.make_reads(v, gs, ge, w, 6000, 600 + s, qname_prefix="p%d." % s)
+        rf = rb.select(synth.samtools_keep(rb, 255))
+        sam = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+        out, eng = run_product(mapper, "\n".join(synth.vcf_lines([v])) + "\n", {"sample%d.bam" % s: {"chr7": sam}}, "cuda")
+        hc = out["haplotypic_counts"]
+        table = gene_ae.gene_ae(hc.encode(), bed)
+        assert go.canonical(table) == go.canonical(go.gene_ae(hc, bed))                          # K_genes path == pinned oracle
+        (gdir / ("sample%d.gene_ae.txt" % s)).write_text(table)
+        per_sample["sample%d" % s] = [r.split("\t") for r in table.split("\n")[1:] if r]
+    a, g, log = expr_matrix.expr_matrix(str(gdir), str(tmp_path / "genes.bed"))
+    assert not log
+    rows = [r.split("\t") for r in a.split("\n") if r]
+    assert rows[0][:4] == ["#contig", "start", "stop", "name"] and rows[0][4:] == ["sample0", "sample1", "sample2"]
+    assert len(rows) - 1 == len(bed.splitlines())
+    for k, r in enumerate(rows[1:]):
+        for si, s in enumerate(rows[0][4:]):
+            assert r[4 + si] == per_sample[s][k][4] + "|" + per_sample[s][k][5]
+    assert any(c != "0|0" for r in rows[1:] for c in r[4:])
