@@ -225,10 +225,47 @@ struct phz_bam { Bam b; };
 
 // QNAME table split into hash partitions so that one call can be processed by many threads; ids are still handed out in
 // first-appearance order over the whole input (what a sequential dictionary would do), see phz_intern.
+// open-addressing table hash -> value; equality of the key text is decided by the caller (hash match + string compare)
+struct FlatMap {
+    std::vector<uint64_t> hs; std::vector<int32_t> val;
+    size_t mask = 0, count = 0;
+    void reserve(size_t n) {          // room for n entries at load <= 0.5
+        size_t cap = 16;
+        while (cap < 2 * n) cap <<= 1;
+        if (cap <= hs.size()) return;
+        std::vector<uint64_t> oh; std::vector<int32_t> ov;
+        oh.swap(hs); ov.swap(val);
+        hs.assign(cap, 0); val.assign(cap, -1); mask = cap - 1;
+        for (size_t i = 0; i < oh.size(); i++)
+            if (ov[i] >= 0) { size_t k = (size_t)oh[i] & mask; while (val[k] >= 0) k = (k + 1) & mask; hs[k] = oh[i]; val[k] = ov[i]; }
+    }
+    template <class Eq> int32_t find(uint64_t h, Eq eq) const {
+        if (hs.empty()) return -1;
+        for (size_t k = (size_t)h & mask;; k = (k + 1) & mask) {
+            if (val[k] < 0) return -1;
+            if (hs[k] == h && eq(val[k])) return val[k];
+        }
+    }
+    void insert(uint64_t h, int32_t v) {          // the key is known to be absent; reserve() was called
+        size_t k = (size_t)h & mask;
+        while (val[k] >= 0) k = (k + 1) & mask;
+        hs[k] = h; val[k] = v; count++;
+    }
+};
+
+inline uint64_t hash_name(const char *p, size_t n) {       // FNV-1a with a final mix
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= (uint8_t)p[i]; h *= 1099511628211ull; }
+    h ^= h >> 32; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+    return h;
+}
+
+// QNAME table split into hash partitions so that one call can be processed by many threads; ids are still handed out in
+// first-appearance order over the whole input (what a sequential dictionary would do), see phz_intern.
 struct phz_interner {
     static constexpr int P = 64;
     struct Part {
-        std::unordered_map<std::string_view, int32_t> ids;
+        FlatMap ids;                               // name hash -> id (text compared through `names`)
         std::vector<std::unique_ptr<char[]>> arena; size_t arena_used = 0, arena_cap = 0;
         const char *keep(std::string_view s) {
             if (arena_used + s.size() > arena_cap) {
@@ -282,7 +319,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
     // a plausibility scan, every segment is hopped by its own thread, and the guess is VERIFIED afterwards: segment k must
     // end exactly where segment k+1 began (segment 0 starts at the true first record, so this proves every boundary).
     // Any mismatch falls back to the plain sequential hop.
-    struct Rec { size_t off; int32_t ref; uint32_t n_ops, nb; };
+    struct Rec { size_t off; int32_t ref; uint32_t n_ops, nb; uint32_t l_qn; };      // l_qn: QNAME length without the NUL
     auto plausible = [&](size_t p) -> size_t {          // -> offset of the next record, 0 when p cannot start a record
         if (p + 36 > n) return 0;
         const int32_t bs = rdi32(d + p);
@@ -317,7 +354,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
                 uint32_t nb;
                 if (l_seq <= 0) nb = 1;                               // SEQ '*' / QUAL '*': zip() keeps one character
                 else nb = qual[0] == 0xFF ? 1u : (uint32_t)l_seq;     // QUAL '*'
-                out.push_back({p + 4, ref, (uint32_t)norm_ops(cig, (int)n_cig, (int)nb, nullptr), nb});
+                out.push_back({p + 4, ref, (uint32_t)norm_ops(cig, (int)n_cig, (int)nb, nullptr), nb, l_rn ? l_rn - 1 : 0u});
             }
             p += 4 + (size_t)bs;
         }
@@ -405,15 +442,44 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
     }
     if (getenv("PHZ_TIMING")) fprintf(stderr, "[phz timing]   bam record hop: %s, %zu records kept\n", done ? "parallel segments, boundaries verified" : "sequential", recs.size());
     if (unsorted) return PHZ_E_UNSUPPORTED;
-    // bucket by reference, in reference order (file order within a reference is preserved)
+    // bucket by reference, in reference order (file order within a reference is preserved).  A coordinate-sorted BAM has its
+    // references in ascending order already, so the permutation is the identity; anything else goes through a counting sort.
     std::vector<size_t> count((size_t)n_ref + 1, 0);
-    for (const Rec &x : recs) count[(size_t)x.ref + 1]++;
-    for (int i = 0; i < n_ref; i++) count[(size_t)i + 1] += count[(size_t)i];
-    std::vector<uint32_t> order(recs.size());
+    const int ntb = n_threads(threads);
     {
+        std::vector<std::vector<size_t>> hc((size_t)ntb, std::vector<size_t>((size_t)n_ref + 1, 0));
+        std::vector<std::thread> th;
+        for (int t = 0; t < ntb; t++)
+            th.emplace_back([&, t] {
+                const size_t lo = recs.size() * (size_t)t / (size_t)ntb, hi = recs.size() * (size_t)(t + 1) / (size_t)ntb;
+                for (size_t i = lo; i < hi; i++) hc[(size_t)t][(size_t)recs[i].ref + 1]++;
+            });
+        for (auto &x : th) x.join();
+        for (auto &h2 : hc) for (int i = 0; i <= n_ref; i++) count[(size_t)i] += h2[(size_t)i];
+    }
+    for (int i = 0; i < n_ref; i++) count[(size_t)i + 1] += count[(size_t)i];
+    bool grouped = true;
+    for (size_t i = 1; i < recs.size() && grouped; i += 4096) {        // sampled check first, exact check below only if it passes
+        if (recs[i].ref < recs[i - 1].ref) grouped = false;
+    }
+    if (grouped) {
+        std::atomic<bool> bad(false);
+        std::vector<std::thread> th;
+        for (int t = 0; t < ntb; t++)
+            th.emplace_back([&, t] {
+                const size_t lo = std::max<size_t>(1, recs.size() * (size_t)t / (size_t)ntb), hi = recs.size() * (size_t)(t + 1) / (size_t)ntb;
+                for (size_t i = lo; i < hi; i++) if (recs[i].ref < recs[i - 1].ref) { bad = true; break; }
+            });
+        for (auto &x : th) x.join();
+        grouped = !bad;
+    }
+    std::vector<uint32_t> order;
+    if (!grouped) {
+        order.resize(recs.size());
         std::vector<size_t> cur(count.begin(), count.end() - 1);
         for (size_t i = 0; i < recs.size(); i++) order[cur[(size_t)recs[i].ref]++] = (uint32_t)i;
     }
+    auto rec_at = [&](size_t k) -> const Rec & { return grouped ? recs[k] : recs[order[k]]; };
     b.shards.clear();
     for (int i = 0; i < n_ref; i++) {
         const size_t lo = count[(size_t)i], hi = count[(size_t)i + 1];
@@ -424,13 +490,37 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         const size_t m = hi - lo;
         s.pos.resize(m); s.aln.resize(m); s.has_as.resize(m);
         s.cigar_off.resize(m + 1); s.seq_off.resize(m + 1); s.qname_off.resize(m + 1);
+        // offsets = exclusive prefix sums of the per-record sizes: per-slice totals, then every slice fills its own part
         uint64_t co = 0, so = 0, qo = 0;
-        for (size_t k = 0; k < m; k++) {
-            const Rec &x = recs[order[lo + k]];
-            s.cigar_off[k] = (uint32_t)co; s.seq_off[k] = (uint32_t)so; s.qname_off[k] = (uint32_t)qo;
-            co += x.n_ops; so += (x.nb + 3) / 4; qo += (uint32_t)(d[x.off + 8] ? d[x.off + 8] - 1 : 0);
+        {
+            const int nsl = m < 65536 ? 1 : ntb;
+            std::vector<uint64_t> tc((size_t)nsl + 1, 0), ts((size_t)nsl + 1, 0), tq((size_t)nsl + 1, 0);
+            auto slice = [&](int t, size_t *a, size_t *z) { *a = m * (size_t)t / (size_t)nsl; *z = m * (size_t)(t + 1) / (size_t)nsl; };
+            auto run = [&](auto fn) {
+                if (nsl == 1) { fn(0); return; }
+                std::vector<std::thread> th;
+                for (int t = 0; t < nsl; t++) th.emplace_back([&, t] { fn(t); });
+                for (auto &x : th) x.join();
+            };
+            run([&](int t) {
+                size_t a, z; slice(t, &a, &z);
+                uint64_t c2 = 0, s2 = 0, q2 = 0;
+                for (size_t k = a; k < z; k++) { const Rec &x = rec_at(lo + k); c2 += x.n_ops; s2 += (x.nb + 3) / 4; q2 += x.l_qn; }
+                tc[(size_t)t + 1] = c2; ts[(size_t)t + 1] = s2; tq[(size_t)t + 1] = q2;
+            });
+            for (int t = 0; t < nsl; t++) { tc[(size_t)t + 1] += tc[(size_t)t]; ts[(size_t)t + 1] += ts[(size_t)t]; tq[(size_t)t + 1] += tq[(size_t)t]; }
+            co = tc[(size_t)nsl]; so = ts[(size_t)nsl]; qo = tq[(size_t)nsl];
+            if (co >= (1ull << 31) || so >= (1ull << 31) || qo >= (1ull << 32)) { b.err = "shard exceeds 32-bit offsets"; return PHZ_E_UNSUPPORTED; }
+            run([&](int t) {
+                size_t a, z; slice(t, &a, &z);
+                uint64_t c2 = tc[(size_t)t], s2 = ts[(size_t)t], q2 = tq[(size_t)t];
+                for (size_t k = a; k < z; k++) {
+                    const Rec &x = rec_at(lo + k);
+                    s.cigar_off[k] = (uint32_t)c2; s.seq_off[k] = (uint32_t)s2; s.qname_off[k] = (uint32_t)q2;
+                    c2 += x.n_ops; s2 += (x.nb + 3) / 4; q2 += x.l_qn;
+                }
+            });
         }
-        if (co >= (1ull << 31) || so >= (1ull << 31) || qo >= (1ull << 32)) { b.err = "shard exceeds 32-bit offsets"; return PHZ_E_UNSUPPORTED; }
         s.cigar_off[m] = (uint32_t)co; s.seq_off[m] = (uint32_t)so; s.qname_off[m] = (uint32_t)qo;
         s.cigar.resize(co); s.qnames.resize(qo);
         if (!s.seq2.resize(so) || !s.qual.resize(so * 4)) return PHZ_E_NOMEM;
@@ -447,7 +537,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
                     if (k0 >= m) break;
                     const size_t k1 = k0 + grain < m ? k0 + grain : m;
                     for (size_t k = k0; k < k1; k++) {
-                        const Rec &x = recs[order[lo + k]];
+                        const Rec &x = rec_at(lo + k);
                         const uint8_t *r = d + x.off;
                         const uint32_t l_rn = r[8], n_cig = rd16(r + 12);
                         const int32_t l_seq = rdi32(r + 16);
@@ -520,13 +610,21 @@ int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t 
         for (auto &x : th) x.join();
     };
     auto name_of = [&](int64_t i) { return std::string_view(blob + off[i], off[i + 1] - off[i]); };
-    std::vector<uint8_t> bucket((size_t)n);
-    par(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) bucket[(size_t)i] = (uint8_t)(std::hash<std::string_view>()(name_of(i)) % P); });
+    std::vector<uint64_t> hv((size_t)n);
+    par(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) hv[(size_t)i] = hash_name(blob + off[i], off[i + 1] - off[i]); });
+    auto bucket_of = [&](int64_t i) { return (int)(hv[(size_t)i] >> 58); };        // top 6 bits; the table uses the low ones
+    // bucket lists in input order: per-slice histograms -> offsets -> scatter (all parallel)
+    const int ns = (n < 65536 || nt == 1) ? 1 : nt;
+    std::vector<std::vector<int64_t>> hist((size_t)ns, std::vector<int64_t>(P, 0));
+    par(n, [&](int64_t lo, int64_t hi) { auto &hc = hist[ns == 1 ? 0 : (size_t)((lo * nt + n - 1) / n)]; for (int64_t i = lo; i < hi; i++) hc[(size_t)bucket_of(i)]++; });
     std::vector<int64_t> start(P + 1, 0);
-    for (int64_t i = 0; i < n; i++) start[(size_t)bucket[(size_t)i] + 1]++;
-    for (int p = 0; p < P; p++) start[(size_t)p + 1] += start[(size_t)p];
+    for (int p = 0; p < P; p++) { int64_t c = 0; for (int t = 0; t < ns; t++) c += hist[(size_t)t][(size_t)p]; start[(size_t)p + 1] = start[(size_t)p] + c; }
+    {   // turn the histograms into write cursors: slice t of bucket p starts after slices < t
+        std::vector<int64_t> run(start.begin(), start.end() - 1);
+        for (int t = 0; t < ns; t++) for (int p = 0; p < P; p++) { const int64_t c = hist[(size_t)t][(size_t)p]; hist[(size_t)t][(size_t)p] = run[(size_t)p]; run[(size_t)p] += c; }
+    }
     std::vector<int32_t> order((size_t)n);
-    { std::vector<int64_t> cur(start.begin(), start.end() - 1); for (int64_t i = 0; i < n; i++) order[(size_t)cur[bucket[(size_t)i]]++] = (int32_t)i; }
+    par(n, [&](int64_t lo, int64_t hi) { auto &cur = hist[ns == 1 ? 0 : (size_t)((lo * nt + n - 1) / n)]; for (int64_t i = lo; i < hi; i++) order[(size_t)cur[(size_t)bucket_of(i)]++] = (int32_t)i; });
     // rep[i] >= 0: index of the first occurrence of this new name in the input; < 0: -(existing id) - 1
     std::vector<int32_t> rep((size_t)n);
     std::vector<uint8_t> first((size_t)n, 0);
@@ -537,16 +635,18 @@ int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t 
                 const int p = next.fetch_add(1);
                 if (p >= P) break;
                 phz_interner::Part &T = it->part[p];
-                std::unordered_map<std::string_view, int32_t> fresh;
-                fresh.reserve((size_t)(start[(size_t)p + 1] - start[(size_t)p]) / 2 + 8);
+                FlatMap fresh;
+                fresh.reserve((size_t)(start[(size_t)p + 1] - start[(size_t)p]));
                 for (int64_t k = start[(size_t)p]; k < start[(size_t)p + 1]; k++) {
                     const int32_t i = order[(size_t)k];
                     const std::string_view nm = name_of(i);
-                    auto e = T.ids.find(nm);
-                    if (e != T.ids.end()) { rep[(size_t)i] = -e->second - 1; continue; }
-                    auto r = fresh.emplace(nm, i);
-                    rep[(size_t)i] = r.first->second;
-                    if (r.second) first[(size_t)i] = 1;
+                    const uint64_t h = hv[(size_t)i];
+                    const int32_t known = T.ids.find(h, [&](int32_t id) { return it->names[(size_t)id] == nm; });
+                    if (known >= 0) { rep[(size_t)i] = -known - 1; continue; }
+                    const int32_t seen = fresh.find(h, [&](int32_t j) { return name_of(j) == nm; });
+                    if (seen >= 0) { rep[(size_t)i] = seen; continue; }
+                    fresh.insert(h, i);
+                    rep[(size_t)i] = i; first[(size_t)i] = 1;
                 }
             }
         };
@@ -574,14 +674,17 @@ int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t 
                 const int p = next.fetch_add(1);
                 if (p >= P) break;
                 phz_interner::Part &T = it->part[p];
+                size_t add = 0;
+                for (int64_t k = start[(size_t)p]; k < start[(size_t)p + 1]; k++) add += first[(size_t)order[(size_t)k]];
+                T.ids.reserve(T.ids.count + add);
                 for (int64_t k = start[(size_t)p]; k < start[(size_t)p + 1]; k++) {
                     const int32_t i = order[(size_t)k];
                     if (!first[(size_t)i]) continue;
                     const std::string_view nm = name_of(i);
                     const std::string_view kept(T.keep(nm), nm.size());
                     const int32_t id = (int32_t)(base + rank[(size_t)i]);
-                    T.ids.emplace(kept, id);
                     it->names[(size_t)id] = kept;
+                    T.ids.insert(hv[(size_t)i], id);
                 }
             }
         };

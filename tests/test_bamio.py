@@ -188,3 +188,19 @@ def test_parallel_record_hop_gives_the_same_shards(tmp_path, monkeypatch):
         for c in want:
             for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
                 assert torch.equal(getattr(got[c], f), getattr(want[c], f)), (c, f, th)
+
+
+def test_threaded_decoder_on_a_larger_bam(tmp_path, monkeypatch):
+    """> 65,536 kept records on one reference: the sliced offset computation and the parallel hop agree with the one-thread run."""
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, gs, ge, w = synth.make_variants("chr21", 1, 8_000_000, 400, 91, n_genes=40)
+    rb = synth.make_reads(v, gs, ge, w, 90_000, 92)
+    path = str(tmp_path / "big.bam")
+    bamio.readbatch_to_bam_native(path, [rb], [("chr21", 46709983)], 4)
+    want = bamio.shards_from_bam_native(path, {}, 0, False, False, threads=1)["chr21"]
+    assert want.n > 150_000
+    monkeypatch.setenv("PHZ_BAM_PAR_MIN", "0")
+    got = bamio.shards_from_bam_native(path, {}, 0, False, False, threads=6)["chr21"]
+    for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
+        assert torch.equal(getattr(got, f), getattr(want, f)), f
