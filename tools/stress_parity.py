@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""GPU-box stress: product (GPU path) vs the pinned oracle on freshly seeded inputs nobody has seen -- random numbers of BAMs and
+chromosomes, error rates, block-size limits, option flags.  Exits non-zero on the first canonical difference in any of the five
+files.  usage: tools/stress_parity.py [iterations=40] [first_seed=100]"""
+import os, random, subprocess, sys, tempfile
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, os.path.join(REPO, "oracle"))
+import phasing_oracle as po
+from helpers import OUTPUTS, canonical
+from phaser_amd import samio, synth, vcf
+from phaser_amd.engine import Config, Engine
+from phaser_amd.mapper import Mapper
+subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle")])
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+mapper = Mapper(0)
+CONTIGS = [("chr3", 198295559), ("chr11", 135086622), ("chr19", 58617616)]
+for it in range(iters):
+    rng = random.Random(seed0 + it)
+    nchrom = rng.choice([1, 1, 2, 3]); nbam = rng.choice([1, 1, 2, 3])
+    contigs = CONTIGS[:nchrom]
+    err = rng.choice([0.001, 0.002, 0.02, 0.05, 0.08]); mbs = rng.choice([3, 5, 8, 15])
+    cfg = {"max_block_size": mbs}
+    if rng.random() < 0.3: cfg["unphased_vars"] = 0
+    if rng.random() < 0.3: cfg["unique_ids"] = 1
+    if rng.random() < 0.3: cfg["cc_threshold"] = rng.choice([0.001, 0.05, 0.2])
+    if rng.random() < 0.3: cfg["as_q_cutoff"] = rng.choice([0.0, 0.2, 0.5])
+    if nbam > 1 and rng.random() < 0.3: cfg["haplo_count_bam_exclude"] = [rng.randrange(nbam)]
+    if rng.random() < 0.2: cfg["output_read_ids"] = 1
+    vs_ = []; bams = {"x%d.bam" % b: {} for b in range(nbam)}
+    for ci, (chrom, ln) in enumerate(contigs):
+        v, gs, ge, w = synth.make_variants(chrom, 1, rng.choice([600_000, 1_500_000]), rng.choice([60, 150, 260]), seed0 * 7 + 13 * it + ci, n_genes=rng.choice([4, 10]))
+        vs_.append(v)
+        for bi, bam in enumerate(bams):
+            rb = synth.make_reads(v, gs, ge, w, rng.choice([1500, 4000, 7000]), seed0 * 11 + 17 * it + 10 * ci + bi, qname_prefix="q" if rng.random() < 0.7 else "q%d." % bi,
+                                  err_rate=err)
+            rf = rb.select(synth.samtools_keep(rb, 255))
+            bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf_text = "\n".join(synth.vcf_lines(vs_)) + "\n"
+    # product
+    vset = vcf.load_variants(vcf_text)
+    eng = Engine(vset, po.bam_display_names(list(bams.keys())), Config(host_threads=rng.choice([1, 4]), **cfg), mapper=mapper)
+    interners = {}
+    for bi, (bam, per_chrom) in enumerate(bams.items()):
+        for chrom in vset.chroms:
+            for c2, sh in samio.shards_from_sam(per_chrom[chrom], interners, 0.0).items():
+                eng.add_shard(bi, c2, sh.to("cuda"), len(interners[c2]), interners[c2].names)
+        for c2 in interners:
+            eng.n_qid[c2] = len(interners[c2])
+        eng.close_bam(bi)
+    got = eng.finish()
+    # oracle
+    pool, _, _ = po.load_vcf(vcf_text)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), **cfg)
+    with tempfile.TemporaryDirectory() as tmp:
+        for bam, per_chrom in bams.items():
+            texts = []
+            for c in pool:
+                tp = os.path.join(tmp, "t.tsv"); open(tp, "w").write("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+                op = os.path.join(tmp, "c.tsv")
+                subprocess.run([os.path.join(REPO, "oracle", "rvm_oracle"), "--variant_table", tp, "--baseq", "10", "--o", op], input=per_chrom[c].encode(), check=True)
+                texts.append(open(op).read())
+            ph.add_bam(texts)
+    want = ph.finish()
+    bad = [n for n in OUTPUTS if canonical(n, got[n]) != canonical(n, want[n])]
+    print("iter %d seed %d: chroms %d bams %d err %.3f cfg %s -> phased %d %s" % (it, seed0 + it, nchrom, nbam, err, cfg, eng.phased, "OK" if not bad else "DIFF " + str(bad)), flush=True)
+    if bad or eng.phased != ph.phased:
+        sys.exit(1)
+print("all %d iterations identical" % iters)
