@@ -111,3 +111,33 @@ def test_phased_vcf_takes_the_sample_column_of_a_wide_vcf():
             wide.append("\t".join(c[:9] + ["OTHER" if l.startswith("#") else "0/0:1", c[9], "X" if l.startswith("#") else "1/1"]))
     got, up, pc = vcfout.phased_vcf_text("\n".join(wide), 10, eng, gw_phase_vcf=1)
     assert got == gz_text(os.path.join(d, "out.vcf_gw1.txt.gz"))
+
+
+def _more_vcf_cases():
+    out = []
+    for case, gold in (("pipe_noisy_a", "pipe_noisy_a"), ("pipe_noisy_b", "pipe_noisy_b"), ("opts_gw_maf", os.path.join("pipe_opts", "gw_maf")),
+                       ("opts_separator", os.path.join("pipe_opts", "separator")), ("opts_unique_ids", os.path.join("pipe_opts", "unique_ids"))):
+        for mode, conf in ((1, 0.6), (2, 0.6), (2, 0.95)):
+            out.append((case, gold, mode, conf))
+    return out
+
+
+@pytest.mark.parametrize("case,gold,mode,conf", _more_vcf_cases(), ids=["%s-gw%d-c%d" % (c[0], c[2], int(c[3] * 100)) for c in _more_vcf_cases()])
+def test_phased_vcf_noisy_maf_separator(case, gold, mode, conf):
+    """write_vcf on low-confidence blocks, the MAF-weighted genome-wide phase, an odd id separator and unique ids, with GT rewriting
+    (--gw_phase_vcf 1 / 2) at lower confidence thresholds: byte-identical to what the reference wrote."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from phasing_oracle import bam_display_names
+    from phaser_amd import vcfout
+    d = os.path.join(GOLD, gold)
+    if case.startswith("opts_"):
+        meta = json.load(open(os.path.join(GOLD, "pipe_opts", "cases.json")))
+        name = case[5:]
+        load, cfg, baseq, isize = option_case_kwargs(name, meta["cases"][name], meta["blacklist"])
+        vcf_text = open(os.path.join(GOLD, "pipe_opts", "in.vcf")).read(); bams = ["o1.bam", "o2.bam"]
+    else:
+        load = {}; cfg = {"max_block_size": json.load(open(os.path.join(d, "meta.json")))["max_block_size"]}
+        vcf_text = open(os.path.join(d, "in.vcf")).read(); bams = ["n.bam"]
+    out, eng = run_host_stages(case, load, cfg, vcf_text, bam_display_names(bams))
+    got, up, pc = vcfout.phased_vcf_text(vcf_text, 9, eng, id_separator=cfg.get("id_separator", "_"), gw_phase_vcf=mode, min_confidence=conf, threads=2)
+    assert got == gz_text(os.path.join(d, "out.vcf_gw%d_c%d.txt.gz" % (mode, int(conf * 100))))

@@ -426,6 +426,26 @@ def fx_write_vcf(phaser, rvm):
         print("write_vcf", src, len(res["vcf"].splitlines()), "lines")
 
 
+def fx_write_vcf_more(phaser, rvm):
+    """More phased-VCF goldens: noisy inputs (low-confidence blocks), the MAF-weighted genome-wide phase (--gw_phase_method 1),
+    an odd id separator and unique ids, with --gw_phase_vcf 1 / 2 at lower --gw_phase_vcf_min_confidence thresholds."""
+    jobs = []
+    for tag in ("a", "b"):
+        d = os.path.join(GOLD, "pipe_noisy_" + tag)
+        mbs = json.load(open(os.path.join(d, "meta.json")))["max_block_size"]
+        sams = {"n.bam": {"chr22": gzip.open(os.path.join(d, "n.chr22.sam.gz"), "rt").read()}}
+        jobs.append((d, open(os.path.join(d, "in.vcf")).read(), sams, {"max_block_size": mbs}))
+    d0 = os.path.join(GOLD, "pipe_opts")
+    sams = {b + ".bam": {c: gzip.open(os.path.join(d0, "%s.%s.sam.gz" % (b, c)), "rt").read() for c in ("chr21", "chr22")} for b in ("o1", "o2")}
+    for name in ("gw_maf", "separator", "unique_ids"):
+        jobs.append((os.path.join(d0, name), open(os.path.join(d0, "in.vcf")).read(), sams, dict(OPT_CASES[name])))
+    for d, vcf, sams, kw in jobs:
+        for mode, conf in ((1, 0.6), (2, 0.6), (2, 0.95)):
+            res, _ = run_pipeline(phaser, rvm, vcf, sams, d, capture_calls=False, write_vcf=1, gw_phase_vcf=mode, gw_phase_vcf_min_confidence=conf, **kw)
+            wgz(os.path.join(d, "out.vcf_gw%d_c%d.txt.gz" % (mode, int(conf * 100))), res["vcf"])
+        print("write_vcf_more", os.path.relpath(d, GOLD), len(res["vcf"].splitlines()), "lines")
+
+
 def gene_ae_features(hc_text, seed):
     """Synthetic BED features for a haplotypic_counts file: clusters over runs of variants, nested features, features that
     END exactly at (variant position - 1) inside multi-variant blocks (the inclusive-end quirk of variant_feature_reads,
@@ -564,7 +584,7 @@ def fx_expr_matrix(phaser, rvm):
         print("expr_matrix", order, len(files), "files ->", out_all.split("\n")[0].count("\t") - 3, "sample columns,", len(out_all.splitlines()) - 1, "rows")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix}
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "write_vcf_more": fx_write_vcf_more, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
