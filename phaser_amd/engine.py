@@ -241,7 +241,7 @@ class Engine:
         match, mism = pdist.allreduce_counts(*self.tally_all())
         noise = self.noise_from_counts(match, mism)
         t1 = _t.perf_counter()
-        local = {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
+        local = self._fragments(noise)
         t2 = _t.perf_counter()
         frags = pdist.gather_fragments(local)
         self.stats.update({"tally_s": t1 - t0, "fragments_s": t2 - t1})
@@ -266,6 +266,28 @@ class Engine:
             return out
         out = {k: b"".join(v) for k, v in out.items()}
         return out if binary else {k: v.decode() for k, v in out.items()}
+
+    def _fragments(self, noise: float) -> Dict[str, dict]:
+        """Stage C for every owned chromosome.  C2 of chromosome i (native, releases the GIL) runs on a helper thread while
+        C1 of chromosome i+1 (numpy / scipy / GPU components) runs here."""
+        if len(self.chrom_list) <= 1:
+            return {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
+        import time as _t
+        from concurrent.futures import ThreadPoolExecutor
+        local: Dict[str, dict] = {}
+        with ThreadPoolExecutor(1) as ex:
+            pending = None
+            for c in self.chrom_list:
+                t0 = _t.perf_counter()
+                frag = self.chrom_prepare(c, noise, self.all_chroms.index(c))
+                self.stats["prepare_s"] = self.stats.get("prepare_s", 0.0) + _t.perf_counter() - t0
+                if pending is not None:
+                    pc, pf, fut = pending
+                    pf.update(fut.result()); del self._pre[pc]; local[pc] = pf
+                pending = (c, frag, ex.submit(rows.format_chrom, self, c, self.cfg.host_threads))
+            pc, pf, fut = pending
+            pf.update(fut.result()); del self._pre[pc]; local[pc] = pf
+        return {c: local[c] for c in self.chrom_list}
 
     def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
         """Stage C for one chromosome: C1 = ordering ranks, pair tests, pruning, components (numpy / scipy / GPU);
