@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: het-SNP allele calls/s of the read-backed phasing hot path on MI355X.
+"""Headline benchmark: het-SNP allele calls/s + phased variants/s of the read-backed phasing hot path, whole-genome RNA-seq shape.
 
 python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one resident shard: BASELINE.json configs[1]
-(chr1, 40k het SNPs, 50M records of 76 bp) already packed as structure-of-arrays in HBM.  With N GPUs every
-rank owns its own shard of that shape (chromosomes / BAMs are independent shards):
-weak scaling, no data-path collective; value = calls of all ranks / max-over-ranks time.
+Workload = BASELINE.json configs[2]: one GTEx-shape sample over the 22 autosomes, ~80M records of 76 bp and
+~1.5M het SNPs distributed in proportion to chromosome length, packed as structure-of-arrays shards resident in HBM.
+  * step (the K timed steps, `value`): K_map over every chromosome shard this rank owns, submitted as one batch
+    (phz_map_reads_batch: the reference's pool.map over chromosomes, phaser.py:533) -> allele calls/s.
+  * phasing pass (`phasing.value`): stages T1-O2 on the same call lists -- AS cutoff (histogram + all-reduce), K_tally, noise
+    all-reduce, pair tests, components, block phasing, the rows of the five files, gather to rank 0 -> phased variants/s.
+With N GPUs the SAME 22 chromosomes are LPT-assigned to ranks by record count (strong scaling); both regions are bracketed by a
+barrier + synchronize on every rank and the max over ranks is reported.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,38 +30,49 @@ HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md); measured copy pea
 CALL_BYTES = 17           # read_idx 4 + var_idx 4 + code 1 + aux0 4 + aux1 4
 
 
+def file_sha(*paths):
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(open(os.path.join(REPO, p), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
-    """HBM bytes per k_map launch from the committed PMC passes (profiles/<round>/pmc_kmap_*/{fetch,write}.csv, collected
-    with tools/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs).  Units are KiB; FETCH_SIZE is
-    doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B).  None when no PMC summary is present."""
+    """HBM bytes per k_map launch from a PMC summary committed under profiles/ (tools/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 --pmc passes of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  The summary carries the
+    hash of the kernel source it was measured on; a summary of an older kernel is NOT reported (None)."""
     import csv, glob
     dirs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_kmap_*")))
-    if not dirs:
-        return None
-    vals = {}
-    for name in ("fetch", "write"):
-        f = os.path.join(dirs[-1], name + ".csv")
-        if not os.path.exists(f):
-            return None
-        rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_map" in r["Kernel_Name"]]
-        if not rows:
-            return None
-        vals[name] = sum(rows) / len(rows)
-    return {"bytes_per_launch": 2 * vals["fetch"] * 1024 + vals["write"] * 1024, "fetch_raw_kib": vals["fetch"], "write_kib": vals["write"],
-            "source": os.path.relpath(dirs[-1], REPO), "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; same command as bench (configs[1] shard)"}
+    src = file_sha("phaser_amd/csrc/phz_map.hip")
+    for d in reversed(dirs):
+        meta = os.path.join(d, "meta.json")
+        if not os.path.exists(meta):
+            continue
+        m = json.load(open(meta))
+        if m.get("kernel_source_sha16") != src or m.get("workload") != "configs[2]":
+            continue
+        vals = {}
+        for name in ("fetch", "write"):
+            f = os.path.join(d, name + ".csv")
+            rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_map" in r["Kernel_Name"]] if os.path.exists(f) else []
+            if not rows:
+                return None
+            vals[name] = sum(rows) / len(rows)
+        return {"bytes_per_launch": 2 * vals["fetch"] * 1024 + vals["write"] * 1024, "fetch_raw_kib": vals["fetch"], "write_kib": vals["write"],
+                "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
+                "note": "mean over the k_map launches of this command; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE"}
+    return None
 
 
-def cpu_baseline(sample, vpos, baseq):
-    """Oracle (CPU restatement, kind 'port') timed on one host core over a bounded sample."""
+def cpu_mapper_baseline(sample, vpos, baseq):
+    """Mapper oracle (C restatement, kind 'port') on one host core and on all cores over a bounded sample."""
     import subprocess
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from helpers import oracle_map_readbatch
+    from helpers import oracle_map_readbatch, oracle_map_readbatch_threads
     subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle")])
-    from helpers import oracle_map_readbatch_threads
     t0 = time.perf_counter()
     o_r, o_v, o_c, _ = oracle_map_readbatch(os.path.join(REPO, "oracle"), sample, vpos, baseq, with_text=False)
     dt = time.perf_counter() - t0
-    # all host cores (the reference's own fan-out is one process per chromosome, phaser.py:2077-2094)
     cores = max(1, min(64, os.cpu_count() or 1))
     t0 = time.perf_counter()
     m_all = oracle_map_readbatch_threads(os.path.join(REPO, "oracle"), sample, vpos, baseq, cores)
@@ -65,16 +81,48 @@ def cpu_baseline(sample, vpos, baseq):
     return (o_r, o_v, o_c), dt, (cores, dt_all)
 
 
+def cpu_phasing_baseline(sample_chroms, vsets, shards, calls_of, mapper, baseq):
+    """oracle/phasing_oracle.py (CPU restatement of process_vcf's stages T1-O2, one core) on whole chromosomes of the same
+    sample; the product path is run on exactly those chromosomes as well and the five files must agree (canonical form)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle")); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import phasing_oracle as po
+    from helpers import OUTPUTS, canonical, call_text
+    from phaser_amd import synth, vcf as pvcf
+    from phaser_amd.engine import Engine, Config
+    vs_list = [vsets[c] for c in sample_chroms]
+    vcf_text = "\n".join(synth.vcf_lines(vs_list)) + "\n"
+    texts = [call_text(vsets[c], shards[c], calls_of[c]) for c in sample_chroms]
+    n_lines = sum(t.count("\n") for t in texts)
+    t0 = time.perf_counter()
+    ph = po.Phaser(["bench"], baseq=baseq)
+    ph.add_bam(texts)
+    want = ph.finish()
+    dt = time.perf_counter() - t0
+    eng = Engine(pvcf.load_variants(vcf_text), ["bench"], Config(baseq=baseq, host_threads=8, want_vcf=False), mapper=mapper)
+    for c in sample_chroms:
+        eng.add_mapped(0, c, shards[c], calls_of[c], int(shards[c].qid.max()) + 1)
+    eng.close_bam(0)
+    got = eng.finish()
+    same = all(canonical(n, got[n]) == canonical(n, want[n]) for n in OUTPUTS) and eng.phased == ph.phased
+    assert same, "product != phasing oracle on the sampled chromosomes"
+    return {"value": ph.phased / dt, "unit": "phased variants/s", "cores": 1, "kind": "port",
+            "sample": "chromosomes %s of the same sample (%d call lines, %d phased variants) through oracle/phasing_oracle.py, %.1f s"
+                      % ("+".join(sample_chroms), n_lines, ph.phased, dt),
+            "parity_on_sample": "five output files identical in canonical form (%d phased variants)" % ph.phased}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--records", type=int, default=50_000_000)
-    ap.add_argument("--snps", type=int, default=40_000)
+    ap.add_argument("--records", type=int, default=80_000_000)
+    ap.add_argument("--snps", type=int, default=1_500_000)
     ap.add_argument("--baseq", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=24_000_000)
-    ap.add_argument("--no-phasing", action="store_true", help="skip the (untimed-for-value) phasing-stage measurement")
+    ap.add_argument("--phasing-passes", type=int, default=3)
+    ap.add_argument("--no-phasing", action="store_true", help="skip the phasing-stage measurement")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
+    ap.add_argument("--no-c2", action="store_true", help="skip the secondary configs[1] entry (chr1, 50M records, 40k het SNPs)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,46 +131,46 @@ def main():
     # multi-rank path on a 1-GPU box)
     backend = os.environ.get("PHZ_BENCH_BACKEND", "nccl")
     local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     red_dev = dev if backend == "nccl" else "cpu"
 
-    from phaser_amd import workloads
-    from phaser_amd.mapper import Mapper
+    from phaser_amd import workloads, synth, vcf as pvcf
+    from phaser_amd import dist as pdist
+    from phaser_amd.mapper import Mapper, Calls
+    from phaser_amd.engine import Engine, Config
     from phaser_amd import _lib
-    import ctypes as C
 
+    plan = workloads.genome_plan(a.records, a.snps)
+    owner = pdist.assign_chromosomes({p[0]: float(p[3]) for p in plan}, world)       # LPT by record count
+    mine = [p for p in plan if owner[p[0]] == rank]
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu
     t_gen = time.perf_counter()
-    v, shard, sample = workloads.make_shard("chr1", workloads.CHR1_LEN, a.snps, a.records, 20240807 + 17 * rank, dev,
-                                            keep_sample=a.cpu_sample if (rank == 0 and world == 1) else 0)
+    vsets = {}; shards = {}; sample = None
+    for chrom, ln, n_snps, n_rec, seed in mine:
+        v, shard, smp = workloads.make_shard(chrom, ln, n_snps, n_rec, seed, dev, keep_sample=n_rec if (want_cpu and chrom == "chr1") else 0)
+        vsets[chrom] = v; shards[chrom] = shard
+        if smp is not None:
+            sample = smp
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     mapper = Mapper(local)
-    vpos = v.pos.to(dev)
+    chroms = [p[0] for p in mine]
+    sh_list = [shards[c] for c in chroms]
+    vp_list = [vsets[c].pos for c in chroms]
 
-    # first (untimed) pass sizes the output buffers; later passes reuse them through the raw ABI
-    calls = mapper.map(shard, vpos, a.baseq)
-    n_calls = calls.n
-    cap = n_calls + 16
-    bufs = [torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
-            torch.empty(cap, dtype=torch.uint8, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
-            torch.empty(cap, dtype=torch.int32, device=dev)]
-    p = lambda t: C.c_void_p(t.data_ptr())
-    r = _lib.phz_reads(shard.n, int(shard.cigar.numel()), int(shard.seq2.numel()), p(shard.pos), p(shard.cigar_off),
-                       p(shard.cigar), p(shard.seq_off), p(shard.seq2), p(shard.qual))
-    vv = _lib.phz_variants(int(vpos.numel()), p(vpos), None)
-    cc = _lib.phz_calls(cap, *[p(b) for b in bufs])
-    n_out = C.c_int64(0)
+    # first (untimed) pass sizes the output buffers; the timed passes reuse exact-size buffers through the raw ABI
+    first = mapper.map_batch(sh_list, vp_list, a.baseq)
+    n_calls = [c.n for c in first]
+    call, bufs, N = mapper.prepare_batch(sh_list, vp_list, a.baseq, [n + 16 for n in n_calls])
 
     def step():
-        mapper.ctx.check(mapper.ctx.lib.phz_map_reads(mapper.ctx.h, C.byref(r), C.byref(vv), a.baseq, C.byref(cc),
-                                                      C.byref(n_out), _lib.PHZ_DEVICE))
-        assert n_out.value == n_calls
+        mapper.ctx.check(call())
 
     for _ in range(a.warmup):
         step()
@@ -138,87 +186,161 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     _, k_total_ms, k_n = mapper.ctx.timing(_lib.PHZ_T_MAP)
+    assert [int(N[i]) for i in range(len(chroms))] == n_calls
 
-    # idempotence: the timed passes reproduce the first pass bit for bit
-    same = all(bool(torch.equal(b[:n_calls], c)) for b, c in zip(bufs, (calls.read_idx, calls.var_idx, calls.code, calls.aux0, calls.aux1)))
-    assert same, "repeated passes differ"
-    # sortedness: mapper order == (record, variant) lexicographic
-    key = bufs[0][:n_calls].to(torch.int64) * (int(vpos.numel()) + 1) + bufs[1][:n_calls].to(torch.int64)
-    assert bool((key[1:] > key[:-1]).all()), "call list not in mapper order"
+    # idempotence + mapper order (sortedness) on every shard at full size
+    for i, c in enumerate(chroms):
+        m = n_calls[i]
+        f = first[i]
+        assert all(bool(torch.equal(b[:m], t)) for b, t in zip(bufs[i], (f.read_idx, f.var_idx, f.code, f.aux0, f.aux1))), "repeated passes differ"
+        key = bufs[i][0][:m].to(torch.int64) * (len(vsets[c]) + 1) + bufs[i][1][:m].to(torch.int64)
+        assert bool((key[1:] > key[:-1]).all()), "call list not in mapper order"
 
-    tot_calls = torch.tensor([float(n_calls)], device=red_dev, dtype=torch.float64); tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
-    tot_recs = torch.tensor([float(shard.n)], device=red_dev, dtype=torch.float64)
+    loc_calls = float(sum(n_calls)); loc_recs = float(sum(s.n for s in sh_list)); loc_snps = float(sum(len(vsets[c]) for c in chroms))
+    loc_alg = float(sum(s.nbytes_map_inputs() for s in sh_list) + 4 * loc_snps + CALL_BYTES * loc_calls)
+    red = torch.tensor([loc_calls, loc_recs, loc_snps, loc_alg, k_total_ms, float(k_n)], device=red_dev, dtype=torch.float64)
+    tmax = torch.tensor([dt, k_total_ms], device=red_dev, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(tot_calls); dist.all_reduce(tot_recs); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(red); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot_calls, tot_recs, tot_snps, tot_alg, k_ms_sum, k_launches = [float(x) for x in red.tolist()]
+    dt = float(tmax[0]); k_ms_max_rank = float(tmax[1])
 
-    # ---- second rate of the metric: phased variants/s over stages T1-O2 (AS cutoff, K_tally, pair test, components,
-    #      native block phasing + row writer) on the same resident shard; two passes, outside the timed K_map region
+    # ---- second rate of the metric: phased variants/s over stages T1-O2 on the same call lists
     phasing = None
     if not a.no_phasing:
-        from phaser_amd import synth, vcf as pvcf
-        from phaser_amd.engine import Engine, Config
-        vs = pvcf.load_variants("\n".join(synth.vcf_lines([v])))
+        vs = pvcf.load_variants("\n".join(synth.vcf_lines([workloads_variants(plan, vsets, p) for p in plan])))
         host_threads = max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
+        calls_now = [Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i in range(len(chroms))]
         runs = []
-        for rep in range(2):            # two passes over the same shard (fresh Engine each time); the faster one is reported, both are listed
+        for rep in range(max(1, a.phasing_passes)):
             eng = Engine(vs, ["bench"], Config(baseq=a.baseq, host_threads=host_threads, want_vcf=False), mapper=mapper)
-            eng.add_shard(0, "chr1", shard, int(shard.qid.max()) + 1)
+            eng.set_owned(chroms)
+            for i, c in enumerate(chroms):
+                eng.add_mapped(0, c, shards[c], calls_now[i], int(shards[c].qid.max()) + 1)
+            mapper.ctx.reset_timing()
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
             tp0 = time.perf_counter()
-            eng.close_bam(0)
+            eng.close_bam(0)                       # AS histogram per shard + all-reduce + percentile
             tp1 = time.perf_counter()
-            counts = eng.tally_all()
+            files = eng.finish(chunks=True)        # K_tally, noise all-reduce, pair tests, components, block phasing, rows, gather
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
             tp2 = time.perf_counter()
-            noise = eng.noise_from_counts(*counts)
-            frag = eng.chrom_fragment("chr1", noise, 0)
-            tp3 = time.perf_counter()
-            runs.append({"value": frag["phased"] / (tp3 - tp0), "unit": "phased variants/s", "phased_variants": frag["phased"],
-                         "call_lines_kept": frag["lines"], "blocks": frag["n_blocks"],
-                         "seconds": {"as_cutoff": tp1 - tp0, "k_tally_incl_copies": tp2 - tp1, "host_assembly": tp3 - tp2,
-                                     "ordering_pairtest_components": eng.stats.get("prepare_s"), "block_phasing_and_rows": eng.stats.get("rows_s")},
-                         "host_threads": host_threads, "k_tally_kernel_ms": eng.ctx.timing(_lib.PHZ_T_TALLY)[0]})
-            del eng, frag
-        phasing = dict(max(runs, key=lambda r: r["value"]))
-        phasing["passes"] = [round(r["value"]) for r in runs]
+            tt = torch.tensor([tp2 - tp0], device=red_dev, dtype=torch.float64)
+            cnt = torch.tensor([float(mapper.ctx.counter(_lib.PHZ_C_LINES)), float(mapper.ctx.counter(_lib.PHZ_C_PAIR_EVENTS)),
+                                float(mapper.ctx.counter(_lib.PHZ_C_ITEMS)), float(mapper.ctx.counter(_lib.PHZ_C_EDGES)),
+                                mapper.ctx.timing(_lib.PHZ_T_TALLY)[1]], device=red_dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(cnt)
+            if rank == 0:
+                lines, events, items, edges, tally_ms = [float(x) for x in cnt.tolist()]
+                tally_bytes = 8.0 * lines + 16.0 * events
+                runs.append({"value": eng.phased / float(tt[0]), "unit": "phased variants/s", "phased_variants": eng.phased,
+                             "seconds_per_pass": float(tt[0]), "call_lines_kept": eng.total_lines,
+                             "output_bytes": int(sum(len(x) for v_ in files.values() for x in v_)),
+                             "seconds": {"as_cutoff": tp1 - tp0, "tally_to_rows_and_gather": tp2 - tp1,
+                                         **{k: round(v_, 4) for k, v_ in eng.stats.items()}},
+                             "host_threads": host_threads,
+                             "roofline": {"bound": "hbm", "kernel": "K_tally (all kernels of phz_tally, HIP events on the ctx stream)",
+                                          "achieved": tally_bytes / (tally_ms / 1e3) / 1e9 if tally_ms > 0 else None, "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": tally_bytes / (tally_ms / 1e3) / 1e9 / HBM_PEAK_GBS if tally_ms > 0 else None,
+                                          "traffic": None, "algorithmic_bytes": tally_bytes,
+                                          "model": "8 B x call lines + 16 B x pair events (SURVEY.md 8(d))", "call_lines": lines,
+                                          "pair_events": events, "items": items, "edges": edges, "kernel_ms_sum_over_ranks": tally_ms}})
+            del eng, files
+        if rank == 0:
+            phasing = dict(max(runs, key=lambda r: r["value"]))
+            phasing["passes"] = [round(r["value"]) for r in runs]
 
     if rank == 0:
-        alg_bytes = shard.nbytes_map_inputs() + int(vpos.numel()) * 4 + CALL_BYTES * n_calls
-        k_avg_s = k_total_ms / max(1, k_n) / 1e3
-        achieved = alg_bytes / k_avg_s / 1e9
+        k_avg_s = k_ms_sum / max(1.0, k_launches) / 1e3
+        alg_per_launch = tot_alg / max(1.0, k_launches / a.steps)
+        achieved = alg_per_launch / k_avg_s / 1e9
         out = {
-            "metric": "het-SNP allele calls/sec (value) + phased variants/sec (phasing.value), RNA-seq shape, per-GPU shards",
-            "value": float(tot_calls.item()) * a.steps / dt, "unit": "allele calls/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "het-SNP allele calls/sec + phased variants/sec, whole-genome RNA-seq, 1→8 GPUs",
+            "value": tot_calls * a.steps / dt, "unit": "allele calls/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-            "config": {"workload": "configs[1]: chr1 full, %d het SNPs, %d records x 76bp, one shard per GPU" % (a.snps, a.records),
-                       "records_per_gpu": shard.n, "het_snps": int(vpos.numel()), "calls_per_gpu": n_calls,
-                       "records_per_s": float(tot_recs.item()) * a.steps / dt, "gen_seconds": round(t_gen, 1)},
+            "config": {"workload": "configs[2]: whole genome (22 autosomes), one GTEx-shape RNA-seq sample, %d records x 76 bp, %d het SNPs, "
+                                   "one shard per chromosome; chromosomes LPT-assigned to GPUs by record count" % (int(tot_recs), int(tot_snps)),
+                       "records": int(tot_recs), "het_snps": int(tot_snps), "calls_per_step": int(tot_calls), "shards": len(plan),
+                       "records_per_s": tot_recs * a.steps / dt, "gen_seconds": round(t_gen, 1),
+                       "step": "K_map over all chromosome shards of the rank in one batched submission (phz_map_reads_batch)"},
             "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                         "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_record": alg_bytes / shard.n,
-                         "kernel_ms_avg": k_avg_s * 1e3, "launches": k_n},
+                         "algorithmic_bytes_per_launch": alg_per_launch, "bytes_per_record": tot_alg / tot_recs,
+                         "kernel_ms_avg": k_avg_s * 1e3, "launches": int(k_launches),
+                         "kernel_ms_per_step_max_rank": k_ms_max_rank / a.steps,
+                         "note": "achieved = algorithmic bytes of the launches (shard arrays + 4 B/SNP + 17 B/call) / their HIP-event time; "
+                                 "the kernel reads seq/qual only under a het SNP, so bytes actually moved are lower (traffic)"},
         }
         if phasing is not None:
             out["phasing"] = phasing
-        if world == 1 and sample is not None:
-            (o_r, o_v, o_c), cpu_dt, (cpu_cores, cpu_dt_all) = cpu_baseline(sample, v.pos.numpy(), a.baseq)
+            out["end_to_end"] = {"seconds": dt / a.steps + phasing["seconds_per_pass"], "unit": "s per sample, shards resident in HBM -> rows of the five files on rank 0",
+                                 "allele_calls_per_s": tot_calls / (dt / a.steps + phasing["seconds_per_pass"]),
+                                 "phased_variants_per_s": phasing["phased_variants"] / (dt / a.steps + phasing["seconds_per_pass"])}
+        if want_cpu and sample is not None:
+            (o_r, o_v, o_c), cpu_dt, (cpu_cores, cpu_dt_all) = cpu_mapper_baseline(sample, vsets["chr1"].pos.numpy(), a.baseq)
             m = len(o_r)
-            # at-scale parity: the GPU call list restricted to the sampled records equals the oracle's
-            assert np.array_equal(bufs[0][:m].cpu().numpy(), o_r) and np.array_equal(bufs[1][:m].cpu().numpy(), o_v) \
-                and np.array_equal(bufs[2][:m].cpu().numpy(), o_c), "GPU != oracle on the sampled prefix"
-            assert n_calls == m or int(bufs[0][m]) >= len(sample)
+            i1 = chroms.index("chr1")
+            # at-scale parity: the GPU call list of the sampled chromosome equals the oracle's
+            assert m == n_calls[i1] and np.array_equal(bufs[i1][0][:m].cpu().numpy(), o_r) and np.array_equal(bufs[i1][1][:m].cpu().numpy(), o_v) \
+                and np.array_equal(bufs[i1][2][:m].cpu().numpy(), o_c), "GPU != oracle on the sampled chromosome"
             out["cpu_baseline"] = {"value": m / cpu_dt, "unit": "allele calls/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d records of the same shard through oracle/rvm_oracle.c (array front end, "
+                                   "sample": "all %d records of chr1 of the same sample through oracle/rvm_oracle.c (array front end, "
                                              "no SAM text parsing), %.1f s; %.0f records/s" % (len(sample), cpu_dt, len(sample) / cpu_dt),
                                    "parity_on_sample": "bit-exact (%d calls)" % m,
                                    "all_cores": {"value": m / cpu_dt_all, "unit": "allele calls/s", "cores": cpu_cores,
                                                  "records_per_s": len(sample) / cpu_dt_all},
                                    "reference_note": "the reference's own Cython mapper ran 1.03e5 records/s/core in the build container "
                                                      "(BASELINE.md); this port is the faster, parity-locked stand-in on the GPU box"}
+            del sample
+            if phasing is not None:
+                calls_of = {c: Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i, c in enumerate(chroms)}
+                phasing["cpu_baseline"] = cpu_phasing_baseline(["chr21", "chr22"], vsets, shards, calls_of, mapper, a.baseq)
+        if world == 1 and not a.no_c2:
+            out["secondary"] = configs1_entry(mapper, a, dev)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def workloads_variants(plan, vsets, p):
+    """Variants of chromosome p for the VCF text every rank parses (chromosomes owned by other ranks are regenerated from the
+    plan's seeds: the table is tiny next to the reads)."""
+    from phaser_amd import synth
+    if p[0] in vsets:
+        return vsets[p[0]]
+    v, _, _, _ = synth.make_variants(p[0], 1, p[1], p[2], p[4], n_genes=max(1, p[2] // 10))
+    return v
+
+
+def configs1_entry(mapper, a, dev):
+    """Secondary, labelled entry: the configs[1] shard of round 1 (chr1 full, 40k het SNPs, 50M records) through the same ABI."""
+    from phaser_amd import workloads, _lib
+    torch.cuda.empty_cache()
+    v, shard, _ = workloads.make_shard("chr1", workloads.CHR1_LEN, 40_000, 50_000_000, 20240807, dev)
+    first = mapper.map_batch([shard], [v.pos], a.baseq)
+    call, bufs, N = mapper.prepare_batch([shard], [v.pos], a.baseq, [first[0].n + 16])
+    for _ in range(3):
+        mapper.ctx.check(call())
+    mapper.ctx.reset_timing()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 10
+    for _ in range(steps):
+        mapper.ctx.check(call())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    _, tot, n = mapper.ctx.timing(_lib.PHZ_T_MAP)
+    alg = shard.nbytes_map_inputs() + 4 * len(v) + CALL_BYTES * first[0].n
+    k = tot / n / 1e3
+    return {"workload": "configs[1]: chr1 full, 40000 het SNPs, 50000000 records x 76 bp, one shard", "value": first[0].n / dt,
+            "unit": "allele calls/s", "ms_per_step": dt * 1e3, "kernel_ms_avg": k * 1e3, "roofline_frac": alg / k / 1e9 / HBM_PEAK_GBS,
+            "bytes_per_record": alg / shard.n}
 
 
 if __name__ == "__main__":

@@ -134,6 +134,11 @@ typedef struct {
 /* timing slots for phz_get_timing */
 enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_GENES = 4, PHZ_T_COUNT = 8 };
 
+/* work counters accumulated over phz_tally calls since the last phz_reset_timing (the units of K_tally's byte model):
+ * call lines seen, distinct (QNAME, variant, class) items, pair events = sum over QNAMEs of C(k, 2) item pairs on different
+ * variants, distinct variant pairs (edges) */
+enum { PHZ_C_LINES = 0, PHZ_C_ITEMS = 1, PHZ_C_PAIR_EVENTS = 2, PHZ_C_EDGES = 3, PHZ_C_COUNT = 8 };
+
 int phz_version(void);
 const char *phz_strerror(int status);
 const char *phz_last_error(const phz_ctx *ctx);
@@ -148,6 +153,12 @@ void *phz_ctx_stream(phz_ctx *ctx);
 /* Read -> variant allele mapper.  On PHZ_E_CAPACITY *n_calls holds the required capacity. */
 int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_variants *vars, int baseq,
                   phz_calls *out, int64_t *n_calls, int space);
+
+/* The (chromosome, BAM) shards of one fan-out -- parallelize(call_mapping_script, chromosomes) at phaser/phaser.py:533 --
+ * submitted back to back on the ctx stream with ONE host wait.  Device pointers only (shards resident in HBM); reads[i],
+ * vars[i], out[i], n_calls[i] describe shard i.  PHZ_E_CAPACITY when some out[i] is too small (its n_calls[i] holds the need). */
+int phz_map_reads_batch(phz_ctx *ctx, int n_shards, const phz_reads *reads, const phz_variants *vars, int baseq,
+                        const phz_calls *out, int64_t *n_calls);
 
 /* AS histogram of one shard's call lines, ACCUMULATED into hist[PHZ_AS_BINS] (int64). */
 int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *hist, int space);
@@ -418,6 +429,7 @@ int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_column, con
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
 int phz_reset_timing(phz_ctx *ctx);
+int phz_get_counter(phz_ctx *ctx, int slot, int64_t *value);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 PHZ_OK, PHZ_E_ARG, PHZ_E_HIP, PHZ_E_CAPACITY, PHZ_E_UNSUPPORTED, PHZ_E_NOMEM = 0, -1, -2, -3, -4, -5
 PHZ_HOST, PHZ_DEVICE = 0, 1
 PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS, PHZ_T_GENES = 0, 1, 2, 3, 4
+PHZ_C_LINES, PHZ_C_ITEMS, PHZ_C_PAIR_EVENTS, PHZ_C_EDGES = 0, 1, 2, 3
 
 
 class PhzError(RuntimeError):
@@ -160,6 +161,8 @@ SYMBOLS = {
     "phz_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "phz_map_reads": (C.c_int, [C.c_void_p, C.POINTER(phz_reads), C.POINTER(phz_variants), C.c_int,
                                 C.POINTER(phz_calls), C.POINTER(C.c_int64), C.c_int]),
+    "phz_map_reads_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_reads), C.POINTER(phz_variants), C.c_int,
+                                      C.POINTER(phz_calls), C.POINTER(C.c_int64)]),
     "phz_as_histogram": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_void_p, C.c_int]),
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                             C.POINTER(phz_tally_out), C.POINTER(C.c_int64), C.c_int]),
@@ -206,6 +209,7 @@ SYMBOLS = {
     "phz_get_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int64)]),
     "phz_reset_timing": (C.c_int, [C.c_void_p]),
+    "phz_get_counter": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -216,17 +220,32 @@ def hip_sources():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 into phaser_amd/libphz.so (in-tree)."""
+    """Compile every HIP translation unit for gfx950 into phaser_amd/libphz.so (in-tree).  One object per source under
+    csrc/build/ (compiled concurrently, rebuilt only when the source or a header changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = hip_sources()
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-        [os.path.join(REPO, "include", "phz.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(REPO, "include", "phz.h")]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    jobs = []
+    objs = []
+    for src in srcs:
+        obj = os.path.join(bdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append(["hipcc"] + flags + ["-c", src, "-o", obj])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH, "-lz", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB_PATH, "-lz", "-lpthread"])
     return LIB_PATH
 
 
@@ -285,6 +304,11 @@ class Context:
         last = C.c_float(); tot = C.c_double(); n = C.c_int64()
         self.check(self.lib.phz_get_timing(self.h, slot, C.byref(last), C.byref(tot), C.byref(n)))
         return last.value, tot.value, n.value
+
+    def counter(self, slot):
+        v = C.c_int64()
+        self.check(self.lib.phz_get_counter(self.h, slot, C.byref(v)))
+        return v.value
 
     def reset_timing(self):
         self.check(self.lib.phz_reset_timing(self.h))

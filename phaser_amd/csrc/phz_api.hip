@@ -53,6 +53,8 @@ int phz_ctx_destroy(phz_ctx *c) {
                      &c->r_qual, &c->v_pos, &c->v_reflen, &c->c_read, &c->c_var, &c->c_code, &c->c_aux0, &c->c_aux1};
     for (DevBuf *b : all) free_buf(*b);
     for (DevBuf &b : c->scratch) free_buf(b);
+    if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
+    for (hipEvent_t e : c->map_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -76,6 +78,13 @@ int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int
 
 int phz_reset_timing(phz_ctx *ctx) {
     for (int i = 0; i < PHZ_T_COUNT; i++) { ctx->last_ms[i] = 0; ctx->total_ms[i] = 0; ctx->launches[i] = 0; }
+    for (int i = 0; i < PHZ_C_COUNT; i++) ctx->counters[i] = 0;
+    return PHZ_OK;
+}
+
+int phz_get_counter(phz_ctx *ctx, int slot, int64_t *value) {
+    if (!ctx || !value || slot < 0 || slot >= PHZ_C_COUNT) return PHZ_E_ARG;
+    *value = ctx->counters[slot];
     return PHZ_OK;
 }
 
@@ -100,6 +109,17 @@ int phz_reserve(phz_ctx *ctx, DevBuf &b, size_t bytes) {
     return PHZ_OK;
 }
 
+int phz_reserve_host(phz_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return PHZ_OK;
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) return phz_fail(ctx, PHZ_E_NOMEM, "hipHostMalloc", e);
+    b.cap = want;
+    return PHZ_OK;
+}
+
 static int upload(phz_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
     if (int s = phz_reserve(ctx, b, bytes ? bytes : 1)) return s;
     if (bytes) PHZ_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -112,6 +132,15 @@ static int check_variants(phz_ctx *ctx, const phz_variants *v, int space) {
         for (int64_t i = 0; i < v->n; i++)
             if (v->ref_len[i] != 1) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "variants with ref_len != 1 (indel mode) are not supported by K_map yet");
     return PHZ_OK;
+}
+
+extern "C" int phz_map_reads_batch(phz_ctx *ctx, int n_shards, const phz_reads *reads, const phz_variants *vars, int baseq,
+                                   const phz_calls *out, int64_t *n_calls) {
+    if (!ctx || n_shards < 0 || (n_shards && (!reads || !vars || !out || !n_calls))) return PHZ_E_ARG;
+    for (int i = 0; i < n_shards; i++)
+        if (reads[i].n_reads < 0 || vars[i].n < 0 || out[i].cap < 0) return phz_fail(ctx, PHZ_E_ARG, "negative size");
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    return phz_launch_map_batch(ctx, n_shards, reads, vars, baseq, out, n_calls);
 }
 
 extern "C" int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_variants *vars, int baseq,

@@ -22,8 +22,11 @@ struct phz_ctx {
     float last_ms[PHZ_T_COUNT] = {0};
     double total_ms[PHZ_T_COUNT] = {0};
     int64_t launches[PHZ_T_COUNT] = {0};
+    int64_t counters[PHZ_C_COUNT] = {0};     // work counters accumulated by phz_tally (phz_get_counter)
     // scratch
     DevBuf desc, tile_w0, scalars;
+    DevBuf h_scalars;                  // pinned host mirror of `scalars` (hipHostMalloc)
+    std::vector<hipEvent_t> map_ev;    // event pairs around every k_map launch of a batch
     // staging for PHZ_HOST callers
     DevBuf r_pos, r_coff, r_cig, r_soff, r_seq, r_qual, v_pos, v_reflen;
     DevBuf c_read, c_var, c_code, c_aux0, c_aux1;
@@ -35,6 +38,7 @@ struct phz_ctx {
 
 int phz_fail(phz_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
 int phz_reserve(phz_ctx *ctx, DevBuf &b, size_t bytes);
+int phz_reserve_host(phz_ctx *ctx, DevBuf &b, size_t bytes);      // pinned host memory
 
 #define PHZ_HIP(ctx, call)                                                      \
     do {                                                                        \
@@ -45,6 +49,8 @@ int phz_reserve(phz_ctx *ctx, DevBuf &b, size_t bytes);
 // launchers implemented in the kernel translation units (device pointers only)
 int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int baseq, const phz_calls &out,
                    int64_t *n_calls);
+int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out,
+                         int64_t *n_calls);
 
 // Scoped staging of host arrays for PHZ_HOST callers: device copies live until the object dies.
 struct Staging {

@@ -596,11 +596,9 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
 
 }  // namespace
 
-int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int baseq, const phz_calls &out,
-                   int64_t *n_calls) {
-    *n_calls = 0;
-    if (r.n_reads == 0 || v.n == 0) return PHZ_OK;
-    if (v.n > 0x7fffffff) return phz_fail(ctx, PHZ_E_ARG, "too many variants in one shard");
+// Enqueue one shard's kernels on the ctx stream without waiting: pre-pass, k_map, tile scan, compaction.  The two result
+// scalars (total calls, largest tile) land in ctx->scalars[2*slot .. 2*slot+1]; HIP events ctx->map_ev[2*slot..] bracket k_map.
+static int map_enqueue(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int baseq, const phz_calls &out, int slot) {
     int rpt = 2, blk = 128;
     { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) > 0) rpt = atoi(e); }
     { const char *e = getenv("PHZ_MAP_BLOCK"); if (e && atoi(e) > 0) blk = atoi(e); }
@@ -609,7 +607,6 @@ int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int 
     const int64_t ntiles = (r.n_reads + tile_reads - 1) / tile_reads;
     DevBuf *S = ctx->scratch;      // 17..23: tile_total, tile_base, staged read/var/code/aux0/aux1
     if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 16)) return s;
-    if (int s = phz_reserve(ctx, ctx->scalars, 64)) return s;
     if (int s = phz_reserve(ctx, S[17], (size_t)ntiles * 4)) return s;
     const int nchunks = (int)((ntiles + 1023) / 1024);
     if (int s = phz_reserve(ctx, ctx->desc, (size_t)ntiles * 4 + (size_t)nchunks * 24 + 64)) return s;
@@ -621,58 +618,116 @@ int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int 
     hipStream_t sm = ctx->stream;
     hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm,
                        r.pos, r.cigar_off, r.n_reads, v.pos, (int)v.n, (int32_t *)ctx->tile_w0.p, ntiles, tile_reads);
-    float ms_total = 0;
-    unsigned long long scal[2] = {0, 0};
-    for (int attempt = 0; attempt < 3; attempt++) {
-        const int slot_cap = ctx->map_slot_cap;
-        const size_t slots = (size_t)ntiles * (size_t)slot_cap;
-        if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
-        if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
-        if (int s = phz_reserve(ctx, S[20], slots)) return s;
-        if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
-        if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
-        MapArgs a;
-        a.pos = r.pos; a.cigar_off = r.cigar_off; a.cigar = r.cigar; a.seq_off = r.seq_off; a.seq2 = r.seq2; a.qual = r.qual;
-        a.n = r.n_reads; a.vpos = v.pos; a.nv = (int)v.n; a.baseq = baseq;
-        a.o_read = (int32_t *)S[18].p; a.o_var = (int32_t *)S[19].p; a.o_code = (uint8_t *)S[20].p;
-        a.o_aux0 = (uint32_t *)S[21].p; a.o_aux1 = (uint32_t *)S[22].p;
-        a.tile_w0 = (const int32_t *)ctx->tile_w0.p;
-        a.tile_total = (int32_t *)S[17].p;
-        a.slot_cap = slot_cap;
-        a.ntiles = ntiles;
-        { const char *e = getenv("PHZ_MAP_DBG"); a.dbg = e ? atoi(e) : 0; }
-        PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
+    const int slot_cap = ctx->map_slot_cap;
+    const size_t slots = (size_t)ntiles * (size_t)slot_cap;
+    if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
+    if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
+    if (int s = phz_reserve(ctx, S[20], slots)) return s;
+    if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
+    if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
+    MapArgs a;
+    a.pos = r.pos; a.cigar_off = r.cigar_off; a.cigar = r.cigar; a.seq_off = r.seq_off; a.seq2 = r.seq2; a.qual = r.qual;
+    a.n = r.n_reads; a.vpos = v.pos; a.nv = (int)v.n; a.baseq = baseq;
+    a.o_read = (int32_t *)S[18].p; a.o_var = (int32_t *)S[19].p; a.o_code = (uint8_t *)S[20].p;
+    a.o_aux0 = (uint32_t *)S[21].p; a.o_aux1 = (uint32_t *)S[22].p;
+    a.tile_w0 = (const int32_t *)ctx->tile_w0.p;
+    a.tile_total = (int32_t *)S[17].p;
+    a.slot_cap = slot_cap;
+    a.ntiles = ntiles;
+    { const char *e = getenv("PHZ_MAP_DBG"); a.dbg = e ? atoi(e) : 0; }
+    PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[2 * slot], sm));
 #define PHZ_LAUNCH_MAP(B, R) hipLaunchKernelGGL((k_map<B, R>), dim3((unsigned)ntiles), dim3(B), 0, sm, a)
-        if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
-        else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
-        else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
-        else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
-        else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
-        else PHZ_LAUNCH_MAP(256, 4);
+    if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
+    else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
+    else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
+    else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
+    else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
+    else PHZ_LAUNCH_MAP(256, 4);
 #undef PHZ_LAUNCH_MAP
-        PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
-        hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
-                           chunk_max);
-        hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(1024), 0, sm, (const int64_t *)chunk_sum, (const int32_t *)chunk_max, nchunks, chunk_base,
-                           (unsigned long long *)ctx->scalars.p);
-        CompactArgs c;
-        c.s_read = a.o_read; c.s_var = a.o_var; c.s_code = a.o_code; c.s_aux0 = a.o_aux0; c.s_aux1 = a.o_aux1;
-        c.o_read = out.read_idx; c.o_var = out.var_idx; c.o_code = out.code; c.o_aux0 = out.aux0; c.o_aux1 = out.aux1;
-        c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base;
-        c.slot_cap = slot_cap; c.cap = out.cap; c.ntiles = ntiles;
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
-        PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, 16, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipStreamSynchronize(sm));
-        float ms = 0;
-        PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        ms_total += ms;
-        if ((int64_t)scal[1] <= slot_cap) break;
-        // some tile produced more calls than a slot holds: grow the slots to the exact maximum and redo
-        ctx->map_slot_cap = (int)((scal[1] + 63) / 64 * 64);
-        if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging slots did not converge");
+    PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[2 * slot + 1], sm));
+    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
+                       chunk_max);
+    hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(1024), 0, sm, (const int64_t *)chunk_sum, (const int32_t *)chunk_max, nchunks, chunk_base,
+                       (unsigned long long *)ctx->scalars.p + 2 * slot);
+    CompactArgs c;
+    c.s_read = a.o_read; c.s_var = a.o_var; c.s_code = a.o_code; c.s_aux0 = a.o_aux0; c.s_aux1 = a.o_aux1;
+    c.o_read = out.read_idx; c.o_var = out.var_idx; c.o_code = out.code; c.o_aux0 = out.aux0; c.o_aux1 = out.aux1;
+    c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base;
+    c.slot_cap = slot_cap; c.cap = out.cap; c.ntiles = ntiles;
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
+
+// n shards submitted back to back, ONE host wait: scratch is sized for the largest shard up front (growing a buffer while
+// kernels are in flight would free memory under them), results come back in one small copy.  A shard whose densest tile
+// overflowed its staging slot is redone alone with larger slots.
+int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out,
+                         int64_t *n_calls) {
+    for (int i = 0; i < n; i++) n_calls[i] = 0;
+    if (n <= 0) return PHZ_OK;
+    for (int i = 0; i < n; i++)
+        if (v[i].n > 0x7fffffff) return phz_fail(ctx, PHZ_E_ARG, "too many variants in one shard");
+    if ((int)ctx->map_ev.size() < 2 * n) {
+        const size_t old = ctx->map_ev.size();
+        ctx->map_ev.resize((size_t)2 * n, nullptr);
+        for (size_t k = old; k < ctx->map_ev.size(); k++) PHZ_HIP(ctx, hipEventCreate(&ctx->map_ev[k]));
     }
-    ctx->last_ms[PHZ_T_MAP] = ms_total; ctx->total_ms[PHZ_T_MAP] += ms_total; ctx->launches[PHZ_T_MAP]++;
-    *n_calls = (int64_t)scal[0];
-    return (int64_t)scal[0] > out.cap ? PHZ_E_CAPACITY : PHZ_OK;
+    if (int s = phz_reserve(ctx, ctx->scalars, (size_t)16 * n + 64)) return s;
+    if (int s = phz_reserve_host(ctx, ctx->h_scalars, (size_t)16 * n + 64)) return s;
+    unsigned long long *scal = (unsigned long long *)ctx->h_scalars.p;
+    float ms_total = 0;
+    std::vector<int> todo;
+    for (int i = 0; i < n; i++) if (r[i].n_reads > 0 && v[i].n > 0) todo.push_back(i);
+    for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++) {
+        // size the shared scratch for the largest pending shard before anything is enqueued
+        int big = todo[0];
+        for (int i : todo) if (r[i].n_reads > r[big].n_reads) big = i;
+        {
+            // dry reservation: same sizes map_enqueue will ask for
+            int rpt = 2, blk = 128;
+            { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) > 0) rpt = atoi(e); }
+            { const char *e = getenv("PHZ_MAP_BLOCK"); if (e && atoi(e) > 0) blk = atoi(e); }
+            const int tile_reads = blk * rpt;
+            if (ctx->map_slot_cap <= 0 || ctx->map_tile_reads != tile_reads) { ctx->map_slot_cap = tile_reads / 2 < 64 ? 64 : tile_reads / 2; ctx->map_tile_reads = tile_reads; }
+            const int64_t ntiles = (r[big].n_reads + tile_reads - 1) / tile_reads;
+            const size_t slots = (size_t)ntiles * (size_t)ctx->map_slot_cap;
+            DevBuf *S = ctx->scratch;
+            const int nchunks = (int)((ntiles + 1023) / 1024);
+            if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 16)) return s;
+            if (int s = phz_reserve(ctx, S[17], (size_t)ntiles * 4)) return s;
+            if (int s = phz_reserve(ctx, ctx->desc, (size_t)ntiles * 4 + (size_t)nchunks * 24 + 64)) return s;
+            if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
+            if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
+            if (int s = phz_reserve(ctx, S[20], slots)) return s;
+            if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
+            if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
+        }
+        for (int i : todo) if (int s = map_enqueue(ctx, r[i], v[i], baseq, out[i], i)) return s;
+        PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)16 * n, hipMemcpyDeviceToHost, ctx->stream));
+        PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int> again;
+        unsigned long long need = 0;
+        for (int i : todo) {
+            float ms = 0;
+            PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->map_ev[2 * i], ctx->map_ev[2 * i + 1]));
+            ms_total += ms;
+            if ((int64_t)scal[2 * i + 1] > ctx->map_slot_cap) { again.push_back(i); need = scal[2 * i + 1] > need ? scal[2 * i + 1] : need; }
+            else n_calls[i] = (int64_t)scal[2 * i];
+        }
+        if (!again.empty()) {
+            if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging slots did not converge");
+            ctx->map_slot_cap = (int)((need + 63) / 64 * 64);      // grow the slots to the exact maximum and redo those shards
+        }
+        todo.swap(again);
+    }
+    ctx->last_ms[PHZ_T_MAP] = ms_total; ctx->total_ms[PHZ_T_MAP] += ms_total; ctx->launches[PHZ_T_MAP] += n;
+    int st = PHZ_OK;
+    for (int i = 0; i < n; i++) if (n_calls[i] > out[i].cap) st = PHZ_E_CAPACITY;
+    return st;
+}
+
+int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int baseq, const phz_calls &out,
+                   int64_t *n_calls) {
+    return phz_launch_map_batch(ctx, 1, &r, &v, baseq, &out, n_calls);
 }

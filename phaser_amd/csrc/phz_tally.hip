@@ -482,12 +482,14 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         m = (int64_t)hm;
     }
     int64_t ne = 0;
+    unsigned long long pair_events = 0;
     if (m > 0) {
         hipLaunchKernelGGL(k_distinct, dim3((unsigned)((m + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, items, m, d_dist);
         hipLaunchKernelGGL(k_pair_count, dim3((unsigned)((m + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, items, m, counters + 2);
         unsigned long long events = 0;
         PHZ_HIP(ctx, hipMemcpyAsync(&events, counters + 2, 8, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
+        pair_events = events;
         if (events > 0) {
             uint64_t cap = 1024;
             while (cap < 2 * events && cap < (1ull << 31)) cap <<= 1;
@@ -531,6 +533,8 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     }
     PHZ_HIP(ctx, hipGetLastError());
     timer.stop();
+    ctx->counters[PHZ_C_LINES] += total; ctx->counters[PHZ_C_ITEMS] += m; ctx->counters[PHZ_C_PAIR_EVENTS] += (int64_t)pair_events;
+    ctx->counters[PHZ_C_EDGES] += ne;
     *n_edges = ne;
     if (space == PHZ_HOST) {
         PHZ_HIP(ctx, hipMemcpyAsync(out->var_count, d_cnt, (size_t)nv * 12, hipMemcpyDeviceToHost, sm));

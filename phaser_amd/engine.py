@@ -122,6 +122,28 @@ class Engine:
         if qnames is not None:
             self.qnames[chrom] = qnames
 
+    def add_shards(self, bam_index: int, items):
+        """Several chromosomes of one BAM at once: items = [(chrom, device-resident ReadShard, n_qid, qnames or None)].  SNP-mode
+        chromosomes go through ONE batched K_map submission (phz_map_reads_batch); indel-mode ones one by one."""
+        batch = [it for it in items if not self.vs.chroms[it[0]].is_general and it[1].device.type == "cuda"]
+        rest = [it for it in items if it not in batch]
+        if batch:
+            calls = self.mapper.map_batch([it[1] for it in batch], [torch.from_numpy(self.vs.chroms[it[0]].pos) for it in batch],
+                                          self.cfg.baseq)
+            for it, c in zip(batch, calls):
+                self.add_mapped(bam_index, it[0], it[1], c, it[2], it[3] if len(it) > 3 else None)
+        for it in rest:
+            self.add_shard(bam_index, it[0], it[1], it[2], it[3] if len(it) > 3 else None)
+
+    def add_mapped(self, bam_index: int, chrom: str, shard: ReadShard, calls: Calls, n_qid: int, qnames: Optional[List[str]] = None):
+        """Attach a shard whose K_map call list already exists."""
+        has_as = shard.has_as
+        self.shards[chrom][bam_index] = _Shard(calls, shard.qid.contiguous(), shard.aln_score.contiguous(),
+                                               None if has_as is None else has_as.contiguous(), shard.n)
+        self.n_qid[chrom] = max(self.n_qid[chrom], n_qid)
+        if qnames is not None:
+            self.qnames[chrom] = qnames
+
     def _lines(self, sh: _Shard, bam_index: int) -> _lib.phz_lines:
         c = sh.calls
         return _lib.phz_lines(c.n, _p(c.read_idx), _p(c.var_idx), _p(c.code), sh.n_reads, _p(sh.qid), _p(sh.aln), _p(sh.has_as),

@@ -77,6 +77,48 @@ class Mapper:
             m = int(n.value)
             return Calls(*[b[:m] for b in bufs])
 
+    def prepare_batch(self, shards, vposs, baseq: int, caps):
+        """ctypes argument arrays + output buffers for phz_map_reads_batch over device-resident shards (built once, reusable
+        for repeated passes).  -> (call(), bufs, n_out) where call() submits the whole batch and returns the status."""
+        n = len(shards)
+        R = (_lib.phz_reads * n)(); V = (_lib.phz_variants * n)(); O = (_lib.phz_calls * n)(); N = (C.c_int64 * n)()
+        bufs = []
+        keep = []
+        for i, (sh, vp, cap) in enumerate(zip(shards, vposs, caps)):
+            if sh.device.type != "cuda":
+                raise _lib.PhzError(_lib.PHZ_E_ARG, "map_batch needs shards resident in HBM")
+            vp = vp.to(sh.device).to(torch.int32).contiguous(); keep.append(vp)
+            R[i] = _lib.phz_reads(sh.n, int(sh.cigar.numel()), int(sh.seq2.numel()), _ptr(sh.pos), _ptr(sh.cigar_off), _ptr(sh.cigar),
+                                  _ptr(sh.seq_off), _ptr(sh.seq2), _ptr(sh.qual))
+            V[i] = _lib.phz_variants(int(vp.numel()), _ptr(vp), None)
+            b = [torch.empty(cap, dtype=torch.int32, device=sh.device), torch.empty(cap, dtype=torch.int32, device=sh.device),
+                 torch.empty(cap, dtype=torch.uint8, device=sh.device), torch.empty(cap, dtype=torch.int32, device=sh.device),
+                 torch.empty(cap, dtype=torch.int32, device=sh.device)]
+            bufs.append(b)
+            O[i] = _lib.phz_calls(cap, *[_ptr(t) for t in b])
+        h = self.ctx.h; fn = self.ctx.lib.phz_map_reads_batch; bq = int(baseq)
+
+        def call():
+            return fn(h, n, R, V, bq, O, N)
+        call.keep = (R, V, O, N, keep, bufs)
+        return call, bufs, N
+
+    def map_batch(self, shards, vposs, baseq: int):
+        """K_map over several device-resident (chromosome, BAM) shards in one submission (phz_map_reads_batch: the reference's
+        pool.map over chromosomes, phaser.py:533).  -> list of Calls."""
+        if not shards:
+            return []
+        caps = [sh.n // 2 + 4096 for sh in shards]
+        torch.cuda.synchronize(shards[0].device)
+        while True:
+            call, bufs, N = self.prepare_batch(shards, vposs, baseq, caps)
+            st = call()
+            self.ctx.check(st, allow=(_lib.PHZ_E_CAPACITY,))
+            if st == _lib.PHZ_E_CAPACITY:
+                caps = [max(c, int(N[i]) + 16) for i, c in enumerate(caps)]
+                continue
+            return [Calls(*[t[:int(N[i])] for t in bufs[i]]) for i in range(len(shards))]
+
     def map_general(self, shard: ReadShard, vpos: torch.Tensor, ref_len: torch.Tensor, allele_off: torch.Tensor,
                     allele_bytes: torch.Tensor, baseq: int, want_text: bool = False):
         """K_map_general (indel mode).  Returns Calls (codes 5/6 = allele 0/1) and, when want_text, a TextPool."""

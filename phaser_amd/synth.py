@@ -78,12 +78,13 @@ def make_variants(chrom: str, start: int, end: int, n_snps: int, seed: int,
     dot = torch.rand(n, generator=g) < dot_id_frac
     gt = []
     rsid = []
+    unph_l = unph.tolist(); hap_l = hap_alt.tolist(); dot_l = dot.tolist()
     for i in range(n):
-        if bool(unph[i]):
+        if unph_l[i]:
             gt.append("0/1")
         else:
-            gt.append("1|0" if int(hap_alt[i]) == 0 else "0|1")
-        rsid.append("." if bool(dot[i]) else "rs%d" % (1000 + i))
+            gt.append("1|0" if hap_l[i] == 0 else "0|1")
+        rsid.append("." if dot_l[i] else "rs%d" % (1000 + i))
     v = Variants(chrom, pos.to(torch.int32), ref, alt, gt, hap_alt, rsid)
     if indel_frac > 0:
         # a share of the sites become deletions (REF = 2-4 reference bases, ALT = its first base) or insertions

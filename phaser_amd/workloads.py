@@ -14,12 +14,26 @@ CONFIGS = {
 }
 
 
+# hg38 autosome lengths, chr1..chr22
+HG38_AUTOSOMES = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+                  133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468]
+
+
+def genome_plan(total_records: int = 80_000_000, total_snps: int = 1_500_000, seed: int = 777, scale: float = 1.0):
+    """BASELINE.json configs[2]: one GTEx-shape sample over the autosomes, het SNPs and records proportional to
+    chromosome length.  -> [(chrom, length, n_snps, n_records, seed)] in VCF order; the same plan on every rank."""
+    total_len = sum(HG38_AUTOSOMES)
+    return [("chr%d" % (i + 1), ln, max(1, int(total_snps * scale * ln / total_len)), max(2, int(total_records * scale * ln / total_len)), seed + i)
+            for i, ln in enumerate(HG38_AUTOSOMES)]
+
+
 def make_shard(chrom: str, length: int, n_snps: int, n_records: int, seed: int, device: str,
-               chunk: int = 2_000_000, keep_sample: int = 0):
+               chunk: int = 2_000_000, keep_sample: int = 0, read_seed=None):
     """One (chromosome, BAM) shard with every record passing the upstream samtools filters.
-    Returns (variants, ReadShard on `device`, sample ReadBatch on the CPU holding the first keep_sample records)."""
+    Returns (variants, ReadShard on `device`, sample ReadBatch on the CPU holding the first keep_sample records).
+    read_seed: seed of the reads alone (several BAMs of one sample share `seed`, i.e. the variants, and differ in read_seed)."""
     v, gs, ge, w = synth.make_variants(chrom, 1, length, n_snps, seed, n_genes=max(1, n_snps // 10))
-    plan = synth.make_read_plan(v, gs, ge, w, (n_records + 1) // 2, seed + 1, device=device, all_pass=True)
+    plan = synth.make_read_plan(v, gs, ge, w, (n_records + 1) // 2, seed + 1 if read_seed is None else read_seed, device=device, all_pass=True)
     n = len(plan)
     parts = []
     sample = None

@@ -138,3 +138,17 @@ def oracle_map_readbatch_threads(oracle_dir, rb, vpos, baseq, n_threads):
                                       o_v.ctypes.data, o_c.ctypes.data, None)
     with ThreadPoolExecutor(n_threads) as ex:
         return sum(ex.map(work, range(n_threads)))
+
+
+def call_text(v, shard, calls, qname_prefix="q"):
+    """Mapper TSV (read_variant_map.py:117) of one chromosome from a GPU call list + the shard's per-record fields, as input
+    for the phasing oracle.  Composite allele texts (code 4: inserted bases / IUPAC symbols) are written as '<other>': any
+    text outside the individual's alleles lands in the same class downstream (phaser.py:1312-1324)."""
+    ri = calls.read_idx.cpu().numpy(); vi = calls.var_idx.cpu().numpy(); cd = calls.code.cpu().numpy()
+    qid = shard.qid.cpu().numpy()[ri]; asc = shard.aln_score.cpu().numpy()[ri]
+    pos = v.pos.tolist(); ref = v.ref.tolist(); alt = v.alt.tolist()
+    uid = ["%s_%d_%s_%s" % (v.chrom, pos[i], synth.BASES[ref[i]], synth.BASES[alt[i]]) for i in range(len(v))]
+    names = ["A", "C", "G", "T", "<other>"]
+    rs = v.rsid; gt = v.gt
+    return "".join("%s%d\t%s\t%s\t%s\t%d\t%s\tNone\n" % (qname_prefix, q, uid[j], rs[j], names[c if c < 4 else 4], a, gt[j])
+                   for q, j, c, a in zip(qid.tolist(), vi.tolist(), cd.tolist(), asc.tolist()))

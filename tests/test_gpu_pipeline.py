@@ -260,3 +260,29 @@ def test_population_flow_three_samples(mapper, tmp_path):
         for si, s in enumerate(rows[0][4:]):
             assert r[4 + si] == per_sample[s][k][4] + "|" + per_sample[s][k][5]
     assert any(c != "0|0" for r in rows[1:] for c in r[4:])
+
+
+def test_population_flow_matches_reference(mapper, tmp_path):
+    """next-4 on the GPU box: SAM inputs of fixture pipe_two -> phaser (K_map / K_tally) -> phaser_gene_ae (K_genes) under the three
+    option sets of tests/golden/expr_matrix -> phaser_expr_matrix, compared with the matrices the REFERENCE's phaser_expr_matrix.py
+    wrote from the reference's own gene_ae files of the reference's own haplotypic counts (tools/make_golden.py fx_expr_matrix)."""
+    from phaser_amd import expr_matrix, gene_ae
+    d = os.path.join(GOLD, "pipe_two")
+    bams = {b + ".bam": {c: gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")} for b in ("t1", "t2")}
+    out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(), bams, "cuda")
+    hc = out["haplotypic_counts"].encode()
+    e = os.path.join(GOLD, "expr_matrix")
+    bed = open(os.path.join(e, "features.bed")).read()
+    gdir = tmp_path / "in"; gdir.mkdir()
+    for tag, kw in (("A", {}), ("B", {"gw_cutoff": 0.6}), ("C", {"min_cov": 5})):
+        text = gene_ae.gene_ae(hc, bed, **kw)
+        lines = text.split("\n")
+        head, rows = lines[0], [l for l in lines[1:] if l]
+        for bam in ("t1", "t2"):
+            name = "%s_%s" % (tag, bam)
+            body = [l.rsplit("\t", 1)[0] + "\t" + name for l in rows if l.rsplit("\t", 1)[1] == bam]
+            (gdir / (name + ".gene_ae.txt")).write_text(head + "\n" + "\n".join(body) + "\n")
+    for order in ("sorted", "reversed"):
+        a, g, log = expr_matrix.expr_matrix(str(gdir), os.path.join(e, "features.bed"), order)
+        assert a == gz_text(os.path.join(e, "out.%s.bed.gz" % order)), order
+        assert g == gz_text(os.path.join(e, "out.%s.gw_phased.bed.gz" % order)), order

@@ -1,0 +1,150 @@
+"""GPU parity at the shapes of BASELINE.json configs[2] (whole genome: 22 autosomes, ~80M records, ~1.5M het SNPs, one BAM) and
+configs[3] (the same sample with 4 BAMs whose QNAMEs collide).  No oracle run exists at these sizes, so each test combines
+  * a bit-exact oracle check of K_map on the first 200k records of EVERY chromosome shard (denser het-SNP windows than the
+    configs[1] shard: the MAP_WIN truncation path of phz_map.hip is exercised),
+  * the size-independent relations that tie the five output files together, over all chromosomes, and
+  * full equality with the pinned phasing oracle on a 2 % scale replica of the same plan (22 chromosomes: the global merge order
+    of blocks / allelic_counts / singleton rows across chromosomes and BAMs, SURVEY.md 8.1 rules 2 and 4).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from helpers import OUTPUTS, call_text, canonical, oracle_map_readbatch
+
+pytestmark = pytest.mark.gpu
+
+PREFIX = 200_000
+
+
+@pytest.fixture(scope="module")
+def mapper():
+    from phaser_amd.mapper import Mapper
+    return Mapper(0)
+
+
+def build(plan, n_bams, keep):
+    """-> variants per chromosome, shards[bam][chrom], samples[bam][chrom] (host prefix of `keep` records)."""
+    from phaser_amd import workloads
+    vsets = {}; shards = [dict() for _ in range(n_bams)]; samples = [dict() for _ in range(n_bams)]
+    for chrom, ln, n_snps, n_rec, seed in plan:
+        for b in range(n_bams):
+            v, sh, smp = workloads.make_shard(chrom, ln, n_snps, n_rec, seed, "cuda:0", keep_sample=keep, read_seed=seed + 1 + 7919 * b)
+            vsets[chrom] = v; shards[b][chrom] = sh; samples[b][chrom] = smp
+    return vsets, shards, samples
+
+
+def run_engine(mapper, vsets, shards, plan, **cfg):
+    from phaser_amd import synth, vcf
+    from phaser_amd.engine import Config, Engine
+    vs = vcf.load_variants("\n".join(synth.vcf_lines([vsets[p[0]] for p in plan])))
+    eng = Engine(vs, ["bam%d" % b for b in range(len(shards))], Config(want_vcf=False, **cfg), mapper=mapper)
+    for b, per_chrom in enumerate(shards):
+        # QNAME ids are shared by the BAMs of a chromosome: id k of every BAM is the same template name "q<k>"
+        eng.add_shards(b, [(c, sh, int(sh.qid.max()) + 1) for c, sh in per_chrom.items()])
+        eng.close_bam(b)
+    return eng, eng.finish()
+
+
+def check_oracle_prefix(oracle_build, eng, vsets, samples, plan):
+    for b, per_chrom in enumerate(samples):
+        for chrom, *_ in plan:
+            smp = per_chrom[chrom]
+            o_r, o_v, o_c, _ = oracle_map_readbatch(oracle_build, smp, vsets[chrom].pos.numpy(), 10, with_text=False)
+            calls = eng.shards[chrom][b].calls
+            m = len(o_r)
+            assert m > 0
+            got_r = calls.read_idx[:m + 1].cpu().numpy()
+            assert np.array_equal(got_r[:m], o_r), (chrom, b)
+            assert np.array_equal(calls.var_idx[:m].cpu().numpy(), o_v), (chrom, b)
+            assert np.array_equal(calls.code[:m].cpu().numpy(), o_c), (chrom, b)
+            assert calls.n == m or int(got_r[m]) >= len(smp)          # the next call belongs to a record past the prefix
+
+
+def check_invariants(eng, out, plan, n_bams):
+    rows = lambda name: [l.split("\t") for l in out[name].split("\n")[1:] if l]
+    kept = 0
+    for chrom, *_ in plan:
+        R = eng.tally[chrom]
+        k = int((R["line_cls"] != 255).sum())
+        assert int(R["var_count"].sum()) == k
+        assert (R["var_distinct"] <= R["var_count"]).all()
+        kept += k
+    assert kept == eng.total_lines
+    order = {p[0]: i for i, p in enumerate(plan)}
+    al = rows("allelic_counts")
+    assert all(int(r[5]) + int(r[6]) == int(r[7]) for r in al)
+    # allelic_counts: per first BAM the chromosomes in VCF order (rule 2); inside one chromosome of one BAM first-appearance order
+    seq = [order[r[0]] for r in al]
+    drops = sum(1 for x, y in zip(seq, seq[1:]) if y < x)
+    assert drops <= n_bams - 1
+    for chrom in (plan[0][0], plan[-1][0]):
+        R = eng.tally[chrom]
+        idx = {u: i for i, u in enumerate(eng.vs.chroms[chrom].uid)}
+        for r in [x for x in al if x[0] == chrom][::211]:
+            i = idx[r[2]]
+            assert (int(r[5]), int(r[6])) == (int(R["var_distinct"][i][0]), int(R["var_distinct"][i][1]))
+    hap = rows("haplotypes")
+    blocks = [r for r in hap if int(r[4]) > 1]
+    # blocks: chromosomes in VCF order (rule 4 + :863-867), every phased variant in exactly one block
+    bseq = [order[r[0]] for r in blocks]
+    assert bseq == sorted(bseq)
+    phased_ids = [x for r in blocks for x in r[5].split(",")]
+    assert len(phased_ids) == len(set(phased_ids)) == eng.phased
+    assert sum(int(r[4]) * (int(r[4]) - 1) for r in blocks) == len(rows("allele_config"))
+    assert all(int(r[7]) + int(r[8]) == int(r[9]) for r in hap)
+    ase = rows("haplotypic_counts")
+    assert all(int(r[9]) + int(r[10]) == int(r[11]) for r in ase)
+    for r in [x for x in ase if int(x[4]) > 1][::307]:
+        la = set(t for g in r[16].split(";") for t in g.split(",") if t); lb = set(t for g in r[17].split(";") for t in g.split(",") if t)
+        assert len(la) == int(r[9]) and len(lb) == int(r[10])
+    conn = rows("variant_connections")
+    assert all(int(r[2]) <= int(r[3]) for r in conn)
+    assert len(conn) == sum(int(eng.tally[p[0]]["linked"].sum()) for p in plan)
+
+
+def check_replica_vs_oracle(mapper, plan_small, n_bams, min_phased=1000):
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import phasing_oracle as po
+    from phaser_amd import synth
+    vsets, shards, _ = build(plan_small, n_bams, 0)
+    eng, got = run_engine(mapper, vsets, shards, plan_small, host_threads=4)
+    ph = po.Phaser(["bam%d" % b for b in range(n_bams)])
+    for b in range(n_bams):
+        ph.add_bam([call_text(vsets[p[0]], shards[b][p[0]], eng.shards[p[0]][b].calls) for p in plan_small])
+    want = ph.finish()
+    for name in OUTPUTS:
+        assert canonical(name, got[name]) == canonical(name, want[name]), name
+    assert eng.phased == ph.phased and eng.phased > min_phased
+
+
+def test_whole_genome_one_bam(mapper, oracle_build):
+    """configs[2]: 22 chromosome shards, 80M records, 1.5M het SNPs."""
+    from phaser_amd import workloads
+    plan = workloads.genome_plan()
+    vsets, shards, samples = build(plan, 1, PREFIX)
+    eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
+    assert sum(sh.n for sh in shards[0].values()) > 79_000_000 and eng.vs.het_count > 1_400_000
+    check_oracle_prefix(oracle_build, eng, vsets, samples, plan)
+    check_invariants(eng, out, plan, 1)
+    del eng, out, shards, samples
+    torch.cuda.empty_cache()
+    check_replica_vs_oracle(mapper, workloads.genome_plan(scale=0.02), 1)
+
+
+def test_whole_genome_four_bams_shared_qnames(mapper, oracle_build):
+    """configs[3] shape on one GPU: the same sample's 22 chromosomes with 4 BAMs (20M records each) whose QNAME ids collide, so the
+    cross-BAM merge (last BAM owns a QNAME's read_vars list, phaser.py:558-581) runs on every chromosome."""
+    from phaser_amd import workloads
+    plan = workloads.genome_plan(total_records=20_000_000)
+    vsets, shards, samples = build(plan, 4, PREFIX // 4)
+    eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
+    check_oracle_prefix(oracle_build, eng, vsets, samples, plan)
+    check_invariants(eng, out, plan, 4)
+    del eng, out, shards, samples
+    torch.cuda.empty_cache()
+    check_replica_vs_oracle(mapper, workloads.genome_plan(total_records=20_000_000, scale=0.02), 4, min_phased=200)
