@@ -89,6 +89,7 @@ bool aux_as(const uint8_t *p, const uint8_t *e, int32_t *out) {
                                    p = z + 1; continue; }
             case 'B': { if (p + 5 > e) return found; const uint8_t st = p[0]; const uint32_t cnt = rd32(p + 1);
                         int es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                        if ((size_t)cnt * (size_t)es > (size_t)(e - p) - 5) return found;
                         p += 5 + (size_t)cnt * es; continue; }
             default: return found;
         }
@@ -289,11 +290,18 @@ int phz_bam_open(const char *path, int threads, phz_bam **out) {
     if (int st = inflate_bgzf_file(path, threads, h->b.data)) { delete h; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
     const RawBuf &d = h->b.data;
     if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { delete h; return PHZ_E_ARG; }
-    size_t p = 8 + (size_t)rdi32(d.data() + 4);
+    // untrusted input: every header field is checked against the inflated size before it is used
+    const size_t dn = d.size();
+    const int32_t l_text = rdi32(d.data() + 4);
+    if (l_text < 0 || (size_t)l_text > dn - 12) { delete h; return PHZ_E_ARG; }
+    size_t p = 8 + (size_t)l_text;
     const int32_t n_ref = rdi32(d.data() + p); p += 4;
+    if (n_ref < 0 || (size_t)n_ref > (dn - p) / 9) { delete h; return PHZ_E_ARG; }        // a reference entry takes >= 9 bytes
     for (int32_t i = 0; i < n_ref; i++) {
+        if (p + 4 > dn) { delete h; return PHZ_E_ARG; }
         const int32_t l = rdi32(d.data() + p); p += 4;
-        std::string name((const char *)d.data() + p, (size_t)(l > 0 ? l - 1 : 0)); p += (size_t)l;
+        if (l < 1 || (size_t)l > dn - p || dn - p - (size_t)l < 4) { delete h; return PHZ_E_ARG; }
+        std::string name((const char *)d.data() + p, (size_t)(l - 1)); p += (size_t)l;
         h->b.refs.emplace_back(name, rdi32(d.data() + p)); p += 4;
     }
     h->b.first_record = p;
@@ -334,14 +342,20 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         for (uint32_t k = 0; k + 1 < l_rn; k++) if (r[32 + k] < 33 || r[32 + k] > 126) return 0;
         return p + 4 + (size_t)bs;
     };
-    auto hop = [&](size_t p, size_t stop, std::vector<Rec> &out, std::vector<int32_t> &last_pos, bool *unsorted) -> size_t {
-        while (p < stop && p + 4 <= n) {
+    // hop() returns where the chain stopped; *corrupt is set when a record does not fit its own block_size (or the stream ends
+    // inside a record): the fixed fields, QNAME, CIGAR, SEQ and QUAL of EVERY record are proven to lie inside the inflated
+    // buffer here, so the packer below never reads past a record
+    auto hop = [&](size_t p, size_t stop, std::vector<Rec> &out, std::vector<int32_t> &last_pos, bool *unsorted, bool *corrupt) -> size_t {
+        while (p < stop) {
+            if (p + 4 > n) { *corrupt = true; return p; }
             const int32_t bs = rdi32(d + p);
-            if (bs < 32 || p + 4 + (size_t)bs > n) return p;
+            if (bs < 32 || (size_t)bs > n - p - 4) { *corrupt = true; return p; }
             const uint8_t *r = d + p + 4;
             const int32_t ref = rdi32(r);
             const uint32_t l_rn = r[8], mapq = r[9], n_cig = rd16(r + 12), flag = rd16(r + 14);
             const int32_t l_seq = rdi32(r + 16), tlen = rdi32(r + 28);
+            if (l_seq < 0 || l_rn < 1 ||
+                32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) { *corrupt = true; return p; }
             bool keep = ref >= 0 && ref < n_ref && (!ref_mask || ref_mask[ref]) && (int)mapq >= min_mapq &&
                         ((int)flag & flag_required) == flag_required && ((int)flag & flag_forbidden) == 0;
             if (keep && isize_cutoff != 0) { const double tl = tlen < 0 ? -(double)tlen : (double)tlen; keep = tl <= isize_cutoff; }
@@ -405,9 +419,10 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
                         const int k = next.fetch_add(1);
                         if (k >= K) break;
                         part[(size_t)k].reserve((seg_start[(size_t)k + 1] - seg_start[(size_t)k]) / 180 + 64);
-                        bool u = false;
-                        seg_end[(size_t)k] = hop(seg_start[(size_t)k], seg_start[(size_t)k + 1], part[(size_t)k], lastp[(size_t)k], &u);
+                        bool u = false, cr = false;
+                        seg_end[(size_t)k] = hop(seg_start[(size_t)k], seg_start[(size_t)k + 1], part[(size_t)k], lastp[(size_t)k], &u, &cr);
                         bad[(size_t)k] = u ? 1 : 0;
+                        if (cr) seg_end[(size_t)k] = (size_t)-1;          // never equals a segment start: forces the sequential hop
                         for (const Rec &x : part[(size_t)k])
                             if (firstp[(size_t)k][(size_t)x.ref] < 0) firstp[(size_t)k][(size_t)x.ref] = rdi32(d + x.off + 4) + 1;   // +1: 0 is a valid POS
                     }
@@ -438,7 +453,9 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         recs.clear(); unsorted = false;
         recs.reserve(n / 180 + 1024);
         std::vector<int32_t> last_pos((size_t)n_ref, -1);
-        hop(b.first_record, n, recs, last_pos, &unsorted);
+        bool corrupt = false;
+        hop(b.first_record, n, recs, last_pos, &unsorted, &corrupt);
+        if (corrupt) { b.err = "truncated or corrupt BAM record"; return PHZ_E_ARG; }
     }
     if (getenv("PHZ_TIMING")) fprintf(stderr, "[phz timing]   bam record hop: %s, %zu records kept\n", done ? "parallel segments, boundaries verified" : "sequential", recs.size());
     if (unsorted) return PHZ_E_UNSUPPORTED;

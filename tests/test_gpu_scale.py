@@ -93,7 +93,7 @@ def check_invariants(eng, out, plan, n_bams):
     # blocks: chromosomes in VCF order (rule 4 + :863-867), every phased variant in exactly one block
     bseq = [order[r[0]] for r in blocks]
     assert bseq == sorted(bseq)
-    phased_ids = [x for r in blocks for x in r[5].split(",")]
+    phased_ids = [(r[0], x) for r in blocks for x in r[5].split(",")]          # names are rsids: unique per chromosome only
     assert len(phased_ids) == len(set(phased_ids)) == eng.phased
     assert sum(int(r[4]) * (int(r[4]) - 1) for r in blocks) == len(rows("allele_config"))
     assert all(int(r[7]) + int(r[8]) == int(r[9]) for r in hap)

@@ -78,3 +78,72 @@ def test_phased_vcf_writer_survives_malformed_lines():
         except _lib.PhzError:
             bad += 1
     assert ok > 20 and ok + bad == 200
+
+
+def test_bam_decoder_survives_corrupt_records(tmp_path):
+    """a truncated / corrupt BAM must come back as a status (PhzError), never as an out-of-bounds read.  The inflated
+    stream of a small BAM is mutated (header fields, l_read_name / n_cigar / l_seq / block_size of records, random bytes, cut
+    tails), re-wrapped as BGZF and decoded with the native reader; tools/asan_check.sh runs this under AddressSanitizer."""
+    import gzip
+    import struct
+    import ctypes as C
+    import numpy as np
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, gs, ge, w = synth.make_variants("chr22", 1, 2_000_000, 100, 31, n_genes=8)
+    rb = synth.make_reads(v, gs, ge, w, 400, 32)
+    bam = str(tmp_path / "a.bam")
+    bamio.readbatch_to_bam(bam, [rb], [("chr21", 46709983), ("chr22", 50818468)])
+    raw = bytearray(gzip.open(bam, "rb").read())          # BGZF members are gzip members
+    assert raw[:4] == b"BAM\1"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]; p += 4
+    for _ in range(n_ref):
+        l = struct.unpack_from("<i", raw, p)[0]; p += 4 + l + 4
+    first = p
+    recs = []
+    while p + 4 <= len(raw):
+        recs.append(p); p += 4 + struct.unpack_from("<i", raw, p)[0]
+    assert len(recs) > 500
+    rng = random.Random(7)
+
+    def write(data, name):
+        path = str(tmp_path / name)
+        st = _lib.load().phz_bgzf_write(path.encode(), bytes(data), len(data), 2, 1)
+        assert st == 0
+        return path
+
+    def decode(path):
+        interners = {}
+        return bamio.shards_from_bam_native(path, interners, 0, False, False, 0.0, threads=rng.choice([0, 2]))
+    base = decode(write(raw, "ok.bam"))
+    assert sum(s.n for s in base.values()) == len(recs)
+    ok = bad = 0
+    for it in range(160):
+        m = bytearray(raw)
+        kind = it % 8
+        r = rng.choice(recs)
+        if kind == 0:
+            struct.pack_into("<i", m, r, rng.choice([-1, 0, 31, 33, 1 << 30, struct.unpack_from("<i", m, r)[0] - 1]))       # block_size
+        elif kind == 1:
+            m[r + 4 + 8] = rng.choice([0, 1, 255])                                                                          # l_read_name
+        elif kind == 2:
+            struct.pack_into("<H", m, r + 4 + 12, rng.choice([0, 1000, 65535]))                                             # n_cigar_op
+        elif kind == 3:
+            struct.pack_into("<i", m, r + 4 + 16, rng.choice([-5, 0, 1 << 20, 0x7fffffff]))                                 # l_seq
+        elif kind == 4:
+            m = m[:rng.randrange(first, len(m))]                                                                            # cut tail
+        elif kind == 5:
+            for _ in range(rng.randrange(1, 20)):
+                m[rng.randrange(first, len(m))] = rng.randrange(256)                                                        # noise in records
+        elif kind == 6:
+            struct.pack_into("<i", m, rng.choice([4, 8 + l_text, 8 + l_text + 4]), rng.choice([-1, 0x7fffffff, 1 << 28, 3]))  # header
+        else:
+            m = m[:rng.randrange(0, first + 8)]                                                                             # cut header
+        try:
+            decode(write(m, "m%d.bam" % it))
+            ok += 1
+        except _lib.PhzError:
+            bad += 1
+    assert ok + bad == 160 and bad >= 60
