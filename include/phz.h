@@ -12,7 +12,8 @@
  *   phz_as_histogram     phaser/phaser.py:545-553        `cut -f 5` over all call files + numpy.percentile
  *   phz_tally            phaser/phaser.py:1287-1328      process_mapping_result (per-variant read lists),
  *                        :610-632 noise counters, :1265-1285 generate_connectivity_map,
- *                        :1594-1635 test_variant_connection's nine set intersections
+ *                        :1594-1635 test_variant_connection's nine set intersections, :917-931 / :1086-1115 the
+ *                        per-haplotype read lists of the block output loop (what SURVEY.md 8(b) calls phz_hap_counts)
  *   phz_components       phaser/phaser.py:1861-1882      build_haplotypes / :1985 build_haplotype_v3
  *
  * Conventions
@@ -93,7 +94,7 @@ typedef struct {
 typedef struct {
     int64_t n_calls;
     const int32_t *read_idx;
-    const int32_t *var_idx;
+    const int32_t *var_idx;      /* index into the shard's chromosome's variant table */
     const uint8_t *code;
     int64_t n_reads;
     const int32_t *read_qid;     /* template (QNAME) id per record; ids are per chromosome, shared by all BAMs */
@@ -102,23 +103,39 @@ typedef struct {
     double as_cutoff;            /* numpy.percentile value (phaser.py:551); used when use_cutoff != 0 */
     int32_t use_cutoff;
     int32_t bam_index;
+    int64_t var_base;            /* phz_tally over several chromosomes: index of the chromosome's first variant / first QNAME id */
+    int64_t qid_base;            /* in the call's joint index spaces (0 for a single chromosome) */
 } phz_lines;
 
 #define PHZ_AS_BINS 65536        /* histogram bin = AS + 32768 */
 
+/* What one phz_tally produced (sizes of the arrays phz_tally_fetch hands out) */
+typedef struct {
+    int64_t n_lines;         /* call lines of all shards */
+    int64_t n_kept;          /* lines that passed the AS cutoff */
+    int64_t n_edges;         /* distinct variant pairs */
+    int64_t n_read_list;     /* kept ref/alt lines = entries of rl_qid */
+    int64_t n_items;         /* distinct (QNAME, variant, class) */
+    int64_t pair_events;     /* sum over QNAMEs of item pairs on different variants */
+} phz_tally_sizes;
+
+/* Destination arrays of phz_tally_fetch; a NULL member is skipped.  Variant indices are positions in the call's joint variant
+ * space (var_base + index), line numbers positions in the concatenation of the shards' lines in the order they were passed. */
 typedef struct {
     int32_t *var_count;      /* [nv*3] kept call lines per (variant, class ref/alt/other), duplicates kept */
-    int64_t *var_first;      /* [nv]   global index of the first kept line, -1 if none */
+    int64_t *var_first;      /* [nv]   first kept line, -1 if none */
     int32_t *var_distinct;   /* [nv*3] distinct QNAMEs per (variant, class) */
-    uint8_t *line_cls;       /* [sum n_calls] 0 ref / 1 alt / 2 other / 255 dropped by the AS cutoff */
-    int64_t edge_cap;
-    int32_t *edge_a;         /* variant pair a < b (indices), sorted by (a, b) */
-    int32_t *edge_b;
-    int32_t *edge_cells;     /* [edge_cap*9] |S_a[i] & S_b[j]| at i*3+j, classes ref/alt/other */
-    uint8_t *edge_linked;    /* 1 when some QNAME's surviving read_vars list holds both variants */
     uint64_t *var_rank;      /* [nv] order in which variants enter the connectivity map (phaser.py:1271-1283): smallest
                               * (first ref/alt line of the QNAME << 32 | line) over surviving read_vars entries of QNAMEs
                               * with >= 2 distinct variants; UINT64_MAX when the variant never gets a key */
+    uint8_t *line_cls;       /* [n_lines] 0 ref / 1 alt / 2 other / 255 dropped by the AS cutoff */
+    int32_t *edge_a;         /* [n_edges] variant pair a < b, sorted by (a, b) */
+    int32_t *edge_b;
+    int32_t *edge_cells;     /* [n_edges*9] |S_a[i] & S_b[j]| at i*3+j, classes ref/alt/other */
+    uint8_t *edge_linked;    /* [n_edges] 1 when some QNAME's surviving read_vars list holds both variants */
+    uint32_t *rl_start;      /* [nv*2*n_bams + 1] read lists (phaser.py:1318-1322): the kept lines of (variant v, allele k, BAM b) */
+    int32_t *rl_qid;         /* [n_read_list]     are rl_qid[rl_start[(2v+k)*n_bams+b] : rl_start[... + 1]] = their QNAME ids
+                              *                   (chromosome-local, as passed in read_qid) in line order */
 } phz_tally_out;
 
 /* Variant table for the general (indel) mapper: per variant REF length and the individual's two allele strings. */
@@ -162,15 +179,20 @@ int phz_map_reads_batch(phz_ctx *ctx, int n_shards, const phz_reads *reads, cons
 
 /* AS histogram of one shard's call lines, ACCUMULATED into hist[PHZ_AS_BINS] (int64). */
 int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *hist, int space);
+/* the same for several device-resident shards into one device-resident histogram, one host wait */
+int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t *hist);
 
-/* Per-variant counters, distinct read sets and variant-pair co-occurrence cells of one chromosome over
- * all its BAM shards (in BAM order).  a0/a1: the individual's two allele base codes per variant (255 when an
- * allele is not a single ACGT base).  On PHZ_E_CAPACITY *n_edges holds the required edge capacity. */
+/* Per-variant counters, distinct read sets, variant-pair co-occurrence cells and per-(variant, allele, BAM) read lists over
+ * any number of (chromosome, BAM) shards in one submission.  Shards must be ordered by (chromosome, BAM); a chromosome's
+ * shards share var_base / qid_base; nv / n_qid are the sizes of the joint index spaces.  a0/a1: the individual's two allele
+ * base codes per variant (255 when an allele is not a single ACGT base).  The results stay resident in HBM until the next
+ * phz_tally on this ctx: phz_tally_fetch copies what the caller wants, phz_components can use the edge list in place. */
 int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1,
-              int64_t n_qid, phz_tally_out *out, int64_t *n_edges, int space);
+              int64_t n_qid, int n_bams, phz_tally_sizes *sizes, int space);
+int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space);
 
 /* Connected components of the variant graph restricted to edges with keep != 0: label[v] = smallest variant
- * index of v's component. */
+ * index of v's component.  edge_a == edge_b == NULL: the edge list of the last phz_tally (n_edges must match). */
 int phz_components(phz_ctx *ctx, int64_t nv, int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b,
                    const uint8_t *keep, int32_t *label, int space);
 
@@ -263,9 +285,11 @@ typedef struct {
     const uint8_t *blacklisted;   /* [nv] --haplo_count_blacklist hit, may be NULL */
     const int32_t *var_count;     /* [3nv] from phz_tally */
     const int32_t *var_distinct;  /* [3nv] */
-    int64_t n_lines;
-    const int32_t *line_var, *line_qid, *line_bam;
-    const uint8_t *line_cls;
+    /* read lists from phz_tally: the kept lines of (variant v, allele k, BAM b) carry the QNAME ids
+     * rl_qid[rl_start[(2v+k)*nb+b] : rl_start[(2v+k)*nb+b+1]] in line order.  rl_start points at THIS chromosome's first entry of
+     * the tally's array (its values index the tally's whole rl_qid, which is passed as is) */
+    const uint32_t *rl_start;
+    const int32_t *rl_qid;
     /* tested variant pairs (linked edges), oriented by first appearance: rows of variant_connections in eorder */
     int64_t n_edges;
     const int32_t *va, *vb, *ea, *eb;
@@ -301,6 +325,8 @@ typedef struct {
 } phz_rows_out;
 
 int phz_rows_format(const phz_rows_in *in, phz_rows_out *out);
+/* several chromosomes through one pool of `threads` workers: in[i] -> out[i] */
+int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_rows_out *out, int threads);
 void phz_rows_free(phz_rows_out *out);
 /* phase_v3 (phaser.py:2107-2170) on one connected component: n position-sorted variants, edges (i, j, cfg 0 cis / 1 trans /
  * -1 tie) in local indices.  Outputs the final sub-blocks: first local variant, length, and haplotype-A allele characters

@@ -52,13 +52,17 @@ class phz_calls(C.Structure):
 class phz_lines(C.Structure):
     _fields_ = [("n_calls", C.c_int64), ("read_idx", C.c_void_p), ("var_idx", C.c_void_p), ("code", C.c_void_p),
                 ("n_reads", C.c_int64), ("read_qid", C.c_void_p), ("read_as", C.c_void_p), ("read_has_as", C.c_void_p),
-                ("as_cutoff", C.c_double), ("use_cutoff", C.c_int32), ("bam_index", C.c_int32)]
+                ("as_cutoff", C.c_double), ("use_cutoff", C.c_int32), ("bam_index", C.c_int32),
+                ("var_base", C.c_int64), ("qid_base", C.c_int64)]
+
+
+class phz_tally_sizes(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_lines", "n_kept", "n_edges", "n_read_list", "n_items", "pair_events")]
 
 
 class phz_tally_out(C.Structure):
-    _fields_ = [("var_count", C.c_void_p), ("var_first", C.c_void_p), ("var_distinct", C.c_void_p), ("line_cls", C.c_void_p),
-                ("edge_cap", C.c_int64), ("edge_a", C.c_void_p), ("edge_b", C.c_void_p), ("edge_cells", C.c_void_p),
-                ("edge_linked", C.c_void_p), ("var_rank", C.c_void_p)]
+    _fields_ = [(k, C.c_void_p) for k in ("var_count", "var_first", "var_distinct", "var_rank", "line_cls", "edge_a", "edge_b", "edge_cells",
+                                          "edge_linked", "rl_start", "rl_qid")]
 
 
 class phz_host_shard(C.Structure):
@@ -74,8 +78,7 @@ class phz_rows_in(C.Structure):
                 ("allele_off", C.c_void_p), ("allele", C.c_void_p), ("maf_off", C.c_void_p), ("maf_txt", C.c_void_p),
                 ("maf", C.c_void_p), ("is_ref", C.c_void_p), ("phase_idx", C.c_void_p), ("blacklisted", C.c_void_p),
                 ("var_count", C.c_void_p), ("var_distinct", C.c_void_p),
-                ("n_lines", C.c_int64), ("line_var", C.c_void_p), ("line_qid", C.c_void_p), ("line_bam", C.c_void_p),
-                ("line_cls", C.c_void_p),
+                ("rl_start", C.c_void_p), ("rl_qid", C.c_void_p),
                 ("n_edges", C.c_int64), ("va", C.c_void_p), ("vb", C.c_void_p), ("ea", C.c_void_p), ("eb", C.c_void_p),
                 ("sup", C.c_void_p), ("tot", C.c_void_p), ("cis", C.c_void_p), ("trans", C.c_void_p), ("cfgv", C.c_void_p),
                 ("eorder", C.c_void_p), ("pv", C.c_void_p),
@@ -164,8 +167,10 @@ SYMBOLS = {
     "phz_map_reads_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_reads), C.POINTER(phz_variants), C.c_int,
                                       C.POINTER(phz_calls), C.POINTER(C.c_int64)]),
     "phz_as_histogram": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_void_p, C.c_int]),
-    "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
-                            C.POINTER(phz_tally_out), C.POINTER(C.c_int64), C.c_int]),
+    "phz_as_histogram_batch": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_void_p]),
+    "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                            C.POINTER(phz_tally_sizes), C.c_int]),
+    "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),
     "phz_components": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "phz_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "phz_bam_close": (C.c_int, [C.c_void_p]),
@@ -188,6 +193,7 @@ SYMBOLS = {
                                         C.POINTER(phz_calls), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64,
                                         C.POINTER(C.c_int64), C.c_int]),
     "phz_rows_format": (C.c_int, [C.POINTER(phz_rows_in), C.POINTER(phz_rows_out)]),
+    "phz_rows_format_multi": (C.c_int, [C.POINTER(phz_rows_in), C.c_int, C.POINTER(phz_rows_out), C.c_int]),
     "phz_rows_free": (None, [C.POINTER(phz_rows_out)]),
     "phz_phase_block": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(C.c_int32)]),

@@ -53,6 +53,8 @@ int phz_ctx_destroy(phz_ctx *c) {
                      &c->r_qual, &c->v_pos, &c->v_reflen, &c->c_read, &c->c_var, &c->c_code, &c->c_aux0, &c->c_aux1};
     for (DevBuf *b : all) free_buf(*b);
     for (DevBuf &b : c->scratch) free_buf(b);
+    for (DevBuf &b : c->stage_pool) free_buf(b);
+    for (DevBuf &b : c->tally_buf) free_buf(b);
     if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
     for (hipEvent_t e : c->map_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);

@@ -32,6 +32,20 @@ struct phz_ctx {
     DevBuf c_read, c_var, c_code, c_aux0, c_aux1;
     // generic per-call scratch slots (tally / components), grown on demand and reused across calls
     DevBuf scratch[24];
+    // device copies of PHZ_HOST callers' arrays (Staging): slot k of a call reuses stage_pool[k], grown on demand, so the
+    // steady state allocates nothing
+    std::vector<DevBuf> stage_pool;
+    std::vector<DevBuf> tally_buf;     // result + read-list buffers of phz_tally
+    // results of the last phz_tally, resident in HBM until the next one (phz_tally_fetch / phz_components read them)
+    struct {
+        int64_t nv = 0, n_lines = 0, n_kept = 0, n_edges = 0, n_rl = 0;
+        int nb = 0;
+        int32_t *var_count = nullptr, *var_distinct = nullptr, *ea = nullptr, *eb = nullptr, *cells = nullptr, *rl_qid = nullptr;
+        int64_t *var_first = nullptr;
+        uint64_t *var_rank = nullptr;
+        uint32_t *rl_start = nullptr;
+        uint8_t *linked = nullptr, *line_cls = nullptr;
+    } tally;
     int map_tile_reads = 0;
     int map_slot_cap = 0;      // calls per tile slot of K_map's staging area (grown on demand)
 };
@@ -52,21 +66,26 @@ int phz_launch_map(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int 
 int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out,
                          int64_t *n_calls);
 
-// Scoped staging of host arrays for PHZ_HOST callers: device copies live until the object dies.
+// Scoped staging of host arrays for PHZ_HOST callers: the k-th array of a call lives in ctx->stage_pool[k] (kept across
+// calls, grown on demand -- no allocation in the steady state).
 struct Staging {
     phz_ctx *ctx;
-    std::vector<void *> owned;
+    size_t next = 0;
     explicit Staging(phz_ctx *c) : ctx(c) {}
-    ~Staging() { for (void *p : owned) (void)hipFree(p); }
-    // returns a device pointer holding `bytes` bytes copied from host pointer src (or src itself in device space)
+    int slot(size_t bytes, void **d) {
+        if (next >= ctx->stage_pool.size()) ctx->stage_pool.resize(next + 1);
+        DevBuf &b = ctx->stage_pool[next++];
+        if (int s = phz_reserve(ctx, b, bytes ? bytes : 1)) return s;
+        *d = b.p;
+        return PHZ_OK;
+    }
+    // returns a device pointer holding `count` items copied from host pointer src (or src itself in device space)
     template <class T> int in(const T *src, size_t count, int space, const T **dst) {
         if (space == PHZ_DEVICE || src == nullptr) { *dst = src; return PHZ_OK; }
         void *d = nullptr;
-        size_t bytes = count * sizeof(T);
-        hipError_t e = hipMalloc(&d, bytes ? bytes : 1);
-        if (e != hipSuccess) return phz_fail(ctx, PHZ_E_NOMEM, "hipMalloc(staging)", e);
-        owned.push_back(d);
-        if (bytes) { e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream); if (e != hipSuccess) return phz_fail(ctx, PHZ_E_HIP, "H2D", e); }
+        const size_t bytes = count * sizeof(T);
+        if (int s = slot(bytes, &d)) return s;
+        if (bytes) { hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream); if (e != hipSuccess) return phz_fail(ctx, PHZ_E_HIP, "H2D", e); }
         *dst = (const T *)d;
         return PHZ_OK;
     }
@@ -74,10 +93,7 @@ struct Staging {
     template <class T> int out(T *host, size_t count, int space, T **dev) {
         if (space == PHZ_DEVICE) { *dev = host; return PHZ_OK; }
         void *d = nullptr;
-        size_t bytes = count * sizeof(T);
-        hipError_t e = hipMalloc(&d, bytes ? bytes : 1);
-        if (e != hipSuccess) return phz_fail(ctx, PHZ_E_NOMEM, "hipMalloc(staging)", e);
-        owned.push_back(d);
+        if (int s = slot(count * sizeof(T), &d)) return s;
         *dev = (T *)d;
         return PHZ_OK;
     }

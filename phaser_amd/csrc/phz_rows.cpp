@@ -243,10 +243,24 @@ struct Ranker {
 struct Ctx {
     const phz_rows_in *in;
     Pool uid, rsid, alle, maftxt, qname;
-    std::vector<int64_t> lstart;       // [2nv+1] read-list ranges per (variant, class 0/1)
-    std::vector<int32_t> lorder;       // kept ref/alt line indices grouped by (variant, class), line order inside
     std::vector<uint8_t> phased;       // [nv]
     std::string_view name_of(int g) const { return in->unique_ids ? uid.at(g) : rsid.at(g); }
+    // read list of (variant g, allele k, BAM b): QNAME ids of its kept lines in line order (phaser.py:1318-1322)
+    const int32_t *rl(int g, int k, int b, int64_t *n) const {
+        const size_t e = ((size_t)2 * g + k) * (size_t)in->nb + (size_t)b;
+        *n = (int64_t)in->rl_start[e + 1] - (int64_t)in->rl_start[e];
+        return in->rl_qid + in->rl_start[e];
+    }
+    // ... over all BAMs (the BAM lists are adjacent, in BAM order = line order across BAMs)
+    const int32_t *rl_all(int g, int k, int64_t *n) const {
+        const size_t e = ((size_t)2 * g + k) * (size_t)in->nb;
+        *n = (int64_t)in->rl_start[e + in->nb] - (int64_t)in->rl_start[e];
+        return in->rl_qid + in->rl_start[e];
+    }
+    int64_t lines_of(int g) const {
+        const size_t e = (size_t)2 * g * (size_t)in->nb;
+        return (int64_t)in->rl_start[e + 2 * (size_t)in->nb] - (int64_t)in->rl_start[e];
+    }
 };
 
 struct BlockChunk {
@@ -258,10 +272,6 @@ struct BlockChunk {
     int64_t phased = 0;
     int status = 0;
 };
-
-void join_sv(std::string &s, const std::vector<std::string_view> &items) {
-    for (size_t i = 0; i < items.size(); i++) { if (i) s += ','; s.append(items[i]); }
-}
 
 // one final (phased) block: rows of haplotypes.txt, haplotypic_counts.txt, allele_config.txt (:865-1172)
 void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &ha, double sup_edges, double tot_edges, Ranker &rk,
@@ -282,7 +292,8 @@ void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &h
         for (int i = 0; i < n; i++) {
             const int g = vars[i], k = (*hx[h])[i] - '0';
             phs[h][i] = I.phase_idx[2 * g + k];
-            for (int64_t t = C.lstart[2 * g + k]; t < C.lstart[2 * g + k + 1]; t++) pool.push_back(I.line_qid[C.lorder[t]]);
+            int64_t m; const int32_t *q = C.rl_all(g, k, &m);
+            pool.insert(pool.end(), q, q + m);
         }
         rk.run(pool, nullptr, nullptr, &counts[h]);
     }
@@ -360,12 +371,9 @@ void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &h
                 if (!(I.blacklisted && I.blacklisted[g])) {
                     const int k = (*hx[h])[i] - '0';
                     if (h == 0) used_vars.push_back(g);
-                    const size_t before = allq.size();
-                    for (int64_t t = C.lstart[2 * g + k]; t < C.lstart[2 * g + k + 1]; t++) {
-                        const int32_t ln = C.lorder[t];
-                        if (I.line_bam[ln] == b) allq.push_back(I.line_qid[ln]);
-                    }
-                    vlen.push_back(allq.size() - before);
+                    int64_t m; const int32_t *q = C.rl(g, k, b, &m);
+                    allq.insert(allq.end(), q, q + m);
+                    vlen.push_back((size_t)m);
                 } else if (h == 0) black.push_back(g);
             }
             rk.run(allq, &label, &ids[h], &ns[h]);
@@ -545,11 +553,8 @@ void run_singles(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
             for (int b = 0; b < I.nb; b++) {
                 if (I.bam_excluded && I.bam_excluded[b]) continue;
                 for (int k = 0; k < 2; k++) {
-                    q[k].clear();
-                    for (int64_t u = C.lstart[2 * g + k]; u < C.lstart[2 * g + k + 1]; u++) {
-                        const int32_t ln = C.lorder[u];
-                        if (I.line_bam[ln] == b) q[k].push_back(I.line_qid[ln]);
-                    }
+                    int64_t m; const int32_t *src = C.rl(g, k, b, &m);
+                    q[k].assign(src, src + m);
                     std::sort(q[k].begin(), q[k].end());
                     q[k].erase(std::unique(q[k].begin(), q[k].end()), q[k].end());
                 }
@@ -594,12 +599,6 @@ void parallel_chunks(int threads, int64_t nchunks, F fn) {
     for (auto &t : th) t.join();
 }
 
-char *take(const std::string &s) {
-    char *p = (char *)malloc(s.size() + 1);
-    if (p) memcpy(p, s.data(), s.size() + 1);
-    return p;
-}
-
 template <class T>
 T *take_vec(const std::vector<T> &v) {
     T *p = (T *)malloc(std::max<size_t>(1, v.size() * sizeof(T)));
@@ -618,118 +617,144 @@ std::vector<int64_t> key_chunks(const phz_rows_in &I, int64_t step) {
     return b;
 }
 
+// everything one chromosome needs between the phases of phz_rows_format_multi
+struct ChromState {
+    Ctx C;
+    std::vector<int64_t> cb, kb;              // block-chunk / key-chunk boundaries
+    std::vector<int64_t> w;                   // weight of every component (block chunks are balanced by it)
+    std::vector<BlockChunk> bc;
+    std::vector<TextChunk> cc, ac, sc;
+};
+
 }  // namespace
+
+// Several chromosomes in ONE thread pool (a genome's chromosomes differ 5x in size: per-chromosome calls would leave threads idle
+// at every chromosome's tail).  in[i] / out[i] describe chromosome i; `threads` workers in total.
+extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_rows_out *out, int threads) {
+    if ((!in || !out) && n_chroms) return PHZ_E_ARG;
+    if (n_chroms <= 0) return PHZ_OK;
+    threads = std::max(1, threads);
+    for (int c = 0; c < n_chroms; c++) memset(&out[c], 0, sizeof(out[c]));
+    std::vector<ChromState> st((size_t)n_chroms);
+    // ---- phase A: per-chromosome setup + component weights
+    std::vector<int64_t> totals((size_t)n_chroms, 0);
+    parallel_chunks(threads, n_chroms, [&](int64_t c) {
+        const phz_rows_in &I = in[c];
+        ChromState &S = st[(size_t)c];
+        S.C.in = &in[c];
+        S.C.uid = {I.uid_off, I.uid}; S.C.rsid = {I.rsid_off, I.rsid}; S.C.alle = {I.allele_off, I.allele}; S.C.maftxt = {I.maf_off, I.maf_txt};
+        S.C.qname = {I.qname_off, I.qname};
+        S.C.phased.assign((size_t)I.nv + 1, 0);
+        S.w.resize((size_t)I.ncomp);
+        int64_t total = 0;
+        for (int64_t r = 0; r < I.ncomp; r++) {
+            const int64_t ci = I.comp_order[r];
+            const int64_t sz = I.comp_ends[ci] - I.comp_starts[ci];
+            int64_t x = 4;
+            for (int64_t t = I.comp_starts[ci]; t < I.comp_ends[ci]; t++) x += 2 + S.C.lines_of((int)I.mem_s[t]) + sz;
+            S.w[(size_t)r] = x; total += x;
+        }
+        totals[(size_t)c] = total;
+    });
+    int64_t grand = 0;
+    for (int64_t t : totals) grand += t;
+    const int64_t target = std::max<int64_t>(4096, grand / ((int64_t)threads * 8) + 1);
+    struct Task { int c; int kind; int64_t i; };      // kind 0: block chunk i, 1: connection chunk i
+    std::vector<Task> tasks;
+    const int64_t estep = 16384;
+    for (int c = 0; c < n_chroms; c++) {
+        const phz_rows_in &I = in[c];
+        ChromState &S = st[(size_t)c];
+        S.cb.assign(1, 0);
+        int64_t acc = 0;
+        for (int64_t r = 0; r < I.ncomp; r++) {
+            acc += S.w[(size_t)r];
+            if (acc >= target) { S.cb.push_back(r + 1); acc = 0; }
+        }
+        if (S.cb.back() != I.ncomp) S.cb.push_back(I.ncomp);
+        S.bc.resize(S.cb.size() - 1);
+        S.cc.resize((size_t)((I.n_edges + estep - 1) / estep));
+        for (size_t i = 0; i < S.bc.size(); i++) tasks.push_back({c, 0, (int64_t)i});
+        for (size_t i = 0; i < S.cc.size(); i++) tasks.push_back({c, 1, (int64_t)i});
+    }
+    // ---- phase B1: blocks (phasing + rows) and connection rows
+    parallel_chunks(threads, (int64_t)tasks.size(), [&](int64_t t) {
+        const Task &k = tasks[(size_t)t];
+        ChromState &S = st[(size_t)k.c];
+        if (k.kind == 0) run_block_chunk(S.C, S.cb[(size_t)k.i], S.cb[(size_t)k.i + 1], S.bc[(size_t)k.i]);
+        else run_conn(S.C, k.i * estep, std::min<int64_t>(in[k.c].n_edges, (k.i + 1) * estep), S.cc[(size_t)k.i]);
+    });
+    for (auto &S : st) for (auto &c : S.bc) if (c.status) return c.status;
+    // ---- phase B2: allelic counts + singleton rows (need to know which variants ended up in a block)
+    tasks.clear();
+    for (int c = 0; c < n_chroms; c++) {
+        ChromState &S = st[(size_t)c];
+        S.kb = key_chunks(in[c], 8192);
+        S.ac.resize(S.kb.size() - 1); S.sc.resize(S.kb.size() - 1);
+        for (size_t i = 0; i + 1 < S.kb.size(); i++) tasks.push_back({c, 2, (int64_t)i});
+    }
+    parallel_chunks(threads, (int64_t)tasks.size(), [&](int64_t t) {
+        const Task &k = tasks[(size_t)t];
+        ChromState &S = st[(size_t)k.c];
+        run_allelic(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.ac[(size_t)k.i]);
+        if (in[k.c].unphased_vars == 1) run_singles(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.sc[(size_t)k.i]);
+    });
+    // ---- phase C: one allocation per (chromosome, file); every chunk copied into place by the pool
+    struct Copy { char *dst; const std::string *src; };
+    std::vector<Copy> copies;
+    bool nomem = false;
+    auto lay = [&](const std::vector<const std::string *> &parts, char **p, int64_t *len) {
+        size_t total = 0;
+        for (auto *x : parts) total += x->size();
+        *p = (char *)malloc(total + 1);
+        if (!*p) { nomem = true; return; }
+        (*p)[total] = 0; *len = (int64_t)total;
+        size_t off = 0;
+        for (auto *x : parts) { if (x->size()) copies.push_back({*p + off, x}); off += x->size(); }
+    };
+    for (int c = 0; c < n_chroms; c++) {
+        const phz_rows_in &I = in[c];
+        ChromState &S = st[(size_t)c];
+        phz_rows_out &O = out[c];
+        std::vector<const std::string *> p_hap, p_ase, p_cfg, p_conn, p_all, p_sa, p_sh;
+        std::vector<int32_t> bvar, bsize, bmaxmaf; std::vector<uint8_t> bhap, bstat_int; std::vector<int8_t> bcor; std::vector<double> bstat;
+        int64_t phased = 0;
+        for (auto &x : S.bc) {
+            p_hap.push_back(&x.hap); p_ase.push_back(&x.ase); p_cfg.push_back(&x.cfg); phased += x.phased;
+            if (I.want_vcf) {
+                bvar.insert(bvar.end(), x.bvar.begin(), x.bvar.end()); bhap.insert(bhap.end(), x.bhap.begin(), x.bhap.end());
+                bcor.insert(bcor.end(), x.bcor.begin(), x.bcor.end()); bmaxmaf.insert(bmaxmaf.end(), x.bmaxmaf.begin(), x.bmaxmaf.end());
+                bstat.insert(bstat.end(), x.bstat.begin(), x.bstat.end()); bstat_int.insert(bstat_int.end(), x.bstat_int.begin(), x.bstat_int.end());
+            }
+            bsize.insert(bsize.end(), x.bsize.begin(), x.bsize.end());
+        }
+        for (auto &x : S.cc) p_conn.push_back(&x.a);
+        std::vector<int64_t> aseg((size_t)I.nb + 1, 0), sseg_a((size_t)I.nb + 1, 0), sseg_h((size_t)I.nb + 1, 0);
+        int64_t arows = 0, la = 0, lsa = 0, lsh = 0;
+        for (size_t i = 0; i + 1 < S.kb.size(); i++) {
+            const int64_t b = S.kb[i] < I.n_keys ? I.key_bam[S.kb[i]] : 0;
+            p_all.push_back(&S.ac[i].a); p_sa.push_back(&S.sc[i].a); p_sh.push_back(&S.sc[i].b); arows += S.ac[i].rows;
+            la += (int64_t)S.ac[i].a.size(); lsa += (int64_t)S.sc[i].a.size(); lsh += (int64_t)S.sc[i].b.size();
+            for (int64_t k = b + 1; k <= I.nb; k++) { aseg[(size_t)k] = la; sseg_a[(size_t)k] = lsa; sseg_h[(size_t)k] = lsh; }
+        }
+        lay(p_conn, &O.conn, &O.conn_len); lay(p_hap, &O.hap, &O.hap_len); lay(p_ase, &O.ase, &O.ase_len); lay(p_cfg, &O.cfg, &O.cfg_len);
+        lay(p_all, &O.allelic, &O.allelic_len); lay(p_sa, &O.single_ase, &O.single_ase_len); lay(p_sh, &O.single_hap, &O.single_hap_len);
+        O.allelic_rows = arows;
+        O.allelic_seg = take_vec(aseg); O.single_ase_seg = take_vec(sseg_a); O.single_hap_seg = take_vec(sseg_h);
+        O.n_blocks = (int64_t)bsize.size(); O.phased = phased;
+        O.blk_size = take_vec(bsize);
+        O.n_blk_vars = (int64_t)bvar.size();
+        O.blk_var = take_vec(bvar); O.blk_hap = take_vec(bhap); O.blk_cor = take_vec(bcor); O.blk_stat = take_vec(bstat);
+        O.blk_stat_int = take_vec(bstat_int); O.blk_maxmaf = take_vec(bmaxmaf);
+    }
+    if (nomem) { for (int c = 0; c < n_chroms; c++) phz_rows_free(&out[c]); return PHZ_E_NOMEM; }
+    parallel_chunks(threads, (int64_t)copies.size(), [&](int64_t i) { memcpy(copies[(size_t)i].dst, copies[(size_t)i].src->data(), copies[(size_t)i].src->size()); });
+    return PHZ_OK;
+}
 
 extern "C" int phz_rows_format(const phz_rows_in *in, phz_rows_out *out) {
     if (!in || !out) return PHZ_E_ARG;
-    memset(out, 0, sizeof(*out));
-    const phz_rows_in &I = *in;
-    Ctx C;
-    C.in = in;
-    C.uid = {I.uid_off, I.uid}; C.rsid = {I.rsid_off, I.rsid}; C.alle = {I.allele_off, I.allele}; C.maftxt = {I.maf_off, I.maf_txt};
-    C.qname = {I.qname_off, I.qname};
-    const int nv = I.nv;
-    C.phased.assign((size_t)nv + 1, 0);
-    // read lists per (variant, class): counting sort of the kept ref/alt lines, line order preserved
-    C.lstart.assign((size_t)2 * nv + 2, 0);
-    for (int64_t l = 0; l < I.n_lines; l++)
-        if (I.line_cls[l] < 2) C.lstart[(size_t)2 * I.line_var[l] + I.line_cls[l] + 1]++;
-    for (int64_t k = 0; k < 2 * (int64_t)nv; k++) C.lstart[k + 1] += C.lstart[k];
-    C.lorder.resize((size_t)C.lstart[(size_t)2 * nv]);
-    {
-        std::vector<int64_t> cur(C.lstart.begin(), C.lstart.end() - 1);
-        for (int64_t l = 0; l < I.n_lines; l++)
-            if (I.line_cls[l] < 2) C.lorder[(size_t)cur[(size_t)2 * I.line_var[l] + I.line_cls[l]]++] = (int32_t)l;
-    }
-    const int threads = std::max(1, I.threads);
-
-    // ---- blocks: chunks of components balanced by size (members + read labels)
-    std::vector<int64_t> cb(1, 0);
-    {
-        int64_t total = 0;
-        std::vector<int64_t> w((size_t)I.ncomp);
-        for (int64_t r = 0; r < I.ncomp; r++) {
-            const int64_t ci = I.comp_order[r];
-            int64_t x = 4;
-            for (int64_t t = I.comp_starts[ci]; t < I.comp_ends[ci]; t++) {
-                const int g = (int)I.mem_s[t];
-                x += 2 + (C.lstart[2 * g + 2] - C.lstart[2 * g]) + (I.comp_ends[ci] - I.comp_starts[ci]);
-            }
-            w[r] = x; total += x;
-        }
-        const int64_t target = std::max<int64_t>(4096, total / (threads * 8) + 1);
-        int64_t acc = 0;
-        for (int64_t r = 0; r < I.ncomp; r++) {
-            acc += w[r];
-            if (acc >= target) { cb.push_back(r + 1); acc = 0; }
-        }
-        if (cb.back() != I.ncomp) cb.push_back(I.ncomp);
-    }
-    std::vector<BlockChunk> bc(cb.size() - 1);
-    parallel_chunks(threads, (int64_t)bc.size(), [&](int64_t i) { run_block_chunk(C, cb[i], cb[i + 1], bc[i]); });
-    for (auto &c : bc) if (c.status) return c.status;
-
-    // ---- connections, allelic counts, singletons
-    const int64_t estep = 16384;
-    std::vector<TextChunk> cc((size_t)((I.n_edges + estep - 1) / estep));
-    parallel_chunks(threads, (int64_t)cc.size(), [&](int64_t i) { run_conn(C, i * estep, std::min(I.n_edges, (i + 1) * estep), cc[i]); });
-    const std::vector<int64_t> kb = key_chunks(I, 8192);
-    std::vector<TextChunk> ac(kb.size() - 1), sc(kb.size() - 1);
-    parallel_chunks(threads, (int64_t)ac.size(), [&](int64_t i) {
-        run_allelic(C, kb[i], kb[i + 1], ac[i]);
-        if (I.unphased_vars == 1) run_singles(C, kb[i], kb[i + 1], sc[i]);
-    });
-
-    // ---- assemble: one allocation per file, chunks copied into place in parallel
-    auto gather = [&](const std::vector<const std::string *> &parts, int64_t *len) -> char * {
-        std::vector<size_t> off(parts.size() + 1, 0);
-        for (size_t i = 0; i < parts.size(); i++) off[i + 1] = off[i] + parts[i]->size();
-        char *p = (char *)malloc(off.back() + 1);
-        if (!p) return nullptr;
-        parallel_chunks(threads, (int64_t)parts.size(), [&](int64_t i) { if (parts[i]->size()) memcpy(p + off[i], parts[i]->data(), parts[i]->size()); });
-        p[off.back()] = 0;
-        *len = (int64_t)off.back();
-        return p;
-    };
-    std::vector<const std::string *> p_hap, p_ase, p_cfg, p_conn, p_all, p_sa, p_sh;
-    std::vector<int32_t> bvar, bsize, bmaxmaf; std::vector<uint8_t> bhap, bstat_int; std::vector<int8_t> bcor; std::vector<double> bstat;
-    int64_t phased = 0;
-    for (auto &x : bc) {
-        p_hap.push_back(&x.hap); p_ase.push_back(&x.ase); p_cfg.push_back(&x.cfg); phased += x.phased;
-        if (I.want_vcf) {
-            bvar.insert(bvar.end(), x.bvar.begin(), x.bvar.end()); bhap.insert(bhap.end(), x.bhap.begin(), x.bhap.end());
-            bcor.insert(bcor.end(), x.bcor.begin(), x.bcor.end()); bmaxmaf.insert(bmaxmaf.end(), x.bmaxmaf.begin(), x.bmaxmaf.end());
-            bstat.insert(bstat.end(), x.bstat.begin(), x.bstat.end()); bstat_int.insert(bstat_int.end(), x.bstat_int.begin(), x.bstat_int.end());
-        }
-        bsize.insert(bsize.end(), x.bsize.begin(), x.bsize.end());
-    }
-    for (auto &x : cc) p_conn.push_back(&x.a);
-    std::vector<int64_t> aseg((size_t)I.nb + 1, 0), sseg_a((size_t)I.nb + 1, 0), sseg_h((size_t)I.nb + 1, 0);
-    int64_t arows = 0, la = 0, lsa = 0, lsh = 0;
-    for (size_t i = 0; i + 1 < kb.size(); i++) {
-        const int64_t b = kb[i] < I.n_keys ? I.key_bam[kb[i]] : 0;
-        p_all.push_back(&ac[i].a); p_sa.push_back(&sc[i].a); p_sh.push_back(&sc[i].b); arows += ac[i].rows;
-        la += (int64_t)ac[i].a.size(); lsa += (int64_t)sc[i].a.size(); lsh += (int64_t)sc[i].b.size();
-        for (int64_t k = b + 1; k <= I.nb; k++) { aseg[k] = la; sseg_a[k] = lsa; sseg_h[k] = lsh; }
-    }
-    out->conn = gather(p_conn, &out->conn_len);
-    out->hap = gather(p_hap, &out->hap_len);
-    out->ase = gather(p_ase, &out->ase_len);
-    out->cfg = gather(p_cfg, &out->cfg_len);
-    out->allelic = gather(p_all, &out->allelic_len); out->allelic_rows = arows;
-    out->single_ase = gather(p_sa, &out->single_ase_len);
-    out->single_hap = gather(p_sh, &out->single_hap_len);
-    out->allelic_seg = take_vec(aseg); out->single_ase_seg = take_vec(sseg_a); out->single_hap_seg = take_vec(sseg_h);
-    out->n_blocks = (int64_t)bsize.size(); out->phased = phased;
-    out->blk_size = take_vec(bsize);
-    out->n_blk_vars = (int64_t)bvar.size();
-    out->blk_var = take_vec(bvar); out->blk_hap = take_vec(bhap); out->blk_cor = take_vec(bcor); out->blk_stat = take_vec(bstat);
-    out->blk_stat_int = take_vec(bstat_int); out->blk_maxmaf = take_vec(bmaxmaf);
-    if (!out->conn || !out->hap || !out->ase || !out->cfg || !out->allelic || !out->single_ase || !out->single_hap) {
-        phz_rows_free(out);
-        return PHZ_E_NOMEM;
-    }
-    return PHZ_OK;
+    return phz_rows_format_multi(in, 1, out, in->threads);
 }
 
 // phase_v3 on one connected component (variants position-sorted, local indices): the same routine phz_rows_format runs

@@ -1,16 +1,20 @@
-// K_tally family: what phaser/phaser.py does between the mapper's call files and the binomial test,
-// for one chromosome over all of its BAM shards:
+// K_tally family: what phaser/phaser.py does between the mapper's call files and the binomial test, for ANY number of
+// (chromosome, BAM) shards in one submission (variant and QNAME ids are offset per chromosome into one index space, so a whole
+// genome is one call and nothing ever pairs across chromosomes):
 //   k_as_hist      :545-553   AS column histogram (host turns it into numpy.percentile's value)
 //   k_line         :1287-1328 process_mapping_result: AS cutoff, allele class, per-variant line counters,
-//                             first-appearance index; plus the "last BAM wins" owner of every QNAME's
-//                             read_vars list (:576-581, stale-variable quirk)
-//   k_keys/sort/k_unique      set construction :636-640 as sorted distinct (QNAME, variant, class) items
+//                             first-appearance index; the "last BAM wins" owner of every QNAME's read_vars list
+//                             (:576-581, stale-variable quirk); lines per QNAME and per (variant, allele, BAM) read list
+//   k_items + k_qsort         set construction :636-640: lines are grouped per QNAME by a counting sort over the dense QNAME
+//                             ids (count in k_line, exclusive scan, scatter), each tiny group sorted and de-duplicated in place
 //   k_pairs        :1265-1285 + :1602-1632: every QNAME contributes one count to cell (class_a, class_b) of
 //                             every variant pair it touches -- the nine set intersections of
-//                             test_variant_connection, accumulated for all pairs at once
+//                             test_variant_connection, accumulated for all pairs at once (LDS hash -> global hash)
+//   k_edge_*                  edge list in (a, b) order: counting sort by a over the used hash slots, tiny groups sorted by b
+//   read lists     :1318, :917-931, :1086-1115: the QNAMEs of every (variant, allele, BAM) in line order, as one CSR
+//                             (stable radix sort of the line keys on their significant bits)
 //   k_components   :1861-1882/:1985-1998 connected components (lock-free union-find)
-// Integer work: sorting via rocPRIM's radix sort (AMD's device primitive library), everything else
-// hand-written; pair cells are aggregated in an LDS hash table per workgroup and flushed with global atomics.
+// Integer work, hand-written kernels; the only library call left is rocPRIM's stable radix sort for the read lists.
 #include <cstring>
 #include "phz_internal.h"
 #include <rocprim/rocprim.hpp>
@@ -28,6 +32,9 @@ struct LinesDev {
     const uint8_t *read_has_as;
     double cutoff;
     int use_cutoff, bam;
+    int32_t var_base;          // first variant of the shard's chromosome in the call's variant space
+    uint32_t qid_base;         // first QNAME id of the shard's chromosome in the call's id space
+    int64_t line_base;         // index of the shard's first line in the call's line space (shards ordered chromosome, BAM)
 };
 
 __global__ __launch_bounds__(256) void k_as_hist(LinesDev L, unsigned long long *hist) {
@@ -47,6 +54,97 @@ __global__ __launch_bounds__(256) void k_as_hist(LinesDev L, unsigned long long 
         if (s_h[j]) atomicAdd(&hist[j - AS_LDS_BINS / 2 + 32768], (unsigned long long)s_h[j]);
 }
 
+// ------------------------------------------------------------------------------------------------ exclusive scan (uint32)
+// out[i] = sum(in[0..i)), out[n] = total.  Three passes: chunk sums, one-block scan of the sums, chunk-local scan + base.
+constexpr int SCAN_ITEMS = 16, SCAN_CHUNK = SCAN_ITEMS * 256;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *in, int64_t n, uint32_t *partial) {
+    __shared__ uint32_t s[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    uint32_t x = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { const int64_t i = base + k * 256 + threadIdx.x; if (i < n) x += in[i]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_partials(uint32_t *partial, int64_t nb, uint32_t *total) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+        const int64_t i = b0 + tid;
+        const uint32_t v = i < nb ? partial[i] : 0;
+        const uint32_t x = wave_incl_scan(v, lane);
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w2 = 0; w2 < wave; w2++) before += s_w[w2];
+        if (i < nb) partial[i] = before + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint32_t *out, int64_t n, const uint32_t *partial) {
+    __shared__ uint32_t s_v[SCAN_CHUNK + SCAN_CHUNK / 16];      // padded: item i at i + i/16 (thread t's 16 items: no bank conflicts)
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int j = k * 256 + tid;
+        const int64_t i = base + j;
+        s_v[j + (j >> 4)] = i < n ? in[i] : 0;
+    }
+    __syncthreads();
+    uint32_t loc[SCAN_ITEMS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { loc[k] = s_v[tid * 17 + k]; sum += loc[k]; }
+    const uint32_t incl = wave_incl_scan(sum, lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t run = partial[blockIdx.x] + incl - sum;
+    for (int w2 = 0; w2 < wave; w2++) run += s_w[w2];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { s_v[tid * 17 + k] = run; run += loc[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int j = k * 256 + tid;
+        const int64_t i = base + j;
+        if (i < n) out[i] = s_v[j + (j >> 4)];
+    }
+}
+
+int scan_excl(phz_ctx *ctx, const uint32_t *in, uint32_t *out /* [n + 1] */, int64_t n, DevBuf &tmp) {
+    hipStream_t sm = ctx->stream;
+    if (n <= 0) { PHZ_HIP(ctx, hipMemsetAsync(out, 0, 4, sm)); return PHZ_OK; }
+    const int64_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (int s = phz_reserve(ctx, tmp, (size_t)nb * 4 + 16)) return s;
+    uint32_t *partial = (uint32_t *)tmp.p;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, sm, in, n, partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, sm, partial, nb, out + n);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, sm, in, out, n, (const uint32_t *)partial);
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-line pass
 // Call lines arrive in mapper order (record, then variant) and records are coordinate-sorted, so the lines of one
 // workgroup touch a narrow run of variant indices, and deeply covered variants repeat hundreds of times in a row.
 // Counters are therefore accumulated in an LDS window [vbase, vbase + TW) with LDS atomics and flushed once per
@@ -54,79 +152,131 @@ __global__ __launch_bounds__(256) void k_as_hist(LinesDev L, unsigned long long 
 constexpr int TW = 1024;            // variants per LDS window
 constexpr int LINES_PER_BLOCK = 2048;
 
-__global__ __launch_bounds__(256) void k_line(LinesDev L, int64_t line_base, const uint8_t *a0, const uint8_t *a1,
-                                              uint8_t *line_cls, int32_t *var_count, unsigned long long *var_first,
-                                              int32_t *qid_owner, uint32_t *qid_first, int single_bam) {
+struct LineOut {
+    const uint8_t *a0, *a1;
+    uint8_t *line_cls;
+    int32_t *var_count;              // [nv*3]
+    unsigned long long *var_first;   // [nv]
+    uint32_t *rl_cnt;                // [nv*2*nb] kept ref/alt lines per (variant, allele, BAM)
+    int32_t *qid_owner;              // [nq] last BAM holding a ref/alt line of the QNAME
+    uint32_t *qid_first;             // [nq] first ref/alt line of the QNAME
+    uint32_t *qcount;                // [nq] kept lines of the QNAME
+    unsigned long long *n_kept;
+    int nb, single_bam;
+};
+
+__global__ __launch_bounds__(256) void k_line(LinesDev L, LineOut O) {
     __shared__ int s_cnt[TW * 3];
     __shared__ unsigned long long s_first[TW];
     __shared__ int s_vbase;
+    __shared__ unsigned int s_kept;
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
     for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
     for (int j = tid; j < TW; j += 256) s_first[j] = ~0ull;
-    if (tid == 0) s_vbase = L.var_idx[i0];       // lines are (record, variant)-ordered: the first line holds ~the smallest index
+    if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
     __syncthreads();
     const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;       // a little room below (mate pairs / overlapping records)
+    unsigned int kept = 0;
     for (int64_t i = i0 + tid; i < i0 + LINES_PER_BLOCK && i < L.n; i += 256) {
-        const int r = L.read_idx[i], v = L.var_idx[i];
+        const int r = L.read_idx[i], v = L.var_idx[i] + L.var_base;
+        const int64_t g = L.line_base + i;
         bool keep = true;
         if (L.use_cutoff) {
             if (L.read_has_as && !L.read_has_as[r]) keep = false;
             else keep = (double)L.read_as[r] >= L.cutoff;
         }
-        if (!keep) { line_cls[line_base + i] = 255; continue; }
+        if (!keep) { O.line_cls[g] = 255; continue; }
+        kept++;
         const uint8_t c = L.code[i];
         // codes 5 / 6 come from the general (indel) mapper, which compared the text with the allele strings itself
-        const int cls = c == 5 ? 0 : (c == 6 ? 1 : ((c < 4 && c == a0[v]) ? 0 : ((c < 4 && c == a1[v]) ? 1 : 2)));
-        line_cls[line_base + i] = (uint8_t)cls;
+        const int cls = c == 5 ? 0 : (c == 6 ? 1 : ((c < 4 && c == O.a0[v]) ? 0 : ((c < 4 && c == O.a1[v]) ? 1 : 2)));
+        O.line_cls[g] = (uint8_t)cls;
         const unsigned d = (unsigned)(v - vbase);
         if (d < (unsigned)TW) {
             atomicAdd(&s_cnt[d * 3 + cls], 1);
-            atomicMin(&s_first[d], (unsigned long long)(line_base + i));
+            atomicMin(&s_first[d], (unsigned long long)g);
         } else {
-            atomicAdd(&var_count[(int64_t)v * 3 + cls], 1);
-            atomicMin(&var_first[v], (unsigned long long)(line_base + i));
+            atomicAdd(&O.var_count[(int64_t)v * 3 + cls], 1);
+            atomicMin(&O.var_first[v], (unsigned long long)g);
+            if (cls < 2) atomicAdd(&O.rl_cnt[((int64_t)v * 2 + cls) * O.nb + L.bam], 1u);
         }
+        const uint32_t q = L.qid_base + (uint32_t)L.read_qid[r];
+        atomicAdd(&O.qcount[q], 1u);
         if (cls < 2) {
-            const int q = L.read_qid[r];
-            if (!single_bam) atomicMax(&qid_owner[q], L.bam);
-            atomicMin(&qid_first[q], (uint32_t)(line_base + i));      // first ref/alt line of the QNAME over all BAMs
+            if (!O.single_bam) atomicMax(&O.qid_owner[q], L.bam);
+            atomicMin(&O.qid_first[q], (uint32_t)g);      // first ref/alt line of the QNAME over all BAMs
         }
     }
+    if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
     for (int j = tid; j < TW * 3; j += 256) {
         const int c = s_cnt[j];
-        if (c) atomicAdd(&var_count[(int64_t)(vbase + j / 3) * 3 + (j % 3)], c);
+        if (c) {
+            const int64_t v = vbase + j / 3; const int cls = j % 3;
+            atomicAdd(&O.var_count[v * 3 + cls], c);
+            if (cls < 2) atomicAdd(&O.rl_cnt[(v * 2 + cls) * O.nb + L.bam], (uint32_t)c);
+        }
     }
     for (int j = tid; j < TW; j += 256) {
         const unsigned long long f = s_first[j];
-        if (f != ~0ull) atomicMin(&var_first[vbase + j], f);
+        if (f != ~0ull) atomicMin(&O.var_first[vbase + j], f);
     }
+    if (tid == 0 && s_kept) atomicAdd(O.n_kept, (unsigned long long)s_kept);
 }
 
-// key = qid:32 | var:28 | cls:2 | spare:1 | linked:1
-__global__ __launch_bounds__(256) void k_keys(LinesDev L, int64_t line_base, const uint8_t *line_cls,
-                                              const int32_t *qid_owner, uint64_t *keys, uint32_t *qid_vmin, int32_t *qid_vmax,
-                                              int single_bam) {
+// item = qid:32 | var:28 | cls:2 | spare:1 | linked:1, scattered into the QNAME's slot range [qoff[q], qoff[q+1]);
+// read-list sort key = ((variant * 2 + allele) * nb + bam) for kept ref/alt lines, rl_drop for every other line
+__global__ __launch_bounds__(256) void k_items(LinesDev L, const uint8_t *line_cls, const int32_t *qid_owner, const uint32_t *qoff,
+                                               uint32_t *qcount, uint64_t *items, uint32_t *qid_vmin, int32_t *qid_vmax,
+                                               uint32_t *rl_key, int32_t *rl_val, int nb, int single_bam, uint32_t rl_drop) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= L.n) return;
-    const uint8_t cls = line_cls[line_base + i];
-    uint64_t k = KEY_DROPPED;
-    if (cls != 255) {
-        const int r = L.read_idx[i];
-        const uint32_t q = (uint32_t)L.read_qid[r];
-        const uint32_t linked = (cls < 2 && (single_bam || qid_owner[q] == L.bam)) ? 1u : 0u;
-        const uint32_t v = (uint32_t)L.var_idx[i];
-        k = ((uint64_t)q << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;
-        if (linked) { atomicMin(&qid_vmin[q], v); atomicMax(&qid_vmax[q], (int32_t)v); }     // span of the surviving read_vars list
+    const int64_t g = L.line_base + i;
+    const uint8_t cls = line_cls[g];
+    if (cls == 255) { rl_key[g] = rl_drop; rl_val[g] = 0; return; }
+    const int r = L.read_idx[i];
+    const int32_t ql = L.read_qid[r];
+    const uint32_t q = L.qid_base + (uint32_t)ql;
+    const uint32_t linked = (cls < 2 && (single_bam || qid_owner[q] == L.bam)) ? 1u : 0u;
+    const uint32_t v = (uint32_t)(L.var_idx[i] + L.var_base);
+    const uint64_t k = ((uint64_t)q << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;
+    if (linked) { atomicMin(&qid_vmin[q], v); atomicMax(&qid_vmax[q], (int32_t)v); }     // span of the surviving read_vars list
+    const uint32_t old = atomicSub(&qcount[q], 1u);            // counts back down to zero: the array is clean for the next call
+    items[qoff[q] + old - 1] = k;
+    rl_key[g] = cls < 2 ? (uint32_t)((v * 2u + cls) * (uint32_t)nb + (uint32_t)L.bam) : rl_drop;
+    rl_val[g] = ql;
+}
+
+// one thread per QNAME: sort its (tiny) item group, keep the LAST of every (variant, class) run (it carries linked = max over
+// the run, because linked is the lowest key bit); the others become KEY_DROPPED and are skipped downstream
+__global__ __launch_bounds__(256) void k_qsort(const uint32_t *qoff, int64_t nq, uint64_t *items) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t lo = qoff[q], hi = qoff[q + 1];
+    if (hi - lo < 2) return;
+    for (uint32_t i = lo + 1; i < hi; i++) {
+        const uint64_t x = items[i];
+        uint32_t j = i;
+        while (j > lo) {
+            const uint64_t y = items[j - 1];
+            if (y <= x) break;
+            items[j] = y; j--;
+        }
+        items[j] = x;
     }
-    keys[line_base + i] = k;
+    uint64_t cur = items[lo];
+    for (uint32_t i = lo; i + 1 < hi; i++) {
+        const uint64_t nx = items[i + 1];
+        if ((nx >> 2) == (cur >> 2)) items[i] = KEY_DROPPED;
+        cur = nx;
+    }
 }
 
 // Overlap-dictionary key order (SURVEY.md 8.1 rule 4, phaser.py:1271-1283): a variant's rank is the smallest
 // (first ref/alt line of the QNAME, line) over the surviving read_vars entries of QNAMEs that hold >= 2 distinct
 // variants; variants that never get a key keep the maximum value.  LDS window like k_line.
-__global__ __launch_bounds__(256) void k_rank(LinesDev L, int64_t line_base, const uint8_t *line_cls, const int32_t *qid_owner,
+__global__ __launch_bounds__(256) void k_rank(LinesDev L, const uint8_t *line_cls, const int32_t *qid_owner,
                                               const uint32_t *qid_first, const uint32_t *qid_vmin, const int32_t *qid_vmax,
                                               unsigned long long *var_rank, int single_bam) {
     __shared__ unsigned long long s_rank[TW];
@@ -134,17 +284,18 @@ __global__ __launch_bounds__(256) void k_rank(LinesDev L, int64_t line_base, con
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
     for (int j = tid; j < TW; j += 256) s_rank[j] = ~0ull;
-    if (tid == 0) s_vbase = L.var_idx[i0];
+    if (tid == 0) s_vbase = L.var_idx[i0] + L.var_base;
     __syncthreads();
     const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;
     for (int64_t i = i0 + tid; i < i0 + LINES_PER_BLOCK && i < L.n; i += 256) {
-        const uint8_t cls = line_cls[line_base + i];
+        const int64_t g = L.line_base + i;
+        const uint8_t cls = line_cls[g];
         if (cls >= 2) continue;
-        const uint32_t q = (uint32_t)L.read_qid[L.read_idx[i]];
+        const uint32_t q = L.qid_base + (uint32_t)L.read_qid[L.read_idx[i]];
         if (!(single_bam || qid_owner[q] == L.bam)) continue;
         if (qid_vmin[q] == (uint32_t)qid_vmax[q]) continue;
-        const int v = L.var_idx[i];
-        const unsigned long long key = ((unsigned long long)qid_first[q] << 32) | (unsigned long long)(line_base + i);
+        const int v = L.var_idx[i] + L.var_base;
+        const unsigned long long key = ((unsigned long long)qid_first[q] << 32) | (unsigned long long)g;
         const unsigned d = (unsigned)(v - vbase);
         if (d < (unsigned)TW) atomicMin(&s_rank[d], key);
         else atomicMin(&var_rank[v], key);
@@ -156,30 +307,27 @@ __global__ __launch_bounds__(256) void k_rank(LinesDev L, int64_t line_base, con
     }
 }
 
-// after the sort: an element is the representative of its (qid, var, cls) run when it is the LAST of the
-// run (it then carries linked = max over the run, because linked is the lowest key bit)
-__global__ __launch_bounds__(256) void k_unique_flags(const uint64_t *keys, int64_t n, uint8_t *flag) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = keys[i];
-    bool f = false;
-    if (k != KEY_DROPPED) f = (i == n - 1) || ((keys[i + 1] >> 2) != (k >> 2));
-    flag[i] = f;
-}
-
-// items are sorted by (QNAME id, variant, class); QNAME ids follow first appearance in coordinate-sorted input, so one
-// workgroup's items again fall in a narrow run of variants: same LDS window as k_line
-__global__ __launch_bounds__(256) void k_distinct(const uint64_t *items, int64_t m, int32_t *var_distinct) {
+// items are grouped by QNAME id; ids follow first appearance in coordinate-sorted input, so one workgroup's items again fall in
+// a narrow run of variants: same LDS window as k_line.  *m_ptr = number of item slots in use (= kept lines).
+__global__ __launch_bounds__(256) void k_distinct(const uint64_t *items, const uint32_t *m_ptr, int32_t *var_distinct) {
     __shared__ int s_cnt[TW * 3];
-    __shared__ int s_vbase;
+    __shared__ unsigned int s_vmin;
+    const int64_t m = *m_ptr;
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
+    if (i0 >= m) return;
     for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
-    if (tid == 0) s_vbase = (int)((uint32_t)(items[i0] >> 4) & 0x0FFFFFFFu);
+    if (tid == 0) s_vmin = 0xFFFFFFFFu;
     __syncthreads();
-    const int vbase = s_vbase - TW / 2 > 0 ? s_vbase - TW / 2 : 0;
+    {
+        const int64_t i = i0 + tid;
+        if (i < m) { const uint64_t k = items[i]; if (k != KEY_DROPPED) atomicMin(&s_vmin, (uint32_t)(k >> 4) & 0x0FFFFFFFu); }
+    }
+    __syncthreads();
+    const int vbase = (s_vmin != 0xFFFFFFFFu && (int)s_vmin - 64 > 0) ? (int)s_vmin - 64 : 0;
     for (int64_t i = i0 + tid; i < i0 + LINES_PER_BLOCK && i < m; i += 256) {
         const uint64_t k = items[i];
+        if (k == KEY_DROPPED) continue;
         const uint32_t v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u;
         const unsigned d = (unsigned)((int)v - vbase);
         if (d < (unsigned)TW) atomicAdd(&s_cnt[d * 3 + cls], 1);
@@ -197,118 +345,133 @@ __device__ __forceinline__ uint32_t hash64(uint64_t k) {
     return (uint32_t)k;
 }
 
-// number of (i, j) item pairs inside one QNAME with different variants, counted from the smaller index; one atomic
-// per workgroup of LINES_PER_BLOCK items (a per-wave atomic on the single total serialises: 1.9 ms for 10M items)
-__global__ __launch_bounds__(256) void k_pair_count(const uint64_t *items, int64_t m, unsigned long long *total) {
-    __shared__ unsigned int s_part[4];
-    const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
-    unsigned int c = 0;
-    for (int64_t i = i0 + threadIdx.x; i < i0 + LINES_PER_BLOCK && i < m; i += 256) {
-        const uint64_t k = items[i];
-        const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu;
-        for (int64_t j = i + 1; j < m; j++) {
-            const uint64_t k2 = items[j];
-            if ((uint32_t)(k2 >> 32) != q) break;
-            if (((uint32_t)(k2 >> 4) & 0x0FFFFFFFu) != v) c++;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long t = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (t) atomicAdd(total, t);
-    }
-}
-
 constexpr int PH_SLOTS = 1024;     // LDS hash slots per workgroup
 constexpr int PH_VALS = 10;        // 9 cells + linked flag
 constexpr int PH_PROBES = 24;
+constexpr int GH_PROBES = 2048;    // global probe bound; beyond it the table is declared too small and the pass is redone
 
-__device__ __forceinline__ uint32_t global_slot(uint64_t *gkeys, uint32_t gmask, uint64_t key) {
+// counters[]: 0 distinct items, 1 pair events, 2 global hash overflow, 3 kept lines
+__device__ __forceinline__ int global_slot(uint64_t *gkeys, uint32_t gmask, uint64_t key, unsigned long long *counters) {
     uint32_t s = hash64(key) & gmask;
-    for (;;) {
+    for (int t = 0; t < GH_PROBES; t++) {
         const unsigned long long prev = atomicCAS((unsigned long long *)&gkeys[s], (unsigned long long)KEY_DROPPED,
                                                   (unsigned long long)key);
-        if (prev == KEY_DROPPED || prev == key) return s;
+        if (prev == KEY_DROPPED || prev == key) return (int)s;
         s = (s + 1) & gmask;
     }
-}
-__device__ __forceinline__ void global_add(uint64_t *gkeys, int32_t *gvals, uint32_t gmask, uint64_t key, int cell, int val,
-                                           int linked) {
-    const uint32_t s = global_slot(gkeys, gmask, key);
-    if (val) atomicAdd(&gvals[(int64_t)s * PH_VALS + cell], val);
-    if (linked) atomicOr(&gvals[(int64_t)s * PH_VALS + 9], 1);
+    atomicAdd(&counters[2], 1ull);
+    return -1;
 }
 
-__global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m, uint64_t *gkeys, int32_t *gvals, uint32_t gmask) {
+__global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, const uint32_t *m_ptr, uint64_t *gkeys, int32_t *gvals, uint32_t gmask,
+                                               unsigned long long *counters) {
     __shared__ unsigned long long s_keys[PH_SLOTS];
     __shared__ int s_vals[PH_SLOTS * PH_VALS];
+    __shared__ unsigned int s_part[8];
+    const int64_t m = *m_ptr;
+    if ((int64_t)blockIdx.x * 256 >= m) return;
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) s_keys[j] = KEY_DROPPED;
     for (int j = threadIdx.x; j < PH_SLOTS * PH_VALS; j += 256) s_vals[j] = 0;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned int n_item = 0, n_event = 0;
     if (i < m) {
         const uint64_t k = items[i];
-        const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
-        for (int64_t j = i + 1; j < m; j++) {
-            const uint64_t k2 = items[j];
-            if ((uint32_t)(k2 >> 32) != q) break;
-            const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
-            if (v2 == v) continue;
-            const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
-            const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because items are sorted
-            const int cell = (int)(cls * 3 + cls2);
-            const int linked = (int)(ln & ln2);
-            uint32_t s = hash64(pk) & (PH_SLOTS - 1);
-            bool done = false;
-            for (int t = 0; t < PH_PROBES; t++) {
-                const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
-                if (prev == KEY_DROPPED || prev == pk) {
-                    atomicAdd(&s_vals[s * PH_VALS + cell], 1);
-                    if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
-                    done = true;
-                    break;
+        if (k != KEY_DROPPED) {
+            n_item = 1;
+            const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
+            for (int64_t j = i + 1; j < m; j++) {
+                const uint64_t k2 = items[j];
+                if (k2 == KEY_DROPPED) continue;
+                if ((uint32_t)(k2 >> 32) != q) break;
+                const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
+                if (v2 == v) continue;
+                n_event++;
+                const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
+                const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
+                const int cell = (int)(cls * 3 + cls2);
+                const int linked = (int)(ln & ln2);
+                uint32_t s = hash64(pk) & (PH_SLOTS - 1);
+                bool done = false;
+                for (int t = 0; t < PH_PROBES; t++) {
+                    const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
+                    if (prev == KEY_DROPPED || prev == pk) {
+                        atomicAdd(&s_vals[s * PH_VALS + cell], 1);
+                        if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
+                        done = true;
+                        break;
+                    }
+                    s = (s + 1) & (PH_SLOTS - 1);
                 }
-                s = (s + 1) & (PH_SLOTS - 1);
+                if (!done) {
+                    const int gs = global_slot(gkeys, gmask, pk, counters);
+                    if (gs >= 0) {
+                        atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
+                        if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
+                    }
+                }
             }
-            if (!done) global_add(gkeys, gvals, gmask, pk, cell, 1, linked);
         }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { n_item += __shfl_xor(n_item, d); n_event += __shfl_xor(n_event, d); }
+    if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6] = n_item; s_part[4 + (threadIdx.x >> 6)] = n_event; }
     __syncthreads();
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) {
         const uint64_t pk = s_keys[j];
         if (pk == KEY_DROPPED) continue;
-        const uint32_t gs = global_slot(gkeys, gmask, pk);
+        const int gs = global_slot(gkeys, gmask, pk, counters);
+        if (gs < 0) continue;
         for (int c = 0; c < 9; c++) {
             const int val = s_vals[j * PH_VALS + c];
             if (val) atomicAdd(&gvals[(int64_t)gs * PH_VALS + c], val);
         }
         if (s_vals[j * PH_VALS + 9]) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
     }
+    if (threadIdx.x == 0) {
+        const unsigned long long a = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const unsigned long long b = (unsigned long long)s_part[4] + s_part[5] + s_part[6] + s_part[7];
+        if (a) atomicAdd(&counters[0], a);
+        if (b) atomicAdd(&counters[1], b);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_edge_flags(const uint64_t *gkeys, int64_t cap, uint8_t *flag) {
+// ---- edge list in (a, b) order: counting sort of the used hash slots by a, each (small) group sorted by b
+__global__ __launch_bounds__(256) void k_edge_count(const uint64_t *gkeys, int64_t cap, uint32_t *deg) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < cap) flag[i] = gkeys[i] != KEY_DROPPED;
+    if (i >= cap) return;
+    const uint64_t k = gkeys[i];
+    if (k != KEY_DROPPED) atomicAdd(&deg[(uint32_t)(k >> 32)], 1u);
 }
-
-__global__ __launch_bounds__(256) void k_edge_gather(const uint64_t *skeys, const uint32_t *sslot, int64_t ne, const int32_t *gvals,
-                                                     int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked, int64_t cap) {
+__global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *gkeys, int64_t cap, const uint32_t *eoff, uint32_t *deg,
+                                                      uint32_t *e_b, uint32_t *e_slot) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= ne || i >= cap) return;
-    const uint64_t k = skeys[i];
-    ea[i] = (int32_t)(k >> 32); eb[i] = (int32_t)(uint32_t)k;
-    const int64_t s = sslot[i];
+    if (i >= cap) return;
+    const uint64_t k = gkeys[i];
+    if (k == KEY_DROPPED) return;
+    const uint32_t a = (uint32_t)(k >> 32);
+    const uint32_t old = atomicSub(&deg[a], 1u);
+    const uint32_t p = eoff[a] + old - 1;
+    e_b[p] = (uint32_t)k; e_slot[p] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, const int32_t *gvals,
+                                                    int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= nv) return;
+    const uint32_t lo = eoff[a], hi = eoff[a + 1];
+    for (uint32_t i = lo + 1; i < hi; i++) {
+        const uint32_t xb = e_b[i], xs = e_slot[i];
+        uint32_t j = i;
+        while (j > lo && e_b[j - 1] > xb) { e_b[j] = e_b[j - 1]; e_slot[j] = e_slot[j - 1]; j--; }
+        e_b[j] = xb; e_slot[j] = xs;
+    }
+    for (uint32_t i = lo; i < hi; i++) {
+        ea[i] = (int32_t)a; eb[i] = (int32_t)e_b[i];
+        const int64_t s = e_slot[i];
 #pragma unroll
-    for (int c = 0; c < 9; c++) cells[i * 9 + c] = gvals[s * PH_VALS + c];
-    linked[i] = (uint8_t)(gvals[s * PH_VALS + 9] & 1);
-}
-
-__global__ __launch_bounds__(256) void k_iota_u32(uint32_t *p, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = (uint32_t)i;
+        for (int c = 0; c < 9; c++) cells[(int64_t)i * 9 + c] = gvals[s * PH_VALS + c];
+        linked[i] = (uint8_t)(gvals[s * PH_VALS + 9] & 1);
+    }
 }
 
 // ---- union-find
@@ -343,19 +506,25 @@ __global__ __launch_bounds__(256) void k_uf_flatten(int32_t *parent, int32_t *la
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// HIP-event timing of a stage on the ctx stream; stop() waits for the stage and reports HIP errors
 struct Timer {
-    phz_ctx *c; int slot;
-    Timer(phz_ctx *ctx, int s) : c(ctx), slot(s) { (void)hipEventRecord(c->ev0, c->stream); }
-    void stop() {
-        (void)hipEventRecord(c->ev1, c->stream);
-        (void)hipEventSynchronize(c->ev1);
-        float ms = 0; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    phz_ctx *c; int slot; hipError_t err;
+    Timer(phz_ctx *ctx, int s) : c(ctx), slot(s) { err = hipEventRecord(c->ev0, c->stream); }
+    int stop() {
+        hipError_t e = hipEventRecord(c->ev1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        if (err != hipSuccess) e = err;
+        if (e != hipSuccess) return phz_fail(c, PHZ_E_HIP, "stage timing / kernel execution", e);
         c->last_ms[slot] = ms; c->total_ms[slot] += ms; c->launches[slot]++;
+        return PHZ_OK;
     }
 };
 
 int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
     d->n = h.n_calls; d->cutoff = h.as_cutoff; d->use_cutoff = h.use_cutoff; d->bam = h.bam_index;
+    d->var_base = (int32_t)h.var_base; d->qid_base = (uint32_t)h.qid_base; d->line_base = 0;
     if (int s = st.in(h.read_idx, (size_t)h.n_calls, space, &d->read_idx)) return s;
     if (int s = st.in(h.var_idx, (size_t)h.n_calls, space, &d->var_idx)) return s;
     if (int s = st.in(h.code, (size_t)h.n_calls, space, &d->code)) return s;
@@ -364,6 +533,12 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
     if (int s = st.in(h.read_has_as, (size_t)h.n_reads, space, &d->read_has_as)) return s;
     return PHZ_OK;
 }
+
+// scratch slots of ctx->scratch used by the tally (0 is the AS histogram, 16.. belong to components / K_map)
+enum { T_QOWN = 1, T_QFIRST, T_QCOUNT, T_QOFF, T_ITEMS, T_SORT_TMP, T_COUNTERS, T_GKEYS, T_GVALS, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP };
+// results and the read-list sort buffers live in their own buffers (ctx->tally_buf)
+enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_RLCNT, R_RLSTART, R_RLKEY, R_RLKEY2, R_RLVAL, R_RLQID, R_A0, R_A1,
+       R_COUNT };
 
 }  // namespace
 
@@ -386,182 +561,241 @@ extern "C" int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *h
         hipLaunchKernelGGL(k_as_hist, dim3(grid), dim3(256), 0, ctx->stream, L, dh);
     }
     PHZ_HIP(ctx, hipGetLastError());
-    t.stop();
+    if (int s = t.stop()) return s;
     if (space == PHZ_HOST) PHZ_HIP(ctx, hipMemcpyAsync(hist, dh, PHZ_AS_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
     PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PHZ_OK;
 }
 
-extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1,
-                         int64_t n_qid, phz_tally_out *out, int64_t *n_edges, int space) {
-    if (!ctx || (!shards && n_shards) || !out || !n_edges || nv < 0 || n_qid < 0) return PHZ_E_ARG;
-    if (nv >= (1ll << 28)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^28 variants in one chromosome");
+// AS histograms of several device-resident shards accumulated into one device histogram, one host wait
+extern "C" int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t *hist) {
+    if (!ctx || (!shards && n_shards) || !hist || n_shards < 0) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
-    *n_edges = 0;
+    Timer t(ctx, PHZ_T_ASHIST);
+    for (int i = 0; i < n_shards; i++) {
+        Staging st(ctx);
+        LinesDev L;
+        if (int s = stage_lines(st, shards[i], PHZ_DEVICE, &L)) return s;
+        if (L.n > 0) {
+            unsigned grid = nblk(L.n); if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL(k_as_hist, dim3(grid), dim3(256), 0, ctx->stream, L, (unsigned long long *)hist);
+        }
+    }
+    PHZ_HIP(ctx, hipGetLastError());
+    return t.stop();
+}
+
+extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1,
+                         int64_t n_qid, int n_bams, phz_tally_sizes *sizes, int space) {
+    if (!ctx || (!shards && n_shards) || !sizes || nv < 0 || n_qid < 0 || n_shards < 0 || n_bams < 1) return PHZ_E_ARG;
+    if (nv >= (1ll << 28)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^28 variants in one call");
+    if (n_qid >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^31 QNAME ids in one call");
+    if (2 * nv * n_bams >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "variants x BAMs exceeds the read-list key space");
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    memset(sizes, 0, sizeof(*sizes));
     Staging st(ctx);
     std::vector<LinesDev> L((size_t)n_shards);
     int64_t total = 0;
-    for (int b = 0; b < n_shards; b++) { if (int s = stage_lines(st, shards[b], space, &L[b])) return s; total += L[b].n; }
+    for (int b = 0; b < n_shards; b++) {
+        if (shards[b].bam_index < 0 || shards[b].bam_index >= n_bams) return phz_fail(ctx, PHZ_E_ARG, "bam_index outside [0, n_bams)");
+        if (shards[b].var_base < 0 || shards[b].qid_base < 0) return phz_fail(ctx, PHZ_E_ARG, "negative base");
+        if (int s = stage_lines(st, shards[b], space, &L[b])) return s;
+        L[b].line_base = total;
+        total += L[b].n;
+    }
+    if (total >= (1ll << 32) - 16) return phz_fail(ctx, PHZ_E_ARG, "more than 2^32 call lines in one call");
+    const size_t NV = (size_t)(nv ? nv : 1), NQ = (size_t)(n_qid ? n_qid : 1), TOT = (size_t)(total ? total : 1);
+    const size_t NRL = NV * 2 * (size_t)n_bams;
+    if (ctx->tally_buf.size() < (size_t)R_COUNT) ctx->tally_buf.resize(R_COUNT);
+    DevBuf *R = ctx->tally_buf.data();
+    DevBuf *S = ctx->scratch;
     const uint8_t *d_a0, *d_a1;
-    if (int s = st.in(a0, (size_t)nv, space, &d_a0)) return s;
-    if (int s = st.in(a1, (size_t)nv, space, &d_a1)) return s;
-    int32_t *d_cnt, *d_dist, *d_ea, *d_eb, *d_cells; int64_t *d_first; uint8_t *d_cls, *d_linked;
-    if (int s = st.out(out->var_count, (size_t)nv * 3, space, &d_cnt)) return s;
-    if (int s = st.out(out->var_first, (size_t)nv, space, &d_first)) return s;
-    if (int s = st.out(out->var_distinct, (size_t)nv * 3, space, &d_dist)) return s;
-    if (int s = st.out(out->line_cls, (size_t)total, space, &d_cls)) return s;
-    if (int s = st.out(out->edge_a, (size_t)out->edge_cap, space, &d_ea)) return s;
-    if (int s = st.out(out->edge_b, (size_t)out->edge_cap, space, &d_eb)) return s;
-    if (int s = st.out(out->edge_cells, (size_t)out->edge_cap * 9, space, &d_cells)) return s;
-    if (int s = st.out(out->edge_linked, (size_t)out->edge_cap, space, &d_linked)) return s;
-    uint64_t *d_rank;
-    if (int s = st.out(out->var_rank, (size_t)nv, space, &d_rank)) return s;
-    if (total >= (1ll << 32)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^32 call lines in one chromosome");
+    if (space == PHZ_DEVICE) { d_a0 = a0; d_a1 = a1; }
+    else {
+        if (int s = phz_reserve(ctx, R[R_A0], NV)) return s;
+        if (int s = phz_reserve(ctx, R[R_A1], NV)) return s;
+        if (nv) {
+            PHZ_HIP(ctx, hipMemcpyAsync(R[R_A0].p, a0, (size_t)nv, hipMemcpyHostToDevice, ctx->stream));
+            PHZ_HIP(ctx, hipMemcpyAsync(R[R_A1].p, a1, (size_t)nv, hipMemcpyHostToDevice, ctx->stream));
+        }
+        d_a0 = (const uint8_t *)R[R_A0].p; d_a1 = (const uint8_t *)R[R_A1].p;
+    }
+    if (int s = phz_reserve(ctx, R[R_CNT], NV * 12)) return s;
+    if (int s = phz_reserve(ctx, R[R_FIRST], NV * 8)) return s;
+    if (int s = phz_reserve(ctx, R[R_DIST], NV * 12)) return s;
+    if (int s = phz_reserve(ctx, R[R_RANK], NV * 8)) return s;
+    if (int s = phz_reserve(ctx, R[R_CLS], TOT)) return s;
+    if (int s = phz_reserve(ctx, R[R_RLCNT], NRL * 4)) return s;
+    if (int s = phz_reserve(ctx, R[R_RLSTART], (NRL + 1) * 4)) return s;
+    if (int s = phz_reserve(ctx, R[R_RLKEY], TOT * 4)) return s;
+    if (int s = phz_reserve(ctx, R[R_RLKEY2], TOT * 4)) return s;
+    if (int s = phz_reserve(ctx, R[R_RLVAL], TOT * 4)) return s;
+    if (int s = phz_reserve(ctx, R[R_RLQID], TOT * 4)) return s;
+    if (int s = phz_reserve(ctx, S[T_QOWN], NQ * 4)) return s;
+    if (int s = phz_reserve(ctx, S[T_QFIRST], NQ * 12)) return s;        // per QNAME: first ref/alt line, min / max linked variant
+    if (int s = phz_reserve(ctx, S[T_QOFF], (NQ + 1) * 4)) return s;
+    if (int s = phz_reserve(ctx, S[T_ITEMS], TOT * 8)) return s;
+    if (int s = phz_reserve(ctx, S[T_COUNTERS], 64)) return s;
+    if (int s = phz_reserve(ctx, S[T_DEG], NV * 4)) return s;
+    if (int s = phz_reserve(ctx, S[T_EOFF], (NV + 1) * 4)) return s;
+    {   // qcount must start at zero; k_items counts it back to zero, so the array is cleared only when (re)allocated
+        const size_t before = S[T_QCOUNT].cap;
+        if (int s = phz_reserve(ctx, S[T_QCOUNT], NQ * 4)) return s;
+        if (S[T_QCOUNT].cap != before) PHZ_HIP(ctx, hipMemsetAsync(S[T_QCOUNT].p, 0, S[T_QCOUNT].cap, ctx->stream));
+    }
+    int32_t *d_cnt = (int32_t *)R[R_CNT].p, *d_dist = (int32_t *)R[R_DIST].p;
+    unsigned long long *d_first = (unsigned long long *)R[R_FIRST].p, *d_rank = (unsigned long long *)R[R_RANK].p;
+    uint8_t *d_cls = (uint8_t *)R[R_CLS].p;
+    uint32_t *rl_cnt = (uint32_t *)R[R_RLCNT].p, *rl_start = (uint32_t *)R[R_RLSTART].p, *rl_key = (uint32_t *)R[R_RLKEY].p,
+             *rl_key2 = (uint32_t *)R[R_RLKEY2].p;
+    int32_t *rl_val = (int32_t *)R[R_RLVAL].p, *rl_qid = (int32_t *)R[R_RLQID].p;
+    int32_t *qid_owner = (int32_t *)S[T_QOWN].p;
+    uint32_t *qid_first = (uint32_t *)S[T_QFIRST].p, *qid_vmin = qid_first + NQ;
+    int32_t *qid_vmax = (int32_t *)(qid_vmin + NQ);
+    uint32_t *qcount = (uint32_t *)S[T_QCOUNT].p, *qoff = (uint32_t *)S[T_QOFF].p;
+    uint64_t *items = (uint64_t *)S[T_ITEMS].p;
+    unsigned long long *counters = (unsigned long long *)S[T_COUNTERS].p;      // 0 items, 1 events, 2 overflow, 3 kept lines
+    uint32_t *deg = (uint32_t *)S[T_DEG].p, *eoff = (uint32_t *)S[T_EOFF].p;
 
     hipStream_t sm = ctx->stream;
     Timer timer(ctx, PHZ_T_TALLY);
-    PHZ_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)nv * 12, sm));
-    PHZ_HIP(ctx, hipMemsetAsync(d_dist, 0, (size_t)nv * 12, sm));
-    // scratch: 1 qid_owner, 2 keys, 3 keys sorted, 4 flags, 5 items, 6 rocprim temp, 7 counters, 8 gkeys, 9 gvals, 10.. edge sort
-    DevBuf *S = ctx->scratch;
-    if (int s = phz_reserve(ctx, S[1], (size_t)(n_qid ? n_qid : 1) * 4)) return s;
-    if (int s = phz_reserve(ctx, S[2], (size_t)(total ? total : 1) * 8)) return s;
-    if (int s = phz_reserve(ctx, S[3], (size_t)(total ? total : 1) * 8)) return s;
-    if (int s = phz_reserve(ctx, S[4], (size_t)(total ? total : 1))) return s;
-    if (int s = phz_reserve(ctx, S[5], (size_t)(total ? total : 1) * 8)) return s;
-    if (int s = phz_reserve(ctx, S[7], 64)) return s;
-    int32_t *qid_owner = (int32_t *)S[1].p;
-    const size_t nq = (size_t)(n_qid ? n_qid : 1);
-    if (int s = phz_reserve(ctx, S[16], nq * 12)) return s;          // per QNAME: first ref/alt line, min / max linked variant
-    uint32_t *qid_first = (uint32_t *)S[16].p, *qid_vmin = qid_first + nq;
-    int32_t *qid_vmax = (int32_t *)(qid_vmin + nq);
-    PHZ_HIP(ctx, hipMemsetAsync(qid_first, 0xff, nq * 12, sm));      // first = vmin = UINT_MAX, vmax = -1
-    PHZ_HIP(ctx, hipMemsetAsync(d_rank, 0xff, (size_t)nv * 8, sm));
-    uint64_t *keys = (uint64_t *)S[2].p, *skeys = (uint64_t *)S[3].p, *items = (uint64_t *)S[5].p;
-    uint8_t *flags = (uint8_t *)S[4].p;
-    unsigned long long *counters = (unsigned long long *)S[7].p;
-    PHZ_HIP(ctx, hipMemsetAsync(qid_owner, 0xff, (size_t)(n_qid ? n_qid : 1) * 4, sm));      // -1
+    PHZ_HIP(ctx, hipMemsetAsync(d_cnt, 0, NV * 12, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(d_dist, 0, NV * 12, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(rl_cnt, 0, NRL * 4, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(qid_first, 0xff, NQ * 12, sm));      // first = vmin = UINT_MAX, vmax = -1
+    PHZ_HIP(ctx, hipMemsetAsync(d_rank, 0xff, NV * 8, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(qid_owner, 0xff, NQ * 4, sm));       // -1
     PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 64, sm));
-    PHZ_HIP(ctx, hipMemsetAsync(d_first, 0xff, (size_t)nv * 8, sm));       // unsigned max for atomicMin == -1 as int64 ("none")
+    PHZ_HIP(ctx, hipMemsetAsync(d_first, 0xff, NV * 8, sm));         // unsigned max for atomicMin == -1 as int64 ("none")
 
-    const int single_bam = n_shards <= 1 ? 1 : 0;     // one BAM: every QNAME's read_vars list is owned by that BAM
-    int64_t base = 0;
-    for (int b = 0; b < n_shards; b++) {
-        if (L[b].n) hipLaunchKernelGGL(k_line, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b], base,
-                                       d_a0, d_a1, d_cls, d_cnt, (unsigned long long *)d_first, qid_owner, qid_first, single_bam);
-        base += L[b].n;
-    }
-    base = 0;
-    for (int b = 0; b < n_shards; b++) {
-        if (L[b].n) hipLaunchKernelGGL(k_keys, dim3(nblk(L[b].n)), dim3(256), 0, sm, L[b], base, d_cls, qid_owner, keys, qid_vmin, qid_vmax,
-                                       single_bam);
-        base += L[b].n;
-    }
-    base = 0;
-    for (int b = 0; b < n_shards; b++) {
-        if (L[b].n) hipLaunchKernelGGL(k_rank, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b], base,
-                                       d_cls, qid_owner, qid_first, qid_vmin, qid_vmax, (unsigned long long *)d_rank, single_bam);
-        base += L[b].n;
-    }
+    const int single_bam = n_bams <= 1 ? 1 : 0;     // one BAM: every QNAME's read_vars list is owned by that BAM
+    LineOut O;
+    O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt; O.qid_owner = qid_owner;
+    O.qid_first = qid_first; O.qcount = qcount; O.n_kept = counters + 3; O.nb = n_bams; O.single_bam = single_bam;
+    for (int b = 0; b < n_shards; b++)
+        if (L[b].n) hipLaunchKernelGGL(k_line, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b], O);
     PHZ_HIP(ctx, hipGetLastError());
-    int64_t m = 0;
+    // lines per QNAME -> slot ranges; scatter; sort + de-duplicate each group.  qoff[n_qid] = kept lines = item slots in use
+    if (int s = scan_excl(ctx, qcount, qoff, n_qid, S[T_SCAN_TMP])) return s;
+    const uint32_t *m_ptr = qoff + n_qid;
+    const uint32_t rl_drop = (uint32_t)NRL;
+    for (int b = 0; b < n_shards; b++)
+        if (L[b].n) hipLaunchKernelGGL(k_items, dim3(nblk(L[b].n)), dim3(256), 0, sm, L[b], (const uint8_t *)d_cls, (const int32_t *)qid_owner,
+                                       (const uint32_t *)qoff, qcount, items, qid_vmin, qid_vmax, rl_key, rl_val, n_bams, single_bam, rl_drop);
+    if (n_qid) hipLaunchKernelGGL(k_qsort, dim3(nblk(n_qid)), dim3(256), 0, sm, (const uint32_t *)qoff, n_qid, items);
+    for (int b = 0; b < n_shards; b++)
+        if (L[b].n) hipLaunchKernelGGL(k_rank, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b],
+                                       (const uint8_t *)d_cls, (const int32_t *)qid_owner, (const uint32_t *)qid_first, (const uint32_t *)qid_vmin,
+                                       (const int32_t *)qid_vmax, d_rank, single_bam);
+    PHZ_HIP(ctx, hipGetLastError());
+    // read lists: stable sort of the lines by (variant, allele, BAM) on the significant key bits; CSR starts from the counts
     if (total > 0) {
+        int bits = 1;
+        while ((1ull << bits) <= (unsigned long long)NRL) bits++;
         size_t tmp = 0;
-        PHZ_HIP(ctx, rocprim::radix_sort_keys(nullptr, tmp, keys, skeys, (size_t)total, 0, 64, sm));
-        if (int s = phz_reserve(ctx, S[6], tmp)) return s;
-        PHZ_HIP(ctx, rocprim::radix_sort_keys(S[6].p, tmp, keys, skeys, (size_t)total, 0, 64, sm));
-        hipLaunchKernelGGL(k_unique_flags, dim3(nblk(total)), dim3(256), 0, sm, skeys, total, flags);
-        size_t tmp2 = 0;
-        unsigned long long *d_m = counters + 1;
-        PHZ_HIP(ctx, rocprim::select(nullptr, tmp2, skeys, flags, items, d_m, (size_t)total, sm));
-        if (int s = phz_reserve(ctx, S[6], tmp2 > tmp ? tmp2 : tmp)) return s;
-        PHZ_HIP(ctx, rocprim::select(S[6].p, tmp2, skeys, flags, items, d_m, (size_t)total, sm));
-        unsigned long long hm = 0;
-        PHZ_HIP(ctx, hipMemcpyAsync(&hm, d_m, 8, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipStreamSynchronize(sm));
-        m = (int64_t)hm;
+        PHZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, rl_key, rl_key2, rl_val, rl_qid, (size_t)total, 0, (unsigned)bits, sm));
+        if (int s = phz_reserve(ctx, S[T_SORT_TMP], tmp)) return s;
+        PHZ_HIP(ctx, rocprim::radix_sort_pairs(S[T_SORT_TMP].p, tmp, rl_key, rl_key2, rl_val, rl_qid, (size_t)total, 0, (unsigned)bits, sm));
     }
+    if (int s = scan_excl(ctx, rl_cnt, rl_start, (int64_t)NRL, S[T_SCAN_TMP])) return s;
+    if (total > 0) hipLaunchKernelGGL(k_distinct, dim3((unsigned)((total + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm,
+                                      (const uint64_t *)items, m_ptr, d_dist);
+    // variant pairs.  Table sized from the variant count; a pass that overflows it is redone with a larger one
+    uint64_t cap = 1 << 16;
+    while (cap < 4 * (uint64_t)NV && cap < (1ull << 30)) cap <<= 1;
     int64_t ne = 0;
-    unsigned long long pair_events = 0;
-    if (m > 0) {
-        hipLaunchKernelGGL(k_distinct, dim3((unsigned)((m + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, items, m, d_dist);
-        hipLaunchKernelGGL(k_pair_count, dim3((unsigned)((m + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, items, m, counters + 2);
-        unsigned long long events = 0;
-        PHZ_HIP(ctx, hipMemcpyAsync(&events, counters + 2, 8, hipMemcpyDeviceToHost, sm));
+    unsigned long long h_counters[4] = {0, 0, 0, 0};
+    uint32_t h_tail[2] = {0, 0};
+    for (int attempt = 0;; attempt++) {
+        if (int s = phz_reserve(ctx, S[T_GKEYS], cap * 8)) return s;
+        if (int s = phz_reserve(ctx, S[T_GVALS], cap * PH_VALS * 4)) return s;
+        uint64_t *gkeys = (uint64_t *)S[T_GKEYS].p; int32_t *gvals = (int32_t *)S[T_GVALS].p;
+        PHZ_HIP(ctx, hipMemsetAsync(gkeys, 0xff, cap * 8, sm));
+        PHZ_HIP(ctx, hipMemsetAsync(gvals, 0, cap * PH_VALS * 4, sm));
+        PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 24, sm));
+        if (total > 0) hipLaunchKernelGGL(k_pairs, dim3(nblk(total)), dim3(256), 0, sm, (const uint64_t *)items, m_ptr, gkeys, gvals,
+                                          (uint32_t)(cap - 1), counters);
+        PHZ_HIP(ctx, hipMemsetAsync(deg, 0, NV * 4, sm));
+        hipLaunchKernelGGL(k_edge_count, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, (const uint64_t *)gkeys, (int64_t)cap, deg);
+        if (int s = scan_excl(ctx, deg, eoff, nv, S[T_SCAN_TMP])) return s;
+        PHZ_HIP(ctx, hipGetLastError());
+        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 32, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[0], eoff + nv, 4, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[1], rl_start + NRL, 4, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
-        pair_events = events;
-        if (events > 0) {
-            uint64_t cap = 1024;
-            while (cap < 2 * events && cap < (1ull << 31)) cap <<= 1;
-            if (int s = phz_reserve(ctx, S[8], cap * 8)) return s;
-            if (int s = phz_reserve(ctx, S[9], cap * PH_VALS * 4)) return s;
-            uint64_t *gkeys = (uint64_t *)S[8].p; int32_t *gvals = (int32_t *)S[9].p;
-            PHZ_HIP(ctx, hipMemsetAsync(gkeys, 0xff, cap * 8, sm));
-            PHZ_HIP(ctx, hipMemsetAsync(gvals, 0, cap * PH_VALS * 4, sm));
-            hipLaunchKernelGGL(k_pairs, dim3(nblk(m)), dim3(256), 0, sm, items, m, gkeys, gvals, (uint32_t)(cap - 1));
-            // compact used slots, sort by pair key for a deterministic edge order
-            if (int s = phz_reserve(ctx, S[10], cap)) return s;              // flags
-            if (int s = phz_reserve(ctx, S[11], cap * 4)) return s;          // iota
-            if (int s = phz_reserve(ctx, S[12], cap * 4)) return s;          // slots (compacted)
-            if (int s = phz_reserve(ctx, S[13], cap * 8)) return s;          // keys (compacted)
-            if (int s = phz_reserve(ctx, S[14], cap * 8)) return s;          // keys sorted
-            if (int s = phz_reserve(ctx, S[15], cap * 4)) return s;          // slots sorted
-            uint8_t *ef = (uint8_t *)S[10].p; uint32_t *iota = (uint32_t *)S[11].p, *cslot = (uint32_t *)S[12].p, *sslot = (uint32_t *)S[15].p;
-            uint64_t *ckeys = (uint64_t *)S[13].p, *sk = (uint64_t *)S[14].p;
-            hipLaunchKernelGGL(k_edge_flags, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, gkeys, (int64_t)cap, ef);
-            hipLaunchKernelGGL(k_iota_u32, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, iota, (int64_t)cap);
-            size_t t1 = 0, t2 = 0, t3 = 0;
-            unsigned long long *d_ne = counters + 3;
-            PHZ_HIP(ctx, rocprim::select(nullptr, t1, gkeys, ef, ckeys, d_ne, (size_t)cap, sm));
-            PHZ_HIP(ctx, rocprim::select(nullptr, t2, iota, ef, cslot, d_ne, (size_t)cap, sm));
-            size_t tm = t1 > t2 ? t1 : t2;
-            if (int s = phz_reserve(ctx, S[6], tm)) return s;
-            PHZ_HIP(ctx, rocprim::select(S[6].p, t1, gkeys, ef, ckeys, d_ne, (size_t)cap, sm));
-            PHZ_HIP(ctx, rocprim::select(S[6].p, t2, iota, ef, cslot, d_ne, (size_t)cap, sm));
-            unsigned long long hne = 0;
-            PHZ_HIP(ctx, hipMemcpyAsync(&hne, d_ne, 8, hipMemcpyDeviceToHost, sm));
-            PHZ_HIP(ctx, hipStreamSynchronize(sm));
-            ne = (int64_t)hne;
-            if (ne > 0) {
-                PHZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t3, ckeys, sk, cslot, sslot, (size_t)ne, 0, 64, sm));
-                if (int s = phz_reserve(ctx, S[6], t3)) return s;
-                PHZ_HIP(ctx, rocprim::radix_sort_pairs(S[6].p, t3, ckeys, sk, cslot, sslot, (size_t)ne, 0, 64, sm));
-                hipLaunchKernelGGL(k_edge_gather, dim3(nblk(ne)), dim3(256), 0, sm, sk, sslot, ne, gvals, d_ea, d_eb, d_cells, d_linked,
-                                   out->edge_cap);
-            }
-        }
+        if (h_counters[2] == 0) { ne = (int64_t)h_tail[0]; break; }
+        if (attempt == 4 || cap >= (1ull << 31)) return phz_fail(ctx, PHZ_E_NOMEM, "variant-pair table did not converge");
+        cap <<= 2;
+    }
+    const size_t NE = (size_t)(ne ? ne : 1);
+    if (int s = phz_reserve(ctx, R[R_EA], NE * 4)) return s;
+    if (int s = phz_reserve(ctx, R[R_EB], NE * 4)) return s;
+    if (int s = phz_reserve(ctx, R[R_CELLS], NE * 36)) return s;
+    if (int s = phz_reserve(ctx, R[R_LINKED], NE)) return s;
+    if (int s = phz_reserve(ctx, S[T_EB], NE * 4)) return s;
+    if (int s = phz_reserve(ctx, S[T_ESLOT], NE * 4)) return s;
+    if (ne > 0) {
+        hipLaunchKernelGGL(k_edge_scatter, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, (const uint64_t *)S[T_GKEYS].p, (int64_t)cap,
+                           (const uint32_t *)eoff, deg, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
+        hipLaunchKernelGGL(k_edge_final, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p,
+                           (const int32_t *)S[T_GVALS].p, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p);
     }
     PHZ_HIP(ctx, hipGetLastError());
-    timer.stop();
-    ctx->counters[PHZ_C_LINES] += total; ctx->counters[PHZ_C_ITEMS] += m; ctx->counters[PHZ_C_PAIR_EVENTS] += (int64_t)pair_events;
+    if (int s = timer.stop()) return s;
+    auto &T = ctx->tally;
+    T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = (int64_t)h_counters[3]; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
+    T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;
+    T.ea = (int32_t *)R[R_EA].p; T.eb = (int32_t *)R[R_EB].p; T.cells = (int32_t *)R[R_CELLS].p; T.linked = (uint8_t *)R[R_LINKED].p;
+    T.rl_start = rl_start; T.rl_qid = rl_qid;
+    sizes->n_lines = total; sizes->n_kept = T.n_kept; sizes->n_edges = ne; sizes->n_read_list = T.n_rl;
+    sizes->n_items = (int64_t)h_counters[0]; sizes->pair_events = (int64_t)h_counters[1];
+    ctx->counters[PHZ_C_LINES] += total; ctx->counters[PHZ_C_ITEMS] += sizes->n_items; ctx->counters[PHZ_C_PAIR_EVENTS] += sizes->pair_events;
     ctx->counters[PHZ_C_EDGES] += ne;
-    *n_edges = ne;
-    if (space == PHZ_HOST) {
-        PHZ_HIP(ctx, hipMemcpyAsync(out->var_count, d_cnt, (size_t)nv * 12, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(out->var_first, d_first, (size_t)nv * 8, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(out->var_distinct, d_dist, (size_t)nv * 12, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(out->var_rank, d_rank, (size_t)nv * 8, hipMemcpyDeviceToHost, sm));
-        if (total) PHZ_HIP(ctx, hipMemcpyAsync(out->line_cls, d_cls, (size_t)total, hipMemcpyDeviceToHost, sm));
-        const size_t k = (size_t)(ne < out->edge_cap ? ne : out->edge_cap);
-        if (k) {
-            PHZ_HIP(ctx, hipMemcpyAsync(out->edge_a, d_ea, k * 4, hipMemcpyDeviceToHost, sm));
-            PHZ_HIP(ctx, hipMemcpyAsync(out->edge_b, d_eb, k * 4, hipMemcpyDeviceToHost, sm));
-            PHZ_HIP(ctx, hipMemcpyAsync(out->edge_cells, d_cells, k * 36, hipMemcpyDeviceToHost, sm));
-            PHZ_HIP(ctx, hipMemcpyAsync(out->edge_linked, d_linked, k, hipMemcpyDeviceToHost, sm));
-        }
-    }
-    PHZ_HIP(ctx, hipStreamSynchronize(sm));
-    return ne > out->edge_cap ? PHZ_E_CAPACITY : PHZ_OK;
+    return PHZ_OK;
 }
 
+// copy the results of the last phz_tally into the caller's arrays (NULL members are skipped); one host wait
+extern "C" int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space) {
+    if (!ctx || !out) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    auto &T = ctx->tally;
+    const hipMemcpyKind kind = space == PHZ_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    hipStream_t sm = ctx->stream;
+    auto cp = [&](void *dst, const void *src, size_t bytes) -> int {
+        if (!dst || !bytes) return PHZ_OK;
+        PHZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, kind, sm));
+        return PHZ_OK;
+    };
+    const size_t nv = (size_t)T.nv, ne = (size_t)T.n_edges;
+    if (int s = cp(out->var_count, T.var_count, nv * 12)) return s;
+    if (int s = cp(out->var_first, T.var_first, nv * 8)) return s;
+    if (int s = cp(out->var_distinct, T.var_distinct, nv * 12)) return s;
+    if (int s = cp(out->var_rank, T.var_rank, nv * 8)) return s;
+    if (int s = cp(out->line_cls, T.line_cls, (size_t)T.n_lines)) return s;
+    if (int s = cp(out->edge_a, T.ea, ne * 4)) return s;
+    if (int s = cp(out->edge_b, T.eb, ne * 4)) return s;
+    if (int s = cp(out->edge_cells, T.cells, ne * 36)) return s;
+    if (int s = cp(out->edge_linked, T.linked, ne)) return s;
+    if (int s = cp(out->rl_start, T.rl_start, (nv * 2 * (size_t)T.nb + 1) * 4)) return s;
+    if (int s = cp(out->rl_qid, T.rl_qid, (size_t)T.n_rl * 4)) return s;
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    return PHZ_OK;
+}
+
+// edge_a == edge_b == NULL: the edges of the last phz_tally, still resident in HBM (n_edges must match); keep[] lives in `space`
 extern "C" int phz_components(phz_ctx *ctx, int64_t nv, int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b,
                               const uint8_t *keep, int32_t *label, int space) {
     if (!ctx || nv < 0 || n_edges < 0 || (!label && nv)) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     Staging st(ctx);
     const int32_t *ea, *eb; const uint8_t *kp; int32_t *lab;
-    if (int s = st.in(edge_a, (size_t)n_edges, space, &ea)) return s;
-    if (int s = st.in(edge_b, (size_t)n_edges, space, &eb)) return s;
+    if (!edge_a && !edge_b && n_edges) {
+        if (n_edges != ctx->tally.n_edges || nv != ctx->tally.nv) return phz_fail(ctx, PHZ_E_ARG, "no resident edge list of that size");
+        ea = ctx->tally.ea; eb = ctx->tally.eb;
+    } else {
+        if (int s = st.in(edge_a, (size_t)n_edges, space, &ea)) return s;
+        if (int s = st.in(edge_b, (size_t)n_edges, space, &eb)) return s;
+    }
     if (int s = st.in(keep, (size_t)n_edges, space, &kp)) return s;
     if (int s = st.out(label, (size_t)nv, space, &lab)) return s;
     if (int s = phz_reserve(ctx, ctx->scratch[16], (size_t)(nv ? nv : 1) * 4)) return s;
@@ -571,7 +805,7 @@ extern "C" int phz_components(phz_ctx *ctx, int64_t nv, int64_t n_edges, const i
     if (n_edges) hipLaunchKernelGGL(k_uf_hook, dim3(nblk(n_edges)), dim3(256), 0, ctx->stream, parent, ea, eb, kp, n_edges);
     if (nv) hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(nv)), dim3(256), 0, ctx->stream, parent, lab, nv);
     PHZ_HIP(ctx, hipGetLastError());
-    t.stop();
+    if (int s = t.stop()) return s;
     if (space == PHZ_HOST && nv) PHZ_HIP(ctx, hipMemcpyAsync(label, lab, (size_t)nv * 4, hipMemcpyDeviceToHost, ctx->stream));
     PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PHZ_OK;

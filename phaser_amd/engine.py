@@ -78,6 +78,7 @@ class _Shard:
     def __init__(self, calls: Calls, qid, aln, has_as, n_reads):
         self.calls = calls; self.qid = qid; self.aln = aln; self.has_as = has_as; self.n_reads = n_reads
         self.cutoff = 0.0; self.use_cutoff = 0
+        self.as_absmax = None
 
 
 class Engine:
@@ -144,10 +145,10 @@ class Engine:
         if qnames is not None:
             self.qnames[chrom] = qnames
 
-    def _lines(self, sh: _Shard, bam_index: int) -> _lib.phz_lines:
+    def _lines(self, sh: _Shard, bam_index: int, var_base: int = 0, qid_base: int = 0) -> _lib.phz_lines:
         c = sh.calls
         return _lib.phz_lines(c.n, _p(c.read_idx), _p(c.var_idx), _p(c.code), sh.n_reads, _p(sh.qid), _p(sh.aln), _p(sh.has_as),
-                              float(sh.cutoff), int(sh.use_cutoff), bam_index)
+                              float(sh.cutoff), int(sh.use_cutoff), bam_index, var_base, qid_base)
 
     def close_bam(self, bam_index: int):
         """AS quantile cutoff of one BAM over all its chromosomes (phaser.py:545-553)."""
@@ -155,13 +156,20 @@ class Engine:
         if self.cfg.as_q_cutoff > 0:
             dev = shards[0].calls.read_idx.device if shards else self.mapper.device
             hist = torch.zeros(_lib.PHZ_AS_BINS, dtype=torch.int64, device=dev)
-            space = _lib.PHZ_DEVICE if dev.type == "cuda" else _lib.PHZ_HOST
-            for sh in shards:
-                if sh.calls.n:
-                    if int(sh.aln.abs().max()) >= 32768:
-                        raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
+            live = [sh for sh in shards if sh.calls.n]
+            for sh in live:
+                if sh.as_absmax is None:
+                    sh.as_absmax = int(sh.aln.abs().max())
+                if sh.as_absmax >= 32768:
+                    raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
+            if live and dev.type == "cuda":         # every shard of the BAM in one submission
+                arr = (_lib.phz_lines * len(live))(*[self._lines(sh, bam_index) for sh in live])
+                torch.cuda.synchronize(dev)
+                self.ctx.check(self.lib.phz_as_histogram_batch(self.ctx.h, arr, len(live), _p(hist)))
+            else:
+                for sh in live:
                     ln = self._lines(sh, bam_index)
-                    self.ctx.check(self.lib.phz_as_histogram(self.ctx.h, C.byref(ln), _p(hist), space))
+                    self.ctx.check(self.lib.phz_as_histogram(self.ctx.h, C.byref(ln), _p(hist), _lib.PHZ_HOST))
             pdist.allreduce_sum_(hist)          # the quantile is over ALL chromosomes of this BAM
             h = hist.cpu().numpy()
             if int(h.sum()) > 0:
@@ -173,77 +181,93 @@ class Engine:
                 self.log.append("          no alignment score value found in reads, cannot use cutoff")
 
     # ---------------------------------------------------------------- stages 3-6
-    def _tally_chrom(self, chrom: str):
-        cv = self.vs.chroms[chrom]
-        nv = len(cv)
-        present = [(b, sh) for b, sh in enumerate(self.shards[chrom]) if sh is not None]
-        dev = present[0][1].calls.read_idx.device if present else torch.device("cpu")
-        space = _lib.PHZ_DEVICE if dev.type == "cuda" else _lib.PHZ_HOST
-        arr = (_lib.phz_lines * max(1, len(present)))()
-        total = 0
-        for i, (b, sh) in enumerate(present):
-            arr[i] = self._lines(sh, b)
-            total += sh.calls.n
-        if cv.is_general:      # codes 5 / 6 carry the class; single-base codes must not be matched through a0 / a1
-            a0 = torch.full((nv,), 255, dtype=torch.uint8, device=dev); a1 = torch.full((nv,), 255, dtype=torch.uint8, device=dev)
-        else:
-            a0 = torch.from_numpy(cv.a0).to(dev); a1 = torch.from_numpy(cv.a1).to(dev)
-        var_count = torch.empty(nv * 3, dtype=torch.int32, device=dev); var_first = torch.empty(nv, dtype=torch.int64, device=dev)
-        var_distinct = torch.empty(nv * 3, dtype=torch.int32, device=dev); line_cls = torch.empty(max(1, total), dtype=torch.uint8, device=dev)
-        var_rank = torch.empty(max(1, nv), dtype=torch.int64, device=dev)
-        cap = max(1024, 4 * nv)
+    def _bases(self):
+        """Joint index spaces of this rank's chromosomes (VCF order): first variant / first QNAME id of each."""
+        vb = {}; qb = {}; v = q = 0
+        for c in self.chrom_list:
+            vb[c] = v; qb[c] = q
+            v += len(self.vs.chroms[c]); q += max(1, self.n_qid[c])
+        return vb, qb, v, q
+
+    def _pinned(self, name: str, count: int, dtype):
+        """numpy array over page-locked host memory, kept per name and grown on demand (D2H at full PCIe rate)."""
+        dt = np.dtype(dtype)
+        need = max(1, count) * dt.itemsize
+        pool = self.__dict__.setdefault("_pin", {})
+        t = pool.get(name)
+        if t is None or t.numel() < need:
+            t = torch.empty(need + need // 8 + 64, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            pool[name] = t
+        return t.numpy()[:need].view(dt)[:count]
+
+    def _tally_genome(self) -> dict:
+        """K_tally over every (chromosome, BAM) shard of this rank in ONE submission; results fetched into pinned host arrays."""
         import time as _t
+        nb = len(self.bam_names)
+        vb, qb, NV, NQ = self._bases()
+        lines = []; line_base = {}; total = 0
+        dev = None
+        for c in self.chrom_list:
+            for b, sh in enumerate(self.shards[c]):
+                if sh is None:
+                    continue
+                dev = sh.calls.read_idx.device
+                lines.append(self._lines(sh, b, vb[c], qb[c]))
+                line_base[(c, b)] = (total, sh.calls.n)
+                total += sh.calls.n
+        if dev is None:
+            dev = torch.device("cpu")
+        space = _lib.PHZ_DEVICE if dev.type == "cuda" else _lib.PHZ_HOST
+        a0 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a0
+                             for c in self.chrom_list]) if self.chrom_list else np.zeros(0, np.uint8)
+        a1 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a1
+                             for c in self.chrom_list]) if self.chrom_list else np.zeros(0, np.uint8)
+        a0 = np.ascontiguousarray(a0, dtype=np.uint8); a1 = np.ascontiguousarray(a1, dtype=np.uint8)
         t0 = _t.perf_counter()
-        while True:
-            ea = torch.empty(cap, dtype=torch.int32, device=dev); eb = torch.empty(cap, dtype=torch.int32, device=dev)
-            cells = torch.empty(cap * 9, dtype=torch.int32, device=dev); linked = torch.empty(cap, dtype=torch.uint8, device=dev)
-            out = _lib.phz_tally_out(_p(var_count), _p(var_first), _p(var_distinct), _p(line_cls), cap, _p(ea), _p(eb), _p(cells), _p(linked),
-                                     _p(var_rank))
-            ne = C.c_int64(0)
-            if dev.type == "cuda":
-                torch.cuda.synchronize(dev)
-            st = self.lib.phz_tally(self.ctx.h, arr, len(present), nv, _p(a0), _p(a1), max(1, self.n_qid[chrom]), C.byref(out),
-                                    C.byref(ne), space)
-            self.ctx.check(st, allow=(_lib.PHZ_E_CAPACITY,))
-            if st == _lib.PHZ_E_CAPACITY:
-                cap = int(ne.value) + 16
-                continue
-            break
-        ne = int(ne.value)
+        if space == _lib.PHZ_DEVICE:
+            ta0 = torch.from_numpy(a0).to(dev); ta1 = torch.from_numpy(a1).to(dev)
+            torch.cuda.synchronize(dev)
+            pa0, pa1 = _p(ta0), _p(ta1)
+        else:
+            pa0, pa1 = C.c_void_p(a0.ctypes.data), C.c_void_p(a1.ctypes.data)
+        arr = (_lib.phz_lines * max(1, len(lines)))(*lines)
+        sz = _lib.phz_tally_sizes()
+        self.ctx.check(self.lib.phz_tally(self.ctx.h, arr, len(lines), NV, pa0, pa1, NQ, nb, C.byref(sz), space))
         t1 = _t.perf_counter()
-        res = {
-            "nv": nv, "var_count": var_count.cpu().numpy().reshape(nv, 3), "var_first": var_first.cpu().numpy(),
-            "var_distinct": var_distinct.cpu().numpy().reshape(nv, 3), "line_cls": line_cls[:total].cpu().numpy(),
-            "ea": ea[:ne].cpu().numpy(), "eb": eb[:ne].cpu().numpy(), "cells": cells[:ne * 9].cpu().numpy().reshape(ne, 9),
-            "linked": linked[:ne].cpu().numpy().astype(bool), "dev": dev, "space": space,
-            "var_rank": var_rank[:nv].cpu().numpy().view(np.uint64),
-        }
-        # host copies of the kept call lines (for ordering rules and read lists)
-        lv = []; lq = []; lb = []; offs = []
-        base = 0
-        for b, sh in present:
-            offs.append((b, base, sh.calls.n))
-            v = sh.calls.var_idx.cpu().numpy()
-            lv.append(v); lq.append(sh.qid[sh.calls.read_idx.long()].cpu().numpy()); lb.append(np.full(len(v), b, dtype=np.int32))
-            base += sh.calls.n
-        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
-        res["line_var"] = cat(lv, np.int32); res["line_qid"] = cat(lq, np.int32); res["line_bam"] = cat(lb, np.int32)
-        res["bam_offsets"] = offs
+        ne = int(sz.n_edges); nrl = int(sz.n_read_list)
+        G = {"nv": NV, "nb": nb, "var_base": vb, "line_base": line_base, "n_lines": int(sz.n_lines), "n_kept": int(sz.n_kept),
+             "var_count": self._pinned("var_count", NV * 3, np.int32), "var_first": self._pinned("var_first", NV, np.int64),
+             "var_distinct": self._pinned("var_distinct", NV * 3, np.int32), "var_rank": self._pinned("var_rank", NV, np.uint64),
+             "ea": self._pinned("ea", ne, np.int32), "eb": self._pinned("eb", ne, np.int32), "cells": self._pinned("cells", ne * 9, np.int32),
+             "linked": self._pinned("linked", ne, np.uint8), "rl_start": self._pinned("rl_start", NV * 2 * nb + 1, np.uint32),
+             "rl_qid": self._pinned("rl_qid", nrl, np.int32)}
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a.size else None
+        out = _lib.phz_tally_out(vp(G["var_count"]), vp(G["var_first"]), vp(G["var_distinct"]), vp(G["var_rank"]), None, vp(G["ea"]), vp(G["eb"]),
+                                 vp(G["cells"]), vp(G["linked"]), vp(G["rl_start"]), vp(G["rl_qid"]))
+        self.ctx.check(self.lib.phz_tally_fetch(self.ctx.h, C.byref(out), _lib.PHZ_HOST))
+        G["var_count"] = G["var_count"].reshape(NV, 3); G["var_distinct"] = G["var_distinct"].reshape(NV, 3); G["cells"] = G["cells"].reshape(ne, 9)
+        G["resident"] = True            # the edge list is still in HBM: phz_components can use it in place
         self.stats["tally_call_s"] = self.stats.get("tally_call_s", 0.0) + t1 - t0
         self.stats["tally_d2h_s"] = self.stats.get("tally_d2h_s", 0.0) + _t.perf_counter() - t1
-        return res
+        return G
+
+    def chrom_view(self, c: str) -> dict:
+        """One chromosome's part of the tally results, local variant indices (views; for tests and tools)."""
+        G = self.G; v0 = G["var_base"][c]; nv = len(self.vs.chroms[c])
+        lo = int(np.searchsorted(G["ea"], v0, side="left")); hi = int(np.searchsorted(G["ea"], v0 + nv, side="left"))
+        vc = G["var_count"][v0:v0 + nv]
+        return {"nv": nv, "var_count": vc, "var_distinct": G["var_distinct"][v0:v0 + nv], "var_first": G["var_first"][v0:v0 + nv],
+                "var_rank": G["var_rank"][v0:v0 + nv], "ea": G["ea"][lo:hi] - v0, "eb": G["eb"][lo:hi] - v0, "cells": G["cells"][lo:hi],
+                "linked": G["linked"][lo:hi].astype(bool), "kept": int(vc.sum())}
 
     def tally_all(self):
-        """Stage A: K_tally per owned chromosome; returns the two global noise counters of these chromosomes."""
-        self.tally = {c: self._tally_chrom(c) for c in self.chrom_list}
-        match = mism = 0
-        for c in self.chrom_list:
-            vc = self.tally[c]["var_count"].astype(np.int64)
-            m = vc[:, 0] + vc[:, 1]; mm = vc[:, 2]
-            with np.errstate(divide="ignore", invalid="ignore"):
-                ok = (m > 0) & ((mm.astype(np.float64) / (mm + m).astype(np.float64)) < 0.05)
-            match += int(m[ok].sum()); mism += int(mm[ok].sum())
-        return match, mism
+        """Stage A: K_tally over this rank's chromosomes; returns the two global noise counters of these chromosomes."""
+        self.G = self._tally_genome()
+        vc = self.G["var_count"].astype(np.int64)
+        m = vc[:, 0] + vc[:, 1]; mm = vc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ok = (m > 0) & ((mm.astype(np.float64) / (mm + m).astype(np.float64)) < 0.05)
+        return int(m[ok].sum()), int(mm[ok].sum())
 
     @staticmethod
     def noise_from_counts(match: int, mism: int) -> float:
@@ -290,77 +314,67 @@ class Engine:
         return out if binary else {k: v.decode() for k, v in out.items()}
 
     def _fragments(self, noise: float) -> Dict[str, dict]:
-        """Stage C for every owned chromosome.  C2 of chromosome i (native, releases the GIL) runs on a helper thread while
-        C1 of chromosome i+1 (numpy / scipy / GPU components) runs here."""
-        if len(self.chrom_list) <= 1:
-            return {c: self.chrom_fragment(c, noise, self.all_chroms.index(c)) for c in self.chrom_list}
-        import time as _t
-        from concurrent.futures import ThreadPoolExecutor
-        local: Dict[str, dict] = {}
-        with ThreadPoolExecutor(1) as ex:
-            pending = None
-            for c in self.chrom_list:
-                t0 = _t.perf_counter()
-                frag = self.chrom_prepare(c, noise, self.all_chroms.index(c))
-                self.stats["prepare_s"] = self.stats.get("prepare_s", 0.0) + _t.perf_counter() - t0
-                if pending is not None:
-                    pc, pf, fut = pending
-                    pf.update(fut.result()); del self._pre[pc]; local[pc] = pf
-                pending = (c, frag, ex.submit(rows.format_chrom, self, c, self.cfg.host_threads))
-            pc, pf, fut = pending
-            pf.update(fut.result()); del self._pre[pc]; local[pc] = pf
-        return {c: local[c] for c in self.chrom_list}
-
-    def chrom_fragment(self, c: str, noise: float, chrom_index: int) -> dict:
-        """Stage C for one chromosome: C1 = ordering ranks, pair tests, pruning, components (numpy / scipy / GPU);
-        C2 = block phasing + row text in native code (rows.format_chrom -> phz_rows_format)."""
+        """Stage C for every owned chromosome: C1 = pair tests, pruning, components, ordering keys (numpy / scipy / GPU, the
+        heavy parts once over all chromosomes); C2 = block phasing + row text, all chromosomes through ONE native thread pool."""
         import time as _t
         t0 = _t.perf_counter()
-        frag = self.chrom_prepare(c, noise, chrom_index)
+        frags = self._prepare(noise)
         t1 = _t.perf_counter()
-        frag.update(rows.format_chrom(self, c, self.cfg.host_threads))
+        done = rows.format_chroms(self, self.chrom_list, self.cfg.host_threads)
+        for c in self.chrom_list:
+            frags[c].update(done[c])
+        self._pre = {}
         self.stats["prepare_s"] = self.stats.get("prepare_s", 0.0) + t1 - t0
         self.stats["rows_s"] = self.stats.get("rows_s", 0.0) + _t.perf_counter() - t1
-        del self._pre[c]
-        return frag
+        return {c: frags[c] for c in self.chrom_list}
 
-    def chrom_prepare(self, c: str, noise: float, chrom_index: int) -> dict:
-        """Stage C1: ordering ranks, pair tests (scipy), pruning, connected components on the GPU, allelic counts.
-        Leaves the chromosome's unphased blocks and first-appearance keys in self._pre[c] for stage C2."""
+    def _prepare(self, noise: float) -> Dict[str, dict]:
+        """Stage C1.  Genome-wide: the nine cells -> supporting / total counts, the binomial test (scipy, the reference's own
+        call at phaser.py:1649), pruning, connected components on the GPU.  Per chromosome (slices of those arrays, local
+        variant indices): row orders, component lists, first-appearance keys -> self._pre[c] for the row writer."""
         cfg = self.cfg
-        R = self.tally[c]; cv = self.vs.chroms[c]; nv = R["nv"]
-        frag = {"chrom": c, "lines": int((R["line_cls"] != 255).sum())}
-        if True:
-            kept = R["line_cls"] != 255
-            cls = R["line_cls"]
-            # ---- ordering rule 4 (SURVEY.md 8.1): overlap-dict key order, computed by K_tally (k_rank)
-            rank = R["var_rank"]
-            # ---- test every linked pair (phaser.py:1594-1654)
-            sel = np.nonzero(R["linked"])[0]
-            ea = R["ea"][sel]; eb = R["eb"][sel]; cells = R["cells"][sel].astype(np.int64)
+        G = self.G
+        NV = G["nv"]
+        rank_all = G["var_rank"]
+        # ---- test every linked pair (phaser.py:1594-1654)
+        sel = np.nonzero(G["linked"])[0]
+        ea_g = G["ea"][sel]; eb_g = G["eb"][sel]; cells = G["cells"][sel].astype(np.int64)
+        cis = cells[:, 0] + cells[:, 4]
+        trans = cells[:, 3] + cells[:, 1]
+        oth = cells[:, 6] + cells[:, 7] + cells[:, 2] + cells[:, 5] + cells[:, 8]
+        sup = np.maximum(cis, trans); tot = cis + trans + oth
+        cfgv = np.where(cis > trans, 0, np.where(cis < trans, 1, -1))
+        prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
+        pv = np.ones(len(sel), dtype=np.float64)
+        test = (sup > 0) & ((tot - sup) > 0)
+        if test.any():
+            pv[test] = binom.cdf(sup[test], tot[test], prob)
+        pv[sup == 0] = 0.0
+        keep_edge = ~(pv < cfg.cc_threshold)
+        # ---- connected components of the surviving graph on the GPU (phaser.py:1861-1882)
+        keep_all = np.zeros(len(G["ea"]), dtype=np.uint8)
+        keep_all[sel[keep_edge]] = 1
+        label_all = self._component_labels(keep_all)
+        frags: Dict[str, dict] = {}
+        self._pre = {}
+        vb = G["var_base"]
+        for ci, c in enumerate(self.chrom_list):
+            nv = len(self.vs.chroms[c]); v0 = vb[c]
+            lo = int(np.searchsorted(ea_g, v0, side="left")); hi = int(np.searchsorted(ea_g, v0 + nv, side="left"))
+            ea = ea_g[lo:hi] - v0; eb = eb_g[lo:hi] - v0
+            rank = rank_all[v0:v0 + nv]
+            kcis = cis[lo:hi]; ktrans = trans[lo:hi]; keep = keep_edge[lo:hi]
             swap = rank[eb] < rank[ea]
-            va = np.where(swap, eb, ea); vb = np.where(swap, ea, eb)
-            cis = cells[:, 0] + cells[:, 4]
-            trans = cells[:, 3] + cells[:, 1]
-            oth = cells[:, 6] + cells[:, 7] + cells[:, 2] + cells[:, 5] + cells[:, 8]
-            sup = np.maximum(cis, trans); tot = cis + trans + oth
-            cfgv = np.where(cis > trans, 0, np.where(cis < trans, 1, -1))
-            prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
-            pv = np.ones(len(sel), dtype=np.float64)
-            test = (sup > 0) & ((tot - sup) > 0)
-            if test.any():
-                pv[test] = binom.cdf(sup[test], tot[test], prob)
-            pv[sup == 0] = 0.0
-            keep_edge = ~(pv < cfg.cc_threshold)
+            va = np.where(swap, eb, ea); vb_ = np.where(swap, ea, eb)
             # row order of variant_connections is hash order in the reference; we emit sorted by (rank a, rank b)
-            eorder = np.lexsort((rank[vb], rank[va]))
-            frag["dropped"] = int((~keep_edge).sum())
-            # ---- connected components of the surviving graph on the GPU (phaser.py:1861-1882)
-            label = self._component_labels(c, ea, eb, keep_edge)
-            deg = np.bincount(ea[keep_edge], minlength=nv) + np.bincount(eb[keep_edge], minlength=nv)
+            eorder = np.lexsort((rank[vb_], rank[va]))
+            vc = G["var_count"][v0:v0 + nv]
+            frag = {"chrom": c, "lines": int(vc.sum()), "dropped": int((~keep).sum())}
+            label = label_all[v0:v0 + nv] - v0
+            deg = np.bincount(ea[keep], minlength=nv) + np.bincount(eb[keep], minlength=nv)
             members = np.nonzero(deg > 0)[0]
-            P = {"va": va, "vb": vb, "cis": cis, "trans": trans, "sup": sup, "tot": tot, "pv": pv, "eorder": eorder, "ea": ea, "eb": eb,
-                 "cfgv": cfgv, "ncomp": 0}
+            P = {"va": va, "vb": vb_, "cis": kcis, "trans": ktrans, "sup": sup[lo:hi], "tot": tot[lo:hi], "pv": pv[lo:hi], "eorder": eorder,
+                 "ea": ea, "eb": eb, "cfgv": cfgv[lo:hi], "ncomp": 0, "v0": v0, "nv": nv}
             if len(members):
                 lab = label[members]
                 o2 = np.lexsort((members, lab))
@@ -368,36 +382,38 @@ class Engine:
                 starts = np.nonzero(np.r_[True, lab_s[1:] != lab_s[:-1]])[0]
                 ends = np.r_[starts[1:], len(lab_s)]
                 comp_rank = np.minimum.reduceat(rank[mem_s], starts)
-                e_keep = np.nonzero(keep_edge)[0]
+                e_keep = np.nonzero(keep)[0]
                 e_lab = label[ea[e_keep]]
                 eo = np.argsort(e_lab, kind="stable")
                 e_lab_s = e_lab[eo]
                 e_starts = np.searchsorted(e_lab_s, lab_s[starts], side="left"); e_ends = np.searchsorted(e_lab_s, lab_s[starts], side="right")
                 P.update({"mem_s": mem_s, "starts": starts, "ends": ends, "comp_order": np.argsort(comp_rank, kind="stable"), "e_keep": e_keep,
                           "eo": eo, "e_starts": e_starts, "e_ends": e_ends, "ncomp": len(starts)})
-        # ---- first-appearance order keys of this chromosome's variants (rule 2): (BAM of first kept line, chromosome, line)
-        vf = R["var_first"]
-        seen = np.nonzero(vf >= 0)[0]
-        bam_of = np.zeros(len(seen), dtype=np.int64)
-        for b_, base, n in R["bam_offsets"]:
-            bam_of[(vf[seen] >= base) & (vf[seen] < base + n)] = b_
-        ko = np.lexsort((seen, vf[seen], bam_of))
-        P.update({"key_bam": bam_of[ko], "key_line": vf[seen][ko], "key_g": seen[ko], "chrom_index": chrom_index})
-        if not hasattr(self, "_pre"):
-            self._pre = {}
-        self._pre[c] = P
-        return frag
+            # ---- first-appearance order keys of this chromosome's variants (rule 2): (BAM of first kept line, chromosome, line)
+            vf = G["var_first"][v0:v0 + nv]
+            seen = np.nonzero(vf >= 0)[0]
+            bam_of = np.zeros(len(seen), dtype=np.int64)
+            for b_ in range(G["nb"]):
+                if (c, b_) in G["line_base"]:
+                    base, n = G["line_base"][(c, b_)]
+                    bam_of[(vf[seen] >= base) & (vf[seen] < base + n)] = b_
+            ko = np.lexsort((seen, vf[seen], bam_of))
+            P.update({"key_bam": bam_of[ko], "key_line": vf[seen][ko], "key_g": seen[ko], "chrom_index": self.all_chroms.index(c)})
+            self._pre[c] = P
+            frags[c] = frag
+        return frags
 
-    def _component_labels(self, c, ea, eb, keep_edge):
-        """Connected-component label per variant of the surviving graph, on the GPU (phz_components)."""
-        R = self.tally[c]; nv = R["nv"]; dev = R["dev"]
-        t_ea = torch.from_numpy(np.ascontiguousarray(ea)).to(dev); t_eb = torch.from_numpy(np.ascontiguousarray(eb)).to(dev)
-        t_keep = torch.from_numpy(keep_edge.astype(np.uint8)).to(dev)
-        label = torch.empty(max(1, nv), dtype=torch.int32, device=dev)
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
-        self.ctx.check(self.lib.phz_components(self.ctx.h, nv, len(ea), _p(t_ea), _p(t_eb), _p(t_keep), _p(label), R["space"]))
-        return label[:nv].cpu().numpy()
+    def _component_labels(self, keep_all):
+        """Connected-component label (smallest member) per variant of the surviving graph, on the GPU (phz_components), using the
+        edge list K_tally left in HBM."""
+        G = self.G; NV = G["nv"]
+        label = self._pinned("label", NV, np.int32)
+        if NV == 0:
+            return label
+        st = self.lib.phz_components(self.ctx.h, NV, len(keep_all), None, None, C.c_void_p(keep_all.ctypes.data) if len(keep_all) else None,
+                                     C.c_void_p(label.ctypes.data), _lib.PHZ_HOST)
+        self.ctx.check(st)
+        return label
 
 
 HEAD_ASE = ["contig", "start", "stop", "variants", "variantCount", "variantsBlacklisted", "variantCountBlacklisted", "haplotypeA",

@@ -23,16 +23,12 @@ def _vp(a):
     return C.c_void_p(a.ctypes.data) if isinstance(a, np.ndarray) else C.cast(C.c_char_p(a), C.c_void_p)
 
 
-def format_chrom(eng, c: str, threads: int) -> Dict:
-    """-> the chromosome's fragment fields produced by stage C2 (bytes row text, counts, write_vcf arrays)."""
-    import time as _t
-    t0 = _t.perf_counter()
-    lib = _lib.load()
+def _fill(eng, c: str, keep: list) -> "_lib.phz_rows_in":
+    """phz_rows_in of one chromosome: slices / views of the engine's genome-wide arrays (nothing is copied but small vectors)."""
     cfg = eng.cfg
-    P = eng._pre[c]; R = eng.tally[c]; cv = eng.vs.chroms[c]
-    nv = R["nv"]
+    P = eng._pre[c]; G = eng.G; cv = eng.vs.chroms[c]
+    nv = P["nv"]; v0 = P["v0"]; nb = G["nb"]
     pools = cv.pools()
-    keep = []                      # keeps every buffer alive across the call
 
     def A(x, dt):
         a = _arr(x, dt); keep.append(a); return _vp(a)
@@ -52,10 +48,9 @@ def format_chrom(eng, c: str, threads: int) -> Dict:
     if cfg.haplo_blacklist:
         bl = np.fromiter((c + "_" + str(int(p)) in cfg.haplo_blacklist for p in cv.pos), dtype=np.uint8, count=nv)
         I.blacklisted = A(bl, np.uint8)
-    I.var_count = A(R["var_count"], np.int32); I.var_distinct = A(R["var_distinct"], np.int32)
-    I.n_lines = len(R["line_cls"])
-    I.line_var = A(R["line_var"], np.int32); I.line_qid = A(R["line_qid"], np.int32); I.line_bam = A(R["line_bam"], np.int32)
-    I.line_cls = A(R["line_cls"], np.uint8)
+    I.var_count = A(G["var_count"][v0:v0 + nv], np.int32); I.var_distinct = A(G["var_distinct"][v0:v0 + nv], np.int32)
+    rs = G["rl_start"][2 * nb * v0: 2 * nb * (v0 + nv) + 1]          # this chromosome's entries; values index the whole rl_qid
+    I.rl_start = A(rs, np.uint32); I.rl_qid = A(G["rl_qid"], np.int32)
     I.n_edges = len(P["eorder"])
     I.va = A(P["va"], np.int32); I.vb = A(P["vb"], np.int32); I.ea = A(P["ea"], np.int32); I.eb = A(P["eb"], np.int32)
     for k in ("sup", "tot", "cis", "trans", "cfgv", "eorder"):
@@ -69,7 +64,6 @@ def format_chrom(eng, c: str, threads: int) -> Dict:
             setattr(I, k, A(P[src], np.int64))
     I.n_keys = len(P["key_g"])
     I.key_bam = A(P["key_bam"], np.int64); I.key_g = A(P["key_g"], np.int64)
-    nb = len(eng.bam_names)
     names = (C.c_char_p * nb)(*[b.encode() for b in eng.bam_names]); keep.append(names)
     I.nb = nb; I.bam_names = names
     if cfg.haplo_count_bam_exclude:
@@ -80,46 +74,68 @@ def format_chrom(eng, c: str, threads: int) -> Dict:
         I.bam_excluded = A(ex, np.uint8)
     I.unique_ids = int(cfg.unique_ids); I.gw_phase_method = int(cfg.gw_phase_method); I.output_read_ids = int(cfg.output_read_ids)
     I.unphased_vars = int(cfg.unphased_vars); I.max_block_size = int(cfg.max_block_size); I.want_vcf = 1 if cfg.want_vcf else 0
-    I.threads = max(1, int(threads))
+    I.threads = 1
     if cfg.output_read_ids == 1:
         from .vcf import sep_pool
         qoff, qb = sep_pool(list(eng.qnames[c]))
         I.qname_off = A(qoff, np.uint32); I.qname = B(qb)
-    O = _lib.phz_rows_out()
+    return I
+
+
+def format_chroms(eng, chroms, threads: int) -> Dict[str, Dict]:
+    """-> per chromosome the fragment fields produced by stage C2 (bytes row text, counts, write_vcf arrays).  All chromosomes go
+    through one native call (phz_rows_format_multi): their block / row chunks share one pool of `threads` workers."""
+    import time as _t
+    t0 = _t.perf_counter()
+    lib = _lib.load()
+    cfg = eng.cfg
+    n = len(chroms)
+    if n == 0:
+        return {}
+    keep = []                      # keeps every buffer alive across the call
+    IN = (_lib.phz_rows_in * n)(*[_fill(eng, c, keep) for c in chroms])
+    OUT = (_lib.phz_rows_out * n)()
     t1 = _t.perf_counter()
-    st = lib.phz_rows_format(C.byref(I), C.byref(O))
+    st = lib.phz_rows_format_multi(IN, n, OUT, max(1, int(threads)))
     eng.stats["rows_glue_s"] = eng.stats.get("rows_glue_s", 0.0) + t1 - t0
     eng.stats["rows_native_s"] = eng.stats.get("rows_native_s", 0.0) + _t.perf_counter() - t1
     if st != _lib.PHZ_OK:
-        raise _lib.PhzError(st, "phz_rows_format(%s): %s" % (c, lib.phz_strerror(st).decode()))
-    owner = _NativeRows(lib, O)
+        raise _lib.PhzError(st, "phz_rows_format_multi: %s" % lib.phz_strerror(st).decode())
+    nb = len(eng.bam_names)
+    res = {}
+    for i, c in enumerate(chroms):
+        O = OUT[i]
+        owner = _NativeRows(lib, O)
 
-    def seg(name):
-        p = getattr(O, name)
-        return [int(p[i]) for i in range(nb + 1)]
+        def seg(name, O=O):
+            p = getattr(O, name)
+            return [int(p[k]) for k in range(nb + 1)]
 
-    def vec(name, dt, n):
-        if n == 0:
-            return np.zeros(0, dtype=dt)
-        return np.frombuffer(C.string_at(getattr(O, name), n * np.dtype(dt).itemsize), dtype=dt).copy()
-    out = {"conn": owner.text("conn"), "hap": owner.text("hap"), "ase": owner.text("ase"), "cfg": owner.text("cfg"),
-           "allelic": owner.text("allelic"), "allelic_seg": seg("allelic_seg"), "allelic_rows": int(O.allelic_rows),
-           "single_ase": owner.text("single_ase"), "single_ase_seg": seg("single_ase_seg"),
-           "single_hap": owner.text("single_hap"), "single_hap_seg": seg("single_hap_seg"),
-           "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None}
-    if cfg.want_vcf:
-        nbk = int(O.n_blocks); nvv = int(O.n_blk_vars)
-        out["vcf"] = {"size": vec("blk_size", np.int32, nbk), "var": vec("blk_var", np.int32, nvv), "hap": vec("blk_hap", np.uint8, nvv),
-                      "cor": vec("blk_cor", np.int8, 2 * nvv), "stat": vec("blk_stat", np.float64, nbk),
-                      "stat_int": vec("blk_stat_int", np.uint8, nbk), "maxmaf": vec("blk_maxmaf", np.int32, nbk)}
-    return out
+        def vec(name, dt, cnt, O=O):
+            if cnt == 0:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(C.string_at(getattr(O, name), cnt * np.dtype(dt).itemsize), dtype=dt).copy()
+        out = {"conn": owner.text("conn"), "hap": owner.text("hap"), "ase": owner.text("ase"), "cfg": owner.text("cfg"),
+               "allelic": owner.text("allelic"), "allelic_seg": seg("allelic_seg"), "allelic_rows": int(O.allelic_rows),
+               "single_ase": owner.text("single_ase"), "single_ase_seg": seg("single_ase_seg"),
+               "single_hap": owner.text("single_hap"), "single_hap_seg": seg("single_hap_seg"),
+               "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None}
+        if cfg.want_vcf:
+            nbk = int(O.n_blocks); nvv = int(O.n_blk_vars)
+            out["vcf"] = {"size": vec("blk_size", np.int32, nbk), "var": vec("blk_var", np.int32, nvv), "hap": vec("blk_hap", np.uint8, nvv),
+                          "cor": vec("blk_cor", np.int8, 2 * nvv), "stat": vec("blk_stat", np.float64, nbk),
+                          "stat_int": vec("blk_stat_int", np.uint8, nbk), "maxmaf": vec("blk_maxmaf", np.int32, nbk)}
+        res[c] = out
+    return res
 
 
 class _NativeRows:
     """Owns one phz_rows_out: hands out zero-copy views of its text buffers and frees them when the last view dies."""
 
     def __init__(self, lib, O):
-        self.lib = lib; self.O = O
+        self.lib = lib
+        self.O = _lib.phz_rows_out()
+        C.memmove(C.byref(self.O), C.byref(O), C.sizeof(_lib.phz_rows_out))      # own copy of the descriptor (O lives in an array)
 
     def text(self, name):
         n = getattr(self.O, name + "_len")

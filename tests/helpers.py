@@ -152,3 +152,65 @@ def call_text(v, shard, calls, qname_prefix="q"):
     rs = v.rsid; gt = v.gt
     return "".join("%s%d\t%s\t%s\t%s\t%d\t%s\tNone\n" % (qname_prefix, q, uid[j], rs[j], names[c if c < 4 else 4], a, gt[j])
                    for q, j, c, a in zip(qid.tolist(), vi.tolist(), cd.tolist(), asc.tolist()))
+
+
+# ------------------------------------------------------------------ GPU stage results from fixtures (CPU-only host-stage tests)
+def genome_from_saved(saved, chrom_list, n_bams):
+    """tests/golden/tally/*.pkl.gz hold, per chromosome, what K_tally produced on an MI355X (per-variant counters, edges with their
+    nine cells, first-appearance ranks) plus the kept call lines.  Builds what Engine._tally_genome() returns for `chrom_list`:
+    the chromosomes' arrays concatenated into joint variant / line spaces and the per-(variant, allele, BAM) read lists as a CSR
+    (a stable grouping of the saved lines: what the device sort does)."""
+    nb = n_bams
+    var_base = {}; line_base = {}
+    NV = 0; L = 0
+    parts = {k: [] for k in ("var_count", "var_first", "var_distinct", "var_rank", "ea", "eb", "cells", "linked")}
+    keys = []; vals = []
+    for c in chrom_list:
+        R = saved["tally"][c]; nv = R["nv"]
+        var_base[c] = NV
+        n_lines = len(R["line_cls"])
+        for b, base, n in R["bam_offsets"]:
+            line_base[(c, b)] = (L + base, n)
+        parts["var_count"].append(R["var_count"].reshape(nv, 3)); parts["var_distinct"].append(R["var_distinct"].reshape(nv, 3))
+        vf = R["var_first"].astype(np.int64).copy(); vf[vf >= 0] += L
+        parts["var_first"].append(vf)
+        vr = R["var_rank"].astype(np.uint64).copy()
+        ok = vr != np.uint64(0xFFFFFFFFFFFFFFFF)
+        vr[ok] += np.uint64((L << 32) + L)
+        parts["var_rank"].append(vr)
+        parts["ea"].append(R["ea"].astype(np.int32) + NV); parts["eb"].append(R["eb"].astype(np.int32) + NV)
+        parts["cells"].append(R["cells"].reshape(-1, 9)); parts["linked"].append(R["linked"].astype(np.uint8))
+        cls = R["line_cls"]; sel = np.nonzero(cls < 2)[0]
+        keys.append(((R["line_var"][sel].astype(np.int64) + NV) * 2 + cls[sel]) * nb + R["line_bam"][sel])
+        vals.append(R["line_qid"][sel].astype(np.int32))
+        NV += nv; L += n_lines
+    cat = lambda xs, dt, shape=None: (np.concatenate(xs).astype(dt) if xs else np.zeros((0,) + (shape or ()), dt))
+    key = cat(keys, np.int64); val = cat(vals, np.int32)
+    order = np.argsort(key, kind="stable")
+    rl_start = np.zeros(NV * 2 * nb + 1, dtype=np.uint32)
+    np.cumsum(np.bincount(key, minlength=NV * 2 * nb), out=rl_start[1:])
+    vc = cat(parts["var_count"], np.int32).reshape(NV, 3)
+    return {"nv": NV, "nb": nb, "var_base": var_base, "line_base": line_base, "n_lines": L, "n_kept": int(vc.sum()), "var_count": vc,
+            "var_first": cat(parts["var_first"], np.int64), "var_distinct": cat(parts["var_distinct"], np.int32).reshape(NV, 3),
+            "var_rank": cat(parts["var_rank"], np.uint64), "ea": cat(parts["ea"], np.int32), "eb": cat(parts["eb"], np.int32),
+            "cells": cat(parts["cells"], np.int32).reshape(-1, 9), "linked": cat(parts["linked"], np.uint8), "rl_start": rl_start,
+            "rl_qid": val[order], "resident": False}
+
+
+def component_labels_cpu(G, keep_all):
+    """label[v] = smallest variant of v's connected component over the kept edges (what phz_components returns)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    nv = G["nv"]
+    k = np.nonzero(keep_all)[0]
+    g = coo_matrix((np.ones(len(k), np.int8), (G["ea"][k], G["eb"][k])), shape=(nv, nv))
+    _, comp = connected_components(g, directed=False)
+    first = np.full(comp.max() + 1 if nv else 0, nv, dtype=np.int64)
+    np.minimum.at(first, comp, np.arange(nv))
+    return first[comp].astype(np.int32)
+
+
+def stub_gpu_stages(eng, saved):
+    """Engine whose GPU stages (K_tally, components) answer from a fixture: the host stages run unchanged on CPU."""
+    eng._tally_genome = lambda: genome_from_saved(saved, eng.chrom_list, len(eng.bam_names))
+    eng._component_labels = lambda keep_all: component_labels_cpu(eng.G, keep_all)

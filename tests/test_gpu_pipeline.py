@@ -197,9 +197,9 @@ def test_full_size_pipeline_invariants(mapper):
     eng.add_shard(0, "chr1", shard, int(shard.qid.max()) + 1)
     eng.close_bam(0)
     out = eng.finish()
-    R = eng.tally["chr1"]
-    kept = int((R["line_cls"] != 255).sum())
-    assert int(R["var_count"].sum()) == kept == eng.total_lines and kept > 5_000_000
+    R = eng.chrom_view("chr1")
+    kept = R["kept"]
+    assert kept == eng.G["n_kept"] == eng.total_lines and kept > 5_000_000
     assert (R["var_distinct"] <= R["var_count"]).all()
     rows = lambda name: [l.split("\t") for l in out[name].split("\n")[1:] if l]
     # allelic_counts: one row per covered variant, distinct-read counts from the tally

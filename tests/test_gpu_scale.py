@@ -69,12 +69,10 @@ def check_invariants(eng, out, plan, n_bams):
     rows = lambda name: [l.split("\t") for l in out[name].split("\n")[1:] if l]
     kept = 0
     for chrom, *_ in plan:
-        R = eng.tally[chrom]
-        k = int((R["line_cls"] != 255).sum())
-        assert int(R["var_count"].sum()) == k
+        R = eng.chrom_view(chrom)
         assert (R["var_distinct"] <= R["var_count"]).all()
-        kept += k
-    assert kept == eng.total_lines
+        kept += R["kept"]
+    assert kept == eng.total_lines == eng.G["n_kept"]
     order = {p[0]: i for i, p in enumerate(plan)}
     al = rows("allelic_counts")
     assert all(int(r[5]) + int(r[6]) == int(r[7]) for r in al)
@@ -83,7 +81,7 @@ def check_invariants(eng, out, plan, n_bams):
     drops = sum(1 for x, y in zip(seq, seq[1:]) if y < x)
     assert drops <= n_bams - 1
     for chrom in (plan[0][0], plan[-1][0]):
-        R = eng.tally[chrom]
+        R = eng.chrom_view(chrom)
         idx = {u: i for i, u in enumerate(eng.vs.chroms[chrom].uid)}
         for r in [x for x in al if x[0] == chrom][::211]:
             i = idx[r[2]]
@@ -104,7 +102,7 @@ def check_invariants(eng, out, plan, n_bams):
         assert len(la) == int(r[9]) and len(lb) == int(r[10])
     conn = rows("variant_connections")
     assert all(int(r[2]) <= int(r[3]) for r in conn)
-    assert len(conn) == sum(int(eng.tally[p[0]]["linked"].sum()) for p in plan)
+    assert len(conn) == int(eng.G["linked"].sum())
 
 
 def check_replica_vs_oracle(mapper, plan_small, n_bams, min_phased=1000):

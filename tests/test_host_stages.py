@@ -10,7 +10,7 @@ import sys
 import pytest
 
 from conftest import GOLD, REPO, gz_text
-from helpers import OUTPUTS, canonical, option_case_kwargs
+from helpers import OUTPUTS, canonical, option_case_kwargs, stub_gpu_stages
 
 
 def _cases():
@@ -41,8 +41,7 @@ def run_host_stages(case, load, cfg, vcf_text, bam_names, host_threads=1):
         device = None
     eng = Engine(vs, bam_names, Config(include_indels=inc, host_threads=host_threads, **cfg), mapper=_M())
     eng.n_qid.update(saved["n_qid"]); eng.qnames.update(saved["qnames"])
-    eng._tally_chrom = lambda c: saved["tally"][c]
-    eng._component_labels = lambda c, ea, eb, keep: saved["labels"][c]
+    stub_gpu_stages(eng, saved)
     return eng.finish(), eng
 
 
