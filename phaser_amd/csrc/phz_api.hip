@@ -55,7 +55,10 @@ int phz_ctx_destroy(phz_ctx *c) {
     for (DevBuf &b : c->scratch) free_buf(b);
     for (DevBuf &b : c->stage_pool) free_buf(b);
     for (DevBuf &b : c->tally_buf) free_buf(b);
+    free_buf(c->tally_qcount);
     if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
+    if (c->h_shard_tab.p) (void)hipHostFree(c->h_shard_tab.p);
+    free_buf(c->shard_tab);
     for (hipEvent_t e : c->map_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);

@@ -26,6 +26,7 @@ struct phz_ctx {
     // scratch
     DevBuf desc, tile_w0, scalars;
     DevBuf h_scalars;                  // pinned host mirror of `scalars` (hipHostMalloc)
+    DevBuf shard_tab, h_shard_tab;     // shard table of a batched K_map submission (device / pinned host image)
     std::vector<hipEvent_t> map_ev;    // event pairs around every k_map launch of a batch
     // staging for PHZ_HOST callers
     DevBuf r_pos, r_coff, r_cig, r_soff, r_seq, r_qual, v_pos, v_reflen;
@@ -36,6 +37,8 @@ struct phz_ctx {
     // steady state allocates nothing
     std::vector<DevBuf> stage_pool;
     std::vector<DevBuf> tally_buf;     // result + read-list buffers of phz_tally
+    bool tally_dirty = false;
+    DevBuf tally_qcount;               // lines per QNAME: all zero between phz_tally calls (never shared with other stages)
     // results of the last phz_tally, resident in HBM until the next one (phz_tally_fetch / phz_components read them)
     struct {
         int64_t nv = 0, n_lines = 0, n_kept = 0, n_edges = 0, n_rl = 0;

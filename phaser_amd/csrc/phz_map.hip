@@ -54,6 +54,43 @@ struct MapArgs {
     int dbg;          // ablation switches for profiling (PHZ_MAP_DBG env); 0 in production
 };
 
+// one shard of a batch; the array lives in device memory for the duration of the launches
+struct ShardDev {
+    const int32_t *pos;
+    const uint32_t *cigar_off, *cigar, *seq_off;
+    const uint8_t *seq2, *qual;
+    int64_t n;
+    const int32_t *vpos;
+    int nv, pad;
+    int32_t *o_read, *o_var;          // final (dense, mapper-order) outputs of the shard
+    uint8_t *o_code;
+    uint32_t *o_aux0, *o_aux1;
+    int64_t cap;
+};
+
+// all shards of one submission share ONE grid: global tile T belongs to the shard s with tile0[s] <= T < tile0[s+1]
+struct MapBatch {
+    const ShardDev *shards;
+    const int64_t *tile0;         // [n_shards + 1]
+    int n_shards, baseq;
+    int32_t *s_read, *s_var;      // staging slots: global tile T owns [T*slot_cap, (T+1)*slot_cap)
+    uint8_t *s_code;
+    uint32_t *s_aux0, *s_aux1;
+    int32_t *tile_w0;             // [4*ntiles]
+    int32_t *tile_total;          // [ntiles]
+    int slot_cap, dbg;
+    int64_t ntiles;
+};
+
+__device__ __forceinline__ int shard_of(const int64_t *tile0, int n_shards, int64_t T) {
+    int lo = 0, hi = n_shards - 1;          // largest s with tile0[s] <= T
+    while (lo < hi) {
+        const int m = (lo + hi + 1) >> 1;
+        if (tile0[m] <= T) lo = m; else hi = m - 1;
+    }
+    return lo;
+}
+
 struct VarWin {
     const int32_t *g;
     const int32_t *lds;
@@ -201,10 +238,15 @@ constexpr int MAP_SLACK = 64;      // ... plus this many further entries (probe 
 
 // per-tile het-SNP window: start = lower_bound(vpos, POS of the tile's first read); tile_w[4t+1] = staged length,
 // bit 30 set when the window is complete (not truncated by MAP_WIN), which enables the LDS-only fast path
-__global__ void k_tile_window(const int32_t *pos, const uint32_t *cigar_off, int64_t n, const int32_t *vpos, int nv, int32_t *tile_w,
-                              int64_t ntiles, int tile_reads) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles) return;
+__global__ void k_tile_window(MapBatch bt, int tile_reads) {
+    const int64_t T = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (T >= bt.ntiles) return;
+    const int si = shard_of(bt.tile0, bt.n_shards, T);
+    const ShardDev &sh = bt.shards[si];
+    const int64_t t = T - bt.tile0[si];
+    const int32_t *pos = sh.pos; const uint32_t *cigar_off = sh.cigar_off; const int32_t *vpos = sh.vpos;
+    const int nv = sh.nv; const int64_t n = sh.n;
+    int32_t *tile_w = bt.tile_w0;
     const int key = pos[t * tile_reads];
     int lo = 0, hi = nv;
     while (lo < hi) {
@@ -221,10 +263,10 @@ __global__ void k_tile_window(const int32_t *pos, const uint32_t *cigar_off, int
     int len = lo2 - lo + MAP_SLACK;
     int complete = 1 << 30;
     if (len > MAP_WIN) { len = MAP_WIN; complete = 0; }
-    tile_w[4 * t] = lo;
-    tile_w[4 * t + 1] = len | complete;
-    tile_w[4 * t + 2] = (int32_t)cigar_off[t * tile_reads];            // first CIGAR word of the tile
-    tile_w[4 * t + 3] = (int32_t)(cigar_off[last + 1] - cigar_off[t * tile_reads]);
+    tile_w[4 * T] = lo;
+    tile_w[4 * T + 1] = len | complete;
+    tile_w[4 * T + 2] = (int32_t)cigar_off[t * tile_reads];            // first CIGAR word of the tile
+    tile_w[4 * T + 3] = (int32_t)(cigar_off[last + 1] - cigar_off[t * tile_reads]);
 }
 
 // block-wide exclusive scan of RPT per-thread values laid out at [k*MAP_BLOCK + tid]; returns the block total
@@ -259,7 +301,17 @@ __device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT
 }
 
 template <int MAP_BLOCK, int RPT>
-__global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
+__global__ __launch_bounds__(MAP_BLOCK) void k_map(MapBatch bt) {
+    const int64_t gtile = blockIdx.x;
+    const int si = shard_of(bt.tile0, bt.n_shards, gtile);
+    MapArgs a;
+    {
+        const ShardDev &sh = bt.shards[si];
+        a.pos = sh.pos; a.cigar_off = sh.cigar_off; a.cigar = sh.cigar; a.seq_off = sh.seq_off; a.seq2 = sh.seq2; a.qual = sh.qual;
+        a.n = sh.n; a.vpos = sh.vpos; a.nv = sh.nv; a.baseq = bt.baseq;
+        a.o_read = bt.s_read; a.o_var = bt.s_var; a.o_code = bt.s_code; a.o_aux0 = bt.s_aux0; a.o_aux1 = bt.s_aux1;
+        a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = bt.dbg;
+    }
     constexpr int TILE = MAP_BLOCK * RPT;
     constexpr int CIG = TILE * 5 / 2;          // packed CIGAR words staged per tile (max)
     constexpr int CAND = TILE * 3 / 4;         // candidate buffer entries (complex records only)
@@ -278,7 +330,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
     __shared__ int s_ncand, s_ncx;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t tile = blockIdx.x;
+    const int64_t tile = gtile - bt.tile0[si];          // tile index inside the shard
     const int64_t r0 = tile * TILE;
     const int nr = (int)((a.n - r0) < TILE ? (a.n - r0) : TILE);
 
@@ -296,7 +348,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
     }
     if (tid == 0) { s_coff[TILE] = a.cigar_off[r0 + nr]; s_ncand = 0; s_ncx = 0; }
     VarWin vw;
-    const int4 tw = *reinterpret_cast<const int4 *>(a.tile_w0 + 4 * tile);
+    const int4 tw = *reinterpret_cast<const int4 *>(a.tile_w0 + 4 * gtile);
     vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = tw.x;
     vw.wlen = tw.y & 0xFFFF;
     const bool complete = (tw.y >> 30) & 1;
@@ -418,7 +470,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
     __syncthreads();
     const int ncand = s_ncand;
     const bool fb = ncand > CAND;              // candidate buffer overflow: complex records fall back to in-lane work
-    const int64_t slot0 = tile * (int64_t)a.slot_cap;
+    const int64_t slot0 = gtile * (int64_t)a.slot_cap;
     int cnt[RPT], off[RPT];
     if (!fb) {
         // ---- phase 2b: resolve the buffered candidates with all lanes gathering at once
@@ -454,7 +506,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapArgs a) {
     const int T = block_scan<MAP_BLOCK, RPT>(cnt, off, s_wsum, lane, wave);
 #pragma unroll
     for (int k = 0; k < RPT; k++) s_coff[k * MAP_BLOCK + tid] = (uint32_t)off[k];
-    if (tid == 0) a.tile_total[tile] = T;
+    if (tid == 0) a.tile_total[gtile] = T;
     __syncthreads();
     if (a.dbg & 2) return;
     // ---- phase 4: ordered flush into the tile's staging slot
@@ -569,43 +621,102 @@ __global__ __launch_bounds__(1024) void k_chunk_base(const int64_t *chunk_sum, c
 
 struct CompactArgs {
     const int32_t *s_read, *s_var; const uint8_t *s_code; const uint32_t *s_aux0, *s_aux1;
-    int32_t *o_read, *o_var; uint8_t *o_code; uint32_t *o_aux0, *o_aux1;
-    const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base;
-    int slot_cap; int64_t cap; int64_t ntiles;
+    const ShardDev *shards; const int64_t *tile0; int n_shards;
+    const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base; const int64_t *shard_base;
+    int slot_cap; int64_t ntiles;
 };
 
-// one wave per tile: copy the tile's slot to its final offset
+// calls before global tile T over all shards (T < ntiles)
+__device__ __forceinline__ int64_t calls_before(const int64_t *chunk_base, const int32_t *tile_pref, int64_t T) {
+    return chunk_base[T >> 10] + tile_pref[T];
+}
+
+// per shard: offset of its first call in the batch-wide numbering and its number of calls -> scal[2 + s] (scal[0] total, [1] max tile)
+__global__ void k_shard_totals(const int64_t *tile0, int n_shards, int64_t ntiles, const int32_t *tile_pref, const int64_t *chunk_base,
+                               unsigned long long *scal, int64_t *shard_base) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_shards) return;
+    const int64_t a = tile0[s], b = tile0[s + 1];
+    const int64_t lo = a < ntiles ? calls_before(chunk_base, tile_pref, a) : (int64_t)scal[0];
+    const int64_t hi = b < ntiles ? calls_before(chunk_base, tile_pref, b) : (int64_t)scal[0];
+    shard_base[s] = lo;
+    scal[2 + s] = (unsigned long long)(hi - lo);
+}
+
+// one wave per tile: copy the tile's slot to its final offset in its shard's output
 __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= c.ntiles) return;
+    const int64_t T = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (T >= c.ntiles) return;
     const int lane = threadIdx.x & 63;
-    int n = c.tile_total[tile];
+    int n = c.tile_total[T];
+    if (n == 0) return;
     if (n > c.slot_cap) n = c.slot_cap;
-    const int64_t src = tile * (int64_t)c.slot_cap, dst = c.chunk_base[tile >> 10] + c.tile_pref[tile];
+    const int si = shard_of(c.tile0, c.n_shards, T);
+    const ShardDev &sh = c.shards[si];
+    const int64_t src = T * (int64_t)c.slot_cap, dst = calls_before(c.chunk_base, c.tile_pref, T) - c.shard_base[si];
     for (int e = lane; e < n; e += 64) {
         const int64_t o = dst + e;
-        if (o < c.cap) {
-            c.o_read[o] = c.s_read[src + e];
-            c.o_var[o] = c.s_var[src + e];
-            c.o_code[o] = c.s_code[src + e];
-            c.o_aux0[o] = c.s_aux0[src + e];
-            c.o_aux1[o] = c.s_aux1[src + e];
+        if (o < sh.cap) {
+            sh.o_read[o] = c.s_read[src + e];
+            sh.o_var[o] = c.s_var[src + e];
+            sh.o_code[o] = c.s_code[src + e];
+            sh.o_aux0[o] = c.s_aux0[src + e];
+            sh.o_aux1[o] = c.s_aux1[src + e];
         }
     }
 }
 
 }  // namespace
 
-// Enqueue one shard's kernels on the ctx stream without waiting: pre-pass, k_map, tile scan, compaction.  The two result
-// scalars (total calls, largest tile) land in ctx->scalars[2*slot .. 2*slot+1]; HIP events ctx->map_ev[2*slot..] bracket k_map.
-static int map_enqueue(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, int baseq, const phz_calls &out, int slot) {
+// All shards of a submission run through ONE grid per stage (pre-pass, k_map, tile scan, per-shard totals, compaction): a whole
+// genome is 5 launches and one host wait, with no per-shard ramp-up / tail.  A batch whose densest tile overflows its staging slot
+// is redone with larger slots (rare: the slot capacity is kept across calls).
+int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out,
+                         int64_t *n_calls) {
+    for (int i = 0; i < n; i++) n_calls[i] = 0;
+    if (n <= 0) return PHZ_OK;
     int rpt = 2, blk = 128;
     { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) > 0) rpt = atoi(e); }
     { const char *e = getenv("PHZ_MAP_BLOCK"); if (e && atoi(e) > 0) blk = atoi(e); }
     if (!((blk == 64 || blk == 128 || blk == 256) && (rpt == 2 || rpt == 4))) return phz_fail(ctx, PHZ_E_ARG, "bad PHZ_MAP_BLOCK / PHZ_MAP_RPT");
     const int tile_reads = blk * rpt;
-    const int64_t ntiles = (r.n_reads + tile_reads - 1) / tile_reads;
-    DevBuf *S = ctx->scratch;      // 17..23: tile_total, tile_base, staged read/var/code/aux0/aux1
+    // live shards (records and variants present) and their tile ranges
+    std::vector<int> live;
+    for (int i = 0; i < n; i++) {
+        if (v[i].n > 0x7fffffff) return phz_fail(ctx, PHZ_E_ARG, "too many variants in one shard");
+        if (r[i].n_reads > 0 && v[i].n > 0) live.push_back(i);
+    }
+    const int m = (int)live.size();
+    if (m == 0) return PHZ_OK;
+    // host image of the shard table: [ShardDev x m][tile0 x (m+1)], pinned; device copy in ctx->shard_tab
+    const size_t tab_bytes = (size_t)m * sizeof(ShardDev) + (size_t)(m + 1) * 8;
+    if (int s = phz_reserve_host(ctx, ctx->h_shard_tab, tab_bytes)) return s;
+    if (int s = phz_reserve(ctx, ctx->shard_tab, tab_bytes + (size_t)m * 8)) return s;
+    ShardDev *hs = (ShardDev *)ctx->h_shard_tab.p;
+    int64_t *ht0 = (int64_t *)((char *)ctx->h_shard_tab.p + (size_t)m * sizeof(ShardDev));
+    int64_t ntiles = 0;
+    for (int k = 0; k < m; k++) {
+        const int i = live[(size_t)k];
+        ShardDev &d = hs[k];
+        d.pos = r[i].pos; d.cigar_off = r[i].cigar_off; d.cigar = r[i].cigar; d.seq_off = r[i].seq_off; d.seq2 = r[i].seq2; d.qual = r[i].qual;
+        d.n = r[i].n_reads; d.vpos = v[i].pos; d.nv = (int)v[i].n; d.pad = 0;
+        d.o_read = out[i].read_idx; d.o_var = out[i].var_idx; d.o_code = out[i].code; d.o_aux0 = out[i].aux0; d.o_aux1 = out[i].aux1;
+        d.cap = out[i].cap;
+        ht0[k] = ntiles;
+        ntiles += (r[i].n_reads + tile_reads - 1) / tile_reads;
+    }
+    ht0[m] = ntiles;
+    if (ntiles >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "too many tiles in one submission");
+    const ShardDev *d_shards = (const ShardDev *)ctx->shard_tab.p;
+    const int64_t *d_tile0 = (const int64_t *)((char *)ctx->shard_tab.p + (size_t)m * sizeof(ShardDev));
+    int64_t *d_shard_base = (int64_t *)((char *)ctx->shard_tab.p + tab_bytes);
+    hipStream_t sm = ctx->stream;
+    PHZ_HIP(ctx, hipMemcpyAsync(ctx->shard_tab.p, ctx->h_shard_tab.p, tab_bytes, hipMemcpyHostToDevice, sm));
+    if ((int)ctx->map_ev.size() < 2) {
+        ctx->map_ev.resize(2, nullptr);
+        for (auto &e : ctx->map_ev) if (!e) PHZ_HIP(ctx, hipEventCreate(&e));
+    }
+    DevBuf *S = ctx->scratch;      // 17..22: tile_total, staged read/var/code/aux0/aux1
     if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 16)) return s;
     if (int s = phz_reserve(ctx, S[17], (size_t)ntiles * 4)) return s;
     const int nchunks = (int)((ntiles + 1023) / 1024);
@@ -614,116 +725,66 @@ static int map_enqueue(phz_ctx *ctx, const phz_reads &r, const phz_variants &v, 
     int64_t *chunk_sum = (int64_t *)((char *)ctx->desc.p + (((size_t)ntiles * 4 + 15) & ~(size_t)15));
     int64_t *chunk_base = chunk_sum + nchunks;
     int32_t *chunk_max = (int32_t *)(chunk_base + nchunks);
-    if (ctx->map_slot_cap <= 0 || ctx->map_tile_reads != tile_reads) { ctx->map_slot_cap = tile_reads / 2 < 64 ? 64 : tile_reads / 2; ctx->map_tile_reads = tile_reads; }
-    hipStream_t sm = ctx->stream;
-    hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm,
-                       r.pos, r.cigar_off, r.n_reads, v.pos, (int)v.n, (int32_t *)ctx->tile_w0.p, ntiles, tile_reads);
-    const int slot_cap = ctx->map_slot_cap;
-    const size_t slots = (size_t)ntiles * (size_t)slot_cap;
-    if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
-    if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
-    if (int s = phz_reserve(ctx, S[20], slots)) return s;
-    if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
-    if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
-    MapArgs a;
-    a.pos = r.pos; a.cigar_off = r.cigar_off; a.cigar = r.cigar; a.seq_off = r.seq_off; a.seq2 = r.seq2; a.qual = r.qual;
-    a.n = r.n_reads; a.vpos = v.pos; a.nv = (int)v.n; a.baseq = baseq;
-    a.o_read = (int32_t *)S[18].p; a.o_var = (int32_t *)S[19].p; a.o_code = (uint8_t *)S[20].p;
-    a.o_aux0 = (uint32_t *)S[21].p; a.o_aux1 = (uint32_t *)S[22].p;
-    a.tile_w0 = (const int32_t *)ctx->tile_w0.p;
-    a.tile_total = (int32_t *)S[17].p;
-    a.slot_cap = slot_cap;
-    a.ntiles = ntiles;
-    { const char *e = getenv("PHZ_MAP_DBG"); a.dbg = e ? atoi(e) : 0; }
-    PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[2 * slot], sm));
-#define PHZ_LAUNCH_MAP(B, R) hipLaunchKernelGGL((k_map<B, R>), dim3((unsigned)ntiles), dim3(B), 0, sm, a)
-    if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
-    else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
-    else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
-    else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
-    else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
-    else PHZ_LAUNCH_MAP(256, 4);
-#undef PHZ_LAUNCH_MAP
-    PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[2 * slot + 1], sm));
-    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
-                       chunk_max);
-    hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(1024), 0, sm, (const int64_t *)chunk_sum, (const int32_t *)chunk_max, nchunks, chunk_base,
-                       (unsigned long long *)ctx->scalars.p + 2 * slot);
-    CompactArgs c;
-    c.s_read = a.o_read; c.s_var = a.o_var; c.s_code = a.o_code; c.s_aux0 = a.o_aux0; c.s_aux1 = a.o_aux1;
-    c.o_read = out.read_idx; c.o_var = out.var_idx; c.o_code = out.code; c.o_aux0 = out.aux0; c.o_aux1 = out.aux1;
-    c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base;
-    c.slot_cap = slot_cap; c.cap = out.cap; c.ntiles = ntiles;
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
-    PHZ_HIP(ctx, hipGetLastError());
-    return PHZ_OK;
-}
-
-// n shards submitted back to back, ONE host wait: scratch is sized for the largest shard up front (growing a buffer while
-// kernels are in flight would free memory under them), results come back in one small copy.  A shard whose densest tile
-// overflowed its staging slot is redone alone with larger slots.
-int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out,
-                         int64_t *n_calls) {
-    for (int i = 0; i < n; i++) n_calls[i] = 0;
-    if (n <= 0) return PHZ_OK;
-    for (int i = 0; i < n; i++)
-        if (v[i].n > 0x7fffffff) return phz_fail(ctx, PHZ_E_ARG, "too many variants in one shard");
-    if ((int)ctx->map_ev.size() < 2 * n) {
-        const size_t old = ctx->map_ev.size();
-        ctx->map_ev.resize((size_t)2 * n, nullptr);
-        for (size_t k = old; k < ctx->map_ev.size(); k++) PHZ_HIP(ctx, hipEventCreate(&ctx->map_ev[k]));
-    }
-    if (int s = phz_reserve(ctx, ctx->scalars, (size_t)16 * n + 64)) return s;
-    if (int s = phz_reserve_host(ctx, ctx->h_scalars, (size_t)16 * n + 64)) return s;
+    if (int s = phz_reserve(ctx, ctx->scalars, (size_t)8 * (m + 2) + 64)) return s;
+    if (int s = phz_reserve_host(ctx, ctx->h_scalars, (size_t)8 * (m + 2) + 64)) return s;
     unsigned long long *scal = (unsigned long long *)ctx->h_scalars.p;
+    if (ctx->map_slot_cap <= 0 || ctx->map_tile_reads != tile_reads) { ctx->map_slot_cap = tile_reads / 2 < 64 ? 64 : tile_reads / 2; ctx->map_tile_reads = tile_reads; }
     float ms_total = 0;
-    std::vector<int> todo;
-    for (int i = 0; i < n; i++) if (r[i].n_reads > 0 && v[i].n > 0) todo.push_back(i);
-    for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++) {
-        // size the shared scratch for the largest pending shard before anything is enqueued
-        int big = todo[0];
-        for (int i : todo) if (r[i].n_reads > r[big].n_reads) big = i;
-        {
-            // dry reservation: same sizes map_enqueue will ask for
-            int rpt = 2, blk = 128;
-            { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) > 0) rpt = atoi(e); }
-            { const char *e = getenv("PHZ_MAP_BLOCK"); if (e && atoi(e) > 0) blk = atoi(e); }
-            const int tile_reads = blk * rpt;
-            if (ctx->map_slot_cap <= 0 || ctx->map_tile_reads != tile_reads) { ctx->map_slot_cap = tile_reads / 2 < 64 ? 64 : tile_reads / 2; ctx->map_tile_reads = tile_reads; }
-            const int64_t ntiles = (r[big].n_reads + tile_reads - 1) / tile_reads;
-            const size_t slots = (size_t)ntiles * (size_t)ctx->map_slot_cap;
-            DevBuf *S = ctx->scratch;
-            const int nchunks = (int)((ntiles + 1023) / 1024);
-            if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 16)) return s;
-            if (int s = phz_reserve(ctx, S[17], (size_t)ntiles * 4)) return s;
-            if (int s = phz_reserve(ctx, ctx->desc, (size_t)ntiles * 4 + (size_t)nchunks * 24 + 64)) return s;
-            if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
-            if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
-            if (int s = phz_reserve(ctx, S[20], slots)) return s;
-            if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
-            if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
-        }
-        for (int i : todo) if (int s = map_enqueue(ctx, r[i], v[i], baseq, out[i], i)) return s;
-        PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)16 * n, hipMemcpyDeviceToHost, ctx->stream));
-        PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        std::vector<int> again;
-        unsigned long long need = 0;
-        for (int i : todo) {
-            float ms = 0;
-            PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->map_ev[2 * i], ctx->map_ev[2 * i + 1]));
-            ms_total += ms;
-            if ((int64_t)scal[2 * i + 1] > ctx->map_slot_cap) { again.push_back(i); need = scal[2 * i + 1] > need ? scal[2 * i + 1] : need; }
-            else n_calls[i] = (int64_t)scal[2 * i];
-        }
-        if (!again.empty()) {
-            if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging slots did not converge");
-            ctx->map_slot_cap = (int)((need + 63) / 64 * 64);      // grow the slots to the exact maximum and redo those shards
-        }
-        todo.swap(again);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const int slot_cap = ctx->map_slot_cap;
+        const size_t slots = (size_t)ntiles * (size_t)slot_cap;
+        if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
+        if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
+        if (int s = phz_reserve(ctx, S[20], slots)) return s;
+        if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
+        if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
+        MapBatch bt;
+        bt.shards = d_shards; bt.tile0 = d_tile0; bt.n_shards = m; bt.baseq = baseq;
+        bt.s_read = (int32_t *)S[18].p; bt.s_var = (int32_t *)S[19].p; bt.s_code = (uint8_t *)S[20].p;
+        bt.s_aux0 = (uint32_t *)S[21].p; bt.s_aux1 = (uint32_t *)S[22].p;
+        bt.tile_w0 = (int32_t *)ctx->tile_w0.p; bt.tile_total = (int32_t *)S[17].p;
+        bt.slot_cap = slot_cap; bt.ntiles = ntiles;
+        { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
+        hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm, bt, tile_reads);
+        PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[0], sm));
+#define PHZ_LAUNCH_MAP(B, R) hipLaunchKernelGGL((k_map<B, R>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt)
+        if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
+        else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
+        else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
+        else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
+        else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
+        else PHZ_LAUNCH_MAP(256, 4);
+#undef PHZ_LAUNCH_MAP
+        PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[1], sm));
+        hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
+                           chunk_max);
+        hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(1024), 0, sm, (const int64_t *)chunk_sum, (const int32_t *)chunk_max, nchunks, chunk_base,
+                           (unsigned long long *)ctx->scalars.p);
+        hipLaunchKernelGGL(k_shard_totals, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, sm, d_tile0, m, ntiles, (const int32_t *)tile_pref,
+                           (const int64_t *)chunk_base, (unsigned long long *)ctx->scalars.p, d_shard_base);
+        CompactArgs c;
+        c.s_read = bt.s_read; c.s_var = bt.s_var; c.s_code = bt.s_code; c.s_aux0 = bt.s_aux0; c.s_aux1 = bt.s_aux1;
+        c.shards = d_shards; c.tile0 = d_tile0; c.n_shards = m;
+        c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base; c.shard_base = d_shard_base;
+        c.slot_cap = slot_cap; c.ntiles = ntiles;
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
+        PHZ_HIP(ctx, hipGetLastError());
+        PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)8 * (m + 2), hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));
+        float ms = 0;
+        PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->map_ev[0], ctx->map_ev[1]));
+        ms_total += ms;
+        if ((int64_t)scal[1] <= slot_cap) break;
+        if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging slots did not converge");
+        ctx->map_slot_cap = (int)((scal[1] + 63) / 64 * 64);      // grow the slots to the exact maximum and redo the batch
     }
-    ctx->last_ms[PHZ_T_MAP] = ms_total; ctx->total_ms[PHZ_T_MAP] += ms_total; ctx->launches[PHZ_T_MAP] += n;
+    ctx->last_ms[PHZ_T_MAP] = ms_total; ctx->total_ms[PHZ_T_MAP] += ms_total; ctx->launches[PHZ_T_MAP]++;
     int st = PHZ_OK;
-    for (int i = 0; i < n; i++) if (n_calls[i] > out[i].cap) st = PHZ_E_CAPACITY;
+    for (int k = 0; k < m; k++) {
+        const int i = live[(size_t)k];
+        n_calls[i] = (int64_t)scal[2 + k];
+        if (n_calls[i] > out[i].cap) st = PHZ_E_CAPACITY;
+    }
     return st;
 }
 

@@ -638,10 +638,12 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     if (int s = phz_reserve(ctx, S[T_COUNTERS], 64)) return s;
     if (int s = phz_reserve(ctx, S[T_DEG], NV * 4)) return s;
     if (int s = phz_reserve(ctx, S[T_EOFF], (NV + 1) * 4)) return s;
-    {   // qcount must start at zero; k_items counts it back to zero, so the array is cleared only when (re)allocated
-        const size_t before = S[T_QCOUNT].cap;
-        if (int s = phz_reserve(ctx, S[T_QCOUNT], NQ * 4)) return s;
-        if (S[T_QCOUNT].cap != before) PHZ_HIP(ctx, hipMemsetAsync(S[T_QCOUNT].p, 0, S[T_QCOUNT].cap, ctx->stream));
+    {   // qcount must start at zero; k_items counts it back to zero, so the array (owned by the tally alone) is cleared only
+        // when it is (re)allocated -- or after a call that failed half way
+        const size_t before = ctx->tally_qcount.cap;
+        if (int s = phz_reserve(ctx, ctx->tally_qcount, NQ * 4)) return s;
+        if (ctx->tally_qcount.cap != before || ctx->tally_dirty) PHZ_HIP(ctx, hipMemsetAsync(ctx->tally_qcount.p, 0, ctx->tally_qcount.cap, ctx->stream));
+        ctx->tally_dirty = true;           // cleared again when the call completes
     }
     int32_t *d_cnt = (int32_t *)R[R_CNT].p, *d_dist = (int32_t *)R[R_DIST].p;
     unsigned long long *d_first = (unsigned long long *)R[R_FIRST].p, *d_rank = (unsigned long long *)R[R_RANK].p;
@@ -652,7 +654,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     int32_t *qid_owner = (int32_t *)S[T_QOWN].p;
     uint32_t *qid_first = (uint32_t *)S[T_QFIRST].p, *qid_vmin = qid_first + NQ;
     int32_t *qid_vmax = (int32_t *)(qid_vmin + NQ);
-    uint32_t *qcount = (uint32_t *)S[T_QCOUNT].p, *qoff = (uint32_t *)S[T_QOFF].p;
+    uint32_t *qcount = (uint32_t *)ctx->tally_qcount.p, *qoff = (uint32_t *)S[T_QOFF].p;
     uint64_t *items = (uint64_t *)S[T_ITEMS].p;
     unsigned long long *counters = (unsigned long long *)S[T_COUNTERS].p;      // 0 items, 1 events, 2 overflow, 3 kept lines
     uint32_t *deg = (uint32_t *)S[T_DEG].p, *eoff = (uint32_t *)S[T_EOFF].p;
@@ -742,6 +744,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = timer.stop()) return s;
+    ctx->tally_dirty = false;
     auto &T = ctx->tally;
     T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = (int64_t)h_counters[3]; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
     T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;

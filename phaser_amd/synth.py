@@ -180,9 +180,10 @@ def make_read_plan(v: Variants, gstart, gend, weight, n_pairs: int, seed: int, L
     dev = torch.device(device)
     g = torch.Generator(device=dev).manual_seed(seed)
     rnd = lambda *shape: torch.rand(*shape, generator=g, device=dev)
+    prob = (weight / weight.sum()).to(dev)          # normalised on the host: a device-side sum may differ in the last bit run to run
     gstart = gstart.to(dev); gend = gend.to(dev); weight = weight.to(dev)
     n = 2 * n_pairs
-    gene = torch.multinomial(weight / weight.sum(), n_pairs, replacement=True, generator=g)
+    gene = torch.multinomial(prob, n_pairs, replacement=True, generator=g)
     frag_start = gstart[gene] - L + (rnd(n_pairs).double() * (gend[gene] - gstart[gene] + L).double()).to(torch.int64)
     frag_start = torch.clamp(frag_start, min=1)
     tl = torch.clamp((torch.randn(n_pairs, generator=g, device=dev) * 60 + 250).to(torch.int64), min=L)
