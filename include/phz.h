@@ -307,6 +307,19 @@ typedef struct {
     const uint8_t *bam_excluded;  /* [nb], may be NULL */
     int32_t unique_ids, gw_phase_method, output_read_ids, unphased_vars, max_block_size, want_vcf, threads;
     const uint32_t *qname_off;  const char *qname;     /* QNAME per template id; only read when output_read_ids == 1 */
+    /* raw != 0: the ordering stage runs inside the library.  Then ea / eb hold the tested pairs as indices of the tally's joint
+     * variant space (v0 = this chromosome's first variant there), sorted by (ea, eb); sup / tot / cis / trans / cfgv / pv are
+     * per tested pair; keep[e] != 0 when the pair survived the conflict test; rank / label / var_first are this chromosome's
+     * slices of phz_tally's var_rank, phz_components' labels (joint space) and var_first; lines of BAM b occupy
+     * [bam_line_lo[b], bam_line_hi[b]) of the tally's line space (-1, -1 when the BAM has no shard here).  va, vb, eorder, the
+     * component arrays and the first-appearance keys are derived from those and need not be set. */
+    int32_t raw;
+    int64_t v0;
+    const uint8_t *keep;
+    const uint64_t *rank;
+    const int32_t *label;
+    const int64_t *var_first;
+    const int64_t *bam_line_lo, *bam_line_hi;
 } phz_rows_in;
 
 typedef struct {

@@ -89,7 +89,9 @@ class phz_rows_in(C.Structure):
                 ("nb", C.c_int32), ("bam_names", C.POINTER(C.c_char_p)), ("bam_excluded", C.c_void_p),
                 ("unique_ids", C.c_int32), ("gw_phase_method", C.c_int32), ("output_read_ids", C.c_int32),
                 ("unphased_vars", C.c_int32), ("max_block_size", C.c_int32), ("want_vcf", C.c_int32), ("threads", C.c_int32),
-                ("qname_off", C.c_void_p), ("qname", C.c_void_p)]
+                ("qname_off", C.c_void_p), ("qname", C.c_void_p),
+                ("raw", C.c_int32), ("v0", C.c_int64), ("keep", C.c_void_p), ("rank", C.c_void_p), ("label", C.c_void_p),
+                ("var_first", C.c_void_p), ("bam_line_lo", C.c_void_p), ("bam_line_hi", C.c_void_p)]
 
 
 class phz_rows_out(C.Structure):

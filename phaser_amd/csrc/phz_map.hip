@@ -43,10 +43,9 @@ struct MapArgs {
     const int32_t *vpos;
     int nv;
     int baseq;
-    // staging slots: tile t owns [t*slot_cap, (t+1)*slot_cap)
-    int32_t *o_read, *o_var;
-    uint8_t *o_code;
-    uint32_t *o_aux0, *o_aux1;
+    // staging slots: global tile t owns stage[t*slot_cap, (t+1)*slot_cap); one packed 16-byte record per call
+    // {var, aux0, aux1, record index inside the tile | code << 16}: one store per call here, one load in k_compact
+    uint4 *stage;
     const int32_t *tile_w0;       // [4*ntiles]: window start, window length | complete flag, first CIGAR word, CIGAR word count
     int32_t *tile_total;          // [ntiles] calls per tile
     int slot_cap;
@@ -73,9 +72,7 @@ struct MapBatch {
     const ShardDev *shards;
     const int64_t *tile0;         // [n_shards + 1]
     int n_shards, baseq;
-    int32_t *s_read, *s_var;      // staging slots: global tile T owns [T*slot_cap, (T+1)*slot_cap)
-    uint8_t *s_code;
-    uint32_t *s_aux0, *s_aux1;
+    uint4 *stage;                 // staging slots: global tile T owns [T*slot_cap, (T+1)*slot_cap)
     int32_t *tile_w0;             // [4*ntiles]
     int32_t *tile_total;          // [ntiles]
     int slot_cap, dbg;
@@ -207,11 +204,7 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
                             if (MODE == 2) {
                                 const int64_t o = out_base + cnt;
                                 if (o < out_limit) {
-                                    a.o_read[o] = (int32_t)r;
-                                    a.o_var[o] = i;
-                                    a.o_code[o] = (uint8_t)code;
-                                    a.o_aux0[o] = x0;
-                                    a.o_aux1[o] = x1;
+                                    a.stage[o] = make_uint4((uint32_t)i, x0, x1, (uint32_t)j | ((uint32_t)code << 16));
                                 }
                             }
                             cnt++;
@@ -309,7 +302,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapBatch bt) {
         const ShardDev &sh = bt.shards[si];
         a.pos = sh.pos; a.cigar_off = sh.cigar_off; a.cigar = sh.cigar; a.seq_off = sh.seq_off; a.seq2 = sh.seq2; a.qual = sh.qual;
         a.n = sh.n; a.vpos = sh.vpos; a.nv = sh.nv; a.baseq = bt.baseq;
-        a.o_read = bt.s_read; a.o_var = bt.s_var; a.o_code = bt.s_code; a.o_aux0 = bt.s_aux0; a.o_aux1 = bt.s_aux1;
+        a.stage = bt.stage;
         a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = bt.dbg;
     }
     constexpr int TILE = MAP_BLOCK * RPT;
@@ -519,11 +512,8 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapBatch bt) {
                 if (!((vmask_[k] >> o) & 1)) continue;
                 if (o2 < a.slot_cap) {
                     const int64_t g = slot0 + o2;
-                    a.o_read[g] = (int32_t)(r0 + j);
-                    a.o_var[g] = vw.w0 + base_[k] + o;
-                    a.o_code[g] = (uint8_t)((codes_[k] >> (4 * o)) & 15);
-                    a.o_aux0[g] = (uint32_t)(s_vpos[base_[k] + o] - rpos_[k]);
-                    a.o_aux1[g] = 0;
+                    a.stage[g] = make_uint4((uint32_t)(vw.w0 + base_[k] + o), (uint32_t)(s_vpos[base_[k] + o] - rpos_[k]), 0u,
+                                            (uint32_t)j | (((codes_[k] >> (4 * o)) & 15u) << 16));
                 }
                 o2++;
             }
@@ -540,11 +530,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapBatch bt) {
             const int o = (int)s_coff[j] + __popc(s_mask[j] & ((1u << ord) - 1));
             if (o < a.slot_cap) {
                 const int64_t g = slot0 + o;
-                a.o_read[g] = (int32_t)(r0 + j);
-                a.o_var[g] = s_var[e];
-                a.o_code[g] = (uint8_t)(key & 0xFF);
-                a.o_aux0[g] = s_aux0[e];
-                a.o_aux1[g] = s_aux1[e];
+                a.stage[g] = make_uint4((uint32_t)s_var[e], s_aux0[e], s_aux1[e], (uint32_t)j | ((key & 0xFFu) << 16));
             }
         }
     }
@@ -620,10 +606,10 @@ __global__ __launch_bounds__(1024) void k_chunk_base(const int64_t *chunk_sum, c
 }
 
 struct CompactArgs {
-    const int32_t *s_read, *s_var; const uint8_t *s_code; const uint32_t *s_aux0, *s_aux1;
+    const uint4 *stage;
     const ShardDev *shards; const int64_t *tile0; int n_shards;
     const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base; const int64_t *shard_base;
-    int slot_cap; int64_t ntiles;
+    int slot_cap, tile_reads; int64_t ntiles;
 };
 
 // calls before global tile T over all shards (T < ntiles)
@@ -643,7 +629,7 @@ __global__ void k_shard_totals(const int64_t *tile0, int n_shards, int64_t ntile
     scal[2 + s] = (unsigned long long)(hi - lo);
 }
 
-// one wave per tile: copy the tile's slot to its final offset in its shard's output
+// one wave per tile: unpack the tile's slot to its final offset in its shard's output arrays
 __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
     const int64_t T = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (T >= c.ntiles) return;
@@ -653,15 +639,18 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
     if (n > c.slot_cap) n = c.slot_cap;
     const int si = shard_of(c.tile0, c.n_shards, T);
     const ShardDev &sh = c.shards[si];
-    const int64_t src = T * (int64_t)c.slot_cap, dst = calls_before(c.chunk_base, c.tile_pref, T) - c.shard_base[si];
+    const uint4 *src = c.stage + T * (int64_t)c.slot_cap;
+    const int64_t dst = calls_before(c.chunk_base, c.tile_pref, T) - c.shard_base[si];
+    const int32_t r0 = (int32_t)((T - c.tile0[si]) * c.tile_reads);
     for (int e = lane; e < n; e += 64) {
         const int64_t o = dst + e;
+        const uint4 w = src[e];
         if (o < sh.cap) {
-            sh.o_read[o] = c.s_read[src + e];
-            sh.o_var[o] = c.s_var[src + e];
-            sh.o_code[o] = c.s_code[src + e];
-            sh.o_aux0[o] = c.s_aux0[src + e];
-            sh.o_aux1[o] = c.s_aux1[src + e];
+            sh.o_read[o] = r0 + (int32_t)(w.w & 0xFFFFu);
+            sh.o_var[o] = (int32_t)w.x;
+            sh.o_code[o] = (uint8_t)(w.w >> 16);
+            sh.o_aux0[o] = w.y;
+            sh.o_aux1[o] = w.z;
         }
     }
 }
@@ -716,7 +705,7 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         ctx->map_ev.resize(2, nullptr);
         for (auto &e : ctx->map_ev) if (!e) PHZ_HIP(ctx, hipEventCreate(&e));
     }
-    DevBuf *S = ctx->scratch;      // 17..22: tile_total, staged read/var/code/aux0/aux1
+    DevBuf *S = ctx->scratch;      // 17: tile_total, 18: packed staging slots
     if (int s = phz_reserve(ctx, ctx->tile_w0, (size_t)ntiles * 16)) return s;
     if (int s = phz_reserve(ctx, S[17], (size_t)ntiles * 4)) return s;
     const int nchunks = (int)((ntiles + 1023) / 1024);
@@ -733,15 +722,10 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
     for (int attempt = 0; attempt < 3; attempt++) {
         const int slot_cap = ctx->map_slot_cap;
         const size_t slots = (size_t)ntiles * (size_t)slot_cap;
-        if (int s = phz_reserve(ctx, S[18], slots * 4)) return s;
-        if (int s = phz_reserve(ctx, S[19], slots * 4)) return s;
-        if (int s = phz_reserve(ctx, S[20], slots)) return s;
-        if (int s = phz_reserve(ctx, S[21], slots * 4)) return s;
-        if (int s = phz_reserve(ctx, S[22], slots * 4)) return s;
+        if (int s = phz_reserve(ctx, S[18], slots * 16)) return s;
         MapBatch bt;
         bt.shards = d_shards; bt.tile0 = d_tile0; bt.n_shards = m; bt.baseq = baseq;
-        bt.s_read = (int32_t *)S[18].p; bt.s_var = (int32_t *)S[19].p; bt.s_code = (uint8_t *)S[20].p;
-        bt.s_aux0 = (uint32_t *)S[21].p; bt.s_aux1 = (uint32_t *)S[22].p;
+        bt.stage = (uint4 *)S[18].p;
         bt.tile_w0 = (int32_t *)ctx->tile_w0.p; bt.tile_total = (int32_t *)S[17].p;
         bt.slot_cap = slot_cap; bt.ntiles = ntiles;
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
@@ -763,10 +747,10 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         hipLaunchKernelGGL(k_shard_totals, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, sm, d_tile0, m, ntiles, (const int32_t *)tile_pref,
                            (const int64_t *)chunk_base, (unsigned long long *)ctx->scalars.p, d_shard_base);
         CompactArgs c;
-        c.s_read = bt.s_read; c.s_var = bt.s_var; c.s_code = bt.s_code; c.s_aux0 = bt.s_aux0; c.s_aux1 = bt.s_aux1;
+        c.stage = bt.stage;
         c.shards = d_shards; c.tile0 = d_tile0; c.n_shards = m;
         c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base; c.shard_base = d_shard_base;
-        c.slot_cap = slot_cap; c.ntiles = ntiles;
+        c.slot_cap = slot_cap; c.tile_reads = tile_reads; c.ntiles = ntiles;
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
         PHZ_HIP(ctx, hipGetLastError());
         PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)8 * (m + 2), hipMemcpyDeviceToHost, sm));

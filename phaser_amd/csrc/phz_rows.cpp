@@ -617,9 +617,109 @@ std::vector<int64_t> key_chunks(const phz_rows_in &I, int64_t step) {
     return b;
 }
 
+// ---- ordering stage (what the host did with numpy before): from the tested pairs, the component labels and the tally's
+// first-appearance numbers to the orders the writers follow (SURVEY.md 8.1 rules 2, 4, 5)
+struct Prep {
+    std::vector<int32_t> ea, eb, va, vb, mem_s;
+    std::vector<int64_t> eorder, comp_starts, comp_ends, comp_order, e_keep, eo, e_starts, e_ends, key_bam, key_g;
+};
+
+void derive(const phz_rows_in &in, Prep &P, phz_rows_in &I) {
+    I = in;
+    const int nv = in.nv;
+    const int64_t ne = in.n_edges;
+    const int32_t v0 = (int32_t)in.v0;
+    // pairs in local indices, oriented by first appearance (phaser.py:667-678 enumerates from the earlier key)
+    P.ea.resize((size_t)ne); P.eb.resize((size_t)ne); P.va.resize((size_t)ne); P.vb.resize((size_t)ne);
+    for (int64_t e = 0; e < ne; e++) {
+        const int32_t a = in.ea[e] - v0, b = in.eb[e] - v0;
+        P.ea[(size_t)e] = a; P.eb[(size_t)e] = b;
+        const bool swap = in.rank[b] < in.rank[a];
+        P.va[(size_t)e] = swap ? b : a; P.vb[(size_t)e] = swap ? a : b;
+    }
+    // rows of variant_connections: hash order in the reference, (rank a, rank b) here
+    {
+        struct K { uint64_t ra, rb; int64_t e; };
+        std::vector<K> k((size_t)ne);
+        for (int64_t e = 0; e < ne; e++) k[(size_t)e] = {in.rank[P.va[(size_t)e]], in.rank[P.vb[(size_t)e]], e};
+        std::sort(k.begin(), k.end(), [](const K &x, const K &y) { return x.ra != y.ra ? x.ra < y.ra : (x.rb != y.rb ? x.rb < y.rb : x.e < y.e); });
+        P.eorder.resize((size_t)ne);
+        for (int64_t e = 0; e < ne; e++) P.eorder[(size_t)e] = k[(size_t)e].e;
+    }
+    // components of the surviving graph: members grouped by label (= smallest member), components in label order
+    std::vector<int32_t> deg((size_t)nv + 1, 0);
+    for (int64_t e = 0; e < ne; e++) if (in.keep[e]) { deg[(size_t)P.ea[(size_t)e]]++; deg[(size_t)P.eb[(size_t)e]]++; }
+    std::vector<int32_t> comp_of((size_t)nv + 1, -1);          // label -> component index
+    std::vector<int64_t> csize;
+    for (int g = 0; g < nv; g++) {
+        if (!deg[(size_t)g]) continue;
+        const int l = in.label[g] - v0;
+        if (comp_of[(size_t)l] < 0) { comp_of[(size_t)l] = (int32_t)csize.size(); csize.push_back(0); }     // labels are met in ascending order (label <= member)
+        csize[(size_t)comp_of[(size_t)l]]++;
+    }
+    const int64_t nc = (int64_t)csize.size();
+    P.comp_starts.assign((size_t)nc, 0); P.comp_ends.assign((size_t)nc, 0);
+    {
+        int64_t acc = 0;
+        for (int64_t c = 0; c < nc; c++) { P.comp_starts[(size_t)c] = acc; acc += csize[(size_t)c]; P.comp_ends[(size_t)c] = P.comp_starts[(size_t)c]; }
+        P.mem_s.resize((size_t)acc);
+        for (int g = 0; g < nv; g++) {
+            if (!deg[(size_t)g]) continue;
+            const int c = comp_of[(size_t)(in.label[g] - v0)];
+            P.mem_s[(size_t)P.comp_ends[(size_t)c]++] = g;
+        }
+    }
+    // block order = order in which the components' first keys enter the connectivity map (rule 4)
+    {
+        std::vector<std::pair<uint64_t, int64_t>> k((size_t)nc);
+        for (int64_t c = 0; c < nc; c++) {
+            uint64_t m = ~0ull;
+            for (int64_t t = P.comp_starts[(size_t)c]; t < P.comp_ends[(size_t)c]; t++) m = std::min(m, in.rank[P.mem_s[(size_t)t]]);
+            k[(size_t)c] = {m, c};
+        }
+        std::sort(k.begin(), k.end());
+        P.comp_order.resize((size_t)nc);
+        for (int64_t c = 0; c < nc; c++) P.comp_order[(size_t)c] = k[(size_t)c].second;
+    }
+    // surviving pairs grouped by component, pair order kept inside
+    P.e_starts.assign((size_t)nc, 0); P.e_ends.assign((size_t)nc, 0);
+    {
+        std::vector<int64_t> cnt((size_t)nc, 0);
+        int64_t nk = 0;
+        for (int64_t e = 0; e < ne; e++) if (in.keep[e]) { cnt[(size_t)comp_of[(size_t)(in.label[P.ea[(size_t)e]] - v0)]]++; nk++; }
+        int64_t acc = 0;
+        for (int64_t c = 0; c < nc; c++) { P.e_starts[(size_t)c] = acc; P.e_ends[(size_t)c] = acc; acc += cnt[(size_t)c]; }
+        P.e_keep.resize((size_t)nk); P.eo.resize((size_t)nk);
+        for (int64_t e = 0; e < ne; e++)
+            if (in.keep[e]) { const int c = comp_of[(size_t)(in.label[P.ea[(size_t)e]] - v0)]; P.e_keep[(size_t)P.e_ends[(size_t)c]++] = e; }
+        for (int64_t t = 0; t < nk; t++) P.eo[(size_t)t] = t;
+    }
+    // first-appearance keys of the covered variants: (BAM of the first kept line, line) (rule 2)
+    {
+        struct K { int64_t bam, line; int32_t g; };
+        std::vector<K> k;
+        for (int g = 0; g < nv; g++) {
+            const int64_t f = in.var_first[g];
+            if (f < 0) continue;
+            int64_t b = 0;
+            for (int t = 0; t < in.nb; t++) if (f >= in.bam_line_lo[t] && f < in.bam_line_hi[t]) b = t;
+            k.push_back({b, f, g});
+        }
+        std::sort(k.begin(), k.end(), [](const K &x, const K &y) { return x.bam != y.bam ? x.bam < y.bam : (x.line != y.line ? x.line < y.line : x.g < y.g); });
+        P.key_bam.resize(k.size()); P.key_g.resize(k.size());
+        for (size_t t = 0; t < k.size(); t++) { P.key_bam[t] = k[t].bam; P.key_g[t] = k[t].g; }
+    }
+    I.ea = P.ea.data(); I.eb = P.eb.data(); I.va = P.va.data(); I.vb = P.vb.data(); I.eorder = P.eorder.data();
+    I.ncomp = nc; I.mem_s = P.mem_s.data(); I.comp_starts = P.comp_starts.data(); I.comp_ends = P.comp_ends.data();
+    I.comp_order = P.comp_order.data(); I.e_keep = P.e_keep.data(); I.eo = P.eo.data(); I.e_starts = P.e_starts.data(); I.e_ends = P.e_ends.data();
+    I.n_keys = (int64_t)P.key_g.size(); I.key_bam = P.key_bam.data(); I.key_g = P.key_g.data();
+}
+
 // everything one chromosome needs between the phases of phz_rows_format_multi
 struct ChromState {
     Ctx C;
+    Prep P;
+    phz_rows_in I2;                           // the chromosome's input with the derived arrays plugged in (raw mode)
     std::vector<int64_t> cb, kb;              // block-chunk / key-chunk boundaries
     std::vector<int64_t> w;                   // weight of every component (block chunks are balanced by it)
     std::vector<BlockChunk> bc;
@@ -638,10 +738,12 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
     std::vector<ChromState> st((size_t)n_chroms);
     // ---- phase A: per-chromosome setup + component weights
     std::vector<int64_t> totals((size_t)n_chroms, 0);
+    std::vector<const phz_rows_in *> use((size_t)n_chroms);
     parallel_chunks(threads, n_chroms, [&](int64_t c) {
-        const phz_rows_in &I = in[c];
         ChromState &S = st[(size_t)c];
-        S.C.in = &in[c];
+        if (in[c].raw) { derive(in[c], S.P, S.I2); use[(size_t)c] = &S.I2; } else use[(size_t)c] = &in[c];
+        const phz_rows_in &I = *use[(size_t)c];
+        S.C.in = use[(size_t)c];
         S.C.uid = {I.uid_off, I.uid}; S.C.rsid = {I.rsid_off, I.rsid}; S.C.alle = {I.allele_off, I.allele}; S.C.maftxt = {I.maf_off, I.maf_txt};
         S.C.qname = {I.qname_off, I.qname};
         S.C.phased.assign((size_t)I.nv + 1, 0);
@@ -663,7 +765,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
     std::vector<Task> tasks;
     const int64_t estep = 16384;
     for (int c = 0; c < n_chroms; c++) {
-        const phz_rows_in &I = in[c];
+        const phz_rows_in &I = *use[(size_t)c];
         ChromState &S = st[(size_t)c];
         S.cb.assign(1, 0);
         int64_t acc = 0;
@@ -682,14 +784,14 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         const Task &k = tasks[(size_t)t];
         ChromState &S = st[(size_t)k.c];
         if (k.kind == 0) run_block_chunk(S.C, S.cb[(size_t)k.i], S.cb[(size_t)k.i + 1], S.bc[(size_t)k.i]);
-        else run_conn(S.C, k.i * estep, std::min<int64_t>(in[k.c].n_edges, (k.i + 1) * estep), S.cc[(size_t)k.i]);
+        else run_conn(S.C, k.i * estep, std::min<int64_t>(use[(size_t)k.c]->n_edges, (k.i + 1) * estep), S.cc[(size_t)k.i]);
     });
     for (auto &S : st) for (auto &c : S.bc) if (c.status) return c.status;
     // ---- phase B2: allelic counts + singleton rows (need to know which variants ended up in a block)
     tasks.clear();
     for (int c = 0; c < n_chroms; c++) {
         ChromState &S = st[(size_t)c];
-        S.kb = key_chunks(in[c], 8192);
+        S.kb = key_chunks(*use[(size_t)c], 8192);
         S.ac.resize(S.kb.size() - 1); S.sc.resize(S.kb.size() - 1);
         for (size_t i = 0; i + 1 < S.kb.size(); i++) tasks.push_back({c, 2, (int64_t)i});
     }
@@ -697,7 +799,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         const Task &k = tasks[(size_t)t];
         ChromState &S = st[(size_t)k.c];
         run_allelic(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.ac[(size_t)k.i]);
-        if (in[k.c].unphased_vars == 1) run_singles(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.sc[(size_t)k.i]);
+        if (use[(size_t)k.c]->unphased_vars == 1) run_singles(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.sc[(size_t)k.i]);
     });
     // ---- phase C: one allocation per (chromosome, file); every chunk copied into place by the pool
     struct Copy { char *dst; const std::string *src; };
@@ -713,7 +815,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         for (auto *x : parts) { if (x->size()) copies.push_back({*p + off, x}); off += x->size(); }
     };
     for (int c = 0; c < n_chroms; c++) {
-        const phz_rows_in &I = in[c];
+        const phz_rows_in &I = *use[(size_t)c];
         ChromState &S = st[(size_t)c];
         phz_rows_out &O = out[c];
         std::vector<const std::string *> p_hap, p_ase, p_cfg, p_conn, p_all, p_sa, p_sh;

@@ -51,19 +51,21 @@ def _fill(eng, c: str, keep: list) -> "_lib.phz_rows_in":
     I.var_count = A(G["var_count"][v0:v0 + nv], np.int32); I.var_distinct = A(G["var_distinct"][v0:v0 + nv], np.int32)
     rs = G["rl_start"][2 * nb * v0: 2 * nb * (v0 + nv) + 1]          # this chromosome's entries; values index the whole rl_qid
     I.rl_start = A(rs, np.uint32); I.rl_qid = A(G["rl_qid"], np.int32)
-    I.n_edges = len(P["eorder"])
-    I.va = A(P["va"], np.int32); I.vb = A(P["vb"], np.int32); I.ea = A(P["ea"], np.int32); I.eb = A(P["eb"], np.int32)
-    for k in ("sup", "tot", "cis", "trans", "cfgv", "eorder"):
+    # raw mode: tested pairs + labels + first-appearance numbers; the library derives every order itself
+    I.raw = 1; I.v0 = v0
+    I.n_edges = len(P["ea"])
+    I.ea = A(P["ea"], np.int32); I.eb = A(P["eb"], np.int32)
+    for k in ("sup", "tot", "cis", "trans", "cfgv"):
         setattr(I, k, A(P[k], np.int64))
-    I.pv = A(P["pv"], np.float64)
-    I.ncomp = P["ncomp"]
-    if P["ncomp"]:
-        I.mem_s = A(P["mem_s"], np.int32)
-        for k, src in (("comp_starts", "starts"), ("comp_ends", "ends"), ("comp_order", "comp_order"), ("e_keep", "e_keep"), ("eo", "eo"),
-                       ("e_starts", "e_starts"), ("e_ends", "e_ends")):
-            setattr(I, k, A(P[src], np.int64))
-    I.n_keys = len(P["key_g"])
-    I.key_bam = A(P["key_bam"], np.int64); I.key_g = A(P["key_g"], np.int64)
+    I.pv = A(P["pv"], np.float64); I.keep = A(P["keep"], np.uint8)
+    I.rank = A(G["var_rank"][v0:v0 + nv], np.uint64); I.label = A(eng._label_all[v0:v0 + nv], np.int32)
+    I.var_first = A(G["var_first"][v0:v0 + nv], np.int64)
+    lo_ = np.full(nb, -1, dtype=np.int64); hi_ = np.full(nb, -1, dtype=np.int64)
+    for b in range(nb):
+        if (c, b) in G["line_base"]:
+            base, n = G["line_base"][(c, b)]
+            lo_[b] = base; hi_[b] = base + n
+    I.bam_line_lo = A(lo_, np.int64); I.bam_line_hi = A(hi_, np.int64)
     names = (C.c_char_p * nb)(*[b.encode() for b in eng.bam_names]); keep.append(names)
     I.nb = nb; I.bam_names = names
     if cfg.haplo_count_bam_exclude:
