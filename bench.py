@@ -209,7 +209,7 @@ def main():
     phasing = None
     if not a.no_phasing:
         vs = pvcf.load_variants("\n".join(synth.vcf_lines([workloads_variants(plan, vsets, p) for p in plan])))
-        host_threads = max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
+        host_threads = max(1, min(64, (os.cpu_count() or 1) // max(1, world)))
         calls_now = [Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i in range(len(chroms))]
         runs = []
         for rep in range(max(1, a.phasing_passes)):

@@ -426,17 +426,23 @@ typedef struct {
     const char *const *contig_ban;    /* strings that must not occur in a contig name (:386-392) */
     int32_t threads;
     int32_t grep_hom;                 /* 1: drop lines whose columns 1-9 + sample hold "0|0" or "1|1" (the grep of :220-225) */
+    /* BED intervals (0-based, half-open), any order.  A VCF record is the interval [POS-1, POS-1+len(REF)) (bedtools).
+     * drop_*: `bedtools intersect -v` of --blacklist (:220-221): overlapping records vanish before anything is counted.
+     * mark_*: `bedtools intersect` of --haplo_count_blacklist (:232-241): overlapping variants get blacklisted[] = 1. */
+    int64_t n_drop; const char *const *drop_chrom; const int64_t *drop_start, *drop_end;
+    int64_t n_mark; const char *const *mark_chrom; const int64_t *mark_start, *mark_end;
 } phz_vcf_opts;
 typedef struct {
     const char *name;                 /* chr_prefix + CHROM */
     int64_t n;
     const int32_t *pos;
-    const uint8_t *ref_len, *a0, *a1; /* len(REF) capped at 255; base code of the individual's allele 0 / 1 (255 = not one ACGT base) */
+    const uint8_t *ref_len, *a0, *a1; /* len(REF) (a longer REF than 255 bases is refused); base code of the individual's allele 0 / 1 (255 = not one ACGT base) */
     const uint8_t *is_ref;            /* [2n] */
     const int8_t *phase_idx;          /* [2n] */
     const double *maf;
     const char *pool[11];
     int64_t pool_len[11];
+    const uint8_t *blacklisted;       /* [n] 1 when the record overlaps a mark_* interval */
 } phz_vcf_table;
 
 int phz_vcf_parse(const char *text, int64_t len, const phz_vcf_opts *opts, phz_vcf **out);

@@ -121,12 +121,15 @@ class phz_gene_work(C.Structure):
 class phz_vcf_opts(C.Structure):
     _fields_ = [("sample_column", C.c_int32), ("chrom_of_interest", C.c_char_p), ("pass_only", C.c_int32), ("include_indels", C.c_int32),
                 ("chr_prefix", C.c_char_p), ("id_separator", C.c_char_p), ("gw_phase_method", C.c_int32), ("gw_af_field", C.c_char_p),
-                ("n_contig_ban", C.c_int32), ("contig_ban", C.POINTER(C.c_char_p)), ("threads", C.c_int32), ("grep_hom", C.c_int32)]
+                ("n_contig_ban", C.c_int32), ("contig_ban", C.POINTER(C.c_char_p)), ("threads", C.c_int32), ("grep_hom", C.c_int32),
+                ("n_drop", C.c_int64), ("drop_chrom", C.POINTER(C.c_char_p)), ("drop_start", C.c_void_p), ("drop_end", C.c_void_p),
+                ("n_mark", C.c_int64), ("mark_chrom", C.POINTER(C.c_char_p)), ("mark_start", C.c_void_p), ("mark_end", C.c_void_p)]
 
 
 class phz_vcf_table(C.Structure):
     _fields_ = [("name", C.c_char_p), ("n", C.c_int64), ("pos", C.c_void_p), ("ref_len", C.c_void_p), ("a0", C.c_void_p), ("a1", C.c_void_p),
-                ("is_ref", C.c_void_p), ("phase_idx", C.c_void_p), ("maf", C.c_void_p), ("pool", C.c_void_p * 11), ("pool_len", C.c_int64 * 11)]
+                ("is_ref", C.c_void_p), ("phase_idx", C.c_void_p), ("maf", C.c_void_p), ("pool", C.c_void_p * 11), ("pool_len", C.c_int64 * 11),
+                ("blacklisted", C.c_void_p)]
 
 
 class phz_vcfout_chrom(C.Structure):

@@ -7,12 +7,14 @@
 // in the reference's row order plus the per-block arrays write_vcf needs.  Numbers are printed the way Python prints
 // them (str(int), repr(float), str(numpy.float64)) because that is what ends up in the files (SURVEY.md 8.1 rule 7).
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -734,6 +736,14 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
     if ((!in || !out) && n_chroms) return PHZ_E_ARG;
     if (n_chroms <= 0) return PHZ_OK;
     threads = std::max(1, threads);
+    const bool timing = getenv("PHZ_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[phz timing]   rows: %-42s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     for (int c = 0; c < n_chroms; c++) memset(&out[c], 0, sizeof(out[c]));
     std::vector<ChromState> st((size_t)n_chroms);
     // ---- phase A: per-chromosome setup + component weights
@@ -758,6 +768,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         }
         totals[(size_t)c] = total;
     });
+    lap("ordering stage (per chromosome)");
     int64_t grand = 0;
     for (int64_t t : totals) grand += t;
     const int64_t target = std::max<int64_t>(4096, grand / ((int64_t)threads * 8) + 1);
@@ -786,6 +797,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         if (k.kind == 0) run_block_chunk(S.C, S.cb[(size_t)k.i], S.cb[(size_t)k.i + 1], S.bc[(size_t)k.i]);
         else run_conn(S.C, k.i * estep, std::min<int64_t>(use[(size_t)k.c]->n_edges, (k.i + 1) * estep), S.cc[(size_t)k.i]);
     });
+    lap("block phasing + block / connection rows");
     for (auto &S : st) for (auto &c : S.bc) if (c.status) return c.status;
     // ---- phase B2: allelic counts + singleton rows (need to know which variants ended up in a block)
     tasks.clear();
@@ -801,6 +813,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         run_allelic(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.ac[(size_t)k.i]);
         if (use[(size_t)k.c]->unphased_vars == 1) run_singles(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.sc[(size_t)k.i]);
     });
+    lap("allelic counts + singleton rows");
     // ---- phase C: one allocation per (chromosome, file); every chunk copied into place by the pool
     struct Copy { char *dst; const std::string *src; };
     std::vector<Copy> copies;
@@ -850,7 +863,9 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         O.blk_stat_int = take_vec(bstat_int); O.blk_maxmaf = take_vec(bmaxmaf);
     }
     if (nomem) { for (int c = 0; c < n_chroms; c++) phz_rows_free(&out[c]); return PHZ_E_NOMEM; }
+    lap("layout of the output buffers");
     parallel_chunks(threads, (int64_t)copies.size(), [&](int64_t i) { memcpy(copies[(size_t)i].dst, copies[(size_t)i].src->data(), copies[(size_t)i].src->size()); });
+    lap("chunks copied into place");
     return PHZ_OK;
 }
 

@@ -348,6 +348,7 @@ __device__ __forceinline__ uint32_t hash64(uint64_t k) {
 constexpr int PH_SLOTS = 1024;     // LDS hash slots per workgroup
 constexpr int PH_VALS = 10;        // 9 cells + linked flag
 constexpr int PH_PROBES = 24;
+constexpr int PAIR_ITEMS = 2048;   // items per workgroup of k_pairs (the LDS table is set up / flushed once per workgroup)
 constexpr int GH_PROBES = 2048;    // global probe bound; beyond it the table is declared too small and the pass is redone
 
 // counters[]: 0 distinct items, 1 pair events, 2 global hash overflow, 3 kept lines
@@ -369,46 +370,45 @@ __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, const uint
     __shared__ int s_vals[PH_SLOTS * PH_VALS];
     __shared__ unsigned int s_part[8];
     const int64_t m = *m_ptr;
-    if ((int64_t)blockIdx.x * 256 >= m) return;
+    const int64_t i0 = (int64_t)blockIdx.x * PAIR_ITEMS;
+    if (i0 >= m) return;
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) s_keys[j] = KEY_DROPPED;
     for (int j = threadIdx.x; j < PH_SLOTS * PH_VALS; j += 256) s_vals[j] = 0;
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned int n_item = 0, n_event = 0;
-    if (i < m) {
+    for (int64_t i = i0 + threadIdx.x; i < i0 + PAIR_ITEMS && i < m; i += 256) {
         const uint64_t k = items[i];
-        if (k != KEY_DROPPED) {
-            n_item = 1;
-            const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
-            for (int64_t j = i + 1; j < m; j++) {
-                const uint64_t k2 = items[j];
-                if (k2 == KEY_DROPPED) continue;
-                if ((uint32_t)(k2 >> 32) != q) break;
-                const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
-                if (v2 == v) continue;
-                n_event++;
-                const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
-                const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
-                const int cell = (int)(cls * 3 + cls2);
-                const int linked = (int)(ln & ln2);
-                uint32_t s = hash64(pk) & (PH_SLOTS - 1);
-                bool done = false;
-                for (int t = 0; t < PH_PROBES; t++) {
-                    const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
-                    if (prev == KEY_DROPPED || prev == pk) {
-                        atomicAdd(&s_vals[s * PH_VALS + cell], 1);
-                        if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
-                        done = true;
-                        break;
-                    }
-                    s = (s + 1) & (PH_SLOTS - 1);
+        if (k == KEY_DROPPED) continue;
+        n_item++;
+        const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
+        for (int64_t j = i + 1; j < m; j++) {
+            const uint64_t k2 = items[j];
+            if (k2 == KEY_DROPPED) continue;
+            if ((uint32_t)(k2 >> 32) != q) break;
+            const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
+            if (v2 == v) continue;
+            n_event++;
+            const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
+            const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
+            const int cell = (int)(cls * 3 + cls2);
+            const int linked = (int)(ln & ln2);
+            uint32_t s = hash64(pk) & (PH_SLOTS - 1);
+            bool done = false;
+            for (int t = 0; t < PH_PROBES; t++) {
+                const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
+                if (prev == KEY_DROPPED || prev == pk) {
+                    atomicAdd(&s_vals[s * PH_VALS + cell], 1);
+                    if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
+                    done = true;
+                    break;
                 }
-                if (!done) {
-                    const int gs = global_slot(gkeys, gmask, pk, counters);
-                    if (gs >= 0) {
-                        atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
-                        if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
-                    }
+                s = (s + 1) & (PH_SLOTS - 1);
+            }
+            if (!done) {
+                const int gs = global_slot(gkeys, gmask, pk, counters);
+                if (gs >= 0) {
+                    atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
+                    if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
                 }
             }
         }
@@ -715,7 +715,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         PHZ_HIP(ctx, hipMemsetAsync(gkeys, 0xff, cap * 8, sm));
         PHZ_HIP(ctx, hipMemsetAsync(gvals, 0, cap * PH_VALS * 4, sm));
         PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 24, sm));
-        if (total > 0) hipLaunchKernelGGL(k_pairs, dim3(nblk(total)), dim3(256), 0, sm, (const uint64_t *)items, m_ptr, gkeys, gvals,
+        if (total > 0) hipLaunchKernelGGL(k_pairs, dim3((unsigned)((total + PAIR_ITEMS - 1) / PAIR_ITEMS)), dim3(256), 0, sm, (const uint64_t *)items, m_ptr, gkeys, gvals,
                                           (uint32_t)(cap - 1), counters);
         PHZ_HIP(ctx, hipMemsetAsync(deg, 0, NV * 4, sm));
         hipLaunchKernelGGL(k_edge_count, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, (const uint64_t *)gkeys, (int64_t)cap, deg);

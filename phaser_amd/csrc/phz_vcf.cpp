@@ -24,7 +24,7 @@ namespace {
 
 struct Cols {
     std::vector<int32_t> pos;
-    std::vector<uint8_t> ref_len, a0, a1, is_ref;      // is_ref: 2 per variant
+    std::vector<uint8_t> ref_len, a0, a1, is_ref, black;      // is_ref: 2 per variant; black: --haplo_count_blacklist hit
     std::vector<int8_t> phase_idx;                    // 2 per variant
     std::vector<double> maf;
     std::string uid, rsid_field, rsid, ref, all_alleles, alleles, phase, gt, maf_text, maf_str, allele2;
@@ -32,6 +32,7 @@ struct Cols {
     void append(const Cols &o) {
         pos.insert(pos.end(), o.pos.begin(), o.pos.end()); ref_len.insert(ref_len.end(), o.ref_len.begin(), o.ref_len.end());
         a0.insert(a0.end(), o.a0.begin(), o.a0.end()); a1.insert(a1.end(), o.a1.begin(), o.a1.end());
+        black.insert(black.end(), o.black.begin(), o.black.end());
         is_ref.insert(is_ref.end(), o.is_ref.begin(), o.is_ref.end()); phase_idx.insert(phase_idx.end(), o.phase_idx.begin(), o.phase_idx.end());
         maf.insert(maf.end(), o.maf.begin(), o.maf.end());
         uid += o.uid; rsid_field += o.rsid_field; rsid += o.rsid; ref += o.ref; all_alleles += o.all_alleles; alleles += o.alleles;
@@ -51,6 +52,35 @@ struct Chunk {
 using phztext::put_pyfloat;
 using phztext::split;
 
+// BED intervals of one file: per chromosome sorted by start and merged, queried by binary search
+struct BedIndex {
+    std::unordered_map<std::string, std::vector<std::pair<int64_t, int64_t>>> by_chrom;
+    bool empty() const { return by_chrom.empty(); }
+    void build(int64_t n, const char *const *chrom, const int64_t *start, const int64_t *end) {
+        for (int64_t i = 0; i < n; i++) if (end[i] > start[i]) by_chrom[chrom[i]].emplace_back(start[i], end[i]);
+        for (auto &kv : by_chrom) {
+            auto &v = kv.second;
+            std::sort(v.begin(), v.end());
+            size_t w = 0;
+            for (size_t i = 0; i < v.size(); i++) {
+                if (w && v[i].first <= v[w - 1].second) v[w - 1].second = std::max(v[w - 1].second, v[i].second);
+                else v[w++] = v[i];
+            }
+            v.resize(w);
+        }
+    }
+    // does [s, e) share at least one base with an interval of `chrom`?
+    bool hit(std::string_view chrom, int64_t s, int64_t e) const {
+        auto it = by_chrom.find(std::string(chrom));
+        if (it == by_chrom.end()) return false;
+        const auto &v = it->second;
+        // first interval whose end is beyond s (merged intervals: ends are ascending too)
+        size_t lo = 0, hi = v.size();
+        while (lo < hi) { const size_t m = (lo + hi) >> 1; if (v[m].second <= s) lo = m + 1; else hi = m; }
+        return lo < v.size() && v[lo].first < e;
+    }
+};
+
 // Python float(): accepts surrounding whitespace, inf/nan spellings; here: strtod over the whole token
 bool py_float(std::string_view s, double *out) {
     std::string t(s);
@@ -69,7 +99,8 @@ inline uint8_t base_code(std::string_view s) {
     switch (s[0]) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 255; }
 }
 
-void parse_lines(const char *text, const std::vector<int64_t> &ls, size_t lo, size_t hi, const phz_vcf_opts &O, Chunk &c) {
+void parse_lines(const char *text, const std::vector<int64_t> &ls, size_t lo, size_t hi, const phz_vcf_opts &O, const BedIndex &drop,
+                 const BedIndex &mark, Chunk &c) {
     std::vector<std::string_view> f, fmt, sf, alts, every, info, ind, ph, afs_s;
     std::vector<char> g;
     std::vector<double> afs;
@@ -87,6 +118,18 @@ void parse_lines(const char *text, const std::vector<int64_t> &ls, size_t lo, si
             if (hom) continue;
         }
         const std::string_view chrom0 = f[0];
+        // --chr: the reference reads `tabix -h vcf chr:` (:206-208), so records of other contigs never reach any check
+        if (!coi.empty() && coi != chrom0) continue;
+        if (!drop.empty() || !mark.empty()) {
+            if (f.size() < 4) { c.status = PHZ_E_ARG; c.error = "VCF line with too few columns"; return; }
+        }
+        long long pos_bed = 0;
+        if (!drop.empty() || !mark.empty()) {
+            std::string t(f[1]); char *e2 = nullptr; pos_bed = strtoll(t.c_str(), &e2, 10);
+            if (t.empty() || *e2) { c.status = PHZ_E_ARG; c.error = "VCF POS is not an integer"; return; }
+            const int64_t rl = (int64_t)std::max<size_t>(1, f[3].size());
+            if (!drop.empty() && drop.hit(chrom0, pos_bed - 1, pos_bed - 1 + rl)) continue;      // bedtools intersect -v (:220)
+        }
         for (int b = 0; b < O.n_contig_ban; b++)
             if (chrom0.find(O.contig_ban[b]) != std::string_view::npos) {
                 c.status = PHZ_E_ARG;
@@ -94,7 +137,6 @@ void parse_lines(const char *text, const std::vector<int64_t> &ls, size_t lo, si
                           "using --id_separator to a character not found in the contig names and try again.";
                 return;
             }
-        if (!coi.empty() && coi != chrom0) continue;
         std::string chrom(prefix); chrom += chrom0;
         auto it = c.idx.find(chrom);
         int ci;
@@ -178,7 +220,12 @@ void parse_lines(const char *text, const std::vector<int64_t> &ls, size_t lo, si
         long long posv = 0;
         { std::string t(f[1]); char *e2 = nullptr; posv = strtoll(t.c_str(), &e2, 10); if (t.empty() || *e2) { c.status = PHZ_E_ARG; c.error = "VCF POS is not an integer"; return; } }
         K.pos.push_back((int32_t)posv);
-        K.ref_len.push_back((uint8_t)std::min<size_t>(255, f[3].size()));
+        if (f[3].size() > 255) {       // the general mapper's window is len(REF) (read_variant_map.py:237-244): never silently shortened
+            c.status = PHZ_E_UNSUPPORTED; c.error = "REF allele longer than 255 bases at " + chrom + ":" + std::string(f[1]);
+            return;
+        }
+        K.ref_len.push_back((uint8_t)f[3].size());
+        K.black.push_back((!mark.empty() && mark.hit(chrom0, pos_bed - 1, pos_bed - 1 + (int64_t)std::max<size_t>(1, f[3].size()))) ? 1 : 0);
         std::string uid(chrom); uid += sep; uid += f[1];
         for (auto &x : every) { uid += sep; uid += x; }
         K.uid += uid; K.uid += '\n';
@@ -229,12 +276,15 @@ extern "C" int phz_vcf_parse(const char *text, int64_t len, const phz_vcf_opts *
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, opts->threads), (nlines + 8191) / 8192));
     const size_t nchunks = nlines ? (size_t)nt * 4 : 0;
     std::vector<Chunk> ch(nchunks);
+    BedIndex drop, mark;
+    if (opts->n_drop > 0) drop.build(opts->n_drop, opts->drop_chrom, opts->drop_start, opts->drop_end);
+    if (opts->n_mark > 0) mark.build(opts->n_mark, opts->mark_chrom, opts->mark_start, opts->mark_end);
     std::atomic<size_t> next(0);
     auto work = [&]() {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= nchunks) break;
-            parse_lines(text, ls, nlines * i / nchunks, nlines * (i + 1) / nchunks, *opts, ch[i]);
+            parse_lines(text, ls, nlines * i / nchunks, nlines * (i + 1) / nchunks, *opts, drop, mark, ch[i]);
         }
     };
     if (nt == 1) work();
@@ -281,7 +331,7 @@ extern "C" int phz_vcf_chrom(const phz_vcf *h, int32_t i, phz_vcf_table *t) {
     memset(t, 0, sizeof(*t));
     t->name = h->names[(size_t)i].c_str(); t->n = K.n;
     t->pos = K.pos.data(); t->ref_len = K.ref_len.data(); t->a0 = K.a0.data(); t->a1 = K.a1.data(); t->is_ref = K.is_ref.data();
-    t->phase_idx = K.phase_idx.data(); t->maf = K.maf.data();
+    t->phase_idx = K.phase_idx.data(); t->maf = K.maf.data(); t->blacklisted = K.black.data();
     const std::string *pools[11] = {&K.uid, &K.rsid_field, &K.rsid, &K.ref, &K.all_alleles, &K.alleles, &K.phase, &K.gt, &K.maf_text, &K.maf_str, &K.allele2};
     for (int k = 0; k < 11; k++) { t->pool[k] = pools[k]->data(); t->pool_len[k] = (int64_t)pools[k]->size(); }
     return PHZ_OK;

@@ -352,10 +352,11 @@ class Engine:
         """Stage C1.  Genome-wide: the nine cells -> supporting / total counts, the binomial test (scipy, the reference's own
         call at phaser.py:1649), pruning, connected components on the GPU.  Per chromosome (slices of those arrays, local
         variant indices): row orders, component lists, first-appearance keys -> self._pre[c] for the row writer."""
+        import time as _t
         cfg = self.cfg
         G = self.G
         NV = G["nv"]
-        rank_all = G["var_rank"]
+        tp0 = _t.perf_counter()
         # ---- test every linked pair (phaser.py:1594-1654)
         sel = np.nonzero(G["linked"])[0]
         ea_g = G["ea"][sel]; eb_g = G["eb"][sel]; cells = G["cells"][sel].astype(np.int64)
@@ -366,15 +367,20 @@ class Engine:
         cfgv = np.where(cis > trans, 0, np.where(cis < trans, 1, -1))
         prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
         pv = np.ones(len(sel), dtype=np.float64)
+        tp1 = _t.perf_counter()
         test = (sup > 0) & ((tot - sup) > 0)
         if test.any():
             pv[test] = binom_cdf_dedup(sup[test], tot[test], prob)
         pv[sup == 0] = 0.0
         keep_edge = ~(pv < cfg.cc_threshold)
         # ---- connected components of the surviving graph on the GPU (phaser.py:1861-1882)
+        tp2 = _t.perf_counter()
         keep_all = np.zeros(len(G["ea"]), dtype=np.uint8)
         keep_all[sel[keep_edge]] = 1
         label_all = self._component_labels(keep_all)
+        tp3 = _t.perf_counter()
+        for k_, v_ in (("prep_cells_s", tp1 - tp0), ("prep_binom_s", tp2 - tp1), ("prep_components_s", tp3 - tp2)):
+            self.stats[k_] = self.stats.get(k_, 0.0) + v_
         frags: Dict[str, dict] = {}
         self._pre = {}
         vb = G["var_base"]

@@ -3,7 +3,7 @@
 Same flags, defaults and output files as phaser/phaser.py:26-178 (`main`), :182-321 (`parse_sample`) and
 :378-1263 (`process_vcf`).  What differs is below the CLI: no samtools / bedtools / tabix subprocesses (BAM,
 BED and VCF are read in-process) and the seven multiprocessing stages are one `Engine` driving libphz.so.
-The phased VCF (`write_vcf`) is written as BGZF `<o>.vcf.gz` without a tabix index.  Not supported:
+The phased VCF (`write_vcf`) is written as BGZF `<o>.vcf.gz` with its tabix index `<o>.vcf.gz.tbi`.  Not supported:
 `--process_slow`, `--output_network`.
 
     python -m phaser_amd.phaser --vcf S.vcf.gz --bam a.bam,b.bam --sample S1 --mapq 255 --baseq 10 --paired_end 1 --o out
@@ -78,20 +78,15 @@ def build_parser():
     return p
 
 
-def load_bed(path: str) -> Dict[str, List[tuple]]:
-    iv: Dict[str, List[tuple]] = {}
+def load_bed(path: str) -> List[tuple]:
+    """BED file -> [(chrom, start, end)] (0-based, half-open); header / track lines skipped."""
+    iv = []
     with open(path) as f:
         for line in f:
             c = line.rstrip("\n").split("\t")
             if len(c) >= 3 and not line.startswith(("#", "track", "browser")):
-                iv.setdefault(c[0], []).append((int(c[1]), int(c[2])))
+                iv.append((c[0], int(c[1]), int(c[2])))
     return iv
-
-
-def overlaps(iv, chrom, pos1, ref_len) -> bool:
-    """bedtools treats a VCF record as the 0-based interval [POS-1, POS-1+len(REF))."""
-    s, e = pos1 - 1, pos1 - 1 + max(1, ref_len)
-    return any(a < e and s < b for a, b in iv.get(chrom, ()))
 
 
 def main(argv=None):
@@ -146,37 +141,19 @@ def main(argv=None):
             break
     if sample_col is None:
         fatal_error("Sample '%s' not found in the input VCF file." % args.sample)
-    # cut -f 1-9,S | grep -v '0|0\|1|1' [| bedtools intersect -v]   (phaser.py:220-225): the cut + grep run inside the native
-    # loader; only a --blacklist needs the lines here first
-    bl = load_bed(args.blacklist) if args.blacklist != "" else None
-    kept = None
+    # cut -f 1-9,S | grep -v '0|0\|1|1' [| bedtools intersect -v -b blacklist]   (phaser.py:220-225) and the bedtools intersect of
+    # --haplo_count_blacklist (:232-241) all run inside the native loader (interval lookups by binary search)
     load_kw = dict(chrom_of_interest=args.chr, pass_only=args.pass_only, include_indels=args.include_indels, chr_prefix=args.chr_prefix,
                    id_separator=args.id_separator, gw_phase_method=args.gw_phase_method, gw_af_field=args.gw_af_field,
                    contig_ban=(args.id_separator, ":"), threads=max(1, args.threads))
-    if bl is None and args.haplo_count_blacklist == "":
-        vs = vcf.load_variants(data, sample_column=sample_col, grep_hom=True, **load_kw)
-    else:
-        kept = []
-        for line in data.decode().split("\n"):
-            if not line or line[0] == "#":
-                continue
-            c = line.split("\t")
-            cut = "\t".join(c[0:9] + [c[sample_col]])
-            if "0|0" in cut or "1|1" in cut:
-                continue
-            if bl is not None and overlaps(bl, c[0], int(c[1]), len(c[3])):
-                continue
-            kept.append(cut)
-        vs = vcf.load_variants("\n".join(kept), sample_column=9, **load_kw)
-    mark("vcf read + het-variant table")
-    haplo_bl = set()
+    if args.blacklist != "":
+        say("    removing blacklisted variants and processing VCF...")
     if args.haplo_count_blacklist != "":
         say("#1b. Loading haplotypic count blacklist intervals...")
-        hb = load_bed(args.haplo_count_blacklist)
-        for line in kept:
-            c = line.split("\t")
-            if (args.chr == "" or args.chr == c[0]) and overlaps(hb, c[0], int(c[1]), len(c[3])):
-                haplo_bl.add(c[0] + "_" + str(int(c[1])))
+    vs = vcf.load_variants(data, sample_column=sample_col, grep_hom=True, drop_bed=load_bed(args.blacklist) if args.blacklist != "" else None,
+                           mark_bed=load_bed(args.haplo_count_blacklist) if (args.haplo_count_blacklist != "" and args.chr_prefix == "") else None,
+                           **load_kw)       # with --chr_prefix the reference's blacklist keys (VCF names) never match its lookups (prefixed names, :1070)
+    mark("vcf read + het-variant table")
     say("     creating variant mapping table...")
     say("          %d heterozygous sites being used for phasing (%d filtered, %d indels excluded, %d unphased)" %
         (vs.het_count, vs.filter_count, vs.indels_excluded, vs.unphased_count))
@@ -210,7 +187,7 @@ def main(argv=None):
     cfg = Config(baseq=args.baseq, as_q_cutoff=args.as_q_cutoff, cc_threshold=args.cc_threshold, max_block_size=args.max_block_size,
                  id_separator=args.id_separator, unphased_vars=args.unphased_vars, gw_phase_method=args.gw_phase_method,
                  output_read_ids=args.output_read_ids, unique_ids=args.unique_ids, haplo_count_bam_exclude=excl,
-                 haplo_blacklist=frozenset(haplo_bl), include_indels=args.include_indels, host_threads=max(1, args.threads))
+                 include_indels=args.include_indels, host_threads=max(1, args.threads))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     eng = Engine(vs, bam_names, cfg, device=local)
     device = "cuda:%d" % local

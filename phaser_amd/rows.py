@@ -45,8 +45,13 @@ def _fill(eng, c: str, keep: list) -> "_lib.phz_rows_in":
     I.maf_off = A(pools["maf"][0], np.uint32); I.maf_txt = B(pools["maf"][1])
     I.maf = A(pools["maf_val"], np.float64)
     I.is_ref = A(cv.is_ref, np.uint8); I.phase_idx = A(cv.phase_idx, np.int8)
+    # --haplo_count_blacklist: the loader marked the variants under the BED intervals; Config.haplo_blacklist ("chrom_pos" names,
+    # phaser.py:1070) adds to it
+    bl = cv.blacklisted if getattr(cv, "blacklisted", None) is not None and len(cv.blacklisted) == nv and cv.blacklisted.any() else None
     if cfg.haplo_blacklist:
-        bl = np.fromiter((c + "_" + str(int(p)) in cfg.haplo_blacklist for p in cv.pos), dtype=np.uint8, count=nv)
+        named = np.fromiter((c + "_" + str(int(p)) in cfg.haplo_blacklist for p in cv.pos), dtype=np.uint8, count=nv)
+        bl = named if bl is None else (bl | named)
+    if bl is not None:
         I.blacklisted = A(bl, np.uint8)
     I.var_count = A(G["var_count"][v0:v0 + nv], np.int32); I.var_distinct = A(G["var_distinct"][v0:v0 + nv], np.int32)
     rs = G["rl_start"][2 * nb * v0: 2 * nb * (v0 + nv) + 1]          # this chromosome's entries; values index the whole rl_qid

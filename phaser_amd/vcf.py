@@ -49,6 +49,7 @@ class ChromVariants:
         self.chrom = chrom
         self.pos = arrays["pos"]; self.ref_len = arrays["ref_len"]; self.a0 = arrays["a0"]; self.a1 = arrays["a1"]
         self.is_ref = arrays["is_ref"]; self.phase_idx = arrays["phase_idx"]; self.maf_val = arrays["maf"]
+        self.blacklisted = arrays.get("blacklisted")        # uint8 [n]: overlaps a --haplo_count_blacklist interval
         self._raw = raw
         self._pools = None
 
@@ -130,16 +131,30 @@ def read_bytes(path: str, threads: int = 0) -> bytes:
 
 def load_variants(vcf_text, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
                   include_indels: int = 0, chr_prefix: str = "", id_separator: str = "_", gw_phase_method: int = 0,
-                  gw_af_field: str = "AF", contig_ban=("_", ":"), threads: int = 8, grep_hom: bool = False) -> VariantSet:
+                  gw_af_field: str = "AF", contig_ban=("_", ":"), threads: int = 8, grep_hom: bool = False,
+                  drop_bed=None, mark_bed=None) -> VariantSet:
     """vcf_text: str or bytes of the (decompressed) VCF.  Raises SystemExit with the reference's message on a banned
     contig character (phaser.py:386-392) and on unsorted records.  grep_hom=True applies the reference's
-    `cut -f 1-9,S | grep -v '0|0\\|1|1'` pre-filter (phaser.py:220-225) inside the loader."""
+    `cut -f 1-9,S | grep -v '0|0\\|1|1'` pre-filter (phaser.py:220-225) inside the loader.  drop_bed / mark_bed: BED intervals as
+    [(chrom, start, end)]: records overlapping drop_bed vanish (--blacklist, `bedtools intersect -v`), variants overlapping
+    mark_bed get ChromVariants.blacklisted = 1 (--haplo_count_blacklist)."""
     lib = _lib.load()
     data = vcf_text.encode() if isinstance(vcf_text, str) else bytes(vcf_text)
     ban = [str(x).encode() for x in contig_ban]
     ban_arr = (C.c_char_p * max(1, len(ban)))(*ban) if ban else (C.c_char_p * 1)()
+    keep = []
+
+    def bed(iv):
+        iv = list(iv or [])
+        n = len(iv)
+        names = (C.c_char_p * max(1, n))(*[str(x[0]).encode() for x in iv]) if n else (C.c_char_p * 1)()
+        st_ = np.ascontiguousarray([int(x[1]) for x in iv], dtype=np.int64); en_ = np.ascontiguousarray([int(x[2]) for x in iv], dtype=np.int64)
+        keep.extend([names, st_, en_])
+        return n, names, C.c_void_p(st_.ctypes.data) if n else None, C.c_void_p(en_.ctypes.data) if n else None
+    nd, dn, ds, de = bed(drop_bed); nm, mn, ms, me = bed(mark_bed)
     o = _lib.phz_vcf_opts(int(sample_column), chrom_of_interest.encode(), int(pass_only), int(include_indels), chr_prefix.encode(),
-                          id_separator.encode(), int(gw_phase_method), gw_af_field.encode(), len(ban), ban_arr, max(1, int(threads)), 1 if grep_hom else 0)
+                          id_separator.encode(), int(gw_phase_method), gw_af_field.encode(), len(ban), ban_arr, max(1, int(threads)), 1 if grep_hom else 0,
+                          nd, dn, ds, de, nm, mn, ms, me)
     h = C.c_void_p()
     st = lib.phz_vcf_parse(C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(o), C.byref(h))
     try:
@@ -162,7 +177,7 @@ def load_variants(vcf_text, sample_column: int = 9, chrom_of_interest: str = "",
                 return np.frombuffer(C.string_at(ptr, count * np.dtype(dt).itemsize), dtype=dt).copy()
             arrays = {"pos": arr(t.pos, n, np.int32), "ref_len": arr(t.ref_len, n, np.uint8), "a0": arr(t.a0, n, np.uint8),
                       "a1": arr(t.a1, n, np.uint8), "is_ref": arr(t.is_ref, 2 * n, np.uint8), "phase_idx": arr(t.phase_idx, 2 * n, np.int8),
-                      "maf": arr(t.maf, n, np.float64)}
+                      "maf": arr(t.maf, n, np.float64), "blacklisted": arr(t.blacklisted, n, np.uint8)}
             raw = {name: (C.string_at(t.pool[k], int(t.pool_len[k])) if t.pool_len[k] else b"") for k, name in enumerate(_POOLS)}
             cv = ChromVariants(t.name.decode(), arrays, raw)
             chroms[cv.chrom] = cv

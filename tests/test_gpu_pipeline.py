@@ -286,3 +286,24 @@ def test_population_flow_matches_reference(mapper, tmp_path):
         a, g, log = expr_matrix.expr_matrix(str(gdir), os.path.join(e, "features.bed"), order)
         assert a == gz_text(os.path.join(e, "out.%s.bed.gz" % order)), order
         assert g == gz_text(os.path.join(e, "out.%s.gw_phased.bed.gz" % order)), order
+
+
+def test_cli_blacklist_beds_match_reference(tmp_path):
+    """--blacklist and --haplo_count_blacklist through the drop-in CLI (phaser.py:220-243): the FULL VCF plus two BED files in,
+    the five files the reference wrote for the equivalently pre-filtered VCF / blacklist set out (tests/golden/pipe_bed)."""
+    from phaser_amd import phaser
+    d0 = os.path.join(GOLD, "pipe_opts"); d = os.path.join(GOLD, "pipe_bed")
+    bams = []
+    for b in ("o1", "o2"):
+        p = tmp_path / (b + ".sam")
+        p.write_text("".join(gz_text(os.path.join(d0, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")))
+        bams.append(str(p))
+    prefix = str(tmp_path / "out")
+    rc = phaser.main(["--vcf", os.path.join(d0, "in.vcf"), "--bam", ",".join(bams), "--sample", "S1", "--mapq", "255", "--baseq", "10",
+                      "--paired_end", "1", "--o", prefix, "--write_vcf", "0", "--threads", "2",
+                      "--blacklist", os.path.join(d, "blacklist.bed"), "--haplo_count_blacklist", os.path.join(d, "haplo_blacklist.bed")])
+    assert rc == 0
+    out = {name: open(prefix + "." + name + ".txt").read() for name in OUTPUTS}
+    compare(out, d)
+    ase = [l.split("\t") for l in out["haplotypic_counts"].split("\n")[1:] if l]
+    assert any(int(r[6]) > 0 for r in ase)           # some block really lost a variant to the haplotype-count blacklist

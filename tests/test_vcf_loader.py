@@ -111,3 +111,71 @@ def test_grep_hom_prefilter_inside_the_loader():
         assert list(a.chroms) == list(b.chroms) and a.het_count == b.het_count and a.filter_count == b.filter_count
         for c in a.chroms:
             assert a.chroms[c].table_rows() == b.chroms[c].table_rows()
+
+
+def _bed(path):
+    rows = [l.split("\t") for l in open(path).read().split("\n") if l and not l.startswith("track")]
+    return [(c[0], int(c[1]), int(c[2])) for c in rows if len(c) >= 3]
+
+
+def _hits(iv, chrom, pos1, ref_len):
+    s, e = pos1 - 1, pos1 - 1 + max(1, ref_len)
+    return any(c == chrom and a < e and s < b for c, a, b in iv)
+
+
+def test_bed_filters_match_brute_force():
+    """--blacklist / --haplo_count_blacklist inside the native loader (merged intervals + binary search) vs the bedtools rule applied
+    line by line: dropped records vanish before anything is counted, marked variants carry blacklisted = 1."""
+    import json
+    import random
+    from conftest import GOLD
+    from phaser_amd import vcf
+    d = os.path.join(GOLD, "pipe_bed")
+    text = open(os.path.join(GOLD, "pipe_opts", "in.vcf")).read()
+    drop = _bed(os.path.join(d, "blacklist.bed")); mark = _bed(os.path.join(d, "haplo_blacklist.bed"))
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    rng = random.Random(3)
+    for rep in range(6):
+        if rep:      # more interval soups: nested, adjacent, duplicated, empty, unsorted
+            pos = [int(l.split("\t")[1]) for l in text.split("\n") if l and l[0] != "#"]
+            drop = []; mark = []
+            for iv in (drop, mark):
+                for _ in range(rng.randrange(1, 40)):
+                    p = rng.choice(pos); a = p - 1 + rng.randrange(-3, 3); iv.append((rng.choice(["chr21", "chr22"]), max(0, a), max(0, a) + rng.randrange(0, 4000)))
+                iv += iv[:3]
+        kept = [l for l in text.split("\n") if not l or l[0] == "#" or not _hits(drop, l.split("\t")[0], int(l.split("\t")[1]), len(l.split("\t")[3]))]
+        want = vcf.load_variants("\n".join(kept), gw_phase_method=1)
+        got = vcf.load_variants(text, gw_phase_method=1, drop_bed=drop, mark_bed=mark, threads=3)
+        assert list(got.chroms) == list(want.chroms) and (got.het_count, got.filter_count, got.unphased_count) == (want.het_count, want.filter_count, want.unphased_count)
+        marked = set()
+        for c in want.chroms:
+            assert got.chroms[c].uid == want.chroms[c].uid and (got.chroms[c].pos == want.chroms[c].pos).all()
+            bl = [_hits(mark, c, int(p), 1) for p in want.chroms[c].pos]
+            assert got.chroms[c].blacklisted.tolist() == [int(x) for x in bl]
+            marked |= set("%s_%d" % (c, int(p)) for p, x in zip(want.chroms[c].pos, bl) if x)
+        if rep == 0:
+            assert text.count("\n") - "\n".join(kept).count("\n") == meta["dropped_lines"]
+            assert marked <= set(meta["haplo_blacklist"])          # the reference's set also holds non-het / filtered lines
+
+
+def test_chr_restriction_precedes_the_contig_check():
+    """with --chr the reference reads `tabix -h vcf chr:`, so a banned character in ANOTHER contig's name is never seen."""
+    from phaser_amd import vcf
+    text = ("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+            "chr1\t100\t.\tA\tG\t50\tPASS\t.\tGT\t0|1\n"
+            "chr1_gl000191_random\t50\t.\tC\tT\t50\tPASS\t.\tGT\t0|1\n"
+            "chrUn_x\t70\t.\tC\tT\t50\tPASS\t.\tGT\t1|0\n")
+    vs = vcf.load_variants(text, chrom_of_interest="chr1")
+    assert list(vs.chroms) == ["chr1"] and vs.het_count == 1
+    with pytest.raises(SystemExit):
+        vcf.load_variants(text)
+
+
+def test_long_ref_is_refused_not_truncated():
+    """len(REF) > 255 with --include_indels 1 used to be stored saturated; now it is an explicit 'unsupported'."""
+    from phaser_amd import _lib, vcf
+    text = ("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+            "chr1\t100\t.\t" + "A" * 300 + "\tA\t50\tPASS\t.\tGT\t0|1\n")
+    assert vcf.load_variants(text).het_count == 0                    # SNP mode: the indel is simply excluded
+    with pytest.raises(_lib.PhzError):
+        vcf.load_variants(text, include_indels=1)

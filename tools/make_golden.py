@@ -20,6 +20,7 @@ import argparse
 import gzip
 import hashlib
 import io
+import random
 import json
 import os
 import shutil
@@ -409,6 +410,57 @@ def fx_options(phaser, rvm):
         print("pipe_opts/%s" % name, [l.strip() for l in res["log"].splitlines() if "PHASED" in l])
 
 
+def bed_overlaps(iv, chrom, pos1, ref_len):
+    """bedtools semantics, brute force: a VCF record is the 0-based interval [POS-1, POS-1+len(REF)); hit = >= 1 shared base."""
+    s, e = pos1 - 1, pos1 - 1 + max(1, ref_len)
+    return any(c == chrom and a < e and s < b for c, a, b in iv)
+
+
+def fx_blacklist_bed(phaser, rvm):
+    """--blacklist / --haplo_count_blacklist (phaser.py:220-243).  bedtools is not installed, so the reference cannot run its own
+    BED step here; what it does with the result is pinned instead: process_vcf is run on the VCF with the lines `bedtools intersect -v`
+    would remove already removed (brute-force overlap above), and with the haplotype-count blacklist set `bedtools intersect`
+    would yield (same brute force over the remaining lines).  The product is then fed the FULL VCF plus the two BED files."""
+    d0 = os.path.join(GOLD, "pipe_bed"); os.makedirs(d0, exist_ok=True)
+    vs, sams, vcf = opts_inputs()
+    rng = random.Random(4242)
+    drop = []; mark = []
+    for v in vs:
+        pos = v.pos.tolist()
+        for k in range(6):                      # blocks of neighbouring variants, HLA-style
+            i = rng.randrange(0, len(pos) - 4)
+            drop.append((v.chrom, pos[i] - 1 - rng.randrange(0, 200), pos[i + rng.randrange(0, 3)] + rng.randrange(0, 200)))
+        j = rng.randrange(0, len(pos))
+        drop.append((v.chrom, pos[j] - 1, pos[j]))                      # exactly one base: the variant itself
+        drop.append((v.chrom, pos[(j + 5) % len(pos)], pos[(j + 5) % len(pos)] + 40))      # starts right AFTER a variant: no hit
+        drop.append((v.chrom, max(0, pos[(j + 9) % len(pos)] - 41), pos[(j + 9) % len(pos)] - 1))  # ends right BEFORE a variant: no hit
+        for k in range(10):
+            i = rng.randrange(0, len(pos) - 2)
+            mark.append((v.chrom, pos[i] - 1 - rng.randrange(0, 50), pos[i + rng.randrange(0, 2)] + rng.randrange(0, 50)))
+        mark.append((v.chrom, pos[3], pos[3] + 1))                      # the base after a variant: no hit
+    drop.append(("chrUn_other", 0, 10 ** 9)); mark.append(("chr_absent", 5, 50))
+    rng.shuffle(drop); rng.shuffle(mark)
+    open(os.path.join(d0, "blacklist.bed"), "w").write("track name=test\n" + "".join("%s\t%d\t%d\n" % x for x in drop))
+    open(os.path.join(d0, "haplo_blacklist.bed"), "w").write("".join("%s\t%d\t%d\tx\n" % x for x in mark))
+    kept = []; hb = set(); n_drop = 0
+    for line in vcf.split("\n"):
+        if not line or line[0] == "#":
+            kept.append(line); continue
+        c = line.split("\t")
+        if bed_overlaps(drop, c[0], int(c[1]), len(c[3])):
+            n_drop += 1
+            continue
+        kept.append(line)
+        if bed_overlaps(mark, c[0], int(c[1]), len(c[3])):
+            hb.add(c[0] + "_" + str(int(c[1])))
+    res, _ = run_pipeline(phaser, rvm, "\n".join(kept), sams, d0, capture_calls=False, haplo_blacklist=hb)
+    for k, t in res.items():
+        wgz(os.path.join(d0, "out." + k + ".txt.gz"), t)
+    json.dump({"dropped_lines": n_drop, "haplo_blacklist": sorted(hb)}, open(os.path.join(d0, "meta.json"), "w"), indent=1)
+    print("pipe_bed: %d VCF lines dropped, %d variants on the haplotype-count blacklist" % (n_drop, len(hb)),
+          [l.strip() for l in res["log"].splitlines() if "PHASED" in l])
+
+
 def fx_write_vcf(phaser, rvm):
     """Phased VCF text (write_vcf, phaser.py:1661-1855) for pipe_one / pipe_noisy_c inputs under the three --gw_phase_vcf modes."""
     for src, mbs in [("pipe_one", 15), ("pipe_noisy_c", 15), ("pipe_two", 15)]:
@@ -584,7 +636,7 @@ def fx_expr_matrix(phaser, rvm):
         print("expr_matrix", order, len(files), "files ->", out_all.split("\n")[0].count("\t") - 3, "sample columns,", len(out_all.splitlines()) - 1, "rows")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "write_vcf_more": fx_write_vcf_more, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix}
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "write_vcf_more": fx_write_vcf_more, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix, "blacklist_bed": fx_blacklist_bed}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
