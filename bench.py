@@ -251,6 +251,7 @@ def main():
                                           "model": "8 B x call lines + 16 B x pair events (SURVEY.md 8(d))", "call_lines": lines,
                                           "pair_events": events, "items": items, "edges": edges, "kernel_ms_sum_over_ranks": tally_ms}})
             del eng, files
+            pdist.cleanup_spool()          # every rank: the spooled row text of this pass is no longer needed
         if rank == 0:
             phasing = dict(max(runs, key=lambda r: r["value"]))
             phasing["passes"] = [round(r["value"]) for r in runs]

@@ -133,6 +133,8 @@ typedef struct {
     int32_t *edge_b;
     int32_t *edge_cells;     /* [n_edges*9] |S_a[i] & S_b[j]| at i*3+j, classes ref/alt/other */
     uint8_t *edge_linked;    /* [n_edges] 1 when some QNAME's surviving read_vars list holds both variants */
+    int32_t *edge_cto;       /* [n_edges*3] the three sums of test_variant_connection (:1634-1636): same configuration (rr+aa),
+                              * opposite (ar+ra), other (the five cells with an "other" allele) */
     uint32_t *rl_start;      /* [nv*2*n_bams + 1] read lists (phaser.py:1318-1322): the kept lines of (variant v, allele k, BAM b) */
     int32_t *rl_qid;         /* [n_read_list]     are rl_qid[rl_start[(2v+k)*n_bams+b] : rl_start[... + 1]] = their QNAME ids
                               *                   (chromosome-local, as passed in read_qid) in line order */
@@ -293,7 +295,8 @@ typedef struct {
     /* tested variant pairs (linked edges), oriented by first appearance: rows of variant_connections in eorder */
     int64_t n_edges;
     const int32_t *va, *vb, *ea, *eb;
-    const int64_t *sup, *tot, *cis, *trans, *cfgv, *eorder;
+    const int32_t *sup, *tot, *cis, *trans, *cfgv;
+    const int64_t *eorder;
     const double *pv;
     /* connected components of the surviving graph */
     int64_t ncomp;
@@ -322,10 +325,17 @@ typedef struct {
     const int64_t *bam_line_lo, *bam_line_hi;
 } phz_rows_in;
 
+/* Row text comes back as the buffers the worker threads filled, in output order (no concatenation pass: at whole-genome scale the
+ * text is ~1 GB).  bam[i] (allelic counts / singleton rows only) = the first BAM the rows of part i are keyed to (rule 2). */
 typedef struct {
-    char *conn, *hap, *ase, *cfg, *allelic, *single_ase, *single_hap;     /* row text, reference order within the chromosome */
-    int64_t conn_len, hap_len, ase_len, cfg_len, allelic_len, single_ase_len, single_hap_len;
-    int64_t *allelic_seg, *single_ase_seg, *single_hap_seg;   /* [nb+1] byte offsets of the rows keyed to each first BAM */
+    int64_t n;
+    const char *const *ptr;
+    const int64_t *len;
+    const int32_t *bam;
+} phz_text_parts;
+
+typedef struct {
+    phz_text_parts conn, hap, ase, cfg, allelic, single_ase, single_hap;     /* reference row order within the chromosome */
     int64_t allelic_rows, n_blocks, phased, n_blk_vars;
     int32_t *blk_size;        /* [n_blocks] variants per block */
     /* filled when want_vcf: per block variant lists and genome-wide phase for write_vcf (:1661-1855) */
@@ -335,6 +345,7 @@ typedef struct {
     double *blk_stat;         /* [n_blocks] gw confidence */
     uint8_t *blk_stat_int;    /* [n_blocks] 1 when the reference prints the int 1 */
     int32_t *blk_maxmaf;      /* [n_blocks] variant carrying max(maf) */
+    void *owner;              /* keeps the text buffers alive until phz_rows_free */
 } phz_rows_out;
 
 int phz_rows_format(const phz_rows_in *in, phz_rows_out *out);

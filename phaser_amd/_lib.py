@@ -62,7 +62,7 @@ class phz_tally_sizes(C.Structure):
 
 class phz_tally_out(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("var_count", "var_first", "var_distinct", "var_rank", "line_cls", "edge_a", "edge_b", "edge_cells",
-                                          "edge_linked", "rl_start", "rl_qid")]
+                                          "edge_linked", "edge_cto", "rl_start", "rl_qid")]
 
 
 class phz_host_shard(C.Structure):
@@ -94,13 +94,15 @@ class phz_rows_in(C.Structure):
                 ("var_first", C.c_void_p), ("bam_line_lo", C.c_void_p), ("bam_line_hi", C.c_void_p)]
 
 
+class phz_text_parts(C.Structure):
+    _fields_ = [("n", C.c_int64), ("ptr", C.POINTER(C.c_void_p)), ("len", C.POINTER(C.c_int64)), ("bam", C.POINTER(C.c_int32))]
+
+
 class phz_rows_out(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("conn", "hap", "ase", "cfg", "allelic", "single_ase", "single_hap")] + \
-               [(k, C.c_int64) for k in ("conn_len", "hap_len", "ase_len", "cfg_len", "allelic_len", "single_ase_len",
-                                         "single_hap_len")] + \
-               [(k, C.POINTER(C.c_int64)) for k in ("allelic_seg", "single_ase_seg", "single_hap_seg")] + \
+    _fields_ = [(k, phz_text_parts) for k in ("conn", "hap", "ase", "cfg", "allelic", "single_ase", "single_hap")] + \
                [(k, C.c_int64) for k in ("allelic_rows", "n_blocks", "phased", "n_blk_vars")] + \
-               [(k, C.c_void_p) for k in ("blk_size", "blk_var", "blk_hap", "blk_cor", "blk_stat", "blk_stat_int", "blk_maxmaf")]
+               [(k, C.c_void_p) for k in ("blk_size", "blk_var", "blk_hap", "blk_cor", "blk_stat", "blk_stat_int", "blk_maxmaf")] + \
+               [("owner", C.c_void_p)]
 
 
 class phz_hc_arrays(C.Structure):

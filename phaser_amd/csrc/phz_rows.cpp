@@ -728,6 +728,12 @@ struct ChromState {
     std::vector<TextChunk> cc, ac, sc;
 };
 
+// the chunk buffers of one phz_rows_format_multi call; every phz_rows_out of the call holds a reference
+struct RowsOwner {
+    std::vector<ChromState> st;
+    std::atomic<int> refs{0};
+};
+
 }  // namespace
 
 // Several chromosomes in ONE thread pool (a genome's chromosomes differ 5x in size: per-chromosome calls would leave threads idle
@@ -745,7 +751,9 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         t_prev = now;
     };
     for (int c = 0; c < n_chroms; c++) memset(&out[c], 0, sizeof(out[c]));
-    std::vector<ChromState> st((size_t)n_chroms);
+    RowsOwner *keep = new RowsOwner();
+    keep->st.resize((size_t)n_chroms);
+    std::vector<ChromState> &st = keep->st;
     // ---- phase A: per-chromosome setup + component weights
     std::vector<int64_t> totals((size_t)n_chroms, 0);
     std::vector<const phz_rows_in *> use((size_t)n_chroms);
@@ -798,7 +806,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         else run_conn(S.C, k.i * estep, std::min<int64_t>(use[(size_t)k.c]->n_edges, (k.i + 1) * estep), S.cc[(size_t)k.i]);
     });
     lap("block phasing + block / connection rows");
-    for (auto &S : st) for (auto &c : S.bc) if (c.status) return c.status;
+    for (auto &S : st) for (auto &c : S.bc) if (c.status) { const int code = c.status; delete keep; return code; }
     // ---- phase B2: allelic counts + singleton rows (need to know which variants ended up in a block)
     tasks.clear();
     for (int c = 0; c < n_chroms; c++) {
@@ -814,24 +822,25 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         if (use[(size_t)k.c]->unphased_vars == 1) run_singles(S.C, S.kb[(size_t)k.i], S.kb[(size_t)k.i + 1], S.sc[(size_t)k.i]);
     });
     lap("allelic counts + singleton rows");
-    // ---- phase C: one allocation per (chromosome, file); every chunk copied into place by the pool
-    struct Copy { char *dst; const std::string *src; };
-    std::vector<Copy> copies;
+    // ---- phase C: hand the chunk buffers over as they are (no concatenation); they stay alive through the shared owner
     bool nomem = false;
-    auto lay = [&](const std::vector<const std::string *> &parts, char **p, int64_t *len) {
-        size_t total = 0;
-        for (auto *x : parts) total += x->size();
-        *p = (char *)malloc(total + 1);
-        if (!*p) { nomem = true; return; }
-        (*p)[total] = 0; *len = (int64_t)total;
-        size_t off = 0;
-        for (auto *x : parts) { if (x->size()) copies.push_back({*p + off, x}); off += x->size(); }
+    auto parts = [&](const std::vector<const std::string *> &src, const std::vector<int32_t> *bam, phz_text_parts *P) {
+        std::vector<const char *> ptr; std::vector<int64_t> len; std::vector<int32_t> bm;
+        for (size_t i = 0; i < src.size(); i++) {
+            if (src[i]->empty()) continue;
+            ptr.push_back(src[i]->data()); len.push_back((int64_t)src[i]->size());
+            if (bam) bm.push_back((*bam)[i]);
+        }
+        P->n = (int64_t)ptr.size();
+        P->ptr = take_vec(ptr); P->len = take_vec(len); P->bam = bam ? take_vec(bm) : nullptr;
+        if (!P->ptr || !P->len || (bam && !P->bam)) nomem = true;
     };
     for (int c = 0; c < n_chroms; c++) {
         const phz_rows_in &I = *use[(size_t)c];
         ChromState &S = st[(size_t)c];
         phz_rows_out &O = out[c];
         std::vector<const std::string *> p_hap, p_ase, p_cfg, p_conn, p_all, p_sa, p_sh;
+        std::vector<int32_t> kbam;
         std::vector<int32_t> bvar, bsize, bmaxmaf; std::vector<uint8_t> bhap, bstat_int; std::vector<int8_t> bcor; std::vector<double> bstat;
         int64_t phased = 0;
         for (auto &x : S.bc) {
@@ -844,28 +853,25 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
             bsize.insert(bsize.end(), x.bsize.begin(), x.bsize.end());
         }
         for (auto &x : S.cc) p_conn.push_back(&x.a);
-        std::vector<int64_t> aseg((size_t)I.nb + 1, 0), sseg_a((size_t)I.nb + 1, 0), sseg_h((size_t)I.nb + 1, 0);
-        int64_t arows = 0, la = 0, lsa = 0, lsh = 0;
+        int64_t arows = 0;
         for (size_t i = 0; i + 1 < S.kb.size(); i++) {
             const int64_t b = S.kb[i] < I.n_keys ? I.key_bam[S.kb[i]] : 0;
             p_all.push_back(&S.ac[i].a); p_sa.push_back(&S.sc[i].a); p_sh.push_back(&S.sc[i].b); arows += S.ac[i].rows;
-            la += (int64_t)S.ac[i].a.size(); lsa += (int64_t)S.sc[i].a.size(); lsh += (int64_t)S.sc[i].b.size();
-            for (int64_t k = b + 1; k <= I.nb; k++) { aseg[(size_t)k] = la; sseg_a[(size_t)k] = lsa; sseg_h[(size_t)k] = lsh; }
+            kbam.push_back((int32_t)b);
         }
-        lay(p_conn, &O.conn, &O.conn_len); lay(p_hap, &O.hap, &O.hap_len); lay(p_ase, &O.ase, &O.ase_len); lay(p_cfg, &O.cfg, &O.cfg_len);
-        lay(p_all, &O.allelic, &O.allelic_len); lay(p_sa, &O.single_ase, &O.single_ase_len); lay(p_sh, &O.single_hap, &O.single_hap_len);
+        parts(p_conn, nullptr, &O.conn); parts(p_hap, nullptr, &O.hap); parts(p_ase, nullptr, &O.ase); parts(p_cfg, nullptr, &O.cfg);
+        parts(p_all, &kbam, &O.allelic); parts(p_sa, &kbam, &O.single_ase); parts(p_sh, &kbam, &O.single_hap);
         O.allelic_rows = arows;
-        O.allelic_seg = take_vec(aseg); O.single_ase_seg = take_vec(sseg_a); O.single_hap_seg = take_vec(sseg_h);
         O.n_blocks = (int64_t)bsize.size(); O.phased = phased;
         O.blk_size = take_vec(bsize);
         O.n_blk_vars = (int64_t)bvar.size();
         O.blk_var = take_vec(bvar); O.blk_hap = take_vec(bhap); O.blk_cor = take_vec(bcor); O.blk_stat = take_vec(bstat);
         O.blk_stat_int = take_vec(bstat_int); O.blk_maxmaf = take_vec(bmaxmaf);
+        O.owner = keep;
     }
+    keep->refs = n_chroms;
+    lap("hand-over of the text buffers");
     if (nomem) { for (int c = 0; c < n_chroms; c++) phz_rows_free(&out[c]); return PHZ_E_NOMEM; }
-    lap("layout of the output buffers");
-    parallel_chunks(threads, (int64_t)copies.size(), [&](int64_t i) { memcpy(copies[(size_t)i].dst, copies[(size_t)i].src->data(), copies[(size_t)i].src->size()); });
-    lap("chunks copied into place");
     return PHZ_OK;
 }
 
@@ -909,8 +915,14 @@ extern "C" int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i
 
 extern "C" void phz_rows_free(phz_rows_out *o) {
     if (!o) return;
-    free(o->conn); free(o->hap); free(o->ase); free(o->cfg); free(o->allelic); free(o->single_ase); free(o->single_hap);
-    free(o->allelic_seg); free(o->single_ase_seg); free(o->single_hap_seg); free(o->blk_size); free(o->blk_var); free(o->blk_hap);
+    for (phz_text_parts *P : {&o->conn, &o->hap, &o->ase, &o->cfg, &o->allelic, &o->single_ase, &o->single_hap}) {
+        free((void *)P->ptr); free((void *)P->len); free((void *)P->bam);
+    }
+    free(o->blk_size); free(o->blk_var); free(o->blk_hap);
     free(o->blk_cor); free(o->blk_stat); free(o->blk_stat_int); free(o->blk_maxmaf);
+    if (o->owner) {
+        RowsOwner *k = (RowsOwner *)o->owner;
+        if (k->refs.fetch_sub(1) == 1) delete k;
+    }
     memset(o, 0, sizeof(*o));
 }

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *gkeys, int
     e_b[p] = (uint32_t)k; e_slot[p] = (uint32_t)i;
 }
 __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, const int32_t *gvals,
-                                                    int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked) {
+                                                    int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked, int32_t *cto) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= nv) return;
     const uint32_t lo = eoff[a], hi = eoff[a + 1];
@@ -468,9 +468,12 @@ __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *
     for (uint32_t i = lo; i < hi; i++) {
         ea[i] = (int32_t)a; eb[i] = (int32_t)e_b[i];
         const int64_t s = e_slot[i];
+        int32_t x[9];
 #pragma unroll
-        for (int c = 0; c < 9; c++) cells[(int64_t)i * 9 + c] = gvals[s * PH_VALS + c];
+        for (int c = 0; c < 9; c++) { x[c] = gvals[s * PH_VALS + c]; cells[(int64_t)i * 9 + c] = x[c]; }
         linked[i] = (uint8_t)(gvals[s * PH_VALS + 9] & 1);
+        // test_variant_connection's three sums (phaser.py:1634-1636): same configuration rr+aa, opposite ar+ra, the five "other" cells
+        cto[(int64_t)i * 3] = x[0] + x[4]; cto[(int64_t)i * 3 + 1] = x[3] + x[1]; cto[(int64_t)i * 3 + 2] = x[6] + x[7] + x[2] + x[5] + x[8];
     }
 }
 
@@ -537,7 +540,7 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
 // scratch slots of ctx->scratch used by the tally (0 is the AS histogram, 16.. belong to components / K_map)
 enum { T_QOWN = 1, T_QFIRST, T_QCOUNT, T_QOFF, T_ITEMS, T_SORT_TMP, T_COUNTERS, T_GKEYS, T_GVALS, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP };
 // results and the read-list sort buffers live in their own buffers (ctx->tally_buf)
-enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_RLCNT, R_RLSTART, R_RLKEY, R_RLKEY2, R_RLVAL, R_RLQID, R_A0, R_A1,
+enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_RLCNT, R_RLSTART, R_RLKEY, R_RLKEY2, R_RLVAL, R_RLQID, R_A0, R_A1,
        R_COUNT };
 
 }  // namespace
@@ -734,13 +737,15 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     if (int s = phz_reserve(ctx, R[R_EB], NE * 4)) return s;
     if (int s = phz_reserve(ctx, R[R_CELLS], NE * 36)) return s;
     if (int s = phz_reserve(ctx, R[R_LINKED], NE)) return s;
+    if (int s = phz_reserve(ctx, R[R_CTO], NE * 12)) return s;
     if (int s = phz_reserve(ctx, S[T_EB], NE * 4)) return s;
     if (int s = phz_reserve(ctx, S[T_ESLOT], NE * 4)) return s;
     if (ne > 0) {
         hipLaunchKernelGGL(k_edge_scatter, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, (const uint64_t *)S[T_GKEYS].p, (int64_t)cap,
                            (const uint32_t *)eoff, deg, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
         hipLaunchKernelGGL(k_edge_final, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p,
-                           (const int32_t *)S[T_GVALS].p, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p);
+                           (const int32_t *)S[T_GVALS].p, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
+                           (int32_t *)R[R_CTO].p);
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = timer.stop()) return s;
@@ -749,6 +754,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = (int64_t)h_counters[3]; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
     T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;
     T.ea = (int32_t *)R[R_EA].p; T.eb = (int32_t *)R[R_EB].p; T.cells = (int32_t *)R[R_CELLS].p; T.linked = (uint8_t *)R[R_LINKED].p;
+    T.cto = (int32_t *)R[R_CTO].p;
     T.rl_start = rl_start; T.rl_qid = rl_qid;
     sizes->n_lines = total; sizes->n_kept = T.n_kept; sizes->n_edges = ne; sizes->n_read_list = T.n_rl;
     sizes->n_items = (int64_t)h_counters[0]; sizes->pair_events = (int64_t)h_counters[1];
@@ -779,6 +785,7 @@ extern "C" int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space
     if (int s = cp(out->edge_b, T.eb, ne * 4)) return s;
     if (int s = cp(out->edge_cells, T.cells, ne * 36)) return s;
     if (int s = cp(out->edge_linked, T.linked, ne)) return s;
+    if (int s = cp(out->edge_cto, T.cto, ne * 12)) return s;
     if (int s = cp(out->rl_start, T.rl_start, (nv * 2 * (size_t)T.nb + 1) * 4)) return s;
     if (int s = cp(out->rl_qid, T.rl_qid, (size_t)T.n_rl * 4)) return s;
     PHZ_HIP(ctx, hipStreamSynchronize(sm));

@@ -258,14 +258,14 @@ class Engine:
         G = {"nv": NV, "nb": nb, "var_base": vb, "line_base": line_base, "n_lines": int(sz.n_lines), "n_kept": int(sz.n_kept),
              "var_count": self._pinned("var_count", NV * 3, np.int32), "var_first": self._pinned("var_first", NV, np.int64),
              "var_distinct": self._pinned("var_distinct", NV * 3, np.int32), "var_rank": self._pinned("var_rank", NV, np.uint64),
-             "ea": self._pinned("ea", ne, np.int32), "eb": self._pinned("eb", ne, np.int32), "cells": self._pinned("cells", ne * 9, np.int32),
+             "ea": self._pinned("ea", ne, np.int32), "eb": self._pinned("eb", ne, np.int32), "cto": self._pinned("cto", ne * 3, np.int32),
              "linked": self._pinned("linked", ne, np.uint8), "rl_start": self._pinned("rl_start", NV * 2 * nb + 1, np.uint32),
              "rl_qid": self._pinned("rl_qid", nrl, np.int32)}
         vp = lambda a: C.c_void_p(a.ctypes.data) if a.size else None
         out = _lib.phz_tally_out(vp(G["var_count"]), vp(G["var_first"]), vp(G["var_distinct"]), vp(G["var_rank"]), None, vp(G["ea"]), vp(G["eb"]),
-                                 vp(G["cells"]), vp(G["linked"]), vp(G["rl_start"]), vp(G["rl_qid"]))
+                                 None, vp(G["linked"]), vp(G["cto"]), vp(G["rl_start"]), vp(G["rl_qid"]))
         self.ctx.check(self.lib.phz_tally_fetch(self.ctx.h, C.byref(out), _lib.PHZ_HOST))
-        G["var_count"] = G["var_count"].reshape(NV, 3); G["var_distinct"] = G["var_distinct"].reshape(NV, 3); G["cells"] = G["cells"].reshape(ne, 9)
+        G["var_count"] = G["var_count"].reshape(NV, 3); G["var_distinct"] = G["var_distinct"].reshape(NV, 3); G["cto"] = G["cto"].reshape(ne, 3)
         G["resident"] = True            # the edge list is still in HBM: phz_components can use it in place
         self.stats["tally_call_s"] = self.stats.get("tally_call_s", 0.0) + t1 - t0
         self.stats["tally_d2h_s"] = self.stats.get("tally_d2h_s", 0.0) + _t.perf_counter() - t1
@@ -277,7 +277,7 @@ class Engine:
         lo = int(np.searchsorted(G["ea"], v0, side="left")); hi = int(np.searchsorted(G["ea"], v0 + nv, side="left"))
         vc = G["var_count"][v0:v0 + nv]
         return {"nv": nv, "var_count": vc, "var_distinct": G["var_distinct"][v0:v0 + nv], "var_first": G["var_first"][v0:v0 + nv],
-                "var_rank": G["var_rank"][v0:v0 + nv], "ea": G["ea"][lo:hi] - v0, "eb": G["eb"][lo:hi] - v0, "cells": G["cells"][lo:hi],
+                "var_rank": G["var_rank"][v0:v0 + nv], "ea": G["ea"][lo:hi] - v0, "eb": G["eb"][lo:hi] - v0, "cto": G["cto"][lo:hi],
                 "linked": G["linked"][lo:hi].astype(bool), "kept": int(vc.sum())}
 
     def tally_all(self):
@@ -301,7 +301,9 @@ class Engine:
     def finish(self, binary: bool = False, chunks: bool = False) -> Optional[Dict[str, str]]:
         """Stages 3-6.  With torch.distributed initialised, every rank handles its own chromosomes and rank 0
         returns the assembled files (other ranks return None).  binary=True returns bytes (no decode pass);
-        chunks=True returns, per file, the list of buffers in output order (no join pass; write them with writelines)."""
+        chunks=True returns, per file, the list of buffers in output order (no join pass): write them with dist.write_chunks (with
+        several ranks some of them are byte ranges of the other ranks' spool files) and call dist.cleanup_spool() on EVERY rank
+        afterwards."""
         import time as _t
         t0 = _t.perf_counter()
         match, mism = pdist.allreduce_counts(*self.tally_all())
@@ -309,10 +311,12 @@ class Engine:
         t1 = _t.perf_counter()
         local = self._fragments(noise)
         t2 = _t.perf_counter()
-        frags = pdist.gather_fragments(local)
+        frags = pdist.gather_fragments(local, getattr(self, "spool_dir", None))
         self.stats.update({"tally_s": t1 - t0, "fragments_s": t2 - t1})
         self.noise = noise
         if frags is None:
+            if not chunks:
+                pdist.cleanup_spool()       # waits (barrier) until rank 0 has read the spooled row text
             return None
         t3 = _t.perf_counter()
         chroms = [c for c in self.all_chroms if c in frags]
@@ -330,7 +334,8 @@ class Engine:
         self.phased = summary["phased"]; self.total_lines = summary["lines"]
         if chunks:
             return out
-        out = {k: b"".join(v) for k, v in out.items()}
+        out = {k: b"".join(pdist.as_bytes(x) for x in v) for k, v in out.items()}
+        pdist.cleanup_spool()
         return out if binary else {k: v.decode() for k, v in out.items()}
 
     def _fragments(self, noise: float) -> Dict[str, dict]:
@@ -358,13 +363,16 @@ class Engine:
         NV = G["nv"]
         tp0 = _t.perf_counter()
         # ---- test every linked pair (phaser.py:1594-1654)
-        sel = np.nonzero(G["linked"])[0]
-        ea_g = G["ea"][sel]; eb_g = G["eb"][sel]; cells = G["cells"][sel].astype(np.int64)
-        cis = cells[:, 0] + cells[:, 4]
-        trans = cells[:, 3] + cells[:, 1]
-        oth = cells[:, 6] + cells[:, 7] + cells[:, 2] + cells[:, 5] + cells[:, 8]
+        # the three sums per pair (same configuration / opposite / other) come from the device (k_edge_final)
+        linked = G["linked"].view(bool)
+        if linked.all():
+            sel = np.arange(len(linked)); ea_g = G["ea"]; eb_g = G["eb"]; cto = G["cto"]
+        else:
+            sel = np.nonzero(linked)[0]
+            ea_g = G["ea"][sel]; eb_g = G["eb"][sel]; cto = G["cto"][sel]
+        cis = np.ascontiguousarray(cto[:, 0]); trans = np.ascontiguousarray(cto[:, 1]); oth = cto[:, 2]
         sup = np.maximum(cis, trans); tot = cis + trans + oth
-        cfgv = np.where(cis > trans, 0, np.where(cis < trans, 1, -1))
+        cfgv = np.where(cis > trans, 0, np.where(cis < trans, 1, -1)).astype(np.int32)
         prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
         pv = np.ones(len(sel), dtype=np.float64)
         tp1 = _t.perf_counter()
@@ -436,17 +444,13 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
     dropped = phased = lines = covered = 0
     for c in chrom_list:
         f = frags[c]
-        conn.append(f["conn"]); hap.append(f["hap"]); ase.append(f["ase"]); cfgf.append(f["cfg"])
+        conn += f["conn"]; hap += f["hap"]; ase += f["ase"]; cfgf += f["cfg"]
         dropped += f["dropped"]; phased += f["phased"]; lines += f["lines"]; covered += f["allelic_rows"]
-    for b in range(n_bams):
-        for c in chrom_list:
-            f = frags[c]
-            s = f["allelic_seg"]; allelic.append(f["allelic"][s[b]:s[b + 1]])
-    for key, dst in (("single_ase", ase), ("single_hap", hap)):
+    for key, dst in (("allelic", allelic), ("single_ase", ase), ("single_hap", hap)):
         for b in range(n_bams):
             for c in chrom_list:
                 f = frags[c]
-                s = f[key + "_seg"]; dst.append(f[key][s[b]:s[b + 1]])
+                dst += [p for p, pb in zip(f[key], f[key + "_bam"]) if pb == b]
     out = {"variant_connections": conn, "allelic_counts": allelic, "haplotypic_counts": ase, "haplotypes": hap, "allele_config": cfgf}
     log = ["     sequencing noise level estimated at %f" % noise,
            "     %d variant connections dropped because of conflicting configurations (threshold = %f)" % (dropped, cfg.cc_threshold),

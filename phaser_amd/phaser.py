@@ -92,8 +92,17 @@ def load_bed(path: str) -> List[tuple]:
 def main(argv=None):
     args = build_parser().parse_args(argv)
     rank, world = pdist.world()
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, n_dev)
+    if n_dev:
+        torch.cuda.set_device(local)          # before any collective: NCCL / barrier use the current device
     if world == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # one rank per GPU over RCCL ("nccl"); PHZ_DIST_BACKEND=gloo lets several ranks share a GPU (tests on a 1-GPU box)
+        backend = os.environ.get("PHZ_DIST_BACKEND", "nccl" if n_dev else "gloo")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         rank, world = pdist.world()
     say = out if rank == 0 else (lambda *_: None)
     say("")
@@ -188,8 +197,8 @@ def main(argv=None):
                  id_separator=args.id_separator, unphased_vars=args.unphased_vars, gw_phase_method=args.gw_phase_method,
                  output_read_ids=args.output_read_ids, unique_ids=args.unique_ids, haplo_count_bam_exclude=excl,
                  include_indels=args.include_indels, host_threads=max(1, args.threads))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     eng = Engine(vs, bam_names, cfg, device=local)
+    eng.spool_dir = os.path.dirname(os.path.abspath(args.o))       # ranks hand their row text to rank 0 through files next to the outputs
     device = "cuda:%d" % local
     interners: Dict[str, object] = {}
     any_sam = any(b.endswith(".sam") for b in bam_list)       # text inputs keep everything on the Python reader
@@ -238,7 +247,7 @@ def main(argv=None):
         say("#6. Outputting haplotypes...")
         for name, body in files.items():
             with open(args.o + "." + name + ".txt", "wb") as f:
-                f.writelines(body)
+                pdist.write_chunks(f, body)
         mark("write the five files")
         up = pc = 0
         if args.write_vcf == 1:
@@ -272,8 +281,7 @@ def main(argv=None):
             for (_, t_prev), (name, t) in zip(marks[:-1], marks[1:]):
                 sys.stderr.write("[phz timing] %-55s %7.2f s\n" % (name, t - t_prev))
             sys.stderr.write("[phz timing] %-55s %7.2f s\n" % ("total", marks[-1][1] - marks[0][1]))
-    if world > 1:
-        dist.barrier()
+    pdist.cleanup_spool()          # (barrier) every rank removes its spool file once rank 0 has written the outputs
     return 0
 
 

@@ -61,7 +61,7 @@ def _fill(eng, c: str, keep: list) -> "_lib.phz_rows_in":
     I.n_edges = len(P["ea"])
     I.ea = A(P["ea"], np.int32); I.eb = A(P["eb"], np.int32)
     for k in ("sup", "tot", "cis", "trans", "cfgv"):
-        setattr(I, k, A(P[k], np.int64))
+        setattr(I, k, A(P[k], np.int32))
     I.pv = A(P["pv"], np.float64); I.keep = A(P["keep"], np.uint8)
     I.rank = A(G["var_rank"][v0:v0 + nv], np.uint64); I.label = A(eng._label_all[v0:v0 + nv], np.int32)
     I.var_first = A(G["var_first"][v0:v0 + nv], np.int64)
@@ -108,25 +108,20 @@ def format_chroms(eng, chroms, threads: int) -> Dict[str, Dict]:
     eng.stats["rows_native_s"] = eng.stats.get("rows_native_s", 0.0) + _t.perf_counter() - t1
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_rows_format_multi: %s" % lib.phz_strerror(st).decode())
-    nb = len(eng.bam_names)
     res = {}
     for i, c in enumerate(chroms):
         O = OUT[i]
         owner = _NativeRows(lib, O)
 
-        def seg(name, O=O):
-            p = getattr(O, name)
-            return [int(p[k]) for k in range(nb + 1)]
-
         def vec(name, dt, cnt, O=O):
             if cnt == 0:
                 return np.zeros(0, dtype=dt)
             return np.frombuffer(C.string_at(getattr(O, name), cnt * np.dtype(dt).itemsize), dtype=dt).copy()
-        out = {"conn": owner.text("conn"), "hap": owner.text("hap"), "ase": owner.text("ase"), "cfg": owner.text("cfg"),
-               "allelic": owner.text("allelic"), "allelic_seg": seg("allelic_seg"), "allelic_rows": int(O.allelic_rows),
-               "single_ase": owner.text("single_ase"), "single_ase_seg": seg("single_ase_seg"),
-               "single_hap": owner.text("single_hap"), "single_hap_seg": seg("single_hap_seg"),
-               "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None}
+        out = {"allelic_rows": int(O.allelic_rows), "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None}
+        for name in ("conn", "hap", "ase", "cfg"):
+            out[name] = owner.parts(name)[0]
+        for name in ("allelic", "single_ase", "single_hap"):
+            out[name], out[name + "_bam"] = owner.parts(name)
         if cfg.want_vcf:
             nbk = int(O.n_blocks); nvv = int(O.n_blk_vars)
             out["vcf"] = {"size": vec("blk_size", np.int32, nbk), "var": vec("blk_var", np.int32, nvv), "hap": vec("blk_hap", np.uint8, nvv),
@@ -144,11 +139,12 @@ class _NativeRows:
         self.O = _lib.phz_rows_out()
         C.memmove(C.byref(self.O), C.byref(O), C.sizeof(_lib.phz_rows_out))      # own copy of the descriptor (O lives in an array)
 
-    def text(self, name):
-        n = getattr(self.O, name + "_len")
-        if not n:
-            return b""
-        return memoryview(_lib.native_view(getattr(self.O, name), n, C.c_uint8, self))
+    def parts(self, name):
+        """-> (list of memoryviews over the native chunk buffers in output order, list of their BAM keys or None)"""
+        P = getattr(self.O, name)
+        views = [memoryview(_lib.native_view(P.ptr[i], int(P.len[i]), C.c_uint8, self)) for i in range(int(P.n))]
+        bams = [int(P.bam[i]) for i in range(int(P.n))] if P.bam else None
+        return views, bams
 
     def __del__(self):
         try:

@@ -193,8 +193,14 @@ def genome_from_saved(saved, chrom_list, n_bams):
     return {"nv": NV, "nb": nb, "var_base": var_base, "line_base": line_base, "n_lines": L, "n_kept": int(vc.sum()), "var_count": vc,
             "var_first": cat(parts["var_first"], np.int64), "var_distinct": cat(parts["var_distinct"], np.int32).reshape(NV, 3),
             "var_rank": cat(parts["var_rank"], np.uint64), "ea": cat(parts["ea"], np.int32), "eb": cat(parts["eb"], np.int32),
-            "cells": cat(parts["cells"], np.int32).reshape(-1, 9), "linked": cat(parts["linked"], np.uint8), "rl_start": rl_start,
+            "cto": _cto(cat(parts["cells"], np.int32).reshape(-1, 9)), "linked": cat(parts["linked"], np.uint8), "rl_start": rl_start,
             "rl_qid": val[order], "resident": False}
+
+
+def _cto(cells):
+    """the three sums of test_variant_connection per pair (what k_edge_final hands out): same configuration, opposite, other"""
+    c = cells.astype(np.int64)
+    return np.stack([c[:, 0] + c[:, 4], c[:, 3] + c[:, 1], c[:, 6] + c[:, 7] + c[:, 2] + c[:, 5] + c[:, 8]], 1).astype(np.int32)
 
 
 def component_labels_cpu(G, keep_all):
