@@ -220,6 +220,12 @@ typedef struct {                 /* one reference sequence's filtered records, a
 } phz_host_shard;
 
 int phz_bam_open(const char *path, int threads, phz_bam **out);      /* reads + inflates the file, parses the header */
+/* Chromosome-restricted open (`samtools view BAM 'chr':`, phaser.py:1346, without an index file): only the BGZF members that can
+ * hold records of the named references are inflated (found by binary search over the member table of a coordinate-sorted BAM);
+ * ref_names == NULL opens everything.  ref_bytes (may be NULL, room for max_refs): compressed bytes per reference, a proxy of its
+ * record count before anything is decoded.  out == NULL: only ref_bytes is produced (nothing but a few members is inflated). */
+int phz_bam_open_refs(const char *path, int threads, const char *const *ref_names, int n_names, int64_t *ref_bytes, int max_refs,
+                      phz_bam **out);
 int phz_bam_close(phz_bam *bam);
 int phz_bam_n_ref(const phz_bam *bam);
 const char *phz_bam_ref_name(const phz_bam *bam, int i);

@@ -180,6 +180,7 @@ SYMBOLS = {
     "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),
     "phz_components": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "phz_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "phz_bam_open_refs": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "phz_bam_close": (C.c_int, [C.c_void_p]),
     "phz_bam_n_ref": (C.c_int, [C.c_void_p]),
     "phz_bam_ref_name": (C.c_char_p, [C.c_void_p, C.c_int]),

@@ -248,7 +248,13 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
     import time as _t0m
     _topen = _t0m.perf_counter()
     h = C.c_void_p()
-    st = lib.phz_bam_open(path.encode(), threads, C.byref(h))
+    if chroms is not None:
+        # only the BGZF members holding these chromosomes are inflated (a rank of a multi-GPU run reads its own share of the file)
+        names = [str(c).encode() for c in chroms]
+        arr = (C.c_char_p * max(1, len(names)))(*names) if names else (C.c_char_p * 1)()
+        st = lib.phz_bam_open_refs(path.encode(), threads, arr, len(names), None, 0, C.byref(h))
+    else:
+        st = lib.phz_bam_open(path.encode(), threads, C.byref(h))
     if st != 0:
         raise _lib.PhzError(st, "cannot read BAM " + path)
     import os as _os, sys as _sys, time as _t
@@ -301,3 +307,23 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
         _sys.stderr.write("[phz timing]   bam: open+inflate %.2f s, decode+filter+pack %.2f s, shard views %.2f s, qname interning %.2f s\n"
                           % (_t0 - _topen, _t1 - _t0, _t.perf_counter() - _t1 - _tin, _tin))
     return out
+
+
+def bam_ref_weights(path: str, threads: int = 0) -> Dict[str, int]:
+    """-> {reference name: compressed bytes its records occupy in the BAM}: a proxy of the record count per chromosome that costs a
+    few dozen member inflations (binary search over the BGZF member table), used as LPT weights before anything is decoded."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    cap = 1 << 16
+    w = np.zeros(cap, dtype=np.int64)
+    none = (C.c_char_p * 1)()
+    h = C.c_void_p()
+    st = lib.phz_bam_open_refs(path.encode(), threads, none, 0, C.c_void_p(w.ctypes.data), cap, C.byref(h))
+    if st != 0:
+        raise _lib.PhzError(st, "cannot read BAM " + path)
+    try:
+        n = lib.phz_bam_n_ref(h)
+        return {lib.phz_bam_ref_name(h, i).decode(): int(w[i]) for i in range(min(n, cap))}
+    finally:
+        lib.phz_bam_close(h)

@@ -220,6 +220,83 @@ int inflate_bgzf_file(const char *path, int threads, Vec &outbuf) {
     return bad ? PHZ_E_ARG : PHZ_OK;
 }
 
+// BAM header of an inflated stream prefix: 0 = parsed, 1 = need more bytes, 2 = malformed.  Every field is checked against the
+// size before it is used (untrusted input).
+int parse_bam_header(const uint8_t *d, size_t dn, std::vector<std::pair<std::string, int32_t>> &refs, size_t *first_record) {
+    if (dn < 12) return 1;
+    if (memcmp(d, "BAM\1", 4) != 0) return 2;
+    const int32_t l_text = rdi32(d + 4);
+    if (l_text < 0) return 2;
+    if ((size_t)l_text > dn - 12) return 1;
+    size_t p = 8 + (size_t)l_text;
+    const int32_t n_ref = rdi32(d + p); p += 4;
+    if (n_ref < 0) return 2;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (p + 4 > dn) return 1;
+        const int32_t l = rdi32(d + p); p += 4;
+        if (l < 1) return 2;
+        if ((size_t)l > dn - p || dn - p - (size_t)l < 4) return 1;
+        refs.emplace_back(std::string((const char *)d + p, (size_t)(l - 1)), 0); p += (size_t)l;
+        refs.back().second = rdi32(d + p); p += 4;
+    }
+    *first_record = p;
+    return 0;
+}
+
+// can offset p of the inflated bytes d[0, n) start a record?  -> offset of the next record, 0 when it cannot
+size_t plausible_at(const uint8_t *d, size_t n, size_t p, int n_ref) {
+    if (p + 36 > n) return 0;
+    const int32_t bs = rdi32(d + p);
+    if (bs < 32 || bs > (1 << 24) || p + 4 + (size_t)bs > n) return 0;
+    const uint8_t *r = d + p + 4;
+    const int32_t ref = rdi32(r), pos0 = rdi32(r + 4), l_seq = rdi32(r + 16), nref = rdi32(r + 20);
+    const uint32_t l_rn = r[8], n_cig = rd16(r + 12);
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 1) return 0;
+    const size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (need > (size_t)bs) return 0;
+    if (r[32 + l_rn - 1] != 0) return 0;                 // read name is NUL-terminated
+    for (uint32_t k = 0; k + 1 < l_rn; k++) if (r[32 + k] < 33 || r[32 + k] > 126) return 0;
+    return p + 4 + (size_t)bs;
+}
+
+// member table of a BGZF file (mapped, nothing inflated)
+struct BgzfMap {
+    struct Blk { size_t off, csize, isize, dst; };
+    const uint8_t *f = nullptr; size_t fsz = 0, total = 0;
+    std::vector<Blk> blks;
+    ~BgzfMap() { if (f) munmap((void *)f, fsz); }
+    int open(const char *path) {
+        int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return PHZ_E_ARG;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 28) { close(fd); return PHZ_E_ARG; }
+        fsz = (size_t)st.st_size;
+        f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (f == MAP_FAILED) { f = nullptr; return PHZ_E_NOMEM; }
+        size_t off = 0;
+        while (off + 18 <= fsz) {
+            if (f[off] != 0x1f || f[off + 1] != 0x8b) return PHZ_E_ARG;
+            if (!(f[off + 3] & 4)) return PHZ_E_UNSUPPORTED;
+            const uint16_t xlen = rd16(f + off + 10);
+            size_t x = off + 12, xe = x + xlen;
+            uint32_t bsize = 0;
+            while (x + 4 <= xe && xe <= fsz) {
+                const uint16_t slen = rd16(f + x + 2);
+                if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = (uint32_t)rd16(f + x + 4) + 1;
+                x += 4 + slen;
+            }
+            if (!bsize) return PHZ_E_UNSUPPORTED;
+            if (off + bsize > fsz || bsize < (uint32_t)xlen + 20) return PHZ_E_ARG;
+            const uint32_t isize = rd32(f + off + bsize - 4);
+            blks.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isize, total});
+            total += isize;
+            off += bsize;
+        }
+        return blks.empty() ? PHZ_E_ARG : PHZ_OK;
+    }
+};
+
 }  // namespace
 
 struct phz_bam { Bam b; };
@@ -288,23 +365,168 @@ int phz_bam_open(const char *path, int threads, phz_bam **out) {
     *out = nullptr;
     phz_bam *h = new phz_bam();
     if (int st = inflate_bgzf_file(path, threads, h->b.data)) { delete h; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
-    const RawBuf &d = h->b.data;
-    if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { delete h; return PHZ_E_ARG; }
-    // untrusted input: every header field is checked against the inflated size before it is used
-    const size_t dn = d.size();
-    const int32_t l_text = rdi32(d.data() + 4);
-    if (l_text < 0 || (size_t)l_text > dn - 12) { delete h; return PHZ_E_ARG; }
-    size_t p = 8 + (size_t)l_text;
-    const int32_t n_ref = rdi32(d.data() + p); p += 4;
-    if (n_ref < 0 || (size_t)n_ref > (dn - p) / 9) { delete h; return PHZ_E_ARG; }        // a reference entry takes >= 9 bytes
-    for (int32_t i = 0; i < n_ref; i++) {
-        if (p + 4 > dn) { delete h; return PHZ_E_ARG; }
-        const int32_t l = rdi32(d.data() + p); p += 4;
-        if (l < 1 || (size_t)l > dn - p || dn - p - (size_t)l < 4) { delete h; return PHZ_E_ARG; }
-        std::string name((const char *)d.data() + p, (size_t)(l - 1)); p += (size_t)l;
-        h->b.refs.emplace_back(name, rdi32(d.data() + p)); p += 4;
+    if (parse_bam_header(h->b.data.data(), h->b.data.size(), h->b.refs, &h->b.first_record) != 0) { delete h; return PHZ_E_ARG; }
+    *out = h;
+    return PHZ_OK;
+}
+
+// Chromosome-restricted open (what `samtools view BAM 'chr':` does with the .bai, phaser/phaser.py:1346; here without an index
+// file): the BGZF member table is read from the member headers alone, the members in which the wanted references begin / end are
+// found by binary search (a coordinate-sorted BAM keeps every reference's records contiguous; a probe inflates two members and
+// looks for the first record boundary with the same plausibility chain the parallel record hop uses), and only the members that
+// hold wanted records are inflated.  The result is a stream cut at record boundaries, i.e. a valid record chain: phz_bam_decode
+// works on it unchanged.  ref_bytes (may be NULL) receives, per reference, the compressed bytes between the members where it and
+// the next reference begin: a proxy of its record count, available before anything is decoded (LPT weights).
+int phz_bam_open_refs(const char *path, int threads, const char *const *ref_names, int n_names, int64_t *ref_bytes, int max_refs,
+                      phz_bam **out) {
+    if (out) *out = nullptr;
+    BgzfMap M;
+    if (int st = M.open(path)) return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st;
+    phz_bam *h = out ? new phz_bam() : nullptr;
+    std::vector<std::pair<std::string, int32_t>> refs_local;
+    std::vector<std::pair<std::string, int32_t>> &refs = h ? h->b.refs : refs_local;
+    // header: inflate members until it parses
+    std::vector<uint8_t> head;
+    size_t hb = 0, first_record = 0;
+    for (;;) {
+        if (hb >= M.blks.size()) { delete h; return PHZ_E_ARG; }
+        const size_t old = head.size();
+        head.resize(old + M.blks[hb].isize);
+        if (M.blks[hb].isize && !inflate_block(M.f + M.blks[hb].off, M.blks[hb].csize, head.data() + old, M.blks[hb].isize)) { delete h; return PHZ_E_ARG; }
+        hb++;
+        refs.clear();
+        const int rc = parse_bam_header(head.data(), head.size(), refs, &first_record);
+        if (rc == 0) break;
+        if (rc < 0 && head.size() > (1u << 30)) { delete h; return PHZ_E_ARG; }
+        if (rc == 2) { delete h; return PHZ_E_ARG; }       // malformed, not merely short
     }
-    h->b.first_record = p;
+    const int n_ref = (int)refs.size();
+    const size_t nb = M.blks.size();
+    // first member that holds the first record
+    size_t b0 = 0;
+    while (b0 + 1 < nb && M.blks[b0 + 1].dst <= first_record) b0++;
+    // probe(b): global uncompressed offset and refID of the first record that STARTS in member b or later members (up to 8 ahead)
+    auto probe = [&](size_t b, uint64_t *uoff, int32_t *ref) -> bool {
+        std::vector<uint8_t> tmp;
+        for (size_t b1 = b; b1 < nb && b1 < b + 8; b1++) {
+            tmp.clear();                                   // window = members b1 .. b1+2
+            for (size_t k = b1; k < nb && k < b1 + 3; k++) {
+                const size_t old = tmp.size();
+                tmp.resize(old + M.blks[k].isize);
+                if (M.blks[k].isize && !inflate_block(M.f + M.blks[k].off, M.blks[k].csize, tmp.data() + old, M.blks[k].isize)) return false;
+            }
+            if (b1 == b0) {                                // the true first record: no guess needed
+                const size_t p = first_record - M.blks[b0].dst;
+                if (p + 8 > tmp.size()) return false;      // a BAM without records
+                *uoff = first_record; *ref = rdi32(tmp.data() + p + 4);
+                return true;
+            }
+            const bool at_eof = b1 + 3 >= nb;
+            const size_t lim = M.blks[b1].isize;
+            for (size_t p = 0; p < lim; p++) {
+                size_t q = p; int ok = 0;
+                while (ok < 12) {
+                    const size_t nx = plausible_at(tmp.data(), tmp.size(), q, n_ref);
+                    if (!nx) break;
+                    ok++; q = nx;
+                    if (at_eof && q + 36 > tmp.size()) { ok = 12; break; }      // the chain ran into the end of the file
+                }
+                if (ok >= 12) { *uoff = M.blks[b1].dst + p; *ref = rdi32(tmp.data() + p + 4); return true; }
+            }
+        }
+        return false;
+    };
+    const int32_t INF = 0x7fffffff;
+    // first member b in [b0, nb] whose first starting record has refID >= r (unmapped = -1 sorts last; no boundary = past the end)
+    auto search = [&](int32_t r) -> size_t {
+        size_t lo = b0, hi = nb;
+        while (lo < hi) {
+            const size_t m = (lo + hi) >> 1;
+            uint64_t u; int32_t ref;
+            int32_t key = INF;
+            if (probe(m, &u, &ref)) key = ref < 0 ? INF : ref;
+            if (key >= r) hi = m; else lo = m + 1;
+        }
+        return lo;
+    };
+    std::vector<size_t> begin_blk((size_t)n_ref + 1, nb);
+    std::vector<char> want((size_t)n_ref, 0);
+    for (int i = 0; i < n_ref; i++) {
+        if (!ref_names) { want[(size_t)i] = 1; continue; }
+        for (int k = 0; k < n_names; k++) if (refs[(size_t)i].first == ref_names[k]) want[(size_t)i] = 1;
+    }
+    if (ref_bytes) {
+        for (int i = 0; i <= n_ref; i++) begin_blk[(size_t)i] = i == 0 ? b0 : search(i);
+        for (int i = 0; i < n_ref && i < max_refs; i++) {
+            const size_t a = begin_blk[(size_t)i], b = begin_blk[(size_t)i + 1];
+            const size_t fa = a < nb ? M.blks[a].off : M.fsz, fb = b < nb ? M.blks[b].off : M.fsz;
+            ref_bytes[i] = (int64_t)(fb > fa ? fb - fa : 0);
+        }
+    }
+    if (!h) return PHZ_OK;
+    // runs of consecutive wanted references -> byte ranges [u_begin, u_end) of the uncompressed stream, cut at record boundaries
+    struct Piece { uint64_t u0, u1; };
+    std::vector<Piece> pieces;
+    uint64_t total_u = M.total;
+    for (int i = 0; i < n_ref;) {
+        if (!want[(size_t)i]) { i++; continue; }
+        int j = i;
+        while (j + 1 < n_ref && want[(size_t)j + 1]) j++;
+        const size_t bs = ref_bytes ? begin_blk[(size_t)i] : (i == 0 ? b0 : search(i));
+        const size_t be = ref_bytes ? begin_blk[(size_t)j + 1] : search(j + 1);
+        uint64_t u0 = first_record, u1 = total_u; int32_t rr;
+        const size_t sb = bs > b0 ? bs - 1 : b0;                  // records of reference i may begin in the member before bs
+        if (sb > b0) { if (!probe(sb, &u0, &rr)) u0 = M.blks[sb].dst; }
+        if (be < nb) { if (!probe(be, &u1, &rr)) u1 = total_u; }
+        if (!pieces.empty() && u0 < pieces.back().u1) u0 = pieces.back().u1;       // the member before this run may belong to the previous piece
+        if (u1 > u0) pieces.push_back({u0, u1});
+        i = j + 1;
+    }
+    size_t out_size = first_record;
+    for (auto &p : pieces) out_size += (size_t)(p.u1 - p.u0);
+    if (!h->b.data.resize(out_size)) { delete h; return PHZ_E_NOMEM; }
+    memcpy(h->b.data.data(), head.data(), first_record);
+    // inflate plan: members fully inside a piece go straight to their place, edge members through a scratch buffer
+    struct Job { size_t blk; size_t dst; size_t skip, take; };
+    std::vector<Job> jobs;
+    size_t base = first_record;
+    for (auto &p : pieces) {
+        size_t b = b0;
+        {   // first member overlapping u0
+            size_t lo = 0, hi = nb;
+            while (lo < hi) { const size_t m = (lo + hi) >> 1; if (M.blks[m].dst + M.blks[m].isize <= p.u0) lo = m + 1; else hi = m; }
+            b = lo;
+        }
+        for (; b < nb && M.blks[b].dst < p.u1; b++) {
+            const uint64_t s0 = std::max<uint64_t>(M.blks[b].dst, p.u0), s1 = std::min<uint64_t>(M.blks[b].dst + M.blks[b].isize, p.u1);
+            if (s1 > s0) jobs.push_back({b, base + (size_t)(s0 - p.u0), (size_t)(s0 - M.blks[b].dst), (size_t)(s1 - s0)});
+        }
+        base += (size_t)(p.u1 - p.u0);
+    }
+    const int nt = n_threads(threads);
+    std::atomic<size_t> next(0);
+    std::atomic<bool> bad(false);
+    std::vector<std::thread> th;
+    uint8_t *dstbuf = h->b.data.data();
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&] {
+            std::vector<uint8_t> scratch;
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= jobs.size()) break;
+                const Job &j = jobs[k];
+                const auto &B = M.blks[j.blk];
+                if (j.skip == 0 && j.take == B.isize) { if (!inflate_block(M.f + B.off, B.csize, dstbuf + j.dst, B.isize)) bad = true; }
+                else {
+                    scratch.resize(B.isize);
+                    if (!inflate_block(M.f + B.off, B.csize, scratch.data(), B.isize)) { bad = true; continue; }
+                    memcpy(dstbuf + j.dst, scratch.data() + j.skip, j.take);
+                }
+            }
+        });
+    for (auto &t : th) t.join();
+    if (bad) { delete h; return PHZ_E_ARG; }
+    h->b.first_record = first_record;
     *out = h;
     return PHZ_OK;
 }

@@ -204,3 +204,37 @@ def test_threaded_decoder_on_a_larger_bam(tmp_path, monkeypatch):
     got = bamio.shards_from_bam_native(path, {}, 0, False, False, threads=6)["chr21"]
     for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
         assert torch.equal(getattr(got, f), getattr(want, f)), f
+
+
+def test_region_open_equals_full_decode(tmp_path):
+    """phz_bam_open_refs (only the BGZF members of the wanted chromosomes are inflated) gives exactly the shards of the full decode,
+    for every subset of references, incl. references without records and the first / last one; the byte weights are positive for
+    populated references and their order of magnitude follows the record counts."""
+    import itertools
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    contigs = [("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrEmpty", 1000)]
+    batches = []
+    counts = {}
+    for i, (c, ln) in enumerate(contigs[:4]):
+        if c == "chr20":
+            continue                                            # a reference between two populated ones with no records at all
+        v, gs, ge, w = synth.make_variants(c, 1, 3_000_000, 150, 40 + i, n_genes=12)
+        rb = synth.make_reads(v, gs, ge, w, 4000 * (i + 1), 50 + i)
+        batches.append(rb); counts[c] = len(rb)
+    bam = str(tmp_path / "r.bam")
+    bamio.readbatch_to_bam(bam, batches, contigs)
+    full = bamio.shards_from_bam_native(bam, {}, 0, False, False, 0.0, threads=2)
+    assert {c: s.n for c, s in full.items()} == counts
+    names = [c for c, _ in contigs]
+    for k in range(1, 4):
+        for sub in itertools.combinations(names, k):
+            got = bamio.shards_from_bam_native(bam, {}, 0, False, False, 0.0, chroms=set(sub), threads=2)
+            assert set(got) == set(sub) & set(full), sub
+            for c in got:
+                for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score"):
+                    assert torch.equal(getattr(got[c], f), getattr(full[c], f)), (sub, c, f)
+    w = bamio.bam_ref_weights(bam, threads=2)
+    assert list(w) == names and w["chr20"] == 0 and w["chrEmpty"] == 0
+    assert w["chr19"] > 0 and w["chr22"] > w["chr19"]
+    assert abs(sum(w.values()) - os.path.getsize(bam)) < 70000            # everything but the header member and the EOF marker
