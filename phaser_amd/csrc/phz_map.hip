@@ -78,9 +78,6 @@ struct MapBatch {
     int32_t *tile_total;          // [ntiles]
     int slot_cap, dbg;
     int64_t ntiles;
-    int32_t *hard_list;           // tiles the fast kernel leaves to the general one (bit 29 of their tile_w0[4T+1])
-    unsigned int *n_hard;
-    int all_hard;                 // 1: every tile goes to the general kernel (non-default tiling / A-B runs)
 };
 
 __device__ __forceinline__ int shard_of(const int64_t *tile0, int n_shards, int64_t T) {
@@ -230,8 +227,6 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
     return cnt;
 }
 
-constexpr int OPS_TILE = 256;      // records per tile of the op-parallel kernel
-constexpr int OPS_MAX = 768;       // CIGAR words it stages per tile (3 per record; tiles with more are "hard")
 constexpr int MAP_COVER = 65536;   // the staged window holds every het SNP below POS(last read of the tile) + MAP_COVER ...
 constexpr int MAP_SLACK = 64;      // ... plus this many further entries (probe overshoot / loop sentinels)
 
@@ -263,12 +258,8 @@ __global__ void k_tile_window(MapBatch bt, int tile_reads) {
     int complete = 1 << 30;
     if (len > MAP_WIN) { len = MAP_WIN; complete = 0; }
     const uint32_t n_ops = cigar_off[last + 1] - cigar_off[t * tile_reads];
-    // the op-parallel kernel takes tiles whose window and CIGAR words fit its LDS arrays; the rest goes to the general kernel
-    int hard = 0;
-    if (bt.all_hard) hard = 1 << 29;
-    else if (!complete || n_ops > (uint32_t)OPS_MAX) { hard = 1 << 29; bt.hard_list[atomicAdd(bt.n_hard, 1u)] = (int32_t)T; }
     tile_w[4 * T] = lo;
-    tile_w[4 * T + 1] = len | complete | hard;
+    tile_w[4 * T + 1] = len | complete | (si << 16);          // bits 0-15 window length, 16-28 shard of the tile, 30 window complete
     tile_w[4 * T + 2] = (int32_t)cigar_off[t * tile_reads];            // first CIGAR word of the tile
     tile_w[4 * T + 3] = (int32_t)n_ops;
 }
@@ -305,8 +296,9 @@ __device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT
 }
 
 template <int MAP_BLOCK, int RPT>
-__device__ void map_tile_general(const MapBatch &bt, const int64_t gtile) {
-    const int si = shard_of(bt.tile0, bt.n_shards, gtile);
+__device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile) {
+    const int4 tw = *reinterpret_cast<const int4 *>(bt.tile_w0 + 4 * gtile);      // the pre-pass left the tile's shard here: no search
+    const int si = (tw.y >> 16) & 0x1FFF;
     MapArgs a;
     {
         const ShardDev &sh = bt.shards[si];
@@ -351,7 +343,6 @@ __device__ void map_tile_general(const MapBatch &bt, const int64_t gtile) {
     }
     if (tid == 0) { s_coff[TILE] = a.cigar_off[r0 + nr]; s_ncand = 0; s_ncx = 0; }
     VarWin vw;
-    const int4 tw = *reinterpret_cast<const int4 *>(a.tile_w0 + 4 * gtile);
     vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = tw.x;
     vw.wlen = tw.y & 0xFFFF;
     const bool complete = (tw.y >> 30) & 1;
@@ -546,287 +537,9 @@ __device__ void map_tile_general(const MapBatch &bt, const int64_t gtile) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ op-parallel kernel
-// Same rule, organised around CIGAR ops instead of records.  Every aligned run (M / = / X op) of the tile is one work item:
-//   R   a record's lane turns its op list into per-op start offsets (reference offset from POS, read offset); single-run records
-//       (the common case) need no loop, multi-op records are packed densely first so the short op loop runs on full waves.
-//       Records the lean rules cannot express (an insertion or a packer 'G' op: the reference's insertion keying quirk, or a
-//       read longer than 65535 bases) are marked SLOW and go through walk_read, the general per-record walker.
-//   S   one lane per op (consecutive lanes = consecutive ops = neighbouring positions): ONE wave-uniform window search brackets
-//       the het SNPs any of the wave's runs can touch -- empty for most waves -- and each run scans just that bracket
-//   G   one gather (2-bit base + quality byte) per candidate, again one lane per op
-//   F   block scan of the per-op call counts; ops are in (record, op) order, which IS mapper order, so the scan offsets are final
-// There is no per-record divergent walk on the fast path and no candidate buffer; the kernel is launched for all tiles and
-// returns at once on the few "hard" ones (window or op list larger than the LDS arrays), which k_map_general_tiles handles.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_map_ops(MapBatch bt) {
-    constexpr int TILE = OPS_TILE;
-    constexpr int RPT = TILE / BLOCK;
-    constexpr int NW = BLOCK / 64;
-    constexpr int ROWS = OPS_MAX / BLOCK;
-    static_assert(TILE % BLOCK == 0 && OPS_MAX % BLOCK == 0, "tile shape");
-    __shared__ int32_t s_vpos[MAP_WIN];
-    __shared__ int32_t s_pos[TILE];
-    __shared__ uint32_t s_coff[TILE + 1];
-    __shared__ uint32_t s_soff[TILE];
-    __shared__ uint32_t s_cig[OPS_MAX];
-    __shared__ int32_t s_og[OPS_MAX];        // R: reference offset of the op's first base from POS; S onwards: read offset minus reference position
-    __shared__ uint16_t s_or[OPS_MAX];       // R: read offset at the op's start; S onwards: window index of the first het SNP under the run
-    __shared__ uint16_t s_oj[OPS_MAX];       // record of the op; 0xFFFF = nothing to do; bit 15 set = head of a SLOW record
-    __shared__ uint8_t s_oc[OPS_MAX];        // S: candidates under the run; G onwards: mask of those that are calls
-    __shared__ uint32_t s_ocode[OPS_MAX];    // 4 bits per candidate: base code, 4 = other text
-    __shared__ uint16_t s_cx[TILE];          // multi-op records, dense
-    __shared__ uint16_t s_rcnt[TILE];        // calls of a SLOW record
-    __shared__ uint8_t s_slow[TILE];
-    __shared__ int s_ncx;
-    __shared__ int s_rowsum[ROWS * NW];
-
-    const int64_t gtile = blockIdx.x;
-    const int4 tw = *reinterpret_cast<const int4 *>(bt.tile_w0 + 4 * gtile);
-    if ((tw.y >> 29) & 1) return;            // hard tile
-    const int si = shard_of(bt.tile0, bt.n_shards, gtile);
-    MapArgs a;
-    {
-        const ShardDev &sh = bt.shards[si];
-        a.pos = sh.pos; a.cigar_off = sh.cigar_off; a.cigar = sh.cigar; a.seq_off = sh.seq_off; a.seq2 = sh.seq2; a.qual = sh.qual;
-        a.n = sh.n; a.vpos = sh.vpos; a.nv = sh.nv; a.baseq = bt.baseq;
-        a.stage = bt.stage;
-        a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = bt.dbg;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t tile = gtile - bt.tile0[si];
-    const int64_t r0 = tile * TILE;
-    const int nr = (int)((a.n - r0) < TILE ? (a.n - r0) : TILE);
-    const uint32_t c_begin = (uint32_t)tw.z;
-    const int n_ops = tw.w;
-    const int wlen = tw.y & 0xFFFF;
-    const int w0 = tw.x;
-
-    // ---- staging: coalesced loads of the tile's slices, its CIGAR words and its het-SNP window
-#pragma unroll
-    for (int k = 0; k < RPT; k++) {
-        const int j = k * BLOCK + tid;
-        const bool ok = j < nr;
-        s_pos[j] = ok ? a.pos[r0 + j] : 0;
-        s_soff[j] = ok ? a.seq_off[r0 + j] : 0;
-        s_coff[j] = a.cigar_off[r0 + (ok ? j : nr)];
-        s_slow[j] = 0;
-    }
-    if (tid == 0) { s_coff[TILE] = a.cigar_off[r0 + nr]; s_ncx = 0; }
-    for (int j = tid; j < wlen; j += BLOCK) {
-        const int idx = w0 + j;
-        s_vpos[j] = idx < a.nv ? a.vpos[idx] : 0x7fffffff;
-    }
-    for (int o = tid; o < n_ops; o += BLOCK) { s_cig[o] = a.cigar[c_begin + o]; s_oj[o] = 0xFFFFu; s_oc[o] = 0; }
-    __syncthreads();
-    const long long cover = (long long)s_pos[nr - 1] + MAP_COVER;     // every het SNP below this is inside the window
-
-    // ---- R: records -> per-op offsets
-#pragma unroll
-    for (int k = 0; k < RPT; k++) {
-        const int j = k * BLOCK + tid;
-        if (j >= nr) continue;
-        const uint32_t c0 = s_coff[j] - c_begin, c1 = s_coff[j + 1] - c_begin;
-        if (c1 - c0 == 1) {
-            const uint32_t op = s_cig[c0] & 15;
-            if (op == OP_M || op == OP_EQ || op == OP_X) { s_oj[c0] = (uint16_t)j; s_og[c0] = 0; s_or[c0] = 0; }
-            else if (op == OP_I || op == OP_G) s_slow[j] = 1;      // never yields a call, but keep the general walker the judge of that
-        } else if (c1 - c0 > 1) {
-            s_cx[atomicAdd(&s_ncx, 1)] = (uint16_t)j;
-        }
-    }
-    __syncthreads();
-    const int ncx = s_ncx;
-    for (int t = tid; t < ncx; t += BLOCK) {
-        const int j = s_cx[t];
-        const uint32_t c0 = s_coff[j] - c_begin, c1 = s_coff[j + 1] - c_begin;
-        int g = 0; uint32_t r = 0;
-        bool slow = false;
-        for (uint32_t k = c0; k < c1; k++) {
-            const uint32_t w = s_cig[k];
-            const uint32_t len = w >> 4, op = w & 15;
-            if (op == OP_M || op == OP_EQ || op == OP_X) {
-                if (r + len > 65535u) slow = true;
-                s_oj[k] = (uint16_t)j; s_og[k] = g; s_or[k] = (uint16_t)r;
-                g += (int)len; r += len;
-            } else if (op == OP_D || op == OP_N) g += (int)len;
-            else if (op == OP_S) r += len;
-            else if (op == OP_I || op == OP_G) slow = true;
-            // H, P: no effect (read_variant_map.py:227-229)
-        }
-        if (slow) s_slow[j] = 1;
-    }
-    __syncthreads();
-
-    // ---- S: one lane per op; wave-uniform bracket of the window, per-run scan inside it
-#pragma unroll
-    for (int row = 0; row < ROWS; row++) {
-        if (row * BLOCK >= n_ops) break;
-        const int o = row * BLOCK + tid;
-        int j = 0, lo = 0x7fffffff, hi = (int)0x80000000;
-        bool valid = false;
-        if (o < n_ops) {
-            const uint32_t oj = s_oj[o];
-            if (oj != 0xFFFFu) {
-                j = (int)oj;
-                if (!s_slow[j]) {
-                    lo = s_pos[j] + s_og[o];
-                    const long long h2 = (long long)lo + (long long)(s_cig[o] >> 4);
-                    if (h2 > cover) { s_slow[j] = 1; lo = 0x7fffffff; }        // the run reaches past the staged window: general walker
-                    else { hi = (int)h2; valid = true; }
-                }
-            }
-        }
-        int wmin = lo, wmax = hi;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(wmin, d); wmin = y < wmin ? y : wmin; const int z = __shfl_xor(wmax, d); wmax = z > wmax ? z : wmax; }
-        if (wmax <= wmin) continue;                                     // no run on this wave (wave-uniform)
-        const int target = lane < 32 ? wmin : wmax;
-        int bound = 0;
-        {
-            int n = wlen;
-            while (n > 1) {
-                const int half = n >> 1;
-                bound += (s_vpos[bound + half - 1] < target) ? half : 0;
-                n -= half;
-            }
-            bound += (wlen > 0 && s_vpos[bound] < target) ? 1 : 0;
-        }
-        const int ba = __shfl(bound, 0), bb = __shfl(bound, 32);
-        if (bb <= ba) continue;                                         // no het SNP under any run of the wave
-        if (valid) {
-            int base, c = 0;
-            if (bb - ba <= 24) {
-                int below = 0;
-                for (int e = ba; e < bb; e++) {
-                    const int vp = s_vpos[e];
-                    below += vp < lo ? 1 : 0;
-                    c += (vp >= lo && vp < hi) ? 1 : 0;
-                }
-                base = ba + below;
-            } else {
-                base = 0;
-                int n = wlen;
-                while (n > 1) {
-                    const int half = n >> 1;
-                    base += (s_vpos[base + half - 1] < lo) ? half : 0;
-                    n -= half;
-                }
-                base += (s_vpos[base] < lo) ? 1 : 0;
-                while (base + c < wlen && s_vpos[base + c] < hi && c <= 8) c++;
-            }
-            if (c > 8) s_slow[j] = 1;                                   // a run over more than 8 het SNPs: general walker
-            else if (c > 0) {
-                s_og[o] = (int)s_or[o] - lo;                            // read offset of a base = its reference position + this
-                s_or[o] = (uint16_t)base;
-                s_oc[o] = (uint8_t)c;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- G: resolve the candidates (the only global gathers of the fast path: two bytes per candidate)
-#pragma unroll
-    for (int row = 0; row < ROWS; row++) {
-        if (row * BLOCK >= n_ops) break;
-        const int o = row * BLOCK + tid;
-        if (o >= n_ops) continue;
-        const int c = s_oc[o];
-        if (c == 0) continue;
-        const int j = s_oj[o];
-        if (s_slow[j]) { s_oc[o] = 0; continue; }
-        const uint32_t soff = s_soff[j];
-        const int delta = s_og[o], base = s_or[o];
-        uint32_t mask = 0, codes = 0;
-        for (int i = 0; i < c; i++) {
-            const int x = s_vpos[base + i] + delta;
-            const int sy = masked_base(a, soff, x);
-            if (sy != 4) { mask |= 1u << i; codes |= (uint32_t)(sy < 4 ? sy : 4) << (4 * i); }
-        }
-        s_oc[o] = (uint8_t)mask;
-        s_ocode[o] = codes;
-    }
-    // ---- SLOW records: the general walker counts their calls; the count sits on the record's first op
-    VarWin vw; vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = w0; vw.wlen = wlen;
-    CigWin cw; cw.g = a.cigar; cw.lds = s_cig; cw.c_begin = c_begin; cw.cap = (uint32_t)n_ops;
-    CandBuf cb; cb.key = nullptr; cb.var = nullptr; cb.aux0 = nullptr; cb.aux1 = nullptr; cb.n = nullptr; cb.cap = 0;
-#pragma unroll
-    for (int k = 0; k < RPT; k++) {
-        const int j = k * BLOCK + tid;
-        if (j >= nr || !s_slow[j]) continue;
-        const uint32_t c0 = s_coff[j], c1 = s_coff[j + 1];
-        int cnt = walk_read<1>(a, vw, cw, cb, j, r0 + j, s_pos[j], c0, c1, s_soff[j], 0, 0);
-        if (cnt > 65535) cnt = 65535;           // cannot happen below slot capacities that fit memory; keeps the field honest
-        s_rcnt[j] = (uint16_t)cnt;
-        s_oj[c0 - c_begin] = (uint16_t)(0x8000u | (uint32_t)j);
-    }
-    __syncthreads();
-
-    // ---- F: scan of the per-op call counts (ops are in mapper order) and flush into the tile's staging slot
-    int cnt[ROWS], incl[ROWS];
-#pragma unroll
-    for (int row = 0; row < ROWS; row++) {
-        const int o = row * BLOCK + tid;
-        int x = 0;
-        if (o < n_ops) {
-            const uint32_t oj = s_oj[o];
-            if (oj != 0xFFFFu && (oj & 0x8000u)) x = s_rcnt[oj & 0x7FFFu];
-            else if (oj != 0xFFFFu && !s_slow[oj]) x = __popc((unsigned)s_oc[o]);
-        }
-        cnt[row] = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
-        incl[row] = x;
-        if (lane == 63) s_rowsum[row * NW + wave] = x;
-    }
-    __syncthreads();
-    int total = 0;
-    int before[ROWS];
-#pragma unroll
-    for (int row = 0; row < ROWS; row++) {
-#pragma unroll
-        for (int w2 = 0; w2 < NW; w2++) {
-            const int sct = s_rowsum[row * NW + w2];
-            if (w2 == wave) before[row] = total;
-            total += sct;
-        }
-    }
-    if (tid == 0) a.tile_total[gtile] = total;
-    const int64_t slot0 = gtile * (int64_t)a.slot_cap;
-#pragma unroll
-    for (int row = 0; row < ROWS; row++) {
-        if (cnt[row] == 0) continue;
-        const int o = row * BLOCK + tid;
-        int off = before[row] + incl[row] - cnt[row];
-        const uint32_t oj = s_oj[o];
-        if (oj & 0x8000u) {
-            const int j = (int)(oj & 0x7FFFu);
-            const int64_t lim = off + cnt[row] < a.slot_cap ? off + cnt[row] : a.slot_cap;
-            walk_read<2>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], s_soff[j], slot0 + off, slot0 + lim);
-        } else {
-            const int j = (int)oj;
-            const uint32_t mask = s_oc[o], codes = s_ocode[o];
-            const int delta = s_og[o], base = s_or[o];
-            for (int i = 0; i < 8; i++) {
-                if (!((mask >> i) & 1)) continue;
-                if (off < a.slot_cap)
-                    a.stage[slot0 + off] = make_uint4((uint32_t)(w0 + base + i), (uint32_t)(s_vpos[base + i] + delta), 0u,
-                                                      (uint32_t)j | (((codes >> (4 * i)) & 15u) << 16));
-                off++;
-            }
-        }
-    }
-}
-
-// the general kernel: every tile (all_hard) or only the tiles the op-parallel kernel left (a few workgroups walk the hard list)
 template <int MAP_BLOCK, int RPT>
-__global__ __launch_bounds__(MAP_BLOCK) void k_map_general_tiles(MapBatch bt) {
-    if (bt.all_hard) { map_tile_general<MAP_BLOCK, RPT>(bt, (int64_t)blockIdx.x); return; }
-    const unsigned n = *bt.n_hard;
-    for (unsigned h = blockIdx.x; h < n; h += gridDim.x) {
-        map_tile_general<MAP_BLOCK, RPT>(bt, (int64_t)bt.hard_list[h]);
-        __syncthreads();
-    }
+__global__ __launch_bounds__(MAP_BLOCK) void k_map(MapBatch bt) {
+    map_tile<MAP_BLOCK, RPT>(bt, (int64_t)blockIdx.x);
 }
 
 // two-level exclusive prefix sum of the per-tile totals: 1024-tile chunks in parallel, then one small pass
@@ -902,6 +615,7 @@ struct CompactArgs {
     const uint4 *stage;
     const ShardDev *shards; const int64_t *tile0; int n_shards;
     const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base; const int64_t *shard_base;
+    const int32_t *tile_w0;
     int slot_cap, tile_reads; int64_t ntiles;
 };
 
@@ -930,7 +644,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
     int n = c.tile_total[T];
     if (n == 0) return;
     if (n > c.slot_cap) n = c.slot_cap;
-    const int si = shard_of(c.tile0, c.n_shards, T);
+    const int si = (c.tile_w0[4 * T + 1] >> 16) & 0x1FFF;
     const ShardDev &sh = c.shards[si];
     const uint4 *src = c.stage + T * (int64_t)c.slot_cap;
     const int64_t dst = calls_before(c.chunk_base, c.tile_pref, T) - c.shard_base[si];
@@ -962,9 +676,6 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
     { const char *e = getenv("PHZ_MAP_BLOCK"); if (e && atoi(e) > 0) blk = atoi(e); }
     if (!((blk == 64 || blk == 128 || blk == 256) && (rpt == 2 || rpt == 4))) return phz_fail(ctx, PHZ_E_ARG, "bad PHZ_MAP_BLOCK / PHZ_MAP_RPT");
     const int tile_reads = blk * rpt;
-    bool use_general = false; int ops_block = 256;
-    { const char *e = getenv("PHZ_MAP_KERNEL"); if (e && !strcmp(e, "general")) use_general = true; }
-    { const char *e = getenv("PHZ_MAP_OPS_BLOCK"); if (e && atoi(e) == 128) ops_block = 128; }
     // live shards (records and variants present) and their tile ranges
     std::vector<int> live;
     for (int i = 0; i < n; i++) {
@@ -992,6 +703,7 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
     }
     ht0[m] = ntiles;
     if (ntiles >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "too many tiles in one submission");
+    if (m > 0x1FFF) return phz_fail(ctx, PHZ_E_ARG, "more than 8191 shards in one submission");
     const ShardDev *d_shards = (const ShardDev *)ctx->shard_tab.p;
     const int64_t *d_tile0 = (const int64_t *)((char *)ctx->shard_tab.p + (size_t)m * sizeof(ShardDev));
     int64_t *d_shard_base = (int64_t *)((char *)ctx->shard_tab.p + tab_bytes);
@@ -1019,36 +731,23 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         const int slot_cap = ctx->map_slot_cap;
         const size_t slots = (size_t)ntiles * (size_t)slot_cap;
         if (int s = phz_reserve(ctx, S[18], slots * 16)) return s;
-        if (int s = phz_reserve(ctx, S[19], (size_t)ntiles * 4 + 16)) return s;
-        if (int s = phz_reserve(ctx, S[20], 64)) return s;
         MapBatch bt;
         bt.shards = d_shards; bt.tile0 = d_tile0; bt.n_shards = m; bt.baseq = baseq;
         bt.stage = (uint4 *)S[18].p;
         bt.tile_w0 = (int32_t *)ctx->tile_w0.p; bt.tile_total = (int32_t *)S[17].p;
         bt.slot_cap = slot_cap; bt.ntiles = ntiles;
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
-        bt.hard_list = (int32_t *)S[19].p; bt.n_hard = (unsigned int *)S[20].p;
-        bt.all_hard = (use_general || tile_reads != OPS_TILE) ? 1 : 0;
-        PHZ_HIP(ctx, hipMemsetAsync(bt.n_hard, 0, 4, sm));
         hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm, bt, tile_reads);
         PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[0], sm));
-        if (!bt.all_hard) {
-            if (ops_block == 128) hipLaunchKernelGGL((k_map_ops<128>), dim3((unsigned)ntiles), dim3(128), 0, sm, bt);
-            else hipLaunchKernelGGL((k_map_ops<256>), dim3((unsigned)ntiles), dim3(256), 0, sm, bt);
-        }
-        if (bt.all_hard) {
-#define PHZ_LAUNCH_MAP(B, R) hipLaunchKernelGGL((k_map_general_tiles<B, R>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt)
-            if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
-            else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
-            else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
-            else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
-            else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
-            else PHZ_LAUNCH_MAP(256, 4);
+#define PHZ_LAUNCH_MAP(B, R) hipLaunchKernelGGL((k_map<B, R>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt)
+        if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
+        else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
+        else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
+        else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
+        else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
+        else PHZ_LAUNCH_MAP(256, 4);
 #undef PHZ_LAUNCH_MAP
-        }
         PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[1], sm));
-        // tiles the op-parallel kernel left (window / op list beyond its LDS arrays): a small fixed grid walks the list
-        if (!bt.all_hard) hipLaunchKernelGGL((k_map_general_tiles<128, 2>), dim3(512), dim3(128), 0, sm, bt);
         hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
                            chunk_max);
         hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(1024), 0, sm, (const int64_t *)chunk_sum, (const int32_t *)chunk_max, nchunks, chunk_base,
@@ -1059,6 +758,7 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         c.stage = bt.stage;
         c.shards = d_shards; c.tile0 = d_tile0; c.n_shards = m;
         c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base; c.shard_base = d_shard_base;
+        c.tile_w0 = bt.tile_w0;
         c.slot_cap = slot_cap; c.tile_reads = tile_reads; c.ntiles = ntiles;
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
         PHZ_HIP(ctx, hipGetLastError());
