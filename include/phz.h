@@ -237,6 +237,25 @@ int phz_bam_decode(phz_bam *bam, const uint8_t *ref_mask, int min_mapq, int flag
                    double isize_cutoff, int threads, int *n_shards);
 int phz_bam_shard(phz_bam *bam, int i, phz_host_shard *out);
 
+/* ---- SAM text front end of the mapper seam (phaser/read_variant_map.py:25-64 per input line + the packing of one shard per
+ * chromosome): @SQ contigs, field split, |TLEN| <= isize_cutoff (0 = no filter), AS = last AS: tag, records grouped per RNAME in
+ * input order.  `text` must stay alive as long as the handle (records keep pointers into it). */
+typedef struct phz_sam phz_sam;
+int phz_sam_parse(const char *text, int64_t len, double isize_cutoff, int threads, phz_sam **out);
+const char *phz_sam_error(const phz_sam *h);
+void phz_sam_free(phz_sam *h);
+int64_t phz_sam_n_records(const phz_sam *h);          /* alignment lines seen (before the TLEN filter) */
+int phz_sam_n_contigs(const phz_sam *h);
+const char *phz_sam_contig(const phz_sam *h, int i);
+int phz_sam_n_shards(const phz_sam *h);
+int phz_sam_shard(phz_sam *h, int i, phz_host_shard *out);
+/* the mapper's output lines of one chromosome (read_variant_map.py:117) from a K_map call list; id / rsid / gt / maf are sep pools
+ * over the chromosome's variant-table rows.  out is malloc'd (phz_buf_free). */
+int phz_sam_calls_tsv(const phz_sam *h, int shard, int64_t n_calls, const int32_t *read_idx, const int32_t *var_idx, const uint8_t *code,
+                      const uint32_t *aux0, const uint32_t *aux1, int baseq, const uint32_t *id_off, const char *id,
+                      const uint32_t *rsid_off, const char *rsid, const uint32_t *gt_off, const char *gt, const uint32_t *maf_off,
+                      const char *maf, int threads, char **out, int64_t *out_len);
+
 /* whole BGZF file -> malloc'd buffer (free with phz_buf_free); PHZ_E_UNSUPPORTED when the file is plain gzip */
 int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len);
 void phz_buf_free(char *p);

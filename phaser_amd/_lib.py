@@ -187,6 +187,16 @@ SYMBOLS = {
     "phz_bam_ref_length": (C.c_int64, [C.c_void_p, C.c_int]),
     "phz_bam_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]),
     "phz_bam_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_host_shard)]),
+    "phz_sam_parse": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
+    "phz_sam_error": (C.c_char_p, [C.c_void_p]),
+    "phz_sam_free": (None, [C.c_void_p]),
+    "phz_sam_n_records": (C.c_int64, [C.c_void_p]),
+    "phz_sam_n_contigs": (C.c_int, [C.c_void_p]),
+    "phz_sam_contig": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "phz_sam_n_shards": (C.c_int, [C.c_void_p]),
+    "phz_sam_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_host_shard)]),
+    "phz_sam_calls_tsv": (C.c_int, [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_int64)]),
     "phz_bgzf_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "phz_buf_free": (None, [C.c_void_p]),
     "phz_bgzf_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),

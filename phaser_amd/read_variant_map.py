@@ -61,8 +61,95 @@ def _allele_text(code, aux0, aux1, seq, qual, baseq):
     return s.replace("D", "")
 
 
-def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=None):
+def _native_sam(data: bytes, isize_cutoff: float, threads: int):
+    """phz_sam_parse: header contigs + one packed shard per chromosome (input order).  -> (handle owner, contigs, [(chrom, shard)])"""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    st = lib.phz_sam_parse(C.cast(C.c_char_p(data), C.c_void_p), len(data), float(isize_cutoff), int(threads), C.byref(h))
+    if st != _lib.PHZ_OK:
+        msg = (lib.phz_sam_error(h) or b"").decode()
+        lib.phz_sam_free(h)
+        raise _lib.PhzError(st, msg or "phz_sam_parse failed")
+
+    class _Owner:
+        def __init__(self):
+            self.h = h; self.data = data          # the records point into `data`
+
+        def __del__(self):
+            try:
+                lib.phz_sam_free(self.h)
+            except Exception:
+                pass
+    owner = _Owner()
+    contigs = [lib.phz_sam_contig(h, i).decode() for i in range(lib.phz_sam_n_contigs(h))]
+    shards = []
+    for i in range(lib.phz_sam_n_shards(h)):
+        hs = _lib.phz_host_shard()
+        lib.phz_sam_shard(h, i, C.byref(hs))
+        n = hs.n_reads
+
+        def arr(ptr, count, dt):
+            ct = {torch.int32: C.c_int32, torch.uint8: C.c_uint8}[dt]
+            return torch.from_numpy(_lib.native_view(ptr, count, ct, owner))
+        sh = soa.ReadShard(arr(hs.pos, n, torch.int32), arr(hs.cigar_off, n + 1, torch.int32), arr(hs.cigar, hs.n_ops, torch.int32),
+                           arr(hs.seq_off, n + 1, torch.int32), arr(hs.seq2, hs.n_seq_bytes, torch.uint8),
+                           arr(hs.qual, hs.n_seq_bytes * 4, torch.uint8))
+        shards.append((hs.ref_name.decode(), sh))
+    return owner, contigs, shards
+
+
+def _do_native(table, baseq, o, isize_cutoff, mapper, threads):
+    """SNP-mode fast path: native SAM parse / pack, K_map, native TSV formatting."""
+    import ctypes as C
+    from . import _lib
+    from .vcf import sep_pool
+    lib = _lib.load()
+    data = sys.stdin.buffer.read() if hasattr(sys.stdin, "buffer") else sys.stdin.read().encode()
+    owner, contigs, shards = _native_sam(data, float(isize_cutoff), threads)
+    tchroms = []
+    for c in table.chr:
+        if not tchroms or tchroms[-1] != c:
+            tchroms.append(c)
+    for rc, _ in shards:
+        for vc in tchroms:
+            if vc != rc and vc not in contigs:
+                print("Error, VCF and BAM contigs do not match VCF = %s BAM = %s" % (vc, rc))
+                sys.exit(1)
+    tchr = np.asarray(table.chr, dtype=object)
+    with open(o, "wb") as out:
+        for si, (chrom, shard) in enumerate(shards):
+            vsel = np.nonzero(tchr == chrom)[0]
+            if len(vsel) == 0 or shard.n == 0:
+                continue
+            vpos = torch.tensor([table.pos[i] for i in vsel], dtype=torch.int32)
+            calls = mapper.map(shard, vpos, int(baseq)).cpu()
+            if calls.n == 0:
+                continue
+            pools = [sep_pool([col[i] for i in vsel]) for col in (table.id, table.rsid, table.gt, table.maf)]
+            arrs = [np.ascontiguousarray(t.numpy()) for t in (calls.read_idx, calls.var_idx, calls.code, calls.aux0, calls.aux1)]
+            p = C.c_void_p(); n = C.c_int64(0)
+            args = [C.c_void_p(a.ctypes.data) for a in arrs]
+            pool_args = []
+            for off, b in pools:
+                pool_args += [C.c_void_p(off.ctypes.data), C.cast(C.c_char_p(b), C.c_void_p)]
+            st = lib.phz_sam_calls_tsv(owner.h, si, calls.n, *args, int(baseq), *pool_args, int(threads), C.byref(p), C.byref(n))
+            if st != _lib.PHZ_OK:
+                raise _lib.PhzError(st, "phz_sam_calls_tsv failed")
+            try:
+                out.write(C.string_at(p, n.value))
+            finally:
+                lib.phz_buf_free(p)
+
+
+def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=None, threads: int = 0):
     table = VariantTable(variant_table)
+    snp_only = all(rl == 1 for rl in table.ref_len) and all(len(a) == 1 and a in _BASES for al in
+                                                            (_individual_alleles(x, g) for x, g in zip(table.alleles, table.gt)) for a in al)
+    if splice == 1 and snp_only:
+        # the whole stream through native code: parse + pack (host threads), K_map, TSV formatting
+        return _do_native(table, baseq, o, isize_cutoff, _mapper or Mapper(), threads)
     contigs: List[str] = []
     # records grouped per chromosome in input order
     chrom_order: List[str] = []

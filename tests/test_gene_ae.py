@@ -101,3 +101,20 @@ def test_gene_ae_gpu_big_block_matches_oracle():
     hc = head + row
     got = gene_ae.gene_ae(hc.encode(), bed)
     assert _canon(got) == _canon(go.gene_ae(hc, bed))
+
+
+def test_null_feature_interval_is_refused_like_intervaltree():
+    """intervaltree 3.x refuses `tree[a:b] = x` with a >= b (ValueError "Null Interval objects not allowed"), which ends the
+    reference's script at phaser_gene_ae.py:51; product and oracle stop with the same error instead of inventing a result.  The other
+    interval rules relied on (tree[a:b] returns the intervals with begin < b and end > a; the per-variant test at :191 is CLOSED at the
+    feature end) are pinned by the *_bounds fixtures, generated by the reference's script on features that sit on those edges."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import gene_ae_oracle as go
+    from phaser_amd import _lib, gene_ae
+    _lib.build()
+    hc, bed, kw, want = case_inputs("pipe_one")
+    bad = bed + "chr22\t500\t500\tnull\n"
+    with pytest.raises(ValueError):
+        go.gene_ae(hc, bad)
+    with pytest.raises(ValueError):
+        gene_ae.gene_ae(hc.encode(), bad, _pair_counts=_items_on_cpu)

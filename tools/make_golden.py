@@ -535,6 +535,32 @@ def gene_ae_features(hc_text, seed):
     return "".join("%s\t%d\t%d\t%s\n" % f for f in feats if f[2] > f[1])
 
 
+def gene_ae_boundary_features(hc_text):
+    """Features that sit exactly on the edges the two overlap rules of phaser_gene_ae.py disagree about: the IntervalTree query is
+    half-open (`tree[start-1:stop]`, :107) while the per-variant test is closed at the feature end (`(pos-1) - feature.end <= 0`,
+    :191).  For every block with >= 3 variants p0 < p1 < p2 ... (1-based): a feature ending right at p1-1 (closed rule pulls p1 in),
+    one starting right after p1, a single-base feature on p1, a twin with identical coordinates, features touching the block from
+    the left / right by zero and by one base."""
+    rows = [l.split("\t") for l in hc_text.split("\n")[1:] if l]
+    feats = []
+    seen = set()
+    for r in rows:
+        vs = r[3].split(",")
+        if len(vs) < 3 or (r[0], r[1]) in seen:
+            continue
+        seen.add((r[0], r[1]))
+        p = [int(u.split("_")[1]) for u in vs]
+        s0, e0 = int(r[1]) - 1, int(r[2])                 # the row's query interval [start-1, stop)
+        k = len(feats)
+        feats += [(r[0], p[0] - 1, p[1] - 1, "b%d_end_on_next" % k), (r[0], p[1], p[2], "b%d_starts_after" % k),
+                  (r[0], p[1] - 1, p[1], "b%d_single" % k), (r[0], p[0] - 1, p[1] - 1, "b%d_twin" % k),
+                  (r[0], e0, e0 + 50, "b%d_right_touch" % k), (r[0], max(0, s0 - 50), s0, "b%d_left_touch" % k),
+                  (r[0], max(0, s0 - 50), s0 + 1, "b%d_left_one" % k), (r[0], e0 - 1, e0 + 50, "b%d_right_one" % k)]
+        if len(feats) > 160:
+            break
+    return "".join("%s\t%d\t%d\t%s\n" % f for f in feats if f[2] > f[1])
+
+
 def fx_gene_ae(phaser, rvm):
     """phaser_gene_ae: run the reference's script on haplotypic_counts files the reference's phASER wrote
     (other fixtures) and on synthetic BED features.  `intervaltree` is not installed here; the script gets a stand-in that
@@ -567,10 +593,12 @@ def fx_gene_ae(phaser, rvm):
              ("opts_blacklist", os.path.join("pipe_opts", "blacklist"), 17, ["--gw_cutoff", "0.75", "--min_cov", "2"]),
              ("pipe_two_strict", "pipe_two", 18, ["--gw_cutoff", "1.01"]), ("pipe_noisy_b", "pipe_noisy_b", 19, []),
              ("opts_gw_maf_strict", os.path.join("pipe_opts", "gw_maf"), 20, ["--min_haplo_maf", "0.35", "--min_cov", "1"])]
+    cases.append(("pipe_two_bounds", "pipe_two", 0, []))
+    cases.append(("noisy_c_bounds", "pipe_noisy_c", 0, ["--min_cov", "1"]))
     for name, src, seed, extra in cases:
         hc = gzip.open(os.path.join(GOLD, src, "out.haplotypic_counts.txt.gz"), "rt").read()
         d = os.path.join(GOLD, "gene_ae", name); os.makedirs(d, exist_ok=True)
-        bed = gene_ae_features(hc, seed)
+        bed = gene_ae_boundary_features(hc) if name.endswith("_bounds") else gene_ae_features(hc, seed)
         with tempfile.TemporaryDirectory() as tmp:
             hp = os.path.join(tmp, "hc.txt"); bp = os.path.join(tmp, "f.bed"); op = os.path.join(tmp, "o.txt")
             open(hp, "w").write(hc); open(bp, "w").write(bed)
