@@ -6,10 +6,12 @@
 //   code 5 = text equals allele 0, 6 = equals allele 1 (first match wins, as `list.index` does at phaser.py:1317),
 //   0..3 = some other single base, 4 = any other text (its read offsets go to an optional pool so the host can print it).
 // This mode is off by default in phASER ("will likely result in poor quality phasing", phaser.py:48); it is built for
-// completeness, not speed: one lane per record, count pass + rocPRIM exclusive scan + emit pass, no LDS staging.
+// completeness: one lane per record, count pass + exclusive scan + emit pass.  Records are coordinate-sorted, so a workgroup's 256
+// records share one window start (one uniform search per workgroup, every per-segment search gallops from there), and the emit pass
+// returns at once for the records the count pass found empty (most of them).
 #include <cstring>
 #include "phz_internal.h"
-#include <rocprim/rocprim.hpp>
+#include "phz_scan.h"
 
 namespace {
 
@@ -26,7 +28,7 @@ struct GenArgs {
     const char *abytes;
     int nv, baseq;
     uint32_t *n_calls, *n_text;                  // per record (count pass)
-    const uint64_t *call_base, *text_base;       // exclusive scans (emit pass)
+    const uint32_t *call_base, *text_base;       // exclusive scans (emit pass)
     int32_t *o_read, *o_var; uint8_t *o_code; uint32_t *o_aux0, *o_aux1;
     uint32_t *o_text_off; uint32_t *o_text;      // optional
     int64_t cap, text_cap;
@@ -57,13 +59,24 @@ struct Compose {
     }
 };
 
+// first index in [lo, nv) with vpos >= key, galloping from lo (the answer is almost always a few entries away)
+__device__ __forceinline__ int gallop_lb(const int32_t *vpos, int nv, int lo, long long key) {
+    if (lo >= nv || (long long)vpos[lo] >= key) return lo;
+    int step = 1;
+    while (lo + step < nv && (long long)vpos[lo + step] < key) { lo += step; step <<= 1; }
+    int l = lo + 1, h = lo + step < nv ? lo + step : nv;
+    while (l < h) { const int m = (l + h) >> 1; if ((long long)vpos[m] < key) l = m + 1; else h = m; }
+    return l;
+}
+
 template <bool EMIT>
-__device__ void gen_read(const GenArgs &a, int64_t r) {
+__device__ void gen_read(const GenArgs &a, int64_t r, int w0) {
     const int pos = a.pos[r];
     const uint32_t c0 = a.cigar_off[r], c1 = a.cigar_off[r + 1];
     const uint32_t soff = a.seq_off[r];
     uint32_t ncalls = 0, ntext = 0;
     const uint64_t cbase = EMIT ? a.call_base[r] : 0, tbase = EMIT ? a.text_base[r] : 0;
+    if (EMIT && a.call_base[r + 1] == a.call_base[r]) return;          // nothing under this record (the count pass knows)
     int gpos = 0, rpos = 0;
     uint32_t k = c0;
     for (;;) {
@@ -76,8 +89,7 @@ __device__ void gen_read(const GenArgs &a, int64_t r) {
             if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) plen += (int)(w >> 4);
         }
         const long long lo = (long long)pos + seg_start;
-        int i;
-        { int l = 0, h = a.nv; while (l < h) { int m = (l + h) >> 1; if ((long long)a.vpos[m] < lo) l = m + 1; else h = m; } i = l; }
+        int i = gallop_lb(a.vpos, a.nv, w0, lo);
         for (; i < a.nv && (long long)a.vpos[i] < lo + plen; i++) {
             const int rs = (int)((long long)a.vpos[i] - lo), rl = a.ref_len[i];
             if (rs + rl > plen) continue;
@@ -158,7 +170,12 @@ __device__ void gen_read(const GenArgs &a, int64_t r) {
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_map_general(GenArgs a) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r < a.n) gen_read<EMIT>(a, r);
+    // window start of the workgroup: first variant at or after the first record's POS (uniform search: every lane reads the
+    // same addresses); later records only move forward from it
+    const int key = a.pos[(int64_t)blockIdx.x * 256];
+    int lo = 0, hi = a.nv;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (a.vpos[m] < key) lo = m + 1; else hi = m; }
+    if (r < a.n) gen_read<EMIT>(a, r, lo);
 }
 
 }  // namespace
@@ -190,27 +207,22 @@ extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const
     DevBuf *S = ctx->scratch;
     if (int s = phz_reserve(ctx, S[0], (size_t)n * 4)) return s;
     if (int s = phz_reserve(ctx, S[1], (size_t)n * 4)) return s;
-    if (int s = phz_reserve(ctx, S[2], (size_t)(n + 1) * 8)) return s;
-    if (int s = phz_reserve(ctx, S[3], (size_t)(n + 1) * 8)) return s;
+    if (int s = phz_reserve(ctx, S[2], (size_t)(n + 1) * 4)) return s;
+    if (int s = phz_reserve(ctx, S[3], (size_t)(n + 1) * 4)) return s;
     a.n_calls = (uint32_t *)S[0].p; a.n_text = (uint32_t *)S[1].p;
-    uint64_t *cb = (uint64_t *)S[2].p, *tb = (uint64_t *)S[3].p;
+    uint32_t *cb = (uint32_t *)S[2].p, *tb = (uint32_t *)S[3].p;
     a.call_base = cb; a.text_base = tb;
     hipStream_t sm = ctx->stream;
     const unsigned grid = (unsigned)((n + 255) / 256);
     PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
     hipLaunchKernelGGL(k_map_general<false>, dim3(grid), dim3(256), 0, sm, a);
-    size_t tmp = 0;
-    PHZ_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, a.n_calls, cb, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), sm));
-    if (int s = phz_reserve(ctx, S[6], tmp)) return s;
-    PHZ_HIP(ctx, rocprim::exclusive_scan(S[6].p, tmp, a.n_calls, cb, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), sm));
-    PHZ_HIP(ctx, rocprim::exclusive_scan(S[6].p, tmp, a.n_text, tb, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), sm));
-    uint64_t last[2]; uint32_t lastn[2];
-    PHZ_HIP(ctx, hipMemcpyAsync(&last[0], cb + (n - 1), 8, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&last[1], tb + (n - 1), 8, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&lastn[0], a.n_calls + (n - 1), 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&lastn[1], a.n_text + (n - 1), 4, hipMemcpyDeviceToHost, sm));
+    if (int s = scan_excl(ctx, a.n_calls, cb, n, S[6])) return s;
+    if (int s = scan_excl(ctx, a.n_text, tb, n, S[6])) return s;
+    uint32_t last[2];
+    PHZ_HIP(ctx, hipMemcpyAsync(&last[0], cb + n, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&last[1], tb + n, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
-    const int64_t total = (int64_t)(last[0] + lastn[0]), ttotal = (int64_t)(last[1] + lastn[1]);
+    const int64_t total = (int64_t)last[0], ttotal = (int64_t)last[1];
     *n_calls = total;
     if (n_text) *n_text = ttotal;
     if (total > out->cap || (text_roff && ttotal > text_cap)) return PHZ_E_CAPACITY;
