@@ -202,9 +202,19 @@ def main(argv=None):
     device = "cuda:%d" % local
     interners: Dict[str, object] = {}
     any_sam = any(b.endswith(".sam") for b in bam_list)       # text inputs keep everything on the Python reader
-    # multi-GPU: chromosomes are sharded across ranks by variant count (a proxy for reads before decoding)
+    # multi-GPU: chromosomes are sharded across ranks by record count (LPT).  Before anything is decoded the count is not known; its
+    # proxy is the compressed bytes each chromosome occupies in the BAMs (a few dozen BGZF member inflations per file); text inputs
+    # fall back to the variant count
     if world > 1:
-        owner = pdist.assign_chromosomes({c: float(len(v)) for c, v in vs.chroms.items()}, world)
+        weights = {c: 0.0 for c in vs.chroms}
+        if not any_sam:
+            for bam in bam_list:
+                for name, nbytes in bamio.bam_ref_weights(bam, threads=max(0, args.threads if args.threads > 1 else 0)).items():
+                    if name in weights:              # VCF names already carry --chr_prefix (they are the BAM's names)
+                        weights[name] += float(nbytes)
+        if sum(weights.values()) <= 0:
+            weights = {c: float(len(v)) for c, v in vs.chroms.items()}
+        owner = pdist.assign_chromosomes(weights, world)
         eng.set_owned([c for c in vs.chroms if owner[c] == rank])
     mine = set(eng.chrom_list)
     for bi, (bam, mq, isz, pe) in enumerate(zip(bam_list, mapq_list, isize_list, pe_list)):
@@ -219,11 +229,13 @@ def main(argv=None):
             shards = bamio.shards_from_bam_native(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
                                                   threads=max(0, args.threads if args.threads > 1 else 0))
         mark("bam decode + filters + qname interning")
+        items = []
         for chrom in vs.chroms:
             if chrom in shards and chrom in mine:
-                eng.add_shard(bi, chrom, shards[chrom].to(device), len(interners[chrom]),
-                              interners[chrom].names if args.output_read_ids == 1 else None)
-                say("               completed chromosome %s..." % chrom)
+                items.append((chrom, shards[chrom].to(device), len(interners[chrom]), interners[chrom].names if args.output_read_ids == 1 else None))
+        eng.add_shards(bi, items)                # all chromosomes of the BAM in one K_map submission
+        for it in items:
+            say("               completed chromosome %s..." % it[0])
         for chrom in interners:
             if chrom in eng.n_qid:
                 eng.n_qid[chrom] = len(interners[chrom])

@@ -38,18 +38,14 @@ for bi, (bam, per_chrom) in enumerate(bams.items()):
         hists["%d:%s" % (bi, c2)] = [[int(i), int(hh[i])] for i in nz]
     eng.close_bam(bi)
 counts = {}
-eng.tally = {}
-for c in eng.chrom_list:
-    eng.chrom_list_backup = eng.chrom_list
 match = mism = 0
-per = {}
+all_chroms = list(eng.chrom_list)
 for c in list(vs.chroms):
-    eng.chrom_list = [c]
+    eng.chrom_list = [c]                 # what the rank owning c alone would contribute
     m, mm = eng.tally_all()
-    per[c] = eng.tally[c]
     counts[c] = [m, mm]
     match += m; mism += mm
-eng.tally = per
+eng.chrom_list = all_chroms
 noise = Engine.noise_from_counts(match, mism)
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 json.dump({"hists": hists, "counts": counts, "chroms": list(vs.chroms), "log": eng.log},

@@ -69,15 +69,35 @@ for name, vcf_text, bams, load, cfg, isize in cases():
         for c2 in interners:
             eng.n_qid[c2] = len(interners[c2])
         eng.close_bam(bi)
-    labels = {}
-    orig = eng._component_labels
-
-    def rec(c, ea, eb, keep, _o=orig):
-        labels[c] = _o(c, ea, eb, keep)
-        return labels[c]
-    eng._component_labels = rec
     out = eng.finish()
-    tally = {c: {k: v for k, v in R.items() if k not in ("dev", "space", "by_var")} for c, R in eng.tally.items()}
+    # per chromosome, the GPU stage results in the fixture format of tests/helpers.genome_from_saved: K_tally arrays of that
+    # chromosome alone + its kept call lines (variant, QNAME id, BAM, class)
+    import ctypes as C
+    from phaser_amd import _lib
+    tally = {}
+    all_chroms = list(eng.chrom_list)
+    for c in all_chroms:
+        eng.chrom_list = [c]
+        G = eng._tally_genome()
+        nv = G["nv"]; ne = len(G["ea"]); nl = G["n_lines"]
+        cls = np.zeros(max(1, nl), dtype=np.uint8); cells = np.zeros(max(1, ne * 9), dtype=np.int32)
+        o = _lib.phz_tally_out(None, None, None, None, C.c_void_p(cls.ctypes.data), None, None, C.c_void_p(cells.ctypes.data), None, None, None, None)
+        eng.ctx.check(eng.lib.phz_tally_fetch(eng.ctx.h, C.byref(o), _lib.PHZ_HOST))
+        lv = []; lq = []; lb = []; offs = []
+        base = 0
+        for b, sh in enumerate(eng.shards[c]):
+            if sh is None:
+                continue
+            offs.append((b, base, sh.calls.n))
+            lv.append(sh.calls.var_idx.cpu().numpy()); lq.append(sh.qid[sh.calls.read_idx.long()].cpu().numpy())
+            lb.append(np.full(sh.calls.n, b, dtype=np.int32)); base += sh.calls.n
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+        tally[c] = {"nv": nv, "var_count": G["var_count"].copy(), "var_first": G["var_first"].copy(), "var_distinct": G["var_distinct"].copy(),
+                    "line_cls": cls[:nl].copy(), "ea": G["ea"].copy(), "eb": G["eb"].copy(), "cells": cells[:ne * 9].reshape(ne, 9).copy(),
+                    "linked": G["linked"].astype(bool), "var_rank": G["var_rank"].copy(), "line_var": cat(lv, np.int32),
+                    "line_qid": cat(lq, np.int32), "line_bam": cat(lb, np.int32), "bam_offsets": offs}
+    eng.chrom_list = all_chroms
+    labels = {}
     rec_ = {"tally": tally, "labels": labels, "n_qid": dict(eng.n_qid), "qnames": dict(eng.qnames), "as_log": [l for l in eng.log if "alignment score" in l]}
     with gzip.open(os.path.join(REPO, "gpurun_out", "tally", name + ".pkl.gz"), "wb") as f:
         pickle.dump(rec_, f, protocol=4)

@@ -17,13 +17,13 @@ torch.cuda.synchronize(); t2 = time.perf_counter()
 eng.close_bam(0); t3 = time.perf_counter()
 m = eng.tally_all(); t4 = time.perf_counter()
 noise = eng.noise_from_counts(*m)
-frag = eng.chrom_fragment("chr1", noise, 0); t5 = time.perf_counter()
+frag = eng._fragments(noise)["chr1"]; t5 = time.perf_counter()
 print("records %d snps %d | gen %.2fs map %.3fs as_cutoff %.3fs tally %.3fs (kernel %.2f ms) fragment(host) %.2fs %s | phased %d lines %d blocks %d"
       % (n, snps, t1 - t0, t2 - t1, t3 - t2, t4 - t3, eng.ctx.timing(2)[0], t5 - t4, {k: round(v, 3) for k, v in eng.stats.items()},
          frag["phased"], frag["lines"], frag["n_blocks"]))
 if len(sys.argv) > 3:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()
-    eng.chrom_fragment("chr1", noise, 0)
+    eng._fragments(noise)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
