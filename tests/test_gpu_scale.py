@@ -1,7 +1,7 @@
 """GPU parity at the shapes of BASELINE.json configs[2] (whole genome: 22 autosomes, ~80M records, ~1.5M het SNPs, one BAM) and
 configs[3] (the same sample with 4 BAMs whose QNAMEs collide).  No oracle run exists at these sizes, so each test combines
-  * a bit-exact oracle check of K_map on the first 200k records of EVERY chromosome shard (denser het-SNP windows than the
-    configs[1] shard: the MAP_WIN truncation path of phz_map.hip is exercised),
+  * a bit-exact oracle check of K_map on the first 200k records of EVERY chromosome shard (het-SNP windows 3x denser than on the
+    configs[1] shard, all shards of a BAM through one batched submission),
   * the size-independent relations that tie the five output files together, over all chromosomes, and
   * full equality with the pinned phasing oracle on a 2 % scale replica of the same plan (22 chromosomes: the global merge order
     of blocks / allelic_counts / singleton rows across chromosomes and BAMs, SURVEY.md 8.1 rules 2 and 4).
