@@ -32,7 +32,16 @@
 
 namespace {
 
-constexpr int MAP_WIN = 512;       // het-SNP positions staged per tile (max)
+#ifndef PHZ_MAP_WIN
+#define PHZ_MAP_WIN 512
+#endif
+#ifndef PHZ_CIG_X2
+#define PHZ_CIG_X2 5
+#endif
+#ifndef PHZ_CAND_X4
+#define PHZ_CAND_X4 3
+#endif
+constexpr int MAP_WIN = PHZ_MAP_WIN;       // het-SNP positions staged per tile (max)
 
 constexpr uint32_t OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_EQ = 7, OP_X = 8, OP_G = 9;
 
@@ -227,6 +236,84 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
     return cnt;
 }
 
+// Lean walker for the records the general walker costs most on: any mix of M / = / X / D / N / S / H / P and up to two insertions,
+// every run inside the staged window and every CIGAR word in LDS.  Same rule as walk_read<0> (candidates appended to the LDS
+// buffer, position rule only), organised for short instruction streams: a pre-scan decides support and collects the insertions
+// (key = read-relative genome offset - 1 at the I op, looked up segment-relative: the reference's keying quirk, kept), then one
+// pass over the ops with a branch-free LDS search per aligned run.  Returns false -- having appended nothing -- for a record it
+// does not cover ('G' ops of malformed records, > 2 insertions, runs beyond the window, words beyond the staged prefix).
+__device__ __forceinline__ int lds_lower_bound(const int32_t *w, int wlen, int key) {
+    int base = 0, n = wlen;
+    while (n > 1) {
+        const int half = n >> 1;
+        base += (w[base + half - 1] < key) ? half : 0;
+        n -= half;
+    }
+    base += (wlen > 0 && w[base] < key) ? 1 : 0;
+    return base;
+}
+
+__device__ bool walk_lean(const int32_t *s_vpos, int wlen, int w0, const uint32_t *s_cig, uint32_t c_begin, uint32_t cig_cap,
+                          const CandBuf &cb, int j, int pos, uint32_t c0, uint32_t c1, long long cover) {
+    if (c1 - c_begin > cig_cap) return false;
+    int ins_key[2] = {0, 0}, ins_seg[2] = {0, 0};
+    uint32_t ins_x[2] = {0, 0}, ins_off[2] = {0, 0};
+    int nins = 0;
+    {
+        int g = 0, seg = 0; uint32_t r = 0;
+        for (uint32_t k = c0; k < c1; k++) {
+            const uint32_t w = s_cig[k - c_begin];
+            const int len = (int)(w >> 4); const uint32_t op = w & 15;
+            if (op == OP_G) return false;
+            if (op == OP_I) {
+                if (nins == 2) return false;
+                ins_key[nins] = g - 1; ins_seg[nins] = seg; ins_off[nins] = r; ins_x[nins] = (uint32_t)(len > 4095 ? 4095 : len);
+                nins++;
+            }
+            if ((0x185u >> op) & 1u) { if ((long long)pos + g + len > cover) return false; }      // M, D, =, X: the run must lie inside the window
+            g += ((0x38Du >> op) & 1u) ? len : 0;          // M D N = X G advance the genome
+            r += ((0x193u >> op) & 1u) ? (uint32_t)len : 0u;   // M I S = X advance the read
+            seg += op == OP_N ? 1 : 0;
+        }
+    }
+    int g = 0, seg = 0, seg_start = 0, cnt = 0; uint32_t r = 0;
+    for (uint32_t k = c0; k < c1; k++) {
+        const uint32_t w = s_cig[k - c_begin];
+        const int len = (int)(w >> 4); const uint32_t op = w & 15;
+        const bool mlike = (0x181u >> op) & 1u;
+        if (mlike || (op == OP_D && nins > 0)) {
+            const int lo = pos + g, hi = lo + len;
+            int i = lds_lower_bound(s_vpos, wlen, lo);
+            while (i < wlen) {
+                const int vp = s_vpos[i];
+                if (vp >= hi) break;
+                const int p = vp - pos - seg_start;
+                uint32_t ioff = 0, ilen = 0;
+                if (nins > 0) {
+                    if (nins == 2 && ins_seg[1] == seg && ins_key[1] == p) { ioff = ins_off[1]; ilen = ins_x[1]; }       // the later insertion wins
+                    else if (ins_seg[0] == seg && ins_key[0] == p) { ioff = ins_off[0]; ilen = ins_x[0]; }
+                }
+                const int nchars = (mlike ? 1 : 0) + (int)ilen;
+                if (nchars > 0) {
+                    const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicAdd(cb.n, 1 << 20), 1 << 20);
+                    if (slot < cb.cap) {
+                        cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)cnt << 8) | (nchars == 1 ? 7u : 4u);
+                        cb.var[slot] = w0 + i;
+                        cb.aux0[slot] = mlike ? (uint32_t)(r + (uint32_t)(vp - lo)) : 0xFFFFFFFFu;
+                        cb.aux1[slot] = ilen > 0 ? ((ioff << 12) | ilen) : 0u;
+                    }
+                    cnt++;
+                }
+                i++;
+            }
+        }
+        g += ((0x38Du >> op) & 1u) ? len : 0;
+        r += ((0x193u >> op) & 1u) ? (uint32_t)len : 0u;
+        if (op == OP_N) { seg++; seg_start = g; }
+    }
+    return true;
+}
+
 constexpr int MAP_COVER = 65536;   // the staged window holds every het SNP below POS(last read of the tile) + MAP_COVER ...
 constexpr int MAP_SLACK = 64;      // ... plus this many further entries (probe overshoot / loop sentinels)
 
@@ -308,8 +395,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = bt.dbg;
     }
     constexpr int TILE = MAP_BLOCK * RPT;
-    constexpr int CIG = TILE * 5 / 2;          // packed CIGAR words staged per tile (max)
-    constexpr int CAND = TILE * 3 / 4;         // candidate buffer entries (complex records only)
+    constexpr int CIG = TILE * PHZ_CIG_X2 / 2;          // packed CIGAR words staged per tile (max)
+    constexpr int CAND = TILE * PHZ_CAND_X4 / 4;         // candidate buffer entries (complex records only)
     __shared__ int32_t s_vpos[MAP_WIN];
     __shared__ uint32_t s_coff[TILE + 1];      // cigar_off slice; reused as per-read output offsets after the walk
     __shared__ uint32_t s_soff[TILE];
@@ -457,9 +544,19 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     __syncthreads();
     // ---- phase 1b: spliced / gapped / clipped records, densely re-packed so the divergent walk runs on full waves
     const int ncx = walk_on ? s_ncx : 0;
+    const bool lean_on = complete && !(a.dbg & 32);
+    // 1b: the lean walker first (one lane per multi-op record, densely packed); what it declines is redone by the general walker
+    bool redo_any = false;
     for (int t = tid; t < ncx; t += MAP_BLOCK) {
         const int j = s_cx[t];
-        walk_read<0>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], 0, 0, 0);
+        const bool done = lean_on && walk_lean(s_vpos, vw.wlen, vw.w0, s_cig, cw.c_begin, (uint32_t)CIG, cb, j, s_pos[j], s_coff[j], s_coff[j + 1], cover);
+        if (!done) { s_cx[t] = (uint16_t)(j | 0x8000); redo_any = true; }
+    }
+    if (__syncthreads_or(redo_any ? 1 : 0)) {
+        for (int t = tid; t < ncx; t += MAP_BLOCK) {
+            const int jf = s_cx[t];
+            if (jf & 0x8000) { const int j = jf & 0x7FFF; walk_read<0>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], 0, 0, 0); }
+        }
     }
     __syncthreads();
     const int ncand = s_ncand;
