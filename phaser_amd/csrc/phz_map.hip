@@ -236,12 +236,17 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
     return cnt;
 }
 
-// Lean walker for the records the general walker costs most on: any mix of M / = / X / D / N / S / H / P and up to two insertions,
-// every run inside the staged window and every CIGAR word in LDS.  Same rule as walk_read<0> (candidates appended to the LDS
-// buffer, position rule only), organised for short instruction streams: a pre-scan decides support and collects the insertions
-// (key = read-relative genome offset - 1 at the I op, looked up segment-relative: the reference's keying quirk, kept), then one
-// pass over the ops with a branch-free LDS search per aligned run.  Returns false -- having appended nothing -- for a record it
-// does not cover ('G' ops of malformed records, > 2 insertions, runs beyond the window, words beyond the staged prefix).
+// Lean walker for multi-op records: any mix of M / = / X / D / N / S / H / P and up to two insertions, every run inside the staged
+// window and every CIGAR word in LDS.  Same rule as walk_read<0> (candidates appended to the LDS buffer, position rule only), organised
+// for a short, branch-light instruction stream -- this phase is VALU-issue bound, and a wave pays the stream once whatever its lanes do:
+//   * ONE pass over the ops: the window search runs unconditionally (empty interval for ops that are not runs), wave-uniform ballots
+//     skip the insertion bookkeeping and the search when no lane needs them;
+//   * what the pass cannot express ('G' ops, a third insertion, an insertion not directly after a non-empty reference-consuming op,
+//     a run beyond the window) is found on the way: the record is POISONED (its lean-origin candidates, key bit 15, are dropped by
+//     the resolve phase) and left to the general walker.
+// Insertions follow the reference's keying (key = genome offset - 1 at the I op, looked up SEGMENT-relative): while seg_start is 0
+// that is the last base of the op before the I (found by peeking at the next op); after an N the key lands seg_start bases further
+// on, i.e. in a later run of the same segment (carried forward in two register slots, the later insertion wins).
 __device__ __forceinline__ int lds_lower_bound(const int32_t *w, int wlen, int key) {
     int base = 0, n = wlen;
     while (n > 1) {
@@ -254,50 +259,48 @@ __device__ __forceinline__ int lds_lower_bound(const int32_t *w, int wlen, int k
 }
 
 __device__ bool walk_lean(const int32_t *s_vpos, int wlen, int w0, const uint32_t *s_cig, uint32_t c_begin, uint32_t cig_cap,
-                          const CandBuf &cb, int j, int pos, uint32_t c0, uint32_t c1, long long cover) {
+                          const CandBuf &cb, uint32_t *s_poison, int j, int pos, uint32_t c0, uint32_t c1, long long cover) {
     if (c1 - c_begin > cig_cap) return false;
-    int ins_key[2] = {0, 0}, ins_seg[2] = {0, 0};
-    uint32_t ins_x[2] = {0, 0}, ins_off[2] = {0, 0};
-    int nins = 0;
-    {
-        int g = 0, seg = 0; uint32_t r = 0;
-        for (uint32_t k = c0; k < c1; k++) {
-            const uint32_t w = s_cig[k - c_begin];
-            const int len = (int)(w >> 4); const uint32_t op = w & 15;
-            if (op == OP_G) return false;
-            if (op == OP_I) {
-                if (nins == 2) return false;
-                ins_key[nins] = g - 1; ins_seg[nins] = seg; ins_off[nins] = r; ins_x[nins] = (uint32_t)(len > 4095 ? 4095 : len);
-                nins++;
-            }
-            if ((0x185u >> op) & 1u) { if ((long long)pos + g + len > cover) return false; }      // M, D, =, X: the run must lie inside the window
-            g += ((0x38Du >> op) & 1u) ? len : 0;          // M D N = X G advance the genome
-            r += ((0x193u >> op) & 1u) ? (uint32_t)len : 0u;   // M I S = X advance the read
-            seg += op == OP_N ? 1 : 0;
-        }
-    }
-    int g = 0, seg = 0, seg_start = 0, cnt = 0; uint32_t r = 0;
+    int g = 0, seg_start = 0, cnt = 0, nins = 0; uint32_t r = 0;
+    bool bad = false;
+    int t0 = -1, t1 = -1; uint32_t o0 = 0, o1 = 0, l0 = 0, l1 = 0;      // insertions carried forward inside a later segment
+    uint32_t prev = 0x10u, prev_len = 1;                                // "previous op" of the first op: S-like
     for (uint32_t k = c0; k < c1; k++) {
         const uint32_t w = s_cig[k - c_begin];
-        const int len = (int)(w >> 4); const uint32_t op = w & 15;
-        const bool mlike = (0x181u >> op) & 1u;
-        if (mlike || (op == OP_D && nins > 0)) {
-            const int lo = pos + g, hi = lo + len;
+        const int len = (int)(w >> 4); const uint32_t op = w & 15, bit = 1u << op;
+        const bool mlike = (bit & 0x181u) != 0;
+        if (__builtin_amdgcn_ballot_w64(op == OP_I) != 0) {
+            if (op == OP_I) {
+                bad |= (prev & 0x272u) != 0 || prev_len == 0 || nins == 2;      // after I / S / H / P / G / an empty op; a third insertion
+                nins++;
+                t1 = t0; o1 = o0; l1 = l0; t0 = g - 1 + seg_start; o0 = r; l0 = (uint32_t)(len > 4095 ? 4095 : len);
+            }
+        }
+        bad |= op == OP_G;
+        const bool search = mlike || op == OP_D;
+        if (__builtin_amdgcn_ballot_w64(search) != 0) {
+            const int lo = pos + g;
+            bad |= search && (long long)lo + len > cover;                       // the run must lie inside the staged window
+            const int hi = (search && !bad) ? lo + len : lo;
             int i = lds_lower_bound(s_vpos, wlen, lo);
             while (i < wlen) {
                 const int vp = s_vpos[i];
                 if (vp >= hi) break;
-                const int p = vp - pos - seg_start;
                 uint32_t ioff = 0, ilen = 0;
-                if (nins > 0) {
-                    if (nins == 2 && ins_seg[1] == seg && ins_key[1] == p) { ioff = ins_off[1]; ilen = ins_x[1]; }       // the later insertion wins
-                    else if (ins_seg[0] == seg && ins_key[0] == p) { ioff = ins_off[0]; ilen = ins_x[0]; }
+                if (seg_start == 0) {           // key = offset of the base before the I: the last base of this op
+                    if (vp == hi - 1 && k + 1 < c1) {
+                        const uint32_t wn = s_cig[k + 1 - c_begin];
+                        if ((wn & 15) == OP_I) { ilen = wn >> 4; ilen = ilen > 4095u ? 4095u : ilen; ioff = r + (mlike ? (uint32_t)len : 0u); }
+                    }
+                } else {
+                    const int off = vp - pos;
+                    if (t0 == off) { ioff = o0; ilen = l0; } else if (t1 == off) { ioff = o1; ilen = l1; }
                 }
                 const int nchars = (mlike ? 1 : 0) + (int)ilen;
                 if (nchars > 0) {
                     const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicAdd(cb.n, 1 << 20), 1 << 20);
                     if (slot < cb.cap) {
-                        cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)cnt << 8) | (nchars == 1 ? 7u : 4u);
+                        cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)(cnt | 0x80) << 8) | (nchars == 1 ? 7u : 4u);
                         cb.var[slot] = w0 + i;
                         cb.aux0[slot] = mlike ? (uint32_t)(r + (uint32_t)(vp - lo)) : 0xFFFFFFFFu;
                         cb.aux1[slot] = ilen > 0 ? ((ioff << 12) | ilen) : 0u;
@@ -307,15 +310,17 @@ __device__ bool walk_lean(const int32_t *s_vpos, int wlen, int w0, const uint32_
                 i++;
             }
         }
-        g += ((0x38Du >> op) & 1u) ? len : 0;
-        r += ((0x193u >> op) & 1u) ? (uint32_t)len : 0u;
-        if (op == OP_N) { seg++; seg_start = g; }
+        g += (bit & 0x38Du) ? len : 0;
+        r += (bit & 0x193u) ? (uint32_t)len : 0u;
+        if (op == OP_N) { seg_start = g; t0 = -1; t1 = -1; }
+        prev = bit; prev_len = (uint32_t)len;
     }
-    return true;
+    if (bad) atomicOr(&s_poison[j >> 5], 1u << (j & 31));
+    return !bad;
 }
 
 constexpr int MAP_COVER = 65536;   // the staged window holds every het SNP below POS(last read of the tile) + MAP_COVER ...
-constexpr int MAP_SLACK = 64;      // ... plus this many further entries (probe overshoot / loop sentinels)
+constexpr int MAP_SLACK = 8;       // ... plus this many further entries (probe overshoot / loop sentinels)
 
 // per-tile het-SNP window: start = lower_bound(vpos, POS of the tile's first read); tile_w[4t+1] = staged length,
 // bit 30 set when the window is complete (not truncated by MAP_WIN), which enables the LDS-only fast path
@@ -409,7 +414,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     __shared__ uint32_t s_aux0[CAND];
     __shared__ uint32_t s_aux1[CAND];
     __shared__ int s_wsum[RPT][MAP_BLOCK / 64];
-    __shared__ int s_ncand, s_ncx;
+    __shared__ int s_ncand, s_ncx, s_nlong;
+    __shared__ uint32_t s_poison[TILE / 32];   // records the lean walker gave up on after it had appended candidates
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t tile = gtile - bt.tile0[si];          // tile index inside the shard
@@ -428,7 +434,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         s_coff[j] = a.cigar_off[r0 + (ok ? j : nr)];
         s_mask[j] = 0;
     }
-    if (tid == 0) { s_coff[TILE] = a.cigar_off[r0 + nr]; s_ncand = 0; s_ncx = 0; }
+    if (tid == 0) { s_coff[TILE] = a.cigar_off[r0 + nr]; s_ncand = 0; s_ncx = 0; s_nlong = 0; }
+    if (tid < TILE / 32) s_poison[tid] = 0;
     VarWin vw;
     vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = tw.x;
     vw.wlen = tw.y & 0xFFFF;
@@ -527,7 +534,12 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
                 if (c <= 8) { fast_[k] = true; base_[k] = base; n_[k] = c; }
             }
         }
-        if (j < nr && walk_on && !fast_[k]) s_cx[atomicAdd(&s_ncx, 1)] = (uint16_t)j;
+        if (j < nr && walk_on && !fast_[k]) {
+            // two lists in one array: records of <= 3 ops from the front, longer ones from the back -- the walk's trip count is the
+            // longest CIGAR of the wave, so the first wave gets the short records and the stragglers share the last one
+            if (s_coff[j + 1] - s_coff[j] > 3u) s_cx[TILE - 1 - atomicAdd(&s_nlong, 1)] = (uint16_t)j;
+            else s_cx[atomicAdd(&s_ncx, 1)] = (uint16_t)j;
+        }
     }
     // ---- phase 2a: resolve the fast records' bases; iteration o gathers for every lane that has an o-th SNP
 #pragma unroll
@@ -543,18 +555,20 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     }
     __syncthreads();
     // ---- phase 1b: spliced / gapped / clipped records, densely re-packed so the divergent walk runs on full waves
-    const int ncx = walk_on ? s_ncx : 0;
+    const int nshort = walk_on ? s_ncx : 0;
+    const int ncx = walk_on ? nshort + s_nlong : 0;
     const bool lean_on = complete && !(a.dbg & 32);
     // 1b: the lean walker first (one lane per multi-op record, densely packed); what it declines is redone by the general walker
     bool redo_any = false;
     for (int t = tid; t < ncx; t += MAP_BLOCK) {
-        const int j = s_cx[t];
-        const bool done = lean_on && walk_lean(s_vpos, vw.wlen, vw.w0, s_cig, cw.c_begin, (uint32_t)CIG, cb, j, s_pos[j], s_coff[j], s_coff[j + 1], cover);
-        if (!done) { s_cx[t] = (uint16_t)(j | 0x8000); redo_any = true; }
+        const int ts = t < nshort ? t : TILE - 1 - (t - nshort);
+        const int j = s_cx[ts];
+        const bool done = lean_on && walk_lean(s_vpos, vw.wlen, vw.w0, s_cig, cw.c_begin, (uint32_t)CIG, cb, s_poison, j, s_pos[j], s_coff[j], s_coff[j + 1], cover);
+        if (!done) { s_cx[ts] = (uint16_t)(j | 0x8000); redo_any = true; }
     }
     if (__syncthreads_or(redo_any ? 1 : 0)) {
         for (int t = tid; t < ncx; t += MAP_BLOCK) {
-            const int jf = s_cx[t];
+            const int jf = s_cx[t < nshort ? t : TILE - 1 - (t - nshort)];
             if (jf & 0x8000) { const int j = jf & 0x7FFF; walk_read<0>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], 0, 0, 0); }
         }
     }
@@ -569,7 +583,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             uint32_t key = s_key[e];
             const int j = (int)(key >> 16);
             int code = (int)(key & 0xFF);
-            if (code == 7) {
+            if ((key & 0x8000u) && ((s_poison[j >> 5] >> (j & 31)) & 1u)) code = -1;      // lean-origin candidate of a poisoned record
+            else if (code == 7) {
                 const uint32_t x0 = s_aux0[e];
                 const int x = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(s_aux1[e] >> 12);
                 const int sy = (a.dbg & 1) ? (x & 3) : masked_base(a, s_soff[j], x);
