@@ -117,6 +117,8 @@ typedef struct {
     int64_t n_read_list;     /* kept ref/alt lines = entries of rl_qid */
     int64_t n_items;         /* distinct (QNAME, variant, class) */
     int64_t pair_events;     /* sum over QNAMEs of item pairs on different variants */
+    int64_t noise_match;     /* sequencing-noise counters of these variants (phaser.py:610-632): ref+alt lines ... */
+    int64_t noise_mismatch;  /* ... and other-allele lines, over variants whose other share is below 5 % */
 } phz_tally_sizes;
 
 /* Destination arrays of phz_tally_fetch; a NULL member is skipped.  Variant indices are positions in the call's joint variant
@@ -138,6 +140,8 @@ typedef struct {
     uint32_t *rl_start;      /* [nv*2*n_bams + 1] read lists (phaser.py:1318-1322): the kept lines of (variant v, allele k, BAM b) */
     int32_t *rl_qid;         /* [n_read_list]     are rl_qid[rl_start[(2v+k)*n_bams+b] : rl_start[... + 1]] = their QNAME ids
                               *                   (chromosome-local, as passed in read_qid) in line order */
+    int32_t *edge_stats;     /* [5*n_edges] five planes of n_edges: same-configuration count, opposite count, supporting = max of the
+                              * two, total = all nine cells, chosen configuration 0 same / 1 opposite / -1 tie (:1637-1649) */
 } phz_tally_out;
 
 /* Variant table for the general (indel) mapper: per variant REF length and the individual's two allele strings. */

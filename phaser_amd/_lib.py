@@ -57,12 +57,13 @@ class phz_lines(C.Structure):
 
 
 class phz_tally_sizes(C.Structure):
-    _fields_ = [(k, C.c_int64) for k in ("n_lines", "n_kept", "n_edges", "n_read_list", "n_items", "pair_events")]
+    _fields_ = [(k, C.c_int64) for k in ("n_lines", "n_kept", "n_edges", "n_read_list", "n_items", "pair_events", "noise_match",
+                                           "noise_mismatch")]
 
 
 class phz_tally_out(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("var_count", "var_first", "var_distinct", "var_rank", "line_cls", "edge_a", "edge_b", "edge_cells",
-                                          "edge_linked", "edge_cto", "rl_start", "rl_qid")]
+                                          "edge_linked", "edge_cto", "rl_start", "rl_qid", "edge_stats")]
 
 
 class phz_host_shard(C.Structure):

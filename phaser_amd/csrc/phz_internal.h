@@ -43,7 +43,7 @@ struct phz_ctx {
     struct {
         int64_t nv = 0, n_lines = 0, n_kept = 0, n_edges = 0, n_rl = 0;
         int nb = 0;
-        int32_t *var_count = nullptr, *var_distinct = nullptr, *ea = nullptr, *eb = nullptr, *cells = nullptr, *cto = nullptr, *rl_qid = nullptr;
+        int32_t *var_count = nullptr, *var_distinct = nullptr, *ea = nullptr, *eb = nullptr, *cells = nullptr, *cto = nullptr, *stats = nullptr, *rl_qid = nullptr;
         int64_t *var_first = nullptr;
         uint64_t *var_rank = nullptr;
         uint32_t *rl_start = nullptr;

@@ -38,11 +38,30 @@ struct LinesDev {
     int64_t line_base;         // index of the shard's first line in the call's line space (shards ordered chromosome, BAM)
 };
 
-__global__ __launch_bounds__(256) void k_as_hist(LinesDev L, unsigned long long *hist) {
+// All shards of a call go through ONE grid per per-line stage: block b belongs to the shard s with blk0[s] <= b < blk0[s+1]
+// (a genome is 22+ shards of well under a million lines each: one launch per shard is mostly ramp-up and tail).
+struct LinesTab {
+    const LinesDev *L;
+    const uint32_t *blk0;      // [n + 1]
+    int n;
+};
+__device__ __forceinline__ int tab_find(const LinesTab &t, uint32_t blk) {
+    int lo = 0, hi = t.n - 1;          // largest s with blk0[s] <= blk (shards without blocks share their successor's start)
+    while (lo < hi) {
+        const int m = (lo + hi + 1) >> 1;
+        if (t.blk0[m] <= blk) lo = m; else hi = m - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long *hist) {
+    const int sh_ = tab_find(T, blockIdx.x);
+    const LinesDev L = T.L[sh_];
+    const uint32_t bx = blockIdx.x - T.blk0[sh_], gx = T.blk0[sh_ + 1] - T.blk0[sh_];
     __shared__ unsigned int s_h[AS_LDS_BINS];
     for (int j = threadIdx.x; j < AS_LDS_BINS; j += 256) s_h[j] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L.n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < L.n; i += (int64_t)gx * 256) {
         const int r = L.read_idx[i];
         if (L.read_has_as && !L.read_has_as[r]) continue;
         const int a = L.read_as[r];
@@ -76,13 +95,16 @@ struct LineOut {
     int nb, single_bam;
 };
 
-__global__ __launch_bounds__(256) void k_line(LinesDev L, LineOut O) {
+__global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
+    const int sh_ = tab_find(T, blockIdx.x);
+    const LinesDev L = T.L[sh_];
+    const uint32_t bx = blockIdx.x - T.blk0[sh_];
     __shared__ int s_cnt[TW * 3];
     __shared__ unsigned long long s_first[TW];
     __shared__ int s_vbase;
     __shared__ unsigned int s_kept;
     const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
+    const int64_t i0 = (int64_t)bx * LINES_PER_BLOCK;
     for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
     for (int j = tid; j < TW; j += 256) s_first[j] = ~0ull;
     if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
@@ -138,10 +160,12 @@ __global__ __launch_bounds__(256) void k_line(LinesDev L, LineOut O) {
 
 // item = qid:32 | var:28 | cls:2 | spare:1 | linked:1, scattered into the QNAME's slot range [qoff[q], qoff[q+1]);
 // read-list sort key = ((variant * 2 + allele) * nb + bam) for kept ref/alt lines, rl_drop for every other line
-__global__ __launch_bounds__(256) void k_items(LinesDev L, const uint8_t *line_cls, const int32_t *qid_owner, const uint32_t *qoff,
+__global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_cls, const int32_t *qid_owner, const uint32_t *qoff,
                                                uint32_t *qcount, uint64_t *items, uint32_t *qid_vmin, int32_t *qid_vmax,
                                                uint32_t *rl_key, int32_t *rl_val, int nb, int single_bam, uint32_t rl_drop) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int sh_ = tab_find(T, blockIdx.x);
+    const LinesDev L = T.L[sh_];
+    const int64_t i = (int64_t)(blockIdx.x - T.blk0[sh_]) * 256 + threadIdx.x;
     if (i >= L.n) return;
     const int64_t g = L.line_base + i;
     const uint8_t cls = line_cls[g];
@@ -187,13 +211,16 @@ __global__ __launch_bounds__(256) void k_qsort(const uint32_t *qoff, int64_t nq,
 // Overlap-dictionary key order (SURVEY.md 8.1 rule 4, phaser.py:1271-1283): a variant's rank is the smallest
 // (first ref/alt line of the QNAME, line) over the surviving read_vars entries of QNAMEs that hold >= 2 distinct
 // variants; variants that never get a key keep the maximum value.  LDS window like k_line.
-__global__ __launch_bounds__(256) void k_rank(LinesDev L, const uint8_t *line_cls, const int32_t *qid_owner,
+__global__ __launch_bounds__(256) void k_rank(LinesTab T, const uint8_t *line_cls, const int32_t *qid_owner,
                                               const uint32_t *qid_first, const uint32_t *qid_vmin, const int32_t *qid_vmax,
                                               unsigned long long *var_rank, int single_bam) {
+    const int sh_ = tab_find(T, blockIdx.x);
+    const LinesDev L = T.L[sh_];
+    const uint32_t bx = blockIdx.x - T.blk0[sh_];
     __shared__ unsigned long long s_rank[TW];
     __shared__ int s_vbase;
     const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
+    const int64_t i0 = (int64_t)bx * LINES_PER_BLOCK;
     for (int j = tid; j < TW; j += 256) s_rank[j] = ~0ull;
     if (tid == 0) s_vbase = L.var_idx[i0] + L.var_base;
     __syncthreads();
@@ -366,7 +393,7 @@ __global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *gkeys, int
     e_b[p] = (uint32_t)k; e_slot[p] = (uint32_t)i;
 }
 __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, const int32_t *gvals,
-                                                    int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked, int32_t *cto) {
+                                                    int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked, int32_t *cto, int32_t *stats, int64_t ne) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= nv) return;
     const uint32_t lo = eoff[a], hi = eoff[a + 1];
@@ -384,7 +411,33 @@ __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *
         for (int c = 0; c < 9; c++) { x[c] = gvals[s * PH_VALS + c]; cells[(int64_t)i * 9 + c] = x[c]; }
         linked[i] = (uint8_t)(gvals[s * PH_VALS + 9] & 1);
         // test_variant_connection's three sums (phaser.py:1634-1636): same configuration rr+aa, opposite ar+ra, the five "other" cells
-        cto[(int64_t)i * 3] = x[0] + x[4]; cto[(int64_t)i * 3 + 1] = x[3] + x[1]; cto[(int64_t)i * 3 + 2] = x[6] + x[7] + x[2] + x[5] + x[8];
+        const int32_t cis = x[0] + x[4], trans = x[3] + x[1], oth = x[6] + x[7] + x[2] + x[5] + x[8];
+        cto[(int64_t)i * 3] = cis; cto[(int64_t)i * 3 + 1] = trans; cto[(int64_t)i * 3 + 2] = oth;
+        // the derived columns of the pair test (:1637-1649), one plane each: same-configuration / opposite counts, supporting =
+        // the larger of the two, total, chosen configuration (0 same, 1 opposite, -1 tie)
+        stats[i] = cis; stats[ne + i] = trans; stats[2 * ne + i] = cis > trans ? cis : trans; stats[3 * ne + i] = cis + trans + oth;
+        stats[4 * ne + i] = cis > trans ? 0 : (cis < trans ? 1 : -1);
+    }
+}
+
+// sequencing-noise counters (phaser.py:610-632): over the variants with ref+alt lines and an "other" share below 5 %, the ref+alt
+// lines (match) and the other-allele lines (mismatch); the caller all-reduces them over chromosomes / ranks
+__global__ __launch_bounds__(256) void k_noise(const int32_t *var_count, int64_t nv, unsigned long long *out /* [0] match, [1] mismatch */) {
+    __shared__ unsigned long long s_m[4], s_x[4];
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long m = 0, x = 0;
+    if (v < nv) {
+        const long long mm = (long long)var_count[v * 3] + var_count[v * 3 + 1], oo = var_count[v * 3 + 2];
+        if (mm > 0 && (double)oo / (double)(oo + mm) < 0.05) { m = (unsigned long long)mm; x = (unsigned long long)oo; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { m += __shfl_xor(m, d); x += __shfl_xor(x, d); }
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_x[threadIdx.x >> 6] = x; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = s_m[0] + s_m[1] + s_m[2] + s_m[3]; x = s_x[0] + s_x[1] + s_x[2] + s_x[3];
+        if (m) atomicAdd(&out[0], m);
+        if (x) atomicAdd(&out[1], x);
     }
 }
 
@@ -451,10 +504,38 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
 // scratch slots of ctx->scratch used by the tally (0 is the AS histogram, 16.. belong to components / K_map)
 enum { T_QOWN = 1, T_QFIRST, T_QCOUNT, T_QOFF, T_ITEMS, T_SORT_TMP, T_COUNTERS, T_GKEYS, T_GVALS, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP };
 // results and the read-list sort buffers live in their own buffers (ctx->tally_buf)
-enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_RLCNT, R_RLSTART, R_RLKEY, R_RLKEY2, R_RLVAL, R_RLQID, R_A0, R_A1,
+enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_STATS, R_RLCNT, R_RLSTART, R_RLKEY, R_RLKEY2, R_RLVAL, R_RLQID, R_A0, R_A1,
        R_COUNT };
 
 }  // namespace
+
+// k_as_hist is grid-stride with one LDS histogram per block, flushed with global atomics at the end: few, long-running blocks
+static unsigned as_hist_blocks(const LinesDev &l) { const unsigned g = nblk((l.n + 15) / 16); return g > 512u ? 512u : (g ? g : 1u); }
+
+// Device image of a shard table for one batched stage: [LinesDev x n][blk0 x (n+1)], blocks per shard from `blocks_of`.  Every
+// table of a call gets its own slice of ctx->shard_tab (`slot`), so stages with different block sizes can be in flight together.
+template <class F>
+static int upload_tab(phz_ctx *ctx, const LinesDev *L, int n, F blocks_of, LinesTab *out, std::vector<uint32_t> *blk0_host, int slot = 0,
+                      int n_slots = 1) {
+    const size_t one = ((size_t)n * sizeof(LinesDev) + (size_t)(n + 1) * 4 + 63) & ~(size_t)63;
+    if (int s = phz_reserve_host(ctx, ctx->h_shard_tab, one * (size_t)n_slots)) return s;
+    if (int s = phz_reserve(ctx, ctx->shard_tab, one * (size_t)n_slots)) return s;
+    char *h = (char *)ctx->h_shard_tab.p + one * (size_t)slot;
+    char *d = (char *)ctx->shard_tab.p + one * (size_t)slot;
+    memcpy(h, L, (size_t)n * sizeof(LinesDev));
+    uint32_t *b0 = (uint32_t *)(h + (size_t)n * sizeof(LinesDev));
+    blk0_host->assign((size_t)n + 1, 0u);
+    uint64_t acc = 0;
+    for (int i = 0; i < n; i++) {
+        b0[i] = (uint32_t)acc; (*blk0_host)[(size_t)i] = (uint32_t)acc;
+        acc += L[i].n > 0 ? (uint64_t)blocks_of(L[i]) : 0u;
+        if (acc >= (1ull << 31)) return phz_fail(ctx, PHZ_E_ARG, "too many blocks in one batched stage");
+    }
+    b0[n] = (uint32_t)acc; (*blk0_host)[(size_t)n] = (uint32_t)acc;
+    PHZ_HIP(ctx, hipMemcpyAsync(d, h, one, hipMemcpyHostToDevice, ctx->stream));
+    out->L = (const LinesDev *)d; out->blk0 = (const uint32_t *)(d + (size_t)n * sizeof(LinesDev)); out->n = n;
+    return PHZ_OK;
+}
 
 extern "C" int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *hist, int space) {
     if (!ctx || !shard || !hist) return PHZ_E_ARG;
@@ -471,8 +552,10 @@ extern "C" int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *h
     }
     Timer t(ctx, PHZ_T_ASHIST);
     if (L.n > 0) {
-        unsigned grid = nblk(L.n); if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(k_as_hist, dim3(grid), dim3(256), 0, ctx->stream, L, dh);
+        LinesTab T;
+        std::vector<uint32_t> grids;
+        if (int s2 = upload_tab(ctx, &L, 1, as_hist_blocks, &T, &grids)) return s2;
+        hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, dh);
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = t.stop()) return s;
@@ -486,14 +569,15 @@ extern "C" int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int
     if (!ctx || (!shards && n_shards) || !hist || n_shards < 0) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     Timer t(ctx, PHZ_T_ASHIST);
-    for (int i = 0; i < n_shards; i++) {
-        Staging st(ctx);
-        LinesDev L;
-        if (int s = stage_lines(st, shards[i], PHZ_DEVICE, &L)) return s;
-        if (L.n > 0) {
-            unsigned grid = nblk(L.n); if (grid > 2048) grid = 2048;
-            hipLaunchKernelGGL(k_as_hist, dim3(grid), dim3(256), 0, ctx->stream, L, (unsigned long long *)hist);
-        }
+    Staging st(ctx);
+    std::vector<LinesDev> L((size_t)n_shards);
+    for (int i = 0; i < n_shards; i++)
+        if (int s = stage_lines(st, shards[i], PHZ_DEVICE, &L[(size_t)i])) return s;
+    if (n_shards > 0) {
+        LinesTab T;
+        std::vector<uint32_t> grids;
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, as_hist_blocks, &T, &grids)) return s2;
+        if (grids.back() > 0) hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, (unsigned long long *)hist);
     }
     PHZ_HIP(ctx, hipGetLastError());
     return t.stop();
@@ -588,21 +672,26 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     LineOut O;
     O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt; O.qid_owner = qid_owner;
     O.qid_first = qid_first; O.qcount = qcount; O.n_kept = counters + 3; O.nb = n_bams; O.single_bam = single_bam;
-    for (int b = 0; b < n_shards; b++)
-        if (L[b].n) hipLaunchKernelGGL(k_line, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b], O);
+    // shard tables of the per-line stages: LINES_PER_BLOCK lines per block (k_line, k_rank) and 256 lines per block (k_items)
+    LinesTab TL, TI;
+    std::vector<uint32_t> gl, gi;
+    if (n_shards > 0) {
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK); }, &TL, &gl, 0, 2)) return s2;
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return nblk(l.n); }, &TI, &gi, 1, 2)) return s2;
+    }
+    const unsigned grid_l = n_shards > 0 ? gl.back() : 0u, grid_i = n_shards > 0 ? gi.back() : 0u;
+    if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(256), 0, sm, TL, O);
+    if (nv) hipLaunchKernelGGL(k_noise, dim3(nblk(nv)), dim3(256), 0, sm, (const int32_t *)d_cnt, nv, counters + 4);
     PHZ_HIP(ctx, hipGetLastError());
     // lines per QNAME -> slot ranges; scatter; sort + de-duplicate each group.  qoff[n_qid] = kept lines = item slots in use
     if (int s = scan_excl(ctx, qcount, qoff, n_qid, S[T_SCAN_TMP])) return s;
     const uint32_t *m_ptr = qoff + n_qid;
     const uint32_t rl_drop = (uint32_t)NRL;
-    for (int b = 0; b < n_shards; b++)
-        if (L[b].n) hipLaunchKernelGGL(k_items, dim3(nblk(L[b].n)), dim3(256), 0, sm, L[b], (const uint8_t *)d_cls, (const int32_t *)qid_owner,
-                                       (const uint32_t *)qoff, qcount, items, qid_vmin, qid_vmax, rl_key, rl_val, n_bams, single_bam, rl_drop);
+    if (grid_i) hipLaunchKernelGGL(k_items, dim3(grid_i), dim3(256), 0, sm, TI, (const uint8_t *)d_cls, (const int32_t *)qid_owner,
+                                   (const uint32_t *)qoff, qcount, items, qid_vmin, qid_vmax, rl_key, rl_val, n_bams, single_bam, rl_drop);
     if (n_qid) hipLaunchKernelGGL(k_qsort, dim3(nblk(n_qid)), dim3(256), 0, sm, (const uint32_t *)qoff, n_qid, items);
-    for (int b = 0; b < n_shards; b++)
-        if (L[b].n) hipLaunchKernelGGL(k_rank, dim3((unsigned)((L[b].n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm, L[b],
-                                       (const uint8_t *)d_cls, (const int32_t *)qid_owner, (const uint32_t *)qid_first, (const uint32_t *)qid_vmin,
-                                       (const int32_t *)qid_vmax, d_rank, single_bam);
+    if (grid_l) hipLaunchKernelGGL(k_rank, dim3(grid_l), dim3(256), 0, sm, TL, (const uint8_t *)d_cls, (const int32_t *)qid_owner,
+                                   (const uint32_t *)qid_first, (const uint32_t *)qid_vmin, (const int32_t *)qid_vmax, d_rank, single_bam);
     PHZ_HIP(ctx, hipGetLastError());
     // read lists: stable sort of the lines by (variant, allele, BAM) on the significant key bits; CSR starts from the counts
     if (total > 0) {
@@ -620,7 +709,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     uint64_t cap = 1 << 16;
     while (cap < 4 * (uint64_t)NV && cap < (1ull << 30)) cap <<= 1;
     int64_t ne = 0;
-    unsigned long long h_counters[4] = {0, 0, 0, 0};
+    unsigned long long h_counters[6] = {0, 0, 0, 0, 0, 0};       // + 4 noise match, 5 noise mismatch
     uint32_t h_tail[2] = {0, 0};
     for (int attempt = 0;; attempt++) {
         if (int s = phz_reserve(ctx, S[T_GKEYS], cap * 8)) return s;
@@ -635,7 +724,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         hipLaunchKernelGGL(k_edge_count, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, (const uint64_t *)gkeys, (int64_t)cap, deg);
         if (int s = scan_excl(ctx, deg, eoff, nv, S[T_SCAN_TMP])) return s;
         PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 32, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 48, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[0], eoff + nv, 4, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[1], rl_start + NRL, 4, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
@@ -649,6 +738,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     if (int s = phz_reserve(ctx, R[R_CELLS], NE * 36)) return s;
     if (int s = phz_reserve(ctx, R[R_LINKED], NE)) return s;
     if (int s = phz_reserve(ctx, R[R_CTO], NE * 12)) return s;
+    if (int s = phz_reserve(ctx, R[R_STATS], NE * 20)) return s;
     if (int s = phz_reserve(ctx, S[T_EB], NE * 4)) return s;
     if (int s = phz_reserve(ctx, S[T_ESLOT], NE * 4)) return s;
     if (ne > 0) {
@@ -656,7 +746,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
                            (const uint32_t *)eoff, deg, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
         hipLaunchKernelGGL(k_edge_final, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p,
                            (const int32_t *)S[T_GVALS].p, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
-                           (int32_t *)R[R_CTO].p);
+                           (int32_t *)R[R_CTO].p, (int32_t *)R[R_STATS].p, ne);
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = timer.stop()) return s;
@@ -665,10 +755,11 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = (int64_t)h_counters[3]; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
     T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;
     T.ea = (int32_t *)R[R_EA].p; T.eb = (int32_t *)R[R_EB].p; T.cells = (int32_t *)R[R_CELLS].p; T.linked = (uint8_t *)R[R_LINKED].p;
-    T.cto = (int32_t *)R[R_CTO].p;
+    T.cto = (int32_t *)R[R_CTO].p; T.stats = (int32_t *)R[R_STATS].p;
     T.rl_start = rl_start; T.rl_qid = rl_qid;
     sizes->n_lines = total; sizes->n_kept = T.n_kept; sizes->n_edges = ne; sizes->n_read_list = T.n_rl;
     sizes->n_items = (int64_t)h_counters[0]; sizes->pair_events = (int64_t)h_counters[1];
+    sizes->noise_match = (int64_t)h_counters[4]; sizes->noise_mismatch = (int64_t)h_counters[5];
     ctx->counters[PHZ_C_LINES] += total; ctx->counters[PHZ_C_ITEMS] += sizes->n_items; ctx->counters[PHZ_C_PAIR_EVENTS] += sizes->pair_events;
     ctx->counters[PHZ_C_EDGES] += ne;
     return PHZ_OK;
@@ -697,6 +788,7 @@ extern "C" int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space
     if (int s = cp(out->edge_cells, T.cells, ne * 36)) return s;
     if (int s = cp(out->edge_linked, T.linked, ne)) return s;
     if (int s = cp(out->edge_cto, T.cto, ne * 12)) return s;
+    if (int s = cp(out->edge_stats, T.stats, ne * 20)) return s;
     if (int s = cp(out->rl_start, T.rl_start, (nv * 2 * (size_t)T.nb + 1) * 4)) return s;
     if (int s = cp(out->rl_qid, T.rl_qid, (size_t)T.n_rl * 4)) return s;
     PHZ_HIP(ctx, hipStreamSynchronize(sm));

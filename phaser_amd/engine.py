@@ -259,13 +259,15 @@ class Engine:
              "var_count": self._pinned("var_count", NV * 3, np.int32), "var_first": self._pinned("var_first", NV, np.int64),
              "var_distinct": self._pinned("var_distinct", NV * 3, np.int32), "var_rank": self._pinned("var_rank", NV, np.uint64),
              "ea": self._pinned("ea", ne, np.int32), "eb": self._pinned("eb", ne, np.int32), "cto": self._pinned("cto", ne * 3, np.int32),
-             "linked": self._pinned("linked", ne, np.uint8), "rl_start": self._pinned("rl_start", NV * 2 * nb + 1, np.uint32),
+             "linked": self._pinned("linked", ne, np.uint8), "stats": self._pinned("stats", ne * 5, np.int32), "rl_start": self._pinned("rl_start", NV * 2 * nb + 1, np.uint32),
              "rl_qid": self._pinned("rl_qid", nrl, np.int32)}
         vp = lambda a: C.c_void_p(a.ctypes.data) if a.size else None
         out = _lib.phz_tally_out(vp(G["var_count"]), vp(G["var_first"]), vp(G["var_distinct"]), vp(G["var_rank"]), None, vp(G["ea"]), vp(G["eb"]),
-                                 None, vp(G["linked"]), vp(G["cto"]), vp(G["rl_start"]), vp(G["rl_qid"]))
+                                 None, vp(G["linked"]), vp(G["cto"]), vp(G["rl_start"]), vp(G["rl_qid"]), vp(G["stats"]))
         self.ctx.check(self.lib.phz_tally_fetch(self.ctx.h, C.byref(out), _lib.PHZ_HOST))
         G["var_count"] = G["var_count"].reshape(NV, 3); G["var_distinct"] = G["var_distinct"].reshape(NV, 3); G["cto"] = G["cto"].reshape(ne, 3)
+        G["stats"] = G["stats"].reshape(5, ne)       # planes: same-configuration, opposite, supporting, total, chosen configuration
+        G["noise"] = (int(sz.noise_match), int(sz.noise_mismatch))
         G["resident"] = True            # the edge list is still in HBM: phz_components can use it in place
         self.stats["tally_call_s"] = self.stats.get("tally_call_s", 0.0) + t1 - t0
         self.stats["tally_d2h_s"] = self.stats.get("tally_d2h_s", 0.0) + _t.perf_counter() - t1
@@ -283,11 +285,7 @@ class Engine:
     def tally_all(self):
         """Stage A: K_tally over this rank's chromosomes; returns the two global noise counters of these chromosomes."""
         self.G = self._tally_genome()
-        vc = self.G["var_count"].astype(np.int64)
-        m = vc[:, 0] + vc[:, 1]; mm = vc[:, 2]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            ok = (m > 0) & ((mm.astype(np.float64) / (mm + m).astype(np.float64)) < 0.05)
-        return int(m[ok].sum()), int(mm[ok].sum())
+        return self.G["noise"]            # k_noise: the two counters of phaser.py:610-632 over these chromosomes' variants
 
     @staticmethod
     def noise_from_counts(match: int, mism: int) -> float:
@@ -365,14 +363,14 @@ class Engine:
         # ---- test every linked pair (phaser.py:1594-1654)
         # the three sums per pair (same configuration / opposite / other) come from the device (k_edge_final)
         linked = G["linked"].view(bool)
+        st = G["stats"]
         if linked.all():
-            sel = np.arange(len(linked)); ea_g = G["ea"]; eb_g = G["eb"]; cto = G["cto"]
+            sel = np.arange(len(linked)); ea_g = G["ea"]; eb_g = G["eb"]
+            cis, trans, sup, tot, cfgv = st[0], st[1], st[2], st[3], st[4]
         else:
             sel = np.nonzero(linked)[0]
-            ea_g = G["ea"][sel]; eb_g = G["eb"][sel]; cto = G["cto"][sel]
-        cis = np.ascontiguousarray(cto[:, 0]); trans = np.ascontiguousarray(cto[:, 1]); oth = cto[:, 2]
-        sup = np.maximum(cis, trans); tot = cis + trans + oth
-        cfgv = np.where(cis > trans, 0, np.where(cis < trans, 1, -1)).astype(np.int32)
+            ea_g = G["ea"][sel]; eb_g = G["eb"][sel]
+            cis, trans, sup, tot, cfgv = (np.ascontiguousarray(st[k][sel]) for k in range(5))
         prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
         pv = np.ones(len(sel), dtype=np.float64)
         tp1 = _t.perf_counter()

@@ -190,10 +190,11 @@ def genome_from_saved(saved, chrom_list, n_bams):
     rl_start = np.zeros(NV * 2 * nb + 1, dtype=np.uint32)
     np.cumsum(np.bincount(key, minlength=NV * 2 * nb), out=rl_start[1:])
     vc = cat(parts["var_count"], np.int32).reshape(NV, 3)
-    return {"nv": NV, "nb": nb, "var_base": var_base, "line_base": line_base, "n_lines": L, "n_kept": int(vc.sum()), "var_count": vc,
+    cto = _cto(cat(parts["cells"], np.int32).reshape(-1, 9))
+    return {"stats": _stats(cto), "noise": _noise(vc), "nv": NV, "nb": nb, "var_base": var_base, "line_base": line_base, "n_lines": L, "n_kept": int(vc.sum()), "var_count": vc,
             "var_first": cat(parts["var_first"], np.int64), "var_distinct": cat(parts["var_distinct"], np.int32).reshape(NV, 3),
             "var_rank": cat(parts["var_rank"], np.uint64), "ea": cat(parts["ea"], np.int32), "eb": cat(parts["eb"], np.int32),
-            "cto": _cto(cat(parts["cells"], np.int32).reshape(-1, 9)), "linked": cat(parts["linked"], np.uint8), "rl_start": rl_start,
+            "cto": cto, "linked": cat(parts["linked"], np.uint8), "rl_start": rl_start,
             "rl_qid": val[order], "resident": False}
 
 
@@ -201,6 +202,22 @@ def _cto(cells):
     """the three sums of test_variant_connection per pair (what k_edge_final hands out): same configuration, opposite, other"""
     c = cells.astype(np.int64)
     return np.stack([c[:, 0] + c[:, 4], c[:, 3] + c[:, 1], c[:, 6] + c[:, 7] + c[:, 2] + c[:, 5] + c[:, 8]], 1).astype(np.int32)
+
+
+def _stats(cto):
+    """the five derived planes k_edge_final hands out (phaser.py:1637-1649): same, opposite, supporting, total, configuration"""
+    cis = cto[:, 0].astype(np.int32); trans = cto[:, 1].astype(np.int32); oth = cto[:, 2].astype(np.int32)
+    cfg = np.where(cis > trans, 0, np.where(cis < trans, 1, -1)).astype(np.int32)
+    return np.ascontiguousarray(np.stack([cis, trans, np.maximum(cis, trans), cis + trans + oth, cfg], 0))
+
+
+def _noise(vc):
+    """the two noise counters k_noise hands out (phaser.py:610-632)"""
+    vc = vc.astype(np.int64)
+    m = vc[:, 0] + vc[:, 1]; mm = vc[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ok = (m > 0) & ((mm.astype(np.float64) / (mm + m).astype(np.float64)) < 0.05)
+    return int(m[ok].sum()), int(mm[ok].sum())
 
 
 def component_labels_cpu(G, keep_all):
