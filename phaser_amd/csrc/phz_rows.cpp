@@ -273,6 +273,7 @@ struct BlockChunk {
     std::vector<double> bstat;
     int64_t phased = 0;
     int status = 0;
+    int64_t est_hap = 0, est_ase = 0, est_cfg = 0;      // byte estimates of the three texts: one reservation instead of a growth chain
 };
 
 // one final (phased) block: rows of haplotypes.txt, haplotypic_counts.txt, allele_config.txt (:865-1172)
@@ -444,6 +445,8 @@ void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &h
 // components ranked [lo, hi) in first-key order: phase them and write their rows
 void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
     const phz_rows_in &I = *C.in;
+    const int64_t res_max = 256ll << 20;      // an estimate, not a bound: the strings still grow when it falls short
+    o.hap.reserve((size_t)std::min(o.est_hap, res_max)); o.ase.reserve((size_t)std::min(o.est_ase, res_max)); o.cfg.reserve((size_t)std::min(o.est_cfg, res_max));
     Ranker rk;
     AlleleGraph g;
     std::vector<int> mem, vars, sub_of, alle_of;
@@ -512,6 +515,7 @@ struct TextChunk { std::string a, b; int64_t rows = 0; };
 // variant_connections rows (:691-695) for eorder[lo, hi)
 void run_conn(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
     const phz_rows_in &I = *C.in;
+    o.a.reserve((size_t)(hi - lo) * 72);
     for (int64_t t = lo; t < hi; t++) {
         const int64_t k = I.eorder[t];
         const int a = I.va[k], b = I.vb[k];
@@ -532,6 +536,7 @@ void run_conn(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
 // allelic_counts rows (:737-749) for the first-appearance keys [lo, hi)
 void run_allelic(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
     const phz_rows_in &I = *C.in;
+    o.a.reserve((size_t)(hi - lo) * 56);
     for (int64_t t = lo; t < hi; t++) {
         const int g = (int)I.key_g[t];
         const long long r0 = I.var_distinct[3 * g], r1 = I.var_distinct[3 * g + 1];
@@ -546,6 +551,7 @@ void run_allelic(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
 // singleton rows (:1180-1239) for the first-appearance keys [lo, hi): a = haplotypic_counts rows, b = haplotypes rows
 void run_singles(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
     const phz_rows_in &I = *C.in;
+    if (o.a.capacity() == 0) { o.a.reserve((size_t)(hi - lo) * 48); o.b.reserve((size_t)(hi - lo) * 40); }     // most keys sit in blocks
     std::vector<int32_t> q[2];
     for (int64_t t = lo; t < hi; t++) {
         const int g = (int)I.key_g[t];
@@ -724,6 +730,7 @@ struct ChromState {
     phz_rows_in I2;                           // the chromosome's input with the derived arrays plugged in (raw mode)
     std::vector<int64_t> cb, kb;              // block-chunk / key-chunk boundaries
     std::vector<int64_t> w;                   // weight of every component (block chunks are balanced by it)
+    std::vector<int64_t> eh, ea, ec;          // ... and byte estimates of its haplotypes / haplotypic_counts / allele_config rows
     std::vector<BlockChunk> bc;
     std::vector<TextChunk> cc, ac, sc;
 };
@@ -765,14 +772,18 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         S.C.uid = {I.uid_off, I.uid}; S.C.rsid = {I.rsid_off, I.rsid}; S.C.alle = {I.allele_off, I.allele}; S.C.maftxt = {I.maf_off, I.maf_txt};
         S.C.qname = {I.qname_off, I.qname};
         S.C.phased.assign((size_t)I.nv + 1, 0);
-        S.w.resize((size_t)I.ncomp);
+        S.w.resize((size_t)I.ncomp); S.eh.resize((size_t)I.ncomp); S.ea.resize((size_t)I.ncomp); S.ec.resize((size_t)I.ncomp);
         int64_t total = 0;
+        const int64_t idlen = I.nv > 0 ? (int64_t)(I.uid_off[I.nv] / (uint32_t)I.nv) + 2 : 24;      // mean id text + separator
         for (int64_t r = 0; r < I.ncomp; r++) {
             const int64_t ci = I.comp_order[r];
             const int64_t sz = I.comp_ends[ci] - I.comp_starts[ci];
-            int64_t x = 4;
-            for (int64_t t = I.comp_starts[ci]; t < I.comp_ends[ci]; t++) x += 2 + S.C.lines_of((int)I.mem_s[t]) + sz;
+            int64_t x = 4, lines = 0;
+            for (int64_t t = I.comp_starts[ci]; t < I.comp_ends[ci]; t++) { const int64_t l = S.C.lines_of((int)I.mem_s[t]); lines += l; x += 2 + l + sz; }
             S.w[(size_t)r] = x; total += x;
+            S.eh[(size_t)r] = 160 + sz * (2 * idlen + 12);
+            S.ea[(size_t)r] = (int64_t)I.nb * (200 + sz * (idlen + 8) + lines * 9);
+            S.ec[(size_t)r] = sz * (sz - 1) * (4 * idlen + 8);
         }
         totals[(size_t)c] = total;
     });
@@ -794,6 +805,10 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         }
         if (S.cb.back() != I.ncomp) S.cb.push_back(I.ncomp);
         S.bc.resize(S.cb.size() - 1);
+        for (size_t i = 0; i + 1 < S.cb.size(); i++)
+            for (int64_t r = S.cb[i]; r < S.cb[i + 1]; r++) {
+                S.bc[i].est_hap += S.eh[(size_t)r]; S.bc[i].est_ase += S.ea[(size_t)r]; S.bc[i].est_cfg += S.ec[(size_t)r];
+            }
         S.cc.resize((size_t)((I.n_edges + estep - 1) / estep));
         for (size_t i = 0; i < S.bc.size(); i++) tasks.push_back({c, 0, (int64_t)i});
         for (size_t i = 0; i < S.cc.size(); i++) tasks.push_back({c, 1, (int64_t)i});
