@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <string_view>
@@ -22,6 +23,20 @@
 #include <vector>
 
 #include "phz.h"
+
+namespace {
+// PHZ_TIMING=1: wall-clock laps of the host stages on stderr
+struct Laps {
+    bool on; const char *tag; std::chrono::steady_clock::time_point t;
+    explicit Laps(const char *tag_) : on(getenv("PHZ_TIMING") != nullptr), tag(tag_), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[phz timing]     %s: %-36s %7.1f ms\n", tag, what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
 
 namespace {
 
@@ -59,13 +74,26 @@ struct RawBuf {
     }
 };
 
+// std::vector whose resize() leaves new elements uninitialised: the per-record arrays of a shard are written in full by the
+// parallel pack, a value-initialising resize would first sweep gigabytes of zeros on one thread
+template <class T>
+struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    NoInit() = default;
+    template <class U> NoInit(const NoInit<U> &) {}
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using RawVec = std::vector<T, NoInit<T>>;
+
 struct Shard {
     std::string name;
-    std::vector<int32_t> pos, aln;
-    std::vector<uint32_t> cigar_off, cigar, seq_off, qname_off;
-    std::vector<uint8_t> has_as;
+    RawVec<int32_t> pos, aln;
+    RawVec<uint32_t> cigar_off, cigar, seq_off, qname_off;
+    RawVec<uint8_t> has_as;
     RawBuf seq2, qual;                         // filled record by record in the parallel pack (no serial zero fill)
-    std::vector<char> qnames;
+    RawVec<char> qnames;
 };
 
 struct Range { size_t rec_begin, rec_end; };
@@ -150,14 +178,23 @@ struct Bam {
     std::string err;
 };
 
+// one raw-deflate stream per thread, reset between members (a BGZF file is ~16 members per MB: the per-member
+// inflateInit2 / inflateEnd pair is an allocation of the 7 KB state each time)
+struct ZState {
+    z_stream zs; bool live = false;
+    ~ZState() { if (live) inflateEnd(&zs); }
+};
 bool inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t isize) {
-    z_stream zs; memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) return false;
-    zs.next_in = (Bytef *)src; zs.avail_in = (uInt)csize;
-    zs.next_out = dst; zs.avail_out = (uInt)isize;
-    const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    return rc == Z_STREAM_END && zs.avail_out == 0;
+    static thread_local ZState Z;
+    if (!Z.live) {
+        memset(&Z.zs, 0, sizeof Z.zs);
+        if (inflateInit2(&Z.zs, -15) != Z_OK) return false;
+        Z.live = true;
+    } else if (inflateReset(&Z.zs) != Z_OK) return false;
+    Z.zs.next_in = (Bytef *)src; Z.zs.avail_in = (uInt)csize;
+    Z.zs.next_out = dst; Z.zs.avail_out = (uInt)isize;
+    const int rc = inflate(&Z.zs, Z_FINISH);
+    return rc == Z_STREAM_END && Z.zs.avail_out == 0;
 }
 
 int n_threads(int want) {
@@ -380,8 +417,10 @@ int phz_bam_open(const char *path, int threads, phz_bam **out) {
 int phz_bam_open_refs(const char *path, int threads, const char *const *ref_names, int n_names, int64_t *ref_bytes, int max_refs,
                       phz_bam **out) {
     if (out) *out = nullptr;
+    Laps laps(out ? "bam open" : "bam weights");
     BgzfMap M;
     if (int st = M.open(path)) return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st;
+    laps.lap("member table");
     phz_bam *h = out ? new phz_bam() : nullptr;
     std::vector<std::pair<std::string, int32_t>> refs_local;
     std::vector<std::pair<std::string, int32_t>> &refs = h ? h->b.refs : refs_local;
@@ -463,6 +502,7 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
             ref_bytes[i] = (int64_t)(fb > fa ? fb - fa : 0);
         }
     }
+    laps.lap("reference boundary search");
     if (!h) return PHZ_OK;
     // runs of consecutive wanted references -> byte ranges [u_begin, u_end) of the uncompressed stream, cut at record boundaries
     struct Piece { uint64_t u0, u1; };
@@ -486,6 +526,7 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
     for (auto &p : pieces) out_size += (size_t)(p.u1 - p.u0);
     if (!h->b.data.resize(out_size)) { delete h; return PHZ_E_NOMEM; }
     memcpy(h->b.data.data(), head.data(), first_record);
+    laps.lap("piece boundaries + buffer");
     // inflate plan: members fully inside a piece go straight to their place, edge members through a scratch buffer
     struct Job { size_t blk; size_t dst; size_t skip, take; };
     std::vector<Job> jobs;
@@ -525,6 +566,7 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
             }
         });
     for (auto &t : th) t.join();
+    laps.lap("parallel inflate");
     if (bad) { delete h; return PHZ_E_ARG; }
     h->b.first_record = first_record;
     *out = h;
@@ -541,6 +583,7 @@ int64_t phz_bam_ref_length(const phz_bam *h, int i) { return h->b.refs[(size_t)i
 int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_required, int flag_forbidden, double isize_cutoff,
                    int threads, int *n_shards) {
     Bam &b = h->b;
+    Laps laps("bam decode");
     const uint8_t *d = b.data.data();
     const size_t n = b.data.size();
     const int n_ref = (int)b.refs.size();
@@ -567,7 +610,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
     // hop() returns where the chain stopped; *corrupt is set when a record does not fit its own block_size (or the stream ends
     // inside a record): the fixed fields, QNAME, CIGAR, SEQ and QUAL of EVERY record are proven to lie inside the inflated
     // buffer here, so the packer below never reads past a record
-    auto hop = [&](size_t p, size_t stop, std::vector<Rec> &out, std::vector<int32_t> &last_pos, bool *unsorted, bool *corrupt) -> size_t {
+    auto hop = [&](size_t p, size_t stop, auto &out, std::vector<int32_t> &last_pos, bool *unsorted, bool *corrupt) -> size_t {
         while (p < stop) {
             if (p + 4 > n) { *corrupt = true; return p; }
             const int32_t bs = rdi32(d + p);
@@ -596,7 +639,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         }
         return p;
     };
-    std::vector<Rec> recs;
+    RawVec<Rec> recs;
     bool unsorted = false;
     bool done = false;
     const int nt1 = n_threads(threads);
@@ -655,9 +698,9 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         for (int k = 0; k < K; k++)
             if (seg_start[(size_t)k + 1] < n && seg_end[(size_t)k] != seg_start[(size_t)k + 1]) ok = false;
         if (ok) {
-            size_t total = 0;
-            for (auto &v : part) total += v.size();
-            recs.reserve(total);
+            std::vector<size_t> at((size_t)K + 1, 0);
+            for (int k = 0; k < K; k++) at[(size_t)k + 1] = at[(size_t)k] + part[(size_t)k].size();
+            recs.resize(at[(size_t)K]);            // uninitialised; the segments copy themselves in (in parallel)
             std::vector<int32_t> last((size_t)n_ref, -1);
             for (int k = 0; k < K; k++) {
                 if (bad[(size_t)k]) unsorted = true;
@@ -665,8 +708,20 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
                     if (firstp[(size_t)k][(size_t)r2] >= 0 && firstp[(size_t)k][(size_t)r2] - 1 < last[(size_t)r2]) unsorted = true;
                     if (lastp[(size_t)k][(size_t)r2] >= 0 || firstp[(size_t)k][(size_t)r2] >= 0) last[(size_t)r2] = std::max(last[(size_t)r2], lastp[(size_t)k][(size_t)r2]);
                 }
-                recs.insert(recs.end(), part[(size_t)k].begin(), part[(size_t)k].end());
-                std::vector<Rec>().swap(part[(size_t)k]);
+            }
+            {
+                std::atomic<int> next(0);
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt1; t++)
+                    th.emplace_back([&] {
+                        for (;;) {
+                            const int k = next.fetch_add(1);
+                            if (k >= K) break;
+                            if (!part[(size_t)k].empty()) memcpy(recs.data() + at[(size_t)k], part[(size_t)k].data(), part[(size_t)k].size() * sizeof(Rec));
+                            std::vector<Rec>().swap(part[(size_t)k]);
+                        }
+                    });
+                for (auto &x : th) x.join();
             }
             done = true;
         }
@@ -679,6 +734,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         hop(b.first_record, n, recs, last_pos, &unsorted, &corrupt);
         if (corrupt) { b.err = "truncated or corrupt BAM record"; return PHZ_E_ARG; }
     }
+    laps.lap("record hop + filters");
     if (getenv("PHZ_TIMING")) fprintf(stderr, "[phz timing]   bam record hop: %s, %zu records kept\n", done ? "parallel segments, boundaries verified" : "sequential", recs.size());
     if (unsorted) return PHZ_E_UNSUPPORTED;
     // bucket by reference, in reference order (file order within a reference is preserved).  A coordinate-sorted BAM has its
@@ -719,6 +775,7 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         for (size_t i = 0; i < recs.size(); i++) order[cur[(size_t)recs[i].ref]++] = (uint32_t)i;
     }
     auto rec_at = [&](size_t k) -> const Rec & { return grouped ? recs[k] : recs[order[k]]; };
+    laps.lap("bucket by reference");
     b.shards.clear();
     for (int i = 0; i < n_ref; i++) {
         const size_t lo = count[(size_t)i], hi = count[(size_t)i + 1];
@@ -816,7 +873,11 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         for (auto &t : th) t.join();
     }
     *n_shards = (int)b.shards.size();
-    b.data.resize(0);            // the inflated stream is not needed once the shards are packed (decode is a one-shot call)
+    laps.lap("offsets + packing (all shards)");
+    // the inflated stream is not needed once the shards are packed (decode is a one-shot call); unmapping ~10 GB takes most of a
+    // second, so a helper thread does it while the caller goes on
+    { RawBuf gone(std::move(b.data)); std::thread([g = std::move(gone)]() mutable { g.drop(); }).detach(); }
+    laps.lap("release of the inflated stream");
     return PHZ_OK;
 }
 
@@ -849,7 +910,8 @@ int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t 
         for (auto &x : th) x.join();
     };
     auto name_of = [&](int64_t i) { return std::string_view(blob + off[i], off[i + 1] - off[i]); };
-    std::vector<uint64_t> hv((size_t)n);
+    // scratch arrays are default-initialised (no zero fill: every element is written before it is read)
+    std::unique_ptr<uint64_t[]> hv(new uint64_t[(size_t)n]);
     par(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) hv[(size_t)i] = hash_name(blob + off[i], off[i + 1] - off[i]); });
     auto bucket_of = [&](int64_t i) { return (int)(hv[(size_t)i] >> 58); };        // top 6 bits; the table uses the low ones
     // bucket lists in input order: per-slice histograms -> offsets -> scatter (all parallel)
@@ -862,11 +924,11 @@ int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t 
         std::vector<int64_t> run(start.begin(), start.end() - 1);
         for (int t = 0; t < ns; t++) for (int p = 0; p < P; p++) { const int64_t c = hist[(size_t)t][(size_t)p]; hist[(size_t)t][(size_t)p] = run[(size_t)p]; run[(size_t)p] += c; }
     }
-    std::vector<int32_t> order((size_t)n);
+    std::unique_ptr<int32_t[]> order(new int32_t[(size_t)n]);
     par(n, [&](int64_t lo, int64_t hi) { auto &cur = hist[ns == 1 ? 0 : (size_t)((lo * nt + n - 1) / n)]; for (int64_t i = lo; i < hi; i++) order[(size_t)cur[(size_t)bucket_of(i)]++] = (int32_t)i; });
     // rep[i] >= 0: index of the first occurrence of this new name in the input; < 0: -(existing id) - 1
-    std::vector<int32_t> rep((size_t)n);
-    std::vector<uint8_t> first((size_t)n, 0);
+    std::unique_ptr<int32_t[]> rep(new int32_t[(size_t)n]);
+    std::unique_ptr<uint8_t[]> first(new uint8_t[(size_t)n]);
     {
         std::atomic<int> next(0);
         auto work = [&] {
@@ -881,6 +943,7 @@ int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t 
                     const std::string_view nm = name_of(i);
                     const uint64_t h = hv[(size_t)i];
                     const int32_t known = T.ids.find(h, [&](int32_t id) { return it->names[(size_t)id] == nm; });
+                    first[(size_t)i] = 0;
                     if (known >= 0) { rep[(size_t)i] = -known - 1; continue; }
                     const int32_t seen = fresh.find(h, [&](int32_t j) { return name_of(j) == nm; });
                     if (seen >= 0) { rep[(size_t)i] = seen; continue; }
@@ -894,9 +957,15 @@ int phz_intern(phz_interner *it, const char *blob, const uint32_t *off, int64_t 
         for (auto &x : th) x.join();
     }
     const int64_t base = (int64_t)it->names.size();
-    std::vector<int32_t> rank((size_t)n);
+    std::unique_ptr<int32_t[]> rank(new int32_t[(size_t)n]);
     int64_t nnew = 0;
-    for (int64_t i = 0; i < n; i++) { rank[(size_t)i] = (int32_t)nnew; nnew += first[(size_t)i]; }
+    {   // exclusive prefix sum of the first-occurrence marks: per-slice totals, then every slice numbers its own part
+        std::vector<int64_t> tot((size_t)ns + 1, 0);
+        par(n, [&](int64_t lo, int64_t hi) { int64_t c = 0; for (int64_t i = lo; i < hi; i++) c += first[(size_t)i]; tot[(ns == 1 ? 0 : (size_t)((lo * nt + n - 1) / n)) + 1] = c; });
+        for (int t = 0; t < ns; t++) tot[(size_t)t + 1] += tot[(size_t)t];
+        nnew = tot[(size_t)ns];
+        par(n, [&](int64_t lo, int64_t hi) { int64_t c = tot[ns == 1 ? 0 : (size_t)((lo * nt + n - 1) / n)]; for (int64_t i = lo; i < hi; i++) { rank[(size_t)i] = (int32_t)c; c += first[(size_t)i]; } });
+    }
     if (base + nnew > 0x7fffffff) return PHZ_E_ARG;
     par(n, [&](int64_t lo, int64_t hi) {
         for (int64_t i = lo; i < hi; i++) {
