@@ -155,7 +155,7 @@ typedef struct {
 } phz_variants_general;
 
 /* timing slots for phz_get_timing */
-enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_GENES = 4, PHZ_T_COUNT = 8 };
+enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_GENES = 4, PHZ_T_INFLATE = 5, PHZ_T_BAMPACK = 6, PHZ_T_COUNT = 8 };
 
 /* work counters accumulated over phz_tally calls since the last phz_reset_timing (the units of K_tally's byte model):
  * call lines seen, distinct (QNAME, variant, class) items, pair events = sum over QNAMEs of C(k, 2) item pairs on different
@@ -201,6 +201,41 @@ int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space);
  * index of v's component.  edge_a == edge_b == NULL: the edge list of the last phz_tally (n_edges must match). */
 int phz_components(phz_ctx *ctx, int64_t nv, int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b,
                    const uint8_t *keep, int32_t *label, int space);
+
+/* ---- device side of the path's input (SURVEY.md 8(f) next-1 on the GPU): BGZF inflate, BAM record decode, filters and SoA packing in
+ * HBM.  Replaces the same samtools pipeline as the host functions below (phaser/phaser.py:1346, :505-513). */
+typedef struct {                 /* one BGZF member */
+    uint64_t src;                /* byte offset of its raw deflate stream in the compressed buffer */
+    uint32_t csize, isize;       /* compressed size of that stream; ISIZE (uncompressed size) from the member trailer */
+    uint64_t dst;                /* byte offset of its output */
+} phz_bgzf_member;
+
+/* Inflates members whose compressed bytes are in DEVICE memory (readable for 8 bytes past the last member) into `out` (device).
+ * *bad = 0, or a code > 0 when some member is not valid DEFLATE / does not produce ISIZE bytes: the output is unusable then. */
+int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t n_members, uint8_t *out, int *bad);
+
+/* A coordinate-sorted BAM file decoded on the device: plan on the host (member table, header, chromosome ranges), then H2D of the
+ * compressed members, K_inflate, record boundaries + filters + kept-record list, and k_pack into caller-allocated DEVICE arrays with
+ * the layout of the phz_reads arrays plus the AS and QNAME columns.  PHZ_E_UNSUPPORTED: the file needs the host path (phz_bam_open*). */
+typedef struct phz_bamdev phz_bamdev;
+typedef struct { int32_t min_mapq, flag_required, flag_forbidden; double isize_cutoff; } phz_bam_filters;
+typedef struct { int64_t n_reads, n_ops, n_seq_bytes, n_qname_bytes; } phz_bamdev_sizes;
+typedef struct {                 /* device pointers; sizes from phz_bamdev_sizes_of: pos/aln_score/has_as [n_reads], *_off [n_reads+1], */
+    int32_t *pos;                /* cigar [n_ops], seq2 [n_seq_bytes], qual [4*n_seq_bytes], qnames [n_qname_bytes] (no separators)    */
+    uint32_t *cigar_off, *cigar, *seq_off;
+    uint8_t *seq2, *qual;
+    int32_t *aln_score;
+    uint8_t *has_as;
+    uint32_t *qname_off;
+    char *qnames;
+} phz_dev_shard;
+int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names, int n_names, const phz_bam_filters *filters, phz_bamdev **out);
+int phz_bamdev_close(phz_bamdev *h);
+int phz_bamdev_n_ref(const phz_bamdev *h);
+const char *phz_bamdev_ref_name(const phz_bamdev *h, int i);
+int64_t phz_bamdev_ref_length(const phz_bamdev *h, int i);
+int phz_bamdev_sizes_of(const phz_bamdev *h, int ref, phz_bamdev_sizes *out);
+int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst);      /* dst[r] for reference r; entries of empty references are ignored */
 
 /* ---- host side of the path's input: native BGZF/BAM decode, SoA packing, QNAME interning -------------------
  * Replaces `samtools view -h BAM 'chr': | samtools view -Sh [-F 0x400] [-f 2] -q MAPQ -` (phaser/phaser.py:1346)

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 PHZ_OK, PHZ_E_ARG, PHZ_E_HIP, PHZ_E_CAPACITY, PHZ_E_UNSUPPORTED, PHZ_E_NOMEM = 0, -1, -2, -3, -4, -5
 PHZ_HOST, PHZ_DEVICE = 0, 1
-PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS, PHZ_T_GENES = 0, 1, 2, 3, 4
+PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS, PHZ_T_GENES, PHZ_T_INFLATE, PHZ_T_BAMPACK = 0, 1, 2, 3, 4, 5, 6
 PHZ_C_LINES, PHZ_C_ITEMS, PHZ_C_PAIR_EVENTS, PHZ_C_EDGES = 0, 1, 2, 3
 
 
@@ -64,6 +64,18 @@ class phz_tally_sizes(C.Structure):
 class phz_tally_out(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("var_count", "var_first", "var_distinct", "var_rank", "line_cls", "edge_a", "edge_b", "edge_cells",
                                           "edge_linked", "edge_cto", "rl_start", "rl_qid", "edge_stats")]
+
+
+class phz_bam_filters(C.Structure):
+    _fields_ = [("min_mapq", C.c_int32), ("flag_required", C.c_int32), ("flag_forbidden", C.c_int32), ("isize_cutoff", C.c_double)]
+
+
+class phz_bamdev_sizes(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_reads", "n_ops", "n_seq_bytes", "n_qname_bytes")]
+
+
+class phz_dev_shard(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "aln_score", "has_as", "qname_off", "qnames")]
 
 
 class phz_host_shard(C.Structure):
@@ -180,6 +192,14 @@ SYMBOLS = {
                             C.POINTER(phz_tally_sizes), C.c_int]),
     "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),
     "phz_components": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "phz_bgzf_inflate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]),
+    "phz_bamdev_open": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(phz_bam_filters), C.POINTER(C.c_void_p)]),
+    "phz_bamdev_close": (C.c_int, [C.c_void_p]),
+    "phz_bamdev_n_ref": (C.c_int, [C.c_void_p]),
+    "phz_bamdev_ref_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "phz_bamdev_ref_length": (C.c_int64, [C.c_void_p, C.c_int]),
+    "phz_bamdev_sizes_of": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_bamdev_sizes)]),
+    "phz_bamdev_pack": (C.c_int, [C.c_void_p, C.POINTER(phz_dev_shard), C.c_int]),
     "phz_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "phz_bam_open_refs": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "phz_bam_close": (C.c_int, [C.c_void_p]),

@@ -12,7 +12,7 @@ from __future__ import annotations
 import gzip
 import struct
 import zlib
-from typing import Dict, Iterator, List, Tuple
+from typing import Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -306,6 +306,73 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
     if _prof:
         _sys.stderr.write("[phz timing]   bam: open+inflate %.2f s, decode+filter+pack %.2f s, shard views %.2f s, qname interning %.2f s\n"
                           % (_t0 - _topen, _t1 - _t0, _t.perf_counter() - _t1 - _tin, _tin))
+    return out
+
+
+def shards_from_bam_device(ctx, path: str, interners: Dict[str, "NativeInterner"], mapq: int, remove_dups: bool, paired_end: bool,
+                           isize_cutoff: float = 0.0, chroms=None, device="cuda:0", threads: int = 0) -> Optional[Dict[str, soa.ReadShard]]:
+    """The same shards as shards_from_bam_native, decoded ON THE GPU (phz_bamdev_*: K_inflate, record hop, k_pack) and left in HBM.
+    QNAME interning stays on the host (the interner persists across BAMs): the name bytes are the only part that travels back.
+    Returns None when the file needs the host path (the library says PHZ_E_UNSUPPORTED; the reason goes to stderr under PHZ_TIMING)."""
+    import ctypes as C, os as _os, sys as _sys, time as _t
+    from . import _lib
+    lib = _lib.load()
+    _prof = _os.environ.get("PHZ_TIMING"); t0 = _t.perf_counter()
+    f = _lib.phz_bam_filters(int(mapq), 0x2 if paired_end else 0, 0x400 if remove_dups else 0, float(isize_cutoff))
+    h = C.c_void_p()
+    if chroms is not None:
+        names = [str(c).encode() for c in chroms]
+        arr = (C.c_char_p * max(1, len(names)))(*names) if names else (C.c_char_p * 1)()
+        st = lib.phz_bamdev_open(ctx.h, path.encode(), arr, len(names), C.byref(f), C.byref(h))
+    else:
+        st = lib.phz_bamdev_open(ctx.h, path.encode(), None, 0, C.byref(f), C.byref(h))
+    if st == _lib.PHZ_E_UNSUPPORTED:
+        if _prof:
+            _sys.stderr.write("[phz timing]   bam: device path declined (%s), using the host decoder\n" % lib.phz_last_error(ctx.h).decode())
+        return None
+    if st != 0:
+        raise _lib.PhzError(st, "cannot read BAM %s: %s" % (path, lib.phz_last_error(ctx.h).decode()))
+    t1 = _t.perf_counter()
+    try:
+        n_ref = lib.phz_bamdev_n_ref(h)
+        tab = (_lib.phz_dev_shard * max(1, n_ref))()
+        out = {}; held = {}
+        dev = torch.device(device)
+        for i in range(n_ref):
+            sz = _lib.phz_bamdev_sizes()
+            lib.phz_bamdev_sizes_of(h, i, C.byref(sz))
+            n = int(sz.n_reads)
+            if n == 0:
+                continue
+            chrom = lib.phz_bamdev_ref_name(h, i).decode()
+            e = lambda count, dt: torch.empty(max(1, int(count)), dtype=dt, device=dev)
+            t = {"pos": e(n, torch.int32), "cigar_off": e(n + 1, torch.int32), "cigar": e(sz.n_ops, torch.int32), "seq_off": e(n + 1, torch.int32),
+                 "seq2": e(sz.n_seq_bytes, torch.uint8), "qual": e(sz.n_seq_bytes * 4, torch.uint8), "aln_score": e(n, torch.int32),
+                 "has_as": e(n, torch.uint8), "qname_off": e(n + 1, torch.int32), "qnames": e(sz.n_qname_bytes, torch.uint8)}
+            for k, v in t.items():
+                setattr(tab[i], k, v.data_ptr())
+            held[chrom] = (t, n, sz)
+        st = lib.phz_bamdev_pack(h, tab, n_ref)
+        if st != 0:
+            raise _lib.PhzError(st, "device BAM pack failed: " + lib.phz_last_error(ctx.h).decode())
+    finally:
+        lib.phz_bamdev_close(h)
+    t2 = _t.perf_counter(); tin = 0.0
+    for chrom, (t, n, sz) in held.items():
+        sh = soa.ReadShard(t["pos"][:n], t["cigar_off"][:n + 1], t["cigar"][:int(sz.n_ops)], t["seq_off"][:n + 1], t["seq2"][:int(sz.n_seq_bytes)],
+                           t["qual"][:int(sz.n_seq_bytes) * 4])
+        it = interners.setdefault(chrom, NativeInterner())
+        qn = t["qnames"][:int(sz.n_qname_bytes)].cpu().numpy(); qo = t["qname_off"][:n + 1].cpu().numpy()
+        qid = np.zeros(n, dtype=np.int32)
+        ti = _t.perf_counter()
+        lib.phz_intern(it.h, C.c_void_p(qn.ctypes.data), C.c_void_p(qo.ctypes.data), n, C.c_void_p(qid.ctypes.data))
+        tin += _t.perf_counter() - ti
+        sh.qid = torch.from_numpy(qid).to(dev)
+        sh.aln_score = t["aln_score"][:n]; sh.has_as = t["has_as"][:n]
+        out[chrom] = sh
+    if _prof:
+        _sys.stderr.write("[phz timing]   bam (device): plan + H2D + inflate + hop %.2f s, allocate + pack %.2f s, names D2H + qid H2D %.2f s, qname interning %.2f s\n"
+                          % (t1 - t0, t2 - t1, _t.perf_counter() - t2 - tin, tin))
     return out
 
 

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "phz.h"
+#include "phz_internal.h"
 
 namespace {
 // PHZ_TIMING=1: wall-clock laps of the host stages on stderr
@@ -396,48 +397,25 @@ struct phz_interner {
     std::vector<std::string_view> names;          // id -> name
 };
 
-extern "C" {
-
-int phz_bam_open(const char *path, int threads, phz_bam **out) {
-    *out = nullptr;
-    phz_bam *h = new phz_bam();
-    if (int st = inflate_bgzf_file(path, threads, h->b.data)) { delete h; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
-    if (parse_bam_header(h->b.data.data(), h->b.data.size(), h->b.refs, &h->b.first_record) != 0) { delete h; return PHZ_E_ARG; }
-    *out = h;
-    return PHZ_OK;
-}
-
-// Chromosome-restricted open (what `samtools view BAM 'chr':` does with the .bai, phaser/phaser.py:1346; here without an index
-// file): the BGZF member table is read from the member headers alone, the members in which the wanted references begin / end are
-// found by binary search (a coordinate-sorted BAM keeps every reference's records contiguous; a probe inflates two members and
-// looks for the first record boundary with the same plausibility chain the parallel record hop uses), and only the members that
-// hold wanted records are inflated.  The result is a stream cut at record boundaries, i.e. a valid record chain: phz_bam_decode
-// works on it unchanged.  ref_bytes (may be NULL) receives, per reference, the compressed bytes between the members where it and
-// the next reference begin: a proxy of its record count, available before anything is decoded (LPT weights).
-int phz_bam_open_refs(const char *path, int threads, const char *const *ref_names, int n_names, int64_t *ref_bytes, int max_refs,
-                      phz_bam **out) {
-    if (out) *out = nullptr;
-    Laps laps(out ? "bam open" : "bam weights");
-    BgzfMap M;
-    if (int st = M.open(path)) return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st;
-    laps.lap("member table");
-    phz_bam *h = out ? new phz_bam() : nullptr;
-    std::vector<std::pair<std::string, int32_t>> refs_local;
-    std::vector<std::pair<std::string, int32_t>> &refs = h ? h->b.refs : refs_local;
+// Plan of a chromosome-restricted read: BAM header, and the byte ranges [u0, u1) of the inflated stream (cut at record boundaries)
+// that hold the records of the wanted references.  Shared by the host open (phz_bam_open_refs) and the device open (phz_bamdev_open).
+struct BamPiece { uint64_t u0, u1; };
+static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64_t *ref_bytes, int max_refs, bool want_pieces,
+                    std::vector<std::pair<std::string, int32_t>> &refs, std::vector<uint8_t> &head, size_t *first_record_out,
+                    std::vector<BamPiece> &pieces, Laps &laps) {
     // header: inflate members until it parses
-    std::vector<uint8_t> head;
     size_t hb = 0, first_record = 0;
     for (;;) {
-        if (hb >= M.blks.size()) { delete h; return PHZ_E_ARG; }
+        if (hb >= M.blks.size()) return PHZ_E_ARG;
         const size_t old = head.size();
         head.resize(old + M.blks[hb].isize);
-        if (M.blks[hb].isize && !inflate_block(M.f + M.blks[hb].off, M.blks[hb].csize, head.data() + old, M.blks[hb].isize)) { delete h; return PHZ_E_ARG; }
+        if (M.blks[hb].isize && !inflate_block(M.f + M.blks[hb].off, M.blks[hb].csize, head.data() + old, M.blks[hb].isize)) return PHZ_E_ARG;
         hb++;
         refs.clear();
         const int rc = parse_bam_header(head.data(), head.size(), refs, &first_record);
         if (rc == 0) break;
-        if (rc < 0 && head.size() > (1u << 30)) { delete h; return PHZ_E_ARG; }
-        if (rc == 2) { delete h; return PHZ_E_ARG; }       // malformed, not merely short
+        if (rc < 0 && head.size() > (1u << 30)) return PHZ_E_ARG;
+        if (rc == 2) return PHZ_E_ARG;       // malformed, not merely short
     }
     const int n_ref = (int)refs.size();
     const size_t nb = M.blks.size();
@@ -503,10 +481,9 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
         }
     }
     laps.lap("reference boundary search");
-    if (!h) return PHZ_OK;
+    *first_record_out = first_record;
+    if (!want_pieces) return PHZ_OK;
     // runs of consecutive wanted references -> byte ranges [u_begin, u_end) of the uncompressed stream, cut at record boundaries
-    struct Piece { uint64_t u0, u1; };
-    std::vector<Piece> pieces;
     uint64_t total_u = M.total;
     for (int i = 0; i < n_ref;) {
         if (!want[(size_t)i]) { i++; continue; }
@@ -522,6 +499,73 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
         if (u1 > u0) pieces.push_back({u0, u1});
         i = j + 1;
     }
+    return PHZ_OK;
+}
+
+int phz_bam_plan_file(const char *path, const char *const *ref_names, int n_names, PhzBamPlan *out) {
+    Laps laps("bam plan");
+    BgzfMap *M = new BgzfMap();
+    if (int st = M->open(path)) { delete M; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
+    laps.lap("member table");
+    std::vector<BamPiece> pieces;
+    if (int st = bam_plan(*M, ref_names, n_names, nullptr, 0, true, out->refs, out->head, &out->first_record, pieces, laps)) { delete M; return st; }
+    for (auto &p : pieces) out->pieces.emplace_back(p.u0, p.u1);
+    const size_t nb = M->blks.size();
+    size_t b = 0;
+    for (auto &p : pieces) {
+        size_t lo = b, hi = nb;       // first member overlapping u0 (pieces ascend, members are taken once)
+        while (lo < hi) { const size_t m = (lo + hi) >> 1; if (M->blks[m].dst + M->blks[m].isize <= p.u0) lo = m + 1; else hi = m; }
+        for (b = lo; b < nb && M->blks[b].dst < p.u1; b++) {
+            if (!out->members.empty() && out->members.back().dst == M->blks[b].dst) continue;
+            out->members.push_back({(uint64_t)M->blks[b].off, (uint32_t)M->blks[b].csize, (uint32_t)M->blks[b].isize, (uint64_t)M->blks[b].dst});
+        }
+        if (b > lo) b--;              // the last member of this piece may also be the first of the next one
+    }
+    out->file = M->f; out->file_size = M->fsz; out->owner = M;
+    laps.lap("pieces + member list");
+    return PHZ_OK;
+}
+
+void phz_bam_plan_release(PhzBamPlan *p) {
+    if (p && p->owner) { delete (BgzfMap *)p->owner; p->owner = nullptr; p->file = nullptr; }
+}
+
+extern "C" {
+
+int phz_bam_open(const char *path, int threads, phz_bam **out) {
+    *out = nullptr;
+    phz_bam *h = new phz_bam();
+    if (int st = inflate_bgzf_file(path, threads, h->b.data)) { delete h; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
+    if (parse_bam_header(h->b.data.data(), h->b.data.size(), h->b.refs, &h->b.first_record) != 0) { delete h; return PHZ_E_ARG; }
+    *out = h;
+    return PHZ_OK;
+}
+
+// Chromosome-restricted open (what `samtools view BAM 'chr':` does with the .bai, phaser/phaser.py:1346; here without an index
+// file): the BGZF member table is read from the member headers alone, the members in which the wanted references begin / end are
+// found by binary search (a coordinate-sorted BAM keeps every reference's records contiguous; a probe inflates two members and
+// looks for the first record boundary with the same plausibility chain the parallel record hop uses), and only the members that
+// hold wanted records are inflated.  The result is a stream cut at record boundaries, i.e. a valid record chain: phz_bam_decode
+// works on it unchanged.  ref_bytes (may be NULL) receives, per reference, the compressed bytes between the members where it and
+// the next reference begin: a proxy of its record count, available before anything is decoded (LPT weights).
+int phz_bam_open_refs(const char *path, int threads, const char *const *ref_names, int n_names, int64_t *ref_bytes, int max_refs,
+                      phz_bam **out) {
+    if (out) *out = nullptr;
+    Laps laps(out ? "bam open" : "bam weights");
+    BgzfMap M;
+    if (int st = M.open(path)) return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st;
+    laps.lap("member table");
+    phz_bam *h = out ? new phz_bam() : nullptr;
+    std::vector<std::pair<std::string, int32_t>> refs_local;
+    std::vector<std::pair<std::string, int32_t>> &refs = h ? h->b.refs : refs_local;
+    std::vector<uint8_t> head;
+    size_t first_record = 0;
+    std::vector<BamPiece> pieces;
+    if (int st = bam_plan(M, ref_names, n_names, ref_bytes, max_refs, h != nullptr, refs, head, &first_record, pieces, laps)) { delete h; return st; }
+    if (!h) return PHZ_OK;
+    const size_t nb = M.blks.size();
+    size_t b0 = 0;
+    while (b0 + 1 < nb && M.blks[b0 + 1].dst <= first_record) b0++;
     size_t out_size = first_record;
     for (auto &p : pieces) out_size += (size_t)(p.u1 - p.u0);
     if (!h->b.data.resize(out_size)) { delete h; return PHZ_E_NOMEM; }

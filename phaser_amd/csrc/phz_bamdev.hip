@@ -1,0 +1,531 @@
+// Device-side BAM path (SURVEY.md 8(f) next-1 on the GPU): from the BGZF members of a coordinate-sorted BAM in a file to the
+// structure-of-arrays shards K_map reads, without the records ever visiting the host.  Replaces, like phz_bam.cpp, what phASER gets
+// from `samtools view -h BAM 'chr': | samtools view -Sh [-F 0x400] [-f 2] -q MAPQ -` (phaser/phaser.py:1346, :505-513) plus the
+// mapper's per-record text parsing (phaser/read_variant_map.py:27-64) -- same filters, same packed arrays (tests compare the two
+// paths array by array).
+//
+//   host   member table + header + chromosome ranges (phz_bam_plan_file: a few probe members inflated with zlib)
+//   H2D    the compressed members that hold wanted records
+//   K_inflate (phz_inflate.hip)  one lane per BGZF member
+//   k_seg_start   the stream is cut into ~256 KB segments; the first record boundary of each is GUESSED by a plausibility chain
+//   k_hop<0>      one lane per segment hops its record chain: filters, kept-record count, sortedness; every guess is VERIFIED
+//                 (segment k must end exactly where segment k+1 starts -- the same proof the host's parallel hop uses)
+//   scan + k_hop<1>   kept-record list (offset, reference, op count, bases, name length)
+//   scans + k_pack    one lane per kept record writes its slots of the shard arrays (normalised CIGAR, 2-bit bases, quals, AS)
+// Anything the device path cannot prove (a member that is not valid DEFLATE, a boundary that does not verify, an unsorted file,
+// 32-bit offsets exceeded) returns PHZ_E_UNSUPPORTED and the caller uses the host path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "phz.h"
+#include "phz_internal.h"
+#include "phz_scan.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__device__ __forceinline__ int32_t ldi32(const uint8_t *p) { return (int32_t)ld32(p); }
+
+struct Seg { uint64_t guess, end; uint32_t exact, piece; };     // end = end of the segment's piece
+
+struct Filters {
+    int min_mapq, flag_required, flag_forbidden;
+    double isize_cutoff;
+    const uint8_t *ref_mask;      // [n_ref] device, 1 = wanted
+    int n_ref;
+};
+
+// can offset p of d[0, n) start a record?  -> offset of the next record, 0 when it cannot (same test as the host's plausible_at)
+__device__ uint64_t plausible(const uint8_t *d, uint64_t n, uint64_t p, int n_ref) {
+    if (p + 36 > n) return 0;
+    const int32_t bs = ldi32(d + p);
+    if (bs < 32 || bs > (1 << 24) || p + 4 + (uint64_t)bs > n) return 0;
+    const uint8_t *r = d + p + 4;
+    const int32_t ref = ldi32(r), pos0 = ldi32(r + 4), l_seq = ldi32(r + 16), nref = ldi32(r + 20);
+    const uint32_t l_rn = r[8], n_cig = ld16(r + 12);
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 1) return 0;
+    const uint64_t need = 32 + (uint64_t)l_rn + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    if (need > (uint64_t)bs) return 0;
+    if (r[32 + l_rn - 1] != 0) return 0;
+    for (uint32_t k = 0; k + 1 < l_rn; k++) if (r[32 + k] < 33 || r[32 + k] > 126) return 0;
+    return p + 4 + (uint64_t)bs;
+}
+
+__global__ __launch_bounds__(64) void k_seg_start(const uint8_t *d, const Seg *segs, int64_t nseg, int n_ref, uint64_t *start) {
+    const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (k >= nseg) return;
+    const Seg s = segs[k];
+    if (s.exact) { start[k] = s.guess; return; }
+    const uint64_t limit = s.guess + (32u << 20) < s.end ? s.guess + (32u << 20) : s.end;
+    uint64_t found = s.end;
+    for (uint64_t p = s.guess; p < limit; p++) {
+        uint64_t q = p; int ok = 0;
+        while (ok < 12) {
+            const uint64_t nx = plausible(d, s.end, q, n_ref);
+            if (!nx) break;
+            ok++; q = nx;
+            if (q + 4 > s.end) { ok = 12; break; }
+        }
+        if (ok >= 12) { found = p; break; }
+    }
+    start[k] = found;
+}
+
+// number of ops of a record's normalised op list (see norm_ops in phz_bam.cpp / soa.pack_sam); out != nullptr: write them
+__device__ int norm_ops_dev(const uint8_t *cig, int n_cig, int nb, uint32_t *out) {
+    int n = 0;
+    long long read_pos = 0;
+    for (int i = 0; i < n_cig; i++) {
+        const uint32_t c = ld32(cig + 4 * i);
+        const uint32_t op = c & 15, len = c >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            const long long lo = read_pos < nb ? read_pos : nb, hi = read_pos + (long long)len < nb ? read_pos + (long long)len : nb;
+            const uint32_t avail = (uint32_t)(hi > lo ? hi - lo : 0);
+            if (avail == len) { if (out) out[n] = c; n++; }
+            else {
+                if (avail) { if (out) out[n] = (avail << 4) | op; n++; }
+                if (out) out[n] = ((len - avail) << 4) | 9u;
+                n++;
+            }
+            read_pos += len;
+        } else if (op == 1) {
+            const long long lo = read_pos < nb ? read_pos : nb, hi = read_pos + (long long)len < nb ? read_pos + (long long)len : nb;
+            const uint32_t avail = (uint32_t)(hi > lo ? hi - lo : 0);
+            if (out) out[n] = (avail << 4) | 1u;
+            n++;
+            read_pos += len;
+        } else if (op == 4) {
+            if (out) out[n] = c;
+            n++;
+            read_pos += len;
+        } else if (op == 2 || op == 3) {
+            if (out) out[n] = c;
+            n++;
+        }                                  // H, P and anything else leave no trace (as in the host packer)
+    }
+    return n;
+}
+
+struct SegOut {                 // per segment, written by the counting hop
+    uint32_t kept;
+    uint32_t flags;             // 1 corrupt chain, 2 boundary mismatch, 4 unsorted inside the segment
+    int32_t first_ref, first_pos, last_ref, last_pos;      // of the kept records (first_ref = -2 when none)
+    uint64_t sq_sum, qn_sum, op_sum;                       // 64-bit sums of base groups, name bytes and 2 x CIGAR ops (upper bound of the
+                                                           // normalised op count) over the kept records: the scans below are 32-bit
+};
+
+struct KeptOut {                // kept-record list (structure of arrays)
+    uint64_t *off; int32_t *ref; uint32_t *nops, *sq, *nb, *lqn;
+};
+
+template <int WRITE>
+__global__ __launch_bounds__(64) void k_hop(const uint8_t *d, const Seg *segs, int64_t nseg, const uint64_t *start, Filters F, SegOut *so,
+                                            const uint32_t *kept_base, KeptOut K) {
+    const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (k >= nseg) return;
+    const Seg s = segs[k];
+    const uint64_t n = s.end;
+    uint64_t p = start[k];
+    const uint64_t stop = (k + 1 < nseg && segs[k + 1].piece == s.piece) ? start[k + 1] : s.end;
+    uint32_t kept = 0, flags = 0;
+    uint64_t sq_sum = 0, qn_sum = 0, op_sum = 0;
+    int32_t first_ref = -2, first_pos = 0, last_ref = -2, last_pos = 0;
+    uint64_t w = WRITE ? kept_base[k] : 0;
+    while (p < stop) {
+        if (p + 36 > n) { flags |= 1; break; }
+        const int32_t bs = ldi32(d + p);
+        if (bs < 32 || (uint64_t)bs > n - p - 4) { flags |= 1; break; }
+        const uint8_t *r = d + p + 4;
+        const int32_t ref = ldi32(r);
+        const uint32_t l_rn = r[8], mapq = r[9], n_cig = ld16(r + 12), flag = ld16(r + 14);
+        const int32_t l_seq = ldi32(r + 16), tlen = ldi32(r + 28);
+        if (l_seq < 0 || l_rn < 1 || 32 + (uint64_t)l_rn + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > (uint64_t)bs) { flags |= 1; break; }
+        bool keep = ref >= 0 && ref < F.n_ref && F.ref_mask[ref] && (int)mapq >= F.min_mapq && ((int)flag & F.flag_required) == F.flag_required &&
+                    ((int)flag & F.flag_forbidden) == 0;
+        if (keep && F.isize_cutoff != 0) { const double tl = tlen < 0 ? -(double)tlen : (double)tlen; keep = tl <= F.isize_cutoff; }
+        if (keep) {
+            const int32_t pos0 = ldi32(r + 4);
+            if (last_ref != -2 && (ref < last_ref || (ref == last_ref && pos0 < last_pos))) flags |= 4;
+            if (first_ref == -2) { first_ref = ref; first_pos = pos0; }
+            last_ref = ref; last_pos = pos0;
+            if (!WRITE) {
+                const uint8_t *qual0 = r + 32 + l_rn + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2;
+                const uint32_t nb0 = l_seq <= 0 ? 1u : (qual0[0] == 0xFF ? 1u : (uint32_t)l_seq);
+                sq_sum += (nb0 + 3) / 4; qn_sum += l_rn - 1; op_sum += 2 * (uint64_t)n_cig;
+            }
+            if (WRITE) {
+                const uint8_t *cig = r + 32 + l_rn;
+                const uint8_t *qual = cig + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2;
+                uint32_t nb;
+                if (l_seq <= 0) nb = 1; else nb = qual[0] == 0xFF ? 1u : (uint32_t)l_seq;
+                K.off[w] = p + 4; K.ref[w] = ref; K.nops[w] = (uint32_t)norm_ops_dev(cig, (int)n_cig, (int)nb, nullptr);
+                K.sq[w] = (nb + 3) / 4; K.nb[w] = nb; K.lqn[w] = l_rn - 1;
+                w++;
+            }
+            kept++;
+        }
+        p += 4 + (uint64_t)bs;
+    }
+    if (!(flags & 1) && p != stop) flags |= 2;
+    if (!WRITE) { SegOut o; o.kept = kept; o.flags = flags; o.first_ref = first_ref; o.first_pos = first_pos; o.last_ref = last_ref; o.last_pos = last_pos;
+                  o.sq_sum = sq_sum; o.qn_sum = qn_sum; o.op_sum = op_sum; so[k] = o; }
+}
+
+__global__ void k_seg_kept(const SegOut *so, int64_t nseg, uint32_t *kept) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nseg) kept[k] = so[k].kept;
+}
+
+// ref_begin[r] = first kept record with reference >= r (the list is grouped by reference: the file is coordinate-sorted)
+__global__ void k_ref_bounds(const int32_t *ref, int64_t n, int n_ref, int64_t *ref_begin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_ref) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (ref[m] < r) lo = m + 1; else hi = m; }
+    ref_begin[r] = lo;
+}
+
+struct DevShard {               // device pointers of one reference's output arrays (caller-allocated)
+    int32_t *pos; uint32_t *cigar_off, *cigar, *seq_off; uint8_t *seq2, *qual; int32_t *aln; uint8_t *has_as; uint32_t *qname_off; char *qnames;
+};
+
+// value of the last AS tag among the aux fields [p, e); false when absent (same walk as aux_as in phz_bam.cpp)
+__device__ bool aux_as_dev(const uint8_t *p, const uint8_t *e, int32_t *out) {
+    bool found = false;
+    while (p + 3 <= e) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        p += 3;
+        uint64_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { const uint8_t *q = p; while (q < e && *q) q++; if (q >= e) return found; sz = (uint64_t)(q - p) + 1; break; }
+            case 'B': {
+                if (p + 5 > e) return found;
+                const uint8_t sub = p[0];
+                const uint32_t cnt = ld32(p + 1);
+                uint64_t es = 0;
+                switch (sub) { case 'c': case 'C': es = 1; break; case 's': case 'S': es = 2; break; case 'i': case 'I': case 'f': es = 4; break; default: return found; }
+                sz = 5 + es * (uint64_t)cnt;
+                break;
+            }
+            default: return found;
+        }
+        if (sz > (uint64_t)(e - p)) return found;
+        if (t0 == 'A' && t1 == 'S' && ty != 'A' && ty != 'f' && ty != 'Z' && ty != 'H' && ty != 'B') {
+            int32_t v = 0;
+            switch (ty) {
+                case 'c': v = (int8_t)p[0]; break;
+                case 'C': v = p[0]; break;
+                case 's': v = (int16_t)ld16(p); break;
+                case 'S': v = (int32_t)ld16(p); break;
+                case 'i': v = ldi32(p); break;
+                case 'I': v = (int32_t)ld32(p); break;
+            }
+            *out = v; found = true;
+        }
+        p += sz;
+    }
+    return found;
+}
+
+__constant__ int8_t c_code_of[16] = {-2, 0, 1, -2, 2, -2, -2, -2, 3, -2, -2, -2, -2, -1, -2, -1};   // =ACMGRSVTWYHKDBN
+
+__global__ __launch_bounds__(256) void k_pack(const uint8_t *d, KeptOut K, int64_t n_kept, const int64_t *ref_begin, const uint32_t *co,
+                                              const uint32_t *so, const uint32_t *qo, const DevShard *shards) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_kept) return;
+    const int ref = K.ref[i];
+    const int64_t b = ref_begin[ref], e = ref_begin[ref + 1];
+    const int64_t k = i - b;
+    const DevShard S = shards[ref];
+    const uint32_t c0 = co[i] - co[b], s0 = so[i] - so[b], q0 = qo[i] - qo[b];
+    const uint8_t *r = d + K.off[i];
+    const uint32_t l_rn = r[8], n_cig = ld16(r + 12);
+    const int32_t l_seq = ldi32(r + 16);
+    const int32_t bs = ldi32(r - 4);
+    const uint32_t nb = K.nb[i];
+    S.pos[k] = ldi32(r + 4) + 1;
+    S.cigar_off[k] = c0; S.seq_off[k] = s0; S.qname_off[k] = q0;
+    if (i + 1 == e) { S.cigar_off[k + 1] = co[e] - co[b]; S.seq_off[k + 1] = so[e] - so[b]; S.qname_off[k + 1] = qo[e] - qo[b]; }
+    for (uint32_t t = 0; t + 1 < l_rn; t++) S.qnames[q0 + t] = (char)r[32 + t];
+    const uint8_t *cig = r + 32 + l_rn;
+    norm_ops_dev(cig, (int)n_cig, (int)nb, S.cigar + c0);
+    const uint8_t *sq = cig + 4 * (uint64_t)n_cig;
+    const uint8_t *ql = sq + ((uint64_t)(l_seq > 0 ? l_seq : 0) + 1) / 2;
+    uint8_t *o2 = S.seq2 + s0;
+    uint8_t *oq = S.qual + (uint64_t)s0 * 4;
+    const uint32_t groups = (nb + 3) / 4;
+    if (l_seq <= 0) {                     // SEQ '*' QUAL '*': one IUPAC-other character with phred 9
+        o2[0] = 1; oq[0] = (uint8_t)(9 | 0x80); oq[1] = 0; oq[2] = 0; oq[3] = 0;
+    } else {
+        const bool noq = ql[0] == 0xFF;
+        for (uint32_t g = 0; g < groups; g++) {
+            uint32_t packed = 0;
+            for (uint32_t t = 0; t < 4; t++) {
+                const uint32_t j = g * 4 + t;
+                uint8_t q = 0;
+                if (j < nb) {
+                    const uint8_t nib = (j & 1) ? (sq[j >> 1] & 15) : (sq[j >> 1] >> 4);
+                    const int c = c_code_of[nib];
+                    q = noq ? 9 : (ql[j] > 127 ? 127 : ql[j]);
+                    uint32_t code2;
+                    if (c >= 0) code2 = (uint32_t)c; else { code2 = c == -1 ? 0u : 1u; q |= 0x80; }
+                    packed |= code2 << (2 * t);
+                }
+                oq[j] = q;
+            }
+            o2[g] = (uint8_t)packed;
+        }
+    }
+    int32_t as = 0;
+    const uint8_t *aux = ql + (l_seq > 0 ? l_seq : 0);
+    const bool has = aux_as_dev(aux, r + bs, &as);
+    S.aln[k] = has ? as : 0; S.has_as[k] = has ? 1 : 0;
+}
+
+}  // namespace
+
+struct phz_bamdev {
+    phz_ctx *ctx = nullptr;
+    std::vector<std::pair<std::string, int32_t>> refs;
+    void *d_stream = nullptr;           // inflated bytes of the needed members
+    void *d_work = nullptr;             // kept-record list + offsets (one allocation)
+    KeptOut K{};
+    int64_t n_kept = 0;
+    uint32_t *co = nullptr, *so = nullptr, *qo = nullptr;      // exclusive prefix sums over the kept list ([n_kept + 1] each)
+    int64_t *d_ref_begin = nullptr;
+    std::vector<int64_t> ref_begin;     // host copy [n_ref + 1]
+    std::vector<uint32_t> h_co, h_so, h_qo;     // values at the reference boundaries
+    std::string err;
+    ~phz_bamdev() { if (d_stream) (void)hipFree(d_stream); if (d_work) (void)hipFree(d_work); }
+};
+
+#define BD_HIP(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (call);                                                                           \
+        if (_e != hipSuccess) { phz_fail(ctx, PHZ_E_HIP, #call, _e); delete h; phz_bam_plan_release(&plan); return PHZ_E_HIP; } \
+    } while (0)
+
+extern "C" {
+
+int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names, int n_names, const phz_bam_filters *f, phz_bamdev **out) {
+    if (!ctx || !path || !f || !out) return PHZ_E_ARG;
+    *out = nullptr;
+    const bool timing = getenv("PHZ_TIMING") != nullptr;
+    PhzBamPlan plan;
+    if (int st = phz_bam_plan_file(path, ref_names, n_names, &plan)) { phz_bam_plan_release(&plan); return st; }
+    phz_bamdev *h = new phz_bamdev();
+    h->ctx = ctx;
+    h->refs = plan.refs;
+    const int n_ref = (int)plan.refs.size();
+    h->ref_begin.assign((size_t)n_ref + 1, 0);
+    h->h_co.assign((size_t)n_ref + 1, 0); h->h_so.assign((size_t)n_ref + 1, 0); h->h_qo.assign((size_t)n_ref + 1, 0);
+    if (plan.members.empty() || plan.pieces.empty()) { phz_bam_plan_release(&plan); *out = h; return PHZ_OK; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { delete h; phz_bam_plan_release(&plan); return PHZ_E_HIP; }
+    hipStream_t sm = ctx->stream;
+    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+    // ---- H2D of the compressed bytes: one contiguous file range per run of members; device member table with local offsets
+    std::vector<phz_bgzf_member> mem(plan.members.size());
+    uint64_t comp_bytes = 0, out_bytes = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> runs;          // file ranges [a, b)
+    std::vector<uint64_t> run_dev;                            // their offsets in the device buffer
+    {
+        uint64_t run_a = 0, run_b = 0;
+        for (size_t i = 0; i < plan.members.size(); i++) {
+            const auto &m = plan.members[i];
+            const uint64_t a = m.src, b = m.src + m.csize;
+            if (i == 0 || a > run_b + 65536) {
+                if (i) { runs.emplace_back(run_a, run_b); }
+                run_a = a; run_b = b;
+            } else run_b = b;
+        }
+        runs.emplace_back(run_a, run_b);
+        for (auto &r : runs) { run_dev.push_back(comp_bytes); comp_bytes += (r.second - r.first + 15) & ~(uint64_t)15; }
+    }
+    // inflated layout: members back to back in file order; dev offset of a global inflated offset u = u - dst(first member of its
+    // contiguous member run) + base of that run.  Members of one piece are contiguous in the file, so one base per piece suffices.
+    std::vector<uint64_t> mem_dev_dst(plan.members.size());
+    {
+        size_t ri = 0;
+        for (size_t i = 0; i < plan.members.size(); i++) {
+            const auto &m = plan.members[i];
+            while (ri + 1 < runs.size() && m.src >= runs[ri].second) ri++;
+            mem[i].src = run_dev[ri] + (m.src - runs[ri].first);
+            mem[i].csize = m.csize; mem[i].isize = m.isize; mem[i].dst = out_bytes;
+            mem_dev_dst[i] = out_bytes;
+            out_bytes += m.isize;
+        }
+    }
+    auto dev_of = [&](uint64_t u) -> uint64_t {                // global inflated offset -> device stream offset
+        size_t lo = 0, hi = plan.members.size();
+        while (lo < hi) { const size_t m = (lo + hi) >> 1; if (plan.members[m].dst + plan.members[m].isize <= u) lo = m + 1; else hi = m; }
+        if (lo >= plan.members.size()) return out_bytes;       // u == end of the last member
+        return mem_dev_dst[lo] + (u - plan.members[lo].dst);
+    };
+    void *d_comp = nullptr, *d_mem = nullptr;
+    BD_HIP(hipMalloc(&d_comp, comp_bytes + 64));
+    if (hipMalloc(&d_mem, mem.size() * sizeof(phz_bgzf_member)) != hipSuccess || hipMalloc(&h->d_stream, out_bytes + 64) != hipSuccess) {
+        (void)hipFree(d_comp); if (d_mem) (void)hipFree(d_mem);
+        delete h; phz_bam_plan_release(&plan); return phz_fail(ctx, PHZ_E_NOMEM, "device BAM buffers");
+    }
+    auto t_h2d0 = std::chrono::steady_clock::now();
+    for (size_t r = 0; r < runs.size(); r++)
+        (void)hipMemcpyAsync((char *)d_comp + run_dev[r], plan.file + runs[r].first, runs[r].second - runs[r].first, hipMemcpyHostToDevice, sm);
+    (void)hipMemcpyAsync(d_mem, mem.data(), mem.size() * sizeof(phz_bgzf_member), hipMemcpyHostToDevice, sm);
+    (void)hipStreamSynchronize(sm);
+    const double h2d_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count();
+    int bad = 0;
+    int st = phz_bgzf_inflate_device(ctx, (const uint8_t *)d_comp, (const phz_bgzf_member *)d_mem, (int64_t)mem.size(), (uint8_t *)h->d_stream, &bad);
+    (void)hipFree(d_comp); (void)hipFree(d_mem);
+    const float inflate_ms = ctx->last_ms[PHZ_T_INFLATE];
+    if (st != PHZ_OK || bad) { delete h; phz_bam_plan_release(&plan); return st != PHZ_OK ? st : PHZ_E_UNSUPPORTED; }
+    phz_bam_plan_release(&plan);
+    // ---- segments
+    const uint64_t SEG = 256u << 10;
+    std::vector<Seg> segs;
+    for (size_t pi = 0; pi < plan.pieces.size(); pi++) {
+        const uint64_t a = dev_of(plan.pieces[pi].first), b = a + (plan.pieces[pi].second - plan.pieces[pi].first);
+        for (uint64_t g = a; g < b; g += SEG) segs.push_back({g, b, g == a ? 1u : 0u, (uint32_t)pi});
+    }
+    const int64_t nseg = (int64_t)segs.size();
+    if (nseg == 0) { *out = h; return PHZ_OK; }
+    void *d_seg = nullptr;
+    const size_t seg_bytes = ((size_t)nseg * sizeof(Seg) + 255) & ~(size_t)255, start_bytes = ((size_t)(nseg + 1) * 8 + 255) & ~(size_t)255,
+                 so_bytes = ((size_t)nseg * sizeof(SegOut) + 255) & ~(size_t)255, kept_bytes = ((size_t)(nseg + 2) * 4 + 255) & ~(size_t)255;
+    const size_t mask_bytes = ((size_t)n_ref + 255) & ~(size_t)255;
+    if (hipMalloc(&d_seg, seg_bytes + start_bytes + so_bytes + 2 * kept_bytes + mask_bytes) != hipSuccess) { delete h; return phz_fail(ctx, PHZ_E_NOMEM, "device BAM segments"); }
+    Seg *dsegs = (Seg *)d_seg;
+    uint64_t *dstart = (uint64_t *)((char *)d_seg + seg_bytes);
+    SegOut *dso = (SegOut *)((char *)dstart + start_bytes);
+    uint32_t *dkept = (uint32_t *)((char *)dso + so_bytes), *dkbase = (uint32_t *)((char *)dkept + kept_bytes);
+    uint8_t *dmask = (uint8_t *)((char *)dkbase + kept_bytes);
+    std::vector<uint8_t> mask((size_t)n_ref, ref_names ? 0 : 1);
+    if (ref_names) for (int i = 0; i < n_ref; i++) for (int k = 0; k < n_names; k++) if (h->refs[(size_t)i].first == ref_names[k]) mask[(size_t)i] = 1;
+    auto fail = [&](int code, const char *what) { (void)hipFree(d_seg); if (what) ctx->err = what; delete h; return code; };
+    if (hipMemcpyAsync(dsegs, segs.data(), (size_t)nseg * sizeof(Seg), hipMemcpyHostToDevice, sm) != hipSuccess ||
+        hipMemcpyAsync(dmask, mask.data(), (size_t)n_ref, hipMemcpyHostToDevice, sm) != hipSuccess) return fail(PHZ_E_HIP, "hipMemcpyAsync");
+    Filters F; F.min_mapq = f->min_mapq; F.flag_required = f->flag_required; F.flag_forbidden = f->flag_forbidden; F.isize_cutoff = f->isize_cutoff;
+    F.ref_mask = dmask; F.n_ref = n_ref;
+    const uint8_t *d = (const uint8_t *)h->d_stream;
+    (void)hipEventRecord(e0, sm);
+    const unsigned gseg = (unsigned)((nseg + 63) / 64);
+    hipLaunchKernelGGL(k_seg_start, dim3(gseg), dim3(64), 0, sm, d, (const Seg *)dsegs, nseg, n_ref, dstart);
+    KeptOut none{};
+    hipLaunchKernelGGL(k_hop<0>, dim3(gseg), dim3(64), 0, sm, d, (const Seg *)dsegs, nseg, (const uint64_t *)dstart, F, dso, (const uint32_t *)nullptr, none);
+    hipLaunchKernelGGL(k_seg_kept, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, sm, (const SegOut *)dso, nseg, dkept);
+    if (int s2 = scan_excl(ctx, dkept, dkbase, nseg, ctx->scratch[6])) return fail(s2, nullptr);
+    std::vector<SegOut> hso((size_t)nseg);
+    uint32_t total_kept = 0;
+    if (hipMemcpyAsync(hso.data(), dso, (size_t)nseg * sizeof(SegOut), hipMemcpyDeviceToHost, sm) != hipSuccess ||
+        hipMemcpyAsync(&total_kept, dkbase + nseg, 4, hipMemcpyDeviceToHost, sm) != hipSuccess || hipStreamSynchronize(sm) != hipSuccess)
+        return fail(PHZ_E_HIP, "segment read-back");
+    {   // every guessed boundary verified, chain intact, records sorted (inside segments and across them)
+        int32_t lr = -2, lp = 0;
+        uint64_t sum = 0, sq = 0, qn = 0, ops = 0;
+        for (int64_t k = 0; k < nseg; k++) {
+            const SegOut &o = hso[(size_t)k];
+            if (o.flags & 1) return fail(PHZ_E_ARG, "truncated or corrupt BAM record");
+            if (o.flags & 2) return fail(PHZ_E_UNSUPPORTED, "record boundary guess did not verify");
+            if (o.flags & 4) return fail(PHZ_E_UNSUPPORTED, "BAM is not coordinate-sorted");
+            if (o.first_ref != -2) {
+                if (lr != -2 && (o.first_ref < lr || (o.first_ref == lr && o.first_pos < lp))) return fail(PHZ_E_UNSUPPORTED, "BAM is not coordinate-sorted");
+                lr = o.last_ref; lp = o.last_pos;
+            }
+            sum += o.kept; sq += o.sq_sum; qn += o.qn_sum; ops += o.op_sum;
+        }
+        if (sum >= (1ull << 31) || sq >= (1ull << 32) - 16 || qn >= (1ull << 32) - 16 || ops >= (1ull << 32) - 16)
+            return fail(PHZ_E_UNSUPPORTED, "call exceeds the 32-bit offsets of the device path");
+    }
+    const int64_t nk = (int64_t)total_kept;
+    h->n_kept = nk;
+    // ---- kept-record list + prefix sums
+    const size_t NK = (size_t)(nk ? nk : 1);
+    const size_t a8 = (NK * 8 + 255) & ~(size_t)255, a4 = ((NK + 1) * 4 + 255) & ~(size_t)255, rb = ((size_t)(n_ref + 2) * 8 + 255) & ~(size_t)255;
+    if (hipMalloc(&h->d_work, a8 + 8 * a4 + rb) != hipSuccess) return fail(PHZ_E_NOMEM, "device BAM record list");
+    char *w = (char *)h->d_work;
+    h->K.off = (uint64_t *)w; w += a8;
+    h->K.ref = (int32_t *)w; w += a4;
+    h->K.nops = (uint32_t *)w; w += a4; h->K.sq = (uint32_t *)w; w += a4; h->K.nb = (uint32_t *)w; w += a4; h->K.lqn = (uint32_t *)w; w += a4;
+    h->co = (uint32_t *)w; w += a4; h->so = (uint32_t *)w; w += a4; h->qo = (uint32_t *)w; w += a4;
+    h->d_ref_begin = (int64_t *)w;
+    if (nk > 0) {
+        hipLaunchKernelGGL(k_hop<1>, dim3(gseg), dim3(64), 0, sm, d, (const Seg *)dsegs, nseg, (const uint64_t *)dstart, F, dso, (const uint32_t *)dkbase, h->K);
+        if (int s2 = scan_excl(ctx, h->K.nops, h->co, nk, ctx->scratch[6])) return fail(s2, nullptr);
+        if (int s2 = scan_excl(ctx, h->K.sq, h->so, nk, ctx->scratch[6])) return fail(s2, nullptr);
+        if (int s2 = scan_excl(ctx, h->K.lqn, h->qo, nk, ctx->scratch[6])) return fail(s2, nullptr);
+    } else {
+        (void)hipMemsetAsync(h->co, 0, 4, sm); (void)hipMemsetAsync(h->so, 0, 4, sm); (void)hipMemsetAsync(h->qo, 0, 4, sm);
+    }
+    hipLaunchKernelGGL(k_ref_bounds, dim3((unsigned)((n_ref + 1 + 63) / 64)), dim3(64), 0, sm, (const int32_t *)h->K.ref, nk, n_ref, h->d_ref_begin);
+    (void)hipEventRecord(e1, sm);
+    if (hipMemcpyAsync(h->ref_begin.data(), h->d_ref_begin, (size_t)(n_ref + 1) * 8, hipMemcpyDeviceToHost, sm) != hipSuccess || hipStreamSynchronize(sm) != hipSuccess)
+        return fail(PHZ_E_HIP, "reference bounds read-back");
+    // totals must fit the 32-bit offsets of the scans: 64-bit sums of the per-segment kept counts are fine, the byte sums are
+    // checked through the per-reference values (a wrapped scan makes a reference's span negative or absurd)
+    for (int r = 0; r <= n_ref; r++) {
+        const int64_t i = h->ref_begin[(size_t)r];
+        (void)hipMemcpyAsync(&h->h_co[(size_t)r], h->co + i, 4, hipMemcpyDeviceToHost, sm);
+        (void)hipMemcpyAsync(&h->h_so[(size_t)r], h->so + i, 4, hipMemcpyDeviceToHost, sm);
+        (void)hipMemcpyAsync(&h->h_qo[(size_t)r], h->qo + i, 4, hipMemcpyDeviceToHost, sm);
+    }
+    if (hipStreamSynchronize(sm) != hipSuccess) return fail(PHZ_E_HIP, "offset read-back");
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ctx->last_ms[PHZ_T_BAMPACK] = ms; ctx->total_ms[PHZ_T_BAMPACK] += ms; ctx->launches[PHZ_T_BAMPACK]++;
+    (void)hipFree(d_seg);
+    if (timing)
+        fprintf(stderr, "[phz timing]     bam device: H2D %.1f MB %.1f ms, K_inflate %.1f ms (%.1f MB), boundaries + hop + scans %.1f ms, %lld of the records kept\n",
+                comp_bytes / 1e6, h2d_ms, inflate_ms, out_bytes / 1e6, ms, (long long)nk);
+    *out = h;
+    return PHZ_OK;
+}
+
+int phz_bamdev_close(phz_bamdev *h) { delete h; return PHZ_OK; }
+int phz_bamdev_n_ref(const phz_bamdev *h) { return (int)h->refs.size(); }
+const char *phz_bamdev_ref_name(const phz_bamdev *h, int i) { return (i < 0 || (size_t)i >= h->refs.size()) ? nullptr : h->refs[(size_t)i].first.c_str(); }
+int64_t phz_bamdev_ref_length(const phz_bamdev *h, int i) { return (i < 0 || (size_t)i >= h->refs.size()) ? -1 : (int64_t)h->refs[(size_t)i].second; }
+
+int phz_bamdev_sizes_of(const phz_bamdev *h, int ref, phz_bamdev_sizes *out) {
+    if (!h || !out || ref < 0 || (size_t)ref >= h->refs.size()) return PHZ_E_ARG;
+    const size_t r = (size_t)ref;
+    out->n_reads = h->ref_begin[r + 1] - h->ref_begin[r];
+    out->n_ops = (int64_t)(uint32_t)(h->h_co[r + 1] - h->h_co[r]);
+    out->n_seq_bytes = (int64_t)(uint32_t)(h->h_so[r + 1] - h->h_so[r]);
+    out->n_qname_bytes = (int64_t)(uint32_t)(h->h_qo[r + 1] - h->h_qo[r]);
+    return PHZ_OK;
+}
+
+// Fill the caller's (device) arrays of every reference: dst[r] is used for reference r when it holds records, ignored otherwise.
+int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst) {
+    if (!h || !dst || n_dst != (int)h->refs.size()) return PHZ_E_ARG;
+    phz_ctx *ctx = h->ctx;
+    if (h->n_kept == 0) return PHZ_OK;
+    static_assert(sizeof(phz_dev_shard) == sizeof(DevShard), "shard pointer table layout");
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t sm = ctx->stream;
+    if (int s = phz_reserve(ctx, ctx->shard_tab, (size_t)n_dst * sizeof(DevShard))) return s;
+    PHZ_HIP(ctx, hipMemcpyAsync(ctx->shard_tab.p, dst, (size_t)n_dst * sizeof(DevShard), hipMemcpyHostToDevice, sm));
+    PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((h->n_kept + 255) / 256)), dim3(256), 0, sm, (const uint8_t *)h->d_stream, h->K, h->n_kept,
+                       (const int64_t *)h->d_ref_begin, (const uint32_t *)h->co, (const uint32_t *)h->so, (const uint32_t *)h->qo,
+                       (const DevShard *)ctx->shard_tab.p);
+    PHZ_HIP(ctx, hipGetLastError());
+    PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    float ms = 0;
+    PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->last_ms[PHZ_T_BAMPACK] = ms; ctx->total_ms[PHZ_T_BAMPACK] += ms; ctx->launches[PHZ_T_BAMPACK]++;
+    if (getenv("PHZ_TIMING")) fprintf(stderr, "[phz timing]     bam device: k_pack %.1f ms for %lld records\n", ms, (long long)h->n_kept);
+    return PHZ_OK;
+}
+
+}  // extern "C"

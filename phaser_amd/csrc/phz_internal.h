@@ -101,3 +101,18 @@ struct Staging {
         return PHZ_OK;
     }
 };
+
+// ---- plan of a (chromosome-restricted) BAM read, shared by the host decode and the device decode (phz_bam.cpp)
+struct PhzBamPlan {
+    std::vector<std::pair<std::string, int32_t>> refs;
+    std::vector<uint8_t> head;                             // inflated bytes from the file start; the header ends at first_record
+    size_t first_record = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> pieces;     // [u0, u1) of the inflated stream (global offsets), cut at record boundaries
+    struct Mem { uint64_t src; uint32_t csize, isize; uint64_t dst; };
+    std::vector<Mem> members;                              // members that overlap a piece, file order; dst = global inflated offset
+    const uint8_t *file = nullptr; size_t file_size = 0;   // the mapped file (valid until phz_bam_plan_release)
+    void *owner = nullptr;
+};
+int phz_bam_plan_file(const char *path, const char *const *ref_names, int n_names, PhzBamPlan *out);
+void phz_bam_plan_release(PhzBamPlan *p);
+

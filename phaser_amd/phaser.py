@@ -225,9 +225,16 @@ def main(argv=None):
             shards = samio.shards_from_sam(open(bam).read(), interners, isz)
         elif any_sam:
             shards = bamio.shards_from_bam(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine)
-        else:   # native BGZF inflate + packer + QNAME interning (phz_bam_*), --threads host threads
-            shards = bamio.shards_from_bam_native(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
-                                                  threads=max(0, args.threads if args.threads > 1 else 0))
+        else:
+            # BGZF inflate + record decode + filters + packing on the GPU (phz_bamdev_*); files it declines, and PHZ_BAM_HOST=1, go
+            # through the host decoder (phz_bam_*, --threads host threads).  QNAME interning is host-side in both.
+            shards = None
+            if os.environ.get("PHZ_BAM_HOST") != "1":
+                shards = bamio.shards_from_bam_device(eng.ctx, bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
+                                                      device=device)
+            if shards is None:
+                shards = bamio.shards_from_bam_native(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
+                                                      threads=max(0, args.threads if args.threads > 1 else 0))
         mark("bam decode + filters + qname interning")
         items = []
         for chrom in vs.chroms:

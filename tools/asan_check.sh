@@ -3,7 +3,7 @@
 # tests that exercise them against that build (PHZ_LIB_PATH).  Last run (round 2, incl. the BAM corruption test): see the commit log.
 set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
-g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -shared -fPIC -I$R/include -I$R/phaser_amd/csrc \
+g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$R/include -I$R/phaser_amd/csrc \
     $R/phaser_amd/csrc/phz_vcf.cpp $R/phaser_amd/csrc/phz_vcfout.cpp $R/phaser_amd/csrc/phz_genes.cpp $R/phaser_amd/csrc/phz_rows.cpp \
     $R/phaser_amd/csrc/phz_bam.cpp -o /tmp/libphz_asan.so -lz -lpthread
 cd $R
