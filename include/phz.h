@@ -236,6 +236,11 @@ const char *phz_bamdev_ref_name(const phz_bamdev *h, int i);
 int64_t phz_bamdev_ref_length(const phz_bamdev *h, int i);
 int phz_bamdev_sizes_of(const phz_bamdev *h, int ref, phz_bamdev_sizes *out);
 int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst);      /* dst[r] for reference r; entries of empty references are ignored */
+/* QNAME ids of a device-resident shard in first-appearance order (= what phz_intern assigns when none of these names is in the
+ * interner yet and it holds `base` names): qid[n]; first_idx[0, *n_new) = record of the first occurrence of every new name, in id
+ * order.  All pointers device, n_new host. */
+int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, int64_t n, int32_t base, int32_t *qid, int32_t *first_idx,
+                      int64_t *n_new);
 
 /* ---- host side of the path's input: native BGZF/BAM decode, SoA packing, QNAME interning -------------------
  * Replaces `samtools view -h BAM 'chr': | samtools view -Sh [-F 0x400] [-f 2] -q MAPQ -` (phaser/phaser.py:1346)

@@ -204,7 +204,11 @@ def readbatch_to_bam_native(path: str, rbs, refs: List[Tuple[str, int]], threads
 
 # ----------------------------------------------------------------------------------------- native reader (libphz.so)
 class NativeInterner:
-    """QNAME -> id map held in C++ (phz_interner); same first-appearance numbering as samio.QnameInterner."""
+    """QNAME -> id map held in C++ (phz_interner); same first-appearance numbering as samio.QnameInterner.
+
+    A shard whose ids were assigned on the GPU (phz_intern_device, first BAM of a chromosome) leaves its distinct names DEFERRED:
+    the device arrays are kept, the C++ table is only filled when something needs it (a later BAM's names, --output_read_ids) --
+    a single-BAM run never pays for the host-side hashing."""
 
     def __init__(self):
         import ctypes as C
@@ -212,20 +216,56 @@ class NativeInterner:
         self.lib = _lib.load()
         h = C.c_void_p()
         self.lib.phz_interner_create(C.byref(h))
-        self.h = h
+        self._h = h
+        self._deferred = None          # (qnames uint8 [cuda], qname_off int32 [cuda], first_idx int32 [cuda], n_new)
+
+    def defer(self, qnames, qname_off, first_idx, n_new: int):
+        assert self._deferred is None and int(self.lib.phz_interner_size(self._h)) == 0
+        self._deferred = (qnames, qname_off, first_idx, int(n_new))
+
+    def _materialize(self):
+        if self._deferred is None:
+            return
+        import ctypes as C
+        qn, qo, first, n_new = self._deferred
+        self._deferred = None
+        if n_new == 0:
+            return
+        idx = first[:n_new].long()
+        a = qo.long()[idx]; b = qo.long()[idx + 1]
+        ln = (b - a)
+        off = torch.zeros(n_new + 1, dtype=torch.int64, device=qn.device)
+        off[1:] = torch.cumsum(ln, 0)
+        total = int(off[-1])
+        # bytes of the distinct names in id order: position p of the compact blob belongs to name r = upper bound of p in off
+        pos = torch.arange(total, device=qn.device)
+        r = torch.searchsorted(off, pos, right=True) - 1
+        blob = qn[(a[r] + (pos - off[r]))].cpu().numpy()
+        off32 = off.to(torch.int32).cpu().numpy().astype(np.uint32)
+        ids = np.zeros(n_new, dtype=np.int32)
+        self.lib.phz_intern(self._h, C.c_void_p(blob.ctypes.data), C.c_void_p(off32.ctypes.data), n_new, C.c_void_p(ids.ctypes.data))
+        assert int(ids[-1]) == n_new - 1 and int(self.lib.phz_interner_size(self._h)) == n_new
+
+    @property
+    def h(self):
+        self._materialize()
+        return self._h
 
     def __len__(self):
-        return int(self.lib.phz_interner_size(self.h))
+        if self._deferred is not None:
+            return self._deferred[3]
+        return int(self.lib.phz_interner_size(self._h))
 
     @property
     def names(self) -> List[str]:
         import ctypes as C
+        h = self.h
         n = len(self)
         off = np.zeros(n + 1, dtype=np.uint32)
         cap = 1 << 20
         while True:
             blob = np.zeros(cap, dtype=np.uint8)
-            st = self.lib.phz_interner_names(self.h, C.c_void_p(blob.ctypes.data), cap, C.c_void_p(off.ctypes.data))
+            st = self.lib.phz_interner_names(h, C.c_void_p(blob.ctypes.data), cap, C.c_void_p(off.ctypes.data))
             if st == 0:
                 break
             cap = int(off[n]) + 16
@@ -234,7 +274,7 @@ class NativeInterner:
 
     def __del__(self):
         try:
-            self.lib.phz_interner_destroy(self.h)
+            self.lib.phz_interner_destroy(self._h)
         except Exception:
             pass
 
@@ -362,16 +402,25 @@ def shards_from_bam_device(ctx, path: str, interners: Dict[str, "NativeInterner"
         sh = soa.ReadShard(t["pos"][:n], t["cigar_off"][:n + 1], t["cigar"][:int(sz.n_ops)], t["seq_off"][:n + 1], t["seq2"][:int(sz.n_seq_bytes)],
                            t["qual"][:int(sz.n_seq_bytes) * 4])
         it = interners.setdefault(chrom, NativeInterner())
-        qn = t["qnames"][:int(sz.n_qname_bytes)].cpu().numpy(); qo = t["qname_off"][:n + 1].cpu().numpy()
-        qid = np.zeros(n, dtype=np.int32)
         ti = _t.perf_counter()
-        lib.phz_intern(it.h, C.c_void_p(qn.ctypes.data), C.c_void_p(qo.ctypes.data), n, C.c_void_p(qid.ctypes.data))
+        if len(it) == 0:
+            # first BAM of the chromosome: ids on the device, the names stay there until something asks for them
+            qid_d = torch.empty(n, dtype=torch.int32, device=dev); first_d = torch.empty(n, dtype=torch.int32, device=dev)
+            nn = C.c_int64(0)
+            ctx.check(lib.phz_intern_device(ctx.h, C.c_void_p(t["qnames"].data_ptr()), C.c_void_p(t["qname_off"].data_ptr()), n, 0,
+                                            C.c_void_p(qid_d.data_ptr()), C.c_void_p(first_d.data_ptr()), C.byref(nn)))
+            it.defer(t["qnames"][:int(sz.n_qname_bytes)], t["qname_off"][:n + 1], first_d, nn.value)
+            sh.qid = qid_d
+        else:
+            qn = t["qnames"][:int(sz.n_qname_bytes)].cpu().numpy(); qo = t["qname_off"][:n + 1].cpu().numpy()
+            qid = np.zeros(n, dtype=np.int32)
+            lib.phz_intern(it.h, C.c_void_p(qn.ctypes.data), C.c_void_p(qo.ctypes.data), n, C.c_void_p(qid.ctypes.data))
+            sh.qid = torch.from_numpy(qid).to(dev)
         tin += _t.perf_counter() - ti
-        sh.qid = torch.from_numpy(qid).to(dev)
         sh.aln_score = t["aln_score"][:n]; sh.has_as = t["has_as"][:n]
         out[chrom] = sh
     if _prof:
-        _sys.stderr.write("[phz timing]   bam (device): plan + H2D + inflate + hop %.2f s, allocate + pack %.2f s, names D2H + qid H2D %.2f s, qname interning %.2f s\n"
+        _sys.stderr.write("[phz timing]   bam (device): plan + H2D + inflate + hop %.2f s, allocate + pack %.2f s, other %.2f s, qname ids %.2f s\n"
                           % (t1 - t0, t2 - t1, _t.perf_counter() - t2 - tin, tin))
     return out
 

@@ -292,6 +292,50 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t *d, KeptOut K, int64
     S.aln[k] = has ? as : 0; S.has_as[k] = has ? 1 : 0;
 }
 
+// ---- QNAME interning on the device: ids in first-appearance order (what a sequential dictionary would hand out; mates and
+// repeated templates share an id).  Open-addressing table of record indices keyed by a 64-bit hash of the name, equality decided
+// by comparing the name bytes; a slot belongs to one name for good, its value converges to the smallest record index of that name.
+__device__ __forceinline__ uint64_t name_hash(const char *p, uint32_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint32_t i = 0; i < n; i++) { h ^= (uint8_t)p[i]; h *= 0x100000001b3ull; }
+    h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+    return h;
+}
+__device__ __forceinline__ bool name_eq(const char *blob, const uint32_t *off, uint32_t a, uint32_t b) {
+    const uint32_t la = off[a + 1] - off[a], lb = off[b + 1] - off[b];
+    if (la != lb) return false;
+    const char *pa = blob + off[a], *pb = blob + off[b];
+    for (uint32_t i = 0; i < la; i++) if (pa[i] != pb[i]) return false;
+    return true;
+}
+__global__ __launch_bounds__(256) void k_intern_insert(const char *blob, const uint32_t *off, int64_t n, uint32_t *table, uint32_t mask, uint32_t *slot_of) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = (uint32_t)name_hash(blob + off[i], off[i + 1] - off[i]) & mask;
+    for (;;) {
+        uint32_t cur = table[s];
+        if (cur == 0xFFFFFFFFu) {
+            cur = atomicCAS(&table[s], 0xFFFFFFFFu, (uint32_t)i);
+            if (cur == 0xFFFFFFFFu) break;                       // claimed for this name
+        }
+        if (cur == (uint32_t)i || name_eq(blob, off, cur, (uint32_t)i)) { atomicMin(&table[s], (uint32_t)i); break; }
+        s = (s + 1) & mask;
+    }
+    slot_of[i] = s;
+}
+__global__ __launch_bounds__(256) void k_intern_first(const uint32_t *table, const uint32_t *slot_of, int64_t n, uint32_t *first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) first[i] = table[slot_of[i]] == (uint32_t)i ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_intern_assign(const uint32_t *table, const uint32_t *slot_of, const uint32_t *first, const uint32_t *rank, int64_t n,
+                                                       int32_t base, int32_t *qid, int32_t *first_idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t rep = table[slot_of[i]];
+    qid[i] = base + (int32_t)rank[rep];
+    if (first[i]) first_idx[rank[i]] = (int32_t)i;
+}
+
 }  // namespace
 
 struct phz_bamdev {
@@ -525,6 +569,40 @@ int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst) {
     PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->last_ms[PHZ_T_BAMPACK] = ms; ctx->total_ms[PHZ_T_BAMPACK] += ms; ctx->launches[PHZ_T_BAMPACK]++;
     if (getenv("PHZ_TIMING")) fprintf(stderr, "[phz timing]     bam device: k_pack %.1f ms for %lld records\n", ms, (long long)h->n_kept);
+    return PHZ_OK;
+}
+
+// QNAME ids of one shard on the device: qid[i] = base + (number of distinct names that first appear before record i's name does), the
+// ids phz_intern hands out for an interner that holds `base` names none of which occurs here (the caller guarantees that: it uses
+// this for the first BAM of a chromosome).  first_idx[0, *n_new) = record index of the first occurrence of every new name, in id order.
+int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, int64_t n, int32_t base, int32_t *qid, int32_t *first_idx,
+                      int64_t *n_new) {
+    if (!ctx || !n_new || n < 0 || (n > 0 && (!qnames || !qname_off || !qid || !first_idx))) return PHZ_E_ARG;
+    *n_new = 0;
+    if (n == 0) return PHZ_OK;
+    if (n >= (1ll << 31) - 16) return PHZ_E_UNSUPPORTED;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t sm = ctx->stream;
+    uint64_t cap = 1024;
+    while (cap < 2 * (uint64_t)n) cap <<= 1;
+    DevBuf *S = ctx->scratch;
+    if (int s = phz_reserve(ctx, S[7], cap * 4)) return s;
+    if (int s = phz_reserve(ctx, S[8], (size_t)n * 4)) return s;
+    if (int s = phz_reserve(ctx, S[9], (size_t)n * 4)) return s;
+    if (int s = phz_reserve(ctx, S[10], ((size_t)n + 1) * 4)) return s;
+    uint32_t *table = (uint32_t *)S[7].p, *slot_of = (uint32_t *)S[8].p, *first = (uint32_t *)S[9].p, *rank = (uint32_t *)S[10].p;
+    PHZ_HIP(ctx, hipMemsetAsync(table, 0xff, cap * 4, sm));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_intern_insert, dim3(grid), dim3(256), 0, sm, qnames, qname_off, n, table, (uint32_t)(cap - 1), slot_of);
+    hipLaunchKernelGGL(k_intern_first, dim3(grid), dim3(256), 0, sm, (const uint32_t *)table, (const uint32_t *)slot_of, n, first);
+    if (int s = scan_excl(ctx, first, rank, n, S[6])) return s;
+    hipLaunchKernelGGL(k_intern_assign, dim3(grid), dim3(256), 0, sm, (const uint32_t *)table, (const uint32_t *)slot_of, (const uint32_t *)first,
+                       (const uint32_t *)rank, n, base, qid, first_idx);
+    PHZ_HIP(ctx, hipGetLastError());
+    uint32_t total = 0;
+    PHZ_HIP(ctx, hipMemcpyAsync(&total, rank + n, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    *n_new = (int64_t)total;
     return PHZ_OK;
 }
 

@@ -182,3 +182,28 @@ def test_device_path_refuses_what_it_cannot_prove(ctx, tmp_path):
     assert bamio.shards_from_bam_device(ctx, path, {}, 0, False, False) is None
     with pytest.raises(_lib.PhzError):
         bamio.shards_from_bam_native(path, {}, 0, False, False)
+
+
+def test_device_interning_then_a_second_bam(ctx, tmp_path):
+    """First BAM of a chromosome: ids assigned on the GPU, names deferred; a second BAM (shared and new QNAMEs) materialises the
+    interner and continues the numbering exactly as the all-host path does."""
+    import torch
+    from phaser_amd import bamio, synth
+    path1 = _two_chrom_bam(tmp_path)
+    v, gs, ge, w = synth.make_variants("chr22", 1, 2_000_000, 120, 79, n_genes=8)
+    rb_same = synth.make_reads(v, gs, ge, w, 3000, 80)          # same seed: QNAMEs of the first BAM again
+    rb_new = synth.make_reads(v, gs, ge, w, 2000, 81, qname_prefix="other.") if "qname_prefix" in synth.make_reads.__code__.co_varnames else synth.make_reads(v, gs, ge, w, 2000, 81)
+    path2 = str(tmp_path / "second.bam")
+    bamio.readbatch_to_bam_native(path2, [rb_same], [("chr21", 46709983), ("chr22", 50818468), ("chrEmpty", 1000)])
+    path3 = str(tmp_path / "third.bam")
+    bamio.readbatch_to_bam_native(path3, [rb_new], [("chr21", 46709983), ("chr22", 50818468), ("chrEmpty", 1000)])
+    hi = {}; di = {}
+    for p in (path1, path2, path3):
+        host = bamio.shards_from_bam_native(p, hi, 0, False, False, threads=2)
+        dev = bamio.shards_from_bam_device(ctx, p, di, 0, False, False)
+        assert dev is not None
+        _same(host, dev, p)
+        for c in hi:
+            assert len(hi[c]) == len(di[c]), (p, c)
+    for c in hi:
+        assert hi[c].names == di[c].names
