@@ -288,8 +288,10 @@ size_t plausible_at(const uint8_t *d, size_t n, size_t p, int n_ref) {
     if (bs < 32 || bs > (1 << 24) || p + 4 + (size_t)bs > n) return 0;
     const uint8_t *r = d + p + 4;
     const int32_t ref = rdi32(r), pos0 = rdi32(r + 4), l_seq = rdi32(r + 16), nref = rdi32(r + 20);
-    const uint32_t l_rn = r[8], n_cig = rd16(r + 12);
-    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 1) return 0;
+    const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14);
+    // a QNAME has at least one character (SAM: [!-?A-~]{1,254}; an empty name would make every zero byte a candidate), FLAG has 12
+    // defined bits, mate position >= -1
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 2 || flag >= 4096 || rdi32(r + 24) < -1) return 0;
     const size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
     if (need > (size_t)bs) return 0;
     if (r[32 + l_rn - 1] != 0) return 0;                 // read name is NUL-terminated
@@ -643,8 +645,8 @@ int phz_bam_decode(phz_bam *h, const uint8_t *ref_mask, int min_mapq, int flag_r
         if (bs < 32 || bs > (1 << 24) || p + 4 + (size_t)bs > n) return 0;
         const uint8_t *r = d + p + 4;
         const int32_t ref = rdi32(r), pos0 = rdi32(r + 4), l_seq = rdi32(r + 16), nref = rdi32(r + 20);
-        const uint32_t l_rn = r[8], n_cig = rd16(r + 12);
-        if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 1) return 0;
+        const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14);
+        if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 2 || flag >= 4096 || rdi32(r + 24) < -1) return 0;
         const size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
         if (need > (size_t)bs) return 0;
         if (r[32 + l_rn - 1] != 0) return 0;                 // read name is NUL-terminated

@@ -43,18 +43,21 @@ struct Filters {
 };
 
 // can offset p of d[0, n) start a record?  -> offset of the next record, 0 when it cannot (same test as the host's plausible_at)
-__device__ uint64_t plausible(const uint8_t *d, uint64_t n, uint64_t p, int n_ref) {
+__device__ uint64_t plausible(const uint8_t *d, uint64_t n, uint64_t p, int n_ref, uint64_t *key) {
     if (p + 36 > n) return 0;
     const int32_t bs = ldi32(d + p);
     if (bs < 32 || bs > (1 << 24) || p + 4 + (uint64_t)bs > n) return 0;
     const uint8_t *r = d + p + 4;
     const int32_t ref = ldi32(r), pos0 = ldi32(r + 4), l_seq = ldi32(r + 16), nref = ldi32(r + 20);
-    const uint32_t l_rn = r[8], n_cig = ld16(r + 12);
-    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 1) return 0;
+    const uint32_t l_rn = r[8], n_cig = ld16(r + 12), flag = ld16(r + 14);
+    // a QNAME has at least one character (SAM: [!-?A-~]{1,254}; an empty name would make every zero byte a candidate), FLAG has 12
+    // defined bits, mate position >= -1
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos0 < -1 || l_seq < 0 || l_rn < 2 || flag >= 4096 || ldi32(r + 24) < -1) return 0;
     const uint64_t need = 32 + (uint64_t)l_rn + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
     if (need > (uint64_t)bs) return 0;
     if (r[32 + l_rn - 1] != 0) return 0;
     for (uint32_t k = 0; k + 1 < l_rn; k++) if (r[32 + k] < 33 || r[32 + k] > 126) return 0;
+    *key = ((uint64_t)(ref < 0 ? 0x7fffffff : ref) << 32) | (uint32_t)(pos0 + 1);      // coordinate-sort key (unmapped last)
     return p + 4 + (uint64_t)bs;
 }
 
@@ -66,10 +69,12 @@ __global__ __launch_bounds__(64) void k_seg_start(const uint8_t *d, const Seg *s
     const uint64_t limit = s.guess + (32u << 20) < s.end ? s.guess + (32u << 20) : s.end;
     uint64_t found = s.end;
     for (uint64_t p = s.guess; p < limit; p++) {
-        uint64_t q = p; int ok = 0;
+        uint64_t q = p, prev_key = 0; int ok = 0;
         while (ok < 12) {
-            const uint64_t nx = plausible(d, s.end, q, n_ref);
-            if (!nx) break;
+            uint64_t key;
+            const uint64_t nx = plausible(d, s.end, q, n_ref, &key);
+            if (!nx || key < prev_key) break;              // the records of a chain are in coordinate order, too
+            prev_key = key;
             ok++; q = nx;
             if (q + 4 > s.end) { ok = 12; break; }
         }
@@ -117,6 +122,7 @@ struct SegOut {                 // per segment, written by the counting hop
     uint32_t kept;
     uint32_t flags;             // 1 corrupt chain, 2 boundary mismatch, 4 unsorted inside the segment
     int32_t first_ref, first_pos, last_ref, last_pos;      // of the kept records (first_ref = -2 when none)
+    uint64_t end_pos;                                      // where the chain arrived (>= the segment's stop)
     uint64_t sq_sum, qn_sum, op_sum;                       // 64-bit sums of base groups, name bytes and 2 x CIGAR ops (upper bound of the
                                                            // normalised op count) over the kept records: the scans below are 32-bit
 };
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(64) void k_hop(const uint8_t *d, const Seg *segs, i
     }
     if (!(flags & 1) && p != stop) flags |= 2;
     if (!WRITE) { SegOut o; o.kept = kept; o.flags = flags; o.first_ref = first_ref; o.first_pos = first_pos; o.last_ref = last_ref; o.last_pos = last_pos;
-                  o.sq_sum = sq_sum; o.qn_sum = qn_sum; o.op_sum = op_sum; so[k] = o; }
+                  o.sq_sum = sq_sum; o.qn_sum = qn_sum; o.op_sum = op_sum; o.end_pos = p; so[k] = o; }
 }
 
 __global__ void k_seg_kept(const SegOut *so, int64_t nseg, uint32_t *kept) {
@@ -464,21 +470,48 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     const unsigned gseg = (unsigned)((nseg + 63) / 64);
     hipLaunchKernelGGL(k_seg_start, dim3(gseg), dim3(64), 0, sm, d, (const Seg *)dsegs, nseg, n_ref, dstart);
     KeptOut none{};
-    hipLaunchKernelGGL(k_hop<0>, dim3(gseg), dim3(64), 0, sm, d, (const Seg *)dsegs, nseg, (const uint64_t *)dstart, F, dso, (const uint32_t *)nullptr, none);
-    hipLaunchKernelGGL(k_seg_kept, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, sm, (const SegOut *)dso, nseg, dkept);
-    if (int s2 = scan_excl(ctx, dkept, dkbase, nseg, ctx->scratch[6])) return fail(s2, nullptr);
     std::vector<SegOut> hso((size_t)nseg);
     uint32_t total_kept = 0;
-    if (hipMemcpyAsync(hso.data(), dso, (size_t)nseg * sizeof(SegOut), hipMemcpyDeviceToHost, sm) != hipSuccess ||
-        hipMemcpyAsync(&total_kept, dkbase + nseg, 4, hipMemcpyDeviceToHost, sm) != hipSuccess || hipStreamSynchronize(sm) != hipSuccess)
+    // The counting hop, repeated while a guessed boundary turns out to be a fake (a byte pattern inside a record that passes the
+    // plausibility chain): segment k's chain is the truth when its own start is, so where it ARRIVES becomes the start of segment
+    // k + 1, and the hop runs again.  Every boundary is verified in the end, or the file goes to the host path.
+    for (int pass = 0;; pass++) {
+        hipLaunchKernelGGL(k_hop<0>, dim3(gseg), dim3(64), 0, sm, d, (const Seg *)dsegs, nseg, (const uint64_t *)dstart, F, dso, (const uint32_t *)nullptr, none);
+        if (hipMemcpyAsync(hso.data(), dso, (size_t)nseg * sizeof(SegOut), hipMemcpyDeviceToHost, sm) != hipSuccess || hipStreamSynchronize(sm) != hipSuccess)
+            return fail(PHZ_E_HIP, "segment read-back");
+        int repaired = 0;
+        bool prev_clean = true;
+        for (int64_t k = 0; k < nseg; k++) {
+            const SegOut &o = hso[(size_t)k];
+            const bool last_of_piece = !(k + 1 < nseg && segs[(size_t)k + 1].piece == segs[(size_t)k].piece);
+            if ((o.flags & 1) && prev_clean) return fail(PHZ_E_ARG, "truncated or corrupt BAM record");
+            if ((o.flags & 2) && prev_clean) {
+                if (last_of_piece) return fail(PHZ_E_ARG, "truncated or corrupt BAM record");      // ran past the end of the piece
+                const uint64_t e = o.end_pos;
+                if (hipMemcpyAsync(dstart + k + 1, &hso[(size_t)k].end_pos, 8, hipMemcpyHostToDevice, sm) != hipSuccess) return fail(PHZ_E_HIP, "boundary repair");
+                (void)e;
+                repaired++;
+            }
+            prev_clean = (o.flags & 3) == 0;
+        }
+        if (!repaired) {
+            bool any = false;
+            for (auto &o : hso) if (o.flags & 3) any = true;
+            if (!any) break;
+        }
+        if (timing) fprintf(stderr, "[phz timing]     bam device: %d guessed record boundaries were fakes, repaired from the preceding chain (pass %d)\n", repaired, pass);
+        if (pass == 7) return fail(PHZ_E_UNSUPPORTED, "record boundaries did not converge");
+        if (hipStreamSynchronize(sm) != hipSuccess) return fail(PHZ_E_HIP, "boundary repair");
+    }
+    hipLaunchKernelGGL(k_seg_kept, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, sm, (const SegOut *)dso, nseg, dkept);
+    if (int s2 = scan_excl(ctx, dkept, dkbase, nseg, ctx->scratch[6])) return fail(s2, nullptr);
+    if (hipMemcpyAsync(&total_kept, dkbase + nseg, 4, hipMemcpyDeviceToHost, sm) != hipSuccess || hipStreamSynchronize(sm) != hipSuccess)
         return fail(PHZ_E_HIP, "segment read-back");
-    {   // every guessed boundary verified, chain intact, records sorted (inside segments and across them)
+    {   // records sorted (inside segments and across them); 64-bit totals within the 32-bit scans
         int32_t lr = -2, lp = 0;
         uint64_t sum = 0, sq = 0, qn = 0, ops = 0;
         for (int64_t k = 0; k < nseg; k++) {
             const SegOut &o = hso[(size_t)k];
-            if (o.flags & 1) return fail(PHZ_E_ARG, "truncated or corrupt BAM record");
-            if (o.flags & 2) return fail(PHZ_E_UNSUPPORTED, "record boundary guess did not verify");
             if (o.flags & 4) return fail(PHZ_E_UNSUPPORTED, "BAM is not coordinate-sorted");
             if (o.first_ref != -2) {
                 if (lr != -2 && (o.first_ref < lr || (o.first_ref == lr && o.first_pos < lp))) return fail(PHZ_E_UNSUPPORTED, "BAM is not coordinate-sorted");
