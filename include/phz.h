@@ -210,7 +210,7 @@ typedef struct {                 /* one BGZF member */
     uint64_t dst;                /* byte offset of its output */
 } phz_bgzf_member;
 
-/* Inflates members whose compressed bytes are in DEVICE memory (readable for 8 bytes past the last member) into `out` (device).
+/* Inflates members whose compressed bytes are in DEVICE memory (16-byte aligned, readable for 16 bytes past the last member) into `out` (device).
  * *bad = 0, or a code > 0 when some member is not valid DEFLATE / does not produce ISIZE bytes: the output is unusable then. */
 int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t n_members, uint8_t *out, int *bad);
 

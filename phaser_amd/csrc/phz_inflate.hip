@@ -6,7 +6,8 @@
 // flight.  A lane is a slow decoder (bit-serial canonical Huffman decode, byte-wise LZ77 copies through global memory), but the
 // whole chip runs tens of thousands of them at once.  Per lane: the code-length counts of the two Huffman codes live in registers
 // (the decode loop over code lengths 1..15 is unrolled, so every count is a fixed register), the symbol tables in LDS
-// ([symbol slot][lane] layout: lanes that are at the same slot hit different banks).
+// ([symbol slot][lane] layout: lanes that are at the same slot hit different banks), packed to 25 KB per wave: the kernel lives on
+// memory latency, so the number of waves a CU can hold is its throughput.
 //
 // Every member is checked as it is decoded (code validity, distances, output size == ISIZE of the member trailer); a member that
 // fails sets the call's status word and the host falls back to zlib for the whole file -- nothing is silently wrong.
@@ -20,16 +21,34 @@
 namespace {
 
 constexpr int IL = 64;             // lanes (members) per workgroup
-constexpr int MAXL = 288, MAXD = 32, MAXLENS = 320;
+constexpr int MAXL = 288, MAXD = 32, MAXLENS = 320;      // MAXL is a multiple of 32, MAXLENS even (bit plane / nibble packing)
 
 struct BitIn {
-    const uint32_t *p;             // next aligned dword
-    const uint32_t *end;           // one past the last dword that may be read
+    // Input arrives 16 bytes at a time and one load AHEAD of its use: `nxt` was requested when `cur` became current, so the
+    // ~1 us of a global load is spent decoding the 128 bits before it.  (All 64 lanes of the wave stall when one of them waits.)
+    const uint4 *p;                // next aligned 16-byte unit to request
+    const uint4 *end;              // one past the last unit that may be read
+    uint4 cur, nxt;
+    int k;                         // dwords of cur already consumed (0..4)
     uint64_t bb; int bc;
+    __device__ __forceinline__ uint4 fetch() { const uint4 z = make_uint4(0, 0, 0, 0); const uint4 v = p < end ? *p : z; p++; return v; }
+    __device__ __forceinline__ void start(const uint8_t *at, const uint8_t *stop) {
+        const uintptr_t a = (uintptr_t)at;
+        p = (const uint4 *)(a & ~(uintptr_t)15);
+        end = (const uint4 *)(((uintptr_t)stop + 15) & ~(uintptr_t)15);
+        cur = fetch(); nxt = fetch();
+        k = (int)((a & 15) >> 2);
+        bb = 0; bc = 0;
+        refill();
+        const int skip = (int)(a & 3) * 8;
+        bb >>= skip; bc -= skip;
+        refill();
+    }
     __device__ __forceinline__ void refill() {
         if (bc <= 32) {
-            const uint32_t w = p < end ? *p : 0u;
-            p++;
+            if (k == 4) { cur = nxt; nxt = fetch(); k = 0; }
+            const uint32_t w = k == 0 ? cur.x : (k == 1 ? cur.y : (k == 2 ? cur.z : cur.w));
+            k++;
             bb |= (uint64_t)w << bc; bc += 32;
         }
     }
@@ -58,6 +77,8 @@ __device__ __forceinline__ int decode_sym(BitIn &in, const uint16_t (&cnt)[16], 
 }
 
 struct Member { uint64_t src; uint32_t csize, isize; uint64_t dst; };
+typedef uint32_t __attribute__((aligned(1))) u32u;      // unaligned global accesses (gfx950 does them in hardware)
+typedef uint64_t __attribute__((aligned(1))) u64u;
 
 __constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -68,31 +89,63 @@ __constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // status codes written to the per-call status word (first failure wins)
 enum { INF_OK = 0, INF_BAD_BLOCK = 1, INF_BAD_CODE = 2, INF_BAD_DIST = 3, INF_OVERRUN = 4, INF_SHORT = 5, INF_BAD_LENS = 6 };
 
-__global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Member *mem, int64_t n_members, uint8_t *out, int *status) {
-    __shared__ uint16_t s_syml[MAXL][IL];
-    __shared__ uint16_t s_symd[MAXD][IL];
-    __shared__ uint8_t s_lens[MAXLENS][IL];
-    __shared__ uint16_t s_cnt[16][IL];
-    __shared__ uint16_t s_off[16][IL];
+// Per-lane tables in LDS, [slot][lane] (lanes on the same slot hit different banks), squeezed so that six waves fit a CU's 160 KB:
+// literal/length symbols as 8 low bits + a bit plane for bit 8 (values < 288), distance symbols as bytes.
+struct Tables {
+    uint8_t syml_lo[MAXL][IL];
+    uint32_t syml_hi[MAXL / 32][IL];
+    uint8_t symd[MAXD][IL];
+    uint16_t cnt[16][IL];          // counts, then running offsets while a table is filled
+};
+struct Lane {
+    Tables &t; const int lane;
+    uint8_t *lens;                 // [MAXLENS] code lengths of the block being set up: global scratch of this member (touched only at
+                                   // block headers; keeping them out of LDS is two more waves per CU)
+    __device__ __forceinline__ int len_at(int i) const { return lens[i]; }
+    __device__ __forceinline__ void set_len(int i, int v) { lens[i] = (uint8_t)v; }
+    __device__ __forceinline__ int syml(int k) const { return (int)t.syml_lo[k][lane] | (int)(((t.syml_hi[k >> 5][lane] >> (k & 31)) & 1u) << 8); }
+    __device__ __forceinline__ void set_syml(int k, int v) {
+        t.syml_lo[k][lane] = (uint8_t)v;
+        uint32_t &w = t.syml_hi[k >> 5][lane];
+        w = (w & ~(1u << (k & 31))) | ((uint32_t)(v >> 8) << (k & 31));
+    }
+};
+
+// canonical code of symbols [first, first + n) with lengths len_at(): counts -> cnt (returned in registers), symbols in code order
+// through `put`; returns "left" of the Kraft sum (0 complete, > 0 incomplete, < 0 over-subscribed) and the number of coded symbols
+template <class Put>
+__device__ __forceinline__ int build_code(Lane &L, int first, int n, uint16_t (&cnt)[16], int *coded, Put put) {
+    Tables &t = L.t; const int lane = L.lane;
+    for (int l = 0; l < 16; l++) t.cnt[l][lane] = 0;
+    for (int i = 0; i < n; i++) t.cnt[L.len_at(first + i)][lane]++;
+#pragma unroll
+    for (int l = 0; l < 16; l++) cnt[l] = t.cnt[l][lane];
+    int left = 1;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) { left <<= 1; left -= cnt[l]; }
+    *coded = n - cnt[0];
+    if (left < 0) return left;
+    uint16_t off = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) { t.cnt[l][lane] = off; off += cnt[l]; }
+    for (int i = 0; i < n; i++) { const int l = L.len_at(first + i); if (l) put((int)t.cnt[l][lane]++, i); }
+    return left;
+}
+
+__global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Member *mem, int64_t n_members, uint8_t *out, uint8_t *lens_scratch,
+                                                int *status) {
+    __shared__ Tables T;
     const int lane = threadIdx.x;
     const int64_t m = (int64_t)blockIdx.x * IL + lane;
     if (m >= n_members) return;
+    Lane L{T, lane, lens_scratch + m * MAXLENS};
     const Member M = mem[m];
     uint8_t *o = out + M.dst;
     uint32_t op = 0;
     const uint32_t oend = M.isize;
     if (oend == 0) return;
     BitIn in;
-    {
-        const uintptr_t a = (uintptr_t)(comp + M.src);
-        in.p = (const uint32_t *)(a & ~(uintptr_t)3);
-        in.end = (const uint32_t *)(((uintptr_t)(comp + M.src + M.csize) + 3) & ~(uintptr_t)3);
-        in.bb = 0; in.bc = 0;
-        in.refill();
-        const int skip = (int)(a & 3) * 8;
-        in.bb >>= skip; in.bc -= skip;
-        in.refill();
-    }
+    in.start(comp + M.src, comp + M.src + M.csize);
     int err = INF_OK;
     uint16_t cl[16], cd[16];
     bool last = false;
@@ -114,86 +167,57 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
         if (type == 3) { err = INF_BAD_BLOCK; break; }
         int nlen = 288, ndist = 30;
         if (type == 1) {                                   // fixed code
-            for (int i = 0; i < 144; i++) s_lens[i][lane] = 8;
-            for (int i = 144; i < 256; i++) s_lens[i][lane] = 9;
-            for (int i = 256; i < 280; i++) s_lens[i][lane] = 7;
-            for (int i = 280; i < 288; i++) s_lens[i][lane] = 8;
+            for (int i = 0; i < 144; i++) L.set_len(i, 8);
+            for (int i = 144; i < 256; i++) L.set_len(i, 9);
+            for (int i = 256; i < 280; i++) L.set_len(i, 7);
+            for (int i = 280; i < 288; i++) L.set_len(i, 8);
             ndist = 32;                                    // the fixed distance code has 32 five-bit codes (30 and 31 never occur)
-            for (int i = 0; i < 32; i++) s_lens[288 + i][lane] = 5;
-        } else {                                           // dynamic code: the code-length code first (tables in the distance arrays)
+            for (int i = 0; i < 32; i++) L.set_len(288 + i, 5);
+        } else {                                           // dynamic code: the code-length code first (its table in the distance array)
             nlen = (int)in.bits(5) + 257; ndist = (int)in.bits(5) + 1;
             const int ncode = (int)in.bits(4) + 4;
             if (nlen > 286 || ndist > 30) { err = INF_BAD_LENS; break; }
-            for (int i = 0; i < 19; i++) s_lens[i][lane] = 0;
-            for (int i = 0; i < ncode; i++) { in.refill(); s_lens[c_clorder[i]][lane] = (uint8_t)in.bits(3); }
-            for (int l = 0; l < 16; l++) s_cnt[l][lane] = 0;
-            for (int i = 0; i < 19; i++) s_cnt[s_lens[i][lane]][lane]++;
-            {
-                int left = 1;
-                for (int l = 1; l <= 7; l++) { left <<= 1; left -= s_cnt[l][lane]; }
-                if (left < 0) { err = INF_BAD_LENS; break; }
-            }
-            s_off[1][lane] = 0;
-            for (int l = 1; l < 15; l++) s_off[l + 1][lane] = s_off[l][lane] + s_cnt[l][lane];
-            for (int i = 0; i < 19; i++) { const int l = s_lens[i][lane]; if (l) s_symd[s_off[l][lane]++][lane] = (uint16_t)i; }
+            for (int i = 0; i < 19; i++) L.set_len(i, 0);
+            for (int i = 0; i < ncode; i++) { in.refill(); L.set_len(c_clorder[i], (int)in.bits(3)); }
             uint16_t cc[16];
-#pragma unroll
-            for (int l = 0; l < 16; l++) cc[l] = l <= 7 ? s_cnt[l][lane] : (uint16_t)0;
+            int coded;
+            if (build_code(L, 0, 19, cc, &coded, [&](int k, int sym) { T.symd[k][lane] = (uint8_t)sym; }) < 0) { err = INF_BAD_LENS; break; }
             // literal/length and distance code lengths, run-length coded
             int idx = 0;
             while (idx < nlen + ndist && !err) {
                 in.refill();
-                const int sym = decode_sym(in, cc, [&](int k) { return (int)s_symd[k & (MAXD - 1)][lane]; });
+                const int sym = decode_sym(in, cc, [&](int k) { return (int)T.symd[k & (MAXD - 1)][lane]; });
                 if (sym < 0) { err = INF_BAD_CODE; break; }
-                if (sym < 16) s_lens[idx++][lane] = (uint8_t)sym;
+                if (sym < 16) L.set_len(idx++, sym);
                 else {
                     int rep, val = 0;
                     in.refill();
                     if (sym == 16) {
                         if (idx == 0) { err = INF_BAD_LENS; break; }
-                        val = s_lens[idx - 1][lane]; rep = 3 + (int)in.bits(2);
+                        val = L.len_at(idx - 1); rep = 3 + (int)in.bits(2);
                     } else if (sym == 17) rep = 3 + (int)in.bits(3);
                     else rep = 11 + (int)in.bits(7);
                     if (idx + rep > nlen + ndist) { err = INF_BAD_LENS; break; }
-                    while (rep--) s_lens[idx++][lane] = (uint8_t)val;
+                    while (rep--) L.set_len(idx++, val);
                 }
             }
             if (err) break;
-            if (s_lens[256][lane] == 0) { err = INF_BAD_LENS; break; }      // no end-of-block code
+            if (L.len_at(256) == 0) { err = INF_BAD_LENS; break; }          // no end-of-block code
             // the distance lengths follow the literal/length lengths: move them to a fixed place
-            for (int i = ndist - 1; i >= 0; i--) s_lens[288 + i][lane] = s_lens[nlen + i][lane];
+            for (int i = ndist - 1; i >= 0; i--) L.set_len(288 + i, L.len_at(nlen + i));
         }
-        // literal/length table
-        for (int l = 0; l < 16; l++) s_cnt[l][lane] = 0;
-        for (int i = 0; i < nlen; i++) s_cnt[s_lens[i][lane]][lane]++;
         {
-            int left = 1;
-            for (int l = 1; l <= 15; l++) { left <<= 1; left -= s_cnt[l][lane]; }
-            if (left < 0 || (left > 0 && nlen - s_cnt[0][lane] != 1)) { err = INF_BAD_LENS; break; }
-        }
-        s_off[1][lane] = 0;
-        for (int l = 1; l < 15; l++) s_off[l + 1][lane] = s_off[l][lane] + s_cnt[l][lane];
-        for (int i = 0; i < nlen; i++) { const int l = s_lens[i][lane]; if (l) s_syml[s_off[l][lane]++][lane] = (uint16_t)i; }
-#pragma unroll
-        for (int l = 0; l < 16; l++) cl[l] = s_cnt[l][lane];
-        // distance table
-        for (int l = 0; l < 16; l++) s_cnt[l][lane] = 0;
-        for (int i = 0; i < ndist; i++) s_cnt[s_lens[288 + i][lane]][lane]++;
-        {
-            int left = 1;
-            for (int l = 1; l <= 15; l++) { left <<= 1; left -= s_cnt[l][lane]; }
+            int coded;
+            const int left = build_code(L, 0, nlen, cl, &coded, [&](int k, int sym) { L.set_syml(k, sym); });
+            if (left < 0 || (left > 0 && coded != 1)) { err = INF_BAD_LENS; break; }
             // incomplete is fine for a single one-bit code, and for NO distance codes at all (a block of literals only)
-            if (left < 0 || (left > 0 && ndist - s_cnt[0][lane] > 1)) { err = INF_BAD_LENS; break; }
+            const int leftd = build_code(L, 288, ndist, cd, &coded, [&](int k, int sym) { T.symd[k][lane] = (uint8_t)sym; });
+            if (leftd < 0 || (leftd > 0 && coded > 1)) { err = INF_BAD_LENS; break; }
         }
-        s_off[1][lane] = 0;
-        for (int l = 1; l < 15; l++) s_off[l + 1][lane] = s_off[l][lane] + s_cnt[l][lane];
-        for (int i = 0; i < ndist; i++) { const int l = s_lens[288 + i][lane]; if (l) s_symd[s_off[l][lane]++][lane] = (uint16_t)i; }
-#pragma unroll
-        for (int l = 0; l < 16; l++) cd[l] = s_cnt[l][lane];
         // the block's symbols
         for (;;) {
             in.refill();
-            int sym = decode_sym(in, cl, [&](int k) { return (int)s_syml[k < MAXL ? k : 0][lane]; });
+            int sym = decode_sym(in, cl, [&](int k) { return L.syml(k < MAXL ? k : 0); });
             if (sym < 0) { err = INF_BAD_CODE; break; }
             if (sym < 256) {
                 if (op >= oend) { err = INF_OVERRUN; break; }
@@ -206,7 +230,7 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
             in.refill();
             const uint32_t len = c_lbase[sym] + in.bits(c_lext[sym]);
             in.refill();
-            const int ds = decode_sym(in, cd, [&](int k) { return (int)s_symd[k & (MAXD - 1)][lane]; });
+            const int ds = decode_sym(in, cd, [&](int k) { return (int)T.symd[k & (MAXD - 1)][lane]; });
             if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
             in.refill();
             const uint32_t dist = c_dbase[ds] + in.bits(c_dext[ds]);
@@ -214,12 +238,18 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
             if (op + len > oend) { err = INF_OVERRUN; break; }
             const uint8_t *src = o + op - dist;
             uint8_t *dst = o + op;
-            if (dist >= 4) {
-                uint32_t i = 0;
-                for (; i + 4 <= len; i += 4) {
-                    const uint8_t b0 = src[i], b1 = src[i + 1], b2 = src[i + 2], b3 = src[i + 3];
-                    dst[i] = b0; dst[i + 1] = b1; dst[i + 2] = b2; dst[i + 3] = b3;
+            // LZ77 copy.  Every chunk is a load -> store round trip through L2, so the chunk is as wide as the distance allows; wide
+            // chunks may write a few bytes past the match (inside the member's own output, rewritten by what follows)
+            if (dist >= 16 && op + ((len + 15u) & ~15u) <= oend) {
+                for (uint32_t i = 0; i < len; i += 16) {
+                    const uint64_t a = *(const u64u *)(src + i), b = *(const u64u *)(src + i + 8);
+                    *(u64u *)(dst + i) = a; *(u64u *)(dst + i + 8) = b;
                 }
+            } else if (dist >= 8 && op + ((len + 7u) & ~7u) <= oend) {
+                for (uint32_t i = 0; i < len; i += 8) *(u64u *)(dst + i) = *(const u64u *)(src + i);
+            } else if (dist >= 4) {
+                uint32_t i = 0;
+                for (; i + 4 <= len; i += 4) *(u32u *)(dst + i) = *(const u32u *)(src + i);
                 for (; i < len; i++) dst[i] = src[i];
             } else {
                 for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
@@ -234,7 +264,7 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
 }  // namespace
 
 // Inflate `n_members` BGZF members whose compressed bytes sit in device memory.  members[i] = {byte offset of the raw deflate
-// stream in comp, its compressed size, ISIZE, offset of its output in out}; comp must be readable for 8 bytes past the last member.
+// stream in comp, its compressed size, ISIZE, offset of its output in out}; comp 16-byte aligned and readable for 16 bytes past the last member.
 // *bad receives 0 or the code of the first member that failed (nothing else about the output can be trusted then).
 extern "C" int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t n_members, uint8_t *out,
                                        int *bad) {
@@ -245,10 +275,11 @@ extern "C" int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const 
     if (n_members == 0) return PHZ_OK;
     hipStream_t sm = ctx->stream;
     if (int s = phz_reserve(ctx, ctx->scalars, 64)) return s;
+    if (int s = phz_reserve(ctx, ctx->scratch[11], (size_t)n_members * MAXLENS)) return s;
     int *d_status = (int *)ctx->scalars.p;
     PHZ_HIP(ctx, hipMemsetAsync(d_status, 0, 4, sm));
     PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n_members + IL - 1) / IL)), dim3(IL), 0, sm, comp, (const Member *)members, n_members, out, d_status);
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n_members + IL - 1) / IL)), dim3(IL), 0, sm, comp, (const Member *)members, n_members, out, (uint8_t *)ctx->scratch[11].p, d_status);
     PHZ_HIP(ctx, hipGetLastError());
     PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(bad, d_status, 4, hipMemcpyDeviceToHost, sm));
