@@ -243,59 +243,87 @@ __device__ bool aux_as_dev(const uint8_t *p, const uint8_t *e, int32_t *out) {
     return found;
 }
 
+// l_seq of the record at r (phase B needs it for the offset of the qualities)
+__device__ __forceinline__ uint32_t nb_seq_len(const uint8_t *r) { const int32_t l = ldi32(r + 16); return l > 0 ? (uint32_t)l : 0u; }
+
 __constant__ int8_t c_code_of[16] = {-2, 0, 1, -2, 2, -2, -2, -2, 3, -2, -2, -2, -2, -1, -2, -1};   // =ACMGRSVTWYHKDBN
 
+// One wave per 64 kept records.  Phase A, lane = record: the scalar columns, the normalised CIGAR and the AS tag (a few dependent
+// loads per lane).  Phase B, lane = byte: the wave walks its 64 records and moves each one's name, bases and qualities with
+// coalesced accesses -- a lane reading its own record byte by byte pulls a whole cache line per byte through L2 (the first version
+// of this kernel did, and was bound by exactly that: 0.21 s for 59M records).
 __global__ __launch_bounds__(256) void k_pack(const uint8_t *d, KeptOut K, int64_t n_kept, const int64_t *ref_begin, const uint32_t *co,
                                               const uint32_t *so, const uint32_t *qo, const DevShard *shards) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_kept) return;
-    const int ref = K.ref[i];
-    const int64_t b = ref_begin[ref], e = ref_begin[ref + 1];
-    const int64_t k = i - b;
-    const DevShard S = shards[ref];
-    const uint32_t c0 = co[i] - co[b], s0 = so[i] - so[b], q0 = qo[i] - qo[b];
-    const uint8_t *r = d + K.off[i];
-    const uint32_t l_rn = r[8], n_cig = ld16(r + 12);
-    const int32_t l_seq = ldi32(r + 16);
-    const int32_t bs = ldi32(r - 4);
-    const uint32_t nb = K.nb[i];
-    S.pos[k] = ldi32(r + 4) + 1;
-    S.cigar_off[k] = c0; S.seq_off[k] = s0; S.qname_off[k] = q0;
-    if (i + 1 == e) { S.cigar_off[k + 1] = co[e] - co[b]; S.seq_off[k + 1] = so[e] - so[b]; S.qname_off[k + 1] = qo[e] - qo[b]; }
-    for (uint32_t t = 0; t + 1 < l_rn; t++) S.qnames[q0 + t] = (char)r[32 + t];
-    const uint8_t *cig = r + 32 + l_rn;
-    norm_ops_dev(cig, (int)n_cig, (int)nb, S.cigar + c0);
-    const uint8_t *sq = cig + 4 * (uint64_t)n_cig;
-    const uint8_t *ql = sq + ((uint64_t)(l_seq > 0 ? l_seq : 0) + 1) / 2;
-    uint8_t *o2 = S.seq2 + s0;
-    uint8_t *oq = S.qual + (uint64_t)s0 * 4;
-    const uint32_t groups = (nb + 3) / 4;
-    if (l_seq <= 0) {                     // SEQ '*' QUAL '*': one IUPAC-other character with phred 9
-        o2[0] = 1; oq[0] = (uint8_t)(9 | 0x80); oq[1] = 0; oq[2] = 0; oq[3] = 0;
+    __shared__ const uint8_t *s_src[256];
+    __shared__ char *s_qn[256];
+    __shared__ uint8_t *s_o2[256], *s_oq[256];
+    __shared__ uint32_t s_meta[256];           // l_rn | n_cig << 8 | star << 24 (SEQ '*')
+    __shared__ uint32_t s_nb[256];
+    const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = i < n_kept;
+    if (live) {
+        const int ref = K.ref[i];
+        const int64_t b = ref_begin[ref], e = ref_begin[ref + 1];
+        const int64_t k = i - b;
+        const DevShard S = shards[ref];
+        const uint32_t c0 = co[i] - co[b], s0 = so[i] - so[b], q0 = qo[i] - qo[b];
+        const uint8_t *r = d + K.off[i];
+        const uint32_t l_rn = r[8], n_cig = ld16(r + 12);
+        const int32_t l_seq = ldi32(r + 16);
+        const int32_t bs = ldi32(r - 4);
+        const uint32_t nb = K.nb[i];
+        S.pos[k] = ldi32(r + 4) + 1;
+        S.cigar_off[k] = c0; S.seq_off[k] = s0; S.qname_off[k] = q0;
+        if (i + 1 == e) { S.cigar_off[k + 1] = co[e] - co[b]; S.seq_off[k + 1] = so[e] - so[b]; S.qname_off[k + 1] = qo[e] - qo[b]; }
+        const uint8_t *cig = r + 32 + l_rn;
+        norm_ops_dev(cig, (int)n_cig, (int)nb, S.cigar + c0);
+        const uint8_t *ql = cig + 4 * (uint64_t)n_cig + ((uint64_t)(l_seq > 0 ? l_seq : 0) + 1) / 2;
+        int32_t as = 0;
+        const bool has = aux_as_dev(ql + (l_seq > 0 ? l_seq : 0), r + bs, &as);
+        S.aln[k] = has ? as : 0; S.has_as[k] = has ? 1 : 0;
+        s_src[tid] = r; s_qn[tid] = S.qnames + q0; s_o2[tid] = S.seq2 + s0; s_oq[tid] = S.qual + (uint64_t)s0 * 4;
+        s_meta[tid] = l_rn | (n_cig << 8) | (l_seq <= 0 ? 1u << 24 : 0u);
+        s_nb[tid] = nb;
     } else {
+        s_nb[tid] = 0; s_meta[tid] = 0;
+    }
+    __syncthreads();
+    for (int j = 0; j < 64; j++) {
+        const uint32_t nb = s_nb[wbase + j];
+        if (nb == 0) continue;                 // record beyond the end of the list
+        const uint32_t meta = s_meta[wbase + j];
+        const uint32_t l_rn = meta & 0xFF, n_cig = (meta >> 8) & 0xFFFF;
+        const uint8_t *r = s_src[wbase + j];
+        char *qn = s_qn[wbase + j];
+        for (uint32_t t = lane; t + 1 < l_rn; t += 64) qn[t] = (char)r[32 + t];
+        uint8_t *o2 = s_o2[wbase + j], *oq = s_oq[wbase + j];
+        if (meta >> 24) {                      // SEQ '*' QUAL '*': one IUPAC-other character with phred 9
+            if (lane < 4) oq[lane] = lane == 0 ? (uint8_t)(9 | 0x80) : 0;
+            if (lane == 0) o2[0] = 1;
+            continue;
+        }
+        const uint8_t *sq = r + 32 + l_rn + 4 * (uint64_t)n_cig;
+        const uint8_t *ql = sq + ((uint64_t)nb_seq_len(r) + 1) / 2;
         const bool noq = ql[0] == 0xFF;
-        for (uint32_t g = 0; g < groups; g++) {
-            uint32_t packed = 0;
-            for (uint32_t t = 0; t < 4; t++) {
-                const uint32_t j = g * 4 + t;
-                uint8_t q = 0;
-                if (j < nb) {
-                    const uint8_t nib = (j & 1) ? (sq[j >> 1] & 15) : (sq[j >> 1] >> 4);
-                    const int c = c_code_of[nib];
-                    q = noq ? 9 : (ql[j] > 127 ? 127 : ql[j]);
-                    uint32_t code2;
-                    if (c >= 0) code2 = (uint32_t)c; else { code2 = c == -1 ? 0u : 1u; q |= 0x80; }
-                    packed |= code2 << (2 * t);
-                }
-                oq[j] = q;
+        const uint32_t padded = ((nb + 3) / 4) * 4;
+        for (uint32_t jb = lane; jb < ((padded + 63) & ~63u); jb += 64) {
+            uint32_t code2 = 0; uint8_t q = 0;
+            if (jb < nb) {
+                const uint8_t by = sq[jb >> 1];
+                const uint8_t nib = (jb & 1) ? (by & 15) : (by >> 4);
+                const int c = c_code_of[nib];
+                q = noq ? 9 : (ql[jb] > 127 ? 127 : ql[jb]);
+                if (c >= 0) code2 = (uint32_t)c; else { code2 = c == -1 ? 0u : 1u; q |= 0x80; }
             }
-            o2[g] = (uint8_t)packed;
+            uint32_t v = code2 << (2 * (jb & 3));
+            v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2);
+            if (jb < padded) {
+                oq[jb] = q;
+                if ((jb & 3) == 0) o2[jb >> 2] = (uint8_t)v;
+            }
         }
     }
-    int32_t as = 0;
-    const uint8_t *aux = ql + (l_seq > 0 ? l_seq : 0);
-    const bool has = aux_as_dev(aux, r + bs, &as);
-    S.aln[k] = has ? as : 0; S.has_as[k] = has ? 1 : 0;
 }
 
 // ---- QNAME interning on the device: ids in first-appearance order (what a sequential dictionary would hand out; mates and
