@@ -263,6 +263,18 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
 
 }  // namespace
 
+// internal: members [first, first + count) of a device member table on stream `s`; d_status (device int, zeroed by the caller) and
+// the code-length scratch ([n_members * 320] bytes) are shared by all launches of a call
+int phz_inflate_launch(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t first, int64_t count, uint8_t *out,
+                       uint8_t *lens_scratch, int *d_status, hipStream_t s) {
+    if (count <= 0) return PHZ_OK;
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)((count + IL - 1) / IL)), dim3(IL), 0, s, comp, (const Member *)members + first, count, out,
+                       lens_scratch + first * MAXLENS, d_status);
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
+int phz_inflate_scratch_bytes_per_member() { return MAXLENS; }
+
 // Inflate `n_members` BGZF members whose compressed bytes sit in device memory.  members[i] = {byte offset of the raw deflate
 // stream in comp, its compressed size, ISIZE, offset of its output in out}; comp 16-byte aligned and readable for 16 bytes past the last member.
 // *bad receives 0 or the code of the first member that failed (nothing else about the output can be trusted then).

@@ -116,3 +116,8 @@ struct PhzBamPlan {
 int phz_bam_plan_file(const char *path, const char *const *ref_names, int n_names, PhzBamPlan *out);
 void phz_bam_plan_release(PhzBamPlan *p);
 
+// K_inflate launcher for callers that pipeline it with their own copies (phz_inflate.hip)
+int phz_inflate_launch(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t first, int64_t count, uint8_t *out,
+                       uint8_t *lens_scratch, int *d_status, hipStream_t s);
+int phz_inflate_scratch_bytes_per_member();
+
