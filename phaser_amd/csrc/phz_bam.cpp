@@ -386,7 +386,7 @@ struct phz_interner {
         FlatMap ids;                               // name hash -> id (text compared through `names`)
         std::vector<std::unique_ptr<char[]>> arena; size_t arena_used = 0, arena_cap = 0;
         const char *keep(std::string_view s) {
-            if (arena_used + s.size() > arena_cap) {
+            if (arena.empty() || arena_used + s.size() > arena_cap) {       // (an empty name must not find an empty arena)
                 arena_cap = std::max<size_t>(1 << 20, s.size());
                 arena.emplace_back(new char[arena_cap]); arena_used = 0;
             }

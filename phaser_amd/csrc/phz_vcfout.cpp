@@ -55,7 +55,9 @@ void join(std::string &o, const std::vector<std::string> &v, char sep) {
 
 // one data line (:1741-1850); returns false when the line is dropped (--chr filter)
 bool data_line(const Work &W, std::string_view line, std::string &o, int64_t &unphased_phased, int64_t &corrections, int *status) {
-    std::vector<std::string_view> c, fmt, x, all_alleles, ind;
+    // scratch containers are per thread and keep their capacity from line to line (a genome is millions of lines)
+    static thread_local std::vector<std::string_view> c, fmt, x, all_alleles, ind, alts, xs, tsplit;
+    static thread_local std::vector<std::string> fmt2, sf, xv;
     split(line, '\t', c);
     if ((int)c.size() <= 8 || (int)c.size() <= W.sample_column) { *status = PHZ_E_ARG; return false; }
     if (!W.coi.empty() && c[0] != W.coi) return false;
@@ -72,10 +74,10 @@ bool data_line(const Work &W, std::string_view line, std::string &o, int64_t &un
         { size_t q = genotype.find('|'); if (q != std::string::npos) genotype.erase(q, 1); }
         { size_t q = genotype.find('/'); if (q != std::string::npos) genotype.erase(q, 1); }
         all_alleles.clear(); all_alleles.push_back(c[3]);
-        { std::vector<std::string_view> alts; split(c[4], ',', alts); for (auto &a : alts) all_alleles.push_back(a); }
+        { split(c[4], ',', alts); for (auto &a : alts) all_alleles.push_back(a); }
         const size_t n_fields = fmt.size();
         if (x.size() < n_fields) sample.append(n_fields - x.size(), ':');
-        std::vector<std::string> fmt2(fmt.begin(), fmt.end());
+        fmt2.assign(fmt.begin(), fmt.end());
         for (const char *tag : TAGS) if (std::find(fmt2.begin(), fmt2.end(), tag) == fmt2.end()) fmt2.emplace_back(tag);
         auto fi = [&](const char *tag) { return (size_t)(std::find(fmt2.begin(), fmt2.end(), tag) - fmt2.begin()); };
         // id rebuilt WITHOUT --chr_prefix and with str(int(POS)), as the reference does (:1763)
@@ -83,8 +85,8 @@ bool data_line(const Work &W, std::string_view line, std::string &o, int64_t &un
         { long long pv = strtoll(std::string(c[1]).c_str(), nullptr, 10); uid += W.sep; put_int(uid, pv); }
         for (auto &a : all_alleles) { uid += W.sep; uid.append(a); }
         auto hit = W.lookup.find(std::string_view(uid));
-        std::vector<std::string> sf;
-        auto split_sample = [&]() { std::vector<std::string_view> t; split(sample, ':', t); sf.assign(t.begin(), t.end()); if (sf.size() < fmt2.size()) sf.resize(fmt2.size()); };
+        sf.clear();
+        auto split_sample = [&]() { split(sample, ':', tsplit); sf.assign(tsplit.begin(), tsplit.end()); if (sf.size() < fmt2.size()) sf.resize(fmt2.size()); };
         if (hit != W.lookup.end()) {
             const Hit &H = hit->second;
             const phz_vcfout_chrom &C = W.chroms[H.chrom];
@@ -109,8 +111,8 @@ bool data_line(const Work &W, std::string_view line, std::string &o, int64_t &un
             }
             const double stat = C.blk_stat[H.block];
             {
-                std::vector<std::string_view> xs; split(sample, ':', xs);
-                std::vector<std::string> xv(xs.begin(), xs.end());
+                split(sample, ':', xs);
+                xv.assign(xs.begin(), xs.end());
                 const std::string new_phase = gw_out[0] + "|" + gw_out[1];
                 bool changed = false;
                 if (stat >= W.min_confidence) {
@@ -134,7 +136,7 @@ bool data_line(const Work &W, std::string_view line, std::string &o, int64_t &un
                 std::string t; put_int(t, C.first_block_index + H.block + 1); sf[fi("PS")] = t;
             }
         } else {
-            std::vector<std::string_view> xs; split(sample, ':', xs);
+            split(sample, ':', xs);
             const std::string pw(xs[(size_t)gt_index]);
             split_sample();
             std::string sorted_gt(genotype);

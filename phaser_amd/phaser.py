@@ -279,7 +279,7 @@ def main(argv=None):
             else:
                 say("     GT field is not being updated with phASER genome wide phase. This can be changed using the --gw_phase_vcf argument.")
             vtxt, up, pc = vcfout.phased_vcf_text(data, sample_col, eng, args.id_separator, args.chr, args.gw_phase_vcf,
-                                                  args.gw_phase_vcf_min_confidence, threads=max(1, args.threads))
+                                                  args.gw_phase_vcf_min_confidence, threads=max(1, args.threads), as_bytes=True)
             mark("phased VCF text")
             say("     Compressing and tabix indexing output VCF...")
             vcfout.write_bgzf(args.o + ".vcf.gz", vtxt, max(0, args.threads if args.threads > 1 else 0))

@@ -17,8 +17,9 @@ from . import _lib
 
 
 def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", chromosome_of_interest: str = "",
-                    gw_phase_vcf: int = 0, min_confidence: float = 0.9, threads: int = 8) -> Tuple[str, int, int]:
-    """-> (vcf text, unphased_phased, phase_corrections).  eng: the Engine whose finish() ran with want_vcf (its vcf_blocks)."""
+                    gw_phase_vcf: int = 0, min_confidence: float = 0.9, threads: int = 8, as_bytes: bool = False) -> Tuple[str, int, int]:
+    """-> (vcf text, unphased_phased, phase_corrections).  eng: the Engine whose finish() ran with want_vcf (its vcf_blocks).
+    as_bytes: return the text as bytes (what write_bgzf takes as it is: no decode / encode round trip over ~100 MB)."""
     lib = _lib.load()
     data = vcf_text.encode() if isinstance(vcf_text, str) else bytes(vcf_text)
     keep = []
@@ -47,7 +48,8 @@ def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", 
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_vcf_phase_text failed (malformed VCF line?)")
     try:
-        return C.string_at(out, n.value).decode(), int(up.value), int(pc.value)
+        raw = C.string_at(out, n.value)
+        return (raw if as_bytes else raw.decode()), int(up.value), int(pc.value)
     finally:
         lib.phz_buf_free(out)
 

@@ -238,3 +238,19 @@ def test_region_open_equals_full_decode(tmp_path):
     assert list(w) == names and w["chr20"] == 0 and w["chrEmpty"] == 0
     assert w["chr19"] > 0 and w["chr22"] > w["chr19"]
     assert abs(sum(w.values()) - os.path.getsize(bam)) < 70000            # everything but the header member and the EOF marker
+
+
+def test_empty_qname_record(tmp_path):
+    """l_read_name == 1 (just the NUL): the name is the empty string; it interns like any other name (this used to read the back of
+    an empty arena in the interner)."""
+    from phaser_amd import _lib, bamio
+    _lib.build()
+    recs = [{"ref_id": 0, "pos": 100 + 10 * i, "mapq": 60, "flag": 0, "tlen": 0, "qname": nm, "cigar": [(0, 4)], "seq": "ACGT", "qual": [30] * 4, "tags": {}}
+            for i, nm in enumerate(["", "a", "", "b"])]
+    path = str(tmp_path / "e.bam")
+    bamio.write_bam(path, [("c1", 1000)], recs)
+    ip = {}; inn = {}
+    want = bamio.shards_from_bam(path, ip, 0, False, False)["c1"]
+    got = bamio.shards_from_bam_native(path, inn, 0, False, False)["c1"]
+    assert got.qid.tolist() == want.qid.tolist() == [0, 1, 0, 2]
+    assert inn["c1"].names == ["", "a", "b"]

@@ -207,3 +207,73 @@ def test_device_interning_then_a_second_bam(ctx, tmp_path):
             assert len(hi[c]) == len(di[c]), (p, c)
     for c in hi:
         assert hi[c].names == di[c].names
+
+
+def test_device_path_on_corrupt_bam_streams(ctx, tmp_path):
+    """The mutations of tests/test_native_robustness.py (block_size / l_read_name / n_cigar / l_seq of records, noise, cut tails, header
+    fields) through the DEVICE path: it raises, declines (None) or returns exactly what the host decoder returns -- never a crash,
+    never a different answer."""
+    import gzip, random, struct
+    import torch
+    from phaser_amd import _lib, bamio, synth
+    v, gs, ge, w = synth.make_variants("chr22", 1, 2_000_000, 100, 31, n_genes=8)
+    rb = synth.make_reads(v, gs, ge, w, 400, 32)
+    bam = str(tmp_path / "a.bam")
+    bamio.readbatch_to_bam(bam, [rb], [("chr21", 46709983), ("chr22", 50818468)])
+    raw = bytearray(gzip.open(bam, "rb").read())
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]; p += 4
+    for _ in range(n_ref):
+        l = struct.unpack_from("<i", raw, p)[0]; p += 4 + l + 4
+    first = p
+    recs = []
+    while p + 4 <= len(raw):
+        recs.append(p); p += 4 + struct.unpack_from("<i", raw, p)[0]
+    rng = random.Random(11)
+
+    def write(data, name):
+        path = str(tmp_path / name)
+        assert _lib.load().phz_bgzf_write(path.encode(), bytes(data), len(data), 2, 1) == 0
+        return path
+    outcomes = {"same": 0, "both raise": 0, "declined": 0, "device raises, host decodes": 0}
+    for it in range(96):
+        m = bytearray(raw)
+        kind = it % 8
+        r = rng.choice(recs)
+        if kind == 0:
+            struct.pack_into("<i", m, r, rng.choice([-1, 0, 31, 33, 1 << 30, struct.unpack_from("<i", m, r)[0] - 1]))
+        elif kind == 1:
+            m[r + 4 + 8] = rng.choice([0, 1, 255])
+        elif kind == 2:
+            struct.pack_into("<H", m, r + 4 + 12, rng.choice([0, 1000, 65535]))
+        elif kind == 3:
+            struct.pack_into("<i", m, r + 4 + 16, rng.choice([-5, 0, 1 << 20, 0x7fffffff]))
+        elif kind == 4:
+            m = m[:rng.randrange(first, len(m))]
+        elif kind == 5:
+            for _ in range(rng.randrange(1, 20)):
+                m[rng.randrange(first, len(m))] = rng.randrange(256)
+        elif kind == 6:
+            struct.pack_into("<i", m, rng.choice([4, 8 + l_text, 8 + l_text + 4]), rng.choice([-1, 0x7fffffff, 1 << 28, 3]))
+        else:
+            m = m[:rng.randrange(0, first + 8)]
+        path = write(m, "m%d.bam" % it)
+        try:
+            host = bamio.shards_from_bam_native(path, {}, 0, False, False, 0.0, threads=2)
+        except _lib.PhzError:
+            host = "raise"
+        try:
+            dev = bamio.shards_from_bam_device(ctx, path, {}, 0, False, False, 0.0)
+        except _lib.PhzError:
+            dev = "raise"
+        if dev is None:
+            outcomes["declined"] += 1
+        elif dev == "raise":
+            outcomes["both raise" if host == "raise" else "device raises, host decodes"] += 1
+        else:
+            assert host != "raise", (it, kind)
+            _same(host, dev, (it, kind))
+            outcomes["same"] += 1
+    torch.cuda.synchronize()
+    assert outcomes["same"] >= 10 and outcomes["both raise"] >= 20, outcomes
