@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--no-phasing", action="store_true", help="skip the phasing-stage measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
     ap.add_argument("--no-c2", action="store_true", help="skip the secondary configs[1] entry (chr1, 50M records, 40k het SNPs)")
+    ap.add_argument("--no-bam", action="store_true", help="skip the BAM-path entry (a quarter-genome BAM written to /tmp, decoded on the GPU and on the host)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -304,6 +305,11 @@ def main():
                 phasing["cpu_baseline"] = cpu_phasing_baseline(["chr21", "chr22"], vsets, shards, calls_of, mapper, a.baseq)
         if world == 1 and not a.no_c2:
             out["secondary"] = configs1_entry(mapper, a, dev)
+        if world == 1 and not a.no_bam:
+            try:
+                out["bam_path"] = bam_path_entry(mapper, dev)
+            except Exception as e:                      # a side entry must never cost the bench line
+                out["bam_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -317,6 +323,62 @@ def workloads_variants(plan, vsets, p):
         return vsets[p[0]]
     v, _, _, _ = synth.make_variants(p[0], 1, p[1], p[2], p[4], n_genes=max(1, p[2] // 10))
     return v
+
+
+def bam_path_entry(mapper, dev):
+    """Side entry: a quarter-genome unfiltered BAM (22 chromosomes, 20M records) written to /tmp, then decoded
+    file -> resident shards on the GPU (phz_bamdev_*: K_inflate, record hop, k_pack, QNAME ids) and by the host decoder, shards
+    compared array by array.  Quarter scale keeps the bench short; K_inflate is faster on the whole genome (more members in flight)."""
+    import shutil, tempfile
+    from phaser_amd import bamio, synth, workloads, _lib
+    torch.cuda.empty_cache()
+    tmp = tempfile.mkdtemp(prefix="phz_bench_bam_")
+    try:
+        path = os.path.join(tmp, "q.bam")
+        items = [("chr%d" % (i + 1), ln) for i, ln in enumerate(workloads.HG38_AUTOSOMES)]
+        total_len = float(sum(workloads.HG38_AUTOSOMES))
+        batches = []; nrec = 0
+        for i, (chrom, ln) in enumerate(items):
+            n_snps = int(375_000 * ln / total_len); n_pairs = int(10_000_000 * ln / total_len)
+            v, gs, ge, w = synth.make_variants(chrom, 1, ln, n_snps, 777 + i, n_genes=max(1, n_snps // 10))
+            plan = synth.make_read_plan(v, gs, ge, w, n_pairs, 1777 + i, device=dev)
+            rb = synth.fill_reads(plan, 0, len(plan), v, qname_prefix="s0.b0.%d." % i)
+            batches.append(synth.ReadBatch(rb.chrom, rb.L, rb.pos.cpu(), rb.flag.cpu(), rb.mapq.cpu(), rb.tlen.cpu(), rb.aln_score.cpu(), rb.qid.cpu(),
+                                           rb.cigar_off.cpu(), rb.cigar.cpu(), rb.seq.cpu(), rb.qual.cpu(), rb.qname_prefix))
+            nrec += len(rb)
+            del plan, rb
+        bamio.readbatch_to_bam_native(path, batches, [(c, l) for c, l in items], 0)
+        del batches
+        torch.cuda.empty_cache()
+        size = os.path.getsize(path)
+        ctx = mapper.ctx
+        best = None
+        for rep in range(3):
+            ctx.reset_timing()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            dev_sh = bamio.shards_from_bam_device(ctx, path, {}, 255, True, True, 0.0, device=dev)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            if dev_sh is None:
+                return {"error": "device path declined the file"}
+            infl = ctx.timing(_lib.PHZ_T_INFLATE)[0]
+            if best is None or dt < best[0]:
+                best = (dt, infl)
+            if rep < 2:
+                del dev_sh
+        t0 = time.perf_counter()
+        host_sh = bamio.shards_from_bam_native(path, {}, 255, True, True, 0.0, threads=0)
+        t_host = time.perf_counter() - t0
+        same = list(host_sh) == list(dev_sh) and all(torch.equal(getattr(host_sh[c], f), getattr(dev_sh[c], f).cpu()) for c in host_sh
+                                                     for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"))
+        kept = sum(s.n for s in dev_sh.values())
+        return {"workload": "quarter genome: 22 chromosomes, %d BAM records unfiltered (dups, improper pairs, low MAPQ present), %.0f MB BGZF, "
+                            "filters -q 255 -f 2 -F 0x400" % (nrec, size / 1e6),
+                "value": nrec / best[0], "unit": "BAM records/s, file -> resident shards (GPU)", "seconds": best[0],
+                "records_kept": kept, "copy_plus_inflate_ms": best[1],
+                "host_decoder": {"seconds": t_host, "records_per_s": nrec / t_host, "threads": "library default (<= 32), container CPU quota applies"},
+                "shards_identical_to_host_decoder": bool(same)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def configs1_entry(mapper, a, dev):
