@@ -236,11 +236,15 @@ const char *phz_bamdev_ref_name(const phz_bamdev *h, int i);
 int64_t phz_bamdev_ref_length(const phz_bamdev *h, int i);
 int phz_bamdev_sizes_of(const phz_bamdev *h, int ref, phz_bamdev_sizes *out);
 int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst);      /* dst[r] for reference r; entries of empty references are ignored */
-/* QNAME ids of a device-resident shard in first-appearance order (= what phz_intern assigns when none of these names is in the
- * interner yet and it holds `base` names): qid[n]; first_idx[0, *n_new) = record of the first occurrence of every new name, in id
- * order.  All pointers device, n_new host. */
-int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, int64_t n, int32_t base, int32_t *qid, int32_t *first_idx,
-                      int64_t *n_new);
+/* QNAME ids of a device-resident shard, continuing the numbering of earlier BAMs: `store` / `store_off` [n_old + 1] hold the names of
+ * ids [0, n_old) in id order (NULL / 0: none yet).  qid[n] = exactly what phz_intern assigns; first_idx[0, *n_new) = record of the
+ * first occurrence of every new name, in id order.  All pointers device, n_new host. */
+int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, int64_t n, const char *store, const uint32_t *store_off,
+                      int64_t n_old, int32_t *qid, int32_t *first_idx, int64_t *n_new);
+/* Appends the names of the new ids to the store, in two calls: dst == NULL fills dst_off[0 .. m] (byte offsets of the new names, the
+ * first at base_bytes) and *total_bytes; dst != NULL copies the name bytes there. */
+int phz_names_append_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, const int32_t *first_idx, int64_t m, uint32_t base_bytes,
+                            uint32_t *dst_off, char *dst, int64_t *total_bytes);
 
 /* ---- host side of the path's input: native BGZF/BAM decode, SoA packing, QNAME interning -------------------
  * Replaces `samtools view -h BAM 'chr': | samtools view -Sh [-F 0x400] [-f 2] -q MAPQ -` (phaser/phaser.py:1346)

@@ -200,7 +200,10 @@ SYMBOLS = {
     "phz_bamdev_ref_length": (C.c_int64, [C.c_void_p, C.c_int]),
     "phz_bamdev_sizes_of": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(phz_bamdev_sizes)]),
     "phz_bamdev_pack": (C.c_int, [C.c_void_p, C.POINTER(phz_dev_shard), C.c_int]),
-    "phz_intern_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "phz_intern_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_int64)]),
+    "phz_names_append_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_int64)]),
     "phz_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "phz_bam_open_refs": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "phz_bam_close": (C.c_int, [C.c_void_p]),

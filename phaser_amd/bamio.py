@@ -204,11 +204,12 @@ def readbatch_to_bam_native(path: str, rbs, refs: List[Tuple[str, int]], threads
 
 # ----------------------------------------------------------------------------------------- native reader (libphz.so)
 class NativeInterner:
-    """QNAME -> id map held in C++ (phz_interner); same first-appearance numbering as samio.QnameInterner.
+    """QNAME -> id map of one chromosome; same first-appearance numbering as samio.QnameInterner, continued across BAMs.
 
-    A shard whose ids were assigned on the GPU (phz_intern_device, first BAM of a chromosome) leaves its distinct names DEFERRED:
-    the device arrays are kept, the C++ table is only filled when something needs it (a later BAM's names, --output_read_ids) --
-    a single-BAM run never pays for the host-side hashing."""
+    Two homes: the C++ table (phz_interner) that the host decoders fill, and a DEVICE store (name bytes + offsets in id order) that
+    the GPU path fills with phz_intern_device.  While only the GPU path is used the C++ table stays empty -- it is synchronised from
+    the store when something host-side needs it (names for --output_read_ids, a BAM that goes through the host decoder), and from
+    then on the store is dropped and the chromosome stays on the host table."""
 
     def __init__(self):
         import ctypes as C
@@ -217,55 +218,81 @@ class NativeInterner:
         h = C.c_void_p()
         self.lib.phz_interner_create(C.byref(h))
         self._h = h
-        self._deferred = None          # (qnames uint8 [cuda], qname_off int32 [cuda], first_idx int32 [cuda], n_new)
+        self._store = None             # {"blob": uint8 cuda, "off": int32 cuda [n + 1], "n": ids, "bytes": blob bytes in use}
 
-    def defer(self, qnames, qname_off, first_idx, n_new: int):
-        assert self._deferred is None and int(self.lib.phz_interner_size(self._h)) == 0
-        self._deferred = (qnames, qname_off, first_idx, int(n_new))
+    def _host_size(self) -> int:
+        return int(self.lib.phz_interner_size(self._h))
 
-    def _materialize(self):
-        if self._deferred is None:
+    def _sync(self):
+        """names [host size, store size) of the device store enter the C++ table (ids come out the same: inserted in id order)"""
+        st = self._store
+        if st is None or st["n"] <= self._host_size():
             return
         import ctypes as C
-        qn, qo, first, n_new = self._deferred
-        self._deferred = None
-        if n_new == 0:
-            return
-        idx = first[:n_new].long()
-        a = qo.long()[idx]; b = qo.long()[idx + 1]
-        ln = (b - a)
-        off = torch.zeros(n_new + 1, dtype=torch.int64, device=qn.device)
-        off[1:] = torch.cumsum(ln, 0)
-        total = int(off[-1])
-        # bytes of the distinct names in id order: position p of the compact blob belongs to name r = upper bound of p in off
-        pos = torch.arange(total, device=qn.device)
-        r = torch.searchsorted(off, pos, right=True) - 1
-        blob = qn[(a[r] + (pos - off[r]))].cpu().numpy()
-        off32 = off.to(torch.int32).cpu().numpy().astype(np.uint32)
-        ids = np.zeros(n_new, dtype=np.int32)
-        self.lib.phz_intern(self._h, C.c_void_p(blob.ctypes.data), C.c_void_p(off32.ctypes.data), n_new, C.c_void_p(ids.ctypes.data))
-        assert int(ids[-1]) == n_new - 1 and int(self.lib.phz_interner_size(self._h)) == n_new
+        k0 = self._host_size(); n = st["n"]
+        off = st["off"][k0:n + 1].cpu().numpy().astype(np.uint32)
+        b0 = int(off[0])
+        blob = st["blob"][b0:int(off[-1])].cpu().numpy()
+        off = (off - np.uint32(b0)).astype(np.uint32)
+        ids = np.zeros(n - k0, dtype=np.int32)
+        self.lib.phz_intern(self._h, C.c_void_p(blob.ctypes.data), C.c_void_p(off.ctypes.data), n - k0, C.c_void_p(ids.ctypes.data))
+        assert int(ids[-1]) == n - 1 and self._host_size() == n
+
+    def intern_device(self, ctx, qnames, qname_off, n: int):
+        """ids of a device-resident shard (qnames uint8 [cuda], qname_off int32 [n + 1, cuda]); None when this chromosome's names
+        already live on the host table only."""
+        import ctypes as C
+        st = self._store
+        if st is None and self._host_size() > 0:
+            return None
+        dev = qnames.device
+        n_old = st["n"] if st else 0
+        qid = torch.empty(max(1, n), dtype=torch.int32, device=dev); first = torch.empty(max(1, n), dtype=torch.int32, device=dev)
+        nn = C.c_int64(0)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        rc = self.lib.phz_intern_device(ctx.h, P(qnames), P(qname_off), n, P(st["blob"]) if st else None, P(st["off"]) if st else None, n_old,
+                                        P(qid), P(first), C.byref(nn))
+        ctx.check(rc)
+        m = int(nn.value)
+        if m:
+            base = st["bytes"] if st else 0
+            new_off = torch.empty(m + 1, dtype=torch.int32, device=dev)
+            tot = C.c_int64(0)
+            ctx.check(self.lib.phz_names_append_device(ctx.h, P(qnames), P(qname_off), P(first), m, base, P(new_off), None, C.byref(tot)))
+            total = int(tot.value)
+            if st and st["blob"].numel() >= total:
+                blob = st["blob"]
+            else:                                   # grow geometrically: a sample's BAMs arrive one after the other
+                blob = torch.empty(max(total, int(1.5 * (st["blob"].numel() if st else 0))), dtype=torch.uint8, device=dev)
+                if st:
+                    blob[:base] = st["blob"][:base]
+            ctx.check(self.lib.phz_names_append_device(ctx.h, P(qnames), P(qname_off), P(first), m, base, P(new_off), P(blob), C.byref(tot)))
+            off = torch.cat([st["off"][:n_old], new_off]) if st else new_off
+            self._store = {"blob": blob, "off": off, "n": n_old + m, "bytes": total}
+        elif st is None:
+            self._store = {"blob": torch.empty(1, dtype=torch.uint8, device=dev), "off": torch.zeros(1, dtype=torch.int32, device=dev), "n": 0, "bytes": 0}
+        return qid[:n]
 
     @property
     def h(self):
-        self._materialize()
+        """the C++ table, for host-side interning: brought up to date, and from now on the only home of this chromosome's names"""
+        self._sync()
+        self._store = None
         return self._h
 
     def __len__(self):
-        if self._deferred is not None:
-            return self._deferred[3]
-        return int(self.lib.phz_interner_size(self._h))
+        return max(self._host_size(), self._store["n"] if self._store else 0)
 
     @property
     def names(self) -> List[str]:
         import ctypes as C
-        h = self.h
-        n = len(self)
+        self._sync()
+        n = self._host_size()
         off = np.zeros(n + 1, dtype=np.uint32)
         cap = 1 << 20
         while True:
             blob = np.zeros(cap, dtype=np.uint8)
-            st = self.lib.phz_interner_names(h, C.c_void_p(blob.ctypes.data), cap, C.c_void_p(off.ctypes.data))
+            st = self.lib.phz_interner_names(self._h, C.c_void_p(blob.ctypes.data), cap, C.c_void_p(off.ctypes.data))
             if st == 0:
                 break
             cap = int(off[n]) + 16
@@ -403,15 +430,10 @@ def shards_from_bam_device(ctx, path: str, interners: Dict[str, "NativeInterner"
                            t["qual"][:int(sz.n_seq_bytes) * 4])
         it = interners.setdefault(chrom, NativeInterner())
         ti = _t.perf_counter()
-        if len(it) == 0:
-            # first BAM of the chromosome: ids on the device, the names stay there until something asks for them
-            qid_d = torch.empty(n, dtype=torch.int32, device=dev); first_d = torch.empty(n, dtype=torch.int32, device=dev)
-            nn = C.c_int64(0)
-            ctx.check(lib.phz_intern_device(ctx.h, C.c_void_p(t["qnames"].data_ptr()), C.c_void_p(t["qname_off"].data_ptr()), n, 0,
-                                            C.c_void_p(qid_d.data_ptr()), C.c_void_p(first_d.data_ptr()), C.byref(nn)))
-            it.defer(t["qnames"][:int(sz.n_qname_bytes)], t["qname_off"][:n + 1], first_d, nn.value)
+        qid_d = it.intern_device(ctx, t["qnames"], t["qname_off"], n)
+        if qid_d is not None:
             sh.qid = qid_d
-        else:
+        else:                                   # this chromosome's names are on the host table (an earlier BAM went through the host decoder)
             qn = t["qnames"][:int(sz.n_qname_bytes)].cpu().numpy(); qo = t["qname_off"][:n + 1].cpu().numpy()
             qid = np.zeros(n, dtype=np.int32)
             lib.phz_intern(it.h, C.c_void_p(qn.ctypes.data), C.c_void_p(qo.ctypes.data), n, C.c_void_p(qid.ctypes.data))

@@ -327,47 +327,80 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t *d, KeptOut K, int64
 }
 
 // ---- QNAME interning on the device: ids in first-appearance order (what a sequential dictionary would hand out; mates and
-// repeated templates share an id).  Open-addressing table of record indices keyed by a 64-bit hash of the name, equality decided
-// by comparing the name bytes; a slot belongs to one name for good, its value converges to the smallest record index of that name.
+// repeated templates share an id), continuing the numbering of the BAMs seen before.  The names of the ids handed out so far live
+// in a device-side store (blob + offsets, id order).  Per call: an open-addressing table keyed by a 64-bit hash of the name, equality
+// decided by comparing the name bytes; a slot belongs to one name for good.  Slot values: an OLD id (< 2^31), or 2^31 | record index
+// of a name that is new in this call -- that value converges to the smallest record index of the name.
+constexpr uint32_t NEWBIT = 0x80000000u, EMPTY = 0xFFFFFFFFu;
 __device__ __forceinline__ uint64_t name_hash(const char *p, uint32_t n) {
     uint64_t h = 0xcbf29ce484222325ull;
     for (uint32_t i = 0; i < n; i++) { h ^= (uint8_t)p[i]; h *= 0x100000001b3ull; }
     h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
     return h;
 }
-__device__ __forceinline__ bool name_eq(const char *blob, const uint32_t *off, uint32_t a, uint32_t b) {
-    const uint32_t la = off[a + 1] - off[a], lb = off[b + 1] - off[b];
+__device__ __forceinline__ bool bytes_eq(const char *pa, uint32_t la, const char *pb, uint32_t lb) {
     if (la != lb) return false;
-    const char *pa = blob + off[a], *pb = blob + off[b];
     for (uint32_t i = 0; i < la; i++) if (pa[i] != pb[i]) return false;
     return true;
 }
-__global__ __launch_bounds__(256) void k_intern_insert(const char *blob, const uint32_t *off, int64_t n, uint32_t *table, uint32_t mask, uint32_t *slot_of) {
+// the names already in the store claim their slots (they are distinct: no comparisons)
+__global__ __launch_bounds__(256) void k_intern_old(const char *store, const uint32_t *store_off, int64_t n_old, uint32_t *table, uint32_t mask) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n_old) return;
+    uint32_t s = (uint32_t)name_hash(store + store_off[id], store_off[id + 1] - store_off[id]) & mask;
+    while (atomicCAS(&table[s], EMPTY, (uint32_t)id) != EMPTY) s = (s + 1) & mask;
+}
+__global__ __launch_bounds__(256) void k_intern_insert(const char *blob, const uint32_t *off, int64_t n, const char *store, const uint32_t *store_off,
+                                                       uint32_t *table, uint32_t mask, uint32_t *slot_of) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    uint32_t s = (uint32_t)name_hash(blob + off[i], off[i + 1] - off[i]) & mask;
+    const char *nm = blob + off[i];
+    const uint32_t ln = off[i + 1] - off[i];
+    const uint32_t mine = NEWBIT | (uint32_t)i;
+    uint32_t s = (uint32_t)name_hash(nm, ln) & mask;
     for (;;) {
         uint32_t cur = table[s];
-        if (cur == 0xFFFFFFFFu) {
-            cur = atomicCAS(&table[s], 0xFFFFFFFFu, (uint32_t)i);
-            if (cur == 0xFFFFFFFFu) break;                       // claimed for this name
+        if (cur == EMPTY) {
+            cur = atomicCAS(&table[s], EMPTY, mine);
+            if (cur == EMPTY) break;                             // claimed for this name
         }
-        if (cur == (uint32_t)i || name_eq(blob, off, cur, (uint32_t)i)) { atomicMin(&table[s], (uint32_t)i); break; }
+        if (cur & NEWBIT) {                                      // a name that is new in this call: compare with that record's name
+            const uint32_t j = cur & ~NEWBIT;
+            if (j == (uint32_t)i || bytes_eq(nm, ln, blob + off[j], off[j + 1] - off[j])) { atomicMin(&table[s], mine); break; }
+        } else if (bytes_eq(nm, ln, store + store_off[cur], store_off[cur + 1] - store_off[cur])) break;      // a name of an earlier BAM
         s = (s + 1) & mask;
     }
     slot_of[i] = s;
 }
 __global__ __launch_bounds__(256) void k_intern_first(const uint32_t *table, const uint32_t *slot_of, int64_t n, uint32_t *first) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) first[i] = table[slot_of[i]] == (uint32_t)i ? 1u : 0u;
+    if (i < n) first[i] = table[slot_of[i]] == (NEWBIT | (uint32_t)i) ? 1u : 0u;
 }
 __global__ __launch_bounds__(256) void k_intern_assign(const uint32_t *table, const uint32_t *slot_of, const uint32_t *first, const uint32_t *rank, int64_t n,
                                                        int32_t base, int32_t *qid, int32_t *first_idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t rep = table[slot_of[i]];
-    qid[i] = base + (int32_t)rank[rep];
+    const uint32_t v = table[slot_of[i]];
+    qid[i] = (v & NEWBIT) ? base + (int32_t)rank[v & ~NEWBIT] : (int32_t)v;
     if (first[i]) first_idx[rank[i]] = (int32_t)i;
+}
+// the names of the new ids appended to a store: name k = blob[off[first_idx[k]] ..), written at dst_off[k]
+__global__ __launch_bounds__(256) void k_names_gather(const char *blob, const uint32_t *off, const int32_t *first_idx, int64_t m, const uint32_t *dst_off, char *dst) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const int32_t i = first_idx[k];
+    const char *src = blob + off[i];
+    const uint32_t ln = off[i + 1] - off[i];
+    char *d = dst + dst_off[k];
+    for (uint32_t t = 0; t < ln; t++) d[t] = src[t];
+}
+__global__ void k_add_u32(uint32_t *a, int64_t n, uint32_t x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += x;
+}
+__global__ __launch_bounds__(256) void k_names_len(const uint32_t *off, const int32_t *first_idx, int64_t m, uint32_t *len) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < m) { const int32_t i = first_idx[k]; len[k] = off[i + 1] - off[i]; }
 }
 
 }  // namespace
@@ -429,8 +462,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
         runs.emplace_back(run_a, run_b);
         for (auto &r : runs) { run_dev.push_back(comp_bytes); comp_bytes += (r.second - r.first + 15) & ~(uint64_t)15; }
     }
-    // inflated layout: members back to back in file order; dev offset of a global inflated offset u = u - dst(first member of its
-    // contiguous member run) + base of that run.  Members of one piece are contiguous in the file, so one base per piece suffices.
+    // inflated layout: the needed members back to back in file order (mem_dev_dst[i] = where member i's output starts)
     std::vector<uint64_t> mem_dev_dst(plan.members.size());
     {
         size_t ri = 0;
@@ -560,9 +592,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
             if ((o.flags & 1) && prev_clean) return fail(PHZ_E_ARG, "truncated or corrupt BAM record");
             if ((o.flags & 2) && prev_clean) {
                 if (last_of_piece) return fail(PHZ_E_ARG, "truncated or corrupt BAM record");      // ran past the end of the piece
-                const uint64_t e = o.end_pos;
                 if (hipMemcpyAsync(dstart + k + 1, &hso[(size_t)k].end_pos, 8, hipMemcpyHostToDevice, sm) != hipSuccess) return fail(PHZ_E_HIP, "boundary repair");
-                (void)e;
                 repaired++;
             }
             prev_clean = (o.flags & 3) == 0;
@@ -678,19 +708,21 @@ int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst) {
     return PHZ_OK;
 }
 
-// QNAME ids of one shard on the device: qid[i] = base + (number of distinct names that first appear before record i's name does), the
-// ids phz_intern hands out for an interner that holds `base` names none of which occurs here (the caller guarantees that: it uses
-// this for the first BAM of a chromosome).  first_idx[0, *n_new) = record index of the first occurrence of every new name, in id order.
-int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, int64_t n, int32_t base, int32_t *qid, int32_t *first_idx,
-                      int64_t *n_new) {
-    if (!ctx || !n_new || n < 0 || (n > 0 && (!qnames || !qname_off || !qid || !first_idx))) return PHZ_E_ARG;
+// QNAME ids of one shard on the device, continuing a numbering: the store holds the names of ids [0, n_old) in id order
+// (store_off[n_old + 1]; NULL / 0 for an empty store).  qid[i] = the id of record i's name (an old id, or n_old + the number of new
+// names that first appear before it does) -- exactly what phz_intern assigns.  first_idx[0, *n_new) = record of the first occurrence
+// of every new name, in id order.
+int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, int64_t n, const char *store, const uint32_t *store_off,
+                      int64_t n_old, int32_t *qid, int32_t *first_idx, int64_t *n_new) {
+    if (!ctx || !n_new || n < 0 || n_old < 0 || (n > 0 && (!qnames || !qname_off || !qid || !first_idx)) || (n_old > 0 && (!store || !store_off)))
+        return PHZ_E_ARG;
     *n_new = 0;
     if (n == 0) return PHZ_OK;
-    if (n >= (1ll << 31) - 16) return PHZ_E_UNSUPPORTED;
+    if (n + n_old >= (1ll << 31) - 16) return PHZ_E_UNSUPPORTED;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t sm = ctx->stream;
     uint64_t cap = 1024;
-    while (cap < 2 * (uint64_t)n) cap <<= 1;
+    while (cap < 2 * (uint64_t)(n + n_old)) cap <<= 1;
     DevBuf *S = ctx->scratch;
     if (int s = phz_reserve(ctx, S[7], cap * 4)) return s;
     if (int s = phz_reserve(ctx, S[8], (size_t)n * 4)) return s;
@@ -699,16 +731,53 @@ int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_of
     uint32_t *table = (uint32_t *)S[7].p, *slot_of = (uint32_t *)S[8].p, *first = (uint32_t *)S[9].p, *rank = (uint32_t *)S[10].p;
     PHZ_HIP(ctx, hipMemsetAsync(table, 0xff, cap * 4, sm));
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_intern_insert, dim3(grid), dim3(256), 0, sm, qnames, qname_off, n, table, (uint32_t)(cap - 1), slot_of);
+    if (n_old > 0) hipLaunchKernelGGL(k_intern_old, dim3((unsigned)((n_old + 255) / 256)), dim3(256), 0, sm, store, store_off, n_old, table, (uint32_t)(cap - 1));
+    hipLaunchKernelGGL(k_intern_insert, dim3(grid), dim3(256), 0, sm, qnames, qname_off, n, store, store_off, table, (uint32_t)(cap - 1), slot_of);
     hipLaunchKernelGGL(k_intern_first, dim3(grid), dim3(256), 0, sm, (const uint32_t *)table, (const uint32_t *)slot_of, n, first);
     if (int s = scan_excl(ctx, first, rank, n, S[6])) return s;
     hipLaunchKernelGGL(k_intern_assign, dim3(grid), dim3(256), 0, sm, (const uint32_t *)table, (const uint32_t *)slot_of, (const uint32_t *)first,
-                       (const uint32_t *)rank, n, base, qid, first_idx);
+                       (const uint32_t *)rank, n, (int32_t)n_old, qid, first_idx);
     PHZ_HIP(ctx, hipGetLastError());
     uint32_t total = 0;
     PHZ_HIP(ctx, hipMemcpyAsync(&total, rank + n, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
     *n_new = (int64_t)total;
+    return PHZ_OK;
+}
+
+// Appends the names of new ids to a store: step 1 (dst == NULL): dst_off[0 .. m] = exclusive prefix sums of their lengths starting at
+// `base_bytes`, *total_bytes = the store's size afterwards; step 2 (dst = the store blob, at least *total_bytes long): copies the bytes.
+int phz_names_append_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, const int32_t *first_idx, int64_t m, uint32_t base_bytes,
+                            uint32_t *dst_off, char *dst, int64_t *total_bytes) {
+    if (!ctx || m < 0 || !total_bytes || (m > 0 && (!qnames || !qname_off || !first_idx || !dst_off))) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t sm = ctx->stream;
+    if (m == 0) { *total_bytes = base_bytes; return PHZ_OK; }
+    const unsigned grid = (unsigned)((m + 255) / 256);
+    if (!dst) {
+        DevBuf *S = ctx->scratch;
+        if (int s = phz_reserve(ctx, S[8], (size_t)m * 4)) return s;
+        if (int s = phz_reserve(ctx, S[9], ((size_t)m + 1) * 4)) return s;
+        uint32_t *len = (uint32_t *)S[8].p, *pre = (uint32_t *)S[9].p;
+        hipLaunchKernelGGL(k_names_len, dim3(grid), dim3(256), 0, sm, qname_off, first_idx, m, len);
+        if (int s = scan_excl(ctx, len, pre, m, S[6])) return s;
+        uint32_t total = 0;
+        PHZ_HIP(ctx, hipMemcpyAsync(&total, pre + m, 4, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));
+        if ((uint64_t)total + base_bytes >= (1ull << 32) - 16) return PHZ_E_UNSUPPORTED;
+        // dst_off = pre + base_bytes (one more tiny pass keeps scan_excl generic)
+        PHZ_HIP(ctx, hipMemcpyAsync(dst_off, pre, ((size_t)m + 1) * 4, hipMemcpyDeviceToDevice, sm));
+        if (base_bytes) {
+            hipLaunchKernelGGL(k_add_u32, dim3((unsigned)((m + 1 + 255) / 256)), dim3(256), 0, sm, dst_off, m + 1, base_bytes);
+            PHZ_HIP(ctx, hipGetLastError());
+        }
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));
+        *total_bytes = (int64_t)total + base_bytes;
+        return PHZ_OK;
+    }
+    hipLaunchKernelGGL(k_names_gather, dim3(grid), dim3(256), 0, sm, qnames, qname_off, first_idx, m, (const uint32_t *)dst_off, dst);
+    PHZ_HIP(ctx, hipGetLastError());
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
     return PHZ_OK;
 }
 
