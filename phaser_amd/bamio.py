@@ -393,9 +393,11 @@ def shards_from_bam_device(ctx, path: str, interners: Dict[str, "NativeInterner"
         st = lib.phz_bamdev_open(ctx.h, path.encode(), arr, len(names), C.byref(f), C.byref(h))
     else:
         st = lib.phz_bamdev_open(ctx.h, path.encode(), None, 0, C.byref(f), C.byref(h))
-    if st == _lib.PHZ_E_UNSUPPORTED:
+    if st in (_lib.PHZ_E_UNSUPPORTED, _lib.PHZ_E_ARG, _lib.PHZ_E_NOMEM):
+        # declined, not enough HBM for the inflated stream, or a file the plan cannot read / a record chain that breaks: the host decoder is the one that reports on files
+        # (same messages as before the device path existed)
         if _prof:
-            _sys.stderr.write("[phz timing]   bam: device path declined (%s), using the host decoder\n" % lib.phz_last_error(ctx.h).decode())
+            _sys.stderr.write("[phz timing]   bam: device path declined (status %d: %s), using the host decoder\n" % (st, lib.phz_last_error(ctx.h).decode()))
         return None
     if st != 0:
         raise _lib.PhzError(st, "cannot read BAM %s: %s" % (path, lib.phz_last_error(ctx.h).decode()))
