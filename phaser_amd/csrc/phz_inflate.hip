@@ -3,9 +3,9 @@
 //
 // A BGZF file is a sequence of independent gzip members of at most 64 KB of payload each (a whole-genome RNA-seq BAM: ~200,000 of
 // them), so the parallelism is across members, not inside one: ONE LANE PER MEMBER, 64 members per wave, a few hundred waves in
-// flight.  A lane is a slow decoder (bit-serial canonical Huffman decode, byte-wise LZ77 copies through global memory), but the
-// whole chip runs tens of thousands of them at once.  Per lane: the code-length counts of the two Huffman codes live in registers
-// (the decode loop over code lengths 1..15 is unrolled, so every count is a fixed register), the symbol tables in LDS
+// flight.  A lane is a slow decoder (one Huffman symbol per step, LZ77 copies through global memory), but the whole chip runs
+// tens of thousands of them at once.  Per lane: the per-length code limits of the two Huffman codes live in registers (15
+// independent comparisons find a code's length: no bit-serial walk, no divergence between lanes), the symbol tables in LDS
 // ([symbol slot][lane] layout: lanes that are at the same slot hit different banks), packed to 25 KB per wave: the kernel lives on
 // memory latency, so the number of waves a CU can hold is its throughput.
 //
@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int IL = 64;             // lanes (members) per workgroup
+constexpr int SCRATCH = 352;        // global scratch per member: 320 code lengths + 16 uint16 counters used while a table is built
 constexpr int MAXL = 288, MAXD = 32, MAXLENS = 320;      // MAXL is a multiple of 32, MAXLENS even (bit plane / nibble packing)
 
 struct BitIn {
@@ -59,21 +60,21 @@ struct BitIn {
     }
 };
 
-// canonical Huffman decode with the per-length counts in registers: code lengths 1..15, symbols of equal length are consecutive
-// in sym[] (ordered by symbol value) -- the classic counting decode, one bit per step, fully unrolled
-template <class SymAt>
-__device__ __forceinline__ int decode_sym(BitIn &in, const uint16_t (&cnt)[16], SymAt sym_at) {
-    int code = 0, first = 0, index = 0;
+// Canonical Huffman decode without a bit-serial walk: the next 15 bits, reversed (DEFLATE packs codes most significant bit first),
+// give the candidate code of every length l as rev >> (15 - l); a code of length l is a real one iff it is below limit[l] =
+// first code of that length + number of codes of that length (prefixes of longer codes are >= limit[l]: canonical order).  The 15
+// comparisons are independent (no dependency chain, no divergence between lanes), the shortest hit is the length, and the symbol
+// sits at base[l] + code in the table that lists symbols in code order.  limit[] lives in registers, base[] in LDS.
+template <class BaseAt, class SymAt>
+__device__ __forceinline__ int decode_sym(BitIn &in, const uint16_t (&limit)[16], BaseAt base_at, SymAt sym_at) {
+    const uint32_t rev = __builtin_bitreverse32((uint32_t)in.bb) >> 17;          // 15 bits, first stream bit on top
+    uint32_t hits = 0;
 #pragma unroll
-    for (int len = 1; len <= 15; len++) {
-        code |= (int)((uint32_t)in.bb & 1u);
-        in.bb >>= 1; in.bc--;
-        const int count = cnt[len];
-        if (code - count < first) return sym_at(index + (code - first));
-        index += count; first += count;
-        first <<= 1; code <<= 1;
-    }
-    return -1;
+    for (int l = 1; l <= 15; l++) hits |= ((rev >> (15 - l)) < (uint32_t)limit[l] ? 1u : 0u) << l;
+    if (hits == 0) return -1;
+    const int len = __builtin_ctz(hits);
+    in.bb >>= len; in.bc -= len;
+    return sym_at(base_at(len) + (int)(rev >> (15 - len)));
 }
 
 struct Member { uint64_t src; uint32_t csize, isize; uint64_t dst; };
@@ -89,13 +90,13 @@ __constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // status codes written to the per-call status word (first failure wins)
 enum { INF_OK = 0, INF_BAD_BLOCK = 1, INF_BAD_CODE = 2, INF_BAD_DIST = 3, INF_OVERRUN = 4, INF_SHORT = 5, INF_BAD_LENS = 6 };
 
-// Per-lane tables in LDS, [slot][lane] (lanes on the same slot hit different banks), squeezed so that six waves fit a CU's 160 KB:
+// Per-lane tables in LDS, [slot][lane] (lanes on the same slot hit different banks), squeezed so that six waves fit a CU's 160 KB (26 KB each):
 // literal/length symbols as 8 low bits + a bit plane for bit 8 (values < 288), distance symbols as bytes.
 struct Tables {
     uint8_t syml_lo[MAXL][IL];
     uint32_t syml_hi[MAXL / 32][IL];
     uint8_t symd[MAXD][IL];
-    uint16_t cnt[16][IL];          // counts, then running offsets while a table is filled
+    int16_t basel[16][IL], based[16][IL];      // per code length: (index of its first symbol in the table) - (its first code)
 };
 struct Lane {
     Tables &t; const int lane;
@@ -114,21 +115,30 @@ struct Lane {
 // canonical code of symbols [first, first + n) with lengths len_at(): counts -> cnt (returned in registers), symbols in code order
 // through `put`; returns "left" of the Kraft sum (0 complete, > 0 incomplete, < 0 over-subscribed) and the number of coded symbols
 template <class Put>
-__device__ __forceinline__ int build_code(Lane &L, int first, int n, uint16_t (&cnt)[16], int *coded, Put put) {
-    Tables &t = L.t; const int lane = L.lane;
-    for (int l = 0; l < 16; l++) t.cnt[l][lane] = 0;
-    for (int i = 0; i < n; i++) t.cnt[L.len_at(first + i)][lane]++;
+__device__ __forceinline__ int build_code(Lane &L, int first, int n, uint16_t (&limit)[16], int16_t (*base)[IL], int *coded, Put put) {
+    const int lane = L.lane;
+    uint16_t *tc = (uint16_t *)(L.lens + MAXLENS);       // counts, then running offsets while the table is filled (global scratch: rare)
+    for (int l = 0; l < 16; l++) tc[l] = 0;
+    for (int i = 0; i < n; i++) tc[L.len_at(first + i)]++;
+    uint16_t cnt[16];
 #pragma unroll
-    for (int l = 0; l < 16; l++) cnt[l] = t.cnt[l][lane];
+    for (int l = 0; l < 16; l++) cnt[l] = tc[l];
     int left = 1;
 #pragma unroll
     for (int l = 1; l <= 15; l++) { left <<= 1; left -= cnt[l]; }
     *coded = n - cnt[0];
     if (left < 0) return left;
-    uint16_t off = 0;
+    uint32_t off = 0, code = 0;
+    limit[0] = 0;
 #pragma unroll
-    for (int l = 1; l <= 15; l++) { t.cnt[l][lane] = off; off += cnt[l]; }
-    for (int i = 0; i < n; i++) { const int l = L.len_at(first + i); if (l) put((int)t.cnt[l][lane]++, i); }
+    for (int l = 1; l <= 15; l++) {
+        tc[l] = (uint16_t)off;
+        base[l][lane] = (int16_t)((int)off - (int)code);
+        limit[l] = (uint16_t)(code + cnt[l]);            // <= 2^l <= 32768
+        off += cnt[l];
+        code = (code + cnt[l]) << 1;
+    }
+    for (int i = 0; i < n; i++) { const int l = L.len_at(first + i); if (l) put((int)tc[l]++, i); }
     return left;
 }
 
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
     const int lane = threadIdx.x;
     const int64_t m = (int64_t)blockIdx.x * IL + lane;
     if (m >= n_members) return;
-    Lane L{T, lane, lens_scratch + m * MAXLENS};
+    Lane L{T, lane, lens_scratch + m * SCRATCH};
     const Member M = mem[m];
     uint8_t *o = out + M.dst;
     uint32_t op = 0;
@@ -181,12 +191,12 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
             for (int i = 0; i < ncode; i++) { in.refill(); L.set_len(c_clorder[i], (int)in.bits(3)); }
             uint16_t cc[16];
             int coded;
-            if (build_code(L, 0, 19, cc, &coded, [&](int k, int sym) { T.symd[k][lane] = (uint8_t)sym; }) < 0) { err = INF_BAD_LENS; break; }
+            if (build_code(L, 0, 19, cc, T.based, &coded, [&](int k, int sym) { T.symd[k][lane] = (uint8_t)sym; }) < 0) { err = INF_BAD_LENS; break; }
             // literal/length and distance code lengths, run-length coded
             int idx = 0;
             while (idx < nlen + ndist && !err) {
                 in.refill();
-                const int sym = decode_sym(in, cc, [&](int k) { return (int)T.symd[k & (MAXD - 1)][lane]; });
+                const int sym = decode_sym(in, cc, [&](int l) { return (int)T.based[l][lane]; }, [&](int k) { return (int)T.symd[k & (MAXD - 1)][lane]; });
                 if (sym < 0) { err = INF_BAD_CODE; break; }
                 if (sym < 16) L.set_len(idx++, sym);
                 else {
@@ -208,16 +218,16 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
         }
         {
             int coded;
-            const int left = build_code(L, 0, nlen, cl, &coded, [&](int k, int sym) { L.set_syml(k, sym); });
+            const int left = build_code(L, 0, nlen, cl, T.basel, &coded, [&](int k, int sym) { L.set_syml(k, sym); });
             if (left < 0 || (left > 0 && coded != 1)) { err = INF_BAD_LENS; break; }
             // incomplete is fine for a single one-bit code, and for NO distance codes at all (a block of literals only)
-            const int leftd = build_code(L, 288, ndist, cd, &coded, [&](int k, int sym) { T.symd[k][lane] = (uint8_t)sym; });
+            const int leftd = build_code(L, 288, ndist, cd, T.based, &coded, [&](int k, int sym) { T.symd[k][lane] = (uint8_t)sym; });
             if (leftd < 0 || (leftd > 0 && coded > 1)) { err = INF_BAD_LENS; break; }
         }
         // the block's symbols
         for (;;) {
             in.refill();
-            int sym = decode_sym(in, cl, [&](int k) { return L.syml(k < MAXL ? k : 0); });
+            int sym = decode_sym(in, cl, [&](int l) { return (int)T.basel[l][lane]; }, [&](int k) { return L.syml((unsigned)k < (unsigned)MAXL ? k : 0); });
             if (sym < 0) { err = INF_BAD_CODE; break; }
             if (sym < 256) {
                 if (op >= oend) { err = INF_OVERRUN; break; }
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
             in.refill();
             const uint32_t len = c_lbase[sym] + in.bits(c_lext[sym]);
             in.refill();
-            const int ds = decode_sym(in, cd, [&](int k) { return (int)T.symd[k & (MAXD - 1)][lane]; });
+            const int ds = decode_sym(in, cd, [&](int l) { return (int)T.based[l][lane]; }, [&](int k) { return (int)T.symd[k & (MAXD - 1)][lane]; });
             if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
             in.refill();
             const uint32_t dist = c_dbase[ds] + in.bits(c_dext[ds]);
@@ -269,11 +279,11 @@ int phz_inflate_launch(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member 
                        uint8_t *lens_scratch, int *d_status, hipStream_t s) {
     if (count <= 0) return PHZ_OK;
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)((count + IL - 1) / IL)), dim3(IL), 0, s, comp, (const Member *)members + first, count, out,
-                       lens_scratch + first * MAXLENS, d_status);
+                       lens_scratch + first * SCRATCH, d_status);
     PHZ_HIP(ctx, hipGetLastError());
     return PHZ_OK;
 }
-int phz_inflate_scratch_bytes_per_member() { return MAXLENS; }
+int phz_inflate_scratch_bytes_per_member() { return SCRATCH; }
 
 // Inflate `n_members` BGZF members whose compressed bytes sit in device memory.  members[i] = {byte offset of the raw deflate
 // stream in comp, its compressed size, ISIZE, offset of its output in out}; comp 16-byte aligned and readable for 16 bytes past the last member.
@@ -287,7 +297,7 @@ extern "C" int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const 
     if (n_members == 0) return PHZ_OK;
     hipStream_t sm = ctx->stream;
     if (int s = phz_reserve(ctx, ctx->scalars, 64)) return s;
-    if (int s = phz_reserve(ctx, ctx->scratch[11], (size_t)n_members * MAXLENS)) return s;
+    if (int s = phz_reserve(ctx, ctx->scratch[11], (size_t)n_members * SCRATCH)) return s;
     int *d_status = (int *)ctx->scalars.p;
     PHZ_HIP(ctx, hipMemsetAsync(d_status, 0, 4, sm));
     PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
