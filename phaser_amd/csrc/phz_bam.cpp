@@ -314,10 +314,11 @@ struct BgzfMap {
         f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
         close(fd);
         if (f == MAP_FAILED) { f = nullptr; return PHZ_E_NOMEM; }
-        size_t off = 0;
-        while (off + 18 <= fsz) {
-            if (f[off] != 0x1f || f[off + 1] != 0x8b) return PHZ_E_ARG;
-            if (!(f[off + 3] & 4)) return PHZ_E_UNSUPPORTED;
+        // one member header: 0 = not a BGZF member header at `off`, else its total size; *xl = XLEN
+        auto header = [&](size_t off, uint16_t *xl, int *why) -> uint32_t {
+            *why = PHZ_E_ARG;
+            if (off + 18 > fsz || f[off] != 0x1f || f[off + 1] != 0x8b) return 0;
+            if (!(f[off + 3] & 4)) { *why = PHZ_E_UNSUPPORTED; return 0; }
             const uint16_t xlen = rd16(f + off + 10);
             size_t x = off + 12, xe = x + xlen;
             uint32_t bsize = 0;
@@ -326,13 +327,73 @@ struct BgzfMap {
                 if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = (uint32_t)rd16(f + x + 4) + 1;
                 x += 4 + slen;
             }
-            if (!bsize) return PHZ_E_UNSUPPORTED;
-            if (off + bsize > fsz || bsize < (uint32_t)xlen + 20) return PHZ_E_ARG;
-            const uint32_t isize = rd32(f + off + bsize - 4);
-            blks.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isize, total});
-            total += isize;
-            off += bsize;
+            if (!bsize) { *why = PHZ_E_UNSUPPORTED; return 0; }
+            if (off + bsize > fsz || bsize < (uint32_t)xlen + 20) return 0;
+            *xl = xlen;
+            return bsize;
+        };
+        // the member chain from `off` up to (not beyond) `stop`: -> where it arrived, members appended without their dst
+        auto walk = [&](size_t off, size_t stop, std::vector<Blk> &out, int *status) -> size_t {
+            while (off < stop && off + 18 <= fsz) {
+                uint16_t xlen; int why;
+                const uint32_t bsize = header(off, &xlen, &why);
+                if (!bsize) { *status = why; return off; }
+                out.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, rd32(f + off + bsize - 4), 0});
+                off += bsize;
+            }
+            return off;
+        };
+        // Big files: the chain is walked in K segments at once.  A segment's first member is GUESSED (the first offset where four
+        // member headers follow each other) and VERIFIED: segment k must arrive exactly where segment k+1 starts; any mismatch falls
+        // back to the one sequential walk.  (The walk is page faults on the mapping: ~0.4 us per member, 250,000 members per genome.)
+        bool done = false;
+        size_t par_min = 256u << 20;
+        { const char *e = getenv("PHZ_BGZF_PAR_MIN"); if (e) par_min = (size_t)atoll(e); }       // tests force the segmented walk on small files
+        const int K = fsz >= par_min ? 16 : 1;
+        if (K > 1) {
+            std::vector<size_t> start((size_t)K + 1, fsz);
+            start[0] = 0;
+            std::vector<std::vector<Blk>> part((size_t)K);
+            std::vector<size_t> arrive((size_t)K, 0);
+            std::vector<int> stt((size_t)K, PHZ_OK);
+            std::vector<std::thread> th;
+            for (int k = 1; k < K; k++)
+                th.emplace_back([&, k] {
+                    const size_t g = fsz / (size_t)K * (size_t)k, lim = std::min(fsz, g + (1u << 20));
+                    for (size_t p = g; p < lim; p++) {
+                        if (f[p] != 0x1f) continue;
+                        size_t q = p; int ok = 0;
+                        while (ok < 4) { uint16_t xl; int why; const uint32_t bs = header(q, &xl, &why); if (!bs) break; ok++; q += bs; if (q >= fsz) { ok = 4; break; } }
+                        if (ok >= 4) { start[(size_t)k] = p; break; }
+                    }
+                });
+            for (auto &x : th) x.join();
+            th.clear();
+            for (int k = 0; k < K; k++)
+                th.emplace_back([&, k] { if (start[(size_t)k] < fsz) arrive[(size_t)k] = walk(start[(size_t)k], start[(size_t)k + 1], part[(size_t)k], &stt[(size_t)k]); else arrive[(size_t)k] = fsz; });
+            for (auto &x : th) x.join();
+            bool ok = true;
+            for (int k = 0; k < K; k++) {
+                if (stt[(size_t)k] != PHZ_OK) ok = false;
+                if (start[(size_t)k] < fsz && start[(size_t)k + 1] < fsz && arrive[(size_t)k] != start[(size_t)k + 1]) ok = false;
+                if (k + 1 < K && start[(size_t)k + 1] < start[(size_t)k]) ok = false;
+            }
+            if (ok) {
+                size_t n = 0;
+                for (auto &v : part) n += v.size();
+                blks.reserve(n);
+                for (auto &v : part) blks.insert(blks.end(), v.begin(), v.end());
+                done = true;
+            }
         }
+        if (!done) {
+            blks.clear();
+            int status = PHZ_OK;
+            const size_t end = walk(0, fsz, blks, &status);
+            if (status != PHZ_OK && end + 18 <= fsz) return status;
+        }
+        total = 0;
+        for (auto &b : blks) { b.dst = total; total += b.isize; }
         return blks.empty() ? PHZ_E_ARG : PHZ_OK;
     }
 };

@@ -433,8 +433,16 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     if (!ctx || !path || !f || !out) return PHZ_E_ARG;
     *out = nullptr;
     const bool timing = getenv("PHZ_TIMING") != nullptr;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[phz timing]     bam device: %-40s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     PhzBamPlan plan;
     if (int st = phz_bam_plan_file(path, ref_names, n_names, &plan)) { phz_bam_plan_release(&plan); return st; }
+    lap("plan (member table, header, chromosome ranges)");
     phz_bamdev *h = new phz_bamdev();
     h->ctx = ctx;
     h->refs = plan.refs;
@@ -488,6 +496,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
         (void)hipFree(d_comp); if (d_mem) (void)hipFree(d_mem);
         delete h; phz_bam_plan_release(&plan); return phz_fail(ctx, PHZ_E_NOMEM, "device BAM buffers");
     }
+    lap("device buffers");
     // H2D and K_inflate overlapped: the members go over in chunks of ~1.3 GB of compressed bytes on a copy stream (the file is pageable
     // memory, so every copy keeps this thread busy staging it), and each chunk's members are inflated on the compute stream as soon as
     // its bytes have arrived -- the copy of chunk c+1 runs while chunk c inflates
@@ -556,7 +565,9 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     ctx->last_ms[PHZ_T_INFLATE] = inflate_ms; ctx->total_ms[PHZ_T_INFLATE] += inflate_ms; ctx->launches[PHZ_T_INFLATE]++;
     (void)hipFree(d_comp); (void)hipFree(d_mem);
     if (st != PHZ_OK || bad) { delete h; phz_bam_plan_release(&plan); if (st == PHZ_OK) ctx->err = "a BGZF member is not valid DEFLATE"; return st != PHZ_OK ? st : PHZ_E_UNSUPPORTED; }
-    phz_bam_plan_release(&plan);
+    lap("H2D + K_inflate (+ free of the compressed copy)");
+    phz_bam_plan_release(&plan);         // (a helper thread does not help: whoever touches the address space next waits for the unmap)
+    lap("unmap of the file");
     // ---- segments
     const uint64_t SEG = 256u << 10;
     std::vector<Seg> segs;
@@ -638,6 +649,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
         if (sum >= (1ull << 31) || sq >= (1ull << 32) - 16 || qn >= (1ull << 32) - 16 || ops >= (1ull << 32) - 16)
             return fail(PHZ_E_UNSUPPORTED, "call exceeds the 32-bit offsets of the device path");
     }
+    lap("segments + counting hop");
     const int64_t nk = (int64_t)total_kept;
     h->n_kept = nk;
     // ---- kept-record list + prefix sums
@@ -675,6 +687,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     (void)hipEventElapsedTime(&ms, e0, e1);
     ctx->last_ms[PHZ_T_BAMPACK] = ms; ctx->total_ms[PHZ_T_BAMPACK] += ms; ctx->launches[PHZ_T_BAMPACK]++;
     (void)hipFree(d_seg);
+    lap("kept-record list + scans");
     if (timing)
         fprintf(stderr, "[phz timing]     bam device: H2D of %.1f MB overlapped with K_inflate (%.1f MB out): %.1f ms wall, first launch to last %.1f ms; boundaries + hop + scans %.1f ms, %lld records kept\n",
                 comp_bytes / 1e6, out_bytes / 1e6, h2d_ms, inflate_ms, ms, (long long)nk);

@@ -254,3 +254,21 @@ def test_empty_qname_record(tmp_path):
     got = bamio.shards_from_bam_native(path, inn, 0, False, False)["c1"]
     assert got.qid.tolist() == want.qid.tolist() == [0, 1, 0, 2]
     assert inn["c1"].names == ["", "a", "b"]
+
+
+def test_segmented_member_walk_gives_the_same_table(tmp_path, monkeypatch):
+    """Files >= 256 MB have their BGZF member chain walked in 16 segments with guessed, then verified, first members; forced here."""
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, gs, ge, w = synth.make_variants("chr21", 1, 8_000_000, 400, 91, n_genes=40)
+    rb = synth.make_reads(v, gs, ge, w, 60_000, 92)
+    path = str(tmp_path / "m.bam")
+    bamio.readbatch_to_bam_native(path, [rb], [("chr21", 46709983), ("chr22", 50818468)], 4)
+    want = bamio.shards_from_bam_native(path, {}, 0, False, False, chroms={"chr21"}, threads=2)["chr21"]
+    monkeypatch.setenv("PHZ_BGZF_PAR_MIN", "0")
+    got = bamio.shards_from_bam_native(path, {}, 0, False, False, chroms={"chr21"}, threads=2)["chr21"]
+    for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
+        assert torch.equal(getattr(got, f), getattr(want, f)), f
+    w0 = bamio.bam_ref_weights(path)
+    monkeypatch.delenv("PHZ_BGZF_PAR_MIN")
+    assert bamio.bam_ref_weights(path) == w0
