@@ -258,6 +258,8 @@ def main(argv=None):
     n_before = len(eng.log)
     files = eng.finish(chunks=True)
     mark("tally + pair tests + components + block phasing + rows")
+    if os.environ.get("PHZ_TIMING"):
+        sys.stderr.write("[phz timing]   finish: %s\n" % ", ".join("%s %.3f" % (k, v) for k, v in eng.stats.items()))
     if files is not None:
         for line in eng.log[n_before:]:
             say(line)
