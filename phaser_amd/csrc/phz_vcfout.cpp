@@ -2,11 +2,14 @@
 // PG / PB / PI / PW / PC / PM (/ PS) filled from the haplotype blocks.  Input is the original VCF text and the sample's
 // column (the reference feeds `gunzip -c | cut -f 1-9,S`), plus per chromosome the block arrays phz_rows_format returned
 // and the variant table's string pools.  Header lines are handled in order, data lines in parallel.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -26,6 +29,7 @@ struct Hit { int32_t chrom, block, i; };       // chromosome, block within it, p
 
 struct ChromIdx {
     std::vector<uint32_t> uid_off, rsid_off, alle_off, maf_off;
+    std::vector<int32_t> blk_of;                // block of every slot e of the block arrays
     std::vector<int64_t> blk_start;             // prefix of blk_size
     std::vector<std::string> names, stat_txt;   // per block: PB text, PC text
 };
@@ -36,11 +40,20 @@ struct Work {
     const phz_vcfout_chrom *chroms;
     int n_chroms;
     std::vector<ChromIdx> idx;
-    std::unordered_map<std::string_view, Hit> lookup;
+    // uid -> (chromosome, slot e of its block arrays): flat open-addressing table, filled by one thread per chromosome (atomic claims).
+    // entry = tag (24 bits of the hash) << 40 | chromosome << 32 | e; the uid text decides equality
+    std::unique_ptr<std::atomic<uint64_t>[]> table; uint64_t tmask = 0;
     int sample_column, gw_phase_vcf;
     double min_confidence;
     std::string_view sep, coi;
 };
+
+inline uint64_t uid_hash(std::string_view s) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char ch : s) { h ^= ch; h *= 0x100000001b3ull; }
+    h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+    return h;
+}
 
 std::string_view pool_at(const char *b, const std::vector<uint32_t> &off, int64_t i) {
     return std::string_view(b + off[(size_t)i], off[(size_t)i + 1] - off[(size_t)i] - 1);
@@ -84,11 +97,24 @@ bool data_line(const Work &W, std::string_view line, std::string &o, int64_t &un
         std::string uid(c[0]);
         { long long pv = strtoll(std::string(c[1]).c_str(), nullptr, 10); uid += W.sep; put_int(uid, pv); }
         for (auto &a : all_alleles) { uid += W.sep; uid.append(a); }
-        auto hit = W.lookup.find(std::string_view(uid));
+        bool found = false; Hit H{0, 0, 0};
+        if (W.table) {
+            const uint64_t hh = uid_hash(uid);
+            for (uint64_t sl = hh & W.tmask;; sl = (sl + 1) & W.tmask) {
+                const uint64_t ent = W.table[sl].load(std::memory_order_relaxed);
+                if (ent == ~0ull) break;
+                if ((ent >> 40) != (hh >> 40)) continue;
+                const int ci = (int)((ent >> 32) & 0xFF); const int64_t e = (int64_t)(ent & 0xFFFFFFFFull);
+                const phz_vcfout_chrom &Cc = W.chroms[ci];
+                if (pool_at(Cc.uid, W.idx[(size_t)ci].uid_off, Cc.blk_var[e]) == std::string_view(uid)) {
+                    const int32_t b = W.idx[(size_t)ci].blk_of[(size_t)e];
+                    H = Hit{ci, b, (int32_t)(e - W.idx[(size_t)ci].blk_start[(size_t)b])}; found = true; break;
+                }
+            }
+        }
         sf.clear();
         auto split_sample = [&]() { split(sample, ':', tsplit); sf.assign(tsplit.begin(), tsplit.end()); if (sf.size() < fmt2.size()) sf.resize(fmt2.size()); };
-        if (hit != W.lookup.end()) {
-            const Hit &H = hit->second;
+        if (found) {
             const phz_vcfout_chrom &C = W.chroms[H.chrom];
             const ChromIdx &X = W.idx[(size_t)H.chrom];
             const int64_t e = X.blk_start[(size_t)H.block] + H.i;
@@ -160,32 +186,76 @@ extern "C" int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_
                                   char **out, int64_t *out_len, int64_t *unphased_phased, int64_t *corrections) {
     if (!text || len < 0 || !out || !out_len || (!chroms && n_chroms)) return PHZ_E_ARG;
     *out = nullptr; *out_len = 0;
+    const bool timing = getenv("PHZ_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[phz timing]     vcf out: %-36s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     Work W;
     W.chroms = chroms; W.n_chroms = n_chroms; W.sample_column = sample_column; W.gw_phase_vcf = gw_phase_vcf; W.min_confidence = min_confidence;
     W.sep = id_separator ? id_separator : "_"; W.coi = chrom_of_interest ? chrom_of_interest : "";
     W.idx.resize((size_t)n_chroms);
+    if (n_chroms > 256) return PHZ_E_ARG;
     size_t total_vars = 0;
     for (int ci = 0; ci < n_chroms; ci++) total_vars += (size_t)chroms[ci].n_blk_vars;
-    W.lookup.reserve(total_vars * 2);
-    for (int ci = 0; ci < n_chroms; ci++) {
-        const phz_vcfout_chrom &C = chroms[ci];
-        ChromIdx &X = W.idx[(size_t)ci];
-        X.uid_off = phztext::pool_offsets(C.uid, C.uid_len); X.rsid_off = phztext::pool_offsets(C.rsid, C.rsid_len);
-        X.alle_off = phztext::pool_offsets(C.alleles, C.alleles_len); X.maf_off = phztext::pool_offsets(C.maf_str, C.maf_str_len);
-        X.blk_start.assign((size_t)C.n_blocks + 1, 0);
-        for (int64_t b = 0; b < C.n_blocks; b++) X.blk_start[(size_t)b + 1] = X.blk_start[(size_t)b] + C.blk_size[b];
-        X.names.resize((size_t)C.n_blocks); X.stat_txt.resize((size_t)C.n_blocks);
-        for (int64_t b = 0; b < C.n_blocks; b++) {
-            std::string &nm = X.names[(size_t)b];
-            for (int64_t e = X.blk_start[(size_t)b]; e < X.blk_start[(size_t)b + 1]; e++) {
-                if (e > X.blk_start[(size_t)b]) nm += ',';
-                const std::string_view r = pool_at(C.rsid, X.rsid_off, C.blk_var[e]);
-                for (char ch : r) nm += ch == ':' ? '_' : ch;
-                W.lookup[pool_at(C.uid, X.uid_off, C.blk_var[e])] = Hit{ci, (int32_t)b, (int32_t)(e - X.blk_start[(size_t)b])};
-            }
-            if (C.blk_stat_int[b]) X.stat_txt[(size_t)b] = "1"; else put_pyfloat(X.stat_txt[(size_t)b], C.blk_stat[b]);
-        }
+    if (total_vars >= (1ull << 32)) return PHZ_E_ARG;
+    if (total_vars) {
+        uint64_t cap = 1024;
+        while (cap < 2 * total_vars) cap <<= 1;
+        W.table.reset(new std::atomic<uint64_t>[cap]);
+        W.tmask = cap - 1;
+        const int nt0 = std::max(1, threads);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt0; t++) th.emplace_back([&, t] { for (uint64_t i = cap * (uint64_t)t / (uint64_t)nt0; i < cap * (uint64_t)(t + 1) / (uint64_t)nt0; i++) W.table[i].store(~0ull, std::memory_order_relaxed); });
+        for (auto &x : th) x.join();
     }
+    {   // per chromosome, in parallel: pool offsets, block starts, PB / PC texts, table entries of its block variants
+        std::atomic<int> next(0);
+        auto work = [&] {
+            for (;;) {
+                const int ci = next.fetch_add(1);
+                if (ci >= n_chroms) break;
+                const phz_vcfout_chrom &C = chroms[ci];
+                ChromIdx &X = W.idx[(size_t)ci];
+                X.uid_off = phztext::pool_offsets(C.uid, C.uid_len); X.rsid_off = phztext::pool_offsets(C.rsid, C.rsid_len);
+                X.alle_off = phztext::pool_offsets(C.alleles, C.alleles_len); X.maf_off = phztext::pool_offsets(C.maf_str, C.maf_str_len);
+                X.blk_start.assign((size_t)C.n_blocks + 1, 0);
+                for (int64_t b = 0; b < C.n_blocks; b++) X.blk_start[(size_t)b + 1] = X.blk_start[(size_t)b] + C.blk_size[b];
+                X.names.resize((size_t)C.n_blocks); X.stat_txt.resize((size_t)C.n_blocks);
+                X.blk_of.resize((size_t)C.n_blk_vars);
+                for (int64_t b = 0; b < C.n_blocks; b++) {
+                    std::string &nm = X.names[(size_t)b];
+                    for (int64_t e = X.blk_start[(size_t)b]; e < X.blk_start[(size_t)b + 1]; e++) {
+                        if (e > X.blk_start[(size_t)b]) nm += ',';
+                        const std::string_view r = pool_at(C.rsid, X.rsid_off, C.blk_var[e]);
+                        for (char ch : r) nm += ch == ':' ? '_' : ch;
+                        X.blk_of[(size_t)e] = (int32_t)b;
+                        const std::string_view u = pool_at(C.uid, X.uid_off, C.blk_var[e]);
+                        const uint64_t hh = uid_hash(u);
+                        const uint64_t ent = (hh >> 40 << 40) | ((uint64_t)ci << 32) | (uint64_t)e;
+                        // a uid that is already there (the same variant listed twice) keeps the LATER entry, as the dict assignment did
+                        for (uint64_t sl = hh & W.tmask;; sl = (sl + 1) & W.tmask) {
+                            uint64_t cur = W.table[sl].load(std::memory_order_relaxed);
+                            if (cur == ~0ull) { if (W.table[sl].compare_exchange_strong(cur, ent, std::memory_order_relaxed)) break; }
+                            if ((cur >> 40) == (hh >> 40) && ((cur >> 32) & 0xFF) == (uint64_t)ci &&
+                                pool_at(C.uid, X.uid_off, C.blk_var[(int64_t)(cur & 0xFFFFFFFFull)]) == u) {
+                                while (cur < ent && !W.table[sl].compare_exchange_weak(cur, ent, std::memory_order_relaxed)) {}
+                                break;
+                            }
+                        }
+                    }
+                    if (C.blk_stat_int[b]) X.stat_txt[(size_t)b] = "1"; else put_pyfloat(X.stat_txt[(size_t)b], C.blk_stat[b]);
+                }
+            }
+        };
+        const int ntc = std::max(1, std::min(threads, n_chroms));
+        if (ntc == 1) work();
+        else { std::vector<std::thread> th; for (int t = 0; t < ntc; t++) th.emplace_back(work); for (auto &x : th) x.join(); }
+    }
+    lap("block names + variant lookup");
     // lines
     std::vector<int64_t> ls(1, 0);
     for (const char *p = text, *e = text + len; p < e;) {
@@ -223,6 +293,7 @@ extern "C" int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_
             else { head.append(line); head += '\n'; }
         }
     }
+    lap("line index + header");
     const size_t ndata = nlines - first_data;
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), (ndata + 8191) / 8192));
     const size_t nchunks = ndata ? (size_t)nt * 4 : 0;
@@ -245,6 +316,7 @@ extern "C" int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_
     };
     if (nt == 1) work();
     else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto &t : th) t.join(); }
+    lap("data lines (threads)");
     size_t total = head.size();
     int64_t up = 0, pc = 0;
     for (auto &P : parts) { if (P.status) return P.status; total += P.o.size(); up += P.up; pc += P.pc; }
@@ -252,8 +324,17 @@ extern "C" int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_
     if (!buf) return PHZ_E_NOMEM;
     size_t w = 0;
     memcpy(buf, head.data(), head.size()); w += head.size();
-    for (auto &P : parts) { memcpy(buf + w, P.o.data(), P.o.size()); w += P.o.size(); }
+    {
+        std::vector<size_t> at(parts.size() + 1, w);
+        for (size_t k = 0; k < parts.size(); k++) at[k + 1] = at[k] + parts[k].o.size();
+        std::atomic<size_t> nx(0);
+        auto cp = [&] { for (;;) { const size_t k = nx.fetch_add(1); if (k >= parts.size()) break; memcpy(buf + at[k], parts[k].o.data(), parts[k].o.size()); std::string().swap(parts[k].o); } };
+        if (nt == 1) cp();
+        else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(cp); for (auto &x : th) x.join(); }
+        w = at[parts.size()];
+    }
     buf[w] = 0;
+    lap("concatenation");
     *out = buf; *out_len = (int64_t)w;
     if (unphased_phased) *unphased_phased = up;
     if (corrections) *corrections = pc;

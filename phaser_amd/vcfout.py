@@ -20,6 +20,8 @@ def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", 
                     gw_phase_vcf: int = 0, min_confidence: float = 0.9, threads: int = 8, as_bytes: bool = False) -> Tuple[str, int, int]:
     """-> (vcf text, unphased_phased, phase_corrections).  eng: the Engine whose finish() ran with want_vcf (its vcf_blocks).
     as_bytes: return the text as bytes (what write_bgzf takes as it is: no decode / encode round trip over ~100 MB)."""
+    import os, sys, time
+    t0 = time.perf_counter()
     lib = _lib.load()
     data = vcf_text.encode() if isinstance(vcf_text, str) else bytes(vcf_text)
     keep = []
@@ -42,13 +44,17 @@ def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", 
         x.blk_hap = A(v["hap"], np.uint8); x.blk_stat_int = A(v["stat_int"], np.uint8); x.blk_cor = A(v["cor"], np.int8)
         x.blk_stat = A(v["stat"], np.float64)
     out = C.c_void_p(); n = C.c_int64(0); up = C.c_int64(0); pc = C.c_int64(0)
+    t1 = time.perf_counter()
     st = lib.phz_vcf_phase_text(C.cast(C.c_char_p(data), C.c_void_p), len(data), int(sample_column), id_separator.encode(),
                                 chromosome_of_interest.encode(), int(gw_phase_vcf), float(min_confidence), arr, len(eng.vcf_blocks),
                                 max(1, int(threads)), C.byref(out), C.byref(n), C.byref(up), C.byref(pc))
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_vcf_phase_text failed (malformed VCF line?)")
+    t2 = time.perf_counter()
     try:
         raw = C.string_at(out, n.value)
+        if os.environ.get("PHZ_TIMING"):
+            sys.stderr.write("[phz timing]     vcf out (python): inputs %.3f s, native %.3f s, copy out %.3f s\n" % (t1 - t0, t2 - t1, time.perf_counter() - t2))
         return (raw if as_bytes else raw.decode()), int(up.value), int(pc.value)
     finally:
         lib.phz_buf_free(out)
