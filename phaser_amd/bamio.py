@@ -377,7 +377,7 @@ def shards_from_bam_native(path: str, interners: Dict[str, "NativeInterner"], ma
 
 
 def shards_from_bam_device(ctx, path: str, interners: Dict[str, "NativeInterner"], mapq: int, remove_dups: bool, paired_end: bool,
-                           isize_cutoff: float = 0.0, chroms=None, device="cuda:0", threads: int = 0) -> Optional[Dict[str, soa.ReadShard]]:
+                           isize_cutoff: float = 0.0, chroms=None, device="cuda:0", threads: int = 0, _depth: int = 0) -> Optional[Dict[str, soa.ReadShard]]:
     """The same shards as shards_from_bam_native, decoded ON THE GPU (phz_bamdev_*: K_inflate, record hop, k_pack) and left in HBM.
     QNAME interning stays on the host (the interner persists across BAMs): the name bytes are the only part that travels back.
     Returns None when the file needs the host path (the library says PHZ_E_UNSUPPORTED; the reason goes to stderr under PHZ_TIMING)."""
@@ -393,6 +393,25 @@ def shards_from_bam_device(ctx, path: str, interners: Dict[str, "NativeInterner"
         st = lib.phz_bamdev_open(ctx.h, path.encode(), arr, len(names), C.byref(f), C.byref(h))
     else:
         st = lib.phz_bamdev_open(ctx.h, path.encode(), None, 0, C.byref(f), C.byref(h))
+    if st == _lib.PHZ_E_UNSUPPORTED and b"32-bit offsets" in (lib.phz_last_error(ctx.h) or b"") and _depth < 6:
+        # a very deep BAM: one call is limited to 2^32 bytes of names / base groups -- decode the chromosomes in two halves of
+        # about equal compressed size (the member ranges of each half are all that is copied and inflated)
+        w = bam_ref_weights(path, threads)
+        names_all = [c for c in (chroms if chroms is not None else list(w)) if w.get(str(c), 0) > 0 or chroms is not None]
+        if len(names_all) > 1:
+            order = sorted(names_all, key=lambda c: -w.get(str(c), 0))
+            halves = ([], []); tot = [0, 0]
+            for c in order:
+                k = 0 if tot[0] <= tot[1] else 1
+                halves[k].append(c); tot[k] += w.get(str(c), 0)
+            merged = {}
+            for part in halves:
+                sub = shards_from_bam_device(ctx, path, interners, mapq, remove_dups, paired_end, isize_cutoff, chroms=part, device=device,
+                                             threads=threads, _depth=_depth + 1)
+                if sub is None:
+                    return None
+                merged.update(sub)
+            return merged
     if st in (_lib.PHZ_E_UNSUPPORTED, _lib.PHZ_E_ARG, _lib.PHZ_E_NOMEM):
         # declined, not enough HBM for the inflated stream, or a file the plan cannot read / a record chain that breaks: the host decoder is the one that reports on files
         # (same messages as before the device path existed)

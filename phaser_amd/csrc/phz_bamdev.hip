@@ -646,7 +646,9 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
             }
             sum += o.kept; sq += o.sq_sum; qn += o.qn_sum; ops += o.op_sum;
         }
-        if (sum >= (1ull << 31) || sq >= (1ull << 32) - 16 || qn >= (1ull << 32) - 16 || ops >= (1ull << 32) - 16)
+        uint64_t lim = (1ull << 32) - 16;
+        { const char *e = getenv("PHZ_BAMDEV_LIMIT"); if (e) lim = (uint64_t)atoll(e); }      // tests lower it to exercise the caller's split
+        if (sum >= (1ull << 31) || sq >= lim || qn >= lim || ops >= lim)
             return fail(PHZ_E_UNSUPPORTED, "call exceeds the 32-bit offsets of the device path");
     }
     lap("segments + counting hop");

@@ -277,3 +277,18 @@ def test_device_path_on_corrupt_bam_streams(ctx, tmp_path):
             outcomes["same"] += 1
     torch.cuda.synchronize()
     assert outcomes["same"] >= 10 and outcomes.get("declined (host path decides)", 0) + outcomes["both raise"] >= 20, outcomes
+
+
+def test_deep_bam_is_decoded_in_chromosome_halves(ctx, tmp_path, monkeypatch):
+    """One device call is limited to 2^32 bytes of names / base groups; beyond that the loader splits the chromosomes into halves
+    (lowered limit here) and the result is still the host decoder's."""
+    from phaser_amd import bamio
+    path = _two_chrom_bam(tmp_path)
+    host = bamio.shards_from_bam_native(path, {}, 0, False, False, threads=2)
+    monkeypatch.setenv("PHZ_BAMDEV_LIMIT", str(300_000))          # either chromosome fits (152k and 228k base groups), both together do not
+    di = {}
+    dev = bamio.shards_from_bam_device(ctx, path, di, 0, False, False)
+    assert dev is not None
+    _same(host, {c: dev[c] for c in host}, "split")
+    monkeypatch.setenv("PHZ_BAMDEV_LIMIT", "1000")                # nothing fits: declined, the host path takes over
+    assert bamio.shards_from_bam_device(ctx, path, {}, 0, False, False) is None
