@@ -1308,8 +1308,12 @@ int phz_tabix_build(const char *bgzf_path, int preset, int threads) {
     RawBuf text;
     if (int s2 = inflate_bgzf_file(bgzf_path, threads, text)) return s2;
     const char *d = (const char *)text.data(); const size_t n = text.size();
+    size_t vb = 0;                       // lines are visited front to back: the member of a position only moves forward
     auto voff = [&](uint64_t upos) -> uint64_t {
-        size_t b = (size_t)(std::upper_bound(ustart.begin(), ustart.end() - 1, upos) - ustart.begin()) - 1;
+        size_t b = vb;
+        if (ustart[b] > upos) b = 0;
+        while (b + 2 < ustart.size() && ustart[b + 1] <= upos) b++;
+        vb = b;
         while (b + 2 < ustart.size() && ustart[b + 1] == ustart[b]) b++;           // skip empty members
         return (coff[b] << 16) | (upos - ustart[b]);
     };
@@ -1335,9 +1339,17 @@ int phz_tabix_build(const char *bgzf_path, int preset, int threads) {
             const char *t1 = (const char *)memchr(c0, '\t', (size_t)(le - c0));
             if (!t1) return PHZ_E_ARG;
             const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
-            const std::string chrom(c0, (size_t)(t1 - c0));
+            const std::string_view chrom_sv(c0, (size_t)(t1 - c0));
             int64_t beg, end;
-            const long long v1 = strtoll(std::string(t1 + 1, (size_t)((t2 ? t2 : le) - t1 - 1)).c_str(), nullptr, 10);
+            auto to_ll = [](const char *a, const char *z) {           // strtoll(..., 10) of [a, z): blanks, sign, digits
+                while (a < z && (*a == ' ' || *a == '\t')) a++;
+                bool neg = false;
+                if (a < z && (*a == '-' || *a == '+')) { neg = *a == '-'; a++; }
+                long long v = 0;
+                while (a < z && *a >= '0' && *a <= '9') { v = v * 10 + (*a - '0'); a++; }
+                return neg ? -v : v;
+            };
+            const long long v1 = to_ll(t1 + 1, t2 ? t2 : le);
             if (preset == 0) {          // VCF: POS is 1-based, the record covers len(REF) bases unless INFO carries END=
                 beg = v1 - 1;
                 const char *t3 = t2 ? (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1)) : nullptr;        // end of ID
@@ -1351,7 +1363,7 @@ int phz_tabix_build(const char *bgzf_path, int preset, int threads) {
                     size_t q = 0;
                     while (q < info.size()) {
                         size_t r = info.find(';', q); if (r == std::string_view::npos) r = info.size();
-                        if (info.substr(q, 4) == "END=") { const long long ev = strtoll(std::string(info.substr(q + 4, r - q - 4)).c_str(), nullptr, 10); if (ev > beg) end = ev; }
+                        if (info.substr(q, 4) == "END=") { const long long ev = to_ll(info.data() + q + 4, info.data() + r); if (ev > beg) end = ev; }
                         q = r + 1;
                     }
                 }
@@ -1359,14 +1371,18 @@ int phz_tabix_build(const char *bgzf_path, int preset, int threads) {
                 if (!t2) return PHZ_E_ARG;
                 const char *t3 = (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1));
                 beg = v1;
-                end = strtoll(std::string(t2 + 1, (size_t)((t3 ? t3 : le) - t2 - 1)).c_str(), nullptr, 10);
+                end = to_ll(t2 + 1, t3 ? t3 : le);
             }
             if (beg < 0) beg = 0;
             if (end <= beg) end = beg + 1;
-            auto it = ref_idx.find(chrom);
             size_t ri;
-            if (it == ref_idx.end()) { ri = refs.size(); ref_idx.emplace(chrom, ri); refs.emplace_back(); refs.back().name = chrom; }
-            else ri = it->second;
+            if (last_ref >= 0 && refs[(size_t)last_ref].name == chrom_sv) ri = (size_t)last_ref;        // the common case: same contig as the line before
+            else {
+                const std::string chrom(chrom_sv);
+                auto it = ref_idx.find(chrom);
+                if (it == ref_idx.end()) { ri = refs.size(); ref_idx.emplace(chrom, ri); refs.emplace_back(); refs.back().name = chrom; }
+                else ri = it->second;
+            }
             Ref &R = refs[ri];
             // tabix needs every contig in one run and ascending starts inside it (it refuses such files too)
             if (((int64_t)ri != last_ref && R.n_rec) || ((int64_t)ri == last_ref && beg < R.last_beg)) return PHZ_E_UNSUPPORTED;
