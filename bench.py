@@ -210,7 +210,8 @@ def main():
     phasing = None
     if not a.no_phasing:
         vs = pvcf.load_variants("\n".join(synth.vcf_lines([workloads_variants(plan, vsets, p) for p in plan])))
-        host_threads = max(1, min(64, (os.cpu_count() or 1) // max(1, world)))
+        # host threads of the row writer: four per CPU the container may really use (quota-aware; the phases are short and bursty), shared by the ranks of the node
+        host_threads = max(1, min(64, 4 * pdist.effective_cpus() // max(1, world)))
         calls_now = [Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i in range(len(chroms))]
         runs = []
         for rep in range(max(1, a.phasing_passes)):
@@ -384,6 +385,7 @@ def bam_path_entry(mapper, dev):
 def configs1_entry(mapper, a, dev):
     """Secondary, labelled entry: the configs[1] shard of round 1 (chr1 full, 40k het SNPs, 50M records) through the same ABI."""
     from phaser_amd import workloads, _lib, synth, vcf as pvcf
+    from phaser_amd import dist as pdist
     from phaser_amd.mapper import Calls
     from phaser_amd.engine import Engine, Config
     torch.cuda.empty_cache()
@@ -412,7 +414,7 @@ def configs1_entry(mapper, a, dev):
         calls = Calls(*[t[:first[0].n] for t in bufs[0]])
         best = None
         for _ in range(max(1, a.phasing_passes)):
-            eng = Engine(vs, ["bench"], Config(baseq=a.baseq, host_threads=max(1, min(64, os.cpu_count() or 1)), want_vcf=False), mapper=mapper)
+            eng = Engine(vs, ["bench"], Config(baseq=a.baseq, host_threads=max(1, min(64, 4 * pdist.effective_cpus())), want_vcf=False), mapper=mapper)
             eng.add_mapped(0, "chr1", shard, calls, int(shard.qid.max()) + 1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -186,3 +186,29 @@ def cleanup_spool():
             os.remove(SPOOL_FILES.pop())
         except OSError:
             pass
+
+
+def effective_cpus() -> int:
+    """CPUs this process can really use: the affinity mask, cut down by the cgroup CPU quota when there is one (a container with
+    256 visible cores and `cpu.max` = 16 CPUs gets throttled for most of every scheduling period if it runs 64 busy threads)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
