@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--records", type=int, default=80_000_000)
     ap.add_argument("--snps", type=int, default=1_500_000)
     ap.add_argument("--baseq", type=int, default=10)
-    ap.add_argument("--phasing-passes", type=int, default=3)
+    ap.add_argument("--phasing-passes", type=int, default=5)
     ap.add_argument("--no-phasing", action="store_true", help="skip the phasing-stage measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
     ap.add_argument("--no-c2", action="store_true", help="skip the secondary configs[1] entry (chr1, 50M records, 40k het SNPs)")
