@@ -266,9 +266,7 @@ def main(argv=None):
         say("#4. Identifying haplotype blocks...")
         say("#5. Phasing blocks...")
         say("#6. Outputting haplotypes...")
-        for name, body in files.items():
-            with open(args.o + "." + name + ".txt", "wb") as f:
-                pdist.write_chunks(f, body)
+        pdist.write_files([(args.o + "." + name + ".txt", body) for name, body in files.items()], threads=max(1, min(16, args.threads)))
         mark("write the five files")
         up = pc = 0
         if args.write_vcf == 1:
