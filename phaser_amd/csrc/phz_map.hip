@@ -541,16 +541,17 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             else s_cx[atomicAdd(&s_ncx, 1)] = (uint16_t)j;
         }
     }
-    // ---- phase 2a: resolve the fast records' bases; iteration o gathers for every lane that has an o-th SNP
+    // ---- phase 2a, first half: the quality / base bytes under the FIRST het SNP of every fast record are requested now and used
+    //      after the multi-op walk below -- the two gathers are dependent global round trips that nothing else in this phase hides
+    uint32_t pre_q[RPT], pre_s[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-        if (!fast_[k]) continue;
-        const int j = k * MAP_BLOCK + tid;
-        const uint32_t soff = s_soff[j];
-        for (int o = 0; o < n_[k]; o++) {
-            const int x = s_vpos[base_[k] + o] - rpos_[k];
-            const int sy = (a.dbg & 1) ? (x & 3) : masked_base(a, soff, x);
-            if (sy != 4) { vmask_[k] |= 1u << o; codes_[k] |= (uint32_t)(sy < 4 ? sy : 4) << (4 * o); }
+        pre_q[k] = 0; pre_s[k] = 0;
+        if (fast_[k] && n_[k] > 0 && !(a.dbg & 1)) {
+            const uint32_t soff = s_soff[k * MAP_BLOCK + tid];
+            const int x = s_vpos[base_[k]] - rpos_[k];
+            pre_q[k] = a.qual[(size_t)soff * 4 + x];
+            pre_s[k] = a.seq2[(size_t)soff + (x >> 2)];
         }
     }
     __syncthreads();
@@ -570,6 +571,23 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         for (int t = tid; t < ncx; t += MAP_BLOCK) {
             const int jf = s_cx[t < nshort ? t : TILE - 1 - (t - nshort)];
             if (jf & 0x8000) { const int j = jf & 0x7FFF; walk_read<0>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], 0, 0, 0); }
+        }
+    }
+    // ---- phase 2a, second half: resolve the fast records' bases (the first one from the bytes requested above)
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        if (!fast_[k]) continue;
+        const int j = k * MAP_BLOCK + tid;
+        const uint32_t soff = s_soff[j];
+        for (int o = 0; o < n_[k]; o++) {
+            const int x = s_vpos[base_[k] + o] - rpos_[k];
+            int sy;
+            if (a.dbg & 1) sy = x & 3;
+            else if (o == 0) {
+                const uint32_t q = pre_q[k], sb = (pre_s[k] >> (2 * (x & 3))) & 3;
+                sy = (int)(q & 0x7f) < a.baseq ? 4 : ((q & 0x80) ? (sb == 0 ? 4 : 5) : (int)sb);
+            } else sy = masked_base(a, soff, x);
+            if (sy != 4) { vmask_[k] |= 1u << o; codes_[k] |= (uint32_t)(sy < 4 ? sy : 4) << (4 * o); }
         }
     }
     __syncthreads();
