@@ -422,35 +422,48 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     const int64_t r0 = tile * TILE;
     const int nr = (int)((a.n - r0) < TILE ? (a.n - r0) : TILE);
 
-    // ---- coalesced streaming loads: pos / seq_off / cigar_off slices into LDS
+    // ---- coalesced streaming loads: pos / seq_off / cigar_off slices, the het-SNP window and the tile's CIGAR words into LDS.
+    //      Every load a lane needs (the window and the CIGAR words almost always fit one and three rounds of the workgroup) is
+    //      REQUESTED before the first LDS store waits for anything: one global round trip at the start of a tile instead of three.
+    VarWin vw;
+    vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = tw.x;
+    vw.wlen = tw.y & 0xFFFF;
+    const bool complete = (tw.y >> 30) & 1;
+    CigWin cw;
+    cw.g = a.cigar; cw.lds = s_cig; cw.c_begin = (uint32_t)tw.z; cw.cap = CIG;
+    uint32_t cnt_w = (uint32_t)tw.w;
+    if (cnt_w > (uint32_t)CIG) cnt_w = CIG;
     int rpos_[RPT];
+    uint32_t soff_[RPT], coff_[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
         const int j = k * MAP_BLOCK + tid;
         const bool ok = j < nr;
         rpos_[k] = ok ? a.pos[r0 + j] : 0;
-        s_pos[j] = rpos_[k];
-        s_soff[j] = ok ? a.seq_off[r0 + j] : 0;
-        s_coff[j] = a.cigar_off[r0 + (ok ? j : nr)];
-        s_mask[j] = 0;
+        soff_[k] = ok ? a.seq_off[r0 + j] : 0;
+        coff_[k] = a.cigar_off[r0 + (ok ? j : nr)];
     }
-    if (tid == 0) { s_coff[TILE] = a.cigar_off[r0 + nr]; s_ncand = 0; s_ncx = 0; s_nlong = 0; }
+    const uint32_t coff_end = a.cigar_off[r0 + nr];
+    int v_first = 0x7fffffff;
+    if (tid < vw.wlen) { const int idx = vw.w0 + tid; v_first = idx < a.nv ? a.vpos[idx] : 0x7fffffff; }
+    uint32_t cg[3] = {0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 3; u++) { const uint32_t j = (uint32_t)tid + (uint32_t)u * MAP_BLOCK; if (j < cnt_w) cg[u] = a.cigar[cw.c_begin + j]; }
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int j = k * MAP_BLOCK + tid;
+        s_pos[j] = rpos_[k]; s_soff[j] = soff_[k]; s_coff[j] = coff_[k]; s_mask[j] = 0;
+    }
+    if (tid == 0) { s_coff[TILE] = coff_end; s_ncand = 0; s_ncx = 0; s_nlong = 0; }
     if (tid < TILE / 32) s_poison[tid] = 0;
-    VarWin vw;
-    vw.g = a.vpos; vw.lds = s_vpos; vw.nv = a.nv; vw.w0 = tw.x;
-    vw.wlen = tw.y & 0xFFFF;
-    const bool complete = (tw.y >> 30) & 1;
-    for (int j = tid; j < vw.wlen; j += MAP_BLOCK) {
+    if (tid < vw.wlen) s_vpos[tid] = v_first;
+    for (int j = tid + MAP_BLOCK; j < vw.wlen; j += MAP_BLOCK) {
         const int idx = vw.w0 + j;
         s_vpos[j] = idx < a.nv ? a.vpos[idx] : 0x7fffffff;
     }
-    CigWin cw;
-    cw.g = a.cigar; cw.lds = s_cig; cw.c_begin = (uint32_t)tw.z; cw.cap = CIG;
-    {
-        uint32_t cnt_w = (uint32_t)tw.w;
-        if (cnt_w > (uint32_t)CIG) cnt_w = CIG;
-        for (uint32_t j = tid; j < cnt_w; j += MAP_BLOCK) s_cig[j] = a.cigar[cw.c_begin + j];
-    }
+#pragma unroll
+    for (int u = 0; u < 3; u++) { const uint32_t j = (uint32_t)tid + (uint32_t)u * MAP_BLOCK; if (j < cnt_w) s_cig[j] = cg[u]; }
+    for (uint32_t j = (uint32_t)tid + 3u * MAP_BLOCK; j < cnt_w; j += MAP_BLOCK) s_cig[j] = a.cigar[cw.c_begin + j];
     __syncthreads();
     CandBuf cb;
     cb.key = s_key; cb.var = s_var; cb.aux0 = s_aux0; cb.aux1 = s_aux1; cb.n = &s_ncand; cb.cap = CAND;
