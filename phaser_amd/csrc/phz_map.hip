@@ -356,18 +356,40 @@ __global__ void k_tile_window(MapBatch bt, int tile_reads) {
     tile_w[4 * T + 3] = (int32_t)n_ops;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave in seven DPP adds (row shifts inside the rows of 16 lanes, then the row
+// broadcasts of gfx9): the shuffle version is six ds_bpermute round trips with their address arithmetic and selects
+__device__ __forceinline__ int wave_incl_scan(int v0) {
+    int v1 = v0 + __builtin_amdgcn_update_dpp(0, v0, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v1 += __builtin_amdgcn_update_dpp(0, v0, 0x112, 0xf, 0xf, true);              // row_shr:2
+    v1 += __builtin_amdgcn_update_dpp(0, v0, 0x113, 0xf, 0xf, true);              // row_shr:3  -> sums of 4
+    v1 += __builtin_amdgcn_update_dpp(0, v1, 0x114, 0xf, 0xe, true);              // row_shr:4, banks 1-3 -> sums of 8
+    v1 += __builtin_amdgcn_update_dpp(0, v1, 0x118, 0xf, 0xc, true);              // row_shr:8, banks 2-3 -> sums inside the row
+    v1 += __builtin_amdgcn_update_dpp(0, v1, 0x142, 0xa, 0xf, true);              // row_bcast:15 into rows 1 and 3
+    v1 += __builtin_amdgcn_update_dpp(0, v1, 0x143, 0xc, 0xf, true);              // row_bcast:31 into rows 2 and 3
+    return v1;
+}
+
+// maximum over the 64 lanes of a wave (same DPP ladder, the result of lane 63 read into a scalar)
+__device__ __forceinline__ int wave_max(int v0) {
+    const int lo = (int)0x80000000;
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    int v1 = mx(v0, __builtin_amdgcn_update_dpp(lo, v0, 0x111, 0xf, 0xf, false));
+    v1 = mx(v1, __builtin_amdgcn_update_dpp(lo, v0, 0x112, 0xf, 0xf, false));
+    v1 = mx(v1, __builtin_amdgcn_update_dpp(lo, v0, 0x113, 0xf, 0xf, false));
+    v1 = mx(v1, __builtin_amdgcn_update_dpp(lo, v1, 0x114, 0xf, 0xe, false));
+    v1 = mx(v1, __builtin_amdgcn_update_dpp(lo, v1, 0x118, 0xf, 0xc, false));
+    v1 = mx(v1, __builtin_amdgcn_update_dpp(lo, v1, 0x142, 0xa, 0xf, false));
+    v1 = mx(v1, __builtin_amdgcn_update_dpp(lo, v1, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v1, 63);
+}
+
 // block-wide exclusive scan of RPT per-thread values laid out at [k*MAP_BLOCK + tid]; returns the block total
 template <int MAP_BLOCK, int RPT>
 __device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT], int (*s_wsum)[MAP_BLOCK / 64], int lane, int wave) {
     int incl[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-        int x = cnt[k];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
+        const int x = wave_incl_scan(cnt[k]);
         incl[k] = x;
         if (lane == 63) s_wsum[k][wave] = x;
     }
@@ -503,10 +525,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     int target = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-        int e = one_[k] ? rpos_[k] + len_[k] : (int)0x80000000;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(e, d); e = y > e ? y : e; }
-        const int first = __shfl(rpos_[k], 0);
+        const int e = wave_max(one_[k] ? rpos_[k] + len_[k] : (int)0x80000000);
+        const int first = __builtin_amdgcn_readfirstlane(rpos_[k]);
         if ((lane / GROUP) == 2 * k) target = first;
         if ((lane / GROUP) == 2 * k + 1) target = e;
     }
