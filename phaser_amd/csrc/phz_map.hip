@@ -543,7 +543,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
         const int j = k * MAP_BLOCK + tid;
-        const int lo = __shfl(bound, 2 * k * GROUP), hi = __shfl(bound, (2 * k + 1) * GROUP);
+        const int lo = __builtin_amdgcn_readlane(bound, 2 * k * GROUP), hi = __builtin_amdgcn_readlane(bound, (2 * k + 1) * GROUP);
         if (one_[k]) {
             const int pos = rpos_[k], end = pos + len_[k];
             if (hi - lo <= 24) {
