@@ -334,17 +334,17 @@ __global__ void k_tile_window(MapBatch bt, int tile_reads) {
     const int nv = sh.nv; const int64_t n = sh.n;
     int32_t *tile_w = bt.tile_w0;
     const int key = pos[t * tile_reads];
-    int lo = 0, hi = nv;
-    while (lo < hi) {
-        int m = (lo + hi) >> 1;
-        if (vpos[m] < key) lo = m + 1; else hi = m;
-    }
     const int64_t last = (t + 1) * tile_reads - 1 < n ? (t + 1) * tile_reads - 1 : n - 1;
     const long long key2 = (long long)pos[last] + MAP_COVER;
-    int lo2 = lo; hi = nv;
-    while (lo2 < hi) {
-        int m = (lo2 + hi) >> 1;
-        if ((long long)vpos[m] < key2) lo2 = m + 1; else hi = m;
+    // both lower bounds in ONE loop over the whole table: their probes are independent, so the two chains of dependent loads
+    // overlap instead of following each other
+    int lo = 0, hi = nv, lo2 = 0, hi2 = nv;
+    while (lo < hi || lo2 < hi2) {
+        const int m = (lo + hi) >> 1, m2 = (lo2 + hi2) >> 1;
+        const bool go = lo < hi, go2 = lo2 < hi2;
+        const int v = go ? vpos[m] : 0, v2 = go2 ? vpos[m2] : 0;
+        if (go) { if (v < key) lo = m + 1; else hi = m; }
+        if (go2) { if ((long long)v2 < key2) lo2 = m2 + 1; else hi2 = m2; }
     }
     int len = lo2 - lo + MAP_SLACK;
     int complete = 1 << 30;
