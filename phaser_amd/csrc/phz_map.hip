@@ -606,6 +606,21 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             if (jf & 0x8000) { const int j = jf & 0x7FFF; walk_read<0>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], 0, 0, 0); }
         }
     }
+    __syncthreads();
+    const int ncand = s_ncand;
+    const bool fb = ncand > CAND;              // candidate buffer overflow: complex records fall back to in-lane work
+    // the bytes of this lane's buffered candidate (if it has one) are requested now and used after the arithmetic below
+    uint32_t cq = 0, cs = 0; int cx_off = -1;
+    if (!fb && tid < ncand && !(a.dbg & 1)) {
+        const uint32_t key = s_key[tid];
+        if ((key & 0xFF) == 7u) {
+            const uint32_t x0 = s_aux0[tid];
+            cx_off = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(s_aux1[tid] >> 12);
+            const uint32_t soff = s_soff[key >> 16];
+            cq = a.qual[(size_t)soff * 4 + cx_off];
+            cs = a.seq2[(size_t)soff + (cx_off >> 2)];
+        }
+    }
     // ---- phase 2a, second half: resolve the fast records' bases (the first one from the bytes requested above)
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -623,9 +638,6 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             if (sy != 4) { vmask_[k] |= 1u << o; codes_[k] |= (uint32_t)(sy < 4 ? sy : 4) << (4 * o); }
         }
     }
-    __syncthreads();
-    const int ncand = s_ncand;
-    const bool fb = ncand > CAND;              // candidate buffer overflow: complex records fall back to in-lane work
     const int64_t slot0 = gtile * (int64_t)a.slot_cap;
     int cnt[RPT], off[RPT];
     if (!fb) {
@@ -638,7 +650,12 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             else if (code == 7) {
                 const uint32_t x0 = s_aux0[e];
                 const int x = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(s_aux1[e] >> 12);
-                const int sy = (a.dbg & 1) ? (x & 3) : masked_base(a, s_soff[j], x);
+                int sy;
+                if (a.dbg & 1) sy = x & 3;
+                else if (e == tid && cx_off == x) {
+                    const uint32_t sb = (cs >> (2 * (x & 3))) & 3;
+                    sy = (int)(cq & 0x7f) < a.baseq ? 4 : ((cq & 0x80) ? (sb == 0 ? 4 : 5) : (int)sb);
+                } else sy = masked_base(a, s_soff[j], x);
                 code = sy < 4 ? sy : (sy == 4 ? -1 : 4);
             }
             if (code >= 0) {
