@@ -53,9 +53,11 @@ struct MapArgs {
     const int32_t *vpos;
     int nv;
     int baseq;
-    // staging slots: global tile t owns stage[t*slot_cap, (t+1)*slot_cap); one packed 16-byte record per call
-    // {var, aux0, aux1, record index inside the tile | code << 16}: one store per call here, one load in k_compact
-    uint4 *stage;
+    // staging slots: global tile t owns stage[t*slot_cap, (t+1)*slot_cap); one packed 8-byte record per call (stage_put):
+    // one store per call here, one load in k_compact
+    uint2 *stage;
+    uint32_t *side;               // [2*slots] aux words that do not fit the packed record (insertions, offsets >= 2^16)
+    int64_t slots;
     const int32_t *tile_w0;       // [4*ntiles]: window start, window length | complete flag, first CIGAR word, CIGAR word count
     int32_t *tile_total;          // [ntiles] calls per tile
     int slot_cap;
@@ -82,7 +84,8 @@ struct MapBatch {
     const ShardDev *shards;
     const int64_t *tile0;         // [n_shards + 1]
     int n_shards, baseq;
-    uint4 *stage;                 // staging slots: global tile T owns [T*slot_cap, (T+1)*slot_cap)
+    uint2 *stage;                 // staging slots: global tile T owns [T*slot_cap, (T+1)*slot_cap)
+    uint32_t *side; int64_t slots;
     int32_t *tile_w0;             // [4*ntiles]
     int32_t *tile_total;          // [ntiles]
     int slot_cap, dbg;
@@ -123,6 +126,17 @@ struct VarWin {
         return l;
     }
 };
+
+// Staging record of one call: {variant index, rec[0:10) | code[10:14) | wide1[14] | wide0[15] | aux0[16:32)}.  aux0 (offset of the
+// base in the read) below 2^16 and aux1 == 0 (no inserted text) is all but a handful of calls; the others keep the full words in the
+// side planes at the same slot, so that the common call is 8 bytes out of k_map and 8 bytes into k_compact.
+__device__ __forceinline__ void stage_put(uint2 *stage, uint32_t *side, int64_t slots, int64_t g, uint32_t var, uint32_t a0, uint32_t a1,
+                                          uint32_t rec, uint32_t code) {
+    const bool w0 = a0 >= 0x10000u, w1 = a1 != 0u;
+    stage[g] = make_uint2(var, rec | (code << 10) | ((uint32_t)w1 << 14) | ((uint32_t)w0 << 15) | (w0 ? 0u : a0 << 16));
+    if (w0) side[g] = a0;
+    if (w1) side[slots + g] = a1;
+}
 
 // the tile's packed CIGAR words: LDS for the staged prefix, global beyond it
 struct CigWin {
@@ -214,7 +228,7 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
                             if (MODE == 2) {
                                 const int64_t o = out_base + cnt;
                                 if (o < out_limit) {
-                                    a.stage[o] = make_uint4((uint32_t)i, x0, x1, (uint32_t)j | ((uint32_t)code << 16));
+                                    stage_put(a.stage, a.side, a.slots, o, (uint32_t)i, x0, x1, (uint32_t)j, (uint32_t)code);
                                 }
                             }
                             cnt++;
@@ -418,7 +432,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         const ShardDev &sh = bt.shards[si];
         a.pos = sh.pos; a.cigar_off = sh.cigar_off; a.cigar = sh.cigar; a.seq_off = sh.seq_off; a.seq2 = sh.seq2; a.qual = sh.qual;
         a.n = sh.n; a.vpos = sh.vpos; a.nv = sh.nv; a.baseq = bt.baseq;
-        a.stage = bt.stage;
+        a.stage = bt.stage; a.side = bt.side; a.slots = bt.slots;
         a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = bt.dbg;
     }
     constexpr int TILE = MAP_BLOCK * RPT;
@@ -693,8 +707,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
                 if (!((vmask_[k] >> o) & 1)) continue;
                 if (o2 < a.slot_cap) {
                     const int64_t g = slot0 + o2;
-                    a.stage[g] = make_uint4((uint32_t)(vw.w0 + base_[k] + o), (uint32_t)(s_vpos[base_[k] + o] - rpos_[k]), 0u,
-                                            (uint32_t)j | (((codes_[k] >> (4 * o)) & 15u) << 16));
+                    stage_put(a.stage, a.side, a.slots, g, (uint32_t)(vw.w0 + base_[k] + o), (uint32_t)(s_vpos[base_[k] + o] - rpos_[k]), 0u,
+                              (uint32_t)j, (codes_[k] >> (4 * o)) & 15u);
                 }
                 o2++;
             }
@@ -711,7 +725,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             const int o = (int)s_coff[j] + __popc(s_mask[j] & ((1u << ord) - 1));
             if (o < a.slot_cap) {
                 const int64_t g = slot0 + o;
-                a.stage[g] = make_uint4((uint32_t)s_var[e], s_aux0[e], s_aux1[e], (uint32_t)j | ((key & 0xFFu) << 16));
+                stage_put(a.stage, a.side, a.slots, g, (uint32_t)s_var[e], s_aux0[e], s_aux1[e], (uint32_t)j, key & 15u);
             }
         }
     }
@@ -792,7 +806,7 @@ __global__ __launch_bounds__(1024) void k_chunk_base(const int64_t *chunk_sum, c
 }
 
 struct CompactArgs {
-    const uint4 *stage;
+    const uint2 *stage; const uint32_t *side; int64_t slots;
     const ShardDev *shards; const int64_t *tile0; int n_shards;
     const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base; const int64_t *shard_base;
     const int32_t *tile_w0;
@@ -816,30 +830,79 @@ __global__ void k_shard_totals(const int64_t *tile0, int n_shards, int64_t ntile
     scal[2 + s] = (unsigned long long)(hi - lo);
 }
 
-// one wave per tile: unpack the tile's slot to its final offset in its shard's output arrays
-__global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
-    const int64_t T = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (T >= c.ntiles) return;
-    const int lane = threadIdx.x & 63;
-    int n = c.tile_total[T];
-    if (n == 0) return;
-    if (n > c.slot_cap) n = c.slot_cap;
-    const int si = (c.tile_w0[4 * T + 1] >> 16) & 0x1FFF;
-    const ShardDev &sh = c.shards[si];
-    const uint4 *src = c.stage + T * (int64_t)c.slot_cap;
-    const int64_t dst = calls_before(c.chunk_base, c.tile_pref, T) - c.shard_base[si];
-    const int32_t r0 = (int32_t)((T - c.tile0[si]) * c.tile_reads);
-    for (int e = lane; e < n; e += 64) {
-        const int64_t o = dst + e;
-        const uint4 w = src[e];
-        if (o < sh.cap) {
-            sh.o_read[o] = r0 + (int32_t)(w.w & 0xFFFFu);
-            sh.o_var[o] = (int32_t)w.x;
-            sh.o_code[o] = (uint8_t)(w.w >> 16);
-            sh.o_aux0[o] = w.y;
-            sh.o_aux1[o] = w.z;
+// One wave per CT consecutive tiles.  A lane first fetches one tile's bookkeeping (count, shard, destination, first record), so the
+// chain of dependent loads a tile needs is paid once per CT tiles; the wave then walks the CT slots as ONE flat list of calls, UNR
+// elements per lane in flight, each finding its tile by a lower bound over the wave's prefix in LDS.  One wave per tile was bound
+// by that chain (~5 round trips for ~60 calls: 254 us per genome whatever the record size); larger CT amortises it further but
+// leaves the tail to the waves that drew the densest tiles (CT 4 / 8 / 16 / 64: 1.50 / 1.49 / 1.50 / 1.52 ms per genome step,
+// 0.91 / 0.93 / 0.96 / 1.08 ms on configs[1], whose calls sit in a few tiles).
+#ifndef PHZ_CT
+#define PHZ_CT 4
+#endif
+constexpr int CT = PHZ_CT, CT_UNR = 4;
+template <bool UNI>
+__device__ __forceinline__ void compact_run(const CompactArgs &c, const int *pref, const int64_t *dstv, const int32_t *r0v, const int32_t *siv,
+                                            int64_t T0, int M, int lane, int si0) {
+    for (int e0 = lane; e0 < M; e0 += 64 * CT_UNR) {
+        int k_[CT_UNR]; uint2 w_[CT_UNR]; int64_t g_[CT_UNR];
+#pragma unroll
+        for (int u = 0; u < CT_UNR; u++) {
+            const int e = e0 + 64 * u;
+            int k = 0;
+#pragma unroll
+            for (int st = CT / 2; st > 0; st >>= 1) k += (pref[k + st] <= e) ? st : 0;     // last k with pref[k] <= e
+            k_[u] = k;
+            g_[u] = (T0 + k) * (int64_t)c.slot_cap + (e - pref[k]);
+            w_[u] = e < M ? c.stage[g_[u]] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < CT_UNR; u++) {
+            const int e = e0 + 64 * u;
+            if (e >= M) break;
+            const int k = k_[u];
+            const uint2 w = w_[u];
+            const ShardDev &sh = c.shards[UNI ? si0 : siv[k]];
+            const int64_t o = dstv[k] + (e - pref[k]);
+            uint32_t a0 = w.y >> 16, a1 = 0u;
+            if (w.y & 0x8000u) a0 = c.side[g_[u]];
+            if (w.y & 0x4000u) a1 = c.side[c.slots + g_[u]];
+            if (o < sh.cap) {
+                sh.o_read[o] = r0v[k] + (int32_t)(w.y & 0x3FFu);
+                sh.o_var[o] = (int32_t)w.x;
+                sh.o_code[o] = (uint8_t)((w.y >> 10) & 15u);
+                sh.o_aux0[o] = a0;
+                sh.o_aux1[o] = a1;
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
+    __shared__ int s_pref[4][CT + 1];
+    __shared__ int64_t s_dst[4][CT];
+    __shared__ int32_t s_r0[4][CT], s_si[4][CT];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t T0 = ((int64_t)blockIdx.x * 4 + w) * CT;
+    const int64_t T = T0 + lane;
+    int n = 0, si = -1;
+    if (lane < CT && T < c.ntiles) {
+        n = c.tile_total[T];
+        if (n > c.slot_cap) n = c.slot_cap;
+        si = (c.tile_w0[4 * T + 1] >> 16) & 0x1FFF;
+        s_dst[w][lane] = calls_before(c.chunk_base, c.tile_pref, T) - c.shard_base[si];
+        s_r0[w][lane] = (int32_t)((T - c.tile0[si]) * c.tile_reads);
+        s_si[w][lane] = si;
+    }
+    const int incl = wave_incl_scan(n);
+    if (lane < CT) s_pref[w][lane + 1] = incl;
+    if (lane == 0) s_pref[w][0] = 0;
+    __syncthreads();
+    const int M = __builtin_amdgcn_readlane(incl, CT - 1);
+    if (M == 0) return;
+    const int si0 = __builtin_amdgcn_readfirstlane(si);
+    const bool uni = __ballot(si >= 0 && si != si0) == 0ull;
+    if (uni) compact_run<true>(c, s_pref[w], s_dst[w], s_r0[w], s_si[w], T0, M, lane, si0);
+    else compact_run<false>(c, s_pref[w], s_dst[w], s_r0[w], s_si[w], T0, M, lane, si0);
 }
 
 }  // namespace
@@ -913,7 +976,7 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         if (int s = phz_reserve(ctx, S[18], slots * 16)) return s;
         MapBatch bt;
         bt.shards = d_shards; bt.tile0 = d_tile0; bt.n_shards = m; bt.baseq = baseq;
-        bt.stage = (uint4 *)S[18].p;
+        bt.stage = (uint2 *)S[18].p; bt.side = (uint32_t *)((char *)S[18].p + slots * 8); bt.slots = (int64_t)slots;
         bt.tile_w0 = (int32_t *)ctx->tile_w0.p; bt.tile_total = (int32_t *)S[17].p;
         bt.slot_cap = slot_cap; bt.ntiles = ntiles;
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
@@ -935,12 +998,12 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         hipLaunchKernelGGL(k_shard_totals, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, sm, d_tile0, m, ntiles, (const int32_t *)tile_pref,
                            (const int64_t *)chunk_base, (unsigned long long *)ctx->scalars.p, d_shard_base);
         CompactArgs c;
-        c.stage = bt.stage;
+        c.stage = bt.stage; c.side = bt.side; c.slots = bt.slots;
         c.shards = d_shards; c.tile0 = d_tile0; c.n_shards = m;
         c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base; c.shard_base = d_shard_base;
         c.tile_w0 = bt.tile_w0;
         c.slot_cap = slot_cap; c.tile_reads = tile_reads; c.ntiles = ntiles;
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sm, c);
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 4 * CT - 1) / (4 * CT))), dim3(256), 0, sm, c);
         PHZ_HIP(ctx, hipGetLastError());
         PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)8 * (m + 2), hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));

@@ -103,6 +103,46 @@ def test_random_vs_oracle(mapper, oracle_build, n_pairs, n_snps, baseq, seed):
         assert txt == o_t[k]
 
 
+def test_long_records_wide_offsets(mapper, oracle_build):
+    """Offsets of the called base at and beyond 2^16 and calls carrying inserted text leave the packed 8-byte staging record
+    (side planes, phz_map.hip stage_put): single-run and multi-op records of 200 kb against the oracle, offsets and text included."""
+    from phaser_amd import soa, synth
+    from phaser_amd.read_variant_map import _allele_text
+    from phaser_amd.soa import parse_cigar
+    rng = np.random.default_rng(11)
+    L = 200000
+    cigars = ["200000M", "65530M3I10M2D134457M", "100S65536M5N134364M", "65535M1I134464M", "70000M130000S", "200000M"]
+    n = len(cigars)
+    ops = [[(ln << 4) | op for op, ln in parse_cigar(c)] for c in cigars]
+    coff = np.zeros(n + 1, np.int64); coff[1:] = np.cumsum([len(o) for o in ops])
+    z = torch.zeros(n, dtype=torch.int32)
+    rb = synth.ReadBatch("chr1", L, torch.tensor([1000, 1000, 1000, 1001, 1500, 70000], dtype=torch.int32), z, torch.full((n,), 255, dtype=torch.uint8),
+                         z, z, torch.arange(n, dtype=torch.int32), torch.from_numpy(coff),
+                         torch.tensor([x for o in ops for x in o], dtype=torch.int64),
+                         torch.from_numpy(rng.integers(0, 4, (n, L)).astype(np.uint8)), torch.from_numpy(rng.integers(2, 41, (n, L)).astype(np.uint8)))
+    edge = 1000 + np.array([65528, 65529, 65530, 65531, 65534, 65535, 65536, 65537, 65540, 65541, 65542])
+    vpos = np.unique(np.concatenate([rng.integers(1000, 271000, 400), edge])).astype(np.int32)
+    baseq = 10
+    o_r, o_v, o_c, o_t = oracle_map_readbatch(oracle_build, rb, vpos, baseq)
+    calls = mapper.map(soa.pack_readbatch(rb).to("cuda"), torch.from_numpy(vpos), baseq).cpu()
+    assert calls.n == len(o_r) and calls.n > 500
+    assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v)
+    assert np.array_equal(calls.code.numpy(), o_c)
+    a0 = calls.aux0.numpy().view(np.uint32); a1 = calls.aux1.numpy().view(np.uint32)
+    lut = "ACGTN"
+    wide = texts = 0
+    for k in range(calls.n):
+        r = int(o_r[k])
+        if o_c[k] < 4:
+            assert int(rb.seq[r, int(a0[k])]) == int(o_c[k]) and a1[k] == 0        # the offset names the called base
+            wide += int(a0[k]) >= 65536
+        else:
+            seq = "".join(lut[x] for x in rb.seq[r].tolist()); qual = "".join(chr(33 + q) for q in rb.qual[r].tolist())
+            assert _allele_text(4, int(a0[k]), int(a1[k]), seq, qual, baseq) == o_t[k]
+            texts += 1
+    assert wide > 100 and texts >= 1
+
+
 def test_empty_and_edge_shards(mapper):
     from phaser_amd import soa
     # no reads
