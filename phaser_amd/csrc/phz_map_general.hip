@@ -7,8 +7,11 @@
 //   0..3 = some other single base, 4 = any other text (its read offsets go to an optional pool so the host can print it).
 // This mode is off by default in phASER ("will likely result in poor quality phasing", phaser.py:48); it is built for
 // completeness: one lane per record, count pass + exclusive scan + emit pass.  Records are coordinate-sorted, so a workgroup's 256
-// records share one window start (one uniform search per workgroup, every per-segment search gallops from there), and the emit pass
-// returns at once for the records the count pass found empty (most of them).
+// records share one window of variants: a pre-pass finds each workgroup's window once for both passes, the workgroup stages the
+// window's positions and one packed descriptor per variant (REF length, the two alleles when they are single characters) in LDS,
+// and every per-segment search gallops through LDS from the window start.  A one-base REF under a segment without I / D ops -- the
+// bulk of any real variant set -- is then classified from the descriptor and one (qual, seq) byte pair; everything else takes the
+// general composition below.  The emit pass returns at once for workgroups and records the count pass found empty.
 #include <cstring>
 #include "phz_internal.h"
 #include "phz_scan.h"
@@ -27,6 +30,10 @@ struct GenArgs {
     const uint32_t *aoff;
     const char *abytes;
     int nv, baseq;
+    const int32_t *win;                          // [2 * grid] window start, length per workgroup (k_gen_window)
+    const uint32_t *desc;                        // [nv] ref_len | allele0 char << 8 | allele1 char << 16 (0 = not one character)
+    uint4 *side;                                 // [n] packed calls of the fast pass (k_map_general -> k_gen_emit)
+    uint32_t *wl_n, *wl;                         // records left to the general composition (count pass appends, both list passes read)
     uint32_t *n_calls, *n_text;                  // per record (count pass)
     const uint32_t *call_base, *text_base;       // exclusive scans (emit pass)
     int32_t *o_read, *o_var; uint8_t *o_code; uint32_t *o_aux0, *o_aux1;
@@ -34,12 +41,16 @@ struct GenArgs {
     int64_t cap, text_cap;
 };
 
-__device__ __forceinline__ int sym_at(const GenArgs &a, uint32_t soff, int x) {
-    const uint32_t q = a.qual[(size_t)soff * 4 + x];
-    const uint32_t s = (a.seq2[(size_t)soff + (x >> 2)] >> (2 * (x & 3))) & 3;
-    if ((int)(q & 0x7f) < a.baseq) return 4;
+// "ACGTN?"[sym] without the trip to constant memory
+__device__ __forceinline__ uint32_t sym_char(int sym) { return (uint32_t)((0x3F4E54474341ull >> (8 * sym)) & 0xFFu); }
+__device__ __forceinline__ int sym_of(int baseq, uint32_t q, uint32_t sbyte, int x) {
+    const uint32_t s = (sbyte >> (2 * (x & 3))) & 3;
+    if ((int)(q & 0x7f) < baseq) return 4;
     if (q & 0x80) return s == 0 ? 4 : 5;
     return (int)s;
+}
+__device__ __forceinline__ int sym_at(const GenArgs &a, uint32_t soff, int x) {
+    return sym_of(a.baseq, a.qual[(size_t)soff * 4 + x], a.seq2[(size_t)soff + (x >> 2)], x);
 }
 
 struct Compose {
@@ -50,7 +61,7 @@ struct Compose {
     uint32_t *text;           // where read offsets of this call's characters go (EMIT + pool present), else nullptr
     int64_t text_room;
     __device__ __forceinline__ void add(int sym, uint32_t roff) {
-        const char ch = "ACGTN?"[sym];
+        const char ch = (char)sym_char(sym);
         if (n == 0) first = sym;
         m0 = m0 && ((uint32_t)n < l0) && ab[p0 + n] == ch;
         m1 = m1 && ((uint32_t)n < l1) && ab[p1 + n] == ch;
@@ -60,39 +71,77 @@ struct Compose {
 };
 
 // first index in [lo, nv) with vpos >= key, galloping from lo (the answer is almost always a few entries away)
-__device__ __forceinline__ int gallop_lb(const int32_t *vpos, int nv, int lo, long long key) {
-    if (lo >= nv || (long long)vpos[lo] >= key) return lo;
+template <class VP>
+__device__ __forceinline__ int gallop_lb(const VP &vpos, int nv, int lo, long long key) {
+    if (lo >= nv || (long long)vpos(lo) >= key) return lo;
     int step = 1;
-    while (lo + step < nv && (long long)vpos[lo + step] < key) { lo += step; step <<= 1; }
+    while (lo + step < nv && (long long)vpos(lo + step) < key) { lo += step; step <<= 1; }
     int l = lo + 1, h = lo + step < nv ? lo + step : nv;
-    while (l < h) { const int m = (l + h) >> 1; if ((long long)vpos[m] < key) l = m + 1; else h = m; }
+    while (l < h) { const int m = (l + h) >> 1; if ((long long)vpos(m) < key) l = m + 1; else h = m; }
     return l;
 }
 
+constexpr int GEN_WIN = 1024;      // variants staged per workgroup (max); beyond it the same arrays are read from global memory
+constexpr int GEN_COVER = 65536;   // the staged window reaches POS(last record of the workgroup) + GEN_COVER
+
+// The complete rule for one record (any REF length, any CIGAR): run by k_map_general_list on the records the fast pass hands over.
 template <bool EMIT>
-__device__ void gen_read(const GenArgs &a, int64_t r, int w0) {
-    const int pos = a.pos[r];
-    const uint32_t c0 = a.cigar_off[r], c1 = a.cigar_off[r + 1];
-    const uint32_t soff = a.seq_off[r];
+__device__ void gen_read(const GenArgs &a, int64_t r, int w0, int wlen, const int32_t *s_vpos, const uint32_t *s_desc, int pos, uint32_t c0,
+                         uint32_t c1, uint32_t soff, uint32_t cb, uint32_t ncig, const uint32_t *s_cig, int hint, int pre_i, uint32_t pre_q, uint32_t pre_s) {
     uint32_t ncalls = 0, ntext = 0;
     const uint64_t cbase = EMIT ? a.call_base[r] : 0, tbase = EMIT ? a.text_base[r] : 0;
     if (EMIT && a.call_base[r + 1] == a.call_base[r]) return;          // nothing under this record (the count pass knows)
-    int gpos = 0, rpos = 0;
+    auto VP = [&](int i) -> int { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_vpos[t] : a.vpos[i]; };
+    auto CIG = [&](uint32_t kx) -> uint32_t { const uint32_t t = kx - cb; return t < ncig ? s_cig[t] : a.cigar[kx]; };
+    auto DESC = [&](int i) -> uint32_t { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_desc[t] : a.desc[i]; };
+    int gpos = 0, rpos = 0, istart = hint;      // segments move forward: each search starts where the previous one ended
     uint32_t k = c0;
     for (;;) {
         const int seg_start = gpos, seg_rpos = rpos;
         int plen = 0;
         uint32_t k2 = k;
+        bool plain = true;            // no I / D / G op in the segment: pseudo-read index <-> read offset is a walk over M runs
         for (; k2 < c1; k2++) {
-            const uint32_t w = a.cigar[k2], op = w & 15;
+            const uint32_t w = CIG(k2), op = w & 15;
             if (op == OP_N) break;
             if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) plen += (int)(w >> 4);
+            plain = plain && op != OP_I && op != OP_D && op != OP_G;
         }
         const long long lo = (long long)pos + seg_start;
-        int i = gallop_lb(a.vpos, a.nv, w0, lo);
-        for (; i < a.nv && (long long)a.vpos[i] < lo + plen; i++) {
-            const int rs = (int)((long long)a.vpos[i] - lo), rl = a.ref_len[i];
+        int i = gallop_lb(VP, a.nv, istart, lo);
+        for (; i < a.nv; i++) {
+            const long long vp = VP(i);
+            if (vp >= lo + plen) break;
+            const uint32_t d = DESC(i);
+            const int rs = (int)(vp - lo), rl = (int)(d & 0xFFu);
             if (rs + rl > plen) continue;
+            if (plain && rl == 1) {
+                int pi = 0, ro = seg_rpos, x = 0;
+                for (uint32_t kk = k; kk < k2; kk++) {
+                    const uint32_t w = CIG(kk), op = w & 15;
+                    const int len = (int)(w >> 4);
+                    if (op == OP_M || op == OP_EQ || op == OP_X) {
+                        if (rs < pi + len) { x = ro + (rs - pi); break; }
+                        pi += len; ro += len;
+                    } else if (op == OP_S) ro += len;
+                }
+                const int sym = i == pre_i ? sym_of(a.baseq, pre_q, pre_s, x) : sym_at(a, soff, x);
+                if (sym == 4) continue;
+                const uint32_t ch = sym_char(sym);
+                const int code = ch == ((d >> 8) & 0xFFu) ? 5 : ch == ((d >> 16) & 0xFFu) ? 6 : sym < 4 ? sym : 4;
+                if (EMIT) {
+                    const int64_t o = (int64_t)(cbase + ncalls);
+                    if (o < a.cap) {
+                        a.o_read[o] = (int32_t)r; a.o_var[o] = i; a.o_code[o] = (uint8_t)code;
+                        a.o_aux0[o] = 0xFFFFFFFFu; a.o_aux1[o] = 0;
+                        if (a.o_text_off) a.o_text_off[o] = (uint32_t)(tbase + ntext);
+                    }
+                    if (code == 4 && a.o_text && (int64_t)(tbase + ntext) < a.text_cap) a.o_text[tbase + ntext] = (uint32_t)x;
+                }
+                ncalls++;
+                if (code == 4) ntext++;
+                continue;
+            }
             Compose c;
             // pass 0 classifies; a code-4 call in the emit pass is composed once more to record its read offsets (never
             // speculatively: a neighbouring record owns the pool space right after this record's share)
@@ -107,7 +156,7 @@ __device__ void gen_read(const GenArgs &a, int64_t r, int w0) {
                 }
                 int pi = 0, ro = seg_rpos;
                 for (uint32_t kk = k; kk < k2; kk++) {
-                    const uint32_t w = a.cigar[kk], op = w & 15;
+                    const uint32_t w = CIG(kk), op = w & 15;
                     const int len = (int)(w >> 4);
                     if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) {
                         const int from = pi > rs ? pi : rs, to = (pi + len) < (rs + rl) ? (pi + len) : (rs + rl);
@@ -116,7 +165,7 @@ __device__ void gen_read(const GenArgs &a, int64_t r, int w0) {
                             // insertion stored under key == p in this segment (later one wins; key is read-relative)
                             int ioff = 0, ilen = 0, g2 = seg_start, r2 = seg_rpos;
                             for (uint32_t q = k; q < k2; q++) {
-                                const uint32_t w2 = a.cigar[q], o2 = w2 & 15;
+                                const uint32_t w2 = CIG(q), o2 = w2 & 15;
                                 const int l2 = (int)(w2 >> 4);
                                 if (o2 == OP_M || o2 == OP_EQ || o2 == OP_X) { g2 += l2; r2 += l2; }
                                 else if (o2 == OP_D || o2 == OP_G) g2 += l2;
@@ -154,28 +203,230 @@ __device__ void gen_read(const GenArgs &a, int64_t r, int w0) {
             if (code == 4) ntext += (uint32_t)c.n;
         }
         for (uint32_t kk = k; kk < k2; kk++) {
-            const uint32_t w = a.cigar[kk], op = w & 15;
+            const uint32_t w = CIG(kk), op = w & 15;
             const int len = (int)(w >> 4);
             if (op == OP_M || op == OP_EQ || op == OP_X) { gpos += len; rpos += len; }
             else if (op == OP_D || op == OP_G) gpos += len;
             else if (op == OP_I || op == OP_S) rpos += len;
         }
         if (k2 >= c1) break;
-        gpos += (int)(a.cigar[k2] >> 4);
+        gpos += (int)(CIG(k2) >> 4);
         k = k2 + 1;
     }
     if (!EMIT) { a.n_calls[r] = ncalls; a.n_text[r] = ntext; }
 }
 
-template <bool EMIT>
+// per workgroup of `tile` records: first variant at or after the first record's POS, and how many variants lie below
+// POS(last record) + GEN_COVER, plus the one after them (at most GEN_WIN); later records only move forward from the start
+__global__ void k_gen_window(const int32_t *pos, int64_t n, int tile, const int32_t *vpos, int nv, int64_t grid, int32_t *win) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= grid) return;
+    const int64_t last = (b + 1) * tile - 1 < n ? (b + 1) * tile - 1 : n - 1;
+    const long long k0 = pos[b * tile], k1 = (long long)pos[last] + GEN_COVER;
+    int l0 = 0, h0 = nv, l1 = 0, h1 = nv;
+    while (l0 < h0 || l1 < h1) {
+        if (l0 < h0) { const int m = (l0 + h0) >> 1; if ((long long)vpos[m] < k0) l0 = m + 1; else h0 = m; }
+        if (l1 < h1) { const int m = (l1 + h1) >> 1; if ((long long)vpos[m] < k1) l1 = m + 1; else h1 = m; }
+    }
+    int len = l1 - l0 + 1;                      // one past the cover: the entry that ends most searches
+    if (len > nv - l0) len = nv - l0;
+    win[2 * b] = l0; win[2 * b + 1] = len < 0 ? 0 : (len > GEN_WIN ? GEN_WIN : len);
+}
+
+__global__ void k_gen_desc(const uint8_t *ref_len, const uint32_t *aoff, const char *ab, int nv, uint32_t *desc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const uint32_t p0 = aoff[2 * i], p1 = aoff[2 * i + 1], p2 = aoff[2 * i + 2];
+    const uint32_t c0 = p1 - p0 == 1 ? (uint8_t)ab[p0] : 0u, c1 = p2 - p1 == 1 ? (uint8_t)ab[p1] : 0u;
+    desc[i] = (uint32_t)ref_len[i] | (c0 << 8) | (c1 << 16);
+}
+
+constexpr int GEN_NC = 2;          // candidates a record keeps in registers in the fast pass; a record with more goes to the work list
+static_assert(GEN_NC == 2, "side[r] packs two calls per record");
+
+// Fast pass, step 1: walk one record against the staged window without touching its bases.  Returns the number of candidates
+// (variant index, descriptor, read offset of the base under it), or -1 when the record has to take the complete rule: a candidate
+// whose REF is longer than a base or whose segment holds an I / D / G op, or more than GEN_NC candidates.  The general composition is
+// a long chain of dependent loads, and one such lane used to hold the other 63 of its wave for its whole length; the handed-over
+// records are redone from scratch by dense waves (k_map_general_list).
+__device__ __forceinline__ int walk_fast(const GenArgs &a, int w0, int wlen, const int32_t *s_vpos, const uint32_t *s_desc, int pos, uint32_t c0,
+                                         uint32_t c1, uint32_t cb, uint32_t ncig, const uint32_t *s_cig, int *ci, uint32_t *cd, int *cx) {
+    auto VP = [&](int i) -> int { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_vpos[t] : a.vpos[i]; };
+    auto CIG = [&](uint32_t kx) -> uint32_t { const uint32_t t = kx - cb; return t < ncig ? s_cig[t] : a.cigar[kx]; };
+    auto DESC = [&](int i) -> uint32_t { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_desc[t] : a.desc[i]; };
+    int gpos = 0, rpos = 0, istart = w0, cnt = 0;
+    uint32_t k = c0;
+    for (;;) {
+        const int seg_start = gpos, seg_rpos = rpos;
+        int plen = 0;
+        uint32_t k2 = k;
+        bool plain = true;
+        for (; k2 < c1; k2++) {
+            const uint32_t w = CIG(k2), op = w & 15;
+            const int len = (int)(w >> 4);
+            if (op == OP_N) break;
+            if (op == OP_M || op == OP_EQ || op == OP_X) { plen += len; gpos += len; rpos += len; }
+            else if (op == OP_D) { plen += len; gpos += len; }
+            else if (op == OP_G) gpos += len;
+            else if (op == OP_I || op == OP_S) rpos += len;
+            plain = plain && op != OP_I && op != OP_D && op != OP_G;
+        }
+        const long long lo = (long long)pos + seg_start;
+        int i = gallop_lb(VP, a.nv, istart, lo);
+        for (; i < a.nv; i++) {
+            const long long vp = VP(i);
+            if (vp >= lo + plen) break;
+            const uint32_t d = DESC(i);
+            const int rs = (int)(vp - lo), rl = (int)(d & 0xFFu);
+            if (rs + rl > plen) continue;
+            if (!(plain && rl == 1) || cnt >= GEN_NC) return -1;
+            int pi = 0, ro = seg_rpos, x = 0;
+            for (uint32_t kk = k; kk < k2; kk++) {
+                const uint32_t w = CIG(kk), op = w & 15;
+                const int len = (int)(w >> 4);
+                if (op == OP_M || op == OP_EQ || op == OP_X) {
+                    if (rs < pi + len) { x = ro + (rs - pi); break; }
+                    pi += len; ro += len;
+                } else if (op == OP_S) ro += len;
+            }
+#pragma unroll
+            for (int c = 0; c < GEN_NC; c++) if (c == cnt) { ci[c] = i; cd[c] = d; cx[c] = x; }
+            cnt++;
+        }
+        istart = i;
+        if (k2 >= c1) break;
+        gpos += (int)(CIG(k2) >> 4);
+        k = k2 + 1;
+    }
+    return cnt;
+}
+
+constexpr int GEN_RPL = 4;         // records per lane: their loads are requested together, stage by stage
+constexpr int GEN_TILE = 256 * GEN_RPL;
+constexpr int GEN_CIG = 4 * GEN_TILE;   // CIGAR words staged per workgroup (max); the rest is read from global memory
+
+// Fast pass (count): GEN_RPL records per lane.  Besides the per-record counts it leaves each record's calls packed in side[r]
+// ({variant, offset | code << 24 | 1 << 31} x GEN_NC; .y == 1 << 30 marks a handed-over record), so that the emit pass is a plain
+// streaming kernel and nothing is walked twice.
 __global__ __launch_bounds__(256) void k_map_general(GenArgs a) {
+    __shared__ int32_t s_vpos[GEN_WIN];
+    __shared__ uint32_t s_desc[GEN_WIN];
+    __shared__ uint32_t s_cig[GEN_CIG];
+    __shared__ uint32_t s_wl[GEN_TILE], s_wln, s_wlbase;
+    uint32_t cb, ncig;
+    if (threadIdx.x == 0) s_wln = 0;
+    const int64_t r0 = (int64_t)blockIdx.x * GEN_TILE;
+    const int w0 = a.win[2 * blockIdx.x], wlen = a.win[2 * blockIdx.x + 1];
+    // stage 1: the record words of this lane's GEN_RPL records
+    int pos[GEN_RPL]; uint32_t c0[GEN_RPL], c1[GEN_RPL], soff[GEN_RPL]; bool live[GEN_RPL];
+#pragma unroll
+    for (int j = 0; j < GEN_RPL; j++) {
+        const int64_t r = r0 + j * 256 + threadIdx.x;
+        live[j] = r < a.n;
+        pos[j] = 0; c0[j] = c1[j] = soff[j] = 0;
+        if (live[j]) { pos[j] = a.pos[r]; c0[j] = a.cigar_off[r]; c1[j] = a.cigar_off[r + 1]; soff[j] = a.seq_off[r]; }
+    }
+    for (int t = threadIdx.x; t < wlen; t += 256) { s_vpos[t] = a.vpos[w0 + t]; s_desc[t] = a.desc[w0 + t]; }
+    // stage 2: the tile's CIGAR words (one contiguous range, records being stored in order) into LDS
+    {
+        const int64_t re = r0 + GEN_TILE < a.n ? r0 + GEN_TILE : a.n;
+        cb = a.cigar_off[r0];
+        const uint32_t ce = a.cigar_off[re];
+        ncig = ce - cb < (uint32_t)GEN_CIG ? ce - cb : (uint32_t)GEN_CIG;
+        for (uint32_t t = threadIdx.x; t < ncig; t += 256) s_cig[t] = a.cigar[cb + t];
+    }
+    __syncthreads();
+    // stage 3: walk (LDS only), then request the bytes under every candidate of the lane's records together
+    int cnt[GEN_RPL], ci[GEN_RPL][GEN_NC], cx[GEN_RPL][GEN_NC]; uint32_t cd[GEN_RPL][GEN_NC], q[GEN_RPL][GEN_NC], sb[GEN_RPL][GEN_NC];
+#pragma unroll
+    for (int j = 0; j < GEN_RPL; j++) {
+#pragma unroll
+        for (int c = 0; c < GEN_NC; c++) { ci[j][c] = 0; cx[j][c] = 0; cd[j][c] = 0; }
+        cnt[j] = live[j] ? walk_fast(a, w0, wlen, s_vpos, s_desc, pos[j], c0[j], c1[j], cb, ncig, s_cig, ci[j], cd[j], cx[j]) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < GEN_RPL; j++) {
+#pragma unroll
+        for (int c = 0; c < GEN_NC; c++) {
+            q[j][c] = sb[j][c] = 0;
+            if (c < cnt[j]) { q[j][c] = a.qual[(size_t)soff[j] * 4 + cx[j][c]]; sb[j][c] = a.seq2[(size_t)soff[j] + (cx[j][c] >> 2)]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GEN_RPL; j++) {
+        const int64_t r = r0 + j * 256 + threadIdx.x;
+        if (!live[j]) continue;
+        if (cnt[j] < 0) {                                         // hand-over, gathered per workgroup; the list kernel writes its counts
+            s_wl[atomicAdd(&s_wln, 1u)] = (uint32_t)r;
+            a.side[r] = make_uint4(0u, 0x40000000u, 0u, 0u);
+            continue;
+        }
+        uint32_t ncalls = 0, ntext = 0, pk[2 * GEN_NC];
+#pragma unroll
+        for (int c = 0; c < 2 * GEN_NC; c++) pk[c] = 0;
+#pragma unroll
+        for (int c = 0; c < GEN_NC; c++) {
+            if (c >= cnt[j]) break;
+            const int x = cx[j][c];
+            const int sym = sym_of(a.baseq, q[j][c], sb[j][c], x);
+            if (sym == 4) continue;
+            const uint32_t d = cd[j][c], ch = sym_char(sym);
+            const uint32_t code = ch == ((d >> 8) & 0xFFu) ? 5u : ch == ((d >> 16) & 0xFFu) ? 6u : sym < 4 ? (uint32_t)sym : 4u;
+            const uint32_t w = ((uint32_t)x & 0xFFFFFFu) | (code << 24) | 0x80000000u;
+#pragma unroll
+            for (int e = 0; e < GEN_NC; e++) if ((uint32_t)e == ncalls) { pk[2 * e] = (uint32_t)ci[j][c]; pk[2 * e + 1] = w; }
+            ncalls++;
+            if (code == 4) ntext++;
+        }
+        a.n_calls[r] = ncalls; a.n_text[r] = ntext;
+        if (ncalls) a.side[r] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    // one global atomic per workgroup: a shared counter hit once per wave cost more than the rest of the pass
+    __syncthreads();
+    if (s_wln) {
+        if (threadIdx.x == 0) s_wlbase = atomicAdd(a.wl_n, s_wln);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < s_wln; t += 256) a.wl[s_wlbase + t] = s_wl[t];
+    }
+}
+
+// Fast pass (emit): unpack side[r] to the record's place in the call arrays
+__global__ __launch_bounds__(256) void k_gen_emit(GenArgs a) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // window start of the workgroup: first variant at or after the first record's POS (uniform search: every lane reads the
-    // same addresses); later records only move forward from it
-    const int key = a.pos[(int64_t)blockIdx.x * 256];
-    int lo = 0, hi = a.nv;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (a.vpos[m] < key) lo = m + 1; else hi = m; }
-    if (r < a.n) gen_read<EMIT>(a, r, lo);
+    if (r >= a.n) return;
+    const uint32_t b0 = a.call_base[r], b1 = a.call_base[r + 1];
+    if (b0 == b1) return;
+    const uint4 v = a.side[r];
+    if (v.y & 0x40000000u) return;                               // a handed-over record: k_map_general_list<true> writes it
+    const uint32_t tb = a.text_base[r];
+    uint32_t ntext = 0;
+#pragma unroll
+    for (int c = 0; c < GEN_NC; c++) {
+        const uint32_t var = c ? v.z : v.x, w = c ? v.w : v.y;
+        if (!(w & 0x80000000u)) break;
+        const uint32_t code = (w >> 24) & 7u;
+        const int64_t o = (int64_t)b0 + c;
+        if (o < a.cap) {
+            a.o_read[o] = (int32_t)r; a.o_var[o] = (int32_t)var; a.o_code[o] = (uint8_t)code;
+            a.o_aux0[o] = 0xFFFFFFFFu; a.o_aux1[o] = 0;
+            if (a.o_text_off) a.o_text_off[o] = tb + ntext;
+        }
+        if (code == 4) {
+            if (a.o_text && (int64_t)tb + ntext < a.text_cap) a.o_text[(size_t)tb + ntext] = w & 0xFFFFFFu;
+            ntext++;
+        }
+    }
+}
+
+// the records the fast pass left: one lane each, dense
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_map_general_list(GenArgs a) {
+    const uint32_t m = *a.wl_n;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < m; t += gridDim.x * 256) {
+        const int64_t r = a.wl[t];
+        const int w0 = a.win[2 * (r / GEN_TILE)];
+        gen_read<EMIT>(a, r, w0, 0, nullptr, nullptr, a.pos[r], a.cigar_off[r], a.cigar_off[r + 1], a.seq_off[r], 0u, 0u, nullptr, w0, -1, 0u, 0u);
+    }
 }
 
 }  // namespace
@@ -213,12 +464,26 @@ extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const
     uint32_t *cb = (uint32_t *)S[2].p, *tb = (uint32_t *)S[3].p;
     a.call_base = cb; a.text_base = tb;
     hipStream_t sm = ctx->stream;
-    const unsigned grid = (unsigned)((n + 255) / 256);
+    const unsigned grid = (unsigned)((n + GEN_TILE - 1) / GEN_TILE);
+    if (int s = phz_reserve(ctx, S[4], (size_t)grid * 8)) return s;
+    if (int s = phz_reserve(ctx, S[5], (size_t)nv * 4)) return s;
+    if (n >= (1ll << 32)) return phz_fail(ctx, PHZ_E_ARG, "too many records in one shard");
+    if (int s = phz_reserve(ctx, S[7], (size_t)n * 4)) return s;
+    if (int s = phz_reserve(ctx, S[8], 64)) return s;
+    if (int s = phz_reserve(ctx, S[9], (size_t)n * 16)) return s;
+    a.side = (uint4 *)S[9].p;
+    a.win = (const int32_t *)S[4].p; a.desc = (const uint32_t *)S[5].p;
+    a.wl = (uint32_t *)S[7].p; a.wl_n = (uint32_t *)S[8].p;
+    PHZ_HIP(ctx, hipMemsetAsync(a.wl_n, 0, 4, sm));
     PHZ_HIP(ctx, hipEventRecord(ctx->ev0, sm));
-    hipLaunchKernelGGL(k_map_general<false>, dim3(grid), dim3(256), 0, sm, a);
+    hipLaunchKernelGGL(k_gen_window, dim3((grid + 255) / 256), dim3(256), 0, sm, a.pos, n, GEN_TILE, a.vpos, (int)nv, (int64_t)grid, (int32_t *)S[4].p);
+    hipLaunchKernelGGL(k_gen_desc, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, sm, a.ref_len, a.aoff, a.abytes, (int)nv, (uint32_t *)S[5].p);
+    hipLaunchKernelGGL(k_map_general, dim3(grid), dim3(256), 0, sm, a);
+    hipLaunchKernelGGL(k_map_general_list<false>, dim3(2048), dim3(256), 0, sm, a);     // grid-stride over a list whose length only the device knows
     if (int s = scan_excl(ctx, a.n_calls, cb, n, S[6])) return s;
     if (int s = scan_excl(ctx, a.n_text, tb, n, S[6])) return s;
-    uint32_t last[2];
+    uint32_t last[2], n_listed = 0;
+    PHZ_HIP(ctx, hipMemcpyAsync(&n_listed, a.wl_n, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&last[0], cb + n, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&last[1], tb + n, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
@@ -237,7 +502,8 @@ extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const
         if (int s = st.out(text_roff, (size_t)(text_cap ? text_cap : 1), space, &d_text)) return s;
     }
     a.o_text_off = d_toff; a.o_text = d_text; a.cap = out->cap; a.text_cap = text_cap;
-    hipLaunchKernelGGL(k_map_general<true>, dim3(grid), dim3(256), 0, sm, a);
+    hipLaunchKernelGGL(k_gen_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sm, a);
+    if (n_listed) hipLaunchKernelGGL(k_map_general_list<true>, dim3((n_listed + 255) / 256), dim3(256), 0, sm, a);
     PHZ_HIP(ctx, hipGetLastError());
     PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
     if (d_toff) { const uint32_t tt = (uint32_t)ttotal; PHZ_HIP(ctx, hipMemcpyAsync(d_toff + total, &tt, 4, hipMemcpyHostToDevice, sm)); }
