@@ -34,8 +34,10 @@ struct GenArgs {
     const uint32_t *desc;                        // [nv] ref_len | allele0 char << 8 | allele1 char << 16 (0 = not one character)
     uint4 *side;                                 // [n] packed calls of the fast pass (k_map_general -> k_gen_emit)
     uint32_t *wl_n, *wl;                         // records left to the general composition (count pass appends, both list passes read)
-    uint32_t *n_calls, *n_text;                  // per record (count pass)
-    const uint32_t *call_base, *text_base;       // exclusive scans (emit pass)
+    uint32_t *n_calls;                           // per record (count pass)
+    uint32_t *tile_calls, *tile_text;            // per workgroup tile of the fast pass: calls / text characters under its records
+    const uint32_t *tile_cbase, *tile_tbase;     // their exclusive scans
+    uint32_t *call_base, *text_base;             // per record, written by k_gen_emit for the handed-over records only
     int32_t *o_read, *o_var; uint8_t *o_code; uint32_t *o_aux0, *o_aux1;
     uint32_t *o_text_off; uint32_t *o_text;      // optional
     int64_t cap, text_cap;
@@ -81,6 +83,9 @@ __device__ __forceinline__ int gallop_lb(const VP &vpos, int nv, int lo, long lo
     return l;
 }
 
+constexpr int GEN_RPL = 4;         // records per lane: their loads are requested together, stage by stage
+constexpr int GEN_TILE = 256 * GEN_RPL;
+constexpr int GEN_CIG = 4 * GEN_TILE;   // CIGAR words staged per workgroup (max); the rest is read from global memory
 constexpr int GEN_WIN = 1024;      // variants staged per workgroup (max); beyond it the same arrays are read from global memory
 constexpr int GEN_COVER = 65536;   // the staged window reaches POS(last record of the workgroup) + GEN_COVER
 
@@ -89,8 +94,8 @@ template <bool EMIT>
 __device__ void gen_read(const GenArgs &a, int64_t r, int w0, int wlen, const int32_t *s_vpos, const uint32_t *s_desc, int pos, uint32_t c0,
                          uint32_t c1, uint32_t soff, uint32_t cb, uint32_t ncig, const uint32_t *s_cig, int hint, int pre_i, uint32_t pre_q, uint32_t pre_s) {
     uint32_t ncalls = 0, ntext = 0;
+    if (EMIT && a.n_calls[r] == 0) return;                             // nothing under this record (the count pass knows)
     const uint64_t cbase = EMIT ? a.call_base[r] : 0, tbase = EMIT ? a.text_base[r] : 0;
-    if (EMIT && a.call_base[r + 1] == a.call_base[r]) return;          // nothing under this record (the count pass knows)
     auto VP = [&](int i) -> int { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_vpos[t] : a.vpos[i]; };
     auto CIG = [&](uint32_t kx) -> uint32_t { const uint32_t t = kx - cb; return t < ncig ? s_cig[t] : a.cigar[kx]; };
     auto DESC = [&](int i) -> uint32_t { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_desc[t] : a.desc[i]; };
@@ -213,7 +218,12 @@ __device__ void gen_read(const GenArgs &a, int64_t r, int w0, int wlen, const in
         gpos += (int)(CIG(k2) >> 4);
         k = k2 + 1;
     }
-    if (!EMIT) { a.n_calls[r] = ncalls; a.n_text[r] = ntext; }
+    if (!EMIT) {
+        a.n_calls[r] = ncalls;
+        a.side[r] = make_uint4(ncalls, 0x40000000u, ntext, 0u);
+        if (ncalls) atomicAdd(&a.tile_calls[r / GEN_TILE], ncalls);
+        if (ntext) atomicAdd(&a.tile_text[r / GEN_TILE], ntext);
+    }
 }
 
 // per workgroup of `tile` records: first variant at or after the first record's POS, and how many variants lie below
@@ -301,10 +311,6 @@ __device__ __forceinline__ int walk_fast(const GenArgs &a, int w0, int wlen, con
     return cnt;
 }
 
-constexpr int GEN_RPL = 4;         // records per lane: their loads are requested together, stage by stage
-constexpr int GEN_TILE = 256 * GEN_RPL;
-constexpr int GEN_CIG = 4 * GEN_TILE;   // CIGAR words staged per workgroup (max); the rest is read from global memory
-
 // Fast pass (count): GEN_RPL records per lane.  Besides the per-record counts it leaves each record's calls packed in side[r]
 // ({variant, offset | code << 24 | 1 << 31} x GEN_NC; .y == 1 << 30 marks a handed-over record), so that the emit pass is a plain
 // streaming kernel and nothing is walked twice.
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(256) void k_map_general(GenArgs a) {
     __shared__ int32_t s_vpos[GEN_WIN];
     __shared__ uint32_t s_desc[GEN_WIN];
     __shared__ uint32_t s_cig[GEN_CIG];
-    __shared__ uint32_t s_wl[GEN_TILE], s_wln, s_wlbase;
+    __shared__ uint32_t s_wl[GEN_TILE], s_wln, s_wlbase, s_sum[8];
     uint32_t cb, ncig;
     if (threadIdx.x == 0) s_wln = 0;
     const int64_t r0 = (int64_t)blockIdx.x * GEN_TILE;
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(256) void k_map_general(GenArgs a) {
             if (c < cnt[j]) { q[j][c] = a.qual[(size_t)soff[j] * 4 + cx[j][c]]; sb[j][c] = a.seq2[(size_t)soff[j] + (cx[j][c] >> 2)]; }
         }
     }
+    uint32_t sum_c = 0, sum_t = 0;
 #pragma unroll
     for (int j = 0; j < GEN_RPL; j++) {
         const int64_t r = r0 + j * 256 + threadIdx.x;
@@ -378,11 +385,20 @@ __global__ __launch_bounds__(256) void k_map_general(GenArgs a) {
             ncalls++;
             if (code == 4) ntext++;
         }
-        a.n_calls[r] = ncalls; a.n_text[r] = ntext;
+        a.n_calls[r] = ncalls;
         if (ncalls) a.side[r] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        sum_c += ncalls; sum_t += ntext;
     }
+    // the tile's totals over its fast records (the list pass adds the handed-over ones)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { sum_c += __shfl_xor(sum_c, d); sum_t += __shfl_xor(sum_t, d); }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum_c; s_sum[4 + (threadIdx.x >> 6)] = sum_t; }
     // one global atomic per workgroup: a shared counter hit once per wave cost more than the rest of the pass
     __syncthreads();
+    if (threadIdx.x == 0) {
+        a.tile_calls[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        a.tile_text[blockIdx.x] = s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7];
+    }
     if (s_wln) {
         if (threadIdx.x == 0) s_wlbase = atomicAdd(a.wl_n, s_wln);
         __syncthreads();
@@ -390,31 +406,66 @@ __global__ __launch_bounds__(256) void k_map_general(GenArgs a) {
     }
 }
 
-// Fast pass (emit): unpack side[r] to the record's place in the call arrays
+// Emit, fast records: one workgroup per tile of the count pass, four consecutive records per thread.  The offsets of a record's
+// calls are the tile's base (a scan over ~n/1024 tile totals) plus a scan inside the workgroup, so no per-record scan of the whole
+// shard exists; text characters are counted from the packed calls themselves.  Handed-over records only get their two offsets
+// written down for k_map_general_list<true>.
+static_assert(GEN_TILE == 1024, "k_gen_emit: 256 threads x 4 records");
 __global__ __launch_bounds__(256) void k_gen_emit(GenArgs a) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.n) return;
-    const uint32_t b0 = a.call_base[r], b1 = a.call_base[r + 1];
-    if (b0 == b1) return;
-    const uint4 v = a.side[r];
-    if (v.y & 0x40000000u) return;                               // a handed-over record: k_map_general_list<true> writes it
-    const uint32_t tb = a.text_base[r];
-    uint32_t ntext = 0;
+    __shared__ uint32_t s_c[4], s_t[4];
+    if (a.tile_cbase[blockIdx.x + 1] == a.tile_cbase[blockIdx.x]) return;
+    const int64_t rb = (int64_t)blockIdx.x * GEN_TILE + 4 * threadIdx.x;
+    uint32_t nc[4] = {0u, 0u, 0u, 0u}, nt[4] = {0u, 0u, 0u, 0u};
+    uint4 sd[4];
+    if (rb + 3 < a.n) { const uint4 v = *(const uint4 *)(a.n_calls + rb); nc[0] = v.x; nc[1] = v.y; nc[2] = v.z; nc[3] = v.w; }
+    else { for (int j = 0; j < 4; j++) if (rb + j < a.n) nc[j] = a.n_calls[rb + j]; }
+    uint32_t tc = 0, tt = 0;
 #pragma unroll
-    for (int c = 0; c < GEN_NC; c++) {
-        const uint32_t var = c ? v.z : v.x, w = c ? v.w : v.y;
-        if (!(w & 0x80000000u)) break;
-        const uint32_t code = (w >> 24) & 7u;
-        const int64_t o = (int64_t)b0 + c;
-        if (o < a.cap) {
-            a.o_read[o] = (int32_t)r; a.o_var[o] = (int32_t)var; a.o_code[o] = (uint8_t)code;
-            a.o_aux0[o] = 0xFFFFFFFFu; a.o_aux1[o] = 0;
-            if (a.o_text_off) a.o_text_off[o] = tb + ntext;
+    for (int j = 0; j < 4; j++) {
+        sd[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (nc[j]) {
+            sd[j] = a.side[rb + j];
+            if (sd[j].y & 0x40000000u) nt[j] = sd[j].z;
+            else nt[j] = (uint32_t)(((sd[j].y >> 24) & 0x87u) == 0x84u) + (uint32_t)(((sd[j].w >> 24) & 0x87u) == 0x84u);
         }
-        if (code == 4) {
-            if (a.o_text && (int64_t)tb + ntext < a.text_cap) a.o_text[(size_t)tb + ntext] = w & 0xFFFFFFu;
-            ntext++;
+        tc += nc[j]; tt += nt[j];
+    }
+    uint32_t ic = tc, it = tt;                                    // inclusive scans over the wave, then over the four waves
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t uc = __shfl_up(ic, d), ut = __shfl_up(it, d);
+        if (lane >= d) { ic += uc; it += ut; }
+    }
+    if (lane == 63) { s_c[wv] = ic; s_t[wv] = it; }
+    __syncthreads();
+    uint32_t ec = a.tile_cbase[blockIdx.x] + (ic - tc), et = a.tile_tbase[blockIdx.x] + (it - tt);
+    for (int w = 0; w < wv; w++) { ec += s_c[w]; et += s_t[w]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!nc[j]) continue;
+        const int64_t r = rb + j;
+        if (sd[j].y & 0x40000000u) { a.call_base[r] = ec; a.text_base[r] = et; }
+        else {
+            uint32_t ntext = 0;
+#pragma unroll
+            for (int c = 0; c < GEN_NC; c++) {
+                const uint32_t var = c ? sd[j].z : sd[j].x, w = c ? sd[j].w : sd[j].y;
+                if (!(w & 0x80000000u)) break;
+                const uint32_t code = (w >> 24) & 7u;
+                const int64_t o = (int64_t)ec + c;
+                if (o < a.cap) {
+                    a.o_read[o] = (int32_t)r; a.o_var[o] = (int32_t)var; a.o_code[o] = (uint8_t)code;
+                    a.o_aux0[o] = 0xFFFFFFFFu; a.o_aux1[o] = 0;
+                    if (a.o_text_off) a.o_text_off[o] = et + ntext;
+                }
+                if (code == 4) {
+                    if (a.o_text && (int64_t)et + ntext < a.text_cap) a.o_text[(size_t)et + ntext] = w & 0xFFFFFFu;
+                    ntext++;
+                }
+            }
         }
+        ec += nc[j]; et += nt[j];
     }
 }
 
@@ -457,14 +508,16 @@ extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const
     a.n = n; a.nv = (int)nv; a.baseq = baseq;
     DevBuf *S = ctx->scratch;
     if (int s = phz_reserve(ctx, S[0], (size_t)n * 4)) return s;
-    if (int s = phz_reserve(ctx, S[1], (size_t)n * 4)) return s;
-    if (int s = phz_reserve(ctx, S[2], (size_t)(n + 1) * 4)) return s;
-    if (int s = phz_reserve(ctx, S[3], (size_t)(n + 1) * 4)) return s;
-    a.n_calls = (uint32_t *)S[0].p; a.n_text = (uint32_t *)S[1].p;
-    uint32_t *cb = (uint32_t *)S[2].p, *tb = (uint32_t *)S[3].p;
-    a.call_base = cb; a.text_base = tb;
-    hipStream_t sm = ctx->stream;
     const unsigned grid = (unsigned)((n + GEN_TILE - 1) / GEN_TILE);
+    if (int s = phz_reserve(ctx, S[1], (size_t)(grid + 1) * 16)) return s;
+    if (int s = phz_reserve(ctx, S[2], (size_t)n * 4)) return s;
+    if (int s = phz_reserve(ctx, S[3], (size_t)n * 4)) return s;
+    a.n_calls = (uint32_t *)S[0].p;
+    a.tile_calls = (uint32_t *)S[1].p; a.tile_text = a.tile_calls + grid;
+    uint32_t *cb = a.tile_text + grid, *tb = cb + grid + 1;
+    a.tile_cbase = cb; a.tile_tbase = tb;
+    a.call_base = (uint32_t *)S[2].p; a.text_base = (uint32_t *)S[3].p;
+    hipStream_t sm = ctx->stream;
     if (int s = phz_reserve(ctx, S[4], (size_t)grid * 8)) return s;
     if (int s = phz_reserve(ctx, S[5], (size_t)nv * 4)) return s;
     if (n >= (1ll << 32)) return phz_fail(ctx, PHZ_E_ARG, "too many records in one shard");
@@ -480,14 +533,15 @@ extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const
     hipLaunchKernelGGL(k_gen_desc, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, sm, a.ref_len, a.aoff, a.abytes, (int)nv, (uint32_t *)S[5].p);
     hipLaunchKernelGGL(k_map_general, dim3(grid), dim3(256), 0, sm, a);
     hipLaunchKernelGGL(k_map_general_list<false>, dim3(2048), dim3(256), 0, sm, a);     // grid-stride over a list whose length only the device knows
-    if (int s = scan_excl(ctx, a.n_calls, cb, n, S[6])) return s;
-    if (int s = scan_excl(ctx, a.n_text, tb, n, S[6])) return s;
+    if (int s = scan_excl(ctx, a.tile_calls, cb, (int64_t)grid, S[6])) return s;
+    if (int s = scan_excl(ctx, a.tile_text, tb, (int64_t)grid, S[6])) return s;
     uint32_t last[2], n_listed = 0;
     PHZ_HIP(ctx, hipMemcpyAsync(&n_listed, a.wl_n, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&last[0], cb + n, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&last[1], tb + n, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&last[0], cb + grid, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&last[1], tb + grid, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
     const int64_t total = (int64_t)last[0], ttotal = (int64_t)last[1];
+    if (getenv("PHZ_GEN_DBG")) fprintf(stderr, "K_map_general: %lld records, %u handed to the list, %lld calls, %lld text\n", (long long)n, n_listed, (long long)total, (long long)ttotal);
     *n_calls = total;
     if (n_text) *n_text = ttotal;
     if (total > out->cap || (text_roff && ttotal > text_cap)) return PHZ_E_CAPACITY;
@@ -502,7 +556,7 @@ extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const
         if (int s = st.out(text_roff, (size_t)(text_cap ? text_cap : 1), space, &d_text)) return s;
     }
     a.o_text_off = d_toff; a.o_text = d_text; a.cap = out->cap; a.text_cap = text_cap;
-    hipLaunchKernelGGL(k_gen_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sm, a);
+    hipLaunchKernelGGL(k_gen_emit, dim3(grid), dim3(256), 0, sm, a);
     if (n_listed) hipLaunchKernelGGL(k_map_general_list<true>, dim3((n_listed + 255) / 256), dim3(256), 0, sm, a);
     PHZ_HIP(ctx, hipGetLastError());
     PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
