@@ -261,51 +261,70 @@ static_assert(GEN_NC == 2, "side[r] packs two calls per record");
 // records are redone from scratch by dense waves (k_map_general_list).
 __device__ __forceinline__ int walk_fast(const GenArgs &a, int w0, int wlen, const int32_t *s_vpos, const uint32_t *s_desc, int pos, uint32_t c0,
                                          uint32_t c1, uint32_t cb, uint32_t ncig, const uint32_t *s_cig, int *ci, uint32_t *cd, int *cx) {
-    auto VP = [&](int i) -> int { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_vpos[t] : a.vpos[i]; };
-    auto CIG = [&](uint32_t kx) -> uint32_t { const uint32_t t = kx - cb; return t < ncig ? s_cig[t] : a.cigar[kx]; };
-    auto DESC = [&](int i) -> uint32_t { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_desc[t] : a.desc[i]; };
+    // Everything the fast walk reads is in LDS, through explicit LDS pointers and 32-bit arithmetic: a step outside the staged window
+    // or the staged CIGAR words (or a coordinate near 2^30) hands the record over instead of reaching for global memory, which keeps
+    // the per-step instruction count down -- the pass is bound by VALU issue, not by latency.
+    typedef const __attribute__((address_space(3))) int32_t *lds_i32;
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+    const lds_i32 l_vpos = (lds_i32)s_vpos;
+    const lds_u32 l_desc = (lds_u32)s_desc, l_cig = (lds_u32)s_cig;
+    if ((unsigned)pos >= (1u << 30) || c1 - cb > ncig) return -1;
+    const int wend = w0 + wlen;                 // staged variants: [w0, wend); wend == nv or vpos[wend - 1] is past the cover
     int gpos = 0, rpos = 0, istart = w0, cnt = 0;
-    uint32_t k = c0;
+    uint32_t k = c0 - cb, kend = c1 - cb;
     for (;;) {
         const int seg_start = gpos, seg_rpos = rpos;
-        int plen = 0;
+        int plen = 0, runs = 0, run_ro = 0;      // runs of bases in the segment, read offset of the first one
         uint32_t k2 = k;
         bool plain = true;
-        for (; k2 < c1; k2++) {
-            const uint32_t w = CIG(k2), op = w & 15;
+        for (; k2 < kend; k2++) {
+            const uint32_t w = l_cig[k2], op = w & 15;
             const int len = (int)(w >> 4);
             if (op == OP_N) break;
-            if (op == OP_M || op == OP_EQ || op == OP_X) { plen += len; gpos += len; rpos += len; }
+            if (op == OP_M || op == OP_EQ || op == OP_X) { if (runs++ == 0) run_ro = rpos; plen += len; gpos += len; rpos += len; }
             else if (op == OP_D) { plen += len; gpos += len; }
             else if (op == OP_G) gpos += len;
             else if (op == OP_I || op == OP_S) rpos += len;
             plain = plain && op != OP_I && op != OP_D && op != OP_G;
         }
-        const long long lo = (long long)pos + seg_start;
-        int i = gallop_lb(VP, a.nv, istart, lo);
-        for (; i < a.nv; i++) {
-            const long long vp = VP(i);
-            if (vp >= lo + plen) break;
-            const uint32_t d = DESC(i);
-            const int rs = (int)(vp - lo), rl = (int)(d & 0xFFu);
+        if ((unsigned)gpos >= (1u << 30)) return -1;
+        const int lo = pos + seg_start, hi = lo + plen;
+        // first staged variant at or after lo, galloping from where the previous segment ended
+        int i = istart;
+        if (i < wend && l_vpos[i - w0] < lo) {
+            int step = 1;
+            while (i + step < wend && l_vpos[i + step - w0] < lo) { i += step; step <<= 1; }
+            int l = i + 1, h = i + step < wend ? i + step : wend;
+            while (l < h) { const int m = (l + h) >> 1; if (l_vpos[m - w0] < lo) l = m + 1; else h = m; }
+            i = l;
+        }
+        for (;; i++) {
+            if (i >= wend) { if (wend < a.nv) return -1; break; }          // ran off the staged window with variants left
+            const int vp = l_vpos[i - w0];
+            if (vp >= hi) break;
+            const uint32_t d = l_desc[i - w0];
+            const int rs = vp - lo, rl = (int)(d & 0xFFu);
             if (rs + rl > plen) continue;
             if (!(plain && rl == 1) || cnt >= GEN_NC) return -1;
-            int pi = 0, ro = seg_rpos, x = 0;
-            for (uint32_t kk = k; kk < k2; kk++) {
-                const uint32_t w = CIG(kk), op = w & 15;
-                const int len = (int)(w >> 4);
-                if (op == OP_M || op == OP_EQ || op == OP_X) {
-                    if (rs < pi + len) { x = ro + (rs - pi); break; }
-                    pi += len; ro += len;
-                } else if (op == OP_S) ro += len;
+            int x = run_ro + rs;                 // one run of bases in a plain segment: the usual case
+            if (runs > 1) {
+                int pi = 0, ro = seg_rpos;
+                for (uint32_t kk = k; kk < k2; kk++) {
+                    const uint32_t w = l_cig[kk], op = w & 15;
+                    const int len = (int)(w >> 4);
+                    if (op == OP_M || op == OP_EQ || op == OP_X) {
+                        if (rs < pi + len) { x = ro + (rs - pi); break; }
+                        pi += len; ro += len;
+                    } else if (op == OP_S) ro += len;
+                }
             }
 #pragma unroll
             for (int c = 0; c < GEN_NC; c++) if (c == cnt) { ci[c] = i; cd[c] = d; cx[c] = x; }
             cnt++;
         }
         istart = i;
-        if (k2 >= c1) break;
-        gpos += (int)(CIG(k2) >> 4);
+        if (k2 >= kend) break;
+        gpos += (int)(l_cig[k2] >> 4);
         k = k2 + 1;
     }
     return cnt;
