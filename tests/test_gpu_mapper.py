@@ -162,6 +162,38 @@ def test_empty_and_edge_shards(mapper):
         mapper.map(shard, vpos, 10, ref_len=torch.full((30,), 2, dtype=torch.uint8))
 
 
+@pytest.mark.parametrize("n_snps,span,shift", [(400, 2_000_000, 0), (20_000, 2_000_000, 0), (200_000, 2_000_000, 0), (3000, 3_000_000, 1_200_000_000)])
+def test_general_kernel_agrees_with_snp_kernel(mapper, n_snps, span, shift):
+    """K_map_general on het SNPs handed over as allele strings must produce K_map's (record, variant) list, with code 5 / 6 where
+    the base is allele 0 / 1.  The four shapes walk its fast pass, its staged-window overflow (one SNP per 10 bp: every record is
+    handed to the work list), and the hand-over of coordinates beyond 2^30."""
+    from phaser_amd import soa, synth
+    v, gs, ge, w = synth.make_variants("chr1", 1, span, n_snps, 31, n_genes=max(4, n_snps // 50))
+    rb = synth.make_reads(v, gs, ge, w, 60_000, 32, n_rate=0.002)
+    rb = rb.select(synth.samtools_keep(rb, 255))
+    if shift:
+        rb.pos = rb.pos + shift
+    vpos = (v.pos + shift).to(torch.int32)
+    shard = soa.pack_readbatch(rb).to("cuda")
+    base = mapper.map(shard, vpos, 10).cpu()
+    nv = len(v)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ab = np.zeros(2 * nv + 1, dtype=np.uint8); ab[0:2 * nv:2] = letters[v.ref.numpy()]; ab[1:2 * nv:2] = letters[v.alt.numpy()]
+    calls, pool = mapper.map_general(shard, vpos, torch.ones(nv, dtype=torch.uint8), torch.arange(2 * nv + 1, dtype=torch.int32),
+                                     torch.from_numpy(ab), 10, want_text=True)
+    calls = calls.cpu()
+    assert base.n > 1000 and calls.n == base.n
+    assert torch.equal(calls.read_idx, base.read_idx) and torch.equal(calls.var_idx, base.var_idx)
+    bc = base.code.numpy().astype(np.int64); gc = calls.code.numpy().astype(np.int64); vi = base.var_idx.numpy()
+    single = bc < 4
+    want = np.where(bc == v.ref.numpy()[vi], 5, np.where(bc == v.alt.numpy()[vi], 6, bc))
+    assert np.array_equal(gc[single], want[single])
+    assert np.all(gc[~single] == 4) or np.all(np.isin(gc[~single], (4, 5, 6)))
+    # text pool: one offset per character of every code-4 call, in call order
+    toff = pool.call_off.numpy(); n4 = int((gc == 4).sum())
+    assert toff[0] == 0 and toff[-1] == len(pool.roff) and np.all(np.diff(toff) >= 0) and (np.diff(toff) > 0).sum() == n4
+
+
 def test_indel_mode_calls_bytes(mapper, tmp_path):
     """Mapper TSV with indel variants in the table (ref_len > 1, multi-base alleles): byte-identical to the reference."""
     d = os.path.join(GOLD, "pipe_indel")
