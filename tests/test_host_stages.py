@@ -140,3 +140,24 @@ def test_phased_vcf_noisy_maf_separator(case, gold, mode, conf):
     out, eng = run_host_stages(case, load, cfg, vcf_text, bam_display_names(bams))
     got, up, pc = vcfout.phased_vcf_text(vcf_text, 9, eng, id_separator=cfg.get("id_separator", "_"), gw_phase_vcf=mode, min_confidence=conf, threads=2)
     assert got == gz_text(os.path.join(d, "out.vcf_gw%d_c%d.txt.gz" % (mode, int(conf * 100))))
+
+
+def test_binom_cdf_bits_are_pinned():
+    """The pair test's p-value is scipy.stats.binom.cdf (phaser/phaser.py:1649).  tests/golden/binom_pins.json holds its bit
+    patterns from the scipy that ran the reference for the golden files (tools/make_binom_pins.py); both branches of
+    engine.binom_cdf_dedup (lookup table for small n, np.unique beyond) must reproduce them exactly on whatever box runs this."""
+    import numpy as np
+    from phaser_amd import engine
+    doc = json.load(open(os.path.join(GOLD, "binom_pins.json")))
+    pins = doc["pins"]
+    for p in sorted({x[2] for x in pins}):
+        rows = [x for x in pins if x[2] == p]
+        k = np.array([x[0] for x in rows], dtype=np.int64); n = np.array([x[1] for x in rows], dtype=np.int64)
+        want = np.array([float.fromhex(x[3]) for x in rows])
+        small = n <= 4000                      # lookup-table branch: (max n + 1)^2 <= 2^24
+        got = engine.binom_cdf_dedup(k[small], n[small], p)
+        assert got.tobytes() == want[small].tobytes(), (p, doc["scipy"])
+        # the np.unique branch: one large n forces it; the pinned rows must come out the same
+        k2 = np.concatenate([k, [3]]); n2 = np.concatenate([n, [5000]])
+        got2 = engine.binom_cdf_dedup(k2, n2, p)[:-1]
+        assert got2.tobytes() == want.tobytes(), (p, doc["scipy"])
