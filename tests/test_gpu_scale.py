@@ -38,11 +38,11 @@ def build(plan, n_bams, keep):
     return vsets, shards, samples
 
 
-def run_engine(mapper, vsets, shards, plan, **cfg):
+def run_engine(mapper, vsets, shards, plan, names=None, **cfg):
     from phaser_amd import synth, vcf
     from phaser_amd.engine import Config, Engine
     vs = vcf.load_variants("\n".join(synth.vcf_lines([vsets[p[0]] for p in plan])))
-    eng = Engine(vs, ["bam%d" % b for b in range(len(shards))], Config(want_vcf=False, **cfg), mapper=mapper)
+    eng = Engine(vs, names or ["bam%d" % b for b in range(len(shards))], Config(want_vcf=False, **cfg), mapper=mapper)
     for b, per_chrom in enumerate(shards):
         # QNAME ids are shared by the BAMs of a chromosome: id k of every BAM is the same template name "q<k>"
         eng.add_shards(b, [(c, sh, int(sh.qid.max()) + 1) for c, sh in per_chrom.items()])
@@ -146,3 +146,59 @@ def test_whole_genome_four_bams_shared_qnames(mapper, oracle_build):
     del eng, out, shards, samples
     torch.cuda.empty_cache()
     check_replica_vs_oracle(mapper, workloads.genome_plan(total_records=20_000_000, scale=0.02), 4, min_phased=200)
+
+
+def test_sample_stream_configs4_shape(mapper, tmp_path):
+    """configs[4] shape on one rank: whole-genome samples (22 chromosomes each, different variant sets, read sets and SIZES) streamed
+    one after the other through ONE device context -- the per-rank loop of the 128-sample batch (tools/run_c5.py) -- each through
+    the hot path, phaser_gene_ae and, at the end, phaser_expr_matrix.  Every sample's five files must equal the pinned phasing
+    oracle's (no state of sample k may leak into sample k+1: the scratch buffers, staging slots and shard tables are reused at other
+    sizes), every gene table the pinned gene_ae oracle's, and the matrices must carry exactly those tables' cells."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import phasing_oracle as po
+    import gene_ae_oracle as go
+    from phaser_amd import expr_matrix, gene_ae, workloads
+    scales = [0.008, 0.02, 0.004, 0.012]              # growing and shrinking: buffer reuse both ways
+    gdir = tmp_path / "gene_ae"; gdir.mkdir()
+    bed = None; tables = {}
+    for s, scale in enumerate(scales):
+        plan = workloads.genome_plan(scale=scale, seed=4000 + 100 * s)
+        vsets, shards, _ = build(plan, 1, 0)
+        eng, got = run_engine(mapper, vsets, shards, plan, names=["sample%03d" % s], host_threads=4)
+        ph = po.Phaser(["sample%03d" % s])
+        ph.add_bam([call_text(vsets[p[0]], shards[0][p[0]], eng.shards[p[0]][0].calls) for p in plan])
+        want = ph.finish()
+        for name in OUTPUTS:
+            assert canonical(name, got[name]) == canonical(name, want[name]), (s, name)
+        assert eng.phased == ph.phased and eng.phased > 300
+        hc = got["haplotypic_counts"]
+        if bed is None:                               # one gene model for the batch: merged spans of the first sample's rows
+            spans = {}
+            for line in hc.split("\n")[1:]:
+                if line:
+                    c = line.split("\t", 3); spans.setdefault(c[0], []).append((int(c[1]) - 1, int(c[2])))
+            feats = []
+            for chrom, sp in spans.items():
+                sp.sort(); a0, b0 = sp[0]
+                for a, b in sp[1:]:
+                    if a - b0 < 5000: b0 = max(b0, b)
+                    else: feats.append((chrom, a0, b0)); a0, b0 = a, b
+                feats.append((chrom, a0, b0))
+            bed = "".join("%s\t%d\t%d\tg%d\n" % (c, max(0, a - 50), b + 50, k) for k, (c, a, b) in enumerate(feats))
+            (tmp_path / "genes.bed").write_text(bed)
+        table = gene_ae.gene_ae(hc.encode(), bed, ctx=mapper.ctx)
+        assert go.canonical(table) == go.canonical(go.gene_ae(hc, bed)), s
+        (gdir / ("sample%03d.gene_ae.txt" % s)).write_text(table)
+        tables["sample%03d" % s] = {r.split("\t")[3]: r.split("\t") for r in table.split("\n")[1:] if r}
+        del eng, got, shards
+        torch.cuda.empty_cache()
+    a, g, log = expr_matrix.expr_matrix(str(gdir), str(tmp_path / "genes.bed"))
+    assert not log
+    rows = [r.split("\t") for r in a.split("\n") if r]
+    assert rows[0][4:] == sorted(tables) and len(rows) - 1 == len(bed.splitlines())
+    hdr = open(str(gdir / "sample000.gene_ae.txt")).readline().rstrip("\n").split("\t")
+    ia, ib = hdr.index("aCount"), hdr.index("bCount")
+    for r in rows[1:]:
+        for k, smp in enumerate(sorted(tables)):
+            t = tables[smp].get(r[3])
+            assert t is not None and r[4 + k] == "%s|%s" % (t[ia], t[ib]), (r[3], smp)
