@@ -24,6 +24,9 @@
 #include "phz_text.h"
 
 namespace {
+std::atomic<long long> g_phase_ns{0};     // PHZ_TIMING: thread-time spent inside phase_component (block phasing proper)
+bool g_phase_timing = false;
+
 
 using phztext::Pool;
 using phztext::put_int;
@@ -480,7 +483,11 @@ void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
             }
         }
         subs.clear();
-        o.status = phase_component(g, I.max_block_size, subs);
+        if (g_phase_timing) {
+            const auto t0 = std::chrono::steady_clock::now();
+            o.status = phase_component(g, I.max_block_size, subs);
+            g_phase_ns.fetch_add((long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+        } else o.status = phase_component(g, I.max_block_size, subs);
         if (o.status) return;
         sub_of.assign((size_t)n, -1); alle_of.assign((size_t)n, 0);
         for (size_t s = 0; s < subs.size(); s++)
@@ -750,6 +757,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
     if (n_chroms <= 0) return PHZ_OK;
     threads = std::max(1, threads);
     const bool timing = getenv("PHZ_TIMING") != nullptr;
+    g_phase_timing = timing;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -821,6 +829,7 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
         else run_conn(S.C, k.i * estep, std::min<int64_t>(use[(size_t)k.c]->n_edges, (k.i + 1) * estep), S.cc[(size_t)k.i]);
     });
     lap("block phasing + block / connection rows");
+    if (timing) fprintf(stderr, "  phz_rows:   of which phase_component (phase_v3 + brute force) %.4f thread-seconds over %d threads\n", g_phase_ns.exchange(0) / 1e9, threads);
     for (auto &S : st) for (auto &c : S.bc) if (c.status) { const int code = c.status; delete keep; return code; }
     // ---- phase B2: allelic counts + singleton rows (need to know which variants ended up in a block)
     tasks.clear();
