@@ -20,7 +20,7 @@
 //   k_gen_emit                 streams side[r] to each record's place (tile base + an in-workgroup scan of the counts)
 //   k_map_general_list<true>   writes the calls of the few listed records that did not fit the packed form
 // Measured on the configs[1] shard (50M records, 40k het SNPs as allele strings, 10.2M calls): 3.6 ms before this layout, 1.8 ms
-// now, K_map on the same shard 0.91 ms; the fast pass is bound by VALU issue (about 2,700 vector instructions per wave).
+// now, K_map on the same shard 0.91 ms; the fast pass is bound by instruction issue (1,929 vector + 2,561 scalar instructions per wave of 256 records).
 #include <cstring>
 #include "phz_internal.h"
 #include "phz_scan.h"
