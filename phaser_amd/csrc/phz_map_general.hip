@@ -19,8 +19,8 @@
 //   scan over ~n/1024 tile totals; host reads the totals and sizes the output
 //   k_gen_emit                 streams side[r] to each record's place (tile base + an in-workgroup scan of the counts)
 //   k_map_general_list<true>   writes the calls of the few listed records that did not fit the packed form
-// Measured on the configs[1] shard (50M records, 40k het SNPs as allele strings, 10.2M calls): 3.6 ms before this layout, 1.8 ms
-// now, K_map on the same shard 0.91 ms; the fast pass is bound by instruction issue (1,929 vector + 2,561 scalar instructions per wave of 256 records).
+// Measured on the configs[1] shard (50M records, 40k het SNPs as allele strings, 10.2M calls): 3.6 ms before this layout, 1.6 ms
+// now, K_map on the same shard 0.90 ms; the fast pass is bound by instruction issue (2,076 vector + 1,730 scalar instructions per wave of 256 records).
 #include <cstring>
 #include "phz_internal.h"
 #include "phz_scan.h"
@@ -283,27 +283,30 @@ __device__ __forceinline__ int walk_fast(const GenArgs &a, int w0, int wlen, con
     const lds_u32 l_desc = (lds_u32)s_desc, l_cig = (lds_u32)s_cig;
     if ((unsigned)pos >= (1u << 30) || c1 - cb > ncig) return -1;
     const int wend = w0 + wlen;                 // staged variants: [w0, wend); wend == nv or vpos[wend - 1] is past the cover
-    int gpos = 0, rpos = 0, istart = w0, cnt = 0;
-    uint32_t k = c0 - cb, kend = c1 - cb;
-    for (;;) {
+    int gpos = 0, rpos = 0, i = w0, cnt = 0;
+    bool bail = false;                          // sticky: the record goes to the work list (no early returns: every divergent exit
+    uint32_t k = c0 - cb, kend = c1 - cb;       // costs a handful of exec-mask instructions, and the pass is bound by those)
+    bool more = true;
+    while (more) {
         const int seg_start = gpos, seg_rpos = rpos;
         int plen = 0, runs = 0, run_ro = 0;      // runs of bases in the segment, read offset of the first one
         uint32_t k2 = k;
         bool plain = true;
-        for (; k2 < kend; k2++) {
-            const uint32_t w = l_cig[k2], op = w & 15;
+        for (; k2 < kend; k2++) {                 // op classes as bit sets, selects instead of branches
+            const uint32_t w = l_cig[k2], op = w & 15, bit = 1u << op;
             const int len = (int)(w >> 4);
             if (op == OP_N) break;
-            if (op == OP_M || op == OP_EQ || op == OP_X) { if (runs++ == 0) run_ro = rpos; plen += len; gpos += len; rpos += len; }
-            else if (op == OP_D) { plen += len; gpos += len; }
-            else if (op == OP_G) gpos += len;
-            else if (op == OP_I || op == OP_S) rpos += len;
-            plain = plain && op != OP_I && op != OP_D && op != OP_G;
+            const bool bases = (bit & 0x181u) != 0;                          // M = X
+            run_ro = (bases && runs == 0) ? rpos : run_ro;
+            runs += bases ? 1 : 0;
+            plen += (bit & 0x185u) ? len : 0;                                // M = X D
+            gpos += (bit & 0x385u) ? len : 0;                                // M = X D G
+            rpos += (bit & 0x193u) ? len : 0;                                // M = X I S
+            plain = plain && (bit & 0x206u) == 0;                            // no I D G
         }
-        if ((unsigned)gpos >= (1u << 30)) return -1;
+        bail = bail || (unsigned)gpos >= (1u << 30);
         const int lo = pos + seg_start, hi = lo + plen;
         // first staged variant at or after lo, galloping from where the previous segment ended
-        int i = istart;
         if (i < wend && l_vpos[i - w0] < lo) {
             int step = 1;
             while (i + step < wend && l_vpos[i + step - w0] < lo) { i += step; step <<= 1; }
@@ -311,16 +314,20 @@ __device__ __forceinline__ int walk_fast(const GenArgs &a, int w0, int wlen, con
             while (l < h) { const int m = (l + h) >> 1; if (l_vpos[m - w0] < lo) l = m + 1; else h = m; }
             i = l;
         }
-        for (;; i++) {
-            if (i >= wend) { if (wend < a.nv) return -1; break; }          // ran off the staged window with variants left
-            const int vp = l_vpos[i - w0];
-            if (vp >= hi) break;
-            const uint32_t d = l_desc[i - w0];
+        bool go = !bail;
+        while (go) {
+            const bool inw = i < wend;
+            const int t = inw ? i - w0 : 0;
+            const int vp = l_vpos[t];
+            const uint32_t d = l_desc[t];
+            bail = bail || (!inw && wend < a.nv);                            // ran off the staged window with variants left
+            const bool inside = inw && vp < hi;
             const int rs = vp - lo, rl = (int)(d & 0xFFu);
-            if (rs + rl > plen) continue;
-            if (!(plain && rl == 1) || cnt >= GEN_NC) return -1;
+            const bool cand = inside && rs + rl <= plen;
+            bail = bail || (cand && (!(plain && rl == 1) || cnt >= GEN_NC));
+            const bool take = cand && !bail;
             int x = run_ro + rs;                 // one run of bases in a plain segment: the usual case
-            if (runs > 1) {
+            if (take && runs > 1) {
                 int pi = 0, ro = seg_rpos;
                 for (uint32_t kk = k; kk < k2; kk++) {
                     const uint32_t w = l_cig[kk], op = w & 15;
@@ -332,15 +339,19 @@ __device__ __forceinline__ int walk_fast(const GenArgs &a, int w0, int wlen, con
                 }
             }
 #pragma unroll
-            for (int c = 0; c < GEN_NC; c++) if (c == cnt) { ci[c] = i; cd[c] = d; cx[c] = x; }
-            cnt++;
+            for (int c = 0; c < GEN_NC; c++) {
+                const bool put = take && c == cnt;
+                ci[c] = put ? i : ci[c]; cd[c] = put ? d : cd[c]; cx[c] = put ? x : cx[c];
+            }
+            cnt += take ? 1 : 0;
+            go = inside && !bail;
+            i += go ? 1 : 0;
         }
-        istart = i;
-        if (k2 >= kend) break;
-        gpos += (int)(l_cig[k2] >> 4);
+        more = !bail && k2 < kend;
+        gpos += more ? (int)(l_cig[k2 < kend ? k2 : 0u] >> 4) : 0;
         k = k2 + 1;
     }
-    return cnt;
+    return bail ? -1 : cnt;
 }
 
 // Fast pass (count): GEN_RPL records per lane.  Besides the per-record counts it leaves each record's calls packed in side[r]
