@@ -391,11 +391,16 @@ _view_from_memory.restype = C.py_object
 _view_from_memory.argtypes = [C.c_void_p, C.c_ssize_t, C.c_int]
 
 
+_DTYPE_OF: dict = {}
+
+
 def native_view(ptr, count: int, ctype, owner):
     """-> numpy array over `count` items of `ctype` at `ptr`, alive as long as the array (or anything built on it) is."""
+    dt = _DTYPE_OF.get(ctype)
+    if dt is None:
+        dt = _DTYPE_OF[ctype] = np.dtype(ctype)      # numpy derives a dtype from a ctypes type in ~3 us: once per type, not per view
     if count == 0 or not ptr:
-        return np.zeros(0, dtype=np.dtype(ctype))
+        return np.zeros(0, dtype=dt)
     # PyMemoryView_FromMemory + frombuffer: ~1 us; np.ctypeslib.as_array builds a ctypes array type per distinct length (~20 us)
-    dt = np.dtype(ctype)
     a = np.frombuffer(_view_from_memory(ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value, count * dt.itemsize, 0x200), dtype=dt)
     return OwnedArray(a, owner)
