@@ -512,6 +512,11 @@ __global__ __launch_bounds__(256) void k_gen_emit(GenArgs a) {
     }
 }
 
+// terminator of the per-call text offsets: call_text_off[total] = text total
+__global__ void k_gen_tail(const uint32_t *total, const uint32_t *ttotal, uint32_t *toff, int64_t cap) {
+    if ((int64_t)*total <= cap) toff[*total] = *ttotal;
+}
+
 // the records the fast pass left: one lane each, dense
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_map_general_list(GenArgs a) {
@@ -579,6 +584,30 @@ extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const
     if (int s = scan_excl(ctx, a.tile_calls, cb, (int64_t)grid, S[6])) return s;
     if (int s = scan_excl(ctx, a.tile_text, tb, (int64_t)grid, S[6])) return s;
     uint32_t last[2], n_listed = 0;
+    if (space == PHZ_DEVICE) {
+        // device-resident outputs already exist at their capacity: nothing on the host has to know the totals before the emit
+        // kernels run (every store is bounded by cap / text_cap), so the whole call is queued at once and waited for once
+        a.o_read = out->read_idx; a.o_var = out->var_idx; a.o_code = out->code; a.o_aux0 = out->aux0; a.o_aux1 = out->aux1;
+        a.o_text_off = (call_text_off && text_roff) ? call_text_off : nullptr; a.o_text = (call_text_off && text_roff) ? text_roff : nullptr;
+        a.cap = out->cap; a.text_cap = text_cap;
+        hipLaunchKernelGGL(k_gen_emit, dim3(grid), dim3(256), 0, sm, a);
+        hipLaunchKernelGGL(k_map_general_list<true>, dim3(2048), dim3(256), 0, sm, a);
+        if (a.o_text_off) hipLaunchKernelGGL(k_gen_tail, dim3(1), dim3(1), 0, sm, (const uint32_t *)(cb + grid), (const uint32_t *)(tb + grid), a.o_text_off, a.cap);
+        PHZ_HIP(ctx, hipGetLastError());
+        PHZ_HIP(ctx, hipEventRecord(ctx->ev1, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(&n_listed, a.wl_n, 4, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(&last[0], cb + grid, 4, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(&last[1], tb + grid, 4, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));
+        if (getenv("PHZ_GEN_DBG")) fprintf(stderr, "K_map_general: %lld records, %u handed to the list, %u calls, %u text\n", (long long)n, n_listed, last[0], last[1]);
+        *n_calls = (int64_t)last[0];
+        if (n_text) *n_text = (int64_t)last[1];
+        float ms = 0;
+        PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_ms[PHZ_T_MAP] = ms; ctx->total_ms[PHZ_T_MAP] += ms; ctx->launches[PHZ_T_MAP]++;
+        if ((int64_t)last[0] > out->cap || (text_roff && (int64_t)last[1] > text_cap)) return PHZ_E_CAPACITY;
+        return PHZ_OK;
+    }
     PHZ_HIP(ctx, hipMemcpyAsync(&n_listed, a.wl_n, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&last[0], cb + grid, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&last[1], tb + grid, 4, hipMemcpyDeviceToHost, sm));
