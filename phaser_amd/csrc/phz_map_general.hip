@@ -19,7 +19,7 @@
 //   scan over ~n/1024 tile totals; host reads the totals and sizes the output
 //   k_gen_emit                 streams side[r] to each record's place (tile base + an in-workgroup scan of the counts)
 //   k_map_general_list<true>   writes the calls of the few listed records that did not fit the packed form
-// Measured on the configs[1] shard (50M records, 40k het SNPs as allele strings, 10.2M calls): 3.6 ms before this layout, 1.6 ms
+// Measured on the configs[1] shard (50M records, 40k het SNPs as allele strings, 10.2M calls): 3.6 ms before this layout, 1.6-1.7 ms
 // now, K_map on the same shard 0.90 ms; the fast pass is bound by instruction issue (2,076 vector + 1,730 scalar instructions per wave of 256 records).
 #include <cstring>
 #include "phz_internal.h"
@@ -99,16 +99,19 @@ constexpr int GEN_WIN = 1024;      // variants staged per workgroup (max); beyon
 constexpr int GEN_COVER = 65536;   // the staged window reaches POS(last record of the workgroup) + GEN_COVER
 
 // The complete rule for one record (any REF length, any CIGAR): run by k_map_general_list on the records the fast pass hands over.
+// w0: first variant at or after the POS of the first record of r's tile (k_gen_window): every search starts there or later.
 template <bool EMIT>
-__device__ void gen_read(const GenArgs &a, int64_t r, int w0, int wlen, const int32_t *s_vpos, const uint32_t *s_desc, int pos, uint32_t c0,
-                         uint32_t c1, uint32_t soff, uint32_t cb, uint32_t ncig, const uint32_t *s_cig, int hint, int pre_i, uint32_t pre_q, uint32_t pre_s) {
+__device__ void gen_read(const GenArgs &a, int64_t r, int w0) {
     uint32_t ncalls = 0, ntext = 0, pkv[2] = {0u, 0u}, pkw[2] = {0u, 0u};
-    if (EMIT && (a.n_calls[r] == 0 || !(a.side[r].y & 0x40000000u))) return;                             // nothing under this record (the count pass knows)
+    // emit pass: nothing under this record, or its calls went out with the packed ones (k_gen_emit)
+    if (EMIT && (a.n_calls[r] == 0 || !(a.side[r].y & 0x40000000u))) return;
     const uint64_t cbase = EMIT ? a.call_base[r] : 0, tbase = EMIT ? a.text_base[r] : 0;
-    auto VP = [&](int i) -> int { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_vpos[t] : a.vpos[i]; };
-    auto CIG = [&](uint32_t kx) -> uint32_t { const uint32_t t = kx - cb; return t < ncig ? s_cig[t] : a.cigar[kx]; };
-    auto DESC = [&](int i) -> uint32_t { const unsigned t = (unsigned)(i - w0); return t < (unsigned)wlen ? s_desc[t] : a.desc[i]; };
-    int gpos = 0, rpos = 0, istart = hint;      // segments move forward: each search starts where the previous one ended
+    const int pos = a.pos[r];
+    const uint32_t c0 = a.cigar_off[r], c1 = a.cigar_off[r + 1], soff = a.seq_off[r];
+    auto VP = [&](int i) -> int { return a.vpos[i]; };
+    auto CIG = [&](uint32_t kx) -> uint32_t { return a.cigar[kx]; };
+    auto DESC = [&](int i) -> uint32_t { return a.desc[i]; };
+    int gpos = 0, rpos = 0, istart = w0;        // segments move forward: each search starts where the previous one ended
     uint32_t k = c0;
     for (;;) {
         const int seg_start = gpos, seg_rpos = rpos;
@@ -139,7 +142,7 @@ __device__ void gen_read(const GenArgs &a, int64_t r, int w0, int wlen, const in
                         pi += len; ro += len;
                     } else if (op == OP_S) ro += len;
                 }
-                const int sym = i == pre_i ? sym_of(a.baseq, pre_q, pre_s, x) : sym_at(a, soff, x);
+                const int sym = sym_at(a, soff, x);
                 if (sym == 4) continue;
                 const uint32_t ch = sym_char(sym);
                 const int code = ch == ((d >> 8) & 0xFFu) ? 5 : ch == ((d >> 16) & 0xFFu) ? 6 : sym < 4 ? sym : 4;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void k_map_general_list(GenArgs a) {
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < m; t += gridDim.x * 256) {
         const int64_t r = a.wl[t];
         const int w0 = a.win[2 * (r / GEN_TILE)];
-        gen_read<EMIT>(a, r, w0, 0, nullptr, nullptr, a.pos[r], a.cigar_off[r], a.cigar_off[r + 1], a.seq_off[r], 0u, 0u, nullptr, w0, -1, 0u, 0u);
+        gen_read<EMIT>(a, r, w0);
     }
 }
 
