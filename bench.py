@@ -175,12 +175,12 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    import gc
+    gc.collect(); gc.disable()          # before the barrier: a collector pause inside twenty 1.5 ms steps would be a visible share of the timed region
     mapper.ctx.reset_timing()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    import gc
-    gc.collect(); gc.disable()          # a collector pause inside twenty 1.5 ms steps would be a visible share of the timed region
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
