@@ -127,6 +127,10 @@ def main():
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the container's CPU quota (cpu.max), not the host's core count, bounds what torch's intra-op pool may use: 256 OpenMP threads
+    # spinning on a 16-CPU quota get the whole cgroup throttled, timed regions included
+    from phaser_amd import dist as pdist
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), pdist.effective_cpus() // max(1, world))))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # one rank per GPU over RCCL ("nccl"); PHZ_BENCH_BACKEND=gloo lets several ranks share a GPU (used only to exercise the
     # multi-rank path on a 1-GPU box)
@@ -215,6 +219,8 @@ def main():
         vs = pvcf.load_variants("\n".join(synth.vcf_lines([workloads_variants(plan, vsets, p) for p in plan])))
         # host threads of the row writer: four per CPU the container may really use (quota-aware; the phases are short and bursty), shared by the ranks of the node
         host_threads = max(1, min(64, 4 * pdist.effective_cpus() // max(1, world)))
+        if os.environ.get("PHZ_BENCH_HOST_THREADS"):
+            host_threads = int(os.environ["PHZ_BENCH_HOST_THREADS"])
         calls_now = [Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i in range(len(chroms))]
         runs = []
         for rep in range(max(1, a.phasing_passes)):

@@ -92,6 +92,8 @@ def load_bed(path: str) -> List[tuple]:
 def main(argv=None):
     args = build_parser().parse_args(argv)
     rank, world = pdist.world()
+    # torch's intra-op pool sized by the container's CPU quota, not by the host's core count (see dist.effective_cpus)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), pdist.effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, n_dev)
     if n_dev:
