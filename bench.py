@@ -180,6 +180,7 @@ def main():
     for _ in range(a.warmup):
         step()
     import gc
+    time.sleep(0.12)                    # let a CPU-quota period that the set-up may have exhausted run out before the timed region starts
     gc.collect(); gc.disable()          # before the barrier: a collector pause inside twenty 1.5 ms steps would be a visible share of the timed region
     mapper.ctx.reset_timing()
     if world > 1:
