@@ -15,6 +15,7 @@
 #include <atomic>
 #include <charconv>
 #include <chrono>
+#include <sys/resource.h>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -226,6 +227,14 @@ int phase_component(AlleleGraph &g, int max_block_size, std::vector<std::pair<in
 // distinct values of q[0..n) numbered by first appearance; label[i] = number of q[i]; ids = distinct values in that order
 struct Ranker {
     std::vector<int32_t> key, val;
+    // scratch of emit_block, kept across the blocks of a chunk: a block used to construct (and free) fifteen small containers
+    struct Scratch {
+        std::vector<int8_t> phs[2], cor[2];
+        std::vector<int32_t> pool, allq, label, ids[2];
+        std::vector<int> used_vars, black;
+        std::vector<size_t> vlen;
+        std::string labels[2], stat_txt;
+    } s;
     void run(const std::vector<int32_t> &q, std::vector<int32_t> *label, std::vector<int32_t> *ids, int64_t *ndistinct) {
         size_t cap = 16;
         while (cap < q.size() * 2) cap <<= 1;
@@ -289,9 +298,9 @@ void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &h
     int minpos = I.pos[vars[0]], maxpos = I.pos[vars[0]];
     for (int g : vars) { minpos = std::min(minpos, I.pos[g]); maxpos = std::max(maxpos, I.pos[g]); }
     // phase indices of each haplotype's alleles in the VCF phase (-1 = not phased there)
-    std::vector<int8_t> phs[2];
+    std::vector<int8_t> (&phs)[2] = rk.s.phs;
     int64_t counts[2];
-    std::vector<int32_t> pool;
+    std::vector<int32_t> &pool = rk.s.pool;
     for (int h = 0; h < 2; h++) {
         phs[h].resize((size_t)n);
         pool.clear();
@@ -314,7 +323,8 @@ void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &h
     }
     const int conc = all_equal ? 1 : 0;                       // usable values all the same (or none)
     // genome-wide phase (:945-1025)
-    std::vector<int8_t> cor[2] = {phs[0], phs[1]};
+    std::vector<int8_t> (&cor)[2] = rk.s.cor;
+    cor[0] = phs[0]; cor[1] = phs[1];
     double stat = 0.5; bool stat_int = false;
     auto by_mean = [&]() {
         double m = (double)ksum / (double)nknown;
@@ -340,7 +350,8 @@ void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &h
             } else by_mean();
         }
     }
-    std::string stat_txt;
+    std::string &stat_txt = rk.s.stat_txt;
+    stat_txt.clear();
     if (stat_int) stat_txt = "1"; else put_pyfloat(stat_txt, stat);
     int maxmaf_g = vars[0];
     for (int g : vars) if (I.maf[g] > I.maf[maxmaf_g]) maxmaf_g = g;       // first maximal element, like max()
@@ -362,10 +373,10 @@ void emit_block(const Ctx &C, const std::vector<int> &vars, const std::string &h
     phase_chars(cor[0], H); H += '|'; phase_chars(cor[1], H); H += '\t'; H += stat_txt; H += '\n';
 
     // ---- haplotypic_counts.txt: one row per BAM (:1048-1125)
-    std::vector<int> used_vars, black;
-    std::vector<int32_t> allq, label, ids[2];
-    std::vector<size_t> vlen;
-    std::string labels[2];
+    std::vector<int> &used_vars = rk.s.used_vars, &black = rk.s.black;
+    std::vector<int32_t> &allq = rk.s.allq, &label = rk.s.label, (&ids)[2] = rk.s.ids;
+    std::vector<size_t> &vlen = rk.s.vlen;
+    std::string (&labels)[2] = rk.s.labels;
     for (int b = 0; b < I.nb; b++) {
         if (I.bam_excluded && I.bam_excluded[b]) continue;
         used_vars.clear(); black.clear();
@@ -452,7 +463,8 @@ void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
     o.hap.reserve((size_t)std::min(o.est_hap, res_max)); o.ase.reserve((size_t)std::min(o.est_ase, res_max)); o.cfg.reserve((size_t)std::min(o.est_cfg, res_max));
     Ranker rk;
     AlleleGraph g;
-    std::vector<int> mem, vars, sub_of, alle_of;
+    std::vector<int> mem, vars, sub_of, alle_of, byid, idx;
+    std::vector<long> sup, tot;
     std::vector<std::pair<int, std::string>> subs;
     struct LE { int i, j, k; };
     std::vector<LE> edges;
@@ -461,13 +473,18 @@ void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
         mem.assign(I.mem_s + I.comp_starts[ci], I.mem_s + I.comp_ends[ci]);
         std::sort(mem.begin(), mem.end(), [&](int a, int b) { return I.pos[a] != I.pos[b] ? I.pos[a] < I.pos[b] : a < b; });   // sort_var_ids :1884
         const int n = (int)mem.size();
-        std::vector<int> byid(mem);                                 // for the global -> local lookup
-        std::vector<int> idx((size_t)n);
+        byid.assign(mem.begin(), mem.end());                        // for the global -> local lookup
+        idx.resize((size_t)n);
         for (int i = 0; i < n; i++) idx[i] = i;
         std::sort(idx.begin(), idx.end(), [&](int a, int b) { return mem[a] < mem[b]; });
         for (int i = 0; i < n; i++) byid[i] = mem[idx[i]];
         auto loc = [&](int gid) { return idx[std::lower_bound(byid.begin(), byid.end(), gid) - byid.begin()]; };
-        g.n = n; g.adj.assign((size_t)2 * n, {}); g.vedges.clear(); g.mark.assign((size_t)2 * n + 2, 0);
+        // the per-node neighbour vectors outlive the component (cleared, not destroyed), like every other temporary of this loop:
+        // a genome is ~1M components of two or three variants
+        g.n = n;
+        if (g.adj.size() < (size_t)2 * n) g.adj.resize((size_t)2 * n);
+        for (int k = 0; k < 2 * n; k++) g.adj[(size_t)k].clear();
+        g.vedges.clear(); g.mark.assign((size_t)2 * n + 2, 0);
         edges.clear();
         for (int64_t t = I.e_starts[ci]; t < I.e_ends[ci]; t++) {
             const int64_t e = I.e_keep[I.eo[t]];
@@ -496,7 +513,7 @@ void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
                 if (li < n) { sub_of[li] = (int)s; alle_of[li] = subs[s].second[t] - '0'; }
             }
         // allele edges supporting / total inside each final block (:876-895; ordered pairs halved = edges)
-        std::vector<long> sup(subs.size(), 0), tot(subs.size(), 0);
+        sup.assign(subs.size(), 0); tot.assign(subs.size(), 0);
         for (auto &e : edges) {
             if (e.k < 0 || sub_of[e.i] < 0 || sub_of[e.i] != sub_of[e.j]) continue;
             tot[sub_of[e.i]]++;
@@ -759,11 +776,21 @@ extern "C" int phz_rows_format_multi(const phz_rows_in *in, int n_chroms, phz_ro
     const bool timing = getenv("PHZ_TIMING") != nullptr;
     g_phase_timing = timing;
     auto t_prev = std::chrono::steady_clock::now();
+    // wall time and, next to it, the CPU time the whole process spent in the lap: under a container CPU quota the second one is what
+    // a pass really costs (wall time then depends on how much of the period's quota is left)
+    struct Cpu { double user, sys; };
+    auto cpu_now = []() {
+        rusage ru; getrusage(RUSAGE_SELF, &ru);
+        return Cpu{(double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec, (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec};
+    };
+    Cpu cpu_prev = timing ? cpu_now() : Cpu{0, 0};
     auto lap = [&](const char *what) {
         if (!timing) return;
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[phz timing]   rows: %-42s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
-        t_prev = now;
+        const Cpu cpu = cpu_now();
+        fprintf(stderr, "[phz timing]   rows: %-42s %7.1f ms wall, cpu %7.1f ms user + %7.1f ms system\n", what,
+                std::chrono::duration<double, std::milli>(now - t_prev).count(), (cpu.user - cpu_prev.user) * 1e3, (cpu.sys - cpu_prev.sys) * 1e3);
+        t_prev = now; cpu_prev = cpu;
     };
     for (int c = 0; c < n_chroms; c++) memset(&out[c], 0, sizeof(out[c]));
     RowsOwner *keep = new RowsOwner();
