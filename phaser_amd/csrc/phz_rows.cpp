@@ -465,6 +465,7 @@ void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
     AlleleGraph g;
     std::vector<int> mem, vars, sub_of, alle_of, byid, idx;
     std::vector<long> sup, tot;
+    std::string ha2 = "00";
     std::vector<std::pair<int, std::string>> subs;
     struct LE { int i, j, k; };
     std::vector<LE> edges;
@@ -473,6 +474,19 @@ void run_block_chunk(Ctx &C, int64_t lo, int64_t hi, BlockChunk &o) {
         mem.assign(I.mem_s + I.comp_starts[ci], I.mem_s + I.comp_ends[ci]);
         std::sort(mem.begin(), mem.end(), [&](int a, int b) { return I.pos[a] != I.pos[b] ? I.pos[a] < I.pos[b] : a < b; });   // sort_var_ids :1884
         const int n = (int)mem.size();
+        // The commonest component by far: two variants joined by one edge with a verdict.  resolve_phase floods (variant 0, allele 0)
+        // to (variant 1, allele 0) for a cis edge and to (variant 1, allele 1) for a trans edge, i.e. one block "00" / "01" with
+        // one supporting edge out of one (phaser.py:2172-2207, :876-895): nothing of the graph machinery below is needed.
+        if (n == 2 && I.e_ends[ci] - I.e_starts[ci] == 1) {
+            const int k = (int)I.cfgv[I.e_keep[I.eo[I.e_starts[ci]]]];
+            if (k == 0 || k == 1) {
+                vars.assign(mem.begin(), mem.end());
+                C.phased[vars[0]] = 1; C.phased[vars[1]] = 1;
+                ha2[1] = k == 0 ? '0' : '1';
+                emit_block(C, vars, ha2, 1.0, 1.0, rk, o);
+                continue;
+            }
+        }
         byid.assign(mem.begin(), mem.end());                        // for the global -> local lookup
         idx.resize((size_t)n);
         for (int i = 0; i < n; i++) idx[i] = i;
