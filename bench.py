@@ -64,6 +64,32 @@ def pmc_traffic():
     return None
 
 
+def pmc_traffic_tally():
+    """HBM bytes per phasing pass of the K_tally family (phz_tally.hip kernels, phz_components, the rocPRIM sorts / scans they call)
+    from a PMC summary committed under profiles/ (tools/prof_pmc_tally.sh; same rules as pmc_traffic: separate --pmc passes,
+    FETCH_SIZE doubled, reported only while the kernel source hash matches)."""
+    import csv, glob
+    src = file_sha("phaser_amd/csrc/phz_tally.hip")
+    for d in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_ktally_*")))):
+        meta = os.path.join(d, "meta.json")
+        if not os.path.exists(meta):
+            continue
+        m = json.load(open(meta))
+        if m.get("kernel_source_sha16") != src or m.get("workload") != "configs[2]" or not m.get("passes"):
+            continue
+        tot = {}
+        for name in ("fetch", "write"):
+            f = os.path.join(d, name + ".csv")
+            if not os.path.exists(f):
+                return None
+            tot[name] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)))
+        return {"bytes_per_pass": (2 * tot["fetch"] + tot["write"]) * 1024 / m["passes"], "fetch_raw_kib_per_pass": tot["fetch"] / m["passes"],
+                "write_kib_per_pass": tot["write"] / m["passes"], "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
+                "note": "sum over the K_tally family of one pass; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; the sort passes and the "
+                        "sector-granular scattered writes move ~30x the algorithmic bytes"}
+    return None
+
+
 def cpu_mapper_baseline(sample, vpos, baseq):
     """Mapper oracle (C restatement, kind 'port') on one host core and on all cores over a bounded sample."""
     import subprocess
@@ -259,7 +285,7 @@ def main():
                              "roofline": {"bound": "hbm", "kernel": "K_tally (all kernels of phz_tally, HIP events on the ctx stream)",
                                           "achieved": tally_bytes / (tally_ms / 1e3) / 1e9 if tally_ms > 0 else None, "peak": HBM_PEAK_GBS,
                                           "unit": "GB/s", "frac": tally_bytes / (tally_ms / 1e3) / 1e9 / HBM_PEAK_GBS if tally_ms > 0 else None,
-                                          "traffic": None, "algorithmic_bytes": tally_bytes,
+                                          "traffic": pmc_traffic_tally() if world == 1 else None, "algorithmic_bytes": tally_bytes,
                                           "model": "8 B x call lines + 16 B x pair events (SURVEY.md 8(d))", "call_lines": lines,
                                           "pair_events": events, "items": items, "edges": edges, "kernel_ms_sum_over_ranks": tally_ms}})
             del eng, files
