@@ -155,7 +155,7 @@ typedef struct {
 } phz_variants_general;
 
 /* timing slots for phz_get_timing */
-enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_GENES = 4, PHZ_T_INFLATE = 5, PHZ_T_BAMPACK = 6, PHZ_T_COUNT = 8 };
+enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, PHZ_T_GENES = 4, PHZ_T_INFLATE = 5, PHZ_T_BAMPACK = 6, PHZ_T_ROWS = 7, PHZ_T_COUNT = 8 };
 
 /* work counters accumulated over phz_tally calls since the last phz_reset_timing (the units of K_tally's byte model):
  * call lines seen, distinct (QNAME, variant, class) items, pair events = sum over QNAMEs of C(k, 2) item pairs on different
@@ -430,6 +430,82 @@ void phz_rows_free(phz_rows_out *out);
  * written back to back into config (capacity n); sub_first / sub_len need capacity n. */
 int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i, const int32_t *edge_j, const int8_t *edge_cfg,
                     int32_t max_block_size, int32_t *sub_first, int32_t *sub_len, char *config, int32_t *n_subs);
+
+/* ---- device row stage: stages T7-O2 of the phasing path on the GPU, on the results phz_tally left in HBM --------------------
+ * What it replaces in the reference (phaser/phaser.py): the bookkeeping of test_variant_connection :1594-1654 (the binomial p-value
+ * itself stays the caller's scipy call, evaluated once per distinct argument pair), pruning :686-726, build_haplotypes :1861-1882,
+ * phase_v3 :2107-2324, the output loops :691-695, :737-749, :865-1239.  The host twin is phz_rows_format_multi above; it still serves
+ * the options this stage declines with PHZ_E_UNSUPPORTED (--gw_phase_method 1, --output_read_ids 1, a block of more than 512 variants,
+ * more than 65536 distinct read-count pairs).
+ *
+ *   phz_rowsdev_create     upload the per-variant tables of this rank's chromosomes (joint variant index space of phz_tally)
+ *   phz_rowsdev_pair_keys  stage 1: the distinct (total, supporting) read-count pairs of the pairs under test -> host
+ *   phz_rowsdev_run        stage 2: verdicts, components, ordering, block phasing, read sets, the text of the five files in HBM
+ *   phz_rowsdev_fetch_*    copy a finished text / the per-block arrays of write_vcf to host memory
+ * String pools: item i of a pool = bytes [off[i], off[i+1] - 1) (one separator byte after every item). */
+typedef struct phz_rowsdev phz_rowsdev;
+enum { PHZ_PAIR_SLOTS = 65536 };
+enum { PHZ_TXT_CONN = 0, PHZ_TXT_HAP = 1, PHZ_TXT_ASE = 2, PHZ_TXT_CFG = 3, PHZ_TXT_ALLELIC = 4, PHZ_TXT_SINGLE_ASE = 5, PHZ_TXT_SINGLE_HAP = 6,
+       PHZ_TXT_COUNT = 7 };
+
+typedef struct {
+    int64_t nv;                       /* variants of all chromosomes of this rank, chromosomes in VCF order */
+    int32_t n_chroms;
+    const int64_t *chrom_v0;          /* [n_chroms + 1] first variant of every chromosome */
+    const uint32_t *chrom_name_off; const char *chrom_names;
+    const int32_t *pos;               /* [nv] */
+    const uint32_t *uid_off; const char *uid;            /* nv items: unique id (chrom_pos_alleles, :1376) */
+    const uint32_t *rsid_off; const char *rsid;          /* nv items: rsid, or the unique id when the VCF has '.' (:1451-1455) */
+    const uint32_t *allele_off; const char *allele;      /* 2 nv items: the individual's two alleles in allele-index order */
+    const uint32_t *maf_off; const char *maf_txt;        /* nv items: str(maf) */
+    const double *maf;                /* [nv] */
+    const uint8_t *is_ref;            /* [2 nv] allele k of variant v is the reference allele */
+    const int8_t *phase_idx;          /* [2 nv] position of allele k in the VCF phase, -1 = unphased genotype */
+    const uint8_t *blacklisted;       /* [nv] --haplo_count_blacklist, or NULL */
+} phz_rowsdev_tables;
+
+typedef struct {
+    int32_t n_bams;
+    const uint32_t *bam_name_off; const char *bam_names;
+    const uint8_t *bam_excluded;      /* [n_bams] --haplo_count_bam_exclude, or NULL */
+    int32_t n_shards;                 /* the (chromosome, BAM) shards of the phz_tally call: their line ranges and BAMs */
+    const int64_t *shard_line_lo, *shard_line_hi;
+    const int32_t *shard_bam;
+    int32_t unique_ids, gw_phase_method, output_read_ids, unphased_vars, max_block_size, want_vcf;
+    double cc_threshold;
+} phz_rowsdev_opts;
+
+typedef struct {
+    int64_t bytes[PHZ_TXT_COUNT];
+    /* byte offsets of the per-chromosome segments of every text (host arrays owned by the handle, valid until the next run):
+     * CONN / HAP / ASE / CFG: [n_chroms + 1]; ALLELIC / SINGLE_*: [n_bams * n_chroms + 1], BAM of the first kept line major */
+    const int64_t *seg_off[PHZ_TXT_COUNT];
+    const int64_t *chrom_blocks, *chrom_blk_vars;        /* [n_chroms] blocks / block variants per chromosome */
+    int64_t n_blocks, n_blk_vars, phased, dropped, allelic_rows, n_components, n_linked, n_complex, n_exceptions, n_big_segments;
+    double gpu_ms;                    /* HIP-event time of the sync-free sections of the run */
+} phz_rowsdev_result;
+
+int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *tables, phz_rowsdev **out);
+void phz_rowsdev_destroy(phz_rowsdev *h);
+int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host /* [PHZ_PAIR_SLOTS] */);
+int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *opts, const double *slot_pv /* [PHZ_PAIR_SLOTS] */,
+                    const uint32_t *slot_txt_off /* [PHZ_PAIR_SLOTS + 1] */, const char *slot_txt, phz_rowsdev_result *result);
+int phz_rowsdev_fetch_text(phz_ctx *ctx, phz_rowsdev *h, int which, void *dst, int64_t bytes);
+const void *phz_rowsdev_text_ptr(phz_rowsdev *h, int which);      /* device pointer of a finished text */
+int phz_rowsdev_fetch_blocks(phz_ctx *ctx, phz_rowsdev *h, int32_t *blk_size, int32_t *blk_var, uint8_t *blk_hap, int8_t *blk_cor, double *blk_stat,
+                             uint8_t *blk_stat_int, int32_t *blk_maxmaf);
+
+/* phase_v3 (phaser/phaser.py:2107-2170; the worker `parallelize(phase_v3, ...)` fans out at :808) for a batch of connected components on the
+ * GPU: flood fill, weak-point split, 2^(n-1) brute force shared by the lanes of a wave, stitching.  Component c = position-sorted variants
+ * [comp_start[c], comp_start[c+1]) with the pairs [pair_start[c], pair_start[c+1]); pair_i / pair_j are LOCAL variant indices, pair_cfg 0 same
+ * configuration / 1 opposite / -1 tie.  Host arrays in and out.  sub_of[v] = ordinal of v's final block inside its component (-1: none),
+ * alle_of[v] = its allele on haplotype A, n_sub[c] = final blocks of component c.  Same results as phz_phase_block per component. */
+int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t *comp_start, const uint32_t *pair_start, const int32_t *pair_i, const int32_t *pair_j,
+                         const int8_t *pair_cfg, int32_t max_block_size, int16_t *sub_of, uint8_t *alle_of, uint32_t *n_sub);
+
+/* Adopt tally results computed elsewhere (another process / device, or a fixture) as the resident results of this ctx: the arrays of
+ * phz_tally_out + sizes, in `space`.  rl_list[i] = index (variant * 2 + allele) * n_bams + bam of the read list entry i belongs to. */
+int phz_tally_import(phz_ctx *ctx, int64_t nv, int n_bams, const phz_tally_sizes *sizes, const phz_tally_out *arrays, const uint32_t *rl_list, int space);
 
 /* ---- phaser_gene_ae (phaser_gene_ae/phaser_gene_ae.py): gene-level haplotypic counts from a haplotypic_counts.txt ---------
  * phz_hc_parse: multi-threaded parse of the file text (:78 pandas.read_csv + the per-row string splitting of :172-204).

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 PHZ_OK, PHZ_E_ARG, PHZ_E_HIP, PHZ_E_CAPACITY, PHZ_E_UNSUPPORTED, PHZ_E_NOMEM = 0, -1, -2, -3, -4, -5
 PHZ_HOST, PHZ_DEVICE = 0, 1
-PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS, PHZ_T_GENES, PHZ_T_INFLATE, PHZ_T_BAMPACK = 0, 1, 2, 3, 4, 5, 6
+PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS, PHZ_T_GENES, PHZ_T_INFLATE, PHZ_T_BAMPACK, PHZ_T_ROWS = 0, 1, 2, 3, 4, 5, 6, 7
 PHZ_C_LINES, PHZ_C_ITEMS, PHZ_C_PAIR_EVENTS, PHZ_C_EDGES = 0, 1, 2, 3
 
 
@@ -116,6 +116,32 @@ class phz_rows_out(C.Structure):
                [(k, C.c_int64) for k in ("allelic_rows", "n_blocks", "phased", "n_blk_vars")] + \
                [(k, C.c_void_p) for k in ("blk_size", "blk_var", "blk_hap", "blk_cor", "blk_stat", "blk_stat_int", "blk_maxmaf")] + \
                [("owner", C.c_void_p)]
+
+
+PHZ_PAIR_SLOTS = 65536
+PHZ_TXT_NAMES = ("conn", "hap", "ase", "cfg", "allelic", "single_ase", "single_hap")     # PHZ_TXT_* order
+PHZ_TXT_COUNT = 7
+
+
+class phz_rowsdev_tables(C.Structure):
+    _fields_ = [("nv", C.c_int64), ("n_chroms", C.c_int32), ("chrom_v0", C.c_void_p), ("chrom_name_off", C.c_void_p), ("chrom_names", C.c_void_p),
+                ("pos", C.c_void_p), ("uid_off", C.c_void_p), ("uid", C.c_void_p), ("rsid_off", C.c_void_p), ("rsid", C.c_void_p),
+                ("allele_off", C.c_void_p), ("allele", C.c_void_p), ("maf_off", C.c_void_p), ("maf_txt", C.c_void_p), ("maf", C.c_void_p),
+                ("is_ref", C.c_void_p), ("phase_idx", C.c_void_p), ("blacklisted", C.c_void_p)]
+
+
+class phz_rowsdev_opts(C.Structure):
+    _fields_ = [("n_bams", C.c_int32), ("bam_name_off", C.c_void_p), ("bam_names", C.c_void_p), ("bam_excluded", C.c_void_p),
+                ("n_shards", C.c_int32), ("shard_line_lo", C.c_void_p), ("shard_line_hi", C.c_void_p), ("shard_bam", C.c_void_p),
+                ("unique_ids", C.c_int32), ("gw_phase_method", C.c_int32), ("output_read_ids", C.c_int32), ("unphased_vars", C.c_int32),
+                ("max_block_size", C.c_int32), ("want_vcf", C.c_int32), ("cc_threshold", C.c_double)]
+
+
+class phz_rowsdev_result(C.Structure):
+    _fields_ = [("bytes", C.c_int64 * PHZ_TXT_COUNT), ("seg_off", C.POINTER(C.c_int64) * PHZ_TXT_COUNT), ("chrom_blocks", C.POINTER(C.c_int64)),
+                ("chrom_blk_vars", C.POINTER(C.c_int64))] + \
+               [(k, C.c_int64) for k in ("n_blocks", "n_blk_vars", "phased", "dropped", "allelic_rows", "n_components", "n_linked", "n_complex",
+                                          "n_exceptions", "n_big_segments")] + [("gpu_ms", C.c_double)]
 
 
 class phz_hc_arrays(C.Structure):
@@ -238,6 +264,15 @@ SYMBOLS = {
     "phz_rows_format": (C.c_int, [C.POINTER(phz_rows_in), C.POINTER(phz_rows_out)]),
     "phz_rows_format_multi": (C.c_int, [C.POINTER(phz_rows_in), C.c_int, C.POINTER(phz_rows_out), C.c_int]),
     "phz_rows_free": (None, [C.POINTER(phz_rows_out)]),
+    "phz_rowsdev_create": (C.c_int, [C.c_void_p, C.POINTER(phz_rowsdev_tables), C.POINTER(C.c_void_p)]),
+    "phz_rowsdev_destroy": (None, [C.c_void_p]),
+    "phz_rowsdev_pair_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "phz_rowsdev_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_result)]),
+    "phz_rowsdev_fetch_text": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "phz_rowsdev_text_ptr": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "phz_rowsdev_fetch_blocks": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_void_p] * 7),
+    "phz_phase_components": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3),
+    "phz_tally_import": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(phz_tally_sizes), C.POINTER(phz_tally_out), C.c_void_p, C.c_int]),
     "phz_phase_block": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(C.c_int32)]),
     "phz_hc_parse": (C.c_int, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),

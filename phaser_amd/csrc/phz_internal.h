@@ -37,6 +37,7 @@ struct phz_ctx {
     // steady state allocates nothing
     std::vector<DevBuf> stage_pool;
     std::vector<DevBuf> tally_buf;     // result + read-list buffers of phz_tally
+    std::vector<DevBuf> import_buf;    // arrays adopted by phz_tally_import
     bool tally_dirty = false;
     DevBuf tally_qcount;               // lines per QNAME: all zero between phz_tally calls (never shared with other stages)
     // results of the last phz_tally, resident in HBM until the next one (phz_tally_fetch / phz_components read them)
@@ -46,7 +47,7 @@ struct phz_ctx {
         int32_t *var_count = nullptr, *var_distinct = nullptr, *ea = nullptr, *eb = nullptr, *cells = nullptr, *cto = nullptr, *stats = nullptr, *rl_qid = nullptr;
         int64_t *var_first = nullptr;
         uint64_t *var_rank = nullptr;
-        uint32_t *rl_start = nullptr;
+        uint32_t *rl_start = nullptr, *rl_list = nullptr;
         uint8_t *linked = nullptr, *line_cls = nullptr;
     } tally;
     int map_tile_reads = 0;

@@ -1,0 +1,1670 @@
+// Device row stage: stages T7-O2 of the phasing path on the GPU, from the results phz_tally left in HBM to the finished text of the
+// five output files (phaser/phaser.py line numbers):
+//   pair test bookkeeping          :1594-1654  distinct (supporting, total) arguments -> the host evaluates scipy's binom.cdf once per
+//                                              distinct pair (the reference's own third-party call) and hands back value + repr text
+//   pruning + components           :686-726, :1861-1882, :1985-1998
+//   ordering rules                 SURVEY.md 8.1 rules 2, 4, 5 (hand-written radix sorts, phz_sort.h)
+//   block phasing                  :2107-2324  phase_v3: flood fill (resolve_phase), weak-point split, 2^(n-1) brute force per fragment
+//                                              (lanes of a wave share the configurations), left-to-right stitching
+//   haplotype read sets            :917-931, :1086-1115  distinct QNAMEs per (block, haplotype[, BAM]) and the first-appearance labels
+//   rows                           :691-695 variant_connections, :737-749 allelic_counts, :865-1172 haplotypes / haplotypic_counts /
+//                                  allele_config, :1180-1239 singletons
+// Every file is produced in two passes over its rows (byte counts -> scan -> write) by the SAME row function instantiated with a
+// counting sink and a writing sink, so the two passes cannot disagree.  Integer / byte work: no MFMA; the stage streams the tally's
+// arrays and the string pools and writes ~1 GB of text per genome.
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "phz_internal.h"
+#include "phz_sort.h"
+#include "phz_text.h"
+#include "phz_uf.h"
+
+namespace {
+
+constexpr int PS_SLOTS = 1 << 16;              // hash set of the distinct (total, supporting) arguments of the binomial test
+constexpr unsigned long long PS_EMPTY = ~0ull;
+constexpr int STAT_N = 512;                    // largest block (variants) covered by the gwStat text table
+constexpr int PH_NMAX = 256, PH_EMAX = 2048;   // largest component (variants / kept pairs) k_phase_general takes; larger ones go to the host
+constexpr int PH_BRUTE_MAX = 22;               // largest fragment brute-forced on the device (2^21 configurations shared by 64 lanes)
+constexpr int SEG_SMALL = 32, SEG_LDS = 2048, SEG_LDS_SLOTS = 4096;
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr unsigned long long NONE64 = ~0ull;
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// separator-joined string pool: item i = b[off[i] .. off[i+1] - 1)
+struct PoolD {
+    const uint32_t *off;
+    const char *b;
+    __device__ __forceinline__ uint32_t len(int64_t i) const { return off[i + 1] - off[i] - 1u; }
+    __device__ __forceinline__ const char *at(int64_t i) const { return b + off[i]; }
+};
+
+__device__ __forceinline__ int ndigits(unsigned long long v) {
+    int d = 1;
+    while (v >= 10ull) { v /= 10ull; d++; }
+    return d;
+}
+
+// ---- sinks: the same row function counts bytes or writes them
+struct SCount {
+    static constexpr bool writing = false;
+    uint32_t n = 0;
+    __device__ __forceinline__ void ch(char) { n++; }
+    template <int N> __device__ __forceinline__ void lit(const char (&)[N]) { n += (uint32_t)(N - 1); }
+    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) { n += P.len(i); }
+    __device__ __forceinline__ void num(long long v) { n += v < 0 ? 1u + (uint32_t)ndigits((unsigned long long)(-v)) : (uint32_t)ndigits((unsigned long long)v); }
+    __device__ __forceinline__ void skip(uint32_t k) { n += k; }
+    __device__ __forceinline__ unsigned long long where() const { return 0; }
+};
+struct SWrite {
+    static constexpr bool writing = true;
+    char *p0, *p;
+    unsigned long long base;         // file offset of p0
+    __device__ __forceinline__ void ch(char c) { *p++ = c; }
+    template <int N> __device__ __forceinline__ void lit(const char (&s)[N]) { for (int i = 0; i < N - 1; i++) p[i] = s[i]; p += N - 1; }
+    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) {
+        const char *s = P.at(i); const uint32_t l = P.len(i);
+        for (uint32_t k = 0; k < l; k++) p[k] = s[k];
+        p += l;
+    }
+    __device__ __forceinline__ void num(long long v) {
+        unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+        if (v < 0) *p++ = '-';
+        const int d = ndigits(u);
+        for (int k = d - 1; k >= 0; k--) { p[k] = (char)('0' + (int)(u % 10ull)); u /= 10ull; }
+        p += d;
+    }
+    __device__ __forceinline__ void skip(uint32_t k) { p += k; }            // bytes somebody else writes (label text)
+    __device__ __forceinline__ unsigned long long where() const { return base + (unsigned long long)(p - p0); }
+};
+
+// ---- everything the row functions read (device pointers)
+struct RD {
+    int64_t nv, ne, nblocks, n_linked, n_keys;
+    int nchrom, nb, unique_ids, unphased_vars;
+    const uint16_t *vchrom; const int32_t *pos;
+    PoolD uid, rsid, alle, maft, chromn, bamn, statt, pvt;
+    const double *mafv; const uint8_t *is_ref; const int8_t *phase_idx; const uint8_t *black; const uint8_t *bam_excl;
+    // tally
+    const int32_t *var_count, *var_distinct, *ea, *eb, *cis, *trans, *sup, *tot, *cfgv;
+    const uint32_t *rl_start; const int32_t *rl_qid; const uint32_t *rl_list;
+    // derived
+    const uint32_t *eorder; const int32_t *va, *vb; const uint32_t *e_slot;
+    const uint32_t *key_g;
+    const uint32_t *mem_s, *blk_mstart, *blk_len; const int32_t *blk_of; const uint8_t *v_alle;
+    const uint32_t *blk_sup, *blk_tot, *blk_cnt, *seg_ns, *single_n;
+    const uint8_t *blk_conc, *blk_cormode, *blk_statkind; const uint32_t *blk_statidx; const int32_t *blk_maxmaf;
+    const uint32_t *its, *labels; unsigned long long *piece_dst;
+    const unsigned long long *cfg_base;
+};
+
+__device__ __forceinline__ int8_t hap_phase(const RD &D, int b, int h, uint32_t t) {        // VCF phase index of haplotype h's allele at the block's t-th variant
+    const uint32_t g = D.mem_s[D.blk_mstart[b] + t];
+    return D.phase_idx[2 * (int64_t)g + (D.v_alle[g] ^ h)];
+}
+__device__ __forceinline__ char phase_char(int8_t x) { return x < 0 ? '-' : (char)('0' + x); }
+
+template <class S> __device__ __forceinline__ void put_stat(const RD &D, int b, S &s) {     // gwStat: int 1, 0.5, or repr(float) from the table
+    const uint8_t k = D.blk_statkind[b];
+    if (k == 1) s.ch('1');
+    else if (k == 2) s.lit("0.5");
+    else s.pool(D.statt, D.blk_statidx[b]);
+}
+
+// ---------------------------------------------------------------------------------------------- row functions
+// variant_connections.txt (:691-695); row = position in the (rank a, rank b) order of the tested pairs
+struct RowConn {
+    template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
+        const uint32_t e = D.eorder[r];
+        const int a = D.va[e], b = D.vb[e];
+        const int sup = D.sup[e], tot = D.tot[e];
+        s.pool(D.uid, a); s.ch('\t'); s.pool(D.uid, b); s.ch('\t'); s.num(sup); s.ch('\t'); s.num(tot); s.ch('\t');
+        if (sup == 0) s.ch('0');
+        else if (tot - sup > 0) s.pool(D.pvt, D.e_slot[e]);
+        else s.ch('1');
+        s.ch('\t');
+        const int8_t pa0 = D.phase_idx[2 * (int64_t)a], pb0 = D.phase_idx[2 * (int64_t)b];
+        const int cis = D.cis[e], trans = D.trans[e];
+        if (pa0 >= 0 && pb0 >= 0 && cis != trans) {
+            const int8_t pa = cis > trans ? pa0 : D.phase_idx[2 * (int64_t)a + 1];
+            s.ch(pa == pb0 ? '1' : '0');
+        } else s.ch('.');
+        s.ch('\n');
+    }
+};
+
+// allelic_counts.txt (:737-749); row = first-appearance key
+struct RowAllelic {
+    template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
+        const int64_t g = D.key_g[r];
+        const long long r0 = D.var_distinct[3 * g], r1 = D.var_distinct[3 * g + 1];
+        if (r0 + r1 <= 0) return;
+        s.pool(D.chromn, D.vchrom[g]); s.ch('\t'); s.num(D.pos[g]); s.ch('\t'); s.pool(D.uid, g); s.ch('\t'); s.pool(D.alle, 2 * g); s.ch('\t');
+        s.pool(D.alle, 2 * g + 1); s.ch('\t'); s.num(r0); s.ch('\t'); s.num(r1); s.ch('\t'); s.num(r0 + r1); s.ch('\n');
+    }
+};
+
+__device__ __forceinline__ bool single_live(const RD &D, int64_t g) {
+    return (long long)D.var_count[3 * g] + D.var_count[3 * g + 1] != 0 && D.blk_of[g] < 0;
+}
+template <class S> __device__ __forceinline__ void put_vcf_phase(const RD &D, int64_t g, S &s, bool slash) {
+    if (D.phase_idx[2 * g] >= 0) { s.num(D.phase_idx[2 * g]); s.ch('|'); s.num(D.phase_idx[2 * g + 1]); }
+    else if (slash) s.lit("0/1");
+    else s.lit("-|-");
+}
+
+// singleton rows of haplotypic_counts.txt (:1180-1239); row = key * nb + bam
+struct RowSingleAse {
+    template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
+        const int64_t g = D.key_g[r / D.nb]; const int b = (int)(r % D.nb);
+        if (!D.unphased_vars || !single_live(D, g)) return;
+        if (D.black && D.black[g]) return;
+        if (D.bam_excl && D.bam_excl[b]) return;
+        const long long n0 = D.nb == 1 ? D.var_distinct[3 * g] : D.single_n[(2 * g) * D.nb + b];
+        const long long n1 = D.nb == 1 ? D.var_distinct[3 * g + 1] : D.single_n[(2 * g + 1) * D.nb + b];
+        if (n0 + n1 <= 0) return;
+        s.pool(D.chromn, D.vchrom[g]); s.ch('\t'); s.num(D.pos[g]); s.ch('\t'); s.num(D.pos[g]); s.ch('\t'); s.pool(D.uid, g);
+        s.lit("\t1\t\t0\t"); s.pool(D.alle, 2 * g); s.ch('\t'); s.pool(D.alle, 2 * g + 1); s.ch('\t');
+        s.num(n0); s.ch('\t'); s.num(n1); s.ch('\t'); s.num(n0 + n1); s.ch('\t');
+        put_vcf_phase(D, g, s, true);
+        s.lit("\t1\t");
+        s.pool(D.maft, g); s.ch('\t'); s.pool(D.bamn, b); s.lit("\t\t\n");
+    }
+};
+
+// singleton rows of haplotypes.txt; row = key
+struct RowSingleHap {
+    template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
+        const int64_t g = D.key_g[r];
+        if (!D.unphased_vars || !single_live(D, g)) return;
+        const long long d0 = D.var_distinct[3 * g], d1 = D.var_distinct[3 * g + 1];
+        s.pool(D.chromn, D.vchrom[g]); s.ch('\t'); s.num((long long)D.pos[g] - 1); s.ch('\t'); s.num(D.pos[g]); s.lit("\t1\t1\t");
+        s.pool(D.unique_ids ? D.uid : D.rsid, g); s.ch('\t'); s.pool(D.alle, 2 * g); s.ch('|'); s.pool(D.alle, 2 * g + 1); s.ch('\t');
+        s.num(d0); s.ch('\t'); s.num(d1); s.ch('\t'); s.num(d0 + d1); s.lit("\t0\t0\t");
+        put_vcf_phase(D, g, s, false); s.lit("\tnan\t"); put_vcf_phase(D, g, s, false); s.lit("\tnan\n");
+    }
+};
+
+// haplotypes.txt, one row per block (:865-1043)
+struct RowHap {
+    template <class S> __device__ static void emit(const RD &D, int64_t b, S &s) {
+        const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
+        const int64_t g0 = D.mem_s[m0], g1 = D.mem_s[m0 + n - 1];
+        const int minpos = D.pos[g0], maxpos = D.pos[g1];
+        s.pool(D.chromn, D.vchrom[g0]); s.ch('\t'); s.num(minpos); s.ch('\t'); s.num(maxpos); s.ch('\t'); s.num(maxpos - minpos); s.ch('\t');
+        s.num(n); s.ch('\t');
+        const PoolD &names = D.unique_ids ? D.uid : D.rsid;
+        for (uint32_t t = 0; t < n; t++) { if (t) s.ch(','); s.pool(names, D.mem_s[m0 + t]); }
+        s.ch('\t');
+        for (int h = 0; h < 2; h++) {
+            if (h) s.ch('|');
+            for (uint32_t t = 0; t < n; t++) { const int64_t g = D.mem_s[m0 + t]; if (t) s.ch(','); s.pool(D.alle, 2 * g + (D.v_alle[g] ^ h)); }
+        }
+        const long long c0 = D.blk_cnt[2 * b], c1 = D.blk_cnt[2 * b + 1];
+        s.ch('\t'); s.num(c0); s.ch('\t'); s.num(c1); s.ch('\t'); s.num(c0 + c1); s.ch('\t');
+        s.num(D.blk_sup[b]); s.lit(".0\t"); s.num(D.blk_tot[b]); s.lit(".0\t");
+        for (int h = 0; h < 2; h++) { if (h) s.ch('|'); for (uint32_t t = 0; t < n; t++) s.ch(phase_char(hap_phase(D, (int)b, h, t))); }
+        s.ch('\t'); s.num(D.blk_conc[b]); s.ch('\t');
+        const uint8_t cm = D.blk_cormode[b];
+        for (int h = 0; h < 2; h++) {
+            if (h) s.ch('|');
+            for (uint32_t t = 0; t < n; t++) s.ch(cm == 0 ? phase_char(hap_phase(D, (int)b, h, t)) : (char)('0' + ((cm == 1 ? 0 : 1) ^ h)));
+        }
+        s.ch('\t'); put_stat(D, (int)b, s); s.ch('\n');
+    }
+};
+
+// haplotypic_counts.txt, one row per (block, BAM) (:1048-1125); the label lists at the end of the row are written by k_label_write:
+// this function leaves room for them and records where each (variant, allele, BAM) list starts
+struct RowAse {
+    template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
+        const int64_t b = r / D.nb; const int bb = (int)(r % D.nb);
+        if (D.bam_excl && D.bam_excl[bb]) return;
+        const long long ns0 = D.seg_ns[(2 * b) * D.nb + bb], ns1 = D.seg_ns[(2 * b + 1) * D.nb + bb];
+        if (ns0 + ns1 <= 0) return;
+        const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
+        const int64_t g0 = D.mem_s[m0], g1 = D.mem_s[m0 + n - 1];
+        s.pool(D.chromn, D.vchrom[g0]); s.ch('\t'); s.num(D.pos[g0]); s.ch('\t'); s.num(D.pos[g1]); s.ch('\t');
+        long long used = 0, nblack = 0;
+        for (uint32_t t = 0; t < n; t++) { const int64_t g = D.mem_s[m0 + t]; if (D.black && D.black[g]) continue; if (used) s.ch(','); s.pool(D.uid, g); used++; }
+        s.ch('\t'); s.num(used); s.ch('\t');
+        if (D.black) for (uint32_t t = 0; t < n; t++) { const int64_t g = D.mem_s[m0 + t]; if (!D.black[g]) continue; if (nblack) s.ch(','); s.pool(D.uid, g); nblack++; }
+        s.ch('\t'); s.num(nblack); s.ch('\t');
+        for (int h = 0; h < 2; h++) {
+            bool first = true;
+            for (uint32_t t = 0; t < n; t++) {
+                const int64_t g = D.mem_s[m0 + t];
+                if (D.black && D.black[g]) continue;
+                if (!first) s.ch(',');
+                first = false;
+                s.pool(D.alle, 2 * g + (D.v_alle[g] ^ h));
+            }
+            s.ch('\t');
+        }
+        s.num(ns0); s.ch('\t'); s.num(ns1); s.ch('\t'); s.num(ns0 + ns1); s.ch('\t');
+        const uint8_t cm = D.blk_cormode[b];
+        const int c00 = cm == 0 ? (int)hap_phase(D, (int)b, 0, 0) : (cm == 1 ? 0 : 1);
+        if (c00 == 0) s.lit("0|1"); else if (c00 == 1) s.lit("1|0"); else s.lit("0/1");
+        s.ch('\t'); put_stat(D, (int)b, s); s.ch('\t');
+        s.pool(D.maft, D.blk_maxmaf[b]); s.ch('\t'); s.pool(D.bamn, bb); s.ch('\t');
+        for (int h = 0; h < 2; h++) {
+            bool first = true;
+            for (uint32_t t = 0; t < n; t++) {
+                const int64_t g = D.mem_s[m0 + t];
+                if (D.black && D.black[g]) continue;
+                if (!first) s.ch(';');
+                first = false;
+                const int64_t e = (2 * g + (D.v_alle[g] ^ h)) * D.nb + bb;
+                const uint32_t lo = D.rl_start[e], hi = D.rl_start[e + 1];
+                if (S::writing) D.piece_dst[e] = s.where();
+                if (hi > lo) s.skip(D.its[hi] - D.its[lo] - 1u);          // every label is followed by one separator byte except the list's last
+            }
+            s.ch(h == 0 ? '\t' : '\n');
+        }
+    }
+};
+
+// allele_config.txt (:1160-1172); row = cfg_base[block] + i * (n - 1) + (j with i skipped)
+struct RowCfg {
+    template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
+        int64_t lo = 0, hi = D.nblocks;                     // largest b with cfg_base[b] <= r
+        while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (D.cfg_base[m] <= (unsigned long long)r) lo = m; else hi = m; }
+        const int64_t b = lo;
+        const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
+        const uint32_t idx = (uint32_t)((unsigned long long)r - D.cfg_base[b]);
+        const uint32_t i = idx / (n - 1); uint32_t j = idx % (n - 1);
+        if (j >= i) j++;
+        const int64_t ga = D.mem_s[m0 + i], gb = D.mem_s[m0 + j];
+        const bool ra = D.is_ref[2 * ga + D.v_alle[ga]] != 0, rb = D.is_ref[2 * gb + (D.v_alle[gb] ^ 1)] != 0;
+        s.pool(D.uid, ga); s.ch('\t'); s.pool(D.rsid, ga); s.ch('\t'); s.pool(D.uid, gb); s.ch('\t'); s.pool(D.rsid, gb);
+        if (ra == rb) s.lit("\ttrans\n"); else s.lit("\tcis\n");
+    }
+};
+
+template <class ROW> __global__ __launch_bounds__(256) void k_row_len(RD D, int64_t nrows, uint32_t *len) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    SCount s;
+    ROW::emit(D, r, s);
+    len[r] = s.n;
+}
+template <class ROW> __global__ __launch_bounds__(256) void k_row_write(RD D, int64_t nrows, const unsigned long long *off, char *out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    if (off[r + 1] == off[r]) return;
+    SWrite s; s.p0 = s.p = out + off[r]; s.base = off[r];
+    ROW::emit(D, r, s);
+}
+
+// label text of haplotypic_counts: one thread per read-list entry
+__global__ __launch_bounds__(256) void k_item_len(const uint32_t *labels, int64_t n, uint32_t *tl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) tl[i] = (uint32_t)ndigits(labels[i]) + 1u;
+}
+__global__ __launch_bounds__(256) void k_label_write(RD D, int64_t n_rl, char *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rl) return;
+    const uint32_t e = D.rl_list[i];
+    const unsigned long long dst = D.piece_dst[e];
+    if (dst == NONE64) return;
+    const uint32_t lo = D.rl_start[e], hi = D.rl_start[e + 1];
+    char *p = out + dst + (D.its[i] - D.its[lo]);
+    unsigned long long u = D.labels[i];
+    const int d = ndigits(u);
+    for (int k = d - 1; k >= 0; k--) { p[k] = (char)('0' + (int)(u % 10ull)); u /= 10ull; }
+    if (i + 1 < (int64_t)hi) p[d] = ',';
+}
+
+// ---------------------------------------------------------------------------------------------- pair test bookkeeping
+__device__ __forceinline__ uint32_t ps_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (uint32_t)k;
+}
+__device__ __forceinline__ bool pair_tested(const uint8_t *linked, const int32_t *sup, const int32_t *tot, int64_t e) {
+    return linked[e] && sup[e] > 0 && tot[e] - sup[e] > 0;
+}
+// flags[0]: table full
+__global__ __launch_bounds__(256) void k_pair_keys(int64_t ne, const uint8_t *linked, const int32_t *sup, const int32_t *tot, unsigned long long *hkeys, uint32_t *flags) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne || !pair_tested(linked, sup, tot, e)) return;
+    const unsigned long long key = ((unsigned long long)(uint32_t)tot[e] << 32) | (uint32_t)sup[e];
+    uint32_t s = ps_hash(key) & (PS_SLOTS - 1);
+    for (int t = 0; t < PS_SLOTS; t++) {
+        const unsigned long long cur = hkeys[s];
+        if (cur == key) return;
+        if (cur == PS_EMPTY) {
+            const unsigned long long prev = atomicCAS(&hkeys[s], PS_EMPTY, key);
+            if (prev == PS_EMPTY || prev == key) return;
+        }
+        s = (s + 1) & (PS_SLOTS - 1);
+    }
+    atomicOr(&flags[0], 1u);
+}
+// verdict per pair (:1645-1652, :686-700): p = 0 without supporting reads, 1 without conflicting ones, else the table; counters[0] linked pairs,
+// [1] linked pairs dropped
+__global__ __launch_bounds__(256) void k_keep(int64_t ne, const uint8_t *linked, const int32_t *sup, const int32_t *tot, const unsigned long long *hkeys,
+                                              const double *slot_pv, double threshold, uint8_t *keep, uint32_t *e_slot, uint32_t *deg, const int32_t *ea,
+                                              const int32_t *eb, unsigned long long *counters) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool is_linked = false, kept = false;
+    if (e < ne) {
+        uint32_t slot = NONE32;
+        is_linked = linked[e] != 0;
+        if (is_linked) {
+            double pv = 1.0;
+            if (sup[e] == 0) pv = 0.0;
+            else if (tot[e] - sup[e] > 0) {
+                const unsigned long long key = ((unsigned long long)(uint32_t)tot[e] << 32) | (uint32_t)sup[e];
+                uint32_t s = ps_hash(key) & (PS_SLOTS - 1);
+                while (hkeys[s] != key) s = (s + 1) & (PS_SLOTS - 1);
+                slot = s; pv = slot_pv[s];
+            }
+            kept = !(pv < threshold);
+        }
+        keep[e] = kept ? 1 : 0; e_slot[e] = slot;
+        if (kept) { atomicAdd(&deg[ea[e]], 1u); atomicAdd(&deg[eb[e]], 1u); }
+    }
+    const unsigned long long ml = __ballot(is_linked ? 1 : 0), md = __ballot(is_linked && !kept ? 1 : 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (ml) atomicAdd(&counters[0], (unsigned long long)__popcll(ml));
+        if (md) atomicAdd(&counters[1], (unsigned long long)__popcll(md));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- ordering stage
+__global__ __launch_bounds__(256) void k_iota_rank(int64_t nv, const unsigned long long *var_rank, unsigned long long *key, uint32_t *val) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < nv) { key[v] = var_rank[v]; val[v] = (uint32_t)v; }
+}
+__global__ __launch_bounds__(256) void k_invert(int64_t n, const uint32_t *perm, uint32_t *inv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inv[perm[i]] = (uint32_t)i;
+}
+// pairs oriented by first appearance (:667-678 enumerates from the earlier key); sort key = (rank index of a, rank index of b), untested pairs last
+__global__ __launch_bounds__(256) void k_edge_keys(int64_t ne, const uint8_t *linked, const int32_t *ea, const int32_t *eb, const uint32_t *ridx, int32_t *va, int32_t *vb,
+                                                   unsigned long long *key, uint32_t *val) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne) return;
+    int a = ea[e], b = eb[e];
+    val[e] = (uint32_t)e;
+    if (!linked[e]) { va[e] = a; vb[e] = b; key[e] = ~0ull; return; }
+    if (ridx[b] < ridx[a]) { const int t = a; a = b; b = t; }
+    va[e] = a; vb[e] = b;
+    key[e] = ((unsigned long long)ridx[a] << 32) | ridx[b];
+}
+__global__ __launch_bounds__(256) void k_flag_members(int64_t nv, const uint32_t *deg, const int32_t *label, uint32_t *is_mem, uint32_t *is_root) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const bool m = deg[v] > 0;
+    is_mem[v] = m ? 1u : 0u; is_root[v] = (m && label[v] == (int32_t)v) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_compact_members(int64_t nv, const uint32_t *deg, const uint32_t *mem_pos, const int32_t *label, uint32_t *key, uint32_t *val) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv || deg[v] == 0) return;
+    key[mem_pos[v]] = (uint32_t)label[v]; val[mem_pos[v]] = (uint32_t)v;
+}
+// group starts of a sorted key array: start[id_of[key]] = first position of the key
+__global__ __launch_bounds__(256) void k_group_starts(int64_t n, const uint32_t *sorted_key, const uint32_t *id_of, uint32_t *start) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    if (t == 0 || sorted_key[t] != sorted_key[t - 1]) start[id_of ? id_of[sorted_key[t]] : sorted_key[t]] = (uint32_t)t;
+}
+__global__ __launch_bounds__(256) void k_comp_min(int64_t ncomp, const uint32_t *cstart, const uint32_t *mem_s, const uint32_t *ridx, uint32_t *key, uint32_t *val) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncomp) return;
+    uint32_t m = NONE32;
+    for (uint32_t t = cstart[c]; t < cstart[c + 1]; t++) m = min(m, ridx[mem_s[t]]);
+    key[c] = m; val[c] = (uint32_t)c;
+}
+__global__ __launch_bounds__(256) void k_flag_u8(int64_t n, const uint8_t *f, uint32_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = f[i] ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_compact_kept(int64_t ne, const uint8_t *keep, const uint32_t *kpos, const int32_t *ea, const int32_t *label, const uint32_t *cid,
+                                                      uint32_t *key, uint32_t *val) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne || !keep[e]) return;
+    key[kpos[e]] = cid[label[ea[e]]]; val[kpos[e]] = (uint32_t)e;
+}
+struct ShardTab { const long long *lo, *hi; const int32_t *bam; int n; };
+// first-appearance keys (rule 2): covered variants by (BAM of the first kept line, line)
+__global__ __launch_bounds__(256) void k_flag_keys(int64_t nv, const long long *var_first, uint32_t *is_key) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < nv) is_key[v] = var_first[v] >= 0 ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_compact_keys(int64_t nv, const long long *var_first, const uint32_t *kpos, ShardTab T, const uint16_t *vchrom, int nchrom,
+                                                      unsigned long long *key, uint32_t *val, uint32_t *seg_count /* [nb * nchrom] */) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const long long f = var_first[v];
+    if (f < 0) return;
+    int bam = 0;
+    for (int t = 0; t < T.n; t++) if (f >= T.lo[t] && f < T.hi[t]) bam = T.bam[t];
+    key[kpos[v]] = ((unsigned long long)(uint32_t)bam << 32) | (unsigned long long)f;
+    val[kpos[v]] = (uint32_t)v;
+    atomicAdd(&seg_count[(size_t)bam * nchrom + vchrom[v]], 1u);
+}
+__global__ __launch_bounds__(256) void k_conn_chrom(int64_t n_linked, const uint32_t *eorder, const int32_t *va, const uint16_t *vchrom, uint32_t *count) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < n_linked) atomicAdd(&count[vchrom[va[eorder[r]]]], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------- block phasing (phase_v3)
+struct PH {
+    const uint32_t *cstart, *mem_s, *estart, *ekeep;
+    const int32_t *ea, *eb, *cfgv;
+    uint8_t *alle_of; int16_t *sub_of; uint32_t *nsub;
+    uint32_t *complex_list, *exc_list; uint32_t *counters;       // [0] complex components, [1] exceptions, [2] unsupported (the reference loops forever / 2^30 configurations)
+    int max_block_size;
+};
+
+// the commonest component: two variants, one pair with a verdict.  resolve_phase (:2172-2207) floods (variant 0, allele 0) to (variant 1,
+// allele 0) for a same-configuration pair and to (variant 1, allele 1) for an opposite one: block "00" / "01"
+__global__ __launch_bounds__(256) void k_phase_pair(int64_t ncomp, PH P) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncomp) return;
+    const uint32_t m0 = P.cstart[c], n = P.cstart[c + 1] - m0, e0 = P.estart[c], ne = P.estart[c + 1] - e0;
+    if (n == 2 && ne == 1) {
+        const int k = P.cfgv[P.ekeep[e0]];
+        if (k == 0 || k == 1) {
+            P.alle_of[m0] = 0; P.alle_of[m0 + 1] = (uint8_t)k; P.sub_of[m0] = 0; P.sub_of[m0 + 1] = 0; P.nsub[c] = 1;
+            return;
+        }
+    }
+    P.complex_list[atomicAdd(&P.counters[0], 1u)] = (uint32_t)c;
+}
+
+__device__ __forceinline__ char flipc(char c) { return c == '-' ? '-' : (c == '0' ? '1' : '0'); }
+
+// One wave per component.  Lane-parallel: loading the pairs, the flood fills, the 2^(n-1) brute force; everything sequential in the
+// reference (weak-point selection, stitching) runs on lane 0 between wave barriers.
+__global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
+    __shared__ uint8_t s_i[PH_EMAX], s_j[PH_EMAX];
+    __shared__ int8_t s_k[PH_EMAX];
+    __shared__ uint8_t s_fi[PH_EMAX], s_fj[PH_EMAX], s_fk[PH_EMAX];       // pairs of the fragment under brute force, fragment-local indices
+    __shared__ uint8_t s_mark[2 * PH_NMAX + 2];
+    __shared__ int32_t s_weak[PH_NMAX + 4];
+    __shared__ uint8_t s_inpts[PH_NMAX + 4];
+    __shared__ uint16_t s_bounds[PH_NMAX + 4];
+    __shared__ char s_p0[PH_NMAX + 4];                                     // configuration of haplotype A per fragment, concatenated
+    __shared__ uint16_t s_p0off[PH_NMAX + 4];
+    __shared__ char s_cur[4 * PH_NMAX], s_cand[4 * PH_NMAX], s_fin[4 * PH_NMAX];
+    __shared__ uint16_t s_finlen[PH_NMAX + 4];
+    __shared__ int s_nf, s_nfe, s_status, s_nfin, s_ok;
+    const int lane = threadIdx.x;
+    const uint32_t c = P.complex_list[blockIdx.x];
+    (void)nlist;
+    const uint32_t m0 = P.cstart[c], e0 = P.estart[c];
+    const int n = (int)(P.cstart[c + 1] - m0), E = (int)(P.estart[c + 1] - e0);
+    if (n > PH_NMAX || E > PH_EMAX) {
+        if (lane == 0) P.exc_list[atomicAdd(&P.counters[1], 1u)] = c;
+        return;
+    }
+    for (int t = lane; t < E; t += 64) {
+        const uint32_t e = P.ekeep[e0 + t];
+        const uint32_t ga = (uint32_t)P.ea[e], gb = (uint32_t)P.eb[e];
+        int lo = 0, hi = n;
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (P.mem_s[m0 + m] <= ga) lo = m; else hi = m; }
+        s_i[t] = (uint8_t)lo;
+        lo = 0; hi = n;
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (P.mem_s[m0 + m] <= gb) lo = m; else hi = m; }
+        s_j[t] = (uint8_t)lo;
+        s_k[t] = (int8_t)P.cfgv[e];
+    }
+    if (lane == 0) { s_status = 0; s_nfin = 0; }
+    __syncthreads();
+
+    // flood fill from (variant lo, allele 0) over the pairs inside [lo, hi) (all pairs when lo = 0, hi = n): resolve_phase :2172-2207.
+    // Returns the number of allele nodes reached (the reference accepts iff it equals hi - lo); marks stay in s_mark.
+    auto flood = [&](int lo, int hi) -> int {
+        for (int t = lane; t < 2 * n; t += 64) s_mark[t] = 0;
+        __syncthreads();
+        if (lane == 0) s_mark[2 * lo] = 1;
+        __syncthreads();
+        for (;;) {
+            int changed = 0;
+            for (int t = lane; t < E; t += 64) {
+                const int k = s_k[t];
+                if (k < 0) continue;
+                const int i = s_i[t], j = s_j[t];
+                if (i < lo || i >= hi || j < lo || j >= hi) continue;
+                for (int a = 0; a < 2; a++) {
+                    const int u = 2 * i + a, w = 2 * j + (a ^ k);
+                    const int mu = s_mark[u], mw = s_mark[w];
+                    if (mu && !mw) { s_mark[w] = 1; changed = 1; }
+                    else if (mw && !mu) { s_mark[u] = 1; changed = 1; }
+                }
+            }
+            const int any = __any(changed);
+            __syncthreads();
+            if (!any) break;
+        }
+        int cnt = 0;
+        for (int t = lane; t < 2 * n; t += 64) cnt += s_mark[t];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        return cnt;
+    };
+    // configuration string of [lo, hi) from the marks (a variant without a reached allele is skipped: quirk kept); lane 0 only
+    auto marks_to_string = [&](int lo, int hi, char *dst) -> int {
+        int w = 0;
+        for (int i = lo; i < hi; i++) {
+            if (s_mark[2 * i]) dst[w++] = '0';
+            else if (s_mark[2 * i + 1]) dst[w++] = '1';
+        }
+        return w;
+    };
+    // supporting allele pairs of configuration cfg over variants idx0.. (:2236-2249; twice the number of consistent pairs); lane 0 only
+    auto score_cfg = [&](int idx0, int idx_n, const char *cfg, int len) -> int {
+        const int L = idx_n < len ? idx_n : len;
+        int s = 0;
+        for (int t = 0; t < E; t++) {
+            const int k = s_k[t];
+            if (k < 0) continue;
+            const int i = (int)s_i[t] - idx0, j = (int)s_j[t] - idx0;
+            if (i < 0 || j < 0 || i >= L || j >= L) continue;
+            const char ci = cfg[i], cj = cfg[j];
+            if (ci == '-' || cj == '-') continue;
+            if ((cj - '0') == ((ci - '0') ^ k)) s += 2;
+        }
+        return s;
+    };
+
+    const int reached = flood(0, n);
+    if (reached == n) {
+        if (lane == 0) { s_finlen[0] = (uint16_t)marks_to_string(0, n, s_fin); s_nfin = 1; }
+    } else {
+        const int xmax = P.max_block_size == 0 ? n : P.max_block_size;
+        // split_by_weak (:2271-2324)
+        if (lane == 0) {
+            for (int p = 0; p <= n + 1; p++) { s_weak[p] = 0; s_inpts[p] = 0; }
+            for (int t = 0; t < E; t++) {
+                const int i = s_i[t] < s_j[t] ? s_i[t] : s_j[t], j = s_i[t] < s_j[t] ? s_j[t] : s_i[t];
+                if (i == j) continue;
+                s_weak[i + 1] += 1; s_weak[j + 1] -= 1;             // a pair (i, j) spans the cut positions p in (i, j]
+            }
+            int run = 0, maxw = 0;
+            for (int p = 0; p <= n; p++) { run += s_weak[p]; s_weak[p] = run; }
+            for (int p = 2; p < n - 1; p++) maxw = s_weak[p] > maxw ? s_weak[p] : maxw;
+            int biggest = n, level = 1, nbd = 0;
+            s_bounds[0] = 0; s_bounds[1] = (uint16_t)n; nbd = 2;
+            while (biggest > xmax || level == 1) {
+                for (int p = 2; p < n - 1; p++)
+                    if (s_weak[p] == level && !s_inpts[p + 1] && !s_inpts[p - 1]) s_inpts[p] = 1;
+                nbd = 0; s_bounds[nbd++] = 0;
+                for (int p = 2; p < n - 1; p++) if (s_inpts[p]) s_bounds[nbd++] = (uint16_t)p;
+                s_bounds[nbd++] = (uint16_t)n;
+                biggest = 0;
+                for (int t = 1; t < nbd; t++) biggest = (int)s_bounds[t] - (int)s_bounds[t - 1] > biggest ? (int)s_bounds[t] - (int)s_bounds[t - 1] : biggest;
+                level++;
+                if (level > maxw + 1 && biggest > xmax) { s_status = 1; break; }          // the reference never leaves this loop
+            }
+            s_nf = nbd - 1;
+        }
+        __syncthreads();
+        if (s_status) { if (lane == 0) atomicAdd(&P.counters[2], 1u); return; }
+        const int nf = s_nf;
+        // sub_block_phase without a given configuration, per fragment (:2209-2258)
+        if (lane == 0) s_p0off[0] = 0;
+        __syncthreads();
+        for (int f = 0; f < nf; f++) {
+            const int base = s_bounds[f], len = (int)s_bounds[f + 1] - base;
+            bool done = false;
+            if (nf > 1) {
+                const int r = flood(base, base + len);
+                if (r == len) {
+                    if (lane == 0) s_p0off[f + 1] = (uint16_t)(s_p0off[f] + marks_to_string(base, base + len, s_p0 + s_p0off[f]));
+                    done = true;
+                }
+            }
+            if (!done) {
+                if (len > PH_BRUTE_MAX) {                  // the host takes it (the reference's limit is its patience)
+                    if (lane == 0) P.exc_list[atomicAdd(&P.counters[1], 1u)] = c;
+                    return;
+                }
+                if (lane == 0) {
+                    int w = 0;
+                    for (int t = 0; t < E; t++) {
+                        const int k = s_k[t];
+                        if (k < 0) continue;
+                        const int i = (int)s_i[t] - base, j = (int)s_j[t] - base;
+                        if (i < 0 || j < 0 || i >= len || j >= len) continue;
+                        s_fi[w] = (uint8_t)i; s_fj[w] = (uint8_t)j; s_fk[w] = (uint8_t)k; w++;
+                    }
+                    s_nfe = w;
+                }
+                __syncthreads();
+                const int nfe = s_nfe;
+                const uint32_t ncode = 1u << (len - 1);
+                int best_s = -1; uint32_t best_c = 0; uint32_t ties = 0;
+                for (uint32_t code = (uint32_t)lane; code < ncode; code += 64) {
+                    int s = 0;
+                    for (int t = 0; t < nfe; t++) {
+                        const int i = s_fi[t], j = s_fj[t];
+                        const uint32_t bi = i == 0 ? 0u : (code >> (len - 1 - i)) & 1u, bj = j == 0 ? 0u : (code >> (len - 1 - j)) & 1u;
+                        s += ((bi ^ bj) == (uint32_t)s_fk[t]) ? 1 : 0;
+                    }
+                    if (s > best_s) { best_s = s; best_c = code; ties = 1; }
+                    else if (s == best_s) ties++;
+                }
+                int gmax = best_s;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(gmax, d); gmax = o > gmax ? o : gmax; }
+                uint32_t tt = best_s == gmax ? ties : 0u, cc = best_s == gmax ? best_c : NONE32;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { tt += __shfl_xor(tt, d); const uint32_t o = __shfl_xor(cc, d); cc = o < cc ? o : cc; }
+                if (lane == 0) {
+                    char *dst = s_p0 + s_p0off[f];
+                    if (tt == 1) { dst[0] = '0'; for (int k = 1; k < len; k++) dst[k] = ((cc >> (len - 1 - k)) & 1u) ? '1' : '0'; }
+                    else for (int k = 0; k < len; k++) dst[k] = '-';              // a tie for the best score: all '-' (:2255-2258)
+                    s_p0off[f + 1] = (uint16_t)(s_p0off[f] + len);
+                }
+            }
+            __syncthreads();
+        }
+        // stitching, left to right (:2138-2160); haplotype B is always the flip of haplotype A, so only A is carried
+        if (lane == 0) {
+            int curlen = (int)s_p0off[1];
+            for (int k = 0; k < curlen; k++) s_cur[k] = s_p0[k];
+            int start = 0, nfin = 0, finpos = 0;
+            for (int f = 1; f < nf; f++) {
+                const char *nxt = s_p0 + s_p0off[f];
+                const int nlen = (int)s_p0off[f + 1] - (int)s_p0off[f];
+                const int used = curlen + nlen;                     // (|cur A| + |cur B| + |next A| + |next B| + 1) / 2
+                const int hi = n < start + used ? n : start + used;
+                const int idx_n = hi - start > 0 ? hi - start : 0;
+                // candidates: cur A + next A, cur A + next B; the other two joint configurations are their complements (skipped, :2228-2234)
+                bool cur_inv = true, nxt_inv = true;                // a string of '-' (or an empty one) equals its own flip
+                for (int k = 0; k < curlen; k++) if (s_cur[k] != '-') cur_inv = false;
+                for (int k = 0; k < nlen; k++) if (nxt[k] != '-') nxt_inv = false;
+                for (int k = 0; k < curlen; k++) s_cand[k] = s_cur[k];
+                for (int k = 0; k < nlen; k++) s_cand[curlen + k] = nxt[k];
+                const int s0 = score_cfg(start, idx_n, s_cand, used);
+                int ncand = 1, s1 = -1;
+                if (!cur_inv && !nxt_inv) {
+                    for (int k = 0; k < nlen; k++) s_cand[used + curlen + k] = flipc(nxt[k]);
+                    for (int k = 0; k < curlen; k++) s_cand[used + k] = s_cur[k];
+                    s1 = score_cfg(start, idx_n, s_cand + used, used);
+                    ncand = 2;
+                }
+                int win = -1;
+                if (ncand == 1) win = 0;
+                else if (s0 > s1) win = 0;
+                else if (s1 > s0) win = 1;
+                bool has_dash;
+                int outlen;
+                if (win >= 0) {
+                    outlen = used; has_dash = false;
+                    for (int k = 0; k < used; k++) if (s_cand[win * used + k] == '-') has_dash = true;
+                } else { outlen = idx_n; has_dash = idx_n > 0; }               // all '-' (length idx_n); empty string holds no '-'
+                if (has_dash) {
+                    for (int k = 0; k < curlen; k++) s_fin[finpos + k] = s_cur[k];
+                    s_finlen[nfin++] = (uint16_t)curlen; finpos += curlen;
+                    start = used;                                                // ASSIGNED, not advanced (:2152)
+                    for (int k = 0; k < nlen; k++) s_cur[k] = nxt[k];
+                    curlen = nlen;
+                } else {
+                    for (int k = 0; k < outlen; k++) s_cur[k] = win >= 0 ? s_cand[win * used + k] : '-';
+                    curlen = outlen;
+                }
+            }
+            for (int k = 0; k < curlen; k++) s_fin[finpos + k] = s_cur[k];
+            s_finlen[nfin++] = (uint16_t)curlen;
+            s_nfin = nfin;
+        }
+    }
+    __syncthreads();
+    // final sub-blocks (:2162-2169): strings laid end to end over the variants; one that starts with '-' is dropped
+    if (lane == 0) {
+        for (int t = 0; t < n; t++) P.sub_of[m0 + t] = -1;
+        int vi = 0, fp = 0, ns = 0;
+        for (int q = 0; q < s_nfin; q++) {
+            const int len = s_finlen[q];
+            if (len > 0 && s_fin[fp] != '-') {
+                int put = 0;
+                for (int t = 0; t < len; t++) {
+                    const int li = vi + t;
+                    if (li < n) { P.sub_of[m0 + li] = (int16_t)ns; P.alle_of[m0 + li] = (uint8_t)(s_fin[fp + t] == '1' ? 1 : 0); put++; }
+                }
+                if (put > 0) ns++;
+            }
+            vi += len; fp += len;
+        }
+        P.nsub[c] = (uint32_t)ns;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- blocks
+// blocks of the components in block order (rule 4): component r of the order owns blocks [blk_base[r], blk_base[r + 1])
+struct BK {
+    const uint32_t *corder, *blk_base, *cstart, *mem_s;
+    const int16_t *sub_of; const uint8_t *alle_of;
+    uint32_t *blk_mstart, *blk_len; int32_t *blk_of; uint8_t *v_alle;
+    const uint16_t *vchrom;
+    uint32_t *chrom_blocks, *chrom_blkvars; unsigned long long *chrom_cfgrows;      // [nchrom]
+    unsigned long long *counters;                                                   // [2] phased variants, [3] longest block
+};
+__global__ __launch_bounds__(256) void k_blocks(int64_t ncomp, BK B) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= ncomp) return;
+    const uint32_t c = B.corder[r], base = B.blk_base[r];
+    const uint32_t m0 = B.cstart[c], n = B.cstart[c + 1] - m0;
+    const int ch = B.vchrom[B.mem_s[m0]];
+    uint32_t nblk = 0, nvars = 0, longest = 0; unsigned long long cfgrows = 0;
+    int cur = -1; uint32_t run0 = 0;
+    for (uint32_t t = 0; t <= n; t++) {
+        const int s = t < n ? (int)B.sub_of[m0 + t] : -2;
+        if (s != cur) {
+            if (cur >= 0) {
+                const uint32_t len = t - run0;
+                B.blk_mstart[base + (uint32_t)cur] = m0 + run0; B.blk_len[base + (uint32_t)cur] = len;
+                nblk++; nvars += len; cfgrows += (unsigned long long)len * (len - 1); longest = len > longest ? len : longest;
+            }
+            cur = s; run0 = t;
+        }
+        if (t < n && s >= 0) { const uint32_t v = B.mem_s[m0 + t]; B.blk_of[v] = (int32_t)(base + (uint32_t)s); B.v_alle[v] = B.alle_of[m0 + t]; }
+    }
+    if (nblk) {
+        atomicAdd(&B.chrom_blocks[ch], nblk); atomicAdd(&B.chrom_blkvars[ch], nvars); atomicAdd(&B.chrom_cfgrows[ch], cfgrows);
+        atomicAdd(&B.counters[2], (unsigned long long)nvars); atomicMax(&B.counters[3], (unsigned long long)longest);
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_nsub(int64_t ncomp, const uint32_t *corder, const uint32_t *nsub, uint32_t *out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < ncomp) out[r] = nsub[corder[r]];
+}
+// allele pairs supporting / inside each final block (:876-895; ordered pairs halved = pairs)
+__global__ __launch_bounds__(256) void k_blk_edges(int64_t nkeep, const uint32_t *ekeep, const int32_t *ea, const int32_t *eb, const int32_t *cfgv, const int32_t *blk_of,
+                                                   const uint8_t *v_alle, uint32_t *blk_sup, uint32_t *blk_tot) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nkeep) return;
+    const uint32_t e = ekeep[t];
+    const int k = cfgv[e];
+    if (k < 0) return;
+    const int a = ea[e], b = eb[e];
+    const int ba = blk_of[a];
+    if (ba < 0 || ba != blk_of[b]) return;
+    atomicAdd(&blk_tot[ba], 1u);
+    const int want = k == 0 ? v_alle[a] : 1 - v_alle[a];
+    if ((int)v_alle[b] == want) atomicAdd(&blk_sup[ba], 1u);
+}
+// per block: annotated phase, concordance, genome-wide phase by majority (:945-980), gwStat, the variant whose maf text is printed,
+// rows of allele_config
+struct BS {
+    const uint32_t *mem_s, *blk_mstart, *blk_len; const uint8_t *v_alle; const int8_t *phase_idx; const double *mafv;
+    uint8_t *conc, *cormode, *statkind; uint32_t *statidx; int32_t *maxmaf; double *stat; unsigned long long *cfg_rows;
+};
+__global__ __launch_bounds__(256) void k_blk_stats(int64_t nblocks, BS S) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t m0 = S.blk_mstart[b], n = S.blk_len[b];
+    int nknown = 0, ksum = 0, first_known = -1;
+    bool all_equal = true, any_nan = false;
+    int64_t best = S.mem_s[m0];
+    for (uint32_t t = 0; t < n; t++) {
+        const int64_t g = S.mem_s[m0 + t];
+        const int p = S.phase_idx[2 * g + S.v_alle[g]];
+        if (p >= 0) {
+            if (first_known < 0) first_known = p; else if (p != first_known) all_equal = false;
+            nknown++; ksum += p;
+        } else any_nan = true;
+        if (S.mafv[g] > S.mafv[best]) best = g;                      // first maximal element, like max()
+    }
+    uint8_t cm = 0, kind = 2; uint32_t idx = 0; double stat = 0.5;
+    if (nknown > 0) {
+        if (!any_nan && all_equal) { kind = 1; stat = 1.0; }
+        else {
+            const double m = (double)ksum / (double)nknown;
+            if (m < 0.5) cm = 1; else if (m > 0.5) cm = 2;
+            const double other = 1 - m;
+            stat = m >= other ? m : other;
+            kind = 0; idx = (uint32_t)nknown * (STAT_N + 1) + (uint32_t)ksum;
+        }
+    }
+    S.conc[b] = all_equal ? 1 : 0; S.cormode[b] = cm; S.statkind[b] = kind; S.statidx[b] = idx; S.maxmaf[b] = (int32_t)best; S.stat[b] = stat;
+    S.cfg_rows[b] = (unsigned long long)n * (n - 1);
+}
+
+// ---------------------------------------------------------------------------------------------- read sets of the haplotypes
+// A segment is a list of read-list pieces; its items (QNAME ids, in line order) get the number of their QNAME by first appearance
+// and the segment its number of distinct QNAMEs.
+//   MODE 0: segment (block, haplotype, BAM): the haplotype's allele lists of the block's non-blacklisted variants in that BAM; labels written
+//   MODE 1: segment (block, haplotype): all variants, all BAMs; count only (reads_hap_a / reads_hap_b of haplotypes.txt)
+//   MODE 2: segment = one (variant, allele, BAM) list; count only (singleton rows when there are several BAMs)
+struct SG {
+    int64_t nseg; int nb;
+    const uint32_t *mem_s, *blk_mstart, *blk_len; const uint8_t *v_alle, *black;
+    const uint32_t *rl_start; const int32_t *rl_qid;
+    uint32_t *labels, *ns;
+    uint32_t *big_list; uint32_t *counters;         // [0] segments left to the block kernel, [1] pool slots used, [2] pool overflow
+    uint32_t *pool; uint32_t pool_cap;
+};
+template <int MODE> __device__ __forceinline__ uint32_t seg_pieces(const SG &G, int64_t seg) {      // number of pieces (some may be empty / skipped)
+    if (MODE == 2) return 1;
+    const int64_t b = MODE == 0 ? seg / (2 * G.nb) : seg / 2;
+    return G.blk_len[b];
+}
+template <int MODE> __device__ __forceinline__ bool seg_piece(const SG &G, int64_t seg, uint32_t t, uint32_t *lo, uint32_t *hi) {
+    if (MODE == 2) { *lo = G.rl_start[seg]; *hi = G.rl_start[seg + 1]; return true; }
+    const int64_t b = MODE == 0 ? seg / (2 * G.nb) : seg / 2;
+    const int h = MODE == 0 ? (int)((seg / G.nb) & 1) : (int)(seg & 1);
+    const int64_t g = G.mem_s[G.blk_mstart[b] + t];
+    const int64_t l = 2 * g + (G.v_alle[g] ^ h);
+    if (MODE == 0) {
+        if (G.black && G.black[g]) return false;
+        const int bb = (int)(seg % G.nb);
+        *lo = G.rl_start[l * G.nb + bb]; *hi = G.rl_start[l * G.nb + bb + 1];
+    } else { *lo = G.rl_start[l * G.nb]; *hi = G.rl_start[l * G.nb + G.nb]; }
+    return true;
+}
+
+template <int MODE> __global__ __launch_bounds__(64) void k_seg_small(SG G) {
+    __shared__ int32_t s_q[64][SEG_SMALL + 1];
+    __shared__ uint8_t s_l[64][SEG_SMALL + 4];
+    const int64_t seg = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (seg >= G.nseg) return;
+    const int tid = threadIdx.x;
+    const uint32_t np = seg_pieces<MODE>(G, seg);
+    uint32_t M = 0;
+    for (uint32_t t = 0; t < np; t++) { uint32_t lo, hi; if (seg_piece<MODE>(G, seg, t, &lo, &hi)) M += hi - lo; }
+    if (M == 0) { G.ns[seg] = 0; return; }
+    if (M > SEG_SMALL) { G.big_list[atomicAdd(&G.counters[0], 1u)] = (uint32_t)seg; return; }
+    uint32_t idx = 0;
+    for (uint32_t t = 0; t < np; t++) {
+        uint32_t lo, hi;
+        if (!seg_piece<MODE>(G, seg, t, &lo, &hi)) continue;
+        for (uint32_t p = lo; p < hi; p++) s_q[tid][idx++] = G.rl_qid[p];
+    }
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < M; i++) {
+        const int32_t q = s_q[tid][i];
+        uint32_t first = i;
+        for (uint32_t j = 0; j < i; j++) if (s_q[tid][j] == q) { first = j; break; }
+        s_l[tid][i] = first == i ? (uint8_t)cnt++ : s_l[tid][first];
+    }
+    G.ns[seg] = cnt;
+    if (MODE == 0) {
+        idx = 0;
+        for (uint32_t t = 0; t < np; t++) {
+            uint32_t lo, hi;
+            if (!seg_piece<MODE>(G, seg, t, &lo, &hi)) continue;
+            for (uint32_t p = lo; p < hi; p++) G.labels[p] = s_l[tid][idx++];
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t seg_hash(uint32_t q) { q ^= q >> 16; q *= 0x7feb352du; q ^= q >> 15; q *= 0x846ca68bu; q ^= q >> 16; return q; }
+
+// one workgroup per segment with more than SEG_SMALL items: open-addressing table keyed by QNAME id holding the first position (then
+// the number) of the QNAME -- in LDS up to SEG_LDS items, in a slice of the global pool beyond
+template <int MODE> __global__ __launch_bounds__(256) void k_seg_big(SG G) {
+    __shared__ uint32_t s_tab[3 * SEG_LDS_SLOTS];
+    __shared__ uint32_t s_pref[STAT_N + 2], s_lo[STAT_N + 2];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry, s_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t seg = G.big_list[blockIdx.x];
+    const uint32_t np = seg_pieces<MODE>(G, seg);
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t t = 0; t < np; t++) {
+            uint32_t lo = 0, hi = 0;
+            const bool ok = seg_piece<MODE>(G, seg, t, &lo, &hi);
+            s_pref[t] = acc; s_lo[t] = lo;
+            if (ok) acc += hi - lo;
+        }
+        s_pref[np] = acc; s_carry = 0; s_off = 0;
+    }
+    __syncthreads();
+    const uint32_t M = s_pref[np];
+    uint32_t cap = SEG_LDS_SLOTS;
+    uint32_t *keys = s_tab;
+    if (M > SEG_LDS) {
+        while (cap < 2 * M) cap <<= 1;
+        if (tid == 0) {
+            const uint32_t off = atomicAdd(&G.counters[1], 3 * cap);
+            s_off = off;
+            if ((unsigned long long)off + 3ull * cap > (unsigned long long)G.pool_cap) { atomicOr(&G.counters[2], 1u); s_off = NONE32; }
+        }
+        __syncthreads();
+        if (s_off == NONE32) return;
+        keys = G.pool + s_off;
+    }
+    uint32_t *first = keys + cap, *rank = keys + 2 * cap;
+    const uint32_t mask = cap - 1;
+    for (uint32_t s = tid; s < cap; s += 256) { keys[s] = 0; first[s] = NONE32; }
+    __syncthreads();
+    auto item_pos = [&](uint32_t idx) -> uint32_t {
+        uint32_t lo = 0, hi = np;                              // largest t with s_pref[t] <= idx (pieces of length 0 share a start: the last one wins, it is the non-empty one)
+        while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (s_pref[m] <= idx) lo = m; else hi = m; }
+        return s_lo[lo] + (idx - s_pref[lo]);
+    };
+    auto slot_of = [&](uint32_t q) -> uint32_t {
+        uint32_t s = seg_hash(q) & mask;
+        while (keys[s] != q + 1u) s = (s + 1) & mask;
+        return s;
+    };
+    for (uint32_t idx = tid; idx < M; idx += 256) {
+        const uint32_t q = (uint32_t)G.rl_qid[item_pos(idx)];
+        uint32_t s = seg_hash(q) & mask;
+        for (;;) {
+            const uint32_t prev = atomicCAS(&keys[s], 0u, q + 1u);
+            if (prev == 0u || prev == q + 1u) { atomicMin(&first[s], idx); break; }
+            s = (s + 1) & mask;
+        }
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < M; base += 256) {
+        const uint32_t idx = base + tid;
+        uint32_t slot = 0; bool isf = false;
+        if (idx < M) { slot = slot_of((uint32_t)G.rl_qid[item_pos(idx)]); isf = first[slot] == idx; }
+        const unsigned long long bal = __ballot(isf ? 1 : 0);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w = 0; w < wave; w++) before += s_w[w];
+        if (isf) rank[slot] = before + (uint32_t)__popcll(bal & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        __syncthreads();
+        if (tid == 0) s_carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) G.ns[seg] = s_carry;
+    if (MODE == 0)
+        for (uint32_t idx = tid; idx < M; idx += 256) {
+            const uint32_t p = item_pos(idx);
+            G.labels[p] = rank[slot_of((uint32_t)G.rl_qid[p])];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- small helpers of the orchestration
+// seg_off[s] = off[sum of count[0..s)]: byte offsets of the per-chromosome (per BAM x chromosome) segments of a file
+__global__ void k_seg_offsets(const uint32_t *count, const uint32_t *mult, int nseg, const unsigned long long *off, unsigned long long *seg_off) {
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long rows = 0;
+    for (int s = 0; s <= nseg; s++) {
+        seg_off[s] = off[rows];
+        if (s < nseg) rows += (unsigned long long)count[s] * (mult ? *mult : 1u);
+    }
+}
+__global__ void k_seg_offsets64(const unsigned long long *count, int nseg, const unsigned long long *off, unsigned long long *seg_off) {
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long rows = 0;
+    for (int s = 0; s <= nseg; s++) { seg_off[s] = off[rows]; if (s < nseg) rows += count[s]; }
+}
+__global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *len, int64_t n, unsigned long long *counter) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && len[i] != 0 ? 1 : 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, int64_t n, uint32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// per-block arrays of write_vcf in block order, chromosome-local variant indices
+struct VB {
+    const uint32_t *mem_s, *blk_mstart, *blk_len, *blk_voff; const uint8_t *v_alle, *cormode; const int8_t *phase_idx; const int32_t *maxmaf;
+    const uint16_t *vchrom; const long long *chrom_v0;
+    int32_t *o_var, *o_maxmaf; uint8_t *o_hap; int8_t *o_cor;
+};
+__global__ __launch_bounds__(256) void k_vcf_blocks(int64_t nblocks, VB V) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t m0 = V.blk_mstart[b], n = V.blk_len[b], o = V.blk_voff[b];
+    const long long v0 = V.chrom_v0[V.vchrom[V.mem_s[m0]]];
+    const uint8_t cm = V.cormode[b];
+    V.o_maxmaf[b] = (int32_t)(V.maxmaf[b] - v0);
+    for (uint32_t t = 0; t < n; t++) {
+        const int64_t g = V.mem_s[m0 + t];
+        const uint8_t a = V.v_alle[g];
+        V.o_var[o + t] = (int32_t)(g - v0); V.o_hap[o + t] = a;
+        V.o_cor[2 * (size_t)(o + t)] = cm == 0 ? V.phase_idx[2 * g + a] : (int8_t)(cm == 1 ? 0 : 1);
+        V.o_cor[2 * (size_t)(o + t) + 1] = cm == 0 ? V.phase_idx[2 * g + (a ^ 1)] : (int8_t)(cm == 1 ? 1 : 0);
+    }
+}
+__global__ __launch_bounds__(256) void k_vchrom(int64_t nv, const long long *chrom_v0, int nchrom, uint16_t *vchrom) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    int lo = 0, hi = nchrom;
+    while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (chrom_v0[m] <= v) lo = m; else hi = m; }
+    vchrom[v] = (uint16_t)lo;
+}
+
+}  // namespace
+
+// ================================================================================================ host side
+struct phz_rowsdev {
+    int64_t nv = 0;
+    int nchrom = 0;
+    bool has_black = false;
+    std::vector<long long> chrom_v0;
+    // static tables in HBM
+    DevBuf d_chrom_v0, d_vchrom, d_pos, d_maf, d_isref, d_phase, d_black;
+    DevBuf p_off[6], p_txt[6];          // pools: 0 uid, 1 rsid, 2 allele, 3 maf text, 4 chromosome names, 5 gwStat table
+    // per pass
+    DevBuf hkeys, flags, slot_pv, pv_off, pv_txt, bam_off, bam_txt, bam_excl, sh_lo, sh_hi, sh_bam;
+    DevBuf keep, e_slot, deg, parent, label, f_a, f_b, f_c, f_d, mem_pos, cid, kpos, keypos;
+    DevBuf k64a, k64b, k32a, k32b, v32a, v32b, sort_cnt, scan_tmp;
+    DevBuf ridx, va, vb, eorder, mem_s, cstart, corder, ekeep, estart, key_g;
+    DevBuf cnt64, cnt32, chrom_cnt;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
+    DevBuf alle_of, sub_of, nsub, complex_list, exc_list, nsub_o, blk_base;
+    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, blk_voff;
+    DevBuf labels, seg_ns, blk_cnt, single_n, big_list, pool, tl, its, piece_dst, rowlen;
+    DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
+    DevBuf o_var, o_maxmaf, o_hap, o_cor;
+    // results (host)
+    int64_t bytes[PHZ_TXT_COUNT] = {0};
+    std::vector<int64_t> seg_off[PHZ_TXT_COUNT];
+    std::vector<int64_t> chrom_blocks, chrom_blk_vars;
+    int64_t n_blocks = 0, n_blk_vars = 0;
+    bool keys_ready = false, have_vcf = false;
+    std::vector<DevBuf *> all() {
+        std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &slot_pv, &pv_off, &pv_txt, &bam_off, &bam_txt,
+                                   &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
+                                   &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
+                                   &key_g, &cnt64, &cnt32, &chrom_cnt, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
+                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &blk_voff, &labels,
+                                   &seg_ns, &blk_cnt, &single_n, &big_list, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
+        for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
+        for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
+        return v;
+    }
+};
+
+namespace {
+
+int up(phz_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
+    if (int s = phz_reserve(ctx, b, bytes ? bytes : 1)) return s;
+    if (bytes) PHZ_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PHZ_OK;
+}
+template <class T> T *P(DevBuf &b) { return (T *)b.p; }
+
+// GPU time of the stage = sum over the sync-free sections between two host waits (the host work in between -- scipy, exceptions -- is not GPU time)
+struct Sections {
+    phz_ctx *c; double ms = 0; bool open = false;
+    explicit Sections(phz_ctx *ctx) : c(ctx) {}
+    void begin() { if (!open) { (void)hipEventRecord(c->ev0, c->stream); open = true; } }
+    int wait() {                        // host wait: closes the section
+        begin();
+        hipError_t e = hipEventRecord(c->ev1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+        float x = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&x, c->ev0, c->ev1);
+        if (e != hipSuccess) return phz_fail(c, PHZ_E_HIP, "device row stage", e);
+        ms += x; open = false;
+        return PHZ_OK;
+    }
+};
+
+// sort `n` (key, value) pairs living in (ka, va) with scratch (kb, vb); the sorted values are copied to `dst_val` (and keys to dst_key if given)
+template <class K>
+int sort_into(phz_ctx *ctx, phz_rowsdev *h, DevBuf &ka, DevBuf &kb, int64_t n, const int (*ranges)[2], int nranges, uint32_t *dst_val, K *dst_key) {
+    K *k0 = P<K>(ka), *k1 = P<K>(kb); uint32_t *v0 = P<uint32_t>(h->v32a), *v1 = P<uint32_t>(h->v32b);
+    for (int r = 0; r < nranges; r++) {
+        int where = 0;
+        if (int s = radix_sort_pairs<K, uint32_t>(ctx, k0, k1, v0, v1, n, ranges[r][0], ranges[r][1], h->sort_cnt, h->scan_tmp, &where)) return s;
+        if (where) { std::swap(k0, k1); std::swap(v0, v1); }
+    }
+    if (n > 0) {
+        PHZ_HIP(ctx, hipMemcpyAsync(dst_val, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (dst_key) PHZ_HIP(ctx, hipMemcpyAsync(dst_key, k0, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return PHZ_OK;
+}
+
+// phase_v3 over all components: the two-variant fast path, the general kernel, the host for what exceeds the kernel's limits.
+// cstart / estart: CSR of members (mem_s: variant ids, ascending inside a component) and kept pairs (ekeep: pair ids into ea / eb / cfgv).
+int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf &estart, DevBuf &ekeep, const int32_t *ea, const int32_t *eb, const int32_t *cfgv,
+              int64_t ncomp, int64_t nmem, int64_t nkeep, int64_t ne, int max_block_size, DevBuf &alle_of, DevBuf &sub_of, DevBuf &nsub, DevBuf &complex_list,
+              DevBuf &exc_list, uint32_t *cnt32, int64_t *n_complex, int64_t *n_exc) {
+    hipStream_t sm = ctx->stream;
+    *n_complex = 0; *n_exc = 0;
+    if (int s = phz_reserve(ctx, alle_of, (size_t)(nmem + 1))) return s;
+    if (int s = phz_reserve(ctx, sub_of, (size_t)(nmem + 1) * 2)) return s;
+    if (int s = phz_reserve(ctx, nsub, (size_t)(ncomp + 1) * 4)) return s;
+    if (int s = phz_reserve(ctx, complex_list, (size_t)(ncomp + 1) * 4)) return s;
+    if (int s = phz_reserve(ctx, exc_list, (size_t)(2 * ncomp + 2) * 4)) return s;
+    if (!ncomp) return PHZ_OK;
+    PH ph; ph.cstart = P<uint32_t>(cstart); ph.mem_s = P<uint32_t>(mem_s); ph.estart = P<uint32_t>(estart); ph.ekeep = P<uint32_t>(ekeep);
+    ph.ea = ea; ph.eb = eb; ph.cfgv = cfgv; ph.alle_of = P<uint8_t>(alle_of); ph.sub_of = P<int16_t>(sub_of); ph.nsub = P<uint32_t>(nsub);
+    ph.complex_list = P<uint32_t>(complex_list); ph.exc_list = P<uint32_t>(exc_list); ph.counters = cnt32; ph.max_block_size = max_block_size;
+    uint32_t h_c32[4] = {0, 0, 0, 0};
+    PHZ_HIP(ctx, hipMemsetAsync(cnt32, 0, 12, sm));
+    hipLaunchKernelGGL(k_phase_pair, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, ph);
+    PHZ_HIP(ctx, hipMemcpyAsync(h_c32, cnt32, 4, hipMemcpyDeviceToHost, sm));
+    if (int s = sec.wait()) return s;
+    sec.begin();
+    if (h_c32[0]) hipLaunchKernelGGL(k_phase_general, dim3(h_c32[0]), dim3(64), 0, sm, ph, h_c32[0]);
+    PHZ_HIP(ctx, hipGetLastError());
+    PHZ_HIP(ctx, hipMemcpyAsync(h_c32, cnt32, 12, hipMemcpyDeviceToHost, sm));
+    if (int s = sec.wait()) return s;
+    if (h_c32[2]) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "a haplotype block cannot be split to --max_block_size (the reference does not terminate on it)");
+    *n_complex = h_c32[0]; *n_exc = h_c32[1];
+    if (h_c32[1]) {
+        // components beyond the kernel's limits (more than PH_NMAX variants / PH_EMAX pairs / a brute-force fragment of more than
+        // PH_BRUTE_MAX variants): phase_v3 on the host (the same routine the host row stage runs), results written back
+        std::vector<uint32_t> exc(h_c32[1]), cs((size_t)ncomp + 1), es((size_t)ncomp + 1), mem((size_t)nmem), ek((size_t)nkeep);
+        std::vector<int32_t> hea((size_t)ne), heb((size_t)ne), hcf((size_t)ne);
+        PHZ_HIP(ctx, hipMemcpy(exc.data(), exc_list.p, exc.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(cs.data(), cstart.p, cs.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(es.data(), estart.p, es.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(mem.data(), mem_s.p, mem.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(ek.data(), ekeep.p, ek.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(hea.data(), ea, hea.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(heb.data(), eb, heb.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(hcf.data(), cfgv, hcf.size() * 4, hipMemcpyDeviceToHost));
+        std::sort(exc.begin(), exc.end());
+        exc.erase(std::unique(exc.begin(), exc.end()), exc.end());
+        for (uint32_t c : exc) {
+            const uint32_t m0 = cs[c], n = cs[c + 1] - m0, e0 = es[c], E = es[c + 1] - e0;
+            std::vector<int32_t> ei(E), ej(E), sf(n + 1), sl(n + 1); std::vector<int8_t> ec(E); std::vector<char> cfg((size_t)n + 1);
+            for (uint32_t t = 0; t < E; t++) {
+                const uint32_t e = ek[e0 + t];
+                ei[t] = (int32_t)(std::lower_bound(mem.begin() + m0, mem.begin() + m0 + n, (uint32_t)hea[e]) - (mem.begin() + m0));
+                ej[t] = (int32_t)(std::lower_bound(mem.begin() + m0, mem.begin() + m0 + n, (uint32_t)heb[e]) - (mem.begin() + m0));
+                ec[t] = (int8_t)hcf[e];
+            }
+            int32_t nsubs = 0;
+            const int st = phz_phase_block((int32_t)n, (int64_t)E, ei.data(), ej.data(), ec.data(), max_block_size, sf.data(), sl.data(), cfg.data(), &nsubs);
+            if (st != PHZ_OK) return phz_fail(ctx, st, "block phasing of a large component on the host");
+            std::vector<int16_t> so(n, (int16_t)-1); std::vector<uint8_t> ao(n, 0);
+            uint32_t ns = 0; size_t w = 0;
+            for (int32_t k = 0; k < nsubs; k++) {
+                if (sl[k] <= 0) continue;
+                if (ns >= 32767) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "more than 32767 blocks in one component");
+                for (int32_t t = 0; t < sl[k]; t++) { so[(size_t)sf[k] + t] = (int16_t)ns; ao[(size_t)sf[k] + t] = (uint8_t)(cfg[w++] == '1'); }
+                ns++;
+            }
+            PHZ_HIP(ctx, hipMemcpy(P<int16_t>(sub_of) + m0, so.data(), (size_t)n * 2, hipMemcpyHostToDevice));
+            PHZ_HIP(ctx, hipMemcpy(P<uint8_t>(alle_of) + m0, ao.data(), (size_t)n, hipMemcpyHostToDevice));
+            PHZ_HIP(ctx, hipMemcpy(P<uint32_t>(nsub) + c, &ns, 4, hipMemcpyHostToDevice));
+        }
+    }
+    sec.begin();
+    return PHZ_OK;
+}
+
+}  // namespace
+
+extern "C" int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *t, phz_rowsdev **out) {
+    if (!ctx || !t || !out || t->nv < 0 || t->n_chroms < 0 || t->n_chroms > 65535) return PHZ_E_ARG;
+    if (t->nv >= (1ll << 28)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^28 variants");
+    *out = nullptr;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    phz_rowsdev *h = new (std::nothrow) phz_rowsdev();
+    if (!h) return PHZ_E_NOMEM;
+    const size_t nv = (size_t)t->nv;
+    h->nv = t->nv; h->nchrom = t->n_chroms;
+    h->chrom_v0.assign(t->chrom_v0, t->chrom_v0 + t->n_chroms + 1);
+    int st = PHZ_OK;
+    auto U = [&](DevBuf &b, const void *src, size_t bytes) { if (st == PHZ_OK) st = up(ctx, b, src, bytes); };
+    U(h->d_chrom_v0, h->chrom_v0.data(), (size_t)(t->n_chroms + 1) * 8);
+    U(h->d_pos, t->pos, nv * 4); U(h->d_maf, t->maf, nv * 8); U(h->d_isref, t->is_ref, 2 * nv); U(h->d_phase, t->phase_idx, 2 * nv);
+    h->has_black = t->blacklisted != nullptr;
+    if (h->has_black) U(h->d_black, t->blacklisted, nv);
+    const uint32_t *offs[5] = {t->uid_off, t->rsid_off, t->allele_off, t->maf_off, t->chrom_name_off};
+    const char *txts[5] = {t->uid, t->rsid, t->allele, t->maf_txt, t->chrom_names};
+    const size_t cnts[5] = {nv, nv, 2 * nv, nv, (size_t)t->n_chroms};
+    for (int i = 0; i < 5; i++) { U(h->p_off[i], offs[i], (cnts[i] + 1) * 4); U(h->p_txt[i], txts[i], (size_t)offs[i][cnts[i]]); }
+    // gwStat text of a block whose annotated phases are not all equal (:968-980): m = mean of the known phase indices, printed max(m, 1 - m)
+    // as str(numpy.float64).  Entry [nknown * (STAT_N + 1) + ksum]; the same float64 operations as numpy.mean of 0/1 values and 1 - m
+    {
+        std::string txt; std::vector<uint32_t> off((size_t)(STAT_N + 1) * (STAT_N + 1) + 1);
+        size_t w = 0;
+        for (int nk = 0; nk <= STAT_N; nk++)
+            for (int ks = 0; ks <= STAT_N; ks++) {
+                off[w++] = (uint32_t)txt.size();
+                if (nk > 0 && ks <= nk) { const double m = (double)ks / (double)nk, o = 1 - m; phztext::put_pyfloat(txt, m >= o ? m : o); }
+                txt += '\n';
+            }
+        off[w] = (uint32_t)txt.size();
+        U(h->p_off[5], off.data(), off.size() * 4); U(h->p_txt[5], txt.data(), txt.size());
+        if (st == PHZ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = PHZ_E_HIP;     // txt / off die with this scope
+    }
+    if (st == PHZ_OK) st = phz_reserve(ctx, h->d_vchrom, nv * 2 + 2);
+    if (st == PHZ_OK && nv) hipLaunchKernelGGL(k_vchrom, dim3(nblk(t->nv)), dim3(256), 0, ctx->stream, t->nv, (const long long *)h->d_chrom_v0.p, t->n_chroms, P<uint16_t>(h->d_vchrom));
+    if (st == PHZ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = phz_fail(ctx, PHZ_E_HIP, "phz_rowsdev_create");
+    if (st != PHZ_OK) { phz_rowsdev_destroy(h); return st; }
+    *out = h;
+    return PHZ_OK;
+}
+
+extern "C" void phz_rowsdev_destroy(phz_rowsdev *h) {
+    if (!h) return;
+    for (DevBuf *b : h->all()) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    delete h;
+}
+
+// Stage 1: the distinct (total, supporting) argument pairs of the binomial test over the tested pairs of the last phz_tally.  keys_host
+// [PHZ_PAIR_SLOTS] receives the hash set as it lives on the device: slot s holds (total << 32 | supporting) or all ones when empty.  The caller
+// evaluates the p-value of every occupied slot (the reference's scipy call) and passes values and their text to phz_rowsdev_run by slot.
+extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host) {
+    if (!ctx || !h || !keys_host) return PHZ_E_ARG;
+    auto &T = ctx->tally;
+    if (T.nv != h->nv) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not belong to these variant tables");
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    if (int s = phz_reserve(ctx, h->hkeys, (size_t)PS_SLOTS * 8)) return s;
+    if (int s = phz_reserve(ctx, h->flags, 64)) return s;
+    hipStream_t sm = ctx->stream;
+    PHZ_HIP(ctx, hipMemsetAsync(h->hkeys.p, 0xff, (size_t)PS_SLOTS * 8, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->flags.p, 0, 64, sm));
+    const int64_t ne = T.n_edges;
+    if (ne > 0) hipLaunchKernelGGL(k_pair_keys, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, (const int32_t *)(T.stats + 2 * ne),
+                                   (const int32_t *)(T.stats + 3 * ne), P<unsigned long long>(h->hkeys), P<uint32_t>(h->flags));
+    PHZ_HIP(ctx, hipGetLastError());
+    uint32_t fl = 0;
+    PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, (size_t)PS_SLOTS * 8, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&fl, h->flags.p, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    if (fl & 1u) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "more than 65536 distinct (supporting, total) read-count pairs");
+    h->keys_ready = true;
+    return PHZ_OK;
+}
+
+// Stage 2: everything else, up to the finished text in HBM.
+extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *o, const double *slot_pv, const uint32_t *slot_txt_off,
+                               const char *slot_txt, phz_rowsdev_result *res) {
+    if (!ctx || !h || !o || !slot_pv || !slot_txt_off || !slot_txt || !res) return PHZ_E_ARG;
+    auto &T = ctx->tally;
+    if (!h->keys_ready) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run without phz_rowsdev_pair_keys");
+    h->keys_ready = false;
+    if (T.nv != h->nv || T.nb != o->n_bams) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not match (variants / BAMs)");
+    if (o->gw_phase_method != 0) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: --gw_phase_method 1 is formatted by the host stage");
+    if (o->output_read_ids) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: --output_read_ids 1 is formatted by the host stage");
+    if (!T.rl_list && T.n_rl) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally carries no list index per read-list entry");
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    memset(res, 0, sizeof(*res));
+    hipStream_t sm = ctx->stream;
+    const int64_t nv = T.nv, ne = T.n_edges, n_rl = T.n_rl, n_lines = T.n_lines;
+    const int nb = T.nb, nchrom = h->nchrom;
+    const size_t NV = (size_t)(nv ? nv : 1), NE = (size_t)(ne ? ne : 1), NRL = NV * 2 * (size_t)nb, NR = (size_t)(n_rl ? n_rl : 1);
+    const int32_t *cis = T.stats, *trans = T.stats + ne, *sup = T.stats + 2 * ne, *tot = T.stats + 3 * ne, *cfgv = T.stats + 4 * ne;
+    Sections sec(ctx);
+    sec.begin();
+    // ---- per-pass uploads
+    if (int s = up(ctx, h->slot_pv, slot_pv, (size_t)PS_SLOTS * 8)) return s;
+    if (int s = up(ctx, h->pv_off, slot_txt_off, (size_t)(PS_SLOTS + 1) * 4)) return s;
+    if (int s = up(ctx, h->pv_txt, slot_txt, (size_t)slot_txt_off[PS_SLOTS])) return s;
+    if (int s = up(ctx, h->bam_off, o->bam_name_off, (size_t)(nb + 1) * 4)) return s;
+    if (int s = up(ctx, h->bam_txt, o->bam_names, (size_t)o->bam_name_off[nb])) return s;
+    if (o->bam_excluded) { if (int s = up(ctx, h->bam_excl, o->bam_excluded, (size_t)nb)) return s; }
+    if (int s = up(ctx, h->sh_lo, o->shard_line_lo, (size_t)o->n_shards * 8)) return s;
+    if (int s = up(ctx, h->sh_hi, o->shard_line_hi, (size_t)o->n_shards * 8)) return s;
+    if (int s = up(ctx, h->sh_bam, o->shard_bam, (size_t)o->n_shards * 4)) return s;
+    // ---- pruning (:686-700) + components
+#define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, h->buf, (bytes))) return s_; } while (0)
+    RSV(keep, NE); RSV(e_slot, NE * 4); RSV(deg, NV * 4); RSV(parent, NV * 4); RSV(label, NV * 4);
+    RSV(cnt64, 64); RSV(cnt32, 64);
+    const size_t n_cc = (size_t)nchrom * 3 + (size_t)nb * nchrom;          // uint32 counters per chromosome, then uint64 cfg rows per chromosome
+    RSV(chrom_cnt, n_cc * 4 + 8 + (size_t)nchrom * 8);
+    uint32_t *cc_conn = P<uint32_t>(h->chrom_cnt), *cc_blocks = cc_conn + nchrom, *cc_blkvars = cc_blocks + nchrom, *cc_keys = cc_blkvars + nchrom;
+    unsigned long long *cc_cfg = (unsigned long long *)((char *)h->chrom_cnt.p + ((n_cc * 4 + 7) & ~(size_t)7));
+    PHZ_HIP(ctx, hipMemsetAsync(h->chrom_cnt.p, 0, h->chrom_cnt.cap, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->deg.p, 0, NV * 4, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->cnt64.p, 0, 64, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->cnt32.p, 0, 64, sm));
+    unsigned long long *cnt64 = P<unsigned long long>(h->cnt64);
+    uint32_t *cnt32 = P<uint32_t>(h->cnt32);
+    if (ne) hipLaunchKernelGGL(k_keep, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, sup, tot, (const unsigned long long *)h->hkeys.p,
+                               (const double *)h->slot_pv.p, o->cc_threshold, P<uint8_t>(h->keep), P<uint32_t>(h->e_slot), P<uint32_t>(h->deg), (const int32_t *)T.ea,
+                               (const int32_t *)T.eb, cnt64);
+    if (nv) hipLaunchKernelGGL(k_uf_init, dim3(nblk(nv)), dim3(256), 0, sm, P<int32_t>(h->parent), nv);
+    if (ne) hipLaunchKernelGGL(k_uf_hook, dim3(nblk(ne)), dim3(256), 0, sm, P<int32_t>(h->parent), (const int32_t *)T.ea, (const int32_t *)T.eb, (const uint8_t *)h->keep.p, ne);
+    if (nv) hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(nv)), dim3(256), 0, sm, P<int32_t>(h->parent), P<int32_t>(h->label), nv);
+    // ---- sizes of the compacted lists: members, components, kept pairs, first-appearance keys
+    RSV(f_a, std::max(NV, NE) * 4); RSV(f_b, NV * 4); RSV(f_c, NE * 4); RSV(f_d, NV * 4);
+    RSV(mem_pos, (NV + 1) * 4); RSV(cid, (NV + 1) * 4); RSV(kpos, (NE + 1) * 4); RSV(keypos, (NV + 1) * 4);
+    if (nv) hipLaunchKernelGGL(k_flag_members, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->deg.p, (const int32_t *)h->label.p, P<uint32_t>(h->f_a), P<uint32_t>(h->f_b));
+    if (ne) hipLaunchKernelGGL(k_flag_u8, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)h->keep.p, P<uint32_t>(h->f_c));
+    if (nv) hipLaunchKernelGGL(k_flag_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, P<uint32_t>(h->f_d));
+    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_a), P<uint32_t>(h->mem_pos), nv, h->scan_tmp)) return s;
+    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_b), P<uint32_t>(h->cid), nv, h->scan_tmp)) return s;
+    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_c), P<uint32_t>(h->kpos), ne, h->scan_tmp)) return s;
+    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_d), P<uint32_t>(h->keypos), nv, h->scan_tmp)) return s;
+    PHZ_HIP(ctx, hipGetLastError());
+    uint32_t h_n[4] = {0, 0, 0, 0}; unsigned long long h_c64[8] = {0};
+    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[0], P<uint32_t>(h->mem_pos) + nv, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[1], P<uint32_t>(h->cid) + nv, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[2], P<uint32_t>(h->kpos) + ne, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[3], P<uint32_t>(h->keypos) + nv, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(h_c64, cnt64, 16, hipMemcpyDeviceToHost, sm));
+    if (int s = sec.wait()) return s;
+    const int64_t nmem = h_n[0], ncomp = h_n[1], nkeep = h_n[2], nkeys = h_n[3], n_linked = (int64_t)h_c64[0];
+    res->dropped = (int64_t)h_c64[1];
+    sec.begin();
+    // ---- ordering stage: rank index of every variant, pair order, members by component, component order, kept pairs by component, keys
+    const int bv = bits_for((uint64_t)(nv > 1 ? nv - 1 : 1)), bl = bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1));
+    const size_t NS = std::max(NV, NE);
+    RSV(k64a, NS * 8); RSV(k64b, NS * 8); RSV(k32a, NS * 4); RSV(k32b, NS * 4); RSV(v32a, NS * 4); RSV(v32b, NS * 4);
+    RSV(ridx, NV * 4); RSV(va, NE * 4); RSV(vb, NE * 4); RSV(eorder, NE * 4);
+    RSV(mem_s, (size_t)(nmem + 1) * 4); RSV(cstart, (size_t)(ncomp + 2) * 4); RSV(corder, (size_t)(ncomp + 1) * 4); RSV(ekeep, (size_t)(nkeep + 1) * 4);
+    RSV(estart, (size_t)(ncomp + 2) * 4); RSV(key_g, (size_t)(nkeys + 1) * 4);
+    if (nv) {
+        hipLaunchKernelGGL(k_iota_rank, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
+        const int rg[2][2] = {{0, bl}, {32, 32 + bl}};
+        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nv, rg, 2, P<uint32_t>(h->k32a), nullptr)) return s;      // k32a: variants in rank order
+        hipLaunchKernelGGL(k_invert, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->k32a.p, P<uint32_t>(h->ridx));
+    }
+    if (ne) {
+        hipLaunchKernelGGL(k_edge_keys, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, (const int32_t *)T.ea, (const int32_t *)T.eb,
+                           (const uint32_t *)h->ridx.p, P<int32_t>(h->va), P<int32_t>(h->vb), P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
+        const int rg[2][2] = {{0, bv}, {32, 32 + bv + 1}};
+        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, ne, rg, 2, P<uint32_t>(h->eorder), nullptr)) return s;
+        if (n_linked) hipLaunchKernelGGL(k_conn_chrom, dim3(nblk(n_linked)), dim3(256), 0, sm, n_linked, (const uint32_t *)h->eorder.p, (const int32_t *)h->va.p,
+                                         (const uint16_t *)h->d_vchrom.p, cc_conn);
+    }
+    if (nmem) {
+        hipLaunchKernelGGL(k_compact_members, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->deg.p, (const uint32_t *)h->mem_pos.p, (const int32_t *)h->label.p,
+                           P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
+        const int rg[1][2] = {{0, bv}};
+        if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nmem, rg, 1, P<uint32_t>(h->mem_s), P<uint32_t>(h->f_a))) return s;         // f_a: sorted labels
+        hipLaunchKernelGGL(k_group_starts, dim3(nblk(nmem)), dim3(256), 0, sm, nmem, (const uint32_t *)h->f_a.p, (const uint32_t *)h->cid.p, P<uint32_t>(h->cstart));
+        hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, sm, P<uint32_t>(h->cstart) + ncomp, (int64_t)1, (uint32_t)nmem);
+        hipLaunchKernelGGL(k_comp_min, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, (const uint32_t *)h->cstart.p, (const uint32_t *)h->mem_s.p, (const uint32_t *)h->ridx.p,
+                           P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
+        if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, ncomp, rg, 1, P<uint32_t>(h->corder), nullptr)) return s;
+        hipLaunchKernelGGL(k_compact_kept, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)h->keep.p, (const uint32_t *)h->kpos.p, (const int32_t *)T.ea,
+                           (const int32_t *)h->label.p, (const uint32_t *)h->cid.p, P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
+        const int rgc[1][2] = {{0, bits_for((uint64_t)(ncomp > 1 ? ncomp - 1 : 1))}};
+        if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nkeep, rgc, 1, P<uint32_t>(h->ekeep), P<uint32_t>(h->f_a))) return s;        // f_a: component of every kept pair
+        hipLaunchKernelGGL(k_group_starts, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, (const uint32_t *)h->f_a.p, (const uint32_t *)nullptr, P<uint32_t>(h->estart));
+        hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, sm, P<uint32_t>(h->estart) + ncomp, (int64_t)1, (uint32_t)nkeep);
+    }
+    if (nkeys) {
+        ShardTab ST; ST.lo = (const long long *)h->sh_lo.p; ST.hi = (const long long *)h->sh_hi.p; ST.bam = (const int32_t *)h->sh_bam.p; ST.n = o->n_shards;
+        hipLaunchKernelGGL(k_compact_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST, (const uint16_t *)h->d_vchrom.p,
+                           nchrom, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a), cc_keys);
+        const int rg[2][2] = {{0, bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1))}, {32, 32 + (nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0)}};
+        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nkeys, rg, 2, P<uint32_t>(h->key_g), nullptr)) return s;
+    }
+    // ---- block phasing
+    {
+        int64_t ncx = 0, nex = 0;
+        if (int s = phase_all(ctx, sec, h->cstart, h->mem_s, h->estart, h->ekeep, T.ea, T.eb, cfgv, ncomp, nmem, nkeep, ne, o->max_block_size, h->alle_of, h->sub_of, h->nsub,
+                              h->complex_list, h->exc_list, cnt32, &ncx, &nex)) return s;
+        res->n_complex = ncx; res->n_exceptions = nex;
+    }
+    // ---- blocks in block order; per-block statistics
+    const size_t NBK = (size_t)(nmem / 2 + 2);
+    RSV(nsub_o, (size_t)(ncomp + 1) * 4); RSV(blk_base, (size_t)(ncomp + 2) * 4);
+    RSV(blk_mstart, NBK * 4); RSV(blk_len, NBK * 4); RSV(blk_of, NV * 4); RSV(v_alle, NV); RSV(blk_sup, NBK * 4); RSV(blk_tot, NBK * 4);
+    RSV(conc, NBK); RSV(cormode, NBK); RSV(statkind, NBK); RSV(statidx, NBK * 4); RSV(maxmaf, NBK * 4); RSV(stat, NBK * 8); RSV(cfg_rows, NBK * 8);
+    RSV(cfg_base, (NBK + 1) * 8); RSV(blk_voff, (NBK + 1) * 4);
+    PHZ_HIP(ctx, hipMemsetAsync(h->blk_of.p, 0xff, NV * 4, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->v_alle.p, 0, NV, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->blk_sup.p, 0, NBK * 4, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->blk_tot.p, 0, NBK * 4, sm));
+    int64_t nblocks = 0;
+    unsigned long long h_cfg_total = 0;
+    std::vector<uint32_t> h_cc(n_cc, 0u); std::vector<unsigned long long> h_cfgc((size_t)nchrom, 0ull);
+    if (ncomp) {
+        hipLaunchKernelGGL(k_gather_nsub, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, (const uint32_t *)h->corder.p, (const uint32_t *)h->nsub.p, P<uint32_t>(h->nsub_o));
+        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->nsub_o), P<uint32_t>(h->blk_base), ncomp, h->scan_tmp)) return s;
+        BK bk; bk.corder = P<uint32_t>(h->corder); bk.blk_base = P<uint32_t>(h->blk_base); bk.cstart = P<uint32_t>(h->cstart); bk.mem_s = P<uint32_t>(h->mem_s);
+        bk.sub_of = P<int16_t>(h->sub_of); bk.alle_of = P<uint8_t>(h->alle_of); bk.blk_mstart = P<uint32_t>(h->blk_mstart); bk.blk_len = P<uint32_t>(h->blk_len);
+        bk.blk_of = P<int32_t>(h->blk_of); bk.v_alle = P<uint8_t>(h->v_alle); bk.vchrom = P<uint16_t>(h->d_vchrom); bk.chrom_blocks = cc_blocks; bk.chrom_blkvars = cc_blkvars;
+        bk.chrom_cfgrows = cc_cfg; bk.counters = cnt64;
+        hipLaunchKernelGGL(k_blocks, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, bk);
+        if (nkeep) hipLaunchKernelGGL(k_blk_edges, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, (const uint32_t *)h->ekeep.p, (const int32_t *)T.ea, (const int32_t *)T.eb, cfgv,
+                                      (const int32_t *)h->blk_of.p, (const uint8_t *)h->v_alle.p, P<uint32_t>(h->blk_sup), P<uint32_t>(h->blk_tot));
+        uint32_t nb32 = 0;
+        PHZ_HIP(ctx, hipGetLastError());
+        PHZ_HIP(ctx, hipMemcpyAsync(&nb32, P<uint32_t>(h->blk_base) + ncomp, 4, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(h_c64, cnt64, 32, hipMemcpyDeviceToHost, sm));
+        if (int s = sec.wait()) return s;
+        sec.begin();
+        nblocks = nb32;
+        if ((int64_t)h_c64[3] > STAT_N) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: a haplotype block of more than 512 variants is formatted by the host stage");
+    }
+    res->phased = (int64_t)h_c64[2];
+    if (nblocks) {
+        BS bs; bs.mem_s = P<uint32_t>(h->mem_s); bs.blk_mstart = P<uint32_t>(h->blk_mstart); bs.blk_len = P<uint32_t>(h->blk_len); bs.v_alle = P<uint8_t>(h->v_alle);
+        bs.phase_idx = P<int8_t>(h->d_phase); bs.mafv = P<double>(h->d_maf); bs.conc = P<uint8_t>(h->conc); bs.cormode = P<uint8_t>(h->cormode); bs.statkind = P<uint8_t>(h->statkind);
+        bs.statidx = P<uint32_t>(h->statidx); bs.maxmaf = P<int32_t>(h->maxmaf); bs.stat = P<double>(h->stat); bs.cfg_rows = P<unsigned long long>(h->cfg_rows);
+        hipLaunchKernelGGL(k_blk_stats, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, bs);
+    }
+    if (int s = gscan_excl<unsigned long long, unsigned long long>(ctx, P<unsigned long long>(h->cfg_rows), P<unsigned long long>(h->cfg_base), nblocks, h->scan_tmp)) return s;
+    // ---- read sets of the haplotypes: labels + distinct counts
+    const bool need_all = nb > 1 || h->has_black;
+    RSV(labels, NR * 4); RSV(seg_ns, (size_t)(nblocks + 1) * 2 * nb * 4); RSV(big_list, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4);
+    if (need_all) RSV(blk_cnt, (size_t)(nblocks + 1) * 2 * 4);
+    if (nb > 1) RSV(single_n, NRL * 4);
+    if (h->pool.cap == 0) RSV(pool, (size_t)12 << 20);
+    PHZ_HIP(ctx, hipMemsetAsync(h->labels.p, 0, NR * 4, sm));
+    SG sg; sg.nb = nb; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
+    sg.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.labels = P<uint32_t>(h->labels);
+    sg.big_list = P<uint32_t>(h->big_list); sg.counters = cnt32 + 4;
+    for (int attempt = 0;; attempt++) {
+        sg.pool = P<uint32_t>(h->pool); sg.pool_cap = (uint32_t)std::min<size_t>(h->pool.cap / 4, 0xFFFFFFF0u);
+        uint32_t h_seg[3] = {0, 0, 0};
+        bool overflow = false;
+        for (int mode = 0; mode < 3; mode++) {
+            if (mode == 1 && !need_all) continue;
+            if (mode == 2 && nb <= 1) continue;
+            sg.nseg = mode == 0 ? nblocks * 2 * nb : (mode == 1 ? nblocks * 2 : (int64_t)NRL);
+            sg.ns = mode == 0 ? P<uint32_t>(h->seg_ns) : (mode == 1 ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->single_n));
+            if (sg.nseg == 0) continue;
+            PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 4, 0, 12, sm));
+            const unsigned g = (unsigned)((sg.nseg + 63) / 64);
+            if (mode == 0) hipLaunchKernelGGL(k_seg_small<0>, dim3(g), dim3(64), 0, sm, sg);
+            else if (mode == 1) hipLaunchKernelGGL(k_seg_small<1>, dim3(g), dim3(64), 0, sm, sg);
+            else hipLaunchKernelGGL(k_seg_small<2>, dim3(g), dim3(64), 0, sm, sg);
+            PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 4, hipMemcpyDeviceToHost, sm));
+            if (int s = sec.wait()) return s;
+            sec.begin();
+            if (h_seg[0]) {
+                if (mode == 0) hipLaunchKernelGGL(k_seg_big<0>, dim3(h_seg[0]), dim3(256), 0, sm, sg);
+                else if (mode == 1) hipLaunchKernelGGL(k_seg_big<1>, dim3(h_seg[0]), dim3(256), 0, sm, sg);
+                else hipLaunchKernelGGL(k_seg_big<2>, dim3(h_seg[0]), dim3(256), 0, sm, sg);
+                PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 12, hipMemcpyDeviceToHost, sm));
+                if (int s = sec.wait()) return s;
+                sec.begin();
+                if (h_seg[2]) { overflow = true; break; }
+            }
+            res->n_big_segments += h_seg[0];
+        }
+        if (!overflow) break;
+        if (attempt == 3) return phz_fail(ctx, PHZ_E_NOMEM, "read-set table pool did not converge");
+        if (int s = phz_reserve(ctx, h->pool, h->pool.cap * 4)) return s;           // a segment of more than SEG_LDS reads needs 24 B per read: grow and redo
+        res->n_big_segments = 0;
+    }
+    const uint32_t *blk_cnt = need_all ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->seg_ns);     // one BAM, nothing blacklisted: the two read sets coincide
+    // ---- text: byte counts -> scan -> write, file by file
+    RSV(tl, NR * 4); RSV(its, (NR + 1) * 4); RSV(piece_dst, NRL * 8);
+    if (n_rl) hipLaunchKernelGGL(k_item_len, dim3(nblk(n_rl)), dim3(256), 0, sm, (const uint32_t *)h->labels.p, n_rl, P<uint32_t>(h->tl));
+    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->tl), P<uint32_t>(h->its), n_rl, h->scan_tmp)) return s;
+    PHZ_HIP(ctx, hipMemsetAsync(h->piece_dst.p, 0xff, NRL * 8, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(&h_cfg_total, P<unsigned long long>(h->cfg_base) + nblocks, 8, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(h_cc.data(), h->chrom_cnt.p, n_cc * 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(h_cfgc.data(), cc_cfg, (size_t)nchrom * 8, hipMemcpyDeviceToHost, sm));
+    if (int s = sec.wait()) return s;
+    sec.begin();
+    if (n_rl * 12 >= (1ll << 32)) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: read-label text beyond 4 GiB");
+    RD D; memset(&D, 0, sizeof(D));
+    D.nv = nv; D.ne = ne; D.nblocks = nblocks; D.n_linked = n_linked; D.n_keys = nkeys; D.nchrom = nchrom; D.nb = nb; D.unique_ids = o->unique_ids; D.unphased_vars = o->unphased_vars;
+    D.vchrom = P<uint16_t>(h->d_vchrom); D.pos = P<int32_t>(h->d_pos);
+    auto pool = [&](int i) { PoolD p; p.off = P<uint32_t>(h->p_off[i]); p.b = P<char>(h->p_txt[i]); return p; };
+    D.uid = pool(0); D.rsid = pool(1); D.alle = pool(2); D.maft = pool(3); D.chromn = pool(4); D.statt = pool(5);
+    D.bamn.off = P<uint32_t>(h->bam_off); D.bamn.b = P<char>(h->bam_txt); D.pvt.off = P<uint32_t>(h->pv_off); D.pvt.b = P<char>(h->pv_txt);
+    D.mafv = P<double>(h->d_maf); D.is_ref = P<uint8_t>(h->d_isref); D.phase_idx = P<int8_t>(h->d_phase); D.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr;
+    D.bam_excl = o->bam_excluded ? P<uint8_t>(h->bam_excl) : nullptr;
+    D.var_count = T.var_count; D.var_distinct = T.var_distinct; D.ea = T.ea; D.eb = T.eb; D.cis = cis; D.trans = trans; D.sup = sup; D.tot = tot; D.cfgv = cfgv;
+    D.rl_start = T.rl_start; D.rl_qid = T.rl_qid; D.rl_list = T.rl_list;
+    D.eorder = P<uint32_t>(h->eorder); D.va = P<int32_t>(h->va); D.vb = P<int32_t>(h->vb); D.e_slot = P<uint32_t>(h->e_slot); D.key_g = P<uint32_t>(h->key_g);
+    D.mem_s = P<uint32_t>(h->mem_s); D.blk_mstart = P<uint32_t>(h->blk_mstart); D.blk_len = P<uint32_t>(h->blk_len); D.blk_of = P<int32_t>(h->blk_of); D.v_alle = P<uint8_t>(h->v_alle);
+    D.blk_sup = P<uint32_t>(h->blk_sup); D.blk_tot = P<uint32_t>(h->blk_tot); D.blk_cnt = blk_cnt; D.seg_ns = P<uint32_t>(h->seg_ns); D.single_n = nb > 1 ? P<uint32_t>(h->single_n) : nullptr;
+    D.blk_conc = P<uint8_t>(h->conc); D.blk_cormode = P<uint8_t>(h->cormode); D.blk_statkind = P<uint8_t>(h->statkind); D.blk_statidx = P<uint32_t>(h->statidx);
+    D.blk_maxmaf = P<int32_t>(h->maxmaf); D.its = P<uint32_t>(h->its); D.labels = P<uint32_t>(h->labels); D.piece_dst = P<unsigned long long>(h->piece_dst);
+    D.cfg_base = P<unsigned long long>(h->cfg_base);
+    const int64_t rows[PHZ_TXT_COUNT] = {n_linked, nblocks, nblocks * nb, (int64_t)h_cfg_total, nkeys, nkeys * nb, nkeys};
+    int64_t max_rows = 1;
+    for (int f = 0; f < PHZ_TXT_COUNT; f++) max_rows = std::max(max_rows, rows[f]);
+    RSV(rowlen, (size_t)max_rows * 4);
+    // per-file segment tables: rows per chromosome (per BAM x chromosome for the key files), prefix-summed on the device into byte offsets
+    const int nseg[PHZ_TXT_COUNT] = {nchrom, nchrom, nchrom, nchrom, nb * nchrom, nb * nchrom, nb * nchrom};
+    uint32_t *d_nb = cnt32 + 8;
+    hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, sm, d_nb, (int64_t)1, (uint32_t)nb);
+    for (int f = 0; f < PHZ_TXT_COUNT; f++) {
+        RSV(off[f], (size_t)(rows[f] + 1) * 8); RSV(seg_off_d[f], (size_t)(nseg[f] + 1) * 8);
+        const unsigned g = nblk(rows[f]);
+        uint32_t *len = P<uint32_t>(h->rowlen);
+        if (rows[f]) switch (f) {
+            case PHZ_TXT_CONN: hipLaunchKernelGGL(k_row_len<RowConn>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_row_len<RowHap>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_row_len<RowAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_row_len<RowCfg>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+            case PHZ_TXT_ALLELIC: hipLaunchKernelGGL(k_row_len<RowAllelic>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_row_len<RowSingleAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+            default: hipLaunchKernelGGL(k_row_len<RowSingleHap>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+        }
+        if (f == PHZ_TXT_ALLELIC && rows[f]) hipLaunchKernelGGL(k_count_nonzero, dim3(g), dim3(256), 0, sm, (const uint32_t *)len, rows[f], cnt64 + 4);
+        if (int s = gscan_excl<uint32_t, unsigned long long>(ctx, len, P<unsigned long long>(h->off[f]), rows[f], h->scan_tmp)) return s;
+        unsigned long long *so = P<unsigned long long>(h->seg_off_d[f]);
+        const unsigned long long *of = P<unsigned long long>(h->off[f]);
+        switch (f) {
+            case PHZ_TXT_CONN: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_conn, (const uint32_t *)nullptr, nseg[f], of, so); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)nullptr, nseg[f], of, so); break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)d_nb, nseg[f], of, so); break;
+            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_seg_offsets64, dim3(1), dim3(1), 0, sm, (const unsigned long long *)cc_cfg, nseg[f], of, so); break;
+            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)d_nb, nseg[f], of, so); break;
+            default: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)nullptr, nseg[f], of, so); break;
+        }
+    }
+    PHZ_HIP(ctx, hipGetLastError());
+    std::vector<unsigned long long> h_so[PHZ_TXT_COUNT];
+    PHZ_HIP(ctx, hipMemcpyAsync(&h_c64[4], cnt64 + 4, 8, hipMemcpyDeviceToHost, sm));
+    for (int f = 0; f < PHZ_TXT_COUNT; f++) {
+        h_so[f].assign((size_t)nseg[f] + 1, 0ull);
+        PHZ_HIP(ctx, hipMemcpyAsync(h_so[f].data(), h->seg_off_d[f].p, h_so[f].size() * 8, hipMemcpyDeviceToHost, sm));
+    }
+    if (int s = sec.wait()) return s;
+    sec.begin();
+    for (int f = 0; f < PHZ_TXT_COUNT; f++) {
+        h->bytes[f] = (int64_t)h_so[f].back();
+        h->seg_off[f].assign(h_so[f].begin(), h_so[f].end());
+        res->bytes[f] = h->bytes[f]; res->seg_off[f] = h->seg_off[f].data();
+        RSV(text[f], (size_t)h->bytes[f] + 16);
+        const unsigned g = nblk(rows[f]);
+        const unsigned long long *of = P<unsigned long long>(h->off[f]);
+        char *out = P<char>(h->text[f]);
+        if (rows[f]) switch (f) {
+            case PHZ_TXT_CONN: hipLaunchKernelGGL(k_row_write<RowConn>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_row_write<RowHap>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_row_write<RowAse>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_row_write<RowCfg>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_ALLELIC: hipLaunchKernelGGL(k_row_write<RowAllelic>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_row_write<RowSingleAse>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+            default: hipLaunchKernelGGL(k_row_write<RowSingleHap>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+        }
+        if (f == PHZ_TXT_ASE && n_rl && rows[f]) hipLaunchKernelGGL(k_label_write, dim3(nblk(n_rl)), dim3(256), 0, sm, D, n_rl, out);
+    }
+    // ---- per-block arrays for write_vcf
+    h->have_vcf = false;
+    h->n_blocks = nblocks; h->n_blk_vars = res->phased;
+    if (o->want_vcf && nblocks) {
+        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->blk_len), P<uint32_t>(h->blk_voff), nblocks, h->scan_tmp)) return s;
+        RSV(o_var, (size_t)(res->phased + 1) * 4); RSV(o_maxmaf, (size_t)(nblocks + 1) * 4); RSV(o_hap, (size_t)(res->phased + 1)); RSV(o_cor, (size_t)(res->phased + 1) * 2);
+        VB vbk; vbk.mem_s = P<uint32_t>(h->mem_s); vbk.blk_mstart = P<uint32_t>(h->blk_mstart); vbk.blk_len = P<uint32_t>(h->blk_len); vbk.blk_voff = P<uint32_t>(h->blk_voff);
+        vbk.v_alle = P<uint8_t>(h->v_alle); vbk.cormode = P<uint8_t>(h->cormode); vbk.phase_idx = P<int8_t>(h->d_phase); vbk.maxmaf = P<int32_t>(h->maxmaf);
+        vbk.vchrom = P<uint16_t>(h->d_vchrom); vbk.chrom_v0 = (const long long *)h->d_chrom_v0.p; vbk.o_var = P<int32_t>(h->o_var); vbk.o_maxmaf = P<int32_t>(h->o_maxmaf);
+        vbk.o_hap = P<uint8_t>(h->o_hap); vbk.o_cor = P<int8_t>(h->o_cor);
+        hipLaunchKernelGGL(k_vcf_blocks, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, vbk);
+        h->have_vcf = true;
+    }
+    PHZ_HIP(ctx, hipGetLastError());
+    if (int s = sec.wait()) return s;
+#undef RSV
+    h->chrom_blocks.assign((size_t)nchrom, 0); h->chrom_blk_vars.assign((size_t)nchrom, 0);
+    for (int c = 0; c < nchrom; c++) { h->chrom_blocks[(size_t)c] = h_cc[(size_t)nchrom + c]; h->chrom_blk_vars[(size_t)c] = h_cc[(size_t)2 * nchrom + c]; }
+    res->chrom_blocks = h->chrom_blocks.data(); res->chrom_blk_vars = h->chrom_blk_vars.data();
+    res->n_blocks = nblocks; res->n_blk_vars = res->phased; res->n_components = ncomp; res->n_linked = n_linked;
+    res->allelic_rows = (int64_t)h_c64[4];
+    res->gpu_ms = sec.ms;
+    ctx->last_ms[PHZ_T_ROWS] = (float)sec.ms; ctx->total_ms[PHZ_T_ROWS] += sec.ms; ctx->launches[PHZ_T_ROWS]++;
+    return PHZ_OK;
+}
+
+// copy one finished text (PHZ_TXT_*) to host memory (page-locked memory gives the full PCIe rate)
+extern "C" int phz_rowsdev_fetch_text(phz_ctx *ctx, phz_rowsdev *h, int which, void *dst, int64_t bytes) {
+    if (!ctx || !h || which < 0 || which >= PHZ_TXT_COUNT || bytes != h->bytes[which] || (!dst && bytes)) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) PHZ_HIP(ctx, hipMemcpyAsync(dst, h->text[which].p, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PHZ_OK;
+}
+
+extern "C" const void *phz_rowsdev_text_ptr(phz_rowsdev *h, int which) {
+    return (h && which >= 0 && which < PHZ_TXT_COUNT) ? h->text[which].p : nullptr;
+}
+
+// per-block arrays of the last run (want_vcf): block order = file order; variant indices are chromosome-local
+extern "C" int phz_rowsdev_fetch_blocks(phz_ctx *ctx, phz_rowsdev *h, int32_t *blk_size, int32_t *blk_var, uint8_t *blk_hap, int8_t *blk_cor, double *blk_stat,
+                                        uint8_t *blk_stat_int, int32_t *blk_maxmaf) {
+    if (!ctx || !h || !h->have_vcf) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nbk = (size_t)h->n_blocks, nvr = (size_t)h->n_blk_vars;
+    hipStream_t sm = ctx->stream;
+    std::vector<uint8_t> kind(nbk);
+    if (blk_size) PHZ_HIP(ctx, hipMemcpyAsync(blk_size, h->blk_len.p, nbk * 4, hipMemcpyDeviceToHost, sm));
+    if (blk_var) PHZ_HIP(ctx, hipMemcpyAsync(blk_var, h->o_var.p, nvr * 4, hipMemcpyDeviceToHost, sm));
+    if (blk_hap) PHZ_HIP(ctx, hipMemcpyAsync(blk_hap, h->o_hap.p, nvr, hipMemcpyDeviceToHost, sm));
+    if (blk_cor) PHZ_HIP(ctx, hipMemcpyAsync(blk_cor, h->o_cor.p, nvr * 2, hipMemcpyDeviceToHost, sm));
+    if (blk_stat) PHZ_HIP(ctx, hipMemcpyAsync(blk_stat, h->stat.p, nbk * 8, hipMemcpyDeviceToHost, sm));
+    if (blk_maxmaf) PHZ_HIP(ctx, hipMemcpyAsync(blk_maxmaf, h->o_maxmaf.p, nbk * 4, hipMemcpyDeviceToHost, sm));
+    if (blk_stat_int) PHZ_HIP(ctx, hipMemcpyAsync(kind.data(), h->statkind.p, nbk, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    if (blk_stat_int) for (size_t b = 0; b < nbk; b++) blk_stat_int[b] = kind[b] == 1 ? 1 : 0;
+    return PHZ_OK;
+}
+
+// phase_v3 (phaser/phaser.py:2107-2170, the worker of `parallelize(phase_v3, ...)` at :808) for a batch of connected components on the
+// GPU.  Component c holds the position-sorted variants [comp_start[c], comp_start[c+1]) and the pairs [pair_start[c], pair_start[c+1]);
+// pair_i / pair_j are LOCAL variant indices inside the component, pair_cfg 0 same configuration / 1 opposite / -1 tie.  Outputs per
+// variant: sub_of = ordinal of its final block inside the component (-1: in none), alle_of = its allele on haplotype A; n_sub per component.
+extern "C" int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t *comp_start, const uint32_t *pair_start, const int32_t *pair_i, const int32_t *pair_j,
+                                    const int8_t *pair_cfg, int32_t max_block_size, int16_t *sub_of, uint8_t *alle_of, uint32_t *n_sub) {
+    if (!ctx || n_comp < 0 || (n_comp && (!comp_start || !pair_start || !sub_of || !alle_of || !n_sub))) return PHZ_E_ARG;
+    if (!n_comp) return PHZ_OK;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t nmem = comp_start[n_comp], ne = pair_start[n_comp];
+    if (ne && (!pair_i || !pair_j || !pair_cfg)) return PHZ_E_ARG;
+    std::vector<uint32_t> mem((size_t)nmem + 1), ek((size_t)ne + 1);
+    std::vector<int32_t> ea((size_t)ne + 1), eb((size_t)ne + 1), cf((size_t)ne + 1);
+    for (int64_t t = 0; t < nmem; t++) mem[(size_t)t] = (uint32_t)t;
+    for (int64_t c = 0; c < n_comp; c++) {
+        if (comp_start[c + 1] <= comp_start[c] || pair_start[c + 1] < pair_start[c]) return phz_fail(ctx, PHZ_E_ARG, "phz_phase_components: empty component or offsets not ascending");
+        const int64_t n = (int64_t)comp_start[c + 1] - comp_start[c];
+        for (uint32_t e = pair_start[c]; e < pair_start[c + 1]; e++) {
+            if (pair_i[e] < 0 || pair_j[e] < 0 || pair_i[e] >= n || pair_j[e] >= n || pair_i[e] == pair_j[e]) return phz_fail(ctx, PHZ_E_ARG, "phz_phase_components: pair outside its component");
+            ek[e] = e; ea[e] = (int32_t)(comp_start[c] + (uint32_t)pair_i[e]); eb[e] = (int32_t)(comp_start[c] + (uint32_t)pair_j[e]); cf[e] = pair_cfg[e];
+        }
+    }
+    enum { B_CS, B_MEM, B_ES, B_EK, B_EA, B_EB, B_CF, B_CNT, B_AL, B_SUB, B_NSUB, B_CX, B_EX, B_N };
+    DevBuf d[B_N];
+    int st = PHZ_OK;
+    auto fin = [&](int code) { for (DevBuf &b : d) if (b.p) (void)hipFree(b.p); return code; };
+    auto U = [&](DevBuf &b, const void *src, size_t bytes) { if (st == PHZ_OK) st = up(ctx, b, src, bytes); };
+    U(d[B_CS], comp_start, (size_t)(n_comp + 1) * 4); U(d[B_MEM], mem.data(), (size_t)nmem * 4); U(d[B_ES], pair_start, (size_t)(n_comp + 1) * 4);
+    U(d[B_EK], ek.data(), (size_t)ne * 4); U(d[B_EA], ea.data(), (size_t)ne * 4); U(d[B_EB], eb.data(), (size_t)ne * 4); U(d[B_CF], cf.data(), (size_t)ne * 4);
+    if (st == PHZ_OK) st = phz_reserve(ctx, d[B_CNT], 64);
+    if (st != PHZ_OK) return fin(st);
+    Sections sec(ctx);
+    sec.begin();
+    int64_t ncx = 0, nex = 0;
+    st = phase_all(ctx, sec, d[B_CS], d[B_MEM], d[B_ES], d[B_EK], P<int32_t>(d[B_EA]), P<int32_t>(d[B_EB]), P<int32_t>(d[B_CF]), n_comp, nmem, ne, ne, max_block_size,
+                   d[B_AL], d[B_SUB], d[B_NSUB], d[B_CX], d[B_EX], P<uint32_t>(d[B_CNT]), &ncx, &nex);
+    if (st != PHZ_OK) return fin(st);
+    hipError_t e = hipMemcpyAsync(sub_of, d[B_SUB].p, (size_t)nmem * 2, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(alle_of, d[B_AL].p, (size_t)nmem, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(n_sub, d[B_NSUB].p, (size_t)n_comp * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fin(phz_fail(ctx, PHZ_E_HIP, "phz_phase_components", e));
+    ctx->last_ms[PHZ_T_ROWS] = (float)sec.ms;
+    return fin(PHZ_OK);
+}

@@ -1,0 +1,161 @@
+// Device-wide primitives written for this library (no rocPRIM / hipCUB): a generic exclusive scan and a stable LSD radix sort of
+// (key, value) pairs.  Header-only: every translation unit that needs them gets its own copy of the kernels.
+//
+// Radix sort: 8 bits per pass over the significant bits only.  One wave per tile of 1024 keys (16 rows of 64): the stable rank of a
+// key inside its row comes from eight wave ballots (lanes holding the same digit), the running per-digit offsets of the tile live
+// in LDS, so a pass is three launches: per-tile digit histograms, one scan over the [digit][tile] table, scatter.
+#pragma once
+#include "phz_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ exclusive scan TI -> TO
+// out[i] = sum(in[0..i)), out[n] = total.  Three passes: chunk sums, one-block scan of the sums, chunk-local scan + base.
+constexpr int GS_ITEMS = 16, GS_CHUNK = GS_ITEMS * 256;
+
+template <class T> __device__ __forceinline__ T gs_wave_incl(T x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const T y = __shfl_up(x, d); if (lane >= d) x += y; }
+    return x;
+}
+
+template <class TI, class TO> __global__ __launch_bounds__(256) void k_gs_reduce(const TI *in, int64_t n, TO *partial) {
+    __shared__ TO s[4];
+    const int64_t base = (int64_t)blockIdx.x * GS_CHUNK;
+    TO x = 0;
+#pragma unroll
+    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k * 256 + threadIdx.x; if (i < n) x += (TO)in[i]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <class TO> __global__ __launch_bounds__(1024) void k_gs_partials(TO *partial, int64_t nb, TO *total) {
+    __shared__ TO s_w[16];
+    __shared__ TO s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+        const int64_t i = b0 + tid;
+        const TO v = i < nb ? partial[i] : (TO)0;
+        const TO x = gs_wave_incl(v, lane);
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        TO before = s_carry;
+        for (int w2 = 0; w2 < wave; w2++) before += s_w[w2];
+        if (i < nb) partial[i] = before + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
+}
+
+template <class TI, class TO> __global__ __launch_bounds__(256) void k_gs_apply(const TI *in, TO *out, int64_t n, const TO *partial) {
+    __shared__ TO s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * GS_CHUNK + (int64_t)tid * GS_ITEMS;
+    TO loc[GS_ITEMS];
+    TO sum = 0;
+#pragma unroll
+    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; loc[k] = i < n ? (TO)in[i] : (TO)0; sum += loc[k]; }
+    const TO incl = gs_wave_incl(sum, lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    TO run = partial[blockIdx.x] + incl - sum;
+    for (int w2 = 0; w2 < wave; w2++) run += s_w[w2];
+#pragma unroll
+    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; if (i < n) out[i] = run; run += loc[k]; }
+}
+
+template <class TI, class TO> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out /* [n + 1] */, int64_t n, DevBuf &tmp) {
+    hipStream_t sm = ctx->stream;
+    if (n <= 0) { PHZ_HIP(ctx, hipMemsetAsync(out, 0, sizeof(TO), sm)); return PHZ_OK; }
+    const int64_t nb = (n + GS_CHUNK - 1) / GS_CHUNK;
+    if (int s = phz_reserve(ctx, tmp, (size_t)nb * sizeof(TO) + 16)) return s;
+    TO *partial = (TO *)tmp.p;
+    hipLaunchKernelGGL((k_gs_reduce<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, n, partial);
+    hipLaunchKernelGGL((k_gs_partials<TO>), dim3(1), dim3(1024), 0, sm, partial, nb, out + n);
+    hipLaunchKernelGGL((k_gs_apply<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, out, n, (const TO *)partial);
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LSD radix sort of pairs
+constexpr int RS_ROWS = 16, RS_TILE = 64 * RS_ROWS;
+
+template <class K> __global__ __launch_bounds__(64) void k_rs_hist(const K *keys, int64_t n, int shift, uint32_t *cnt, uint32_t ntile) {
+    __shared__ uint32_t s_h[256];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) s_h[lane + 64 * j] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int64_t i = base + r * 64 + lane;
+        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt[(size_t)(lane + 64 * j) * ntile + blockIdx.x] = s_h[lane + 64 * j];
+}
+
+template <class K, class V> __global__ __launch_bounds__(64) void k_rs_scatter(const K *kin, const V *vin, K *kout, V *vout, int64_t n, int shift,
+                                                                               const uint32_t *off, uint32_t ntile) {
+    __shared__ uint32_t s_off[256];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) s_off[lane + 64 * j] = off[(size_t)(lane + 64 * j) * ntile + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int64_t i = base + r * 64 + lane;
+        const bool valid = i < n;
+        const K k = valid ? kin[i] : (K)0;
+        const uint32_t d = (uint32_t)(k >> shift) & 255u;
+        unsigned long long peers = __ballot(valid ? 1 : 0);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((int)((d >> b) & 1u));
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const int rank = __popcll(peers & below);
+        const uint32_t pos = valid ? s_off[d] + (uint32_t)rank : 0u;
+        __syncthreads();
+        if (valid && rank == 0) s_off[d] += (uint32_t)__popcll(peers);      // the lowest lane of every digit group moves the digit's cursor
+        __syncthreads();
+        if (valid) { kout[pos] = k; vout[pos] = vin[i]; }
+    }
+}
+
+// Sorts n (key, value) pairs by bits [bit_lo, bit_hi) of the key, stable.  Buffers ping-pong between (k0, v0) and (k1, v1); *where says
+// which pair holds the result (0 or 1).  cnt / tmp: scratch.
+template <class K, class V>
+int radix_sort_pairs(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &cnt, DevBuf &tmp, int *where) {
+    *where = 0;
+    if (n <= 1 || bit_hi <= bit_lo) return PHZ_OK;
+    if (n >= (1ll << 32)) return phz_fail(ctx, PHZ_E_ARG, "radix sort of more than 2^32 items");
+    const uint32_t ntile = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    const size_t ncnt = (size_t)256 * ntile;
+    if (int s = phz_reserve(ctx, cnt, (ncnt + 1) * 4)) return s;
+    uint32_t *c = (uint32_t *)cnt.p;
+    K *ka = k0, *kb = k1; V *va = v0, *vb = v1;
+    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+        hipLaunchKernelGGL((k_rs_hist<K>), dim3(ntile), dim3(64), 0, ctx->stream, (const K *)ka, n, shift, c, ntile);
+        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, c, c, (int64_t)ncnt, tmp)) return s;
+        hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(ntile), dim3(64), 0, ctx->stream, (const K *)ka, (const V *)va, kb, vb, n, shift, (const uint32_t *)c, ntile);
+        std::swap(ka, kb); std::swap(va, vb);
+        *where ^= 1;
+    }
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
+
+inline int bits_for(uint64_t max_value) { int b = 1; while (b < 64 && (max_value >> b)) b++; return b; }
+
+}  // namespace

@@ -18,6 +18,7 @@
 #include <cstring>
 #include "phz_internal.h"
 #include "phz_scan.h"
+#include "phz_uf.h"
 #include <rocprim/rocprim.hpp>
 
 namespace {
@@ -441,36 +442,6 @@ __global__ __launch_bounds__(256) void k_noise(const int32_t *var_count, int64_t
     }
 }
 
-// ---- union-find
-__device__ __forceinline__ int uf_find(int32_t *parent, int x) {
-    int p = parent[x];
-    while (p != x) {
-        const int g = parent[p];
-        if (g != p) parent[x] = g;      // path halving (benign race: only ever points closer to the root)
-        x = p; p = g;
-    }
-    return x;
-}
-__global__ __launch_bounds__(256) void k_uf_init(int32_t *parent, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) parent[i] = (int32_t)i;
-}
-__global__ __launch_bounds__(256) void k_uf_hook(int32_t *parent, const int32_t *ea, const int32_t *eb, const uint8_t *keep, int64_t ne) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= ne || (keep && !keep[i])) return;
-    int a = uf_find(parent, ea[i]), b = uf_find(parent, eb[i]);
-    while (a != b) {
-        if (a < b) { const int t = a; a = b; b = t; }      // hook the larger root under the smaller
-        const int old = atomicCAS(&parent[a], a, b);
-        if (old == a) break;
-        a = uf_find(parent, old); b = uf_find(parent, b);
-    }
-}
-__global__ __launch_bounds__(256) void k_uf_flatten(int32_t *parent, int32_t *label, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) label[i] = uf_find(parent, (int)i);
-}
-
 inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 // HIP-event timing of a stage on the ctx stream; stop() waits for the stage and reports HIP errors
@@ -756,7 +727,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;
     T.ea = (int32_t *)R[R_EA].p; T.eb = (int32_t *)R[R_EB].p; T.cells = (int32_t *)R[R_CELLS].p; T.linked = (uint8_t *)R[R_LINKED].p;
     T.cto = (int32_t *)R[R_CTO].p; T.stats = (int32_t *)R[R_STATS].p;
-    T.rl_start = rl_start; T.rl_qid = rl_qid;
+    T.rl_start = rl_start; T.rl_qid = rl_qid; T.rl_list = rl_key2;        // sorted keys = list index of every read-list entry
     sizes->n_lines = total; sizes->n_kept = T.n_kept; sizes->n_edges = ne; sizes->n_read_list = T.n_rl;
     sizes->n_items = (int64_t)h_counters[0]; sizes->pair_events = (int64_t)h_counters[1];
     sizes->noise_match = (int64_t)h_counters[4]; sizes->noise_mismatch = (int64_t)h_counters[5];

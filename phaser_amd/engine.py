@@ -44,6 +44,8 @@ class Config:
         self.include_indels = 0
         self.want_vcf = True           # keep per-block info for write_vcf (vcfout.phased_vcf_text)
         self.host_threads = 1          # threads of the native block phasing / row writer (the reference's --threads)
+        self.device_rows = True        # stages T7-O2 on the GPU (phz_rowsdev_*); the host stage takes what the device stage declines
+        self.fetch_text = True         # copy the finished row text to (page-locked) host memory; False leaves it in HBM (bench)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown option " + k)
@@ -254,27 +256,38 @@ class Engine:
         sz = _lib.phz_tally_sizes()
         self.ctx.check(self.lib.phz_tally(self.ctx.h, arr, len(lines), NV, pa0, pa1, NQ, nb, C.byref(sz), space))
         t1 = _t.perf_counter()
-        ne = int(sz.n_edges); nrl = int(sz.n_read_list)
         G = {"nv": NV, "nb": nb, "var_base": vb, "line_base": line_base, "n_lines": int(sz.n_lines), "n_kept": int(sz.n_kept),
-             "var_count": self._pinned("var_count", NV * 3, np.int32), "var_first": self._pinned("var_first", NV, np.int64),
-             "var_distinct": self._pinned("var_distinct", NV * 3, np.int32), "var_rank": self._pinned("var_rank", NV, np.uint64),
-             "ea": self._pinned("ea", ne, np.int32), "eb": self._pinned("eb", ne, np.int32), "cto": self._pinned("cto", ne * 3, np.int32),
-             "linked": self._pinned("linked", ne, np.uint8), "stats": self._pinned("stats", ne * 5, np.int32), "rl_start": self._pinned("rl_start", NV * 2 * nb + 1, np.uint32),
-             "rl_qid": self._pinned("rl_qid", nrl, np.int32)}
+             "n_edges": int(sz.n_edges), "n_read_list": int(sz.n_read_list), "noise": (int(sz.noise_match), int(sz.noise_mismatch)),
+             "resident": True,          # the results are still in HBM: the device row stage and phz_components use them in place
+             "fetched": False}
+        self.stats["tally_call_s"] = self.stats.get("tally_call_s", 0.0) + t1 - t0
+        return G
+
+    def _fetch_tally(self):
+        """Copy the resident tally results into pinned host arrays (what the HOST row stage and the tools read)."""
+        import time as _t
+        G = self.G
+        if G.get("fetched", True):
+            return
+        t1 = _t.perf_counter()
+        NV = G["nv"]; nb = G["nb"]; ne = G["n_edges"]; nrl = G["n_read_list"]
+        G.update({"var_count": self._pinned("var_count", NV * 3, np.int32), "var_first": self._pinned("var_first", NV, np.int64),
+                  "var_distinct": self._pinned("var_distinct", NV * 3, np.int32), "var_rank": self._pinned("var_rank", NV, np.uint64),
+                  "ea": self._pinned("ea", ne, np.int32), "eb": self._pinned("eb", ne, np.int32), "cto": self._pinned("cto", ne * 3, np.int32),
+                  "linked": self._pinned("linked", ne, np.uint8), "stats": self._pinned("stats", ne * 5, np.int32),
+                  "rl_start": self._pinned("rl_start", NV * 2 * nb + 1, np.uint32), "rl_qid": self._pinned("rl_qid", nrl, np.int32)})
         vp = lambda a: C.c_void_p(a.ctypes.data) if a.size else None
         out = _lib.phz_tally_out(vp(G["var_count"]), vp(G["var_first"]), vp(G["var_distinct"]), vp(G["var_rank"]), None, vp(G["ea"]), vp(G["eb"]),
                                  None, vp(G["linked"]), vp(G["cto"]), vp(G["rl_start"]), vp(G["rl_qid"]), vp(G["stats"]))
         self.ctx.check(self.lib.phz_tally_fetch(self.ctx.h, C.byref(out), _lib.PHZ_HOST))
         G["var_count"] = G["var_count"].reshape(NV, 3); G["var_distinct"] = G["var_distinct"].reshape(NV, 3); G["cto"] = G["cto"].reshape(ne, 3)
         G["stats"] = G["stats"].reshape(5, ne)       # planes: same-configuration, opposite, supporting, total, chosen configuration
-        G["noise"] = (int(sz.noise_match), int(sz.noise_mismatch))
-        G["resident"] = True            # the edge list is still in HBM: phz_components can use it in place
-        self.stats["tally_call_s"] = self.stats.get("tally_call_s", 0.0) + t1 - t0
+        G["fetched"] = True
         self.stats["tally_d2h_s"] = self.stats.get("tally_d2h_s", 0.0) + _t.perf_counter() - t1
-        return G
 
     def chrom_view(self, c: str) -> dict:
         """One chromosome's part of the tally results, local variant indices (views; for tests and tools)."""
+        self._fetch_tally()
         G = self.G; v0 = G["var_base"][c]; nv = len(self.vs.chroms[c])
         lo = int(np.searchsorted(G["ea"], v0, side="left")); hi = int(np.searchsorted(G["ea"], v0 + nv, side="left"))
         vc = G["var_count"][v0:v0 + nv]
@@ -340,6 +353,21 @@ class Engine:
         """Stage C for every owned chromosome: C1 = pair tests, pruning, components, ordering keys (numpy / scipy / GPU, the
         heavy parts once over all chromosomes); C2 = block phasing + row text, all chromosomes through ONE native thread pool."""
         import time as _t
+        from . import rowsdev
+        G = self.G
+        if self.cfg.device_rows and G.get("resident") and getattr(self, "lib", None) is not None and rowsdev.supported(self.cfg):
+            try:
+                t0 = _t.perf_counter()
+                frags = rowsdev.run(self, noise, fetch_text=self.cfg.fetch_text)
+                self.stats["rows_device_s"] = self.stats.get("rows_device_s", 0.0) + _t.perf_counter() - t0
+                self.rows_path = "device"
+                return frags
+            except _lib.PhzError as e:
+                if e.status != _lib.PHZ_E_UNSUPPORTED:
+                    raise
+                self.rows_fallback = str(e)          # the host stage takes the pass (a limit of the device stage, named in the message)
+        self.rows_path = "host"
+        self._fetch_tally()
         t0 = _t.perf_counter()
         frags = self._prepare(noise)
         t1 = _t.perf_counter()

@@ -1,0 +1,204 @@
+"""Glue for the device row stage (phz_rowsdev_* in libphz.so, phaser_amd/csrc/phz_rowsdev.hip): stages T7-O2 of the phasing path on the
+GPU -- pair-test bookkeeping, pruning, components, ordering, block phasing (phase_v3), haplotype read sets and the text of the five
+output files (phaser/phaser.py:686-726, :1861-1882, :2107-2324, :691-695, :737-749, :865-1239) -- on the results phz_tally left in HBM.
+
+The only arithmetic kept on the host is the reference's own third-party call: scipy.stats.binom.cdf (phaser.py:1649), evaluated once per
+DISTINCT (supporting, total) read-count pair the device reports (a few thousand per genome), with the same scalar arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .vcf import sep_pool
+
+
+def _vp(a):
+    if a is None:
+        return None
+    return C.c_void_p(a.ctypes.data) if isinstance(a, np.ndarray) else C.cast(C.c_char_p(a), C.c_void_p)
+
+
+class Tables:
+    """The per-variant tables of one rank's chromosomes in HBM (uploaded once per variant set and chromosome list)."""
+
+    def __init__(self, ctx, vs, chrom_list: List[str], cfg):
+        self.ctx = ctx; self.lib = ctx.lib
+        self.chrom_list = list(chrom_list)
+        cvs = [vs.chroms[c] for c in chrom_list]
+        n = [len(cv) for cv in cvs]
+        self.nv = int(sum(n))
+        v0 = np.zeros(len(cvs) + 1, dtype=np.int64)
+        np.cumsum(n, out=v0[1:])
+        self.chrom_v0 = v0
+
+        def joint(name, per_item=1):
+            offs = []; parts = []; base = 0
+            for cv in cvs:
+                off, b = cv.pools()[name]
+                offs.append(off[:-1].astype(np.int64) + base)
+                parts.append(bytes(b)); base += len(b)
+            if base >= 2 ** 32:
+                raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "string tables beyond 4 GiB")
+            offs.append(np.array([base], dtype=np.int64))
+            return np.ascontiguousarray(np.concatenate(offs).astype(np.uint32)), b"".join(parts) or b"\n"
+
+        cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs).astype(dt)) if xs else np.zeros(0, dt)
+        keep = self._keep = []
+        uid = joint("uid"); rsid = joint("rsid"); alle = joint("allele"); maf = joint("maf")
+        cn = sep_pool(list(chrom_list))
+        pos = cat([cv.pos for cv in cvs], np.int32); mafv = cat([cv.pools()["maf_val"] for cv in cvs], np.float64)
+        is_ref = cat([cv.is_ref for cv in cvs], np.uint8); phase = cat([cv.phase_idx for cv in cvs], np.int8)
+        bl = None
+        marks = []
+        for c, cv in zip(chrom_list, cvs):
+            m = cv.blacklisted if getattr(cv, "blacklisted", None) is not None and len(cv.blacklisted) == len(cv) else np.zeros(len(cv), np.uint8)
+            if cfg.haplo_blacklist:
+                named = np.fromiter((c + "_" + str(int(p)) in cfg.haplo_blacklist for p in cv.pos), dtype=np.uint8, count=len(cv))
+                m = m | named
+            marks.append(m)
+        if marks and any(m.any() for m in marks):
+            bl = cat(marks, np.uint8)
+        keep += [uid, rsid, alle, maf, cn, pos, mafv, is_ref, phase, bl, v0]
+        t = _lib.phz_rowsdev_tables(self.nv, len(cvs), _vp(v0), _vp(cn[0]), _vp(cn[1]), _vp(pos), _vp(uid[0]), _vp(uid[1]), _vp(rsid[0]), _vp(rsid[1]),
+                                    _vp(alle[0]), _vp(alle[1]), _vp(maf[0]), _vp(maf[1]), _vp(mafv), _vp(is_ref), _vp(phase), _vp(bl))
+        h = C.c_void_p()
+        ctx.check(self.lib.phz_rowsdev_create(ctx.h, C.byref(t), C.byref(h)))
+        self.h = h
+        self._keep = []            # the library holds its own copies
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.phz_rowsdev_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def tables_for(eng) -> Tables:
+    """Cached on the variant set: one upload per (context, chromosome list, blacklist)."""
+    cache = eng.vs.__dict__.setdefault("_rowsdev_tables", {})
+    key = (id(eng.ctx), tuple(eng.chrom_list), frozenset(eng.cfg.haplo_blacklist))
+    t = cache.get(key)
+    if t is None:
+        cache.clear()              # one resident copy per variant set is enough (a new chromosome list replaces the old tables)
+        t = cache[key] = Tables(eng.ctx, eng.vs, eng.chrom_list, eng.cfg)
+    return t
+
+
+_PINNED: Dict[str, torch.Tensor] = {}
+
+
+def pinned(name: str, nbytes: int) -> np.ndarray:
+    """uint8 view of a page-locked host buffer kept per name for the life of the process (grown on demand): D2H at the full PCIe rate,
+    and no page-locking cost per pass."""
+    t = _PINNED.get(name)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(1, nbytes + nbytes // 8 + 4096), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        _PINNED[name] = t
+    return t.numpy()[:nbytes]
+
+
+def supported(cfg) -> bool:
+    return cfg.gw_phase_method == 0 and cfg.output_read_ids == 0
+
+
+def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
+    """-> {chrom: fragment} in the format Engine._fragments returns (row text per file as buffers over page-locked host memory, in the
+    reference's order), or raises PhzError(PHZ_E_UNSUPPORTED) when the host stage has to take the pass."""
+    import time as _t
+    from scipy.stats import binom
+    cfg = eng.cfg; ctx = eng.ctx; lib = eng.lib
+    G = eng.G
+    nb = G["nb"]
+    t0 = _t.perf_counter()
+    T = tables_for(eng)
+    t1 = _t.perf_counter()
+    # ---- stage 1: distinct (total, supporting) pairs -> scipy -> value + repr text per slot (phaser.py:1645-1652)
+    keys = np.empty(_lib.PHZ_PAIR_SLOTS, dtype=np.uint64)
+    ctx.check(lib.phz_rowsdev_pair_keys(ctx.h, T.h, _vp(keys)))
+    used = np.flatnonzero(keys != np.uint64(0xFFFFFFFFFFFFFFFF))
+    tot = (keys[used] >> np.uint64(32)).astype(np.int64); sup = (keys[used] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
+    slot_pv = np.ones(_lib.PHZ_PAIR_SLOTS, dtype=np.float64)
+    texts = [""] * _lib.PHZ_PAIR_SLOTS
+    if len(used):
+        pv = binom.cdf(sup, tot, prob)
+        slot_pv[used] = pv
+        for s, x in zip(used.tolist(), pv.tolist()):
+            texts[s] = repr(x)
+    txt_off, txt = sep_pool(texts)
+    t2 = _t.perf_counter()
+    # ---- stage 2
+    bam_off, bam_txt = sep_pool(list(eng.bam_names))
+    ex = None
+    if cfg.haplo_count_bam_exclude:
+        ex = np.zeros(nb, dtype=np.uint8)
+        for b in cfg.haplo_count_bam_exclude:
+            if 0 <= b < nb:
+                ex[b] = 1
+    sh = sorted(((base, base + n, b) for (c, b), (base, n) in G["line_base"].items()))
+    lo = np.array([x[0] for x in sh], dtype=np.int64); hi = np.array([x[1] for x in sh], dtype=np.int64); sb = np.array([x[2] for x in sh], dtype=np.int32)
+    o = _lib.phz_rowsdev_opts(nb, _vp(bam_off), _vp(bam_txt), _vp(ex), len(sh), _vp(lo), _vp(hi), _vp(sb), int(cfg.unique_ids), int(cfg.gw_phase_method),
+                              int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.max_block_size), 1 if cfg.want_vcf else 0, float(cfg.cc_threshold))
+    R = _lib.phz_rowsdev_result()
+    ctx.check(lib.phz_rowsdev_run(ctx.h, T.h, C.byref(o), _vp(slot_pv), _vp(txt_off), _vp(txt), C.byref(R)))
+    t3 = _t.perf_counter()
+    nch = len(eng.chrom_list)
+    frags: Dict[str, dict] = {c: {"chrom": c, "lines": 0, "dropped": 0, "phased": 0, "allelic_rows": 0, "n_blocks": 0, "vcf": None} for c in eng.chrom_list}
+    for name in _lib.PHZ_TXT_NAMES:
+        for c in eng.chrom_list:
+            frags[c][name] = []
+            if name in ("allelic", "single_ase", "single_hap"):
+                frags[c][name + "_bam"] = []
+    total_bytes = 0
+    for f, name in enumerate(_lib.PHZ_TXT_NAMES):
+        nbytes = int(R.bytes[f]); total_bytes += nbytes
+        if not fetch_text:
+            continue
+        buf = pinned("rows_" + name, nbytes)
+        ctx.check(lib.phz_rowsdev_fetch_text(ctx.h, T.h, f, _vp(buf) if nbytes else None, nbytes))
+        mv = memoryview(buf)
+        nseg = nch if f < 4 else nb * nch
+        so = [int(R.seg_off[f][i]) for i in range(nseg + 1)]
+        if f < 4:
+            for ci, c in enumerate(eng.chrom_list):
+                if so[ci + 1] > so[ci]:
+                    frags[c][name].append(mv[so[ci]:so[ci + 1]])
+        else:
+            for b in range(nb):
+                for ci, c in enumerate(eng.chrom_list):
+                    i = b * nch + ci
+                    if so[i + 1] > so[i]:
+                        frags[c][name].append(mv[so[i]:so[i + 1]]); frags[c][name + "_bam"].append(b)
+    if eng.chrom_list:
+        f0 = frags[eng.chrom_list[0]]            # the counts only ever enter sums over chromosomes
+        f0["lines"] = int(G["n_kept"]); f0["dropped"] = int(R.dropped); f0["phased"] = int(R.phased); f0["allelic_rows"] = int(R.allelic_rows)
+    if cfg.want_vcf and int(R.n_blocks) > 0:
+        nbk = int(R.n_blocks); nvr = int(R.n_blk_vars)
+        size = np.empty(nbk, np.int32); var = np.empty(nvr, np.int32); hap = np.empty(nvr, np.uint8); cor = np.empty(2 * nvr, np.int8)
+        stat = np.empty(nbk, np.float64); stat_int = np.empty(nbk, np.uint8); maxmaf = np.empty(nbk, np.int32)
+        ctx.check(lib.phz_rowsdev_fetch_blocks(ctx.h, T.h, _vp(size), _vp(var), _vp(hap), _vp(cor), _vp(stat), _vp(stat_int), _vp(maxmaf)))
+        b0 = v0 = 0
+        for ci, c in enumerate(eng.chrom_list):
+            kb = int(R.chrom_blocks[ci]); kv = int(R.chrom_blk_vars[ci])
+            frags[c]["n_blocks"] = kb
+            if kb:
+                frags[c]["vcf"] = {"size": size[b0:b0 + kb], "var": var[v0:v0 + kv], "hap": hap[v0:v0 + kv], "cor": cor[2 * v0:2 * (v0 + kv)],
+                                   "stat": stat[b0:b0 + kb], "stat_int": stat_int[b0:b0 + kb], "maxmaf": maxmaf[b0:b0 + kb]}
+            b0 += kb; v0 += kv
+    t4 = _t.perf_counter()
+    st = eng.stats
+    for k, v in (("rowsdev_tables_s", t1 - t0), ("rowsdev_pairs_s", t2 - t1), ("rowsdev_run_s", t3 - t2), ("rowsdev_fetch_s", t4 - t3)):
+        st[k] = st.get(k, 0.0) + v
+    st["rowsdev_gpu_ms"] = st.get("rowsdev_gpu_ms", 0.0) + float(R.gpu_ms)
+    st["rowsdev_text_bytes"] = float(total_bytes)
+    for k in ("n_components", "n_complex", "n_exceptions", "n_big_segments", "n_blocks"):
+        st["rowsdev_" + k] = float(getattr(R, k))
+    return frags

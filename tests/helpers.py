@@ -237,3 +237,62 @@ def stub_gpu_stages(eng, saved):
     """Engine whose GPU stages (K_tally, components) answer from a fixture: the host stages run unchanged on CPU."""
     eng._tally_genome = lambda: genome_from_saved(saved, eng.chrom_list, len(eng.bam_names))
     eng._component_labels = lambda keep_all: component_labels_cpu(eng.G, keep_all)
+
+
+# ------------------------------------------------------------------ kernel logic under the host-side HIP emulation (tests/hipemu)
+def emu_library():
+    """ctypes handle of tests/hipemu/_build/libphz_emu.so (built on first use): the translation units of libphz without gfx950
+    intrinsics, compiled by g++ against tests/hipemu/hipemu.h.  TEST INFRASTRUCTURE: the product never loads it."""
+    import importlib.util
+    from phaser_amd import _lib
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
+    spec = importlib.util.spec_from_file_location("build_emu", os.path.join(here, "build_emu.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    lib = ctypes.CDLL(mod.build())
+    for name, (res, args) in _lib.SYMBOLS.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+    return lib
+
+
+class EmuContext:
+    """A phz_ctx of the emulation library with the interface of phaser_amd._lib.Context."""
+
+    def __init__(self, lib=None):
+        from phaser_amd import _lib
+        self.lib = lib or emu_library()
+        h = ctypes.c_void_p()
+        assert self.lib.phz_ctx_create(0, ctypes.byref(h)) == 0
+        self.h = h; self.device = 0; self._lib = _lib
+
+    def check(self, st, allow=()):
+        if st != 0 and st not in allow:
+            raise self._lib.PhzError(st, (self.lib.phz_last_error(self.h) or b"").decode() or self.lib.phz_strerror(st).decode())
+        return st
+
+    def __del__(self):
+        try:
+            self.lib.phz_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+
+def stub_emu_stages(eng, saved):
+    """Engine on an EmuContext: the tally results come from a fixture and are adopted as the ctx's resident tally (phz_tally_import), so
+    that the DEVICE row stage (phz_rowsdev_*) runs on them under the emulation; the host stage stays available as its fallback."""
+    from phaser_amd import _lib
+
+    def tally():
+        G = genome_from_saved(saved, eng.chrom_list, len(eng.bam_names))
+        nv = G["nv"]; nb = G["nb"]
+        rl_list = np.repeat(np.arange(nv * 2 * nb, dtype=np.uint32), np.diff(G["rl_start"].astype(np.int64))).astype(np.uint32)
+        sz = _lib.phz_tally_sizes(G["n_lines"], G["n_kept"], len(G["ea"]), len(G["rl_qid"]), 0, 0, G["noise"][0], G["noise"][1])
+        keep = [np.ascontiguousarray(G[k]) for k in ("var_count", "var_first", "var_distinct", "var_rank", "ea", "eb", "linked", "cto", "rl_start", "rl_qid", "stats")]
+        vp = lambda a: ctypes.c_void_p(a.ctypes.data) if a.size else None
+        out = _lib.phz_tally_out(vp(keep[0]), vp(keep[1]), vp(keep[2]), vp(keep[3]), None, vp(keep[4]), vp(keep[5]), None, vp(keep[6]), vp(keep[7]),
+                                 vp(keep[8]), vp(keep[9]), vp(keep[10]))
+        eng.ctx.check(eng.lib.phz_tally_import(eng.ctx.h, nv, nb, ctypes.byref(sz), ctypes.byref(out), vp(rl_list), _lib.PHZ_HOST))
+        G["resident"] = True; G["fetched"] = True; G["n_edges"] = len(G["ea"]); G["n_read_list"] = len(G["rl_qid"])
+        return G
+    eng._tally_genome = tally
+    eng._component_labels = lambda keep_all: component_labels_cpu(eng.G, keep_all)
