@@ -242,6 +242,7 @@ def main():
 
     # ---- second rate of the metric: phased variants/s over stages T1-O2 on the same call lists
     phasing = None
+    gc.enable()
     if not a.no_phasing:
         vs = pvcf.load_variants("\n".join(synth.vcf_lines([workloads_variants(plan, vsets, p) for p in plan])))
         # host threads of the row writer: four per CPU the container may really use (quota-aware; the phases are short and bursty), shared by the ranks of the node
@@ -249,52 +250,67 @@ def main():
         if os.environ.get("PHZ_BENCH_HOST_THREADS"):
             host_threads = int(os.environ["PHZ_BENCH_HOST_THREADS"])
         calls_now = [Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i in range(len(chroms))]
-        runs = []
-        for rep in range(max(1, a.phasing_passes)):
-            eng = Engine(vs, ["bench"], Config(baseq=a.baseq, host_threads=host_threads, want_vcf=False), mapper=mapper)
-            eng.set_owned(chroms)
-            for i, c in enumerate(chroms):
-                eng.add_mapped(0, c, shards[c], calls_now[i], int(shards[c].qid.max()) + 1)
-            mapper.ctx.reset_timing()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            tp0 = time.perf_counter()
-            eng.close_bam(0)                       # AS histogram per shard + all-reduce + percentile
-            tp1 = time.perf_counter()
-            files = eng.finish(chunks=True)        # K_tally, noise all-reduce, pair tests, components, block phasing, rows, gather
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            tp2 = time.perf_counter()
-            tt = torch.tensor([tp2 - tp0], device=red_dev, dtype=torch.float64)
-            cnt = torch.tensor([float(mapper.ctx.counter(_lib.PHZ_C_LINES)), float(mapper.ctx.counter(_lib.PHZ_C_PAIR_EVENTS)),
-                                float(mapper.ctx.counter(_lib.PHZ_C_ITEMS)), float(mapper.ctx.counter(_lib.PHZ_C_EDGES)),
-                                mapper.ctx.timing(_lib.PHZ_T_TALLY)[1]], device=red_dev, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(cnt)
-            if rank == 0:
-                lines, events, items, edges, tally_ms = [float(x) for x in cnt.tolist()]
-                tally_bytes = 8.0 * lines + 16.0 * events
-                runs.append({"value": eng.phased / float(tt[0]), "unit": "phased variants/s", "phased_variants": eng.phased,
-                             "seconds_per_pass": float(tt[0]), "call_lines_kept": eng.total_lines,
-                             "output_bytes": int(sum(len(x) for v_ in files.values() for x in v_)),
-                             "seconds": {"as_cutoff": tp1 - tp0, "tally_to_rows_and_gather": tp2 - tp1,
-                                         **{k: round(v_, 4) for k, v_ in eng.stats.items()}},
-                             "host_threads": host_threads,
-                             "roofline": {"bound": "hbm", "kernel": "K_tally (all kernels of phz_tally, HIP events on the ctx stream)",
-                                          "achieved": tally_bytes / (tally_ms / 1e3) / 1e9 if tally_ms > 0 else None, "peak": HBM_PEAK_GBS,
-                                          "unit": "GB/s", "frac": tally_bytes / (tally_ms / 1e3) / 1e9 / HBM_PEAK_GBS if tally_ms > 0 else None,
-                                          "traffic": pmc_traffic_tally() if world == 1 else None, "algorithmic_bytes": tally_bytes,
-                                          "model": "8 B x call lines + 16 B x pair events (SURVEY.md 8(d))", "call_lines": lines,
-                                          "pair_events": events, "items": items, "edges": edges, "kernel_ms_sum_over_ranks": tally_ms}})
-            del eng, files
-            pdist.cleanup_spool()          # every rank: the spooled row text of this pass is no longer needed
+        # two series of passes: row text left in HBM (`value`: inputs and outputs resident, like the mapper step) and copied to page-locked
+        # host memory (`d2h_inclusive`: what the CLI pays before it can write the files; PCIe-bound, ~1 GB per genome)
+        series = {"resident": [], "d2h": []}
+        for mode in ("resident", "d2h"):
+            for rep in range(max(1, a.phasing_passes) + 1):          # the first pass of a series sizes buffers: not reported
+                eng = Engine(vs, ["bench"], Config(baseq=a.baseq, host_threads=host_threads, want_vcf=False, fetch_text=(mode == "d2h"),
+                                                   device_rows=os.environ.get("PHZ_BENCH_HOST_ROWS") != "1"), mapper=mapper)
+                eng.set_owned(chroms)
+                for i, c in enumerate(chroms):
+                    eng.add_mapped(0, c, shards[c], calls_now[i], int(shards[c].qid.max()) + 1)
+                mapper.ctx.reset_timing()
+                gc.collect(); gc.disable()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                tp0 = time.perf_counter()
+                eng.close_bam(0)                       # AS histogram per shard + all-reduce + percentile
+                tp1 = time.perf_counter()
+                files = eng.finish(chunks=True)        # K_tally, noise all-reduce, pair tests, components, block phasing, rows, gather
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                tp2 = time.perf_counter()
+                gc.enable()
+                tt = torch.tensor([tp2 - tp0], device=red_dev, dtype=torch.float64)
+                gpu_ms = sum(mapper.ctx.timing(sl)[1] for sl in (_lib.PHZ_T_ASHIST, _lib.PHZ_T_TALLY, _lib.PHZ_T_COMPONENTS, _lib.PHZ_T_ROWS))
+                cnt = torch.tensor([float(mapper.ctx.counter(_lib.PHZ_C_LINES)), float(mapper.ctx.counter(_lib.PHZ_C_PAIR_EVENTS)),
+                                    float(mapper.ctx.counter(_lib.PHZ_C_ITEMS)), float(mapper.ctx.counter(_lib.PHZ_C_EDGES)),
+                                    mapper.ctx.timing(_lib.PHZ_T_TALLY)[1], float(eng.stats.get("rowsdev_text_bytes", 0.0))], device=red_dev, dtype=torch.float64)
+                gm = torch.tensor([gpu_ms], device=red_dev, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(cnt); dist.all_reduce(gm, op=dist.ReduceOp.MAX)
+                if rank == 0 and rep > 0:
+                    lines, events, items, edges, tally_ms, text_bytes = [float(x) for x in cnt.tolist()]
+                    tally_bytes = 8.0 * lines + 16.0 * events
+                    host_bytes = int(sum(len(x) for v_ in files.values() for x in v_))
+                    series[mode].append({"value": eng.phased / float(tt[0]), "unit": "phased variants/s", "phased_variants": eng.phased,
+                                 "seconds_per_pass": float(tt[0]), "call_lines_kept": eng.total_lines, "rows": getattr(eng, "rows_path", "host"),
+                                 "output_bytes": int(text_bytes) if text_bytes else host_bytes,
+                                 "gpu_ms_per_pass_max_rank": float(gm[0]), "gpu_share": float(gm[0]) / 1e3 / float(tt[0]),
+                                 "seconds": {"as_cutoff": tp1 - tp0, "tally_to_rows_and_gather": tp2 - tp1,
+                                             **{k: round(v_, 4) for k, v_ in eng.stats.items() if k.endswith("_s")}},
+                                 "counts": {k: int(v_) for k, v_ in eng.stats.items() if k.startswith("rowsdev_n_")},
+                                 "host_threads": host_threads,
+                                 "roofline": {"bound": "hbm", "kernel": "K_tally (all kernels of phz_tally, HIP events on the ctx stream)",
+                                              "achieved": tally_bytes / (tally_ms / 1e3) / 1e9 if tally_ms > 0 else None, "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": tally_bytes / (tally_ms / 1e3) / 1e9 / HBM_PEAK_GBS if tally_ms > 0 else None,
+                                              "traffic": pmc_traffic_tally() if world == 1 else None, "algorithmic_bytes": tally_bytes,
+                                              "model": "8 B x call lines + 16 B x pair events (SURVEY.md 8(d))", "call_lines": lines,
+                                              "pair_events": events, "items": items, "edges": edges, "kernel_ms_sum_over_ranks": tally_ms}})
+                del eng, files
+                pdist.cleanup_spool()          # every rank: the spooled row text of this pass is no longer needed
         if rank == 0:
-            phasing = dict(max(runs, key=lambda r: r["value"]))
-            phasing["passes"] = [round(r["value"]) for r in runs]
-            phasing["statistic"] = "value / seconds_per_pass = the best of the listed passes (the first ones fault in ~1 GB of fresh text buffers); median below"
-            phasing["median_value"] = float(sorted(r["value"] for r in runs)[len(runs) // 2])
+            med = lambda runs: sorted(runs, key=lambda r: r["value"])[len(runs) // 2]
+            phasing = dict(med(series["resident"]))
+            phasing["passes"] = [round(r["value"]) for r in series["resident"]]
+            phasing["statistic"] = ("value / seconds_per_pass = the MEDIAN of the listed passes; inputs (call lists) and outputs (the text of the five "
+                                    "files) resident in HBM; d2h_inclusive = the same pass with the text copied to page-locked host memory")
+            m2 = med(series["d2h"])
+            phasing["d2h_inclusive"] = {"value": m2["value"], "seconds_per_pass": m2["seconds_per_pass"], "passes": [round(r["value"]) for r in series["d2h"]],
+                                        "seconds": m2["seconds"], "gpu_share": m2["gpu_share"]}
 
     if rank == 0:
         k_avg_s = k_ms_sum / max(1.0, k_launches) / 1e3

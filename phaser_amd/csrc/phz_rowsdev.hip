@@ -31,7 +31,7 @@ constexpr unsigned long long PS_EMPTY = ~0ull;
 constexpr int STAT_N = 512;                    // largest block (variants) covered by the gwStat text table
 constexpr int PH_NMAX = 256, PH_EMAX = 2048;   // largest component (variants / kept pairs) k_phase_general takes; larger ones go to the host
 constexpr int PH_BRUTE_MAX = 22;               // largest fragment brute-forced on the device (2^21 configurations shared by 64 lanes)
-constexpr int SEG_SMALL = 32, SEG_LDS = 2048, SEG_LDS_SLOTS = 4096;
+constexpr int SEG_SMALL = 32, SEG_MID = 256, SEG_LDS = 2048;       // read-set sizes: one thread / one wave (512-slot table) / one workgroup (4096 slots, global pool beyond)
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr unsigned long long NONE64 = ~0ull;
 
@@ -294,12 +294,35 @@ template <class ROW> __global__ __launch_bounds__(256) void k_row_len(RD D, int6
     ROW::emit(D, r, s);
     len[r] = s.n;
 }
-template <class ROW> __global__ __launch_bounds__(256) void k_row_write(RD D, int64_t nrows, const unsigned long long *off, char *out) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrows) return;
-    if (off[r + 1] == off[r]) return;
-    SWrite s; s.p0 = s.p = out + off[r]; s.base = off[r];
-    ROW::emit(D, r, s);
+// One workgroup writes ROWS consecutive rows.  The rows are formatted into LDS at the position they have in the file (shifted so that LDS
+// byte i and file byte i agree modulo 16) and copied out with aligned 16-byte stores: a thread writing its row byte by byte to global memory
+// reaches ~0.2 TB/s (680 MB of allele_config rows: 3 ms), the staged copy streams.  A row range that does not fit the stage (rows with
+// thousands of read labels) is written directly.
+constexpr int ROW_STAGE = 40 * 1024;
+template <class ROW, int ROWS> __global__ __launch_bounds__(ROWS) void k_row_write(RD D, int64_t nrows, const unsigned long long *off, char *out) {
+    __shared__ __attribute__((aligned(16))) char s_buf[ROW_STAGE];
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+    const int64_t r1 = r0 + ROWS < nrows ? r0 + ROWS : nrows;
+    const int64_t r = r0 + threadIdx.x;
+    const unsigned long long b0 = off[r0], b1 = off[r1];
+    if (b1 == b0) return;
+    const unsigned mis = (unsigned)((unsigned long long)(out + b0) & 15ull);
+    if ((b1 - b0) + mis <= (unsigned long long)ROW_STAGE) {
+        if (r < r1 && off[r + 1] > off[r]) {
+            SWrite s; s.p0 = s.p = s_buf + mis + (unsigned)(off[r] - b0); s.base = off[r];
+            ROW::emit(D, r, s);
+        }
+        __syncthreads();
+        const unsigned total = mis + (unsigned)(b1 - b0);
+        char *g = out + b0 - mis;                       // 16-byte aligned
+        for (unsigned c = threadIdx.x * 16u; c < total; c += ROWS * 16u) {
+            if (c >= mis && c + 16u <= total) *(uint4 *)(g + c) = *(const uint4 *)(s_buf + c);
+            else for (unsigned k = c < mis ? mis : c; k < c + 16u && k < total; k++) g[k] = s_buf[k];
+        }
+    } else if (r < r1 && off[r + 1] > off[r]) {
+        SWrite s; s.p0 = s.p = out + off[r]; s.base = off[r];
+        ROW::emit(D, r, s);
+    }
 }
 
 // label text of haplotypic_counts: one thread per read-list entry
@@ -351,12 +374,12 @@ __global__ __launch_bounds__(256) void k_pair_keys(int64_t ne, const uint8_t *li
 __global__ __launch_bounds__(256) void k_keep(int64_t ne, const uint8_t *linked, const int32_t *sup, const int32_t *tot, const unsigned long long *hkeys,
                                               const double *slot_pv, double threshold, uint8_t *keep, uint32_t *e_slot, uint32_t *deg, const int32_t *ea,
                                               const int32_t *eb, unsigned long long *counters) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool is_linked = false, kept = false;
-    if (e < ne) {
+    __shared__ unsigned int s_c[8];
+    unsigned int n_linked = 0, n_dropped = 0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < ne; e += (int64_t)gridDim.x * 256) {
         uint32_t slot = NONE32;
-        is_linked = linked[e] != 0;
-        if (is_linked) {
+        bool kept = false;
+        if (linked[e]) {
             double pv = 1.0;
             if (sup[e] == 0) pv = 0.0;
             else if (tot[e] - sup[e] > 0) {
@@ -366,14 +389,19 @@ __global__ __launch_bounds__(256) void k_keep(int64_t ne, const uint8_t *linked,
                 slot = s; pv = slot_pv[s];
             }
             kept = !(pv < threshold);
+            n_linked++; n_dropped += kept ? 0u : 1u;
         }
         keep[e] = kept ? 1 : 0; e_slot[e] = slot;
-        if (kept) { atomicAdd(&deg[ea[e]], 1u); atomicAdd(&deg[eb[e]], 1u); }
+        if (kept) { deg[ea[e]] = 1u; deg[eb[e]] = 1u; }          // membership flag of the surviving graph (any writer stores the same value)
     }
-    const unsigned long long ml = __ballot(is_linked ? 1 : 0), md = __ballot(is_linked && !kept ? 1 : 0);
-    if ((threadIdx.x & 63) == 0) {
-        if (ml) atomicAdd(&counters[0], (unsigned long long)__popcll(ml));
-        if (md) atomicAdd(&counters[1], (unsigned long long)__popcll(md));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { n_linked += __shfl_xor(n_linked, d); n_dropped += __shfl_xor(n_dropped, d); }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = n_linked; s_c[4 + (threadIdx.x >> 6)] = n_dropped; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int a = s_c[0] + s_c[1] + s_c[2] + s_c[3], b = s_c[4] + s_c[5] + s_c[6] + s_c[7];
+        if (a) atomicAdd(&counters[0], (unsigned long long)a);
+        if (b) atomicAdd(&counters[1], (unsigned long long)b);
     }
 }
 
@@ -438,8 +466,7 @@ __global__ __launch_bounds__(256) void k_flag_keys(int64_t nv, const long long *
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v < nv) is_key[v] = var_first[v] >= 0 ? 1u : 0u;
 }
-__global__ __launch_bounds__(256) void k_compact_keys(int64_t nv, const long long *var_first, const uint32_t *kpos, ShardTab T, const uint16_t *vchrom, int nchrom,
-                                                      unsigned long long *key, uint32_t *val, uint32_t *seg_count /* [nb * nchrom] */) {
+__global__ __launch_bounds__(256) void k_compact_keys(int64_t nv, const long long *var_first, const uint32_t *kpos, ShardTab T, unsigned long long *key, uint32_t *val) {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= nv) return;
     const long long f = var_first[v];
@@ -448,24 +475,85 @@ __global__ __launch_bounds__(256) void k_compact_keys(int64_t nv, const long lon
     for (int t = 0; t < T.n; t++) if (f >= T.lo[t] && f < T.hi[t]) bam = T.bam[t];
     key[kpos[v]] = ((unsigned long long)(uint32_t)bam << 32) | (unsigned long long)f;
     val[kpos[v]] = (uint32_t)v;
-    atomicAdd(&seg_count[(size_t)bam * nchrom + vchrom[v]], 1u);
 }
-__global__ __launch_bounds__(256) void k_conn_chrom(int64_t n_linked, const uint32_t *eorder, const int32_t *va, const uint16_t *vchrom, uint32_t *count) {
+// Rows of every file are chromosome-major (BAM x chromosome-major for the key files): the rows of a segment are found from the first row of
+// each segment (one thread per row compares with its predecessor; same-address atomics on two dozen counters cost 15 ms per genome)
+__global__ __launch_bounds__(256) void k_conn_starts(int64_t n_linked, const uint32_t *eorder, const int32_t *va, const uint16_t *vchrom, uint32_t *start) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r < n_linked) atomicAdd(&count[vchrom[va[eorder[r]]]], 1u);
+    if (r >= n_linked) return;
+    const uint32_t s = vchrom[va[eorder[r]]];
+    if (r == 0 || vchrom[va[eorder[r - 1]]] != s) start[s] = (uint32_t)r;
+}
+__global__ __launch_bounds__(256) void k_key_starts(int64_t nkeys, const unsigned long long *key_sorted, const uint32_t *key_g, const uint16_t *vchrom, int nchrom, uint32_t *start) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nkeys) return;
+    const uint32_t s = (uint32_t)(key_sorted[r] >> 32) * (uint32_t)nchrom + vchrom[key_g[r]];
+    if (r == 0 || (uint32_t)(key_sorted[r - 1] >> 32) * (uint32_t)nchrom + vchrom[key_g[r - 1]] != s) start[s] = (uint32_t)r;
+}
+__global__ __launch_bounds__(256) void k_block_starts(int64_t nblocks, const uint32_t *blk_mstart, const uint32_t *mem_s, const uint16_t *vchrom, uint32_t *start) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t s = vchrom[mem_s[blk_mstart[b]]];
+    if (b == 0 || vchrom[mem_s[blk_mstart[b - 1]]] != s) start[s] = (uint32_t)b;
+}
+// first rows -> row counts per segment (a segment without rows starts where its successor starts)
+__global__ void k_starts_to_counts(uint32_t *start, int nseg, uint32_t total, uint32_t *count) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t next = total;
+    for (int s = nseg - 1; s >= 0; s--) {
+        if (start[s] == NONE32) start[s] = next;
+        count[s] = next - start[s];
+        next = start[s];
+    }
+}
+// per chromosome: blocks, block variants, allele_config rows, from the chromosomes' first blocks
+__global__ void k_block_counts(const uint32_t *start, const uint32_t *count, int nchrom, const uint32_t *blk_voff, const unsigned long long *cfg_base, uint32_t *blkvars,
+                               unsigned long long *cfgrows) {
+    if (threadIdx.x || blockIdx.x) return;
+    for (int c = 0; c < nchrom; c++) {
+        const uint32_t b0 = start[c], b1 = b0 + count[c];
+        blkvars[c] = blk_voff[b1] - blk_voff[b0]; cfgrows[c] = cfg_base[b1] - cfg_base[b0];
+    }
+}
+__global__ __launch_bounds__(256) void k_max_u32(const uint32_t *x, int64_t n, unsigned long long *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = i < n ? x[i] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, (unsigned long long)v);
 }
 
 // ---------------------------------------------------------------------------------------------- block phasing (phase_v3)
 struct PH {
-    const uint32_t *cstart, *mem_s, *estart, *ekeep;
+    const uint32_t *cstart, *mem_s, *estart, *ekeep, *eloc;
     const int32_t *ea, *eb, *cfgv;
     uint8_t *alle_of; int16_t *sub_of; uint32_t *nsub;
     uint32_t *complex_list, *exc_list; uint32_t *counters;       // [0] complex components, [1] exceptions, [2] unsupported (the reference loops forever / 2^30 configurations)
     int max_block_size;
 };
 
-// the commonest component: two variants, one pair with a verdict.  resolve_phase (:2172-2207) floods (variant 0, allele 0) to (variant 1,
-// allele 0) for a same-configuration pair and to (variant 1, allele 1) for an opposite one: block "00" / "01"
+// component-local indices of every kept pair: eloc[t] = i | j << 12 | (configuration + 1) << 24 (NONE32 for components of 4096+ variants)
+__global__ __launch_bounds__(256) void k_edge_local(int64_t nkeep, int64_t ncomp, PH P, uint32_t *eloc) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nkeep) return;
+    int64_t lo = 0, hi = ncomp;                            // component of the pair: largest c with estart[c] <= t
+    while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (P.estart[m] <= (uint32_t)t) lo = m; else hi = m; }
+    const uint32_t m0 = P.cstart[lo], n = P.cstart[lo + 1] - m0;
+    if (n >= 4096) { eloc[t] = NONE32; return; }
+    const uint32_t e = P.ekeep[t];
+    const uint32_t ga = (uint32_t)P.ea[e], gb = (uint32_t)P.eb[e];
+    uint32_t a = 0, b = n;
+    while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (P.mem_s[m0 + m] <= ga) a = m; else b = m; }
+    const uint32_t i = a;
+    a = 0; b = n;
+    while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (P.mem_s[m0 + m] <= gb) a = m; else b = m; }
+    eloc[t] = i | (a << 12) | ((uint32_t)(P.cfgv[e] + 1) << 24);
+}
+
+// One thread per component: the cases resolve_phase (:2172-2207) settles.  Two variants joined by one pair with a verdict: the flood goes from
+// (variant 0, allele 0) to (variant 1, allele 0) for a same-configuration pair and to (variant 1, allele 1) for an opposite one, block "00" /
+// "01".  Up to 32 variants: the flood over the allele graph as a 64-bit mask; accepted when it reaches exactly one allele of every variant.
+// Everything else (conflicts, larger components, the quirk cases of the string construction) goes to k_phase_general.
 __global__ __launch_bounds__(256) void k_phase_pair(int64_t ncomp, PH P) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= ncomp) return;
@@ -474,6 +562,31 @@ __global__ __launch_bounds__(256) void k_phase_pair(int64_t ncomp, PH P) {
         const int k = P.cfgv[P.ekeep[e0]];
         if (k == 0 || k == 1) {
             P.alle_of[m0] = 0; P.alle_of[m0 + 1] = (uint8_t)k; P.sub_of[m0] = 0; P.sub_of[m0 + 1] = 0; P.nsub[c] = 1;
+            return;
+        }
+    }
+    if (n <= 32 && ne <= 512) {
+        unsigned long long reach = 1ull;
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (uint32_t t = e0; t < e0 + ne; t++) {
+                const uint32_t x = P.eloc[t];
+                const int k = (int)(x >> 24) - 1;
+                if (k < 0) continue;
+                const uint32_t i = x & 0xFFFu, j = (x >> 12) & 0xFFFu;
+                for (uint32_t a = 0; a < 2; a++) {
+                    const uint32_t u = 2 * i + a, w = 2 * j + (a ^ (uint32_t)k);
+                    const bool bu = (reach >> u) & 1ull, bw = (reach >> w) & 1ull;
+                    if (bu && !bw) { reach |= 1ull << w; changed = true; }
+                    else if (bw && !bu) { reach |= 1ull << u; changed = true; }
+                }
+            }
+        }
+        const unsigned long long even = n == 32 ? 0x5555555555555555ull : (0x5555555555555555ull & ((1ull << (2 * n)) - 1ull));
+        const unsigned long long lo = reach & even, hi = (reach >> 1) & even;
+        if ((lo ^ hi) == even) {                              // exactly one allele of every variant: |reach| = n, the string has n characters
+            for (uint32_t t = 0; t < n; t++) { P.alle_of[m0 + t] = (uint8_t)((hi >> (2 * t)) & 1ull); P.sub_of[m0 + t] = 0; }
+            P.nsub[c] = 1;
             return;
         }
     }
@@ -487,7 +600,7 @@ __device__ __forceinline__ char flipc(char c) { return c == '-' ? '-' : (c == '0
 __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
     __shared__ uint8_t s_i[PH_EMAX], s_j[PH_EMAX];
     __shared__ int8_t s_k[PH_EMAX];
-    __shared__ uint8_t s_fi[PH_EMAX], s_fj[PH_EMAX], s_fk[PH_EMAX];       // pairs of the fragment under brute force, fragment-local indices
+    __shared__ uint32_t s_m[2][32];                                        // pairs of the fragment under brute force as bit masks by index distance
     __shared__ uint8_t s_mark[2 * PH_NMAX + 2];
     __shared__ int32_t s_weak[PH_NMAX + 4];
     __shared__ uint8_t s_inpts[PH_NMAX + 4];
@@ -496,7 +609,7 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
     __shared__ uint16_t s_p0off[PH_NMAX + 4];
     __shared__ char s_cur[4 * PH_NMAX], s_cand[4 * PH_NMAX], s_fin[4 * PH_NMAX];
     __shared__ uint16_t s_finlen[PH_NMAX + 4];
-    __shared__ int s_nf, s_nfe, s_status, s_nfin, s_ok;
+    __shared__ int s_nf, s_status, s_nfin, s_st[8];
     const int lane = threadIdx.x;
     const uint32_t c = P.complex_list[blockIdx.x];
     (void)nlist;
@@ -507,15 +620,8 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
         return;
     }
     for (int t = lane; t < E; t += 64) {
-        const uint32_t e = P.ekeep[e0 + t];
-        const uint32_t ga = (uint32_t)P.ea[e], gb = (uint32_t)P.eb[e];
-        int lo = 0, hi = n;
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (P.mem_s[m0 + m] <= ga) lo = m; else hi = m; }
-        s_i[t] = (uint8_t)lo;
-        lo = 0; hi = n;
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (P.mem_s[m0 + m] <= gb) lo = m; else hi = m; }
-        s_j[t] = (uint8_t)lo;
-        s_k[t] = (int8_t)P.cfgv[e];
+        const uint32_t x = P.eloc[e0 + t];
+        s_i[t] = (uint8_t)(x & 0xFFFu); s_j[t] = (uint8_t)((x >> 12) & 0xFFFu); s_k[t] = (int8_t)((int)(x >> 24) - 1);
     }
     if (lane == 0) { s_status = 0; s_nfin = 0; }
     __syncthreads();
@@ -560,22 +666,6 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
         }
         return w;
     };
-    // supporting allele pairs of configuration cfg over variants idx0.. (:2236-2249; twice the number of consistent pairs); lane 0 only
-    auto score_cfg = [&](int idx0, int idx_n, const char *cfg, int len) -> int {
-        const int L = idx_n < len ? idx_n : len;
-        int s = 0;
-        for (int t = 0; t < E; t++) {
-            const int k = s_k[t];
-            if (k < 0) continue;
-            const int i = (int)s_i[t] - idx0, j = (int)s_j[t] - idx0;
-            if (i < 0 || j < 0 || i >= L || j >= L) continue;
-            const char ci = cfg[i], cj = cfg[j];
-            if (ci == '-' || cj == '-') continue;
-            if ((cj - '0') == ((ci - '0') ^ k)) s += 2;
-        }
-        return s;
-    };
-
     const int reached = flood(0, n);
     if (reached == n) {
         if (lane == 0) { s_finlen[0] = (uint16_t)marks_to_string(0, n, s_fin); s_nfin = 1; }
@@ -628,30 +718,37 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
                     if (lane == 0) P.exc_list[atomicAdd(&P.counters[1], 1u)] = c;
                     return;
                 }
-                if (lane == 0) {
-                    int w = 0;
-                    for (int t = 0; t < E; t++) {
-                        const int k = s_k[t];
-                        if (k < 0) continue;
-                        const int i = (int)s_i[t] - base, j = (int)s_j[t] - base;
-                        if (i < 0 || j < 0 || i >= len || j >= len) continue;
-                        s_fi[w] = (uint8_t)i; s_fj[w] = (uint8_t)j; s_fk[w] = (uint8_t)k; w++;
-                    }
-                    s_nfe = w;
+                // Pairs of the fragment as bit masks by index distance d = j - i: bit i of s_m[0][d] / s_m[1][d] = a same-configuration /
+                // opposite pair (i, i + d).  A configuration is the bit vector b (bit t = allele of variant t, bit 0 = 0); its consistent pairs at
+                // distance d are popc(~(b ^ b >> d) & same) + popc((b ^ b >> d) & opposite): no memory access per configuration.  (The reference
+                // scores 2^(n-1) configurations pair by pair, :2236-2258; only the maximum, the number of configurations reaching it and the
+                // unique winner matter, so the order of enumeration is free.)
+                for (int t = lane; t < 2 * 32; t += 64) s_m[t >> 5][t & 31] = 0u;
+                __syncthreads();
+                for (int t = lane; t < E; t += 64) {
+                    const int k = s_k[t];
+                    if (k < 0) continue;
+                    int i = (int)s_i[t] - base, j = (int)s_j[t] - base;
+                    if (i < 0 || j < 0 || i >= len || j >= len) continue;
+                    if (i > j) { const int x = i; i = j; j = x; }
+                    atomicOr(&s_m[k][j - i], 1u << i);
                 }
                 __syncthreads();
-                const int nfe = s_nfe;
+                uint32_t m0[PH_BRUTE_MAX], m1[PH_BRUTE_MAX];
+#pragma unroll
+                for (int d = 1; d < PH_BRUTE_MAX; d++) { m0[d] = s_m[0][d]; m1[d] = s_m[1][d]; }
                 const uint32_t ncode = 1u << (len - 1);
                 int best_s = -1; uint32_t best_c = 0; uint32_t ties = 0;
                 for (uint32_t code = (uint32_t)lane; code < ncode; code += 64) {
-                    int s = 0;
-                    for (int t = 0; t < nfe; t++) {
-                        const int i = s_fi[t], j = s_fj[t];
-                        const uint32_t bi = i == 0 ? 0u : (code >> (len - 1 - i)) & 1u, bj = j == 0 ? 0u : (code >> (len - 1 - j)) & 1u;
-                        s += ((bi ^ bj) == (uint32_t)s_fk[t]) ? 1 : 0;
+                    const uint32_t bv = code << 1;
+                    int sc = 0;
+#pragma unroll
+                    for (int d = 1; d < PH_BRUTE_MAX; d++) {
+                        const uint32_t x = bv ^ (bv >> d);
+                        sc += __popc(~x & m0[d]) + __popc(x & m1[d]);
                     }
-                    if (s > best_s) { best_s = s; best_c = code; ties = 1; }
-                    else if (s == best_s) ties++;
+                    if (sc > best_s) { best_s = sc; best_c = code; ties = 1; }
+                    else if (sc == best_s) ties++;
                 }
                 int gmax = best_s;
 #pragma unroll
@@ -661,42 +758,59 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
                 for (int d = 32; d >= 1; d >>= 1) { tt += __shfl_xor(tt, d); const uint32_t o = __shfl_xor(cc, d); cc = o < cc ? o : cc; }
                 if (lane == 0) {
                     char *dst = s_p0 + s_p0off[f];
-                    if (tt == 1) { dst[0] = '0'; for (int k = 1; k < len; k++) dst[k] = ((cc >> (len - 1 - k)) & 1u) ? '1' : '0'; }
+                    if (tt == 1) { dst[0] = '0'; for (int k = 1; k < len; k++) dst[k] = ((cc >> (k - 1)) & 1u) ? '1' : '0'; }
                     else for (int k = 0; k < len; k++) dst[k] = '-';              // a tie for the best score: all '-' (:2255-2258)
                     s_p0off[f + 1] = (uint16_t)(s_p0off[f] + len);
                 }
             }
             __syncthreads();
         }
-        // stitching, left to right (:2138-2160); haplotype B is always the flip of haplotype A, so only A is carried
+        // stitching, left to right (:2138-2160); haplotype B is always the flip of haplotype A, so only A is carried.  The control flow is
+        // wave-uniform (state in LDS, written by lane 0): the scores of the joint configurations are summed over the pairs by all lanes
         if (lane == 0) {
-            int curlen = (int)s_p0off[1];
+            const int curlen = (int)s_p0off[1];
             for (int k = 0; k < curlen; k++) s_cur[k] = s_p0[k];
-            int start = 0, nfin = 0, finpos = 0;
-            for (int f = 1; f < nf; f++) {
-                const char *nxt = s_p0 + s_p0off[f];
-                const int nlen = (int)s_p0off[f + 1] - (int)s_p0off[f];
-                const int used = curlen + nlen;                     // (|cur A| + |cur B| + |next A| + |next B| + 1) / 2
-                const int hi = n < start + used ? n : start + used;
-                const int idx_n = hi - start > 0 ? hi - start : 0;
-                // candidates: cur A + next A, cur A + next B; the other two joint configurations are their complements (skipped, :2228-2234)
+            s_st[0] = curlen; s_st[1] = 0; s_st[2] = 0; s_st[3] = 0;        // |cur|, start, strings in fin, characters in fin
+        }
+        __syncthreads();
+        for (int f = 1; f < nf; f++) {
+            const char *nxt = s_p0 + s_p0off[f];
+            const int nlen = (int)s_p0off[f + 1] - (int)s_p0off[f];
+            const int curlen = s_st[0], start = s_st[1];
+            const int used = curlen + nlen;                     // (|cur A| + |cur B| + |next A| + |next B| + 1) / 2
+            const int hi = n < start + used ? n : start + used;
+            const int idx_n = hi - start > 0 ? hi - start : 0;
+            // candidates: cur A + next A, cur A + next B; the other two joint configurations are their complements (skipped, :2228-2234)
+            if (lane == 0) {
                 bool cur_inv = true, nxt_inv = true;                // a string of '-' (or an empty one) equals its own flip
                 for (int k = 0; k < curlen; k++) if (s_cur[k] != '-') cur_inv = false;
                 for (int k = 0; k < nlen; k++) if (nxt[k] != '-') nxt_inv = false;
-                for (int k = 0; k < curlen; k++) s_cand[k] = s_cur[k];
-                for (int k = 0; k < nlen; k++) s_cand[curlen + k] = nxt[k];
-                const int s0 = score_cfg(start, idx_n, s_cand, used);
-                int ncand = 1, s1 = -1;
-                if (!cur_inv && !nxt_inv) {
-                    for (int k = 0; k < nlen; k++) s_cand[used + curlen + k] = flipc(nxt[k]);
-                    for (int k = 0; k < curlen; k++) s_cand[used + k] = s_cur[k];
-                    s1 = score_cfg(start, idx_n, s_cand + used, used);
-                    ncand = 2;
+                for (int k = 0; k < curlen; k++) { s_cand[k] = s_cur[k]; s_cand[used + k] = s_cur[k]; }
+                for (int k = 0; k < nlen; k++) { s_cand[curlen + k] = nxt[k]; s_cand[used + curlen + k] = flipc(nxt[k]); }
+                s_st[4] = (!cur_inv && !nxt_inv) ? 2 : 1;
+            }
+            __syncthreads();
+            const int ncand = s_st[4];
+            // supporting allele pairs of a joint configuration over variants start.. (:2236-2249): twice the number of consistent pairs
+            int sc[2] = {0, 0};
+            const int L = idx_n < used ? idx_n : used;
+            for (int t = lane; t < E; t += 64) {
+                const int k = s_k[t];
+                if (k < 0) continue;
+                const int i = (int)s_i[t] - start, j = (int)s_j[t] - start;
+                if (i < 0 || j < 0 || i >= L || j >= L) continue;
+                for (int q = 0; q < ncand; q++) {
+                    const char ci = s_cand[q * used + i], cj = s_cand[q * used + j];
+                    if (ci != '-' && cj != '-' && (cj - '0') == ((ci - '0') ^ k)) sc[q] += 2;
                 }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { sc[0] += __shfl_xor(sc[0], d); sc[1] += __shfl_xor(sc[1], d); }
+            if (lane == 0) {
                 int win = -1;
                 if (ncand == 1) win = 0;
-                else if (s0 > s1) win = 0;
-                else if (s1 > s0) win = 1;
+                else if (sc[0] > sc[1]) win = 0;
+                else if (sc[1] > sc[0]) win = 1;
                 bool has_dash;
                 int outlen;
                 if (win >= 0) {
@@ -704,19 +818,24 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
                     for (int k = 0; k < used; k++) if (s_cand[win * used + k] == '-') has_dash = true;
                 } else { outlen = idx_n; has_dash = idx_n > 0; }               // all '-' (length idx_n); empty string holds no '-'
                 if (has_dash) {
+                    const int finpos = s_st[3];
                     for (int k = 0; k < curlen; k++) s_fin[finpos + k] = s_cur[k];
-                    s_finlen[nfin++] = (uint16_t)curlen; finpos += curlen;
-                    start = used;                                                // ASSIGNED, not advanced (:2152)
+                    s_finlen[s_st[2]] = (uint16_t)curlen; s_st[2] += 1; s_st[3] = finpos + curlen;
+                    s_st[1] = used;                                              // ASSIGNED, not advanced (:2152)
                     for (int k = 0; k < nlen; k++) s_cur[k] = nxt[k];
-                    curlen = nlen;
+                    s_st[0] = nlen;
                 } else {
                     for (int k = 0; k < outlen; k++) s_cur[k] = win >= 0 ? s_cand[win * used + k] : '-';
-                    curlen = outlen;
+                    s_st[0] = outlen;
                 }
             }
+            __syncthreads();
+        }
+        if (lane == 0) {
+            const int curlen = s_st[0], finpos = s_st[3];
             for (int k = 0; k < curlen; k++) s_fin[finpos + k] = s_cur[k];
-            s_finlen[nfin++] = (uint16_t)curlen;
-            s_nfin = nfin;
+            s_finlen[s_st[2]] = (uint16_t)curlen;
+            s_nfin = s_st[2] + 1;
         }
     }
     __syncthreads();
@@ -746,17 +865,12 @@ struct BK {
     const uint32_t *corder, *blk_base, *cstart, *mem_s;
     const int16_t *sub_of; const uint8_t *alle_of;
     uint32_t *blk_mstart, *blk_len; int32_t *blk_of; uint8_t *v_alle;
-    const uint16_t *vchrom;
-    uint32_t *chrom_blocks, *chrom_blkvars; unsigned long long *chrom_cfgrows;      // [nchrom]
-    unsigned long long *counters;                                                   // [2] phased variants, [3] longest block
 };
 __global__ __launch_bounds__(256) void k_blocks(int64_t ncomp, BK B) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= ncomp) return;
     const uint32_t c = B.corder[r], base = B.blk_base[r];
     const uint32_t m0 = B.cstart[c], n = B.cstart[c + 1] - m0;
-    const int ch = B.vchrom[B.mem_s[m0]];
-    uint32_t nblk = 0, nvars = 0, longest = 0; unsigned long long cfgrows = 0;
     int cur = -1; uint32_t run0 = 0;
     for (uint32_t t = 0; t <= n; t++) {
         const int s = t < n ? (int)B.sub_of[m0 + t] : -2;
@@ -764,15 +878,10 @@ __global__ __launch_bounds__(256) void k_blocks(int64_t ncomp, BK B) {
             if (cur >= 0) {
                 const uint32_t len = t - run0;
                 B.blk_mstart[base + (uint32_t)cur] = m0 + run0; B.blk_len[base + (uint32_t)cur] = len;
-                nblk++; nvars += len; cfgrows += (unsigned long long)len * (len - 1); longest = len > longest ? len : longest;
             }
             cur = s; run0 = t;
         }
         if (t < n && s >= 0) { const uint32_t v = B.mem_s[m0 + t]; B.blk_of[v] = (int32_t)(base + (uint32_t)s); B.v_alle[v] = B.alle_of[m0 + t]; }
-    }
-    if (nblk) {
-        atomicAdd(&B.chrom_blocks[ch], nblk); atomicAdd(&B.chrom_blkvars[ch], nvars); atomicAdd(&B.chrom_cfgrows[ch], cfgrows);
-        atomicAdd(&B.counters[2], (unsigned long long)nvars); atomicMax(&B.counters[3], (unsigned long long)longest);
     }
 }
 __global__ __launch_bounds__(256) void k_gather_nsub(int64_t ncomp, const uint32_t *corder, const uint32_t *nsub, uint32_t *out) {
@@ -842,7 +951,7 @@ struct SG {
     const uint32_t *mem_s, *blk_mstart, *blk_len; const uint8_t *v_alle, *black;
     const uint32_t *rl_start; const int32_t *rl_qid;
     uint32_t *labels, *ns;
-    uint32_t *big_list; uint32_t *counters;         // [0] segments left to the block kernel, [1] pool slots used, [2] pool overflow
+    uint32_t *big_list, *big_list2; uint32_t *counters;         // [0] segments left to the wave kernel, [1] pool slots used, [2] pool overflow, [3] segments left to the workgroup kernel
     uint32_t *pool; uint32_t pool_cap;
 };
 template <int MODE> __device__ __forceinline__ uint32_t seg_pieces(const SG &G, int64_t seg) {      // number of pieces (some may be empty / skipped)
@@ -874,6 +983,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_seg_small(SG G) {
     uint32_t M = 0;
     for (uint32_t t = 0; t < np; t++) { uint32_t lo, hi; if (seg_piece<MODE>(G, seg, t, &lo, &hi)) M += hi - lo; }
     if (M == 0) { G.ns[seg] = 0; return; }
+    if (M > SEG_MID) { G.big_list2[atomicAdd(&G.counters[3], 1u)] = (uint32_t)seg; return; }
     if (M > SEG_SMALL) { G.big_list[atomicAdd(&G.counters[0], 1u)] = (uint32_t)seg; return; }
     uint32_t idx = 0;
     for (uint32_t t = 0; t < np; t++) {
@@ -903,13 +1013,13 @@ __device__ __forceinline__ uint32_t seg_hash(uint32_t q) { q ^= q >> 16; q *= 0x
 
 // one workgroup per segment with more than SEG_SMALL items: open-addressing table keyed by QNAME id holding the first position (then
 // the number) of the QNAME -- in LDS up to SEG_LDS items, in a slice of the global pool beyond
-template <int MODE> __global__ __launch_bounds__(256) void k_seg_big(SG G) {
-    __shared__ uint32_t s_tab[3 * SEG_LDS_SLOTS];
+template <int MODE, int SLOTS, int THREADS> __global__ __launch_bounds__(THREADS) void k_seg_big(SG G) {
+    __shared__ uint32_t s_tab[3 * SLOTS];
     __shared__ uint32_t s_pref[STAT_N + 2], s_lo[STAT_N + 2];
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_carry, s_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t seg = G.big_list[blockIdx.x];
+    const int64_t seg = THREADS == 64 ? G.big_list[blockIdx.x] : G.big_list2[blockIdx.x];
     const uint32_t np = seg_pieces<MODE>(G, seg);
     if (tid == 0) {
         uint32_t acc = 0;
@@ -923,10 +1033,10 @@ template <int MODE> __global__ __launch_bounds__(256) void k_seg_big(SG G) {
     }
     __syncthreads();
     const uint32_t M = s_pref[np];
-    uint32_t cap = SEG_LDS_SLOTS;
+    uint32_t cap = 64;
+    while (cap < 2 * M) cap <<= 1;                          // <= SLOTS as long as the table is in LDS
     uint32_t *keys = s_tab;
-    if (M > SEG_LDS) {
-        while (cap < 2 * M) cap <<= 1;
+    if (2 * M > (uint32_t)SLOTS) {
         if (tid == 0) {
             const uint32_t off = atomicAdd(&G.counters[1], 3 * cap);
             s_off = off;
@@ -938,7 +1048,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k_seg_big(SG G) {
     }
     uint32_t *first = keys + cap, *rank = keys + 2 * cap;
     const uint32_t mask = cap - 1;
-    for (uint32_t s = tid; s < cap; s += 256) { keys[s] = 0; first[s] = NONE32; }
+    for (uint32_t s = tid; s < cap; s += THREADS) { keys[s] = 0; first[s] = NONE32; }
     __syncthreads();
     auto item_pos = [&](uint32_t idx) -> uint32_t {
         uint32_t lo = 0, hi = np;                              // largest t with s_pref[t] <= idx (pieces of length 0 share a start: the last one wins, it is the non-empty one)
@@ -950,7 +1060,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k_seg_big(SG G) {
         while (keys[s] != q + 1u) s = (s + 1) & mask;
         return s;
     };
-    for (uint32_t idx = tid; idx < M; idx += 256) {
+    for (uint32_t idx = tid; idx < M; idx += THREADS) {
         const uint32_t q = (uint32_t)G.rl_qid[item_pos(idx)];
         uint32_t s = seg_hash(q) & mask;
         for (;;) {
@@ -960,7 +1070,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k_seg_big(SG G) {
         }
     }
     __syncthreads();
-    for (uint32_t base = 0; base < M; base += 256) {
+    for (uint32_t base = 0; base < M; base += THREADS) {
         const uint32_t idx = base + tid;
         uint32_t slot = 0; bool isf = false;
         if (idx < M) { slot = slot_of((uint32_t)G.rl_qid[item_pos(idx)]); isf = first[slot] == idx; }
@@ -971,12 +1081,12 @@ template <int MODE> __global__ __launch_bounds__(256) void k_seg_big(SG G) {
         for (int w = 0; w < wave; w++) before += s_w[w];
         if (isf) rank[slot] = before + (uint32_t)__popcll(bal & (lane ? (~0ull >> (64 - lane)) : 0ull));
         __syncthreads();
-        if (tid == 0) s_carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (tid == 0) { uint32_t add = 0; for (int w = 0; w < THREADS / 64; w++) add += s_w[w]; s_carry += add; }
         __syncthreads();
     }
     if (tid == 0) G.ns[seg] = s_carry;
     if (MODE == 0)
-        for (uint32_t idx = tid; idx < M; idx += 256) {
+        for (uint32_t idx = tid; idx < M; idx += THREADS) {
             const uint32_t p = item_pos(idx);
             G.labels[p] = rank[slot_of((uint32_t)G.rl_qid[p])];
         }
@@ -998,9 +1108,14 @@ __global__ void k_seg_offsets64(const unsigned long long *count, int nseg, const
     for (int s = 0; s <= nseg; s++) { seg_off[s] = off[rows]; if (s < nseg) rows += count[s]; }
 }
 __global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *len, int64_t n, unsigned long long *counter) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long m = __ballot(i < n && len[i] != 0 ? 1 : 0);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
+    __shared__ unsigned int s_c[4];
+    unsigned int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c += len[i] != 0 ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_c[0] + s_c[1] + s_c[2] + s_c[3])) atomicAdd(counter, (unsigned long long)(s_c[0] + s_c[1] + s_c[2] + s_c[3]));
 }
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, int64_t n, uint32_t v) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1051,10 +1166,10 @@ struct phz_rowsdev {
     DevBuf keep, e_slot, deg, parent, label, f_a, f_b, f_c, f_d, mem_pos, cid, kpos, keypos;
     DevBuf k64a, k64b, k32a, k32b, v32a, v32b, sort_cnt, scan_tmp;
     DevBuf ridx, va, vb, eorder, mem_s, cstart, corder, ekeep, estart, key_g;
-    DevBuf cnt64, cnt32, chrom_cnt;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
+    DevBuf cnt64, cnt32, chrom_cnt, seg_start, key64s, eloc;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
     DevBuf alle_of, sub_of, nsub, complex_list, exc_list, nsub_o, blk_base;
     DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, blk_voff;
-    DevBuf labels, seg_ns, blk_cnt, single_n, big_list, pool, tl, its, piece_dst, rowlen;
+    DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, pool, tl, its, piece_dst, rowlen;
     DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
     DevBuf o_var, o_maxmaf, o_hap, o_cor;
     // results (host)
@@ -1067,9 +1182,9 @@ struct phz_rowsdev {
         std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &slot_pv, &pv_off, &pv_txt, &bam_off, &bam_txt,
                                    &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
-                                   &key_g, &cnt64, &cnt32, &chrom_cnt, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
+                                   &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
                                    &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &blk_voff, &labels,
-                                   &seg_ns, &blk_cnt, &single_n, &big_list, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
+                                   &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
         return v;
@@ -1122,7 +1237,7 @@ int sort_into(phz_ctx *ctx, phz_rowsdev *h, DevBuf &ka, DevBuf &kb, int64_t n, c
 // cstart / estart: CSR of members (mem_s: variant ids, ascending inside a component) and kept pairs (ekeep: pair ids into ea / eb / cfgv).
 int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf &estart, DevBuf &ekeep, const int32_t *ea, const int32_t *eb, const int32_t *cfgv,
               int64_t ncomp, int64_t nmem, int64_t nkeep, int64_t ne, int max_block_size, DevBuf &alle_of, DevBuf &sub_of, DevBuf &nsub, DevBuf &complex_list,
-              DevBuf &exc_list, uint32_t *cnt32, int64_t *n_complex, int64_t *n_exc) {
+              DevBuf &exc_list, DevBuf &eloc, uint32_t *cnt32, int64_t *n_complex, int64_t *n_exc) {
     hipStream_t sm = ctx->stream;
     *n_complex = 0; *n_exc = 0;
     if (int s = phz_reserve(ctx, alle_of, (size_t)(nmem + 1))) return s;
@@ -1130,12 +1245,15 @@ int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf
     if (int s = phz_reserve(ctx, nsub, (size_t)(ncomp + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, complex_list, (size_t)(ncomp + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, exc_list, (size_t)(2 * ncomp + 2) * 4)) return s;
+    if (int s = phz_reserve(ctx, eloc, (size_t)(nkeep + 1) * 4)) return s;
     if (!ncomp) return PHZ_OK;
     PH ph; ph.cstart = P<uint32_t>(cstart); ph.mem_s = P<uint32_t>(mem_s); ph.estart = P<uint32_t>(estart); ph.ekeep = P<uint32_t>(ekeep);
     ph.ea = ea; ph.eb = eb; ph.cfgv = cfgv; ph.alle_of = P<uint8_t>(alle_of); ph.sub_of = P<int16_t>(sub_of); ph.nsub = P<uint32_t>(nsub);
     ph.complex_list = P<uint32_t>(complex_list); ph.exc_list = P<uint32_t>(exc_list); ph.counters = cnt32; ph.max_block_size = max_block_size;
+    ph.eloc = P<uint32_t>(eloc);
     uint32_t h_c32[4] = {0, 0, 0, 0};
     PHZ_HIP(ctx, hipMemsetAsync(cnt32, 0, 12, sm));
+    if (nkeep) hipLaunchKernelGGL(k_edge_local, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, ncomp, ph, P<uint32_t>(eloc));
     hipLaunchKernelGGL(k_phase_pair, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, ph);
     PHZ_HIP(ctx, hipMemcpyAsync(h_c32, cnt32, 4, hipMemcpyDeviceToHost, sm));
     if (int s = sec.wait()) return s;
@@ -1306,12 +1424,15 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     uint32_t *cc_conn = P<uint32_t>(h->chrom_cnt), *cc_blocks = cc_conn + nchrom, *cc_blkvars = cc_blocks + nchrom, *cc_keys = cc_blkvars + nchrom;
     unsigned long long *cc_cfg = (unsigned long long *)((char *)h->chrom_cnt.p + ((n_cc * 4 + 7) & ~(size_t)7));
     PHZ_HIP(ctx, hipMemsetAsync(h->chrom_cnt.p, 0, h->chrom_cnt.cap, sm));
+    RSV(seg_start, (n_cc + 1) * 4);            // first row of every segment, same layout as the counters
+    uint32_t *ss_conn = P<uint32_t>(h->seg_start), *ss_blocks = ss_conn + nchrom, *ss_keys = ss_blocks + 2 * nchrom;
+    PHZ_HIP(ctx, hipMemsetAsync(h->seg_start.p, 0xff, (n_cc + 1) * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->deg.p, 0, NV * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->cnt64.p, 0, 64, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->cnt32.p, 0, 64, sm));
     unsigned long long *cnt64 = P<unsigned long long>(h->cnt64);
     uint32_t *cnt32 = P<uint32_t>(h->cnt32);
-    if (ne) hipLaunchKernelGGL(k_keep, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, sup, tot, (const unsigned long long *)h->hkeys.p,
+    if (ne) hipLaunchKernelGGL(k_keep, dim3(std::min(nblk(ne), 2048u)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, sup, tot, (const unsigned long long *)h->hkeys.p,
                                (const double *)h->slot_pv.p, o->cc_threshold, P<uint8_t>(h->keep), P<uint32_t>(h->e_slot), P<uint32_t>(h->deg), (const int32_t *)T.ea,
                                (const int32_t *)T.eb, cnt64);
     if (nv) hipLaunchKernelGGL(k_uf_init, dim3(nblk(nv)), dim3(256), 0, sm, P<int32_t>(h->parent), nv);
@@ -1356,8 +1477,11 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
                            (const uint32_t *)h->ridx.p, P<int32_t>(h->va), P<int32_t>(h->vb), P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
         const int rg[2][2] = {{0, bv}, {32, 32 + bv + 1}};
         if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, ne, rg, 2, P<uint32_t>(h->eorder), nullptr)) return s;
-        if (n_linked) hipLaunchKernelGGL(k_conn_chrom, dim3(nblk(n_linked)), dim3(256), 0, sm, n_linked, (const uint32_t *)h->eorder.p, (const int32_t *)h->va.p,
-                                         (const uint16_t *)h->d_vchrom.p, cc_conn);
+        if (n_linked) hipLaunchKernelGGL(k_conn_starts, dim3(nblk(n_linked)), dim3(256), 0, sm, n_linked, (const uint32_t *)h->eorder.p, (const int32_t *)h->va.p,
+                                         (const uint16_t *)h->d_vchrom.p, ss_conn);
+    }
+    hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_conn, nchrom, (uint32_t)n_linked, cc_conn);
+    {
     }
     if (nmem) {
         hipLaunchKernelGGL(k_compact_members, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->deg.p, (const uint32_t *)h->mem_pos.p, (const int32_t *)h->label.p,
@@ -1378,16 +1502,20 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     }
     if (nkeys) {
         ShardTab ST; ST.lo = (const long long *)h->sh_lo.p; ST.hi = (const long long *)h->sh_hi.p; ST.bam = (const int32_t *)h->sh_bam.p; ST.n = o->n_shards;
-        hipLaunchKernelGGL(k_compact_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST, (const uint16_t *)h->d_vchrom.p,
-                           nchrom, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a), cc_keys);
+        hipLaunchKernelGGL(k_compact_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST,
+                           P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
         const int rg[2][2] = {{0, bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1))}, {32, 32 + (nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0)}};
-        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nkeys, rg, 2, P<uint32_t>(h->key_g), nullptr)) return s;
+        RSV(key64s, (size_t)(nkeys + 1) * 8);
+        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nkeys, rg, 2, P<uint32_t>(h->key_g), P<unsigned long long>(h->key64s))) return s;
+        hipLaunchKernelGGL(k_key_starts, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const unsigned long long *)h->key64s.p, (const uint32_t *)h->key_g.p,
+                           (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
     }
+    hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_keys, nb * nchrom, (uint32_t)nkeys, cc_keys);
     // ---- block phasing
     {
         int64_t ncx = 0, nex = 0;
         if (int s = phase_all(ctx, sec, h->cstart, h->mem_s, h->estart, h->ekeep, T.ea, T.eb, cfgv, ncomp, nmem, nkeep, ne, o->max_block_size, h->alle_of, h->sub_of, h->nsub,
-                              h->complex_list, h->exc_list, cnt32, &ncx, &nex)) return s;
+                              h->complex_list, h->exc_list, h->eloc, cnt32, &ncx, &nex)) return s;
         res->n_complex = ncx; res->n_exceptions = nex;
     }
     // ---- blocks in block order; per-block statistics
@@ -1406,43 +1534,56 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     if (ncomp) {
         hipLaunchKernelGGL(k_gather_nsub, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, (const uint32_t *)h->corder.p, (const uint32_t *)h->nsub.p, P<uint32_t>(h->nsub_o));
         if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->nsub_o), P<uint32_t>(h->blk_base), ncomp, h->scan_tmp)) return s;
-        BK bk; bk.corder = P<uint32_t>(h->corder); bk.blk_base = P<uint32_t>(h->blk_base); bk.cstart = P<uint32_t>(h->cstart); bk.mem_s = P<uint32_t>(h->mem_s);
-        bk.sub_of = P<int16_t>(h->sub_of); bk.alle_of = P<uint8_t>(h->alle_of); bk.blk_mstart = P<uint32_t>(h->blk_mstart); bk.blk_len = P<uint32_t>(h->blk_len);
-        bk.blk_of = P<int32_t>(h->blk_of); bk.v_alle = P<uint8_t>(h->v_alle); bk.vchrom = P<uint16_t>(h->d_vchrom); bk.chrom_blocks = cc_blocks; bk.chrom_blkvars = cc_blkvars;
-        bk.chrom_cfgrows = cc_cfg; bk.counters = cnt64;
-        hipLaunchKernelGGL(k_blocks, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, bk);
-        if (nkeep) hipLaunchKernelGGL(k_blk_edges, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, (const uint32_t *)h->ekeep.p, (const int32_t *)T.ea, (const int32_t *)T.eb, cfgv,
-                                      (const int32_t *)h->blk_of.p, (const uint8_t *)h->v_alle.p, P<uint32_t>(h->blk_sup), P<uint32_t>(h->blk_tot));
         uint32_t nb32 = 0;
         PHZ_HIP(ctx, hipGetLastError());
         PHZ_HIP(ctx, hipMemcpyAsync(&nb32, P<uint32_t>(h->blk_base) + ncomp, 4, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(h_c64, cnt64, 32, hipMemcpyDeviceToHost, sm));
         if (int s = sec.wait()) return s;
         sec.begin();
         nblocks = nb32;
-        if ((int64_t)h_c64[3] > STAT_N) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: a haplotype block of more than 512 variants is formatted by the host stage");
+        BK bk; bk.corder = P<uint32_t>(h->corder); bk.blk_base = P<uint32_t>(h->blk_base); bk.cstart = P<uint32_t>(h->cstart); bk.mem_s = P<uint32_t>(h->mem_s);
+        bk.sub_of = P<int16_t>(h->sub_of); bk.alle_of = P<uint8_t>(h->alle_of); bk.blk_mstart = P<uint32_t>(h->blk_mstart); bk.blk_len = P<uint32_t>(h->blk_len);
+        bk.blk_of = P<int32_t>(h->blk_of); bk.v_alle = P<uint8_t>(h->v_alle);
+        hipLaunchKernelGGL(k_blocks, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, bk);
+        if (nkeep) hipLaunchKernelGGL(k_blk_edges, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, (const uint32_t *)h->ekeep.p, (const int32_t *)T.ea, (const int32_t *)T.eb, cfgv,
+                                      (const int32_t *)h->blk_of.p, (const uint8_t *)h->v_alle.p, P<uint32_t>(h->blk_sup), P<uint32_t>(h->blk_tot));
     }
-    res->phased = (int64_t)h_c64[2];
     if (nblocks) {
         BS bs; bs.mem_s = P<uint32_t>(h->mem_s); bs.blk_mstart = P<uint32_t>(h->blk_mstart); bs.blk_len = P<uint32_t>(h->blk_len); bs.v_alle = P<uint8_t>(h->v_alle);
         bs.phase_idx = P<int8_t>(h->d_phase); bs.mafv = P<double>(h->d_maf); bs.conc = P<uint8_t>(h->conc); bs.cormode = P<uint8_t>(h->cormode); bs.statkind = P<uint8_t>(h->statkind);
         bs.statidx = P<uint32_t>(h->statidx); bs.maxmaf = P<int32_t>(h->maxmaf); bs.stat = P<double>(h->stat); bs.cfg_rows = P<unsigned long long>(h->cfg_rows);
         hipLaunchKernelGGL(k_blk_stats, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, bs);
+        hipLaunchKernelGGL(k_max_u32, dim3(nblk(nblocks)), dim3(256), 0, sm, (const uint32_t *)h->blk_len.p, nblocks, cnt64 + 3);
+        hipLaunchKernelGGL(k_block_starts, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, (const uint32_t *)h->blk_mstart.p, (const uint32_t *)h->mem_s.p,
+                           (const uint16_t *)h->d_vchrom.p, ss_blocks);
     }
     if (int s = gscan_excl<unsigned long long, unsigned long long>(ctx, P<unsigned long long>(h->cfg_rows), P<unsigned long long>(h->cfg_base), nblocks, h->scan_tmp)) return s;
+    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->blk_len), P<uint32_t>(h->blk_voff), nblocks, h->scan_tmp)) return s;
+    hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_blocks, nchrom, (uint32_t)nblocks, cc_blocks);
+    hipLaunchKernelGGL(k_block_counts, dim3(1), dim3(1), 0, sm, (const uint32_t *)ss_blocks, (const uint32_t *)cc_blocks, nchrom, (const uint32_t *)h->blk_voff.p,
+                       (const unsigned long long *)h->cfg_base.p, cc_blkvars, cc_cfg);
+    {
+        uint32_t h_phased = 0;
+        PHZ_HIP(ctx, hipGetLastError());
+        PHZ_HIP(ctx, hipMemcpyAsync(&h_c64[3], cnt64 + 3, 8, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(&h_phased, P<uint32_t>(h->blk_voff) + nblocks, 4, hipMemcpyDeviceToHost, sm));
+        if (int s = sec.wait()) return s;
+        sec.begin();
+        if ((int64_t)h_c64[3] > STAT_N) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: a haplotype block of more than 512 variants is formatted by the host stage");
+        res->phased = (int64_t)h_phased;
+    }
     // ---- read sets of the haplotypes: labels + distinct counts
     const bool need_all = nb > 1 || h->has_black;
-    RSV(labels, NR * 4); RSV(seg_ns, (size_t)(nblocks + 1) * 2 * nb * 4); RSV(big_list, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4);
+    RSV(labels, NR * 4); RSV(seg_ns, (size_t)(nblocks + 1) * 2 * nb * 4); RSV(big_list, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4); RSV(big_list2, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4);
     if (need_all) RSV(blk_cnt, (size_t)(nblocks + 1) * 2 * 4);
     if (nb > 1) RSV(single_n, NRL * 4);
     if (h->pool.cap == 0) RSV(pool, (size_t)12 << 20);
     PHZ_HIP(ctx, hipMemsetAsync(h->labels.p, 0, NR * 4, sm));
     SG sg; sg.nb = nb; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
     sg.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.labels = P<uint32_t>(h->labels);
-    sg.big_list = P<uint32_t>(h->big_list); sg.counters = cnt32 + 4;
+    sg.big_list = P<uint32_t>(h->big_list); sg.big_list2 = P<uint32_t>(h->big_list2); sg.counters = cnt32 + 4;
     for (int attempt = 0;; attempt++) {
         sg.pool = P<uint32_t>(h->pool); sg.pool_cap = (uint32_t)std::min<size_t>(h->pool.cap / 4, 0xFFFFFFF0u);
-        uint32_t h_seg[3] = {0, 0, 0};
+        uint32_t h_seg[4] = {0, 0, 0, 0};
         bool overflow = false;
         for (int mode = 0; mode < 3; mode++) {
             if (mode == 1 && !need_all) continue;
@@ -1450,24 +1591,30 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
             sg.nseg = mode == 0 ? nblocks * 2 * nb : (mode == 1 ? nblocks * 2 : (int64_t)NRL);
             sg.ns = mode == 0 ? P<uint32_t>(h->seg_ns) : (mode == 1 ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->single_n));
             if (sg.nseg == 0) continue;
-            PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 4, 0, 12, sm));
+            PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 4, 0, 16, sm));
             const unsigned g = (unsigned)((sg.nseg + 63) / 64);
             if (mode == 0) hipLaunchKernelGGL(k_seg_small<0>, dim3(g), dim3(64), 0, sm, sg);
             else if (mode == 1) hipLaunchKernelGGL(k_seg_small<1>, dim3(g), dim3(64), 0, sm, sg);
             else hipLaunchKernelGGL(k_seg_small<2>, dim3(g), dim3(64), 0, sm, sg);
-            PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 4, hipMemcpyDeviceToHost, sm));
+            PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 16, hipMemcpyDeviceToHost, sm));
             if (int s = sec.wait()) return s;
             sec.begin();
-            if (h_seg[0]) {
-                if (mode == 0) hipLaunchKernelGGL(k_seg_big<0>, dim3(h_seg[0]), dim3(256), 0, sm, sg);
-                else if (mode == 1) hipLaunchKernelGGL(k_seg_big<1>, dim3(h_seg[0]), dim3(256), 0, sm, sg);
-                else hipLaunchKernelGGL(k_seg_big<2>, dim3(h_seg[0]), dim3(256), 0, sm, sg);
+            const uint32_t n_mid = h_seg[0], n_large = h_seg[3];
+            if (n_mid) {
+                if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
+                else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
+                else hipLaunchKernelGGL((k_seg_big<2, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
+            }
+            if (n_large) {
+                if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, 256>), dim3(n_large), dim3(256), 0, sm, sg);
+                else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 4096, 256>), dim3(n_large), dim3(256), 0, sm, sg);
+                else hipLaunchKernelGGL((k_seg_big<2, 4096, 256>), dim3(n_large), dim3(256), 0, sm, sg);
                 PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 12, hipMemcpyDeviceToHost, sm));
                 if (int s = sec.wait()) return s;
                 sec.begin();
                 if (h_seg[2]) { overflow = true; break; }
             }
-            res->n_big_segments += h_seg[0];
+            res->n_big_segments += n_mid + n_large;
         }
         if (!overflow) break;
         if (attempt == 3) return phz_fail(ctx, PHZ_E_NOMEM, "read-set table pool did not converge");
@@ -1523,7 +1670,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
             case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_row_len<RowSingleAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
             default: hipLaunchKernelGGL(k_row_len<RowSingleHap>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
         }
-        if (f == PHZ_TXT_ALLELIC && rows[f]) hipLaunchKernelGGL(k_count_nonzero, dim3(g), dim3(256), 0, sm, (const uint32_t *)len, rows[f], cnt64 + 4);
+        if (f == PHZ_TXT_ALLELIC && rows[f]) hipLaunchKernelGGL(k_count_nonzero, dim3(g < 512u ? g : 512u), dim3(256), 0, sm, (const uint32_t *)len, rows[f], cnt64 + 4);
         if (int s = gscan_excl<uint32_t, unsigned long long>(ctx, len, P<unsigned long long>(h->off[f]), rows[f], h->scan_tmp)) return s;
         unsigned long long *so = P<unsigned long long>(h->seg_off_d[f]);
         const unsigned long long *of = P<unsigned long long>(h->off[f]);
@@ -1554,13 +1701,13 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         const unsigned long long *of = P<unsigned long long>(h->off[f]);
         char *out = P<char>(h->text[f]);
         if (rows[f]) switch (f) {
-            case PHZ_TXT_CONN: hipLaunchKernelGGL(k_row_write<RowConn>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_row_write<RowHap>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_row_write<RowAse>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_row_write<RowCfg>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_ALLELIC: hipLaunchKernelGGL(k_row_write<RowAllelic>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_row_write<RowSingleAse>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
-            default: hipLaunchKernelGGL(k_row_write<RowSingleHap>, dim3(g), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_CONN: hipLaunchKernelGGL((k_row_write<RowConn, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL((k_row_write<RowHap, 128>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, 64>), dim3((unsigned)((rows[f] + 63) / 64)), dim3(64), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_CFG: hipLaunchKernelGGL((k_row_write<RowCfg, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_ALLELIC: hipLaunchKernelGGL((k_row_write<RowAllelic, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL((k_row_write<RowSingleAse, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            default: hipLaunchKernelGGL((k_row_write<RowSingleHap, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
         }
         if (f == PHZ_TXT_ASE && n_rl && rows[f]) hipLaunchKernelGGL(k_label_write, dim3(nblk(n_rl)), dim3(256), 0, sm, D, n_rl, out);
     }
@@ -1568,7 +1715,6 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     h->have_vcf = false;
     h->n_blocks = nblocks; h->n_blk_vars = res->phased;
     if (o->want_vcf && nblocks) {
-        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->blk_len), P<uint32_t>(h->blk_voff), nblocks, h->scan_tmp)) return s;
         RSV(o_var, (size_t)(res->phased + 1) * 4); RSV(o_maxmaf, (size_t)(nblocks + 1) * 4); RSV(o_hap, (size_t)(res->phased + 1)); RSV(o_cor, (size_t)(res->phased + 1) * 2);
         VB vbk; vbk.mem_s = P<uint32_t>(h->mem_s); vbk.blk_mstart = P<uint32_t>(h->blk_mstart); vbk.blk_len = P<uint32_t>(h->blk_len); vbk.blk_voff = P<uint32_t>(h->blk_voff);
         vbk.v_alle = P<uint8_t>(h->v_alle); vbk.cormode = P<uint8_t>(h->cormode); vbk.phase_idx = P<int8_t>(h->d_phase); vbk.maxmaf = P<int32_t>(h->maxmaf);
@@ -1645,7 +1791,7 @@ extern "C" int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t
             ek[e] = e; ea[e] = (int32_t)(comp_start[c] + (uint32_t)pair_i[e]); eb[e] = (int32_t)(comp_start[c] + (uint32_t)pair_j[e]); cf[e] = pair_cfg[e];
         }
     }
-    enum { B_CS, B_MEM, B_ES, B_EK, B_EA, B_EB, B_CF, B_CNT, B_AL, B_SUB, B_NSUB, B_CX, B_EX, B_N };
+    enum { B_CS, B_MEM, B_ES, B_EK, B_EA, B_EB, B_CF, B_CNT, B_AL, B_SUB, B_NSUB, B_CX, B_EX, B_EL, B_N };
     DevBuf d[B_N];
     int st = PHZ_OK;
     auto fin = [&](int code) { for (DevBuf &b : d) if (b.p) (void)hipFree(b.p); return code; };
@@ -1658,7 +1804,7 @@ extern "C" int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t
     sec.begin();
     int64_t ncx = 0, nex = 0;
     st = phase_all(ctx, sec, d[B_CS], d[B_MEM], d[B_ES], d[B_EK], P<int32_t>(d[B_EA]), P<int32_t>(d[B_EB]), P<int32_t>(d[B_CF]), n_comp, nmem, ne, ne, max_block_size,
-                   d[B_AL], d[B_SUB], d[B_NSUB], d[B_CX], d[B_EX], P<uint32_t>(d[B_CNT]), &ncx, &nex);
+                   d[B_AL], d[B_SUB], d[B_NSUB], d[B_CX], d[B_EX], d[B_EL], P<uint32_t>(d[B_CNT]), &ncx, &nex);
     if (st != PHZ_OK) return fin(st);
     hipError_t e = hipMemcpyAsync(sub_of, d[B_SUB].p, (size_t)nmem * 2, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(alle_of, d[B_AL].p, (size_t)nmem, hipMemcpyDeviceToHost, ctx->stream);

@@ -55,7 +55,7 @@ __device__ __forceinline__ int tab_find(const LinesTab &t, uint32_t blk) {
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long *hist) {
+__global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long *hist, unsigned int *out_of_range) {
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
     const uint32_t bx = blockIdx.x - T.blk0[sh_], gx = T.blk0[sh_ + 1] - T.blk0[sh_];
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long 
         const int a = L.read_as[r];
         const int b = a + AS_LDS_BINS / 2;
         if ((unsigned)b < (unsigned)AS_LDS_BINS) atomicAdd(&s_h[b], 1u);
-        else atomicAdd(&hist[(a + 32768) & 0xFFFF], 1ull);
+        else if (a >= -32768 && a < 32768) atomicAdd(&hist[a + 32768], 1ull);
+        else if (out_of_range) atomicOr(out_of_range, 1u);              // an alignment score outside int16: the caller refuses the input
     }
     __syncthreads();
     for (int j = threadIdx.x; j < AS_LDS_BINS; j += 256)
@@ -526,7 +527,7 @@ extern "C" int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *h
         LinesTab T;
         std::vector<uint32_t> grids;
         if (int s2 = upload_tab(ctx, &L, 1, as_hist_blocks, &T, &grids)) return s2;
-        hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, dh);
+        hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, dh, (unsigned int *)nullptr);
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = t.stop()) return s;
@@ -548,10 +549,16 @@ extern "C" int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int
         LinesTab T;
         std::vector<uint32_t> grids;
         if (int s2 = upload_tab(ctx, L.data(), n_shards, as_hist_blocks, &T, &grids)) return s2;
-        if (grids.back() > 0) hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, (unsigned long long *)hist);
+        if (int s2 = phz_reserve(ctx, ctx->scratch[0], 64)) return s2;
+        PHZ_HIP(ctx, hipMemsetAsync(ctx->scratch[0].p, 0, 4, ctx->stream));
+        if (grids.back() > 0) hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, (unsigned long long *)hist, (unsigned int *)ctx->scratch[0].p);
     }
     PHZ_HIP(ctx, hipGetLastError());
-    return t.stop();
+    unsigned int oor = 0;
+    if (n_shards > 0) PHZ_HIP(ctx, hipMemcpyAsync(&oor, ctx->scratch[0].p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (int s = t.stop()) return s;
+    if (oor) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "AS value outside int16");
+    return PHZ_OK;
 }
 
 extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1,

@@ -179,17 +179,16 @@ class Engine:
             dev = shards[0].calls.read_idx.device if shards else self.mapper.device
             hist = torch.zeros(_lib.PHZ_AS_BINS, dtype=torch.int64, device=dev)
             live = [sh for sh in shards if sh.calls.n]
-            for sh in live:
-                if sh.as_absmax is None:
-                    sh.as_absmax = int(sh.aln.abs().max())
-                if sh.as_absmax >= 32768:
-                    raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
-            if live and dev.type == "cuda":         # every shard of the BAM in one submission
+            if live and dev.type == "cuda":         # every shard of the BAM in one submission (it also refuses AS values outside int16)
                 arr = (_lib.phz_lines * len(live))(*[self._lines(sh, bam_index) for sh in live])
                 torch.cuda.synchronize(dev)
                 self.ctx.check(self.lib.phz_as_histogram_batch(self.ctx.h, arr, len(live), _p(hist)))
             else:
                 for sh in live:
+                    if sh.as_absmax is None:
+                        sh.as_absmax = int(sh.aln.abs().max())
+                    if sh.as_absmax >= 32768:
+                        raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
                     ln = self._lines(sh, bam_index)
                     self.ctx.check(self.lib.phz_as_histogram(self.ctx.h, C.byref(ln), _p(hist), _lib.PHZ_HOST))
             pdist.allreduce_sum_(hist)          # the quantile is over ALL chromosomes of this BAM
@@ -213,14 +212,10 @@ class Engine:
 
     def _pinned(self, name: str, count: int, dtype):
         """numpy array over page-locked host memory, kept per name and grown on demand (D2H at full PCIe rate)."""
+        from . import rowsdev
         dt = np.dtype(dtype)
         need = max(1, count) * dt.itemsize
-        pool = self.__dict__.setdefault("_pin", {})
-        t = pool.get(name)
-        if t is None or t.numel() < need:
-            t = torch.empty(need + need // 8 + 64, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-            pool[name] = t
-        return t.numpy()[:need].view(dt)[:count]
+        return rowsdev.pinned("tally_" + name, need).view(dt)[:count]       # process-wide pool: a new Engine does not page-lock again
 
     def _tally_genome(self) -> dict:
         """K_tally over every (chromosome, BAM) shard of this rank in ONE submission; results fetched into pinned host arrays."""

@@ -25,6 +25,9 @@
 #include <tuple>
 #include <utility>
 
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+
 struct dim3 {
     unsigned x, y, z;
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}

@@ -144,6 +144,49 @@ def test_fresh_seed_vs_oracle(mapper, oracle_build, tmp_path, seed, err):
     assert eng.phased == ph.phased and eng.phased > 50
 
 
+@pytest.mark.parametrize("seed,err,pairs,mbs", [(9101, 0.004, 30000, 15), (9102, 0.06, 14000, 6)])
+def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pairs, mbs):
+    """Few genes, thousands of reads over every het SNP, two BAMs with shared QNAMEs: read sets of thousands of QNAMEs per haplotype (the
+    workgroup / global-table paths of the read-set kernels), rows with tens of kilobytes of labels (the direct write path), long blocks and,
+    with 6 % base errors, conflicting components (weak-point split, brute force, stitching on the GPU).  Product vs the pinned oracle, and the
+    device row stage vs the host row stage byte for byte."""
+    import subprocess
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import phasing_oracle as po
+    from phaser_amd import synth
+    contigs = [("chr7", 159345973)]
+    chrom = "chr7"
+    v, gs, ge, w = synth.make_variants(chrom, 1, 400_000, 90, seed, n_genes=3)
+    bams = {"d1.bam": {}, "d2.bam": {}}
+    for bi, bam in enumerate(bams):
+        rb = synth.make_reads(v, gs, ge, w, pairs, seed + bi + 100, qname_prefix="q", err_rate=err)
+        rf = rb.select(synth.samtools_keep(rb, 255))
+        bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf_text = "\n".join(synth.vcf_lines([v])) + "\n"
+    got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs)
+    assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
+    host, heng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs, device_rows=False)
+    assert heng.rows_path == "host"
+    for name in OUTPUTS:
+        assert got[name] == host[name], name
+    pool, _, _ = po.load_vcf(vcf_text)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs)
+    for bam, per_chrom in bams.items():
+        texts = []
+        for c in pool:
+            tp = tmp_path / "t.tsv"; tp.write_text("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+            op = tmp_path / "c.tsv"
+            subprocess.run([os.path.join(oracle_build, "rvm_oracle"), "--variant_table", str(tp), "--baseq", "10", "--o", str(op)],
+                           input=per_chrom[c].encode(), check=True)
+            texts.append(op.read_text())
+        ph.add_bam(texts)
+    want = ph.finish()
+    for name in OUTPUTS:
+        assert canonical(name, got[name]) == canonical(name, want[name]), name
+    assert eng.phased == ph.phased and eng.phased > 20
+    assert eng.stats["rowsdev_n_big_segments"] > 0
+
+
 @pytest.mark.parametrize("src,mode", [("pipe_one", 0), ("pipe_one", 1), ("pipe_one", 2), ("pipe_noisy_c", 2), ("pipe_two", 1)])
 def test_phased_vcf_matches_reference(mapper, src, mode):
     """write_vcf (phaser.py:1661-1855): the phased VCF text equals what the reference wrote, byte for byte."""
