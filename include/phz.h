@@ -16,6 +16,13 @@
  *                        per-haplotype read lists of the block output loop (what SURVEY.md 8(b) calls phz_hap_counts)
  *   phz_components       phaser/phaser.py:1861-1882      build_haplotypes / :1985 build_haplotype_v3
  *
+ * Deliberately NOT exported (SURVEY.md 8(b) suggested them):
+ *   phz_load_variants    variant arrays travel with every call instead (6 B per SNP; nothing to keep resident between shards)
+ *   phz_hap_counts       folded into phz_tally: the per-(variant, allele, BAM) read lists it leaves in HBM are exactly what the
+ *                        haplotype-count loops of phaser/phaser.py:917-931 / :1086-1115 consume (phz_rowsdev_run, phz_rows_format)
+ *   *_cpu twins          the CPU restatement of this path is test infrastructure (oracle/), never part of the product library:
+ *                        every entry point here needs the GPU and fails loudly without one
+ *
  * Conventions
  *   - every function returns 0 (PHZ_OK) or a negative phz_status; nothing throws across the ABI.
  *   - a phz_ctx owns one HIP stream and scratch buffers; it is NOT thread-safe, use one per thread/GPU.

@@ -485,50 +485,85 @@ static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64
     // first member that holds the first record
     size_t b0 = 0;
     while (b0 + 1 < nb && M.blks[b0 + 1].dst <= first_record) b0++;
-    // probe(b): global uncompressed offset and refID of the first record that STARTS in member b or later members (up to 8 ahead)
-    auto probe = [&](size_t b, uint64_t *uoff, int32_t *ref) -> bool {
+    // probe(b): global uncompressed offset and refID of the first record that STARTS in member b or later members (up to 8 ahead).
+    //   1  found;   0  the members from b to the end of the file hold no record start (past the last record);
+    //  -1  no record boundary could be PROVEN in members b .. b+7 (records longer than the window, damaged members): the caller must
+    //      not guess -- a wrong "past this reference" would silently drop records -- and gives the file to the full, order-agnostic open.
+    // The window starts at three members and grows (x4, up to 256 members = 16 MB) while candidate chains run out of data, so records of
+    // tens of kilobytes (long reads, large aux fields) are still chained 12 deep.
+    auto probe = [&](size_t b, uint64_t *uoff, int32_t *ref) -> int {
         std::vector<uint8_t> tmp;
-        for (size_t b1 = b; b1 < nb && b1 < b + 8; b1++) {
-            tmp.clear();                                   // window = members b1 .. b1+2
-            for (size_t k = b1; k < nb && k < b1 + 3; k++) {
-                const size_t old = tmp.size();
-                tmp.resize(old + M.blks[k].isize);
-                if (M.blks[k].isize && !inflate_block(M.f + M.blks[k].off, M.blks[k].csize, tmp.data() + old, M.blks[k].isize)) return false;
-            }
-            if (b1 == b0) {                                // the true first record: no guess needed
-                const size_t p = first_record - M.blks[b0].dst;
-                if (p + 8 > tmp.size()) return false;      // a BAM without records
-                *uoff = first_record; *ref = rdi32(tmp.data() + p + 4);
-                return true;
-            }
-            const bool at_eof = b1 + 3 >= nb;
-            const size_t lim = M.blks[b1].isize;
-            for (size_t p = 0; p < lim; p++) {
-                size_t q = p; int ok = 0;
-                while (ok < 12) {
-                    const size_t nx = plausible_at(tmp.data(), tmp.size(), q, n_ref);
-                    if (!nx) break;
-                    ok++; q = nx;
-                    if (at_eof && q + 36 > tmp.size()) { ok = 12; break; }      // the chain ran into the end of the file
+        size_t b1 = b;
+        for (; b1 < nb && b1 < b + 8; b1++) {
+            for (size_t win = 3;; win *= 4) {
+                tmp.clear();                                   // window = members b1 .. b1+win-1
+                for (size_t k = b1; k < nb && k < b1 + win; k++) {
+                    const size_t old = tmp.size();
+                    tmp.resize(old + M.blks[k].isize);
+                    if (M.blks[k].isize && !inflate_block(M.f + M.blks[k].off, M.blks[k].csize, tmp.data() + old, M.blks[k].isize)) return -1;
                 }
-                if (ok >= 12) { *uoff = M.blks[b1].dst + p; *ref = rdi32(tmp.data() + p + 4); return true; }
+                if (b1 == b0) {                                // the true first record: no guess needed
+                    const size_t p = first_record - M.blks[b0].dst;
+                    if (p + 8 > tmp.size()) return 0;          // a BAM without records
+                    *uoff = first_record; *ref = rdi32(tmp.data() + p + 4);
+                    return 1;
+                }
+                const bool at_eof = b1 + win >= nb;
+                const size_t lim = M.blks[b1].isize;
+                bool short_of_data = false;
+                for (size_t p = 0; p < lim; p++) {
+                    size_t q = p; int ok = 0;
+                    while (ok < 12) {
+                        const size_t nx = plausible_at(tmp.data(), tmp.size(), q, n_ref);
+                        if (!nx) {
+                            // out of window with a header that still looks like a record: a larger window may complete the chain
+                            if (ok > 0 || q == p) {
+                                if (q + 36 <= tmp.size()) {
+                                    const int32_t bs = rdi32(tmp.data() + q);
+                                    if (bs >= 32 && bs <= (1 << 24) && q + 4 + (size_t)bs > tmp.size()) short_of_data = true;
+                                } else if (ok > 0) short_of_data = true;
+                            }
+                            break;
+                        }
+                        ok++; q = nx;
+                        if (at_eof && q + 36 > tmp.size()) { ok = 12; break; }      // the chain ran into the end of the file
+                    }
+                    if (ok >= 12) { *uoff = M.blks[b1].dst + p; *ref = rdi32(tmp.data() + p + 4); return 1; }
+                }
+                if (!short_of_data || at_eof || win >= 256) break;
             }
         }
-        return false;
+        return b1 >= nb ? 0 : -1;
     };
     const int32_t INF = 0x7fffffff;
-    // first member b in [b0, nb] whose first starting record has refID >= r (unmapped = -1 sorts last; no boundary = past the end)
+    bool uncertain = false;
+    // first member b in [b0, nb] whose first starting record has refID >= r (unmapped = -1 sorts last; no boundary = past the end).
+    // The refIDs met on the way must ascend with the member index: anything else is not a coordinate-sorted file.
+    std::vector<std::pair<size_t, int32_t>> samples;
     auto search = [&](int32_t r) -> size_t {
         size_t lo = b0, hi = nb;
         while (lo < hi) {
             const size_t m = (lo + hi) >> 1;
             uint64_t u; int32_t ref;
             int32_t key = INF;
-            if (probe(m, &u, &ref)) key = ref < 0 ? INF : ref;
+            const int pr = probe(m, &u, &ref);
+            if (pr < 0) { uncertain = true; return nb; }
+            if (pr > 0) key = ref < 0 ? INF : ref;
+            samples.emplace_back(m, key);
             if (key >= r) hi = m; else lo = m + 1;
         }
         return lo;
     };
+    // a header that declares another order settles it without a search
+    {
+        const int32_t l_text = rdi32(head.data() + 4);
+        const std::string_view text((const char *)head.data() + 8, (size_t)l_text);
+        const size_t hd = text.rfind("@HD", 0) == 0 ? 0 : std::string_view::npos;
+        if (hd == 0) {
+            const std::string_view line = text.substr(0, text.find('\n'));
+            if (line.find("SO:unsorted") != std::string_view::npos || line.find("SO:queryname") != std::string_view::npos) return PHZ_E_UNSUPPORTED;
+        }
+    }
     std::vector<size_t> begin_blk((size_t)n_ref + 1, nb);
     std::vector<char> want((size_t)n_ref, 0);
     for (int i = 0; i < n_ref; i++) {
@@ -545,6 +580,7 @@ static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64
     }
     laps.lap("reference boundary search");
     *first_record_out = first_record;
+    if (uncertain) return PHZ_E_UNSUPPORTED;
     if (!want_pieces) return PHZ_OK;
     // runs of consecutive wanted references -> byte ranges [u_begin, u_end) of the uncompressed stream, cut at record boundaries
     uint64_t total_u = M.total;
@@ -555,13 +591,17 @@ static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64
         const size_t bs = ref_bytes ? begin_blk[(size_t)i] : (i == 0 ? b0 : search(i));
         const size_t be = ref_bytes ? begin_blk[(size_t)j + 1] : search(j + 1);
         uint64_t u0 = first_record, u1 = total_u; int32_t rr;
+        if (uncertain) return PHZ_E_UNSUPPORTED;
         const size_t sb = bs > b0 ? bs - 1 : b0;                  // records of reference i may begin in the member before bs
-        if (sb > b0) { if (!probe(sb, &u0, &rr)) u0 = M.blks[sb].dst; }
-        if (be < nb) { if (!probe(be, &u1, &rr)) u1 = total_u; }
+        if (sb > b0) { const int pr = probe(sb, &u0, &rr); if (pr < 0) return PHZ_E_UNSUPPORTED; if (pr == 0) u0 = M.blks[sb].dst; }
+        if (be < nb) { const int pr = probe(be, &u1, &rr); if (pr < 0) return PHZ_E_UNSUPPORTED; if (pr == 0) u1 = total_u; }
         if (!pieces.empty() && u0 < pieces.back().u1) u0 = pieces.back().u1;       // the member before this run may belong to the previous piece
         if (u1 > u0) pieces.push_back({u0, u1});
         i = j + 1;
     }
+    std::sort(samples.begin(), samples.end());
+    for (size_t t = 1; t < samples.size(); t++)
+        if (samples[t].second < samples[t - 1].second) return PHZ_E_UNSUPPORTED;      // refIDs do not ascend along the file: not coordinate-sorted
     return PHZ_OK;
 }
 
@@ -624,7 +664,13 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
     std::vector<uint8_t> head;
     size_t first_record = 0;
     std::vector<BamPiece> pieces;
-    if (int st = bam_plan(M, ref_names, n_names, ref_bytes, max_refs, h != nullptr, refs, head, &first_record, pieces, laps)) { delete h; return st; }
+    if (int st = bam_plan(M, ref_names, n_names, ref_bytes, max_refs, h != nullptr, refs, head, &first_record, pieces, laps)) {
+        delete h;
+        // reference boundaries that cannot be proven (records longer than the probe window, a file that is not coordinate-sorted): the
+        // whole file through the order-agnostic full open -- slower, never lossy; the caller's reference mask still selects the records
+        if (st == PHZ_E_UNSUPPORTED && out) return phz_bam_open(path, threads, out);
+        return st;
+    }
     if (!h) return PHZ_OK;
     const size_t nb = M.blks.size();
     size_t b0 = 0;

@@ -3,9 +3,9 @@
 Only three things cross ranks, all tiny and latency-bound (single-shot collectives, no ring tuning):
   1. the AS histogram of each BAM (phaser.py:545-553 takes the quantile over ALL chromosomes)  -> all_reduce(SUM)
   2. the two noise counters (phaser.py:610-632 is global over variants)                        -> all_reduce(SUM)
-  3. per-chromosome output tables (counts, segment offsets, block arrays), gathered to rank 0 which assembles the files in
-     the reference's global order (engine.merge_fragments); the row TEXT itself (GBs at whole-genome scale) never enters a
-     collective: ranks spool it to files and rank 0 splices byte ranges                      -> gather_object of KBs
+  3. per-chromosome output tables (counts, byte ranges), gathered to rank 0 which assembles the files in the reference's
+     global order (engine.merge_fragments); the row TEXT itself (GBs at whole-genome scale) and the block arrays of write_vcf
+     never enter a collective: ranks spool them to files and rank 0 splices byte ranges     -> all_gather of an int64 table (KBs)
 Backend "nccl" (= RCCL over xGMI) on GPUs; the same code runs on "gloo" for the CPU tests.
 """
 from __future__ import annotations
@@ -121,54 +121,154 @@ def write_chunks(f, chunks):
             f.write(c)
 
 
-def gather_fragments(local: Dict[str, dict], spool_dir: Optional[str] = None) -> Optional[Dict[str, dict]]:
-    """-> on rank 0 the union of all ranks' {chrom: fragment}; None elsewhere.  Only the small tables travel through the
-    collective (counts, segment offsets, block arrays): every rank writes its row text to spool files on the node's filesystem
-    (spool_dir, default the system temp directory) and rank 0 receives (path, offset, length) spans, which it splices into the
-    output files in the reference's global order.  At whole-genome scale the text is ~1 GB (allele_config alone 680 MB) while the
-    tables are KBs -- the "final gather" of SURVEY.md 8(e)."""
+VCF_FIELDS = (("size", "int32"), ("var", "int32"), ("hap", "uint8"), ("cor", "int8"), ("stat", "float64"), ("stat_int", "uint8"), ("maxmaf", "int32"))
+COUNT_FIELDS = ("lines", "dropped", "phased", "allelic_rows", "n_blocks")
+
+
+def _coll_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _all_gather_i64(vec: List[int]) -> List[List[int]]:
+    """Variable-length int64 vectors of all ranks, through two fixed-layout tensor collectives (lengths, then padded payloads): the same
+    calls on nccl (= RCCL over xGMI) and gloo, no pickling."""
+    r, w = world()
+    dev = _coll_device()
+    n = torch.tensor([len(vec)], dtype=torch.int64, device=dev)
+    lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(w)]
+    dist.all_gather(lens, n)
+    lens = [int(x.item()) for x in lens]
+    m = max(1, max(lens))
+    mine = torch.zeros(m, dtype=torch.int64, device=dev)
+    if vec:
+        mine[:len(vec)] = torch.tensor(vec, dtype=torch.int64, device=dev)
+    parts = [torch.zeros(m, dtype=torch.int64, device=dev) for _ in range(w)]
+    dist.all_gather(parts, mine)
+    return [p[:k].cpu().tolist() for p, k in zip(parts, lens)]
+
+
+def gather_fragments(local: Dict[str, dict], spool_dir: Optional[str] = None, chrom_order: Optional[List[str]] = None) -> Optional[Dict[str, dict]]:
+    """-> on rank 0 the union of all ranks' {chrom: fragment}; None elsewhere (the "final gather" of SURVEY.md 8(e)).
+    What crosses the collective is a fixed-layout int64 table per rank (counts, byte ranges): every rank writes its row text -- ~1 GB at
+    whole-genome scale -- and the per-block arrays of write_vcf to ONE spool file in `spool_dir` (a directory all ranks of the node share;
+    default the system temp directory) and rank 0 receives (offset, length) ranges, which it splices into the output files in the
+    reference's global order.  A rank whose spool file rank 0 cannot see (no shared filesystem) sends the bytes through the process group
+    instead.  chrom_order: all chromosomes in VCF order (identical on every rank); chromosomes travel as indices into it."""
     r, w = world()
     if w == 1:
         return dict(local)
     import os
     import tempfile
-    import uuid
-    token = [uuid.uuid4().hex if r == 0 else None]
-    dist.broadcast_object_list(token, src=0)
+    import numpy as np
+    dev = _coll_device()
+    tok = torch.zeros(2, dtype=torch.int64, device=dev)
+    if r == 0:
+        tok = torch.tensor([int.from_bytes(os.urandom(7), "little"), os.getpid()], dtype=torch.int64, device=dev)
+    dist.broadcast(tok, src=0)
+    token = "%014x_%d" % (int(tok[0]), int(tok[1]))
     d = spool_dir or os.environ.get("PHZ_SPOOL_DIR") or tempfile.gettempdir()
-    path = os.path.join(d, "phz_spool_%s_rank%d.bin" % (token[0], r))
-    small: Dict[str, dict] = {}
+    path_of = lambda rank: os.path.join(d, "phz_spool_%s_rank%d.bin" % (token, rank))
+    if chrom_order is None:
+        raise ValueError("gather_fragments needs chrom_order (all chromosomes, same order on every rank) with more than one rank")
+    order = list(chrom_order)
+    index = {c: i for i, c in enumerate(order)}
+    # ---- spool file + table: [n_chroms, then per chromosome: index, counts..., per text field: n_spans, (bam, off, len)..., has_vcf, per vcf field (off, count)]
+    table: List[int] = [len(local)]
+    path = path_of(r)
+    SPOOL_FILES.append(path)
     with open(path, "wb") as f:
         off = 0
         for c, frag in local.items():
-            g = dict(frag)
+            table.append(index[c])
+            table += [int(frag.get(k, 0)) for k in COUNT_FIELDS]
             for k in TEXT_FIELDS:
-                # a field is a list of buffers; the BAM-keyed ones (k + "_bam") become one span per run of equal keys
                 keys = frag.get(k + "_bam")
-                spans = []; span_keys = []
+                spans = []                     # (bam key or -1, offset, length); adjacent buffers with the same key become one span
                 for i, b in enumerate(frag[k]):
                     n = len(b)
                     if n == 0:
                         continue
                     f.write(b)
-                    kb = keys[i] if keys is not None else None
-                    if spans and (keys is None or span_keys[-1] == kb):
-                        spans[-1] = FileSpan(path, spans[-1].off, spans[-1].n + n)
+                    kb = int(keys[i]) if keys is not None else -1
+                    if spans and spans[-1][0] == kb:
+                        spans[-1][2] += n
                     else:
-                        spans.append(FileSpan(path, off, n)); span_keys.append(kb)
+                        spans.append([kb, off, n])
                     off += n
-                g[k] = spans
-                if keys is not None:
-                    g[k + "_bam"] = span_keys
-            small[c] = g
-    bucket: List[Optional[dict]] = [None] * w if r == 0 else None
-    dist.gather_object((path, small), bucket, dst=0)
-    SPOOL_FILES.append(path)
+                table.append(len(spans))
+                for sp in spans:
+                    table += sp
+            v = frag.get("vcf")
+            table.append(1 if v is not None else 0)
+            if v is not None:
+                for name, dt in VCF_FIELDS:
+                    a = np.ascontiguousarray(v[name], dtype=dt)
+                    f.write(a.tobytes())
+                    table += [off, int(a.size)]
+                    off += a.nbytes
+        total = off
+    table.append(total)
+    tables = _all_gather_i64(table)
+    # ---- can rank 0 see every spool file?  (all ranks learn the answer: the senders must take part in the transfer)
+    seen = torch.ones(w, dtype=torch.int64, device=dev)
+    if r == 0:
+        for k in range(1, w):
+            try:
+                ok = os.path.getsize(path_of(k)) == tables[k][-1]
+            except OSError:
+                ok = False
+            seen[k] = 1 if ok else 0
+    dist.broadcast(seen, src=0)
+    seen = seen.cpu().tolist()
+    for k in range(1, w):
+        if seen[k]:
+            continue
+        nbytes = tables[k][-1]
+        if r == k:
+            buf = torch.from_numpy(np.fromfile(path, dtype=np.uint8)) if nbytes else torch.zeros(0, dtype=torch.uint8)
+            for lo in range(0, nbytes, 1 << 28):
+                dist.send(buf[lo:lo + (1 << 28)].to(dev), dst=0)
+        elif r == 0:
+            lp = os.path.join(d, "phz_spool_%s_rank%d.recv.bin" % (token, k))
+            SPOOL_FILES.append(lp)
+            with open(lp, "wb") as f:
+                for lo in range(0, nbytes, 1 << 28):
+                    t = torch.empty(min(1 << 28, nbytes - lo), dtype=torch.uint8, device=dev)
+                    dist.recv(t, src=k)
+                    f.write(t.cpu().numpy().tobytes())
+            path_of = (lambda rank, _p=path_of, _k=k, _lp=lp: _lp if rank == _k else _p(rank))
     if r != 0:
         return None
     merged: Dict[str, dict] = {}
-    for p_, part in bucket:
-        merged.update(part)
+    for k in range(w):
+        t = tables[k]; p = 0
+        nchr = t[p]; p += 1
+        src = path_of(k)
+        for _ in range(nchr):
+            c = order[t[p]]; p += 1
+            g = {"chrom": c}
+            for name in COUNT_FIELDS:
+                g[name] = t[p]; p += 1
+            for name in TEXT_FIELDS:
+                ns = t[p]; p += 1
+                spans = []; skeys = []
+                for _s in range(ns):
+                    kb, o, n = t[p], t[p + 1], t[p + 2]; p += 3
+                    spans.append(FileSpan(src, o, n)); skeys.append(kb)
+                g[name] = spans
+                if name in ("allelic", "single_ase", "single_hap"):
+                    g[name + "_bam"] = skeys
+            has_vcf = t[p]; p += 1
+            g["vcf"] = None
+            if has_vcf:
+                v = {}
+                with open(src, "rb") as f:
+                    for name, dt in VCF_FIELDS:
+                        o, cnt = t[p], t[p + 1]; p += 2
+                        f.seek(o)
+                        v[name] = np.frombuffer(f.read(cnt * np.dtype(dt).itemsize), dtype=dt)
+                g["vcf"] = v
+            merged[c] = g
     return merged
 
 
@@ -180,7 +280,10 @@ def cleanup_spool():
     import os
     r, w = world()
     if w > 1:
-        dist.barrier()
+        try:
+            dist.barrier()
+        except Exception:              # a rank that failed must still remove its files
+            pass
     while SPOOL_FILES:
         try:
             os.remove(SPOOL_FILES.pop())

@@ -317,7 +317,7 @@ class Engine:
         t1 = _t.perf_counter()
         local = self._fragments(noise)
         t2 = _t.perf_counter()
-        frags = pdist.gather_fragments(local, getattr(self, "spool_dir", None))
+        frags = pdist.gather_fragments(local, getattr(self, "spool_dir", None), self.all_chroms)
         self.stats.update({"tally_s": t1 - t0, "fragments_s": t2 - t1})
         self.noise = noise
         if frags is None:

@@ -240,6 +240,59 @@ def test_region_open_equals_full_decode(tmp_path):
     assert abs(sum(w.values()) - os.path.getsize(bam)) < 70000            # everything but the header member and the EOF marker
 
 
+def _long_read_bam(path, refs, per_ref, L, shuffle=False):
+    """records of L bases (tens of kilobytes each): (ref_id, pos) ascending unless shuffle"""
+    import random
+    import struct
+    from phaser_amd import bamio
+    rng = random.Random(5)
+    recs = []
+    for rid, n in enumerate(per_ref):
+        for i in range(n):
+            seq = "".join(rng.choice("ACGT") for _ in range(64)) * (L // 64)
+            recs.append({"ref_id": rid, "pos": 1000 + 37 * i, "mapq": 60, "flag": 0, "tlen": 0, "qname": "lr%d_%d" % (rid, i), "cigar": [(0, len(seq))],
+                         "seq": seq, "qual": [30 + (i + k) % 10 for k in range(len(seq))], "tags": {"AS": 100 + i % 50}})
+    if shuffle:
+        rng.shuffle(recs)
+    bamio.write_bam(path, refs, recs)
+    return recs
+
+
+def test_region_open_with_records_larger_than_the_probe_window(tmp_path):
+    """Records of ~30 KB and ~100 KB (long reads): the reference-boundary probe needs 12 chained records, i.e. far more than the three
+    BGZF members it starts with -- the window grows, and where a boundary cannot be proven the file goes through the full open.  Either
+    way the chromosome-restricted open returns exactly the shards of the full decode (nothing may be dropped silently)."""
+    from phaser_amd import _lib, bamio
+    _lib.build()
+    refs = [("chrA", 5_000_000), ("chrB", 5_000_000), ("chrC", 5_000_000)]
+    for L, per_ref in ((20_032, (40, 55, 30)), (66_048, (14, 9, 16))):
+        bam = str(tmp_path / ("long%d.bam" % L))
+        _long_read_bam(bam, refs, per_ref, L)
+        full = bamio.shards_from_bam_native(bam, {}, 0, False, False, 0.0, threads=2)
+        assert {c: s.n for c, s in full.items()} == {r[0]: n for r, n in zip(refs, per_ref)}
+        for sub in ({"chrA"}, {"chrB"}, {"chrC"}, {"chrA", "chrC"}, {"chrB", "chrC"}):
+            got = bamio.shards_from_bam_native(bam, {}, 0, False, False, 0.0, chroms=set(sub), threads=2)
+            assert set(got) == sub
+            for c in got:
+                for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "aln_score"):
+                    assert torch.equal(getattr(got[c], f), getattr(full[c], f)), (L, sub, c, f)
+
+
+def test_region_open_of_an_unsorted_file_takes_the_full_open(tmp_path):
+    """A file whose records are not grouped by reference cannot be cut at reference boundaries: the chromosome-restricted open must see
+    every record of the wanted reference (the refIDs met by the boundary search do not ascend -> full, order-agnostic open), and the decoder
+    then refuses the file for being unsorted exactly as it does after a full open."""
+    from phaser_amd import _lib, bamio
+    _lib.build()
+    refs = [("chrA", 5_000_000), ("chrB", 5_000_000)]
+    bam = str(tmp_path / "shuffled.bam")
+    _long_read_bam(bam, refs, (60, 60), 4_096, shuffle=True)
+    with pytest.raises((_lib.PhzError, SystemExit)):
+        bamio.shards_from_bam_native(bam, {}, 0, False, False, 0.0, threads=2)
+    with pytest.raises((_lib.PhzError, SystemExit)):
+        bamio.shards_from_bam_native(bam, {}, 0, False, False, 0.0, chroms={"chrB"}, threads=2)
+
+
 def test_empty_qname_record(tmp_path):
     """l_read_name == 1 (just the NUL): the name is the empty string; it interns like any other name (this used to read the back of
     an empty arena in the interner)."""

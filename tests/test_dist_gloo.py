@@ -20,7 +20,7 @@ from conftest import GOLD, REPO, gz_text
 from helpers import OUTPUTS, canonical
 
 
-def _worker(rank, world, port, result_path):
+def _worker(rank, world, port, result_path, private_spool=False):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,6 +55,8 @@ def _worker(rank, world, port, result_path):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from helpers import stub_gpu_stages
     stub_gpu_stages(eng, saved)
+    if private_spool:                     # no directory shared by the ranks: rank 0 cannot see the other spool files, the bytes travel through the group
+        eng.spool_dir = os.path.join(os.path.dirname(result_path), "spool%d" % rank); os.makedirs(eng.spool_dir, exist_ok=True)
     out = eng.finish()                    # all-reduce of the noise counters + gather of the fragments inside
     if rank == 0:
         json.dump({"out": out, "cutoffs": cutoffs, "noise": eng.noise, "log": eng.log, "phased": eng.phased}, open(result_path, "w"))
@@ -64,10 +66,13 @@ def _worker(rank, world, port, result_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_reduce_gather_merge(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("private_spool", [False, True])
+def test_two_rank_reduce_gather_merge(tmp_path, private_spool):
+    port = 29500 + (os.getpid() % 2000) + (7 if private_spool else 0)
     res = str(tmp_path / "res.json")
-    mp.spawn(_worker, args=(2, port, res), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, res, private_spool), nprocs=2, join=True)
+    if private_spool:
+        assert not os.listdir(str(tmp_path / "spool0")) and not os.listdir(str(tmp_path / "spool1")), "spool files left behind"
     r = json.load(open(res))
     d = os.path.join(GOLD, "pipe_two")
     assert r["phased"] == 229

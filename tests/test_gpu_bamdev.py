@@ -148,6 +148,29 @@ def test_device_shards_equal_host_shards(ctx, tmp_path):
                 assert hi[c].names == di[c].names
 
 
+def test_device_out_of_memory_falls_back_to_the_host_decoder(ctx, tmp_path, monkeypatch):
+    """An allocation failure of the device BAM path (HBM short because earlier BAMs' shards stay resident) is PHZ_E_NOMEM at every
+    allocation: the loader answers None, the host decoder takes the file, and the ctx carries no stale HIP error into the next launch
+    (K_map right after it).  PHZ_BAMDEV_FORCE_NOMEM takes the out-of-memory exit without exhausting the GPU."""
+    import torch
+    from phaser_amd import bamio
+    from phaser_amd.mapper import Mapper
+    path = _two_chrom_bam(tmp_path)
+    monkeypatch.setenv("PHZ_BAMDEV_FORCE_NOMEM", "1")
+    assert bamio.shards_from_bam_device(ctx, path, {}, 255, True, True, 0.0) is None
+    monkeypatch.delenv("PHZ_BAMDEV_FORCE_NOMEM")
+    hi = {}; di = {}
+    host = bamio.shards_from_bam_native(path, hi, 255, True, True, 0.0, threads=2)
+    dev = bamio.shards_from_bam_device(ctx, path, di, 255, True, True, 0.0)       # the same ctx right after the failure
+    assert dev is not None
+    _same(host, dev, "after a forced out-of-memory")
+    m = Mapper(0, ctx=ctx)
+    c = next(iter(dev))
+    vpos = torch.arange(1000, 2_000_000, 5000, dtype=torch.int32)
+    calls = m.map(dev[c], vpos, 10)                                                 # a kernel launch + its error check on this ctx
+    assert calls.n >= 0
+
+
 def test_device_decoder_odd_records(ctx, tmp_path):
     """SEQ '*', QUAL missing, IUPAC bases, hard clips, padding, CIGAR longer than SEQ, no AS, AS in a wide type, B-array tags."""
     from phaser_amd import bamio

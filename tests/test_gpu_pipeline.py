@@ -353,12 +353,17 @@ def test_cli_blacklist_beds_match_reference(tmp_path):
     assert any(int(r[6]) > 0 for r in ase)           # some block really lost a variant to the haplotype-count blacklist
 
 
-def test_two_ranks_one_gpu_real_kernels(tmp_path):
-    """The multi-rank path with REAL kernels on both ranks (they share the one GPU of the box; PHZ_DIST_BACKEND=gloo carries the
-    collectives): chromosomes LPT-assigned, per-BAM AS histograms all-reduced, noise counters all-reduced, row text spooled to
-    files and spliced by rank 0.  The assembled files must be what the reference wrote (fixture pipe_two: two BAMs with shared
-    QNAMEs, two chromosomes -> one chromosome per rank)."""
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_one_gpu_real_kernels(tmp_path, backend):
+    """The multi-rank path with REAL kernels on both ranks: chromosomes LPT-assigned, per-BAM AS histograms all-reduced, noise counters
+    all-reduced, the fragment tables all-gathered as int64 tensors, row text spooled to files and spliced by rank 0.  The assembled files must be
+    what the reference wrote (fixture pipe_two: two BAMs with shared QNAMEs, two chromosomes -> one chromosome per rank).
+    backend gloo: the two ranks share the one GPU of the box; backend nccl (= RCCL over xGMI): one rank per GPU, runs where two GPUs are
+    visible and is skipped on a one-GPU box."""
     import subprocess
+    import torch
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL path needs two GPUs")
     d = os.path.join(GOLD, "pipe_two")
     bams = []
     for b in ("t1", "t2"):
@@ -370,7 +375,7 @@ def test_two_ranks_one_gpu_real_kernels(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PHZ_DIST_BACKEND="gloo", PYTHONPATH=REPO)
+                   PHZ_DIST_BACKEND=backend, PYTHONPATH=REPO)
         cmd = [sys.executable, "-m", "phaser_amd.phaser", "--vcf", os.path.join(d, "in.vcf"), "--bam", ",".join(bams), "--sample", "S1",
                "--mapq", "255", "--baseq", "10", "--paired_end", "1", "--o", prefix, "--write_vcf", "0", "--threads", "2"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))

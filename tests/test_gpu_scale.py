@@ -1,7 +1,9 @@
 """GPU parity at the shapes of BASELINE.json configs[2] (whole genome: 22 autosomes, ~80M records, ~1.5M het SNPs, one BAM) and
-configs[3] (the same sample with 4 BAMs whose QNAMEs collide).  No oracle run exists at these sizes, so each test combines
-  * a bit-exact oracle check of K_map on the first 200k records of EVERY chromosome shard (het-SNP windows 3x denser than on the
-    configs[1] shard, all shards of a BAM through one batched submission),
+configs[3] (the same sample with 4 BAMs whose QNAMEs collide).  Each test combines
+  * a bit-exact check of K_map's call list for EVERY record of EVERY chromosome shard against the C mapper oracle run on all host
+    cores (all shards of a BAM through one batched submission),
+  * configs[2]: the five files of the largest chromosome (chr1, ~1.7M call lines) against the pinned phasing oracle at full size
+    (the whole genome, one oracle process per chromosome, is tools/full_parity_c3.py; its log is under profiles/),
   * the size-independent relations that tie the five output files together, over all chromosomes, and
   * full equality with the pinned phasing oracle on a 2 % scale replica of the same plan (22 chromosomes: the global merge order
     of blocks / allelic_counts / singleton rows across chromosomes and BAMs, SURVEY.md 8.1 rules 2 and 4).
@@ -65,6 +67,27 @@ def check_oracle_prefix(oracle_build, eng, vsets, samples, plan):
             assert calls.n == m or int(got_r[m]) >= len(smp)          # the next call belongs to a record past the prefix
 
 
+def check_oracle_all_records(oracle_build, eng, plan, n_bams):
+    """Every record of every shard: the shard is regenerated from its seeds with a host copy of all records (one chromosome at a time keeps
+    the host memory at one shard), the C oracle maps it on all host cores, the call list must equal K_map's."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from full_parity_c3 import oracle_all_records
+    from phaser_amd import dist as pdist, workloads
+    cores = max(1, pdist.effective_cpus())
+    total = 0
+    for chrom, ln, n_snps, n_rec, seed in plan:
+        for b in range(n_bams):
+            v, sh, smp = workloads.make_shard(chrom, ln, n_snps, n_rec, seed, "cuda:0", keep_sample=n_rec, read_seed=seed + 1 + 7919 * b)
+            o_r, o_v, o_c = oracle_all_records(oracle_build, smp, v.pos.numpy(), 10, cores)
+            calls = eng.shards[chrom][b].calls
+            assert calls.n == len(o_r), (chrom, b)
+            assert np.array_equal(calls.read_idx.cpu().numpy(), o_r) and np.array_equal(calls.var_idx.cpu().numpy(), o_v) and \
+                np.array_equal(calls.code.cpu().numpy(), o_c), (chrom, b)
+            total += len(smp)
+            del sh, smp
+    return total
+
+
 def check_invariants(eng, out, plan, n_bams):
     rows = lambda name: [l.split("\t") for l in out[name].split("\n")[1:] if l]
     kept = 0
@@ -120,16 +143,32 @@ def check_replica_vs_oracle(mapper, plan_small, n_bams, min_phased=1000):
     assert eng.phased == ph.phased and eng.phased > min_phased
 
 
-def test_whole_genome_one_bam(mapper, oracle_build):
+def test_whole_genome_one_bam(mapper, oracle_build, tmp_path):
     """configs[2]: 22 chromosome shards, 80M records, 1.5M het SNPs."""
     from phaser_amd import workloads
     plan = workloads.genome_plan()
-    vsets, shards, samples = build(plan, 1, PREFIX)
+    import hashlib
+    import subprocess
+    vsets, shards, samples = build(plan, 1, 0)
     eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
+    assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
     assert sum(sh.n for sh in shards[0].values()) > 79_000_000 and eng.vs.het_count > 1_400_000
-    check_oracle_prefix(oracle_build, eng, vsets, samples, plan)
+    # chr1 at full size through the pinned phasing oracle (a separate process, ~1.5 minutes) while the mapper check below runs
+    big = plan[0][0]
+    calls_tsv = tmp_path / "chr1.calls.tsv"
+    calls_tsv.write_text(call_text(vsets[big], shards[0][big], eng.shards[big][0].calls))
+    worker = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "oracle_chrom_worker.py"), str(calls_tsv), "10"], stdout=subprocess.PIPE, text=True)
+    assert check_oracle_all_records(oracle_build, eng, plan, 1) > 79_000_000
     check_invariants(eng, out, plan, 1)
-    del eng, out, shards, samples
+    one, got1 = run_engine(mapper, {big: vsets[big]}, [{big: shards[0][big]}], plan[:1], names=["bam0"])
+    h = hashlib.sha256()
+    for name in OUTPUTS:
+        h.update(canonical(name, got1[name]).encode())
+    res = worker.communicate()[0].split()
+    assert worker.returncode == 0
+    assert int(res[0]) == one.phased and res[2] == h.hexdigest(), "chr1 at full size: the five files differ from the phasing oracle"
+    assert one.phased > 50_000
+    del eng, out, shards, samples, one, got1
     torch.cuda.empty_cache()
     check_replica_vs_oracle(mapper, workloads.genome_plan(scale=0.02), 1)
 
@@ -139,9 +178,10 @@ def test_whole_genome_four_bams_shared_qnames(mapper, oracle_build):
     cross-BAM merge (last BAM owns a QNAME's read_vars list, phaser.py:558-581) runs on every chromosome."""
     from phaser_amd import workloads
     plan = workloads.genome_plan(total_records=20_000_000)
-    vsets, shards, samples = build(plan, 4, PREFIX // 4)
+    vsets, shards, samples = build(plan, 4, 0)
     eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
-    check_oracle_prefix(oracle_build, eng, vsets, samples, plan)
+    assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
+    assert check_oracle_all_records(oracle_build, eng, plan, 4) > 79_000_000
     check_invariants(eng, out, plan, 4)
     del eng, out, shards, samples
     torch.cuda.empty_cache()
