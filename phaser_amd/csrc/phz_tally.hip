@@ -2,24 +2,26 @@
 // (chromosome, BAM) shards in one submission (variant and QNAME ids are offset per chromosome into one index space, so a whole
 // genome is one call and nothing ever pairs across chromosomes):
 //   k_as_hist      :545-553   AS column histogram (host turns it into numpy.percentile's value)
-//   k_line         :1287-1328 process_mapping_result: AS cutoff, allele class, per-variant line counters,
-//                             first-appearance index; the "last BAM wins" owner of every QNAME's read_vars list
-//                             (:576-581, stale-variable quirk); lines per QNAME and per (variant, allele, BAM) read list
-//   k_items + k_qsort         set construction :636-640: lines are grouped per QNAME by a counting sort over the dense QNAME
-//                             ids (count in k_line, exclusive scan, scatter), each tiny group sorted and de-duplicated in place
-//   k_pairs        :1265-1285 + :1602-1632: every QNAME contributes one count to cell (class_a, class_b) of
-//                             every variant pair it touches -- the nine set intersections of
-//                             test_variant_connection, accumulated for all pairs at once (LDS hash -> global hash)
-//   k_edge_*                  edge list in (a, b) order: counting sort by a over the used hash slots, tiny groups sorted by b
-//   read lists     :1318, :917-931, :1086-1115: the QNAMEs of every (variant, allele, BAM) in line order, as one CSR
-//                             (stable radix sort of the line keys on their significant bits)
+//   k_line         :1287-1328 process_mapping_result: AS cutoff, allele class, per-variant line counters, first-appearance index, lines per
+//                             QNAME and per (variant, allele, BAM) read list; the QNAMEs that own at least one kept line are collected
+//                             on the way (only they get a group: a genome has 40M QNAME ids and 8M of them with lines)
+//   k_items                   set construction :636-640: the lines of a QNAME are gathered into its group (ranges handed out by a scan over
+//                             the touched QNAMEs only); read-list entries are placed into their (variant, allele, BAM) list
+//   k_groups       :558-581, :1265-1285  one thread per QNAME: its (tiny) group sorted, the owner BAM of its read_vars list ("last BAM
+//                             wins", stale-variable quirk), its first ref/alt line, the connectivity-map rank of its variants, the
+//                             distinct (variant, class) items and the per-variant distinct-QNAME counters
+//   k_pairs        :1602-1632 every QNAME contributes one count to cell (class_a, class_b) of every variant pair it touches -- the nine set
+//                             intersections of test_variant_connection for all pairs at once (LDS hash -> global hash)
+//   k_edge_*                  edge list in (a, b) order: counting sort by a over the USED hash slots, tiny groups sorted by b; the table is
+//                             cleaned slot by slot while it is read (no per-call memset of a 400 MB table)
+//   k_rl_sort*     :1318, :917-931, :1086-1115  read lists: the entries of every list put into line order (they were placed by atomics)
 //   k_components   :1861-1882/:1985-1998 connected components (lock-free union-find)
-// Integer work, hand-written kernels; the only library call left is rocPRIM's stable radix sort for the read lists.
+// Integer work, hand-written kernels and primitives only (phz_sort.h).  Nothing is sized or cleared by the number of QNAME ids per call
+// except two persistent arrays (lines per QNAME -- returned to zero by the kernels themselves -- and the group base per QNAME).
 #include <cstring>
 #include "phz_internal.h"
-#include "phz_scan.h"
+#include "phz_sort.h"
 #include "phz_uf.h"
-#include <rocprim/rocprim.hpp>
 
 namespace {
 
@@ -54,6 +56,15 @@ __device__ __forceinline__ int tab_find(const LinesTab &t, uint32_t blk) {
     }
     return lo;
 }
+// BAM of a line of the call's line space (shards ordered by line_base)
+__device__ __forceinline__ int bam_of_line(const LinesTab &t, uint32_t g) {
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) {
+        const int m = (lo + hi + 1) >> 1;
+        if ((uint64_t)t.L[m].line_base <= g) lo = m; else hi = m - 1;
+    }
+    return t.L[lo].bam;
+}
 
 __global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long *hist, unsigned int *out_of_range) {
     const int sh_ = tab_find(T, blockIdx.x);
@@ -86,15 +97,15 @@ constexpr int LINES_PER_BLOCK = 2048;
 
 struct LineOut {
     const uint8_t *a0, *a1;
-    uint8_t *line_cls;
+    uint8_t *line_cls;               // [n_lines] 0 ref / 1 alt / 2 other / 255 dropped by the AS cutoff
+    uint32_t *line_q;                // [n_lines] QNAME id of the line in the call's id space
     int32_t *var_count;              // [nv*3]
     unsigned long long *var_first;   // [nv]
     uint32_t *rl_cnt;                // [nv*2*nb] kept ref/alt lines per (variant, allele, BAM)
-    int32_t *qid_owner;              // [nq] last BAM holding a ref/alt line of the QNAME
-    uint32_t *qid_first;             // [nq] first ref/alt line of the QNAME
-    uint32_t *qcount;                // [nq] kept lines of the QNAME
-    unsigned long long *n_kept;
-    int nb, single_bam;
+    uint32_t *qcount;                // [nq] kept lines of the QNAME (persistent, all zero between calls)
+    uint32_t *touched;               // QNAMEs with at least one kept line, in no particular order
+    unsigned long long *counters;    // [3] kept lines, [6] touched QNAMEs
+    int nb;
 };
 
 __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
@@ -103,13 +114,15 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
     const uint32_t bx = blockIdx.x - T.blk0[sh_];
     __shared__ int s_cnt[TW * 3];
     __shared__ unsigned long long s_first[TW];
+    __shared__ uint32_t s_new[LINES_PER_BLOCK];
     __shared__ int s_vbase;
-    __shared__ unsigned int s_kept;
+    __shared__ unsigned int s_kept, s_nnew;
+    __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)bx * LINES_PER_BLOCK;
     for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
     for (int j = tid; j < TW; j += 256) s_first[j] = ~0ull;
-    if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
+    if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; s_nnew = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
     __syncthreads();
     const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;       // a little room below (mate pairs / overlapping records)
     unsigned int kept = 0;
@@ -137,11 +150,8 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
             if (cls < 2) atomicAdd(&O.rl_cnt[((int64_t)v * 2 + cls) * O.nb + L.bam], 1u);
         }
         const uint32_t q = L.qid_base + (uint32_t)L.read_qid[r];
-        atomicAdd(&O.qcount[q], 1u);
-        if (cls < 2) {
-            if (!O.single_bam) atomicMax(&O.qid_owner[q], L.bam);
-            atomicMin(&O.qid_first[q], (uint32_t)g);      // first ref/alt line of the QNAME over all BAMs
-        }
+        O.line_q[g] = q;
+        if (atomicAdd(&O.qcount[q], 1u) == 0u) s_new[atomicAdd(&s_nnew, 1u)] = q;      // the first kept line of the QNAME (in this call)
     }
     if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
@@ -157,127 +167,141 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
         const unsigned long long f = s_first[j];
         if (f != ~0ull) atomicMin(&O.var_first[vbase + j], f);
     }
-    if (tid == 0 && s_kept) atomicAdd(O.n_kept, (unsigned long long)s_kept);
+    if (tid == 0) {
+        if (s_kept) atomicAdd(&O.counters[3], (unsigned long long)s_kept);
+        s_base = s_nnew ? atomicAdd(&O.counters[6], (unsigned long long)s_nnew) : 0ull;       // one global atomic per workgroup
+    }
+    __syncthreads();
+    for (unsigned j = tid; j < s_nnew; j += 256) O.touched[s_base + j] = s_new[j];
 }
 
-// item = qid:32 | var:28 | cls:2 | spare:1 | linked:1, scattered into the QNAME's slot range [qoff[q], qoff[q+1]);
-// read-list sort key = ((variant * 2 + allele) * nb + bam) for kept ref/alt lines, rl_drop for every other line
-__global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_cls, const int32_t *qid_owner, const uint32_t *qoff,
-                                               uint32_t *qcount, uint64_t *items, uint32_t *qid_vmin, int32_t *qid_vmax,
-                                               uint32_t *rl_key, int32_t *rl_val, int nb, int single_bam, uint32_t rl_drop) {
+// group of every touched QNAME: its line count (the counter goes back to zero and serves as the fill cursor of k_items)
+__global__ __launch_bounds__(256) void k_group_plan(int64_t nt, const uint32_t *touched, uint32_t *qcount, uint32_t *cnt_t) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt) return;
+    const uint32_t q = touched[i];
+    cnt_t[i] = qcount[q]; qcount[q] = 0u;
+}
+__global__ __launch_bounds__(256) void k_group_base(int64_t nt, const uint32_t *touched, const uint32_t *base_t, uint32_t *qbase) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nt) qbase[touched[i]] = base_t[i];
+}
+
+// item = variant:28 | class:2 | line:32 (sorts by variant, class, line); read-list entry = line:32 | chromosome-local QNAME id:32
+__device__ __forceinline__ uint64_t item_pack(uint32_t v, uint32_t cls, uint32_t g) { return ((uint64_t)v << 34) | ((uint64_t)cls << 32) | g; }
+__global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_cls, const uint32_t *line_q, const uint32_t *qbase, uint32_t *qcount, uint64_t *items,
+                                               const uint32_t *rl_start, uint32_t *rl_fill, uint64_t *rl_tmp, uint32_t *rl_list, int nb) {
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
     const int64_t i = (int64_t)(blockIdx.x - T.blk0[sh_]) * 256 + threadIdx.x;
     if (i >= L.n) return;
     const int64_t g = L.line_base + i;
     const uint8_t cls = line_cls[g];
-    if (cls == 255) { rl_key[g] = rl_drop; rl_val[g] = 0; return; }
-    const int r = L.read_idx[i];
-    const int32_t ql = L.read_qid[r];
-    const uint32_t q = L.qid_base + (uint32_t)ql;
-    const uint32_t linked = (cls < 2 && (single_bam || qid_owner[q] == L.bam)) ? 1u : 0u;
+    if (cls == 255) return;
+    const uint32_t q = line_q[g];
     const uint32_t v = (uint32_t)(L.var_idx[i] + L.var_base);
-    const uint64_t k = ((uint64_t)q << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;
-    if (linked) { atomicMin(&qid_vmin[q], v); atomicMax(&qid_vmax[q], (int32_t)v); }     // span of the surviving read_vars list
-    const uint32_t old = atomicSub(&qcount[q], 1u);            // counts back down to zero: the array is clean for the next call
-    items[qoff[q] + old - 1] = k;
-    rl_key[g] = cls < 2 ? (uint32_t)((v * 2u + cls) * (uint32_t)nb + (uint32_t)L.bam) : rl_drop;
-    rl_val[g] = ql;
-}
-
-// one thread per QNAME: sort its (tiny) item group, keep the LAST of every (variant, class) run (it carries linked = max over
-// the run, because linked is the lowest key bit); the others become KEY_DROPPED and are skipped downstream
-__global__ __launch_bounds__(256) void k_qsort(const uint32_t *qoff, int64_t nq, uint64_t *items) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq) return;
-    const uint32_t lo = qoff[q], hi = qoff[q + 1];
-    if (hi - lo < 2) return;
-    for (uint32_t i = lo + 1; i < hi; i++) {
-        const uint64_t x = items[i];
-        uint32_t j = i;
-        while (j > lo) {
-            const uint64_t y = items[j - 1];
-            if (y <= x) break;
-            items[j] = y; j--;
-        }
-        items[j] = x;
-    }
-    uint64_t cur = items[lo];
-    for (uint32_t i = lo; i + 1 < hi; i++) {
-        const uint64_t nx = items[i + 1];
-        if ((nx >> 2) == (cur >> 2)) items[i] = KEY_DROPPED;
-        cur = nx;
+    items[qbase[q] + atomicAdd(&qcount[q], 1u)] = item_pack(v, cls, (uint32_t)g);
+    if (cls < 2) {
+        const uint32_t e = (v * 2u + cls) * (uint32_t)nb + (uint32_t)L.bam;
+        const uint32_t p = rl_start[e] + atomicAdd(&rl_fill[e], 1u);
+        rl_tmp[p] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)(q - L.qid_base);
+        rl_list[p] = e;
     }
 }
 
-// Overlap-dictionary key order (SURVEY.md 8.1 rule 4, phaser.py:1271-1283): a variant's rank is the smallest
-// (first ref/alt line of the QNAME, line) over the surviving read_vars entries of QNAMEs that hold >= 2 distinct
-// variants; variants that never get a key keep the maximum value.  LDS window like k_line.
-__global__ __launch_bounds__(256) void k_rank(LinesTab T, const uint8_t *line_cls, const int32_t *qid_owner,
-                                              const uint32_t *qid_first, const uint32_t *qid_vmin, const int32_t *qid_vmax,
-                                              unsigned long long *var_rank, int single_bam) {
-    const int sh_ = tab_find(T, blockIdx.x);
-    const LinesDev L = T.L[sh_];
-    const uint32_t bx = blockIdx.x - T.blk0[sh_];
+// One thread per QNAME group.  Sorts the group (insertion sort: a QNAME owns a handful of lines), then
+//   owner  = last BAM holding a ref/alt line of the QNAME (the stale-variable overwrite at phaser.py:578: a later BAM replaces the read_vars list)
+//   first  = first ref/alt line of the QNAME over all BAMs
+//   linked = ref/alt line of the owner BAM (an entry of the surviving read_vars list)
+//   rank   : overlap-dictionary key order (SURVEY.md 8.1 rule 4, phaser.py:1271-1283): for QNAMEs whose surviving list holds >= 2 distinct
+//            variants, every variant gets (first << 32 | its first linked line) as a candidate for its smallest key
+//   the distinct (variant, class) items (the LAST of a run carries linked = max over the run), written back compacted as
+//            variant:28 << 4 | class << 2 | linked, and the per-variant distinct-QNAME counters
+struct GroupOut {
+    uint32_t *qcount; uint64_t *items; uint32_t *cnt_t; const uint32_t *base_t, *touched;
+    unsigned long long *var_rank; int32_t *var_distinct; unsigned long long *counters;      // [0] distinct items
+    int single_bam;
+};
+__global__ __launch_bounds__(256) void k_groups(int64_t nt, LinesTab T, GroupOut O) {
+    __shared__ int s_cnt[TW * 3];
     __shared__ unsigned long long s_rank[TW];
     __shared__ int s_vbase;
+    __shared__ unsigned int s_items[4];
     const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)bx * LINES_PER_BLOCK;
-    for (int j = tid; j < TW; j += 256) s_rank[j] = ~0ull;
-    if (tid == 0) s_vbase = L.var_idx[i0] + L.var_base;
-    __syncthreads();
-    const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;
-    for (int64_t i = i0 + tid; i < i0 + LINES_PER_BLOCK && i < L.n; i += 256) {
-        const int64_t g = L.line_base + i;
-        const uint8_t cls = line_cls[g];
-        if (cls >= 2) continue;
-        const uint32_t q = L.qid_base + (uint32_t)L.read_qid[L.read_idx[i]];
-        if (!(single_bam || qid_owner[q] == L.bam)) continue;
-        if (qid_vmin[q] == (uint32_t)qid_vmax[q]) continue;
-        const int v = L.var_idx[i] + L.var_base;
-        const unsigned long long key = ((unsigned long long)qid_first[q] << 32) | (unsigned long long)g;
-        const unsigned d = (unsigned)(v - vbase);
-        if (d < (unsigned)TW) atomicMin(&s_rank[d], key);
-        else atomicMin(&var_rank[v], key);
-    }
-    __syncthreads();
-    for (int j = tid; j < TW; j += 256) {
-        const unsigned long long f = s_rank[j];
-        if (f != ~0ull) atomicMin(&var_rank[vbase + j], f);
-    }
-}
-
-// items are grouped by QNAME id; ids follow first appearance in coordinate-sorted input, so one workgroup's items again fall in
-// a narrow run of variants: same LDS window as k_line.  *m_ptr = number of item slots in use (= kept lines).
-__global__ __launch_bounds__(256) void k_distinct(const uint64_t *items, const uint32_t *m_ptr, int32_t *var_distinct) {
-    __shared__ int s_cnt[TW * 3];
-    __shared__ unsigned int s_vmin;
-    const int64_t m = *m_ptr;
-    const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * LINES_PER_BLOCK;
-    if (i0 >= m) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
-    if (tid == 0) s_vmin = 0xFFFFFFFFu;
+    for (int j = tid; j < TW; j += 256) s_rank[j] = ~0ull;
+    if (tid == 0) { const int64_t i0 = (int64_t)blockIdx.x * 256; s_vbase = (int)(O.items[O.base_t[i0]] >> 34); }
     __syncthreads();
-    {
-        const int64_t i = i0 + tid;
-        if (i < m) { const uint64_t k = items[i]; if (k != KEY_DROPPED) atomicMin(&s_vmin, (uint32_t)(k >> 4) & 0x0FFFFFFFu); }
+    const int vbase = s_vbase - 256 > 0 ? s_vbase - 256 : 0;
+    unsigned int ndist = 0;
+    if (i < nt) {
+        const uint32_t b = O.base_t[i], c = O.cnt_t[i];
+        O.qcount[O.touched[i]] = 0u;                         // the fill cursor goes back to zero: clean for the next call
+        uint64_t *it = O.items + b;
+        for (uint32_t a = 1; a < c; a++) {
+            const uint64_t x = it[a];
+            uint32_t j = a;
+            while (j > 0 && it[j - 1] > x) { it[j] = it[j - 1]; j--; }
+            it[j] = x;
+        }
+        int owner = -1; uint32_t first = 0xFFFFFFFFu;
+        for (uint32_t a = 0; a < c; a++) {
+            const uint64_t x = it[a];
+            if (((x >> 32) & 3ull) >= 2ull) continue;
+            const uint32_t g = (uint32_t)x;
+            first = g < first ? g : first;
+            if (!O.single_bam) { const int bm = bam_of_line(T, g); owner = bm > owner ? bm : owner; }
+        }
+        uint32_t vmin = 0xFFFFFFFFu, vmax = 0;
+        for (uint32_t a = 0; a < c; a++) {
+            const uint64_t x = it[a];
+            if (((x >> 32) & 3ull) >= 2ull) continue;
+            if (!O.single_bam && bam_of_line(T, (uint32_t)x) != owner) continue;
+            const uint32_t v = (uint32_t)(x >> 34);
+            vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+        }
+        const bool multi = vmin != 0xFFFFFFFFu && vmin != vmax;
+        // runs of equal (variant, class): one distinct item each; the variant's first linked line competes for its rank
+        uint32_t w = 0, a = 0;
+        uint32_t prev_v = 0xFFFFFFFFu;
+        while (a < c) {
+            const uint64_t key = it[a] >> 32;                  // variant:28 | class:2
+            const uint32_t v = (uint32_t)(key >> 2), cls = (uint32_t)(key & 3ull);
+            uint32_t linked = 0, gl = 0xFFFFFFFFu;
+            while (a < c && (it[a] >> 32) == key) {
+                const uint32_t g = (uint32_t)it[a];
+                if (cls < 2u && (O.single_bam || bam_of_line(T, g) == owner)) { linked = 1u; gl = g < gl ? g : gl; }
+                a++;
+            }
+            if (multi && linked) {
+                const unsigned long long rk = ((unsigned long long)first << 32) | gl;
+                const unsigned d = (unsigned)((int)v - vbase);
+                if (d < (unsigned)TW) atomicMin(&s_rank[d], rk); else atomicMin(&O.var_rank[v], rk);
+            }
+            (void)prev_v;
+            {
+                const unsigned d = (unsigned)((int)v - vbase);
+                if (d < (unsigned)TW) atomicAdd(&s_cnt[d * 3 + cls], 1); else atomicAdd(&O.var_distinct[(int64_t)v * 3 + cls], 1);
+            }
+            it[w++] = ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;
+        }
+        O.cnt_t[i] = w;
+        ndist = w;
     }
-    __syncthreads();
-    const int vbase = (s_vmin != 0xFFFFFFFFu && (int)s_vmin - 64 > 0) ? (int)s_vmin - 64 : 0;
-    for (int64_t i = i0 + tid; i < i0 + LINES_PER_BLOCK && i < m; i += 256) {
-        const uint64_t k = items[i];
-        if (k == KEY_DROPPED) continue;
-        const uint32_t v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u;
-        const unsigned d = (unsigned)((int)v - vbase);
-        if (d < (unsigned)TW) atomicAdd(&s_cnt[d * 3 + cls], 1);
-        else atomicAdd(&var_distinct[(int64_t)v * 3 + cls], 1);
-    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ndist += __shfl_xor(ndist, d);
+    if ((tid & 63) == 0) s_items[tid >> 6] = ndist;
     __syncthreads();
     for (int j = tid; j < TW * 3; j += 256) {
-        const int c = s_cnt[j];
-        if (c) atomicAdd(&var_distinct[(int64_t)(vbase + j / 3) * 3 + (j % 3)], c);
+        const int cc = s_cnt[j];
+        if (cc) atomicAdd(&O.var_distinct[(int64_t)(vbase + j / 3) * 3 + (j % 3)], cc);
     }
+    for (int j = tid; j < TW; j += 256) {
+        const unsigned long long f = s_rank[j];
+        if (f != ~0ull) atomicMin(&O.var_rank[vbase + j], f);
+    }
+    if (tid == 0) { const unsigned int t = s_items[0] + s_items[1] + s_items[2] + s_items[3]; if (t) atomicAdd(&O.counters[0], (unsigned long long)t); }
 }
 
 __device__ __forceinline__ uint32_t hash64(uint64_t k) {
@@ -288,113 +312,123 @@ __device__ __forceinline__ uint32_t hash64(uint64_t k) {
 constexpr int PH_SLOTS = 1024;     // LDS hash slots per workgroup
 constexpr int PH_VALS = 10;        // 9 cells + linked flag
 constexpr int PH_PROBES = 24;
-constexpr int PAIR_ITEMS = 2048;   // items per workgroup of k_pairs (the LDS table is set up / flushed once per workgroup)
+constexpr int PAIR_GROUPS = 512;   // QNAME groups per workgroup of k_pairs (the LDS table is set up / flushed once per workgroup)
 constexpr int GH_PROBES = 2048;    // global probe bound; beyond it the table is declared too small and the pass is redone
 
-// counters[]: 0 distinct items, 1 pair events, 2 global hash overflow, 3 kept lines
-__device__ __forceinline__ int global_slot(uint64_t *gkeys, uint32_t gmask, uint64_t key, unsigned long long *counters) {
+// counters[]: 0 distinct items, 1 pair events, 2 global hash overflow, 3 kept lines, 4/5 noise, 6 touched QNAMEs, 7 used hash slots
+// -> slot of the pair in the global table, claiming it if new (*claimed); -1 when the probe bound is hit
+__device__ __forceinline__ int global_slot(uint64_t *gkeys, uint32_t gmask, uint64_t key, unsigned long long *counters, bool *claimed) {
     uint32_t s = hash64(key) & gmask;
+    *claimed = false;
     for (int t = 0; t < GH_PROBES; t++) {
-        const unsigned long long prev = atomicCAS((unsigned long long *)&gkeys[s], (unsigned long long)KEY_DROPPED,
-                                                  (unsigned long long)key);
-        if (prev == KEY_DROPPED || prev == key) return (int)s;
+        const unsigned long long prev = atomicCAS((unsigned long long *)&gkeys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)key);
+        if (prev == KEY_DROPPED) { *claimed = true; return (int)s; }
+        if (prev == key) return (int)s;
         s = (s + 1) & gmask;
     }
     atomicAdd(&counters[2], 1ull);
     return -1;
 }
 
-__global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, const uint32_t *m_ptr, uint64_t *gkeys, int32_t *gvals, uint32_t gmask,
-                                               unsigned long long *counters) {
+// QNAME groups hold their distinct items sorted by (variant, class): every pair of items on different variants adds 1 to cell
+// (class_a, class_b) of that variant pair.  The slots this workgroup claims in the global table go to the list of used slots.
+__global__ __launch_bounds__(256) void k_pairs(int64_t nt, const uint32_t *base_t, const uint32_t *cnt_t, const uint64_t *items, uint64_t *gkeys, int32_t *gvals,
+                                               uint32_t gmask, uint32_t *used, unsigned long long *counters) {
     __shared__ unsigned long long s_keys[PH_SLOTS];
     __shared__ int s_vals[PH_SLOTS * PH_VALS];
-    __shared__ unsigned int s_part[8];
-    const int64_t m = *m_ptr;
-    const int64_t i0 = (int64_t)blockIdx.x * PAIR_ITEMS;
-    if (i0 >= m) return;
+    __shared__ uint32_t s_claim[PH_SLOTS];
+    __shared__ unsigned int s_part[4], s_nclaim;
+    __shared__ unsigned long long s_ubase;
+    const int64_t i0 = (int64_t)blockIdx.x * PAIR_GROUPS;
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) s_keys[j] = KEY_DROPPED;
     for (int j = threadIdx.x; j < PH_SLOTS * PH_VALS; j += 256) s_vals[j] = 0;
+    if (threadIdx.x == 0) s_nclaim = 0;
     __syncthreads();
-    unsigned int n_item = 0, n_event = 0;
-    for (int64_t i = i0 + threadIdx.x; i < i0 + PAIR_ITEMS && i < m; i += 256) {
-        const uint64_t k = items[i];
-        if (k == KEY_DROPPED) continue;
-        n_item++;
-        const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
-        for (int64_t j = i + 1; j < m; j++) {
-            const uint64_t k2 = items[j];
-            if (k2 == KEY_DROPPED) continue;
-            if ((uint32_t)(k2 >> 32) != q) break;
-            const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
-            if (v2 == v) continue;
-            n_event++;
-            const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
-            const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
-            const int cell = (int)(cls * 3 + cls2);
-            const int linked = (int)(ln & ln2);
-            uint32_t s = hash64(pk) & (PH_SLOTS - 1);
-            bool done = false;
-            for (int t = 0; t < PH_PROBES; t++) {
-                const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
-                if (prev == KEY_DROPPED || prev == pk) {
-                    atomicAdd(&s_vals[s * PH_VALS + cell], 1);
-                    if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
-                    done = true;
-                    break;
+    unsigned int n_event = 0;
+    for (int64_t i = i0 + threadIdx.x; i < i0 + PAIR_GROUPS && i < nt; i += 256) {
+        const uint64_t *it = items + base_t[i];
+        const uint32_t c = cnt_t[i];
+        for (uint32_t a = 0; a + 1 < c; a++) {
+            const uint64_t k = it[a];
+            const uint32_t v = (uint32_t)(k >> 4), cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
+            for (uint32_t b = a + 1; b < c; b++) {
+                const uint64_t k2 = it[b];
+                const uint32_t v2 = (uint32_t)(k2 >> 4);
+                if (v2 == v) continue;
+                n_event++;
+                const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
+                const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
+                const int cell = (int)(cls * 3 + cls2);
+                const int linked = (int)(ln & ln2);
+                uint32_t s = hash64(pk) & (PH_SLOTS - 1);
+                bool done = false;
+                for (int t = 0; t < PH_PROBES; t++) {
+                    const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
+                    if (prev == KEY_DROPPED || prev == pk) {
+                        atomicAdd(&s_vals[s * PH_VALS + cell], 1);
+                        if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
+                        done = true;
+                        break;
+                    }
+                    s = (s + 1) & (PH_SLOTS - 1);
                 }
-                s = (s + 1) & (PH_SLOTS - 1);
-            }
-            if (!done) {
-                const int gs = global_slot(gkeys, gmask, pk, counters);
-                if (gs >= 0) {
-                    atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
-                    if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
+                if (!done) {
+                    bool claimed;
+                    const int gs = global_slot(gkeys, gmask, pk, counters, &claimed);
+                    if (gs >= 0) {
+                        if (claimed) used[atomicAdd(&counters[7], 1ull)] = (uint32_t)gs;
+                        atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
+                        if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { n_item += __shfl_xor(n_item, d); n_event += __shfl_xor(n_event, d); }
-    if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6] = n_item; s_part[4 + (threadIdx.x >> 6)] = n_event; }
+    for (int d = 32; d >= 1; d >>= 1) n_event += __shfl_xor(n_event, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = n_event;
     __syncthreads();
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) {
         const uint64_t pk = s_keys[j];
         if (pk == KEY_DROPPED) continue;
-        const int gs = global_slot(gkeys, gmask, pk, counters);
+        bool claimed;
+        const int gs = global_slot(gkeys, gmask, pk, counters, &claimed);
         if (gs < 0) continue;
+        if (claimed) s_claim[atomicAdd(&s_nclaim, 1u)] = (uint32_t)gs;
         for (int c = 0; c < 9; c++) {
             const int val = s_vals[j * PH_VALS + c];
             if (val) atomicAdd(&gvals[(int64_t)gs * PH_VALS + c], val);
         }
         if (s_vals[j * PH_VALS + 9]) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long a = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        const unsigned long long b = (unsigned long long)s_part[4] + s_part[5] + s_part[6] + s_part[7];
-        if (a) atomicAdd(&counters[0], a);
+        const unsigned long long b = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
         if (b) atomicAdd(&counters[1], b);
+        s_ubase = s_nclaim ? atomicAdd(&counters[7], (unsigned long long)s_nclaim) : 0ull;      // one global atomic per workgroup
     }
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < s_nclaim; j += 256) used[s_ubase + j] = s_claim[j];
 }
 
-// ---- edge list in (a, b) order: counting sort of the used hash slots by a, each (small) group sorted by b
-__global__ __launch_bounds__(256) void k_edge_count(const uint64_t *gkeys, int64_t cap, uint32_t *deg) {
+// ---- edge list in (a, b) order: counting sort of the USED hash slots by a, each (small) group sorted by b
+__global__ __launch_bounds__(256) void k_edge_count(const uint32_t *used, int64_t n_used, const uint64_t *gkeys, uint32_t *deg) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= cap) return;
-    const uint64_t k = gkeys[i];
-    if (k != KEY_DROPPED) atomicAdd(&deg[(uint32_t)(k >> 32)], 1u);
+    if (i < n_used) atomicAdd(&deg[(uint32_t)(gkeys[used[i]] >> 32)], 1u);
 }
-__global__ __launch_bounds__(256) void k_edge_scatter(const uint64_t *gkeys, int64_t cap, const uint32_t *eoff, uint32_t *deg,
+__global__ __launch_bounds__(256) void k_edge_scatter(const uint32_t *used, int64_t n_used, const uint64_t *gkeys, const uint32_t *eoff, uint32_t *deg,
                                                       uint32_t *e_b, uint32_t *e_slot) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= cap) return;
-    const uint64_t k = gkeys[i];
-    if (k == KEY_DROPPED) return;
+    if (i >= n_used) return;
+    const uint32_t s = used[i];
+    const uint64_t k = gkeys[s];
     const uint32_t a = (uint32_t)(k >> 32);
     const uint32_t old = atomicSub(&deg[a], 1u);
     const uint32_t p = eoff[a] + old - 1;
-    e_b[p] = (uint32_t)k; e_slot[p] = (uint32_t)i;
+    e_b[p] = (uint32_t)k; e_slot[p] = s;
 }
-__global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, const int32_t *gvals,
+// ... and the table is left clean (keys empty, counters zero) slot by slot, so the next call needs no memset of it
+__global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, uint64_t *gkeys, int32_t *gvals,
                                                     int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked, int32_t *cto, int32_t *stats, int64_t ne) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= nv) return;
@@ -410,8 +444,9 @@ __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *
         const int64_t s = e_slot[i];
         int32_t x[9];
 #pragma unroll
-        for (int c = 0; c < 9; c++) { x[c] = gvals[s * PH_VALS + c]; cells[(int64_t)i * 9 + c] = x[c]; }
+        for (int c = 0; c < 9; c++) { x[c] = gvals[s * PH_VALS + c]; cells[(int64_t)i * 9 + c] = x[c]; gvals[s * PH_VALS + c] = 0; }
         linked[i] = (uint8_t)(gvals[s * PH_VALS + 9] & 1);
+        gvals[s * PH_VALS + 9] = 0; gkeys[s] = KEY_DROPPED;
         // test_variant_connection's three sums (phaser.py:1634-1636): same configuration rr+aa, opposite ar+ra, the five "other" cells
         const int32_t cis = x[0] + x[4], trans = x[3] + x[1], oth = x[6] + x[7] + x[2] + x[5] + x[8];
         cto[(int64_t)i * 3] = cis; cto[(int64_t)i * 3 + 1] = trans; cto[(int64_t)i * 3 + 2] = oth;
@@ -420,6 +455,54 @@ __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *
         stats[i] = cis; stats[ne + i] = trans; stats[2 * ne + i] = cis > trans ? cis : trans; stats[3 * ne + i] = cis + trans + oth;
         stats[4 * ne + i] = cis > trans ? 0 : (cis < trans ? 1 : -1);
     }
+}
+
+// ---- read lists: entries were placed by atomics; put every list into line order and keep the QNAME ids
+constexpr int RL_SMALL = 64, RL_LDS = 4096;
+// counters32[0] lists left to the workgroup kernel, [1] lists left to the host-driven sort
+__global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t *rl_start, uint64_t *rl_tmp, int32_t *rl_qid, uint32_t *mid_list, uint32_t *big_list,
+                                                 uint32_t *counters32) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nlists) return;
+    const uint32_t lo = rl_start[e], hi = rl_start[e + 1], n = hi - lo;
+    if (n == 0) return;
+    if (n > (uint32_t)RL_LDS) { big_list[atomicAdd(&counters32[1], 1u)] = (uint32_t)e; return; }
+    if (n > (uint32_t)RL_SMALL) { mid_list[atomicAdd(&counters32[0], 1u)] = (uint32_t)e; return; }
+    uint64_t *x = rl_tmp + lo;
+    for (uint32_t a = 1; a < n; a++) {
+        const uint64_t t = x[a];
+        uint32_t j = a;
+        while (j > 0 && x[j - 1] > t) { x[j] = x[j - 1]; j--; }
+        x[j] = t;
+    }
+    for (uint32_t a = 0; a < n; a++) rl_qid[lo + a] = (int32_t)(uint32_t)x[a];
+}
+// one workgroup per list of 65..4096 entries: bitonic sort in LDS
+__global__ __launch_bounds__(256) void k_rl_sort_mid(const uint32_t *mid_list, const uint32_t *rl_start, const uint64_t *rl_tmp, int32_t *rl_qid) {
+    __shared__ unsigned long long s_x[RL_LDS];
+    const uint32_t e = mid_list[blockIdx.x];
+    const uint32_t lo = rl_start[e], n = rl_start[e + 1] - lo;
+    uint32_t m = 64;
+    while (m < n) m <<= 1;
+    for (uint32_t t = threadIdx.x; t < m; t += 256) s_x[t] = t < n ? rl_tmp[lo + t] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < m; t += 256) {
+                const uint32_t p = t ^ j;
+                if (p > t) {
+                    const unsigned long long a = s_x[t], b = s_x[p];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { s_x[t] = b; s_x[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t t = threadIdx.x; t < n; t += 256) rl_qid[lo + t] = (int32_t)(uint32_t)s_x[t];
+}
+__global__ __launch_bounds__(256) void k_rl_take_qid(const uint64_t *src, int64_t n, int32_t *dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (int32_t)(uint32_t)src[i];
 }
 
 // sequencing-noise counters (phaser.py:610-632): over the variants with ref+alt lines and an "other" share below 5 %, the ref+alt
@@ -473,11 +556,12 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
     return PHZ_OK;
 }
 
+
 // scratch slots of ctx->scratch used by the tally (0 is the AS histogram, 16.. belong to components / K_map)
-enum { T_QOWN = 1, T_QFIRST, T_QCOUNT, T_QOFF, T_ITEMS, T_SORT_TMP, T_COUNTERS, T_GKEYS, T_GVALS, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP };
-// results and the read-list sort buffers live in their own buffers (ctx->tally_buf)
-enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_STATS, R_RLCNT, R_RLSTART, R_RLKEY, R_RLKEY2, R_RLVAL, R_RLQID, R_A0, R_A1,
-       R_COUNT };
+enum { T_QBASE = 1, T_TOUCHED, T_CNT_T, T_BASE_T, T_ITEMS, T_COUNTERS, T_GKEYS, T_GVALS, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP, T_USED, T_MISC };
+// results and the read-list buffers live in their own buffers (ctx->tally_buf)
+enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_STATS, R_RLCNT, R_RLSTART, R_RLFILL, R_RLTMP, R_RLLIST, R_RLQID, R_A0, R_A1,
+       R_LINEQ, R_SORTK, R_SORTV0, R_SORTV1, R_SORTCNT, R_COUNT };
 
 }  // namespace
 
@@ -596,62 +680,51 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         }
         d_a0 = (const uint8_t *)R[R_A0].p; d_a1 = (const uint8_t *)R[R_A1].p;
     }
-    if (int s = phz_reserve(ctx, R[R_CNT], NV * 12)) return s;
-    if (int s = phz_reserve(ctx, R[R_FIRST], NV * 8)) return s;
-    if (int s = phz_reserve(ctx, R[R_DIST], NV * 12)) return s;
-    if (int s = phz_reserve(ctx, R[R_RANK], NV * 8)) return s;
-    if (int s = phz_reserve(ctx, R[R_CLS], TOT)) return s;
-    if (int s = phz_reserve(ctx, R[R_RLCNT], NRL * 4)) return s;
-    if (int s = phz_reserve(ctx, R[R_RLSTART], (NRL + 1) * 4)) return s;
-    if (int s = phz_reserve(ctx, R[R_RLKEY], TOT * 4)) return s;
-    if (int s = phz_reserve(ctx, R[R_RLKEY2], TOT * 4)) return s;
-    if (int s = phz_reserve(ctx, R[R_RLVAL], TOT * 4)) return s;
-    if (int s = phz_reserve(ctx, R[R_RLQID], TOT * 4)) return s;
-    if (int s = phz_reserve(ctx, S[T_QOWN], NQ * 4)) return s;
-    if (int s = phz_reserve(ctx, S[T_QFIRST], NQ * 12)) return s;        // per QNAME: first ref/alt line, min / max linked variant
-    if (int s = phz_reserve(ctx, S[T_QOFF], (NQ + 1) * 4)) return s;
-    if (int s = phz_reserve(ctx, S[T_ITEMS], TOT * 8)) return s;
-    if (int s = phz_reserve(ctx, S[T_COUNTERS], 64)) return s;
-    if (int s = phz_reserve(ctx, S[T_DEG], NV * 4)) return s;
-    if (int s = phz_reserve(ctx, S[T_EOFF], (NV + 1) * 4)) return s;
-    {   // qcount must start at zero; k_items counts it back to zero, so the array (owned by the tally alone) is cleared only
-        // when it is (re)allocated -- or after a call that failed half way
+#define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, buf, (bytes))) return s_; } while (0)
+    RSV(R[R_CNT], NV * 12); RSV(R[R_FIRST], NV * 8); RSV(R[R_DIST], NV * 12); RSV(R[R_RANK], NV * 8); RSV(R[R_CLS], TOT); RSV(R[R_LINEQ], TOT * 4);
+    RSV(R[R_RLCNT], NRL * 4); RSV(R[R_RLSTART], (NRL + 1) * 4); RSV(R[R_RLFILL], NRL * 4); RSV(R[R_RLTMP], TOT * 8); RSV(R[R_RLLIST], TOT * 4); RSV(R[R_RLQID], TOT * 4);
+    RSV(S[T_TOUCHED], TOT * 4); RSV(S[T_CNT_T], (TOT + 1) * 4); RSV(S[T_BASE_T], (TOT + 1) * 4); RSV(S[T_ITEMS], TOT * 8); RSV(S[T_COUNTERS], 128);
+    RSV(S[T_DEG], NV * 4); RSV(S[T_EOFF], (NV + 1) * 4); RSV(S[T_MISC], std::max(NRL, (size_t)1) * 8 + 64);
+    hipStream_t sm = ctx->stream;
+    {   // the two arrays indexed by QNAME id are persistent: `lines per QNAME` is all zero between calls (the kernels count it back down), the group
+        // base is written before it is read.  They are cleared only when (re)allocated -- or after a call that failed half way
         const size_t before = ctx->tally_qcount.cap;
-        if (int s = phz_reserve(ctx, ctx->tally_qcount, NQ * 4)) return s;
-        if (ctx->tally_qcount.cap != before || ctx->tally_dirty) PHZ_HIP(ctx, hipMemsetAsync(ctx->tally_qcount.p, 0, ctx->tally_qcount.cap, ctx->stream));
-        ctx->tally_dirty = true;           // cleared again when the call completes
+        RSV(ctx->tally_qcount, NQ * 4);
+        if (ctx->tally_qcount.cap != before || ctx->tally_dirty) PHZ_HIP(ctx, hipMemsetAsync(ctx->tally_qcount.p, 0, ctx->tally_qcount.cap, sm));
+        RSV(S[T_QBASE], NQ * 4);
     }
     int32_t *d_cnt = (int32_t *)R[R_CNT].p, *d_dist = (int32_t *)R[R_DIST].p;
     unsigned long long *d_first = (unsigned long long *)R[R_FIRST].p, *d_rank = (unsigned long long *)R[R_RANK].p;
     uint8_t *d_cls = (uint8_t *)R[R_CLS].p;
-    uint32_t *rl_cnt = (uint32_t *)R[R_RLCNT].p, *rl_start = (uint32_t *)R[R_RLSTART].p, *rl_key = (uint32_t *)R[R_RLKEY].p,
-             *rl_key2 = (uint32_t *)R[R_RLKEY2].p;
-    int32_t *rl_val = (int32_t *)R[R_RLVAL].p, *rl_qid = (int32_t *)R[R_RLQID].p;
-    int32_t *qid_owner = (int32_t *)S[T_QOWN].p;
-    uint32_t *qid_first = (uint32_t *)S[T_QFIRST].p, *qid_vmin = qid_first + NQ;
-    int32_t *qid_vmax = (int32_t *)(qid_vmin + NQ);
-    uint32_t *qcount = (uint32_t *)ctx->tally_qcount.p, *qoff = (uint32_t *)S[T_QOFF].p;
+    uint32_t *line_q = (uint32_t *)R[R_LINEQ].p;
+    uint32_t *rl_cnt = (uint32_t *)R[R_RLCNT].p, *rl_start = (uint32_t *)R[R_RLSTART].p, *rl_fill = (uint32_t *)R[R_RLFILL].p, *rl_list = (uint32_t *)R[R_RLLIST].p;
+    uint64_t *rl_tmp = (uint64_t *)R[R_RLTMP].p;
+    int32_t *rl_qid = (int32_t *)R[R_RLQID].p;
+    uint32_t *qcount = (uint32_t *)ctx->tally_qcount.p, *qbase = (uint32_t *)S[T_QBASE].p;
+    uint32_t *touched = (uint32_t *)S[T_TOUCHED].p, *cnt_t = (uint32_t *)S[T_CNT_T].p, *base_t = (uint32_t *)S[T_BASE_T].p;
     uint64_t *items = (uint64_t *)S[T_ITEMS].p;
-    unsigned long long *counters = (unsigned long long *)S[T_COUNTERS].p;      // 0 items, 1 events, 2 overflow, 3 kept lines
+    unsigned long long *counters = (unsigned long long *)S[T_COUNTERS].p;      // see k_pairs
+    uint32_t *counters32 = (uint32_t *)(counters + 8);
     uint32_t *deg = (uint32_t *)S[T_DEG].p, *eoff = (uint32_t *)S[T_EOFF].p;
+    uint32_t *mid_list = (uint32_t *)S[T_MISC].p, *big_list = mid_list + NRL;
 
-    hipStream_t sm = ctx->stream;
     Timer timer(ctx, PHZ_T_TALLY);
+    ctx->tally_dirty = true;           // cleared again when the call completes
     PHZ_HIP(ctx, hipMemsetAsync(d_cnt, 0, NV * 12, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_dist, 0, NV * 12, sm));
     PHZ_HIP(ctx, hipMemsetAsync(rl_cnt, 0, NRL * 4, sm));
-    PHZ_HIP(ctx, hipMemsetAsync(qid_first, 0xff, NQ * 12, sm));      // first = vmin = UINT_MAX, vmax = -1
+    PHZ_HIP(ctx, hipMemsetAsync(rl_fill, 0, NRL * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_rank, 0xff, NV * 8, sm));
-    PHZ_HIP(ctx, hipMemsetAsync(qid_owner, 0xff, NQ * 4, sm));       // -1
-    PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 64, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 128, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_first, 0xff, NV * 8, sm));         // unsigned max for atomicMin == -1 as int64 ("none")
 
     const int single_bam = n_bams <= 1 ? 1 : 0;     // one BAM: every QNAME's read_vars list is owned by that BAM
     LineOut O;
-    O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt; O.qid_owner = qid_owner;
-    O.qid_first = qid_first; O.qcount = qcount; O.n_kept = counters + 3; O.nb = n_bams; O.single_bam = single_bam;
-    // shard tables of the per-line stages: LINES_PER_BLOCK lines per block (k_line, k_rank) and 256 lines per block (k_items)
+    O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.line_q = line_q; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt; O.qcount = qcount;
+    O.touched = touched; O.counters = counters; O.nb = n_bams;
+    // shard tables of the per-line stages: LINES_PER_BLOCK lines per block (k_line) and 256 lines per block (k_items)
     LinesTab TL, TI;
+    TL.L = nullptr; TL.blk0 = nullptr; TL.n = 0; TI = TL;
     std::vector<uint32_t> gl, gi;
     if (n_shards > 0) {
         if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK); }, &TL, &gl, 0, 2)) return s2;
@@ -660,81 +733,98 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     const unsigned grid_l = n_shards > 0 ? gl.back() : 0u, grid_i = n_shards > 0 ? gi.back() : 0u;
     if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(256), 0, sm, TL, O);
     if (nv) hipLaunchKernelGGL(k_noise, dim3(nblk(nv)), dim3(256), 0, sm, (const int32_t *)d_cnt, nv, counters + 4);
+    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, rl_cnt, rl_start, (int64_t)NRL, S[T_SCAN_TMP])) return s;
     PHZ_HIP(ctx, hipGetLastError());
-    // lines per QNAME -> slot ranges; scatter; sort + de-duplicate each group.  qoff[n_qid] = kept lines = item slots in use
-    if (int s = scan_excl(ctx, qcount, qoff, n_qid, S[T_SCAN_TMP])) return s;
-    const uint32_t *m_ptr = qoff + n_qid;
-    const uint32_t rl_drop = (uint32_t)NRL;
-    if (grid_i) hipLaunchKernelGGL(k_items, dim3(grid_i), dim3(256), 0, sm, TI, (const uint8_t *)d_cls, (const int32_t *)qid_owner,
-                                   (const uint32_t *)qoff, qcount, items, qid_vmin, qid_vmax, rl_key, rl_val, n_bams, single_bam, rl_drop);
-    if (n_qid) hipLaunchKernelGGL(k_qsort, dim3(nblk(n_qid)), dim3(256), 0, sm, (const uint32_t *)qoff, n_qid, items);
-    if (grid_l) hipLaunchKernelGGL(k_rank, dim3(grid_l), dim3(256), 0, sm, TL, (const uint8_t *)d_cls, (const int32_t *)qid_owner,
-                                   (const uint32_t *)qid_first, (const uint32_t *)qid_vmin, (const int32_t *)qid_vmax, d_rank, single_bam);
-    PHZ_HIP(ctx, hipGetLastError());
-    // read lists: stable sort of the lines by (variant, allele, BAM) on the significant key bits; CSR starts from the counts
-    if (total > 0) {
-        int bits = 1;
-        while ((1ull << bits) <= (unsigned long long)NRL) bits++;
-        size_t tmp = 0;
-        PHZ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, rl_key, rl_key2, rl_val, rl_qid, (size_t)total, 0, (unsigned)bits, sm));
-        if (int s = phz_reserve(ctx, S[T_SORT_TMP], tmp)) return s;
-        PHZ_HIP(ctx, rocprim::radix_sort_pairs(S[T_SORT_TMP].p, tmp, rl_key, rl_key2, rl_val, rl_qid, (size_t)total, 0, (unsigned)bits, sm));
+    unsigned long long h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 64, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    const int64_t nt = (int64_t)h_counters[6];           // QNAMEs that own kept lines: one group each
+    // group ranges: scan over the touched QNAMEs' line counts
+    if (nt) {
+        hipLaunchKernelGGL(k_group_plan, dim3(nblk(nt)), dim3(256), 0, sm, nt, (const uint32_t *)touched, qcount, cnt_t);
+        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, cnt_t, base_t, nt, S[T_SCAN_TMP])) return s;
+        hipLaunchKernelGGL(k_group_base, dim3(nblk(nt)), dim3(256), 0, sm, nt, (const uint32_t *)touched, (const uint32_t *)base_t, qbase);
     }
-    if (int s = scan_excl(ctx, rl_cnt, rl_start, (int64_t)NRL, S[T_SCAN_TMP])) return s;
-    if (total > 0) hipLaunchKernelGGL(k_distinct, dim3((unsigned)((total + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK)), dim3(256), 0, sm,
-                                      (const uint64_t *)items, m_ptr, d_dist);
-    // variant pairs.  Table sized from the variant count; a pass that overflows it is redone with a larger one
+    if (grid_i) hipLaunchKernelGGL(k_items, dim3(grid_i), dim3(256), 0, sm, TI, (const uint8_t *)d_cls, (const uint32_t *)line_q, (const uint32_t *)qbase, qcount, items,
+                                   (const uint32_t *)rl_start, rl_fill, rl_tmp, rl_list, n_bams);
+    if (nt) {
+        GroupOut G; G.qcount = qcount; G.items = items; G.cnt_t = cnt_t; G.base_t = base_t; G.touched = touched; G.var_rank = d_rank; G.var_distinct = d_dist;
+        G.counters = counters; G.single_bam = single_bam;
+        hipLaunchKernelGGL(k_groups, dim3(nblk(nt)), dim3(256), 0, sm, nt, TI, G);
+    }
+    // read lists into line order
+    PHZ_HIP(ctx, hipMemsetAsync(counters32, 0, 16, sm));
+    hipLaunchKernelGGL(k_rl_sort, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_tmp, rl_qid, mid_list, big_list, counters32);
+    // variant pairs.  The table lives in the ctx, sized from the variant count and kept clean by k_edge_final; a pass that overflows it is redone
+    // with a larger one
     uint64_t cap = 1 << 16;
     while (cap < 4 * (uint64_t)NV && cap < (1ull << 30)) cap <<= 1;
     int64_t ne = 0;
-    unsigned long long h_counters[6] = {0, 0, 0, 0, 0, 0};       // + 4 noise match, 5 noise mismatch
+    uint32_t h_c32[4] = {0, 0, 0, 0};
     uint32_t h_tail[2] = {0, 0};
     for (int attempt = 0;; attempt++) {
-        if (int s = phz_reserve(ctx, S[T_GKEYS], cap * 8)) return s;
-        if (int s = phz_reserve(ctx, S[T_GVALS], cap * PH_VALS * 4)) return s;
+        const size_t old_k = S[T_GKEYS].cap, old_v = S[T_GVALS].cap;
+        RSV(S[T_GKEYS], cap * 8); RSV(S[T_GVALS], cap * PH_VALS * 4); RSV(S[T_USED], cap * 4);
         uint64_t *gkeys = (uint64_t *)S[T_GKEYS].p; int32_t *gvals = (int32_t *)S[T_GVALS].p;
-        PHZ_HIP(ctx, hipMemsetAsync(gkeys, 0xff, cap * 8, sm));
-        PHZ_HIP(ctx, hipMemsetAsync(gvals, 0, cap * PH_VALS * 4, sm));
-        PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 24, sm));
-        if (total > 0) hipLaunchKernelGGL(k_pairs, dim3((unsigned)((total + PAIR_ITEMS - 1) / PAIR_ITEMS)), dim3(256), 0, sm, (const uint64_t *)items, m_ptr, gkeys, gvals,
-                                          (uint32_t)(cap - 1), counters);
-        PHZ_HIP(ctx, hipMemsetAsync(deg, 0, NV * 4, sm));
-        hipLaunchKernelGGL(k_edge_count, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, (const uint64_t *)gkeys, (int64_t)cap, deg);
-        if (int s = scan_excl(ctx, deg, eoff, nv, S[T_SCAN_TMP])) return s;
+        if (S[T_GKEYS].cap != old_k || S[T_GVALS].cap != old_v || ctx->tally_table_dirty || attempt > 0) {
+            PHZ_HIP(ctx, hipMemsetAsync(gkeys, 0xff, S[T_GKEYS].cap, sm));
+            PHZ_HIP(ctx, hipMemsetAsync(gvals, 0, S[T_GVALS].cap, sm));
+        }
+        ctx->tally_table_dirty = true;
+        PHZ_HIP(ctx, hipMemsetAsync(counters + 1, 0, 16, sm));          // pair events, overflow
+        PHZ_HIP(ctx, hipMemsetAsync(counters + 7, 0, 8, sm));           // used slots
+        if (nt) hipLaunchKernelGGL(k_pairs, dim3((unsigned)((nt + PAIR_GROUPS - 1) / PAIR_GROUPS)), dim3(256), 0, sm, nt, (const uint32_t *)base_t, (const uint32_t *)cnt_t,
+                                   (const uint64_t *)items, gkeys, gvals, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
         PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 48, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[0], eoff + nv, 4, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 64, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(h_c32, counters32, 16, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[1], rl_start + NRL, 4, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
-        if (h_counters[2] == 0) { ne = (int64_t)h_tail[0]; break; }
+        if (h_counters[2] == 0) { ne = (int64_t)h_counters[7]; break; }
         if (attempt == 4 || cap >= (1ull << 31)) return phz_fail(ctx, PHZ_E_NOMEM, "variant-pair table did not converge");
         cap <<= 2;
     }
+    // the longer read lists: one workgroup each (bitonic sort in LDS), the few beyond that through the device radix sort
+    if (h_c32[0]) hipLaunchKernelGGL(k_rl_sort_mid, dim3(h_c32[0]), dim3(256), 0, sm, (const uint32_t *)mid_list, (const uint32_t *)rl_start, (const uint64_t *)rl_tmp, rl_qid);
+    if (h_c32[1]) {
+        std::vector<uint32_t> big(h_c32[1]), rs((size_t)NRL + 1);
+        PHZ_HIP(ctx, hipMemcpy(big.data(), big_list, big.size() * 4, hipMemcpyDeviceToHost));
+        PHZ_HIP(ctx, hipMemcpy(rs.data(), rl_start, rs.size() * 4, hipMemcpyDeviceToHost));
+        size_t longest = 0;
+        for (uint32_t e : big) longest = std::max(longest, (size_t)(rs[e + 1] - rs[e]));
+        RSV(R[R_SORTK], longest * 8); RSV(R[R_SORTV0], longest * 4); RSV(R[R_SORTV1], longest * 4);
+        const int hi_bit = 32 + bits_for((uint64_t)(total > 1 ? total - 1 : 1));
+        for (uint32_t e : big) {
+            const int64_t n = (int64_t)rs[e + 1] - rs[e];
+            int where = 0;
+            if (int s = radix_sort_pairs<uint64_t, uint32_t>(ctx, rl_tmp + rs[e], (uint64_t *)R[R_SORTK].p, (uint32_t *)R[R_SORTV0].p, (uint32_t *)R[R_SORTV1].p, n, 32, hi_bit,
+                                                            R[R_SORTCNT], S[T_SCAN_TMP], &where)) return s;
+            hipLaunchKernelGGL(k_rl_take_qid, dim3(nblk(n)), dim3(256), 0, sm, (const uint64_t *)(where ? (uint64_t *)R[R_SORTK].p : rl_tmp + rs[e]), n, rl_qid + rs[e]);
+        }
+    }
     const size_t NE = (size_t)(ne ? ne : 1);
-    if (int s = phz_reserve(ctx, R[R_EA], NE * 4)) return s;
-    if (int s = phz_reserve(ctx, R[R_EB], NE * 4)) return s;
-    if (int s = phz_reserve(ctx, R[R_CELLS], NE * 36)) return s;
-    if (int s = phz_reserve(ctx, R[R_LINKED], NE)) return s;
-    if (int s = phz_reserve(ctx, R[R_CTO], NE * 12)) return s;
-    if (int s = phz_reserve(ctx, R[R_STATS], NE * 20)) return s;
-    if (int s = phz_reserve(ctx, S[T_EB], NE * 4)) return s;
-    if (int s = phz_reserve(ctx, S[T_ESLOT], NE * 4)) return s;
+    RSV(R[R_EA], NE * 4); RSV(R[R_EB], NE * 4); RSV(R[R_CELLS], NE * 36); RSV(R[R_LINKED], NE); RSV(R[R_CTO], NE * 12); RSV(R[R_STATS], NE * 20);
+    RSV(S[T_EB], NE * 4); RSV(S[T_ESLOT], NE * 4);
+    PHZ_HIP(ctx, hipMemsetAsync(deg, 0, NV * 4, sm));
     if (ne > 0) {
-        hipLaunchKernelGGL(k_edge_scatter, dim3(nblk((int64_t)cap)), dim3(256), 0, sm, (const uint64_t *)S[T_GKEYS].p, (int64_t)cap,
-                           (const uint32_t *)eoff, deg, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
+        hipLaunchKernelGGL(k_edge_count, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint64_t *)S[T_GKEYS].p, deg);
+        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, deg, eoff, nv, S[T_SCAN_TMP])) return s;
+        hipLaunchKernelGGL(k_edge_scatter, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint64_t *)S[T_GKEYS].p, (const uint32_t *)eoff, deg,
+                           (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
         hipLaunchKernelGGL(k_edge_final, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p,
-                           (const int32_t *)S[T_GVALS].p, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
+                           (uint64_t *)S[T_GKEYS].p, (int32_t *)S[T_GVALS].p, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
                            (int32_t *)R[R_CTO].p, (int32_t *)R[R_STATS].p, ne);
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = timer.stop()) return s;
-    ctx->tally_dirty = false;
+#undef RSV
+    ctx->tally_dirty = false; ctx->tally_table_dirty = false;
     auto &T = ctx->tally;
     T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = (int64_t)h_counters[3]; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
     T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;
     T.ea = (int32_t *)R[R_EA].p; T.eb = (int32_t *)R[R_EB].p; T.cells = (int32_t *)R[R_CELLS].p; T.linked = (uint8_t *)R[R_LINKED].p;
     T.cto = (int32_t *)R[R_CTO].p; T.stats = (int32_t *)R[R_STATS].p;
-    T.rl_start = rl_start; T.rl_qid = rl_qid; T.rl_list = rl_key2;        // sorted keys = list index of every read-list entry
+    T.rl_start = rl_start; T.rl_qid = rl_qid; T.rl_list = rl_list;
     sizes->n_lines = total; sizes->n_kept = T.n_kept; sizes->n_edges = ne; sizes->n_read_list = T.n_rl;
     sizes->n_items = (int64_t)h_counters[0]; sizes->pair_events = (int64_t)h_counters[1];
     sizes->noise_match = (int64_t)h_counters[4]; sizes->noise_mismatch = (int64_t)h_counters[5];

@@ -1,0 +1,131 @@
+"""K_tally (phaser_amd/csrc/phz_tally.hip: per-line pass, QNAME groups, variant-pair cells, read lists) executed under the host-side HIP
+emulation of tests/hipemu on the call lines of the fixtures written on an MI355X (tests/golden/tally): every result array must equal what the
+GPU produced (those results are pinned against the reference through the five files), and the chain K_tally -> device row stage must give
+the reference's files.  Kernel LOGIC on the CPU box; the real kernels are checked by the -m gpu tests."""
+import ctypes as C
+import gzip
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, REPO, gz_text
+from helpers import OUTPUTS, EmuContext, canonical, emu_library, genome_from_saved
+from test_host_stages import _cases
+
+
+def lines_from_saved(saved, chrom_list, n_bams):
+    """phz_lines arrays of every (chromosome, BAM) shard of a fixture: one synthetic record per call line (read_idx = line), the class of a
+    line expressed through the general mapper's codes (5 / 6 = allele 0 / 1, 4 = other), dropped lines as records without an AS value."""
+    shards = []; keep = []
+    vb = qb = 0
+    for c in chrom_list:
+        R = saved["tally"][c]
+        nq = max(1, saved["n_qid"].get(c, int(R["line_qid"].max()) + 1 if len(R["line_qid"]) else 1))
+        for b, base, n in R["bam_offsets"]:
+            sl = slice(base, base + n)
+            cls = R["line_cls"][sl]
+            code = np.where(cls == 0, 5, np.where(cls == 1, 6, 4)).astype(np.uint8)
+            arr = {"read_idx": np.arange(n, dtype=np.int32), "var_idx": np.ascontiguousarray(R["line_var"][sl], dtype=np.int32), "code": code,
+                   "read_qid": np.ascontiguousarray(R["line_qid"][sl], dtype=np.int32), "read_as": np.zeros(max(1, n), dtype=np.int32),
+                   "has_as": (cls != 255).astype(np.uint8)}
+            keep.append(arr)
+            shards.append((arr, n, b, vb, qb))
+        vb += R["nv"]; qb += nq
+    return shards, keep, vb, qb
+
+
+def run_tally(ctx, saved, chrom_list, n_bams):
+    from phaser_amd import _lib
+    shards, keep, NV, NQ = lines_from_saved(saved, chrom_list, n_bams)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    arr = (_lib.phz_lines * max(1, len(shards)))(*[_lib.phz_lines(n, vp(a["read_idx"]), vp(a["var_idx"]), vp(a["code"]), max(1, n), vp(a["read_qid"]), vp(a["read_as"]),
+                                                                  vp(a["has_as"]), 0.0, 1, b, v0, q0) for a, n, b, v0, q0 in shards])
+    a0 = np.full(max(1, NV), 255, dtype=np.uint8)
+    sz = _lib.phz_tally_sizes()
+    ctx.check(ctx.lib.phz_tally(ctx.h, arr, len(shards), NV, vp(a0), vp(a0), NQ, n_bams, C.byref(sz), _lib.PHZ_HOST))
+    ne = int(sz.n_edges); nrl = int(sz.n_read_list)
+    out = {"var_count": np.zeros(NV * 3, np.int32), "var_first": np.zeros(NV, np.int64), "var_distinct": np.zeros(NV * 3, np.int32), "var_rank": np.zeros(NV, np.uint64),
+           "line_cls": np.zeros(max(1, int(sz.n_lines)), np.uint8), "ea": np.zeros(ne, np.int32), "eb": np.zeros(ne, np.int32), "cells": np.zeros(ne * 9, np.int32),
+           "linked": np.zeros(ne, np.uint8), "cto": np.zeros(ne * 3, np.int32), "rl_start": np.zeros(NV * 2 * n_bams + 1, np.uint32), "rl_qid": np.zeros(nrl, np.int32),
+           "stats": np.zeros(ne * 5, np.int32)}
+    p = lambda k: vp(out[k]) if out[k].size else None
+    o = _lib.phz_tally_out(p("var_count"), p("var_first"), p("var_distinct"), p("var_rank"), p("line_cls"), p("ea"), p("eb"), p("cells"), p("linked"), p("cto"),
+                           p("rl_start"), p("rl_qid"), p("stats"))
+    ctx.check(ctx.lib.phz_tally_fetch(ctx.h, C.byref(o), _lib.PHZ_HOST))
+    return out, sz
+
+
+@pytest.mark.parametrize("case", sorted(set(c[0] for c in _cases())))
+def test_tally_kernels_reproduce_the_gpu_fixture(case):
+    ctx = EmuContext(emu_library())
+    saved = pickle.load(gzip.open(os.path.join(GOLD, "tally", case + ".pkl.gz"), "rb"))
+    chroms = list(saved["tally"])
+    nb = 1 + max(b for c in chroms for b, _, _ in saved["tally"][c]["bam_offsets"])
+    want = genome_from_saved(saved, chroms, nb)
+    for rep in range(2):                       # twice on the same ctx: the persistent per-QNAME counters and the pair table must come back clean
+        got, sz = run_tally(ctx, saved, chroms, nb)
+        NV = want["nv"]
+        assert np.array_equal(got["var_count"].reshape(NV, 3), want["var_count"])
+        assert np.array_equal(got["var_first"], want["var_first"])
+        assert np.array_equal(got["var_distinct"].reshape(NV, 3), want["var_distinct"])
+        assert np.array_equal(got["var_rank"], want["var_rank"])
+        assert np.array_equal(got["ea"], want["ea"]) and np.array_equal(got["eb"], want["eb"])
+        assert np.array_equal(got["linked"], want["linked"])
+        assert np.array_equal(got["cto"].reshape(-1, 3), want["cto"])
+        assert np.array_equal(got["stats"].reshape(5, -1), want["stats"])
+        assert np.array_equal(got["rl_start"], want["rl_start"]) and np.array_equal(got["rl_qid"], want["rl_qid"])
+        assert (int(sz.noise_match), int(sz.noise_mismatch)) == want["noise"] and int(sz.n_kept) == want["n_kept"]
+
+
+def test_tally_kernels_on_skewed_synthetic_lines():
+    """Read lists of thousands of entries (workgroup bitonic sort, device radix sort), QNAMEs shared by two BAMs (owner = last BAM), dropped
+    lines: against a direct restatement with Python sets / sorts on the same lines."""
+    rng = np.random.default_rng(7)
+    nv = 24; nq = 3000
+    saved = {"tally": {}, "n_qid": {"chrS": nq}}
+    lines = []
+    for b in range(2):
+        n = 30000 if b == 0 else 7000
+        var = np.sort(rng.choice(nv, size=n, p=np.array([0.55, 0.2] + [0.25 / 22] * 22)))          # variant 0: thousands of lines
+        qid = rng.integers(0, nq, size=n)
+        cls = rng.choice([0, 1, 2, 255], size=n, p=[0.45, 0.4, 0.1, 0.05]).astype(np.uint8)
+        lines.append((var.astype(np.int32), qid.astype(np.int32), cls, np.full(n, b, np.int32)))
+    R = {"nv": nv, "line_var": np.concatenate([l[0] for l in lines]), "line_qid": np.concatenate([l[1] for l in lines]), "line_cls": np.concatenate([l[2] for l in lines]),
+         "line_bam": np.concatenate([l[3] for l in lines]), "bam_offsets": [(0, 0, 30000), (1, 30000, 7000)]}
+    saved["tally"]["chrS"] = R
+    ctx = EmuContext(emu_library())
+    got, sz = run_tally(ctx, saved, ["chrS"], 2)
+    var, qid, cls, bam = R["line_var"], R["line_qid"], R["line_cls"], R["line_bam"]
+    kept = cls != 255
+    # per-variant counters
+    vc = np.zeros((nv, 3), np.int64)
+    np.add.at(vc, (var[kept], cls[kept]), 1)
+    assert np.array_equal(got["var_count"].reshape(nv, 3), vc)
+    sets = [[set(), set(), set()] for _ in range(nv)]
+    for v, q, c in zip(var[kept], qid[kept], cls[kept]):
+        sets[v][c].add(int(q))
+    assert np.array_equal(got["var_distinct"].reshape(nv, 3), np.array([[len(s) for s in row] for row in sets]))
+    # read lists in line order per (variant, allele, BAM)
+    rs = got["rl_start"]
+    for v in range(nv):
+        for k in range(2):
+            for b in range(2):
+                e = (2 * v + k) * 2 + b
+                want = qid[kept & (var == v) & (cls == k) & (bam == b)]
+                assert np.array_equal(got["rl_qid"][rs[e]:rs[e + 1]], want), (v, k, b)
+    assert int(rs[-1]) == int((kept & (cls < 2)).sum())
+    # nine cells of every variant pair = sizes of the set intersections (phaser.py:1602-1632)
+    cells = got["cells"].reshape(-1, 9)
+    seen = {}
+    for i, (a, b2) in enumerate(zip(got["ea"], got["eb"])):
+        seen[(int(a), int(b2))] = cells[i]
+    for a in range(nv):
+        for b2 in range(a + 1, nv):
+            want = [len(sets[a][i] & sets[b2][j]) for i in range(3) for j in range(3)]
+            if sum(want) == 0:
+                assert (a, b2) not in seen
+            else:
+                assert list(seen[(a, b2)]) == want, (a, b2)

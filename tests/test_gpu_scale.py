@@ -67,24 +67,22 @@ def check_oracle_prefix(oracle_build, eng, vsets, samples, plan):
             assert calls.n == m or int(got_r[m]) >= len(smp)          # the next call belongs to a record past the prefix
 
 
-def check_oracle_all_records(oracle_build, eng, plan, n_bams):
-    """Every record of every shard: the shard is regenerated from its seeds with a host copy of all records (one chromosome at a time keeps
-    the host memory at one shard), the C oracle maps it on all host cores, the call list must equal K_map's."""
+def check_oracle_all_records(oracle_build, eng, vsets, samples, plan):
+    """Every record of every shard (host copies kept by build()): the C oracle maps them on all host cores, the call list must equal K_map's."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     from full_parity_c3 import oracle_all_records
-    from phaser_amd import dist as pdist, workloads
+    from phaser_amd import dist as pdist
     cores = max(1, pdist.effective_cpus())
     total = 0
-    for chrom, ln, n_snps, n_rec, seed in plan:
-        for b in range(n_bams):
-            v, sh, smp = workloads.make_shard(chrom, ln, n_snps, n_rec, seed, "cuda:0", keep_sample=n_rec, read_seed=seed + 1 + 7919 * b)
-            o_r, o_v, o_c = oracle_all_records(oracle_build, smp, v.pos.numpy(), 10, cores)
+    for b, per_chrom in enumerate(samples):
+        for chrom, *_ in plan:
+            smp = per_chrom[chrom]
+            o_r, o_v, o_c = oracle_all_records(oracle_build, smp, vsets[chrom].pos.numpy(), 10, cores)
             calls = eng.shards[chrom][b].calls
             assert calls.n == len(o_r), (chrom, b)
             assert np.array_equal(calls.read_idx.cpu().numpy(), o_r) and np.array_equal(calls.var_idx.cpu().numpy(), o_v) and \
                 np.array_equal(calls.code.cpu().numpy(), o_c), (chrom, b)
             total += len(smp)
-            del sh, smp
     return total
 
 
@@ -149,7 +147,7 @@ def test_whole_genome_one_bam(mapper, oracle_build, tmp_path):
     plan = workloads.genome_plan()
     import hashlib
     import subprocess
-    vsets, shards, samples = build(plan, 1, 0)
+    vsets, shards, samples = build(plan, 1, 1 << 40)            # host copies of ALL records (13 GB) for the mapper oracle
     eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
     assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
     assert sum(sh.n for sh in shards[0].values()) > 79_000_000 and eng.vs.het_count > 1_400_000
@@ -158,9 +156,9 @@ def test_whole_genome_one_bam(mapper, oracle_build, tmp_path):
     calls_tsv = tmp_path / "chr1.calls.tsv"
     calls_tsv.write_text(call_text(vsets[big], shards[0][big], eng.shards[big][0].calls))
     worker = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "oracle_chrom_worker.py"), str(calls_tsv), "10"], stdout=subprocess.PIPE, text=True)
-    assert check_oracle_all_records(oracle_build, eng, plan, 1) > 79_000_000
+    assert check_oracle_all_records(oracle_build, eng, vsets, samples, plan) > 79_000_000
     check_invariants(eng, out, plan, 1)
-    one, got1 = run_engine(mapper, {big: vsets[big]}, [{big: shards[0][big]}], plan[:1], names=["bam0"])
+    one, got1 = run_engine(mapper, {big: vsets[big]}, [{big: shards[0][big]}], plan[:1], names=["bench"])
     h = hashlib.sha256()
     for name in OUTPUTS:
         h.update(canonical(name, got1[name]).encode())
@@ -178,10 +176,10 @@ def test_whole_genome_four_bams_shared_qnames(mapper, oracle_build):
     cross-BAM merge (last BAM owns a QNAME's read_vars list, phaser.py:558-581) runs on every chromosome."""
     from phaser_amd import workloads
     plan = workloads.genome_plan(total_records=20_000_000)
-    vsets, shards, samples = build(plan, 4, 0)
+    vsets, shards, samples = build(plan, 4, 1 << 40)
     eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
     assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
-    assert check_oracle_all_records(oracle_build, eng, plan, 4) > 79_000_000
+    assert check_oracle_all_records(oracle_build, eng, vsets, samples, plan) > 79_000_000
     check_invariants(eng, out, plan, 4)
     del eng, out, shards, samples
     torch.cuda.empty_cache()

@@ -80,7 +80,18 @@ def main():
             open(os.path.join(d, "calls.tsv"), "w").write(call_text(v, sh, c))
             del smp
         print("K_map: all %d records of %d shards, %d calls identical" % (n_rec, len(plan), n_calls), flush=True)
-        # ---- phasing oracle: one process per chromosome, `cores` at a time, largest first
+        # ---- product: the whole genome in one pass (device row stage)
+        vs = pvcf.load_variants("\n".join(synth.vcf_lines([vsets[p[0]] for p in plan])))
+        eng = Engine(vs, ["bench"], Config(baseq=baseq, want_vcf=False), mapper=mapper)
+        for p in plan:
+            eng.add_mapped(0, p[0], shards[p[0]], calls[p[0]], int(shards[p[0]].qid.max()) + 1)
+        eng.close_bam(0)
+        t0 = time.perf_counter()
+        got = eng.finish()
+        cutoff = float(next(sh for sh in eng.shards[plan[0][0]] if sh is not None).cutoff)
+        print("product: stages T1-O2 of the whole genome in %.3f s (first pass), rows on the %s, %d phased variants" % (time.perf_counter() - t0, eng.rows_path, eng.phased), flush=True)
+        # ---- phasing oracle: one process per chromosome, `cores` at a time, largest first; every process gets the two scalars the reference computes over
+        # ALL chromosomes (AS cutoff :545-553, noise level :610-632) from the product's run -- they are pinned by the log lines of the fixtures
         t0 = time.perf_counter()
         order = sorted(plan, key=lambda p: -p[3])
         running = []; results = {}
@@ -97,22 +108,13 @@ def main():
             while len(running) >= cores:
                 reap(False); time.sleep(0.2)
             d = os.path.join(tmp, p[0])
-            running.append((p[0], subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "oracle_chrom_worker.py"), os.path.join(d, "calls.tsv"), str(baseq), d],
+            running.append((p[0], subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "oracle_chrom_worker.py"), os.path.join(d, "calls.tsv"), str(baseq), d, repr(cutoff), float(eng.noise).hex()],
                                                    stdout=subprocess.PIPE, text=True)))
         while running:
             reap(True)
         t_or = time.perf_counter() - t0
         print("phasing oracle: %d processes (<= %d at a time), %.1f s wall, %.1f CPU-seconds, %d phased variants" %
               (len(plan), cores, t_or, sum(r[1] for r in results.values()), sum(r[0] for r in results.values())), flush=True)
-        # ---- product: the whole genome in one pass (device row stage)
-        vs = pvcf.load_variants("\n".join(synth.vcf_lines([vsets[p[0]] for p in plan])))
-        eng = Engine(vs, ["bench"], Config(baseq=baseq, want_vcf=False), mapper=mapper)
-        for p in plan:
-            eng.add_mapped(0, p[0], shards[p[0]], calls[p[0]], int(shards[p[0]].qid.max()) + 1)
-        eng.close_bam(0)
-        t0 = time.perf_counter()
-        got = eng.finish()
-        print("product: stages T1-O2 of the whole genome in %.3f s (first pass), rows on the %s, %d phased variants" % (time.perf_counter() - t0, eng.rows_path, eng.phased), flush=True)
         assert eng.phased == sum(r[0] for r in results.values())
         bad = 0
         for name in OUTPUTS:

@@ -16,10 +16,12 @@ def main():
     import phasing_oracle as po
     from helpers import OUTPUTS, canonical
     path, baseq = sys.argv[1], int(sys.argv[2])
-    out_dir = sys.argv[3] if len(sys.argv) > 3 else None          # optional: the five files in canonical form are written there
+    out_dir = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None          # optional: the five files in canonical form are written there
+    cutoff = float(sys.argv[4]) if len(sys.argv) > 4 else None           # optional: the run's global AS cutoff and noise level (the chromosome is
+    noise = float.fromhex(sys.argv[5]) if len(sys.argv) > 5 else None    # one shard of a whole-genome run)
     text = open(path).read()
     t0 = time.perf_counter()
-    ph = po.Phaser(["bench"], baseq=baseq)
+    ph = po.Phaser(["bench"], baseq=baseq, global_as_cutoffs=None if cutoff is None else [cutoff], global_noise=noise)
     ph.add_bam([text])
     out = ph.finish()
     dt = time.perf_counter() - t0
