@@ -182,15 +182,24 @@ __global__ __launch_bounds__(256) void k_group_plan(int64_t nt, const uint32_t *
     const uint32_t q = touched[i];
     cnt_t[i] = qcount[q]; qcount[q] = 0u;
 }
-__global__ __launch_bounds__(256) void k_group_base(int64_t nt, const uint32_t *touched, const uint32_t *base_t, uint32_t *qbase) {
+// ... and the counter becomes the QNAME's write cursor: it starts at the group's base, k_items takes slots from it, k_groups returns it to zero
+__global__ __launch_bounds__(256) void k_group_base(int64_t nt, const uint32_t *touched, const uint32_t *base_t, uint32_t *qcount) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < nt) qbase[touched[i]] = base_t[i];
+    if (i < nt) qcount[touched[i]] = base_t[i];
+}
+// list index of every read-list entry (entry -> (variant, allele, BAM)); lists are short, one thread each
+__global__ __launch_bounds__(256) void k_rl_expand(int64_t nlists, const uint32_t *rl_start, uint32_t *rl_list, uint32_t *rl_cursor) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nlists) return;
+    const uint32_t lo = rl_start[e], hi = rl_start[e + 1];
+    rl_cursor[e] = lo;                                   // write cursor of the list for k_items
+    for (uint32_t p = lo; p < hi; p++) rl_list[p] = (uint32_t)e;
 }
 
 // item = variant:28 | class:2 | line:32 (sorts by variant, class, line); read-list entry = line:32 | chromosome-local QNAME id:32
 __device__ __forceinline__ uint64_t item_pack(uint32_t v, uint32_t cls, uint32_t g) { return ((uint64_t)v << 34) | ((uint64_t)cls << 32) | g; }
-__global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_cls, const uint32_t *line_q, const uint32_t *qbase, uint32_t *qcount, uint64_t *items,
-                                               const uint32_t *rl_start, uint32_t *rl_fill, uint64_t *rl_tmp, uint32_t *rl_list, int nb) {
+__global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_cls, const uint32_t *line_q, uint32_t *qcount, uint64_t *items,
+                                               uint32_t *rl_cursor, uint64_t *rl_tmp, int nb) {
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
     const int64_t i = (int64_t)(blockIdx.x - T.blk0[sh_]) * 256 + threadIdx.x;
@@ -200,12 +209,10 @@ __global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_c
     if (cls == 255) return;
     const uint32_t q = line_q[g];
     const uint32_t v = (uint32_t)(L.var_idx[i] + L.var_base);
-    items[qbase[q] + atomicAdd(&qcount[q], 1u)] = item_pack(v, cls, (uint32_t)g);
+    items[atomicAdd(&qcount[q], 1u)] = item_pack(v, cls, (uint32_t)g);
     if (cls < 2) {
         const uint32_t e = (v * 2u + cls) * (uint32_t)nb + (uint32_t)L.bam;
-        const uint32_t p = rl_start[e] + atomicAdd(&rl_fill[e], 1u);
-        rl_tmp[p] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)(q - L.qid_base);
-        rl_list[p] = e;
+        rl_tmp[atomicAdd(&rl_cursor[e], 1u)] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)(q - L.qid_base);
     }
 }
 
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_c
 //   linked = ref/alt line of the owner BAM (an entry of the surviving read_vars list)
 //   rank   : overlap-dictionary key order (SURVEY.md 8.1 rule 4, phaser.py:1271-1283): for QNAMEs whose surviving list holds >= 2 distinct
 //            variants, every variant gets (first << 32 | its first linked line) as a candidate for its smallest key
-//   the distinct (variant, class) items (the LAST of a run carries linked = max over the run), written back compacted as
-//            variant:28 << 4 | class << 2 | linked, and the per-variant distinct-QNAME counters
+//   the distinct (variant, class) items (linked = max over the run of equal lines), written back at the front of the group as
+//            group:32 | variant:28 << 4 | class << 2 | linked (the rest of the group becomes KEY_DROPPED), and the per-variant distinct-QNAME counters
 struct GroupOut {
     uint32_t *qcount; uint64_t *items; uint32_t *cnt_t; const uint32_t *base_t, *touched;
     unsigned long long *var_rank; int32_t *var_distinct; unsigned long long *counters;      // [0] distinct items
@@ -284,8 +291,9 @@ __global__ __launch_bounds__(256) void k_groups(int64_t nt, LinesTab T, GroupOut
                 const unsigned d = (unsigned)((int)v - vbase);
                 if (d < (unsigned)TW) atomicAdd(&s_cnt[d * 3 + cls], 1); else atomicAdd(&O.var_distinct[(int64_t)v * 3 + cls], 1);
             }
-            it[w++] = ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;
+            it[w++] = ((uint64_t)(uint32_t)i << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;       // group number in the high word
         }
+        for (uint32_t k = w; k < c; k++) it[k] = KEY_DROPPED;
         O.cnt_t[i] = w;
         ndist = w;
     }
@@ -312,7 +320,6 @@ __device__ __forceinline__ uint32_t hash64(uint64_t k) {
 constexpr int PH_SLOTS = 1024;     // LDS hash slots per workgroup
 constexpr int PH_VALS = 10;        // 9 cells + linked flag
 constexpr int PH_PROBES = 24;
-constexpr int PAIR_GROUPS = 512;   // QNAME groups per workgroup of k_pairs (the LDS table is set up / flushed once per workgroup)
 constexpr int GH_PROBES = 2048;    // global probe bound; beyond it the table is declared too small and the pass is redone
 
 // counters[]: 0 distinct items, 1 pair events, 2 global hash overflow, 3 kept lines, 4/5 noise, 6 touched QNAMEs, 7 used hash slots
@@ -331,55 +338,54 @@ __device__ __forceinline__ int global_slot(uint64_t *gkeys, uint32_t gmask, uint
 }
 
 // QNAME groups hold their distinct items sorted by (variant, class): every pair of items on different variants adds 1 to cell
-// (class_a, class_b) of that variant pair.  The slots this workgroup claims in the global table go to the list of used slots.
-__global__ __launch_bounds__(256) void k_pairs(int64_t nt, const uint32_t *base_t, const uint32_t *cnt_t, const uint64_t *items, uint64_t *gkeys, int32_t *gvals,
-                                               uint32_t gmask, uint32_t *used, unsigned long long *counters) {
+// (class_a, class_b) of that variant pair.  One thread per item slot (the pairs of an item with the later items of its group): PAIR_ITEMS
+// slots per workgroup.  The slots this workgroup claims in the global table go to the list of used slots.
+constexpr int PAIR_ITEMS = 2048;
+__global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m, uint64_t *gkeys, int32_t *gvals, uint32_t gmask, uint32_t *used, unsigned long long *counters) {
     __shared__ unsigned long long s_keys[PH_SLOTS];
     __shared__ int s_vals[PH_SLOTS * PH_VALS];
     __shared__ uint32_t s_claim[PH_SLOTS];
     __shared__ unsigned int s_part[4], s_nclaim;
     __shared__ unsigned long long s_ubase;
-    const int64_t i0 = (int64_t)blockIdx.x * PAIR_GROUPS;
+    const int64_t i0 = (int64_t)blockIdx.x * PAIR_ITEMS;
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) s_keys[j] = KEY_DROPPED;
     for (int j = threadIdx.x; j < PH_SLOTS * PH_VALS; j += 256) s_vals[j] = 0;
     if (threadIdx.x == 0) s_nclaim = 0;
     __syncthreads();
     unsigned int n_event = 0;
-    for (int64_t i = i0 + threadIdx.x; i < i0 + PAIR_GROUPS && i < nt; i += 256) {
-        const uint64_t *it = items + base_t[i];
-        const uint32_t c = cnt_t[i];
-        for (uint32_t a = 0; a + 1 < c; a++) {
-            const uint64_t k = it[a];
-            const uint32_t v = (uint32_t)(k >> 4), cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
-            for (uint32_t b = a + 1; b < c; b++) {
-                const uint64_t k2 = it[b];
-                const uint32_t v2 = (uint32_t)(k2 >> 4);
-                if (v2 == v) continue;
-                n_event++;
-                const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
-                const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
-                const int cell = (int)(cls * 3 + cls2);
-                const int linked = (int)(ln & ln2);
-                uint32_t s = hash64(pk) & (PH_SLOTS - 1);
-                bool done = false;
-                for (int t = 0; t < PH_PROBES; t++) {
-                    const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
-                    if (prev == KEY_DROPPED || prev == pk) {
-                        atomicAdd(&s_vals[s * PH_VALS + cell], 1);
-                        if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
-                        done = true;
-                        break;
-                    }
-                    s = (s + 1) & (PH_SLOTS - 1);
+    for (int64_t i = i0 + threadIdx.x; i < i0 + PAIR_ITEMS && i < m; i += 256) {
+        const uint64_t k = items[i];
+        if (k == KEY_DROPPED) continue;
+        const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
+        for (int64_t j = i + 1; j < m; j++) {
+            const uint64_t k2 = items[j];
+            if (k2 == KEY_DROPPED || (uint32_t)(k2 >> 32) != q) break;        // the distinct items of a group sit at its front
+            const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
+            if (v2 == v) continue;
+            n_event++;
+            const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
+            const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
+            const int cell = (int)(cls * 3 + cls2);
+            const int linked = (int)(ln & ln2);
+            uint32_t s = hash64(pk) & (PH_SLOTS - 1);
+            bool done = false;
+            for (int t = 0; t < PH_PROBES; t++) {
+                const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
+                if (prev == KEY_DROPPED || prev == pk) {
+                    atomicAdd(&s_vals[s * PH_VALS + cell], 1);
+                    if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
+                    done = true;
+                    break;
                 }
-                if (!done) {
-                    bool claimed;
-                    const int gs = global_slot(gkeys, gmask, pk, counters, &claimed);
-                    if (gs >= 0) {
-                        if (claimed) used[atomicAdd(&counters[7], 1ull)] = (uint32_t)gs;
-                        atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
-                        if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
-                    }
+                s = (s + 1) & (PH_SLOTS - 1);
+            }
+            if (!done) {
+                bool claimed;
+                const int gs = global_slot(gkeys, gmask, pk, counters, &claimed);
+                if (gs >= 0) {
+                    if (claimed) used[atomicAdd(&counters[7], 1ull)] = (uint32_t)gs;
+                    atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
+                    if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
                 }
             }
         }
@@ -458,24 +464,55 @@ __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *
 }
 
 // ---- read lists: entries were placed by atomics; put every list into line order and keep the QNAME ids
-constexpr int RL_SMALL = 64, RL_LDS = 4096;
+constexpr int RL_SMALL = 16, RL_LDS = 4096;
 // counters32[0] lists left to the workgroup kernel, [1] lists left to the host-driven sort
-__global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t *rl_start, uint64_t *rl_tmp, int32_t *rl_qid, uint32_t *mid_list, uint32_t *big_list,
-                                                 uint32_t *counters32) {
+__global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t *rl_start, uint64_t *rl_tmp, int32_t *rl_qid, uint32_t *wave_list, uint32_t *mid_list,
+                                                 uint32_t *big_list, uint32_t *counters32) {
+    __shared__ uint32_t s_list[3][256];
+    __shared__ uint32_t s_n[3], s_base[3];
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nlists) return;
-    const uint32_t lo = rl_start[e], hi = rl_start[e + 1], n = hi - lo;
-    if (n == 0) return;
-    if (n > (uint32_t)RL_LDS) { big_list[atomicAdd(&counters32[1], 1u)] = (uint32_t)e; return; }
-    if (n > (uint32_t)RL_SMALL) { mid_list[atomicAdd(&counters32[0], 1u)] = (uint32_t)e; return; }
-    uint64_t *x = rl_tmp + lo;
-    for (uint32_t a = 1; a < n; a++) {
-        const uint64_t t = x[a];
-        uint32_t j = a;
-        while (j > 0 && x[j - 1] > t) { x[j] = x[j - 1]; j--; }
-        x[j] = t;
+    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    if (e < nlists) {
+        const uint32_t lo = rl_start[e], hi = rl_start[e + 1], n = hi - lo;
+        if (n > (uint32_t)RL_LDS) s_list[1][atomicAdd(&s_n[1], 1u)] = (uint32_t)e;
+        else if (n > 64u) s_list[0][atomicAdd(&s_n[0], 1u)] = (uint32_t)e;
+        else if (n > (uint32_t)RL_SMALL) s_list[2][atomicAdd(&s_n[2], 1u)] = (uint32_t)e;
+        else if (n > 0) {
+            uint64_t *x = rl_tmp + lo;
+            for (uint32_t a = 1; a < n; a++) {
+                const uint64_t t = x[a];
+                uint32_t j = a;
+                while (j > 0 && x[j - 1] > t) { x[j] = x[j - 1]; j--; }
+                x[j] = t;
+            }
+            for (uint32_t a = 0; a < n; a++) rl_qid[lo + a] = (int32_t)(uint32_t)x[a];
+        }
     }
-    for (uint32_t a = 0; a < n; a++) rl_qid[lo + a] = (int32_t)(uint32_t)x[a];
+    __syncthreads();
+    if (threadIdx.x < 3) s_base[threadIdx.x] = s_n[threadIdx.x] ? atomicAdd(&counters32[threadIdx.x], s_n[threadIdx.x]) : 0u;      // one global atomic per workgroup and class
+    __syncthreads();
+    for (int k = 0; k < 3; k++) {
+        uint32_t *dst = k == 0 ? mid_list : (k == 1 ? big_list : wave_list);
+        if (threadIdx.x < s_n[k]) dst[s_base[k] + threadIdx.x] = s_list[k][threadIdx.x];
+    }
+}
+// one wave per list of 17..64 entries: bitonic network over the lanes (entries of different tiles of lines interleave arbitrarily, an
+// insertion sort would go quadratic)
+__global__ __launch_bounds__(64) void k_rl_sort_wave(const uint32_t *wave_list, const uint32_t *rl_start, const uint64_t *rl_tmp, int32_t *rl_qid) {
+    const uint32_t e = wave_list[blockIdx.x];
+    const uint32_t lo = rl_start[e], n = rl_start[e + 1] - lo;
+    const uint32_t t = threadIdx.x;
+    unsigned long long x = t < n ? rl_tmp[lo + t] : ~0ull;
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const unsigned long long y = __shfl_xor(x, (int)j);
+            const bool up = (t & k) == 0, lower = (t & j) == 0;
+            x = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
+        }
+    if (t < n) rl_qid[lo + t] = (int32_t)(uint32_t)x;
 }
 // one workgroup per list of 65..4096 entries: bitonic sort in LDS
 __global__ __launch_bounds__(256) void k_rl_sort_mid(const uint32_t *mid_list, const uint32_t *rl_start, const uint64_t *rl_tmp, int32_t *rl_qid) {
@@ -684,14 +721,13 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     RSV(R[R_CNT], NV * 12); RSV(R[R_FIRST], NV * 8); RSV(R[R_DIST], NV * 12); RSV(R[R_RANK], NV * 8); RSV(R[R_CLS], TOT); RSV(R[R_LINEQ], TOT * 4);
     RSV(R[R_RLCNT], NRL * 4); RSV(R[R_RLSTART], (NRL + 1) * 4); RSV(R[R_RLFILL], NRL * 4); RSV(R[R_RLTMP], TOT * 8); RSV(R[R_RLLIST], TOT * 4); RSV(R[R_RLQID], TOT * 4);
     RSV(S[T_TOUCHED], TOT * 4); RSV(S[T_CNT_T], (TOT + 1) * 4); RSV(S[T_BASE_T], (TOT + 1) * 4); RSV(S[T_ITEMS], TOT * 8); RSV(S[T_COUNTERS], 128);
-    RSV(S[T_DEG], NV * 4); RSV(S[T_EOFF], (NV + 1) * 4); RSV(S[T_MISC], std::max(NRL, (size_t)1) * 8 + 64);
+    RSV(S[T_DEG], NV * 4); RSV(S[T_EOFF], (NV + 1) * 4); RSV(S[T_MISC], std::max(NRL, (size_t)1) * 12 + 64);
     hipStream_t sm = ctx->stream;
-    {   // the two arrays indexed by QNAME id are persistent: `lines per QNAME` is all zero between calls (the kernels count it back down), the group
-        // base is written before it is read.  They are cleared only when (re)allocated -- or after a call that failed half way
+    {   // the one array indexed by QNAME id is persistent: `lines per QNAME`, then the QNAME's write cursor, all zero between calls (k_groups returns it
+        // to zero).  It is cleared only when (re)allocated -- or after a call that failed half way
         const size_t before = ctx->tally_qcount.cap;
         RSV(ctx->tally_qcount, NQ * 4);
         if (ctx->tally_qcount.cap != before || ctx->tally_dirty) PHZ_HIP(ctx, hipMemsetAsync(ctx->tally_qcount.p, 0, ctx->tally_qcount.cap, sm));
-        RSV(S[T_QBASE], NQ * 4);
     }
     int32_t *d_cnt = (int32_t *)R[R_CNT].p, *d_dist = (int32_t *)R[R_DIST].p;
     unsigned long long *d_first = (unsigned long long *)R[R_FIRST].p, *d_rank = (unsigned long long *)R[R_RANK].p;
@@ -700,20 +736,19 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     uint32_t *rl_cnt = (uint32_t *)R[R_RLCNT].p, *rl_start = (uint32_t *)R[R_RLSTART].p, *rl_fill = (uint32_t *)R[R_RLFILL].p, *rl_list = (uint32_t *)R[R_RLLIST].p;
     uint64_t *rl_tmp = (uint64_t *)R[R_RLTMP].p;
     int32_t *rl_qid = (int32_t *)R[R_RLQID].p;
-    uint32_t *qcount = (uint32_t *)ctx->tally_qcount.p, *qbase = (uint32_t *)S[T_QBASE].p;
+    uint32_t *qcount = (uint32_t *)ctx->tally_qcount.p;
     uint32_t *touched = (uint32_t *)S[T_TOUCHED].p, *cnt_t = (uint32_t *)S[T_CNT_T].p, *base_t = (uint32_t *)S[T_BASE_T].p;
     uint64_t *items = (uint64_t *)S[T_ITEMS].p;
     unsigned long long *counters = (unsigned long long *)S[T_COUNTERS].p;      // see k_pairs
     uint32_t *counters32 = (uint32_t *)(counters + 8);
     uint32_t *deg = (uint32_t *)S[T_DEG].p, *eoff = (uint32_t *)S[T_EOFF].p;
-    uint32_t *mid_list = (uint32_t *)S[T_MISC].p, *big_list = mid_list + NRL;
+    uint32_t *mid_list = (uint32_t *)S[T_MISC].p, *big_list = mid_list + NRL, *wave_list = big_list + NRL;
 
     Timer timer(ctx, PHZ_T_TALLY);
     ctx->tally_dirty = true;           // cleared again when the call completes
     PHZ_HIP(ctx, hipMemsetAsync(d_cnt, 0, NV * 12, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_dist, 0, NV * 12, sm));
     PHZ_HIP(ctx, hipMemsetAsync(rl_cnt, 0, NRL * 4, sm));
-    PHZ_HIP(ctx, hipMemsetAsync(rl_fill, 0, NRL * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_rank, 0xff, NV * 8, sm));
     PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 128, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_first, 0xff, NV * 8, sm));         // unsigned max for atomicMin == -1 as int64 ("none")
@@ -743,10 +778,10 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     if (nt) {
         hipLaunchKernelGGL(k_group_plan, dim3(nblk(nt)), dim3(256), 0, sm, nt, (const uint32_t *)touched, qcount, cnt_t);
         if (int s = gscan_excl<uint32_t, uint32_t>(ctx, cnt_t, base_t, nt, S[T_SCAN_TMP])) return s;
-        hipLaunchKernelGGL(k_group_base, dim3(nblk(nt)), dim3(256), 0, sm, nt, (const uint32_t *)touched, (const uint32_t *)base_t, qbase);
+        hipLaunchKernelGGL(k_group_base, dim3(nblk(nt)), dim3(256), 0, sm, nt, (const uint32_t *)touched, (const uint32_t *)base_t, qcount);
     }
-    if (grid_i) hipLaunchKernelGGL(k_items, dim3(grid_i), dim3(256), 0, sm, TI, (const uint8_t *)d_cls, (const uint32_t *)line_q, (const uint32_t *)qbase, qcount, items,
-                                   (const uint32_t *)rl_start, rl_fill, rl_tmp, rl_list, n_bams);
+    hipLaunchKernelGGL(k_rl_expand, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_list, rl_fill);
+    if (grid_i) hipLaunchKernelGGL(k_items, dim3(grid_i), dim3(256), 0, sm, TI, (const uint8_t *)d_cls, (const uint32_t *)line_q, qcount, items, rl_fill, rl_tmp, n_bams);
     if (nt) {
         GroupOut G; G.qcount = qcount; G.items = items; G.cnt_t = cnt_t; G.base_t = base_t; G.touched = touched; G.var_rank = d_rank; G.var_distinct = d_dist;
         G.counters = counters; G.single_bam = single_bam;
@@ -754,7 +789,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     }
     // read lists into line order
     PHZ_HIP(ctx, hipMemsetAsync(counters32, 0, 16, sm));
-    hipLaunchKernelGGL(k_rl_sort, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_tmp, rl_qid, mid_list, big_list, counters32);
+    hipLaunchKernelGGL(k_rl_sort, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_tmp, rl_qid, wave_list, mid_list, big_list, counters32);
     // variant pairs.  The table lives in the ctx, sized from the variant count and kept clean by k_edge_final; a pass that overflows it is redone
     // with a larger one
     uint64_t cap = 1 << 16;
@@ -773,8 +808,9 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         ctx->tally_table_dirty = true;
         PHZ_HIP(ctx, hipMemsetAsync(counters + 1, 0, 16, sm));          // pair events, overflow
         PHZ_HIP(ctx, hipMemsetAsync(counters + 7, 0, 8, sm));           // used slots
-        if (nt) hipLaunchKernelGGL(k_pairs, dim3((unsigned)((nt + PAIR_GROUPS - 1) / PAIR_GROUPS)), dim3(256), 0, sm, nt, (const uint32_t *)base_t, (const uint32_t *)cnt_t,
-                                   (const uint64_t *)items, gkeys, gvals, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
+        const int64_t m_items = (int64_t)h_counters[3];               // kept lines = item slots
+        if (m_items) hipLaunchKernelGGL(k_pairs, dim3((unsigned)((m_items + PAIR_ITEMS - 1) / PAIR_ITEMS)), dim3(256), 0, sm, (const uint64_t *)items, m_items, gkeys, gvals,
+                                        (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
         PHZ_HIP(ctx, hipGetLastError());
         PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 64, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(h_c32, counters32, 16, hipMemcpyDeviceToHost, sm));
@@ -785,6 +821,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         cap <<= 2;
     }
     // the longer read lists: one workgroup each (bitonic sort in LDS), the few beyond that through the device radix sort
+    if (h_c32[2]) hipLaunchKernelGGL(k_rl_sort_wave, dim3(h_c32[2]), dim3(64), 0, sm, (const uint32_t *)wave_list, (const uint32_t *)rl_start, (const uint64_t *)rl_tmp, rl_qid);
     if (h_c32[0]) hipLaunchKernelGGL(k_rl_sort_mid, dim3(h_c32[0]), dim3(256), 0, sm, (const uint32_t *)mid_list, (const uint32_t *)rl_start, (const uint64_t *)rl_tmp, rl_qid);
     if (h_c32[1]) {
         std::vector<uint32_t> big(h_c32[1]), rs((size_t)NRL + 1);
