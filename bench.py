@@ -58,35 +58,59 @@ def pmc_traffic():
             if not rows:
                 return None
             vals[name] = sum(rows) / len(rows)
+        insts = {}
+        f = os.path.join(d, "sq1.csv")
+        if os.path.exists(f):
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if "k_map" in r["Kernel_Name"]:
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            insts = {k.replace("SQ_INSTS_", "").lower(): sum(v) / len(v) for k, v in acc.items() if k.startswith("SQ_INSTS_")}
         return {"bytes_per_launch": 2 * vals["fetch"] * 1024 + vals["write"] * 1024, "fetch_raw_kib": vals["fetch"], "write_kib": vals["write"],
-                "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
-                "note": "mean over the k_map launches of this command; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE"}
+                "wave_insts_per_launch": insts, "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
+                "note": "mean over the k_map launches of this command; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; SQ_INSTS_* = wave64 instructions"}
     return None
 
 
+SURVEY_BYTES_PER_RECORD = 115.0          # L = 76, 1.6 CIGAR ops, 0.19 calls per record
+
+
+def issue_rates(ctx):
+    """Issue ceilings of the chip, measured live (phz_microbench: wave64 VALU / SALU / LDS instructions per second, best over 2..8 waves
+    per SIMD); the figures of tools/ubench.py kept under profiles/ are the same measurement."""
+    import ctypes as C
+    out = {}
+    for kind, name in ((0, "valu"), (1, "salu"), (2, "lds")):
+        best = 0.0
+        for w in (2, 4, 8):
+            r = C.c_double(0); cu = C.c_int(0); mhz = C.c_int(0)
+            ctx.check(ctx.lib.phz_microbench(ctx.h, kind, w, 4000, C.byref(r), C.byref(cu), C.byref(mhz)))
+            best = max(best, r.value)
+        out[name] = best
+    return out
+
+
 def pmc_traffic_tally():
-    """HBM bytes per phasing pass of the K_tally family (phz_tally.hip kernels, phz_components, the rocPRIM sorts / scans they call)
-    from a PMC summary committed under profiles/ (tools/prof_pmc_tally.sh; same rules as pmc_traffic: separate --pmc passes,
-    FETCH_SIZE doubled, reported only while the kernel source hash matches)."""
-    import csv, glob
-    src = file_sha("phaser_amd/csrc/phz_tally.hip")
+    """HBM bytes per phasing pass of the K_tally family and of the device row stage from a PMC summary committed under profiles/
+    (tools/prof_pmc_tally.sh; same rules as pmc_traffic: separate --pmc passes, FETCH_SIZE doubled, reported only while the kernel source
+    hashes match)."""
+    import glob
+    src = file_sha("phaser_amd/csrc/phz_tally.hip"); src_rows = file_sha("phaser_amd/csrc/phz_rowsdev.hip")
     for d in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_ktally_*")))):
         meta = os.path.join(d, "meta.json")
         if not os.path.exists(meta):
             continue
         m = json.load(open(meta))
-        if m.get("kernel_source_sha16") != src or m.get("workload") != "configs[2]" or not m.get("passes"):
+        if m.get("kernel_source_sha16") != src or m.get("workload") != "configs[2]" or not m.get("passes") or "kib" not in m:
             continue
-        tot = {}
-        for name in ("fetch", "write"):
-            f = os.path.join(d, name + ".csv")
-            if not os.path.exists(f):
-                return None
-            tot[name] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)))
-        return {"bytes_per_pass": (2 * tot["fetch"] + tot["write"]) * 1024 / m["passes"], "fetch_raw_kib_per_pass": tot["fetch"] / m["passes"],
-                "write_kib_per_pass": tot["write"] / m["passes"], "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
-                "note": "sum over the K_tally family of one pass; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; the sort passes and the "
-                        "sector-granular scattered writes move ~30x the algorithmic bytes"}
+        t = m["kib"]["tally"]
+        out = {"bytes_per_pass": (2 * t["fetch"] + t["write"]) * 1024 / m["passes"], "fetch_raw_kib_per_pass": t["fetch"] / m["passes"],
+               "write_kib_per_pass": t["write"] / m["passes"], "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
+               "note": "sum over the K_tally family (k_as_hist .. k_edge_final, incl. the scans / sorts in between) of one pass; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE"}
+        if m.get("rows_source_sha16") == src_rows:
+            r = m["kib"]["rows"]
+            out["row_stage_bytes_per_pass"] = (2 * r["fetch"] + r["write"]) * 1024 / m["passes"]
+        return out
     return None
 
 
@@ -158,6 +182,37 @@ def cpu_phasing_baseline(sample_chroms, vsets, shards, calls_of, mapper, baseq, 
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     return out
+
+
+def kmap_roofline(ctx, tot_recs, tot_alg, k_avg_s, k_launches, steps, k_ms_max_rank, world):
+    """Three fractions for k_map: (1) SURVEY.md 8(d)'s byte model, 115 B per record / kernel time against the 8 TB/s HBM peak -- the contract's
+    `achieved` / `frac`; (2) the bytes the kernel really moves (PMC FETCH_SIZE x 2 + WRITE_SIZE of a committed pass) against the same peak;
+    (3) its wave64 instruction counts (PMC SQ_INSTS_*) against the chip's measured issue rates (phz_microbench): the share of the launch
+    each issue port is busy if nothing else stalls.  `bound` names the largest of the three."""
+    recs_per_launch = tot_recs / max(1.0, k_launches / steps)
+    model_bytes = SURVEY_BYTES_PER_RECORD * recs_per_launch
+    achieved = model_bytes / k_avg_s / 1e9
+    tr = pmc_traffic() if world == 1 else None
+    fr = {"hbm_byte_model": achieved / HBM_PEAK_GBS}
+    issue = None
+    if tr is not None:
+        fr["hbm_measured_traffic"] = tr["bytes_per_launch"] / k_avg_s / 1e9 / HBM_PEAK_GBS
+        if tr.get("wave_insts_per_launch"):
+            rates = issue_rates(ctx)
+            wi = tr["wave_insts_per_launch"]
+            issue = {k: {"wave_insts_per_launch": wi.get(k), "peak_wave_insts_per_s": rates[k], "frac": wi[k] / rates[k] / k_avg_s} for k in ("valu", "salu", "lds") if k in wi}
+            if issue:
+                top = max(issue, key=lambda k: issue[k]["frac"])
+                fr["issue_" + top] = issue[top]["frac"]
+    bound = max(fr, key=lambda k: fr[k])
+    return {"bound": "hbm" if bound.startswith("hbm") else "issue", "bound_detail": bound, "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "fractions": fr, "traffic": tr, "issue": issue,
+            "algorithmic_bytes_per_launch": model_bytes, "bytes_per_record": SURVEY_BYTES_PER_RECORD,
+            "resident_array_bytes_per_record": tot_alg / tot_recs,
+            "kernel_ms_avg": k_avg_s * 1e3, "launches": int(k_launches), "kernel_ms_per_step_max_rank": k_ms_max_rank / steps,
+            "note": "achieved = 115 B x records (SURVEY.md 8(d): the arrays of a record incl. all of its bases and qualities) / HIP-event time of k_map.  The kernel "
+                    "reads bases / qualities only under a het SNP, so it moves far fewer bytes than the model (fractions.hbm_measured_traffic) and is "
+                    "paced by instruction issue and memory latency, not by bandwidth (fractions.issue_*, issue)"}
 
 
 def main():
@@ -337,8 +392,6 @@ def main():
 
     if rank == 0:
         k_avg_s = k_ms_sum / max(1.0, k_launches) / 1e3
-        alg_per_launch = tot_alg / max(1.0, k_launches / a.steps)
-        achieved = alg_per_launch / k_avg_s / 1e9
         out = {
             "metric": "het-SNP allele calls/sec + phased variants/sec, whole-genome RNA-seq, 1→8 GPUs",
             "value": tot_calls * a.steps / dt, "unit": "allele calls/s", "n_gpus": world, "steps": a.steps,
@@ -349,13 +402,7 @@ def main():
                        "records": int(tot_recs), "het_snps": int(tot_snps), "calls_per_step": int(tot_calls), "shards": len(plan),
                        "records_per_s": tot_recs * a.steps / dt, "gen_seconds": round(t_gen, 1),
                        "step": "K_map over all chromosome shards of the rank in one batched submission (phz_map_reads_batch)"},
-            "roofline": {"bound": "hbm", "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                         "algorithmic_bytes_per_launch": alg_per_launch, "bytes_per_record": tot_alg / tot_recs,
-                         "kernel_ms_avg": k_avg_s * 1e3, "launches": int(k_launches),
-                         "kernel_ms_per_step_max_rank": k_ms_max_rank / a.steps,
-                         "note": "achieved = algorithmic bytes of the launches (shard arrays + 4 B/SNP + 17 B/call) / their HIP-event time; "
-                                 "the kernel reads seq/qual only under a het SNP, so bytes actually moved are lower (traffic)"},
+            "roofline": kmap_roofline(mapper.ctx, tot_recs, tot_alg, k_avg_s, k_launches, a.steps, k_ms_max_rank, world),
         }
         if phasing is not None:
             out["phasing"] = phasing
@@ -484,8 +531,8 @@ def configs1_entry(mapper, a, dev):
     alg = shard.nbytes_map_inputs() + 4 * len(v) + CALL_BYTES * first[0].n
     k = tot / n / 1e3
     out = {"workload": "configs[1]: chr1 full, 40000 het SNPs, 50000000 records x 76 bp, one shard", "value": first[0].n / dt,
-           "unit": "allele calls/s", "ms_per_step": dt * 1e3, "kernel_ms_avg": k * 1e3, "roofline_frac": alg / k / 1e9 / HBM_PEAK_GBS,
-           "bytes_per_record": alg / shard.n}
+           "unit": "allele calls/s", "ms_per_step": dt * 1e3, "kernel_ms_avg": k * 1e3, "roofline_frac": SURVEY_BYTES_PER_RECORD * shard.n / k / 1e9 / HBM_PEAK_GBS,
+           "bytes_per_record": SURVEY_BYTES_PER_RECORD, "resident_array_bytes_per_record": alg / shard.n}
     if not a.no_phasing:
         # stages T1-O2 on the same shard (round 1 measured 76 ms here)
         vs = pvcf.load_variants("\n".join(synth.vcf_lines([v])))

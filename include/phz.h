@@ -638,6 +638,11 @@ int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_column, con
                        int32_t gw_phase_vcf, double min_confidence, const phz_vcfout_chrom *chroms, int32_t n_chroms, int32_t threads,
                        char **out, int64_t *out_len, int64_t *unphased_phased, int64_t *corrections);
 
+/* Issue-rate microbenchmark (gfx950): wave64 instructions per second over the whole chip for kind 0 vector ALU (v_add_u32), 1 scalar ALU
+ * (s_add_u32), 2 LDS (ds_read_b32), with waves_per_simd (1..8) waves resident on every SIMD; the ceilings K_map's instruction stream is
+ * measured against (bench.py roofline.issue).  n_cu / clock_mhz: compute units and reported engine clock of the device. */
+int phz_microbench(phz_ctx *ctx, int kind, int waves_per_simd, int iters, double *wave_insts_per_s, int *n_cu, int *clock_mhz);
+
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
 int phz_reset_timing(phz_ctx *ctx);
