@@ -46,6 +46,7 @@ class Config:
         self.host_threads = 1          # threads of the native block phasing / row writer (the reference's --threads)
         self.device_rows = True        # stages T7-O2 on the GPU (phz_rowsdev_*); the host stage takes what the device stage declines
         self.fetch_text = True         # copy the finished row text to (page-locked) host memory; False leaves it in HBM (bench)
+        self.py_hash_order = 0         # 1: rows / read labels in the order CPython 3.10 gives the reference's sets (pyorder.py; needs PYTHONHASHSEED=0)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown option " + k)
@@ -290,6 +291,29 @@ class Engine:
                 "var_rank": G["var_rank"][v0:v0 + nv], "ea": G["ea"][lo:hi] - v0, "eb": G["eb"][lo:hi] - v0, "cto": G["cto"][lo:hi],
                 "linked": G["linked"][lo:hi].astype(bool), "kept": int(vc.sum())}
 
+    def kept_lines(self) -> dict:
+        """Host arrays of the kept call lines, per chromosome and BAM in line order: (QNAME id, variant index, class 0 ref / 1 alt / 2 other) -- what
+        pyorder.replay walks.  The classes come from the resident tally (phz_tally_fetch line_cls)."""
+        G = self.G
+        n = G["n_lines"]
+        cls_all = np.zeros(max(1, n), dtype=np.uint8)
+        o = _lib.phz_tally_out(None, None, None, None, C.c_void_p(cls_all.ctypes.data), None, None, None, None, None, None, None, None)
+        self.ctx.check(self.lib.phz_tally_fetch(self.ctx.h, C.byref(o), _lib.PHZ_HOST))
+        out = {}
+        for c in self.chrom_list:
+            per = []
+            for b, sh in enumerate(self.shards[c]):
+                if sh is None or (c, b) not in G["line_base"]:
+                    per.append(None); continue
+                base, m = G["line_base"][(c, b)]
+                cls = cls_all[base:base + m]
+                keep = cls != 255
+                ri = sh.calls.read_idx.cpu().numpy().astype(np.int64)
+                qid = sh.qid.cpu().numpy()[ri]
+                per.append((qid[keep], sh.calls.var_idx.cpu().numpy()[keep], cls[keep]))
+            out[c] = per
+        return out
+
     def tally_all(self):
         """Stage A: K_tally over this rank's chromosomes; returns the two global noise counters of these chromosomes."""
         self.G = self._tally_genome()
@@ -329,7 +353,7 @@ class Engine:
         out, summary = merge_fragments(frags, chroms, self.cfg, noise, len(self.bam_names))
         # per chromosome with blocks: (name, block arrays of phz_rows_format, blocks before it) -- what write_vcf needs
         self.vcf_blocks = []
-        if self.cfg.want_vcf:
+        if self.cfg.want_vcf or self.cfg.py_hash_order:
             block_index = 0
             for c in chroms:
                 if frags[c]["vcf"] is not None:
@@ -338,6 +362,16 @@ class Engine:
         self.stats["merge_s"] = _t.perf_counter() - t3
         self.log += summary["log"]
         self.phased = summary["phased"]; self.total_lines = summary["lines"]
+        if self.cfg.py_hash_order:
+            # raw-byte tier: replay the reference's set constructions over the same strings (an exactness mode: pure Python over every call line)
+            from . import pyorder
+            if pdist.world()[1] > 1:
+                raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "py_hash_order needs all chromosomes on one rank")
+            text = {k: b"".join(pdist.as_bytes(x) for x in v).decode() for k, v in out.items()}
+            text = pyorder.replay(self, text)
+            if chunks:
+                return {k: [v.encode()] for k, v in text.items()}
+            return {k: v.encode() for k, v in text.items()} if binary else text
         if chunks:
             return out
         out = {k: b"".join(pdist.as_bytes(x) for x in v) for k, v in out.items()}

@@ -72,6 +72,9 @@ def build_parser():
     p.add_argument("--debug", type=int, default=0)
     p.add_argument("--chr", default="")
     p.add_argument("--unique_ids", type=int, default=0)
+    p.add_argument("--py_hash_order", type=int, default=0,
+                   help="1: rows and read labels of variant_connections / haplotypes / haplotypic_counts in the order CPython 3.10 gives the reference's sets "
+                        "(byte-identical files; needs PYTHONHASHSEED=0; a pure-Python pass over every call line, not the fast path)")
     p.add_argument("--id_separator", default="_")
     p.add_argument("--output_network", default="")
     p.add_argument("--process_slow", type=int, default=0, required=False)
@@ -203,7 +206,7 @@ def main(argv=None):
     excl = [x - 1 for x in map(int, args.haplo_count_bam_exclude.split(","))] if args.haplo_count_bam_exclude != "" else []
     cfg = Config(baseq=args.baseq, as_q_cutoff=args.as_q_cutoff, cc_threshold=args.cc_threshold, max_block_size=args.max_block_size,
                  id_separator=args.id_separator, unphased_vars=args.unphased_vars, gw_phase_method=args.gw_phase_method,
-                 output_read_ids=args.output_read_ids, unique_ids=args.unique_ids, haplo_count_bam_exclude=excl,
+                 output_read_ids=args.output_read_ids, unique_ids=args.unique_ids, haplo_count_bam_exclude=excl, py_hash_order=args.py_hash_order,
                  include_indels=args.include_indels, host_threads=max(1, args.threads))
     eng = Engine(vs, bam_names, cfg, device=local)
     eng.spool_dir = os.path.dirname(os.path.abspath(args.o))       # ranks hand their row text to rank 0 through files next to the outputs
@@ -247,7 +250,7 @@ def main(argv=None):
         items = []
         for chrom in vs.chroms:
             if chrom in shards and chrom in mine:
-                items.append((chrom, shards[chrom].to(device), len(interners[chrom]), interners[chrom].names if args.output_read_ids == 1 else None))
+                items.append((chrom, shards[chrom].to(device), len(interners[chrom]), interners[chrom].names if (args.output_read_ids == 1 or args.py_hash_order == 1) else None))
         eng.add_shards(bi, items)                # all chromosomes of the BAM in one K_map submission
         for it in items:
             say("               completed chromosome %s..." % it[0])

@@ -80,7 +80,7 @@ def _fill(eng, c: str, keep: list) -> "_lib.phz_rows_in":
                 ex[b] = 1
         I.bam_excluded = A(ex, np.uint8)
     I.unique_ids = int(cfg.unique_ids); I.gw_phase_method = int(cfg.gw_phase_method); I.output_read_ids = int(cfg.output_read_ids)
-    I.unphased_vars = int(cfg.unphased_vars); I.max_block_size = int(cfg.max_block_size); I.want_vcf = 1 if cfg.want_vcf else 0
+    I.unphased_vars = int(cfg.unphased_vars); I.max_block_size = int(cfg.max_block_size); I.want_vcf = 1 if (cfg.want_vcf or cfg.py_hash_order) else 0
     I.threads = 1
     if cfg.output_read_ids == 1:
         from .vcf import sep_pool
@@ -122,7 +122,7 @@ def format_chroms(eng, chroms, threads: int) -> Dict[str, Dict]:
             out[name] = owner.parts(name)[0]
         for name in ("allelic", "single_ase", "single_hap"):
             out[name], out[name + "_bam"] = owner.parts(name)
-        if cfg.want_vcf:
+        if cfg.want_vcf or cfg.py_hash_order:
             nbk = int(O.n_blocks); nvv = int(O.n_blk_vars)
             out["vcf"] = {"size": vec("blk_size", np.int32, nbk), "var": vec("blk_var", np.int32, nvv), "hap": vec("blk_hap", np.uint8, nvv),
                           "cor": vec("blk_cor", np.int8, 2 * nvv), "stat": vec("blk_stat", np.float64, nbk),

@@ -146,7 +146,7 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     sh = sorted(((base, base + n, b) for (c, b), (base, n) in G["line_base"].items()))
     lo = np.array([x[0] for x in sh], dtype=np.int64); hi = np.array([x[1] for x in sh], dtype=np.int64); sb = np.array([x[2] for x in sh], dtype=np.int32)
     o = _lib.phz_rowsdev_opts(nb, _vp(bam_off), _vp(bam_txt), _vp(ex), len(sh), _vp(lo), _vp(hi), _vp(sb), int(cfg.unique_ids), int(cfg.gw_phase_method),
-                              int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.max_block_size), 1 if cfg.want_vcf else 0, float(cfg.cc_threshold))
+                              int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.max_block_size), 1 if (cfg.want_vcf or cfg.py_hash_order) else 0, float(cfg.cc_threshold))
     R = _lib.phz_rowsdev_result()
     ctx.check(lib.phz_rowsdev_run(ctx.h, T.h, C.byref(o), _vp(slot_pv), _vp(txt_off), _vp(txt), C.byref(R)))
     t3 = _t.perf_counter()
@@ -180,7 +180,7 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     if eng.chrom_list:
         f0 = frags[eng.chrom_list[0]]            # the counts only ever enter sums over chromosomes
         f0["lines"] = int(G["n_kept"]); f0["dropped"] = int(R.dropped); f0["phased"] = int(R.phased); f0["allelic_rows"] = int(R.allelic_rows)
-    if cfg.want_vcf and int(R.n_blocks) > 0:
+    if (cfg.want_vcf or cfg.py_hash_order) and int(R.n_blocks) > 0:
         nbk = int(R.n_blocks); nvr = int(R.n_blk_vars)
         size = np.empty(nbk, np.int32); var = np.empty(nvr, np.int32); hap = np.empty(nvr, np.uint8); cor = np.empty(2 * nvr, np.int8)
         stat = np.empty(nbk, np.float64); stat_int = np.empty(nbk, np.uint8); maxmaf = np.empty(nbk, np.int32)

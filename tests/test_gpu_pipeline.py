@@ -108,6 +108,29 @@ def test_cli_from_bam_matches_reference(tmp_path):
     assert gzip.open(prefix + ".vcf.gz.tbi", "rb").read()[:4] == b"TBI\x01"
 
 
+def test_cli_py_hash_order_gives_the_reference_bytes(tmp_path):
+    """--py_hash_order 1 under PYTHONHASHSEED=0: the drop-in CLI (GPU path from an unfiltered BAM) writes the reference's five files BYTE FOR BYTE
+    (fixture pipe_one was written by the reference under the same hash seed): the raw tier of SURVEY.md 8(a)."""
+    import gzip
+    import subprocess
+    from phaser_amd import bamio, synth
+    v, gs, ge, w = synth.make_variants("chr22", 1, 3_000_000, 300, 201, n_genes=20)
+    rb = synth.make_reads(v, gs, ge, w, 9000, 202)
+    bam = str(tmp_path / "a.bam")
+    bamio.readbatch_to_bam(bam, [rb], [("chr21", 46709983), ("chr22", 50818468)])
+    d = os.path.join(GOLD, "pipe_one")
+    vcfgz = str(tmp_path / "in.vcf.gz")
+    with gzip.open(vcfgz, "wt") as f:
+        f.write(open(os.path.join(d, "in.vcf")).read())
+    prefix = str(tmp_path / "out")
+    env = dict(os.environ, PYTHONHASHSEED="0", PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-m", "phaser_amd.phaser", "--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1",
+                        "--o", prefix, "--write_vcf", "0", "--threads", "3", "--py_hash_order", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for name in OUTPUTS:
+        assert open(prefix + "." + name + ".txt").read() == gz_text(os.path.join(d, "out.%s.txt.gz" % name)), name
+
+
 @pytest.mark.parametrize("seed,err", [(9001, 0.002), (9002, 0.04)])
 def test_fresh_seed_vs_oracle(mapper, oracle_build, tmp_path, seed, err):
     """Inputs nobody has seen before (2 chromosomes x 2 BAMs with shared QNAMEs): product (GPU) vs the pinned oracle."""
