@@ -3,13 +3,16 @@
 // genome is one call and nothing ever pairs across chromosomes):
 //   k_as_hist      :545-553   AS column histogram (host turns it into numpy.percentile's value)
 //   k_line         :1287-1328 process_mapping_result: AS cutoff, allele class, per-variant line counters, first-appearance index, lines per
-//                             QNAME and per (variant, allele, BAM) read list; the QNAMEs that own at least one kept line are collected
-//                             on the way (only they get a group: a genome has 40M QNAME ids and 8M of them with lines)
-//   k_items                   set construction :636-640: the lines of a QNAME are gathered into its group (ranges handed out by a scan over
-//                             the touched QNAMEs only); read-list entries are placed into their (variant, allele, BAM) list
-//   k_groups       :558-581, :1265-1285  one thread per QNAME: its (tiny) group sorted, the owner BAM of its read_vars list ("last BAM
-//                             wins", stale-variable quirk), its first ref/alt line, the connectivity-map rank of its variants, the
-//                             distinct (variant, class) items and the per-variant distinct-QNAME counters
+//                             QNAME and per (variant, allele, BAM) read list
+//   k_tile         :636-640, :558-581, :1265-1285  the lines of a QNAME are its mates' records, a few hundred bases apart: nearly every QNAME has
+//                             all its lines inside one tile of 1,024 consecutive lines.  A workgroup groups its tile's lines by QNAME in LDS
+//                             (hash on the id); a group that holds ALL lines of its QNAME (the per-QNAME total of k_line says so) is finished
+//                             in place: sorted, its first ref/alt line, the connectivity-map rank of its variants, the distinct
+//                             (variant, class) items and the per-variant distinct-QNAME counters.  Lines of the few QNAMEs that straddle
+//                             tiles (or BAMs) are spilled.  Read-list entries are placed into their (variant, allele, BAM) list, one global
+//                             cursor step per (tile, list)
+//   k_groups                  the spilled QNAMEs (a per cent of them): gathered into groups through cursors, one thread per group, incl. the
+//                             owner BAM of the read_vars list ("last BAM wins", stale-variable quirk)
 //   k_pairs        :1602-1632 every QNAME contributes one count to cell (class_a, class_b) of every variant pair it touches -- the nine set
 //                             intersections of test_variant_connection for all pairs at once (LDS hash -> global hash)
 //   k_edge_*                  edge list in (a, b) order: counting sort by a over the USED hash slots, tiny groups sorted by b; the table is
@@ -103,8 +106,7 @@ struct LineOut {
     unsigned long long *var_first;   // [nv]
     uint32_t *rl_cnt;                // [nv*2*nb] kept ref/alt lines per (variant, allele, BAM)
     uint32_t *qcount;                // [nq] kept lines of the QNAME (persistent, all zero between calls)
-    uint32_t *touched;               // QNAMEs with at least one kept line, in no particular order
-    unsigned long long *counters;    // [3] kept lines, [6] touched QNAMEs
+    unsigned long long *counters;    // [3] kept lines
     int nb;
 };
 
@@ -114,15 +116,13 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
     const uint32_t bx = blockIdx.x - T.blk0[sh_];
     __shared__ int s_cnt[TW * 3];
     __shared__ unsigned long long s_first[TW];
-    __shared__ uint32_t s_new[LINES_PER_BLOCK];
     __shared__ int s_vbase;
-    __shared__ unsigned int s_kept, s_nnew;
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned int s_kept;
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)bx * LINES_PER_BLOCK;
     for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
     for (int j = tid; j < TW; j += 256) s_first[j] = ~0ull;
-    if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; s_nnew = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
+    if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
     __syncthreads();
     const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;       // a little room below (mate pairs / overlapping records)
     unsigned int kept = 0;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
         }
         const uint32_t q = L.qid_base + (uint32_t)L.read_qid[r];
         O.line_q[g] = q;
-        if (atomicAdd(&O.qcount[q], 1u) == 0u) s_new[atomicAdd(&s_nnew, 1u)] = q;      // the first kept line of the QNAME (in this call)
+        atomicAdd(&O.qcount[q], 1u);
     }
     if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
@@ -167,20 +167,15 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
         const unsigned long long f = s_first[j];
         if (f != ~0ull) atomicMin(&O.var_first[vbase + j], f);
     }
-    if (tid == 0) {
-        if (s_kept) atomicAdd(&O.counters[3], (unsigned long long)s_kept);
-        s_base = s_nnew ? atomicAdd(&O.counters[6], (unsigned long long)s_nnew) : 0ull;       // one global atomic per workgroup
-    }
-    __syncthreads();
-    for (unsigned j = tid; j < s_nnew; j += 256) O.touched[s_base + j] = s_new[j];
+    if (tid == 0 && s_kept) atomicAdd(&O.counters[3], (unsigned long long)s_kept);
 }
 
-// group of every touched QNAME: its line count (the counter goes back to zero and serves as the fill cursor of k_items)
+// group of every spilled QNAME: its line count (the counter goes back to zero and serves as the fill cursor of k_items_spill)
 __global__ __launch_bounds__(256) void k_group_plan(int64_t nt, const uint32_t *touched, uint32_t *qcount, uint32_t *cnt_t) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nt) return;
     const uint32_t q = touched[i];
-    cnt_t[i] = qcount[q]; qcount[q] = 0u;
+    cnt_t[i] = qcount[q] & 0x7FFFFFFFu; qcount[q] = 0u;          // bit 31: "already on the list of spilled QNAMEs"
 }
 // ... and the counter becomes the QNAME's write cursor: it starts at the group's base, k_items takes slots from it, k_groups returns it to zero
 __global__ __launch_bounds__(256) void k_group_base(int64_t nt, const uint32_t *touched, const uint32_t *base_t, uint32_t *qcount) {
@@ -198,22 +193,231 @@ __global__ __launch_bounds__(256) void k_rl_expand(int64_t nlists, const uint32_
 
 // item = variant:28 | class:2 | line:32 (sorts by variant, class, line); read-list entry = line:32 | chromosome-local QNAME id:32
 __device__ __forceinline__ uint64_t item_pack(uint32_t v, uint32_t cls, uint32_t g) { return ((uint64_t)v << 34) | ((uint64_t)cls << 32) | g; }
-__global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_cls, const uint32_t *line_q, uint32_t *qcount, uint64_t *items,
-                                               uint32_t *rl_cursor, uint64_t *rl_tmp, int nb) {
+// distinct item of a group = QNAME id:32 | variant:28 << 4 | class << 2 | linked (the QNAME id in the high word keeps the groups apart in k_pairs)
+__device__ __forceinline__ uint64_t dist_pack(uint32_t q, uint32_t v, uint32_t cls, uint32_t linked) { return ((uint64_t)q << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked; }
+
+#ifndef PHZ_TALLY_TILE
+#define PHZ_TALLY_TILE 1024        // (the emulation tests also build a 256-line variant so that small fixtures straddle tiles)
+#endif
+constexpr int TL = PHZ_TALLY_TILE; // lines per tile of k_tile
+constexpr int TH = 2 * TL;         // LDS hash slots (at most TL distinct QNAMEs: load factor <= 0.5)
+constexpr int TSP = TH / 256;      // slots per thread
+constexpr int TH_SHIFT = TL == 1024 ? 21 : (TL == 512 ? 22 : 23);
+static_assert(TL == 1024 || TL == 512 || TL == 256, "tile of 256 / 512 / 1024 lines");
+constexpr int TWT = 512;           // variants per LDS window of k_tile
+constexpr uint32_t Q_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t Q_SPILLED = 0x80000000u;
+
+struct TileOut {
+    const uint8_t *line_cls; const uint32_t *line_q;
+    uint32_t *qcount;                // [nq] total kept lines per QNAME from k_line; complete groups return it to zero, spilled ones get bit 31
+    uint64_t *items;                 // [tiles * TL] distinct items of the complete groups in the slots of their tile, holes = KEY_DROPPED
+    uint32_t *sp_q; uint64_t *sp_item;       // spilled lines (cursor: low word of counters[10])
+    uint32_t *touched;               // spilled QNAMEs, once each (cursor: high word of counters[10])
+    unsigned long long *var_rank; int32_t *var_distinct;
+    uint32_t *rl_cursor; uint64_t *rl_tmp;
+    unsigned long long *counters;
+    int nb;
+};
+
+__global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
-    const int64_t i = (int64_t)(blockIdx.x - T.blk0[sh_]) * 256 + threadIdx.x;
-    if (i >= L.n) return;
-    const int64_t g = L.line_base + i;
-    const uint8_t cls = line_cls[g];
-    if (cls == 255) return;
-    const uint32_t q = line_q[g];
-    const uint32_t v = (uint32_t)(L.var_idx[i] + L.var_base);
-    items[atomicAdd(&qcount[q], 1u)] = item_pack(v, cls, (uint32_t)g);
-    if (cls < 2) {
-        const uint32_t e = (v * 2u + cls) * (uint32_t)nb + (uint32_t)L.bam;
-        rl_tmp[atomicAdd(&rl_cursor[e], 1u)] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)(q - L.qid_base);
+    const uint32_t bx = blockIdx.x - T.blk0[sh_];
+    __shared__ uint32_t s_q[TH];                 // QNAME id of the slot
+    __shared__ uint32_t s_c[TH];                 // lines of the slot's QNAME in this tile -> write cursor of its group (ends at the group's end)
+    __shared__ uint16_t s_n[TH];                 // lines of the slot's group
+    __shared__ uint64_t s_it[TL];                // the tile's kept lines as items, group by group
+    __shared__ int s_cnt[TWT * 3];
+    __shared__ unsigned long long s_rank[TWT];
+    __shared__ uint32_t s_rl[TWT * 2];           // read-list entries of (variant, allele) in this tile -> base of the tile's chunk in the list
+    __shared__ uint32_t s_touch[TL];             // QNAMEs this tile puts on the list of spilled QNAMEs
+    __shared__ uint32_t s_part[4];
+    __shared__ int s_vbase;
+    __shared__ uint32_t s_nspill, s_ntouch, s_nkept;
+    __shared__ unsigned long long s_obase;
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)bx * TL;
+    if (tid == 0) { s_nspill = 0; s_ntouch = 0; }
+    for (int j = tid; j < TH; j += 256) { s_q[j] = Q_EMPTY; s_c[j] = 0u; }
+    for (int j = tid; j < TWT * 3; j += 256) s_cnt[j] = 0;
+    for (int j = tid; j < TWT; j += 256) s_rank[j] = ~0ull;
+    for (int j = tid; j < TWT * 2; j += 256) s_rl[j] = 0u;
+    if (tid == 0) s_vbase = L.var_idx[i0] + L.var_base;
+    __syncthreads();
+    const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;
+    // ---- 1. the tile's lines: QNAME -> slot (count), read-list entry -> rank inside the tile's chunk
+    constexpr int K = TL / 256;
+    uint32_t l_cls[K], l_q[K], l_v[K], l_slot[K], l_rank[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int64_t i = i0 + tid + 256 * k;
+        l_cls[k] = 255u; l_q[k] = 0u; l_v[k] = 0u;
+        if (i < L.n) {
+            const int64_t g = L.line_base + i;
+            l_cls[k] = O.line_cls[g]; l_q[k] = O.line_q[g]; l_v[k] = (uint32_t)(L.var_idx[i] + L.var_base);
+        }
     }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        l_slot[k] = Q_EMPTY; l_rank[k] = Q_EMPTY;
+        if (l_cls[k] == 255u) continue;
+        const uint32_t q = l_q[k];
+        uint32_t s = (q * 2654435761u) >> TH_SHIFT;
+        for (;;) {
+            const uint32_t prev = atomicCAS(&s_q[s], Q_EMPTY, q);
+            if (prev == Q_EMPTY || prev == q) break;
+            s = (s + 1) & (TH - 1);
+        }
+        atomicAdd(&s_c[s], 1u);
+        l_slot[k] = s;
+        if (l_cls[k] < 2u) {
+            const unsigned d = l_v[k] - (unsigned)vbase;
+            if (d < (unsigned)TWT) l_rank[k] = atomicAdd(&s_rl[d * 2 + l_cls[k]], 1u);
+            else {                                               // a line far from the tile's window (long intron): straight to its list
+                const int64_t i = i0 + tid + 256 * k;
+                const uint32_t e = (l_v[k] * 2u + l_cls[k]) * (uint32_t)O.nb + (uint32_t)L.bam;
+                O.rl_tmp[atomicAdd(&O.rl_cursor[e], 1u)] = ((uint64_t)(uint32_t)(L.line_base + i) << 32) | (uint32_t)(q - L.qid_base);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. group ranges (exclusive scan of the slot counts); one cursor step per (tile, read list)
+    {
+        uint32_t c[TSP], sum = 0;
+#pragma unroll
+        for (int j = 0; j < TSP; j++) { c[j] = s_c[tid * TSP + j]; sum += c[j]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if ((tid & 63) >= d) incl += y; }
+        if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t base = incl - sum;
+        for (int w = 0; w < (tid >> 6); w++) base += s_part[w];
+        if (tid == 255) s_nkept = base + sum;
+#pragma unroll
+        for (int j = 0; j < TSP; j++) { s_n[tid * TSP + j] = (uint16_t)c[j]; s_c[tid * TSP + j] = base; base += c[j]; }
+    }
+    {
+        uint32_t c[TWT * 2 / 256];
+#pragma unroll
+        for (int j = 0; j < TWT * 2 / 256; j++) {
+            const int x = tid + 256 * j;
+            c[j] = s_rl[x];
+            if (c[j]) c[j] = atomicAdd(&O.rl_cursor[((uint32_t)(vbase + (x >> 1)) * 2u + (uint32_t)(x & 1)) * (uint32_t)O.nb + (uint32_t)L.bam], c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < TWT * 2 / 256; j++) s_rl[tid + 256 * j] = c[j];
+    }
+    __syncthreads();
+    // ---- 3. lines into their groups, read-list entries into their lists
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (l_slot[k] == Q_EMPTY) continue;
+        const int64_t i = i0 + tid + 256 * k;
+        const uint32_t g = (uint32_t)(L.line_base + i);
+        s_it[atomicAdd(&s_c[l_slot[k]], 1u)] = item_pack(l_v[k], l_cls[k], g);
+        if (l_rank[k] != Q_EMPTY) {
+            const unsigned d = l_v[k] - (unsigned)vbase;
+            O.rl_tmp[s_rl[d * 2 + l_cls[k]] + l_rank[k]] = ((uint64_t)g << 32) | (uint32_t)(l_q[k] - L.qid_base);
+        }
+    }
+    __syncthreads();
+    // ---- 4. one thread per group.  A group holding every line of its QNAME is finished here (all its lines come from this shard's BAM: that
+    //         BAM owns the read_vars list, every ref/alt line is linked): its distinct items stay at the front of its range, the rest of the
+    //         range becomes KEY_DROPPED.  The others hand their lines to the spill list (ranges inside the tile's share from LDS counters)
+    uint32_t sp_beg[TSP], sp_n[TSP], sp_at[TSP], tot[TSP];
+#pragma unroll
+    for (int j = 0; j < TSP; j++) {
+        const int slot = tid + 256 * j;
+        tot[j] = s_n[slot] ? O.qcount[s_q[slot]] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < TSP; j++) {
+        const int slot = tid + 256 * j;
+        const uint32_t n = s_n[slot];
+        sp_n[j] = 0; sp_beg[j] = 0; sp_at[j] = 0;
+        if (!n) continue;
+        const uint32_t q = s_q[slot];
+        const uint32_t beg = s_c[slot] - n;
+        uint64_t *it = s_it + beg;
+        if ((tot[j] & 0x7FFFFFFFu) != n) {
+            if (!(atomicOr(&O.qcount[q], Q_SPILLED) & Q_SPILLED)) s_touch[atomicAdd(&s_ntouch, 1u)] = q;       // the first tile to meet it lists the QNAME
+            sp_n[j] = n; sp_beg[j] = beg; sp_at[j] = atomicAdd(&s_nspill, n);
+            continue;
+        }
+        O.qcount[q] = 0u;                                      // clean for the next call
+        for (uint32_t a = 1; a < n; a++) {
+            const uint64_t x = it[a];
+            uint32_t b = a;
+            while (b > 0 && it[b - 1] > x) { it[b] = it[b - 1]; b--; }
+            it[b] = x;
+        }
+        uint32_t first = 0xFFFFFFFFu, vmin = 0xFFFFFFFFu, vmax = 0;
+        for (uint32_t a = 0; a < n; a++) {
+            const uint64_t x = it[a];
+            if (((x >> 32) & 3ull) >= 2ull) continue;
+            const uint32_t g = (uint32_t)x, v = (uint32_t)(x >> 34);
+            first = g < first ? g : first;
+            vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+        }
+        const bool multi = vmin != 0xFFFFFFFFu && vmin != vmax;
+        uint32_t w = 0, a = 0;
+        while (a < n) {
+            const uint64_t key = it[a] >> 32;                  // variant:28 | class:2
+            const uint32_t v = (uint32_t)(key >> 2), cls = (uint32_t)(key & 3ull);
+            const uint32_t gl = (uint32_t)it[a];               // the run is sorted by line: its first line
+            while (a < n && (it[a] >> 32) == key) a++;
+            const uint32_t linked = cls < 2u ? 1u : 0u;
+            const unsigned d = v - (unsigned)vbase;
+            if (multi && linked) {
+                const unsigned long long rk = ((unsigned long long)first << 32) | gl;
+                if (d < (unsigned)TWT) atomicMin(&s_rank[d], rk); else atomicMin(&O.var_rank[v], rk);
+            }
+            if (d < (unsigned)TWT) atomicAdd(&s_cnt[d * 3 + cls], 1); else atomicAdd(&O.var_distinct[(int64_t)v * 3 + cls], 1);
+            it[w++] = dist_pack(q, v, cls, linked);
+        }
+        for (uint32_t k = w; k < n; k++) it[k] = KEY_DROPPED;
+    }
+    __syncthreads();
+    // ---- 5. ONE global cursor step per tile (spilled lines in the low word, listed QNAMEs in the high word), the spilled lines out, and the
+    //         tile's slots of the item array written in one sweep (groups in place, holes = KEY_DROPPED)
+    if (tid == 0) {
+        const unsigned long long add = ((unsigned long long)s_ntouch << 32) | s_nspill;
+        s_obase = add ? atomicAdd(&O.counters[10], add) : 0ull;
+    }
+    __syncthreads();
+    const uint32_t spill_base = (uint32_t)s_obase, touch_base = (uint32_t)(s_obase >> 32);
+#pragma unroll
+    for (int j = 0; j < TSP; j++) {
+        if (!sp_n[j]) continue;
+        const uint32_t q = s_q[tid + 256 * j];
+        for (uint32_t a = 0; a < sp_n[j]; a++) {
+            O.sp_q[spill_base + sp_at[j] + a] = q; O.sp_item[spill_base + sp_at[j] + a] = s_it[sp_beg[j] + a];
+            s_it[sp_beg[j] + a] = KEY_DROPPED;
+        }
+    }
+    for (uint32_t j = tid; j < s_ntouch; j += 256) O.touched[touch_base + j] = s_touch[j];
+    __syncthreads();
+    {
+        const uint32_t nk = s_nkept;
+        uint64_t *dst = O.items + ((int64_t)blockIdx.x * TL);
+        for (int j = tid; j < TL; j += 256) dst[j] = (uint32_t)j < nk ? s_it[j] : KEY_DROPPED;
+    }
+    for (int j = tid; j < TWT * 3; j += 256) {
+        const int cc = s_cnt[j];
+        if (cc) atomicAdd(&O.var_distinct[(int64_t)(vbase + j / 3) * 3 + (j % 3)], cc);
+    }
+    for (int j = tid; j < TWT; j += 256) {
+        const unsigned long long f = s_rank[j];
+        if (f != ~0ull) atomicMin(&O.var_rank[vbase + j], f);
+    }
+}
+
+// the spilled lines into the groups of their QNAMEs (ranges from the scan over the spilled QNAMEs' line counts)
+__global__ __launch_bounds__(256) void k_items_spill(int64_t n, const uint32_t *sp_q, const uint64_t *sp_item, uint32_t *qcount, uint64_t *items) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) items[atomicAdd(&qcount[sp_q[i]], 1u)] = sp_item[i];
 }
 
 // One thread per QNAME group.  Sorts the group (insertion sort: a QNAME owns a handful of lines), then
@@ -223,7 +427,7 @@ __global__ __launch_bounds__(256) void k_items(LinesTab T, const uint8_t *line_c
 //   rank   : overlap-dictionary key order (SURVEY.md 8.1 rule 4, phaser.py:1271-1283): for QNAMEs whose surviving list holds >= 2 distinct
 //            variants, every variant gets (first << 32 | its first linked line) as a candidate for its smallest key
 //   the distinct (variant, class) items (linked = max over the run of equal lines), written back at the front of the group as
-//            group:32 | variant:28 << 4 | class << 2 | linked (the rest of the group becomes KEY_DROPPED), and the per-variant distinct-QNAME counters
+//            QNAME id:32 | variant:28 << 4 | class << 2 | linked (the rest of the group becomes KEY_DROPPED), and the per-variant distinct-QNAME counters
 struct GroupOut {
     uint32_t *qcount; uint64_t *items; uint32_t *cnt_t; const uint32_t *base_t, *touched;
     unsigned long long *var_rank; int32_t *var_distinct; unsigned long long *counters;      // [0] distinct items
@@ -233,7 +437,6 @@ __global__ __launch_bounds__(256) void k_groups(int64_t nt, LinesTab T, GroupOut
     __shared__ int s_cnt[TW * 3];
     __shared__ unsigned long long s_rank[TW];
     __shared__ int s_vbase;
-    __shared__ unsigned int s_items[4];
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
@@ -241,7 +444,6 @@ __global__ __launch_bounds__(256) void k_groups(int64_t nt, LinesTab T, GroupOut
     if (tid == 0) { const int64_t i0 = (int64_t)blockIdx.x * 256; s_vbase = (int)(O.items[O.base_t[i0]] >> 34); }
     __syncthreads();
     const int vbase = s_vbase - 256 > 0 ? s_vbase - 256 : 0;
-    unsigned int ndist = 0;
     if (i < nt) {
         const uint32_t b = O.base_t[i], c = O.cnt_t[i];
         O.qcount[O.touched[i]] = 0u;                         // the fill cursor goes back to zero: clean for the next call
@@ -271,7 +473,6 @@ __global__ __launch_bounds__(256) void k_groups(int64_t nt, LinesTab T, GroupOut
         const bool multi = vmin != 0xFFFFFFFFu && vmin != vmax;
         // runs of equal (variant, class): one distinct item each; the variant's first linked line competes for its rank
         uint32_t w = 0, a = 0;
-        uint32_t prev_v = 0xFFFFFFFFu;
         while (a < c) {
             const uint64_t key = it[a] >> 32;                  // variant:28 | class:2
             const uint32_t v = (uint32_t)(key >> 2), cls = (uint32_t)(key & 3ull);
@@ -286,20 +487,15 @@ __global__ __launch_bounds__(256) void k_groups(int64_t nt, LinesTab T, GroupOut
                 const unsigned d = (unsigned)((int)v - vbase);
                 if (d < (unsigned)TW) atomicMin(&s_rank[d], rk); else atomicMin(&O.var_rank[v], rk);
             }
-            (void)prev_v;
             {
                 const unsigned d = (unsigned)((int)v - vbase);
                 if (d < (unsigned)TW) atomicAdd(&s_cnt[d * 3 + cls], 1); else atomicAdd(&O.var_distinct[(int64_t)v * 3 + cls], 1);
             }
-            it[w++] = ((uint64_t)(uint32_t)i << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked;       // group number in the high word
+            it[w++] = dist_pack(O.touched[i], v, cls, linked);
         }
         for (uint32_t k = w; k < c; k++) it[k] = KEY_DROPPED;
         O.cnt_t[i] = w;
-        ndist = w;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) ndist += __shfl_xor(ndist, d);
-    if ((tid & 63) == 0) s_items[tid >> 6] = ndist;
     __syncthreads();
     for (int j = tid; j < TW * 3; j += 256) {
         const int cc = s_cnt[j];
@@ -309,7 +505,6 @@ __global__ __launch_bounds__(256) void k_groups(int64_t nt, LinesTab T, GroupOut
         const unsigned long long f = s_rank[j];
         if (f != ~0ull) atomicMin(&O.var_rank[vbase + j], f);
     }
-    if (tid == 0) { const unsigned int t = s_items[0] + s_items[1] + s_items[2] + s_items[3]; if (t) atomicAdd(&O.counters[0], (unsigned long long)t); }
 }
 
 __device__ __forceinline__ uint32_t hash64(uint64_t k) {
@@ -345,17 +540,18 @@ __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m,
     __shared__ unsigned long long s_keys[PH_SLOTS];
     __shared__ int s_vals[PH_SLOTS * PH_VALS];
     __shared__ uint32_t s_claim[PH_SLOTS];
-    __shared__ unsigned int s_part[4], s_nclaim;
+    __shared__ unsigned int s_part[4], s_ipart[4], s_nclaim;
     __shared__ unsigned long long s_ubase;
     const int64_t i0 = (int64_t)blockIdx.x * PAIR_ITEMS;
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) s_keys[j] = KEY_DROPPED;
     for (int j = threadIdx.x; j < PH_SLOTS * PH_VALS; j += 256) s_vals[j] = 0;
     if (threadIdx.x == 0) s_nclaim = 0;
     __syncthreads();
-    unsigned int n_event = 0;
+    unsigned int n_event = 0, n_item = 0;
     for (int64_t i = i0 + threadIdx.x; i < i0 + PAIR_ITEMS && i < m; i += 256) {
         const uint64_t k = items[i];
         if (k == KEY_DROPPED) continue;
+        n_item++;
         const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
         for (int64_t j = i + 1; j < m; j++) {
             const uint64_t k2 = items[j];
@@ -391,8 +587,8 @@ __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m,
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n_event += __shfl_xor(n_event, d);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = n_event;
+    for (int d = 32; d >= 1; d >>= 1) { n_event += __shfl_xor(n_event, d); n_item += __shfl_xor(n_item, d); }
+    if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6] = n_event; s_ipart[threadIdx.x >> 6] = n_item; }
     __syncthreads();
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) {
         const uint64_t pk = s_keys[j];
@@ -411,6 +607,8 @@ __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m,
     if (threadIdx.x == 0) {
         const unsigned long long b = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
         if (b) atomicAdd(&counters[1], b);
+        const unsigned long long ni = (unsigned long long)s_ipart[0] + s_ipart[1] + s_ipart[2] + s_ipart[3];
+        if (ni) atomicAdd(&counters[0], ni);                  // distinct (QNAME, variant, class) items
         s_ubase = s_nclaim ? atomicAdd(&counters[7], (unsigned long long)s_nclaim) : 0ull;      // one global atomic per workgroup
     }
     __syncthreads();
@@ -546,11 +744,10 @@ __global__ __launch_bounds__(256) void k_rl_take_qid(const uint64_t *src, int64_
 // lines (match) and the other-allele lines (mismatch); the caller all-reduces them over chromosomes / ranks
 __global__ __launch_bounds__(256) void k_noise(const int32_t *var_count, int64_t nv, unsigned long long *out /* [0] match, [1] mismatch */) {
     __shared__ unsigned long long s_m[4], s_x[4];
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long m = 0, x = 0;
-    if (v < nv) {
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (int64_t)gridDim.x * 256) {       // few workgroups: two same-address atomics each
         const long long mm = (long long)var_count[v * 3] + var_count[v * 3 + 1], oo = var_count[v * 3 + 2];
-        if (mm > 0 && (double)oo / (double)(oo + mm) < 0.05) { m = (unsigned long long)mm; x = (unsigned long long)oo; }
+        if (mm > 0 && (double)oo / (double)(oo + mm) < 0.05) { m += (unsigned long long)mm; x += (unsigned long long)oo; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { m += __shfl_xor(m, d); x += __shfl_xor(x, d); }
@@ -598,7 +795,7 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
 enum { T_QBASE = 1, T_TOUCHED, T_CNT_T, T_BASE_T, T_ITEMS, T_COUNTERS, T_GKEYS, T_GVALS, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP, T_USED, T_MISC };
 // results and the read-list buffers live in their own buffers (ctx->tally_buf)
 enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_STATS, R_RLCNT, R_RLSTART, R_RLFILL, R_RLTMP, R_RLLIST, R_RLQID, R_A0, R_A1,
-       R_LINEQ, R_SORTK, R_SORTV0, R_SORTV1, R_SORTCNT, R_COUNT };
+       R_LINEQ, R_SORTK, R_SORTV0, R_SORTV1, R_SORTCNT, R_SPQ, R_SPITEM, R_COUNT };
 
 }  // namespace
 
@@ -720,7 +917,8 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
 #define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, buf, (bytes))) return s_; } while (0)
     RSV(R[R_CNT], NV * 12); RSV(R[R_FIRST], NV * 8); RSV(R[R_DIST], NV * 12); RSV(R[R_RANK], NV * 8); RSV(R[R_CLS], TOT); RSV(R[R_LINEQ], TOT * 4);
     RSV(R[R_RLCNT], NRL * 4); RSV(R[R_RLSTART], (NRL + 1) * 4); RSV(R[R_RLFILL], NRL * 4); RSV(R[R_RLTMP], TOT * 8); RSV(R[R_RLLIST], TOT * 4); RSV(R[R_RLQID], TOT * 4);
-    RSV(S[T_TOUCHED], TOT * 4); RSV(S[T_CNT_T], (TOT + 1) * 4); RSV(S[T_BASE_T], (TOT + 1) * 4); RSV(S[T_ITEMS], TOT * 8); RSV(S[T_COUNTERS], 128);
+    RSV(R[R_SPQ], TOT * 4); RSV(R[R_SPITEM], TOT * 8);
+    RSV(S[T_TOUCHED], TOT * 4); RSV(S[T_CNT_T], (TOT + 1) * 4); RSV(S[T_BASE_T], (TOT + 1) * 4); RSV(S[T_ITEMS], (2 * TOT + (size_t)(n_shards + 1) * TL) * 8); RSV(S[T_COUNTERS], 128);
     RSV(S[T_DEG], NV * 4); RSV(S[T_EOFF], (NV + 1) * 4); RSV(S[T_MISC], std::max(NRL, (size_t)1) * 12 + 64);
     hipStream_t sm = ctx->stream;
     {   // the one array indexed by QNAME id is persistent: `lines per QNAME`, then the QNAME's write cursor, all zero between calls (k_groups returns it
@@ -756,36 +954,42 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     const int single_bam = n_bams <= 1 ? 1 : 0;     // one BAM: every QNAME's read_vars list is owned by that BAM
     LineOut O;
     O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.line_q = line_q; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt; O.qcount = qcount;
-    O.touched = touched; O.counters = counters; O.nb = n_bams;
-    // shard tables of the per-line stages: LINES_PER_BLOCK lines per block (k_line) and 256 lines per block (k_items)
-    LinesTab TL, TI;
-    TL.L = nullptr; TL.blk0 = nullptr; TL.n = 0; TI = TL;
-    std::vector<uint32_t> gl, gi;
+    O.counters = counters; O.nb = n_bams;
+    // shard tables of the per-line stages: LINES_PER_BLOCK lines per block (k_line) and TL lines per block (k_tile)
+    LinesTab TLn, TT;
+    TLn.L = nullptr; TLn.blk0 = nullptr; TLn.n = 0; TT = TLn;
+    std::vector<uint32_t> gl, gt;
     if (n_shards > 0) {
-        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK); }, &TL, &gl, 0, 2)) return s2;
-        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return nblk(l.n); }, &TI, &gi, 1, 2)) return s2;
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK); }, &TLn, &gl, 0, 2)) return s2;
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + TL - 1) / TL); }, &TT, &gt, 1, 2)) return s2;
     }
-    const unsigned grid_l = n_shards > 0 ? gl.back() : 0u, grid_i = n_shards > 0 ? gi.back() : 0u;
-    if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(256), 0, sm, TL, O);
-    if (nv) hipLaunchKernelGGL(k_noise, dim3(nblk(nv)), dim3(256), 0, sm, (const int32_t *)d_cnt, nv, counters + 4);
+    const unsigned grid_l = n_shards > 0 ? gl.back() : 0u, grid_t = n_shards > 0 ? gt.back() : 0u;
+    if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(256), 0, sm, TLn, O);
+    if (nv) hipLaunchKernelGGL(k_noise, dim3(std::min(nblk(nv), 256u)), dim3(256), 0, sm, (const int32_t *)d_cnt, nv, counters + 4);
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, rl_cnt, rl_start, (int64_t)NRL, S[T_SCAN_TMP])) return s;
+    hipLaunchKernelGGL(k_rl_expand, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_list, rl_fill);
+    uint32_t *sp_q = (uint32_t *)R[R_SPQ].p; uint64_t *sp_item = (uint64_t *)R[R_SPITEM].p;
+    if (grid_t) {
+        TileOut TO;
+        TO.line_cls = d_cls; TO.line_q = line_q; TO.qcount = qcount; TO.items = items; TO.sp_q = sp_q; TO.sp_item = sp_item; TO.touched = touched;
+        TO.var_rank = d_rank; TO.var_distinct = d_dist; TO.rl_cursor = rl_fill; TO.rl_tmp = rl_tmp; TO.counters = counters; TO.nb = n_bams;
+        hipLaunchKernelGGL(k_tile, dim3(grid_t), dim3(256), 0, sm, TT, TO);
+    }
     PHZ_HIP(ctx, hipGetLastError());
-    unsigned long long h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 64, hipMemcpyDeviceToHost, sm));
+    unsigned long long h_counters[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 128, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
-    const int64_t nt = (int64_t)h_counters[6];           // QNAMEs that own kept lines: one group each
-    // group ranges: scan over the touched QNAMEs' line counts
+    const int64_t n_complete = (int64_t)grid_t * TL;     // item slots of the tiles (groups finished inside their tile, holes in between)
+    const int64_t nt = (int64_t)(h_counters[10] >> 32);  // QNAMEs whose lines straddle tiles: one group each, built from the spilled lines
+    const int64_t n_spill = (int64_t)(h_counters[10] & 0xFFFFFFFFull);
     if (nt) {
         hipLaunchKernelGGL(k_group_plan, dim3(nblk(nt)), dim3(256), 0, sm, nt, (const uint32_t *)touched, qcount, cnt_t);
         if (int s = gscan_excl<uint32_t, uint32_t>(ctx, cnt_t, base_t, nt, S[T_SCAN_TMP])) return s;
         hipLaunchKernelGGL(k_group_base, dim3(nblk(nt)), dim3(256), 0, sm, nt, (const uint32_t *)touched, (const uint32_t *)base_t, qcount);
-    }
-    hipLaunchKernelGGL(k_rl_expand, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_list, rl_fill);
-    if (grid_i) hipLaunchKernelGGL(k_items, dim3(grid_i), dim3(256), 0, sm, TI, (const uint8_t *)d_cls, (const uint32_t *)line_q, qcount, items, rl_fill, rl_tmp, n_bams);
-    if (nt) {
-        GroupOut G; G.qcount = qcount; G.items = items; G.cnt_t = cnt_t; G.base_t = base_t; G.touched = touched; G.var_rank = d_rank; G.var_distinct = d_dist;
+        hipLaunchKernelGGL(k_items_spill, dim3(nblk(n_spill)), dim3(256), 0, sm, n_spill, (const uint32_t *)sp_q, (const uint64_t *)sp_item, qcount, items + n_complete);
+        GroupOut G; G.qcount = qcount; G.items = items + n_complete; G.cnt_t = cnt_t; G.base_t = base_t; G.touched = touched; G.var_rank = d_rank; G.var_distinct = d_dist;
         G.counters = counters; G.single_bam = single_bam;
-        hipLaunchKernelGGL(k_groups, dim3(nblk(nt)), dim3(256), 0, sm, nt, TI, G);
+        hipLaunchKernelGGL(k_groups, dim3(nblk(nt)), dim3(256), 0, sm, nt, TT, G);
     }
     // read lists into line order
     PHZ_HIP(ctx, hipMemsetAsync(counters32, 0, 16, sm));
@@ -806,9 +1010,9 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
             PHZ_HIP(ctx, hipMemsetAsync(gvals, 0, S[T_GVALS].cap, sm));
         }
         ctx->tally_table_dirty = true;
-        PHZ_HIP(ctx, hipMemsetAsync(counters + 1, 0, 16, sm));          // pair events, overflow
+        PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 24, sm));              // distinct items, pair events, overflow
         PHZ_HIP(ctx, hipMemsetAsync(counters + 7, 0, 8, sm));           // used slots
-        const int64_t m_items = (int64_t)h_counters[3];               // kept lines = item slots
+        const int64_t m_items = n_complete + n_spill;                // the tiles' slots, then one slot per spilled line
         if (m_items) hipLaunchKernelGGL(k_pairs, dim3((unsigned)((m_items + PAIR_ITEMS - 1) / PAIR_ITEMS)), dim3(256), 0, sm, (const uint64_t *)items, m_items, gkeys, gvals,
                                         (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
         PHZ_HIP(ctx, hipGetLastError());

@@ -13,8 +13,11 @@ LIB = os.path.join(OUT, "libphz_emu.so")
 UNITS = ["phz_api.hip", "phz_tally.hip", "phz_rowsdev.hip", "phz_rows.cpp"]
 
 
-def build(verbose=False):
+def build(verbose=False, tally_tile=0):
+    """tally_tile: build the variant libphz_emu_t<N>.so whose K_tally groups tiles of N lines (256 / 512): the small fixtures then
+    straddle tiles, which is what sends QNAMEs through the spill path of k_tile"""
     os.makedirs(OUT, exist_ok=True)
+    LIB = os.path.join(OUT, "libphz_emu_t%d.so" % tally_tile if tally_tile else "libphz_emu.so")
     hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(REPO, "include", "phz.h"),
                                                                                   os.path.join(HERE, "hipemu.h"), os.path.join(HERE, "hipemu.cpp")]
     newest_hdr = max(os.path.getmtime(h) for h in hdr)
@@ -22,9 +25,10 @@ def build(verbose=False):
     jobs = []; objs = []
     for u in UNITS + ["hipemu.cpp"]:
         src = os.path.join(HERE if u == "hipemu.cpp" else CSRC, u)
-        obj = os.path.join(OUT, u + ".o"); objs.append(obj)
+        variant = tally_tile and u == "phz_tally.hip"
+        obj = os.path.join(OUT, u + (".t%d" % tally_tile if variant else "") + ".o"); objs.append(obj)
         if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
-            jobs.append(["g++"] + flags + ["-x", "c++", "-c", src, "-o", obj])
+            jobs.append(["g++"] + flags + (["-DPHZ_TALLY_TILE=%d" % tally_tile] if variant else []) + ["-x", "c++", "-c", src, "-o", obj])
     if jobs or not os.path.exists(LIB):
         def run(cmd):
             if verbose:

@@ -58,9 +58,10 @@ def run_tally(ctx, saved, chrom_list, n_bams):
     return out, sz
 
 
+@pytest.mark.parametrize("tile", [0, 256])      # 256: tiles of 256 lines, so that the fixtures' QNAMEs straddle tiles (spill path of k_tile)
 @pytest.mark.parametrize("case", sorted(set(c[0] for c in _cases())))
-def test_tally_kernels_reproduce_the_gpu_fixture(case):
-    ctx = EmuContext(emu_library())
+def test_tally_kernels_reproduce_the_gpu_fixture(case, tile):
+    ctx = EmuContext(emu_library(tile))
     saved = pickle.load(gzip.open(os.path.join(GOLD, "tally", case + ".pkl.gz"), "rb"))
     chroms = list(saved["tally"])
     nb = 1 + max(b for c in chroms for b, _, _ in saved["tally"][c]["bam_offsets"])
