@@ -29,6 +29,10 @@
 namespace {
 
 constexpr uint64_t KEY_DROPPED = ~0ull;
+// Statistics that every workgroup of a kernel adds to live in SPREAD counters: N_SPREAD copies, one memory sector each, picked by the
+// workgroup number (atomics on one address are served one after the other, ~8 ns each: ten thousand workgroups x 3 counters on one sector
+// would be a quarter of a millisecond of queueing); the host adds the copies up.  spread[c][0] distinct items, [1] pair events, [2] kept lines
+constexpr int N_SPREAD = 32, SPREAD_WORDS = 8;
 constexpr int AS_LDS_BINS = 8192;       // AS in [-4096, 4096) is histogrammed in LDS
 
 struct LinesDev {
@@ -126,19 +130,33 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
     __syncthreads();
     const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;       // a little room below (mate pairs / overlapping records)
     unsigned int kept = 0;
-    for (int64_t i = i0 + tid; i < i0 + LINES_PER_BLOCK && i < L.n; i += 256) {
-        const int r = L.read_idx[i], v = L.var_idx[i] + L.var_base;
-        const int64_t g = L.line_base + i;
-        bool keep = true;
-        if (L.use_cutoff) {
-            if (L.read_has_as && !L.read_has_as[r]) keep = false;
-            else keep = (double)L.read_as[r] >= L.cutoff;
-        }
+    // all loads of a lane's eight lines are requested before the first one is used (two dependent rounds: the line, then its record / variant)
+    constexpr int K = LINES_PER_BLOCK / 256;
+    int l_r[K], l_v[K], l_as[K]; uint32_t l_q[K]; uint8_t l_code[K], l_has[K], l_a0[K], l_a1[K]; bool l_in[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int64_t i = i0 + tid + 256 * k;
+        l_in[k] = i < L.n;
+        l_r[k] = l_in[k] ? L.read_idx[i] : 0; l_v[k] = l_in[k] ? L.var_idx[i] + L.var_base : 0; l_code[k] = l_in[k] ? L.code[i] : (uint8_t)4;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        l_as[k] = (l_in[k] && L.use_cutoff) ? L.read_as[l_r[k]] : 0;
+        l_has[k] = (l_in[k] && L.use_cutoff && L.read_has_as) ? L.read_has_as[l_r[k]] : (uint8_t)1;
+        l_q[k] = l_in[k] ? L.qid_base + (uint32_t)L.read_qid[l_r[k]] : 0u;
+        l_a0[k] = l_in[k] ? O.a0[l_v[k]] : (uint8_t)0; l_a1[k] = l_in[k] ? O.a1[l_v[k]] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (!l_in[k]) continue;
+        const int64_t g = L.line_base + i0 + tid + 256 * k;
+        const int v = l_v[k];
+        const bool keep = !L.use_cutoff || (l_has[k] && (double)l_as[k] >= L.cutoff);
         if (!keep) { O.line_cls[g] = 255; continue; }
         kept++;
-        const uint8_t c = L.code[i];
+        const uint8_t c = l_code[k];
         // codes 5 / 6 come from the general (indel) mapper, which compared the text with the allele strings itself
-        const int cls = c == 5 ? 0 : (c == 6 ? 1 : ((c < 4 && c == O.a0[v]) ? 0 : ((c < 4 && c == O.a1[v]) ? 1 : 2)));
+        const int cls = c == 5 ? 0 : (c == 6 ? 1 : ((c < 4 && c == l_a0[k]) ? 0 : ((c < 4 && c == l_a1[k]) ? 1 : 2)));
         O.line_cls[g] = (uint8_t)cls;
         const unsigned d = (unsigned)(v - vbase);
         if (d < (unsigned)TW) {
@@ -149,9 +167,8 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
             atomicMin(&O.var_first[v], (unsigned long long)g);
             if (cls < 2) atomicAdd(&O.rl_cnt[((int64_t)v * 2 + cls) * O.nb + L.bam], 1u);
         }
-        const uint32_t q = L.qid_base + (uint32_t)L.read_qid[r];
-        O.line_q[g] = q;
-        atomicAdd(&O.qcount[q], 1u);
+        O.line_q[g] = l_q[k];
+        atomicAdd(&O.qcount[l_q[k]], 1u);
     }
     if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
         const unsigned long long f = s_first[j];
         if (f != ~0ull) atomicMin(&O.var_first[vbase + j], f);
     }
-    if (tid == 0 && s_kept) atomicAdd(&O.counters[3], (unsigned long long)s_kept);
+    if (tid == 0 && s_kept) atomicAdd(&O.counters[16 + (blockIdx.x % N_SPREAD) * SPREAD_WORDS + 2], (unsigned long long)s_kept);
 }
 
 // group of every spilled QNAME: its line count (the counter goes back to zero and serves as the fill cursor of k_items_spill)
@@ -204,7 +221,7 @@ constexpr int TH = 2 * TL;         // LDS hash slots (at most TL distinct QNAMEs
 constexpr int TSP = TH / 256;      // slots per thread
 constexpr int TH_SHIFT = TL == 1024 ? 21 : (TL == 512 ? 22 : 23);
 static_assert(TL == 1024 || TL == 512 || TL == 256, "tile of 256 / 512 / 1024 lines");
-constexpr int TWT = 512;           // variants per LDS window of k_tile
+constexpr int TWT = 256;           // variants per LDS window of k_tile (1,024 lines span ~100 variants)
 constexpr uint32_t Q_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t Q_SPILLED = 0x80000000u;
 
@@ -225,17 +242,17 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     const LinesDev L = T.L[sh_];
     const uint32_t bx = blockIdx.x - T.blk0[sh_];
     __shared__ uint32_t s_q[TH];                 // QNAME id of the slot
-    __shared__ uint32_t s_c[TH];                 // lines of the slot's QNAME in this tile -> write cursor of its group (ends at the group's end)
-    __shared__ uint16_t s_n[TH];                 // lines of the slot's group
+    __shared__ uint32_t s_c[TH];                 // lines of the slot's QNAME in this tile -> write cursor of its group -> end of its group (groups lie in slot order)
     __shared__ uint64_t s_it[TL];                // the tile's kept lines as items, group by group
     __shared__ int s_cnt[TWT * 3];
     __shared__ unsigned long long s_rank[TWT];
-    __shared__ uint32_t s_rl[TWT * 2];           // read-list entries of (variant, allele) in this tile -> base of the tile's chunk in the list
-    __shared__ uint32_t s_touch[TL];             // QNAMEs this tile puts on the list of spilled QNAMEs
+    __shared__ uint32_t s_rl[TL / 2 > TWT * 2 ? TL / 2 : TWT * 2];   // read-list entries of (variant, allele) in this tile -> base of the tile's chunk in the list;
+                                                 // later: the slots whose QNAMEs this tile puts on the list of spilled QNAMEs (16 bits each)
     __shared__ uint32_t s_part[4];
     __shared__ int s_vbase;
     __shared__ uint32_t s_nspill, s_ntouch, s_nkept;
     __shared__ unsigned long long s_obase;
+    uint16_t *s_touch = (uint16_t *)s_rl;
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)bx * TL;
     if (tid == 0) { s_nspill = 0; s_ntouch = 0; }
@@ -244,8 +261,6 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     for (int j = tid; j < TWT; j += 256) s_rank[j] = ~0ull;
     for (int j = tid; j < TWT * 2; j += 256) s_rl[j] = 0u;
     if (tid == 0) s_vbase = L.var_idx[i0] + L.var_base;
-    __syncthreads();
-    const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;
     // ---- 1. the tile's lines: QNAME -> slot (count), read-list entry -> rank inside the tile's chunk
     constexpr int K = TL / 256;
     uint32_t l_cls[K], l_q[K], l_v[K], l_slot[K], l_rank[K];
@@ -258,6 +273,8 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
             l_cls[k] = O.line_cls[g]; l_q[k] = O.line_q[g]; l_v[k] = (uint32_t)(L.var_idx[i] + L.var_base);
         }
     }
+    __syncthreads();
+    const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         l_slot[k] = Q_EMPTY; l_rank[k] = Q_EMPTY;
@@ -282,7 +299,22 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         }
     }
     __syncthreads();
-    // ---- 2. group ranges (exclusive scan of the slot counts); one cursor step per (tile, read list)
+    // ---- 2. requested now, used later: the totals of the QNAMEs in this lane's slots and one cursor step per (tile, read list);
+    //         meanwhile the group ranges (exclusive scan of the slot counts)
+    uint32_t tot[TSP], my_q[TSP];
+#pragma unroll
+    for (int j = 0; j < TSP; j++) {
+        const int slot = tid + 256 * j;
+        my_q[j] = s_q[slot];
+        tot[j] = my_q[j] != Q_EMPTY ? O.qcount[my_q[j]] : 0u;
+    }
+    uint32_t rl_base[TWT * 2 / 256];
+#pragma unroll
+    for (int j = 0; j < TWT * 2 / 256; j++) {
+        const int x = tid + 256 * j;
+        rl_base[j] = s_rl[x];
+        if (rl_base[j]) rl_base[j] = atomicAdd(&O.rl_cursor[((uint32_t)(vbase + (x >> 1)) * 2u + (uint32_t)(x & 1)) * (uint32_t)O.nb + (uint32_t)L.bam], rl_base[j]);
+    }
     {
         uint32_t c[TSP], sum = 0;
 #pragma unroll
@@ -296,19 +328,10 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         for (int w = 0; w < (tid >> 6); w++) base += s_part[w];
         if (tid == 255) s_nkept = base + sum;
 #pragma unroll
-        for (int j = 0; j < TSP; j++) { s_n[tid * TSP + j] = (uint16_t)c[j]; s_c[tid * TSP + j] = base; base += c[j]; }
+        for (int j = 0; j < TSP; j++) { s_c[tid * TSP + j] = base; base += c[j]; }
     }
-    {
-        uint32_t c[TWT * 2 / 256];
 #pragma unroll
-        for (int j = 0; j < TWT * 2 / 256; j++) {
-            const int x = tid + 256 * j;
-            c[j] = s_rl[x];
-            if (c[j]) c[j] = atomicAdd(&O.rl_cursor[((uint32_t)(vbase + (x >> 1)) * 2u + (uint32_t)(x & 1)) * (uint32_t)O.nb + (uint32_t)L.bam], c[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < TWT * 2 / 256; j++) s_rl[tid + 256 * j] = c[j];
-    }
+    for (int j = 0; j < TWT * 2 / 256; j++) s_rl[tid + 256 * j] = rl_base[j];
     __syncthreads();
     // ---- 3. lines into their groups, read-list entries into their lists
 #pragma unroll
@@ -326,23 +349,17 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     // ---- 4. one thread per group.  A group holding every line of its QNAME is finished here (all its lines come from this shard's BAM: that
     //         BAM owns the read_vars list, every ref/alt line is linked): its distinct items stay at the front of its range, the rest of the
     //         range becomes KEY_DROPPED.  The others hand their lines to the spill list (ranges inside the tile's share from LDS counters)
-    uint32_t sp_beg[TSP], sp_n[TSP], sp_at[TSP], tot[TSP];
+    uint32_t sp_beg[TSP], sp_n[TSP], sp_at[TSP];
 #pragma unroll
     for (int j = 0; j < TSP; j++) {
         const int slot = tid + 256 * j;
-        tot[j] = s_n[slot] ? O.qcount[s_q[slot]] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < TSP; j++) {
-        const int slot = tid + 256 * j;
-        const uint32_t n = s_n[slot];
         sp_n[j] = 0; sp_beg[j] = 0; sp_at[j] = 0;
-        if (!n) continue;
-        const uint32_t q = s_q[slot];
-        const uint32_t beg = s_c[slot] - n;
+        if (my_q[j] == Q_EMPTY) continue;
+        const uint32_t q = my_q[j];
+        const uint32_t beg = slot ? s_c[slot - 1] : 0u, n = s_c[slot] - beg;        // the cursors stopped at the groups' ends
         uint64_t *it = s_it + beg;
         if ((tot[j] & 0x7FFFFFFFu) != n) {
-            if (!(atomicOr(&O.qcount[q], Q_SPILLED) & Q_SPILLED)) s_touch[atomicAdd(&s_ntouch, 1u)] = q;       // the first tile to meet it lists the QNAME
+            if (!(atomicOr(&O.qcount[q], Q_SPILLED) & Q_SPILLED)) s_touch[atomicAdd(&s_ntouch, 1u)] = (uint16_t)slot;   // the first tile to meet it lists the QNAME
             sp_n[j] = n; sp_beg[j] = beg; sp_at[j] = atomicAdd(&s_nspill, n);
             continue;
         }
@@ -380,28 +397,17 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         for (uint32_t k = w; k < n; k++) it[k] = KEY_DROPPED;
     }
     __syncthreads();
-    // ---- 5. ONE global cursor step per tile (spilled lines in the low word, listed QNAMEs in the high word), the spilled lines out, and the
-    //         tile's slots of the item array written in one sweep (groups in place, holes = KEY_DROPPED)
+    // ---- 5. ONE global cursor step per tile (spilled lines in the low word, listed QNAMEs in the high word) -- while it is under way the
+    //         tile's slots of the item array are written in one sweep (groups in place, holes = KEY_DROPPED) -- then the spilled lines go
+    //         out and their slots of the item array are crossed out
+    unsigned long long cur = 0;
     if (tid == 0) {
         const unsigned long long add = ((unsigned long long)s_ntouch << 32) | s_nspill;
-        s_obase = add ? atomicAdd(&O.counters[10], add) : 0ull;
+        if (add) cur = atomicAdd(&O.counters[10], add);
     }
-    __syncthreads();
-    const uint32_t spill_base = (uint32_t)s_obase, touch_base = (uint32_t)(s_obase >> 32);
-#pragma unroll
-    for (int j = 0; j < TSP; j++) {
-        if (!sp_n[j]) continue;
-        const uint32_t q = s_q[tid + 256 * j];
-        for (uint32_t a = 0; a < sp_n[j]; a++) {
-            O.sp_q[spill_base + sp_at[j] + a] = q; O.sp_item[spill_base + sp_at[j] + a] = s_it[sp_beg[j] + a];
-            s_it[sp_beg[j] + a] = KEY_DROPPED;
-        }
-    }
-    for (uint32_t j = tid; j < s_ntouch; j += 256) O.touched[touch_base + j] = s_touch[j];
-    __syncthreads();
+    uint64_t *dst = O.items + ((int64_t)blockIdx.x * TL);
     {
         const uint32_t nk = s_nkept;
-        uint64_t *dst = O.items + ((int64_t)blockIdx.x * TL);
         for (int j = tid; j < TL; j += 256) dst[j] = (uint32_t)j < nk ? s_it[j] : KEY_DROPPED;
     }
     for (int j = tid; j < TWT * 3; j += 256) {
@@ -412,6 +418,19 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         const unsigned long long f = s_rank[j];
         if (f != ~0ull) atomicMin(&O.var_rank[vbase + j], f);
     }
+    if (tid == 0) s_obase = cur;
+    __syncthreads();
+    if (s_nspill == 0) return;
+    const uint32_t spill_base = (uint32_t)s_obase, touch_base = (uint32_t)(s_obase >> 32);
+#pragma unroll
+    for (int j = 0; j < TSP; j++) {
+        if (!sp_n[j]) continue;
+        for (uint32_t a = 0; a < sp_n[j]; a++) {
+            O.sp_q[spill_base + sp_at[j] + a] = my_q[j]; O.sp_item[spill_base + sp_at[j] + a] = s_it[sp_beg[j] + a];
+            dst[sp_beg[j] + a] = KEY_DROPPED;
+        }
+    }
+    for (uint32_t j = tid; j < s_ntouch; j += 256) O.touched[touch_base + j] = s_q[s_touch[j]];
 }
 
 // the spilled lines into the groups of their QNAMEs (ranges from the scan over the spilled QNAMEs' line counts)
@@ -513,18 +532,26 @@ __device__ __forceinline__ uint32_t hash64(uint64_t k) {
 }
 
 constexpr int PH_SLOTS = 1024;     // LDS hash slots per workgroup
-constexpr int PH_VALS = 10;        // 9 cells + linked flag
+constexpr int PH_WORDS = 5;        // LDS counters of a slot: the nine cells as 16-bit halves (a tile holds < 2^16 QNAMEs), linked flag = bit 16 of word 4
 constexpr int PH_PROBES = 24;
 constexpr int GH_PROBES = 2048;    // global probe bound; beyond it the table is declared too small and the pass is redone
+// the global table: one 64-byte entry per slot = one memory sector: key (words 0-1, 0 = empty: a pair key (a << 32 | b) has b > a >= 0),
+// the nine cells (words 2-10), the linked flag (word 11)
+constexpr int GE_WORDS = 16;
+constexpr int GE_CELL0 = 2, GE_LINKED = 11;
 
-// counters[]: 0 distinct items, 1 pair events, 2 global hash overflow, 3 kept lines, 4/5 noise, 6 touched QNAMEs, 7 used hash slots
+// counters[]: 2 global hash overflow, 3 kept lines, 4/5 noise, 7 used hash slots, 10 spilled lines | spilled QNAMEs << 32
 // -> slot of the pair in the global table, claiming it if new (*claimed); -1 when the probe bound is hit
-__device__ __forceinline__ int global_slot(uint64_t *gkeys, uint32_t gmask, uint64_t key, unsigned long long *counters, bool *claimed) {
-    uint32_t s = hash64(key) & gmask;
+// Home slot of a pair: a scattering hash.  (A table kept in variant order -- the pairs of variant a from slot 4a on, so that a tile's pairs
+// share a few dozen KB -- was measured: k_pairs 0.38 -> 1.65 ms.  The workgroups in flight work on neighbouring tiles, their atomics
+// then queue on the few L2 channels that own that stretch of the table.)
+__device__ __forceinline__ uint32_t pair_home(uint64_t key, uint32_t gmask) { return hash64(key) & gmask; }
+__device__ __forceinline__ int global_slot(uint32_t *tab, uint32_t gmask, uint64_t key, unsigned long long *counters, bool *claimed) {
+    uint32_t s = pair_home(key, gmask);
     *claimed = false;
     for (int t = 0; t < GH_PROBES; t++) {
-        const unsigned long long prev = atomicCAS((unsigned long long *)&gkeys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)key);
-        if (prev == KEY_DROPPED) { *claimed = true; return (int)s; }
+        const unsigned long long prev = atomicCAS((unsigned long long *)(tab + (size_t)s * GE_WORDS), 0ull, (unsigned long long)key);
+        if (prev == 0ull) { *claimed = true; return (int)s; }
         if (prev == key) return (int)s;
         s = (s + 1) & gmask;
     }
@@ -535,27 +562,50 @@ __device__ __forceinline__ int global_slot(uint64_t *gkeys, uint32_t gmask, uint
 // QNAME groups hold their distinct items sorted by (variant, class): every pair of items on different variants adds 1 to cell
 // (class_a, class_b) of that variant pair.  One thread per item slot (the pairs of an item with the later items of its group): PAIR_ITEMS
 // slots per workgroup.  The slots this workgroup claims in the global table go to the list of used slots.
-constexpr int PAIR_ITEMS = 2048;
-__global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m, uint64_t *gkeys, int32_t *gvals, uint32_t gmask, uint32_t *used, unsigned long long *counters) {
+constexpr int PAIR_ITEMS = 2048;      // item slots per round
+constexpr int PAIR_ROUNDS = 1;        // rounds per workgroup sharing one LDS table and one flush (2: the table overflows, 0.35 -> 0.43 ms)
+template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m, uint32_t *tab, uint32_t gmask, uint32_t *used, unsigned long long *counters) {
     __shared__ unsigned long long s_keys[PH_SLOTS];
-    __shared__ int s_vals[PH_SLOTS * PH_VALS];
+    __shared__ uint32_t s_vals[PH_SLOTS * PH_WORDS];
     __shared__ uint32_t s_claim[PH_SLOTS];
     __shared__ unsigned int s_part[4], s_ipart[4], s_nclaim;
     __shared__ unsigned long long s_ubase;
-    const int64_t i0 = (int64_t)blockIdx.x * PAIR_ITEMS;
     for (int j = threadIdx.x; j < PH_SLOTS; j += 256) s_keys[j] = KEY_DROPPED;
-    for (int j = threadIdx.x; j < PH_SLOTS * PH_VALS; j += 256) s_vals[j] = 0;
+    for (int j = threadIdx.x; j < PH_SLOTS * PH_WORDS; j += 256) s_vals[j] = 0;
     if (threadIdx.x == 0) s_nclaim = 0;
     __syncthreads();
     unsigned int n_event = 0, n_item = 0;
-    for (int64_t i = i0 + threadIdx.x; i < i0 + PAIR_ITEMS && i < m; i += 256) {
-        const uint64_t k = items[i];
-        if (k == KEY_DROPPED) continue;
-        n_item++;
+    constexpr int KI = PAIR_ITEMS / 256;
+    // A wave holds 64 consecutive items per round (one per lane) plus the 64 after them: the later items of a lane's group are read from the
+    // neighbouring lanes (the groups are a handful of items long), no memory access inside the pair loop
+    const int lane = threadIdx.x & 63;
+    for (int round = 0; round < PAIR_ROUNDS; round++) {
+    const int64_t i0 = ((int64_t)blockIdx.x * PAIR_ROUNDS + round) * PAIR_ITEMS;
+    if (i0 >= m) break;
+    unsigned long long my_item[KI], nx_item[KI];
+#pragma unroll
+    for (int t = 0; t < KI; t++) {                           // all of the lane's items requested together
+        const int64_t i = i0 + threadIdx.x + 256 * t;
+        my_item[t] = i < m ? items[i] : KEY_DROPPED;
+        nx_item[t] = i + 64 < m ? items[i + 64] : KEY_DROPPED;
+    }
+#pragma unroll
+    for (int t = 0; t < KI; t++) {
+        const int64_t i = i0 + threadIdx.x + 256 * t;
+        const unsigned long long k = my_item[t];
+        bool active = k != KEY_DROPPED;
+        if (active) n_item++;
+        if (MODE == 2) continue;
         const uint32_t q = (uint32_t)(k >> 32), v = (uint32_t)(k >> 4) & 0x0FFFFFFFu, cls = (uint32_t)(k >> 2) & 3u, ln = (uint32_t)k & 1u;
-        for (int64_t j = i + 1; j < m; j++) {
-            const uint64_t k2 = items[j];
-            if (k2 == KEY_DROPPED || (uint32_t)(k2 >> 32) != q) break;        // the distinct items of a group sit at its front
+        for (int d = 1; __any(active); d++) {
+            unsigned long long k2;
+            if (d < 64) {
+                const int src = lane + d;
+                const unsigned long long a_ = __shfl(k, src & 63), b_ = __shfl(nx_item[t], src & 63);
+                k2 = src < 64 ? a_ : b_;
+            } else k2 = (active && i + d < m) ? items[i + d] : KEY_DROPPED;      // a group of more than 64 distinct items
+            if (!active) continue;
+            if (k2 == KEY_DROPPED || (uint32_t)(k2 >> 32) != q) { active = false; continue; }        // the distinct items of a group sit at its front
             const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
             if (v2 == v) continue;
             n_event++;
@@ -565,11 +615,11 @@ __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m,
             const int linked = (int)(ln & ln2);
             uint32_t s = hash64(pk) & (PH_SLOTS - 1);
             bool done = false;
-            for (int t = 0; t < PH_PROBES; t++) {
+            for (int pr = 0; pr < PH_PROBES; pr++) {
                 const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
                 if (prev == KEY_DROPPED || prev == pk) {
-                    atomicAdd(&s_vals[s * PH_VALS + cell], 1);
-                    if (linked) atomicOr(&s_vals[s * PH_VALS + 9], 1);
+                    atomicAdd(&s_vals[s * PH_WORDS + (cell >> 1)], 1u << ((cell & 1) * 16));
+                    if (linked) atomicOr(&s_vals[s * PH_WORDS + 4], 0x10000u);
                     done = true;
                     break;
                 }
@@ -577,63 +627,78 @@ __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m,
             }
             if (!done) {
                 bool claimed;
-                const int gs = global_slot(gkeys, gmask, pk, counters, &claimed);
+                const int gs = global_slot(tab, gmask, pk, counters, &claimed);
                 if (gs >= 0) {
                     if (claimed) used[atomicAdd(&counters[7], 1ull)] = (uint32_t)gs;
-                    atomicAdd(&gvals[(int64_t)gs * PH_VALS + cell], 1);
-                    if (linked) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
+                    atomicAdd(&tab[(size_t)gs * GE_WORDS + GE_CELL0 + cell], 1u);
+                    if (linked) atomicOr(&tab[(size_t)gs * GE_WORDS + GE_LINKED], 1u);
                 }
             }
         }
+    }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { n_event += __shfl_xor(n_event, d); n_item += __shfl_xor(n_item, d); }
     if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6] = n_event; s_ipart[threadIdx.x >> 6] = n_item; }
     __syncthreads();
-    for (int j = threadIdx.x; j < PH_SLOTS; j += 256) {
-        const uint64_t pk = s_keys[j];
-        if (pk == KEY_DROPPED) continue;
-        bool claimed;
-        const int gs = global_slot(gkeys, gmask, pk, counters, &claimed);
-        if (gs < 0) continue;
-        if (claimed) s_claim[atomicAdd(&s_nclaim, 1u)] = (uint32_t)gs;
-        for (int c = 0; c < 9; c++) {
-            const int val = s_vals[j * PH_VALS + c];
-            if (val) atomicAdd(&gvals[(int64_t)gs * PH_VALS + c], val);
+    if (MODE != 0) { if (n_item == 12345678u) used[0] = s_vals[threadIdx.x]; return; }
+    {
+        constexpr int KS = PH_SLOTS / 256;
+        uint64_t pk[KS]; uint32_t hs[KS]; unsigned long long prev[KS];
+#pragma unroll
+        for (int t = 0; t < KS; t++) {                       // the first probe of each of the lane's slots requested together
+            pk[t] = s_keys[threadIdx.x + 256 * t];
+            hs[t] = pair_home(pk[t], gmask); prev[t] = 0ull;
+            if (pk[t] != KEY_DROPPED) prev[t] = atomicCAS((unsigned long long *)(tab + (size_t)hs[t] * GE_WORDS), 0ull, (unsigned long long)pk[t]);
         }
-        if (s_vals[j * PH_VALS + 9]) atomicOr(&gvals[(int64_t)gs * PH_VALS + 9], 1);
+#pragma unroll
+        for (int t = 0; t < KS; t++) {
+            if (pk[t] == KEY_DROPPED) continue;
+            const int j = threadIdx.x + 256 * t;
+            bool claimed = prev[t] == 0ull;
+            int gs = (int)hs[t];
+            if (!claimed && prev[t] != pk[t]) gs = global_slot(tab, gmask, pk[t], counters, &claimed);      // taken by another pair: probe on
+            if (gs < 0) continue;
+            if (claimed) s_claim[atomicAdd(&s_nclaim, 1u)] = (uint32_t)gs;
+            uint32_t *e = tab + (size_t)gs * GE_WORDS;
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const uint32_t val = (s_vals[j * PH_WORDS + (c >> 1)] >> ((c & 1) * 16)) & 0xFFFFu;
+                if (val) atomicAdd(&e[GE_CELL0 + c], val);
+            }
+            if (s_vals[j * PH_WORDS + 4] & 0x10000u) atomicOr(&e[GE_LINKED], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long b = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (b) atomicAdd(&counters[1], b);
+        unsigned long long *spread = counters + 16 + (blockIdx.x % N_SPREAD) * SPREAD_WORDS;
+        if (b) atomicAdd(&spread[1], b);
         const unsigned long long ni = (unsigned long long)s_ipart[0] + s_ipart[1] + s_ipart[2] + s_ipart[3];
-        if (ni) atomicAdd(&counters[0], ni);                  // distinct (QNAME, variant, class) items
+        if (ni) atomicAdd(&spread[0], ni);                    // distinct (QNAME, variant, class) items
         s_ubase = s_nclaim ? atomicAdd(&counters[7], (unsigned long long)s_nclaim) : 0ull;      // one global atomic per workgroup
     }
     __syncthreads();
     for (unsigned j = threadIdx.x; j < s_nclaim; j += 256) used[s_ubase + j] = s_claim[j];
 }
 
-// ---- edge list in (a, b) order: counting sort of the USED hash slots by a, each (small) group sorted by b
-__global__ __launch_bounds__(256) void k_edge_count(const uint32_t *used, int64_t n_used, const uint64_t *gkeys, uint32_t *deg) {
+// ---- edge list in (a, b) order: counting sort of the USED table slots by a, each (small) group sorted by b
+__global__ __launch_bounds__(256) void k_edge_count(const uint32_t *used, int64_t n_used, const uint32_t *tab, uint32_t *deg) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n_used) atomicAdd(&deg[(uint32_t)(gkeys[used[i]] >> 32)], 1u);
+    if (i < n_used) atomicAdd(&deg[tab[(size_t)used[i] * GE_WORDS + 1]], 1u);            // word 1 = high half of the key = a
 }
-__global__ __launch_bounds__(256) void k_edge_scatter(const uint32_t *used, int64_t n_used, const uint64_t *gkeys, const uint32_t *eoff, uint32_t *deg,
+__global__ __launch_bounds__(256) void k_edge_scatter(const uint32_t *used, int64_t n_used, const uint32_t *tab, const uint32_t *eoff, uint32_t *deg,
                                                       uint32_t *e_b, uint32_t *e_slot) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_used) return;
     const uint32_t s = used[i];
-    const uint64_t k = gkeys[s];
-    const uint32_t a = (uint32_t)(k >> 32);
-    const uint32_t old = atomicSub(&deg[a], 1u);
-    const uint32_t p = eoff[a] + old - 1;
-    e_b[p] = (uint32_t)k; e_slot[p] = s;
+    const uint2 k = *(const uint2 *)(tab + (size_t)s * GE_WORDS);            // .x = b, .y = a
+    const uint32_t old = atomicSub(&deg[k.y], 1u);
+    const uint32_t p = eoff[k.y] + old - 1;
+    e_b[p] = k.x; e_slot[p] = s;
 }
-// ... and the table is left clean (keys empty, counters zero) slot by slot, so the next call needs no memset of it
-__global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, uint64_t *gkeys, int32_t *gvals,
-                                                    int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked, int32_t *cto, int32_t *stats, int64_t ne) {
+// one thread per variant: its (few) edges sorted by b
+__global__ __launch_bounds__(256) void k_edge_sort(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, int32_t *ea, int32_t *eb) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= nv) return;
     const uint32_t lo = eoff[a], hi = eoff[a + 1];
@@ -643,22 +708,28 @@ __global__ __launch_bounds__(256) void k_edge_final(int64_t nv, const uint32_t *
         while (j > lo && e_b[j - 1] > xb) { e_b[j] = e_b[j - 1]; e_slot[j] = e_slot[j - 1]; j--; }
         e_b[j] = xb; e_slot[j] = xs;
     }
-    for (uint32_t i = lo; i < hi; i++) {
-        ea[i] = (int32_t)a; eb[i] = (int32_t)e_b[i];
-        const int64_t s = e_slot[i];
-        int32_t x[9];
+    for (uint32_t i = lo; i < hi; i++) { ea[i] = (int32_t)a; eb[i] = (int32_t)e_b[i]; }
+}
+// one thread per edge: its table entry (one sector) read, the result columns written, the entry returned to "empty" -- the table is left
+// clean slot by slot, so the next call needs no memset of it
+__global__ __launch_bounds__(256) void k_edge_out(int64_t ne, const uint32_t *e_slot, uint32_t *tab, int32_t *cells, uint8_t *linked, int32_t *cto, int32_t *stats) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ne) return;
+    uint4 *e = (uint4 *)(tab + (size_t)e_slot[i] * GE_WORDS);
+    const uint4 w0 = e[0], w1 = e[1], w2 = e[2];
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    e[0] = z; e[1] = z; e[2] = z;
+    const int32_t x[9] = {(int32_t)w0.z, (int32_t)w0.w, (int32_t)w1.x, (int32_t)w1.y, (int32_t)w1.z, (int32_t)w1.w, (int32_t)w2.x, (int32_t)w2.y, (int32_t)w2.z};
 #pragma unroll
-        for (int c = 0; c < 9; c++) { x[c] = gvals[s * PH_VALS + c]; cells[(int64_t)i * 9 + c] = x[c]; gvals[s * PH_VALS + c] = 0; }
-        linked[i] = (uint8_t)(gvals[s * PH_VALS + 9] & 1);
-        gvals[s * PH_VALS + 9] = 0; gkeys[s] = KEY_DROPPED;
-        // test_variant_connection's three sums (phaser.py:1634-1636): same configuration rr+aa, opposite ar+ra, the five "other" cells
-        const int32_t cis = x[0] + x[4], trans = x[3] + x[1], oth = x[6] + x[7] + x[2] + x[5] + x[8];
-        cto[(int64_t)i * 3] = cis; cto[(int64_t)i * 3 + 1] = trans; cto[(int64_t)i * 3 + 2] = oth;
-        // the derived columns of the pair test (:1637-1649), one plane each: same-configuration / opposite counts, supporting =
-        // the larger of the two, total, chosen configuration (0 same, 1 opposite, -1 tie)
-        stats[i] = cis; stats[ne + i] = trans; stats[2 * ne + i] = cis > trans ? cis : trans; stats[3 * ne + i] = cis + trans + oth;
-        stats[4 * ne + i] = cis > trans ? 0 : (cis < trans ? 1 : -1);
-    }
+    for (int c = 0; c < 9; c++) cells[i * 9 + c] = x[c];
+    linked[i] = (uint8_t)(w2.w & 1u);
+    // test_variant_connection's three sums (phaser.py:1634-1636): same configuration rr+aa, opposite ar+ra, the five "other" cells
+    const int32_t cis = x[0] + x[4], trans = x[3] + x[1], oth = x[6] + x[7] + x[2] + x[5] + x[8];
+    cto[i * 3] = cis; cto[i * 3 + 1] = trans; cto[i * 3 + 2] = oth;
+    // the derived columns of the pair test (:1637-1649), one plane each: same-configuration / opposite counts, supporting =
+    // the larger of the two, total, chosen configuration (0 same, 1 opposite, -1 tie)
+    stats[i] = cis; stats[ne + i] = trans; stats[2 * ne + i] = cis > trans ? cis : trans; stats[3 * ne + i] = cis + trans + oth;
+    stats[4 * ne + i] = cis > trans ? 0 : (cis < trans ? 1 : -1);
 }
 
 // ---- read lists: entries were placed by atomics; put every list into line order and keep the QNAME ids
@@ -760,6 +831,7 @@ __global__ __launch_bounds__(256) void k_noise(const int32_t *var_count, int64_t
     }
 }
 
+constexpr size_t CNT_BYTES = 128 + (size_t)N_SPREAD * SPREAD_WORDS * 8;
 inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 // HIP-event timing of a stage on the ctx stream; stop() waits for the stage and reports HIP errors
@@ -918,7 +990,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     RSV(R[R_CNT], NV * 12); RSV(R[R_FIRST], NV * 8); RSV(R[R_DIST], NV * 12); RSV(R[R_RANK], NV * 8); RSV(R[R_CLS], TOT); RSV(R[R_LINEQ], TOT * 4);
     RSV(R[R_RLCNT], NRL * 4); RSV(R[R_RLSTART], (NRL + 1) * 4); RSV(R[R_RLFILL], NRL * 4); RSV(R[R_RLTMP], TOT * 8); RSV(R[R_RLLIST], TOT * 4); RSV(R[R_RLQID], TOT * 4);
     RSV(R[R_SPQ], TOT * 4); RSV(R[R_SPITEM], TOT * 8);
-    RSV(S[T_TOUCHED], TOT * 4); RSV(S[T_CNT_T], (TOT + 1) * 4); RSV(S[T_BASE_T], (TOT + 1) * 4); RSV(S[T_ITEMS], (2 * TOT + (size_t)(n_shards + 1) * TL) * 8); RSV(S[T_COUNTERS], 128);
+    RSV(S[T_TOUCHED], TOT * 4); RSV(S[T_CNT_T], (TOT + 1) * 4); RSV(S[T_BASE_T], (TOT + 1) * 4); RSV(S[T_ITEMS], (2 * TOT + (size_t)(n_shards + 1) * TL) * 8); RSV(S[T_COUNTERS], CNT_BYTES);
     RSV(S[T_DEG], NV * 4); RSV(S[T_EOFF], (NV + 1) * 4); RSV(S[T_MISC], std::max(NRL, (size_t)1) * 12 + 64);
     hipStream_t sm = ctx->stream;
     {   // the one array indexed by QNAME id is persistent: `lines per QNAME`, then the QNAME's write cursor, all zero between calls (k_groups returns it
@@ -948,7 +1020,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     PHZ_HIP(ctx, hipMemsetAsync(d_dist, 0, NV * 12, sm));
     PHZ_HIP(ctx, hipMemsetAsync(rl_cnt, 0, NRL * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_rank, 0xff, NV * 8, sm));
-    PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 128, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(counters, 0, CNT_BYTES, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_first, 0xff, NV * 8, sm));         // unsigned max for atomicMin == -1 as int64 ("none")
 
     const int single_bam = n_bams <= 1 ? 1 : 0;     // one BAM: every QNAME's read_vars list is owned by that BAM
@@ -976,9 +1048,12 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         hipLaunchKernelGGL(k_tile, dim3(grid_t), dim3(256), 0, sm, TT, TO);
     }
     PHZ_HIP(ctx, hipGetLastError());
-    unsigned long long h_counters[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 128, hipMemcpyDeviceToHost, sm));
+    std::vector<unsigned long long> h_cnt(CNT_BYTES / 8, 0ull);
+    unsigned long long *h_counters = h_cnt.data();
+    auto spread_sum = [&](int k) { unsigned long long t = 0; for (int c = 0; c < N_SPREAD; c++) t += h_counters[16 + c * SPREAD_WORDS + k]; return t; };
+    PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    const int64_t n_kept = (int64_t)spread_sum(2);
     const int64_t n_complete = (int64_t)grid_t * TL;     // item slots of the tiles (groups finished inside their tile, holes in between)
     const int64_t nt = (int64_t)(h_counters[10] >> 32);  // QNAMEs whose lines straddle tiles: one group each, built from the spilled lines
     const int64_t n_spill = (int64_t)(h_counters[10] & 0xFFFFFFFFull);
@@ -1002,21 +1077,23 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     uint32_t h_c32[4] = {0, 0, 0, 0};
     uint32_t h_tail[2] = {0, 0};
     for (int attempt = 0;; attempt++) {
-        const size_t old_k = S[T_GKEYS].cap, old_v = S[T_GVALS].cap;
-        RSV(S[T_GKEYS], cap * 8); RSV(S[T_GVALS], cap * PH_VALS * 4); RSV(S[T_USED], cap * 4);
-        uint64_t *gkeys = (uint64_t *)S[T_GKEYS].p; int32_t *gvals = (int32_t *)S[T_GVALS].p;
-        if (S[T_GKEYS].cap != old_k || S[T_GVALS].cap != old_v || ctx->tally_table_dirty || attempt > 0) {
-            PHZ_HIP(ctx, hipMemsetAsync(gkeys, 0xff, S[T_GKEYS].cap, sm));
-            PHZ_HIP(ctx, hipMemsetAsync(gvals, 0, S[T_GVALS].cap, sm));
-        }
+        const size_t old_k = S[T_GKEYS].cap;
+        RSV(S[T_GKEYS], cap * GE_WORDS * 4); RSV(S[T_USED], cap * 4);
+        uint32_t *tab = (uint32_t *)S[T_GKEYS].p;
+        if (S[T_GKEYS].cap != old_k || ctx->tally_table_dirty || attempt > 0) PHZ_HIP(ctx, hipMemsetAsync(tab, 0, S[T_GKEYS].cap, sm));
         ctx->tally_table_dirty = true;
-        PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 24, sm));              // distinct items, pair events, overflow
+        PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 24, sm));              // overflow
+        PHZ_HIP(ctx, hipMemsetAsync(counters + 16, 0, CNT_BYTES - 128, sm));      // spread statistics
         PHZ_HIP(ctx, hipMemsetAsync(counters + 7, 0, 8, sm));           // used slots
         const int64_t m_items = n_complete + n_spill;                // the tiles' slots, then one slot per spilled line
-        if (m_items) hipLaunchKernelGGL(k_pairs, dim3((unsigned)((m_items + PAIR_ITEMS - 1) / PAIR_ITEMS)), dim3(256), 0, sm, (const uint64_t *)items, m_items, gkeys, gvals,
+        if (m_items && getenv("PHZ_TALLY_DEBUG")) {
+            hipLaunchKernelGGL(k_pairs<1>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(256), 0, sm, (const uint64_t *)items, m_items, tab, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
+            hipLaunchKernelGGL(k_pairs<2>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(256), 0, sm, (const uint64_t *)items, m_items, tab, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
+        }
+        if (m_items) hipLaunchKernelGGL(k_pairs<0>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(256), 0, sm, (const uint64_t *)items, m_items, tab,
                                         (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
         PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, 64, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(h_c32, counters32, 16, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[1], rl_start + NRL, 4, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
@@ -1048,26 +1125,28 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     RSV(S[T_EB], NE * 4); RSV(S[T_ESLOT], NE * 4);
     PHZ_HIP(ctx, hipMemsetAsync(deg, 0, NV * 4, sm));
     if (ne > 0) {
-        hipLaunchKernelGGL(k_edge_count, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint64_t *)S[T_GKEYS].p, deg);
+        uint32_t *tab = (uint32_t *)S[T_GKEYS].p;
+        hipLaunchKernelGGL(k_edge_count, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint32_t *)tab, deg);
         if (int s = gscan_excl<uint32_t, uint32_t>(ctx, deg, eoff, nv, S[T_SCAN_TMP])) return s;
-        hipLaunchKernelGGL(k_edge_scatter, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint64_t *)S[T_GKEYS].p, (const uint32_t *)eoff, deg,
+        hipLaunchKernelGGL(k_edge_scatter, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint32_t *)tab, (const uint32_t *)eoff, deg,
                            (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
-        hipLaunchKernelGGL(k_edge_final, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p,
-                           (uint64_t *)S[T_GKEYS].p, (int32_t *)S[T_GVALS].p, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
-                           (int32_t *)R[R_CTO].p, (int32_t *)R[R_STATS].p, ne);
+        hipLaunchKernelGGL(k_edge_sort, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p,
+                           (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p);
+        hipLaunchKernelGGL(k_edge_out, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint32_t *)S[T_ESLOT].p, tab, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
+                           (int32_t *)R[R_CTO].p, (int32_t *)R[R_STATS].p);
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = timer.stop()) return s;
 #undef RSV
     ctx->tally_dirty = false; ctx->tally_table_dirty = false;
     auto &T = ctx->tally;
-    T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = (int64_t)h_counters[3]; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
+    T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = n_kept; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
     T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;
     T.ea = (int32_t *)R[R_EA].p; T.eb = (int32_t *)R[R_EB].p; T.cells = (int32_t *)R[R_CELLS].p; T.linked = (uint8_t *)R[R_LINKED].p;
     T.cto = (int32_t *)R[R_CTO].p; T.stats = (int32_t *)R[R_STATS].p;
     T.rl_start = rl_start; T.rl_qid = rl_qid; T.rl_list = rl_list;
     sizes->n_lines = total; sizes->n_kept = T.n_kept; sizes->n_edges = ne; sizes->n_read_list = T.n_rl;
-    sizes->n_items = (int64_t)h_counters[0]; sizes->pair_events = (int64_t)h_counters[1];
+    sizes->n_items = (int64_t)spread_sum(0); sizes->pair_events = (int64_t)spread_sum(1);
     sizes->noise_match = (int64_t)h_counters[4]; sizes->noise_mismatch = (int64_t)h_counters[5];
     ctx->counters[PHZ_C_LINES] += total; ctx->counters[PHZ_C_ITEMS] += sizes->n_items; ctx->counters[PHZ_C_PAIR_EVENTS] += sizes->pair_events;
     ctx->counters[PHZ_C_EDGES] += ne;

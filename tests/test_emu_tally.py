@@ -96,9 +96,13 @@ def test_tally_kernels_on_skewed_synthetic_lines():
         lines.append((var.astype(np.int32), qid.astype(np.int32), cls, np.full(n, b, np.int32)))
     R = {"nv": nv, "line_var": np.concatenate([l[0] for l in lines]), "line_qid": np.concatenate([l[1] for l in lines]), "line_cls": np.concatenate([l[2] for l in lines]),
          "line_bam": np.concatenate([l[3] for l in lines]), "bam_offsets": [(0, 0, 30000), (1, 30000, 7000)]}
-    saved["tally"]["chrS"] = R
-    ctx = EmuContext(emu_library())
-    got, sz = run_tally(ctx, saved, ["chrS"], 2)
+    _check_against_sets(R, nv, nq, 2)
+
+
+def _check_against_sets(R, nv, nq, nb, tile=0):
+    saved = {"tally": {"chrS": R}, "n_qid": {"chrS": nq}}
+    ctx = EmuContext(emu_library(tile))
+    got, sz = run_tally(ctx, saved, ["chrS"], nb)
     var, qid, cls, bam = R["line_var"], R["line_qid"], R["line_cls"], R["line_bam"]
     kept = cls != 255
     # per-variant counters
@@ -113,8 +117,8 @@ def test_tally_kernels_on_skewed_synthetic_lines():
     rs = got["rl_start"]
     for v in range(nv):
         for k in range(2):
-            for b in range(2):
-                e = (2 * v + k) * 2 + b
+            for b in range(nb):
+                e = (2 * v + k) * nb + b
                 want = qid[kept & (var == v) & (cls == k) & (bam == b)]
                 assert np.array_equal(got["rl_qid"][rs[e]:rs[e + 1]], want), (v, k, b)
     assert int(rs[-1]) == int((kept & (cls < 2)).sum())
@@ -130,3 +134,22 @@ def test_tally_kernels_on_skewed_synthetic_lines():
                 assert (a, b2) not in seen
             else:
                 assert list(seen[(a, b2)]) == want, (a, b2)
+
+
+@pytest.mark.parametrize("tile", [0, 256])
+def test_tally_kernels_on_long_groups(tile):
+    """QNAMEs with more than 64 distinct (variant, class) items: groups that sit inside one tile (finished in place; their later items come
+    from the 64-item look-ahead and, beyond it, from memory) and groups that straddle tiles (spill path)."""
+    rng = np.random.default_rng(11)
+    nv = 160; nq = 60
+    var = []; qid = []
+    for q in range(40):                                   # 40 QNAMEs x 110 lines on 110 different variants, contiguous: tile-local groups
+        v = np.sort(rng.choice(nv, size=110, replace=False))
+        var.append(v); qid.append(np.full(110, q))
+    v2 = rng.integers(0, nv, size=6000); q2 = rng.integers(40, nq, size=6000)      # 20 QNAMEs x ~300 lines spread over everything
+    var.append(v2); qid.append(q2)
+    var = np.concatenate(var).astype(np.int32); qid = np.concatenate(qid).astype(np.int32)
+    n = len(var)
+    cls = rng.choice([0, 1, 2, 255], size=n, p=[0.45, 0.4, 0.1, 0.05]).astype(np.uint8)
+    R = {"nv": nv, "line_var": var, "line_qid": qid, "line_cls": cls, "line_bam": np.zeros(n, np.int32), "bam_offsets": [(0, 0, n)]}
+    _check_against_sets(R, nv, nq, 1, tile)
