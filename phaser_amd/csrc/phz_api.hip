@@ -56,7 +56,7 @@ int phz_ctx_destroy(phz_ctx *c) {
     for (DevBuf &b : c->stage_pool) free_buf(b);
     for (DevBuf &b : c->tally_buf) free_buf(b);
     for (DevBuf &b : c->import_buf) free_buf(b);
-    free_buf(c->tally_qcount);
+    free_buf(c->tally_qcount); free_buf(c->scan_state);
     if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
     if (c->h_shard_tab.p) (void)hipHostFree(c->h_shard_tab.p);
     free_buf(c->shard_tab);

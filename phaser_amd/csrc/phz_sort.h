@@ -71,17 +71,90 @@ template <class TI, class TO> __global__ __launch_bounds__(256) void k_gs_apply(
     for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; if (i < n) out[i] = run; run += loc[k]; }
 }
 
+// ---- the same scan in ONE launch for 32-bit sums (decoupled look-back): tiles take tickets in start order, publish their sum, and the
+// first wave of a tile looks back over its predecessors' status words (64 at a time) until it meets one that already knows its prefix.
+// A status word = epoch:30 | state:2 | value:32, written and read as one 64-bit access; words of older scans carry an older epoch and
+// read as "not there yet", so nothing is cleared between scans.
+constexpr unsigned GS_AGG = 1u, GS_PREFIX = 2u;
+__device__ __forceinline__ unsigned long long gs_word(uint32_t epoch, unsigned state, uint32_t value) {
+    return ((unsigned long long)epoch << 34) | ((unsigned long long)state << 32) | value;
+}
+template <class TI> __global__ __launch_bounds__(256) void k_gs_lookback(const TI *in, uint32_t *out, int64_t n, unsigned long long *status, uint32_t *ticket,
+                                                                          uint32_t ticket_base, uint32_t epoch) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_tile, s_prefix;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const int64_t base = (int64_t)tile * GS_CHUNK + (int64_t)tid * GS_ITEMS;
+    uint32_t loc[GS_ITEMS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; loc[k] = i < n ? (uint32_t)in[i] : 0u; sum += loc[k]; }
+    const uint32_t incl = gs_wave_incl(sum, lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t block_sum = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (lane == 0) __hip_atomic_store(&status[tile], gs_word(epoch, tile == 0 ? GS_PREFIX : GS_AGG, block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int64_t j = (int64_t)tile - 1;
+            for (;;) {
+                const int64_t idx = j - lane;
+                const unsigned long long w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs_word(epoch, GS_PREFIX, 0u);
+                const unsigned state = (uint32_t)(w >> 34) == epoch ? (unsigned)(w >> 32) & 3u : 0u;
+                // usable: every word from the nearest predecessor up to the first one that holds a prefix
+                const unsigned long long have = __ballot(state != 0u), pref = __ballot(state == GS_PREFIX);
+                const unsigned long long upto = pref ? ((pref & (~pref + 1ull)) << 1) - 1ull : ~0ull;        // lanes 0 .. first prefix lane
+                if ((have & upto) != upto) { __builtin_amdgcn_s_sleep(1); continue; }                  // a predecessor in that stretch has not published yet
+                uint32_t v = ((upto >> lane) & 1ull) ? (uint32_t)w : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                excl += v;
+                if (pref) break;
+                j -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&status[tile], gs_word(epoch, GS_PREFIX, excl + block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_prefix = excl;
+    }
+    __syncthreads();
+    uint32_t run = s_prefix + incl - sum;
+    for (int w2 = 0; w2 < wave; w2++) run += s_w[w2];
+#pragma unroll
+    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; if (i < n) out[i] = run; run += loc[k]; }
+    if (base <= n - 1 && n - 1 < base + GS_ITEMS) out[n] = run;        // the thread holding the last element also holds the total
+}
+
 template <class TI, class TO> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out /* [n + 1] */, int64_t n, DevBuf &tmp) {
     hipStream_t sm = ctx->stream;
     if (n <= 0) { PHZ_HIP(ctx, hipMemsetAsync(out, 0, sizeof(TO), sm)); return PHZ_OK; }
     const int64_t nb = (n + GS_CHUNK - 1) / GS_CHUNK;
-    if (int s = phz_reserve(ctx, tmp, (size_t)nb * sizeof(TO) + 16)) return s;
-    TO *partial = (TO *)tmp.p;
-    hipLaunchKernelGGL((k_gs_reduce<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, n, partial);
-    hipLaunchKernelGGL((k_gs_partials<TO>), dim3(1), dim3(1024), 0, sm, partial, nb, out + n);
-    hipLaunchKernelGGL((k_gs_apply<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, out, n, (const TO *)partial);
-    PHZ_HIP(ctx, hipGetLastError());
-    return PHZ_OK;
+    if constexpr (sizeof(TO) == 4) {
+        const size_t before = ctx->scan_state.cap;
+        if (int s = phz_reserve(ctx, ctx->scan_state, 64 + (size_t)nb * 8)) return s;
+        if (ctx->scan_state.cap != before || ctx->scan_epoch >= (1u << 30) - 2u) {
+            PHZ_HIP(ctx, hipMemsetAsync(ctx->scan_state.p, 0, ctx->scan_state.cap, sm));
+            ctx->scan_epoch = 0; ctx->scan_ticket_base = 0;
+        }
+        const uint32_t epoch = ++ctx->scan_epoch;
+        hipLaunchKernelGGL((k_gs_lookback<TI>), dim3((unsigned)nb), dim3(256), 0, sm, in, (uint32_t *)out, n, (unsigned long long *)((char *)ctx->scan_state.p + 64),
+                           (uint32_t *)ctx->scan_state.p, ctx->scan_ticket_base, epoch);
+        ctx->scan_ticket_base += (uint32_t)nb;
+        PHZ_HIP(ctx, hipGetLastError());
+        (void)tmp;
+        return PHZ_OK;
+    } else {
+        if (int s = phz_reserve(ctx, tmp, (size_t)nb * sizeof(TO) + 16)) return s;
+        TO *partial = (TO *)tmp.p;
+        hipLaunchKernelGGL((k_gs_reduce<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, n, partial);
+        hipLaunchKernelGGL((k_gs_partials<TO>), dim3(1), dim3(1024), 0, sm, partial, nb, out + n);
+        hipLaunchKernelGGL((k_gs_apply<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, out, n, (const TO *)partial);
+        PHZ_HIP(ctx, hipGetLastError());
+        return PHZ_OK;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ LSD radix sort of pairs

@@ -153,3 +153,23 @@ def test_tally_kernels_on_long_groups(tile):
     cls = rng.choice([0, 1, 2, 255], size=n, p=[0.45, 0.4, 0.1, 0.05]).astype(np.uint8)
     R = {"nv": nv, "line_var": var, "line_qid": qid, "line_cls": cls, "line_bam": np.zeros(n, np.int32), "bam_offsets": [(0, 0, n)]}
     _check_against_sets(R, nv, nq, 1, tile)
+
+
+def test_scan_over_many_tiles():
+    """The single-launch scan (look-back over the predecessors' status words) on a read-list table of 100 tiles, twice on one context (the
+    status words of the first scan must read as stale in the second)."""
+    rng = np.random.default_rng(5)
+    nv = 200000; nq = 500; n = 30000
+    var = np.sort(rng.integers(0, nv, size=n)).astype(np.int32); qid = rng.integers(0, nq, size=n).astype(np.int32)
+    cls = rng.choice([0, 1, 2, 255], size=n, p=[0.45, 0.4, 0.1, 0.05]).astype(np.uint8)
+    R = {"nv": nv, "line_var": var, "line_qid": qid, "line_cls": cls, "line_bam": np.zeros(n, np.int32), "bam_offsets": [(0, 0, n)]}
+    saved = {"tally": {"chrS": R}, "n_qid": {"chrS": nq}}
+    ctx = EmuContext(emu_library())
+    for rep in range(2):
+        got, sz = run_tally(ctx, saved, ["chrS"], 1)
+        cnt = np.zeros(nv * 2, np.int64)
+        k = cls < 2
+        np.add.at(cnt, var[k].astype(np.int64) * 2 + cls[k], 1)
+        assert np.array_equal(got["rl_start"], np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32))
+        for e in np.flatnonzero(cnt)[:200]:
+            assert np.array_equal(got["rl_qid"][got["rl_start"][e]:got["rl_start"][e + 1]], qid[k & (var == e // 2) & (cls == e % 2)])
