@@ -68,9 +68,13 @@ struct SWrite {
     unsigned long long base;         // file offset of p0
     __device__ __forceinline__ void ch(char c) { *p++ = c; }
     template <int N> __device__ __forceinline__ void lit(const char (&s)[N]) { for (int i = 0; i < N - 1; i++) p[i] = s[i]; p += N - 1; }
-    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) {
-        const char *s = P.at(i); const uint32_t l = P.len(i);
-        for (uint32_t k = 0; k < l; k++) p[k] = s[k];
+    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) {       // exactly l bytes, eight at a time (gfx950 serves unaligned 8-byte accesses to
+        const char *s = P.at(i); const uint32_t l = P.len(i);               // global memory and LDS; byte by byte this copy was most of the row kernels' time)
+        uint32_t k = 0;
+        for (; k + 8 <= l; k += 8) { unsigned long long w; __builtin_memcpy(&w, s + k, 8); __builtin_memcpy(p + k, &w, 8); }
+        if (l & 4u) { uint32_t w; __builtin_memcpy(&w, s + k, 4); __builtin_memcpy(p + k, &w, 4); k += 4; }
+        if (l & 2u) { uint16_t w; __builtin_memcpy(&w, s + k, 2); __builtin_memcpy(p + k, &w, 2); k += 2; }
+        if (l & 1u) p[k] = s[k];
         p += l;
     }
     __device__ __forceinline__ void num(long long v) {
@@ -101,7 +105,7 @@ struct RD {
     const uint32_t *blk_sup, *blk_tot, *blk_cnt, *seg_ns, *single_n;
     const uint8_t *blk_conc, *blk_cormode, *blk_statkind; const uint32_t *blk_statidx; const int32_t *blk_maxmaf;
     const uint32_t *its, *labels; unsigned long long *piece_dst;
-    const unsigned long long *cfg_base;
+    const unsigned long long *cfg_base; const uint32_t *cfg_chunk;
 };
 
 __device__ __forceinline__ int8_t hap_phase(const RD &D, int b, int h, uint32_t t) {        // VCF phase index of haplotype h's allele at the block's t-th variant
@@ -273,7 +277,8 @@ struct RowAse {
 // allele_config.txt (:1160-1172); row = cfg_base[block] + i * (n - 1) + (j with i skipped)
 struct RowCfg {
     template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
-        int64_t lo = 0, hi = D.nblocks;                     // largest b with cfg_base[b] <= r
+        // largest b with cfg_base[b] <= r: the block of the row's 256-row chunk is known, and a block has >= 2 rows
+        int64_t lo = D.cfg_chunk[r >> 8], hi = lo + 257 < D.nblocks ? lo + 257 : D.nblocks;
         while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (D.cfg_base[m] <= (unsigned long long)r) lo = m; else hi = m; }
         const int64_t b = lo;
         const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
@@ -287,6 +292,15 @@ struct RowCfg {
     }
 };
 
+// block of the first row of every 256-row chunk of allele_config (one search of the whole block table per chunk instead of per row)
+__global__ __launch_bounds__(256) void k_cfg_chunks(int64_t nchunks, int64_t nblocks, const unsigned long long *cfg_base, uint32_t *cfg_chunk) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    const unsigned long long r = (unsigned long long)c << 8;
+    int64_t lo = 0, hi = nblocks;
+    while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (cfg_base[m] <= r) lo = m; else hi = m; }
+    cfg_chunk[c] = (uint32_t)lo;
+}
 template <class ROW> __global__ __launch_bounds__(256) void k_row_len(RD D, int64_t nrows, uint32_t *len) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= nrows) return;
@@ -298,8 +312,9 @@ template <class ROW> __global__ __launch_bounds__(256) void k_row_len(RD D, int6
 // byte i and file byte i agree modulo 16) and copied out with aligned 16-byte stores: a thread writing its row byte by byte to global memory
 // reaches ~0.2 TB/s (680 MB of allele_config rows: 3 ms), the staged copy streams.  A row range that does not fit the stage (rows with
 // thousands of read labels) is written directly.
-constexpr int ROW_STAGE = 40 * 1024;
-template <class ROW, int ROWS> __global__ __launch_bounds__(ROWS) void k_row_write(RD D, int64_t nrows, const unsigned long long *off, char *out) {
+// The stage is sized per file (rows x typical row length): it decides how many workgroups a CU holds, and the row functions are chains of
+// dependent loads that only occupancy hides.
+template <class ROW, int ROWS, int ROW_STAGE> __global__ __launch_bounds__(ROWS) void k_row_write(RD D, int64_t nrows, const unsigned long long *off, char *out) {
     __shared__ __attribute__((aligned(16))) char s_buf[ROW_STAGE];
     const int64_t r0 = (int64_t)blockIdx.x * ROWS;
     const int64_t r1 = r0 + ROWS < nrows ? r0 + ROWS : nrows;
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256) void k_keep(int64_t ne, const uint8_t *linked,
 // ---------------------------------------------------------------------------------------------- ordering stage
 __global__ __launch_bounds__(256) void k_iota_rank(int64_t nv, const unsigned long long *var_rank, unsigned long long *key, uint32_t *val) {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v < nv) { key[v] = var_rank[v]; val[v] = (uint32_t)v; }
+    if (v < nv) { const unsigned long long r = var_rank[v]; key[v] = (r & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)r - (uint32_t)(r >> 32)); val[v] = (uint32_t)v; }   // (first, gap)
 }
 __global__ __launch_bounds__(256) void k_invert(int64_t n, const uint32_t *perm, uint32_t *inv) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -462,9 +477,25 @@ __global__ __launch_bounds__(256) void k_compact_kept(int64_t ne, const uint8_t 
 }
 struct ShardTab { const long long *lo, *hi; const int32_t *bam; int n; };
 // first-appearance keys (rule 2): covered variants by (BAM of the first kept line, line)
-__global__ __launch_bounds__(256) void k_flag_keys(int64_t nv, const long long *var_first, uint32_t *is_key) {
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v < nv) is_key[v] = var_first[v] >= 0 ? 1u : 0u;
+// ... and, on the way, the largest distance between the two halves of a connectivity-map rank (first ref/alt line of the QNAME, the variant's first
+// linked line in it: a few hundred lines apart at most in practice), which decides how many radix passes the rank sort needs for its low half
+__global__ __launch_bounds__(256) void k_flag_keys(int64_t nv, const long long *var_first, uint32_t *is_key, const unsigned long long *var_rank, unsigned long long *max_gap) {
+    __shared__ uint32_t s_m[4];
+    uint32_t m = 0;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (int64_t)gridDim.x * 256) {
+        is_key[v] = var_first[v] >= 0 ? 1u : 0u;
+        const unsigned long long r = var_rank[v];
+        const uint32_t gap = (uint32_t)r - (uint32_t)(r >> 32);
+        m = gap > m ? gap : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = __shfl_xor(m, d); m = y > m ? y : m; }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) m = s_m[w] > m ? s_m[w] : m;
+        if (m) atomicMax(max_gap, (unsigned long long)m);
+    }
 }
 __global__ __launch_bounds__(256) void k_compact_keys(int64_t nv, const long long *var_first, const uint32_t *kpos, ShardTab T, unsigned long long *key, uint32_t *val) {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1168,7 +1199,7 @@ struct phz_rowsdev {
     DevBuf ridx, va, vb, eorder, mem_s, cstart, corder, ekeep, estart, key_g;
     DevBuf cnt64, cnt32, chrom_cnt, seg_start, key64s, eloc;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
     DevBuf alle_of, sub_of, nsub, complex_list, exc_list, nsub_o, blk_base;
-    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, blk_voff;
+    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, blk_voff;
     DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, pool, tl, its, piece_dst, rowlen;
     DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
     DevBuf o_var, o_maxmaf, o_hap, o_cor;
@@ -1183,7 +1214,7 @@ struct phz_rowsdev {
                                    &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
-                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &blk_voff, &labels,
+                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &blk_voff, &labels,
                                    &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
@@ -1443,7 +1474,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     RSV(mem_pos, (NV + 1) * 4); RSV(cid, (NV + 1) * 4); RSV(kpos, (NE + 1) * 4); RSV(keypos, (NV + 1) * 4);
     if (nv) hipLaunchKernelGGL(k_flag_members, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->deg.p, (const int32_t *)h->label.p, P<uint32_t>(h->f_a), P<uint32_t>(h->f_b));
     if (ne) hipLaunchKernelGGL(k_flag_u8, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)h->keep.p, P<uint32_t>(h->f_c));
-    if (nv) hipLaunchKernelGGL(k_flag_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, P<uint32_t>(h->f_d));
+    if (nv) hipLaunchKernelGGL(k_flag_keys, dim3(std::min(nblk(nv), 512u)), dim3(256), 0, sm, nv, (const long long *)T.var_first, P<uint32_t>(h->f_d), (const unsigned long long *)T.var_rank, cnt64 + 2);
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_a), P<uint32_t>(h->mem_pos), nv, h->scan_tmp)) return s;
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_b), P<uint32_t>(h->cid), nv, h->scan_tmp)) return s;
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_c), P<uint32_t>(h->kpos), ne, h->scan_tmp)) return s;
@@ -1454,7 +1485,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     PHZ_HIP(ctx, hipMemcpyAsync(&h_n[1], P<uint32_t>(h->cid) + nv, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&h_n[2], P<uint32_t>(h->kpos) + ne, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&h_n[3], P<uint32_t>(h->keypos) + nv, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(h_c64, cnt64, 16, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(h_c64, cnt64, 24, hipMemcpyDeviceToHost, sm));
     if (int s = sec.wait()) return s;
     const int64_t nmem = h_n[0], ncomp = h_n[1], nkeep = h_n[2], nkeys = h_n[3], n_linked = (int64_t)h_c64[0];
     res->dropped = (int64_t)h_c64[1];
@@ -1468,7 +1499,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     RSV(estart, (size_t)(ncomp + 2) * 4); RSV(key_g, (size_t)(nkeys + 1) * 4);
     if (nv) {
         hipLaunchKernelGGL(k_iota_rank, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
-        const int rg[2][2] = {{0, bl}, {32, 32 + bl}};
+        const int rg[2][2] = {{0, bits_for((uint64_t)(h_c64[2] ? h_c64[2] : 1))}, {32, 32 + bl}};      // (first line of the QNAME, distance to the variant's line)
         if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nv, rg, 2, P<uint32_t>(h->k32a), nullptr)) return s;      // k32a: variants in rank order
         hipLaunchKernelGGL(k_invert, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->k32a.p, P<uint32_t>(h->ridx));
     }
@@ -1649,6 +1680,12 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     D.blk_conc = P<uint8_t>(h->conc); D.blk_cormode = P<uint8_t>(h->cormode); D.blk_statkind = P<uint8_t>(h->statkind); D.blk_statidx = P<uint32_t>(h->statidx);
     D.blk_maxmaf = P<int32_t>(h->maxmaf); D.its = P<uint32_t>(h->its); D.labels = P<uint32_t>(h->labels); D.piece_dst = P<unsigned long long>(h->piece_dst);
     D.cfg_base = P<unsigned long long>(h->cfg_base);
+    {
+        const int64_t nchunks = ((int64_t)h_cfg_total + 255) / 256;
+        RSV(cfg_chunk, (size_t)(nchunks + 1) * 4);
+        if (nchunks) hipLaunchKernelGGL(k_cfg_chunks, dim3(nblk(nchunks)), dim3(256), 0, sm, nchunks, nblocks, (const unsigned long long *)h->cfg_base.p, P<uint32_t>(h->cfg_chunk));
+        D.cfg_chunk = P<uint32_t>(h->cfg_chunk);
+    }
     const int64_t rows[PHZ_TXT_COUNT] = {n_linked, nblocks, nblocks * nb, (int64_t)h_cfg_total, nkeys, nkeys * nb, nkeys};
     int64_t max_rows = 1;
     for (int f = 0; f < PHZ_TXT_COUNT; f++) max_rows = std::max(max_rows, rows[f]);
@@ -1701,13 +1738,13 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         const unsigned long long *of = P<unsigned long long>(h->off[f]);
         char *out = P<char>(h->text[f]);
         if (rows[f]) switch (f) {
-            case PHZ_TXT_CONN: hipLaunchKernelGGL((k_row_write<RowConn, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_HAP: hipLaunchKernelGGL((k_row_write<RowHap, 128>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, 64>), dim3((unsigned)((rows[f] + 63) / 64)), dim3(64), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_CFG: hipLaunchKernelGGL((k_row_write<RowCfg, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_ALLELIC: hipLaunchKernelGGL((k_row_write<RowAllelic, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL((k_row_write<RowSingleAse, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
-            default: hipLaunchKernelGGL((k_row_write<RowSingleHap, 256>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_CONN: hipLaunchKernelGGL((k_row_write<RowConn, 256, 24 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL((k_row_write<RowHap, 128, 32 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, 64, 16 * 1024>), dim3((unsigned)((rows[f] + 63) / 64)), dim3(64), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_CFG: hipLaunchKernelGGL((k_row_write<RowCfg, 128, 12 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_ALLELIC: hipLaunchKernelGGL((k_row_write<RowAllelic, 256, 24 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL((k_row_write<RowSingleAse, 256, 32 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
+            default: hipLaunchKernelGGL((k_row_write<RowSingleHap, 256, 32 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
         }
         if (f == PHZ_TXT_ASE && n_rl && rows[f]) hipLaunchKernelGGL(k_label_write, dim3(nblk(n_rl)), dim3(256), 0, sm, D, n_rl, out);
     }

@@ -186,10 +186,17 @@ template <class K, class V> __global__ __launch_bounds__(64) void k_rs_scatter(c
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    K rk[RS_ROWS]; V rv[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {                   // the tile's 16 rows requested together: one memory round trip, not sixteen
+        const int64_t i = base + r * 64 + lane;
+        rk[r] = i < n ? kin[i] : (K)0; rv[r] = i < n ? vin[i] : (V)0;
+    }
+#pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
         const int64_t i = base + r * 64 + lane;
         const bool valid = i < n;
-        const K k = valid ? kin[i] : (K)0;
+        const K k = rk[r];
         const uint32_t d = (uint32_t)(k >> shift) & 255u;
         unsigned long long peers = __ballot(valid ? 1 : 0);
 #pragma unroll
@@ -202,7 +209,7 @@ template <class K, class V> __global__ __launch_bounds__(64) void k_rs_scatter(c
         __syncthreads();
         if (valid && rank == 0) s_off[d] += (uint32_t)__popcll(peers);      // the lowest lane of every digit group moves the digit's cursor
         __syncthreads();
-        if (valid) { kout[pos] = k; vout[pos] = vin[i]; }
+        if (valid) { kout[pos] = k; vout[pos] = rv[r]; }
     }
 }
 
