@@ -31,6 +31,12 @@ constexpr unsigned long long PS_EMPTY = ~0ull;
 constexpr int STAT_N = 512;                    // largest block (variants) covered by the gwStat text table
 constexpr int PH_NMAX = 256, PH_EMAX = 2048;   // largest component (variants / kept pairs) k_phase_general takes; larger ones go to the host
 constexpr int PH_BRUTE_MAX = 22;               // largest fragment brute-forced on the device (2^21 configurations shared by 64 lanes)
+#ifdef PHZ_PHASE_PROFILE      // build flag: cycle counts of the slowest component's sections, printed by phase_all
+#define PH_TICK() __builtin_readcyclecounter()
+#else
+#define PH_TICK() 0ull
+#endif
+constexpr int PH_DP_MAXD = 10, PH_DP_MINLEN = 8;   // fragments of >= 8 variants whose pairs span <= 10 variants: dynamic programme instead of brute force
 constexpr int SEG_SMALL = 32, SEG_MID = 256, SEG_LDS = 2048;       // read-set sizes: one thread / one wave (512-slot table) / one workgroup (4096 slots, global pool beyond)
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr unsigned long long NONE64 = ~0ull;
@@ -634,13 +640,15 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
     __shared__ uint32_t s_m[2][32];                                        // pairs of the fragment under brute force as bit masks by index distance
     __shared__ uint8_t s_mark[2 * PH_NMAX + 2];
     __shared__ int32_t s_weak[PH_NMAX + 4];
-    __shared__ uint8_t s_inpts[PH_NMAX + 4];
     __shared__ uint16_t s_bounds[PH_NMAX + 4];
     __shared__ char s_p0[PH_NMAX + 4];                                     // configuration of haplotype A per fragment, concatenated
     __shared__ uint16_t s_p0off[PH_NMAX + 4];
     __shared__ char s_cur[4 * PH_NMAX], s_cand[4 * PH_NMAX], s_fin[4 * PH_NMAX];
     __shared__ uint16_t s_finlen[PH_NMAX + 4];
     __shared__ int s_nf, s_status, s_nfin, s_st[8];
+    __shared__ int32_t s_dp[2][1 << PH_DP_MAXD];                          // dynamic programme over the last D alleles: best score, number of ways (capped at 2),
+    __shared__ uint8_t s_dc[2][1 << PH_DP_MAXD];
+    __shared__ uint32_t s_ch[PH_BRUTE_MAX][(1 << PH_DP_MAXD) / 32];         // and the predecessor taken, one bit per (step, state)
     const int lane = threadIdx.x;
     const uint32_t c = P.complex_list[blockIdx.x];
     (void)nlist;
@@ -697,38 +705,93 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
         }
         return w;
     };
+    const unsigned long long tk0 = PH_TICK();
+    unsigned long long tk1 = tk0, tk2 = tk0, tk3 = tk0;
     const int reached = flood(0, n);
+    tk1 = PH_TICK();
     if (reached == n) {
         if (lane == 0) { s_finlen[0] = (uint16_t)marks_to_string(0, n, s_fin); s_nfin = 1; }
     } else {
         const int xmax = P.max_block_size == 0 ? n : P.max_block_size;
         // split_by_weak (:2271-2324)
-        if (lane == 0) {
-            for (int p = 0; p <= n + 1; p++) { s_weak[p] = 0; s_inpts[p] = 0; }
-            for (int t = 0; t < E; t++) {
-                const int i = s_i[t] < s_j[t] ? s_i[t] : s_j[t], j = s_i[t] < s_j[t] ? s_j[t] : s_i[t];
-                if (i == j) continue;
-                s_weak[i + 1] += 1; s_weak[j + 1] -= 1;             // a pair (i, j) spans the cut positions p in (i, j]
-            }
-            int run = 0, maxw = 0;
-            for (int p = 0; p <= n; p++) { run += s_weak[p]; s_weak[p] = run; }
-            for (int p = 2; p < n - 1; p++) maxw = s_weak[p] > maxw ? s_weak[p] : maxw;
-            int biggest = n, level = 1, nbd = 0;
-            s_bounds[0] = 0; s_bounds[1] = (uint16_t)n; nbd = 2;
-            while (biggest > xmax || level == 1) {
-                for (int p = 2; p < n - 1; p++)
-                    if (s_weak[p] == level && !s_inpts[p + 1] && !s_inpts[p - 1]) s_inpts[p] = 1;
-                nbd = 0; s_bounds[nbd++] = 0;
-                for (int p = 2; p < n - 1; p++) if (s_inpts[p]) s_bounds[nbd++] = (uint16_t)p;
-                s_bounds[nbd++] = (uint16_t)n;
-                biggest = 0;
-                for (int t = 1; t < nbd; t++) biggest = (int)s_bounds[t] - (int)s_bounds[t - 1] > biggest ? (int)s_bounds[t] - (int)s_bounds[t - 1] : biggest;
-                level++;
-                if (level > maxw + 1 && biggest > xmax) { s_status = 1; break; }          // the reference never leaves this loop
-            }
-            s_nf = nbd - 1;
+        // weak[p] = pairs spanning the cut before variant p.  Everything below is wave-uniform and lives in registers: the cut set is a 256-bit
+        // mask, a level's candidate cuts come from ballots, and only the levels that occur are visited.  (Done by one lane over LDS arrays -- one
+        // pass over all positions per level -- this was 0.3 ms for a component of 96 variants: the tail of the whole launch.)
+        for (int p = lane; p <= n + 1; p += 64) s_weak[p] = 0;
+        __syncthreads();
+        for (int t = lane; t < E; t += 64) {
+            const int i = s_i[t] < s_j[t] ? s_i[t] : s_j[t], j = s_i[t] < s_j[t] ? s_j[t] : s_i[t];
+            if (i == j) continue;
+            atomicAdd(&s_weak[i + 1], 1); atomicSub(&s_weak[j + 1], 1);             // a pair (i, j) spans the cut positions p in (i, j]
         }
         __syncthreads();
+        {   // running sum over positions 0 .. n: four consecutive positions per lane + wave scan
+            int v[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int q = 4 * lane + k; v[k] = q <= n ? s_weak[q] : 0; sum += v[k]; }
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+            int run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int q = 4 * lane + k; run += v[k]; if (q <= n) s_weak[q] = run; }
+        }
+        __syncthreads();
+        int wv[4];                                               // weak value of the candidate positions 64k + lane (2 <= p < n - 1), -1 elsewhere
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int q = 64 * k + lane; wv[k] = (q >= 2 && q < n - 1) ? s_weak[q] : -1; }
+        unsigned long long cut[4] = {0ull, 0ull, 0ull, 0ull};
+        auto is_cut = [&](int q) -> bool { return (cut[(q >> 6) & 3] >> (q & 63)) & 1ull; };
+        int biggest = n, level = 1, status = 0;
+        bool first_round = true;
+        while (biggest > xmax || first_round) {
+            unsigned long long cm[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cm[k] = __ballot(wv[k] == level);
+            if (cm[0] | cm[1] | cm[2] | cm[3]) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {                      // ascending positions: a cut made here blocks its right neighbour (:2296-2300)
+                    unsigned long long m = cm[k];
+                    while (m) {
+                        const int q = 64 * k + __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        if (!is_cut(q - 1) && !is_cut(q + 1)) cut[k] |= 1ull << (q & 63);
+                    }
+                }
+                int prev = 0, big = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    unsigned long long m = cut[k];
+                    while (m) {
+                        const int q = 64 * k + __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        big = q - prev > big ? q - prev : big; prev = q;
+                    }
+                }
+                biggest = n - prev > big ? n - prev : big;
+            }
+            first_round = false;
+            int nl = 0x7FFFFFFF;                                 // the next level that occurs
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (wv[k] > level && wv[k] < nl) nl = wv[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(nl, d); nl = y < nl ? y : nl; }
+            if (nl == 0x7FFFFFFF) { if (biggest > xmax) status = 1; break; }          // no level left: the reference never leaves this loop
+            level = nl;
+        }
+        if (lane == 0) {
+            int nbd = 0;
+            s_bounds[nbd++] = 0;
+            for (int k = 0; k < 4; k++) {
+                unsigned long long m = cut[k];
+                while (m) { s_bounds[nbd++] = (uint16_t)(64 * k + __builtin_ctzll(m)); m &= m - 1ull; }
+            }
+            s_bounds[nbd++] = (uint16_t)n;
+            s_nf = nbd - 1;
+            if (status) s_status = 1;
+        }
+        __syncthreads();
+        tk2 = PH_TICK();
         if (s_status) { if (lane == 0) atomicAdd(&P.counters[2], 1u); return; }
         const int nf = s_nf;
         // sub_block_phase without a given configuration, per fragment (:2209-2258)
@@ -737,23 +800,10 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
         for (int f = 0; f < nf; f++) {
             const int base = s_bounds[f], len = (int)s_bounds[f + 1] - base;
             bool done = false;
-            if (nf > 1) {
-                const int r = flood(base, base + len);
-                if (r == len) {
-                    if (lane == 0) s_p0off[f + 1] = (uint16_t)(s_p0off[f] + marks_to_string(base, base + len, s_p0 + s_p0off[f]));
-                    done = true;
-                }
-            }
-            if (!done) {
-                if (len > PH_BRUTE_MAX) {                  // the host takes it (the reference's limit is its patience)
-                    if (lane == 0) P.exc_list[atomicAdd(&P.counters[1], 1u)] = c;
-                    return;
-                }
-                // Pairs of the fragment as bit masks by index distance d = j - i: bit i of s_m[0][d] / s_m[1][d] = a same-configuration /
-                // opposite pair (i, i + d).  A configuration is the bit vector b (bit t = allele of variant t, bit 0 = 0); its consistent pairs at
-                // distance d are popc(~(b ^ b >> d) & same) + popc((b ^ b >> d) & opposite): no memory access per configuration.  (The reference
-                // scores 2^(n-1) configurations pair by pair, :2236-2258; only the maximum, the number of configurations reaching it and the
-                // unique winner matter, so the order of enumeration is free.)
+            // Pairs of the fragment as bit masks by index distance d = j - i: bit i of s_m[0][d] / s_m[1][d] = a same-configuration /
+            // opposite pair (i, i + d) -- for the flood fill of a fragment of up to 32 variants and for the search over its configurations
+            const bool small = len <= 32;
+            if (small) {
                 for (int t = lane; t < 2 * 32; t += 64) s_m[t >> 5][t & 31] = 0u;
                 __syncthreads();
                 for (int t = lane; t < E; t += 64) {
@@ -765,6 +815,110 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
                     atomicOr(&s_m[k][j - i], 1u << i);
                 }
                 __syncthreads();
+            }
+            if (nf > 1) {
+                if (small) {
+                    // flood fill on bit masks (r0 / r1 = variants reached with allele 0 / 1): lane d spreads along the pairs at distance d, the lanes'
+                    // results are OR-ed; a same-configuration pair keeps the allele, an opposite pair swaps it
+                    const int sh = lane & 31;
+                    const uint32_t a0 = (lane >= 1 && lane < 32) ? s_m[0][sh] : 0u, a1 = (lane >= 1 && lane < 32) ? s_m[1][sh] : 0u;
+                    uint32_t r0 = 1u, r1 = 0u;
+                    for (;;) {
+                        uint32_t n0 = r0 | ((r0 & a0) << sh) | ((r0 >> sh) & a0) | ((r1 & a1) << sh) | ((r1 >> sh) & a1);
+                        uint32_t n1 = r1 | ((r1 & a0) << sh) | ((r1 >> sh) & a0) | ((r0 & a1) << sh) | ((r0 >> sh) & a1);
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) { n0 |= __shfl_xor(n0, d); n1 |= __shfl_xor(n1, d); }
+                        if (n0 == r0 && n1 == r1) break;
+                        r0 = n0; r1 = n1;
+                    }
+                    if (__popc(r0) + __popc(r1) == len) {          // the reference accepts iff that many allele nodes were reached (:2199)
+                        const uint32_t any = r0 | r1;                // a variant without a reached allele is skipped: quirk kept
+                        if (lane < len && ((any >> lane) & 1u)) s_p0[s_p0off[f] + __popc(any & ((1u << lane) - 1u))] = ((r0 >> lane) & 1u) ? '0' : '1';
+                        if (lane == 0) s_p0off[f + 1] = (uint16_t)(s_p0off[f] + __popc(any));
+                        done = true;
+                    }
+                } else {
+                    const int r = flood(base, base + len);
+                    if (r == len) {
+                        if (lane == 0) s_p0off[f + 1] = (uint16_t)(s_p0off[f] + marks_to_string(base, base + len, s_p0 + s_p0off[f]));
+                        done = true;
+                    }
+                }
+            }
+            if (!done) {
+                if (len > PH_BRUTE_MAX) {                  // the host takes it (the reference's limit is its patience)
+                    if (lane == 0) P.exc_list[atomicAdd(&P.counters[1], 1u)] = c;
+                    return;
+                }
+                // A configuration is the bit vector b (bit t = allele of variant t, bit 0 = 0); its consistent pairs at distance d are
+                // popc(~(b ^ b >> d) & same) + popc((b ^ b >> d) & opposite): no memory access per configuration.  (The reference scores
+                // 2^(n-1) configurations pair by pair, :2236-2258; only the maximum, the number of configurations reaching it and the unique
+                // winner matter, so the order of enumeration is free.)
+                // The score is a sum over pairs (i, i + d): when no pair of the fragment reaches further than D <= PH_DP_MAXD variants, the maximum
+                // over the 2^(len-1) configurations, the number of configurations reaching it (1 or "several") and the winner follow from a dynamic
+                // programme over the last D alleles -- len * 2^D steps instead of 2^(len-1) * len.  (A fragment of 20 variants, brute force on
+                // one wave, was the 0.77 ms tail of the whole phasing launch.)
+                int D = 0;
+                for (int d = 1; d < len && d < 32; d++) if (s_m[0][d] | s_m[1][d]) D = d;
+                uint32_t tt, cc;
+                if (len >= PH_DP_MINLEN && D <= PH_DP_MAXD) {
+                    const int De = D > 0 ? D : 1;
+                    const int NS = 1 << De;
+                    const int32_t NEG = -(1 << 28);
+                    for (int sp = lane; sp < NS; sp += 64) { s_dp[0][sp] = sp == 0 ? 0 : NEG; s_dc[0][sp] = sp == 0 ? 1 : 0; }
+                    __syncthreads();
+                    int cur = 0;
+                    for (int t = 1; t < len; t++) {
+                        // pairs (t - d, t) as masks over the state bits: bit d - 1 = allele of variant t - d
+                        const int dd = lane + 1;
+                        const bool inr = dd <= De && t - dd >= 0;
+                        const uint32_t A = (uint32_t)__ballot(inr && ((s_m[0][dd & 31] >> ((t - dd) & 31)) & 1u));
+                        const uint32_t B = (uint32_t)__ballot(inr && ((s_m[1][dd & 31] >> ((t - dd) & 31)) & 1u));
+                        for (int s0 = 0; s0 < NS; s0 += 64) {
+                            const int sp = s0 + lane;
+                            const bool valid = sp < NS;
+                            int32_t best = NEG; uint32_t cnt = 0; bool take1 = false;
+                            if (valid) {
+                                const uint32_t X = (sp & 1) ? ~0u : 0u;
+                                const uint32_t p0 = (uint32_t)sp >> 1, p1 = p0 | (1u << (De - 1));
+                                const int32_t d0 = s_dp[cur][p0], d1 = s_dp[cur][p1];
+                                const int32_t c0 = d0 < 0 ? NEG : d0 + __popc(~(p0 ^ X) & A) + __popc((p0 ^ X) & B);
+                                const int32_t c1 = d1 < 0 ? NEG : d1 + __popc(~(p1 ^ X) & A) + __popc((p1 ^ X) & B);
+                                best = c0 > c1 ? c0 : c1;
+                                if (best >= 0) cnt = (c0 == best ? s_dc[cur][p0] : 0u) + (c1 == best ? s_dc[cur][p1] : 0u);
+                                cnt = cnt > 2u ? 2u : cnt;
+                                take1 = c1 > c0;
+                            }
+                            const unsigned long long chb = __ballot(valid && take1);
+                            if (valid) { s_dp[cur ^ 1][sp] = best; s_dc[cur ^ 1][sp] = (uint8_t)cnt; }
+                            if (lane == 0) { s_ch[t][s0 >> 5] = (uint32_t)chb; if (s0 + 32 < NS) s_ch[t][(s0 >> 5) + 1] = (uint32_t)(chb >> 32); }
+                        }
+                        __syncthreads();
+                        cur ^= 1;
+                    }
+                    int32_t best_s = NEG; uint32_t ties = 0, arg = NONE32;
+                    for (int sp = lane; sp < NS; sp += 64) {
+                        const int32_t v = s_dp[cur][sp];
+                        if (v > best_s) { best_s = v; ties = s_dc[cur][sp]; arg = (uint32_t)sp; }
+                        else if (v == best_s && v >= 0) ties += s_dc[cur][sp];
+                    }
+                    int32_t gmax = best_s;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { const int32_t o = __shfl_xor(gmax, d); gmax = o > gmax ? o : gmax; }
+                    tt = best_s == gmax ? ties : 0u;
+                    uint32_t aa = best_s == gmax ? arg : NONE32;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { tt += __shfl_xor(tt, d); const uint32_t o = __shfl_xor(aa, d); aa = o < aa ? o : aa; }
+                    cc = 0;
+                    if (tt == 1) {                                   // the winner, back through the recorded predecessors (every lane walks the same path)
+                        uint32_t st = aa;
+                        for (int t = len - 1; t >= 1; t--) {
+                            cc |= (st & 1u) << (t - 1);
+                            const uint32_t hb = (s_ch[t][st >> 5] >> (st & 31u)) & 1u;
+                            st = (st >> 1) | (hb << (De - 1));
+                        }
+                    }
+                } else {
                 uint32_t m0[PH_BRUTE_MAX], m1[PH_BRUTE_MAX];
 #pragma unroll
                 for (int d = 1; d < PH_BRUTE_MAX; d++) { m0[d] = s_m[0][d]; m1[d] = s_m[1][d]; }
@@ -784,9 +938,10 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
                 int gmax = best_s;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(gmax, d); gmax = o > gmax ? o : gmax; }
-                uint32_t tt = best_s == gmax ? ties : 0u, cc = best_s == gmax ? best_c : NONE32;
+                tt = best_s == gmax ? ties : 0u; cc = best_s == gmax ? best_c : NONE32;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) { tt += __shfl_xor(tt, d); const uint32_t o = __shfl_xor(cc, d); cc = o < cc ? o : cc; }
+                }
                 if (lane == 0) {
                     char *dst = s_p0 + s_p0off[f];
                     if (tt == 1) { dst[0] = '0'; for (int k = 1; k < len; k++) dst[k] = ((cc >> (k - 1)) & 1u) ? '1' : '0'; }
@@ -796,6 +951,7 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
             }
             __syncthreads();
         }
+        tk3 = PH_TICK();
         // stitching, left to right (:2138-2160); haplotype B is always the flip of haplotype A, so only A is carried.  The control flow is
         // wave-uniform (state in LDS, written by lane 0): the scores of the joint configurations are summed over the pairs by all lanes
         if (lane == 0) {
@@ -811,14 +967,15 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
             const int used = curlen + nlen;                     // (|cur A| + |cur B| + |next A| + |next B| + 1) / 2
             const int hi = n < start + used ? n : start + used;
             const int idx_n = hi - start > 0 ? hi - start : 0;
-            // candidates: cur A + next A, cur A + next B; the other two joint configurations are their complements (skipped, :2228-2234)
-            if (lane == 0) {
-                bool cur_inv = true, nxt_inv = true;                // a string of '-' (or an empty one) equals its own flip
-                for (int k = 0; k < curlen; k++) if (s_cur[k] != '-') cur_inv = false;
-                for (int k = 0; k < nlen; k++) if (nxt[k] != '-') nxt_inv = false;
-                for (int k = 0; k < curlen; k++) { s_cand[k] = s_cur[k]; s_cand[used + k] = s_cur[k]; }
-                for (int k = 0; k < nlen; k++) { s_cand[curlen + k] = nxt[k]; s_cand[used + curlen + k] = flipc(nxt[k]); }
-                s_st[4] = (!cur_inv && !nxt_inv) ? 2 : 1;
+            // candidates: cur A + next A, cur A + next B; the other two joint configurations are their complements (skipped, :2228-2234).
+            // All string work is spread over the lanes (a component of 250 variants stitches a hundred fragments: done by one lane, these loops were
+            // the tail of the launch); the decisions are wave-uniform
+            {
+                int cur_not = 0, nxt_not = 0;                       // a string of '-' (or an empty one) equals its own flip
+                for (int k = lane; k < curlen; k += 64) { const char ch = s_cur[k]; if (ch != '-') cur_not = 1; s_cand[k] = ch; s_cand[used + k] = ch; }
+                for (int k = lane; k < nlen; k += 64) { const char ch = nxt[k]; if (ch != '-') nxt_not = 1; s_cand[curlen + k] = ch; s_cand[used + curlen + k] = flipc(ch); }
+                const int both = __any(cur_not) && __any(nxt_not);
+                if (lane == 0) s_st[4] = both ? 2 : 1;
             }
             __syncthreads();
             const int ncand = s_st[4];
@@ -837,7 +994,7 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { sc[0] += __shfl_xor(sc[0], d); sc[1] += __shfl_xor(sc[1], d); }
-            if (lane == 0) {
+            {
                 int win = -1;
                 if (ncand == 1) win = 0;
                 else if (sc[0] > sc[1]) win = 0;
@@ -845,19 +1002,25 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
                 bool has_dash;
                 int outlen;
                 if (win >= 0) {
-                    outlen = used; has_dash = false;
-                    for (int k = 0; k < used; k++) if (s_cand[win * used + k] == '-') has_dash = true;
+                    outlen = used;
+                    int dash = 0;
+                    for (int k = lane; k < used; k += 64) if (s_cand[win * used + k] == '-') dash = 1;
+                    has_dash = __any(dash) != 0;
                 } else { outlen = idx_n; has_dash = idx_n > 0; }               // all '-' (length idx_n); empty string holds no '-'
+                const int finpos = s_st[3], nfin_now = s_st[2];
+                __syncthreads();                                               // everybody has read the state before lane 0 changes it
                 if (has_dash) {
-                    const int finpos = s_st[3];
-                    for (int k = 0; k < curlen; k++) s_fin[finpos + k] = s_cur[k];
-                    s_finlen[s_st[2]] = (uint16_t)curlen; s_st[2] += 1; s_st[3] = finpos + curlen;
-                    s_st[1] = used;                                              // ASSIGNED, not advanced (:2152)
-                    for (int k = 0; k < nlen; k++) s_cur[k] = nxt[k];
-                    s_st[0] = nlen;
+                    for (int k = lane; k < curlen; k += 64) s_fin[finpos + k] = s_cur[k];
+                    __syncthreads();
+                    for (int k = lane; k < nlen; k += 64) s_cur[k] = nxt[k];
+                    if (lane == 0) {
+                        s_finlen[nfin_now] = (uint16_t)curlen; s_st[2] = nfin_now + 1; s_st[3] = finpos + curlen;
+                        s_st[1] = used;                                          // ASSIGNED, not advanced (:2152)
+                        s_st[0] = nlen;
+                    }
                 } else {
-                    for (int k = 0; k < outlen; k++) s_cur[k] = win >= 0 ? s_cand[win * used + k] : '-';
-                    s_st[0] = outlen;
+                    for (int k = lane; k < outlen; k += 64) s_cur[k] = win >= 0 ? s_cand[win * used + k] : '-';
+                    if (lane == 0) s_st[0] = outlen;
                 }
             }
             __syncthreads();
@@ -887,7 +1050,13 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
             vi += len; fp += len;
         }
         P.nsub[c] = (uint32_t)ns;
+#ifdef PHZ_PHASE_PROFILE
+        const unsigned long long tk4 = PH_TICK();
+        const uint32_t tot = (uint32_t)(tk4 - tk0);
+        if (atomicMax(&P.counters[4], tot) < tot) { P.counters[5] = (uint32_t)(tk1 - tk0); P.counters[6] = (uint32_t)(tk2 - tk1); P.counters[7] = (uint32_t)(tk3 - tk2); P.counters[9] = (uint32_t)(tk4 - tk3); P.counters[10] = (uint32_t)n; P.counters[11] = (uint32_t)E; P.counters[12] = (uint32_t)s_nf; }
+#endif
     }
+    (void)tk1; (void)tk2; (void)tk3;
 }
 
 // ---------------------------------------------------------------------------------------------- blocks
@@ -1283,7 +1452,7 @@ int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf
     ph.complex_list = P<uint32_t>(complex_list); ph.exc_list = P<uint32_t>(exc_list); ph.counters = cnt32; ph.max_block_size = max_block_size;
     ph.eloc = P<uint32_t>(eloc);
     uint32_t h_c32[4] = {0, 0, 0, 0};
-    PHZ_HIP(ctx, hipMemsetAsync(cnt32, 0, 12, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(cnt32, 0, 32, sm));
     if (nkeep) hipLaunchKernelGGL(k_edge_local, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, ncomp, ph, P<uint32_t>(eloc));
     hipLaunchKernelGGL(k_phase_pair, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, ph);
     PHZ_HIP(ctx, hipMemcpyAsync(h_c32, cnt32, 4, hipMemcpyDeviceToHost, sm));
@@ -1292,7 +1461,13 @@ int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf
     if (h_c32[0]) hipLaunchKernelGGL(k_phase_general, dim3(h_c32[0]), dim3(64), 0, sm, ph, h_c32[0]);
     PHZ_HIP(ctx, hipGetLastError());
     PHZ_HIP(ctx, hipMemcpyAsync(h_c32, cnt32, 12, hipMemcpyDeviceToHost, sm));
+#ifdef PHZ_PHASE_PROFILE
+    uint32_t dbg[16] = {0}; PHZ_HIP(ctx, hipMemcpyAsync(dbg, cnt32, 64, hipMemcpyDeviceToHost, sm));
+#endif
     if (int s = sec.wait()) return s;
+#ifdef PHZ_PHASE_PROFILE
+    fprintf(stderr, "phase profile: slowest component total %u ticks: flood %u split %u fragments %u stitch+out %u; n %u E %u nf %u\n", dbg[4], dbg[5], dbg[6], dbg[7], dbg[9], dbg[10], dbg[11], dbg[12]);
+#endif
     if (h_c32[2]) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "a haplotype block cannot be split to --max_block_size (the reference does not terminate on it)");
     *n_complex = h_c32[0]; *n_exc = h_c32[1];
     if (h_c32[1]) {

@@ -43,7 +43,7 @@ def batch_phase(ctx, comps, mbs):
     return cs, sub, al, ns
 
 
-@pytest.mark.parametrize("seed,mbs", [(1, 3), (2, 5), (3, 9), (4, 15), (5, 0), (6, 4)])
+@pytest.mark.parametrize("seed,mbs", [(1, 3), (2, 5), (3, 9), (4, 15), (5, 0), (6, 4), (7, 18), (8, 12)])
 def test_device_phase_matches_host_routine(seed, mbs):
     lib = emu_library()
     ctx = EmuContext(lib)
