@@ -59,6 +59,7 @@ int phz_ctx_destroy(phz_ctx *c) {
     free_buf(c->tally_qcount); free_buf(c->scan_state);
     if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
     if (c->h_shard_tab.p) (void)hipHostFree(c->h_shard_tab.p);
+    if (c->h_bam_stage.p) (void)hipHostFree(c->h_bam_stage.p);
     free_buf(c->shard_tab);
     for (hipEvent_t e : c->map_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);

@@ -305,7 +305,9 @@ struct BgzfMap {
     const uint8_t *f = nullptr; size_t fsz = 0, total = 0;
     std::vector<Blk> blks;
     ~BgzfMap() { if (f) munmap((void *)f, fsz); }
-    int open(const char *path) {
+    // sparse: only the member headers (and a few members) will be read through the mapping -- no read-ahead / fault-around, so that the
+    // mapping stays a few thousand page-table entries and its munmap is cheap
+    int open(const char *path, bool sparse = false) {
         int fd = ::open(path, O_RDONLY);
         if (fd < 0) return PHZ_E_ARG;
         struct stat st;
@@ -314,6 +316,7 @@ struct BgzfMap {
         f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
         close(fd);
         if (f == MAP_FAILED) { f = nullptr; return PHZ_E_NOMEM; }
+        if (sparse) (void)madvise((void *)f, fsz, MADV_RANDOM);
         // one member header: 0 = not a BGZF member header at `off`, else its total size; *xl = XLEN
         auto header = [&](size_t off, uint16_t *xl, int *why) -> uint32_t {
             *why = PHZ_E_ARG;
@@ -608,7 +611,7 @@ static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64
 int phz_bam_plan_file(const char *path, const char *const *ref_names, int n_names, PhzBamPlan *out) {
     Laps laps("bam plan");
     BgzfMap *M = new BgzfMap();
-    if (int st = M->open(path)) { delete M; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
+    if (int st = M->open(path, true)) { delete M; return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st; }
     laps.lap("member table");
     std::vector<BamPiece> pieces;
     if (int st = bam_plan(*M, ref_names, n_names, nullptr, 0, true, out->refs, out->head, &out->first_record, pieces, laps)) { delete M; return st; }

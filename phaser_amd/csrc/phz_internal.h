@@ -26,6 +26,7 @@ struct phz_ctx {
     // scratch
     DevBuf desc, tile_w0, scalars;
     DevBuf h_scalars;                  // pinned host mirror of `scalars` (hipHostMalloc)
+    DevBuf h_bam_stage;                // page-locked staging of the device BAM path (phz_bamdev.hip)
     DevBuf shard_tab, h_shard_tab;     // shard table of a batched K_map submission (device / pinned host image)
     std::vector<hipEvent_t> map_ev;    // event pairs around every k_map launch of a batch
     // staging for PHZ_HOST callers

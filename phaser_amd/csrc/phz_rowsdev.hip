@@ -1221,15 +1221,25 @@ template <int MODE, int SLOTS, int THREADS> __global__ __launch_bounds__(THREADS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t seg = THREADS == 64 ? G.big_list[blockIdx.x] : G.big_list2[blockIdx.x];
     const uint32_t np = seg_pieces<MODE>(G, seg);
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (uint32_t t = 0; t < np; t++) {
-            uint32_t lo = 0, hi = 0;
-            const bool ok = seg_piece<MODE>(G, seg, t, &lo, &hi);
-            s_pref[t] = acc; s_lo[t] = lo;
-            if (ok) acc += hi - lo;
-        }
-        s_pref[np] = acc; s_carry = 0; s_off = 0;
+    // the pieces of the segment (one read list each) looked up by all threads -- a chain of dependent loads per piece: one thread doing
+    // them one after the other was the tail of the launch --, then their exclusive prefix by the first wave
+    for (uint32_t t = tid; t < np; t += THREADS) {
+        uint32_t lo = 0, hi = 0;
+        const bool ok = seg_piece<MODE>(G, seg, t, &lo, &hi);
+        s_lo[t] = lo; s_pref[t] = ok ? hi - lo : 0u;
+    }
+    if (tid == 0) { s_carry = 0; s_off = 0; }
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t chunk = (np + 63u) / 64u, beg = (uint32_t)lane * chunk;
+        uint32_t sum = 0;
+        for (uint32_t t = beg; t < beg + chunk && t < np; t++) sum += s_pref[t];
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        uint32_t run = incl - sum;
+        for (uint32_t t = beg; t < beg + chunk && t < np; t++) { const uint32_t x = s_pref[t]; s_pref[t] = run; run += x; }
+        if (lane == 63) s_pref[np] = incl;
     }
     __syncthreads();
     const uint32_t M = s_pref[np];

@@ -236,18 +236,23 @@ class Engine:
         if dev is None:
             dev = torch.device("cpu")
         space = _lib.PHZ_DEVICE if dev.type == "cuda" else _lib.PHZ_HOST
-        a0 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a0
-                             for c in self.chrom_list]) if self.chrom_list else np.zeros(0, np.uint8)
-        a1 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a1
-                             for c in self.chrom_list]) if self.chrom_list else np.zeros(0, np.uint8)
-        a0 = np.ascontiguousarray(a0, dtype=np.uint8); a1 = np.ascontiguousarray(a1, dtype=np.uint8)
         t0 = _t.perf_counter()
+        key = (str(dev), tuple(self.chrom_list))
+        cached = getattr(self, "_allele_codes", None)
+        if cached is None or cached[0] != key:                  # allele base codes of the joint variant space: constant for the life of the engine
+            a0 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a0
+                                 for c in self.chrom_list]) if self.chrom_list else np.zeros(0, np.uint8)
+            a1 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a1
+                                 for c in self.chrom_list]) if self.chrom_list else np.zeros(0, np.uint8)
+            a0 = np.ascontiguousarray(a0, dtype=np.uint8); a1 = np.ascontiguousarray(a1, dtype=np.uint8)
+            if space == _lib.PHZ_DEVICE:
+                a0 = torch.from_numpy(a0).to(dev); a1 = torch.from_numpy(a1).to(dev)
+                torch.cuda.synchronize(dev)
+            cached = self._allele_codes = (key, a0, a1)
         if space == _lib.PHZ_DEVICE:
-            ta0 = torch.from_numpy(a0).to(dev); ta1 = torch.from_numpy(a1).to(dev)
-            torch.cuda.synchronize(dev)
-            pa0, pa1 = _p(ta0), _p(ta1)
+            pa0, pa1 = _p(cached[1]), _p(cached[2])
         else:
-            pa0, pa1 = C.c_void_p(a0.ctypes.data), C.c_void_p(a1.ctypes.data)
+            pa0, pa1 = C.c_void_p(cached[1].ctypes.data), C.c_void_p(cached[2].ctypes.data)
         arr = (_lib.phz_lines * max(1, len(lines)))(*lines)
         sz = _lib.phz_tally_sizes()
         self.ctx.check(self.lib.phz_tally(self.ctx.h, arr, len(lines), NV, pa0, pa1, NQ, nb, C.byref(sz), space))

@@ -147,6 +147,24 @@ def main(argv=None):
     say('STARTED "Read backed phasing and ASE/haplotype analyses" ... ')
     say("    DATE, TIME : %s" % (datetime.datetime.now().strftime('%Y-%m-%d, %H:%M:%S')))
     say("#1. Loading heterozygous variants into intervals...")
+    # the host region that will receive the row text is page-locked on a helper thread while the VCF is read (~0.1 s per GB, independent of
+    # everything else); sized from the BAMs, grown later if it turns out too small
+    arena = None
+    if args.output_read_ids == 0 and args.gw_phase_method == 0 and not any(b.endswith(".sam") for b in args.bam.split(",")):
+        import threading
+
+        def _arena():
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    from . import rowsdev
+                    total = sum(os.path.getsize(b) for b in args.bam.split(",") if os.path.exists(b))
+                    rowsdev.prepare_arena(int(min(4 << 30, max(64 << 20, total // 4))))
+            except Exception:
+                pass
+
+        arena = threading.Thread(target=_arena, daemon=True)
+        arena.start()
     data = vcf.read_bytes(args.vcf)
     sample_col = None
     for raw in data.split(b"\n", 20000)[:20000]:          # the header sits at the top
@@ -228,6 +246,23 @@ def main(argv=None):
         owner = pdist.assign_chromosomes(weights, world)
         eng.set_owned([c for c in vs.chroms if owner[c] == rank])
     mine = set(eng.chrom_list)
+    # While the BAMs are read: the per-variant tables of the row stage go to the GPU (0.07 s at genome scale, independent of the reads)
+    warm = None
+    if not any_sam and cfg.device_rows and args.output_read_ids == 0 and args.gw_phase_method == 0:
+        import threading
+
+        def _warm():
+            try:
+                import torch
+                if not torch.cuda.is_available():
+                    return
+                from . import rowsdev
+                rowsdev.tables_for(eng)
+            except Exception:
+                pass            # finish() does both itself when they are not there
+
+        warm = threading.Thread(target=_warm, daemon=True)
+        warm.start()
     for bi, (bam, mq, isz, pe) in enumerate(zip(bam_list, mapq_list, isize_list, pe_list)):
         say("     file: %s" % bam)
         say("          minimum mapq: %s" % mq)
@@ -267,6 +302,10 @@ def main(argv=None):
     say("#3. Identifying connected variants...")
     say("     calculating sequencing noise level...")
     n_before = len(eng.log)
+    if warm is not None:
+        warm.join()
+    if arena is not None:
+        arena.join()
     files = eng.finish(chunks=True)
     mark("tally + pair tests + components + block phasing + rows")
     if os.environ.get("PHZ_TIMING"):
@@ -277,8 +316,23 @@ def main(argv=None):
         say("#4. Identifying haplotype blocks...")
         say("#5. Phasing blocks...")
         say("#6. Outputting haplotypes...")
-        pdist.write_files([(args.o + "." + name + ".txt", body) for name, body in files.items()], threads=max(1, min(16, args.threads)))
-        mark("write the five files")
+        writer = None
+        five = [(args.o + "." + name + ".txt", body) for name, body in files.items()]
+        if args.write_vcf == 1:                 # the five files go out on a helper thread while the phased VCF is put together
+            import threading
+            werr = []
+
+            def _write():
+                try:
+                    pdist.write_files(five, threads=max(1, min(16, args.threads)))
+                except BaseException as e:      # re-raised on the main thread
+                    werr.append(e)
+
+            writer = threading.Thread(target=_write)
+            writer.start()
+        else:
+            pdist.write_files(five, threads=max(1, min(16, args.threads)))
+            mark("write the five files")
         up = pc = 0
         if args.write_vcf == 1:
             from . import vcfout
@@ -291,7 +345,10 @@ def main(argv=None):
                 say("     GT field is not being updated with phASER genome wide phase. This can be changed using the --gw_phase_vcf argument.")
             vtxt, up, pc = vcfout.phased_vcf_text(data, sample_col, eng, args.id_separator, args.chr, args.gw_phase_vcf,
                                                   args.gw_phase_vcf_min_confidence, threads=max(1, args.threads), as_bytes=True)
-            mark("phased VCF text")
+            writer.join()
+            if werr:
+                raise werr[0]
+            mark("phased VCF text (+ the five files on a helper thread)")
             say("     Compressing and tabix indexing output VCF...")
             vcfout.write_bgzf(args.o + ".vcf.gz", vtxt, max(0, args.threads if args.threads > 1 else 0))
             if not vcfout.tabix_index(args.o + ".vcf.gz", "vcf", max(0, args.threads if args.threads > 1 else 0)):

@@ -93,11 +93,29 @@ def tables_for(eng) -> Tables:
 
 
 _PINNED: Dict[str, torch.Tensor] = {}
+_ARENA = {"buf": None, "used": 0}
+
+
+def prepare_arena(nbytes: int):
+    """Page-lock one host region for the row text of the coming pass ahead of time (the CLI does it on a helper thread while the BAM is
+    decoded: page-locking costs ~0.1 s per GB).  The text buffers of a pass are carved from it as long as they fit."""
+    if not torch.cuda.is_available():
+        return
+    b = _ARENA["buf"]
+    if b is None or b.numel() < nbytes:
+        _ARENA["buf"] = torch.empty(max(1, nbytes), dtype=torch.uint8, pin_memory=True)
+    _ARENA["used"] = 0
 
 
 def pinned(name: str, nbytes: int) -> np.ndarray:
     """uint8 view of a page-locked host buffer kept per name for the life of the process (grown on demand): D2H at the full PCIe rate,
     and no page-locking cost per pass."""
+    b = _ARENA["buf"]
+    if b is not None and name.startswith("rows_") and name not in _PINNED:
+        lo = (_ARENA["used"] + 4095) & ~4095
+        if lo + nbytes <= b.numel():
+            _ARENA["used"] = lo + nbytes
+            return b.numpy()[lo:lo + nbytes]
     t = _PINNED.get(name)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(1, nbytes + nbytes // 8 + 4096), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
@@ -158,6 +176,7 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
             if name in ("allelic", "single_ase", "single_hap"):
                 frags[c][name + "_bam"] = []
     total_bytes = 0
+    _ARENA["used"] = 0                          # the previous pass's text buffers are given up (as the per-name buffers always were)
     for f, name in enumerate(_lib.PHZ_TXT_NAMES):
         nbytes = int(R.bytes[f]); total_bytes += nbytes
         if not fetch_text:

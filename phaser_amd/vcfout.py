@@ -51,11 +51,25 @@ def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", 
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_vcf_phase_text failed (malformed VCF line?)")
     t2 = time.perf_counter()
+    if as_bytes:            # the native buffer itself (a uint8 array that frees it when it dies): no copy of ~100 MB
+        class _Owner:
+            def __init__(self, lib, ptr):
+                self.lib = lib; self.ptr = ptr
+
+            def __del__(self):
+                try:
+                    self.lib.phz_buf_free(self.ptr)
+                except Exception:
+                    pass
+        raw = _lib.native_view(out.value, n.value, C.c_uint8, _Owner(lib, out))
+        if os.environ.get("PHZ_TIMING"):
+            sys.stderr.write("[phz timing]     vcf out (python): inputs %.3f s, native %.3f s, copy out %.3f s\n" % (t1 - t0, t2 - t1, time.perf_counter() - t2))
+        return raw, int(up.value), int(pc.value)
     try:
         raw = C.string_at(out, n.value)
         if os.environ.get("PHZ_TIMING"):
             sys.stderr.write("[phz timing]     vcf out (python): inputs %.3f s, native %.3f s, copy out %.3f s\n" % (t1 - t0, t2 - t1, time.perf_counter() - t2))
-        return (raw if as_bytes else raw.decode()), int(up.value), int(pc.value)
+        return raw.decode(), int(up.value), int(pc.value)
     finally:
         lib.phz_buf_free(out)
 
@@ -65,8 +79,14 @@ def write_bgzf(path: str, text, threads: int = 0):
     import ctypes as C
     from . import _lib
     lib = _lib.load()
-    data = text.encode() if isinstance(text, str) else bytes(text)
-    st = lib.phz_bgzf_write(path.encode(), C.cast(C.c_char_p(data), C.c_void_p), len(data), int(threads), 6)
+    import numpy as np
+    if isinstance(text, np.ndarray):            # what phased_vcf_text(as_bytes=True) returns: compressed where it lies
+        data = np.ascontiguousarray(text, dtype=np.uint8)
+        ptr, n = C.c_void_p(data.ctypes.data), int(data.size)
+    else:
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        ptr, n = C.cast(C.c_char_p(data), C.c_void_p), len(data)
+    st = lib.phz_bgzf_write(path.encode(), ptr, n, int(threads), 6)
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_bgzf_write(%s) failed" % path)
 

@@ -60,3 +60,10 @@ rc = phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", ",".
 t4 = time.perf_counter()
 sizes = {n: os.path.getsize("/tmp/cli_scale_out.%s.txt" % n) for n in ("allelic_counts", "variant_connections", "haplotypes", "haplotypic_counts", "allele_config")}
 print("CLI rc=%d wall %.1fs for %d BAM records (%.0f records/s end to end from files) | outputs %s" % (rc, t4 - t3, nrec, nrec / (t4 - t3), sizes))
+if os.environ.get("PHZ_CLI_SWEEP_CHUNK_MB"):        # BAM-stage experiment: the same command again with other H2D chunk sizes (warm process: compare the bam lines only)
+    for mb in os.environ["PHZ_CLI_SWEEP_CHUNK_MB"].split(","):
+        os.environ["PHZ_BAM_CHUNK_MB"] = mb
+        print("=== PHZ_BAM_CHUNK_MB=%s" % mb, flush=True)
+        sys.stderr.write("=== PHZ_BAM_CHUNK_MB=%s\n" % mb); sys.stderr.flush()
+        phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", ",".join(["255"] * n_bams), "--baseq", "10", "--paired_end", "1", "--o", "/tmp/cli_scale_out",
+                     "--threads", str(threads), "--write_vcf", str(write_vcf)])
