@@ -64,6 +64,7 @@ struct SCount {
     __device__ __forceinline__ void ch(char) { n++; }
     template <int N> __device__ __forceinline__ void lit(const char (&)[N]) { n += (uint32_t)(N - 1); }
     __device__ __forceinline__ void pool(const PoolD &P, int64_t i) { n += P.len(i); }
+    __device__ __forceinline__ void raw(const char *, uint32_t l) { n += l; }
     __device__ __forceinline__ void num(long long v) { n += v < 0 ? 1u + (uint32_t)ndigits((unsigned long long)(-v)) : (uint32_t)ndigits((unsigned long long)v); }
     __device__ __forceinline__ void skip(uint32_t k) { n += k; }
     __device__ __forceinline__ unsigned long long where() const { return 0; }
@@ -74,15 +75,15 @@ struct SWrite {
     unsigned long long base;         // file offset of p0
     __device__ __forceinline__ void ch(char c) { *p++ = c; }
     template <int N> __device__ __forceinline__ void lit(const char (&s)[N]) { for (int i = 0; i < N - 1; i++) p[i] = s[i]; p += N - 1; }
-    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) {       // exactly l bytes, eight at a time (gfx950 serves unaligned 8-byte accesses to
-        const char *s = P.at(i); const uint32_t l = P.len(i);               // global memory and LDS; byte by byte this copy was most of the row kernels' time)
-        uint32_t k = 0;
+    __device__ __forceinline__ void raw(const char *s, uint32_t l) {        // exactly l bytes, eight at a time (gfx950 serves unaligned 8-byte accesses to
+        uint32_t k = 0;                                                     // global memory and LDS; byte by byte this copy was most of the row kernels' time)
         for (; k + 8 <= l; k += 8) { unsigned long long w; __builtin_memcpy(&w, s + k, 8); __builtin_memcpy(p + k, &w, 8); }
         if (l & 4u) { uint32_t w; __builtin_memcpy(&w, s + k, 4); __builtin_memcpy(p + k, &w, 4); k += 4; }
         if (l & 2u) { uint16_t w; __builtin_memcpy(&w, s + k, 2); __builtin_memcpy(p + k, &w, 2); k += 2; }
         if (l & 1u) p[k] = s[k];
         p += l;
     }
+    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) { raw(P.at(i), P.len(i)); }
     __device__ __forceinline__ void num(long long v) {
         unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
         if (v < 0) *p++ = '-';
@@ -93,6 +94,15 @@ struct SWrite {
     __device__ __forceinline__ void skip(uint32_t k) { p += k; }            // bytes somebody else writes (label text)
     __device__ __forceinline__ unsigned long long where() const { return base + (unsigned long long)(p - p0); }
 };
+
+// Per block member (index into mem_s), built once per pass by k_mem_rec: everything the block rows need of the variant in ONE 32-byte load -- the
+// row functions walked mem_s -> v_alle -> pool offsets -> bytes per variant and section, a chain of dependent loads that was their whole run time
+struct __attribute__((aligned(16))) MemRec {
+    uint32_t uid_off, rsid_off, a_off[2];       // a_off / a_len / ph[h]: the allele of haplotype h (A = 0, B = 1) and its VCF phase index
+    uint16_t uid_len, rsid_len, a_len[2];
+    uint8_t black, ref_a, ref_b; int8_t ph[2]; uint8_t wide, pad[2];
+};
+static_assert(sizeof(MemRec) == 32, "MemRec is two 16-byte loads");
 
 // ---- everything the row functions read (device pointers)
 struct RD {
@@ -112,8 +122,20 @@ struct RD {
     const uint8_t *blk_conc, *blk_cormode, *blk_statkind; const uint32_t *blk_statidx; const int32_t *blk_maxmaf;
     const uint32_t *its, *labels; unsigned long long *piece_dst;
     const unsigned long long *cfg_base; const uint32_t *cfg_chunk;
+    const MemRec *mrec; const uint32_t *lab_e, *lab_skip; int64_t nmem;       // lab_*[(h * nb + bam) * nmem + member]: read list and room for its label text
 };
 
+// strings of a block member through its record; a string of 64 KB or more (a structural variant's allele) does not fit the record's 16-bit lengths:
+// such a member is marked wide and read through the pools
+template <class S> __device__ __forceinline__ void put_uid(const RD &D, const MemRec &r, int64_t m, S &s) {
+    if (r.wide) s.pool(D.uid, D.mem_s[m]); else s.raw(D.uid.b + r.uid_off, r.uid_len);
+}
+template <class S> __device__ __forceinline__ void put_rsid(const RD &D, const MemRec &r, int64_t m, S &s) {
+    if (r.wide) s.pool(D.rsid, D.mem_s[m]); else s.raw(D.rsid.b + r.rsid_off, r.rsid_len);
+}
+template <class S> __device__ __forceinline__ void put_alle(const RD &D, const MemRec &r, int64_t m, int h, S &s) {
+    if (r.wide) { const int64_t g = D.mem_s[m]; s.pool(D.alle, 2 * g + (D.v_alle[g] ^ h)); } else s.raw(D.alle.b + r.a_off[h], r.a_len[h]);
+}
 __device__ __forceinline__ int8_t hap_phase(const RD &D, int b, int h, uint32_t t) {        // VCF phase index of haplotype h's allele at the block's t-th variant
     const uint32_t g = D.mem_s[D.blk_mstart[b] + t];
     return D.phase_idx[2 * (int64_t)g + (D.v_alle[g] ^ h)];
@@ -209,22 +231,26 @@ struct RowHap {
         const int minpos = D.pos[g0], maxpos = D.pos[g1];
         s.pool(D.chromn, D.vchrom[g0]); s.ch('\t'); s.num(minpos); s.ch('\t'); s.num(maxpos); s.ch('\t'); s.num(maxpos - minpos); s.ch('\t');
         s.num(n); s.ch('\t');
-        const PoolD &names = D.unique_ids ? D.uid : D.rsid;
-        for (uint32_t t = 0; t < n; t++) { if (t) s.ch(','); s.pool(names, D.mem_s[m0 + t]); }
+        const MemRec *R = D.mrec + m0;
+        for (uint32_t t = 0; t < n; t++) {
+            const MemRec r = R[t];
+            if (t) s.ch(',');
+            if (D.unique_ids) put_uid(D, r, m0 + t, s); else put_rsid(D, r, m0 + t, s);
+        }
         s.ch('\t');
         for (int h = 0; h < 2; h++) {
             if (h) s.ch('|');
-            for (uint32_t t = 0; t < n; t++) { const int64_t g = D.mem_s[m0 + t]; if (t) s.ch(','); s.pool(D.alle, 2 * g + (D.v_alle[g] ^ h)); }
+            for (uint32_t t = 0; t < n; t++) { const MemRec r = R[t]; if (t) s.ch(','); put_alle(D, r, m0 + t, h, s); }
         }
         const long long c0 = D.blk_cnt[2 * b], c1 = D.blk_cnt[2 * b + 1];
         s.ch('\t'); s.num(c0); s.ch('\t'); s.num(c1); s.ch('\t'); s.num(c0 + c1); s.ch('\t');
         s.num(D.blk_sup[b]); s.lit(".0\t"); s.num(D.blk_tot[b]); s.lit(".0\t");
-        for (int h = 0; h < 2; h++) { if (h) s.ch('|'); for (uint32_t t = 0; t < n; t++) s.ch(phase_char(hap_phase(D, (int)b, h, t))); }
+        for (int h = 0; h < 2; h++) { if (h) s.ch('|'); for (uint32_t t = 0; t < n; t++) s.ch(phase_char(R[t].ph[h])); }
         s.ch('\t'); s.num(D.blk_conc[b]); s.ch('\t');
         const uint8_t cm = D.blk_cormode[b];
         for (int h = 0; h < 2; h++) {
             if (h) s.ch('|');
-            for (uint32_t t = 0; t < n; t++) s.ch(cm == 0 ? phase_char(hap_phase(D, (int)b, h, t)) : (char)('0' + ((cm == 1 ? 0 : 1) ^ h)));
+            for (uint32_t t = 0; t < n; t++) s.ch(cm == 0 ? phase_char(R[t].ph[h]) : (char)('0' + ((cm == 1 ? 0 : 1) ^ h)));
         }
         s.ch('\t'); put_stat(D, (int)b, s); s.ch('\n');
     }
@@ -242,38 +268,38 @@ struct RowAse {
         const int64_t g0 = D.mem_s[m0], g1 = D.mem_s[m0 + n - 1];
         s.pool(D.chromn, D.vchrom[g0]); s.ch('\t'); s.num(D.pos[g0]); s.ch('\t'); s.num(D.pos[g1]); s.ch('\t');
         long long used = 0, nblack = 0;
-        for (uint32_t t = 0; t < n; t++) { const int64_t g = D.mem_s[m0 + t]; if (D.black && D.black[g]) continue; if (used) s.ch(','); s.pool(D.uid, g); used++; }
+        const MemRec *R = D.mrec + m0;
+        for (uint32_t t = 0; t < n; t++) { const MemRec r = R[t]; if (r.black) continue; if (used) s.ch(','); put_uid(D, r, m0 + t, s); used++; }
         s.ch('\t'); s.num(used); s.ch('\t');
-        if (D.black) for (uint32_t t = 0; t < n; t++) { const int64_t g = D.mem_s[m0 + t]; if (!D.black[g]) continue; if (nblack) s.ch(','); s.pool(D.uid, g); nblack++; }
+        if (D.black) for (uint32_t t = 0; t < n; t++) { const MemRec r = R[t]; if (!r.black) continue; if (nblack) s.ch(','); put_uid(D, r, m0 + t, s); nblack++; }
         s.ch('\t'); s.num(nblack); s.ch('\t');
         for (int h = 0; h < 2; h++) {
             bool first = true;
             for (uint32_t t = 0; t < n; t++) {
-                const int64_t g = D.mem_s[m0 + t];
-                if (D.black && D.black[g]) continue;
+                const MemRec r = R[t];
+                if (r.black) continue;
                 if (!first) s.ch(',');
                 first = false;
-                s.pool(D.alle, 2 * g + (D.v_alle[g] ^ h));
+                put_alle(D, r, m0 + t, h, s);
             }
             s.ch('\t');
         }
         s.num(ns0); s.ch('\t'); s.num(ns1); s.ch('\t'); s.num(ns0 + ns1); s.ch('\t');
         const uint8_t cm = D.blk_cormode[b];
-        const int c00 = cm == 0 ? (int)hap_phase(D, (int)b, 0, 0) : (cm == 1 ? 0 : 1);
+        const int c00 = cm == 0 ? (int)R[0].ph[0] : (cm == 1 ? 0 : 1);
         if (c00 == 0) s.lit("0|1"); else if (c00 == 1) s.lit("1|0"); else s.lit("0/1");
         s.ch('\t'); put_stat(D, (int)b, s); s.ch('\t');
         s.pool(D.maft, D.blk_maxmaf[b]); s.ch('\t'); s.pool(D.bamn, bb); s.ch('\t');
         for (int h = 0; h < 2; h++) {
             bool first = true;
+            const size_t lab0 = (size_t)(h * D.nb + bb) * (size_t)D.nmem + m0;
             for (uint32_t t = 0; t < n; t++) {
-                const int64_t g = D.mem_s[m0 + t];
-                if (D.black && D.black[g]) continue;
+                if (R[t].black) continue;
                 if (!first) s.ch(';');
                 first = false;
-                const int64_t e = (2 * g + (D.v_alle[g] ^ h)) * D.nb + bb;
-                const uint32_t lo = D.rl_start[e], hi = D.rl_start[e + 1];
-                if (S::writing) D.piece_dst[e] = s.where();
-                if (hi > lo) s.skip(D.its[hi] - D.its[lo] - 1u);          // every label is followed by one separator byte except the list's last
+                if (S::writing) D.piece_dst[D.lab_e[lab0 + t]] = s.where();
+                const uint32_t room = D.lab_skip[lab0 + t];
+                if (room) s.skip(room);                             // every label is followed by one separator byte except the list's last
             }
             s.ch(h == 0 ? '\t' : '\n');
         }
@@ -291,13 +317,42 @@ struct RowCfg {
         const uint32_t idx = (uint32_t)((unsigned long long)r - D.cfg_base[b]);
         const uint32_t i = idx / (n - 1); uint32_t j = idx % (n - 1);
         if (j >= i) j++;
-        const int64_t ga = D.mem_s[m0 + i], gb = D.mem_s[m0 + j];
-        const bool ra = D.is_ref[2 * ga + D.v_alle[ga]] != 0, rb = D.is_ref[2 * gb + (D.v_alle[gb] ^ 1)] != 0;
-        s.pool(D.uid, ga); s.ch('\t'); s.pool(D.rsid, ga); s.ch('\t'); s.pool(D.uid, gb); s.ch('\t'); s.pool(D.rsid, gb);
-        if (ra == rb) s.lit("\ttrans\n"); else s.lit("\tcis\n");
+        const MemRec xa = D.mrec[m0 + i], xb = D.mrec[m0 + j];
+        put_uid(D, xa, m0 + i, s); s.ch('\t'); put_rsid(D, xa, m0 + i, s); s.ch('\t');
+        put_uid(D, xb, m0 + j, s); s.ch('\t'); put_rsid(D, xb, m0 + j, s);
+        if ((xa.ref_a != 0) == (xb.ref_b != 0)) s.lit("\ttrans\n"); else s.lit("\tcis\n");
     }
 };
 
+__global__ __launch_bounds__(256) void k_mem_rec(RD D, MemRec *out) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= D.nmem) return;
+    const int64_t g = D.mem_s[m];
+    const int va = D.v_alle[g];
+    MemRec r;
+    uint32_t longest = D.uid.len(g) > D.rsid.len(g) ? D.uid.len(g) : D.rsid.len(g);
+    r.uid_off = D.uid.off[g]; r.uid_len = (uint16_t)D.uid.len(g); r.rsid_off = D.rsid.off[g]; r.rsid_len = (uint16_t)D.rsid.len(g);
+    for (int h = 0; h < 2; h++) {
+        const int64_t a = 2 * g + (va ^ h);
+        r.a_off[h] = D.alle.off[a]; r.a_len[h] = (uint16_t)D.alle.len(a); r.ph[h] = D.phase_idx[a];
+        longest = D.alle.len(a) > longest ? D.alle.len(a) : longest;
+    }
+    r.wide = longest >= 65536u ? 1 : 0;
+    r.black = (D.black && D.black[g]) ? 1 : 0;
+    r.ref_a = D.is_ref[2 * g + va]; r.ref_b = D.is_ref[2 * g + (va ^ 1)];
+    r.pad[0] = r.pad[1] = 0;
+    out[m] = r;
+}
+// read list of (member, haplotype, BAM) and the room its label text takes in the member's row of haplotypic_counts
+__global__ __launch_bounds__(256) void k_mem_lab(RD D, uint32_t *lab_e, uint32_t *lab_skip) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= D.nmem * 2 * D.nb) return;
+    const int64_t m = i % D.nmem; const int hb = (int)(i / D.nmem), h = hb / D.nb, bb = hb % D.nb;
+    const int64_t g = D.mem_s[m];
+    const int64_t e = (2 * g + (D.v_alle[g] ^ h)) * D.nb + bb;
+    const uint32_t lo = D.rl_start[e], hi = D.rl_start[e + 1];
+    lab_e[i] = (uint32_t)e; lab_skip[i] = hi > lo ? D.its[hi] - D.its[lo] - 1u : 0u;
+}
 // block of the first row of every 256-row chunk of allele_config (one search of the whole block table per chunk instead of per row)
 __global__ __launch_bounds__(256) void k_cfg_chunks(int64_t nchunks, int64_t nblocks, const unsigned long long *cfg_base, uint32_t *cfg_chunk) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1378,7 +1433,7 @@ struct phz_rowsdev {
     DevBuf ridx, va, vb, eorder, mem_s, cstart, corder, ekeep, estart, key_g;
     DevBuf cnt64, cnt32, chrom_cnt, seg_start, key64s, eloc;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
     DevBuf alle_of, sub_of, nsub, complex_list, exc_list, nsub_o, blk_base;
-    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, blk_voff;
+    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, blk_voff, mrec, lab_e, lab_skip;
     DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, pool, tl, its, piece_dst, rowlen;
     DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
     DevBuf o_var, o_maxmaf, o_hap, o_cor;
@@ -1393,7 +1448,7 @@ struct phz_rowsdev {
                                    &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
-                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &blk_voff, &labels,
+                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &blk_voff, &mrec, &lab_e, &lab_skip, &labels,
                                    &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
@@ -1865,6 +1920,13 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     D.blk_conc = P<uint8_t>(h->conc); D.blk_cormode = P<uint8_t>(h->cormode); D.blk_statkind = P<uint8_t>(h->statkind); D.blk_statidx = P<uint32_t>(h->statidx);
     D.blk_maxmaf = P<int32_t>(h->maxmaf); D.its = P<uint32_t>(h->its); D.labels = P<uint32_t>(h->labels); D.piece_dst = P<unsigned long long>(h->piece_dst);
     D.cfg_base = P<unsigned long long>(h->cfg_base);
+    D.nmem = nmem;
+    RSV(mrec, (size_t)(nmem + 1) * sizeof(MemRec)); RSV(lab_e, (size_t)(nmem + 1) * 2 * nb * 4); RSV(lab_skip, (size_t)(nmem + 1) * 2 * nb * 4);
+    D.mrec = P<MemRec>(h->mrec); D.lab_e = P<uint32_t>(h->lab_e); D.lab_skip = P<uint32_t>(h->lab_skip);
+    if (nmem) {
+        hipLaunchKernelGGL(k_mem_rec, dim3(nblk(nmem)), dim3(256), 0, sm, D, P<MemRec>(h->mrec));
+        hipLaunchKernelGGL(k_mem_lab, dim3(nblk(nmem * 2 * nb)), dim3(256), 0, sm, D, P<uint32_t>(h->lab_e), P<uint32_t>(h->lab_skip));
+    }
     {
         const int64_t nchunks = ((int64_t)h_cfg_total + 255) / 256;
         RSV(cfg_chunk, (size_t)(nchunks + 1) * 4);

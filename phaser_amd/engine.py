@@ -244,8 +244,8 @@ class Engine:
         space = _lib.PHZ_DEVICE if dev.type == "cuda" else _lib.PHZ_HOST
         t0 = _t.perf_counter()
         key = (str(dev), tuple(self.chrom_list))
-        cached = getattr(self, "_allele_codes", None)
-        if cached is None or cached[0] != key:                  # allele base codes of the joint variant space: constant for the life of the engine
+        cached = self.vs.__dict__.get("_allele_codes")
+        if cached is None or cached[0] != key:                  # allele base codes of the joint variant space: constant for the variant set
             a0 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a0
                                  for c in self.chrom_list]) if self.chrom_list else np.zeros(0, np.uint8)
             a1 = np.concatenate([np.full(len(self.vs.chroms[c]), 255, np.uint8) if self.vs.chroms[c].is_general else self.vs.chroms[c].a1
@@ -254,7 +254,7 @@ class Engine:
             if space == _lib.PHZ_DEVICE:
                 a0 = torch.from_numpy(a0).to(dev); a1 = torch.from_numpy(a1).to(dev)
                 torch.cuda.synchronize(dev)
-            cached = self._allele_codes = (key, a0, a1)
+            cached = self.vs.__dict__["_allele_codes"] = (key, a0, a1)
         if space == _lib.PHZ_DEVICE:
             pa0, pa1 = _p(cached[1]), _p(cached[2])
         else:
