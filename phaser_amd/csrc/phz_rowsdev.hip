@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include <type_traits>
 #include "phz_internal.h"
 #include "phz_sort.h"
 #include "phz_text.h"
@@ -57,6 +58,11 @@ __device__ __forceinline__ int ndigits(unsigned long long v) {
     return d;
 }
 
+#ifndef PHZ_ROW_WAVE_MIN
+#define PHZ_ROW_WAVE_MIN 16          // block rows of more variants than this are formatted by a wave each (the emulation tests also build a variant with 0)
+#endif
+constexpr int ROW_WAVE_MIN = PHZ_ROW_WAVE_MIN;
+
 // ---- sinks: the same row function counts bytes or writes them
 struct SCount {
     static constexpr bool writing = false;
@@ -68,6 +74,11 @@ struct SCount {
     __device__ __forceinline__ void num(long long v) { n += v < 0 ? 1u + (uint32_t)ndigits((unsigned long long)(-v)) : (uint32_t)ndigits((unsigned long long)v); }
     __device__ __forceinline__ void skip(uint32_t k) { n += k; }
     __device__ __forceinline__ unsigned long long where() const { return 0; }
+    // elements t = 0 .. cnt-1 with inc(t) true, joined by sep (0 = nothing between them); put(t, sink) emits element t
+    template <class INC, class PUT> __device__ __forceinline__ void join(uint32_t cnt, char sep, INC inc, PUT put) {
+        bool first = true;
+        for (uint32_t t = 0; t < cnt; t++) { if (!inc(t)) continue; if (!first && sep) n++; first = false; put(t, *this); }
+    }
 };
 struct SWrite {
     static constexpr bool writing = true;
@@ -93,6 +104,79 @@ struct SWrite {
     }
     __device__ __forceinline__ void skip(uint32_t k) { p += k; }            // bytes somebody else writes (label text)
     __device__ __forceinline__ unsigned long long where() const { return base + (unsigned long long)(p - p0); }
+    template <class INC, class PUT> __device__ __forceinline__ void join(uint32_t cnt, char sep, INC inc, PUT put) {
+        bool first = true;
+        for (uint32_t t = 0; t < cnt; t++) { if (!inc(t)) continue; if (!first && sep) *p++ = sep; first = false; put(t, *this); }
+    }
+};
+
+// ---- the same sinks for ONE ROW FORMATTED BY A WAVE (rows of blocks with dozens to hundreds of variants: one thread walking them was the tail of the
+// row kernels).  All 64 lanes run the row function together on the same row; the scalar pieces are identical on every lane (lane 0 stores them), join()
+// spreads the elements over the lanes: lengths by a counting sub-sink, positions by a wave scan, then every lane writes its element in place.
+struct WCount {
+    static constexpr bool writing = false;
+    uint32_t n = 0;
+    __device__ __forceinline__ void ch(char) { n++; }
+    template <int N> __device__ __forceinline__ void lit(const char (&)[N]) { n += (uint32_t)(N - 1); }
+    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) { n += P.len(i); }
+    __device__ __forceinline__ void raw(const char *, uint32_t l) { n += l; }
+    __device__ __forceinline__ void num(long long v) { SCount c; c.num(v); n += c.n; }
+    __device__ __forceinline__ void skip(uint32_t k) { n += k; }
+    __device__ __forceinline__ unsigned long long where() const { return 0; }
+    template <class INC, class PUT> __device__ __forceinline__ void join(uint32_t cnt, char sep, INC inc, PUT put) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t bytes = 0, members = 0;
+        for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const bool in = t < cnt && inc(t);
+            SCount c;
+            if (in) put(t, c);
+            uint32_t l = c.n, k = in ? 1u : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { l += __shfl_xor(l, d); k += __shfl_xor(k, d); }
+            bytes += l; members += k;
+        }
+        n += bytes + ((sep && members > 1) ? members - 1 : 0u);
+    }
+};
+struct WWrite {
+    static constexpr bool writing = true;
+    char *p0, *p;
+    unsigned long long base;
+    __device__ __forceinline__ bool first_lane() const { return (threadIdx.x & 63u) == 0u; }
+    __device__ __forceinline__ void ch(char c) { if (first_lane()) *p = c; p++; }
+    template <int N> __device__ __forceinline__ void lit(const char (&s)[N]) { if (first_lane()) for (int i = 0; i < N - 1; i++) p[i] = s[i]; p += N - 1; }
+    __device__ __forceinline__ void raw(const char *s, uint32_t l) { if (first_lane()) { SWrite w; w.p0 = w.p = p; w.base = 0; w.raw(s, l); } p += l; }
+    __device__ __forceinline__ void pool(const PoolD &P, int64_t i) { raw(P.at(i), P.len(i)); }
+    __device__ __forceinline__ void num(long long v) { SWrite w; w.p0 = w.p = p; w.base = 0; if (first_lane()) w.num(v); else { SCount c; c.num(v); w.p += c.n; } p = w.p; }
+    __device__ __forceinline__ void skip(uint32_t k) { p += k; }
+    __device__ __forceinline__ unsigned long long where() const { return base + (unsigned long long)(p - p0); }
+    template <class INC, class PUT> __device__ __forceinline__ void join(uint32_t cnt, char sep, INC inc, PUT put) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t members = 0;                                   // elements placed so far (uniform)
+        for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const bool in = t < cnt && inc(t);
+            SCount c;
+            if (in) put(t, c);
+            const uint32_t l = c.n, k = in ? 1u : 0u;
+            uint32_t il = l, ik = k;                            // inclusive scans over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t yl = __shfl_up(il, d), yk = __shfl_up(ik, d); if (lane >= (uint32_t)d) { il += yl; ik += yk; } }
+            const uint32_t before_k = members + ik - k;         // elements before this one in the whole section
+            if (in) {
+                char *q = p + (il - l) + (sep ? (before_k > 0 ? (ik - k) + (members > 0 ? 1u : 0u) : 0u) : 0u);
+                // separators written before this chunk's elements: one per earlier element of the chunk, plus one in front of the chunk's first
+                // element when elements were placed before the chunk
+                if (sep && before_k > 0) q[-1] = sep;
+                SWrite w; w.p0 = w.p = q; w.base = base + (unsigned long long)(q - p0);
+                put(t, w);
+            }
+            const uint32_t tl = __shfl(il, 63), tk = __shfl(ik, 63);
+            p += tl + (sep ? (tk > 0 ? (members > 0 ? tk : tk - 1u) : 0u) : 0u);
+            members += tk;
+        }
+    }
 };
 
 // Per block member (index into mem_s), built once per pass by k_mem_rec: everything the block rows need of the variant in ONE 32-byte load -- the
@@ -152,6 +236,7 @@ template <class S> __device__ __forceinline__ void put_stat(const RD &D, int b, 
 // ---------------------------------------------------------------------------------------------- row functions
 // variant_connections.txt (:691-695); row = position in the (rank a, rank b) order of the tested pairs
 struct RowConn {
+    __device__ static bool big(const RD &, int64_t) { return false; }
     template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
         const uint32_t e = D.eorder[r];
         const int a = D.va[e], b = D.vb[e];
@@ -173,6 +258,7 @@ struct RowConn {
 
 // allelic_counts.txt (:737-749); row = first-appearance key
 struct RowAllelic {
+    __device__ static bool big(const RD &, int64_t) { return false; }
     template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
         const int64_t g = D.key_g[r];
         const long long r0 = D.var_distinct[3 * g], r1 = D.var_distinct[3 * g + 1];
@@ -193,6 +279,7 @@ template <class S> __device__ __forceinline__ void put_vcf_phase(const RD &D, in
 
 // singleton rows of haplotypic_counts.txt (:1180-1239); row = key * nb + bam
 struct RowSingleAse {
+    __device__ static bool big(const RD &, int64_t) { return false; }
     template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
         const int64_t g = D.key_g[r / D.nb]; const int b = (int)(r % D.nb);
         if (!D.unphased_vars || !single_live(D, g)) return;
@@ -212,6 +299,7 @@ struct RowSingleAse {
 
 // singleton rows of haplotypes.txt; row = key
 struct RowSingleHap {
+    __device__ static bool big(const RD &, int64_t) { return false; }
     template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
         const int64_t g = D.key_g[r];
         if (!D.unphased_vars || !single_live(D, g)) return;
@@ -225,6 +313,7 @@ struct RowSingleHap {
 
 // haplotypes.txt, one row per block (:865-1043)
 struct RowHap {
+    __device__ static bool big(const RD &D, int64_t b) { return D.blk_len[b] > (uint32_t)ROW_WAVE_MIN; }      // formatted by a wave (k_row_wave_*)
     template <class S> __device__ static void emit(const RD &D, int64_t b, S &s) {
         const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
         const int64_t g0 = D.mem_s[m0], g1 = D.mem_s[m0 + n - 1];
@@ -232,25 +321,22 @@ struct RowHap {
         s.pool(D.chromn, D.vchrom[g0]); s.ch('\t'); s.num(minpos); s.ch('\t'); s.num(maxpos); s.ch('\t'); s.num(maxpos - minpos); s.ch('\t');
         s.num(n); s.ch('\t');
         const MemRec *R = D.mrec + m0;
-        for (uint32_t t = 0; t < n; t++) {
-            const MemRec r = R[t];
-            if (t) s.ch(',');
-            if (D.unique_ids) put_uid(D, r, m0 + t, s); else put_rsid(D, r, m0 + t, s);
-        }
+        auto all = [&](uint32_t) { return true; };
+        s.join(n, ',', all, [&](uint32_t t, auto &o) { const MemRec r = R[t]; if (D.unique_ids) put_uid(D, r, m0 + t, o); else put_rsid(D, r, m0 + t, o); });
         s.ch('\t');
         for (int h = 0; h < 2; h++) {
             if (h) s.ch('|');
-            for (uint32_t t = 0; t < n; t++) { const MemRec r = R[t]; if (t) s.ch(','); put_alle(D, r, m0 + t, h, s); }
+            s.join(n, ',', all, [&](uint32_t t, auto &o) { const MemRec r = R[t]; put_alle(D, r, m0 + t, h, o); });
         }
         const long long c0 = D.blk_cnt[2 * b], c1 = D.blk_cnt[2 * b + 1];
         s.ch('\t'); s.num(c0); s.ch('\t'); s.num(c1); s.ch('\t'); s.num(c0 + c1); s.ch('\t');
         s.num(D.blk_sup[b]); s.lit(".0\t"); s.num(D.blk_tot[b]); s.lit(".0\t");
-        for (int h = 0; h < 2; h++) { if (h) s.ch('|'); for (uint32_t t = 0; t < n; t++) s.ch(phase_char(R[t].ph[h])); }
+        for (int h = 0; h < 2; h++) { if (h) s.ch('|'); s.join(n, (char)0, all, [&](uint32_t t, auto &o) { o.ch(phase_char(R[t].ph[h])); }); }
         s.ch('\t'); s.num(D.blk_conc[b]); s.ch('\t');
         const uint8_t cm = D.blk_cormode[b];
         for (int h = 0; h < 2; h++) {
             if (h) s.ch('|');
-            for (uint32_t t = 0; t < n; t++) s.ch(cm == 0 ? phase_char(R[t].ph[h]) : (char)('0' + ((cm == 1 ? 0 : 1) ^ h)));
+            s.join(n, (char)0, all, [&](uint32_t t, auto &o) { o.ch(cm == 0 ? phase_char(R[t].ph[h]) : (char)('0' + ((cm == 1 ? 0 : 1) ^ h))); });
         }
         s.ch('\t'); put_stat(D, (int)b, s); s.ch('\n');
     }
@@ -259,6 +345,7 @@ struct RowHap {
 // haplotypic_counts.txt, one row per (block, BAM) (:1048-1125); the label lists at the end of the row are written by k_label_write:
 // this function leaves room for them and records where each (variant, allele, BAM) list starts
 struct RowAse {
+    __device__ static bool big(const RD &D, int64_t r) { return D.blk_len[r / D.nb] > (uint32_t)ROW_WAVE_MIN; }
     template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
         const int64_t b = r / D.nb; const int bb = (int)(r % D.nb);
         if (D.bam_excl && D.bam_excl[bb]) return;
@@ -267,21 +354,17 @@ struct RowAse {
         const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
         const int64_t g0 = D.mem_s[m0], g1 = D.mem_s[m0 + n - 1];
         s.pool(D.chromn, D.vchrom[g0]); s.ch('\t'); s.num(D.pos[g0]); s.ch('\t'); s.num(D.pos[g1]); s.ch('\t');
-        long long used = 0, nblack = 0;
         const MemRec *R = D.mrec + m0;
-        for (uint32_t t = 0; t < n; t++) { const MemRec r = R[t]; if (r.black) continue; if (used) s.ch(','); put_uid(D, r, m0 + t, s); used++; }
+        long long nblack = 0;
+        if (D.black) for (uint32_t t = 0; t < n; t++) nblack += R[t].black ? 1 : 0;
+        const long long used = (long long)n - nblack;
+        auto live = [&](uint32_t t) { return R[t].black == 0; };
+        s.join(n, ',', live, [&](uint32_t t, auto &o) { const MemRec r = R[t]; put_uid(D, r, m0 + t, o); });
         s.ch('\t'); s.num(used); s.ch('\t');
-        if (D.black) for (uint32_t t = 0; t < n; t++) { const MemRec r = R[t]; if (!r.black) continue; if (nblack) s.ch(','); put_uid(D, r, m0 + t, s); nblack++; }
+        if (D.black) s.join(n, ',', [&](uint32_t t) { return R[t].black != 0; }, [&](uint32_t t, auto &o) { const MemRec r = R[t]; put_uid(D, r, m0 + t, o); });
         s.ch('\t'); s.num(nblack); s.ch('\t');
         for (int h = 0; h < 2; h++) {
-            bool first = true;
-            for (uint32_t t = 0; t < n; t++) {
-                const MemRec r = R[t];
-                if (r.black) continue;
-                if (!first) s.ch(',');
-                first = false;
-                put_alle(D, r, m0 + t, h, s);
-            }
+            s.join(n, ',', live, [&](uint32_t t, auto &o) { const MemRec r = R[t]; put_alle(D, r, m0 + t, h, o); });
             s.ch('\t');
         }
         s.num(ns0); s.ch('\t'); s.num(ns1); s.ch('\t'); s.num(ns0 + ns1); s.ch('\t');
@@ -291,16 +374,12 @@ struct RowAse {
         s.ch('\t'); put_stat(D, (int)b, s); s.ch('\t');
         s.pool(D.maft, D.blk_maxmaf[b]); s.ch('\t'); s.pool(D.bamn, bb); s.ch('\t');
         for (int h = 0; h < 2; h++) {
-            bool first = true;
             const size_t lab0 = (size_t)(h * D.nb + bb) * (size_t)D.nmem + m0;
-            for (uint32_t t = 0; t < n; t++) {
-                if (R[t].black) continue;
-                if (!first) s.ch(';');
-                first = false;
-                if (S::writing) D.piece_dst[D.lab_e[lab0 + t]] = s.where();
+            s.join(n, ';', live, [&](uint32_t t, auto &o) {
+                if (std::remove_reference_t<decltype(o)>::writing) D.piece_dst[D.lab_e[lab0 + t]] = o.where();
                 const uint32_t room = D.lab_skip[lab0 + t];
-                if (room) s.skip(room);                             // every label is followed by one separator byte except the list's last
-            }
+                if (room) o.skip(room);                             // every label is followed by one separator byte except the list's last
+            });
             s.ch(h == 0 ? '\t' : '\n');
         }
     }
@@ -308,6 +387,7 @@ struct RowAse {
 
 // allele_config.txt (:1160-1172); row = cfg_base[block] + i * (n - 1) + (j with i skipped)
 struct RowCfg {
+    __device__ static bool big(const RD &, int64_t) { return false; }
     template <class S> __device__ static void emit(const RD &D, int64_t r, S &s) {
         // largest b with cfg_base[b] <= r: the block of the row's 256-row chunk is known, and a block has >= 2 rows
         int64_t lo = D.cfg_chunk[r >> 8], hi = lo + 257 < D.nblocks ? lo + 257 : D.nblocks;
@@ -364,10 +444,36 @@ __global__ __launch_bounds__(256) void k_cfg_chunks(int64_t nchunks, int64_t nbl
 }
 template <class ROW> __global__ __launch_bounds__(256) void k_row_len(RD D, int64_t nrows, uint32_t *len) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrows) return;
+    if (r >= nrows || ROW::big(D, r)) return;
     SCount s;
     ROW::emit(D, r, s);
     len[r] = s.n;
+}
+// rows of big blocks: one wave per row (block index from the list of big blocks; per_blk rows per block)
+template <class ROW> __global__ __launch_bounds__(64) void k_row_wave_len(RD D, const uint32_t *big_blk, int per_blk, uint32_t *len) {
+    const int64_t r = (int64_t)big_blk[blockIdx.x / per_blk] * per_blk + (blockIdx.x % per_blk);
+    WCount s;
+    ROW::emit(D, r, s);
+    if (threadIdx.x == 0) len[r] = s.n;
+}
+template <class ROW> __global__ __launch_bounds__(64) void k_row_wave_write(RD D, const uint32_t *big_blk, int per_blk, const unsigned long long *off, char *out) {
+    const int64_t r = (int64_t)big_blk[blockIdx.x / per_blk] * per_blk + (blockIdx.x % per_blk);
+    if (off[r + 1] == off[r]) return;
+    WWrite s; s.p0 = s.p = out + off[r]; s.base = off[r];
+    ROW::emit(D, r, s);
+}
+__global__ __launch_bounds__(256) void k_big_blocks(int64_t nblocks, const uint32_t *blk_len, uint32_t *big_blk, uint32_t *count) {
+    __shared__ uint32_t s_n, s_base;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const bool big = b < nblocks && blk_len[b] > (uint32_t)ROW_WAVE_MIN;
+    uint32_t at = 0;
+    if (big) at = atomicAdd(&s_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_n ? atomicAdd(count, s_n) : 0u;
+    __syncthreads();
+    if (big) big_blk[s_base + at] = (uint32_t)b;
 }
 // One workgroup writes ROWS consecutive rows.  The rows are formatted into LDS at the position they have in the file (shifted so that LDS
 // byte i and file byte i agree modulo 16) and copied out with aligned 16-byte stores: a thread writing its row byte by byte to global memory
@@ -384,7 +490,7 @@ template <class ROW, int ROWS, int ROW_STAGE> __global__ __launch_bounds__(ROWS)
     if (b1 == b0) return;
     const unsigned mis = (unsigned)((unsigned long long)(out + b0) & 15ull);
     if ((b1 - b0) + mis <= (unsigned long long)ROW_STAGE) {
-        if (r < r1 && off[r + 1] > off[r]) {
+        if (r < r1 && off[r + 1] > off[r] && !ROW::big(D, r)) {      // (a big row's bytes are written by k_row_wave_write afterwards)
             SWrite s; s.p0 = s.p = s_buf + mis + (unsigned)(off[r] - b0); s.base = off[r];
             ROW::emit(D, r, s);
         }
@@ -395,7 +501,7 @@ template <class ROW, int ROWS, int ROW_STAGE> __global__ __launch_bounds__(ROWS)
             if (c >= mis && c + 16u <= total) *(uint4 *)(g + c) = *(const uint4 *)(s_buf + c);
             else for (unsigned k = c < mis ? mis : c; k < c + 16u && k < total; k++) g[k] = s_buf[k];
         }
-    } else if (r < r1 && off[r + 1] > off[r]) {
+    } else if (r < r1 && off[r + 1] > off[r] && !ROW::big(D, r)) {
         SWrite s; s.p0 = s.p = out + off[r]; s.base = off[r];
         ROW::emit(D, r, s);
     }
@@ -1433,7 +1539,7 @@ struct phz_rowsdev {
     DevBuf ridx, va, vb, eorder, mem_s, cstart, corder, ekeep, estart, key_g;
     DevBuf cnt64, cnt32, chrom_cnt, seg_start, key64s, eloc;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
     DevBuf alle_of, sub_of, nsub, complex_list, exc_list, nsub_o, blk_base;
-    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, blk_voff, mrec, lab_e, lab_skip;
+    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, blk_voff, mrec, lab_e, lab_skip, big_blk;
     DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, pool, tl, its, piece_dst, rowlen;
     DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
     DevBuf o_var, o_maxmaf, o_hap, o_cor;
@@ -1448,7 +1554,7 @@ struct phz_rowsdev {
                                    &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
-                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &blk_voff, &mrec, &lab_e, &lab_skip, &labels,
+                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &blk_voff, &mrec, &lab_e, &lab_skip, &big_blk, &labels,
                                    &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
@@ -1898,6 +2004,11 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     if (n_rl) hipLaunchKernelGGL(k_item_len, dim3(nblk(n_rl)), dim3(256), 0, sm, (const uint32_t *)h->labels.p, n_rl, P<uint32_t>(h->tl));
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->tl), P<uint32_t>(h->its), n_rl, h->scan_tmp)) return s;
     PHZ_HIP(ctx, hipMemsetAsync(h->piece_dst.p, 0xff, NRL * 8, sm));
+    RSV(big_blk, (size_t)(nblocks + 1) * 4);
+    uint32_t h_nbig = 0;
+    PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 12, 0, 4, sm));
+    if (nblocks) hipLaunchKernelGGL(k_big_blocks, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, (const uint32_t *)h->blk_len.p, P<uint32_t>(h->big_blk), cnt32 + 12);
+    PHZ_HIP(ctx, hipMemcpyAsync(&h_nbig, cnt32 + 12, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&h_cfg_total, P<unsigned long long>(h->cfg_base) + nblocks, 8, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(h_cc.data(), h->chrom_cnt.p, n_cc * 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(h_cfgc.data(), cc_cfg, (size_t)nchrom * 8, hipMemcpyDeviceToHost, sm));
@@ -1947,8 +2058,12 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         uint32_t *len = P<uint32_t>(h->rowlen);
         if (rows[f]) switch (f) {
             case PHZ_TXT_CONN: hipLaunchKernelGGL(k_row_len<RowConn>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
-            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_row_len<RowHap>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
-            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_row_len<RowAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_row_len<RowHap>, dim3(g), dim3(256), 0, sm, D, rows[f], len);
+                if (h_nbig) hipLaunchKernelGGL(k_row_wave_len<RowHap>, dim3(h_nbig), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, 1, len);
+                break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_row_len<RowAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len);
+                if (h_nbig) hipLaunchKernelGGL(k_row_wave_len<RowAse>, dim3(h_nbig * (unsigned)nb), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, nb, len);
+                break;
             case PHZ_TXT_CFG: hipLaunchKernelGGL(k_row_len<RowCfg>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
             case PHZ_TXT_ALLELIC: hipLaunchKernelGGL(k_row_len<RowAllelic>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
             case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_row_len<RowSingleAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
@@ -1986,8 +2101,12 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         char *out = P<char>(h->text[f]);
         if (rows[f]) switch (f) {
             case PHZ_TXT_CONN: hipLaunchKernelGGL((k_row_write<RowConn, 256, 24 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_HAP: hipLaunchKernelGGL((k_row_write<RowHap, 128, 32 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, 64, 16 * 1024>), dim3((unsigned)((rows[f] + 63) / 64)), dim3(64), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL((k_row_write<RowHap, 128, 32 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out);
+                if (h_nbig) hipLaunchKernelGGL(k_row_wave_write<RowHap>, dim3(h_nbig), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, 1, of, out);
+                break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, 64, 16 * 1024>), dim3((unsigned)((rows[f] + 63) / 64)), dim3(64), 0, sm, D, rows[f], of, out);
+                if (h_nbig) hipLaunchKernelGGL(k_row_wave_write<RowAse>, dim3(h_nbig * (unsigned)nb), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, nb, of, out);
+                break;
             case PHZ_TXT_CFG: hipLaunchKernelGGL((k_row_write<RowCfg, 128, 12 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
             case PHZ_TXT_ALLELIC: hipLaunchKernelGGL((k_row_write<RowAllelic, 256, 24 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
             case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL((k_row_write<RowSingleAse, 256, 32 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;

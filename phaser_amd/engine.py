@@ -57,6 +57,9 @@ def percentile_from_hist(h: np.ndarray, q: float) -> float:
     """numpy.percentile(scores, q) (default linear method, numpy/lib/_function_base_impl.py _quantile/_lerp) for the
     multiset scores = {bin - 32768 repeated h[bin] times}, computed from the histogram: same float64 operations on the
     two neighbouring order statistics, without materialising the scores (phaser.py:551)."""
+    nz = np.flatnonzero(h)                  # alignment scores live in a narrow band of the 64Ki bins: work on that band only
+    first_bin = int(nz[0]) if len(nz) else 0
+    h = h[first_bin:int(nz[-1]) + 1] if len(nz) else h[:1]
     n = int(h.sum())
     quant = np.true_divide(q, 100)
     virt = (n - 1) * quant
@@ -68,8 +71,8 @@ def percentile_from_hist(h: np.ndarray, q: float) -> float:
     if virt < 0:
         prev = nxt = 0
     csum = np.cumsum(h)
-    a = np.int64(int(np.searchsorted(csum, prev, side="right")) - 32768)
-    b = np.int64(int(np.searchsorted(csum, nxt, side="right")) - 32768)
+    a = np.int64(int(np.searchsorted(csum, prev, side="right")) + first_bin - 32768)
+    b = np.int64(int(np.searchsorted(csum, nxt, side="right")) + first_bin - 32768)
     diff = np.subtract(b, a)
     out = np.add(a, diff * gamma)
     if gamma >= 0.5:

@@ -145,13 +145,24 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     tot = (keys[used] >> np.uint64(32)).astype(np.int64); sup = (keys[used] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
     slot_pv = np.ones(_lib.PHZ_PAIR_SLOTS, dtype=np.float64)
-    texts = [""] * _lib.PHZ_PAIR_SLOTS
+    lens = np.zeros(_lib.PHZ_PAIR_SLOTS, dtype=np.int64)
+    parts = []
     if len(used):
         pv = binom.cdf(sup, tot, prob)
         slot_pv[used] = pv
-        for s, x in zip(used.tolist(), pv.tolist()):
-            texts[s] = repr(x)
-    txt_off, txt = sep_pool(texts)
+        reprs = [r.encode() for r in map(repr, pv.tolist())]      # float.__repr__: what the reference's str(p) writes (phaser.py:693)
+        lens[used] = np.fromiter(map(len, reprs), dtype=np.int64, count=len(reprs))
+        prev = 0
+        for sl, r in zip(used.tolist(), reprs):                   # slot order (flatnonzero ascends); an empty slot is just its separator byte
+            parts.append(b"\n" * (sl - prev)); parts.append(r); parts.append(b"\n")
+            prev = sl + 1
+        parts.append(b"\n" * (_lib.PHZ_PAIR_SLOTS - prev))
+    else:
+        parts.append(b"\n" * _lib.PHZ_PAIR_SLOTS)
+    txt = b"".join(parts)
+    txt_off = np.zeros(_lib.PHZ_PAIR_SLOTS + 1, dtype=np.uint32)
+    np.cumsum(lens + 1, out=lens)
+    txt_off[1:] = lens
     t2 = _t.perf_counter()
     # ---- stage 2
     bam_off, bam_txt = sep_pool(list(eng.bam_names))

@@ -13,11 +13,19 @@ LIB = os.path.join(OUT, "libphz_emu.so")
 UNITS = ["phz_api.hip", "phz_tally.hip", "phz_rowsdev.hip", "phz_rows.cpp"]
 
 
-def build(verbose=False, tally_tile=0):
+def build(verbose=False, tally_tile=0, row_wave_min=None):
     """tally_tile: build the variant libphz_emu_t<N>.so whose K_tally groups tiles of N lines (256 / 512): the small fixtures then
-    straddle tiles, which is what sends QNAMEs through the spill path of k_tile"""
+    straddle tiles, which is what sends QNAMEs through the spill path of k_tile.
+    row_wave_min: the variant libphz_emu_w<N>.so whose row stage formats the rows of blocks with more than N variants by a wave each
+    (0: every block row, so that the fixtures exercise the wave sinks)"""
     os.makedirs(OUT, exist_ok=True)
-    LIB = os.path.join(OUT, "libphz_emu_t%d.so" % tally_tile if tally_tile else "libphz_emu.so")
+    tag = ("_t%d" % tally_tile if tally_tile else "") + ("_w%d" % row_wave_min if row_wave_min is not None else "")
+    LIB = os.path.join(OUT, "libphz_emu%s.so" % tag)
+    variant_defs = {}
+    if tally_tile:
+        variant_defs["phz_tally.hip"] = ["-DPHZ_TALLY_TILE=%d" % tally_tile]
+    if row_wave_min is not None:
+        variant_defs["phz_rowsdev.hip"] = ["-DPHZ_ROW_WAVE_MIN=%d" % row_wave_min]
     hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(REPO, "include", "phz.h"),
                                                                                   os.path.join(HERE, "hipemu.h"), os.path.join(HERE, "hipemu.cpp")]
     newest_hdr = max(os.path.getmtime(h) for h in hdr)
@@ -25,10 +33,10 @@ def build(verbose=False, tally_tile=0):
     jobs = []; objs = []
     for u in UNITS + ["hipemu.cpp"]:
         src = os.path.join(HERE if u == "hipemu.cpp" else CSRC, u)
-        variant = tally_tile and u == "phz_tally.hip"
-        obj = os.path.join(OUT, u + (".t%d" % tally_tile if variant else "") + ".o"); objs.append(obj)
+        defs = variant_defs.get(u, [])
+        obj = os.path.join(OUT, u + (tag if defs else "") + ".o"); objs.append(obj)
         if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
-            jobs.append(["g++"] + flags + (["-DPHZ_TALLY_TILE=%d" % tally_tile] if variant else []) + ["-x", "c++", "-c", src, "-o", obj])
+            jobs.append(["g++"] + flags + defs + ["-x", "c++", "-c", src, "-o", obj])
     if jobs or not os.path.exists(LIB):
         def run(cmd):
             if verbose:

@@ -15,9 +15,11 @@ from helpers import OUTPUTS, EmuContext, canonical, emu_library, option_case_kwa
 from test_host_stages import _cases
 
 
-@pytest.fixture(scope="module")
-def emu():
-    return emu_library()
+@pytest.fixture(scope="module", params=[None, 0], ids=["rows_by_thread", "rows_by_wave"])
+def emu(request):
+    """None: the product's thresholds; 0: the variant whose row stage formats EVERY block row by a wave (the fixtures' blocks are small:
+    with the product's threshold they would all take the one-thread-per-row path)"""
+    return emu_library(row_wave_min=request.param)
 
 
 def run_stages(emu, case, load, cfg, vcf_text, bam_names, device_rows=True, **extra):
@@ -70,3 +72,50 @@ def test_device_rows_match_reference(emu, case, gold, load, cfg, c1_inputs):
         for name in OUTPUTS:
             assert out[name] == host[name], name
         assert eng.phased == heng.phased and eng.log == heng.log
+
+
+def test_rows_of_a_block_of_150_variants_by_wave_and_by_thread():
+    """A clean component of 150 variants stays ONE block whatever --max_block_size says (phaser.py:2116-2136): its rows of haplotypes.txt /
+    haplotypic_counts.txt are joins of 150 elements, i.e. three rounds of 64 lanes in the wave sinks.  Built from synthetic call lines through
+    the emulated K_tally; the wave-formatted rows must equal the thread-formatted ones and the host row stage's, byte for byte."""
+    import numpy as np
+    from phaser_amd import vcf
+    from phaser_amd.engine import Config, Engine
+    from test_emu_tally import run_tally
+    rng = np.random.default_rng(3)
+    nv = 150
+    truth = rng.integers(0, 2, size=nv)
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+    vcf_text = head + "".join("chrS\t%d\trs%d\tA\tG\t.\tPASS\t.\tGT\t%s\n" % (1000 + 40 * i, i, "0|1" if i % 3 else "1|0") for i in range(nv))
+    var = []; qid = []; cls = []
+    q = 0
+    for i in range(nv - 1):
+        for _ in range(4):
+            hap = int(rng.integers(0, 2))
+            for v in (i, i + 1):
+                var.append(v); qid.append(q); cls.append(int(truth[v]) ^ hap)
+            q += 1
+    n = len(var)
+    R = {"nv": nv, "line_var": np.asarray(var, np.int32), "line_qid": np.asarray(qid, np.int32), "line_cls": np.asarray(cls, np.uint8),
+         "line_bam": np.zeros(n, np.int32), "bam_offsets": [(0, 0, n)]}
+    saved = {"tally": {"chrS": R}, "n_qid": {"chrS": q}, "qnames": {"chrS": ["q%d" % i for i in range(q)]}}
+    got, sz = run_tally(EmuContext(emu_library()), saved, ["chrS"], 1)
+    R.update({"var_count": got["var_count"], "var_first": got["var_first"], "var_distinct": got["var_distinct"], "var_rank": got["var_rank"], "ea": got["ea"], "eb": got["eb"],
+              "cells": got["cells"], "linked": got["linked"]})
+    vs = vcf.load_variants(vcf_text)
+    outs = []
+    for wave_min, device_rows in ((0, True), (100000, True), (None, False)):
+        lib = emu_library(row_wave_min=wave_min)
+
+        class _M:
+            ctx = EmuContext(lib)
+            device = None
+        eng = Engine(vs, ["s"], Config(device_rows=device_rows), mapper=_M())
+        eng.n_qid.update(saved["n_qid"]); eng.qnames.update(saved["qnames"])
+        (stub_emu_stages if device_rows else stub_gpu_stages)(eng, saved)
+        outs.append(eng.finish())
+        assert eng.rows_path == ("device" if device_rows else "host")
+    hap_rows = outs[0]["haplotypes"].split("\n")
+    assert len(hap_rows) == 3 and hap_rows[1].split("\t")[4] == "150"          # header, ONE block of 150 variants, trailing newline
+    for name in OUTPUTS:
+        assert outs[0][name] == outs[1][name] == outs[2][name], name
