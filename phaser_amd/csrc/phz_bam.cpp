@@ -341,7 +341,9 @@ struct BgzfMap {
                 uint16_t xlen; int why;
                 const uint32_t bsize = header(off, &xlen, &why);
                 if (!bsize) { *status = why; return off; }
-                out.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, rd32(f + off + bsize - 4), 0});
+                const uint32_t isz = rd32(f + off + bsize - 4);
+                if (isz > 65536u) { *status = PHZ_E_ARG; return off; }        // BGZF: a member inflates to at most 64 KiB; the trailer is not trusted beyond that
+                out.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isz, 0});
                 off += bsize;
             }
             return off;

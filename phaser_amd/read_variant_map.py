@@ -100,13 +100,12 @@ def _native_sam(data: bytes, isize_cutoff: float, threads: int):
     return owner, contigs, shards
 
 
-def _do_native(table, baseq, o, isize_cutoff, mapper, threads):
+def _do_native(table, baseq, o, isize_cutoff, mapper, threads, data):
     """SNP-mode fast path: native SAM parse / pack, K_map, native TSV formatting."""
     import ctypes as C
     from . import _lib
     from .vcf import sep_pool
     lib = _lib.load()
-    data = sys.stdin.buffer.read() if hasattr(sys.stdin, "buffer") else sys.stdin.read().encode()
     owner, contigs, shards = _native_sam(data, float(isize_cutoff), threads)
     tchroms = []
     for c in table.chr:
@@ -147,15 +146,25 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
     table = VariantTable(variant_table)
     snp_only = all(rl == 1 for rl in table.ref_len) and all(len(a) == 1 and a in _BASES for al in
                                                             (_individual_alleles(x, g) for x, g in zip(table.alleles, table.gt)) for a in al)
+    stream = sys.stdin
     if splice == 1 and snp_only:
-        # the whole stream through native code: parse + pack (host threads), K_map, TSV formatting
-        return _do_native(table, baseq, o, isize_cutoff, _mapper or Mapper(), threads)
+        # the whole stream through native code: parse + pack (host threads), K_map, TSV formatting.  Streams the native parser declines
+        # (records of a chromosome out of order, a chromosome that comes back later: the reference takes them as they come) go on below
+        from . import _lib
+        import io
+        data = sys.stdin.buffer.read() if hasattr(sys.stdin, "buffer") else sys.stdin.read().encode()
+        try:
+            return _do_native(table, baseq, o, isize_cutoff, _mapper or Mapper(), threads, data)
+        except _lib.PhzError as e:
+            if getattr(e, "status", None) != _lib.PHZ_E_UNSUPPORTED:
+                raise
+            stream = io.TextIOWrapper(io.BytesIO(data))
     contigs: List[str] = []
     # records grouped per chromosome in input order
     chrom_order: List[str] = []
     by_chrom = {}
     read_counter = 0
-    for line in sys.stdin:
+    for line in stream:
         cols = line.rstrip().split("\t")
         if cols[0][0:3] == "@SQ":
             contigs.append(cols[1].split(":")[1])
@@ -197,6 +206,13 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
                 continue
             vpos = torch.tensor([table.pos[i] for i in vsel], dtype=torch.int32)
             ref_len = torch.tensor([table.ref_len[i] for i in vsel], dtype=torch.uint8)
+            # The kernels want a chromosome's records in coordinate order.  The reference takes them as they come (read_variant_map.py:25-117), so a
+            # stream that is out of order (or a chromosome that comes back later) is mapped in sorted order and its lines are put back into
+            # stream order afterwards
+            order = None
+            if any(recs[i][1] < recs[i - 1][1] for i in range(1, len(recs))):
+                order = sorted(range(len(recs)), key=lambda i: recs[i][1])
+                recs = [recs[i] for i in order]
             shard = soa.pack_sam([(r[1], r[2], r[3], r[4]) for r in recs])
             ind = [_individual_alleles(table.alleles[i], table.gt[i]) for i in vsel]
             general = bool((ref_len != 1).any()) or any(len(a) != 1 or a not in _BASES for al in ind for a in al)
@@ -230,5 +246,8 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
                     rec = recs[ri[k]]; v = int(vsel[vi[k]])
                     allele = _allele_text(cd[k], a0[k], a1[k], rec[3], rec[4], baseq)
                     lines.append("\t".join([rec[0], table.id[v], table.rsid[v], allele, rec[5], table.gt[v], table.maf[v]]))
+            if lines and order is not None:
+                back = sorted(range(len(lines)), key=lambda k: order[ri[k]])          # stable: the calls of a record keep their order
+                lines = [lines[k] for k in back]
             if lines:
                 out.write("\n".join(lines) + "\n")

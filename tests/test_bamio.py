@@ -325,3 +325,24 @@ def test_segmented_member_walk_gives_the_same_table(tmp_path, monkeypatch):
     w0 = bamio.bam_ref_weights(path)
     monkeypatch.delenv("PHZ_BGZF_PAR_MIN")
     assert bamio.bam_ref_weights(path) == w0
+
+
+def test_bgzf_member_claiming_more_than_64k_is_refused(tmp_path):
+    """BGZF members inflate to at most 64 KiB; a trailer that claims more is not trusted (it would size host and device buffers)."""
+    import struct
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, gs, ge, w = synth.make_variants("chr22", 1, 2_000_000, 100, 51, n_genes=5)
+    rb = synth.make_reads(v, gs, ge, w, 300, 52)
+    path = str(tmp_path / "s.bam")
+    bamio.readbatch_to_bam(path, [rb], [("chr22", 50818468)])
+    raw = bytearray(open(path, "rb").read())
+    assert raw[:4] == b"\x1f\x8b\x08\x04"
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1            # first member: BSIZE sits at offset 16 (XLEN 6, subfield BC)
+    struct.pack_into("<I", raw, bsize - 4, 70000)               # its ISIZE
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(_lib.PhzError):
+        bamio.shards_from_bam_native(bad, {}, mapq=0, paired_end=False, remove_dups=False)
+    with pytest.raises(_lib.PhzError):
+        bamio.shards_from_bam_native(bad, {}, mapq=0, paired_end=False, remove_dups=False, chroms={"chr22"})
