@@ -42,6 +42,7 @@ struct phz_ctx {
     bool tally_dirty = false, tally_table_dirty = true;     // per-QNAME counters / variant-pair table not known to be clean
     // single-pass scan (phz_sort.h): ticket counter + one status word per tile, valid for the current epoch only (never cleared between scans)
     DevBuf scan_state; uint32_t scan_epoch = 0, scan_ticket_base = 0;
+    uint64_t tally_table_cap = 0;      // slots of the variant-pair table that the last phz_tally needed
     DevBuf tally_qcount;               // lines per QNAME: all zero between phz_tally calls (never shared with other stages)
     // results of the last phz_tally, resident in HBM until the next one (phz_tally_fetch / phz_components read them)
     struct {

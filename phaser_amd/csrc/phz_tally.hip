@@ -534,7 +534,8 @@ __device__ __forceinline__ uint32_t hash64(uint64_t k) {
 constexpr int PH_SLOTS = 1024;     // LDS hash slots per workgroup
 constexpr int PH_WORDS = 5;        // LDS counters of a slot: the nine cells as 16-bit halves (a tile holds < 2^16 QNAMEs), linked flag = bit 16 of word 4
 constexpr int PH_PROBES = 24;
-constexpr int GH_PROBES = 2048;    // global probe bound; beyond it the table is declared too small and the pass is redone
+constexpr int GH_PROBES = 256;     // global probe bound; beyond it the table is declared too small and the pass is redone with a larger one (once
+                                   // that is decided nobody probes any more: a full table made every insertion a walk of the whole bound)
 // the global table: one 64-byte entry per slot = one memory sector: key (words 0-1, 0 = empty: a pair key (a << 32 | b) has b > a >= 0),
 // the nine cells (words 2-10), the linked flag (word 11)
 constexpr int GE_WORDS = 16;
@@ -549,6 +550,7 @@ __device__ __forceinline__ uint32_t pair_home(uint64_t key, uint32_t gmask) { re
 __device__ __forceinline__ int global_slot(uint32_t *tab, uint32_t gmask, uint64_t key, unsigned long long *counters, bool *claimed) {
     uint32_t s = pair_home(key, gmask);
     *claimed = false;
+    if (__hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return -1;      // the pass is lost already
     for (int t = 0; t < GH_PROBES; t++) {
         const unsigned long long prev = atomicCAS((unsigned long long *)(tab + (size_t)s * GE_WORDS), 0ull, (unsigned long long)key);
         if (prev == 0ull) { *claimed = true; return (int)s; }
@@ -604,35 +606,49 @@ template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_
                 const unsigned long long a_ = __shfl(k, src & 63), b_ = __shfl(nx_item[t], src & 63);
                 k2 = src < 64 ? a_ : b_;
             } else k2 = (active && i + d < m) ? items[i + d] : KEY_DROPPED;      // a group of more than 64 distinct items
-            if (!active) continue;
-            if (k2 == KEY_DROPPED || (uint32_t)(k2 >> 32) != q) { active = false; continue; }        // the distinct items of a group sit at its front
+            bool ev = active;                                  // this lane pairs its item with k2 in this round
+            if (ev && (k2 == KEY_DROPPED || (uint32_t)(k2 >> 32) != q)) { active = false; ev = false; }        // the distinct items of a group sit at its front
             const uint32_t v2 = (uint32_t)(k2 >> 4) & 0x0FFFFFFFu;
-            if (v2 == v) continue;
-            n_event++;
-            const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
-            const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
-            const int cell = (int)(cls * 3 + cls2);
-            const int linked = (int)(ln & ln2);
-            uint32_t s = hash64(pk) & (PH_SLOTS - 1);
-            bool done = false;
-            for (int pr = 0; pr < PH_PROBES; pr++) {
-                const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
-                if (prev == KEY_DROPPED || prev == pk) {
-                    atomicAdd(&s_vals[s * PH_WORDS + (cell >> 1)], 1u << ((cell & 1) * 16));
-                    if (linked) atomicOr(&s_vals[s * PH_WORDS + 4], 0x10000u);
-                    done = true;
-                    break;
+            if (v2 == v) ev = false;
+            bool claimed = false;
+            int gs = -1;
+            if (ev) {
+                n_event++;
+                const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
+                const uint64_t pk = ((uint64_t)v << 32) | v2;          // v < v2 because the group is sorted
+                const int cell = (int)(cls * 3 + cls2);
+                const int linked = (int)(ln & ln2);
+                uint32_t s = hash64(pk) & (PH_SLOTS - 1);
+                bool done = false;
+                for (int pr = 0; pr < PH_PROBES; pr++) {
+                    const unsigned long long prev = atomicCAS(&s_keys[s], (unsigned long long)KEY_DROPPED, (unsigned long long)pk);
+                    if (prev == KEY_DROPPED || prev == pk) {
+                        atomicAdd(&s_vals[s * PH_WORDS + (cell >> 1)], 1u << ((cell & 1) * 16));
+                        if (linked) atomicOr(&s_vals[s * PH_WORDS + 4], 0x10000u);
+                        done = true;
+                        break;
+                    }
+                    s = (s + 1) & (PH_SLOTS - 1);
                 }
-                s = (s + 1) & (PH_SLOTS - 1);
+                // the LDS table is full (a tile whose QNAMEs pair up variants all over the chromosome: QNAME ids shared by unrelated reads of
+                // several BAMs): straight to the global table
+                if (!done) {
+                    gs = global_slot(tab, gmask, pk, counters, &claimed);
+                    if (gs >= 0) {
+                        atomicAdd(&tab[(size_t)gs * GE_WORDS + GE_CELL0 + cell], 1u);
+                        if (linked) atomicOr(&tab[(size_t)gs * GE_WORDS + GE_LINKED], 1u);
+                    }
+                }
             }
-            if (!done) {
-                bool claimed;
-                const int gs = global_slot(tab, gmask, pk, counters, &claimed);
-                if (gs >= 0) {
-                    if (claimed) used[atomicAdd(&counters[7], 1ull)] = (uint32_t)gs;
-                    atomicAdd(&tab[(size_t)gs * GE_WORDS + GE_CELL0 + cell], 1u);
-                    if (linked) atomicOr(&tab[(size_t)gs * GE_WORDS + GE_LINKED], 1u);
-                }
+            // the lanes that claimed a slot there take their places in the used-slot list with ONE cursor step per wave and round (one
+            // same-address atomic per claim was 48 ms for such a sample); every lane of the wave gets here
+            const unsigned long long cm = __ballot(claimed ? 1 : 0);
+            if (cm) {
+                const int leader = __builtin_ctzll(cm);
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(&counters[7], (unsigned long long)__popcll(cm));
+                base = __shfl(base, leader);
+                if (claimed) used[base + (unsigned long long)__popcll(cm & ((1ull << lane) - 1ull))] = (uint32_t)gs;
             }
         }
     }
@@ -701,12 +717,34 @@ __global__ __launch_bounds__(256) void k_edge_scatter(const uint32_t *used, int6
 __global__ __launch_bounds__(256) void k_edge_sort(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, int32_t *ea, int32_t *eb) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= nv) return;
-    const uint32_t lo = eoff[a], hi = eoff[a + 1];
-    for (uint32_t i = lo + 1; i < hi; i++) {
-        const uint32_t xb = e_b[i], xs = e_slot[i];
-        uint32_t j = i;
-        while (j > lo && e_b[j - 1] > xb) { e_b[j] = e_b[j - 1]; e_slot[j] = e_slot[j - 1]; j--; }
-        e_b[j] = xb; e_slot[j] = xs;
+    const uint32_t lo = eoff[a], hi = eoff[a + 1], d = hi - lo;
+    if (d <= 24u) {
+        for (uint32_t i = lo + 1; i < hi; i++) {
+            const uint32_t xb = e_b[i], xs = e_slot[i];
+            uint32_t j = i;
+            while (j > lo && e_b[j - 1] > xb) { e_b[j] = e_b[j - 1]; e_slot[j] = e_slot[j - 1]; j--; }
+            e_b[j] = xb; e_slot[j] = xs;
+        }
+    } else {
+        // a variant paired with thousands of others (QNAME ids shared by unrelated reads): heap sort in place, the keys are distinct
+        uint32_t *kb = e_b + lo, *ks = e_slot + lo;
+        auto sift = [&](uint32_t root, uint32_t n) {
+            const uint32_t xb = kb[root], xs = ks[root];
+            for (;;) {
+                uint32_t c = 2 * root + 1;
+                if (c >= n) break;
+                if (c + 1 < n && kb[c + 1] > kb[c]) c++;
+                if (kb[c] <= xb) break;
+                kb[root] = kb[c]; ks[root] = ks[c]; root = c;
+            }
+            kb[root] = xb; ks[root] = xs;
+        };
+        for (uint32_t i = d / 2; i-- > 0;) sift(i, d);
+        for (uint32_t n = d - 1; n > 0; n--) {
+            const uint32_t tb = kb[0], ts = ks[0];
+            kb[0] = kb[n]; ks[0] = ks[n]; kb[n] = tb; ks[n] = ts;
+            sift(0, n);
+        }
     }
     for (uint32_t i = lo; i < hi; i++) { ea[i] = (int32_t)a; eb[i] = (int32_t)e_b[i]; }
 }
@@ -1073,6 +1111,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     // with a larger one
     uint64_t cap = 1 << 16;
     while (cap < 4 * (uint64_t)NV && cap < (1ull << 30)) cap <<= 1;
+    if (ctx->tally_table_cap > cap) cap = ctx->tally_table_cap;          // a sample that needed a larger table keeps it (no overflow + redo per call)
     int64_t ne = 0;
     uint32_t h_c32[4] = {0, 0, 0, 0};
     uint32_t h_tail[2] = {0, 0};
@@ -1097,7 +1136,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         PHZ_HIP(ctx, hipMemcpyAsync(h_c32, counters32, 16, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[1], rl_start + NRL, 4, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
-        if (h_counters[2] == 0) { ne = (int64_t)h_counters[7]; break; }
+        if (h_counters[2] == 0) { ne = (int64_t)h_counters[7]; ctx->tally_table_cap = cap; break; }
         if (attempt == 4 || cap >= (1ull << 31)) return phz_fail(ctx, PHZ_E_NOMEM, "variant-pair table did not converge");
         cap <<= 2;
     }

@@ -124,6 +124,8 @@ def _check_against_sets(R, nv, nq, nb, tile=0):
     assert int(rs[-1]) == int((kept & (cls < 2)).sum())
     # nine cells of every variant pair = sizes of the set intersections (phaser.py:1602-1632)
     cells = got["cells"].reshape(-1, 9)
+    key = got["ea"].astype(np.int64) * (1 << 32) + got["eb"].astype(np.int64)
+    assert np.all(np.diff(key) > 0)                      # the pair list is in (a, b) order, every pair once
     seen = {}
     for i, (a, b2) in enumerate(zip(got["ea"], got["eb"])):
         seen[(int(a), int(b2))] = cells[i]
