@@ -550,8 +550,10 @@ __device__ __forceinline__ uint32_t pair_home(uint64_t key, uint32_t gmask) { re
 __device__ __forceinline__ int global_slot(uint32_t *tab, uint32_t gmask, uint64_t key, unsigned long long *counters, bool *claimed) {
     uint32_t s = pair_home(key, gmask);
     *claimed = false;
-    if (__hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return -1;      // the pass is lost already
     for (int t = 0; t < GH_PROBES; t++) {
+        // a long probe sequence is the sign of a table that is filling up: look whether the pass is lost already (not on every call: the
+        // flag shares a memory sector with the used-slot cursor, and a load per insertion tripled the kernel's time)
+        if ((t & 15) == 15 && __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return -1;
         const unsigned long long prev = atomicCAS((unsigned long long *)(tab + (size_t)s * GE_WORDS), 0ull, (unsigned long long)key);
         if (prev == 0ull) { *claimed = true; return (int)s; }
         if (prev == key) return (int)s;
