@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void k_phase_pair(int64_t ncomp, PH P) {
             return;
         }
     }
-    if (n <= 32 && ne <= 512) {
+    if (n <= 32 && ne <= 16) {            // (more pairs than that: a wave is quicker than one thread re-reading them until nothing changes)
         unsigned long long reach = 1ull;
         for (bool changed = true; changed;) {
             changed = false;
