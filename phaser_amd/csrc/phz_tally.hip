@@ -112,9 +112,11 @@ struct LineOut {
     uint32_t *qcount;                // [nq] kept lines of the QNAME (persistent, all zero between calls)
     unsigned long long *counters;    // [3] kept lines
     int nb;
+    unsigned long long *prof;        // PHZ_TALLY_PROFILE=1: start / end clock of every workgroup
 };
 
 __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
+    if (O.prof && threadIdx.x == 0) O.prof[2 * (size_t)blockIdx.x] = wall_clock64();
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
     const uint32_t bx = blockIdx.x - T.blk0[sh_];
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
         if (f != ~0ull) atomicMin(&O.var_first[vbase + j], f);
     }
     if (tid == 0 && s_kept) atomicAdd(&O.counters[16 + (blockIdx.x % N_SPREAD) * SPREAD_WORDS + 2], (unsigned long long)s_kept);
+    if (O.prof && tid == 0) O.prof[2 * (size_t)blockIdx.x + 1] = wall_clock64();
 }
 
 // group of every spilled QNAME: its line count (the counter goes back to zero and serves as the fill cursor of k_items_spill)
@@ -235,9 +238,11 @@ struct TileOut {
     uint32_t *rl_cursor; uint64_t *rl_tmp;
     unsigned long long *counters;
     int nb;
+    unsigned long long *prof;
 };
 
 __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
+    if (O.prof && threadIdx.x == 0) O.prof[2 * (size_t)blockIdx.x] = wall_clock64();
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
     const uint32_t bx = blockIdx.x - T.blk0[sh_];
@@ -420,6 +425,7 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     }
     if (tid == 0) s_obase = cur;
     __syncthreads();
+    if (O.prof && tid == 0) O.prof[2 * (size_t)blockIdx.x + 1] = wall_clock64();
     if (s_nspill == 0) return;
     const uint32_t spill_base = (uint32_t)s_obase, touch_base = (uint32_t)(s_obase >> 32);
 #pragma unroll
@@ -1066,7 +1072,8 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     const int single_bam = n_bams <= 1 ? 1 : 0;     // one BAM: every QNAME's read_vars list is owned by that BAM
     LineOut O;
     O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.line_q = line_q; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt; O.qcount = qcount;
-    O.counters = counters; O.nb = n_bams;
+    O.counters = counters; O.nb = n_bams; O.prof = nullptr;
+    const bool profiling = getenv("PHZ_TALLY_PROFILE") != nullptr;
     // shard tables of the per-line stages: LINES_PER_BLOCK lines per block (k_line) and TL lines per block (k_tile)
     LinesTab TLn, TT;
     TLn.L = nullptr; TLn.blk0 = nullptr; TLn.n = 0; TT = TLn;
@@ -1076,6 +1083,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + TL - 1) / TL); }, &TT, &gt, 1, 2)) return s2;
     }
     const unsigned grid_l = n_shards > 0 ? gl.back() : 0u, grid_t = n_shards > 0 ? gt.back() : 0u;
+    if (profiling) { RSV(S[20], (size_t)(grid_l + grid_t + 2) * 16); O.prof = (unsigned long long *)S[20].p; PHZ_HIP(ctx, hipMemsetAsync(S[20].p, 0, (size_t)(grid_l + grid_t + 2) * 16, sm)); }
     if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(256), 0, sm, TLn, O);
     if (nv) hipLaunchKernelGGL(k_noise, dim3(std::min(nblk(nv), 256u)), dim3(256), 0, sm, (const int32_t *)d_cnt, nv, counters + 4);
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, rl_cnt, rl_start, (int64_t)NRL, S[T_SCAN_TMP])) return s;
@@ -1085,6 +1093,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         TileOut TO;
         TO.line_cls = d_cls; TO.line_q = line_q; TO.qcount = qcount; TO.items = items; TO.sp_q = sp_q; TO.sp_item = sp_item; TO.touched = touched;
         TO.var_rank = d_rank; TO.var_distinct = d_dist; TO.rl_cursor = rl_fill; TO.rl_tmp = rl_tmp; TO.counters = counters; TO.nb = n_bams;
+        TO.prof = profiling ? (unsigned long long *)S[20].p + 2 * (size_t)grid_l : nullptr;
         hipLaunchKernelGGL(k_tile, dim3(grid_t), dim3(256), 0, sm, TT, TO);
     }
     PHZ_HIP(ctx, hipGetLastError());
@@ -1094,6 +1103,22 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
     const int64_t n_kept = (int64_t)spread_sum(2);
+    if (profiling) {
+        std::vector<unsigned long long> pr((size_t)(grid_l + grid_t) * 2);
+        PHZ_HIP(ctx, hipMemcpy(pr.data(), S[20].p, pr.size() * 8, hipMemcpyDeviceToHost));
+        for (int which = 0; which < 2; which++) {
+            const size_t b0 = which ? grid_l : 0, nb_ = which ? grid_t : grid_l;
+            if (!nb_) continue;
+            unsigned long long t0 = ~0ull, t1 = 0; double sum = 0; unsigned long long mx = 0; std::vector<unsigned long long> d;
+            for (size_t b = 0; b < nb_; b++) { const unsigned long long a = pr[2 * (b0 + b)], e = pr[2 * (b0 + b) + 1]; t0 = std::min(t0, a); t1 = std::max(t1, e); sum += (double)(e - a); mx = std::max(mx, e - a); d.push_back(e - a); }
+            std::sort(d.begin(), d.end());
+            // start-time profile: how many workgroups had started by 10 %, 50 %, 90 % of the kernel's span
+            size_t s10 = 0, s50 = 0, s90 = 0; const double span = (double)(t1 - t0);
+            for (size_t b = 0; b < nb_; b++) { const double st = (double)(pr[2 * (b0 + b)] - t0) / span; s10 += st <= 0.1; s50 += st <= 0.5; s90 += st <= 0.9; }
+            fprintf(stderr, "[tally profile] %s: %zu workgroups, span %.1f us, lifetime avg %.2f us median %.2f p99 %.2f max %.2f us, sum %.1f ms -> avg %.0f resident; started by 10/50/90%% of the span: %zu %zu %zu\n",
+                    which ? "k_tile" : "k_line", nb_, span / 100.0, sum / nb_ / 100.0, d[nb_ / 2] / 100.0, d[nb_ * 99 / 100] / 100.0, mx / 100.0, sum / 1e5, sum / span, s10, s50, s90);
+        }
+    }
     const int64_t n_complete = (int64_t)grid_t * TL;     // item slots of the tiles (groups finished inside their tile, holes in between)
     const int64_t nt = (int64_t)(h_counters[10] >> 32);  // QNAMEs whose lines straddle tiles: one group each, built from the spilled lines
     const int64_t n_spill = (int64_t)(h_counters[10] & 0xFFFFFFFFull);

@@ -158,6 +158,7 @@ template <class T> inline T __shfl_xor(T v, int m, int width = 64) {
 template <class T> inline T __hip_atomic_load(const T *p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 template <class T, class V> inline void __hip_atomic_store(T *p, V v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
 inline void __builtin_amdgcn_s_sleep(int) {}
+inline unsigned long long wall_clock64() { return 0ull; }
 inline unsigned long long __ballot(int pred) {
     hipemu::Gather<int> g(pred ? 1 : 0);
     unsigned long long m = 0;
