@@ -253,9 +253,10 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     __shared__ unsigned long long s_rank[TWT];
     __shared__ uint32_t s_rl[TL / 2 > TWT * 2 ? TL / 2 : TWT * 2];   // read-list entries of (variant, allele) in this tile -> base of the tile's chunk in the list;
                                                  // later: the slots whose QNAMEs this tile puts on the list of spilled QNAMEs (16 bits each)
+    __shared__ uint16_t s_grp[TL];               // the occupied slots, densely: group g of the tile lives in slot s_grp[g]
     __shared__ uint32_t s_part[4];
     __shared__ int s_vbase;
-    __shared__ uint32_t s_nspill, s_ntouch, s_nkept;
+    __shared__ uint32_t s_nspill, s_ntouch, s_nkept, s_ngroups;
     __shared__ unsigned long long s_obase;
     uint16_t *s_touch = (uint16_t *)s_rl;
     const int tid = threadIdx.x;
@@ -306,13 +307,6 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     __syncthreads();
     // ---- 2. requested now, used later: the totals of the QNAMEs in this lane's slots and one cursor step per (tile, read list);
     //         meanwhile the group ranges (exclusive scan of the slot counts)
-    uint32_t tot[TSP], my_q[TSP];
-#pragma unroll
-    for (int j = 0; j < TSP; j++) {
-        const int slot = tid + 256 * j;
-        my_q[j] = s_q[slot];
-        tot[j] = my_q[j] != Q_EMPTY ? O.qcount[my_q[j]] : 0u;
-    }
     uint32_t rl_base[TWT * 2 / 256];
 #pragma unroll
     for (int j = 0; j < TWT * 2 / 256; j++) {
@@ -321,9 +315,10 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         if (rl_base[j]) rl_base[j] = atomicAdd(&O.rl_cursor[((uint32_t)(vbase + (x >> 1)) * 2u + (uint32_t)(x & 1)) * (uint32_t)O.nb + (uint32_t)L.bam], rl_base[j]);
     }
     {
+        // one scan for both: lines (low half) and occupied slots (high half) before every slot
         uint32_t c[TSP], sum = 0;
 #pragma unroll
-        for (int j = 0; j < TSP; j++) { c[j] = s_c[tid * TSP + j]; sum += c[j]; }
+        for (int j = 0; j < TSP; j++) { c[j] = s_c[tid * TSP + j]; sum += c[j] + (c[j] ? 0x10000u : 0u); }
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if ((tid & 63) >= d) incl += y; }
@@ -331,14 +326,29 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         __syncthreads();
         uint32_t base = incl - sum;
         for (int w = 0; w < (tid >> 6); w++) base += s_part[w];
-        if (tid == 255) s_nkept = base + sum;
+        if (tid == 255) { s_nkept = (base + sum) & 0xFFFFu; s_ngroups = (base + sum) >> 16; }
 #pragma unroll
-        for (int j = 0; j < TSP; j++) { s_c[tid * TSP + j] = base; base += c[j]; }
+        for (int j = 0; j < TSP; j++) {
+            s_c[tid * TSP + j] = base & 0xFFFFu;
+            if (c[j]) s_grp[base >> 16] = (uint16_t)(tid * TSP + j);
+            base += c[j] + (c[j] ? 0x10000u : 0u);
+        }
     }
 #pragma unroll
     for (int j = 0; j < TWT * 2 / 256; j++) s_rl[tid + 256 * j] = rl_base[j];
     __syncthreads();
-    // ---- 3. lines into their groups, read-list entries into their lists
+    // ---- 3. lines into their groups, read-list entries into their lists; the totals of the QNAMEs of this lane's groups are requested
+    //         first (used after the next barrier)
+    constexpr int GK = TL / 256;                            // groups per lane (a tile of TL lines holds at most TL groups)
+    const uint32_t ngroups = s_ngroups;
+    uint32_t tot[GK], my_q[GK], my_slot[GK];
+#pragma unroll
+    for (int j = 0; j < GK; j++) {
+        const uint32_t gi = (uint32_t)tid + 256u * (uint32_t)j;
+        my_slot[j] = gi < ngroups ? (uint32_t)s_grp[gi] : Q_EMPTY;
+        my_q[j] = my_slot[j] != Q_EMPTY ? s_q[my_slot[j]] : Q_EMPTY;
+        tot[j] = my_q[j] != Q_EMPTY ? O.qcount[my_q[j]] : 0u;
+    }
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (l_slot[k] == Q_EMPTY) continue;
@@ -354,12 +364,12 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     // ---- 4. one thread per group.  A group holding every line of its QNAME is finished here (all its lines come from this shard's BAM: that
     //         BAM owns the read_vars list, every ref/alt line is linked): its distinct items stay at the front of its range, the rest of the
     //         range becomes KEY_DROPPED.  The others hand their lines to the spill list (ranges inside the tile's share from LDS counters)
-    uint32_t sp_beg[TSP], sp_n[TSP], sp_at[TSP];
+    uint32_t sp_beg[GK], sp_n[GK], sp_at[GK];
 #pragma unroll
-    for (int j = 0; j < TSP; j++) {
-        const int slot = tid + 256 * j;
+    for (int j = 0; j < GK; j++) {
         sp_n[j] = 0; sp_beg[j] = 0; sp_at[j] = 0;
         if (my_q[j] == Q_EMPTY) continue;
+        const int slot = (int)my_slot[j];
         const uint32_t q = my_q[j];
         const uint32_t beg = slot ? s_c[slot - 1] : 0u, n = s_c[slot] - beg;        // the cursors stopped at the groups' ends
         uint64_t *it = s_it + beg;
@@ -369,6 +379,14 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
             continue;
         }
         O.qcount[q] = 0u;                                      // clean for the next call
+        if (n == 1u) {                                         // most QNAMEs: one line, nothing to sort, no pair, no rank
+            const uint64_t x = it[0];
+            const uint32_t v = (uint32_t)(x >> 34), cls = (uint32_t)(x >> 32) & 3u;
+            const unsigned d = v - (unsigned)vbase;
+            if (d < (unsigned)TWT) atomicAdd(&s_cnt[d * 3 + cls], 1); else atomicAdd(&O.var_distinct[(int64_t)v * 3 + cls], 1);
+            it[0] = dist_pack(q, v, cls, cls < 2u ? 1u : 0u);
+            continue;
+        }
         for (uint32_t a = 1; a < n; a++) {
             const uint64_t x = it[a];
             uint32_t b = a;
@@ -429,7 +447,7 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     if (s_nspill == 0) return;
     const uint32_t spill_base = (uint32_t)s_obase, touch_base = (uint32_t)(s_obase >> 32);
 #pragma unroll
-    for (int j = 0; j < TSP; j++) {
+    for (int j = 0; j < GK; j++) {
         if (!sp_n[j]) continue;
         for (uint32_t a = 0; a < sp_n[j]; a++) {
             O.sp_q[spill_base + sp_at[j] + a] = my_q[j]; O.sp_item[spill_base + sp_at[j] + a] = s_it[sp_beg[j] + a];
