@@ -837,6 +837,10 @@ __global__ __launch_bounds__(64) void k_rl_sort_wave(const uint32_t *wave_list, 
     const uint32_t lo = rl_start[e], n = rl_start[e + 1] - lo;
     const uint32_t t = threadIdx.x;
     unsigned long long x = t < n ? rl_tmp[lo + t] : ~0ull;
+    {   // entries arrive tile by tile and mostly in line order: a list that is in order already skips the network
+        const unsigned long long nxt = __shfl_down(x, 1);
+        if (!__any(t + 1 < n && x > nxt)) { if (t < n) rl_qid[lo + t] = (int32_t)(uint32_t)x; return; }
+    }
 #pragma unroll
     for (uint32_t k = 2; k <= 64; k <<= 1)
 #pragma unroll
