@@ -54,21 +54,71 @@ template <class TO> __global__ __launch_bounds__(1024) void k_gs_partials(TO *pa
     if (tid == 0) *total = s_carry;
 }
 
-template <class TI, class TO> __global__ __launch_bounds__(256) void k_gs_apply(const TI *in, TO *out, int64_t n, const TO *partial) {
-    __shared__ TO s_w[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * GS_CHUNK + (int64_t)tid * GS_ITEMS;
-    TO loc[GS_ITEMS];
-    TO sum = 0;
+// A workgroup's chunk of GS_CHUNK elements as GS_ROWS rows of 256 x 4: thread t holds elements (row * 256 + t) * 4 .. + 3 of every row, so a wave
+// reads / writes 1 KB of consecutive memory per instruction (16 consecutive elements per thread made every access instruction touch 64 cache lines:
+// the 18.8 M-element scan of a genome's read-label widths ran at 0.9 TB/s).  Exclusive prefix of the chunk with ONE barrier: wave scans of the four
+// row sums, the waves' totals of every row in LDS.
+constexpr int GS_ROWS = GS_ITEMS / 4;
+template <class TI, class TO> __device__ __forceinline__ void gs_load_rows(const TI *in, int64_t n, int64_t chunk0, int tid, TO v[GS_ROWS][4]) {
 #pragma unroll
-    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; loc[k] = i < n ? (TO)in[i] : (TO)0; sum += loc[k]; }
-    const TO incl = gs_wave_incl(sum, lane);
-    if (lane == 63) s_w[wave] = incl;
+    for (int r = 0; r < GS_ROWS; r++) {
+        const int64_t i = chunk0 + ((int64_t)r * 256 + tid) * 4;
+        if (sizeof(TI) == 4 && i + 3 < n && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0)) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(in + i);
+            v[r][0] = (TO)x.x; v[r][1] = (TO)x.y; v[r][2] = (TO)x.z; v[r][3] = (TO)x.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[r][j] = i + j < n ? (TO)in[i + j] : (TO)0;
+        }
+    }
+}
+// -> exclusive prefix (inside the chunk) of the first element of every row of this thread; *chunk_sum = sum of the chunk.  s_w: [GS_ROWS][4] in LDS
+template <class TO> __device__ __forceinline__ void gs_chunk_scan(const TO v[GS_ROWS][4], int tid, TO (*s_w)[4], TO base[GS_ROWS], TO *chunk_sum) {
+    const int lane = tid & 63, wave = tid >> 6;
+    TO rs[GS_ROWS], incl[GS_ROWS];
+#pragma unroll
+    for (int r = 0; r < GS_ROWS; r++) {
+        rs[r] = v[r][0] + v[r][1] + v[r][2] + v[r][3];
+        incl[r] = gs_wave_incl(rs[r], lane);
+        if (lane == 63) s_w[r][wave] = incl[r];
+    }
     __syncthreads();
-    TO run = partial[blockIdx.x] + incl - sum;
-    for (int w2 = 0; w2 < wave; w2++) run += s_w[w2];
+    TO carry = 0;
 #pragma unroll
-    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; if (i < n) out[i] = run; run += loc[k]; }
+    for (int r = 0; r < GS_ROWS; r++) {
+        TO before = carry;
+        for (int w2 = 0; w2 < wave; w2++) before += s_w[r][w2];
+        base[r] = before + incl[r] - rs[r];
+        carry += s_w[r][0] + s_w[r][1] + s_w[r][2] + s_w[r][3];
+    }
+    *chunk_sum = carry;
+}
+template <class TO> __device__ __forceinline__ void gs_store_rows(TO *out, int64_t n, int64_t chunk0, int tid, const TO v[GS_ROWS][4], const TO base[GS_ROWS], TO offset) {
+#pragma unroll
+    for (int r = 0; r < GS_ROWS; r++) {
+        const int64_t i = chunk0 + ((int64_t)r * 256 + tid) * 4;
+        TO run = offset + base[r];
+        TO o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] = run; run += v[r][j]; }
+        if (sizeof(TO) == 4 && i + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
+            *reinterpret_cast<uint4 *>(out + i) = make_uint4((uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (i + j < n) out[i + j] = o[j];
+        }
+        if (i <= n - 1 && n - 1 < i + 4) out[n] = run;      // the thread holding the last element also holds the total (elements beyond n read as 0)
+    }
+}
+
+template <class TI, class TO> __global__ __launch_bounds__(256) void k_gs_apply(const TI *in, TO *out, int64_t n, const TO *partial) {
+    __shared__ TO s_w[GS_ROWS][4];
+    const int tid = threadIdx.x;
+    const int64_t chunk0 = (int64_t)blockIdx.x * GS_CHUNK;
+    TO v[GS_ROWS][4], base[GS_ROWS], sum;
+    gs_load_rows<TI, TO>(in, n, chunk0, tid, v);
+    gs_chunk_scan<TO>(v, tid, s_w, base, &sum);
+    gs_store_rows<TO>(out, n, chunk0, tid, v, base, partial[blockIdx.x]);
 }
 
 // ---- the same scan in ONE launch for 32-bit sums (decoupled look-back): tiles take tickets in start order, publish their sum, and the
@@ -81,22 +131,17 @@ __device__ __forceinline__ unsigned long long gs_word(uint32_t epoch, unsigned s
 }
 template <class TI> __global__ __launch_bounds__(256) void k_gs_lookback(const TI *in, uint32_t *out, int64_t n, unsigned long long *status, uint32_t *ticket,
                                                                           uint32_t ticket_base, uint32_t epoch) {
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[GS_ROWS][4];
     __shared__ uint32_t s_tile, s_prefix;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
     __syncthreads();
     const uint32_t tile = s_tile;
-    const int64_t base = (int64_t)tile * GS_CHUNK + (int64_t)tid * GS_ITEMS;
-    uint32_t loc[GS_ITEMS];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; loc[k] = i < n ? (uint32_t)in[i] : 0u; sum += loc[k]; }
-    const uint32_t incl = gs_wave_incl(sum, lane);
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
+    const int64_t chunk0 = (int64_t)tile * GS_CHUNK;
+    uint32_t v[GS_ROWS][4], base[GS_ROWS], block_sum;
+    gs_load_rows<TI, uint32_t>(in, n, chunk0, tid, v);
+    gs_chunk_scan<uint32_t>(v, tid, s_w, base, &block_sum);
     if (wave == 0) {
-        const uint32_t block_sum = s_w[0] + s_w[1] + s_w[2] + s_w[3];
         if (lane == 0) __hip_atomic_store(&status[tile], gs_word(epoch, tile == 0 ? GS_PREFIX : GS_AGG, block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
         if (tile > 0) {
@@ -109,10 +154,10 @@ template <class TI> __global__ __launch_bounds__(256) void k_gs_lookback(const T
                 const unsigned long long have = __ballot(state != 0u), pref = __ballot(state == GS_PREFIX);
                 const unsigned long long upto = pref ? ((pref & (~pref + 1ull)) << 1) - 1ull : ~0ull;        // lanes 0 .. first prefix lane
                 if ((have & upto) != upto) { __builtin_amdgcn_s_sleep(1); continue; }                  // a predecessor in that stretch has not published yet
-                uint32_t v = ((upto >> lane) & 1ull) ? (uint32_t)w : 0u;
+                uint32_t x = ((upto >> lane) & 1ull) ? (uint32_t)w : 0u;
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-                excl += v;
+                for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+                excl += x;
                 if (pref) break;
                 j -= 64;
             }
@@ -121,18 +166,17 @@ template <class TI> __global__ __launch_bounds__(256) void k_gs_lookback(const T
         if (lane == 0) s_prefix = excl;
     }
     __syncthreads();
-    uint32_t run = s_prefix + incl - sum;
-    for (int w2 = 0; w2 < wave; w2++) run += s_w[w2];
-#pragma unroll
-    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k; if (i < n) out[i] = run; run += loc[k]; }
-    if (base <= n - 1 && n - 1 < base + GS_ITEMS) out[n] = run;        // the thread holding the last element also holds the total
+    gs_store_rows<uint32_t>(out, n, chunk0, tid, v, base, s_prefix);
 }
 
 template <class TI, class TO> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out /* [n + 1] */, int64_t n, DevBuf &tmp) {
     hipStream_t sm = ctx->stream;
     if (n <= 0) { PHZ_HIP(ctx, hipMemsetAsync(out, 0, sizeof(TO), sm)); return PHZ_OK; }
     const int64_t nb = (n + GS_CHUNK - 1) / GS_CHUNK;
-    if constexpr (sizeof(TO) == 4) {
+    // (beyond a few million elements the prefix front of the look-back -- 64 tiles per round trip -- is slower than two streaming passes:
+    //  18.8 M elements took 161 us in one launch)
+    if (sizeof(TO) == 4 && n < (int64_t)(4 << 20)) {
+      if constexpr (sizeof(TO) == 4) {
         const size_t before = ctx->scan_state.cap;
         if (int s = phz_reserve(ctx, ctx->scan_state, 64 + (size_t)nb * 8)) return s;
         if (ctx->scan_state.cap != before || ctx->scan_epoch >= (1u << 30) - 2u) {
@@ -146,7 +190,9 @@ template <class TI, class TO> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out
         PHZ_HIP(ctx, hipGetLastError());
         (void)tmp;
         return PHZ_OK;
-    } else {
+      }
+    }
+    {
         if (int s = phz_reserve(ctx, tmp, (size_t)nb * sizeof(TO) + 16)) return s;
         TO *partial = (TO *)tmp.p;
         hipLaunchKernelGGL((k_gs_reduce<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, n, partial);
