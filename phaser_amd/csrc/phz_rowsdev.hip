@@ -423,15 +423,21 @@ __global__ __launch_bounds__(256) void k_mem_rec(RD D, MemRec *out) {
     r.pad[0] = r.pad[1] = 0;
     out[m] = r;
 }
-// read list of (member, haplotype, BAM) and the room its label text takes in the member's row of haplotypic_counts
+// read list of (haplotype, BAM, block member) -- as soon as the blocks are known: the read-set kernels walk a block's members through it
+__global__ __launch_bounds__(256) void k_lab_e(int64_t nmem, int nb, const uint32_t *mem_s, const uint8_t *v_alle, uint32_t *lab_e) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nmem * 2 * nb) return;
+    const int64_t m = i % nmem; const int hb = (int)(i / nmem), h = hb / nb, bb = hb % nb;
+    const int64_t g = mem_s[m];
+    lab_e[i] = (uint32_t)((2 * g + (v_alle[g] ^ h)) * nb + bb);
+}
+// ... and the room its label text takes in the member's row of haplotypic_counts
 __global__ __launch_bounds__(256) void k_mem_lab(RD D, uint32_t *lab_e, uint32_t *lab_skip) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= D.nmem * 2 * D.nb) return;
-    const int64_t m = i % D.nmem; const int hb = (int)(i / D.nmem), h = hb / D.nb, bb = hb % D.nb;
-    const int64_t g = D.mem_s[m];
-    const int64_t e = (2 * g + (D.v_alle[g] ^ h)) * D.nb + bb;
+    const uint32_t e = lab_e[i];
     const uint32_t lo = D.rl_start[e], hi = D.rl_start[e + 1];
-    lab_e[i] = (uint32_t)e; lab_skip[i] = hi > lo ? D.its[hi] - D.its[lo] - 1u : 0u;
+    lab_skip[i] = hi > lo ? D.its[hi] - D.its[lo] - 1u : 0u;
 }
 // block of the first row of every 256-row chunk of allele_config (one search of the whole block table per chunk instead of per row)
 __global__ __launch_bounds__(256) void k_cfg_chunks(int64_t nchunks, int64_t nblocks, const unsigned long long *cfg_base, uint32_t *cfg_chunk) {
@@ -1253,16 +1259,36 @@ __global__ __launch_bounds__(256) void k_gather_nsub(int64_t ncomp, const uint32
 __global__ __launch_bounds__(256) void k_blk_edges(int64_t nkeep, const uint32_t *ekeep, const int32_t *ea, const int32_t *eb, const int32_t *cfgv, const int32_t *blk_of,
                                                    const uint8_t *v_alle, uint32_t *blk_sup, uint32_t *blk_tot) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= nkeep) return;
-    const uint32_t e = ekeep[t];
-    const int k = cfgv[e];
-    if (k < 0) return;
-    const int a = ea[e], b = eb[e];
-    const int ba = blk_of[a];
-    if (ba < 0 || ba != blk_of[b]) return;
-    atomicAdd(&blk_tot[ba], 1u);
-    const int want = k == 0 ? v_alle[a] : 1 - v_alle[a];
-    if ((int)v_alle[b] == want) atomicAdd(&blk_sup[ba], 1u);
+    // the kept pairs come component by component, so the lanes of a wave count for a handful of blocks: one pair of atomics per block and wave
+    // (one per pair meant up to 64 same-address atomics per instruction)
+    int ba = -1; bool sup = false;
+    if (t < nkeep) {
+        const uint32_t e = ekeep[t];
+        const int k = cfgv[e];
+        if (k >= 0) {
+            const int a = ea[e], b = eb[e];
+            const int x = blk_of[a];
+            if (x >= 0 && x == blk_of[b]) {
+                ba = x;
+                const int want = k == 0 ? v_alle[a] : 1 - v_alle[a];
+                sup = (int)v_alle[b] == want;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(ba >= 0);
+    const unsigned long long supm = __ballot(sup);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int key = __shfl(ba, leader);
+        const unsigned long long m = __ballot(ba == key) & todo;
+        if (lane == leader) {
+            atomicAdd(&blk_tot[key], (uint32_t)__popcll(m));
+            const uint32_t ns = (uint32_t)__popcll(m & supm);
+            if (ns) atomicAdd(&blk_sup[key], ns);
+        }
+        todo &= ~m;
+    }
 }
 // per block: annotated phase, concordance, genome-wide phase by majority (:945-980), gwStat, the variant whose maf text is printed,
 // rows of allele_config
@@ -1314,6 +1340,7 @@ struct SG {
     uint32_t *labels, *ns;
     uint32_t *big_list, *big_list2; uint32_t *counters;         // [0] segments left to the wave kernel, [1] pool slots used, [2] pool overflow, [3] segments left to the workgroup kernel
     uint32_t *pool; uint32_t pool_cap;
+    const uint32_t *lab_e; int64_t nmem;        // read list of (haplotype, BAM, block member): one load instead of mem_s -> v_alle -> index arithmetic
 };
 template <int MODE> __device__ __forceinline__ uint32_t seg_pieces(const SG &G, int64_t seg) {      // number of pieces (some may be empty / skipped)
     if (MODE == 2) return 1;
@@ -1324,13 +1351,16 @@ template <int MODE> __device__ __forceinline__ bool seg_piece(const SG &G, int64
     if (MODE == 2) { *lo = G.rl_start[seg]; *hi = G.rl_start[seg + 1]; return true; }
     const int64_t b = MODE == 0 ? seg / (2 * G.nb) : seg / 2;
     const int h = MODE == 0 ? (int)((seg / G.nb) & 1) : (int)(seg & 1);
-    const int64_t g = G.mem_s[G.blk_mstart[b] + t];
-    const int64_t l = 2 * g + (G.v_alle[g] ^ h);
+    const uint32_t m = G.blk_mstart[b] + t;
     if (MODE == 0) {
-        if (G.black && G.black[g]) return false;
+        if (G.black && G.black[G.mem_s[m]]) return false;
         const int bb = (int)(seg % G.nb);
-        *lo = G.rl_start[l * G.nb + bb]; *hi = G.rl_start[l * G.nb + bb + 1];
-    } else { *lo = G.rl_start[l * G.nb]; *hi = G.rl_start[l * G.nb + G.nb]; }
+        const uint32_t e = G.lab_e[(size_t)(h * G.nb + bb) * (size_t)G.nmem + m];
+        *lo = G.rl_start[e]; *hi = G.rl_start[e + 1];
+    } else {
+        const uint32_t e0 = G.lab_e[(size_t)(h * G.nb) * (size_t)G.nmem + m];         // the lists of the member's allele over all BAMs are adjacent
+        *lo = G.rl_start[e0]; *hi = G.rl_start[e0 + G.nb];
+    }
     return true;
 }
 
@@ -1338,27 +1368,57 @@ template <int MODE> __global__ __launch_bounds__(64) void k_seg_small(SG G) {
     __shared__ int32_t s_q[64][SEG_SMALL + 1];
     __shared__ uint8_t s_l[64][SEG_SMALL + 4];
     const int64_t seg = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (seg >= G.nseg) return;
     const int tid = threadIdx.x;
-    const uint32_t np = seg_pieces<MODE>(G, seg);
+    const bool live = seg < G.nseg;
+    const uint32_t np = live ? seg_pieces<MODE>(G, seg) : 0u;
     uint32_t M = 0;
     for (uint32_t t = 0; t < np; t++) { uint32_t lo, hi; if (seg_piece<MODE>(G, seg, t, &lo, &hi)) M += hi - lo; }
-    if (M == 0) { G.ns[seg] = 0; return; }
-    if (M > SEG_MID) { G.big_list2[atomicAdd(&G.counters[3], 1u)] = (uint32_t)seg; return; }
-    if (M > SEG_SMALL) { G.big_list[atomicAdd(&G.counters[0], 1u)] = (uint32_t)seg; return; }
+    if (live && M == 0) G.ns[seg] = 0;
+    // the segments left to the wave / workgroup kernels take their places in the two lists with one cursor step per wave and list (82,000 of a
+    // genome's 370,000 segments: one same-address atomic each was most of this kernel's time)
+    {
+        const unsigned long long m2 = __ballot(M > (uint32_t)SEG_MID), m1 = __ballot(M > (uint32_t)SEG_SMALL && M <= (uint32_t)SEG_MID);
+        const unsigned long long below = tid ? (~0ull >> (64 - tid)) : 0ull;
+        if (m2) {
+            uint32_t base = 0;
+            const int leader = __builtin_ctzll(m2);
+            if (tid == leader) base = atomicAdd(&G.counters[3], (uint32_t)__popcll(m2));
+            base = __shfl(base, leader);
+            if ((m2 >> tid) & 1ull) G.big_list2[base + (uint32_t)__popcll(m2 & below)] = (uint32_t)seg;
+        }
+        if (m1) {
+            uint32_t base = 0;
+            const int leader = __builtin_ctzll(m1);
+            if (tid == leader) base = atomicAdd(&G.counters[0], (uint32_t)__popcll(m1));
+            base = __shfl(base, leader);
+            if ((m1 >> tid) & 1ull) G.big_list[base + (uint32_t)__popcll(m1 & below)] = (uint32_t)seg;
+        }
+    }
+    if (!live || M == 0 || M > (uint32_t)SEG_SMALL) return;
     uint32_t idx = 0;
     for (uint32_t t = 0; t < np; t++) {
         uint32_t lo, hi;
         if (!seg_piece<MODE>(G, seg, t, &lo, &hi)) continue;
         for (uint32_t p = lo; p < hi; p++) s_q[tid][idx++] = G.rl_qid[p];
     }
+    // labels by first appearance, in registers: every QNAME id against all earlier ones with selects (fully unrolled, no memory access; the loop
+    // over LDS it replaces -- up to 500 dependent reads per thread -- took 23 us per wave)
+    int32_t qv[SEG_SMALL];
+#pragma unroll
+    for (int i = 0; i < SEG_SMALL; i++) qv[i] = (uint32_t)i < M ? s_q[tid][i] : -(i + 2);       // padding never matches (QNAME ids are >= 0)
     uint32_t cnt = 0;
-    for (uint32_t i = 0; i < M; i++) {
-        const int32_t q = s_q[tid][i];
-        uint32_t first = i;
-        for (uint32_t j = 0; j < i; j++) if (s_q[tid][j] == q) { first = j; break; }
-        s_l[tid][i] = first == i ? (uint8_t)cnt++ : s_l[tid][first];
+    uint32_t lab[SEG_SMALL];
+#pragma unroll
+    for (int i = 0; i < SEG_SMALL; i++) {
+        uint32_t l = cnt;                                    // label if new
+        bool seen = false;
+#pragma unroll
+        for (int j = i - 1; j >= 0; j--) { const bool eq = qv[j] == qv[i]; l = eq ? lab[j] : l; seen = seen || eq; }
+        lab[i] = l;
+        if (!seen && (uint32_t)i < M) cnt++;
     }
+#pragma unroll
+    for (int i = 0; i < SEG_SMALL; i++) s_l[tid][i] = (uint8_t)lab[i];
     G.ns[seg] = cnt;
     if (MODE == 0) {
         idx = 0;
@@ -1955,7 +2015,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     if (nb > 1) RSV(single_n, NRL * 4);
     if (h->pool.cap == 0) RSV(pool, (size_t)12 << 20);
     PHZ_HIP(ctx, hipMemsetAsync(h->labels.p, 0, NR * 4, sm));
-    SG sg; sg.nb = nb; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
+    RSV(lab_e, (size_t)(nmem + 1) * 2 * nb * 4);
+    if (nmem) hipLaunchKernelGGL(k_lab_e, dim3(nblk(nmem * 2 * nb)), dim3(256), 0, sm, nmem, nb, (const uint32_t *)h->mem_s.p, (const uint8_t *)h->v_alle.p, P<uint32_t>(h->lab_e));
+    SG sg; sg.nb = nb; sg.lab_e = P<uint32_t>(h->lab_e); sg.nmem = nmem; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
     sg.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.labels = P<uint32_t>(h->labels);
     sg.big_list = P<uint32_t>(h->big_list); sg.big_list2 = P<uint32_t>(h->big_list2); sg.counters = cnt32 + 4;
     for (int attempt = 0;; attempt++) {
