@@ -343,10 +343,18 @@ def main():
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize()
+                prof = None
+                if os.environ.get("PHZ_BENCH_PYPROFILE") and mode == "resident" and rep == max(1, a.phasing_passes):      # host-side profile of the last resident pass
+                    import cProfile
+                    prof = cProfile.Profile(); prof.enable()
                 tp0 = time.perf_counter()
                 eng.close_bam(0)                       # AS histogram per shard + all-reduce + percentile
                 tp1 = time.perf_counter()
                 files = eng.finish(chunks=True)        # K_tally, noise all-reduce, pair tests, components, block phasing, rows, gather
+                if prof is not None:
+                    prof.disable()
+                    import pstats
+                    pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(28)
                 torch.cuda.synchronize()
                 if world > 1:
                     dist.barrier()
