@@ -175,3 +175,25 @@ def test_scan_over_many_tiles():
         assert np.array_equal(got["rl_start"], np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32))
         for e in np.flatnonzero(cnt)[:200]:
             assert np.array_equal(got["rl_qid"][got["rl_start"][e]:got["rl_start"][e + 1]], qid[k & (var == e // 2) & (cls == e % 2)])
+
+
+def test_tally_on_empty_and_fully_dropped_input():
+    """No shard at all, a shard without lines, a shard whose lines are all dropped by the AS cutoff: empty results, and the context stays usable."""
+    from phaser_amd import _lib
+    ctx = EmuContext(emu_library())
+    nv = 50; nq = 10
+    empty = {"nv": nv, "line_var": np.zeros(0, np.int32), "line_qid": np.zeros(0, np.int32), "line_cls": np.zeros(0, np.uint8), "line_bam": np.zeros(0, np.int32),
+             "bam_offsets": [(0, 0, 0)]}
+    got, sz = run_tally(ctx, {"tally": {"chrS": empty}, "n_qid": {"chrS": nq}}, ["chrS"], 1)
+    assert int(sz.n_lines) == 0 and int(sz.n_edges) == 0 and int(sz.n_kept) == 0 and not got["var_count"].any() and not got["rl_start"].any()
+    n = 300
+    rng = np.random.default_rng(2)
+    dropped = {"nv": nv, "line_var": np.sort(rng.integers(0, nv, n)).astype(np.int32), "line_qid": rng.integers(0, nq, n).astype(np.int32),
+               "line_cls": np.full(n, 255, np.uint8), "line_bam": np.zeros(n, np.int32), "bam_offsets": [(0, 0, n)]}
+    got, sz = run_tally(ctx, {"tally": {"chrS": dropped}, "n_qid": {"chrS": nq}}, ["chrS"], 1)
+    assert int(sz.n_lines) == n and int(sz.n_kept) == 0 and int(sz.n_edges) == 0 and not got["var_count"].any() and int(got["rl_start"][-1]) == 0
+    assert np.all(got["var_first"] == -1) and np.all(got["line_cls"][:n] == 255)
+    # ... and a normal call afterwards
+    live = dict(dropped); live["line_cls"] = rng.choice([0, 1, 2], size=n).astype(np.uint8)
+    got, sz = run_tally(ctx, {"tally": {"chrS": live}, "n_qid": {"chrS": nq}}, ["chrS"], 1)
+    assert int(sz.n_kept) == n and int(got["var_count"].sum()) == n
