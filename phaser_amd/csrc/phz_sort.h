@@ -227,17 +227,20 @@ template <class K, class V> __global__ __launch_bounds__(64) void k_rs_scatter(c
                                                                                const uint32_t *off, uint32_t ntile) {
     __shared__ uint32_t s_off[256];
     const int lane = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 4; j++) s_off[lane + 64 * j] = off[(size_t)(lane + 64 * j) * ntile + blockIdx.x];
-    __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     K rk[RS_ROWS]; V rv[RS_ROWS];
 #pragma unroll
-    for (int r = 0; r < RS_ROWS; r++) {                   // the tile's 16 rows requested together: one memory round trip, not sixteen
+    for (int r = 0; r < RS_ROWS; r++) {                   // the tile's 16 rows AND its 256 digit offsets requested together: one memory round trip
         const int64_t i = base + r * 64 + lane;
         rk[r] = i < n ? kin[i] : (K)0; rv[r] = i < n ? vin[i] : (V)0;
     }
+    uint32_t o4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) o4[j] = off[(size_t)(lane + 64 * j) * ntile + blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; j++) s_off[lane + 64 * j] = o4[j];
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
         const int64_t i = base + r * 64 + lane;
