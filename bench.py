@@ -218,8 +218,8 @@ def kmap_roofline(ctx, tot_recs, tot_alg, k_avg_s, k_launches, steps, k_ms_max_r
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)      # 0.3 s of timed steps by default (twenty 1.5 ms steps were a fragile headline)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--records", type=int, default=80_000_000)
     ap.add_argument("--snps", type=int, default=1_500_000)
     ap.add_argument("--baseq", type=int, default=10)
@@ -285,7 +285,7 @@ def main():
         step()
     import gc
     time.sleep(0.12)                    # let a CPU-quota period that the set-up may have exhausted run out before the timed region starts
-    gc.collect(); gc.disable()          # before the barrier: a collector pause inside twenty 1.5 ms steps would be a visible share of the timed region
+    gc.collect(); gc.disable()          # before the barrier: a collector pause inside the timed steps (1.5 ms each) would be a visible share of a short run
     mapper.ctx.reset_timing()
     if world > 1:
         dist.barrier()
