@@ -333,6 +333,9 @@ int phz_bam_write(const char *path, int n_ref, const char *const *ref_names, con
 
 /* tabix index <bgzf_path>.tbi of a BGZF-compressed position-sorted file; preset 0 = VCF (tabix -p vcf), 1 = BED (tabix -p bed) */
 int phz_tabix_build(const char *bgzf_path, int preset, int threads);
+/* phz_bgzf_write + phz_tabix_build of the same text in one call (`bgzip` + `tabix -p vcf -f`, phaser.py:1851): the index is gathered
+ * next to the deflate workers, nothing is read back.  PHZ_E_UNSUPPORTED: text not position-sorted -- the .gz is written, no .tbi. */
+int phz_bgzf_write_indexed(const char *path, const char *data, int64_t len, int threads, int level, int preset);
 
 int phz_interner_create(phz_interner **out);
 int phz_interner_destroy(phz_interner *it);

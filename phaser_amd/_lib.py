@@ -253,6 +253,7 @@ SYMBOLS = {
     "phz_bgzf_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     "phz_bam_write": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(phz_read_batch), C.c_int, C.c_int]),
     "phz_tabix_build": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
+    "phz_bgzf_write_indexed": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "phz_interner_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "phz_interner_destroy": (C.c_int, [C.c_void_p]),
     "phz_interner_size": (C.c_int64, [C.c_void_p]),

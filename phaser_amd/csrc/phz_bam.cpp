@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -1190,16 +1191,21 @@ int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len) {
 void phz_buf_free(char *p) { free(p); }
 
 // Writes data as a BGZF file (60,000-byte members deflated in parallel, EOF marker at the end) -- what `bgzip` produces
-// for the phased VCF (phaser.py:1851).
-int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads, int level) {
+// for the phased VCF (phaser.py:1851).  side (may be empty) runs on a thread of its own next to the deflate workers; members (may be
+// NULL) receives the member table of the written file: compressed offset / uncompressed start per member incl. the EOF marker, plus
+// one closing entry.
+static int bgzf_write_impl(const char *path, const char *data, int64_t len, int threads, int level, const std::function<void()> &side,
+                           std::vector<uint64_t> *m_coff, std::vector<uint64_t> *m_ustart) {
     if (!path || (!data && len) || len < 0) return PHZ_E_ARG;
     const size_t BLK = 60000;
     const size_t nblk = ((size_t)len + BLK - 1) / BLK;
     std::vector<std::string> out(nblk);
     std::atomic<size_t> next(0);
     std::atomic<bool> bad(false);
-    const int nt = n_threads(threads);
+    int nt = threads > 0 ? threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));     // deflate scales with the cores
+    if ((size_t)nt > nblk) nt = (int)std::max<size_t>(1, nblk);
     std::vector<std::thread> th;
+    if (side) th.emplace_back(side);
     for (int t = 0; t < nt; t++)
         th.emplace_back([&] {
             std::vector<uint8_t> tmp(BLK + 1024);
@@ -1231,6 +1237,13 @@ int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads,
         });
     for (auto &t : th) t.join();
     if (bad) return PHZ_E_ARG;
+    if (m_coff && m_ustart) {
+        m_coff->clear(); m_ustart->clear();
+        uint64_t c = 0;
+        for (size_t i = 0; i < nblk; i++) { m_coff->push_back(c); m_ustart->push_back((uint64_t)i * BLK); c += out[i].size(); }
+        m_coff->push_back(c); m_ustart->push_back((uint64_t)len);                  // the EOF marker: an empty member
+        m_coff->push_back(c + 28); m_ustart->push_back((uint64_t)len);
+    }
     FILE *fp = fopen(path, "wb");
     if (!fp) return PHZ_E_ARG;
     bool ok = true;
@@ -1239,6 +1252,10 @@ int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads,
     ok = ok && fwrite(eof_marker, 1, 28, fp) == 28;
     ok = fclose(fp) == 0 && ok;
     return ok ? PHZ_OK : PHZ_E_ARG;
+}
+
+int phz_bgzf_write(const char *path, const char *data, int64_t len, int threads, int level) {
+    return bgzf_write_impl(path, data, len, threads, level, std::function<void()>(), nullptr, nullptr);
 }
 
 // ---- BAM writer for synthetic read batches (test / benchmark tooling: there is no samtools in the image) ----------------------
@@ -1329,6 +1346,201 @@ inline int reg2bin(int64_t beg, int64_t end) {
 }
 }  // namespace
 
+// The index is gathered over UNCOMPRESSED text offsets (scan) and turned into BGZF virtual offsets when the member table is known
+// (serialise): the scan of the phased VCF then runs next to its deflate workers instead of after a re-read of the written file.
+namespace {
+struct TbxIndex {
+    struct Ref {
+        std::string name;
+        std::vector<std::pair<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;   // in order of first use
+        std::unordered_map<uint32_t, size_t> bin_idx;
+        std::vector<uint64_t> ioff;
+        uint64_t off_beg = 0, off_end = 0, n_rec = 0;
+        int64_t last_beg = -1, first_beg = -1;
+        uint32_t first_bin = 0xffffffffu, last_bin = 0xffffffffu;     // bins of the first / last record (what merge() needs at the seam)
+    };
+    std::vector<Ref> refs;
+    std::unordered_map<std::string, size_t> ref_idx;
+
+    // lines of d[lo, n) (lo at a line start); offsets are positions in d
+    int scan(const char *d, size_t lo, size_t n, int preset) {
+        size_t p = lo;
+        int64_t last_ref = -1; uint32_t last_bin = 0xffffffffu;
+        while (p < n) {
+            const char *nl = (const char *)memchr(d + p, '\n', n - p);
+            const size_t e = nl ? (size_t)(nl - d) : n;
+            const size_t next = nl ? e + 1 : n;
+            if (e > p && d[p] != '#') {
+                // columns
+                const char *c0 = d + p; const char *le = d + e;
+                const char *t1 = (const char *)memchr(c0, '\t', (size_t)(le - c0));
+                if (!t1) return PHZ_E_ARG;
+                const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
+                const std::string_view chrom_sv(c0, (size_t)(t1 - c0));
+                int64_t beg, end;
+                auto to_ll = [](const char *a, const char *z) {           // strtoll(..., 10) of [a, z): blanks, sign, digits
+                    while (a < z && (*a == ' ' || *a == '\t')) a++;
+                    bool neg = false;
+                    if (a < z && (*a == '-' || *a == '+')) { neg = *a == '-'; a++; }
+                    long long v = 0;
+                    while (a < z && *a >= '0' && *a <= '9') { v = v * 10 + (*a - '0'); a++; }
+                    return neg ? -v : v;
+                };
+                const long long v1 = to_ll(t1 + 1, t2 ? t2 : le);
+                if (preset == 0) {          // VCF: POS is 1-based, the record covers len(REF) bases unless INFO carries END=
+                    beg = v1 - 1;
+                    const char *t3 = t2 ? (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1)) : nullptr;        // end of ID
+                    const char *t4 = t3 ? (const char *)memchr(t3 + 1, '\t', (size_t)(le - t3 - 1)) : nullptr;        // end of REF
+                    end = beg + (t3 && t4 ? (int64_t)(t4 - t3 - 1) : 1);
+                    const char *t = t4; int col = 4;
+                    while (t && col < 7) { t = (const char *)memchr(t + 1, '\t', (size_t)(le - t - 1)); col++; }      // t = tab before INFO
+                    if (t) {
+                        const char *ie = (const char *)memchr(t + 1, '\t', (size_t)(le - t - 1));
+                        std::string_view info(t + 1, (size_t)((ie ? ie : le) - t - 1));
+                        size_t q = 0;
+                        while (q < info.size()) {
+                            size_t r = info.find(';', q); if (r == std::string_view::npos) r = info.size();
+                            if (info.substr(q, 4) == "END=") { const long long ev = to_ll(info.data() + q + 4, info.data() + r); if (ev > beg) end = ev; }
+                            q = r + 1;
+                        }
+                    }
+                } else {                    // BED: 0-based start, end exclusive
+                    if (!t2) return PHZ_E_ARG;
+                    const char *t3 = (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1));
+                    beg = v1;
+                    end = to_ll(t2 + 1, t3 ? t3 : le);
+                }
+                if (beg < 0) beg = 0;
+                if (end <= beg) end = beg + 1;
+                size_t ri;
+                if (last_ref >= 0 && refs[(size_t)last_ref].name == chrom_sv) ri = (size_t)last_ref;        // the common case: same contig as the line before
+                else {
+                    const std::string chrom(chrom_sv);
+                    auto it = ref_idx.find(chrom);
+                    if (it == ref_idx.end()) { ri = refs.size(); ref_idx.emplace(chrom, ri); refs.emplace_back(); refs.back().name = chrom; }
+                    else ri = it->second;
+                }
+                Ref &R = refs[ri];
+                // tabix needs every contig in one run and ascending starts inside it (it refuses such files too)
+                if (((int64_t)ri != last_ref && R.n_rec) || ((int64_t)ri == last_ref && beg < R.last_beg)) return PHZ_E_UNSUPPORTED;
+                R.last_beg = beg;
+                const uint64_t v0 = p, v1e = next;                           // uncompressed offsets here: virtual offsets at serialisation
+                if ((int64_t)ri != last_ref) { last_bin = 0xffffffffu; last_ref = (int64_t)ri; if (!R.n_rec) R.off_beg = v0; }
+                R.off_end = v1e; R.n_rec++;
+                const uint32_t bin = (uint32_t)reg2bin(beg, end);
+                if (R.n_rec == 1) { R.first_beg = beg; R.first_bin = bin; }
+                R.last_bin = bin;
+                if (bin != last_bin || R.bins.empty()) {
+                    auto bi = R.bin_idx.find(bin);
+                    size_t k;
+                    if (bi == R.bin_idx.end()) { k = R.bins.size(); R.bin_idx.emplace(bin, k); R.bins.emplace_back(bin, std::vector<std::pair<uint64_t, uint64_t>>()); }
+                    else k = bi->second;
+                    R.bins[k].second.emplace_back(v0, v1e);
+                    last_bin = bin;
+                } else {
+                    R.bins[R.bin_idx[bin]].second.back().second = v1e;
+                }
+                const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+                if (R.ioff.size() <= w1) R.ioff.resize(w1 + 1, 0);
+                for (size_t w = w0; w <= w1; w++) if (R.ioff[w] == 0) R.ioff[w] = v0;
+            }
+            p = next;
+        }
+        return PHZ_OK;
+    }
+
+    // Appends the index of the text that FOLLOWS this one (scanned on its own, as if it were a file) -- the result is what one scan over
+    // both texts builds: a contig continues across the seam, its first record extends the open chunk when it falls into the bin of
+    // the last record before the seam, bins keep the order of their first use, a linear-index window keeps its first offset.
+    int merge(TbxIndex &b) {
+        for (size_t k = 0; k < b.refs.size(); k++) {
+            Ref &B = b.refs[k];
+            if (!B.n_rec) continue;
+            if (k == 0 && !refs.empty() && refs.back().name == B.name) {
+                Ref &A = refs.back();
+                if (B.first_beg < A.last_beg) return PHZ_E_UNSUPPORTED;
+                for (auto &bn : B.bins) {
+                    auto it = A.bin_idx.find(bn.first);
+                    if (it == A.bin_idx.end()) { A.bin_idx.emplace(bn.first, A.bins.size()); A.bins.emplace_back(std::move(bn)); continue; }
+                    auto &dst = A.bins[it->second].second;
+                    size_t from = 0;
+                    if (bn.first == B.first_bin && bn.first == A.last_bin) { dst.back().second = bn.second.front().second; from = 1; }
+                    dst.insert(dst.end(), bn.second.begin() + (long)from, bn.second.end());
+                }
+                if (A.ioff.size() < B.ioff.size()) A.ioff.resize(B.ioff.size(), 0);
+                for (size_t w = 0; w < B.ioff.size(); w++) if (A.ioff[w] == 0) A.ioff[w] = B.ioff[w];
+                A.off_end = B.off_end; A.n_rec += B.n_rec; A.last_beg = B.last_beg; A.last_bin = B.last_bin;
+            } else {
+                if (ref_idx.count(B.name)) return PHZ_E_UNSUPPORTED;           // a contig in two runs
+                ref_idx.emplace(B.name, refs.size());
+                refs.emplace_back(std::move(B));
+            }
+        }
+        return PHZ_OK;
+    }
+
+    // scan() over nt line-aligned pieces of d[0, n) at once, merged in order
+    int scan_parallel(const char *d, size_t n, int preset, int nt) {
+        if (nt > 1 && n / (size_t)nt < (1u << 12)) nt = (int)std::max<size_t>(1, n >> 12);
+        if (nt <= 1) return scan(d, 0, n, preset);
+        std::vector<size_t> cut((size_t)nt + 1, n);
+        cut[0] = 0;
+        for (int t = 1; t < nt; t++) {
+            const size_t at = std::max(cut[(size_t)t - 1], n / (size_t)nt * (size_t)t);
+            const char *nl = at < n ? (const char *)memchr(d + at, '\n', n - at) : nullptr;
+            cut[(size_t)t] = nl ? (size_t)(nl - d) + 1 : n;
+        }
+        std::vector<TbxIndex> part((size_t)nt - 1);
+        std::vector<int> status((size_t)nt, PHZ_OK);
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back([&, t] { status[(size_t)t] = part[(size_t)t - 1].scan(d, cut[(size_t)t], cut[(size_t)t + 1], preset); });
+        status[0] = scan(d, 0, cut[1], preset);
+        for (auto &x : th) x.join();
+        for (int v : status) if (v != PHZ_OK) return v;
+        for (auto &q : part) if (int v = merge(q)) return v;
+        return PHZ_OK;
+    }
+
+    // coff / ustart: compressed offset and uncompressed start of every member, plus one closing entry
+    void serialise(const std::vector<uint64_t> &coff, const std::vector<uint64_t> &ustart, int preset, std::string &o) {
+        auto voff = [&](uint64_t upos) -> uint64_t {
+            size_t b = (size_t)(std::upper_bound(ustart.begin() + 1, ustart.end(), upos) - (ustart.begin() + 1));
+            if (b + 2 > ustart.size()) b = ustart.size() - 2;
+            while (b + 2 < ustart.size() && ustart[b + 1] == ustart[b]) b++;           // skip empty members
+            return (coff[b] << 16) | (upos - ustart[b]);
+        };
+        for (auto &R : refs) {
+            for (size_t w = 1; w < R.ioff.size(); w++) if (R.ioff[w] == 0) R.ioff[w] = R.ioff[w - 1];
+            for (auto &v : R.ioff) v = voff(v);
+            for (auto &b : R.bins) for (auto &c : b.second) { c.first = voff(c.first); c.second = voff(c.second); }
+            R.off_beg = voff(R.off_beg); R.off_end = voff(R.off_end);
+        }
+        o.assign("TBI\1", 4);
+        auto p32 = [&](int32_t v) { o.append((const char *)&v, 4); };
+        auto p64 = [&](uint64_t v) { o.append((const char *)&v, 8); };
+        p32((int32_t)refs.size());
+        if (preset == 0) { p32(2); p32(1); p32(2); p32(0); } else { p32(0x10000); p32(1); p32(2); p32(3); }
+        p32('#'); p32(0);
+        size_t l_nm = 0;
+        for (auto &R : refs) l_nm += R.name.size() + 1;
+        p32((int32_t)l_nm);
+        for (auto &R : refs) { o += R.name; o.push_back('\0'); }
+        for (auto &R : refs) {
+            p32((int32_t)R.bins.size() + 1);
+            for (auto &b : R.bins) {
+                o.append((const char *)&b.first, 4); p32((int32_t)b.second.size());
+                for (auto &c : b.second) { p64(c.first); p64(c.second); }
+            }
+            const uint32_t meta_bin = 37450; o.append((const char *)&meta_bin, 4); p32(2);       // htslib's pseudo-bin: file span + record counts
+            p64(R.off_beg); p64(R.off_end); p64(R.n_rec); p64(0);
+            p32((int32_t)R.ioff.size());
+            for (uint64_t v : R.ioff) p64(v);
+        }
+        p64(0);                                                                                  // n_no_coor
+    }
+};
+}  // namespace
+
 int phz_tabix_build(const char *bgzf_path, int preset, int threads) {
     if (!bgzf_path || (preset != 0 && preset != 1)) return PHZ_E_ARG;
     // member table (compressed offset, uncompressed start) + inflated text
@@ -1356,134 +1568,32 @@ int phz_tabix_build(const char *bgzf_path, int preset, int threads) {
         coff.push_back(off); ustart.push_back(u);
     }
     munmap((void *)f, fsz);
+    if (coff.size() < 2) return PHZ_E_ARG;
     RawBuf text;
     if (int s2 = inflate_bgzf_file(bgzf_path, threads, text)) return s2;
-    const char *d = (const char *)text.data(); const size_t n = text.size();
-    size_t vb = 0;                       // lines are visited front to back: the member of a position only moves forward
-    auto voff = [&](uint64_t upos) -> uint64_t {
-        size_t b = vb;
-        if (ustart[b] > upos) b = 0;
-        while (b + 2 < ustart.size() && ustart[b + 1] <= upos) b++;
-        vb = b;
-        while (b + 2 < ustart.size() && ustart[b + 1] == ustart[b]) b++;           // skip empty members
-        return (coff[b] << 16) | (upos - ustart[b]);
-    };
-    struct Ref {
-        std::string name;
-        std::vector<std::pair<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;   // in order of first use
-        std::unordered_map<uint32_t, size_t> bin_idx;
-        std::vector<uint64_t> ioff;
-        uint64_t off_beg = 0, off_end = 0, n_rec = 0;
-        int64_t last_beg = -1;
-    };
-    std::vector<Ref> refs;
-    std::unordered_map<std::string, size_t> ref_idx;
-    size_t p = 0;
-    int64_t last_ref = -1; uint32_t last_bin = 0xffffffffu;
-    while (p < n) {
-        const char *nl = (const char *)memchr(d + p, '\n', n - p);
-        const size_t e = nl ? (size_t)(nl - d) : n;
-        const size_t next = nl ? e + 1 : n;
-        if (e > p && d[p] != '#') {
-            // columns
-            const char *c0 = d + p; const char *le = d + e;
-            const char *t1 = (const char *)memchr(c0, '\t', (size_t)(le - c0));
-            if (!t1) return PHZ_E_ARG;
-            const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
-            const std::string_view chrom_sv(c0, (size_t)(t1 - c0));
-            int64_t beg, end;
-            auto to_ll = [](const char *a, const char *z) {           // strtoll(..., 10) of [a, z): blanks, sign, digits
-                while (a < z && (*a == ' ' || *a == '\t')) a++;
-                bool neg = false;
-                if (a < z && (*a == '-' || *a == '+')) { neg = *a == '-'; a++; }
-                long long v = 0;
-                while (a < z && *a >= '0' && *a <= '9') { v = v * 10 + (*a - '0'); a++; }
-                return neg ? -v : v;
-            };
-            const long long v1 = to_ll(t1 + 1, t2 ? t2 : le);
-            if (preset == 0) {          // VCF: POS is 1-based, the record covers len(REF) bases unless INFO carries END=
-                beg = v1 - 1;
-                const char *t3 = t2 ? (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1)) : nullptr;        // end of ID
-                const char *t4 = t3 ? (const char *)memchr(t3 + 1, '\t', (size_t)(le - t3 - 1)) : nullptr;        // end of REF
-                end = beg + (t3 && t4 ? (int64_t)(t4 - t3 - 1) : 1);
-                const char *t = t4; int col = 4;
-                while (t && col < 7) { t = (const char *)memchr(t + 1, '\t', (size_t)(le - t - 1)); col++; }      // t = tab before INFO
-                if (t) {
-                    const char *ie = (const char *)memchr(t + 1, '\t', (size_t)(le - t - 1));
-                    std::string_view info(t + 1, (size_t)((ie ? ie : le) - t - 1));
-                    size_t q = 0;
-                    while (q < info.size()) {
-                        size_t r = info.find(';', q); if (r == std::string_view::npos) r = info.size();
-                        if (info.substr(q, 4) == "END=") { const long long ev = to_ll(info.data() + q + 4, info.data() + r); if (ev > beg) end = ev; }
-                        q = r + 1;
-                    }
-                }
-            } else {                    // BED: 0-based start, end exclusive
-                if (!t2) return PHZ_E_ARG;
-                const char *t3 = (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1));
-                beg = v1;
-                end = to_ll(t2 + 1, t3 ? t3 : le);
-            }
-            if (beg < 0) beg = 0;
-            if (end <= beg) end = beg + 1;
-            size_t ri;
-            if (last_ref >= 0 && refs[(size_t)last_ref].name == chrom_sv) ri = (size_t)last_ref;        // the common case: same contig as the line before
-            else {
-                const std::string chrom(chrom_sv);
-                auto it = ref_idx.find(chrom);
-                if (it == ref_idx.end()) { ri = refs.size(); ref_idx.emplace(chrom, ri); refs.emplace_back(); refs.back().name = chrom; }
-                else ri = it->second;
-            }
-            Ref &R = refs[ri];
-            // tabix needs every contig in one run and ascending starts inside it (it refuses such files too)
-            if (((int64_t)ri != last_ref && R.n_rec) || ((int64_t)ri == last_ref && beg < R.last_beg)) return PHZ_E_UNSUPPORTED;
-            R.last_beg = beg;
-            const uint64_t v0 = voff(p), v1e = voff(next);
-            if ((int64_t)ri != last_ref) { last_bin = 0xffffffffu; last_ref = (int64_t)ri; if (!R.n_rec) R.off_beg = v0; }
-            R.off_end = v1e; R.n_rec++;
-            const uint32_t bin = (uint32_t)reg2bin(beg, end);
-            if (bin != last_bin || R.bins.empty()) {
-                auto bi = R.bin_idx.find(bin);
-                size_t k;
-                if (bi == R.bin_idx.end()) { k = R.bins.size(); R.bin_idx.emplace(bin, k); R.bins.emplace_back(bin, std::vector<std::pair<uint64_t, uint64_t>>()); }
-                else k = bi->second;
-                R.bins[k].second.emplace_back(v0, v1e);
-                last_bin = bin;
-            } else {
-                R.bins[R.bin_idx[bin]].second.back().second = v1e;
-            }
-            const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
-            if (R.ioff.size() <= w1) R.ioff.resize(w1 + 1, 0);
-            for (size_t w = w0; w <= w1; w++) if (R.ioff[w] == 0) R.ioff[w] = v0;
-        }
-        p = next;
-    }
-    // serialise
-    std::string o("TBI\1", 4);
-    auto p32 = [&](int32_t v) { o.append((const char *)&v, 4); };
-    auto p64 = [&](uint64_t v) { o.append((const char *)&v, 8); };
-    p32((int32_t)refs.size());
-    if (preset == 0) { p32(2); p32(1); p32(2); p32(0); } else { p32(0x10000); p32(1); p32(2); p32(3); }
-    p32('#'); p32(0);
-    size_t l_nm = 0;
-    for (auto &R : refs) l_nm += R.name.size() + 1;
-    p32((int32_t)l_nm);
-    for (auto &R : refs) { o += R.name; o.push_back('\0'); }
-    for (auto &R : refs) {
-        p32((int32_t)R.bins.size() + 1);
-        for (auto &b : R.bins) {
-            o.append((const char *)&b.first, 4); p32((int32_t)b.second.size());
-            for (auto &c : b.second) { p64(c.first); p64(c.second); }
-        }
-        const uint32_t meta_bin = 37450; o.append((const char *)&meta_bin, 4); p32(2);       // htslib's pseudo-bin: file span + record counts
-        p64(R.off_beg); p64(R.off_end); p64(R.n_rec); p64(0);
-        for (size_t w = 1; w < R.ioff.size(); w++) if (R.ioff[w] == 0) R.ioff[w] = R.ioff[w - 1];
-        p32((int32_t)R.ioff.size());
-        for (uint64_t v : R.ioff) p64(v);
-    }
-    p64(0);                                                                                  // n_no_coor
+    TbxIndex ix;
+    if (int s3 = ix.scan_parallel((const char *)text.data(), text.size(), preset, std::min(16, n_threads(threads)))) return s3;
+    std::string o;
+    ix.serialise(coff, ustart, preset, o);
     const std::string out_path = std::string(bgzf_path) + ".tbi";
-    return phz_bgzf_write(out_path.c_str(), o.data(), (int64_t)o.size(), 1, 6);
+    return phz_bgzf_write(out_path.c_str(), o.data(), (int64_t)o.size(), std::min(16, n_threads(threads)), 6);
+}
+
+// phz_bgzf_write + phz_tabix_build of the same text in one call: the index scan runs beside the deflate workers and nothing is read
+// back.  The .gz is written in any case; PHZ_E_UNSUPPORTED = the text is not position-sorted, no .tbi written (as tabix refuses).
+int phz_bgzf_write_indexed(const char *path, const char *data, int64_t len, int threads, int level, int preset) {
+    if (preset != 0 && preset != 1) return PHZ_E_ARG;
+    TbxIndex ix;
+    int scan_status = PHZ_OK;
+    std::vector<uint64_t> coff, ustart;
+    const int scan_threads = std::min(16, n_threads(threads));
+    const int st = bgzf_write_impl(path, data, len, threads, level, [&] { scan_status = ix.scan_parallel(data, (size_t)len, preset, scan_threads); }, &coff, &ustart);
+    if (st != PHZ_OK) return st;
+    if (scan_status != PHZ_OK) return scan_status;
+    std::string o;
+    ix.serialise(coff, ustart, preset, o);
+    const std::string out_path = std::string(path) + ".tbi";
+    return phz_bgzf_write(out_path.c_str(), o.data(), (int64_t)o.size(), scan_threads, 6);
 }
 
 }  // extern "C"

@@ -261,19 +261,38 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
 // Insertions follow the reference's keying (key = genome offset - 1 at the I op, looked up SEGMENT-relative): while seg_start is 0
 // that is the last base of the op before the I (found by peeking at the next op); after an N the key lands seg_start bases further
 // on, i.e. in a later run of the same segment (carried forward in two register slots, the later insertion wins).
-__device__ __forceinline__ int lds_lower_bound(const int32_t *w, int wlen, int key) {
-    int base = 0, n = wlen;
-    while (n > 1) {
-        const int half = n >> 1;
-        base += (w[base + half - 1] < key) ? half : 0;
-        n -= half;
+// Lower bound over the staged window, branch-free per step: the window is padded with INT_MAX up to MAP_WIN entries, so a probe needs
+// no bounds test, and the number of steps (wave-uniform, computed once per tile from the window length) selects the entry point of a
+// fully unrolled halving chain -- three vector instructions and one LDS read per step, no loop bookkeeping on the scalar unit.
+__device__ __forceinline__ int window_depth(int wlen) {          // steps 2^(d-1) .. 1, then one closing probe: reaches every count <= wlen
+    const int d = wlen > 0 ? 32 - __builtin_clz((unsigned)wlen) : 0;
+    constexpr int dmax = 31 - __builtin_clz((unsigned)MAP_WIN);
+    return d < dmax ? d : dmax;
+}
+__device__ __forceinline__ int lds_lower_bound(const int32_t *w, int depth, int key) {
+    static_assert(MAP_WIN >= 2 && MAP_WIN <= 1024 && (MAP_WIN & (MAP_WIN - 1)) == 0, "MAP_WIN: a power of two up to 1024");
+    int base = 0;
+#define PHZ_LB_STEP(S) base = (w[base + (S) - 1] < key) ? base + (S) : base
+    switch (depth) {
+    default: PHZ_LB_STEP(512); [[fallthrough]];
+    case 9: PHZ_LB_STEP(256); [[fallthrough]];
+    case 8: PHZ_LB_STEP(128); [[fallthrough]];
+    case 7: PHZ_LB_STEP(64); [[fallthrough]];
+    case 6: PHZ_LB_STEP(32); [[fallthrough]];
+    case 5: PHZ_LB_STEP(16); [[fallthrough]];
+    case 4: PHZ_LB_STEP(8); [[fallthrough]];
+    case 3: PHZ_LB_STEP(4); [[fallthrough]];
+    case 2: PHZ_LB_STEP(2); [[fallthrough]];
+    case 1: PHZ_LB_STEP(1); [[fallthrough]];
+    case 0: break;
     }
-    base += (wlen > 0 && w[base] < key) ? 1 : 0;
+#undef PHZ_LB_STEP
+    base += (w[base] < key) ? 1 : 0;
     return base;
 }
 
-__device__ bool walk_lean(const int32_t *s_vpos, int wlen, int w0, const uint32_t *s_cig, uint32_t c_begin, uint32_t cig_cap,
-                          const CandBuf &cb, uint32_t *s_poison, int j, int pos, uint32_t c0, uint32_t c1, long long cover) {
+__device__ bool walk_lean(const int32_t *s_vpos, int wlen, int wdepth, int w0, const uint32_t *s_cig, uint32_t c_begin, uint32_t cig_cap,
+                          const CandBuf &cb, uint32_t *s_poison, int j, int pos, uint32_t c0, uint32_t c1, long long cover, int dbg) {
     if (c1 - c_begin > cig_cap) return false;
     int g = 0, seg_start = 0, cnt = 0, nins = 0; uint32_t r = 0;
     bool bad = false;
@@ -291,13 +310,13 @@ __device__ bool walk_lean(const int32_t *s_vpos, int wlen, int w0, const uint32_
             }
         }
         bad |= op == OP_G;
-        const bool search = mlike || op == OP_D;
+        const bool search = (mlike || op == OP_D) && !(dbg & 64);
         if (__builtin_amdgcn_ballot_w64(search) != 0) {
             const int lo = pos + g;
             bad |= search && (long long)lo + len > cover;                       // the run must lie inside the staged window
             const int hi = (search && !bad) ? lo + len : lo;
-            int i = lds_lower_bound(s_vpos, wlen, lo);
-            while (i < wlen) {
+            int i = lds_lower_bound(s_vpos, wdepth, lo);
+            while (i < wlen && !(dbg & 128)) {
                 const int vp = s_vpos[i];
                 if (vp >= hi) break;
                 uint32_t ioff = 0, ilen = 0;
@@ -492,11 +511,12 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     }
     if (tid == 0) { s_coff[TILE] = coff_end; s_ncand = 0; s_ncx = 0; s_nlong = 0; }
     if (tid < TILE / 32) s_poison[tid] = 0;
-    if (tid < vw.wlen) s_vpos[tid] = v_first;
-    for (int j = tid + MAP_BLOCK; j < vw.wlen; j += MAP_BLOCK) {
+    if (tid < MAP_WIN) s_vpos[tid] = v_first;                       // INT_MAX beyond the window: lds_lower_bound probes without a bounds test
+    for (int j = tid + MAP_BLOCK; j < MAP_WIN; j += MAP_BLOCK) {
         const int idx = vw.w0 + j;
-        s_vpos[j] = idx < a.nv ? a.vpos[idx] : 0x7fffffff;
+        s_vpos[j] = (j < vw.wlen && idx < a.nv) ? a.vpos[idx] : 0x7fffffff;
     }
+    const int wdepth = window_depth(vw.wlen);
 #pragma unroll
     for (int u = 0; u < 3; u++) { const uint32_t j = (uint32_t)tid + (uint32_t)u * MAP_BLOCK; if (j < cnt_w) s_cig[j] = cg[u]; }
     for (uint32_t j = (uint32_t)tid + 3u * MAP_BLOCK; j < cnt_w; j += MAP_BLOCK) s_cig[j] = a.cigar[cw.c_begin + j];
@@ -544,16 +564,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         if ((lane / GROUP) == 2 * k) target = first;
         if ((lane / GROUP) == 2 * k + 1) target = e;
     }
-    int bound = 0;
-    {
-        int n = vw.wlen;
-        while (n > 1) {
-            const int half = n >> 1;
-            bound += (s_vpos[bound + half - 1] < target) ? half : 0;
-            n -= half;
-        }
-        bound += (vw.wlen > 0 && s_vpos[bound] < target) ? 1 : 0;
-    }
+    const int bound = lds_lower_bound(s_vpos, wdepth, target);
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
         const int j = k * MAP_BLOCK + tid;
@@ -569,13 +580,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
                 }
                 if (c <= 8) { fast_[k] = true; base_[k] = lo + below; n_[k] = c; }
             } else {
-                int base = 0, n = vw.wlen;
-                while (n > 1) {
-                    const int half = n >> 1;
-                    base += (s_vpos[base + half - 1] < pos) ? half : 0;
-                    n -= half;
-                }
-                base += (s_vpos[base] < pos) ? 1 : 0;
+                const int base = lds_lower_bound(s_vpos, wdepth, pos);
                 int c = 0;
                 while (base + c < vw.wlen && s_vpos[base + c] < end && c <= 8) c++;
                 if (c <= 8) { fast_[k] = true; base_[k] = base; n_[k] = c; }
@@ -611,7 +616,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     for (int t = tid; t < ncx; t += MAP_BLOCK) {
         const int ts = t < nshort ? t : TILE - 1 - (t - nshort);
         const int j = s_cx[ts];
-        const bool done = lean_on && walk_lean(s_vpos, vw.wlen, vw.w0, s_cig, cw.c_begin, (uint32_t)CIG, cb, s_poison, j, s_pos[j], s_coff[j], s_coff[j + 1], cover);
+        const bool done = lean_on && walk_lean(s_vpos, vw.wlen, wdepth, vw.w0, s_cig, cw.c_begin, (uint32_t)CIG, cb, s_poison, j, s_pos[j], s_coff[j], s_coff[j + 1], cover, a.dbg);
         if (!done) { s_cx[ts] = (uint16_t)(j | 0x8000); redo_any = true; }
     }
     if (__syncthreads_or(redo_any ? 1 : 0)) {

@@ -350,8 +350,7 @@ def main(argv=None):
                 raise werr[0]
             mark("phased VCF text (+ the five files on a helper thread)")
             say("     Compressing and tabix indexing output VCF...")
-            vcfout.write_bgzf(args.o + ".vcf.gz", vtxt, max(0, args.threads if args.threads > 1 else 0))
-            if not vcfout.tabix_index(args.o + ".vcf.gz", "vcf", max(0, args.threads if args.threads > 1 else 0)):
+            if not vcfout.write_bgzf(args.o + ".vcf.gz", vtxt, max(0, args.threads if args.threads > 1 else 0), index="vcf"):
                 say("     WARNING: the VCF is not position-sorted, no tabix index written")
             mark("phased VCF bgzf + tabix")
         say('')

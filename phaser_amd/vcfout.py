@@ -74,8 +74,10 @@ def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", 
         lib.phz_buf_free(out)
 
 
-def write_bgzf(path: str, text, threads: int = 0):
-    """BGZF-compress the phased VCF text (what the reference gets from `bgzip`, phaser.py:1851) with the native parallel writer."""
+def write_bgzf(path: str, text, threads: int = 0, index: str = None) -> bool:
+    """BGZF-compress the phased VCF text (what the reference gets from `bgzip`, phaser.py:1851) with the native parallel writer.
+    index: "vcf" / "bed" also writes <path>.tbi (`tabix -p ... -f`) from the text in memory while it is being compressed; returns
+    False when that index was refused (text not position-sorted: the .gz is written, tabix refuses such files as well)."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -86,9 +88,15 @@ def write_bgzf(path: str, text, threads: int = 0):
     else:
         data = text.encode() if isinstance(text, str) else bytes(text)
         ptr, n = C.cast(C.c_char_p(data), C.c_void_p), len(data)
-    st = lib.phz_bgzf_write(path.encode(), ptr, n, int(threads), 6)
+    if index is not None:
+        st = lib.phz_bgzf_write_indexed(path.encode(), ptr, n, int(threads), 6, {"vcf": 0, "bed": 1}[index])
+        if st == _lib.PHZ_E_UNSUPPORTED:
+            return False
+    else:
+        st = lib.phz_bgzf_write(path.encode(), ptr, n, int(threads), 6)
     if st != _lib.PHZ_OK:
         raise _lib.PhzError(st, "phz_bgzf_write(%s) failed" % path)
+    return True
 
 
 def tabix_index(path: str, preset: str = "vcf", threads: int = 0) -> bool:

@@ -163,3 +163,40 @@ def test_tabix_refuses_unsorted(tmp_path):
     q = str(tmp_path / "v.bed.gz")
     vcfout.write_bgzf(q, "chr1\t100\t200\ta\nchr2\t100\t200\tb\nchr1\t300\t400\tc\n")
     assert vcfout.tabix_index(q, "bed") is False
+
+
+def test_one_call_write_and_index_equals_the_two_steps(tmp_path):
+    """phz_bgzf_write_indexed (index gathered from the text in memory, next to the deflate workers) writes byte for byte the files
+    that phz_bgzf_write followed by phz_tabix_build (index from the re-read file) writes -- VCF over hundreds of members, BED, empty."""
+    from phaser_amd import _lib, synth, vcfout
+    _lib.build()
+    vs = []
+    for i, (c, ln) in enumerate((("chr1", 40_000_000), ("chr2", 25_000_000), ("chrX", 900_000))):
+        v, gs, ge, w = synth.make_variants(c, 1, ln, 30_000 if ln > 1_000_000 else 50, 23 + i, n_genes=1500 if ln > 1_000_000 else 3)
+        vs.append(v)
+    vcf = "\n".join(synth.vcf_lines(vs)) + "\n"
+    bed = "#chr\tstart\tend\tname\n" + "".join("chr%d\t%d\t%d\tg%d\n" % (1 + k // 400, 1000 * (k % 400), 1000 * (k % 400) + 1 + 37 * (k % 11), k) for k in range(1200))
+    for name, text, preset in (("a.vcf.gz", vcf, "vcf"), ("b.bed.gz", bed, "bed"), ("e.vcf.gz", "", "vcf"), ("h.vcf.gz", "##only a header\n", "vcf")):
+        two = str(tmp_path / ("two_" + name)); one = str(tmp_path / ("one_" + name))
+        vcfout.write_bgzf(two, text, 3)
+        assert vcfout.tabix_index(two, preset, 1) is True               # one thread: one scan over the whole text
+        for threads in (5, 16):                                         # the index merged from 5 / 16 separately scanned pieces
+            assert vcfout.write_bgzf(one, text, threads, index=preset) is True
+            assert open(one, "rb").read() == open(two, "rb").read()
+            assert open(one + ".tbi", "rb").read() == open(two + ".tbi", "rb").read()
+        three = str(tmp_path / ("three_" + name))
+        vcfout.write_bgzf(three, text, 2)
+        assert vcfout.tabix_index(three, preset, 7) is True
+        assert open(three + ".tbi", "rb").read() == open(two + ".tbi", "rb").read()
+    _check(str(tmp_path / "one_a.vcf.gz"), _vcf_span, n_queries=80, seed=9)
+    # unsorted text: the .gz is written, the index refused
+    u = str(tmp_path / "u.bed.gz")
+    assert vcfout.write_bgzf(u, "chr1\t500\t600\ta\nchr1\t100\t200\tb\n", index="bed") is False
+    assert gzip.open(u, "rb").read() == b"chr1\t500\t600\ta\nchr1\t100\t200\tb\n" and not os.path.exists(u + ".tbi")
+    # disorder that only shows at a seam between two pieces: a start going backwards / a contig coming back
+    rows = ["chr1\t%d\t%d\tx" % (100 * k, 100 * k + 50) for k in range(400)]
+    back = rows[:200] + ["chr1\t5\t9\tlate"] + rows[200:]
+    again = rows[:200] + ["chr2\t5\t9\tother"] + rows[200:]
+    for bad in (back, again):
+        assert vcfout.write_bgzf(u, "\n".join(bad) + "\n", 4, index="bed") is False
+    assert vcfout.write_bgzf(u, "\n".join(rows) + "\n", 4, index="bed") is True
