@@ -166,6 +166,37 @@ def main(argv=None):
         arena = threading.Thread(target=_arena, daemon=True)
         arena.start()
     data = vcf.read_bytes(args.vcf)
+    # The first BAM is inflated / decoded / filtered on the GPU (PCIe- and GPU-bound) WHILE the host parses the VCF: the stages share
+    # nothing but the names of the chromosomes to keep, which are guessed from the text here (vcf.contig_names_guess) and checked
+    # against the parsed table below -- a guess that does not cover the table discards the prefetch and the BAM is read as before.
+    pre = None
+    if (world == 1 and args.chr == "" and n_dev and os.environ.get("PHZ_BAM_HOST") != "1" and os.environ.get("PHZ_BAM_PREFETCH", "1") == "1"
+            and not any(b.endswith(".sam") for b in bam_list)):
+        guess = [args.chr_prefix + c for c in vcf.contig_names_guess(data)]
+        if guess:
+            pre = {"guess": set(guess), "ready": threading.Event()}
+            try:
+                pre["key"] = (int(args.mapq.split(",")[0]), float(args.isize.split(",")[0]), int(args.paired_end.split(",")[0]))
+            except ValueError:
+                pre = None
+        if pre is not None:
+            def _prefetch():
+                try:
+                    from .mapper import Mapper
+                    pre["mapper"] = Mapper(local)
+                    pre["ready"].set()
+                    its = {}
+                    mq0, isz0, pe0 = pre["key"]
+                    pre["shards"] = bamio.shards_from_bam_device(pre["mapper"].ctx, bam_list[0], its, mq0, args.remove_dups == 1, pe0 == 1, isz0, chroms=guess,
+                                                                 device="cuda:%d" % local)
+                    pre["interners"] = its
+                except BaseException as e:               # reported by the ordinary path, which runs instead
+                    pre["err"] = e
+                finally:
+                    pre["ready"].set()
+
+            pre["thread"] = threading.Thread(target=_prefetch, daemon=True)
+            pre["thread"].start()
     sample_col = None
     for raw in data.split(b"\n", 20000)[:20000]:          # the header sits at the top
         if b"#CHR" in raw:
@@ -226,7 +257,9 @@ def main(argv=None):
                  id_separator=args.id_separator, unphased_vars=args.unphased_vars, gw_phase_method=args.gw_phase_method,
                  output_read_ids=args.output_read_ids, unique_ids=args.unique_ids, haplo_count_bam_exclude=excl, py_hash_order=args.py_hash_order,
                  include_indels=args.include_indels, host_threads=max(1, args.threads))
-    eng = Engine(vs, bam_names, cfg, device=local)
+    if pre is not None:
+        pre["ready"].wait()
+    eng = Engine(vs, bam_names, cfg, device=local, mapper=pre.get("mapper") if pre is not None else None)
     eng.spool_dir = os.path.dirname(os.path.abspath(args.o))       # ranks hand their row text to rank 0 through files next to the outputs
     device = "cuda:%d" % local
     interners: Dict[str, object] = {}
@@ -275,7 +308,23 @@ def main(argv=None):
             # BGZF inflate + record decode + filters + packing on the GPU (phz_bamdev_*); files it declines, and PHZ_BAM_HOST=1, go
             # through the host decoder (phz_bam_*, --threads host threads).  QNAME interning is host-side in both.
             shards = None
-            if os.environ.get("PHZ_BAM_HOST") != "1":
+            declined = False
+            if bi == 0 and pre is not None:
+                pre["thread"].join()
+                verdict = "discarded (%s)" % ("error in the prefetch" if "err" in pre else "chromosomes %s not in the guess" % sorted(mine - pre["guess"])
+                                              if not mine <= pre["guess"] else "filters differ")
+                if "err" not in pre and mine <= pre["guess"] and pre["key"] == (int(mq), isz, int(pe)):
+                    if pre.get("shards") is None:
+                        declined = True                  # the device path declined the file: straight to the host decoder
+                        verdict = "device path declined the file"
+                    else:
+                        shards = {c: s for c, s in pre["shards"].items() if c in mine}
+                        interners.update({c: it for c, it in pre["interners"].items() if c in mine})
+                        verdict = "used"
+                if os.environ.get("PHZ_TIMING"):
+                    sys.stderr.write("[phz timing]   bam prefetch during the VCF parse: %s\n" % verdict)
+                pre.pop("shards", None); pre.pop("interners", None)
+            if shards is None and not declined and os.environ.get("PHZ_BAM_HOST") != "1":
                 shards = bamio.shards_from_bam_device(eng.ctx, bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
                                                       device=device)
             if shards is None:

@@ -129,6 +129,57 @@ def read_bytes(path: str, threads: int = 0) -> bytes:
         return f.read()
 
 
+def contig_names_guess(data: bytes, max_probes: int = 50000):
+    """Distinct CHROM values of a VCF text whose contigs come in runs (every tabix-able file), found by bisection between line probes:
+    O(contigs x log lines) line lookups instead of a pass over the text.  A GUESS: a contig scattered inside another contig's run can
+    be missed -- callers check the result against the parsed table (phaser.main does, before it trusts the BAM prefetch)."""
+    n = len(data)
+    p = 0
+    while p < n and data[p:p + 1] == b"#":
+        j = data.find(b"\n", p)
+        if j < 0:
+            return []
+        p = j + 1
+    if p >= n:
+        return []
+
+    def line_at(off):                    # start of the first line that begins at or after off
+        if off <= p:
+            return p
+        j = data.find(b"\n", off - 1)
+        return n if j < 0 else j + 1
+
+    def chrom(s):
+        e = data.find(b"\n", s)
+        t = data.find(b"\t", s, n if e < 0 else e)
+        return data[s:t] if t > 0 else None
+
+    last = data.rfind(b"\n", 0, n - 1) + 1 if n > 1 else 0
+    if last < p:
+        last = p
+    names = {}
+    stack = [(p, last)]
+    probes = 0
+    while stack:
+        a, b = stack.pop()
+        ca, cb = chrom(a), chrom(b)
+        for c in (ca, cb):
+            if c:
+                names[c] = 1
+        if ca == cb or a >= b:
+            continue
+        m = line_at((a + b) // 2)
+        if m >= b:
+            m = line_at(a + 1)
+            if m >= b:
+                continue                 # neighbours
+        probes += 1
+        if probes > max_probes:
+            return []
+        stack.append((a, m)); stack.append((m, b))
+    return [c.decode("latin1") for c in names]
+
+
 def load_variants(vcf_text, sample_column: int = 9, chrom_of_interest: str = "", pass_only: int = 1,
                   include_indels: int = 0, chr_prefix: str = "", id_separator: str = "_", gw_phase_method: int = 0,
                   gw_af_field: str = "AF", contig_ban=("_", ":"), threads: int = 8, grep_hom: bool = False,

@@ -376,6 +376,60 @@ def test_cli_blacklist_beds_match_reference(tmp_path):
     assert any(int(r[6]) > 0 for r in ase)           # some block really lost a variant to the haplotype-count blacklist
 
 
+def test_cli_bam_prefetch_equals_the_plain_order(tmp_path, monkeypatch, capfd):
+    """The first BAM is decoded on the GPU while the VCF is parsed, for the chromosomes vcf.contig_names_guess names (phaser.main).  The
+    files must be the ones the plain order (PHZ_BAM_PREFETCH=0: VCF first, then the BAM for the parsed table's chromosomes) writes --
+    with a BAM that holds a reference the VCF lacks, a VCF contig without a het site, two BAMs, and with a VCF whose contigs do NOT
+    come in runs (the guess misses one: the prefetch has to be thrown away)."""
+    import gzip
+    from phaser_amd import bamio, phaser, synth, vcf
+    refs = [("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrM", 16569)]
+    vs, rbs1, rbs2 = [], [], []
+    for i, c in enumerate(("chr20", "chr21", "chr22", "chrM")):
+        v, gs, ge, w = synth.make_variants(c, 1, 2_000_000 if c != "chrM" else 16000, 260 if c != "chrM" else 12, 301 + i, n_genes=14 if c != "chrM" else 1)
+        if c != "chrM":
+            vs.append(v)                                  # chrM: reads in the BAMs, no variants in the first VCF
+        else:
+            v_m = v
+        rbs1.append(synth.make_reads(v, gs, ge, w, 5000 if c != "chrM" else 300, 401 + i))
+        rbs2.append(synth.make_reads(v, gs, ge, w, 3000 if c != "chrM" else 200, 501 + i))
+    b1, b2 = str(tmp_path / "t1.bam"), str(tmp_path / "t2.bam")
+    bamio.readbatch_to_bam(b1, rbs1, refs); bamio.readbatch_to_bam(b2, rbs2, refs)
+    lines = synth.vcf_lines(vs)
+    head = [l for l in lines if l.startswith("#")]; body = [l for l in lines if not l.startswith("#")]
+    homs = ["chr19\t%d\t.\tA\tG\t50\tPASS\t.\tGT\t1|1" % (100 * k) for k in range(1, 40)]            # a contig with no het site, first in the file
+    runs = "\n".join(head + homs + body) + "\n"
+    # two chrM het sites in the middle of the chr20 run and nowhere else: the bisection does not see them
+    k20 = max(i for i, l in enumerate(body) if l.startswith("chr20\t")) // 2
+    scattered = "\n".join(head + homs + body[:k20] + [l for l in synth.vcf_lines([v_m]) if not l.startswith("#")][:2] + body[k20:]) + "\n"
+    assert "chrM" not in vcf.contig_names_guess(scattered.encode())
+    assert sorted(vcf.contig_names_guess(runs.encode())) == ["chr19", "chr20", "chr21", "chr22"]
+
+    def run(text, tag, prefetch):
+        vp = str(tmp_path / (tag + ".vcf.gz"))
+        with gzip.open(vp, "wt") as f:
+            f.write(text)
+        monkeypatch.setenv("PHZ_BAM_PREFETCH", prefetch)
+        monkeypatch.setenv("PHZ_TIMING", "1")
+        prefix = str(tmp_path / (tag + "_" + prefetch))
+        assert phaser.main(["--vcf", vp, "--bam", b1 + "," + b2, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1", "--o", prefix,
+                            "--write_vcf", "1", "--threads", "3"]) == 0
+        out = {name: open(prefix + "." + name + ".txt").read() for name in OUTPUTS}
+        out["vcf"] = gzip.open(prefix + ".vcf.gz", "rt").read()
+        return out
+
+    plain = run(runs, "runs", "0")
+    assert len(plain["haplotypes"].split("\n")) > 20 and "\nchr22\t" in plain["haplotypes"] and "\tt2\t" in plain["haplotypic_counts"]
+    assert "bam prefetch" not in capfd.readouterr().err
+    assert run(runs, "runs", "1") == plain
+    assert "bam prefetch during the VCF parse: used" in capfd.readouterr().err
+    sc_plain = run(scattered, "scat", "0")
+    assert "\nchrM\t" in sc_plain["allelic_counts"]
+    capfd.readouterr()
+    assert run(scattered, "scat", "1") == sc_plain
+    assert "bam prefetch during the VCF parse: discarded (chromosomes ['chrM'] not in the guess)" in capfd.readouterr().err
+
+
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_two_ranks_one_gpu_real_kernels(tmp_path, backend):
     """The multi-rank path with REAL kernels on both ranks: chromosomes LPT-assigned, per-BAM AS histograms all-reduced, noise counters

@@ -179,3 +179,32 @@ def test_long_ref_is_refused_not_truncated():
     assert vcf.load_variants(text).het_count == 0                    # SNP mode: the indel is simply excluded
     with pytest.raises(_lib.PhzError):
         vcf.load_variants(text, include_indels=1)
+
+
+def test_contig_names_guess():
+    """vcf.contig_names_guess finds every contig of a text whose contigs come in runs (any run lengths, header or not, last line with or
+    without a newline) with a handful of line probes; it is allowed to miss a contig scattered inside another run -- never to invent one."""
+    import random
+    from phaser_amd import vcf
+    rng = random.Random(5)
+    for trial in range(60):
+        n_contigs = rng.choice([1, 2, 3, 7, 40])
+        names = ["c%d_%s" % (k, "x" * rng.randint(0, 5)) for k in range(n_contigs)]
+        rng.shuffle(names)
+        lines = []
+        for c in names:
+            run = rng.choice([1, 1, 2, 3, 50, 4000]) if trial % 3 else 1
+            pos = 1
+            for _ in range(run):
+                pos += rng.randint(1, 900)
+                lines.append("%s\t%d\t.\tA\tG\t.\tPASS\t.\tGT\t0|1" % (c, pos))
+        head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n" if trial % 2 else ""
+        text = head + "\n".join(lines) + ("\n" if trial % 5 else "")
+        assert sorted(vcf.contig_names_guess(text.encode())) == sorted(names)
+    assert vcf.contig_names_guess(b"") == [] and vcf.contig_names_guess(b"##h\n#CHROM\n") == []
+    assert vcf.contig_names_guess(b"chr1\t5\t.\tA\tG\n") == ["chr1"]
+    # a stray contig inside a run: found or not, but nothing that is not in the text
+    body = ["chr1\t%d\t.\tA\tG" % (10 * k) for k in range(1, 3000)]
+    body.insert(1234, "chrStray\t7\t.\tA\tG")
+    got = set(vcf.contig_names_guess(("\n".join(body) + "\n").encode()))
+    assert "chr1" in got and got <= {"chr1", "chrStray"}
