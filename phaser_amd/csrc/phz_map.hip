@@ -258,6 +258,9 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
 //   * what the pass cannot express ('G' ops, a third insertion, an insertion not directly after a non-empty reference-consuming op,
 //     a run beyond the window) is found on the way: the record is POISONED (its lean-origin candidates, key bit 15, are dropped by
 //     the resolve phase) and left to the general walker.
+// (Tried and dropped, round 3: a second, bookkeeping-free walker for the pure spliced shapes M N M / M N M N M, listed apart.  It runs
+// in half the instructions of this one, but a 256-record tile has ~80 multi-op records: split by shape they fill three partial waves
+// instead of two, the instruction total does not move and the extra barrier lengthens the tile: 1.57 ms against 1.28 ms.)
 // Insertions follow the reference's keying (key = genome offset - 1 at the I op, looked up SEGMENT-relative): while seg_start is 0
 // that is the last base of the op before the I (found by peeking at the next op); after an N the key lands seg_start bases further
 // on, i.e. in a later run of the same segment (carried forward in two register slots, the later insertion wins).
@@ -609,7 +612,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     __syncthreads();
     // ---- phase 1b: spliced / gapped / clipped records, densely re-packed so the divergent walk runs on full waves
     const int nshort = walk_on ? s_ncx : 0;
-    const int ncx = walk_on ? nshort + s_nlong : 0;
+    const int ncx = (walk_on && !(a.dbg & 256)) ? nshort + s_nlong : 0;       // dbg 256: multi-op records listed but not walked
     const bool lean_on = complete && !(a.dbg & 32);
     // 1b: the lean walker first (one lane per multi-op record, densely packed); what it declines is redone by the general walker
     bool redo_any = false;
@@ -913,7 +916,10 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
 }  // namespace
 
 // All shards of a submission run through ONE grid per stage (pre-pass, k_map, tile scan, per-shard totals, compaction): a whole
-// genome is 5 launches and one host wait, with no per-shard ramp-up / tail.  A batch whose densest tile overflows its staging slot
+// genome is 5 launches and one host wait, with no per-shard ramp-up / tail.
+// (Tried and dropped, round 3: k_map writing every call to its final place, the calls before a tile found by decoupled look-back over
+// per-tile status words -- no staging, no k_compact.  A tile knows its count only at the END of its work (the count needs the quality
+// bytes), so its flush waits for every earlier tile still in flight: 3.01 ms against 1.32 + 0.16 ms for k_map + k_compact.)  A batch whose densest tile overflows its staging slot
 // is redone with larger slots (rare: the slot capacity is kept across calls).
 int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out,
                          int64_t *n_calls) {
