@@ -93,6 +93,18 @@ def load_bed(path: str) -> List[tuple]:
 
 
 def main(argv=None):
+    """The CLI.  Whatever way it ends (result, fatal_error, exception), a BAM prefetch still running on its helper thread is waited for:
+    the interpreter must not start tearing down with GPU work of ours in flight."""
+    state = {}
+    try:
+        return _main(argv, state)
+    finally:
+        t = state.get("prefetch")
+        if t is not None and t.is_alive():
+            t.join()
+
+
+def _main(argv, state):
     args = build_parser().parse_args(argv)
     rank, world = pdist.world()
     # torch's intra-op pool sized by the container's CPU quota, not by the host's core count (see dist.effective_cpus)
@@ -195,7 +207,8 @@ def main(argv=None):
                 finally:
                     pre["ready"].set()
 
-            pre["thread"] = threading.Thread(target=_prefetch, daemon=True)
+            pre["thread"] = threading.Thread(target=_prefetch, daemon=True, name="phz-bam-prefetch")
+            state["prefetch"] = pre["thread"]
             pre["thread"].start()
     sample_col = None
     for raw in data.split(b"\n", 20000)[:20000]:          # the header sits at the top

@@ -430,6 +430,24 @@ def test_cli_bam_prefetch_equals_the_plain_order(tmp_path, monkeypatch, capfd):
     assert "bam prefetch during the VCF parse: discarded (chromosomes ['chrM'] not in the guess)" in capfd.readouterr().err
 
 
+def test_cli_fatal_error_waits_for_the_prefetch(tmp_path):
+    """A fatal_error raised while the BAM prefetch is running (here: the sample is not in the VCF, found right after the prefetch was started)
+    leaves main() only when that thread is done -- no GPU work of ours is in flight when the interpreter goes down."""
+    import gzip, threading
+    from phaser_amd import bamio, phaser, synth
+    v, gs, ge, w = synth.make_variants("chr22", 1, 3_000_000, 300, 201, n_genes=20)
+    rb = synth.make_reads(v, gs, ge, w, 60000, 203)
+    bam = str(tmp_path / "a.bam")
+    bamio.readbatch_to_bam(bam, [rb], [("chr22", 50818468)])
+    vcfgz = str(tmp_path / "in.vcf.gz")
+    with gzip.open(vcfgz, "wt") as f:
+        f.write("\n".join(synth.vcf_lines([v])) + "\n")
+    with pytest.raises(SystemExit):
+        phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "NOT_THERE", "--mapq", "255", "--baseq", "10", "--paired_end", "1", "--o", str(tmp_path / "o"),
+                     "--threads", "2"])
+    assert not any(t.name == "phz-bam-prefetch" and t.is_alive() for t in threading.enumerate())
+
+
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_two_ranks_one_gpu_real_kernels(tmp_path, backend):
     """The multi-rank path with REAL kernels on both ranks: chromosomes LPT-assigned, per-BAM AS histograms all-reduced, noise counters
