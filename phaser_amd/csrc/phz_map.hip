@@ -210,7 +210,7 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
                     const uint32_t x1 = ilen > 0 ? (((uint32_t)ioff << 12) | (uint32_t)(ilen > 4095 ? 4095 : ilen)) : 0u;
                     if (MODE == 0) {
                         // code 7 = one character, to be resolved from seq/qual; 4 = composite text (always a call)
-                        const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicAdd(cb.n, 1 << 20), 1 << 20);
+                        const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicOr(cb.n, 1 << 30), 1 << 30);      // OR, not ADD: thousands of these in one tile must not wrap the counter
                         if (slot < cb.cap) {
                             cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)cnt << 8) | (nchars == 1 ? 7u : 4u);
                             cb.var[slot] = i;
@@ -334,7 +334,7 @@ __device__ bool walk_lean(const int32_t *s_vpos, int wlen, int wdepth, int w0, c
                 }
                 const int nchars = (mlike ? 1 : 0) + (int)ilen;
                 if (nchars > 0) {
-                    const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicAdd(cb.n, 1 << 20), 1 << 20);
+                    const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicOr(cb.n, 1 << 30), 1 << 30);      // OR, not ADD: thousands of these in one tile must not wrap the counter
                     if (slot < cb.cap) {
                         cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)(cnt | 0x80) << 8) | (nchars == 1 ? 7u : 4u);
                         cb.var[slot] = w0 + i;

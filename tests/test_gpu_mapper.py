@@ -103,6 +103,27 @@ def test_random_vs_oracle(mapper, oracle_build, n_pairs, n_snps, baseq, seed):
         assert txt == o_t[k]
 
 
+@pytest.mark.parametrize("n_snps", [1500, 3000, 7800])
+def test_dense_windows_vs_oracle(mapper, oracle_build, n_snps):
+    """Het SNPs packed into six short genes: the staged window of a tile holds anything from 8 to several thousand entries, so the
+    tiles of one shard exercise every entry depth of the unrolled window search (2^d <= window < 2^(d+1), up to the 512 staged
+    entries), windows exactly at and beyond that capacity (truncated: the LDS-only walkers are off, the general walker reads the
+    table) and records with tens of het SNPs under them."""
+    from phaser_amd import soa, synth
+    v, gs, ge, w = synth.make_variants("chr1", 1, 2_000_000, n_snps, 11, n_genes=6)
+    rb = synth.make_reads(v, gs, ge, w, 60000, 12, n_rate=0.002)
+    rb = rb.select(synth.samtools_keep(rb, 255))
+    pos = rb.pos.numpy().astype(np.int64); vp = v.pos.numpy().astype(np.int64)
+    first = pos[::256]; last = pos[np.minimum(np.arange(255, len(pos) + 255, 256), len(pos) - 1)]
+    wl = np.searchsorted(vp, last + 65536) - np.searchsorted(vp, first) + 8
+    depths = set(int(x).bit_length() for x in wl if x <= 512)
+    assert len(depths) >= 3 and (n_snps < 3000 or (wl > 512).any())    # the inputs do what the docstring says
+    o_r, o_v, o_c, o_t = oracle_map_readbatch(oracle_build, rb, v.pos.numpy(), 10)
+    calls = mapper.map(soa.pack_readbatch(rb).to("cuda"), v.pos, 10).cpu()
+    assert calls.n == len(o_r) and calls.n > 10000
+    assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v) and np.array_equal(calls.code.numpy(), o_c)
+
+
 def test_long_records_wide_offsets(mapper, oracle_build):
     """Offsets of the called base at and beyond 2^16 and calls carrying inserted text leave the packed 8-byte staging record
     (side planes, phz_map.hip stage_put): single-run and multi-op records of 200 kb against the oracle, offsets and text included."""
