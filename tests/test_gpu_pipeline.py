@@ -210,6 +210,48 @@ def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pair
     assert eng.stats["rowsdev_n_big_segments"] > 0
 
 
+@pytest.mark.parametrize("seed,n_snps,err,pairs,mbs,L", [(9201, 400, 0.003, 3000, 15, 76), (9202, 1500, 0.03, 2500, 10, 76), (9301, 1500, 0.01, 200, 15, 1000)])
+def test_dense_variants_vs_oracle(mapper, oracle_build, tmp_path, seed, n_snps, err, pairs, mbs, L):
+    """Het SNPs every 5-40 bp inside a few genes: a read covers up to ~20 of them (the mapper's candidate buffers past the 8-call fast
+    path), a QNAME contributes hundreds of variant pairs (long groups in the tally tiles), components run to hundreds of variants and,
+    with 3 % base errors, have to be split and stitched.  The third case has 1,000-base reads: ~60 calls per read (past the 32 ordinals
+    of the candidate buffer: in-lane fallback of the mapper), ~7,000 variant pairs per QNAME.  Product vs the pinned oracle; device row
+    stage vs host row stage."""
+    import subprocess
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import phasing_oracle as po
+    from phaser_amd import synth
+    contigs = [("chr7", 159345973)]
+    chrom = "chr7"
+    v, gs, ge, w = synth.make_variants(chrom, 1, 600_000, n_snps, seed, n_genes=4)
+    bams = {"d1.bam": {}, "d2.bam": {}}
+    for bi, bam in enumerate(bams):
+        rb = synth.make_reads(v, gs, ge, w, pairs, seed + bi + 100, L=L, qname_prefix="q", err_rate=err)
+        rf = rb.select(synth.samtools_keep(rb, 255))
+        bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf_text = "\n".join(synth.vcf_lines([v])) + "\n"
+    got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs)
+    host, heng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs, device_rows=False)
+    assert heng.rows_path == "host"
+    for name in OUTPUTS:
+        assert got[name] == host[name], (name, eng.rows_path)
+    pool, _, _ = po.load_vcf(vcf_text)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs)
+    for bam, per_chrom in bams.items():
+        texts = []
+        for c in pool:
+            tp = tmp_path / "t.tsv"; tp.write_text("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+            op = tmp_path / "c.tsv"
+            subprocess.run([os.path.join(oracle_build, "rvm_oracle"), "--variant_table", str(tp), "--baseq", "10", "--o", str(op)],
+                           input=per_chrom[c].encode(), check=True)
+            texts.append(op.read_text())
+        ph.add_bam(texts)
+    want = ph.finish()
+    for name in OUTPUTS:
+        assert canonical(name, got[name]) == canonical(name, want[name]), name
+    assert eng.phased == ph.phased and eng.phased > 100
+
+
 @pytest.mark.parametrize("src,mode", [("pipe_one", 0), ("pipe_one", 1), ("pipe_one", 2), ("pipe_noisy_c", 2), ("pipe_two", 1)])
 def test_phased_vcf_matches_reference(mapper, src, mode):
     """write_vcf (phaser.py:1661-1855): the phased VCF text equals what the reference wrote, byte for byte."""
