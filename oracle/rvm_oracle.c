@@ -31,16 +31,15 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAX_INS 64
-
+/* No fixed capacities anywhere in this file: the reference keeps CIGAR operations in a list and insertions in a dict, so a record
+ * with hundreds of operations or insertions (long, indel-rich reads) must come out the same.  (Until round 3 the array front end cut a
+ * CIGAR at 64 operations and a segment kept 64 insertions -- silently; tests/test_gpu_mapper.py::test_many_op_records_vs_oracle found it
+ * when the PRODUCT, which has no such cap, disagreed with this file and agreed with the reference.) */
 typedef struct {
     int start;          /* genome_start: offset of the segment from POS (:207 first field) */
     char *pseudo;       /* pseudo_read */
     int plen;
-    int n_ins;
-    int ins_key[MAX_INS];
-    const char *ins_ptr[MAX_INS];
-    int ins_len[MAX_INS];
+    int ins_first, n_ins;       /* the segment's insertions: entries [ins_first, ins_first + n_ins) of the split's insertion arrays */
 } segment_t;
 
 typedef struct {
@@ -50,9 +49,22 @@ typedef struct {
     int nb;
     char *pool;         /* storage for pseudo reads */
     size_t pool_cap;
+    int *ins_key; const char **ins_ptr; int *ins_len;       /* insertions of all segments of the record (the dict of :217-222, per segment) */
+    int ins_n, ins_cap;
 } split_t;
 
-static void split_free(split_t *s) { free(s->seg); free(s->masked); free(s->pool); memset(s, 0, sizeof *s); }
+static void split_free(split_t *s) { free(s->seg); free(s->masked); free(s->pool); free(s->ins_key); free((void *)s->ins_ptr); free(s->ins_len); memset(s, 0, sizeof *s); }
+
+/* growable (op, length) list of one CIGAR */
+typedef struct { char *op; int *len; int n, cap; } ops_t;
+static void ops_push(ops_t *o, char c, int len) {
+    if (o->n == o->cap) {
+        o->cap = o->cap ? 2 * o->cap : 64;
+        o->op = (char *)realloc(o->op, (size_t)o->cap); o->len = (int *)realloc(o->len, (size_t)o->cap * sizeof(int));
+    }
+    o->op[o->n] = c; o->len[o->n++] = len;
+}
+static void ops_free(ops_t *o) { free(o->op); free(o->len); memset(o, 0, sizeof *o); }
 
 static segment_t *new_segment(split_t *s, int start, char *pseudo) {
     if (s->n_seg == s->cap_seg) {
@@ -61,7 +73,7 @@ static segment_t *new_segment(split_t *s, int start, char *pseudo) {
     }
     segment_t *g = &s->seg[s->n_seg++];
     memset(g, 0, sizeof *g);
-    g->start = start; g->pseudo = pseudo;
+    g->start = start; g->pseudo = pseudo; g->ins_first = s->ins_n;
     return g;
 }
 
@@ -77,7 +89,7 @@ static int clamp_slice(int a, int len, int n, int *from) {
 static void split_read(split_t *s, const char *seq, int nseq, const char *qual, int nqual, int baseq,
                        const char *op, const int *oplen, int n_ops) {
     int nb = nseq < nqual ? nseq : nqual;
-    s->n_seg = 0;
+    s->n_seg = 0; s->ins_n = 0;
     s->masked = (char *)realloc(s->masked, nb + 1);
     s->nb = nb;
     for (int i = 0; i < nb; i++) s->masked[i] = ((int)(unsigned char)qual[i] - 33 >= baseq) ? seq[i] : 'N';
@@ -104,9 +116,17 @@ static void split_read(split_t *s, const char *seq, int nseq, const char *qual, 
         } else if (c == 'I') {
             int from, cnt = clamp_slice(read_pos, len, nb, &from);
             int key = genome_pos - 1, slot = -1;
-            for (int k = 0; k < cur->n_ins; k++) if (cur->ins_key[k] == key) slot = k;   /* dict overwrite */
-            if (slot < 0 && cur->n_ins < MAX_INS) slot = cur->n_ins++;
-            if (slot >= 0) { cur->ins_key[slot] = key; cur->ins_ptr[slot] = s->masked + from; cur->ins_len[slot] = cnt; }
+            for (int k = cur->ins_first; k < cur->ins_first + cur->n_ins; k++) if (s->ins_key[k] == key) slot = k;   /* dict overwrite */
+            if (slot < 0) {
+                if (s->ins_n == s->ins_cap) {
+                    s->ins_cap = s->ins_cap ? 2 * s->ins_cap : 64;
+                    s->ins_key = (int *)realloc(s->ins_key, (size_t)s->ins_cap * sizeof(int));
+                    s->ins_ptr = (const char **)realloc((void *)s->ins_ptr, (size_t)s->ins_cap * sizeof(char *));
+                    s->ins_len = (int *)realloc(s->ins_len, (size_t)s->ins_cap * sizeof(int));
+                }
+                slot = s->ins_n++; cur->n_ins++;
+            }
+            s->ins_key[slot] = key; s->ins_ptr[slot] = s->masked + from; s->ins_len[slot] = cnt;
             read_pos += len;
         } else if (c == 'S') {
             read_pos += len;
@@ -115,14 +135,14 @@ static void split_read(split_t *s, const char *seq, int nseq, const char *qual, 
 }
 
 /* read_variant_map.py:236-258; returns allele length (0 = no call), writes into out (cap bytes) */
-static int identify_allele(const segment_t *g, int read_pos, int vpos, int ref_len, char *out, int cap) {
+static int identify_allele(const split_t *s, const segment_t *g, int read_pos, int vpos, int ref_len, char *out, int cap) {
     int rs = vpos - (read_pos + g->start), re = rs + ref_len, n = 0;
     if (rs < 0 || re > g->plen) return 0;
     for (int p = rs; p < re; p++) {
         char c = g->pseudo[p];
         if (c != 'D' && n < cap) out[n++] = c;
-        for (int k = 0; k < g->n_ins; k++) if (g->ins_key[k] == p)
-            for (int j = 0; j < g->ins_len[k]; j++) { char d = g->ins_ptr[k][j]; if (d != 'D' && n < cap) out[n++] = d; }
+        for (int k = g->ins_first; k < g->ins_first + g->n_ins; k++) if (s->ins_key[k] == p)
+            for (int j = 0; j < s->ins_len[k]; j++) { char d = s->ins_ptr[k][j]; if (d != 'D' && n < cap) out[n++] = d; }
     }
     if (n == 1 && out[0] == 'N') return 0;
     return n;
@@ -148,21 +168,21 @@ long rvm_oracle_map_soa(long n, const int32_t *pos, const int64_t *cigar_off, co
                         long cap, int32_t *o_read, int32_t *o_var, uint8_t *o_code, char *o_str) {
     split_t s; memset(&s, 0, sizeof s);
     char *sq = (char *)malloc(L + 1), *ql = (char *)malloc(L + 1);
-    char ops[64]; int lens[64];
+    ops_t o; memset(&o, 0, sizeof o);
     long nc = 0;
     int max_reflen = 1;
     for (long i = 0; i < nv; i++) if (vreflen[i] > max_reflen) max_reflen = vreflen[i];
     for (long r = 0; r < n; r++) {
         for (int j = 0; j < L; j++) { sq[j] = "ACGTN"[seq[r * L + j] > 4 ? 4 : seq[r * L + j]]; ql[j] = (char)(qual[r * L + j] + 33); }
-        int no = (int)(cigar_off[r + 1] - cigar_off[r]); if (no > 64) no = 64;
-        for (int k = 0; k < no; k++) { uint32_t c = cigar[cigar_off[r] + k]; ops[k] = OPCH[c & 15]; lens[k] = (int)(c >> 4); }
-        split_read(&s, sq, L, ql, L, baseq, ops, lens, no);
+        o.n = 0;
+        for (int64_t k = cigar_off[r]; k < cigar_off[r + 1]; k++) { uint32_t c = cigar[k]; ops_push(&o, OPCH[c & 15], (int)(c >> 4)); }
+        split_read(&s, sq, L, ql, L, baseq, o.op, o.len, o.n);
         for (int g = 0; g < s.n_seg; g++) {
             const segment_t *sg = &s.seg[g];
             long lo = (long)pos[r] + sg->start, hi = lo + sg->plen;
             for (long v = lower_bound_i32(vpos, nv, lo); v < nv && vpos[v] < hi; v++) {
                 char buf[32];
-                int len = identify_allele(sg, pos[r], vpos[v], vreflen[v], buf, 31);
+                int len = identify_allele(&s, sg, pos[r], vpos[v], vreflen[v], buf, 31);
                 if (!len) continue;
                 if (nc < cap) {
                     o_read[nc] = (int32_t)r; o_var[nc] = (int32_t)v;
@@ -175,25 +195,26 @@ long rvm_oracle_map_soa(long n, const int32_t *pos, const int64_t *cigar_off, co
             }
         }
     }
-    free(sq); free(ql); split_free(&s);
+    free(sq); free(ql); split_free(&s); ops_free(&o);
     return nc;
 }
 
 /* Known-answer front end: one record given as text, one variant; returns allele per segment joined by '|' */
 int rvm_oracle_kat(int pos, const char *seq, const char *qual, const char *cigar, int baseq, int vpos, int ref_len,
                    char *out, int cap) {
-    char ops[256]; int lens[256]; int no = 0; long num = 0;
+    ops_t o; memset(&o, 0, sizeof o); long num = 0;
     if (strcmp(cigar, "*") != 0)
-        for (const char *p = cigar; *p && no < 256; p++) {
+        for (const char *p = cigar; *p; p++) {
             if (isdigit((unsigned char)*p)) num = num * 10 + (*p - '0');
-            else { ops[no] = *p; lens[no++] = (int)num; num = 0; }
+            else { ops_push(&o, *p, (int)num); num = 0; }
         }
     split_t s; memset(&s, 0, sizeof s);
-    split_read(&s, seq, (int)strlen(seq), qual, (int)strlen(qual), baseq, ops, lens, no);
+    split_read(&s, seq, (int)strlen(seq), qual, (int)strlen(qual), baseq, o.op, o.len, o.n);
+    ops_free(&o);
     int n = 0;
     for (int g = 0; g < s.n_seg; g++) {
         char buf[256];
-        int len = identify_allele(&s.seg[g], pos, vpos, ref_len, buf, 255);
+        int len = identify_allele(&s, &s.seg[g], pos, vpos, ref_len, buf, 255);
         if (g && n < cap - 1) out[n++] = '|';
         for (int j = 0; j < len && n < cap - 1; j++) out[n++] = buf[j];
     }
@@ -239,6 +260,7 @@ int main(int argc, char **argv) {
     fclose(ft);
     FILE *fo = fopen(outp, "w"); if (!fo) { perror(outp); return 2; }
     split_t s; memset(&s, 0, sizeof s);
+    ops_t cig; memset(&cig, 0, sizeof cig);
     char **col = NULL; int ccap = 0;
     char *abuf = (char *)malloc(1 << 16);
     while ((ll = getline(&line, &lcap, stdin)) > 0) {
@@ -258,17 +280,18 @@ int main(int argc, char **argv) {
             const char *c2 = strchr(col[i] + 3, ':');
             if (c2) { snprintf(as_norm, sizeof as_norm, "%ld", atol(c2 + 1)); as_str = as_norm; }
         }
-        char ops[1024]; int lens[1024]; int no = 0; long num = 0;
-        for (const char *c = col[5]; *c && no < 1024; c++) {
+        long num = 0;
+        cig.n = 0;
+        for (const char *c = col[5]; *c; c++) {
             if (*c >= '0' && *c <= '9') num = num * 10 + (*c - '0');
-            else { ops[no] = *c; lens[no++] = (int)num; num = 0; }
+            else { ops_push(&cig, *c, (int)num); num = 0; }
         }
-        split_read(&s, col[9], (int)strlen(col[9]), col[10], (int)strlen(col[10]), baseq, ops, lens, no);
+        split_read(&s, col[9], (int)strlen(col[9]), col[10], (int)strlen(col[10]), baseq, cig.op, cig.len, cig.n);
         for (int g = 0; g < s.n_seg; g++) {
             const segment_t *sg = &s.seg[g];
             long lo = (long)read_pos + sg->start, hi = lo + sg->plen;
             for (long v = lower_bound_i32(vpos, nv, lo); v < nv && vpos[v] < hi; v++) {
-                int len = identify_allele(sg, read_pos, vars[v].pos, vars[v].ref_len, abuf, (1 << 16) - 1);
+                int len = identify_allele(&s, sg, read_pos, vars[v].pos, vars[v].ref_len, abuf, (1 << 16) - 1);
                 if (!len) continue;
                 abuf[len] = 0;
                 fprintf(fo, "%s\t%s\t%s\t%s\t%s\t%s\t%s\n", col[0], vars[v].id, vars[v].rsid, abuf, as_str, vars[v].gt, vars[v].maf);

@@ -124,6 +124,66 @@ def test_dense_windows_vs_oracle(mapper, oracle_build, n_snps):
     assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v) and np.array_equal(calls.code.numpy(), o_c)
 
 
+@pytest.mark.parametrize("seed,max_gap_ops,snp_every", [(31, 4, 25), (32, 40, 25), (33, 40, 6)])
+def test_many_op_records_vs_oracle(mapper, oracle_build, seed, max_gap_ops, snp_every):
+    """Thousands of records made of many short runs (the shape of long, indel-rich reads): M / = / X runs separated by I, D and N in random
+    order, soft clips at the ends, 400 bases each.  With up to 40 gaps per record a 256-record tile has ten times the CIGAR words its LDS
+    staging holds (the general walker reads the operators from global memory), the runs are a few bases long so insertions sit next to het SNPs
+    all the time (composite calls, text compared), and with a het SNP every 6 bases a record has up to ~60 calls.  All of it against the C oracle."""
+    from phaser_amd import soa, synth
+    from phaser_amd.read_variant_map import _allele_text
+    rng = np.random.default_rng(seed)
+    L, n = 400, 6000
+    OP = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "=": 7, "X": 8}
+    words = []; coff = [0]; span = []
+    for _ in range(n):
+        ops = []
+        left = L
+        lead = int(rng.integers(0, 15)) if rng.random() < 0.3 else 0
+        trail = int(rng.integers(0, 15)) if rng.random() < 0.3 else 0
+        if lead: ops.append(("S", lead)); left -= lead
+        left -= trail
+        gaps = int(rng.integers(1, max_gap_ops + 1))
+        ref = 0
+        for g in range(gaps):
+            run = int(rng.integers(1, max(2, left // (gaps - g + 1) + 1)))
+            run = min(run, left - (gaps - g))           # keep a base for every later run
+            if run < 1: break
+            ops.append((str(rng.choice(["M", "M", "M", "=", "X"])), run)); left -= run; ref += run
+            kind = str(rng.choice(["I", "D", "N", "N"]))
+            if kind == "I":
+                k = int(rng.integers(1, 6)); k = min(k, left - 1)
+                if k < 1: continue
+                ops.append(("I", k)); left -= k
+            elif kind == "D":
+                k = int(rng.integers(1, 9)); ops.append(("D", k)); ref += k
+            else:
+                k = int(rng.integers(20, 3000)); ops.append(("N", k)); ref += k
+        if ops and ops[-1][0] in "IDN":                 # a record does not end on a gap
+            pass
+        ops.append(("M", left)); ref += left
+        if trail: ops.append(("S", trail))
+        assert sum(k for o, k in ops if o in "MIS=X") == L
+        words += [(k << 4) | OP[o] for o, k in ops]; coff.append(len(words)); span.append(ref)
+    pos = np.sort(rng.integers(1000, 600_000, n)).astype(np.int32)
+    z = torch.zeros(n, dtype=torch.int32)
+    rb = synth.ReadBatch("chr1", L, torch.from_numpy(pos), z, torch.full((n,), 255, dtype=torch.uint8), z, z, torch.arange(n, dtype=torch.int32),
+                         torch.tensor(coff, dtype=torch.int64), torch.tensor(words, dtype=torch.int64),
+                         torch.from_numpy(rng.integers(0, 4, (n, L)).astype(np.uint8)), torch.from_numpy(rng.integers(2, 41, (n, L)).astype(np.uint8)))
+    vpos = np.unique(rng.integers(900, 600_000 + max(span) + 100, (600_000 + max(span)) // snp_every)).astype(np.int32)
+    o_r, o_v, o_c, o_t = oracle_map_readbatch(oracle_build, rb, vpos, 10)
+    calls = mapper.map(soa.pack_readbatch(rb).to("cuda"), torch.from_numpy(vpos), 10).cpu()
+    assert calls.n == len(o_r) and calls.n > 20000
+    assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v) and np.array_equal(calls.code.numpy(), o_c)
+    comp = np.nonzero(o_c == 4)[0]
+    assert len(comp) > 50                                # insertions next to het SNPs did occur
+    lut = "ACGTN"
+    for k in comp[:1500]:
+        r = int(o_r[k])
+        seq = "".join(lut[x] for x in rb.seq[r].tolist()); qual = "".join(chr(33 + q) for q in rb.qual[r].tolist())
+        assert _allele_text(4, int(calls.aux0[k]) & 0xFFFFFFFF, int(calls.aux1[k]) & 0xFFFFFFFF, seq, qual, 10) == o_t[k]
+
+
 def test_long_records_wide_offsets(mapper, oracle_build):
     """Offsets of the called base at and beyond 2^16 and calls carrying inserted text leave the packed 8-byte staging record
     (side planes, phz_map.hip stage_put): single-run and multi-op records of 200 kb against the oracle, offsets and text included."""

@@ -29,9 +29,16 @@ for rd in range(rounds):
     pos = 90
     for r in range(rng.randint(20, 60)):
         pos += rng.randint(0, 40)
-        nops = rng.randint(1, 7)
-        cig = "".join("%d%s" % (rng.choice([0, 1, 2, 3, 5, 8, 13, 30, 76, 200]), rng.choice(OPS)) for _ in range(nops)) or "*"
-        qlen = rng.choice([0, 1, 5, 20, 76, 100, 150])
+        if rng.random() < 0.12:          # a long, indel-rich record: hundreds of operations, more than 64 insertions in one segment
+            nops = rng.randint(80, 400)
+            parts = [(rng.choice([1, 1, 2, 3, 5]), rng.choice("MMMIIDD=X" if rng.random() < 0.97 else "N")) for _ in range(nops)]
+            cig = "".join("%d%s" % p_ for p_ in parts)
+            qlen = sum(k for k, o in parts if o in "MI=XS") + rng.choice([0, 0, -3, 4])
+            qlen = max(0, qlen)
+        else:
+            nops = rng.randint(1, 7)
+            cig = "".join("%d%s" % (rng.choice([0, 1, 2, 3, 5, 8, 13, 30, 76, 200]), rng.choice(OPS)) for _ in range(nops)) or "*"
+            qlen = rng.choice([0, 1, 5, 20, 76, 100, 150])
         seq = "".join(rng.choice("ACGTACGTACGTNRYK") for _ in range(qlen)) or "*"
         if rng.random() < 0.1:
             qual = "*"
