@@ -192,6 +192,30 @@ def test_device_decoder_odd_records(ctx, tmp_path):
     _same(host, dev, "odd records")
 
 
+@pytest.mark.parametrize("L,pairs", [(30000, 30), (100000, 12)])
+def test_long_reads_through_the_device_decoder_and_k_map(ctx, tmp_path, oracle_build, L, pairs):
+    """Records of 30,000 / 100,000 bases (45 - 150 KB each: every record spans several BGZF members, a read covers hundreds of het
+    SNPs): the device decoder's shards are the host decoder's array by array, and K_map on them gives the C oracle's calls for the
+    arrays the BAM was written from."""
+    import numpy as np
+    import torch
+    from helpers import oracle_map_readbatch
+    from phaser_amd import bamio, synth
+    from phaser_amd.mapper import Mapper
+    v, gs, ge, w = synth.make_variants("chr22", 1, 3_000_000, 3000, 5, n_genes=8)
+    rb = synth.make_reads(v, gs, ge, w, pairs, 6, L=L)
+    path = str(tmp_path / "long.bam")
+    bamio.readbatch_to_bam_native(path, [rb], [("chr22", 50818468)])
+    host = bamio.shards_from_bam_native(path, {}, 0, False, False, 0.0, threads=2)
+    dev = bamio.shards_from_bam_device(ctx, path, {}, 0, False, False, 0.0)
+    assert dev is not None
+    _same(host, dev, "long reads")
+    calls = Mapper(0, ctx=ctx).map(dev["chr22"], v.pos, 10).cpu()
+    o_r, o_v, o_c, _ = oracle_map_readbatch(oracle_build, rb, v.pos.numpy(), 10, with_text=False)
+    assert calls.n == len(o_r) and calls.n > 50 * len(rb)
+    assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v) and np.array_equal(calls.code.numpy(), o_c)
+
+
 def test_device_path_refuses_what_it_cannot_prove(ctx, tmp_path):
     """An unsorted BAM is declined (None: the host path then raises its own error); a truncated record is an error."""
     import dataclasses
