@@ -14,10 +14,11 @@ subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle")])
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 mapper = Mapper(0)
-CONTIGS = [("chr3", 198295559), ("chr11", 135086622), ("chr19", 58617616)]
+CONTIGS = [("chr3", 198295559), ("chr11", 135086622), ("chr19", 58617616)] + [("ctg%02d" % k, 3_000_000 + 1000 * k) for k in range(40)]
 for it in range(iters):
     rng = random.Random(seed0 + it)
-    nchrom = rng.choice([1, 1, 2, 3]); nbam = rng.choice([1, 1, 2, 3])
+    nchrom = rng.choice([1, 1, 2, 3, 3, 30]); nbam = rng.choice([1, 1, 2, 3, 3, 11])       # now and then: scaffolds by the dozen, a sample of many BAMs
+    many = nchrom * nbam > 9
     contigs = CONTIGS[:nchrom]
     err = rng.choice([0.001, 0.002, 0.02, 0.05, 0.08]); mbs = rng.choice([3, 5, 8, 15])
     cfg = {"max_block_size": mbs}
@@ -29,13 +30,13 @@ for it in range(iters):
     if rng.random() < 0.2: cfg["output_read_ids"] = 1
     vs_ = []; bams = {"x%d.bam" % b: {} for b in range(nbam)}
     for ci, (chrom, ln) in enumerate(contigs):
-        dense = rng.random() < 0.35              # het SNPs every 5-40 bp: tens of calls per read, components of hundreds of variants
+        dense = rng.random() < 0.35 and not many  # het SNPs every 5-40 bp: tens of calls per read, components of hundreds of variants
         v, gs, ge, w = synth.make_variants(chrom, 1, rng.choice([600_000, 1_500_000]), rng.choice([600, 1500]) if dense else rng.choice([60, 150, 260]),
                                            seed0 * 7 + 13 * it + ci, n_genes=rng.choice([2, 4]) if dense else rng.choice([4, 10]))
         L = rng.choice([76, 76, 150, 600]) if dense else rng.choice([76, 76, 76, 150])
         vs_.append(v)
         for bi, bam in enumerate(bams):
-            rb = synth.make_reads(v, gs, ge, w, rng.choice([300, 800]) if (dense and L > 150) else rng.choice([1500, 4000, 7000]), seed0 * 11 + 17 * it + 10 * ci + bi, L=L,
+            rb = synth.make_reads(v, gs, ge, w, rng.choice([300, 800]) if ((dense and L > 150) or many) else rng.choice([1500, 4000, 7000]), seed0 * 11 + 17 * it + 10 * ci + bi, L=L,
                                   qname_prefix="q" if rng.random() < 0.7 else "q%d." % bi, err_rate=err)
             rf = rb.select(synth.samtools_keep(rb, 255))
             bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
