@@ -472,6 +472,40 @@ def test_cli_bam_prefetch_equals_the_plain_order(tmp_path, monkeypatch, capfd):
     assert "bam prefetch during the VCF parse: discarded (chromosomes ['chrM'] not in the guess)" in capfd.readouterr().err
 
 
+def test_four_ranks_from_bams_equal_one_rank(tmp_path):
+    """The CLI from BAM files as four ranks sharing the GPU (gloo) over a sample with three chromosomes: every rank decodes only its own
+    chromosomes on the device (the fourth rank none at all), the files are byte for byte the one-rank run's."""
+    import gzip, subprocess
+    from phaser_amd import bamio, phaser, synth
+    refs = [("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468)]
+    vs, rbs1, rbs2 = [], [], []
+    for i, (c, _) in enumerate(refs):
+        v, gs, ge, w = synth.make_variants(c, 1, 2_000_000, 200 + 40 * i, 601 + i, n_genes=10)
+        vs.append(v)
+        rbs1.append(synth.make_reads(v, gs, ge, w, 4000 + 1500 * i, 701 + i)); rbs2.append(synth.make_reads(v, gs, ge, w, 2500, 801 + i))
+    b1, b2 = str(tmp_path / "t1.bam"), str(tmp_path / "t2.bam")
+    bamio.readbatch_to_bam(b1, rbs1, refs); bamio.readbatch_to_bam(b2, rbs2, refs)
+    vp = str(tmp_path / "in.vcf.gz")
+    with gzip.open(vp, "wt") as f:
+        f.write("\n".join(synth.vcf_lines(vs)) + "\n")
+    common = ["--vcf", vp, "--bam", b1 + "," + b2, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1", "--write_vcf", "1", "--threads", "2"]
+    one = str(tmp_path / "one")
+    assert phaser.main(common + ["--o", one]) == 0
+    four = str(tmp_path / "four")
+    port = 29700 + (os.getpid() % 1000)
+    procs = []
+    for rank in range(4):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="4", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PHZ_DIST_BACKEND="gloo", PYTHONPATH=REPO)
+        procs.append(subprocess.Popen([sys.executable, "-m", "phaser_amd.phaser"] + common + ["--o", four], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    assert "using 4 GPU(s)" in logs[0]
+    for name in OUTPUTS:
+        assert open(four + "." + name + ".txt").read() == open(one + "." + name + ".txt").read(), name
+    assert gzip.open(four + ".vcf.gz", "rb").read() == gzip.open(one + ".vcf.gz", "rb").read()
+    assert len(open(one + ".haplotypes.txt").read().split("\n")) > 50
+
+
 def test_cli_fatal_error_waits_for_the_prefetch(tmp_path):
     """A fatal_error raised while the BAM prefetch is running (here: the sample is not in the VCF, found right after the prefetch was started)
     leaves main() only when that thread is done -- no GPU work of ours is in flight when the interpreter goes down."""
@@ -490,13 +524,13 @@ def test_cli_fatal_error_waits_for_the_prefetch(tmp_path):
     assert not any(t.name == "phz-bam-prefetch" and t.is_alive() for t in threading.enumerate())
 
 
-@pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_two_ranks_one_gpu_real_kernels(tmp_path, backend):
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 2), ("gloo", 3)])
+def test_two_ranks_one_gpu_real_kernels(tmp_path, backend, world):
     """The multi-rank path with REAL kernels on both ranks: chromosomes LPT-assigned, per-BAM AS histograms all-reduced, noise counters
     all-reduced, the fragment tables all-gathered as int64 tensors, row text spooled to files and spliced by rank 0.  The assembled files must be
     what the reference wrote (fixture pipe_two: two BAMs with shared QNAMEs, two chromosomes -> one chromosome per rank).
     backend gloo: the two ranks share the one GPU of the box; backend nccl (= RCCL over xGMI): one rank per GPU, runs where two GPUs are
-    visible and is skipped on a one-GPU box."""
+    visible and is skipped on a one-GPU box.  world 3: the third rank owns no chromosome -- it still has to take part in every collective."""
     import subprocess
     import torch
     if backend == "nccl" and torch.cuda.device_count() < 2:
@@ -510,15 +544,15 @@ def test_two_ranks_one_gpu_real_kernels(tmp_path, backend):
     prefix = str(tmp_path / "out")
     port = 29600 + (os.getpid() % 1000)
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    PHZ_DIST_BACKEND=backend, PYTHONPATH=REPO)
         cmd = [sys.executable, "-m", "phaser_amd.phaser", "--vcf", os.path.join(d, "in.vcf"), "--bam", ",".join(bams), "--sample", "S1",
                "--mapq", "255", "--baseq", "10", "--paired_end", "1", "--o", prefix, "--write_vcf", "0", "--threads", "2"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), logs
-    assert "using 2 GPU(s)" in logs[0] and "phASER" not in logs[1]          # rank 0 speaks, rank 1 is silent
+    assert "using %d GPU(s)" % world in logs[0] and "phASER" not in logs[1]          # rank 0 speaks, rank 1 is silent
     out = {name: open(prefix + "." + name + ".txt").read().replace("\tt1.sam\t", "\tt1\t").replace("\tt2.sam\t", "\tt2\t") for name in OUTPUTS}
     compare(out, d)
     assert not [f for f in os.listdir(tmp_path) if f.startswith("phz_spool_")]          # spool files removed
