@@ -31,10 +31,14 @@ for it in range(iters):
     vs_ = []; names = ["x%d.bam" % b for b in range(nbam)]
     sams = {b: {} for b in names}
     for ci, (chrom, ln) in enumerate(contigs):
-        v, gs, ge, w = synth.make_variants(chrom, 1, rng.choice([600_000, 1_500_000]), rng.choice([60, 150, 260]), seed0 * 7 + 13 * it + ci, n_genes=rng.choice([4, 10]))
+        dense = rng.random() < float(os.environ.get("PHZ_FUZZ_DENSE", "0.3"))      # het SNPs every 5-40 bp: tens of calls per read, components of hundreds of variants
+        v, gs, ge, w = synth.make_variants(chrom, 1, rng.choice([600_000, 1_500_000]), rng.choice([600, 1500]) if dense else rng.choice([60, 150, 260]),
+                                           seed0 * 7 + 13 * it + ci, n_genes=rng.choice([2, 4]) if dense else rng.choice([4, 10]))
         vs_.append(v)
+        L = rng.choice([76, 150, 600]) if dense else 76
         for bi, bam in enumerate(names):
-            rb = synth.make_reads(v, gs, ge, w, rng.choice([1500, 4000]), seed0 * 11 + 17 * it + 10 * ci + bi, qname_prefix="q" if rng.random() < 0.7 else "q%d." % bi, err_rate=err)
+            rb = synth.make_reads(v, gs, ge, w, rng.choice([200, 500]) if (dense and L > 150) else rng.choice([1500, 4000]), seed0 * 11 + 17 * it + 10 * ci + bi, L=L,
+                                  qname_prefix="q" if rng.random() < 0.7 else "q%d." % bi, err_rate=err)
             rf = rb.select(synth.samtools_keep(rb, 255))
             sams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
     vcf_text = "\n".join(synth.vcf_lines(vs_)) + "\n"
