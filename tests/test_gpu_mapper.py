@@ -173,10 +173,10 @@ def test_many_op_records_vs_oracle(mapper, oracle_build, seed, max_gap_ops, snp_
     vpos = np.unique(rng.integers(900, 600_000 + max(span) + 100, (600_000 + max(span)) // snp_every)).astype(np.int32)
     o_r, o_v, o_c, o_t = oracle_map_readbatch(oracle_build, rb, vpos, 10)
     calls = mapper.map(soa.pack_readbatch(rb).to("cuda"), torch.from_numpy(vpos), 10).cpu()
-    assert calls.n == len(o_r) and calls.n > 20000
+    assert calls.n == len(o_r) and (calls.n > 20000 or snp_every > 25)
     assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v) and np.array_equal(calls.code.numpy(), o_c)
     comp = np.nonzero(o_c == 4)[0]
-    assert len(comp) > 50                                # insertions next to het SNPs did occur
+    assert len(comp) > 50 or snp_every > 25 or max_gap_ops < 4      # insertions next to het SNPs did occur
     lut = "ACGTN"
     for k in comp[:1500]:
         r = int(o_r[k])
