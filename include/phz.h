@@ -25,7 +25,11 @@
  *
  * Conventions
  *   - every function returns 0 (PHZ_OK) or a negative phz_status; nothing throws across the ABI.
- *   - a phz_ctx owns one HIP stream and scratch buffers; it is NOT thread-safe, use one per thread/GPU.
+ *   - a phz_ctx owns one HIP stream, scratch buffers, the resident tally and an error string.  Calls on ONE ctx are serialised by a
+ *     lock inside the ctx (thread-safe per phz_ctx): two threads that share a ctx take turns, whole call by whole
+ *     call, and phz_last_error() then reports the LAST failing call of either.  For concurrency use one ctx per thread -- several
+ *     may sit on one GPU, and device objects created through one (phz_rowsdev_create's tables) may be used through another ctx of
+ *     the same device once the creating call has returned.
  *   - `space` says where the caller's pointers live: PHZ_HOST (the library stages through HBM itself)
  *     or PHZ_DEVICE (pointers are device pointers on the ctx's GPU; zero copies, used when the shard is
  *     already resident in HBM).

@@ -18,6 +18,12 @@
  * stateless per (record, segment, variant) -- SURVEY.md 3.3 -- so this file enumerates the
  * candidate variants of each segment directly.  Input contract (same as the reference's use
  * from phaser.py:1346): one chromosome per run, reads coordinate-sorted, variant table sorted.
+ * The text front end (main) also follows the buffer on a stream that is NOT coordinate-sorted, where
+ * it is not stateless: the buffer is the index range [b_lo, L) of the table -- L = variants consumed
+ * so far (:88-93 skips those behind the record, :106-112 appends up to the segment's end; neither
+ * ever rewinds), b_lo = consumed variants pruned because they lay behind some earlier record (:37-50,
+ * done for EVERY record, also one the isize filter drops) -- and a record that steps backwards only
+ * sees what is still inside it (pinned by tests/golden/mapper_unsorted/).
  *
  * Quirks reproduced on purpose (each has a known-answer fixture):
  *   - insertion keys are read-relative (:220) but looked up segment-relative (:246-251)
@@ -263,6 +269,7 @@ int main(int argc, char **argv) {
     ops_t cig; memset(&cig, 0, sizeof cig);
     char **col = NULL; int ccap = 0;
     char *abuf = (char *)malloc(1 << 16);
+    long b_lo = 0, L = 0;       /* the reference's variant buffer = table entries [b_lo, L) */
     while ((ll = getline(&line, &lcap, stdin)) > 0) {
         while (ll && (line[ll - 1] == '\n' || line[ll - 1] == '\r' || line[ll - 1] == ' ' || line[ll - 1] == '\t')) line[--ll] = 0; /* rstrip */
         if (line[0] == '@') continue;
@@ -274,7 +281,13 @@ int main(int argc, char **argv) {
         if (nc < 11) continue;
         int read_pos = atoi(col[3]);
         long tl = labs(atol(col[8]));
-        if (!(isize == 0 || (double)tl <= isize)) continue;
+        {   /* :37-50: consumed variants behind this record leave the buffer, whatever happens to the record afterwards */
+            long lb = lower_bound_i32(vpos, nv, read_pos);
+            long cut = lb < L ? lb : L;
+            if (cut > b_lo) b_lo = cut;
+            if (!(isize == 0 || (double)tl <= isize)) continue;
+            if (L < lb) { L = lb; b_lo = lb; }      /* :88-93: variants behind the record are skipped for good */
+        }
         const char *as_str = ""; char as_norm[32];
         for (int i = 11; i < nc; i++) if (!strncmp(col[i], "AS:", 3)) {      /* last AS: tag wins (:56-59) */
             const char *c2 = strchr(col[i] + 3, ':');
@@ -290,7 +303,10 @@ int main(int argc, char **argv) {
         for (int g = 0; g < s.n_seg; g++) {
             const segment_t *sg = &s.seg[g];
             long lo = (long)read_pos + sg->start, hi = lo + sg->plen;
-            for (long v = lower_bound_i32(vpos, nv, lo); v < nv && vpos[v] < hi; v++) {
+            while (L < nv && vpos[L] <= hi) L++;      /* :106-112: the buffer grows up to the segment's end (inclusive) */
+            long v0 = lower_bound_i32(vpos, nv, lo);
+            if (v0 < b_lo) v0 = b_lo;                 /* only on a stream out of coordinate order */
+            for (long v = v0; v < nv && vpos[v] < hi; v++) {
                 int len = identify_allele(&s, sg, read_pos, vars[v].pos, vars[v].ref_len, abuf, (1 << 16) - 1);
                 if (!len) continue;
                 abuf[len] = 0;

@@ -69,6 +69,7 @@ int phz_ctx_destroy(phz_ctx *c) {
 }
 
 int phz_ctx_sync(phz_ctx *ctx) {
+    PhzEnter phz_guard_(ctx);
     PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PHZ_OK;
 }
@@ -76,6 +77,7 @@ int phz_ctx_sync(phz_ctx *ctx) {
 void *phz_ctx_stream(phz_ctx *ctx) { return (void *)ctx->stream; }
 
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches) {
+    PhzEnter phz_guard_(ctx);
     if (slot < 0 || slot >= PHZ_T_COUNT) return PHZ_E_ARG;
     if (last_ms) *last_ms = ctx->last_ms[slot];
     if (total_ms) *total_ms = ctx->total_ms[slot];
@@ -84,12 +86,14 @@ int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int
 }
 
 int phz_reset_timing(phz_ctx *ctx) {
+    PhzEnter phz_guard_(ctx);
     for (int i = 0; i < PHZ_T_COUNT; i++) { ctx->last_ms[i] = 0; ctx->total_ms[i] = 0; ctx->launches[i] = 0; }
     for (int i = 0; i < PHZ_C_COUNT; i++) ctx->counters[i] = 0;
     return PHZ_OK;
 }
 
 int phz_get_counter(phz_ctx *ctx, int slot, int64_t *value) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !value || slot < 0 || slot >= PHZ_C_COUNT) return PHZ_E_ARG;
     *value = ctx->counters[slot];
     return PHZ_OK;
@@ -130,6 +134,7 @@ int phz_reserve_host(phz_ctx *ctx, DevBuf &b, size_t bytes) {
 // Adopt results computed elsewhere as the resident tally of this ctx (see phz.h).  Arrays a caller leaves NULL stay unset; the device
 // row stage needs var_count, var_first, var_distinct, var_rank, edge_a / edge_b, edge_linked, edge_stats, rl_start, rl_qid and rl_list.
 extern "C" int phz_tally_import(phz_ctx *ctx, int64_t nv, int n_bams, const phz_tally_sizes *sz, const phz_tally_out *a, const uint32_t *rl_list, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !sz || !a || nv < 0 || n_bams < 1) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     auto &T = ctx->tally;

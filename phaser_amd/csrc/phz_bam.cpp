@@ -1587,13 +1587,18 @@ int phz_bgzf_write_indexed(const char *path, const char *data, int64_t len, int 
     int scan_status = PHZ_OK;
     std::vector<uint64_t> coff, ustart;
     const int scan_threads = std::min(16, n_threads(threads));
+    const std::string out_path = std::string(path) + ".tbi";
+    // An index left by an earlier run under the same name describes ANOTHER file from the moment the .gz is rewritten: it goes first,
+    // so that every way out of this function leaves either the new index or none (tabix on a stale one returns wrong records silently).
+    (void)unlink(out_path.c_str());
     const int st = bgzf_write_impl(path, data, len, threads, level, [&] { scan_status = ix.scan_parallel(data, (size_t)len, preset, scan_threads); }, &coff, &ustart);
     if (st != PHZ_OK) return st;
     if (scan_status != PHZ_OK) return scan_status;
     std::string o;
     ix.serialise(coff, ustart, preset, o);
-    const std::string out_path = std::string(path) + ".tbi";
-    return phz_bgzf_write(out_path.c_str(), o.data(), (int64_t)o.size(), scan_threads, 6);
+    const int wst = phz_bgzf_write(out_path.c_str(), o.data(), (int64_t)o.size(), scan_threads, 6);
+    if (wst != PHZ_OK) (void)unlink(out_path.c_str());
+    return wst;
 }
 
 }  // extern "C"

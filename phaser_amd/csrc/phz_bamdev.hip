@@ -432,6 +432,7 @@ struct phz_bamdev {
 extern "C" {
 
 int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names, int n_names, const phz_bam_filters *f, phz_bamdev **out) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !path || !f || !out) return PHZ_E_ARG;
     *out = nullptr;
     const bool timing = getenv("PHZ_TIMING") != nullptr;
@@ -756,6 +757,7 @@ int phz_bamdev_sizes_of(const phz_bamdev *h, int ref, phz_bamdev_sizes *out) {
 int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst) {
     if (!h || !dst || n_dst != (int)h->refs.size()) return PHZ_E_ARG;
     phz_ctx *ctx = h->ctx;
+    PhzEnter phz_guard_(ctx);
     if (h->n_kept == 0) return PHZ_OK;
     static_assert(sizeof(phz_dev_shard) == sizeof(DevShard), "shard pointer table layout");
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
@@ -782,6 +784,7 @@ int phz_bamdev_pack(phz_bamdev *h, const phz_dev_shard *dst, int n_dst) {
 // of every new name, in id order.
 int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, int64_t n, const char *store, const uint32_t *store_off,
                       int64_t n_old, int32_t *qid, int32_t *first_idx, int64_t *n_new) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !n_new || n < 0 || n_old < 0 || (n > 0 && (!qnames || !qname_off || !qid || !first_idx)) || (n_old > 0 && (!store || !store_off)))
         return PHZ_E_ARG;
     *n_new = 0;
@@ -817,6 +820,7 @@ int phz_intern_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_of
 // `base_bytes`, *total_bytes = the store's size afterwards; step 2 (dst = the store blob, at least *total_bytes long): copies the bytes.
 int phz_names_append_device(phz_ctx *ctx, const char *qnames, const uint32_t *qname_off, const int32_t *first_idx, int64_t m, uint32_t base_bytes,
                             uint32_t *dst_off, char *dst, int64_t *total_bytes) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || m < 0 || !total_bytes || (m > 0 && (!qnames || !qname_off || !first_idx || !dst_off))) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t sm = ctx->stream;

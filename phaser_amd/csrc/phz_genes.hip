@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void k_gene_items(int64_t n_items, const int64
 }  // namespace
 
 extern "C" int phz_gene_counts(phz_ctx *ctx, const phz_gene_work *w, int32_t *pair_counts, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !w || (!pair_counts && w->n_pairs) || w->n_items < 0 || w->n_pairs < 0) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     Staging st(ctx);

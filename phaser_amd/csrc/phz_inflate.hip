@@ -290,6 +290,7 @@ int phz_inflate_scratch_bytes_per_member() { return SCRATCH; }
 // *bad receives 0 or the code of the first member that failed (nothing else about the output can be trusted then).
 extern "C" int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t n_members, uint8_t *out,
                                        int *bad) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !comp || !members || !out || !bad || n_members < 0) return PHZ_E_ARG;
     static_assert(sizeof(phz_bgzf_member) == sizeof(Member), "member record layout");
     PHZ_HIP(ctx, hipSetDevice(ctx->device));

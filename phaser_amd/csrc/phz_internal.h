@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -14,6 +15,9 @@ struct DevBuf {
 };
 
 struct phz_ctx {
+    // Every public entry point that works on a ctx holds this lock for the whole call (PhzEnter): two threads that share a ctx are
+    // serialised, never interleaved inside its stream / scratch / error string.  Recursive because entry points call each other.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -56,6 +60,11 @@ struct phz_ctx {
     } tally;
     int map_tile_reads = 0;
     int map_slot_cap = 0;      // calls per tile slot of K_map's staging area (grown on demand)
+};
+
+struct PhzEnter {
+    std::unique_lock<std::recursive_mutex> lk;
+    explicit PhzEnter(phz_ctx *ctx) { if (ctx) lk = std::unique_lock<std::recursive_mutex>(ctx->mu); }
 };
 
 int phz_fail(phz_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);

@@ -18,6 +18,7 @@ static int check_variants(phz_ctx *ctx, const phz_variants *v, int space) {
 
 extern "C" int phz_map_reads_batch(phz_ctx *ctx, int n_shards, const phz_reads *reads, const phz_variants *vars, int baseq,
                                    const phz_calls *out, int64_t *n_calls) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || n_shards < 0 || (n_shards && (!reads || !vars || !out || !n_calls))) return PHZ_E_ARG;
     for (int i = 0; i < n_shards; i++)
         if (reads[i].n_reads < 0 || vars[i].n < 0 || out[i].cap < 0) return phz_fail(ctx, PHZ_E_ARG, "negative size");
@@ -27,6 +28,7 @@ extern "C" int phz_map_reads_batch(phz_ctx *ctx, int n_shards, const phz_reads *
 
 extern "C" int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_variants *vars, int baseq,
                              phz_calls *out, int64_t *n_calls, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !reads || !vars || !out || !n_calls) return PHZ_E_ARG;
     if (reads->n_reads < 0 || vars->n < 0 || out->cap < 0) return phz_fail(ctx, PHZ_E_ARG, "negative size");
     PHZ_HIP(ctx, hipSetDevice(ctx->device));

@@ -536,6 +536,7 @@ __global__ __launch_bounds__(256) void k_map_general_list(GenArgs a) {
 extern "C" int phz_map_reads_general(phz_ctx *ctx, const phz_reads *reads, const phz_variants_general *vars, int baseq,
                                      phz_calls *out, int64_t *n_calls, uint32_t *call_text_off, uint32_t *text_roff,
                                      int64_t text_cap, int64_t *n_text, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !reads || !vars || !out || !n_calls) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     *n_calls = 0;

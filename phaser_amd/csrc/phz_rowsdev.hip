@@ -1748,6 +1748,7 @@ int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf
 }  // namespace
 
 extern "C" int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *t, phz_rowsdev **out) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !t || !out || t->nv < 0 || t->n_chroms < 0 || t->n_chroms > 65535) return PHZ_E_ARG;
     if (t->nv >= (1ll << 28)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^28 variants");
     *out = nullptr;
@@ -1800,6 +1801,7 @@ extern "C" void phz_rowsdev_destroy(phz_rowsdev *h) {
 // [PHZ_PAIR_SLOTS] receives the hash set as it lives on the device: slot s holds (total << 32 | supporting) or all ones when empty.  The caller
 // evaluates the p-value of every occupied slot (the reference's scipy call) and passes values and their text to phz_rowsdev_run by slot.
 extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !h || !keys_host) return PHZ_E_ARG;
     auto &T = ctx->tally;
     if (T.nv != h->nv) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not belong to these variant tables");
@@ -1825,6 +1827,7 @@ extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *key
 // Stage 2: everything else, up to the finished text in HBM.
 extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *o, const double *slot_pv, const uint32_t *slot_txt_off,
                                const char *slot_txt, phz_rowsdev_result *res) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !h || !o || !slot_pv || !slot_txt_off || !slot_txt || !res) return PHZ_E_ARG;
     auto &T = ctx->tally;
     if (!h->keys_ready) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run without phz_rowsdev_pair_keys");
@@ -2203,6 +2206,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
 
 // copy one finished text (PHZ_TXT_*) to host memory (page-locked memory gives the full PCIe rate)
 extern "C" int phz_rowsdev_fetch_text(phz_ctx *ctx, phz_rowsdev *h, int which, void *dst, int64_t bytes) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !h || which < 0 || which >= PHZ_TXT_COUNT || bytes != h->bytes[which] || (!dst && bytes)) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     if (bytes) PHZ_HIP(ctx, hipMemcpyAsync(dst, h->text[which].p, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -2217,6 +2221,7 @@ extern "C" const void *phz_rowsdev_text_ptr(phz_rowsdev *h, int which) {
 // per-block arrays of the last run (want_vcf): block order = file order; variant indices are chromosome-local
 extern "C" int phz_rowsdev_fetch_blocks(phz_ctx *ctx, phz_rowsdev *h, int32_t *blk_size, int32_t *blk_var, uint8_t *blk_hap, int8_t *blk_cor, double *blk_stat,
                                         uint8_t *blk_stat_int, int32_t *blk_maxmaf) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !h || !h->have_vcf) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nbk = (size_t)h->n_blocks, nvr = (size_t)h->n_blk_vars;
@@ -2240,6 +2245,7 @@ extern "C" int phz_rowsdev_fetch_blocks(phz_ctx *ctx, phz_rowsdev *h, int32_t *b
 // variant: sub_of = ordinal of its final block inside the component (-1: in none), alle_of = its allele on haplotype A; n_sub per component.
 extern "C" int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t *comp_start, const uint32_t *pair_start, const int32_t *pair_i, const int32_t *pair_j,
                                     const int8_t *pair_cfg, int32_t max_block_size, int16_t *sub_of, uint8_t *alle_of, uint32_t *n_sub) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || n_comp < 0 || (n_comp && (!comp_start || !pair_start || !sub_of || !alle_of || !n_sub))) return PHZ_E_ARG;
     if (!n_comp) return PHZ_OK;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));

@@ -968,6 +968,7 @@ static int upload_tab(phz_ctx *ctx, const LinesDev *L, int n, F blocks_of, Lines
 }
 
 extern "C" int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *hist, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !shard || !hist) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     Staging st(ctx);
@@ -996,6 +997,7 @@ extern "C" int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *h
 
 // AS histograms of several device-resident shards accumulated into one device histogram, one host wait
 extern "C" int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t *hist) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || (!shards && n_shards) || !hist || n_shards < 0) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     Timer t(ctx, PHZ_T_ASHIST);
@@ -1021,6 +1023,7 @@ extern "C" int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int
 
 extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1,
                          int64_t n_qid, int n_bams, phz_tally_sizes *sizes, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || (!shards && n_shards) || !sizes || nv < 0 || n_qid < 0 || n_shards < 0 || n_bams < 1) return PHZ_E_ARG;
     if (nv >= (1ll << 28)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^28 variants in one call");
     if (n_qid >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "more than 2^31 QNAME ids in one call");
@@ -1243,6 +1246,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
 
 // copy the results of the last phz_tally into the caller's arrays (NULL members are skipped); one host wait
 extern "C" int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || !out) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     auto &T = ctx->tally;
@@ -1274,6 +1278,7 @@ extern "C" int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space
 // edge_a == edge_b == NULL: the edges of the last phz_tally, still resident in HBM (n_edges must match); keep[] lives in `space`
 extern "C" int phz_components(phz_ctx *ctx, int64_t nv, int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b,
                               const uint8_t *keep, int32_t *label, int space) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || nv < 0 || n_edges < 0 || (!label && nv)) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     Staging st(ctx);

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void k_ub_lds(int iters, uint32_t *out) {
 // (workgroups of 256 threads = one wave per SIMD of a CU); *wave_insts_per_s = measured wave-instructions per second over the chip,
 // *n_cu = compute units of the device, *clock_mhz = its reported engine clock.
 extern "C" int phz_microbench(phz_ctx *ctx, int kind, int waves_per_simd, int iters, double *wave_insts_per_s, int *n_cu, int *clock_mhz) {
+    PhzEnter phz_guard_(ctx);
     if (!ctx || kind < 0 || kind > 2 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !wave_insts_per_s) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     int cus = 0, mhz = 0;

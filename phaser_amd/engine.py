@@ -246,11 +246,13 @@ class Engine:
         return vb, qb, v, q
 
     def _pinned(self, name: str, count: int, dtype):
-        """numpy array over page-locked host memory, kept per name and grown on demand (D2H at full PCIe rate)."""
+        """numpy array over page-locked host memory, kept per name and grown on demand (D2H at full PCIe rate).  The pool belongs to
+        THIS Engine (rowsdev.PinnedPool): the arrays a pass hands out are overwritten by this Engine's next pass only, never by another
+        Engine of the process; a dead Engine's buffers are reused by the next one, so a stream of Engines page-locks once."""
         from . import rowsdev
         dt = np.dtype(dtype)
         need = max(1, count) * dt.itemsize
-        return rowsdev.pinned("tally_" + name, need).view(dt)[:count]       # process-wide pool: a new Engine does not page-lock again
+        return rowsdev.pool_of(self).get("tally_" + name, need).view(dt)[:count]
 
     def _tally_genome(self) -> dict:
         """K_tally over every (chromosome, BAM) shard of this rank in ONE submission; results fetched into pinned host arrays."""
@@ -321,7 +323,8 @@ class Engine:
         self.stats["tally_d2h_s"] = self.stats.get("tally_d2h_s", 0.0) + _t.perf_counter() - t1
 
     def chrom_view(self, c: str) -> dict:
-        """One chromosome's part of the tally results, local variant indices (views; for tests and tools)."""
+        """One chromosome's part of the tally results, local variant indices (views; for tests and tools).  The views sit in this
+        Engine's page-locked buffers: valid until THIS Engine's next pass (no other Engine touches them); copy what must outlive it."""
         self._fetch_tally()
         G = self.G; v0 = G["var_base"][c]; nv = len(self.vs.chroms[c])
         lo = int(np.searchsorted(G["ea"], v0, side="left")); hi = int(np.searchsorted(G["ea"], v0 + nv, side="left"))
@@ -372,8 +375,12 @@ class Engine:
         returns the assembled files (other ranks return None).  binary=True returns bytes (no decode pass);
         chunks=True returns, per file, the list of buffers in output order (no join pass): write them with dist.write_chunks (with
         several ranks some of them are byte ranges of the other ranks' spool files) and call dist.cleanup_spool() on EVERY rank
-        afterwards."""
+        afterwards.  The chunks are views of this Engine's own page-locked buffers (rowsdev.PinnedPool): write or copy them before
+        THIS Engine runs its next pass; passes of other Engines in the process never overwrite them."""
         import time as _t
+        if self.cfg.py_hash_order and pdist.world()[1] > 1:
+            # refused on EVERY rank before the first collective (a rank-0-only refusal after the gather left the others in a barrier)
+            raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "py_hash_order needs all chromosomes on one rank")
         t0 = _t.perf_counter()
         match, mism = pdist.allreduce_counts(*self.tally_all())
         noise = self.noise_from_counts(match, mism)
@@ -404,8 +411,6 @@ class Engine:
         if self.cfg.py_hash_order:
             # raw-byte tier: replay the reference's set constructions over the same strings (an exactness mode: pure Python over every call line)
             from . import pyorder
-            if pdist.world()[1] > 1:
-                raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "py_hash_order needs all chromosomes on one rank")
             text = {k: b"".join(pdist.as_bytes(x) for x in v).decode() for k, v in out.items()}
             text = pyorder.replay(self, text)
             if chunks:

@@ -136,6 +136,9 @@ def _main(argv, state):
         fatal_error("--process_slow is not supported by this build (the GPU path holds all chromosomes; SURVEY.md section 2).")
     if args.output_network != "":
         fatal_error("--output_network is not supported by this build.")
+    if args.py_hash_order and world > 1:
+        # every rank sees the same arguments and stops HERE, before the first collective: nobody is left waiting in a barrier
+        fatal_error("--py_hash_order 1 needs all chromosomes on one rank (run it without torch.distributed).")
     if not os.path.isfile(args.vcf):
         fatal_error("VCF file does not exist.")
     for xfile in [args.blacklist, args.haplo_count_blacklist]:
@@ -303,7 +306,10 @@ def _main(argv, state):
                 if not torch.cuda.is_available():
                     return
                 from . import rowsdev
-                rowsdev.tables_for(eng)
+                from ._lib import Context
+                # its OWN phz_ctx (stream, scratch, error string): the BAM prefetch thread may still be inside phz_bamdev_* on the
+                # Engine's ctx, and a phz_ctx serves one thread at a time (include/phz.h)
+                rowsdev.tables_for(eng, ctx=Context(local))
             except Exception:
                 pass            # finish() does both itself when they are not there
 

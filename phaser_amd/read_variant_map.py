@@ -142,6 +142,52 @@ def _do_native(table, baseq, o, isize_cutoff, mapper, threads, data):
                 lib.phz_buf_free(p)
 
 
+def _segment_spans(cigar: str, n_bases: int):
+    """(start, length of the pseudo read) of every N-split segment, as split_read builds them (read_variant_map.py:191-232): M / = / X take
+    what the read still has (a slice clamps at the end of the string), D adds placeholders, N closes the segment."""
+    spans = []
+    num = 0; rpos = 0; gpos = 0; start = 0; plen = 0
+    for c in cigar:
+        if "0" <= c <= "9":
+            num = num * 10 + ord(c) - 48
+            continue
+        if c in "MX=":
+            plen += max(0, min(num, n_bases - rpos)); rpos += num; gpos += num
+        elif c == "N":
+            spans.append((start, plen)); gpos += num; start = gpos; plen = 0
+        elif c == "D":
+            plen += num; gpos += num
+        elif c in "IS":
+            rpos += num
+        num = 0
+    spans.append((start, plen))
+    return spans
+
+
+def _buffer_floors(events, recs, vpos):
+    """The reference's streaming variant buffer on a chromosome whose records are NOT in coordinate order.  The buffer is the index range
+    [b_lo, L) of the chromosome's (position-sorted) variants: L counts the variants consumed so far -- skipped because they lie behind the
+    current record (read_variant_map.py:88-93) or appended up to the end of a segment (:106-112); the variant stream never rewinds -- and
+    b_lo the consumed ones pruned for lying behind SOME earlier record (:37-50, done for every record of the stream, also one the isize
+    filter then drops).  A record sees only what is inside the buffer (:114), so its calls are the stateless rule's calls on variants
+    >= the b_lo of its moment.  -> b_lo per kept record (0 everywhere on a sorted stream).  events = (POS, kept index or -1) in stream order."""
+    import bisect
+    floors = [0] * len(recs)
+    b_lo = 0; L = 0; nv = len(vpos)
+    for pos, k in events:
+        lb = bisect.bisect_left(vpos, pos)
+        b_lo = max(b_lo, min(lb, L))
+        if k < 0:
+            continue
+        if L < lb:
+            L = lb; b_lo = lb
+        floors[k] = b_lo
+        rec = recs[k]
+        for start, plen in _segment_spans(rec[2], min(len(rec[3]), len(rec[4]))):
+            L = max(L, bisect.bisect_right(vpos, pos + start + plen))
+    return floors
+
+
 def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=None, threads: int = 0):
     table = VariantTable(variant_table)
     snp_only = all(rl == 1 for rl in table.ref_len) and all(len(a) == 1 and a in _BASES for al in
@@ -149,7 +195,7 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
     stream = sys.stdin
     if splice == 1 and snp_only:
         # the whole stream through native code: parse + pack (host threads), K_map, TSV formatting.  Streams the native parser declines
-        # (records of a chromosome out of order, a chromosome that comes back later: the reference takes them as they come) go on below
+        # (records of a chromosome out of coordinate order) go on below, where the reference's forward-only variant buffer is followed
         from . import _lib
         import io
         data = sys.stdin.buffer.read() if hasattr(sys.stdin, "buffer") else sys.stdin.read().encode()
@@ -163,6 +209,8 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
     # records grouped per chromosome in input order
     chrom_order: List[str] = []
     by_chrom = {}
+    events = {}                 # per chromosome: (POS, index among the kept records or -1) of EVERY record, in stream order
+    last_chrom = None
     read_counter = 0
     for line in stream:
         cols = line.rstrip().split("\t")
@@ -171,9 +219,21 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
         elif cols[0][0:1] != "@":
             read_counter += 1
             template_length = abs(int(cols[8]))
+            if cols[2] != last_chrom:
+                if cols[2] in events:
+                    # The reference cannot follow such a stream either: its variant stream never rewinds (read_variant_map.py:88-93) and
+                    # identify_allele (:236) compares positions only, so the returning chromosome's records would be matched against
+                    # whatever chromosome's variants sit in the buffer.  phaser.py:1346 hands the mapper one chromosome per run.
+                    print("Error, the records of %s are not contiguous in the SAM stream (a chromosome comes back after another one); "
+                          "sort the input by coordinate" % cols[2])
+                    sys.exit(1)
+                last_chrom = cols[2]
+                events[last_chrom] = []
             if not (isize_cutoff == 0 or template_length <= isize_cutoff):
+                events[last_chrom].append((int(cols[3]), -1))       # dropped, but the reference prunes its variant buffer before it drops it (:37-51)
                 continue
             if not (splice == 1 or "N" not in cols[5]):
+                events[last_chrom].append((int(cols[3]), -1))
                 continue
             alignment_score = ""
             for i in range(11, len(cols)):
@@ -183,6 +243,7 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
             if chrom not in by_chrom:
                 by_chrom[chrom] = []
                 chrom_order.append(chrom)
+            events[chrom].append((int(cols[3]), len(by_chrom[chrom])))
             by_chrom[chrom].append((cols[0], int(cols[3]), cols[5], cols[9], cols[10], alignment_score))
 
     # VCF / BAM contig check (read_variant_map.py:66-71)
@@ -206,17 +267,20 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
                 continue
             vpos = torch.tensor([table.pos[i] for i in vsel], dtype=torch.int32)
             ref_len = torch.tensor([table.ref_len[i] for i in vsel], dtype=torch.uint8)
-            # The kernels want a chromosome's records in coordinate order.  The reference takes them as they come (read_variant_map.py:25-117), so a
-            # stream that is out of order (or a chromosome that comes back later) is mapped in sorted order and its lines are put back into
-            # stream order afterwards
-            order = None
-            if any(recs[i][1] < recs[i - 1][1] for i in range(1, len(recs))):
+            # The kernels want a chromosome's records in coordinate order.  A stream that is out of order is mapped in sorted order, its
+            # lines are put back into stream order, and the calls the reference's forward-only variant buffer would not have made are
+            # dropped (_buffer_floors: a record that steps backwards misses the variants the buffer has already let go)
+            order = None; floors = None
+            ev = events[chrom]
+            if any(ev[i][0] < ev[i - 1][0] for i in range(1, len(ev))):
+                floors = _buffer_floors(ev, recs, [table.pos[i] for i in vsel])
                 order = sorted(range(len(recs)), key=lambda i: recs[i][1])
+                floors = [floors[i] for i in order]
                 recs = [recs[i] for i in order]
             shard = soa.pack_sam([(r[1], r[2], r[3], r[4]) for r in recs])
             ind = [_individual_alleles(table.alleles[i], table.gt[i]) for i in vsel]
             general = bool((ref_len != 1).any()) or any(len(a) != 1 or a not in _BASES for al in ind for a in al)
-            lines = []
+            lines = []; line_rec = []
             if general:
                 # indel mode: the kernel classifies against the allele strings (codes 5 / 6) and reports, for any other
                 # text, which read offsets compose it
@@ -230,7 +294,10 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
                 ri = calls.read_idx.tolist(); vi = calls.var_idx.tolist(); cd = calls.code.tolist()
                 toff = pool.call_off.tolist(); tro = pool.roff.tolist()
                 for k in range(len(ri)):
+                    if floors is not None and vi[k] < floors[ri[k]]:
+                        continue
                     rec = recs[ri[k]]; v = int(vsel[vi[k]])
+                    line_rec.append(ri[k])
                     if cd[k] == 5 or cd[k] == 6:
                         allele = ind[vi[k]][cd[k] - 5]
                     elif cd[k] < 4:
@@ -243,11 +310,14 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
                 ri = calls.read_idx.tolist(); vi = calls.var_idx.tolist(); cd = calls.code.tolist()
                 a0 = (calls.aux0.to(torch.int64) & 0xFFFFFFFF).tolist(); a1 = (calls.aux1.to(torch.int64) & 0xFFFFFFFF).tolist()
                 for k in range(len(ri)):
+                    if floors is not None and vi[k] < floors[ri[k]]:
+                        continue
                     rec = recs[ri[k]]; v = int(vsel[vi[k]])
+                    line_rec.append(ri[k])
                     allele = _allele_text(cd[k], a0[k], a1[k], rec[3], rec[4], baseq)
                     lines.append("\t".join([rec[0], table.id[v], table.rsid[v], allele, rec[5], table.gt[v], table.maf[v]]))
             if lines and order is not None:
-                back = sorted(range(len(lines)), key=lambda k: order[ri[k]])          # stable: the calls of a record keep their order
+                back = sorted(range(len(lines)), key=lambda k: order[line_rec[k]])          # stable: the calls of a record keep their order
                 lines = [lines[k] for k in back]
             if lines:
                 out.write("\n".join(lines) + "\n")

@@ -81,46 +81,100 @@ class Tables:
             pass
 
 
-def tables_for(eng) -> Tables:
-    """Cached on the variant set: one upload per (context, chromosome list, blacklist)."""
-    cache = eng.vs.__dict__.setdefault("_rowsdev_tables", {})
-    key = (id(eng.ctx), tuple(eng.chrom_list), frozenset(eng.cfg.haplo_blacklist))
-    t = cache.get(key)
-    if t is None:
-        cache.clear()              # one resident copy per variant set is enough (a new chromosome list replaces the old tables)
-        t = cache[key] = Tables(eng.ctx, eng.vs, eng.chrom_list, eng.cfg)
-    return t
+_TABLES_LOCK = __import__("threading").Lock()
 
 
-_PINNED: Dict[str, torch.Tensor] = {}
-_ARENA = {"buf": None, "used": 0}
+def tables_for(eng, ctx=None) -> Tables:
+    """Cached on the variant set: one upload per (device, chromosome list, blacklist).  The tables are plain device memory of the
+    ctx's GPU -- any phz_ctx of that device may run the row stage on them -- so a helper thread uploads them through a ctx of its
+    own (`ctx`) while the Engine's ctx is busy elsewhere; the upload has completed when the constructor returns."""
+    with _TABLES_LOCK:
+        cache = eng.vs.__dict__.setdefault("_rowsdev_tables", {})
+        key = (eng.ctx.device, tuple(eng.chrom_list), frozenset(eng.cfg.haplo_blacklist))
+        t = cache.get(key)
+        if t is None:
+            cache.clear()              # one resident copy per variant set is enough (a new chromosome list replaces the old tables)
+            t = cache[key] = Tables(ctx or eng.ctx, eng.vs, eng.chrom_list, eng.cfg)
+        return t
+
+
+class PinnedPool:
+    """Page-locked host buffers of ONE owner (an Engine), kept per name and grown on demand: D2H at the full PCIe rate and no page-locking
+    cost per pass.  Two live owners never share memory: what an Engine hands out (the G[...] arrays, chrom_view() views, the text chunks of
+    finish()) is overwritten only by THAT Engine's next pass.  Buffers return to a process-wide free list when their owner goes away, so a
+    process that creates Engines one after the other (a sample stream) still page-locks once."""
+
+    _free: List[torch.Tensor] = []          # buffers given up by dead owners, reusable by the next pool
+    _arena = {"buf": None, "used": 0, "owner": None}
+
+    def __init__(self):
+        self._bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, nbytes: int) -> np.ndarray:
+        """uint8 view of this owner's buffer `name` (>= nbytes).  Text buffers ('rows_*') are carved from the arena prepare_arena()
+        page-locked ahead of time, as long as no other live owner holds it and they fit."""
+        a = PinnedPool._arena
+        b = a["buf"]
+        if b is not None and name.startswith("rows_") and name not in self._bufs and a["owner"] in (None, id(self)):
+            lo = (a["used"] + 4095) & ~4095
+            if lo + nbytes <= b.numel():
+                a["owner"] = id(self)
+                a["used"] = lo + nbytes
+                return b.numpy()[lo:lo + nbytes]
+        t = self._bufs.get(name)
+        if t is None or t.numel() < nbytes:
+            want = max(1, nbytes + nbytes // 8 + 4096)
+            t = None
+            free = PinnedPool._free
+            fit = [i for i, f in enumerate(free) if f.numel() >= nbytes]
+            if fit:
+                t = free.pop(min(fit, key=lambda i: free[i].numel()))
+            if t is None:
+                t = torch.empty(want, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            old = self._bufs.get(name)
+            if old is not None:
+                free.append(old)
+            self._bufs[name] = t
+        return t.numpy()[:nbytes]
+
+    def new_pass(self):
+        """The owner's previous text buffers inside the arena are given up (as its per-name buffers always are)."""
+        a = PinnedPool._arena
+        if a["owner"] == id(self):
+            a["used"] = 0
+
+    def release(self):
+        """Owner gone: its buffers may serve the next pool, the arena is free again."""
+        PinnedPool._free.extend(self._bufs.values())
+        self._bufs = {}
+        del PinnedPool._free[:-32]                # bounded: a long stream of Engines keeps the 32 newest buffers
+        a = PinnedPool._arena
+        if a["owner"] == id(self):
+            a["owner"] = None; a["used"] = 0
 
 
 def prepare_arena(nbytes: int):
     """Page-lock one host region for the row text of the coming pass ahead of time (the CLI does it on a helper thread while the BAM is
-    decoded: page-locking costs ~0.1 s per GB).  The text buffers of a pass are carved from it as long as they fit."""
+    decoded: page-locking costs ~0.1 s per GB).  The text buffers of the first Engine that asks are carved from it as long as they fit."""
     if not torch.cuda.is_available():
         return
-    b = _ARENA["buf"]
+    a = PinnedPool._arena
+    if a["owner"] is not None:
+        return                                   # in use by a live Engine: its views stay valid
+    b = a["buf"]
     if b is None or b.numel() < nbytes:
-        _ARENA["buf"] = torch.empty(max(1, nbytes), dtype=torch.uint8, pin_memory=True)
-    _ARENA["used"] = 0
+        a["buf"] = torch.empty(max(1, nbytes), dtype=torch.uint8, pin_memory=True)
+    a["used"] = 0
 
 
-def pinned(name: str, nbytes: int) -> np.ndarray:
-    """uint8 view of a page-locked host buffer kept per name for the life of the process (grown on demand): D2H at the full PCIe rate,
-    and no page-locking cost per pass."""
-    b = _ARENA["buf"]
-    if b is not None and name.startswith("rows_") and name not in _PINNED:
-        lo = (_ARENA["used"] + 4095) & ~4095
-        if lo + nbytes <= b.numel():
-            _ARENA["used"] = lo + nbytes
-            return b.numpy()[lo:lo + nbytes]
-    t = _PINNED.get(name)
-    if t is None or t.numel() < nbytes:
-        t = torch.empty(max(1, nbytes + nbytes // 8 + 4096), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-        _PINNED[name] = t
-    return t.numpy()[:nbytes]
+def pool_of(eng) -> PinnedPool:
+    """The Engine's own pool (created on first use, released when the Engine is collected)."""
+    p = eng.__dict__.get("_pinned_pool")
+    if p is None:
+        import weakref
+        p = eng.__dict__["_pinned_pool"] = PinnedPool()
+        weakref.finalize(eng, p.release)
+    return p
 
 
 def supported(cfg) -> bool:
@@ -187,12 +241,13 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
             if name in ("allelic", "single_ase", "single_hap"):
                 frags[c][name + "_bam"] = []
     total_bytes = 0
-    _ARENA["used"] = 0                          # the previous pass's text buffers are given up (as the per-name buffers always were)
+    pool = pool_of(eng)
+    pool.new_pass()                             # THIS Engine's previous text buffers are given up; another Engine's are never touched
     for f, name in enumerate(_lib.PHZ_TXT_NAMES):
         nbytes = int(R.bytes[f]); total_bytes += nbytes
         if not fetch_text:
             continue
-        buf = pinned("rows_" + name, nbytes)
+        buf = pool.get("rows_" + name, nbytes)
         ctx.check(lib.phz_rowsdev_fetch_text(ctx.h, T.h, f, _vp(buf) if nbytes else None, nbytes))
         mv = memoryview(buf)
         nseg = nch if f < 4 else nb * nch

@@ -40,6 +40,61 @@ def test_mapper_small_bytes(oracle_build, tmp_path):
         assert got == gz_text(os.path.join(d, run["file"])), run
 
 
+def test_unsorted_stream_bytes(oracle_build, tmp_path):
+    """Streams out of coordinate order: the oracle's text front end follows the reference's forward-only variant buffer (fixtures written
+    by the reference's compiled mapper: local disorder, records moved far ahead, with and without the isize filter)."""
+    d = os.path.join(GOLD, "mapper_unsorted")
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    assert len(meta["runs"]) == 4
+    for run in meta["runs"]:
+        sam = gz_text(os.path.join(d, "in_%s.sam.gz" % run["stream"]))
+        got = run_oracle_cli(oracle_build, sam, os.path.join(GOLD, "mapper_small", "table.tsv"), str(tmp_path / "o.tsv"), run["baseq"], run["isize"])
+        assert got == gz_text(os.path.join(d, run["file"])), run
+        assert got.count("\n") == run["lines"] and run["lines"] < 1316       # fewer calls than the sorted stream's
+
+
+def test_buffer_floors_follow_the_literal_buffer():
+    """phaser_amd.read_variant_map._buffer_floors (the closed form the drop-in uses on an unsorted stream) against a literal, list-based
+    replay of the reference's loop (read_variant_map.py:37-50 prune, :88-93 skip, :106-112 append, :114 every buffered variant is tried)."""
+    import random
+    from phaser_amd.read_variant_map import _buffer_floors, _segment_spans
+    rng = random.Random(11)
+    for trial in range(300):
+        vpos = sorted(rng.sample(range(1, 3000), rng.randrange(0, 60)))
+        recs = []; events = []
+        p = 1
+        for _ in range(rng.randrange(1, 80)):
+            p = max(1, p + rng.choice([-400, -60, -5, 0, 3, 20, 90, 700]) if rng.random() < 0.5 else p + rng.randrange(0, 30))
+            cigar = rng.choice(["50M", "20M300N30M", "10S40M", "25M2D25M", "20M5I25M", "10M100N10M100N30M", "*"])
+            nb = rng.choice([50, 50, 50, 30, 1])
+            filtered = rng.random() < 0.2
+            if cigar == "*":
+                cigar = "50M"; nb = 1
+            if filtered:
+                events.append((p, -1))
+            else:
+                events.append((p, len(recs))); recs.append(("q", p, cigar, "A" * nb, "I" * nb, ""))
+        floors = _buffer_floors(events, recs, vpos)
+        buf = []; nxt = 0
+        for pos, k in events:
+            buf = [v for v in buf if not vpos[v] < pos]
+            if k < 0:
+                continue
+            while nxt < len(vpos) and vpos[nxt] < pos:
+                nxt += 1
+            seen = set()
+            rec = recs[k]
+            for start, plen in _segment_spans(rec[2], min(len(rec[3]), len(rec[4]))):
+                while nxt < len(vpos) and vpos[nxt] <= pos + start + plen:
+                    buf.append(nxt); nxt += 1
+                seen |= {v for v in buf if pos + start <= vpos[v] < pos + start + plen}
+            lo = floors[k]
+            rule = set()
+            for start, plen in _segment_spans(rec[2], min(len(rec[3]), len(rec[4]))):
+                rule |= {v for v in range(len(vpos)) if pos + start <= vpos[v] < pos + start + plen}
+            assert seen == {v for v in rule if v >= lo}, (trial, pos, rec[2])
+
+
 def test_pipe_one_calls_bytes(oracle_build, tmp_path):
     d = os.path.join(GOLD, "pipe_one")
     sam = gz_text(os.path.join(d, "a.chr22.sam.gz"))

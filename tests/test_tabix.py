@@ -200,3 +200,8 @@ def test_one_call_write_and_index_equals_the_two_steps(tmp_path):
     for bad in (back, again):
         assert vcfout.write_bgzf(u, "\n".join(bad) + "\n", 4, index="bed") is False
     assert vcfout.write_bgzf(u, "\n".join(rows) + "\n", 4, index="bed") is True
+    # ... and an index left by an earlier run under the same name does not survive a rewrite that cannot be indexed (a stale .tbi
+    # answers tabix queries with the wrong records, silently)
+    assert os.path.exists(u + ".tbi")
+    assert vcfout.write_bgzf(u, "\n".join(back) + "\n", 4, index="bed") is False
+    assert not os.path.exists(u + ".tbi")

@@ -248,6 +248,40 @@ def fx_mapper_small(phaser, rvm):
     print("mapper_small:", meta)
 
 
+def fx_mapper_unsorted(phaser, rvm):
+    """A stream whose records are OUT of coordinate order: the reference's variant buffer is forward-only (read_variant_map.py:37-50 prunes
+    what lies behind the current record -- for every record, also one the isize filter drops --, :88-93 and :106-112 never rewind the
+    variant stream), so a record that steps backwards misses the variants already dropped.  Same records and table as mapper_small."""
+    d = os.path.join(GOLD, "mapper_unsorted"); os.makedirs(d, exist_ok=True)
+    src = os.path.join(GOLD, "mapper_small")
+    sam = gzip.open(os.path.join(src, "in.sam.gz"), "rt").read()
+    tab = open(os.path.join(src, "table.tsv")).read()
+    head = [l for l in sam.split("\n") if l.startswith("@")]
+    recs = [l for l in sam.split("\n") if l and not l.startswith("@")]
+    rng = random.Random(5)
+    shuffled = list(recs)
+    for _ in range(len(recs) // 3):                            # local disorder ...
+        i = rng.randrange(len(shuffled) - 1)
+        shuffled[i], shuffled[i + 1] = shuffled[i + 1], shuffled[i]
+    for _ in range(5):                                         # ... and a few long-range moves to the end of the stream
+        shuffled.append(shuffled.pop(rng.randrange(len(shuffled) // 2)))
+    far = list(shuffled)
+    for _ in range(6):                                         # records moved far FORWARD: what follows them steps backwards, and the
+        i = rng.randrange(len(far) // 8, len(far))             # variants they make the mapper skip are gone for good
+        far.insert(max(0, i - rng.randrange(200, 700)), far.pop(i))
+    meta = {"records": len(shuffled), "runs": []}
+    for name, stream in (("local", shuffled), ("far", far)):
+        text = "\n".join(head + stream) + "\n"
+        wgz(os.path.join(d, "in_%s.sam.gz" % name), text)
+        for baseq, isize in [(10, 0.0), (10, 260.0)]:
+            out = run_mapper(rvm, text, tab, baseq, isize)
+            fn = "calls_%s_bq%d_is%d.tsv.gz" % (name, baseq, int(isize))
+            wgz(os.path.join(d, fn), out)
+            meta["runs"].append({"stream": name, "baseq": baseq, "isize": isize, "file": fn, "lines": out.count("\n")})
+    json.dump(meta, open(os.path.join(d, "meta.json"), "w"), indent=1)
+    print("mapper_unsorted:", meta)
+
+
 def split_by_chrom(sam_lists):
     return sam_lists
 
@@ -664,7 +698,7 @@ def fx_expr_matrix(phaser, rvm):
         print("expr_matrix", order, len(files), "files ->", out_all.split("\n")[0].count("\t") - 3, "sample columns,", len(out_all.splitlines()) - 1, "rows")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "write_vcf_more": fx_write_vcf_more, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix, "blacklist_bed": fx_blacklist_bed}
+FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "mapper_unsorted": fx_mapper_unsorted, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "write_vcf_more": fx_write_vcf_more, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix, "blacklist_bed": fx_blacklist_bed}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
