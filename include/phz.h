@@ -304,6 +304,10 @@ int phz_sam_parse(const char *text, int64_t len, double isize_cutoff, int thread
 const char *phz_sam_error(const phz_sam *h);
 void phz_sam_free(phz_sam *h);
 int64_t phz_sam_n_records(const phz_sam *h);          /* alignment lines seen (before the TLEN filter) */
+/* 1 when every chromosome is ONE run of the stream in coordinate order, counting ALL alignment lines (also the ones the TLEN filter
+ * drops: the reference prunes its variant buffer by every record, read_variant_map.py:37-50).  Only then is the mapper's result the
+ * stateless rule the kernels implement; the drop-in sends any other stream down its forward-only-buffer path (or refuses it). */
+int phz_sam_stream_order(const phz_sam *h);
 int phz_sam_n_contigs(const phz_sam *h);
 const char *phz_sam_contig(const phz_sam *h, int i);
 int phz_sam_n_shards(const phz_sam *h);

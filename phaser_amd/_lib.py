@@ -242,6 +242,7 @@ SYMBOLS = {
     "phz_sam_error": (C.c_char_p, [C.c_void_p]),
     "phz_sam_free": (None, [C.c_void_p]),
     "phz_sam_n_records": (C.c_int64, [C.c_void_p]),
+    "phz_sam_stream_order": (C.c_int, [C.c_void_p]),
     "phz_sam_n_contigs": (C.c_int, [C.c_void_p]),
     "phz_sam_contig": (C.c_char_p, [C.c_void_p, C.c_int]),
     "phz_sam_n_shards": (C.c_int, [C.c_void_p]),

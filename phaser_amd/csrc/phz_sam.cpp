@@ -123,6 +123,7 @@ struct phz_sam {
     std::vector<std::string> contigs;           // @SQ names in header order
     std::vector<SamShard> shards;               // chromosomes in first-appearance order
     int64_t n_records = 0;                      // alignment lines read (before the TLEN filter), like the mapper's read_counter
+    int stream_order = 1;                       // 1: every chromosome is ONE run of the stream, in coordinate order, counting ALL alignment lines
     std::string err;
     const char *text = nullptr;
 };
@@ -144,7 +145,12 @@ int phz_sam_parse(const char *text, int64_t len, double isize_cutoff, int thread
     }
     const size_t nlines = ls.size() - 1;
     // ---- per line: classify, split, filter (parallel over line ranges, merged in order)
-    struct Part { std::vector<Rec> recs; std::vector<std::string_view> chroms; std::vector<std::string> contigs; int64_t n = 0; int status = 0; std::string err; };
+    // runs: the chromosome runs of ALL records of the part (also the ones the isize filter drops: the reference prunes its variant buffer by
+    // every record, read_variant_map.py:37-50), with their first / last POS -- the stream is taken here only when every chromosome is one run
+    // in coordinate order; anything else is the Python path's business (forward-only buffer semantics / refusal)
+    struct Run { std::string_view chrom; int32_t first, last; };
+    struct Part { std::vector<Rec> recs; std::vector<std::string_view> chroms; std::vector<std::string> contigs; std::vector<Run> runs; bool disorder = false;
+                  int64_t n = 0; int status = 0; std::string err; };
     const size_t nparts = nlines ? (size_t)std::max(1, std::min<int>(nt * 4, (int)((nlines + 2047) / 2048))) : 0;
     std::vector<Part> parts(nparts);
     std::atomic<size_t> next(0);
@@ -195,6 +201,11 @@ int phz_sam_parse(const char *text, int64_t len, double isize_cutoff, int thread
                 r.pos = (int32_t)v;
                 if (!parse_int(p + r.f[8], p + r.f[9] - 1, &v)) { P.status = PHZ_E_ARG; P.err = "SAM TLEN is not an integer"; break; }
                 const double tl = v < 0 ? -(double)v : (double)v;
+                {
+                    const std::string_view cn(p + r.f[2], (size_t)(r.f[3] - 1 - r.f[2]));
+                    if (P.runs.empty() || P.runs.back().chrom != cn) P.runs.push_back(Run{cn, r.pos, r.pos});
+                    else { if (r.pos < P.runs.back().last) P.disorder = true; P.runs.back().last = r.pos; }
+                }
                 if (!(isize_cutoff == 0 || tl <= isize_cutoff)) continue;
                 // AS = last optional field that starts with "AS:" -> int(field.split(":")[2])
                 r.has_as = 0; r.as = 0;
@@ -225,6 +236,22 @@ int phz_sam_parse(const char *text, int64_t len, double isize_cutoff, int thread
     };
     if (nt == 1 || nparts <= 1) work();
     else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto &x : th) x.join(); }
+    {
+        std::unordered_map<std::string, int> seen;
+        std::string cur; int32_t last = 0; bool any = false;
+        for (auto &P : parts) {
+            if (P.status) { h->err = P.err; return P.status; }
+            if (P.disorder) h->stream_order = 0;
+            for (auto &r : P.runs) {
+                if (any && cur == r.chrom) { if (r.first < last) h->stream_order = 0; }
+                else {
+                    cur.assign(r.chrom);
+                    if (!seen.emplace(cur, 1).second) h->stream_order = 0;       // a chromosome that comes back
+                }
+                last = r.last; any = true;
+            }
+        }
+    }
     std::unordered_map<std::string, int> idx;
     for (auto &P : parts) {
         if (P.status) { h->err = P.err; return P.status; }
@@ -287,6 +314,7 @@ int phz_sam_parse(const char *text, int64_t len, double isize_cutoff, int thread
 const char *phz_sam_error(const phz_sam *h) { return h ? h->err.c_str() : ""; }
 void phz_sam_free(phz_sam *h) { delete h; }
 int64_t phz_sam_n_records(const phz_sam *h) { return h->n_records; }
+int phz_sam_stream_order(const phz_sam *h) { return h ? h->stream_order : 0; }
 int phz_sam_n_contigs(const phz_sam *h) { return (int)h->contigs.size(); }
 const char *phz_sam_contig(const phz_sam *h, int i) { return h->contigs[(size_t)i].c_str(); }
 int phz_sam_n_shards(const phz_sam *h) { return (int)h->shards.size(); }

@@ -107,6 +107,10 @@ def _do_native(table, baseq, o, isize_cutoff, mapper, threads, data):
     from .vcf import sep_pool
     lib = _lib.load()
     owner, contigs, shards = _native_sam(data, float(isize_cutoff), threads)
+    if not lib.phz_sam_stream_order(owner.h):
+        # a record (kept or dropped by the isize filter) steps backwards, or a chromosome comes back: the reference's result is no longer
+        # the stateless rule; do_read_variant_map's Python path follows its forward-only variant buffer
+        raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "SAM stream is not one coordinate-sorted run per chromosome")
     tchroms = []
     for c in table.chr:
         if not tchroms or tchroms[-1] != c:
