@@ -158,10 +158,13 @@ struct CandBuf {
     int cap;
 };
 
+// experiment (PHZ_MAP_DBG bit 1024, timing only -- wrong bases): the byte that holds a base's two bits is read from the quality plane, inside the
+// 4-byte group of its quality byte, i.e. what a layout with both in one memory sector would fetch
+#define PHZ_SEQ_BYTE(a, soff, x) (((a).dbg & 1024) ? (a).qual[(size_t)(soff) * 4 + ((x) | 3)] : (a).seq2[(size_t)(soff) + ((x) >> 2)])
 // symbol of read base x after baseq masking: 0..3 = ACGT, 4 = 'N', 5 = other IUPAC character
 __device__ __forceinline__ int masked_base(const MapArgs &a, uint32_t soff, int x) {
     uint32_t q = a.qual[(size_t)soff * 4 + x];
-    uint32_t s = (a.seq2[(size_t)soff + (x >> 2)] >> (2 * (x & 3))) & 3;
+    uint32_t s = (PHZ_SEQ_BYTE(a, soff, x) >> (2 * (x & 3))) & 3;
     if ((int)(q & 0x7f) < a.baseq) return 4;
     if (q & 0x80) return s == 0 ? 4 : 5;
     return (int)s;
@@ -445,7 +448,9 @@ __device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT
     return running;
 }
 
-template <int MAP_BLOCK, int RPT>
+// ABL: the ablation switches of PHZ_MAP_DBG are live (profiling build of the same code); the production instantiation sees dbg == 0 at
+// compile time, so none of its tests reach the scalar unit
+template <int MAP_BLOCK, int RPT, bool ABL>
 __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile) {
     const int4 tw = *reinterpret_cast<const int4 *>(bt.tile_w0 + 4 * gtile);      // the pre-pass left the tile's shard here: no search
     const int si = (tw.y >> 16) & 0x1FFF;
@@ -455,7 +460,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         a.pos = sh.pos; a.cigar_off = sh.cigar_off; a.cigar = sh.cigar; a.seq_off = sh.seq_off; a.seq2 = sh.seq2; a.qual = sh.qual;
         a.n = sh.n; a.vpos = sh.vpos; a.nv = sh.nv; a.baseq = bt.baseq;
         a.stage = bt.stage; a.side = bt.side; a.slots = bt.slots;
-        a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = bt.dbg;
+        a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = ABL ? bt.dbg : 0;
     }
     constexpr int TILE = MAP_BLOCK * RPT;
     constexpr int CIG = TILE * PHZ_CIG_X2 / 2;          // packed CIGAR words staged per tile (max)
@@ -514,12 +519,19 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     }
     if (tid == 0) { s_coff[TILE] = coff_end; s_ncand = 0; s_ncx = 0; s_nlong = 0; }
     if (tid < TILE / 32) s_poison[tid] = 0;
-    if (tid < MAP_WIN) s_vpos[tid] = v_first;                       // INT_MAX beyond the window: lds_lower_bound probes without a bounds test
-    for (int j = tid + MAP_BLOCK; j < MAP_WIN; j += MAP_BLOCK) {
+    const int wdepth = window_depth(vw.wlen);
+    // INT_MAX beyond the window: lds_lower_bound probes without a bounds test.  Its halving chain enters at step 2^(wdepth-1) and its closing
+    // probe reads at most index 2^wdepth - 1 -- but the scans of phase 1a read up to wlen -- so the padding stops at max(wlen, 2^wdepth)
+#ifdef PHZ_FILL_ALL
+    const int wfill = MAP_WIN;
+#else
+    const int wfill = (1 << wdepth) > vw.wlen ? (1 << wdepth) : vw.wlen;
+#endif
+    if (tid < wfill) s_vpos[tid] = v_first;
+    for (int j = tid + MAP_BLOCK; j < wfill; j += MAP_BLOCK) {
         const int idx = vw.w0 + j;
         s_vpos[j] = (j < vw.wlen && idx < a.nv) ? a.vpos[idx] : 0x7fffffff;
     }
-    const int wdepth = window_depth(vw.wlen);
 #pragma unroll
     for (int u = 0; u < 3; u++) { const uint32_t j = (uint32_t)tid + (uint32_t)u * MAP_BLOCK; if (j < cnt_w) s_cig[j] = cg[u]; }
     for (uint32_t j = (uint32_t)tid + 3u * MAP_BLOCK; j < cnt_w; j += MAP_BLOCK) s_cig[j] = a.cigar[cw.c_begin + j];
@@ -606,7 +618,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             const uint32_t soff = s_soff[k * MAP_BLOCK + tid];
             const int x = s_vpos[base_[k]] - rpos_[k];
             pre_q[k] = a.qual[(size_t)soff * 4 + x];
-            pre_s[k] = a.seq2[(size_t)soff + (x >> 2)];
+            pre_s[k] = PHZ_SEQ_BYTE(a, soff, x);
         }
     }
     __syncthreads();
@@ -640,7 +652,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             cx_off = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(s_aux1[tid] >> 12);
             const uint32_t soff = s_soff[key >> 16];
             cq = a.qual[(size_t)soff * 4 + cx_off];
-            cs = a.seq2[(size_t)soff + (cx_off >> 2)];
+            cs = PHZ_SEQ_BYTE(a, soff, cx_off);
         }
     }
     // ---- phase 2a, second half: resolve the fast records' bases (the first one from the bytes requested above)
@@ -739,12 +751,12 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     }
 }
 
-template <int MAP_BLOCK, int RPT>
+template <int MAP_BLOCK, int RPT, bool ABL>
 __global__ __launch_bounds__(MAP_BLOCK) void k_map(MapBatch bt) {
     // (XCD-contiguous tile order -- workgroup i runs on XCD i % 8; every XCD given one contiguous eighth of the tiles -- was measured in
     // round 4 for k_map, k_line, k_tile and k_pairs: no gain anywhere, 1.291 against 1.282 ms here.  Neighbouring tiles share only their
     // het-SNP window, which the memory-side cache serves.)
-    map_tile<MAP_BLOCK, RPT>(bt, (int64_t)blockIdx.x);
+    map_tile<MAP_BLOCK, RPT, ABL>(bt, (int64_t)blockIdx.x);
 }
 
 // two-level exclusive prefix sum of the per-tile totals: 1024-tile chunks in parallel, then one small pass
@@ -996,7 +1008,8 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm, bt, tile_reads);
         PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[0], sm));
-#define PHZ_LAUNCH_MAP(B, R) hipLaunchKernelGGL((k_map<B, R>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt)
+#define PHZ_LAUNCH_MAP(B, R) do { if (bt.dbg) hipLaunchKernelGGL((k_map<B, R, true>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt); \
+                                 else hipLaunchKernelGGL((k_map<B, R, false>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt); } while (0)
         if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
         else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
         else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
