@@ -19,6 +19,13 @@ def build(verbose=False, tally_tile=0, row_wave_min=None):
     row_wave_min: the variant libphz_emu_w<N>.so whose row stage formats the rows of blocks with more than N variants by a wave each
     (0: every block row, so that the fixtures exercise the wave sinks)"""
     os.makedirs(OUT, exist_ok=True)
+    import fcntl
+    with open(os.path.join(OUT, ".lock"), "w") as lk:        # pytest-xdist workers build the same files: one at a time
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build_locked(verbose, tally_tile, row_wave_min)
+
+
+def _build_locked(verbose, tally_tile, row_wave_min):
     tag = ("_t%d" % tally_tile if tally_tile else "") + ("_w%d" % row_wave_min if row_wave_min is not None else "")
     LIB = os.path.join(OUT, "libphz_emu%s.so" % tag)
     variant_defs = {}
@@ -44,7 +51,8 @@ def build(verbose=False, tally_tile=0, row_wave_min=None):
             subprocess.check_call(cmd)
         with ThreadPoolExecutor(4) as ex:
             list(ex.map(run, jobs))
-        run(["g++", "-shared", "-fPIC"] + objs + ["-o", LIB, "-lpthread"])
+        run(["g++", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp", "-lpthread"])
+        os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
