@@ -149,14 +149,45 @@ struct CigWin {
     }
 };
 
-// LDS candidate buffer (one per workgroup): every (read, variant) pair that passes the position rule
+// LDS candidate buffer (one per workgroup): every (read, variant) pair that passes the position rule.  Eight bytes per entry plus a
+// short side list (the buffer's size decides how many tiles a CU holds, and the kernel's time follows the residency): the variant as a
+// 16-bit offset from the tile's window start, the base's read offset in 16 bits, inserted text -- one candidate in hundreds -- in the side
+// list.  What does not fit those widths (a variant 65,535 entries beyond the window start, a base beyond offset 65,534, more than
+// CAND_INS insertion candidates in a tile) flags the buffer as overflowed: the tile then takes the in-lane fallback, which needs no buffer.
+#ifndef PHZ_CAND_INS
+#define PHZ_CAND_INS 16
+#endif
+constexpr int CAND_INS = PHZ_CAND_INS;
+constexpr uint32_t KEY_HAS_INS = 0x4000u;
 struct CandBuf {
-    uint32_t *key;    // local read index << 16 | ordinal within the read << 8 | code (filled by the resolve phase)
-    int32_t *var;
-    uint32_t *aux0, *aux1;
+    uint32_t *key;    // local read index << 16 | lean-origin << 15 | has inserted text << 14 | ordinal within the read << 8 | code (filled by the resolve phase)
+    uint16_t *var;    // variant index - w0
+    uint16_t *x0;     // read offset of the base, 0xFFFF = none (deleted base)
+    unsigned long long *ins;      // slot << 32 | (offset << 12 | length) of the inserted text
     int *n;           // candidates appended; > cap (or an ordinal >= 32) sends the tile down the in-lane fallback
-    int cap;
+    int *nins;
+    int cap, w0;
 };
+__device__ __forceinline__ void cand_put(const CandBuf &cb, int slot, uint32_t key, int var, uint32_t x0, uint32_t x1) {
+    const uint32_t dv = (uint32_t)(var - cb.w0);
+    bool wide = dv >= 0xFFFFu || (x0 != 0xFFFFFFFFu && x0 >= 0xFFFFu);
+    if (x1 != 0u) {
+        const int t = atomicAdd(cb.nins, 1);
+        if (t < CAND_INS) cb.ins[t] = ((unsigned long long)(uint32_t)slot << 32) | x1; else wide = true;
+        key |= KEY_HAS_INS;
+    }
+    if (wide) atomicOr(cb.n, 1 << 30);
+    cb.key[slot] = key;
+    cb.var[slot] = (uint16_t)dv;
+    cb.x0[slot] = (uint16_t)(x0 == 0xFFFFFFFFu ? 0xFFFFu : x0);
+}
+__device__ __forceinline__ uint32_t cand_x0(const CandBuf &cb, int e) { const uint32_t v = cb.x0[e]; return v == 0xFFFFu ? 0xFFFFFFFFu : v; }
+__device__ __forceinline__ uint32_t cand_x1(const CandBuf &cb, int e, uint32_t key) {
+    if (!(key & KEY_HAS_INS)) return 0u;
+    const int m = *cb.nins < CAND_INS ? *cb.nins : CAND_INS;
+    for (int t = 0; t < m; t++) { const unsigned long long w = cb.ins[t]; if ((int)(w >> 32) == e) return (uint32_t)w; }
+    return 0u;
+}
 
 // experiment (PHZ_MAP_DBG bit 1024, timing only -- wrong bases): the byte that holds a base's two bits is read from the quality plane, inside the
 // 4-byte group of its quality byte, i.e. what a layout with both in one memory sector would fetch
@@ -214,12 +245,7 @@ __device__ int walk_read(const MapArgs &a, const VarWin &vw, const CigWin &cw, c
                     if (MODE == 0) {
                         // code 7 = one character, to be resolved from seq/qual; 4 = composite text (always a call)
                         const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicOr(cb.n, 1 << 30), 1 << 30);      // OR, not ADD: thousands of these in one tile must not wrap the counter
-                        if (slot < cb.cap) {
-                            cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)cnt << 8) | (nchars == 1 ? 7u : 4u);
-                            cb.var[slot] = i;
-                            cb.aux0[slot] = x0;
-                            cb.aux1[slot] = x1;
-                        }
+                        if (slot < cb.cap) cand_put(cb, slot, ((uint32_t)j << 16) | ((uint32_t)cnt << 8) | (nchars == 1 ? 7u : 4u), i, x0, x1);
                         cnt++;
                     } else {
                         int code = 4;
@@ -338,12 +364,9 @@ __device__ bool walk_lean(const int32_t *s_vpos, int wlen, int wdepth, int w0, c
                 const int nchars = (mlike ? 1 : 0) + (int)ilen;
                 if (nchars > 0) {
                     const int slot = cnt < 32 ? atomicAdd(cb.n, 1) : (atomicOr(cb.n, 1 << 30), 1 << 30);      // OR, not ADD: thousands of these in one tile must not wrap the counter
-                    if (slot < cb.cap) {
-                        cb.key[slot] = ((uint32_t)j << 16) | ((uint32_t)(cnt | 0x80) << 8) | (nchars == 1 ? 7u : 4u);
-                        cb.var[slot] = w0 + i;
-                        cb.aux0[slot] = mlike ? (uint32_t)(r + (uint32_t)(vp - lo)) : 0xFFFFFFFFu;
-                        cb.aux1[slot] = ilen > 0 ? ((ioff << 12) | ilen) : 0u;
-                    }
+                    if (slot < cb.cap)
+                        cand_put(cb, slot, ((uint32_t)j << 16) | ((uint32_t)(cnt | 0x80) << 8) | (nchars == 1 ? 7u : 4u), w0 + i,
+                                 mlike ? (uint32_t)(r + (uint32_t)(vp - lo)) : 0xFFFFFFFFu, ilen > 0 ? ((ioff << 12) | ilen) : 0u);
                     cnt++;
                 }
                 i++;
@@ -468,16 +491,16 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     __shared__ int32_t s_vpos[MAP_WIN];
     __shared__ uint32_t s_coff[TILE + 1];      // cigar_off slice; reused as per-read output offsets after the walk
     __shared__ uint32_t s_soff[TILE];
-    __shared__ int32_t s_pos[TILE];
-    __shared__ uint32_t s_mask[TILE];          // per read: bit o set <=> candidate with ordinal o is a call
+    __shared__ int32_t s_pos[TILE];            // record positions for the multi-op walk; after it the same words are s_mask
+    uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_pos);      // per read: bit o set <=> candidate with ordinal o is a call (resolve phase on)
     __shared__ uint16_t s_cx[TILE];            // reads that need the general CIGAR walk
     __shared__ uint32_t s_cig[CIG];
     __shared__ uint32_t s_key[CAND];
-    __shared__ int32_t s_var[CAND];
-    __shared__ uint32_t s_aux0[CAND];
-    __shared__ uint32_t s_aux1[CAND];
+    __shared__ uint16_t s_var[CAND];
+    __shared__ uint16_t s_x0[CAND];
+    __shared__ unsigned long long s_ins[CAND_INS];
     __shared__ int s_wsum[RPT][MAP_BLOCK / 64];
-    __shared__ int s_ncand, s_ncx, s_nlong;
+    __shared__ int s_ncand, s_ncx, s_nlong, s_nins;
     __shared__ uint32_t s_poison[TILE / 32];   // records the lean walker gave up on after it had appended candidates
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -515,9 +538,9 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
         const int j = k * MAP_BLOCK + tid;
-        s_pos[j] = rpos_[k]; s_soff[j] = soff_[k]; s_coff[j] = coff_[k]; s_mask[j] = 0;
+        s_pos[j] = rpos_[k]; s_soff[j] = soff_[k]; s_coff[j] = coff_[k];
     }
-    if (tid == 0) { s_coff[TILE] = coff_end; s_ncand = 0; s_ncx = 0; s_nlong = 0; }
+    if (tid == 0) { s_coff[TILE] = coff_end; s_ncand = 0; s_ncx = 0; s_nlong = 0; s_nins = 0; }
     if (tid < TILE / 32) s_poison[tid] = 0;
     const int wdepth = window_depth(vw.wlen);
     // INT_MAX beyond the window: lds_lower_bound probes without a bounds test.  Its halving chain enters at step 2^(wdepth-1) and its closing
@@ -537,7 +560,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     for (uint32_t j = (uint32_t)tid + 3u * MAP_BLOCK; j < cnt_w; j += MAP_BLOCK) s_cig[j] = a.cigar[cw.c_begin + j];
     __syncthreads();
     CandBuf cb;
-    cb.key = s_key; cb.var = s_var; cb.aux0 = s_aux0; cb.aux1 = s_aux1; cb.n = &s_ncand; cb.cap = CAND;
+    cb.key = s_key; cb.var = s_var; cb.x0 = s_x0; cb.ins = s_ins; cb.n = &s_ncand; cb.nins = &s_nins; cb.cap = CAND; cb.w0 = vw.w0;
     const long long cover = (long long)s_pos[nr - 1] + MAP_COVER;     // every het SNP below this is inside the window
 
     // ---- phase 1a: records made of one aligned run (the common case) never leave registers: an LDS-only,
@@ -634,10 +657,15 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         const bool done = lean_on && walk_lean(s_vpos, vw.wlen, wdepth, vw.w0, s_cig, cw.c_begin, (uint32_t)CIG, cb, s_poison, j, s_pos[j], s_coff[j], s_coff[j + 1], cover, a.dbg);
         if (!done) { s_cx[ts] = (uint16_t)(j | 0x8000); redo_any = true; }
     }
-    if (__syncthreads_or(redo_any ? 1 : 0)) {
+    const bool redo = __syncthreads_or(redo_any ? 1 : 0) != 0;
+    // the lean walk was the last reader of s_pos: its words become the per-record call masks (zeroed here, OR-ed after the next barrier);
+    // the few records left to the general walker fetch their position again
+#pragma unroll
+    for (int k = 0; k < RPT; k++) s_mask[k * MAP_BLOCK + tid] = 0;
+    if (redo) {
         for (int t = tid; t < ncx; t += MAP_BLOCK) {
             const int jf = s_cx[t < nshort ? t : TILE - 1 - (t - nshort)];
-            if (jf & 0x8000) { const int j = jf & 0x7FFF; walk_read<0>(a, vw, cw, cb, j, r0 + j, s_pos[j], s_coff[j], s_coff[j + 1], 0, 0, 0); }
+            if (jf & 0x8000) { const int j = jf & 0x7FFF; walk_read<0>(a, vw, cw, cb, j, r0 + j, a.pos[r0 + j], s_coff[j], s_coff[j + 1], 0, 0, 0); }
         }
     }
     __syncthreads();
@@ -648,8 +676,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     if (!fb && tid < ncand && !(a.dbg & 1)) {
         const uint32_t key = s_key[tid];
         if ((key & 0xFF) == 7u) {
-            const uint32_t x0 = s_aux0[tid];
-            cx_off = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(s_aux1[tid] >> 12);
+            const uint32_t x0 = cand_x0(cb, tid);
+            cx_off = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(cand_x1(cb, tid, key) >> 12);
             const uint32_t soff = s_soff[key >> 16];
             cq = a.qual[(size_t)soff * 4 + cx_off];
             cs = PHZ_SEQ_BYTE(a, soff, cx_off);
@@ -682,8 +710,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             int code = (int)(key & 0xFF);
             if ((key & 0x8000u) && ((s_poison[j >> 5] >> (j & 31)) & 1u)) code = -1;      // lean-origin candidate of a poisoned record
             else if (code == 7) {
-                const uint32_t x0 = s_aux0[e];
-                const int x = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(s_aux1[e] >> 12);
+                const uint32_t x0 = cand_x0(cb, e);
+                const int x = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(cand_x1(cb, e, key) >> 12);
                 int sy;
                 if (a.dbg & 1) sy = x & 3;
                 else if (e == tid && cx_off == x) {
@@ -745,14 +773,26 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             const int o = (int)s_coff[j] + __popc(s_mask[j] & ((1u << ord) - 1));
             if (o < a.slot_cap) {
                 const int64_t g = slot0 + o;
-                stage_put(a.stage, a.side, a.slots, g, (uint32_t)s_var[e], s_aux0[e], s_aux1[e], (uint32_t)j, key & 15u);
+                stage_put(a.stage, a.side, a.slots, g, (uint32_t)(vw.w0 + (int)s_var[e]), cand_x0(cb, e), cand_x1(cb, e, key), (uint32_t)j, key & 15u);
             }
         }
     }
 }
 
+// Eight waves per SIMD: the kernel's time follows the number of resident tiles (measured by padding the workgroups with unused LDS:
+// 12 / 11 / 10 / 8 / 6 tiles per CU = 1.21 / 1.39 / 1.51 / 1.67 / 2.56 ms), so the tile's LDS is kept under 10 KB (16 tiles per CU: tools/occ_probe2.hip
+// maps LDS bytes to resident workgroups) and the register allocation is held to 64 VGPRs (the scalar registers that no longer fit spill to
+// lanes of a vector register): 1.21 -> 1.09 ms.
+#ifndef PHZ_MAP_WAVES
+#define PHZ_MAP_WAVES 8
+#endif
+#if PHZ_MAP_WAVES > 0
+#define PHZ_MAP_OCC __attribute__((amdgpu_waves_per_eu(PHZ_MAP_WAVES, PHZ_MAP_WAVES)))
+#else
+#define PHZ_MAP_OCC
+#endif
 template <int MAP_BLOCK, int RPT, bool ABL>
-__global__ __launch_bounds__(MAP_BLOCK) void k_map(MapBatch bt) {
+__global__ __launch_bounds__(MAP_BLOCK) PHZ_MAP_OCC void k_map(MapBatch bt) {
     // (XCD-contiguous tile order -- workgroup i runs on XCD i % 8; every XCD given one contiguous eighth of the tiles -- was measured in
     // round 4 for k_map, k_line, k_tile and k_pairs: no gain anywhere, 1.291 against 1.282 ms here.  Neighbouring tiles share only their
     // het-SNP window, which the memory-side cache serves.)
@@ -1008,8 +1048,10 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm, bt, tile_reads);
         PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[0], sm));
-#define PHZ_LAUNCH_MAP(B, R) do { if (bt.dbg) hipLaunchKernelGGL((k_map<B, R, true>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt); \
-                                 else hipLaunchKernelGGL((k_map<B, R, false>), dim3((unsigned)ntiles), dim3(B), 0, sm, bt); } while (0)
+        unsigned dyn_lds = 0;          // experiment: dynamic LDS nobody uses, to bound the workgroups per CU (PHZ_MAP_DYNLDS bytes)
+        { const char *e = getenv("PHZ_MAP_DYNLDS"); if (e && atoi(e) > 0) dyn_lds = (unsigned)atoi(e); }
+#define PHZ_LAUNCH_MAP(B, R) do { if (bt.dbg) hipLaunchKernelGGL((k_map<B, R, true>), dim3((unsigned)ntiles), dim3(B), dyn_lds, sm, bt); \
+                                 else hipLaunchKernelGGL((k_map<B, R, false>), dim3((unsigned)ntiles), dim3(B), dyn_lds, sm, bt); } while (0)
         if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
         else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
         else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
