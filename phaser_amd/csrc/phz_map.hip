@@ -983,7 +983,9 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
     int rpt = 2, blk = 128;
     { const char *e = getenv("PHZ_MAP_RPT"); if (e && atoi(e) > 0) rpt = atoi(e); }
     { const char *e = getenv("PHZ_MAP_BLOCK"); if (e && atoi(e) > 0) blk = atoi(e); }
-    if (!((blk == 64 || blk == 128 || blk == 256) && (rpt == 2 || rpt == 4))) return phz_fail(ctx, PHZ_E_ARG, "bad PHZ_MAP_BLOCK / PHZ_MAP_RPT");
+    // (64 x 2 / 64 x 4 / 128 x 4 / 256 x 4 records per tile were swept in rounds 1-3 -- 1.84 ms and worse against 1.28 -- and are no longer built:
+    // their tiles cannot be held at eight waves per SIMD)
+    if (!((blk == 128 || blk == 256) && rpt == 2)) return phz_fail(ctx, PHZ_E_ARG, "bad PHZ_MAP_BLOCK / PHZ_MAP_RPT");
     const int tile_reads = blk * rpt;
     // live shards (records and variants present) and their tile ranges
     std::vector<int> live;
@@ -1052,12 +1054,8 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         { const char *e = getenv("PHZ_MAP_DYNLDS"); if (e && atoi(e) > 0) dyn_lds = (unsigned)atoi(e); }
 #define PHZ_LAUNCH_MAP(B, R) do { if (bt.dbg) hipLaunchKernelGGL((k_map<B, R, true>), dim3((unsigned)ntiles), dim3(B), dyn_lds, sm, bt); \
                                  else hipLaunchKernelGGL((k_map<B, R, false>), dim3((unsigned)ntiles), dim3(B), dyn_lds, sm, bt); } while (0)
-        if (blk == 64 && rpt == 2) PHZ_LAUNCH_MAP(64, 2);
-        else if (blk == 64 && rpt == 4) PHZ_LAUNCH_MAP(64, 4);
-        else if (blk == 128 && rpt == 2) PHZ_LAUNCH_MAP(128, 2);
-        else if (blk == 128 && rpt == 4) PHZ_LAUNCH_MAP(128, 4);
-        else if (blk == 256 && rpt == 2) PHZ_LAUNCH_MAP(256, 2);
-        else PHZ_LAUNCH_MAP(256, 4);
+        if (blk == 128) PHZ_LAUNCH_MAP(128, 2);
+        else PHZ_LAUNCH_MAP(256, 2);
 #undef PHZ_LAUNCH_MAP
         PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[1], sm));
         hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(1024), 0, sm, (const int32_t *)S[17].p, ntiles, tile_pref, chunk_sum,
