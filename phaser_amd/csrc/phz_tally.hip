@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long 
 // workgroup; only lines outside the window (introns reaching far) use global atomics directly.
 constexpr int TW = 1024;            // variants per LDS window
 constexpr int LINES_PER_BLOCK = 2048;
+#ifndef PHZ_LINE_TB
+#define PHZ_LINE_TB 512
+#endif
+constexpr int LINE_TB = PHZ_LINE_TB;   // threads per workgroup of k_line
 
 struct LineOut {
     const uint8_t *a0, *a1;
@@ -115,7 +119,7 @@ struct LineOut {
     unsigned long long *prof;        // PHZ_TALLY_PROFILE=1: start / end clock of every workgroup
 };
 
-__global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
+__global__ __launch_bounds__(LINE_TB) void k_line(LinesTab T, LineOut O) {
     if (O.prof && threadIdx.x == 0) O.prof[2 * (size_t)blockIdx.x] = wall_clock64();
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
@@ -126,18 +130,18 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
     __shared__ unsigned int s_kept;
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)bx * LINES_PER_BLOCK;
-    for (int j = tid; j < TW * 3; j += 256) s_cnt[j] = 0;
-    for (int j = tid; j < TW; j += 256) s_first[j] = ~0ull;
+    for (int j = tid; j < TW * 3; j += LINE_TB) s_cnt[j] = 0;
+    for (int j = tid; j < TW; j += LINE_TB) s_first[j] = ~0ull;
     if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
     __syncthreads();
     const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;       // a little room below (mate pairs / overlapping records)
     unsigned int kept = 0;
     // all loads of a lane's eight lines are requested before the first one is used (two dependent rounds: the line, then its record / variant)
-    constexpr int K = LINES_PER_BLOCK / 256;
+    constexpr int K = LINES_PER_BLOCK / LINE_TB;
     int l_r[K], l_v[K], l_as[K]; uint32_t l_q[K]; uint8_t l_code[K], l_has[K], l_a0[K], l_a1[K]; bool l_in[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int64_t i = i0 + tid + 256 * k;
+        const int64_t i = i0 + tid + LINE_TB * k;
         l_in[k] = i < L.n;
         l_r[k] = l_in[k] ? L.read_idx[i] : 0; l_v[k] = l_in[k] ? L.var_idx[i] + L.var_base : 0; l_code[k] = l_in[k] ? L.code[i] : (uint8_t)4;
     }
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (!l_in[k]) continue;
-        const int64_t g = L.line_base + i0 + tid + 256 * k;
+        const int64_t g = L.line_base + i0 + tid + LINE_TB * k;
         const int v = l_v[k];
         const bool keep = !L.use_cutoff || (l_has[k] && (double)l_as[k] >= L.cutoff);
         if (!keep) { O.line_cls[g] = 255; continue; }
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
     }
     if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
-    for (int j = tid; j < TW * 3; j += 256) {
+    for (int j = tid; j < TW * 3; j += LINE_TB) {
         const int c = s_cnt[j];
         if (c) {
             const int64_t v = vbase + j / 3; const int cls = j % 3;
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void k_line(LinesTab T, LineOut O) {
             if (cls < 2) atomicAdd(&O.rl_cnt[(v * 2 + cls) * O.nb + L.bam], (uint32_t)c);
         }
     }
-    for (int j = tid; j < TW; j += 256) {
+    for (int j = tid; j < TW; j += LINE_TB) {
         const unsigned long long f = s_first[j];
         if (f != ~0ull) atomicMin(&O.var_first[vbase + j], f);
     }
@@ -221,7 +225,11 @@ __device__ __forceinline__ uint64_t dist_pack(uint32_t q, uint32_t v, uint32_t c
 #endif
 constexpr int TL = PHZ_TALLY_TILE; // lines per tile of k_tile
 constexpr int TH = 2 * TL;         // LDS hash slots (at most TL distinct QNAMEs: load factor <= 0.5)
-constexpr int TSP = TH / 256;      // slots per thread
+#ifndef PHZ_TILE_TB
+#define PHZ_TILE_TB 512
+#endif
+constexpr int TILE_TB = PHZ_TILE_TB < TL ? PHZ_TILE_TB : TL;   // threads per workgroup of k_tile
+constexpr int TSP = TH / TILE_TB;  // slots per thread
 constexpr int TH_SHIFT = TL == 1024 ? 21 : (TL == 512 ? 22 : 23);
 static_assert(TL == 1024 || TL == 512 || TL == 256, "tile of 256 / 512 / 1024 lines");
 constexpr int TWT = 256;           // variants per LDS window of k_tile (1,024 lines span ~100 variants)
@@ -241,7 +249,7 @@ struct TileOut {
     unsigned long long *prof;
 };
 
-__global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
+__global__ __launch_bounds__(TILE_TB) void k_tile(LinesTab T, TileOut O) {
     if (O.prof && threadIdx.x == 0) O.prof[2 * (size_t)blockIdx.x] = wall_clock64();
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     __shared__ uint32_t s_rl[TL / 2 > TWT * 2 ? TL / 2 : TWT * 2];   // read-list entries of (variant, allele) in this tile -> base of the tile's chunk in the list;
                                                  // later: the slots whose QNAMEs this tile puts on the list of spilled QNAMEs (16 bits each)
     __shared__ uint16_t s_grp[TL];               // the occupied slots, densely: group g of the tile lives in slot s_grp[g]
-    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_part[TILE_TB / 64];
     __shared__ int s_vbase;
     __shared__ uint32_t s_nspill, s_ntouch, s_nkept, s_ngroups;
     __shared__ unsigned long long s_obase;
@@ -262,17 +270,17 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     const int tid = threadIdx.x;
     const int64_t i0 = (int64_t)bx * TL;
     if (tid == 0) { s_nspill = 0; s_ntouch = 0; }
-    for (int j = tid; j < TH; j += 256) { s_q[j] = Q_EMPTY; s_c[j] = 0u; }
-    for (int j = tid; j < TWT * 3; j += 256) s_cnt[j] = 0;
-    for (int j = tid; j < TWT; j += 256) s_rank[j] = ~0ull;
-    for (int j = tid; j < TWT * 2; j += 256) s_rl[j] = 0u;
+    for (int j = tid; j < TH; j += TILE_TB) { s_q[j] = Q_EMPTY; s_c[j] = 0u; }
+    for (int j = tid; j < TWT * 3; j += TILE_TB) s_cnt[j] = 0;
+    for (int j = tid; j < TWT; j += TILE_TB) s_rank[j] = ~0ull;
+    for (int j = tid; j < TWT * 2; j += TILE_TB) s_rl[j] = 0u;
     if (tid == 0) s_vbase = L.var_idx[i0] + L.var_base;
     // ---- 1. the tile's lines: QNAME -> slot (count), read-list entry -> rank inside the tile's chunk
-    constexpr int K = TL / 256;
+    constexpr int K = TL / TILE_TB;
     uint32_t l_cls[K], l_q[K], l_v[K], l_slot[K], l_rank[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int64_t i = i0 + tid + 256 * k;
+        const int64_t i = i0 + tid + TILE_TB * k;
         l_cls[k] = 255u; l_q[k] = 0u; l_v[k] = 0u;
         if (i < L.n) {
             const int64_t g = L.line_base + i;
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
             const unsigned d = l_v[k] - (unsigned)vbase;
             if (d < (unsigned)TWT) l_rank[k] = atomicAdd(&s_rl[d * 2 + l_cls[k]], 1u);
             else {                                               // a line far from the tile's window (long intron): straight to its list
-                const int64_t i = i0 + tid + 256 * k;
+                const int64_t i = i0 + tid + TILE_TB * k;
                 const uint32_t e = (l_v[k] * 2u + l_cls[k]) * (uint32_t)O.nb + (uint32_t)L.bam;
                 O.rl_tmp[atomicAdd(&O.rl_cursor[e], 1u)] = ((uint64_t)(uint32_t)(L.line_base + i) << 32) | (uint32_t)(q - L.qid_base);
             }
@@ -307,11 +315,12 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     __syncthreads();
     // ---- 2. requested now, used later: the totals of the QNAMEs in this lane's slots and one cursor step per (tile, read list);
     //         meanwhile the group ranges (exclusive scan of the slot counts)
-    uint32_t rl_base[TWT * 2 / 256];
+    constexpr int NRLB = (TWT * 2 + TILE_TB - 1) / TILE_TB;
+    uint32_t rl_base[NRLB];
 #pragma unroll
-    for (int j = 0; j < TWT * 2 / 256; j++) {
-        const int x = tid + 256 * j;
-        rl_base[j] = s_rl[x];
+    for (int j = 0; j < NRLB; j++) {
+        const int x = tid + TILE_TB * j;
+        rl_base[j] = x < TWT * 2 ? s_rl[x] : 0u;
         if (rl_base[j]) rl_base[j] = atomicAdd(&O.rl_cursor[((uint32_t)(vbase + (x >> 1)) * 2u + (uint32_t)(x & 1)) * (uint32_t)O.nb + (uint32_t)L.bam], rl_base[j]);
     }
     {
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         __syncthreads();
         uint32_t base = incl - sum;
         for (int w = 0; w < (tid >> 6); w++) base += s_part[w];
-        if (tid == 255) { s_nkept = (base + sum) & 0xFFFFu; s_ngroups = (base + sum) >> 16; }
+        if (tid == TILE_TB - 1) { s_nkept = (base + sum) & 0xFFFFu; s_ngroups = (base + sum) >> 16; }
 #pragma unroll
         for (int j = 0; j < TSP; j++) {
             s_c[tid * TSP + j] = base & 0xFFFFu;
@@ -335,16 +344,16 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < TWT * 2 / 256; j++) s_rl[tid + 256 * j] = rl_base[j];
+    for (int j = 0; j < NRLB; j++) if (tid + TILE_TB * j < TWT * 2) s_rl[tid + TILE_TB * j] = rl_base[j];
     __syncthreads();
     // ---- 3. lines into their groups, read-list entries into their lists; the totals of the QNAMEs of this lane's groups are requested
     //         first (used after the next barrier)
-    constexpr int GK = TL / 256;                            // groups per lane (a tile of TL lines holds at most TL groups)
+    constexpr int GK = TL / TILE_TB;                            // groups per lane (a tile of TL lines holds at most TL groups)
     const uint32_t ngroups = s_ngroups;
     uint32_t tot[GK], my_q[GK], my_slot[GK];
 #pragma unroll
     for (int j = 0; j < GK; j++) {
-        const uint32_t gi = (uint32_t)tid + 256u * (uint32_t)j;
+        const uint32_t gi = (uint32_t)tid + (uint32_t)TILE_TB * (uint32_t)j;
         my_slot[j] = gi < ngroups ? (uint32_t)s_grp[gi] : Q_EMPTY;
         my_q[j] = my_slot[j] != Q_EMPTY ? s_q[my_slot[j]] : Q_EMPTY;
         tot[j] = my_q[j] != Q_EMPTY ? O.qcount[my_q[j]] : 0u;
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (l_slot[k] == Q_EMPTY) continue;
-        const int64_t i = i0 + tid + 256 * k;
+        const int64_t i = i0 + tid + TILE_TB * k;
         const uint32_t g = (uint32_t)(L.line_base + i);
         s_it[atomicAdd(&s_c[l_slot[k]], 1u)] = item_pack(l_v[k], l_cls[k], g);
         if (l_rank[k] != Q_EMPTY) {
@@ -431,13 +440,13 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
     uint64_t *dst = O.items + ((int64_t)blockIdx.x * TL);
     {
         const uint32_t nk = s_nkept;
-        for (int j = tid; j < TL; j += 256) dst[j] = (uint32_t)j < nk ? s_it[j] : KEY_DROPPED;
+        for (int j = tid; j < TL; j += TILE_TB) dst[j] = (uint32_t)j < nk ? s_it[j] : KEY_DROPPED;
     }
-    for (int j = tid; j < TWT * 3; j += 256) {
+    for (int j = tid; j < TWT * 3; j += TILE_TB) {
         const int cc = s_cnt[j];
         if (cc) atomicAdd(&O.var_distinct[(int64_t)(vbase + j / 3) * 3 + (j % 3)], cc);
     }
-    for (int j = tid; j < TWT; j += 256) {
+    for (int j = tid; j < TWT; j += TILE_TB) {
         const unsigned long long f = s_rank[j];
         if (f != ~0ull) atomicMin(&O.var_rank[vbase + j], f);
     }
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(256) void k_tile(LinesTab T, TileOut O) {
             dst[sp_beg[j] + a] = KEY_DROPPED;
         }
     }
-    for (uint32_t j = tid; j < s_ntouch; j += 256) O.touched[touch_base + j] = s_q[s_touch[j]];
+    for (uint32_t j = tid; j < s_ntouch; j += TILE_TB) O.touched[touch_base + j] = s_q[s_touch[j]];
 }
 
 // the spilled lines into the groups of their QNAMEs (ranges from the scan over the spilled QNAMEs' line counts)
@@ -591,19 +600,25 @@ __device__ __forceinline__ int global_slot(uint32_t *tab, uint32_t gmask, uint64
 // (class_a, class_b) of that variant pair.  One thread per item slot (the pairs of an item with the later items of its group): PAIR_ITEMS
 // slots per workgroup.  The slots this workgroup claims in the global table go to the list of used slots.
 constexpr int PAIR_ITEMS = 2048;      // item slots per round
+#ifndef PHZ_PAIRS_TB
+#define PHZ_PAIRS_TB 512
+#endif
+constexpr int PAIRS_TB = PHZ_PAIRS_TB;   // threads per workgroup of k_pairs
 constexpr int PAIR_ROUNDS = 1;        // rounds per workgroup sharing one LDS table and one flush (2: the table overflows, 0.35 -> 0.43 ms)
-template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_t *items, int64_t m, uint32_t *tab, uint32_t gmask, uint32_t *used, unsigned long long *counters) {
+template <int MODE> __global__ __launch_bounds__(PAIRS_TB) void k_pairs(const uint64_t *items, int64_t m, uint32_t *tab, uint32_t gmask, uint32_t *used, uint64_t *used_key, uint32_t *deg,
+                                                                       unsigned long long *counters) {
     __shared__ unsigned long long s_keys[PH_SLOTS];
     __shared__ uint32_t s_vals[PH_SLOTS * PH_WORDS];
     __shared__ uint32_t s_claim[PH_SLOTS];
-    __shared__ unsigned int s_part[4], s_ipart[4], s_nclaim;
+    __shared__ uint16_t s_claim_l[PH_SLOTS];     // LDS slot of the claim (its key is still there when the list goes out)
+    __shared__ unsigned int s_part[PAIRS_TB / 64], s_ipart[PAIRS_TB / 64], s_nclaim;
     __shared__ unsigned long long s_ubase;
-    for (int j = threadIdx.x; j < PH_SLOTS; j += 256) s_keys[j] = KEY_DROPPED;
-    for (int j = threadIdx.x; j < PH_SLOTS * PH_WORDS; j += 256) s_vals[j] = 0;
+    for (int j = threadIdx.x; j < PH_SLOTS; j += PAIRS_TB) s_keys[j] = KEY_DROPPED;
+    for (int j = threadIdx.x; j < PH_SLOTS * PH_WORDS; j += PAIRS_TB) s_vals[j] = 0;
     if (threadIdx.x == 0) s_nclaim = 0;
     __syncthreads();
     unsigned int n_event = 0, n_item = 0;
-    constexpr int KI = PAIR_ITEMS / 256;
+    constexpr int KI = PAIR_ITEMS / PAIRS_TB;
     // A wave holds 64 consecutive items per round (one per lane) plus the 64 after them: the later items of a lane's group are read from the
     // neighbouring lanes (the groups are a handful of items long), no memory access inside the pair loop
     const int lane = threadIdx.x & 63;
@@ -613,13 +628,13 @@ template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_
     unsigned long long my_item[KI], nx_item[KI];
 #pragma unroll
     for (int t = 0; t < KI; t++) {                           // all of the lane's items requested together
-        const int64_t i = i0 + threadIdx.x + 256 * t;
+        const int64_t i = i0 + threadIdx.x + PAIRS_TB * t;
         my_item[t] = i < m ? items[i] : KEY_DROPPED;
         nx_item[t] = i + 64 < m ? items[i + 64] : KEY_DROPPED;
     }
 #pragma unroll
     for (int t = 0; t < KI; t++) {
-        const int64_t i = i0 + threadIdx.x + 256 * t;
+        const int64_t i = i0 + threadIdx.x + PAIRS_TB * t;
         const unsigned long long k = my_item[t];
         bool active = k != KEY_DROPPED;
         if (active) n_item++;
@@ -638,6 +653,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_
             if (v2 == v) ev = false;
             bool claimed = false;
             int gs = -1;
+            uint64_t ck = 0;
             if (ev) {
                 n_event++;
                 const uint32_t cls2 = (uint32_t)(k2 >> 2) & 3u, ln2 = (uint32_t)k2 & 1u;
@@ -659,6 +675,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_
                 // the LDS table is full (a tile whose QNAMEs pair up variants all over the chromosome: QNAME ids shared by unrelated reads of
                 // several BAMs): straight to the global table
                 if (!done) {
+                    ck = pk;
                     gs = global_slot(tab, gmask, pk, counters, &claimed);
                     if (gs >= 0) {
                         atomicAdd(&tab[(size_t)gs * GE_WORDS + GE_CELL0 + cell], 1u);
@@ -674,7 +691,11 @@ template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_
                 unsigned long long base = 0;
                 if (lane == leader) base = atomicAdd(&counters[7], (unsigned long long)__popcll(cm));
                 base = __shfl(base, leader);
-                if (claimed) used[base + (unsigned long long)__popcll(cm & ((1ull << lane) - 1ull))] = (uint32_t)gs;
+                if (claimed) {
+                    const unsigned long long at = base + (unsigned long long)__popcll(cm & ((1ull << lane) - 1ull));
+                    used[at] = (uint32_t)gs; used_key[at] = ck;
+                    atomicAdd(&deg[(uint32_t)(ck >> 32)], 1u);
+                }
             }
         }
     }
@@ -685,23 +706,23 @@ template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_
     __syncthreads();
     if (MODE != 0) { if (n_item == 12345678u) used[0] = s_vals[threadIdx.x]; return; }
     {
-        constexpr int KS = PH_SLOTS / 256;
+        constexpr int KS = PH_SLOTS / PAIRS_TB;
         uint64_t pk[KS]; uint32_t hs[KS]; unsigned long long prev[KS];
 #pragma unroll
         for (int t = 0; t < KS; t++) {                       // the first probe of each of the lane's slots requested together
-            pk[t] = s_keys[threadIdx.x + 256 * t];
+            pk[t] = s_keys[threadIdx.x + PAIRS_TB * t];
             hs[t] = pair_home(pk[t], gmask); prev[t] = 0ull;
             if (pk[t] != KEY_DROPPED) prev[t] = atomicCAS((unsigned long long *)(tab + (size_t)hs[t] * GE_WORDS), 0ull, (unsigned long long)pk[t]);
         }
 #pragma unroll
         for (int t = 0; t < KS; t++) {
             if (pk[t] == KEY_DROPPED) continue;
-            const int j = threadIdx.x + 256 * t;
+            const int j = threadIdx.x + PAIRS_TB * t;
             bool claimed = prev[t] == 0ull;
             int gs = (int)hs[t];
             if (!claimed && prev[t] != pk[t]) gs = global_slot(tab, gmask, pk[t], counters, &claimed);      // taken by another pair: probe on
             if (gs < 0) continue;
-            if (claimed) s_claim[atomicAdd(&s_nclaim, 1u)] = (uint32_t)gs;
+            if (claimed) { const uint32_t at = atomicAdd(&s_nclaim, 1u); s_claim[at] = (uint32_t)gs; s_claim_l[at] = (uint16_t)j; }
             uint32_t *e = tab + (size_t)gs * GE_WORDS;
 #pragma unroll
             for (int c = 0; c < 9; c++) {
@@ -713,76 +734,81 @@ template <int MODE> __global__ __launch_bounds__(256) void k_pairs(const uint64_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long b = (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        unsigned long long b = 0, ni = 0;
+        for (int w = 0; w < PAIRS_TB / 64; w++) { b += s_part[w]; ni += s_ipart[w]; }
         unsigned long long *spread = counters + 16 + (blockIdx.x % N_SPREAD) * SPREAD_WORDS;
         if (b) atomicAdd(&spread[1], b);
-        const unsigned long long ni = (unsigned long long)s_ipart[0] + s_ipart[1] + s_ipart[2] + s_ipart[3];
         if (ni) atomicAdd(&spread[0], ni);                    // distinct (QNAME, variant, class) items
         s_ubase = s_nclaim ? atomicAdd(&counters[7], (unsigned long long)s_nclaim) : 0ull;      // one global atomic per workgroup
     }
     __syncthreads();
-    for (unsigned j = threadIdx.x; j < s_nclaim; j += 256) used[s_ubase + j] = s_claim[j];
+    // the claimed slots go to the used-slot list together with their keys, and every claim counts as one edge of its first variant: the
+    // counting sort of the edges by variant starts from finished degrees and never has to look a key up in the table
+    for (unsigned j = threadIdx.x; j < s_nclaim; j += PAIRS_TB) {
+        const unsigned long long key = s_keys[s_claim_l[j]];
+        used[s_ubase + j] = s_claim[j]; used_key[s_ubase + j] = key;
+        atomicAdd(&deg[(uint32_t)(key >> 32)], 1u);
+    }
 }
 
-// ---- edge list in (a, b) order: counting sort of the USED table slots by a, each (small) group sorted by b
-__global__ __launch_bounds__(256) void k_edge_count(const uint32_t *used, int64_t n_used, const uint32_t *tab, uint32_t *deg) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n_used) atomicAdd(&deg[tab[(size_t)used[i] * GE_WORDS + 1]], 1u);            // word 1 = high half of the key = a
-}
-__global__ __launch_bounds__(256) void k_edge_scatter(const uint32_t *used, int64_t n_used, const uint32_t *tab, const uint32_t *eoff, uint32_t *deg,
-                                                      uint32_t *e_b, uint32_t *e_slot) {
+// ---- edge list in (a, b) order: counting sort of the used table slots by a (the degrees were counted by k_pairs as it claimed the slots);
+//      the position of an edge inside its variant's (small) group is the number of group members with a smaller b
+constexpr uint32_t EDGE_RANK_MAX = 24;      // groups up to this size are ranked by counting; larger ones are sorted first
+__global__ __launch_bounds__(256) void k_edge_scatter(const uint32_t *used, const uint64_t *used_key, int64_t n_used, const uint32_t *eoff, uint32_t *deg,
+                                                      uint32_t *e_a, uint32_t *e_b, uint32_t *e_slot) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_used) return;
-    const uint32_t s = used[i];
-    const uint2 k = *(const uint2 *)(tab + (size_t)s * GE_WORDS);            // .x = b, .y = a
-    const uint32_t old = atomicSub(&deg[k.y], 1u);
-    const uint32_t p = eoff[k.y] + old - 1;
-    e_b[p] = k.x; e_slot[p] = s;
+    const uint64_t k = used_key[i];
+    const uint32_t a = (uint32_t)(k >> 32);
+    const uint32_t old = atomicSub(&deg[a], 1u);               // the counters go back to zero
+    const uint32_t p = eoff[a] + old - 1;
+    e_a[p] = a; e_b[p] = (uint32_t)k; e_slot[p] = used[i];
 }
-// one thread per variant: its (few) edges sorted by b
-__global__ __launch_bounds__(256) void k_edge_sort(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot, int32_t *ea, int32_t *eb) {
+// one thread per variant with more than EDGE_RANK_MAX edges (QNAME ids shared by unrelated reads pair a variant with thousands of others):
+// heap sort of its group in place, the keys are distinct
+__global__ __launch_bounds__(256) void k_edge_sort_big(int64_t nv, const uint32_t *eoff, uint32_t *e_b, uint32_t *e_slot) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= nv) return;
     const uint32_t lo = eoff[a], hi = eoff[a + 1], d = hi - lo;
-    if (d <= 24u) {
-        for (uint32_t i = lo + 1; i < hi; i++) {
-            const uint32_t xb = e_b[i], xs = e_slot[i];
-            uint32_t j = i;
-            while (j > lo && e_b[j - 1] > xb) { e_b[j] = e_b[j - 1]; e_slot[j] = e_slot[j - 1]; j--; }
-            e_b[j] = xb; e_slot[j] = xs;
+    if (d <= EDGE_RANK_MAX) return;
+    uint32_t *kb = e_b + lo, *ks = e_slot + lo;
+    auto sift = [&](uint32_t root, uint32_t n) {
+        const uint32_t xb = kb[root], xs = ks[root];
+        for (;;) {
+            uint32_t c = 2 * root + 1;
+            if (c >= n) break;
+            if (c + 1 < n && kb[c + 1] > kb[c]) c++;
+            if (kb[c] <= xb) break;
+            kb[root] = kb[c]; ks[root] = ks[c]; root = c;
         }
-    } else {
-        // a variant paired with thousands of others (QNAME ids shared by unrelated reads): heap sort in place, the keys are distinct
-        uint32_t *kb = e_b + lo, *ks = e_slot + lo;
-        auto sift = [&](uint32_t root, uint32_t n) {
-            const uint32_t xb = kb[root], xs = ks[root];
-            for (;;) {
-                uint32_t c = 2 * root + 1;
-                if (c >= n) break;
-                if (c + 1 < n && kb[c + 1] > kb[c]) c++;
-                if (kb[c] <= xb) break;
-                kb[root] = kb[c]; ks[root] = ks[c]; root = c;
-            }
-            kb[root] = xb; ks[root] = xs;
-        };
-        for (uint32_t i = d / 2; i-- > 0;) sift(i, d);
-        for (uint32_t n = d - 1; n > 0; n--) {
-            const uint32_t tb = kb[0], ts = ks[0];
-            kb[0] = kb[n]; ks[0] = ks[n]; kb[n] = tb; ks[n] = ts;
-            sift(0, n);
-        }
+        kb[root] = xb; ks[root] = xs;
+    };
+    for (uint32_t i = d / 2; i-- > 0;) sift(i, d);
+    for (uint32_t n = d - 1; n > 0; n--) {
+        const uint32_t tb = kb[0], ts = ks[0];
+        kb[0] = kb[n]; ks[0] = ks[n]; kb[n] = tb; ks[n] = ts;
+        sift(0, n);
     }
-    for (uint32_t i = lo; i < hi; i++) { ea[i] = (int32_t)a; eb[i] = (int32_t)e_b[i]; }
 }
-// one thread per edge: its table entry (one sector) read, the result columns written, the entry returned to "empty" -- the table is left
-// clean slot by slot, so the next call needs no memset of it
-__global__ __launch_bounds__(256) void k_edge_out(int64_t ne, const uint32_t *e_slot, uint32_t *tab, int32_t *cells, uint8_t *linked, int32_t *cto, int32_t *stats) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= ne) return;
-    uint4 *e = (uint4 *)(tab + (size_t)e_slot[i] * GE_WORDS);
-    const uint4 w0 = e[0], w1 = e[1], w2 = e[2];
+// one thread per edge: its place in the (a, b)-ordered list, its table entry (one sector) read, the result columns written, the entry returned
+// to "empty" -- the table is left clean slot by slot, so the next call needs no memset of it
+__global__ __launch_bounds__(256) void k_edge_out(int64_t ne, const uint32_t *eoff, const uint32_t *e_a, const uint32_t *e_b, const uint32_t *e_slot, uint32_t *tab,
+                                                  int32_t *ea, int32_t *eb, int32_t *cells, uint8_t *linked, int32_t *cto, int32_t *stats) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= ne) return;
+    uint4 *e = (uint4 *)(tab + (size_t)e_slot[p] * GE_WORDS);
+    const uint4 w0 = e[0], w1 = e[1], w2 = e[2];                      // requested before the group is looked at
+    const uint32_t a = e_a[p], b = e_b[p];
+    const uint32_t lo = eoff[a], hi = eoff[a + 1];
+    uint32_t rank = (uint32_t)p - lo;                                 // a sorted group
+    if (hi - lo <= EDGE_RANK_MAX) {
+        rank = 0;
+        for (uint32_t j = lo; j < hi; j++) rank += e_b[j] < b ? 1u : 0u;
+    }
+    const int64_t i = (int64_t)lo + rank;
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     e[0] = z; e[1] = z; e[2] = z;
+    ea[i] = (int32_t)a; eb[i] = (int32_t)b;
     const int32_t x[9] = {(int32_t)w0.z, (int32_t)w0.w, (int32_t)w1.x, (int32_t)w1.y, (int32_t)w1.z, (int32_t)w1.w, (int32_t)w2.x, (int32_t)w2.y, (int32_t)w2.z};
 #pragma unroll
     for (int c = 0; c < 9; c++) cells[i * 9 + c] = x[c];
@@ -798,31 +824,58 @@ __global__ __launch_bounds__(256) void k_edge_out(int64_t ne, const uint32_t *e_
 
 // ---- read lists: entries were placed by atomics; put every list into line order and keep the QNAME ids
 constexpr int RL_SMALL = 16, RL_LDS = 4096;
-// counters32[0] lists left to the workgroup kernel, [1] lists left to the host-driven sort
-__global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t *rl_start, uint64_t *rl_tmp, int32_t *rl_qid, uint32_t *wave_list, uint32_t *mid_list,
-                                                 uint32_t *big_list, uint32_t *counters32) {
+#ifndef PHZ_RL_STAGE
+#define PHZ_RL_STAGE 2048
+#endif
+constexpr int RL_STAGE = PHZ_RL_STAGE;      // entries a workgroup of k_rl_sort stages in LDS (the emulation tests also build a tiny stage: both paths)
+template <class P> __device__ __forceinline__ void rl_insertion_sort(P x, uint32_t n) {
+    for (uint32_t a = 1; a < n; a++) {
+        const unsigned long long t = x[a];
+        uint32_t j = a;
+        while (j > 0 && x[j - 1] > t) { x[j] = x[j - 1]; j--; }
+        x[j] = t;
+    }
+}
+// counters32[0] lists left to the workgroup kernel, [1] lists left to the host-driven sort, [2] lists left to the wave kernel.
+// One thread per list; the entries of a workgroup's 256 consecutive lists are one contiguous stretch of rl_tmp, which is staged in LDS
+// with coalesced loads, sorted there list by list (<= 16 entries: insertion sort by the list's thread) and written back with coalesced
+// stores -- one thread walking its list in global memory touched a memory sector per 8-byte entry: 0.22 ms per genome against 0.08 ms.
+// (A stretch longer than the stage -- deeply covered variants -- keeps the walk in global memory.)
+__global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t *rl_start, uint64_t *rl_tmp, int32_t *rl_qid, const uint32_t *rl_list, uint32_t *wave_list,
+                                                 uint32_t *mid_list, uint32_t *big_list, uint32_t *counters32) {
     __shared__ uint32_t s_list[3][256];
     __shared__ uint32_t s_n[3], s_base[3];
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned long long s_x[RL_STAGE];
+    __shared__ uint32_t s_start[257];
+    const int64_t e0 = (int64_t)blockIdx.x * 256, e = e0 + threadIdx.x;
     if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+    s_start[threadIdx.x] = rl_start[e < nlists ? e : nlists];
+    if (threadIdx.x == 0) s_start[256] = rl_start[e0 + 256 < nlists ? e0 + 256 : nlists];
+    __syncthreads();
+    const uint32_t base = s_start[0], total = s_start[256] - base;
+    const bool staged = total <= (uint32_t)RL_STAGE;
+    if (staged) for (uint32_t p = threadIdx.x; p < total; p += 256) s_x[p] = rl_tmp[base + p];
     __syncthreads();
     if (e < nlists) {
-        const uint32_t lo = rl_start[e], hi = rl_start[e + 1], n = hi - lo;
+        const uint32_t lo = s_start[threadIdx.x], hi = s_start[threadIdx.x + 1], n = hi - lo;
         if (n > (uint32_t)RL_LDS) s_list[1][atomicAdd(&s_n[1], 1u)] = (uint32_t)e;
         else if (n > 64u) s_list[0][atomicAdd(&s_n[0], 1u)] = (uint32_t)e;
         else if (n > (uint32_t)RL_SMALL) s_list[2][atomicAdd(&s_n[2], 1u)] = (uint32_t)e;
         else if (n > 0) {
-            uint64_t *x = rl_tmp + lo;
-            for (uint32_t a = 1; a < n; a++) {
-                const uint64_t t = x[a];
-                uint32_t j = a;
-                while (j > 0 && x[j - 1] > t) { x[j] = x[j - 1]; j--; }
-                x[j] = t;
+            if (staged) rl_insertion_sort(s_x + (lo - base), n);
+            else {
+                uint64_t *x = rl_tmp + lo;
+                rl_insertion_sort(x, n);
+                for (uint32_t a = 0; a < n; a++) rl_qid[lo + a] = (int32_t)(uint32_t)x[a];
             }
-            for (uint32_t a = 0; a < n; a++) rl_qid[lo + a] = (int32_t)(uint32_t)x[a];
         }
     }
     __syncthreads();
+    if (staged)
+        for (uint32_t p = threadIdx.x; p < total; p += 256) {
+            const uint32_t l = rl_list[base + p] - (uint32_t)e0;              // the entry's list, relative to the workgroup's first
+            if (s_start[l + 1] - s_start[l] <= (uint32_t)RL_SMALL) rl_qid[base + p] = (int32_t)(uint32_t)s_x[p];
+        }
     if (threadIdx.x < 3) s_base[threadIdx.x] = s_n[threadIdx.x] ? atomicAdd(&counters32[threadIdx.x], s_n[threadIdx.x]) : 0u;      // one global atomic per workgroup and class
     __syncthreads();
     for (int k = 0; k < 3; k++) {
@@ -932,7 +985,7 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
 
 
 // scratch slots of ctx->scratch used by the tally (0 is the AS histogram, 16.. belong to components / K_map)
-enum { T_QBASE = 1, T_TOUCHED, T_CNT_T, T_BASE_T, T_ITEMS, T_COUNTERS, T_GKEYS, T_GVALS, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP, T_USED, T_MISC };
+enum { T_QBASE = 1, T_TOUCHED, T_CNT_T, T_BASE_T, T_ITEMS, T_COUNTERS, T_GKEYS, T_USEDKEY, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP, T_USED, T_MISC, T_EA = 19 };
 // results and the read-list buffers live in their own buffers (ctx->tally_buf)
 enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_STATS, R_RLCNT, R_RLSTART, R_RLFILL, R_RLTMP, R_RLLIST, R_RLQID, R_A0, R_A1,
        R_LINEQ, R_SORTK, R_SORTV0, R_SORTV1, R_SORTCNT, R_SPQ, R_SPITEM, R_COUNT };
@@ -1109,7 +1162,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     }
     const unsigned grid_l = n_shards > 0 ? gl.back() : 0u, grid_t = n_shards > 0 ? gt.back() : 0u;
     if (profiling) { RSV(S[20], (size_t)(grid_l + grid_t + 2) * 16); O.prof = (unsigned long long *)S[20].p; PHZ_HIP(ctx, hipMemsetAsync(S[20].p, 0, (size_t)(grid_l + grid_t + 2) * 16, sm)); }
-    if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(256), 0, sm, TLn, O);
+    if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(LINE_TB), 0, sm, TLn, O);
     if (nv) hipLaunchKernelGGL(k_noise, dim3(std::min(nblk(nv), 256u)), dim3(256), 0, sm, (const int32_t *)d_cnt, nv, counters + 4);
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, rl_cnt, rl_start, (int64_t)NRL, S[T_SCAN_TMP])) return s;
     hipLaunchKernelGGL(k_rl_expand, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_list, rl_fill);
@@ -1119,7 +1172,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         TO.line_cls = d_cls; TO.line_q = line_q; TO.qcount = qcount; TO.items = items; TO.sp_q = sp_q; TO.sp_item = sp_item; TO.touched = touched;
         TO.var_rank = d_rank; TO.var_distinct = d_dist; TO.rl_cursor = rl_fill; TO.rl_tmp = rl_tmp; TO.counters = counters; TO.nb = n_bams;
         TO.prof = profiling ? (unsigned long long *)S[20].p + 2 * (size_t)grid_l : nullptr;
-        hipLaunchKernelGGL(k_tile, dim3(grid_t), dim3(256), 0, sm, TT, TO);
+        hipLaunchKernelGGL(k_tile, dim3(grid_t), dim3(TILE_TB), 0, sm, TT, TO);
     }
     PHZ_HIP(ctx, hipGetLastError());
     std::vector<unsigned long long> h_cnt(CNT_BYTES / 8, 0ull);
@@ -1158,7 +1211,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     }
     // read lists into line order
     PHZ_HIP(ctx, hipMemsetAsync(counters32, 0, 16, sm));
-    hipLaunchKernelGGL(k_rl_sort, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_tmp, rl_qid, wave_list, mid_list, big_list, counters32);
+    hipLaunchKernelGGL(k_rl_sort, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_tmp, rl_qid, (const uint32_t *)rl_list, wave_list, mid_list, big_list, counters32);
     // variant pairs.  The table lives in the ctx, sized from the variant count and kept clean by k_edge_final; a pass that overflows it is redone
     // with a larger one
     uint64_t cap = 1 << 16;
@@ -1169,20 +1222,21 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     uint32_t h_tail[2] = {0, 0};
     for (int attempt = 0;; attempt++) {
         const size_t old_k = S[T_GKEYS].cap;
-        RSV(S[T_GKEYS], cap * GE_WORDS * 4); RSV(S[T_USED], cap * 4);
+        RSV(S[T_GKEYS], cap * GE_WORDS * 4); RSV(S[T_USED], cap * 4); RSV(S[T_USEDKEY], cap * 8);
         uint32_t *tab = (uint32_t *)S[T_GKEYS].p;
         if (S[T_GKEYS].cap != old_k || ctx->tally_table_dirty || attempt > 0) PHZ_HIP(ctx, hipMemsetAsync(tab, 0, S[T_GKEYS].cap, sm));
         ctx->tally_table_dirty = true;
         PHZ_HIP(ctx, hipMemsetAsync(counters, 0, 24, sm));              // overflow
         PHZ_HIP(ctx, hipMemsetAsync(counters + 16, 0, CNT_BYTES - 128, sm));      // spread statistics
         PHZ_HIP(ctx, hipMemsetAsync(counters + 7, 0, 8, sm));           // used slots
+        PHZ_HIP(ctx, hipMemsetAsync(deg, 0, NV * 4, sm));               // edges per first variant, counted while the slots are claimed
         const int64_t m_items = n_complete + n_spill;                // the tiles' slots, then one slot per spilled line
         if (m_items && getenv("PHZ_TALLY_DEBUG")) {
-            hipLaunchKernelGGL(k_pairs<1>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(256), 0, sm, (const uint64_t *)items, m_items, tab, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
-            hipLaunchKernelGGL(k_pairs<2>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(256), 0, sm, (const uint64_t *)items, m_items, tab, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
+            hipLaunchKernelGGL(k_pairs<1>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(PAIRS_TB), 0, sm, (const uint64_t *)items, m_items, tab, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, (uint64_t *)S[T_USEDKEY].p, deg, counters);
+            hipLaunchKernelGGL(k_pairs<2>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(PAIRS_TB), 0, sm, (const uint64_t *)items, m_items, tab, (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, (uint64_t *)S[T_USEDKEY].p, deg, counters);
         }
-        if (m_items) hipLaunchKernelGGL(k_pairs<0>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(256), 0, sm, (const uint64_t *)items, m_items, tab,
-                                        (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, counters);
+        if (m_items) hipLaunchKernelGGL(k_pairs<0>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(PAIRS_TB), 0, sm, (const uint64_t *)items, m_items, tab,
+                                        (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, (uint64_t *)S[T_USEDKEY].p, deg, counters);
         PHZ_HIP(ctx, hipGetLastError());
         PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(h_c32, counters32, 16, hipMemcpyDeviceToHost, sm));
@@ -1213,17 +1267,15 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     }
     const size_t NE = (size_t)(ne ? ne : 1);
     RSV(R[R_EA], NE * 4); RSV(R[R_EB], NE * 4); RSV(R[R_CELLS], NE * 36); RSV(R[R_LINKED], NE); RSV(R[R_CTO], NE * 12); RSV(R[R_STATS], NE * 20);
-    RSV(S[T_EB], NE * 4); RSV(S[T_ESLOT], NE * 4);
-    PHZ_HIP(ctx, hipMemsetAsync(deg, 0, NV * 4, sm));
+    RSV(S[T_EB], NE * 4); RSV(S[T_ESLOT], NE * 4); RSV(S[T_EA], NE * 4);
     if (ne > 0) {
         uint32_t *tab = (uint32_t *)S[T_GKEYS].p;
-        hipLaunchKernelGGL(k_edge_count, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint32_t *)tab, deg);
         if (int s = gscan_excl<uint32_t, uint32_t>(ctx, deg, eoff, nv, S[T_SCAN_TMP])) return s;
-        hipLaunchKernelGGL(k_edge_scatter, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, ne, (const uint32_t *)tab, (const uint32_t *)eoff, deg,
-                           (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
-        hipLaunchKernelGGL(k_edge_sort, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p,
-                           (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p);
-        hipLaunchKernelGGL(k_edge_out, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint32_t *)S[T_ESLOT].p, tab, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
+        hipLaunchKernelGGL(k_edge_scatter, dim3(nblk(ne)), dim3(256), 0, sm, (const uint32_t *)S[T_USED].p, (const uint64_t *)S[T_USEDKEY].p, ne, (const uint32_t *)eoff, deg,
+                           (uint32_t *)S[T_EA].p, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
+        hipLaunchKernelGGL(k_edge_sort_big, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)eoff, (uint32_t *)S[T_EB].p, (uint32_t *)S[T_ESLOT].p);
+        hipLaunchKernelGGL(k_edge_out, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint32_t *)eoff, (const uint32_t *)S[T_EA].p, (const uint32_t *)S[T_EB].p,
+                           (const uint32_t *)S[T_ESLOT].p, tab, (int32_t *)R[R_EA].p, (int32_t *)R[R_EB].p, (int32_t *)R[R_CELLS].p, (uint8_t *)R[R_LINKED].p,
                            (int32_t *)R[R_CTO].p, (int32_t *)R[R_STATS].p);
     }
     PHZ_HIP(ctx, hipGetLastError());

@@ -27,10 +27,14 @@ def build(verbose=False, tally_tile=0, row_wave_min=None):
 
 def _build_locked(verbose, tally_tile, row_wave_min):
     tag = ("_t%d" % tally_tile if tally_tile else "") + ("_w%d" % row_wave_min if row_wave_min is not None else "")
+    extra = os.environ.get("PHZ_EMU_EXTRA_DEFS", "").split()      # experiment builds: extra -D flags for every unit, e.g. "-DPHZ_TILE_TB=512"
+    if extra:
+        import hashlib
+        tag += "_x" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8]
     LIB = os.path.join(OUT, "libphz_emu%s.so" % tag)
     variant_defs = {}
     if tally_tile:
-        variant_defs["phz_tally.hip"] = ["-DPHZ_TALLY_TILE=%d" % tally_tile]
+        variant_defs["phz_tally.hip"] = ["-DPHZ_TALLY_TILE=%d" % tally_tile, "-DPHZ_RL_STAGE=8"]      # + a tiny read-list stage: the fallback of k_rl_sort
     if row_wave_min is not None:
         variant_defs["phz_rowsdev.hip"] = ["-DPHZ_ROW_WAVE_MIN=%d" % row_wave_min]
     hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(REPO, "include", "phz.h"),
@@ -40,7 +44,7 @@ def _build_locked(verbose, tally_tile, row_wave_min):
     jobs = []; objs = []
     for u in UNITS + ["hipemu.cpp"]:
         src = os.path.join(HERE if u == "hipemu.cpp" else CSRC, u)
-        defs = variant_defs.get(u, [])
+        defs = variant_defs.get(u, []) + extra
         obj = os.path.join(OUT, u + (tag if defs else "") + ".o"); objs.append(obj)
         if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
             jobs.append(["g++"] + flags + defs + ["-x", "c++", "-c", src, "-o", obj])
