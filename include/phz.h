@@ -198,6 +198,11 @@ int phz_map_reads_batch(phz_ctx *ctx, int n_shards, const phz_reads *reads, cons
 int phz_as_histogram(phz_ctx *ctx, const phz_lines *shard, int64_t *hist, int space);
 /* the same for several device-resident shards into one device-resident histogram, one host wait */
 int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t *hist);
+/* the same for a caller that needs no all-reduce of the histogram: it stays on the device and the host gets its occupied bins, in bin
+ * order (bin b holds AS == b - 32768; alignment scores live in a narrow band).  cap <= 4096; more occupied bins than cap: PHZ_E_CAPACITY with
+ * *n_bins = their number (take phz_as_histogram_batch then). */
+int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, int n_shards, int cap, int32_t *bins /* [cap] */, int64_t *counts /* [cap] */,
+                            int32_t *n_bins);
 
 /* Per-variant counters, distinct read sets, variant-pair co-occurrence cells and per-(variant, allele, BAM) read lists over
  * any number of (chromosome, BAM) shards in one submission.  Shards must be ordered by (chromosome, BAM); a chromosome's
@@ -506,6 +511,11 @@ typedef struct {
 int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *tables, phz_rowsdev **out);
 void phz_rowsdev_destroy(phz_rowsdev *h);
 int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host /* [PHZ_PAIR_SLOTS] */);
+/* host helper between the two stages: values and repr() text of the p-values laid out by slot (used[] ascending = the occupied slots of
+ * phz_rowsdev_pair_keys, pv[i] = scipy.stats.binom.cdf for slot used[i]).  Returns the bytes of txt, -1 on bad arguments / txt_cap too small
+ * (n_slots + 40 bytes per used slot always fits). */
+int64_t phz_pair_slot_text(const uint32_t *used, const double *pv, int64_t n_used, int64_t n_slots, double *slot_pv /* [n_slots] */,
+                           uint32_t *txt_off /* [n_slots + 1] */, char *txt, int64_t txt_cap);
 int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *opts, const double *slot_pv /* [PHZ_PAIR_SLOTS] */,
                     const uint32_t *slot_txt_off /* [PHZ_PAIR_SLOTS + 1] */, const char *slot_txt, phz_rowsdev_result *result);
 int phz_rowsdev_fetch_text(phz_ctx *ctx, phz_rowsdev *h, int which, void *dst, int64_t bytes);

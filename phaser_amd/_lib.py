@@ -214,6 +214,7 @@ SYMBOLS = {
                                       C.POINTER(phz_calls), C.POINTER(C.c_int64)]),
     "phz_as_histogram": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_void_p, C.c_int]),
     "phz_as_histogram_batch": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_void_p]),
+    "phz_as_histogram_sparse": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.POINTER(phz_tally_sizes), C.c_int]),
     "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),
@@ -269,6 +270,7 @@ SYMBOLS = {
     "phz_rowsdev_create": (C.c_int, [C.c_void_p, C.POINTER(phz_rowsdev_tables), C.POINTER(C.c_void_p)]),
     "phz_rowsdev_destroy": (None, [C.c_void_p]),
     "phz_rowsdev_pair_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "phz_pair_slot_text": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "phz_rowsdev_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_result)]),
     "phz_rowsdev_fetch_text": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "phz_rowsdev_text_ptr": (C.c_void_p, [C.c_void_p, C.c_int]),

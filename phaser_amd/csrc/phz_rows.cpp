@@ -978,6 +978,34 @@ extern "C" int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i
     return PHZ_OK;
 }
 
+// The host half of the pair test's text: phaser.py:693 writes str(p) of the binomial p-value.  The caller evaluates scipy once per distinct
+// (supporting, total) pair -- the used slots of phz_rowsdev_pair_keys -- and this lays the values and their repr() text out by slot, the form
+// phz_rowsdev_run takes: slot_pv[s] = value (1.0 for an empty slot), the text of slot s = txt[txt_off[s], txt_off[s + 1] - 1) followed by one
+// separator byte.  Returns the bytes written, or -1 when txt_cap is too small (n_slots + 32 bytes per used slot always fits).
+extern "C" int64_t phz_pair_slot_text(const uint32_t *used, const double *pv, int64_t n_used, int64_t n_slots, double *slot_pv, uint32_t *txt_off,
+                                      char *txt, int64_t txt_cap) {
+    if (n_used < 0 || n_slots < 0 || (n_used && (!used || !pv)) || !slot_pv || !txt_off || !txt) return -1;
+    for (int64_t sidx = 0; sidx < n_slots; sidx++) slot_pv[sidx] = 1.0;
+    int64_t at = 0, next = 0;               // bytes written, next slot to lay out
+    std::string r;
+    for (int64_t i = 0; i < n_used; i++) {
+        const int64_t sidx = used[i];
+        if (sidx < next || sidx >= n_slots) return -1;             // ascending, inside the table
+        if (at + (sidx - next) + 40 > txt_cap) return -1;
+        for (; next < sidx; next++) { txt_off[next] = (uint32_t)at; txt[at++] = '\n'; }
+        slot_pv[sidx] = pv[i];
+        r.clear();
+        phztext::put_pyfloat(r, pv[i]);
+        txt_off[next++] = (uint32_t)at;
+        memcpy(txt + at, r.data(), r.size()); at += (int64_t)r.size();
+        txt[at++] = '\n';
+    }
+    if (at + (n_slots - next) > txt_cap) return -1;
+    for (; next < n_slots; next++) { txt_off[next] = (uint32_t)at; txt[at++] = '\n'; }
+    txt_off[n_slots] = (uint32_t)at;
+    return at;
+}
+
 extern "C" void phz_rows_free(phz_rows_out *o) {
     if (!o) return;
     for (phz_text_parts *P : {&o->conn, &o->hap, &o->ase, &o->cfg, &o->allelic, &o->single_ase, &o->single_hap}) {

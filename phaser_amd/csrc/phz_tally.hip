@@ -94,6 +94,29 @@ __global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long 
         if (s_h[j]) atomicAdd(&hist[j - AS_LDS_BINS / 2 + 32768], (unsigned long long)s_h[j]);
 }
 
+// the occupied bins of the 64 Ki-bin histogram as (bin, count) pairs in bin order (alignment scores live in a narrow band: a few dozen bins),
+// so that the host reads a few hundred bytes instead of 512 KB; out[0] = number of pairs (may exceed cap: the caller then takes the dense path)
+__global__ __launch_bounds__(1024) void k_hist_compact(const unsigned long long *hist, int cap, int32_t *bins, unsigned long long *counts, int32_t *n_out) {
+    __shared__ int s_w[16];
+    constexpr int PER = PHZ_AS_BINS / 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long c[PER];
+    int nz = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { c[j] = hist[tid * PER + j]; nz += c[j] ? 1 : 0; }
+    int incl = nz;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int at = incl - nz;
+    for (int w = 0; w < wave; w++) at += s_w[w];
+    if (tid == 1023) n_out[0] = at + nz;
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+        if (c[j]) { if (at < cap) { bins[at] = tid * PER + j; counts[at] = c[j]; } at++; }
+}
+
 // ------------------------------------------------------------------------------------------------ per-line pass
 // Call lines arrive in mapper order (record, then variant) and records are coordinate-sorted, so the lines of one
 // workgroup touch a narrow run of variant indices, and deeply covered variants repeat hundreds of times in a row.
@@ -1071,6 +1094,45 @@ extern "C" int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int
     if (n_shards > 0) PHZ_HIP(ctx, hipMemcpyAsync(&oor, ctx->scratch[0].p, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (int s = t.stop()) return s;
     if (oor) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "AS value outside int16");
+    return PHZ_OK;
+}
+
+// ... and for one rank that needs no all-reduce: the histogram never leaves the device, the host gets its occupied bins
+extern "C" int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, int n_shards, int cap, int32_t *bins, int64_t *counts, int32_t *n_bins) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || (!shards && n_shards) || n_shards < 0 || cap < 1 || cap > 4096 || !bins || !counts || !n_bins) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    Timer t(ctx, PHZ_T_ASHIST);
+    Staging st(ctx);
+    std::vector<LinesDev> L((size_t)n_shards);
+    for (int i = 0; i < n_shards; i++)
+        if (int s = stage_lines(st, shards[i], PHZ_DEVICE, &L[(size_t)i])) return s;
+    // scratch[0]: [hist 64 Ki x 8][out-of-range flag, pair count][bins cap x 4][counts cap x 8]; the host image of the tail in h_scalars
+    const size_t tail = 16 + (size_t)cap * 12;
+    if (int s2 = phz_reserve(ctx, ctx->scratch[0], PHZ_AS_BINS * 8 + tail)) return s2;
+    if (int s2 = phz_reserve_host(ctx, ctx->h_scalars, tail)) return s2;
+    char *d = (char *)ctx->scratch[0].p;
+    unsigned long long *hist = (unsigned long long *)d;
+    unsigned int *flags = (unsigned int *)(d + PHZ_AS_BINS * 8);
+    int32_t *d_bins = (int32_t *)(d + PHZ_AS_BINS * 8 + 16);
+    unsigned long long *d_counts = (unsigned long long *)(d + PHZ_AS_BINS * 8 + 16 + (size_t)cap * 4);
+    PHZ_HIP(ctx, hipMemsetAsync(d, 0, PHZ_AS_BINS * 8 + 16, ctx->stream));
+    if (n_shards > 0) {
+        LinesTab T;
+        std::vector<uint32_t> grids;
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, as_hist_blocks, &T, &grids)) return s2;
+        if (grids.back() > 0) hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, hist, flags);
+    }
+    hipLaunchKernelGGL(k_hist_compact, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist, cap, d_bins, d_counts, (int32_t *)(flags + 1));
+    PHZ_HIP(ctx, hipGetLastError());
+    PHZ_HIP(ctx, hipMemcpyAsync(ctx->h_scalars.p, flags, tail, hipMemcpyDeviceToHost, ctx->stream));
+    if (int s = t.stop()) return s;
+    const unsigned int *hf = (const unsigned int *)ctx->h_scalars.p;
+    if (hf[0]) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "AS value outside int16");
+    *n_bins = (int32_t)hf[1];
+    if ((int)hf[1] > cap) return PHZ_E_CAPACITY;
+    memcpy(bins, (const char *)ctx->h_scalars.p + 16, (size_t)hf[1] * 4);
+    memcpy(counts, (const char *)ctx->h_scalars.p + 16 + (size_t)cap * 4, (size_t)hf[1] * 8);
     return PHZ_OK;
 }
 

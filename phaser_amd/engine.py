@@ -63,6 +63,21 @@ def percentile_from_hist(h: np.ndarray, q: float) -> float:
         return None                          # no alignment score at all
     first_bin = int(rows[0]) * 256 if len(rows) else 0
     h = h[first_bin:(int(rows[-1]) + 1) * 256] if len(rows) else h
+    return percentile_from_band(h, first_bin, q)
+
+
+def percentile_from_sparse(bins: np.ndarray, counts: np.ndarray, q: float) -> float:
+    """The same from the occupied bins alone (phz_as_histogram_sparse: ascending bin numbers and their counts)."""
+    if len(bins) == 0:
+        return None
+    first_bin = int(bins[0])
+    h = np.zeros(int(bins[-1]) - first_bin + 1, dtype=np.int64)
+    h[bins.astype(np.int64) - first_bin] = counts
+    return percentile_from_band(h, first_bin, q)
+
+
+def percentile_from_band(h: np.ndarray, first_bin: int, q: float) -> float:
+    """h[i] = number of scores equal to first_bin + i - 32768."""
     n = int(h.sum())
     if n == 0:
         return None
@@ -207,34 +222,55 @@ class Engine:
                 except Exception:
                     pass
             hist = hb[0]
-            hist.zero_()
             live = [sh for sh in shards if sh.calls.n]
-            if live and dev.type == "cuda":         # every shard of the BAM in one submission (it also refuses AS values outside int16)
+            cutoff = None; done = False
+            if live and dev.type == "cuda" and pdist.world()[1] == 1:
+                # one rank: nothing to all-reduce, so the histogram stays on the device and only its occupied bins come back (a few hundred
+                # bytes instead of 512 KB; one call, one host wait)
                 arr = (_lib.phz_lines * len(live))(*[self._lines(sh, bam_index) for sh in live])
-                torch.cuda.synchronize(dev)
-                self.ctx.check(self.lib.phz_as_histogram_batch(self.ctx.h, arr, len(live), _p(hist)))
-            else:
-                for sh in live:
-                    if sh.as_absmax is None:
-                        sh.as_absmax = int(sh.aln.abs().max())
-                    if sh.as_absmax >= 32768:
-                        raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
-                    ln = self._lines(sh, bam_index)
-                    self.ctx.check(self.lib.phz_as_histogram(self.ctx.h, C.byref(ln), _p(hist), _lib.PHZ_HOST))
-            pdist.allreduce_sum_(hist)          # the quantile is over ALL chromosomes of this BAM
-            if dev.type == "cuda":
-                hb[1].copy_(hist, non_blocking=True)
+                sb = self.mapper.__dict__.get("_as_sparse")
+                if sb is None:
+                    sb = self.mapper.__dict__["_as_sparse"] = (np.empty(2048, np.int32), np.empty(2048, np.int64), C.c_int32(0))
                 torch.cuda.current_stream(dev).synchronize()
-                h = hb[1].numpy()
-            else:
-                h = hist.numpy()
-            cutoff = percentile_from_hist(h, self.cfg.as_q_cutoff * 100)
+                st = self.ctx.check(self.lib.phz_as_histogram_sparse(self.ctx.h, arr, len(live), 2048, C.c_void_p(sb[0].ctypes.data),
+                                                                     C.c_void_p(sb[1].ctypes.data), C.byref(sb[2])), allow=(_lib.PHZ_E_CAPACITY,))
+                if st == 0:
+                    k = int(sb[2].value)
+                    cutoff = percentile_from_sparse(sb[0][:k], sb[1][:k], self.cfg.as_q_cutoff * 100)
+                    done = True
+            if not done:
+                cutoff = self._as_cutoff_dense(hb, live, dev, bam_index)
             if cutoff is not None:
                 self.log.append("          using alignment score cutoff of %d" % cutoff)
                 for sh in shards:
                     sh.cutoff = float(cutoff); sh.use_cutoff = 1
             else:
                 self.log.append("          no alignment score value found in reads, cannot use cutoff")
+
+    def _as_cutoff_dense(self, hb, live, dev, bam_index):
+        """The dense 64 Ki-bin histogram (all-reduced over the ranks) -> cutoff."""
+        hist = hb[0]
+        hist.zero_()
+        if live and dev.type == "cuda":         # every shard of the BAM in one submission (it also refuses AS values outside int16)
+            arr = (_lib.phz_lines * len(live))(*[self._lines(sh, bam_index) for sh in live])
+            torch.cuda.synchronize(dev)
+            self.ctx.check(self.lib.phz_as_histogram_batch(self.ctx.h, arr, len(live), _p(hist)))
+        else:
+            for sh in live:
+                if sh.as_absmax is None:
+                    sh.as_absmax = int(sh.aln.abs().max())
+                if sh.as_absmax >= 32768:
+                    raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
+                ln = self._lines(sh, bam_index)
+                self.ctx.check(self.lib.phz_as_histogram(self.ctx.h, C.byref(ln), _p(hist), _lib.PHZ_HOST))
+        pdist.allreduce_sum_(hist)          # the quantile is over ALL chromosomes of this BAM
+        if dev.type == "cuda":
+            hb[1].copy_(hist, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            h = hb[1].numpy()
+        else:
+            h = hist.numpy()
+        return percentile_from_hist(h, self.cfg.as_q_cutoff * 100)
 
     # ---------------------------------------------------------------- stages 3-6
     def _bases(self):

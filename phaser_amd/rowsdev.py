@@ -177,6 +177,38 @@ def pool_of(eng) -> PinnedPool:
     return p
 
 
+_BINOM_DIRECT = None
+
+
+def binom_cdf(k: np.ndarray, n: np.ndarray, p: float) -> np.ndarray:
+    """scipy.stats.binom.cdf(k, n, p) -- the reference's call (phaser.py:1649) -- for integer arrays 0 <= k <= n.  The public method spends
+    most of its time on argument handling; what it computes for these arguments is 1.0 where k >= n and clip(_binom_cdf(k, n, p), 0, 1)
+    elsewhere (scipy/stats/_distn_infrastructure.py rv_discrete.cdf, _discrete_distns.py binom_gen._cdf).  The ufunc is called directly ONLY
+    after it has reproduced the public method bit for bit on a probe grid in this process; any surprise (another scipy layout, a different
+    result) leaves the public method in charge."""
+    global _BINOM_DIRECT
+    from scipy.stats import binom
+    if _BINOM_DIRECT is None:
+        _BINOM_DIRECT = False
+        try:
+            import scipy.special._ufuncs as scu
+            f = scu._binom_cdf
+            kk, nn = np.meshgrid(np.arange(0, 70, dtype=np.int64), np.arange(1, 70, dtype=np.int64))
+            m = kk <= nn
+            kk = np.concatenate([kk[m], np.array([150, 300, 999, 1000, 4000, 0])]); nn = np.concatenate([nn[m], np.array([300, 300, 1000, 1000, 5000, 100000])])
+            ok = True
+            for q in (0.9934, 0.97, 0.999999, 0.5):
+                direct = np.where(kk >= nn, 1.0, np.clip(f(kk.astype(np.float64), nn, q), 0, 1))
+                ok = ok and bool(np.array_equal(direct, binom.cdf(kk, nn, q)))
+            if ok:
+                _BINOM_DIRECT = f
+        except Exception:
+            _BINOM_DIRECT = False
+    if _BINOM_DIRECT is False or not (0.0 <= p <= 1.0) or (len(k) and (int(k.min()) < 0 or int(n.min()) < 0)):
+        return binom.cdf(k, n, p)
+    return np.where(k >= n, 1.0, np.clip(_BINOM_DIRECT(k.astype(np.float64), n, p), 0, 1))
+
+
 def supported(cfg) -> bool:
     return cfg.gw_phase_method == 0 and cfg.output_read_ids == 0
 
@@ -185,7 +217,6 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     """-> {chrom: fragment} in the format Engine._fragments returns (row text per file as buffers over page-locked host memory, in the
     reference's order), or raises PhzError(PHZ_E_UNSUPPORTED) when the host stage has to take the pass."""
     import time as _t
-    from scipy.stats import binom
     cfg = eng.cfg; ctx = eng.ctx; lib = eng.lib
     G = eng.G
     nb = G["nb"]
@@ -193,30 +224,21 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     T = tables_for(eng)
     t1 = _t.perf_counter()
     # ---- stage 1: distinct (total, supporting) pairs -> scipy -> value + repr text per slot (phaser.py:1645-1652)
-    keys = np.empty(_lib.PHZ_PAIR_SLOTS, dtype=np.uint64)
+    keys = pool_of(eng).get("pair_keys", _lib.PHZ_PAIR_SLOTS * 8).view(np.uint64)
     ctx.check(lib.phz_rowsdev_pair_keys(ctx.h, T.h, _vp(keys)))
-    used = np.flatnonzero(keys != np.uint64(0xFFFFFFFFFFFFFFFF))
-    tot = (keys[used] >> np.uint64(32)).astype(np.int64); sup = (keys[used] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    used = np.flatnonzero(keys != np.uint64(0xFFFFFFFFFFFFFFFF)).astype(np.uint32)
+    ku = keys[used]
+    tot = (ku >> np.uint64(32)).astype(np.int64); sup = (ku & np.uint64(0xFFFFFFFF)).astype(np.int64)
     prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
-    slot_pv = np.ones(_lib.PHZ_PAIR_SLOTS, dtype=np.float64)
-    lens = np.zeros(_lib.PHZ_PAIR_SLOTS, dtype=np.int64)
-    parts = []
-    if len(used):
-        pv = binom.cdf(sup, tot, prob)
-        slot_pv[used] = pv
-        reprs = [r.encode() for r in map(repr, pv.tolist())]      # float.__repr__: what the reference's str(p) writes (phaser.py:693)
-        lens[used] = np.fromiter(map(len, reprs), dtype=np.int64, count=len(reprs))
-        prev = 0
-        for sl, r in zip(used.tolist(), reprs):                   # slot order (flatnonzero ascends); an empty slot is just its separator byte
-            parts.append(b"\n" * (sl - prev)); parts.append(r); parts.append(b"\n")
-            prev = sl + 1
-        parts.append(b"\n" * (_lib.PHZ_PAIR_SLOTS - prev))
-    else:
-        parts.append(b"\n" * _lib.PHZ_PAIR_SLOTS)
-    txt = b"".join(parts)
-    txt_off = np.zeros(_lib.PHZ_PAIR_SLOTS + 1, dtype=np.uint32)
-    np.cumsum(lens + 1, out=lens)
-    txt_off[1:] = lens
+    pv = binom_cdf(sup, tot, prob) if len(used) else np.zeros(0, dtype=np.float64)
+    # values and text by slot (float.__repr__ of the value: what the reference's str(p) writes, phaser.py:693) -- laid out natively
+    slot_pv = np.empty(_lib.PHZ_PAIR_SLOTS, dtype=np.float64)
+    txt_off = np.empty(_lib.PHZ_PAIR_SLOTS + 1, dtype=np.uint32)
+    txt = np.empty(_lib.PHZ_PAIR_SLOTS + 40 * len(used) + 64, dtype=np.uint8)
+    nbytes_txt = lib.phz_pair_slot_text(_vp(used), _vp(np.ascontiguousarray(pv, dtype=np.float64)), len(used), _lib.PHZ_PAIR_SLOTS, _vp(slot_pv), _vp(txt_off),
+                                        _vp(txt), txt.size)
+    if nbytes_txt < 0:
+        raise _lib.PhzError(_lib.PHZ_E_ARG, "phz_pair_slot_text")
     t2 = _t.perf_counter()
     # ---- stage 2
     bam_off, bam_txt = sep_pool(list(eng.bam_names))

@@ -556,3 +556,41 @@ def test_two_ranks_one_gpu_real_kernels(tmp_path, backend, world):
     out = {name: open(prefix + "." + name + ".txt").read().replace("\tt1.sam\t", "\tt1\t").replace("\tt2.sam\t", "\tt2\t") for name in OUTPUTS}
     compare(out, d)
     assert not [f for f in os.listdir(tmp_path) if f.startswith("phz_spool_")]          # spool files removed
+
+
+def test_as_histogram_sparse_equals_dense(mapper):
+    """phz_as_histogram_sparse (one rank: the histogram stays on the device, its occupied bins come back) = the dense 64 Ki-bin histogram of
+    phz_as_histogram_batch, on a shard whose alignment scores are spread over thousands of values; more occupied bins than the caller's room
+    is reported, not truncated."""
+    import ctypes as C
+    import numpy as np
+    from phaser_amd import _lib
+    g = torch.Generator().manual_seed(99)
+    n_reads, n_lines = 50_000, 400_000
+    aln = torch.randint(-1500, 1500, (n_reads,), generator=g, dtype=torch.int32)
+    aln[:100] = torch.arange(-32768, -32768 + 100, dtype=torch.int32)
+    has = (torch.rand(n_reads, generator=g) > 0.1).to(torch.uint8)
+    read_idx = torch.sort(torch.randint(0, n_reads, (n_lines,), generator=g, dtype=torch.int32)).values
+    dev = torch.device("cuda:0")
+    t = {k: v.to(dev) for k, v in dict(read_idx=read_idx, var_idx=torch.zeros(n_lines, dtype=torch.int32), code=torch.zeros(n_lines, dtype=torch.uint8),
+                                       qid=torch.zeros(n_reads, dtype=torch.int32), aln=aln, has=has).items()}
+    p = lambda x: C.c_void_p(x.data_ptr())
+    ln = _lib.phz_lines(n_lines, p(t["read_idx"]), p(t["var_idx"]), p(t["code"]), n_reads, p(t["qid"]), p(t["aln"]), p(t["has"]), 0.0, 0, 0, 0, 0)
+    arr = (_lib.phz_lines * 2)(ln, ln)
+    ctx = mapper.ctx
+    dense = torch.zeros(_lib.PHZ_AS_BINS, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.phz_as_histogram_batch(ctx.h, arr, 2, p(dense)))
+    h = dense.cpu().numpy()
+    want = np.bincount(aln.numpy()[read_idx.numpy()][has.numpy()[read_idx.numpy()] != 0].astype(np.int64) + 32768, minlength=65536) * 2
+    assert np.array_equal(h, want)
+    bins = np.empty(4096, np.int32); counts = np.empty(4096, np.int64); k = C.c_int32(0)
+    st = ctx.lib.phz_as_histogram_sparse(ctx.h, arr, 2, 4096, C.c_void_p(bins.ctypes.data), C.c_void_p(counts.ctypes.data), C.byref(k))
+    nz = np.flatnonzero(h)
+    if len(nz) <= 4096:
+        assert st == 0 and k.value == len(nz)
+        assert np.array_equal(bins[:k.value], nz) and np.array_equal(counts[:k.value], h[nz])
+    else:
+        assert st == _lib.PHZ_E_CAPACITY and k.value == len(nz)
+    st = ctx.lib.phz_as_histogram_sparse(ctx.h, arr, 2, 64, C.c_void_p(bins.ctypes.data), C.c_void_p(counts.ctypes.data), C.byref(k))
+    assert st == _lib.PHZ_E_CAPACITY and k.value == len(nz)

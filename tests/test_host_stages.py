@@ -83,7 +83,7 @@ def test_phased_vcf_from_host_stages(src, mode):
 def test_percentile_from_histogram_equals_numpy():
     """AS cutoff (phaser.py:551): the histogram route reproduces numpy.percentile bit for bit."""
     import numpy as np
-    from phaser_amd.engine import percentile_from_hist
+    from phaser_amd.engine import percentile_from_hist, percentile_from_sparse
     rng = np.random.default_rng(7)
     for t in range(400):
         n = int(rng.integers(1, 300)) if t % 2 else int(rng.integers(1, 50000))
@@ -91,6 +91,8 @@ def test_percentile_from_histogram_equals_numpy():
         h = np.bincount(sc + 32768, minlength=65536).astype(np.int64)
         for q in (0.05 * 100, 0.2 * 100, 0.0, 100.0, 37.3, 99.9):
             assert float(np.percentile(sc.astype(np.int64), q)) == percentile_from_hist(h, q)
+            bins = np.flatnonzero(h).astype(np.int32)          # what phz_as_histogram_sparse hands over: the occupied bins in order
+            assert percentile_from_sparse(bins, h[bins], q) == percentile_from_hist(h, q)
 
 
 def test_phased_vcf_takes_the_sample_column_of_a_wide_vcf():
@@ -161,3 +163,45 @@ def test_binom_cdf_bits_are_pinned():
         k2 = np.concatenate([k, [3]]); n2 = np.concatenate([n, [5000]])
         got2 = engine.binom_cdf_dedup(k2, n2, p)[:-1]
         assert got2.tobytes() == want.tobytes(), (p, doc["scipy"])
+
+
+def test_pair_slot_text_is_python_repr_by_slot():
+    """phz_pair_slot_text (the host half between the two device row-stage calls) = repr() of every value, laid out by slot."""
+    import ctypes as C
+    import numpy as np
+    from phaser_amd import _lib
+    f = _lib.load().phz_pair_slot_text
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([rng.random(3000), 10.0 ** rng.uniform(-320, 0, 3000), np.array([0.0, 1.0, 0.5, 1e-4, 1e-5, 9.999e-5, 0.0001234, 1e-300, 5e-324, 0.1, 0.3, 1 - 2 ** -53,
+                                                                                          0.30000000000000004, 2.5e-16, 1e16, 1e15, 123456789012345678.0, 1.5])])
+    n_slots = 65536
+    used = np.sort(rng.choice(n_slots, len(vals), replace=False)).astype(np.uint32)
+    used[0] = 0; used[-1] = n_slots - 1
+    used = np.unique(used); vals = vals[:len(used)]
+    slot_pv = np.empty(n_slots, np.float64); off = np.empty(n_slots + 1, np.uint32); txt = np.empty(n_slots + 40 * len(used) + 64, np.uint8)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    nb = f(vp(used), vp(np.ascontiguousarray(vals)), len(used), n_slots, vp(slot_pv), vp(off), vp(txt), txt.size)
+    assert nb > 0 and off[n_slots] == nb
+    raw = txt[:nb].tobytes()
+    want = [b""] * n_slots
+    for s, v in zip(used.tolist(), vals.tolist()):
+        want[s] = repr(v).encode()
+    assert raw == b"".join(w + b"\n" for w in want)
+    for s in (0, int(used[len(used) // 2]), n_slots - 1, 7):
+        assert raw[off[s]:off[s + 1] - 1] == want[s]
+    exp = np.ones(n_slots); exp[used] = vals
+    assert np.array_equal(slot_pv, exp)
+    assert f(vp(used), vp(np.ascontiguousarray(vals)), len(used), n_slots, vp(slot_pv), vp(off), vp(txt), 100) == -1          # too small: refused, nothing overrun
+
+
+def test_direct_binom_ufunc_equals_the_public_method():
+    """rowsdev.binom_cdf (scipy's ufunc behind binom.cdf, called without the argument handling) = scipy.stats.binom.cdf bit for bit."""
+    import numpy as np
+    from scipy.stats import binom
+    from phaser_amd import rowsdev
+    rng = np.random.default_rng(11)
+    n = rng.integers(1, 2000, 20000); k = (n * rng.uniform(0.4, 1.0, len(n))).astype(np.int64)
+    k[:200] = n[:200]; k[200:300] = 0
+    for noise in (0.0010883, 0.004, 0.02, 1e-6):
+        p = 1 - ((6 * noise) + (10 * noise ** 2))
+        assert np.array_equal(rowsdev.binom_cdf(k, n, p), binom.cdf(k, n, p))
