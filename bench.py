@@ -27,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
-CALL_BYTES = 17           # read_idx 4 + var_idx 4 + code 1 + aux0 4 + aux1 4
+CALL_BYTES = 9            # read_idx 4 + var_idx 4 + code 1: the call list the phasing stage reads (the two planes behind the mapper drop-in's allele TEXT, 8 B more, are timed apart)
 
 
 def file_sha(*paths):
@@ -210,9 +210,11 @@ def kmap_roofline(ctx, tot_recs, tot_alg, k_avg_s, k_launches, steps, k_ms_max_r
             "algorithmic_bytes_per_launch": model_bytes, "bytes_per_record": SURVEY_BYTES_PER_RECORD,
             "resident_array_bytes_per_record": tot_alg / tot_recs,
             "kernel_ms_avg": k_avg_s * 1e3, "launches": int(k_launches), "kernel_ms_per_step_max_rank": k_ms_max_rank / steps,
-            "note": "achieved = 115 B x records (SURVEY.md 8(d): the arrays of a record incl. all of its bases and qualities) / HIP-event time of k_map.  The kernel "
-                    "reads bases / qualities only under a het SNP, so it moves far fewer bytes than the model (fractions.hbm_measured_traffic) and is "
-                    "paced by instruction issue and memory latency, not by bandwidth (fractions.issue_*, issue)"}
+            "note": "achieved = 115 B x records (SURVEY.md 8(d): the arrays of a record incl. ALL of its bases and qualities) / HIP-event time of k_map: the rate a "
+                    "mapper that streams every base would need.  This kernel reads bases / qualities only under a het SNP, so it moves far fewer bytes than the "
+                    "model (fractions.hbm_measured_traffic) -- which is how the model fraction can pass 1: it is the contract's figure, not a share of a ceiling "
+                    "the kernel runs against.  The kernel is paced by memory LATENCY: its time follows the number of resident tiles per CU (DESIGN 4), "
+                    "the issue ports are half busy (fractions.issue_*, issue)"}
 
 
 def main():
@@ -276,7 +278,9 @@ def main():
     # first (untimed) pass sizes the output buffers; the timed passes reuse exact-size buffers through the raw ABI
     first = mapper.map_batch(sh_list, vp_list, a.baseq)
     n_calls = [c.n for c in first]
-    call, bufs, N = mapper.prepare_batch(sh_list, vp_list, a.baseq, [n + 16 for n in n_calls])
+    # the timed step produces what Engine.add_shards asks K_map for -- (record, variant, allele code) per call, SURVEY.md 8(a) M1's GPU form; the
+    # same submission with the two extra planes of the mapper drop-in's text output is timed after it (config.step_with_text_planes_ms)
+    call, bufs, N = mapper.prepare_batch(sh_list, vp_list, a.baseq, [n + 16 for n in n_calls], aux=False)
 
     def step():
         mapper.ctx.check(call())
@@ -305,10 +309,23 @@ def main():
     for i, c in enumerate(chroms):
         m = n_calls[i]
         f = first[i]
-        assert all(bool(torch.equal(b[:m], t)) for b, t in zip(bufs[i], (f.read_idx, f.var_idx, f.code, f.aux0, f.aux1))), "repeated passes differ"
+        assert all(bool(torch.equal(b[:m], t)) for b, t in zip(bufs[i][:3], (f.read_idx, f.var_idx, f.code))), "repeated passes differ"
         key = bufs[i][0][:m].to(torch.int64) * (len(vsets[c]) + 1) + bufs[i][1][:m].to(torch.int64)
         assert bool((key[1:] > key[:-1]).all()), "call list not in mapper order"
 
+    # the same submission with the text planes (what the mapper drop-in asks for): a short series, reported next to the headline
+    call5, bufs5, N5 = mapper.prepare_batch(sh_list, vp_list, a.baseq, [n + 16 for n in n_calls], aux=True)
+    for _ in range(2):
+        mapper.ctx.check(call5())
+    torch.cuda.synchronize(); t5 = time.perf_counter()
+    for _ in range(max(1, min(a.steps, 20))):
+        mapper.ctx.check(call5())
+    torch.cuda.synchronize(); ms_with_text = (time.perf_counter() - t5) / max(1, min(a.steps, 20)) * 1e3
+    for i in range(len(chroms)):
+        m = n_calls[i]; f = first[i]
+        assert all(bool(torch.equal(b[:m], t)) for b, t in zip(bufs5[i], (f.read_idx, f.var_idx, f.code, f.aux0, f.aux1))), "text planes differ between passes"
+        assert all(bool(torch.equal(bufs5[i][k][:m], bufs[i][k][:m])) for k in range(3)), "call list differs with / without the text planes"
+    del call5, bufs5
     loc_calls = float(sum(n_calls)); loc_recs = float(sum(s.n for s in sh_list)); loc_snps = float(sum(len(vsets[c]) for c in chroms))
     loc_alg = float(sum(s.nbytes_map_inputs() for s in sh_list) + 4 * loc_snps + CALL_BYTES * loc_calls)
     red = torch.tensor([loc_calls, loc_recs, loc_snps, loc_alg, k_total_ms, float(k_n)], device=red_dev, dtype=torch.float64)
@@ -327,7 +344,7 @@ def main():
         host_threads = max(1, min(64, 4 * pdist.effective_cpus() // max(1, world)))
         if os.environ.get("PHZ_BENCH_HOST_THREADS"):
             host_threads = int(os.environ["PHZ_BENCH_HOST_THREADS"])
-        calls_now = [Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i in range(len(chroms))]
+        calls_now = [Calls(*[None if t is None else t[:n_calls[i]] for t in bufs[i]]) for i in range(len(chroms))]
         # two series of passes: row text left in HBM (`value`: inputs and outputs resident, like the mapper step) and copied to page-locked
         # host memory (`d2h_inclusive`: what the CLI pays before it can write the files; PCIe-bound, ~1 GB per genome)
         series = {"resident": [], "d2h": []}
@@ -409,7 +426,11 @@ def main():
                                    "one shard per chromosome; chromosomes LPT-assigned to GPUs by record count" % (int(tot_recs), int(tot_snps)),
                        "records": int(tot_recs), "het_snps": int(tot_snps), "calls_per_step": int(tot_calls), "shards": len(plan),
                        "records_per_s": tot_recs * a.steps / dt, "gen_seconds": round(t_gen, 1),
-                       "step": "K_map over all chromosome shards of the rank in one batched submission (phz_map_reads_batch)"},
+                       "step": "K_map over all chromosome shards of the rank in one batched submission (phz_map_reads_batch); call list = (record, variant, allele "
+                               "code) per call, the form the phasing stage reads (SURVEY.md 8(a) M1)",
+                       "step_with_text_planes_ms": ms_with_text,
+                       "step_with_text_planes_note": "the same submission also writing the two planes behind the mapper drop-in's allele text (read offset, inserted bases: "
+                                                     "8 more bytes per call), rank 0's shards, mean of a short series"},
             "roofline": kmap_roofline(mapper.ctx, tot_recs, tot_alg, k_avg_s, k_launches, a.steps, k_ms_max_rank, world),
         }
         if phasing is not None:
@@ -434,7 +455,7 @@ def main():
                                                      "(BASELINE.md); this port is the faster, parity-locked stand-in on the GPU box"}
             del sample
             if phasing is not None:
-                calls_of = {c: Calls(*[t[:n_calls[i]] for t in bufs[i]]) for i, c in enumerate(chroms)}
+                calls_of = {c: Calls(*[None if t is None else t[:n_calls[i]] for t in bufs[i]]) for i, c in enumerate(chroms)}
                 phasing["cpu_baseline"] = cpu_phasing_baseline(["chr21", "chr22"], vsets, shards, calls_of, mapper, a.baseq,
                                                                all_cores_chroms=["chr%d" % i for i in range(15, 23)])
         if world == 1 and not a.no_c2:
@@ -524,7 +545,7 @@ def configs1_entry(mapper, a, dev):
     torch.cuda.empty_cache()
     v, shard, _ = workloads.make_shard("chr1", workloads.CHR1_LEN, 40_000, 50_000_000, 20240807, dev)
     first = mapper.map_batch([shard], [v.pos], a.baseq)
-    call, bufs, N = mapper.prepare_batch([shard], [v.pos], a.baseq, [first[0].n + 16])
+    call, bufs, N = mapper.prepare_batch([shard], [v.pos], a.baseq, [first[0].n + 16], aux=False)
     for _ in range(3):
         mapper.ctx.check(call())
     mapper.ctx.reset_timing()
@@ -544,7 +565,7 @@ def configs1_entry(mapper, a, dev):
     if not a.no_phasing:
         # stages T1-O2 on the same shard (round 1 measured 76 ms here)
         vs = pvcf.load_variants("\n".join(synth.vcf_lines([v])))
-        calls = Calls(*[t[:first[0].n] for t in bufs[0]])
+        calls = Calls(*[None if t is None else t[:first[0].n] for t in bufs[0]])
         best = None
         for _ in range(max(1, a.phasing_passes)):
             eng = Engine(vs, ["bench"], Config(baseq=a.baseq, host_threads=max(1, min(64, 4 * pdist.effective_cpus())), want_vcf=False), mapper=mapper)

@@ -96,8 +96,8 @@ typedef struct {
     int32_t *read_idx;
     int32_t *var_idx;
     uint8_t *code;
-    uint32_t *aux0;
-    uint32_t *aux1;
+    uint32_t *aux0;          /* aux0 and aux1 may both be NULL: a caller that needs (record, variant, code) only -- the phasing stage -- */
+    uint32_t *aux1;          /* saves their 8 of 17 output bytes per call (phz_map_reads, phz_map_reads_batch) */
 } phz_calls;
 
 /* One (chromosome, BAM) shard's call lines = K_map output + the per-record fields the phasing core reads

@@ -926,15 +926,17 @@ __device__ __forceinline__ void compact_run(const CompactArgs &c, const int *pre
             const uint2 w = w_[u];
             const ShardDev &sh = c.shards[UNI ? si0 : siv[k]];
             const int64_t o = dstv[k] + (e - pref[k]);
-            uint32_t a0 = w.y >> 16, a1 = 0u;
-            if (w.y & 0x8000u) a0 = c.side[g_[u]];
-            if (w.y & 0x4000u) a1 = c.side[c.slots + g_[u]];
             if (o < sh.cap) {
                 sh.o_read[o] = r0v[k] + (int32_t)(w.y & 0x3FFu);
                 sh.o_var[o] = (int32_t)w.x;
                 sh.o_code[o] = (uint8_t)((w.y >> 10) & 15u);
-                sh.o_aux0[o] = a0;
-                sh.o_aux1[o] = a1;
+                if (sh.o_aux0) {             // the two planes only the mapper's text output reads (NULL for a caller that wants (record, variant, code))
+                    uint32_t a0 = w.y >> 16, a1 = 0u;
+                    if (w.y & 0x8000u) a0 = c.side[g_[u]];
+                    if (w.y & 0x4000u) a1 = c.side[c.slots + g_[u]];
+                    sh.o_aux0[o] = a0;
+                    sh.o_aux1[o] = a1;
+                }
             }
         }
     }
@@ -1008,6 +1010,7 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         d.pos = r[i].pos; d.cigar_off = r[i].cigar_off; d.cigar = r[i].cigar; d.seq_off = r[i].seq_off; d.seq2 = r[i].seq2; d.qual = r[i].qual;
         d.n = r[i].n_reads; d.vpos = v[i].pos; d.nv = (int)v[i].n; d.pad = 0;
         d.o_read = out[i].read_idx; d.o_var = out[i].var_idx; d.o_code = out[i].code; d.o_aux0 = out[i].aux0; d.o_aux1 = out[i].aux1;
+        if (!d.o_aux0 || !d.o_aux1) { d.o_aux0 = nullptr; d.o_aux1 = nullptr; }           // both or none
         d.cap = out[i].cap;
         ht0[k] = ntiles;
         ntiles += (r[i].n_reads + tile_reads - 1) / tile_reads;

@@ -60,6 +60,7 @@ extern "C" int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_var
     if (int s = phz_reserve(ctx, ctx->c_aux1, cap * 4)) return s;
     dc.read_idx = (int32_t *)ctx->c_read.p; dc.var_idx = (int32_t *)ctx->c_var.p; dc.code = (uint8_t *)ctx->c_code.p;
     dc.aux0 = (uint32_t *)ctx->c_aux0.p; dc.aux1 = (uint32_t *)ctx->c_aux1.p;
+    if (!out->aux0 || !out->aux1) { dc.aux0 = nullptr; dc.aux1 = nullptr; }
     int st = phz_launch_map(ctx, dr, dv, baseq, dc, n_calls);
     if (st != PHZ_OK && st != PHZ_E_CAPACITY) return st;
     const size_t m = (size_t)(*n_calls < out->cap ? *n_calls : out->cap);
@@ -67,8 +68,10 @@ extern "C" int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_var
         PHZ_HIP(ctx, hipMemcpyAsync(out->read_idx, dc.read_idx, m * 4, hipMemcpyDeviceToHost, ctx->stream));
         PHZ_HIP(ctx, hipMemcpyAsync(out->var_idx, dc.var_idx, m * 4, hipMemcpyDeviceToHost, ctx->stream));
         PHZ_HIP(ctx, hipMemcpyAsync(out->code, dc.code, m, hipMemcpyDeviceToHost, ctx->stream));
-        PHZ_HIP(ctx, hipMemcpyAsync(out->aux0, dc.aux0, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PHZ_HIP(ctx, hipMemcpyAsync(out->aux1, dc.aux1, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (dc.aux0) {
+            PHZ_HIP(ctx, hipMemcpyAsync(out->aux0, dc.aux0, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            PHZ_HIP(ctx, hipMemcpyAsync(out->aux1, dc.aux1, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
     PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return st;

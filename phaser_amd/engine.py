@@ -176,7 +176,7 @@ class Engine:
         rest = [it for it in items if it not in batch]
         if batch:
             calls = self.mapper.map_batch([it[1] for it in batch], [torch.from_numpy(self.vs.chroms[it[0]].pos) for it in batch],
-                                          self.cfg.baseq)
+                                          self.cfg.baseq, aux=False)          # the phasing stage reads (record, variant, code) only
             for it, c in zip(batch, calls):
                 self.add_mapped(bam_index, it[0], it[1], c, it[2], it[3] if len(it) > 3 else None)
         for it in rest:

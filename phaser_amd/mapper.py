@@ -17,15 +17,15 @@ class Calls:
     read_idx: torch.Tensor   # int32
     var_idx: torch.Tensor    # int32
     code: torch.Tensor       # uint8: 0..3 = A,C,G,T; 4 = other text
-    aux0: torch.Tensor       # int32 bits of uint32
-    aux1: torch.Tensor
+    aux0: Optional[torch.Tensor] = None      # int32 bits of uint32; None for a call list made without the text planes (aux=False)
+    aux1: Optional[torch.Tensor] = None
 
     @property
     def n(self) -> int:
         return int(self.read_idx.numel())
 
     def cpu(self) -> "Calls":
-        return Calls(*(t.cpu() for t in (self.read_idx, self.var_idx, self.code, self.aux0, self.aux1)))
+        return Calls(*(None if t is None else t.cpu() for t in (self.read_idx, self.var_idx, self.code, self.aux0, self.aux1)))
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -77,9 +77,10 @@ class Mapper:
             m = int(n.value)
             return Calls(*[b[:m] for b in bufs])
 
-    def prepare_batch(self, shards, vposs, baseq: int, caps):
+    def prepare_batch(self, shards, vposs, baseq: int, caps, aux: bool = True):
         """ctypes argument arrays + output buffers for phz_map_reads_batch over device-resident shards (built once, reusable
-        for repeated passes).  -> (call(), bufs, n_out) where call() submits the whole batch and returns the status."""
+        for repeated passes).  -> (call(), bufs, n_out) where call() submits the whole batch and returns the status.
+        aux=False: (record, variant, code) only -- what the phasing stage reads; the planes behind the mapper's allele TEXT are not written."""
         n = len(shards)
         R = (_lib.phz_reads * n)(); V = (_lib.phz_variants * n)(); O = (_lib.phz_calls * n)(); N = (C.c_int64 * n)()
         bufs = []
@@ -92,8 +93,8 @@ class Mapper:
                                   _ptr(sh.seq_off), _ptr(sh.seq2), _ptr(sh.qual))
             V[i] = _lib.phz_variants(int(vp.numel()), _ptr(vp), None)
             b = [torch.empty(cap, dtype=torch.int32, device=sh.device), torch.empty(cap, dtype=torch.int32, device=sh.device),
-                 torch.empty(cap, dtype=torch.uint8, device=sh.device), torch.empty(cap, dtype=torch.int32, device=sh.device),
-                 torch.empty(cap, dtype=torch.int32, device=sh.device)]
+                 torch.empty(cap, dtype=torch.uint8, device=sh.device)]
+            b += [torch.empty(cap, dtype=torch.int32, device=sh.device), torch.empty(cap, dtype=torch.int32, device=sh.device)] if aux else [None, None]
             bufs.append(b)
             O[i] = _lib.phz_calls(cap, *[_ptr(t) for t in b])
         h = self.ctx.h; fn = self.ctx.lib.phz_map_reads_batch; bq = int(baseq)
@@ -103,7 +104,7 @@ class Mapper:
         call.keep = (R, V, O, N, keep, bufs)
         return call, bufs, N
 
-    def map_batch(self, shards, vposs, baseq: int):
+    def map_batch(self, shards, vposs, baseq: int, aux: bool = True):
         """K_map over several device-resident (chromosome, BAM) shards in one submission (phz_map_reads_batch: the reference's
         pool.map over chromosomes, phaser.py:533).  -> list of Calls."""
         if not shards:
@@ -111,13 +112,13 @@ class Mapper:
         caps = [sh.n // 2 + 4096 for sh in shards]
         torch.cuda.synchronize(shards[0].device)
         while True:
-            call, bufs, N = self.prepare_batch(shards, vposs, baseq, caps)
+            call, bufs, N = self.prepare_batch(shards, vposs, baseq, caps, aux)
             st = call()
             self.ctx.check(st, allow=(_lib.PHZ_E_CAPACITY,))
             if st == _lib.PHZ_E_CAPACITY:
                 caps = [max(c, int(N[i]) + 16) for i, c in enumerate(caps)]
                 continue
-            return [Calls(*[t[:int(N[i])] for t in bufs[i]]) for i in range(len(shards))]
+            return [Calls(*[None if t is None else t[:int(N[i])] for t in bufs[i]]) for i in range(len(shards))]
 
     def map_general(self, shard: ReadShard, vpos: torch.Tensor, ref_len: torch.Tensor, allele_off: torch.Tensor,
                     allele_bytes: torch.Tensor, baseq: int, want_text: bool = False):
