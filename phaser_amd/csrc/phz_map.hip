@@ -90,6 +90,7 @@ struct MapBatch {
     int32_t *tile_total;          // [ntiles]
     int slot_cap, dbg;
     int64_t ntiles;
+    unsigned long long *prof;     // PHZ_MAP_DBG bit 2048 (profiling build of the kernel only): 8 clock stamps per tile
 };
 
 __device__ __forceinline__ int shard_of(const int64_t *tile0, int n_shards, int64_t T) {
@@ -485,6 +486,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         a.stage = bt.stage; a.side = bt.side; a.slots = bt.slots;
         a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = ABL ? bt.dbg : 0;
     }
+#define PHZ_STAMP(K) do { if (ABL && (bt.dbg & 2048) && threadIdx.x == 0) bt.prof[8 * gtile + (K)] = wall_clock64(); } while (0)
+    PHZ_STAMP(0);
     constexpr int TILE = MAP_BLOCK * RPT;
     constexpr int CIG = TILE * PHZ_CIG_X2 / 2;          // packed CIGAR words staged per tile (max)
     constexpr int CAND = TILE * PHZ_CAND_X4 / 4;         // candidate buffer entries (complex records only)
@@ -559,6 +562,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     for (int u = 0; u < 3; u++) { const uint32_t j = (uint32_t)tid + (uint32_t)u * MAP_BLOCK; if (j < cnt_w) s_cig[j] = cg[u]; }
     for (uint32_t j = (uint32_t)tid + 3u * MAP_BLOCK; j < cnt_w; j += MAP_BLOCK) s_cig[j] = a.cigar[cw.c_begin + j];
     __syncthreads();
+    PHZ_STAMP(1);
     CandBuf cb;
     cb.key = s_key; cb.var = s_var; cb.x0 = s_x0; cb.ins = s_ins; cb.n = &s_ncand; cb.nins = &s_nins; cb.cap = CAND; cb.w0 = vw.w0;
     const long long cover = (long long)s_pos[nr - 1] + MAP_COVER;     // every het SNP below this is inside the window
@@ -644,7 +648,9 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             pre_s[k] = PHZ_SEQ_BYTE(a, soff, x);
         }
     }
+    PHZ_STAMP(2);
     __syncthreads();
+    PHZ_STAMP(3);
     // ---- phase 1b: spliced / gapped / clipped records, densely re-packed so the divergent walk runs on full waves
     const int nshort = walk_on ? s_ncx : 0;
     const int ncx = (walk_on && !(a.dbg & 256)) ? nshort + s_nlong : 0;       // dbg 256: multi-op records listed but not walked
@@ -669,6 +675,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         }
     }
     __syncthreads();
+    PHZ_STAMP(4);
     const int ncand = s_ncand;
     const bool fb = ncand > CAND;              // candidate buffer overflow: complex records fall back to in-lane work
     // the bytes of this lane's buffered candidate (if it has one) are requested now and used after the arithmetic below
@@ -738,12 +745,14 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
                               : (j < nr && walk_on ? walk_read<1>(a, vw, cw, cb, j, r0 + j, rpos_[k], c0_[k], c1_[k], s_soff[j], 0, 0) : 0);
         }
     }
+    PHZ_STAMP(5);
     // ---- phase 3: per-record counts -> offsets (s_coff is free now)
     const int T = block_scan<MAP_BLOCK, RPT>(cnt, off, s_wsum, lane, wave);
 #pragma unroll
     for (int k = 0; k < RPT; k++) s_coff[k * MAP_BLOCK + tid] = (uint32_t)off[k];
     if (tid == 0) a.tile_total[gtile] = T;
     __syncthreads();
+    PHZ_STAMP(6);
     if (a.dbg & 2) return;
     // ---- phase 4: ordered flush into the tile's staging slot
 #pragma unroll
@@ -777,6 +786,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             }
         }
     }
+    PHZ_STAMP(7);
+#undef PHZ_STAMP
 }
 
 // Eight waves per SIMD: the kernel's time follows the number of resident tiles (measured by padding the workgroups with unused LDS:
@@ -1051,6 +1062,8 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         bt.tile_w0 = (int32_t *)ctx->tile_w0.p; bt.tile_total = (int32_t *)S[17].p;
         bt.slot_cap = slot_cap; bt.ntiles = ntiles;
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
+        bt.prof = nullptr;
+        if (bt.dbg & 2048) { if (int s = phz_reserve(ctx, S[21], (size_t)ntiles * 64)) return s; bt.prof = (unsigned long long *)S[21].p; }
         hipLaunchKernelGGL(k_tile_window, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sm, bt, tile_reads);
         PHZ_HIP(ctx, hipEventRecord(ctx->map_ev[0], sm));
         unsigned dyn_lds = 0;          // experiment: dynamic LDS nobody uses, to bound the workgroups per CU (PHZ_MAP_DYNLDS bytes)
@@ -1079,6 +1092,15 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
         float ms = 0;
         PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->map_ev[0], ctx->map_ev[1]));
+        if (bt.prof) {          // mean time between the stamps of a tile (wall_clock64: 100 MHz), first wave's view
+            std::vector<unsigned long long> pr((size_t)ntiles * 8);
+            PHZ_HIP(ctx, hipMemcpy(pr.data(), bt.prof, pr.size() * 8, hipMemcpyDeviceToHost));
+            double seg[7] = {0, 0, 0, 0, 0, 0, 0}; double life = 0;
+            for (int64_t t = 0; t < ntiles; t++) { for (int k = 0; k < 7; k++) seg[k] += (double)(pr[8 * t + k + 1] - pr[8 * t + k]); life += (double)(pr[8 * t + 7] - pr[8 * t]); }
+            fprintf(stderr, "[k_map profile] %lld tiles, kernel %.3f ms, tile lifetime %.2f us: stage loads -> LDS %.2f | single-run records + first gathers %.2f | barrier %.2f | "
+                            "multi-op walk %.2f | candidate gathers + resolve %.2f | scan %.2f | flush %.2f us\n", (long long)ntiles, ms, life / ntiles / 100.0,
+                    seg[0] / ntiles / 100.0, seg[1] / ntiles / 100.0, seg[2] / ntiles / 100.0, seg[3] / ntiles / 100.0, seg[4] / ntiles / 100.0, seg[5] / ntiles / 100.0, seg[6] / ntiles / 100.0);
+        }
         ms_total += ms;
         if ((int64_t)scal[1] <= slot_cap) break;
         if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging slots did not converge");
