@@ -719,12 +719,19 @@ __global__ void k_block_counts(const uint32_t *start, const uint32_t *count, int
         blkvars[c] = blk_voff[b1] - blk_voff[b0]; cfgrows[c] = cfg_base[b1] - cfg_base[b0];
     }
 }
+// (few workgroups, one same-address atomic each: one per wave of 64 elements was 35 us for 186,000 blocks)
 __global__ __launch_bounds__(256) void k_max_u32(const uint32_t *x, int64_t n, unsigned long long *out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t v = i < n ? x[i] : 0u;
+    __shared__ uint32_t s_m[4];
+    uint32_t v = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const uint32_t y = x[i]; v = y > v ? y : v; }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, (unsigned long long)v);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) v = s_m[w] > v ? s_m[w] : v;
+        if (v) atomicMax(out, (unsigned long long)v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- block phasing (phase_v3)
@@ -1525,18 +1532,27 @@ template <int MODE, int SLOTS, int THREADS> __global__ __launch_bounds__(THREADS
 
 // ---------------------------------------------------------------------------------------------- small helpers of the orchestration
 // seg_off[s] = off[sum of count[0..s)]: byte offsets of the per-chromosome (per BAM x chromosome) segments of a file
-__global__ void k_seg_offsets(const uint32_t *count, const uint32_t *mult, int nseg, const unsigned long long *off, unsigned long long *seg_off) {
-    if (threadIdx.x || blockIdx.x) return;
+// (one workgroup: every thread sums a contiguous chunk of the counts, the chunks' prefix comes from LDS -- one thread walking the segments with
+//  a dependent load each was 8 us per file)
+template <class C> __device__ __forceinline__ void seg_offsets_block(const C *count, unsigned long long mult, int nseg, const unsigned long long *off, unsigned long long *seg_off) {
+    __shared__ unsigned long long s_part[256];
+    const int tid = threadIdx.x;
+    const int chunk = (nseg + 1 + 255) / 256, beg = tid * chunk, end = beg + chunk < nseg + 1 ? beg + chunk : nseg + 1;
+    unsigned long long sum = 0;
+    for (int j = beg; j < end; j++) if (j < nseg) sum += (unsigned long long)count[j] * mult;
+    s_part[tid] = sum;
+    __syncthreads();
     unsigned long long rows = 0;
-    for (int s = 0; s <= nseg; s++) {
-        seg_off[s] = off[rows];
-        if (s < nseg) rows += (unsigned long long)count[s] * (mult ? *mult : 1u);
-    }
+    for (int t = 0; t < tid; t++) rows += s_part[t];
+    for (int j = beg; j < end; j++) { seg_off[j] = off[rows]; if (j < nseg) rows += (unsigned long long)count[j] * mult; }
 }
-__global__ void k_seg_offsets64(const unsigned long long *count, int nseg, const unsigned long long *off, unsigned long long *seg_off) {
-    if (threadIdx.x || blockIdx.x) return;
-    unsigned long long rows = 0;
-    for (int s = 0; s <= nseg; s++) { seg_off[s] = off[rows]; if (s < nseg) rows += count[s]; }
+__global__ __launch_bounds__(256) void k_seg_offsets(const uint32_t *count, const uint32_t *mult, int nseg, const unsigned long long *off, unsigned long long *seg_off) {
+    if (blockIdx.x) return;
+    seg_offsets_block<uint32_t>(count, mult ? (unsigned long long)*mult : 1ull, nseg, off, seg_off);
+}
+__global__ __launch_bounds__(256) void k_seg_offsets64(const unsigned long long *count, int nseg, const unsigned long long *off, unsigned long long *seg_off) {
+    if (blockIdx.x) return;
+    seg_offsets_block<unsigned long long>(count, 1ull, nseg, off, seg_off);
 }
 __global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *len, int64_t n, unsigned long long *counter) {
     __shared__ unsigned int s_c[4];
@@ -1992,7 +2008,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         bs.phase_idx = P<int8_t>(h->d_phase); bs.mafv = P<double>(h->d_maf); bs.conc = P<uint8_t>(h->conc); bs.cormode = P<uint8_t>(h->cormode); bs.statkind = P<uint8_t>(h->statkind);
         bs.statidx = P<uint32_t>(h->statidx); bs.maxmaf = P<int32_t>(h->maxmaf); bs.stat = P<double>(h->stat); bs.cfg_rows = P<unsigned long long>(h->cfg_rows);
         hipLaunchKernelGGL(k_blk_stats, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, bs);
-        hipLaunchKernelGGL(k_max_u32, dim3(nblk(nblocks)), dim3(256), 0, sm, (const uint32_t *)h->blk_len.p, nblocks, cnt64 + 3);
+        hipLaunchKernelGGL(k_max_u32, dim3(std::min(nblk(nblocks), 64u)), dim3(256), 0, sm, (const uint32_t *)h->blk_len.p, nblocks, cnt64 + 3);
         hipLaunchKernelGGL(k_block_starts, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, (const uint32_t *)h->blk_mstart.p, (const uint32_t *)h->mem_s.p,
                            (const uint16_t *)h->d_vchrom.p, ss_blocks);
     }
@@ -2139,12 +2155,12 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         unsigned long long *so = P<unsigned long long>(h->seg_off_d[f]);
         const unsigned long long *of = P<unsigned long long>(h->off[f]);
         switch (f) {
-            case PHZ_TXT_CONN: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_conn, (const uint32_t *)nullptr, nseg[f], of, so); break;
-            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)nullptr, nseg[f], of, so); break;
-            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)d_nb, nseg[f], of, so); break;
-            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_seg_offsets64, dim3(1), dim3(1), 0, sm, (const unsigned long long *)cc_cfg, nseg[f], of, so); break;
-            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)d_nb, nseg[f], of, so); break;
-            default: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)nullptr, nseg[f], of, so); break;
+            case PHZ_TXT_CONN: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_conn, (const uint32_t *)nullptr, nseg[f], of, so); break;
+            case PHZ_TXT_HAP: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)nullptr, nseg[f], of, so); break;
+            case PHZ_TXT_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)d_nb, nseg[f], of, so); break;
+            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_seg_offsets64, dim3(1), dim3(256), 0, sm, (const unsigned long long *)cc_cfg, nseg[f], of, so); break;
+            case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)d_nb, nseg[f], of, so); break;
+            default: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)nullptr, nseg[f], of, so); break;
         }
     }
     PHZ_HIP(ctx, hipGetLastError());

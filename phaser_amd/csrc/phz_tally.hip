@@ -94,27 +94,28 @@ __global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long 
         if (s_h[j]) atomicAdd(&hist[j - AS_LDS_BINS / 2 + 32768], (unsigned long long)s_h[j]);
 }
 
-// the occupied bins of the 64 Ki-bin histogram as (bin, count) pairs in bin order (alignment scores live in a narrow band: a few dozen bins),
-// so that the host reads a few hundred bytes instead of 512 KB; out[0] = number of pairs (may exceed cap: the caller then takes the dense path)
+// the occupied bins of the 64 Ki-bin histogram as (bin, count) pairs (alignment scores live in a narrow band: a few dozen bins), so that the
+// host reads a few hundred bytes instead of 512 KB.  One thread per bin, one cursor step per workgroup with occupied bins: the pairs come out
+// in no particular order (the caller sorts the handful); n_out[0] = number of pairs (may exceed cap: the caller then takes the dense path)
 __global__ __launch_bounds__(1024) void k_hist_compact(const unsigned long long *hist, int cap, int32_t *bins, unsigned long long *counts, int32_t *n_out) {
     __shared__ int s_w[16];
-    constexpr int PER = PHZ_AS_BINS / 1024;
+    __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long c[PER];
-    int nz = 0;
-#pragma unroll
-    for (int j = 0; j < PER; j++) { c[j] = hist[tid * PER + j]; nz += c[j] ? 1 : 0; }
-    int incl = nz;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-    if (lane == 63) s_w[wave] = incl;
+    const int bin = blockIdx.x * 1024 + tid;
+    const unsigned long long c = hist[bin];
+    const unsigned long long m = __ballot(c != 0ull);
+    if (lane == 0) s_w[wave] = __popcll(m);
     __syncthreads();
-    int at = incl - nz;
-    for (int w = 0; w < wave; w++) at += s_w[w];
-    if (tid == 1023) n_out[0] = at + nz;
-#pragma unroll
-    for (int j = 0; j < PER; j++)
-        if (c[j]) { if (at < cap) { bins[at] = tid * PER + j; counts[at] = c[j]; } at++; }
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; w++) { const int x = s_w[w]; s_w[w] = tot; tot += x; }
+        s_base = tot ? atomicAdd(n_out, tot) : 0;
+    }
+    __syncthreads();
+    if (c) {
+        const int at = s_base + s_w[wave] + __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        if (at < cap) { bins[at] = bin; counts[at] = c; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ per-line pass
@@ -776,7 +777,7 @@ template <int MODE> __global__ __launch_bounds__(PAIRS_TB) void k_pairs(const ui
 
 // ---- edge list in (a, b) order: counting sort of the used table slots by a (the degrees were counted by k_pairs as it claimed the slots);
 //      the position of an edge inside its variant's (small) group is the number of group members with a smaller b
-constexpr uint32_t EDGE_RANK_MAX = 24;      // groups up to this size are ranked by counting; larger ones are sorted first
+constexpr uint32_t EDGE_RANK_MAX = 128;     // groups up to this size are ranked by counting (<= 128 cached loads per edge); larger ones are sorted first
 __global__ __launch_bounds__(256) void k_edge_scatter(const uint32_t *used, const uint64_t *used_key, int64_t n_used, const uint32_t *eoff, uint32_t *deg,
                                                       uint32_t *e_a, uint32_t *e_b, uint32_t *e_slot) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -876,8 +877,8 @@ __global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t 
     if (threadIdx.x == 0) s_start[256] = rl_start[e0 + 256 < nlists ? e0 + 256 : nlists];
     __syncthreads();
     const uint32_t base = s_start[0], total = s_start[256] - base;
-    const bool staged = total <= (uint32_t)RL_STAGE;
-    if (staged) for (uint32_t p = threadIdx.x; p < total; p += 256) s_x[p] = rl_tmp[base + p];
+    const uint32_t n_staged = total <= (uint32_t)RL_STAGE ? total : (uint32_t)RL_STAGE;      // the front of the stretch; lists reaching beyond it are walked in global memory
+    for (uint32_t p = threadIdx.x; p < n_staged; p += 256) s_x[p] = rl_tmp[base + p];
     __syncthreads();
     if (e < nlists) {
         const uint32_t lo = s_start[threadIdx.x], hi = s_start[threadIdx.x + 1], n = hi - lo;
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t 
         else if (n > 64u) s_list[0][atomicAdd(&s_n[0], 1u)] = (uint32_t)e;
         else if (n > (uint32_t)RL_SMALL) s_list[2][atomicAdd(&s_n[2], 1u)] = (uint32_t)e;
         else if (n > 0) {
-            if (staged) rl_insertion_sort(s_x + (lo - base), n);
+            if (hi - base <= n_staged) rl_insertion_sort(s_x + (lo - base), n);
             else {
                 uint64_t *x = rl_tmp + lo;
                 rl_insertion_sort(x, n);
@@ -894,11 +895,10 @@ __global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t 
         }
     }
     __syncthreads();
-    if (staged)
-        for (uint32_t p = threadIdx.x; p < total; p += 256) {
-            const uint32_t l = rl_list[base + p] - (uint32_t)e0;              // the entry's list, relative to the workgroup's first
-            if (s_start[l + 1] - s_start[l] <= (uint32_t)RL_SMALL) rl_qid[base + p] = (int32_t)(uint32_t)s_x[p];
-        }
+    for (uint32_t p = threadIdx.x; p < n_staged; p += 256) {
+        const uint32_t l = rl_list[base + p] - (uint32_t)e0;              // the entry's list, relative to the workgroup's first
+        if (s_start[l + 1] - s_start[l] <= (uint32_t)RL_SMALL && s_start[l + 1] - base <= n_staged) rl_qid[base + p] = (int32_t)(uint32_t)s_x[p];
+    }
     if (threadIdx.x < 3) s_base[threadIdx.x] = s_n[threadIdx.x] ? atomicAdd(&counters32[threadIdx.x], s_n[threadIdx.x]) : 0u;      // one global atomic per workgroup and class
     __syncthreads();
     for (int k = 0; k < 3; k++) {
@@ -1123,7 +1123,7 @@ extern "C" int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, in
         if (int s2 = upload_tab(ctx, L.data(), n_shards, as_hist_blocks, &T, &grids)) return s2;
         if (grids.back() > 0) hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, hist, flags);
     }
-    hipLaunchKernelGGL(k_hist_compact, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist, cap, d_bins, d_counts, (int32_t *)(flags + 1));
+    hipLaunchKernelGGL(k_hist_compact, dim3(PHZ_AS_BINS / 1024), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist, cap, d_bins, d_counts, (int32_t *)(flags + 1));
     PHZ_HIP(ctx, hipGetLastError());
     PHZ_HIP(ctx, hipMemcpyAsync(ctx->h_scalars.p, flags, tail, hipMemcpyDeviceToHost, ctx->stream));
     if (int s = t.stop()) return s;
@@ -1131,8 +1131,14 @@ extern "C" int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, in
     if (hf[0]) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "AS value outside int16");
     *n_bins = (int32_t)hf[1];
     if ((int)hf[1] > cap) return PHZ_E_CAPACITY;
-    memcpy(bins, (const char *)ctx->h_scalars.p + 16, (size_t)hf[1] * 4);
-    memcpy(counts, (const char *)ctx->h_scalars.p + 16 + (size_t)cap * 4, (size_t)hf[1] * 8);
+    {   // the pairs arrive workgroup by workgroup in no particular order: into bin order (a few dozen of them)
+        const int32_t *hb = (const int32_t *)((const char *)ctx->h_scalars.p + 16);
+        const int64_t *hc = (const int64_t *)((const char *)ctx->h_scalars.p + 16 + (size_t)cap * 4);
+        std::vector<int> order(hf[1]);
+        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return hb[a] < hb[b]; });
+        for (size_t i = 0; i < order.size(); i++) { bins[i] = hb[order[i]]; counts[i] = hc[order[i]]; }
+    }
     return PHZ_OK;
 }
 
