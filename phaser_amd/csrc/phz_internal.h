@@ -31,7 +31,9 @@ struct phz_ctx {
     DevBuf desc, tile_w0, scalars;
     DevBuf h_scalars;                  // pinned host mirror of `scalars` (hipHostMalloc)
     DevBuf h_bam_stage;                // page-locked staging of the device BAM path (phz_bamdev.hip)
-    DevBuf shard_tab, h_shard_tab;     // shard table of a batched K_map submission (device / pinned host image)
+    DevBuf shard_tab, h_shard_tab;     // shard table of a batched stage (device / pinned host image)
+    DevBuf map_tab;                    // K_map's own device copy of its shard table (shard_tab is shared with the tally / BAM stages)
+    std::vector<char> map_tab_image; void *map_tab_dev = nullptr;      // the image last uploaded to map_tab (a repeated submission skips the copy)
     std::vector<hipEvent_t> map_ev;    // event pairs around every k_map launch of a batch
     // staging for PHZ_HOST callers
     DevBuf r_pos, r_coff, r_cig, r_soff, r_seq, r_qual, v_pos, v_reflen;

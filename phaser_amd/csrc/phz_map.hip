@@ -1008,10 +1008,10 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
     }
     const int m = (int)live.size();
     if (m == 0) return PHZ_OK;
-    // host image of the shard table: [ShardDev x m][tile0 x (m+1)], pinned; device copy in ctx->shard_tab
+    // host image of the shard table: [ShardDev x m][tile0 x (m+1)], pinned; device copy in ctx->map_tab
     const size_t tab_bytes = (size_t)m * sizeof(ShardDev) + (size_t)(m + 1) * 8;
     if (int s = phz_reserve_host(ctx, ctx->h_shard_tab, tab_bytes)) return s;
-    if (int s = phz_reserve(ctx, ctx->shard_tab, tab_bytes + (size_t)m * 8)) return s;
+    if (int s = phz_reserve(ctx, ctx->map_tab, tab_bytes + (size_t)m * 8)) return s;
     ShardDev *hs = (ShardDev *)ctx->h_shard_tab.p;
     int64_t *ht0 = (int64_t *)((char *)ctx->h_shard_tab.p + (size_t)m * sizeof(ShardDev));
     int64_t ntiles = 0;
@@ -1029,11 +1029,16 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
     ht0[m] = ntiles;
     if (ntiles >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "too many tiles in one submission");
     if (m > 0x1FFF) return phz_fail(ctx, PHZ_E_ARG, "more than 8191 shards in one submission");
-    const ShardDev *d_shards = (const ShardDev *)ctx->shard_tab.p;
-    const int64_t *d_tile0 = (const int64_t *)((char *)ctx->shard_tab.p + (size_t)m * sizeof(ShardDev));
-    int64_t *d_shard_base = (int64_t *)((char *)ctx->shard_tab.p + tab_bytes);
+    const ShardDev *d_shards = (const ShardDev *)ctx->map_tab.p;
+    const int64_t *d_tile0 = (const int64_t *)((char *)ctx->map_tab.p + (size_t)m * sizeof(ShardDev));
+    int64_t *d_shard_base = (int64_t *)((char *)ctx->map_tab.p + tab_bytes);
     hipStream_t sm = ctx->stream;
-    PHZ_HIP(ctx, hipMemcpyAsync(ctx->shard_tab.p, ctx->h_shard_tab.p, tab_bytes, hipMemcpyHostToDevice, sm));
+    // the table of a repeated submission (same shards, same output buffers) is already on the device
+    if (ctx->map_tab_image.size() != tab_bytes || ctx->map_tab_dev != ctx->map_tab.p || memcmp(ctx->map_tab_image.data(), ctx->h_shard_tab.p, tab_bytes) != 0) {
+        PHZ_HIP(ctx, hipMemcpyAsync(ctx->map_tab.p, ctx->h_shard_tab.p, tab_bytes, hipMemcpyHostToDevice, sm));
+        ctx->map_tab_image.assign((const char *)ctx->h_shard_tab.p, (const char *)ctx->h_shard_tab.p + tab_bytes);
+        ctx->map_tab_dev = ctx->map_tab.p;
+    }
     if ((int)ctx->map_ev.size() < 2) {
         ctx->map_ev.resize(2, nullptr);
         for (auto &e : ctx->map_ev) if (!e) PHZ_HIP(ctx, hipEventCreate(&e));
