@@ -39,3 +39,8 @@ for _ in range(3):
 pr = cProfile.Profile(); pr.enable(); dt, eng = one_pass(); pr.disable()
 print("profiled pass %.4f s" % dt)
 st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28); st.sort_stats("tottime").print_stats(18)
+# own time per function in microseconds (pstats prints milliseconds with three decimals: too coarse for a 9 ms pass)
+rows = sorted(((v[2], v[3], v[0], k) for k, v in st.stats.items()), reverse=True)[:45]
+print("own us   cum us   calls  function")
+for tt, ct, cc, (fn, ln, name) in rows:
+    print("%7.0f %8.0f %6d  %s:%d(%s)" % (tt * 1e6, ct * 1e6, cc, os.path.basename(fn), ln, name))
