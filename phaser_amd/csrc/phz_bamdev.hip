@@ -510,8 +510,11 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     // memory, so every copy keeps this thread busy staging it), and each chunk's members are inflated on the compute stream as soon as
     // its bytes have arrived -- the copy of chunk c+1 runs while chunk c inflates
     auto t_h2d0 = std::chrono::steady_clock::now();
-    constexpr int NCOPY = 8;
-    hipStream_t cs[NCOPY] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    constexpr int NCOPY_MAX = 16;
+    int NCOPY = 8;                      // host threads (and streams) that read the file and send it over; PHZ_BAM_NCOPY = 1..16
+    { const char *e = getenv("PHZ_BAM_NCOPY"); if (e && atoi(e) >= 1 && atoi(e) <= NCOPY_MAX) NCOPY = atoi(e); }
+    hipStream_t cs[NCOPY_MAX];
+    for (int t = 0; t < NCOPY_MAX; t++) cs[t] = nullptr;
     for (int t = 0; t < NCOPY; t++) if (hipStreamCreateWithFlags(&cs[t], hipStreamNonBlocking) != hipSuccess) cs[t] = nullptr;
     if (phz_reserve(ctx, ctx->scalars, 64) != PHZ_OK || phz_reserve(ctx, ctx->scratch[11], mem.size() * (size_t)phz_inflate_scratch_bytes_per_member()) != PHZ_OK) {
         (void)hipFree(d_comp); (void)hipFree(d_mem); for (auto c : cs) if (c) (void)hipStreamDestroy(c);
@@ -530,8 +533,9 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     bool stage_ok = fd >= 0 && phz_reserve_host(ctx, ctx->h_bam_stage, (size_t)NCOPY * 2 * STAGE_BYTES) == PHZ_OK;
     if (!stage_ok) (void)hipGetLastError();
     char *stage = (char *)ctx->h_bam_stage.p;
-    hipEvent_t stage_ev[NCOPY * 2];
-    for (auto &e : stage_ev) { e = nullptr; if (stage_ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr; }
+    hipEvent_t stage_ev[NCOPY_MAX * 2];
+    for (auto &e : stage_ev) e = nullptr;
+    for (int t = 0; t < NCOPY * 2; t++) if (stage_ok && hipEventCreateWithFlags(&stage_ev[t], hipEventDisableTiming) != hipSuccess) stage_ev[t] = nullptr;
     {
         // a launch needs ~100,000 members to fill the chip (a lane takes ~60 ms for its member however few there are): big chunks
         const char *ch_env = getenv("PHZ_BAM_CHUNK_MB");
