@@ -358,3 +358,38 @@ def test_chromosome_coming_back_is_refused(mapper, tmp_path):
     with pytest.raises(SystemExit) as e:
         run_dropin(mapper, text, os.path.join(d, "table.tsv"), str(tmp_path / "o.tsv"), 10, 0)
     assert e.value.code == 1
+
+
+def test_call_lists_without_the_text_planes(mapper, oracle_build):
+    """phz_calls.aux0 / aux1 = NULL (what the phasing stage asks for): the (record, variant, code) planes are those of the full call list and of
+    the oracle, through the batched entry point on two shards at once and through phz_map_reads on a host-resident shard."""
+    import ctypes as C
+    from phaser_amd import _lib, soa, synth
+    shards = []; wants = []; vps = []
+    for seed, n_snps in ((501, 400), (502, 2500)):
+        v, gs, ge, w = synth.make_variants("chr1", 1, 20_000_000, n_snps, seed, n_genes=max(4, n_snps // 25))
+        rb = synth.make_reads(v, gs, ge, w, 6000, seed + 100, n_rate=0.002)
+        rb = rb.select(synth.samtools_keep(rb, 255))
+        wants.append(oracle_map_readbatch(oracle_build, rb, v.pos.numpy(), 10, with_text=False))
+        shards.append(soa.pack_readbatch(rb)); vps.append(v.pos)
+    dev = [s.to("cuda") for s in shards]
+    full = mapper.map_batch(dev, vps, 10)
+    lean = mapper.map_batch(dev, vps, 10, aux=False)
+    for f, l, (o_r, o_v, o_c, _) in zip(full, lean, wants):
+        assert l.aux0 is None and l.aux1 is None and f.aux0 is not None
+        assert l.n == f.n == len(o_r)
+        for a, b, o in ((l.read_idx, f.read_idx, o_r), (l.var_idx, f.var_idx, o_v), (l.code, f.code, o_c)):
+            assert torch.equal(a, b) and np.array_equal(a.cpu().numpy(), o)
+    # host-space entry point with NULL planes
+    sh = shards[0]; o_r, o_v, o_c, _ = wants[0]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    vpos = vps[0].to(torch.int32).contiguous()
+    r = _lib.phz_reads(sh.n, int(sh.cigar.numel()), int(sh.seq2.numel()), p(sh.pos), p(sh.cigar_off), p(sh.cigar), p(sh.seq_off), p(sh.seq2), p(sh.qual))
+    vv = _lib.phz_variants(int(vpos.numel()), p(vpos), None)
+    cap = len(o_r) + 8
+    bufs = [torch.empty(cap, dtype=torch.int32), torch.empty(cap, dtype=torch.int32), torch.empty(cap, dtype=torch.uint8)]
+    c = _lib.phz_calls(cap, p(bufs[0]), p(bufs[1]), p(bufs[2]), None, None)
+    n = C.c_int64(0)
+    mapper.ctx.check(mapper.ctx.lib.phz_map_reads(mapper.ctx.h, C.byref(r), C.byref(vv), 10, C.byref(c), C.byref(n), _lib.PHZ_HOST))
+    assert n.value == len(o_r)
+    assert np.array_equal(bufs[0][:n.value].numpy(), o_r) and np.array_equal(bufs[1][:n.value].numpy(), o_v) and np.array_equal(bufs[2][:n.value].numpy(), o_c)
