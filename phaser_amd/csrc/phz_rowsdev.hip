@@ -487,6 +487,18 @@ __global__ __launch_bounds__(256) void k_big_blocks(int64_t nblocks, const uint3
 // thousands of read labels) is written directly.
 // The stage is sized per file (rows x typical row length): it decides how many workgroups a CU holds, and the row functions are chains of
 // dependent loads that only occupancy hides.
+#ifndef PHZ_HAP_ROWS
+#define PHZ_HAP_ROWS 128
+#endif
+#ifndef PHZ_HAP_STAGE
+#define PHZ_HAP_STAGE (32 * 1024)
+#endif
+#ifndef PHZ_ASE_ROWS
+#define PHZ_ASE_ROWS 64
+#endif
+#ifndef PHZ_ASE_STAGE
+#define PHZ_ASE_STAGE (16 * 1024)
+#endif
 template <class ROW, int ROWS, int ROW_STAGE> __global__ __launch_bounds__(ROWS) void k_row_write(RD D, int64_t nrows, const unsigned long long *off, char *out) {
     __shared__ __attribute__((aligned(16))) char s_buf[ROW_STAGE];
     const int64_t r0 = (int64_t)blockIdx.x * ROWS;
@@ -1441,10 +1453,13 @@ __device__ __forceinline__ uint32_t seg_hash(uint32_t q) { q ^= q >> 16; q *= 0x
 
 // one workgroup per segment with more than SEG_SMALL items: open-addressing table keyed by QNAME id holding the first position (then
 // the number) of the QNAME -- in LDS up to SEG_LDS items, in a slice of the global pool beyond
+#ifndef PHZ_SEG_THREADS
+#define PHZ_SEG_THREADS 512
+#endif
 template <int MODE, int SLOTS, int THREADS> __global__ __launch_bounds__(THREADS) void k_seg_big(SG G) {
     __shared__ uint32_t s_tab[3 * SLOTS];
     __shared__ uint32_t s_pref[STAT_N + 2], s_lo[STAT_N + 2];
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[THREADS / 64 > 4 ? THREADS / 64 : 4];
     __shared__ uint32_t s_carry, s_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t seg = THREADS == 64 ? G.big_list[blockIdx.x] : G.big_list2[blockIdx.x];
@@ -2064,9 +2079,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
                 else hipLaunchKernelGGL((k_seg_big<2, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
             }
             if (n_large) {
-                if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, 256>), dim3(n_large), dim3(256), 0, sm, sg);
-                else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 4096, 256>), dim3(n_large), dim3(256), 0, sm, sg);
-                else hipLaunchKernelGGL((k_seg_big<2, 4096, 256>), dim3(n_large), dim3(256), 0, sm, sg);
+                if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                else hipLaunchKernelGGL((k_seg_big<2, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
                 PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 12, hipMemcpyDeviceToHost, sm));
                 if (int s = sec.wait()) return s;
                 sec.begin();
@@ -2182,10 +2197,10 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         char *out = P<char>(h->text[f]);
         if (rows[f]) switch (f) {
             case PHZ_TXT_CONN: hipLaunchKernelGGL((k_row_write<RowConn, 256, 24 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
-            case PHZ_TXT_HAP: hipLaunchKernelGGL((k_row_write<RowHap, 128, 32 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out);
+            case PHZ_TXT_HAP: hipLaunchKernelGGL((k_row_write<RowHap, PHZ_HAP_ROWS, PHZ_HAP_STAGE>), dim3((unsigned)((rows[f] + PHZ_HAP_ROWS - 1) / PHZ_HAP_ROWS)), dim3(PHZ_HAP_ROWS), 0, sm, D, rows[f], of, out);
                 if (h_nbig) hipLaunchKernelGGL(k_row_wave_write<RowHap>, dim3(h_nbig), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, 1, of, out);
                 break;
-            case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, 64, 16 * 1024>), dim3((unsigned)((rows[f] + 63) / 64)), dim3(64), 0, sm, D, rows[f], of, out);
+            case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, PHZ_ASE_ROWS, PHZ_ASE_STAGE>), dim3((unsigned)((rows[f] + PHZ_ASE_ROWS - 1) / PHZ_ASE_ROWS)), dim3(PHZ_ASE_ROWS), 0, sm, D, rows[f], of, out);
                 if (h_nbig) hipLaunchKernelGGL(k_row_wave_write<RowAse>, dim3(h_nbig * (unsigned)nb), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, nb, of, out);
                 break;
             case PHZ_TXT_CFG: hipLaunchKernelGGL((k_row_write<RowCfg, 128, 12 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
