@@ -206,6 +206,7 @@ struct RD {
     const uint8_t *blk_conc, *blk_cormode, *blk_statkind; const uint32_t *blk_statidx; const int32_t *blk_maxmaf;
     const uint32_t *its, *labels; unsigned long long *piece_dst;
     const unsigned long long *cfg_base; const uint32_t *cfg_chunk;
+    const uint32_t *cfg_pl, *cfg_pb; const unsigned long long *cfg_ps, *cfg_bbase;      // allele_config byte offsets in closed form (k_cfg_prefix)
     const MemRec *mrec; const uint32_t *lab_e, *lab_skip; int64_t nmem;       // lab_*[(h * nb + bam) * nmem + member]: read list and room for its label text
 };
 
@@ -447,6 +448,128 @@ __global__ __launch_bounds__(256) void k_cfg_chunks(int64_t nchunks, int64_t nbl
     int64_t lo = 0, hi = nblocks;
     while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (cfg_base[m] <= r) lo = m; else hi = m; }
     cfg_chunk[c] = (uint32_t)lo;
+}
+
+// ---- allele_config.txt without a length per row and a scan over its 11 M rows: the byte offset of row (i, j) of a block follows from three
+// prefix arrays over the block's members.  A row is uid_i \t rsid_i \t uid_j \t rsid_j + "\ttrans\n" (7) or "\tcis\n" (5); with L = len(uid) +
+// len(rsid), A = the member's haplotype-A allele is the reference, B = its haplotype-B allele is, a row is "trans" iff A_i == B_j:
+//   len(i, j)  = L_i + L_j + 3 + (A_i == B_j ? 7 : 5)
+//   rows (i, j') before (i, j) in group i: cnt = j - [i < j] of them; their bytes = cnt (L_i + 8) + (PL[j] - [i < j] L_i) + 2 (E - [i < j and B_i == A_i]),
+//                                           E = A_i ? PB[j] : j - PB[j]   (PL / PB: prefix of L / of B over the members before j)
+//   group i as a whole: S_i = (n - 1)(L_i + 8) + (TL - L_i) + 2 ((A_i ? NB : n - NB) - [B_i == A_i]);  PS[i] = S_0 + .. + S_{i-1};  block bytes = PS[n]
+__device__ __forceinline__ uint32_t cfg_member_len(const RD &D, const MemRec &r, int64_t m) {
+    if (!r.wide) return (uint32_t)r.uid_len + (uint32_t)r.rsid_len;
+    const int64_t g = D.mem_s[m];
+    return D.uid.len(g) + D.rsid.len(g);
+}
+__global__ __launch_bounds__(256) void k_cfg_prefix(RD D, int64_t nblocks, uint32_t *pl, uint32_t *pb, unsigned long long *ps, unsigned long long *blk_bytes) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
+    if (n > (uint32_t)ROW_WAVE_MIN) return;                  // a wave each (k_cfg_prefix_wave): one thread walking hundreds of members twice was the launch's tail
+    unsigned long long TL = 0; uint32_t NB = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        const MemRec r = D.mrec[m0 + t];
+        pl[m0 + t] = (uint32_t)TL; pb[m0 + t] = NB;
+        TL += cfg_member_len(D, r, m0 + t); NB += r.ref_b != 0 ? 1u : 0u;
+    }
+    unsigned long long run = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        const MemRec r = D.mrec[m0 + t];
+        const unsigned long long L = cfg_member_len(D, r, m0 + t);
+        const bool A = r.ref_a != 0, B = r.ref_b != 0;
+        ps[m0 + t] = run;
+        run += (unsigned long long)(n - 1) * (L + 8ull) + (TL - L) + 2ull * ((unsigned long long)(A ? NB : n - NB) - (B == A ? 1ull : 0ull));
+    }
+    blk_bytes[b] = run;
+}
+__device__ __forceinline__ unsigned long long wave_incl_u64(unsigned long long x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(x, d); if (lane >= d) x += y; }
+    return x;
+}
+// the same for the blocks of more than ROW_WAVE_MIN members, one wave per block (the list k_big_blocks made): lanes take members 64 at a time, prefixes by wave scans
+__global__ __launch_bounds__(64) void k_cfg_prefix_wave(RD D, const uint32_t *big_blk, uint32_t *pl, uint32_t *pb, unsigned long long *ps, unsigned long long *blk_bytes) {
+    const int64_t b = big_blk[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
+    unsigned long long TL = 0, NB = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        unsigned long long L = 0, B = 0;
+        if (t < n) { const MemRec r = D.mrec[m0 + t]; L = cfg_member_len(D, r, m0 + t); B = r.ref_b != 0 ? 1ull : 0ull; }
+        const unsigned long long iL = wave_incl_u64(L, lane), iB = wave_incl_u64(B, lane);
+        if (t < n) { pl[m0 + t] = (uint32_t)(TL + iL - L); pb[m0 + t] = (uint32_t)(NB + iB - B); }
+        TL += __shfl(iL, 63); NB += __shfl(iB, 63);
+    }
+    unsigned long long run = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        unsigned long long S = 0;
+        if (t < n) {
+            const MemRec r = D.mrec[m0 + t];
+            const unsigned long long L = cfg_member_len(D, r, m0 + t);
+            const bool A = r.ref_a != 0, B = r.ref_b != 0;
+            S = (unsigned long long)(n - 1) * (L + 8ull) + (TL - L) + 2ull * ((A ? NB : (unsigned long long)n - NB) - (B == A ? 1ull : 0ull));
+        }
+        const unsigned long long iS = wave_incl_u64(S, lane);
+        if (t < n) ps[m0 + t] = run + iS - S;
+        run += __shfl(iS, 63);
+    }
+    if (lane == 0) blk_bytes[b] = run;
+}
+// the writer: ROWS consecutive rows per workgroup, formatted into LDS at their place in the file and copied out with aligned 16-byte stores (as k_row_write)
+template <int ROWS, int STAGE> __global__ __launch_bounds__(ROWS) void k_cfg_write(RD D, int64_t nrows, char *out) {
+    __shared__ __attribute__((aligned(16))) char s_buf[STAGE];
+    __shared__ unsigned long long s_b[2];
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+    const int64_t r1 = r0 + ROWS < nrows ? r0 + ROWS : nrows;
+    const int64_t r = r0 + threadIdx.x;
+    const bool live = r < r1;
+    unsigned long long off = 0; uint32_t len = 0, ma = 0, mb = 0;
+    MemRec xa, xb;
+    bool trans = false;
+    if (live) {
+        int64_t lo = D.cfg_chunk[r >> 8], hi = lo + 257 < D.nblocks ? lo + 257 : D.nblocks;
+        while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (D.cfg_base[m] <= (unsigned long long)r) lo = m; else hi = m; }
+        const int64_t b = lo;
+        const uint32_t m0 = D.blk_mstart[b], n = D.blk_len[b];
+        const uint32_t idx = (uint32_t)((unsigned long long)r - D.cfg_base[b]);
+        const uint32_t i = idx / (n - 1); uint32_t j = idx % (n - 1);
+        if (j >= i) j++;
+        ma = m0 + i; mb = m0 + j;
+        xa = D.mrec[ma]; xb = D.mrec[mb];
+        const unsigned long long La = cfg_member_len(D, xa, ma), Lb = cfg_member_len(D, xb, mb);
+        const bool A = xa.ref_a != 0, Bi = xa.ref_b != 0, Bj = xb.ref_b != 0, lt = i < j;
+        const unsigned long long cnt = (unsigned long long)j - (lt ? 1ull : 0ull);
+        const unsigned long long PLj = D.cfg_pl[mb], PBj = D.cfg_pb[mb];
+        const unsigned long long E = A ? PBj : (unsigned long long)j - PBj;
+        const unsigned long long W = cnt * (La + 8ull) + (PLj - (lt ? La : 0ull)) + 2ull * (E - ((lt && Bi == A) ? 1ull : 0ull));
+        trans = A == Bj;
+        off = D.cfg_bbase[b] + D.cfg_ps[ma] + W;
+        len = (uint32_t)(La + Lb + 3ull + (trans ? 7ull : 5ull));
+        if (threadIdx.x == 0) s_b[0] = off;
+        if (r == r1 - 1) s_b[1] = off + len;
+    }
+    __syncthreads();
+    const unsigned long long b0 = s_b[0], b1 = s_b[1];
+    const unsigned mis = (unsigned)((unsigned long long)(out + b0) & 15ull);
+    const bool staged = (b1 - b0) + mis <= (unsigned long long)STAGE;
+    if (live) {
+        SWrite s;
+        s.p0 = s.p = staged ? s_buf + mis + (unsigned)(off - b0) : out + off; s.base = off;
+        put_uid(D, xa, ma, s); s.ch('\t'); put_rsid(D, xa, ma, s); s.ch('\t');
+        put_uid(D, xb, mb, s); s.ch('\t'); put_rsid(D, xb, mb, s);
+        if (trans) s.lit("\ttrans\n"); else s.lit("\tcis\n");
+    }
+    if (!staged) return;
+    __syncthreads();
+    const unsigned total = mis + (unsigned)(b1 - b0);
+    char *g = out + b0 - mis;                       // 16-byte aligned
+    for (unsigned c = threadIdx.x * 16u; c < total; c += ROWS * 16u) {
+        if (c >= mis && c + 16u <= total) *(uint4 *)(g + c) = *(const uint4 *)(s_buf + c);
+        else for (unsigned k = c < mis ? mis : c; k < c + 16u && k < total; k++) g[k] = s_buf[k];
+    }
 }
 template <class ROW> __global__ __launch_bounds__(256) void k_row_len(RD D, int64_t nrows, uint32_t *len) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1630,7 +1753,7 @@ struct phz_rowsdev {
     DevBuf ridx, va, vb, eorder, mem_s, cstart, corder, ekeep, estart, key_g;
     DevBuf cnt64, cnt32, chrom_cnt, seg_start, key64s, eloc;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
     DevBuf alle_of, sub_of, nsub, complex_list, exc_list, nsub_o, blk_base;
-    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, blk_voff, mrec, lab_e, lab_skip, big_blk;
+    DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, cfg_pl, cfg_pb, cfg_ps, cfg_bytes, cfg_bbase, blk_voff, mrec, lab_e, lab_skip, big_blk;
     DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, pool, tl, its, piece_dst, rowlen;
     DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
     DevBuf o_var, o_maxmaf, o_hap, o_cor;
@@ -1645,7 +1768,7 @@ struct phz_rowsdev {
                                    &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
-                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &blk_voff, &mrec, &lab_e, &lab_skip, &big_blk, &labels,
+                                   &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &cfg_pl, &cfg_pb, &cfg_ps, &cfg_bytes, &cfg_bbase, &blk_voff, &mrec, &lab_e, &lab_skip, &big_blk, &labels,
                                    &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
@@ -2140,6 +2263,14 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         if (nchunks) hipLaunchKernelGGL(k_cfg_chunks, dim3(nblk(nchunks)), dim3(256), 0, sm, nchunks, nblocks, (const unsigned long long *)h->cfg_base.p, P<uint32_t>(h->cfg_chunk));
         D.cfg_chunk = P<uint32_t>(h->cfg_chunk);
     }
+    // allele_config offsets in closed form: prefix arrays per block member, bytes per block, one scan over the blocks (not over the rows)
+    RSV(cfg_pl, (size_t)(nmem + 1) * 4); RSV(cfg_pb, (size_t)(nmem + 1) * 4); RSV(cfg_ps, (size_t)(nmem + 1) * 8); RSV(cfg_bytes, (size_t)(nblocks + 1) * 8); RSV(cfg_bbase, (size_t)(nblocks + 2) * 8);
+    D.cfg_pl = P<uint32_t>(h->cfg_pl); D.cfg_pb = P<uint32_t>(h->cfg_pb); D.cfg_ps = P<unsigned long long>(h->cfg_ps); D.cfg_bbase = P<unsigned long long>(h->cfg_bbase);
+    if (nblocks) hipLaunchKernelGGL(k_cfg_prefix, dim3(nblk(nblocks)), dim3(256), 0, sm, D, nblocks, P<uint32_t>(h->cfg_pl), P<uint32_t>(h->cfg_pb), P<unsigned long long>(h->cfg_ps),
+                                    P<unsigned long long>(h->cfg_bytes));
+    if (h_nbig) hipLaunchKernelGGL(k_cfg_prefix_wave, dim3(h_nbig), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, P<uint32_t>(h->cfg_pl), P<uint32_t>(h->cfg_pb),
+                                   P<unsigned long long>(h->cfg_ps), P<unsigned long long>(h->cfg_bytes));
+    if (int s = gscan_excl<unsigned long long, unsigned long long>(ctx, P<unsigned long long>(h->cfg_bytes), P<unsigned long long>(h->cfg_bbase), nblocks, h->scan_tmp)) return s;
     const int64_t rows[PHZ_TXT_COUNT] = {n_linked, nblocks, nblocks * nb, (int64_t)h_cfg_total, nkeys, nkeys * nb, nkeys};
     int64_t max_rows = 1;
     for (int f = 0; f < PHZ_TXT_COUNT; f++) max_rows = std::max(max_rows, rows[f]);
@@ -2149,7 +2280,13 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     uint32_t *d_nb = cnt32 + 8;
     hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, sm, d_nb, (int64_t)1, (uint32_t)nb);
     for (int f = 0; f < PHZ_TXT_COUNT; f++) {
-        RSV(off[f], (size_t)(rows[f] + 1) * 8); RSV(seg_off_d[f], (size_t)(nseg[f] + 1) * 8);
+        RSV(seg_off_d[f], (size_t)(nseg[f] + 1) * 8);
+        if (f == PHZ_TXT_CFG) {        // offsets in closed form: per-chromosome byte offsets = the byte base of the chromosome's first block
+            hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)nullptr, nseg[f], (const unsigned long long *)h->cfg_bbase.p,
+                               P<unsigned long long>(h->seg_off_d[f]));
+            continue;
+        }
+        RSV(off[f], (size_t)(rows[f] + 1) * 8);
         const unsigned g = nblk(rows[f]);
         uint32_t *len = P<uint32_t>(h->rowlen);
         if (rows[f]) switch (f) {
@@ -2160,7 +2297,6 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
             case PHZ_TXT_ASE: hipLaunchKernelGGL(k_row_len<RowAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len);
                 if (h_nbig) hipLaunchKernelGGL(k_row_wave_len<RowAse>, dim3(h_nbig * (unsigned)nb), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, nb, len);
                 break;
-            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_row_len<RowCfg>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
             case PHZ_TXT_ALLELIC: hipLaunchKernelGGL(k_row_len<RowAllelic>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
             case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_row_len<RowSingleAse>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
             default: hipLaunchKernelGGL(k_row_len<RowSingleHap>, dim3(g), dim3(256), 0, sm, D, rows[f], len); break;
@@ -2173,7 +2309,6 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
             case PHZ_TXT_CONN: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_conn, (const uint32_t *)nullptr, nseg[f], of, so); break;
             case PHZ_TXT_HAP: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)nullptr, nseg[f], of, so); break;
             case PHZ_TXT_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_blocks, (const uint32_t *)d_nb, nseg[f], of, so); break;
-            case PHZ_TXT_CFG: hipLaunchKernelGGL(k_seg_offsets64, dim3(1), dim3(256), 0, sm, (const unsigned long long *)cc_cfg, nseg[f], of, so); break;
             case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)d_nb, nseg[f], of, so); break;
             default: hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, sm, (const uint32_t *)cc_keys, (const uint32_t *)nullptr, nseg[f], of, so); break;
         }
@@ -2203,7 +2338,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
             case PHZ_TXT_ASE: hipLaunchKernelGGL((k_row_write<RowAse, PHZ_ASE_ROWS, PHZ_ASE_STAGE>), dim3((unsigned)((rows[f] + PHZ_ASE_ROWS - 1) / PHZ_ASE_ROWS)), dim3(PHZ_ASE_ROWS), 0, sm, D, rows[f], of, out);
                 if (h_nbig) hipLaunchKernelGGL(k_row_wave_write<RowAse>, dim3(h_nbig * (unsigned)nb), dim3(64), 0, sm, D, (const uint32_t *)h->big_blk.p, nb, of, out);
                 break;
-            case PHZ_TXT_CFG: hipLaunchKernelGGL((k_row_write<RowCfg, 128, 12 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], of, out); break;
+            case PHZ_TXT_CFG: hipLaunchKernelGGL((k_cfg_write<128, 12 * 1024>), dim3((unsigned)((rows[f] + 127) / 128)), dim3(128), 0, sm, D, rows[f], out); break;
             case PHZ_TXT_ALLELIC: hipLaunchKernelGGL((k_row_write<RowAllelic, 256, 24 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
             case PHZ_TXT_SINGLE_ASE: hipLaunchKernelGGL((k_row_write<RowSingleAse, 256, 32 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
             default: hipLaunchKernelGGL((k_row_write<RowSingleHap, 256, 32 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
