@@ -648,11 +648,8 @@ template <class ROW, int ROWS, int ROW_STAGE> __global__ __launch_bounds__(ROWS)
     }
 }
 
-// label text of haplotypic_counts: one thread per read-list entry
-__global__ __launch_bounds__(256) void k_item_len(const uint32_t *labels, int64_t n, uint32_t *tl) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) tl[i] = (uint32_t)ndigits(labels[i]) + 1u;
-}
+// label text of haplotypic_counts: one thread per read-list entry; width of a label's text + its separator (the input transform of the scan that places them)
+struct LabelWidth { template <class T> __device__ static __forceinline__ T f(T x) { return (T)((uint32_t)ndigits((unsigned long long)x) + 1u); } };
 __global__ __launch_bounds__(256) void k_label_write(RD D, int64_t n_rl, char *out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_rl) return;
@@ -2219,9 +2216,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     }
     const uint32_t *blk_cnt = need_all ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->seg_ns);     // one BAM, nothing blacklisted: the two read sets coincide
     // ---- text: byte counts -> scan -> write, file by file
-    RSV(tl, NR * 4); RSV(its, (NR + 1) * 4); RSV(piece_dst, NRL * 8);
-    if (n_rl) hipLaunchKernelGGL(k_item_len, dim3(nblk(n_rl)), dim3(256), 0, sm, (const uint32_t *)h->labels.p, n_rl, P<uint32_t>(h->tl));
-    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->tl), P<uint32_t>(h->its), n_rl, h->scan_tmp)) return s;
+    RSV(its, (NR + 1) * 4); RSV(piece_dst, NRL * 8);
+    // its = scan of the labels' text widths (digits + one separator), the widths computed as the scan loads the labels (no width array)
+    if (int s = gscan_excl<uint32_t, uint32_t, LabelWidth>(ctx, P<uint32_t>(h->labels), P<uint32_t>(h->its), n_rl, h->scan_tmp)) return s;
     PHZ_HIP(ctx, hipMemsetAsync(h->piece_dst.p, 0xff, NRL * 8, sm));
     RSV(big_blk, (size_t)(nblocks + 1) * 4);
     uint32_t h_nbig = 0;

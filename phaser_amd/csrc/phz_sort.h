@@ -13,18 +13,21 @@ namespace {
 // out[i] = sum(in[0..i)), out[n] = total.  Three passes: chunk sums, one-block scan of the sums, chunk-local scan + base.
 constexpr int GS_ITEMS = 16, GS_CHUNK = GS_ITEMS * 256;
 
+// optional transform of the input on load (a scan over f(in[i]) without materialising f(in)): default = the values themselves
+struct GsIdentity { template <class T> __device__ static __forceinline__ T f(T x) { return x; } };
+
 template <class T> __device__ __forceinline__ T gs_wave_incl(T x, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const T y = __shfl_up(x, d); if (lane >= d) x += y; }
     return x;
 }
 
-template <class TI, class TO> __global__ __launch_bounds__(256) void k_gs_reduce(const TI *in, int64_t n, TO *partial) {
+template <class TI, class TO, class F = GsIdentity> __global__ __launch_bounds__(256) void k_gs_reduce(const TI *in, int64_t n, TO *partial) {
     __shared__ TO s[4];
     const int64_t base = (int64_t)blockIdx.x * GS_CHUNK;
     TO x = 0;
 #pragma unroll
-    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k * 256 + threadIdx.x; if (i < n) x += (TO)in[i]; }
+    for (int k = 0; k < GS_ITEMS; k++) { const int64_t i = base + k * 256 + threadIdx.x; if (i < n) x += (TO)F::f(in[i]); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = x;
@@ -59,16 +62,16 @@ template <class TO> __global__ __launch_bounds__(1024) void k_gs_partials(TO *pa
 // the 18.8 M-element scan of a genome's read-label widths ran at 0.9 TB/s).  Exclusive prefix of the chunk with ONE barrier: wave scans of the four
 // row sums, the waves' totals of every row in LDS.
 constexpr int GS_ROWS = GS_ITEMS / 4;
-template <class TI, class TO> __device__ __forceinline__ void gs_load_rows(const TI *in, int64_t n, int64_t chunk0, int tid, TO v[GS_ROWS][4]) {
+template <class TI, class TO, class F = GsIdentity> __device__ __forceinline__ void gs_load_rows(const TI *in, int64_t n, int64_t chunk0, int tid, TO v[GS_ROWS][4]) {
 #pragma unroll
     for (int r = 0; r < GS_ROWS; r++) {
         const int64_t i = chunk0 + ((int64_t)r * 256 + tid) * 4;
         if (sizeof(TI) == 4 && i + 3 < n && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0)) {
             const uint4 x = *reinterpret_cast<const uint4 *>(in + i);
-            v[r][0] = (TO)x.x; v[r][1] = (TO)x.y; v[r][2] = (TO)x.z; v[r][3] = (TO)x.w;
+            v[r][0] = (TO)F::f((TI)x.x); v[r][1] = (TO)F::f((TI)x.y); v[r][2] = (TO)F::f((TI)x.z); v[r][3] = (TO)F::f((TI)x.w);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[r][j] = i + j < n ? (TO)in[i + j] : (TO)0;
+            for (int j = 0; j < 4; j++) v[r][j] = i + j < n ? (TO)F::f(in[i + j]) : (TO)0;
         }
     }
 }
@@ -111,12 +114,12 @@ template <class TO> __device__ __forceinline__ void gs_store_rows(TO *out, int64
     }
 }
 
-template <class TI, class TO> __global__ __launch_bounds__(256) void k_gs_apply(const TI *in, TO *out, int64_t n, const TO *partial) {
+template <class TI, class TO, class F = GsIdentity> __global__ __launch_bounds__(256) void k_gs_apply(const TI *in, TO *out, int64_t n, const TO *partial) {
     __shared__ TO s_w[GS_ROWS][4];
     const int tid = threadIdx.x;
     const int64_t chunk0 = (int64_t)blockIdx.x * GS_CHUNK;
     TO v[GS_ROWS][4], base[GS_ROWS], sum;
-    gs_load_rows<TI, TO>(in, n, chunk0, tid, v);
+    gs_load_rows<TI, TO, F>(in, n, chunk0, tid, v);
     gs_chunk_scan<TO>(v, tid, s_w, base, &sum);
     gs_store_rows<TO>(out, n, chunk0, tid, v, base, partial[blockIdx.x]);
 }
@@ -129,7 +132,7 @@ constexpr unsigned GS_AGG = 1u, GS_PREFIX = 2u;
 __device__ __forceinline__ unsigned long long gs_word(uint32_t epoch, unsigned state, uint32_t value) {
     return ((unsigned long long)epoch << 34) | ((unsigned long long)state << 32) | value;
 }
-template <class TI> __global__ __launch_bounds__(256) void k_gs_lookback(const TI *in, uint32_t *out, int64_t n, unsigned long long *status, uint32_t *ticket,
+template <class TI, class F = GsIdentity> __global__ __launch_bounds__(256) void k_gs_lookback(const TI *in, uint32_t *out, int64_t n, unsigned long long *status, uint32_t *ticket,
                                                                           uint32_t ticket_base, uint32_t epoch) {
     __shared__ uint32_t s_w[GS_ROWS][4];
     __shared__ uint32_t s_tile, s_prefix;
@@ -139,7 +142,7 @@ template <class TI> __global__ __launch_bounds__(256) void k_gs_lookback(const T
     const uint32_t tile = s_tile;
     const int64_t chunk0 = (int64_t)tile * GS_CHUNK;
     uint32_t v[GS_ROWS][4], base[GS_ROWS], block_sum;
-    gs_load_rows<TI, uint32_t>(in, n, chunk0, tid, v);
+    gs_load_rows<TI, uint32_t, F>(in, n, chunk0, tid, v);
     gs_chunk_scan<uint32_t>(v, tid, s_w, base, &block_sum);
     if (wave == 0) {
         if (lane == 0) __hip_atomic_store(&status[tile], gs_word(epoch, tile == 0 ? GS_PREFIX : GS_AGG, block_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -169,7 +172,7 @@ template <class TI> __global__ __launch_bounds__(256) void k_gs_lookback(const T
     gs_store_rows<uint32_t>(out, n, chunk0, tid, v, base, s_prefix);
 }
 
-template <class TI, class TO> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out /* [n + 1] */, int64_t n, DevBuf &tmp) {
+template <class TI, class TO, class F = GsIdentity> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out /* [n + 1] */, int64_t n, DevBuf &tmp) {
     hipStream_t sm = ctx->stream;
     if (n <= 0) { PHZ_HIP(ctx, hipMemsetAsync(out, 0, sizeof(TO), sm)); return PHZ_OK; }
     const int64_t nb = (n + GS_CHUNK - 1) / GS_CHUNK;
@@ -184,7 +187,7 @@ template <class TI, class TO> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out
             ctx->scan_epoch = 0; ctx->scan_ticket_base = 0;
         }
         const uint32_t epoch = ++ctx->scan_epoch;
-        hipLaunchKernelGGL((k_gs_lookback<TI>), dim3((unsigned)nb), dim3(256), 0, sm, in, (uint32_t *)out, n, (unsigned long long *)((char *)ctx->scan_state.p + 64),
+        hipLaunchKernelGGL((k_gs_lookback<TI, F>), dim3((unsigned)nb), dim3(256), 0, sm, in, (uint32_t *)out, n, (unsigned long long *)((char *)ctx->scan_state.p + 64),
                            (uint32_t *)ctx->scan_state.p, ctx->scan_ticket_base, epoch);
         ctx->scan_ticket_base += (uint32_t)nb;
         PHZ_HIP(ctx, hipGetLastError());
@@ -195,9 +198,9 @@ template <class TI, class TO> int gscan_excl(phz_ctx *ctx, const TI *in, TO *out
     {
         if (int s = phz_reserve(ctx, tmp, (size_t)nb * sizeof(TO) + 16)) return s;
         TO *partial = (TO *)tmp.p;
-        hipLaunchKernelGGL((k_gs_reduce<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, n, partial);
+        hipLaunchKernelGGL((k_gs_reduce<TI, TO, F>), dim3((unsigned)nb), dim3(256), 0, sm, in, n, partial);
         hipLaunchKernelGGL((k_gs_partials<TO>), dim3(1), dim3(1024), 0, sm, partial, nb, out + n);
-        hipLaunchKernelGGL((k_gs_apply<TI, TO>), dim3((unsigned)nb), dim3(256), 0, sm, in, out, n, (const TO *)partial);
+        hipLaunchKernelGGL((k_gs_apply<TI, TO, F>), dim3((unsigned)nb), dim3(256), 0, sm, in, out, n, (const TO *)partial);
         PHZ_HIP(ctx, hipGetLastError());
         return PHZ_OK;
     }
