@@ -784,6 +784,11 @@ struct ShardTab { const long long *lo, *hi; const int32_t *bam; int n; };
 // first-appearance keys (rule 2): covered variants by (BAM of the first kept line, line)
 // ... and, on the way, the largest distance between the two halves of a connectivity-map rank (first ref/alt line of the QNAME, the variant's first
 // linked line in it: a few hundred lines apart at most in practice), which decides how many radix passes the rank sort needs for its low half
+// the same key in 32 bits when (first line, gap) fit: first << gap_bits | gap (a 32-bit sort moves half the bytes per pass and needs fewer passes)
+__global__ __launch_bounds__(256) void k_iota_rank32(int64_t nv, const unsigned long long *var_rank, int gap_bits, uint32_t line_mask, uint32_t *key, uint32_t *val) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < nv) { const unsigned long long r = var_rank[v]; key[v] = (((uint32_t)(r >> 32) & line_mask) << gap_bits) | (uint32_t)((uint32_t)r - (uint32_t)(r >> 32)); val[v] = (uint32_t)v; }
+}
 __global__ __launch_bounds__(256) void k_flag_keys(int64_t nv, const long long *var_first, uint32_t *is_key, const unsigned long long *var_rank, unsigned long long *max_gap) {
     __shared__ uint32_t s_m[4];
     uint32_t m = 0;
@@ -819,6 +824,23 @@ __global__ __launch_bounds__(256) void k_conn_starts(int64_t n_linked, const uin
     if (r >= n_linked) return;
     const uint32_t s = vchrom[va[eorder[r]]];
     if (r == 0 || vchrom[va[eorder[r - 1]]] != s) start[s] = (uint32_t)r;
+}
+// (BAM, first line) in 32 bits when they fit: bam << line_bits | line
+__global__ __launch_bounds__(256) void k_compact_keys32(int64_t nv, const long long *var_first, const uint32_t *kpos, ShardTab T, int line_bits, uint32_t *key, uint32_t *val) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const long long f = var_first[v];
+    if (f < 0) return;
+    int bam = 0;
+    for (int t = 0; t < T.n; t++) if (f >= T.lo[t] && f < T.hi[t]) bam = T.bam[t];
+    key[kpos[v]] = ((uint32_t)bam << line_bits) | (uint32_t)f;
+    val[kpos[v]] = (uint32_t)v;
+}
+__global__ __launch_bounds__(256) void k_key_starts32(int64_t nkeys, const uint32_t *key_sorted, int line_bits, const uint32_t *key_g, const uint16_t *vchrom, int nchrom, uint32_t *start) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nkeys) return;
+    const uint32_t s = (key_sorted[r] >> line_bits) * (uint32_t)nchrom + vchrom[key_g[r]];
+    if (r == 0 || (key_sorted[r - 1] >> line_bits) * (uint32_t)nchrom + vchrom[key_g[r - 1]] != s) start[s] = (uint32_t)r;
 }
 __global__ __launch_bounds__(256) void k_key_starts(int64_t nkeys, const unsigned long long *key_sorted, const uint32_t *key_g, const uint16_t *vchrom, int nchrom, uint32_t *start) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2058,10 +2080,19 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     RSV(mem_s, (size_t)(nmem + 1) * 4); RSV(cstart, (size_t)(ncomp + 2) * 4); RSV(corder, (size_t)(ncomp + 1) * 4); RSV(ekeep, (size_t)(nkeep + 1) * 4);
     RSV(estart, (size_t)(ncomp + 2) * 4); RSV(key_g, (size_t)(nkeys + 1) * 4);
     if (nv) {
-        hipLaunchKernelGGL(k_iota_rank, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
-        const int rg[2][2] = {{0, bits_for((uint64_t)(h_c64[2] ? h_c64[2] : 1))}, {32, 32 + bl}};      // (first line of the QNAME, distance to the variant's line)
-        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nv, rg, 2, P<uint32_t>(h->k32a), nullptr)) return s;      // k32a: variants in rank order
-        hipLaunchKernelGGL(k_invert, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->k32a.p, P<uint32_t>(h->ridx));
+        const int gb = bits_for((uint64_t)(h_c64[2] ? h_c64[2] : 1));
+        const uint32_t *rank_order = P<uint32_t>(h->k32a);
+        if (gb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (first line, gap) in one 32-bit key: half the bytes per pass, one range
+            hipLaunchKernelGGL(k_iota_rank32, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, gb, (uint32_t)((1ull << bl) - 1ull), P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
+            const int rg[1][2] = {{0, gb + bl}};
+            if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nv, rg, 1, P<uint32_t>(h->k64a), nullptr)) return s;      // k64a (as uint32): variants in rank order
+            rank_order = P<uint32_t>(h->k64a);
+        } else {
+            hipLaunchKernelGGL(k_iota_rank, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
+            const int rg[2][2] = {{0, bits_for((uint64_t)(h_c64[2] ? h_c64[2] : 1))}, {32, 32 + bl}};      // (first line of the QNAME, distance to the variant's line)
+            if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nv, rg, 2, P<uint32_t>(h->k32a), nullptr)) return s;      // k32a: variants in rank order
+        }
+        hipLaunchKernelGGL(k_invert, dim3(nblk(nv)), dim3(256), 0, sm, nv, rank_order, P<uint32_t>(h->ridx));
     }
     if (ne) {
         hipLaunchKernelGGL(k_edge_keys, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, (const int32_t *)T.ea, (const int32_t *)T.eb,
@@ -2093,13 +2124,23 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     }
     if (nkeys) {
         ShardTab ST; ST.lo = (const long long *)h->sh_lo.p; ST.hi = (const long long *)h->sh_hi.p; ST.bam = (const int32_t *)h->sh_bam.p; ST.n = o->n_shards;
-        hipLaunchKernelGGL(k_compact_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST,
-                           P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
-        const int rg[2][2] = {{0, bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1))}, {32, 32 + (nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0)}};
+        const int bb = nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0;
         RSV(key64s, (size_t)(nkeys + 1) * 8);
-        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nkeys, rg, 2, P<uint32_t>(h->key_g), P<unsigned long long>(h->key64s))) return s;
-        hipLaunchKernelGGL(k_key_starts, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const unsigned long long *)h->key64s.p, (const uint32_t *)h->key_g.p,
-                           (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
+        if (bb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (BAM, first line) in one 32-bit key
+            hipLaunchKernelGGL(k_compact_keys32, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST, bl,
+                               P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
+            const int rg[1][2] = {{0, bb + bl}};
+            if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nkeys, rg, 1, P<uint32_t>(h->key_g), P<uint32_t>(h->key64s))) return s;
+            hipLaunchKernelGGL(k_key_starts32, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const uint32_t *)h->key64s.p, bl, (const uint32_t *)h->key_g.p,
+                               (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
+        } else {
+            hipLaunchKernelGGL(k_compact_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST,
+                               P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
+            const int rg[2][2] = {{0, bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1))}, {32, 32 + (nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0)}};
+            if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nkeys, rg, 2, P<uint32_t>(h->key_g), P<unsigned long long>(h->key64s))) return s;
+            hipLaunchKernelGGL(k_key_starts, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const unsigned long long *)h->key64s.p, (const uint32_t *)h->key_g.p,
+                               (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
+        }
     }
     hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_keys, nb * nchrom, (uint32_t)nkeys, cc_keys);
     // ---- block phasing
