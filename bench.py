@@ -37,13 +37,48 @@ def file_sha(*paths):
     return h.hexdigest()[:16]
 
 
+def calibration():
+    """The newest memory-counter calibration under profiles/ (tools/prof_calib.sh -> calibration.json): what rocprofv3's FETCH_SIZE / WRITE_SIZE report
+    on gfx950 for access patterns with a KNOWN byte count -- coalesced streams of 4 and 16 bytes per lane, 1-byte gathers at one load per 32..512-byte
+    unit in permuted and in address order (K_map's base / quality bytes under a het SNP), coalesced stores.  -> factors to multiply the counters by."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "calib", "calibration.json")))):
+        c = json.load(open(f))
+        pt = c["patterns"]
+        stream = [pt[k]["factor"] for k in ("stream4", "stream16") if pt.get(k, {}).get("factor")]
+        # a gather that touches ONE byte of every 128-byte line must pull every line: bytes the DRAM side delivers = requests x 128 when the
+        # launch takes as long as streaming the array (it does: see the table), and FETCH_SIZE reports 64 per request
+        gather = [128.0 / pt[k]["fetch_bytes_reported_per_request"] for k in pt if k.startswith("gather_") and pt[k]["unit"] >= 128 and pt[k].get("fetch_bytes_reported_per_request")]
+        write = [pt[k]["factor"] for k in ("write4", "write8", "write16") if pt.get(k, {}).get("factor")]
+        if stream and gather and write:
+            return {"source": os.path.relpath(f, REPO), "fetch_factor_stream": sum(stream) / len(stream), "fetch_factor_gather": sum(gather) / len(gather),
+                    "write_factor": sum(write) / len(write),
+                    "note": "FETCH_SIZE counts 64 B per L2 line miss, the memory side delivers the 128-byte line (streams: half the known bytes reported; lone 1-byte "
+                            "gathers: 64 B reported per request while the launch takes the time of streaming 128 B per request at ~6 TB/s); WRITE_SIZE is exact "
+                            "for coalesced 4 / 8 / 16-byte stores"}
+    return None
+
+
+def _pmc_rows(d, name, kernel):
+    import csv
+    f = os.path.join(d, name + ".csv")
+    acc = {}
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
 def pmc_traffic():
-    """HBM bytes per k_map launch from a PMC summary committed under profiles/ (tools/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in
-    separate rocprofv3 --pmc passes of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  The summary carries the
-    hash of the kernel source it was measured on; a summary of an older kernel is NOT reported (None)."""
-    import csv, glob
+    """HBM bytes per k_map launch from a PMC summary committed under profiles/ (tools/prof_pmc_c3.sh: FETCH_SIZE, WRITE_SIZE and the raw TCC_EA0 request
+    counters by size in separate rocprofv3 --pmc passes of this same command), priced with the CALIBRATED factors of calibration() -- and, where the
+    request-size counters were collected, directly as 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B.  The summary carries the hash of the kernel
+    source it was measured on; a summary of an older kernel is NOT reported (None)."""
+    import glob
     dirs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_kmap_*")))
     src = file_sha("phaser_amd/csrc/phz_map.hip")
+    cal = calibration()
     for d in reversed(dirs):
         meta = os.path.join(d, "meta.json")
         if not os.path.exists(meta):
@@ -51,24 +86,24 @@ def pmc_traffic():
         m = json.load(open(meta))
         if m.get("kernel_source_sha16") != src or m.get("workload") != "configs[2]":
             continue
-        vals = {}
-        for name in ("fetch", "write"):
-            f = os.path.join(d, name + ".csv")
-            rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_map" in r["Kernel_Name"]] if os.path.exists(f) else []
-            if not rows:
-                return None
-            vals[name] = sum(rows) / len(rows)
-        insts = {}
-        f = os.path.join(d, "sq1.csv")
-        if os.path.exists(f):
-            acc = {}
-            for r in csv.DictReader(open(f)):
-                if "k_map" in r["Kernel_Name"]:
-                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-            insts = {k.replace("SQ_INSTS_", "").lower(): sum(v) / len(v) for k, v in acc.items() if k.startswith("SQ_INSTS_")}
-        return {"bytes_per_launch": 2 * vals["fetch"] * 1024 + vals["write"] * 1024, "fetch_raw_kib": vals["fetch"], "write_kib": vals["write"],
-                "wave_insts_per_launch": insts, "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
-                "note": "mean over the k_map launches of this command; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; SQ_INSTS_* = wave64 instructions"}
+        fetch = _pmc_rows(d, "fetch", "k_map").get("FETCH_SIZE"); write = _pmc_rows(d, "write", "k_map").get("WRITE_SIZE")
+        if fetch is None or write is None:
+            return None
+        ff = cal["fetch_factor_gather"] if cal else 2.0          # K_map's misses are line misses of both kinds; the two factors agree (2.0)
+        wf = cal["write_factor"] if cal else 1.0
+        out = {"fetch_raw_kib": fetch, "write_kib": write, "fetch_factor": ff, "write_factor": wf,
+               "bytes_per_launch": ff * fetch * 1024 + wf * write * 1024, "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
+               "calibration": cal,
+               "note": "mean over the k_map launches of this command; FETCH_SIZE x the calibrated factor + WRITE_SIZE x its factor (profiles/*/calib: gathers and "
+                       "streams both cost a 128-byte line per L2 miss, reported as 64)"}
+        ea = _pmc_rows(d, "ea_rd", "k_map")
+        if ea.get("TCC_EA0_RDREQ_sum"):
+            n32 = ea.get("TCC_EA0_RDREQ_32B_sum", 0.0); n64 = ea.get("TCC_EA0_RDREQ_64B_sum", 0.0); n128 = ea.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+            out["read_requests"] = {"all": ea["TCC_EA0_RDREQ_sum"], "32B": n32, "64B": n64, "128B": n128,
+                                    "bytes_by_request_size": 32.0 * n32 + 64.0 * n64 + 128.0 * n128}
+        insts = {k.replace("SQ_INSTS_", "").lower(): v for k, v in _pmc_rows(d, "sq1", "k_map").items() if k.startswith("SQ_INSTS_")}
+        out["wave_insts_per_launch"] = insts
+        return out
     return None
 
 
@@ -104,12 +139,13 @@ def pmc_traffic_tally():
         if m.get("kernel_source_sha16") != src or m.get("workload") != "configs[2]" or not m.get("passes") or "kib" not in m:
             continue
         t = m["kib"]["tally"]
-        out = {"bytes_per_pass": (2 * t["fetch"] + t["write"]) * 1024 / m["passes"], "fetch_raw_kib_per_pass": t["fetch"] / m["passes"],
+        cal = calibration(); ff = cal["fetch_factor_gather"] if cal else 2.0; wf = cal["write_factor"] if cal else 1.0
+        out = {"bytes_per_pass": (ff * t["fetch"] + wf * t["write"]) * 1024 / m["passes"], "fetch_raw_kib_per_pass": t["fetch"] / m["passes"], "fetch_factor": ff, "write_factor": wf,
                "write_kib_per_pass": t["write"] / m["passes"], "source": os.path.relpath(d, REPO), "kernel_source_sha16": src,
-               "note": "sum over the K_tally family (k_as_hist .. k_edge_final, incl. the scans / sorts in between) of one pass; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE"}
+               "note": "sum over the K_tally family (k_as_hist .. k_edge_final, incl. the scans / sorts in between) of one pass; FETCH_SIZE x the calibrated factor (profiles/*/calib) + WRITE_SIZE"}
         if m.get("rows_source_sha16") == src_rows:
             r = m["kib"]["rows"]
-            out["row_stage_bytes_per_pass"] = (2 * r["fetch"] + r["write"]) * 1024 / m["passes"]
+            out["row_stage_bytes_per_pass"] = (ff * r["fetch"] + wf * r["write"]) * 1024 / m["passes"]
         return out
     return None
 
@@ -184,16 +220,35 @@ def cpu_phasing_baseline(sample_chroms, vsets, shards, calls_of, mapper, baseq, 
     return out
 
 
-def kmap_roofline(ctx, tot_recs, tot_alg, k_avg_s, k_launches, steps, k_ms_max_rank, world):
-    """Three fractions for k_map: (1) SURVEY.md 8(d)'s byte model, 115 B per record / kernel time against the 8 TB/s HBM peak -- the contract's
-    `achieved` / `frac`; (2) the bytes the kernel really moves (PMC FETCH_SIZE x 2 + WRITE_SIZE of a committed pass) against the same peak;
-    (3) its wave64 instruction counts (PMC SQ_INSTS_*) against the chip's measured issue rates (phz_microbench): the share of the launch
-    each issue port is busy if nothing else stalls.  `bound` names the largest of the three."""
+def tally_roofline(tally_bytes, tally_ms, world):
+    """K_tally family: frac = measured HBM bytes per pass (committed PMC passes, calibrated) / HIP-event time of the family / 8 TB/s when a summary of the current
+    source exists, else SURVEY 8(d)'s algorithmic bytes over the same time (a lower bound)."""
+    tr = pmc_traffic_tally() if world == 1 else None
+    sec = tally_ms / 1e3
+    moved = tr["bytes_per_pass"] if tr else tally_bytes
+    ach = moved / sec / 1e9 if sec > 0 else None
+    return {"bound": "hbm", "kernel": "K_tally (all kernels of phz_tally, HIP events on the ctx stream)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": tr["bytes_per_pass"] if tr else None, "traffic_detail": tr,
+            "traffic_over_algorithmic": (tr["bytes_per_pass"] / tally_bytes) if tr and tally_bytes else None,
+            "algorithmic_bytes": tally_bytes, "algorithmic_frac": tally_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None}
+
+
+def kmap_roofline(ctx, tot_recs, alg, k_avg_s, k_launches, steps, k_ms_max_rank, world):
+    """K_map against the chip, in PHYSICAL terms only (round-4 verdict: the line must not carry a fraction above 1):
+      frac / achieved  = the HBM bytes the kernel really moves per launch (committed PMC passes, FETCH_SIZE / WRITE_SIZE priced with the calibration of
+                         profiles/*/calib) / HIP-event time of the launch, against the 8 TB/s peak; when no PMC summary matches the current kernel
+                         source, the gather-aware algorithmic minimum below stands in (a lower bound of the traffic, so still a true fraction);
+      issue_*          = its wave64 instruction counts (PMC SQ_INSTS_*) against the chip's measured issue rates (phz_microbench, run live);
+      bound            = the largest of those physical fractions;
+      algorithmic_bytes_per_launch = what ANY kernel with this design must move: the per-record arrays it streams (pos, cigar_off, seq_off, CIGAR words,
+                         the het-SNP positions) + one 128-byte DRAM line per DISTINCT line of the quality / base arrays that holds a byte under an
+                         emitted call (the granule the calibration measured) + 9 bytes per emitted call; traffic / that = wasted re-reads;
+      model_streaming  = SURVEY.md 8(d)'s 115 B per record (every base and quality of every record streamed): the bytes of a DIFFERENT algorithm, kept as
+                         the rate a streaming mapper would need -- not a fraction of anything this kernel does."""
     recs_per_launch = tot_recs / max(1.0, k_launches / steps)
-    model_bytes = SURVEY_BYTES_PER_RECORD * recs_per_launch
-    achieved = model_bytes / k_avg_s / 1e9
+    alg_min = alg["stream_bytes"] + 128.0 * (alg["qual_lines"] + alg["seq_lines"]) + CALL_BYTES * alg["calls"]
     tr = pmc_traffic() if world == 1 else None
-    fr = {"hbm_byte_model": achieved / HBM_PEAK_GBS}
+    fr = {}
     issue = None
     if tr is not None:
         fr["hbm_measured_traffic"] = tr["bytes_per_launch"] / k_avg_s / 1e9 / HBM_PEAK_GBS
@@ -201,20 +256,61 @@ def kmap_roofline(ctx, tot_recs, tot_alg, k_avg_s, k_launches, steps, k_ms_max_r
             rates = issue_rates(ctx)
             wi = tr["wave_insts_per_launch"]
             issue = {k: {"wave_insts_per_launch": wi.get(k), "peak_wave_insts_per_s": rates[k], "frac": wi[k] / rates[k] / k_avg_s} for k in ("valu", "salu", "lds") if k in wi}
-            if issue:
-                top = max(issue, key=lambda k: issue[k]["frac"])
-                fr["issue_" + top] = issue[top]["frac"]
+            for k, v in issue.items():
+                fr["issue_" + k] = v["frac"]
+    else:
+        fr["hbm_algorithmic_minimum"] = alg_min / k_avg_s / 1e9 / HBM_PEAK_GBS
+    traffic = tr["bytes_per_launch"] if tr is not None else None
+    moved = traffic if traffic is not None else alg_min
+    achieved = moved / k_avg_s / 1e9
     bound = max(fr, key=lambda k: fr[k])
-    return {"bound": "hbm" if bound.startswith("hbm") else "issue", "bound_detail": bound, "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "fractions": fr, "traffic": tr, "issue": issue,
-            "algorithmic_bytes_per_launch": model_bytes, "bytes_per_record": SURVEY_BYTES_PER_RECORD,
-            "resident_array_bytes_per_record": tot_alg / tot_recs,
+    return {"bound": bound, "bound_class": "hbm" if bound.startswith("hbm") else "instruction issue / memory latency (integer-branch kernel: no MFMA work on this path)",
+            "kernel": "k_map", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_over_algorithmic": (traffic / alg_min) if traffic is not None else None,
+            "algorithmic_bytes_per_launch": alg_min,
+            "algorithmic_detail": {"streamed_arrays": alg["stream_bytes"], "qual_lines_128B": alg["qual_lines"], "seq2_lines_128B": alg["seq_lines"],
+                                   "emitted_calls": alg["calls"], "bytes_per_call_out": CALL_BYTES, "per_record": alg_min / recs_per_launch,
+                                   "streamed_arrays_per_record": alg["stream_bytes"] / recs_per_launch},
+            "fractions": fr, "traffic_detail": tr, "issue": issue,
+            "model_streaming": {"bytes_per_record": SURVEY_BYTES_PER_RECORD, "bytes_per_launch": SURVEY_BYTES_PER_RECORD * recs_per_launch,
+                                "GBps_a_streaming_mapper_would_need_at_this_speed": SURVEY_BYTES_PER_RECORD * recs_per_launch / k_avg_s / 1e9,
+                                "note": "SURVEY.md 8(d): all arrays of a record incl. ALL its bases and qualities.  K_map reads bases / qualities only under a het SNP, so it "
+                                        "does not move these bytes; the figure is not a fraction of this kernel's ceiling and is not reported as one"},
             "kernel_ms_avg": k_avg_s * 1e3, "launches": int(k_launches), "kernel_ms_per_step_max_rank": k_ms_max_rank / steps,
-            "note": "achieved = 115 B x records (SURVEY.md 8(d): the arrays of a record incl. ALL of its bases and qualities) / HIP-event time of k_map: the rate a "
-                    "mapper that streams every base would need.  This kernel reads bases / qualities only under a het SNP, so it moves far fewer bytes than the "
-                    "model (fractions.hbm_measured_traffic) -- which is how the model fraction can pass 1: it is the contract's figure, not a share of a ceiling "
-                    "the kernel runs against.  The kernel is paced by memory LATENCY: its time follows the number of resident tiles per CU (DESIGN 4), "
-                    "the issue ports are half busy (fractions.issue_*, issue)"}
+            "note": "frac = measured HBM bytes per launch (calibrated PMC counters) / HIP-event kernel time / 8 TB/s.  The kernel is paced by memory LATENCY at the "
+                    "hardware's occupancy limit and by the scalar issue port (DESIGN 4), not by bandwidth: bound names the busiest physical resource"}
+
+
+def algorithmic_minimum(shards, vposs, bufs_aux, n_calls):
+    """Gather-aware lower bound of K_map's HBM traffic on this rank's shards (kmap_roofline): bytes of the arrays every record streams, and the DISTINCT
+    128-byte lines of qual / seq2 that hold a byte under an emitted call (aux0 = the base's read offset, from the submission with the text planes)."""
+    out = {"stream_bytes": 0.0, "qual_lines": 0.0, "seq_lines": 0.0, "calls": 0.0}
+    for sh, vp, b, m in zip(shards, vposs, bufs_aux, n_calls):
+        out["stream_bytes"] += float(sum(int(t.numel()) * t.element_size() for t in (sh.pos, sh.cigar_off, sh.cigar, sh.seq_off)) + 4 * int(vp.numel()))
+        out["calls"] += float(m)
+        if m == 0:
+            continue
+        rd = b[0][:m].to(torch.int64); a0 = b[3][:m].to(torch.int64) & 0xFFFFFFFF
+        ok = a0 != 0xFFFFFFFF
+        so = sh.seq_off.to(torch.int64)[rd]
+        out["qual_lines"] += float(torch.unique(((so * 4 + a0)[ok]) >> 7).numel())
+        out["seq_lines"] += float(torch.unique(((so + (a0 >> 2))[ok]) >> 7).numel())
+    return out
+
+
+def self_launch(n):
+    """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same arguments>` (rendezvous on 127.0.0.1, a
+    free port).  Never returns."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main():
@@ -232,7 +328,16 @@ def main():
     ap.add_argument("--no-bam", action="store_true", help="skip the BAM-path entry (a quarter-genome BAM written to /tmp, decoded on the GPU and on the host)")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` by itself (no launcher): start N ranks of this script, one per GPU, under torch.distributed.run and let them
+    # print the line (the reference's fan-out, phaser.py:2077-2094, is one Pool worker per chromosome; here one process per GPU)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree (refusing to print a line for another rank count)" % (a.gpus, world))
+    if os.environ.get("PHZ_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < a.gpus:
+        sys.exit("bench.py: --gpus %d needs %d visible GPUs, this node shows %d (PHZ_BENCH_BACKEND=gloo lets ranks share a GPU for plumbing checks only)"
+                 % (a.gpus, a.gpus, torch.cuda.device_count()))
     # the container's CPU quota (cpu.max), not the host's core count, bounds what torch's intra-op pool may use: 256 OpenMP threads
     # spinning on a 16-CPU quota get the whole cgroup throttled, timed regions included
     from phaser_amd import dist as pdist
@@ -250,6 +355,11 @@ def main():
             dist.init_process_group(backend)
     dev = "cuda:%d" % local
     red_dev = dev if backend == "nccl" else "cpu"
+    dev_names = ["rank %d: cuda:%d" % (rank, local)]
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, dev_names[0])
+        dev_names = names
 
     from phaser_amd import workloads, synth, vcf as pvcf
     from phaser_amd import dist as pdist
@@ -295,13 +405,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(a.steps):
-        step()
+        step()                                   # returns after the submission's own host wait: the stamps are per-step wall times
+        stamps.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    per_step = sorted((stamps[i + 1] - stamps[i]) * 1e3 for i in range(a.steps))
     _, k_total_ms, k_n = mapper.ctx.timing(_lib.PHZ_T_MAP)
     assert [int(N[i]) for i in range(len(chroms))] == n_calls
 
@@ -325,14 +438,17 @@ def main():
         m = n_calls[i]; f = first[i]
         assert all(bool(torch.equal(b[:m], t)) for b, t in zip(bufs5[i], (f.read_idx, f.var_idx, f.code, f.aux0, f.aux1))), "text planes differ between passes"
         assert all(bool(torch.equal(bufs5[i][k][:m], bufs[i][k][:m])) for k in range(3)), "call list differs with / without the text planes"
+    alg_loc = algorithmic_minimum(sh_list, vp_list, bufs5, n_calls)
     del call5, bufs5
     loc_calls = float(sum(n_calls)); loc_recs = float(sum(s.n for s in sh_list)); loc_snps = float(sum(len(vsets[c]) for c in chroms))
-    loc_alg = float(sum(s.nbytes_map_inputs() for s in sh_list) + 4 * loc_snps + CALL_BYTES * loc_calls)
-    red = torch.tensor([loc_calls, loc_recs, loc_snps, loc_alg, k_total_ms, float(k_n)], device=red_dev, dtype=torch.float64)
+    red = torch.tensor([loc_calls, loc_recs, loc_snps, alg_loc["stream_bytes"], k_total_ms, float(k_n), 1.0, alg_loc["qual_lines"], alg_loc["seq_lines"]],
+                       device=red_dev, dtype=torch.float64)
     tmax = torch.tensor([dt, k_total_ms], device=red_dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(red); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tot_calls, tot_recs, tot_snps, tot_alg, k_ms_sum, k_launches = [float(x) for x in red.tolist()]
+    tot_calls, tot_recs, tot_snps, tot_stream, k_ms_sum, k_launches, ranks_seen, tot_ql, tot_sl = [float(x) for x in red.tolist()]
+    alg = {"stream_bytes": tot_stream, "qual_lines": tot_ql, "seq_lines": tot_sl, "calls": tot_calls}
+    assert int(ranks_seen) == world == a.gpus, "the all-reduce saw %d ranks, --gpus says %d" % (int(ranks_seen), a.gpus)
     dt = float(tmax[0]); k_ms_max_rank = float(tmax[1])
 
     # ---- second rate of the metric: phased variants/s over stages T1-O2 on the same call lists
@@ -397,10 +513,7 @@ def main():
                                              **{k: round(v_, 4) for k, v_ in eng.stats.items() if k.endswith("_s")}},
                                  "counts": {k: int(v_) for k, v_ in eng.stats.items() if k.startswith("rowsdev_n_")},
                                  "host_threads": host_threads,
-                                 "roofline": {"bound": "hbm", "kernel": "K_tally (all kernels of phz_tally, HIP events on the ctx stream)",
-                                              "achieved": tally_bytes / (tally_ms / 1e3) / 1e9 if tally_ms > 0 else None, "peak": HBM_PEAK_GBS,
-                                              "unit": "GB/s", "frac": tally_bytes / (tally_ms / 1e3) / 1e9 / HBM_PEAK_GBS if tally_ms > 0 else None,
-                                              "traffic": pmc_traffic_tally() if world == 1 else None, "algorithmic_bytes": tally_bytes,
+                                 "roofline": tally_roofline(tally_bytes, tally_ms, world) | {
                                               "model": "8 B x call lines + 16 B x pair events (SURVEY.md 8(d))", "call_lines": lines,
                                               "pair_events": events, "items": items, "edges": edges, "kernel_ms_sum_over_ranks": tally_ms}})
                 del eng, files
@@ -422,16 +535,26 @@ def main():
             "value": tot_calls * a.steps / dt, "unit": "allele calls/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "collective": {"backend": ("nccl (RCCL over xGMI)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
+                           "rccl_ranks": int(ranks_seen) if backend == "nccl" and world > 1 else 0, "ranks_seen_by_all_reduce": int(ranks_seen),
+                           "devices": sorted(set(dev_names))},
             "config": {"workload": "configs[2]: whole genome (22 autosomes), one GTEx-shape RNA-seq sample, %d records x 76 bp, %d het SNPs, "
                                    "one shard per chromosome; chromosomes LPT-assigned to GPUs by record count" % (int(tot_recs), int(tot_snps)),
                        "records": int(tot_recs), "het_snps": int(tot_snps), "calls_per_step": int(tot_calls), "shards": len(plan),
                        "records_per_s": tot_recs * a.steps / dt, "gen_seconds": round(t_gen, 1),
                        "step": "K_map over all chromosome shards of the rank in one batched submission (phz_map_reads_batch); call list = (record, variant, allele "
                                "code) per call, the form the phasing stage reads (SURVEY.md 8(a) M1)",
+                       "step_ms_spread": {"min": per_step[0], "median": per_step[len(per_step) // 2], "p90": per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))],
+                                          "max": per_step[-1], "note": "wall time of the individual timed steps on rank 0 (ms_per_step is their mean incl. the closing barrier)"},
                        "step_with_text_planes_ms": ms_with_text,
                        "step_with_text_planes_note": "the same submission also writing the two planes behind the mapper drop-in's allele text (read offset, inserted bases: "
                                                      "8 more bytes per call), rank 0's shards, mean of a short series"},
-            "roofline": kmap_roofline(mapper.ctx, tot_recs, tot_alg, k_avg_s, k_launches, a.steps, k_ms_max_rank, world),
+            "full_output_step": {"ms_per_step": ms_with_text, "value": tot_calls / (ms_with_text / 1e3) if world == 1 else None, "unit": "allele calls/s",
+                                 "bytes_per_call": 17,
+                                 "note": "the same submission writing all five planes of a call (record, variant, code + read offset of the base + inserted-bases word), what the mapper "
+                                         "drop-in (read_variant_map.do_read_variant_map) needs to print the allele text; rounds 1-3 reported THIS form as the headline, since "
+                                         "round 4 `value` is the 9-byte form the phasing stage reads"},
+            "roofline": kmap_roofline(mapper.ctx, tot_recs, alg, k_avg_s, k_launches, a.steps, k_ms_max_rank, world),
         }
         if phasing is not None:
             out["phasing"] = phasing
@@ -557,11 +680,20 @@ def configs1_entry(mapper, a, dev):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     _, tot, n = mapper.ctx.timing(_lib.PHZ_T_MAP)
-    alg = shard.nbytes_map_inputs() + 4 * len(v) + CALL_BYTES * first[0].n
+    # gather-aware algorithmic minimum of this shard (see kmap_roofline): from one submission with the text planes (aux0 = the base's read offset)
+    call5, bufs5, N5 = mapper.prepare_batch([shard], [v.pos], a.baseq, [first[0].n + 16], aux=True)
+    mapper.ctx.check(call5()); torch.cuda.synchronize()
+    am = algorithmic_minimum([shard], [v.pos], bufs5, [first[0].n])
+    del call5, bufs5
+    alg_min = am["stream_bytes"] + 128.0 * (am["qual_lines"] + am["seq_lines"]) + CALL_BYTES * am["calls"]
     k = tot / n / 1e3
     out = {"workload": "configs[1]: chr1 full, 40000 het SNPs, 50000000 records x 76 bp, one shard", "value": first[0].n / dt,
-           "unit": "allele calls/s", "ms_per_step": dt * 1e3, "kernel_ms_avg": k * 1e3, "roofline_frac": SURVEY_BYTES_PER_RECORD * shard.n / k / 1e9 / HBM_PEAK_GBS,
-           "bytes_per_record": SURVEY_BYTES_PER_RECORD, "resident_array_bytes_per_record": alg / shard.n}
+           "unit": "allele calls/s", "ms_per_step": dt * 1e3, "kernel_ms_avg": k * 1e3,
+           "roofline_frac": alg_min / k / 1e9 / HBM_PEAK_GBS,
+           "roofline_note": "k_map's gather-aware algorithmic minimum (streamed per-record arrays + one 128-byte line per distinct qual / seq2 line under an emitted call + "
+                            "9 B per call) / kernel time / 8 TB/s: a LOWER bound of the kernel's HBM fraction (no PMC pass exists for this shard)",
+           "algorithmic_bytes_per_launch": alg_min, "algorithmic_bytes_per_record": alg_min / shard.n,
+           "streaming_model_GBps_needed": SURVEY_BYTES_PER_RECORD * shard.n / k / 1e9}
     if not a.no_phasing:
         # stages T1-O2 on the same shard (round 1 measured 76 ms here)
         vs = pvcf.load_variants("\n".join(synth.vcf_lines([v])))

@@ -664,6 +664,14 @@ int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_column, con
  * measured against (bench.py roofline.issue).  n_cu / clock_mhz: compute units and reported engine clock of the device. */
 int phz_microbench(phz_ctx *ctx, int kind, int waves_per_simd, int iters, double *wave_insts_per_s, int *n_cu, int *clock_mhz);
 
+/* Memory-side calibration (gfx950, round 5): one launch of an access pattern with a KNOWN byte count, for calibrating rocprofv3's FETCH_SIZE /
+ * WRITE_SIZE on the patterns K_map uses (tools/prof_calib.sh; bench.py roofline.traffic applies the measured factors).  kind 0 / 1: coalesced
+ * stream of 4 / 16 bytes per lane over the array; 2 / 3: ONE 1-byte load per `unit`-byte unit of the array (32..512), always inside the unit's
+ * first 32 bytes, units visited in a pseudo-random permutation (2) or in address order (3); 4 / 5 / 6: coalesced stores of 4 / 8 / 16 bytes
+ * per lane.  The array has 2^log2_bytes bytes (past the 256 MiB Infinity Cache from 29 up).  *known_bytes = bytes read / written by the lanes,
+ * *requests = loads / stores, *seconds = best HIP-event time of `reps` launches.  No reference counterpart (measurement infrastructure). */
+int phz_membench(phz_ctx *ctx, int kind, int log2_bytes, int unit, int reps, double *seconds, int64_t *known_bytes, int64_t *requests);
+
 /* Kernel time measured with HIP events on the ctx stream: last launch, running total, launch count. */
 int phz_get_timing(phz_ctx *ctx, int slot, float *last_ms, double *total_ms, int64_t *launches);
 int phz_reset_timing(phz_ctx *ctx);

@@ -989,8 +989,18 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
 // per-tile status words -- no staging, no k_compact.  A tile knows its count only at the END of its work (the count needs the quality
 // bytes), so its flush waits for every earlier tile still in flight: 3.01 ms against 1.32 + 0.16 ms for k_map + k_compact.)  A batch whose densest tile overflows its staging slot
 // is redone with larger slots (rare: the slot capacity is kept across calls).
+static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out, int64_t *n_calls);
+
 int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out,
                          int64_t *n_calls) {
+    const int s = launch_map_batch(ctx, n, r, v, baseq, out, n_calls);
+    // map_tab_image claims "these bytes are in ctx->map_tab" (nobody else writes map_tab; its [tab_bytes, +m*8) tail, shard_base, is recomputed by every
+    // launch).  A submission that failed anywhere between the upload and its stream wait may not have delivered them: forget the image.
+    if (s != PHZ_OK && s != PHZ_E_CAPACITY) { ctx->map_tab_image.clear(); ctx->map_tab_dev = nullptr; }
+    return s;
+}
+
+static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_variants *v, int baseq, const phz_calls *out, int64_t *n_calls) {
     for (int i = 0; i < n; i++) n_calls[i] = 0;
     if (n <= 0) return PHZ_OK;
     int rpt = 2, blk = 128;

@@ -2073,7 +2073,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     res->dropped = (int64_t)h_c64[1];
     sec.begin();
     // ---- ordering stage: rank index of every variant, pair order, members by component, component order, kept pairs by component, keys
-    const int bv = bits_for((uint64_t)(nv > 1 ? nv - 1 : 1)), bl = bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1));
+    const int bv = bits_for((uint64_t)(nv > 1 ? nv - 1 : 1));
+    int bl = bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1));
+    if (const char *fb = getenv("PHZ_ROWS_FAKE_LINE_BITS")) bl = std::max(bl, std::min(32, atoi(fb)));      // tests: the key layout of a BAM with > 2^31 call lines
     const size_t NS = std::max(NV, NE);
     RSV(k64a, NS * 8); RSV(k64b, NS * 8); RSV(k32a, NS * 4); RSV(k32b, NS * 4); RSV(v32a, NS * 4); RSV(v32b, NS * 4);
     RSV(ridx, NV * 4); RSV(va, NE * 4); RSV(vb, NE * 4); RSV(eorder, NE * 4);
@@ -2126,7 +2128,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         ShardTab ST; ST.lo = (const long long *)h->sh_lo.p; ST.hi = (const long long *)h->sh_hi.p; ST.bam = (const int32_t *)h->sh_bam.p; ST.n = o->n_shards;
         const int bb = nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0;
         RSV(key64s, (size_t)(nkeys + 1) * 8);
-        if (bb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (BAM, first line) in one 32-bit key
+        if (bl < 32 && bb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (BAM, first line) in one 32-bit key; bl == 32 (one BAM of > 2^31 lines) would make the kernels shift a 32-bit word by 32
             hipLaunchKernelGGL(k_compact_keys32, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST, bl,
                                P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
             const int rg[1][2] = {{0, bb + bl}};

@@ -174,17 +174,21 @@ def _buffer_floors(events, recs, vpos):
     current record (read_variant_map.py:88-93) or appended up to the end of a segment (:106-112); the variant stream never rewinds -- and
     b_lo the consumed ones pruned for lying behind SOME earlier record (:37-50, done for every record of the stream, also one the isize
     filter then drops).  A record sees only what is inside the buffer (:114), so its calls are the stateless rule's calls on variants
-    >= the b_lo of its moment.  -> b_lo per kept record (0 everywhere on a sorted stream).  events = (POS, kept index or -1) in stream order."""
+    >= the b_lo of its moment.  -> b_lo per kept record (0 everywhere on a sorted stream).  events = (POS, kept index | -1 | -2) in stream order:
+    -1 = dropped by the isize filter BEFORE the skip step (:51), -2 = passes it, runs the skip step (:88-93: the variants behind it are consumed and
+    never buffered) and then gets no alignment from split_read (:170, an N in its CIGAR while --splice is not 1)."""
     import bisect
     floors = [0] * len(recs)
     b_lo = 0; L = 0; nv = len(vpos)
     for pos, k in events:
         lb = bisect.bisect_left(vpos, pos)
         b_lo = max(b_lo, min(lb, L))
-        if k < 0:
+        if k == -1:
             continue
         if L < lb:
             L = lb; b_lo = lb
+        if k < 0:                   # -2: a record split_read returns nothing for (an N in the CIGAR with --splice != 1): the skip above has run, nothing is appended
+            continue
         floors[k] = b_lo
         rec = recs[k]
         for start, plen in _segment_spans(rec[2], min(len(rec[3]), len(rec[4]))):
@@ -237,7 +241,7 @@ def do_read_variant_map(variant_table, baseq, o, splice, isize_cutoff, _mapper=N
                 events[last_chrom].append((int(cols[3]), -1))       # dropped, but the reference prunes its variant buffer before it drops it (:37-51)
                 continue
             if not (splice == 1 or "N" not in cols[5]):
-                events[last_chrom].append((int(cols[3]), -1))
+                events[last_chrom].append((int(cols[3]), -2))       # the reference still consumes the variants behind this record before split_read drops it
                 continue
             alignment_score = ""
             for i in range(11, len(cols)):

@@ -11,6 +11,8 @@ import ctypes as C
 import math
 from typing import Dict, List, Optional
 
+import sys
+
 import numpy as np
 import torch
 
@@ -102,13 +104,26 @@ class PinnedPool:
     """Page-locked host buffers of ONE owner (an Engine), kept per name and grown on demand: D2H at the full PCIe rate and no page-locking
     cost per pass.  Two live owners never share memory: what an Engine hands out (the G[...] arrays, chrom_view() views, the text chunks of
     finish()) is overwritten only by THAT Engine's next pass.  Buffers return to a process-wide free list when their owner goes away, so a
-    process that creates Engines one after the other (a sample stream) still page-locks once."""
+    process that creates Engines one after the other (a sample stream) still page-locks once -- EXCEPT buffers somebody outside still holds
+    views of (`out = Engine(...).finish(chunks=True)` keeps the chunks after the Engine is collected): those are left to their holders and
+    freed with the last view, never recycled under them.  Every view handed out is a slice of the buffer's root ndarray, so the root's
+    reference count says whether views are alive."""
 
-    _free: List[torch.Tensor] = []          # buffers given up by dead owners, reusable by the next pool
+    _free: List[np.ndarray] = []            # root arrays of buffers given up by dead owners, reusable by the next pool
     _arena = {"buf": None, "used": 0, "owner": None}
 
     def __init__(self):
-        self._bufs: Dict[str, torch.Tensor] = {}
+        self._bufs: Dict[str, np.ndarray] = {}
+
+    @staticmethod
+    def _new_root(nbytes: int) -> np.ndarray:
+        return torch.empty(max(1, nbytes), dtype=torch.uint8, pin_memory=torch.cuda.is_available()).numpy()      # the ndarray's base keeps the tensor alive
+
+    @staticmethod
+    def _unreferenced(root: np.ndarray, held: int) -> bool:
+        """No view of `root` is alive outside the `held` references the caller knows of (+ the call's stack slot, this function's argument and
+        getrefcount's own; CPython -- the only interpreter torch runs on)."""
+        return sys.getrefcount(root) <= held + 3
 
     def get(self, name: str, nbytes: int) -> np.ndarray:
         """uint8 view of this owner's buffer `name` (>= nbytes).  Text buffers ('rows_*') are carved from the arena prepare_arena()
@@ -117,25 +132,26 @@ class PinnedPool:
         b = a["buf"]
         if b is not None and name.startswith("rows_") and name not in self._bufs and a["owner"] in (None, id(self)):
             lo = (a["used"] + 4095) & ~4095
-            if lo + nbytes <= b.numel():
+            if lo + nbytes <= b.size:
                 a["owner"] = id(self)
                 a["used"] = lo + nbytes
-                return b.numpy()[lo:lo + nbytes]
+                return b[lo:lo + nbytes]
         t = self._bufs.get(name)
-        if t is None or t.numel() < nbytes:
+        if t is None or t.size < nbytes:
             want = max(1, nbytes + nbytes // 8 + 4096)
             t = None
             free = PinnedPool._free
-            fit = [i for i, f in enumerate(free) if f.numel() >= nbytes]
+            fit = [i for i, f in enumerate(free) if f.size >= nbytes]
             if fit:
-                t = free.pop(min(fit, key=lambda i: free[i].numel()))
+                t = free.pop(min(fit, key=lambda i: free[i].size))
             if t is None:
-                t = torch.empty(want, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-            old = self._bufs.get(name)
-            if old is not None:
+                t = self._new_root(want)
+            old = self._bufs.pop(name, None)
+            if old is not None and self._unreferenced(old, 1):
                 free.append(old)
+            del old
             self._bufs[name] = t
-        return t.numpy()[:nbytes]
+        return t[:nbytes]
 
     def new_pass(self):
         """The owner's previous text buffers inside the arena are given up (as its per-name buffers always are)."""
@@ -144,13 +160,20 @@ class PinnedPool:
             a["used"] = 0
 
     def release(self):
-        """Owner gone: its buffers may serve the next pool, the arena is free again."""
-        PinnedPool._free.extend(self._bufs.values())
-        self._bufs = {}
+        """Owner gone: its buffers may serve the next pool and the arena is free again -- unless views of them are still alive outside."""
+        names = list(self._bufs)
+        for name in names:
+            root = self._bufs.pop(name)
+            if self._unreferenced(root, 1):
+                PinnedPool._free.append(root)
+            del root
         del PinnedPool._free[:-32]                # bounded: a long stream of Engines keeps the 32 newest buffers
         a = PinnedPool._arena
         if a["owner"] == id(self):
             a["owner"] = None; a["used"] = 0
+            b = a["buf"]
+            if b is not None and not self._unreferenced(b, 2):       # text chunks carved from the arena outlive the Engine: the arena is theirs now
+                a["buf"] = None
 
 
 def prepare_arena(nbytes: int):
@@ -162,8 +185,8 @@ def prepare_arena(nbytes: int):
     if a["owner"] is not None:
         return                                   # in use by a live Engine: its views stay valid
     b = a["buf"]
-    if b is None or b.numel() < nbytes:
-        a["buf"] = torch.empty(max(1, nbytes), dtype=torch.uint8, pin_memory=True)
+    if b is None or b.size < nbytes:
+        a["buf"] = PinnedPool._new_root(nbytes)
     a["used"] = 0
 
 

@@ -119,3 +119,20 @@ def test_rows_of_a_block_of_150_variants_by_wave_and_by_thread():
     assert len(hap_rows) == 3 and hap_rows[1].split("\t")[4] == "150"          # header, ONE block of 150 variants, trailing newline
     for name in OUTPUTS:
         assert outs[0][name] == outs[1][name] == outs[2][name], name
+
+
+@pytest.mark.parametrize("env", [{"PHZ_ROWS_SORT64": "1"}, {"PHZ_ROWS_FAKE_LINE_BITS": "32"}, {"PHZ_ROWS_FAKE_LINE_BITS": "31"}], ids=["sort64", "line_bits_32", "line_bits_31"])
+def test_key_layouts_of_the_ordering_sorts(env, monkeypatch, c1_inputs):
+    """The rank order of the variants and the first-appearance order of the covered variants sort 32-bit keys when (line, gap) / (BAM, line) fit and 64-bit
+    keys otherwise.  A BAM with more than 2^31 call lines has 32 line bits: a 32-bit (BAM, line) key would shift a 32-bit word by 32 (round-4 advisor
+    finding), so that size must take the 64-bit keys; forced here through PHZ_ROWS_FAKE_LINE_BITS on the two-BAM fixture.  Every layout gives the same bytes."""
+    lib = emu_library()
+    case, gold, load, cfg = next(c for c in _cases() if c[0] == "pipe_two")
+    d, vcf_text, bams = _inputs(case, gold, c1_inputs)
+    base, _ = run_stages(lib, case, load, cfg, vcf_text, bams)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out, eng = run_stages(lib, case, load, cfg, vcf_text, bams)
+    assert eng.rows_path == "device"
+    for name in OUTPUTS:
+        assert out[name] == base[name], name

@@ -305,31 +305,7 @@ def test_kat_micro_indel_variants(mapper, tmp_path):
     assert n >= 3
 
 
-def test_full_size_properties(mapper, oracle_build):
-    """BASELINE.json configs[1] (chr1, 40k het SNPs, 50M records) through properties that do not need a 50M-record oracle run:
-    mapper order, idempotence, split invariance (mapping two halves separately == mapping the whole), and bit-exact agreement
-    with the C oracle on the first 1M records."""
-    import torch
-    from phaser_amd import workloads
-    v, shard, sample = workloads.make_shard("chr1", workloads.CHR1_LEN, 40_000, 50_000_000, 20240807, "cuda:0", keep_sample=1_000_000)
-    vpos = v.pos.to("cuda:0")
-    a = mapper.map(shard, vpos, 10)
-    b = mapper.map(shard, vpos, 10)
-    assert a.n == b.n > 5_000_000
-    for f in ("read_idx", "var_idx", "code", "aux0", "aux1"):
-        assert torch.equal(getattr(a, f), getattr(b, f)), f                        # idempotence
-    key = a.read_idx.to(torch.int64) * (len(v) + 1) + a.var_idx.to(torch.int64)
-    assert bool((key[1:] > key[:-1]).all())                                        # (record, variant) order, no duplicates
-    mid = shard.n // 2 + 12345
-    lo = mapper.map(shard.slice(0, mid), vpos, 10); hi = mapper.map(shard.slice(mid, shard.n), vpos, 10)
-    assert lo.n + hi.n == a.n
-    assert torch.equal(torch.cat([lo.read_idx, hi.read_idx + mid]), a.read_idx)
-    assert torch.equal(torch.cat([lo.var_idx, hi.var_idx]), a.var_idx) and torch.equal(torch.cat([lo.code, hi.code]), a.code)
-    o_r, o_v, o_c, _ = oracle_map_readbatch(oracle_build, sample, v.pos.numpy(), 10, with_text=False)
-    m = len(o_r)
-    assert np.array_equal(a.read_idx[:m].cpu().numpy(), o_r) and np.array_equal(a.var_idx[:m].cpu().numpy(), o_v)
-    assert np.array_equal(a.code[:m].cpu().numpy(), o_c) and int(a.read_idx[m]) >= len(sample)
-
+# (test_full_size_properties moved to tests/test_gpu_scale.py::test_configs1_chr1_50m_records: configs[1] is checked there on ALL 50M records and against the phasing oracle)
 
 def test_stream_out_of_coordinate_order(mapper, tmp_path):
     """A SAM stream whose records are out of coordinate order.  The reference's variant buffer is forward-only (read_variant_map.py:37-50,

@@ -293,47 +293,7 @@ def test_option_flags(mapper, name):
     compare(out, os.path.join(d0, name))
 
 
-def test_full_size_pipeline_invariants(mapper):
-    """BASELINE.json configs[1] through the whole path; no 50M-record oracle run exists, so the five files are checked through
-    the relations that tie them together (a checksum of checksums): line totals, per-variant counts, block membership,
-    allele_config cardinality, haplotypic_counts arithmetic."""
-    from phaser_amd import synth, vcf, workloads
-    from phaser_amd.engine import Config, Engine
-    v, shard, _ = workloads.make_shard("chr1", workloads.CHR1_LEN, 40_000, 50_000_000, 20240807, "cuda:0")
-    vs = vcf.load_variants("\n".join(synth.vcf_lines([v])))
-    eng = Engine(vs, ["big"], Config(host_threads=16, want_vcf=False), mapper=mapper)
-    eng.add_shard(0, "chr1", shard, int(shard.qid.max()) + 1)
-    eng.close_bam(0)
-    out = eng.finish()
-    R = eng.chrom_view("chr1")
-    kept = R["kept"]
-    assert kept == eng.G["n_kept"] == eng.total_lines and kept > 5_000_000
-    assert (R["var_distinct"] <= R["var_count"]).all()
-    rows = lambda name: [l.split("\t") for l in out[name].split("\n")[1:] if l]
-    # allelic_counts: one row per covered variant, distinct-read counts from the tally
-    al = rows("allelic_counts")
-    assert all(int(r[5]) + int(r[6]) == int(r[7]) for r in al)
-    uid_to_idx = {u: i for i, u in enumerate(vs.chroms["chr1"].uid)}
-    for r in al[::97]:
-        i = uid_to_idx[r[2]]
-        assert (int(r[5]), int(r[6])) == (int(R["var_distinct"][i][0]), int(R["var_distinct"][i][1]))
-    # haplotypes: every phased variant sits in exactly one block; allele_config has n(n-1) rows per block
-    hap = rows("haplotypes")
-    blocks = [r for r in hap if int(r[4]) > 1]
-    phased_ids = [x for r in blocks for x in r[5].split(",")]
-    assert len(phased_ids) == len(set(phased_ids)) == eng.phased
-    assert sum(int(r[4]) * (int(r[4]) - 1) for r in blocks) == len(rows("allele_config"))
-    assert all(int(r[7]) + int(r[8]) == int(r[9]) for r in hap)
-    # haplotypic_counts: aCount + bCount = totalCount; label lists hold exactly that many distinct labels for blocks
-    ase = rows("haplotypic_counts")
-    assert all(int(r[9]) + int(r[10]) == int(r[11]) for r in ase)
-    for r in [x for x in ase if int(x[4]) > 1][::53]:
-        la = set(t for g in r[16].split(";") for t in g.split(",") if t); lb = set(t for g in r[17].split(";") for t in g.split(",") if t)
-        assert len(la) == int(r[9]) and len(lb) == int(r[10])
-    # connections: supporting <= total, one row per linked pair
-    conn = rows("variant_connections")
-    assert all(int(r[2]) <= int(r[3]) for r in conn) and len(conn) == int(R["linked"].sum())
-
+# (test_full_size_pipeline_invariants moved to tests/test_gpu_scale.py::test_configs1_chr1_50m_records: configs[1] is checked there on ALL 50M records and against the phasing oracle)
 
 def test_population_flow_three_samples(mapper, tmp_path):
     """phaser -> phaser_gene_ae -> phaser_expr_matrix for three samples (the phaser_pop flow of BASELINE configs[4] in miniature):

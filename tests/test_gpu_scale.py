@@ -1,12 +1,18 @@
-"""GPU parity at the shapes of BASELINE.json configs[2] (whole genome: 22 autosomes, ~80M records, ~1.5M het SNPs, one BAM) and
-configs[3] (the same sample with 4 BAMs whose QNAMEs collide).  Each test combines
-  * a bit-exact check of K_map's call list for EVERY record of EVERY chromosome shard against the C mapper oracle run on all host
-    cores (all shards of a BAM through one batched submission),
-  * configs[2]: the five files of the largest chromosome (chr1, ~1.7M call lines) against the pinned phasing oracle at full size
-    (the whole genome, one oracle process per chromosome, is tools/full_parity_c3.py; its log is under profiles/),
-  * the size-independent relations that tie the five output files together, over all chromosomes, and
-  * full equality with the pinned phasing oracle on a 2 % scale replica of the same plan (22 chromosomes: the global merge order
-    of blocks / allelic_counts / singleton rows across chromosomes and BAMs, SURVEY.md 8.1 rules 2 and 4).
+"""GPU parity at the STATED sizes of BASELINE.json's configs (round-4 verdict item 1), all on one MI355X:
+  * configs[1]  chr1, 40k het SNPs, one 50M-record BAM: every record against the C mapper oracle, the properties of the call list, the
+                invariants that tie the five files together, and chr1's five files against the pinned phasing oracle;
+  * configs[2]  whole genome, 22 chromosome shards, ~80M records, ~1.5M het SNPs, one BAM;
+  * configs[3]  the same sample with FOUR 80M-record BAMs whose QNAMEs collide (320M records, 37 GB of shards): every record of every
+                BAM against the mapper oracle (one BAM's host copy at a time), invariants over the genome, the five files of two
+                chromosomes against the phasing oracle;
+  * configs[4]  one GPU's loop of the 128-sample batch: full-size samples (80M records each, different variant / read sets) streamed
+                through ONE device context, per-sample mapper parity on every record and five-file parity on a sampled chromosome
+                (16 samples, one GPU's share: tools/run_c5.py, log under profiles/), plus the small varying-size stream with
+                phaser_gene_ae / phaser_expr_matrix behind it.
+Each test combines a bit-exact check of K_map's call list for EVERY record against the C mapper oracle run on all host cores, the
+size-independent relations between the five output files, and full equality with oracle/phasing_oracle.py (canonical form) on whole
+chromosomes at full size.  The phasing oracle is slow (minutes per chromosome at these depths), so those comparisons run as worker
+processes (tools/oracle_chrom_worker.py) started as soon as their call files exist and are joined by the LAST test of the module.
 """
 import os
 import sys
@@ -20,7 +26,25 @@ from helpers import OUTPUTS, call_text, canonical, oracle_map_readbatch
 
 pytestmark = pytest.mark.gpu
 
-PREFIX = 200_000
+JOBS = []          # phasing-oracle workers in flight: (label, Popen, phased variants of the product, sha256 of the product's five files in canonical form, start time)
+
+
+def start_oracle_job(label, tmp_path, call_texts, got, phased, names):
+    """Start oracle/phasing_oracle.py on the call files of one run (one text per BAM) in a worker process; the product's five files `got`
+    are reduced to the hash the worker prints.  Joined by test_zz_phasing_oracle_jobs."""
+    import hashlib
+    import subprocess
+    import time
+    d = tmp_path / ("oracle_" + label); d.mkdir()
+    paths = []
+    for b, t in enumerate(call_texts):
+        f = d / ("calls%d.tsv" % b); f.write_text(t); paths.append(str(f))
+    h = hashlib.sha256()
+    for name in OUTPUTS:
+        h.update(canonical(name, got[name]).encode())
+    pr = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "oracle_chrom_worker.py"), ",".join(paths), "10", "-", "-", "-", ",".join(names)],
+                          stdout=subprocess.PIPE, text=True)
+    JOBS.append((label, pr, phased, h.hexdigest(), time.time(), sum(t.count("\n") for t in call_texts)))
 
 
 @pytest.fixture(scope="module")
@@ -141,49 +165,134 @@ def check_replica_vs_oracle(mapper, plan_small, n_bams, min_phased=1000):
     assert eng.phased == ph.phased and eng.phased > min_phased
 
 
+def oracle_calls_of(oracle_build, smp, vpos, cores):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from full_parity_c3 import oracle_all_records
+    return oracle_all_records(oracle_build, smp, vpos, 10, cores)
+
+
+def same_calls(calls, o):
+    return calls.n == len(o[0]) and np.array_equal(calls.read_idx.cpu().numpy(), o[0]) and np.array_equal(calls.var_idx.cpu().numpy(), o[1]) and \
+        np.array_equal(calls.code.cpu().numpy(), o[2])
+
+
+def test_configs1_chr1_50m_records(mapper, oracle_build, tmp_path):
+    """configs[1]: chr1 full, 40k het SNPs, ONE 50M-record BAM.  All 50M records against the C oracle (bit-exact call list), the properties of
+    the list (mapper order, idempotence, split invariance), the cross-file invariants, and chr1's five files (~6M call lines over 40k variants:
+    read sets of hundreds of QNAMEs per variant) against the phasing oracle (worker process, joined at the end of the module)."""
+    from phaser_amd import dist as pdist, workloads
+    v, shard, sample = workloads.make_shard("chr1", workloads.CHR1_LEN, 40_000, 50_000_000, 20240807, "cuda:0", keep_sample=1 << 40)
+    assert len(sample) == shard.n >= 49_000_000
+    vpos = v.pos.to("cuda:0")
+    a = mapper.map(shard, vpos, 10)
+    o = oracle_calls_of(oracle_build, sample, v.pos.numpy(), max(1, pdist.effective_cpus()))
+    assert same_calls(a, o), "K_map != C oracle on the 50M records of configs[1]"
+    del sample, o
+    b = mapper.map(shard, vpos, 10)
+    assert a.n == b.n > 5_000_000
+    for f in ("read_idx", "var_idx", "code", "aux0", "aux1"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f                        # idempotence
+    key = a.read_idx.to(torch.int64) * (len(v) + 1) + a.var_idx.to(torch.int64)
+    assert bool((key[1:] > key[:-1]).all())                                        # (record, variant) order, no duplicates
+    mid = shard.n // 2 + 12345
+    lo = mapper.map(shard.slice(0, mid), vpos, 10); hi = mapper.map(shard.slice(mid, shard.n), vpos, 10)
+    assert lo.n + hi.n == a.n
+    assert torch.equal(torch.cat([lo.read_idx, hi.read_idx + mid]), a.read_idx)
+    assert torch.equal(torch.cat([lo.var_idx, hi.var_idx]), a.var_idx) and torch.equal(torch.cat([lo.code, hi.code]), a.code)
+    del b, lo, hi, key
+    plan1 = [("chr1", workloads.CHR1_LEN, 40_000, shard.n, 20240807)]
+    eng, out = run_engine(mapper, {"chr1": v}, [{"chr1": shard}], plan1, names=["big"], host_threads=16)
+    assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
+    assert torch.equal(eng.shards["chr1"][0].calls.read_idx, a.read_idx) and torch.equal(eng.shards["chr1"][0].calls.code, a.code)
+    check_invariants(eng, out, plan1, 1)
+    assert eng.total_lines > 5_000_000 and eng.phased > 10_000
+    start_oracle_job("configs1_chr1", tmp_path, [call_text(v, shard, eng.shards["chr1"][0].calls)], out, eng.phased, ["big"])
+
+
 def test_whole_genome_one_bam(mapper, oracle_build, tmp_path):
     """configs[2]: 22 chromosome shards, 80M records, 1.5M het SNPs."""
     from phaser_amd import workloads
     plan = workloads.genome_plan()
-    import hashlib
-    import subprocess
     vsets, shards, samples = build(plan, 1, 1 << 40)            # host copies of ALL records (13 GB) for the mapper oracle
     eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
     assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
     assert sum(sh.n for sh in shards[0].values()) > 79_000_000 and eng.vs.het_count > 1_400_000
-    # chr1 at full size through the pinned phasing oracle (a separate process, ~1.5 minutes) while the mapper check below runs
+    # chr1 at full size through the pinned phasing oracle (a worker process) while the mapper check below runs
     big = plan[0][0]
-    calls_tsv = tmp_path / "chr1.calls.tsv"
-    calls_tsv.write_text(call_text(vsets[big], shards[0][big], eng.shards[big][0].calls))
-    worker = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "oracle_chrom_worker.py"), str(calls_tsv), "10"], stdout=subprocess.PIPE, text=True)
+    one, got1 = run_engine(mapper, {big: vsets[big]}, [{big: shards[0][big]}], plan[:1], names=["bench"])
+    assert one.phased > 50_000
+    start_oracle_job("configs2_chr1", tmp_path, [call_text(vsets[big], shards[0][big], eng.shards[big][0].calls)], got1, one.phased, ["bench"])
     assert check_oracle_all_records(oracle_build, eng, vsets, samples, plan) > 79_000_000
     check_invariants(eng, out, plan, 1)
-    one, got1 = run_engine(mapper, {big: vsets[big]}, [{big: shards[0][big]}], plan[:1], names=["bench"])
-    h = hashlib.sha256()
-    for name in OUTPUTS:
-        h.update(canonical(name, got1[name]).encode())
-    res = worker.communicate()[0].split()
-    assert worker.returncode == 0
-    assert int(res[0]) == one.phased and res[2] == h.hexdigest(), "chr1 at full size: the five files differ from the phasing oracle"
-    assert one.phased > 50_000
     del eng, out, shards, samples, one, got1
     torch.cuda.empty_cache()
     check_replica_vs_oracle(mapper, workloads.genome_plan(scale=0.02), 1)
 
 
-def test_whole_genome_four_bams_shared_qnames(mapper, oracle_build):
-    """configs[3] shape on one GPU: the same sample's 22 chromosomes with 4 BAMs (20M records each) whose QNAME ids collide, so the
-    cross-BAM merge (last BAM owns a QNAME's read_vars list, phaser.py:558-581) runs on every chromosome."""
-    from phaser_amd import workloads
-    plan = workloads.genome_plan(total_records=20_000_000)
-    vsets, shards, samples = build(plan, 4, 1 << 40)
+def test_whole_genome_four_bams_full_size(mapper, oracle_build, tmp_path):
+    """configs[3] at its stated size on one GPU: the sample of configs[2] with FOUR BAMs of 80M records each (320M records, 37 GB of shards) whose
+    QNAME ids collide, so the cross-BAM merge (last BAM owns a QNAME's read_vars list, phaser.py:558-581) runs on every chromosome.  Every record
+    of every BAM against the C mapper oracle -- one BAM's host copy (13 GB) at a time --, the invariants over the genome, and the five files of
+    chr21 and of chr22 with all four BAMs against the phasing oracle (workers)."""
+    from phaser_amd import dist as pdist, workloads
+    plan = workloads.genome_plan()
+    cores = max(1, pdist.effective_cpus())
+    n_bams = 4
+    vsets = {}; shards = [dict() for _ in range(n_bams)]; direct = [dict() for _ in range(n_bams)]
+    total = 0
+    for b in range(n_bams):
+        for chrom, ln, n_snps, n_rec, seed in plan:
+            v, sh, smp = workloads.make_shard(chrom, ln, n_snps, n_rec, seed, "cuda:0", keep_sample=1 << 40, read_seed=seed + 1 + 7919 * b)
+            vsets[chrom] = v; shards[b][chrom] = sh
+            c = mapper.map(sh, v.pos, 10)
+            assert same_calls(c, oracle_calls_of(oracle_build, smp, v.pos.numpy(), cores)), (chrom, b)
+            direct[b][chrom] = (c.n, c.read_idx, c.var_idx, c.code)
+            total += len(smp)
+            del smp
+    assert total > 319_000_000
     eng, out = run_engine(mapper, vsets, shards, plan, host_threads=16)
     assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
-    assert check_oracle_all_records(oracle_build, eng, vsets, samples, plan) > 79_000_000
-    check_invariants(eng, out, plan, 4)
-    del eng, out, shards, samples
+    for b in range(n_bams):                         # the batched submission of the pipeline gives the lists that were checked shard by shard
+        for chrom, *_ in plan:
+            calls = eng.shards[chrom][b].calls; n, r_, v_, c_ = direct[b][chrom]
+            assert calls.n == n and torch.equal(calls.read_idx, r_) and torch.equal(calls.var_idx, v_) and torch.equal(calls.code, c_), (chrom, b)
+    del direct
+    check_invariants(eng, out, plan, n_bams)
+    names = ["bam%d" % b for b in range(n_bams)]
+    for chrom in ("chr21", "chr22"):
+        sub_plan = [p for p in plan if p[0] == chrom]
+        one, got1 = run_engine(mapper, {chrom: vsets[chrom]}, [{chrom: shards[b][chrom]} for b in range(n_bams)], sub_plan, names=names)
+        assert one.rows_path == "device" and one.phased > 5_000
+        start_oracle_job("configs3_" + chrom, tmp_path, [call_text(vsets[chrom], shards[b][chrom], one.shards[chrom][b].calls) for b in range(n_bams)],
+                         got1, one.phased, names)
+        del one, got1
+    del eng, out, shards
     torch.cuda.empty_cache()
     check_replica_vs_oracle(mapper, workloads.genome_plan(total_records=20_000_000, scale=0.02), 4, min_phased=200)
+
+
+def test_sample_stream_full_size(mapper, oracle_build, tmp_path):
+    """configs[4], one rank's loop at the stated size: four whole-genome samples of 80M records each (different variant sets and reads) streamed one
+    after the other through ONE device context.  Per sample: every record of every chromosome against the C mapper oracle, the invariants of the
+    five files over the genome, and the five files of one chromosome (a different one per sample) against the phasing oracle (worker).  The
+    16-sample run of one GPU's share is tools/run_c5.py (profiles/r05/run_c5_16samples.txt)."""
+    from phaser_amd import workloads
+    sampled = ["chr22", "chr19", "chr21", "chr20"]
+    for s in range(4):
+        plan = workloads.genome_plan(seed=4000 + 100 * s)
+        vsets, shards, samples = build(plan, 1, 1 << 40)
+        name = "sample%03d" % s
+        eng, out = run_engine(mapper, vsets, shards, plan, names=[name], host_threads=16)
+        assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
+        assert check_oracle_all_records(oracle_build, eng, vsets, samples, plan) > 79_000_000
+        del samples
+        check_invariants(eng, out, plan, 1)
+        c = sampled[s]
+        one, got1 = run_engine(mapper, {c: vsets[c]}, [{c: shards[0][c]}], [p for p in plan if p[0] == c], names=[name])
+        assert one.phased > 5_000
+        start_oracle_job("configs4_%s_%s" % (name, c), tmp_path, [call_text(vsets[c], shards[0][c], one.shards[c][0].calls)], got1, one.phased, [name])
+        del eng, out, shards, one, got1
+        torch.cuda.empty_cache()
 
 
 def test_sample_stream_configs4_shape(mapper, tmp_path):
@@ -240,3 +349,20 @@ def test_sample_stream_configs4_shape(mapper, tmp_path):
         for k, smp in enumerate(sorted(tables)):
             t = tables[smp].get(r[3])
             assert t is not None and r[4 + k] == "%s|%s" % (t[ia], t[ib]), (r[3], smp)
+
+
+def test_zz_phasing_oracle_jobs():
+    """Joins the phasing-oracle workers the tests above started: the five files of every whole chromosome they were given must equal the product's
+    (canonical form; same phased-variant count)."""
+    import time
+    assert JOBS, "no oracle job was started"
+    bad = []
+    for label, pr, phased, sha, t0, n_lines in JOBS:
+        res = pr.communicate()[0].split()
+        print("oracle job %-28s %8d call lines  %6d phased variants  oracle %6.1f CPU-s, done %4.0f s after its start: %s"
+              % (label, n_lines, phased, float(res[1]) if len(res) > 1 else -1, time.time() - t0,
+                 "identical" if pr.returncode == 0 and len(res) == 3 and int(res[0]) == phased and res[2] == sha else "DIFFERENT"))
+        if not (pr.returncode == 0 and len(res) == 3 and int(res[0]) == phased and res[2] == sha):
+            bad.append(label)
+    del JOBS[:]
+    assert not bad, "the five files differ from the phasing oracle: %s" % bad

@@ -205,3 +205,30 @@ def test_direct_binom_ufunc_equals_the_public_method():
     for noise in (0.0010883, 0.004, 0.02, 1e-6):
         p = 1 - ((6 * noise) + (10 * noise ** 2))
         assert np.array_equal(rowsdev.binom_cdf(k, n, p), binom.cdf(k, n, p))
+
+
+def test_pinned_pool_never_recycles_a_buffer_with_live_views():
+    """rowsdev.PinnedPool: a dead owner's buffers serve the next pool, except those somebody still holds views of (the text chunks of
+    `Engine(...).finish(chunks=True)` kept after the Engine was collected) -- round-4 advisor finding: they were recycled and overwritten."""
+    import gc
+    from phaser_amd.rowsdev import PinnedPool
+    del PinnedPool._free[:]
+    a = PinnedPool()
+    kept = a.get("rows_x", 1000)[10:20]; kept[:] = 7            # a view that outlives its owner
+    gone = a.get("tally_y", 2000); gone[:] = 1
+    del gone
+    a.release()
+    assert len(PinnedPool._free) == 1 and PinnedPool._free[0].size >= 2000          # only the unreferenced buffer came back
+    b = PinnedPool()
+    w = b.get("rows_x", 900); w[:] = 9
+    assert (kept == 7).all()
+    y = b.get("tally_y", 1500)
+    assert y.base is not None and len(PinnedPool._free) == 0                          # the recycled one
+    # growing a name inside one owner: the old buffer is recycled only when nothing points into it
+    v = b.get("g", 100); hold = v[:5]; hold[:] = 3
+    b.get("g", 100000)[:] = 4
+    assert (hold == 3).all() and len(PinnedPool._free) == 0
+    del v, hold, w, y
+    b.release(); gc.collect()
+    assert len(PinnedPool._free) == 3
+    del PinnedPool._free[:]

@@ -72,16 +72,20 @@ def test_buffer_floors_follow_the_literal_buffer():
                 cigar = "50M"; nb = 1
             if filtered:
                 events.append((p, -1))
+            elif rng.random() < 0.15:
+                events.append((p, -2))          # passes the isize filter, then split_read gives it no alignment (N in the CIGAR, --splice 0)
             else:
                 events.append((p, len(recs))); recs.append(("q", p, cigar, "A" * nb, "I" * nb, ""))
         floors = _buffer_floors(events, recs, vpos)
         buf = []; nxt = 0
         for pos, k in events:
             buf = [v for v in buf if not vpos[v] < pos]
-            if k < 0:
+            if k == -1:
                 continue
             while nxt < len(vpos) and vpos[nxt] < pos:
                 nxt += 1
+            if k < 0:
+                continue
             seen = set()
             rec = recs[k]
             for start, plen in _segment_spans(rec[2], min(len(rec[3]), len(rec[4]))):

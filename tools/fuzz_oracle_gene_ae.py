@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Build-container fuzz (needs /root/reference): oracle/gene_ae_oracle.py vs the reference's phaser_gene_ae.py (run with the same
-intervaltree stand-in tools/make_golden.py uses) on random feature sets and argument combinations over the committed
+"""Build-container fuzz (needs /root/reference): oracle/gene_ae_oracle.py vs the reference's phaser_gene_ae.py (run with the real
+intervaltree 3.1.0 package, loaded by path from the image's conda tree like tools/make_golden.py does) on random feature sets and argument combinations over the committed
 haplotypic_counts fixtures.  usage: tools/fuzz_oracle_gene_ae.py [iterations=100] [seed=1]"""
 import collections, gzip, io, os, random, runpy, sys, tempfile, types
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,26 +8,11 @@ sys.path.insert(0, os.path.join(REPO, "tools")); sys.path.insert(0, os.path.join
 os.environ.setdefault("PYTHONHASHSEED", "0")
 import make_golden as mg
 import gene_ae_oracle as go
-Interval = collections.namedtuple("Interval", ["begin", "end", "data"])
-
-
-class IntervalTree:
-    def __init__(self):
-        self.ivs = []
-
-    def __setitem__(self, sl, data):
-        if sl.start >= sl.stop:
-            raise ValueError("IntervalTree: Null Interval objects not allowed in IntervalTree")
-        self.ivs.append(Interval(sl.start, sl.stop, data))
-
-    def __getitem__(self, sl):
-        if sl.start >= sl.stop:
-            return set()
-        return set(iv for iv in self.ivs if iv.begin < sl.stop and iv.end > sl.start)
-
-
-mod = types.ModuleType("intervaltree"); mod.IntervalTree = IntervalTree; mod.Interval = Interval
-sys.modules["intervaltree"] = mod
+# the REAL intervaltree 3.1.0: pure-Python sources in the image's conda tree, loaded by path (its dependency sortedcontainers is installed here)
+import importlib.util
+_real = "/opt/conda/lib/python3.9/site-packages/intervaltree"
+_spec = importlib.util.spec_from_file_location("intervaltree", os.path.join(_real, "__init__.py"), submodule_search_locations=[_real])
+mod = importlib.util.module_from_spec(_spec); sys.modules["intervaltree"] = mod; _spec.loader.exec_module(mod)
 script = "/root/reference/phaser_gene_ae/phaser_gene_ae.py"
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

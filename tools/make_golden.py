@@ -597,14 +597,21 @@ def gene_ae_boundary_features(hc_text):
 
 def fx_gene_ae(phaser, rvm):
     """phaser_gene_ae: run the reference's script on haplotypic_counts files the reference's phASER wrote
-    (other fixtures) and on synthetic BED features.  `intervaltree` is not installed here; the script gets a stand-in that
-    implements only what it uses (half-open intervals, `tree[a:b] = data`, `tree[a:b]` -> set of overlapping Interval tuples,
-    the published semantics of intervaltree 3.x `overlap(begin, end)`: iv.begin < end and iv.end > begin)."""
+    (other fixtures) and on synthetic BED features, with the REAL `intervaltree` package behind it: intervaltree 3.1.0 is not installed for
+    this interpreter but its pure-Python sources sit in the image's conda tree (/opt/conda/lib/python3.9/site-packages/intervaltree; its one
+    dependency, sortedcontainers, is installed here), so the package is loaded from there by path.  Every case is run a second time with an
+    independently written brute-force stand-in (a list scan with the documented overlap rule) and both outputs must be identical -- the
+    stand-in is what rounds 1-4 generated these fixtures with; the fixtures did not change when the real package took over."""
     import collections
+    import importlib.util
     import runpy
+    real_dir = "/opt/conda/lib/python3.9/site-packages/intervaltree"
+    spec = importlib.util.spec_from_file_location("intervaltree", os.path.join(real_dir, "__init__.py"), submodule_search_locations=[real_dir])
+    real_mod = importlib.util.module_from_spec(spec); sys.modules["intervaltree"] = real_mod; spec.loader.exec_module(real_mod)
+    assert real_mod.IntervalTree.__module__.startswith("intervaltree") and os.path.dirname(real_mod.__file__) == real_dir
     Interval = collections.namedtuple("Interval", ["begin", "end", "data"])
 
-    class IntervalTree:
+    class BruteTree:
         def __init__(self):
             self.ivs = []
 
@@ -617,8 +624,7 @@ def fx_gene_ae(phaser, rvm):
             if sl.start >= sl.stop:
                 return set()
             return set(iv for iv in self.ivs if iv.begin < sl.stop and iv.end > sl.start)
-    mod = types.ModuleType("intervaltree"); mod.IntervalTree = IntervalTree; mod.Interval = Interval
-    sys.modules["intervaltree"] = mod
+    brute_mod = types.ModuleType("intervaltree"); brute_mod.IntervalTree = BruteTree; brute_mod.Interval = Interval
     script = "/root/reference/phaser_gene_ae/phaser_gene_ae.py"
     cases = [("pipe_one", "pipe_one", 11, []), ("pipe_two", "pipe_two", 12, []), ("pipe_two_mincov", "pipe_two", 12, ["--min_cov", "5"]),
              ("pipe_two_gw06", "pipe_two", 12, ["--gw_cutoff", "0.6"]), ("pipe_noisy_c", "pipe_noisy_c", 13, []), ("c1", "c1", 14, []),
@@ -636,14 +642,19 @@ def fx_gene_ae(phaser, rvm):
         with tempfile.TemporaryDirectory() as tmp:
             hp = os.path.join(tmp, "hc.txt"); bp = os.path.join(tmp, "f.bed"); op = os.path.join(tmp, "o.txt")
             open(hp, "w").write(hc); open(bp, "w").write(bed)
-            argv = sys.argv
-            sys.argv = [script, "--haplotypic_counts", hp, "--features", bp, "--o", op] + extra
-            buf = io.StringIO(); old = sys.stdout; sys.stdout = buf
-            try:
-                runpy.run_path(script, run_name="__main__")
-            finally:
-                sys.stdout = old; sys.argv = argv
-            out = open(op).read()
+            outs = []
+            for mod in (real_mod, brute_mod):
+                sys.modules["intervaltree"] = mod
+                argv = sys.argv
+                sys.argv = [script, "--haplotypic_counts", hp, "--features", bp, "--o", op] + extra
+                buf = io.StringIO(); old = sys.stdout; sys.stdout = buf
+                try:
+                    runpy.run_path(script, run_name="__main__")
+                finally:
+                    sys.stdout = old; sys.argv = argv
+                outs.append(open(op).read()); os.remove(op)
+            assert outs[0] == outs[1], "intervaltree 3.1.0 and the brute-force overlap disagree on " + name
+            out = outs[0]
         open(os.path.join(d, "features.bed"), "w").write(bed)
         wgz(os.path.join(d, "out.gene_ae.txt.gz"), out)
         json.dump({"haplotypic_counts": src.replace(os.sep, "/") + "/out.haplotypic_counts.txt.gz", "args": extra}, open(os.path.join(d, "case.json"), "w"))

@@ -15,14 +15,17 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle")); sys.
 def main():
     import phasing_oracle as po
     from helpers import OUTPUTS, canonical
-    path, baseq = sys.argv[1], int(sys.argv[2])
+    paths, baseq = sys.argv[1].split(","), int(sys.argv[2])               # one call file per BAM (comma-separated), the chromosome's lines of that BAM
     out_dir = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None          # optional: the five files in canonical form are written there
-    cutoff = float(sys.argv[4]) if len(sys.argv) > 4 else None           # optional: the run's global AS cutoff and noise level (the chromosome is
-    noise = float.fromhex(sys.argv[5]) if len(sys.argv) > 5 else None    # one shard of a whole-genome run)
-    text = open(path).read()
+    # optional: the run's global AS cutoffs (one per BAM, comma-separated) and noise level (the chromosome is one shard of a whole-genome run)
+    cutoffs = [float(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 and sys.argv[4] != "-" else None
+    noise = float.fromhex(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+    names = sys.argv[6].split(",") if len(sys.argv) > 6 else (["bench"] if len(paths) == 1 else ["bam%d" % b for b in range(len(paths))])
+    texts = [open(p).read() for p in paths]
     t0 = time.perf_counter()
-    ph = po.Phaser(["bench"], baseq=baseq, global_as_cutoffs=None if cutoff is None else [cutoff], global_noise=noise)
-    ph.add_bam([text])
+    ph = po.Phaser(names, baseq=baseq, global_as_cutoffs=cutoffs, global_noise=noise)
+    for text in texts:
+        ph.add_bam([text])
     out = ph.finish()
     dt = time.perf_counter() - t0
     h = hashlib.sha256()
