@@ -50,12 +50,19 @@ def calibration():
         # launch takes as long as streaming the array (it does: see the table), and FETCH_SIZE reports 64 per request
         gather = [128.0 / pt[k]["fetch_bytes_reported_per_request"] for k in pt if k.startswith("gather_") and pt[k]["unit"] >= 128 and pt[k].get("fetch_bytes_reported_per_request")]
         write = [pt[k]["factor"] for k in ("write4", "write8", "write16") if pt.get(k, {}).get("factor")]
+        # where the pass with the raw request counters exists: bytes by request size (128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B) over FETCH_SIZE
+        by_size = []
+        for k in pt:
+            c = pt[k].get("counters_per_launch", {})
+            if not k.startswith("write") and c.get("TCC_EA0_RDREQ_sum") and c.get("FETCH_SIZE"):
+                by_size.append((128.0 * c.get("TCC_EA0_RDREQ_128B_sum", 0) + 64.0 * c.get("TCC_EA0_RDREQ_64B_sum", 0) + 32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0)) / (c["FETCH_SIZE"] * 1024))
         if stream and gather and write:
             return {"source": os.path.relpath(f, REPO), "fetch_factor_stream": sum(stream) / len(stream), "fetch_factor_gather": sum(gather) / len(gather),
                     "write_factor": sum(write) / len(write),
-                    "note": "FETCH_SIZE counts 64 B per L2 line miss, the memory side delivers the 128-byte line (streams: half the known bytes reported; lone 1-byte "
-                            "gathers: 64 B reported per request while the launch takes the time of streaming 128 B per request at ~6 TB/s); WRITE_SIZE is exact "
-                            "for coalesced 4 / 8 / 16-byte stores"}
+                    "fetch_factor_by_request_size": {"min": min(by_size), "max": max(by_size), "patterns": len(by_size)} if by_size else None,
+                    "note": "FETCH_SIZE counts 64 B per read request while every read request of these patterns is a 128-byte one (TCC_EA0_RDREQ_128B = "
+                            "TCC_EA0_RDREQ; rocprofv3's formula prices 128-byte requests through TCC_BUBBLE, which stays 0 on gfx950): streams report half their known "
+                            "bytes, a lone 1-byte gather costs a 128-byte line and reports 64; WRITE_SIZE is exact for coalesced 4 / 8 / 16-byte stores (64-byte requests)"}
     return None
 
 
@@ -96,11 +103,19 @@ def pmc_traffic():
                "calibration": cal,
                "note": "mean over the k_map launches of this command; FETCH_SIZE x the calibrated factor + WRITE_SIZE x its factor (profiles/*/calib: gathers and "
                        "streams both cost a 128-byte line per L2 miss, reported as 64)"}
-        ea = _pmc_rows(d, "ea_rd", "k_map")
+        ea = _pmc_rows(d, "ea_rd", "k_map"); ew = _pmc_rows(d, "ea_wr", "k_map")
         if ea.get("TCC_EA0_RDREQ_sum"):
+            # the raw request counters of the same command: exact bytes by request size; this is the figure reported, FETCH_SIZE x factor stays as the cross-check
             n32 = ea.get("TCC_EA0_RDREQ_32B_sum", 0.0); n64 = ea.get("TCC_EA0_RDREQ_64B_sum", 0.0); n128 = ea.get("TCC_EA0_RDREQ_128B_sum", 0.0)
-            out["read_requests"] = {"all": ea["TCC_EA0_RDREQ_sum"], "32B": n32, "64B": n64, "128B": n128,
-                                    "bytes_by_request_size": 32.0 * n32 + 64.0 * n64 + 128.0 * n128}
+            rd = 32.0 * n32 + 64.0 * n64 + 128.0 * n128
+            out["read_requests"] = {"all": ea["TCC_EA0_RDREQ_sum"], "32B": n32, "64B": n64, "128B": n128, "bytes_by_request_size": rd}
+            wr = wf * write * 1024
+            if ew.get("TCC_EA0_WRREQ_sum"):
+                w64 = ew.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+                wr = 64.0 * w64 + 32.0 * (ew["TCC_EA0_WRREQ_sum"] - w64)
+                out["write_requests"] = {"all": ew["TCC_EA0_WRREQ_sum"], "64B": w64, "bytes_by_request_size": wr}
+            out["bytes_per_launch_from_fetch_size"] = out["bytes_per_launch"]
+            out["bytes_per_launch"] = rd + wr
         insts = {k.replace("SQ_INSTS_", "").lower(): v for k, v in _pmc_rows(d, "sq1", "k_map").items() if k.startswith("SQ_INSTS_")}
         out["wave_insts_per_launch"] = insts
         return out

@@ -218,12 +218,12 @@ def test_whole_genome_one_bam(mapper, oracle_build, tmp_path):
     assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
     assert sum(sh.n for sh in shards[0].values()) > 79_000_000 and eng.vs.het_count > 1_400_000
     # chr1 at full size through the pinned phasing oracle (a worker process) while the mapper check below runs
+    check_invariants(eng, out, plan, 1)              # reads the ctx's resident tally: before any other pass on this mapper
     big = plan[0][0]
     one, got1 = run_engine(mapper, {big: vsets[big]}, [{big: shards[0][big]}], plan[:1], names=["bench"])
     assert one.phased > 50_000
     start_oracle_job("configs2_chr1", tmp_path, [call_text(vsets[big], shards[0][big], eng.shards[big][0].calls)], got1, one.phased, ["bench"])
     assert check_oracle_all_records(oracle_build, eng, vsets, samples, plan) > 79_000_000
-    check_invariants(eng, out, plan, 1)
     del eng, out, shards, samples, one, got1
     torch.cuda.empty_cache()
     check_replica_vs_oracle(mapper, workloads.genome_plan(scale=0.02), 1)

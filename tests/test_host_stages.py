@@ -212,6 +212,7 @@ def test_pinned_pool_never_recycles_a_buffer_with_live_views():
     `Engine(...).finish(chunks=True)` kept after the Engine was collected) -- round-4 advisor finding: they were recycled and overwritten."""
     import gc
     from phaser_amd.rowsdev import PinnedPool
+    gc.collect()                                             # Engines of earlier tests release their pools now, not in the middle of this one
     del PinnedPool._free[:]
     a = PinnedPool()
     kept = a.get("rows_x", 1000)[10:20]; kept[:] = 7            # a view that outlives its owner
@@ -228,7 +229,9 @@ def test_pinned_pool_never_recycles_a_buffer_with_live_views():
     v = b.get("g", 100); hold = v[:5]; hold[:] = 3
     b.get("g", 100000)[:] = 4
     assert (hold == 3).all() and len(PinnedPool._free) == 0
+    mine = {id(r) for r in b._bufs.values()}
+    assert len(mine) == 3
     del v, hold, w, y
-    b.release(); gc.collect()
-    assert len(PinnedPool._free) == 3
+    b.release()
+    assert mine <= {id(r) for r in PinnedPool._free}          # nothing points into them any more: all three are reusable (other tests' dead Engines may add theirs)
     del PinnedPool._free[:]
