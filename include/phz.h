@@ -458,8 +458,9 @@ int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i, const int
  * What it replaces in the reference (phaser/phaser.py): the bookkeeping of test_variant_connection :1594-1654 (the binomial p-value
  * itself stays the caller's scipy call, evaluated once per distinct argument pair), pruning :686-726, build_haplotypes :1861-1882,
  * phase_v3 :2107-2324, the output loops :691-695, :737-749, :865-1239.  The host twin is phz_rows_format_multi above; it still serves
- * the options this stage declines with PHZ_E_UNSUPPORTED (--gw_phase_method 1, --output_read_ids 1, a block of more than 512 variants,
- * more than 65536 distinct read-count pairs).
+ * the options this stage declines with PHZ_E_UNSUPPORTED (--gw_phase_method 1, --output_read_ids 1).  No size of a component, a block or
+ * the read-count pairs sends a pass to it: components beyond the phasing kernel's limits are phased by the host routine inside the call
+ * (that component only), the pair-key table grows on demand (PHZ_E_CAPACITY -> phz_rowsdev_set_pair_slots).
  *
  *   phz_rowsdev_create     upload the per-variant tables of this rank's chromosomes (joint variant index space of phz_tally)
  *   phz_rowsdev_pair_keys  stage 1: the distinct (total, supporting) read-count pairs of the pairs under test -> host
@@ -510,13 +511,17 @@ typedef struct {
 
 int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *tables, phz_rowsdev **out);
 void phz_rowsdev_destroy(phz_rowsdev *h);
-int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host /* [PHZ_PAIR_SLOTS] */);
+/* Size of the pair-key hash set: a power of two in [16, 2^28] (below PHZ_PAIR_SLOTS: tests only), PHZ_PAIR_SLOTS by default and kept by the handle.  phz_rowsdev_pair_keys returns
+ * PHZ_E_CAPACITY when the distinct (supporting, total) pairs of a pass do not fit (very deep coverage): quadruple and call it again. */
+int phz_rowsdev_set_pair_slots(phz_rowsdev *h, int64_t n_slots);
+int64_t phz_rowsdev_pair_slots(const phz_rowsdev *h);
+int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host /* [phz_rowsdev_pair_slots(h)] */);
 /* host helper between the two stages: values and repr() text of the p-values laid out by slot (used[] ascending = the occupied slots of
  * phz_rowsdev_pair_keys, pv[i] = scipy.stats.binom.cdf for slot used[i]).  Returns the bytes of txt, -1 on bad arguments / txt_cap too small
  * (n_slots + 40 bytes per used slot always fits). */
 int64_t phz_pair_slot_text(const uint32_t *used, const double *pv, int64_t n_used, int64_t n_slots, double *slot_pv /* [n_slots] */,
                            uint32_t *txt_off /* [n_slots + 1] */, char *txt, int64_t txt_cap);
-int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *opts, const double *slot_pv /* [PHZ_PAIR_SLOTS] */,
+int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *opts, const double *slot_pv /* [phz_rowsdev_pair_slots(h)] */,
                     const uint32_t *slot_txt_off /* [PHZ_PAIR_SLOTS + 1] */, const char *slot_txt, phz_rowsdev_result *result);
 int phz_rowsdev_fetch_text(phz_ctx *ctx, phz_rowsdev *h, int which, void *dst, int64_t bytes);
 const void *phz_rowsdev_text_ptr(phz_rowsdev *h, int which);      /* device pointer of a finished text */
@@ -529,7 +534,7 @@ int phz_rowsdev_fetch_blocks(phz_ctx *ctx, phz_rowsdev *h, int32_t *blk_size, in
  * configuration / 1 opposite / -1 tie.  Host arrays in and out.  sub_of[v] = ordinal of v's final block inside its component (-1: none),
  * alle_of[v] = its allele on haplotype A, n_sub[c] = final blocks of component c.  Same results as phz_phase_block per component. */
 int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t *comp_start, const uint32_t *pair_start, const int32_t *pair_i, const int32_t *pair_j,
-                         const int8_t *pair_cfg, int32_t max_block_size, int16_t *sub_of, uint8_t *alle_of, uint32_t *n_sub);
+                         const int8_t *pair_cfg, int32_t max_block_size, int32_t *sub_of, uint8_t *alle_of, uint32_t *n_sub);
 
 /* Adopt tally results computed elsewhere (another process / device, or a fixture) as the resident results of this ctx: the arrays of
  * phz_tally_out + sizes, in `space`.  rl_list[i] = index (variant * 2 + allele) * n_bams + bam of the read list entry i belongs to. */

@@ -269,6 +269,8 @@ SYMBOLS = {
     "phz_rows_free": (None, [C.POINTER(phz_rows_out)]),
     "phz_rowsdev_create": (C.c_int, [C.c_void_p, C.POINTER(phz_rowsdev_tables), C.POINTER(C.c_void_p)]),
     "phz_rowsdev_destroy": (None, [C.c_void_p]),
+    "phz_rowsdev_set_pair_slots": (C.c_int, [C.c_void_p, C.c_int64]),
+    "phz_rowsdev_pair_slots": (C.c_int64, [C.c_void_p]),
     "phz_rowsdev_pair_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "phz_pair_slot_text": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "phz_rowsdev_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_result)]),

@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int PS_SLOTS = 1 << 16;              // hash set of the distinct (total, supporting) arguments of the binomial test
+constexpr int PS_SLOTS = 1 << 16;              // default size of the hash set of the distinct (total, supporting) arguments of the binomial test (phz_rowsdev::ps_slots)
 constexpr unsigned long long PS_EMPTY = ~0ull;
 constexpr int STAT_N = 512;                    // largest block (variants) covered by the gwStat text table
 constexpr int PH_NMAX = 256, PH_EMAX = 2048;   // largest component (variants / kept pairs) k_phase_general takes; larger ones go to the host
@@ -673,25 +673,27 @@ __device__ __forceinline__ bool pair_tested(const uint8_t *linked, const int32_t
     return linked[e] && sup[e] > 0 && tot[e] - sup[e] > 0;
 }
 // flags[0]: table full
-__global__ __launch_bounds__(256) void k_pair_keys(int64_t ne, const uint8_t *linked, const int32_t *sup, const int32_t *tot, unsigned long long *hkeys, uint32_t *flags) {
+__global__ __launch_bounds__(256) void k_pair_keys(int64_t ne, const uint8_t *linked, const int32_t *sup, const int32_t *tot, unsigned long long *hkeys, uint32_t mask, uint32_t *flags) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= ne || !pair_tested(linked, sup, tot, e)) return;
     const unsigned long long key = ((unsigned long long)(uint32_t)tot[e] << 32) | (uint32_t)sup[e];
-    uint32_t s = ps_hash(key) & (PS_SLOTS - 1);
-    for (int t = 0; t < PS_SLOTS; t++) {
+    uint32_t s = ps_hash(key) & mask;
+    // a probe sequence this long means the table is (nearly) full: the host redoes the stage with a larger one (phz_rowsdev_set_pair_slots)
+    for (int t = 0; t < 2048; t++) {
         const unsigned long long cur = hkeys[s];
         if (cur == key) return;
         if (cur == PS_EMPTY) {
             const unsigned long long prev = atomicCAS(&hkeys[s], PS_EMPTY, key);
             if (prev == PS_EMPTY || prev == key) return;
         }
-        s = (s + 1) & (PS_SLOTS - 1);
+        s = (s + 1) & mask;
+        if ((t & 63) == 63 && ((volatile uint32_t *)flags)[0]) return;          // somebody has given up already
     }
     atomicOr(&flags[0], 1u);
 }
 // verdict per pair (:1645-1652, :686-700): p = 0 without supporting reads, 1 without conflicting ones, else the table; counters[0] linked pairs,
 // [1] linked pairs dropped
-__global__ __launch_bounds__(256) void k_keep(int64_t ne, const uint8_t *linked, const int32_t *sup, const int32_t *tot, const unsigned long long *hkeys,
+__global__ __launch_bounds__(256) void k_keep(int64_t ne, const uint8_t *linked, const int32_t *sup, const int32_t *tot, const unsigned long long *hkeys, uint32_t mask,
                                               const double *slot_pv, double threshold, uint8_t *keep, uint32_t *e_slot, uint32_t *deg, const int32_t *ea,
                                               const int32_t *eb, unsigned long long *counters) {
     __shared__ unsigned int s_c[8];
@@ -704,8 +706,8 @@ __global__ __launch_bounds__(256) void k_keep(int64_t ne, const uint8_t *linked,
             if (sup[e] == 0) pv = 0.0;
             else if (tot[e] - sup[e] > 0) {
                 const unsigned long long key = ((unsigned long long)(uint32_t)tot[e] << 32) | (uint32_t)sup[e];
-                uint32_t s = ps_hash(key) & (PS_SLOTS - 1);
-                while (hkeys[s] != key) s = (s + 1) & (PS_SLOTS - 1);
+                uint32_t s = ps_hash(key) & mask;
+                while (hkeys[s] != key) s = (s + 1) & mask;
                 slot = s; pv = slot_pv[s];
             }
             kept = !(pv < threshold);
@@ -892,7 +894,7 @@ __global__ __launch_bounds__(256) void k_max_u32(const uint32_t *x, int64_t n, u
 struct PH {
     const uint32_t *cstart, *mem_s, *estart, *ekeep, *eloc;
     const int32_t *ea, *eb, *cfgv;
-    uint8_t *alle_of; int16_t *sub_of; uint32_t *nsub;
+    uint8_t *alle_of; int32_t *sub_of; uint32_t *nsub;
     uint32_t *complex_list, *exc_list; uint32_t *counters;       // [0] complex components, [1] exceptions, [2] unsupported (the reference loops forever / 2^30 configurations)
     int max_block_size;
 };
@@ -1371,7 +1373,7 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
                 int put = 0;
                 for (int t = 0; t < len; t++) {
                     const int li = vi + t;
-                    if (li < n) { P.sub_of[m0 + li] = (int16_t)ns; P.alle_of[m0 + li] = (uint8_t)(s_fin[fp + t] == '1' ? 1 : 0); put++; }
+                    if (li < n) { P.sub_of[m0 + li] = (int32_t)ns; P.alle_of[m0 + li] = (uint8_t)(s_fin[fp + t] == '1' ? 1 : 0); put++; }
                 }
                 if (put > 0) ns++;
             }
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
 // blocks of the components in block order (rule 4): component r of the order owns blocks [blk_base[r], blk_base[r + 1])
 struct BK {
     const uint32_t *corder, *blk_base, *cstart, *mem_s;
-    const int16_t *sub_of; const uint8_t *alle_of;
+    const int32_t *sub_of; const uint8_t *alle_of;
     uint32_t *blk_mstart, *blk_len; int32_t *blk_of; uint8_t *v_alle;
 };
 __global__ __launch_bounds__(256) void k_blocks(int64_t ncomp, BK B) {
@@ -1782,6 +1784,7 @@ struct phz_rowsdev {
     std::vector<int64_t> chrom_blocks, chrom_blk_vars;
     int64_t n_blocks = 0, n_blk_vars = 0;
     bool keys_ready = false, have_vcf = false;
+    int64_t ps_slots = PS_SLOTS;        // slots of the pair-key hash set (a power of two; grown by the host when a pass reports PHZ_E_CAPACITY)
     std::vector<DevBuf *> all() {
         std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &slot_pv, &pv_off, &pv_txt, &bam_off, &bam_txt,
                                    &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
@@ -1845,14 +1848,14 @@ int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf
     hipStream_t sm = ctx->stream;
     *n_complex = 0; *n_exc = 0;
     if (int s = phz_reserve(ctx, alle_of, (size_t)(nmem + 1))) return s;
-    if (int s = phz_reserve(ctx, sub_of, (size_t)(nmem + 1) * 2)) return s;
+    if (int s = phz_reserve(ctx, sub_of, (size_t)(nmem + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, nsub, (size_t)(ncomp + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, complex_list, (size_t)(ncomp + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, exc_list, (size_t)(2 * ncomp + 2) * 4)) return s;
     if (int s = phz_reserve(ctx, eloc, (size_t)(nkeep + 1) * 4)) return s;
     if (!ncomp) return PHZ_OK;
     PH ph; ph.cstart = P<uint32_t>(cstart); ph.mem_s = P<uint32_t>(mem_s); ph.estart = P<uint32_t>(estart); ph.ekeep = P<uint32_t>(ekeep);
-    ph.ea = ea; ph.eb = eb; ph.cfgv = cfgv; ph.alle_of = P<uint8_t>(alle_of); ph.sub_of = P<int16_t>(sub_of); ph.nsub = P<uint32_t>(nsub);
+    ph.ea = ea; ph.eb = eb; ph.cfgv = cfgv; ph.alle_of = P<uint8_t>(alle_of); ph.sub_of = P<int32_t>(sub_of); ph.nsub = P<uint32_t>(nsub);
     ph.complex_list = P<uint32_t>(complex_list); ph.exc_list = P<uint32_t>(exc_list); ph.counters = cnt32; ph.max_block_size = max_block_size;
     ph.eloc = P<uint32_t>(eloc);
     uint32_t h_c32[4] = {0, 0, 0, 0};
@@ -1901,15 +1904,14 @@ int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf
             int32_t nsubs = 0;
             const int st = phz_phase_block((int32_t)n, (int64_t)E, ei.data(), ej.data(), ec.data(), max_block_size, sf.data(), sl.data(), cfg.data(), &nsubs);
             if (st != PHZ_OK) return phz_fail(ctx, st, "block phasing of a large component on the host");
-            std::vector<int16_t> so(n, (int16_t)-1); std::vector<uint8_t> ao(n, 0);
+            std::vector<int32_t> so(n, -1); std::vector<uint8_t> ao(n, 0);
             uint32_t ns = 0; size_t w = 0;
             for (int32_t k = 0; k < nsubs; k++) {
                 if (sl[k] <= 0) continue;
-                if (ns >= 32767) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "more than 32767 blocks in one component");
-                for (int32_t t = 0; t < sl[k]; t++) { so[(size_t)sf[k] + t] = (int16_t)ns; ao[(size_t)sf[k] + t] = (uint8_t)(cfg[w++] == '1'); }
+                for (int32_t t = 0; t < sl[k]; t++) { so[(size_t)sf[k] + t] = (int32_t)ns; ao[(size_t)sf[k] + t] = (uint8_t)(cfg[w++] == '1'); }
                 ns++;
             }
-            PHZ_HIP(ctx, hipMemcpy(P<int16_t>(sub_of) + m0, so.data(), (size_t)n * 2, hipMemcpyHostToDevice));
+            PHZ_HIP(ctx, hipMemcpy(P<int32_t>(sub_of) + m0, so.data(), (size_t)n * 4, hipMemcpyHostToDevice));
             PHZ_HIP(ctx, hipMemcpy(P<uint8_t>(alle_of) + m0, ao.data(), (size_t)n, hipMemcpyHostToDevice));
             PHZ_HIP(ctx, hipMemcpy(P<uint32_t>(nsub) + c, &ns, 4, hipMemcpyHostToDevice));
         }
@@ -1973,26 +1975,36 @@ extern "C" void phz_rowsdev_destroy(phz_rowsdev *h) {
 // Stage 1: the distinct (total, supporting) argument pairs of the binomial test over the tested pairs of the last phz_tally.  keys_host
 // [PHZ_PAIR_SLOTS] receives the hash set as it lives on the device: slot s holds (total << 32 | supporting) or all ones when empty.  The caller
 // evaluates the p-value of every occupied slot (the reference's scipy call) and passes values and their text to phz_rowsdev_run by slot.
+// Size of the pair-key hash set (a power of two in [16, 2^28]; anything below the default 2^16 is for tests); keys_host / slot_pv / slot_txt_off of the two stages are sized by it.
+extern "C" int phz_rowsdev_set_pair_slots(phz_rowsdev *h, int64_t n_slots) {
+    if (!h || n_slots < 16 || n_slots > (1ll << 28) || (n_slots & (n_slots - 1))) return PHZ_E_ARG;
+    h->ps_slots = n_slots; h->keys_ready = false;
+    return PHZ_OK;
+}
+extern "C" int64_t phz_rowsdev_pair_slots(const phz_rowsdev *h) { return h ? h->ps_slots : 0; }
+
 extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host) {
     PhzEnter phz_guard_(ctx);
     if (!ctx || !h || !keys_host) return PHZ_E_ARG;
     auto &T = ctx->tally;
     if (T.nv != h->nv) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not belong to these variant tables");
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
-    if (int s = phz_reserve(ctx, h->hkeys, (size_t)PS_SLOTS * 8)) return s;
+    const size_t slots = (size_t)h->ps_slots;
+    if (int s = phz_reserve(ctx, h->hkeys, slots * 8)) return s;
     if (int s = phz_reserve(ctx, h->flags, 64)) return s;
     hipStream_t sm = ctx->stream;
-    PHZ_HIP(ctx, hipMemsetAsync(h->hkeys.p, 0xff, (size_t)PS_SLOTS * 8, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->hkeys.p, 0xff, slots * 8, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->flags.p, 0, 64, sm));
     const int64_t ne = T.n_edges;
     if (ne > 0) hipLaunchKernelGGL(k_pair_keys, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, (const int32_t *)(T.stats + 2 * ne),
-                                   (const int32_t *)(T.stats + 3 * ne), P<unsigned long long>(h->hkeys), P<uint32_t>(h->flags));
+                                   (const int32_t *)(T.stats + 3 * ne), P<unsigned long long>(h->hkeys), (uint32_t)(slots - 1), P<uint32_t>(h->flags));
     PHZ_HIP(ctx, hipGetLastError());
     uint32_t fl = 0;
-    PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, (size_t)PS_SLOTS * 8, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(&fl, h->flags.p, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
-    if (fl & 1u) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "more than 65536 distinct (supporting, total) read-count pairs");
+    if (fl & 1u) return phz_fail(ctx, PHZ_E_CAPACITY, "the distinct (supporting, total) read-count pairs do not fit the pair-key table: grow it (phz_rowsdev_set_pair_slots) and call again");
+    PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, slots * 8, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
     h->keys_ready = true;
     return PHZ_OK;
 }
@@ -2019,9 +2031,10 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     Sections sec(ctx);
     sec.begin();
     // ---- per-pass uploads
-    if (int s = up(ctx, h->slot_pv, slot_pv, (size_t)PS_SLOTS * 8)) return s;
-    if (int s = up(ctx, h->pv_off, slot_txt_off, (size_t)(PS_SLOTS + 1) * 4)) return s;
-    if (int s = up(ctx, h->pv_txt, slot_txt, (size_t)slot_txt_off[PS_SLOTS])) return s;
+    const size_t ps_slots = (size_t)h->ps_slots;
+    if (int s = up(ctx, h->slot_pv, slot_pv, ps_slots * 8)) return s;
+    if (int s = up(ctx, h->pv_off, slot_txt_off, (ps_slots + 1) * 4)) return s;
+    if (int s = up(ctx, h->pv_txt, slot_txt, (size_t)slot_txt_off[ps_slots])) return s;
     if (int s = up(ctx, h->bam_off, o->bam_name_off, (size_t)(nb + 1) * 4)) return s;
     if (int s = up(ctx, h->bam_txt, o->bam_names, (size_t)o->bam_name_off[nb])) return s;
     if (o->bam_excluded) { if (int s = up(ctx, h->bam_excl, o->bam_excluded, (size_t)nb)) return s; }
@@ -2045,7 +2058,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     PHZ_HIP(ctx, hipMemsetAsync(h->cnt32.p, 0, 64, sm));
     unsigned long long *cnt64 = P<unsigned long long>(h->cnt64);
     uint32_t *cnt32 = P<uint32_t>(h->cnt32);
-    if (ne) hipLaunchKernelGGL(k_keep, dim3(std::min(nblk(ne), 2048u)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, sup, tot, (const unsigned long long *)h->hkeys.p,
+    if (ne) hipLaunchKernelGGL(k_keep, dim3(std::min(nblk(ne), 2048u)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, sup, tot, (const unsigned long long *)h->hkeys.p, (uint32_t)(ps_slots - 1),
                                (const double *)h->slot_pv.p, o->cc_threshold, P<uint8_t>(h->keep), P<uint32_t>(h->e_slot), P<uint32_t>(h->deg), (const int32_t *)T.ea,
                                (const int32_t *)T.eb, cnt64);
     if (nv) hipLaunchKernelGGL(k_uf_init, dim3(nblk(nv)), dim3(256), 0, sm, P<int32_t>(h->parent), nv);
@@ -2175,7 +2188,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         sec.begin();
         nblocks = nb32;
         BK bk; bk.corder = P<uint32_t>(h->corder); bk.blk_base = P<uint32_t>(h->blk_base); bk.cstart = P<uint32_t>(h->cstart); bk.mem_s = P<uint32_t>(h->mem_s);
-        bk.sub_of = P<int16_t>(h->sub_of); bk.alle_of = P<uint8_t>(h->alle_of); bk.blk_mstart = P<uint32_t>(h->blk_mstart); bk.blk_len = P<uint32_t>(h->blk_len);
+        bk.sub_of = P<int32_t>(h->sub_of); bk.alle_of = P<uint8_t>(h->alle_of); bk.blk_mstart = P<uint32_t>(h->blk_mstart); bk.blk_len = P<uint32_t>(h->blk_len);
         bk.blk_of = P<int32_t>(h->blk_of); bk.v_alle = P<uint8_t>(h->v_alle);
         hipLaunchKernelGGL(k_blocks, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, bk);
         if (nkeep) hipLaunchKernelGGL(k_blk_edges, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, (const uint32_t *)h->ekeep.p, (const int32_t *)T.ea, (const int32_t *)T.eb, cfgv,
@@ -2450,7 +2463,7 @@ extern "C" int phz_rowsdev_fetch_blocks(phz_ctx *ctx, phz_rowsdev *h, int32_t *b
 // pair_i / pair_j are LOCAL variant indices inside the component, pair_cfg 0 same configuration / 1 opposite / -1 tie.  Outputs per
 // variant: sub_of = ordinal of its final block inside the component (-1: in none), alle_of = its allele on haplotype A; n_sub per component.
 extern "C" int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t *comp_start, const uint32_t *pair_start, const int32_t *pair_i, const int32_t *pair_j,
-                                    const int8_t *pair_cfg, int32_t max_block_size, int16_t *sub_of, uint8_t *alle_of, uint32_t *n_sub) {
+                                    const int8_t *pair_cfg, int32_t max_block_size, int32_t *sub_of, uint8_t *alle_of, uint32_t *n_sub) {
     PhzEnter phz_guard_(ctx);
     if (!ctx || n_comp < 0 || (n_comp && (!comp_start || !pair_start || !sub_of || !alle_of || !n_sub))) return PHZ_E_ARG;
     if (!n_comp) return PHZ_OK;
@@ -2483,7 +2496,7 @@ extern "C" int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t
     st = phase_all(ctx, sec, d[B_CS], d[B_MEM], d[B_ES], d[B_EK], P<int32_t>(d[B_EA]), P<int32_t>(d[B_EB]), P<int32_t>(d[B_CF]), n_comp, nmem, ne, ne, max_block_size,
                    d[B_AL], d[B_SUB], d[B_NSUB], d[B_CX], d[B_EX], d[B_EL], P<uint32_t>(d[B_CNT]), &ncx, &nex);
     if (st != PHZ_OK) return fin(st);
-    hipError_t e = hipMemcpyAsync(sub_of, d[B_SUB].p, (size_t)nmem * 2, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(sub_of, d[B_SUB].p, (size_t)nmem * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(alle_of, d[B_AL].p, (size_t)nmem, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(n_sub, d[B_NSUB].p, (size_t)n_comp * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

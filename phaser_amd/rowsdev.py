@@ -247,18 +247,28 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     T = tables_for(eng)
     t1 = _t.perf_counter()
     # ---- stage 1: distinct (total, supporting) pairs -> scipy -> value + repr text per slot (phaser.py:1645-1652)
-    keys = pool_of(eng).get("pair_keys", _lib.PHZ_PAIR_SLOTS * 8).view(np.uint64)
-    ctx.check(lib.phz_rowsdev_pair_keys(ctx.h, T.h, _vp(keys)))
+    import os as _os
+    if _os.environ.get("PHZ_ROWS_PAIR_SLOTS") and not getattr(T, "_pair_slots_forced", False):          # tests: start from a tiny table so that the growth path runs
+        ctx.check(lib.phz_rowsdev_set_pair_slots(T.h, int(_os.environ["PHZ_ROWS_PAIR_SLOTS"]))); T._pair_slots_forced = True
+    while True:
+        n_slots = int(lib.phz_rowsdev_pair_slots(T.h))
+        keys = pool_of(eng).get("pair_keys", n_slots * 8).view(np.uint64)
+        st_ = ctx.check(lib.phz_rowsdev_pair_keys(ctx.h, T.h, _vp(keys)), allow=(_lib.PHZ_E_CAPACITY,))
+        if st_ != _lib.PHZ_E_CAPACITY:
+            break
+        # very deep coverage: more distinct (supporting, total) pairs than the table holds -- quadruple it (the handle keeps the size) and redo the stage
+        ctx.check(lib.phz_rowsdev_set_pair_slots(T.h, n_slots * 4))
+        eng.stats["rowsdev_n_pair_table_growths"] = eng.stats.get("rowsdev_n_pair_table_growths", 0) + 1
     used = np.flatnonzero(keys != np.uint64(0xFFFFFFFFFFFFFFFF)).astype(np.uint32)
     ku = keys[used]
     tot = (ku >> np.uint64(32)).astype(np.int64); sup = (ku & np.uint64(0xFFFFFFFF)).astype(np.int64)
     prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
     pv = binom_cdf(sup, tot, prob) if len(used) else np.zeros(0, dtype=np.float64)
     # values and text by slot (float.__repr__ of the value: what the reference's str(p) writes, phaser.py:693) -- laid out natively
-    slot_pv = np.empty(_lib.PHZ_PAIR_SLOTS, dtype=np.float64)
-    txt_off = np.empty(_lib.PHZ_PAIR_SLOTS + 1, dtype=np.uint32)
-    txt = np.empty(_lib.PHZ_PAIR_SLOTS + 40 * len(used) + 64, dtype=np.uint8)
-    nbytes_txt = lib.phz_pair_slot_text(_vp(used), _vp(np.ascontiguousarray(pv, dtype=np.float64)), len(used), _lib.PHZ_PAIR_SLOTS, _vp(slot_pv), _vp(txt_off),
+    slot_pv = np.empty(n_slots, dtype=np.float64)
+    txt_off = np.empty(n_slots + 1, dtype=np.uint32)
+    txt = np.empty(n_slots + 40 * len(used) + 64, dtype=np.uint8)
+    nbytes_txt = lib.phz_pair_slot_text(_vp(used), _vp(np.ascontiguousarray(pv, dtype=np.float64)), len(used), n_slots, _vp(slot_pv), _vp(txt_off),
                                         _vp(txt), txt.size)
     if nbytes_txt < 0:
         raise _lib.PhzError(_lib.PHZ_E_ARG, "phz_pair_slot_text")

