@@ -29,7 +29,11 @@ namespace {
 
 constexpr int PS_SLOTS = 1 << 16;              // default size of the hash set of the distinct (total, supporting) arguments of the binomial test (phz_rowsdev::ps_slots)
 constexpr unsigned long long PS_EMPTY = ~0ull;
-constexpr int STAT_N = 512;                    // largest block (variants) covered by the gwStat text table
+#ifndef PHZ_STAT_N
+#define PHZ_STAT_N 512          // the emulation tests also build a variant with a tiny value: every block then takes the paths of a block beyond the table
+#endif
+constexpr int STAT_N = PHZ_STAT_N;             // largest block (variants) covered by the gwStat text table and by the LDS piece arrays of k_seg_big; larger blocks:
+                                               // gwStat text formatted by the host inside the run (kind 3), piece arrays in the global pool (k_seg_big<.., HUGE>)
 constexpr int PH_NMAX = 256, PH_EMAX = 2048;   // largest component (variants / kept pairs) k_phase_general takes; larger ones go to the host
 constexpr int PH_BRUTE_MAX = 22;               // largest fragment brute-forced on the device (2^21 configurations shared by 64 lanes)
 #ifdef PHZ_PHASE_PROFILE      // build flag: cycle counts of the slowest component's sections, printed by phase_all
@@ -193,7 +197,7 @@ struct RD {
     int64_t nv, ne, nblocks, n_linked, n_keys;
     int nchrom, nb, unique_ids, unphased_vars;
     const uint16_t *vchrom; const int32_t *pos;
-    PoolD uid, rsid, alle, maft, chromn, bamn, statt, pvt;
+    PoolD uid, rsid, alle, maft, chromn, bamn, statt, statx, pvt;
     const double *mafv; const uint8_t *is_ref; const int8_t *phase_idx; const uint8_t *black; const uint8_t *bam_excl;
     // tally
     const int32_t *var_count, *var_distinct, *ea, *eb, *cis, *trans, *sup, *tot, *cfgv;
@@ -231,6 +235,7 @@ template <class S> __device__ __forceinline__ void put_stat(const RD &D, int b, 
     const uint8_t k = D.blk_statkind[b];
     if (k == 1) s.ch('1');
     else if (k == 2) s.lit("0.5");
+    else if (k == 3) s.pool(D.statx, D.blk_statidx[b]);          // a block of more known phases than the table covers: text laid out by the host during the run
     else s.pool(D.statt, D.blk_statidx[b]);
 }
 
@@ -1458,6 +1463,7 @@ __global__ __launch_bounds__(256) void k_blk_edges(int64_t nkeep, const uint32_t
 struct BS {
     const uint32_t *mem_s, *blk_mstart, *blk_len; const uint8_t *v_alle; const int8_t *phase_idx; const double *mafv;
     uint8_t *conc, *cormode, *statkind; uint32_t *statidx; int32_t *maxmaf; double *stat; unsigned long long *cfg_rows;
+    uint32_t *big_stat, *big_stat_n;        // (known phases, their sum) of the blocks beyond the gwStat table, slot = the block's statidx; count
 };
 __global__ __launch_bounds__(256) void k_blk_stats(int64_t nblocks, BS S) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1483,7 +1489,8 @@ __global__ __launch_bounds__(256) void k_blk_stats(int64_t nblocks, BS S) {
             if (m < 0.5) cm = 1; else if (m > 0.5) cm = 2;
             const double other = 1 - m;
             stat = m >= other ? m : other;
-            kind = 0; idx = (uint32_t)nknown * (STAT_N + 1) + (uint32_t)ksum;
+            if (nknown <= STAT_N) { kind = 0; idx = (uint32_t)nknown * (STAT_N + 1) + (uint32_t)ksum; }
+            else { kind = 3; idx = atomicAdd(S.big_stat_n, 1u); S.big_stat[2 * idx] = (uint32_t)nknown; S.big_stat[2 * idx + 1] = (uint32_t)ksum; }
         }
     }
     S.conc[b] = all_equal ? 1 : 0; S.cormode[b] = cm; S.statkind[b] = kind; S.statidx[b] = idx; S.maxmaf[b] = (int32_t)best; S.stat[b] = stat;
@@ -1502,6 +1509,7 @@ struct SG {
     const uint32_t *rl_start; const int32_t *rl_qid;
     uint32_t *labels, *ns;
     uint32_t *big_list, *big_list2; uint32_t *counters;         // [0] segments left to the wave kernel, [1] pool slots used, [2] pool overflow, [3] segments left to the workgroup kernel
+    uint32_t *huge_list, *huge_count;                             // segments of more than STAT_N pieces (a block of more than STAT_N variants): k_seg_big<.., HUGE>, piece arrays in the pool
     uint32_t *pool; uint32_t pool_cap;
     const uint32_t *lab_e; int64_t nmem;        // read list of (haplotype, BAM, block member): one load instead of mem_s -> v_alle -> index arithmetic
 };
@@ -1540,7 +1548,9 @@ template <int MODE> __global__ __launch_bounds__(64) void k_seg_small(SG G) {
     // the segments left to the wave / workgroup kernels take their places in the two lists with one cursor step per wave and list (82,000 of a
     // genome's 370,000 segments: one same-address atomic each was most of this kernel's time)
     {
-        const unsigned long long m2 = __ballot(M > (uint32_t)SEG_MID), m1 = __ballot(M > (uint32_t)SEG_SMALL && M <= (uint32_t)SEG_MID);
+        const bool huge = np > (uint32_t)STAT_N && M > (uint32_t)SEG_SMALL;              // its pieces do not fit the LDS arrays of k_seg_big
+        if (huge) G.huge_list[atomicAdd(G.huge_count, 1u)] = (uint32_t)seg;                 // (rare: one atomic each)
+        const unsigned long long m2 = __ballot(!huge && M > (uint32_t)SEG_MID), m1 = __ballot(!huge && M > (uint32_t)SEG_SMALL && M <= (uint32_t)SEG_MID);
         const unsigned long long below = tid ? (~0ull >> (64 - tid)) : 0ull;
         if (m2) {
             uint32_t base = 0;
@@ -1600,14 +1610,27 @@ __device__ __forceinline__ uint32_t seg_hash(uint32_t q) { q ^= q >> 16; q *= 0x
 #ifndef PHZ_SEG_THREADS
 #define PHZ_SEG_THREADS 512
 #endif
-template <int MODE, int SLOTS, int THREADS> __global__ __launch_bounds__(THREADS) void k_seg_big(SG G) {
+template <int MODE, int SLOTS, int THREADS, bool HUGE = false> __global__ __launch_bounds__(THREADS) void k_seg_big(SG G) {
     __shared__ uint32_t s_tab[3 * SLOTS];
-    __shared__ uint32_t s_pref[STAT_N + 2], s_lo[STAT_N + 2];
+    __shared__ uint32_t s_pref_l[HUGE ? 2 : STAT_N + 2], s_lo_l[HUGE ? 2 : STAT_N + 2];
     __shared__ uint32_t s_w[THREADS / 64 > 4 ? THREADS / 64 : 4];
     __shared__ uint32_t s_carry, s_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t seg = THREADS == 64 ? G.big_list[blockIdx.x] : G.big_list2[blockIdx.x];
+    const int64_t seg = HUGE ? G.huge_list[blockIdx.x] : (THREADS == 64 ? G.big_list[blockIdx.x] : G.big_list2[blockIdx.x]);
     const uint32_t np = seg_pieces<MODE>(G, seg);
+    uint32_t *s_pref = s_pref_l, *s_lo = s_lo_l;
+    if (HUGE) {          // piece starts and their prefix live in a slice of the global pool (same overflow protocol as the tables: grow and redo)
+        if (tid == 0) {
+            const uint32_t need = 2u * (np + 2u);
+            const uint32_t off = atomicAdd(&G.counters[1], need);
+            s_off = off;
+            if ((unsigned long long)off + need > (unsigned long long)G.pool_cap) { atomicOr(&G.counters[2], 1u); s_off = NONE32; }
+        }
+        __syncthreads();
+        if (s_off == NONE32) return;
+        s_pref = G.pool + s_off; s_lo = s_pref + (np + 2u);
+        __syncthreads();                                          // s_off is reused below
+    }
     // the pieces of the segment (one read list each) looked up by all threads -- a chain of dependent loads per piece: one thread doing
     // them one after the other was the tail of the launch --, then their exclusive prefix by the first wave
     for (uint32_t t = tid; t < np; t += THREADS) {
@@ -1775,7 +1798,7 @@ struct phz_rowsdev {
     DevBuf cnt64, cnt32, chrom_cnt, seg_start, key64s, eloc;     // chrom_cnt: uint32 [conn rows | blocks | block vars | keys per (bam, chrom)], then uint64 cfg rows
     DevBuf alle_of, sub_of, nsub, complex_list, exc_list, nsub_o, blk_base;
     DevBuf blk_mstart, blk_len, blk_of, v_alle, blk_sup, blk_tot, conc, cormode, statkind, statidx, maxmaf, stat, cfg_rows, cfg_base, cfg_chunk, cfg_pl, cfg_pb, cfg_ps, cfg_bytes, cfg_bbase, blk_voff, mrec, lab_e, lab_skip, big_blk;
-    DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, pool, tl, its, piece_dst, rowlen;
+    DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, huge_list, big_stat, px_off, px_txt, pool, tl, its, piece_dst, rowlen;
     DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
     DevBuf o_var, o_maxmaf, o_hap, o_cor;
     // results (host)
@@ -1791,7 +1814,7 @@ struct phz_rowsdev {
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
                                    &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &cfg_pl, &cfg_pb, &cfg_ps, &cfg_bytes, &cfg_bbase, &blk_voff, &mrec, &lab_e, &lab_skip, &big_blk, &labels,
-                                   &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
+                                   &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &huge_list, &big_stat, &px_off, &px_txt, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
         return v;
@@ -2198,8 +2221,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         BS bs; bs.mem_s = P<uint32_t>(h->mem_s); bs.blk_mstart = P<uint32_t>(h->blk_mstart); bs.blk_len = P<uint32_t>(h->blk_len); bs.v_alle = P<uint8_t>(h->v_alle);
         bs.phase_idx = P<int8_t>(h->d_phase); bs.mafv = P<double>(h->d_maf); bs.conc = P<uint8_t>(h->conc); bs.cormode = P<uint8_t>(h->cormode); bs.statkind = P<uint8_t>(h->statkind);
         bs.statidx = P<uint32_t>(h->statidx); bs.maxmaf = P<int32_t>(h->maxmaf); bs.stat = P<double>(h->stat); bs.cfg_rows = P<unsigned long long>(h->cfg_rows);
+        RSV(big_stat, (size_t)(nmem / (STAT_N + 1) + 2) * 8);          // a block beyond the table has more than STAT_N members
+        bs.big_stat = P<uint32_t>(h->big_stat); bs.big_stat_n = cnt32 + 13;
         hipLaunchKernelGGL(k_blk_stats, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, bs);
-        hipLaunchKernelGGL(k_max_u32, dim3(std::min(nblk(nblocks), 64u)), dim3(256), 0, sm, (const uint32_t *)h->blk_len.p, nblocks, cnt64 + 3);
         hipLaunchKernelGGL(k_block_starts, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, (const uint32_t *)h->blk_mstart.p, (const uint32_t *)h->mem_s.p,
                            (const uint16_t *)h->d_vchrom.p, ss_blocks);
     }
@@ -2209,14 +2233,28 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     hipLaunchKernelGGL(k_block_counts, dim3(1), dim3(1), 0, sm, (const uint32_t *)ss_blocks, (const uint32_t *)cc_blocks, nchrom, (const uint32_t *)h->blk_voff.p,
                        (const unsigned long long *)h->cfg_base.p, cc_blkvars, cc_cfg);
     {
-        uint32_t h_phased = 0;
+        uint32_t h_phased = 0, h_nbs = 0;
         PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(&h_c64[3], cnt64 + 3, 8, hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(&h_nbs, cnt32 + 13, 4, hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipMemcpyAsync(&h_phased, P<uint32_t>(h->blk_voff) + nblocks, 4, hipMemcpyDeviceToHost, sm));
         if (int s = sec.wait()) return s;
         sec.begin();
-        if ((int64_t)h_c64[3] > STAT_N) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: a haplotype block of more than 512 variants is formatted by the host stage");
         res->phased = (int64_t)h_phased;
+        // gwStat text of the blocks with more known phases than the table covers (:968-980, the same float64 operations): formatted here, a handful per genome at most
+        if (h_nbs) {
+            std::string xt; std::vector<uint32_t> xo((size_t)h_nbs + 1, 0u), bsv((size_t)h_nbs * 2);
+            PHZ_HIP(ctx, hipMemcpy(bsv.data(), h->big_stat.p, bsv.size() * 4, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < h_nbs; i++) {
+                xo[i] = (uint32_t)xt.size();
+                const double m = (double)bsv[2 * (size_t)i + 1] / (double)bsv[2 * (size_t)i], ot = 1 - m;
+                phztext::put_pyfloat(xt, m >= ot ? m : ot);
+                xt += '\n';
+            }
+            xo[h_nbs] = (uint32_t)xt.size();
+            if (int s = up(ctx, h->px_off, xo.data(), xo.size() * 4)) return s;
+            if (int s = up(ctx, h->px_txt, xt.data(), xt.size())) return s;
+            PHZ_HIP(ctx, hipStreamSynchronize(sm));            // xo / xt die with this scope
+        }
     }
     // ---- read sets of the haplotypes: labels + distinct counts
     const bool need_all = nb > 1 || h->has_black;
@@ -2230,6 +2268,8 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     SG sg; sg.nb = nb; sg.lab_e = P<uint32_t>(h->lab_e); sg.nmem = nmem; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
     sg.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.labels = P<uint32_t>(h->labels);
     sg.big_list = P<uint32_t>(h->big_list); sg.big_list2 = P<uint32_t>(h->big_list2); sg.counters = cnt32 + 4;
+    RSV(huge_list, ((size_t)(nmem / (STAT_N + 1) + 2) * 2 * (size_t)nb + 16) * 4);
+    sg.huge_list = P<uint32_t>(h->huge_list); sg.huge_count = cnt32 + 14;
     for (int attempt = 0;; attempt++) {
         sg.pool = P<uint32_t>(h->pool); sg.pool_cap = (uint32_t)std::min<size_t>(h->pool.cap / 4, 0xFFFFFFF0u);
         uint32_t h_seg[4] = {0, 0, 0, 0};
@@ -2241,11 +2281,14 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
             sg.ns = mode == 0 ? P<uint32_t>(h->seg_ns) : (mode == 1 ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->single_n));
             if (sg.nseg == 0) continue;
             PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 4, 0, 16, sm));
+            PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 14, 0, 4, sm));
             const unsigned g = (unsigned)((sg.nseg + 63) / 64);
             if (mode == 0) hipLaunchKernelGGL(k_seg_small<0>, dim3(g), dim3(64), 0, sm, sg);
             else if (mode == 1) hipLaunchKernelGGL(k_seg_small<1>, dim3(g), dim3(64), 0, sm, sg);
             else hipLaunchKernelGGL(k_seg_small<2>, dim3(g), dim3(64), 0, sm, sg);
+            uint32_t n_huge = 0;
             PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 16, hipMemcpyDeviceToHost, sm));
+            PHZ_HIP(ctx, hipMemcpyAsync(&n_huge, cnt32 + 14, 4, hipMemcpyDeviceToHost, sm));
             if (int s = sec.wait()) return s;
             sec.begin();
             const uint32_t n_mid = h_seg[0], n_large = h_seg[3];
@@ -2254,16 +2297,22 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
                 else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
                 else hipLaunchKernelGGL((k_seg_big<2, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
             }
-            if (n_large) {
-                if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
-                else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
-                else hipLaunchKernelGGL((k_seg_big<2, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+            if (n_large || n_huge) {
+                if (n_large) {
+                    if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                    else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                    else hipLaunchKernelGGL((k_seg_big<2, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                }
+                if (n_huge) {        // segments of a block of more than STAT_N variants (mode 2 has one piece per segment: never)
+                    if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS, true>), dim3(n_huge), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                    else hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS, true>), dim3(n_huge), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                }
                 PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 12, hipMemcpyDeviceToHost, sm));
                 if (int s = sec.wait()) return s;
                 sec.begin();
                 if (h_seg[2]) { overflow = true; break; }
             }
-            res->n_big_segments += n_mid + n_large;
+            res->n_big_segments += n_mid + n_large + n_huge;
         }
         if (!overflow) break;
         if (attempt == 3) return phz_fail(ctx, PHZ_E_NOMEM, "read-set table pool did not converge");
@@ -2292,6 +2341,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     D.vchrom = P<uint16_t>(h->d_vchrom); D.pos = P<int32_t>(h->d_pos);
     auto pool = [&](int i) { PoolD p; p.off = P<uint32_t>(h->p_off[i]); p.b = P<char>(h->p_txt[i]); return p; };
     D.uid = pool(0); D.rsid = pool(1); D.alle = pool(2); D.maft = pool(3); D.chromn = pool(4); D.statt = pool(5);
+    D.statx.off = P<uint32_t>(h->px_off); D.statx.b = P<char>(h->px_txt);
     D.bamn.off = P<uint32_t>(h->bam_off); D.bamn.b = P<char>(h->bam_txt); D.pvt.off = P<uint32_t>(h->pv_off); D.pvt.b = P<char>(h->pv_txt);
     D.mafv = P<double>(h->d_maf); D.is_ref = P<uint8_t>(h->d_isref); D.phase_idx = P<int8_t>(h->d_phase); D.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr;
     D.bam_excl = o->bam_excluded ? P<uint8_t>(h->bam_excl) : nullptr;

@@ -240,17 +240,17 @@ def stub_gpu_stages(eng, saved):
 
 
 # ------------------------------------------------------------------ kernel logic under the host-side HIP emulation (tests/hipemu)
-def emu_library(tally_tile=0, row_wave_min=None):
+def emu_library(tally_tile=0, row_wave_min=None, stat_n=None):
     """ctypes handle of tests/hipemu/_build/libphz_emu.so (built on first use): the translation units of libphz without gfx950
     intrinsics, compiled by g++ against tests/hipemu/hipemu.h.  TEST INFRASTRUCTURE: the product never loads it.
     tally_tile = 256 / 512: the variant whose K_tally works on tiles of that many lines; row_wave_min = 0: the variant whose row stage
-    formats every block row by a wave."""
+    formats every block row by a wave; stat_n: the variant whose row stage treats blocks of more than stat_n variants as "beyond the tables"."""
     import importlib.util
     from phaser_amd import _lib
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
     spec = importlib.util.spec_from_file_location("build_emu", os.path.join(here, "build_emu.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    lib = ctypes.CDLL(mod.build(tally_tile=tally_tile, row_wave_min=row_wave_min))
+    lib = ctypes.CDLL(mod.build(tally_tile=tally_tile, row_wave_min=row_wave_min, stat_n=stat_n))
     for name, (res, args) in _lib.SYMBOLS.items():
         if hasattr(lib, name):
             fn = getattr(lib, name); fn.restype = res; fn.argtypes = args

@@ -13,20 +13,22 @@ LIB = os.path.join(OUT, "libphz_emu.so")
 UNITS = ["phz_api.hip", "phz_tally.hip", "phz_rowsdev.hip", "phz_rows.cpp"]
 
 
-def build(verbose=False, tally_tile=0, row_wave_min=None):
+def build(verbose=False, tally_tile=0, row_wave_min=None, stat_n=None):
     """tally_tile: build the variant libphz_emu_t<N>.so whose K_tally groups tiles of N lines (256 / 512): the small fixtures then
     straddle tiles, which is what sends QNAMEs through the spill path of k_tile.
     row_wave_min: the variant libphz_emu_w<N>.so whose row stage formats the rows of blocks with more than N variants by a wave each
-    (0: every block row, so that the fixtures exercise the wave sinks)"""
+    (0: every block row, so that the fixtures exercise the wave sinks)
+    stat_n: the variant libphz_emu_s<N>.so whose gwStat table and LDS piece arrays cover blocks of up to N variants only (product: 512), so that the
+    fixtures' blocks take the paths of a block beyond them (host-formatted gwStat text, piece arrays in the global pool)"""
     os.makedirs(OUT, exist_ok=True)
     import fcntl
     with open(os.path.join(OUT, ".lock"), "w") as lk:        # pytest-xdist workers build the same files: one at a time
         fcntl.flock(lk, fcntl.LOCK_EX)
-        return _build_locked(verbose, tally_tile, row_wave_min)
+        return _build_locked(verbose, tally_tile, row_wave_min, stat_n)
 
 
-def _build_locked(verbose, tally_tile, row_wave_min):
-    tag = ("_t%d" % tally_tile if tally_tile else "") + ("_w%d" % row_wave_min if row_wave_min is not None else "")
+def _build_locked(verbose, tally_tile, row_wave_min, stat_n=None):
+    tag = ("_t%d" % tally_tile if tally_tile else "") + ("_w%d" % row_wave_min if row_wave_min is not None else "") + ("_s%d" % stat_n if stat_n is not None else "")
     extra = os.environ.get("PHZ_EMU_EXTRA_DEFS", "").split()      # experiment builds: extra -D flags for every unit, e.g. "-DPHZ_TILE_TB=512"
     if extra:
         import hashlib
@@ -37,6 +39,8 @@ def _build_locked(verbose, tally_tile, row_wave_min):
         variant_defs["phz_tally.hip"] = ["-DPHZ_TALLY_TILE=%d" % tally_tile, "-DPHZ_RL_STAGE=8"]      # + a tiny read-list stage: the fallback of k_rl_sort
     if row_wave_min is not None:
         variant_defs["phz_rowsdev.hip"] = ["-DPHZ_ROW_WAVE_MIN=%d" % row_wave_min]
+    if stat_n is not None:
+        variant_defs["phz_rowsdev.hip"] = variant_defs.get("phz_rowsdev.hip", []) + ["-DPHZ_STAT_N=%d" % stat_n]
     hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(REPO, "include", "phz.h"),
                                                                                   os.path.join(HERE, "hipemu.h"), os.path.join(HERE, "hipemu.cpp")]
     newest_hdr = max(os.path.getmtime(h) for h in hdr)
