@@ -1463,7 +1463,8 @@ __global__ __launch_bounds__(256) void k_blk_edges(int64_t nkeep, const uint32_t
 struct BS {
     const uint32_t *mem_s, *blk_mstart, *blk_len; const uint8_t *v_alle; const int8_t *phase_idx; const double *mafv;
     uint8_t *conc, *cormode, *statkind; uint32_t *statidx; int32_t *maxmaf; double *stat; unsigned long long *cfg_rows;
-    uint32_t *big_stat, *big_stat_n;        // (known phases, their sum) of the blocks beyond the gwStat table, slot = the block's statidx; count
+    double *big_stat; uint32_t *big_stat_n;        // gwStat of the blocks whose text the table does not hold (slot = the block's statidx); count
+    int gw_phase_method;                    // 1: MAF-weighted genome-wide phase (:982-1025)
 };
 __global__ __launch_bounds__(256) void k_blk_stats(int64_t nblocks, BS S) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1485,12 +1486,32 @@ __global__ __launch_bounds__(256) void k_blk_stats(int64_t nblocks, BS S) {
     if (nknown > 0) {
         if (!any_nan && all_equal) { kind = 1; stat = 1.0; }
         else {
-            const double m = (double)ksum / (double)nknown;
-            if (m < 0.5) cm = 1; else if (m > 0.5) cm = 2;
-            const double other = 1 - m;
-            stat = m >= other ? m : other;
-            if (nknown <= STAT_N) { kind = 0; idx = (uint32_t)nknown * (STAT_N + 1) + (uint32_t)ksum; }
-            else { kind = 3; idx = atomicAdd(S.big_stat_n, 1u); S.big_stat[2 * idx] = (uint32_t)nknown; S.big_stat[2 * idx + 1] = (uint32_t)ksum; }
+            bool by_mean = true;
+            if (S.gw_phase_method == 1) {
+                // phase_support (:993-1000): the MAFs of the variants with annotated phase 0 / 1 on haplotype A, added up in block order
+                double w0 = 0, w1 = 0;
+                for (uint32_t t = 0; t < n; t++) {
+                    const int64_t g = S.mem_s[m0 + t];
+                    const int p = S.phase_idx[2 * g + S.v_alle[g]];
+                    if (p == 0) w0 += S.mafv[g]; else if (p == 1) w1 += S.mafv[g];
+                }
+                const double sw = w0 + w1;
+                if (sw > 0) {
+                    by_mean = false;
+                    stat = (w0 >= w1 ? w0 : w1) / sw;
+                    if (w0 > w1) cm = 1; else if (w1 > w0) cm = 2;
+                    kind = 3;
+                }
+            }
+            if (by_mean) {
+                const double m = (double)ksum / (double)nknown;
+                if (m < 0.5) cm = 1; else if (m > 0.5) cm = 2;
+                const double other = 1 - m;
+                stat = m >= other ? m : other;
+                if (nknown <= STAT_N) { kind = 0; idx = (uint32_t)nknown * (STAT_N + 1) + (uint32_t)ksum; }
+                else kind = 3;
+            }
+            if (kind == 3) { idx = atomicAdd(S.big_stat_n, 1u); S.big_stat[idx] = stat; }          // text formatted by the host inside the run
         }
     }
     S.conc[b] = all_equal ? 1 : 0; S.cormode[b] = cm; S.statkind[b] = kind; S.statidx[b] = idx; S.maxmaf[b] = (int32_t)best; S.stat[b] = stat;
@@ -2041,7 +2062,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     if (!h->keys_ready) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run without phz_rowsdev_pair_keys");
     h->keys_ready = false;
     if (T.nv != h->nv || T.nb != o->n_bams) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not match (variants / BAMs)");
-    if (o->gw_phase_method != 0) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: --gw_phase_method 1 is formatted by the host stage");
+    if (o->gw_phase_method != 0 && o->gw_phase_method != 1) return phz_fail(ctx, PHZ_E_ARG, "device row stage: gw_phase_method must be 0 or 1");
     if (o->output_read_ids) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: --output_read_ids 1 is formatted by the host stage");
     if (!T.rl_list && T.n_rl) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally carries no list index per read-list entry");
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
@@ -2221,8 +2242,8 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         BS bs; bs.mem_s = P<uint32_t>(h->mem_s); bs.blk_mstart = P<uint32_t>(h->blk_mstart); bs.blk_len = P<uint32_t>(h->blk_len); bs.v_alle = P<uint8_t>(h->v_alle);
         bs.phase_idx = P<int8_t>(h->d_phase); bs.mafv = P<double>(h->d_maf); bs.conc = P<uint8_t>(h->conc); bs.cormode = P<uint8_t>(h->cormode); bs.statkind = P<uint8_t>(h->statkind);
         bs.statidx = P<uint32_t>(h->statidx); bs.maxmaf = P<int32_t>(h->maxmaf); bs.stat = P<double>(h->stat); bs.cfg_rows = P<unsigned long long>(h->cfg_rows);
-        RSV(big_stat, (size_t)(nmem / (STAT_N + 1) + 2) * 8);          // a block beyond the table has more than STAT_N members
-        bs.big_stat = P<uint32_t>(h->big_stat); bs.big_stat_n = cnt32 + 13;
+        RSV(big_stat, (o->gw_phase_method == 1 ? (size_t)nblocks + 2 : (size_t)(nmem / (STAT_N + 1) + 2)) * 8);      // method 0: only blocks beyond the table (more than STAT_N members)
+        bs.big_stat = P<double>(h->big_stat); bs.big_stat_n = cnt32 + 13; bs.gw_phase_method = o->gw_phase_method;
         hipLaunchKernelGGL(k_blk_stats, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, bs);
         hipLaunchKernelGGL(k_block_starts, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, (const uint32_t *)h->blk_mstart.p, (const uint32_t *)h->mem_s.p,
                            (const uint16_t *)h->d_vchrom.p, ss_blocks);
@@ -2240,14 +2261,14 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         if (int s = sec.wait()) return s;
         sec.begin();
         res->phased = (int64_t)h_phased;
-        // gwStat text of the blocks with more known phases than the table covers (:968-980, the same float64 operations): formatted here, a handful per genome at most
+        // gwStat text the table does not hold -- blocks with more known phases than it covers (:968-980), and with --gw_phase_method 1 every block phased by MAF weight (:1002) --: repr() of the float64 the device computed
         if (h_nbs) {
-            std::string xt; std::vector<uint32_t> xo((size_t)h_nbs + 1, 0u), bsv((size_t)h_nbs * 2);
-            PHZ_HIP(ctx, hipMemcpy(bsv.data(), h->big_stat.p, bsv.size() * 4, hipMemcpyDeviceToHost));
+            std::string xt; std::vector<uint32_t> xo((size_t)h_nbs + 1, 0u); std::vector<double> bsv((size_t)h_nbs);
+            PHZ_HIP(ctx, hipMemcpy(bsv.data(), h->big_stat.p, bsv.size() * 8, hipMemcpyDeviceToHost));
+            xt.reserve((size_t)h_nbs * 20);
             for (uint32_t i = 0; i < h_nbs; i++) {
                 xo[i] = (uint32_t)xt.size();
-                const double m = (double)bsv[2 * (size_t)i + 1] / (double)bsv[2 * (size_t)i], ot = 1 - m;
-                phztext::put_pyfloat(xt, m >= ot ? m : ot);
+                phztext::put_pyfloat(xt, bsv[i]);
                 xt += '\n';
             }
             xo[h_nbs] = (uint32_t)xt.size();

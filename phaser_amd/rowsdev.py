@@ -233,7 +233,7 @@ def binom_cdf(k: np.ndarray, n: np.ndarray, p: float) -> np.ndarray:
 
 
 def supported(cfg) -> bool:
-    return cfg.gw_phase_method == 0 and cfg.output_read_ids == 0
+    return cfg.output_read_ids == 0          # --output_read_ids 1 (QNAME strings in the rows, a debugging aid) is the one option left to the host stage
 
 
 def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:

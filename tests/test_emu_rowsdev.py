@@ -64,7 +64,7 @@ def _inputs(case, gold, c1_inputs):
 def test_device_rows_match_reference(emu, case, gold, load, cfg, c1_inputs):
     d, vcf_text, bams = _inputs(case, gold, c1_inputs)
     out, eng = run_stages(emu, case, load, cfg, vcf_text, bams)
-    declined = cfg.get("gw_phase_method", 0) == 1 or cfg.get("output_read_ids", 0) == 1
+    declined = cfg.get("output_read_ids", 0) == 1
     assert eng.rows_path == ("host" if declined else "device"), getattr(eng, "rows_fallback", "")
     for name in OUTPUTS:
         want = gz_text(os.path.join(d, "out.%s.txt.gz" % name))
