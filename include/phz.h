@@ -669,6 +669,13 @@ int phz_vcf_phase_text(const char *text, int64_t len, int32_t sample_column, con
  * measured against (bench.py roofline.issue).  n_cu / clock_mhz: compute units and reported engine clock of the device. */
 int phz_microbench(phz_ctx *ctx, int kind, int waves_per_simd, int iters, double *wave_insts_per_s, int *n_cu, int *clock_mhz);
 
+/* Self-test of the library's device radix sort (stable LSD sort of (key, value) pairs over bit ranges; one launch per pass with decoupled look-back,
+ * or the three-launch passes it replaced with three_launch = 1): host arrays in and out, keys of key_bytes = 4 or 8, ranges = nranges x [lo, hi) bit
+ * ranges, least significant range first.  The row stage's ordering rules (phaser.py:1271-1283, :1310, :1870, :1884-1887) rest on it; the tests
+ * compare it with a stable host sort.  No reference counterpart. */
+int phz_selftest_sort(phz_ctx *ctx, int key_bytes, const void *keys, const uint32_t *vals, int64_t n, const int32_t *ranges, int nranges, int three_launch,
+                      void *keys_out, uint32_t *vals_out);
+
 /* Memory-side calibration (gfx950, round 5): one launch of an access pattern with a KNOWN byte count, for calibrating rocprofv3's FETCH_SIZE /
  * WRITE_SIZE on the patterns K_map uses (tools/prof_calib.sh; bench.py roofline.traffic applies the measured factors).  kind 0 / 1: coalesced
  * stream of 4 / 16 bytes per lane over the array; 2 / 3: ONE 1-byte load per `unit`-byte unit of the array (32..512), always inside the unit's

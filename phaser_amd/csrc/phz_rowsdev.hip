@@ -1868,18 +1868,17 @@ struct Sections {
     }
 };
 
-// sort `n` (key, value) pairs living in (ka, va) with scratch (kb, vb); the sorted values are copied to `dst_val` (and keys to dst_key if given)
+// sort `n` (key, value) pairs living in (ka, va) with scratch (kb, vb); the sorted values land in `dst_val` (and the keys in dst_key if given): the last
+// pass of the one-launch-per-pass sort writes there directly
 template <class K>
 int sort_into(phz_ctx *ctx, phz_rowsdev *h, DevBuf &ka, DevBuf &kb, int64_t n, const int (*ranges)[2], int nranges, uint32_t *dst_val, K *dst_key) {
     K *k0 = P<K>(ka), *k1 = P<K>(kb); uint32_t *v0 = P<uint32_t>(h->v32a), *v1 = P<uint32_t>(h->v32b);
-    for (int r = 0; r < nranges; r++) {
-        int where = 0;
-        if (int s = radix_sort_pairs<K, uint32_t>(ctx, k0, k1, v0, v1, n, ranges[r][0], ranges[r][1], h->sort_cnt, h->scan_tmp, &where)) return s;
-        if (where) { std::swap(k0, k1); std::swap(v0, v1); }
-    }
-    if (n > 0) {
-        PHZ_HIP(ctx, hipMemcpyAsync(dst_val, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        if (dst_key) PHZ_HIP(ctx, hipMemcpyAsync(dst_key, k0, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream));
+    int where = 0;
+    if (int s = radix_sort_ranges<K, uint32_t>(ctx, k0, k1, v0, v1, n, ranges, nranges, h->sort_cnt, h->scan_tmp, &where, dst_val, dst_key)) return s;
+    if (where != 2 && n > 0) {           // nothing to sort (n <= 1 or no significant bits): the input order is the result
+        const K *ks = where ? k1 : k0; const uint32_t *vs = where ? v1 : v0;
+        PHZ_HIP(ctx, hipMemcpyAsync(dst_val, vs, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (dst_key) PHZ_HIP(ctx, hipMemcpyAsync(dst_key, ks, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream));
     }
     return PHZ_OK;
 }
@@ -2492,6 +2491,34 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     res->gpu_ms = sec.ms;
     ctx->last_ms[PHZ_T_ROWS] = (float)sec.ms; ctx->total_ms[PHZ_T_ROWS] += sec.ms; ctx->launches[PHZ_T_ROWS]++;
     return PHZ_OK;
+}
+
+// Self-test entry of the device radix sort (phz_sort.h): sorts n host (key, value) pairs by the given bit ranges with the one-launch-per-pass sort
+// (three_launch = 0) or the three-launch passes (1) and returns keys and values in sorted order.  Used by the tests (GPU and emulation) against a
+// stable host sort; no reference counterpart.
+extern "C" int phz_selftest_sort(phz_ctx *ctx, int key_bytes, const void *keys, const uint32_t *vals, int64_t n, const int32_t *ranges, int nranges, int three_launch,
+                                 void *keys_out, uint32_t *vals_out) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || (key_bytes != 4 && key_bytes != 8) || n < 0 || nranges < 1 || nranges > 4 || !ranges || (n && (!keys || !vals || !keys_out || !vals_out))) return PHZ_E_ARG;
+    if (!n) return PHZ_OK;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d[6];
+    auto fin = [&](int code) { for (DevBuf &b : d) if (b.p) (void)hipFree(b.p); return code; };
+    int st = PHZ_OK;
+    const size_t kb = (size_t)n * (size_t)key_bytes, vb = (size_t)n * 4;
+    if ((st = up(ctx, d[0], keys, kb)) || (st = phz_reserve(ctx, d[1], kb)) || (st = up(ctx, d[2], vals, vb)) || (st = phz_reserve(ctx, d[3], vb))) return fin(st);
+    int rg[4][2];
+    for (int r = 0; r < nranges; r++) { rg[r][0] = ranges[2 * r]; rg[r][1] = ranges[2 * r + 1]; }
+    int where = 0;
+    if (three_launch) setenv("PHZ_SORT_THREE_LAUNCH", "1", 1);
+    if (key_bytes == 4) st = radix_sort_ranges<uint32_t, uint32_t>(ctx, P<uint32_t>(d[0]), P<uint32_t>(d[1]), P<uint32_t>(d[2]), P<uint32_t>(d[3]), n, rg, nranges, d[4], d[5], &where);
+    else st = radix_sort_ranges<unsigned long long, uint32_t>(ctx, P<unsigned long long>(d[0]), P<unsigned long long>(d[1]), P<uint32_t>(d[2]), P<uint32_t>(d[3]), n, rg, nranges, d[4], d[5], &where);
+    if (three_launch) unsetenv("PHZ_SORT_THREE_LAUNCH");
+    if (st != PHZ_OK) return fin(st);
+    hipError_t e = hipMemcpyAsync(keys_out, where ? d[1].p : d[0].p, kb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(vals_out, where ? d[3].p : d[2].p, vb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    return fin(e == hipSuccess ? PHZ_OK : phz_fail(ctx, PHZ_E_HIP, "phz_selftest_sort", e));
 }
 
 // copy one finished text (PHZ_TXT_*) to host memory (page-locked memory gives the full PCIe rate)

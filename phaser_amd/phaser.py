@@ -92,6 +92,9 @@ def load_bed(path: str) -> List[tuple]:
     return iv
 
 
+LAST_STAGE_SECONDS = {}          # stage name -> seconds of the last main() of this process (rank 0): read by bench.py's end_to_end_files entry
+
+
 def main(argv=None):
     """The CLI.  Whatever way it ends (result, fatal_error, exception), a BAM prefetch still running on its helper thread is waited for:
     the interpreter must not start tearing down with GPU work of ours in flight."""
@@ -165,7 +168,7 @@ def _main(argv, state):
     # the host region that will receive the row text is page-locked on a helper thread while the VCF is read (~0.1 s per GB, independent of
     # everything else); sized from the BAMs, grown later if it turns out too small
     arena = None
-    if args.output_read_ids == 0 and args.gw_phase_method == 0 and not any(b.endswith(".sam") for b in args.bam.split(",")):
+    if args.output_read_ids == 0 and not any(b.endswith(".sam") for b in args.bam.split(",")):
         import threading
 
         def _arena():
@@ -431,6 +434,9 @@ def _main(argv, state):
             say("     GENOME WIDE PHASE CORRECTED  %d of %d variants (= %f)" % (pc, vs.het_count, float(pc) / float(vs.het_count)))
         say('')
         say("The End.")
+        global LAST_STAGE_SECONDS
+        LAST_STAGE_SECONDS = {name: t - t_prev for (_, t_prev), (name, t) in zip(marks[:-1], marks[1:])}
+        LAST_STAGE_SECONDS["total"] = marks[-1][1] - marks[0][1]
         if os.environ.get("PHZ_TIMING"):
             for (_, t_prev), (name, t) in zip(marks[:-1], marks[1:]):
                 sys.stderr.write("[phz timing] %-55s %7.2f s\n" % (name, t - t_prev))

@@ -275,7 +275,7 @@ def test_block_and_component_beyond_the_device_tables(mapper, oracle_build, tmp_
     got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs)
     assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
     assert eng.stats.get("rowsdev_n_exceptions", 0) >= 1, eng.stats                 # the component went through the host phase_v3 inside the device stage
-    assert eng.stats.get("rowsdev_n_pair_table_growths", 0) >= 1
+    assert err == 0.0 or eng.stats.get("rowsdev_n_pair_table_growths", 0) >= 1       # (without base errors no pair has conflicting reads: nothing to test, no key)
     sizes = [int(l.split("\t")[4]) for l in got["haplotypes"].split("\n")[1:] if l]
     if err == 0.0:
         assert max(sizes) > 512, max(sizes)                                             # one block beyond the tables
@@ -600,3 +600,31 @@ def test_as_histogram_sparse_equals_dense(mapper):
         assert st == _lib.PHZ_E_CAPACITY and k.value == len(nz)
     st = ctx.lib.phz_as_histogram_sparse(ctx.h, arr, 2, 64, C.c_void_p(bins.ctypes.data), C.c_void_p(counts.ctypes.data), C.byref(k))
     assert st == _lib.PHZ_E_CAPACITY and k.value == len(nz)
+
+
+@pytest.mark.parametrize("dtype,ranges,n", [("uint32", [(0, 21)], 1_500_000), ("uint64", [(0, 21), (32, 54)], 1_460_000), ("uint32", [(0, 32)], 3_000_001), ("uint64", [(0, 40)], 70_000),
+                                             ("uint32", [(0, 18)], 5)])
+def test_device_sort_matches_a_stable_host_sort(mapper, dtype, ranges, n):
+    """The radix sort behind the row stage's ordering rules (phz_sort.h: one launch per pass, tiles of 4,096 keys in ticket order, decoupled look-back over the
+    tiles' digit counts) at the sizes of a genome's passes (1.5 M variants, 1.46 M pairs), on the GPU: equal to numpy's stable sort and to the three-launch
+    passes it replaced.  Hundreds of tiles really run concurrently here, which the emulation (tests/test_emu_sort.py) cannot show."""
+    import ctypes as C
+    ctx = mapper.ctx
+    rng = np.random.default_rng(23)
+    mask = 0
+    for lo_, hi_ in ranges:
+        mask |= ((1 << (hi_ - lo_)) - 1) << lo_
+    keys = (rng.integers(0, 1 << 62, size=n, dtype=np.uint64) & np.uint64(mask)).astype(dtype)
+    keys[rng.integers(0, n, n // 4)] = keys[0]
+    vals = np.arange(n, dtype=np.uint32)
+    order = np.arange(n)
+    for lo_, hi_ in ranges:
+        d = (keys[order].astype(np.uint64) >> np.uint64(lo_)) & np.uint64((1 << (hi_ - lo_)) - 1)
+        order = order[np.argsort(d, kind="stable")]
+    rg = np.asarray(ranges, dtype=np.int32).reshape(-1)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    for three in (0, 1):
+        for rep in range(3 if three == 0 else 1):
+            ko = np.empty_like(keys); vo = np.empty_like(vals)
+            ctx.check(ctx.lib.phz_selftest_sort(ctx.h, keys.dtype.itemsize, vp(keys), vp(vals), n, vp(rg), len(ranges), three, vp(ko), vp(vo)))
+            assert np.array_equal(vo, vals[order]) and np.array_equal(ko, keys[order]), (three, rep)
