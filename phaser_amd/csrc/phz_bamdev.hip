@@ -527,11 +527,13 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     (void)hipEventRecord(e0, sm);
     int st = PHZ_OK;
     std::vector<hipEvent_t> evs;
-    // Registration of the mapped file's needed span with the runtime (PHZ_BAM_REGISTER=0: the staging path): page-aligned, covering every run
+    // PHZ_BAM_REGISTER=1 (experiment, off by default): the mapped file's needed span registered with the runtime, DMA straight out of the page cache.  The
+    // copies then run at PCIe speed without host threads (212 against 241 ms for copy + K_inflate of a 3.8 GB BAM), but faulting the mapping's 930,000 pages
+    // into the page table costs 177 ms up front (profiles/r05/bam_device_sweep.txt): pread into page-locked staging never maps them and stays the default
     bool reg_ok = false; void *reg_p = nullptr;
     {
         const char *e = getenv("PHZ_BAM_REGISTER");
-        if (!(e && atoi(e) == 0) && !runs.empty() && plan.file) {
+        if (e && atoi(e) == 1 && !runs.empty() && plan.file) {
             const uint64_t r0 = runs.front().first & ~(uint64_t)4095;
             uint64_t r1 = (runs.back().second + 4095) & ~(uint64_t)4095;
             if (r1 > ((plan.file_size + 4095) & ~(uint64_t)4095)) r1 = (plan.file_size + 4095) & ~(uint64_t)4095;
@@ -549,10 +551,18 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     hipEvent_t stage_ev[NCOPY_MAX * 2];
     for (auto &e : stage_ev) e = nullptr;
     for (int t = 0; t < NCOPY * 2; t++) if (stage_ok && hipEventCreateWithFlags(&stage_ev[t], hipEventDisableTiming) != hipSuccess) stage_ev[t] = nullptr;
+    int n_is = 3, n_launch = 0;
+    { const char *e = getenv("PHZ_BAM_INFLATE_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= 8) n_is = atoi(e); }
+    std::vector<hipStream_t> is((size_t)n_is, nullptr);
+    if (n_is > 1) {
+        (void)hipStreamSynchronize(sm);                  // the member table and the cleared status word are on the device before any other stream reads them
+        for (int t = 0; t < n_is; t++) if (hipStreamCreateWithFlags(&is[(size_t)t], hipStreamNonBlocking) != hipSuccess) { is[(size_t)t] = nullptr; n_is = 1; }
+    }
     {
-        // a launch needs ~100,000 members to fill the chip (a lane takes ~60 ms for its member however few there are): big chunks
+        // one launch alone needs ~100,000 members to fill the chip (a lane takes ~60 ms for its member however few there are); with the launches overlapping
+        // on several streams the chunks can be smaller, which starts the first K_inflate earlier (PHZ_BAM_CHUNK_MB, default 512)
         const char *ch_env = getenv("PHZ_BAM_CHUNK_MB");
-        const uint64_t CH = (ch_env && atoll(ch_env) > 0 ? (uint64_t)atoll(ch_env) : 1280ull) << 20;
+        const uint64_t CH = (ch_env && atoll(ch_env) > 0 ? (uint64_t)atoll(ch_env) : (n_is > 1 ? 512ull : 1280ull)) << 20;
         size_t ri = 0, i0 = 0;
         while (i0 < plan.members.size() && st == PHZ_OK) {
             while (ri + 1 < runs.size() && plan.members[i0].src >= runs[ri].second) ri++;
@@ -618,11 +628,16 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
                 if (st != PHZ_OK) break;
                 }
             }
+            // K_inflate launches take turns on PHZ_BAM_INFLATE_STREAMS streams (default 3): a launch lives as long as its slowest lanes (~60 ms for a 64 KB
+            // member however few are left), so the next chunk's members start on the CUs the current launch's tail leaves idle instead of queueing behind it
+            hipStream_t si = n_is > 1 ? is[(size_t)(n_launch % n_is)] : sm;
             st = phz_inflate_launch(ctx, (const uint8_t *)d_comp, (const phz_bgzf_member *)d_mem, (int64_t)i0, (int64_t)(i1 - i0), (uint8_t *)h->d_stream,
-                                    (uint8_t *)ctx->scratch[11].p, d_status, sm);
+                                    (uint8_t *)ctx->scratch[11].p, d_status, si);
+            n_launch++;
             i0 = i1;
         }
     }
+    for (int t = 0; t < n_is; t++) if (is[(size_t)t]) { (void)hipStreamSynchronize(is[(size_t)t]); (void)hipStreamDestroy(is[(size_t)t]); }
     (void)hipEventRecord(e1, sm);
     int bad = 0;
     (void)hipMemcpyAsync(&bad, d_status, 4, hipMemcpyDeviceToHost, sm);

@@ -356,13 +356,25 @@ template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(con
         __hip_atomic_store(mine, (tile == 0 ? OS_PREFIX : OS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
         if (tile > 0) {
+            // eight predecessors per round trip (independent loads), consumed nearest first up to the first one that has not published yet or that knows
+            // its prefix: all tiles of a small sort start together, so most predecessors hold an aggregate only and a one-word-at-a-time walk
+            // would be hundreds of dependent loads
             int64_t t = (int64_t)tile - 1;
-            for (;;) {
-                const uint32_t w = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((w >> 30) == 0u) { __builtin_amdgcn_s_sleep(1); continue; }           // that tile has its ticket and will publish without waiting for anybody
-                excl += w & OS_VALUE;
-                if (w & OS_PREFIX) break;
-                t--;
+            bool done = false;
+            while (!done) {
+                uint32_t w[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) w[j] = t - j >= 0 ? __hip_atomic_load(status + (size_t)(t - j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREFIX;
+                int used = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (done || used != j) continue;                 // stopped at an earlier word of this batch
+                    if ((w[j] >> 30) == 0u) continue;                // that tile has its ticket and will publish without waiting for anybody: ask again
+                    excl += w[j] & OS_VALUE; used = j + 1;
+                    if (w[j] & OS_PREFIX) done = true;
+                }
+                t -= used;
+                if (!used) __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(mine, OS_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
