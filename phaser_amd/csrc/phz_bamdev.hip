@@ -551,7 +551,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     hipEvent_t stage_ev[NCOPY_MAX * 2];
     for (auto &e : stage_ev) e = nullptr;
     for (int t = 0; t < NCOPY * 2; t++) if (stage_ok && hipEventCreateWithFlags(&stage_ev[t], hipEventDisableTiming) != hipSuccess) stage_ev[t] = nullptr;
-    int n_is = 3, n_launch = 0;
+    int n_is = 1, n_launch = 0;
     { const char *e = getenv("PHZ_BAM_INFLATE_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= 8) n_is = atoi(e); }
     std::vector<hipStream_t> is((size_t)n_is, nullptr);
     if (n_is > 1) {
@@ -559,10 +559,9 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
         for (int t = 0; t < n_is; t++) if (hipStreamCreateWithFlags(&is[(size_t)t], hipStreamNonBlocking) != hipSuccess) { is[(size_t)t] = nullptr; n_is = 1; }
     }
     {
-        // one launch alone needs ~100,000 members to fill the chip (a lane takes ~60 ms for its member however few there are); with the launches overlapping
-        // on several streams the chunks can be smaller, which starts the first K_inflate earlier (PHZ_BAM_CHUNK_MB, default 512)
+        // a launch needs ~100,000 members to fill the chip (a lane takes ~60 ms for its member however few there are): big chunks (PHZ_BAM_CHUNK_MB, default 1280)
         const char *ch_env = getenv("PHZ_BAM_CHUNK_MB");
-        const uint64_t CH = (ch_env && atoll(ch_env) > 0 ? (uint64_t)atoll(ch_env) : (n_is > 1 ? 512ull : 1280ull)) << 20;
+        const uint64_t CH = (ch_env && atoll(ch_env) > 0 ? (uint64_t)atoll(ch_env) : 1280ull) << 20;
         size_t ri = 0, i0 = 0;
         while (i0 < plan.members.size() && st == PHZ_OK) {
             while (ri + 1 < runs.size() && plan.members[i0].src >= runs[ri].second) ri++;
@@ -628,8 +627,9 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
                 if (st != PHZ_OK) break;
                 }
             }
-            // K_inflate launches take turns on PHZ_BAM_INFLATE_STREAMS streams (default 3): a launch lives as long as its slowest lanes (~60 ms for a 64 KB
-            // member however few are left), so the next chunk's members start on the CUs the current launch's tail leaves idle instead of queueing behind it
+            // PHZ_BAM_INFLATE_STREAMS > 1 (experiment, default 1): the K_inflate launches take turns on several streams so that a chunk's members could start on
+            // the CUs the previous launch's tail leaves idle.  Measured (profiles/r05/bam_device_sweep.txt): no gain at 1,280 MB chunks (245 against 241 ms),
+            // and smaller chunks lose (640 MB: 327 ms) -- every launch pays the ~60 ms a lane needs for its member, however many launches overlap
             hipStream_t si = n_is > 1 ? is[(size_t)(n_launch % n_is)] : sm;
             st = phz_inflate_launch(ctx, (const uint8_t *)d_comp, (const phz_bgzf_member *)d_mem, (int64_t)i0, (int64_t)(i1 - i0), (uint8_t *)h->d_stream,
                                     (uint8_t *)ctx->scratch[11].p, d_status, si);

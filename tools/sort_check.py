@@ -15,6 +15,8 @@ for dtype, ranges in (("uint32", [(0, 21)]), ("uint64", [(0, 21), (32, 54)]), ("
         for lo_, hi_ in ranges:
             mask |= ((1 << (hi_ - lo_)) - 1) << lo_
         keys = (rng.integers(0, 1 << 62, size=n, dtype=np.uint64) & np.uint64(mask)).astype(dtype)
+        if n >= 100_000:
+            keys[rng.integers(0, n, n // 4)] = keys[0]          # a quarter of the keys equal: one digit carries most of every tile
         vals = np.arange(n, dtype=np.uint32)
         order = np.arange(n)
         for lo_, hi_ in ranges:
