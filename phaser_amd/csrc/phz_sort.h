@@ -300,14 +300,34 @@ constexpr int OS_WAVES = 4, OS_TILE = OS_WAVES * RS_TILE, OS_MAXPASS = 8;
 constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_VALUE = (1u << 30) - 1u;
 struct OsShifts { int n; int shift[OS_MAXPASS]; };
 
+// lanes of the wave that hold the same 8-bit digit as this lane (among the `valid` ones): eight ballots
+__device__ __forceinline__ unsigned long long os_peers(uint32_t d, bool valid) {
+    unsigned long long peers = __ballot(valid ? 1 : 0);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const unsigned long long m = __ballot((int)((d >> b) & 1u));
+        peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    return peers;
+}
+// (a plain `atomicAdd(&s_h[digit], 1)` per key was 40 us per sort: the high digits of these keys are nearly constant, so all 256 threads of a workgroup
+//  queued on one LDS word; now the lowest lane of every group of equal digits adds the group's size)
 template <class K> __global__ __launch_bounds__(256) void k_os_hist(const K *keys, int64_t n, OsShifts sh, uint32_t *ghist) {
     __shared__ uint32_t s_h[OS_MAXPASS * 256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (int j = tid; j < sh.n * 256; j += 256) s_h[j] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
-        const K k = keys[i];
-        for (int p = 0; p < sh.n; p++) atomicAdd(&s_h[p * 256 + ((uint32_t)(k >> sh.shift[p]) & 255u)], 1u);
+    const int64_t rounds = (n + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);          // the same trip count for every lane: the ballots need whole waves
+    for (int64_t q = 0; q < rounds; q++) {
+        const int64_t i = (q * gridDim.x + blockIdx.x) * 256 + tid;
+        const bool valid = i < n;
+        const K k = valid ? keys[i] : (K)0;
+        for (int p = 0; p < sh.n; p++) {
+            const uint32_t d = (uint32_t)(k >> sh.shift[p]) & 255u;
+            const unsigned long long peers = os_peers(d, valid);
+            if (valid && (peers & below) == 0ull) atomicAdd(&s_h[p * 256 + d], (uint32_t)__popcll(peers));
+        }
     }
     __syncthreads();
     for (int j = tid; j < sh.n * 256; j += 256) if (s_h[j]) atomicAdd(&ghist[j], s_h[j]);
@@ -325,9 +345,17 @@ __global__ __launch_bounds__(256) void k_os_bases(uint32_t *ghist) {
     for (int w = 0; w < wave; w++) before += s_w[w];
     h[tid] = before + incl - v;
 }
+// wave-level ordering point between LDS accesses of different lanes of ONE wave: the hardware executes a wave's LDS instructions in order, so the compiler
+// barrier is all that is needed; the emulation (a fiber per lane) needs a rendezvous
+#ifdef HIPEMU_H
+#define PHZ_WAVE_SYNC() ((void)__ballot(1))
+#else
+#define PHZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(const K *kin, const V *vin, K *kout, V *vout, int64_t n, int shift, const uint32_t *base,
                                                                             uint32_t *status, uint32_t *ticket) {
-    __shared__ uint32_t s_cnt[OS_WAVES][256];          // per-wave digit counts, then the wave's running cursor inside the tile's stretch of a digit
+    __shared__ uint32_t s_cnt[OS_WAVES][256];          // per-wave digit counts (built row by row: a key's place among its wave's keys of that digit), then the
+                                                       // wave's offset inside the tile's stretch of the digit
     __shared__ uint32_t s_base[256];                   // output position of the tile's first key of a digit
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,8 +372,20 @@ template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(con
         const int64_t i = wbase + r * 64 + lane;
         rk[r] = i < n ? kin[i] : (K)0; rv[r] = i < n ? vin[i] : (V)0;
     }
+    // place of every key among the keys of its wave with the same digit (stable: rows in order, lanes in order inside a row), without atomics: the lanes of a
+    // row that share a digit read the wave's running count, the lowest of them adds the group's size
+    uint32_t off[RS_ROWS];
 #pragma unroll
-    for (int r = 0; r < RS_ROWS; r++) if (wbase + r * 64 + lane < n) atomicAdd(&s_cnt[wave][(uint32_t)(rk[r] >> shift) & 255u], 1u);
+    for (int r = 0; r < RS_ROWS; r++) {
+        const bool valid = wbase + r * 64 + lane < n;
+        const uint32_t d = (uint32_t)(rk[r] >> shift) & 255u;
+        const unsigned long long peers = os_peers(d, valid);
+        const uint32_t before = s_cnt[wave][d];
+        off[r] = before + (uint32_t)__popcll(peers & below);
+        PHZ_WAVE_SYNC();
+        if (valid && (peers & below) == 0ull) s_cnt[wave][d] = before + (uint32_t)__popcll(peers);
+        PHZ_WAVE_SYNC();
+    }
     __syncthreads();
     {
         // thread d: digit d of this tile -- counts of the waves -> exclusive offsets, publish, look back
@@ -383,22 +423,12 @@ template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(con
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
-        const int64_t i = wbase + r * 64 + lane;
-        const bool valid = i < n;
-        const K k = rk[r];
-        const uint32_t d = (uint32_t)(k >> shift) & 255u;
-        unsigned long long peers = __ballot(valid ? 1 : 0);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const unsigned long long m = __ballot((int)((d >> b) & 1u));
-            peers &= ((d >> b) & 1u) ? m : ~m;
+        if (wbase + r * 64 + lane < n) {
+            const K k = rk[r];
+            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t pos = s_base[d] + s_cnt[wave][d] + off[r];
+            kout[pos] = k; vout[pos] = rv[r];
         }
-        const int rank = __popcll(peers & below);
-        const uint32_t pos = valid ? s_base[d] + s_cnt[wave][d] + (uint32_t)rank : 0u;
-        __syncthreads();                                                       // (the cursors are per wave; a workgroup barrier keeps the emulation's lanes in step too)
-        if (valid && rank == 0) s_cnt[wave][d] += (uint32_t)__popcll(peers);      // the lowest lane of every digit group moves the wave's cursor of that digit
-        __syncthreads();
-        if (valid) { kout[pos] = k; vout[pos] = rv[r]; }
     }
 }
 

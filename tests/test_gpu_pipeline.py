@@ -4,6 +4,7 @@ import json
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
