@@ -296,7 +296,7 @@ int radix_sort_pairs(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, int bi
 // the status words of their predecessors -- thread d follows digit d's chain, a wave reads 64 consecutive words per step -- until a tile that
 // already knows its inclusive prefix (decoupled look-back; tickets make every predecessor a tile that has started).  A status word =
 // state:2 | count:30 (n < 2^30), zeroed once per sort for all its passes.  The last pass writes straight into the caller's arrays.
-constexpr int OS_WAVES = 4, OS_TILE = OS_WAVES * RS_TILE, OS_MAXPASS = 8;
+constexpr int OS_WAVES = 4, OS_TILE = OS_WAVES * RS_TILE, OS_MAXPASS = 8, OS_LOOK = 32;
 constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_VALUE = (1u << 30) - 1u;
 struct OsShifts { int n; int shift[OS_MAXPASS]; };
 
@@ -396,18 +396,18 @@ template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(con
         __hip_atomic_store(mine, (tile == 0 ? OS_PREFIX : OS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
         if (tile > 0) {
-            // eight predecessors per round trip (independent loads), consumed nearest first up to the first one that has not published yet or that knows
-            // its prefix: all tiles of a small sort start together, so most predecessors hold an aggregate only and a one-word-at-a-time walk
-            // would be hundreds of dependent loads
+            // OS_LOOK predecessors per round trip (independent loads), consumed nearest first up to the first one that has not published yet or that knows
+            // its prefix.  All tiles of a small sort start together, so most predecessors hold an aggregate only: tile t meets a resolved tile about t / 2
+            // tiles back, i.e. after t / (2 OS_LOOK) round trips -- one word at a time that was hundreds of dependent loads, eight at a time still 22 us per pass
             int64_t t = (int64_t)tile - 1;
             bool done = false;
             while (!done) {
-                uint32_t w[8];
+                uint32_t w[OS_LOOK];
 #pragma unroll
-                for (int j = 0; j < 8; j++) w[j] = t - j >= 0 ? __hip_atomic_load(status + (size_t)(t - j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREFIX;
+                for (int j = 0; j < OS_LOOK; j++) w[j] = t - j >= 0 ? __hip_atomic_load(status + (size_t)(t - j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREFIX;
                 int used = 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < OS_LOOK; j++) {
                     if (done || used != j) continue;                 // stopped at an earlier word of this batch
                     if ((w[j] >> 30) == 0u) continue;                // that tile has its ticket and will publish without waiting for anybody: ask again
                     excl += w[j] & OS_VALUE; used = j + 1;
@@ -463,7 +463,9 @@ int radix_sort_ranges(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, const
     uint32_t *ghist = (uint32_t *)cnt.p, *tickets = ghist + OS_MAXPASS * 256, *status = ghist + hist_words;
     PHZ_HIP(ctx, hipMemsetAsync(cnt.p, 0, (hist_words + status_words) * 4, sm));
     int cus = 256;
-    hipLaunchKernelGGL((k_os_hist<K>), dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)cus * 8)), dim3(256), 0, sm, (const K *)k0, n, sh, ghist);
+    // (256 workgroups at most: every workgroup ends with one global atomic per (pass, digit) -- 2,048 workgroups queueing on the same 768 words was most of this
+    //  kernel's 37 us)
+    hipLaunchKernelGGL((k_os_hist<K>), dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)cus)), dim3(256), 0, sm, (const K *)k0, n, sh, ghist);
     hipLaunchKernelGGL(k_os_bases, dim3((unsigned)sh.n), dim3(256), 0, sm, ghist);
     K *ka = k0, *kb = k1; V *va = v0, *vb = v1;
     for (int p = 0; p < sh.n; p++) {
