@@ -296,7 +296,7 @@ int radix_sort_pairs(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, int bi
 // the status words of their predecessors -- thread d follows digit d's chain, a wave reads 64 consecutive words per step -- until a tile that
 // already knows its inclusive prefix (decoupled look-back; tickets make every predecessor a tile that has started).  A status word =
 // state:2 | count:30 (n < 2^30), zeroed once per sort for all its passes.  The last pass writes straight into the caller's arrays.
-constexpr int OS_WAVES = 4, OS_TILE = OS_WAVES * RS_TILE, OS_MAXPASS = 8, OS_LOOK = 32;
+constexpr int OS_WAVES = 4, OS_TILE = OS_WAVES * RS_TILE, OS_MAXPASS = 8, OS_LOOK = 8;
 constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_VALUE = (1u << 30) - 1u;
 struct OsShifts { int n; int shift[OS_MAXPASS]; };
 
@@ -398,7 +398,8 @@ template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(con
         if (tile > 0) {
             // OS_LOOK predecessors per round trip (independent loads), consumed nearest first up to the first one that has not published yet or that knows
             // its prefix.  All tiles of a small sort start together, so most predecessors hold an aggregate only: tile t meets a resolved tile about t / 2
-            // tiles back, i.e. after t / (2 OS_LOOK) round trips -- one word at a time that was hundreds of dependent loads, eight at a time still 22 us per pass
+            // tiles back, i.e. after t / (2 OS_LOOK) round trips (one word at a time that was hundreds of dependent loads).  Measured on a genome's six ordering
+            // sorts: 8 words per step 25 passes = 598 us, 32 words 690 us -- the look-back's own L2 traffic (tiles x 256 digits x words) is what a pass pays for
             int64_t t = (int64_t)tile - 1;
             bool done = false;
             while (!done) {
