@@ -61,7 +61,8 @@ struct phz_ctx {
         uint8_t *linked = nullptr, *line_cls = nullptr;
     } tally;
     int map_tile_reads = 0;
-    int map_slot_cap = 0;      // calls per tile slot of K_map's staging area (grown on demand)
+    int map_slot_cap = 0;      // calls per tile slot of K_map's staging area
+    int64_t map_ovf_cap = 0;   // calls the overflow area behind the slots holds (grown to what the densest submission needed)
 };
 
 struct PhzEnter {

@@ -91,6 +91,9 @@ struct MapBatch {
     int slot_cap, dbg;
     int64_t ntiles;
     unsigned long long *prof;     // PHZ_MAP_DBG bit 2048 (profiling build of the kernel only): 8 clock stamps per tile
+    // overflow area of the staging slots: a tile with more calls than slot_cap takes a stretch of [ovf_base, ovf_base + ovf_cap) (slot indices of the same
+    // stage / side arrays) with one cursor step and leaves its first slot in tile_ovf[tile] (-1: the area was too small; the host redoes the batch)
+    long long *tile_ovf; unsigned long long *ovf_cursor; long long ovf_base, ovf_cap;
 };
 
 __device__ __forceinline__ int shard_of(const int64_t *tile0, int n_shards, int64_t T) {
@@ -707,7 +710,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             if (sy != 4) { vmask_[k] |= 1u << o; codes_[k] |= (uint32_t)(sy < 4 ? sy : 4) << (4 * o); }
         }
     }
-    const int64_t slot0 = gtile * (int64_t)a.slot_cap;
+    int64_t slot0 = gtile * (int64_t)a.slot_cap;
+    int slot_n = a.slot_cap;               // calls the tile's stretch of the staging area holds
     int cnt[RPT], off[RPT];
     if (!fb) {
         // ---- phase 2b: resolve the buffered candidates with all lanes gathering at once
@@ -754,6 +758,19 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     __syncthreads();
     PHZ_STAMP(6);
     if (a.dbg & 2) return;
+    if (T > a.slot_cap) {
+        // a tile denser than a slot (block-uniform test): its calls go to the overflow area -- the slots are sized for the typical tile, not for the densest of a
+        // submission (a deep sample with one dense region would have cost tiles x densest x 16 bytes of staging)
+        if (tid == 0) {
+            const unsigned long long at = atomicAdd(bt.ovf_cursor, (unsigned long long)T);
+            const long long first = at + (unsigned long long)T <= (unsigned long long)bt.ovf_cap ? bt.ovf_base + (long long)at : -1ll;
+            bt.tile_ovf[gtile] = first;
+            s_wsum[0][0] = (int)(uint32_t)(unsigned long long)first; s_wsum[0][1] = (int)(uint32_t)((unsigned long long)first >> 32);       // (free since the scan's barrier)
+        }
+        __syncthreads();
+        const long long first = (long long)(((unsigned long long)(uint32_t)s_wsum[0][1] << 32) | (uint32_t)s_wsum[0][0]);
+        if (first >= 0) { slot0 = first; slot_n = T; }
+    }
     // ---- phase 4: ordered flush into the tile's staging slot
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -762,7 +779,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             int o2 = off[k];
             for (int o = 0; o < n_[k]; o++) {
                 if (!((vmask_[k] >> o) & 1)) continue;
-                if (o2 < a.slot_cap) {
+                if (o2 < slot_n) {
                     const int64_t g = slot0 + o2;
                     stage_put(a.stage, a.side, a.slots, g, (uint32_t)(vw.w0 + base_[k] + o), (uint32_t)(s_vpos[base_[k] + o] - rpos_[k]), 0u,
                               (uint32_t)j, (codes_[k] >> (4 * o)) & 15u);
@@ -770,7 +787,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
                 o2++;
             }
         } else if (fb && cnt[k] > 0) {
-            walk_read<2>(a, vw, cw, cb, j, r0 + j, rpos_[k], c0_[k], c1_[k], s_soff[j], slot0 + off[k], slot0 + a.slot_cap);
+            walk_read<2>(a, vw, cw, cb, j, r0 + j, rpos_[k], c0_[k], c1_[k], s_soff[j], slot0 + off[k], slot0 + slot_n);
         }
     }
     if (!fb) {
@@ -780,7 +797,7 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             const int j = (int)(key >> 16);
             const uint32_t ord = (key >> 8) & 31;
             const int o = (int)s_coff[j] + __popc(s_mask[j] & ((1u << ord) - 1));
-            if (o < a.slot_cap) {
+            if (o < slot_n) {
                 const int64_t g = slot0 + o;
                 stage_put(a.stage, a.side, a.slots, g, (uint32_t)(vw.w0 + (int)s_var[e]), cand_x0(cb, e), cand_x1(cb, e, key), (uint32_t)j, key & 15u);
             }
@@ -885,6 +902,7 @@ struct CompactArgs {
     const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base; const int64_t *shard_base;
     const int32_t *tile_w0;
     int slot_cap, tile_reads; int64_t ntiles;
+    const long long *tile_ovf;            // first slot of a tile with more than slot_cap calls (overflow area), -1: it did not fit
 };
 
 // calls before global tile T over all shards (T < ntiles)
@@ -915,7 +933,7 @@ __global__ void k_shard_totals(const int64_t *tile0, int n_shards, int64_t ntile
 #endif
 constexpr int CT = PHZ_CT, CT_UNR = 4;
 template <bool UNI>
-__device__ __forceinline__ void compact_run(const CompactArgs &c, const int *pref, const int64_t *dstv, const int32_t *r0v, const int32_t *siv,
+__device__ __forceinline__ void compact_run(const CompactArgs &c, const int *pref, const int64_t *dstv, const int32_t *r0v, const int32_t *siv, const int64_t *slotv,
                                             int64_t T0, int M, int lane, int si0) {
     for (int e0 = lane; e0 < M; e0 += 64 * CT_UNR) {
         int k_[CT_UNR]; uint2 w_[CT_UNR]; int64_t g_[CT_UNR];
@@ -926,7 +944,7 @@ __device__ __forceinline__ void compact_run(const CompactArgs &c, const int *pre
 #pragma unroll
             for (int st = CT / 2; st > 0; st >>= 1) k += (pref[k + st] <= e) ? st : 0;     // last k with pref[k] <= e
             k_[u] = k;
-            g_[u] = (T0 + k) * (int64_t)c.slot_cap + (e - pref[k]);
+            g_[u] = slotv[k] + (e - pref[k]);
             w_[u] = e < M ? c.stage[g_[u]] : make_uint2(0u, 0u);
         }
 #pragma unroll
@@ -955,7 +973,7 @@ __device__ __forceinline__ void compact_run(const CompactArgs &c, const int *pre
 
 __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
     __shared__ int s_pref[4][CT + 1];
-    __shared__ int64_t s_dst[4][CT];
+    __shared__ int64_t s_dst[4][CT], s_slot[4][CT];
     __shared__ int32_t s_r0[4][CT], s_si[4][CT];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t T0 = ((int64_t)blockIdx.x * 4 + w) * CT;
@@ -963,7 +981,12 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
     int n = 0, si = -1;
     if (lane < CT && T < c.ntiles) {
         n = c.tile_total[T];
-        if (n > c.slot_cap) n = c.slot_cap;
+        int64_t first = T * (int64_t)c.slot_cap;
+        if (n > c.slot_cap) {
+            const long long ov = c.tile_ovf[T];
+            if (ov >= 0) first = ov; else n = c.slot_cap;         // (no room in the overflow area: the batch is redone with a larger one)
+        }
+        s_slot[w][lane] = first;
         si = (c.tile_w0[4 * T + 1] >> 16) & 0x1FFF;
         s_dst[w][lane] = calls_before(c.chunk_base, c.tile_pref, T) - c.shard_base[si];
         s_r0[w][lane] = (int32_t)((T - c.tile0[si]) * c.tile_reads);
@@ -977,8 +1000,8 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
     if (M == 0) return;
     const int si0 = __builtin_amdgcn_readfirstlane(si);
     const bool uni = __ballot(si >= 0 && si != si0) == 0ull;
-    if (uni) compact_run<true>(c, s_pref[w], s_dst[w], s_r0[w], s_si[w], T0, M, lane, si0);
-    else compact_run<false>(c, s_pref[w], s_dst[w], s_r0[w], s_si[w], T0, M, lane, si0);
+    if (uni) compact_run<true>(c, s_pref[w], s_dst[w], s_r0[w], s_si[w], s_slot[w], T0, M, lane, si0);
+    else compact_run<false>(c, s_pref[w], s_dst[w], s_r0[w], s_si[w], s_slot[w], T0, M, lane, si0);
 }
 
 }  // namespace
@@ -1062,20 +1085,33 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
     int64_t *chunk_sum = (int64_t *)((char *)ctx->desc.p + (((size_t)ntiles * 4 + 15) & ~(size_t)15));
     int64_t *chunk_base = chunk_sum + nchunks;
     int32_t *chunk_max = (int32_t *)(chunk_base + nchunks);
-    if (int s = phz_reserve(ctx, ctx->scalars, (size_t)8 * (m + 2) + 64)) return s;
-    if (int s = phz_reserve_host(ctx, ctx->h_scalars, (size_t)8 * (m + 2) + 64)) return s;
+    if (int s = phz_reserve(ctx, ctx->scalars, (size_t)8 * (m + 3) + 64)) return s;            // [0] total, [1] densest tile, [2, 2 + m) calls per shard, [2 + m] overflow-area cursor
+    if (int s = phz_reserve_host(ctx, ctx->h_scalars, (size_t)8 * (m + 3) + 64)) return s;
+    if (int s = phz_reserve(ctx, S[19], (size_t)ntiles * 8)) return s;                          // tile_ovf
     unsigned long long *scal = (unsigned long long *)ctx->h_scalars.p;
-    if (ctx->map_slot_cap <= 0 || ctx->map_tile_reads != tile_reads) { ctx->map_slot_cap = tile_reads / 2 < 64 ? 64 : tile_reads / 2; ctx->map_tile_reads = tile_reads; }
+    // Staging: every tile owns a slot of slot_cap calls (half a tile's records: the typical RNA-seq tile has ~60) and a tile with more takes a stretch of
+    // the OVERFLOW AREA behind the slots (one cursor step per such tile).  The area starts at a quarter of the slots' size and is kept at what the densest
+    // submission so far needed; a submission that needs more is redone once with exactly that (round 4 sized EVERY slot for the densest tile: 50 GB for a
+    // deep sample with one dense region).  PHZ_MAP_SLOT_CAP: another slot size (tests: 8, so that most tiles overflow).
+    if (ctx->map_slot_cap <= 0 || ctx->map_tile_reads != tile_reads) {
+        ctx->map_slot_cap = tile_reads / 2 < 64 ? 64 : tile_reads / 2; ctx->map_tile_reads = tile_reads;
+        const char *e = getenv("PHZ_MAP_SLOT_CAP"); if (e && atoi(e) >= 1) ctx->map_slot_cap = atoi(e);
+    }
     float ms_total = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         const int slot_cap = ctx->map_slot_cap;
-        const size_t slots = (size_t)ntiles * (size_t)slot_cap;
+        const size_t base_slots = (size_t)ntiles * (size_t)slot_cap;
+        if (ctx->map_ovf_cap < (int64_t)(base_slots / 4)) ctx->map_ovf_cap = (int64_t)(base_slots / 4);
+        if (ctx->map_ovf_cap < 65536) ctx->map_ovf_cap = 65536;
+        const size_t slots = base_slots + (size_t)ctx->map_ovf_cap;
         if (int s = phz_reserve(ctx, S[18], slots * 16)) return s;
         MapBatch bt;
         bt.shards = d_shards; bt.tile0 = d_tile0; bt.n_shards = m; bt.baseq = baseq;
         bt.stage = (uint2 *)S[18].p; bt.side = (uint32_t *)((char *)S[18].p + slots * 8); bt.slots = (int64_t)slots;
         bt.tile_w0 = (int32_t *)ctx->tile_w0.p; bt.tile_total = (int32_t *)S[17].p;
         bt.slot_cap = slot_cap; bt.ntiles = ntiles;
+        bt.tile_ovf = (long long *)S[19].p; bt.ovf_cursor = (unsigned long long *)ctx->scalars.p + (2 + m); bt.ovf_base = (long long)base_slots; bt.ovf_cap = (long long)ctx->map_ovf_cap;
+        PHZ_HIP(ctx, hipMemsetAsync(bt.ovf_cursor, 0, 8, sm));
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
         bt.prof = nullptr;
         if (bt.dbg & 2048) { if (int s = phz_reserve(ctx, S[21], (size_t)ntiles * 64)) return s; bt.prof = (unsigned long long *)S[21].p; }
@@ -1100,10 +1136,10 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
         c.shards = d_shards; c.tile0 = d_tile0; c.n_shards = m;
         c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base; c.shard_base = d_shard_base;
         c.tile_w0 = bt.tile_w0;
-        c.slot_cap = slot_cap; c.tile_reads = tile_reads; c.ntiles = ntiles;
+        c.slot_cap = slot_cap; c.tile_reads = tile_reads; c.ntiles = ntiles; c.tile_ovf = bt.tile_ovf;
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 4 * CT - 1) / (4 * CT))), dim3(256), 0, sm, c);
         PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)8 * (m + 2), hipMemcpyDeviceToHost, sm));
+        PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)8 * (m + 3), hipMemcpyDeviceToHost, sm));
         PHZ_HIP(ctx, hipStreamSynchronize(sm));
         float ms = 0;
         PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->map_ev[0], ctx->map_ev[1]));
@@ -1117,9 +1153,9 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
                     seg[0] / ntiles / 100.0, seg[1] / ntiles / 100.0, seg[2] / ntiles / 100.0, seg[3] / ntiles / 100.0, seg[4] / ntiles / 100.0, seg[5] / ntiles / 100.0, seg[6] / ntiles / 100.0);
         }
         ms_total += ms;
-        if ((int64_t)scal[1] <= slot_cap) break;
-        if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging slots did not converge");
-        ctx->map_slot_cap = (int)((scal[1] + 63) / 64 * 64);      // grow the slots to the exact maximum and redo the batch
+        if ((int64_t)scal[2 + m] <= ctx->map_ovf_cap) break;          // every dense tile found room
+        if (attempt == 2) return phz_fail(ctx, PHZ_E_HIP, "K_map staging overflow area did not converge");
+        ctx->map_ovf_cap = (int64_t)scal[2 + m] + (int64_t)(scal[2 + m] / 16) + 4096;      // the calls of all dense tiles (+ slack for the next submission): redo the batch
     }
     ctx->last_ms[PHZ_T_MAP] = ms_total; ctx->total_ms[PHZ_T_MAP] += ms_total; ctx->launches[PHZ_T_MAP]++;
     int st = PHZ_OK;

@@ -369,3 +369,31 @@ def test_call_lists_without_the_text_planes(mapper, oracle_build):
     mapper.ctx.check(mapper.ctx.lib.phz_map_reads(mapper.ctx.h, C.byref(r), C.byref(vv), 10, C.byref(c), C.byref(n), _lib.PHZ_HOST))
     assert n.value == len(o_r)
     assert np.array_equal(bufs[0][:n.value].numpy(), o_r) and np.array_equal(bufs[1][:n.value].numpy(), o_v) and np.array_equal(bufs[2][:n.value].numpy(), o_c)
+
+
+@pytest.mark.parametrize("slot_cap", [8, 1])
+def test_dense_tiles_take_the_overflow_area(oracle_build, monkeypatch, slot_cap):
+    """K_map stages a tile's calls in a slot sized for the TYPICAL tile; a denser tile takes a stretch of the overflow area behind the slots (round 4 sized every
+    slot of a submission for its densest tile).  With slots of 8 calls (and of ONE call) nearly every tile of a dense-variant shard overflows: the first
+    submission finds the area too small, is redone with exactly what it needs, the following ones reuse it -- call lists identical to the C oracle every time,
+    with and without the text planes, one shard and a batch of three."""
+    from phaser_amd import soa, synth
+    from phaser_amd.mapper import Mapper
+    monkeypatch.setenv("PHZ_MAP_SLOT_CAP", str(slot_cap))
+    m = Mapper(0)                                           # its own context: the slot size is fixed at a context's first submission
+    shards = []; want = []; vps = []
+    for seed, n_snps, pairs in ((41, 3000, 40000), (42, 200, 3000), (43, 6000, 60000)):
+        v, gs, ge, w = synth.make_variants("chr1", 1, 2_000_000, n_snps, seed, n_genes=6)
+        rb = synth.make_reads(v, gs, ge, w, pairs, seed + 1, n_rate=0.002)
+        rb = rb.select(synth.samtools_keep(rb, 255))
+        want.append(oracle_map_readbatch(oracle_build, rb, v.pos.numpy(), 10))
+        shards.append(soa.pack_readbatch(rb).to("cuda")); vps.append(v.pos)
+    def same(calls, o):
+        c = calls.cpu()
+        return c.n == len(o[0]) and np.array_equal(c.read_idx.numpy(), o[0]) and np.array_equal(c.var_idx.numpy(), o[1]) and np.array_equal(c.code.numpy(), o[2])
+    for rep in range(2):
+        assert same(m.map(shards[0], vps[0], 10), want[0]), rep             # the densest single shard: area too small the first time
+    for aux in (True, False):
+        got = m.map_batch(shards, vps, 10, aux=aux)
+        assert all(same(g, o) for g, o in zip(got, want)), aux
+    assert want[0][0].size > 50000 and max(np.bincount(want[0][0] // 256)) > 8 * 8          # tiles with far more calls than a slot
