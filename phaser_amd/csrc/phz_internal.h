@@ -63,6 +63,7 @@ struct phz_ctx {
     int map_tile_reads = 0;
     int map_slot_cap = 0;      // calls per tile slot of K_map's staging area
     int64_t map_ovf_cap = 0;   // calls the overflow area behind the slots holds (grown to what the densest submission needed)
+    long long map_ovf_image[5] = {0, 0, 0, 0, 0};      // the overflow-area record last uploaded (+ where): a repeated submission skips the copy
 };
 
 struct PhzEnter {

@@ -91,10 +91,12 @@ struct MapBatch {
     int slot_cap, dbg;
     int64_t ntiles;
     unsigned long long *prof;     // PHZ_MAP_DBG bit 2048 (profiling build of the kernel only): 8 clock stamps per tile
-    // overflow area of the staging slots: a tile with more calls than slot_cap takes a stretch of [ovf_base, ovf_base + ovf_cap) (slot indices of the same
-    // stage / side arrays) with one cursor step and leaves its first slot in tile_ovf[tile] (-1: the area was too small; the host redoes the batch)
-    long long *tile_ovf; unsigned long long *ovf_cursor; long long ovf_base, ovf_cap;
+    // overflow area of the staging slots: a tile with more calls than slot_cap takes a stretch of [ovf->base, ovf->base + ovf->cap) (slot indices of the same
+    // stage / side arrays) with one cursor step and leaves its first slot in ovf->tile_first[tile] (0xFFFFFFFF: the area was too small; the host redoes the
+    // batch).  Behind ONE pointer, read by the rare tile that needs it: four more kernel arguments cost the kernel 50 scalar registers spilled to vector lanes
+    const struct OvfArea *ovf;
 };
+struct OvfArea { uint32_t *tile_first; unsigned long long *cursor; long long base, cap; };
 
 __device__ __forceinline__ int shard_of(const int64_t *tile0, int n_shards, int64_t T) {
     int lo = 0, hi = n_shards - 1;          // largest s with tile0[s] <= T
@@ -392,6 +394,7 @@ constexpr int MAP_SLACK = 8;       // ... plus this many further entries (probe 
 // bit 30 set when the window is complete (not truncated by MAP_WIN), which enables the LDS-only fast path
 __global__ void k_tile_window(MapBatch bt, int tile_reads) {
     const int64_t T = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (T == 0) *bt.ovf->cursor = 0ull;                     // the overflow area of this submission's staging starts empty
     if (T >= bt.ntiles) return;
     const int si = shard_of(bt.tile0, bt.n_shards, T);
     const ShardDev &sh = bt.shards[si];
@@ -710,8 +713,6 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             if (sy != 4) { vmask_[k] |= 1u << o; codes_[k] |= (uint32_t)(sy < 4 ? sy : 4) << (4 * o); }
         }
     }
-    int64_t slot0 = gtile * (int64_t)a.slot_cap;
-    int slot_n = a.slot_cap;               // calls the tile's stretch of the staging area holds
     int cnt[RPT], off[RPT];
     if (!fb) {
         // ---- phase 2b: resolve the buffered candidates with all lanes gathering at once
@@ -754,23 +755,27 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
     const int T = block_scan<MAP_BLOCK, RPT>(cnt, off, s_wsum, lane, wave);
 #pragma unroll
     for (int k = 0; k < RPT; k++) s_coff[k * MAP_BLOCK + tid] = (uint32_t)off[k];
-    if (tid == 0) a.tile_total[gtile] = T;
+    if (tid == 0) {
+        a.tile_total[gtile] = T;
+        // where the tile's calls are staged: its own slot, or -- a tile denser than a slot -- a stretch of the overflow area behind the slots, taken with one
+        // cursor step (the slots are sized for the typical tile, not for the densest of a submission: a deep sample with one dense region would have cost
+        // tiles x densest x 16 bytes).  Published through two LDS words that are dead by now (slot indices fit 32 bits: checked by the host).
+        uint32_t first = (uint32_t)(gtile * (int64_t)a.slot_cap);
+        int room = a.slot_cap;
+        if (T > a.slot_cap) {
+            const OvfArea ov = *bt.ovf;
+            const unsigned long long at = atomicAdd(ov.cursor, (unsigned long long)T);
+            const bool fits = at + (unsigned long long)T <= (unsigned long long)ov.cap;
+            if (fits) { first = (uint32_t)(ov.base + (long long)at); room = T; }
+            ov.tile_first[gtile] = fits ? first : 0xFFFFFFFFu;
+        }
+        s_ncx = (int)first; s_nlong = room;
+    }
     __syncthreads();
     PHZ_STAMP(6);
     if (a.dbg & 2) return;
-    if (T > a.slot_cap) {
-        // a tile denser than a slot (block-uniform test): its calls go to the overflow area -- the slots are sized for the typical tile, not for the densest of a
-        // submission (a deep sample with one dense region would have cost tiles x densest x 16 bytes of staging)
-        if (tid == 0) {
-            const unsigned long long at = atomicAdd(bt.ovf_cursor, (unsigned long long)T);
-            const long long first = at + (unsigned long long)T <= (unsigned long long)bt.ovf_cap ? bt.ovf_base + (long long)at : -1ll;
-            bt.tile_ovf[gtile] = first;
-            s_wsum[0][0] = (int)(uint32_t)(unsigned long long)first; s_wsum[0][1] = (int)(uint32_t)((unsigned long long)first >> 32);       // (free since the scan's barrier)
-        }
-        __syncthreads();
-        const long long first = (long long)(((unsigned long long)(uint32_t)s_wsum[0][1] << 32) | (uint32_t)s_wsum[0][0]);
-        if (first >= 0) { slot0 = first; slot_n = T; }
-    }
+    const int64_t slot0 = (int64_t)(uint32_t)s_ncx;
+    const int slot_n = s_nlong;               // calls the tile's stretch of the staging area holds
     // ---- phase 4: ordered flush into the tile's staging slot
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -902,7 +907,7 @@ struct CompactArgs {
     const int32_t *tile_total; const int32_t *tile_pref; const int64_t *chunk_base; const int64_t *shard_base;
     const int32_t *tile_w0;
     int slot_cap, tile_reads; int64_t ntiles;
-    const long long *tile_ovf;            // first slot of a tile with more than slot_cap calls (overflow area), -1: it did not fit
+    const uint32_t *tile_ovf;             // first slot of a tile with more than slot_cap calls (overflow area), 0xFFFFFFFF: it did not fit
 };
 
 // calls before global tile T over all shards (T < ntiles)
@@ -983,8 +988,8 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs c) {
         n = c.tile_total[T];
         int64_t first = T * (int64_t)c.slot_cap;
         if (n > c.slot_cap) {
-            const long long ov = c.tile_ovf[T];
-            if (ov >= 0) first = ov; else n = c.slot_cap;         // (no room in the overflow area: the batch is redone with a larger one)
+            const uint32_t ov = c.tile_ovf[T];
+            if (ov != 0xFFFFFFFFu) first = (int64_t)ov; else n = c.slot_cap;         // (no room in the overflow area: the batch is redone with a larger one)
         }
         s_slot[w][lane] = first;
         si = (c.tile_w0[4 * T + 1] >> 16) & 0x1FFF;
@@ -1019,7 +1024,7 @@ int phz_launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_vari
     const int s = launch_map_batch(ctx, n, r, v, baseq, out, n_calls);
     // map_tab_image claims "these bytes are in ctx->map_tab" (nobody else writes map_tab; its [tab_bytes, +m*8) tail, shard_base, is recomputed by every
     // launch).  A submission that failed anywhere between the upload and its stream wait may not have delivered them: forget the image.
-    if (s != PHZ_OK && s != PHZ_E_CAPACITY) { ctx->map_tab_image.clear(); ctx->map_tab_dev = nullptr; }
+    if (s != PHZ_OK && s != PHZ_E_CAPACITY) { ctx->map_tab_image.clear(); ctx->map_tab_dev = nullptr; memset(ctx->map_ovf_image, 0, sizeof ctx->map_ovf_image); }
     return s;
 }
 
@@ -1044,7 +1049,7 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
     // host image of the shard table: [ShardDev x m][tile0 x (m+1)], pinned; device copy in ctx->map_tab
     const size_t tab_bytes = (size_t)m * sizeof(ShardDev) + (size_t)(m + 1) * 8;
     if (int s = phz_reserve_host(ctx, ctx->h_shard_tab, tab_bytes)) return s;
-    if (int s = phz_reserve(ctx, ctx->map_tab, tab_bytes + (size_t)m * 8)) return s;
+    if (int s = phz_reserve(ctx, ctx->map_tab, tab_bytes + (size_t)m * 8 + 64)) return s;          // [table][shard_base x m][overflow-area record]
     ShardDev *hs = (ShardDev *)ctx->h_shard_tab.p;
     int64_t *ht0 = (int64_t *)((char *)ctx->h_shard_tab.p + (size_t)m * sizeof(ShardDev));
     int64_t ntiles = 0;
@@ -1085,9 +1090,9 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
     int64_t *chunk_sum = (int64_t *)((char *)ctx->desc.p + (((size_t)ntiles * 4 + 15) & ~(size_t)15));
     int64_t *chunk_base = chunk_sum + nchunks;
     int32_t *chunk_max = (int32_t *)(chunk_base + nchunks);
-    if (int s = phz_reserve(ctx, ctx->scalars, (size_t)8 * (m + 3) + 64)) return s;            // [0] total, [1] densest tile, [2, 2 + m) calls per shard, [2 + m] overflow-area cursor
-    if (int s = phz_reserve_host(ctx, ctx->h_scalars, (size_t)8 * (m + 3) + 64)) return s;
-    if (int s = phz_reserve(ctx, S[19], (size_t)ntiles * 8)) return s;                          // tile_ovf
+    if (int s = phz_reserve(ctx, ctx->scalars, (size_t)8 * (m + 3) + 128)) return s;           // [0] total, [1] densest tile, [2, 2 + m) calls per shard, [2 + m] overflow-area cursor, then the OvfArea record
+    if (int s = phz_reserve_host(ctx, ctx->h_scalars, (size_t)8 * (m + 3) + 128)) return s;
+    if (int s = phz_reserve(ctx, S[19], (size_t)ntiles * 4)) return s;                          // tile_ovf
     unsigned long long *scal = (unsigned long long *)ctx->h_scalars.p;
     // Staging: every tile owns a slot of slot_cap calls (half a tile's records: the typical RNA-seq tile has ~60) and a tile with more takes a stretch of
     // the OVERFLOW AREA behind the slots (one cursor step per such tile).  The area starts at a quarter of the slots' size and is kept at what the densest
@@ -1104,14 +1109,25 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
         if (ctx->map_ovf_cap < (int64_t)(base_slots / 4)) ctx->map_ovf_cap = (int64_t)(base_slots / 4);
         if (ctx->map_ovf_cap < 65536) ctx->map_ovf_cap = 65536;
         const size_t slots = base_slots + (size_t)ctx->map_ovf_cap;
+        if (slots >= 0xFFFFFFF0ull) return phz_fail(ctx, PHZ_E_ARG, "K_map staging area beyond 2^32 slots: submit the shards in smaller batches");
         if (int s = phz_reserve(ctx, S[18], slots * 16)) return s;
         MapBatch bt;
         bt.shards = d_shards; bt.tile0 = d_tile0; bt.n_shards = m; bt.baseq = baseq;
         bt.stage = (uint2 *)S[18].p; bt.side = (uint32_t *)((char *)S[18].p + slots * 8); bt.slots = (int64_t)slots;
         bt.tile_w0 = (int32_t *)ctx->tile_w0.p; bt.tile_total = (int32_t *)S[17].p;
         bt.slot_cap = slot_cap; bt.ntiles = ntiles;
-        bt.tile_ovf = (long long *)S[19].p; bt.ovf_cursor = (unsigned long long *)ctx->scalars.p + (2 + m); bt.ovf_base = (long long)base_slots; bt.ovf_cap = (long long)ctx->map_ovf_cap;
-        PHZ_HIP(ctx, hipMemsetAsync(bt.ovf_cursor, 0, 8, sm));
+        {
+            OvfArea *h_ov = (OvfArea *)((char *)ctx->h_scalars.p + (size_t)8 * (m + 3) + 64);          // (pinned; behind the words the read-back fills)
+            h_ov->tile_first = (uint32_t *)S[19].p; h_ov->cursor = (unsigned long long *)ctx->scalars.p + (2 + m); h_ov->base = (long long)base_slots; h_ov->cap = (long long)ctx->map_ovf_cap;
+            OvfArea *d_ov = (OvfArea *)((char *)ctx->map_tab.p + tab_bytes + (size_t)m * 8);            // in K_map's own buffer: ctx->scalars is shared scratch
+            // (uploaded only when it changed -- like the shard table --; the cursor is zeroed by the pre-pass kernel: no extra operation on the stream per step)
+            long long img[5] = {(long long)(intptr_t)h_ov->tile_first, (long long)(intptr_t)h_ov->cursor, h_ov->base, h_ov->cap, (long long)(intptr_t)d_ov};
+            if (memcmp(img, ctx->map_ovf_image, sizeof img) != 0) {
+                PHZ_HIP(ctx, hipMemcpyAsync(d_ov, h_ov, sizeof(OvfArea), hipMemcpyHostToDevice, sm));
+                memcpy(ctx->map_ovf_image, img, sizeof img);
+            }
+            bt.ovf = d_ov;
+        }
         { const char *e = getenv("PHZ_MAP_DBG"); bt.dbg = e ? atoi(e) : 0; }
         bt.prof = nullptr;
         if (bt.dbg & 2048) { if (int s = phz_reserve(ctx, S[21], (size_t)ntiles * 64)) return s; bt.prof = (unsigned long long *)S[21].p; }
@@ -1136,7 +1152,7 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
         c.shards = d_shards; c.tile0 = d_tile0; c.n_shards = m;
         c.tile_total = (const int32_t *)S[17].p; c.tile_pref = tile_pref; c.chunk_base = chunk_base; c.shard_base = d_shard_base;
         c.tile_w0 = bt.tile_w0;
-        c.slot_cap = slot_cap; c.tile_reads = tile_reads; c.ntiles = ntiles; c.tile_ovf = bt.tile_ovf;
+        c.slot_cap = slot_cap; c.tile_reads = tile_reads; c.ntiles = ntiles; c.tile_ovf = (const uint32_t *)S[19].p;
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((ntiles + 4 * CT - 1) / (4 * CT))), dim3(256), 0, sm, c);
         PHZ_HIP(ctx, hipGetLastError());
         PHZ_HIP(ctx, hipMemcpyAsync(scal, ctx->scalars.p, (size_t)8 * (m + 3), hipMemcpyDeviceToHost, sm));

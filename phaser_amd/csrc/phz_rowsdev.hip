@@ -2510,10 +2510,8 @@ extern "C" int phz_selftest_sort(phz_ctx *ctx, int key_bytes, const void *keys, 
     int rg[4][2];
     for (int r = 0; r < nranges; r++) { rg[r][0] = ranges[2 * r]; rg[r][1] = ranges[2 * r + 1]; }
     int where = 0;
-    if (three_launch) setenv("PHZ_SORT_THREE_LAUNCH", "1", 1);
-    if (key_bytes == 4) st = radix_sort_ranges<uint32_t, uint32_t>(ctx, P<uint32_t>(d[0]), P<uint32_t>(d[1]), P<uint32_t>(d[2]), P<uint32_t>(d[3]), n, rg, nranges, d[4], d[5], &where);
-    else st = radix_sort_ranges<unsigned long long, uint32_t>(ctx, P<unsigned long long>(d[0]), P<unsigned long long>(d[1]), P<uint32_t>(d[2]), P<uint32_t>(d[3]), n, rg, nranges, d[4], d[5], &where);
-    if (three_launch) unsetenv("PHZ_SORT_THREE_LAUNCH");
+    if (key_bytes == 4) st = radix_sort_ranges<uint32_t, uint32_t>(ctx, P<uint32_t>(d[0]), P<uint32_t>(d[1]), P<uint32_t>(d[2]), P<uint32_t>(d[3]), n, rg, nranges, d[4], d[5], &where, nullptr, nullptr, !three_launch);
+    else st = radix_sort_ranges<unsigned long long, uint32_t>(ctx, P<unsigned long long>(d[0]), P<unsigned long long>(d[1]), P<uint32_t>(d[2]), P<uint32_t>(d[3]), n, rg, nranges, d[4], d[5], &where, nullptr, nullptr, !three_launch);
     if (st != PHZ_OK) return fin(st);
     hipError_t e = hipMemcpyAsync(keys_out, where ? d[1].p : d[0].p, kb, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(vals_out, where ? d[3].p : d[2].p, vb, hipMemcpyDeviceToHost, ctx->stream);

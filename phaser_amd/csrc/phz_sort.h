@@ -436,14 +436,20 @@ template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(con
 // Sorts n (key, value) pairs by the bit ranges [lo, hi) of `ranges`, least significant range first, stable.  Buffers ping-pong between (k0, v0) and
 // (k1, v1); with dst_val (and dst_key) given the LAST pass writes there and *where = 2, else *where = 0 / 1 says which pair holds the result.
 template <class K, class V>
-int radix_sort_ranges(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, const int (*ranges)[2], int nranges, DevBuf &cnt, DevBuf &tmp, int *where, V *dst_val = nullptr, K *dst_key = nullptr) {
+int radix_sort_ranges(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, const int (*ranges)[2], int nranges, DevBuf &cnt, DevBuf &tmp, int *where, V *dst_val = nullptr, K *dst_key = nullptr,
+                      bool force_one_launch = false) {
     *where = 0;
     OsShifts sh; sh.n = 0;
     bool fits = n < (1ll << 30);
     for (int r = 0; r < nranges; r++)
         for (int s = ranges[r][0]; s < ranges[r][1]; s += 8) { if (sh.n < OS_MAXPASS) sh.shift[sh.n] = s; sh.n++; }
     if (sh.n > OS_MAXPASS) fits = false;
-    if (n <= 1 || sh.n == 0 || !fits || getenv("PHZ_SORT_THREE_LAUNCH")) {          // the three-launch passes (also the reference the tests compare against)
+    // Which sort: the one-launch passes are correct and take 60 launches fewer per phasing pass, but on the six ordering sorts of a genome (1.5 M keys each)
+    // they LOSE to the three-launch passes -- 7.89 / 7.93 against 7.77 / 7.79 ms per pass, same box, alternating runs (profiles/r05/ab_sort.txt): with 366
+    // tiles all in flight at once a tile's look-back walks ~t / 16 round trips, and the launches it saves cost only ~1.5 us each here.  So the three-launch
+    // passes stay the default; PHZ_SORT_ONE_LAUNCH=1 selects the other one (tests run both).
+    static const bool one_launch = getenv("PHZ_SORT_ONE_LAUNCH") != nullptr;
+    if (n <= 1 || sh.n == 0 || !fits || !(one_launch || force_one_launch)) {
         K *ka = k0, *kb = k1; V *va = v0, *vb = v1;
         for (int r = 0; r < nranges; r++) {
             int w = 0;
