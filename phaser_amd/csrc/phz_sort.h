@@ -268,7 +268,8 @@ template <class K, class V> __global__ __launch_bounds__(64) void k_rs_scatter(c
 // Sorts n (key, value) pairs by bits [bit_lo, bit_hi) of the key, stable.  Buffers ping-pong between (k0, v0) and (k1, v1); *where says
 // which pair holds the result (0 or 1).  cnt / tmp: scratch.
 template <class K, class V>
-int radix_sort_pairs(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &cnt, DevBuf &tmp, int *where) {
+int radix_sort_pairs(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &cnt, DevBuf &tmp, int *where, V *last_v = nullptr, K *last_k = nullptr) {
+    // last_v (and last_k): the LAST pass scatters into these arrays instead of the ping-pong buffer (*where = 2 then): no copy of the result afterwards
     *where = 0;
     if (n <= 1 || bit_hi <= bit_lo) return PHZ_OK;
     if (n >= (1ll << 32)) return phz_fail(ctx, PHZ_E_ARG, "radix sort of more than 2^32 items");
@@ -280,7 +281,11 @@ int radix_sort_pairs(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, int bi
     for (int shift = bit_lo; shift < bit_hi; shift += 8) {
         hipLaunchKernelGGL((k_rs_hist<K>), dim3(ntile), dim3(64), 0, ctx->stream, (const K *)ka, n, shift, c, ntile);
         if (int s = gscan_excl<uint32_t, uint32_t>(ctx, c, c, (int64_t)ncnt, tmp)) return s;
-        hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(ntile), dim3(64), 0, ctx->stream, (const K *)ka, (const V *)va, kb, vb, n, shift, (const uint32_t *)c, ntile);
+        const bool last = last_v != nullptr && shift + 8 >= bit_hi;
+        // (the keys of the last pass go to the ping-pong buffer when the caller does not want them)
+        hipLaunchKernelGGL((k_rs_scatter<K, V>), dim3(ntile), dim3(64), 0, ctx->stream, (const K *)ka, (const V *)va, last && last_k ? last_k : kb, last ? last_v : vb, n, shift,
+                           (const uint32_t *)c, ntile);
+        if (last) { *where = 2; break; }
         std::swap(ka, kb); std::swap(va, vb);
         *where ^= 1;
     }
@@ -451,9 +456,13 @@ int radix_sort_ranges(phz_ctx *ctx, K *k0, K *k1, V *v0, V *v1, int64_t n, const
     static const bool one_launch = getenv("PHZ_SORT_ONE_LAUNCH") != nullptr;
     if (n <= 1 || sh.n == 0 || !fits || !(one_launch || force_one_launch)) {
         K *ka = k0, *kb = k1; V *va = v0, *vb = v1;
+        int last_range = -1;
+        for (int r = 0; r < nranges; r++) if (ranges[r][1] > ranges[r][0]) last_range = r;
         for (int r = 0; r < nranges; r++) {
             int w = 0;
-            if (int s = radix_sort_pairs<K, V>(ctx, ka, kb, va, vb, n, ranges[r][0], ranges[r][1], cnt, tmp, &w)) return s;
+            const bool fin = dst_val != nullptr && r == last_range && n > 1;
+            if (int s = radix_sort_pairs<K, V>(ctx, ka, kb, va, vb, n, ranges[r][0], ranges[r][1], cnt, tmp, &w, fin ? dst_val : (V *)nullptr, fin ? dst_key : (K *)nullptr)) return s;
+            if (w == 2) { *where = 2; return PHZ_OK; }
             if (w) { std::swap(ka, kb); std::swap(va, vb); *where ^= 1; }
         }
         if (dst_val && n > 0) {
