@@ -1828,6 +1828,7 @@ struct phz_rowsdev {
     std::vector<int64_t> chrom_blocks, chrom_blk_vars;
     int64_t n_blocks = 0, n_blk_vars = 0;
     bool keys_ready = false, have_vcf = false;
+    bool pre_done = false; unsigned long long pre_max_gap = 0;      // the p-value-independent ordering sorts were enqueued by phz_rowsdev_pair_keys (for the resident tally)
     int64_t ps_slots = PS_SLOTS;        // slots of the pair-key hash set (a power of two; grown by the host when a pass reports PHZ_E_CAPACITY)
     std::vector<DevBuf *> all() {
         std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &slot_pv, &pv_off, &pv_txt, &bam_off, &bam_txt,
@@ -1963,6 +1964,47 @@ int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf
     return PHZ_OK;
 }
 
+// Ordering rules 3 / 4 / 6 of SURVEY 8.1 that do NOT depend on the pair tests' p-values: the rank index of every variant (first appearance in the connectivity map:
+// sort by (first line of the QNAME, distance to the variant's line)) and the order of the tested pairs by (rank a, rank b).  Enqueued by phz_rowsdev_pair_keys
+// right after it has read the pair keys back, so that these ~14 sort passes run while the host evaluates scipy on the keys (they were the first thing
+// phz_rowsdev_run did after that round trip), or by phz_rowsdev_run itself (PHZ_ROWS_NO_PRESTAGE=1, or a caller that skipped the first stage's result).
+int order_variants_and_pairs(phz_ctx *ctx, phz_rowsdev *h, unsigned long long max_gap) {
+    auto &T = ctx->tally;
+    hipStream_t sm = ctx->stream;
+    const int64_t nv = T.nv, ne = T.n_edges, n_lines = T.n_lines;
+    const size_t NV = (size_t)(nv ? nv : 1), NE = (size_t)(ne ? ne : 1), NS = std::max(NV, NE);
+#define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, h->buf, (bytes))) return s_; } while (0)
+    RSV(k64a, NS * 8); RSV(k64b, NS * 8); RSV(k32a, NS * 4); RSV(k32b, NS * 4); RSV(v32a, NS * 4); RSV(v32b, NS * 4);
+    RSV(ridx, NV * 4); RSV(va, NE * 4); RSV(vb, NE * 4); RSV(eorder, NE * 4);
+#undef RSV
+    const int bv = bits_for((uint64_t)(nv > 1 ? nv - 1 : 1));
+    int bl = bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1));
+    if (const char *fb = getenv("PHZ_ROWS_FAKE_LINE_BITS")) bl = std::max(bl, std::min(32, atoi(fb)));      // tests: the key layout of a BAM with > 2^31 call lines
+    if (nv) {
+        const int gb = bits_for((uint64_t)(max_gap ? max_gap : 1));
+        const uint32_t *rank_order = P<uint32_t>(h->k32a);
+        if (gb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (first line, gap) in one 32-bit key: half the bytes per pass, one range
+            hipLaunchKernelGGL(k_iota_rank32, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, gb, (uint32_t)((1ull << bl) - 1ull), P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
+            const int rg[1][2] = {{0, gb + bl}};
+            if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nv, rg, 1, P<uint32_t>(h->k64a), nullptr)) return s;      // k64a (as uint32): variants in rank order
+            rank_order = P<uint32_t>(h->k64a);
+        } else {
+            hipLaunchKernelGGL(k_iota_rank, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
+            const int rg[2][2] = {{0, gb}, {32, 32 + bl}};      // (first line of the QNAME, distance to the variant's line)
+            if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nv, rg, 2, P<uint32_t>(h->k32a), nullptr)) return s;      // k32a: variants in rank order
+        }
+        hipLaunchKernelGGL(k_invert, dim3(nblk(nv)), dim3(256), 0, sm, nv, rank_order, P<uint32_t>(h->ridx));
+    }
+    if (ne) {
+        hipLaunchKernelGGL(k_edge_keys, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, (const int32_t *)T.ea, (const int32_t *)T.eb,
+                           (const uint32_t *)h->ridx.p, P<int32_t>(h->va), P<int32_t>(h->vb), P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
+        const int rg[2][2] = {{0, bv}, {32, 32 + bv + 1}};
+        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, ne, rg, 2, P<uint32_t>(h->eorder), nullptr)) return s;
+    }
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
+
 }  // namespace
 
 extern "C" int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *t, phz_rowsdev **out) {
@@ -2038,16 +2080,37 @@ extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *key
     hipStream_t sm = ctx->stream;
     PHZ_HIP(ctx, hipMemsetAsync(h->hkeys.p, 0xff, slots * 8, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->flags.p, 0, 64, sm));
-    const int64_t ne = T.n_edges;
+    const int64_t ne = T.n_edges, nv = T.nv;
     if (ne > 0) hipLaunchKernelGGL(k_pair_keys, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, (const int32_t *)(T.stats + 2 * ne),
                                    (const int32_t *)(T.stats + 3 * ne), P<unsigned long long>(h->hkeys), (uint32_t)(slots - 1), P<uint32_t>(h->flags));
     PHZ_HIP(ctx, hipGetLastError());
+    // the first p-value-independent step of the row stage rides on this call's host wait: which variants are covered (the keys of allelic_counts / the singleton
+    // rows) and the largest (QNAME line, variant line) gap, which decides the key width of the rank sort
+    h->pre_done = false;
+    const bool pre = getenv("PHZ_ROWS_NO_PRESTAGE") == nullptr && nv > 0;
+    unsigned long long h_gap = 0;
+    if (pre) {
+        const size_t NV = (size_t)nv, NE = (size_t)(ne ? ne : 1);
+        if (int s = phz_reserve(ctx, h->cnt64, 64)) return s;
+        if (int s = phz_reserve(ctx, h->f_d, NV * 4)) return s;
+        if (int s = phz_reserve(ctx, h->keypos, (NV + 1) * 4)) return s;
+        if (int s = phz_reserve(ctx, h->f_a, std::max(NV, NE) * 4)) return s;          // (the sizes phz_rowsdev_run asks for: its own reservations must not move these buffers)
+        PHZ_HIP(ctx, hipMemsetAsync(h->cnt64.p, 0, 64, sm));
+        hipLaunchKernelGGL(k_flag_keys, dim3(std::min(nblk(nv), 512u)), dim3(256), 0, sm, nv, (const long long *)T.var_first, P<uint32_t>(h->f_d), (const unsigned long long *)T.var_rank,
+                           P<unsigned long long>(h->cnt64) + 2);
+        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_d), P<uint32_t>(h->keypos), nv, h->scan_tmp)) return s;
+        PHZ_HIP(ctx, hipMemcpyAsync(&h_gap, P<unsigned long long>(h->cnt64) + 2, 8, hipMemcpyDeviceToHost, sm));
+    }
     uint32_t fl = 0;
     PHZ_HIP(ctx, hipMemcpyAsync(&fl, h->flags.p, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, slots * 8, hipMemcpyDeviceToHost, sm));          // (512 KB: copied before the verdict on the table is known -- one wait instead of two)
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
     if (fl & 1u) return phz_fail(ctx, PHZ_E_CAPACITY, "the distinct (supporting, total) read-count pairs do not fit the pair-key table: grow it (phz_rowsdev_set_pair_slots) and call again");
-    PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, slots * 8, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    if (pre) {
+        // ... and the ordering sorts that need no p-value are on the stream before this call returns: they run while the caller evaluates scipy on the keys
+        if (int s = order_variants_and_pairs(ctx, h, h_gap)) return s;
+        h->pre_done = true; h->pre_max_gap = h_gap;
+    }
     h->keys_ready = true;
     return PHZ_OK;
 }
@@ -2112,11 +2175,11 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     RSV(mem_pos, (NV + 1) * 4); RSV(cid, (NV + 1) * 4); RSV(kpos, (NE + 1) * 4); RSV(keypos, (NV + 1) * 4);
     if (nv) hipLaunchKernelGGL(k_flag_members, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const uint32_t *)h->deg.p, (const int32_t *)h->label.p, P<uint32_t>(h->f_a), P<uint32_t>(h->f_b));
     if (ne) hipLaunchKernelGGL(k_flag_u8, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)h->keep.p, P<uint32_t>(h->f_c));
-    if (nv) hipLaunchKernelGGL(k_flag_keys, dim3(std::min(nblk(nv), 512u)), dim3(256), 0, sm, nv, (const long long *)T.var_first, P<uint32_t>(h->f_d), (const unsigned long long *)T.var_rank, cnt64 + 2);
+    if (nv && !h->pre_done) hipLaunchKernelGGL(k_flag_keys, dim3(std::min(nblk(nv), 512u)), dim3(256), 0, sm, nv, (const long long *)T.var_first, P<uint32_t>(h->f_d), (const unsigned long long *)T.var_rank, cnt64 + 2);
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_a), P<uint32_t>(h->mem_pos), nv, h->scan_tmp)) return s;
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_b), P<uint32_t>(h->cid), nv, h->scan_tmp)) return s;
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_c), P<uint32_t>(h->kpos), ne, h->scan_tmp)) return s;
-    if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_d), P<uint32_t>(h->keypos), nv, h->scan_tmp)) return s;
+    if (!h->pre_done) { if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_d), P<uint32_t>(h->keypos), nv, h->scan_tmp)) return s; }
     PHZ_HIP(ctx, hipGetLastError());
     uint32_t h_n[4] = {0, 0, 0, 0}; unsigned long long h_c64[8] = {0};
     PHZ_HIP(ctx, hipMemcpyAsync(&h_n[0], P<uint32_t>(h->mem_pos) + nv, 4, hipMemcpyDeviceToHost, sm));
@@ -2125,6 +2188,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     PHZ_HIP(ctx, hipMemcpyAsync(&h_n[3], P<uint32_t>(h->keypos) + nv, 4, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipMemcpyAsync(h_c64, cnt64, 24, hipMemcpyDeviceToHost, sm));
     if (int s = sec.wait()) return s;
+    if (h->pre_done) h_c64[2] = h->pre_max_gap;          // (measured by the first stage; this run's counters were cleared after it)
     const int64_t nmem = h_n[0], ncomp = h_n[1], nkeep = h_n[2], nkeys = h_n[3], n_linked = (int64_t)h_c64[0];
     res->dropped = (int64_t)h_c64[1];
     sec.begin();
@@ -2137,26 +2201,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     RSV(ridx, NV * 4); RSV(va, NE * 4); RSV(vb, NE * 4); RSV(eorder, NE * 4);
     RSV(mem_s, (size_t)(nmem + 1) * 4); RSV(cstart, (size_t)(ncomp + 2) * 4); RSV(corder, (size_t)(ncomp + 1) * 4); RSV(ekeep, (size_t)(nkeep + 1) * 4);
     RSV(estart, (size_t)(ncomp + 2) * 4); RSV(key_g, (size_t)(nkeys + 1) * 4);
-    if (nv) {
-        const int gb = bits_for((uint64_t)(h_c64[2] ? h_c64[2] : 1));
-        const uint32_t *rank_order = P<uint32_t>(h->k32a);
-        if (gb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (first line, gap) in one 32-bit key: half the bytes per pass, one range
-            hipLaunchKernelGGL(k_iota_rank32, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, gb, (uint32_t)((1ull << bl) - 1ull), P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
-            const int rg[1][2] = {{0, gb + bl}};
-            if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nv, rg, 1, P<uint32_t>(h->k64a), nullptr)) return s;      // k64a (as uint32): variants in rank order
-            rank_order = P<uint32_t>(h->k64a);
-        } else {
-            hipLaunchKernelGGL(k_iota_rank, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const unsigned long long *)T.var_rank, P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
-            const int rg[2][2] = {{0, bits_for((uint64_t)(h_c64[2] ? h_c64[2] : 1))}, {32, 32 + bl}};      // (first line of the QNAME, distance to the variant's line)
-            if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nv, rg, 2, P<uint32_t>(h->k32a), nullptr)) return s;      // k32a: variants in rank order
-        }
-        hipLaunchKernelGGL(k_invert, dim3(nblk(nv)), dim3(256), 0, sm, nv, rank_order, P<uint32_t>(h->ridx));
-    }
+    if (!h->pre_done) { if (int s = order_variants_and_pairs(ctx, h, h_c64[2])) return s; }
+    h->pre_done = false;
     if (ne) {
-        hipLaunchKernelGGL(k_edge_keys, dim3(nblk(ne)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, (const int32_t *)T.ea, (const int32_t *)T.eb,
-                           (const uint32_t *)h->ridx.p, P<int32_t>(h->va), P<int32_t>(h->vb), P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
-        const int rg[2][2] = {{0, bv}, {32, 32 + bv + 1}};
-        if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, ne, rg, 2, P<uint32_t>(h->eorder), nullptr)) return s;
         if (n_linked) hipLaunchKernelGGL(k_conn_starts, dim3(nblk(n_linked)), dim3(256), 0, sm, n_linked, (const uint32_t *)h->eorder.p, (const int32_t *)h->va.p,
                                          (const uint16_t *)h->d_vchrom.p, ss_conn);
     }

@@ -69,5 +69,43 @@ for it in range(iters):
     bad = [n for n in OUTPUTS if canonical(n, got[n]) != canonical(n, want[n])]
     print("iter %d seed %d: chroms %d bams %d err %.3f cfg %s -> phased %d %s" % (it, seed0 + it, nchrom, nbam, err, cfg, eng.phased, "OK" if not bad else "DIFF " + str(bad)), flush=True)
     if bad or eng.phased != ph.phased:
+        # which path disagrees, and where: the same inputs through the other row stage / without the QNAME columns, first differing rows of every file
+        def product(**over):
+            c2 = dict(cfg); c2.update(over)
+            e2 = Engine(vset, po.bam_display_names(list(bams.keys())), Config(host_threads=1, **c2), mapper=mapper)
+            it2 = {}
+            for bi, (bam, per_chrom) in enumerate(bams.items()):
+                for chrom in vset.chroms:
+                    for c3, sh in samio.shards_from_sam(per_chrom[chrom], it2, 0.0).items():
+                        e2.add_shard(bi, c3, sh.to("cuda"), len(it2[c3]), it2[c3].names)
+                for c3 in it2:
+                    e2.n_qid[c3] = len(it2[c3])
+                e2.close_bam(bi)
+            return e2.finish(), e2
+        for label, over in (("rows path as run", {}), ("device_rows=False", {"device_rows": False}), ("output_read_ids=0 (device rows)", {"output_read_ids": 0})):
+            g2, e2 = product(**over)
+            w2 = want
+            if over.get("output_read_ids") == 0 and cfg.get("output_read_ids"):
+                ph2 = po.Phaser(po.bam_display_names(list(bams.keys())), **{k: v for k, v in cfg.items() if k != "output_read_ids"})
+                with tempfile.TemporaryDirectory() as tmp:
+                    for bam, per_chrom in bams.items():
+                        texts = []
+                        for c in pool:
+                            tp = os.path.join(tmp, "t.tsv"); open(tp, "w").write("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+                            op = os.path.join(tmp, "c.tsv")
+                            subprocess.run([os.path.join(REPO, "oracle", "rvm_oracle"), "--variant_table", tp, "--baseq", "10", "--o", op], input=per_chrom[c].encode(), check=True)
+                            texts.append(open(op).read())
+                        ph2.add_bam(texts)
+                w2 = ph2.finish()
+            b2 = [n for n in OUTPUTS if canonical(n, g2[n]) != canonical(n, w2[n])]
+            print("   %-34s rows on the %-6s -> %s" % (label, e2.rows_path, "identical" if not b2 else "DIFF " + str(b2)), flush=True)
+            for n in b2:
+                a_ = canonical(n, g2[n]).split("\n"); b_ = canonical(n, w2[n]).split("\n")
+                k = next((i for i in range(min(len(a_), len(b_))) if a_[i] != b_[i]), min(len(a_), len(b_)))
+                print("      %s: %d rows (product) vs %d (oracle), first difference at row %d" % (n, len(a_), len(b_), k))
+                for i in range(max(0, k - 1), min(k + 3, max(len(a_), len(b_)))):
+                    print("        product: %s" % (a_[i][:200] if i < len(a_) else "<none>")); print("        oracle : %s" % (b_[i][:200] if i < len(b_) else "<none>"))
+                same_set = sorted(a_) == sorted(b_)
+                print("      same multiset of rows: %s" % same_set)
         sys.exit(1)
 print("all %d iterations identical" % iters)
