@@ -505,6 +505,9 @@ typedef struct {
      * CONN / HAP / ASE / CFG: [n_chroms + 1]; ALLELIC / SINGLE_*: [n_bams * n_chroms + 1], BAM of the first kept line major */
     const int64_t *seg_off[PHZ_TXT_COUNT];
     const int64_t *chrom_blocks, *chrom_blk_vars;        /* [n_chroms] blocks / block variants per chromosome */
+    const int32_t *chrom_first_bam;                      /* [n_chroms] first BAM with a kept call line on the chromosome (-1: none): the reference lists the
+                                                          * chromosomes of the block files in (that BAM, VCF order) order -- read_vars is keyed by the chromosome
+                                                          * process_mapping_result returns, "" for a call file without kept lines (phaser.py:1299, :573-574) */
     int64_t n_blocks, n_blk_vars, phased, dropped, allelic_rows, n_components, n_linked, n_complex, n_exceptions, n_big_segments;
     double gpu_ms;                    /* HIP-event time of the sync-free sections of the run */
 } phz_rowsdev_result;

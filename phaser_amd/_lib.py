@@ -139,7 +139,7 @@ class phz_rowsdev_opts(C.Structure):
 
 class phz_rowsdev_result(C.Structure):
     _fields_ = [("bytes", C.c_int64 * PHZ_TXT_COUNT), ("seg_off", C.POINTER(C.c_int64) * PHZ_TXT_COUNT), ("chrom_blocks", C.POINTER(C.c_int64)),
-                ("chrom_blk_vars", C.POINTER(C.c_int64))] + \
+                ("chrom_blk_vars", C.POINTER(C.c_int64)), ("chrom_first_bam", C.POINTER(C.c_int32))] + \
                [(k, C.c_int64) for k in ("n_blocks", "n_blk_vars", "phased", "dropped", "allelic_rows", "n_components", "n_linked", "n_complex",
                                           "n_exceptions", "n_big_segments")] + [("gpu_ms", C.c_double)]
 

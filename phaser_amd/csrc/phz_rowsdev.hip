@@ -1826,6 +1826,7 @@ struct phz_rowsdev {
     int64_t bytes[PHZ_TXT_COUNT] = {0};
     std::vector<int64_t> seg_off[PHZ_TXT_COUNT];
     std::vector<int64_t> chrom_blocks, chrom_blk_vars;
+    std::vector<int32_t> chrom_first_bam;          // first BAM in which the chromosome has a kept call line (-1: none): its place in the block order (phaser.py:558-581, :1299)
     int64_t n_blocks = 0, n_blk_vars = 0;
     bool keys_ready = false, have_vcf = false;
     bool pre_done = false; unsigned long long pre_max_gap = 0;      // the p-value-independent ordering sorts were enqueued by phz_rowsdev_pair_keys (for the resident tally)
@@ -2533,6 +2534,14 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     h->chrom_blocks.assign((size_t)nchrom, 0); h->chrom_blk_vars.assign((size_t)nchrom, 0);
     for (int c = 0; c < nchrom; c++) { h->chrom_blocks[(size_t)c] = h_cc[(size_t)nchrom + c]; h->chrom_blk_vars[(size_t)c] = h_cc[(size_t)2 * nchrom + c]; }
     res->chrom_blocks = h->chrom_blocks.data(); res->chrom_blk_vars = h->chrom_blk_vars.data();
+    // the reference orders the chromosomes of the block files by the first BAM whose call file has a kept line on them (read_vars is keyed by the `chrom` that
+    // process_mapping_result returns, "" for a file without kept lines: phaser.py:1299, :573-574), VCF order inside a BAM.  A chromosome's covered variants are
+    // counted per (BAM of the first kept line, chromosome): its first BAM is the first of those counters that is not zero.
+    h->chrom_first_bam.assign((size_t)nchrom, -1);
+    for (int c = 0; c < nchrom; c++)
+        for (int b = 0; b < nb; b++)
+            if (h_cc[(size_t)3 * nchrom + (size_t)b * nchrom + c]) { h->chrom_first_bam[(size_t)c] = b; break; }
+    res->chrom_first_bam = h->chrom_first_bam.data();
     res->n_blocks = nblocks; res->n_blk_vars = res->phased; res->n_components = ncomp; res->n_linked = n_linked;
     res->allelic_rows = (int64_t)h_c64[4];
     res->gpu_ms = sec.ms;

@@ -122,7 +122,7 @@ def write_chunks(f, chunks):
 
 
 VCF_FIELDS = (("size", "int32"), ("var", "int32"), ("hap", "uint8"), ("cor", "int8"), ("stat", "float64"), ("stat_int", "uint8"), ("maxmaf", "int32"))
-COUNT_FIELDS = ("lines", "dropped", "phased", "allelic_rows", "n_blocks")
+COUNT_FIELDS = ("lines", "dropped", "phased", "allelic_rows", "n_blocks", "first_bam1")
 
 
 def _coll_device():

@@ -432,12 +432,13 @@ class Engine:
             return None
         t3 = _t.perf_counter()
         chroms = [c for c in self.all_chroms if c in frags]
-        out, summary = merge_fragments(frags, chroms, self.cfg, noise, len(self.bam_names))
+        blocks_order = block_chrom_order(frags, chroms)
+        out, summary = merge_fragments(frags, chroms, self.cfg, noise, len(self.bam_names), blocks_order)
         # per chromosome with blocks: (name, block arrays of phz_rows_format, blocks before it) -- what write_vcf needs
         self.vcf_blocks = []
         if self.cfg.want_vcf or self.cfg.py_hash_order:
             block_index = 0
-            for c in chroms:
+            for c in blocks_order:                 # block numbers (PI of write_vcf, phaser.py:863-867) follow the order of the block files
                 if frags[c]["vcf"] is not None:
                     self.vcf_blocks.append((c, frags[c]["vcf"], block_index))
                     block_index += len(frags[c]["vcf"]["size"])
@@ -561,11 +562,21 @@ HEAD_HAP = ['contig', 'start', 'stop', 'length', 'variants', 'variant_ids', 'var
             'reads_total', 'edges_supporting', 'edges_total', 'annotated_phase', 'phase_concordant', 'gw_phase', 'gw_confidence']
 
 
-def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config", noise: float, n_bams: int = 1):
+def block_chrom_order(frags: Dict[str, dict], chrom_list: List[str]) -> List[str]:
+    """The chromosomes in the order the reference lists them in variant_connections / haplotypes / haplotypic_counts / allele_config: `read_vars` -- whose key
+    order becomes that of dict_variant_overlap (phaser.py:646-650) and of the blocks (:784) -- is keyed by the chromosome `process_mapping_result` returns, which is
+    "" for a call file WITHOUT a kept line (:1299), and new keys are appended BAM after BAM (:573-574).  So a chromosome takes its place with the first BAM that
+    has a kept line on it, chromosomes of one BAM in VCF order (= chrom_list order); one with no kept line anywhere has no rows.  With one BAM, or whenever the
+    first BAM covers every chromosome, this is the VCF order (found by tools/stress_parity.py in round 5: 11 sparse BAMs x 3 chromosomes)."""
+    key = {c: ((frags[c].get("first_bam1", 0) or (1 << 30)), i) for i, c in enumerate(chrom_list)}
+    return sorted(chrom_list, key=lambda c: key[c])
+
+
+def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config", noise: float, n_bams: int = 1, blocks_order: List[str] = None):
     """Stage D (rank 0): order the per-chromosome fragments of the five files in the reference's global order (returns, per
     file, the list of buffers to write one after the other):
-    chromosomes in VCF order for connections / blocks; allelic_counts and singleton rows follow the first-appearance
-    keys (BAM of the first kept line, chromosome, line), i.e. per first BAM the chromosomes in VCF order.  Works on
+    connections / blocks by chromosome in block_chrom_order (the VCF order unless the first BAM misses a chromosome); allelic_counts and singleton rows
+    follow the first-appearance keys (BAM of the first kept line, chromosome, line), i.e. per first BAM the chromosomes in VCF order.  Works on
     the bytes the row writer produced, so it is also what the multi-GPU gather feeds."""
     cols = list(HEAD_ASE)
     if cfg.output_read_ids == 1:
@@ -577,7 +588,7 @@ def merge_fragments(frags: Dict[str, dict], chrom_list: List[str], cfg: "Config"
     cfgf = [enc(['variant_a', 'rsid_a', 'variant_b', 'rsid_b', 'configuration'])]
     allelic = [b"contig\tposition\tvariantID\trefAllele\taltAllele\trefCount\taltCount\ttotalCount\n"]
     dropped = phased = lines = covered = 0
-    for c in chrom_list:
+    for c in (blocks_order if blocks_order is not None else block_chrom_order(frags, chrom_list)):
         f = frags[c]
         conn += f["conn"]; hap += f["hap"]; ase += f["ase"]; cfgf += f["cfg"]
         dropped += f["dropped"]; phased += f["phased"]; lines += f["lines"]; covered += f["allelic_rows"]

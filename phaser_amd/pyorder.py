@@ -45,6 +45,8 @@ def replay(eng, out: Dict[str, str]) -> Dict[str, str]:
             if L is None or L[b] is None:
                 continue
             qid, var, cls = L[b]
+            if len(qid) == 0:
+                continue                        # a call file without a kept line returns chromosome "" (phaser.py:1299): it does not place this chromosome in read_vars
             names = eng.qnames[c]
             u = uid[c]
             rv: "OrderedDict[str, list]" = OrderedDict()

@@ -89,6 +89,23 @@ def _fill(eng, c: str, keep: list) -> "_lib.phz_rows_in":
     return I
 
 
+def _first_bam1(eng, c) -> int:
+    """1 + the first BAM whose call lines on chromosome c include a kept one, 0 if there is none: the chromosome's place in the reference's block order (read_vars
+    is keyed by the chromosome process_mapping_result returns, "" for a call file without kept lines: phaser.py:1299, :573-574)."""
+    G = eng.G; P = eng._pre[c]
+    vf = G["var_first"][P["v0"]:P["v0"] + P["nv"]]
+    vf = vf[vf >= 0]
+    if vf.size == 0:
+        return 0
+    # the earliest kept line of every BAM: a variant's var_first is its first kept line over all BAMs, so walk the BAMs and ask whether any variant starts there
+    for b in range(G["nb"]):
+        if (c, b) in G["line_base"]:
+            base, n = G["line_base"][(c, b)]
+            if ((vf >= base) & (vf < base + n)).any():
+                return b + 1
+    return 0
+
+
 def format_chroms(eng, chroms, threads: int) -> Dict[str, Dict]:
     """-> per chromosome the fragment fields produced by stage C2 (bytes row text, counts, write_vcf arrays).  All chromosomes go
     through one native call (phz_rows_format_multi): their block / row chunks share one pool of `threads` workers."""
@@ -117,7 +134,7 @@ def format_chroms(eng, chroms, threads: int) -> Dict[str, Dict]:
             if cnt == 0:
                 return np.zeros(0, dtype=dt)
             return np.frombuffer(C.string_at(getattr(O, name), cnt * np.dtype(dt).itemsize), dtype=dt).copy()
-        out = {"allelic_rows": int(O.allelic_rows), "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None}
+        out = {"allelic_rows": int(O.allelic_rows), "n_blocks": int(O.n_blocks), "phased": int(O.phased), "vcf": None, "first_bam1": _first_bam1(eng, c)}
         for name in ("conn", "hap", "ase", "cfg"):
             out[name] = owner.parts(name)[0]
         for name in ("allelic", "single_ase", "single_hap"):

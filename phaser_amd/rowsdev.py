@@ -317,6 +317,8 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
                     i = b * nch + ci
                     if so[i + 1] > so[i]:
                         frags[c][name].append(mv[so[i]:so[i + 1]]); frags[c][name + "_bam"].append(b)
+    for ci, c in enumerate(eng.chrom_list):
+        frags[c]["first_bam1"] = int(R.chrom_first_bam[ci]) + 1          # 0: no kept line on this chromosome (place in the block order: engine.block_chrom_order)
     if eng.chrom_list:
         f0 = frags[eng.chrom_list[0]]            # the counts only ever enter sums over chromosomes
         f0["lines"] = int(G["n_kept"]); f0["dropped"] = int(R.dropped); f0["phased"] = int(R.phased); f0["allelic_rows"] = int(R.allelic_rows)

@@ -59,6 +59,24 @@ def test_pipe_one(mapper, device):
         assert line in log, line
 
 
+@pytest.mark.parametrize("device_rows", [True, False])
+def test_pipe_sparse_first_bam_misses_chromosomes(mapper, device_rows):
+    """tests/golden/pipe_sparse, written by the reference: three chromosomes, three BAMs, the first with reads on chr11 only -- the blocks of chr11 come first, then
+    chr3 and chr19 (the chromosomes BAM 2 brings in, VCF order), in the five files and in the block numbers (PI) of the phased VCF.  Found by tools/stress_parity.py
+    in round 5 (the product listed the chromosomes in VCF order); both row stages."""
+    from phaser_amd import vcfout
+    d = os.path.join(GOLD, "pipe_sparse")
+    vcf_text = open(os.path.join(d, "in.vcf")).read()
+    bams = {b + ".bam": {c: gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr3", "chr11", "chr19")} for b in ("s1", "s2", "s3")}
+    out, eng = run_product(mapper, vcf_text, bams, "cuda", want_vcf=True, device_rows=device_rows)
+    assert eng.rows_path == ("device" if device_rows else "host")
+    compare(out, d)
+    first = [l.split("\t")[0].split("_")[0] for l in out["allele_config"].split("\n")[1:] if l]
+    assert [c for i, c in enumerate(first) if i == 0 or first[i - 1] != c] == ["chr11", "chr3", "chr19"]
+    text, up, pc = vcfout.phased_vcf_text(vcf_text, 9, eng)
+    assert text == gz_text(os.path.join(d, "out.vcf.txt.gz"))
+
+
 @pytest.mark.parametrize("host_threads", [1, 3])
 def test_pipe_two_bams_two_chroms(mapper, host_threads):
     """host_threads > 1: the native block phasing / row writer runs multi-threaded (the reference's --threads)."""

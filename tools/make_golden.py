@@ -340,6 +340,40 @@ def fx_pipeline(phaser, rvm):
         print("pipe_noisy_" + tag, [l for l in res["log"].splitlines() if "PHASED" in l or "noise" in l or "dropped" in l])
 
 
+def fx_sparse(phaser, rvm):
+    """Round 5 (found by tools/stress_parity.py): the chromosome order of the block files when the FIRST BAM has no kept line on a chromosome.  read_vars is keyed
+    by the chromosome process_mapping_result returns -- "" for a call file without kept lines (phaser.py:1299) -- and later BAMs append their new keys (:573-574),
+    so the blocks of such a chromosome come AFTER those of the chromosomes the first BAM covers, whatever the VCF order.  Three chromosomes (VCF order chr3,
+    chr11, chr19), three BAMs: BAM 1 has reads on chr11 only, BAM 2 on chr19 and chr3, BAM 3 on all; --write_vcf numbers the blocks (PI) in that order too."""
+    from phaser_amd import synth
+    contigs = [("chr3", 198295559), ("chr11", 135086622), ("chr19", 58617616)]
+    d = os.path.join(GOLD, "pipe_sparse"); os.makedirs(d, exist_ok=True)
+    vs = []; sams = {"s1.bam": {}, "s2.bam": {}, "s3.bam": {}}
+    covers = {"s1.bam": {"chr11"}, "s2.bam": {"chr19", "chr3"}, "s3.bam": {"chr3", "chr11", "chr19"}}
+    for ci, (chrom, ln) in enumerate(contigs):
+        v, gs, ge, w = synth.make_variants(chrom, 1, 1_000_000, 120, 700 + ci, n_genes=8)
+        vs.append(v)
+        for bi, bam in enumerate(sams):
+            rb = synth.make_reads(v, gs, ge, w, 2500, 710 + 10 * ci + bi, qname_prefix="s0.r")
+            rf = rb.select(synth.samtools_keep(rb, 255))
+            lines = list(synth.sam_lines(rf, contigs))
+            if chrom not in covers[bam]:
+                lines = [l for l in lines if l.startswith("@")]          # what `samtools view -h BAM chrom:` prints for a chromosome without reads: the header
+            sams[bam][chrom] = "\n".join(lines) + "\n"
+    vcf = "\n".join(synth.vcf_lines(vs)) + "\n"
+    res, calls = run_pipeline(phaser, rvm, vcf, sams, d, write_vcf=1)
+    open(os.path.join(d, "in.vcf"), "w").write(vcf)
+    for bam in sams:
+        for chrom in sams[bam]:
+            wgz(os.path.join(d, "%s.%s.sam.gz" % (bam.replace(".bam", ""), chrom)), sams[bam][chrom])
+    for k, t in res.items():
+        wgz(os.path.join(d, "out." + k + ".txt.gz"), t)
+    first = [l.split("\t")[0].split("_")[0] for l in res["allele_config"].split("\n")[1:] if l]
+    order = [c for i, c in enumerate(first) if i == 0 or first[i - 1] != c]
+    print("pipe_sparse: chromosome order of allele_config:", order, [l for l in res["log"].splitlines() if "PHASED" in l])
+    assert order == ["chr11", "chr3", "chr19"], order          # chr11 with BAM 1; chr3 and chr19 with BAM 2, in VCF order
+
+
 def fx_c1(phaser, rvm):
     """BASELINE.json configs[0]: chr22:1-20Mb, 1k het SNPs, 100k records.  Inputs are regenerated from the
     seed by tests (too large to commit); expected outputs are committed gz + sha256 of the inputs."""
@@ -709,7 +743,7 @@ def fx_expr_matrix(phaser, rvm):
         print("expr_matrix", order, len(files), "files ->", out_all.split("\n")[0].count("\t") - 3, "sample columns,", len(out_all.splitlines()) - 1, "rows")
 
 
-FIXTURES = {"kat": fx_kat, "mapper_small": fx_mapper_small, "mapper_unsorted": fx_mapper_unsorted, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "write_vcf_more": fx_write_vcf_more, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix, "blacklist_bed": fx_blacklist_bed}
+FIXTURES = {"sparse": fx_sparse, "kat": fx_kat, "mapper_small": fx_mapper_small, "mapper_unsorted": fx_mapper_unsorted, "pipeline": fx_pipeline, "c1": fx_c1, "write_vcf": fx_write_vcf, "write_vcf_more": fx_write_vcf_more, "indels": fx_indels, "options": fx_options, "gene_ae": fx_gene_ae, "expr_matrix": fx_expr_matrix, "blacklist_bed": fx_blacklist_bed}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

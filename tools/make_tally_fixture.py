@@ -28,6 +28,9 @@ def cases():
     d = os.path.join(GOLD, "pipe_two")
     yield ("pipe_two", open(os.path.join(d, "in.vcf")).read(),
            {b + ".bam": {c: gz(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")} for b in ("t1", "t2")}, {}, {}, 0.0)
+    d = os.path.join(GOLD, "pipe_sparse")
+    yield ("pipe_sparse", open(os.path.join(d, "in.vcf")).read(),
+           {b + ".bam": {c: gz(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr3", "chr11", "chr19")} for b in ("s1", "s2", "s3")}, {}, {}, 0.0)
     for tag in "abc":
         d = os.path.join(GOLD, "pipe_noisy_" + tag)
         meta = json.load(open(os.path.join(d, "meta.json")))
@@ -52,7 +55,10 @@ def cases():
 
 
 os.makedirs(os.path.join(REPO, "gpurun_out", "tally"), exist_ok=True)
+ONLY = sys.argv[1:]
 for name, vcf_text, bams, load, cfg, isize in cases():
+    if ONLY and name not in ONLY:
+        continue
     load = dict(load); cfgk = dict(cfg)
     inc = load.pop("include_indels", 0); cfgk.pop("include_indels", None)
     vs = vcf.load_variants(vcf_text, include_indels=inc, **load)
