@@ -64,7 +64,7 @@ for name, vcf_text, bams, load, cfg, isize in cases():
     vs = vcf.load_variants(vcf_text, include_indels=inc, **load)
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from phasing_oracle import bam_display_names
-    eng = Engine(vs, bam_display_names(list(bams.keys())), Config(include_indels=inc, **cfgk), mapper=mapper)
+    eng = Engine(vs, bam_display_names(list(bams.keys())), Config(include_indels=inc, device_rows=False, **cfgk), mapper=mapper)
     interners = {}
     for bi, (bam, per_chrom) in enumerate(bams.items()):
         for chrom in vs.chroms:
@@ -84,7 +84,8 @@ for name, vcf_text, bams, load, cfg, isize in cases():
     all_chroms = list(eng.chrom_list)
     for c in all_chroms:
         eng.chrom_list = [c]
-        G = eng._tally_genome()
+        G = eng.G = eng._tally_genome()
+        eng._fetch_tally()
         nv = G["nv"]; ne = len(G["ea"]); nl = G["n_lines"]
         cls = np.zeros(max(1, nl), dtype=np.uint8); cells = np.zeros(max(1, ne * 9), dtype=np.int32)
         o = _lib.phz_tally_out(None, None, None, None, C.c_void_p(cls.ctypes.data), None, None, C.c_void_p(cells.ctypes.data), None, None, None, None)
