@@ -34,7 +34,7 @@ def main():
             vcf_text = "\n".join(synth.vcf_lines([v])) + "\n"; bams = ["c1.bam"]
         else:
             vcf_text = open(os.path.join(d, "in.vcf")).read()
-            bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"], "pipe_indel": ["i.bam"]}.get(case, ["n.bam"])
+            bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"], "pipe_sparse": ["s1.bam", "s2.bam", "s3.bam"], "pipe_indel": ["i.bam"]}.get(case, ["n.bam"])
         if case.startswith("pipe_noisy"):
             cfg["max_block_size"] = json.load(open(os.path.join(d, "meta.json")))["max_block_size"]
         if case == "pipe_indel":

@@ -56,7 +56,7 @@ def _inputs(case, gold, c1_inputs):
         vcf_text = open(os.path.join(GOLD, "pipe_opts", "in.vcf")).read(); bams = ["o1.bam", "o2.bam"]
     else:
         vcf_text = open(os.path.join(d, "in.vcf")).read()
-        bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"], "pipe_indel": ["i.bam"]}.get(case, ["n.bam"])
+        bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"], "pipe_sparse": ["s1.bam", "s2.bam", "s3.bam"], "pipe_indel": ["i.bam"]}.get(case, ["n.bam"])
     return d, vcf_text, bam_display_names(bams)
 
 

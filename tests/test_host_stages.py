@@ -14,7 +14,7 @@ from helpers import OUTPUTS, canonical, option_case_kwargs, stub_gpu_stages
 
 
 def _cases():
-    base = [("pipe_one", "pipe_one", {}, {}), ("pipe_two", "pipe_two", {}, {}), ("c1", "c1", {}, {}),
+    base = [("pipe_one", "pipe_one", {}, {}), ("pipe_two", "pipe_two", {}, {}), ("pipe_sparse", "pipe_sparse", {}, {}), ("c1", "c1", {}, {}),
             ("pipe_indel", "pipe_indel", {"include_indels": 1}, {"include_indels": 1})]
     for tag in "abc":
         d = os.path.join(GOLD, "pipe_noisy_" + tag)
@@ -56,7 +56,7 @@ def test_host_stages_match_reference(case, gold, load, cfg, c1_inputs):
         vcf_text = open(os.path.join(GOLD, "pipe_opts", "in.vcf")).read(); bams = ["o1.bam", "o2.bam"]
     else:
         vcf_text = open(os.path.join(d, "in.vcf")).read()
-        bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"], "pipe_indel": ["i.bam"]}.get(case, ["n.bam"])
+        bams = {"pipe_one": ["a.bam"], "pipe_two": ["t1.bam", "t2.bam"], "pipe_sparse": ["s1.bam", "s2.bam", "s3.bam"], "pipe_indel": ["i.bam"]}.get(case, ["n.bam"])
     out, eng = run_host_stages(case, load, cfg, vcf_text, bam_display_names(bams))
     for name in OUTPUTS:
         want = gz_text(os.path.join(d, "out.%s.txt.gz" % name))
