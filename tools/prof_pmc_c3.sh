@@ -7,7 +7,7 @@ R=$PWD; OUT=$R/gpurun_out/$1/pmc_kmap_c3; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 run() { name=$1; shift
   rm -rf /tmp/pmc_$name
-  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python $R/bench.py --no-cpu --no-phasing --no-c2 --steps 3 --warmup 1 > /tmp/pmc_$name.log 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python $R/bench.py --no-cpu --no-phasing --no-c2 --no-bam --steps 3 --warmup 1 > /tmp/pmc_$name.log 2>&1
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then head -1 $f > $OUT/$name.csv; grep "k_map\|k_compact\|k_tile_window" $f >> $OUT/$name.csv; else echo "no counter file for $name"; tail -5 /tmp/pmc_$name.log; fi
 }
@@ -27,7 +27,7 @@ python - $OUT $R <<'PY'
 import csv, sys, os, json, hashlib, collections
 out, repo = sys.argv[1], sys.argv[2]
 sha = hashlib.sha256(open(os.path.join(repo, "phaser_amd/csrc/phz_map.hip"), "rb").read()).hexdigest()[:16]
-json.dump({"workload": "configs[2]", "kernel_source_sha16": sha, "command": "python bench.py --no-cpu --no-phasing --no-c2 --steps 3 --warmup 1",
+json.dump({"workload": "configs[2]", "kernel_source_sha16": sha, "command": "python bench.py --no-cpu --no-phasing --no-c2 --no-bam --steps 3 --warmup 1",
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md)"}, open(os.path.join(out, "meta.json"), "w"), indent=1)
 for name in ("fetch", "write", "ea_rd", "ea_wr", "sq1", "sq2"):
     f = os.path.join(out, name + ".csv")
