@@ -28,6 +28,7 @@ for it in range(iters):
     if rng.random() < 0.3: cfg["as_q_cutoff"] = rng.choice([0.0, 0.2, 0.5])
     if nbam > 1 and rng.random() < 0.3: cfg["haplo_count_bam_exclude"] = [rng.randrange(nbam)]
     if rng.random() < 0.2: cfg["output_read_ids"] = 1
+    if rng.random() < 0.25: cfg["gw_phase_method"] = 1          # MAF-weighted genome-wide phase (the synthetic VCF carries AF=...): on the device since round 5
     vs_ = []; bams = {"x%d.bam" % b: {} for b in range(nbam)}
     for ci, (chrom, ln) in enumerate(contigs):
         dense = rng.random() < 0.35 and not many  # het SNPs every 5-40 bp: tens of calls per read, components of hundreds of variants
@@ -42,7 +43,7 @@ for it in range(iters):
             bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
     vcf_text = "\n".join(synth.vcf_lines(vs_)) + "\n"
     # product
-    vset = vcf.load_variants(vcf_text)
+    vset = vcf.load_variants(vcf_text, gw_phase_method=cfg.get("gw_phase_method", 0))
     eng = Engine(vset, po.bam_display_names(list(bams.keys())), Config(host_threads=rng.choice([1, 4]), **cfg), mapper=mapper)
     interners = {}
     for bi, (bam, per_chrom) in enumerate(bams.items()):
@@ -60,7 +61,7 @@ for it in range(iters):
         for bam, per_chrom in bams.items():
             texts = []
             for c in pool:
-                tp = os.path.join(tmp, "t.tsv"); open(tp, "w").write("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+                tp = os.path.join(tmp, "t.tsv"); open(tp, "w").write("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c], gw_phase_method=cfg.get("gw_phase_method", 0))[0]))
                 op = os.path.join(tmp, "c.tsv")
                 subprocess.run([os.path.join(REPO, "oracle", "rvm_oracle"), "--variant_table", tp, "--baseq", "10", "--o", op], input=per_chrom[c].encode(), check=True)
                 texts.append(open(op).read())
@@ -91,7 +92,7 @@ for it in range(iters):
                     for bam, per_chrom in bams.items():
                         texts = []
                         for c in pool:
-                            tp = os.path.join(tmp, "t.tsv"); open(tp, "w").write("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+                            tp = os.path.join(tmp, "t.tsv"); open(tp, "w").write("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c], gw_phase_method=cfg.get("gw_phase_method", 0))[0]))
                             op = os.path.join(tmp, "c.tsv")
                             subprocess.run([os.path.join(REPO, "oracle", "rvm_oracle"), "--variant_table", tp, "--baseq", "10", "--o", op], input=per_chrom[c].encode(), check=True)
                             texts.append(open(op).read())
