@@ -408,10 +408,26 @@ __global__ __launch_bounds__(256) void k_names_len(const uint32_t *off, const in
 
 }  // namespace
 
+// The two big buffers of a device BAM read are kept in the ctx between calls (the larger one wins a slot): take / give back
+static bool bam_keep_buffers() { const char *e = getenv("PHZ_BAM_KEEP_BUFFERS"); return !(e && atoi(e) == 0); }
+static void *bam_take(DevBuf *slot, size_t bytes, size_t *cap) {
+    if (slot && slot->p && slot->cap >= bytes) { void *p = slot->p; *cap = slot->cap; slot->p = nullptr; slot->cap = 0; return p; }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *cap = bytes;
+    return p;
+}
+static void bam_give_back(DevBuf *slot, void *p, size_t cap) {
+    if (!p) return;
+    if (slot && bam_keep_buffers() && cap > slot->cap) { if (slot->p) (void)hipFree(slot->p); slot->p = p; slot->cap = cap; return; }
+    (void)hipFree(p);
+}
+
 struct phz_bamdev {
     phz_ctx *ctx = nullptr;
     std::vector<std::pair<std::string, int32_t>> refs;
     void *d_stream = nullptr;           // inflated bytes of the needed members
+    size_t d_stream_cap = 0;            // its size (the buffer goes back to the ctx's cache when the handle is closed)
     void *d_work = nullptr;             // kept-record list + offsets (one allocation)
     KeptOut K{};
     int64_t n_kept = 0;
@@ -420,7 +436,10 @@ struct phz_bamdev {
     std::vector<int64_t> ref_begin;     // host copy [n_ref + 1]
     std::vector<uint32_t> h_co, h_so, h_qo;     // values at the reference boundaries
     std::string err;
-    ~phz_bamdev() { if (d_stream) (void)hipFree(d_stream); if (d_work) (void)hipFree(d_work); }
+    ~phz_bamdev() {
+        if (d_stream) bam_give_back(ctx ? &ctx->bam_stream : nullptr, d_stream, d_stream_cap);
+        if (d_work) (void)hipFree(d_work);
+    }
 };
 
 #define BD_HIP(call)                                                                                      \
@@ -498,10 +517,22 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     // resident, so HBM can legitimately be short here), and the runtime's sticky last-error is cleared so that the next kernel-launch check
     // of this ctx does not report a stale out-of-memory.  PHZ_BAMDEV_FORCE_NOMEM=1 (tests) takes this exit without exhausting a GPU.
     const bool force_nomem = getenv("PHZ_BAMDEV_FORCE_NOMEM") != nullptr;
-    if (force_nomem || hipMalloc(&d_comp, comp_bytes + 64) != hipSuccess || hipMalloc(&d_mem, mem.size() * sizeof(phz_bgzf_member)) != hipSuccess ||
-        hipMalloc(&h->d_stream, out_bytes + 64) != hipSuccess) {
-        if (d_comp) (void)hipFree(d_comp);
-        if (d_mem) (void)hipFree(d_mem);
+    size_t d_comp_cap = 0;
+    bool got = false;
+    for (int attempt = 0; attempt < 2 && !force_nomem && !got; attempt++) {
+        d_comp = bam_take(&ctx->bam_comp, comp_bytes + 64, &d_comp_cap);
+        if (d_comp && hipMalloc(&d_mem, mem.size() * sizeof(phz_bgzf_member)) != hipSuccess) { (void)hipGetLastError(); d_mem = nullptr; }
+        if (d_comp && d_mem) h->d_stream = bam_take(&ctx->bam_stream, out_bytes + 64, &h->d_stream_cap);
+        got = d_comp && d_mem && h->d_stream;
+        if (!got) {             // short of memory: the kept buffers (too small for this file) go back to the runtime, then one more try
+            if (d_comp) { (void)hipFree(d_comp); d_comp = nullptr; }
+            if (d_mem) { (void)hipFree(d_mem); d_mem = nullptr; }
+            if (h->d_stream) { (void)hipFree(h->d_stream); h->d_stream = nullptr; }
+            if (ctx->bam_comp.p) { (void)hipFree(ctx->bam_comp.p); ctx->bam_comp = DevBuf(); }
+            if (ctx->bam_stream.p) { (void)hipFree(ctx->bam_stream.p); ctx->bam_stream = DevBuf(); }
+        }
+    }
+    if (!got) {
         (void)hipGetLastError();
         delete h; phz_bam_plan_release(&plan); return phz_fail(ctx, PHZ_E_NOMEM, "device BAM buffers");
     }
@@ -517,7 +548,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     for (int t = 0; t < NCOPY_MAX; t++) cs[t] = nullptr;
     for (int t = 0; t < NCOPY; t++) if (hipStreamCreateWithFlags(&cs[t], hipStreamNonBlocking) != hipSuccess) cs[t] = nullptr;
     if (phz_reserve(ctx, ctx->scalars, 64) != PHZ_OK || phz_reserve(ctx, ctx->scratch[11], mem.size() * (size_t)phz_inflate_scratch_bytes_per_member()) != PHZ_OK) {
-        (void)hipFree(d_comp); (void)hipFree(d_mem); for (auto c : cs) if (c) (void)hipStreamDestroy(c);
+        bam_give_back(&ctx->bam_comp, d_comp, d_comp_cap); (void)hipFree(d_mem); for (auto c : cs) if (c) (void)hipStreamDestroy(c);
         (void)hipGetLastError();
         delete h; phz_bam_plan_release(&plan); return PHZ_E_NOMEM;
     }
@@ -651,7 +682,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     float inflate_ms = 0;
     (void)hipEventElapsedTime(&inflate_ms, e0, e1);
     ctx->last_ms[PHZ_T_INFLATE] = inflate_ms; ctx->total_ms[PHZ_T_INFLATE] += inflate_ms; ctx->launches[PHZ_T_INFLATE]++;
-    (void)hipFree(d_comp); (void)hipFree(d_mem);
+    bam_give_back(&ctx->bam_comp, d_comp, d_comp_cap); (void)hipFree(d_mem);
     if (st != PHZ_OK || bad) { delete h; phz_bam_plan_release(&plan); if (st == PHZ_OK) ctx->err = "a BGZF member is not valid DEFLATE"; return st != PHZ_OK ? st : PHZ_E_UNSUPPORTED; }
     lap("H2D + K_inflate (+ free of the compressed copy)");
     phz_bam_plan_release(&plan);         // (a helper thread does not help: whoever touches the address space next waits for the unmap)
