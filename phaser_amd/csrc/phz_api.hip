@@ -60,7 +60,7 @@ int phz_ctx_destroy(phz_ctx *c) {
     if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
     if (c->h_shard_tab.p) (void)hipHostFree(c->h_shard_tab.p);
     if (c->h_bam_stage.p) (void)hipHostFree(c->h_bam_stage.p);
-    free_buf(c->shard_tab); free_buf(c->map_tab); free_buf(c->bam_comp); free_buf(c->bam_stream);
+    free_buf(c->shard_tab); free_buf(c->map_tab); free_buf(c->bam_comp); free_buf(c->bam_stream); free_buf(c->bam_work);
     for (hipEvent_t e : c->map_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);

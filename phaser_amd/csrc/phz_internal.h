@@ -31,7 +31,7 @@ struct phz_ctx {
     DevBuf desc, tile_w0, scalars;
     DevBuf h_scalars;                  // pinned host mirror of `scalars` (hipHostMalloc)
     DevBuf h_bam_stage;                // page-locked staging of the device BAM path (phz_bamdev.hip)
-    DevBuf bam_comp, bam_stream;       // the device BAM path's two big buffers (compressed members, inflated stream) kept between BAMs: a fresh hipMalloc of ~19 GB
+    DevBuf bam_comp, bam_stream, bam_work;       // the device BAM path's big buffers (compressed members, inflated stream, kept-record list) kept between BAMs: a fresh hipMalloc of ~19 GB
                                        // took 1.1-1.5 s every few calls (profiles/r05/cli_4bam_full.txt); given back to the runtime when an allocation fails
                                        // and by phz_ctx_destroy; PHZ_BAM_KEEP_BUFFERS=0 turns the cache off
     DevBuf shard_tab, h_shard_tab;     // shard table of a batched stage (device / pinned host image)
