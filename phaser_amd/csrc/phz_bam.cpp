@@ -300,62 +300,116 @@ size_t plausible_at(const uint8_t *d, size_t n, size_t p, int n_ref) {
     return p + 4 + (size_t)bs;
 }
 
-// member table of a BGZF file (mapped, nothing inflated)
+// member table of a BGZF file (nothing inflated)
 struct BgzfMap {
     struct Blk { size_t off, csize, isize, dst; };
     const uint8_t *f = nullptr; size_t fsz = 0, total = 0;
+    int fd = -1;
     std::vector<Blk> blks;
-    ~BgzfMap() { if (f) munmap((void *)f, fsz); }
-    // sparse: only the member headers (and a few members) will be read through the mapping -- no read-ahead / fault-around, so that the
-    // mapping stays a few thousand page-table entries and its munmap is cheap
+    ~BgzfMap() { if (f) munmap((void *)f, fsz); if (fd >= 0) close(fd); }
+    // the whole file mapped (on first use): the host decoder inflates out of the mapping
+    const uint8_t *map() {
+        if (!f && fd >= 0) {
+            void *m = mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) f = (const uint8_t *)m;
+        }
+        return f;
+    }
+    // n bytes at `off`: out of the mapping when there is one, else pread
+    // (rfd: a descriptor of the reading thread's own -- sixteen threads on ONE descriptor spend their time on its reference count)
+    bool fetch(size_t off, size_t n, uint8_t *dst, int rfd = -1) const {
+        if (off > fsz || n > fsz - off) return false;
+        if (f) { memcpy(dst, f + off, n); return true; }
+        if (rfd < 0) rfd = fd;
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t r = pread(rfd, dst + got, n - got, (off_t)(off + got));
+            if (r <= 0) return false;
+            got += (size_t)r;
+        }
+        return true;
+    }
+    // the compressed bytes of member k (its deflate stream): a pointer into the mapping, or into `tmp`
+    const uint8_t *member(size_t k, std::vector<uint8_t> &tmp) const {
+        if (f) return f + blks[k].off;
+        tmp.resize(blks[k].csize + 1);
+        return fetch(blks[k].off, blks[k].csize, tmp.data()) ? tmp.data() : nullptr;
+    }
+    // sparse: only the member headers (and a few members) are wanted -- they are read with pread (one 64-byte read per member: the
+    // trailer of one member and the header of the next are neighbours), nothing is mapped.  Reading them through a mapping left one
+    // page-table entry per member behind: 55 ms of munmap for a 3.8 GB BAM, on top of 250,000 page faults.
     int open(const char *path, bool sparse = false) {
-        int fd = ::open(path, O_RDONLY);
+        fd = ::open(path, O_RDONLY);
         if (fd < 0) return PHZ_E_ARG;
         struct stat st;
-        if (fstat(fd, &st) != 0 || st.st_size < 28) { close(fd); return PHZ_E_ARG; }
+        if (fstat(fd, &st) != 0 || st.st_size < 28) return PHZ_E_ARG;
         fsz = (size_t)st.st_size;
-        f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
-        close(fd);
-        if (f == MAP_FAILED) { f = nullptr; return PHZ_E_NOMEM; }
-        if (sparse) (void)madvise((void *)f, fsz, MADV_RANDOM);
-        // one member header: 0 = not a BGZF member header at `off`, else its total size; *xl = XLEN
-        auto header = [&](size_t off, uint16_t *xl, int *why) -> uint32_t {
+        if (getenv("PHZ_BGZF_NO_MAP")) sparse = true;           // tests: the pread walk under the host decoder too (which maps the file afterwards)
+        if (!sparse && !map()) return PHZ_E_NOMEM;
+        constexpr size_t PEEK = 64;
+        // one member header out of h = the `avail` bytes at `off` (avail = min(PEEK, fsz - off) at least): 0 = not a BGZF member header,
+        // else the member's total size; *xl = XLEN
+        auto header_in = [&](size_t off, const uint8_t *h, size_t avail, uint16_t *xl, int *why, int rfd) -> uint32_t {
             *why = PHZ_E_ARG;
-            if (off + 18 > fsz || f[off] != 0x1f || f[off + 1] != 0x8b) return 0;
-            if (!(f[off + 3] & 4)) { *why = PHZ_E_UNSUPPORTED; return 0; }
-            const uint16_t xlen = rd16(f + off + 10);
-            size_t x = off + 12, xe = x + xlen;
+            if (off + 18 > fsz || avail < 18 || h[0] != 0x1f || h[1] != 0x8b) return 0;
+            if (!(h[3] & 4)) { *why = PHZ_E_UNSUPPORTED; return 0; }
+            const uint16_t xlen = rd16(h + 10);
+            std::vector<uint8_t> wide;
+            if (12 + (size_t)xlen > avail) {                   // an extra field longer than the peek (BGZF writers use 6 bytes)
+                if (off + 12 + xlen > fsz) { *why = PHZ_E_UNSUPPORTED; return 0; }
+                wide.resize(12 + (size_t)xlen);
+                if (!fetch(off, wide.size(), wide.data(), rfd)) return 0;
+                h = wide.data();
+            }
+            size_t x = 12;
+            const size_t xe = 12 + (size_t)xlen;
             uint32_t bsize = 0;
-            while (x + 4 <= xe && xe <= fsz) {
-                const uint16_t slen = rd16(f + x + 2);
-                if (f[x] == 'B' && f[x + 1] == 'C' && slen == 2) bsize = (uint32_t)rd16(f + x + 4) + 1;
-                x += 4 + slen;
+            while (x + 4 <= xe) {
+                const uint16_t slen = rd16(h + x + 2);
+                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= xe) bsize = (uint32_t)rd16(h + x + 4) + 1;
+                x += 4 + (size_t)slen;
             }
             if (!bsize) { *why = PHZ_E_UNSUPPORTED; return 0; }
             if (off + bsize > fsz || bsize < (uint32_t)xlen + 20) return 0;
             *xl = xlen;
             return bsize;
         };
-        // the member chain from `off` up to (not beyond) `stop`: -> where it arrived, members appended without their dst
-        auto walk = [&](size_t off, size_t stop, std::vector<Blk> &out, int *status) -> size_t {
+        auto header = [&](size_t off, uint16_t *xl, int *why, int rfd) -> uint32_t {
+            uint8_t h[PEEK];
+            const size_t avail = off < fsz ? std::min(PEEK, fsz - off) : 0;
+            if (avail < 18 || !fetch(off, avail, h, rfd)) { *why = PHZ_E_ARG; return 0; }
+            return header_in(off, h, avail, xl, why, rfd);
+        };
+        auto own_fd = [&]() -> int { return f ? -1 : ::open(path, O_RDONLY); };       // -1: the shared one (or the mapping)
+        // the member chain from `off` up to (not beyond) `stop`: -> where it arrived, members appended without their dst.  One read per
+        // member: the last four bytes of member i (ISIZE) and the header of member i+1.
+        auto walk = [&](size_t off, size_t stop, std::vector<Blk> &out, int *status, int rfd) -> size_t {
+            uint8_t h[4 + PEEK];
+            size_t avail = 0;
+            if (off < stop && off + 18 <= fsz) { avail = std::min(PEEK, fsz - off); if (!fetch(off, avail, h + 4, rfd)) { *status = PHZ_E_ARG; return off; } }
             while (off < stop && off + 18 <= fsz) {
                 uint16_t xlen; int why;
-                const uint32_t bsize = header(off, &xlen, &why);
+                const uint32_t bsize = header_in(off, h + 4, avail, &xlen, &why, rfd);
                 if (!bsize) { *status = why; return off; }
-                const uint32_t isz = rd32(f + off + bsize - 4);
+                const size_t nxt = off + bsize;
+                avail = std::min(PEEK, fsz - nxt);
+                if (!fetch(nxt - 4, 4 + avail, h, rfd)) { *status = PHZ_E_ARG; return off; }
+                const uint32_t isz = rd32(h);
                 if (isz > 65536u) { *status = PHZ_E_ARG; return off; }        // BGZF: a member inflates to at most 64 KiB; the trailer is not trusted beyond that
                 out.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isz, 0});
-                off += bsize;
+                off = nxt;
             }
             return off;
         };
         // Big files: the chain is walked in K segments at once.  A segment's first member is GUESSED (the first offset where four
         // member headers follow each other) and VERIFIED: segment k must arrive exactly where segment k+1 starts; any mismatch falls
-        // back to the one sequential walk.  (The walk is page faults on the mapping: ~0.4 us per member, 250,000 members per genome.)
+        // back to the one sequential walk.  (250,000 members per genome, one small read each.)
         bool done = false;
         size_t par_min = 256u << 20;
         { const char *e = getenv("PHZ_BGZF_PAR_MIN"); if (e) par_min = (size_t)atoll(e); }       // tests force the segmented walk on small files
-        const int K = fsz >= par_min ? 16 : 1;
+        // (the pread walk has no address-space lock to fight over: as many segments as the host has threads, 16..48)
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int K = fsz >= par_min ? (f ? 16 : std::max(16, std::min(48, hw))) : 1;
         if (K > 1) {
             std::vector<size_t> start((size_t)K + 1, fsz);
             start[0] = 0;
@@ -366,17 +420,27 @@ struct BgzfMap {
             for (int k = 1; k < K; k++)
                 th.emplace_back([&, k] {
                     const size_t g = fsz / (size_t)K * (size_t)k, lim = std::min(fsz, g + (1u << 20));
+                    std::vector<uint8_t> win;
+                    size_t w0 = g;                               // the window holds [w0, w0 + win.size())
+                    const int rfd = own_fd();
                     for (size_t p = g; p < lim; p++) {
-                        if (f[p] != 0x1f) continue;
+                        if (p >= w0 + win.size()) { w0 = p; win.resize(std::min<size_t>(128u << 10, lim - p)); if (!fetch(w0, win.size(), win.data(), rfd)) break; }
+                        if (win[p - w0] != 0x1f) continue;
                         size_t q = p; int ok = 0;
-                        while (ok < 4) { uint16_t xl; int why; const uint32_t bs = header(q, &xl, &why); if (!bs) break; ok++; q += bs; if (q >= fsz) { ok = 4; break; } }
+                        while (ok < 4) { uint16_t xl; int why; const uint32_t bs = header(q, &xl, &why, rfd); if (!bs) break; ok++; q += bs; if (q >= fsz) { ok = 4; break; } }
                         if (ok >= 4) { start[(size_t)k] = p; break; }
                     }
+                    if (rfd >= 0) close(rfd);
                 });
             for (auto &x : th) x.join();
             th.clear();
             for (int k = 0; k < K; k++)
-                th.emplace_back([&, k] { if (start[(size_t)k] < fsz) arrive[(size_t)k] = walk(start[(size_t)k], start[(size_t)k + 1], part[(size_t)k], &stt[(size_t)k]); else arrive[(size_t)k] = fsz; });
+                th.emplace_back([&, k] {
+                    if (start[(size_t)k] >= fsz) { arrive[(size_t)k] = fsz; return; }
+                    const int rfd = own_fd();
+                    arrive[(size_t)k] = walk(start[(size_t)k], start[(size_t)k + 1], part[(size_t)k], &stt[(size_t)k], rfd);
+                    if (rfd >= 0) close(rfd);
+                });
             for (auto &x : th) x.join();
             bool ok = true;
             for (int k = 0; k < K; k++) {
@@ -395,7 +459,7 @@ struct BgzfMap {
         if (!done) {
             blks.clear();
             int status = PHZ_OK;
-            const size_t end = walk(0, fsz, blks, &status);
+            const size_t end = walk(0, fsz, blks, &status, -1);
             if (status != PHZ_OK && end + 18 <= fsz) return status;
         }
         total = 0;
@@ -474,11 +538,15 @@ static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64
                     std::vector<BamPiece> &pieces, Laps &laps) {
     // header: inflate members until it parses
     size_t hb = 0, first_record = 0;
+    std::vector<uint8_t> comp_tmp;
     for (;;) {
         if (hb >= M.blks.size()) return PHZ_E_ARG;
         const size_t old = head.size();
         head.resize(old + M.blks[hb].isize);
-        if (M.blks[hb].isize && !inflate_block(M.f + M.blks[hb].off, M.blks[hb].csize, head.data() + old, M.blks[hb].isize)) return PHZ_E_ARG;
+        if (M.blks[hb].isize) {
+            const uint8_t *src = M.member(hb, comp_tmp);
+            if (!src || !inflate_block(src, M.blks[hb].csize, head.data() + old, M.blks[hb].isize)) return PHZ_E_ARG;
+        }
         hb++;
         refs.clear();
         const int rc = parse_bam_header(head.data(), head.size(), refs, &first_record);
@@ -498,7 +566,7 @@ static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64
     // The window starts at three members and grows (x4, up to 256 members = 16 MB) while candidate chains run out of data, so records of
     // tens of kilobytes (long reads, large aux fields) are still chained 12 deep.
     auto probe = [&](size_t b, uint64_t *uoff, int32_t *ref) -> int {
-        std::vector<uint8_t> tmp;
+        std::vector<uint8_t> tmp, ctmp;
         size_t b1 = b;
         for (; b1 < nb && b1 < b + 8; b1++) {
             for (size_t win = 3;; win *= 4) {
@@ -506,7 +574,10 @@ static int bam_plan(BgzfMap &M, const char *const *ref_names, int n_names, int64
                 for (size_t k = b1; k < nb && k < b1 + win; k++) {
                     const size_t old = tmp.size();
                     tmp.resize(old + M.blks[k].isize);
-                    if (M.blks[k].isize && !inflate_block(M.f + M.blks[k].off, M.blks[k].csize, tmp.data() + old, M.blks[k].isize)) return -1;
+                    if (M.blks[k].isize) {
+                        const uint8_t *src = M.member(k, ctmp);
+                        if (!src || !inflate_block(src, M.blks[k].csize, tmp.data() + old, M.blks[k].isize)) return -1;
+                    }
                 }
                 if (b1 == b0) {                                // the true first record: no guess needed
                     const size_t p = first_record - M.blks[b0].dst;
@@ -635,6 +706,11 @@ int phz_bam_plan_file(const char *path, const char *const *ref_names, int n_name
     return PHZ_OK;
 }
 
+const uint8_t *phz_bam_plan_map(PhzBamPlan *p) {
+    if (p && p->owner && !p->file) p->file = ((BgzfMap *)p->owner)->map();
+    return p ? p->file : nullptr;
+}
+
 void phz_bam_plan_release(PhzBamPlan *p) {
     if (p && p->owner) { delete (BgzfMap *)p->owner; p->owner = nullptr; p->file = nullptr; }
 }
@@ -662,7 +738,7 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
     if (out) *out = nullptr;
     Laps laps(out ? "bam open" : "bam weights");
     BgzfMap M;
-    if (int st = M.open(path)) return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st;
+    if (int st = M.open(path, out == nullptr)) return st == PHZ_E_UNSUPPORTED ? PHZ_E_ARG : st;
     laps.lap("member table");
     phz_bam *h = out ? new phz_bam() : nullptr;
     std::vector<std::pair<std::string, int32_t>> refs_local;
@@ -708,6 +784,7 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
     std::atomic<bool> bad(false);
     std::vector<std::thread> th;
     uint8_t *dstbuf = h->b.data.data();
+    if (!M.map()) { delete h; return PHZ_E_NOMEM; }
     for (int t = 0; t < nt; t++)
         th.emplace_back([&] {
             std::vector<uint8_t> scratch;

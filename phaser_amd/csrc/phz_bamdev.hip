@@ -566,7 +566,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     bool reg_ok = false; void *reg_p = nullptr;
     {
         const char *e = getenv("PHZ_BAM_REGISTER");
-        if (e && atoi(e) == 1 && !runs.empty() && plan.file) {
+        if (e && atoi(e) == 1 && !runs.empty() && phz_bam_plan_map(&plan)) {
             const uint64_t r0 = runs.front().first & ~(uint64_t)4095;
             uint64_t r1 = (runs.back().second + 4095) & ~(uint64_t)4095;
             if (r1 > ((plan.file_size + 4095) & ~(uint64_t)4095)) r1 = (plan.file_size + 4095) & ~(uint64_t)4095;
@@ -579,7 +579,14 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     constexpr uint64_t STAGE_BYTES = 8ull << 20;
     const int fd = ::open(path, O_RDONLY);
     bool stage_ok = !reg_ok && fd >= 0 && phz_reserve_host(ctx, ctx->h_bam_stage, (size_t)NCOPY * 2 * STAGE_BYTES) == PHZ_OK;
-    if (!stage_ok && !reg_ok) (void)hipGetLastError();
+    if (!stage_ok && !reg_ok) {
+        (void)hipGetLastError();
+        if (!phz_bam_plan_map(&plan)) {                    // no page-locked staging and no mapping either
+            if (fd >= 0) ::close(fd);
+            bam_give_back(&ctx->bam_comp, d_comp, d_comp_cap); (void)hipFree(d_mem); for (auto c : cs) if (c) (void)hipStreamDestroy(c);
+            delete h; phz_bam_plan_release(&plan); return PHZ_E_NOMEM;
+        }
+    }
     char *stage = (char *)ctx->h_bam_stage.p;
     hipEvent_t stage_ev[NCOPY_MAX * 2];
     for (auto &e : stage_ev) e = nullptr;
@@ -687,8 +694,8 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     bam_give_back(&ctx->bam_comp, d_comp, d_comp_cap); (void)hipFree(d_mem);
     if (st != PHZ_OK || bad) { delete h; phz_bam_plan_release(&plan); if (st == PHZ_OK) ctx->err = "a BGZF member is not valid DEFLATE"; return st != PHZ_OK ? st : PHZ_E_UNSUPPORTED; }
     lap("H2D + K_inflate (+ free of the compressed copy)");
-    phz_bam_plan_release(&plan);         // (a helper thread does not help: whoever touches the address space next waits for the unmap)
-    lap("unmap of the file");
+    phz_bam_plan_release(&plan);         // closes the file (nothing was mapped unless a fallback copied out of a mapping)
+    lap("release of the plan");
     // ---- segments
     const uint64_t SEG = 256u << 10;
     std::vector<Seg> segs;

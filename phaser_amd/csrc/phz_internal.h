@@ -131,10 +131,11 @@ struct PhzBamPlan {
     std::vector<std::pair<uint64_t, uint64_t>> pieces;     // [u0, u1) of the inflated stream (global offsets), cut at record boundaries
     struct Mem { uint64_t src; uint32_t csize, isize; uint64_t dst; };
     std::vector<Mem> members;                              // members that overlap a piece, file order; dst = global inflated offset
-    const uint8_t *file = nullptr; size_t file_size = 0;   // the mapped file (valid until phz_bam_plan_release)
+    const uint8_t *file = nullptr; size_t file_size = 0;   // the mapped file: NULL until phz_bam_plan_map (valid until phz_bam_plan_release)
     void *owner = nullptr;
 };
 int phz_bam_plan_file(const char *path, const char *const *ref_names, int n_names, PhzBamPlan *out);
+const uint8_t *phz_bam_plan_map(PhzBamPlan *p);          // maps the file on first use (the plan itself reads it with pread)
 void phz_bam_plan_release(PhzBamPlan *p);
 
 // K_inflate launcher for callers that pipeline it with their own copies (phz_inflate.hip)

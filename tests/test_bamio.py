@@ -327,6 +327,55 @@ def test_segmented_member_walk_gives_the_same_table(tmp_path, monkeypatch):
     assert bamio.bam_ref_weights(path) == w0
 
 
+def test_member_walk_without_a_mapping(tmp_path, monkeypatch):
+    """The device path's plan reads the member headers with pread (one 64-byte read per member) instead of through a mapping of the file;
+    PHZ_BGZF_NO_MAP puts the host decoder on the same walk.  Same shards, one-segment and 16-segment walk; a member whose gzip extra field is
+    longer than the 64-byte peek (other subfields before BC) is still parsed."""
+    import struct, zlib
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, gs, ge, w = synth.make_variants("chr21", 1, 8_000_000, 400, 93, n_genes=40)
+    rb = synth.make_reads(v, gs, ge, w, 30_000, 94)
+    path = str(tmp_path / "m.bam")
+    bamio.readbatch_to_bam_native(path, [rb], [("chr21", 46709983), ("chr22", 50818468)], 4)
+    want = bamio.shards_from_bam_native(path, {}, 0, False, False, chroms={"chr21"}, threads=2)["chr21"]
+    w0 = bamio.bam_ref_weights(path)
+    # the same file with every member's extra field padded by a 90-byte subfield in front of BC
+    raw = open(path, "rb").read()
+    wide = bytearray(); off = 0; n_members = 0
+    while off < len(raw):
+        xlen = struct.unpack_from("<H", raw, off + 10)[0]
+        assert xlen == 6 and raw[off + 12:off + 14] == b"BC"
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        pad = b"ZZ" + struct.pack("<H", 90) + bytes(90)
+        wide += raw[off:off + 10] + struct.pack("<H", 6 + len(pad)) + pad + b"BC\x02\x00" + struct.pack("<H", bsize + len(pad) - 1) + raw[off + 18:off + bsize]
+        off += bsize; n_members += 1
+    assert n_members > 20
+    wpath = str(tmp_path / "wide.bam")
+    open(wpath, "wb").write(bytes(wide))
+    monkeypatch.setenv("PHZ_BGZF_NO_MAP", "1")
+    for par_min in (None, "0"):
+        if par_min is not None:
+            monkeypatch.setenv("PHZ_BGZF_PAR_MIN", par_min)
+        for pth in (path, wpath):
+            got = bamio.shards_from_bam_native(pth, {}, 0, False, False, chroms={"chr21"}, threads=2)["chr21"]
+            for f in ("pos", "cigar_off", "cigar", "seq_off", "seq2", "qual", "qid", "aln_score", "has_as"):
+                assert torch.equal(getattr(got, f), getattr(want, f)), (pth, par_min, f)
+        assert bamio.bam_ref_weights(path) == w0
+    # a file cut in the middle of a member header / of a member: refused or read up to the last whole member exactly as with the mapping
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(raw[:len(raw) // 2])
+    def outcome():
+        try:
+            s = bamio.shards_from_bam_native(cut, {}, 0, False, False, threads=2)
+            return sorted((c, x.pos.tolist()[:50], x.n) for c, x in s.items())
+        except Exception as e:
+            return str(e)
+    a = outcome()
+    monkeypatch.delenv("PHZ_BGZF_NO_MAP")
+    assert outcome() == a
+
+
 def test_bgzf_member_claiming_more_than_64k_is_refused(tmp_path):
     """BGZF members inflate to at most 64 KiB; a trailer that claims more is not trusted (it would size host and device buffers)."""
     import struct
