@@ -647,7 +647,7 @@ def write_genome_files(tmp, a, dev):
         vsets.append(v)
         del plan
     bamio.readbatch_to_bam_native(path, batches, [(c, l) for c, l in items], 0)
-    vcfout.write_bgzf(vcfgz, "\n".join(synth.vcf_lines(vsets)) + "\n", 0)
+    vcfout.write_bgzf(vcfgz, "\n".join(synth.vcf_lines(vsets)) + "\n", 0, index="vcf")          # "must be gzipped and tabix indexed" (phaser.py:31)
     del batches
     torch.cuda.empty_cache()
     return path, vcfgz, vsets, nrec, time.perf_counter() - t0

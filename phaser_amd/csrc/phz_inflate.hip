@@ -6,8 +6,12 @@
 // flight.  A lane is a slow decoder (one Huffman symbol per step, LZ77 copies through global memory), but the whole chip runs
 // tens of thousands of them at once.  Per lane: the per-length code limits of the two Huffman codes live in registers (15
 // independent comparisons find a code's length: no bit-serial walk, no divergence between lanes), the symbol tables in LDS
-// ([symbol slot][lane] layout: lanes that are at the same slot hit different banks), packed to 25 KB per wave: the kernel lives on
-// memory latency, so the number of waves a CU can hold is its throughput.
+// ([symbol slot][lane] layout: lanes that are at the same slot hit different banks).  The kernel lives on memory latency (rocprofv3, a
+// whole-genome BAM: waves wait 74 % of their cycles, the vector ALUs are busy 12 %), so the number of waves a CU can hold is its
+// throughput: only the HOT first symbols of the literal/length table in code order -- the shortest codes, i.e. nearly all lookups -- are
+// kept in LDS, the rest of the table lives in the member's global scratch (8.3 KB of LDS per wave instead of 26: 16 waves per CU --
+// the register file's limit at 125 VGPRs -- instead of 6; HOT = 288 / 128 / 64 / 32: 167 / 142 / 140 / 101 ms for the 248,779 members of a
+// whole-genome BAM, the last one because all 3,888 waves are resident at once).
 //
 // Every member is checked as it is decoded (code validity, distances, output size == ISIZE of the member trailer); a member that
 // fails sets the call's status word and the host falls back to zlib for the whole file -- nothing is silently wrong.
@@ -21,7 +25,11 @@
 namespace {
 
 constexpr int IL = 64;             // lanes (members) per workgroup
-constexpr int SCRATCH = 352;        // global scratch per member: 320 code lengths + 16 uint16 counters used while a table is built
+#ifndef PHZ_INF_HOT
+#define PHZ_INF_HOT 32
+#endif
+constexpr int HOT = PHZ_INF_HOT;    // literal/length symbols (code order) kept in LDS; a multiple of 32, <= 288
+constexpr int SCRATCH = 352 + 2 * 288;        // global scratch per member: 320 code lengths + 16 uint16 counters used while a table is built + the cold part of the symbol table (uint16 per slot)
 constexpr int MAXL = 288, MAXD = 32, MAXLENS = 320;      // MAXL is a multiple of 32, MAXLENS even (bit plane / nibble packing)
 
 struct BitIn {
@@ -80,11 +88,9 @@ __device__ __forceinline__ int decode_sym(BitIn &in, const uint16_t (&limit)[16]
 struct Member { uint64_t src; uint32_t csize, isize; uint64_t dst; };
 typedef uint32_t __attribute__((aligned(1))) u32u;      // unaligned global accesses (gfx950 does them in hardware)
 typedef uint64_t __attribute__((aligned(1))) u64u;
+typedef uint32_t v4u_ __attribute__((ext_vector_type(4)));
+typedef v4u_ __attribute__((aligned(1))) v4u;            // 16 unaligned bytes in ONE request
 
-__constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // status codes written to the per-call status word (first failure wins)
@@ -93,8 +99,8 @@ enum { INF_OK = 0, INF_BAD_BLOCK = 1, INF_BAD_CODE = 2, INF_BAD_DIST = 3, INF_OV
 // Per-lane tables in LDS, [slot][lane] (lanes on the same slot hit different banks), squeezed so that six waves fit a CU's 160 KB (26 KB each):
 // literal/length symbols as 8 low bits + a bit plane for bit 8 (values < 288), distance symbols as bytes.
 struct Tables {
-    uint8_t syml_lo[MAXL][IL];
-    uint32_t syml_hi[MAXL / 32][IL];
+    uint8_t syml_lo[HOT][IL];
+    uint32_t syml_hi[HOT / 32][IL];
     uint8_t symd[MAXD][IL];
     int16_t basel[16][IL], based[16][IL];      // per code length: (index of its first symbol in the table) - (its first code)
 };
@@ -104,11 +110,17 @@ struct Lane {
                                    // block headers; keeping them out of LDS is two more waves per CU)
     __device__ __forceinline__ int len_at(int i) const { return lens[i]; }
     __device__ __forceinline__ void set_len(int i, int v) { lens[i] = (uint8_t)v; }
-    __device__ __forceinline__ int syml(int k) const { return (int)t.syml_lo[k][lane] | (int)(((t.syml_hi[k >> 5][lane] >> (k & 31)) & 1u) << 8); }
+    __device__ __forceinline__ uint16_t *cold() const { return (uint16_t *)(lens + 352); }
+    __device__ __forceinline__ int syml(int k) const {
+        if (k < HOT) return (int)t.syml_lo[k][lane] | (int)(((t.syml_hi[k >> 5][lane] >> (k & 31)) & 1u) << 8);
+        return (int)cold()[k];
+    }
     __device__ __forceinline__ void set_syml(int k, int v) {
-        t.syml_lo[k][lane] = (uint8_t)v;
-        uint32_t &w = t.syml_hi[k >> 5][lane];
-        w = (w & ~(1u << (k & 31))) | ((uint32_t)(v >> 8) << (k & 31));
+        if (k < HOT) {
+            t.syml_lo[k][lane] = (uint8_t)v;
+            uint32_t &w = t.syml_hi[k >> 5][lane];
+            w = (w & ~(1u << (k & 31))) | ((uint32_t)(v >> 8) << (k & 31));
+        } else cold()[k] = (uint16_t)v;
     }
 };
 
@@ -159,6 +171,19 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
     int err = INF_OK;
     uint16_t cl[16], cd[16];
     bool last = false;
+    // The kernel is bound by the number of memory REQUESTS it makes (a wave's byte store is 64 of them, one per member), not by bytes: literals are
+    // collected eight to a register and leave as one 8-byte store -- when the register is full, or when something else needs the output to be
+    // complete (a match, the end of a block).  A partly filled register is stored whole: the zero bytes past the run are inside the member's
+    // own output and rewritten by what follows.
+    uint64_t lit = 0; uint32_t nl = 0;             // pending literals: output bytes [op - nl, op)
+    auto flush_literals = [&]() {
+        if (nl) {
+            uint8_t *q = o + (op - nl);
+            if (op - nl + 8 <= oend) *(u64u *)q = lit;
+            else for (uint32_t i = 0; i < nl; i++) q[i] = (uint8_t)(lit >> (8 * i));
+            nl = 0; lit = 0;
+        }
+    };
     while (!last && !err) {
         in.refill();
         last = in.bits(1) != 0;
@@ -230,31 +255,52 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
             int sym = decode_sym(in, cl, [&](int l) { return (int)T.basel[l][lane]; }, [&](int k) { return L.syml((unsigned)k < (unsigned)MAXL ? k : 0); });
             if (sym < 0) { err = INF_BAD_CODE; break; }
             if (sym < 256) {
+                // (a literal run kept in an inner loop of its own, so that the match path below runs once for all lanes that have reached one, was
+                // measured: 20 % slower -- the lanes at a match idle through the literal trips instead of advancing with them)
                 if (op >= oend) { err = INF_OVERRUN; break; }
-                o[op++] = (uint8_t)sym;
+                lit |= (uint64_t)(uint32_t)sym << (8 * nl);
+                nl++; op++;
+                if (nl == 8) { *(u64u *)(o + (op - 8)) = lit; nl = 0; lit = 0; }
                 continue;
             }
+            flush_literals();
             if (sym == 256) break;
             sym -= 257;
             if (sym >= 29) { err = INF_BAD_CODE; break; }
             in.refill();
-            const uint32_t len = c_lbase[sym] + in.bits(c_lext[sym]);
+            // base and extra bits of length code sym in closed form (RFC 1951 3.2.5: codes come in groups of four per extra bit): no table load
+            const uint32_t lext = sym < 8 ? 0u : (sym == 28 ? 0u : (uint32_t)(sym - 4) >> 2);
+            const uint32_t lbase = sym < 8 ? (uint32_t)sym + 3u : (sym == 28 ? 258u : ((4u + ((uint32_t)sym & 3u)) << lext) + 3u);
+            const uint32_t len = lbase + in.bits((int)lext);
             in.refill();
             const int ds = decode_sym(in, cd, [&](int l) { return (int)T.based[l][lane]; }, [&](int k) { return (int)T.symd[k & (MAXD - 1)][lane]; });
             if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
             in.refill();
-            const uint32_t dist = c_dbase[ds] + in.bits(c_dext[ds]);
+            const uint32_t dext = ds < 4 ? 0u : (uint32_t)(ds - 2) >> 1;          // distance codes: groups of two per extra bit
+            const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dext) + 1u;
+            const uint32_t dist = dbase + in.bits((int)dext);
             if (dist > op) { err = INF_BAD_DIST; break; }
             if (op + len > oend) { err = INF_OVERRUN; break; }
             const uint8_t *src = o + op - dist;
             uint8_t *dst = o + op;
             // LZ77 copy.  Every chunk is a load -> store round trip through L2, so the chunk is as wide as the distance allows; wide
             // chunks may write a few bytes past the match (inside the member's own output, rewritten by what follows)
-            if (dist >= 16 && op + ((len + 15u) & ~15u) <= oend) {
-                for (uint32_t i = 0; i < len; i += 16) {
-                    const uint64_t a = *(const u64u *)(src + i), b = *(const u64u *)(src + i + 8);
-                    *(u64u *)(dst + i) = a; *(u64u *)(dst + i + 8) = b;
+            if (dist >= 64 && op + ((len + 15u) & ~15u) <= oend) {
+                // far enough back that 64 bytes of source cannot overlap what this round writes: up to four 16-byte chunks requested together,
+                // then stored -- one round trip per 64 bytes (the wave waits for its LONGEST match every step)
+                for (uint32_t i = 0; i < len; i += 64) {
+                    const uint32_t r = len - i;
+                    v4u a = *(const v4u *)(src + i), b = a, c = a, d = a;
+                    if (r > 16) b = *(const v4u *)(src + i + 16);
+                    if (r > 32) c = *(const v4u *)(src + i + 32);
+                    if (r > 48) d = *(const v4u *)(src + i + 48);
+                    *(v4u *)(dst + i) = a;
+                    if (r > 16) *(v4u *)(dst + i + 16) = b;
+                    if (r > 32) *(v4u *)(dst + i + 32) = c;
+                    if (r > 48) *(v4u *)(dst + i + 48) = d;
                 }
+            } else if (dist >= 16 && op + ((len + 15u) & ~15u) <= oend) {
+                for (uint32_t i = 0; i < len; i += 16) *(v4u *)(dst + i) = *(const v4u *)(src + i);
             } else if (dist >= 8 && op + ((len + 7u) & ~7u) <= oend) {
                 for (uint32_t i = 0; i < len; i += 8) *(u64u *)(dst + i) = *(const u64u *)(src + i);
             } else if (dist >= 4) {

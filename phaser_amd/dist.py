@@ -116,7 +116,7 @@ def write_chunks(f, chunks):
                         f.write(buf); left -= len(buf)
                     f.flush()
                 else:
-                    f.seek(0, 2)
+                    f.seek(os.lseek(f.fileno(), 0, os.SEEK_CUR))      # where sendfile left the descriptor (not the end: the file may be an older, longer one being overwritten)
         else:
             f.write(c)
 
@@ -298,9 +298,14 @@ def write_files(paths_and_chunks, threads: int = 8):
     items = list(paths_and_chunks)
 
     def put(item):
+        # No O_TRUNC: a file left by an earlier run under the same prefix is overwritten IN PLACE and cut to the new length at the end.  Truncating
+        # it first hands its page-cache pages back only to allocate as many again (0.09 s for the 770 MB of a genome's five files, measured).
+        import os
         path, chunks = item
-        with open(path, "wb") as f:
+        with os.fdopen(os.open(path, os.O_WRONLY | os.O_CREAT, 0o666), "wb") as f:
             write_chunks(f, chunks)
+            f.flush()
+            f.truncate(f.tell())
     if len(items) <= 1 or threads <= 1:
         for it in items:
             put(it)

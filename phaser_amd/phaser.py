@@ -102,9 +102,10 @@ def main(argv=None):
     try:
         return _main(argv, state)
     finally:
-        t = state.get("prefetch")
-        if t is not None and t.is_alive():
-            t.join()
+        for key in ("prefetch", "early"):
+            t = state.get(key)
+            if t is not None and t.is_alive():
+                t.join()
 
 
 def _main(argv, state):
@@ -160,6 +161,26 @@ def _main(argv, state):
     from .engine import binom_cdf_dedup
     threading.Thread(target=lambda: binom_cdf_dedup(_np.array([1]), _np.array([3]), 0.99), daemon=True).start()
 
+    # The device context (HIP runtime start-up, the library's code objects, the K_map stream: 0.1-0.2 s in a fresh process) is created on a
+    # helper thread from the first moment on -- the VCF is being read and gunzipped meanwhile; the BAM prefetch below takes it over
+    early = None
+    if (world == 1 and args.chr == "" and n_dev and os.environ.get("PHZ_BAM_HOST") != "1" and os.environ.get("PHZ_BAM_PREFETCH", "1") == "1"
+            and not any(b.endswith(".sam") for b in bam_list)):
+        early = {}
+
+        def _early():
+            t0 = time.perf_counter()
+            try:
+                from .mapper import Mapper
+                early["mapper"] = Mapper(local)
+            except BaseException as e:
+                early["err"] = e
+            early["seconds"] = time.perf_counter() - t0
+
+        early["thread"] = threading.Thread(target=_early, daemon=True, name="phz-ctx")
+        state["early"] = early["thread"]
+        early["thread"].start()
+
     def mark(name):          # PHZ_TIMING=1: stage timings on stderr at the end (not part of the reference's output)
         marks.append((name, time.perf_counter()))
     say('STARTED "Read backed phasing and ASE/haplotype analyses" ... ')
@@ -183,39 +204,57 @@ def _main(argv, state):
 
         arena = threading.Thread(target=_arena, daemon=True)
         arena.start()
-    data = vcf.read_bytes(args.vcf)
-    # The first BAM is inflated / decoded / filtered on the GPU (PCIe- and GPU-bound) WHILE the host parses the VCF: the stages share
-    # nothing but the names of the chromosomes to keep, which are guessed from the text here (vcf.contig_names_guess) and checked
-    # against the parsed table below -- a guess that does not cover the table discards the prefetch and the BAM is read as before.
+    # The first BAM is inflated / decoded / filtered on the GPU (PCIe- and GPU-bound) WHILE the host reads and parses the VCF: the stages
+    # share nothing but the names of the chromosomes to keep.  Those come from the VCF's tabix index when there is one (its sequence
+    # names: a few KB, before the VCF itself is touched), else they are guessed from the text once it is gunzipped
+    # (vcf.contig_names_guess); either way they are checked against the parsed table below -- names that do not cover the table discard
+    # the prefetch and the BAM is read as before.
     pre = None
-    if (world == 1 and args.chr == "" and n_dev and os.environ.get("PHZ_BAM_HOST") != "1" and os.environ.get("PHZ_BAM_PREFETCH", "1") == "1"
-            and not any(b.endswith(".sam") for b in bam_list)):
+    pre_ok = early is not None
+
+    def start_prefetch(guess):
+        nonlocal pre
+        pre = {"guess": set(guess), "ready": threading.Event()}
+        try:
+            pre["key"] = (int(args.mapq.split(",")[0]), float(args.isize.split(",")[0]), int(args.paired_end.split(",")[0]))
+        except ValueError:
+            pre = None
+            return
+
+        def _prefetch():
+            try:
+                t0 = time.perf_counter()
+                early["thread"].join()
+                if "err" in early:
+                    raise early["err"]
+                pre["mapper"] = early["mapper"]
+                pre["ready"].set()
+                its = {}
+                mq0, isz0, pe0 = pre["key"]
+                if os.environ.get("PHZ_TIMING"):
+                    sys.stderr.write("[phz timing]   device context %.3f s on its own thread; the BAM prefetch waited %.3f s for it and starts %.3f s into the run\n" % (
+                        early["seconds"], time.perf_counter() - t0, time.perf_counter() - marks[0][1]))
+                pre["shards"] = bamio.shards_from_bam_device(pre["mapper"].ctx, bam_list[0], its, mq0, args.remove_dups == 1, pe0 == 1, isz0, chroms=guess,
+                                                             device="cuda:%d" % local)
+                pre["interners"] = its
+            except BaseException as e:               # reported by the ordinary path, which runs instead
+                pre["err"] = e
+            finally:
+                pre["ready"].set()
+
+        pre["thread"] = threading.Thread(target=_prefetch, daemon=True, name="phz-bam-prefetch")
+        state["prefetch"] = pre["thread"]
+        pre["thread"].start()
+
+    if pre_ok:
+        names = vcf.contig_names_from_tbi(args.vcf + ".tbi")
+        if names:
+            start_prefetch([args.chr_prefix + c for c in names])
+    data = vcf.read_bytes(args.vcf)
+    if pre_ok and pre is None:
         guess = [args.chr_prefix + c for c in vcf.contig_names_guess(data)]
         if guess:
-            pre = {"guess": set(guess), "ready": threading.Event()}
-            try:
-                pre["key"] = (int(args.mapq.split(",")[0]), float(args.isize.split(",")[0]), int(args.paired_end.split(",")[0]))
-            except ValueError:
-                pre = None
-        if pre is not None:
-            def _prefetch():
-                try:
-                    from .mapper import Mapper
-                    pre["mapper"] = Mapper(local)
-                    pre["ready"].set()
-                    its = {}
-                    mq0, isz0, pe0 = pre["key"]
-                    pre["shards"] = bamio.shards_from_bam_device(pre["mapper"].ctx, bam_list[0], its, mq0, args.remove_dups == 1, pe0 == 1, isz0, chroms=guess,
-                                                                 device="cuda:%d" % local)
-                    pre["interners"] = its
-                except BaseException as e:               # reported by the ordinary path, which runs instead
-                    pre["err"] = e
-                finally:
-                    pre["ready"].set()
-
-            pre["thread"] = threading.Thread(target=_prefetch, daemon=True, name="phz-bam-prefetch")
-            state["prefetch"] = pre["thread"]
-            pre["thread"].start()
+            start_prefetch(guess)
     sample_col = None
     for raw in data.split(b"\n", 20000)[:20000]:          # the header sits at the top
         if b"#CHR" in raw:
@@ -278,7 +317,11 @@ def _main(argv, state):
                  include_indels=args.include_indels, host_threads=max(1, args.threads))
     if pre is not None:
         pre["ready"].wait()
-    eng = Engine(vs, bam_names, cfg, device=local, mapper=pre.get("mapper") if pre is not None else None)
+    mapper0 = pre.get("mapper") if pre is not None else None
+    if mapper0 is None and early is not None:          # no prefetch after all: the context made for it serves the ordinary path
+        early["thread"].join()
+        mapper0 = early.get("mapper")
+    eng = Engine(vs, bam_names, cfg, device=local, mapper=mapper0)
     eng.spool_dir = os.path.dirname(os.path.abspath(args.o))       # ranks hand their row text to rank 0 through files next to the outputs
     device = "cuda:%d" % local
     interners: Dict[str, object] = {}

@@ -129,6 +129,29 @@ def read_bytes(path: str, threads: int = 0) -> bytes:
         return f.read()
 
 
+def contig_names_from_tbi(path: str):
+    """Sequence names of a tabix index (.tbi: BGZF-compressed; magic TBI\\1, n_ref, five format words, l_nm, the names NUL-terminated),
+    or None when there is no such file / it is not a tabix index.  The names of the contigs that HAVE lines in the indexed file."""
+    import os, struct, zlib
+    try:
+        if not os.path.isfile(path) or os.path.getsize(path) > (256 << 20):
+            return None
+        with gzip.open(path, "rb") as f:
+            head = f.read(36)
+            if len(head) < 36 or head[:4] != b"TBI\x01":
+                return None
+            n_ref, l_nm = struct.unpack_from("<i", head, 4)[0], struct.unpack_from("<i", head, 32)[0]
+            if n_ref <= 0 or l_nm <= 0 or l_nm > (64 << 20):
+                return None
+            blob = f.read(l_nm)
+        if len(blob) != l_nm:
+            return None
+        names = [x.decode() for x in blob.split(b"\x00") if x]
+        return names if len(names) == n_ref else None
+    except (OSError, EOFError, ValueError, struct.error, UnicodeDecodeError, zlib.error):
+        return None
+
+
 def contig_names_guess(data: bytes, max_probes: int = 50000):
     """Distinct CHROM values of a VCF text whose contigs come in runs (every tabix-able file), found by bisection between line probes:
     O(contigs x log lines) line lookups instead of a pass over the text.  A GUESS: a contig scattered inside another contig's run can

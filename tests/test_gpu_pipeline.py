@@ -127,6 +127,37 @@ def test_cli_from_bam_matches_reference(tmp_path):
     assert gzip.open(prefix + ".vcf.gz.tbi", "rb").read()[:4] == b"TBI\x01"
 
 
+@pytest.mark.parametrize("index", ["tbi", "stale"])
+def test_cli_bam_prefetch_from_the_tabix_index(tmp_path, index, capfd):
+    """A tabix-indexed VCF (what the reference asks for, phaser.py:31): the first BAM's decode starts from the index's contig names before the VCF is gunzipped.
+    "stale": an index left over from another file names other contigs -- the prefetch is discarded after the VCF is parsed and the BAM is read again;
+    same five files either way (fixture pipe_one)."""
+    import gzip
+    from phaser_amd import bamio, phaser, synth, vcfout
+    v, gs, ge, w = synth.make_variants("chr22", 1, 3_000_000, 300, 201, n_genes=20)
+    rb = synth.make_reads(v, gs, ge, w, 9000, 202)
+    bam = str(tmp_path / "a.bam")
+    bamio.readbatch_to_bam(bam, [rb], [("chr21", 46709983), ("chr22", 50818468)])
+    d = os.path.join(GOLD, "pipe_one")
+    vcfgz = str(tmp_path / "in.vcf.gz")
+    assert vcfout.write_bgzf(vcfgz, open(os.path.join(d, "in.vcf")).read(), 2, index="vcf")
+    if index == "stale":
+        other = str(tmp_path / "other.vcf.gz")
+        text = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\nchr21\t100\tr1\tA\tC\t.\tPASS\t.\tGT\t0|1\n"
+        assert vcfout.write_bgzf(other, text, 1, index="vcf")
+        os.replace(other + ".tbi", vcfgz + ".tbi")
+    prefix = str(tmp_path / "out")
+    os.environ["PHZ_TIMING"] = "1"
+    try:
+        rc = phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1", "--o", prefix, "--write_vcf", "0", "--threads", "3"])
+    finally:
+        del os.environ["PHZ_TIMING"]
+    assert rc == 0
+    compare({name: open(prefix + "." + name + ".txt").read() for name in OUTPUTS}, d)
+    err = capfd.readouterr().err
+    assert ("bam prefetch during the VCF parse: used" in err) if index == "tbi" else ("bam prefetch during the VCF parse: discarded" in err), err[-1500:]
+
+
 def test_cli_py_hash_order_gives_the_reference_bytes(tmp_path):
     """--py_hash_order 1 under PYTHONHASHSEED=0: the drop-in CLI (GPU path from an unfiltered BAM) writes the reference's five files BYTE FOR BYTE
     (fixture pipe_one was written by the reference under the same hash seed): the raw tier of SURVEY.md 8(a)."""

@@ -235,3 +235,19 @@ def test_pinned_pool_never_recycles_a_buffer_with_live_views():
     b.release()
     assert mine <= {id(r) for r in PinnedPool._free}          # nothing points into them any more: all three are reusable (other tests' dead Engines may add theirs)
     del PinnedPool._free[:]
+
+
+def test_write_files_overwrites_in_place(tmp_path):
+    """dist.write_files over files left by an earlier run (longer, shorter, absent): exactly the new bytes, spliced spool ranges (sendfile) included."""
+    from phaser_amd import dist as pdist
+    spool = tmp_path / "spool.bin"
+    spool.write_bytes(bytes(range(256)) * 40)
+    new = {"a": [b"alpha\n", pdist.FileSpan(str(spool), 10, 5000), b"tail-a\n"], "b": [b"x" * 70000], "c": [pdist.FileSpan(str(spool), 0, 0), b""], "d": [b"d" * 10, pdist.FileSpan(str(spool), 256, 256)]}
+    want = {k: b"".join(pdist.as_bytes(c) for c in v) for k, v in new.items()}
+    (tmp_path / "a.txt").write_bytes(b"OLD" * 100000)            # longer than the new content
+    (tmp_path / "b.txt").write_bytes(b"old")                     # shorter
+    (tmp_path / "c.txt").write_bytes(b"something")               # new content is empty
+    for threads in (1, 4):
+        pdist.write_files([(str(tmp_path / (k + ".txt")), v) for k, v in new.items()], threads=threads)
+        for k in new:
+            assert (tmp_path / (k + ".txt")).read_bytes() == want[k], (k, threads)

@@ -205,3 +205,26 @@ def test_one_call_write_and_index_equals_the_two_steps(tmp_path):
     assert os.path.exists(u + ".tbi")
     assert vcfout.write_bgzf(u, "\n".join(back) + "\n", 4, index="bed") is False
     assert not os.path.exists(u + ".tbi")
+
+
+def test_contig_names_from_a_tabix_index(tmp_path):
+    """The CLI starts decoding the first BAM before the VCF is gunzipped when the VCF's .tbi names the contigs (phaser_amd/phaser.py); anything that is not
+    a tabix index gives None and the names are guessed from the text instead."""
+    from phaser_amd import _lib, vcf, vcfout
+    _lib.build()
+    text = gz_text(os.path.join(GOLD, "pipe_two", "out.vcf_gw1.txt.gz"))
+    p = str(tmp_path / "o.vcf.gz")
+    assert vcfout.write_bgzf(p, text, 2, index="vcf")
+    want = []
+    for line in text.split("\n"):
+        if line and not line.startswith("#"):
+            c = line.split("\t", 1)[0]
+            if c not in want:
+                want.append(c)
+    assert vcf.contig_names_from_tbi(p + ".tbi") == want and len(want) >= 2
+    assert vcf.contig_names_from_tbi(str(tmp_path / "none.tbi")) is None
+    assert vcf.contig_names_from_tbi(p) is None                      # a BGZF file, not an index
+    junk = str(tmp_path / "junk.tbi"); open(junk, "wb").write(b"\x1f\x8b\x08\x00 not gzip at all")
+    assert vcf.contig_names_from_tbi(junk) is None
+    cut = str(tmp_path / "cut.tbi"); open(cut, "wb").write(open(p + ".tbi", "rb").read()[:40])
+    assert vcf.contig_names_from_tbi(cut) is None

@@ -16,9 +16,14 @@ try:
     path, vcfgz, vsets, nrec, t_write = bench.write_genome_files(tmp, a, "cuda:0")
     print("BAM %d records, %.2f GB, written in %.1f s" % (nrec, os.path.getsize(path) / 1e9, t_write), flush=True)
     ctx = Mapper(0).ctx
-    for reg in ("1", "0"):
-        for mb in ("1280", "640", "2048", "4096"):
-            os.environ["PHZ_BAM_REGISTER"] = reg; os.environ["PHZ_BAM_CHUNK_MB"] = mb
+    settings = [(r, "1", mb) for r in ("1", "0") for mb in ("1280", "640", "2048", "4096")]
+    if os.environ.get("PHZ_SWEEP") == "streams":        # K_inflate launches of consecutive chunks on several streams (they fit the chip together since the hot/cold symbol tables)
+        settings = [("0", st, mb) for st, mb in (("1", "4096"), ("1", "1280"), ("3", "1280"), ("3", "640"), ("4", "320"))]
+    if os.environ.get("PHZ_SWEEP") == "streams2":
+        settings = [("0", st, mb) for st, mb in (("3", "1280"), ("2", "1280"), ("2", "2048"), ("3", "960"), ("4", "960"), ("4", "1280"), ("3", "1600"))]
+    for reg, nst, mb in settings:
+        if True:
+            os.environ["PHZ_BAM_REGISTER"] = reg; os.environ["PHZ_BAM_CHUNK_MB"] = mb; os.environ["PHZ_BAM_INFLATE_STREAMS"] = nst
             best = None
             for rep in range(3):
                 if rep == 2:
@@ -31,7 +36,7 @@ try:
                 kept = sum(s.n for s in sh.values())
                 del sh
                 best = dt if best is None else min(best, dt)
-            print("PHZ_BAM_REGISTER=%s PHZ_BAM_CHUNK_MB=%-5s file -> shards %.3f s (%.1f M BAM records/s, %.1f GB/s of BGZF), %d kept" %
-                  (reg, mb, best, nrec / best / 1e6, os.path.getsize(path) / best / 1e9, kept), flush=True)
+            print("PHZ_BAM_REGISTER=%s PHZ_BAM_INFLATE_STREAMS=%s PHZ_BAM_CHUNK_MB=%-5s file -> shards %.3f s (%.1f M BAM records/s, %.1f GB/s of BGZF), %d kept" %
+                  (reg, nst, mb, best, nrec / best / 1e6, os.path.getsize(path) / best / 1e9, kept), flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Build-container fuzz (needs /root/reference): the Python restatement of the phasing core (oracle/phasing_oracle.py, fed by the C
 mapper oracle) vs the reference's own process_vcf on freshly seeded inputs -- 1-3 chromosomes, 1-3 BAMs with shared QNAMEs, error
-rates up to 8 %, random max_block_size / cc_threshold / as_q_cutoff / unphased_vars / unique_ids / output_read_ids / BAM exclusion.
+rates up to 8 %, random max_block_size / cc_threshold / as_q_cutoff / unphased_vars / unique_ids / output_read_ids / gw_phase_method / BAM exclusion,
+BAMs without reads on some chromosomes.
 Canonical comparison of all five files.  usage: PYTHONHASHSEED=0 tools/fuzz_oracle_phasing.py [iterations=60] [seed=500]"""
 import os, random, subprocess, sys, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +28,8 @@ for it in range(iters):
     if rng.random() < 0.3: okw["cc_threshold"] = rng.choice([0.001, 0.05, 0.2])
     if rng.random() < 0.3: okw["as_q_cutoff"] = rng.choice([0.2, 0.5])
     if rng.random() < 0.2: okw["output_read_ids"] = 1
+    if rng.random() < 0.25: okw["gw_phase_method"] = 1          # MAF-weighted genome-wide phase (phaser.py:982-1025; the synthetic VCF carries AF=)
+    sparse = rng.random() < 0.3                                    # some BAMs have no read at all on some chromosomes (read_vars keys follow the first BAM with a kept line)
     excl = [rng.randrange(nbam)] if nbam > 1 and rng.random() < 0.3 else []
     vs_ = []; names = ["x%d.bam" % b for b in range(nbam)]
     sams = {b: {} for b in names}
@@ -40,7 +43,7 @@ for it in range(iters):
             rb = synth.make_reads(v, gs, ge, w, rng.choice([200, 500]) if (dense and L > 150) else rng.choice([1500, 4000]), seed0 * 11 + 17 * it + 10 * ci + bi, L=L,
                                   qname_prefix="q" if rng.random() < 0.7 else "q%d." % bi, err_rate=err)
             rf = rb.select(synth.samtools_keep(rb, 255))
-            sams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+            sams[bam][chrom] = "" if (sparse and rng.random() < 0.4 and not (ci == len(contigs) - 1 and bi == nbam - 1)) else "\n".join(synth.sam_lines(rf, contigs)) + "\n"
     vcf_text = "\n".join(synth.vcf_lines(vs_)) + "\n"
     refkw = dict(okw)
     if excl:
@@ -54,5 +57,5 @@ for it in range(iters):
     got = ph.finish()
     bad = [n for n in OUTPUTS if canonical(n, got[n]) != canonical(n, want[n])]
     bad_total += bool(bad)
-    print("iter %d: chroms %d bams %d err %.3f %s excl %s -> %s" % (it, nchrom, nbam, err, okw, excl, "OK" if not bad else "DIFF " + str(bad)), flush=True)
+    print("iter %d: chroms %d bams %d err %.3f %s excl %s%s -> %s" % (it, nchrom, nbam, err, okw, excl, " sparse" if sparse else "", "OK" if not bad else "DIFF " + str(bad)), flush=True)
 print("%d iterations, %d with differences" % (iters, bad_total))

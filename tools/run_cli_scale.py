@@ -47,7 +47,7 @@ for bi in range(n_bams):
     del batches
     t_write += time.perf_counter() - tw
 tw = time.perf_counter()
-vcfout.write_bgzf(vcfgz, "\n".join(synth.vcf_lines(vsets)) + "\n", threads)
+vcfout.write_bgzf(vcfgz, "\n".join(synth.vcf_lines(vsets)) + "\n", threads, index="vcf")       # the reference asks for a tabix-indexed VCF (phaser.py:31)
 t_write += time.perf_counter() - tw
 print("inputs: %d records in %d BAM(s), %d het SNPs | generate %.1fs | write BAM (%.2f GB) + VCF.gz (%.1f MB) %.1fs" %
       (nrec, n_bams, sum(len(v) for v in vsets), t_gen, sum(os.path.getsize(b) for b in bams) / 1e9, os.path.getsize(vcfgz) / 1e6, t_write), flush=True)
@@ -67,3 +67,13 @@ if os.environ.get("PHZ_CLI_SWEEP_CHUNK_MB"):        # BAM-stage experiment: the 
         sys.stderr.write("=== PHZ_BAM_CHUNK_MB=%s\n" % mb); sys.stderr.flush()
         phaser.main(["--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", ",".join(["255"] * n_bams), "--baseq", "10", "--paired_end", "1", "--o", "/tmp/cli_scale_out",
                      "--threads", str(threads), "--write_vcf", str(write_vcf)])
+if os.environ.get("PHZ_CLI_SUBPROCESS"):            # the same command in FRESH processes (what a user runs): the stage timers of each run, PHZ_TIMING=1
+    import subprocess
+    for k in range(int(os.environ["PHZ_CLI_SUBPROCESS"])):
+        env = dict(os.environ, PHZ_TIMING="1")
+        t5 = time.perf_counter()
+        pr = subprocess.run([sys.executable, "-m", "phaser_amd.phaser", "--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", ",".join(["255"] * n_bams), "--baseq", "10",
+                             "--paired_end", "1", "--o", "/tmp/cli_scale_out", "--threads", str(threads), "--write_vcf", str(write_vcf)], cwd=REPO, env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        keep = [l for l in pr.stdout.split("\n") if l.startswith("[phz timing]") and ("bam device:" in l or "total" in l or not l.startswith("[phz timing]  "))]
+        print("=== fresh process %d: rc %d, process wall %.2f s (interpreter + imports included)\n%s" % (k, pr.returncode, time.perf_counter() - t5, "\n".join(keep)), flush=True)

@@ -29,6 +29,7 @@ for it in range(iters):
     if nbam > 1 and rng.random() < 0.3: cfg["haplo_count_bam_exclude"] = [rng.randrange(nbam)]
     if rng.random() < 0.2: cfg["output_read_ids"] = 1
     if rng.random() < 0.25: cfg["gw_phase_method"] = 1          # MAF-weighted genome-wide phase (the synthetic VCF carries AF=...): on the device since round 5
+    sparse = rng.random() < 0.25                # some BAMs have no read at all on some chromosomes (block order then follows the first BAM that has one)
     vs_ = []; bams = {"x%d.bam" % b: {} for b in range(nbam)}
     for ci, (chrom, ln) in enumerate(contigs):
         dense = rng.random() < 0.35 and not many  # het SNPs every 5-40 bp: tens of calls per read, components of hundreds of variants
@@ -40,7 +41,7 @@ for it in range(iters):
             rb = synth.make_reads(v, gs, ge, w, rng.choice([300, 800]) if ((dense and L > 150) or many) else rng.choice([1500, 4000, 7000]), seed0 * 11 + 17 * it + 10 * ci + bi, L=L,
                                   qname_prefix="q" if rng.random() < 0.7 else "q%d." % bi, err_rate=err)
             rf = rb.select(synth.samtools_keep(rb, 255))
-            bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+            bams[bam][chrom] = "" if (sparse and rng.random() < 0.4 and not (ci == len(contigs) - 1 and bi == nbam - 1)) else "\n".join(synth.sam_lines(rf, contigs)) + "\n"
     vcf_text = "\n".join(synth.vcf_lines(vs_)) + "\n"
     # product
     vset = vcf.load_variants(vcf_text, gw_phase_method=cfg.get("gw_phase_method", 0))
@@ -68,7 +69,7 @@ for it in range(iters):
             ph.add_bam(texts)
     want = ph.finish()
     bad = [n for n in OUTPUTS if canonical(n, got[n]) != canonical(n, want[n])]
-    print("iter %d seed %d: chroms %d bams %d err %.3f cfg %s -> phased %d %s" % (it, seed0 + it, nchrom, nbam, err, cfg, eng.phased, "OK" if not bad else "DIFF " + str(bad)), flush=True)
+    print("iter %d seed %d: chroms %d bams %d%s err %.3f cfg %s -> phased %d %s" % (it, seed0 + it, nchrom, nbam, " sparse" if sparse else "", err, cfg, eng.phased, "OK" if not bad else "DIFF " + str(bad)), flush=True)
     if bad or eng.phased != ph.phased:
         # which path disagrees, and where: the same inputs through the other row stage / without the QNAME columns, first differing rows of every file
         def product(**over):
