@@ -782,19 +782,31 @@ def files_entries(mapper, dev, a):
         threads = max(1, min(64, 4 * pdist.effective_cpus()))
         runs = []
         out_prefix = os.path.join(tmp, "out")
-        import io, contextlib
+        # In a FRESH process each time, as a user runs it (the runtime's start-up inside the timed total): in this process the decoder's first hipMalloc of 19 GB
+        # right after torch has handed tens of GB back takes 0.25-0.4 s on some boxes (2 ms in a fresh process), which is the benchmark's doing, not the CLI's
+        import re, subprocess
+        wall = []
         for rep in range(2):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            with contextlib.redirect_stdout(io.StringIO()):
-                rc = phaser.main(["--vcf", vcfgz, "--bam", path, "--sample", "S1", "--mapq", "255", "--baseq", str(a.baseq), "--paired_end", "1", "--o", out_prefix,
-                                  "--threads", str(threads), "--write_vcf", "1"])
-            torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            runs.append((dt, dict(phaser.LAST_STAGE_SECONDS), rc))
+            env = dict(os.environ, PHZ_TIMING="1", PYTHONPATH=os.path.dirname(os.path.abspath(__file__)) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+                env.pop(k, None)
+            t0 = time.perf_counter()
+            pr = subprocess.run([sys.executable, "-m", "phaser_amd.phaser", "--vcf", vcfgz, "--bam", path, "--sample", "S1", "--mapq", "255", "--baseq", str(a.baseq), "--paired_end", "1",
+                                 "--o", out_prefix, "--threads", str(threads), "--write_vcf", "1"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                cwd=os.path.dirname(os.path.abspath(__file__)))
+            wall.append(time.perf_counter() - t0)
+            st_ = {}
+            for line in pr.stderr.split("\n"):
+                m_ = re.match(r"^\[phz timing\] (\S.*?)\s+([0-9.]+) s$", line)
+                if m_:
+                    st_[m_.group(1)] = float(m_.group(2))
+            runs.append((st_.get("total", wall[-1]), st_, pr.returncode))
         dt, stages, rc = min(runs, key=lambda r: r[0])
         sizes = {n: os.path.getsize("%s.%s.txt" % (out_prefix, n)) for n in ("allelic_counts", "variant_connections", "haplotypes", "haplotypic_counts", "allele_config")}
         e2e = {"workload": bam_path["workload"] + "; %d het SNPs in a bgzipped VCF; --write_vcf 1 --threads %d" % (sum(len(v) for v in vsets), threads),
                "command": "python -m phaser_amd.phaser --vcf g.vcf.gz --bam g.bam --sample S1 --mapq 255 --baseq %d --paired_end 1 --o out --threads %d --write_vcf 1" % (a.baseq, threads),
                "seconds": dt, "rc": rc, "bam_records_per_s": nrec / dt, "runs_s": [round(r[0], 3) for r in runs],
+               "process_wall_s": [round(w, 2) for w in wall], "seconds_is": "the CLI's own clock around main() in a fresh process (runtime start-up, device context, all stages); process_wall_s adds the interpreter and `import torch`",
                "stages_s": {k: round(v_, 3) for k, v_ in stages.items()}, "output_bytes": sizes,
                "phased_vcf_bytes": os.path.getsize(out_prefix + ".vcf.gz") if os.path.exists(out_prefix + ".vcf.gz") else None,
                "note": "files in /tmp (page cache); everything a user's run pays is inside: VCF read, BGZF inflate + BAM decode on the GPU (H2D of the compressed file), "

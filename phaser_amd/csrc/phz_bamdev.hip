@@ -592,6 +592,14 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     for (auto &e : stage_ev) e = nullptr;
     for (int t = 0; t < NCOPY * 2; t++) if (stage_ok && hipEventCreateWithFlags(&stage_ev[t], hipEventDisableTiming) != hipSuccess) stage_ev[t] = nullptr;
     int n_is = 1, n_launch = 0;
+    // K_inflate launches of consecutive chunks overlap only when their streams sit on different HARDWARE queues: the runtime spreads a process's streams over
+    // GPU_MAX_HW_QUEUES of them (default 4) and this call alone has eight copy streams -- a copy stream that shares the queue of a running K_inflate waits
+    // behind it, which serialised everything (profiles/r05/bam_device_sweep_streams.txt: 12 chunks on 4 streams 0.69 s with 4 queues, 0.30 s with 16).  With
+    // >= 16 queues (the package asks for them before the runtime starts, phaser_amd/__init__.py): 3 streams x 1,280 MB chunks, file -> shards 0.24 s; a host
+    // application that keeps the runtime's default gets ONE launch per 4 GB (0.27 s; 0.32 s with the old 1,280 MB chunks on one stream).
+    bool many_queues = false;
+    { const char *q = getenv("GPU_MAX_HW_QUEUES"); many_queues = q && atoi(q) >= 16; }
+    if (many_queues) n_is = 3;
     { const char *e = getenv("PHZ_BAM_INFLATE_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= 8) n_is = atoi(e); }
     std::vector<hipStream_t> is((size_t)n_is, nullptr);
     if (n_is > 1) {
@@ -599,9 +607,9 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
         for (int t = 0; t < n_is; t++) if (hipStreamCreateWithFlags(&is[(size_t)t], hipStreamNonBlocking) != hipSuccess) { is[(size_t)t] = nullptr; n_is = 1; }
     }
     {
-        // a launch needs ~100,000 members to fill the chip (a lane takes ~60 ms for its member however few there are): big chunks (PHZ_BAM_CHUNK_MB, default 1280)
+        // a launch lasts as long as its slowest member (60-100 ms) however few it holds, and the chip holds 262,000 members at once: big chunks (PHZ_BAM_CHUNK_MB)
         const char *ch_env = getenv("PHZ_BAM_CHUNK_MB");
-        const uint64_t CH = (ch_env && atoll(ch_env) > 0 ? (uint64_t)atoll(ch_env) : 1280ull) << 20;
+        const uint64_t CH = (ch_env && atoll(ch_env) > 0 ? (uint64_t)atoll(ch_env) : (many_queues ? 1280ull : 4096ull)) << 20;
         size_t ri = 0, i0 = 0;
         while (i0 < plan.members.size() && st == PHZ_OK) {
             while (ri + 1 < runs.size() && plan.members[i0].src >= runs[ri].second) ri++;
@@ -667,9 +675,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
                 if (st != PHZ_OK) break;
                 }
             }
-            // PHZ_BAM_INFLATE_STREAMS > 1 (experiment, default 1): the K_inflate launches take turns on several streams so that a chunk's members could start on
-            // the CUs the previous launch's tail leaves idle.  Measured (profiles/r05/bam_device_sweep.txt): no gain at 1,280 MB chunks (245 against 241 ms),
-            // and smaller chunks lose (640 MB: 327 ms) -- every launch pays the ~60 ms a lane needs for its member, however many launches overlap
+            // the K_inflate launches take turns on n_is streams: a chunk's members start while the previous launches are still running (see above)
             hipStream_t si = n_is > 1 ? is[(size_t)(n_launch % n_is)] : sm;
             st = phz_inflate_launch(ctx, (const uint8_t *)d_comp, (const phz_bgzf_member *)d_mem, (int64_t)i0, (int64_t)(i1 - i0), (uint8_t *)h->d_stream,
                                     (uint8_t *)ctx->scratch[11].p, d_status, si);

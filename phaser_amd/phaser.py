@@ -189,7 +189,7 @@ def _main(argv, state):
     # the host region that will receive the row text is page-locked on a helper thread while the VCF is read (~0.1 s per GB, independent of
     # everything else); sized from the BAMs, grown later if it turns out too small
     arena = None
-    if args.output_read_ids == 0 and not any(b.endswith(".sam") for b in args.bam.split(",")):
+    if args.output_read_ids == 0 and not any(b.endswith(".sam") for b in args.bam.split(",")) and os.environ.get("PHZ_EARLY_ARENA", "1") == "1":
         import threading
 
         def _arena():
@@ -482,8 +482,8 @@ def _main(argv, state):
         LAST_STAGE_SECONDS["total"] = marks[-1][1] - marks[0][1]
         if os.environ.get("PHZ_TIMING"):
             for (_, t_prev), (name, t) in zip(marks[:-1], marks[1:]):
-                sys.stderr.write("[phz timing] %-55s %7.2f s\n" % (name, t - t_prev))
-            sys.stderr.write("[phz timing] %-55s %7.2f s\n" % ("total", marks[-1][1] - marks[0][1]))
+                sys.stderr.write("[phz timing] %-55s %8.3f s\n" % (name, t - t_prev))
+            sys.stderr.write("[phz timing] %-55s %8.3f s\n" % ("total", marks[-1][1] - marks[0][1]))
     pdist.cleanup_spool()          # (barrier) every rank removes its spool file once rank 0 has written the outputs
     return 0
 

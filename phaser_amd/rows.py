@@ -84,7 +84,7 @@ def _fill(eng, c: str, keep: list) -> "_lib.phz_rows_in":
     I.threads = 1
     if cfg.output_read_ids == 1:
         from .vcf import sep_pool
-        qoff, qb = sep_pool(list(eng.qnames[c]))
+        qoff, qb = sep_pool(list(eng.qnames.get(c) or []))          # (a chromosome without a read in any BAM has no QNAME table)
         I.qname_off = A(qoff, np.uint32); I.qname = B(qb)
     return I
 
