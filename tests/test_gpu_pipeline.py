@@ -217,6 +217,43 @@ def test_fresh_seed_vs_oracle(mapper, oracle_build, tmp_path, seed, err):
     assert eng.phased == ph.phased and eng.phased > 50
 
 
+@pytest.mark.parametrize("read_ids", [0, 1])
+def test_chromosome_without_reads_in_any_bam(mapper, oracle_build, tmp_path, read_ids):
+    """Three chromosomes in the VCF, two BAMs: the middle chromosome has het SNPs but no read in either BAM (no shard, no QNAME table), the first one has
+    reads only in the second BAM.  Device row stage (read_ids 0) and the host twin with the QNAME columns (--output_read_ids 1) vs the pinned oracle."""
+    import subprocess
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import phasing_oracle as po
+    from phaser_amd import synth
+    contigs = [("chr3", 198295559), ("chr11", 135086622), ("chr19", 58617616)]
+    vs = []; bams = {"x1.bam": {}, "x2.bam": {}}
+    for ci, (chrom, ln) in enumerate(contigs):
+        v, gs, ge, w = synth.make_variants(chrom, 1, 1_000_000, 150, 9700 + ci, n_genes=8)
+        vs.append(v)
+        for bi, bam in enumerate(bams):
+            rb = synth.make_reads(v, gs, ge, w, 3000, 9710 + 10 * ci + bi, qname_prefix="q", err_rate=0.01)
+            rf = rb.select(synth.samtools_keep(rb, 255))
+            empty = ci == 1 or (ci == 0 and bi == 0)
+            bams[bam][chrom] = "" if empty else "\n".join(synth.sam_lines(rf, contigs)) + "\n"
+    vcf_text = "\n".join(synth.vcf_lines(vs)) + "\n"
+    got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=8, output_read_ids=read_ids)
+    assert eng.rows_path == ("device" if read_ids == 0 else "host")
+    pool, _, _ = po.load_vcf(vcf_text)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=8, output_read_ids=read_ids)
+    for bam, per_chrom in bams.items():
+        texts = []
+        for c in pool:
+            tp = tmp_path / "t.tsv"; tp.write_text("".join("\t".join(r) + "\n" for r in po.variant_table_rows(pool[c])[0]))
+            op = tmp_path / "c.tsv"
+            subprocess.run([os.path.join(oracle_build, "rvm_oracle"), "--variant_table", str(tp), "--baseq", "10", "--o", str(op)], input=per_chrom[c].encode(), check=True)
+            texts.append(op.read_text())
+        ph.add_bam(texts)
+    want = ph.finish()
+    for name in OUTPUTS:
+        assert canonical(name, got[name]) == canonical(name, want[name]), name
+    assert eng.phased == ph.phased and eng.phased > 30
+
+
 @pytest.mark.parametrize("seed,err,pairs,mbs", [(9101, 0.004, 30000, 15), (9102, 0.06, 14000, 6)])
 def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pairs, mbs):
     """Few genes, thousands of reads over every het SNP, two BAMs with shared QNAMEs: read sets of thousands of QNAMEs per haplotype (the
