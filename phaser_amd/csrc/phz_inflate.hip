@@ -25,6 +25,14 @@
 namespace {
 
 constexpr int IL = 64;             // lanes (members) per workgroup
+// PHZ_INF_ABL (tools/inflate_ab.sh, timing experiments only -- the output is wrong): 1 = no match copies, 2 = no literal stores.  Whole-genome BAM, 16 waves
+// per CU: 109 ms as shipped, 51 ms without the copies, 105 ms without the literal stores, 42 ms without both: half of the kernel is the load -> store round
+// trip of the LZ77 copies.  Storing a match's last chunks one step later (their loads under the next symbol's decode) changed nothing (100.7 against
+// 100.2 ms): every trip of the loop drains the wave's memory counter anyway -- some lane of the 64 needs its next 16 input bytes, and on gfx9 loads and
+// stores share one in-order counter.
+#ifndef PHZ_INF_ABL
+#define PHZ_INF_ABL 0
+#endif
 #ifndef PHZ_INF_HOT
 #define PHZ_INF_HOT 32
 #endif
@@ -178,9 +186,11 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
     uint64_t lit = 0; uint32_t nl = 0;             // pending literals: output bytes [op - nl, op)
     auto flush_literals = [&]() {
         if (nl) {
+#if !(PHZ_INF_ABL & 2)
             uint8_t *q = o + (op - nl);
             if (op - nl + 8 <= oend) *(u64u *)q = lit;
             else for (uint32_t i = 0; i < nl; i++) q[i] = (uint8_t)(lit >> (8 * i));
+#endif
             nl = 0; lit = 0;
         }
     };
@@ -260,7 +270,11 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
                 if (op >= oend) { err = INF_OVERRUN; break; }
                 lit |= (uint64_t)(uint32_t)sym << (8 * nl);
                 nl++; op++;
+#if PHZ_INF_ABL & 2          // timing experiment: literals dropped (wrong output)
+                if (nl == 8) { nl = 0; lit = 0; }
+#else
                 if (nl == 8) { *(u64u *)(o + (op - 8)) = lit; nl = 0; lit = 0; }
+#endif
                 continue;
             }
             flush_literals();
@@ -283,6 +297,9 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
             if (op + len > oend) { err = INF_OVERRUN; break; }
             const uint8_t *src = o + op - dist;
             uint8_t *dst = o + op;
+#if PHZ_INF_ABL & 1          // timing experiment: no match copies (wrong output)
+            op += len; continue;
+#endif
             // LZ77 copy.  Every chunk is a load -> store round trip through L2, so the chunk is as wide as the distance allows; wide
             // chunks may write a few bytes past the match (inside the member's own output, rewritten by what follows)
             if (dist >= 64 && op + ((len + 15u) & ~15u) <= oend) {
