@@ -229,6 +229,9 @@ typedef struct {                 /* one BGZF member */
 /* Inflates members whose compressed bytes are in DEVICE memory (16-byte aligned, readable for 16 bytes past the last member) into `out` (device).
  * *bad = 0, or a code > 0 when some member is not valid DEFLATE / does not produce ISIZE bytes: the output is unusable then. */
 int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t n_members, uint8_t *out, int *bad);
+/* CRC-32 of the inflated members in `out` (device) against `crc` (device; the CRC32 field of each member's trailer, in member order) -- the check htslib makes
+ * after inflating a BGZF block, i.e. where the reference's `samtools view` (phaser/phaser.py:1346) stops on a damaged file.  *bad = 0, or 7 on a mismatch. */
+int phz_bgzf_crc_device(phz_ctx *ctx, const uint8_t *out, const phz_bgzf_member *members, int64_t n_members, const uint32_t *crc, int *bad);
 
 /* A coordinate-sorted BAM file decoded on the device: plan on the host (member table, header, chromosome ranges), then H2D of the
  * compressed members, K_inflate, record boundaries + filters + kept-record list, and k_pack into caller-allocated DEVICE arrays with

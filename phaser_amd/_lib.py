@@ -220,6 +220,7 @@ SYMBOLS = {
     "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),
     "phz_components": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "phz_bgzf_inflate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]),
+    "phz_bgzf_crc_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]),
     "phz_bamdev_open": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(phz_bam_filters), C.POINTER(C.c_void_p)]),
     "phz_bamdev_close": (C.c_int, [C.c_void_p]),
     "phz_bamdev_n_ref": (C.c_int, [C.c_void_p]),

@@ -199,6 +199,11 @@ bool inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t isize)
     return rc == Z_STREAM_END && Z.zs.avail_out == 0;
 }
 
+// the CRC32 of a member's payload against the value in its trailer
+static bool crc_ok(const uint8_t *p, size_t n, uint32_t want) {
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)p, (uInt)n) == want;
+}
+
 int n_threads(int want) {
     if (want > 0) return want;
     unsigned h = std::thread::hardware_concurrency();
@@ -217,7 +222,7 @@ int inflate_bgzf_file(const char *path, int threads, Vec &outbuf) {
     const uint8_t *f = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (f == MAP_FAILED) return PHZ_E_NOMEM;
-    struct Blk { size_t off, csize, isize, dst; };
+    struct Blk { size_t off, csize, isize, dst; uint32_t crc; };
     std::vector<Blk> blks;
     size_t off = 0, total = 0;
     int status = PHZ_OK;
@@ -233,9 +238,9 @@ int inflate_bgzf_file(const char *path, int threads, Vec &outbuf) {
             x += 4 + slen;
         }
         if (!bsize) { status = PHZ_E_UNSUPPORTED; break; }
-        if (off + bsize > fsz) { status = PHZ_E_ARG; break; }
+        if (off + bsize > fsz || bsize < (uint32_t)xlen + 20) { status = PHZ_E_ARG; break; }
         const uint32_t isize = rd32(f + off + bsize - 4);
-        blks.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isize, total});
+        blks.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isize, total, rd32(f + off + bsize - 8)});
         total += isize;
         off += bsize;
     }
@@ -252,6 +257,7 @@ int inflate_bgzf_file(const char *path, int threads, Vec &outbuf) {
                 const size_t i = next.fetch_add(1);
                 if (i >= blks.size()) break;
                 if (blks[i].isize && !inflate_block(f + blks[i].off, blks[i].csize, (uint8_t *)outbuf.data() + blks[i].dst, blks[i].isize)) bad = true;
+                else if (!crc_ok((const uint8_t *)outbuf.data() + blks[i].dst, blks[i].isize, blks[i].crc)) bad = true;      // (htslib checks the same after inflating a block)
             }
         });
     for (auto &t : th) t.join();
@@ -302,7 +308,7 @@ size_t plausible_at(const uint8_t *d, size_t n, size_t p, int n_ref) {
 
 // member table of a BGZF file (nothing inflated)
 struct BgzfMap {
-    struct Blk { size_t off, csize, isize, dst; };
+    struct Blk { size_t off, csize, isize, dst; uint32_t crc; };          // crc: CRC32 of the member's payload, from its trailer
     const uint8_t *f = nullptr; size_t fsz = 0, total = 0;
     int fd = -1;
     std::vector<Blk> blks;
@@ -384,19 +390,19 @@ struct BgzfMap {
         // the member chain from `off` up to (not beyond) `stop`: -> where it arrived, members appended without their dst.  One read per
         // member: the last four bytes of member i (ISIZE) and the header of member i+1.
         auto walk = [&](size_t off, size_t stop, std::vector<Blk> &out, int *status, int rfd) -> size_t {
-            uint8_t h[4 + PEEK];
+            uint8_t h[8 + PEEK];
             size_t avail = 0;
-            if (off < stop && off + 18 <= fsz) { avail = std::min(PEEK, fsz - off); if (!fetch(off, avail, h + 4, rfd)) { *status = PHZ_E_ARG; return off; } }
+            if (off < stop && off + 18 <= fsz) { avail = std::min(PEEK, fsz - off); if (!fetch(off, avail, h + 8, rfd)) { *status = PHZ_E_ARG; return off; } }
             while (off < stop && off + 18 <= fsz) {
                 uint16_t xlen; int why;
-                const uint32_t bsize = header_in(off, h + 4, avail, &xlen, &why, rfd);
+                const uint32_t bsize = header_in(off, h + 8, avail, &xlen, &why, rfd);
                 if (!bsize) { *status = why; return off; }
                 const size_t nxt = off + bsize;
                 avail = std::min(PEEK, fsz - nxt);
-                if (!fetch(nxt - 4, 4 + avail, h, rfd)) { *status = PHZ_E_ARG; return off; }
-                const uint32_t isz = rd32(h);
+                if (!fetch(nxt - 8, 8 + avail, h, rfd)) { *status = PHZ_E_ARG; return off; }      // the trailer (CRC32, ISIZE) of this member and the header of the next
+                const uint32_t crc = rd32(h), isz = rd32(h + 4);
                 if (isz > 65536u) { *status = PHZ_E_ARG; return off; }        // BGZF: a member inflates to at most 64 KiB; the trailer is not trusted beyond that
-                out.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isz, 0});
+                out.push_back({off + 12 + xlen, (size_t)bsize - xlen - 20, isz, 0, crc});
                 off = nxt;
             }
             return off;
@@ -697,7 +703,7 @@ int phz_bam_plan_file(const char *path, const char *const *ref_names, int n_name
         while (lo < hi) { const size_t m = (lo + hi) >> 1; if (M->blks[m].dst + M->blks[m].isize <= p.u0) lo = m + 1; else hi = m; }
         for (b = lo; b < nb && M->blks[b].dst < p.u1; b++) {
             if (!out->members.empty() && out->members.back().dst == M->blks[b].dst) continue;
-            out->members.push_back({(uint64_t)M->blks[b].off, (uint32_t)M->blks[b].csize, (uint32_t)M->blks[b].isize, (uint64_t)M->blks[b].dst});
+            out->members.push_back({(uint64_t)M->blks[b].off, (uint32_t)M->blks[b].csize, (uint32_t)M->blks[b].isize, (uint64_t)M->blks[b].dst, M->blks[b].crc});
         }
         if (b > lo) b--;              // the last member of this piece may also be the first of the next one
     }
@@ -793,10 +799,10 @@ int phz_bam_open_refs(const char *path, int threads, const char *const *ref_name
                 if (k >= jobs.size()) break;
                 const Job &j = jobs[k];
                 const auto &B = M.blks[j.blk];
-                if (j.skip == 0 && j.take == B.isize) { if (!inflate_block(M.f + B.off, B.csize, dstbuf + j.dst, B.isize)) bad = true; }
+                if (j.skip == 0 && j.take == B.isize) { if (!inflate_block(M.f + B.off, B.csize, dstbuf + j.dst, B.isize) || !crc_ok(dstbuf + j.dst, B.isize, B.crc)) bad = true; }
                 else {
                     scratch.resize(B.isize);
-                    if (!inflate_block(M.f + B.off, B.csize, scratch.data(), B.isize)) { bad = true; continue; }
+                    if (!inflate_block(M.f + B.off, B.csize, scratch.data(), B.isize) || !crc_ok(scratch.data(), B.isize, B.crc)) { bad = true; continue; }
                     memcpy(dstbuf + j.dst, scratch.data() + j.skip, j.take);
                 }
             }

@@ -522,7 +522,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     bool got = false;
     for (int attempt = 0; attempt < 2 && !force_nomem && !got; attempt++) {
         d_comp = bam_take(&ctx->bam_comp, comp_bytes + 64, &d_comp_cap);
-        if (d_comp && hipMalloc(&d_mem, mem.size() * sizeof(phz_bgzf_member)) != hipSuccess) { (void)hipGetLastError(); d_mem = nullptr; }
+        if (d_comp && hipMalloc(&d_mem, mem.size() * sizeof(phz_bgzf_member) + mem.size() * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); d_mem = nullptr; }      // member table + the trailers' CRC32s behind it
         if (d_comp && d_mem) h->d_stream = bam_take(&ctx->bam_stream, out_bytes + 64, &h->d_stream_cap);
         got = d_comp && d_mem && h->d_stream;
         if (!got) {             // short of memory: the kept buffers (too small for this file) go back to the runtime, then one more try
@@ -557,6 +557,14 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     int *d_status = (int *)ctx->scalars.p;
     (void)hipMemsetAsync(d_status, 0, 4, sm);
     (void)hipMemcpyAsync(d_mem, mem.data(), mem.size() * sizeof(phz_bgzf_member), hipMemcpyHostToDevice, sm);
+    // every member's output is checked against the CRC32 of its trailer after it has been inflated (htslib does, so the reference's `samtools view` stops on a
+    // damaged file that is still valid DEFLATE); PHZ_BAM_CRC=0 skips the check
+    std::vector<uint32_t> crcs(plan.members.size());
+    for (size_t i = 0; i < plan.members.size(); i++) crcs[i] = plan.members[i].crc;
+    uint32_t *d_crc = (uint32_t *)((char *)d_mem + mem.size() * sizeof(phz_bgzf_member));
+    bool crc_on = true;
+    { const char *e = getenv("PHZ_BAM_CRC"); if (e && atoi(e) == 0) crc_on = false; }
+    if (crc_on) (void)hipMemcpyAsync(d_crc, crcs.data(), crcs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, sm);
     (void)hipEventRecord(e0, sm);
     int st = PHZ_OK;
     std::vector<hipEvent_t> evs;
@@ -679,6 +687,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
             hipStream_t si = n_is > 1 ? is[(size_t)(n_launch % n_is)] : sm;
             st = phz_inflate_launch(ctx, (const uint8_t *)d_comp, (const phz_bgzf_member *)d_mem, (int64_t)i0, (int64_t)(i1 - i0), (uint8_t *)h->d_stream,
                                     (uint8_t *)ctx->scratch[11].p, d_status, si);
+            if (st == PHZ_OK && crc_on) st = phz_crc_launch(ctx, (const phz_bgzf_member *)d_mem, (int64_t)i0, (int64_t)(i1 - i0), (const uint8_t *)h->d_stream, d_crc, d_status, si);
             n_launch++;
             i0 = i1;
         }
@@ -698,7 +707,7 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     (void)hipEventElapsedTime(&inflate_ms, e0, e1);
     ctx->last_ms[PHZ_T_INFLATE] = inflate_ms; ctx->total_ms[PHZ_T_INFLATE] += inflate_ms; ctx->launches[PHZ_T_INFLATE]++;
     bam_give_back(&ctx->bam_comp, d_comp, d_comp_cap); (void)hipFree(d_mem);
-    if (st != PHZ_OK || bad) { delete h; phz_bam_plan_release(&plan); if (st == PHZ_OK) ctx->err = "a BGZF member is not valid DEFLATE"; return st != PHZ_OK ? st : PHZ_E_UNSUPPORTED; }
+    if (st != PHZ_OK || bad) { delete h; phz_bam_plan_release(&plan); if (st == PHZ_OK) ctx->err = bad == 7 ? "a BGZF member does not give the CRC32 of its trailer" : "a BGZF member is not valid DEFLATE"; return st != PHZ_OK ? st : PHZ_E_UNSUPPORTED; }
     lap("H2D + K_inflate (+ free of the compressed copy)");
     phz_bam_plan_release(&plan);         // closes the file (nothing was mapped unless a fallback copied out of a mapping)
     lap("release of the plan");

@@ -102,7 +102,7 @@ typedef v4u_ __attribute__((aligned(1))) v4u;            // 16 unaligned bytes i
 __constant__ uint8_t c_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // status codes written to the per-call status word (first failure wins)
-enum { INF_OK = 0, INF_BAD_BLOCK = 1, INF_BAD_CODE = 2, INF_BAD_DIST = 3, INF_OVERRUN = 4, INF_SHORT = 5, INF_BAD_LENS = 6 };
+enum { INF_OK = 0, INF_BAD_BLOCK = 1, INF_BAD_CODE = 2, INF_BAD_DIST = 3, INF_OVERRUN = 4, INF_SHORT = 5, INF_BAD_LENS = 6, INF_BAD_CRC = 7 };
 
 // Per-lane tables in LDS, [slot][lane] (lanes on the same slot hit different banks), squeezed so that six waves fit a CU's 160 KB (26 KB each):
 // literal/length symbols as 8 low bits + a bit plane for bit 8 (values < 288), distance symbols as bytes.
@@ -334,7 +334,50 @@ __global__ __launch_bounds__(IL) void k_inflate(const uint8_t *comp, const Membe
     if (err) atomicCAS(status, 0, err);
 }
 
+// CRC-32 of every member's output against the value in its BGZF trailer (what htslib checks after inflating a block, so `samtools view` -- phaser.py:1346 --
+// stops on a damaged file where DEFLATE alone would accept it: a flipped bit inside a literal's code gives another valid literal).  One lane per member like
+// K_inflate, four bytes per step (slicing-by-4: four 256-entry tables in LDS, built by the workgroup), the output read in 16-byte requests.
+constexpr int CRC_BLOCK = 256;
+__global__ __launch_bounds__(CRC_BLOCK) void k_crc32(const uint8_t *out, const Member *mem, int64_t n_members, const uint32_t *want, int *status) {
+    __shared__ uint32_t T[4][256];
+    {
+        uint32_t c = (uint32_t)threadIdx.x;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        T[0][threadIdx.x] = c;
+    }
+    __syncthreads();
+    {
+        uint32_t c = T[0][threadIdx.x];
+        for (int t = 1; t < 4; t++) { c = T[0][c & 0xffu] ^ (c >> 8); T[t][threadIdx.x] = c; }
+    }
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * CRC_BLOCK + threadIdx.x;
+    if (m >= n_members) return;
+    const Member M = mem[m];
+    const uint8_t *p = out + M.dst;
+    const uint32_t n = M.isize;
+    uint32_t crc = 0xFFFFFFFFu, i = 0;
+    auto word = [&](uint32_t w) {
+        crc ^= w;
+        crc = T[3][crc & 0xffu] ^ T[2][(crc >> 8) & 0xffu] ^ T[1][(crc >> 16) & 0xffu] ^ T[0][crc >> 24];
+    };
+    for (; i + 16 <= n; i += 16) {
+        const v4u v = *(const v4u *)(p + i);
+        word(v[0]); word(v[1]); word(v[2]); word(v[3]);
+    }
+    for (; i < n; i++) crc = T[0][(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    if ((crc ^ 0xFFFFFFFFu) != want[m]) atomicCAS(status, 0, (int)INF_BAD_CRC);
+}
+
 }  // namespace
+
+// internal: CRC check of members [first, first + count) on stream `s` (after their K_inflate on the same stream); want = the trailers' CRC32s (device, per member of the table)
+int phz_crc_launch(phz_ctx *ctx, const phz_bgzf_member *members, int64_t first, int64_t count, const uint8_t *out, const uint32_t *want, int *d_status, hipStream_t s) {
+    if (count <= 0) return PHZ_OK;
+    hipLaunchKernelGGL(k_crc32, dim3((unsigned)((count + CRC_BLOCK - 1) / CRC_BLOCK)), dim3(CRC_BLOCK), 0, s, out, (const Member *)members + first, count, want + first, d_status);
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
 
 // internal: members [first, first + count) of a device member table on stream `s`; d_status (device int, zeroed by the caller) and
 // the code-length scratch ([n_members * 320] bytes) are shared by all launches of a call
@@ -373,5 +416,23 @@ extern "C" int phz_bgzf_inflate_device(phz_ctx *ctx, const uint8_t *comp, const 
     float ms = 0;
     PHZ_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->last_ms[PHZ_T_INFLATE] = ms; ctx->total_ms[PHZ_T_INFLATE] += ms; ctx->launches[PHZ_T_INFLATE]++;
+    return PHZ_OK;
+}
+
+// CRC-32 of the inflated members in `out` (device) against `crc` (device: the CRC32 field of every member's BGZF trailer, member order): *bad = 0, or 7 when
+// some member's bytes do not give its checksum.
+extern "C" int phz_bgzf_crc_device(phz_ctx *ctx, const uint8_t *out, const phz_bgzf_member *members, int64_t n_members, const uint32_t *crc, int *bad) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || !out || !members || !crc || !bad || n_members < 0) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    *bad = 0;
+    if (n_members == 0) return PHZ_OK;
+    hipStream_t sm = ctx->stream;
+    if (int s = phz_reserve(ctx, ctx->scalars, 64)) return s;
+    int *d_status = (int *)ctx->scalars.p;
+    PHZ_HIP(ctx, hipMemsetAsync(d_status, 0, 4, sm));
+    if (int s = phz_crc_launch(ctx, members, 0, n_members, out, crc, d_status, sm)) return s;
+    PHZ_HIP(ctx, hipMemcpyAsync(bad, d_status, 4, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipStreamSynchronize(sm));
     return PHZ_OK;
 }

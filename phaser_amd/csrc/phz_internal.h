@@ -129,7 +129,7 @@ struct PhzBamPlan {
     std::vector<uint8_t> head;                             // inflated bytes from the file start; the header ends at first_record
     size_t first_record = 0;
     std::vector<std::pair<uint64_t, uint64_t>> pieces;     // [u0, u1) of the inflated stream (global offsets), cut at record boundaries
-    struct Mem { uint64_t src; uint32_t csize, isize; uint64_t dst; };
+    struct Mem { uint64_t src; uint32_t csize, isize; uint64_t dst; uint32_t crc; };          // crc: the CRC32 field of the member's trailer
     std::vector<Mem> members;                              // members that overlap a piece, file order; dst = global inflated offset
     const uint8_t *file = nullptr; size_t file_size = 0;   // the mapped file: NULL until phz_bam_plan_map (valid until phz_bam_plan_release)
     void *owner = nullptr;
@@ -142,4 +142,6 @@ void phz_bam_plan_release(PhzBamPlan *p);
 int phz_inflate_launch(phz_ctx *ctx, const uint8_t *comp, const phz_bgzf_member *members, int64_t first, int64_t count, uint8_t *out,
                        uint8_t *lens_scratch, int *d_status, hipStream_t s);
 int phz_inflate_scratch_bytes_per_member();
+// CRC-32 check of the same members' output against the trailers' values (want: device array, one per member of the table), status code 7 into d_status
+int phz_crc_launch(phz_ctx *ctx, const phz_bgzf_member *members, int64_t first, int64_t count, const uint8_t *out, const uint32_t *want, int *d_status, hipStream_t s);
 

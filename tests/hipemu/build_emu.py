@@ -10,7 +10,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "phaser_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libphz_emu.so")
-UNITS = ["phz_api.hip", "phz_tally.hip", "phz_rowsdev.hip", "phz_rows.cpp"]
+UNITS = ["phz_api.hip", "phz_tally.hip", "phz_rowsdev.hip", "phz_rows.cpp", "phz_inflate.hip"]
 
 
 def build(verbose=False, tally_tile=0, row_wave_min=None, stat_n=None):

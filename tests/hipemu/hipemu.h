@@ -117,6 +117,14 @@ template <class T> struct Gather {
 #define __device__
 #define __host__
 #define __shared__ static
+#define __constant__ static const
+#define ext_vector_type(N) vector_size(4 * (N))          // clang's vector attribute spelled for g++ (the emulated units use 4-byte elements only)
+inline unsigned __builtin_bitreverse32(unsigned v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(v);
+}
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict

@@ -376,6 +376,42 @@ def test_member_walk_without_a_mapping(tmp_path, monkeypatch):
     assert outcome() == a
 
 
+def _damage_bgzf(raw, rng, what):
+    """raw: a BGZF file; -> a copy with ONE member damaged below the BAM level: `crc` = a flipped bit in a trailer's CRC32, `payload` = a flipped bit somewhere in a
+    deflate stream (often still valid DEFLATE of the right length)."""
+    import struct
+    members = []; off = 0
+    while off + 18 <= len(raw):
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        members.append((off, bsize)); off += bsize
+    off, bsize = members[int(rng.integers(1, len(members) - 1))]         # not the header member, not the EOF member
+    m = bytearray(raw)
+    at = off + bsize - 8 + int(rng.integers(0, 4)) if what == "crc" else off + 18 + int(rng.integers(0, bsize - 26))
+    m[at] ^= 1 << int(rng.integers(0, 8))
+    return bytes(m)
+
+
+def test_damaged_bgzf_members_are_refused(tmp_path):
+    """htslib checks the CRC32 of every BGZF block it inflates, so `samtools view` (phaser/phaser.py:1346) stops on a file whose bytes were damaged in storage;
+    so does the host decoder here: a flipped bit in a trailer's CRC32 or in a deflate stream never yields shards."""
+    from phaser_amd import _lib, bamio, synth
+    _lib.build()
+    v, gs, ge, w = synth.make_variants("chr21", 1, 8_000_000, 400, 95, n_genes=40)
+    rb = synth.make_reads(v, gs, ge, w, 20_000, 96)
+    path = str(tmp_path / "m.bam")
+    bamio.readbatch_to_bam_native(path, [rb], [("chr21", 46709983), ("chr22", 50818468)], 4)
+    raw = open(path, "rb").read()
+    want = bamio.shards_from_bam_native(path, {}, 0, False, False, threads=2)["chr21"]
+    assert want.n > 10_000
+    rng = np.random.default_rng(8)
+    for trial in range(16):
+        bad = str(tmp_path / ("bad%d.bam" % trial))
+        open(bad, "wb").write(_damage_bgzf(raw, rng, "crc" if trial % 2 == 0 else "payload"))
+        for chroms in (None, {"chr21"}):                       # whole-file open and the member-table open
+            with pytest.raises(_lib.PhzError):
+                bamio.shards_from_bam_native(bad, {}, 0, False, False, chroms=chroms, threads=2)
+
+
 def test_bgzf_member_claiming_more_than_64k_is_refused(tmp_path):
     """BGZF members inflate to at most 64 KiB; a trailer that claims more is not trusted (it would size host and device buffers)."""
     import struct

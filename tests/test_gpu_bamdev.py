@@ -256,6 +256,43 @@ def test_device_interning_then_a_second_bam(ctx, tmp_path):
         assert hi[c].names == di[c].names
 
 
+def test_device_path_refuses_damaged_bgzf_members(ctx, tmp_path):
+    """Bits flipped BELOW the BAM level -- in a member's CRC32 or in its deflate stream, which often stays valid DEFLATE of the right length: the device path checks
+    every member's output against its trailer's CRC32 (k_crc32; htslib does the same, so the reference's samtools stops on such a file) and hands the file over
+    (None) -- to the host decoder, which refuses it for the same reason.  It never returns shards."""
+    import numpy as np
+    from test_bamio import _damage_bgzf
+    from phaser_amd import _lib, bamio, synth
+    v, gs, ge, w = synth.make_variants("chr21", 1, 8_000_000, 400, 95, n_genes=40)
+    rb = synth.make_reads(v, gs, ge, w, 20_000, 96)
+    path = str(tmp_path / "m.bam")
+    bamio.readbatch_to_bam_native(path, [rb], [("chr21", 46709983), ("chr22", 50818468)], 4)
+    raw = open(path, "rb").read()
+    good = bamio.shards_from_bam_device(ctx, path, {}, 0, False, False, 0.0, device="cuda:0")
+    assert good is not None and good["chr21"].n > 10_000
+    rng = np.random.default_rng(9)
+    n_crc_only = 0
+    for trial in range(16):
+        bad = str(tmp_path / ("bad%d.bam" % trial))
+        open(bad, "wb").write(_damage_bgzf(raw, rng, "crc" if trial % 2 == 0 else "payload"))
+        try:
+            got = bamio.shards_from_bam_device(ctx, bad, {}, 0, False, False, 0.0, device="cuda:0")
+        except _lib.PhzError:
+            got = None
+        assert got is None, trial
+        os.environ["PHZ_BAM_CRC"] = "0"                      # without the check: what DEFLATE alone lets through
+        try:
+            try:
+                n_crc_only += bamio.shards_from_bam_device(ctx, bad, {}, 0, False, False, 0.0, device="cuda:0") is not None
+            except _lib.PhzError:
+                pass
+        finally:
+            del os.environ["PHZ_BAM_CRC"]
+        with pytest.raises(_lib.PhzError):
+            bamio.shards_from_bam_native(bad, {}, 0, False, False, threads=2)
+    assert n_crc_only >= 8                                   # (every damaged checksum, and some of the damaged streams)
+
+
 def test_device_path_on_corrupt_bam_streams(ctx, tmp_path):
     """The mutations of tests/test_native_robustness.py (block_size / l_read_name / n_cigar / l_seq of records, noise, cut tails, header
     fields) through the DEVICE path: it raises, declines (None) or returns exactly what the host decoder returns -- never a crash,
