@@ -47,3 +47,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(root, f)).read()
                 assert "rvm_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_package_asks_for_hardware_queues_unless_the_user_did():
+    """phaser_amd/__init__.py: GPU_MAX_HW_QUEUES=16 before the ROCm runtime starts (the device BAM decoder overlaps K_inflate launches and copies on
+    separate hardware queues), never over a value the user exported."""
+    import subprocess, sys
+    code = "import os, phaser_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["PYTHONPATH"] = REPO
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip() == "16"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip() == "4"
