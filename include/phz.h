@@ -116,7 +116,13 @@ typedef struct {
     int32_t bam_index;
     int64_t var_base;            /* phz_tally over several chromosomes: index of the chromosome's first variant / first QNAME id */
     int64_t qid_base;            /* in the call's joint index spaces (0 for a single chromosome) */
+    const int16_t *read_as16;    /* optional (NULL = absent): AS per record as ONE 2-byte plane with the has-AS flag folded in (SURVEY.md 8(a) M1 `as:int16`):
+                                  * PHZ_AS16_NONE = the record carries no AS tag, +-PHZ_AS16_RANGE = an AS value outside [-32766, 32766] (refused like any value
+                                  * outside int16).  When present the kernels gather this plane instead of read_as + read_has_as (2 instead of 5 bytes per record
+                                  * touched, one memory line instead of two) */
 } phz_lines;
+#define PHZ_AS16_NONE (-32768)
+#define PHZ_AS16_RANGE 32767
 
 #define PHZ_AS_BINS 65536        /* histogram bin = AS + 32768 */
 
@@ -171,7 +177,8 @@ enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, P
 /* work counters accumulated over phz_tally calls since the last phz_reset_timing (the units of K_tally's byte model):
  * call lines seen, distinct (QNAME, variant, class) items, pair events = sum over QNAMEs of C(k, 2) item pairs on different
  * variants, distinct variant pairs (edges) */
-enum { PHZ_C_LINES = 0, PHZ_C_ITEMS = 1, PHZ_C_PAIR_EVENTS = 2, PHZ_C_EDGES = 3, PHZ_C_COUNT = 8 };
+enum { PHZ_C_LINES = 0, PHZ_C_ITEMS = 1, PHZ_C_PAIR_EVENTS = 2, PHZ_C_EDGES = 3, PHZ_C_FAR_LINES = 4 /* call lines outside their tile's variant window */,
+       PHZ_C_DIRTY_LISTS = 5 /* read lists filled through a cursor and sorted (they hold a far line) */, PHZ_C_COUNT = 8 };
 
 int phz_version(void);
 const char *phz_strerror(int status);

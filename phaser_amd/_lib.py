@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 PHZ_OK, PHZ_E_ARG, PHZ_E_HIP, PHZ_E_CAPACITY, PHZ_E_UNSUPPORTED, PHZ_E_NOMEM = 0, -1, -2, -3, -4, -5
 PHZ_HOST, PHZ_DEVICE = 0, 1
 PHZ_T_MAP, PHZ_T_ASHIST, PHZ_T_TALLY, PHZ_T_COMPONENTS, PHZ_T_GENES, PHZ_T_INFLATE, PHZ_T_BAMPACK, PHZ_T_ROWS = 0, 1, 2, 3, 4, 5, 6, 7
-PHZ_C_LINES, PHZ_C_ITEMS, PHZ_C_PAIR_EVENTS, PHZ_C_EDGES = 0, 1, 2, 3
+PHZ_C_LINES, PHZ_C_ITEMS, PHZ_C_PAIR_EVENTS, PHZ_C_EDGES, PHZ_C_FAR_LINES, PHZ_C_DIRTY_LISTS = 0, 1, 2, 3, 4, 5
 
 
 class PhzError(RuntimeError):
@@ -53,7 +53,7 @@ class phz_lines(C.Structure):
     _fields_ = [("n_calls", C.c_int64), ("read_idx", C.c_void_p), ("var_idx", C.c_void_p), ("code", C.c_void_p),
                 ("n_reads", C.c_int64), ("read_qid", C.c_void_p), ("read_as", C.c_void_p), ("read_has_as", C.c_void_p),
                 ("as_cutoff", C.c_double), ("use_cutoff", C.c_int32), ("bam_index", C.c_int32),
-                ("var_base", C.c_int64), ("qid_base", C.c_int64)]
+                ("var_base", C.c_int64), ("qid_base", C.c_int64), ("read_as16", C.c_void_p)]
 
 
 class phz_tally_sizes(C.Structure):

@@ -2,25 +2,30 @@
 // (chromosome, BAM) shards in one submission (variant and QNAME ids are offset per chromosome into one index space, so a whole
 // genome is one call and nothing ever pairs across chromosomes):
 //   k_as_hist      :545-553   AS column histogram (host turns it into numpy.percentile's value)
-//   k_line         :1287-1328 process_mapping_result: AS cutoff, allele class, per-variant line counters, first-appearance index, lines per
-//                             QNAME and per (variant, allele, BAM) read list
+//   k_tile_base               window base of every tile of 1,024 call lines: the variant of its first line, made monotone over the shard's tiles
+//   k_line         :1287-1328 process_mapping_result: AS cutoff, allele class, first-appearance index; per TILE the kept lines of every
+//                             (window variant, class) -- the band matrix M -- and the tile's QNAMEs as bits of two bitmaps over the QNAME ids
+//                             ("seen by a tile", "seen by a second tile")
+//   k_colscan                 column sums and column prefixes of M: per-variant line counters, lines per (variant, allele, BAM) read list, and
+//                             for every (tile, list) the number of the list's entries in EARLIER tiles -- so that k_tile can put a read-list
+//                             entry at its final, line-ordered place (:1318, :917-931, :1086-1115) without a sort
 //   k_tile         :636-640, :558-581, :1265-1285  the lines of a QNAME are its mates' records, a few hundred bases apart: nearly every QNAME has
-//                             all its lines inside one tile of 1,024 consecutive lines.  A workgroup groups its tile's lines by QNAME in LDS
-//                             (hash on the id); a group that holds ALL lines of its QNAME (the per-QNAME total of k_line says so) is finished
-//                             in place: sorted, its first ref/alt line, the connectivity-map rank of its variants, the distinct
-//                             (variant, class) items and the per-variant distinct-QNAME counters.  Lines of the few QNAMEs that straddle
-//                             tiles (or BAMs) are spilled.  Read-list entries are placed into their (variant, allele, BAM) list, one global
-//                             cursor step per (tile, list)
+//                             all its lines inside one tile.  A workgroup groups its tile's lines by QNAME in LDS (hash on the id); a group whose
+//                             QNAME no other tile has seen is finished in place: sorted, its first ref/alt line, the connectivity-map rank of its
+//                             variants, the distinct (variant, class) items and the per-variant distinct-QNAME counters.  Lines of the few QNAMEs
+//                             that straddle tiles (or BAMs) are spilled.  Read-list entries go straight to their place: list start + entries in
+//                             earlier tiles (k_colscan) + entries in earlier rows of the tile + rank inside the row (wave ballots)
 //   k_groups                  the spilled QNAMEs (a per cent of them): gathered into groups through cursors, one thread per group, incl. the
 //                             owner BAM of the read_vars list ("last BAM wins", stale-variable quirk)
 //   k_pairs        :1602-1632 every QNAME contributes one count to cell (class_a, class_b) of every variant pair it touches -- the nine set
 //                             intersections of test_variant_connection for all pairs at once (LDS hash -> global hash)
 //   k_edge_*                  edge list in (a, b) order: counting sort by a over the USED hash slots, tiny groups sorted by b; the table is
 //                             cleaned slot by slot while it is read (no per-call memset of a 400 MB table)
-//   k_rl_sort*     :1318, :917-931, :1086-1115  read lists: the entries of every list put into line order (they were placed by atomics)
+//   k_rl_sort_dirty           the few read lists with a line outside its tile's variant window (a read spliced over hundreds of het SNPs) are
+//                             filled through cursors and sorted afterwards
 //   k_components   :1861-1882/:1985-1998 connected components (lock-free union-find)
-// Integer work, hand-written kernels and primitives only (phz_sort.h).  Nothing is sized or cleared by the number of QNAME ids per call
-// except two persistent arrays (lines per QNAME -- returned to zero by the kernels themselves -- and the group base per QNAME).
+// Integer work, hand-written kernels and primitives only (phz_sort.h).  Nothing is swept by the number of QNAME ids per call except two
+// bitmaps (one bit per id each, cleared per call); the per-QNAME cursor array is touched for spilled QNAMEs only and returns to zero.
 #include <cstring>
 #include "phz_internal.h"
 #include "phz_sort.h"
@@ -46,7 +51,22 @@ struct LinesDev {
     int32_t var_base;          // first variant of the shard's chromosome in the call's variant space
     uint32_t qid_base;         // first QNAME id of the shard's chromosome in the call's id space
     int64_t line_base;         // index of the shard's first line in the call's line space (shards ordered chromosome, BAM)
+    const int16_t *read_as16;  // 2-byte AS plane with the has-AS flag folded in (phz.h), or NULL
+    int32_t nv_chrom;          // variants of the shard's chromosome: [var_base, var_base + nv_chrom) of the call's variant space
 };
+// AS of record r from whichever form the shard carries; false = the record has no AS tag.  *range = the value lies outside the band the
+// histogram accepts (the caller refuses the input)
+__device__ __forceinline__ bool as_of(const LinesDev &L, int r, int *a, bool *range) {
+    if (L.read_as16) {
+        const int x = L.read_as16[r];
+        *a = x; *range = x == PHZ_AS16_RANGE || x == -PHZ_AS16_RANGE;
+        return x != PHZ_AS16_NONE;
+    }
+    if (L.read_has_as && !L.read_has_as[r]) { *a = 0; *range = false; return false; }
+    const int x = L.read_as[r];
+    *a = x; *range = x < -32768 || x >= 32768;
+    return true;
+}
 
 // All shards of a call go through ONE grid per per-line stage: block b belongs to the shard s with blk0[s] <= b < blk0[s+1]
 // (a genome is 22+ shards of well under a million lines each: one launch per shard is mostly ramp-up and tail).
@@ -82,12 +102,12 @@ __global__ __launch_bounds__(256) void k_as_hist(LinesTab T, unsigned long long 
     __syncthreads();
     for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < L.n; i += (int64_t)gx * 256) {
         const int r = L.read_idx[i];
-        if (L.read_has_as && !L.read_has_as[r]) continue;
-        const int a = L.read_as[r];
+        int a; bool range;
+        if (!as_of(L, r, &a, &range)) continue;
         const int b = a + AS_LDS_BINS / 2;
-        if ((unsigned)b < (unsigned)AS_LDS_BINS) atomicAdd(&s_h[b], 1u);
-        else if (a >= -32768 && a < 32768) atomicAdd(&hist[a + 32768], 1ull);
-        else if (out_of_range) atomicOr(out_of_range, 1u);              // an alignment score outside int16: the caller refuses the input
+        if (range) { if (out_of_range) atomicOr(out_of_range, 1u); }    // an alignment score outside int16: the caller refuses the input
+        else if ((unsigned)b < (unsigned)AS_LDS_BINS) atomicAdd(&s_h[b], 1u);
+        else atomicAdd(&hist[a + 32768], 1ull);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < AS_LDS_BINS; j += 256)
@@ -118,27 +138,61 @@ __global__ __launch_bounds__(1024) void k_hist_compact(const unsigned long long 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ per-line pass
-// Call lines arrive in mapper order (record, then variant) and records are coordinate-sorted, so the lines of one
-// workgroup touch a narrow run of variant indices, and deeply covered variants repeat hundreds of times in a row.
-// Counters are therefore accumulated in an LDS window [vbase, vbase + TW) with LDS atomics and flushed once per
-// workgroup; only lines outside the window (introns reaching far) use global atomics directly.
-constexpr int TW = 1024;            // variants per LDS window
-constexpr int LINES_PER_BLOCK = 2048;
+// ------------------------------------------------------------------------------------------------ tiles, windows, the per-line pass
+// Call lines arrive in mapper order (record, then variant) and records are coordinate-sorted, so a TILE of TL consecutive lines of a shard
+// touches a narrow run of variant indices -- its WINDOW [wb, wb + TWT) -- and deeply covered variants repeat hundreds of times in a row.
+// k_line and k_tile work on the same tiles (workgroup = tile) and the same windows.
+constexpr int TW = 1024;            // variants per LDS window of k_groups
+#ifndef PHZ_TALLY_TILE
+#define PHZ_TALLY_TILE 1024        // (the emulation tests also build a 256-line variant so that small fixtures straddle tiles)
+#endif
+constexpr int TL = PHZ_TALLY_TILE; // lines per tile
+static_assert(TL == 1024 || TL == 512 || TL == 256, "tile of 256 / 512 / 1024 lines");
+constexpr int TWT = 256;           // variants per tile window (1,024 lines span ~100 variants)
+constexpr int QW = 16384;          // QNAME ids of the LDS bitmap of k_line (a tile's QNAMEs: the ids handed out while its ~4,000 records went by, and their mates')
 #ifndef PHZ_LINE_TB
 #define PHZ_LINE_TB 512
 #endif
-constexpr int LINE_TB = PHZ_LINE_TB;   // threads per workgroup of k_line
+constexpr int LINE_TB = PHZ_LINE_TB < TL ? PHZ_LINE_TB : TL;   // threads per workgroup of k_line
+
+// Window base of every tile: the variant of the tile's first line minus a little room (mate pairs / overlapping records), then made
+// non-decreasing over the shard's tiles by a suffix minimum.  (The first line of a tile can sit in the middle of a spliced record, far to the
+// right of the records that follow: without the suffix minimum such a tile would push later, lower windows out of order, and k_colscan finds
+// the tiles of a variant block by bisection over these bases.)  A line outside its tile's window -- a read spliced over hundreds of het SNPs --
+// is a FAR line: global atomics, and its read list is filled through a cursor and sorted afterwards (k_rl_sort_dirty).
+// One workgroup per shard.
+__global__ __launch_bounds__(256) void k_tile_base(LinesTab TT, int32_t *tile_wb) {
+    const LinesDev L = TT.L[blockIdx.x];
+    const uint32_t T0 = TT.blk0[blockIdx.x], n = TT.blk0[blockIdx.x + 1] - T0;
+    if (n == 0) return;
+    __shared__ int s_min[256];
+    const uint32_t per = (n + 255u) / 256u;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int m = 0x7FFFFFFF;
+    for (uint32_t t = lo; t < hi; t++) { const int v = L.var_idx[(int64_t)t * TL] + L.var_base; m = v < m ? v : m; }
+    s_min[threadIdx.x] = m;
+    __syncthreads();
+    int after = 0x7FFFFFFF;                                  // minimum over the chunks behind this thread's
+    for (int j = threadIdx.x + 1; j < 256; j++) after = s_min[j] < after ? s_min[j] : after;
+    for (uint32_t t = hi; t-- > lo;) {
+        const int v = L.var_idx[(int64_t)t * TL] + L.var_base;
+        after = v < after ? v : after;
+        tile_wb[T0 + t] = after - 64 > 0 ? after - 64 : 0;
+    }
+}
 
 struct LineOut {
     const uint8_t *a0, *a1;
     uint8_t *line_cls;               // [n_lines] 0 ref / 1 alt / 2 other / 255 dropped by the AS cutoff
     uint32_t *line_q;                // [n_lines] QNAME id of the line in the call's id space
-    int32_t *var_count;              // [nv*3]
+    int32_t *var_count;              // [nv*3]   (far lines only: the rest comes from k_colscan)
     unsigned long long *var_first;   // [nv]
-    uint32_t *rl_cnt;                // [nv*2*nb] kept ref/alt lines per (variant, allele, BAM)
-    uint32_t *qcount;                // [nq] kept lines of the QNAME (persistent, all zero between calls)
-    unsigned long long *counters;    // [3] kept lines
+    uint32_t *rl_cnt;                // [nv*2*nb] kept ref/alt lines per (variant, allele, BAM)  (far lines only)
+    const int32_t *tile_wb;          // [tiles] window base
+    uint16_t *tile_m;                // [tiles][TWT*3] kept lines per (window variant, class)
+    uint32_t *q_seen, *q_dup;        // one bit per QNAME id: some tile holds a kept line of it / a second tile (or BAM) does too
+    uint32_t *rl_dirty, *dirty_list; // one bit per read list: it has a far line; the lists with the bit, once each (cursor: counters[11])
+    unsigned long long *counters;    // [12] far lines
     int nb;
     unsigned long long *prof;        // PHZ_TALLY_PROFILE=1: start / end clock of every workgroup
 };
@@ -148,21 +202,25 @@ __global__ __launch_bounds__(LINE_TB) void k_line(LinesTab T, LineOut O) {
     const int sh_ = tab_find(T, blockIdx.x);
     const LinesDev L = T.L[sh_];
     const uint32_t bx = blockIdx.x - T.blk0[sh_];
-    __shared__ int s_cnt[TW * 3];
-    __shared__ unsigned long long s_first[TW];
-    __shared__ int s_vbase;
-    __shared__ unsigned int s_kept;
+    __shared__ int s_cnt[TWT * 3];
+    __shared__ unsigned long long s_first[TWT];
+    __shared__ uint32_t s_qb[QW / 32];
+    __shared__ unsigned int s_kept, s_far;
     const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)bx * LINES_PER_BLOCK;
-    for (int j = tid; j < TW * 3; j += LINE_TB) s_cnt[j] = 0;
-    for (int j = tid; j < TW; j += LINE_TB) s_first[j] = ~0ull;
-    if (tid == 0) { s_vbase = L.var_idx[i0] + L.var_base; s_kept = 0; }      // (record, variant)-ordered lines: the first one holds ~the smallest index
-    __syncthreads();
-    const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;       // a little room below (mate pairs / overlapping records)
-    unsigned int kept = 0;
-    // all loads of a lane's eight lines are requested before the first one is used (two dependent rounds: the line, then its record / variant)
-    constexpr int K = LINES_PER_BLOCK / LINE_TB;
-    int l_r[K], l_v[K], l_as[K]; uint32_t l_q[K]; uint8_t l_code[K], l_has[K], l_a0[K], l_a1[K]; bool l_in[K];
+    const int64_t i0 = (int64_t)bx * TL;
+    for (int j = tid; j < TWT * 3; j += LINE_TB) s_cnt[j] = 0;
+    for (int j = tid; j < TWT; j += LINE_TB) s_first[j] = ~0ull;
+    for (int j = tid; j < QW / 32; j += LINE_TB) s_qb[j] = 0u;
+    if (tid == 0) { s_kept = 0; s_far = 0; }
+    const int wb = O.tile_wb[blockIdx.x];
+    // the LDS bitmap covers the QNAME ids around the tile's first line (ids are handed out in coordinate order: a tile's QNAMEs are the
+    // ones that first appeared while its records went by, and mates of slightly earlier ones)
+    const uint32_t q0 = L.qid_base + (uint32_t)L.read_qid[L.read_idx[i0]];
+    const uint32_t qb = q0 > (uint32_t)(QW / 2) ? ((q0 - (uint32_t)(QW / 2)) & ~31u) : 0u;
+    unsigned int kept = 0, far = 0;
+    // all loads of a lane's lines are requested before the first one is used (two dependent rounds: the line, then its record / variant)
+    constexpr int K = TL / LINE_TB;
+    int l_r[K], l_v[K], l_as[K]; uint32_t l_q[K]; uint8_t l_code[K], l_a0[K], l_a1[K]; bool l_in[K], l_has[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int64_t i = i0 + tid + LINE_TB * k;
@@ -171,11 +229,12 @@ __global__ __launch_bounds__(LINE_TB) void k_line(LinesTab T, LineOut O) {
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        l_as[k] = (l_in[k] && L.use_cutoff) ? L.read_as[l_r[k]] : 0;
-        l_has[k] = (l_in[k] && L.use_cutoff && L.read_has_as) ? L.read_has_as[l_r[k]] : (uint8_t)1;
+        l_as[k] = 0; l_has[k] = true;
+        if (l_in[k] && L.use_cutoff) { bool range; l_has[k] = as_of(L, l_r[k], &l_as[k], &range); }
         l_q[k] = l_in[k] ? L.qid_base + (uint32_t)L.read_qid[l_r[k]] : 0u;
         l_a0[k] = l_in[k] ? O.a0[l_v[k]] : (uint8_t)0; l_a1[k] = l_in[k] ? O.a1[l_v[k]] : (uint8_t)0;
     }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if (!l_in[k]) continue;
@@ -188,34 +247,110 @@ __global__ __launch_bounds__(LINE_TB) void k_line(LinesTab T, LineOut O) {
         // codes 5 / 6 come from the general (indel) mapper, which compared the text with the allele strings itself
         const int cls = c == 5 ? 0 : (c == 6 ? 1 : ((c < 4 && c == l_a0[k]) ? 0 : ((c < 4 && c == l_a1[k]) ? 1 : 2)));
         O.line_cls[g] = (uint8_t)cls;
-        const unsigned d = (unsigned)(v - vbase);
-        if (d < (unsigned)TW) {
+        O.line_q[g] = l_q[k];
+        const unsigned d = (unsigned)(v - wb);
+        if (d < (unsigned)TWT) {
             atomicAdd(&s_cnt[d * 3 + cls], 1);
             atomicMin(&s_first[d], (unsigned long long)g);
-        } else {
+        } else {                                                 // a far line
+            far++;
             atomicAdd(&O.var_count[(int64_t)v * 3 + cls], 1);
             atomicMin(&O.var_first[v], (unsigned long long)g);
-            if (cls < 2) atomicAdd(&O.rl_cnt[((int64_t)v * 2 + cls) * O.nb + L.bam], 1u);
+            if (cls < 2) {
+                const uint32_t e = ((uint32_t)v * 2u + (uint32_t)cls) * (uint32_t)O.nb + (uint32_t)L.bam;
+                atomicAdd(&O.rl_cnt[e], 1u);
+                const uint32_t bit = 1u << (e & 31u);
+                if (!(atomicOr(&O.rl_dirty[e >> 5], bit) & bit)) O.dirty_list[atomicAdd(&O.counters[11], 1ull)] = e;      // the first far line of the list puts it on the work list
+            }
         }
-        O.line_q[g] = l_q[k];
-        atomicAdd(&O.qcount[l_q[k]], 1u);
+        const uint32_t dq = l_q[k] - qb;
+        if (dq < (uint32_t)QW) atomicOr(&s_qb[dq >> 5], 1u << (dq & 31u));
+        else {                                                   // outside the LDS bitmap (a deep region: mates thousands of ids back): straight to the global ones.  Two such
+            const uint32_t bit = 1u << (l_q[k] & 31u);           // lines of one tile make their QNAME look shared -- it then takes the general (spill) path, which is always right
+            if (atomicOr(&O.q_seen[l_q[k] >> 5], bit) & bit) atomicOr(&O.q_dup[l_q[k] >> 5], bit);
+        }
     }
     if (kept) atomicAdd(&s_kept, kept);
+    if (far) atomicAdd(&s_far, far);
     __syncthreads();
-    for (int j = tid; j < TW * 3; j += LINE_TB) {
-        const int c = s_cnt[j];
-        if (c) {
-            const int64_t v = vbase + j / 3; const int cls = j % 3;
-            atomicAdd(&O.var_count[v * 3 + cls], c);
-            if (cls < 2) atomicAdd(&O.rl_cnt[(v * 2 + cls) * O.nb + L.bam], (uint32_t)c);
+    // the tile's row of M, two 16-bit counters per store (a tile holds at most TL <= 1,024 lines)
+    {
+        uint32_t *row = (uint32_t *)(O.tile_m + (size_t)blockIdx.x * (TWT * 3));
+        for (int j = tid; j < TWT * 3 / 2; j += LINE_TB) row[j] = (uint32_t)s_cnt[2 * j] | ((uint32_t)s_cnt[2 * j + 1] << 16);
+    }
+    for (int j = tid; j < TWT; j += LINE_TB) {
+        const unsigned long long f = s_first[j];
+        if (f != ~0ull) atomicMin(&O.var_first[wb + j], f);
+    }
+    // the tile's QNAMEs: one atomic per occupied word; the bits somebody else had set before mark QNAMEs that live in more than one tile
+    for (int j = tid; j < QW / 32; j += LINE_TB) {
+        const uint32_t bits = s_qb[j];
+        if (bits) {
+            const uint32_t w = (qb >> 5) + (uint32_t)j;
+            const uint32_t dup = atomicOr(&O.q_seen[w], bits) & bits;
+            if (dup) atomicOr(&O.q_dup[w], dup);
         }
     }
-    for (int j = tid; j < TW; j += LINE_TB) {
-        const unsigned long long f = s_first[j];
-        if (f != ~0ull) atomicMin(&O.var_first[vbase + j], f);
-    }
     if (tid == 0 && s_kept) atomicAdd(&O.counters[16 + (blockIdx.x % N_SPREAD) * SPREAD_WORDS + 2], (unsigned long long)s_kept);
+    if (tid == 0 && s_far) atomicAdd(&O.counters[12], (unsigned long long)s_far);
     if (O.prof && tid == 0) O.prof[2 * (size_t)blockIdx.x + 1] = wall_clock64();
+}
+
+// Columns of the band matrix M (tiles x variants): for every variant of a block of TWT variants the kept lines per class over all tiles of the
+// shard -- the per-variant counters and the sizes of the read lists -- and, tile by tile, the running sum BEFORE the tile (tile_b), i.e. the
+// number of entries of list (variant, allele, BAM) that lie in earlier tiles = earlier lines.  One workgroup per (shard, variant block); its
+// tiles are found by bisection over the monotone window bases; long tile ranges (deep coverage) are cut into CS_PARTS parts that first add up
+// their own stretch.
+constexpr int CS_PARTS = 4;
+struct ColScan { const int32_t *tile_wb; const uint16_t *tile_m; uint32_t *tile_b; int32_t *var_count; uint32_t *rl_cnt; int nb; };
+__global__ __launch_bounds__(TWT * CS_PARTS) void k_colscan(LinesTab TC, LinesTab TT, ColScan O) {
+    const int sh_ = tab_find(TC, blockIdx.x);
+    const LinesDev L = TC.L[sh_];
+    const int blk = (int)(blockIdx.x - TC.blk0[sh_]);
+    const int a = L.var_base + blk * TWT;                        // first variant of the block
+    const int j = threadIdx.x & (TWT - 1), part = threadIdx.x / TWT;
+    const int v = a + j;
+    const bool live = blk * TWT + j < L.nv_chrom;
+    const uint32_t T0 = TT.blk0[sh_], T1 = TT.blk0[sh_ + 1];
+    // tiles whose window [wb, wb + TWT) meets [a, a + TWT): a - TWT < wb < a + TWT
+    uint32_t lo, hi;
+    { uint32_t x = T0, y = T1; while (x < y) { const uint32_t m = (x + y) >> 1; if (O.tile_wb[m] > a - TWT) y = m; else x = m + 1; } lo = x; }
+    { uint32_t x = lo, y = T1; while (x < y) { const uint32_t m = (x + y) >> 1; if (O.tile_wb[m] >= a + TWT) y = m; else x = m + 1; } hi = x; }
+    const uint32_t n = hi - lo;
+    const bool split = n > 16u;
+    const uint32_t per = split ? (n + CS_PARTS - 1) / CS_PARTS : n;
+    uint32_t t0 = lo + (uint32_t)part * per; t0 = t0 < hi ? t0 : hi;
+    const uint32_t t1 = t0 + per < hi ? t0 + per : hi;
+    __shared__ uint32_t s_tot[CS_PARTS][TWT * 3];
+    uint32_t off0 = 0, off1 = 0, off2 = 0;
+    if (split) {
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll 4
+        for (uint32_t t = t0; t < t1; t++) {
+            const unsigned d = (unsigned)(v - O.tile_wb[t]);
+            if (d < (unsigned)TWT) { const uint16_t *m = O.tile_m + (size_t)t * (TWT * 3) + d * 3; c0 += m[0]; c1 += m[1]; c2 += m[2]; }
+        }
+        s_tot[part][j * 3] = c0; s_tot[part][j * 3 + 1] = c1; s_tot[part][j * 3 + 2] = c2;
+        __syncthreads();
+        for (int p = 0; p < part; p++) { off0 += s_tot[p][j * 3]; off1 += s_tot[p][j * 3 + 1]; off2 += s_tot[p][j * 3 + 2]; }
+    }
+    uint32_t r0 = off0, r1 = off1, r2 = off2;
+#pragma unroll 4
+    for (uint32_t t = t0; t < t1; t++) {
+        const unsigned d = (unsigned)(v - O.tile_wb[t]);
+        if (d < (unsigned)TWT) {
+            const uint16_t *m = O.tile_m + (size_t)t * (TWT * 3) + d * 3;
+            uint32_t *bb = O.tile_b + (size_t)t * (TWT * 2) + d * 2;
+            const uint32_t c0 = m[0], c1 = m[1], c2 = m[2];
+            bb[0] = r0; bb[1] = r1;
+            r0 += c0; r1 += c1; r2 += c2;
+        }
+    }
+    if (!live) return;
+    r0 -= off0; r1 -= off1; r2 -= off2;                          // this part's own lines (several BAMs of a chromosome add to the same variant: atomics)
+    if (r0) { atomicAdd(&O.var_count[(int64_t)v * 3], (int)r0); atomicAdd(&O.rl_cnt[((uint32_t)v * 2u) * (uint32_t)O.nb + (uint32_t)L.bam], r0); }
+    if (r1) { atomicAdd(&O.var_count[(int64_t)v * 3 + 1], (int)r1); atomicAdd(&O.rl_cnt[((uint32_t)v * 2u + 1u) * (uint32_t)O.nb + (uint32_t)L.bam], r1); }
+    if (r2) atomicAdd(&O.var_count[(int64_t)v * 3 + 2], (int)r2);
 }
 
 // group of every spilled QNAME: its line count (the counter goes back to zero and serves as the fill cursor of k_items_spill)
@@ -223,31 +358,18 @@ __global__ __launch_bounds__(256) void k_group_plan(int64_t nt, const uint32_t *
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nt) return;
     const uint32_t q = touched[i];
-    cnt_t[i] = qcount[q] & 0x7FFFFFFFu; qcount[q] = 0u;          // bit 31: "already on the list of spilled QNAMEs"
+    cnt_t[i] = qcount[q]; qcount[q] = 0u;                        // the spilled lines of the QNAME, added up by the tiles that hold them
 }
 // ... and the counter becomes the QNAME's write cursor: it starts at the group's base, k_items takes slots from it, k_groups returns it to zero
 __global__ __launch_bounds__(256) void k_group_base(int64_t nt, const uint32_t *touched, const uint32_t *base_t, uint32_t *qcount) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nt) qcount[touched[i]] = base_t[i];
 }
-// list index of every read-list entry (entry -> (variant, allele, BAM)); lists are short, one thread each
-__global__ __launch_bounds__(256) void k_rl_expand(int64_t nlists, const uint32_t *rl_start, uint32_t *rl_list, uint32_t *rl_cursor) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nlists) return;
-    const uint32_t lo = rl_start[e], hi = rl_start[e + 1];
-    rl_cursor[e] = lo;                                   // write cursor of the list for k_items
-    for (uint32_t p = lo; p < hi; p++) rl_list[p] = (uint32_t)e;
-}
-
 // item = variant:28 | class:2 | line:32 (sorts by variant, class, line); read-list entry = line:32 | chromosome-local QNAME id:32
 __device__ __forceinline__ uint64_t item_pack(uint32_t v, uint32_t cls, uint32_t g) { return ((uint64_t)v << 34) | ((uint64_t)cls << 32) | g; }
 // distinct item of a group = QNAME id:32 | variant:28 << 4 | class << 2 | linked (the QNAME id in the high word keeps the groups apart in k_pairs)
 __device__ __forceinline__ uint64_t dist_pack(uint32_t q, uint32_t v, uint32_t cls, uint32_t linked) { return ((uint64_t)q << 32) | ((uint64_t)v << 4) | ((uint64_t)cls << 2) | linked; }
 
-#ifndef PHZ_TALLY_TILE
-#define PHZ_TALLY_TILE 1024        // (the emulation tests also build a 256-line variant so that small fixtures straddle tiles)
-#endif
-constexpr int TL = PHZ_TALLY_TILE; // lines per tile of k_tile
 constexpr int TH = 2 * TL;         // LDS hash slots (at most TL distinct QNAMEs: load factor <= 0.5)
 #ifndef PHZ_TILE_TB
 #define PHZ_TILE_TB 512
@@ -255,21 +377,24 @@ constexpr int TH = 2 * TL;         // LDS hash slots (at most TL distinct QNAMEs
 constexpr int TILE_TB = PHZ_TILE_TB < TL ? PHZ_TILE_TB : TL;   // threads per workgroup of k_tile
 constexpr int TSP = TH / TILE_TB;  // slots per thread
 constexpr int TH_SHIFT = TL == 1024 ? 21 : (TL == 512 ? 22 : 23);
-static_assert(TL == 1024 || TL == 512 || TL == 256, "tile of 256 / 512 / 1024 lines");
-constexpr int TWT = 256;           // variants per LDS window of k_tile (1,024 lines span ~100 variants)
+constexpr int NROWS = TL / 64;     // rows of 64 consecutive lines in a tile (a wave holds one row per round)
 constexpr uint32_t Q_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t Q_SPILLED = 0x80000000u;
+constexpr uint32_t RL_DIRTY = 0xFFFFFFFFu;      // base of a dirty list in the tile's LDS table: its entries go through the cursor
 
 struct TileOut {
     const uint8_t *line_cls; const uint32_t *line_q;
-    uint32_t *qcount;                // [nq] total kept lines per QNAME from k_line; complete groups return it to zero, spilled ones get bit 31
+    const uint32_t *q_dup;           // bit per QNAME id: lines in more than one tile / BAM (k_line)
+    uint32_t *qcount;                // [nq] spilled lines per QNAME, added up here (all zero between calls; k_group_plan / k_groups return it to zero)
     uint64_t *items;                 // [tiles * TL] distinct items of the complete groups in the slots of their tile, holes = KEY_DROPPED
     uint32_t *sp_q; uint64_t *sp_item;       // spilled lines (cursor: low word of counters[10])
     uint32_t *touched;               // spilled QNAMEs, once each (cursor: high word of counters[10])
     unsigned long long *var_rank; int32_t *var_distinct;
-    uint32_t *rl_cursor; uint64_t *rl_tmp;
+    const int32_t *tile_wb; const uint32_t *tile_b;      // window base; entries of every window list in earlier tiles (k_colscan)
+    const uint32_t *rl_start, *rl_dirty;
+    int32_t *rl_qid; uint32_t *rl_list;                  // the read lists, written in place
+    uint32_t *rl_cursor; uint64_t *rl_tmp;               // dirty lists only: entries in arrival order, line | QNAME id (sorted by k_rl_sort_dirty)
     unsigned long long *counters;
-    int nb;
+    int nb; int64_t nv;
     unsigned long long *prof;
 };
 
@@ -280,28 +405,39 @@ __global__ __launch_bounds__(TILE_TB) void k_tile(LinesTab T, TileOut O) {
     const uint32_t bx = blockIdx.x - T.blk0[sh_];
     __shared__ uint32_t s_q[TH];                 // QNAME id of the slot
     __shared__ uint32_t s_c[TH];                 // lines of the slot's QNAME in this tile -> write cursor of its group -> end of its group (groups lie in slot order)
-    __shared__ uint64_t s_it[TL];                // the tile's kept lines as items, group by group
+    __shared__ uint64_t s_it[TL];                // the tile's kept lines as items, group by group; before that: entries per (row, window list), one byte each
     __shared__ int s_cnt[TWT * 3];
     __shared__ unsigned long long s_rank[TWT];
-    __shared__ uint32_t s_rl[TL / 2 > TWT * 2 ? TL / 2 : TWT * 2];   // read-list entries of (variant, allele) in this tile -> base of the tile's chunk in the list;
+    __shared__ uint32_t s_rl[TL / 2 > TWT * 2 ? TL / 2 : TWT * 2];   // place of the tile's first entry in every window list (RL_DIRTY: the list goes through its cursor);
                                                  // later: the slots whose QNAMEs this tile puts on the list of spilled QNAMEs (16 bits each)
     __shared__ uint16_t s_grp[TL];               // the occupied slots, densely: group g of the tile lives in slot s_grp[g]
     __shared__ uint32_t s_part[TILE_TB / 64];
-    __shared__ int s_vbase;
     __shared__ uint32_t s_nspill, s_ntouch, s_nkept, s_ngroups;
     __shared__ unsigned long long s_obase;
     uint16_t *s_touch = (uint16_t *)s_rl;
-    const int tid = threadIdx.x;
+    uint8_t *s_mat = (uint8_t *)s_it;            // [NROWS][TWT * 2]
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t i0 = (int64_t)bx * TL;
     if (tid == 0) { s_nspill = 0; s_ntouch = 0; }
     for (int j = tid; j < TH; j += TILE_TB) { s_q[j] = Q_EMPTY; s_c[j] = 0u; }
     for (int j = tid; j < TWT * 3; j += TILE_TB) s_cnt[j] = 0;
     for (int j = tid; j < TWT; j += TILE_TB) s_rank[j] = ~0ull;
-    for (int j = tid; j < TWT * 2; j += TILE_TB) s_rl[j] = 0u;
-    if (tid == 0) s_vbase = L.var_idx[i0] + L.var_base;
-    // ---- 1. the tile's lines: QNAME -> slot (count), read-list entry -> rank inside the tile's chunk
+    for (int j = tid; j < TL; j += TILE_TB) s_it[j] = 0ull;
+    const int vbase = O.tile_wb[blockIdx.x];
+    // ---- 0. where the tile's entries of every window list start: list start + entries in earlier tiles
+    for (int x = tid; x < TWT * 2; x += TILE_TB) {
+        const int64_t v = (int64_t)vbase + (x >> 1);
+        uint32_t base = RL_DIRTY;
+        if (v < O.nv) {
+            const uint32_t e = ((uint32_t)v * 2u + (uint32_t)(x & 1)) * (uint32_t)O.nb + (uint32_t)L.bam;
+            if (!((O.rl_dirty[e >> 5] >> (e & 31u)) & 1u)) base = O.rl_start[e] + O.tile_b[(size_t)blockIdx.x * (TWT * 2) + x];
+        }
+        s_rl[x] = base;
+    }
+    // ---- 1. the tile's lines: QNAME -> slot (count); read-list entry -> rank among the row's entries of its list (wave ballots), the row's
+    //         entries per list into s_mat
     constexpr int K = TL / TILE_TB;
-    uint32_t l_cls[K], l_q[K], l_v[K], l_slot[K], l_rank[K];
+    uint32_t l_cls[K], l_q[K], l_v[K], l_slot[K], l_rank[K], l_base[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int64_t i = i0 + tid + TILE_TB * k;
@@ -312,40 +448,58 @@ __global__ __launch_bounds__(TILE_TB) void k_tile(LinesTab T, TileOut O) {
         }
     }
     __syncthreads();
-    const int vbase = s_vbase - 64 > 0 ? s_vbase - 64 : 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        l_slot[k] = Q_EMPTY; l_rank[k] = Q_EMPTY;
-        if (l_cls[k] == 255u) continue;
-        const uint32_t q = l_q[k];
-        uint32_t s = (q * 2654435761u) >> TH_SHIFT;
-        for (;;) {
-            const uint32_t prev = atomicCAS(&s_q[s], Q_EMPTY, q);
-            if (prev == Q_EMPTY || prev == q) break;
-            s = (s + 1) & (TH - 1);
-        }
-        atomicAdd(&s_c[s], 1u);
-        l_slot[k] = s;
-        if (l_cls[k] < 2u) {
-            const unsigned d = l_v[k] - (unsigned)vbase;
-            if (d < (unsigned)TWT) l_rank[k] = atomicAdd(&s_rl[d * 2 + l_cls[k]], 1u);
-            else {                                               // a line far from the tile's window (long intron): straight to its list
-                const int64_t i = i0 + tid + TILE_TB * k;
-                const uint32_t e = (l_v[k] * 2u + l_cls[k]) * (uint32_t)O.nb + (uint32_t)L.bam;
-                O.rl_tmp[atomicAdd(&O.rl_cursor[e], 1u)] = ((uint64_t)(uint32_t)(L.line_base + i) << 32) | (uint32_t)(q - L.qid_base);
+        l_slot[k] = Q_EMPTY;
+        if (l_cls[k] != 255u) {
+            const uint32_t q = l_q[k];
+            uint32_t s = (q * 2654435761u) >> TH_SHIFT;
+            for (;;) {
+                const uint32_t prev = atomicCAS(&s_q[s], Q_EMPTY, q);
+                if (prev == Q_EMPTY || prev == q) break;
+                s = (s + 1) & (TH - 1);
             }
+            atomicAdd(&s_c[s], 1u);
+            l_slot[k] = s;
         }
+        // every lane gets here: the lanes of a row with the same list key find each other by nine ballots
+        const bool isrl = l_cls[k] < 2u;
+        const unsigned d = l_v[k] - (unsigned)vbase;
+        const uint32_t key = (d * 2u + (l_cls[k] & 1u)) & (uint32_t)(TWT * 2 - 1);
+        l_base[k] = (isrl && d < (unsigned)TWT) ? s_rl[key] : RL_DIRTY;      // a far line's list is dirty by construction (k_line flagged it)
+        const bool ord = isrl && l_base[k] != RL_DIRTY;
+        unsigned long long same = __ballot(ord);
+#pragma unroll
+        for (int b = 0; b < 9; b++) {
+            const bool bit = (key >> b) & 1u;
+            const unsigned long long bal = __ballot(ord && bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint32_t inrow = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        l_rank[k] = isrl ? inrow : Q_EMPTY;
+        if (ord && inrow == 0u) s_mat[((tid >> 6) + (TILE_TB / 64) * k) * (TWT * 2) + key] = (uint8_t)__popcll(same);
     }
     __syncthreads();
-    // ---- 2. requested now, used later: the totals of the QNAMEs in this lane's slots and one cursor step per (tile, read list);
-    //         meanwhile the group ranges (exclusive scan of the slot counts)
-    constexpr int NRLB = (TWT * 2 + TILE_TB - 1) / TILE_TB;
-    uint32_t rl_base[NRLB];
+    // ---- 2. read-list entries to their final places (the entries of earlier rows come from s_mat, which step 3 overwrites); meanwhile the
+    //         group ranges (exclusive scan of the slot counts)
 #pragma unroll
-    for (int j = 0; j < NRLB; j++) {
-        const int x = tid + TILE_TB * j;
-        rl_base[j] = x < TWT * 2 ? s_rl[x] : 0u;
-        if (rl_base[j]) rl_base[j] = atomicAdd(&O.rl_cursor[((uint32_t)(vbase + (x >> 1)) * 2u + (uint32_t)(x & 1)) * (uint32_t)O.nb + (uint32_t)L.bam], rl_base[j]);
+    for (int k = 0; k < K; k++) {
+        if (l_rank[k] == Q_EMPTY) continue;
+        const int64_t i = i0 + tid + TILE_TB * k;
+        const uint32_t g = (uint32_t)(L.line_base + i);
+        const uint32_t e = (l_v[k] * 2u + l_cls[k]) * (uint32_t)O.nb + (uint32_t)L.bam;
+        if (l_base[k] != RL_DIRTY) {
+            const unsigned d = l_v[k] - (unsigned)vbase;
+            const uint32_t key = d * 2u + l_cls[k];
+            const int row = (tid >> 6) + (TILE_TB / 64) * k;
+            uint32_t before = 0;
+            for (int r = 0; r < row; r++) before += s_mat[r * (TWT * 2) + key];
+            const uint32_t at = l_base[k] + before + l_rank[k];
+            O.rl_qid[at] = (int32_t)(l_q[k] - L.qid_base); O.rl_list[at] = e;
+        } else {
+            const uint32_t at = O.rl_start[e] + atomicAdd(&O.rl_cursor[e], 1u);
+            O.rl_tmp[at] = ((uint64_t)g << 32) | (uint32_t)(l_q[k] - L.qid_base); O.rl_list[at] = e;
+        }
     }
     {
         // one scan for both: lines (low half) and occupied slots (high half) before every slot
@@ -367,20 +521,18 @@ __global__ __launch_bounds__(TILE_TB) void k_tile(LinesTab T, TileOut O) {
             base += c[j] + (c[j] ? 0x10000u : 0u);
         }
     }
-#pragma unroll
-    for (int j = 0; j < NRLB; j++) if (tid + TILE_TB * j < TWT * 2) s_rl[tid + TILE_TB * j] = rl_base[j];
     __syncthreads();
-    // ---- 3. lines into their groups, read-list entries into their lists; the totals of the QNAMEs of this lane's groups are requested
-    //         first (used after the next barrier)
+    // ---- 3. lines into their groups; whether some other tile holds lines of the QNAMEs of this lane's groups is requested first (used after
+    //         the next barrier)
     constexpr int GK = TL / TILE_TB;                            // groups per lane (a tile of TL lines holds at most TL groups)
     const uint32_t ngroups = s_ngroups;
-    uint32_t tot[GK], my_q[GK], my_slot[GK];
+    uint32_t dupw[GK], my_q[GK], my_slot[GK];
 #pragma unroll
     for (int j = 0; j < GK; j++) {
         const uint32_t gi = (uint32_t)tid + (uint32_t)TILE_TB * (uint32_t)j;
         my_slot[j] = gi < ngroups ? (uint32_t)s_grp[gi] : Q_EMPTY;
         my_q[j] = my_slot[j] != Q_EMPTY ? s_q[my_slot[j]] : Q_EMPTY;
-        tot[j] = my_q[j] != Q_EMPTY ? O.qcount[my_q[j]] : 0u;
+        dupw[j] = my_q[j] != Q_EMPTY ? O.q_dup[my_q[j] >> 5] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -388,14 +540,10 @@ __global__ __launch_bounds__(TILE_TB) void k_tile(LinesTab T, TileOut O) {
         const int64_t i = i0 + tid + TILE_TB * k;
         const uint32_t g = (uint32_t)(L.line_base + i);
         s_it[atomicAdd(&s_c[l_slot[k]], 1u)] = item_pack(l_v[k], l_cls[k], g);
-        if (l_rank[k] != Q_EMPTY) {
-            const unsigned d = l_v[k] - (unsigned)vbase;
-            O.rl_tmp[s_rl[d * 2 + l_cls[k]] + l_rank[k]] = ((uint64_t)g << 32) | (uint32_t)(l_q[k] - L.qid_base);
-        }
     }
     __syncthreads();
     // ---- 4. one thread per group.  A group holding every line of its QNAME is finished here (all its lines come from this shard's BAM: that
-    //         BAM owns the read_vars list, every ref/alt line is linked): its distinct items stay at the front of its range, the rest of the
+    //         BAM owns the read_vars list, every ref/alt line is linked; "all" = no other tile has set the QNAME's bit): its distinct items stay at the front of its range, the rest of the
     //         range becomes KEY_DROPPED.  The others hand their lines to the spill list (ranges inside the tile's share from LDS counters)
     uint32_t sp_beg[GK], sp_n[GK], sp_at[GK];
 #pragma unroll
@@ -406,12 +554,11 @@ __global__ __launch_bounds__(TILE_TB) void k_tile(LinesTab T, TileOut O) {
         const uint32_t q = my_q[j];
         const uint32_t beg = slot ? s_c[slot - 1] : 0u, n = s_c[slot] - beg;        // the cursors stopped at the groups' ends
         uint64_t *it = s_it + beg;
-        if ((tot[j] & 0x7FFFFFFFu) != n) {
-            if (!(atomicOr(&O.qcount[q], Q_SPILLED) & Q_SPILLED)) s_touch[atomicAdd(&s_ntouch, 1u)] = (uint16_t)slot;   // the first tile to meet it lists the QNAME
+        if ((dupw[j] >> (q & 31u)) & 1u) {
+            if (atomicAdd(&O.qcount[q], n) == 0u) s_touch[atomicAdd(&s_ntouch, 1u)] = (uint16_t)slot;   // the first tile to add its lines lists the QNAME
             sp_n[j] = n; sp_beg[j] = beg; sp_at[j] = atomicAdd(&s_nspill, n);
             continue;
         }
-        O.qcount[q] = 0u;                                      // clean for the next call
         if (n == 1u) {                                         // most QNAMEs: one line, nothing to sort, no pair, no rank
             const uint64_t x = it[0];
             const uint32_t v = (uint32_t)(x >> 34), cls = (uint32_t)(x >> 32) & 3u;
@@ -846,92 +993,17 @@ __global__ __launch_bounds__(256) void k_edge_out(int64_t ne, const uint32_t *eo
     stats[4 * ne + i] = cis > trans ? 0 : (cis < trans ? 1 : -1);
 }
 
-// ---- read lists: entries were placed by atomics; put every list into line order and keep the QNAME ids
-constexpr int RL_SMALL = 16, RL_LDS = 4096;
-#ifndef PHZ_RL_STAGE
-#define PHZ_RL_STAGE 2048
-#endif
-constexpr int RL_STAGE = PHZ_RL_STAGE;      // entries a workgroup of k_rl_sort stages in LDS (the emulation tests also build a tiny stage: both paths)
-template <class P> __device__ __forceinline__ void rl_insertion_sort(P x, uint32_t n) {
-    for (uint32_t a = 1; a < n; a++) {
-        const unsigned long long t = x[a];
-        uint32_t j = a;
-        while (j > 0 && x[j - 1] > t) { x[j] = x[j - 1]; j--; }
-        x[j] = t;
-    }
-}
-// counters32[0] lists left to the workgroup kernel, [1] lists left to the host-driven sort, [2] lists left to the wave kernel.
-// One thread per list; the entries of a workgroup's 256 consecutive lists are one contiguous stretch of rl_tmp, which is staged in LDS
-// with coalesced loads, sorted there list by list (<= 16 entries: insertion sort by the list's thread) and written back with coalesced
-// stores -- one thread walking its list in global memory touched a memory sector per 8-byte entry: 0.22 ms per genome against 0.08 ms.
-// (A stretch longer than the stage -- deeply covered variants -- keeps the walk in global memory.)
-__global__ __launch_bounds__(256) void k_rl_sort(int64_t nlists, const uint32_t *rl_start, uint64_t *rl_tmp, int32_t *rl_qid, const uint32_t *rl_list, uint32_t *wave_list,
-                                                 uint32_t *mid_list, uint32_t *big_list, uint32_t *counters32) {
-    __shared__ uint32_t s_list[3][256];
-    __shared__ uint32_t s_n[3], s_base[3];
-    __shared__ unsigned long long s_x[RL_STAGE];
-    __shared__ uint32_t s_start[257];
-    const int64_t e0 = (int64_t)blockIdx.x * 256, e = e0 + threadIdx.x;
-    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
-    s_start[threadIdx.x] = rl_start[e < nlists ? e : nlists];
-    if (threadIdx.x == 0) s_start[256] = rl_start[e0 + 256 < nlists ? e0 + 256 : nlists];
-    __syncthreads();
-    const uint32_t base = s_start[0], total = s_start[256] - base;
-    const uint32_t n_staged = total <= (uint32_t)RL_STAGE ? total : (uint32_t)RL_STAGE;      // the front of the stretch; lists reaching beyond it are walked in global memory
-    for (uint32_t p = threadIdx.x; p < n_staged; p += 256) s_x[p] = rl_tmp[base + p];
-    __syncthreads();
-    if (e < nlists) {
-        const uint32_t lo = s_start[threadIdx.x], hi = s_start[threadIdx.x + 1], n = hi - lo;
-        if (n > (uint32_t)RL_LDS) s_list[1][atomicAdd(&s_n[1], 1u)] = (uint32_t)e;
-        else if (n > 64u) s_list[0][atomicAdd(&s_n[0], 1u)] = (uint32_t)e;
-        else if (n > (uint32_t)RL_SMALL) s_list[2][atomicAdd(&s_n[2], 1u)] = (uint32_t)e;
-        else if (n > 0) {
-            if (hi - base <= n_staged) rl_insertion_sort(s_x + (lo - base), n);
-            else {
-                uint64_t *x = rl_tmp + lo;
-                rl_insertion_sort(x, n);
-                for (uint32_t a = 0; a < n; a++) rl_qid[lo + a] = (int32_t)(uint32_t)x[a];
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < n_staged; p += 256) {
-        const uint32_t l = rl_list[base + p] - (uint32_t)e0;              // the entry's list, relative to the workgroup's first
-        if (s_start[l + 1] - s_start[l] <= (uint32_t)RL_SMALL && s_start[l + 1] - base <= n_staged) rl_qid[base + p] = (int32_t)(uint32_t)s_x[p];
-    }
-    if (threadIdx.x < 3) s_base[threadIdx.x] = s_n[threadIdx.x] ? atomicAdd(&counters32[threadIdx.x], s_n[threadIdx.x]) : 0u;      // one global atomic per workgroup and class
-    __syncthreads();
-    for (int k = 0; k < 3; k++) {
-        uint32_t *dst = k == 0 ? mid_list : (k == 1 ? big_list : wave_list);
-        if (threadIdx.x < s_n[k]) dst[s_base[k] + threadIdx.x] = s_list[k][threadIdx.x];
-    }
-}
-// one wave per list of 17..64 entries: bitonic network over the lanes (entries of different tiles of lines interleave arbitrarily, an
-// insertion sort would go quadratic)
-__global__ __launch_bounds__(64) void k_rl_sort_wave(const uint32_t *wave_list, const uint32_t *rl_start, const uint64_t *rl_tmp, int32_t *rl_qid) {
-    const uint32_t e = wave_list[blockIdx.x];
-    const uint32_t lo = rl_start[e], n = rl_start[e + 1] - lo;
-    const uint32_t t = threadIdx.x;
-    unsigned long long x = t < n ? rl_tmp[lo + t] : ~0ull;
-    {   // entries arrive tile by tile and mostly in line order: a list that is in order already skips the network
-        const unsigned long long nxt = __shfl_down(x, 1);
-        if (!__any(t + 1 < n && x > nxt)) { if (t < n) rl_qid[lo + t] = (int32_t)(uint32_t)x; return; }
-    }
-#pragma unroll
-    for (uint32_t k = 2; k <= 64; k <<= 1)
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const unsigned long long y = __shfl_xor(x, (int)j);
-            const bool up = (t & k) == 0, lower = (t & j) == 0;
-            x = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
-        }
-    if (t < n) rl_qid[lo + t] = (int32_t)(uint32_t)x;
-}
-// one workgroup per list of 65..4096 entries: bitonic sort in LDS
-__global__ __launch_bounds__(256) void k_rl_sort_mid(const uint32_t *mid_list, const uint32_t *rl_start, const uint64_t *rl_tmp, int32_t *rl_qid) {
+// ---- read lists with a far line (dirty lists): their entries were placed through a cursor, in arrival order; one workgroup per list puts them
+//      into line order (bitonic sort in LDS) and keeps the QNAME ids; a list beyond the LDS stage goes to the host-driven radix sort.
+//      counters32[1] = lists left to that sort.  The list's cursor returns to zero (it is persistent, like the per-QNAME one).
+constexpr int RL_LDS = 4096;
+__global__ __launch_bounds__(256) void k_rl_sort_dirty(const uint32_t *dirty_list, const uint32_t *rl_start, const uint64_t *rl_tmp, int32_t *rl_qid, uint32_t *rl_cursor,
+                                                       uint32_t *big_list, uint32_t *counters32) {
     __shared__ unsigned long long s_x[RL_LDS];
-    const uint32_t e = mid_list[blockIdx.x];
+    const uint32_t e = dirty_list[blockIdx.x];
     const uint32_t lo = rl_start[e], n = rl_start[e + 1] - lo;
+    if (threadIdx.x == 0) rl_cursor[e] = 0u;
+    if (n > (uint32_t)RL_LDS) { if (threadIdx.x == 0) big_list[atomicAdd(&counters32[1], 1u)] = e; return; }
     uint32_t m = 64;
     while (m < n) m <<= 1;
     for (uint32_t t = threadIdx.x; t < m; t += 256) s_x[t] = t < n ? rl_tmp[lo + t] : ~0ull;
@@ -1003,6 +1075,8 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
     if (int s = st.in(h.read_qid, (size_t)h.n_reads, space, &d->read_qid)) return s;
     if (int s = st.in(h.read_as, (size_t)h.n_reads, space, &d->read_as)) return s;
     if (int s = st.in(h.read_has_as, (size_t)h.n_reads, space, &d->read_has_as)) return s;
+    if (int s = st.in(h.read_as16, (size_t)h.n_reads, space, &d->read_as16)) return s;
+    d->nv_chrom = 0;
     return PHZ_OK;
 }
 
@@ -1011,7 +1085,7 @@ int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
 enum { T_QBASE = 1, T_TOUCHED, T_CNT_T, T_BASE_T, T_ITEMS, T_COUNTERS, T_GKEYS, T_USEDKEY, T_DEG, T_EOFF, T_EB, T_ESLOT, T_SCAN_TMP, T_USED, T_MISC, T_EA = 19 };
 // results and the read-list buffers live in their own buffers (ctx->tally_buf)
 enum { R_CNT = 0, R_FIRST, R_DIST, R_RANK, R_CLS, R_EA, R_EB, R_CELLS, R_LINKED, R_CTO, R_STATS, R_RLCNT, R_RLSTART, R_RLFILL, R_RLTMP, R_RLLIST, R_RLQID, R_A0, R_A1,
-       R_LINEQ, R_SORTK, R_SORTV0, R_SORTV1, R_SORTCNT, R_SPQ, R_SPITEM, R_COUNT };
+       R_LINEQ, R_SORTK, R_SORTV0, R_SORTV1, R_SORTCNT, R_SPQ, R_SPITEM, R_TILEWB, R_TILEM, R_TILEB, R_QSEEN, R_QDUP, R_RLDIRTY, R_COUNT };
 
 }  // namespace
 
@@ -1162,8 +1236,17 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         total += L[b].n;
     }
     if (total >= (1ll << 32) - 16) return phz_fail(ctx, PHZ_E_ARG, "more than 2^32 call lines in one call");
+    // variants of every shard's chromosome: up to the next chromosome's first variant (shards of a chromosome share var_base)
+    for (int b = 0; b < n_shards; b++) {
+        int64_t end = nv;
+        for (int c = 0; c < n_shards; c++)
+            if (L[c].var_base > L[b].var_base && L[c].var_base < end) end = L[c].var_base;
+        if (L[b].var_base > nv) return phz_fail(ctx, PHZ_E_ARG, "var_base beyond the variant space");
+        L[b].nv_chrom = (int32_t)(end - L[b].var_base);
+    }
     const size_t NV = (size_t)(nv ? nv : 1), NQ = (size_t)(n_qid ? n_qid : 1), TOT = (size_t)(total ? total : 1);
     const size_t NRL = NV * 2 * (size_t)n_bams;
+    const size_t QWORDS = (NQ + 31) / 32 + (size_t)QW / 32, RLWORDS = (NRL + 31) / 32;      // (+ the LDS window of k_line, which may reach past the last id)
     if (ctx->tally_buf.size() < (size_t)R_COUNT) ctx->tally_buf.resize(R_COUNT);
     DevBuf *R = ctx->tally_buf.data();
     DevBuf *S = ctx->scratch;
@@ -1179,17 +1262,30 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         d_a0 = (const uint8_t *)R[R_A0].p; d_a1 = (const uint8_t *)R[R_A1].p;
     }
 #define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, buf, (bytes))) return s_; } while (0)
+    // tiles of the per-line stages (k_line and k_tile: TL lines each) and variant blocks of k_colscan (TWT variants each), over the shard table
+    LinesTab TT, TC;
+    TT.L = nullptr; TT.blk0 = nullptr; TT.n = 0; TC = TT;
+    std::vector<uint32_t> gt, gc;
+    if (n_shards > 0) {
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + TL - 1) / TL); }, &TT, &gt, 0, 2)) return s2;
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.nv_chrom + TWT - 1) / TWT); }, &TC, &gc, 1, 2)) return s2;
+    }
+    const unsigned grid_t = n_shards > 0 ? gt.back() : 0u, grid_c = n_shards > 0 ? gc.back() : 0u;
+    const size_t NT = grid_t ? grid_t : 1;
     RSV(R[R_CNT], NV * 12); RSV(R[R_FIRST], NV * 8); RSV(R[R_DIST], NV * 12); RSV(R[R_RANK], NV * 8); RSV(R[R_CLS], TOT); RSV(R[R_LINEQ], TOT * 4);
-    RSV(R[R_RLCNT], NRL * 4); RSV(R[R_RLSTART], (NRL + 1) * 4); RSV(R[R_RLFILL], NRL * 4); RSV(R[R_RLTMP], TOT * 8); RSV(R[R_RLLIST], TOT * 4); RSV(R[R_RLQID], TOT * 4);
+    RSV(R[R_RLCNT], NRL * 4); RSV(R[R_RLSTART], (NRL + 1) * 4); RSV(R[R_RLTMP], TOT * 8); RSV(R[R_RLLIST], TOT * 4); RSV(R[R_RLQID], TOT * 4);
     RSV(R[R_SPQ], TOT * 4); RSV(R[R_SPITEM], TOT * 8);
+    RSV(R[R_TILEWB], NT * 4); RSV(R[R_TILEM], NT * (TWT * 3) * 2); RSV(R[R_TILEB], NT * (TWT * 2) * 4);
+    RSV(R[R_QSEEN], QWORDS * 4); RSV(R[R_QDUP], QWORDS * 4); RSV(R[R_RLDIRTY], RLWORDS * 4);
     RSV(S[T_TOUCHED], TOT * 4); RSV(S[T_CNT_T], (TOT + 1) * 4); RSV(S[T_BASE_T], (TOT + 1) * 4); RSV(S[T_ITEMS], (2 * TOT + (size_t)(n_shards + 1) * TL) * 8); RSV(S[T_COUNTERS], CNT_BYTES);
-    RSV(S[T_DEG], NV * 4); RSV(S[T_EOFF], (NV + 1) * 4); RSV(S[T_MISC], std::max(NRL, (size_t)1) * 12 + 64);
+    RSV(S[T_DEG], NV * 4); RSV(S[T_EOFF], (NV + 1) * 4); RSV(S[T_MISC], std::max(NRL, (size_t)1) * 8 + 64);
     hipStream_t sm = ctx->stream;
-    {   // the one array indexed by QNAME id is persistent: `lines per QNAME`, then the QNAME's write cursor, all zero between calls (k_groups returns it
-        // to zero).  It is cleared only when (re)allocated -- or after a call that failed half way
-        const size_t before = ctx->tally_qcount.cap;
-        RSV(ctx->tally_qcount, NQ * 4);
+    {   // two arrays are persistent and all zero between calls: the spilled-line counter / fill cursor per QNAME (k_group_plan and k_groups return it to
+        // zero) and the fill cursor per read list (k_rl_sort_dirty does).  They are cleared only when (re)allocated -- or after a call that failed half way
+        const size_t before = ctx->tally_qcount.cap, before_rl = R[R_RLFILL].cap;
+        RSV(ctx->tally_qcount, NQ * 4); RSV(R[R_RLFILL], NRL * 4);
         if (ctx->tally_qcount.cap != before || ctx->tally_dirty) PHZ_HIP(ctx, hipMemsetAsync(ctx->tally_qcount.p, 0, ctx->tally_qcount.cap, sm));
+        if (R[R_RLFILL].cap != before_rl || ctx->tally_dirty) PHZ_HIP(ctx, hipMemsetAsync(R[R_RLFILL].p, 0, R[R_RLFILL].cap, sm));
     }
     int32_t *d_cnt = (int32_t *)R[R_CNT].p, *d_dist = (int32_t *)R[R_DIST].p;
     unsigned long long *d_first = (unsigned long long *)R[R_FIRST].p, *d_rank = (unsigned long long *)R[R_RANK].p;
@@ -1204,7 +1300,9 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     unsigned long long *counters = (unsigned long long *)S[T_COUNTERS].p;      // see k_pairs
     uint32_t *counters32 = (uint32_t *)(counters + 8);
     uint32_t *deg = (uint32_t *)S[T_DEG].p, *eoff = (uint32_t *)S[T_EOFF].p;
-    uint32_t *mid_list = (uint32_t *)S[T_MISC].p, *big_list = mid_list + NRL, *wave_list = big_list + NRL;
+    uint32_t *dirty_list = (uint32_t *)S[T_MISC].p, *big_list = dirty_list + NRL;
+    int32_t *tile_wb = (int32_t *)R[R_TILEWB].p; uint16_t *tile_m = (uint16_t *)R[R_TILEM].p; uint32_t *tile_b = (uint32_t *)R[R_TILEB].p;
+    uint32_t *q_seen = (uint32_t *)R[R_QSEEN].p, *q_dup = (uint32_t *)R[R_QDUP].p, *rl_dirty = (uint32_t *)R[R_RLDIRTY].p;
 
     Timer timer(ctx, PHZ_T_TALLY);
     ctx->tally_dirty = true;           // cleared again when the call completes
@@ -1214,31 +1312,32 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     PHZ_HIP(ctx, hipMemsetAsync(d_rank, 0xff, NV * 8, sm));
     PHZ_HIP(ctx, hipMemsetAsync(counters, 0, CNT_BYTES, sm));
     PHZ_HIP(ctx, hipMemsetAsync(d_first, 0xff, NV * 8, sm));         // unsigned max for atomicMin == -1 as int64 ("none")
+    PHZ_HIP(ctx, hipMemsetAsync(q_seen, 0, QWORDS * 4, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(q_dup, 0, QWORDS * 4, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(rl_dirty, 0, RLWORDS * 4, sm));
 
     const int single_bam = n_bams <= 1 ? 1 : 0;     // one BAM: every QNAME's read_vars list is owned by that BAM
     LineOut O;
-    O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.line_q = line_q; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt; O.qcount = qcount;
+    O.a0 = d_a0; O.a1 = d_a1; O.line_cls = d_cls; O.line_q = line_q; O.var_count = d_cnt; O.var_first = d_first; O.rl_cnt = rl_cnt;
+    O.tile_wb = tile_wb; O.tile_m = tile_m; O.q_seen = q_seen; O.q_dup = q_dup; O.rl_dirty = rl_dirty; O.dirty_list = dirty_list;
     O.counters = counters; O.nb = n_bams; O.prof = nullptr;
     const bool profiling = getenv("PHZ_TALLY_PROFILE") != nullptr;
-    // shard tables of the per-line stages: LINES_PER_BLOCK lines per block (k_line) and TL lines per block (k_tile)
-    LinesTab TLn, TT;
-    TLn.L = nullptr; TLn.blk0 = nullptr; TLn.n = 0; TT = TLn;
-    std::vector<uint32_t> gl, gt;
-    if (n_shards > 0) {
-        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK); }, &TLn, &gl, 0, 2)) return s2;
-        if (int s2 = upload_tab(ctx, L.data(), n_shards, [](const LinesDev &l) { return (unsigned)((l.n + TL - 1) / TL); }, &TT, &gt, 1, 2)) return s2;
-    }
-    const unsigned grid_l = n_shards > 0 ? gl.back() : 0u, grid_t = n_shards > 0 ? gt.back() : 0u;
+    const unsigned grid_l = grid_t;
     if (profiling) { RSV(S[20], (size_t)(grid_l + grid_t + 2) * 16); O.prof = (unsigned long long *)S[20].p; PHZ_HIP(ctx, hipMemsetAsync(S[20].p, 0, (size_t)(grid_l + grid_t + 2) * 16, sm)); }
-    if (grid_l) hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(LINE_TB), 0, sm, TLn, O);
+    if (grid_t) {
+        hipLaunchKernelGGL(k_tile_base, dim3((unsigned)n_shards), dim3(256), 0, sm, TT, tile_wb);
+        hipLaunchKernelGGL(k_line, dim3(grid_l), dim3(LINE_TB), 0, sm, TT, O);
+        ColScan CS; CS.tile_wb = tile_wb; CS.tile_m = tile_m; CS.tile_b = tile_b; CS.var_count = d_cnt; CS.rl_cnt = rl_cnt; CS.nb = n_bams;
+        if (grid_c) hipLaunchKernelGGL(k_colscan, dim3(grid_c), dim3(TWT * CS_PARTS), 0, sm, TC, TT, CS);
+    }
     if (nv) hipLaunchKernelGGL(k_noise, dim3(std::min(nblk(nv), 256u)), dim3(256), 0, sm, (const int32_t *)d_cnt, nv, counters + 4);
     if (int s = gscan_excl<uint32_t, uint32_t>(ctx, rl_cnt, rl_start, (int64_t)NRL, S[T_SCAN_TMP])) return s;
-    hipLaunchKernelGGL(k_rl_expand, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_list, rl_fill);
     uint32_t *sp_q = (uint32_t *)R[R_SPQ].p; uint64_t *sp_item = (uint64_t *)R[R_SPITEM].p;
     if (grid_t) {
         TileOut TO;
-        TO.line_cls = d_cls; TO.line_q = line_q; TO.qcount = qcount; TO.items = items; TO.sp_q = sp_q; TO.sp_item = sp_item; TO.touched = touched;
-        TO.var_rank = d_rank; TO.var_distinct = d_dist; TO.rl_cursor = rl_fill; TO.rl_tmp = rl_tmp; TO.counters = counters; TO.nb = n_bams;
+        TO.line_cls = d_cls; TO.line_q = line_q; TO.q_dup = q_dup; TO.qcount = qcount; TO.items = items; TO.sp_q = sp_q; TO.sp_item = sp_item; TO.touched = touched;
+        TO.var_rank = d_rank; TO.var_distinct = d_dist; TO.tile_wb = tile_wb; TO.tile_b = tile_b; TO.rl_start = rl_start; TO.rl_dirty = rl_dirty;
+        TO.rl_qid = rl_qid; TO.rl_list = rl_list; TO.rl_cursor = rl_fill; TO.rl_tmp = rl_tmp; TO.counters = counters; TO.nb = n_bams; TO.nv = nv;
         TO.prof = profiling ? (unsigned long long *)S[20].p + 2 * (size_t)grid_l : nullptr;
         hipLaunchKernelGGL(k_tile, dim3(grid_t), dim3(TILE_TB), 0, sm, TT, TO);
     }
@@ -1249,6 +1348,8 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
     const int64_t n_kept = (int64_t)spread_sum(2);
+    const int64_t n_dirty = (int64_t)h_counters[11];
+    ctx->counters[PHZ_C_FAR_LINES] += (int64_t)h_counters[12]; ctx->counters[PHZ_C_DIRTY_LISTS] += n_dirty;
     if (profiling) {
         std::vector<unsigned long long> pr((size_t)(grid_l + grid_t) * 2);
         PHZ_HIP(ctx, hipMemcpy(pr.data(), S[20].p, pr.size() * 8, hipMemcpyDeviceToHost));
@@ -1264,6 +1365,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
             fprintf(stderr, "[tally profile] %s: %zu workgroups, span %.1f us, lifetime avg %.2f us median %.2f p99 %.2f max %.2f us, sum %.1f ms -> avg %.0f resident; started by 10/50/90%% of the span: %zu %zu %zu\n",
                     which ? "k_tile" : "k_line", nb_, span / 100.0, sum / nb_ / 100.0, d[nb_ / 2] / 100.0, d[nb_ * 99 / 100] / 100.0, mx / 100.0, sum / 1e5, sum / span, s10, s50, s90);
         }
+        fprintf(stderr, "[tally profile] far lines %llu, dirty read lists %lld\n", h_counters[12], (long long)n_dirty);
     }
     const int64_t n_complete = (int64_t)grid_t * TL;     // item slots of the tiles (groups finished inside their tile, holes in between)
     const int64_t nt = (int64_t)(h_counters[10] >> 32);  // QNAMEs whose lines straddle tiles: one group each, built from the spilled lines
@@ -1277,9 +1379,10 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         G.counters = counters; G.single_bam = single_bam;
         hipLaunchKernelGGL(k_groups, dim3(nblk(nt)), dim3(256), 0, sm, nt, TT, G);
     }
-    // read lists into line order
+    // the read lists with far lines into line order
     PHZ_HIP(ctx, hipMemsetAsync(counters32, 0, 16, sm));
-    hipLaunchKernelGGL(k_rl_sort, dim3(nblk((int64_t)NRL)), dim3(256), 0, sm, (int64_t)NRL, (const uint32_t *)rl_start, rl_tmp, rl_qid, (const uint32_t *)rl_list, wave_list, mid_list, big_list, counters32);
+    if (n_dirty) hipLaunchKernelGGL(k_rl_sort_dirty, dim3((unsigned)n_dirty), dim3(256), 0, sm, (const uint32_t *)dirty_list, (const uint32_t *)rl_start, (const uint64_t *)rl_tmp, rl_qid, rl_fill,
+                                    big_list, counters32);
     // variant pairs.  The table lives in the ctx, sized from the variant count and kept clean by k_edge_final; a pass that overflows it is redone
     // with a larger one
     uint64_t cap = 1 << 16;
@@ -1314,9 +1417,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         if (attempt == 4 || cap >= (1ull << 31)) return phz_fail(ctx, PHZ_E_NOMEM, "variant-pair table did not converge");
         cap <<= 2;
     }
-    // the longer read lists: one workgroup each (bitonic sort in LDS), the few beyond that through the device radix sort
-    if (h_c32[2]) hipLaunchKernelGGL(k_rl_sort_wave, dim3(h_c32[2]), dim3(64), 0, sm, (const uint32_t *)wave_list, (const uint32_t *)rl_start, (const uint64_t *)rl_tmp, rl_qid);
-    if (h_c32[0]) hipLaunchKernelGGL(k_rl_sort_mid, dim3(h_c32[0]), dim3(256), 0, sm, (const uint32_t *)mid_list, (const uint32_t *)rl_start, (const uint64_t *)rl_tmp, rl_qid);
+    // the dirty read lists beyond the LDS stage: through the device radix sort
     if (h_c32[1]) {
         std::vector<uint32_t> big(h_c32[1]), rs((size_t)NRL + 1);
         PHZ_HIP(ctx, hipMemcpy(big.data(), big_list, big.size() * 4, hipMemcpyDeviceToHost));

@@ -22,7 +22,7 @@ from . import _lib
 from . import dist as pdist
 from .mapper import Calls, Mapper
 from . import rows
-from .soa import ReadShard
+from .soa import ReadShard, as16_plane
 from .vcf import ChromVariants, VariantSet
 
 
@@ -121,8 +121,9 @@ def binom_cdf_dedup(k: np.ndarray, n: np.ndarray, p: float) -> np.ndarray:
 
 
 class _Shard:
-    def __init__(self, calls: Calls, qid, aln, has_as, n_reads):
+    def __init__(self, calls: Calls, qid, aln, has_as, n_reads, as16=None):
         self.calls = calls; self.qid = qid; self.aln = aln; self.has_as = has_as; self.n_reads = n_reads
+        self.as16 = as16               # the AS column as one 2-byte plane (soa.as16_plane): what the tally kernels gather
         self.cutoff = 0.0; self.use_cutoff = 0
         self.as_absmax = None
 
@@ -164,7 +165,7 @@ class Engine:
             calls = self.mapper.map(shard, vpos, self.cfg.baseq, torch.from_numpy(cv.ref_len))
         has_as = shard.has_as
         self.shards[chrom][bam_index] = _Shard(calls, shard.qid.contiguous(), shard.aln_score.contiguous(),
-                                               None if has_as is None else has_as.contiguous(), shard.n)
+                                               None if has_as is None else has_as.contiguous(), shard.n, as16_plane(shard))
         self.n_qid[chrom] = max(self.n_qid[chrom], n_qid)
         if qnames is not None:
             self.qnames[chrom] = qnames
@@ -186,7 +187,7 @@ class Engine:
         """Attach a shard whose K_map call list already exists."""
         has_as = shard.has_as
         self.shards[chrom][bam_index] = _Shard(calls, shard.qid.contiguous(), shard.aln_score.contiguous(),
-                                               None if has_as is None else has_as.contiguous(), shard.n)
+                                               None if has_as is None else has_as.contiguous(), shard.n, as16_plane(shard))
         self.n_qid[chrom] = max(self.n_qid[chrom], n_qid)
         if qnames is not None:
             self.qnames[chrom] = qnames
@@ -198,12 +199,13 @@ class Engine:
         if ln is None or sh._ln_n != sh.calls.n:
             c = sh.calls
             cached = c.__dict__.get("_phz_ln") if hasattr(c, "__dict__") else None      # the same call list handed to a new Engine (every pass of the bench)
-            if cached is not None and cached[1] is c.read_idx and cached[2] is sh.qid and cached[3] is sh.aln and cached[4] is sh.has_as and cached[5] == c.n:
+            if cached is not None and cached[1] is c.read_idx and cached[2] is sh.qid and cached[3] is sh.aln and cached[4] is sh.has_as and cached[5] == c.n \
+                    and cached[6] is sh.as16:
                 ln = cached[0]
             else:
-                ln = _lib.phz_lines(c.n, _p(c.read_idx), _p(c.var_idx), _p(c.code), sh.n_reads, _p(sh.qid), _p(sh.aln), _p(sh.has_as), 0.0, 0, 0, 0, 0)
+                ln = _lib.phz_lines(c.n, _p(c.read_idx), _p(c.var_idx), _p(c.code), sh.n_reads, _p(sh.qid), _p(sh.aln), _p(sh.has_as), 0.0, 0, 0, 0, 0, _p(sh.as16))
                 if hasattr(c, "__dict__"):
-                    c.__dict__["_phz_ln"] = (ln, c.read_idx, sh.qid, sh.aln, sh.has_as, c.n)
+                    c.__dict__["_phz_ln"] = (ln, c.read_idx, sh.qid, sh.aln, sh.has_as, c.n, sh.as16)
             sh._ln = ln; sh._ln_n = c.n
         ln.as_cutoff = float(sh.cutoff); ln.use_cutoff = int(sh.use_cutoff); ln.bam_index = bam_index; ln.var_base = var_base; ln.qid_base = qid_base
         return ln

@@ -119,11 +119,39 @@ class PinnedPool:
     def _new_root(nbytes: int) -> np.ndarray:
         return torch.empty(max(1, nbytes), dtype=torch.uint8, pin_memory=torch.cuda.is_available()).numpy()      # the ndarray's base keeps the tensor alive
 
+    # What sys.getrefcount reports for an array beyond the references its caller holds, seen from ONE Python frame below the caller (the
+    # call's own argument slots): CPython 3.10 keeps a reference on the caller's value stack during the call, 3.11+ does not, so the number is
+    # MEASURED at import on an array with no views and checked on one with a view (`_calibrate`); None = the interpreter did not behave as
+    # expected and nothing is ever recycled (buffers are then left to the garbage collector: slower, never wrong).
+    _overhead: Optional[int] = None
+
+    @staticmethod
+    def _raw_refs(root: np.ndarray) -> int:
+        return sys.getrefcount(root)
+
+    @staticmethod
+    def _calibrate() -> Optional[int]:
+        r = np.empty(16, dtype=np.uint8)
+        c0 = PinnedPool._raw_refs(r)                 # the caller holds exactly one reference (the local)
+        v = r[:8]
+        c1 = PinnedPool._raw_refs(r)                 # ... and a view holds one more (its .base)
+        mv = memoryview(v)[2:4]                      # the form finish(chunks=True) hands out: a memoryview slice over a view of the root
+        c2 = PinnedPool._raw_refs(r)
+        del v
+        c3 = PinnedPool._raw_refs(r)                 # the memoryview alone keeps the view, hence the root, referenced
+        del mv
+        c4 = PinnedPool._raw_refs(r)
+        if c1 == c0 + 1 and c2 == c1 and c3 == c1 and c4 == c0 and c0 >= 2:
+            return c0 - 1
+        return None
+
     @staticmethod
     def _unreferenced(root: np.ndarray, held: int) -> bool:
-        """No view of `root` is alive outside the `held` references the caller knows of (+ the call's stack slot, this function's argument and
-        getrefcount's own; CPython -- the only interpreter torch runs on)."""
-        return sys.getrefcount(root) <= held + 3
+        """No view of `root` is alive outside the `held` references the caller knows of.  Every view handed out (ndarray slices, memoryview
+        slices over them) keeps one reference on the root, so the root's reference count beyond `held` + the calibrated call overhead says so.
+        Uncalibrated interpreter: never (the buffer is not recycled)."""
+        oh = PinnedPool._overhead
+        return oh is not None and sys.getrefcount(root) <= held + oh
 
     def get(self, name: str, nbytes: int) -> np.ndarray:
         """uint8 view of this owner's buffer `name` (>= nbytes).  Text buffers ('rows_*') are carved from the arena prepare_arena()
@@ -174,6 +202,9 @@ class PinnedPool:
             b = a["buf"]
             if b is not None and not self._unreferenced(b, 2):       # text chunks carved from the arena outlive the Engine: the arena is theirs now
                 a["buf"] = None
+
+
+PinnedPool._overhead = PinnedPool._calibrate()
 
 
 def prepare_arena(nbytes: int):

@@ -62,6 +62,29 @@ class ReadShard:
                          f(self.qid), f(self.aln_score), f(self.has_as), self.iupac)
 
 
+AS16_NONE = -32768          # phz.h PHZ_AS16_NONE / PHZ_AS16_RANGE
+AS16_RANGE = 32767
+
+
+def as16_plane(shard: "ReadShard") -> Optional[torch.Tensor]:
+    """The shard's AS column as ONE 2-byte plane with the has-AS flag folded in (SURVEY.md 8(a) M1 `as:int16`; phz_lines.read_as16): what the
+    AS histogram and the per-line pass of K_tally gather per call line -- 2 bytes on one memory line instead of 4 + 1 on two.  AS16_NONE = no
+    AS tag; a value outside [-32766, 32766] becomes +-AS16_RANGE and is refused by the histogram like any value outside int16.  Built once per
+    shard (elementwise pass on the shard's device) and kept on it."""
+    a = shard.aln_score
+    if a is None:
+        return None
+    c = shard.__dict__.get("_as16")
+    if c is not None and c[0] is a and c[1] is shard.has_as:
+        return c[2]
+    x = a.clamp(-AS16_RANGE, AS16_RANGE).to(torch.int16)
+    if shard.has_as is not None:
+        x = x.masked_fill(shard.has_as == 0, AS16_NONE)
+    x = x.contiguous()
+    shard.__dict__["_as16"] = (a, shard.has_as, x)
+    return x
+
+
 def pack_fixed(pos: torch.Tensor, cigar_off: torch.Tensor, cigar: torch.Tensor, seq: torch.Tensor,
                qual: torch.Tensor, qid=None, aln_score=None) -> ReadShard:
     """seq: uint8 [n, L] base codes 0..3, 4 = N;  qual: uint8 [n, L] phred."""

@@ -37,12 +37,21 @@ def lines_from_saved(saved, chrom_list, n_bams):
     return shards, keep, vb, qb
 
 
-def run_tally(ctx, saved, chrom_list, n_bams):
+def run_tally(ctx, saved, chrom_list, n_bams, as16=False):
+    """as16: hand the AS column over as the 2-byte plane (phz_lines.read_as16, the form the Engine uses) instead of read_as + read_has_as"""
     from phaser_amd import _lib
     shards, keep, NV, NQ = lines_from_saved(saved, chrom_list, n_bams)
     vp = lambda a: C.c_void_p(a.ctypes.data)
-    arr = (_lib.phz_lines * max(1, len(shards)))(*[_lib.phz_lines(n, vp(a["read_idx"]), vp(a["var_idx"]), vp(a["code"]), max(1, n), vp(a["read_qid"]), vp(a["read_as"]),
-                                                                  vp(a["has_as"]), 0.0, 1, b, v0, q0) for a, n, b, v0, q0 in shards])
+    if as16:
+        for a, n, b, v0, q0 in shards:
+            a["as16"] = np.where(a["has_as"] != 0, a["read_as"][:len(a["has_as"])].astype(np.int16), np.int16(-32768)).astype(np.int16)
+            if len(a["as16"]) == 0:
+                a["as16"] = np.zeros(1, np.int16)
+        arr = (_lib.phz_lines * max(1, len(shards)))(*[_lib.phz_lines(n, vp(a["read_idx"]), vp(a["var_idx"]), vp(a["code"]), max(1, n), vp(a["read_qid"]), None, None,
+                                                                      0.0, 1, b, v0, q0, vp(a["as16"])) for a, n, b, v0, q0 in shards])
+    else:
+        arr = (_lib.phz_lines * max(1, len(shards)))(*[_lib.phz_lines(n, vp(a["read_idx"]), vp(a["var_idx"]), vp(a["code"]), max(1, n), vp(a["read_qid"]), vp(a["read_as"]),
+                                                                      vp(a["has_as"]), 0.0, 1, b, v0, q0) for a, n, b, v0, q0 in shards])
     a0 = np.full(max(1, NV), 255, dtype=np.uint8)
     sz = _lib.phz_tally_sizes()
     ctx.check(ctx.lib.phz_tally(ctx.h, arr, len(shards), NV, vp(a0), vp(a0), NQ, n_bams, C.byref(sz), _lib.PHZ_HOST))
@@ -99,10 +108,10 @@ def test_tally_kernels_on_skewed_synthetic_lines():
     _check_against_sets(R, nv, nq, 2)
 
 
-def _check_against_sets(R, nv, nq, nb, tile=0):
+def _check_against_sets(R, nv, nq, nb, tile=0, as16=False):
     saved = {"tally": {"chrS": R}, "n_qid": {"chrS": nq}}
     ctx = EmuContext(emu_library(tile))
-    got, sz = run_tally(ctx, saved, ["chrS"], nb)
+    got, sz = run_tally(ctx, saved, ["chrS"], nb, as16=as16)
     var, qid, cls, bam = R["line_var"], R["line_qid"], R["line_cls"], R["line_bam"]
     kept = cls != 255
     # per-variant counters
@@ -136,6 +145,27 @@ def _check_against_sets(R, nv, nq, nb, tile=0):
                 assert (a, b2) not in seen
             else:
                 assert list(seen[(a, b2)]) == want, (a, b2)
+
+
+@pytest.mark.parametrize("tile", [0, 256])
+def test_read_lists_with_far_lines_are_sorted_afterwards(tile):
+    """A read spliced over hundreds of het SNPs puts call lines outside the variant window of the tile they arrive in (far lines): their read
+    lists are filled through cursors and put into line order afterwards -- a short one in LDS, one of > 4,096 entries by the device radix
+    sort -- while every other list is written in place, in order, with no sort.  The AS column travels as the 2-byte plane here."""
+    rng = np.random.default_rng(23)
+    nv = 900; nq = 5000
+    var = [np.zeros(6000, np.int64)]                                   # variant 0: 6,000 lines in a row (six tiles with the same window) ...
+    later = np.sort(rng.integers(500, 560, size=3000))                 # ... then lines of variants 500-559, the windows have moved on ...
+    far0 = rng.choice(3000, size=12, replace=False); later[far0] = 0   # ... with twelve more lines of variant 0 among them (far: list (0, *) > 4,096 entries)
+    far7 = rng.choice(3000, size=5, replace=False); later[far7] = 7    # and five of variant 7, which has no other line (a short dirty list)
+    var.append(later)
+    var.append(np.sort(rng.integers(560, 900, size=2500)))
+    var = np.concatenate(var).astype(np.int32)
+    n = len(var)
+    qid = rng.integers(0, nq, size=n).astype(np.int32)
+    cls = rng.choice([0, 1, 2, 255], size=n, p=[0.5, 0.4, 0.05, 0.05]).astype(np.uint8)
+    R = {"nv": nv, "line_var": var, "line_qid": qid, "line_cls": cls, "line_bam": np.zeros(n, np.int32), "bam_offsets": [(0, 0, n)]}
+    _check_against_sets(R, nv, nq, 1, tile, as16=True)
 
 
 @pytest.mark.parametrize("tile", [0, 256])
