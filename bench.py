@@ -313,6 +313,41 @@ def algorithmic_minimum(shards, vposs, bufs_aux, n_calls):
     return out
 
 
+def rccl_selfcheck(local):
+    """N = 1 has no collective on its path (dist.py short-circuits them), so the line of a one-GPU box would never show RCCL running.  This runs the
+    multi-rank layer's own collectives (dist.allreduce_sum_, allreduce_counts, the int64 all-gather) over a world-size-1 process group on backend
+    "nccl" (= RCCL) after the measurements, and reports whether librccl is mapped into the process.  (The whole CLI through that path:
+    tests/test_gpu_pipeline.py::test_one_rank_forced_through_every_collective.)"""
+    from phaser_amd import dist as pdist
+    out = {"backend": "nccl (RCCL)", "world_size": 1}
+    old = os.environ.get("PHZ_DIST_FORCE_COLLECTIVES")
+    try:
+        os.environ["PHZ_DIST_FORCE_COLLECTIVES"] = "1"
+        t0 = time.perf_counter()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 2000), rank=0, world_size=1, device_id=torch.device("cuda", local))
+        t = torch.arange(8, dtype=torch.int64, device="cuda:%d" % local)
+        pdist.allreduce_sum_(t); torch.cuda.synchronize()
+        out["init_plus_first_all_reduce_s"] = time.perf_counter() - t0
+        ok = bool((t.cpu() == torch.arange(8)).all()) and pdist.allreduce_counts(5, 7) == (5, 7) and pdist._all_gather_i64([3, 1, 4]) == [[3, 1, 4]]
+        h = torch.zeros(65536, dtype=torch.int64, device="cuda:%d" % local); h[100] = 3
+        t1 = time.perf_counter()
+        for _ in range(20):
+            pdist.allreduce_sum_(h)
+        torch.cuda.synchronize()
+        out["as_histogram_all_reduce_us"] = (time.perf_counter() - t1) / 20 * 1e6
+        out["rccl_ranks"] = int(dist.get_world_size()); out["collectives_ok"] = ok and int(h[100]) == 3
+        out["librccl_mapped"] = "librccl" in open("/proc/self/maps").read()
+        dist.destroy_process_group()
+    except Exception as e:                       # a side entry must never cost the bench line
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        if old is None:
+            os.environ.pop("PHZ_DIST_FORCE_COLLECTIVES", None)
+        else:
+            os.environ["PHZ_DIST_FORCE_COLLECTIVES"] = old
+    return out
+
+
 def self_launch(n):
     """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same arguments>` (rendezvous on 127.0.0.1, a
     free port).  Never returns."""
@@ -609,6 +644,9 @@ def main():
                 out["bam_path"], out["end_to_end_files"] = files_entries(mapper, dev, a)
             except Exception as e:                      # a side entry must never cost the bench line
                 out["bam_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and backend == "nccl":
+            out["collective"]["rccl_selfcheck"] = rccl_selfcheck(local)
+            out["collective"]["rccl_ranks"] = int(out["collective"]["rccl_selfcheck"].get("rccl_ranks", 0))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -211,6 +211,11 @@ int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int n_shards, 
 int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, int n_shards, int cap, int32_t *bins /* [cap] */, int64_t *counts /* [cap] */,
                             int32_t *n_bins);
 
+/* ... and the whole of phaser.py:545-553 for one BAM in one call and one host wait: histogram of its shards' AS column on the device, occupied bins back,
+ * numpy.percentile(scores, q_percent) (default linear method, the same float64 operations) computed natively.  *found = 0: no record carries an AS tag.
+ * PHZ_E_CAPACITY: more than 4,096 distinct scores (take phz_as_histogram_batch and the host formula then). */
+int phz_as_cutoff(phz_ctx *ctx, const phz_lines *shards, int n_shards, double q_percent, double *cutoff, int32_t *found);
+
 /* Per-variant counters, distinct read sets, variant-pair co-occurrence cells and per-(variant, allele, BAM) read lists over
  * any number of (chromosome, BAM) shards in one submission.  Shards must be ordered by (chromosome, BAM); a chromosome's
  * shards share var_base / qid_base; nv / n_qid are the sizes of the joint index spaces.  a0/a1: the individual's two allele

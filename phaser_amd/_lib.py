@@ -215,6 +215,7 @@ SYMBOLS = {
     "phz_as_histogram": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_void_p, C.c_int]),
     "phz_as_histogram_batch": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_void_p]),
     "phz_as_histogram_sparse": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "phz_as_cutoff": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.POINTER(phz_tally_sizes), C.c_int]),
     "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),

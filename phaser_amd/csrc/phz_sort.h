@@ -351,12 +351,8 @@ __global__ __launch_bounds__(256) void k_os_bases(uint32_t *ghist) {
     h[tid] = before + incl - v;
 }
 // wave-level ordering point between LDS accesses of different lanes of ONE wave: the hardware executes a wave's LDS instructions in order, so the compiler
-// barrier is all that is needed; the emulation (a fiber per lane) needs a rendezvous
-#ifdef HIPEMU_H
-#define PHZ_WAVE_SYNC() ((void)__ballot(1))
-#else
+// barrier is all that is needed
 #define PHZ_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif
 template <class K, class V> __global__ __launch_bounds__(256) void k_os_pass(const K *kin, const V *vin, K *kout, V *vout, int64_t n, int shift, const uint32_t *base,
                                                                             uint32_t *status, uint32_t *ticket) {
     __shared__ uint32_t s_cnt[OS_WAVES][256];          // per-wave digit counts (built row by row: a key's place among its wave's keys of that digit), then the

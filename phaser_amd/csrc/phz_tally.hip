@@ -26,6 +26,7 @@
 //   k_components   :1861-1882/:1985-1998 connected components (lock-free union-find)
 // Integer work, hand-written kernels and primitives only (phz_sort.h).  Nothing is swept by the number of QNAME ids per call except two
 // bitmaps (one bit per id each, cleared per call); the per-QNAME cursor array is touched for spilled QNAMEs only and returns to zero.
+#include <cmath>
 #include <cstring>
 #include "phz_internal.h"
 #include "phz_sort.h"
@@ -1213,6 +1214,45 @@ extern "C" int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, in
         std::sort(order.begin(), order.end(), [&](int a, int b) { return hb[a] < hb[b]; });
         for (size_t i = 0; i < order.size(); i++) { bins[i] = hb[order[i]]; counts[i] = hc[order[i]]; }
     }
+    return PHZ_OK;
+}
+
+// numpy.percentile(scores, q) (the default "linear" method: numpy/lib/_function_base_impl.py _quantile / _lerp; the reference's call at
+// phaser.py:551) over the multiset {bin - 32768 repeated count times}, from the occupied bins in ascending order: the same float64 operations on the
+// two neighbouring order statistics (engine.percentile_from_band is the Python twin, pinned against numpy in the tests)
+static double percentile_of_bins(const int32_t *bins, const int64_t *counts, int nb, double q) {
+    int64_t n = 0;
+    for (int i = 0; i < nb; i++) n += counts[i];
+    const double quant = q / 100.0;
+    const double virt = (double)(n - 1) * quant;
+    int64_t prev = (int64_t)floor(virt);
+    const double gamma = virt - (double)prev;
+    int64_t nxt = prev + 1;
+    if (virt >= (double)(n - 1)) prev = nxt = n - 1;
+    if (virt < 0) prev = nxt = 0;
+    auto value_at = [&](int64_t k) {                 // k-th smallest score (0-based)
+        int64_t c = 0;
+        for (int i = 0; i < nb; i++) { c += counts[i]; if (c > k) return (int64_t)bins[i] - 32768; }
+        return (int64_t)bins[nb - 1] - 32768;
+    };
+    const int64_t a = value_at(prev), b = value_at(nxt), diff = b - a;
+    double out = (double)a + (double)diff * gamma;
+    if (gamma >= 0.5) out = (double)b - (double)diff * (1 - gamma);
+    return out;
+}
+
+// AS histogram of the shards of one BAM + the percentile, in one call and one host wait: *found = 0 when no record carries an alignment score
+extern "C" int phz_as_cutoff(phz_ctx *ctx, const phz_lines *shards, int n_shards, double q_percent, double *cutoff, int32_t *found) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || !cutoff || !found) return PHZ_E_ARG;
+    constexpr int CAP = 4096;
+    std::vector<int32_t> bins(CAP); std::vector<int64_t> counts(CAP);
+    int32_t nb = 0;
+    if (int s = phz_as_histogram_sparse(ctx, shards, n_shards, CAP, bins.data(), counts.data(), &nb)) return s;
+    int64_t n = 0;
+    for (int i = 0; i < nb; i++) n += counts[i];
+    *found = n > 0 ? 1 : 0; *cutoff = 0.0;
+    if (n > 0) *cutoff = percentile_of_bins(bins.data(), counts.data(), nb, q_percent);
     return PHZ_OK;
 }
 

@@ -20,6 +20,16 @@ def world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
+def collectives_live() -> bool:
+    """True when results have to travel through the process group: more than one rank -- or ONE rank with PHZ_DIST_FORCE_COLLECTIVES=1, which
+    runs the whole multi-rank path (the all-reduces, the all-gathers of the fragment tables, the broadcasts, the spool files, the barrier) on a
+    single process.  That is how the backend "nccl" (= RCCL) branch of every function below is executed on a one-GPU box."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PHZ_DIST_FORCE_COLLECTIVES") == "1"
+
+
 def assign_chromosomes(weights: Dict[str, float], world_size: int) -> Dict[str, int]:
     """Longest-processing-time assignment of chromosomes to ranks by record count (deterministic)."""
     load = [0.0] * world_size
@@ -33,8 +43,7 @@ def assign_chromosomes(weights: Dict[str, float], world_size: int) -> Dict[str, 
 
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     """In-place SUM over ranks; tensors must live where the backend wants them (cuda for nccl, cpu for gloo)."""
-    r, w = world()
-    if w > 1:
+    if collectives_live():
         backend = dist.get_backend()
         if backend == "nccl" and t.device.type != "cuda":
             tmp = t.cuda()
@@ -50,8 +59,7 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
 
 
 def allreduce_counts(match: int, mism: int):
-    r, w = world()
-    if w == 1:
+    if not collectives_live():
         return match, mism
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([match, mism], dtype=torch.int64, device=dev)
@@ -155,7 +163,7 @@ def gather_fragments(local: Dict[str, dict], spool_dir: Optional[str] = None, ch
     reference's global order.  A rank whose spool file rank 0 cannot see (no shared filesystem) sends the bytes through the process group
     instead.  chrom_order: all chromosomes in VCF order (identical on every rank); chromosomes travel as indices into it."""
     r, w = world()
-    if w == 1:
+    if not collectives_live():
         return dict(local)
     import os
     import tempfile
@@ -278,8 +286,7 @@ SPOOL_FILES: List[str] = []
 def cleanup_spool():
     """Remove this rank's spool files (call after rank 0 has written the outputs; a barrier separates the two)."""
     import os
-    r, w = world()
-    if w > 1:
+    if collectives_live():
         try:
             dist.barrier()
         except Exception:              # a rank that failed must still remove its files
@@ -300,12 +307,19 @@ def write_files(paths_and_chunks, threads: int = 8):
     def put(item):
         # No O_TRUNC: a file left by an earlier run under the same prefix is overwritten IN PLACE and cut to the new length at the end.  Truncating
         # it first hands its page-cache pages back only to allocate as many again (0.09 s for the 770 MB of a genome's five files, measured).
+        # A write that fails half way (ENOSPC, a short spool file) must not leave the new head followed by the old tail -- a file that looks
+        # complete: it is cut to the bytes written before the error travels on.
         import os
         path, chunks = item
         with os.fdopen(os.open(path, os.O_WRONLY | os.O_CREAT, 0o666), "wb") as f:
-            write_chunks(f, chunks)
-            f.flush()
-            f.truncate(f.tell())
+            try:
+                write_chunks(f, chunks)
+            finally:
+                try:
+                    f.flush()
+                except OSError:
+                    pass
+                f.truncate(os.lseek(f.fileno(), 0, os.SEEK_CUR))
     if len(items) <= 1 or threads <= 1:
         for it in items:
             put(it)

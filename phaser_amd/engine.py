@@ -226,19 +226,17 @@ class Engine:
             hist = hb[0]
             live = [sh for sh in shards if sh.calls.n]
             cutoff = None; done = False
-            if live and dev.type == "cuda" and pdist.world()[1] == 1:
+            if live and dev.type == "cuda" and not pdist.collectives_live():
                 # one rank: nothing to all-reduce, so the histogram stays on the device and only its occupied bins come back (a few hundred
                 # bytes instead of 512 KB; one call, one host wait)
+                # (histogram -> occupied bins -> numpy.percentile's formula, all inside phz_as_cutoff; percentile_from_sparse is its Python twin)
                 arr = (_lib.phz_lines * len(live))(*[self._lines(sh, bam_index) for sh in live])
-                sb = self.mapper.__dict__.get("_as_sparse")
-                if sb is None:
-                    sb = self.mapper.__dict__["_as_sparse"] = (np.empty(2048, np.int32), np.empty(2048, np.int64), C.c_int32(0))
                 torch.cuda.current_stream(dev).synchronize()
-                st = self.ctx.check(self.lib.phz_as_histogram_sparse(self.ctx.h, arr, len(live), 2048, C.c_void_p(sb[0].ctypes.data),
-                                                                     C.c_void_p(sb[1].ctypes.data), C.byref(sb[2])), allow=(_lib.PHZ_E_CAPACITY,))
+                val = C.c_double(0.0); found = C.c_int32(0)
+                st = self.ctx.check(self.lib.phz_as_cutoff(self.ctx.h, arr, len(live), float(self.cfg.as_q_cutoff * 100), C.byref(val), C.byref(found)),
+                                    allow=(_lib.PHZ_E_CAPACITY,))
                 if st == 0:
-                    k = int(sb[2].value)
-                    cutoff = percentile_from_sparse(sb[0][:k], sb[1][:k], self.cfg.as_q_cutoff * 100)
+                    cutoff = float(val.value) if found.value else None
                     done = True
             if not done:
                 cutoff = self._as_cutoff_dense(hb, live, dev, bam_index)

@@ -117,9 +117,13 @@ def _main(argv, state):
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, n_dev)
     if n_dev:
         torch.cuda.set_device(local)          # before any collective: NCCL / barrier use the current device
-    if world == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    force_pg = os.environ.get("PHZ_DIST_FORCE_COLLECTIVES") == "1"        # one rank, yet every collective of the multi-rank path runs (dist.collectives_live)
+    if world == 1 and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (force_pg and not dist.is_initialized())):
         # one rank per GPU over RCCL ("nccl"); PHZ_DIST_BACKEND=gloo lets several ranks share a GPU (tests on a 1-GPU box)
         backend = os.environ.get("PHZ_DIST_BACKEND", "nccl" if n_dev else "gloo")
+        if force_pg and "WORLD_SIZE" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -343,7 +347,7 @@ def _main(argv, state):
     mine = set(eng.chrom_list)
     # While the BAMs are read: the per-variant tables of the row stage go to the GPU (0.07 s at genome scale, independent of the reads)
     warm = None
-    if not any_sam and cfg.device_rows and args.output_read_ids == 0 and args.gw_phase_method == 0:
+    if not any_sam and cfg.device_rows and args.output_read_ids == 0:          # (what rowsdev.supported() accepts)
         import threading
 
         def _warm():
@@ -361,14 +365,17 @@ def _main(argv, state):
 
         warm = threading.Thread(target=_warm, daemon=True)
         warm.start()
+    bam_paths = []                 # which decoder read each BAM: "device" (phz_bamdev_*), "host" (phz_bam_*: the file was declined or PHZ_BAM_HOST=1), "sam" (text)
     for bi, (bam, mq, isz, pe) in enumerate(zip(bam_list, mapq_list, isize_list, pe_list)):
         say("     file: %s" % bam)
         say("          minimum mapq: %s" % mq)
         say("          mapping reads to variants...")
         if bam.endswith(".sam"):
             shards = samio.shards_from_sam(open(bam).read(), interners, isz)
+            bam_paths.append("sam")
         elif any_sam:
             shards = bamio.shards_from_bam(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine)
+            bam_paths.append("host")
         else:
             # BGZF inflate + record decode + filters + packing on the GPU (phz_bamdev_*); files it declines, and PHZ_BAM_HOST=1, go
             # through the host decoder (phz_bam_*, --threads host threads).  QNAME interning is host-side in both.
@@ -392,6 +399,7 @@ def _main(argv, state):
             if shards is None and not declined and os.environ.get("PHZ_BAM_HOST") != "1":
                 shards = bamio.shards_from_bam_device(eng.ctx, bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
                                                       device=device)
+            bam_paths.append("device" if shards is not None else "host")
             if shards is None:
                 shards = bamio.shards_from_bam_native(bam, interners, int(mq), args.remove_dups == 1, int(pe) == 1, isz, chroms=mine,
                                                       threads=max(0, args.threads if args.threads > 1 else 0))
@@ -475,6 +483,9 @@ def _main(argv, state):
             if vs.unphased_count > 0:
                 say("     GENOME WIDE PHASED  %d of %d unphased variants (= %f)" % (up, vs.unphased_count, float(up) / float(vs.unphased_count)))
             say("     GENOME WIDE PHASE CORRECTED  %d of %d variants (= %f)" % (pc, vs.het_count, float(pc) / float(vs.het_count)))
+        # which of this build's paths did the work (not a line of the reference): a run that fell back to a host twin says so
+        say("     HOT PATH  bam: %s, rows: %s%s" % (",".join(bam_paths) if bam_paths else "-", getattr(eng, "rows_path", "-"),
+                                                    " (%s)" % eng.rows_fallback if getattr(eng, "rows_fallback", None) else ""))
         say('')
         say("The End.")
         global LAST_STAGE_SECONDS

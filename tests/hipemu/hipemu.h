@@ -166,6 +166,9 @@ template <class T> inline T __shfl_xor(T v, int m, int width = 64) {
 template <class T> inline T __hip_atomic_load(const T *p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 template <class T, class V> inline void __hip_atomic_store(T *p, V v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
 inline void __builtin_amdgcn_s_sleep(int) {}
+// on the hardware a compiler-level ordering point between the LDS accesses of one wave's lanes (they execute in lock step); here every lane is a
+// fiber of its own, so the ordering point has to be a rendezvous of the wave
+inline void __builtin_amdgcn_wave_barrier();
 inline unsigned long long wall_clock64() { return 0ull; }
 inline unsigned long long __ballot(int pred) {
     hipemu::Gather<int> g(pred ? 1 : 0);
@@ -174,6 +177,7 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
+inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }
 inline int __all(int pred) {
     hipemu::Gather<int> g(pred ? 1 : 0);
     for (int l = 0; l < 64; l++) if (((g.mask >> l) & 1) && !g.at(l)) return 0;

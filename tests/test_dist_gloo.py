@@ -114,6 +114,37 @@ def test_a_rank_without_chromosomes(tmp_path):
         assert canonical(name, r["out"][name]) == canonical(name, gz_text(os.path.join(d, "out.%s.txt.gz" % name))), name
 
 
+def _worker_forced(rank, world, port, result_path):
+    os.environ["PHZ_DIST_FORCE_COLLECTIVES"] = "1"
+    _worker(rank, world, port, result_path)
+
+
+def test_one_rank_forced_through_the_collectives(tmp_path):
+    """PHZ_DIST_FORCE_COLLECTIVES=1: ONE rank takes the multi-rank path (all-reduces, broadcasts, all-gathers, spool file + byte-range splice,
+    barrier) -- the switch behind the GPU test that runs the same path over backend nccl on a one-GPU box; without it a single rank skips
+    every collective."""
+    port = 29500 + (os.getpid() % 2000) + 31
+    res = str(tmp_path / "res.json")
+    mp.spawn(_worker_forced, args=(1, port, res), nprocs=1, join=True)
+    r = json.load(open(res))
+    d = os.path.join(GOLD, "pipe_two")
+    assert r["phased"] == 229
+    for name in OUTPUTS:
+        assert canonical(name, r["out"][name]) == canonical(name, gz_text(os.path.join(d, "out.%s.txt.gz" % name))), name
+    from phaser_amd import dist as pdist
+    assert not pdist.collectives_live()                     # (no process group in this process)
+
+
+def test_write_files_cuts_a_failed_write_to_what_was_written(tmp_path):
+    """Round-5 advisor: outputs are overwritten in place (no O_TRUNC); a write that fails half way must not leave the new head followed by the old tail."""
+    from phaser_amd import dist as pdist
+    p = str(tmp_path / "f.txt")
+    open(p, "wb").write(b"OLD" * 1000)
+    with pytest.raises(IOError):
+        pdist.write_files([(p, [b"new-head", pdist.FileSpan(str(tmp_path / "missing.bin"), 0, 10)])])
+    assert open(p, "rb").read() == b"new-head"
+
+
 def test_lpt_assignment_balanced_and_deterministic():
     from phaser_amd import dist as pdist
     w = {"chr%d" % i: float(250 - 10 * i) for i in range(1, 23)}

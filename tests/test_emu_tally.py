@@ -227,3 +227,33 @@ def test_tally_on_empty_and_fully_dropped_input():
     live = dict(dropped); live["line_cls"] = rng.choice([0, 1, 2], size=n).astype(np.uint8)
     got, sz = run_tally(ctx, {"tally": {"chrS": live}, "n_qid": {"chrS": nq}}, ["chrS"], 1)
     assert int(sz.n_kept) == n and int(got["var_count"].sum()) == n
+
+
+def test_as_cutoff_is_numpy_percentile():
+    """phz_as_cutoff (AS histogram on the device, occupied bins back, numpy.percentile's linear formula in the library -- phaser.py:545-553 in one
+    call) against numpy.percentile itself on the scores of the call lines, bit for bit: narrow and wide score bands, ties at the quantile, a
+    single line, records without an AS tag, every quantile the option accepts in practice."""
+    from phaser_amd import _lib
+    ctx = EmuContext(emu_library())
+    rng = np.random.default_rng(41)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    for trial in range(9):
+        n_reads = int(rng.integers(1, 800)); n_lines = int(rng.integers(1, 900))
+        spread = int(rng.choice([1, 3, 40, 1500]))
+        aln = rng.integers(-spread, spread + 1, size=n_reads).astype(np.int32) - int(rng.integers(0, 200))
+        has = (rng.random(n_reads) > (0.0 if trial % 3 else 0.3)).astype(np.uint8)
+        read_idx = np.sort(rng.integers(0, n_reads, size=n_lines)).astype(np.int32)
+        as16 = np.where(has != 0, aln, -32768).astype(np.int16)
+        z32 = np.zeros(n_lines, np.int32); z8 = np.zeros(n_lines, np.uint8); qid = np.zeros(n_reads, np.int32)
+        for use16 in (False, True):
+            ln = _lib.phz_lines(n_lines, vp(read_idx), vp(z32), vp(z8), n_reads, vp(qid), None if use16 else vp(aln), None if use16 else vp(has), 0.0, 0, 0, 0, 0,
+                                vp(as16) if use16 else None)
+            arr = (_lib.phz_lines * 1)(ln)
+            scores = aln[read_idx][has[read_idx] != 0].astype(np.int64)
+            for q in ((5.0, 0.0, 100.0, 0.05 * 100) if use16 else (5.0, 50.0, 99.9, 12.5)):
+                val = C.c_double(-1.0); found = C.c_int32(-1)
+                ctx.check(ctx.lib.phz_as_cutoff(ctx.h, arr, 1, float(q), C.byref(val), C.byref(found)))
+                if len(scores) == 0:
+                    assert found.value == 0
+                else:
+                    assert found.value == 1 and val.value == float(np.percentile(scores, q)), (trial, q, val.value, float(np.percentile(scores, q)))

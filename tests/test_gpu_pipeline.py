@@ -651,6 +651,39 @@ def test_two_ranks_one_gpu_real_kernels(tmp_path, backend, world):
     assert not [f for f in os.listdir(tmp_path) if f.startswith("phz_spool_")]          # spool files removed
 
 
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_one_rank_forced_through_every_collective(tmp_path, backend):
+    """The RCCL branch on the ONE GPU a test box has (round-5 verdict: `librccl` had never been loaded by this code): PHZ_DIST_FORCE_COLLECTIVES=1
+    makes a single rank take the whole multi-rank path -- process group over backend "nccl" (= RCCL) with world size 1, the dense AS histogram
+    all-reduced on the device, the noise counters all-reduced, the broadcasts and int64 all-gathers of the fragment tables, row text through the
+    spool file and spliced by byte ranges, the closing barrier -- through the CLI on the two-BAM / two-chromosome fixture.  The five files must be
+    the reference's, and with nccl the process must really have RCCL mapped."""
+    import subprocess
+    d = os.path.join(GOLD, "pipe_two")
+    bams = []
+    for b in ("t1", "t2"):
+        p = tmp_path / (b + ".sam")
+        p.write_text("".join(gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")))
+        bams.append(str(p))
+    prefix = str(tmp_path / "out")
+    code = ("import sys\nfrom phaser_amd import phaser, dist as pdist\nrc = phaser.main(sys.argv[1:])\nimport torch.distributed as td\n"
+            "print('PG', td.is_initialized() and td.get_backend(), 'WORLD', td.get_world_size(), 'LIVE', pdist.collectives_live())\n"
+            "print('RCCL_MAPPED', 'librccl' in open('/proc/self/maps').read())\nsys.exit(rc)\n")
+    env = dict(os.environ, PHZ_DIST_FORCE_COLLECTIVES="1", PHZ_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + (os.getpid() % 1000)),
+               PYTHONPATH=REPO)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code, "--vcf", os.path.join(d, "in.vcf"), "--bam", ",".join(bams), "--sample", "S1", "--mapq", "255", "--baseq", "10",
+                        "--paired_end", "1", "--o", prefix, "--write_vcf", "0", "--threads", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert "PG %s WORLD 1 LIVE True" % backend in r.stdout, r.stdout
+    if backend == "nccl":
+        assert "RCCL_MAPPED True" in r.stdout, r.stdout
+    out = {name: open(prefix + "." + name + ".txt").read().replace("\tt1.sam\t", "\tt1\t").replace("\tt2.sam\t", "\tt2\t") for name in OUTPUTS}
+    compare(out, d)
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("phz_spool_")]          # spool file removed
+
+
 def test_as_histogram_sparse_equals_dense(mapper):
     """phz_as_histogram_sparse (one rank: the histogram stays on the device, its occupied bins come back) = the dense 64 Ki-bin histogram of
     phz_as_histogram_batch, on a shard whose alignment scores are spread over thousands of values; more occupied bins than the caller's room
