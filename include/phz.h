@@ -483,7 +483,7 @@ int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i, const int
  *   phz_rowsdev_fetch_*    copy a finished text / the per-block arrays of write_vcf to host memory
  * String pools: item i of a pool = bytes [off[i], off[i+1] - 1) (one separator byte after every item). */
 typedef struct phz_rowsdev phz_rowsdev;
-enum { PHZ_PAIR_SLOTS = 65536 };
+enum { PHZ_PAIR_SLOTS = 16384 };      /* (a genome-wide sample has ~2,000 distinct count pairs; the table grows by itself, see phz_rowsdev_set_pair_slots) */
 enum { PHZ_TXT_CONN = 0, PHZ_TXT_HAP = 1, PHZ_TXT_ASE = 2, PHZ_TXT_CFG = 3, PHZ_TXT_ALLELIC = 4, PHZ_TXT_SINGLE_ASE = 5, PHZ_TXT_SINGLE_HAP = 6,
        PHZ_TXT_COUNT = 7 };
 
@@ -540,7 +540,7 @@ int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host /* [
 int64_t phz_pair_slot_text(const uint32_t *used, const double *pv, int64_t n_used, int64_t n_slots, double *slot_pv /* [n_slots] */,
                            uint32_t *txt_off /* [n_slots + 1] */, char *txt, int64_t txt_cap);
 int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *opts, const double *slot_pv /* [phz_rowsdev_pair_slots(h)] */,
-                    const uint32_t *slot_txt_off /* [PHZ_PAIR_SLOTS + 1] */, const char *slot_txt, phz_rowsdev_result *result);
+                    const uint32_t *slot_txt_off /* [phz_rowsdev_pair_slots(h) + 1] */, const char *slot_txt, phz_rowsdev_result *result);
 int phz_rowsdev_fetch_text(phz_ctx *ctx, phz_rowsdev *h, int which, void *dst, int64_t bytes);
 const void *phz_rowsdev_text_ptr(phz_rowsdev *h, int which);      /* device pointer of a finished text */
 int phz_rowsdev_fetch_blocks(phz_ctx *ctx, phz_rowsdev *h, int32_t *blk_size, int32_t *blk_var, uint8_t *blk_hap, int8_t *blk_cor, double *blk_stat,

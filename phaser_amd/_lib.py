@@ -118,7 +118,7 @@ class phz_rows_out(C.Structure):
                [("owner", C.c_void_p)]
 
 
-PHZ_PAIR_SLOTS = 65536
+PHZ_PAIR_SLOTS = 16384
 PHZ_TXT_NAMES = ("conn", "hap", "ase", "cfg", "allelic", "single_ase", "single_hap")     # PHZ_TXT_* order
 PHZ_TXT_COUNT = 7
 

@@ -58,6 +58,8 @@ int phz_ctx_destroy(phz_ctx *c) {
     for (DevBuf &b : c->import_buf) free_buf(b);
     free_buf(c->tally_qcount); free_buf(c->scan_state);
     if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
+    if (c->mail_host.p) (void)hipHostFree(c->mail_host.p);
+    free_buf(c->mail_dev);
     if (c->h_shard_tab.p) (void)hipHostFree(c->h_shard_tab.p);
     if (c->h_bam_stage.p) (void)hipHostFree(c->h_bam_stage.p);
     free_buf(c->shard_tab); free_buf(c->map_tab); free_buf(c->bam_comp); free_buf(c->bam_stream); free_buf(c->bam_work);
@@ -131,12 +133,34 @@ int phz_reserve_host(phz_ctx *ctx, DevBuf &b, size_t bytes) {
     return PHZ_OK;
 }
 
+// ---- PhzMail (phz_internal.h): gather kernel + one copy to page-locked memory
+namespace {
+struct MailArgs { const void *src[PhzMail::MAX]; uint32_t bytes[PhzMail::MAX], off[PhzMail::MAX]; };
+__global__ __launch_bounds__(64) void k_mail(MailArgs a, char *dst) {
+    const int e = blockIdx.x;
+    const char *s = (const char *)a.src[e];
+    for (uint32_t i = threadIdx.x; i < a.bytes[e]; i += 64) dst[a.off[e] + i] = s[i];
+}
+}  // namespace
+int PhzMail::send() {
+    if (!n) return PHZ_OK;
+    if (int s = phz_reserve(ctx, ctx->mail_dev, total + 64)) return s;
+    if (int s = phz_reserve_host(ctx, ctx->mail_host, total + 64)) return s;
+    MailArgs a;
+    for (int i = 0; i < MAX; i++) { a.src[i] = i < n ? src[i] : nullptr; a.bytes[i] = i < n ? bytes[i] : 0u; a.off[i] = i < n ? off[i] : 0u; }
+    hipLaunchKernelGGL(k_mail, dim3((unsigned)n), dim3(64), 0, ctx->stream, a, (char *)ctx->mail_dev.p);
+    PHZ_HIP(ctx, hipGetLastError());
+    PHZ_HIP(ctx, hipMemcpyAsync(ctx->mail_host.p, ctx->mail_dev.p, total, hipMemcpyDeviceToHost, ctx->stream));
+    return PHZ_OK;
+}
+
 // Adopt results computed elsewhere as the resident tally of this ctx (see phz.h).  Arrays a caller leaves NULL stay unset; the device
 // row stage needs var_count, var_first, var_distinct, var_rank, edge_a / edge_b, edge_linked, edge_stats, rl_start, rl_qid and rl_list.
 extern "C" int phz_tally_import(phz_ctx *ctx, int64_t nv, int n_bams, const phz_tally_sizes *sz, const phz_tally_out *a, const uint32_t *rl_list, int space) {
     PhzEnter phz_guard_(ctx);
     if (!ctx || !sz || !a || nv < 0 || n_bams < 1) return PHZ_E_ARG;
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->tally_gen++;
     auto &T = ctx->tally;
     const size_t NV = (size_t)nv, NE = (size_t)sz->n_edges, NRL = NV * 2 * (size_t)n_bams, NR = (size_t)sz->n_read_list;
     if (ctx->import_buf.size() < 16) ctx->import_buf.resize(16);

@@ -34,6 +34,7 @@ struct phz_ctx {
     DevBuf bam_comp, bam_stream, bam_work;       // the device BAM path's big buffers (compressed members, inflated stream, kept-record list) kept between BAMs: a fresh hipMalloc of ~19 GB
                                        // took 1.1-1.5 s every few calls (profiles/r05/cli_4bam_full.txt); given back to the runtime when an allocation fails
                                        // and by phz_ctx_destroy; PHZ_BAM_KEEP_BUFFERS=0 turns the cache off
+    DevBuf mail_dev, mail_host;        // PhzMail: gathered small read-backs (device block, page-locked host image)
     DevBuf shard_tab, h_shard_tab;     // shard table of a batched stage (device / pinned host image)
     DevBuf map_tab;                    // K_map's own device copy of its shard table (shard_tab is shared with the tally / BAM stages)
     std::vector<char> map_tab_image; void *map_tab_dev = nullptr;      // the image last uploaded to map_tab (a repeated submission skips the copy)
@@ -51,6 +52,7 @@ struct phz_ctx {
     bool tally_dirty = false, tally_table_dirty = true;     // per-QNAME counters / variant-pair table not known to be clean
     // single-pass scan (phz_sort.h): ticket counter + one status word per tile, valid for the current epoch only (never cleared between scans)
     DevBuf scan_state; uint32_t scan_epoch = 0, scan_ticket_base = 0;
+    uint64_t tally_gen = 0;            // bumped by every phz_tally / phz_tally_import: stamps what later stages prepared for "the resident tally"
     uint64_t tally_table_cap = 0;      // slots of the variant-pair table that the last phz_tally needed
     DevBuf tally_qcount;               // lines per QNAME: all zero between phz_tally calls (never shared with other stages)
     // results of the last phz_tally, resident in HBM until the next one (phz_tally_fetch / phz_components read them)
@@ -67,6 +69,26 @@ struct phz_ctx {
     int map_slot_cap = 0;      // calls per tile slot of K_map's staging area
     int64_t map_ovf_cap = 0;   // calls the overflow area behind the slots holds (grown to what the densest submission needed)
     long long map_ovf_image[5] = {0, 0, 0, 0, 0};      // the overflow-area record last uploaded (+ where): a repeated submission skips the copy
+};
+
+// Small values a stage reads back before it can go on (counts, sizes, flags: a few words each, scattered over device buffers) travel as ONE block:
+// a tiny kernel gathers them into ctx->mail_dev and one asynchronous copy brings the block to PAGE-LOCKED host memory.  (A hipMemcpyAsync to a pageable
+// destination -- a stack variable, a std::vector -- is not asynchronous at all: the call waits for the stream and stages the bytes, 20-30 us each; a stage
+// that read ten values back paid that ten times over, measured as 150-250 us of idle GPU per host wait in the phasing pass.)
+struct PhzMail {
+    static constexpr int MAX = 16;
+    phz_ctx *ctx;
+    const void *src[MAX]; uint32_t bytes[MAX], off[MAX];
+    int n = 0; uint32_t total = 0;
+    explicit PhzMail(phz_ctx *c) : ctx(c) {}
+    int add(const void *dev, size_t nbytes) {          // -> slot; the value is at<T>(slot) after send() + a host wait on the ctx stream
+        if (n >= MAX) return -1;
+        src[n] = dev; bytes[n] = (uint32_t)nbytes; off[n] = total;
+        total += ((uint32_t)nbytes + 7u) & ~7u;
+        return n++;
+    }
+    int send();
+    template <class T> const T *at(int slot) const { return (const T *)((const char *)ctx->mail_host.p + off[slot]); }
 };
 
 struct PhzEnter {

@@ -14,6 +14,7 @@
 // arrays and the string pools and writes ~1 GB of text per genome.
 #include <string.h>
 
+#include <chrono>
 #include <algorithm>
 #include <new>
 #include <string>
@@ -27,7 +28,7 @@
 
 namespace {
 
-constexpr int PS_SLOTS = 1 << 16;              // default size of the hash set of the distinct (total, supporting) arguments of the binomial test (phz_rowsdev::ps_slots)
+constexpr int PS_SLOTS = 1 << 14;              // default size of the hash set of the distinct (total, supporting) arguments of the binomial test (phz_rowsdev::ps_slots)
 constexpr unsigned long long PS_EMPTY = ~0ull;
 #ifndef PHZ_STAT_N
 #define PHZ_STAT_N 512          // the emulation tests also build a variant with a tiny value: every block then takes the paths of a block beyond the table
@@ -969,7 +970,7 @@ __device__ __forceinline__ char flipc(char c) { return c == '-' ? '-' : (c == '0
 
 // One wave per component.  Lane-parallel: loading the pairs, the flood fills, the 2^(n-1) brute force; everything sequential in the
 // reference (weak-point selection, stitching) runs on lane 0 between wave barriers.
-__global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
+__device__ void phase_general_one(const PH &P, const uint32_t c) {
     __shared__ uint8_t s_i[PH_EMAX], s_j[PH_EMAX];
     __shared__ int8_t s_k[PH_EMAX];
     __shared__ uint32_t s_m[2][32];                                        // pairs of the fragment under brute force as bit masks by index distance
@@ -985,8 +986,6 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
     __shared__ uint8_t s_dc[2][1 << PH_DP_MAXD];
     __shared__ uint32_t s_ch[PH_BRUTE_MAX][(1 << PH_DP_MAXD) / 32];         // and the predecessor taken, one bit per (step, state)
     const int lane = threadIdx.x;
-    const uint32_t c = P.complex_list[blockIdx.x];
-    (void)nlist;
     const uint32_t m0 = P.cstart[c], e0 = P.estart[c];
     const int n = (int)(P.cstart[c + 1] - m0), E = (int)(P.estart[c + 1] - e0);
     if (n > PH_NMAX || E > PH_EMAX) {
@@ -1393,6 +1392,25 @@ __global__ __launch_bounds__(64) void k_phase_general(PH P, uint32_t nlist) {
     }
     (void)tk1; (void)tk2; (void)tk3;
 }
+// One wave per component of the list k_phase_pair left (counters[0] of them), taken in ticket order by a fixed number of waves: the host launches this
+// kernel right behind k_phase_pair without reading the count back (PH_TICKET: counters word of the ticket)
+constexpr int PH_TICKET = 16;
+__global__ __launch_bounds__(64) void k_phase_general(PH P) {
+    // (tickets in batches: same-address atomics are served one after the other, ~8 ns each -- one per component was the length of the launch)
+    constexpr uint32_t BATCH = 4;
+    __shared__ uint32_t s_t;
+    const uint32_t n = P.counters[0];
+    for (;;) {
+        if (threadIdx.x == 0) s_t = atomicAdd(&P.counters[PH_TICKET], BATCH);
+        __syncthreads();
+        const uint32_t t0 = s_t;
+        if (t0 >= n) return;
+        for (uint32_t t = t0; t < t0 + BATCH && t < n; t++) {
+            phase_general_one(P, P.complex_list[t]);
+            __syncthreads();
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------- blocks
 // blocks of the components in block order (rule 4): component r of the order owns blocks [blk_base[r], blk_base[r + 1])
@@ -1531,6 +1549,8 @@ struct SG {
     uint32_t *labels, *ns;
     uint32_t *big_list, *big_list2; uint32_t *counters;         // [0] segments left to the wave kernel, [1] pool slots used, [2] pool overflow, [3] segments left to the workgroup kernel
     uint32_t *huge_list, *huge_count;                             // segments of more than STAT_N pieces (a block of more than STAT_N variants): k_seg_big<.., HUGE>, piece arrays in the pool
+    uint32_t *tickets;                                            // [3] next list entry of the mid / large / huge kernel
+    uint32_t *overflow;                                           // pool overflow seen by ANY mode of this attempt
     uint32_t *pool; uint32_t pool_cap;
     const uint32_t *lab_e; int64_t nmem;        // read list of (haplotype, BAM, block member): one load instead of mem_s -> v_alle -> index arithmetic
 };
@@ -1631,13 +1651,12 @@ __device__ __forceinline__ uint32_t seg_hash(uint32_t q) { q ^= q >> 16; q *= 0x
 #ifndef PHZ_SEG_THREADS
 #define PHZ_SEG_THREADS 512
 #endif
-template <int MODE, int SLOTS, int THREADS, bool HUGE = false> __global__ __launch_bounds__(THREADS) void k_seg_big(SG G) {
+template <int MODE, int SLOTS, int THREADS, bool HUGE> __device__ void seg_big_one(const SG &G, const int64_t seg) {
     __shared__ uint32_t s_tab[3 * SLOTS];
     __shared__ uint32_t s_pref_l[HUGE ? 2 : STAT_N + 2], s_lo_l[HUGE ? 2 : STAT_N + 2];
     __shared__ uint32_t s_w[THREADS / 64 > 4 ? THREADS / 64 : 4];
     __shared__ uint32_t s_carry, s_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t seg = HUGE ? G.huge_list[blockIdx.x] : (THREADS == 64 ? G.big_list[blockIdx.x] : G.big_list2[blockIdx.x]);
     const uint32_t np = seg_pieces<MODE>(G, seg);
     uint32_t *s_pref = s_pref_l, *s_lo = s_lo_l;
     if (HUGE) {          // piece starts and their prefix live in a slice of the global pool (same overflow protocol as the tables: grow and redo)
@@ -1645,7 +1664,7 @@ template <int MODE, int SLOTS, int THREADS, bool HUGE = false> __global__ __laun
             const uint32_t need = 2u * (np + 2u);
             const uint32_t off = atomicAdd(&G.counters[1], need);
             s_off = off;
-            if ((unsigned long long)off + need > (unsigned long long)G.pool_cap) { atomicOr(&G.counters[2], 1u); s_off = NONE32; }
+            if ((unsigned long long)off + need > (unsigned long long)G.pool_cap) { atomicOr(&G.counters[2], 1u); atomicOr(G.overflow, 1u); s_off = NONE32; }
         }
         __syncthreads();
         if (s_off == NONE32) return;
@@ -1681,7 +1700,7 @@ template <int MODE, int SLOTS, int THREADS, bool HUGE = false> __global__ __laun
         if (tid == 0) {
             const uint32_t off = atomicAdd(&G.counters[1], 3 * cap);
             s_off = off;
-            if ((unsigned long long)off + 3ull * cap > (unsigned long long)G.pool_cap) { atomicOr(&G.counters[2], 1u); s_off = NONE32; }
+            if ((unsigned long long)off + 3ull * cap > (unsigned long long)G.pool_cap) { atomicOr(&G.counters[2], 1u); atomicOr(G.overflow, 1u); s_off = NONE32; }
         }
         __syncthreads();
         if (s_off == NONE32) return;
@@ -1731,6 +1750,28 @@ template <int MODE, int SLOTS, int THREADS, bool HUGE = false> __global__ __laun
             const uint32_t p = item_pos(idx);
             G.labels[p] = rank[slot_of((uint32_t)G.rl_qid[p])];
         }
+}
+// The segments of a list (mid: one wave each, large / huge: one workgroup each) taken in ticket order by a fixed number of workgroups; the list's length is
+// read on the device (k_seg_small counted it in the launch before), so the host enqueues the three kernels without a wait in between.
+// counters: [0] mid, [3] large, *huge_count; tickets: G.tickets[0..2]
+template <int MODE, int SLOTS, int THREADS, bool HUGE = false> __global__ __launch_bounds__(THREADS) void k_seg_big(SG G) {
+    __shared__ uint32_t s_t;
+    const uint32_t n = HUGE ? *G.huge_count : (THREADS == 64 ? G.counters[0] : G.counters[3]);
+    uint32_t *ticket = G.tickets + (HUGE ? 2 : (THREADS == 64 ? 0 : 1));
+    const uint32_t *list = HUGE ? G.huge_list : (THREADS == 64 ? G.big_list : G.big_list2);
+    // (tickets in batches: a genome has 80,000 wave-sized segments, and same-address atomics are served one after the other at ~8 ns each)
+    constexpr uint32_t BATCH = HUGE ? 1 : (THREADS == 64 ? 16 : 2);
+    for (;;) {
+        __syncthreads();                                          // (s_t of the previous round has been read; the previous segment's LDS is dead)
+        if (threadIdx.x == 0) s_t = atomicAdd(ticket, BATCH);
+        __syncthreads();
+        const uint32_t t0 = s_t;
+        if (t0 >= n) return;
+        for (uint32_t t = t0; t < t0 + BATCH && t < n; t++) {
+            seg_big_one<MODE, SLOTS, THREADS, HUGE>(G, (int64_t)list[t]);
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- small helpers of the orchestration
@@ -1812,7 +1853,8 @@ struct phz_rowsdev {
     DevBuf d_chrom_v0, d_vchrom, d_pos, d_maf, d_isref, d_phase, d_black;
     DevBuf p_off[6], p_txt[6];          // pools: 0 uid, 1 rsid, 2 allele, 3 maf text, 4 chromosome names, 5 gwStat table
     // per pass
-    DevBuf hkeys, flags, slot_pv, pv_off, pv_txt, bam_off, bam_txt, bam_excl, sh_lo, sh_hi, sh_bam;
+    DevBuf hkeys, flags, up_dev;        // up_dev: the per-pass uploads (p-values and their text by slot, BAM names, shard line ranges) as pieces of one block
+    DevBuf up_host;                      // ... and its page-locked host image
     DevBuf keep, e_slot, deg, parent, label, f_a, f_b, f_c, f_d, mem_pos, cid, kpos, keypos;
     DevBuf k64a, k64b, k32a, k32b, v32a, v32b, sort_cnt, scan_tmp;
     DevBuf ridx, va, vb, eorder, mem_s, cstart, corder, ekeep, estart, key_g;
@@ -1829,11 +1871,11 @@ struct phz_rowsdev {
     std::vector<int32_t> chrom_first_bam;          // first BAM in which the chromosome has a kept call line (-1: none): its place in the block order (phaser.py:558-581, :1299)
     int64_t n_blocks = 0, n_blk_vars = 0;
     bool keys_ready = false, have_vcf = false;
+    uint64_t pre_gen = 0;               // ... of WHICH resident tally (phz_ctx::tally_gen): another tally between the two stages discards them
     bool pre_done = false; unsigned long long pre_max_gap = 0;      // the p-value-independent ordering sorts were enqueued by phz_rowsdev_pair_keys (for the resident tally)
     int64_t ps_slots = PS_SLOTS;        // slots of the pair-key hash set (a power of two; grown by the host when a pass reports PHZ_E_CAPACITY)
     std::vector<DevBuf *> all() {
-        std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &slot_pv, &pv_off, &pv_txt, &bam_off, &bam_txt,
-                                   &bam_excl, &sh_lo, &sh_hi, &sh_bam, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
+        std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &up_dev, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
                                    &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &cfg_pl, &cfg_pb, &cfg_ps, &cfg_bytes, &cfg_bbase, &blk_voff, &mrec, &lab_e, &lab_skip, &big_blk, &labels,
@@ -1856,16 +1898,26 @@ template <class T> T *P(DevBuf &b) { return (T *)b.p; }
 // GPU time of the stage = sum over the sync-free sections between two host waits (the host work in between -- scipy, exceptions -- is not GPU time)
 struct Sections {
     phz_ctx *c; double ms = 0; bool open = false;
+    // PHZ_ROWS_TRACE=1: per host wait, how long the host spent enqueueing since the previous wait, how long it then blocked, and the GPU time of the section
+    bool trace = getenv("PHZ_ROWS_TRACE") != nullptr; int nwait = 0;
+    std::chrono::steady_clock::time_point t_prev = std::chrono::steady_clock::now();
     explicit Sections(phz_ctx *ctx) : c(ctx) {}
     void begin() { if (!open) { (void)hipEventRecord(c->ev0, c->stream); open = true; } }
-    int wait() {                        // host wait: closes the section
+    int wait(const char *what = "") {   // host wait: closes the section
         begin();
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipEventRecord(c->ev1, c->stream);
         if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
         float x = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&x, c->ev0, c->ev1);
         if (e != hipSuccess) return phz_fail(c, PHZ_E_HIP, "device row stage", e);
         ms += x; open = false;
+        if (trace) {
+            const auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[rows trace] wait %2d %-28s host enqueue %7.1f us, blocked %7.1f us, GPU section %7.1f us\n", nwait++, what,
+                    std::chrono::duration<double, std::micro>(t0 - t_prev).count(), std::chrono::duration<double, std::micro>(t1 - t0).count(), (double)x * 1e3);
+            t_prev = t1;
+        }
         return PHZ_OK;
     }
 };
@@ -1887,81 +1939,73 @@ int sort_into(phz_ctx *ctx, phz_rowsdev *h, DevBuf &ka, DevBuf &kb, int64_t n, c
 
 // phase_v3 over all components: the two-variant fast path, the general kernel, the host for what exceeds the kernel's limits.
 // cstart / estart: CSR of members (mem_s: variant ids, ascending inside a component) and kept pairs (ekeep: pair ids into ea / eb / cfgv).
-int phase_all(phz_ctx *ctx, Sections &sec, DevBuf &cstart, DevBuf &mem_s, DevBuf &estart, DevBuf &ekeep, const int32_t *ea, const int32_t *eb, const int32_t *cfgv,
-              int64_t ncomp, int64_t nmem, int64_t nkeep, int64_t ne, int max_block_size, DevBuf &alle_of, DevBuf &sub_of, DevBuf &nsub, DevBuf &complex_list,
-              DevBuf &exc_list, DevBuf &eloc, uint32_t *cnt32, int64_t *n_complex, int64_t *n_exc) {
+// phase_enqueue puts both kernels on the stream WITHOUT a host wait (k_phase_general takes its components in ticket order and reads their number on the
+// device); the caller reads cnt32[0..2] (complex components, exceptions, "cannot be split" flag) with its next wait and hands them to phase_exceptions.
+constexpr unsigned PH_GRID = 4096;     // waves of k_phase_general (a genome has ~20,000 complex components; each wave takes the next one until the list is empty)
+int phase_enqueue(phz_ctx *ctx, DevBuf &cstart, DevBuf &mem_s, DevBuf &estart, DevBuf &ekeep, const int32_t *ea, const int32_t *eb, const int32_t *cfgv,
+                  int64_t ncomp, int64_t nmem, int64_t nkeep, int max_block_size, DevBuf &alle_of, DevBuf &sub_of, DevBuf &nsub, DevBuf &complex_list,
+                  DevBuf &exc_list, DevBuf &eloc, uint32_t *cnt32) {
     hipStream_t sm = ctx->stream;
-    *n_complex = 0; *n_exc = 0;
     if (int s = phz_reserve(ctx, alle_of, (size_t)(nmem + 1))) return s;
     if (int s = phz_reserve(ctx, sub_of, (size_t)(nmem + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, nsub, (size_t)(ncomp + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, complex_list, (size_t)(ncomp + 1) * 4)) return s;
     if (int s = phz_reserve(ctx, exc_list, (size_t)(2 * ncomp + 2) * 4)) return s;
     if (int s = phz_reserve(ctx, eloc, (size_t)(nkeep + 1) * 4)) return s;
+    PHZ_HIP(ctx, hipMemsetAsync(cnt32, 0, 32, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(cnt32 + PH_TICKET, 0, 4, sm));
     if (!ncomp) return PHZ_OK;
     PH ph; ph.cstart = P<uint32_t>(cstart); ph.mem_s = P<uint32_t>(mem_s); ph.estart = P<uint32_t>(estart); ph.ekeep = P<uint32_t>(ekeep);
     ph.ea = ea; ph.eb = eb; ph.cfgv = cfgv; ph.alle_of = P<uint8_t>(alle_of); ph.sub_of = P<int32_t>(sub_of); ph.nsub = P<uint32_t>(nsub);
     ph.complex_list = P<uint32_t>(complex_list); ph.exc_list = P<uint32_t>(exc_list); ph.counters = cnt32; ph.max_block_size = max_block_size;
     ph.eloc = P<uint32_t>(eloc);
-    uint32_t h_c32[4] = {0, 0, 0, 0};
-    PHZ_HIP(ctx, hipMemsetAsync(cnt32, 0, 32, sm));
     if (nkeep) hipLaunchKernelGGL(k_edge_local, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, ncomp, ph, P<uint32_t>(eloc));
     hipLaunchKernelGGL(k_phase_pair, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, ph);
-    PHZ_HIP(ctx, hipMemcpyAsync(h_c32, cnt32, 4, hipMemcpyDeviceToHost, sm));
-    if (int s = sec.wait()) return s;
-    sec.begin();
-    if (h_c32[0]) hipLaunchKernelGGL(k_phase_general, dim3(h_c32[0]), dim3(64), 0, sm, ph, h_c32[0]);
+    hipLaunchKernelGGL(k_phase_general, dim3((unsigned)std::min<int64_t>(ncomp, (int64_t)PH_GRID)), dim3(64), 0, sm, ph);
     PHZ_HIP(ctx, hipGetLastError());
-    PHZ_HIP(ctx, hipMemcpyAsync(h_c32, cnt32, 12, hipMemcpyDeviceToHost, sm));
-#ifdef PHZ_PHASE_PROFILE
-    uint32_t dbg[16] = {0}; PHZ_HIP(ctx, hipMemcpyAsync(dbg, cnt32, 64, hipMemcpyDeviceToHost, sm));
-#endif
-    if (int s = sec.wait()) return s;
-#ifdef PHZ_PHASE_PROFILE
-    fprintf(stderr, "phase profile: slowest component total %u ticks: flood %u split %u fragments %u stitch+out %u; n %u E %u nf %u\n", dbg[4], dbg[5], dbg[6], dbg[7], dbg[9], dbg[10], dbg[11], dbg[12]);
-#endif
+    return PHZ_OK;
+}
+// components beyond the kernel's limits (more than PH_NMAX variants / PH_EMAX pairs / a brute-force fragment of more than PH_BRUTE_MAX variants):
+// phase_v3 on the host (the same routine the host row stage runs), results written back.  h_c32 = cnt32[0..2] as read by the caller AFTER the kernels.
+int phase_exceptions(phz_ctx *ctx, const uint32_t *h_c32, DevBuf &cstart, DevBuf &mem_s, DevBuf &estart, DevBuf &ekeep, const int32_t *ea, const int32_t *eb, const int32_t *cfgv,
+                     int64_t ncomp, int64_t nmem, int64_t nkeep, int64_t ne, int max_block_size, DevBuf &alle_of, DevBuf &sub_of, DevBuf &nsub, DevBuf &exc_list) {
     if (h_c32[2]) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "a haplotype block cannot be split to --max_block_size (the reference does not terminate on it)");
-    *n_complex = h_c32[0]; *n_exc = h_c32[1];
-    if (h_c32[1]) {
-        // components beyond the kernel's limits (more than PH_NMAX variants / PH_EMAX pairs / a brute-force fragment of more than
-        // PH_BRUTE_MAX variants): phase_v3 on the host (the same routine the host row stage runs), results written back
-        std::vector<uint32_t> exc(h_c32[1]), cs((size_t)ncomp + 1), es((size_t)ncomp + 1), mem((size_t)nmem), ek((size_t)nkeep);
-        std::vector<int32_t> hea((size_t)ne), heb((size_t)ne), hcf((size_t)ne);
-        PHZ_HIP(ctx, hipMemcpy(exc.data(), exc_list.p, exc.size() * 4, hipMemcpyDeviceToHost));
-        PHZ_HIP(ctx, hipMemcpy(cs.data(), cstart.p, cs.size() * 4, hipMemcpyDeviceToHost));
-        PHZ_HIP(ctx, hipMemcpy(es.data(), estart.p, es.size() * 4, hipMemcpyDeviceToHost));
-        PHZ_HIP(ctx, hipMemcpy(mem.data(), mem_s.p, mem.size() * 4, hipMemcpyDeviceToHost));
-        PHZ_HIP(ctx, hipMemcpy(ek.data(), ekeep.p, ek.size() * 4, hipMemcpyDeviceToHost));
-        PHZ_HIP(ctx, hipMemcpy(hea.data(), ea, hea.size() * 4, hipMemcpyDeviceToHost));
-        PHZ_HIP(ctx, hipMemcpy(heb.data(), eb, heb.size() * 4, hipMemcpyDeviceToHost));
-        PHZ_HIP(ctx, hipMemcpy(hcf.data(), cfgv, hcf.size() * 4, hipMemcpyDeviceToHost));
-        std::sort(exc.begin(), exc.end());
-        exc.erase(std::unique(exc.begin(), exc.end()), exc.end());
-        for (uint32_t c : exc) {
-            const uint32_t m0 = cs[c], n = cs[c + 1] - m0, e0 = es[c], E = es[c + 1] - e0;
-            std::vector<int32_t> ei(E), ej(E), sf(n + 1), sl(n + 1); std::vector<int8_t> ec(E); std::vector<char> cfg((size_t)n + 1);
-            for (uint32_t t = 0; t < E; t++) {
-                const uint32_t e = ek[e0 + t];
-                ei[t] = (int32_t)(std::lower_bound(mem.begin() + m0, mem.begin() + m0 + n, (uint32_t)hea[e]) - (mem.begin() + m0));
-                ej[t] = (int32_t)(std::lower_bound(mem.begin() + m0, mem.begin() + m0 + n, (uint32_t)heb[e]) - (mem.begin() + m0));
-                ec[t] = (int8_t)hcf[e];
-            }
-            int32_t nsubs = 0;
-            const int st = phz_phase_block((int32_t)n, (int64_t)E, ei.data(), ej.data(), ec.data(), max_block_size, sf.data(), sl.data(), cfg.data(), &nsubs);
-            if (st != PHZ_OK) return phz_fail(ctx, st, "block phasing of a large component on the host");
-            std::vector<int32_t> so(n, -1); std::vector<uint8_t> ao(n, 0);
-            uint32_t ns = 0; size_t w = 0;
-            for (int32_t k = 0; k < nsubs; k++) {
-                if (sl[k] <= 0) continue;
-                for (int32_t t = 0; t < sl[k]; t++) { so[(size_t)sf[k] + t] = (int32_t)ns; ao[(size_t)sf[k] + t] = (uint8_t)(cfg[w++] == '1'); }
-                ns++;
-            }
-            PHZ_HIP(ctx, hipMemcpy(P<int32_t>(sub_of) + m0, so.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-            PHZ_HIP(ctx, hipMemcpy(P<uint8_t>(alle_of) + m0, ao.data(), (size_t)n, hipMemcpyHostToDevice));
-            PHZ_HIP(ctx, hipMemcpy(P<uint32_t>(nsub) + c, &ns, 4, hipMemcpyHostToDevice));
+    if (!h_c32[1]) return PHZ_OK;
+    std::vector<uint32_t> exc(h_c32[1]), cs((size_t)ncomp + 1), es((size_t)ncomp + 1), mem((size_t)nmem), ek((size_t)nkeep);
+    std::vector<int32_t> hea((size_t)ne), heb((size_t)ne), hcf((size_t)ne);
+    PHZ_HIP(ctx, hipMemcpy(exc.data(), exc_list.p, exc.size() * 4, hipMemcpyDeviceToHost));
+    PHZ_HIP(ctx, hipMemcpy(cs.data(), cstart.p, cs.size() * 4, hipMemcpyDeviceToHost));
+    PHZ_HIP(ctx, hipMemcpy(es.data(), estart.p, es.size() * 4, hipMemcpyDeviceToHost));
+    PHZ_HIP(ctx, hipMemcpy(mem.data(), mem_s.p, mem.size() * 4, hipMemcpyDeviceToHost));
+    PHZ_HIP(ctx, hipMemcpy(ek.data(), ekeep.p, ek.size() * 4, hipMemcpyDeviceToHost));
+    PHZ_HIP(ctx, hipMemcpy(hea.data(), ea, hea.size() * 4, hipMemcpyDeviceToHost));
+    PHZ_HIP(ctx, hipMemcpy(heb.data(), eb, heb.size() * 4, hipMemcpyDeviceToHost));
+    PHZ_HIP(ctx, hipMemcpy(hcf.data(), cfgv, hcf.size() * 4, hipMemcpyDeviceToHost));
+    std::sort(exc.begin(), exc.end());
+    exc.erase(std::unique(exc.begin(), exc.end()), exc.end());
+    for (uint32_t c : exc) {
+        const uint32_t m0 = cs[c], n = cs[c + 1] - m0, e0 = es[c], E = es[c + 1] - e0;
+        std::vector<int32_t> ei(E), ej(E), sf(n + 1), sl(n + 1); std::vector<int8_t> ec(E); std::vector<char> cfg((size_t)n + 1);
+        for (uint32_t t = 0; t < E; t++) {
+            const uint32_t e = ek[e0 + t];
+            ei[t] = (int32_t)(std::lower_bound(mem.begin() + m0, mem.begin() + m0 + n, (uint32_t)hea[e]) - (mem.begin() + m0));
+            ej[t] = (int32_t)(std::lower_bound(mem.begin() + m0, mem.begin() + m0 + n, (uint32_t)heb[e]) - (mem.begin() + m0));
+            ec[t] = (int8_t)hcf[e];
         }
+        int32_t nsubs = 0;
+        const int st = phz_phase_block((int32_t)n, (int64_t)E, ei.data(), ej.data(), ec.data(), max_block_size, sf.data(), sl.data(), cfg.data(), &nsubs);
+        if (st != PHZ_OK) return phz_fail(ctx, st, "block phasing of a large component on the host");
+        std::vector<int32_t> so(n, -1); std::vector<uint8_t> ao(n, 0);
+        uint32_t ns = 0; size_t w = 0;
+        for (int32_t k = 0; k < nsubs; k++) {
+            if (sl[k] <= 0) continue;
+            for (int32_t t = 0; t < sl[k]; t++) { so[(size_t)sf[k] + t] = (int32_t)ns; ao[(size_t)sf[k] + t] = (uint8_t)(cfg[w++] == '1'); }
+            ns++;
+        }
+        PHZ_HIP(ctx, hipMemcpy(P<int32_t>(sub_of) + m0, so.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        PHZ_HIP(ctx, hipMemcpy(P<uint8_t>(alle_of) + m0, ao.data(), (size_t)n, hipMemcpyHostToDevice));
+        PHZ_HIP(ctx, hipMemcpy(P<uint32_t>(nsub) + c, &ns, 4, hipMemcpyHostToDevice));
     }
-    sec.begin();
     return PHZ_OK;
 }
 
@@ -2055,11 +2099,12 @@ extern "C" int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *t, phz
 extern "C" void phz_rowsdev_destroy(phz_rowsdev *h) {
     if (!h) return;
     for (DevBuf *b : h->all()) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (h->up_host.p) (void)hipHostFree(h->up_host.p);
     delete h;
 }
 
 // Stage 1: the distinct (total, supporting) argument pairs of the binomial test over the tested pairs of the last phz_tally.  keys_host
-// [PHZ_PAIR_SLOTS] receives the hash set as it lives on the device: slot s holds (total << 32 | supporting) or all ones when empty.  The caller
+// [phz_rowsdev_pair_slots(h)] receives the hash set as it lives on the device: slot s holds (total << 32 | supporting) or all ones when empty.  The caller
 // evaluates the p-value of every occupied slot (the reference's scipy call) and passes values and their text to phz_rowsdev_run by slot.
 // Size of the pair-key hash set (a power of two in [16, 2^28]; anything below the default 2^16 is for tests); keys_host / slot_pv / slot_txt_off of the two stages are sized by it.
 extern "C" int phz_rowsdev_set_pair_slots(phz_rowsdev *h, int64_t n_slots) {
@@ -2100,17 +2145,22 @@ extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *key
         hipLaunchKernelGGL(k_flag_keys, dim3(std::min(nblk(nv), 512u)), dim3(256), 0, sm, nv, (const long long *)T.var_first, P<uint32_t>(h->f_d), (const unsigned long long *)T.var_rank,
                            P<unsigned long long>(h->cnt64) + 2);
         if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_d), P<uint32_t>(h->keypos), nv, h->scan_tmp)) return s;
-        PHZ_HIP(ctx, hipMemcpyAsync(&h_gap, P<unsigned long long>(h->cnt64) + 2, 8, hipMemcpyDeviceToHost, sm));
     }
     uint32_t fl = 0;
-    PHZ_HIP(ctx, hipMemcpyAsync(&fl, h->flags.p, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, slots * 8, hipMemcpyDeviceToHost, sm));          // (512 KB: copied before the verdict on the table is known -- one wait instead of two)
-    PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    {
+        PhzMail mail(ctx);
+        const int m_gap = pre ? mail.add(P<unsigned long long>(h->cnt64) + 2, 8) : -1, m_fl = mail.add(h->flags.p, 4);
+        if (int s = mail.send()) return s;
+        PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, slots * 8, hipMemcpyDeviceToHost, sm));          // (copied before the verdict on the table is known -- one wait instead of two;
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));                                                             //  the caller hands over page-locked memory)
+        if (pre) h_gap = *mail.at<unsigned long long>(m_gap);
+        fl = *mail.at<uint32_t>(m_fl);
+    }
     if (fl & 1u) return phz_fail(ctx, PHZ_E_CAPACITY, "the distinct (supporting, total) read-count pairs do not fit the pair-key table: grow it (phz_rowsdev_set_pair_slots) and call again");
     if (pre) {
         // ... and the ordering sorts that need no p-value are on the stream before this call returns: they run while the caller evaluates scipy on the keys
         if (int s = order_variants_and_pairs(ctx, h, h_gap)) return s;
-        h->pre_done = true; h->pre_max_gap = h_gap;
+        h->pre_done = true; h->pre_max_gap = h_gap; h->pre_gen = ctx->tally_gen;
     }
     h->keys_ready = true;
     return PHZ_OK;
@@ -2124,6 +2174,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     auto &T = ctx->tally;
     if (!h->keys_ready) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run without phz_rowsdev_pair_keys");
     h->keys_ready = false;
+    if (h->pre_done && h->pre_gen != ctx->tally_gen) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run: the resident tally changed since phz_rowsdev_pair_keys (call it again)");
     if (T.nv != h->nv || T.nb != o->n_bams) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not match (variants / BAMs)");
     if (o->gw_phase_method != 0 && o->gw_phase_method != 1) return phz_fail(ctx, PHZ_E_ARG, "device row stage: gw_phase_method must be 0 or 1");
     if (o->output_read_ids) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: --output_read_ids 1 is formatted by the host stage");
@@ -2139,19 +2190,25 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     sec.begin();
     // ---- per-pass uploads
     const size_t ps_slots = (size_t)h->ps_slots;
-    if (int s = up(ctx, h->slot_pv, slot_pv, ps_slots * 8)) return s;
-    if (int s = up(ctx, h->pv_off, slot_txt_off, (ps_slots + 1) * 4)) return s;
-    if (int s = up(ctx, h->pv_txt, slot_txt, (size_t)slot_txt_off[ps_slots])) return s;
-    if (int s = up(ctx, h->bam_off, o->bam_name_off, (size_t)(nb + 1) * 4)) return s;
-    if (int s = up(ctx, h->bam_txt, o->bam_names, (size_t)o->bam_name_off[nb])) return s;
-    if (o->bam_excluded) { if (int s = up(ctx, h->bam_excl, o->bam_excluded, (size_t)nb)) return s; }
-    if (int s = up(ctx, h->sh_lo, o->shard_line_lo, (size_t)o->n_shards * 8)) return s;
-    if (int s = up(ctx, h->sh_hi, o->shard_line_hi, (size_t)o->n_shards * 8)) return s;
-    if (int s = up(ctx, h->sh_bam, o->shard_bam, (size_t)o->n_shards * 4)) return s;
+    // ONE copy for all of them: gathered in a page-locked block (a hipMemcpyAsync from the caller's pageable arrays is staged synchronously, 10-20 us each
+    // -- nine of them were a third of this stage's first section, which is bound by what the host can enqueue), 256-byte aligned pieces of one device block
+    const void *up_src[9] = {slot_pv, slot_txt_off, slot_txt, o->bam_name_off, o->bam_names, o->bam_excluded, o->shard_line_lo, o->shard_line_hi, o->shard_bam};
+    const size_t up_n[9] = {ps_slots * 8, (ps_slots + 1) * 4, (size_t)slot_txt_off[ps_slots], (size_t)(nb + 1) * 4, (size_t)o->bam_name_off[nb], o->bam_excluded ? (size_t)nb : 0,
+                            (size_t)o->n_shards * 8, (size_t)o->n_shards * 8, (size_t)o->n_shards * 4};
+    size_t up_off[10]; up_off[0] = 0;
+    for (int i = 0; i < 9; i++) up_off[i + 1] = up_off[i] + ((up_n[i] + 255) & ~(size_t)255);
+    if (int s = phz_reserve_host(ctx, h->up_host, up_off[9] + 256)) return s;
+    if (int s = phz_reserve(ctx, h->up_dev, up_off[9] + 256)) return s;
+    for (int i = 0; i < 9; i++) if (up_n[i]) memcpy((char *)h->up_host.p + up_off[i], up_src[i], up_n[i]);
+    PHZ_HIP(ctx, hipMemcpyAsync(h->up_dev.p, h->up_host.p, up_off[9], hipMemcpyHostToDevice, sm));
+    const char *upd = (const char *)h->up_dev.p;
+    const double *d_slot_pv = (const double *)(upd + up_off[0]); const uint32_t *d_pv_off = (const uint32_t *)(upd + up_off[1]); const char *d_pv_txt = upd + up_off[2];
+    const uint32_t *d_bam_off = (const uint32_t *)(upd + up_off[3]); const char *d_bam_txt = upd + up_off[4]; const uint8_t *d_bam_excl = (const uint8_t *)(upd + up_off[5]);
+    const long long *d_sh_lo = (const long long *)(upd + up_off[6]), *d_sh_hi = (const long long *)(upd + up_off[7]); const int32_t *d_sh_bam = (const int32_t *)(upd + up_off[8]);
     // ---- pruning (:686-700) + components
 #define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, h->buf, (bytes))) return s_; } while (0)
     RSV(keep, NE); RSV(e_slot, NE * 4); RSV(deg, NV * 4); RSV(parent, NV * 4); RSV(label, NV * 4);
-    RSV(cnt64, 64); RSV(cnt32, 64);
+    RSV(cnt64, 64); RSV(cnt32, 512);          // cnt32: [0..15] counters of the stages, [16] ticket of k_phase_general, [20] pool overflow of the read-set stage, [32 + 16 m ..] counters and tickets of its mode m
     const size_t n_cc = (size_t)nchrom * 3 + (size_t)nb * nchrom;          // uint32 counters per chromosome, then uint64 cfg rows per chromosome
     RSV(chrom_cnt, n_cc * 4 + 8 + (size_t)nchrom * 8);
     uint32_t *cc_conn = P<uint32_t>(h->chrom_cnt), *cc_blocks = cc_conn + nchrom, *cc_blkvars = cc_blocks + nchrom, *cc_keys = cc_blkvars + nchrom;
@@ -2162,11 +2219,11 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     PHZ_HIP(ctx, hipMemsetAsync(h->seg_start.p, 0xff, (n_cc + 1) * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->deg.p, 0, NV * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->cnt64.p, 0, 64, sm));
-    PHZ_HIP(ctx, hipMemsetAsync(h->cnt32.p, 0, 64, sm));
+    PHZ_HIP(ctx, hipMemsetAsync(h->cnt32.p, 0, 512, sm));
     unsigned long long *cnt64 = P<unsigned long long>(h->cnt64);
     uint32_t *cnt32 = P<uint32_t>(h->cnt32);
     if (ne) hipLaunchKernelGGL(k_keep, dim3(std::min(nblk(ne), 2048u)), dim3(256), 0, sm, ne, (const uint8_t *)T.linked, sup, tot, (const unsigned long long *)h->hkeys.p, (uint32_t)(ps_slots - 1),
-                               (const double *)h->slot_pv.p, o->cc_threshold, P<uint8_t>(h->keep), P<uint32_t>(h->e_slot), P<uint32_t>(h->deg), (const int32_t *)T.ea,
+                               d_slot_pv, o->cc_threshold, P<uint8_t>(h->keep), P<uint32_t>(h->e_slot), P<uint32_t>(h->deg), (const int32_t *)T.ea,
                                (const int32_t *)T.eb, cnt64);
     if (nv) hipLaunchKernelGGL(k_uf_init, dim3(nblk(nv)), dim3(256), 0, sm, P<int32_t>(h->parent), nv);
     if (ne) hipLaunchKernelGGL(k_uf_hook, dim3(nblk(ne)), dim3(256), 0, sm, P<int32_t>(h->parent), (const int32_t *)T.ea, (const int32_t *)T.eb, (const uint8_t *)h->keep.p, ne);
@@ -2183,12 +2240,15 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     if (!h->pre_done) { if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->f_d), P<uint32_t>(h->keypos), nv, h->scan_tmp)) return s; }
     PHZ_HIP(ctx, hipGetLastError());
     uint32_t h_n[4] = {0, 0, 0, 0}; unsigned long long h_c64[8] = {0};
-    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[0], P<uint32_t>(h->mem_pos) + nv, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[1], P<uint32_t>(h->cid) + nv, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[2], P<uint32_t>(h->kpos) + ne, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&h_n[3], P<uint32_t>(h->keypos) + nv, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(h_c64, cnt64, 24, hipMemcpyDeviceToHost, sm));
-    if (int s = sec.wait()) return s;
+    {
+        PhzMail mail(ctx);
+        const int m[5] = {mail.add(P<uint32_t>(h->mem_pos) + nv, 4), mail.add(P<uint32_t>(h->cid) + nv, 4), mail.add(P<uint32_t>(h->kpos) + ne, 4),
+                          mail.add(P<uint32_t>(h->keypos) + nv, 4), mail.add(cnt64, 24)};
+        if (int s = mail.send()) return s;
+        if (int s = sec.wait("sizes: members/comps/kept/keys")) return s;
+        for (int i = 0; i < 4; i++) h_n[i] = *mail.at<uint32_t>(m[i]);
+        memcpy(h_c64, mail.at<char>(m[4]), 24);
+    }
     if (h->pre_done) h_c64[2] = h->pre_max_gap;          // (measured by the first stage; this run's counters were cleared after it)
     const int64_t nmem = h_n[0], ncomp = h_n[1], nkeep = h_n[2], nkeys = h_n[3], n_linked = (int64_t)h_c64[0];
     res->dropped = (int64_t)h_c64[1];
@@ -2229,7 +2289,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, sm, P<uint32_t>(h->estart) + ncomp, (int64_t)1, (uint32_t)nkeep);
     }
     if (nkeys) {
-        ShardTab ST; ST.lo = (const long long *)h->sh_lo.p; ST.hi = (const long long *)h->sh_hi.p; ST.bam = (const int32_t *)h->sh_bam.p; ST.n = o->n_shards;
+        ShardTab ST; ST.lo = d_sh_lo; ST.hi = d_sh_hi; ST.bam = d_sh_bam; ST.n = o->n_shards;
         const int bb = nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0;
         RSV(key64s, (size_t)(nkeys + 1) * 8);
         if (bl < 32 && bb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (BAM, first line) in one 32-bit key; bl == 32 (one BAM of > 2^31 lines) would make the kernels shift a 32-bit word by 32
@@ -2249,13 +2309,10 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         }
     }
     hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_keys, nb * nchrom, (uint32_t)nkeys, cc_keys);
-    // ---- block phasing
-    {
-        int64_t ncx = 0, nex = 0;
-        if (int s = phase_all(ctx, sec, h->cstart, h->mem_s, h->estart, h->ekeep, T.ea, T.eb, cfgv, ncomp, nmem, nkeep, ne, o->max_block_size, h->alle_of, h->sub_of, h->nsub,
-                              h->complex_list, h->exc_list, h->eloc, cnt32, &ncx, &nex)) return s;
-        res->n_complex = ncx; res->n_exceptions = nex;
-    }
+    // ---- block phasing: both kernels behind each other, then -- speculating that no component needs the host (a handful per genome at most) -- the block
+    //      numbering, all before ONE host wait; exceptions are phased on the host and the numbering is redone
+    if (int s = phase_enqueue(ctx, h->cstart, h->mem_s, h->estart, h->ekeep, T.ea, T.eb, cfgv, ncomp, nmem, nkeep, o->max_block_size, h->alle_of, h->sub_of, h->nsub,
+                              h->complex_list, h->exc_list, h->eloc, cnt32)) return s;
     // ---- blocks in block order; per-block statistics
     const size_t NBK = (size_t)(nmem / 2 + 2);
     RSV(nsub_o, (size_t)(ncomp + 1) * 4); RSV(blk_base, (size_t)(ncomp + 2) * 4);
@@ -2270,13 +2327,25 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     unsigned long long h_cfg_total = 0;
     std::vector<uint32_t> h_cc(n_cc, 0u); std::vector<unsigned long long> h_cfgc((size_t)nchrom, 0ull);
     if (ncomp) {
-        hipLaunchKernelGGL(k_gather_nsub, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, (const uint32_t *)h->corder.p, (const uint32_t *)h->nsub.p, P<uint32_t>(h->nsub_o));
-        if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->nsub_o), P<uint32_t>(h->blk_base), ncomp, h->scan_tmp)) return s;
-        uint32_t nb32 = 0;
-        PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(&nb32, P<uint32_t>(h->blk_base) + ncomp, 4, hipMemcpyDeviceToHost, sm));
-        if (int s = sec.wait()) return s;
-        sec.begin();
+        uint32_t nb32 = 0, h_c32[4] = {0, 0, 0, 0};
+        for (int round = 0; round < 2; round++) {
+            hipLaunchKernelGGL(k_gather_nsub, dim3(nblk(ncomp)), dim3(256), 0, sm, ncomp, (const uint32_t *)h->corder.p, (const uint32_t *)h->nsub.p, P<uint32_t>(h->nsub_o));
+            if (int s = gscan_excl<uint32_t, uint32_t>(ctx, P<uint32_t>(h->nsub_o), P<uint32_t>(h->blk_base), ncomp, h->scan_tmp)) return s;
+            PHZ_HIP(ctx, hipGetLastError());
+            {
+                PhzMail mail(ctx);
+                const int m_nb = mail.add(P<uint32_t>(h->blk_base) + ncomp, 4), m_c = mail.add(cnt32, 12);
+                if (int s = mail.send()) return s;
+                if (int s = sec.wait(round ? "blocks: count (after exceptions)" : "phase + blocks: count")) return s;
+                nb32 = *mail.at<uint32_t>(m_nb);
+                if (round == 0) memcpy(h_c32, mail.at<char>(m_c), 12);
+            }
+            sec.begin();
+            if (round == 1 || !(h_c32[1] || h_c32[2])) break;
+            if (int s = phase_exceptions(ctx, h_c32, h->cstart, h->mem_s, h->estart, h->ekeep, T.ea, T.eb, cfgv, ncomp, nmem, nkeep, ne, o->max_block_size, h->alle_of, h->sub_of,
+                                         h->nsub, h->exc_list)) return s;
+        }
+        res->n_complex = h_c32[0]; res->n_exceptions = h_c32[1];
         nblocks = nb32;
         BK bk; bk.corder = P<uint32_t>(h->corder); bk.blk_base = P<uint32_t>(h->blk_base); bk.cstart = P<uint32_t>(h->cstart); bk.mem_s = P<uint32_t>(h->mem_s);
         bk.sub_of = P<int32_t>(h->sub_of); bk.alle_of = P<uint8_t>(h->alle_of); bk.blk_mstart = P<uint32_t>(h->blk_mstart); bk.blk_len = P<uint32_t>(h->blk_len);
@@ -2300,109 +2369,98 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_blocks, nchrom, (uint32_t)nblocks, cc_blocks);
     hipLaunchKernelGGL(k_block_counts, dim3(1), dim3(1), 0, sm, (const uint32_t *)ss_blocks, (const uint32_t *)cc_blocks, nchrom, (const uint32_t *)h->blk_voff.p,
                        (const unsigned long long *)h->cfg_base.p, cc_blkvars, cc_cfg);
-    {
-        uint32_t h_phased = 0, h_nbs = 0;
-        PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(&h_nbs, cnt32 + 13, 4, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(&h_phased, P<uint32_t>(h->blk_voff) + nblocks, 4, hipMemcpyDeviceToHost, sm));
-        if (int s = sec.wait()) return s;
-        sec.begin();
-        res->phased = (int64_t)h_phased;
-        // gwStat text the table does not hold -- blocks with more known phases than it covers (:968-980), and with --gw_phase_method 1 every block phased by MAF weight (:1002) --: repr() of the float64 the device computed
-        if (h_nbs) {
-            std::string xt; std::vector<uint32_t> xo((size_t)h_nbs + 1, 0u); std::vector<double> bsv((size_t)h_nbs);
-            PHZ_HIP(ctx, hipMemcpy(bsv.data(), h->big_stat.p, bsv.size() * 8, hipMemcpyDeviceToHost));
-            xt.reserve((size_t)h_nbs * 20);
-            for (uint32_t i = 0; i < h_nbs; i++) {
-                xo[i] = (uint32_t)xt.size();
-                phztext::put_pyfloat(xt, bsv[i]);
-                xt += '\n';
-            }
-            xo[h_nbs] = (uint32_t)xt.size();
-            if (int s = up(ctx, h->px_off, xo.data(), xo.size() * 4)) return s;
-            if (int s = up(ctx, h->px_txt, xt.data(), xt.size())) return s;
-            PHZ_HIP(ctx, hipStreamSynchronize(sm));            // xo / xt die with this scope
-        }
-    }
-    // ---- read sets of the haplotypes: labels + distinct counts
+    // (phased variants and the blocks whose gwStat text the table does not hold are read with the next wait, below)
+    // ---- read sets of the haplotypes: labels + distinct counts.  No host wait inside: k_seg_small classifies the segments and counts the lists, the wave /
+    //      workgroup kernels take their lists in ticket order and read the counts on the device; the pool-overflow flag is read with the next wait (rare:
+    //      the pool is grown and the stage redone)
     const bool need_all = nb > 1 || h->has_black;
     RSV(labels, NR * 4); RSV(seg_ns, (size_t)(nblocks + 1) * 2 * nb * 4); RSV(big_list, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4); RSV(big_list2, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4);
     if (need_all) RSV(blk_cnt, (size_t)(nblocks + 1) * 2 * 4);
     if (nb > 1) RSV(single_n, NRL * 4);
     if (h->pool.cap == 0) RSV(pool, (size_t)12 << 20);
-    PHZ_HIP(ctx, hipMemsetAsync(h->labels.p, 0, NR * 4, sm));
     RSV(lab_e, (size_t)(nmem + 1) * 2 * nb * 4);
-    if (nmem) hipLaunchKernelGGL(k_lab_e, dim3(nblk(nmem * 2 * nb)), dim3(256), 0, sm, nmem, nb, (const uint32_t *)h->mem_s.p, (const uint8_t *)h->v_alle.p, P<uint32_t>(h->lab_e));
-    SG sg; sg.nb = nb; sg.lab_e = P<uint32_t>(h->lab_e); sg.nmem = nmem; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
-    sg.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.labels = P<uint32_t>(h->labels);
-    sg.big_list = P<uint32_t>(h->big_list); sg.big_list2 = P<uint32_t>(h->big_list2); sg.counters = cnt32 + 4;
     RSV(huge_list, ((size_t)(nmem / (STAT_N + 1) + 2) * 2 * (size_t)nb + 16) * 4);
-    sg.huge_list = P<uint32_t>(h->huge_list); sg.huge_count = cnt32 + 14;
+    RSV(its, (NR + 1) * 4); RSV(piece_dst, NRL * 8);
+    RSV(big_blk, (size_t)(nblocks + 1) * 4);
+    uint32_t h_nbig = 0, h_phased = 0, h_nbs = 0;
     for (int attempt = 0;; attempt++) {
+        PHZ_HIP(ctx, hipMemsetAsync(h->labels.p, 0, NR * 4, sm));
+        if (nmem) hipLaunchKernelGGL(k_lab_e, dim3(nblk(nmem * 2 * nb)), dim3(256), 0, sm, nmem, nb, (const uint32_t *)h->mem_s.p, (const uint8_t *)h->v_alle.p, P<uint32_t>(h->lab_e));
+        SG sg; sg.nb = nb; sg.lab_e = P<uint32_t>(h->lab_e); sg.nmem = nmem; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
+        sg.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.labels = P<uint32_t>(h->labels);
+        sg.big_list = P<uint32_t>(h->big_list); sg.big_list2 = P<uint32_t>(h->big_list2); sg.overflow = cnt32 + 20;
+        sg.huge_list = P<uint32_t>(h->huge_list);
         sg.pool = P<uint32_t>(h->pool); sg.pool_cap = (uint32_t)std::min<size_t>(h->pool.cap / 4, 0xFFFFFFF0u);
-        uint32_t h_seg[4] = {0, 0, 0, 0};
-        bool overflow = false;
-        for (int mode = 0; mode < 3; mode++) {
+        PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 20, 0, 4, sm));
+        PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 32, 0, 3 * 64, sm));          // every mode has its own counters: [0..3] list lengths / pool cursor, [4] huge segments, [5..7] tickets -- nothing is
+        for (int mode = 0; mode < 3; mode++) {                             // overwritten, so all of it is read back at the ONE wait below
             if (mode == 1 && !need_all) continue;
             if (mode == 2 && nb <= 1) continue;
             sg.nseg = mode == 0 ? nblocks * 2 * nb : (mode == 1 ? nblocks * 2 : (int64_t)NRL);
             sg.ns = mode == 0 ? P<uint32_t>(h->seg_ns) : (mode == 1 ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->single_n));
             if (sg.nseg == 0) continue;
-            PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 4, 0, 16, sm));
-            PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 14, 0, 4, sm));
+            uint32_t *mc = cnt32 + 32 + 16 * mode;
+            sg.counters = mc; sg.huge_count = mc + 4; sg.tickets = mc + 5;
             const unsigned g = (unsigned)((sg.nseg + 63) / 64);
-            if (mode == 0) hipLaunchKernelGGL(k_seg_small<0>, dim3(g), dim3(64), 0, sm, sg);
-            else if (mode == 1) hipLaunchKernelGGL(k_seg_small<1>, dim3(g), dim3(64), 0, sm, sg);
-            else hipLaunchKernelGGL(k_seg_small<2>, dim3(g), dim3(64), 0, sm, sg);
-            uint32_t n_huge = 0;
-            PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 16, hipMemcpyDeviceToHost, sm));
-            PHZ_HIP(ctx, hipMemcpyAsync(&n_huge, cnt32 + 14, 4, hipMemcpyDeviceToHost, sm));
-            if (int s = sec.wait()) return s;
-            sec.begin();
-            const uint32_t n_mid = h_seg[0], n_large = h_seg[3];
-            if (n_mid) {
-                if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
-                else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
-                else hipLaunchKernelGGL((k_seg_big<2, 512, 64>), dim3(n_mid), dim3(64), 0, sm, sg);
+            // fixed numbers of workgroups for the list kernels: what a chip holds at once (10 KB / 52 KB of LDS each); a short list leaves most of them with nothing but one ticket
+            const unsigned g_mid = (unsigned)std::min<int64_t>(sg.nseg, 4096), g_large = (unsigned)std::min<int64_t>(sg.nseg, 768), g_huge = (unsigned)std::min<int64_t>(sg.nseg, 64);
+            if (mode == 0) {
+                hipLaunchKernelGGL(k_seg_small<0>, dim3(g), dim3(64), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<0, 512, 64>), dim3(g_mid), dim3(64), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS>), dim3(g_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS, true>), dim3(g_huge), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+            } else if (mode == 1) {
+                hipLaunchKernelGGL(k_seg_small<1>, dim3(g), dim3(64), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<1, 512, 64>), dim3(g_mid), dim3(64), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS>), dim3(g_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS, true>), dim3(g_huge), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+            } else {           // (mode 2 has one piece per segment: never huge)
+                hipLaunchKernelGGL(k_seg_small<2>, dim3(g), dim3(64), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<2, 512, 64>), dim3(g_mid), dim3(64), 0, sm, sg);
+                hipLaunchKernelGGL((k_seg_big<2, 4096, PHZ_SEG_THREADS>), dim3(g_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
             }
-            if (n_large || n_huge) {
-                if (n_large) {
-                    if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
-                    else if (mode == 1) hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
-                    else hipLaunchKernelGGL((k_seg_big<2, 4096, PHZ_SEG_THREADS>), dim3(n_large), dim3(PHZ_SEG_THREADS), 0, sm, sg);
-                }
-                if (n_huge) {        // segments of a block of more than STAT_N variants (mode 2 has one piece per segment: never)
-                    if (mode == 0) hipLaunchKernelGGL((k_seg_big<0, 4096, PHZ_SEG_THREADS, true>), dim3(n_huge), dim3(PHZ_SEG_THREADS), 0, sm, sg);
-                    else hipLaunchKernelGGL((k_seg_big<1, 4096, PHZ_SEG_THREADS, true>), dim3(n_huge), dim3(PHZ_SEG_THREADS), 0, sm, sg);
-                }
-                PHZ_HIP(ctx, hipMemcpyAsync(h_seg, cnt32 + 4, 12, hipMemcpyDeviceToHost, sm));
-                if (int s = sec.wait()) return s;
-                sec.begin();
-                if (h_seg[2]) { overflow = true; break; }
-            }
-            res->n_big_segments += n_mid + n_large + n_huge;
         }
-        if (!overflow) break;
+        // ---- text: byte counts -> scan -> write, file by file.  its = scan of the labels' text widths (digits + one separator), the widths computed as the
+        //      scan loads the labels (no width array)
+        if (int s = gscan_excl<uint32_t, uint32_t, LabelWidth>(ctx, P<uint32_t>(h->labels), P<uint32_t>(h->its), n_rl, h->scan_tmp)) return s;
+        PHZ_HIP(ctx, hipMemsetAsync(h->piece_dst.p, 0xff, NRL * 8, sm));
+        if (attempt) PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 12, 0, 4, sm));
+        if (nblocks) hipLaunchKernelGGL(k_big_blocks, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, (const uint32_t *)h->blk_len.p, P<uint32_t>(h->big_blk), cnt32 + 12);
+        PHZ_HIP(ctx, hipGetLastError());
+        PhzMail mail(ctx);
+        const int m_c = mail.add(cnt32, 512), m_ph = mail.add(P<uint32_t>(h->blk_voff) + nblocks, 4), m_cfg = mail.add(P<unsigned long long>(h->cfg_base) + nblocks, 8),
+                  m_cc = mail.add(h->chrom_cnt.p, n_cc * 4), m_cfgc = mail.add(cc_cfg, (size_t)nchrom * 8);
+        if (int s = mail.send()) return s;
+        if (int s = sec.wait("stats + read sets + text sizes")) return s;
+        sec.begin();
+        const uint32_t *hc = mail.at<uint32_t>(m_c);
+        h_nbig = hc[12]; h_nbs = hc[13]; h_phased = *mail.at<uint32_t>(m_ph); h_cfg_total = *mail.at<unsigned long long>(m_cfg);
+        memcpy(h_cc.data(), mail.at<char>(m_cc), n_cc * 4); memcpy(h_cfgc.data(), mail.at<char>(m_cfgc), (size_t)nchrom * 8);
+        if (!hc[20]) {
+            res->n_big_segments = 0;
+            for (int mode = 0; mode < 3; mode++) res->n_big_segments += (int64_t)hc[32 + 16 * mode] + hc[32 + 16 * mode + 3] + hc[32 + 16 * mode + 4];
+            break;
+        }
         if (attempt == 3) return phz_fail(ctx, PHZ_E_NOMEM, "read-set table pool did not converge");
         if (int s = phz_reserve(ctx, h->pool, h->pool.cap * 4)) return s;           // a segment of more than SEG_LDS reads needs 24 B per read: grow and redo
-        res->n_big_segments = 0;
+    }
+    res->phased = (int64_t)h_phased;
+    // gwStat text the table does not hold -- blocks with more known phases than it covers (:968-980), and with --gw_phase_method 1 every block phased by MAF weight (:1002) --: repr() of the float64 the device computed
+    if (h_nbs) {
+        std::string xt; std::vector<uint32_t> xo((size_t)h_nbs + 1, 0u); std::vector<double> bsv((size_t)h_nbs);
+        PHZ_HIP(ctx, hipMemcpy(bsv.data(), h->big_stat.p, bsv.size() * 8, hipMemcpyDeviceToHost));
+        xt.reserve((size_t)h_nbs * 20);
+        for (uint32_t i = 0; i < h_nbs; i++) {
+            xo[i] = (uint32_t)xt.size();
+            phztext::put_pyfloat(xt, bsv[i]);
+            xt += '\n';
+        }
+        xo[h_nbs] = (uint32_t)xt.size();
+        if (int s = up(ctx, h->px_off, xo.data(), xo.size() * 4)) return s;
+        if (int s = up(ctx, h->px_txt, xt.data(), xt.size())) return s;
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));            // xo / xt die with this scope
     }
     const uint32_t *blk_cnt = need_all ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->seg_ns);     // one BAM, nothing blacklisted: the two read sets coincide
-    // ---- text: byte counts -> scan -> write, file by file
-    RSV(its, (NR + 1) * 4); RSV(piece_dst, NRL * 8);
-    // its = scan of the labels' text widths (digits + one separator), the widths computed as the scan loads the labels (no width array)
-    if (int s = gscan_excl<uint32_t, uint32_t, LabelWidth>(ctx, P<uint32_t>(h->labels), P<uint32_t>(h->its), n_rl, h->scan_tmp)) return s;
-    PHZ_HIP(ctx, hipMemsetAsync(h->piece_dst.p, 0xff, NRL * 8, sm));
-    RSV(big_blk, (size_t)(nblocks + 1) * 4);
-    uint32_t h_nbig = 0;
-    PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 12, 0, 4, sm));
-    if (nblocks) hipLaunchKernelGGL(k_big_blocks, dim3(nblk(nblocks)), dim3(256), 0, sm, nblocks, (const uint32_t *)h->blk_len.p, P<uint32_t>(h->big_blk), cnt32 + 12);
-    PHZ_HIP(ctx, hipMemcpyAsync(&h_nbig, cnt32 + 12, 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(&h_cfg_total, P<unsigned long long>(h->cfg_base) + nblocks, 8, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(h_cc.data(), h->chrom_cnt.p, n_cc * 4, hipMemcpyDeviceToHost, sm));
-    PHZ_HIP(ctx, hipMemcpyAsync(h_cfgc.data(), cc_cfg, (size_t)nchrom * 8, hipMemcpyDeviceToHost, sm));
-    if (int s = sec.wait()) return s;
-    sec.begin();
     if (n_rl * 12 >= (1ll << 32)) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: read-label text beyond 4 GiB");
     RD D; memset(&D, 0, sizeof(D));
     D.nv = nv; D.ne = ne; D.nblocks = nblocks; D.n_linked = n_linked; D.n_keys = nkeys; D.nchrom = nchrom; D.nb = nb; D.unique_ids = o->unique_ids; D.unphased_vars = o->unphased_vars;
@@ -2410,9 +2468,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     auto pool = [&](int i) { PoolD p; p.off = P<uint32_t>(h->p_off[i]); p.b = P<char>(h->p_txt[i]); return p; };
     D.uid = pool(0); D.rsid = pool(1); D.alle = pool(2); D.maft = pool(3); D.chromn = pool(4); D.statt = pool(5);
     D.statx.off = P<uint32_t>(h->px_off); D.statx.b = P<char>(h->px_txt);
-    D.bamn.off = P<uint32_t>(h->bam_off); D.bamn.b = P<char>(h->bam_txt); D.pvt.off = P<uint32_t>(h->pv_off); D.pvt.b = P<char>(h->pv_txt);
+    D.bamn.off = d_bam_off; D.bamn.b = d_bam_txt; D.pvt.off = d_pv_off; D.pvt.b = d_pv_txt;
     D.mafv = P<double>(h->d_maf); D.is_ref = P<uint8_t>(h->d_isref); D.phase_idx = P<int8_t>(h->d_phase); D.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr;
-    D.bam_excl = o->bam_excluded ? P<uint8_t>(h->bam_excl) : nullptr;
+    D.bam_excl = o->bam_excluded ? d_bam_excl : nullptr;
     D.var_count = T.var_count; D.var_distinct = T.var_distinct; D.ea = T.ea; D.eb = T.eb; D.cis = cis; D.trans = trans; D.sup = sup; D.tot = tot; D.cfgv = cfgv;
     D.rl_start = T.rl_start; D.rl_qid = T.rl_qid; D.rl_list = T.rl_list;
     D.eorder = P<uint32_t>(h->eorder); D.va = P<int32_t>(h->va); D.vb = P<int32_t>(h->vb); D.e_slot = P<uint32_t>(h->e_slot); D.key_g = P<uint32_t>(h->key_g);
@@ -2486,12 +2544,16 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     }
     PHZ_HIP(ctx, hipGetLastError());
     std::vector<unsigned long long> h_so[PHZ_TXT_COUNT];
-    PHZ_HIP(ctx, hipMemcpyAsync(&h_c64[4], cnt64 + 4, 8, hipMemcpyDeviceToHost, sm));
-    for (int f = 0; f < PHZ_TXT_COUNT; f++) {
-        h_so[f].assign((size_t)nseg[f] + 1, 0ull);
-        PHZ_HIP(ctx, hipMemcpyAsync(h_so[f].data(), h->seg_off_d[f].p, h_so[f].size() * 8, hipMemcpyDeviceToHost, sm));
+    {
+        PhzMail mail(ctx);
+        int m_so[PHZ_TXT_COUNT];
+        const int m_az = mail.add(cnt64 + 4, 8);
+        for (int f = 0; f < PHZ_TXT_COUNT; f++) m_so[f] = mail.add(h->seg_off_d[f].p, ((size_t)nseg[f] + 1) * 8);
+        if (int s = mail.send()) return s;
+        if (int s = sec.wait("text: byte offsets")) return s;
+        h_c64[4] = *mail.at<unsigned long long>(m_az);
+        for (int f = 0; f < PHZ_TXT_COUNT; f++) { const unsigned long long *q = mail.at<unsigned long long>(m_so[f]); h_so[f].assign(q, q + (size_t)nseg[f] + 1); }
     }
-    if (int s = sec.wait()) return s;
     sec.begin();
     for (int f = 0; f < PHZ_TXT_COUNT; f++) {
         h->bytes[f] = (int64_t)h_so[f].back();
@@ -2529,7 +2591,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         h->have_vcf = true;
     }
     PHZ_HIP(ctx, hipGetLastError());
-    if (int s = sec.wait()) return s;
+    if (int s = sec.wait("end")) return s;
 #undef RSV
     h->chrom_blocks.assign((size_t)nchrom, 0); h->chrom_blk_vars.assign((size_t)nchrom, 0);
     for (int c = 0; c < nchrom; c++) { h->chrom_blocks[(size_t)c] = h_cc[(size_t)nchrom + c]; h->chrom_blk_vars[(size_t)c] = h_cc[(size_t)2 * nchrom + c]; }
@@ -2640,13 +2702,18 @@ extern "C" int phz_phase_components(phz_ctx *ctx, int64_t n_comp, const uint32_t
     auto U = [&](DevBuf &b, const void *src, size_t bytes) { if (st == PHZ_OK) st = up(ctx, b, src, bytes); };
     U(d[B_CS], comp_start, (size_t)(n_comp + 1) * 4); U(d[B_MEM], mem.data(), (size_t)nmem * 4); U(d[B_ES], pair_start, (size_t)(n_comp + 1) * 4);
     U(d[B_EK], ek.data(), (size_t)ne * 4); U(d[B_EA], ea.data(), (size_t)ne * 4); U(d[B_EB], eb.data(), (size_t)ne * 4); U(d[B_CF], cf.data(), (size_t)ne * 4);
-    if (st == PHZ_OK) st = phz_reserve(ctx, d[B_CNT], 64);
+    if (st == PHZ_OK) st = phz_reserve(ctx, d[B_CNT], 128);
     if (st != PHZ_OK) return fin(st);
     Sections sec(ctx);
     sec.begin();
-    int64_t ncx = 0, nex = 0;
-    st = phase_all(ctx, sec, d[B_CS], d[B_MEM], d[B_ES], d[B_EK], P<int32_t>(d[B_EA]), P<int32_t>(d[B_EB]), P<int32_t>(d[B_CF]), n_comp, nmem, ne, ne, max_block_size,
-                   d[B_AL], d[B_SUB], d[B_NSUB], d[B_CX], d[B_EX], d[B_EL], P<uint32_t>(d[B_CNT]), &ncx, &nex);
+    st = phase_enqueue(ctx, d[B_CS], d[B_MEM], d[B_ES], d[B_EK], P<int32_t>(d[B_EA]), P<int32_t>(d[B_EB]), P<int32_t>(d[B_CF]), n_comp, nmem, ne, max_block_size,
+                       d[B_AL], d[B_SUB], d[B_NSUB], d[B_CX], d[B_EX], d[B_EL], P<uint32_t>(d[B_CNT]));
+    if (st != PHZ_OK) return fin(st);
+    uint32_t h_c32[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(h_c32, d[B_CNT].p, 12, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return fin(phz_fail(ctx, PHZ_E_HIP, "phz_phase_components"));
+    st = sec.wait("phase components");
+    if (st == PHZ_OK) st = phase_exceptions(ctx, h_c32, d[B_CS], d[B_MEM], d[B_ES], d[B_EK], P<int32_t>(d[B_EA]), P<int32_t>(d[B_EB]), P<int32_t>(d[B_CF]), n_comp, nmem, ne, ne,
+                                            max_block_size, d[B_AL], d[B_SUB], d[B_NSUB], d[B_EX]);
     if (st != PHZ_OK) return fin(st);
     hipError_t e = hipMemcpyAsync(sub_of, d[B_SUB].p, (size_t)nmem * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(alle_of, d[B_AL].p, (size_t)nmem, hipMemcpyDeviceToHost, ctx->stream);

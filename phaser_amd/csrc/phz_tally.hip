@@ -1382,11 +1382,14 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         hipLaunchKernelGGL(k_tile, dim3(grid_t), dim3(TILE_TB), 0, sm, TT, TO);
     }
     PHZ_HIP(ctx, hipGetLastError());
+    // (read-backs go to page-locked memory: a copy into a pageable vector is a blocking, staged copy -- PhzMail in phz_internal.h)
+    if (int s = phz_reserve_host(ctx, ctx->mail_host, CNT_BYTES + 64)) return s;
     std::vector<unsigned long long> h_cnt(CNT_BYTES / 8, 0ull);
     unsigned long long *h_counters = h_cnt.data();
     auto spread_sum = [&](int k) { unsigned long long t = 0; for (int c = 0; c < N_SPREAD; c++) t += h_counters[16 + c * SPREAD_WORDS + k]; return t; };
-    PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
+    PHZ_HIP(ctx, hipMemcpyAsync(ctx->mail_host.p, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
+    memcpy(h_counters, ctx->mail_host.p, CNT_BYTES);
     const int64_t n_kept = (int64_t)spread_sum(2);
     const int64_t n_dirty = (int64_t)h_counters[11];
     ctx->counters[PHZ_C_FAR_LINES] += (int64_t)h_counters[12]; ctx->counters[PHZ_C_DIRTY_LISTS] += n_dirty;
@@ -1449,10 +1452,15 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
         if (m_items) hipLaunchKernelGGL(k_pairs<0>, dim3((unsigned)((m_items + PAIR_ITEMS * PAIR_ROUNDS - 1) / (PAIR_ITEMS * PAIR_ROUNDS))), dim3(PAIRS_TB), 0, sm, (const uint64_t *)items, m_items, tab,
                                         (uint32_t)(cap - 1), (uint32_t *)S[T_USED].p, (uint64_t *)S[T_USEDKEY].p, deg, counters);
         PHZ_HIP(ctx, hipGetLastError());
-        PHZ_HIP(ctx, hipMemcpyAsync(h_counters, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(h_c32, counters32, 16, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipMemcpyAsync(&h_tail[1], rl_start + NRL, 4, hipMemcpyDeviceToHost, sm));
-        PHZ_HIP(ctx, hipStreamSynchronize(sm));
+        {
+            PhzMail mail(ctx);
+            const int m0 = mail.add(counters, CNT_BYTES), m1 = mail.add(rl_start + NRL, 4);       // (counters32 is part of the counter block)
+            if (int s = mail.send()) return s;
+            PHZ_HIP(ctx, hipStreamSynchronize(sm));
+            memcpy(h_counters, mail.at<char>(m0), CNT_BYTES);
+            memcpy(h_c32, (const char *)mail.at<char>(m0) + 64, 16);
+            h_tail[1] = *mail.at<uint32_t>(m1);
+        }
         if (h_counters[2] == 0) { ne = (int64_t)h_counters[7]; ctx->tally_table_cap = cap; break; }
         if (attempt == 4 || cap >= (1ull << 31)) return phz_fail(ctx, PHZ_E_NOMEM, "variant-pair table did not converge");
         cap <<= 2;
@@ -1491,6 +1499,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     if (int s = timer.stop()) return s;
 #undef RSV
     ctx->tally_dirty = false; ctx->tally_table_dirty = false;
+    ctx->tally_gen++;
     auto &T = ctx->tally;
     T.nv = nv; T.nb = n_bams; T.n_lines = total; T.n_kept = n_kept; T.n_edges = ne; T.n_rl = (int64_t)h_tail[1];
     T.var_count = d_cnt; T.var_distinct = d_dist; T.var_first = (int64_t *)d_first; T.var_rank = (uint64_t *)d_rank; T.line_cls = d_cls;

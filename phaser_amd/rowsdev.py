@@ -290,11 +290,14 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
         # very deep coverage: more distinct (supporting, total) pairs than the table holds -- quadruple it (the handle keeps the size) and redo the stage
         ctx.check(lib.phz_rowsdev_set_pair_slots(T.h, n_slots * 4))
         eng.stats["rowsdev_n_pair_table_growths"] = eng.stats.get("rowsdev_n_pair_table_growths", 0) + 1
+    t1a = _t.perf_counter()
     used = np.flatnonzero(keys != np.uint64(0xFFFFFFFFFFFFFFFF)).astype(np.uint32)
     ku = keys[used]
     tot = (ku >> np.uint64(32)).astype(np.int64); sup = (ku & np.uint64(0xFFFFFFFF)).astype(np.int64)
     prob = 1 - ((6 * noise) + (10 * math.pow(noise, 2)))
+    t1b = _t.perf_counter()
     pv = binom_cdf(sup, tot, prob) if len(used) else np.zeros(0, dtype=np.float64)
+    t1c = _t.perf_counter()
     # values and text by slot (float.__repr__ of the value: what the reference's str(p) writes, phaser.py:693) -- laid out natively
     slot_pv = np.empty(n_slots, dtype=np.float64)
     txt_off = np.empty(n_slots + 1, dtype=np.uint32)
@@ -317,6 +320,7 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     o = _lib.phz_rowsdev_opts(nb, _vp(bam_off), _vp(bam_txt), _vp(ex), len(sh), _vp(lo), _vp(hi), _vp(sb), int(cfg.unique_ids), int(cfg.gw_phase_method),
                               int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.max_block_size), 1 if (cfg.want_vcf or cfg.py_hash_order) else 0, float(cfg.cc_threshold))
     R = _lib.phz_rowsdev_result()
+    t2b = _t.perf_counter()
     ctx.check(lib.phz_rowsdev_run(ctx.h, T.h, C.byref(o), _vp(slot_pv), _vp(txt_off), _vp(txt), C.byref(R)))
     t3 = _t.perf_counter()
     nch = len(eng.chrom_list)
@@ -368,7 +372,9 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
             b0 += kb; v0 += kv
     t4 = _t.perf_counter()
     st = eng.stats
-    for k, v in (("rowsdev_tables_s", t1 - t0), ("rowsdev_pairs_s", t2 - t1), ("rowsdev_run_s", t3 - t2), ("rowsdev_fetch_s", t4 - t3)):
+    for k, v in (("rowsdev_tables_s", t1 - t0), ("rowsdev_pairs_s", t2 - t1), ("rowsdev_run_s", t3 - t2), ("rowsdev_fetch_s", t4 - t3),
+                 ("rowsdev_pairs_keys_call_s", t1a - t1), ("rowsdev_pairs_numpy_s", t1b - t1a), ("rowsdev_pairs_scipy_s", t1c - t1b), ("rowsdev_pairs_text_s", t2 - t1c),
+                 ("rowsdev_run_glue_s", t2b - t2)):
         st[k] = st.get(k, 0.0) + v
     st["rowsdev_gpu_ms"] = st.get("rowsdev_gpu_ms", 0.0) + float(R.gpu_ms)
     st["rowsdev_text_bytes"] = float(total_bytes)
