@@ -180,6 +180,37 @@ enum { PHZ_T_MAP = 0, PHZ_T_ASHIST = 1, PHZ_T_TALLY = 2, PHZ_T_COMPONENTS = 3, P
 enum { PHZ_C_LINES = 0, PHZ_C_ITEMS = 1, PHZ_C_PAIR_EVENTS = 2, PHZ_C_EDGES = 3, PHZ_C_FAR_LINES = 4 /* call lines outside their tile's variant window */,
        PHZ_C_DIRTY_LISTS = 5 /* read lists filled through a cursor and sorted (they hold a far line) */, PHZ_C_COUNT = 8 };
 
+/* ---- Raw-byte tier, native: the rows of variant_connections / haplotypes / haplotypic_counts re-ordered and re-labelled the way
+ * CPython 3.10 with PYTHONHASHSEED=0 orders the reference's sets of strings (phaser/phaser.py:660-678, :930, :1059, :1086, :1106-1115, :1181-1239).  The str
+ * hash (SipHash-2-4, zero key) and the set (probe sequence, growth, difference) are restated in phz_pyorder.cpp; nothing of the interpreter is linked.
+ * String pools: item i of a pool = blob[off[i], off[i + 1]) minus one trailing separator byte for the variant pools (uid, allele2 -- two per variant --,
+ * rsid), no separator for the QNAME pools (id order, per chromosome).  Per-(chromosome, BAM) arrays are indexed [c * n_bams + b]; NULL = no call file. */
+typedef struct {
+    int32_t n_chroms, n_bams;
+    const char *const *chrom_names; const char *const *bam_names;
+    const int64_t *nv; const int32_t *const *pos;
+    const char *const *uid; const uint32_t *const *uid_off;
+    const char *const *allele2; const uint32_t *const *allele2_off;
+    const char *const *rsid; const uint32_t *const *rsid_off;
+    const int64_t *nq; const char *const *qname; const uint32_t *const *qname_off;
+    const int32_t *const *line_qid; const int32_t *const *line_var; const uint8_t *const *line_cls; const int64_t *n_lines;      /* KEPT call lines, line order */
+    const uint8_t *bam_excluded;               /* [n_bams] or NULL (--haplo_count_bam_exclude) */
+    const uint8_t *const *blacklisted;         /* per chromosome [nv] or NULL: the variant is on the haplotype-count blacklist */
+    int64_t n_blocks; const int32_t *blk_chrom; const int64_t *blk_off /* [n_blocks + 1] */; const int32_t *blk_var;              /* blocks in block order, chromosome-local variants */
+    int32_t output_read_ids, unphased_vars, unique_ids;
+} phz_pyorder_in;
+typedef struct phz_pyorder phz_pyorder;
+/* conn / hap / ase: the three files in the product's canonical order (what the fast path writes).  -> handle holding the three texts in the reference's raw order;
+ * PHZ_E_ARG with a message (phz_pyorder_error) when the texts and the call lines do not belong together. */
+int phz_pyorder_replay(const phz_pyorder_in *in, const char *conn, int64_t conn_len, const char *hap, int64_t hap_len, const char *ase, int64_t ase_len, phz_pyorder **out);
+int phz_pyorder_text(const phz_pyorder *h, int which /* 0 variant_connections, 1 haplotypes, 2 haplotypic_counts */, const char **text, int64_t *len);
+const char *phz_pyorder_error(const phz_pyorder *h);
+void phz_pyorder_free(phz_pyorder *h);
+/* the two restated pieces of the interpreter, exported for the tests: hash(str) under PYTHONHASHSEED=0, and the iteration order of set(items) (mode 0) or
+ * of set(items[0, n_a)) - set(items[n_a, n)) (mode 1) as indices into the pool */
+int64_t phz_py_str_hash(const char *s, int64_t len);
+int64_t phz_py_set_order(const char *blob, const uint32_t *off, int64_t n, int64_t n_a, int32_t mode, int32_t *order_out);
+
 int phz_version(void);
 const char *phz_strerror(int status);
 const char *phz_last_error(const phz_ctx *ctx);

@@ -173,6 +173,18 @@ class phz_vcf_table(C.Structure):
                 ("blacklisted", C.c_void_p)]
 
 
+class phz_pyorder_in(C.Structure):
+    _fields_ = [("n_chroms", C.c_int32), ("n_bams", C.c_int32), ("chrom_names", C.POINTER(C.c_char_p)), ("bam_names", C.POINTER(C.c_char_p)),
+                ("nv", C.c_void_p), ("pos", C.POINTER(C.c_void_p)),
+                ("uid", C.POINTER(C.c_void_p)), ("uid_off", C.POINTER(C.c_void_p)), ("allele2", C.POINTER(C.c_void_p)), ("allele2_off", C.POINTER(C.c_void_p)),
+                ("rsid", C.POINTER(C.c_void_p)), ("rsid_off", C.POINTER(C.c_void_p)),
+                ("nq", C.c_void_p), ("qname", C.POINTER(C.c_void_p)), ("qname_off", C.POINTER(C.c_void_p)),
+                ("line_qid", C.POINTER(C.c_void_p)), ("line_var", C.POINTER(C.c_void_p)), ("line_cls", C.POINTER(C.c_void_p)), ("n_lines", C.c_void_p),
+                ("bam_excluded", C.c_void_p), ("blacklisted", C.POINTER(C.c_void_p)),
+                ("n_blocks", C.c_int64), ("blk_chrom", C.c_void_p), ("blk_off", C.c_void_p), ("blk_var", C.c_void_p),
+                ("output_read_ids", C.c_int32), ("unphased_vars", C.c_int32), ("unique_ids", C.c_int32)]
+
+
 class phz_vcfout_chrom(C.Structure):
     _fields_ = [("uid", C.c_void_p), ("uid_len", C.c_int64), ("rsid", C.c_void_p), ("rsid_len", C.c_int64), ("alleles", C.c_void_p),
                 ("alleles_len", C.c_int64), ("maf_str", C.c_void_p), ("maf_str_len", C.c_int64), ("n_blocks", C.c_int64),
@@ -215,6 +227,12 @@ SYMBOLS = {
     "phz_as_histogram": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_void_p, C.c_int]),
     "phz_as_histogram_batch": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_void_p]),
     "phz_as_histogram_sparse": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "phz_pyorder_replay": (C.c_int, [C.POINTER(phz_pyorder_in), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "phz_pyorder_text": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "phz_pyorder_error": (C.c_char_p, [C.c_void_p]),
+    "phz_pyorder_free": (None, [C.c_void_p]),
+    "phz_py_str_hash": (C.c_int64, [C.c_char_p, C.c_int64]),
+    "phz_py_set_order": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "phz_as_cutoff": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.POINTER(phz_tally_sizes), C.c_int]),

@@ -283,6 +283,22 @@ class NativeInterner:
     def __len__(self):
         return max(self._host_size(), self._store["n"] if self._store else 0)
 
+    def pool(self):
+        """-> (blob bytes, offsets uint32 [n + 1]) of the names in id order, without building a Python string per name (the native raw-byte tier reads this:
+        pyorder.replay_native; 40 M names of a whole-genome sample as a list of str cost seconds and gigabytes)"""
+        import ctypes as C
+        self._sync()
+        n = self._host_size()
+        off = np.zeros(n + 1, dtype=np.uint32)
+        cap = 1 << 20
+        while True:
+            blob = np.zeros(cap, dtype=np.uint8)
+            st = self.lib.phz_interner_names(self._h, C.c_void_p(blob.ctypes.data), cap, C.c_void_p(off.ctypes.data))
+            if st == 0:
+                break
+            cap = int(off[n]) + 16
+        return blob[:int(off[n])].tobytes(), off
+
     @property
     def names(self) -> List[str]:
         import ctypes as C

@@ -448,11 +448,16 @@ class Engine:
         if self.cfg.py_hash_order:
             # raw-byte tier: replay the reference's set constructions over the same strings (an exactness mode: pure Python over every call line)
             from . import pyorder
-            text = {k: b"".join(pdist.as_bytes(x) for x in v).decode() for k, v in out.items()}
-            text = pyorder.replay(self, text)
+            import os as _os
+            raw = {k: b"".join(pdist.as_bytes(x) for x in v) for k, v in out.items()}
+            if _os.environ.get("PHZ_PYORDER_PYTHON") == "1":          # the pure-Python twin with real set objects (CPython 3.10 under PYTHONHASHSEED=0 only)
+                text = pyorder.replay(self, {k: v.decode() for k, v in raw.items()})
+                raw = {k: v.encode() for k, v in text.items()}
+            else:                                                       # libphz's restatement of the str hash and the set: any interpreter, seconds at genome scale
+                raw = pyorder.replay_native(self, raw)
             if chunks:
-                return {k: [v.encode()] for k, v in text.items()}
-            return {k: v.encode() for k, v in text.items()} if binary else text
+                return {k: [v] for k, v in raw.items()}
+            return raw if binary else {k: v.decode() for k, v in raw.items()}
         if chunks:
             return out
         out = {k: b"".join(pdist.as_bytes(x) for x in v) for k, v in out.items()}

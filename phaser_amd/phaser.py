@@ -74,7 +74,8 @@ def build_parser():
     p.add_argument("--unique_ids", type=int, default=0)
     p.add_argument("--py_hash_order", type=int, default=0,
                    help="1: rows and read labels of variant_connections / haplotypes / haplotypic_counts in the order CPython 3.10 gives the reference's sets "
-                        "(byte-identical files; needs PYTHONHASHSEED=0; a pure-Python pass over every call line, not the fast path)")
+                        "run under PYTHONHASHSEED=0, i.e. files byte-identical to the reference's (the str hash and the set of that interpreter are restated "
+                        "in libphz: works under any Python, costs seconds at whole-genome scale; PHZ_PYORDER_PYTHON=1 selects the pure-Python twin)")
     p.add_argument("--id_separator", default="_")
     p.add_argument("--output_network", default="")
     p.add_argument("--process_slow", type=int, default=0, required=False)
@@ -260,7 +261,19 @@ def _main(argv, state):
         if guess:
             start_prefetch(guess)
     sample_col = None
-    for raw in data.split(b"\n", 20000)[:20000]:          # the header sits at the top
+    # (the header sits at the top: only the first 20,000 lines are looked at, and only they are split -- split(b"\n", 20000) on the whole text copied the
+    #  75 MB behind them once more, 0.05 s)
+    head_end = 0
+    for _ in range(20000):
+        nxt = data.find(b"\n", head_end)
+        if nxt < 0:
+            head_end = len(data); break
+        head_end = nxt + 1
+        if data[head_end:head_end + 1] not in (b"#", b"\n", b"\r", b""):          # the first record: one more line is taken (it ends the loop below as it always did)
+            nxt = data.find(b"\n", head_end)
+            head_end = len(data) if nxt < 0 else nxt + 1
+            break
+    for raw in data[:head_end].split(b"\n"):
         if b"#CHR" in raw:
             cols = raw.decode().rstrip().split("\t")
             m = {cols[i]: i for i in range(9, len(cols))}
@@ -407,7 +420,12 @@ def _main(argv, state):
         items = []
         for chrom in vs.chroms:
             if chrom in shards and chrom in mine:
-                items.append((chrom, shards[chrom].to(device), len(interners[chrom]), interners[chrom].names if (args.output_read_ids == 1 or args.py_hash_order == 1) else None))
+                names = None
+                if args.output_read_ids == 1 or (args.py_hash_order == 1 and os.environ.get("PHZ_PYORDER_PYTHON") == "1"):
+                    names = interners[chrom].names          # a list of str: the host row twin and the pure-Python raw-byte twin index it
+                elif args.py_hash_order == 1:
+                    names = interners[chrom].pool() if hasattr(interners[chrom], "pool") else interners[chrom].names      # (blob, offsets): what the native raw-byte tier reads
+                items.append((chrom, shards[chrom].to(device), len(interners[chrom]), names))
         eng.add_shards(bi, items)                # all chromosomes of the BAM in one K_map submission
         for it in items:
             say("               completed chromosome %s..." % it[0])

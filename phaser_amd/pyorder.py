@@ -8,14 +8,23 @@ Three of phASER's five files depend on the iteration order of Python sets of str
   haplotypes.txt            the singleton rows (:1226-1239), same set
 Everything else in the files is order-free and comes from the GPU path unchanged.  This module re-orders / re-labels the product's rows by REPLAYING those
 set constructions -- the same strings inserted in the same sequence into real `set` objects of this interpreter -- which gives the reference's bytes when
-the interpreter hashes strings the way the reference's run did: CPython 3.10 with PYTHONHASHSEED=0 (the golden files were written that way).  It is a pure
-Python pass over every call line (minutes at whole-genome scale): an exactness mode (Config.py_hash_order / --py_hash_order 1), not the fast path.
+the interpreter hashes strings the way the reference's run did: CPython 3.10 with PYTHONHASHSEED=0 (the golden files were written that way).
+
+Two implementations of the same replay:
+  replay_native   (the default behind Config.py_hash_order / --py_hash_order 1) libphz's phz_pyorder_replay: the str hash of a seed-0 CPython 3.10 and
+                  its set (probe sequence, growth, difference) restated in C++ (csrc/phz_pyorder.cpp) -- seconds at whole-genome scale, and independent
+                  of the interpreter it runs under (any Python version, any hash seed);
+  replay          the pure-Python twin with REAL set objects (minutes at that scale; needs CPython 3.10 under PYTHONHASHSEED=0): what the native one is
+                  tested against, and selectable with PHZ_PYORDER_PYTHON=1.
 """
 from __future__ import annotations
 
+import ctypes as C
 import sys
 from collections import OrderedDict
 from typing import Dict, List
+
+import numpy as np
 
 
 def check_interpreter():
@@ -220,3 +229,101 @@ def replay(eng, out: Dict[str, str]) -> Dict[str, str]:
     res["haplotypes"] = "\n".join(new) + "\n"
     return res
 
+
+
+def _names_pool(names):
+    """QNAME strings of one chromosome in id order -> (blob bytes, offsets uint32 [n + 1]); `names` is a list of str or already such a pair"""
+    if isinstance(names, tuple):
+        return names
+    n = len(names)
+    off = np.zeros(n + 1, dtype=np.uint32)
+    if n:
+        blob = "".join(names).encode("latin-1")
+        off[1:] = np.cumsum(np.fromiter((len(x) for x in names), dtype=np.int64, count=n)).astype(np.uint32)
+    else:
+        blob = b""
+    return blob, off
+
+
+def replay_native(eng, out: Dict[str, bytes]) -> Dict[str, bytes]:
+    """Same contract as replay(), on bytes, through libphz (phz_pyorder_replay)."""
+    from . import _lib
+    lib = _lib.load()
+    cfg = eng.cfg
+    chroms = list(eng.all_chroms)
+    nb = len(eng.bam_names); nc = len(chroms)
+    lines = eng.kept_lines()
+    keep = []           # everything the struct points into
+
+    def arr(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+        return a.ctypes.data if a.size else 0
+
+    def blob(b):
+        b = bytes(b) if not isinstance(b, bytes) else b
+        if not b:
+            b = b"\0"
+        keep.append(b)
+        return C.cast(C.c_char_p(b), C.c_void_p).value
+    VP = C.c_void_p * max(1, nc)
+    uid = VP(); uid_off = VP(); al = VP(); al_off = VP(); rs = VP(); rs_off = VP(); qn = VP(); qn_off = VP(); pos = VP(); black = VP()
+    nv = np.zeros(max(1, nc), np.int64); nq = np.zeros(max(1, nc), np.int64)
+    for i, c in enumerate(chroms):
+        cv = eng.vs.chroms[c]
+        P = cv.pools()
+        nv[i] = len(cv)
+        uid[i] = blob(P["uid"][1]); uid_off[i] = arr(P["uid"][0], np.uint32)
+        al[i] = blob(P["allele"][1]); al_off[i] = arr(P["allele"][0], np.uint32)
+        rs[i] = blob(P["rsid"][1]); rs_off[i] = arr(P["rsid"][0], np.uint32)
+        pos[i] = arr(cv.pos, np.int32)
+        b_, o_ = _names_pool(eng.qnames.get(c, []))
+        nq[i] = len(o_) - 1
+        qn[i] = blob(b_); qn_off[i] = arr(o_, np.uint32)
+        bl = getattr(cv, "blacklisted", None)
+        m = np.array(bl, dtype=np.uint8) if (bl is not None and len(bl) == len(cv)) else np.zeros(len(cv), np.uint8)
+        if cfg.haplo_blacklist:
+            m = m | np.fromiter((c + "_" + str(int(p)) in cfg.haplo_blacklist for p in cv.pos), dtype=np.uint8, count=len(cv))
+        black[i] = arr(m, np.uint8) if m.any() else 0
+    LP = C.c_void_p * max(1, nc * nb)
+    lq = LP(); lv = LP(); lc = LP(); nl = np.zeros(max(1, nc * nb), np.int64)
+    for i, c in enumerate(chroms):
+        L = lines.get(c)
+        for b in range(nb):
+            t = None if L is None else L[b]
+            if t is None:
+                continue
+            lq[i * nb + b] = arr(t[0], np.int32) or arr(np.zeros(1, np.int32), np.int32); lv[i * nb + b] = arr(t[1], np.int32) or arr(np.zeros(1, np.int32), np.int32)
+            lc[i * nb + b] = arr(t[2], np.uint8) or arr(np.zeros(1, np.uint8), np.uint8); nl[i * nb + b] = len(t[0])
+    index = {c: i for i, c in enumerate(chroms)}
+    bc = []; bo = [0]; bv = []
+    for c, v, _first in eng.vcf_blocks:
+        off = 0
+        var = np.asarray(v["var"])
+        for n in np.asarray(v["size"]).tolist():
+            bc.append(index[c]); bv.append(var[off:off + n]); off += n; bo.append(bo[-1] + n)
+    ex = np.zeros(nb, np.uint8)
+    for b in cfg.haplo_count_bam_exclude:
+        if 0 <= b < nb:
+            ex[b] = 1
+    cn = (C.c_char_p * max(1, nc))(*[c.encode() for c in chroms]); bn = (C.c_char_p * max(1, nb))(*[x.encode() for x in eng.bam_names])
+    CP = lambda a: C.cast(a, C.POINTER(C.c_void_p))
+    I = _lib.phz_pyorder_in(nc, nb, cn, bn, arr(nv, np.int64), CP(pos), CP(uid), CP(uid_off), CP(al), CP(al_off), CP(rs), CP(rs_off), arr(nq, np.int64), CP(qn), CP(qn_off),
+                            CP(lq), CP(lv), CP(lc), arr(nl, np.int64), arr(ex, np.uint8) if ex.any() else None, CP(black), len(bc), arr(np.array(bc, np.int32), np.int32),
+                            arr(np.array(bo, np.int64), np.int64), arr(np.concatenate(bv) if bv else np.zeros(0, np.int32), np.int32),
+                            int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.unique_ids))
+    texts = [out["variant_connections"], out["haplotypes"], out["haplotypic_counts"]]
+    texts = [t if isinstance(t, bytes) else t.encode() for t in texts]
+    h = C.c_void_p()
+    st = lib.phz_pyorder_replay(C.byref(I), C.cast(C.c_char_p(texts[0]), C.c_void_p), len(texts[0]), C.cast(C.c_char_p(texts[1]), C.c_void_p), len(texts[1]),
+                                C.cast(C.c_char_p(texts[2]), C.c_void_p), len(texts[2]), C.byref(h))
+    try:
+        if st != _lib.PHZ_OK:
+            raise _lib.PhzError(st, "raw-byte tier: " + (lib.phz_pyorder_error(h) or b"").decode())
+        res = dict(out)
+        for which, name in enumerate(("variant_connections", "haplotypes", "haplotypic_counts")):
+            p = C.c_void_p(); n = C.c_int64(0)
+            lib.phz_pyorder_text(h, which, C.byref(p), C.byref(n))
+            res[name] = C.string_at(p, n.value)
+        return res
+    finally:
+        lib.phz_pyorder_free(h)

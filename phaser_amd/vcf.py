@@ -108,6 +108,35 @@ class VariantSet:
         self.indels_excluded = indels_excluded; self.unphased_count = unphased_count
 
 
+class _NativeTable:
+    """Owner of a phz_vcf handle: the string pools of the chromosomes stay in native memory and are copied out on first use only (the row stage
+    reads four of the eleven; copying all of them for 1.5 M variants was 150 MB of memcpy per run)."""
+
+    def __init__(self, lib, h):
+        self.lib = lib; self.h = h
+
+    def __del__(self):
+        try:
+            if self.h is not None:
+                self.lib.phz_vcf_free(self.h); self.h = None
+        except Exception:
+            pass
+
+
+class _LazyPools(dict):
+    """raw[name] -> bytes of the pool, fetched from the native table when first asked for."""
+
+    def __init__(self, owner, ptrs):
+        super().__init__()
+        self._owner = owner; self._ptrs = ptrs
+
+    def __missing__(self, name):
+        ptr, n = self._ptrs[name]
+        b = C.string_at(ptr, n) if n else b""
+        self[name] = b
+        return b
+
+
 def read_text(path: str) -> str:
     return read_bytes(path).decode()
 
@@ -231,30 +260,29 @@ def load_variants(vcf_text, sample_column: int = 9, chrom_of_interest: str = "",
                           nd, dn, ds, de, nm, mn, ms, me)
     h = C.c_void_p()
     st = lib.phz_vcf_parse(C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(o), C.byref(h))
-    try:
-        if st != _lib.PHZ_OK:
-            msg = (lib.phz_vcf_error(h) or b"").decode()
-            if "FATAL ERROR" in msg:
-                raise SystemExit(msg)
-            raise _lib.PhzError(st, msg or "phz_vcf_parse failed")
-        nch = C.c_int32(0); het = C.c_int64(0); fc = C.c_int64(0); ex = C.c_int64(0); un = C.c_int64(0)
-        lib.phz_vcf_summary(h, C.byref(nch), C.byref(het), C.byref(fc), C.byref(ex), C.byref(un))
-        chroms: Dict[str, ChromVariants] = {}
-        for i in range(nch.value):
-            t = _lib.phz_vcf_table()
-            lib.phz_vcf_chrom(h, i, C.byref(t))
-            n = int(t.n)
+    owner = _NativeTable(lib, h)          # frees the table when the last chromosome's lazy pools are gone
+    if st != _lib.PHZ_OK:
+        msg = (lib.phz_vcf_error(h) or b"").decode()
+        if "FATAL ERROR" in msg:
+            raise SystemExit(msg)
+        raise _lib.PhzError(st, msg or "phz_vcf_parse failed")
+    nch = C.c_int32(0); het = C.c_int64(0); fc = C.c_int64(0); ex = C.c_int64(0); un = C.c_int64(0)
+    lib.phz_vcf_summary(h, C.byref(nch), C.byref(het), C.byref(fc), C.byref(ex), C.byref(un))
+    chroms: Dict[str, ChromVariants] = {}
+    for i in range(nch.value):
+        t = _lib.phz_vcf_table()
+        lib.phz_vcf_chrom(h, i, C.byref(t))
+        n = int(t.n)
 
-            def arr(ptr, count, dt):
-                if count == 0:
-                    return np.zeros(0, dtype=dt)
-                return np.frombuffer(C.string_at(ptr, count * np.dtype(dt).itemsize), dtype=dt).copy()
-            arrays = {"pos": arr(t.pos, n, np.int32), "ref_len": arr(t.ref_len, n, np.uint8), "a0": arr(t.a0, n, np.uint8),
-                      "a1": arr(t.a1, n, np.uint8), "is_ref": arr(t.is_ref, 2 * n, np.uint8), "phase_idx": arr(t.phase_idx, 2 * n, np.int8),
-                      "maf": arr(t.maf, n, np.float64), "blacklisted": arr(t.blacklisted, n, np.uint8)}
-            raw = {name: (C.string_at(t.pool[k], int(t.pool_len[k])) if t.pool_len[k] else b"") for k, name in enumerate(_POOLS)}
-            cv = ChromVariants(t.name.decode(), arrays, raw)
-            chroms[cv.chrom] = cv
-    finally:
-        lib.phz_vcf_free(h)
+        def arr(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dtype=dt)
+            nb = count * np.dtype(dt).itemsize
+            return np.frombuffer((C.c_char * nb).from_address(ptr), dtype=dt).copy()          # one copy, owned by numpy
+        arrays = {"pos": arr(t.pos, n, np.int32), "ref_len": arr(t.ref_len, n, np.uint8), "a0": arr(t.a0, n, np.uint8),
+                  "a1": arr(t.a1, n, np.uint8), "is_ref": arr(t.is_ref, 2 * n, np.uint8), "phase_idx": arr(t.phase_idx, 2 * n, np.int8),
+                  "maf": arr(t.maf, n, np.float64), "blacklisted": arr(t.blacklisted, n, np.uint8)}
+        raw = _LazyPools(owner, {name: (t.pool[k], int(t.pool_len[k])) for k, name in enumerate(_POOLS)})
+        cv = ChromVariants(t.name.decode(), arrays, raw)
+        chroms[cv.chrom] = cv
     return VariantSet(chroms, int(het.value), int(fc.value), int(ex.value), int(un.value))

@@ -158,9 +158,11 @@ def test_cli_bam_prefetch_from_the_tabix_index(tmp_path, index, capfd):
     assert ("bam prefetch during the VCF parse: used" in err) if index == "tbi" else ("bam prefetch during the VCF parse: discarded" in err), err[-1500:]
 
 
-def test_cli_py_hash_order_gives_the_reference_bytes(tmp_path):
-    """--py_hash_order 1 under PYTHONHASHSEED=0: the drop-in CLI (GPU path from an unfiltered BAM) writes the reference's five files BYTE FOR BYTE
-    (fixture pipe_one was written by the reference under the same hash seed): the raw tier of SURVEY.md 8(a)."""
+@pytest.mark.parametrize("hashseed,twin", [("0", "0"), ("4242", "0"), ("0", "1")])
+def test_cli_py_hash_order_gives_the_reference_bytes(tmp_path, hashseed, twin):
+    """--py_hash_order 1: the drop-in CLI (GPU path from an unfiltered BAM) writes the reference's five files BYTE FOR BYTE (fixture pipe_one was written by
+    the reference under PYTHONHASHSEED=0, CPython 3.10): the raw tier of SURVEY.md 8(a).  The native tier restates that interpreter's str hash and set, so
+    the bytes do not depend on the seed of the interpreter the CLI runs under; twin 1 = the pure-Python replay with real sets (needs seed 0)."""
     import gzip
     import subprocess
     from phaser_amd import bamio, synth
@@ -173,7 +175,7 @@ def test_cli_py_hash_order_gives_the_reference_bytes(tmp_path):
     with gzip.open(vcfgz, "wt") as f:
         f.write(open(os.path.join(d, "in.vcf")).read())
     prefix = str(tmp_path / "out")
-    env = dict(os.environ, PYTHONHASHSEED="0", PYTHONPATH=REPO)
+    env = dict(os.environ, PYTHONHASHSEED=hashseed, PYTHONPATH=REPO, PHZ_PYORDER_PYTHON=twin)
     r = subprocess.run([sys.executable, "-m", "phaser_amd.phaser", "--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", "255", "--baseq", "10", "--paired_end", "1",
                         "--o", prefix, "--write_vcf", "0", "--threads", "3", "--py_hash_order", "1"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
