@@ -83,6 +83,10 @@ typedef struct {
     const uint32_t *seq_off;
     const uint8_t *seq2;
     const uint8_t *qual;
+    const uint8_t *bq;       /* optional (NULL = absent), device shards only: ONE byte per base holding both things a call needs -- bits 7:6 the 2-bit base, bits 5:0
+                              * min(phred, 62), 63 = escape (a non-ACGT base or a phred above 62: seq2 / qual decide) -- at the index of the base's qual byte.
+                              * When EVERY shard of a submission carries it, K_map's ONE instantiation reads it (one memory line per call instead of two; identical
+                              * calls).  Measured on the whole-genome sample: no faster than the two planes (1.0928 against 1.0940 ms), so no producer writes it by default */
 } phz_reads;
 
 typedef struct {

@@ -32,7 +32,7 @@ class PhzError(RuntimeError):
 class phz_reads(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_ops", C.c_int64), ("n_seq_bytes", C.c_int64),
                 ("pos", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
-                ("seq_off", C.c_void_p), ("seq2", C.c_void_p), ("qual", C.c_void_p)]
+                ("seq_off", C.c_void_p), ("seq2", C.c_void_p), ("qual", C.c_void_p), ("bq", C.c_void_p)]
 
 
 class phz_variants(C.Structure):

@@ -49,6 +49,7 @@ struct MapArgs {
     const int32_t *pos;
     const uint32_t *cigar_off, *cigar, *seq_off;
     const uint8_t *seq2, *qual;
+    const uint8_t *bq;            // one byte per base (phz_reads.bq), or NULL
     int64_t n;
     const int32_t *vpos;
     int nv;
@@ -63,6 +64,8 @@ struct MapArgs {
     int slot_cap;
     int64_t ntiles;
     int dbg;          // ablation switches for profiling (PHZ_MAP_DBG env); 0 in production
+    bool one;         // base and quality of a call from the one-byte plane `bq` (a compile-time constant of the instantiation, like dbg == 0)
+    const struct ShardDev *shp;   // ONE instantiation: the shard record, read again by the rare escape (seq2 / qual stay out of the registers)
 };
 
 // one shard of a batch; the array lives in device memory for the duration of the launches
@@ -70,6 +73,7 @@ struct ShardDev {
     const int32_t *pos;
     const uint32_t *cigar_off, *cigar, *seq_off;
     const uint8_t *seq2, *qual;
+    const uint8_t *bq;
     int64_t n;
     const int32_t *vpos;
     int nv, pad;
@@ -105,6 +109,15 @@ __device__ __forceinline__ int shard_of(const int64_t *tile0, int n_shards, int6
         if (tile0[m] <= T) lo = m; else hi = m - 1;
     }
     return lo;
+}
+
+// the escape of the one-byte plane (a non-ACGT base or a phred above 62: one base in two thousand): the two planes, found through the shard record
+__device__ __noinline__ int masked_base_escape(const MapArgs &a, uint32_t soff, int x) {
+    const uint8_t *qual = a.shp->qual, *seq2 = a.shp->seq2;
+    const uint32_t q = qual[(size_t)soff * 4 + x], s = (seq2[(size_t)soff + (x >> 2)] >> (2 * (x & 3))) & 3;
+    if ((int)(q & 0x7f) < a.baseq) return 4;
+    if (q & 0x80) return s == 0 ? 4 : 5;
+    return (int)s;
 }
 
 struct VarWin {
@@ -198,8 +211,25 @@ __device__ __forceinline__ uint32_t cand_x1(const CandBuf &cb, int e, uint32_t k
 // experiment (PHZ_MAP_DBG bit 1024, timing only -- wrong bases): the byte that holds a base's two bits is read from the quality plane, inside the
 // 4-byte group of its quality byte, i.e. what a layout with both in one memory sector would fetch
 #define PHZ_SEQ_BYTE(a, soff, x) (((a).dbg & 1024) ? (a).qual[(size_t)(soff) * 4 + ((x) | 3)] : (a).seq2[(size_t)(soff) + ((x) >> 2)])
+// Base and quality of a call from ONE byte (phz_reads.bq: base << 6 | min(phred, 62), 63 = escape to the two planes): one 128-byte line per call instead of two.
+// The ONE instantiations of the kernel read it (every shard of the submission carries the plane); A/B on the profiling instantiation: PHZ_MAP_DBG bit 4096
+// (tools/ab_kmap_oneplane.py: -3.7 % on the profiling instantiation, -0.1 % on the production one, call lists identical)
+#define PHZ_ONEPLANE(a) ((a).one)
+__device__ __forceinline__ int masked_base_two(const MapArgs &a, uint32_t soff, int x) {
+    const uint32_t q = a.qual[(size_t)soff * 4 + x], s = (a.seq2[(size_t)soff + (x >> 2)] >> (2 * (x & 3))) & 3;
+    if ((int)(q & 0x7f) < a.baseq) return 4;
+    if (q & 0x80) return s == 0 ? 4 : 5;
+    return (int)s;
+}
+__device__ int masked_base_escape(const MapArgs &a, uint32_t soff, int x);
+__device__ __forceinline__ int sym_from_bq(const MapArgs &a, uint32_t soff, int x, uint32_t b) {
+    const uint32_t q6 = b & 63u;
+    if (q6 == 63u) return a.qual ? masked_base_two(a, soff, x) : masked_base_escape(a, soff, x);
+    return (int)q6 < a.baseq ? 4 : (int)(b >> 6);
+}
 // symbol of read base x after baseq masking: 0..3 = ACGT, 4 = 'N', 5 = other IUPAC character
 __device__ __forceinline__ int masked_base(const MapArgs &a, uint32_t soff, int x) {
+    if (PHZ_ONEPLANE(a)) return sym_from_bq(a, soff, x, a.bq[(size_t)soff * 4 + x]);
     uint32_t q = a.qual[(size_t)soff * 4 + x];
     uint32_t s = (PHZ_SEQ_BYTE(a, soff, x) >> (2 * (x & 3))) & 3;
     if ((int)(q & 0x7f) < a.baseq) return 4;
@@ -480,17 +510,19 @@ __device__ __forceinline__ int block_scan(const int (&cnt)[RPT], int (&excl)[RPT
 
 // ABL: the ablation switches of PHZ_MAP_DBG are live (profiling build of the same code); the production instantiation sees dbg == 0 at
 // compile time, so none of its tests reach the scalar unit
-template <int MAP_BLOCK, int RPT, bool ABL>
+template <int MAP_BLOCK, int RPT, bool ABL, bool ONE>
 __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile) {
     const int4 tw = *reinterpret_cast<const int4 *>(bt.tile_w0 + 4 * gtile);      // the pre-pass left the tile's shard here: no search
     const int si = (tw.y >> 16) & 0x1FFF;
     MapArgs a;
     {
         const ShardDev &sh = bt.shards[si];
-        a.pos = sh.pos; a.cigar_off = sh.cigar_off; a.cigar = sh.cigar; a.seq_off = sh.seq_off; a.seq2 = sh.seq2; a.qual = sh.qual;
+        a.pos = sh.pos; a.cigar_off = sh.cigar_off; a.cigar = sh.cigar; a.seq_off = sh.seq_off; a.bq = sh.bq; a.shp = &sh;
+        if (ONE && !ABL) { a.seq2 = nullptr; a.qual = nullptr; } else { a.seq2 = sh.seq2; a.qual = sh.qual; }
         a.n = sh.n; a.vpos = sh.vpos; a.nv = sh.nv; a.baseq = bt.baseq;
         a.stage = bt.stage; a.side = bt.side; a.slots = bt.slots;
         a.tile_w0 = bt.tile_w0; a.tile_total = bt.tile_total; a.slot_cap = bt.slot_cap; a.ntiles = bt.ntiles; a.dbg = ABL ? bt.dbg : 0;
+        a.one = ABL ? ((bt.dbg & 4096) != 0 && sh.bq != nullptr) : ONE;
     }
 #define PHZ_STAMP(K) do { if (ABL && (bt.dbg & 2048) && threadIdx.x == 0) bt.prof[8 * gtile + (K)] = wall_clock64(); } while (0)
     PHZ_STAMP(0);
@@ -650,8 +682,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
         if (fast_[k] && n_[k] > 0 && !(a.dbg & 1)) {
             const uint32_t soff = s_soff[k * MAP_BLOCK + tid];
             const int x = s_vpos[base_[k]] - rpos_[k];
-            pre_q[k] = a.qual[(size_t)soff * 4 + x];
-            pre_s[k] = PHZ_SEQ_BYTE(a, soff, x);
+            if (PHZ_ONEPLANE(a)) pre_q[k] = a.bq[(size_t)soff * 4 + x];
+            else { pre_q[k] = a.qual[(size_t)soff * 4 + x]; pre_s[k] = PHZ_SEQ_BYTE(a, soff, x); }
         }
     }
     PHZ_STAMP(2);
@@ -692,8 +724,8 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             const uint32_t x0 = cand_x0(cb, tid);
             cx_off = x0 != 0xFFFFFFFFu ? (int)x0 : (int)(cand_x1(cb, tid, key) >> 12);
             const uint32_t soff = s_soff[key >> 16];
-            cq = a.qual[(size_t)soff * 4 + cx_off];
-            cs = PHZ_SEQ_BYTE(a, soff, cx_off);
+            if (PHZ_ONEPLANE(a)) cq = a.bq[(size_t)soff * 4 + cx_off];
+            else { cq = a.qual[(size_t)soff * 4 + cx_off]; cs = PHZ_SEQ_BYTE(a, soff, cx_off); }
         }
     }
     // ---- phase 2a, second half: resolve the fast records' bases (the first one from the bytes requested above)
@@ -707,8 +739,11 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
             int sy;
             if (a.dbg & 1) sy = x & 3;
             else if (o == 0) {
-                const uint32_t q = pre_q[k], sb = (pre_s[k] >> (2 * (x & 3))) & 3;
-                sy = (int)(q & 0x7f) < a.baseq ? 4 : ((q & 0x80) ? (sb == 0 ? 4 : 5) : (int)sb);
+                if (PHZ_ONEPLANE(a)) sy = sym_from_bq(a, soff, x, pre_q[k]);
+                else {
+                    const uint32_t q = pre_q[k], sb = (pre_s[k] >> (2 * (x & 3))) & 3;
+                    sy = (int)(q & 0x7f) < a.baseq ? 4 : ((q & 0x80) ? (sb == 0 ? 4 : 5) : (int)sb);
+                }
             } else sy = masked_base(a, soff, x);
             if (sy != 4) { vmask_[k] |= 1u << o; codes_[k] |= (uint32_t)(sy < 4 ? sy : 4) << (4 * o); }
         }
@@ -727,8 +762,11 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
                 int sy;
                 if (a.dbg & 1) sy = x & 3;
                 else if (e == tid && cx_off == x) {
-                    const uint32_t sb = (cs >> (2 * (x & 3))) & 3;
-                    sy = (int)(cq & 0x7f) < a.baseq ? 4 : ((cq & 0x80) ? (sb == 0 ? 4 : 5) : (int)sb);
+                    if (PHZ_ONEPLANE(a)) sy = sym_from_bq(a, s_soff[j], x, cq);
+                    else {
+                        const uint32_t sb = (cs >> (2 * (x & 3))) & 3;
+                        sy = (int)(cq & 0x7f) < a.baseq ? 4 : ((cq & 0x80) ? (sb == 0 ? 4 : 5) : (int)sb);
+                    }
                 } else sy = masked_base(a, s_soff[j], x);
                 code = sy < 4 ? sy : (sy == 4 ? -1 : 4);
             }
@@ -824,12 +862,12 @@ __device__ __forceinline__ void map_tile(const MapBatch &bt, const int64_t gtile
 #else
 #define PHZ_MAP_OCC
 #endif
-template <int MAP_BLOCK, int RPT, bool ABL>
+template <int MAP_BLOCK, int RPT, bool ABL, bool ONE = false>
 __global__ __launch_bounds__(MAP_BLOCK) PHZ_MAP_OCC void k_map(MapBatch bt) {
     // (XCD-contiguous tile order -- workgroup i runs on XCD i % 8; every XCD given one contiguous eighth of the tiles -- was measured in
     // round 4 for k_map, k_line, k_tile and k_pairs: no gain anywhere, 1.291 against 1.282 ms here.  Neighbouring tiles share only their
     // het-SNP window, which the memory-side cache serves.)
-    map_tile<MAP_BLOCK, RPT, ABL>(bt, (int64_t)blockIdx.x);
+    map_tile<MAP_BLOCK, RPT, ABL, ONE>(bt, (int64_t)blockIdx.x);
 }
 
 // two-level exclusive prefix sum of the per-tile totals: 1024-tile chunks in parallel, then one small pass
@@ -1056,7 +1094,7 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
     for (int k = 0; k < m; k++) {
         const int i = live[(size_t)k];
         ShardDev &d = hs[k];
-        d.pos = r[i].pos; d.cigar_off = r[i].cigar_off; d.cigar = r[i].cigar; d.seq_off = r[i].seq_off; d.seq2 = r[i].seq2; d.qual = r[i].qual;
+        d.pos = r[i].pos; d.cigar_off = r[i].cigar_off; d.cigar = r[i].cigar; d.seq_off = r[i].seq_off; d.seq2 = r[i].seq2; d.qual = r[i].qual; d.bq = r[i].bq;
         d.n = r[i].n_reads; d.vpos = v[i].pos; d.nv = (int)v[i].n; d.pad = 0;
         d.o_read = out[i].read_idx; d.o_var = out[i].var_idx; d.o_code = out[i].code; d.o_aux0 = out[i].aux0; d.o_aux1 = out[i].aux1;
         if (!d.o_aux0 || !d.o_aux1) { d.o_aux0 = nullptr; d.o_aux1 = nullptr; }           // both or none
@@ -1065,6 +1103,11 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
         ntiles += (r[i].n_reads + tile_reads - 1) / tile_reads;
     }
     ht0[m] = ntiles;
+    // every shard of the submission carries the one-byte plane (a caller's choice: phz_reads.bq; PHZ_MAP_ONE_PLANE=1 for the Python host): the ONE instantiation
+    // reads it (PHZ_MAP_TWO_PLANES=1: the two-plane instantiation regardless).  Same-box A/B of the two production instantiations on the whole-genome sample:
+    // 1.0940 against 1.0928 ms -- the plane buys nothing there, so nothing in the product builds it by default
+    bool one_plane = m > 0 && getenv("PHZ_MAP_TWO_PLANES") == nullptr;
+    for (int k = 0; k < m; k++) if (!hs[k].bq) one_plane = false;
     if (ntiles >= (1ll << 31)) return phz_fail(ctx, PHZ_E_ARG, "too many tiles in one submission");
     if (m > 0x1FFF) return phz_fail(ctx, PHZ_E_ARG, "more than 8191 shards in one submission");
     const ShardDev *d_shards = (const ShardDev *)ctx->map_tab.p;
@@ -1136,6 +1179,7 @@ static int launch_map_batch(phz_ctx *ctx, int n, const phz_reads *r, const phz_v
         unsigned dyn_lds = 0;          // experiment: dynamic LDS nobody uses, to bound the workgroups per CU (PHZ_MAP_DYNLDS bytes)
         { const char *e = getenv("PHZ_MAP_DYNLDS"); if (e && atoi(e) > 0) dyn_lds = (unsigned)atoi(e); }
 #define PHZ_LAUNCH_MAP(B, R) do { if (bt.dbg) hipLaunchKernelGGL((k_map<B, R, true>), dim3((unsigned)ntiles), dim3(B), dyn_lds, sm, bt); \
+                                 else if (one_plane) hipLaunchKernelGGL((k_map<B, R, false, true>), dim3((unsigned)ntiles), dim3(B), dyn_lds, sm, bt); \
                                  else hipLaunchKernelGGL((k_map<B, R, false>), dim3((unsigned)ntiles), dim3(B), dyn_lds, sm, bt); } while (0)
         if (blk == 128) PHZ_LAUNCH_MAP(128, 2);
         else PHZ_LAUNCH_MAP(256, 2);

@@ -48,7 +48,7 @@ extern "C" int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_var
     if (int s = upload(ctx, ctx->v_pos, vars->pos, (size_t)vars->n * 4)) return s;
     dr.pos = (const int32_t *)ctx->r_pos.p; dr.cigar_off = (const uint32_t *)ctx->r_coff.p;
     dr.cigar = (const uint32_t *)ctx->r_cig.p; dr.seq_off = (const uint32_t *)ctx->r_soff.p;
-    dr.seq2 = (const uint8_t *)ctx->r_seq.p; dr.qual = (const uint8_t *)ctx->r_qual.p;
+    dr.seq2 = (const uint8_t *)ctx->r_seq.p; dr.qual = (const uint8_t *)ctx->r_qual.p; dr.bq = nullptr;
     dv.pos = (const int32_t *)ctx->v_pos.p; dv.ref_len = nullptr;
     phz_calls dc;
     dc.cap = out->cap;

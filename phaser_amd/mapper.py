@@ -8,6 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from . import soa
 from .soa import ReadShard
 
 
@@ -57,7 +58,7 @@ class Mapper:
                 raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "indel variants (ref_len != 1) are not supported by K_map yet")
         r = _lib.phz_reads(shard.n, int(shard.cigar.numel()), int(shard.seq2.numel()), _ptr(shard.pos),
                            _ptr(shard.cigar_off), _ptr(shard.cigar), _ptr(shard.seq_off), _ptr(shard.seq2),
-                           _ptr(shard.qual))
+                           _ptr(shard.qual), _ptr(soa.bq_plane(shard)) if on_gpu else None)
         v = _lib.phz_variants(int(vpos.numel()), _ptr(vpos), None)
         if cap is None:
             cap = shard.n // 2 + 4096
@@ -90,7 +91,7 @@ class Mapper:
                 raise _lib.PhzError(_lib.PHZ_E_ARG, "map_batch needs shards resident in HBM")
             vp = vp.to(sh.device).to(torch.int32).contiguous(); keep.append(vp)
             R[i] = _lib.phz_reads(sh.n, int(sh.cigar.numel()), int(sh.seq2.numel()), _ptr(sh.pos), _ptr(sh.cigar_off), _ptr(sh.cigar),
-                                  _ptr(sh.seq_off), _ptr(sh.seq2), _ptr(sh.qual))
+                                  _ptr(sh.seq_off), _ptr(sh.seq2), _ptr(sh.qual), _ptr(soa.bq_plane(sh)))
             V[i] = _lib.phz_variants(int(vp.numel()), _ptr(vp), None)
             b = [torch.empty(cap, dtype=torch.int32, device=sh.device), torch.empty(cap, dtype=torch.int32, device=sh.device),
                  torch.empty(cap, dtype=torch.uint8, device=sh.device)]

@@ -85,6 +85,34 @@ def as16_plane(shard: "ReadShard") -> Optional[torch.Tensor]:
     return x
 
 
+def bq_plane(shard: "ReadShard") -> Optional[torch.Tensor]:
+    """ONE byte per base holding both things an allele call needs (phz_reads.bq): bits 7:6 the 2-bit base, bits 5:0 min(phred, 62); 63 = escape -- a non-ACGT
+    base (quality byte with the 0x80 flag) or a phred above 62 -- for which K_map goes back to seq2 / qual.  K_map's bytes under a het SNP then come from one
+    memory line instead of two.  MEASURED (tools/ab_kmap_oneplane.py, profiles/r06/ab_kmap_oneplane_production.txt, identical call lists): the production
+    instantiation does not get faster (1.0940 -> 1.0928 ms on the whole-genome sample: the kernel is latency-, not line-bound), only the slower profiling
+    instantiation does (-3.7 %).  So the plane is OFF by default -- it would cost 6 GB per sample for nothing -- and PHZ_MAP_ONE_PLANE=1 turns it on (built
+    once per device-resident shard by an elementwise pass, kept on the shard's quality tensor)."""
+    import os
+    if shard.qual is None or shard.qual.device.type != "cuda" or os.environ.get("PHZ_MAP_ONE_PLANE") != "1":
+        return None
+    q = shard.qual
+    c = getattr(q, "_phz_bq", None)           # kept ON the quality tensor: slices of a shard (ReadShard.slice) share it, and so the plane
+    if c is not None:
+        return c
+    n = q.numel()
+    out = torch.empty(n, dtype=torch.uint8, device=q.device)
+    step = 1 << 28                            # 256 M bases at a time: the temporaries stay under 2 GB whatever the shard's size
+    shifts = torch.arange(4, device=q.device, dtype=torch.uint8) * 2
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        qq = q[lo:hi]
+        base = ((shard.seq2[lo // 4:(hi + 3) // 4].unsqueeze(1) >> shifts) & 3).reshape(-1)[:hi - lo]
+        v = (base << 6) | torch.clamp(qq & 0x7F, max=62)
+        out[lo:hi] = torch.where(((qq & 0x80) != 0) | ((qq & 0x7F) > 62), torch.full_like(qq, 63), v)
+    q._phz_bq = out
+    return out
+
+
 def pack_fixed(pos: torch.Tensor, cigar_off: torch.Tensor, cigar: torch.Tensor, seq: torch.Tensor,
                qual: torch.Tensor, qid=None, aln_score=None) -> ReadShard:
     """seq: uint8 [n, L] base codes 0..3, 4 = N;  qual: uint8 [n, L] phred."""

@@ -103,6 +103,38 @@ def test_random_vs_oracle(mapper, oracle_build, n_pairs, n_snps, baseq, seed):
         assert txt == o_t[k]
 
 
+@pytest.mark.parametrize("baseq", [10, 40, 63, 70])
+def test_one_byte_plane_equals_two_planes_and_the_oracle(oracle_build, monkeypatch, baseq):
+    """K_map's ONE instantiation (base and quality of a call from one byte: soa.bq_plane, phz_reads.bq; PHZ_MAP_ONE_PLANE=1) against its two-plane
+    instantiation (seq2 + qual, the default) and against the C oracle, on reads with everything the plane has to escape for --
+    N bases, phred values above 62 (the plane holds six quality bits) -- and with --baseq on both sides of 62."""
+    from phaser_amd import soa, synth
+    from phaser_amd.mapper import Mapper
+    v, gs, ge, w = synth.make_variants("chr1", 1, 20_000_000, 4000, 61, n_genes=160)
+    rb = synth.make_reads(v, gs, ge, w, 120_000, 62, n_rate=0.01)
+    rb = rb.select(synth.samtools_keep(rb, 255))
+    g = torch.Generator().manual_seed(63)
+    hi = torch.rand(rb.qual.shape, generator=g) < 0.2
+    rb.qual[hi] = torch.randint(60, 94, (int(hi.sum()),), generator=g, dtype=rb.qual.dtype)      # phred 60..93: around and beyond the six bits
+    o_r, o_v, o_c, _ = oracle_map_readbatch(oracle_build, rb, v.pos.numpy(), baseq, with_text=False)
+    shard = soa.pack_readbatch(rb).to("cuda")
+    got = {}
+    for mode in ("two", "one"):
+        if mode == "one":
+            monkeypatch.setenv("PHZ_MAP_ONE_PLANE", "1")          # (off by default: the plane buys the production kernel nothing, soa.bq_plane)
+            bq = soa.bq_plane(shard)
+            assert bq is not None and int(((bq & 63) == 63).sum()) > 1000          # escapes are present
+        else:
+            monkeypatch.delenv("PHZ_MAP_ONE_PLANE", raising=False)
+            assert soa.bq_plane(shard) is None
+        m = Mapper(0)
+        got[mode] = m.map(shard, v.pos, baseq).cpu()
+    for mode, c in got.items():
+        assert c.n == len(o_r) and len(o_r) > 10_000, mode
+        assert np.array_equal(c.read_idx.numpy(), o_r) and np.array_equal(c.var_idx.numpy(), o_v) and np.array_equal(c.code.numpy(), o_c), mode
+    assert np.array_equal(got["one"].aux0.numpy(), got["two"].aux0.numpy()) and np.array_equal(got["one"].aux1.numpy(), got["two"].aux1.numpy())
+
+
 @pytest.mark.parametrize("n_snps", [1500, 3000, 7800])
 def test_dense_windows_vs_oracle(mapper, oracle_build, n_snps):
     """Het SNPs packed into six short genes: the staged window of a tile holds anything from 8 to several thousand entries, so the
