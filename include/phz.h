@@ -246,6 +246,9 @@ int phz_as_histogram_batch(phz_ctx *ctx, const phz_lines *shards, int n_shards, 
 int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, int n_shards, int cap, int32_t *bins /* [cap] */, int64_t *counts /* [cap] */,
                             int32_t *n_bins);
 
+/* DEVICE arrays: the AS column + has-AS flag (NULL = every record has one) of a shard -> the 2-byte plane of phz_lines.read_as16.  Enqueued on the ctx stream, no
+ * host wait (its consumers run on the same stream). */
+int phz_as_plane(phz_ctx *ctx, const int32_t *aln, const uint8_t *has_as, int64_t n, int16_t *out);
 /* ... and the whole of phaser.py:545-553 for one BAM in one call and one host wait: histogram of its shards' AS column on the device, occupied bins back,
  * numpy.percentile(scores, q_percent) (default linear method, the same float64 operations) computed natively.  *found = 0: no record carries an AS tag.
  * PHZ_E_CAPACITY: more than 4,096 distinct scores (take phz_as_histogram_batch and the host formula then). */

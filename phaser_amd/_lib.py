@@ -233,6 +233,7 @@ SYMBOLS = {
     "phz_pyorder_free": (None, [C.c_void_p]),
     "phz_py_str_hash": (C.c_int64, [C.c_char_p, C.c_int64]),
     "phz_py_set_order": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "phz_as_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "phz_as_cutoff": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.POINTER(phz_tally_sizes), C.c_int]),

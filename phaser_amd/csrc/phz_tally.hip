@@ -1217,6 +1217,22 @@ extern "C" int phz_as_histogram_sparse(phz_ctx *ctx, const phz_lines *shards, in
     return PHZ_OK;
 }
 
+// the AS column of a shard as the 2-byte plane (phz_lines.read_as16): what a producer that only has the 4-byte column + flag calls once per shard
+__global__ __launch_bounds__(256) void k_as16(const int32_t *aln, const uint8_t *has, int64_t n, int16_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int a = aln[i];
+    out[i] = (has && !has[i]) ? (int16_t)PHZ_AS16_NONE : (int16_t)(a >= PHZ_AS16_RANGE ? PHZ_AS16_RANGE : (a <= -PHZ_AS16_RANGE ? -PHZ_AS16_RANGE : a));
+}
+extern "C" int phz_as_plane(phz_ctx *ctx, const int32_t *aln, const uint8_t *has_as, int64_t n, int16_t *out) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || n < 0 || (n && (!aln || !out))) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    if (n) hipLaunchKernelGGL(k_as16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, aln, has_as, n, out);
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;          // (no wait: the consumers -- phz_as_cutoff, phz_tally -- run on the same stream)
+}
+
 // numpy.percentile(scores, q) (the default "linear" method: numpy/lib/_function_base_impl.py _quantile / _lerp; the reference's call at
 // phaser.py:551) over the multiset {bin - 32768 repeated count times}, from the occupied bins in ascending order: the same float64 operations on the
 // two neighbouring order statistics (engine.percentile_from_band is the Python twin, pinned against numpy in the tests)

@@ -165,7 +165,7 @@ class Engine:
             calls = self.mapper.map(shard, vpos, self.cfg.baseq, torch.from_numpy(cv.ref_len))
         has_as = shard.has_as
         self.shards[chrom][bam_index] = _Shard(calls, shard.qid.contiguous(), shard.aln_score.contiguous(),
-                                               None if has_as is None else has_as.contiguous(), shard.n, as16_plane(shard))
+                                               None if has_as is None else has_as.contiguous(), shard.n, as16_plane(shard, self.ctx if getattr(self, "lib", None) is not None else None))
         self.n_qid[chrom] = max(self.n_qid[chrom], n_qid)
         if qnames is not None:
             self.qnames[chrom] = qnames
@@ -187,7 +187,7 @@ class Engine:
         """Attach a shard whose K_map call list already exists."""
         has_as = shard.has_as
         self.shards[chrom][bam_index] = _Shard(calls, shard.qid.contiguous(), shard.aln_score.contiguous(),
-                                               None if has_as is None else has_as.contiguous(), shard.n, as16_plane(shard))
+                                               None if has_as is None else has_as.contiguous(), shard.n, as16_plane(shard, self.ctx if getattr(self, "lib", None) is not None else None))
         self.n_qid[chrom] = max(self.n_qid[chrom], n_qid)
         if qnames is not None:
             self.qnames[chrom] = qnames

@@ -66,7 +66,7 @@ AS16_NONE = -32768          # phz.h PHZ_AS16_NONE / PHZ_AS16_RANGE
 AS16_RANGE = 32767
 
 
-def as16_plane(shard: "ReadShard") -> Optional[torch.Tensor]:
+def as16_plane(shard: "ReadShard", ctx=None) -> Optional[torch.Tensor]:
     """The shard's AS column as ONE 2-byte plane with the has-AS flag folded in (SURVEY.md 8(a) M1 `as:int16`; phz_lines.read_as16): what the
     AS histogram and the per-line pass of K_tally gather per call line -- 2 bytes on one memory line instead of 4 + 1 on two.  AS16_NONE = no
     AS tag; a value outside [-32766, 32766] becomes +-AS16_RANGE and is refused by the histogram like any value outside int16.  Built once per
@@ -77,10 +77,19 @@ def as16_plane(shard: "ReadShard") -> Optional[torch.Tensor]:
     c = shard.__dict__.get("_as16")
     if c is not None and c[0] is a and c[1] is shard.has_as:
         return c[2]
-    x = a.clamp(-AS16_RANGE, AS16_RANGE).to(torch.int16)
-    if shard.has_as is not None:
-        x = x.masked_fill(shard.has_as == 0, AS16_NONE)
-    x = x.contiguous()
+    if ctx is not None and a.device.type == "cuda" and a.dtype == torch.int32 and a.is_contiguous() and (shard.has_as is None or shard.has_as.is_contiguous()):
+        # libphz's own one-line kernel on the ctx stream (the consumers' stream): torch's elementwise kernels would do, but the first of them in a
+        # fresh process pays ~90 ms of lazy code-object loading -- the CLI's "H2D + K_map" stage went from 0.02 to 0.11 s on that alone
+        import ctypes as C
+        x = torch.empty(a.numel(), dtype=torch.int16, device=a.device)
+        torch.cuda.current_stream(a.device).synchronize()          # the column may have been produced on torch's stream
+        ctx.check(ctx.lib.phz_as_plane(ctx.h, C.c_void_p(a.data_ptr()), None if shard.has_as is None else C.c_void_p(shard.has_as.data_ptr()), a.numel(),
+                                         C.c_void_p(x.data_ptr())))
+    else:
+        x = a.clamp(-AS16_RANGE, AS16_RANGE).to(torch.int16)
+        if shard.has_as is not None:
+            x = x.masked_fill(shard.has_as == 0, AS16_NONE)
+        x = x.contiguous()
     shard.__dict__["_as16"] = (a, shard.has_as, x)
     return x
 
