@@ -510,10 +510,11 @@ int phz_phase_block(int32_t n, int64_t n_edges, const int32_t *edge_i, const int
 /* ---- device row stage: stages T7-O2 of the phasing path on the GPU, on the results phz_tally left in HBM --------------------
  * What it replaces in the reference (phaser/phaser.py): the bookkeeping of test_variant_connection :1594-1654 (the binomial p-value
  * itself stays the caller's scipy call, evaluated once per distinct argument pair), pruning :686-726, build_haplotypes :1861-1882,
- * phase_v3 :2107-2324, the output loops :691-695, :737-749, :865-1239.  The host twin is phz_rows_format_multi above; it still serves
- * the options this stage declines with PHZ_E_UNSUPPORTED (--gw_phase_method 1, --output_read_ids 1).  No size of a component, a block or
- * the read-count pairs sends a pass to it: components beyond the phasing kernel's limits are phased by the host routine inside the call
- * (that component only), the pair-key table grows on demand (PHZ_E_CAPACITY -> phz_rowsdev_set_pair_slots).
+ * phase_v3 :2107-2324, the output loops :691-695, :737-749, :865-1239.  The host twin is phz_rows_format_multi above; this stage declines
+ * no option of the reference any more (--gw_phase_method 1 since round 5, --output_read_ids 1 since round 6: the QNAME lists of :1120-1123 /
+ * :1196-1204 in first-appearance order, the canonical form of those Python sets).  No size of a component, a block or the read-count pairs
+ * sends a pass to the host twin: components beyond the phasing kernel's limits are phased by the host routine inside the call (that component
+ * only), the pair-key table grows on demand (PHZ_E_CAPACITY -> phz_rowsdev_set_pair_slots).
  *
  *   phz_rowsdev_create     upload the per-variant tables of this rank's chromosomes (joint variant index space of phz_tally)
  *   phz_rowsdev_pair_keys  stage 1: the distinct (total, supporting) read-count pairs of the pairs under test -> host
@@ -550,6 +551,11 @@ typedef struct {
     const int32_t *shard_bam;
     int32_t unique_ids, gw_phase_method, output_read_ids, unphased_vars, max_block_size, want_vcf;
     double cc_threshold;
+    /* only read when output_read_ids == 1: the QNAMEs behind the template ids of the tally's read lists.  Template ids are per chromosome (phz_intern*),
+     * so the names of all chromosomes sit in ONE string pool, chromosome after chromosome in the order of phz_rowsdev_tables, and
+     * qname_base[c] = pool item of template id 0 of chromosome c ([n_chroms + 1]; the last entry = number of pool items). */
+    const uint32_t *qname_off; const char *qname;
+    const int64_t *qname_base;
 } phz_rowsdev_opts;
 
 typedef struct {

@@ -134,7 +134,8 @@ class phz_rowsdev_opts(C.Structure):
     _fields_ = [("n_bams", C.c_int32), ("bam_name_off", C.c_void_p), ("bam_names", C.c_void_p), ("bam_excluded", C.c_void_p),
                 ("n_shards", C.c_int32), ("shard_line_lo", C.c_void_p), ("shard_line_hi", C.c_void_p), ("shard_bam", C.c_void_p),
                 ("unique_ids", C.c_int32), ("gw_phase_method", C.c_int32), ("output_read_ids", C.c_int32), ("unphased_vars", C.c_int32),
-                ("max_block_size", C.c_int32), ("want_vcf", C.c_int32), ("cc_threshold", C.c_double)]
+                ("max_block_size", C.c_int32), ("want_vcf", C.c_int32), ("cc_threshold", C.c_double),
+                ("qname_off", C.c_void_p), ("qname", C.c_void_p), ("qname_base", C.c_void_p)]
 
 
 class phz_rowsdev_result(C.Structure):

@@ -19,6 +19,7 @@
 #include <string>
 #include <string_view>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "phz.h"
@@ -600,9 +601,15 @@ void run_singles(const Ctx &C, int64_t lo, int64_t hi, TextChunk &o) {
                 if (I.bam_excluded && I.bam_excluded[b]) continue;
                 for (int k = 0; k < 2; k++) {
                     int64_t m; const int32_t *src = C.rl(g, k, b, &m);
-                    q[k].assign(src, src + m);
-                    std::sort(q[k].begin(), q[k].end());
-                    q[k].erase(std::unique(q[k].begin(), q[k].end()), q[k].end());
+                    if (I.output_read_ids == 1) {          // the QNAMEs are listed: first-appearance order (what the block rows and the device stage write)
+                        std::unordered_set<int32_t> seen;
+                        q[k].clear();
+                        for (int64_t t = 0; t < m; t++) if (seen.insert(src[t]).second) q[k].push_back(src[t]);
+                    } else {
+                        q[k].assign(src, src + m);
+                        std::sort(q[k].begin(), q[k].end());
+                        q[k].erase(std::unique(q[k].begin(), q[k].end()), q[k].end());
+                    }
                 }
                 const long long n0 = (long long)q[0].size(), n1 = (long long)q[1].size();
                 if (n0 + n1 <= 0) continue;

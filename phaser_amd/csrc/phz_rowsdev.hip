@@ -213,6 +213,9 @@ struct RD {
     const unsigned long long *cfg_base; const uint32_t *cfg_chunk;
     const uint32_t *cfg_pl, *cfg_pb; const unsigned long long *cfg_ps, *cfg_bbase;      // allele_config byte offsets in closed form (k_cfg_prefix)
     const MemRec *mrec; const uint32_t *lab_e, *lab_skip; int64_t nmem;       // lab_*[(h * nb + bam) * nmem + member]: read list and room for its label text
+    // --output_read_ids 1: QNAME pool over all chromosomes, first item of every chromosome, "first of its QNAME" flags per read-list entry for the
+    // (block, haplotype, BAM) segments (isf0) and for the single (variant, allele, BAM) lists (isf2)
+    int read_ids; PoolD qn; const long long *qbase; const uint8_t *isf0, *isf2;
 };
 
 // strings of a block member through its record; a string of 64 KB or more (a structural variant's allele) does not fit the record's 16-bit lengths:
@@ -300,6 +303,20 @@ struct RowSingleAse {
         s.num(n0); s.ch('\t'); s.num(n1); s.ch('\t'); s.num(n0 + n1); s.ch('\t');
         put_vcf_phase(D, g, s, true);
         s.lit("\t1\t");
+        if (D.read_ids) {          // set(haplo_reads[allele][bam]) of :1196-1204 as QNAME strings, first-appearance order (the canonical form of the set)
+            const long long q0 = D.qbase[D.vchrom[g]];
+            for (int k = 0; k < 2; k++) {
+                const int64_t e = (2 * g + k) * D.nb + b;
+                bool first = true;
+                for (uint32_t p = D.rl_start[e]; p < D.rl_start[e + 1]; p++) {
+                    if (!D.isf2[p]) continue;
+                    if (!first) s.ch(',');
+                    first = false;
+                    s.pool(D.qn, q0 + D.rl_qid[p]);
+                }
+                s.ch('\t');
+            }
+        }
         s.pool(D.maft, g); s.ch('\t'); s.pool(D.bamn, b); s.lit("\t\t\n");
     }
 };
@@ -379,6 +396,25 @@ struct RowAse {
         const int c00 = cm == 0 ? (int)R[0].ph[0] : (cm == 1 ? 0 : 1);
         if (c00 == 0) s.lit("0|1"); else if (c00 == 1) s.lit("1|0"); else s.lit("0/1");
         s.ch('\t'); put_stat(D, (int)b, s); s.ch('\t');
+        if (D.read_ids) {          // hap_a_reads / hap_b_reads of :1120-1123: the haplotype's read set in this BAM as QNAME strings, first-appearance order.
+            // A plain loop over the read-list entries (identical on every lane of a wave sink: lane 0 stores): a debugging option, not a hot row
+            const long long q0 = D.qbase[D.vchrom[g0]];
+            for (int h = 0; h < 2; h++) {
+                const size_t lab0 = (size_t)(h * D.nb + bb) * (size_t)D.nmem + m0;
+                bool first = true;
+                for (uint32_t t = 0; t < n; t++) {
+                    if (R[t].black) continue;
+                    const uint32_t e = D.lab_e[lab0 + t];
+                    for (uint32_t p = D.rl_start[e]; p < D.rl_start[e + 1]; p++) {
+                        if (!D.isf0[p]) continue;
+                        if (!first) s.ch(',');
+                        first = false;
+                        s.pool(D.qn, q0 + D.rl_qid[p]);
+                    }
+                }
+                s.ch('\t');
+            }
+        }
         s.pool(D.maft, D.blk_maxmaf[b]); s.ch('\t'); s.pool(D.bamn, bb); s.ch('\t');
         for (int h = 0; h < 2; h++) {
             const size_t lab0 = (size_t)(h * D.nb + bb) * (size_t)D.nmem + m0;
@@ -1553,6 +1589,7 @@ struct SG {
     uint32_t *overflow;                                           // pool overflow seen by ANY mode of this attempt
     uint32_t *pool; uint32_t pool_cap;
     const uint32_t *lab_e; int64_t nmem;        // read list of (haplotype, BAM, block member): one load instead of mem_s -> v_alle -> index arithmetic
+    uint8_t *isf;                                // --output_read_ids 1 (modes 0 and 2): item p is the FIRST of its QNAME in its segment (else nullptr)
 };
 template <int MODE> __device__ __forceinline__ uint32_t seg_pieces(const SG &G, int64_t seg) {      // number of pieces (some may be empty / skipped)
     if (MODE == 2) return 1;
@@ -1634,12 +1671,18 @@ template <int MODE> __global__ __launch_bounds__(64) void k_seg_small(SG G) {
 #pragma unroll
     for (int i = 0; i < SEG_SMALL; i++) s_l[tid][i] = (uint8_t)lab[i];
     G.ns[seg] = cnt;
-    if (MODE == 0) {
+    if (MODE == 0 || (MODE == 2 && G.isf)) {
+        // an item is the first of its QNAME exactly when its label is one more than every label before it (labels count first appearances)
         idx = 0;
+        uint32_t seen_n = 0;
         for (uint32_t t = 0; t < np; t++) {
             uint32_t lo, hi;
             if (!seg_piece<MODE>(G, seg, t, &lo, &hi)) continue;
-            for (uint32_t p = lo; p < hi; p++) G.labels[p] = s_l[tid][idx++];
+            for (uint32_t p = lo; p < hi; p++) {
+                const uint32_t l = s_l[tid][idx++];
+                if (MODE == 0) G.labels[p] = l;
+                if (G.isf) { const bool f = l == seen_n; G.isf[p] = f ? 1 : 0; seen_n += f ? 1u : 0u; }
+            }
         }
     }
 }
@@ -1745,10 +1788,12 @@ template <int MODE, int SLOTS, int THREADS, bool HUGE> __device__ void seg_big_o
         __syncthreads();
     }
     if (tid == 0) G.ns[seg] = s_carry;
-    if (MODE == 0)
+    if (MODE == 0 || (MODE == 2 && G.isf))
         for (uint32_t idx = tid; idx < M; idx += THREADS) {
             const uint32_t p = item_pos(idx);
-            G.labels[p] = rank[slot_of((uint32_t)G.rl_qid[p])];
+            const uint32_t slot = slot_of((uint32_t)G.rl_qid[p]);
+            if (MODE == 0) G.labels[p] = rank[slot];
+            if (G.isf) G.isf[p] = first[slot] == idx ? 1 : 0;
         }
 }
 // The segments of a list (mid: one wave each, large / huge: one workgroup each) taken in ticket order by a fixed number of workgroups; the list's length is
@@ -1864,6 +1909,7 @@ struct phz_rowsdev {
     DevBuf labels, seg_ns, blk_cnt, single_n, big_list, big_list2, huge_list, big_stat, px_off, px_txt, pool, tl, its, piece_dst, rowlen;
     DevBuf off[PHZ_TXT_COUNT], seg_off_d[PHZ_TXT_COUNT], text[PHZ_TXT_COUNT];
     DevBuf o_var, o_maxmaf, o_hap, o_cor;
+    DevBuf qn_off, qn_txt, qn_base, isf0, isf2;      // --output_read_ids 1
     // results (host)
     int64_t bytes[PHZ_TXT_COUNT] = {0};
     std::vector<int64_t> seg_off[PHZ_TXT_COUNT];
@@ -1879,7 +1925,7 @@ struct phz_rowsdev {
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
                                    &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &cfg_pl, &cfg_pb, &cfg_ps, &cfg_bytes, &cfg_bbase, &blk_voff, &mrec, &lab_e, &lab_skip, &big_blk, &labels,
-                                   &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &huge_list, &big_stat, &px_off, &px_txt, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor};
+                                   &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &huge_list, &big_stat, &px_off, &px_txt, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor, &qn_off, &qn_txt, &qn_base, &isf0, &isf2};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
         return v;
@@ -2177,7 +2223,8 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     if (h->pre_done && h->pre_gen != ctx->tally_gen) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run: the resident tally changed since phz_rowsdev_pair_keys (call it again)");
     if (T.nv != h->nv || T.nb != o->n_bams) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not match (variants / BAMs)");
     if (o->gw_phase_method != 0 && o->gw_phase_method != 1) return phz_fail(ctx, PHZ_E_ARG, "device row stage: gw_phase_method must be 0 or 1");
-    if (o->output_read_ids) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "device row stage: --output_read_ids 1 is formatted by the host stage");
+    const bool read_ids = o->output_read_ids != 0;
+    if (read_ids && (!o->qname_off || !o->qname || !o->qname_base)) return phz_fail(ctx, PHZ_E_ARG, "device row stage: --output_read_ids 1 needs the QNAME pool (qname_off / qname / qname_base)");
     if (!T.rl_list && T.n_rl) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally carries no list index per read-list entry");
     PHZ_HIP(ctx, hipSetDevice(ctx->device));
     memset(res, 0, sizeof(*res));
@@ -2205,6 +2252,13 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     const double *d_slot_pv = (const double *)(upd + up_off[0]); const uint32_t *d_pv_off = (const uint32_t *)(upd + up_off[1]); const char *d_pv_txt = upd + up_off[2];
     const uint32_t *d_bam_off = (const uint32_t *)(upd + up_off[3]); const char *d_bam_txt = upd + up_off[4]; const uint8_t *d_bam_excl = (const uint8_t *)(upd + up_off[5]);
     const long long *d_sh_lo = (const long long *)(upd + up_off[6]), *d_sh_hi = (const long long *)(upd + up_off[7]); const int32_t *d_sh_bam = (const int32_t *)(upd + up_off[8]);
+    if (read_ids) {          // (a debugging option: plain uploads)
+        const size_t nq = (size_t)o->qname_base[nchrom];
+        if (int s = up(ctx, h->qn_off, o->qname_off, (nq + 1) * 4)) return s;
+        if (int s = up(ctx, h->qn_txt, o->qname, (size_t)o->qname_off[nq])) return s;
+        if (int s = up(ctx, h->qn_base, o->qname_base, (size_t)(nchrom + 1) * 8)) return s;
+        PHZ_HIP(ctx, hipStreamSynchronize(sm));          // the caller's arrays are pageable
+    }
     // ---- pruning (:686-700) + components
 #define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, h->buf, (bytes))) return s_; } while (0)
     RSV(keep, NE); RSV(e_slot, NE * 4); RSV(deg, NV * 4); RSV(parent, NV * 4); RSV(label, NV * 4);
@@ -2376,7 +2430,8 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     const bool need_all = nb > 1 || h->has_black;
     RSV(labels, NR * 4); RSV(seg_ns, (size_t)(nblocks + 1) * 2 * nb * 4); RSV(big_list, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4); RSV(big_list2, std::max((size_t)(nblocks + 1) * 2 * nb, NRL) * 4 + 4);
     if (need_all) RSV(blk_cnt, (size_t)(nblocks + 1) * 2 * 4);
-    if (nb > 1) RSV(single_n, NRL * 4);
+    if (nb > 1 || read_ids) RSV(single_n, NRL * 4);
+    if (read_ids) { RSV(isf0, NR); RSV(isf2, NR); }
     if (h->pool.cap == 0) RSV(pool, (size_t)12 << 20);
     RSV(lab_e, (size_t)(nmem + 1) * 2 * nb * 4);
     RSV(huge_list, ((size_t)(nmem / (STAT_N + 1) + 2) * 2 * (size_t)nb + 16) * 4);
@@ -2385,6 +2440,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     uint32_t h_nbig = 0, h_phased = 0, h_nbs = 0;
     for (int attempt = 0;; attempt++) {
         PHZ_HIP(ctx, hipMemsetAsync(h->labels.p, 0, NR * 4, sm));
+        if (read_ids) { PHZ_HIP(ctx, hipMemsetAsync(h->isf0.p, 0, NR, sm)); PHZ_HIP(ctx, hipMemsetAsync(h->isf2.p, 0, NR, sm)); }
         if (nmem) hipLaunchKernelGGL(k_lab_e, dim3(nblk(nmem * 2 * nb)), dim3(256), 0, sm, nmem, nb, (const uint32_t *)h->mem_s.p, (const uint8_t *)h->v_alle.p, P<uint32_t>(h->lab_e));
         SG sg; sg.nb = nb; sg.lab_e = P<uint32_t>(h->lab_e); sg.nmem = nmem; sg.mem_s = P<uint32_t>(h->mem_s); sg.blk_mstart = P<uint32_t>(h->blk_mstart); sg.blk_len = P<uint32_t>(h->blk_len); sg.v_alle = P<uint8_t>(h->v_alle);
         sg.black = h->has_black ? P<uint8_t>(h->d_black) : nullptr; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.labels = P<uint32_t>(h->labels);
@@ -2395,7 +2451,8 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         PHZ_HIP(ctx, hipMemsetAsync(cnt32 + 32, 0, 3 * 64, sm));          // every mode has its own counters: [0..3] list lengths / pool cursor, [4] huge segments, [5..7] tickets -- nothing is
         for (int mode = 0; mode < 3; mode++) {                             // overwritten, so all of it is read back at the ONE wait below
             if (mode == 1 && !need_all) continue;
-            if (mode == 2 && nb <= 1) continue;
+            if (mode == 2 && nb <= 1 && !read_ids) continue;
+            sg.isf = !read_ids ? nullptr : (mode == 0 ? P<uint8_t>(h->isf0) : (mode == 2 ? P<uint8_t>(h->isf2) : nullptr));
             sg.nseg = mode == 0 ? nblocks * 2 * nb : (mode == 1 ? nblocks * 2 : (int64_t)NRL);
             sg.ns = mode == 0 ? P<uint32_t>(h->seg_ns) : (mode == 1 ? P<uint32_t>(h->blk_cnt) : P<uint32_t>(h->single_n));
             if (sg.nseg == 0) continue;
@@ -2480,6 +2537,8 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     D.blk_maxmaf = P<int32_t>(h->maxmaf); D.its = P<uint32_t>(h->its); D.labels = P<uint32_t>(h->labels); D.piece_dst = P<unsigned long long>(h->piece_dst);
     D.cfg_base = P<unsigned long long>(h->cfg_base);
     D.nmem = nmem;
+    D.read_ids = read_ids ? 1 : 0;
+    if (read_ids) { D.qn.off = P<uint32_t>(h->qn_off); D.qn.b = P<char>(h->qn_txt); D.qbase = P<long long>(h->qn_base); D.isf0 = P<uint8_t>(h->isf0); D.isf2 = P<uint8_t>(h->isf2); }
     RSV(mrec, (size_t)(nmem + 1) * sizeof(MemRec)); RSV(lab_e, (size_t)(nmem + 1) * 2 * nb * 4); RSV(lab_skip, (size_t)(nmem + 1) * 2 * nb * 4);
     D.mrec = P<MemRec>(h->mrec); D.lab_e = P<uint32_t>(h->lab_e); D.lab_skip = P<uint32_t>(h->lab_skip);
     if (nmem) {

@@ -194,7 +194,7 @@ def _main(argv, state):
     # the host region that will receive the row text is page-locked on a helper thread while the VCF is read (~0.1 s per GB, independent of
     # everything else); sized from the BAMs, grown later if it turns out too small
     arena = None
-    if args.output_read_ids == 0 and not any(b.endswith(".sam") for b in args.bam.split(",")) and os.environ.get("PHZ_EARLY_ARENA", "1") == "1":
+    if not any(b.endswith(".sam") for b in args.bam.split(",")) and os.environ.get("PHZ_EARLY_ARENA", "1") == "1":
         import threading
 
         def _arena():
@@ -360,7 +360,7 @@ def _main(argv, state):
     mine = set(eng.chrom_list)
     # While the BAMs are read: the per-variant tables of the row stage go to the GPU (0.07 s at genome scale, independent of the reads)
     warm = None
-    if not any_sam and cfg.device_rows and args.output_read_ids == 0:          # (what rowsdev.supported() accepts)
+    if not any_sam and cfg.device_rows:
         import threading
 
         def _warm():

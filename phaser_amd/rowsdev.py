@@ -264,7 +264,7 @@ def binom_cdf(k: np.ndarray, n: np.ndarray, p: float) -> np.ndarray:
 
 
 def supported(cfg) -> bool:
-    return cfg.output_read_ids == 0          # --output_read_ids 1 (QNAME strings in the rows, a debugging aid) is the one option left to the host stage
+    return True          # every option of the reference is formatted on the device (round 5: --gw_phase_method 1; round 6: --output_read_ids 1)
 
 
 def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
@@ -319,6 +319,15 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     lo = np.array([x[0] for x in sh], dtype=np.int64); hi = np.array([x[1] for x in sh], dtype=np.int64); sb = np.array([x[2] for x in sh], dtype=np.int32)
     o = _lib.phz_rowsdev_opts(nb, _vp(bam_off), _vp(bam_txt), _vp(ex), len(sh), _vp(lo), _vp(hi), _vp(sb), int(cfg.unique_ids), int(cfg.gw_phase_method),
                               int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.max_block_size), 1 if (cfg.want_vcf or cfg.py_hash_order) else 0, float(cfg.cc_threshold))
+    if cfg.output_read_ids == 1:
+        # the QNAME strings behind the template ids (phaser.py:1120-1123, :1196-1204): template ids are per chromosome, the pool lists the chromosomes' names one after the other
+        names = []; qbase = np.zeros(len(eng.chrom_list) + 1, dtype=np.int64)
+        for ci, c in enumerate(eng.chrom_list):
+            names.extend(eng.qnames.get(c) or [])          # (a chromosome without a read in any BAM has no QNAME table)
+            qbase[ci + 1] = len(names)
+        q_off, q_txt = sep_pool(names)
+        o.qname_off = _vp(q_off); o.qname = _vp(q_txt); o.qname_base = _vp(qbase)
+        _keep_q = (q_off, q_txt, qbase)
     R = _lib.phz_rowsdev_result()
     t2b = _t.perf_counter()
     ctx.check(lib.phz_rowsdev_run(ctx.h, T.h, C.byref(o), _vp(slot_pv), _vp(txt_off), _vp(txt), C.byref(R)))

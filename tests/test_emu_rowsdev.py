@@ -64,18 +64,16 @@ def _inputs(case, gold, c1_inputs):
 def test_device_rows_match_reference(emu, case, gold, load, cfg, c1_inputs):
     d, vcf_text, bams = _inputs(case, gold, c1_inputs)
     out, eng = run_stages(emu, case, load, cfg, vcf_text, bams)
-    declined = cfg.get("output_read_ids", 0) == 1
-    assert eng.rows_path == ("host" if declined else "device"), getattr(eng, "rows_fallback", "")
+    assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")          # no option is declined (--output_read_ids 1 included, since round 6)
     for name in OUTPUTS:
         want = gz_text(os.path.join(d, "out.%s.txt.gz" % name))
         assert canonical(name, out[name]) == canonical(name, want), name
-    if not declined:
-        # the two row stages agree byte for byte, row order included
-        host, heng = run_stages(emu, case, load, cfg, vcf_text, bams, device_rows=False)
-        assert heng.rows_path == "host"
-        for name in OUTPUTS:
-            assert out[name] == host[name], name
-        assert eng.phased == heng.phased and eng.log == heng.log
+    # the two row stages agree byte for byte, row order included (and the order of the QNAME lists of --output_read_ids 1: first appearance)
+    host, heng = run_stages(emu, case, load, cfg, vcf_text, bams, device_rows=False)
+    assert heng.rows_path == "host"
+    for name in OUTPUTS:
+        assert out[name] == host[name], name
+    assert eng.phased == heng.phased and eng.log == heng.log
 
 
 def test_rows_of_a_block_of_150_variants_by_wave_and_by_thread():

@@ -222,7 +222,7 @@ def test_fresh_seed_vs_oracle(mapper, oracle_build, tmp_path, seed, err):
 @pytest.mark.parametrize("read_ids", [0, 1])
 def test_chromosome_without_reads_in_any_bam(mapper, oracle_build, tmp_path, read_ids):
     """Three chromosomes in the VCF, two BAMs: the middle chromosome has het SNPs but no read in either BAM (no shard, no QNAME table), the first one has
-    reads only in the second BAM.  Device row stage (read_ids 0) and the host twin with the QNAME columns (--output_read_ids 1) vs the pinned oracle."""
+    reads only in the second BAM.  Device row stage without and with the QNAME columns (--output_read_ids 1) vs the pinned oracle."""
     import subprocess
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import phasing_oracle as po
@@ -239,7 +239,7 @@ def test_chromosome_without_reads_in_any_bam(mapper, oracle_build, tmp_path, rea
             bams[bam][chrom] = "" if empty else "\n".join(synth.sam_lines(rf, contigs)) + "\n"
     vcf_text = "\n".join(synth.vcf_lines(vs)) + "\n"
     got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=8, output_read_ids=read_ids)
-    assert eng.rows_path == ("device" if read_ids == 0 else "host")
+    assert eng.rows_path == "device"
     pool, _, _ = po.load_vcf(vcf_text)
     ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=8, output_read_ids=read_ids)
     for bam, per_chrom in bams.items():
@@ -256,12 +256,13 @@ def test_chromosome_without_reads_in_any_bam(mapper, oracle_build, tmp_path, rea
     assert eng.phased == ph.phased and eng.phased > 30
 
 
-@pytest.mark.parametrize("seed,err,pairs,mbs", [(9101, 0.004, 30000, 15), (9102, 0.06, 14000, 6)])
-def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pairs, mbs):
+@pytest.mark.parametrize("seed,err,pairs,mbs,read_ids", [(9101, 0.004, 30000, 15, 0), (9102, 0.06, 14000, 6, 0), (9103, 0.01, 9000, 10, 1)])
+def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pairs, mbs, read_ids):
     """Few genes, thousands of reads over every het SNP, two BAMs with shared QNAMEs: read sets of thousands of QNAMEs per haplotype (the
     workgroup / global-table paths of the read-set kernels), rows with tens of kilobytes of labels (the direct write path), long blocks and,
     with 6 % base errors, conflicting components (weak-point split, brute force, stitching on the GPU).  Product vs the pinned oracle, and the
-    device row stage vs the host row stage byte for byte."""
+    device row stage vs the host row stage byte for byte.  The third case writes the QNAME columns of --output_read_ids 1 on the device: read sets of
+    thousands of QNAMEs listed by the wave / workgroup read-set kernels' first-appearance flags."""
     import subprocess
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import phasing_oracle as po
@@ -275,14 +276,14 @@ def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pair
         rf = rb.select(synth.samtools_keep(rb, 255))
         bams[bam][chrom] = "\n".join(synth.sam_lines(rf, contigs)) + "\n"
     vcf_text = "\n".join(synth.vcf_lines([v])) + "\n"
-    got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs)
+    got, eng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs, output_read_ids=read_ids)
     assert eng.rows_path == "device", getattr(eng, "rows_fallback", "")
-    host, heng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs, device_rows=False)
+    host, heng = run_product(mapper, vcf_text, bams, "cuda", max_block_size=mbs, device_rows=False, output_read_ids=read_ids)
     assert heng.rows_path == "host"
     for name in OUTPUTS:
         assert got[name] == host[name], name
     pool, _, _ = po.load_vcf(vcf_text)
-    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs, output_read_ids=read_ids)
     for bam, per_chrom in bams.items():
         texts = []
         for c in pool:
@@ -325,7 +326,7 @@ def test_dense_variants_vs_oracle(mapper, oracle_build, tmp_path, seed, n_snps, 
     for name in OUTPUTS:
         assert got[name] == host[name], (name, eng.rows_path)
     pool, _, _ = po.load_vcf(vcf_text)
-    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs, output_read_ids=read_ids)
     for bam, per_chrom in bams.items():
         texts = []
         for c in pool:
