@@ -99,15 +99,20 @@ inline uint8_t base_code(std::string_view s) {
     switch (s[0]) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 255; }
 }
 
-void parse_lines(const char *text, const std::vector<int64_t> &ls, size_t lo, size_t hi, const phz_vcf_opts &O, const BedIndex &drop,
+// the lines that START in [b0, b1) (both line starts, or the end of the text): every worker finds its own line ends -- a line index over the whole text
+// (75 MB of memchr and a 12 MB vector on one thread) was a tenth of the call
+void parse_lines(const char *text, int64_t len, int64_t b0, int64_t b1, const phz_vcf_opts &O, const BedIndex &drop,
                  const BedIndex &mark, Chunk &c) {
     std::vector<std::string_view> f, fmt, sf, alts, every, info, ind, ph, afs_s;
     std::vector<char> g;
     std::vector<double> afs;
     const std::string_view coi(O.chrom_of_interest ? O.chrom_of_interest : ""), prefix(O.chr_prefix ? O.chr_prefix : ""),
         sep(O.id_separator ? O.id_separator : "_"), af_field(O.gw_af_field ? O.gw_af_field : "AF");
-    for (size_t li = lo; li < hi; li++) {
-        const char *p = text + ls[li]; const char *e = text + ls[li + 1] - 1;
+    for (int64_t at = b0; at < b1;) {
+        const char *p = text + at;
+        const char *e = (const char *)memchr(p, '\n', (size_t)(len - at));
+        if (!e) e = text + len;
+        at = (int64_t)(e - text) + 1;
         if (e <= p || *p == '#') continue;
         split(std::string_view(p, (size_t)(e - p)), '\t', f);
         if (O.grep_hom) {      // cut -f 1-9,S | grep -v '0|0\|1|1' (phaser.py:220-225): the pattern anywhere in those columns drops the line
@@ -266,16 +271,17 @@ extern "C" int phz_vcf_parse(const char *text, int64_t len, const phz_vcf_opts *
     if (!text || len < 0 || !opts || !out) return PHZ_E_ARG;
     phz_vcf *h = new phz_vcf();
     *out = h;
-    std::vector<int64_t> ls(1, 0);
-    for (const char *p = text, *e = text + len; p < e;) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
-        if (!nl) { ls.push_back(len + 1); break; }
-        ls.push_back((int64_t)(nl - text) + 1); p = nl + 1;
-    }
-    const size_t nlines = ls.size() - 1;
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, opts->threads), (nlines + 8191) / 8192));
-    const size_t nchunks = nlines ? (size_t)nt * 4 : 0;
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, opts->threads), ((size_t)len + (400u << 10) - 1) / (400u << 10)));      // ~8,000 lines per thread at least
+    const size_t nchunks = len ? (size_t)nt * 4 : 0;
     std::vector<Chunk> ch(nchunks);
+    // chunk i = the lines starting in [cut[i], cut[i + 1]): cut[i] = start of the first line at or after byte len * i / nchunks
+    std::vector<int64_t> cut(nchunks + 1, len);
+    if (nchunks) cut[0] = 0;
+    for (size_t i = 1; i < nchunks; i++) {
+        const int64_t raw = (int64_t)((__int128)len * (int64_t)i / (int64_t)nchunks);
+        const char *nl = raw > 0 ? (const char *)memchr(text + raw - 1, '\n', (size_t)(len - raw + 1)) : nullptr;
+        cut[i] = raw > 0 ? (nl ? (int64_t)(nl - text) + 1 : len) : 0;
+    }
     BedIndex drop, mark;
     if (opts->n_drop > 0) drop.build(opts->n_drop, opts->drop_chrom, opts->drop_start, opts->drop_end);
     if (opts->n_mark > 0) mark.build(opts->n_mark, opts->mark_chrom, opts->mark_start, opts->mark_end);
@@ -284,7 +290,7 @@ extern "C" int phz_vcf_parse(const char *text, int64_t len, const phz_vcf_opts *
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= nchunks) break;
-            parse_lines(text, ls, nlines * i / nchunks, nlines * (i + 1) / nchunks, *opts, drop, mark, ch[i]);
+            parse_lines(text, len, cut[i], cut[i + 1], *opts, drop, mark, ch[i]);
         }
     };
     if (nt == 1) work();

@@ -255,7 +255,9 @@ def _main(argv, state):
         names = vcf.contig_names_from_tbi(args.vcf + ".tbi")
         if names:
             start_prefetch([args.chr_prefix + c for c in names])
-    data = vcf.read_bytes(args.vcf)
+    _tv0 = time.perf_counter()
+    data = vcf.read_bytes(args.vcf, as_array=True)          # bgzipped: a uint8 array over the native reader's buffer (no 75 MB Python bytes object)
+    _tv1 = time.perf_counter()
     if pre_ok and pre is None:
         guess = [args.chr_prefix + c for c in vcf.contig_names_guess(data)]
         if guess:
@@ -264,6 +266,8 @@ def _main(argv, state):
     # (the header sits at the top: only the first 20,000 lines are looked at, and only they are split -- split(b"\n", 20000) on the whole text copied the
     #  75 MB behind them once more, 0.05 s)
     head_end = 0
+    full = data
+    data = bytes(memoryview(full)[:64 << 20]) if not isinstance(full, (bytes, bytearray)) else full          # the header scan looks at bytes (a header beyond 64 MB: sample not found)
     for _ in range(20000):
         nxt = data.find(b"\n", head_end)
         if nxt < 0:
@@ -273,7 +277,9 @@ def _main(argv, state):
             nxt = data.find(b"\n", head_end)
             head_end = len(data) if nxt < 0 else nxt + 1
             break
-    for raw in data[:head_end].split(b"\n"):
+    head_lines = data[:head_end].split(b"\n")
+    data = full
+    for raw in head_lines:
         if b"#CHR" in raw:
             cols = raw.decode().rstrip().split("\t")
             m = {cols[i]: i for i in range(9, len(cols))}
@@ -294,9 +300,13 @@ def _main(argv, state):
         say("    removing blacklisted variants and processing VCF...")
     if args.haplo_count_blacklist != "":
         say("#1b. Loading haplotypic count blacklist intervals...")
+    _tv2 = time.perf_counter()
     vs = vcf.load_variants(data, sample_column=sample_col, grep_hom=True, drop_bed=load_bed(args.blacklist) if args.blacklist != "" else None,
                            mark_bed=load_bed(args.haplo_count_blacklist) if (args.haplo_count_blacklist != "" and args.chr_prefix == "") else None,
                            **load_kw)       # with --chr_prefix the reference's blacklist keys (VCF names) never match its lookups (prefixed names, :1070)
+    if os.environ.get("PHZ_TIMING"):
+        sys.stderr.write("[phz timing]   vcf: read + inflate %.3f s, contig guess + header %.3f s, parse + tables %.3f s (%d bytes of text)\n" % (
+            _tv1 - _tv0, _tv2 - _tv1, time.perf_counter() - _tv2, len(data)))
     mark("vcf read + het-variant table")
     say("     creating variant mapping table...")
     say("          %d heterozygous sites being used for phasing (%d filtered, %d indels excluded, %d unphased)" %

@@ -141,13 +141,37 @@ def read_text(path: str) -> str:
     return read_bytes(path).decode()
 
 
-def read_bytes(path: str, threads: int = 0) -> bytes:
+class _NativeBuf:
+    def __init__(self, lib, ptr):
+        self.lib = lib; self.ptr = ptr
+
+    def __del__(self):
+        try:
+            self.lib.phz_buf_free(self.ptr)
+        except Exception:
+            pass
+
+
+def text_ptr(text):
+    """(pointer, length, keep-alive) of a VCF text given as str / bytes / uint8 array (read_bytes(as_array=True): the inflated file where the native
+    reader left it -- the 75 MB of a whole-genome VCF are never copied into a Python bytes object, 0.02-0.04 s of page faults in a fresh process)"""
+    if isinstance(text, np.ndarray):
+        a = text if (text.dtype == np.uint8 and text.flags.c_contiguous) else np.ascontiguousarray(text, dtype=np.uint8)
+        return C.c_void_p(a.ctypes.data), int(a.size), a
+    data = text.encode() if isinstance(text, str) else bytes(text)
+    return C.cast(C.c_char_p(data), C.c_void_p), len(data), data
+
+
+def read_bytes(path: str, threads: int = 0, as_array: bool = False):
+    """The (decompressed) text of a VCF file: bytes, or with as_array a uint8 array over the native reader's buffer when the file is bgzipped."""
     if path.endswith(".gz") or path.endswith(".bgz"):
         # bgzip output is a chain of independent members: inflate them in parallel; plain gzip falls to the gzip module
         lib = _lib.load()
         p = C.c_void_p(); n = C.c_int64(0)
         st = lib.phz_bgzf_read(path.encode(), int(threads), C.byref(p), C.byref(n))
         if st == _lib.PHZ_OK:
+            if as_array:
+                return _lib.native_view(p.value, n.value, C.c_uint8, _NativeBuf(lib, p))
             try:
                 return C.string_at(p, n.value)
             finally:
@@ -185,6 +209,8 @@ def contig_names_guess(data: bytes, max_probes: int = 50000):
     """Distinct CHROM values of a VCF text whose contigs come in runs (every tabix-able file), found by bisection between line probes:
     O(contigs x log lines) line lookups instead of a pass over the text.  A GUESS: a contig scattered inside another contig's run can
     be missed -- callers check the result against the parsed table (phaser.main does, before it trusts the BAM prefetch)."""
+    if isinstance(data, np.ndarray):
+        data = data.tobytes()               # (the rare path: a VCF without a tabix index next to it)
     n = len(data)
     p = 0
     while p < n and data[p:p + 1] == b"#":
@@ -242,7 +268,7 @@ def load_variants(vcf_text, sample_column: int = 9, chrom_of_interest: str = "",
     [(chrom, start, end)]: records overlapping drop_bed vanish (--blacklist, `bedtools intersect -v`), variants overlapping
     mark_bed get ChromVariants.blacklisted = 1 (--haplo_count_blacklist)."""
     lib = _lib.load()
-    data = vcf_text.encode() if isinstance(vcf_text, str) else bytes(vcf_text)
+    data_p, data_n, data = text_ptr(vcf_text)
     ban = [str(x).encode() for x in contig_ban]
     ban_arr = (C.c_char_p * max(1, len(ban)))(*ban) if ban else (C.c_char_p * 1)()
     keep = []
@@ -259,7 +285,7 @@ def load_variants(vcf_text, sample_column: int = 9, chrom_of_interest: str = "",
                           id_separator.encode(), int(gw_phase_method), gw_af_field.encode(), len(ban), ban_arr, max(1, int(threads)), 1 if grep_hom else 0,
                           nd, dn, ds, de, nm, mn, ms, me)
     h = C.c_void_p()
-    st = lib.phz_vcf_parse(C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(o), C.byref(h))
+    st = lib.phz_vcf_parse(data_p, data_n, C.byref(o), C.byref(h))
     owner = _NativeTable(lib, h)          # frees the table when the last chromosome's lazy pools are gone
     if st != _lib.PHZ_OK:
         msg = (lib.phz_vcf_error(h) or b"").decode()

@@ -23,7 +23,8 @@ def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", 
     import os, sys, time
     t0 = time.perf_counter()
     lib = _lib.load()
-    data = vcf_text.encode() if isinstance(vcf_text, str) else bytes(vcf_text)
+    from .vcf import text_ptr
+    data_p, data_n, data = text_ptr(vcf_text)
     keep = []
     arr = (_lib.phz_vcfout_chrom * max(1, len(eng.vcf_blocks)))()
 
@@ -45,7 +46,7 @@ def phased_vcf_text(vcf_text, sample_column: int, eng, id_separator: str = "_", 
         x.blk_stat = A(v["stat"], np.float64)
     out = C.c_void_p(); n = C.c_int64(0); up = C.c_int64(0); pc = C.c_int64(0)
     t1 = time.perf_counter()
-    st = lib.phz_vcf_phase_text(C.cast(C.c_char_p(data), C.c_void_p), len(data), int(sample_column), id_separator.encode(),
+    st = lib.phz_vcf_phase_text(data_p, data_n, int(sample_column), id_separator.encode(),
                                 chromosome_of_interest.encode(), int(gw_phase_vcf), float(min_confidence), arr, len(eng.vcf_blocks),
                                 max(1, int(threads)), C.byref(out), C.byref(n), C.byref(up), C.byref(pc))
     if st != _lib.PHZ_OK:

@@ -326,7 +326,7 @@ def test_dense_variants_vs_oracle(mapper, oracle_build, tmp_path, seed, n_snps, 
     for name in OUTPUTS:
         assert got[name] == host[name], (name, eng.rows_path)
     pool, _, _ = po.load_vcf(vcf_text)
-    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs, output_read_ids=read_ids)
+    ph = po.Phaser(po.bam_display_names(list(bams.keys())), max_block_size=mbs)
     for bam, per_chrom in bams.items():
         texts = []
         for c in pool:

@@ -208,3 +208,29 @@ def test_contig_names_guess():
     body.insert(1234, "chrStray\t7\t.\tA\tG")
     got = set(vcf.contig_names_guess(("\n".join(body) + "\n").encode()))
     assert "chr1" in got and got <= {"chr1", "chrStray"}
+
+
+def test_chunked_parse_is_independent_of_the_thread_count():
+    """The loader cuts the text into byte ranges at line starts (no line index over the whole text): 1, 3 and 16 threads give the same tables on a text of a few
+    MB -- with a final newline, without one, with blank lines and with comment lines in the middle of the records -- and the text as a uint8 array (the native
+    reader's buffer) gives what the bytes give."""
+    from phaser_amd import synth, vcf
+    vs_ = []
+    for ci, (chrom, ln) in enumerate([("chr3", 198295559), ("chr11", 135086622), ("chr19", 58617616)]):
+        v, gs, ge, w = synth.make_variants(chrom, 1, 60_000_000, 30_000, 4200 + ci, n_genes=300)
+        vs_.append(v)
+    lines = synth.vcf_lines(vs_)
+    lines.insert(len(lines) // 2, "")
+    lines.insert(len(lines) // 3, "#a comment line between records")
+    for tail in ("\n", ""):
+        text = "\n".join(lines) + tail
+        assert len(text) > 3_000_000
+        base = vcf.load_variants(text, threads=1)
+        for th, form in ((3, text), (16, text.encode()), (16, np.frombuffer(text.encode(), dtype=np.uint8))):
+            got = vcf.load_variants(form, threads=th)
+            assert list(got.chroms) == list(base.chroms) and got.het_count == base.het_count and got.unphased_count == base.unphased_count
+            for c in base.chroms:
+                a, b = base.chroms[c], got.chroms[c]
+                assert np.array_equal(a.pos, b.pos) and np.array_equal(a.phase_idx, b.phase_idx) and np.array_equal(a.maf_val, b.maf_val)
+                assert a._raw["uid"] == b._raw["uid"] and a._raw["alleles"] == b._raw["alleles"] and a._raw["gt"] == b._raw["gt"]
+        assert base.het_count > 60_000
