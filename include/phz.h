@@ -226,6 +226,12 @@ int phz_ctx_sync(phz_ctx *ctx);
 /* raw hipStream_t of the context (so a caller can order its own work against it) */
 void *phz_ctx_stream(phz_ctx *ctx);
 
+/* One chromosome's het-variant table made RESIDENT in the ctx (SURVEY.md 8(b) `phz_load_variants`; the POS / len(REF) columns of generate_mapping_table,
+ * phaser/phaser.py:1355-1413, as the mapper reads them, read_variant_map.py:25-44).  slot in [0, 65536): one per chromosome; pos must be sorted (checked for host
+ * arrays).  *resident receives DEVICE pointers owned by the ctx, valid until the slot is loaded again or the ctx is destroyed: pass it to
+ * phz_map_reads(..., PHZ_DEVICE) / phz_map_reads_batch for every BAM's shard of that chromosome (the table is uploaded once, not per call). */
+int phz_load_variants(phz_ctx *ctx, int slot, const int32_t *pos, const uint8_t *ref_len, int64_t n, int space, phz_variants *resident);
+
 /* Read -> variant allele mapper.  On PHZ_E_CAPACITY *n_calls holds the required capacity. */
 int phz_map_reads(phz_ctx *ctx, const phz_reads *reads, const phz_variants *vars, int baseq,
                   phz_calls *out, int64_t *n_calls, int space);
@@ -262,6 +268,10 @@ int phz_as_cutoff(phz_ctx *ctx, const phz_lines *shards, int n_shards, double q_
 int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1,
               int64_t n_qid, int n_bams, phz_tally_sizes *sizes, int space);
 int phz_tally_fetch(phz_ctx *ctx, const phz_tally_out *out, int space);
+/* SURVEY.md 8(b) `phz_hap_counts`: DISTINCT reads per (variant, allele, BAM) read list of the resident tally = len(set(haplo_reads[allele][bam])), the
+ * per-variant haplotype counts of phaser/phaser.py:1196-1204 (a block's union over its variants is the read-set stage of phz_rowsdev_run).
+ * counts[(variant * 2 + allele) * n_bams + bam]; n_counts must equal variants x 2 x BAMs of the last phz_tally. */
+int phz_hap_counts(phz_ctx *ctx, int32_t *counts, int64_t n_counts, int space);
 
 /* Connected components of the variant graph restricted to edges with keep != 0: label[v] = smallest variant
  * index of v's component.  edge_a == edge_b == NULL: the edge list of the last phz_tally (n_edges must match). */
@@ -377,7 +387,8 @@ int phz_sam_calls_tsv(const phz_sam *h, int shard, int64_t n_calls, const int32_
                       const uint32_t *rsid_off, const char *rsid, const uint32_t *gt_off, const char *gt, const uint32_t *maf_off,
                       const char *maf, int threads, char **out, int64_t *out_len);
 
-/* whole BGZF file -> malloc'd buffer (free with phz_buf_free); PHZ_E_UNSUPPORTED when the file is plain gzip */
+/* whole BGZF file -> buffer owned by the library (release it with phz_buf_free and nothing else: a large text is an anonymous mapping, not a malloc'd block);
+ * PHZ_E_UNSUPPORTED when the file is plain gzip */
 int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len);
 void phz_buf_free(char *p);
 /* data -> BGZF file: 60,000-byte members deflated in parallel + EOF marker (what bgzip writes, phaser.py:1851) */

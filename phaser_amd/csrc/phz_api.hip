@@ -56,6 +56,7 @@ int phz_ctx_destroy(phz_ctx *c) {
     for (DevBuf &b : c->stage_pool) free_buf(b);
     for (DevBuf &b : c->tally_buf) free_buf(b);
     for (DevBuf &b : c->import_buf) free_buf(b);
+    for (DevBuf &b : c->resident_vars) free_buf(b);
     free_buf(c->tally_qcount); free_buf(c->scan_state);
     if (c->h_scalars.p) (void)hipHostFree(c->h_scalars.p);
     if (c->mail_host.p) (void)hipHostFree(c->mail_host.p);
@@ -67,6 +68,29 @@ int phz_ctx_destroy(phz_ctx *c) {
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
     delete c;
+    return PHZ_OK;
+}
+
+// SURVEY.md 8(b) `phz_load_variants`: one chromosome's het-variant table (generate_mapping_table, phaser/phaser.py:1355-1413: the POS and len(REF) columns the
+// mapper reads, read_variant_map.py:25-44) made RESIDENT in the ctx under `slot`; *resident receives device pointers that stay valid until the slot is
+// loaded again or the ctx is destroyed, for phz_map_reads(..., PHZ_DEVICE) / phz_map_reads_batch over every BAM's shard of that chromosome.
+int phz_load_variants(phz_ctx *ctx, int slot, const int32_t *pos, const uint8_t *ref_len, int64_t n, int space, phz_variants *resident) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || !resident || slot < 0 || slot >= 65536 || n < 0 || (n && (!pos || !ref_len)) || (space != PHZ_HOST && space != PHZ_DEVICE)) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    for (int64_t i = 1; space == PHZ_HOST && i < n; i++)
+        if (pos[i] < pos[i - 1]) return phz_fail(ctx, PHZ_E_ARG, "phz_load_variants: positions are not sorted");
+    if (ctx->resident_vars.size() < (size_t)(2 * slot + 2)) ctx->resident_vars.resize((size_t)(2 * slot + 2));
+    DevBuf &P = ctx->resident_vars[(size_t)(2 * slot)], &L = ctx->resident_vars[(size_t)(2 * slot + 1)];
+    if (int s = phz_reserve(ctx, P, (size_t)(n ? n : 1) * 4)) return s;
+    if (int s = phz_reserve(ctx, L, (size_t)(n ? n : 1))) return s;
+    const hipMemcpyKind kind = space == PHZ_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (n) {
+        PHZ_HIP(ctx, hipMemcpyAsync(P.p, pos, (size_t)n * 4, kind, ctx->stream));
+        PHZ_HIP(ctx, hipMemcpyAsync(L.p, ref_len, (size_t)n, kind, ctx->stream));
+        PHZ_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the caller's arrays may go away
+    }
+    resident->n = n; resident->pos = (const int32_t *)P.p; resident->ref_len = (const uint8_t *)L.p;
     return PHZ_OK;
 }
 

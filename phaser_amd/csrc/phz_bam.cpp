@@ -21,6 +21,8 @@
 #include <string_view>
 #include <thread>
 #include <unordered_map>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "phz.h"
@@ -1259,6 +1261,9 @@ int phz_interner_names(const phz_interner *it, char *blob, int64_t blob_cap, uin
 }
 
 // ---- generic BGZF files (bgzip-compressed VCF in, phased VCF out) -------------------------------------------------------
+static std::mutex g_mapped_mu;
+static std::map<void *, size_t> g_mapped;          // buffers handed out by phz_bgzf_read that are mappings (phz_buf_free unmaps them)
+
 // Reads a whole BGZF file with parallel member inflate.  PHZ_E_UNSUPPORTED for plain gzip (the caller streams it itself).
 int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len) {
     if (!path || !data || !len) return PHZ_E_ARG;
@@ -1267,11 +1272,29 @@ int phz_bgzf_read(const char *path, int threads, char **data, int64_t *len) {
     if (int st = inflate_bgzf_file(path, threads, buf)) return st;
     *len = (int64_t)buf.size();
     buf.data()[buf.size()] = 0;
+    // a big text stays where the workers inflated it (an anonymous mapping of huge pages): phz_buf_free unmaps it.  Copying it into a malloc'd block -- 75 MB
+    // of a whole-genome VCF, fresh pages touched by one thread -- was a third of this call.
+    if (buf.mapped) {
+        std::lock_guard<std::mutex> lk(g_mapped_mu);
+        g_mapped[(void *)buf.p] = buf.mapped;
+        *data = (char *)buf.p;
+        buf.p = nullptr; buf.n = 0; buf.mapped = 0;
+        return PHZ_OK;
+    }
     *data = (char *)buf.release();
     return PHZ_OK;
 }
 
-void phz_buf_free(char *p) { free(p); }
+void phz_buf_free(char *p) {
+    if (!p) return;
+    size_t mapped = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mapped_mu);
+        auto it = g_mapped.find((void *)p);
+        if (it != g_mapped.end()) { mapped = it->second; g_mapped.erase(it); }
+    }
+    if (mapped) munmap(p, mapped); else free(p);
+}
 
 // Writes data as a BGZF file (60,000-byte members deflated in parallel, EOF marker at the end) -- what `bgzip` produces
 // for the phased VCF (phaser.py:1851).  side (may be empty) runs on a thread of its own next to the deflate workers; members (may be

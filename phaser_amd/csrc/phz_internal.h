@@ -49,6 +49,7 @@ struct phz_ctx {
     std::vector<DevBuf> stage_pool;
     std::vector<DevBuf> tally_buf;     // result + read-list buffers of phz_tally
     std::vector<DevBuf> import_buf;    // arrays adopted by phz_tally_import
+    std::vector<DevBuf> resident_vars; // phz_load_variants: slot s = {pos, ref_len} of one chromosome's het-variant table at [2 s], [2 s + 1]
     bool tally_dirty = false, tally_table_dirty = true;     // per-QNAME counters / variant-pair table not known to be clean
     // single-pass scan (phz_sort.h): ticket counter + one status word per tile, valid for the current epoch only (never cleared between scans)
     DevBuf scan_state; uint32_t scan_epoch = 0, scan_ticket_base = 0;

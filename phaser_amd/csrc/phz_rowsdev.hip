@@ -2696,6 +2696,50 @@ extern "C" int phz_selftest_sort(phz_ctx *ctx, int key_bytes, const void *keys, 
     return fin(e == hipSuccess ? PHZ_OK : phz_fail(ctx, PHZ_E_HIP, "phz_selftest_sort", e));
 }
 
+// SURVEY.md 8(b) `phz_hap_counts`: the number of DISTINCT reads (QNAMEs) in every (variant, allele, BAM) read list of the resident tally --
+// len(set(dict_variant_reads[v]['haplo_reads'][allele][bam])), what the haplotype-count loops of the reference evaluate per variant (phaser.py:1196-1204; the
+// union over a block's variants is phz_rowsdev_run's read-set stage).  counts[(variant * 2 + allele) * n_bams + bam], host or device array.  The lists are
+// deduplicated by the read-set kernels of the row stage (one thread / wave / workgroup per list by its length).
+extern "C" int phz_hap_counts(phz_ctx *ctx, int32_t *counts, int64_t n_counts, int space) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || (space != PHZ_HOST && space != PHZ_DEVICE)) return PHZ_E_ARG;
+    auto &T = ctx->tally;
+    const int64_t nseg = T.nv * 2 * (int64_t)T.nb;
+    if (n_counts != nseg || (nseg && !counts)) return phz_fail(ctx, PHZ_E_ARG, "phz_hap_counts: counts must hold variants x 2 x BAMs of the resident tally");
+    if (!nseg) return PHZ_OK;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t sm = ctx->stream;
+    DevBuf ns, l1, l2, cnt, pool;
+    auto fin = [&](int code) { for (DevBuf *b : {&ns, &l1, &l2, &cnt, &pool}) if (b->p) (void)hipFree(b->p); return code; };
+    int st = PHZ_OK;
+    if ((st = phz_reserve(ctx, ns, (size_t)nseg * 4)) || (st = phz_reserve(ctx, l1, (size_t)nseg * 4 + 4)) || (st = phz_reserve(ctx, l2, (size_t)nseg * 4 + 4)) ||
+        (st = phz_reserve(ctx, cnt, 256)) || (st = phz_reserve(ctx, pool, (size_t)4 << 20))) return fin(st);
+    for (int attempt = 0;; attempt++) {
+        hipError_t e = hipMemsetAsync(cnt.p, 0, 256, sm);
+        if (e != hipSuccess) return fin(phz_fail(ctx, PHZ_E_HIP, "phz_hap_counts", e));
+        uint32_t *c = P<uint32_t>(cnt);
+        SG sg; memset(&sg, 0, sizeof(sg));
+        sg.nseg = nseg; sg.nb = T.nb; sg.rl_start = T.rl_start; sg.rl_qid = T.rl_qid; sg.ns = P<uint32_t>(ns);
+        sg.big_list = P<uint32_t>(l1); sg.big_list2 = P<uint32_t>(l2); sg.huge_list = P<uint32_t>(l1);      // (a list is one piece: never huge)
+        sg.counters = c; sg.huge_count = c + 4; sg.tickets = c + 5; sg.overflow = c + 20;
+        sg.pool = P<uint32_t>(pool); sg.pool_cap = (uint32_t)std::min<size_t>(pool.cap / 4, 0xFFFFFFF0u);
+        hipLaunchKernelGGL(k_seg_small<2>, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, sm, sg);
+        hipLaunchKernelGGL((k_seg_big<2, 512, 64>), dim3((unsigned)std::min<int64_t>(nseg, 4096)), dim3(64), 0, sm, sg);
+        hipLaunchKernelGGL((k_seg_big<2, 4096, PHZ_SEG_THREADS>), dim3((unsigned)std::min<int64_t>(nseg, 768)), dim3(PHZ_SEG_THREADS), 0, sm, sg);
+        uint32_t ovf = 0;
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&ovf, c + 20, 4, hipMemcpyDeviceToHost, sm);
+        if (e == hipSuccess) e = hipStreamSynchronize(sm);
+        if (e != hipSuccess) return fin(phz_fail(ctx, PHZ_E_HIP, "phz_hap_counts", e));
+        if (!ovf) break;
+        if (attempt == 3) return fin(phz_fail(ctx, PHZ_E_NOMEM, "phz_hap_counts: read-set table pool did not converge"));
+        if ((st = phz_reserve(ctx, pool, pool.cap * 4))) return fin(st);           // a list of more than SEG_LDS reads keeps its table in the pool: grow and redo
+    }
+    hipError_t e = hipMemcpyAsync(counts, ns.p, (size_t)nseg * 4, space == PHZ_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, sm);
+    if (e == hipSuccess) e = hipStreamSynchronize(sm);
+    return fin(e == hipSuccess ? PHZ_OK : phz_fail(ctx, PHZ_E_HIP, "phz_hap_counts", e));
+}
+
 // copy one finished text (PHZ_TXT_*) to host memory (page-locked memory gives the full PCIe rate)
 extern "C" int phz_rowsdev_fetch_text(phz_ctx *ctx, phz_rowsdev *h, int which, void *dst, int64_t bytes) {
     PhzEnter phz_guard_(ctx);

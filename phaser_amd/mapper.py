@@ -45,13 +45,28 @@ class Mapper:
         self.ctx = ctx or _lib.Context(device)
         self.device = torch.device("cuda", self.ctx.device)
 
-    def map(self, shard: ReadShard, vpos: torch.Tensor, baseq: int, ref_len: Optional[torch.Tensor] = None,
-            cap: Optional[int] = None) -> Calls:
-        """Runs K_map.  Host tensors are staged through HBM by the library; cuda tensors are used in place."""
+    def load_variants(self, slot: int, vpos, ref_len=None) -> "_lib.phz_variants":
+        """phz_load_variants (SURVEY.md 8(b)): one chromosome's het-variant table (host numpy arrays or tensors) made resident in the ctx under `slot`;
+        the returned record holds device pointers for map(..., resident=...) over every BAM's shard of the chromosome."""
+        import numpy as np
+        vp = vpos.cpu().numpy() if isinstance(vpos, torch.Tensor) else np.asarray(vpos)
+        vp = np.ascontiguousarray(vp, dtype=np.int32)
+        rl = np.ones(len(vp), dtype=np.uint8) if ref_len is None else np.ascontiguousarray(ref_len.cpu().numpy() if isinstance(ref_len, torch.Tensor) else ref_len, dtype=np.uint8)
+        out = _lib.phz_variants()
+        self.ctx.check(self.ctx.lib.phz_load_variants(self.ctx.h, int(slot), C.c_void_p(vp.ctypes.data), C.c_void_p(rl.ctypes.data), len(vp), _lib.PHZ_HOST, C.byref(out)))
+        return out
+
+    def map(self, shard: ReadShard, vpos: Optional[torch.Tensor], baseq: int, ref_len: Optional[torch.Tensor] = None,
+            cap: Optional[int] = None, resident=None) -> Calls:
+        """Runs K_map.  Host tensors are staged through HBM by the library; cuda tensors are used in place.  resident: a table loaded by
+        load_variants (device shards only) instead of vpos."""
         on_gpu = shard.device.type == "cuda"
         space = _lib.PHZ_DEVICE if on_gpu else _lib.PHZ_HOST
         out_dev = shard.device
-        vpos = vpos.to(out_dev).to(torch.int32).contiguous()
+        if resident is not None and not on_gpu:
+            raise _lib.PhzError(_lib.PHZ_E_ARG, "a resident variant table serves device-resident shards")
+        if resident is None:
+            vpos = vpos.to(out_dev).to(torch.int32).contiguous()
         if ref_len is not None:
             ref_len = ref_len.to(torch.uint8).contiguous()
             if bool((ref_len != 1).any()):
@@ -59,7 +74,7 @@ class Mapper:
         r = _lib.phz_reads(shard.n, int(shard.cigar.numel()), int(shard.seq2.numel()), _ptr(shard.pos),
                            _ptr(shard.cigar_off), _ptr(shard.cigar), _ptr(shard.seq_off), _ptr(shard.seq2),
                            _ptr(shard.qual), _ptr(soa.bq_plane(shard)) if on_gpu else None)
-        v = _lib.phz_variants(int(vpos.numel()), _ptr(vpos), None)
+        v = resident if resident is not None else _lib.phz_variants(int(vpos.numel()), _ptr(vpos), None)
         if cap is None:
             cap = shard.n // 2 + 4096
         if on_gpu:

@@ -267,7 +267,7 @@ def _main(argv, state):
     #  75 MB behind them once more, 0.05 s)
     head_end = 0
     full = data
-    data = bytes(memoryview(full)[:64 << 20]) if not isinstance(full, (bytes, bytearray)) else full          # the header scan looks at bytes (a header beyond 64 MB: sample not found)
+    data = bytes(memoryview(full)[:8 << 20]) if not isinstance(full, (bytes, bytearray)) else full          # the header scan looks at bytes (a header beyond 8 MB: sample not found)
     for _ in range(20000):
         nxt = data.find(b"\n", head_end)
         if nxt < 0:

@@ -155,3 +155,36 @@ def test_pair_key_table_grows_instead_of_declining_the_pass(monkeypatch, c1_inpu
     assert eng.rows_path == "device" and eng.stats.get("rowsdev_n_pair_table_growths", 0) >= 1
     for name in OUTPUTS:
         assert out[name] == base[name], name
+
+
+@pytest.mark.parametrize("case", ["pipe_two", "opts_read_ids", "pipe_sparse"])
+def test_hap_counts_are_the_distinct_reads_per_list(case, c1_inputs):
+    """phz_hap_counts: distinct QNAMEs per (variant, allele, BAM) read list of the resident tally = len(set(haplo_reads[allele][bam]))
+    (phaser.py:1196-1204), computed by the read-set kernels of the row stage; against numpy on the fixture's read lists."""
+    import ctypes
+    import numpy as np
+    from phaser_amd import _lib
+    lib = emu_library()
+    c, gold, load, cfg = next(x for x in _cases() if x[0] == case)
+    d, vcf_text, bams = _inputs(case, gold, c1_inputs)
+    from phaser_amd import vcf
+    from phaser_amd.engine import Config, Engine
+    load = dict(load); cfg = dict(cfg)
+    inc = load.pop("include_indels", 0); cfg.pop("include_indels", None)
+    vs = vcf.load_variants(vcf_text, include_indels=inc, **load)
+    saved = pickle.load(gzip.open(os.path.join(GOLD, "tally", case + ".pkl.gz"), "rb"))
+
+    class _M:
+        ctx = EmuContext(lib)
+        device = None
+    eng = Engine(vs, bams, Config(include_indels=inc, **cfg), mapper=_M())
+    eng.n_qid.update(saved["n_qid"]); eng.qnames.update(saved["qnames"])
+    stub_emu_stages(eng, saved)
+    G = eng._tally_genome()
+    nseg = G["nv"] * 2 * G["nb"]
+    got = np.full(nseg, -1, dtype=np.int32)
+    eng.ctx.check(lib.phz_hap_counts(eng.ctx.h, ctypes.c_void_p(got.ctypes.data), nseg, _lib.PHZ_HOST))
+    rs = G["rl_start"].astype(np.int64); rq = G["rl_qid"]
+    want = np.array([len(set(rq[rs[e]:rs[e + 1]].tolist())) for e in range(nseg)], dtype=np.int32)
+    assert np.array_equal(got, want) and int(want.sum()) > 0
+    assert lib.phz_hap_counts(eng.ctx.h, ctypes.c_void_p(got.ctypes.data), nseg + 1, _lib.PHZ_HOST) == _lib.PHZ_E_ARG

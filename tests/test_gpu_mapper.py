@@ -429,3 +429,32 @@ def test_dense_tiles_take_the_overflow_area(oracle_build, monkeypatch, slot_cap)
         got = m.map_batch(shards, vps, 10, aux=aux)
         assert all(same(g, o) for g, o in zip(got, want)), aux
     assert want[0][0].size > 50000 and max(np.bincount(want[0][0] // 256)) > 8 * 8          # tiles with far more calls than a slot
+
+
+def test_resident_variant_table(mapper, oracle_build):
+    """phz_load_variants: the het-variant table of a chromosome uploaded once into a slot of the ctx, K_map run from the resident pointers
+    over two BAMs' shards, a second chromosome in another slot, the first slot reloaded with a longer table -- every call list = the C oracle's."""
+    from phaser_amd import _lib, soa, synth
+    tabs = {}
+    for slot, (chrom, n_snps, seed) in enumerate([("chr1", 3000, 41), ("chr2", 800, 42)]):
+        v, gs, ge, w = synth.make_variants(chrom, 1, 20_000_000, n_snps, seed, n_genes=60)
+        tabs[slot] = (v, gs, ge, w, mapper.load_variants(slot, v.pos.numpy()))
+    for slot, (v, gs, ge, w, res) in tabs.items():
+        assert res.n == len(v.pos) and res.pos
+        for bam in range(2):
+            rb = synth.make_reads(v, gs, ge, w, 40_000, 500 + 10 * slot + bam)
+            rb = rb.select(synth.samtools_keep(rb, 255))
+            o_r, o_v, o_c, o_t = oracle_map_readbatch(oracle_build, rb, v.pos.numpy(), 10)
+            calls = mapper.map(soa.pack_readbatch(rb).to("cuda"), None, 10, resident=res).cpu()
+            assert calls.n == len(o_r) and calls.n > 1000
+            assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v) and np.array_equal(calls.code.numpy(), o_c)
+    v, gs, ge, w = synth.make_variants("chr1", 1, 20_000_000, 9000, 43, n_genes=60)          # slot 0 again, three times the size: the slot's buffers grow
+    res = mapper.load_variants(0, v.pos.numpy())
+    rb = synth.make_reads(v, gs, ge, w, 40_000, 540)
+    rb = rb.select(synth.samtools_keep(rb, 255))
+    o_r, o_v, o_c, o_t = oracle_map_readbatch(oracle_build, rb, v.pos.numpy(), 10)
+    calls = mapper.map(soa.pack_readbatch(rb).to("cuda"), None, 10, resident=res).cpu()
+    assert np.array_equal(calls.read_idx.numpy(), o_r) and np.array_equal(calls.var_idx.numpy(), o_v) and np.array_equal(calls.code.numpy(), o_c)
+    bad = np.array([5, 3], dtype=np.int32); one = np.ones(2, dtype=np.uint8); out = _lib.phz_variants()
+    import ctypes as C
+    assert mapper.ctx.lib.phz_load_variants(mapper.ctx.h, 1, C.c_void_p(bad.ctypes.data), C.c_void_p(one.ctypes.data), 2, _lib.PHZ_HOST, C.byref(out)) == _lib.PHZ_E_ARG

@@ -298,6 +298,20 @@ def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pair
         assert canonical(name, got[name]) == canonical(name, want[name]), name
     assert eng.phased == ph.phased and eng.phased > 20
     assert eng.stats["rowsdev_n_big_segments"] > 0
+    # phz_hap_counts: distinct reads per (variant, allele, BAM) list of the tally still resident from the host-twin pass -- lists of thousands
+    # of entries here (wave / workgroup read-set kernels) -- against numpy on the fetched lists; device and host destinations
+    import ctypes as C
+    from phaser_amd import _lib
+    heng._fetch_tally()
+    G = heng.G
+    nseg = G["nv"] * 2 * G["nb"]
+    rs = G["rl_start"].astype(np.int64); rq = G["rl_qid"]
+    want_n = np.array([len(np.unique(rq[rs[e]:rs[e + 1]])) for e in range(nseg)], dtype=np.int32)
+    got_h = np.full(nseg, -1, dtype=np.int32)
+    heng.ctx.check(heng.lib.phz_hap_counts(heng.ctx.h, C.c_void_p(got_h.ctypes.data), nseg, _lib.PHZ_HOST))
+    got_d = torch.full((nseg,), -1, dtype=torch.int32, device="cuda")
+    heng.ctx.check(heng.lib.phz_hap_counts(heng.ctx.h, C.c_void_p(got_d.data_ptr()), nseg, _lib.PHZ_DEVICE))
+    assert np.array_equal(got_h, want_n) and np.array_equal(got_d.cpu().numpy(), want_n) and int(want_n.max()) > 256
 
 
 @pytest.mark.parametrize("seed,n_snps,err,pairs,mbs,L", [(9201, 400, 0.003, 3000, 15, 76), (9202, 1500, 0.03, 2500, 10, 76), (9301, 1500, 0.01, 200, 15, 1000)])

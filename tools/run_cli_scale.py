@@ -75,7 +75,7 @@ if os.environ.get("PHZ_CLI_SUBPROCESS"):            # the same command in FRESH 
         pr = subprocess.run([sys.executable, "-m", "phaser_amd.phaser", "--vcf", vcfgz, "--bam", bam, "--sample", "S1", "--mapq", ",".join(["255"] * n_bams), "--baseq", "10",
                              "--paired_end", "1", "--o", "/tmp/cli_scale_out", "--threads", str(threads), "--write_vcf", str(write_vcf)], cwd=REPO, env=env,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        keep = [l for l in pr.stdout.split("\n") if l.startswith("[phz timing]") and ("bam device:" in l or "total" in l or not l.startswith("[phz timing]  "))]
+        keep = [l for l in pr.stdout.split("\n") if l.startswith("[phz timing]") and ("bam device:" in l or " vcf" in l or "total" in l or not l.startswith("[phz timing]  "))]
         print("=== fresh process %d: rc %d, process wall %.2f s (interpreter + imports included)\n%s" % (k, pr.returncode, time.perf_counter() - t5, "\n".join(keep)), flush=True)
 if os.environ.get("PHZ_CLI_RERUN_ENV"):            # the same command again in this (warm) process under other switches, e.g. "PHZ_BAM_CRC=0;PHZ_BAM_CRC=1": compare the bam lines
     for setting in os.environ["PHZ_CLI_RERUN_ENV"].split(";"):
