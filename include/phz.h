@@ -124,6 +124,9 @@ typedef struct {
                                   * PHZ_AS16_NONE = the record carries no AS tag, +-PHZ_AS16_RANGE = an AS value outside [-32766, 32766] (refused like any value
                                   * outside int16).  When present the kernels gather this plane instead of read_as + read_has_as (2 instead of 5 bytes per record
                                   * touched, one memory line instead of two) */
+    const double *as_cutoff_dev; /* optional (NULL = absent), DEVICE pointer to the four doubles phz_as_cutoff_enqueue writes: when present and use_cutoff != 0 the
+                                  * kernels take the cutoff from [0] (and keep every line when [1] == 0: no record of the BAM carries an AS tag) instead of as_cutoff:
+                                  * the percentile never visits the host between the histogram and the tally */
 } phz_lines;
 #define PHZ_AS16_NONE (-32768)
 #define PHZ_AS16_RANGE 32767
@@ -259,6 +262,11 @@ int phz_as_plane(phz_ctx *ctx, const int32_t *aln, const uint8_t *has_as, int64_
  * numpy.percentile(scores, q_percent) (default linear method, the same float64 operations) computed natively.  *found = 0: no record carries an AS tag.
  * PHZ_E_CAPACITY: more than 4,096 distinct scores (take phz_as_histogram_batch and the host formula then). */
 int phz_as_cutoff(phz_ctx *ctx, const phz_lines *shards, int n_shards, double q_percent, double *cutoff, int32_t *found);
+/* The same WITHOUT a host wait: histogram, order statistics and numpy.percentile's interpolation all on the device (the 64 Ki-bin histogram is scanned by one
+ * workgroup; the same float64 operations as phz_as_cutoff, contraction off), enqueued on the ctx stream.  dev_out: DEVICE memory of four doubles --
+ * [0] the cutoff, [1] 1.0 / 0.0 = some / no record carries an AS tag, [2] != 0: an AS value outside int16 was seen (the caller must refuse the input when
+ * it reads the block back), [3] number of scores.  Point phz_lines.as_cutoff_dev of the BAM's shards at it for the phz_tally that follows on the same ctx. */
+int phz_as_cutoff_enqueue(phz_ctx *ctx, const phz_lines *shards, int n_shards, double q_percent, double *dev_out);
 
 /* Per-variant counters, distinct read sets, variant-pair co-occurrence cells and per-(variant, allele, BAM) read lists over
  * any number of (chromosome, BAM) shards in one submission.  Shards must be ordered by (chromosome, BAM); a chromosome's

@@ -53,7 +53,7 @@ class phz_lines(C.Structure):
     _fields_ = [("n_calls", C.c_int64), ("read_idx", C.c_void_p), ("var_idx", C.c_void_p), ("code", C.c_void_p),
                 ("n_reads", C.c_int64), ("read_qid", C.c_void_p), ("read_as", C.c_void_p), ("read_has_as", C.c_void_p),
                 ("as_cutoff", C.c_double), ("use_cutoff", C.c_int32), ("bam_index", C.c_int32),
-                ("var_base", C.c_int64), ("qid_base", C.c_int64), ("read_as16", C.c_void_p)]
+                ("var_base", C.c_int64), ("qid_base", C.c_int64), ("read_as16", C.c_void_p), ("as_cutoff_dev", C.c_void_p)]
 
 
 class phz_tally_sizes(C.Structure):
@@ -236,6 +236,7 @@ SYMBOLS = {
     "phz_py_set_order": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "phz_as_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "phz_as_cutoff": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "phz_as_cutoff_enqueue": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_double, C.c_void_p]),
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.POINTER(phz_tally_sizes), C.c_int]),
     "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),

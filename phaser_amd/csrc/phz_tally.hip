@@ -54,6 +54,7 @@ struct LinesDev {
     int64_t line_base;         // index of the shard's first line in the call's line space (shards ordered chromosome, BAM)
     const int16_t *read_as16;  // 2-byte AS plane with the has-AS flag folded in (phz.h), or NULL
     int32_t nv_chrom;          // variants of the shard's chromosome: [var_base, var_base + nv_chrom) of the call's variant space
+    const double *cut_dev;     // phz_lines.as_cutoff_dev: {cutoff, found, ...} computed on the device (phz_as_cutoff_enqueue), or NULL
 };
 // AS of record r from whichever form the shard carries; false = the record has no AS tag.  *range = the value lies outside the band the
 // histogram accepts (the caller refuses the input)
@@ -228,10 +229,13 @@ __global__ __launch_bounds__(LINE_TB) void k_line(LinesTab T, LineOut O) {
         l_in[k] = i < L.n;
         l_r[k] = l_in[k] ? L.read_idx[i] : 0; l_v[k] = l_in[k] ? L.var_idx[i] + L.var_base : 0; l_code[k] = l_in[k] ? L.code[i] : (uint8_t)4;
     }
+    // the cutoff of the shard's BAM: a host value, or the block the device-side percentile left (phz_as_cutoff_enqueue; [1] == 0: no AS tag in the BAM, every line kept)
+    const bool use_cut = L.use_cutoff != 0 && (L.cut_dev == nullptr || L.cut_dev[1] != 0.0);
+    const double cut = L.cut_dev != nullptr ? L.cut_dev[0] : L.cutoff;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         l_as[k] = 0; l_has[k] = true;
-        if (l_in[k] && L.use_cutoff) { bool range; l_has[k] = as_of(L, l_r[k], &l_as[k], &range); }
+        if (l_in[k] && use_cut) { bool range; l_has[k] = as_of(L, l_r[k], &l_as[k], &range); }
         l_q[k] = l_in[k] ? L.qid_base + (uint32_t)L.read_qid[l_r[k]] : 0u;
         l_a0[k] = l_in[k] ? O.a0[l_v[k]] : (uint8_t)0; l_a1[k] = l_in[k] ? O.a1[l_v[k]] : (uint8_t)0;
     }
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(LINE_TB) void k_line(LinesTab T, LineOut O) {
         if (!l_in[k]) continue;
         const int64_t g = L.line_base + i0 + tid + LINE_TB * k;
         const int v = l_v[k];
-        const bool keep = !L.use_cutoff || (l_has[k] && (double)l_as[k] >= L.cutoff);
+        const bool keep = !use_cut || (l_has[k] && (double)l_as[k] >= cut);
         if (!keep) { O.line_cls[g] = 255; continue; }
         kept++;
         const uint8_t c = l_code[k];
@@ -1068,7 +1072,7 @@ struct Timer {
 };
 
 int stage_lines(Staging &st, const phz_lines &h, int space, LinesDev *d) {
-    d->n = h.n_calls; d->cutoff = h.as_cutoff; d->use_cutoff = h.use_cutoff; d->bam = h.bam_index;
+    d->n = h.n_calls; d->cutoff = h.as_cutoff; d->use_cutoff = h.use_cutoff; d->bam = h.bam_index; d->cut_dev = h.as_cutoff_dev;
     d->var_base = (int32_t)h.var_base; d->qid_base = (uint32_t)h.qid_base; d->line_base = 0;
     if (int s = st.in(h.read_idx, (size_t)h.n_calls, space, &d->read_idx)) return s;
     if (int s = st.in(h.var_idx, (size_t)h.n_calls, space, &d->var_idx)) return s;
@@ -1269,6 +1273,77 @@ extern "C" int phz_as_cutoff(phz_ctx *ctx, const phz_lines *shards, int n_shards
     for (int i = 0; i < nb; i++) n += counts[i];
     *found = n > 0 ? 1 : 0; *cutoff = 0.0;
     if (n > 0) *cutoff = percentile_of_bins(bins.data(), counts.data(), nb, q_percent);
+    return PHZ_OK;
+}
+
+// numpy.percentile on the device: one workgroup over the 64 Ki-bin histogram (bin b = AS b - 32768).  Thread t adds up bins [64 t, 64 t + 64), the partial sums are
+// scanned by the waves, the two order statistics the linear method interpolates between are found by the threads whose ranges hold them; thread 0 then performs
+// percentile_of_bins' float64 operations one by one (contraction off: an fma would round once where numpy rounds twice).
+__global__ __launch_bounds__(1024) void k_as_percentile(const unsigned long long *hist, const unsigned int *flags, double quant, double *out) {
+#pragma clang fp contract(off)
+    __shared__ unsigned long long s_incl[1024];
+    __shared__ unsigned long long s_wsum[16];
+    __shared__ long long s_val[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long mine = 0;
+    for (int b = 0; b < 64; b++) mine += hist[tid * 64 + b];
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int w = 0; w < wave; w++) before += s_wsum[w];
+    incl += before;
+    s_incl[tid] = incl;
+    __syncthreads();
+    const long long n = (long long)s_incl[1023];
+    if (n <= 0) { if (tid == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = flags[0] ? 1.0 : 0.0; out[3] = 0.0; } return; }
+    const double virt = (double)(n - 1) * quant;
+    long long prev = (long long)floor(virt);
+    const double gamma = virt - (double)prev;
+    long long nxt = prev + 1;
+    if (virt >= (double)(n - 1)) prev = nxt = n - 1;
+    if (virt < 0) prev = nxt = 0;
+    const unsigned long long excl = incl - mine;
+    for (int which = 0; which < 2; which++) {
+        const unsigned long long k = (unsigned long long)(which ? nxt : prev);
+        if (k >= excl && k < incl) {          // the k-th smallest score lies in this thread's bins
+            unsigned long long c = excl;
+            for (int b = 0; b < 64; b++) { c += hist[tid * 64 + b]; if (c > k) { s_val[which] = (long long)(tid * 64 + b) - 32768; break; } }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const long long a = s_val[0], b = s_val[1], diff = b - a;
+        double r = (double)a + (double)diff * gamma;
+        if (gamma >= 0.5) r = (double)b - (double)diff * (1 - gamma);
+        out[0] = r; out[1] = 1.0; out[2] = flags[0] ? 1.0 : 0.0; out[3] = (double)n;
+    }
+}
+
+extern "C" int phz_as_cutoff_enqueue(phz_ctx *ctx, const phz_lines *shards, int n_shards, double q_percent, double *dev_out) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || (!shards && n_shards) || n_shards < 0 || !dev_out) return PHZ_E_ARG;
+    PHZ_HIP(ctx, hipSetDevice(ctx->device));
+    Staging st(ctx);
+    std::vector<LinesDev> L((size_t)n_shards);
+    for (int i = 0; i < n_shards; i++)
+        if (int s = stage_lines(st, shards[i], PHZ_DEVICE, &L[(size_t)i])) return s;
+    if (int s2 = phz_reserve(ctx, ctx->scratch[0], PHZ_AS_BINS * 8 + 16)) return s2;
+    char *d = (char *)ctx->scratch[0].p;
+    unsigned long long *hist = (unsigned long long *)d;
+    unsigned int *flags = (unsigned int *)(d + PHZ_AS_BINS * 8);
+    PHZ_HIP(ctx, hipMemsetAsync(d, 0, PHZ_AS_BINS * 8 + 16, ctx->stream));
+    if (n_shards > 0) {
+        LinesTab T;
+        std::vector<uint32_t> grids;
+        if (int s2 = upload_tab(ctx, L.data(), n_shards, as_hist_blocks, &T, &grids)) return s2;
+        if (grids.back() > 0) hipLaunchKernelGGL(k_as_hist, dim3(grids.back()), dim3(256), 0, ctx->stream, T, hist, flags);
+    }
+    static_assert(PHZ_AS_BINS == 65536, "k_as_percentile: 1024 threads x 64 bins");
+    hipLaunchKernelGGL(k_as_percentile, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist, (const unsigned int *)flags, q_percent / 100.0, dev_out);
+    PHZ_HIP(ctx, hipGetLastError());
     return PHZ_OK;
 }
 

@@ -125,6 +125,7 @@ class _Shard:
         self.calls = calls; self.qid = qid; self.aln = aln; self.has_as = has_as; self.n_reads = n_reads
         self.as16 = as16               # the AS column as one 2-byte plane (soa.as16_plane): what the tally kernels gather
         self.cutoff = 0.0; self.use_cutoff = 0
+        self.cut_dev = None            # the BAM's cutoff block on the device (phz_as_cutoff_enqueue), when the percentile never visited the host
         self.as_absmax = None
 
 
@@ -143,6 +144,7 @@ class Engine:
         self.qnames: Dict[str, List[str]] = {}
         self.n_qid: Dict[str, int] = {c: 0 for c in self.all_chroms}
         self.log: List[str] = []
+        self._pending_cut = []         # (log index, device block, shards) of AS cutoffs still on the device (close_bam -> resolve_cutoffs)
         self.stats: Dict[str, float] = {}
         self.total_lines = 0
 
@@ -208,6 +210,7 @@ class Engine:
                     c.__dict__["_phz_ln"] = (ln, c.read_idx, sh.qid, sh.aln, sh.has_as, c.n, sh.as16)
             sh._ln = ln; sh._ln_n = c.n
         ln.as_cutoff = float(sh.cutoff); ln.use_cutoff = int(sh.use_cutoff); ln.bam_index = bam_index; ln.var_base = var_base; ln.qid_base = qid_base
+        ln.as_cutoff_dev = _p(sh.cut_dev) if sh.cut_dev is not None else None
         return ln
 
     def close_bam(self, bam_index: int):
@@ -232,6 +235,17 @@ class Engine:
                 # (histogram -> occupied bins -> numpy.percentile's formula, all inside phz_as_cutoff; percentile_from_sparse is its Python twin)
                 arr = (_lib.phz_lines * len(live))(*[self._lines(sh, bam_index) for sh in live])
                 torch.cuda.current_stream(dev).synchronize()
+                if os.environ.get("PHZ_AS_CUTOFF_HOST") != "1":
+                    # ... and the percentile itself stays there too (phz_as_cutoff_enqueue: no host wait between the histogram and the tally; the kernels of the
+                    # tally read the cutoff from the block).  The value reaches the log when somebody asks for it (resolve_cutoffs: the CLI after every BAM,
+                    # finish() at the latest)
+                    blk = torch.empty(4, dtype=torch.float64, device=dev)          # this Engine's own (another Engine on the same mapper may still hold a pending block)
+                    self.ctx.check(self.lib.phz_as_cutoff_enqueue(self.ctx.h, arr, len(live), float(self.cfg.as_q_cutoff * 100), _p(blk)))
+                    for sh in shards:
+                        sh.cut_dev = blk; sh.use_cutoff = 1; sh.cutoff = 0.0
+                    self._pending_cut.append((len(self.log), blk, shards))
+                    self.log.append(None)          # placeholder of the BAM's log line
+                    return
                 val = C.c_double(0.0); found = C.c_int32(0)
                 st = self.ctx.check(self.lib.phz_as_cutoff(self.ctx.h, arr, len(live), float(self.cfg.as_q_cutoff * 100), C.byref(val), C.byref(found)),
                                     allow=(_lib.PHZ_E_CAPACITY,))
@@ -246,6 +260,26 @@ class Engine:
                     sh.cutoff = float(cutoff); sh.use_cutoff = 1
             else:
                 self.log.append("          no alignment score value found in reads, cannot use cutoff")
+
+    def resolve_cutoffs(self):
+        """The AS cutoffs that were computed on the device without a host wait (close_bam): read them back (one small copy per BAM), write the BAM's log line
+        (phaser.py:552-553) where it belongs, refuse an input whose AS values do not fit int16."""
+        if not self._pending_cut:
+            return
+        pend, self._pending_cut = self._pending_cut, []
+        self.ctx.check(self.lib.phz_ctx_sync(self.ctx.h))
+        for at, blk, shards in pend:
+            v = blk.cpu().numpy()
+            if v[2] != 0:
+                raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
+            if v[1] != 0:
+                self.log[at] = "          using alignment score cutoff of %d" % float(v[0])
+                for sh in shards:
+                    sh.cutoff = float(v[0])
+            else:
+                self.log[at] = "          no alignment score value found in reads, cannot use cutoff"
+                for sh in shards:
+                    sh.use_cutoff = 0; sh.cut_dev = None
 
     def _as_cutoff_dense(self, hb, live, dev, bam_index):
         """The dense 64 Ki-bin histogram (all-reduced over the ranks) -> cutoff."""
@@ -422,6 +456,7 @@ class Engine:
         noise = self.noise_from_counts(match, mism)
         t1 = _t.perf_counter()
         local = self._fragments(noise)
+        self.resolve_cutoffs()          # (cutoffs computed on the device: their log lines, the int16 check)
         t2 = _t.perf_counter()
         frags = pdist.gather_fragments(local, getattr(self, "spool_dir", None), self.all_chroms)
         self.stats.update({"tally_s": t1 - t0, "fragments_s": t2 - t1})

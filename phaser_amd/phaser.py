@@ -446,6 +446,7 @@ def _main(argv, state):
         say("          processing mapped reads...")
         n_before = len(eng.log)
         eng.close_bam(bi)
+        eng.resolve_cutoffs()          # (the CLI prints the BAM's cutoff line here; a caller that streams passes leaves it to finish())
         mark("AS cutoff")
         for line in eng.log[n_before:]:
             say(line)

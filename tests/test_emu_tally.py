@@ -257,3 +257,12 @@ def test_as_cutoff_is_numpy_percentile():
                     assert found.value == 0
                 else:
                     assert found.value == 1 and val.value == float(np.percentile(scores, q)), (trial, q, val.value, float(np.percentile(scores, q)))
+                # the same on the device, no host wait (phz_as_cutoff_enqueue: one workgroup scans the 64 Ki bins and interpolates): identical bits
+                blk = np.full(4, -7.0, dtype=np.float64)
+                ctx.check(ctx.lib.phz_as_cutoff_enqueue(ctx.h, arr, 1, float(q), vp(blk)))
+                ctx.check(ctx.lib.phz_ctx_sync(ctx.h))
+                assert blk[2] == 0.0 and blk[3] == float(len(scores))
+                if len(scores) == 0:
+                    assert blk[1] == 0.0
+                else:
+                    assert blk[1] == 1.0 and blk[0] == float(np.percentile(scores, q)), (trial, q, blk[0], float(np.percentile(scores, q)))

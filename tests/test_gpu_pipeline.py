@@ -311,7 +311,7 @@ def test_deep_coverage_vs_oracle(mapper, oracle_build, tmp_path, seed, err, pair
     heng.ctx.check(heng.lib.phz_hap_counts(heng.ctx.h, C.c_void_p(got_h.ctypes.data), nseg, _lib.PHZ_HOST))
     got_d = torch.full((nseg,), -1, dtype=torch.int32, device="cuda")
     heng.ctx.check(heng.lib.phz_hap_counts(heng.ctx.h, C.c_void_p(got_d.data_ptr()), nseg, _lib.PHZ_DEVICE))
-    assert np.array_equal(got_h, want_n) and np.array_equal(got_d.cpu().numpy(), want_n) and int(want_n.max()) > 256
+    assert np.array_equal(got_h, want_n) and np.array_equal(got_d.cpu().numpy(), want_n) and int(want_n.max()) > 64          # (lists beyond one thread's 32 entries: the wave kernel; the first case has lists of thousands)
 
 
 @pytest.mark.parametrize("seed,n_snps,err,pairs,mbs,L", [(9201, 400, 0.003, 3000, 15, 76), (9202, 1500, 0.03, 2500, 10, 76), (9301, 1500, 0.01, 200, 15, 1000)])
@@ -765,3 +765,44 @@ def test_device_sort_matches_a_stable_host_sort(mapper, dtype, ranges, n):
             ko = np.empty_like(keys); vo = np.empty_like(vals)
             ctx.check(ctx.lib.phz_selftest_sort(ctx.h, keys.dtype.itemsize, vp(keys), vp(vals), n, vp(rg), len(ranges), three, vp(ko), vp(vo)))
             assert np.array_equal(vo, vals[order]) and np.array_equal(ko, keys[order]), (three, rep)
+
+
+@pytest.mark.parametrize("strip", ["none", "some", "second_bam"])
+def test_as_cutoff_on_the_device_equals_the_host_percentile(mapper, monkeypatch, strip):
+    """close_bam leaves the AS percentile on the device (phz_as_cutoff_enqueue: histogram -> order statistics -> numpy's interpolation in one workgroup, no host
+    wait; the tally kernels read the block) -- against the same pass with the percentile taken on the host (PHZ_AS_CUTOFF_HOST=1: phz_as_cutoff), which is pinned
+    against numpy.percentile.  Fixture pipe_two as written by the reference; with the AS tag stripped from a third of the records; with the second BAM
+    carrying no AS tag at all ('no alignment score value found in reads, cannot use cutoff', phaser.py:553: every line of that BAM is kept).  Same five files,
+    same log lines; as_q_cutoff 0.37 puts the percentile between two order statistics (gamma != 0)."""
+    import re
+    d = os.path.join(GOLD, "pipe_two")
+    bams = {}
+    for bi, b in enumerate(("t1", "t2")):
+        bams[b + ".bam"] = {}
+        for c in ("chr21", "chr22"):
+            text = gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c)))
+            if strip == "some":
+                lines = text.split("\n")
+                text = "\n".join(re.sub(r"\tAS:i:-?\d+", "", l) if (i % 3 == 0 and not l.startswith("@")) else l for i, l in enumerate(lines))
+            elif strip == "second_bam" and bi == 1:
+                text = re.sub(r"\tAS:i:-?\d+", "", text)
+            bams[b + ".bam"][c] = text
+    vcf_text = open(os.path.join(d, "in.vcf")).read()
+    runs = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("PHZ_AS_CUTOFF_HOST", "1")
+        else:
+            monkeypatch.delenv("PHZ_AS_CUTOFF_HOST", raising=False)
+        for q in (0.05, 0.37):
+            out, eng = run_product(mapper, vcf_text, bams, "cuda", as_q_cutoff=q)
+            assert all(isinstance(l, str) for l in eng.log)
+            runs[(mode, q)] = (out, [l for l in eng.log if "alignment score" in l])
+    for q in (0.05, 0.37):
+        assert runs[("device", q)][1] == runs[("host", q)][1] and len(runs[("device", q)][1]) == 2
+        for name in OUTPUTS:
+            assert runs[("device", q)][0][name] == runs[("host", q)][0][name], (name, q)
+    if strip == "none":
+        compare(runs[("device", 0.05)][0], d)
+    if strip == "second_bam":
+        assert "cannot use cutoff" in runs[("device", 0.05)][1][1] and "using alignment score cutoff" in runs[("device", 0.05)][1][0]
