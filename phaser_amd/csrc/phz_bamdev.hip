@@ -606,13 +606,18 @@ int phz_bamdev_open(phz_ctx *ctx, const char *path, const char *const *ref_names
     // >= 16 queues (the package asks for them before the runtime starts, phaser_amd/__init__.py): 3 streams x 1,280 MB chunks, file -> shards 0.24 s; a host
     // application that keeps the runtime's default gets ONE launch per 4 GB (0.27 s; 0.32 s with the old 1,280 MB chunks on one stream).
     bool many_queues = false;
-    { const char *q = getenv("GPU_MAX_HW_QUEUES"); many_queues = q && atoi(q) >= 16; }
+    { const char *q = getenv("GPU_MAX_HW_QUEUES"); many_queues = q && atoi(q) >= 16 && getenv("PHZ_HW_QUEUES_LATE") == nullptr; }      // (LATE: the variable was set after the runtime had started)
     if (many_queues) n_is = 3;
     { const char *e = getenv("PHZ_BAM_INFLATE_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= 8) n_is = atoi(e); }
     std::vector<hipStream_t> is((size_t)n_is, nullptr);
     if (n_is > 1) {
         (void)hipStreamSynchronize(sm);                  // the member table and the cleared status word are on the device before any other stream reads them
-        for (int t = 0; t < n_is; t++) if (hipStreamCreateWithFlags(&is[(size_t)t], hipStreamNonBlocking) != hipSuccess) { is[(size_t)t] = nullptr; n_is = 1; }
+        bool all = true;
+        for (size_t t = 0; t < is.size(); t++) if (hipStreamCreateWithFlags(&is[t], hipStreamNonBlocking) != hipSuccess) { is[t] = nullptr; all = false; }
+        if (!all) {          // one stream could not be made: every stream that was goes away again, the chunks take the ctx stream
+            for (size_t t = 0; t < is.size(); t++) if (is[t]) { (void)hipStreamDestroy(is[t]); is[t] = nullptr; }
+            n_is = 1;
+        }
     }
     {
         // a launch lasts as long as its slowest member (60-100 ms) however few it holds, and the chip holds 262,000 members at once: big chunks (PHZ_BAM_CHUNK_MB)

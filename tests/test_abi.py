@@ -59,3 +59,17 @@ def test_package_asks_for_hardware_queues_unless_the_user_did():
     assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip() == "16"
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip() == "4"
+
+
+def test_hardware_queues_are_not_claimed_after_the_runtime_started():
+    """(round-5 advisor) An application that initialised the GPU runtime BEFORE importing the package keeps the runtime's four hardware queues whatever the
+    variable says afterwards: the package then leaves the variable alone and tells the BAM decoder (PHZ_HW_QUEUES_LATE) to keep its one-launch policy.
+    The started runtime is simulated by a torch stand-in whose cuda.is_initialized() answers True."""
+    import subprocess, sys
+    code = ("import sys, types, os; t = types.ModuleType('torch'); t.cuda = types.SimpleNamespace(is_initialized=lambda: True); sys.modules['torch'] = t; "
+            "import phaser_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'), os.environ.get('PHZ_HW_QUEUES_LATE'))")
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "PHZ_HW_QUEUES_LATE")}
+    env["PYTHONPATH"] = REPO
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip() == "None 1"
+    env["GPU_MAX_HW_QUEUES"] = "16"          # exported by the user before the application started: trusted
+    assert subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip() == "16 None"
