@@ -232,6 +232,7 @@ __global__ __launch_bounds__(LINE_TB) void k_line(LinesTab T, LineOut O) {
     // the cutoff of the shard's BAM: a host value, or the block the device-side percentile left (phz_as_cutoff_enqueue; [1] == 0: no AS tag in the BAM, every line kept)
     const bool use_cut = L.use_cutoff != 0 && (L.cut_dev == nullptr || L.cut_dev[1] != 0.0);
     const double cut = L.cut_dev != nullptr ? L.cut_dev[0] : L.cutoff;
+    if (bx == 0 && tid == 0 && L.cut_dev != nullptr && L.cut_dev[2] != 0.0) O.counters[13] = 1ull;      // the histogram saw an AS value outside int16: phz_tally refuses the input at its first wait
 #pragma unroll
     for (int k = 0; k < K; k++) {
         l_as[k] = 0; l_has[k] = true;
@@ -1481,6 +1482,7 @@ extern "C" int phz_tally(phz_ctx *ctx, const phz_lines *shards, int n_shards, in
     PHZ_HIP(ctx, hipMemcpyAsync(ctx->mail_host.p, counters, CNT_BYTES, hipMemcpyDeviceToHost, sm));
     PHZ_HIP(ctx, hipStreamSynchronize(sm));
     memcpy(h_counters, ctx->mail_host.p, CNT_BYTES);
+    if (h_counters[13]) return phz_fail(ctx, PHZ_E_UNSUPPORTED, "AS value outside int16");          // (reported by the device-side percentile of a BAM: phz_as_cutoff_enqueue)
     const int64_t n_kept = (int64_t)spread_sum(2);
     const int64_t n_dirty = (int64_t)h_counters[11];
     ctx->counters[PHZ_C_FAR_LINES] += (int64_t)h_counters[12]; ctx->counters[PHZ_C_DIRTY_LISTS] += n_dirty;

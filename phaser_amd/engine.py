@@ -143,7 +143,7 @@ class Engine:
         self.shards: Dict[str, List[Optional[_Shard]]] = {c: [None] * len(bam_names) for c in self.all_chroms}
         self.qnames: Dict[str, List[str]] = {}
         self.n_qid: Dict[str, int] = {c: 0 for c in self.all_chroms}
-        self.log: List[str] = []
+        self._log: List[str] = []
         self._pending_cut = []         # (log index, device block, shards) of AS cutoffs still on the device (close_bam -> resolve_cutoffs)
         self.stats: Dict[str, float] = {}
         self.total_lines = 0
@@ -243,8 +243,8 @@ class Engine:
                     self.ctx.check(self.lib.phz_as_cutoff_enqueue(self.ctx.h, arr, len(live), float(self.cfg.as_q_cutoff * 100), _p(blk)))
                     for sh in shards:
                         sh.cut_dev = blk; sh.use_cutoff = 1; sh.cutoff = 0.0
-                    self._pending_cut.append((len(self.log), blk, shards))
-                    self.log.append(None)          # placeholder of the BAM's log line
+                    self._pending_cut.append((len(self._log), blk, shards))
+                    self._log.append(None)          # placeholder of the BAM's log line
                     return
                 val = C.c_double(0.0); found = C.c_int32(0)
                 st = self.ctx.check(self.lib.phz_as_cutoff(self.ctx.h, arr, len(live), float(self.cfg.as_q_cutoff * 100), C.byref(val), C.byref(found)),
@@ -255,11 +255,23 @@ class Engine:
             if not done:
                 cutoff = self._as_cutoff_dense(hb, live, dev, bam_index)
             if cutoff is not None:
-                self.log.append("          using alignment score cutoff of %d" % cutoff)
+                self._log.append("          using alignment score cutoff of %d" % cutoff)
                 for sh in shards:
                     sh.cutoff = float(cutoff); sh.use_cutoff = 1
             else:
-                self.log.append("          no alignment score value found in reads, cannot use cutoff")
+                self._log.append("          no alignment score value found in reads, cannot use cutoff")
+
+    @property
+    def log(self) -> List[str]:
+        """The log lines of the run (the reference's stdout lines of the stages this class covers).  Reading them brings in whatever is still on the device
+        (the AS cutoffs of close_bam): a caller that streams passes and never looks at the log pays no host wait for them."""
+        if self._pending_cut:
+            self.resolve_cutoffs()
+        return self._log
+
+    @log.setter
+    def log(self, value):
+        self._log = value
 
     def resolve_cutoffs(self):
         """The AS cutoffs that were computed on the device without a host wait (close_bam): read them back (one small copy per BAM), write the BAM's log line
@@ -273,11 +285,11 @@ class Engine:
             if v[2] != 0:
                 raise _lib.PhzError(_lib.PHZ_E_UNSUPPORTED, "AS value outside int16")
             if v[1] != 0:
-                self.log[at] = "          using alignment score cutoff of %d" % float(v[0])
+                self._log[at] = "          using alignment score cutoff of %d" % float(v[0])
                 for sh in shards:
                     sh.cutoff = float(v[0])
             else:
-                self.log[at] = "          no alignment score value found in reads, cannot use cutoff"
+                self._log[at] = "          no alignment score value found in reads, cannot use cutoff"
                 for sh in shards:
                     sh.use_cutoff = 0; sh.cut_dev = None
 
@@ -456,7 +468,6 @@ class Engine:
         noise = self.noise_from_counts(match, mism)
         t1 = _t.perf_counter()
         local = self._fragments(noise)
-        self.resolve_cutoffs()          # (cutoffs computed on the device: their log lines, the int16 check)
         t2 = _t.perf_counter()
         frags = pdist.gather_fragments(local, getattr(self, "spool_dir", None), self.all_chroms)
         self.stats.update({"tally_s": t1 - t0, "fragments_s": t2 - t1})
@@ -478,7 +489,7 @@ class Engine:
                     self.vcf_blocks.append((c, frags[c]["vcf"], block_index))
                     block_index += len(frags[c]["vcf"]["size"])
         self.stats["merge_s"] = _t.perf_counter() - t3
-        self.log += summary["log"]
+        self._log += summary["log"]
         self.phased = summary["phased"]; self.total_lines = summary["lines"]
         if self.cfg.py_hash_order:
             # raw-byte tier: replay the reference's set constructions over the same strings (an exactness mode: pure Python over every call line)

@@ -806,3 +806,20 @@ def test_as_cutoff_on_the_device_equals_the_host_percentile(mapper, monkeypatch,
         compare(runs[("device", 0.05)][0], d)
     if strip == "second_bam":
         assert "cannot use cutoff" in runs[("device", 0.05)][1][1] and "using alignment score cutoff" in runs[("device", 0.05)][1][0]
+
+
+def test_as_value_outside_int16_is_refused_by_the_pass(mapper):
+    """An AS tag beyond int16 (the histogram's band): the device-side percentile flags it in its block and phz_tally refuses the input at its first host wait
+    (PHZ_E_UNSUPPORTED), exactly as the host percentile refuses it in close_bam (PHZ_AS_CUTOFF_HOST=1)."""
+    import re
+    from phaser_amd import _lib
+    d = os.path.join(GOLD, "pipe_one")
+    sam = gz_text(os.path.join(d, "a.chr22.sam.gz"))
+    lines = sam.split("\n")
+    k = next(i for i, l in enumerate(lines) if not l.startswith("@") and "AS:i:" in l and i > 200)
+    lines[k] = re.sub(r"AS:i:-?\d+", "AS:i:70000", lines[k])
+    with pytest.raises(_lib.PhzError) as e:
+        run_product(mapper, open(os.path.join(d, "in.vcf")).read(), {"a.bam": {"chr22": "\n".join(lines)}}, "cuda")
+    assert e.value.status == _lib.PHZ_E_UNSUPPORTED and "int16" in str(e.value)
+    out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(), {"a.bam": {"chr22": sam}}, "cuda")      # the ctx stays usable
+    compare(out, d)

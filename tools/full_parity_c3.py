@@ -88,6 +88,7 @@ def main():
         eng.close_bam(0)
         t0 = time.perf_counter()
         got = eng.finish()
+        eng.resolve_cutoffs()          # (the percentile was taken on the device: bring the value in)
         cutoff = float(next(sh for sh in eng.shards[plan[0][0]] if sh is not None).cutoff)
         print("product: stages T1-O2 of the whole genome in %.3f s (first pass), rows on the %s, %d phased variants" % (time.perf_counter() - t0, eng.rows_path, eng.phased), flush=True)
         # ---- phasing oracle: one process per chromosome, `cores` at a time, largest first; every process gets the two scalars the reference computes over
