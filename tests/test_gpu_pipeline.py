@@ -808,7 +808,7 @@ def test_as_cutoff_on_the_device_equals_the_host_percentile(mapper, monkeypatch,
         assert "cannot use cutoff" in runs[("device", 0.05)][1][1] and "using alignment score cutoff" in runs[("device", 0.05)][1][0]
 
 
-def test_as_value_outside_int16_is_refused_by_the_pass(mapper):
+def test_as_value_outside_int16_is_refused_by_the_pass(mapper, monkeypatch):
     """An AS tag beyond int16 (the histogram's band): the device-side percentile flags it in its block and phz_tally refuses the input at its first host wait
     (PHZ_E_UNSUPPORTED), exactly as the host percentile refuses it in close_bam (PHZ_AS_CUTOFF_HOST=1)."""
     import re
@@ -816,10 +816,15 @@ def test_as_value_outside_int16_is_refused_by_the_pass(mapper):
     d = os.path.join(GOLD, "pipe_one")
     sam = gz_text(os.path.join(d, "a.chr22.sam.gz"))
     lines = sam.split("\n")
-    k = next(i for i, l in enumerate(lines) if not l.startswith("@") and "AS:i:" in l and i > 200)
-    lines[k] = re.sub(r"AS:i:-?\d+", "AS:i:70000", lines[k])
-    with pytest.raises(_lib.PhzError) as e:
-        run_product(mapper, open(os.path.join(d, "in.vcf")).read(), {"a.bam": {"chr22": "\n".join(lines)}}, "cuda")
-    assert e.value.status == _lib.PHZ_E_UNSUPPORTED and "int16" in str(e.value)
+    for k, l in enumerate(lines):          # (the histogram is over the records of the call lines: every 20th record, so that some of them carry a call)
+        if k % 20 == 0 and not l.startswith("@") and "AS:i:" in l:
+            lines[k] = re.sub(r"AS:i:-?\d+", "AS:i:70000", l)
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("PHZ_AS_CUTOFF_HOST", "1")
+        with pytest.raises(_lib.PhzError) as e:
+            run_product(mapper, open(os.path.join(d, "in.vcf")).read(), {"a.bam": {"chr22": "\n".join(lines)}}, "cuda")
+        assert e.value.status == _lib.PHZ_E_UNSUPPORTED and "int16" in str(e.value), mode
+    monkeypatch.delenv("PHZ_AS_CUTOFF_HOST", raising=False)
     out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(), {"a.bam": {"chr22": sam}}, "cuda")      # the ctx stays usable
     compare(out, d)
