@@ -600,6 +600,9 @@ int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host /* [
 /* host helper between the two stages: values and repr() text of the p-values laid out by slot (used[] ascending = the occupied slots of
  * phz_rowsdev_pair_keys, pv[i] = scipy.stats.binom.cdf for slot used[i]).  Returns the bytes of txt, -1 on bad arguments / txt_cap too small
  * (n_slots + 40 bytes per used slot always fits). */
+/* host helper in front of it: the occupied slots of keys_host in slot order -> used[] (slot), sup[] (supporting count as float64), tot[] (total as int64): the argument
+ * arrays of the binomial call; every output has capacity n_slots; returns their number (-1 on bad arguments). */
+int64_t phz_pair_slots_used(const uint64_t *keys, int64_t n_slots, uint32_t *used, double *sup, int64_t *tot);
 int64_t phz_pair_slot_text(const uint32_t *used, const double *pv, int64_t n_used, int64_t n_slots, double *slot_pv /* [n_slots] */,
                            uint32_t *txt_off /* [n_slots + 1] */, char *txt, int64_t txt_cap);
 int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_opts *opts, const double *slot_pv /* [phz_rowsdev_pair_slots(h)] */,

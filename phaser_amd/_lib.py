@@ -298,6 +298,7 @@ SYMBOLS = {
     "phz_rowsdev_pair_slots": (C.c_int64, [C.c_void_p]),
     "phz_rowsdev_pair_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "phz_pair_slot_text": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "phz_pair_slots_used": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "phz_rowsdev_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_result)]),
     "phz_rowsdev_fetch_text": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "phz_rowsdev_text_ptr": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -1013,6 +1013,21 @@ extern "C" int64_t phz_pair_slot_text(const uint32_t *used, const double *pv, in
     return at;
 }
 
+// host helper in front of it: the occupied slots of the pair-key table (keys as phz_rowsdev_pair_keys left them: total << 32 | supporting, all ones = empty), in slot
+// order, as the arrays the caller hands to scipy.stats.binom.cdf (k as float64, n as int64: the argument types of the reference's call after numpy's conversion).
+// Returns the number of occupied slots (<= n_slots = the capacity of every output array).
+extern "C" int64_t phz_pair_slots_used(const uint64_t *keys, int64_t n_slots, uint32_t *used, double *sup, int64_t *tot) {
+    if (n_slots < 0 || (n_slots && (!keys || !used || !sup || !tot))) return -1;
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_slots; i++) {
+        const uint64_t k = keys[i];
+        if (k == ~0ull) continue;
+        used[n] = (uint32_t)i; sup[n] = (double)(uint32_t)(k & 0xFFFFFFFFull); tot[n] = (int64_t)(k >> 32);
+        n++;
+    }
+    return n;
+}
+
 extern "C" void phz_rows_free(phz_rows_out *o) {
     if (!o) return;
     for (phz_text_parts *P : {&o->conn, &o->hap, &o->ase, &o->cfg, &o->allelic, &o->single_ase, &o->single_hap}) {
