@@ -313,17 +313,26 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
         raise _lib.PhzError(_lib.PHZ_E_ARG, "phz_pair_slot_text")
     t2 = _t.perf_counter()
     # ---- stage 2
-    bam_off, bam_txt = sep_pool(list(eng.bam_names))
-    ex = None
-    if cfg.haplo_count_bam_exclude:
-        ex = np.zeros(nb, dtype=np.uint8)
-        for b in cfg.haplo_count_bam_exclude:
-            if 0 <= b < nb:
-                ex[b] = 1
+    # the options record of the stage: the same for every pass over the same shards (a sample stream, the bench): kept with the variant tables, rebuilt when anything
+    # in it changes (0.05 ms of Python per pass, inside the window in which the GPU waits for the p-values)
     sh = sorted(((base, base + n, b) for (c, b), (base, n) in G["line_base"].items()))
-    lo = np.array([x[0] for x in sh], dtype=np.int64); hi = np.array([x[1] for x in sh], dtype=np.int64); sb = np.array([x[2] for x in sh], dtype=np.int32)
-    o = _lib.phz_rowsdev_opts(nb, _vp(bam_off), _vp(bam_txt), _vp(ex), len(sh), _vp(lo), _vp(hi), _vp(sb), int(cfg.unique_ids), int(cfg.gw_phase_method),
-                              int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.max_block_size), 1 if (cfg.want_vcf or cfg.py_hash_order) else 0, float(cfg.cc_threshold))
+    okey = (tuple(eng.bam_names), tuple(sh), tuple(cfg.haplo_count_bam_exclude or ()), int(cfg.unique_ids), int(cfg.gw_phase_method), int(cfg.output_read_ids),
+            int(cfg.unphased_vars), int(cfg.max_block_size), 1 if (cfg.want_vcf or cfg.py_hash_order) else 0, float(cfg.cc_threshold))
+    oc = T.__dict__.get("_opts_cache")
+    if oc is not None and oc[0] == okey:
+        o = oc[1]
+    else:
+        bam_off, bam_txt = sep_pool(list(eng.bam_names))
+        ex = None
+        if cfg.haplo_count_bam_exclude:
+            ex = np.zeros(nb, dtype=np.uint8)
+            for b in cfg.haplo_count_bam_exclude:
+                if 0 <= b < nb:
+                    ex[b] = 1
+        lo = np.array([x[0] for x in sh], dtype=np.int64); hi = np.array([x[1] for x in sh], dtype=np.int64); sb = np.array([x[2] for x in sh], dtype=np.int32)
+        o = _lib.phz_rowsdev_opts(nb, _vp(bam_off), _vp(bam_txt), _vp(ex), len(sh), _vp(lo), _vp(hi), _vp(sb), int(cfg.unique_ids), int(cfg.gw_phase_method),
+                                  int(cfg.output_read_ids), int(cfg.unphased_vars), int(cfg.max_block_size), 1 if (cfg.want_vcf or cfg.py_hash_order) else 0, float(cfg.cc_threshold))
+        T.__dict__["_opts_cache"] = (okey, o, (bam_off, bam_txt, ex, lo, hi, sb))          # (the arrays the record points at live with it)
     if cfg.output_read_ids == 1:
         # the QNAME strings behind the template ids (phaser.py:1120-1123, :1196-1204): template ids are per chromosome, the pool lists the chromosomes' names one after the other
         names = []; qbase = np.zeros(len(eng.chrom_list) + 1, dtype=np.int64)
@@ -335,7 +344,11 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
         _keep_q = (q_off, q_txt, qbase)
     R = _lib.phz_rowsdev_result()
     t2b = _t.perf_counter()
-    ctx.check(lib.phz_rowsdev_run(ctx.h, T.h, C.byref(o), _vp(slot_pv), _vp(txt_off), _vp(txt), C.byref(R)))
+    try:
+        ctx.check(lib.phz_rowsdev_run(ctx.h, T.h, C.byref(o), _vp(slot_pv), _vp(txt_off), _vp(txt), C.byref(R)))
+    finally:
+        if cfg.output_read_ids == 1:
+            o.qname_off = None; o.qname = None; o.qname_base = None          # (the record is kept; the pool of this pass is not)
     t3 = _t.perf_counter()
     nch = len(eng.chrom_list)
     frags: Dict[str, dict] = {c: {"chrom": c, "lines": 0, "dropped": 0, "phased": 0, "allelic_rows": 0, "n_blocks": 0, "vcf": None} for c in eng.chrom_list}

@@ -188,10 +188,11 @@ def test_tally_kernels_on_long_groups(tile):
 
 
 def test_scan_over_many_tiles():
-    """The single-launch scan (look-back over the predecessors' status words) on a read-list table of 100 tiles, twice on one context (the
-    status words of the first scan must read as stale in the second)."""
+    """The single-launch scan (look-back over the predecessors' status words) on a read-list table of 13 tiles -- more than one round of eight predecessors --,
+    twice on one context (the status words of the first scan must read as stale in the second).  (Until round 6: 100 tiles, 4.5 minutes of fibers since the
+    tally's column scan walks every variant block; the GPU suite runs the scan over thousands of tiles.)"""
     rng = np.random.default_rng(5)
-    nv = 200000; nq = 500; n = 30000
+    nv = 26000; nq = 500; n = 3000
     var = np.sort(rng.integers(0, nv, size=n)).astype(np.int32); qid = rng.integers(0, nq, size=n).astype(np.int32)
     cls = rng.choice([0, 1, 2, 255], size=n, p=[0.45, 0.4, 0.1, 0.05]).astype(np.uint8)
     R = {"nv": nv, "line_var": var, "line_qid": qid, "line_cls": cls, "line_bam": np.zeros(n, np.int32), "bam_offsets": [(0, 0, n)]}
@@ -258,6 +259,8 @@ def test_as_cutoff_is_numpy_percentile():
                 else:
                     assert found.value == 1 and val.value == float(np.percentile(scores, q)), (trial, q, val.value, float(np.percentile(scores, q)))
                 # the same on the device, no host wait (phz_as_cutoff_enqueue: one workgroup scans the 64 Ki bins and interpolates): identical bits
+                if not use16:
+                    continue          # (1,024 fibers per call: the enqueue form is checked on the 2-byte plane, 36 of the 72 cases)
                 blk = np.full(4, -7.0, dtype=np.float64)
                 ctx.check(ctx.lib.phz_as_cutoff_enqueue(ctx.h, arr, 1, float(q), vp(blk)))
                 ctx.check(ctx.lib.phz_ctx_sync(ctx.h))

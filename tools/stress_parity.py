@@ -27,7 +27,7 @@ for it in range(iters):
     if rng.random() < 0.3: cfg["cc_threshold"] = rng.choice([0.001, 0.05, 0.2])
     if rng.random() < 0.3: cfg["as_q_cutoff"] = rng.choice([0.0, 0.2, 0.5])
     if nbam > 1 and rng.random() < 0.3: cfg["haplo_count_bam_exclude"] = [rng.randrange(nbam)]
-    if rng.random() < 0.2: cfg["output_read_ids"] = 1
+    if rng.random() < 0.2 or os.environ.get("PHZ_STRESS_READ_IDS") == "1": cfg["output_read_ids"] = 1          # (PHZ_STRESS_READ_IDS=1: every iteration writes the QNAME columns)
     if rng.random() < 0.25: cfg["gw_phase_method"] = 1          # MAF-weighted genome-wide phase (the synthetic VCF carries AF=...): on the device since round 5
     sparse = rng.random() < 0.25                # some BAMs have no read at all on some chromosomes (block order then follows the first BAM that has one)
     vs_ = []; bams = {"x%d.bam" % b: {} for b in range(nbam)}
