@@ -596,7 +596,15 @@ void phz_rowsdev_destroy(phz_rowsdev *h);
  * PHZ_E_CAPACITY when the distinct (supporting, total) pairs of a pass do not fit (very deep coverage): quadruple and call it again. */
 int phz_rowsdev_set_pair_slots(phz_rowsdev *h, int64_t n_slots);
 int64_t phz_rowsdev_pair_slots(const phz_rowsdev *h);
+/* The (chromosome, BAM) shards of the phz_tally whose results the next phz_rowsdev_pair_keys reads -- line range and BAM per shard, in line order (= phz_rowsdev_opts.shard_*).
+ * Optional: with them the first stage also enqueues the first-appearance keys of allelic_counts / the singleton rows (p-value-independent work that then runs while the
+ * caller evaluates the p-values); phz_rowsdev_run checks them against its own options and redoes the keys when they differ.  phz_tally_pairs sets them itself. */
+int phz_rowsdev_set_shards(phz_rowsdev *h, int32_t n_shards, const int64_t *line_lo, const int64_t *line_hi, const int32_t *bam);
 int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *keys_host /* [phz_rowsdev_pair_slots(h)] */);
+/* phz_tally (same arguments) and phz_rowsdev_pair_keys in one call: no caller glue between the tally's last kernel and the first kernel of the row stage.
+ * Returns phz_tally's status; *pair_status = phz_rowsdev_pair_keys' (PHZ_E_CAPACITY: phz_rowsdev_set_pair_slots, then phz_rowsdev_pair_keys alone). */
+int phz_tally_pairs(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1, int64_t n_qid, int n_bams,
+                    phz_tally_sizes *sizes, int space, phz_rowsdev *h, uint64_t *keys_host, int32_t *pair_status);
 /* host helper between the two stages: values and repr() text of the p-values laid out by slot (used[] ascending = the occupied slots of
  * phz_rowsdev_pair_keys, pv[i] = scipy.stats.binom.cdf for slot used[i]).  Returns the bytes of txt, -1 on bad arguments / txt_cap too small
  * (n_slots + 40 bytes per used slot always fits). */

@@ -239,6 +239,8 @@ SYMBOLS = {
     "phz_as_cutoff_enqueue": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_double, C.c_void_p]),
     "phz_tally": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                             C.POINTER(phz_tally_sizes), C.c_int]),
+    "phz_tally_pairs": (C.c_int, [C.c_void_p, C.POINTER(phz_lines), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                  C.POINTER(phz_tally_sizes), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "phz_tally_fetch": (C.c_int, [C.c_void_p, C.POINTER(phz_tally_out), C.c_int]),
     "phz_hap_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "phz_load_variants": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(phz_variants)]),
@@ -299,6 +301,7 @@ SYMBOLS = {
     "phz_rowsdev_pair_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "phz_pair_slot_text": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "phz_pair_slots_used": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "phz_rowsdev_set_shards": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "phz_rowsdev_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(phz_rowsdev_result)]),
     "phz_rowsdev_fetch_text": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "phz_rowsdev_text_ptr": (C.c_void_p, [C.c_void_p, C.c_int]),

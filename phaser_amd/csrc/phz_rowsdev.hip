@@ -1919,13 +1919,18 @@ struct phz_rowsdev {
     bool keys_ready = false, have_vcf = false;
     uint64_t pre_gen = 0;               // ... of WHICH resident tally (phz_ctx::tally_gen): another tally between the two stages discards them
     bool pre_done = false; unsigned long long pre_max_gap = 0;      // the p-value-independent ordering sorts were enqueued by phz_rowsdev_pair_keys (for the resident tally)
+    // ... and, when the caller has told the handle the (chromosome, BAM) shards of the tally (phz_rowsdev_set_shards / phz_tally_pairs), the first-appearance keys too:
+    // covered variants compacted, sorted by (BAM, first line), their per-(BAM, chromosome) segment starts and counts -- all p-value-independent
+    bool have_shards = false, pre_keys = false; int64_t pre_nkeys = 0;
+    std::vector<long long> sh_lo, sh_hi; std::vector<int32_t> sh_bam;
+    DevBuf sh_dev, sh_host;
     int64_t ps_slots = PS_SLOTS;        // slots of the pair-key hash set (a power of two; grown by the host when a pass reports PHZ_E_CAPACITY)
     std::vector<DevBuf *> all() {
         std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &up_dev, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
                                    &k64a, &k64b, &k32a, &k32b, &v32a, &v32b, &sort_cnt, &scan_tmp, &ridx, &va, &vb, &eorder, &mem_s, &cstart, &corder, &ekeep, &estart,
                                    &key_g, &cnt64, &cnt32, &chrom_cnt, &seg_start, &key64s, &eloc, &alle_of, &sub_of, &nsub, &complex_list, &exc_list, &nsub_o, &blk_base, &blk_mstart, &blk_len,
                                    &blk_of, &v_alle, &blk_sup, &blk_tot, &conc, &cormode, &statkind, &statidx, &maxmaf, &stat, &cfg_rows, &cfg_base, &cfg_chunk, &cfg_pl, &cfg_pb, &cfg_ps, &cfg_bytes, &cfg_bbase, &blk_voff, &mrec, &lab_e, &lab_skip, &big_blk, &labels,
-                                   &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &huge_list, &big_stat, &px_off, &px_txt, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor, &qn_off, &qn_txt, &qn_base, &isf0, &isf2};
+                                   &seg_ns, &blk_cnt, &single_n, &big_list, &big_list2, &huge_list, &big_stat, &px_off, &px_txt, &pool, &tl, &its, &piece_dst, &rowlen, &o_var, &o_maxmaf, &o_hap, &o_cor, &qn_off, &qn_txt, &qn_base, &isf0, &isf2, &sh_dev};
         for (int i = 0; i < 6; i++) { v.push_back(&p_off[i]); v.push_back(&p_txt[i]); }
         for (int i = 0; i < PHZ_TXT_COUNT; i++) { v.push_back(&off[i]); v.push_back(&seg_off_d[i]); v.push_back(&text[i]); }
         return v;
@@ -2096,7 +2101,59 @@ int order_variants_and_pairs(phz_ctx *ctx, phz_rowsdev *h, unsigned long long ma
     return PHZ_OK;
 }
 
+// First-appearance keys (ordering rule 5 of SURVEY 8.1: allelic_counts and the singleton rows list the covered variants by the BAM and line of their first kept call):
+// compaction, sort by (BAM of the first line, line), segment starts per (BAM, chromosome) and their counts.  p-value-independent: enqueued by the first stage when the
+// handle knows the tally's shards, by phz_rowsdev_run otherwise.  ss_keys / cc_keys: the key segments of seg_start / chrom_cnt (cleared by the caller).
+int key_stage(phz_ctx *ctx, phz_rowsdev *h, int64_t nkeys, const long long *d_sh_lo, const long long *d_sh_hi, const int32_t *d_sh_bam, int n_shards, uint32_t *ss_keys, uint32_t *cc_keys) {
+    auto &T = ctx->tally;
+    hipStream_t sm = ctx->stream;
+    const int64_t nv = T.nv, n_lines = T.n_lines;
+    const int nb = T.nb, nchrom = h->nchrom;
+    const size_t NV = (size_t)(nv ? nv : 1), NE = (size_t)(T.n_edges ? T.n_edges : 1), NS = std::max(NV, NE);
+#define RSV(buf, bytes) do { if (int s_ = phz_reserve(ctx, h->buf, (bytes))) return s_; } while (0)
+    RSV(k64a, NS * 8); RSV(k64b, NS * 8); RSV(k32a, NS * 4); RSV(k32b, NS * 4); RSV(v32a, NS * 4); RSV(v32b, NS * 4);
+    RSV(key_g, (size_t)(nkeys + 1) * 4);
+    int bl = bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1));
+    if (const char *fb = getenv("PHZ_ROWS_FAKE_LINE_BITS")) bl = std::max(bl, std::min(32, atoi(fb)));      // tests: the key layout of a BAM with > 2^31 call lines
+    if (nkeys) {
+        ShardTab ST; ST.lo = d_sh_lo; ST.hi = d_sh_hi; ST.bam = d_sh_bam; ST.n = n_shards;
+        const int bb = nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0;
+        RSV(key64s, (size_t)(nkeys + 1) * 8);
+        if (bl < 32 && bb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (BAM, first line) in one 32-bit key; bl == 32 (one BAM of > 2^31 lines) would make the kernels shift a 32-bit word by 32
+            hipLaunchKernelGGL(k_compact_keys32, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST, bl,
+                               P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
+            const int rg[1][2] = {{0, bb + bl}};
+            if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nkeys, rg, 1, P<uint32_t>(h->key_g), P<uint32_t>(h->key64s))) return s;
+            hipLaunchKernelGGL(k_key_starts32, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const uint32_t *)h->key64s.p, bl, (const uint32_t *)h->key_g.p,
+                               (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
+        } else {
+            hipLaunchKernelGGL(k_compact_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST,
+                               P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
+            const int rg[2][2] = {{0, bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1))}, {32, 32 + (nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0)}};
+            if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nkeys, rg, 2, P<uint32_t>(h->key_g), P<unsigned long long>(h->key64s))) return s;
+            hipLaunchKernelGGL(k_key_starts, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const unsigned long long *)h->key64s.p, (const uint32_t *)h->key_g.p,
+                               (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
+        }
+    }
+#undef RSV
+    hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_keys, nb * nchrom, (uint32_t)nkeys, cc_keys);
+    PHZ_HIP(ctx, hipGetLastError());
+    return PHZ_OK;
+}
+
+// layout of the per-chromosome counters / segment starts (chrom_cnt, seg_start): uint32 [conn | blocks | block vars | keys per (BAM, chromosome)], then uint64 cfg rows per chromosome
+inline size_t n_chrom_counters(int nchrom, int nb) { return (size_t)nchrom * 3 + (size_t)nb * nchrom; }
+
 }  // namespace
+
+// The (chromosome, BAM) shards of the phz_tally call whose results the next phz_rowsdev_pair_keys will read: line range and BAM of every shard, in line order (what
+// phz_rowsdev_opts.shard_* carry to phz_rowsdev_run).  With them the first stage also enqueues the first-appearance keys (they need no p-value).
+extern "C" int phz_rowsdev_set_shards(phz_rowsdev *h, int32_t n_shards, const int64_t *line_lo, const int64_t *line_hi, const int32_t *bam) {
+    if (!h || n_shards < 0 || (n_shards && (!line_lo || !line_hi || !bam))) return PHZ_E_ARG;
+    h->sh_lo.assign(line_lo, line_lo + n_shards); h->sh_hi.assign(line_hi, line_hi + n_shards); h->sh_bam.assign(bam, bam + n_shards);
+    h->have_shards = true; h->pre_keys = false;
+    return PHZ_OK;
+}
 
 extern "C" int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *t, phz_rowsdev **out) {
     PhzEnter phz_guard_(ctx);
@@ -2146,6 +2203,7 @@ extern "C" void phz_rowsdev_destroy(phz_rowsdev *h) {
     if (!h) return;
     for (DevBuf *b : h->all()) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (h->up_host.p) (void)hipHostFree(h->up_host.p);
+    if (h->sh_host.p) (void)hipHostFree(h->sh_host.p);
     delete h;
 }
 
@@ -2178,9 +2236,10 @@ extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *key
     PHZ_HIP(ctx, hipGetLastError());
     // the first p-value-independent step of the row stage rides on this call's host wait: which variants are covered (the keys of allelic_counts / the singleton
     // rows) and the largest (QNAME line, variant line) gap, which decides the key width of the rank sort
-    h->pre_done = false;
+    h->pre_done = false; h->pre_keys = false;
     const bool pre = getenv("PHZ_ROWS_NO_PRESTAGE") == nullptr && nv > 0;
-    unsigned long long h_gap = 0;
+    const bool pre_k = pre && h->have_shards && getenv("PHZ_ROWS_NO_PREKEYS") == nullptr;
+    unsigned long long h_gap = 0; uint32_t h_nkeys = 0;
     if (pre) {
         const size_t NV = (size_t)nv, NE = (size_t)(ne ? ne : 1);
         if (int s = phz_reserve(ctx, h->cnt64, 64)) return s;
@@ -2196,10 +2255,12 @@ extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *key
     {
         PhzMail mail(ctx);
         const int m_gap = pre ? mail.add(P<unsigned long long>(h->cnt64) + 2, 8) : -1, m_fl = mail.add(h->flags.p, 4);
+        const int m_nk = pre_k ? mail.add(P<uint32_t>(h->keypos) + nv, 4) : -1;
         if (int s = mail.send()) return s;
         PHZ_HIP(ctx, hipMemcpyAsync(keys_host, h->hkeys.p, slots * 8, hipMemcpyDeviceToHost, sm));          // (copied before the verdict on the table is known -- one wait instead of two;
         PHZ_HIP(ctx, hipStreamSynchronize(sm));                                                             //  the caller hands over page-locked memory)
         if (pre) h_gap = *mail.at<unsigned long long>(m_gap);
+        if (pre_k) h_nkeys = *mail.at<uint32_t>(m_nk);
         fl = *mail.at<uint32_t>(m_fl);
     }
     if (fl & 1u) return phz_fail(ctx, PHZ_E_CAPACITY, "the distinct (supporting, total) read-count pairs do not fit the pair-key table: grow it (phz_rowsdev_set_pair_slots) and call again");
@@ -2207,8 +2268,47 @@ extern "C" int phz_rowsdev_pair_keys(phz_ctx *ctx, phz_rowsdev *h, uint64_t *key
         // ... and the ordering sorts that need no p-value are on the stream before this call returns: they run while the caller evaluates scipy on the keys
         if (int s = order_variants_and_pairs(ctx, h, h_gap)) return s;
         h->pre_done = true; h->pre_max_gap = h_gap; h->pre_gen = ctx->tally_gen;
+        if (pre_k) {
+            // ... and the first-appearance keys: the per-chromosome counter / segment-start tables are cleared HERE (phz_rowsdev_run leaves them alone when it finds the keys done)
+            const int nchrom = h->nchrom, nb = T.nb, nsh = (int)h->sh_bam.size();
+            const size_t n_cc = n_chrom_counters(nchrom, nb);
+            if (int s = phz_reserve(ctx, h->chrom_cnt, n_cc * 4 + 8 + (size_t)nchrom * 8)) return s;
+            if (int s = phz_reserve(ctx, h->seg_start, (n_cc + 1) * 4)) return s;
+            PHZ_HIP(ctx, hipMemsetAsync(h->chrom_cnt.p, 0, h->chrom_cnt.cap, sm));
+            PHZ_HIP(ctx, hipMemsetAsync(h->seg_start.p, 0xff, (n_cc + 1) * 4, sm));
+            const size_t one = ((size_t)nsh * 8 + 255) & ~(size_t)255;
+            if (int s = phz_reserve_host(ctx, h->sh_host, 3 * one + 256)) return s;          // (page-locked, the handle's own: the copy below may still be queued when the caller comes back)
+            if (int s = phz_reserve(ctx, h->sh_dev, 3 * one + 256)) return s;
+            char *hp = (char *)h->sh_host.p;
+            for (int i = 0; i < nsh; i++) { ((long long *)hp)[i] = h->sh_lo[(size_t)i]; ((long long *)(hp + one))[i] = h->sh_hi[(size_t)i]; ((int32_t *)(hp + 2 * one))[i] = h->sh_bam[(size_t)i]; }
+            PHZ_HIP(ctx, hipMemcpyAsync(h->sh_dev.p, hp, 3 * one, hipMemcpyHostToDevice, sm));
+            const char *dp = (const char *)h->sh_dev.p;
+            uint32_t *cc = P<uint32_t>(h->chrom_cnt), *ss = P<uint32_t>(h->seg_start);
+            if (int s = key_stage(ctx, h, (int64_t)h_nkeys, (const long long *)dp, (const long long *)(dp + one), (const int32_t *)(dp + 2 * one), nsh,
+                                  ss + 3 * (size_t)nchrom, cc + 3 * (size_t)nchrom)) return s;
+            h->pre_keys = true; h->pre_nkeys = (int64_t)h_nkeys;
+        }
     }
     h->keys_ready = true;
+    return PHZ_OK;
+}
+
+// phz_tally and stage 1 behind each other inside ONE native call: between the tally's last kernel and k_pair_keys there was nothing but the caller's glue (the return,
+// a few Python frames, the next call's prologue: ~0.1 ms of idle GPU per pass).  *pair_status = what phz_rowsdev_pair_keys answered (PHZ_E_CAPACITY: grow the
+// table and call phz_rowsdev_pair_keys alone); the tally is complete and resident whatever it says.
+extern "C" int phz_tally_pairs(phz_ctx *ctx, const phz_lines *shards, int n_shards, int64_t nv, const uint8_t *a0, const uint8_t *a1, int64_t n_qid, int n_bams,
+                               phz_tally_sizes *sizes, int space, phz_rowsdev *h, uint64_t *keys_host, int32_t *pair_status) {
+    PhzEnter phz_guard_(ctx);
+    if (!ctx || !h || !keys_host || !pair_status) return PHZ_E_ARG;
+    *pair_status = PHZ_E_ARG;
+    if (int s = phz_tally(ctx, shards, n_shards, nv, a0, a1, n_qid, n_bams, sizes, space)) return s;
+    {   // the shards of this tally, in line order: the first stage can then put the first-appearance keys on the stream as well
+        std::vector<int64_t> lo((size_t)n_shards), hi((size_t)n_shards); std::vector<int32_t> bam((size_t)n_shards);
+        int64_t total = 0;
+        for (int i = 0; i < n_shards; i++) { lo[(size_t)i] = total; total += shards[i].n_calls; hi[(size_t)i] = total; bam[(size_t)i] = shards[i].bam_index; }
+        if (int s = phz_rowsdev_set_shards(h, n_shards, lo.data(), hi.data(), bam.data())) return s;
+    }
+    *pair_status = phz_rowsdev_pair_keys(ctx, h, keys_host);
     return PHZ_OK;
 }
 
@@ -2221,6 +2321,11 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     if (!h->keys_ready) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run without phz_rowsdev_pair_keys");
     h->keys_ready = false;
     if (h->pre_done && h->pre_gen != ctx->tally_gen) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run: the resident tally changed since phz_rowsdev_pair_keys (call it again)");
+    // the first-appearance keys of the first stage count only for exactly the shards this call names
+    bool pre_keys = h->pre_keys && h->pre_done && (int)h->sh_bam.size() == o->n_shards;
+    for (int i = 0; pre_keys && i < o->n_shards; i++)
+        pre_keys = h->sh_lo[(size_t)i] == (long long)o->shard_line_lo[i] && h->sh_hi[(size_t)i] == (long long)o->shard_line_hi[i] && h->sh_bam[(size_t)i] == o->shard_bam[i];
+    h->pre_keys = false;
     if (T.nv != h->nv || T.nb != o->n_bams) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev: the resident tally does not match (variants / BAMs)");
     if (o->gw_phase_method != 0 && o->gw_phase_method != 1) return phz_fail(ctx, PHZ_E_ARG, "device row stage: gw_phase_method must be 0 or 1");
     const bool read_ids = o->output_read_ids != 0;
@@ -2267,10 +2372,10 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     RSV(chrom_cnt, n_cc * 4 + 8 + (size_t)nchrom * 8);
     uint32_t *cc_conn = P<uint32_t>(h->chrom_cnt), *cc_blocks = cc_conn + nchrom, *cc_blkvars = cc_blocks + nchrom, *cc_keys = cc_blkvars + nchrom;
     unsigned long long *cc_cfg = (unsigned long long *)((char *)h->chrom_cnt.p + ((n_cc * 4 + 7) & ~(size_t)7));
-    PHZ_HIP(ctx, hipMemsetAsync(h->chrom_cnt.p, 0, h->chrom_cnt.cap, sm));
+    if (!pre_keys) PHZ_HIP(ctx, hipMemsetAsync(h->chrom_cnt.p, 0, h->chrom_cnt.cap, sm));          // (pre_keys: cleared by the first stage, the key counters are in)
     RSV(seg_start, (n_cc + 1) * 4);            // first row of every segment, same layout as the counters
     uint32_t *ss_conn = P<uint32_t>(h->seg_start), *ss_blocks = ss_conn + nchrom, *ss_keys = ss_blocks + 2 * nchrom;
-    PHZ_HIP(ctx, hipMemsetAsync(h->seg_start.p, 0xff, (n_cc + 1) * 4, sm));
+    if (!pre_keys) PHZ_HIP(ctx, hipMemsetAsync(h->seg_start.p, 0xff, (n_cc + 1) * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->deg.p, 0, NV * 4, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->cnt64.p, 0, 64, sm));
     PHZ_HIP(ctx, hipMemsetAsync(h->cnt32.p, 0, 512, sm));
@@ -2342,27 +2447,9 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         hipLaunchKernelGGL(k_group_starts, dim3(nblk(nkeep)), dim3(256), 0, sm, nkeep, (const uint32_t *)h->f_a.p, (const uint32_t *)nullptr, P<uint32_t>(h->estart));
         hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, sm, P<uint32_t>(h->estart) + ncomp, (int64_t)1, (uint32_t)nkeep);
     }
-    if (nkeys) {
-        ShardTab ST; ST.lo = d_sh_lo; ST.hi = d_sh_hi; ST.bam = d_sh_bam; ST.n = o->n_shards;
-        const int bb = nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0;
-        RSV(key64s, (size_t)(nkeys + 1) * 8);
-        if (bl < 32 && bb + bl <= 32 && getenv("PHZ_ROWS_SORT64") == nullptr) {        // (BAM, first line) in one 32-bit key; bl == 32 (one BAM of > 2^31 lines) would make the kernels shift a 32-bit word by 32
-            hipLaunchKernelGGL(k_compact_keys32, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST, bl,
-                               P<uint32_t>(h->k32a), P<uint32_t>(h->v32a));
-            const int rg[1][2] = {{0, bb + bl}};
-            if (int s = sort_into<uint32_t>(ctx, h, h->k32a, h->k32b, nkeys, rg, 1, P<uint32_t>(h->key_g), P<uint32_t>(h->key64s))) return s;
-            hipLaunchKernelGGL(k_key_starts32, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const uint32_t *)h->key64s.p, bl, (const uint32_t *)h->key_g.p,
-                               (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
-        } else {
-            hipLaunchKernelGGL(k_compact_keys, dim3(nblk(nv)), dim3(256), 0, sm, nv, (const long long *)T.var_first, (const uint32_t *)h->keypos.p, ST,
-                               P<unsigned long long>(h->k64a), P<uint32_t>(h->v32a));
-            const int rg[2][2] = {{0, bits_for((uint64_t)(n_lines > 1 ? n_lines - 1 : 1))}, {32, 32 + (nb > 1 ? bits_for((uint64_t)(nb - 1)) : 0)}};
-            if (int s = sort_into<unsigned long long>(ctx, h, h->k64a, h->k64b, nkeys, rg, 2, P<uint32_t>(h->key_g), P<unsigned long long>(h->key64s))) return s;
-            hipLaunchKernelGGL(k_key_starts, dim3(nblk(nkeys)), dim3(256), 0, sm, nkeys, (const unsigned long long *)h->key64s.p, (const uint32_t *)h->key_g.p,
-                               (const uint16_t *)h->d_vchrom.p, nchrom, ss_keys);
-        }
-    }
-    hipLaunchKernelGGL(k_starts_to_counts, dim3(1), dim3(1), 0, sm, ss_keys, nb * nchrom, (uint32_t)nkeys, cc_keys);
+    if (!pre_keys) {          // (else: enqueued by the first stage, under the caller's p-value evaluation)
+        if (int s = key_stage(ctx, h, nkeys, d_sh_lo, d_sh_hi, d_sh_bam, o->n_shards, ss_keys, cc_keys)) return s;
+    } else if (nkeys != h->pre_nkeys) return phz_fail(ctx, PHZ_E_ARG, "phz_rowsdev_run: the covered variants changed since phz_rowsdev_pair_keys");
     // ---- block phasing: both kernels behind each other, then -- speculating that no component needs the host (a handful per genome at most) -- the block
     //      numbering, all before ONE host wait; exceptions are phased on the host and the numbering is redone
     if (int s = phase_enqueue(ctx, h->cstart, h->mem_s, h->estart, h->ekeep, T.ea, T.eb, cfgv, ncomp, nmem, nkeep, o->max_block_size, h->alle_of, h->sub_of, h->nsub,

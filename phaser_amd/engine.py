@@ -373,12 +373,23 @@ class Engine:
             pa0, pa1 = C.c_void_p(cached[1].ctypes.data), C.c_void_p(cached[2].ctypes.data)
         arr = (_lib.phz_lines * max(1, len(lines)))(*lines)
         sz = _lib.phz_tally_sizes()
-        self.ctx.check(self.lib.phz_tally(self.ctx.h, arr, len(lines), NV, pa0, pa1, NQ, nb, C.byref(sz), space))
+        pair_stage = None
+        if space == _lib.PHZ_DEVICE and self.cfg.device_rows and os.environ.get("PHZ_TALLY_PAIRS_FUSED", "1") == "1":
+            # the device row stage follows: its first stage (distinct read-count pairs + the p-value-independent sorts) is issued by the same native call as the tally
+            from . import rowsdev
+            T, keys, n_slots = rowsdev.pair_stage_inputs(self)
+            pst = C.c_int32(0)
+            self.ctx.check(self.lib.phz_tally_pairs(self.ctx.h, arr, len(lines), NV, pa0, pa1, NQ, nb, C.byref(sz), space, T.h, C.c_void_p(keys.ctypes.data), C.byref(pst)))
+            pair_stage = (keys, n_slots, int(pst.value), T)
+        else:
+            self.ctx.check(self.lib.phz_tally(self.ctx.h, arr, len(lines), NV, pa0, pa1, NQ, nb, C.byref(sz), space))
         t1 = _t.perf_counter()
         G = {"nv": NV, "nb": nb, "var_base": vb, "line_base": line_base, "n_lines": int(sz.n_lines), "n_kept": int(sz.n_kept),
              "n_edges": int(sz.n_edges), "n_read_list": int(sz.n_read_list), "noise": (int(sz.noise_match), int(sz.noise_mismatch)),
              "resident": True,          # the results are still in HBM: the device row stage and phz_components use them in place
              "fetched": False}
+        if pair_stage is not None:
+            G["pair_stage"] = pair_stage
         self.stats["tally_call_s"] = self.stats.get("tally_call_s", 0.0) + t1 - t0
         return G
 

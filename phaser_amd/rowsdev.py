@@ -267,6 +267,18 @@ def supported(cfg) -> bool:
     return True          # every option of the reference is formatted on the device (round 5: --gw_phase_method 1; round 6: --output_read_ids 1)
 
 
+def pair_stage_inputs(eng):
+    """(tables, page-locked key buffer, slots) of stage 1 for this Engine -- what Engine._tally_genome hands to phz_tally_pairs so that the tally and the first
+    kernels of the row stage are issued by ONE native call."""
+    import os as _os
+    T = tables_for(eng)
+    if _os.environ.get("PHZ_ROWS_PAIR_SLOTS") and not getattr(T, "_pair_slots_forced", False):          # tests: start from a tiny table so that the growth path runs
+        eng.ctx.check(eng.lib.phz_rowsdev_set_pair_slots(T.h, int(_os.environ["PHZ_ROWS_PAIR_SLOTS"]))); T._pair_slots_forced = True
+    n_slots = int(eng.lib.phz_rowsdev_pair_slots(T.h))
+    keys = pool_of(eng).get("pair_keys", n_slots * 8).view(np.uint64)
+    return T, keys, n_slots
+
+
 def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     """-> {chrom: fragment} in the format Engine._fragments returns (row text per file as buffers over page-locked host memory, in the
     reference's order), or raises PhzError(PHZ_E_UNSUPPORTED) when the host stage has to take the pass."""
@@ -281,10 +293,20 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
     import os as _os
     if _os.environ.get("PHZ_ROWS_PAIR_SLOTS") and not getattr(T, "_pair_slots_forced", False):          # tests: start from a tiny table so that the growth path runs
         ctx.check(lib.phz_rowsdev_set_pair_slots(T.h, int(_os.environ["PHZ_ROWS_PAIR_SLOTS"]))); T._pair_slots_forced = True
+    fused = G.pop("pair_stage", None)          # (keys, slots, status) when phz_tally_pairs already ran stage 1 behind the tally
     while True:
         n_slots = int(lib.phz_rowsdev_pair_slots(T.h))
-        keys = pool_of(eng).get("pair_keys", n_slots * 8).view(np.uint64)
-        st_ = ctx.check(lib.phz_rowsdev_pair_keys(ctx.h, T.h, _vp(keys)), allow=(_lib.PHZ_E_CAPACITY,))
+        if fused is not None and fused[1] == n_slots and fused[3] is T:
+            keys = fused[0]
+            st_ = ctx.check(fused[2], allow=(_lib.PHZ_E_CAPACITY,))
+            fused = None
+        else:
+            fused = None
+            keys = pool_of(eng).get("pair_keys", n_slots * 8).view(np.uint64)
+            sh0 = sorted(((base, base + n, b) for (c, b), (base, n) in G["line_base"].items()))          # the tally's shards: the first stage then prepares the first-appearance keys too
+            lo0 = np.array([x[0] for x in sh0], dtype=np.int64); hi0 = np.array([x[1] for x in sh0], dtype=np.int64); sb0 = np.array([x[2] for x in sh0], dtype=np.int32)
+            ctx.check(lib.phz_rowsdev_set_shards(T.h, len(sh0), _vp(lo0), _vp(hi0), _vp(sb0)))
+            st_ = ctx.check(lib.phz_rowsdev_pair_keys(ctx.h, T.h, _vp(keys)), allow=(_lib.PHZ_E_CAPACITY,))
         if st_ != _lib.PHZ_E_CAPACITY:
             break
         # very deep coverage: more distinct (supporting, total) pairs than the table holds -- quadruple it (the handle keeps the size) and redo the stage

@@ -123,13 +123,15 @@ def test_rows_of_a_block_of_150_variants_by_wave_and_by_thread():
         assert outs[0][name] == outs[1][name] == outs[2][name], name
 
 
-@pytest.mark.parametrize("env", [{"PHZ_ROWS_SORT64": "1"}, {"PHZ_ROWS_FAKE_LINE_BITS": "32"}, {"PHZ_ROWS_FAKE_LINE_BITS": "31"}, {"PHZ_ROWS_NO_PRESTAGE": "1"}, {"PHZ_SORT_ONE_LAUNCH": "1"}],
-                         ids=["sort64", "line_bits_32", "line_bits_31", "no_prestage", "one_launch_sort"])
+@pytest.mark.parametrize("env", [{"PHZ_ROWS_SORT64": "1"}, {"PHZ_ROWS_FAKE_LINE_BITS": "32"}, {"PHZ_ROWS_FAKE_LINE_BITS": "31"}, {"PHZ_ROWS_NO_PRESTAGE": "1"}, {"PHZ_SORT_ONE_LAUNCH": "1"},
+                                 {"PHZ_ROWS_NO_PREKEYS": "1"}],
+                         ids=["sort64", "line_bits_32", "line_bits_31", "no_prestage", "one_launch_sort", "keys_in_the_second_stage"])
 def test_key_layouts_of_the_ordering_sorts(env, monkeypatch, c1_inputs):
     """The rank order of the variants and the first-appearance order of the covered variants sort 32-bit keys when (line, gap) / (BAM, line) fit and 64-bit
     keys otherwise.  A BAM with more than 2^31 call lines has 32 line bits: a 32-bit (BAM, line) key would shift a 32-bit word by 32 (round-4 advisor
     finding), so that size must take the 64-bit keys; forced here through PHZ_ROWS_FAKE_LINE_BITS on the two-BAM fixture.  Also: the p-value-independent sorts
-    enqueued by the first stage (default) or by the second (PHZ_ROWS_NO_PRESTAGE), and the one-launch sort passes.  Every variant gives the same bytes."""
+    enqueued by the first stage (default) or by the second (PHZ_ROWS_NO_PRESTAGE), the first-appearance keys prepared by the first stage (default, the handle knows the
+    tally's shards) or by the second (PHZ_ROWS_NO_PREKEYS), and the one-launch sort passes.  Every variant gives the same bytes."""
     lib = emu_library()
     case, gold, load, cfg = next(c for c in _cases() if c[0] == "pipe_two")
     d, vcf_text, bams = _inputs(case, gold, c1_inputs)
