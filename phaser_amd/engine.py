@@ -145,6 +145,7 @@ class Engine:
         self.n_qid: Dict[str, int] = {c: 0 for c in self.all_chroms}
         self._log: List[str] = []
         self._pending_cut = []         # (log index, device block, shards) of AS cutoffs still on the device (close_bam -> resolve_cutoffs)
+        self._lazy_cut = []            # (BAM, shards with lines, device block, shards, log index) of percentiles not yet enqueued (close_bam -> _issue_cutoffs)
         self.stats: Dict[str, float] = {}
         self.total_lines = 0
 
@@ -240,10 +241,11 @@ class Engine:
                     # tally read the cutoff from the block).  The value reaches the log when somebody asks for it (resolve_cutoffs: the CLI after every BAM,
                     # finish() at the latest)
                     blk = torch.empty(4, dtype=torch.float64, device=dev)          # this Engine's own (another Engine on the same mapper may still hold a pending block)
-                    self.ctx.check(self.lib.phz_as_cutoff_enqueue(self.ctx.h, arr, len(live), float(self.cfg.as_q_cutoff * 100), _p(blk)))
                     for sh in shards:
                         sh.cut_dev = blk; sh.use_cutoff = 1; sh.cutoff = 0.0
-                    self._pending_cut.append((len(self._log), blk, shards))
+                    # ... and it is ISSUED right in front of the tally that reads it (_tally_genome -> _issue_cutoffs), or when somebody asks for the value: kernels
+                    # enqueued here would finish long before the host has put the tally call together, and the GPU would wait for it
+                    self._lazy_cut.append((bam_index, live, blk, shards, len(self._log)))
                     self._log.append(None)          # placeholder of the BAM's log line
                     return
                 val = C.c_double(0.0); found = C.c_int32(0)
@@ -265,7 +267,7 @@ class Engine:
     def log(self) -> List[str]:
         """The log lines of the run (the reference's stdout lines of the stages this class covers).  Reading them brings in whatever is still on the device
         (the AS cutoffs of close_bam): a caller that streams passes and never looks at the log pays no host wait for them."""
-        if self._pending_cut:
+        if self._pending_cut or self._lazy_cut:
             self.resolve_cutoffs()
         return self._log
 
@@ -273,9 +275,20 @@ class Engine:
     def log(self, value):
         self._log = value
 
+    def _issue_cutoffs(self):
+        """Enqueue the device-side AS percentiles close_bam left for later (one small submission per BAM on the ctx stream, no host wait)."""
+        if not self._lazy_cut:
+            return
+        lazy, self._lazy_cut = self._lazy_cut, []
+        for bam_index, live, blk, shards, at in lazy:
+            arr = (_lib.phz_lines * len(live))(*[self._lines(sh, bam_index) for sh in live])
+            self.ctx.check(self.lib.phz_as_cutoff_enqueue(self.ctx.h, arr, len(live), float(self.cfg.as_q_cutoff * 100), _p(blk)))
+            self._pending_cut.append((at, blk, shards))
+
     def resolve_cutoffs(self):
         """The AS cutoffs that were computed on the device without a host wait (close_bam): read them back (one small copy per BAM), write the BAM's log line
         (phaser.py:552-553) where it belongs, refuse an input whose AS values do not fit int16."""
+        self._issue_cutoffs()
         if not self._pending_cut:
             return
         pend, self._pending_cut = self._pending_cut, []
@@ -373,6 +386,7 @@ class Engine:
             pa0, pa1 = C.c_void_p(cached[1].ctypes.data), C.c_void_p(cached[2].ctypes.data)
         arr = (_lib.phz_lines * max(1, len(lines)))(*lines)
         sz = _lib.phz_tally_sizes()
+        self._issue_cutoffs()          # (the percentiles of close_bam: on the stream right in front of the tally that reads them)
         pair_stage = None
         if space == _lib.PHZ_DEVICE and self.cfg.device_rows and os.environ.get("PHZ_TALLY_PAIRS_FUSED", "1") == "1":
             # the device row stage follows: its first stage (distinct read-count pairs + the p-value-independent sorts) is issued by the same native call as the tally
