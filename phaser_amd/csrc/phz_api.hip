@@ -172,9 +172,13 @@ int PhzMail::send() {
     if (int s = phz_reserve_host(ctx, ctx->mail_host, total + 64)) return s;
     MailArgs a;
     for (int i = 0; i < MAX; i++) { a.src[i] = i < n ? src[i] : nullptr; a.bytes[i] = i < n ? bytes[i] : 0u; a.off[i] = i < n ? off[i] : 0u; }
-    hipLaunchKernelGGL(k_mail, dim3((unsigned)n), dim3(64), 0, ctx->stream, a, (char *)ctx->mail_dev.p);
+    // The gather kernel stores straight into the page-locked host block (hipHostMalloc memory is mapped into the device's address space): a few dozen bytes over the
+    // link, visible to the host when the kernel has completed.  The copy that used to follow the kernel -- device block -> host block on a copy engine -- cost every
+    // host wait of a pass ~10 us of queue hand-over (PHZ_MAIL_COPY=1 keeps it, for the A/B).
+    static const bool via_copy = getenv("PHZ_MAIL_COPY") != nullptr;
+    hipLaunchKernelGGL(k_mail, dim3((unsigned)n), dim3(64), 0, ctx->stream, a, via_copy ? (char *)ctx->mail_dev.p : (char *)ctx->mail_host.p);
     PHZ_HIP(ctx, hipGetLastError());
-    PHZ_HIP(ctx, hipMemcpyAsync(ctx->mail_host.p, ctx->mail_dev.p, total, hipMemcpyDeviceToHost, ctx->stream));
+    if (via_copy) PHZ_HIP(ctx, hipMemcpyAsync(ctx->mail_host.p, ctx->mail_dev.p, total, hipMemcpyDeviceToHost, ctx->stream));
     return PHZ_OK;
 }
 
