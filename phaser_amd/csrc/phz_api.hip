@@ -66,6 +66,7 @@ int phz_ctx_destroy(phz_ctx *c) {
     free_buf(c->shard_tab); free_buf(c->map_tab); free_buf(c->bam_comp); free_buf(c->bam_stream); free_buf(c->bam_work);
     for (hipEvent_t e : c->map_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    if (c->tab_ev) (void)hipEventDestroy(c->tab_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PHZ_OK;

@@ -36,6 +36,7 @@ struct phz_ctx {
                                        // and by phz_ctx_destroy; PHZ_BAM_KEEP_BUFFERS=0 turns the cache off
     DevBuf mail_dev, mail_host;        // PhzMail: gathered small read-backs (device block, page-locked host image)
     DevBuf shard_tab, h_shard_tab;     // shard table of a batched stage (device / pinned host image)
+    hipEvent_t tab_ev = nullptr; bool tab_pending = false;      // the last upload of the pinned image: the next one waits for it before it overwrites the image (a stage that returns without a host wait -- phz_as_cutoff_enqueue -- leaves its copy queued)
     DevBuf map_tab;                    // K_map's own device copy of its shard table (shard_tab is shared with the tally / BAM stages)
     std::vector<char> map_tab_image; void *map_tab_dev = nullptr;      // the image last uploaded to map_tab (a repeated submission skips the copy)
     std::vector<hipEvent_t> map_ev;    // event pairs around every k_map launch of a batch

@@ -1104,6 +1104,7 @@ template <class F>
 static int upload_tab(phz_ctx *ctx, const LinesDev *L, int n, F blocks_of, LinesTab *out, std::vector<uint32_t> *blk0_host, int slot = 0,
                       int n_slots = 1) {
     const size_t one = ((size_t)n * sizeof(LinesDev) + (size_t)(n + 1) * 4 + 63) & ~(size_t)63;
+    if (ctx->tab_pending) { PHZ_HIP(ctx, hipEventSynchronize(ctx->tab_ev)); ctx->tab_pending = false; }      // the previous table has left the pinned image
     if (int s = phz_reserve_host(ctx, ctx->h_shard_tab, one * (size_t)n_slots)) return s;
     if (int s = phz_reserve(ctx, ctx->shard_tab, one * (size_t)n_slots)) return s;
     char *h = (char *)ctx->h_shard_tab.p + one * (size_t)slot;
@@ -1119,6 +1120,8 @@ static int upload_tab(phz_ctx *ctx, const LinesDev *L, int n, F blocks_of, Lines
     }
     b0[n] = (uint32_t)acc; (*blk0_host)[(size_t)n] = (uint32_t)acc;
     PHZ_HIP(ctx, hipMemcpyAsync(d, h, one, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->tab_ev) PHZ_HIP(ctx, hipEventCreateWithFlags(&ctx->tab_ev, hipEventDisableTiming));
+    PHZ_HIP(ctx, hipEventRecord(ctx->tab_ev, ctx->stream)); ctx->tab_pending = true;
     out->L = (const LinesDev *)d; out->blk0 = (const uint32_t *)(d + (size_t)n * sizeof(LinesDev)); out->n = n;
     return PHZ_OK;
 }
