@@ -190,3 +190,48 @@ def test_hap_counts_are_the_distinct_reads_per_list(case, c1_inputs):
     want = np.array([len(set(rq[rs[e]:rs[e + 1]].tolist())) for e in range(nseg)], dtype=np.int32)
     assert np.array_equal(got, want) and int(want.sum()) > 0
     assert lib.phz_hap_counts(eng.ctx.h, ctypes.c_void_p(got.ctypes.data), nseg + 1, _lib.PHZ_HOST) == _lib.PHZ_E_ARG
+
+
+@pytest.mark.parametrize("shards", ["right", "wrong"])
+def test_first_stage_issued_with_the_tally_and_keys_for_other_shards(shards, c1_inputs):
+    """The fused order of the product (phz_tally_pairs: stage 1 of the row stage issued by the same native call as the tally; Engine hands its result to rowsdev.run as
+    G["pair_stage"]) replayed under the emulation on the three-BAM fixture -- with the shard table the first stage was told equal to the run's ("right": the first-appearance
+    keys prepared by stage 1 are used) and different from it ("wrong": phz_rowsdev_run must notice and prepare them again).  Same bytes as the plain order either way."""
+    import numpy as np
+    from phaser_amd import _lib, rowsdev
+    lib = emu_library()
+    case, gold, load, cfg = next(c for c in _cases() if c[0] == "pipe_sparse")
+    d, vcf_text, bams = _inputs(case, gold, c1_inputs)
+    base, _ = run_stages(lib, case, load, cfg, vcf_text, bams)
+    from phaser_amd import vcf
+    from phaser_amd.engine import Config, Engine
+    vs = vcf.load_variants(vcf_text, **{k: v for k, v in load.items() if k != "include_indels"})
+    saved = pickle.load(gzip.open(os.path.join(GOLD, "tally", case + ".pkl.gz"), "rb"))
+
+    class _M:
+        ctx = EmuContext(lib)
+        device = None
+    eng = Engine(vs, bams, Config(**{k: v for k, v in cfg.items() if k != "include_indels"}), mapper=_M())
+    eng.n_qid.update(saved["n_qid"]); eng.qnames.update(saved["qnames"])
+    stub_emu_stages(eng, saved)
+    plain = eng._tally_genome
+
+    def fused():
+        G = plain()
+        eng.G = G
+        T, keys, n_slots = rowsdev.pair_stage_inputs(eng)
+        sh = sorted(((b0, b0 + n, b) for (c, b), (b0, n) in G["line_base"].items()))
+        lo = np.array([x[0] for x in sh], np.int64); hi = np.array([x[1] for x in sh], np.int64); sb = np.array([x[2] for x in sh], np.int32)
+        if shards == "wrong":
+            sb = (sb + 1) % max(1, G["nb"]); hi = hi.copy(); hi[-1] += 1
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        eng.ctx.check(lib.phz_rowsdev_set_shards(T.h, len(sh), vp(lo), vp(hi), vp(sb)))
+        st = lib.phz_rowsdev_pair_keys(eng.ctx.h, T.h, vp(keys))
+        G["pair_stage"] = (keys, n_slots, int(st), T)
+        return G
+    import ctypes as C
+    eng._tally_genome = fused
+    out = eng.finish()
+    assert eng.rows_path == "device" and "pair_stage" not in eng.G
+    for name in OUTPUTS:
+        assert out[name] == base[name], name
