@@ -44,7 +44,7 @@ class Config:
         self.include_indels = 0
         self.want_vcf = True           # keep per-block info for write_vcf (vcfout.phased_vcf_text)
         self.host_threads = 1          # threads of the native block phasing / row writer (the reference's --threads)
-        self.device_rows = True        # stages T7-O2 on the GPU (phz_rowsdev_*); the host stage takes what the device stage declines
+        self.device_rows = True        # stages T7-O2 on the GPU (phz_rowsdev_*); False: the host twin (phz_rows_format_multi), which also takes a pass the device stage refuses with PHZ_E_UNSUPPORTED (label text beyond 4 GiB)
         self.fetch_text = True         # copy the finished row text to (page-locked) host memory; False leaves it in HBM (bench)
         self.py_hash_order = 0         # 1: rows / read labels in the order CPython 3.10 gives the reference's sets (pyorder.py; needs PYTHONHASHSEED=0)
         for k, v in kw.items():
