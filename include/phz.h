@@ -575,6 +575,10 @@ typedef struct {
      * qname_base[c] = pool item of template id 0 of chromosome c ([n_chroms + 1]; the last entry = number of pool items). */
     const uint32_t *qname_off; const char *qname;
     const int64_t *qname_base;
+    /* optional (NULL = off): a PAGE-LOCKED host region for the finished text.  When it holds all seven texts (each at a 4 KB boundary) the run copies every text there on a
+     * second stream as soon as its writer kernel has finished -- the largest first -- and phz_rowsdev_result.host_off says where; otherwise host_off is -1 everywhere and
+     * the caller takes the texts with phz_rowsdev_fetch_text as before. */
+    void *host_text; int64_t host_text_cap;
 } phz_rowsdev_opts;
 
 typedef struct {
@@ -588,6 +592,7 @@ typedef struct {
                                                           * process_mapping_result returns, "" for a call file without kept lines (phaser.py:1299, :573-574) */
     int64_t n_blocks, n_blk_vars, phased, dropped, allelic_rows, n_components, n_linked, n_complex, n_exceptions, n_big_segments;
     double gpu_ms;                    /* HIP-event time of the sync-free sections of the run */
+    int64_t host_off[PHZ_TXT_COUNT];  /* byte offset of every text in phz_rowsdev_opts.host_text, -1 = not copied (no region given, or too small) */
 } phz_rowsdev_result;
 
 int phz_rowsdev_create(phz_ctx *ctx, const phz_rowsdev_tables *tables, phz_rowsdev **out);

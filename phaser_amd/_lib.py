@@ -135,14 +135,14 @@ class phz_rowsdev_opts(C.Structure):
                 ("n_shards", C.c_int32), ("shard_line_lo", C.c_void_p), ("shard_line_hi", C.c_void_p), ("shard_bam", C.c_void_p),
                 ("unique_ids", C.c_int32), ("gw_phase_method", C.c_int32), ("output_read_ids", C.c_int32), ("unphased_vars", C.c_int32),
                 ("max_block_size", C.c_int32), ("want_vcf", C.c_int32), ("cc_threshold", C.c_double),
-                ("qname_off", C.c_void_p), ("qname", C.c_void_p), ("qname_base", C.c_void_p)]
+                ("qname_off", C.c_void_p), ("qname", C.c_void_p), ("qname_base", C.c_void_p), ("host_text", C.c_void_p), ("host_text_cap", C.c_int64)]
 
 
 class phz_rowsdev_result(C.Structure):
     _fields_ = [("bytes", C.c_int64 * PHZ_TXT_COUNT), ("seg_off", C.POINTER(C.c_int64) * PHZ_TXT_COUNT), ("chrom_blocks", C.POINTER(C.c_int64)),
                 ("chrom_blk_vars", C.POINTER(C.c_int64)), ("chrom_first_bam", C.POINTER(C.c_int32))] + \
                [(k, C.c_int64) for k in ("n_blocks", "n_blk_vars", "phased", "dropped", "allelic_rows", "n_components", "n_linked", "n_complex",
-                                          "n_exceptions", "n_big_segments")] + [("gpu_ms", C.c_double)]
+                                          "n_exceptions", "n_big_segments")] + [("gpu_ms", C.c_double), ("host_off", C.c_int64 * PHZ_TXT_COUNT)]
 
 
 class phz_hc_arrays(C.Structure):

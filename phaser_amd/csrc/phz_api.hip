@@ -67,6 +67,7 @@ int phz_ctx_destroy(phz_ctx *c) {
     for (hipEvent_t e : c->map_ev) if (e) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     if (c->tab_ev) (void)hipEventDestroy(c->tab_ev);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PHZ_OK;

@@ -20,6 +20,7 @@ struct phz_ctx {
     std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // device -> host copies that run beside the kernels of `stream` (phz_rowsdev_run's copy-as-written), created on first use
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     // timing

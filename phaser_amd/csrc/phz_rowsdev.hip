@@ -1924,6 +1924,7 @@ struct phz_rowsdev {
     bool have_shards = false, pre_keys = false; int64_t pre_nkeys = 0;
     std::vector<long long> sh_lo, sh_hi; std::vector<int32_t> sh_bam;
     DevBuf sh_dev, sh_host;
+    hipEvent_t txt_ev[PHZ_TXT_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // "the writer of file f has finished" (copy-as-written)
     int64_t ps_slots = PS_SLOTS;        // slots of the pair-key hash set (a power of two; grown by the host when a pass reports PHZ_E_CAPACITY)
     std::vector<DevBuf *> all() {
         std::vector<DevBuf *> v = {&d_chrom_v0, &d_vchrom, &d_pos, &d_maf, &d_isref, &d_phase, &d_black, &hkeys, &flags, &up_dev, &keep, &e_slot, &deg, &parent, &label, &f_a, &f_b, &f_c, &f_d, &mem_pos, &cid, &kpos, &keypos,
@@ -2204,6 +2205,7 @@ extern "C" void phz_rowsdev_destroy(phz_rowsdev *h) {
     for (DevBuf *b : h->all()) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (h->up_host.p) (void)hipHostFree(h->up_host.p);
     if (h->sh_host.p) (void)hipHostFree(h->sh_host.p);
+    for (hipEvent_t e : h->txt_ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -2701,10 +2703,28 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         for (int f = 0; f < PHZ_TXT_COUNT; f++) { const unsigned long long *q = mail.at<unsigned long long>(m_so[f]); h_so[f].assign(q, q + (size_t)nseg[f] + 1); }
     }
     sec.begin();
+    // Where the text goes on the host, when the caller gave a page-locked region that holds all of it (phz_rowsdev_opts.host_text): every file at a 4 KB boundary, copied
+    // on the ctx's copy stream AS SOON AS ITS WRITER HAS FINISHED -- largest file first (allele_config is half of the bytes), so that the link is busy from the first
+    // finished file on while the other writers still run.  (The files are all written in the last fifth of a pass: what this hides is that fifth, not the pass.)
+    bool to_host = o->host_text != nullptr && o->host_text_cap > 0;
+    int64_t host_need = 0;
     for (int f = 0; f < PHZ_TXT_COUNT; f++) {
         h->bytes[f] = (int64_t)h_so[f].back();
         h->seg_off[f].assign(h_so[f].begin(), h_so[f].end());
         res->bytes[f] = h->bytes[f]; res->seg_off[f] = h->seg_off[f].data();
+        res->host_off[f] = -1;
+        host_need = ((host_need + 4095) & ~(int64_t)4095) + h->bytes[f];
+    }
+    if (to_host && host_need > o->host_text_cap) to_host = false;
+    if (to_host) {
+        if (!ctx->copy_stream) PHZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        int64_t at = 0;
+        for (int f = 0; f < PHZ_TXT_COUNT; f++) { at = (at + 4095) & ~(int64_t)4095; res->host_off[f] = at; at += h->bytes[f]; }
+        for (int f = 0; f < PHZ_TXT_COUNT; f++) if (!h->txt_ev[f]) PHZ_HIP(ctx, hipEventCreateWithFlags(&h->txt_ev[f], hipEventDisableTiming));
+    }
+    static const int write_order[PHZ_TXT_COUNT] = {PHZ_TXT_CFG, PHZ_TXT_ASE, PHZ_TXT_ALLELIC, PHZ_TXT_CONN, PHZ_TXT_HAP, PHZ_TXT_SINGLE_ASE, PHZ_TXT_SINGLE_HAP};
+    for (int wo = 0; wo < PHZ_TXT_COUNT; wo++) {
+        const int f = write_order[wo];
         RSV(text[f], (size_t)h->bytes[f] + 16);
         const unsigned g = nblk(rows[f]);
         const unsigned long long *of = P<unsigned long long>(h->off[f]);
@@ -2723,6 +2743,11 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
             default: hipLaunchKernelGGL((k_row_write<RowSingleHap, 256, 32 * 1024>), dim3((unsigned)((rows[f] + 255) / 256)), dim3(256), 0, sm, D, rows[f], of, out); break;
         }
         if (f == PHZ_TXT_ASE && n_rl && rows[f]) hipLaunchKernelGGL(k_label_write, dim3(nblk(n_rl)), dim3(256), 0, sm, D, n_rl, out);
+        if (to_host && h->bytes[f]) {
+            PHZ_HIP(ctx, hipEventRecord(h->txt_ev[f], sm));
+            PHZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, h->txt_ev[f], 0));
+            PHZ_HIP(ctx, hipMemcpyAsync((char *)o->host_text + res->host_off[f], h->text[f].p, (size_t)h->bytes[f], hipMemcpyDeviceToHost, ctx->copy_stream));
+        }
     }
     // ---- per-block arrays for write_vcf
     h->have_vcf = false;
@@ -2738,6 +2763,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = sec.wait("end")) return s;
+    if (to_host) PHZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));          // the text is in the caller's region
 #undef RSV
     h->chrom_blocks.assign((size_t)nchrom, 0); h->chrom_blk_vars.assign((size_t)nchrom, 0);
     for (int c = 0; c < nchrom; c++) { h->chrom_blocks[(size_t)c] = h_cc[(size_t)nchrom + c]; h->chrom_blk_vars[(size_t)c] = h_cc[(size_t)2 * nchrom + c]; }

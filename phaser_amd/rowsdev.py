@@ -365,10 +365,22 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
         o.qname_off = _vp(q_off); o.qname = _vp(q_txt); o.qname_base = _vp(qbase)
         _keep_q = (q_off, q_txt, qbase)
     R = _lib.phz_rowsdev_result()
+    # copy-as-written: a page-locked region sized by what the last pass over these tables wrote (+ 1/8); the run copies every finished text there on a second stream while
+    # the remaining writers run.  The first pass over a variant set (size unknown), or a pass that outgrew the guess, takes the texts afterwards as before.
+    pool = pool_of(eng)
+    pool.new_pass()                             # THIS Engine's previous text buffers are given up; another Engine's are never touched
+    arena = None
+    guess = int(T.__dict__.get("_text_total", 0))
+    if fetch_text and guess > 0 and _os.environ.get("PHZ_ROWS_COPY_AS_WRITTEN", "1") == "1":
+        arena = pool.get("rows_all", guess + guess // 8 + 8 * 4096)
+        o.host_text = _vp(arena); o.host_text_cap = int(arena.size)
+    else:
+        o.host_text = None; o.host_text_cap = 0
     t2b = _t.perf_counter()
     try:
         ctx.check(lib.phz_rowsdev_run(ctx.h, T.h, C.byref(o), _vp(slot_pv), _vp(txt_off), _vp(txt), C.byref(R)))
     finally:
+        o.host_text = None; o.host_text_cap = 0
         if cfg.output_read_ids == 1:
             o.qname_off = None; o.qname = None; o.qname_base = None          # (the record is kept; the pool of this pass is not)
     t3 = _t.perf_counter()
@@ -380,14 +392,16 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
             if name in ("allelic", "single_ase", "single_hap"):
                 frags[c][name + "_bam"] = []
     total_bytes = 0
-    pool = pool_of(eng)
-    pool.new_pass()                             # THIS Engine's previous text buffers are given up; another Engine's are never touched
     for f, name in enumerate(_lib.PHZ_TXT_NAMES):
         nbytes = int(R.bytes[f]); total_bytes += nbytes
         if not fetch_text:
             continue
-        buf = pool.get("rows_" + name, nbytes)
-        ctx.check(lib.phz_rowsdev_fetch_text(ctx.h, T.h, f, _vp(buf) if nbytes else None, nbytes))
+        hoff = int(R.host_off[f])
+        if arena is not None and hoff >= 0:
+            buf = arena[hoff:hoff + nbytes]          # copied by the run itself, beside its last kernels
+        else:
+            buf = pool.get("rows_" + name, nbytes)
+            ctx.check(lib.phz_rowsdev_fetch_text(ctx.h, T.h, f, _vp(buf) if nbytes else None, nbytes))
         mv = memoryview(buf)
         nseg = nch if f < 4 else nb * nch
         so = [int(R.seg_off[f][i]) for i in range(nseg + 1)]
@@ -427,6 +441,7 @@ def run(eng, noise: float, fetch_text: bool = True) -> Dict[str, dict]:
         st[k] = st.get(k, 0.0) + v
     st["rowsdev_gpu_ms"] = st.get("rowsdev_gpu_ms", 0.0) + float(R.gpu_ms)
     st["rowsdev_text_bytes"] = float(total_bytes)
+    T.__dict__["_text_total"] = sum(((int(R.bytes[f]) + 4095) & ~4095) for f in range(len(_lib.PHZ_TXT_NAMES)))
     for k in ("n_components", "n_complex", "n_exceptions", "n_big_segments", "n_blocks"):
         st["rowsdev_" + k] = float(getattr(R, k))
     return frags

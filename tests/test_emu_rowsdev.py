@@ -235,3 +235,46 @@ def test_first_stage_issued_with_the_tally_and_keys_for_other_shards(shards, c1_
     assert eng.rows_path == "device" and "pair_stage" not in eng.G
     for name in OUTPUTS:
         assert out[name] == base[name], name
+
+
+def test_copy_as_written_gives_the_same_text(c1_inputs, monkeypatch):
+    """Second and later passes over a variant set hand phz_rowsdev_run a host region sized by the previous pass: the run copies every finished text there itself (on a
+    second stream beside its last writers; largest file first) and reports the offsets.  Same bytes as the first pass (texts fetched afterwards), also when the region is
+    too small for the pass (the guess of a smaller previous pass: every text is fetched as before) and with the path switched off."""
+    from phaser_amd import rowsdev, vcf
+    from phaser_amd.engine import Config, Engine
+    lib = emu_library()
+    case, gold, load, cfg = next(c for c in _cases() if c[0] == "pipe_two")
+    d, vcf_text, bams = _inputs(case, gold, c1_inputs)
+    vs = vcf.load_variants(vcf_text)
+    saved = pickle.load(gzip.open(os.path.join(GOLD, "tally", case + ".pkl.gz"), "rb"))
+
+    def one_pass():
+        class _M:
+            ctx = EmuContext(lib)
+            device = None
+        eng = Engine(vs, bams, Config(), mapper=_M())
+        eng.n_qid.update(saved["n_qid"]); eng.qnames.update(saved["qnames"])
+        stub_emu_stages(eng, saved)
+        out = eng.finish()
+        return out, eng
+    first, e1 = one_pass()
+    T = rowsdev.tables_for(e1)
+    assert T.__dict__.get("_text_total", 0) > 0
+    seen = []
+    real = lib.phz_rowsdev_run
+
+    def spy(ctx_h, th, o, *rest):
+        seen.append(int(o._obj.host_text_cap))
+        return real(ctx_h, th, o, *rest)
+    monkeypatch.setattr(lib, "phz_rowsdev_run", spy, raising=False)
+    second, _ = one_pass()
+    assert seen[-1] > 0
+    T.__dict__["_text_total"] = 4096          # a region far too small: the run declines it, the texts are fetched
+    third, _ = one_pass()
+    monkeypatch.setenv("PHZ_ROWS_COPY_AS_WRITTEN", "0")
+    fourth, _ = one_pass()
+    assert seen[-1] == 0
+    for name in OUTPUTS:
+        assert first[name] == second[name] == third[name] == fourth[name], name
+        assert canonical(name, first[name]) == canonical(name, gz_text(os.path.join(d, "out.%s.txt.gz" % name))), name
