@@ -828,3 +828,38 @@ def test_as_value_outside_int16_is_refused_by_the_pass(mapper, monkeypatch):
     monkeypatch.delenv("PHZ_AS_CUTOFF_HOST", raising=False)
     out, eng = run_product(mapper, open(os.path.join(d, "in.vcf")).read(), {"a.bam": {"chr22": sam}}, "cuda")      # the ctx stays usable
     compare(out, d)
+
+
+def test_copy_as_written_on_later_passes(mapper, monkeypatch):
+    """Passes after the first over one variant set let phz_rowsdev_run copy the finished text into a page-locked region beside its last writer kernels (events per file,
+    second stream, allele_config first): the bytes of pass 2 and 3 equal pass 1's (texts fetched after the run) and the reference's (fixture pipe_two); switched off: the same."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from phasing_oracle import bam_display_names
+    from phaser_amd import rowsdev, samio, vcf
+    from phaser_amd.engine import Config, Engine
+    d = os.path.join(GOLD, "pipe_two")
+    vs = vcf.load_variants(open(os.path.join(d, "in.vcf")).read())
+    bams = {b + ".bam": {c: gz_text(os.path.join(d, "%s.%s.sam.gz" % (b, c))) for c in ("chr21", "chr22")} for b in ("t1", "t2")}
+
+    def one_pass():
+        eng = Engine(vs, bam_display_names(list(bams.keys())), Config(), mapper=mapper)
+        interners = {}
+        for bi, (bam, per_chrom) in enumerate(bams.items()):
+            for chrom in vs.chroms:
+                for c2, sh in samio.shards_from_sam(per_chrom[chrom], interners, 0.0).items():
+                    eng.add_shard(bi, c2, sh.to("cuda"), len(interners[c2]), interners[c2].names)
+            for c2 in interners:
+                eng.n_qid[c2] = len(interners[c2])
+            eng.close_bam(bi)
+        out = eng.finish()
+        assert eng.rows_path == "device"
+        return out, eng
+    first, e1 = one_pass()
+    assert rowsdev.tables_for(e1).__dict__.get("_text_total", 0) > 0
+    second, _ = one_pass()
+    third, _ = one_pass()
+    monkeypatch.setenv("PHZ_ROWS_COPY_AS_WRITTEN", "0")
+    fourth, _ = one_pass()
+    for name in OUTPUTS:
+        assert first[name] == second[name] == third[name] == fourth[name], name
+    compare(first, d)
