@@ -2707,6 +2707,10 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     // on the ctx's copy stream AS SOON AS ITS WRITER HAS FINISHED -- largest file first (allele_config is half of the bytes), so that the link is busy from the first
     // finished file on while the other writers still run.  (The files are all written in the last fifth of a pass: what this hides is that fifth, not the pass.)
     bool to_host = o->host_text != nullptr && o->host_text_cap > 0;
+    struct CopyGuard {          // whatever way this call ends, no copy into the caller's region is still in flight when it returns
+        phz_ctx *c; bool armed = false;
+        ~CopyGuard() { if (armed && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); }
+    } copy_guard{ctx};
     int64_t host_need = 0;
     for (int f = 0; f < PHZ_TXT_COUNT; f++) {
         h->bytes[f] = (int64_t)h_so[f].back();
@@ -2746,6 +2750,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
         if (to_host && h->bytes[f]) {
             PHZ_HIP(ctx, hipEventRecord(h->txt_ev[f], sm));
             PHZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, h->txt_ev[f], 0));
+            copy_guard.armed = true;
             PHZ_HIP(ctx, hipMemcpyAsync((char *)o->host_text + res->host_off[f], h->text[f].p, (size_t)h->bytes[f], hipMemcpyDeviceToHost, ctx->copy_stream));
         }
     }
@@ -2763,7 +2768,7 @@ extern "C" int phz_rowsdev_run(phz_ctx *ctx, phz_rowsdev *h, const phz_rowsdev_o
     }
     PHZ_HIP(ctx, hipGetLastError());
     if (int s = sec.wait("end")) return s;
-    if (to_host) PHZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));          // the text is in the caller's region
+    if (to_host) { copy_guard.armed = false; PHZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream)); }          // the text is in the caller's region
 #undef RSV
     h->chrom_blocks.assign((size_t)nchrom, 0); h->chrom_blk_vars.assign((size_t)nchrom, 0);
     for (int c = 0; c < nchrom; c++) { h->chrom_blocks[(size_t)c] = h_cc[(size_t)nchrom + c]; h->chrom_blk_vars[(size_t)c] = h_cc[(size_t)2 * nchrom + c]; }
