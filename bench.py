@@ -209,7 +209,9 @@ def cpu_phasing_baseline(sample_chroms, vsets, shards, calls_of, mapper, baseq, 
     out = {"value": ph.phased / dt, "unit": "phased variants/s", "cores": 1, "kind": "port",
            "sample": "chromosomes %s of the same sample (%d call lines, %d phased variants) through oracle/phasing_oracle.py, %.1f s"
                      % ("+".join(sample_chroms), n_lines, ph.phased, dt),
-           "parity_on_sample": "five output files identical in canonical form (%d phased variants)" % ph.phased}
+           "parity_on_sample": "five output files identical in canonical form (%d phased variants)" % ph.phased,
+           "reference_note": "the Python restatement is slower than the code it restates: the reference's own phasing core ran ~9e3 phased variants/s on one core in the build "
+                             "container (BASELINE.md, stages #3-#6 of configs[0]); ratios of the GPU figure to THIS value overstate the distance to the reference about tenfold"}
     if all_cores_chroms:
         # one oracle process per chromosome, all at once (the reference's `parallelize` over contigs, phaser.py:2077-2094, "1 thread per contig")
         import subprocess, tempfile, shutil
