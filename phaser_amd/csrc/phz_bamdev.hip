@@ -412,7 +412,13 @@ __global__ __launch_bounds__(256) void k_names_len(const uint32_t *off, const in
 static bool bam_keep_buffers() { const char *e = getenv("PHZ_BAM_KEEP_BUFFERS"); return !(e && atoi(e) == 0); }
 static void *bam_take(DevBuf *slot, size_t bytes, size_t *cap) {
     if (slot && slot->p && slot->cap >= bytes) { void *p = slot->p; *cap = slot->cap; slot->p = nullptr; slot->cap = 0; return p; }
+    // a fresh buffer gets ~3 % + 64 MB of head room: the BAMs of one sample differ by fractions of a percent, and a buffer cut to the byte sent every slightly larger
+    // file to a new 15 GB hipMalloc (0.2-0.7 s each time on this runtime: profiles/r06/cli_4bam_full_before.txt, 'device buffers 684 ms' at the third of four BAMs)
     void *p = nullptr;
+    const size_t roomy = bytes + bytes / 32 + ((size_t)64 << 20);
+    if (bam_keep_buffers() && hipMalloc(&p, roomy) == hipSuccess) { *cap = roomy; return p; }
+    (void)hipGetLastError();
+    p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     *cap = bytes;
     return p;
